@@ -1,0 +1,389 @@
+// colour.hip — fused chroma-upsample + matrix + interleave kernels for gfx950.
+//
+// Replaces the reference's colour pipeline (libheif/color-conversion):
+//   k_ycbcr420_int   : Op_YCbCr420_to_RGB24 / _RGB32            (yuv2rgb.cc:306-366, 416-495)
+//   k_ycbcr_float    : Op_YCbCr_to_RGB<u8|u16> fused with the repack op that follows it
+//                      (yuv2rgb.cc:79-254 + rgb2rgb.cc:66-143 / 189-272 / 676-729) and
+//                      Op_YCbCr420_to_RRGGBBaa (yuv2rgb.cc:550-643)
+// The reference runs 2-3 passes over planar temporaries; here one pass reads Y/Cb/Cr once
+// (1.5 B/px for 8-bit 4:2:0) and writes the interleaved pixels once (3 B/px).
+//
+// Integer / byte work, HBM-bound: no MFMA.  Each lane owns 16 horizontally adjacent pixels
+// (x 2 rows for 4:2:0 so a chroma sample is fetched once), loads are 16 B / 8 B per lane and
+// fully coalesced across the wave; the 48 B of RGB per lane-row are transposed through LDS so
+// that every global store instruction of a wave writes one contiguous 1 KiB run.
+//
+// Bit-exactness: the float path uses individually rounded IEEE binary32 mul/add in the
+// reference's evaluation order (no FMA contraction: __fmul_rn/__fadd_rn and -ffp-contract=off)
+// and trunc(x + 0.5f) rounding (common_utils.h:64-79).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hm_internal.h"
+
+namespace {
+
+__device__ __forceinline__ int clip_u8(int x) { return x < 0 ? 0 : (x > 255 ? 255 : x); }
+
+// common_utils.h:64-70
+__device__ __forceinline__ int clip_f(float fx, int maxi)
+{
+  int x = (int)__fadd_rn(fx, 0.5f); // float->int conversion truncates toward zero like (long)
+  return x < 0 ? 0 : (x > maxi ? maxi : x);
+}
+
+// ---------------------------------------------------------------------------------------
+// Integer 4:2:0 8-bit full range -> RGB24 / RGBA32
+// ---------------------------------------------------------------------------------------
+
+struct IntCoef { int r_cr, g_cb, g_cr, b_cb; };
+
+__device__ __forceinline__ void px_int(int yv, int rt, int gt, int bt, int& r, int& g, int& b)
+{
+  r = clip_u8(yv + rt);
+  g = clip_u8(yv + gt);
+  b = clip_u8(yv + bt);
+}
+
+constexpr int INT_THREADS = 256;
+
+// One lane: 16 px x 2 rows.  BPP = 3 (RGB24) or 4 (RGBA32).
+template <int BPP>
+__global__ __launch_bounds__(INT_THREADS) void k_ycbcr420_int(
+    const uint8_t* __restrict__ Y, const uint8_t* __restrict__ Cb, const uint8_t* __restrict__ Cr,
+    uint8_t* __restrict__ out, int w, int h, int ys, int cbs, int crs, int os, IntCoef k,
+    int groups_per_row, int total_groups)
+{
+  // LDS staging: per wave 64 lanes x (16*BPP) bytes per row, two rows.
+  constexpr int LANE_BYTES = 16 * BPP;                // 48 or 64
+  constexpr int LANE_WORDS = LANE_BYTES / 4;          // 12 or 16
+  constexpr int WAVES = INT_THREADS / 64;
+  __shared__ uint32_t stage[WAVES][2][64 * LANE_WORDS];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int gid = blockIdx.x * INT_THREADS + tid;
+  // wave-uniform geometry: all 64 lanes of a wave work on the same row pair when
+  // groups_per_row is a multiple of 64; otherwise fall back to the direct path.
+  const int wave_first = blockIdx.x * INT_THREADS + wave * 64;
+  const int rp_first = wave_first / groups_per_row;
+  const int g_first = wave_first - rp_first * groups_per_row;
+  const bool wave_in_one_row = (g_first + 63 < groups_per_row) && (wave_first + 63 < total_groups);
+
+  int rp = 0, g = 0;
+  bool active = gid < total_groups;
+  if (active) { rp = gid / groups_per_row; g = gid - rp * groups_per_row; }
+  const int x0 = g * 16;
+  const int y0 = rp * 2;
+  const bool full = active && (x0 + 16 <= w) && (y0 + 1 < h);
+
+  uint32_t o0[LANE_WORDS], o1[LANE_WORDS];
+
+  if (full) {
+    const uint4 ya = *reinterpret_cast<const uint4*>(Y + (size_t)y0 * ys + x0);
+    const uint4 yb = *reinterpret_cast<const uint4*>(Y + (size_t)(y0 + 1) * ys + x0);
+    const uint2 ub = *reinterpret_cast<const uint2*>(Cb + (size_t)rp * cbs + (x0 >> 1));
+    const uint2 vb = *reinterpret_cast<const uint2*>(Cr + (size_t)rp * crs + (x0 >> 1));
+    const uint32_t yw0[4] = {ya.x, ya.y, ya.z, ya.w};
+    const uint32_t yw1[4] = {yb.x, yb.y, yb.z, yb.w};
+    const uint32_t uw[2] = {ub.x, ub.y};
+    const uint32_t vw[2] = {vb.x, vb.y};
+
+    uint8_t b0[LANE_BYTES], b1[LANE_BYTES];
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const int u = (int)((uw[c >> 2] >> ((c & 3) * 8)) & 0xFF) - 128;
+      const int v = (int)((vw[c >> 2] >> ((c & 3) * 8)) & 0xFF) - 128;
+      const int rt = (k.r_cr * v + 128) >> 8;               // yuv2rgb.cc:359
+      const int gt = (k.g_cb * u + k.g_cr * v + 128) >> 8;  // :360
+      const int bt = (k.b_cb * u + 128) >> 8;               // :361
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        const int p = 2 * c + s;
+        const int ya_ = (int)((yw0[p >> 2] >> ((p & 3) * 8)) & 0xFF);
+        const int yb_ = (int)((yw1[p >> 2] >> ((p & 3) * 8)) & 0xFF);
+        int r, gg, b;
+        px_int(ya_, rt, gt, bt, r, gg, b);
+        b0[BPP * p + 0] = (uint8_t)r; b0[BPP * p + 1] = (uint8_t)gg; b0[BPP * p + 2] = (uint8_t)b;
+        if (BPP == 4) b0[BPP * p + 3] = 0xFF;
+        px_int(yb_, rt, gt, bt, r, gg, b);
+        b1[BPP * p + 0] = (uint8_t)r; b1[BPP * p + 1] = (uint8_t)gg; b1[BPP * p + 2] = (uint8_t)b;
+        if (BPP == 4) b1[BPP * p + 3] = 0xFF;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < LANE_WORDS; i++) {
+      o0[i] = (uint32_t)b0[4 * i] | ((uint32_t)b0[4 * i + 1] << 8) | ((uint32_t)b0[4 * i + 2] << 16) | ((uint32_t)b0[4 * i + 3] << 24);
+      o1[i] = (uint32_t)b1[4 * i] | ((uint32_t)b1[4 * i + 1] << 8) | ((uint32_t)b1[4 * i + 2] << 16) | ((uint32_t)b1[4 * i + 3] << 24);
+    }
+  }
+
+  // wave-uniform: every lane full and all in one row pair -> LDS transpose, contiguous stores
+  const bool all_full = __all(full ? 1 : 0) && wave_in_one_row;
+  if (all_full) {
+    uint32_t* s0 = stage[wave][0];
+    uint32_t* s1 = stage[wave][1];
+#pragma unroll
+    for (int i = 0; i < LANE_WORDS; i += 4) {
+      *reinterpret_cast<uint4*>(s0 + lane * LANE_WORDS + i) = make_uint4(o0[i], o0[i + 1], o0[i + 2], o0[i + 3]);
+      *reinterpret_cast<uint4*>(s1 + lane * LANE_WORDS + i) = make_uint4(o1[i], o1[i + 1], o1[i + 2], o1[i + 3]);
+    }
+    // same wave reads back: LDS ops of one wave complete in order, no barrier needed beyond a wave fence
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint8_t* row0 = out + (size_t)y0 * os + (size_t)(g_first * 16) * BPP;
+    uint8_t* row1 = row0 + os;
+#pragma unroll
+    for (int j = 0; j < LANE_WORDS / 4; j++) {
+      const int idx = (j * 64 + lane) * 4;
+      const uint4 a = *reinterpret_cast<const uint4*>(s0 + idx);
+      const uint4 b = *reinterpret_cast<const uint4*>(s1 + idx);
+      *reinterpret_cast<uint4*>(row0 + (size_t)idx * 4) = a;
+      *reinterpret_cast<uint4*>(row1 + (size_t)idx * 4) = b;
+    }
+    return;
+  }
+
+  if (full) { // direct 16 B stores (lane stride 48/64 B)
+    uint8_t* row0 = out + (size_t)y0 * os + (size_t)x0 * BPP;
+    uint8_t* row1 = row0 + os;
+#pragma unroll
+    for (int i = 0; i < LANE_WORDS; i += 4) {
+      *reinterpret_cast<uint4*>(row0 + i * 4) = make_uint4(o0[i], o0[i + 1], o0[i + 2], o0[i + 3]);
+      *reinterpret_cast<uint4*>(row1 + i * 4) = make_uint4(o1[i], o1[i + 1], o1[i + 2], o1[i + 3]);
+    }
+    return;
+  }
+
+  if (!active) return;
+  // ragged edge: scalar
+  for (int dy = 0; dy < 2; dy++) {
+    const int py = y0 + dy;
+    if (py >= h) break;
+    for (int dx = 0; dx < 16; dx++) {
+      const int px = x0 + dx;
+      if (px >= w) break;
+      const int yv = Y[(size_t)py * ys + px];
+      const int u = (int)Cb[(size_t)(py >> 1) * cbs + (px >> 1)] - 128;
+      const int v = (int)Cr[(size_t)(py >> 1) * crs + (px >> 1)] - 128;
+      int r, gg, b;
+      px_int(yv, (k.r_cr * v + 128) >> 8, (k.g_cb * u + k.g_cr * v + 128) >> 8, (k.b_cb * u + 128) >> 8, r, gg, b);
+      uint8_t* o = out + (size_t)py * os + (size_t)px * BPP;
+      o[0] = (uint8_t)r; o[1] = (uint8_t)gg; o[2] = (uint8_t)b;
+      if (BPP == 4) o[3] = 0xFF;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Float path (any chroma, 8..16 bit) fused with the interleave
+// ---------------------------------------------------------------------------------------
+
+struct FloatParams {
+  float r_cr, g_cb, g_cr, b_cb;
+  float lim_off;       // 16 << (bpp-8)
+  int half_range;      // 1 << (bpp-1)
+  int maxv;            // (1<<bpp)-1
+  int mode;            // 0 float matrix, 1 GBR copy, 2 GBR limited->full, 3 YCgCo
+  int limited;         // !full_range (mode 0)
+  int shiftH, shiftV;
+};
+
+enum { OF_RGB24 = 0, OF_RGBA32 = 1, OF_RRGGBB_BE = 2, OF_RRGGBB_LE = 3 };
+
+__device__ __forceinline__ void px_float(const FloatParams& p, int Yv, int U, int V, int& r, int& g, int& b)
+{
+  if (p.mode == 0) { // yuv2rgb.cc:233-247
+    float yv = (float)Yv;
+    float cb = (float)(U - p.half_range);
+    float cr = (float)(V - p.half_range);
+    if (p.limited) {
+      yv = __fmul_rn(__fsub_rn(yv, p.lim_off), 1.1689f);
+      cb = __fmul_rn(cb, 1.1429f);
+      cr = __fmul_rn(cr, 1.1429f);
+    }
+    r = clip_f(__fadd_rn(yv, __fmul_rn(p.r_cr, cr)), p.maxv);
+    g = clip_f(__fadd_rn(__fadd_rn(yv, __fmul_rn(p.g_cb, cb)), __fmul_rn(p.g_cr, cr)), p.maxv);
+    b = clip_f(__fadd_rn(yv, __fmul_rn(p.b_cb, cb)), p.maxv);
+  }
+  else if (p.mode == 1) { r = V; g = Yv; b = U; }           // :207-212
+  else if (p.mode == 2) {                                    // :213-219
+    r = clip_f(__fmul_rn(__fsub_rn((float)V, p.lim_off), 1.1429f), p.maxv);
+    g = clip_f(__fmul_rn(__fsub_rn((float)Yv, p.lim_off), 1.1689f), p.maxv);
+    b = clip_f(__fmul_rn(__fsub_rn((float)U, p.lim_off), 1.1429f), p.maxv);
+  }
+  else {                                                     // :221-232 (clipped to 8 bit)
+    const int cb = U - p.half_range, cr = V - p.half_range;
+    r = clip_u8(Yv - cb + cr);
+    g = clip_u8(Yv + cb);
+    b = clip_u8(Yv - cb - cr);
+  }
+}
+
+template <typename Pix>
+__device__ __forceinline__ int ld(const void* base, int stride, int x, int y)
+{
+  return (int)reinterpret_cast<const Pix*>(reinterpret_cast<const uint8_t*>(base) + (size_t)y * stride)[x];
+}
+
+// One lane: N horizontally adjacent pixels of one row (N = 16 for u8, 8 for u16 -> 48 B RGB).
+template <typename Pix, int OF>
+__global__ __launch_bounds__(256) void k_ycbcr_float(
+    const void* __restrict__ Y, const void* __restrict__ Cb, const void* __restrict__ Cr,
+    uint8_t* __restrict__ out, int w, int h, int ys, int cbs, int crs, int os, FloatParams p,
+    int groups_per_row, int total_groups)
+{
+  constexpr int N = sizeof(Pix) == 1 ? 16 : 8;
+  constexpr int OBPP = OF == OF_RGB24 ? 3 : (OF == OF_RGBA32 ? 4 : 6);
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total_groups) return;
+  const int py = gid / groups_per_row;
+  const int g = gid - py * groups_per_row;
+  const int x0 = g * N;
+  const int cy = py >> p.shiftV;
+
+  const bool full = (x0 + N <= w);
+  int yv[N], uu[N], vv[N];
+  if (full) {
+    // vector loads: luma 16 B; chroma 16 B (444) or 8 B (420/422)
+    const uint4 yq = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(Y) + (size_t)py * ys + (size_t)x0 * sizeof(Pix));
+    const uint32_t yw[4] = {yq.x, yq.y, yq.z, yq.w};
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      if (sizeof(Pix) == 1) yv[i] = (yw[i >> 2] >> ((i & 3) * 8)) & 0xFF;
+      else yv[i] = (yw[i >> 1] >> ((i & 1) * 16)) & 0xFFFF;
+    }
+    if (p.shiftH) {
+      const uint2 uq = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(Cb) + (size_t)cy * cbs + (size_t)(x0 >> 1) * sizeof(Pix));
+      const uint2 vq = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(Cr) + (size_t)cy * crs + (size_t)(x0 >> 1) * sizeof(Pix));
+      const uint32_t uw[2] = {uq.x, uq.y}, vw[2] = {vq.x, vq.y};
+#pragma unroll
+      for (int i = 0; i < N; i++) {
+        const int c = i >> 1;
+        if (sizeof(Pix) == 1) { uu[i] = (uw[c >> 2] >> ((c & 3) * 8)) & 0xFF; vv[i] = (vw[c >> 2] >> ((c & 3) * 8)) & 0xFF; }
+        else { uu[i] = (uw[c >> 1] >> ((c & 1) * 16)) & 0xFFFF; vv[i] = (vw[c >> 1] >> ((c & 1) * 16)) & 0xFFFF; }
+      }
+    }
+    else {
+      const uint4 uq = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(Cb) + (size_t)cy * cbs + (size_t)x0 * sizeof(Pix));
+      const uint4 vq = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(Cr) + (size_t)cy * crs + (size_t)x0 * sizeof(Pix));
+      const uint32_t uw[4] = {uq.x, uq.y, uq.z, uq.w}, vw[4] = {vq.x, vq.y, vq.z, vq.w};
+#pragma unroll
+      for (int i = 0; i < N; i++) {
+        if (sizeof(Pix) == 1) { uu[i] = (uw[i >> 2] >> ((i & 3) * 8)) & 0xFF; vv[i] = (vw[i >> 2] >> ((i & 3) * 8)) & 0xFF; }
+        else { uu[i] = (uw[i >> 1] >> ((i & 1) * 16)) & 0xFFFF; vv[i] = (vw[i >> 1] >> ((i & 1) * 16)) & 0xFFFF; }
+      }
+    }
+  }
+  else {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const int px = x0 + i < w ? x0 + i : w - 1;
+      yv[i] = ld<Pix>(Y, ys, px, py);
+      uu[i] = ld<Pix>(Cb, cbs, px >> p.shiftH, cy);
+      vv[i] = ld<Pix>(Cr, crs, px >> p.shiftH, cy);
+    }
+  }
+
+  uint8_t ob[N * OBPP];
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    int r, gg, b;
+    px_float(p, yv[i], uu[i], vv[i], r, gg, b);
+    if (OF == OF_RGB24) { ob[3 * i] = (uint8_t)r; ob[3 * i + 1] = (uint8_t)gg; ob[3 * i + 2] = (uint8_t)b; }
+    else if (OF == OF_RGBA32) { ob[4 * i] = (uint8_t)r; ob[4 * i + 1] = (uint8_t)gg; ob[4 * i + 2] = (uint8_t)b; ob[4 * i + 3] = 0xFF; }
+    else if (OF == OF_RRGGBB_BE) { // rgb2rgb.cc:250-268
+      ob[6 * i + 0] = (uint8_t)(r >> 8); ob[6 * i + 1] = (uint8_t)r;
+      ob[6 * i + 2] = (uint8_t)(gg >> 8); ob[6 * i + 3] = (uint8_t)gg;
+      ob[6 * i + 4] = (uint8_t)(b >> 8); ob[6 * i + 5] = (uint8_t)b;
+    }
+    else { // + rgb2rgb.cc:721-726
+      ob[6 * i + 1] = (uint8_t)(r >> 8); ob[6 * i + 0] = (uint8_t)r;
+      ob[6 * i + 3] = (uint8_t)(gg >> 8); ob[6 * i + 2] = (uint8_t)gg;
+      ob[6 * i + 5] = (uint8_t)(b >> 8); ob[6 * i + 4] = (uint8_t)b;
+    }
+  }
+
+  uint8_t* o = out + (size_t)py * os + (size_t)x0 * OBPP;
+  if (full) {
+    constexpr int WORDS = N * OBPP / 4;
+#pragma unroll
+    for (int i = 0; i < WORDS; i += 4) {
+      uint32_t wd[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int q = 4 * (i + j);
+        wd[j] = (uint32_t)ob[q] | ((uint32_t)ob[q + 1] << 8) | ((uint32_t)ob[q + 2] << 16) | ((uint32_t)ob[q + 3] << 24);
+      }
+      *reinterpret_cast<uint4*>(o + i * 4) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+    }
+  }
+  else {
+    const int n = w - x0;
+    for (int i = 0; i < n * OBPP; i++) o[i] = ob[i];
+  }
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------
+// host launchers (called from colour_host.cpp through hm_internal.h)
+// ---------------------------------------------------------------------------------------
+
+extern "C" int hm_launch_colour_int420(const hm_colour_desc* d, const int coef[4], const void* y, const void* cb,
+                                       const void* cr, void* out, hipStream_t s)
+{
+  const int gpr = (d->width + 15) / 16;
+  const int rps = (d->height + 1) / 2;
+  const long total = (long)gpr * rps;
+  if (total <= 0) return HM_OK;
+  const int blocks = (int)((total + INT_THREADS - 1) / INT_THREADS);
+  IntCoef k{coef[0], coef[1], coef[2], coef[3]};
+  if (d->out_format == HM_OUT_RGB)
+    hipLaunchKernelGGL(k_ycbcr420_int<3>, dim3(blocks), dim3(INT_THREADS), 0, s, (const uint8_t*)y, (const uint8_t*)cb,
+                       (const uint8_t*)cr, (uint8_t*)out, d->width, d->height, d->y_stride, d->cb_stride, d->cr_stride,
+                       d->out_stride, k, gpr, (int)total);
+  else
+    hipLaunchKernelGGL(k_ycbcr420_int<4>, dim3(blocks), dim3(INT_THREADS), 0, s, (const uint8_t*)y, (const uint8_t*)cb,
+                       (const uint8_t*)cr, (uint8_t*)out, d->width, d->height, d->y_stride, d->cb_stride, d->cr_stride,
+                       d->out_stride, k, gpr, (int)total);
+  return hm_check_hip(hipGetLastError(), "k_ycbcr420_int launch");
+}
+
+template <typename Pix, int OF>
+static int launch_float(const hm_colour_desc* d, const FloatParams& p, const void* y, const void* cb, const void* cr,
+                        void* out, hipStream_t s)
+{
+  constexpr int N = sizeof(Pix) == 1 ? 16 : 8;
+  const int gpr = (d->width + N - 1) / N;
+  const long total = (long)gpr * d->height;
+  if (total <= 0) return HM_OK;
+  const int blocks = (int)((total + 255) / 256);
+  hipLaunchKernelGGL((k_ycbcr_float<Pix, OF>), dim3(blocks), dim3(256), 0, s, y, cb, cr, (uint8_t*)out, d->width,
+                     d->height, d->y_stride, d->cb_stride, d->cr_stride, d->out_stride, p, gpr, (int)total);
+  return hm_check_hip(hipGetLastError(), "k_ycbcr_float launch");
+}
+
+extern "C" int hm_launch_colour_float(const hm_colour_desc* d, const float coef[4], int mode, const void* y,
+                                      const void* cb, const void* cr, void* out, hipStream_t s)
+{
+  FloatParams p;
+  p.r_cr = coef[0]; p.g_cb = coef[1]; p.g_cr = coef[2]; p.b_cb = coef[3];
+  p.lim_off = (float)(16 << (d->bit_depth - 8));
+  p.half_range = 1 << (d->bit_depth - 1);
+  p.maxv = (1 << d->bit_depth) - 1;
+  p.mode = mode;
+  p.limited = d->has_nclx ? !d->full_range : 0;
+  p.shiftH = d->chroma == HM_CHROMA_444 ? 0 : 1;
+  p.shiftV = d->chroma == HM_CHROMA_420 ? 1 : 0;
+  if (d->bit_depth == 8) {
+    if (d->out_format == HM_OUT_RGB) return launch_float<uint8_t, OF_RGB24>(d, p, y, cb, cr, out, s);
+    if (d->out_format == HM_OUT_RGBA) return launch_float<uint8_t, OF_RGBA32>(d, p, y, cb, cr, out, s);
+    return HM_ERR_UNSUPPORTED;
+  }
+  if (d->out_format == HM_OUT_RRGGBB_BE) return launch_float<uint16_t, OF_RRGGBB_BE>(d, p, y, cb, cr, out, s);
+  if (d->out_format == HM_OUT_RRGGBB_LE) return launch_float<uint16_t, OF_RRGGBB_LE>(d, p, y, cb, cr, out, s);
+  return HM_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,166 @@
+// colour_host.cpp — host side of the colour path: op-chain selection, matrix
+// coefficients, plane geometry.  Mirrors what convert_colorspace() decides
+// (libheif/color-conversion/colorconversion.cc:487-596 and the state_after_conversion
+// predicates in yuv2rgb.cc:264-303, 372-413, 498-547, 33-76); the arithmetic runs in colour.hip.
+//
+// Compiled with -ffp-contract=off: the coefficient floats must be produced by the same
+// sequence of binary32 operations as nclx.cc:152-171.
+#include <cmath>
+#include <cstring>
+
+#include "hm_internal.h"
+
+namespace {
+
+struct Primaries { float gx, gy, bx, by, rx, ry, wx, wy; bool defined; };
+
+// chromaticities of ITU-T H.273 colour_primaries (values as in nclx.cc:46-74)
+Primaries primaries_for(int idx)
+{
+  switch (idx) {
+    case 1:  return {0.300f, 0.600f, 0.150f, 0.060f, 0.640f, 0.330f, 0.3127f, 0.3290f, true};
+    case 4:  return {0.21f, 0.71f, 0.14f, 0.08f, 0.67f, 0.33f, 0.310f, 0.316f, true};
+    case 5:  return {0.29f, 0.60f, 0.15f, 0.06f, 0.64f, 0.33f, 0.3127f, 0.3290f, true};
+    case 6: case 7: return {0.310f, 0.595f, 0.155f, 0.070f, 0.630f, 0.340f, 0.3127f, 0.3290f, true};
+    case 8:  return {0.243f, 0.692f, 0.145f, 0.049f, 0.681f, 0.319f, 0.310f, 0.316f, true};
+    case 9:  return {0.170f, 0.797f, 0.131f, 0.046f, 0.708f, 0.292f, 0.3127f, 0.3290f, true};
+    case 10: return {0.0f, 1.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.333333f, 0.33333f, true};
+    case 11: return {0.265f, 0.690f, 0.150f, 0.060f, 0.680f, 0.320f, 0.314f, 0.351f, true};
+    case 12: return {0.265f, 0.690f, 0.150f, 0.060f, 0.680f, 0.320f, 0.3127f, 0.3290f, true};
+    case 22: return {0.295f, 0.605f, 0.155f, 0.077f, 0.630f, 0.340f, 0.3127f, 0.3290f, true};
+    default: return {0, 0, 0, 0, 0, 0, 0, 0, false};
+  }
+}
+
+void luma_weights(int matrix, int primaries, float& Kr, float& Kb) // nclx.cc:85-138
+{
+  Kr = 0; Kb = 0;
+  if (matrix == 12 || matrix == 13) {
+    const Primaries p = primaries_for(primaries);
+    const float zr = 1 - (p.rx + p.ry), zg = 1 - (p.gx + p.gy), zb = 1 - (p.bx + p.by), zw = 1 - (p.wx + p.wy);
+    const float denom = p.wy * (p.rx * (p.gy * zb - p.by * zg) + p.gx * (p.by * zr - p.ry * zb) + p.bx * (p.ry * zg - p.gy * zr));
+    if (denom == 0.0f) return;
+    Kr = (p.ry * (p.wx * (p.gy * zb - p.by * zg) + p.wy * (p.bx * zg - p.gx * zb) + zw * (p.gx * p.by - p.bx * p.gy))) / denom;
+    Kb = (p.by * (p.wx * (p.ry * zg - p.gy * zr) + p.wy * (p.gx * zr - p.rx * zg) + zw * (p.rx * p.gy - p.gx * p.ry))) / denom;
+    return;
+  }
+  switch (matrix) {
+    case 1: Kr = 0.2126f; Kb = 0.0722f; break;
+    case 4: Kr = 0.30f; Kb = 0.11f; break;
+    case 5: case 6: Kr = 0.299f; Kb = 0.114f; break;
+    case 7: Kr = 0.212f; Kb = 0.087f; break;
+    case 9: case 10: Kr = 0.2627f; Kb = 0.0593f; break;
+    default: break;
+  }
+}
+
+// the state convert_colorspace() builds for the input image (colorconversion.cc:520-532):
+// image nclx or the default-constructed profile (2,2,2,full=1, nclx.h:165-168), then
+// replace_undefined_values_with_sRGB_defaults() (nclx.cc:346-359): matrix 2 -> 6.
+void selection_state(const hm_colour_desc* d, int& matrix, bool& full_range)
+{
+  matrix = d->has_nclx ? d->matrix : 2;
+  full_range = d->has_nclx ? d->full_range != 0 : true;
+  if (matrix == 2) matrix = 6;
+}
+
+int validate(const hm_colour_desc* d)
+{
+  if (!d) return hm_fail(HM_ERR_INVALID_ARG, "null colour descriptor");
+  if (d->width <= 0 || d->height <= 0) return hm_fail(HM_ERR_INVALID_ARG, "bad image size %dx%d", d->width, d->height);
+  if (d->bit_depth < 8 || d->bit_depth > 16) return hm_fail(HM_ERR_UNSUPPORTED, "bit depth %d", d->bit_depth);
+  if (d->chroma != HM_CHROMA_420 && d->chroma != HM_CHROMA_422 && d->chroma != HM_CHROMA_444)
+    return hm_fail(HM_ERR_UNSUPPORTED, "chroma format %d", d->chroma);
+  return HM_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int hm_plane_stride(int width, int bytes_per_pixel) // pixelimage.cc:139-148,198-199
+{
+  unsigned mem_w = ((unsigned)width + 1u) & ~1u;
+  if (mem_w < 64u) mem_w = 64u;
+  return (int)((mem_w * (unsigned)bytes_per_pixel + 15u) & ~15u);
+}
+
+int hm_out_bytes_per_pixel(int out_format)
+{
+  switch (out_format) {
+    case HM_OUT_RGB: return 3;
+    case HM_OUT_RGBA: return 4;
+    case HM_OUT_RRGGBB_BE: case HM_OUT_RRGGBB_LE: return 6;
+    default: return hm_fail(HM_ERR_UNSUPPORTED, "output format %d", out_format);
+  }
+}
+
+int hm_ycbcr_coefficients(int has_nclx, int matrix, int primaries, float out[4])
+{
+  if (!out) return hm_fail(HM_ERR_INVALID_ARG, "null output");
+  // YCbCr_to_RGB_coefficients::defaults(), nclx.cc:141-150
+  out[0] = 1.402f; out[1] = -0.344136f; out[2] = -0.714136f; out[3] = 1.772f;
+  if (!has_nclx) return HM_OK;
+  float Kr, Kb;
+  luma_weights(matrix, primaries, Kr, Kb);
+  if (Kb != 0 || Kr != 0) { // nclx.cc:159-165
+    out[0] = 2 * (-Kr + 1);
+    out[1] = 2 * Kb * (-Kb + 1) / (Kb + Kr - 1);
+    out[2] = 2 * Kr * (-Kr + 1) / (Kb + Kr - 1);
+    out[3] = 2 * (-Kb + 1);
+  }
+  return HM_OK;
+}
+
+int hm_colour_pipeline(const hm_colour_desc* d)
+{
+  int rc = validate(d);
+  if (rc) return rc;
+  int matrix; bool full;
+  selection_state(d, matrix, full);
+  const bool rgb8 = d->out_format == HM_OUT_RGB || d->out_format == HM_OUT_RGBA;
+  const bool rgb16 = d->out_format == HM_OUT_RRGGBB_BE || d->out_format == HM_OUT_RRGGBB_LE;
+  if (!rgb8 && !rgb16) return hm_fail(HM_ERR_UNSUPPORTED, "output format %d", d->out_format);
+  if (d->bit_depth == 8 && rgb8) {
+    // Op_YCbCr420_to_RGB24/32 accept: 4:2:0, 8 bit, matrix not in {0,8,11,14}, full range
+    // (yuv2rgb.cc:274-287, 383-397); both cost 11 < 22 of the float chain
+    const bool special = matrix == 0 || matrix == 8 || matrix == 11 || matrix == 14;
+    if (d->chroma == HM_CHROMA_420 && !special && full) return HM_PIPE_INT420;
+    return HM_PIPE_FLOAT; // Op_YCbCr_to_RGB<u8> -> Op_RGB_to_RGB24_32
+  }
+  if (d->bit_depth > 8 && rgb16) return HM_PIPE_FLOAT; // Op_YCbCr_to_RGB<u16> -> RRGGBB (or the 4:2:0 direct op: same arithmetic)
+  // 8 -> 16 or 16 -> 8 bit needs the reference's bit-depth ops (hdr_sdr.cc): outside the hot path (§8f rank 3)
+  return hm_fail(HM_ERR_UNSUPPORTED, "bit depth %d -> output format %d needs a depth-conversion op", d->bit_depth, d->out_format);
+}
+
+int hm_colour_convert(const hm_colour_desc* d, const void* d_y, const void* d_cb, const void* d_cr, void* d_out, void* stream)
+{
+  const int pipe = hm_colour_pipeline(d);
+  if (pipe < 0) return pipe;
+  if (!d_y || !d_cb || !d_cr || !d_out) return hm_fail(HM_ERR_INVALID_ARG, "null device pointer");
+  const int bps = d->bit_depth > 8 ? 2 : 1;
+  // the vector fast paths need 16 B aligned rows (true for every libheif-style plane)
+  if ((d->y_stride % 16) || (d->cb_stride % 8) || (d->cr_stride % 8) || (d->out_stride % 16) ||
+      ((uintptr_t)d_y % 16) || ((uintptr_t)d_cb % 16) || ((uintptr_t)d_cr % 16) || ((uintptr_t)d_out % 16))
+    return hm_fail(HM_ERR_INVALID_ARG, "planes must be 16-byte aligned with 16-byte multiple strides");
+  if (d->y_stride < d->width * bps || d->out_stride < d->width * hm_out_bytes_per_pixel(d->out_format))
+    return hm_fail(HM_ERR_INVALID_ARG, "stride smaller than row");
+
+  float cf[4];
+  // ops read the image's own nclx (not the selection state): yuv2rgb.cc:190-198, 329-334
+  hm_ycbcr_coefficients(d->has_nclx, d->matrix, d->primaries, cf);
+  hipStream_t s = (hipStream_t)stream;
+  if (pipe == HM_PIPE_INT420) {
+    const int ci[4] = {(int)std::lround(256 * cf[0]), (int)std::lround(256 * cf[1]),
+                       (int)std::lround(256 * cf[2]), (int)std::lround(256 * cf[3])}; // yuv2rgb.cc:336-339
+    return hm_launch_colour_int420(d, ci, d_y, d_cb, d_cr, d_out, s);
+  }
+  const int m = d->has_nclx ? d->matrix : 2;
+  const bool full = d->has_nclx ? d->full_range != 0 : true;
+  int mode = 0;
+  if (m == 0) mode = full ? 1 : 2;
+  else if (m == 8) mode = 3;
+  return hm_launch_colour_float(d, cf, mode, d_y, d_cb, d_cr, d_out, s);
+}
+
+} // extern "C"

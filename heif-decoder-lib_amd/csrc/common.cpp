@@ -1,0 +1,52 @@
+// common.cpp — status strings, thread-local error detail, device probing.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "hm_internal.h"
+
+static thread_local char g_last_error[512] = "";
+
+extern "C" {
+
+int hm_fail(int status, const char* fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+  va_end(ap);
+  return status;
+}
+
+int hm_check_hip(hipError_t e, const char* what)
+{
+  if (e == hipSuccess) return HM_OK;
+  return hm_fail(HM_ERR_NO_DEVICE, "%s: %s", what, hipGetErrorString(e));
+}
+
+const char* hm_last_error(void) { return g_last_error; }
+
+const char* hm_status_string(int status)
+{
+  switch (status) {
+    case HM_OK: return "ok";
+    case HM_ERR_INVALID_ARG: return "invalid argument";
+    case HM_ERR_UNSUPPORTED: return "unsupported feature";
+    case HM_ERR_BITSTREAM: return "invalid bitstream";
+    case HM_ERR_NO_DEVICE: return "HIP device/runtime error";
+    case HM_ERR_NOMEM: return "out of memory";
+    case HM_ERR_INTERNAL: return "internal error";
+    default: return "unknown status";
+  }
+}
+
+const char* hm_version(void) { return "heif-mi355x 0.1.0 (gfx950)"; }
+
+int hm_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+} // extern "C"

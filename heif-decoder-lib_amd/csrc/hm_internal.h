@@ -1,0 +1,27 @@
+// hm_internal.h — declarations shared between the host translation units and the HIP
+// launchers of libheif_mi355x.so.  Not part of the public ABI (see include/heif_mi355x.h).
+#ifndef HM_INTERNAL_H
+#define HM_INTERNAL_H
+
+#include <hip/hip_runtime_api.h>
+
+#include "heif_mi355x.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+// records `what` + the HIP error string in the thread-local last-error slot
+int hm_check_hip(hipError_t e, const char* what);
+int hm_fail(int status, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// colour.hip
+int hm_launch_colour_int420(const hm_colour_desc* d, const int coef[4], const void* y, const void* cb,
+                            const void* cr, void* out, hipStream_t s);
+int hm_launch_colour_float(const hm_colour_desc* d, const float coef[4], int mode, const void* y,
+                           const void* cb, const void* cr, void* out, hipStream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

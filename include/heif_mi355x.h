@@ -1,0 +1,98 @@
+/* heif_mi355x.h — C ABI of the MI355X (gfx950) HEIC hot path.
+ *
+ * Drop-in boundary for the path  heif_decode_image() -> grid -> per-tile HEVC-intra
+ * reconstruction -> deblock -> SAO -> paste -> YCbCr->RGB  of aliyun/heif-decoder-lib.
+ * Plain pointers and sizes only; no C++/torch types.  Device pointers are raw HIP
+ * device addresses (e.g. torch.Tensor.data_ptr()); `stream` is a hipStream_t passed
+ * as void* (NULL = the default stream).
+ *
+ * Reference interfaces replaced (paths relative to the reference tree):
+ *   hm_colour_convert        <- convert_colorspace()               libheif/color-conversion/colorconversion.cc:487-596
+ *                               Op_YCbCr420_to_RGB24/32            libheif/color-conversion/yuv2rgb.cc:306-366, 416-495
+ *                               Op_YCbCr_to_RGB<u8/u16> + repack   yuv2rgb.cc:79-254, rgb2rgb.cc:66-143,189-272,676-729
+ *                               Op_YCbCr420_to_RRGGBBaa            yuv2rgb.cc:550-643
+ *   hm_plane_stride          <- HeifPixelImage::ImagePlane::alloc  libheif/pixelimage.cc:139-218
+ *   hm_ycbcr_coefficients    <- get_YCbCr_to_RGB_coefficients      libheif/nclx.cc:152-171
+ *   hm_hevc_parse / hm_stream_* <- libde265 slice-data parsing     third-party/libde265/libde265/slice.cc:2886-5600
+ *                               (CABAC stays on the host; output = the GPU command stream, hm_stream.h)
+ *   hm_batch_* / hm_decode_* <- decode_full_grid_image + decode_and_paste_tile_image
+ *                                                                  libheif/context.cc:2120-2539
+ *                               and libde265's reconstruction      transform.cc, intrapred.{h,cc}, deblock.cc, sao.cc
+ *
+ * Every function returns HM_OK (0) or a negative hm_status; nothing falls back to a
+ * CPU implementation: if the HIP runtime / device is missing the call fails with
+ * HM_ERR_NO_DEVICE.
+ */
+#ifndef HEIF_MI355X_H
+#define HEIF_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define HM_API __attribute__((visibility("default")))
+#else
+#define HM_API
+#endif
+
+typedef enum hm_status {
+  HM_OK = 0,
+  HM_ERR_INVALID_ARG = -1,
+  HM_ERR_UNSUPPORTED = -2,     /* syntax / format outside the supported hot path      */
+  HM_ERR_BITSTREAM = -3,       /* malformed HEVC / HEIF input                           */
+  HM_ERR_NO_DEVICE = -4,       /* no HIP device, or a HIP call failed                   */
+  HM_ERR_NOMEM = -5,
+  HM_ERR_INTERNAL = -6,
+} hm_status;
+
+HM_API const char* hm_status_string(int status);
+/* last error detail for the calling thread (static storage, never NULL) */
+HM_API const char* hm_last_error(void);
+HM_API const char* hm_version(void);
+/* number of visible HIP devices (0 if none); does not initialise a context */
+HM_API int hm_device_count(void);
+
+/* ------------------------------------------------------------------------- */
+/* Colour conversion                              */
+/* ------------------------------------------------------------------------- */
+
+/* values equal enum heif_chroma (libheif/api/libheif/heif.h:481-494) */
+enum {
+  HM_CHROMA_MONO = 0, HM_CHROMA_420 = 1, HM_CHROMA_422 = 2, HM_CHROMA_444 = 3,
+  HM_OUT_RGB = 10, HM_OUT_RGBA = 11, HM_OUT_RRGGBB_BE = 12, HM_OUT_RRGGBB_LE = 14,
+};
+
+typedef struct hm_colour_desc {
+  int32_t width, height;        /* luma size in pixels                                         */
+  int32_t bit_depth;            /* 8..16; planes are uint8 (8) or uint16 little-endian (>8)    */
+  int32_t chroma;               /* HM_CHROMA_420 / _422 / _444                                  */
+  int32_t has_nclx;             /* 0: image carries no nclx (every grid canvas) => defaults     */
+  int32_t matrix, primaries, full_range; /* the attached nclx (ignored when !has_nclx)          */
+  int32_t out_format;           /* HM_OUT_*                                                     */
+  int32_t y_stride, cb_stride, cr_stride, out_stride; /* bytes                                  */
+} hm_colour_desc;
+
+/* which reference op chain convert_colorspace() would pick for this state (§3.4 of SURVEY) */
+enum { HM_PIPE_INT420 = 1, HM_PIPE_FLOAT = 2 };
+HM_API int hm_colour_pipeline(const hm_colour_desc* d); /* HM_PIPE_* or negative status */
+
+/* Observable libheif plane stride for a plane `width` pixels wide (pixelimage.cc:139-218). */
+HM_API int hm_plane_stride(int width, int bytes_per_pixel);
+/* bytes per output pixel of an HM_OUT_* format (3,4,6) */
+HM_API int hm_out_bytes_per_pixel(int out_format);
+
+/* float32 coefficients exactly as nclx.cc:152-171 computes them: r_cr, g_cb, g_cr, b_cb */
+HM_API int hm_ycbcr_coefficients(int has_nclx, int matrix, int primaries, float out[4]);
+
+/* Convert device planes to the interleaved device buffer. Asynchronous on `stream`. */
+HM_API int hm_colour_convert(const hm_colour_desc* d, const void* d_y, const void* d_cb,
+                             const void* d_cr, void* d_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HEIF_MI355X_H */

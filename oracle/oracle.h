@@ -1,0 +1,83 @@
+/* oracle/oracle.h — TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C CPU restatement of the reference arithmetic on the hot path
+ * (SURVEY.md §8a rows R1-R5, F1, F2, A5, C2-C4).  Every function cites the
+ * reference file:line it follows.  Nothing in the product links this; only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg load
+ * oracle/liboracle.so — as the checker, never as the thing measured.
+ *
+ * Pinning status:
+ *   - reconstruction / deblock / SAO: pinned against the real reference decoder
+ *     (oracle/_ref/libde265_ref.so, md5 of BASELINE.md reproduced) on real and
+ *     synthetic streams.
+ *   - colour conversion / grid paste: libheif cannot be built without its cmake
+ *     (generated heif_version.h), so these are pinned by the reference
+ *     fingerprints recorded in BASELINE.md §2 and by the reference's own
+ *     bilinear known-answer test (tests/conversion.cc:635-670).
+ */
+#ifndef HM_ORACLE_H
+#define HM_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- colour ------------------------------------------------------------- */
+
+typedef struct orc_coeffs {
+  float r_cr, g_cb, g_cr, b_cb;
+} orc_coeffs;
+
+/* output layouts (values match enum heif_chroma, libheif/api/libheif/heif.h:481-494) */
+enum {
+  ORC_OUT_RGB24 = 10,
+  ORC_OUT_RGBA32 = 11,
+  ORC_OUT_RRGGBB_BE = 12,
+  ORC_OUT_RRGGBB_LE = 14,
+};
+
+/* nclx.cc:85-171 */
+orc_coeffs orc_ycbcr_to_rgb_coeffs(int has_nclx, int matrix, int primaries);
+
+/* pixelimage.cc:139-218: observable plane stride for a plane of `width` pixels */
+int orc_plane_stride(int width, int bytes_per_pixel);
+
+/* yuv2rgb.cc:306-366 (out_fmt RGB24) and :416-495 (RGBA32, alpha = 0xFF):
+ * integer 8-bit 4:2:0, full range.  */
+void orc_ycbcr420_to_rgb_int(const uint8_t* y, int ys, const uint8_t* cb, int cbs,
+                             const uint8_t* cr, int crs, int w, int h,
+                             int has_nclx, int matrix, int primaries,
+                             uint8_t* out, int os, int out_fmt);
+
+/* yuv2rgb.cc:79-254 followed by rgb2rgb.cc:66-143 (8 bit -> RGB24/RGBA32) or
+ * rgb2rgb.cc:189-272 [+ :676-729 byte swap] (>8 bit -> RRGGBB_BE / _LE);
+ * also covers yuv2rgb.cc:550-643 (4:2:0 >8 bit -> RRGGBB) whose arithmetic is identical.
+ * chroma: 1=420 2=422 3=444.  Planes hold uint8 (bpp==8) or uint16 (bpp>8); strides in BYTES. */
+void orc_ycbcr_to_rgb_float(const void* y, int ys, const void* cb, int cbs,
+                            const void* cr, int crs, int w, int h, int bpp, int chroma,
+                            int has_nclx, int matrix, int primaries, int full_range,
+                            uint8_t* out, int os, int out_fmt);
+
+/* context.cc:2457-2535: paste one decoded tile plane into the grid canvas plane.
+ * channel: 0=Y 1=Cb 2=Cr.  chroma: 1=420 2=422 3=444.  All sizes in samples, strides in bytes.
+ * Reproduces the byte-wise limited->full rescale quirk (Q1/Q2). Returns 0, or -1 if the
+ * tile origin lies outside the canvas (heif_suberror_Invalid_grid_data). */
+int orc_paste_tile_plane(const uint8_t* tile, int tile_stride, int tile_w, int tile_h,
+                         uint8_t* canvas, int canvas_stride, int canvas_w_luma, int canvas_h_luma,
+                         int x0_luma, int y0_luma, int channel, int chroma, int bpp,
+                         int tile_has_nclx, int tile_full_range, int tile_matrix);
+
+/* chroma_sampling.cc:585-700: bilinear 4:2:0 chroma up-sampling to 4:4:4 (8 bit, one plane) */
+void orc_upsample_bilinear_420(const uint8_t* in, int is, int w, int h, uint8_t* out, int os);
+
+uint64_t orc_fnv1a64(const uint8_t* p, size_t n, uint64_t h);
+/* hash `rows` tight rows of `row_bytes` from a strided plane */
+uint64_t orc_fnv1a64_rows(const uint8_t* p, int stride, int row_bytes, int rows, uint64_t h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

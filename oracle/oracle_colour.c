@@ -1,0 +1,329 @@
+/* oracle/oracle_colour.c — TEST INFRASTRUCTURE ONLY (see oracle.h).
+ *
+ * CPU restatement of the reference's YCbCr -> RGB operations, the grid tile paste
+ * and the bilinear chroma up-sampler.  Compiled with -ffp-contract=off and no
+ * -march flags so every float operation is an individually rounded IEEE binary32
+ * operation, exactly like the reference's x86-64 SSE2 scalar code.
+ */
+#include "oracle.h"
+
+#include <math.h>
+#include <string.h>
+
+/* ---- helpers ------------------------------------------------------------ */
+
+/* common_utils.h:56-61 */
+static inline uint8_t clip_int_u8(int x) { return x < 0 ? 0 : (x > 255 ? 255 : (uint8_t)x); }
+
+/* common_utils.h:64-70 : truncation of (fx + 0.5f) through `long` */
+static inline uint16_t clip_f_u16(float fx, int32_t maxi)
+{
+  long x = (long)(fx + 0.5f);
+  if (x < 0) return 0;
+  if (x > maxi) return (uint16_t)maxi;
+  return (uint16_t)x;
+}
+
+/* common_utils.h:73-79 */
+static inline uint8_t clip_f_u8(float fx)
+{
+  long x = (long)(fx + 0.5f);
+  if (x < 0) return 0;
+  if (x > 255) return 255;
+  return (uint8_t)x;
+}
+
+uint64_t orc_fnv1a64(const uint8_t* p, size_t n, uint64_t h)
+{
+  if (h == 0) h = 0xcbf29ce484222325ull;
+  for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 0x100000001b3ull; }
+  return h;
+}
+
+uint64_t orc_fnv1a64_rows(const uint8_t* p, int stride, int row_bytes, int rows, uint64_t h)
+{
+  if (h == 0) h = 0xcbf29ce484222325ull;
+  for (int y = 0; y < rows; y++) h = orc_fnv1a64(p + (size_t)y * stride, (size_t)row_bytes, h);
+  return h;
+}
+
+/* pixelimage.cc:139-148 (rounded_size) and :198-199 (16-byte aligned stride) */
+int orc_plane_stride(int width, int bytes_per_pixel)
+{
+  unsigned mem_w = ((unsigned)width + 1u) & ~1u;
+  if (mem_w < 64) mem_w = 64;
+  unsigned stride = mem_w * (unsigned)bytes_per_pixel;
+  return (int)((stride + 15u) & ~15u);
+}
+
+/* ---- matrix coefficients (nclx.cc:43-171) -------------------------------- */
+
+typedef struct { float gx, gy, bx, by, rx, ry, wx, wy; int defined; } prim_t;
+
+static prim_t primaries_of(int idx) /* nclx.cc:46-74: table of ITU-T H.273 chromaticities */
+{
+  static const struct { int idx; prim_t p; } tab[] = {
+    {1,  {0.300f, 0.600f, 0.150f, 0.060f, 0.640f, 0.330f, 0.3127f, 0.3290f, 1}},
+    {4,  {0.21f, 0.71f, 0.14f, 0.08f, 0.67f, 0.33f, 0.310f, 0.316f, 1}},
+    {5,  {0.29f, 0.60f, 0.15f, 0.06f, 0.64f, 0.33f, 0.3127f, 0.3290f, 1}},
+    {6,  {0.310f, 0.595f, 0.155f, 0.070f, 0.630f, 0.340f, 0.3127f, 0.3290f, 1}},
+    {7,  {0.310f, 0.595f, 0.155f, 0.070f, 0.630f, 0.340f, 0.3127f, 0.3290f, 1}},
+    {8,  {0.243f, 0.692f, 0.145f, 0.049f, 0.681f, 0.319f, 0.310f, 0.316f, 1}},
+    {9,  {0.170f, 0.797f, 0.131f, 0.046f, 0.708f, 0.292f, 0.3127f, 0.3290f, 1}},
+    {10, {0.0f, 1.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.333333f, 0.33333f, 1}},
+    {11, {0.265f, 0.690f, 0.150f, 0.060f, 0.680f, 0.320f, 0.314f, 0.351f, 1}},
+    {12, {0.265f, 0.690f, 0.150f, 0.060f, 0.680f, 0.320f, 0.3127f, 0.3290f, 1}},
+    {22, {0.295f, 0.605f, 0.155f, 0.077f, 0.630f, 0.340f, 0.3127f, 0.3290f, 1}},
+  };
+  for (size_t i = 0; i < sizeof(tab) / sizeof(tab[0]); i++)
+    if (tab[i].idx == idx) return tab[i].p;
+  prim_t none; memset(&none, 0, sizeof(none));
+  return none;
+}
+
+static void kr_kb_of(int matrix, int primaries, float* Kr, float* Kb) /* nclx.cc:85-138 */
+{
+  *Kr = 0; *Kb = 0;
+  if (matrix == 12 || matrix == 13) {
+    prim_t p = primaries_of(primaries);
+    float zr = 1 - (p.rx + p.ry);
+    float zg = 1 - (p.gx + p.gy);
+    float zb = 1 - (p.bx + p.by);
+    float zw = 1 - (p.wx + p.wy);
+    float denom = p.wy * (p.rx * (p.gy * zb - p.by * zg) + p.gx * (p.by * zr - p.ry * zb) +
+                          p.bx * (p.ry * zg - p.gy * zr));
+    if (denom == 0.0f) return;
+    *Kr = (p.ry * (p.wx * (p.gy * zb - p.by * zg) + p.wy * (p.bx * zg - p.gx * zb) +
+                   zw * (p.gx * p.by - p.bx * p.gy))) / denom;
+    *Kb = (p.by * (p.wx * (p.ry * zg - p.gy * zr) + p.wy * (p.gx * zr - p.rx * zg) +
+                   zw * (p.rx * p.gy - p.gx * p.ry))) / denom;
+    return;
+  }
+  switch (matrix) {
+    case 1: *Kr = 0.2126f; *Kb = 0.0722f; break;
+    case 4: *Kr = 0.30f;   *Kb = 0.11f;   break;
+    case 5: case 6: *Kr = 0.299f; *Kb = 0.114f; break;
+    case 7: *Kr = 0.212f;  *Kb = 0.087f;  break;
+    case 9: case 10: *Kr = 0.2627f; *Kb = 0.0593f; break;
+    default: break;
+  }
+}
+
+orc_coeffs orc_ycbcr_to_rgb_coeffs(int has_nclx, int matrix, int primaries)
+{
+  orc_coeffs c = {1.402f, -0.344136f, -0.714136f, 1.772f}; /* nclx.cc:141-150 */
+  if (!has_nclx) return c;
+  float Kr, Kb;
+  kr_kb_of(matrix, primaries, &Kr, &Kb);
+  if (Kb != 0 || Kr != 0) { /* nclx.cc:159-165, float evaluation order preserved */
+    c.r_cr = 2 * (-Kr + 1);
+    c.g_cb = 2 * Kb * (-Kb + 1) / (Kb + Kr - 1);
+    c.g_cr = 2 * Kr * (-Kr + 1) / (Kb + Kr - 1);
+    c.b_cb = 2 * (-Kb + 1);
+  }
+  return c;
+}
+
+/* ---- C2: integer 4:2:0 8-bit full-range op -------------------------------- */
+
+void orc_ycbcr420_to_rgb_int(const uint8_t* y, int ys, const uint8_t* cb, int cbs,
+                             const uint8_t* cr, int crs, int w, int h,
+                             int has_nclx, int matrix, int primaries,
+                             uint8_t* out, int os, int out_fmt)
+{
+  orc_coeffs k = orc_ycbcr_to_rgb_coeffs(has_nclx, matrix, primaries);
+  /* yuv2rgb.cc:336-339 */
+  int r_cr = (int)lround(256 * k.r_cr);
+  int g_cr = (int)lround(256 * k.g_cr);
+  int g_cb = (int)lround(256 * k.g_cb);
+  int b_cb = (int)lround(256 * k.b_cb);
+  int bpp = out_fmt == ORC_OUT_RGBA32 ? 4 : 3;
+
+  for (int py = 0; py < h; py++) {
+    const uint8_t* yrow = y + (size_t)py * ys;
+    const uint8_t* cbrow = cb + (size_t)(py / 2) * cbs;
+    const uint8_t* crrow = cr + (size_t)(py / 2) * crs;
+    uint8_t* o = out + (size_t)py * os;
+    for (int px = 0; px < w; px++) {
+      int yv = yrow[px];
+      int u = cbrow[px / 2] - 128;
+      int v = crrow[px / 2] - 128;
+      /* yuv2rgb.cc:359-361: signed arithmetic shift */
+      o[bpp * px + 0] = clip_int_u8(yv + ((r_cr * v + 128) >> 8));
+      o[bpp * px + 1] = clip_int_u8(yv + ((g_cb * u + g_cr * v + 128) >> 8));
+      o[bpp * px + 2] = clip_int_u8(yv + ((b_cb * u + 128) >> 8));
+      if (bpp == 4) o[4 * px + 3] = 0xFF; /* yuv2rgb.cc:488-490 (no alpha plane) */
+    }
+  }
+}
+
+/* ---- C3: generic float op + interleave ----------------------------------- */
+
+static inline unsigned sample_at(const void* plane, int stride_bytes, int x, int yy, int wide)
+{
+  const uint8_t* row = (const uint8_t*)plane + (size_t)yy * stride_bytes;
+  return wide ? ((const uint16_t*)row)[x] : row[x];
+}
+
+void orc_ycbcr_to_rgb_float(const void* y, int ys, const void* cb, int cbs,
+                            const void* cr, int crs, int w, int h, int bpp, int chroma,
+                            int has_nclx, int matrix, int primaries, int full_range,
+                            uint8_t* out, int os, int out_fmt)
+{
+  const int wide = bpp > 8;
+  /* yuv2rgb.cc:170-177 */
+  const uint16_t halfRange = (uint16_t)(1 << (bpp - 1));
+  const int32_t fullRange = (1 << bpp) - 1;
+  const float limited_range_offset = (float)(16 << (bpp - 8));
+  const int shiftH = (chroma == 3) ? 0 : 1;
+  const int shiftV = (chroma == 1) ? 1 : 0;
+
+  /* yuv2rgb.cc:190-198 */
+  int matrix_coeffs = 2;
+  int full_range_flag = 1;
+  orc_coeffs k = orc_ycbcr_to_rgb_coeffs(0, 0, 0);
+  if (has_nclx) {
+    matrix_coeffs = matrix;
+    full_range_flag = full_range;
+    k = orc_ycbcr_to_rgb_coeffs(1, matrix, primaries);
+  }
+
+  for (int py = 0; py < h; py++) {
+    uint8_t* o = out + (size_t)py * os;
+    for (int px = 0; px < w; px++) {
+      int cx = px >> shiftH, cy = py >> shiftV;
+      unsigned Y = sample_at(y, ys, px, py, wide);
+      unsigned U = sample_at(cb, cbs, cx, cy, wide);
+      unsigned V = sample_at(cr, crs, cx, cy, wide);
+      unsigned r, g, b;
+      if (matrix_coeffs == 0) { /* yuv2rgb.cc:207-219: GBR */
+        if (full_range_flag) { r = V; g = Y; b = U; }
+        else {
+          r = clip_f_u16(((float)V - limited_range_offset) * 1.1429f, fullRange);
+          g = clip_f_u16(((float)Y - limited_range_offset) * 1.1689f, fullRange);
+          b = clip_f_u16(((float)U - limited_range_offset) * 1.1429f, fullRange);
+        }
+        /* the template stores (Pixel)value */
+        if (!wide) { r &= 0xFF; g &= 0xFF; b &= 0xFF; }
+      }
+      else if (matrix_coeffs == 8) { /* yuv2rgb.cc:221-232: YCgCo, clipped to 8 bit even for HDR */
+        int yv = (int)Y, u = (int)U - halfRange, v = (int)V - halfRange;
+        r = clip_int_u8(yv - u + v);
+        g = clip_int_u8(yv + u);
+        b = clip_int_u8(yv - u - v);
+      }
+      else { /* yuv2rgb.cc:233-247 */
+        float yv = (float)Y;
+        float u = (float)((int)U - (int)halfRange);
+        float v = (float)((int)V - (int)halfRange);
+        if (!full_range_flag) {
+          yv = (yv - limited_range_offset) * 1.1689f;
+          u = u * 1.1429f;
+          v = v * 1.1429f;
+        }
+        r = clip_f_u16(yv + k.r_cr * v, fullRange);
+        g = clip_f_u16(yv + k.g_cb * u + k.g_cr * v, fullRange);
+        b = clip_f_u16(yv + k.b_cb * u, fullRange);
+        if (!wide) { r &= 0xFF; g &= 0xFF; b &= 0xFF; } /* (uint8_t) cast of the uint16 result */
+      }
+      switch (out_fmt) {
+        case ORC_OUT_RGB24:  /* rgb2rgb.cc:66-143 */
+          o[3 * px + 0] = (uint8_t)r; o[3 * px + 1] = (uint8_t)g; o[3 * px + 2] = (uint8_t)b; break;
+        case ORC_OUT_RGBA32:
+          o[4 * px + 0] = (uint8_t)r; o[4 * px + 1] = (uint8_t)g; o[4 * px + 2] = (uint8_t)b; o[4 * px + 3] = 0xFF; break;
+        case ORC_OUT_RRGGBB_BE: /* rgb2rgb.cc:250-268 */
+          o[6 * px + 0] = (uint8_t)(r >> 8); o[6 * px + 1] = (uint8_t)(r & 0xFF);
+          o[6 * px + 2] = (uint8_t)(g >> 8); o[6 * px + 3] = (uint8_t)(g & 0xFF);
+          o[6 * px + 4] = (uint8_t)(b >> 8); o[6 * px + 5] = (uint8_t)(b & 0xFF); break;
+        default: /* ORC_OUT_RRGGBB_LE: BE followed by rgb2rgb.cc:721-726 pairwise byte swap */
+          o[6 * px + 1] = (uint8_t)(r >> 8); o[6 * px + 0] = (uint8_t)(r & 0xFF);
+          o[6 * px + 3] = (uint8_t)(g >> 8); o[6 * px + 2] = (uint8_t)(g & 0xFF);
+          o[6 * px + 5] = (uint8_t)(b >> 8); o[6 * px + 4] = (uint8_t)(b & 0xFF); break;
+      }
+    }
+  }
+}
+
+/* ---- A5: grid tile paste (context.cc:2457-2535) --------------------------- */
+
+int orc_paste_tile_plane(const uint8_t* tile, int tile_stride, int tile_w, int tile_h,
+                         uint8_t* canvas, int canvas_stride, int w, int h,
+                         int x0, int y0, int channel, int chroma, int bpp,
+                         int tile_has_nclx, int tile_full_range, int tile_matrix)
+{
+  int channel_w = w, channel_h = h, channel_x0 = x0, channel_y0 = y0;
+  if (channel == 1 || channel == 2) { /* context.cc:2469-2483 */
+    if (chroma == 1) { channel_w = (w + 1) / 2; channel_h = (h + 1) / 2; channel_x0 = (x0 + 1) / 2; channel_y0 = (y0 + 1) / 2; }
+    else if (chroma == 2) { channel_w = (w + 1) / 2; channel_x0 = (x0 + 1) / 2; }
+  }
+  if (channel_w <= channel_x0 || channel_h <= channel_y0) return -1;
+
+  int storage_bytes = (bpp + 7) / 8;
+  int copy_width = tile_w < channel_w - channel_x0 ? tile_w : channel_w - channel_x0;
+  int copy_height = tile_h < channel_h - channel_y0 ? tile_h : channel_h - channel_y0;
+  copy_width *= storage_bytes;             /* context.cc:2499: now a BYTE count */
+  int xs = channel_x0 * storage_bytes, ys = channel_y0;
+
+  float limited_range_offset = (float)(16 << (bpp - 8));
+  int full_range_flag = tile_has_nclx ? tile_full_range : 1;
+  int matrix_coeffs = tile_has_nclx ? tile_matrix : 1;
+
+  if (tile_has_nclx && !full_range_flag && matrix_coeffs != 0) {
+    float ratio = (channel == 1 || channel == 2) ? 1.1429f : 1.1689f;
+    for (int py = 0; py < copy_height; py++)
+      for (int px = 0; px < copy_width; px++) { /* per BYTE (Q1), luma offset for chroma too (Q2) */
+        float limit_value = (float)tile[(size_t)py * tile_stride + px];
+        float full_value = (limit_value - limited_range_offset) * ratio;
+        canvas[xs + (size_t)(ys + py) * canvas_stride + px] = clip_f_u8(full_value);
+      }
+  }
+  else {
+    for (int py = 0; py < copy_height; py++)
+      memcpy(canvas + xs + (size_t)(ys + py) * canvas_stride, tile + (size_t)py * tile_stride, (size_t)copy_width);
+  }
+  return 0;
+}
+
+/* ---- C4: bilinear 4:2:0 -> 4:4:4 (chroma_sampling.cc:585-700), 8 bit ------- */
+
+void orc_upsample_bilinear_420(const uint8_t* in, int is, int w, int h, uint8_t* out, int os)
+{
+#define IN(yy, xx)  ((int)in[(size_t)(yy) * is + (xx)])
+#define OUT(yy, xx) out[(size_t)(yy) * os + (xx)]
+  OUT(0, 0) = in[0];
+  /* top border: note the reference indexes the source with cx/2 (Q8) */
+  for (int cx = 0; cx < (w - 1) / 2; cx++) {
+    OUT(0, 2 * cx + 1) = (uint8_t)((3 * IN(0, cx / 2) + 1 * IN(0, cx / 2 + 1) + 2) / 4);
+    OUT(0, 2 * cx + 2) = (uint8_t)((1 * IN(0, cx / 2) + 3 * IN(0, cx / 2 + 1) + 2) / 4);
+  }
+  if (w % 2 == 0) OUT(0, w - 1) = (uint8_t)IN(0, w / 2 - 1);
+  /* left border (cy/2 source rows, Q8) */
+  for (int cy = 0; cy < (h - 1) / 2; cy++) {
+    OUT(2 * cy + 1, 0) = (uint8_t)((3 * IN(cy / 2, 0) + 1 * IN(cy / 2 + 1, 0) + 2) / 4);
+    OUT(2 * cy + 2, 0) = (uint8_t)((1 * IN(cy / 2, 0) + 3 * IN(cy / 2 + 1, 0) + 2) / 4);
+  }
+  if (h % 2 == 0) OUT(h - 1, 0) = (uint8_t)IN(h / 2 - 1, 0);
+  if (w % 2 == 0)
+    for (int cy = 0; cy < (h - 1) / 2; cy++) {
+      OUT(2 * cy + 1, w - 1) = (uint8_t)((3 * IN(cy / 2, w / 2 - 1) + 1 * IN(cy / 2 + 1, w / 2 - 1) + 2) / 4);
+      OUT(2 * cy + 2, w - 1) = (uint8_t)((1 * IN(cy / 2, w / 2 - 1) + 3 * IN(cy / 2 + 1, w / 2 - 1) + 2) / 4);
+    }
+  if (h % 2 == 0)
+    for (int cx = 0; cx < (w - 1) / 2; cx++) {
+      OUT(h - 1, 2 * cx + 1) = (uint8_t)((3 * IN(h / 2 - 1, cx / 2) + 1 * IN(h / 2 - 1, cx / 2 + 1) + 2) / 4);
+      OUT(h - 1, 2 * cx + 2) = (uint8_t)((1 * IN(h / 2 - 1, cx / 2) + 3 * IN(h / 2 - 1, cx / 2 + 1) + 2) / 4);
+    }
+  if (w % 2 == 0 && h % 2 == 0) OUT(h - 1, w - 1) = (uint8_t)IN(h / 2 - 1, w / 2 - 1);
+  /* interior: 9-3-3-1 / 16 */
+  for (int yy = 1; yy < h - 1; yy += 2)
+    for (int xx = 1; xx < w - 1; xx += 2) {
+      int cx = xx / 2, cy = yy / 2;
+      int a = IN(cy, cx), b = IN(cy, cx + 1), c = IN(cy + 1, cx), d = IN(cy + 1, cx + 1);
+      OUT(yy, xx)         = (uint8_t)((a * 9 + b * 3 + c * 3 + d * 1 + 8) / 16);
+      OUT(yy, xx + 1)     = (uint8_t)((a * 3 + b * 9 + c * 1 + d * 3 + 8) / 16);
+      OUT(yy + 1, xx)     = (uint8_t)((a * 3 + b * 1 + c * 9 + d * 3 + 8) / 16);
+      OUT(yy + 1, xx + 1) = (uint8_t)((a * 1 + b * 3 + c * 3 + d * 9 + 8) / 16);
+    }
+#undef IN
+#undef OUT
+}

@@ -1,0 +1,94 @@
+"""GPU parity: fused YCbCr->RGB kernels (through the C ABI) vs the oracle restatement.
+Bit-exact (integer / byte work; the float op chain is reproduced operation by operation)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _chroma_dims(w, h, chroma):
+    if chroma == 1:
+        return (w + 1) // 2, (h + 1) // 2
+    if chroma == 2:
+        return (w + 1) // 2, h
+    return w, h
+
+
+def _run_gpu(pkg, planes, w, h, bit_depth, chroma, nclx, out_fmt):
+    import torch
+    capi = pkg.capi
+    L = pkg.lib()
+    (y, ys), (cb, cbs), (cr, crs) = planes
+    obpp = {10: 3, 11: 4, 12: 6, 14: 6}[out_fmt]
+    ostride = L.hm_plane_stride(w, obpp)
+    assert ostride == orc.plane_stride(w, obpp)
+    dev = torch.device("cuda:0")
+    dy, dcb, dcr = (torch.from_numpy(a).to(dev) for a in (y, cb, cr))
+    rows = max(64, (h + 1) & ~1)
+    dout = torch.zeros((rows, ostride), dtype=torch.uint8, device=dev)
+    d = capi.ColourDesc(w, h, bit_depth, chroma, nclx[0], nclx[1], nclx[2], nclx[3], out_fmt, ys, cbs, crs, ostride)
+    stream = torch.cuda.current_stream().cuda_stream
+    capi.check(L.hm_colour_convert(C.byref(d), dy.data_ptr(), dcb.data_ptr(), dcr.data_ptr(), dout.data_ptr(), stream))
+    torch.cuda.synchronize()
+    return dout.cpu().numpy(), ostride, obpp
+
+
+SIZES = [(64, 64), (1280, 854), (4032, 3024), (72, 72), (17, 9), (1, 1), (1023, 3), (2, 2), (4030, 31)]
+
+
+@pytest.mark.parametrize("w,h", SIZES)
+@pytest.mark.parametrize("out_fmt", [10, 11])
+@pytest.mark.parametrize("nclx", [(0, 0, 0, 0), (1, 6, 1, 1), (1, 1, 1, 1), (1, 9, 9, 1), (1, 12, 1, 1)])
+def test_int420(pkg, w, h, out_fmt, nclx):
+    rng = np.random.default_rng(w * 7919 + h + out_fmt)
+    cw, ch = _chroma_dims(w, h, 1)
+    planes = [orc.alloc_plane(w, h, 1, rng=rng), orc.alloc_plane(cw, ch, 1, rng=rng), orc.alloc_plane(cw, ch, 1, rng=rng)]
+    d = pkg.capi.ColourDesc(w, h, 8, 1, *nclx, out_fmt, 0, 0, 0, 0)
+    assert pkg.lib().hm_colour_pipeline(C.byref(d)) == pkg.capi.HM_PIPE_INT420
+    got, ostride, obpp = _run_gpu(pkg, planes, w, h, 8, 1, nclx, out_fmt)
+    exp, es = orc.colour_int(planes[0], planes[1], planes[2], w, h, nclx[0], nclx[1], nclx[2], out_fmt)
+    assert es == ostride
+    np.testing.assert_array_equal(got[:h, :w * obpp], exp[:h, :w * obpp])
+
+
+@pytest.mark.parametrize("w,h", SIZES)
+@pytest.mark.parametrize("chroma", [1, 2, 3])
+@pytest.mark.parametrize("nclx", [(1, 2, 2, 0), (1, 6, 1, 0), (1, 1, 1, 0), (1, 0, 1, 1), (1, 0, 1, 0), (1, 8, 1, 1), (1, 11, 1, 1)])
+def test_float_8bit(pkg, w, h, chroma, nclx):
+    if chroma == 1 and nclx[3] == 1 and nclx[1] not in (0, 8, 11, 14):
+        pytest.skip("reference picks the integer op for this state")
+    rng = np.random.default_rng(w * 31 + h * 17 + chroma)
+    cw, ch = _chroma_dims(w, h, chroma)
+    planes = [orc.alloc_plane(w, h, 1, rng=rng), orc.alloc_plane(cw, ch, 1, rng=rng), orc.alloc_plane(cw, ch, 1, rng=rng)]
+    for out_fmt in (10, 11):
+        d = pkg.capi.ColourDesc(w, h, 8, chroma, *nclx, out_fmt, 0, 0, 0, 0)
+        assert pkg.lib().hm_colour_pipeline(C.byref(d)) == pkg.capi.HM_PIPE_FLOAT
+        got, ostride, obpp = _run_gpu(pkg, planes, w, h, 8, chroma, nclx, out_fmt)
+        exp, es = orc.colour_float(planes[0], planes[1], planes[2], w, h, 8, chroma, *nclx, out_fmt)
+        np.testing.assert_array_equal(got[:h, :w * obpp], exp[:h, :w * obpp])
+
+
+@pytest.mark.parametrize("w,h", [(2048, 1536), (64, 64), (33, 5), (1, 1), (4032, 3024)])
+@pytest.mark.parametrize("chroma", [1, 2, 3])
+@pytest.mark.parametrize("bit_depth", [10, 12])
+@pytest.mark.parametrize("nclx", [(0, 0, 0, 0), (1, 9, 9, 0), (1, 9, 9, 1), (1, 1, 1, 0), (1, 0, 1, 0), (1, 8, 1, 1)])
+@pytest.mark.parametrize("out_fmt", [12, 14])
+def test_float_hdr(pkg, w, h, chroma, bit_depth, nclx, out_fmt):
+    rng = np.random.default_rng(w + h * 3 + chroma * 5 + bit_depth)
+    cw, ch = _chroma_dims(w, h, chroma)
+    mv = (1 << bit_depth) - 1
+    planes = [orc.alloc_plane(w, h, 2, rng=rng, maxval=mv), orc.alloc_plane(cw, ch, 2, rng=rng, maxval=mv),
+              orc.alloc_plane(cw, ch, 2, rng=rng, maxval=mv)]
+    got, ostride, obpp = _run_gpu(pkg, planes, w, h, bit_depth, chroma, nclx, out_fmt)
+    exp, es = orc.colour_float(planes[0], planes[1], planes[2], w, h, bit_depth, chroma, *nclx, out_fmt)
+    np.testing.assert_array_equal(got[:h, :w * obpp], exp[:h, :w * obpp])
+
+
+def test_no_silent_fallback(pkg):
+    """unsupported states fail loudly instead of falling back"""
+    d = pkg.capi.ColourDesc(64, 64, 8, 1, 0, 0, 0, 0, 14, 64, 64, 64, 384)
+    assert pkg.lib().hm_colour_pipeline(C.byref(d)) == -2

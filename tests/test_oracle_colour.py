@@ -1,0 +1,50 @@
+"""CPU: pin the colour oracle against the reference's own known-answer vectors."""
+import json
+import os
+
+import numpy as np
+
+import orc
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_bilinear_kat(oracle):
+    # data of the reference's "Bilinear upsampling" test (tests/conversion.cc:635-670)
+    kat = json.load(open(os.path.join(GOLD, "bilinear_kat.json")))
+    for case in kat["cases"]:
+        src = np.array(case["in"], np.uint8).reshape(2, 2)
+        out = np.zeros((4, 4), np.uint8)
+        oracle.orc_upsample_bilinear_420(orc.ptr(src), 2, 4, 4, orc.ptr(out), 4)
+        assert out.flatten().tolist() == case["out"]
+
+
+def test_integer_constants(oracle):
+    # BT.601 full-range constants 359 / -88 / -183 / 454 (yuv2rgb.cc:336-339)
+    w = h = 2
+    y = (np.full((64, 64), 100, np.uint8), 64)
+    cb = (np.full((64, 64), 129, np.uint8), 64)
+    cr = (np.full((64, 64), 127, np.uint8), 64)
+    out, os_ = orc.colour_int(y, cb, cr, w, h, 0, 0, 0, 10)
+    r = 100 + ((359 * -1 + 128) >> 8)
+    g = 100 + ((-88 * 1 + -183 * -1 + 128) >> 8)
+    b = 100 + ((454 * 1 + 128) >> 8)
+    assert out[0, :3].tolist() == [r, g, b]
+
+
+def test_paste_rescale_quirk(oracle):
+    # context.cc:2504-2528: limited->full rescale with the luma offset for chroma too (Q2)
+    tile = np.arange(64 * 64, dtype=np.uint32).astype(np.uint8).reshape(64, 64)
+    canvas = np.zeros((64, 128), np.uint8)
+    assert oracle.orc_paste_tile_plane(orc.ptr(tile), 64, 64, 64, orc.ptr(canvas), 128, 100, 64, 64, 0, 0, 1, 8, 1, 0, 2) == 0
+    f32 = np.float32
+    exp = np.floor(((tile[:, :36].astype(f32) - f32(16)) * f32(1.1689)) + f32(0.5)).clip(0, 255).astype(np.uint8)
+    # trunc == floor for x+0.5 >= 0; negatives clip to 0 either way
+    np.testing.assert_array_equal(canvas[:, 64:100], exp)
+    assert not canvas[:, :64].any() and not canvas[:, 100:].any()
+    cb = np.full((32, 32), 128, np.uint8)
+    cc = np.zeros((32, 64), np.uint8)
+    assert oracle.orc_paste_tile_plane(orc.ptr(cb), 32, 32, 32, orc.ptr(cc), 64, 100, 64, 0, 0, 1, 1, 8, 1, 0, 2) == 0
+    assert cc[0, 0] == 128  # (128-16)*1.1429 = 128.0048 -> 128
+    # origin outside canvas -> error
+    assert oracle.orc_paste_tile_plane(orc.ptr(tile), 64, 64, 64, orc.ptr(canvas), 128, 64, 64, 64, 0, 0, 1, 8, 0, 1, 1) == -1
