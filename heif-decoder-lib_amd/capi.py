@@ -34,6 +34,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise FileNotFoundError(
                 f"{LIB_PATH} not built - run `python -c 'import __graft_entry__ as g; g.build()'`")
+        # torch ships its own libamdhip64; it must be the one HIP runtime of the process, so
+        # load it before our library binds libamdhip64 (two runtimes => "no ROCm-capable device")
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         L.hm_status_string.restype = C.c_char_p
         L.hm_last_error.restype = C.c_char_p
