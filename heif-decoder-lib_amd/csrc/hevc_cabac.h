@@ -1,0 +1,216 @@
+// hevc_cabac.h — CABAC arithmetic decoding engine and context set (ITU-T H.265 §9.3), host side.
+// The reference keeps entropy decoding on the CPU (libde265 cabac.cc / contextmodel.cc); so do we.
+// Tables are the normative ones of the standard (Table 9-46, 9-47; initValues of Tables 9-5..9-37,
+// initType 0 = I slices, the only type on the still-image path).
+#ifndef HM_HEVC_CABAC_H
+#define HM_HEVC_CABAC_H
+
+#include <cstdint>
+#include <cstring>
+
+#include "hevc_types.h"
+
+namespace hm {
+
+// ---- context indices ---------------------------------------------------------------------
+enum Ctx : int {
+  CTX_SAO_MERGE = 0,
+  CTX_SAO_TYPE = 1,
+  CTX_SPLIT_CU = 2,        // 3
+  CTX_TQ_BYPASS = 5,
+  CTX_PART_MODE = 6,
+  CTX_PREV_INTRA = 7,
+  CTX_CHROMA_PRED = 8,
+  CTX_SPLIT_TF = 9,        // 3
+  CTX_CBF_LUMA = 12,       // 2
+  CTX_CBF_CHROMA = 14,     // 5
+  CTX_CU_QP_DELTA = 19,    // 2
+  CTX_TSKIP = 21,          // 2 (luma, chroma)
+  CTX_LAST_X = 23,         // 18
+  CTX_LAST_Y = 41,         // 18
+  CTX_CSBF = 59,           // 4
+  CTX_SIG = 63,            // 44
+  CTX_GT1 = 107,           // 24
+  CTX_GT2 = 131,           // 6
+  CTX_COUNT = 137
+};
+
+struct ContextSet {
+  uint8_t state[CTX_COUNT]; // (pStateIdx << 1) | valMps
+};
+
+namespace cabac_tables {
+static const uint8_t kInit[CTX_COUNT] = {
+    153,                                   // sao_merge
+    200,                                   // sao_type_idx
+    139, 141, 157,                         // split_cu_flag
+    154,                                   // cu_transquant_bypass_flag
+    184,                                   // part_mode
+    184,                                   // prev_intra_luma_pred_flag
+    63,                                    // intra_chroma_pred_mode
+    153, 138, 138,                         // split_transform_flag
+    111, 141,                              // cbf_luma
+    94, 138, 182, 154, 154,                // cbf_cb / cbf_cr
+    154, 154,                              // cu_qp_delta_abs
+    139, 139,                              // transform_skip_flag
+    110, 110, 124, 125, 140, 153, 125, 127, 140, 109, 111, 143, 127, 111, 79, 108, 123, 63, // last x
+    110, 110, 124, 125, 140, 153, 125, 127, 140, 109, 111, 143, 127, 111, 79, 108, 123, 63, // last y
+    91, 171, 134, 141,                     // coded_sub_block_flag
+    111, 111, 125, 110, 110, 94, 124, 108, 124, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125, 107,
+    125, 141, 179, 153, 125, 140, 139, 182, 182, 152, 136, 152, 136, 153, 136, 139, 111, 136, 139, 111, 141, 111, // sig
+    140, 92, 137, 138, 140, 152, 138, 139, 153, 74, 149, 92, 139, 107, 122, 152, 140, 179, 166, 182, 140, 227, 122, 197, // gt1
+    138, 153, 136, 167, 152, 152,          // gt2
+};
+
+static const uint8_t kRangeTabLps[64][4] = {
+    {128, 176, 208, 240}, {128, 167, 197, 227}, {128, 158, 187, 216}, {123, 150, 178, 205}, {116, 142, 169, 195},
+    {111, 135, 160, 185}, {105, 128, 152, 175}, {100, 122, 144, 166}, {95, 116, 137, 158},  {90, 110, 130, 150},
+    {85, 104, 123, 142},  {81, 99, 117, 135},   {77, 94, 111, 128},   {73, 89, 105, 122},   {69, 85, 100, 116},
+    {66, 80, 95, 110},    {62, 76, 90, 104},    {59, 72, 86, 99},     {56, 69, 81, 94},     {53, 65, 77, 89},
+    {51, 62, 73, 85},     {48, 59, 69, 80},     {46, 56, 66, 76},     {43, 53, 63, 72},     {41, 50, 59, 69},
+    {39, 48, 56, 65},     {37, 45, 54, 62},     {35, 43, 51, 59},     {33, 41, 48, 56},     {32, 39, 46, 53},
+    {30, 37, 43, 50},     {29, 35, 41, 48},     {27, 33, 39, 45},     {26, 31, 37, 43},     {24, 30, 35, 41},
+    {23, 28, 33, 39},     {22, 27, 32, 37},     {21, 26, 30, 35},     {20, 24, 29, 33},     {19, 23, 27, 31},
+    {18, 22, 26, 30},     {17, 21, 25, 28},     {16, 20, 23, 27},     {15, 19, 22, 25},     {14, 18, 21, 24},
+    {14, 17, 20, 23},     {13, 16, 19, 22},     {12, 15, 18, 21},     {12, 14, 17, 20},     {11, 14, 16, 19},
+    {11, 13, 15, 18},     {10, 12, 15, 17},     {10, 12, 14, 16},     {9, 11, 13, 15},      {9, 11, 12, 14},
+    {8, 10, 12, 14},      {8, 9, 11, 13},       {7, 9, 11, 12},       {7, 9, 10, 12},       {7, 8, 10, 11},
+    {6, 8, 9, 11},        {6, 7, 9, 10},        {6, 7, 8, 9},         {2, 2, 2, 2}};
+
+static const uint8_t kTransIdxLps[64] = {0,  0,  1,  2,  2,  4,  4,  5,  6,  7,  8,  9,  9,  11, 11, 12,
+                                         13, 13, 15, 15, 16, 16, 18, 18, 19, 19, 21, 21, 22, 22, 23, 24,
+                                         24, 25, 26, 26, 27, 27, 28, 29, 29, 30, 30, 30, 31, 32, 32, 33,
+                                         33, 33, 34, 34, 35, 35, 35, 36, 36, 36, 37, 37, 37, 38, 38, 63};
+} // namespace cabac_tables
+
+// §9.3.2.2: initialisation of context variables
+inline void init_contexts(ContextSet& cs, int slice_qp_y)
+{
+  int qp = slice_qp_y < 0 ? 0 : (slice_qp_y > 51 ? 51 : slice_qp_y);
+  for (int i = 0; i < CTX_COUNT; i++) {
+    int iv = cabac_tables::kInit[i];
+    int m = (iv >> 4) * 5 - 45;
+    int n = ((iv & 15) << 3) - 16;
+    int pre = ((m * qp) >> 4) + n;
+    pre = pre < 1 ? 1 : (pre > 126 ? 126 : pre);
+    int mps = pre <= 63 ? 0 : 1;
+    int st = mps ? pre - 64 : 63 - pre;
+    cs.state[i] = (uint8_t)((st << 1) | mps);
+  }
+}
+
+// ---- arithmetic decoder (§9.3.4.3) -----------------------------------------------------------
+// 9-bit range; `value` carries 7 look-ahead bits (compared against range << 7) and is refilled a
+// byte at a time, so that after a terminating bin the read pointer sits on the next byte-aligned
+// position (start of the next sub-stream / PCM samples).
+class CabacDecoder {
+ public:
+  void init(const uint8_t* p, const uint8_t* end)
+  {
+    cur_ = p;
+    end_ = end;
+    range_ = 510;
+    bits_needed_ = 8;
+    value_ = 0;
+    value_ = next_byte() << 8;
+    bits_needed_ -= 8;
+    value_ |= next_byte();
+    bits_needed_ -= 8;
+    // value_ now holds 16 bits: 9 + 7 look-ahead; bits_needed_ == -8
+  }
+  const uint8_t* position() const { return cur_; }
+  bool overrun() const { return overrun_ > 8; }
+
+  inline int decode_bin(uint8_t& ctx)
+  {
+    const int st = ctx >> 1;
+    int mps = ctx & 1;
+    const uint32_t lps = cabac_tables::kRangeTabLps[st][(range_ >> 6) & 3];
+    range_ -= lps;
+    const uint32_t scaled = range_ << 7;
+    int bin;
+    if (value_ < scaled) { // MPS path
+      bin = mps;
+      ctx = (uint8_t)(((st < 62 ? st + 1 : st) << 1) | mps);
+      if (scaled < (256u << 7)) {
+        range_ = scaled >> 6;
+        value_ <<= 1;
+        if (++bits_needed_ == 0) refill();
+      }
+    }
+    else { // LPS path
+      bin = !mps;
+      value_ -= scaled;
+      int shift = 0;
+      uint32_t r = lps;
+      while (r < 256) { r <<= 1; shift++; }
+      range_ = r;
+      value_ <<= shift;
+      if (st == 0) mps = !mps;
+      ctx = (uint8_t)((cabac_tables::kTransIdxLps[st] << 1) | mps);
+      bits_needed_ += shift;
+      if (bits_needed_ >= 0) {
+        value_ |= next_byte() << bits_needed_;
+        bits_needed_ -= 8;
+      }
+    }
+    return bin;
+  }
+
+  inline int decode_bypass()
+  {
+    value_ <<= 1;
+    if (++bits_needed_ >= 0) {
+      value_ |= next_byte();
+      bits_needed_ = -8;
+    }
+    const uint32_t scaled = range_ << 7;
+    if (value_ >= scaled) {
+      value_ -= scaled;
+      return 1;
+    }
+    return 0;
+  }
+
+  inline uint32_t decode_bypass_bits(int n)
+  {
+    uint32_t v = 0;
+    for (int i = 0; i < n; i++) v = (v << 1) | (uint32_t)decode_bypass();
+    return v;
+  }
+
+  inline int decode_terminate()
+  {
+    range_ -= 2;
+    const uint32_t scaled = range_ << 7;
+    if (value_ >= scaled) return 1;
+    if (scaled < (256u << 7)) {
+      range_ = scaled >> 6;
+      value_ <<= 1;
+      if (++bits_needed_ == 0) refill();
+    }
+    return 0;
+  }
+
+ private:
+  inline uint32_t next_byte()
+  {
+    if (cur_ < end_) return *cur_++;
+    overrun_++;
+    return 0;
+  }
+  inline void refill()
+  {
+    bits_needed_ = -8;
+    value_ |= next_byte();
+  }
+  const uint8_t* cur_ = nullptr;
+  const uint8_t* end_ = nullptr;
+  uint32_t range_ = 510;
+  uint32_t value_ = 0;
+  int bits_needed_ = 0;
+  int overrun_ = 0;
+};
+
+} // namespace hm
+#endif

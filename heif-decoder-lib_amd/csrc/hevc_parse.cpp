@@ -1,0 +1,328 @@
+// hevc_parse.cpp — host front end: NAL de-framing, parameter sets, CABAC slice-data decoding of one
+// coded HEVC intra picture into the GPU command stream (include/hm_stream.h).
+//
+// Replaces, on the host, what the reference does in libheif/plugins/decoder_libde265.cc:269-303
+// (NAL de-framing of the `[u32 BE length][NAL]...` byte string the plugin receives through
+// push_data) and in libde265's decctx.cc:1209-1290 / slice.cc (parameter sets, slice header,
+// slice data).  Reconstruction itself is NOT done here - that is the GPU's job.
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+
+#include "hevc_syntax.h"
+#include "hm_internal.h"
+
+namespace hm {
+
+// entropy-coder adaptor handed to SliceWalker: plain CABAC decoding, kinds ignored
+class DecoderEC {
+ public:
+  DecoderEC(const uint8_t* begin, const uint8_t* end) : cur_(begin), end_(end) {}
+  inline int bin(int ctx, int, int) { return dec_.decode_bin(cs_.state[ctx]); }
+  inline int bypass(int, int) { return dec_.decode_bypass(); }
+  inline int terminate(int) { int b = dec_.decode_terminate(); check(); return b; }
+  ContextSet& contexts() { return cs_; }
+  void start_substream()
+  {
+    if (started_) cur_ = dec_.position();
+    if (end_ - cur_ < 2) throw ParseError(HM_ERR_BITSTREAM, "slice data truncated");
+    dec_.init(cur_, end_);
+    started_ = true;
+  }
+  void check() const
+  {
+    if (dec_.overrun()) throw ParseError(HM_ERR_BITSTREAM, "CABAC read past the end of the slice data");
+  }
+
+ private:
+  CabacDecoder dec_;
+  ContextSet cs_;
+  const uint8_t* cur_;
+  const uint8_t* end_;
+  bool started_ = false;
+};
+
+namespace {
+
+struct Decoder {
+  SPS sps[16];
+  PPS pps[64];
+  PictureState pic;
+  bool pic_started = false;
+  const SPS* cur_sps = nullptr;
+  const PPS* cur_pps = nullptr;
+  SliceHeader prev_sh;
+  bool have_prev_sh = false;
+  int next_ts = 0;
+  ContextSet wpp_store, dep_store;
+  bool wpp_valid = false, dep_valid = false;
+  bool picture_done = false;
+
+  void handle_nal(const uint8_t* p, size_t n)
+  {
+    if (n < 2) return;
+    const int nal_type = (p[0] >> 1) & 0x3F;
+    const int layer = ((p[0] & 1) << 5) | (p[1] >> 3);
+    if (layer != 0) return; // only the base layer
+    if (nal_type == 33 || nal_type == 34 || nal_type <= 21) {
+      std::vector<uint8_t> rbsp = unescape_nal(p, n);
+      BitReader br(rbsp.data() + 2, rbsp.size() - 2);
+      if (nal_type == 33) {
+        SPS s;
+        parse_sps(br, s);
+        sps[s.sps_id] = s;
+      }
+      else if (nal_type == 34) {
+        PPS q;
+        parse_pps(br, q, sps);
+        pps[q.pps_id] = q;
+      }
+      else if (nal_type <= 9 || (nal_type >= 16 && nal_type <= 21)) {
+        if (picture_done) return; // a still-image item holds one picture; ignore anything after it
+        slice_nal(br, nal_type, rbsp);
+      }
+    }
+    // VPS (32), AUD, SEI, EOS ...: nothing the reconstruction needs
+  }
+
+  void slice_nal(BitReader& br, int nal_type, const std::vector<uint8_t>& rbsp)
+  {
+    SliceHeader sh;
+    parse_slice_header(br, nal_type, sps, pps, have_prev_sh ? &prev_sh : nullptr, sh);
+    const PPS& p = pps[sh.pps_id];
+    const SPS& s = sps[p.sps_id];
+    if (sh.first_slice_segment_in_pic) {
+      if (pic_started) throw ParseError(HM_ERR_UNSUPPORTED, "more than one coded picture in the item");
+      check_supported(s, p);
+      cur_sps = &s;
+      cur_pps = &p;
+      pic.reset(s, p);
+      pic_started = true;
+      next_ts = 0;
+      wpp_valid = dep_valid = false;
+    }
+    else if (!pic_started) throw ParseError(HM_ERR_BITSTREAM, "slice segment without a first_slice_segment_in_pic");
+    if (&p != cur_pps) throw ParseError(HM_ERR_UNSUPPORTED, "PPS changes inside a picture");
+
+    if (sh.dependent) sh.SliceAddrRS = prev_sh.SliceAddrRS;
+    int slice_idx;
+    if (!sh.dependent) {
+      hm_slice hs;
+      std::memset(&hs, 0, sizeof(hs));
+      hs.slice_addr = (uint32_t)sh.SliceAddrRS;
+      hs.beta_offset_div2 = (int8_t)sh.beta_offset_div2;
+      hs.tc_offset_div2 = (int8_t)sh.tc_offset_div2;
+      hs.deblocking_disabled = sh.deblocking_disabled;
+      hs.sao_luma = sh.sao_luma;
+      hs.sao_chroma = sh.sao_chroma;
+      hs.lf_across_slices = sh.lf_across_slices;
+      hs.slice_qp = (int8_t)sh.SliceQPY;
+      pic.slices.push_back(hs);
+    }
+    if (pic.slices.empty()) throw ParseError(HM_ERR_BITSTREAM, "dependent slice segment first in picture");
+    slice_idx = (int)pic.slices.size() - 1;
+
+    const int start_ts = p.CtbAddrRStoTS[sh.slice_segment_address];
+    if (start_ts != next_ts) throw ParseError(HM_ERR_BITSTREAM, "slice segments out of order or CTBs missing");
+    // slice data starts right after the header in the unescaped payload (+2 for the NAL header)
+    const uint8_t* begin = rbsp.data() + 2 + sh.data_byte_offset;
+    const uint8_t* end = rbsp.data() + rbsp.size();
+    DecoderEC ec(begin, end);
+    SliceWalker<DecoderEC> walker(ec, pic, sh, slice_idx);
+    next_ts = walker.decode_slice_segment(start_ts, &wpp_store, &wpp_valid, &dep_store, &dep_valid);
+    prev_sh = sh;
+    have_prev_sh = true;
+    if (next_ts == s.ctb_w * s.ctb_h) picture_done = true;
+  }
+
+  static void check_supported(const SPS& s, const PPS& p)
+  {
+    if (s.range_ext_any) throw ParseError(HM_ERR_UNSUPPORTED, "range-extension coding tools");
+    if (s.scaling_list_enabled) throw ParseError(HM_ERR_UNSUPPORTED, "scaling lists");
+    if (s.ChromaArrayType == 0 || s.ChromaArrayType == 3 || s.separate_colour_plane)
+      throw ParseError(HM_ERR_UNSUPPORTED, "chroma format (only 4:2:0 and 4:2:2 are on the GPU path)");
+    if (s.bit_depth_y != s.bit_depth_c) throw ParseError(HM_ERR_UNSUPPORTED, "different luma / chroma bit depth");
+    if (s.bit_depth_y > 12) throw ParseError(HM_ERR_UNSUPPORTED, "bit depth above 12");
+    if (p.cross_component_prediction || p.chroma_qp_offset_list_enabled)
+      throw ParseError(HM_ERR_UNSUPPORTED, "range-extension PPS tools");
+    if (s.width > 16384 || s.height > 16384) throw ParseError(HM_ERR_UNSUPPORTED, "picture larger than 16384x16384");
+  }
+
+  // ---- finalisation: flatten into one blob ---------------------------------------------------
+  std::vector<uint8_t> finish()
+  {
+    if (!pic_started) throw ParseError(HM_ERR_BITSTREAM, "no coded picture in the data");
+    const SPS& s = *cur_sps;
+    const PPS& p = *cur_pps;
+    const int N = s.ctb_w * s.ctb_h;
+    if (!picture_done) throw ParseError(HM_ERR_BITSTREAM, "picture incomplete: missing slice segments");
+
+    size_t n_tus = 0;
+    for (int i = 0; i < N; i++) {
+      if (!(pic.ctbs[i].flags & HM_CTB_CODED)) throw ParseError(HM_ERR_BITSTREAM, "CTB not coded");
+      pic.ctbs[i].tu_first = (uint32_t)n_tus;
+      if (pic.ctb_tus[i].size() > 65535) throw ParseError(HM_ERR_INTERNAL, "too many TUs in a CTB");
+      pic.ctbs[i].tu_count = (uint16_t)pic.ctb_tus[i].size();
+      n_tus += pic.ctb_tus[i].size();
+    }
+    // SAO neighbour masks (sao.cc:323-424 of the reference)
+    const bool sao_fast = p.lf_across_slices && !p.tiles_enabled;
+    static const int dx[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, dy[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+    for (int cy = 0; cy < s.ctb_h; cy++)
+      for (int cx = 0; cx < s.ctb_w; cx++) {
+        const int c = cx + cy * s.ctb_w;
+        uint8_t mask = 0;
+        for (int k = 0; k < 8; k++) {
+          const int nx = cx + dx[k], ny = cy + dy[k];
+          if (nx < 0 || ny < 0 || nx >= s.ctb_w || ny >= s.ctb_h) continue;
+          const int nb = nx + ny * s.ctb_w;
+          bool ok = true;
+          if (!sao_fast) {
+            const int sa = pic.ctb_slice_addr[nb], sc = pic.ctb_slice_addr[c];
+            if (sa < sc && !pic.slices[pic.ctbs[c].slice_idx].lf_across_slices) ok = false;
+            if (sa > sc && !pic.slices[pic.ctbs[nb].slice_idx].lf_across_slices) ok = false;
+            if (!p.lf_across_tiles && p.TileIdRS[nb] != p.TileIdRS[c]) ok = false;
+          }
+          if (ok) mask |= (uint8_t)(1u << k);
+        }
+        pic.ctbs[c].sao_nb_mask = mask;
+      }
+
+    auto align16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t off_slices = align16(sizeof(hm_pic));
+    const size_t off_ctbs = align16(off_slices + pic.slices.size() * sizeof(hm_slice));
+    const size_t off_tus = align16(off_ctbs + (size_t)N * sizeof(hm_ctb));
+    const size_t off_coeffs = align16(off_tus + n_tus * sizeof(hm_tu));
+    const size_t total = align16(off_coeffs + pic.coeffs.size() * sizeof(hm_coeff));
+    if (total > 0xFFFFFFFFu) throw ParseError(HM_ERR_INTERNAL, "command stream too large");
+    std::vector<uint8_t> blob(total, 0);
+    hm_pic h;
+    std::memset(&h, 0, sizeof(h));
+    h.magic = HM_STREAM_MAGIC;
+    h.total_bytes = (uint32_t)total;
+    h.width = (uint16_t)s.width;
+    h.height = (uint16_t)s.height;
+    h.crop_left = (uint16_t)s.conf_left; h.crop_right = (uint16_t)s.conf_right;
+    h.crop_top = (uint16_t)s.conf_top; h.crop_bottom = (uint16_t)s.conf_bottom;
+    h.chroma_format = (uint8_t)s.chroma_format_idc;
+    h.bit_depth_y = (uint8_t)s.bit_depth_y;
+    h.bit_depth_c = (uint8_t)s.bit_depth_c;
+    h.log2_ctb = (uint8_t)s.log2_ctb;
+    h.log2_min_tb = (uint8_t)s.log2_min_tb;
+    h.log2_min_cb = (uint8_t)s.log2_min_cb;
+    h.log2_sao_offset_scale_y = (uint8_t)p.log2_sao_offset_scale_luma;
+    h.log2_sao_offset_scale_c = (uint8_t)p.log2_sao_offset_scale_chroma;
+    h.ctb_w = (uint16_t)s.ctb_w;
+    h.ctb_h = (uint16_t)s.ctb_h;
+    h.pps_cb_qp_offset = (int8_t)p.cb_qp_offset;
+    h.pps_cr_qp_offset = (int8_t)p.cr_qp_offset;
+    h.pcm_loop_filter_disabled = s.pcm_loop_filter_disabled;
+    uint32_t flags = 0;
+    if (s.strong_intra_smoothing) flags |= HM_PIC_STRONG_INTRA_SMOOTHING;
+    if (s.sao_enabled) flags |= HM_PIC_SAO_ENABLED;
+    for (const hm_slice& sl : pic.slices) {
+      if (!sl.deblocking_disabled) flags |= HM_PIC_DEBLOCK_ANY;
+      if (s.sao_enabled && (sl.sao_luma || sl.sao_chroma)) flags |= HM_PIC_SAO_ANY;
+    }
+    if (s.vui_colour_present) flags |= HM_PIC_HAS_VUI_COLOUR;
+    if (p.sign_data_hiding) flags |= HM_PIC_SIGN_HIDING;
+    if (p.tiles_enabled) flags |= HM_PIC_TILES;
+    if (p.lf_across_tiles) flags |= HM_PIC_LF_ACROSS_TILES;
+    h.flags = flags;
+    h.colour_primaries = (uint8_t)s.colour_primaries;
+    h.transfer_characteristics = (uint8_t)s.transfer_characteristics;
+    h.matrix_coeffs = (uint8_t)s.matrix_coeffs;
+    h.full_range = (uint8_t)s.video_full_range;
+    h.n_slices = (uint32_t)pic.slices.size();
+    h.n_ctbs = (uint32_t)N;
+    h.n_tus = (uint32_t)n_tus;
+    h.n_coeffs = (uint32_t)pic.coeffs.size();
+    h.off_slices = (uint32_t)off_slices;
+    h.off_ctbs = (uint32_t)off_ctbs;
+    h.off_tus = (uint32_t)off_tus;
+    h.off_coeffs = (uint32_t)off_coeffs;
+    std::memcpy(blob.data(), &h, sizeof(h));
+    std::memcpy(blob.data() + off_slices, pic.slices.data(), pic.slices.size() * sizeof(hm_slice));
+    std::memcpy(blob.data() + off_ctbs, pic.ctbs.data(), (size_t)N * sizeof(hm_ctb));
+    uint8_t* tp = blob.data() + off_tus;
+    for (int i = 0; i < N; i++) {
+      const size_t b = pic.ctb_tus[i].size() * sizeof(hm_tu);
+      if (b) std::memcpy(tp, pic.ctb_tus[i].data(), b);
+      tp += b;
+    }
+    if (!pic.coeffs.empty()) std::memcpy(blob.data() + off_coeffs, pic.coeffs.data(), pic.coeffs.size() * sizeof(hm_coeff));
+    return blob;
+  }
+};
+
+} // namespace
+} // namespace hm
+
+static_assert(sizeof(hm_tu) == 16, "hm_tu layout");
+static_assert(sizeof(hm_ctb) == 36, "hm_ctb layout");
+static_assert(sizeof(hm_coeff) == 4, "hm_coeff layout");
+static_assert(sizeof(hm_slice) == 12, "hm_slice layout");
+static_assert(sizeof(hm_sao) == 8, "hm_sao layout");
+static_assert(sizeof(hm_pic) % 4 == 0, "hm_pic layout");
+
+extern "C" {
+
+int hm_hevc_parse(const uint8_t* data, size_t size, int annexb, uint8_t** out_blob, size_t* out_size)
+{
+  if (!data || !out_blob || !out_size) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
+  *out_blob = nullptr;
+  *out_size = 0;
+  try {
+    auto dec = std::make_unique<hm::Decoder>();
+    if (annexb) {
+      // split at 00 00 01 start codes
+      size_t i = 0;
+      auto find_sc = [&](size_t from) -> size_t {
+        for (size_t k = from; k + 3 <= size; k++)
+          if (data[k] == 0 && data[k + 1] == 0 && data[k + 2] == 1) return k;
+        return size;
+      };
+      i = find_sc(0);
+      while (i < size) {
+        const size_t start = i + 3;
+        size_t next = find_sc(start);
+        size_t end = next;
+        while (end > start && data[end - 1] == 0) end--; // trailing_zero_8bits
+        if (end > start) dec->handle_nal(data + start, end - start);
+        i = next;
+      }
+    }
+    else {
+      // [u32 big-endian length][NAL] records (decoder_libde265.cc:269-303)
+      size_t p = 0;
+      while (p < size) {
+        if (p + 4 > size) return hm_fail(HM_ERR_BITSTREAM, "truncated NAL length field");
+        const uint32_t n = ((uint32_t)data[p] << 24) | ((uint32_t)data[p + 1] << 16) | ((uint32_t)data[p + 2] << 8) | data[p + 3];
+        p += 4;
+        if (n > size - p) return hm_fail(HM_ERR_BITSTREAM, "NAL length exceeds the data");
+        dec->handle_nal(data + p, n);
+        p += n;
+      }
+    }
+    std::vector<uint8_t> blob = dec->finish();
+    uint8_t* mem = (uint8_t*)std::malloc(blob.size());
+    if (!mem) return hm_fail(HM_ERR_NOMEM, "out of memory");
+    std::memcpy(mem, blob.data(), blob.size());
+    *out_blob = mem;
+    *out_size = blob.size();
+    return HM_OK;
+  }
+  catch (const hm::ParseError& e) {
+    return hm_fail(e.status, "%s", e.what());
+  }
+  catch (const std::bad_alloc&) {
+    return hm_fail(HM_ERR_NOMEM, "out of memory");
+  }
+  catch (const std::exception& e) {
+    return hm_fail(HM_ERR_INTERNAL, "%s", e.what());
+  }
+}
+
+void hm_free(void* p) { std::free(p); }
+
+} // extern "C"

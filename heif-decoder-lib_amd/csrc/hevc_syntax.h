@@ -1,0 +1,854 @@
+// hevc_syntax.h — slice_segment_data() syntax walker for intra slices (ITU-T H.265 §7.3.8,
+// §9.3.4.2 context selection, §8.4.2/8.4.3 intra-mode derivation, §8.6.1 QP derivation).
+//
+// Host-side counterpart of the reference's libde265 slice.cc:2886-4974 (read_sao,
+// read_coding_quadtree, read_coding_unit, read_transform_tree, read_transform_unit,
+// residual_coding) and transform.cc:31-210.  Instead of reconstructing while parsing it emits
+// the GPU command stream of include/hm_stream.h.
+//
+// The walker is a template over the entropy coder `EC`: the product instantiates it with the
+// CABAC *decoder* (hevc_parse.cpp); the test-stream synthesiser instantiates the very same walker
+// with a CABAC *encoder* that draws every bin from a seeded policy (tests/synth), which makes the
+// generated streams valid by construction.  EC provides:
+//     int  bin(int ctxIdx, int kind, int idx)   context coded bin
+//     int  bypass(int kind, int idx)            bypass bin
+//     int  terminate(int expect)                terminating bin (expect: -1 unknown, else the value
+//                                               a conformant stream must carry here)
+//     ContextSet& contexts()
+//     void start_substream()                    (re)initialise the arithmetic engine at a byte boundary
+#ifndef HM_HEVC_SYNTAX_H
+#define HM_HEVC_SYNTAX_H
+
+#include <algorithm>
+#include <cstdint>
+#include <vector>
+
+#include "heif_mi355x.h"
+#include "hevc_cabac.h"
+#include "hevc_types.h"
+#include "hm_stream.h"
+
+namespace hm {
+
+// bin "kinds": meaningless to the decoder, used by the synthesiser's policy
+enum BinKind : int {
+  K_SAO_MERGE, K_SAO_TYPE, K_SAO_OFFSET, K_SAO_SIGN, K_SAO_BAND, K_SAO_CLASS,
+  K_SPLIT_CU, K_TQ_BYPASS, K_PART_MODE, K_PCM, K_PREV_INTRA, K_MPM_IDX, K_REM_MODE, K_CHROMA_MODE,
+  K_SPLIT_TF, K_CBF_LUMA, K_CBF_CHROMA, K_QP_DELTA, K_QP_DELTA_SUFFIX, K_QP_SIGN, K_TSKIP,
+  K_LAST_PREFIX, K_LAST_SUFFIX, K_CSBF, K_SIG, K_GT1, K_GT2, K_SIGN, K_CALR_PREFIX, K_CALR_SUFFIX,
+  K_COUNT
+};
+
+namespace tables {
+// §6.5.3 up-right diagonal, §6.5.4 horizontal, §6.5.5 vertical scans of a 4x4 block: (x,y) by position
+struct Scan { uint8_t x, y; };
+inline const Scan* scan4(int scanIdx)
+{
+  static const Scan diag[16] = {{0,0},{0,1},{1,0},{0,2},{1,1},{2,0},{0,3},{1,2},{2,1},{3,0},{1,3},{2,2},{3,1},{2,3},{3,2},{3,3}};
+  static const Scan horiz[16] = {{0,0},{1,0},{2,0},{3,0},{0,1},{1,1},{2,1},{3,1},{0,2},{1,2},{2,2},{3,2},{0,3},{1,3},{2,3},{3,3}};
+  static const Scan vert[16] = {{0,0},{0,1},{0,2},{0,3},{1,0},{1,1},{1,2},{1,3},{2,0},{2,1},{2,2},{2,3},{3,0},{3,1},{3,2},{3,3}};
+  return scanIdx == 0 ? diag : (scanIdx == 1 ? horiz : vert);
+}
+// scan of the sub-blocks of a (1<<log2)x(1<<log2) grid (log2 = 0..3)
+inline void build_subblock_scan(int scanIdx, int log2w, Scan* out)
+{
+  const int w = 1 << log2w;
+  int n = 0;
+  if (scanIdx == 0) {
+    int x = 0, y = 0;
+    bool stop = false;
+    while (!stop) {
+      while (y >= 0) {
+        if (x < w && y < w) out[n++] = {(uint8_t)x, (uint8_t)y};
+        y--; x++;
+      }
+      y = x; x = 0;
+      if (n >= w * w) stop = true;
+    }
+  }
+  else if (scanIdx == 1) {
+    for (int y = 0; y < w; y++) for (int x = 0; x < w; x++) out[n++] = {(uint8_t)x, (uint8_t)y};
+  }
+  else {
+    for (int x = 0; x < w; x++) for (int y = 0; y < w; y++) out[n++] = {(uint8_t)x, (uint8_t)y};
+  }
+}
+static const uint8_t kCtxIdxMap4x4[16] = {0, 1, 4, 5, 2, 3, 4, 5, 6, 6, 8, 8, 7, 7, 8, 8};
+// Table 8-10: QpC as a function of qPi (ChromaArrayType == 1)
+inline int chroma_qp_table(int qPi)
+{
+  static const int t[14] = {29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37};
+  if (qPi < 30) return qPi;
+  if (qPi >= 44) return qPi - 6;
+  return t[qPi - 30];
+}
+// Table 8-3 (v2): 4:2:2 chroma mode mapping (process of §8.4.3)
+static const uint8_t kMode422[35] = {0, 1, 2, 2, 2, 2, 3, 5, 7, 8, 10, 12, 13, 15, 17, 18, 19, 20,
+                                     21, 22, 23, 23, 24, 24, 25, 25, 26, 27, 27, 28, 28, 29, 29, 30, 31};
+} // namespace tables
+
+// Per-picture state shared by all slice segments of the picture
+struct PictureState {
+  const SPS* sps = nullptr;
+  const PPS* pps = nullptr;
+  std::vector<uint8_t> ct_depth;     // per min CB
+  std::vector<int8_t> qpy;           // per min CB (QpY of the covering CU)
+  std::vector<uint8_t> intra_mode;   // per 4x4 luma block (IntraPredModeY)
+  std::vector<int32_t> ctb_slice_addr; // SliceAddrRS per CTB (-1 = not decoded yet)
+  std::vector<hm_ctb> ctbs;
+  std::vector<hm_slice> slices;
+  std::vector<std::vector<hm_tu>> ctb_tus; // records per CTB (raster address)
+  std::vector<hm_coeff> coeffs;
+  bool uses_pcm = false, uses_tq_bypass = false;
+  // QP predictor state, persists across dependent slice segments (decctx.h thread_context fields)
+  struct { int last_qpy_prev_qg = 0, current_qpy = 0, cur_qg_x = -1, cur_qg_y = -1; } qs;
+
+  void reset(const SPS& s, const PPS& p)
+  {
+    sps = &s; pps = &p;
+    ct_depth.assign((size_t)s.min_cb_w * s.min_cb_h, 0);
+    qpy.assign((size_t)s.min_cb_w * s.min_cb_h, 0);
+    const int w4 = (s.width + 3) >> 2, h4 = (s.height + 3) >> 2;
+    intra_mode.assign((size_t)w4 * h4, 1);
+    const int n = s.ctb_w * s.ctb_h;
+    ctb_slice_addr.assign(n, -1);
+    hm_ctb z; std::memset(&z, 0, sizeof(z));
+    ctbs.assign(n, z);
+    slices.clear();
+    ctb_tus.assign(n, {});
+    coeffs.clear();
+    uses_pcm = uses_tq_bypass = false;
+  }
+};
+
+template <class EC>
+class SliceWalker {
+ public:
+  SliceWalker(EC& ec, PictureState& pic, const SliceHeader& sh, int slice_idx)
+      : ec_(ec), pic_(pic), sps_(*pic.sps), pps_(*pic.pps), sh_(sh), slice_idx_(slice_idx)
+  {
+    w4_ = (sps_.width + 3) >> 2;
+  }
+
+  // §7.3.8.1 slice_segment_data(); `saved_wpp` / `saved_dep` carry context tables between calls
+  // Returns the CTB address (tile scan) following the last decoded CTB.
+  int decode_slice_segment(int start_ts, ContextSet* wpp_store, bool* wpp_valid,
+                           ContextSet* dep_store, bool* dep_valid)
+  {
+    const int W = sps_.ctb_w, N = sps_.ctb_w * sps_.ctb_h;
+    int ts = start_ts;
+    // context initialisation (§9.3.1 / §9.3.2; call pattern of the reference slice.cc:5004-5030,5521-5560)
+    const int rs0 = pps_.CtbAddrTStoRS[ts];
+    const bool tile_start = pps_.tiles_enabled && (ts == 0 || pps_.TileId[ts] != pps_.TileId[ts - 1]);
+    if (tile_start) init_contexts(ec_.contexts(), sh_.SliceQPY);
+    else if (pps_.entropy_coding_sync && (rs0 % W) == 0 && rs0 >= W && wpp_sync_ok(rs0, wpp_valid)) ec_.contexts() = *wpp_store;
+    else if (sh_.dependent && *dep_valid) ec_.contexts() = *dep_store;
+    else init_contexts(ec_.contexts(), sh_.SliceQPY);
+    ec_.start_substream();
+    // QP predictor state
+    first_qg_in_slice_pending_ = !sh_.dependent;
+    if (!sh_.dependent) { pic_.qs.last_qpy_prev_qg = sh_.SliceQPY; pic_.qs.current_qpy = sh_.SliceQPY; pic_.qs.cur_qg_x = pic_.qs.cur_qg_y = -1; }
+
+    for (;;) {
+      if (ts >= N) throw ParseError(HM_ERR_BITSTREAM, "slice data runs past the picture");
+      const int rs = pps_.CtbAddrTStoRS[ts];
+      ctb_addr_ts_ = ts;
+      ctb_addr_rs_ = rs;
+      pic_.ctb_slice_addr[rs] = sh_.SliceAddrRS;
+      pic_.ctbs[rs].slice_idx = (uint16_t)slice_idx_;
+      pic_.ctbs[rs].flags |= HM_CTB_CODED;
+      coding_tree_unit(rs % W, rs / W);
+      // WPP: store after the 2nd CTB of a row (libde265 slice.cc:5071-5083: ctbx == 1)
+      if (pps_.entropy_coding_sync && (rs % W) == 1 && (rs / W) < sps_.ctb_h - 1) {
+        *wpp_store = ec_.contexts();
+        *wpp_valid = true;
+      }
+      const bool last_in_pic = (ts + 1 == N);
+      const int end_of_slice = ec_.terminate(last_in_pic ? 1 : -1);
+      ts++;
+      if (end_of_slice) {
+        if (pps_.dependent_slice_segments_enabled) { *dep_store = ec_.contexts(); *dep_valid = true; }
+        break;
+      }
+      if (ts >= N) throw ParseError(HM_ERR_BITSTREAM, "missing end_of_slice_segment_flag");
+      const int nrs = pps_.CtbAddrTStoRS[ts];
+      const bool new_tile = pps_.tiles_enabled && pps_.TileId[ts] != pps_.TileId[ts - 1];
+      const bool new_row = pps_.entropy_coding_sync && ((nrs % W) == 0 || new_tile);
+      if (new_tile || new_row) {
+        if (!ec_.terminate(1)) throw ParseError(HM_ERR_BITSTREAM, "end_of_subset_one_bit not set");
+        if (new_tile) init_contexts(ec_.contexts(), sh_.SliceQPY);
+        else { // WPP row start
+          if (wpp_sync_ok(nrs, wpp_valid)) ec_.contexts() = *wpp_store;
+          else init_contexts(ec_.contexts(), sh_.SliceQPY);
+        }
+        ec_.start_substream();
+      }
+    }
+    return ts;
+  }
+
+ private:
+  // ---- availability ------------------------------------------------------------------------
+  // WPP: the CTB above-right of a row's first CTB (rs) belongs to this slice and tile, and its
+  // context table was stored
+  bool wpp_sync_ok(int rs, const bool* wpp_valid) const
+  {
+    if (sps_.ctb_w < 2 || !*wpp_valid) return false;
+    const int tr = rs - sps_.ctb_w + 1;
+    return pic_.ctb_slice_addr[tr] == sh_.SliceAddrRS && pps_.TileIdRS[tr] == pps_.TileIdRS[rs];
+  }
+  // §6.4.1 z-scan order availability (luma sample positions)
+  bool avail_z(int xCurr, int yCurr, int xN, int yN) const
+  {
+    if (xN < 0 || yN < 0 || xN >= sps_.width || yN >= sps_.height) return false;
+    const int l2 = sps_.log2_min_tb;
+    const int aN = pps_.MinTbAddrZS[(xN >> l2) + (yN >> l2) * sps_.min_tb_w];
+    const int aC = pps_.MinTbAddrZS[(xCurr >> l2) + (yCurr >> l2) * sps_.min_tb_w];
+    if (aN > aC) return false;
+    const int cc = (xCurr >> sps_.log2_ctb) + (yCurr >> sps_.log2_ctb) * sps_.ctb_w;
+    const int cn = (xN >> sps_.log2_ctb) + (yN >> sps_.log2_ctb) * sps_.ctb_w;
+    if (pic_.ctb_slice_addr[cn] < 0 || pic_.ctb_slice_addr[cn] != pic_.ctb_slice_addr[cc]) return false;
+    return pps_.TileIdRS[cn] == pps_.TileIdRS[cc];
+  }
+
+  // ---- CTU ---------------------------------------------------------------------------------
+  void coding_tree_unit(int xCtb, int yCtb)
+  {
+    const int x0 = xCtb << sps_.log2_ctb, y0 = yCtb << sps_.log2_ctb;
+    hm_ctb& c = pic_.ctbs[ctb_addr_rs_];
+    // deblocking edge permissions of this CTB's left/top edge (deblock.cc:160-196 in the reference)
+    c.flags &= ~(HM_CTB_DEBLOCK_LEFT | HM_CTB_DEBLOCK_TOP);
+    if (x0 > 0) {
+      const int nb = ctb_addr_rs_ - 1;
+      bool ok = true;
+      if (!sh_.lf_across_slices && pic_.ctb_slice_addr[nb] >= 0 && pic_.ctb_slice_addr[nb] != sh_.SliceAddrRS) ok = false;
+      else if (!pps_.lf_across_tiles && pps_.TileIdRS[nb] != pps_.TileIdRS[ctb_addr_rs_]) ok = false;
+      if (ok) c.flags |= HM_CTB_DEBLOCK_LEFT;
+    }
+    if (y0 > 0) {
+      const int nb = ctb_addr_rs_ - sps_.ctb_w;
+      bool ok = true;
+      if (!sh_.lf_across_slices && pic_.ctb_slice_addr[nb] >= 0 && pic_.ctb_slice_addr[nb] != sh_.SliceAddrRS) ok = false;
+      else if (!pps_.lf_across_tiles && pps_.TileIdRS[nb] != pps_.TileIdRS[ctb_addr_rs_]) ok = false;
+      if (ok) c.flags |= HM_CTB_DEBLOCK_TOP;
+    }
+    if (sh_.sao_luma || sh_.sao_chroma) sao(xCtb, yCtb);
+    coding_quadtree(x0, y0, sps_.log2_ctb, 0);
+  }
+
+  // §7.3.8.3 sao()
+  void sao(int rx, int ry)
+  {
+    hm_ctb& c = pic_.ctbs[ctb_addr_rs_];
+    int merge_left = 0, merge_up = 0;
+    if (rx > 0) {
+      const bool left_in_slice = ctb_addr_rs_ > sh_.SliceAddrRS;
+      const bool left_in_tile = pps_.TileIdRS[ctb_addr_rs_] == pps_.TileIdRS[ctb_addr_rs_ - 1];
+      if (left_in_slice && left_in_tile) merge_left = ec_.bin(CTX_SAO_MERGE, K_SAO_MERGE, 0);
+    }
+    if (ry > 0 && !merge_left) {
+      const bool up_in_slice = (ctb_addr_rs_ - sps_.ctb_w) >= sh_.SliceAddrRS;
+      const bool up_in_tile = pps_.TileIdRS[ctb_addr_rs_] == pps_.TileIdRS[ctb_addr_rs_ - sps_.ctb_w];
+      if (up_in_slice && up_in_tile) merge_up = ec_.bin(CTX_SAO_MERGE, K_SAO_MERGE, 1);
+    }
+    if (merge_left) { std::memcpy(c.sao, pic_.ctbs[ctb_addr_rs_ - 1].sao, sizeof(c.sao)); return; }
+    if (merge_up) { std::memcpy(c.sao, pic_.ctbs[ctb_addr_rs_ - sps_.ctb_w].sao, sizeof(c.sao)); return; }
+    std::memset(c.sao, 0, sizeof(c.sao));
+    const int ncomp = sps_.ChromaArrayType == 0 ? 1 : 3;
+    for (int cIdx = 0; cIdx < ncomp; cIdx++) {
+      if (!((sh_.sao_luma && cIdx == 0) || (sh_.sao_chroma && cIdx > 0))) continue;
+      hm_sao& s = c.sao[cIdx];
+      if (cIdx == 0 || cIdx == 1) {
+        int t = 0;
+        if (ec_.bin(CTX_SAO_TYPE, K_SAO_TYPE, 0)) t = ec_.bypass(K_SAO_TYPE, 1) ? 2 : 1;
+        s.type = (uint8_t)t;
+      }
+      else {
+        s.type = c.sao[1].type;
+      }
+      if (s.type == 0) continue;
+      const int bd = cIdx == 0 ? sps_.bit_depth_y : sps_.bit_depth_c;
+      const int cmax = (1 << (std::min(bd, 10) - 5)) - 1;
+      int absv[4];
+      for (int i = 0; i < 4; i++) {
+        int v = 0;
+        while (v < cmax && ec_.bypass(K_SAO_OFFSET, v)) v++;
+        absv[i] = v;
+      }
+      int sign[4] = {1, 1, -1, -1};
+      if (s.type == 1) {
+        for (int i = 0; i < 4; i++) {
+          sign[i] = 1;
+          if (absv[i] != 0) sign[i] = ec_.bypass(K_SAO_SIGN, i) ? -1 : 1;
+        }
+        int bp = 0;
+        for (int i = 0; i < 5; i++) bp = (bp << 1) | ec_.bypass(K_SAO_BAND, i);
+        s.band_position = (uint8_t)bp;
+      }
+      else {
+        if (cIdx == 0 || cIdx == 1) {
+          int cl = ec_.bypass(K_SAO_CLASS, 0);
+          cl = (cl << 1) | ec_.bypass(K_SAO_CLASS, 1);
+          s.eo_class = (uint8_t)cl;
+        }
+        else s.eo_class = c.sao[1].eo_class;
+      }
+      const int scale = cIdx == 0 ? pps_.log2_sao_offset_scale_luma : pps_.log2_sao_offset_scale_chroma;
+      for (int i = 0; i < 4; i++) s.offset[i] = (int8_t)(sign[i] * (absv[i] << scale));
+    }
+  }
+
+  // §7.3.8.4 coding_quadtree()
+  void coding_quadtree(int x0, int y0, int log2CbSize, int cqtDepth)
+  {
+    const int size = 1 << log2CbSize;
+    int split;
+    if (x0 + size <= sps_.width && y0 + size <= sps_.height && log2CbSize > sps_.log2_min_cb) {
+      // §9.3.4.2.2: ctxInc from the coding quadtree depth of the left / above neighbours
+      int inc = 0;
+      if (avail_z(x0, y0, x0 - 1, y0) && ct_depth_at(x0 - 1, y0) > cqtDepth) inc++;
+      if (avail_z(x0, y0, x0, y0 - 1) && ct_depth_at(x0, y0 - 1) > cqtDepth) inc++;
+      split = ec_.bin(CTX_SPLIT_CU + inc, K_SPLIT_CU, log2CbSize);
+    }
+    else {
+      split = log2CbSize > sps_.log2_min_cb ? 1 : 0;
+    }
+    if (pps_.cu_qp_delta_enabled && log2CbSize >= pps_.Log2MinCuQpDeltaSize) {
+      is_cu_qp_delta_coded_ = false;
+      cu_qp_delta_val_ = 0;
+    }
+    if (split) {
+      const int x1 = x0 + (size >> 1), y1 = y0 + (size >> 1);
+      coding_quadtree(x0, y0, log2CbSize - 1, cqtDepth + 1);
+      if (x1 < sps_.width) coding_quadtree(x1, y0, log2CbSize - 1, cqtDepth + 1);
+      if (y1 < sps_.height) coding_quadtree(x0, y1, log2CbSize - 1, cqtDepth + 1);
+      if (x1 < sps_.width && y1 < sps_.height) coding_quadtree(x1, y1, log2CbSize - 1, cqtDepth + 1);
+    }
+    else {
+      // record depth for later split_cu_flag contexts
+      const int n = size >> sps_.log2_min_cb;
+      const int bx = x0 >> sps_.log2_min_cb, by = y0 >> sps_.log2_min_cb;
+      for (int j = 0; j < n; j++)
+        for (int i = 0; i < n; i++) pic_.ct_depth[(bx + i) + (size_t)(by + j) * sps_.min_cb_w] = (uint8_t)cqtDepth;
+      coding_unit(x0, y0, log2CbSize);
+    }
+  }
+  int ct_depth_at(int x, int y) const
+  {
+    return pic_.ct_depth[(x >> sps_.log2_min_cb) + (size_t)(y >> sps_.log2_min_cb) * sps_.min_cb_w];
+  }
+
+  // ---- QP derivation (§8.6.1; call pattern of the reference: transform.cc:31-210) -----------
+  void derive_qp(int xCU, int yCU, int log2CbSize)
+  {
+    const int qgmask = (1 << pps_.Log2MinCuQpDeltaSize) - 1;
+    const int xQG = xCU - (xCU & qgmask), yQG = yCU - (yCU & qgmask);
+    if (xQG != pic_.qs.cur_qg_x || yQG != pic_.qs.cur_qg_y) {
+      pic_.qs.last_qpy_prev_qg = pic_.qs.current_qpy;
+      pic_.qs.cur_qg_x = xQG;
+      pic_.qs.cur_qg_y = yQG;
+    }
+    const int ctbmask = (1 << sps_.log2_ctb) - 1;
+    const bool first_in_ctb_row = (xQG == 0 && (yQG & ctbmask) == 0);
+    const int sx = (sh_.SliceAddrRS % sps_.ctb_w) << sps_.log2_ctb, sy = (sh_.SliceAddrRS / sps_.ctb_w) << sps_.log2_ctb;
+    const bool first_in_slice = (sx == xQG && sy == yQG);
+    bool first_in_tile = false;
+    if (pps_.tiles_enabled && (xQG & ctbmask) == 0 && (yQG & ctbmask) == 0) {
+      const int cx = xQG >> sps_.log2_ctb, cy = yQG >> sps_.log2_ctb;
+      bool col = false, row = false;
+      for (int v : pps_.colBd) if (v == cx) col = true;
+      for (int v : pps_.rowBd) if (v == cy) row = true;
+      first_in_tile = col && row;
+    }
+    int pred;
+    if (first_in_slice || first_in_tile || (first_in_ctb_row && pps_.entropy_coding_sync)) pred = sh_.SliceQPY;
+    else pred = pic_.qs.last_qpy_prev_qg;
+    int qa = pred, qb = pred;
+    if (avail_z(xQG, yQG, xQG - 1, yQG)) {
+      const int cn = ((xQG - 1) >> sps_.log2_ctb) + (yQG >> sps_.log2_ctb) * sps_.ctb_w;
+      if (cn == ctb_addr_rs_) qa = qpy_at(xQG - 1, yQG);
+    }
+    if (avail_z(xQG, yQG, xQG, yQG - 1)) {
+      const int cn = (xQG >> sps_.log2_ctb) + ((yQG - 1) >> sps_.log2_ctb) * sps_.ctb_w;
+      if (cn == ctb_addr_rs_) qb = qpy_at(xQG, yQG - 1);
+    }
+    pred = (qa + qb + 1) >> 1;
+    const int bdY = sps_.qp_bd_offset_y, bdC = sps_.qp_bd_offset_c;
+    const int qpy = ((pred + cu_qp_delta_val_ + 52 + 2 * bdY) % (52 + bdY)) - bdY;
+    qp_prime_[0] = std::max(0, qpy + bdY);
+    for (int c = 1; c <= 2; c++) {
+      const int off = c == 1 ? pps_.cb_qp_offset + sh_.cb_qp_offset : pps_.cr_qp_offset + sh_.cr_qp_offset;
+      int qpi = qpy + off;
+      qpi = qpi < -bdC ? -bdC : (qpi > 57 ? 57 : qpi);
+      // the reference applies Table 8-10 for 4:2:0 and uses qPi unchanged otherwise
+      // (transform.cc:163-170; no Min(qPi,51) for 4:2:2 / 4:4:4) - reproduced for bit-exactness
+      const int qpc = sps_.ChromaArrayType == 1 ? tables::chroma_qp_table(qpi) : qpi;
+      qp_prime_[c] = std::max(0, qpc + bdC);
+    }
+    // store QpY for the whole CU
+    const int n = (1 << log2CbSize) >> sps_.log2_min_cb;
+    const int bx = xCU >> sps_.log2_min_cb, by = yCU >> sps_.log2_min_cb;
+    for (int j = 0; j < n; j++)
+      for (int i = 0; i < n; i++) pic_.qpy[(bx + i) + (size_t)(by + j) * sps_.min_cb_w] = (int8_t)qpy;
+    pic_.qs.current_qpy = qpy;
+    cu_qpy_ = qpy;
+  }
+  int qpy_at(int x, int y) const
+  {
+    return pic_.qpy[(x >> sps_.log2_min_cb) + (size_t)(y >> sps_.log2_min_cb) * sps_.min_cb_w];
+  }
+
+  // ---- CU ----------------------------------------------------------------------------------
+  void coding_unit(int x0, int y0, int log2CbSize)
+  {
+    const int nCbS = 1 << log2CbSize;
+    cu_first_tu_.clear();
+    derive_qp(x0, y0, log2CbSize); // the reference derives QP at CU start (slice.cc:4593)
+    if (pps_.transquant_bypass_enabled) {
+      if (ec_.bin(CTX_TQ_BYPASS, K_TQ_BYPASS, 0)) {
+        pic_.uses_tq_bypass = true;
+        throw ParseError(HM_ERR_UNSUPPORTED, "cu_transquant_bypass_flag=1 is outside the GPU hot path");
+      }
+    }
+    // I slice: no cu_skip_flag / pred_mode_flag
+    bool nxn = false;
+    if (log2CbSize == sps_.log2_min_cb) {
+      // part_mode: bin 1 -> 2Nx2N, 0 -> NxN (NxN requires log2CbSize > MinTbLog2SizeY)
+      const int b = ec_.bin(CTX_PART_MODE, K_PART_MODE, log2CbSize > sps_.log2_min_tb ? 0 : 1);
+      nxn = !b;
+      if (nxn && log2CbSize <= sps_.log2_min_tb) throw ParseError(HM_ERR_BITSTREAM, "PART_NxN at minimum transform size");
+    }
+    if (sps_.pcm_enabled && !nxn && log2CbSize >= sps_.log2_min_pcm_cb && log2CbSize <= sps_.log2_max_pcm_cb) {
+      if (ec_.terminate(0)) {
+        pic_.uses_pcm = true;
+        throw ParseError(HM_ERR_UNSUPPORTED, "pcm_flag=1 is outside the GPU hot path");
+      }
+    }
+    const int pbOffset = nxn ? (nCbS >> 1) : nCbS;
+    const int nParts = nxn ? 4 : 1;
+    int prev_flag[4], mpm_idx[4] = {0, 0, 0, 0}, rem[4] = {0, 0, 0, 0};
+    for (int i = 0; i < nParts; i++) prev_flag[i] = ec_.bin(CTX_PREV_INTRA, K_PREV_INTRA, i);
+    for (int i = 0; i < nParts; i++) {
+      if (prev_flag[i]) {
+        int v = 0;
+        if (ec_.bypass(K_MPM_IDX, 0)) v = ec_.bypass(K_MPM_IDX, 1) ? 2 : 1;
+        mpm_idx[i] = v;
+      }
+      else {
+        int v = 0;
+        for (int k = 0; k < 5; k++) v = (v << 1) | ec_.bypass(K_REM_MODE, k);
+        rem[i] = v;
+      }
+      const int xP = x0 + (i & 1) * pbOffset, yP = y0 + (i >> 1) * pbOffset;
+      const int mode = derive_luma_mode(xP, yP, prev_flag[i], mpm_idx[i], rem[i]);
+      const int n4 = pbOffset >> 2;
+      for (int j = 0; j < n4; j++)
+        for (int k = 0; k < n4; k++) pic_.intra_mode[((xP >> 2) + k) + (size_t)((yP >> 2) + j) * w4_] = (uint8_t)mode;
+      luma_mode_[i] = mode;
+    }
+    if (!nxn) luma_mode_[1] = luma_mode_[2] = luma_mode_[3] = luma_mode_[0];
+    // chroma prediction mode(s)
+    if (sps_.ChromaArrayType == 3) {
+      for (int i = 0; i < nParts; i++) chroma_mode_[i] = map_chroma(read_chroma_pred_mode(), luma_mode_[i]);
+      if (!nxn) chroma_mode_[1] = chroma_mode_[2] = chroma_mode_[3] = chroma_mode_[0];
+    }
+    else if (sps_.ChromaArrayType != 0) {
+      int m = map_chroma(read_chroma_pred_mode(), luma_mode_[0]);
+      if (sps_.ChromaArrayType == 2) m = tables::kMode422[m];
+      chroma_mode_[0] = chroma_mode_[1] = chroma_mode_[2] = chroma_mode_[3] = m;
+    }
+    cu_x_ = x0; cu_y_ = y0; cu_log2_ = log2CbSize; cu_nxn_ = nxn;
+    // intra CU: rqt_root_cbf is not coded; transform_tree always follows
+    const int max_depth = sps_.max_th_depth_intra + (nxn ? 1 : 0);
+    transform_tree(x0, y0, x0, y0, log2CbSize, 0, 0, max_depth, nxn, 1, 1);
+    // all luma records of this CU must carry the CU's final QpY (deblocking uses the QpY map)
+    for (auto& ref : cu_first_tu_) pic_.ctb_tus[ref.ctb][ref.idx].qpy = (int8_t)cu_qpy_;
+  }
+
+  int read_chroma_pred_mode()
+  {
+    if (!ec_.bin(CTX_CHROMA_PRED, K_CHROMA_MODE, 0)) return 4;
+    int v = ec_.bypass(K_CHROMA_MODE, 1);
+    return (v << 1) | ec_.bypass(K_CHROMA_MODE, 2);
+  }
+  static int map_chroma(int intra_chroma_pred_mode, int luma_mode) // §8.4.3, Table 8-2
+  {
+    if (intra_chroma_pred_mode == 4) return luma_mode;
+    static const int cand[4] = {0, 26, 10, 1};
+    const int m = cand[intra_chroma_pred_mode];
+    return m == luma_mode ? 34 : m;
+  }
+
+  // §8.4.2 derivation of IntraPredModeY
+  int derive_luma_mode(int x, int y, int prev_flag, int mpm_idx, int rem)
+  {
+    int candA = 1, candB = 1; // INTRA_DC
+    if (avail_z(x, y, x - 1, y)) candA = pic_.intra_mode[((x - 1) >> 2) + (size_t)(y >> 2) * w4_];
+    if (avail_z(x, y, x, y - 1) && (y - 1) >= ((y >> sps_.log2_ctb) << sps_.log2_ctb))
+      candB = pic_.intra_mode[(x >> 2) + (size_t)((y - 1) >> 2) * w4_];
+    int c[3];
+    if (candA == candB) {
+      if (candA < 2) { c[0] = 0; c[1] = 1; c[2] = 26; }
+      else { c[0] = candA; c[1] = 2 + ((candA + 29) % 32); c[2] = 2 + ((candA - 2 + 1) % 32); }
+    }
+    else {
+      c[0] = candA; c[1] = candB;
+      if (candA != 0 && candB != 0) c[2] = 0;
+      else if (candA != 1 && candB != 1) c[2] = 1;
+      else c[2] = 26;
+    }
+    if (prev_flag) return c[mpm_idx];
+    if (c[0] > c[1]) std::swap(c[0], c[1]);
+    if (c[0] > c[2]) std::swap(c[0], c[2]);
+    if (c[1] > c[2]) std::swap(c[1], c[2]);
+    int mode = rem;
+    for (int i = 0; i < 3; i++) if (mode >= c[i]) mode++;
+    return mode;
+  }
+
+  // ---- transform tree (§7.3.8.8) -----------------------------------------------------------------
+  // parent_cbf_*: 2-bit masks for 4:2:2 (bit0 = upper / only block, bit1 = lower block)
+  void transform_tree(int x0, int y0, int xBase, int yBase, int log2TrafoSize, int trafoDepth, int blkIdx,
+                      int maxTrafoDepth, bool intraSplit, int parent_cbf_cb, int parent_cbf_cr)
+  {
+    int split;
+    if (log2TrafoSize <= sps_.log2_max_tb && log2TrafoSize > sps_.log2_min_tb && trafoDepth < maxTrafoDepth &&
+        !(intraSplit && trafoDepth == 0))
+      split = ec_.bin(CTX_SPLIT_TF + 5 - log2TrafoSize, K_SPLIT_TF, log2TrafoSize);
+    else
+      split = (log2TrafoSize > sps_.log2_max_tb || (intraSplit && trafoDepth == 0)) ? 1 : 0;
+
+    int cbf_cb = 0, cbf_cr = 0;
+    if ((log2TrafoSize > 2 && sps_.ChromaArrayType != 0) || sps_.ChromaArrayType == 3) {
+      const bool two = sps_.ChromaArrayType == 2 && (!split || log2TrafoSize == 3);
+      if (parent_cbf_cb) {
+        cbf_cb = ec_.bin(CTX_CBF_CHROMA + trafoDepth, K_CBF_CHROMA, 0);
+        if (two) cbf_cb |= ec_.bin(CTX_CBF_CHROMA + trafoDepth, K_CBF_CHROMA, 1) << 1;
+      }
+      if (parent_cbf_cr) {
+        cbf_cr = ec_.bin(CTX_CBF_CHROMA + trafoDepth, K_CBF_CHROMA, 2);
+        if (two) cbf_cr |= ec_.bin(CTX_CBF_CHROMA + trafoDepth, K_CBF_CHROMA, 3) << 1;
+      }
+    }
+    else if (log2TrafoSize == 2 && trafoDepth > 0) {
+      // cbf_cb / cbf_cr inferred from the parent for the 4x4 luma case (chroma handled at blkIdx 3)
+      cbf_cb = parent_cbf_cb;
+      cbf_cr = parent_cbf_cr;
+    }
+
+    if (split) {
+      const int x1 = x0 + (1 << (log2TrafoSize - 1)), y1 = y0 + (1 << (log2TrafoSize - 1));
+      transform_tree(x0, y0, x0, y0, log2TrafoSize - 1, trafoDepth + 1, 0, maxTrafoDepth, intraSplit, cbf_cb, cbf_cr);
+      transform_tree(x1, y0, x0, y0, log2TrafoSize - 1, trafoDepth + 1, 1, maxTrafoDepth, intraSplit, cbf_cb, cbf_cr);
+      transform_tree(x0, y1, x0, y0, log2TrafoSize - 1, trafoDepth + 1, 2, maxTrafoDepth, intraSplit, cbf_cb, cbf_cr);
+      transform_tree(x1, y1, x0, y0, log2TrafoSize - 1, trafoDepth + 1, 3, maxTrafoDepth, intraSplit, cbf_cb, cbf_cr);
+    }
+    else {
+      int cbf_luma = 1;
+      // intra CU: cbf_luma is always coded (the "inferred 1" case needs an inter CU)
+      cbf_luma = ec_.bin(CTX_CBF_LUMA + (trafoDepth == 0 ? 1 : 0), K_CBF_LUMA, log2TrafoSize);
+      transform_unit(x0, y0, xBase, yBase, log2TrafoSize, trafoDepth, blkIdx, cbf_luma, cbf_cb, cbf_cr);
+    }
+  }
+
+  // ---- transform unit (§7.3.8.10), reconstruction order of the reference (slice.cc:3979-4118) ----
+  void transform_unit(int x0, int y0, int xBase, int yBase, int log2TrafoSize, int trafoDepth, int blkIdx,
+                      int cbf_luma, int cbf_cb, int cbf_cr)
+  {
+    const int cat = sps_.ChromaArrayType;
+    const int log2C = std::max(2, cat == 3 ? log2TrafoSize : log2TrafoSize - 1);
+    const int cbfChroma = cbf_cb | cbf_cr;
+    if (cbf_luma || cbfChroma) {
+      if (pps_.cu_qp_delta_enabled && !is_cu_qp_delta_coded_) {
+        int v = 0;
+        while (v < 5 && ec_.bin(CTX_CU_QP_DELTA + (v > 0 ? 1 : 0), K_QP_DELTA, v)) v++;
+        if (v == 5) { // EG0 suffix
+          int k = 0;
+          while (ec_.bypass(K_QP_DELTA_SUFFIX, k)) {
+            v += 1 << k;
+            if (++k > 16) throw ParseError(HM_ERR_BITSTREAM, "cu_qp_delta_abs too large");
+          }
+          while (k--) v += ec_.bypass(K_QP_DELTA_SUFFIX, 32 + k) << k;
+        }
+        int sign = 0;
+        if (v) sign = ec_.bypass(K_QP_SIGN, 0);
+        is_cu_qp_delta_coded_ = true;
+        cu_qp_delta_val_ = sign ? -v : v;
+        const int lim_lo = -(26 + sps_.qp_bd_offset_y / 2), lim_hi = 25 + sps_.qp_bd_offset_y / 2;
+        if (cu_qp_delta_val_ < lim_lo || cu_qp_delta_val_ > lim_hi) throw ParseError(HM_ERR_BITSTREAM, "CuQpDeltaVal out of range");
+        derive_qp(cu_x_, cu_y_, cu_log2_);
+      }
+    }
+    // --- luma ---
+    const int part = cu_nxn_ ? (((y0 - cu_y_) >= (1 << (cu_log2_ - 1)) ? 2 : 0) + ((x0 - cu_x_) >= (1 << (cu_log2_ - 1)) ? 1 : 0)) : 0;
+    emit_block(x0, y0, log2TrafoSize, 0, luma_mode_[part], cbf_luma);
+    if (cat == 0) return;
+    // --- chroma ---
+    const int sw = sps_.SubWidthC, shh = sps_.SubHeightC;
+    if (log2TrafoSize > 2 || cat == 3) {
+      const int cmode = chroma_mode_[part];
+      for (int c = 1; c <= 2; c++) {
+        const int cbf = c == 1 ? cbf_cb : cbf_cr;
+        emit_block(x0 / sw, y0 / shh, log2C, c, cmode, cbf & 1);
+        if (cat == 2) emit_block(x0 / sw, y0 / shh + (1 << log2C), log2C, c, cmode, (cbf >> 1) & 1);
+      }
+    }
+    else if (blkIdx == 3) {
+      const int cmode = chroma_mode_[0];
+      for (int c = 1; c <= 2; c++) {
+        const int cbf = c == 1 ? cbf_cb : cbf_cr;
+        emit_block(xBase / sw, yBase / shh, 2, c, cmode, cbf & 1);
+        if (cat == 2) emit_block(xBase / sw, yBase / shh + 4, 2, c, cmode, (cbf >> 1) & 1);
+      }
+    }
+  }
+
+  // one (component) block: optional residual_coding(), then the hm_tu record
+  void emit_block(int xc, int yc, int log2, int cIdx, int mode, int cbf)
+  {
+    const int sw = cIdx ? sps_.SubWidthC : 1, shh = cIdx ? sps_.SubHeightC : 1;
+    const int nT = 1 << log2;
+    hm_tu t;
+    std::memset(&t, 0, sizeof(t));
+    const int ctb_c_w = (1 << sps_.log2_ctb) / sw, ctb_c_h = (1 << sps_.log2_ctb) / shh;
+    t.x = (uint8_t)(xc % ctb_c_w);
+    t.y = (uint8_t)(yc % ctb_c_h);
+    t.info = (uint8_t)(log2 | (cIdx << HM_TU_CIDX_SHIFT));
+    t.pred_mode = (uint8_t)mode;
+    t.coeff_first = (uint32_t)pic_.coeffs.size();
+    bool tskip = false;
+    if (cbf) {
+      residual_coding(log2, cIdx, mode, tskip);
+      t.info |= HM_TU_CBF;
+      if (tskip) t.info |= HM_TU_TSKIP;
+    }
+    const size_t ncoef = pic_.coeffs.size() - t.coeff_first;
+    t.n_coeff = (uint16_t)ncoef;
+    t.qp = (uint8_t)qp_prime_[cIdx];
+    t.qpy = (int8_t)cu_qpy_;
+    // neighbour availability (intrapred.h:536-667 in the reference; equals §8.4.4.2.2)
+    const int xL = xc * sw, yL = yc * shh; // luma position of the block
+    const int cw = cIdx ? sps_.width / sw : sps_.width, chh = cIdx ? sps_.height / shh : sps_.height;
+    const bool aL = avail_z(xL, yL, xL - 1, yL);
+    const bool aT = avail_z(xL, yL, xL, yL - 1);
+    const bool aTL = avail_z(xL, yL, xL - 1, yL - 1);
+    const bool aBL = aL && (yc + nT < chh) && avail_z(xL, yL, xL - 1, (yc + nT) * shh);
+    const bool aTR = (xc + nT < cw) && avail_z(xL, yL, (xc + nT) * sw, yL - 1);
+    t.avail_left = aL ? (uint8_t)nT : 0;
+    t.avail_top = aT ? (uint8_t)nT : 0;
+    if (aTL) t.info |= HM_TU_AVAIL_TL;
+    t.avail_bottom_left = aBL ? (uint8_t)std::min(nT, chh - (yc + nT)) : 0;
+    t.avail_top_right = aTR ? (uint8_t)std::min(nT, cw - (xc + nT)) : 0;
+    auto& vec = pic_.ctb_tus[ctb_addr_rs_];
+    if (cIdx == 0) cu_first_tu_.push_back({ctb_addr_rs_, (uint32_t)vec.size()});
+    vec.push_back(t);
+  }
+
+  // ---- residual_coding (§7.3.8.11) --------------------------------------------------------------
+  void residual_coding(int log2, int cIdx, int predMode, bool& tskip)
+  {
+    const int nT = 1 << log2;
+    tskip = false;
+    if (pps_.transform_skip_enabled && log2 <= pps_.log2_max_transform_skip_size)
+      tskip = ec_.bin(CTX_TSKIP + (cIdx ? 1 : 0), K_TSKIP, cIdx) != 0;
+    // last significant coefficient position
+    int lastX = last_prefix(log2, cIdx, CTX_LAST_X);
+    int lastY = last_prefix(log2, cIdx, CTX_LAST_Y);
+    if (lastX > 3) lastX = last_suffix(lastX);
+    if (lastY > 3) lastY = last_suffix(lastY);
+    // scanIdx (§7.4.9.11)
+    int scanIdx = 0;
+    if (log2 == 2 || (log2 == 3 && cIdx == 0) || (log2 == 3 && sps_.ChromaArrayType == 3)) {
+      if (predMode >= 6 && predMode <= 14) scanIdx = 2;
+      else if (predMode >= 22 && predMode <= 30) scanIdx = 1;
+    }
+    if (scanIdx == 2) std::swap(lastX, lastY);
+    if (lastX >= nT || lastY >= nT) throw ParseError(HM_ERR_BITSTREAM, "last significant coefficient outside block");
+
+    const tables::Scan* pos4 = tables::scan4(scanIdx);
+    tables::Scan sbscan[64];
+    const int log2sb = log2 - 2;
+    tables::build_subblock_scan(scanIdx, log2sb, sbscan);
+    const int sbw = 1 << log2sb;
+    // locate the last sub-block / position
+    int lastSub = 0, lastPos = 0;
+    {
+      const int sx = lastX >> 2, sy = lastY >> 2;
+      for (int i = 0; i < sbw * sbw; i++) if (sbscan[i].x == sx && sbscan[i].y == sy) { lastSub = i; break; }
+      const int px = lastX & 3, py = lastY & 3;
+      for (int i = 0; i < 16; i++) if (pos4[i].x == px && pos4[i].y == py) { lastPos = i; break; }
+    }
+    uint8_t csbf[8][8];
+    std::memset(csbf, 0, sizeof(csbf));
+    int c1 = 1; // greater1Ctx carried between sub-blocks
+    bool first_subblock = true;
+
+    for (int i = lastSub; i >= 0; i--) {
+      const int xS = sbscan[i].x, yS = sbscan[i].y;
+      int inferSbDcSig = 0;
+      int coded;
+      if (i < lastSub && i > 0) {
+        int ctx = 0;
+        if (xS < sbw - 1) ctx |= csbf[yS][xS + 1];
+        if (yS < sbw - 1) ctx |= csbf[yS + 1][xS];
+        coded = ec_.bin(CTX_CSBF + (ctx ? 1 : 0) + (cIdx ? 2 : 0), K_CSBF, 0);
+        inferSbDcSig = 1;
+      }
+      else coded = 1; // first (DC) and last sub-block are inferred coded
+      csbf[yS][xS] = (uint8_t)coded;
+      if (!coded) continue;
+
+      // significant_coeff_flags
+      int sigpos[16]; // scan positions (descending) of significant coefficients
+      int nsig = 0;
+      int startPos = 15;
+      if (i == lastSub) { startPos = lastPos - 1; sigpos[nsig++] = lastPos; }
+      int prevCsbf = 0;
+      if (xS < sbw - 1) prevCsbf |= csbf[yS][xS + 1];
+      if (yS < sbw - 1) prevCsbf |= csbf[yS + 1][xS] << 1;
+      for (int n = startPos; n >= 0; n--) {
+        const int xP = pos4[n].x, yP = pos4[n].y;
+        int sig;
+        if (n > 0 || !inferSbDcSig) {
+          // §9.3.4.2.5
+          int sigCtx;
+          if (log2 == 2) sigCtx = tables::kCtxIdxMap4x4[(yP << 2) + xP];
+          else if (xS == 0 && yS == 0 && n == 0) sigCtx = 0;
+          else {
+            if (prevCsbf == 0) sigCtx = (xP + yP == 0) ? 2 : ((xP + yP < 3) ? 1 : 0);
+            else if (prevCsbf == 1) sigCtx = (yP == 0) ? 2 : ((yP == 1) ? 1 : 0);
+            else if (prevCsbf == 2) sigCtx = (xP == 0) ? 2 : ((xP == 1) ? 1 : 0);
+            else sigCtx = 2;
+            if (cIdx == 0) {
+              if (xS + yS > 0) sigCtx += 3;
+              sigCtx += (log2 == 3) ? (scanIdx == 0 ? 9 : 15) : 21;
+            }
+            else sigCtx += (log2 == 3) ? 9 : 12;
+          }
+          const int inc = cIdx == 0 ? sigCtx : 27 + sigCtx;
+          sig = ec_.bin(CTX_SIG + inc, K_SIG, n);
+          if (sig) inferSbDcSig = 0;
+        }
+        else sig = 1; // inferred: the only coefficient of a coded sub-block
+        if (sig) sigpos[nsig++] = n;
+      }
+      if (nsig == 0) continue;
+
+      // greater1 / greater2 flags
+      int ctxSet = (i == 0 || cIdx > 0) ? 0 : 2;
+      if (!first_subblock && c1 == 0) ctxSet++;
+      first_subblock = false;
+      c1 = 1;
+      int gt1[16], gt2flag = 0;
+      int firstGt1 = -1;
+      const int ngt1 = std::min(nsig, 8);
+      for (int k = 0; k < ngt1; k++) {
+        gt1[k] = ec_.bin(CTX_GT1 + ctxSet * 4 + c1 + (cIdx ? 16 : 0), K_GT1, k);
+        if (gt1[k]) { c1 = 0; if (firstGt1 < 0) firstGt1 = k; }
+        else if (c1 > 0 && c1 < 3) c1++;
+      }
+      if (firstGt1 >= 0) gt2flag = ec_.bin(CTX_GT2 + ctxSet + (cIdx ? 4 : 0), K_GT2, 0);
+
+      // signs
+      const bool signHidden = pps_.sign_data_hiding && (sigpos[0] - sigpos[nsig - 1] > 3);
+      const int nsign = signHidden ? nsig - 1 : nsig;
+      uint32_t signbits = 0;
+      for (int k = 0; k < nsign; k++) signbits = (signbits << 1) | (uint32_t)ec_.bypass(K_SIGN, k);
+      signbits <<= (16 - nsign);
+
+      // remaining levels
+      int rice = 0, sumAbs = 0;
+      for (int k = 0; k < nsig; k++) {
+        int base;
+        if (k < 8) base = 1 + gt1[k] + ((k == firstGt1) ? gt2flag : 0);
+        else base = 1;
+        const int thresh = (k < 8) ? ((k == firstGt1 || firstGt1 < 0 || k < firstGt1) ? 3 : 2) : 1;
+        // a remaining level is coded iff base == ((numSig<8) ? ((k==firstGt1) ? 3 : 2) : 1)
+        const int need = (k < 8) ? ((k == firstGt1) ? 3 : 2) : 1;
+        (void)thresh;
+        int absv = base;
+        if (base == need) {
+          absv += coeff_abs_level_remaining(rice);
+          if (absv > 3 * (1 << rice)) rice = std::min(rice + 1, 4);
+        }
+        if (absv > 32768) throw ParseError(HM_ERR_BITSTREAM, "transform coefficient out of range");
+        int val = absv;
+        bool neg;
+        if (k < nsign) neg = (signbits >> (15 - k)) & 1;
+        else neg = false;
+        sumAbs += absv;
+        if (k == nsig - 1 && signHidden) neg = (sumAbs & 1) != 0;
+        if (neg) val = -val;
+        if (val > 32767) val = 32767; // |coeff| == 32768 only valid negative
+        const int n = sigpos[k];
+        const int xC = (xS << 2) + pos4[n].x, yC = (yS << 2) + pos4[n].y;
+        hm_coeff hc;
+        hc.pos = (uint16_t)(xC + yC * nT);
+        hc.value = (int16_t)val;
+        pic_.coeffs.push_back(hc);
+      }
+    }
+  }
+
+  int last_prefix(int log2, int cIdx, int base)
+  {
+    int off, shift;
+    if (cIdx == 0) { off = 3 * (log2 - 2) + ((log2 - 1) >> 2); shift = (log2 + 1) >> 2; }
+    else { off = 15; shift = log2 - 2; }
+    const int cmax = (log2 << 1) - 1;
+    int v = 0;
+    while (v < cmax && ec_.bin(base + off + (v >> shift), K_LAST_PREFIX, v | (log2 << 8))) v++;
+    return v;
+  }
+  int last_suffix(int prefix)
+  {
+    const int nbits = (prefix >> 1) - 1;
+    int s = 0;
+    for (int i = 0; i < nbits; i++) s = (s << 1) | ec_.bypass(K_LAST_SUFFIX, i);
+    return (1 << nbits) * (2 + (prefix & 1)) + s;
+  }
+  // §9.3.3.11 binarisation of coeff_abs_level_remaining
+  int coeff_abs_level_remaining(int rice)
+  {
+    int prefix = 0;
+    while (ec_.bypass(K_CALR_PREFIX, prefix)) {
+      if (++prefix > 32) throw ParseError(HM_ERR_BITSTREAM, "coeff_abs_level_remaining prefix too long");
+    }
+    if (prefix <= 3) {
+      int v = prefix << rice;
+      for (int i = rice - 1; i >= 0; i--) v += ec_.bypass(K_CALR_SUFFIX, i) << i;
+      return v;
+    }
+    const int nb = prefix - 3 + rice;
+    if (nb > 30) throw ParseError(HM_ERR_BITSTREAM, "coeff_abs_level_remaining too large");
+    int v = (((1 << (prefix - 3)) + 3 - 1) << rice);
+    int s = 0;
+    for (int i = nb - 1; i >= 0; i--) s += ec_.bypass(K_CALR_SUFFIX, i) << i;
+    return v + s;
+  }
+
+  struct TuRef { int ctb; uint32_t idx; };
+
+  EC& ec_;
+  PictureState& pic_;
+  const SPS& sps_;
+  const PPS& pps_;
+  const SliceHeader& sh_;
+  int slice_idx_;
+  int w4_ = 0;
+  int ctb_addr_ts_ = 0, ctb_addr_rs_ = 0;
+  // QP state (thread_context fields of the reference: decctx.h)
+  bool is_cu_qp_delta_coded_ = false;
+  int cu_qp_delta_val_ = 0;
+  bool first_qg_in_slice_pending_ = false;
+  int qp_prime_[3] = {0, 0, 0};
+  int cu_qpy_ = 0;
+  // current CU
+  int cu_x_ = 0, cu_y_ = 0, cu_log2_ = 3;
+  bool cu_nxn_ = false;
+  int luma_mode_[4] = {1, 1, 1, 1}, chroma_mode_[4] = {1, 1, 1, 1};
+  std::vector<TuRef> cu_first_tu_;
+};
+
+} // namespace hm
+#endif

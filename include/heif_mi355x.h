@@ -92,6 +92,21 @@ HM_API int hm_ycbcr_coefficients(int has_nclx, int matrix, int primaries, float 
 HM_API int hm_colour_convert(const hm_colour_desc* d, const void* d_y, const void* d_cb,
                              const void* d_cr, void* d_out, void* stream);
 
+/* ------------------------------------------------------------------------- */
+/* Host entropy decode: HEVC intra picture -> GPU command stream (hm_stream.h) */
+/* ------------------------------------------------------------------------- */
+
+/* Parse one coded picture.  `data` is what a heif_decoder_plugin receives through push_data():
+ * a concatenation of [u32 big-endian length][NAL unit] records, parameter sets first
+ * (libheif/plugins/decoder_libde265.cc:269-303); with annexb != 0 it is an Annex-B byte stream
+ * (00 00 01 start codes) instead.  On success *out_blob (free with hm_free) holds the picture's
+ * command stream (struct hm_pic at offset 0).  CABAC / parsing run on the calling CPU thread -
+ * as in the reference (slice.cc) - and are thread-safe across different calls.
+ * Returns HM_ERR_UNSUPPORTED for syntax outside the GPU hot path (inter slices, PCM,
+ * transquant bypass, scaling lists, range-extension tools, 4:0:0 / 4:4:4). */
+HM_API int hm_hevc_parse(const uint8_t* data, size_t size, int annexb, uint8_t** out_blob, size_t* out_size);
+HM_API void hm_free(void* p);
+
 #ifdef __cplusplus
 }
 #endif

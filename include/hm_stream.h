@@ -1,0 +1,128 @@
+/* hm_stream.h — the GPU command stream of one coded picture (one HEIF tile / image).
+ *
+ * Produced on the host by the entropy decoder (hm_hevc_parse, CABAC stays on the CPU as in
+ * the reference: third-party/libde265/libde265/slice.cc:2886-5600), consumed by the HIP
+ * reconstruction / deblock / SAO kernels and — in tests — by the oracle's scalar executors.
+ * It carries exactly the information libde265 keeps in tctx->coeffList/coeffPos/nCoeff
+ * (decctx.h:88-92), its per-CB/TU metadata arrays (image.h:190-215,414-420) and sao_info
+ * (slice.h:457-465), flattened into plain little-endian POD arrays.
+ *
+ * Layout of one picture blob (all offsets in bytes from the blob start, each 16-byte aligned):
+ *     hm_pic            header
+ *     hm_slice[n_slices]
+ *     hm_ctb[n_ctbs]    raster order
+ *     hm_tu[n_tus]      decode order; the records of one CTB are contiguous
+ *     hm_coeff[n_coeffs]
+ */
+#ifndef HM_STREAM_H
+#define HM_STREAM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HM_STREAM_MAGIC 0x314d5348u /* "HSM1" */
+
+/* hm_pic.flags */
+#define HM_PIC_STRONG_INTRA_SMOOTHING 0x0001u /* sps.strong_intra_smoothing_enable_flag        */
+#define HM_PIC_SAO_ENABLED            0x0002u /* sps.sample_adaptive_offset_enabled_flag       */
+#define HM_PIC_DEBLOCK_ANY            0x0004u /* at least one slice has deblocking enabled     */
+#define HM_PIC_SAO_ANY                0x0008u /* at least one slice has SAO luma or chroma on  */
+#define HM_PIC_HAS_VUI_COLOUR         0x0010u /* video_signal_type present in the VUI          */
+#define HM_PIC_SIGN_HIDING            0x0020u /* informational                                 */
+#define HM_PIC_TILES                  0x0040u /* pps.tiles_enabled_flag                        */
+#define HM_PIC_LF_ACROSS_TILES        0x0080u /* pps.loop_filter_across_tiles_enabled_flag     */
+
+typedef struct hm_pic {
+  uint32_t magic;
+  uint32_t total_bytes;        /* size of the whole blob                                     */
+  uint16_t width, height;      /* luma samples (pic_width/height_in_luma_samples)            */
+  uint16_t crop_left, crop_right, crop_top, crop_bottom; /* conformance window, luma samples */
+  uint8_t  chroma_format;      /* 0 mono, 1 4:2:0, 2 4:2:2, 3 4:4:4                          */
+  uint8_t  bit_depth_y, bit_depth_c;
+  uint8_t  log2_ctb;           /* 4..6                                                       */
+  uint8_t  log2_min_tb;        /* 2..5                                                       */
+  uint8_t  log2_min_cb;
+  uint8_t  log2_sao_offset_scale_y, log2_sao_offset_scale_c; /* already applied to offsets   */
+  uint16_t ctb_w, ctb_h;       /* picture size in CTBs                                       */
+  int8_t   pps_cb_qp_offset, pps_cr_qp_offset; /* chroma deblocking QpC (deblock.cc:1695)   */
+  uint8_t  pcm_loop_filter_disabled;
+  uint8_t  reserved0;
+  uint32_t flags;              /* HM_PIC_*                                                   */
+  /* VUI colour description (vui.cc:93-97 defaults: 2,2,2, full_range 0)                     */
+  uint8_t  colour_primaries, transfer_characteristics, matrix_coeffs, full_range;
+  uint32_t n_slices, n_ctbs, n_tus, n_coeffs;
+  uint32_t off_slices, off_ctbs, off_tus, off_coeffs;
+  uint32_t reserved1[3];
+} hm_pic;
+
+/* one entry per slice (not slice segment) */
+typedef struct hm_slice {
+  uint32_t slice_addr;          /* SliceAddrRS                                               */
+  int8_t   beta_offset_div2, tc_offset_div2;
+  uint8_t  deblocking_disabled; /* slice_deblocking_filter_disabled_flag                     */
+  uint8_t  sao_luma, sao_chroma;
+  uint8_t  lf_across_slices;    /* slice_loop_filter_across_slices_enabled_flag              */
+  int8_t   slice_qp;
+  uint8_t  reserved;
+} hm_slice;
+
+/* hm_ctb.flags */
+#define HM_CTB_DEBLOCK_LEFT  0x01u /* filter this CTB's left picture-internal edge (deblock.cc:160-196) */
+#define HM_CTB_DEBLOCK_TOP   0x02u /* ... top edge                                                       */
+#define HM_CTB_CODED         0x04u /* CTB was present in the bitstream                                   */
+
+/* SAO parameters of one colour component of one CTB (slice.h:457-465, offsets pre-scaled
+ * by log2_sao_offset_scale as slice.cc:2996-3007 does) */
+typedef struct hm_sao {
+  uint8_t type;          /* 0 off, 1 band, 2 edge (SaoTypeIdx)                                */
+  uint8_t eo_class;      /* SaoEoClass 0..3                                                   */
+  uint8_t band_position; /* sao_band_position 0..31                                           */
+  int8_t  offset[4];
+  uint8_t reserved;
+} hm_sao;
+
+typedef struct hm_ctb {
+  uint32_t tu_first;     /* index of the first hm_tu of this CTB                              */
+  uint16_t tu_count;
+  uint16_t slice_idx;    /* index into hm_slice[]                                             */
+  uint8_t  flags;        /* HM_CTB_*                                                          */
+  uint8_t  sao_nb_mask;  /* bit k set: neighbour CTB k usable by SAO edge offset; k = 0..7 =
+                            NW,N,NE,W,E,SW,S,SE (sao.cc:336-424 slice/tile tests)             */
+  uint16_t reserved;
+  hm_sao   sao[3];
+} hm_ctb; /* 36 bytes */
+
+/* hm_tu.info */
+#define HM_TU_LOG2_MASK 0x07u  /* log2 block size 2..5 (component samples)                    */
+#define HM_TU_CIDX_SHIFT 3     /* bits 3-4: colour component                                  */
+#define HM_TU_CBF     0x20u    /* residual present                                            */
+#define HM_TU_TSKIP   0x40u    /* transform_skip_flag                                         */
+#define HM_TU_AVAIL_TL 0x80u   /* top-left neighbour sample available                         */
+
+/* One reconstruction step: predict block, then add its residual.  x,y are relative to the CTB
+ * origin in samples of the component (chroma: chroma samples).  avail_* count available
+ * neighbour samples (intrapred.h:620-667: picture bounds, slice, tile and z-order already
+ * applied, clamped to the picture). */
+typedef struct hm_tu {
+  uint8_t  x, y;
+  uint8_t  info;
+  uint8_t  pred_mode;    /* IntraPredMode 0..34 (chroma: final mode, 4:2:2 remap applied)     */
+  uint8_t  qp;           /* qP of (8.6.1) incl. QpBdOffset: the dequantisation QP             */
+  int8_t   qpy;          /* QpY of the coding unit (deblocking)                               */
+  uint16_t n_coeff;      /* number of hm_coeff pairs                                          */
+  uint32_t coeff_first;  /* index into hm_coeff[]                                             */
+  uint8_t  avail_left, avail_bottom_left, avail_top, avail_top_right;
+} hm_tu; /* 16 bytes */
+
+typedef struct hm_coeff {
+  uint16_t pos;          /* x + y * nT (coeffPos, slice.cc:3694-3696)                         */
+  int16_t  value;        /* TransCoeffLevel before scaling                                    */
+} hm_coeff;
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HM_STREAM_H */

@@ -73,6 +73,20 @@ int orc_paste_tile_plane(const uint8_t* tile, int tile_stride, int tile_w, int t
 /* chroma_sampling.cc:585-700: bilinear 4:2:0 chroma up-sampling to 4:4:4 (8 bit, one plane) */
 void orc_upsample_bilinear_420(const uint8_t* in, int is, int w, int h, uint8_t* out, int os);
 
+/* ---- HEVC intra reconstruction (oracle_recon.c) ------------------------------------------- */
+
+/* width,height,chroma_format,bit_depth, full_range,matrix,primaries,has_vui_colour of a
+ * command-stream blob (include/hm_stream.h).  0 on success. */
+int orc_stream_info(const uint8_t* blob, size_t size, int out[8]);
+
+/* Scalar executors of transform.cc / fallback-dct.cc / intrapred.h / deblock.cc / sao.cc driven by
+ * the command stream.  stages: bit0 = deblocking, bit1 = SAO.  Planes are tight uint16 arrays of
+ * width x height (luma) and the subsampled size (chroma).  0 on success. */
+int orc_decode_picture(const uint8_t* blob, size_t size, int stages, uint16_t* y, uint16_t* cb, uint16_t* cr);
+
+/* the 32x32 inverse-DCT basis used above (row-major) */
+const int16_t* orc_dct_matrix(void);
+
 uint64_t orc_fnv1a64(const uint8_t* p, size_t n, uint64_t h);
 /* hash `rows` tight rows of `row_bytes` from a strided plane */
 uint64_t orc_fnv1a64_rows(const uint8_t* p, int stride, int row_bytes, int rows, uint64_t h);

@@ -1,0 +1,569 @@
+/* oracle/oracle_recon.c — TEST INFRASTRUCTURE ONLY (see oracle.h).
+ *
+ * Scalar CPU restatement of the reference's HEVC-intra reconstruction, deblocking and SAO
+ * (SURVEY §8a rows R1-R5, F1, F2), driven by the command stream of include/hm_stream.h.
+ * Each function cites the libde265 file:line whose arithmetic it follows.  Samples are kept
+ * in uint16_t planes (tight stride = plane width) for every bit depth.
+ */
+#include "oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#include "hm_stream.h"
+
+/* ---- small helpers -------------------------------------------------------------------- */
+static inline int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+static inline int iabs(int v) { return v < 0 ? -v : v; }
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int isign(int v) { return (v > 0) - (v < 0); }
+
+typedef struct {
+  const hm_pic* hdr;
+  const hm_slice* slices;
+  const hm_ctb* ctbs;
+  const hm_tu* tus;
+  const hm_coeff* coeffs;
+  int w[3], h[3];      /* plane sizes */
+  int sw, sh;          /* chroma subsampling factors */
+  uint16_t* pl[3];
+  uint8_t* edge;       /* per 4x4 luma block: bit0 vertical edge on its left, bit1 horizontal edge on its top */
+  int8_t* qpy;         /* per 4x4 luma block */
+  int w4, h4;
+} pic_t;
+
+/* HEVC inverse-DCT basis (ITU-T H.265 eq. 8-xxx transMatrix; fallback-dct.cc:554-587 holds the
+ * same table).  Entry (k,n) = +-C[fold(k*(2n+1) mod 128)]. */
+static int16_t g_dct[32][32];
+static int g_dct_ready = 0;
+static void init_dct(void)
+{
+  static const int C[33] = {64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
+                            61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0};
+  if (g_dct_ready) return;
+  for (int k = 0; k < 32; k++)
+    for (int n = 0; n < 32; n++) {
+      int m = (k * (2 * n + 1)) & 127, v;
+      if (k == 0) v = 64;
+      else if (m <= 32) v = C[m];
+      else if (m <= 64) v = -C[64 - m];
+      else if (m <= 96) v = -C[m - 64];
+      else v = C[128 - m];
+      g_dct[k][n] = (int16_t)v;
+    }
+  g_dct_ready = 1;
+}
+const int16_t* orc_dct_matrix(void) { init_dct(); return &g_dct[0][0]; }
+
+static const int8_t kDst[4][4] = {{29, 55, 74, 84}, {74, 74, 0, -74}, {84, -29, -74, 55}, {55, -84, 74, -29}};
+static const int kLevelScale[6] = {40, 45, 51, 57, 64, 72};
+static const int kIntraPredAngle[35] = {0, 0, 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26,
+                                        -32, -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32};
+static const int kInvAngle[15] = {-4096, -1638, -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096};
+
+/* ---- R4: reference-sample construction (intrapred.h:620-836) --------------------------------- */
+static void build_border(const pic_t* P, const hm_tu* t, int cIdx, int x0, int y0, int nT, int bit_depth, int* border /* centre */)
+{
+  const uint16_t* img = P->pl[cIdx];
+  const int stride = P->w[cIdx];
+  const int aL = t->avail_left, aBL = t->avail_bottom_left, aT = t->avail_top, aTR = t->avail_top_right;
+  const int aTL = (t->info & HM_TU_AVAIL_TL) != 0;
+  int have_left = aL > 0, have_tl = aTL, have_top = aT > 0;
+  if (aL) for (int y = 0; y < nT; y++) border[-1 - y] = img[(x0 - 1) + (size_t)(y0 + y) * stride];
+  if (aBL) {
+    for (int y = nT; y < nT + aBL; y++) border[-1 - y] = img[(x0 - 1) + (size_t)(y0 + y) * stride];
+    for (int y = nT + aBL; y < 2 * nT; y++) border[-1 - y] = border[-(nT + aBL)]; /* pad with last valid */
+  }
+  if (aTL) border[0] = img[(x0 - 1) + (size_t)(y0 - 1) * stride];
+  if (aT) for (int x = 0; x < nT; x++) border[1 + x] = img[(x0 + x) + (size_t)(y0 - 1) * stride];
+  if (aTR) {
+    for (int x = nT; x < nT + aTR; x++) border[1 + x] = img[(x0 + x) + (size_t)(y0 - 1) * stride];
+    for (int x = nT + aTR; x < 2 * nT; x++) border[1 + x] = border[nT + aTR];
+  }
+  if (!aBL) { /* substitution cascade, intrapred.h:687-729 */
+    if (have_left) { for (int i = 0; i < nT; i++) border[-2 * nT + i] = border[-nT]; }
+    else if (have_tl) { for (int i = 0; i < 2 * nT; i++) border[-2 * nT + i] = border[0]; have_left = 1; }
+    else if (have_top) {
+      border[0] = border[1];
+      for (int i = 0; i < 2 * nT; i++) border[-2 * nT + i] = border[0];
+      have_tl = 1; have_left = 1;
+    }
+    else if (aTR) {
+      for (int i = 0; i < nT; i++) border[1 + i] = border[nT + 1];
+      border[0] = border[nT + 1];
+      for (int i = 0; i < 2 * nT; i++) border[-2 * nT + i] = border[0];
+      have_top = 1; have_tl = 1; have_left = 1;
+    }
+    else {
+      border[0] = 1 << (bit_depth - 1);
+      for (int i = 0; i < 2 * nT; i++) { border[1 + i] = border[0]; border[-2 * nT + i] = border[0]; }
+      have_top = 1; have_tl = 1; have_left = 1;
+      return;
+    }
+  }
+  if (!have_left) for (int i = 0; i < nT; i++) border[-nT + i] = border[-nT - 1];
+  if (!have_tl) border[0] = border[-1];
+  if (!have_top) for (int i = 0; i < nT; i++) border[1 + i] = border[0];
+  if (!aTR) for (int i = 0; i < nT; i++) border[nT + 1 + i] = border[nT];
+}
+
+/* ---- R5: smoothing (intrapred.h:192-266) -------------------------------------------------- */
+static void filter_border(int* p, int nT, int mode, int strong_enabled, int bit_depth_luma)
+{
+  int filterFlag;
+  if (mode == 1 || nT == 4) filterFlag = 0;
+  else {
+    int d = imin(iabs(mode - 26), iabs(mode - 10));
+    filterFlag = nT == 8 ? d > 7 : (nT == 16 ? d > 1 : d > 0);
+  }
+  if (!filterFlag) return;
+  int pF_mem[4 * 32 + 1];
+  int* pF = pF_mem + 2 * 32;
+  const int bi = strong_enabled && nT == 32 && iabs(p[0] + p[64] - 2 * p[32]) < (1 << (bit_depth_luma - 5)) &&
+                 iabs(p[0] + p[-64] - 2 * p[-32]) < (1 << (bit_depth_luma - 5));
+  pF[-2 * nT] = p[-2 * nT];
+  pF[2 * nT] = p[2 * nT];
+  if (bi) {
+    pF[0] = p[0];
+    for (int i = 1; i <= 63; i++) {
+      pF[-i] = p[0] + ((i * (p[-64] - p[0]) + 32) >> 6);
+      pF[i] = p[0] + ((i * (p[64] - p[0]) + 32) >> 6);
+    }
+  }
+  else {
+    for (int i = -(2 * nT - 1); i <= 2 * nT - 1; i++) pF[i] = (p[i + 1] + 2 * p[i] + p[i - 1] + 2) >> 2;
+  }
+  for (int i = -2 * nT; i <= 2 * nT; i++) p[i] = pF[i];
+}
+
+/* ---- R5: predictors (intrapred.h:269-441) --------------------------------------------------- */
+static void predict(uint16_t* dst, int stride, int nT, int log2, int cIdx, int mode, const int* border, int bit_depth)
+{
+  const int maxv = (1 << bit_depth) - 1;
+  if (mode == 0) {
+    for (int y = 0; y < nT; y++)
+      for (int x = 0; x < nT; x++)
+        dst[x + y * stride] = (uint16_t)(((nT - 1 - x) * border[-1 - y] + (x + 1) * border[1 + nT] + (nT - 1 - y) * border[1 + x] +
+                                          (y + 1) * border[-1 - nT] + nT) >> (log2 + 1));
+  }
+  else if (mode == 1) {
+    int dc = 0;
+    for (int i = 0; i < nT; i++) dc += border[i + 1] + border[-i - 1];
+    dc = (dc + nT) >> (log2 + 1);
+    for (int y = 0; y < nT; y++) for (int x = 0; x < nT; x++) dst[x + y * stride] = (uint16_t)dc;
+    if (cIdx == 0 && nT < 32) {
+      dst[0] = (uint16_t)((border[-1] + 2 * dc + border[1] + 2) >> 2);
+      for (int x = 1; x < nT; x++) dst[x] = (uint16_t)((border[x + 1] + 3 * dc + 2) >> 2);
+      for (int y = 1; y < nT; y++) dst[y * stride] = (uint16_t)((border[-y - 1] + 3 * dc + 2) >> 2);
+    }
+  }
+  else {
+    int ref_mem[4 * 32 + 1];
+    int* ref = ref_mem + 2 * 32;
+    const int angle = kIntraPredAngle[mode];
+    if (mode >= 18) {
+      for (int x = 0; x <= nT; x++) ref[x] = border[x];
+      if (angle < 0) {
+        const int inv = kInvAngle[mode - 11];
+        if (((nT * angle) >> 5) < -1)
+          for (int x = (nT * angle) >> 5; x <= -1; x++) ref[x] = border[0 - ((x * inv + 128) >> 8)];
+      }
+      else for (int x = nT + 1; x <= 2 * nT; x++) ref[x] = border[x];
+      for (int y = 0; y < nT; y++)
+        for (int x = 0; x < nT; x++) {
+          const int iIdx = ((y + 1) * angle) >> 5, iFact = ((y + 1) * angle) & 31;
+          dst[x + y * stride] = (uint16_t)(iFact ? ((32 - iFact) * ref[x + iIdx + 1] + iFact * ref[x + iIdx + 2] + 16) >> 5 : ref[x + iIdx + 1]);
+        }
+      if (mode == 26 && cIdx == 0 && nT < 32)
+        for (int y = 0; y < nT; y++) dst[y * stride] = (uint16_t)clip3(0, maxv, border[1] + ((border[-1 - y] - border[0]) >> 1));
+    }
+    else {
+      for (int x = 0; x <= nT; x++) ref[x] = border[-x];
+      if (angle < 0) {
+        const int inv = kInvAngle[mode - 11];
+        if (((nT * angle) >> 5) < -1)
+          for (int x = (nT * angle) >> 5; x <= -1; x++) ref[x] = border[(x * inv + 128) >> 8];
+      }
+      else for (int x = nT + 1; x <= 2 * nT; x++) ref[x] = border[-x];
+      for (int y = 0; y < nT; y++)
+        for (int x = 0; x < nT; x++) {
+          const int iIdx = ((x + 1) * angle) >> 5, iFact = ((x + 1) * angle) & 31;
+          dst[x + y * stride] = (uint16_t)(iFact ? ((32 - iFact) * ref[y + iIdx + 1] + iFact * ref[y + iIdx + 2] + 16) >> 5 : ref[y + iIdx + 1]);
+        }
+      if (mode == 10 && cIdx == 0 && nT < 32)
+        for (int x = 0; x < nT; x++) dst[x] = (uint16_t)clip3(0, maxv, border[-1] + ((border[1 + x] - border[0]) >> 1));
+    }
+  }
+}
+
+/* ---- R1-R3: dequantisation + inverse transform + add (transform.cc:386-689, fallback-dct.cc) ---- */
+static void residual_add(uint16_t* dst, int stride, int nT, int log2, int cIdx, const hm_tu* t, const hm_coeff* cf, int bit_depth)
+{
+  int16_t coeff[32 * 32];
+  memset(coeff, 0, sizeof(int16_t) * nT * nT);
+  const int qP = t->qp;
+  /* flat scaling (m = 16 folded into the shift), 32-bit wrapping arithmetic: transform.cc:486-506 (Q3) */
+  const int bdShift = bit_depth + log2 - 5 - 4;
+  const int32_t offset = 1 << (bdShift - 1);
+  const int32_t fact = kLevelScale[qP % 6] << (qP / 6);
+  for (int i = 0; i < t->n_coeff; i++) {
+    const int32_t c = cf[i].value;
+    const int32_t prod = (int32_t)((uint32_t)c * (uint32_t)fact + (uint32_t)offset); /* wraps like the reference's int */
+    coeff[cf[i].pos] = (int16_t)clip3(-32768, 32767, prod >> bdShift);
+  }
+  const int maxv = (1 << bit_depth) - 1;
+  if (t->info & HM_TU_TSKIP) { /* transform.cc:566-643, fallback-dct.cc:80-104 */
+    const int tsShift = 5 + log2, bd2 = 20 - bit_depth, rnd = 1 << (bd2 - 1);
+    for (int y = 0; y < nT; y++)
+      for (int x = 0; x < nT; x++) {
+        const int32_t c = (int32_t)((uint32_t)(int32_t)coeff[x + y * nT] << tsShift);
+        int r = (c + rnd) >> bd2;
+        if (bit_depth == 8 && nT == 4) r = (int16_t)r; /* int16 residual buffer variant (transform.cc:581-607) */
+        dst[x + y * stride] = (uint16_t)clip3(0, maxv, dst[x + y * stride] + r);
+      }
+    return;
+  }
+  const int postShift = 20 - bit_depth, rnd2 = 1 << (postShift - 1);
+  if (nT == 4 && cIdx == 0) { /* DST-VII, fallback-dct.cc:311-449 */
+    int16_t g[4][4];
+    for (int c = 0; c < 4; c++)
+      for (int i = 0; i < 4; i++) {
+        int sum = 0;
+        for (int j = 0; j < 4; j++) sum += kDst[j][i] * coeff[c + j * 4];
+        g[i][c] = (int16_t)clip3(-32768, 32767, (sum + 64) >> 7);
+      }
+    for (int y = 0; y < 4; y++)
+      for (int i = 0; i < 4; i++) {
+        int sum = 0;
+        for (int j = 0; j < 4; j++) sum += kDst[j][i] * g[y][j];
+        const int out = clip3(-32768, 32767, (sum + rnd2) >> postShift);
+        dst[i + y * stride] = (uint16_t)clip3(0, maxv, dst[i + y * stride] + out);
+      }
+    return;
+  }
+  init_dct();
+  const int fct = 32 >> log2;
+  int16_t g[32 * 32];
+  for (int c = 0; c < nT; c++)
+    for (int i = 0; i < nT; i++) {
+      int sum = 0;
+      for (int j = 0; j < nT; j++) sum += g_dct[fct * j][i] * coeff[c + j * nT];
+      g[c + i * nT] = (int16_t)clip3(-32768, 32767, (sum + 64) >> 7);
+    }
+  for (int y = 0; y < nT; y++)
+    for (int i = 0; i < nT; i++) {
+      int sum = 0;
+      for (int j = 0; j < nT; j++) sum += g_dct[fct * j][i] * g[y * nT + j];
+      const int out = (sum + rnd2) >> postShift; /* not clipped to 16 bit (fallback-dct.cc:722-723, Q4) */
+      dst[i + y * stride] = (uint16_t)clip3(0, maxv, dst[i + y * stride] + out);
+    }
+}
+
+/* ---- reconstruction of the whole picture in decoding order --------------------------------- */
+static void reconstruct(pic_t* P)
+{
+  const hm_pic* H = P->hdr;
+  const int ctb = 1 << H->log2_ctb;
+  for (unsigned ci = 0; ci < H->n_ctbs; ci++) {
+    /* decoding order differs from raster order only with tiles; intra dependencies are satisfied
+       in raster order as well (left / above / above-right CTBs precede in both). */
+    const hm_ctb* c = &P->ctbs[ci];
+    const int cx = (int)(ci % H->ctb_w), cy = (int)(ci / H->ctb_w);
+    const hm_slice* sl = &P->slices[c->slice_idx];
+    for (unsigned k = 0; k < c->tu_count; k++) {
+      const hm_tu* t = &P->tus[c->tu_first + k];
+      const int log2 = t->info & HM_TU_LOG2_MASK, nT = 1 << log2;
+      const int cIdx = (t->info >> HM_TU_CIDX_SHIFT) & 3;
+      const int bd = cIdx ? H->bit_depth_c : H->bit_depth_y;
+      const int x0 = cx * (cIdx ? ctb / P->sw : ctb) + t->x;
+      const int y0 = cy * (cIdx ? ctb / P->sh : ctb) + t->y;
+      int border_mem[4 * 32 + 1];
+      int* border = border_mem + 2 * 32;
+      build_border(P, t, cIdx, x0, y0, nT, bd, border);
+      if (cIdx == 0) filter_border(border, nT, t->pred_mode, (H->flags & HM_PIC_STRONG_INTRA_SMOOTHING) != 0, H->bit_depth_y);
+      uint16_t* dst = P->pl[cIdx] + x0 + (size_t)y0 * P->w[cIdx];
+      predict(dst, P->w[cIdx], nT, log2, cIdx, t->pred_mode, border, bd);
+      if (t->info & HM_TU_CBF) residual_add(dst, P->w[cIdx], nT, log2, cIdx, t, P->coeffs + t->coeff_first, bd);
+      if (cIdx == 0) {
+        /* deblocking metadata: transform-block edges (deblock.cc:31-62) and QpY map */
+        const int left_ok = t->x > 0 ? 1 : (c->flags & HM_CTB_DEBLOCK_LEFT) != 0;
+        const int top_ok = t->y > 0 ? 1 : (c->flags & HM_CTB_DEBLOCK_TOP) != 0;
+        const int en = !sl->deblocking_disabled;
+        for (int j = 0; j < nT / 4; j++)
+          for (int i = 0; i < nT / 4; i++) {
+            const int bx = (x0 >> 2) + i, by = (y0 >> 2) + j;
+            if (bx >= P->w4 || by >= P->h4) continue;
+            uint8_t e = 0;
+            if (i == 0 && left_ok && en) e |= 1;
+            if (j == 0 && top_ok && en) e |= 2;
+            P->edge[bx + (size_t)by * P->w4] = e;
+            P->qpy[bx + (size_t)by * P->w4] = t->qpy;
+          }
+      }
+    }
+  }
+}
+
+/* ---- F1: deblocking (deblock.cc:394-404, 709-792, 1608-1772; fallback-postfilter.h:32-183) ---- */
+static const uint8_t kBeta[52] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15,
+                                  16, 17, 18, 20, 22, 24, 26, 28, 30, 32, 34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64};
+static const uint8_t kTc[54] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 5, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24};
+
+static inline int edge_bs(const pic_t* P, int x, int y, int vertical)
+{ /* intra picture: bS = 2 wherever a transform edge is flagged (deblock.cc:241-380) */
+  if ((x >> 2) >= P->w4 || (y >> 2) >= P->h4) return 0;
+  return (P->edge[(x >> 2) + (size_t)(y >> 2) * P->w4] & (vertical ? 1 : 2)) ? 2 : 0;
+}
+static inline int qpy_at(const pic_t* P, int x, int y) { return P->qpy[(x >> 2) + (size_t)(y >> 2) * P->w4]; }
+static const hm_slice* slice_at(const pic_t* P, int x, int y)
+{
+  const hm_pic* H = P->hdr;
+  const int ci = (x >> H->log2_ctb) + (y >> H->log2_ctb) * H->ctb_w;
+  return &P->slices[P->ctbs[ci].slice_idx];
+}
+
+static void filter_luma_segment(uint16_t* pix, int xs, int ys, int beta, const int tc2[2], int bit_depth)
+{ /* xs: step across the edge, ys: step along the edge */
+  const int maxv = (1 << bit_depth) - 1;
+#define PX(i, k) pix[(i) * xs + (k) * ys]
+  for (int j = 0; j < 2; j++) {
+    uint16_t* base = pix + 4 * j * ys;
+#define B(i, k) base[(i) * xs + (k) * ys]
+    const int dp0 = iabs(B(-3, 0) - 2 * B(-2, 0) + B(-1, 0)), dq0 = iabs(B(2, 0) - 2 * B(1, 0) + B(0, 0));
+    const int dp3 = iabs(B(-3, 3) - 2 * B(-2, 3) + B(-1, 3)), dq3 = iabs(B(2, 3) - 2 * B(1, 3) + B(0, 3));
+    const int d0 = dp0 + dq0, d3 = dp3 + dq3, tc = tc2[j];
+    if (d0 + d3 >= beta) continue;
+    const int beta_3 = beta >> 3, beta_2 = beta >> 2, tc25 = (tc * 5 + 1) >> 1;
+    if (iabs(B(-4, 0) - B(-1, 0)) + iabs(B(3, 0) - B(0, 0)) < beta_3 && iabs(B(-1, 0) - B(0, 0)) < tc25 &&
+        iabs(B(-4, 3) - B(-1, 3)) + iabs(B(3, 3) - B(0, 3)) < beta_3 && iabs(B(-1, 3) - B(0, 3)) < tc25 &&
+        (d0 << 1) < beta_2 && (d3 << 1) < beta_2) {
+      const int t2 = tc << 1;
+      for (int d = 0; d < 4; d++) {
+        const int p3 = B(-4, d), p2 = B(-3, d), p1 = B(-2, d), p0 = B(-1, d), q0 = B(0, d), q1 = B(1, d), q2 = B(2, d), q3 = B(3, d);
+        B(-1, d) = (uint16_t)(p0 + clip3(-t2, t2, ((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3) - p0));
+        B(-2, d) = (uint16_t)(p1 + clip3(-t2, t2, ((p2 + p1 + p0 + q0 + 2) >> 2) - p1));
+        B(-3, d) = (uint16_t)(p2 + clip3(-t2, t2, ((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3) - p2));
+        B(0, d) = (uint16_t)(q0 + clip3(-t2, t2, ((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3) - q0));
+        B(1, d) = (uint16_t)(q1 + clip3(-t2, t2, ((p0 + q0 + q1 + q2 + 2) >> 2) - q1));
+        B(2, d) = (uint16_t)(q2 + clip3(-t2, t2, ((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3) - q2));
+      }
+    }
+    else {
+      int nd_p = 1, nd_q = 1;
+      const int tc_2 = tc >> 1;
+      if (dp0 + dp3 < ((beta + (beta >> 1)) >> 3)) nd_p = 2;
+      if (dq0 + dq3 < ((beta + (beta >> 1)) >> 3)) nd_q = 2;
+      for (int d = 0; d < 4; d++) {
+        const int p2 = B(-3, d), p1 = B(-2, d), p0 = B(-1, d), q0 = B(0, d), q1 = B(1, d), q2 = B(2, d);
+        int delta0 = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4;
+        if (iabs(delta0) < 10 * tc) {
+          delta0 = clip3(-tc, tc, delta0);
+          B(-1, d) = (uint16_t)clip3(0, maxv, p0 + delta0);
+          B(0, d) = (uint16_t)clip3(0, maxv, q0 - delta0);
+          if (nd_p > 1) B(-2, d) = (uint16_t)clip3(0, maxv, p1 + clip3(-tc_2, tc_2, (((p2 + p0 + 1) >> 1) - p1 + delta0) >> 1));
+          if (nd_q > 1) B(1, d) = (uint16_t)clip3(0, maxv, q1 + clip3(-tc_2, tc_2, (((q2 + q0 + 1) >> 1) - q1 - delta0) >> 1));
+        }
+      }
+    }
+#undef B
+  }
+#undef PX
+}
+
+static void deblock_luma(pic_t* P, int vertical)
+{
+  const hm_pic* H = P->hdr;
+  const int bd = H->bit_depth_y, stride = P->w[0];
+  for (int y = 0; y < P->h4; y += 2)
+    for (int x = 0; x < P->w4; x += 2) {
+      const int xD = x << 2, yD = y << 2;
+      const int bs0 = edge_bs(P, xD, yD, vertical);
+      const int bs1 = vertical ? edge_bs(P, xD, yD + 4, 1) : edge_bs(P, xD + 4, yD, 0);
+      if (!bs0 && !bs1) continue;
+      const int QP_Q = qpy_at(P, xD, yD);
+      const int QP_P = vertical ? qpy_at(P, xD - 1, yD) : qpy_at(P, xD, yD - 1);
+      const int qPL = (QP_Q + QP_P + 1) >> 1;
+      const hm_slice* sl = slice_at(P, xD, yD);
+      const int beta = kBeta[clip3(0, 51, qPL + sl->beta_offset_div2 * 2)] * (1 << (bd - 8));
+      int tc[2];
+      tc[0] = bs0 ? kTc[clip3(0, 53, qPL + 2 * (bs0 - 1) + sl->tc_offset_div2 * 2)] * (1 << (bd - 8)) : 0;
+      tc[1] = bs1 ? kTc[clip3(0, 53, qPL + 2 * (bs1 - 1) + sl->tc_offset_div2 * 2)] * (1 << (bd - 8)) : 0;
+      uint16_t* ptr = P->pl[0] + xD + (size_t)yD * stride;
+      filter_luma_segment(ptr, vertical ? 1 : stride, vertical ? stride : 1, beta, tc, bd);
+    }
+}
+
+static inline int chroma_qp_map(int qPi) /* Table 8-10 */
+{
+  static const int t[14] = {29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37};
+  if (qPi < 30) return qPi;
+  if (qPi >= 44) return qPi - 6;
+  return t[qPi - 30];
+}
+
+static void deblock_chroma(pic_t* P, int vertical)
+{
+  const hm_pic* H = P->hdr;
+  const int sw = P->sw, sh = P->sh, bd = H->bit_depth_c, maxv = (1 << bd) - 1;
+  const int xIncr = 2 * sw, yIncr = 2 * sh;
+  for (int y = 0; y < P->h4; y += yIncr)
+    for (int x = 0; x < P->w4; x += xIncr) {
+      const int xDi = x << (3 - sw), yDi = y << (3 - sh);
+      const int lx = xDi * sw, ly = yDi * sh;
+      const int bS0 = edge_bs(P, lx, ly, vertical);
+      const int bS1 = vertical ? edge_bs(P, lx, ly + 4 * sh, 1) : edge_bs(P, lx + 4 * sw, ly, 0);
+      if (bS0 != 2 && bS1 != 2) continue;
+      for (int cp = 0; cp < 2; cp++) {
+        const int off = cp == 0 ? H->pps_cb_qp_offset : H->pps_cr_qp_offset;
+        int QP_Q = qpy_at(P, lx, ly);
+        int QP_P = vertical ? qpy_at(P, lx - 1, ly) : qpy_at(P, lx, ly - 1);
+        int qPi = ((QP_Q + QP_P + 1) >> 1) + off;
+        const int QP_C0 = H->chroma_format == 1 ? chroma_qp_map(qPi) : imin(qPi, 51);
+        int QP_C1 = QP_C0;
+        if (bS1 == 2) { /* the second half's QP is only meaningful when that half exists in the picture */
+          QP_Q = vertical ? qpy_at(P, lx, ly + 4 * sh) : qpy_at(P, lx + 4 * sw, ly);
+          QP_P = vertical ? qpy_at(P, lx - 1, ly + 4 * sh) : qpy_at(P, lx + 4 * sw, ly - 1);
+          qPi = ((QP_Q + QP_P + 1) >> 1) + off;
+          QP_C1 = H->chroma_format == 1 ? chroma_qp_map(qPi) : imin(qPi, 51);
+        }
+        const hm_slice* sl = slice_at(P, lx, ly);
+        const int tco = sl->tc_offset_div2 * 2;
+        int tc[2];
+        tc[0] = bS0 == 2 ? kTc[clip3(0, 53, QP_C0 + 2 + tco)] * (1 << (bd - 8)) : 0;
+        tc[1] = bS1 == 2 ? kTc[clip3(0, 53, QP_C1 + 2 + tco)] * (1 << (bd - 8)) : 0;
+        const int stride = P->w[cp + 1];
+        uint16_t* ptr = P->pl[cp + 1] + xDi + (size_t)yDi * stride;
+        const int xs = vertical ? 1 : stride, ys = vertical ? stride : 1;
+        for (int k = 0; k < 8; k++) {
+          const int t = tc[k >> 2];
+          if (t == 0) continue; /* delta clipped to [-0,0]: samples unchanged (and possibly outside the picture) */
+          uint16_t* b = ptr + k * ys;
+          const int p1 = b[-2 * xs], p0 = b[-xs], q0 = b[0], q1 = b[xs];
+          const int delta = clip3(-t, t, ((((q0 - p0) * 4) + p1 - q1 + 4) >> 3));
+          b[-xs] = (uint16_t)clip3(0, maxv, p0 + delta);
+          b[0] = (uint16_t)clip3(0, maxv, q0 - delta);
+        }
+      }
+    }
+}
+
+/* ---- F2: SAO (sao.cc:261-488, fallback-postfilter.h:218-315) ----------------------------------- */
+static void apply_sao(pic_t* P, uint16_t* const src[3])
+{
+  const hm_pic* H = P->hdr;
+  const int ctb = 1 << H->log2_ctb;
+  static const int hPos[4][2] = {{-1, 1}, {0, 0}, {-1, 1}, {1, -1}}, vPos[4][2] = {{0, 0}, {-1, 1}, {-1, 1}, {-1, 1}};
+  for (int cIdx = 0; cIdx < 3; cIdx++) {
+    const int bd = cIdx ? H->bit_depth_c : H->bit_depth_y, maxv = (1 << bd) - 1;
+    const int nSW = cIdx ? ctb / P->sw : ctb, nSH = cIdx ? ctb / P->sh : ctb;
+    const int W = P->w[cIdx], Hh = P->h[cIdx];
+    for (int cy = 0; cy < H->ctb_h; cy++)
+      for (int cx = 0; cx < H->ctb_w; cx++) {
+        const hm_ctb* c = &P->ctbs[cx + cy * H->ctb_w];
+        const hm_slice* sl = &P->slices[c->slice_idx];
+        if (cIdx == 0 ? !sl->sao_luma : !sl->sao_chroma) continue;
+        const hm_sao* s = &c->sao[cIdx];
+        if (s->type == 0) continue;
+        const int xC = cx * nSW, yC = cy * nSH;
+        const int cw = imin(nSW, W - xC), ch = imin(nSH, Hh - yC);
+        if (s->type == 2) {
+          const int off[5] = {s->offset[0], s->offset[1], 0, s->offset[2], s->offset[3]};
+          const int cl = s->eo_class;
+          for (int j = 0; j < ch; j++)
+            for (int i = 0; i < cw; i++) {
+              const int xx = xC + i, yy = yC + j;
+              int ok = 1;
+              for (int k = 0; k < 2 && ok; k++) {
+                const int xS = xx + hPos[cl][k], yS = yy + vPos[cl][k];
+                if (xS < 0 || yS < 0 || xS >= W || yS >= Hh) { ok = 0; break; }
+                /* neighbour in another CTB: usable only if the host marked that CTB (slice / tile rules) */
+                const int ncx = xS / nSW, ncy = yS / nSH;
+                if (ncx != cx || ncy != cy) {
+                  static const int kidx[3][3] = {{0, 1, 2}, {3, -1, 4}, {5, 6, 7}};
+                  const int k8 = kidx[ncy - cy + 1][ncx - cx + 1];
+                  if (!(c->sao_nb_mask & (1u << k8))) ok = 0;
+                }
+              }
+              if (!ok) continue;
+              const int v = src[cIdx][xx + (size_t)yy * W];
+              const int a = src[cIdx][(xx + hPos[cl][0]) + (size_t)(yy + vPos[cl][0]) * W];
+              const int b = src[cIdx][(xx + hPos[cl][1]) + (size_t)(yy + vPos[cl][1]) * W];
+              const int e = isign(v - a) + isign(v - b);
+              P->pl[cIdx][xx + (size_t)yy * W] = (uint16_t)clip3(0, maxv, v + off[e + 2]);
+            }
+        }
+        else {
+          const int shift = bd - 5;
+          int table[32];
+          memset(table, 0, sizeof(table));
+          for (int k = 0; k < 4; k++) table[(k + s->band_position) & 31] = k + 1;
+          for (int j = 0; j < ch; j++)
+            for (int i = 0; i < cw; i++) {
+              const int v = src[cIdx][(xC + i) + (size_t)(yC + j) * W];
+              const int bi = table[v >> shift];
+              if (bi > 0) P->pl[cIdx][(xC + i) + (size_t)(yC + j) * W] = (uint16_t)clip3(0, maxv, v + s->offset[bi - 1]);
+            }
+        }
+      }
+  }
+}
+
+/* ---- public entry --------------------------------------------------------------------------- */
+int orc_stream_info(const uint8_t* blob, size_t size, int out[8])
+{
+  if (size < sizeof(hm_pic)) return -1;
+  const hm_pic* H = (const hm_pic*)blob;
+  if (H->magic != HM_STREAM_MAGIC || H->total_bytes > size) return -1;
+  out[0] = H->width; out[1] = H->height; out[2] = H->chroma_format; out[3] = H->bit_depth_y;
+  out[4] = H->full_range; out[5] = H->matrix_coeffs; out[6] = H->colour_primaries;
+  out[7] = (H->flags & HM_PIC_HAS_VUI_COLOUR) != 0;
+  return 0;
+}
+
+/* stages: bit0 deblocking, bit1 SAO (reconstruction always runs).  Output planes are tight
+ * (stride = plane width in samples), uint16 for every bit depth. */
+int orc_decode_picture(const uint8_t* blob, size_t size, int stages, uint16_t* y, uint16_t* cb, uint16_t* cr)
+{
+  if (size < sizeof(hm_pic)) return -1;
+  pic_t P;
+  memset(&P, 0, sizeof(P));
+  P.hdr = (const hm_pic*)blob;
+  const hm_pic* H = P.hdr;
+  if (H->magic != HM_STREAM_MAGIC || H->total_bytes > size) return -1;
+  if (H->chroma_format != 1 && H->chroma_format != 2) return -2;
+  P.slices = (const hm_slice*)(blob + H->off_slices);
+  P.ctbs = (const hm_ctb*)(blob + H->off_ctbs);
+  P.tus = (const hm_tu*)(blob + H->off_tus);
+  P.coeffs = (const hm_coeff*)(blob + H->off_coeffs);
+  P.sw = 2; P.sh = H->chroma_format == 1 ? 2 : 1;
+  P.w[0] = H->width; P.h[0] = H->height;
+  P.w[1] = P.w[2] = H->width / P.sw; P.h[1] = P.h[2] = H->height / P.sh;
+  P.pl[0] = y; P.pl[1] = cb; P.pl[2] = cr;
+  P.w4 = (H->width + 3) >> 2; P.h4 = (H->height + 3) >> 2;
+  P.edge = (uint8_t*)calloc((size_t)P.w4 * P.h4, 1);
+  P.qpy = (int8_t*)calloc((size_t)P.w4 * P.h4, 1);
+  for (int c = 0; c < 3; c++) memset(P.pl[c], 0, sizeof(uint16_t) * (size_t)P.w[c] * P.h[c]);
+
+  reconstruct(&P);
+
+  if ((stages & 1) && (H->flags & HM_PIC_DEBLOCK_ANY)) { /* deblock.cc:1921-1959: all vertical edges, then all horizontal */
+    deblock_luma(&P, 1);
+    deblock_chroma(&P, 1);
+    deblock_luma(&P, 0);
+    deblock_chroma(&P, 0);
+  }
+  if ((stages & 2) && (H->flags & HM_PIC_SAO_ENABLED)) { /* sao.cc:552-625: SAO reads a copy of the deblocked picture */
+    uint16_t* copy[3];
+    for (int c = 0; c < 3; c++) {
+      const size_t n = (size_t)P.w[c] * P.h[c];
+      copy[c] = (uint16_t*)malloc(n * sizeof(uint16_t));
+      memcpy(copy[c], P.pl[c], n * sizeof(uint16_t));
+    }
+    apply_sao(&P, copy);
+    for (int c = 0; c < 3; c++) free(copy[c]);
+  }
+  free(P.edge);
+  free(P.qpy);
+  return 0;
+}

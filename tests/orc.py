@@ -70,3 +70,67 @@ def colour_float(y, cb, cr, w, h, bpp, chroma, has_nclx, matrix, primaries, full
 
 def fnv_rows(buf, stride, row_bytes, rows):
     return load().orc_fnv1a64_rows(ptr(buf), stride, row_bytes, rows, 0)
+
+
+# ---- HEVC: reference decoder (oracle/_ref) and oracle executors -------------------------------
+
+class RefPicture(C.Structure):
+    _fields_ = [("width", C.c_int * 3), ("height", C.c_int * 3), ("bit_depth", C.c_int * 3),
+                ("chroma", C.c_int), ("full_range", C.c_int), ("primaries", C.c_int),
+                ("transfer", C.c_int), ("matrix", C.c_int),
+                ("plane_bytes", C.c_size_t * 3), ("plane", C.c_void_p * 3)]
+
+
+REF_F_ANNEXB, REF_F_NO_DEBLOCK, REF_F_NO_SAO, REF_F_SCALAR = 1, 2, 4, 8
+_ref = None
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def load_ref():
+    global _ref
+    if _ref is None:
+        _ref = C.CDLL(REF_SO)
+        _ref.ref_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(RefPicture)]
+    return _ref
+
+
+def ref_decode(data, flags=0, threads=0):
+    """Decode with the real reference libde265; returns (planes[3] as uint16 arrays, info dict)."""
+    R = load_ref()
+    pic = RefPicture()
+    rc = R.ref_decode(data, len(data), flags, threads, C.byref(pic))
+    if rc != 0:
+        raise RuntimeError(f"reference decoder failed: {rc}")
+    planes = []
+    for c in range(3):
+        w, h, bd = pic.width[c], pic.height[c], pic.bit_depth[c]
+        n = pic.plane_bytes[c]
+        raw = np.frombuffer(C.string_at(pic.plane[c], n), dtype=np.uint8)
+        a = raw.astype(np.uint16).reshape(h, w) if bd <= 8 else raw.view(np.uint16).reshape(h, w).copy()
+        planes.append(a)
+    info = dict(chroma=pic.chroma, bit_depth=pic.bit_depth[0], full_range=pic.full_range,
+                primaries=pic.primaries, transfer=pic.transfer, matrix=pic.matrix)
+    R.ref_free_picture(C.byref(pic))
+    return planes, info
+
+
+def oracle_decode(blob, stages=3):
+    """Run the oracle's scalar executors on a command-stream blob (bytes)."""
+    o = load()
+    info = (C.c_int * 8)()
+    buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+    if o.orc_stream_info(buf, len(blob), info) != 0:
+        raise RuntimeError("bad command stream")
+    w, h, cf = info[0], info[1], info[2]
+    cw, ch = w // 2, (h // 2 if cf == 1 else h)
+    y = np.zeros((h, w), np.uint16)
+    cb = np.zeros((ch, cw), np.uint16)
+    cr = np.zeros((ch, cw), np.uint16)
+    rc = o.orc_decode_picture(buf, len(blob), stages, ptr(y), ptr(cb), ptr(cr))
+    if rc != 0:
+        raise RuntimeError(f"oracle decode failed: {rc}")
+    return [y, cb, cr], dict(width=w, height=h, chroma=cf, bit_depth=info[3], full_range=info[4],
+                             matrix=info[5], primaries=info[6], has_vui_colour=info[7])
