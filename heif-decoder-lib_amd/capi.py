@@ -44,6 +44,7 @@ def lib():
         L.hm_colour_convert.argtypes = [C.POINTER(ColourDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.hm_colour_pipeline.argtypes = [C.POINTER(ColourDesc)]
         L.hm_ycbcr_coefficients.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
+        bind_decode(L)
         _lib = L
     return _lib
 
@@ -53,3 +54,77 @@ def check(status):
         L = lib()
         raise HmError(status, f"{L.hm_status_string(status).decode()}: {L.hm_last_error().decode()}")
     return status
+
+
+class TileDest(C.Structure):
+    _fields_ = [("plane", C.c_void_p * 3), ("pitch", C.c_int32 * 3),
+                ("canvas_width", C.c_int32), ("canvas_height", C.c_int32),
+                ("x0", C.c_int32), ("y0", C.c_int32),
+                ("tile_has_nclx", C.c_int32), ("tile_full_range", C.c_int32), ("tile_matrix", C.c_int32)]
+
+
+def bind_decode(L):
+    """argtypes of the parse / batch entry points (called once from lib())."""
+    L.hm_hevc_parse.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+    L.hm_free.argtypes = [C.c_void_p]
+    L.hm_batch_create.argtypes = [C.POINTER(C.c_void_p)]
+    L.hm_batch_destroy.argtypes = [C.c_void_p]
+    L.hm_batch_clear.argtypes = [C.c_void_p]
+    L.hm_batch_add.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(TileDest)]
+    L.hm_batch_size.argtypes = [C.c_void_p]
+    L.hm_batch_upload.argtypes = [C.c_void_p, C.c_void_p]
+    L.hm_batch_execute.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+
+
+def parse_hevc(data, annexb=False):
+    """hm_hevc_parse -> command-stream blob (bytes)."""
+    L = lib()
+    blob = C.POINTER(C.c_uint8)()
+    size = C.c_size_t()
+    check(L.hm_hevc_parse(data, len(data), 1 if annexb else 0, C.byref(blob), C.byref(size)))
+    out = C.string_at(blob, size.value)
+    L.hm_free(blob)
+    return out
+
+
+def stream_header(blob):
+    """(width, height, chroma_format, bit_depth, flags, full_range, matrix, primaries, has_vui_colour) of a command stream."""
+    import struct
+    magic, total, w, h = struct.unpack_from("<IIHH", blob, 0)
+    cf, bdy, bdc, l2ctb = struct.unpack_from("<BBBB", blob, 20)
+    flags, = struct.unpack_from("<I", blob, 36)
+    prim, trc, mat, fr = struct.unpack_from("<BBBB", blob, 40)
+    return dict(width=w, height=h, chroma_format=cf, bit_depth=bdy, log2_ctb=l2ctb, flags=flags,
+                primaries=prim, transfer=trc, matrix=mat, full_range=fr, has_vui_colour=bool(flags & 0x10))
+
+
+class Batch:
+    """Thin RAII wrapper of hm_batch."""
+
+    def __init__(self):
+        self.L = lib()
+        self.h = C.c_void_p()
+        check(self.L.hm_batch_create(C.byref(self.h)))
+
+    def add(self, blob, dest):
+        return check(self.L.hm_batch_add(self.h, blob, len(blob), C.byref(dest)))
+
+    def upload(self, stream=None):
+        check(self.L.hm_batch_upload(self.h, stream))
+
+    def execute(self, stages=3, stream=None):
+        check(self.L.hm_batch_execute(self.h, stages, stream))
+
+    def clear(self):
+        self.L.hm_batch_clear(self.h)
+
+    def close(self):
+        if self.h:
+            self.L.hm_batch_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

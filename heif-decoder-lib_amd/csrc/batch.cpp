@@ -1,0 +1,247 @@
+// batch.cpp — host side of the GPU tile-decode path: a batch of coded pictures (HEIF grid tiles
+// or single images) is uploaded once and reconstructed / deblocked / SAO-filtered / pasted by
+// four kernel launches per picture class, independent of the number of pictures.
+//
+// This is the MI355X replacement of the reference's per-tile std::async fan-out
+// (libheif/context.cc:2361-2401: one libde265 instance per tile, pasted into the shared canvas
+// by decode_and_paste_tile_image, context.cc:2407-2539).  Tiles are independent coded pictures,
+// so they become the workgroups of one launch.
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <tuple>
+#include <vector>
+
+#include "hm_device.h"
+#include "hm_internal.h"
+
+namespace {
+
+struct DeviceBuffer {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t n)
+  {
+    if (n <= cap) return HM_OK;
+    if (p) hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = n + n / 4 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) return hm_check_hip(e, "hipMalloc");
+    cap = want;
+    return HM_OK;
+  }
+  ~DeviceBuffer() { if (p) hipFree(p); }
+};
+
+struct Item {
+  std::vector<uint8_t> blob;
+  hm_tile_dest dest;
+  hm_pic hdr;
+};
+
+struct Class {
+  int log2_ctb, chroma_format, bit_depth;
+  std::vector<int> items;
+  int max_ctb_w = 0, max_ctb_h = 0, max_w4 = 0, max_h4 = 0, max_w = 0, max_h = 0;
+  size_t desc_offset = 0; // index of the first descriptor in the descriptor array
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+} // namespace
+
+struct hm_batch {
+  std::vector<Item> items;
+  std::vector<Class> classes;
+  DeviceBuffer d_blobs, d_work, d_desc;
+  std::vector<hm_dev_pic> h_desc;
+  bool uploaded = false;
+  size_t total_pixels = 0;
+};
+
+extern "C" {
+
+int hm_batch_create(hm_batch** out)
+{
+  if (!out) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return hm_fail(HM_ERR_NO_DEVICE, "no HIP device available");
+  *out = new (std::nothrow) hm_batch();
+  return *out ? HM_OK : hm_fail(HM_ERR_NOMEM, "out of memory");
+}
+
+void hm_batch_destroy(hm_batch* b) { delete b; }
+
+void hm_batch_clear(hm_batch* b)
+{
+  if (!b) return;
+  b->items.clear();
+  b->classes.clear();
+  b->h_desc.clear();
+  b->uploaded = false;
+  b->total_pixels = 0;
+}
+
+int hm_batch_add(hm_batch* b, const uint8_t* blob, size_t size, const hm_tile_dest* dest)
+{
+  if (!b || !blob || !dest) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
+  if (size < sizeof(hm_pic)) return hm_fail(HM_ERR_INVALID_ARG, "command stream too small");
+  Item it;
+  std::memcpy(&it.hdr, blob, sizeof(hm_pic));
+  if (it.hdr.magic != HM_STREAM_MAGIC || it.hdr.total_bytes > size) return hm_fail(HM_ERR_INVALID_ARG, "not a command stream");
+  if (it.hdr.chroma_format != 1 && it.hdr.chroma_format != 2) return hm_fail(HM_ERR_UNSUPPORTED, "chroma format %d", it.hdr.chroma_format);
+  for (int c = 0; c < 3; c++)
+    if (!dest->plane[c]) return hm_fail(HM_ERR_INVALID_ARG, "null destination plane");
+  it.blob.assign(blob, blob + it.hdr.total_bytes);
+  it.dest = *dest;
+  b->items.push_back(std::move(it));
+  b->uploaded = false;
+  return (int)b->items.size() - 1;
+}
+
+// Upload command streams, build descriptors, size the working set.  After this the inputs are
+// resident in HBM; hm_batch_execute() only launches kernels.
+int hm_batch_upload(hm_batch* b, void* stream)
+{
+  if (!b) return hm_fail(HM_ERR_INVALID_ARG, "null batch");
+  hipStream_t s = (hipStream_t)stream;
+  const int n = (int)b->items.size();
+  b->classes.clear();
+  b->h_desc.assign(n, hm_dev_pic());
+  if (n == 0) { b->uploaded = true; return HM_OK; }
+
+  // classes: pictures of one launch share CTB size, chroma format and sample width
+  std::map<std::tuple<int, int, int>, int> cls_index;
+  for (int i = 0; i < n; i++) {
+    const hm_pic& h = b->items[i].hdr;
+    auto key = std::make_tuple((int)h.log2_ctb, (int)h.chroma_format, (int)h.bit_depth_y);
+    auto f = cls_index.find(key);
+    if (f == cls_index.end()) {
+      Class c;
+      c.log2_ctb = h.log2_ctb; c.chroma_format = h.chroma_format; c.bit_depth = h.bit_depth_y;
+      f = cls_index.emplace(key, (int)b->classes.size()).first;
+      b->classes.push_back(c);
+    }
+    Class& c = b->classes[f->second];
+    c.items.push_back(i);
+    c.max_ctb_w = std::max<int>(c.max_ctb_w, h.ctb_w);
+    c.max_ctb_h = std::max<int>(c.max_ctb_h, h.ctb_h);
+    c.max_w4 = std::max<int>(c.max_w4, (h.width + 3) >> 2);
+    c.max_h4 = std::max<int>(c.max_h4, (h.height + 3) >> 2);
+    c.max_w = std::max<int>(c.max_w, h.width);
+    c.max_h = std::max<int>(c.max_h, h.height);
+  }
+
+  // layout of blobs and the working set
+  size_t blob_bytes = 0, work_bytes = 0;
+  std::vector<size_t> blob_off(n), work_off(n);
+  b->total_pixels = 0;
+  for (int i = 0; i < n; i++) {
+    const hm_pic& h = b->items[i].hdr;
+    blob_off[i] = blob_bytes;
+    blob_bytes += align_up(h.total_bytes, 256);
+    work_off[i] = work_bytes;
+    const int bps = h.bit_depth_y > 8 ? 2 : 1;
+    const int sh = h.chroma_format == 1 ? 2 : 1;
+    const size_t py = align_up((size_t)h.width * bps, 64), pc = align_up((size_t)(h.width / 2) * bps, 64);
+    const size_t w4 = (h.width + 3) >> 2, h4 = (h.height + 3) >> 2;
+    work_bytes += align_up(py * h.height, 256) + 2 * align_up(pc * (h.height / sh), 256) + 2 * align_up(w4 * h4, 256);
+    b->total_pixels += (size_t)h.width * h.height;
+  }
+  int rc;
+  if ((rc = b->d_blobs.ensure(blob_bytes))) return rc;
+  if ((rc = b->d_work.ensure(work_bytes))) return rc;
+  if ((rc = b->d_desc.ensure(sizeof(hm_dev_pic) * (size_t)n))) return rc;
+
+  // stage all blobs in one pinned-less host buffer -> one H2D copy
+  std::vector<uint8_t> staging(blob_bytes, 0);
+  for (int i = 0; i < n; i++) std::memcpy(staging.data() + blob_off[i], b->items[i].blob.data(), b->items[i].blob.size());
+  hipError_t e = hipMemcpyAsync(b->d_blobs.p, staging.data(), blob_bytes, hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) return hm_check_hip(e, "H2D command streams");
+
+  size_t di = 0;
+  for (Class& c : b->classes) {
+    c.desc_offset = di;
+    for (int idx : c.items) {
+      const Item& it = b->items[idx];
+      const hm_pic& h = it.hdr;
+      hm_dev_pic d;
+      std::memset(&d, 0, sizeof(d));
+      const int bps = h.bit_depth_y > 8 ? 2 : 1;
+      const int sh = h.chroma_format == 1 ? 2 : 1;
+      const size_t py = align_up((size_t)h.width * bps, 64), pc = align_up((size_t)(h.width / 2) * bps, 64);
+      const size_t w4 = (h.width + 3) >> 2, h4 = (h.height + 3) >> 2;
+      uint8_t* wp = (uint8_t*)b->d_work.p + work_off[idx];
+      d.blob = (const uint8_t*)b->d_blobs.p + blob_off[idx];
+      d.plane[0] = wp; wp += align_up(py * h.height, 256);
+      d.plane[1] = wp; wp += align_up(pc * (h.height / sh), 256);
+      d.plane[2] = wp; wp += align_up(pc * (h.height / sh), 256);
+      d.pitch[0] = (int)py; d.pitch[1] = d.pitch[2] = (int)pc;
+      d.edge = wp; wp += align_up(w4 * h4, 256);
+      d.qpy = (int8_t*)wp;
+      d.w4 = (int)w4; d.h4 = (int)h4;
+      d.width = h.width; d.height = h.height;
+      d.chroma_format = h.chroma_format;
+      d.bit_depth = h.bit_depth_y;
+      d.log2_ctb = h.log2_ctb;
+      d.ctb_w = h.ctb_w; d.ctb_h = h.ctb_h;
+      d.flags = (int32_t)h.flags;
+      // destination = tile paste geometry of context.cc:2457-2502
+      const hm_tile_dest& t = it.dest;
+      const int sw = 2;
+      for (int p = 0; p < 3; p++) {
+        int chan_w = t.canvas_width, chan_h = t.canvas_height, cx0 = t.x0, cy0 = t.y0;
+        int pw = h.width, ph = h.height;
+        if (p > 0) {
+          chan_w = (t.canvas_width + 1) / 2; cx0 = (t.x0 + 1) / 2;
+          if (h.chroma_format == 1) { chan_h = (t.canvas_height + 1) / 2; cy0 = (t.y0 + 1) / 2; }
+          pw = h.width / sw; ph = h.height / sh;
+        }
+        if (chan_w <= cx0 || chan_h <= cy0) return hm_fail(HM_ERR_INVALID_ARG, "tile origin outside the canvas (invalid grid data)");
+        d.copy_w[p] = std::min(pw, chan_w - cx0);
+        d.copy_h[p] = std::min(ph, chan_h - cy0);
+        d.dst_pitch[p] = t.pitch[p];
+        d.dst[p] = (uint8_t*)t.plane[p] + (size_t)cy0 * t.pitch[p] + (size_t)cx0 * bps;
+      }
+      // context.cc:2504-2509: rescale iff the tile carries an nclx with !full_range && matrix != 0
+      d.rescale = (t.tile_has_nclx && !t.tile_full_range && t.tile_matrix != 0) ? 1 : 0;
+      b->h_desc[di++] = d;
+    }
+  }
+  e = hipMemcpyAsync(b->d_desc.p, b->h_desc.data(), sizeof(hm_dev_pic) * (size_t)n, hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) return hm_check_hip(e, "H2D descriptors");
+  e = hipStreamSynchronize(s); // staging buffers are pageable and about to go out of scope
+  if (e != hipSuccess) return hm_check_hip(e, "upload sync");
+  b->uploaded = true;
+  return HM_OK;
+}
+
+// Launch reconstruction -> deblocking (V,H) -> SAO+paste for every class.  Asynchronous.
+// stages: bit0 deblocking, bit1 SAO (both normally set; cleared only by stage-wise parity tests).
+int hm_batch_execute(hm_batch* b, int stages, void* stream)
+{
+  if (!b) return hm_fail(HM_ERR_INVALID_ARG, "null batch");
+  if (!b->uploaded) return hm_fail(HM_ERR_INVALID_ARG, "hm_batch_upload() has not been called");
+  hipStream_t s = (hipStream_t)stream;
+  const hm_dev_pic* d = (const hm_dev_pic*)b->d_desc.p;
+  for (const Class& c : b->classes) {
+    const hm_dev_pic* dc = d + c.desc_offset;
+    const int n = (int)c.items.size();
+    int rc = hm_launch_recon(dc, n, c.log2_ctb, c.chroma_format, c.bit_depth, c.max_ctb_w, c.max_ctb_h, s);
+    if (rc) return rc;
+    if (stages & 1) {
+      rc = hm_launch_deblock(dc, n, c.max_w4, c.max_h4, c.chroma_format, c.bit_depth, s);
+      if (rc) return rc;
+    }
+    rc = hm_launch_sao_paste(dc, n, c.max_w, c.max_h, c.bit_depth, (stages & 2) ? 1 : 0, s);
+    if (rc) return rc;
+  }
+  return HM_OK;
+}
+
+int hm_batch_size(const hm_batch* b) { return b ? (int)b->items.size() : 0; }
+
+} // extern "C"

@@ -1,0 +1,342 @@
+// filters.hip — in-loop filters for gfx950: deblocking (two passes) and SAO fused with the grid
+// tile paste.
+//
+// Replaces:
+//   deblocking   deblock.cc:394-404,709-792,1608-1772 + fallback-postfilter.h:32-183
+//   SAO          sao.cc:261-488,552-625 + fallback-postfilter.h:218-315
+//   tile paste   libheif/context.cc:2457-2535 (incl. the limited->full range rescale quirk)
+//
+// Both are embarrassingly parallel byte work, HBM/L2 bound, no MFMA:
+//   * deblocking: one lane per 8-sample edge segment (the unit libde265 filters with one call);
+//     all vertical edges of all pictures in one launch, then all horizontal ones - segments of one
+//     pass touch disjoint samples, so the pass runs in place.  A lane loads its 8x8 window with
+//     eight 8-byte (16-byte for >8 bit) row loads - adjacent lanes cover adjacent windows, so a
+//     wave's row loads are contiguous - filters in registers and stores the window back.
+//   * SAO: one lane per 4 output samples; reads the deblocked plane (plus the one-sample halo
+//     the edge classes need) and writes the final samples straight into the destination image
+//     (the grid canvas at the tile's origin, cropped, optionally range-rescaled), so the decoded
+//     tile never makes a separate trip through HBM for the paste.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hm_device.h"
+#include "hm_internal.h"
+
+namespace {
+
+__device__ __forceinline__ int clip3i(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int iabs_(int v) { return v < 0 ? -v : v; }
+__device__ __forceinline__ int isign_(int v) { return (v > 0) - (v < 0); }
+
+__constant__ uint8_t c_beta[52] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15,
+                                   16, 17, 18, 20, 22, 24, 26, 28, 30, 32, 34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64};
+__constant__ uint8_t c_tc[54] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 5, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24};
+
+__device__ __forceinline__ int chroma_qp_map(int qPi) // Table 8-10
+{
+  if (qPi < 30) return qPi;
+  if (qPi >= 44) return qPi - 6;
+  const int t[14] = {29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37};
+  return t[qPi - 30];
+}
+
+struct PicView {
+  const hm_pic* H;
+  const hm_slice* slices;
+  const hm_ctb* ctbs;
+};
+__device__ __forceinline__ PicView view(const hm_dev_pic& dp)
+{
+  PicView v;
+  v.H = reinterpret_cast<const hm_pic*>(dp.blob);
+  v.slices = reinterpret_cast<const hm_slice*>(dp.blob + v.H->off_slices);
+  v.ctbs = reinterpret_cast<const hm_ctb*>(dp.blob + v.H->off_ctbs);
+  return v;
+}
+__device__ __forceinline__ int edge_bs(const hm_dev_pic& dp, int x, int y, int vertical)
+{
+  if ((x >> 2) >= dp.w4 || (y >> 2) >= dp.h4) return 0;
+  return (dp.edge[(x >> 2) + (size_t)(y >> 2) * dp.w4] & (vertical ? 1 : 2)) ? 2 : 0;
+}
+__device__ __forceinline__ int qpy_at(const hm_dev_pic& dp, int x, int y) { return dp.qpy[(x >> 2) + (size_t)(y >> 2) * dp.w4]; }
+__device__ __forceinline__ const hm_slice& slice_at(const hm_dev_pic& dp, const PicView& v, int x, int y)
+{
+  const int ci = (x >> dp.log2_ctb) + (y >> dp.log2_ctb) * dp.ctb_w;
+  return v.slices[v.ctbs[ci].slice_idx];
+}
+
+// 8 samples along the edge (d), 8 across (i = 0..7 <-> p3 p2 p1 p0 | q0 q1 q2 q3)
+template <typename Pix>
+__device__ __forceinline__ void load_window(const uint8_t* plane, int pitch, int xD, int yD, int vertical, int px[8][8])
+{
+  // row-major 8x8 tile whose top-left is (xD-4, yD) for vertical edges, (xD, yD-4) for horizontal
+  const int tx = vertical ? xD - 4 : xD, ty = vertical ? yD : yD - 4;
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const Pix* row = reinterpret_cast<const Pix*>(plane + (size_t)(ty + r) * pitch) + tx;
+    Pix v[8];
+    __builtin_memcpy(v, row, 8 * sizeof(Pix));
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      if (vertical) px[r][q] = v[q]; // d = r, i = q
+      else px[q][r] = v[q];          // d = q, i = r
+    }
+  }
+}
+template <typename Pix>
+__device__ __forceinline__ void store_window(uint8_t* plane, int pitch, int xD, int yD, int vertical, const int px[8][8])
+{
+  const int tx = vertical ? xD - 4 : xD, ty = vertical ? yD : yD - 4;
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    Pix v[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) v[q] = (Pix)(vertical ? px[r][q] : px[q][r]);
+    Pix* row = reinterpret_cast<Pix*>(plane + (size_t)(ty + r) * pitch) + tx;
+    if (vertical) __builtin_memcpy(row + 1, v + 1, 6 * sizeof(Pix)); // only p2..q2 can change
+    else if (r >= 1 && r <= 6) __builtin_memcpy(row, v, 8 * sizeof(Pix));
+  }
+}
+
+// fallback-postfilter.h:32-138
+__device__ __forceinline__ void filter_luma(int px[8][8], int beta, const int tc2[2], int maxv)
+{
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    int(*B)[8] = px + 4 * j;
+    const int dp0 = iabs_(B[0][1] - 2 * B[0][2] + B[0][3]), dq0 = iabs_(B[0][6] - 2 * B[0][5] + B[0][4]);
+    const int dp3 = iabs_(B[3][1] - 2 * B[3][2] + B[3][3]), dq3 = iabs_(B[3][6] - 2 * B[3][5] + B[3][4]);
+    const int d0 = dp0 + dq0, d3 = dp3 + dq3, tc = tc2[j];
+    if (d0 + d3 >= beta) continue;
+    const int beta_3 = beta >> 3, beta_2 = beta >> 2, tc25 = (tc * 5 + 1) >> 1;
+    if (iabs_(B[0][0] - B[0][3]) + iabs_(B[0][7] - B[0][4]) < beta_3 && iabs_(B[0][3] - B[0][4]) < tc25 &&
+        iabs_(B[3][0] - B[3][3]) + iabs_(B[3][7] - B[3][4]) < beta_3 && iabs_(B[3][3] - B[3][4]) < tc25 &&
+        (d0 << 1) < beta_2 && (d3 << 1) < beta_2) {
+      const int t2 = tc << 1;
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        const int p3 = B[d][0], p2 = B[d][1], p1 = B[d][2], p0 = B[d][3], q0 = B[d][4], q1 = B[d][5], q2 = B[d][6], q3 = B[d][7];
+        B[d][3] = p0 + clip3i(-t2, t2, ((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3) - p0);
+        B[d][2] = p1 + clip3i(-t2, t2, ((p2 + p1 + p0 + q0 + 2) >> 2) - p1);
+        B[d][1] = p2 + clip3i(-t2, t2, ((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3) - p2);
+        B[d][4] = q0 + clip3i(-t2, t2, ((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3) - q0);
+        B[d][5] = q1 + clip3i(-t2, t2, ((p0 + q0 + q1 + q2 + 2) >> 2) - q1);
+        B[d][6] = q2 + clip3i(-t2, t2, ((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3) - q2);
+      }
+    }
+    else {
+      const int tc_2 = tc >> 1;
+      const int thr = (beta + (beta >> 1)) >> 3;
+      const bool np2 = dp0 + dp3 < thr, nq2 = dq0 + dq3 < thr;
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        const int p2 = B[d][1], p1 = B[d][2], p0 = B[d][3], q0 = B[d][4], q1 = B[d][5], q2 = B[d][6];
+        int delta0 = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4;
+        if (iabs_(delta0) < 10 * tc) {
+          delta0 = clip3i(-tc, tc, delta0);
+          B[d][3] = clip3i(0, maxv, p0 + delta0);
+          B[d][4] = clip3i(0, maxv, q0 - delta0);
+          if (np2) B[d][2] = clip3i(0, maxv, p1 + clip3i(-tc_2, tc_2, (((p2 + p0 + 1) >> 1) - p1 + delta0) >> 1));
+          if (nq2) B[d][5] = clip3i(0, maxv, q1 + clip3i(-tc_2, tc_2, (((q2 + q0 + 1) >> 1) - q1 - delta0) >> 1));
+        }
+      }
+    }
+  }
+}
+
+// One launch = one direction for every picture of the batch.  blockIdx.y = picture.
+template <typename Pix>
+__global__ __launch_bounds__(256) void k_deblock(const hm_dev_pic* __restrict__ pics, int vertical)
+{
+  const hm_dev_pic& dp = pics[blockIdx.y];
+  if (!(dp.flags & HM_PIC_DEBLOCK_ANY)) return;
+  const PicView v = view(dp);
+  const int bd = dp.bit_depth, maxv = (1 << bd) - 1;
+  const int item = blockIdx.x * 256 + threadIdx.x;
+  // ---- luma segments: 8x8 grid ----
+  const int lw = (dp.w4 + 1) >> 1, lh = (dp.h4 + 1) >> 1;
+  const int nL = lw * lh;
+  if (item < nL) {
+    const int sx = item % lw, sy = item / lw;
+    const int xD = sx << 3, yD = sy << 3;
+    const int bs0 = edge_bs(dp, xD, yD, vertical);
+    const int bs1 = vertical ? edge_bs(dp, xD, yD + 4, 1) : edge_bs(dp, xD + 4, yD, 0);
+    if (!bs0 && !bs1) return;
+    const int QP_Q = qpy_at(dp, xD, yD);
+    const int QP_P = vertical ? qpy_at(dp, xD - 1, yD) : qpy_at(dp, xD, yD - 1);
+    const int qPL = (QP_Q + QP_P + 1) >> 1;
+    const hm_slice& sl = slice_at(dp, v, xD, yD);
+    const int beta = c_beta[clip3i(0, 51, qPL + sl.beta_offset_div2 * 2)] * (1 << (bd - 8));
+    int tc[2];
+    tc[0] = bs0 ? c_tc[clip3i(0, 53, qPL + 2 * (bs0 - 1) + sl.tc_offset_div2 * 2)] * (1 << (bd - 8)) : 0;
+    tc[1] = bs1 ? c_tc[clip3i(0, 53, qPL + 2 * (bs1 - 1) + sl.tc_offset_div2 * 2)] * (1 << (bd - 8)) : 0;
+    int px[8][8];
+    load_window<Pix>(dp.plane[0], dp.pitch[0], xD, yD, vertical, px);
+    filter_luma(px, beta, tc, maxv);
+    store_window<Pix>(dp.plane[0], dp.pitch[0], xD, yD, vertical, px);
+    return;
+  }
+  // ---- chroma segments (deblock.cc:1608-1772) ----
+  const int sw = 2, sh = dp.chroma_format == 1 ? 2 : 1;
+  const int xIncr = 2 * sw, yIncr = 2 * sh;
+  const int cwn = (dp.w4 + xIncr - 1) / xIncr, chn = (dp.h4 + yIncr - 1) / yIncr;
+  int ci = item - nL;
+  if (ci >= 2 * cwn * chn) return;
+  const int cp = ci / (cwn * chn);
+  ci -= cp * cwn * chn;
+  const int x = (ci % cwn) * xIncr, y = (ci / cwn) * yIncr;
+  const int xDi = x << (3 - sw), yDi = y << (3 - sh);
+  const int lx = xDi * sw, ly = yDi * sh;
+  const int bS0 = edge_bs(dp, lx, ly, vertical);
+  const int bS1 = vertical ? edge_bs(dp, lx, ly + 4 * sh, 1) : edge_bs(dp, lx + 4 * sw, ly, 0);
+  if (bS0 != 2 && bS1 != 2) return;
+  const int off = cp == 0 ? v.H->pps_cb_qp_offset : v.H->pps_cr_qp_offset;
+  int QP_Q = qpy_at(dp, lx, ly);
+  int QP_P = vertical ? qpy_at(dp, lx - 1, ly) : qpy_at(dp, lx, ly - 1);
+  int qPi = ((QP_Q + QP_P + 1) >> 1) + off;
+  const int QP_C0 = dp.chroma_format == 1 ? chroma_qp_map(qPi) : (qPi < 51 ? qPi : 51);
+  int QP_C1 = QP_C0;
+  if (bS1 == 2) {
+    QP_Q = vertical ? qpy_at(dp, lx, ly + 4 * sh) : qpy_at(dp, lx + 4 * sw, ly);
+    QP_P = vertical ? qpy_at(dp, lx - 1, ly + 4 * sh) : qpy_at(dp, lx + 4 * sw, ly - 1);
+    qPi = ((QP_Q + QP_P + 1) >> 1) + off;
+    QP_C1 = dp.chroma_format == 1 ? chroma_qp_map(qPi) : (qPi < 51 ? qPi : 51);
+  }
+  const hm_slice& sl = slice_at(dp, v, lx, ly);
+  const int tco = sl.tc_offset_div2 * 2;
+  int tc[2];
+  tc[0] = bS0 == 2 ? c_tc[clip3i(0, 53, QP_C0 + 2 + tco)] * (1 << (bd - 8)) : 0;
+  tc[1] = bS1 == 2 ? c_tc[clip3i(0, 53, QP_C1 + 2 + tco)] * (1 << (bd - 8)) : 0;
+  uint8_t* plane = dp.plane[cp + 1];
+  const int pitch = dp.pitch[cp + 1];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int t = tc[k >> 2];
+    if (t == 0) continue;
+    Pix* b = reinterpret_cast<Pix*>(plane + (size_t)(vertical ? yDi + k : yDi) * pitch) + (vertical ? xDi : xDi + k);
+    const int xs = vertical ? 1 : pitch / (int)sizeof(Pix);
+    const int p1 = b[-2 * xs], p0 = b[-xs], q0 = b[0], q1 = b[xs];
+    const int delta = clip3i(-t, t, ((((q0 - p0) * 4) + p1 - q1 + 4) >> 3));
+    b[-xs] = (Pix)clip3i(0, maxv, p0 + delta);
+    b[0] = (Pix)clip3i(0, maxv, q0 - delta);
+  }
+}
+
+// common_utils.h:73-79 on the device (no FMA, trunc(x + 0.5f))
+__device__ __forceinline__ int clip_f_u8(float fx)
+{
+  const int x = (int)__fadd_rn(fx, 0.5f);
+  return x < 0 ? 0 : (x > 255 ? 255 : x);
+}
+
+// SAO + paste.  blockIdx.y = picture, blockIdx.z = plane.  One lane = 4 consecutive samples.
+template <typename Pix>
+__global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict__ pics, int apply_sao)
+{
+  const hm_dev_pic& dp = pics[blockIdx.y];
+  const int c = blockIdx.z;
+  const int cw = dp.copy_w[c], chh = dp.copy_h[c];
+  if (cw <= 0 || chh <= 0) return;
+  const int groups = (cw + 3) >> 2;
+  const int item = blockIdx.x * 256 + threadIdx.x;
+  if (item >= groups * chh) return;
+  const int yy = item / groups, x4 = (item - yy * groups) << 2;
+  const PicView v = view(dp);
+  const int sw = c ? 2 : 1, sh = c ? (dp.chroma_format == 1 ? 2 : 1) : 1;
+  const int W = dp.width / sw, Hh = dp.height / sh;
+  const int nSW = (1 << dp.log2_ctb) / sw, nSH = (1 << dp.log2_ctb) / sh;
+  const int bd = dp.bit_depth, maxv = (1 << bd) - 1;
+  const uint8_t* plane = dp.plane[c];
+  const int pitch = dp.pitch[c];
+  const int cx = x4 / nSW, cy = yy / nSH; // 4 | nSW, so the 4 samples share a CTB
+  const hm_ctb& cb = v.ctbs[cx + cy * dp.ctb_w];
+  const hm_slice& sl = v.slices[cb.slice_idx];
+  const bool sao_on = apply_sao && (dp.flags & HM_PIC_SAO_ENABLED) && (c == 0 ? sl.sao_luma : sl.sao_chroma);
+  const hm_sao s = cb.sao[c];
+  const int type = sao_on ? s.type : 0;
+  const Pix* row = reinterpret_cast<const Pix*>(plane + (size_t)yy * pitch);
+  int out[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int xx = x4 + k;
+    int val = xx < W ? row[xx] : 0;
+    if (type == 1 && xx < W) { // band offset
+      const int bi = ((val >> (bd - 5)) - s.band_position) & 31;
+      if (bi < 4) val = clip3i(0, maxv, val + s.offset[bi]);
+    }
+    else if (type == 2 && xx < W) { // edge offset
+      const int cl = s.eo_class;
+      const int hx0 = cl == 1 ? 0 : (cl == 3 ? 1 : -1), hx1 = -hx0;
+      const int vy0 = cl == 0 ? 0 : -1, vy1 = -vy0;
+      bool ok = true;
+#pragma unroll
+      for (int n = 0; n < 2; n++) {
+        const int xS = xx + (n ? hx1 : hx0), yS = yy + (n ? vy1 : vy0);
+        if (xS < 0 || yS < 0 || xS >= W || yS >= Hh) { ok = false; break; }
+        const int dxc = xS / nSW - cx, dyc = yS / nSH - cy;
+        if (dxc != 0 || dyc != 0) {
+          const int k8 = (dyc + 1) * 3 + (dxc + 1); // 0..8 without the centre
+          const int bit = k8 < 4 ? k8 : k8 - 1;
+          if (!(cb.sao_nb_mask & (1u << bit))) ok = false;
+        }
+      }
+      if (ok) {
+        const int a = reinterpret_cast<const Pix*>(plane + (size_t)(yy + vy0) * pitch)[xx + hx0];
+        const int b = reinterpret_cast<const Pix*>(plane + (size_t)(yy + vy1) * pitch)[xx + hx1];
+        const int e = isign_(val - a) + isign_(val - b);
+        const int o = e == -2 ? s.offset[0] : (e == -1 ? s.offset[1] : (e == 1 ? s.offset[2] : (e == 2 ? s.offset[3] : 0)));
+        val = clip3i(0, maxv, val + o);
+      }
+    }
+    out[k] = val;
+  }
+  // ---- paste (context.cc:2504-2535) ----
+  if (dp.rescale) {
+    const float off = (float)(16 << (bd - 8));
+    const float ratio = c ? 1.1429f : 1.1689f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (sizeof(Pix) == 1) out[k] = clip_f_u8(__fmul_rn(__fsub_rn((float)out[k], off), ratio));
+      else { // the reference rescales BYTES of the 16-bit storage (quirk Q1)
+        const int lo = clip_f_u8(__fmul_rn(__fsub_rn((float)(out[k] & 0xFF), off), ratio));
+        const int hi = clip_f_u8(__fmul_rn(__fsub_rn((float)(out[k] >> 8), off), ratio));
+        out[k] = lo | (hi << 8);
+      }
+    }
+  }
+  Pix* drow = reinterpret_cast<Pix*>(dp.dst[c] + (size_t)yy * dp.dst_pitch[c]);
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (x4 + k < cw) drow[x4 + k] = (Pix)out[k];
+}
+
+} // namespace
+
+extern "C" int hm_launch_deblock(const hm_dev_pic* d_pics, int n_pics, int max_w4, int max_h4, int chroma_format,
+                                 int bit_depth, hipStream_t s)
+{
+  if (n_pics <= 0) return HM_OK;
+  const int lw = (max_w4 + 1) >> 1, lh = (max_h4 + 1) >> 1;
+  const int sh = chroma_format == 1 ? 2 : 1;
+  const int cwn = (max_w4 + 3) / 4, chn = (max_h4 + 2 * sh - 1) / (2 * sh);
+  const long items = (long)lw * lh + 2L * cwn * chn;
+  const int blocks = (int)((items + 255) / 256);
+  for (int vertical = 1; vertical >= 0; vertical--) {
+    if (bit_depth > 8) hipLaunchKernelGGL(k_deblock<uint16_t>, dim3(blocks, n_pics), dim3(256), 0, s, d_pics, vertical);
+    else hipLaunchKernelGGL(k_deblock<uint8_t>, dim3(blocks, n_pics), dim3(256), 0, s, d_pics, vertical);
+  }
+  return hm_check_hip(hipGetLastError(), "k_deblock launch");
+}
+
+extern "C" int hm_launch_sao_paste(const hm_dev_pic* d_pics, int n_pics, int max_w, int max_h, int bit_depth, int apply_sao,
+                                   hipStream_t s)
+{
+  if (n_pics <= 0) return HM_OK;
+  const long items = (long)((max_w + 3) / 4) * max_h;
+  const int blocks = (int)((items + 255) / 256);
+  if (bit_depth > 8) hipLaunchKernelGGL(k_sao_paste<uint16_t>, dim3(blocks, n_pics, 3), dim3(256), 0, s, d_pics, apply_sao);
+  else hipLaunchKernelGGL(k_sao_paste<uint8_t>, dim3(blocks, n_pics, 3), dim3(256), 0, s, d_pics, apply_sao);
+  return hm_check_hip(hipGetLastError(), "k_sao_paste launch");
+}

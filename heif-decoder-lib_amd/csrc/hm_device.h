@@ -1,0 +1,32 @@
+// hm_device.h — device-side job descriptors shared by the host batch code and the HIP kernels.
+// Internal (not part of the C ABI).
+#ifndef HM_DEVICE_H
+#define HM_DEVICE_H
+
+#include <stdint.h>
+
+#include "hm_stream.h"
+
+// One coded picture (HEIF tile / single image) of a batch.  All pointers are device pointers.
+struct hm_dev_pic {
+  const uint8_t* blob;      // command stream (hm_pic at offset 0)
+  uint8_t* plane[3];        // working planes: reconstruction, deblocked in place
+  int32_t pitch[3];         // bytes
+  uint8_t* edge;            // per 4x4 luma block: bit0 vertical edge on its left, bit1 horizontal edge on top
+  int8_t* qpy;              // per 4x4 luma block: QpY
+  int32_t w4, h4;           // size of the 4x4-block maps
+  // final output of the in-loop filters (SAO stage): written straight into the destination
+  // image = fused tile paste (context.cc:2457-2535 of the reference)
+  uint8_t* dst[3];          // destination plane origin (tile origin already applied)
+  int32_t dst_pitch[3];     // bytes
+  int32_t copy_w[3], copy_h[3]; // samples to write per plane (tile cropped at the canvas edge)
+  int32_t rescale;          // 1: limited->full range rescale quirk of the grid paste (context.cc:2504-2528)
+  int32_t width, height;    // luma size (copy of the header)
+  int32_t chroma_format;    // 1 or 2
+  int32_t bit_depth;
+  int32_t log2_ctb;
+  int32_t ctb_w, ctb_h;
+  int32_t flags;            // hm_pic.flags
+};
+
+#endif

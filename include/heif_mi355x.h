@@ -107,6 +107,38 @@ HM_API int hm_colour_convert(const hm_colour_desc* d, const void* d_y, const voi
 HM_API int hm_hevc_parse(const uint8_t* data, size_t size, int annexb, uint8_t** out_blob, size_t* out_size);
 HM_API void hm_free(void* p);
 
+/* ------------------------------------------------------------------------- */
+/* GPU tile decode: reconstruction -> deblocking -> SAO -> paste               */
+/* ------------------------------------------------------------------------- */
+
+/* Where a decoded picture goes: a (grid) canvas on the device.  Mirrors the arguments of
+ * HeifContext::decode_and_paste_tile_image (libheif/context.cc:2407-2411) plus the tile's
+ * colour profile, which decides the limited->full range rescale of context.cc:2504-2528.
+ * For a single (non-grid) image use x0 = y0 = 0 and canvas size = picture size. */
+typedef struct hm_tile_dest {
+  void*   plane[3];          /* device pointers to the canvas Y, Cb, Cr planes (origin of the canvas) */
+  int32_t pitch[3];          /* bytes                                                              */
+  int32_t canvas_width, canvas_height; /* luma size of the canvas                                   */
+  int32_t x0, y0;            /* tile origin in the canvas, luma samples                             */
+  int32_t tile_has_nclx;     /* the tile image carries an nclx (VUI or 'colr')                      */
+  int32_t tile_full_range, tile_matrix;
+} hm_tile_dest;
+
+typedef struct hm_batch hm_batch;
+
+HM_API int  hm_batch_create(hm_batch** out);
+HM_API void hm_batch_destroy(hm_batch* b);
+HM_API void hm_batch_clear(hm_batch* b);
+/* queue one picture (command stream from hm_hevc_parse; copied); returns its index (>= 0) or a status */
+HM_API int  hm_batch_add(hm_batch* b, const uint8_t* blob, size_t size, const hm_tile_dest* dest);
+HM_API int  hm_batch_size(const hm_batch* b);
+/* copy the queued command streams to the device and build the job descriptors (synchronous) */
+HM_API int  hm_batch_upload(hm_batch* b, void* stream);
+/* launch the kernels for all queued pictures (asynchronous on `stream`, repeatable).
+ * stages: bit0 = deblocking, bit1 = SAO; pass 3.  Pictures of a batch are independent: this is
+ * the data-parallel replacement of the reference's std::async tile fan-out (context.cc:2361-2401). */
+HM_API int  hm_batch_execute(hm_batch* b, int stages, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,54 @@
+"""CPU: host parser (product, C ABI) + oracle scalar executors reproduce the fingerprints the REAL
+reference decoder (libde265 built from /root/reference by oracle/Makefile) produced for the
+committed fixtures (tests/golden/decode.json, written by tools/make_fixtures.py), stage by stage."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import hevcutil
+import orc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "decode.json")))
+
+
+def _fp(planes):
+    h = 0
+    for p in planes:
+        a = p if p.max() > 255 else p.astype(np.uint8)
+        buf = a.tobytes()
+        h = orc.load().orc_fnv1a64(buf, len(buf), h)
+    return f"{h:016x}"
+
+
+@pytest.mark.parametrize("name", sorted(GOLD))
+def test_oracle_matches_reference_fingerprints(hm, name):
+    data = open(os.path.join(HERE, "data", name + ".hevc"), "rb").read()
+    blob = hevcutil.parse(hm, data)
+    for stage, bits in (("recon", 0), ("deblock", 1), ("full", 3)):
+        planes, info = orc.oracle_decode(blob, bits)
+        assert _fp(planes) == GOLD[name][stage], f"{name}: stage {stage}"
+    assert info["width"] == GOLD[name]["width"] and info["height"] == GOLD[name]["height"]
+    assert info["full_range"] == GOLD[name]["info"]["full_range"]
+    assert info["matrix"] == GOLD[name]["info"]["matrix"]
+
+
+@pytest.mark.parametrize("name", sorted(GOLD))
+def test_oracle_matches_reference_decoder_live(hm, name):
+    """when oracle/_ref is present (build container and GPU box) compare planes directly"""
+    if not orc.have_ref():
+        pytest.skip("oracle/_ref not built")
+    data = open(os.path.join(HERE, "data", name + ".hevc"), "rb").read()
+    ref, _ = orc.ref_decode(data, 0)
+    mine, _ = orc.oracle_decode(hevcutil.parse(hm, data), 3)
+    for c in range(3):
+        np.testing.assert_array_equal(mine[c], ref[c])
+
+
+def test_parser_rejects_garbage(hm):
+    with pytest.raises(RuntimeError):
+        hevcutil.parse(hm, b"\x00\x00\x00\x05hello")
+    with pytest.raises(RuntimeError):
+        hevcutil.parse(hm, b"\x00\x00\x00\xffshort")
