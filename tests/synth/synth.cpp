@@ -1,0 +1,433 @@
+// tests/synth/synth.cpp — TEST TOOL: seeded random-valid-syntax HEVC intra stream synthesiser.
+//
+// There is no HEVC encoder in the environment (the reference's enc265 crashes, no x265), and the
+// reference tree holds no grid / 4:2:2 / 10-bit material, so the BASELINE configurations are
+// exercised with synthetic coded pictures.  The synthesiser instantiates the product's own
+// slice-data walker (heif-decoder-lib_amd/csrc/hevc_syntax.h) with a CABAC *encoder* whose every
+// bin is drawn from a seeded policy: the emitted stream is valid by construction, and since the
+// walker derives contexts / scans / modes exactly as a decoder does, any mistake in it shows up
+// as a mismatch against the real reference decoder (oracle/_ref), which blesses every stream
+// (tools/make_fixtures.py) before it becomes a test input.
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "hevc_syntax.h"
+
+namespace {
+
+using namespace hm;
+
+// ---- bit writer with Exp-Golomb ------------------------------------------------------------
+struct BitWriter {
+  std::vector<uint8_t> buf;
+  int nbits = 0;
+  void put(uint32_t v, int n)
+  {
+    for (int i = n - 1; i >= 0; i--) {
+      if ((nbits & 7) == 0) buf.push_back(0);
+      if ((v >> i) & 1) buf.back() |= (uint8_t)(0x80 >> (nbits & 7));
+      nbits++;
+    }
+  }
+  void flag(bool b) { put(b ? 1 : 0, 1); }
+  void ue(uint32_t v)
+  {
+    uint32_t x = v + 1;
+    int len = 0;
+    while ((x >> len) > 1) len++;
+    put(0, len);
+    put(x, len + 1);
+  }
+  void se(int32_t v) { ue(v > 0 ? (uint32_t)(2 * v - 1) : (uint32_t)(-2 * v)); }
+  void trailing() { put(1, 1); while (nbits & 7) put(0, 1); }
+  void align_zero() { while (nbits & 7) put(0, 1); }
+};
+
+void append_nal(std::vector<uint8_t>& out, int nal_type, const std::vector<uint8_t>& rbsp)
+{
+  std::vector<uint8_t> nal;
+  nal.push_back((uint8_t)(nal_type << 1));
+  nal.push_back(1); // layer 0, temporal id plus1 = 1
+  int zeros = 0;
+  for (uint8_t b : rbsp) {
+    if (zeros >= 2 && b <= 3) { nal.push_back(3); zeros = 0; }
+    nal.push_back(b);
+    zeros = b == 0 ? zeros + 1 : 0;
+  }
+  const uint32_t n = (uint32_t)nal.size();
+  out.push_back((uint8_t)(n >> 24)); out.push_back((uint8_t)(n >> 16)); out.push_back((uint8_t)(n >> 8)); out.push_back((uint8_t)n);
+  out.insert(out.end(), nal.begin(), nal.end());
+}
+
+// ---- CABAC encoder (H.265 9.3.4.x: EncodeDecision / EncodeBypass / EncodeTerminate / EncodeFlush) ----
+struct CabacEncoder {
+  std::vector<uint8_t> out;
+  int nbits = 0;
+  uint32_t low = 0, range = 510;
+  int outstanding = 0;
+  bool first = true;
+  void reset() { low = 0; range = 510; outstanding = 0; first = true; }
+  void wbit(int b)
+  {
+    if ((nbits & 7) == 0) out.push_back(0);
+    if (b) out.back() |= (uint8_t)(0x80 >> (nbits & 7));
+    nbits++;
+  }
+  void put_bit(int b)
+  {
+    if (first) first = false;
+    else wbit(b);
+    while (outstanding > 0) { wbit(1 - b); outstanding--; }
+  }
+  void renorm()
+  {
+    while (range < 256) {
+      if (low < 256) put_bit(0);
+      else if (low >= 512) { low -= 512; put_bit(1); }
+      else { low -= 256; outstanding++; }
+      range <<= 1;
+      low <<= 1;
+    }
+  }
+  void encode(uint8_t& ctx, int bin)
+  {
+    int st = ctx >> 1, mps = ctx & 1;
+    const uint32_t lps = cabac_tables::kRangeTabLps[st][(range >> 6) & 3];
+    range -= lps;
+    if (bin != mps) {
+      low += range;
+      range = lps;
+      if (st == 0) mps = 1 - mps;
+      st = cabac_tables::kTransIdxLps[st];
+    }
+    else if (st < 62) st++;
+    ctx = (uint8_t)((st << 1) | mps);
+    renorm();
+  }
+  void bypass(int bin)
+  {
+    low <<= 1;
+    if (bin) low += range;
+    if (low >= 1024) { put_bit(1); low -= 1024; }
+    else if (low < 512) put_bit(0);
+    else { low -= 512; outstanding++; }
+  }
+  void terminate(int bin)
+  {
+    range -= 2;
+    if (bin) {
+      low += range;
+      range = 2;
+      renorm();
+      put_bit((low >> 9) & 1);
+      wbit((low >> 8) & 1);
+      wbit(1); // doubles as rbsp_stop_one_bit / alignment_bit_equal_to_one
+      while (nbits & 7) wbit(0);
+    }
+    else renorm();
+  }
+};
+
+// ---- xorshift RNG ------------------------------------------------------------------------------
+struct Rng {
+  uint64_t s;
+  explicit Rng(uint64_t seed) : s(seed * 0x9E3779B97F4A7C15ull + 0x1234567ull) { next(); next(); }
+  uint64_t next() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; }
+  bool chance(int permille) { return (int)(next() % 1000) < permille; }
+};
+
+struct SynthParams {
+  int32_t width, height;       // multiples of 8
+  int32_t chroma_format;       // 1 or 2
+  int32_t bit_depth;           // 8..12
+  int32_t log2_ctb;            // 4..6
+  int32_t log2_min_cb;         // 3..log2_ctb
+  int32_t log2_min_tb, log2_max_tb;
+  int32_t max_th_depth_intra;
+  int32_t qp;                  // slice QP
+  int32_t cu_qp_delta;         // 0/1
+  int32_t diff_cu_qp_delta_depth;
+  int32_t sao, deblock_disable; // flags
+  int32_t sign_hiding, transform_skip, strong_intra;
+  int32_t cb_qp_offset, cr_qp_offset;
+  int32_t beta_offset_div2, tc_offset_div2;
+  int32_t vui;                 // 0: no VUI colour info, 1: present
+  int32_t full_range, matrix, primaries;
+  int32_t density;             // residual density knob 0..100 (percent scale of cbf/sig probabilities)
+  int32_t wpp;                 // entropy_coding_sync_enabled_flag
+};
+
+// entropy-coder adaptor for SliceWalker: chooses every bin, encodes it, returns it
+class EncoderEC {
+ public:
+  EncoderEC(uint64_t seed, const SynthParams& p) : rng_(seed), P(p) {}
+  int bin(int ctx, int kind, int idx)
+  {
+    const int b = choose(kind, idx);
+    enc.encode(cs_.state[ctx], b);
+    return b;
+  }
+  int bypass(int kind, int idx)
+  {
+    const int b = choose(kind, idx);
+    enc.bypass(b);
+    return b;
+  }
+  int terminate(int expect)
+  {
+    const int b = expect < 0 ? 0 : expect;
+    enc.terminate(b);
+    if (b) substream_ends.push_back(enc.out.size());
+    return b;
+  }
+  ContextSet& contexts() { return cs_; }
+  void start_substream() { enc.reset(); }
+
+  CabacEncoder enc;
+  std::vector<size_t> substream_ends;
+
+ private:
+  int choose(int kind, int idx)
+  {
+    const int d = P.density; // percent
+    switch (kind) {
+      case K_SAO_MERGE: return rng_.chance(300);
+      case K_SAO_TYPE: return idx == 0 ? rng_.chance(700) : rng_.chance(500);
+      case K_SAO_OFFSET: return rng_.chance(450);
+      case K_SPLIT_CU: return rng_.chance(idx >= 6 ? 900 : (idx == 5 ? 650 : 450));
+      case K_TQ_BYPASS: return 0;
+      case K_PART_MODE: return idx == 1 ? 1 : rng_.chance(600);
+      case K_PREV_INTRA: return rng_.chance(550);
+      case K_SPLIT_TF: return rng_.chance(idx >= 5 ? 550 : (idx == 4 ? 400 : 300));
+      case K_CBF_LUMA: return rng_.chance(7 * d);
+      case K_CBF_CHROMA: return rng_.chance(5 * d);
+      case K_QP_DELTA: return idx >= 3 ? 0 : rng_.chance(idx == 0 ? 350 : 400);
+      case K_QP_DELTA_SUFFIX: return 0;
+      case K_TSKIP: return rng_.chance(150);
+      case K_LAST_PREFIX: return rng_.chance(520);
+      case K_CSBF: return rng_.chance(5 * d);
+      case K_SIG: return rng_.chance(4 * d + 50);
+      case K_GT1: return rng_.chance(300);
+      case K_GT2: return rng_.chance(300);
+      case K_CALR_PREFIX: return idx >= 5 ? 0 : rng_.chance(400);
+      default: return (int)(rng_.next() & 1); // uniform: signs, suffixes, modes, band position, classes
+    }
+  }
+  Rng rng_;
+  const SynthParams& P;
+  ContextSet cs_;
+};
+
+void write_ptl(BitWriter& w, const SynthParams& p)
+{
+  const int profile = (p.chroma_format != 1 || p.bit_depth > 10) ? 4 : (p.bit_depth > 8 ? 2 : 1);
+  w.put(0, 2); w.put(0, 1); w.put(profile, 5);
+  for (int i = 0; i < 32; i++) w.put(i == profile ? 1 : 0, 1);
+  w.put(1, 1); w.put(0, 1); w.put(0, 1); w.put(1, 1); // progressive, !interlaced, !non_packed, frame_only
+  w.put(0, 32); w.put(0, 11);                         // 43 reserved bits
+  w.put(0, 1);
+  w.put(183, 8);                                      // level 6.1
+}
+
+} // namespace
+
+extern "C" {
+
+__attribute__((visibility("default"))) void hm_synth_free(void* p) { std::free(p); }
+
+// Returns 0 and a malloc'd [u32 BE len][NAL]... byte string (VPS, SPS, PPS, IDR slice).
+__attribute__((visibility("default"))) int hm_synth_picture(const SynthParams* pp, uint64_t seed, uint8_t** out, size_t* out_size)
+{
+  const SynthParams& p = *pp;
+  if ((p.width & 7) || (p.height & 7) || p.width <= 0 || p.height <= 0) return -1;
+  if ((p.width & ((1 << p.log2_min_cb) - 1)) || (p.height & ((1 << p.log2_min_cb) - 1))) return -1;
+  std::vector<uint8_t> stream;
+  // ---- VPS ----
+  {
+    BitWriter w;
+    w.put(0, 4); w.put(1, 1); w.put(1, 1); w.put(0, 6); w.put(0, 3); w.put(1, 1); w.put(0xFFFF, 16);
+    write_ptl(w, p);
+    w.flag(1); w.ue(0); w.ue(0); w.ue(0);
+    w.put(0, 6); w.ue(0); w.flag(0); w.flag(0);
+    w.trailing();
+    append_nal(stream, 32, w.buf);
+  }
+  // ---- SPS ----
+  std::vector<uint8_t> sps_rbsp;
+  {
+    BitWriter w;
+    w.put(0, 4); w.put(0, 3); w.put(1, 1);
+    write_ptl(w, p);
+    w.ue(0);
+    w.ue(p.chroma_format);
+    w.ue(p.width); w.ue(p.height);
+    w.flag(0); // conformance window
+    w.ue(p.bit_depth - 8); w.ue(p.bit_depth - 8);
+    w.ue(4);   // log2_max_pic_order_cnt_lsb_minus4
+    w.flag(1); w.ue(0); w.ue(0); w.ue(0);
+    w.ue(p.log2_min_cb - 3); w.ue(p.log2_ctb - p.log2_min_cb);
+    w.ue(p.log2_min_tb - 2); w.ue(p.log2_max_tb - p.log2_min_tb);
+    w.ue(0); w.ue(p.max_th_depth_intra);
+    w.flag(0);                 // scaling_list_enabled_flag
+    w.flag(0);                 // amp
+    w.flag(p.sao != 0);
+    w.flag(0);                 // pcm
+    w.ue(0);                   // num_short_term_ref_pic_sets
+    w.flag(0);                 // long_term_ref_pics_present
+    w.flag(0);                 // temporal mvp
+    w.flag(p.strong_intra != 0);
+    w.flag(p.vui != 0);
+    if (p.vui) {
+      w.flag(0); w.flag(0);    // aspect ratio, overscan
+      w.flag(1);               // video_signal_type_present
+      w.put(5, 3); w.flag(p.full_range != 0); w.flag(1);
+      w.put(p.primaries, 8); w.put(2, 8); w.put(p.matrix, 8);
+      w.flag(0);               // chroma_loc_info
+      w.flag(0); w.flag(0); w.flag(0); // neutral chroma, field_seq, frame_field_info
+      w.flag(0);               // default display window
+      w.flag(0);               // timing info
+      w.flag(0);               // bitstream restriction
+    }
+    w.flag(0);                 // sps_extension
+    w.trailing();
+    sps_rbsp = w.buf;
+    append_nal(stream, 33, w.buf);
+  }
+  // ---- PPS ----
+  std::vector<uint8_t> pps_rbsp;
+  {
+    BitWriter w;
+    w.ue(0); w.ue(0);
+    w.flag(0); w.flag(0); w.put(0, 3);
+    w.flag(p.sign_hiding != 0);
+    w.flag(0);                 // cabac_init_present
+    w.ue(0); w.ue(0);
+    w.se(0);                   // init_qp_minus26
+    w.flag(0);                 // constrained_intra_pred
+    w.flag(p.transform_skip != 0);
+    w.flag(p.cu_qp_delta != 0);
+    if (p.cu_qp_delta) w.ue(p.diff_cu_qp_delta_depth);
+    w.se(p.cb_qp_offset); w.se(p.cr_qp_offset);
+    w.flag(0);                 // slice_chroma_qp_offsets_present
+    w.flag(0); w.flag(0);      // weighted pred
+    w.flag(0);                 // transquant_bypass
+    w.flag(0);                 // tiles
+    w.flag(p.wpp != 0);        // entropy_coding_sync
+    w.flag(1);                 // pps_loop_filter_across_slices_enabled
+    w.flag(1);                 // deblocking_filter_control_present
+    w.flag(0);                 //   override enabled
+    w.flag(p.deblock_disable != 0);
+    if (!p.deblock_disable) { w.se(p.beta_offset_div2); w.se(p.tc_offset_div2); }
+    w.flag(0);                 // pps_scaling_list_data_present
+    w.flag(0);                 // lists_modification_present
+    w.ue(0);                   // log2_parallel_merge_level_minus2
+    w.flag(0);                 // slice_segment_header_extension_present
+    w.flag(0);                 // pps_extension
+    w.trailing();
+    pps_rbsp = w.buf;
+    append_nal(stream, 34, w.buf);
+  }
+  // parse our own parameter sets with the product parser -> structures the walker needs
+  static thread_local SPS sps_table[16];
+  static thread_local PPS pps_table[64];
+  try {
+    BitReader bs(sps_rbsp.data(), sps_rbsp.size());
+    SPS s; parse_sps(bs, s); sps_table[0] = s;
+    BitReader bp(pps_rbsp.data(), pps_rbsp.size());
+    PPS q; parse_pps(bp, q, sps_table); pps_table[0] = q;
+  }
+  catch (const ParseError&) { return -2; }
+  const SPS& sps = sps_table[0];
+  const PPS& pps = pps_table[0];
+
+  // ---- slice data ----
+  SliceHeader sh;
+  sh.nal_unit_type = 19;
+  sh.first_slice_segment_in_pic = true;
+  sh.slice_type = 2;
+  sh.sao_luma = p.sao != 0;
+  sh.sao_chroma = p.sao != 0;
+  sh.slice_qp_delta = p.qp - 26;
+  sh.SliceQPY = p.qp;
+  sh.deblocking_disabled = p.deblock_disable != 0;
+  sh.beta_offset_div2 = p.beta_offset_div2;
+  sh.tc_offset_div2 = p.tc_offset_div2;
+  sh.lf_across_slices = true;
+  sh.SliceAddrRS = 0;
+  PictureState pic;
+  pic.reset(sps, pps);
+  hm_slice hs; std::memset(&hs, 0, sizeof(hs));
+  pic.slices.push_back(hs);
+  EncoderEC ec(seed, p);
+  ContextSet wpp_store, dep_store;
+  bool wpp_valid = false, dep_valid = false;
+  try {
+    SliceWalker<EncoderEC> walker(ec, pic, sh, 0);
+    walker.decode_slice_segment(0, &wpp_store, &wpp_valid, &dep_store, &dep_valid);
+  }
+  catch (const ParseError&) { return -3; }
+  const std::vector<uint8_t>& data = ec.enc.out;
+
+  // ---- slice header ----
+  {
+    BitWriter w;
+    w.flag(1);                 // first_slice_segment_in_pic_flag
+    w.flag(0);                 // no_output_of_prior_pics_flag (IRAP)
+    w.ue(0);                   // pps id
+    w.ue(2);                   // slice_type I
+    if (p.sao) { w.flag(1); w.flag(1); }
+    w.se(sh.slice_qp_delta);
+    // pps_loop_filter_across_slices_enabled_flag = 1 and (sao || !deblocking_disabled)
+    if (p.sao || !p.deblock_disable) w.flag(1);
+    if (p.wpp) {
+      // entry points: sizes of the sub-streams in the escaped domain.  A sub-stream never ends
+      // in a zero byte (it ends with the terminating '1'), so escaping the slice data on its own
+      // yields the same bytes as escaping the whole NAL.
+      std::vector<size_t> ends = ec.substream_ends; // unescaped end offsets (last = end of slice)
+      std::vector<size_t> esc_pos(data.size() + 1, 0);
+      {
+        int zeros = 0; size_t pos = 0;
+        for (size_t i = 0; i < data.size(); i++) {
+          if (zeros >= 2 && data[i] <= 3) { pos++; zeros = 0; }
+          esc_pos[i] = pos;
+          pos++;
+          zeros = data[i] == 0 ? zeros + 1 : 0;
+        }
+        esc_pos[data.size()] = pos;
+      }
+      const int n = (int)ends.size() - 1;
+      w.ue(n);
+      if (n > 0) {
+        std::vector<uint32_t> sizes;
+        size_t prev = 0; uint32_t mx = 1;
+        for (int i = 0; i < n; i++) {
+          // escaped size of sub-stream i = escaped position of the next sub-stream's first byte
+          const size_t e = esc_pos[ends[i]];
+          sizes.push_back((uint32_t)(e - prev));
+          prev = e;
+          mx = sizes.back() > mx ? sizes.back() : mx;
+        }
+        int len = 1;
+        while ((1u << len) < mx) len++;
+        if (len > 32) return -4;
+        w.ue(len - 1);
+        for (uint32_t s : sizes) w.put(s - 1, len);
+      }
+    }
+    w.put(1, 1);
+    w.align_zero();
+    std::vector<uint8_t> rbsp = w.buf;
+    rbsp.insert(rbsp.end(), data.begin(), data.end());
+    append_nal(stream, 19, rbsp);
+  }
+  uint8_t* mem = (uint8_t*)std::malloc(stream.size());
+  if (!mem) return -5;
+  std::memcpy(mem, stream.data(), stream.size());
+  *out = mem;
+  *out_size = stream.size();
+  return 0;
+}
+
+} // extern "C"
