@@ -74,6 +74,9 @@ def bind_decode(L):
     L.hm_batch_size.argtypes = [C.c_void_p]
     L.hm_batch_upload.argtypes = [C.c_void_p, C.c_void_p]
     L.hm_batch_execute.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.hm_batch_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.hm_batch_get_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.hm_batch_algorithmic_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
 
 
 def parse_hevc(data, annexb=False):
@@ -117,6 +120,19 @@ class Batch:
 
     def clear(self):
         self.L.hm_batch_clear(self.h)
+
+    def set_profiling(self, on=True):
+        check(self.L.hm_batch_set_profiling(self.h, 1 if on else 0))
+
+    def timings_ms(self):
+        ms = (C.c_float * 3)()
+        check(self.L.hm_batch_get_timings(self.h, ms))
+        return [ms[0], ms[1], ms[2]]
+
+    def algorithmic_bytes(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        check(self.L.hm_batch_algorithmic_bytes(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def close(self):
         if self.h:

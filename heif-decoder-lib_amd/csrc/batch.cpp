@@ -60,6 +60,11 @@ struct hm_batch {
   std::vector<hm_dev_pic> h_desc;
   bool uploaded = false;
   size_t total_pixels = 0;
+  // optional per-kernel timing with HIP events on the launch stream (bench / profiling)
+  bool profiling = false;
+  std::vector<hipEvent_t> events;   // 4 per class: before recon, after recon, after deblock, after sao
+  int events_used = 0;
+  ~hm_batch() { for (hipEvent_t e : events) hipEventDestroy(e); }
 };
 
 extern "C" {
@@ -227,21 +232,79 @@ int hm_batch_execute(hm_batch* b, int stages, void* stream)
   if (!b->uploaded) return hm_fail(HM_ERR_INVALID_ARG, "hm_batch_upload() has not been called");
   hipStream_t s = (hipStream_t)stream;
   const hm_dev_pic* d = (const hm_dev_pic*)b->d_desc.p;
+  b->events_used = 0;
+  if (b->profiling) {
+    while (b->events.size() < b->classes.size() * 4) {
+      hipEvent_t ev;
+      hipError_t e = hipEventCreate(&ev);
+      if (e != hipSuccess) return hm_check_hip(e, "hipEventCreate");
+      b->events.push_back(ev);
+    }
+  }
+  auto mark = [&]() { if (b->profiling) hipEventRecord(b->events[b->events_used++], s); };
   for (const Class& c : b->classes) {
     const hm_dev_pic* dc = d + c.desc_offset;
     const int n = (int)c.items.size();
+    mark();
     int rc = hm_launch_recon(dc, n, c.log2_ctb, c.chroma_format, c.bit_depth, c.max_ctb_w, c.max_ctb_h, s);
     if (rc) return rc;
+    mark();
     if (stages & 1) {
       rc = hm_launch_deblock(dc, n, c.max_w4, c.max_h4, c.chroma_format, c.bit_depth, s);
       if (rc) return rc;
     }
+    mark();
     rc = hm_launch_sao_paste(dc, n, c.max_w, c.max_h, c.bit_depth, (stages & 2) ? 1 : 0, s);
     if (rc) return rc;
+    mark();
   }
+  return HM_OK;
+}
+
+int hm_batch_set_profiling(hm_batch* b, int enable)
+{
+  if (!b) return hm_fail(HM_ERR_INVALID_ARG, "null batch");
+  b->profiling = enable != 0;
+  return HM_OK;
+}
+
+// Kernel times (ms) of the last hm_batch_execute: recon, deblock (both passes), SAO+paste.
+// Synchronises on the recorded events.
+int hm_batch_get_timings(hm_batch* b, float ms[3])
+{
+  if (!b || !ms) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
+  ms[0] = ms[1] = ms[2] = 0.f;
+  if (!b->profiling || b->events_used == 0) return hm_fail(HM_ERR_INVALID_ARG, "profiling not enabled or nothing executed");
+  hipError_t e = hipEventSynchronize(b->events[b->events_used - 1]);
+  if (e != hipSuccess) return hm_check_hip(e, "hipEventSynchronize");
+  for (int i = 0; i + 3 < b->events_used; i += 4)
+    for (int k = 0; k < 3; k++) {
+      float t = 0.f;
+      e = hipEventElapsedTime(&t, b->events[i + k], b->events[i + k + 1]);
+      if (e != hipSuccess) return hm_check_hip(e, "hipEventElapsedTime");
+      ms[k] += t;
+    }
+  return HM_OK;
+}
+
+// algorithmic bytes of the queued work: command-stream bytes read + sample bytes written by the
+// reconstruction kernel, summed over the batch
+int hm_batch_algorithmic_bytes(const hm_batch* b, uint64_t* stream_bytes, uint64_t* sample_bytes)
+{
+  if (!b || !stream_bytes || !sample_bytes) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
+  uint64_t sb = 0, pb = 0;
+  for (const Item& it : b->items) {
+    sb += it.hdr.total_bytes;
+    const uint64_t bps = it.hdr.bit_depth_y > 8 ? 2 : 1;
+    const uint64_t luma = (uint64_t)it.hdr.width * it.hdr.height;
+    pb += bps * (luma + 2 * (luma / (it.hdr.chroma_format == 1 ? 4 : 2)));
+  }
+  *stream_bytes = sb;
+  *sample_bytes = pb;
   return HM_OK;
 }
 
 int hm_batch_size(const hm_batch* b) { return b ? (int)b->items.size() : 0; }
 
 } // extern "C"
+

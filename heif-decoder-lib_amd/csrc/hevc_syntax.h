@@ -571,7 +571,7 @@ class SliceWalker {
           while (k--) v += ec_.bypass(K_QP_DELTA_SUFFIX, 32 + k) << k;
         }
         int sign = 0;
-        if (v) sign = ec_.bypass(K_QP_SIGN, 0);
+        if (v) sign = ec_.bypass(K_QP_SIGN, pic_.qs.current_qpy - sh_.SliceQPY); // idx = QP drift (synthesiser hint)
         is_cu_qp_delta_coded_ = true;
         cu_qp_delta_val_ = sign ? -v : v;
         const int lim_lo = -(26 + sps_.qp_bd_offset_y / 2), lim_hi = 25 + sps_.qp_bd_offset_y / 2;
@@ -811,7 +811,7 @@ class SliceWalker {
   int coeff_abs_level_remaining(int rice)
   {
     int prefix = 0;
-    while (ec_.bypass(K_CALR_PREFIX, prefix)) {
+    while (ec_.bypass(K_CALR_PREFIX, prefix | (rice << 4))) {
       if (++prefix > 32) throw ParseError(HM_ERR_BITSTREAM, "coeff_abs_level_remaining prefix too long");
     }
     if (prefix <= 3) {

@@ -1,0 +1,42 @@
+"""The synthetic test corpus: named (seed, parameter) cases for tests/synth.  Every case is
+blessed by the real reference decoder in the build container (tools/make_fixtures.py writes its
+fingerprints to tests/golden/synth.json); streams are regenerated deterministically from the
+seed wherever the tests run."""
+
+# BASELINE configs: 512x512 tiles, CTB 32, QP 27 +- cu_qp_delta, SAO, deblock, SDH
+TILE = dict(width=512, height=512, log2_ctb=5, qp=27, cu_qp_delta=1, sao=1, sign_hiding=1, density=60)
+
+CASES = {
+    # config 2 tiles: VUI full_range=1 matrix=6, and the no-VUI variant (limited-range paste rescale)
+    "tile512_a": dict(seed=1200000, vui=1, full_range=1, matrix=6, **TILE),
+    "tile512_b": dict(seed=1200001, vui=1, full_range=1, matrix=6, **TILE),
+    "tile512_novui": dict(seed=1200002, vui=0, **TILE),
+    # config 4: 10-bit 4:2:2 (small variant; the full 2048x1536 one is generated in the bench / slow tests)
+    "hi422_10": dict(seed=4220010, width=256, height=192, chroma_format=2, bit_depth=10, log2_ctb=5, qp=30,
+                     vui=1, full_range=0, matrix=9, primaries=9),
+    "hi422_10_full": dict(seed=4220011, width=192, height=128, chroma_format=2, bit_depth=10, log2_ctb=5, qp=24,
+                          vui=1, full_range=1, matrix=1, primaries=1, cb_qp_offset=3, cr_qp_offset=-2),
+    "hi420_10": dict(seed=4200010, width=128, height=128, chroma_format=1, bit_depth=10, log2_ctb=4, qp=33),
+    "hi422_12": dict(seed=4220012, width=128, height=64, chroma_format=2, bit_depth=12, log2_ctb=5, qp=35),
+    # structure / tool coverage
+    "ctb64": dict(seed=64001, width=192, height=136, log2_ctb=6, qp=25),
+    "ctb64_wpp": dict(seed=64002, width=256, height=192, log2_ctb=6, wpp=1, qp=31),
+    "ctb16_nosao": dict(seed=16001, width=128, height=72, log2_ctb=4, sao=0, qp=29),
+    "ctb32_wpp_422": dict(seed=32002, width=160, height=96, log2_ctb=5, wpp=1, chroma_format=2, qp=28),
+    "no_deblock": dict(seed=7001, width=128, height=128, deblock_disable=1),
+    "no_sao_no_sdh": dict(seed=7002, width=128, height=96, sao=0, sign_hiding=0, transform_skip=0, strong_intra=0),
+    "offsets": dict(seed=7003, width=128, height=128, beta_offset_div2=3, tc_offset_div2=-2, cb_qp_offset=-4, cr_qp_offset=5, qp=36),
+    "dense_lowqp": dict(seed=7004, width=96, height=96, density=95, qp=12),
+    "sparse_highqp": dict(seed=7005, width=96, height=96, density=25, qp=47),
+    "tiny": dict(seed=7006, width=8, height=8, log2_ctb=4),
+    "ragged": dict(seed=7007, width=72, height=40, log2_ctb=5),
+    "min_cb16": dict(seed=7008, width=128, height=64, log2_ctb=5, log2_min_cb=4, log2_min_tb=3, max_th_depth_intra=1),
+    "flat_qp": dict(seed=7009, width=128, height=128, cu_qp_delta=0, max_th_depth_intra=0),
+}
+
+
+def stream(name):
+    import synthutil
+    kw = dict(CASES[name])
+    seed = kw.pop("seed")
+    return synthutil.picture(seed, **kw)

@@ -205,13 +205,21 @@ class EncoderEC {
       case K_CBF_CHROMA: return rng_.chance(5 * d);
       case K_QP_DELTA: return idx >= 3 ? 0 : rng_.chance(idx == 0 ? 350 : 400);
       case K_QP_DELTA_SUFFIX: return 0;
+      case K_QP_SIGN: return idx > 2 ? 1 : (idx < -2 ? 0 : (int)(rng_.next() & 1)); // keep QpY near the slice QP
       case K_TSKIP: return rng_.chance(150);
       case K_LAST_PREFIX: return rng_.chance(520);
       case K_CSBF: return rng_.chance(5 * d);
       case K_SIG: return rng_.chance(4 * d + 50);
       case K_GT1: return rng_.chance(300);
       case K_GT2: return rng_.chance(300);
-      case K_CALR_PREFIX: return idx >= 5 ? 0 : rng_.chance(400);
+      case K_CALR_PREFIX: {
+        // keep |level| small (<= 8, <= 3 at very high QP): real encoders do not emit levels whose
+        // dequantised value saturates int16, and in that regime the reference's own SIMD and
+        // scalar builds disagree
+        const int prefix = idx & 15, rice = idx >> 4;
+        const int maxprefix = P.qp >= 40 ? 0 : (rice >= 2 ? 0 : 2);
+        return prefix >= maxprefix ? 0 : rng_.chance(350);
+      }
       default: return (int)(rng_.next() & 1); // uniform: signs, suffixes, modes, band position, classes
     }
   }

@@ -41,6 +41,42 @@ def test_matches_reference_decoder(pkg, path):
         np.testing.assert_array_equal(got[c], ref[c])
 
 
+import corpus  # noqa: E402
+import json  # noqa: E402
+
+SYNTH = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "synth.json")))
+
+
+def _fp(planes):
+    h = 0
+    for p in planes:
+        a = p if p.max() > 255 else p.astype(np.uint8)
+        buf = a.tobytes()
+        h = orc.load().orc_fnv1a64(buf, len(buf), h)
+    return f"{h:016x}"
+
+
+@pytest.mark.parametrize("name", sorted(corpus.CASES))
+def test_synth_corpus(pkg, name):
+    """every corpus case: HIP == oracle at every stage, and == the reference decoder's fingerprints"""
+    blob = pkg.capi.parse_hevc(corpus.stream(name))
+    for stage, bits in (("recon", 0), ("deblock", 1), ("full", 3)):
+        got = gpudecode.decode_pictures(pkg, [blob], bits)[0]
+        exp, _ = orc.oracle_decode(blob, bits)
+        for c in range(3):
+            bad = np.argwhere(got[c] != exp[c])
+            assert bad.size == 0, f"{name} {stage} plane {c}: {len(bad)} mismatches, first (y,x)={bad[0].tolist()}"
+        assert _fp(got) == SYNTH[name][stage]
+
+
+def test_whole_corpus_in_one_batch(pkg):
+    names = sorted(corpus.CASES)
+    blobs = [pkg.capi.parse_hevc(corpus.stream(n)) for n in names]
+    got = gpudecode.decode_pictures(pkg, blobs, 3)
+    for n, g in zip(names, got):
+        assert _fp(g) == SYNTH[n]["full"], n
+
+
 def test_batch_of_mixed_pictures(pkg):
     """several pictures (different sizes / CTB sizes) in one batch = independent workgroups"""
     paths = _streams()

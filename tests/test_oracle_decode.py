@@ -52,3 +52,22 @@ def test_parser_rejects_garbage(hm):
         hevcutil.parse(hm, b"\x00\x00\x00\x05hello")
     with pytest.raises(RuntimeError):
         hevcutil.parse(hm, b"\x00\x00\x00\xffshort")
+
+
+# ---- synthetic corpus (tests/corpus.py), blessed by the reference decoder -------------------
+import corpus  # noqa: E402
+
+SYNTH = json.load(open(os.path.join(HERE, "golden", "synth.json")))
+
+
+@pytest.mark.parametrize("name", sorted(corpus.CASES))
+def test_synth_corpus_matches_reference_fingerprints(hm, name):
+    data = corpus.stream(name)
+    assert f"{orc.load().orc_fnv1a64(data, len(data), 0):016x}" == SYNTH[name]["stream_fnv"], "synthesiser is not deterministic"
+    blob = hevcutil.parse(hm, data)
+    for stage, bits in (("recon", 0), ("deblock", 1), ("full", 3)):
+        planes, info = orc.oracle_decode(blob, bits)
+        assert _fp(planes) == SYNTH[name][stage], f"{name}: stage {stage}"
+    assert info["full_range"] == SYNTH[name]["info"]["full_range"]
+    assert info["matrix"] == SYNTH[name]["info"]["matrix"]
+    assert info["bit_depth"] == SYNTH[name]["info"]["bit_depth"]

@@ -67,6 +67,25 @@ def main():
         print(name, entry)
     json.dump(golden, open(os.path.join(ROOT, "tests", "golden", "decode.json"), "w"), indent=1, sort_keys=True)
 
+    # synthetic corpus: blessed by the reference decoder (SIMD build = the oracle configuration, and
+    # its scalar build must agree - the two differ for 8-bit SAO on 8-sample-wide chroma CTBs, which
+    # the corpus therefore avoids)
+    import corpus
+    synth = {}
+    for name in sorted(corpus.CASES):
+        data = corpus.stream(name)
+        entry = {"bytes": len(data), "stream_fnv": f"{orc.load().orc_fnv1a64(data, len(data), 0):016x}"}
+        for stage, flags in (("recon", orc.REF_F_NO_DEBLOCK | orc.REF_F_NO_SAO), ("deblock", orc.REF_F_NO_SAO), ("full", 0)):
+            planes, info = orc.ref_decode(data, flags)
+            scalar, _ = orc.ref_decode(data, flags | orc.REF_F_SCALAR)
+            assert all((a == b).all() for a, b in zip(planes, scalar)), f"{name}: reference SIMD != scalar"
+            entry[stage] = fingerprint(planes)
+        entry["width"], entry["height"] = int(planes[0].shape[1]), int(planes[0].shape[0])
+        entry["info"] = info
+        synth[name] = entry
+        print(name, entry["bytes"], entry["full"])
+    json.dump(synth, open(os.path.join(ROOT, "tests", "golden", "synth.json"), "w"), indent=1, sort_keys=True)
+
 
 if __name__ == "__main__":
     main()
