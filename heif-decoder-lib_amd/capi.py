@@ -75,7 +75,7 @@ def bind_decode(L):
     L.hm_batch_upload.argtypes = [C.c_void_p, C.c_void_p]
     L.hm_batch_execute.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.hm_batch_set_profiling.argtypes = [C.c_void_p, C.c_int]
-    L.hm_batch_get_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.hm_batch_get_timings.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     L.hm_batch_algorithmic_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
 
 
@@ -121,12 +121,12 @@ class Batch:
     def clear(self):
         self.L.hm_batch_clear(self.h)
 
-    def set_profiling(self, on=True):
-        check(self.L.hm_batch_set_profiling(self.h, 1 if on else 0))
+    def set_profiling(self, slots=1):
+        check(self.L.hm_batch_set_profiling(self.h, int(slots)))
 
-    def timings_ms(self):
+    def timings_ms(self, slot=0):
         ms = (C.c_float * 3)()
-        check(self.L.hm_batch_get_timings(self.h, ms))
+        check(self.L.hm_batch_get_timings(self.h, slot, ms))
         return [ms[0], ms[1], ms[2]]
 
     def algorithmic_bytes(self):

@@ -61,9 +61,9 @@ struct hm_batch {
   bool uploaded = false;
   size_t total_pixels = 0;
   // optional per-kernel timing with HIP events on the launch stream (bench / profiling)
-  bool profiling = false;
-  std::vector<hipEvent_t> events;   // 4 per class: before recon, after recon, after deblock, after sao
-  int events_used = 0;
+  int profiling = 0;                // number of timing slots (0 = off)
+  std::vector<hipEvent_t> events;   // per slot, 4 per class: before recon, after recon, after deblock, after sao
+  long exec_count = 0;
   ~hm_batch() { for (hipEvent_t e : events) hipEventDestroy(e); }
 };
 
@@ -232,16 +232,18 @@ int hm_batch_execute(hm_batch* b, int stages, void* stream)
   if (!b->uploaded) return hm_fail(HM_ERR_INVALID_ARG, "hm_batch_upload() has not been called");
   hipStream_t s = (hipStream_t)stream;
   const hm_dev_pic* d = (const hm_dev_pic*)b->d_desc.p;
-  b->events_used = 0;
+  const size_t per_slot = b->classes.size() * 4;
+  size_t ev_next = 0;
   if (b->profiling) {
-    while (b->events.size() < b->classes.size() * 4) {
+    ev_next = (size_t)(b->exec_count % b->profiling) * per_slot;
+    while (b->events.size() < per_slot * (size_t)b->profiling) {
       hipEvent_t ev;
       hipError_t e = hipEventCreate(&ev);
       if (e != hipSuccess) return hm_check_hip(e, "hipEventCreate");
       b->events.push_back(ev);
     }
   }
-  auto mark = [&]() { if (b->profiling) hipEventRecord(b->events[b->events_used++], s); };
+  auto mark = [&]() { if (b->profiling) hipEventRecord(b->events[ev_next++], s); };
   for (const Class& c : b->classes) {
     const hm_dev_pic* dc = d + c.desc_offset;
     const int n = (int)c.items.size();
@@ -258,26 +260,31 @@ int hm_batch_execute(hm_batch* b, int stages, void* stream)
     if (rc) return rc;
     mark();
   }
+  b->exec_count++;
   return HM_OK;
 }
 
-int hm_batch_set_profiling(hm_batch* b, int enable)
+int hm_batch_set_profiling(hm_batch* b, int slots)
 {
-  if (!b) return hm_fail(HM_ERR_INVALID_ARG, "null batch");
-  b->profiling = enable != 0;
+  if (!b || slots < 0 || slots > 4096) return hm_fail(HM_ERR_INVALID_ARG, "bad argument");
+  b->profiling = slots;
+  b->exec_count = 0;
   return HM_OK;
 }
 
-// Kernel times (ms) of the last hm_batch_execute: recon, deblock (both passes), SAO+paste.
-// Synchronises on the recorded events.
-int hm_batch_get_timings(hm_batch* b, float ms[3])
+// Kernel times (ms) of the execute call recorded in `slot` (= call index modulo the slot count):
+// recon, deblock (both passes), SAO+paste.  Synchronises on the recorded events.
+int hm_batch_get_timings(hm_batch* b, int slot, float ms[3])
 {
   if (!b || !ms) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
   ms[0] = ms[1] = ms[2] = 0.f;
-  if (!b->profiling || b->events_used == 0) return hm_fail(HM_ERR_INVALID_ARG, "profiling not enabled or nothing executed");
-  hipError_t e = hipEventSynchronize(b->events[b->events_used - 1]);
+  const size_t per_slot = b->classes.size() * 4;
+  if (!b->profiling || slot < 0 || slot >= b->profiling || slot >= b->exec_count || b->events.size() < per_slot * (size_t)(slot + 1))
+    return hm_fail(HM_ERR_INVALID_ARG, "profiling not enabled or slot not recorded");
+  const size_t base = (size_t)slot * per_slot;
+  hipError_t e = hipEventSynchronize(b->events[base + per_slot - 1]);
   if (e != hipSuccess) return hm_check_hip(e, "hipEventSynchronize");
-  for (int i = 0; i + 3 < b->events_used; i += 4)
+  for (size_t i = base; i + 3 < base + per_slot; i += 4)
     for (int k = 0; k < 3; k++) {
       float t = 0.f;
       e = hipEventElapsedTime(&t, b->events[i + k], b->events[i + k + 1]);

@@ -138,10 +138,12 @@ HM_API int  hm_batch_upload(hm_batch* b, void* stream);
  * stages: bit0 = deblocking, bit1 = SAO; pass 3.  Pictures of a batch are independent: this is
  * the data-parallel replacement of the reference's std::async tile fan-out (context.cc:2361-2401). */
 HM_API int  hm_batch_execute(hm_batch* b, int stages, void* stream);
-/* per-kernel timing with HIP events on the launch stream (off by default) */
-HM_API int  hm_batch_set_profiling(hm_batch* b, int enable);
-/* kernel times in ms of the last execute: [0] reconstruction, [1] deblocking (V+H), [2] SAO+paste */
-HM_API int  hm_batch_get_timings(hm_batch* b, float ms[3]);
+/* per-kernel timing with HIP events on the launch stream: `slots` execute calls are kept (ring),
+ * 0 switches it off (default) */
+HM_API int  hm_batch_set_profiling(hm_batch* b, int slots);
+/* kernel times in ms of the execute call in `slot` (call index mod slots):
+ * [0] reconstruction, [1] deblocking (V+H), [2] SAO+paste.  Waits for that call to finish. */
+HM_API int  hm_batch_get_timings(hm_batch* b, int slot, float ms[3]);
 /* algorithmic bytes of the queued pictures: command streams read, reconstructed samples written */
 HM_API int  hm_batch_algorithmic_bytes(const hm_batch* b, uint64_t* stream_bytes, uint64_t* sample_bytes);
 
