@@ -34,9 +34,11 @@ namespace {
 
 // LDS traffic inside a wave needs no barrier (DS ops of one wave execute in order); this keeps
 // the compiler from reordering across the hand-off and drains lgkmcnt.
+// A wavefront-scope fence is a pure ordering point (no vmcnt drain: outstanding global stores of
+// the metadata maps / prefetches stay in flight).
 #define WAVE_SYNC()                                          \
   do {                                                       \
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  \
     __builtin_amdgcn_wave_barrier();                         \
   } while (0)
 
@@ -223,7 +225,7 @@ __device__ void predict(const WaveCtx<Pix>& w, int c, int x0, int y0, int nT, in
 // ---- dequantisation + inverse transform + add (transform.cc:386-689, fallback-dct.cc) --------------------
 template <typename Pix>
 __device__ void residual_add(const WaveCtx<Pix>& w, int c, int x0, int y0, int nT, int log2, const hm_tu t,
-                             const hm_coeff* __restrict__ cf, int bit_depth, int lane)
+                             const hm_coeff* __restrict__ cf, const hm_coeff pre, int bit_depth, int lane)
 {
   const int npx = nT * nT;
   for (int p = lane; p < npx; p += 64) w.coeff[p] = 0;
@@ -234,7 +236,7 @@ __device__ void residual_add(const WaveCtx<Pix>& w, int c, int x0, int y0, int n
   const int32_t fact = c_level_scale[qP % 6] << (qP / 6);
   int mx = 0, my = 0;
   for (int i = lane; i < (int)t.n_coeff; i += 64) {
-    const hm_coeff pr = cf[i];
+    const hm_coeff pr = i < 64 ? pre : cf[i]; // the first 64 pairs were fetched before the prediction started
     const int32_t prod = (int32_t)((uint32_t)(int32_t)pr.value * (uint32_t)fact + (uint32_t)offset); // wraps like the reference (Q3)
     w.coeff[pr.pos] = (int16_t)clip3i(-32768, 32767, prod >> bdShift);
     const int px = pr.pos & (nT - 1), py = pr.pos >> log2;
@@ -301,7 +303,7 @@ __device__ void residual_add(const WaveCtx<Pix>& w, int c, int x0, int y0, int n
 
 // =====================================================================================================
 template <typename Pix>
-__global__ __launch_bounds__(1024) void k_recon(const hm_dev_pic* __restrict__ pics, int per_wave_bytes)
+__global__ __launch_bounds__(512) void k_recon(const hm_dev_pic* __restrict__ pics, int per_wave_bytes)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const hm_dev_pic& dp = pics[blockIdx.x];
@@ -390,8 +392,16 @@ __global__ __launch_bounds__(1024) void k_recon(const hm_dev_pic* __restrict__ p
       const hm_ctb cb = ctbs[cx + row * ctb_w];
       const hm_slice sl = slices[cb.slice_idx];
       const int deblock_en = !sl.deblocking_disabled;
+      // software pipeline over the records: record k+1 and the first coefficient pairs of record k
+      // are in flight while block k is predicted, so no HBM/L2 latency sits on the dependency chain
+      hm_tu t_next;
+      if (cb.tu_count) t_next = tus[cb.tu_first];
       for (int k = 0; k < (int)cb.tu_count; k++) {
-        const hm_tu t = tus[cb.tu_first + k];
+        const hm_tu t = t_next;
+        if (k + 1 < (int)cb.tu_count) t_next = tus[cb.tu_first + k + 1];
+        hm_coeff pre;
+        pre.pos = 0; pre.value = 0;
+        if ((t.info & HM_TU_CBF) && lane < (int)t.n_coeff) pre = coeffs[t.coeff_first + lane];
         const int log2 = t.info & HM_TU_LOG2_MASK, nT = 1 << log2;
         const int c = (t.info >> HM_TU_CIDX_SHIFT) & 3;
         const int x0 = t.x, y0 = t.y;
@@ -405,7 +415,7 @@ __global__ __launch_bounds__(1024) void k_recon(const hm_dev_pic* __restrict__ p
         predict(w, c, x0, y0, nT, log2, t.pred_mode, b, bd, lane);
         WAVE_SYNC();
         if (t.info & HM_TU_CBF) {
-          residual_add(w, c, x0, y0, nT, log2, t, coeffs + t.coeff_first, bd, lane);
+          residual_add(w, c, x0, y0, nT, log2, t, coeffs + t.coeff_first, pre, bd, lane);
           WAVE_SYNC();
         }
         if (c == 0) { // deblocking metadata (deblock.cc:31-62): transform edges + QpY
@@ -479,7 +489,7 @@ extern "C" int hm_launch_recon(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   // useful waves: a CTU row can start once the row above is two CTUs ahead
   int nw = (max_ctb_w + 1) / 2;
   if (nw > max_ctb_h) nw = max_ctb_h;
-  if (nw > 16) nw = 16;
+  if (nw > 8) nw = 8; // 512-thread workgroups: 256 VGPRs per lane available, no spills
   if (nw < 1) nw = 1;
   const int lds_budget = 64 * 1024; // keep <= 64 KiB so that >= 2 workgroups share a CU's 160 KiB
   while (nw > 1 && fixed + nw * pw > lds_budget) nw--;
