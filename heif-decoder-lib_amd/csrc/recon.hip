@@ -67,12 +67,15 @@ __constant__ int8_t c_dst[4][4] = {{29, 55, 74, 84}, {74, 74, 0, -74}, {84, -29,
 __constant__ int8_t c_dct_mag[33] = {64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
                                      61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0};
 
+// Per-block view of the wave's LDS staging for ONE colour plane.  Deliberately no arrays indexed
+// by the (run-time) component: such arrays would live in scratch memory and put a global-memory
+// round trip on every neighbour fetch.
 template <typename Pix>
 struct WaveCtx {
-  Pix* blk[3];      // CTU samples, pitch = ctb size of the plane
-  int bp[3];        // pitch in samples
-  Pix* top[3];      // top[c][1 + x] = sample at (x, -1) relative to the CTU, x = -1 .. 2*ctbW-1
-  Pix* left[3];     // left[c][y]   = sample at (-1, y)
+  Pix* blk;         // CTU samples of the plane
+  int bp;           // its pitch in samples
+  const Pix* top;   // top[1 + x] = sample at (x, -1) relative to the CTU, x = -1 .. 2*ctbW-1
+  const Pix* left;  // left[y]    = sample at (-1, y)
   int16_t* coeff;   // 32*32
   int16_t* tmp;     // 32*32
   int16_t* bA;      // reference samples, centre at index 64 (range -64..64)
@@ -81,11 +84,11 @@ struct WaveCtx {
 };
 
 template <typename Pix>
-__device__ __forceinline__ int nb(const WaveCtx<Pix>& w, int c, int x, int y)
+__device__ __forceinline__ int nb(const WaveCtx<Pix>& w, int /*c*/, int x, int y)
 {
-  if (y < 0) return w.top[c][x + 1];
-  if (x < 0) return w.left[c][y];
-  return w.blk[c][y * w.bp[c] + x];
+  if (y < 0) return w.top[x + 1];
+  if (x < 0) return w.left[y];
+  return w.blk[y * w.bp + x];
 }
 
 // ---- reference samples (intrapred.h:620-836; equals H.265 8.4.4.2.2) ---------------------------------
@@ -167,8 +170,8 @@ template <typename Pix>
 __device__ void predict(const WaveCtx<Pix>& w, int c, int x0, int y0, int nT, int log2, int mode, const int16_t* b,
                         int bit_depth, int lane)
 {
-  Pix* dst = w.blk[c] + y0 * w.bp[c] + x0;
-  const int pitch = w.bp[c];
+  Pix* dst = w.blk + y0 * w.bp + x0;
+  const int pitch = w.bp;
   const int maxv = (1 << bit_depth) - 1;
   const int npx = nT * nT;
   if (mode == 0) {
@@ -246,8 +249,8 @@ __device__ void residual_add(const WaveCtx<Pix>& w, int c, int x0, int y0, int n
   mx = wave_max(mx);
   my = wave_max(my);
   WAVE_SYNC();
-  Pix* dst = w.blk[c] + y0 * w.bp[c] + x0;
-  const int pitch = w.bp[c];
+  Pix* dst = w.blk + y0 * w.bp + x0;
+  const int pitch = w.bp;
   const int maxv = (1 << bit_depth) - 1;
 
   if (t.info & HM_TU_TSKIP) { // transform.cc:566-643
@@ -314,7 +317,8 @@ __global__ __launch_bounds__(512) void k_recon(const hm_dev_pic* __restrict__ pi
   const hm_tu* tus = reinterpret_cast<const hm_tu*>(blob + H->off_tus);
   const hm_coeff* coeffs = reinterpret_cast<const hm_coeff*>(blob + H->off_coeffs);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, NW = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform by construction: lets the compiler keep row state in SGPRs
   const int ctb_w = dp.ctb_w, ctb_h = dp.ctb_h, log2_ctb = dp.log2_ctb, ctb = 1 << log2_ctb;
   const int sw = 2, sh = dp.chroma_format == 1 ? 2 : 1;
   const int bd = dp.bit_depth;
@@ -340,29 +344,23 @@ __global__ __launch_bounds__(512) void k_recon(const hm_dev_pic* __restrict__ pi
   }
   __syncthreads(); // the only workgroup barrier: all waves still converge here
 
-  WaveCtx<Pix> w;
-  {
-    uint8_t* p = wbase;
-    w.coeff = reinterpret_cast<int16_t*>(p); p += 2048;
-    w.tmp = reinterpret_cast<int16_t*>(p); p += 2048;
-    w.bA = reinterpret_cast<int16_t*>(p); p += 272;
-    w.bB = reinterpret_cast<int16_t*>(p); p += 272;
-    w.blk[0] = reinterpret_cast<Pix*>(p); p += (size_t)ctb * ctb * sizeof(Pix);
-    w.blk[1] = reinterpret_cast<Pix*>(p); p += (size_t)cw_c * ch_c * sizeof(Pix);
-    w.blk[2] = reinterpret_cast<Pix*>(p); p += (size_t)cw_c * ch_c * sizeof(Pix);
-    w.top[0] = reinterpret_cast<Pix*>(p); p += (size_t)((2 * ctb + 1 + 7) & ~7) * sizeof(Pix);
-    w.top[1] = reinterpret_cast<Pix*>(p); p += (size_t)((2 * cw_c + 1 + 7) & ~7) * sizeof(Pix);
-    w.top[2] = reinterpret_cast<Pix*>(p); p += (size_t)((2 * cw_c + 1 + 7) & ~7) * sizeof(Pix);
-    w.left[0] = reinterpret_cast<Pix*>(p); p += (size_t)ctb * sizeof(Pix);
-    w.left[1] = reinterpret_cast<Pix*>(p); p += (size_t)ch_c * sizeof(Pix);
-    w.left[2] = reinterpret_cast<Pix*>(p); p += (size_t)ch_c * sizeof(Pix);
-    w.bp[0] = ctb; w.bp[1] = cw_c; w.bp[2] = cw_c;
-    w.dct = dct;
-  }
+  // per-wave LDS pointers as individually named scalars (see WaveCtx)
+  uint8_t* lp = wbase;
+  int16_t* const l_coeff = reinterpret_cast<int16_t*>(lp); lp += 2048;
+  int16_t* const l_tmp = reinterpret_cast<int16_t*>(lp); lp += 2048;
+  int16_t* const l_bA = reinterpret_cast<int16_t*>(lp); lp += 272;
+  int16_t* const l_bB = reinterpret_cast<int16_t*>(lp); lp += 272;
+  Pix* const blk0 = reinterpret_cast<Pix*>(lp); lp += (size_t)ctb * ctb * sizeof(Pix);
+  Pix* const blk1 = reinterpret_cast<Pix*>(lp); lp += (size_t)cw_c * ch_c * sizeof(Pix);
+  Pix* const blk2 = reinterpret_cast<Pix*>(lp); lp += (size_t)cw_c * ch_c * sizeof(Pix);
+  Pix* const top0 = reinterpret_cast<Pix*>(lp); lp += (size_t)((2 * ctb + 1 + 7) & ~7) * sizeof(Pix);
+  Pix* const top1 = reinterpret_cast<Pix*>(lp); lp += (size_t)((2 * cw_c + 1 + 7) & ~7) * sizeof(Pix);
+  Pix* const top2 = reinterpret_cast<Pix*>(lp); lp += (size_t)((2 * cw_c + 1 + 7) & ~7) * sizeof(Pix);
+  Pix* const left0 = reinterpret_cast<Pix*>(lp); lp += (size_t)ctb * sizeof(Pix);
+  Pix* const left1 = reinterpret_cast<Pix*>(lp); lp += (size_t)ch_c * sizeof(Pix);
+  Pix* const left2 = reinterpret_cast<Pix*>(lp); lp += (size_t)ch_c * sizeof(Pix);
   const int strong = (dp.flags & HM_PIC_STRONG_INTRA_SMOOTHING) != 0;
-  const int planeW[3] = {dp.width, dp.width / sw, dp.width / sw};
-  const int planeH[3] = {dp.height, dp.height / sh, dp.height / sh};
-  const int cbw[3] = {ctb, cw_c, cw_c}, cbh[3] = {ctb, ch_c, ch_c};
+  const int planeWc = dp.width / sw, planeHc = dp.height / sh;
 
   for (int row = wave; row < ctb_h; row += NW) {
     for (int cx = 0; cx < ctb_w; cx++) {
@@ -374,19 +372,21 @@ __global__ __launch_bounds__(512) void k_recon(const hm_dev_pic* __restrict__ pi
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       }
       // ---- stage the row of samples above this CTU (and above-right) into LDS ----
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
-        const int ncols = 2 * cbw[c] + 1;
-        const int yy = row * cbh[c] - 1;
-        const int xbase = cx * cbw[c] - 1;
-        const Pix* src = reinterpret_cast<const Pix*>(dp.plane[c] + (size_t)(yy < 0 ? 0 : yy) * dp.pitch[c]);
+      auto stage_top = [&](Pix* top, const uint8_t* plane, int pitch, int bw, int bh, int pw) {
+        const int ncols = 2 * bw + 1;
+        const int yy = row * bh - 1;
+        const int xbase = cx * bw - 1;
+        const Pix* src = reinterpret_cast<const Pix*>(plane + (size_t)(yy < 0 ? 0 : yy) * pitch);
         for (int i = lane; i < ncols; i += 64) {
           const int xx = xbase + i;
           Pix v = 0;
-          if (yy >= 0 && xx >= 0 && xx < planeW[c]) v = src[xx];
-          w.top[c][i] = v;
+          if (yy >= 0 && xx >= 0 && xx < pw) v = src[xx];
+          top[i] = v;
         }
-      }
+      };
+      stage_top(top0, dp.plane[0], dp.pitch[0], ctb, ctb, dp.width);
+      stage_top(top1, dp.plane[1], dp.pitch[1], cw_c, ch_c, planeWc);
+      stage_top(top2, dp.plane[2], dp.pitch[2], cw_c, ch_c, planeWc);
       WAVE_SYNC();
 
       const hm_ctb cb = ctbs[cx + row * ctb_w];
@@ -405,9 +405,15 @@ __global__ __launch_bounds__(512) void k_recon(const hm_dev_pic* __restrict__ pi
         const int log2 = t.info & HM_TU_LOG2_MASK, nT = 1 << log2;
         const int c = (t.info >> HM_TU_CIDX_SHIFT) & 3;
         const int x0 = t.x, y0 = t.y;
+        WaveCtx<Pix> w;
+        w.blk = c == 0 ? blk0 : (c == 1 ? blk1 : blk2);
+        w.bp = c == 0 ? ctb : cw_c;
+        w.top = c == 0 ? top0 : (c == 1 ? top1 : top2);
+        w.left = c == 0 ? left0 : (c == 1 ? left1 : left2);
+        w.coeff = l_coeff; w.tmp = l_tmp; w.bA = l_bA; w.bB = l_bB; w.dct = dct;
         build_border(w, t, c, x0, y0, nT, bd, lane);
         WAVE_SYNC();
-        const int16_t* b = w.bA + 64;
+        const int16_t* b = l_bA + 64;
         if (c == 0) {
           b = filter_border(w, nT, t.pred_mode, strong, bd, lane);
           WAVE_SYNC();
@@ -421,7 +427,7 @@ __global__ __launch_bounds__(512) void k_recon(const hm_dev_pic* __restrict__ pi
         if (c == 0) { // deblocking metadata (deblock.cc:31-62): transform edges + QpY
           const int n4 = nT >> 2;
           if (lane < n4 * n4) {
-            const int i = lane & (n4 - 1), j = lane / n4;
+            const int i = lane & (n4 - 1), j = lane >> (log2 - 2);
             const int bx = ((cx << log2_ctb) + x0) / 4 + i, by = ((row << log2_ctb) + y0) / 4 + j;
             if (bx < dp.w4 && by < dp.h4) {
               const int left_ok = x0 > 0 ? 1 : (cb.flags & HM_CTB_DEBLOCK_LEFT) != 0;
@@ -437,26 +443,27 @@ __global__ __launch_bounds__(512) void k_recon(const hm_dev_pic* __restrict__ pi
       }
 
       // ---- write the finished CTU to the picture (coalesced 4-byte stores) and keep its right column ----
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
-        const int xo = cx * cbw[c], yo = row * cbh[c];
-        const int vw = (planeW[c] - xo) < cbw[c] ? (planeW[c] - xo) : cbw[c]; // valid part inside the picture
-        const int vh = (planeH[c] - yo) < cbh[c] ? (planeH[c] - yo) : cbh[c];
+      auto flush_plane = [&](const Pix* blk, int bp, uint8_t* plane, int pitch, int bw, int bh, int pw, int ph) {
+        const int xo = cx * bw, yo = row * bh;
+        const int vw = (pw - xo) < bw ? (pw - xo) : bw; // valid part inside the picture
+        const int vh = (ph - yo) < bh ? (ph - yo) : bh;
         constexpr int PPW = 4 / sizeof(Pix); // samples per 32-bit word
-        const int wpr = cbw[c] / PPW;
+        const int l2wpr = 31 - __builtin_clz(bw / PPW); // words per row is a power of two
         const int vwords = vw / PPW;
-        for (int p = lane; p < wpr * vh; p += 64) {
-          const int r = p / wpr, q = p - r * wpr;
+        for (int p = lane; p < (vh << l2wpr); p += 64) {
+          const int r = p >> l2wpr, q = p & ((1 << l2wpr) - 1);
           if (q < vwords) {
-            const uint32_t word = *reinterpret_cast<const uint32_t*>(w.blk[c] + r * w.bp[c] + q * PPW);
-            *reinterpret_cast<uint32_t*>(dp.plane[c] + (size_t)(yo + r) * dp.pitch[c] + (size_t)(xo + q * PPW) * sizeof(Pix)) = word;
+            const uint32_t word = *reinterpret_cast<const uint32_t*>(blk + r * bp + q * PPW);
+            *reinterpret_cast<uint32_t*>(plane + (size_t)(yo + r) * pitch + (size_t)(xo + q * PPW) * sizeof(Pix)) = word;
           }
         }
-      }
+      };
+      flush_plane(blk0, ctb, dp.plane[0], dp.pitch[0], ctb, ctb, dp.width, dp.height);
+      flush_plane(blk1, cw_c, dp.plane[1], dp.pitch[1], cw_c, ch_c, planeWc, planeHc);
+      flush_plane(blk2, cw_c, dp.plane[2], dp.pitch[2], cw_c, ch_c, planeWc, planeHc);
       WAVE_SYNC();
-#pragma unroll
-      for (int c = 0; c < 3; c++)
-        for (int r = lane; r < cbh[c]; r += 64) w.left[c][r] = w.blk[c][r * w.bp[c] + cbw[c] - 1];
+      for (int r = lane; r < ctb; r += 64) left0[r] = blk0[r * ctb + ctb - 1];
+      for (int r = lane; r < ch_c; r += 64) { left1[r] = blk1[r * cw_c + cw_c - 1]; left2[r] = blk2[r * cw_c + cw_c - 1]; }
       // ---- publish progress ----
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) __hip_atomic_store(&progress[row], cx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
