@@ -81,6 +81,7 @@ struct WaveCtx {
   int16_t* bA;      // reference samples, centre at index 64 (range -64..64)
   int16_t* bB;      // filtered reference samples
   const int8_t* dct; // 32x32 basis in LDS
+  const int16_t* tab; // small tables in LDS: [0..34] intraPredAngle, [35..49] invAngle, [50..55] levelScale, [56..71] DST basis
 };
 
 template <typename Pix>
@@ -197,8 +198,8 @@ __device__ void predict(const WaveCtx<Pix>& w, int c, int x0, int y0, int nT, in
     }
   }
   else {
-    const int angle = c_intra_angle[mode];
-    const int inv = (mode >= 11 && mode <= 25) ? c_inv_angle[mode - 11] : 0;
+    const int angle = w.tab[mode];
+    const int inv = (mode >= 11 && mode <= 25) ? w.tab[35 + mode - 11] : 0;
     const bool vert = mode >= 18;
     for (int p = lane; p < npx; p += 64) {
       const int x = p & (nT - 1), y = p >> log2;
@@ -236,7 +237,7 @@ __device__ void residual_add(const WaveCtx<Pix>& w, int c, int x0, int y0, int n
   const int qP = t.qp;
   const int bdShift = bit_depth + log2 - 9;
   const int32_t offset = 1 << (bdShift - 1);
-  const int32_t fact = c_level_scale[qP % 6] << (qP / 6);
+  const int32_t fact = (int32_t)w.tab[50 + qP % 6] << (qP / 6);
   int mx = 0, my = 0;
   for (int i = lane; i < (int)t.n_coeff; i += 64) {
     const hm_coeff pr = i < 64 ? pre : cf[i]; // the first 64 pairs were fetched before the prediction started
@@ -270,7 +271,7 @@ __device__ void residual_add(const WaveCtx<Pix>& w, int c, int x0, int y0, int n
       const int cc = lane & 3, i = lane >> 2;
       int sum = 0;
 #pragma unroll
-      for (int j = 0; j < 4; j++) sum += c_dst[j][i] * w.coeff[cc + j * 4];
+      for (int j = 0; j < 4; j++) sum += w.tab[56 + j * 4 + i] * w.coeff[cc + j * 4];
       w.tmp[i * 4 + cc] = (int16_t)clip3i(-32768, 32767, (sum + 64) >> 7);
     }
     WAVE_SYNC();
@@ -278,7 +279,7 @@ __device__ void residual_add(const WaveCtx<Pix>& w, int c, int x0, int y0, int n
       const int i = lane & 3, y = lane >> 2;
       int sum = 0;
 #pragma unroll
-      for (int j = 0; j < 4; j++) sum += c_dst[j][i] * w.tmp[y * 4 + j];
+      for (int j = 0; j < 4; j++) sum += w.tab[56 + j * 4 + i] * w.tmp[y * 4 + j];
       const int out = clip3i(-32768, 32767, (sum + rnd2) >> postShift);
       dst[y * pitch + i] = (Pix)clip3i(0, maxv, (int)dst[y * pitch + i] + out);
     }
@@ -328,7 +329,8 @@ __global__ __launch_bounds__(512) void k_recon(const hm_dev_pic* __restrict__ pi
   int* progress = reinterpret_cast<int*>(lds);
   const int prog_bytes = ((ctb_h * 4) + 15) & ~15;
   int8_t* dct = reinterpret_cast<int8_t*>(lds + prog_bytes);
-  uint8_t* wbase = lds + prog_bytes + 1024 + (size_t)wave * per_wave_bytes;
+  int16_t* tab = reinterpret_cast<int16_t*>(lds + prog_bytes + 1024);
+  uint8_t* wbase = lds + prog_bytes + 1024 + 256 + (size_t)wave * per_wave_bytes;
 
   for (int i = tid; i < ctb_h; i += blockDim.x) progress[i] = 0;
   for (int i = tid; i < 1024; i += blockDim.x) {
@@ -341,6 +343,14 @@ __global__ __launch_bounds__(512) void k_recon(const hm_dev_pic* __restrict__ pi
     else if (m <= 96) v = -c_dct_mag[m - 64];
     else v = c_dct_mag[128 - m];
     dct[i] = (int8_t)v;
+  }
+  for (int i = tid; i < 72; i += blockDim.x) {
+    int v;
+    if (i < 35) v = c_intra_angle[i];
+    else if (i < 50) v = c_inv_angle[i - 35];
+    else if (i < 56) v = c_level_scale[i - 50];
+    else v = c_dst[(i - 56) >> 2][(i - 56) & 3];
+    tab[i] = (int16_t)v;
   }
   __syncthreads(); // the only workgroup barrier: all waves still converge here
 
@@ -410,7 +420,7 @@ __global__ __launch_bounds__(512) void k_recon(const hm_dev_pic* __restrict__ pi
         w.bp = c == 0 ? ctb : cw_c;
         w.top = c == 0 ? top0 : (c == 1 ? top1 : top2);
         w.left = c == 0 ? left0 : (c == 1 ? left1 : left2);
-        w.coeff = l_coeff; w.tmp = l_tmp; w.bA = l_bA; w.bB = l_bB; w.dct = dct;
+        w.coeff = l_coeff; w.tmp = l_tmp; w.bA = l_bA; w.bB = l_bB; w.dct = dct; w.tab = tab;
         build_border(w, t, c, x0, y0, nT, bd, lane);
         WAVE_SYNC();
         const int16_t* b = l_bA + 64;
@@ -492,7 +502,7 @@ extern "C" int hm_launch_recon(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   const int ctb = 1 << log2_ctb;
   const int pix_bytes = bit_depth > 8 ? 2 : 1;
   const int pw = per_wave_lds(ctb, chroma_format, pix_bytes);
-  const int fixed = (((max_ctb_h * 4) + 15) & ~15) + 1024;
+  const int fixed = (((max_ctb_h * 4) + 15) & ~15) + 1024 + 256;
   // useful waves: a CTU row can start once the row above is two CTUs ahead
   int nw = (max_ctb_w + 1) / 2;
   if (nw > max_ctb_h) nw = max_ctb_h;
