@@ -199,11 +199,16 @@ int hm_batch_upload(hm_batch* b, void* stream)
       const int sw = 2;
       for (int p = 0; p < 3; p++) {
         int chan_w = t.canvas_width, chan_h = t.canvas_height, cx0 = t.x0, cy0 = t.y0;
-        int pw = h.width, ph = h.height;
+        // the decoder plugin hands libheif the conformance-window crop of the coded picture
+        // (de265_get_image_width/height, decoder_libde265.cc:88-157)
+        int pw = h.width - h.crop_left - h.crop_right, ph = h.height - h.crop_top - h.crop_bottom;
+        d.src_x[p] = h.crop_left; d.src_y[p] = h.crop_top;
+        if (pw <= 0 || ph <= 0) return hm_fail(HM_ERR_BITSTREAM, "empty conformance window");
         if (p > 0) {
           chan_w = (t.canvas_width + 1) / 2; cx0 = (t.x0 + 1) / 2;
           if (h.chroma_format == 1) { chan_h = (t.canvas_height + 1) / 2; cy0 = (t.y0 + 1) / 2; }
-          pw = h.width / sw; ph = h.height / sh;
+          pw /= sw; ph /= sh;
+          d.src_x[p] /= sw; d.src_y[p] /= sh;
         }
         if (chan_w <= cx0 || chan_h <= cy0) return hm_fail(HM_ERR_INVALID_ARG, "tile origin outside the canvas (invalid grid data)");
         d.copy_w[p] = std::min(pw, chan_w - cx0);

@@ -242,52 +242,57 @@ __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict_
   const int groups = (cw + 3) >> 2;
   const int item = blockIdx.x * 256 + threadIdx.x;
   if (item >= groups * chh) return;
-  const int yy = item / groups, x4 = (item - yy * groups) << 2;
+  const int yd = item / groups, x4 = (item - yd * groups) << 2; // destination coordinates
   const PicView v = view(dp);
   const int sw = c ? 2 : 1, sh = c ? (dp.chroma_format == 1 ? 2 : 1) : 1;
   const int W = dp.width / sw, Hh = dp.height / sh;
-  const int nSW = (1 << dp.log2_ctb) / sw, nSH = (1 << dp.log2_ctb) / sh;
+  const int l2w = dp.log2_ctb - (c ? 1 : 0), l2h = dp.log2_ctb - (sh == 2 ? 1 : 0); // CTB size of this plane (log2)
   const int bd = dp.bit_depth, maxv = (1 << bd) - 1;
   const uint8_t* plane = dp.plane[c];
   const int pitch = dp.pitch[c];
-  const int cx = x4 / nSW, cy = yy / nSH; // 4 | nSW, so the 4 samples share a CTB
-  const hm_ctb& cb = v.ctbs[cx + cy * dp.ctb_w];
-  const hm_slice& sl = v.slices[cb.slice_idx];
-  const bool sao_on = apply_sao && (dp.flags & HM_PIC_SAO_ENABLED) && (c == 0 ? sl.sao_luma : sl.sao_chroma);
-  const hm_sao s = cb.sao[c];
-  const int type = sao_on ? s.type : 0;
+  const int yy = yd + dp.src_y[c];                                // source row inside the coded picture
+  const int cy = yy >> l2h;
   const Pix* row = reinterpret_cast<const Pix*>(plane + (size_t)yy * pitch);
   int out[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    const int xx = x4 + k;
-    int val = xx < W ? row[xx] : 0;
-    if (type == 1 && xx < W) { // band offset
-      const int bi = ((val >> (bd - 5)) - s.band_position) & 31;
-      if (bi < 4) val = clip3i(0, maxv, val + s.offset[bi]);
-    }
-    else if (type == 2 && xx < W) { // edge offset
-      const int cl = s.eo_class;
-      const int hx0 = cl == 1 ? 0 : (cl == 3 ? 1 : -1), hx1 = -hx0;
-      const int vy0 = cl == 0 ? 0 : -1, vy1 = -vy0;
-      bool ok = true;
-#pragma unroll
-      for (int n = 0; n < 2; n++) {
-        const int xS = xx + (n ? hx1 : hx0), yS = yy + (n ? vy1 : vy0);
-        if (xS < 0 || yS < 0 || xS >= W || yS >= Hh) { ok = false; break; }
-        const int dxc = xS / nSW - cx, dyc = yS / nSH - cy;
-        if (dxc != 0 || dyc != 0) {
-          const int k8 = (dyc + 1) * 3 + (dxc + 1); // 0..8 without the centre
-          const int bit = k8 < 4 ? k8 : k8 - 1;
-          if (!(cb.sao_nb_mask & (1u << bit))) ok = false;
-        }
+    const int xx = x4 + k + dp.src_x[c];
+    int val = 0;
+    if (xx < W && x4 + k < cw) {
+      val = row[xx];
+      const int cx = xx >> l2w;
+      const hm_ctb& cb = v.ctbs[cx + cy * dp.ctb_w];
+      const hm_slice& sl = v.slices[cb.slice_idx];
+      const bool sao_on = apply_sao && (dp.flags & HM_PIC_SAO_ENABLED) && (c == 0 ? sl.sao_luma : sl.sao_chroma);
+      const hm_sao s = cb.sao[c];
+      const int type = sao_on ? s.type : 0;
+      if (type == 1) { // band offset (fallback-postfilter.h:218-241)
+        const int bi = ((val >> (bd - 5)) - s.band_position) & 31;
+        if (bi < 4) val = clip3i(0, maxv, val + s.offset[bi]);
       }
-      if (ok) {
-        const int a = reinterpret_cast<const Pix*>(plane + (size_t)(yy + vy0) * pitch)[xx + hx0];
-        const int b = reinterpret_cast<const Pix*>(plane + (size_t)(yy + vy1) * pitch)[xx + hx1];
-        const int e = isign_(val - a) + isign_(val - b);
-        const int o = e == -2 ? s.offset[0] : (e == -1 ? s.offset[1] : (e == 1 ? s.offset[2] : (e == 2 ? s.offset[3] : 0)));
-        val = clip3i(0, maxv, val + o);
+      else if (type == 2) { // edge offset (sao.cc:336-424)
+        const int cl = s.eo_class;
+        const int hx0 = cl == 1 ? 0 : (cl == 3 ? 1 : -1), hx1 = -hx0;
+        const int vy0 = cl == 0 ? 0 : -1, vy1 = -vy0;
+        bool ok = true;
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+          const int xS = xx + (n ? hx1 : hx0), yS = yy + (n ? vy1 : vy0);
+          if (xS < 0 || yS < 0 || xS >= W || yS >= Hh) { ok = false; break; }
+          const int dxc = (xS >> l2w) - cx, dyc = (yS >> l2h) - cy;
+          if (dxc != 0 || dyc != 0) {
+            const int k8 = (dyc + 1) * 3 + (dxc + 1); // 0..8 without the centre
+            const int bit = k8 < 4 ? k8 : k8 - 1;
+            if (!(cb.sao_nb_mask & (1u << bit))) ok = false;
+          }
+        }
+        if (ok) {
+          const int a = reinterpret_cast<const Pix*>(plane + (size_t)(yy + vy0) * pitch)[xx + hx0];
+          const int b = reinterpret_cast<const Pix*>(plane + (size_t)(yy + vy1) * pitch)[xx + hx1];
+          const int e = isign_(val - a) + isign_(val - b);
+          const int o = e == -2 ? s.offset[0] : (e == -1 ? s.offset[1] : (e == 1 ? s.offset[2] : (e == 2 ? s.offset[3] : 0)));
+          val = clip3i(0, maxv, val + o);
+        }
       }
     }
     out[k] = val;
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict_
       }
     }
   }
-  Pix* drow = reinterpret_cast<Pix*>(dp.dst[c] + (size_t)yy * dp.dst_pitch[c]);
+  Pix* drow = reinterpret_cast<Pix*>(dp.dst[c] + (size_t)yd * dp.dst_pitch[c]);
 #pragma unroll
   for (int k = 0; k < 4; k++)
     if (x4 + k < cw) drow[x4 + k] = (Pix)out[k];

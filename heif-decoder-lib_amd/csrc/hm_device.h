@@ -20,6 +20,7 @@ struct hm_dev_pic {
   uint8_t* dst[3];          // destination plane origin (tile origin already applied)
   int32_t dst_pitch[3];     // bytes
   int32_t copy_w[3], copy_h[3]; // samples to write per plane (tile cropped at the canvas edge)
+  int32_t src_x[3], src_y[3];   // first sample to copy (conformance-window offset of the coded picture)
   int32_t rescale;          // 1: limited->full range rescale quirk of the grid paste (context.cc:2504-2528)
   int32_t width, height;    // luma size (copy of the header)
   int32_t chroma_format;    // 1 or 2

@@ -147,6 +147,53 @@ HM_API int  hm_batch_get_timings(hm_batch* b, int slot, float ms[3]);
 /* algorithmic bytes of the queued pictures: command streams read, reconstructed samples written */
 HM_API int  hm_batch_algorithmic_bytes(const hm_batch* b, uint64_t* stream_bytes, uint64_t* sample_bytes);
 
+/* ------------------------------------------------------------------------- */
+/* Image level: HEIF file -> pixels (host box parsing + CABAC, GPU everything else) */
+/* ------------------------------------------------------------------------- */
+
+typedef struct hm_file hm_file;
+
+typedef struct hm_image_info {
+  int32_t width, height;       /* output size (grid: the grid's output size; image: ispe)        */
+  int32_t bit_depth, chroma;   /* from the (first tile's) hvcC                                   */
+  int32_t is_grid, grid_rows, grid_cols, tile_width, tile_height;
+  int32_t has_transforms;      /* irot / imir / clap present on the item                         */
+} hm_image_info;
+
+typedef struct hm_decode_params {
+  int32_t out_format;          /* 0 = native planar YCbCr, else HM_OUT_* (== enum heif_chroma)   */
+  int32_t host_threads;        /* entropy-decode threads (heif_context_set_threads semantics)    */
+  int32_t ignore_transformations;
+  int32_t reserved;
+  void*   stream;              /* hipStream_t or NULL                                            */
+  void*   ext_dst;             /* optional caller buffer for interleaved output (fork API:       */
+  uint32_t ext_dst_len;        /*   heif_decoding_options_add_external_dest, heif.h:1605-1615)   */
+  uint32_t ext_dst_stride;
+} hm_decode_params;
+
+typedef struct hm_decoded {
+  int32_t width, height, bit_depth, chroma;
+  int32_t out_format;          /* as requested                                                    */
+  int32_t has_nclx, primaries, transfer, matrix, full_range; /* profile attached to the result   */
+  int32_t used_ext_dst;
+  uint8_t* plane[3];           /* host memory, libheif plane layout (pixelimage.cc:139-218);       */
+  int32_t stride[3];           /*   interleaved output uses plane[0] only                          */
+  int32_t plane_width[3], plane_height[3];
+} hm_decoded;
+
+/* parse the box structure (the bytes are copied).  Replaces heif_context_read_from_memory. */
+HM_API int      hm_file_open(const uint8_t* data, size_t size, hm_file** out);
+HM_API void     hm_file_close(hm_file* f);
+HM_API uint32_t hm_file_primary_item(const hm_file* f);
+HM_API int      hm_file_top_level_images(const hm_file* f, uint32_t* ids, int max_ids); /* returns the count */
+HM_API int      hm_file_image_info(const hm_file* f, uint32_t id, hm_image_info* info);
+/* the byte string a decoder plugin gets through push_data for an hvc1 item (free with hm_free) */
+HM_API int      hm_file_item_hevc_data(const hm_file* f, uint32_t id, uint8_t** out, size_t* out_size);
+/* decode an hvc1 image or a grid item.  Replaces heif_decode_image (heif.cc:1150-1186 ->
+ * context.cc:1516-1600, 2120-2404).  Free the result with hm_decoded_free. */
+HM_API int      hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params, hm_decoded* out);
+HM_API void     hm_decoded_free(hm_decoded* d);
+
 #ifdef __cplusplus
 }
 #endif

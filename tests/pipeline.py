@@ -1,0 +1,145 @@
+"""CPU restatement of the image-level flow (decode_image_user / decode_full_grid_image /
+decode_and_paste_tile_image / convert_colorspace of the reference) out of oracle pieces:
+product host parsing (C ABI) + oracle executors + oracle paste + oracle colour ops.
+Test infrastructure only."""
+import ctypes as C
+
+import numpy as np
+
+import hevcutil
+import orc
+
+SURVEY_FNV_INIT = 1469598103934665603  # the survey's harness used this (truncated) FNV-1a basis for BASELINE.md §2
+
+
+class ImageInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in "width height bit_depth chroma is_grid grid_rows grid_cols tile_width tile_height has_transforms".split()]
+
+
+class DecodeParams(C.Structure):
+    _fields_ = [("out_format", C.c_int32), ("host_threads", C.c_int32), ("ignore_transformations", C.c_int32),
+                ("reserved", C.c_int32), ("stream", C.c_void_p), ("ext_dst", C.c_void_p),
+                ("ext_dst_len", C.c_uint32), ("ext_dst_stride", C.c_uint32)]
+
+
+class Decoded(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in "width height bit_depth chroma out_format has_nclx primaries transfer matrix full_range used_ext_dst".split()] + \
+               [("plane", C.POINTER(C.c_uint8) * 3), ("stride", C.c_int32 * 3), ("plane_width", C.c_int32 * 3), ("plane_height", C.c_int32 * 3)]
+
+
+def bind(hm):
+    hm.hm_last_error.restype = C.c_char_p
+    hm.hm_file_open.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]
+    hm.hm_file_close.argtypes = [C.c_void_p]
+    hm.hm_file_primary_item.argtypes = [C.c_void_p]
+    hm.hm_file_primary_item.restype = C.c_uint32
+    hm.hm_file_image_info.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(ImageInfo)]
+    hm.hm_file_item_hevc_data.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+    hm.hm_decode_item.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(DecodeParams), C.POINTER(Decoded)]
+    hm.hm_decoded_free.argtypes = [C.POINTER(Decoded)]
+    hm.hm_free.argtypes = [C.c_void_p]
+    return hm
+
+
+class HeifFile:
+    def __init__(self, hm, data):
+        self.hm = bind(hm)
+        self.h = C.c_void_p()
+        rc = hm.hm_file_open(data, len(data), C.byref(self.h))
+        if rc:
+            raise RuntimeError(f"hm_file_open: {rc}: {hm.hm_last_error().decode()}")
+
+    def primary(self):
+        return self.hm.hm_file_primary_item(self.h)
+
+    def info(self, iid):
+        i = ImageInfo()
+        rc = self.hm.hm_file_image_info(self.h, iid, C.byref(i))
+        if rc:
+            raise RuntimeError(f"hm_file_image_info: {rc}: {self.hm.hm_last_error().decode()}")
+        return i
+
+    def hevc_data(self, iid):
+        p = C.POINTER(C.c_uint8)()
+        n = C.c_size_t()
+        rc = self.hm.hm_file_item_hevc_data(self.h, iid, C.byref(p), C.byref(n))
+        if rc:
+            raise RuntimeError(f"hm_file_item_hevc_data: {rc}: {self.hm.hm_last_error().decode()}")
+        out = C.string_at(p, n.value)
+        self.hm.hm_free(p)
+        return out
+
+    def decode(self, iid, out_format, threads=1):
+        """GPU path through the C ABI; returns (array rows x stride, Decoded meta)."""
+        prm = DecodeParams(out_format, threads, 0, 0, None, None, 0, 0)
+        d = Decoded()
+        rc = self.hm.hm_decode_item(self.h, iid, C.byref(prm), C.byref(d))
+        if rc:
+            raise RuntimeError(f"hm_decode_item: {rc}: {self.hm.hm_last_error().decode()}")
+        planes = []
+        n = 1 if out_format else 3
+        for c in range(n):
+            rows = d.plane_height[c]
+            a = np.ctypeslib.as_array(d.plane[c], shape=(rows, d.stride[c])).copy()
+            planes.append(a)
+        meta = {k: getattr(d, k) for k in "width height bit_depth chroma out_format has_nclx primaries transfer matrix full_range".split()}
+        meta["stride"] = [d.stride[c] for c in range(3)]
+        self.hm.hm_decoded_free(C.byref(d))
+        return planes, meta
+
+    def close(self):
+        if self.h:
+            self.hm.hm_file_close(self.h)
+            self.h = C.c_void_p()
+
+
+def cpu_decode(hm, tiles, tile_w, tile_h, canvas_w, canvas_h, cols, is_grid, out_fmt, tile_colr=None, decoder="oracle"):
+    """tiles: list of [len][NAL] strings.  Returns (rgb array, stride) following the reference flow."""
+    o = orc.load()
+    first = None
+    canv = None
+    for i, data in enumerate(tiles):
+        if decoder == "ref":
+            planes, info = orc.ref_decode(data, 0)
+        else:
+            planes, info = orc.oracle_decode(hevcutil.parse(hm, data), 3)
+            cf = info["chroma"]
+            planes = [planes[0][:tile_h, :tile_w], planes[1][:(tile_h + 1) // 2 if cf == 1 else tile_h, :(tile_w + 1) // 2],
+                      planes[2][:(tile_h + 1) // 2 if cf == 1 else tile_h, :(tile_w + 1) // 2]]
+        bd, cf = info["bit_depth"], info["chroma"]
+        bps = 2 if bd > 8 else 1
+        nclx = (1, info["full_range"], info["matrix"], info["primaries"])
+        if tile_colr is not None:
+            nclx = (1, tile_colr[3], tile_colr[2], tile_colr[0])
+        if first is None:
+            first = dict(bd=bd, cf=cf, nclx=nclx)
+            cw = (canvas_w + 1) // 2
+            ch = (canvas_h + 1) // 2 if cf == 1 else canvas_h
+            canv = [orc.alloc_plane(canvas_w, canvas_h, bps), orc.alloc_plane(cw, ch, bps), orc.alloc_plane(cw, ch, bps)]
+        x0, y0 = (i % cols) * tile_w, (i // cols) * tile_h
+        for c in range(3):
+            p = planes[c]
+            raw = np.ascontiguousarray(p.astype(np.uint8)) if bps == 1 else np.ascontiguousarray(p.astype(np.uint16))
+            has, full, mat = (nclx[0], nclx[1], nclx[2]) if is_grid else (0, 1, 1)
+            rc = o.orc_paste_tile_plane(orc.ptr(raw), raw.shape[1] * bps, raw.shape[1], raw.shape[0], orc.ptr(canv[c][0]), canv[c][1],
+                                        canvas_w, canvas_h, x0, y0, c, cf, bd, has, full, mat)
+            assert rc == 0
+    bd, cf = first["bd"], first["cf"]
+    has_nclx = 0 if is_grid else 1
+    _, full, mat, prim = first["nclx"]
+    obpp = {10: 3, 11: 4, 12: 6, 14: 6}[out_fmt]
+    out, os_ = orc.alloc_plane(canvas_w, canvas_h, obpp)
+    sel_m = (mat if has_nclx else 2)
+    sel_m = 6 if sel_m == 2 else sel_m
+    sel_full = full if has_nclx else 1
+    if bd == 8 and cf == 1 and sel_full and sel_m not in (0, 8, 11, 14) and out_fmt in (10, 11):
+        o.orc_ycbcr420_to_rgb_int(orc.ptr(canv[0][0]), canv[0][1], orc.ptr(canv[1][0]), canv[1][1], orc.ptr(canv[2][0]), canv[2][1],
+                                  canvas_w, canvas_h, has_nclx, mat, prim, orc.ptr(out), os_, out_fmt)
+    else:
+        o.orc_ycbcr_to_rgb_float(orc.ptr(canv[0][0]), canv[0][1], orc.ptr(canv[1][0]), canv[1][1], orc.ptr(canv[2][0]), canv[2][1],
+                                 canvas_w, canvas_h, bd, cf, has_nclx, mat, prim, full, orc.ptr(out), os_, out_fmt)
+    return out, os_, canv
+
+
+def survey_fnv(buf, stride, row_bytes, rows):
+    return f"{orc.load().orc_fnv1a64_rows(orc.ptr(buf), stride, row_bytes, rows, SURVEY_FNV_INIT):016x}"

@@ -1,0 +1,84 @@
+"""Pin the image-level flow (HEIF parsing -> tile decode -> crop -> paste/rescale -> colour) against the
+fingerprints of the REAL reference recorded in BASELINE.md (tests/golden/heic.json).
+CPU part: product host parsing + oracle pieces.  GPU part (-m gpu): hm_decode_item through the C ABI."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import heifwriter
+import pipeline
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "heic.json")))
+
+
+def _load(name):
+    return open(os.path.join(HERE, "data", name), "rb").read()
+
+
+def _grid_file(hm):
+    f = pipeline.HeifFile(hm, _load("example.heic"))
+    tiles = [f.hevc_data(i) for i in GOLD["grid_1x2"]["tiles"]]
+    f.close()
+    return heifwriter.write_heic(tiles, (1280, 854), grid=(1, 2, 2560, 854)), tiles
+
+
+@pytest.mark.parametrize("case", GOLD["cases"], ids=lambda c: f"{c['file']}-{c['item']}-{c['fmt']}")
+def test_cpu_flow_matches_reference_fingerprint(hm, case):
+    f = pipeline.HeifFile(hm, _load(case["file"]))
+    iid = case["item"] or f.primary()
+    info = f.info(iid)
+    assert (info.width, info.height) == (case["w"], case["h"])
+    out, stride, _ = pipeline.cpu_decode(hm, [f.hevc_data(iid)], case["w"], case["h"], case["w"], case["h"], 1, False, case["fmt"])
+    f.close()
+    bpp = 3 if case["fmt"] == 10 else 4
+    if "stride" in case:
+        assert stride == case["stride"]
+    if "first" in case:
+        assert out[0, :3].tolist() == case["first"]
+    assert pipeline.survey_fnv(out, stride, case["w"] * bpp, case["h"]) == case["fnv"]
+
+
+def test_cpu_grid_flow_matches_reference_fingerprint(hm):
+    g = GOLD["grid_1x2"]
+    data, tiles = _grid_file(hm)
+    f = pipeline.HeifFile(hm, data)
+    info = f.info(f.primary())
+    assert (info.is_grid, info.grid_rows, info.grid_cols, info.width, info.height) == (1, 1, 2, g["w"], g["h"])
+    f.close()
+    out, stride, canv = pipeline.cpu_decode(hm, tiles, 1280, 854, g["w"], g["h"], 2, True, 10)
+    assert stride == g["stride"] and out[0, :3].tolist() == g["first"]
+    assert pipeline.survey_fnv(out, stride, g["w"] * 3, g["h"]) == g["fnv"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", GOLD["cases"], ids=lambda c: f"{c['file']}-{c['item']}-{c['fmt']}")
+def test_gpu_decode_item_matches_reference_fingerprint(hm, case):
+    f = pipeline.HeifFile(hm, _load(case["file"]))
+    iid = case["item"] or f.primary()
+    planes, meta = f.decode(iid, case["fmt"])
+    f.close()
+    bpp = 3 if case["fmt"] == 10 else 4
+    assert (meta["width"], meta["height"]) == (case["w"], case["h"])
+    if "stride" in case:
+        assert meta["stride"][0] == case["stride"]
+    assert pipeline.survey_fnv(planes[0], meta["stride"][0], case["w"] * bpp, case["h"]) == case["fnv"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads", [1, 4])
+def test_gpu_grid_matches_reference_fingerprint(hm, threads):
+    g = GOLD["grid_1x2"]
+    data, tiles = _grid_file(hm)
+    f = pipeline.HeifFile(hm, data)
+    planes, meta = f.decode(f.primary(), 10, threads=threads)
+    native, nmeta = f.decode(f.primary(), 0)
+    f.close()
+    assert meta["has_nclx"] == 0  # a grid canvas carries no nclx
+    assert pipeline.survey_fnv(planes[0], meta["stride"][0], g["w"] * 3, g["h"]) == g["fnv"]
+    # native canvas planes == CPU flow (limited->full rescale of the paste, context.cc:2504-2528)
+    _, _, canv = pipeline.cpu_decode(hm, tiles, 1280, 854, g["w"], g["h"], 2, True, 10)
+    np.testing.assert_array_equal(native[0][:g["h"], :g["w"]], canv[0][0][:g["h"], :g["w"]])
+    np.testing.assert_array_equal(native[1][:g["h"] // 2, :g["w"] // 2], canv[1][0][:g["h"] // 2, :g["w"] // 2])
