@@ -1,0 +1,161 @@
+// plugin.cpp — `struct heif_decoder_plugin` implementation backed by the MI355X tile-decode path.
+//
+// Drop-in for the reference's libde265 plugin (libheif/plugins/decoder_libde265.cc:160-187,269-369,
+// 392-422): same call sequence (new_decoder -> set_strict_decoding -> push_data* -> decode_image ->
+// free_decoder, context.cc:1787-1835), same output contract: a YCbCr heif_image created through the
+// host libheif's own C API with planes of the conformance-window size and the VUI colour
+// description attached as nclx (decoder_libde265.cc:339-362).
+// Built twice: into libheif_mi355x_api.so (static registration) and as libheif-mi355x-plugin.so
+// (exports `plugin_info` for LIBHEIF_PLUGIN_PATH loading, plugins_unix.cc:96-111); in the latter the
+// heif_image_* symbols resolve against the libheif that loads it.
+#include <hip/hip_runtime_api.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "heif_mi355x.h"
+#include "heif_mi355x_compat.h"
+#include "hm_stream.h"
+
+namespace {
+
+const char kSuccess[] = "Success";
+const char kName[] = "MI355X HIP HEVC-intra decoder (heif-mi355x), gfx950";
+thread_local char g_msg[512];
+
+struct Decoder {
+  std::vector<uint8_t> data;
+  bool strict = false;
+  int nthreads = 0;
+};
+
+heif_error ok() { return {heif_error_Ok, heif_suberror_Unspecified, kSuccess}; }
+
+heif_error from_status(int rc)
+{
+  std::snprintf(g_msg, sizeof(g_msg), "%s", hm_last_error());
+  switch (rc) {
+    case HM_ERR_UNSUPPORTED: return {heif_error_Unsupported_feature, heif_suberror_Unsupported_codec, g_msg};
+    case HM_ERR_BITSTREAM: return {heif_error_Invalid_input, heif_suberror_Unspecified, g_msg};
+    case HM_ERR_NOMEM: return {heif_error_Memory_allocation_error, heif_suberror_Unspecified, g_msg};
+    default: return {heif_error_Decoder_plugin_error, heif_suberror_Unspecified, g_msg};
+  }
+}
+
+const char* plugin_name() { return kName; }
+void init_plugin() {}
+void deinit_plugin() {}
+
+int does_support_format(enum heif_compression_format format)
+{
+  // outrank libde265's 100 (decoder_libde265.cc:43) only when a GPU is really there
+  if (format != heif_compression_HEVC) return 0;
+  return hm_device_count() > 0 ? 150 : 0;
+}
+
+heif_error new_decoder(void** dec, int nthreads)
+{
+  Decoder* d = new (std::nothrow) Decoder();
+  if (!d) return {heif_error_Memory_allocation_error, heif_suberror_Unspecified, "out of memory"};
+  d->nthreads = nthreads;
+  *dec = d;
+  return ok();
+}
+
+void free_decoder(void* dec) { delete static_cast<Decoder*>(dec); }
+
+void set_strict_decoding(void* dec, int flag) { static_cast<Decoder*>(dec)->strict = flag != 0; }
+
+heif_error push_data(void* dec, const void* data, size_t size)
+{
+  Decoder* d = static_cast<Decoder*>(dec);
+  const uint8_t* p = static_cast<const uint8_t*>(data);
+  d->data.insert(d->data.end(), p, p + size); // [u32 BE length][NAL]... records, possibly over several calls
+  return ok();
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) hipFree(p); }
+};
+
+heif_error decode_image(void* dec, struct heif_image** out_img)
+{
+  Decoder* d = static_cast<Decoder*>(dec);
+  *out_img = nullptr;
+  uint8_t* blob = nullptr;
+  size_t blob_size = 0;
+  int rc = hm_hevc_parse(d->data.data(), d->data.size(), 0, &blob, &blob_size);
+  if (rc) return from_status(rc);
+  struct Free { uint8_t* p; ~Free() { hm_free(p); } } blob_guard{blob};
+  const hm_pic* h = reinterpret_cast<const hm_pic*>(blob);
+  const int w = h->width - h->crop_left - h->crop_right, hh = h->height - h->crop_top - h->crop_bottom;
+  const int bd = h->bit_depth_y, bps = bd > 8 ? 2 : 1;
+  const int cw = w / 2, ch = h->chroma_format == 1 ? hh / 2 : hh;
+
+  heif_error err = heif_image_create(w, hh, heif_colorspace_YCbCr, (heif_chroma)h->chroma_format, out_img);
+  if (err.code) return err;
+  const heif_channel chan[3] = {heif_channel_Y, heif_channel_Cb, heif_channel_Cr};
+  const int pw[3] = {w, cw, cw}, ph[3] = {hh, ch, ch};
+  DevBuf dev[3];
+  hm_tile_dest dest;
+  std::memset(&dest, 0, sizeof(dest));
+  for (int c = 0; c < 3; c++) {
+    err = heif_image_add_plane(*out_img, chan[c], pw[c], ph[c], bd);
+    if (err.code) { heif_image_release(*out_img); *out_img = nullptr; return err; }
+    const size_t pitch = ((size_t)pw[c] * bps + 63) / 64 * 64;
+    if (hipMalloc(&dev[c].p, pitch * ph[c]) != hipSuccess) {
+      heif_image_release(*out_img); *out_img = nullptr;
+      return {heif_error_Memory_allocation_error, heif_suberror_Unspecified, "hipMalloc failed"};
+    }
+    dest.plane[c] = dev[c].p;
+    dest.pitch[c] = (int32_t)pitch;
+  }
+  dest.canvas_width = w; dest.canvas_height = hh; // the "canvas" is the picture itself: plain copy, no rescale
+  hm_batch* b = nullptr;
+  rc = hm_batch_create(&b);
+  if (!rc) {
+    rc = hm_batch_add(b, blob, blob_size, &dest);
+    if (rc >= 0) rc = hm_batch_upload(b, nullptr);
+    if (!rc) rc = hm_batch_execute(b, 3, nullptr);
+    for (int c = 0; c < 3 && !rc; c++) {
+      int stride = 0;
+      uint8_t* dst = heif_image_get_plane(*out_img, chan[c], &stride);
+      if (hipMemcpy2D(dst, stride, dev[c].p, dest.pitch[c], (size_t)pw[c] * bps, ph[c], hipMemcpyDeviceToHost) != hipSuccess)
+        rc = HM_ERR_NO_DEVICE;
+    }
+    hm_batch_destroy(b);
+  }
+  if (rc) { heif_image_release(*out_img); *out_img = nullptr; return from_status(rc); }
+
+  // VUI colour description -> nclx, always attached (defaults 2,2,2,limited when the VUI has none)
+  struct heif_color_profile_nclx* nclx = heif_nclx_color_profile_alloc();
+  if (nclx) {
+    heif_nclx_color_profile_set_color_primaries(nclx, h->colour_primaries);
+    heif_nclx_color_profile_set_transfer_characteristics(nclx, h->transfer_characteristics);
+    heif_nclx_color_profile_set_matrix_coefficients(nclx, h->matrix_coeffs);
+    nclx->full_range_flag = h->full_range;
+    heif_image_set_nclx_color_profile(*out_img, nclx);
+    heif_nclx_color_profile_free(nclx);
+  }
+  return ok();
+}
+
+const struct heif_decoder_plugin g_plugin = {
+    3, plugin_name, init_plugin, deinit_plugin, does_support_format, new_decoder, free_decoder,
+    push_data, decode_image, set_strict_decoding, "mi355x"};
+
+} // namespace
+
+extern "C" {
+
+const struct heif_decoder_plugin* hm_get_decoder_plugin(void) { return &g_plugin; }
+
+#ifdef HM_BUILD_PLUGIN_SO
+// heif.h:584-596: what plugins_unix.cc:96-111 looks up with dlsym("plugin_info")
+__attribute__((visibility("default"))) struct heif_plugin_info plugin_info = {1, heif_plugin_type_decoder, &g_plugin, nullptr};
+#endif
+
+} // extern "C"

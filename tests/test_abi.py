@@ -23,6 +23,47 @@ def test_exports(hm):
     assert not missing, f"declared in include/*.h but not exported: {missing}"
 
 
+def _compat_symbols():
+    text = open(os.path.join(ROOT, "include", "heif_mi355x_compat.h")).read()
+    text = "\n".join(l for l in text.splitlines() if not l.lstrip().startswith("#"))
+    return {m.group(1) for m in re.finditer(r"HMC_API\s+[^;(]*?\b(\w+)\s*\(", text)}
+
+
+def test_compat_facade_exports(hm):
+    """libheif_mi355x_api.so exports every heif_* entry point heif_mi355x_compat.h declares"""
+    api = C.CDLL(os.path.join(ROOT, "heif-decoder-lib_amd", "libheif_mi355x_api.so"))
+    syms = _compat_symbols()
+    assert len(syms) >= 45
+    missing = [s for s in sorted(syms) if not hasattr(api, s)]
+    assert not missing, missing
+
+
+def test_plugin_so_exports_plugin_info(hm):
+    """the loadable plugin exports `plugin_info` (plugins_unix.cc:96-111 dlsym target) with the fork ABI struct"""
+    import subprocess
+    so = os.path.join(ROOT, "heif-decoder-lib_amd", "libheif-mi355x-plugin.so")
+    out = subprocess.run(["nm", "-D", so], capture_output=True, text=True, check=True).stdout
+    assert " D plugin_info" in out or " B plugin_info" in out
+    # its heif_image_* calls are left undefined: they bind to the libheif that loads the plugin
+    assert " U heif_image_create" in out and " U heif_image_add_plane" in out
+
+
+def test_decoder_plugin_struct(hm):
+    api = C.CDLL(os.path.join(ROOT, "heif-decoder-lib_amd", "libheif_mi355x_api.so"))
+
+    class Plugin(C.Structure):
+        _fields_ = [("plugin_api_version", C.c_int), ("get_plugin_name", C.CFUNCTYPE(C.c_char_p)), ("init_plugin", C.c_void_p),
+                    ("deinit_plugin", C.c_void_p), ("does_support_format", C.CFUNCTYPE(C.c_int, C.c_int)), ("new_decoder", C.c_void_p),
+                    ("free_decoder", C.c_void_p), ("push_data", C.c_void_p), ("decode_image", C.c_void_p),
+                    ("set_strict_decoding", C.c_void_p), ("id_name", C.c_char_p)]
+    api.hm_get_decoder_plugin.restype = C.POINTER(Plugin)
+    p = api.hm_get_decoder_plugin().contents
+    assert p.plugin_api_version == 3 and p.id_name == b"mi355x"
+    assert b"MI355X" in p.get_plugin_name()
+    assert p.does_support_format(0) == 0          # heif_compression_undefined
+    assert p.does_support_format(1) in (0, 150)   # HEVC: 150 with a GPU, 0 (= "cannot decode") without
+
+
 def test_status_strings(hm):
     assert hm.hm_status_string(0) == b"ok"
     assert b"unsupported" in hm.hm_status_string(-2)

@@ -1,0 +1,160 @@
+"""GPU: the libheif-compatible facade (libheif_mi355x_api.so) driven exactly like the reference's
+README sample / examples/heif_dec.cc:412-554, and the decoder plugin driven like
+HeifContext::decode_image_planar drives a plugin (context.cc:1787-1835)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import heifwriter
+import orc
+import pipeline
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = json.load(open(os.path.join(HERE, "golden", "heic.json")))
+
+
+class Err(C.Structure):
+    _fields_ = [("code", C.c_int), ("subcode", C.c_int), ("message", C.c_char_p)]
+
+
+@pytest.fixture(scope="module")
+def api(pkg):
+    pkg.lib()  # loads torch's HIP runtime + the core library first
+    a = C.CDLL(os.path.join(ROOT, "heif-decoder-lib_amd", "libheif_mi355x_api.so"))
+    a.heif_context_alloc.restype = C.c_void_p
+    a.heif_context_free.argtypes = [C.c_void_p]
+    a.heif_context_read_from_memory.restype = Err
+    a.heif_context_read_from_memory.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p]
+    a.heif_context_get_primary_image_handle.restype = Err
+    a.heif_context_get_primary_image_handle.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    a.heif_context_get_image_handle.restype = Err
+    a.heif_context_get_image_handle.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+    a.heif_context_set_threads.restype = Err
+    a.heif_context_set_threads.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    a.heif_image_handle_release.argtypes = [C.c_void_p]
+    a.heif_image_handle_get_width.argtypes = [C.c_void_p]
+    a.heif_decode_image.restype = Err
+    a.heif_decode_image.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p]
+    a.heif_image_get_plane_readonly.restype = C.POINTER(C.c_uint8)
+    a.heif_image_get_plane_readonly.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    a.heif_image_get_width.argtypes = [C.c_void_p, C.c_int]
+    a.heif_image_get_height.argtypes = [C.c_void_p, C.c_int]
+    a.heif_image_get_bits_per_pixel_range.argtypes = [C.c_void_p, C.c_int]
+    a.heif_image_release.argtypes = [C.c_void_p]
+    a.heif_decoding_options_alloc.restype = C.c_void_p
+    a.heif_decoding_options_free.argtypes = [C.c_void_p]
+    a.heif_decoding_options_add_external_dest.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+    return a
+
+
+def _decode(api, data, item, colorspace, chroma, threads=0, options=None):
+    ctx = api.heif_context_alloc()
+    e = api.heif_context_read_from_memory(ctx, data, len(data), None)
+    assert e.code == 0, e.message
+    h = C.c_void_p()
+    e = api.heif_context_get_image_handle(ctx, item, C.byref(h)) if item else api.heif_context_get_primary_image_handle(ctx, C.byref(h))
+    assert e.code == 0, e.message
+    if threads:
+        api.heif_context_set_threads(ctx, h, threads)
+    img = C.c_void_p()
+    e = api.heif_decode_image(h, C.byref(img), colorspace, chroma, options)
+    return ctx, h, img, e
+
+
+@pytest.mark.parametrize("case", GOLD["cases"][:4], ids=lambda c: f"{c['file']}-{c['item']}-{c['fmt']}")
+def test_heif_decode_image_like_reference_sample(api, case):
+    data = open(os.path.join(HERE, "data", case["file"]), "rb").read()
+    ctx, h, img, e = _decode(api, data, case["item"], 1, case["fmt"])  # heif_colorspace_RGB
+    assert e.code == 0, e.message
+    stride = C.c_int()
+    p = api.heif_image_get_plane_readonly(img, 10, C.byref(stride))  # heif_channel_interleaved
+    w, hh = api.heif_image_get_width(img, 10), api.heif_image_get_height(img, 10)
+    assert (w, hh) == (case["w"], case["h"])
+    bpp = 3 if case["fmt"] == 10 else 4
+    buf = np.ctypeslib.as_array(p, shape=(hh, stride.value))
+    assert pipeline.survey_fnv(np.ascontiguousarray(buf), stride.value, w * bpp, hh) == case["fnv"]
+    api.heif_image_release(img)
+    api.heif_image_handle_release(h)
+    api.heif_context_free(ctx)
+
+
+def test_grid_with_threads_and_ext_dst(api, hm):
+    g = GOLD["grid_1x2"]
+    f = pipeline.HeifFile(hm, open(os.path.join(HERE, "data", "example.heic"), "rb").read())
+    tiles = [f.hevc_data(i) for i in g["tiles"]]
+    f.close()
+    data = heifwriter.write_heic(tiles, (1280, 854), grid=(1, 2, 2560, 854))
+    # RGB24 with 4 host threads (heif_context_set_threads: tile fan-out)
+    ctx, h, img, e = _decode(api, data, 0, 1, 10, threads=4)
+    assert e.code == 0, e.message
+    stride = C.c_int()
+    p = api.heif_image_get_plane_readonly(img, 10, C.byref(stride))
+    assert stride.value == g["stride"]
+    buf = np.ascontiguousarray(np.ctypeslib.as_array(p, shape=(g["h"], stride.value)))
+    assert pipeline.survey_fnv(buf, stride.value, g["w"] * 3, g["h"]) == g["fnv"]
+    api.heif_image_release(img); api.heif_image_handle_release(h); api.heif_context_free(ctx)
+    # RGBA into a caller buffer (fork API heif_decoding_options_add_external_dest, android_jni heif_jni.cpp:80-97)
+    ext = np.zeros((g["h"], g["w"] * 4), np.uint8)
+    opt = api.heif_decoding_options_alloc()
+    api.heif_decoding_options_add_external_dest(opt, ext.ctypes.data_as(C.c_void_p), ext.size, g["w"] * 4)
+    ctx, h, img, e = _decode(api, data, 0, 1, 11, options=opt)
+    assert e.code == 0, e.message
+    exp, es, _ = pipeline.cpu_decode(hm, tiles, 1280, 854, g["w"], g["h"], 2, True, 11)
+    np.testing.assert_array_equal(ext, exp[:g["h"], :g["w"] * 4])
+    api.heif_image_release(img); api.heif_image_handle_release(h); api.heif_context_free(ctx); api.heif_decoding_options_free(opt)
+
+
+def test_unsupported_requests_fail_loudly(api):
+    data = open(os.path.join(HERE, "data", "colors-no-alpha.heic"), "rb").read()
+    ctx, h, img, e = _decode(api, data, 0, 1, 14)  # 8-bit -> RRGGBB_LE needs a depth-conversion op
+    assert e.code == 4 and not img  # heif_error_Unsupported_feature
+    api.heif_image_handle_release(h); api.heif_context_free(ctx)
+
+
+def test_decoder_plugin_call_sequence(api, hm):
+    """new_decoder -> set_strict_decoding -> push_data -> decode_image -> free_decoder, planes == oracle"""
+    import corpus
+    import hevcutil
+
+    class Plugin(C.Structure):
+        _fields_ = [("plugin_api_version", C.c_int), ("get_plugin_name", C.c_void_p), ("init_plugin", C.c_void_p),
+                    ("deinit_plugin", C.c_void_p), ("does_support_format", C.CFUNCTYPE(C.c_int, C.c_int)),
+                    ("new_decoder", C.CFUNCTYPE(Err, C.POINTER(C.c_void_p), C.c_int)), ("free_decoder", C.CFUNCTYPE(None, C.c_void_p)),
+                    ("push_data", C.CFUNCTYPE(Err, C.c_void_p, C.c_char_p, C.c_size_t)),
+                    ("decode_image", C.CFUNCTYPE(Err, C.c_void_p, C.POINTER(C.c_void_p))),
+                    ("set_strict_decoding", C.CFUNCTYPE(None, C.c_void_p, C.c_int)), ("id_name", C.c_char_p)]
+    api.hm_get_decoder_plugin.restype = C.POINTER(Plugin)
+    api.heif_register_decoder_plugin.restype = Err
+    api.heif_register_decoder_plugin.argtypes = [C.POINTER(Plugin)]
+    pl = api.hm_get_decoder_plugin()
+    assert api.heif_register_decoder_plugin(pl).code == 0
+    p = pl.contents
+    assert p.does_support_format(1) == 150
+    for name in ("tile512_novui", "hi422_10"):
+        data = corpus.stream(name)
+        dec = C.c_void_p()
+        assert p.new_decoder(C.byref(dec), 0).code == 0
+        p.set_strict_decoding(dec, 0)
+        half = len(data) // 2
+        assert p.push_data(dec, data[:half], half).code == 0          # data may arrive in several pieces
+        assert p.push_data(dec, data[half:], len(data) - half).code == 0
+        img = C.c_void_p()
+        e = p.decode_image(dec, C.byref(img))
+        assert e.code == 0, e.message
+        p.free_decoder(dec)
+        exp, info = orc.oracle_decode(hevcutil.parse(hm, data), 3)
+        wide = info["bit_depth"] > 8
+        for c in range(3):
+            stride = C.c_int()
+            ptr = api.heif_image_get_plane_readonly(img, c, C.byref(stride))
+            w, hgt = api.heif_image_get_width(img, c), api.heif_image_get_height(img, c)
+            assert api.heif_image_get_bits_per_pixel_range(img, c) == info["bit_depth"]
+            raw = np.ctypeslib.as_array(ptr, shape=(hgt, stride.value))
+            got = raw[:, :w * 2].copy().view(np.uint16).reshape(hgt, w) if wide else raw[:, :w].astype(np.uint16)
+            np.testing.assert_array_equal(got, exp[c][:hgt, :w])
+        api.heif_image_release(img)
