@@ -9,4 +9,5 @@ The directory name contains hyphens, so import it with ``load_package()`` from
 ``__graft_entry__`` (module name ``heif_decoder_lib_amd``).
 """
 from . import capi  # noqa: F401
+from . import shard  # noqa: F401
 from .capi import lib, HmError  # noqa: F401
