@@ -318,7 +318,7 @@ __device__ void residual_add(const Blk<Pix>& B, int16_t* coeff, int16_t* tmp, co
 
 // =====================================================================================================
 template <typename Pix>
-__global__ __launch_bounds__(512) void k_recon(const hm_dev_pic* __restrict__ pics, int per_wave_bytes)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_recon(const hm_dev_pic* __restrict__ pics, int per_wave_bytes)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   // descriptor -> registers once (it is read-only, but the compiler cannot know that across our stores)
