@@ -244,6 +244,7 @@ __device__ void residual_add(const Blk<Pix>& B, int16_t* coeff, int16_t* tmp, co
   const int32_t offset = 1 << (bdShift - 1);
   const int32_t fact = (int32_t)tab[50 + qP % 6] << (qP / 6);
   int mx = 0, my = 0;
+#pragma unroll 1 // more than 64 levels in a block is rare: keep the register footprint of one iteration
   for (int i = lane; i < B.n_coeff; i += 64) {
     const hm_coeff pr = i < 64 ? pre : cf[i]; // the first 64 pairs were fetched before the prediction started
     const int32_t prod = (int32_t)((uint32_t)(int32_t)pr.value * (uint32_t)fact + (uint32_t)offset); // wraps like the reference (Q3)
@@ -310,6 +311,7 @@ __device__ void residual_add(const Blk<Pix>& B, int16_t* coeff, int16_t* tmp, co
   }
   // restore the all-zero invariant: every lane clears the entries it scattered (after the reads above)
   WAVE_SYNC();
+#pragma unroll 1
   for (int i = lane; i < B.n_coeff; i += 64) {
     const hm_coeff pr = i < 64 ? pre : cf[i];
     coeff[pr.pos] = 0;
@@ -318,7 +320,7 @@ __device__ void residual_add(const Blk<Pix>& B, int16_t* coeff, int16_t* tmp, co
 
 // =====================================================================================================
 template <typename Pix>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_recon(const hm_dev_pic* __restrict__ pics, int per_wave_bytes)
+__global__ __launch_bounds__(512) void k_recon(const hm_dev_pic* __restrict__ pics, int per_wave_bytes)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   // descriptor -> registers once (it is read-only, but the compiler cannot know that across our stores)
