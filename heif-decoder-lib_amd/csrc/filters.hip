@@ -231,7 +231,52 @@ __device__ __forceinline__ int clip_f_u8(float fx)
   return x < 0 ? 0 : (x > 255 ? 255 : x);
 }
 
-// SAO + paste.  blockIdx.y = picture, blockIdx.z = plane.  One lane = 4 consecutive samples.
+// SAO + paste.  blockIdx.y = picture, blockIdx.z = plane.  One lane = 8 consecutive samples of one
+// row (8 | every CTB width, so a group never straddles CTBs when the conformance-window offset is a
+// multiple of 8 - the common case; otherwise the generic per-sample path runs).
+template <typename Pix>
+__device__ __forceinline__ int sao_sample(const hm_dev_pic& dp, const PicView& v, const uint8_t* plane, int pitch, int c,
+                                          int xx, int yy, int W, int Hh, int l2w, int l2h, int bd, int apply_sao)
+{
+  const int maxv = (1 << bd) - 1;
+  int val = reinterpret_cast<const Pix*>(plane + (size_t)yy * pitch)[xx];
+  const int cx = xx >> l2w, cy = yy >> l2h;
+  const hm_ctb& cb = v.ctbs[cx + cy * dp.ctb_w];
+  const hm_slice& sl = v.slices[cb.slice_idx];
+  const bool sao_on = apply_sao && (dp.flags & HM_PIC_SAO_ENABLED) && (c == 0 ? sl.sao_luma : sl.sao_chroma);
+  const hm_sao s = cb.sao[c];
+  const int type = sao_on ? s.type : 0;
+  if (type == 1) { // band offset (fallback-postfilter.h:218-241)
+    const int bi = ((val >> (bd - 5)) - s.band_position) & 31;
+    if (bi < 4) val = clip3i(0, maxv, val + s.offset[bi]);
+  }
+  else if (type == 2) { // edge offset (sao.cc:336-424)
+    const int cl = s.eo_class;
+    const int hx0 = cl == 1 ? 0 : (cl == 3 ? 1 : -1), hx1 = -hx0;
+    const int vy0 = cl == 0 ? 0 : -1, vy1 = -vy0;
+    bool ok = true;
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+      const int xS = xx + (n ? hx1 : hx0), yS = yy + (n ? vy1 : vy0);
+      if (xS < 0 || yS < 0 || xS >= W || yS >= Hh) { ok = false; break; }
+      const int dxc = (xS >> l2w) - cx, dyc = (yS >> l2h) - cy;
+      if (dxc != 0 || dyc != 0) {
+        const int k8 = (dyc + 1) * 3 + (dxc + 1); // 0..8 without the centre
+        const int bit = k8 < 4 ? k8 : k8 - 1;
+        if (!(cb.sao_nb_mask & (1u << bit))) ok = false;
+      }
+    }
+    if (ok) {
+      const int a = reinterpret_cast<const Pix*>(plane + (size_t)(yy + vy0) * pitch)[xx + hx0];
+      const int b = reinterpret_cast<const Pix*>(plane + (size_t)(yy + vy1) * pitch)[xx + hx1];
+      const int e = isign_(val - a) + isign_(val - b);
+      const int o = e == -2 ? s.offset[0] : (e == -1 ? s.offset[1] : (e == 1 ? s.offset[2] : (e == 2 ? s.offset[3] : 0)));
+      val = clip3i(0, maxv, val + o);
+    }
+  }
+  return val;
+}
+
 template <typename Pix>
 __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict__ pics, int apply_sao)
 {
@@ -239,70 +284,83 @@ __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict_
   const int c = blockIdx.z;
   const int cw = dp.copy_w[c], chh = dp.copy_h[c];
   if (cw <= 0 || chh <= 0) return;
-  const int groups = (cw + 3) >> 2;
+  constexpr int G = 8;
+  const int groups = (cw + G - 1) / G;
   const int item = blockIdx.x * 256 + threadIdx.x;
   if (item >= groups * chh) return;
-  const int yd = item / groups, x4 = (item - yd * groups) << 2; // destination coordinates
+  const int yd = item / groups, x8 = (item - yd * groups) * G; // destination coordinates
   const PicView v = view(dp);
-  const int sw = c ? 2 : 1, sh = c ? (dp.chroma_format == 1 ? 2 : 1) : 1;
-  const int W = dp.width / sw, Hh = dp.height / sh;
+  const int sh = c ? (dp.chroma_format == 1 ? 2 : 1) : 1;
+  const int W = dp.width >> (c ? 1 : 0), Hh = dp.height / sh;
   const int l2w = dp.log2_ctb - (c ? 1 : 0), l2h = dp.log2_ctb - (sh == 2 ? 1 : 0); // CTB size of this plane (log2)
   const int bd = dp.bit_depth, maxv = (1 << bd) - 1;
   const uint8_t* plane = dp.plane[c];
   const int pitch = dp.pitch[c];
-  const int yy = yd + dp.src_y[c];                                // source row inside the coded picture
-  const int cy = yy >> l2h;
-  const Pix* row = reinterpret_cast<const Pix*>(plane + (size_t)yy * pitch);
-  int out[4];
+  const int yy = yd + dp.src_y[c];            // source row inside the coded picture
+  const int xs = x8 + dp.src_x[c];            // first source column of the group
+  int out[G];
+  const bool fast = ((dp.src_x[c] & (G - 1)) == 0) && (x8 + G <= cw) && (xs + G <= W);
+  if (fast) {
+    const int cx = xs >> l2w, cy = yy >> l2h;
+    const hm_ctb& cb = v.ctbs[cx + cy * dp.ctb_w];
+    const hm_slice& sl = v.slices[cb.slice_idx];
+    const bool sao_on = apply_sao && (dp.flags & HM_PIC_SAO_ENABLED) && (c == 0 ? sl.sao_luma : sl.sao_chroma);
+    const hm_sao s = cb.sao[c];
+    const int type = sao_on ? s.type : 0;
+    Pix cur[G];
+    __builtin_memcpy(cur, reinterpret_cast<const Pix*>(plane + (size_t)yy * pitch) + xs, G * sizeof(Pix));
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int xx = x4 + k + dp.src_x[c];
-    int val = 0;
-    if (xx < W && x4 + k < cw) {
-      val = row[xx];
-      const int cx = xx >> l2w;
-      const hm_ctb& cb = v.ctbs[cx + cy * dp.ctb_w];
-      const hm_slice& sl = v.slices[cb.slice_idx];
-      const bool sao_on = apply_sao && (dp.flags & HM_PIC_SAO_ENABLED) && (c == 0 ? sl.sao_luma : sl.sao_chroma);
-      const hm_sao s = cb.sao[c];
-      const int type = sao_on ? s.type : 0;
-      if (type == 1) { // band offset (fallback-postfilter.h:218-241)
-        const int bi = ((val >> (bd - 5)) - s.band_position) & 31;
-        if (bi < 4) val = clip3i(0, maxv, val + s.offset[bi]);
+    for (int k = 0; k < G; k++) out[k] = cur[k];
+    if (type == 1) {
+#pragma unroll
+      for (int k = 0; k < G; k++) {
+        const int bi = ((out[k] >> (bd - 5)) - s.band_position) & 31;
+        if (bi < 4) out[k] = clip3i(0, maxv, out[k] + s.offset[bi]);
       }
-      else if (type == 2) { // edge offset (sao.cc:336-424)
-        const int cl = s.eo_class;
-        const int hx0 = cl == 1 ? 0 : (cl == 3 ? 1 : -1), hx1 = -hx0;
-        const int vy0 = cl == 0 ? 0 : -1, vy1 = -vy0;
-        bool ok = true;
+    }
+    else if (type == 2) {
+      const int cl = s.eo_class;
+      const int hx0 = cl == 1 ? 0 : (cl == 3 ? 1 : -1);
+      const int vy0 = cl == 0 ? 0 : -1;
+      // rows holding the two neighbours of every sample of the group: (yy+vy0, x+hx0) and (yy-vy0, x-hx0)
+      const int ya = yy + vy0, yb = yy - vy0;
+      const bool rowa_ok = ya >= 0 && ya < Hh, rowb_ok = yb >= 0 && yb < Hh;
+      // neighbour-CTB permissions (only the CTB borders can fail): evaluate per sample, cheap integer tests
+      const Pix* ra = reinterpret_cast<const Pix*>(plane + (size_t)(rowa_ok ? ya : yy) * pitch);
+      const Pix* rb = reinterpret_cast<const Pix*>(plane + (size_t)(rowb_ok ? yb : yy) * pitch);
 #pragma unroll
-        for (int n = 0; n < 2; n++) {
-          const int xS = xx + (n ? hx1 : hx0), yS = yy + (n ? vy1 : vy0);
-          if (xS < 0 || yS < 0 || xS >= W || yS >= Hh) { ok = false; break; }
-          const int dxc = (xS >> l2w) - cx, dyc = (yS >> l2h) - cy;
-          if (dxc != 0 || dyc != 0) {
-            const int k8 = (dyc + 1) * 3 + (dxc + 1); // 0..8 without the centre
-            const int bit = k8 < 4 ? k8 : k8 - 1;
-            if (!(cb.sao_nb_mask & (1u << bit))) ok = false;
-          }
+      for (int k = 0; k < G; k++) {
+        const int xx = xs + k;
+        const int xa = xx + hx0, xb = xx - hx0;
+        bool ok = rowa_ok && rowb_ok && xa >= 0 && xa < W && xb >= 0 && xb < W;
+        if (ok) {
+          const int dxa = (xa >> l2w) - cx, dya = (ya >> l2h) - cy;
+          const int dxb = (xb >> l2w) - cx, dyb = (yb >> l2h) - cy;
+          if (dxa | dya) { const int k8 = (dya + 1) * 3 + (dxa + 1); if (!(cb.sao_nb_mask & (1u << (k8 < 4 ? k8 : k8 - 1)))) ok = false; }
+          if (dxb | dyb) { const int k8 = (dyb + 1) * 3 + (dxb + 1); if (!(cb.sao_nb_mask & (1u << (k8 < 4 ? k8 : k8 - 1)))) ok = false; }
         }
         if (ok) {
-          const int a = reinterpret_cast<const Pix*>(plane + (size_t)(yy + vy0) * pitch)[xx + hx0];
-          const int b = reinterpret_cast<const Pix*>(plane + (size_t)(yy + vy1) * pitch)[xx + hx1];
-          const int e = isign_(val - a) + isign_(val - b);
+          const int a = ra[xa], b = rb[xb];
+          const int e = isign_(out[k] - a) + isign_(out[k] - b);
           const int o = e == -2 ? s.offset[0] : (e == -1 ? s.offset[1] : (e == 1 ? s.offset[2] : (e == 2 ? s.offset[3] : 0)));
-          val = clip3i(0, maxv, val + o);
+          out[k] = clip3i(0, maxv, out[k] + o);
         }
       }
     }
-    out[k] = val;
+  }
+  else {
+#pragma unroll
+    for (int k = 0; k < G; k++) {
+      const int xx = xs + k;
+      out[k] = (xx < W && x8 + k < cw) ? sao_sample<Pix>(dp, v, plane, pitch, c, xx, yy, W, Hh, l2w, l2h, bd, apply_sao) : 0;
+    }
   }
   // ---- paste (context.cc:2504-2535) ----
   if (dp.rescale) {
     const float off = (float)(16 << (bd - 8));
     const float ratio = c ? 1.1429f : 1.1689f;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < G; k++) {
       if (sizeof(Pix) == 1) out[k] = clip_f_u8(__fmul_rn(__fsub_rn((float)out[k], off), ratio));
       else { // the reference rescales BYTES of the 16-bit storage (quirk Q1)
         const int lo = clip_f_u8(__fmul_rn(__fsub_rn((float)(out[k] & 0xFF), off), ratio));
@@ -311,10 +369,17 @@ __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict_
       }
     }
   }
-  Pix* drow = reinterpret_cast<Pix*>(dp.dst[c] + (size_t)yd * dp.dst_pitch[c]);
+  Pix* drow = reinterpret_cast<Pix*>(dp.dst[c] + (size_t)yd * dp.dst_pitch[c]) + x8;
+  if (x8 + G <= cw) {
+    Pix o[G];
 #pragma unroll
-  for (int k = 0; k < 4; k++)
-    if (x4 + k < cw) drow[x4 + k] = (Pix)out[k];
+    for (int k = 0; k < G; k++) o[k] = (Pix)out[k];
+    __builtin_memcpy(drow, o, G * sizeof(Pix));
+  }
+  else {
+    for (int k = 0; k < G; k++)
+      if (x8 + k < cw) drow[k] = (Pix)out[k];
+  }
 }
 
 } // namespace
@@ -339,7 +404,7 @@ extern "C" int hm_launch_sao_paste(const hm_dev_pic* d_pics, int n_pics, int max
                                    hipStream_t s)
 {
   if (n_pics <= 0) return HM_OK;
-  const long items = (long)((max_w + 3) / 4) * max_h;
+  const long items = (long)((max_w + 7) / 8) * max_h;
   const int blocks = (int)((items + 255) / 256);
   if (bit_depth > 8) hipLaunchKernelGGL(k_sao_paste<uint16_t>, dim3(blocks, n_pics, 3), dim3(256), 0, s, d_pics, apply_sao);
   else hipLaunchKernelGGL(k_sao_paste<uint8_t>, dim3(blocks, n_pics, 3), dim3(256), 0, s, d_pics, apply_sao);
