@@ -104,7 +104,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--images", type=int, default=8, help="12 MP images per GPU per step")
+    ap.add_argument("--images", type=int, default=16, help="12 MP images per GPU per step (16 x 48 tiles = one full wave of workgroups on 256 CUs)")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N>1 code path on one GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
@@ -120,13 +121,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if local_rank < ndev else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     B = args.images
     batch, images, strides, host_parse_s = build_images(pkg, B, rank * B, dev)
@@ -188,7 +194,7 @@ def main():
         for q in range(3):
             k_ms[q] += ms[q]
     if dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -216,7 +222,7 @@ def main():
                        "timed_region": "recon+deblock+SAO/paste+colour kernels; command streams resident in HBM",
                        "parity": parity},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None},
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": pmc_traffic(names[dom], B)},
             "kernels": kernels,
             "host_entropy_decode": {"MP_per_s_per_core": round(B * 48 * 0.262144 / host_parse_s, 1) if host_parse_s else None,
                                     "note": "hm_hevc_parse (CABAC -> command stream), 1 thread, outside the timed region"},
@@ -227,6 +233,18 @@ def main():
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel, images):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_traffic.json: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, separate
+    passes, scaled per image); None when no measurement for this kernel is on file."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        per_image = t["kernels"][kernel]["hbm_bytes_per_image"]
+        return int(per_image * images)
+    except Exception:
+        return None
 
 
 def cpu_baseline(image0, strides, budget_s):
