@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--images", type=int, default=16, help="12 MP images per GPU per step (16 x 48 tiles = one full wave of workgroups on 256 CUs)")
+    ap.add_argument("--images", type=int, default=48, help="12 MP images per GPU per step (48 x 48 = 2304 independent tiles)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N>1 code path on one GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-parity", action="store_true")

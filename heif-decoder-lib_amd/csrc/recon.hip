@@ -29,6 +29,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "hm_device.h"
 #include "hm_internal.h"
@@ -523,9 +524,17 @@ extern "C" int hm_launch_recon(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   // useful waves: a CTU row can start once the row above is two CTUs ahead
   int nw = (max_ctb_w + 1) / 2;
   if (nw > max_ctb_h) nw = max_ctb_h;
-  if (nw > 8) nw = 8; // 512-thread workgroups: 256 VGPRs per lane available, no spills
+  if (nw > 8) nw = 8;
   if (nw < 1) nw = 1;
-  const int lds_budget = 64 * 1024; // keep <= 64 KiB so that >= 2 workgroups share a CU's 160 KiB
+  // Occupancy: the kernel needs 64 VGPRs (8 waves per SIMD, 32 per CU), so LDS decides how many pictures
+  // share a CU.  A 16x16-CTU tile keeps only ~5.6 of 8 row-waves busy (wavefront ramp): with many
+  // pictures queued, fewer waves per picture and more pictures per CU give more throughput.
+  // Measured on MI355X (profiles/r01_recon_wave_sweep.txt): <= 768 tiles in flight -> 8 waves per
+  // picture is fastest (latency), beyond that 4 waves per picture / 5 pictures per CU wins (+20 %).
+  const char* env_nw = getenv("HM_RECON_WAVES");
+  const int want = env_nw ? atoi(env_nw) : (n_pics > 1024 ? 4 : 8);
+  if (want >= 1 && want <= 8 && nw > want) nw = want;
+  const int lds_budget = 64 * 1024;
   while (nw > 1 && fixed + nw * pw > lds_budget) nw--;
   const int lds_bytes = fixed + nw * pw;
   if (lds_bytes > 160 * 1024) return hm_fail(HM_ERR_UNSUPPORTED, "CTU staging does not fit LDS (%d bytes)", lds_bytes);
