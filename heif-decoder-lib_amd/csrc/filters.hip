@@ -325,43 +325,25 @@ __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict_
       // rows holding the two neighbours of every sample of the group: (yy+vy0, x+hx0) and (yy-vy0, x-hx0)
       const int ya = yy + vy0, yb = yy - vy0;
       const bool rowa_ok = ya >= 0 && ya < Hh, rowb_ok = yb >= 0 && yb < Hh;
+      // neighbour-CTB permissions (only the CTB borders can fail): evaluate per sample, cheap integer tests
       const Pix* ra = reinterpret_cast<const Pix*>(plane + (size_t)(rowa_ok ? ya : yy) * pitch);
       const Pix* rb = reinterpret_cast<const Pix*>(plane + (size_t)(rowb_ok ? yb : yy) * pitch);
-      // neighbour permissions can only fail on the border of the CTB (or of the picture): groups in
-      // the interior skip the per-sample tests
-      const int mw = (1 << l2w) - 1, mh = (1 << l2h) - 1;
-      const bool on_border = ((xs & mw) == 0) || (((xs + G) & mw) == 0) || (xs + G >= W) ||
-                             ((yy & mh) == 0) || (((yy + 1) & mh) == 0) || (yy + 1 >= Hh);
-      if (!on_border) {
-        Pix na[G + 2], nbv[G + 2]; // columns xs-1 .. xs+G of the two neighbour rows
-        __builtin_memcpy(na, ra + xs - 1, (G + 2) * sizeof(Pix));
-        __builtin_memcpy(nbv, rb + xs - 1, (G + 2) * sizeof(Pix));
 #pragma unroll
-        for (int k = 0; k < G; k++) {
-          const int a = na[k + 1 + hx0], b = nbv[k + 1 - hx0];
+      for (int k = 0; k < G; k++) {
+        const int xx = xs + k;
+        const int xa = xx + hx0, xb = xx - hx0;
+        bool ok = rowa_ok && rowb_ok && xa >= 0 && xa < W && xb >= 0 && xb < W;
+        if (ok) {
+          const int dxa = (xa >> l2w) - cx, dya = (ya >> l2h) - cy;
+          const int dxb = (xb >> l2w) - cx, dyb = (yb >> l2h) - cy;
+          if (dxa | dya) { const int k8 = (dya + 1) * 3 + (dxa + 1); if (!(cb.sao_nb_mask & (1u << (k8 < 4 ? k8 : k8 - 1)))) ok = false; }
+          if (dxb | dyb) { const int k8 = (dyb + 1) * 3 + (dxb + 1); if (!(cb.sao_nb_mask & (1u << (k8 < 4 ? k8 : k8 - 1)))) ok = false; }
+        }
+        if (ok) {
+          const int a = ra[xa], b = rb[xb];
           const int e = isign_(out[k] - a) + isign_(out[k] - b);
           const int o = e == -2 ? s.offset[0] : (e == -1 ? s.offset[1] : (e == 1 ? s.offset[2] : (e == 2 ? s.offset[3] : 0)));
           out[k] = clip3i(0, maxv, out[k] + o);
-        }
-      }
-      else {
-#pragma unroll
-        for (int k = 0; k < G; k++) {
-          const int xx = xs + k;
-          const int xa = xx + hx0, xb = xx - hx0;
-          bool ok = rowa_ok && rowb_ok && xa >= 0 && xa < W && xb >= 0 && xb < W;
-          if (ok) {
-            const int dxa = (xa >> l2w) - cx, dya = (ya >> l2h) - cy;
-            const int dxb = (xb >> l2w) - cx, dyb = (yb >> l2h) - cy;
-            if (dxa | dya) { const int k8 = (dya + 1) * 3 + (dxa + 1); if (!(cb.sao_nb_mask & (1u << (k8 < 4 ? k8 : k8 - 1)))) ok = false; }
-            if (dxb | dyb) { const int k8 = (dyb + 1) * 3 + (dxb + 1); if (!(cb.sao_nb_mask & (1u << (k8 < 4 ? k8 : k8 - 1)))) ok = false; }
-          }
-          if (ok) {
-            const int a = ra[xa], b = rb[xb];
-            const int e = isign_(out[k] - a) + isign_(out[k] - b);
-            const int o = e == -2 ? s.offset[0] : (e == -1 ? s.offset[1] : (e == 1 ? s.offset[2] : (e == 2 ? s.offset[3] : 0)));
-            out[k] = clip3i(0, maxv, out[k] + o);
-          }
         }
       }
     }
