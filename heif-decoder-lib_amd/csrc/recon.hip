@@ -72,6 +72,15 @@ __constant__ int8_t c_dst[4][4] = {{29, 55, 74, 84}, {74, 74, 0, -74}, {84, -29,
 __constant__ int8_t c_dct_mag[33] = {64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
                                      61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0};
 
+// Pointers into HBM are cast to the global address space so that the compiler emits global_load /
+// global_store (vmcnt only) instead of flat_* (which also count on lgkmcnt and would make every LDS wait
+// stall on the in-flight prefetches).
+#define GLOBAL_AS __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ const GLOBAL_AS T* gptr(const void* p) { return (const GLOBAL_AS T*)(uintptr_t)p; }
+template <typename T>
+__device__ __forceinline__ GLOBAL_AS T* gptr_w(void* p) { return (GLOBAL_AS T*)(uintptr_t)p; }
+
 constexpr int UPAD = 4; // unified CTU buffer: row = [3 unused | left neighbour | bw samples]; rows stay 4-byte aligned
 
 // One block to reconstruct; every member is wave-uniform (SGPR).
@@ -236,7 +245,7 @@ __device__ void predict(const Blk<Pix>& B, const int16_t* b, const int16_t* tab,
 // Invariant: the dense coefficient buffer is all zero on entry and on exit.
 template <typename Pix>
 __device__ void residual_add(const Blk<Pix>& B, int16_t* coeff, int16_t* tmp, const int8_t* dct, const int16_t* tab,
-                             const hm_coeff* __restrict__ cf, const hm_coeff pre, int lane)
+                             const GLOBAL_AS uint32_t* __restrict__ cf, const uint32_t pre_raw, int lane)
 {
   const int nT = B.nT, log2 = B.log2, c = B.c, bit_depth = B.bd;
   const int npx = nT * nT;
@@ -247,10 +256,11 @@ __device__ void residual_add(const Blk<Pix>& B, int16_t* coeff, int16_t* tmp, co
   int mx = 0, my = 0;
 #pragma unroll 1 // more than 64 levels in a block is rare: keep the register footprint of one iteration
   for (int i = lane; i < B.n_coeff; i += 64) {
-    const hm_coeff pr = i < 64 ? pre : cf[i]; // the first 64 pairs were fetched before the prediction started
-    const int32_t prod = (int32_t)((uint32_t)(int32_t)pr.value * (uint32_t)fact + (uint32_t)offset); // wraps like the reference (Q3)
-    coeff[pr.pos] = (int16_t)clip3i(-32768, 32767, prod >> bdShift);
-    const int px = pr.pos & (nT - 1), py = pr.pos >> log2;
+    const uint32_t raw = i < 64 ? pre_raw : cf[i]; // the first 64 pairs were fetched before the prediction started
+    const int pos = raw & 0xFFFF, value = (int)(int16_t)(raw >> 16);
+    const int32_t prod = (int32_t)((uint32_t)value * (uint32_t)fact + (uint32_t)offset); // wraps like the reference (Q3)
+    coeff[pos] = (int16_t)clip3i(-32768, 32767, prod >> bdShift);
+    const int px = pos & (nT - 1), py = pos >> log2;
     mx = px > mx ? px : mx;
     my = py > my ? py : my;
   }
@@ -314,8 +324,8 @@ __device__ void residual_add(const Blk<Pix>& B, int16_t* coeff, int16_t* tmp, co
   WAVE_SYNC();
 #pragma unroll 1
   for (int i = lane; i < B.n_coeff; i += 64) {
-    const hm_coeff pr = i < 64 ? pre : cf[i];
-    coeff[pr.pos] = 0;
+    const uint32_t raw = i < 64 ? pre_raw : cf[i];
+    coeff[raw & 0xFFFF] = 0;
   }
 }
 
@@ -327,11 +337,13 @@ __global__ __launch_bounds__(512) void k_recon(const hm_dev_pic* __restrict__ pi
   // descriptor -> registers once (it is read-only, but the compiler cannot know that across our stores)
   const hm_dev_pic dp = pics[blockIdx.x];
   const uint8_t* blob = dp.blob;
-  const hm_pic* H = reinterpret_cast<const hm_pic*>(blob);
-  const hm_slice* slices = reinterpret_cast<const hm_slice*>(blob + H->off_slices);
+  const GLOBAL_AS hm_pic* H = gptr<hm_pic>(blob);
+  const GLOBAL_AS hm_slice* slices = gptr<hm_slice>(blob + H->off_slices);
   const hm_ctb* ctbs = reinterpret_cast<const hm_ctb*>(blob + H->off_ctbs);
-  const uint4* tus = reinterpret_cast<const uint4*>(blob + H->off_tus);
-  const hm_coeff* coeffs = reinterpret_cast<const hm_coeff*>(blob + H->off_coeffs);
+  const GLOBAL_AS uint32_t* tus = gptr<uint32_t>(blob + H->off_tus); // 4 dwords per record
+  const GLOBAL_AS uint32_t* coeffs = gptr<uint32_t>(blob + H->off_coeffs);
+  GLOBAL_AS uint8_t* g_edge = gptr_w<uint8_t>(dp.edge);
+  GLOBAL_AS int8_t* g_qpy = gptr_w<int8_t>(dp.qpy);
 
   const int tid = threadIdx.x, lane = tid & 63, NW = blockDim.x >> 6;
   const int wave = rfl(tid >> 6); // wave-uniform by construction: row state lives in SGPRs
@@ -402,7 +414,7 @@ __global__ __launch_bounds__(512) void k_recon(const hm_dev_pic* __restrict__ pi
         const int ncols = 2 * bw + 1;
         const int yy = row * bh - 1;
         const int xbase = cx * bw - 1;
-        const Pix* src = reinterpret_cast<const Pix*>(plane + (size_t)(yy < 0 ? 0 : yy) * pitch);
+        const GLOBAL_AS Pix* src = gptr<Pix>(plane + (size_t)(yy < 0 ? 0 : yy) * pitch);
         for (int i = lane; i < ncols; i += 64) {
           const int xx = xbase + i;
           Pix v = 0;
@@ -419,12 +431,12 @@ __global__ __launch_bounds__(512) void k_recon(const hm_dev_pic* __restrict__ pi
       const int deblock_en = rfl(!slices[cb.slice_idx].deblocking_disabled);
       // software pipeline over the records: record k+1 (vector load, vmcnt) and the first
       // coefficient pairs of record k are in flight while block k is predicted
-      uint4 raw_next = make_uint4(0, 0, 0, 0);
-      if (tu_count) raw_next = tus[tu_first];
+      uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+      if (tu_count) { const GLOBAL_AS uint32_t* q = tus + 4 * (size_t)tu_first; n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3]; }
       WAVE_SYNC();
       for (int k = 0; k < tu_count; k++) {
-        const uint32_t r0 = rfl(raw_next.x), r1 = rfl(raw_next.y), r2 = rfl(raw_next.z), r3 = rfl(raw_next.w);
-        if (k + 1 < tu_count) raw_next = tus[tu_first + k + 1];
+        const uint32_t r0 = rfl(n0), r1 = rfl(n1), r2 = rfl(n2), r3 = rfl(n3);
+        if (k + 1 < tu_count) { const GLOBAL_AS uint32_t* q = tus + 4 * (size_t)(tu_first + k + 1); n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3]; }
         Blk<Pix> B;
         B.x0 = r0 & 0xFF; B.y0 = (r0 >> 8) & 0xFF;
         B.info = (r0 >> 16) & 0xFF;
@@ -442,8 +454,7 @@ __global__ __launch_bounds__(512) void k_recon(const hm_dev_pic* __restrict__ pi
         B.top = B.c == 0 ? top0 : (B.c == 1 ? top1 : top2);
         B.P = B.c == 0 ? P0 : P1;
         const bool cbf = (B.info & HM_TU_CBF) != 0;
-        hm_coeff pre;
-        pre.pos = 0; pre.value = 0;
+        uint32_t pre = 0; // raw (pos | level << 16); unpacked only when the residual is processed
         if (cbf && lane < B.n_coeff) pre = coeffs[coeff_first + lane];
 
         make_border(B, l_bA, strong, lane);
@@ -465,8 +476,8 @@ __global__ __launch_bounds__(512) void k_recon(const hm_dev_pic* __restrict__ pi
               uint8_t e = 0;
               if (i == 0 && left_ok && deblock_en) e |= 1;
               if (j == 0 && top_ok && deblock_en) e |= 2;
-              dp.edge[bx + (size_t)by * dp.w4] = e;
-              dp.qpy[bx + (size_t)by * dp.w4] = (int8_t)qpy;
+              g_edge[bx + (size_t)by * dp.w4] = e;
+              g_qpy[bx + (size_t)by * dp.w4] = (int8_t)qpy;
             }
           }
         }
@@ -484,7 +495,7 @@ __global__ __launch_bounds__(512) void k_recon(const hm_dev_pic* __restrict__ pi
           const int r = p >> l2wpr, q = p & ((1 << l2wpr) - 1);
           if (q < vwords) {
             const uint32_t word = *reinterpret_cast<const uint32_t*>(u + r * P + UPAD + q * PPW);
-            *reinterpret_cast<uint32_t*>(plane + (size_t)(yo + r) * pitch + (size_t)(xo + q * PPW) * sizeof(Pix)) = word;
+            *gptr_w<uint32_t>(plane + (size_t)(yo + r) * pitch + (size_t)(xo + q * PPW) * sizeof(Pix)) = word;
           }
         }
         WAVE_SYNC();
