@@ -56,6 +56,18 @@ __device__ __forceinline__ int wave_max(int v)
   for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o); v = t > v ? t : v; }
   return v;
 }
+// maximum of a small non-negative value (< 32) over the active lanes: binary search with ballots
+// (VALU compare + SALU only; no cross-lane data movement)
+__device__ __forceinline__ int wave_max5(int v)
+{
+  int m = 0;
+#pragma unroll
+  for (int b = 4; b >= 0; b--) {
+    const int t = m | (1 << b);
+    if (__ballot(v >= t)) m = t;
+  }
+  return m;
+}
 __device__ __forceinline__ int wave_sum(int v)
 {
 #pragma unroll
@@ -140,15 +152,17 @@ __device__ void make_border(const Blk<Pix>& b, int16_t* bA, int strong, int lane
 {
   const int nT = b.nT;
   const int DEF = 1 << (b.bd - 1);
-  int noLeftFill, topFill;
-  if (b.aTL) noLeftFill = nb(b, b.x0 - 1, b.y0 - 1);
-  else if (b.aT) noLeftFill = nb(b, b.x0, b.y0 - 1);
-  else if (b.aTR) noLeftFill = nb(b, b.x0 + nT, b.y0 - 1);
-  else noLeftFill = DEF;
-  if (b.aTL) topFill = noLeftFill;
-  else if (b.aL) topFill = nb(b, b.x0 - 1, b.y0);
-  else if (b.aTR) topFill = nb(b, b.x0 + nT, b.y0 - 1);
-  else topFill = DEF;
+  // substitution fill values are only needed when left, top or the corner is missing (picture /
+  // slice / tile borders): the common interior block skips the two dependent LDS reads
+  int noLeftFill = DEF, topFill = DEF;
+  if (!(b.aL && b.aT && b.aTL)) {
+    if (b.aTL) noLeftFill = nb(b, b.x0 - 1, b.y0 - 1);
+    else if (b.aT) noLeftFill = nb(b, b.x0, b.y0 - 1);
+    else if (b.aTR) noLeftFill = nb(b, b.x0 + nT, b.y0 - 1);
+    if (b.aTL) topFill = noLeftFill;
+    else if (b.aL) topFill = nb(b, b.x0 - 1, b.y0);
+    else if (b.aTR) topFill = nb(b, b.x0 + nT, b.y0 - 1);
+  }
 
   int filterFlag = 0;
   if (b.c == 0 && b.mode != 1 && nT != 4) {
@@ -264,8 +278,8 @@ __device__ void residual_add(const Blk<Pix>& B, int16_t* coeff, int16_t* tmp, co
     mx = px > mx ? px : mx;
     my = py > my ? py : my;
   }
-  mx = rfl(wave_max(mx));
-  my = rfl(wave_max(my));
+  mx = wave_max5(mx);
+  my = wave_max5(my);
   WAVE_SYNC();
   Pix* dst = B.u + B.y0 * B.P + UPAD + B.x0;
   const int pitch = B.P;
