@@ -227,12 +227,36 @@ def main():
             "host_entropy_decode": {"MP_per_s_per_core": round(B * 48 * 0.262144 / host_parse_s, 1) if host_parse_s else None,
                                     "note": "hm_hevc_parse (CABAC -> command stream), 1 thread, outside the timed region"},
         }
+        out["end_to_end"] = end_to_end(pkg, images[0])
         if args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(images[0], strides, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def end_to_end(pkg, image0):
+    """Clock (E) of SURVEY 8d, NOT `value`: one 12 MP grid .heic through hm_decode_item = box parsing + host
+    entropy decode (threads) + H2D + kernels + D2H into a libheif-layout host plane, per image, one at a time."""
+    import heifwriter
+    import pipeline
+    data = heifwriter.write_heic(image0["streams"], (TILE, TILE), grid=(GRID_ROWS, GRID_COLS, OUT_W, OUT_H))
+    res = {}
+    f = pipeline.HeifFile(pkg.lib(), data)
+    try:
+        for threads in (1, 8, 48):
+            f.decode(f.primary(), 10, threads=threads)  # warm-up (allocations, code objects)
+            t0 = time.perf_counter()
+            n = 3
+            for _ in range(n):
+                f.decode(f.primary(), 10, threads=threads)
+            dt = (time.perf_counter() - t0) / n
+            res[f"host_threads_{threads}"] = {"ms_per_image": round(dt * 1e3, 2), "MP_per_s": round(MP_PER_IMAGE / dt, 1)}
+    finally:
+        f.close()
+    res["note"] = "hm_decode_item: HEIF parse + CABAC on host threads + H2D + GPU kernels + D2H (pageable host memory), single image latency"
+    return res
 
 
 def pmc_traffic(kernel, images):
