@@ -44,7 +44,8 @@ struct Plane {
   int width = 0, height = 0, bit_depth = 8, stride = 0;
   uint8_t* mem = nullptr;       // 16-byte aligned start
   uint8_t* allocated = nullptr; // owned block (null for an external buffer)
-  ~Plane() { std::free(allocated); }
+  bool from_core = false;       // block came from hm_decode_item (pinned pool) rather than malloc
+  ~Plane() { if (from_core) hm_host_free(allocated); else std::free(allocated); }
 };
 
 int interleaved_components(heif_chroma c)
@@ -251,7 +252,7 @@ struct heif_error heif_decode_image(const struct heif_image_handle* in, struct h
   auto adopt = [&](heif_channel ch, int c, int w, int h) {
     std::unique_ptr<Plane> p(new Plane());
     p->width = w; p->height = h; p->bit_depth = dec.bit_depth; p->stride = dec.stride[c];
-    if (dec.plane[c]) { p->allocated = dec.plane[c]; p->mem = dec.plane[c]; dec.plane[c] = nullptr; } // malloc'd by the core
+    if (dec.plane[c]) { p->allocated = dec.plane[c]; p->mem = dec.plane[c]; p->from_core = true; dec.plane[c] = nullptr; } // owned by the core's pool
     else p->mem = (uint8_t*)prm.ext_dst;                                                              // external RGBA buffer
     img->planes[ch] = std::move(p);
   };

@@ -24,16 +24,12 @@ struct DeviceBuffer {
   int ensure(size_t n)
   {
     if (n <= cap) return HM_OK;
-    if (p) hipFree(p);
-    p = nullptr;
-    cap = 0;
-    size_t want = n + n / 4 + 256;
-    hipError_t e = hipMalloc(&p, want);
-    if (e != hipSuccess) return hm_check_hip(e, "hipMalloc");
-    cap = want;
-    return HM_OK;
+    if (p) hm_pool_device_free(p);
+    p = hm_pool_device_alloc(n);
+    cap = p ? n : 0;
+    return p ? HM_OK : HM_ERR_NO_DEVICE;
   }
-  ~DeviceBuffer() { if (p) hipFree(p); }
+  ~DeviceBuffer() { if (p) hm_pool_device_free(p); }
 };
 
 struct Item {
@@ -161,10 +157,12 @@ int hm_batch_upload(hm_batch* b, void* stream)
   if ((rc = b->d_work.ensure(work_bytes))) return rc;
   if ((rc = b->d_desc.ensure(sizeof(hm_dev_pic) * (size_t)n))) return rc;
 
-  // stage all blobs in one pinned-less host buffer -> one H2D copy
-  std::vector<uint8_t> staging(blob_bytes, 0);
-  for (int i = 0; i < n; i++) std::memcpy(staging.data() + blob_off[i], b->items[i].blob.data(), b->items[i].blob.size());
-  hipError_t e = hipMemcpyAsync(b->d_blobs.p, staging.data(), blob_bytes, hipMemcpyHostToDevice, s);
+  // stage all blobs in one pinned host buffer -> one H2D copy at PCIe rate
+  struct Pinned { void* p; ~Pinned() { hm_pool_pinned_free(p); } } staging{hm_pool_pinned_alloc(blob_bytes + sizeof(hm_dev_pic) * (size_t)n)};
+  if (!staging.p) return HM_ERR_NO_DEVICE;
+  uint8_t* stg = (uint8_t*)staging.p;
+  for (int i = 0; i < n; i++) std::memcpy(stg + blob_off[i], b->items[i].blob.data(), b->items[i].blob.size());
+  hipError_t e = hipMemcpyAsync(b->d_blobs.p, stg, blob_bytes, hipMemcpyHostToDevice, s);
   if (e != hipSuccess) return hm_check_hip(e, "H2D command streams");
 
   size_t di = 0;
@@ -221,9 +219,10 @@ int hm_batch_upload(hm_batch* b, void* stream)
       b->h_desc[di++] = d;
     }
   }
-  e = hipMemcpyAsync(b->d_desc.p, b->h_desc.data(), sizeof(hm_dev_pic) * (size_t)n, hipMemcpyHostToDevice, s);
+  std::memcpy(stg + blob_bytes, b->h_desc.data(), sizeof(hm_dev_pic) * (size_t)n);
+  e = hipMemcpyAsync(b->d_desc.p, stg + blob_bytes, sizeof(hm_dev_pic) * (size_t)n, hipMemcpyHostToDevice, s);
   if (e != hipSuccess) return hm_check_hip(e, "H2D descriptors");
-  e = hipStreamSynchronize(s); // staging buffers are pageable and about to go out of scope
+  e = hipStreamSynchronize(s); // the staging buffer goes back to the pool
   if (e != hipSuccess) return hm_check_hip(e, "upload sync");
   b->uploaded = true;
   return HM_OK;

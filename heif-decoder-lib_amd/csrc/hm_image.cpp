@@ -28,10 +28,10 @@ struct DevMem {
   void* p = nullptr;
   int alloc(size_t n)
   {
-    hipError_t e = hipMalloc(&p, n ? n : 1);
-    return e == hipSuccess ? HM_OK : hm_check_hip(e, "hipMalloc");
+    p = hm_pool_device_alloc(n);
+    return p ? HM_OK : HM_ERR_NO_DEVICE;
   }
-  ~DevMem() { if (p) hipFree(p); }
+  ~DevMem() { if (p) hm_pool_device_free(p); }
 };
 
 struct Blob {
@@ -117,10 +117,12 @@ int hm_file_item_hevc_data(const hm_file* f, uint32_t id, uint8_t** out, size_t*
   return HM_OK;
 }
 
+void hm_host_free(void* plane) { hm_pool_pinned_free(plane); }
+
 void hm_decoded_free(hm_decoded* d)
 {
   if (!d) return;
-  for (int c = 0; c < 3; c++) { std::free(d->plane[c]); d->plane[c] = nullptr; }
+  for (int c = 0; c < 3; c++) { hm_pool_pinned_free(d->plane[c]); d->plane[c] = nullptr; }
 }
 
 int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params, hm_decoded* out)
@@ -247,7 +249,7 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
     const size_t sz[3] = {ybytes, cbytes, cbytes};
     void* src[3] = {dy.p, dcb.p, dcr.p};
     for (int c = 0; c < 3; c++) {
-      out->plane[c] = (uint8_t*)std::malloc(sz[c]);
+      out->plane[c] = (uint8_t*)hm_pool_pinned_alloc(sz[c]);
       if (!out->plane[c]) { hm_decoded_free(out); return hm_fail(HM_ERR_NOMEM, "out of memory"); }
       out->stride[c] = c == 0 ? ys : cs;
       e = hipMemcpyAsync(out->plane[c], src[c], sz[c], hipMemcpyDeviceToHost, s);
@@ -282,7 +284,7 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
       out->stride[0] = params->ext_dst_stride;
     }
     else {
-      out->plane[0] = (uint8_t*)std::malloc(obytes);
+      out->plane[0] = (uint8_t*)hm_pool_pinned_alloc(obytes);
       if (!out->plane[0]) return hm_fail(HM_ERR_NOMEM, "out of memory");
       e = hipMemcpyAsync(out->plane[0], dout.p, obytes, hipMemcpyDeviceToHost, s);
       if (e != hipSuccess) { hm_decoded_free(out); return hm_check_hip(e, "D2H"); }

@@ -21,6 +21,13 @@ int hm_launch_colour_int420(const hm_colour_desc* d, const int coef[4], const vo
 int hm_launch_colour_float(const hm_colour_desc* d, const float coef[4], int mode, const void* y,
                            const void* cb, const void* cr, void* out, hipStream_t s);
 
+// devpool.cpp: size-bucketed cache of device / pinned-host allocations (hipMalloc + hipFree cost more
+// than the kernels of a 12 MP image)
+void* hm_pool_device_alloc(size_t bytes);
+void hm_pool_device_free(void* p);
+void* hm_pool_pinned_alloc(size_t bytes);
+void hm_pool_pinned_free(void* p);
+
 // recon.hip / filters.hip
 struct hm_dev_pic;
 int hm_launch_recon(const struct hm_dev_pic* d_pics, int n_pics, int log2_ctb, int chroma_format, int bit_depth,

@@ -176,7 +176,8 @@ typedef struct hm_decoded {
   int32_t out_format;          /* as requested                                                    */
   int32_t has_nclx, primaries, transfer, matrix, full_range; /* profile attached to the result   */
   int32_t used_ext_dst;
-  uint8_t* plane[3];           /* host memory, libheif plane layout (pixelimage.cc:139-218);       */
+  uint8_t* plane[3];           /* pinned host memory (owned by the library: release with hm_decoded_free or
+                                  hm_host_free), libheif plane layout (pixelimage.cc:139-218);      */
   int32_t stride[3];           /*   interleaved output uses plane[0] only                          */
   int32_t plane_width[3], plane_height[3];
 } hm_decoded;
@@ -193,6 +194,8 @@ HM_API int      hm_file_item_hevc_data(const hm_file* f, uint32_t id, uint8_t** 
  * context.cc:1516-1600, 2120-2404).  Free the result with hm_decoded_free. */
 HM_API int      hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params, hm_decoded* out);
 HM_API void     hm_decoded_free(hm_decoded* d);
+/* release one plane taken out of an hm_decoded (ownership transfer, used by the libheif facade) */
+HM_API void     hm_host_free(void* plane);
 
 #ifdef __cplusplus
 }
