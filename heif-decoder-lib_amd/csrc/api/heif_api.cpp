@@ -222,6 +222,8 @@ struct heif_error heif_decode_image(const struct heif_image_handle* in, struct h
   prm.host_threads = in->ctx->max_threads;
   if (opt) {
     prm.ignore_transformations = opt->ignore_transformations;
+    if (opt->version >= 2 && opt->convert_hdr_to_8bit && in->info.bit_depth > 8)
+      return err(heif_error_Unsupported_feature, heif_suberror_Unsupported_color_conversion, "convert_hdr_to_8bit needs the reference's bit-depth ops (hdr_sdr.cc), not on the GPU path yet");
     if (opt->decoder_id && std::strcmp(opt->decoder_id, "mi355x") != 0)
       return err(heif_error_Unsupported_feature, heif_suberror_Unsupported_codec, "this build only carries the 'mi355x' HEVC decoder");
     if (opt->version >= 5 && opt->color_conversion_options.only_use_preferred_chroma_algorithm &&

@@ -189,13 +189,23 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
   if (is_grid) {
     hm::GridInfo g;
     f->file.grid_info(id, g, err);
+    // geometry checks and tile origins follow context.cc:2299-2359: positions advance by the tiles'
+    // *declared* ('ispe') size; all tiles must be equally sized and cover the output
+    const hm::Item* t0 = f->file.item(tiles[0].id);
+    const int iw = t0 ? t0->props.ispe_width : 0, ih = t0 ? t0->props.ispe_height : 0;
+    if (canvas_w > 32768 || canvas_h > 32768) return hm_fail(HM_ERR_BITSTREAM, "Image size exceeds the maximum of 32768x32768 (security limit)");
     for (int i = 0; i < nt; i++) {
       const hm_pic* h = reinterpret_cast<const hm_pic*>(blobs[i].p);
+      const hm::Item* ti = f->file.item(tiles[i].id);
+      const int sw_ = ti ? ti->props.ispe_width : 0, sh_ = ti ? ti->props.ispe_height : 0;
+      if (sw_ < canvas_w / g.cols || sh_ < canvas_h / g.rows) return hm_fail(HM_ERR_BITSTREAM, "Grid tiles do not cover whole image");
+      if (sw_ != iw || sh_ != ih) return hm_fail(HM_ERR_BITSTREAM, "Grid tiles have different sizes");
       if (h->chroma_format != chroma) return hm_fail(HM_ERR_BITSTREAM, "Image tile has different chroma format than combined image");
-      if (h->bit_depth_y != bd) return hm_fail(HM_ERR_BITSTREAM, "tile has a different bit depth");
-      tiles[i].x0 = (i % g.cols) * tile_w; // context.cc:2299-2359: x0 += tile width, y0 += tile height
-      tiles[i].y0 = (i / g.cols) * tile_h;
+      if (h->bit_depth_y != bd) return hm_fail(HM_ERR_BITSTREAM, "Image tile has different pixel depth than combined image");
+      tiles[i].x0 = (i % g.cols) * iw;
+      tiles[i].y0 = (i / g.cols) * ih;
     }
+    (void)tile_w; (void)tile_h;
   }
   else { canvas_w = tile_w; canvas_h = tile_h; }
   const int bps = bd > 8 ? 2 : 1;
