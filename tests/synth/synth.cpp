@@ -270,6 +270,7 @@ __attribute__((visibility("default"))) int hm_synth_picture(const SynthParams* p
     write_ptl(w, p);
     w.ue(0);
     w.ue(p.chroma_format);
+    if (p.chroma_format == 3) w.flag(0); // separate_colour_plane_flag
     w.ue(p.width); w.ue(p.height);
     w.flag(0); // conformance window
     w.ue(p.bit_depth - 8); w.ue(p.bit_depth - 8);

@@ -1,0 +1,108 @@
+"""CPU: error behaviour of the host side (no GPU needed): malformed HEIF / HEVC input must produce an
+error status (never a crash), invalid grids report the reference's error conditions
+(context.cc:2142-2153, 2321-2337), and without a GPU the decode entry points fail loudly
+(HM_ERR_NO_DEVICE) instead of falling back to a CPU path."""
+import ctypes as C
+import os
+import random
+import struct
+
+import pytest
+
+import corpus
+import heifwriter
+import hevcutil
+import pipeline
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _tiles(n, **kw):
+    import synthutil
+    return [synthutil.picture(300 + i, width=64, height=64, **kw) for i in range(n)]
+
+
+def test_truncated_and_corrupted_hevc_never_crashes(hm):
+    rng = random.Random(1234)
+    base = [corpus.stream("tiny"), corpus.stream("ragged"), corpus.stream("ctb64_wpp"), corpus.stream("hi422_10")]
+    ok = err = 0
+    for data in base:
+        for _ in range(150):
+            b = bytearray(data)
+            mode = rng.randrange(4)
+            if mode == 0:
+                b = b[:rng.randrange(1, len(b))]
+            elif mode == 1:
+                for _ in range(rng.randrange(1, 6)):
+                    b[rng.randrange(len(b))] ^= 1 << rng.randrange(8)
+            elif mode == 2:
+                i = rng.randrange(len(b))
+                b[i:i + rng.randrange(1, 16)] = bytes(rng.randrange(256) for _ in range(rng.randrange(1, 16)))
+            else:
+                b += bytes(rng.randrange(256) for _ in range(rng.randrange(1, 64)))
+            try:
+                hevcutil.parse(hm, bytes(b))
+                ok += 1
+            except RuntimeError:
+                err += 1
+    assert ok + err == 600 and err > 100
+
+
+def test_truncated_heif_is_an_error(hm):
+    data = heifwriter.write_heic(_tiles(1), (64, 64))
+    for cut in (0, 4, 11, 40, len(data) // 2):
+        with pytest.raises(RuntimeError):
+            f = pipeline.HeifFile(hm, data[:cut])
+            f.info(f.primary())
+    with pytest.raises(RuntimeError):
+        pipeline.HeifFile(hm, b"\x00\x00\x00\x10ftypheic\x00\x00\x00\x00")  # no meta box
+
+
+def _decode_status(hm, data):
+    f = pipeline.HeifFile(hm, data)
+    prm = pipeline.DecodeParams(10, 1, 0, 0, None, None, 0, 0)
+    d = pipeline.Decoded()
+    rc = hm.hm_decode_item(f.h, f.primary(), C.byref(prm), C.byref(d))
+    msg = hm.hm_last_error().decode()
+    f.close()
+    return rc, msg
+
+
+def test_invalid_grids_report_reference_errors(hm):
+    t = _tiles(4)
+    # fewer tiles than rows*cols (context.cc:2142-2153)
+    bad = heifwriter.write_heic(t[:3], (64, 64), grid=(2, 2, 128, 128))
+    with pytest.raises(RuntimeError, match="dimg"):
+        pipeline.HeifFile(hm, bad).info(4)
+    # tiles do not cover the output (context.cc:2321-2326)
+    rc, msg = _decode_status(hm, heifwriter.write_heic(t, (64, 64), grid=(2, 2, 200, 128)))
+    assert rc == -3 and "cover" in msg
+    # tiles of different declared size (context.cc:2333-2337): patch the 2nd tile's ispe
+    import synthutil
+    mixed = t[:3] + [synthutil.picture(399, width=64, height=72)]
+    data = bytearray(heifwriter.write_heic(mixed, (64, 64), grid=(2, 2, 128, 128)))
+    ispe = [i for i in range(len(data) - 4) if data[i:i + 4] == b"ispe"]
+    data[ispe[3] + 8:ispe[3] + 16] = struct.pack(">II", 64, 72)
+    rc, msg = _decode_status(hm, bytes(data))
+    assert rc == -3 and "different sizes" in msg
+
+
+def test_no_gpu_means_loud_failure_not_cpu_fallback(hm):
+    if hm.hm_device_count() > 0:
+        pytest.skip("a GPU is present")
+    rc, msg = _decode_status(hm, heifwriter.write_heic(_tiles(1), (64, 64)))
+    assert rc == -4, (rc, msg)  # HM_ERR_NO_DEVICE
+    b = C.c_void_p()
+    assert hm.hm_batch_create(C.byref(b)) == -4
+
+
+def test_unsupported_syntax_is_reported(hm):
+    """4:4:4 / monochrome are outside the GPU path: HM_ERR_UNSUPPORTED with a reason, not garbage"""
+    import synthutil
+    for cf in (0, 3):
+        try:
+            data = synthutil.picture(5, width=64, height=64, chroma_format=cf)
+        except RuntimeError:
+            continue  # the synthesiser itself may refuse
+        with pytest.raises(RuntimeError, match="-2.*chroma format"):
+            hevcutil.parse(hm, data)
