@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Average the rocprofv3 counter_collection.csv values per kernel and counter (per launch)."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+root = sys.argv[1]
+acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            name = row["Kernel_Name"]
+            for k in ("k_recon", "k_deblock", "k_sao_paste", "k_ycbcr"):
+                if k in name:
+                    a = acc[k][row["Counter_Name"]]
+                    a[0] += float(row["Counter_Value"]); a[1] += 1
+out = {k: {c: v[0] / v[1] for c, v in sorted(cs.items())} for k, cs in acc.items()}
+for k, cs in out.items():
+    wc = cs.get("SQ_WAVE_CYCLES")
+    if wc:
+        cs["_frac_of_wave_cycles"] = {c: round(cs[c] / wc, 4) for c in cs if c.startswith(("SQ_WAIT", "SQ_ACTIVE")) }
+json.dump(out, open(os.path.join(root, "summary.json"), "w"), indent=1)
+print(json.dumps(out.get("k_recon", {}), indent=1))
