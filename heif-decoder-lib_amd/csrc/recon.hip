@@ -18,18 +18,22 @@
 //     the wave above are visible after the acquire);
 //   * the 64 lanes of the wave work on the samples of one transform block at a time.
 // Staging in LDS (per wave): the CTU being reconstructed with the column left of it (one unified
-// buffer per plane, so a neighbour fetch is a single ds_read at a computed address), the row of
-// samples above the CTU, the dense coefficient block, the transform intermediate and the 4nT+1
-// reference samples.  HBM sees one coalesced read of the line above and one coalesced write of the
-// finished CTU (algorithmic traffic: command stream + 1.5 B/px out for 8-bit 4:2:0).
-// The block records are wave-uniform: they are fetched one block ahead with a vector load (vmcnt,
-// so the prefetch never blocks an LDS wait) and moved to SGPRs with v_readfirstlane, which keeps
-// all per-block control flow on the scalar unit.
+// buffer per plane, so a neighbour fetch is a single ds_read at a computed address), the dense
+// coefficient block, the transform intermediate and the 4nT+1 reference samples.  Per workgroup:
+// one line of samples per wave (the bottom sample row of the CTU row that wave is reconstructing),
+// from which the wave of the row below takes its "above" neighbours - the picture in HBM is
+// write-only for this kernel (one coalesced write of each finished CTU; algorithmic traffic:
+// command stream + 1.5 B/px out for 8-bit 4:2:0), the row hand-over needs no global round trip
+// and the progress release/acquire only has to order LDS traffic.
+// The block records are wave-uniform: they are fetched one block ahead - across CTU borders - with
+// a vector load (vmcnt, so the prefetch never blocks an LDS wait) and moved to SGPRs with
+// v_readfirstlane, which keeps all per-block control flow on the scalar unit.
 // Integer work, latency/dependency bound: no MFMA.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "hm_device.h"
 #include "hm_internal.h"
@@ -87,6 +91,9 @@ __constant__ int8_t c_dct_mag[33] = {64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80,
 // Pointers into HBM are cast to the global address space so that the compiler emits global_load /
 // global_store (vmcnt only) instead of flat_* (which also count on lgkmcnt and would make every LDS wait
 // stall on the in-flight prefetches).
+// per-lane loops over the samples of a block: one trip for blocks up to 8x8 (straight-line code), rolled
+// loops for the larger ones (keeps the register footprint at 64 VGPRs)
+#define BLOCK_LOOP _Pragma("unroll 1")
 #define GLOBAL_AS __attribute__((address_space(1)))
 template <typename T>
 __device__ __forceinline__ const GLOBAL_AS T* gptr(const void* p) { return (const GLOBAL_AS T*)(uintptr_t)p; }
@@ -99,7 +106,7 @@ constexpr int UPAD = 4; // unified CTU buffer: row = [3 unused | left neighbour 
 template <typename Pix>
 struct Blk {
   Pix* u;            // unified CTU buffer of the plane: sample (x,y) at u[y*P + UPAD + x], x >= -1
-  const Pix* top;    // top[1 + x] = sample at (x,-1), x = -1 .. 2*bw-1
+  const Pix* top;    // top[1 + x] = sample at (x,-1), x = -1 .. 2*bw-1 (inside the line of the CTU row above)
   int P;             // pitch of u in samples
   int x0, y0, nT, log2, c, mode, qp, info;
   int aL, aBL, aT, aTR, aTL;
@@ -117,10 +124,10 @@ __device__ __forceinline__ int nb(const Blk<Pix>& b, int x, int y)
 // Value of reference sample i (i = -2nT .. 2nT; negative = left column bottom-up, 0 = corner,
 // positive = top row) after the substitution process (intrapred.h:620-836 == H.265 8.4.4.2.2),
 // as a pure function of the staged neighbourhood: one ds_read per call.
-template <typename Pix>
+template <typename Pix, int L2>
 __device__ __forceinline__ int border_value(const Blk<Pix>& b, int i, int noLeftFill, int topFill)
 {
-  const int nT = b.nT;
+  constexpr int nT = 1 << L2;
   int x, y, valid, fill;
   if (i < 0) {
     const int k = -i; // sample (x0-1, y0+k-1)
@@ -147,68 +154,121 @@ __device__ __forceinline__ int border_value(const Blk<Pix>& b, int i, int noLeft
 }
 
 // ---- reference samples incl. smoothing (intrapred.h:192-266), written once to bA -------------------
-template <typename Pix>
-__device__ void make_border(const Blk<Pix>& b, int16_t* bA, int strong, int lane)
+template <typename Pix, int L2>
+__device__ __forceinline__ void make_border(const Blk<Pix>& b, int16_t* bA, int strong, int lane)
 {
-  const int nT = b.nT;
-  const int DEF = 1 << (b.bd - 1);
-  // substitution fill values are only needed when left, top or the corner is missing (picture /
-  // slice / tile borders): the common interior block skips the two dependent LDS reads
-  int noLeftFill = DEF, topFill = DEF;
-  if (!(b.aL && b.aT && b.aTL)) {
-    if (b.aTL) noLeftFill = nb(b, b.x0 - 1, b.y0 - 1);
-    else if (b.aT) noLeftFill = nb(b, b.x0, b.y0 - 1);
-    else if (b.aTR) noLeftFill = nb(b, b.x0 + nT, b.y0 - 1);
-    if (b.aTL) topFill = noLeftFill;
-    else if (b.aL) topFill = nb(b, b.x0 - 1, b.y0);
-    else if (b.aTR) topFill = nb(b, b.x0 + nT, b.y0 - 1);
-  }
-
+  constexpr int nT = 1 << L2;
+  int16_t* const bc = bA + 64; // centre (corner sample)
   int filterFlag = 0;
   if (b.c == 0 && b.mode != 1 && nT != 4) {
     const int d1 = iabs_(b.mode - 26), d2 = iabs_(b.mode - 10);
     const int d = d1 < d2 ? d1 : d2;
     filterFlag = nT == 8 ? d > 7 : (nT == 16 ? d > 1 : d > 0);
   }
+
+  if (b.aL && b.aT && b.aTL) {
+    // Interior block (left, above and corner exist): substitution only replicates the last available
+    // sample of a partly available below-left / above-right run = a clamped coordinate.  One ds_read per lane.
+    const Pix* lp = b.u + (b.y0 * b.P + UPAD + b.x0 - 1);                                    // (x0-1, y0)
+    const Pix* tp = b.y0 > 0 ? b.u + ((b.y0 - 1) * b.P + UPAD + b.x0) : b.top + (1 + b.x0); // (x0, y0-1)
+    const int nL1 = nT + b.aBL - 1, nT1 = nT + b.aTR - 1;
+    if (!filterFlag) {
+      BLOCK_LOOP
+      for (int e = lane; e <= 4 * nT; e += 64) {
+        const int i = e - 2 * nT;
+        const Pix* q = i < 0 ? lp + imin_(-i - 1, nL1) * b.P : tp + imin_(i - 1, nT1);
+        bc[i] = (int16_t)*q;
+      }
+      return;
+    }
+    // [1 2 1] smoothing or strong (bilinear) smoothing; the two end samples stay unfiltered
+    bool bi = false;
+    int p0 = 0, pL = 0, pT = 0;
+    if (strong && nT == 32) {
+      p0 = tp[-1];
+      pL = lp[imin_(63, nL1) * b.P];
+      pT = tp[imin_(63, nT1)];
+      const int mL = lp[31 * b.P], mT = tp[31];
+      const int lim = 1 << (b.bd - 5);
+      bi = iabs_(p0 + pT - 2 * mT) < lim && iabs_(p0 + pL - 2 * mL) < lim;
+    }
+    BLOCK_LOOP
+    for (int e = lane; e <= 4 * nT; e += 64) {
+      const int i = e - 2 * nT;
+      int v;
+      if (bi && i != -2 * nT && i != 2 * nT) {
+        if (i == 0) v = p0;
+        else if (i < 0) v = p0 + (((-i) * (pL - p0) + 32) >> 6);
+        else v = p0 + ((i * (pT - p0) + 32) >> 6);
+      }
+      else {
+        const int im = i - 1, ip = i + 1;
+        const int c0 = *(i < 0 ? lp + imin_(-i - 1, nL1) * b.P : tp + imin_(i - 1, nT1));
+        v = c0;
+        if (i != -2 * nT && i != 2 * nT) {
+          const int cm = *(im < 0 ? lp + imin_(-im - 1, nL1) * b.P : tp + imin_(im - 1, nT1));
+          const int cp = *(ip < 0 ? lp + imin_(-ip - 1, nL1) * b.P : tp + imin_(ip - 1, nT1));
+          v = (cm + 2 * c0 + cp + 2) >> 2;
+        }
+      }
+      bc[i] = (int16_t)v;
+    }
+    return;
+  }
+
+  // ---- picture / slice / tile border: full substitution process ----
+  const int DEF = 1 << (b.bd - 1);
+  int noLeftFill = DEF, topFill = DEF;
+  if (b.aTL) noLeftFill = nb(b, b.x0 - 1, b.y0 - 1);
+  else if (b.aT) noLeftFill = nb(b, b.x0, b.y0 - 1);
+  else if (b.aTR) noLeftFill = nb(b, b.x0 + nT, b.y0 - 1);
+  if (b.aTL) topFill = noLeftFill;
+  else if (b.aL) topFill = nb(b, b.x0 - 1, b.y0);
+  else if (b.aTR) topFill = nb(b, b.x0 + nT, b.y0 - 1);
+
   if (!filterFlag) {
-    for (int e = lane; e <= 4 * nT; e += 64) bA[64 + e - 2 * nT] = (int16_t)border_value(b, e - 2 * nT, noLeftFill, topFill);
+    BLOCK_LOOP
+    for (int e = lane; e <= 4 * nT; e += 64) bc[e - 2 * nT] = (int16_t)border_value<Pix, L2>(b, e - 2 * nT, noLeftFill, topFill);
     return;
   }
   bool bi = false;
   int p0 = 0, pL = 0, pT = 0;
   if (strong && nT == 32) {
-    p0 = border_value(b, 0, noLeftFill, topFill);
-    pL = border_value(b, -64, noLeftFill, topFill);
-    pT = border_value(b, 64, noLeftFill, topFill);
-    const int mL = border_value(b, -32, noLeftFill, topFill), mT = border_value(b, 32, noLeftFill, topFill);
+    p0 = border_value<Pix, L2>(b, 0, noLeftFill, topFill);
+    pL = border_value<Pix, L2>(b, -64, noLeftFill, topFill);
+    pT = border_value<Pix, L2>(b, 64, noLeftFill, topFill);
+    const int mL = border_value<Pix, L2>(b, -32, noLeftFill, topFill), mT = border_value<Pix, L2>(b, 32, noLeftFill, topFill);
     const int lim = 1 << (b.bd - 5);
     bi = iabs_(p0 + pT - 2 * mT) < lim && iabs_(p0 + pL - 2 * mL) < lim;
   }
+  BLOCK_LOOP
   for (int e = lane; e <= 4 * nT; e += 64) {
     const int i = e - 2 * nT;
     int v;
-    if (i == -2 * nT || i == 2 * nT) v = border_value(b, i, noLeftFill, topFill);
+    if (i == -2 * nT || i == 2 * nT) v = border_value<Pix, L2>(b, i, noLeftFill, topFill);
     else if (bi) {
       if (i == 0) v = p0;
       else if (i < 0) v = p0 + (((-i) * (pL - p0) + 32) >> 6);
       else v = p0 + ((i * (pT - p0) + 32) >> 6);
     }
-    else v = (border_value(b, i + 1, noLeftFill, topFill) + 2 * border_value(b, i, noLeftFill, topFill) +
-              border_value(b, i - 1, noLeftFill, topFill) + 2) >> 2;
-    bA[64 + i] = (int16_t)v;
+    else v = (border_value<Pix, L2>(b, i + 1, noLeftFill, topFill) + 2 * border_value<Pix, L2>(b, i, noLeftFill, topFill) +
+              border_value<Pix, L2>(b, i - 1, noLeftFill, topFill) + 2) >> 2;
+    bc[i] = (int16_t)v;
   }
 }
 
 // ---- predictors (intrapred.h:269-441) ------------------------------------------------------------------
-template <typename Pix>
-__device__ void predict(const Blk<Pix>& B, const int16_t* b, const int16_t* tab, int lane)
+template <typename Pix, int L2>
+__device__ __forceinline__ void predict(const Blk<Pix>& B, const int16_t* b, const int16_t* tab, int lane)
 {
-  const int nT = B.nT, log2 = B.log2, mode = B.mode, c = B.c;
+  constexpr int nT = 1 << L2, log2 = L2;
+  const int mode = B.mode, c = B.c;
   Pix* dst = B.u + B.y0 * B.P + UPAD + B.x0;
   const int pitch = B.P;
   const int maxv = (1 << B.bd) - 1;
   const int npx = nT * nT;
   if (mode == 0) {
+    BLOCK_LOOP
     for (int p = lane; p < npx; p += 64) {
       const int x = p & (nT - 1), y = p >> log2;
       dst[y * pitch + x] = (Pix)(((nT - 1 - x) * b[-1 - y] + (x + 1) * b[1 + nT] + (nT - 1 - y) * b[1 + x] + (y + 1) * b[-1 - nT] + nT) >> (log2 + 1));
@@ -219,6 +279,7 @@ __device__ void predict(const Blk<Pix>& B, const int16_t* b, const int16_t* tab,
     if (lane < nT) s = b[lane + 1] + b[-lane - 1];
     const int dc = (wave_sum(s) + nT) >> (log2 + 1);
     const bool edge = (c == 0 && nT < 32);
+    BLOCK_LOOP
     for (int p = lane; p < npx; p += 64) {
       const int x = p & (nT - 1), y = p >> log2;
       int v = dc;
@@ -236,6 +297,7 @@ __device__ void predict(const Blk<Pix>& B, const int16_t* b, const int16_t* tab,
     const bool vert = mode >= 18;
     const int sgn = vert ? 1 : -1; // ref[k] = border[sgn * k] for k >= 0, border[-sgn * proj(k)] for k < 0
     const bool smooth = (c == 0 && nT < 32 && (mode == 26 || mode == 10));
+    BLOCK_LOOP
     for (int p = lane; p < npx; p += 64) {
       const int x = p & (nT - 1), y = p >> log2;
       const int major = vert ? y : x, minor = vert ? x : y;
@@ -257,11 +319,12 @@ __device__ void predict(const Blk<Pix>& B, const int16_t* b, const int16_t* tab,
 
 // ---- dequantisation + inverse transform + add (transform.cc:386-689, fallback-dct.cc) --------------------
 // Invariant: the dense coefficient buffer is all zero on entry and on exit.
-template <typename Pix>
-__device__ void residual_add(const Blk<Pix>& B, int16_t* coeff, int16_t* tmp, const int8_t* dct, const int16_t* tab,
-                             const GLOBAL_AS uint32_t* __restrict__ cf, const uint32_t pre_raw, int lane)
+template <typename Pix, int L2>
+__device__ __forceinline__ void residual_add(const Blk<Pix>& B, int16_t* coeff, int16_t* tmp, const int8_t* dct, const int16_t* tab,
+                                             const GLOBAL_AS uint32_t* __restrict__ cf, const uint32_t pre_raw, int lane)
 {
-  const int nT = B.nT, log2 = B.log2, c = B.c, bit_depth = B.bd;
+  constexpr int nT = 1 << L2, log2 = L2;
+  const int c = B.c, bit_depth = B.bd;
   const int npx = nT * nT;
   const int qP = B.qp;
   const int bdShift = bit_depth + log2 - 9;
@@ -278,8 +341,8 @@ __device__ void residual_add(const Blk<Pix>& B, int16_t* coeff, int16_t* tmp, co
     mx = px > mx ? px : mx;
     my = py > my ? py : my;
   }
-  mx = wave_max5(mx);
-  my = wave_max5(my);
+  if (L2 == 2) mx = my = 3; // a 4x4 block: four multiply-adds per sample are cheaper than the search
+  else { mx = wave_max5(mx); my = wave_max5(my); }
   WAVE_SYNC();
   Pix* dst = B.u + B.y0 * B.P + UPAD + B.x0;
   const int pitch = B.P;
@@ -288,6 +351,7 @@ __device__ void residual_add(const Blk<Pix>& B, int16_t* coeff, int16_t* tmp, co
 
   if (B.info & HM_TU_TSKIP) { // transform.cc:566-643
     const int tsShift = 5 + log2;
+    BLOCK_LOOP
     for (int p = lane; p < npx; p += 64) {
       const int x = p & (nT - 1), y = p >> log2;
       const int32_t cc = (int32_t)((uint32_t)(int32_t)coeff[p] << tsShift);
@@ -316,22 +380,29 @@ __device__ void residual_add(const Blk<Pix>& B, int16_t* coeff, int16_t* tmp, co
   }
   else {
     // inverse DCT, fallback-dct.cc:592-733; rows/columns beyond the last non-zero coefficient are
-    // zero and contribute nothing, so the sums stop at (my, mx)
+    // zero and contribute nothing, so the sums stop at (my, mx).  The intermediate holds 16 rows:
+    // a 32x32 block takes two column-transform / row-transform rounds.
     const int fct = 32 >> log2;
-    for (int p = lane; p < npx; p += 64) {
-      const int cc = p & (nT - 1), i = p >> log2;
-      int sum = 0;
-      if (cc <= mx)
-        for (int j = 0; j <= my; j++) sum += (int)dct[(fct * j) * 32 + i] * (int)coeff[cc + j * nT];
-      tmp[cc + i * nT] = (int16_t)clip3i(-32768, 32767, (sum + 64) >> 7);
-    }
-    WAVE_SYNC();
-    for (int p = lane; p < npx; p += 64) {
-      const int i = p & (nT - 1), y = p >> log2;
-      int sum = 0;
-      for (int j = 0; j <= mx; j++) sum += (int)dct[(fct * j) * 32 + i] * (int)tmp[y * nT + j];
-      const int out = (sum + rnd2) >> postShift; // stage 2 is not clipped to 16 bit (Q4)
-      dst[y * pitch + i] = (Pix)clip3i(0, maxv, (int)dst[y * pitch + i] + out);
+    constexpr int rpp = nT < 16 ? nT : 16, n_part = rpp << log2;
+    for (int i0 = 0; i0 < nT; i0 += rpp) {
+      BLOCK_LOOP
+      for (int p = lane; p < n_part; p += 64) {
+        const int cc = p & (nT - 1), ir = p >> log2, i = i0 + ir;
+        int sum = 0;
+        if (cc <= mx)
+          for (int j = 0; j <= my; j++) sum += (int)dct[(fct * j) * 32 + i] * (int)coeff[cc + j * nT];
+        tmp[cc + ir * nT] = (int16_t)clip3i(-32768, 32767, (sum + 64) >> 7);
+      }
+      WAVE_SYNC();
+      BLOCK_LOOP
+      for (int p = lane; p < n_part; p += 64) {
+        const int i = p & (nT - 1), yr = p >> log2, y = i0 + yr;
+        int sum = 0;
+        for (int j = 0; j <= mx; j++) sum += (int)dct[(fct * j) * 32 + i] * (int)tmp[yr * nT + j];
+        const int out = (sum + rnd2) >> postShift; // stage 2 is not clipped to 16 bit (Q4)
+        dst[y * pitch + i] = (Pix)clip3i(0, maxv, (int)dst[y * pitch + i] + out);
+      }
+      WAVE_SYNC();
     }
   }
   // restore the all-zero invariant: every lane clears the entries it scattered (after the reads above)
@@ -344,35 +415,38 @@ __device__ void residual_add(const Blk<Pix>& B, int16_t* coeff, int16_t* tmp, co
 }
 
 // =====================================================================================================
-template <typename Pix>
-__global__ __launch_bounds__(512) void k_recon(const hm_dev_pic* __restrict__ pics, int per_wave_bytes)
+// line_bytes: size of one sample line (all planes) as laid out by the launcher for the widest picture of the
+// batch class; n_lines = max(waves, 2) of them follow the tables in LDS.
+template <typename Pix, int LOG2_CTB>
+__global__ __launch_bounds__(512) void k_recon(const hm_dev_pic* __restrict__ pics, int per_wave_bytes, int line_bytes, int n_lines)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   // descriptor -> registers once (it is read-only, but the compiler cannot know that across our stores)
   const hm_dev_pic dp = pics[blockIdx.x];
   const uint8_t* blob = dp.blob;
   const GLOBAL_AS hm_pic* H = gptr<hm_pic>(blob);
-  const GLOBAL_AS hm_slice* slices = gptr<hm_slice>(blob + H->off_slices);
-  const hm_ctb* ctbs = reinterpret_cast<const hm_ctb*>(blob + H->off_ctbs);
-  const GLOBAL_AS uint32_t* tus = gptr<uint32_t>(blob + H->off_tus); // 4 dwords per record
+  const GLOBAL_AS uint32_t* ctbq = gptr<uint32_t>(blob + H->off_ctbs);   // 9 dwords per hm_ctb
+  const GLOBAL_AS uint32_t* tus = gptr<uint32_t>(blob + H->off_tus);     // 4 dwords per hm_tu
   const GLOBAL_AS uint32_t* coeffs = gptr<uint32_t>(blob + H->off_coeffs);
   GLOBAL_AS uint8_t* g_edge = gptr_w<uint8_t>(dp.edge);
   GLOBAL_AS int8_t* g_qpy = gptr_w<int8_t>(dp.qpy);
 
   const int tid = threadIdx.x, lane = tid & 63, NW = blockDim.x >> 6;
   const int wave = rfl(tid >> 6); // wave-uniform by construction: row state lives in SGPRs
-  const int ctb_w = dp.ctb_w, ctb_h = dp.ctb_h, log2_ctb = dp.log2_ctb, ctb = 1 << log2_ctb;
+  constexpr int log2_ctb = LOG2_CTB, ctb = 1 << log2_ctb; // the launcher groups pictures by CTB size
+  const int ctb_w = dp.ctb_w, ctb_h = dp.ctb_h;
   const int sh = dp.chroma_format == 1 ? 2 : 1;
-  const int bd = dp.bit_depth;
-  const int cw_c = ctb >> 1, ch_c = ctb / sh; // chroma CTB size
-  const int P0 = ctb + UPAD, P1 = cw_c + UPAD;
+  const int bd = sizeof(Pix) == 1 ? 8 : dp.bit_depth; // 8-bit samples <=> bit depth 8 (compile-time constant)
+  constexpr int cw_c = ctb >> 1, P0 = ctb + UPAD, P1 = cw_c + UPAD;
+  const int ch_c = ctb / sh; // chroma CTB height
 
-  // ---- LDS carve-up: [progress: ctb_h ints][dct 1024 B][tables 256 B][per-wave regions]
+  // ---- LDS carve-up: [progress: ctb_h ints][dct 1024 B][tables 256 B][sample lines][per-wave regions]
   int* progress = reinterpret_cast<int*>(lds);
   const int prog_bytes = ((ctb_h * 4) + 15) & ~15;
   int8_t* dct = reinterpret_cast<int8_t*>(lds + prog_bytes);
   int16_t* tab = reinterpret_cast<int16_t*>(lds + prog_bytes + 1024);
-  uint8_t* wbase = lds + prog_bytes + 1024 + 256 + (size_t)wave * per_wave_bytes;
+  uint8_t* const lines = lds + prog_bytes + 1024 + 256;
+  uint8_t* wbase = lines + (size_t)n_lines * line_bytes + (size_t)wave * per_wave_bytes;
 
   for (int i = tid; i < ctb_h; i += blockDim.x) progress[i] = 0;
   for (int i = tid; i < 1024; i += blockDim.x) {
@@ -403,54 +477,56 @@ __global__ __launch_bounds__(512) void k_recon(const hm_dev_pic* __restrict__ pi
 
   uint8_t* lp = wbase;
   int16_t* const l_coeff = reinterpret_cast<int16_t*>(lp); lp += 2048;
-  int16_t* const l_tmp = reinterpret_cast<int16_t*>(lp); lp += 2048;
+  int16_t* const l_tmp = reinterpret_cast<int16_t*>(lp); lp += 1024;
   int16_t* const l_bA = reinterpret_cast<int16_t*>(lp); lp += 272;
   Pix* const u0 = reinterpret_cast<Pix*>(lp); lp += (size_t)P0 * ctb * sizeof(Pix);
   Pix* const u1 = reinterpret_cast<Pix*>(lp); lp += (size_t)P1 * ch_c * sizeof(Pix);
   Pix* const u2 = reinterpret_cast<Pix*>(lp); lp += (size_t)P1 * ch_c * sizeof(Pix);
-  Pix* const top0 = reinterpret_cast<Pix*>(lp); lp += (size_t)((2 * ctb + 1 + 7) & ~7) * sizeof(Pix);
-  Pix* const top1 = reinterpret_cast<Pix*>(lp); lp += (size_t)((2 * cw_c + 1 + 7) & ~7) * sizeof(Pix);
-  Pix* const top2 = reinterpret_cast<Pix*>(lp); lp += (size_t)((2 * cw_c + 1 + 7) & ~7) * sizeof(Pix);
   const int strong = (dp.flags & HM_PIC_STRONG_INTRA_SMOOTHING) != 0;
   const int planeWc = dp.width >> 1, planeHc = dp.height / sh;
+  // one sample line: [4 pad | luma ctb_w*ctb][4 pad | cb ctb_w*cw_c][4 pad | cr ...]; sample x of a plane at base[x], x >= -1
+  const int Wl = ctb_w << log2_ctb, Wc = ctb_w * cw_c;
+  const int lo1 = 4 + Wl + 4, lo2 = lo1 + Wc + 4; // offsets (in samples) of cb / cr sample 0
 
   for (int row = wave; row < ctb_h; row += NW) {
+    // line written by this row / line of the row above (any legal line for row 0: nothing is read from it)
+    Pix* const lw = reinterpret_cast<Pix*>(lines + (size_t)(row % n_lines) * line_bytes) + 4;
+    const Pix* const lr = reinterpret_cast<const Pix*>(lines + (size_t)((row + n_lines - 1) % n_lines) * line_bytes) + 4;
+    const GLOBAL_AS uint32_t* const crow = ctbq + 9 * (size_t)row * ctb_w;
+    // CTB descriptors are fetched one CTU ahead, block records one block ahead (also across the CTU border)
+    uint32_t c0 = crow[0], c1 = crow[1], c2 = crow[2];
+    uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+    bool rec_ready = false;
     for (int cx = 0; cx < ctb_w; cx++) {
+      const int tu_first = rfl((int)c0), tu_count = rfl((int)(c1 & 0xFFFF)), cb_flags = rfl((int)(c2 & 0xFF));
+      int next_first = 0, next_count = 0;
+      if (cx + 1 < ctb_w) { const GLOBAL_AS uint32_t* q = crow + 9 * (size_t)(cx + 1); c0 = q[0]; c1 = q[1]; c2 = q[2]; }
+      const GLOBAL_AS uint32_t* const rec = tus + 4 * (size_t)tu_first;
+      if (!rec_ready && tu_count) { n0 = rec[0]; n1 = rec[1]; n2 = rec[2]; n3 = rec[3]; }
+      rec_ready = false;
       // ---- wait for the above-right CTU (wavefront dependency) ----
       if (row > 0) {
         const int need = (cx + 2 < ctb_w) ? cx + 2 : ctb_w;
         while (__hip_atomic_load(&progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
           __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
       }
-      // ---- stage the row of samples above this CTU (and above-right) into LDS ----
-      auto stage_top = [&](Pix* top, const uint8_t* plane, int pitch, int bw, int bh, int pw) {
-        const int ncols = 2 * bw + 1;
-        const int yy = row * bh - 1;
-        const int xbase = cx * bw - 1;
-        const GLOBAL_AS Pix* src = gptr<Pix>(plane + (size_t)(yy < 0 ? 0 : yy) * pitch);
-        for (int i = lane; i < ncols; i += 64) {
-          const int xx = xbase + i;
-          Pix v = 0;
-          if (yy >= 0 && xx >= 0 && xx < pw) v = src[xx];
-          top[i] = v;
-        }
-      };
-      stage_top(top0, dp.plane[0], dp.pitch[0], ctb, ctb, dp.width);
-      stage_top(top1, dp.plane[1], dp.pitch[1], cw_c, ch_c, planeWc);
-      stage_top(top2, dp.plane[2], dp.pitch[2], cw_c, ch_c, planeWc);
+      const Pix* const top0 = lr + (cx << log2_ctb) - 1;
+      const Pix* const top1 = lr + lo1 + cx * cw_c - 1;
+      const Pix* const top2 = lr + lo2 + cx * cw_c - 1;
+      const int deblock_en = !(cb_flags & HM_CTB_DEBLOCK_OFF);
 
-      const hm_ctb cb = ctbs[cx + row * ctb_w];
-      const int tu_first = rfl((int)cb.tu_first), tu_count = rfl((int)cb.tu_count), cb_flags = rfl((int)cb.flags);
-      const int deblock_en = rfl(!slices[cb.slice_idx].deblocking_disabled);
-      // software pipeline over the records: record k+1 (vector load, vmcnt) and the first
-      // coefficient pairs of record k are in flight while block k is predicted
-      uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
-      if (tu_count) { const GLOBAL_AS uint32_t* q = tus + 4 * (size_t)tu_first; n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3]; }
-      WAVE_SYNC();
       for (int k = 0; k < tu_count; k++) {
         const uint32_t r0 = rfl(n0), r1 = rfl(n1), r2 = rfl(n2), r3 = rfl(n3);
-        if (k + 1 < tu_count) { const GLOBAL_AS uint32_t* q = tus + 4 * (size_t)(tu_first + k + 1); n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3]; }
+        if (k + 1 < tu_count) { const GLOBAL_AS uint32_t* q = rec + 4 * (size_t)(k + 1); n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3]; }
+        else if (cx + 1 < ctb_w) { // first record of the next CTU (its descriptor arrived long ago)
+          next_first = rfl((int)c0); next_count = rfl((int)(c1 & 0xFFFF));
+          if (next_count) {
+            const GLOBAL_AS uint32_t* q = tus + 4 * (size_t)next_first;
+            n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3];
+            rec_ready = true;
+          }
+        }
         Blk<Pix> B;
         B.x0 = r0 & 0xFF; B.y0 = (r0 >> 8) & 0xFF;
         B.info = (r0 >> 16) & 0xFF;
@@ -471,14 +547,25 @@ __global__ __launch_bounds__(512) void k_recon(const hm_dev_pic* __restrict__ pi
         uint32_t pre = 0; // raw (pos | level << 16); unpacked only when the residual is processed
         if (cbf && lane < B.n_coeff) pre = coeffs[coeff_first + lane];
 
-        make_border(B, l_bA, strong, lane);
-        WAVE_SYNC();
-        predict(B, l_bA + 64, tab, lane);
-        WAVE_SYNC();
-        if (cbf) {
-          residual_add(B, l_coeff, l_tmp, dct, tab, coeffs + coeff_first, pre, lane);
+        auto block = [&](auto l2) { // block size as a compile-time constant: fixed trip counts, shifts and masks
+          constexpr int L2 = decltype(l2)::value;
+          // the lane id is made opaque per block: otherwise every lane-derived index / predicate of the four size
+          // variants is hoisted out of all loops and kept alive for the whole kernel (> 100 spilled SGPRs)
+          int ln = lane;
+          asm volatile("" : "+v"(ln));
+          make_border<Pix, L2>(B, l_bA, strong, ln);
           WAVE_SYNC();
-        }
+          predict<Pix, L2>(B, l_bA + 64, tab, ln);
+          WAVE_SYNC();
+          if (cbf) {
+            residual_add<Pix, L2>(B, l_coeff, l_tmp, dct, tab, coeffs + coeff_first, pre, ln);
+            WAVE_SYNC();
+          }
+        };
+        if (B.log2 == 2) block(std::integral_constant<int, 2>());
+        else if (B.log2 == 3) block(std::integral_constant<int, 3>());
+        else if (B.log2 == 4) block(std::integral_constant<int, 4>());
+        else block(std::integral_constant<int, 5>());
         if (B.c == 0) { // deblocking metadata (deblock.cc:31-62): transform edges + QpY
           const int n4 = B.nT >> 2;
           if (lane < n4 * n4) {
@@ -497,14 +584,15 @@ __global__ __launch_bounds__(512) void k_recon(const hm_dev_pic* __restrict__ pi
         }
       }
 
-      // ---- write the finished CTU to the picture (coalesced 4-byte stores) and keep its right column ----
-      auto flush_plane = [&](Pix* u, int P, uint8_t* plane, int pitch, int bw, int bh, int pw, int ph) {
+      // ---- finished CTU: coalesced 4-byte stores to the picture, bottom row -> line, right column -> left column ----
+      auto flush_plane = [&](Pix* u, int P, Pix* line, uint8_t* plane, int pitch, int bw, int bh, int pw, int ph) {
         const int xo = cx * bw, yo = row * bh;
         const int vw = (pw - xo) < bw ? (pw - xo) : bw; // valid part inside the picture
         const int vh = (ph - yo) < bh ? (ph - yo) : bh;
         constexpr int PPW = 4 / sizeof(Pix); // samples per 32-bit word
         const int l2wpr = 31 - __builtin_clz(bw / PPW); // words per row is a power of two
         const int vwords = vw / PPW;
+        BLOCK_LOOP
         for (int p = lane; p < (vh << l2wpr); p += 64) {
           const int r = p >> l2wpr, q = p & ((1 << l2wpr) - 1);
           if (q < vwords) {
@@ -512,14 +600,16 @@ __global__ __launch_bounds__(512) void k_recon(const hm_dev_pic* __restrict__ pi
             *gptr_w<uint32_t>(plane + (size_t)(yo + r) * pitch + (size_t)(xo + q * PPW) * sizeof(Pix)) = word;
           }
         }
+        if (lane < (1 << l2wpr))
+          *reinterpret_cast<uint32_t*>(line + xo + lane * PPW) = *reinterpret_cast<const uint32_t*>(u + (bh - 1) * P + UPAD + lane * PPW);
         WAVE_SYNC();
         for (int r = lane; r < bh; r += 64) u[r * P + UPAD - 1] = u[r * P + UPAD + bw - 1]; // becomes the left column
       };
-      flush_plane(u0, P0, dp.plane[0], dp.pitch[0], ctb, ctb, dp.width, dp.height);
-      flush_plane(u1, P1, dp.plane[1], dp.pitch[1], cw_c, ch_c, planeWc, planeHc);
-      flush_plane(u2, P1, dp.plane[2], dp.pitch[2], cw_c, ch_c, planeWc, planeHc);
-      // ---- publish progress ----
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      flush_plane(u0, P0, lw, dp.plane[0], dp.pitch[0], ctb, ctb, dp.width, dp.height);
+      flush_plane(u1, P1, lw + lo1, dp.plane[1], dp.pitch[1], cw_c, ch_c, planeWc, planeHc);
+      flush_plane(u2, P1, lw + lo2, dp.plane[2], dp.pitch[2], cw_c, ch_c, planeWc, planeHc);
+      // ---- publish progress: only LDS traffic has to be ordered (the picture stores stay in flight) ----
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
       if (lane == 0) __hip_atomic_store(&progress[row], cx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
@@ -531,10 +621,14 @@ __global__ __launch_bounds__(512) void k_recon(const hm_dev_pic* __restrict__ pi
 static int per_wave_lds(int ctb, int chroma_format, int pix_bytes)
 {
   const int cw = ctb / 2, ch = chroma_format == 1 ? ctb / 2 : ctb;
-  int b = 2048 + 2048 + 272;
+  int b = 2048 + 1024 + 272;
   b += (ctb + UPAD) * ctb * pix_bytes + 2 * (cw + UPAD) * ch * pix_bytes;
-  b += ((2 * ctb + 1 + 7) & ~7) * pix_bytes + 2 * (((2 * cw + 1 + 7) & ~7) * pix_bytes);
   return (b + 15) & ~15;
+}
+// one line of samples (luma + cb + cr, 4 samples of padding in front of each) for a picture ctb_w CTBs wide
+static int line_lds(int ctb, int ctb_w, int pix_bytes)
+{
+  return ((3 * 4 + 2 * ctb_w * ctb) * pix_bytes + 15) & ~15;
 }
 
 // All pictures of one launch share (log2_ctb, chroma_format, bit depth class, ctb_h upper bound).
@@ -545,6 +639,7 @@ extern "C" int hm_launch_recon(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   const int ctb = 1 << log2_ctb;
   const int pix_bytes = bit_depth > 8 ? 2 : 1;
   const int pw = per_wave_lds(ctb, chroma_format, pix_bytes);
+  const int line = line_lds(ctb, max_ctb_w, pix_bytes);
   const int fixed = (((max_ctb_h * 4) + 15) & ~15) + 1024 + 256;
   // useful waves: a CTU row can start once the row above is two CTUs ahead
   int nw = (max_ctb_w + 1) / 2;
@@ -555,24 +650,32 @@ extern "C" int hm_launch_recon(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   // share a CU.  A 16x16-CTU tile keeps only ~5.6 of 8 row-waves busy (wavefront ramp): with many
   // pictures queued, fewer waves per picture and more pictures per CU give more throughput.
   // Measured on MI355X (profiles/r01_recon_wave_sweep.txt): <= 768 tiles in flight -> 8 waves per
-  // picture is fastest (latency), beyond that 4 waves per picture / 5 pictures per CU wins (+20 %).
+  // picture is fastest (latency), beyond that 4 waves per picture wins (+20 %).
   const char* env_nw = getenv("HM_RECON_WAVES");
   const int want = env_nw ? atoi(env_nw) : (n_pics > 1024 ? 4 : 8);
   if (want >= 1 && want <= 8 && nw > want) nw = want;
-  const int lds_budget = 64 * 1024;
-  while (nw > 1 && fixed + nw * pw > lds_budget) nw--;
-  const int lds_bytes = fixed + nw * pw;
+  auto total = [&](int w) { return fixed + (w > 2 ? w : 2) * line + w * pw; };
+  // prefer <= 64 KiB per workgroup (several pictures per CU); wide pictures may take the whole 160 KiB
+  while (nw > 1 && total(nw) > 64 * 1024 && total(nw - 1) >= 32 * 1024) nw--;
+  while (nw > 1 && total(nw) > 160 * 1024) nw--;
+  const int lds_bytes = total(nw);
+  const int n_lines = nw > 2 ? nw : 2;
   if (lds_bytes > 160 * 1024) return hm_fail(HM_ERR_UNSUPPORTED, "CTU staging does not fit LDS (%d bytes)", lds_bytes);
-  hipError_t e;
-  if (pix_bytes == 1) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_recon<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    if (e != hipSuccess) return hm_check_hip(e, "hipFuncSetAttribute(k_recon)");
-    hipLaunchKernelGGL(k_recon<uint8_t>, dim3(n_pics), dim3(nw * 64), lds_bytes, s, d_pics, pw);
+  const void* fn = nullptr;
+  switch (log2_ctb * 2 + (pix_bytes - 1)) {
+    case 8: fn = reinterpret_cast<const void*>(k_recon<uint8_t, 4>); break;
+    case 9: fn = reinterpret_cast<const void*>(k_recon<uint16_t, 4>); break;
+    case 10: fn = reinterpret_cast<const void*>(k_recon<uint8_t, 5>); break;
+    case 11: fn = reinterpret_cast<const void*>(k_recon<uint16_t, 5>); break;
+    case 12: fn = reinterpret_cast<const void*>(k_recon<uint8_t, 6>); break;
+    case 13: fn = reinterpret_cast<const void*>(k_recon<uint16_t, 6>); break;
+    default: return hm_fail(HM_ERR_UNSUPPORTED, "CTB size 2^%d", log2_ctb);
   }
-  else {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_recon<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    if (e != hipSuccess) return hm_check_hip(e, "hipFuncSetAttribute(k_recon)");
-    hipLaunchKernelGGL(k_recon<uint16_t>, dim3(n_pics), dim3(nw * 64), lds_bytes, s, d_pics, pw);
-  }
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess) return hm_check_hip(e, "hipFuncSetAttribute(k_recon)");
+  int a_pw = pw, a_line = line, a_lines = n_lines;
+  void* args[] = {(void*)&d_pics, &a_pw, &a_line, &a_lines};
+  e = hipLaunchKernel(fn, dim3(n_pics), dim3(nw * 64), args, lds_bytes, s);
+  if (e != hipSuccess) return hm_check_hip(e, "k_recon launch");
   return hm_check_hip(hipGetLastError(), "k_recon launch");
 }
