@@ -102,7 +102,11 @@ __device__ __forceinline__ GLOBAL_AS T* gptr_w(void* p) { return (GLOBAL_AS T*)(
 
 constexpr int UPAD = 4; // unified CTU buffer: row = [3 unused | left neighbour | bw samples]; rows stay 4-byte aligned
 
-// One block to reconstruct; every member is wave-uniform (SGPR).
+// One block to reconstruct.  Every member has the same value in all lanes, but only the fields that steer
+// control flow (c, mode, info, aL, aT, aTL) are held in SGPRs; the data fields (position, pointers, pitch,
+// QP, partial availabilities, coefficient count) are deliberately kept in VGPRs: the CU has ONE scalar ALU
+// (1 instruction / cycle for all its waves, measured: tools/ubench/salu_rate.hip) against four vector ALUs,
+// and the per-block address / index arithmetic would otherwise make the scalar unit the bottleneck.
 template <typename Pix>
 struct Blk {
   Pix* u;            // unified CTU buffer of the plane: sample (x,y) at u[y*P + UPAD + x], x >= -1
@@ -428,6 +432,7 @@ __global__ __launch_bounds__(512) void k_recon(const hm_dev_pic* __restrict__ pi
   const GLOBAL_AS uint32_t* ctbq = gptr<uint32_t>(blob + H->off_ctbs);   // 9 dwords per hm_ctb
   const GLOBAL_AS uint32_t* tus = gptr<uint32_t>(blob + H->off_tus);     // 4 dwords per hm_tu
   const GLOBAL_AS uint32_t* coeffs = gptr<uint32_t>(blob + H->off_coeffs);
+  const uint32_t n_tus = H->n_tus;
   GLOBAL_AS uint8_t* g_edge = gptr_w<uint8_t>(dp.edge);
   GLOBAL_AS int8_t* g_qpy = gptr_w<int8_t>(dp.qpy);
 
@@ -493,17 +498,22 @@ __global__ __launch_bounds__(512) void k_recon(const hm_dev_pic* __restrict__ pi
     Pix* const lw = reinterpret_cast<Pix*>(lines + (size_t)(row % n_lines) * line_bytes) + 4;
     const Pix* const lr = reinterpret_cast<const Pix*>(lines + (size_t)((row + n_lines - 1) % n_lines) * line_bytes) + 4;
     const GLOBAL_AS uint32_t* const crow = ctbq + 9 * (size_t)row * ctb_w;
-    // CTB descriptors are fetched one CTU ahead, block records one block ahead (also across the CTU border)
+    // CTB descriptors are fetched one CTU ahead, block records one block ahead.  The records of a CTB row
+    // are contiguous (hm_stream.h: CTBs store their records in raster order), so the prefetch simply runs
+    // on across CTU borders.
     uint32_t c0 = crow[0], c1 = crow[1], c2 = crow[2];
-    uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
-    bool rec_ready = false;
+    uint32_t n0, n1, n2, n3;
+    uint32_t gnext; // index of the next record to fetch (vector register: keeps the address arithmetic off the scalar unit)
+    {
+      const uint32_t first = rfl((int)c0);
+      const GLOBAL_AS uint32_t* q = tus + 4 * (size_t)first;
+      n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3];
+      gnext = first + 1;
+      asm volatile("" : "+v"(gnext));
+    }
     for (int cx = 0; cx < ctb_w; cx++) {
-      const int tu_first = rfl((int)c0), tu_count = rfl((int)(c1 & 0xFFFF)), cb_flags = rfl((int)(c2 & 0xFF));
-      int next_first = 0, next_count = 0;
+      const int tu_count = rfl((int)(c1 & 0xFFFF)), cb_flags = rfl((int)(c2 & 0xFF));
       if (cx + 1 < ctb_w) { const GLOBAL_AS uint32_t* q = crow + 9 * (size_t)(cx + 1); c0 = q[0]; c1 = q[1]; c2 = q[2]; }
-      const GLOBAL_AS uint32_t* const rec = tus + 4 * (size_t)tu_first;
-      if (!rec_ready && tu_count) { n0 = rec[0]; n1 = rec[1]; n2 = rec[2]; n3 = rec[3]; }
-      rec_ready = false;
       // ---- wait for the above-right CTU (wavefront dependency) ----
       if (row > 0) {
         const int need = (cx + 2 < ctb_w) ? cx + 2 : ctb_w;
@@ -517,32 +527,36 @@ __global__ __launch_bounds__(512) void k_recon(const hm_dev_pic* __restrict__ pi
       const int deblock_en = !(cb_flags & HM_CTB_DEBLOCK_OFF);
 
       for (int k = 0; k < tu_count; k++) {
-        const uint32_t r0 = rfl(n0), r1 = rfl(n1), r2 = rfl(n2), r3 = rfl(n3);
-        if (k + 1 < tu_count) { const GLOBAL_AS uint32_t* q = rec + 4 * (size_t)(k + 1); n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3]; }
-        else if (cx + 1 < ctb_w) { // first record of the next CTU (its descriptor arrived long ago)
-          next_first = rfl((int)c0); next_count = rfl((int)(c1 & 0xFFFF));
-          if (next_count) {
-            const GLOBAL_AS uint32_t* q = tus + 4 * (size_t)next_first;
-            n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3];
-            rec_ready = true;
-          }
+        // control fields -> scalar registers; data fields stay in (opaque) vector registers
+        const uint32_t r0 = rfl(n0), r3 = rfl(n3);
+        uint32_t w0 = n0, w1 = n1, w2 = n2, w3 = n3;
+        asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));
+        {
+          const uint32_t g = gnext < n_tus - 1 ? gnext : n_tus - 1; // the last block of the picture re-reads itself
+          const GLOBAL_AS uint32_t* q = tus + 4 * (size_t)g;
+          n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3];
+          gnext += 1;
         }
         Blk<Pix> B;
-        B.x0 = r0 & 0xFF; B.y0 = (r0 >> 8) & 0xFF;
         B.info = (r0 >> 16) & 0xFF;
         B.mode = r0 >> 24;
-        B.qp = r1 & 0xFF;
-        const int qpy = (int)(int8_t)((r1 >> 8) & 0xFF);
-        B.n_coeff = r1 >> 16;
-        const uint32_t coeff_first = r2;
-        B.aL = r3 & 0xFF; B.aBL = (r3 >> 8) & 0xFF; B.aT = (r3 >> 16) & 0xFF; B.aTR = r3 >> 24;
-        B.aTL = (B.info & HM_TU_AVAIL_TL) ? 1 : 0;
-        B.log2 = B.info & HM_TU_LOG2_MASK; B.nT = 1 << B.log2;
+        B.log2 = B.info & HM_TU_LOG2_MASK;
         B.c = (B.info >> HM_TU_CIDX_SHIFT) & 3;
+        B.aL = r3 & 0xFF; B.aT = (r3 >> 16) & 0xFF;
+        B.aTL = (B.info & HM_TU_AVAIL_TL) ? 1 : 0;
         B.bd = bd;
-        B.u = B.c == 0 ? u0 : (B.c == 1 ? u1 : u2);
-        B.top = B.c == 0 ? top0 : (B.c == 1 ? top1 : top2);
-        B.P = B.c == 0 ? P0 : P1;
+        B.x0 = w0 & 0xFF; B.y0 = (w0 >> 8) & 0xFF;
+        B.qp = w1 & 0xFF;
+        const int qpy = (int)(int8_t)((w1 >> 8) & 0xFF);
+        B.n_coeff = w1 >> 16;
+        const uint32_t coeff_first = w2;
+        B.aBL = (w3 >> 8) & 0xFF; B.aTR = w3 >> 24;
+        {
+          const int vc = (w0 >> (16 + HM_TU_CIDX_SHIFT)) & 3; // colour component, vector copy for the selects
+          B.u = vc == 0 ? u0 : (vc == 1 ? u1 : u2);
+          B.top = vc == 0 ? top0 : (vc == 1 ? top1 : top2);
+          B.P = vc == 0 ? P0 : P1;
+        }
         const bool cbf = (B.info & HM_TU_CBF) != 0;
         uint32_t pre = 0; // raw (pos | level << 16); unpacked only when the residual is processed
         if (cbf && lane < B.n_coeff) pre = coeffs[coeff_first + lane];
@@ -561,27 +575,27 @@ __global__ __launch_bounds__(512) void k_recon(const hm_dev_pic* __restrict__ pi
             residual_add<Pix, L2>(B, l_coeff, l_tmp, dct, tab, coeffs + coeff_first, pre, ln);
             WAVE_SYNC();
           }
+          if (B.c == 0) { // deblocking metadata (deblock.cc:31-62): transform edges + QpY
+            constexpr int n4 = 1 << (L2 - 2);
+            if (ln < n4 * n4) {
+              const int i = ln & (n4 - 1), j = ln >> (L2 - 2);
+              const int bx = (((cx << log2_ctb) + B.x0) >> 2) + i, by = (((row << log2_ctb) + B.y0) >> 2) + j;
+              if (bx < dp.w4 && by < dp.h4) {
+                const int left_ok = B.x0 > 0 ? 1 : (cb_flags & HM_CTB_DEBLOCK_LEFT) != 0;
+                const int top_ok = B.y0 > 0 ? 1 : (cb_flags & HM_CTB_DEBLOCK_TOP) != 0;
+                uint8_t e = 0;
+                if (i == 0 && left_ok && deblock_en) e |= 1;
+                if (j == 0 && top_ok && deblock_en) e |= 2;
+                g_edge[bx + (size_t)by * dp.w4] = e;
+                g_qpy[bx + (size_t)by * dp.w4] = (int8_t)qpy;
+              }
+            }
+          }
         };
         if (B.log2 == 2) block(std::integral_constant<int, 2>());
         else if (B.log2 == 3) block(std::integral_constant<int, 3>());
         else if (B.log2 == 4) block(std::integral_constant<int, 4>());
         else block(std::integral_constant<int, 5>());
-        if (B.c == 0) { // deblocking metadata (deblock.cc:31-62): transform edges + QpY
-          const int n4 = B.nT >> 2;
-          if (lane < n4 * n4) {
-            const int i = lane & (n4 - 1), j = lane >> (B.log2 - 2);
-            const int bx = (((cx << log2_ctb) + B.x0) >> 2) + i, by = (((row << log2_ctb) + B.y0) >> 2) + j;
-            if (bx < dp.w4 && by < dp.h4) {
-              const int left_ok = B.x0 > 0 ? 1 : (cb_flags & HM_CTB_DEBLOCK_LEFT) != 0;
-              const int top_ok = B.y0 > 0 ? 1 : (cb_flags & HM_CTB_DEBLOCK_TOP) != 0;
-              uint8_t e = 0;
-              if (i == 0 && left_ok && deblock_en) e |= 1;
-              if (j == 0 && top_ok && deblock_en) e |= 2;
-              g_edge[bx + (size_t)by * dp.w4] = e;
-              g_qpy[bx + (size_t)by * dp.w4] = (int8_t)qpy;
-            }
-          }
-        }
       }
 
       // ---- finished CTU: coalesced 4-byte stores to the picture, bottom row -> line, right column -> left column ----
