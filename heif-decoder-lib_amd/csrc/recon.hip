@@ -157,65 +157,81 @@ __device__ __forceinline__ int border_value(const Blk<Pix>& b, int i, int noLeft
   return valid ? v : fill;
 }
 
+// intra_smoothing decision of intrapred.h:192-214 as one bit per prediction mode: luma only, never for DC,
+// never for 4x4; min(|mode-26|, |mode-10|) > 7 (8x8), > 1 (16x16), > 0 (32x32); planar counts as "far".
+constexpr uint64_t filter_mode_mask(int log2)
+{
+  uint64_t m = 0;
+  for (int mode = 0; mode < 35; mode++) {
+    if (mode == 1 || log2 == 2) continue;
+    const int d1 = mode > 26 ? mode - 26 : 26 - mode, d2 = mode > 10 ? mode - 10 : 10 - mode;
+    const int d = d1 < d2 ? d1 : d2;
+    const bool f = log2 == 3 ? d > 7 : (log2 == 4 ? d > 1 : d > 0);
+    if (f) m |= 1ull << mode;
+  }
+  return m;
+}
+
 // ---- reference samples incl. smoothing (intrapred.h:192-266), written once to bA -------------------
+// Written select-style on purpose (both candidates computed, then chosen): a ternary with arithmetic in
+// its arms becomes an exec-mask branch, i.e. several scalar instructions per lane-level decision.
 template <typename Pix, int L2>
 __device__ __forceinline__ void make_border(const Blk<Pix>& b, int16_t* bA, int strong, int lane)
 {
   constexpr int nT = 1 << L2;
   int16_t* const bc = bA + 64; // centre (corner sample)
-  int filterFlag = 0;
-  if (b.c == 0 && b.mode != 1 && nT != 4) {
-    const int d1 = iabs_(b.mode - 26), d2 = iabs_(b.mode - 10);
-    const int d = d1 < d2 ? d1 : d2;
-    filterFlag = nT == 8 ? d > 7 : (nT == 16 ? d > 1 : d > 0);
-  }
+  const bool filterFlag = L2 != 2 && b.c == 0 && ((filter_mode_mask(L2) >> b.mode) & 1);
 
   if (b.aL && b.aT && b.aTL) {
     // Interior block (left, above and corner exist): substitution only replicates the last available
     // sample of a partly available below-left / above-right run = a clamped coordinate.  One ds_read per lane.
-    const Pix* lp = b.u + (b.y0 * b.P + UPAD + b.x0 - 1);                                    // (x0-1, y0)
-    const Pix* tp = b.y0 > 0 ? b.u + ((b.y0 - 1) * b.P + UPAD + b.x0) : b.top + (1 + b.x0); // (x0, y0-1)
+    const Pix* const lp = b.u + (b.y0 * b.P + UPAD + b.x0 - 1); // (x0-1, y0)
+    const Pix* const tpu = lp - b.P + 1;                        // (x0, y0-1) inside the CTU
+    const Pix* const tpl = b.top + (1 + b.x0);                  // ... in the line of the CTU row above
+    const Pix* const tp = b.y0 > 0 ? tpu : tpl;
     const int nL1 = nT + b.aBL - 1, nT1 = nT + b.aTR - 1;
+    auto ref = [&](int i) -> int { // reference sample i, i in [-2nT, 2nT]
+      const int ol = imin_(-i - 1, nL1) * b.P, ot = imin_(i - 1, nT1);
+      const Pix* const ql = lp + ol;
+      const Pix* const qt = tp + ot;
+      return *(i < 0 ? ql : qt);
+    };
     if (!filterFlag) {
       BLOCK_LOOP
       for (int e = lane; e <= 4 * nT; e += 64) {
         const int i = e - 2 * nT;
-        const Pix* q = i < 0 ? lp + imin_(-i - 1, nL1) * b.P : tp + imin_(i - 1, nT1);
-        bc[i] = (int16_t)*q;
+        bc[i] = (int16_t)ref(i);
       }
       return;
     }
     // [1 2 1] smoothing or strong (bilinear) smoothing; the two end samples stay unfiltered
     bool bi = false;
     int p0 = 0, pL = 0, pT = 0;
-    if (strong && nT == 32) {
-      p0 = tp[-1];
-      pL = lp[imin_(63, nL1) * b.P];
-      pT = tp[imin_(63, nT1)];
-      const int mL = lp[31 * b.P], mT = tp[31];
+    if (L2 == 5 && strong) {
+      p0 = ref(0); pL = ref(-64); pT = ref(64);
+      const int mL = ref(-32), mT = ref(32);
       const int lim = 1 << (b.bd - 5);
       bi = iabs_(p0 + pT - 2 * mT) < lim && iabs_(p0 + pL - 2 * mL) < lim;
+    }
+    if (bi) {
+      BLOCK_LOOP
+      for (int e = lane; e <= 4 * nT; e += 64) {
+        const int i = e - 2 * nT;
+        const int vl = p0 + (((-i) * (pL - p0) + 32) >> 6), vt = p0 + ((i * (pT - p0) + 32) >> 6);
+        int v = i < 0 ? vl : vt; // i == 0 gives p0 either way
+        v = i == -2 * nT ? pL : v;
+        v = i == 2 * nT ? pT : v;
+        bc[i] = (int16_t)v;
+      }
+      return;
     }
     BLOCK_LOOP
     for (int e = lane; e <= 4 * nT; e += 64) {
       const int i = e - 2 * nT;
-      int v;
-      if (bi && i != -2 * nT && i != 2 * nT) {
-        if (i == 0) v = p0;
-        else if (i < 0) v = p0 + (((-i) * (pL - p0) + 32) >> 6);
-        else v = p0 + ((i * (pT - p0) + 32) >> 6);
-      }
-      else {
-        const int im = i - 1, ip = i + 1;
-        const int c0 = *(i < 0 ? lp + imin_(-i - 1, nL1) * b.P : tp + imin_(i - 1, nT1));
-        v = c0;
-        if (i != -2 * nT && i != 2 * nT) {
-          const int cm = *(im < 0 ? lp + imin_(-im - 1, nL1) * b.P : tp + imin_(im - 1, nT1));
-          const int cp = *(ip < 0 ? lp + imin_(-ip - 1, nL1) * b.P : tp + imin_(ip - 1, nT1));
-          v = (cm + 2 * c0 + cp + 2) >> 2;
-        }
-      }
-      bc[i] = (int16_t)v;
+      const bool end = (i == -2 * nT) | (i == 2 * nT); // ends stay unfiltered: (c + 2c + c + 2) >> 2 == c
+      const int im = end ? i : i - 1, ip = end ? i : i + 1;
+      const int cm = ref(im), c0 = ref(i), cp = ref(ip);
+      bc[i] = (int16_t)((cm + 2 * c0 + cp + 2) >> 2);
     }
     return;
   }
@@ -270,7 +286,8 @@ __device__ __forceinline__ void predict(const Blk<Pix>& B, const int16_t* b, con
   Pix* dst = B.u + B.y0 * B.P + UPAD + B.x0;
   const int pitch = B.P;
   const int maxv = (1 << B.bd) - 1;
-  const int npx = nT * nT;
+  constexpr int npx = nT * nT;
+  const bool edge = (c == 0 && nT < 32); // boundary smoothing of DC / pure vertical / pure horizontal (luma, < 32x32)
   if (mode == 0) {
     BLOCK_LOOP
     for (int p = lane; p < npx; p += 64) {
@@ -282,41 +299,52 @@ __device__ __forceinline__ void predict(const Blk<Pix>& B, const int16_t* b, con
     int s = 0;
     if (lane < nT) s = b[lane + 1] + b[-lane - 1];
     const int dc = (wave_sum(s) + nT) >> (log2 + 1);
-    const bool edge = (c == 0 && nT < 32);
     BLOCK_LOOP
     for (int p = lane; p < npx; p += 64) {
       const int x = p & (nT - 1), y = p >> log2;
       int v = dc;
       if (edge) {
-        if (x == 0 && y == 0) v = (b[-1] + 2 * dc + b[1] + 2) >> 2;
-        else if (y == 0) v = (b[x + 1] + 3 * dc + 2) >> 2;
-        else if (x == 0) v = (b[-y - 1] + 3 * dc + 2) >> 2;
+        const int t = b[x + 1], l = b[-y - 1];
+        v = y == 0 ? (t + 3 * dc + 2) >> 2 : v;
+        v = x == 0 ? (l + 3 * dc + 2) >> 2 : v;
+        v = (x | y) == 0 ? (l + 2 * dc + t + 2) >> 2 : v;
+      }
+      dst[y * pitch + x] = (Pix)v;
+    }
+  }
+  else if (mode == 26 || mode == 10) { // pure vertical / horizontal: copy, plus the gradient on the first column / row
+    const bool vert = mode == 26;
+    const int corner = b[0];
+    BLOCK_LOOP
+    for (int p = lane; p < npx; p += 64) {
+      const int x = p & (nT - 1), y = p >> log2;
+      const int t = b[1 + x], l = b[-1 - y];
+      int v = vert ? t : l;
+      if (edge) {
+        const int along = vert ? x : y;                                  // distance from the smoothed border
+        const int g = vert ? b[1] + ((l - corner) >> 1) : b[-1] + ((t - corner) >> 1);
+        v = along == 0 ? clip3i(0, maxv, g) : v;
       }
       dst[y * pitch + x] = (Pix)v;
     }
   }
   else {
     const int angle = tab[mode];
-    const int inv = (mode >= 11 && mode <= 25) ? tab[35 + mode - 11] : 0;
+    const int inv = tab[35 + mode]; // 0 outside modes 11..25
     const bool vert = mode >= 18;
     const int sgn = vert ? 1 : -1; // ref[k] = border[sgn * k] for k >= 0, border[-sgn * proj(k)] for k < 0
-    const bool smooth = (c == 0 && nT < 32 && (mode == 26 || mode == 10));
     BLOCK_LOOP
     for (int p = lane; p < npx; p += 64) {
       const int x = p & (nT - 1), y = p >> log2;
       const int major = vert ? y : x, minor = vert ? x : y;
-      const int iIdx = ((major + 1) * angle) >> 5, iFact = ((major + 1) * angle) & 31;
+      const int t = (major + 1) * angle;
+      const int iIdx = t >> 5, iFact = t & 31;
       const int k0 = minor + iIdx + 1, k1 = k0 + 1;
-      const int j0 = k0 >= 0 ? sgn * k0 : -sgn * ((k0 * inv + 128) >> 8);
-      const int j1 = k1 >= 0 ? sgn * k1 : -sgn * ((k1 * inv + 128) >> 8);
-      const int r0 = b[j0];
-      int v = r0;
-      if (iFact) v = ((32 - iFact) * r0 + iFact * b[j1] + 16) >> 5;
-      if (smooth) { // boundary smoothing of the pure vertical / horizontal modes
-        if (mode == 26 && x == 0) v = clip3i(0, maxv, b[1] + ((b[-1 - y] - b[0]) >> 1));
-        else if (mode == 10 && y == 0) v = clip3i(0, maxv, b[-1] + ((b[1 + x] - b[0]) >> 1));
-      }
-      dst[y * pitch + x] = (Pix)v;
+      const int q0 = -((k0 * inv + 128) >> 8), q1 = -((k1 * inv + 128) >> 8);
+      const int j0 = sgn * (k0 >= 0 ? k0 : q0), j1 = sgn * (k1 >= 0 ? k1 : q1);
+      // b[j1] is read even when iFact == 0 (then it has weight 0; the index stays inside bA: |j1| <= 2nT + 1)
+      const int r0 = b[j0], r1 = b[j1];
+      dst[y * pitch + x] = (Pix)(((32 - iFact) * r0 + iFact * r1 + 16) >> 5);
     }
   }
 }
@@ -333,7 +361,7 @@ __device__ __forceinline__ void residual_add(const Blk<Pix>& B, int16_t* coeff, 
   const int qP = B.qp;
   const int bdShift = bit_depth + log2 - 9;
   const int32_t offset = 1 << (bdShift - 1);
-  const int32_t fact = (int32_t)tab[50 + qP % 6] << (qP / 6);
+  const int32_t fact = (int32_t)tab[70 + qP % 6] << (qP / 6);
   int mx = 0, my = 0;
 #pragma unroll 1 // more than 64 levels in a block is rare: keep the register footprint of one iteration
   for (int i = lane; i < B.n_coeff; i += 64) {
@@ -369,7 +397,7 @@ __device__ __forceinline__ void residual_add(const Blk<Pix>& B, int16_t* coeff, 
       const int cc = lane & 3, i = lane >> 2;
       int sum = 0;
 #pragma unroll
-      for (int j = 0; j < 4; j++) sum += tab[56 + j * 4 + i] * coeff[cc + j * 4];
+      for (int j = 0; j < 4; j++) sum += tab[76 + j * 4 + i] * coeff[cc + j * 4];
       tmp[i * 4 + cc] = (int16_t)clip3i(-32768, 32767, (sum + 64) >> 7);
     }
     WAVE_SYNC();
@@ -377,7 +405,7 @@ __device__ __forceinline__ void residual_add(const Blk<Pix>& B, int16_t* coeff, 
       const int i = lane & 3, y = lane >> 2;
       int sum = 0;
 #pragma unroll
-      for (int j = 0; j < 4; j++) sum += tab[56 + j * 4 + i] * tmp[y * 4 + j];
+      for (int j = 0; j < 4; j++) sum += tab[76 + j * 4 + i] * tmp[y * 4 + j];
       const int out = clip3i(-32768, 32767, (sum + rnd2) >> postShift);
       dst[y * pitch + i] = (Pix)clip3i(0, maxv, (int)dst[y * pitch + i] + out);
     }
@@ -422,7 +450,7 @@ __device__ __forceinline__ void residual_add(const Blk<Pix>& B, int16_t* coeff, 
 // line_bytes: size of one sample line (all planes) as laid out by the launcher for the widest picture of the
 // batch class; n_lines = max(waves, 2) of them follow the tables in LDS.
 template <typename Pix, int LOG2_CTB>
-__global__ __launch_bounds__(512) void k_recon(const hm_dev_pic* __restrict__ pics, int per_wave_bytes, int line_bytes, int n_lines)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k_recon(const hm_dev_pic* __restrict__ pics, int per_wave_bytes, int line_bytes, int n_lines)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   // descriptor -> registers once (it is read-only, but the compiler cannot know that across our stores)
@@ -465,12 +493,12 @@ __global__ __launch_bounds__(512) void k_recon(const hm_dev_pic* __restrict__ pi
     else v = c_dct_mag[128 - m];
     dct[i] = (int8_t)v;
   }
-  for (int i = tid; i < 72; i += blockDim.x) {
+  for (int i = tid; i < 92; i += blockDim.x) { // [0,35) angle, [35,70) inverse angle (0 where unused), [70,76) level scale, [76,92) DST
     int v;
     if (i < 35) v = c_intra_angle[i];
-    else if (i < 50) v = c_inv_angle[i - 35];
-    else if (i < 56) v = c_level_scale[i - 50];
-    else v = c_dst[(i - 56) >> 2][(i - 56) & 3];
+    else if (i < 70) v = (i - 35 >= 11 && i - 35 <= 25) ? c_inv_angle[i - 35 - 11] : 0;
+    else if (i < 76) v = c_level_scale[i - 70];
+    else v = c_dst[(i - 76) >> 2][(i - 76) & 3];
     tab[i] = (int16_t)v;
   }
   // per-wave staging: coefficient block must start all-zero (residual_add keeps it so)
@@ -581,12 +609,10 @@ __global__ __launch_bounds__(512) void k_recon(const hm_dev_pic* __restrict__ pi
               const int i = ln & (n4 - 1), j = ln >> (L2 - 2);
               const int bx = (((cx << log2_ctb) + B.x0) >> 2) + i, by = (((row << log2_ctb) + B.y0) >> 2) + j;
               if (bx < dp.w4 && by < dp.h4) {
-                const int left_ok = B.x0 > 0 ? 1 : (cb_flags & HM_CTB_DEBLOCK_LEFT) != 0;
-                const int top_ok = B.y0 > 0 ? 1 : (cb_flags & HM_CTB_DEBLOCK_TOP) != 0;
-                uint8_t e = 0;
-                if (i == 0 && left_ok && deblock_en) e |= 1;
-                if (j == 0 && top_ok && deblock_en) e |= 2;
-                g_edge[bx + (size_t)by * dp.w4] = e;
+                const int left_ok = (B.x0 > 0) | ((cb_flags & HM_CTB_DEBLOCK_LEFT) != 0);
+                const int top_ok = (B.y0 > 0) | ((cb_flags & HM_CTB_DEBLOCK_TOP) != 0);
+                const int e = ((i == 0) & left_ok & deblock_en) | (((j == 0) & top_ok & deblock_en) << 1);
+                g_edge[bx + (size_t)by * dp.w4] = (uint8_t)e;
                 g_qpy[bx + (size_t)by * dp.w4] = (int8_t)qpy;
               }
             }
