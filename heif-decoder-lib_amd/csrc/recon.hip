@@ -91,9 +91,6 @@ __constant__ int8_t c_dct_mag[33] = {64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80,
 // Pointers into HBM are cast to the global address space so that the compiler emits global_load /
 // global_store (vmcnt only) instead of flat_* (which also count on lgkmcnt and would make every LDS wait
 // stall on the in-flight prefetches).
-// per-lane loops over the samples of a block: one trip for blocks up to 8x8 (straight-line code), rolled
-// loops for the larger ones (keeps the register footprint at 64 VGPRs)
-#define BLOCK_LOOP _Pragma("unroll 1")
 #define GLOBAL_AS __attribute__((address_space(1)))
 template <typename T>
 __device__ __forceinline__ const GLOBAL_AS T* gptr(const void* p) { return (const GLOBAL_AS T*)(uintptr_t)p; }
@@ -112,10 +109,15 @@ struct Blk {
   Pix* u;            // unified CTU buffer of the plane: sample (x,y) at u[y*P + UPAD + x], x >= -1
   const Pix* top;    // top[1 + x] = sample at (x,-1), x = -1 .. 2*bw-1 (inside the line of the CTU row above)
   int P;             // pitch of u in samples
-  int x0, y0, nT, log2, c, mode, qp, info;
-  int aL, aBL, aT, aTR, aTL;
+  int x0, y0, log2, c, mode, qp, info;
+  uint32_t avail;    // hm_tu.avail_* as one word: left | bottom_left << 8 | top << 16 | top_right << 24 (scalar)
+  int aBL, aTR;      // vector copies of the two partial counts
   int n_coeff;
   int bd;
+};
+// neighbour availability of the slow (picture / slice / tile border) path, decoded from Blk::avail / Blk::info
+struct Avail {
+  int aL, aBL, aT, aTR, aTL;
 };
 
 template <typename Pix>
@@ -129,32 +131,52 @@ __device__ __forceinline__ int nb(const Blk<Pix>& b, int x, int y)
 // positive = top row) after the substitution process (intrapred.h:620-836 == H.265 8.4.4.2.2),
 // as a pure function of the staged neighbourhood: one ds_read per call.
 template <typename Pix, int L2>
-__device__ __forceinline__ int border_value(const Blk<Pix>& b, int i, int noLeftFill, int topFill)
+__device__ __forceinline__ int border_value(const Blk<Pix>& b, const Avail& av, int i, int noLeftFill, int topFill)
 {
   constexpr int nT = 1 << L2;
   int x, y, valid, fill;
   if (i < 0) {
     const int k = -i; // sample (x0-1, y0+k-1)
     x = -1;
-    if (k <= nT) { y = k - 1; valid = b.aL; }
-    else if (b.aBL) { y = imin_(k - 1, nT + b.aBL - 1); valid = 1; }
-    else { y = nT - 1; valid = b.aL; }
+    if (k <= nT) { y = k - 1; valid = av.aL; }
+    else if (av.aBL) { y = imin_(k - 1, nT + av.aBL - 1); valid = 1; }
+    else { y = nT - 1; valid = av.aL; }
     fill = noLeftFill;
   }
   else if (i == 0) {
-    x = -1; y = b.aTL ? -1 : 0;
-    valid = b.aTL | b.aL;
+    x = -1; y = av.aTL ? -1 : 0;
+    valid = av.aTL | av.aL;
     fill = noLeftFill;
   }
   else {
     y = -1;
-    if (i <= nT) { x = i - 1; valid = b.aT; }
-    else if (b.aTR) { x = imin_(i - 1, nT + b.aTR - 1); valid = 1; }
-    else { x = nT - 1; valid = b.aT; }
+    if (i <= nT) { x = i - 1; valid = av.aT; }
+    else if (av.aTR) { x = imin_(i - 1, nT + av.aTR - 1); valid = 1; }
+    else { x = nT - 1; valid = av.aT; }
     fill = topFill;
   }
   const int v = nb(b, b.x0 + x, b.y0 + y); // always a legal LDS address inside the staging area
   return valid ? v : fill;
+}
+
+// Per-lane loop over N items (N a compile-time constant, item = lane + 64 * trip): straight-line code for up to
+// two trips, otherwise a loop on a scalar counter; only the last, partial trip is predicated.
+template <int N, typename F>
+__device__ __forceinline__ void lanes_loop(int lane, F&& f)
+{
+  constexpr int FULL = N / 64, REST = N % 64;
+  if constexpr (FULL <= 2) {
+#pragma unroll
+    for (int t = 0; t < FULL; t++) f(lane + 64 * t);
+  }
+  else {
+#pragma unroll 1
+    for (int t = 0; t < FULL; t++) f(lane + 64 * t);
+  }
+  if constexpr (REST != 0) {
+    const int e = lane + 64 * FULL;
+    if (e < N) f(e);
+  }
 }
 
 // intra_smoothing decision of intrapred.h:192-214 as one bit per prediction mode: luma only, never for DC,
@@ -182,7 +204,9 @@ __device__ __forceinline__ void make_border(const Blk<Pix>& b, int16_t* bA, int 
   int16_t* const bc = bA + 64; // centre (corner sample)
   const bool filterFlag = L2 != 2 && b.c == 0 && ((filter_mode_mask(L2) >> b.mode) & 1);
 
-  if (b.aL && b.aT && b.aTL) {
+  // interior <=> left and top runs complete (the counts are 0 or nT: bit L2) and the corner exists
+  constexpr uint32_t need = 0x00010001u << L2;
+  if ((b.avail & need) == need && (b.info & HM_TU_AVAIL_TL)) {
     // Interior block (left, above and corner exist): substitution only replicates the last available
     // sample of a partly available below-left / above-right run = a clamped coordinate.  One ds_read per lane.
     const Pix* const lp = b.u + (b.y0 * b.P + UPAD + b.x0 - 1); // (x0-1, y0)
@@ -197,11 +221,10 @@ __device__ __forceinline__ void make_border(const Blk<Pix>& b, int16_t* bA, int 
       return *(i < 0 ? ql : qt);
     };
     if (!filterFlag) {
-      BLOCK_LOOP
-      for (int e = lane; e <= 4 * nT; e += 64) {
+      lanes_loop<4 * nT + 1>(lane, [&](int e) {
         const int i = e - 2 * nT;
         bc[i] = (int16_t)ref(i);
-      }
+      });
       return;
     }
     // [1 2 1] smoothing or strong (bilinear) smoothing; the two end samples stay unfiltered
@@ -214,67 +237,66 @@ __device__ __forceinline__ void make_border(const Blk<Pix>& b, int16_t* bA, int 
       bi = iabs_(p0 + pT - 2 * mT) < lim && iabs_(p0 + pL - 2 * mL) < lim;
     }
     if (bi) {
-      BLOCK_LOOP
-      for (int e = lane; e <= 4 * nT; e += 64) {
+      lanes_loop<4 * nT + 1>(lane, [&](int e) {
         const int i = e - 2 * nT;
         const int vl = p0 + (((-i) * (pL - p0) + 32) >> 6), vt = p0 + ((i * (pT - p0) + 32) >> 6);
         int v = i < 0 ? vl : vt; // i == 0 gives p0 either way
         v = i == -2 * nT ? pL : v;
         v = i == 2 * nT ? pT : v;
         bc[i] = (int16_t)v;
-      }
+      });
       return;
     }
-    BLOCK_LOOP
-    for (int e = lane; e <= 4 * nT; e += 64) {
+    lanes_loop<4 * nT + 1>(lane, [&](int e) {
       const int i = e - 2 * nT;
       const bool end = (i == -2 * nT) | (i == 2 * nT); // ends stay unfiltered: (c + 2c + c + 2) >> 2 == c
       const int im = end ? i : i - 1, ip = end ? i : i + 1;
       const int cm = ref(im), c0 = ref(i), cp = ref(ip);
       bc[i] = (int16_t)((cm + 2 * c0 + cp + 2) >> 2);
-    }
+    });
     return;
   }
 
   // ---- picture / slice / tile border: full substitution process ----
+  Avail av;
+  av.aL = b.avail & 0xFF; av.aBL = (b.avail >> 8) & 0xFF; av.aT = (b.avail >> 16) & 0xFF; av.aTR = b.avail >> 24;
+  av.aTL = (b.info & HM_TU_AVAIL_TL) ? 1 : 0;
   const int DEF = 1 << (b.bd - 1);
   int noLeftFill = DEF, topFill = DEF;
-  if (b.aTL) noLeftFill = nb(b, b.x0 - 1, b.y0 - 1);
-  else if (b.aT) noLeftFill = nb(b, b.x0, b.y0 - 1);
-  else if (b.aTR) noLeftFill = nb(b, b.x0 + nT, b.y0 - 1);
-  if (b.aTL) topFill = noLeftFill;
-  else if (b.aL) topFill = nb(b, b.x0 - 1, b.y0);
-  else if (b.aTR) topFill = nb(b, b.x0 + nT, b.y0 - 1);
+  if (av.aTL) noLeftFill = nb(b, b.x0 - 1, b.y0 - 1);
+  else if (av.aT) noLeftFill = nb(b, b.x0, b.y0 - 1);
+  else if (av.aTR) noLeftFill = nb(b, b.x0 + nT, b.y0 - 1);
+  if (av.aTL) topFill = noLeftFill;
+  else if (av.aL) topFill = nb(b, b.x0 - 1, b.y0);
+  else if (av.aTR) topFill = nb(b, b.x0 + nT, b.y0 - 1);
 
   if (!filterFlag) {
-    BLOCK_LOOP
-    for (int e = lane; e <= 4 * nT; e += 64) bc[e - 2 * nT] = (int16_t)border_value<Pix, L2>(b, e - 2 * nT, noLeftFill, topFill);
+    lanes_loop<4 * nT + 1>(lane, [&](int e) { bc[e - 2 * nT] = (int16_t)border_value<Pix, L2>(b, av, e - 2 * nT, noLeftFill, topFill); });
     return;
   }
   bool bi = false;
   int p0 = 0, pL = 0, pT = 0;
   if (strong && nT == 32) {
-    p0 = border_value<Pix, L2>(b, 0, noLeftFill, topFill);
-    pL = border_value<Pix, L2>(b, -64, noLeftFill, topFill);
-    pT = border_value<Pix, L2>(b, 64, noLeftFill, topFill);
-    const int mL = border_value<Pix, L2>(b, -32, noLeftFill, topFill), mT = border_value<Pix, L2>(b, 32, noLeftFill, topFill);
+    p0 = border_value<Pix, L2>(b, av, 0, noLeftFill, topFill);
+    pL = border_value<Pix, L2>(b, av, -64, noLeftFill, topFill);
+    pT = border_value<Pix, L2>(b, av, 64, noLeftFill, topFill);
+    const int mL = border_value<Pix, L2>(b, av, -32, noLeftFill, topFill), mT = border_value<Pix, L2>(b, av, 32, noLeftFill, topFill);
     const int lim = 1 << (b.bd - 5);
     bi = iabs_(p0 + pT - 2 * mT) < lim && iabs_(p0 + pL - 2 * mL) < lim;
   }
-  BLOCK_LOOP
-  for (int e = lane; e <= 4 * nT; e += 64) {
+  lanes_loop<4 * nT + 1>(lane, [&](int e) {
     const int i = e - 2 * nT;
     int v;
-    if (i == -2 * nT || i == 2 * nT) v = border_value<Pix, L2>(b, i, noLeftFill, topFill);
+    if (i == -2 * nT || i == 2 * nT) v = border_value<Pix, L2>(b, av, i, noLeftFill, topFill);
     else if (bi) {
       if (i == 0) v = p0;
       else if (i < 0) v = p0 + (((-i) * (pL - p0) + 32) >> 6);
       else v = p0 + ((i * (pT - p0) + 32) >> 6);
     }
-    else v = (border_value<Pix, L2>(b, i + 1, noLeftFill, topFill) + 2 * border_value<Pix, L2>(b, i, noLeftFill, topFill) +
-              border_value<Pix, L2>(b, i - 1, noLeftFill, topFill) + 2) >> 2;
+    else v = (border_value<Pix, L2>(b, av, i + 1, noLeftFill, topFill) + 2 * border_value<Pix, L2>(b, av, i, noLeftFill, topFill) +
+              border_value<Pix, L2>(b, av, i - 1, noLeftFill, topFill) + 2) >> 2;
     bc[i] = (int16_t)v;
-  }
+  });
 }
 
 // ---- predictors (intrapred.h:269-441) ------------------------------------------------------------------
@@ -289,18 +311,16 @@ __device__ __forceinline__ void predict(const Blk<Pix>& B, const int16_t* b, con
   constexpr int npx = nT * nT;
   const bool edge = (c == 0 && nT < 32); // boundary smoothing of DC / pure vertical / pure horizontal (luma, < 32x32)
   if (mode == 0) {
-    BLOCK_LOOP
-    for (int p = lane; p < npx; p += 64) {
+    lanes_loop<npx>(lane, [&](int p) {
       const int x = p & (nT - 1), y = p >> log2;
       dst[y * pitch + x] = (Pix)(((nT - 1 - x) * b[-1 - y] + (x + 1) * b[1 + nT] + (nT - 1 - y) * b[1 + x] + (y + 1) * b[-1 - nT] + nT) >> (log2 + 1));
-    }
+    });
   }
   else if (mode == 1) {
     int s = 0;
     if (lane < nT) s = b[lane + 1] + b[-lane - 1];
     const int dc = (wave_sum(s) + nT) >> (log2 + 1);
-    BLOCK_LOOP
-    for (int p = lane; p < npx; p += 64) {
+    lanes_loop<npx>(lane, [&](int p) {
       const int x = p & (nT - 1), y = p >> log2;
       int v = dc;
       if (edge) {
@@ -310,13 +330,12 @@ __device__ __forceinline__ void predict(const Blk<Pix>& B, const int16_t* b, con
         v = (x | y) == 0 ? (l + 2 * dc + t + 2) >> 2 : v;
       }
       dst[y * pitch + x] = (Pix)v;
-    }
+    });
   }
   else if (mode == 26 || mode == 10) { // pure vertical / horizontal: copy, plus the gradient on the first column / row
     const bool vert = mode == 26;
     const int corner = b[0];
-    BLOCK_LOOP
-    for (int p = lane; p < npx; p += 64) {
+    lanes_loop<npx>(lane, [&](int p) {
       const int x = p & (nT - 1), y = p >> log2;
       const int t = b[1 + x], l = b[-1 - y];
       int v = vert ? t : l;
@@ -326,15 +345,14 @@ __device__ __forceinline__ void predict(const Blk<Pix>& B, const int16_t* b, con
         v = along == 0 ? clip3i(0, maxv, g) : v;
       }
       dst[y * pitch + x] = (Pix)v;
-    }
+    });
   }
   else {
     const int angle = tab[mode];
     const int inv = tab[35 + mode]; // 0 outside modes 11..25
     const bool vert = mode >= 18;
     const int sgn = vert ? 1 : -1; // ref[k] = border[sgn * k] for k >= 0, border[-sgn * proj(k)] for k < 0
-    BLOCK_LOOP
-    for (int p = lane; p < npx; p += 64) {
+    lanes_loop<npx>(lane, [&](int p) {
       const int x = p & (nT - 1), y = p >> log2;
       const int major = vert ? y : x, minor = vert ? x : y;
       const int t = (major + 1) * angle;
@@ -345,7 +363,7 @@ __device__ __forceinline__ void predict(const Blk<Pix>& B, const int16_t* b, con
       // b[j1] is read even when iFact == 0 (then it has weight 0; the index stays inside bA: |j1| <= 2nT + 1)
       const int r0 = b[j0], r1 = b[j1];
       dst[y * pitch + x] = (Pix)(((32 - iFact) * r0 + iFact * r1 + 16) >> 5);
-    }
+    });
   }
 }
 
@@ -357,7 +375,7 @@ __device__ __forceinline__ void residual_add(const Blk<Pix>& B, int16_t* coeff, 
 {
   constexpr int nT = 1 << L2, log2 = L2;
   const int c = B.c, bit_depth = B.bd;
-  const int npx = nT * nT;
+  constexpr int npx = nT * nT;
   const int qP = B.qp;
   const int bdShift = bit_depth + log2 - 9;
   const int32_t offset = 1 << (bdShift - 1);
@@ -383,14 +401,13 @@ __device__ __forceinline__ void residual_add(const Blk<Pix>& B, int16_t* coeff, 
 
   if (B.info & HM_TU_TSKIP) { // transform.cc:566-643
     const int tsShift = 5 + log2;
-    BLOCK_LOOP
-    for (int p = lane; p < npx; p += 64) {
+    lanes_loop<npx>(lane, [&](int p) {
       const int x = p & (nT - 1), y = p >> log2;
       const int32_t cc = (int32_t)((uint32_t)(int32_t)coeff[p] << tsShift);
       int r = (cc + rnd2) >> postShift;
       if (bit_depth == 8 && nT == 4) r = (int16_t)r;
       dst[y * pitch + x] = (Pix)clip3i(0, maxv, (int)dst[y * pitch + x] + r);
-    }
+    });
   }
   else if (nT == 4 && c == 0) { // 4x4 DST-VII, fallback-dct.cc:311-449
     if (lane < 16) {
@@ -417,23 +434,21 @@ __device__ __forceinline__ void residual_add(const Blk<Pix>& B, int16_t* coeff, 
     const int fct = 32 >> log2;
     constexpr int rpp = nT < 16 ? nT : 16, n_part = rpp << log2;
     for (int i0 = 0; i0 < nT; i0 += rpp) {
-      BLOCK_LOOP
-      for (int p = lane; p < n_part; p += 64) {
+      lanes_loop<n_part>(lane, [&](int p) {
         const int cc = p & (nT - 1), ir = p >> log2, i = i0 + ir;
         int sum = 0;
         if (cc <= mx)
           for (int j = 0; j <= my; j++) sum += (int)dct[(fct * j) * 32 + i] * (int)coeff[cc + j * nT];
         tmp[cc + ir * nT] = (int16_t)clip3i(-32768, 32767, (sum + 64) >> 7);
-      }
+      });
       WAVE_SYNC();
-      BLOCK_LOOP
-      for (int p = lane; p < n_part; p += 64) {
+      lanes_loop<n_part>(lane, [&](int p) {
         const int i = p & (nT - 1), yr = p >> log2, y = i0 + yr;
         int sum = 0;
         for (int j = 0; j <= mx; j++) sum += (int)dct[(fct * j) * 32 + i] * (int)tmp[yr * nT + j];
         const int out = (sum + rnd2) >> postShift; // stage 2 is not clipped to 16 bit (Q4)
         dst[y * pitch + i] = (Pix)clip3i(0, maxv, (int)dst[y * pitch + i] + out);
-      }
+      });
       WAVE_SYNC();
     }
   }
@@ -570,8 +585,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
         B.mode = r0 >> 24;
         B.log2 = B.info & HM_TU_LOG2_MASK;
         B.c = (B.info >> HM_TU_CIDX_SHIFT) & 3;
-        B.aL = r3 & 0xFF; B.aT = (r3 >> 16) & 0xFF;
-        B.aTL = (B.info & HM_TU_AVAIL_TL) ? 1 : 0;
+        B.avail = r3;
         B.bd = bd;
         B.x0 = w0 & 0xFF; B.y0 = (w0 >> 8) & 0xFF;
         B.qp = w1 & 0xFF;
@@ -625,29 +639,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
       }
 
       // ---- finished CTU: coalesced 4-byte stores to the picture, bottom row -> line, right column -> left column ----
-      auto flush_plane = [&](Pix* u, int P, Pix* line, uint8_t* plane, int pitch, int bw, int bh, int pw, int ph) {
-        const int xo = cx * bw, yo = row * bh;
-        const int vw = (pw - xo) < bw ? (pw - xo) : bw; // valid part inside the picture
+      auto flush_plane = [&](auto bw_c, Pix* u, int P, Pix* line, uint8_t* plane, int pitch, int bh, int pw, int ph) {
+        constexpr int BW = decltype(bw_c)::value;
+        constexpr int PPW = 4 / sizeof(Pix), WPR = BW / PPW, RPT = 64 / WPR; // samples per 32-bit word, words per row, rows per trip
+        static_assert(WPR >= 1 && WPR <= 64 && (WPR & (WPR - 1)) == 0, "CTB row must be 1..64 words");
+        const int xo = cx * BW, yo = row * bh;
+        const int vw = (pw - xo) < BW ? (pw - xo) : BW; // valid part inside the picture
         const int vh = (ph - yo) < bh ? (ph - yo) : bh;
-        constexpr int PPW = 4 / sizeof(Pix); // samples per 32-bit word
-        const int l2wpr = 31 - __builtin_clz(bw / PPW); // words per row is a power of two
-        const int vwords = vw / PPW;
-        BLOCK_LOOP
-        for (int p = lane; p < (vh << l2wpr); p += 64) {
-          const int r = p >> l2wpr, q = p & ((1 << l2wpr) - 1);
-          if (q < vwords) {
-            const uint32_t word = *reinterpret_cast<const uint32_t*>(u + r * P + UPAD + q * PPW);
-            *gptr_w<uint32_t>(plane + (size_t)(yo + r) * pitch + (size_t)(xo + q * PPW) * sizeof(Pix)) = word;
-          }
+        const int q = lane & (WPR - 1), r0 = lane / WPR;
+        const bool col_ok = q * PPW < vw;
+        GLOBAL_AS uint8_t* const gp = gptr_w<uint8_t>(plane + (size_t)yo * pitch + (size_t)(xo + q * PPW) * sizeof(Pix));
+        for (int rb = 0; rb < vh; rb += RPT) { // scalar trip counter; lanes only differ in (row, word)
+          const int r = rb + r0;
+          if (col_ok && r < vh)
+            *reinterpret_cast<GLOBAL_AS uint32_t*>(gp + (size_t)r * pitch) = *reinterpret_cast<const uint32_t*>(u + r * P + UPAD + q * PPW);
         }
-        if (lane < (1 << l2wpr))
+        if (lane < WPR)
           *reinterpret_cast<uint32_t*>(line + xo + lane * PPW) = *reinterpret_cast<const uint32_t*>(u + (bh - 1) * P + UPAD + lane * PPW);
         WAVE_SYNC();
-        for (int r = lane; r < bh; r += 64) u[r * P + UPAD - 1] = u[r * P + UPAD + bw - 1]; // becomes the left column
+        if (lane < bh) u[lane * P + UPAD - 1] = u[lane * P + UPAD + BW - 1]; // right column becomes the left neighbour
       };
-      flush_plane(u0, P0, lw, dp.plane[0], dp.pitch[0], ctb, ctb, dp.width, dp.height);
-      flush_plane(u1, P1, lw + lo1, dp.plane[1], dp.pitch[1], cw_c, ch_c, planeWc, planeHc);
-      flush_plane(u2, P1, lw + lo2, dp.plane[2], dp.pitch[2], cw_c, ch_c, planeWc, planeHc);
+      flush_plane(std::integral_constant<int, ctb>(), u0, P0, lw, dp.plane[0], dp.pitch[0], ctb, dp.width, dp.height);
+      flush_plane(std::integral_constant<int, cw_c>(), u1, P1, lw + lo1, dp.plane[1], dp.pitch[1], ch_c, planeWc, planeHc);
+      flush_plane(std::integral_constant<int, cw_c>(), u2, P1, lw + lo2, dp.plane[2], dp.pitch[2], ch_c, planeWc, planeHc);
       // ---- publish progress: only LDS traffic has to be ordered (the picture stores stay in flight) ----
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
       if (lane == 0) __hip_atomic_store(&progress[row], cx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
