@@ -194,109 +194,87 @@ constexpr uint64_t filter_mode_mask(int log2)
   return m;
 }
 
-// ---- reference samples incl. smoothing (intrapred.h:192-266), written once to bA -------------------
+// ---- reference samples incl. smoothing (intrapred.h:192-266), written to bA ------------------------
+// Pass 1 gathers the 4nT+1 substituted samples, pass 2 (luma blocks >= 8x8, most angular modes) smooths
+// them in place: all lanes read their three neighbours, then all lanes write.
 // Written select-style on purpose (both candidates computed, then chosen): a ternary with arithmetic in
 // its arms becomes an exec-mask branch, i.e. several scalar instructions per lane-level decision.
 template <typename Pix, int L2>
 __device__ __forceinline__ void make_border(const Blk<Pix>& b, int16_t* bA, int strong, int lane)
 {
-  constexpr int nT = 1 << L2;
+  constexpr int nT = 1 << L2, N = 4 * nT + 1;
   int16_t* const bc = bA + 64; // centre (corner sample)
-  const bool filterFlag = L2 != 2 && b.c == 0 && ((filter_mode_mask(L2) >> b.mode) & 1);
 
   // interior <=> left and top runs complete (the counts are 0 or nT: bit L2) and the corner exists
   constexpr uint32_t need = 0x00010001u << L2;
   if ((b.avail & need) == need && (b.info & HM_TU_AVAIL_TL)) {
-    // Interior block (left, above and corner exist): substitution only replicates the last available
-    // sample of a partly available below-left / above-right run = a clamped coordinate.  One ds_read per lane.
+    // substitution only replicates the last available sample of a partly available below-left /
+    // above-right run = a clamped coordinate.  One ds_read per lane.
     const Pix* const lp = b.u + (b.y0 * b.P + UPAD + b.x0 - 1); // (x0-1, y0)
     const Pix* const tpu = lp - b.P + 1;                        // (x0, y0-1) inside the CTU
     const Pix* const tpl = b.top + (1 + b.x0);                  // ... in the line of the CTU row above
     const Pix* const tp = b.y0 > 0 ? tpu : tpl;
     const int nL1 = nT + b.aBL - 1, nT1 = nT + b.aTR - 1;
-    auto ref = [&](int i) -> int { // reference sample i, i in [-2nT, 2nT]
+    lanes_loop<N>(lane, [&](int e) {
+      const int i = e - 2 * nT;
       const int ol = imin_(-i - 1, nL1) * b.P, ot = imin_(i - 1, nT1);
       const Pix* const ql = lp + ol;
       const Pix* const qt = tp + ot;
-      return *(i < 0 ? ql : qt);
-    };
-    if (!filterFlag) {
-      lanes_loop<4 * nT + 1>(lane, [&](int e) {
-        const int i = e - 2 * nT;
-        bc[i] = (int16_t)ref(i);
-      });
-      return;
-    }
-    // [1 2 1] smoothing or strong (bilinear) smoothing; the two end samples stay unfiltered
+      bc[i] = (int16_t)*(i < 0 ? ql : qt);
+    });
+  }
+  else { // picture / slice / tile border: full substitution process
+    Avail av;
+    av.aL = b.avail & 0xFF; av.aBL = (b.avail >> 8) & 0xFF; av.aT = (b.avail >> 16) & 0xFF; av.aTR = b.avail >> 24;
+    av.aTL = (b.info & HM_TU_AVAIL_TL) ? 1 : 0;
+    const int DEF = 1 << (b.bd - 1);
+    int noLeftFill = DEF, topFill = DEF;
+    if (av.aTL) noLeftFill = nb(b, b.x0 - 1, b.y0 - 1);
+    else if (av.aT) noLeftFill = nb(b, b.x0, b.y0 - 1);
+    else if (av.aTR) noLeftFill = nb(b, b.x0 + nT, b.y0 - 1);
+    if (av.aTL) topFill = noLeftFill;
+    else if (av.aL) topFill = nb(b, b.x0 - 1, b.y0);
+    else if (av.aTR) topFill = nb(b, b.x0 + nT, b.y0 - 1);
+    lanes_loop<N>(lane, [&](int e) { bc[e - 2 * nT] = (int16_t)border_value<Pix, L2>(b, av, e - 2 * nT, noLeftFill, topFill); });
+  }
+
+  if (L2 != 2 && b.c == 0 && ((filter_mode_mask(L2) >> b.mode) & 1)) {
+    WAVE_SYNC();
+    // strong (bilinear) smoothing of 32x32 blocks when both edges are nearly linear, else [1 2 1]; the two
+    // end samples stay as they are (the bilinear formula and the degenerate [c 2c c] both return them)
     bool bi = false;
     int p0 = 0, pL = 0, pT = 0;
     if (L2 == 5 && strong) {
-      p0 = ref(0); pL = ref(-64); pT = ref(64);
-      const int mL = ref(-32), mT = ref(32);
+      p0 = bc[0]; pL = bc[-64]; pT = bc[64];
+      const int mL = bc[-32], mT = bc[32];
       const int lim = 1 << (b.bd - 5);
       bi = iabs_(p0 + pT - 2 * mT) < lim && iabs_(p0 + pL - 2 * mL) < lim;
     }
-    if (bi) {
-      lanes_loop<4 * nT + 1>(lane, [&](int e) {
-        const int i = e - 2 * nT;
-        const int vl = p0 + (((-i) * (pL - p0) + 32) >> 6), vt = p0 + ((i * (pT - p0) + 32) >> 6);
-        int v = i < 0 ? vl : vt; // i == 0 gives p0 either way
-        v = i == -2 * nT ? pL : v;
-        v = i == 2 * nT ? pT : v;
-        bc[i] = (int16_t)v;
-      });
-      return;
+    constexpr int TRIPS = (N + 63) / 64;
+    int v[TRIPS];
+#pragma unroll
+    for (int t = 0; t < TRIPS; t++) {
+      const int e = lane + 64 * t, i = e - 2 * nT;
+      v[t] = 0;
+      if (e < N) {
+        if (bi) {
+          const int vl = p0 + (((-i) * (pL - p0) + 32) >> 6), vt = p0 + ((i * (pT - p0) + 32) >> 6);
+          v[t] = i < 0 ? vl : vt;
+        }
+        else {
+          const bool end = (i == -2 * nT) | (i == 2 * nT);
+          const int im = end ? i : i - 1, ip = end ? i : i + 1;
+          v[t] = (bc[im] + 2 * bc[i] + bc[ip] + 2) >> 2;
+        }
+      }
     }
-    lanes_loop<4 * nT + 1>(lane, [&](int e) {
-      const int i = e - 2 * nT;
-      const bool end = (i == -2 * nT) | (i == 2 * nT); // ends stay unfiltered: (c + 2c + c + 2) >> 2 == c
-      const int im = end ? i : i - 1, ip = end ? i : i + 1;
-      const int cm = ref(im), c0 = ref(i), cp = ref(ip);
-      bc[i] = (int16_t)((cm + 2 * c0 + cp + 2) >> 2);
-    });
-    return;
-  }
-
-  // ---- picture / slice / tile border: full substitution process ----
-  Avail av;
-  av.aL = b.avail & 0xFF; av.aBL = (b.avail >> 8) & 0xFF; av.aT = (b.avail >> 16) & 0xFF; av.aTR = b.avail >> 24;
-  av.aTL = (b.info & HM_TU_AVAIL_TL) ? 1 : 0;
-  const int DEF = 1 << (b.bd - 1);
-  int noLeftFill = DEF, topFill = DEF;
-  if (av.aTL) noLeftFill = nb(b, b.x0 - 1, b.y0 - 1);
-  else if (av.aT) noLeftFill = nb(b, b.x0, b.y0 - 1);
-  else if (av.aTR) noLeftFill = nb(b, b.x0 + nT, b.y0 - 1);
-  if (av.aTL) topFill = noLeftFill;
-  else if (av.aL) topFill = nb(b, b.x0 - 1, b.y0);
-  else if (av.aTR) topFill = nb(b, b.x0 + nT, b.y0 - 1);
-
-  if (!filterFlag) {
-    lanes_loop<4 * nT + 1>(lane, [&](int e) { bc[e - 2 * nT] = (int16_t)border_value<Pix, L2>(b, av, e - 2 * nT, noLeftFill, topFill); });
-    return;
-  }
-  bool bi = false;
-  int p0 = 0, pL = 0, pT = 0;
-  if (strong && nT == 32) {
-    p0 = border_value<Pix, L2>(b, av, 0, noLeftFill, topFill);
-    pL = border_value<Pix, L2>(b, av, -64, noLeftFill, topFill);
-    pT = border_value<Pix, L2>(b, av, 64, noLeftFill, topFill);
-    const int mL = border_value<Pix, L2>(b, av, -32, noLeftFill, topFill), mT = border_value<Pix, L2>(b, av, 32, noLeftFill, topFill);
-    const int lim = 1 << (b.bd - 5);
-    bi = iabs_(p0 + pT - 2 * mT) < lim && iabs_(p0 + pL - 2 * mL) < lim;
-  }
-  lanes_loop<4 * nT + 1>(lane, [&](int e) {
-    const int i = e - 2 * nT;
-    int v;
-    if (i == -2 * nT || i == 2 * nT) v = border_value<Pix, L2>(b, av, i, noLeftFill, topFill);
-    else if (bi) {
-      if (i == 0) v = p0;
-      else if (i < 0) v = p0 + (((-i) * (pL - p0) + 32) >> 6);
-      else v = p0 + ((i * (pT - p0) + 32) >> 6);
+    WAVE_SYNC();
+#pragma unroll
+    for (int t = 0; t < TRIPS; t++) {
+      const int e = lane + 64 * t;
+      if (e < N) bc[e - 2 * nT] = (int16_t)v[t];
     }
-    else v = (border_value<Pix, L2>(b, av, i + 1, noLeftFill, topFill) + 2 * border_value<Pix, L2>(b, av, i, noLeftFill, topFill) +
-              border_value<Pix, L2>(b, av, i - 1, noLeftFill, topFill) + 2) >> 2;
-    bc[i] = (int16_t)v;
-  });
+  }
 }
 
 // ---- predictors (intrapred.h:269-441) ------------------------------------------------------------------
