@@ -301,50 +301,72 @@ __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict_
   int out[G];
   const bool fast = ((dp.src_x[c] & (G - 1)) == 0) && (x8 + G <= cw) && (xs + G <= W);
   if (fast) {
+    // ---- one aligned vector load per row, everything else in registers ----
     const int cx = xs >> l2w, cy = yy >> l2h;
-    const hm_ctb& cb = v.ctbs[cx + cy * dp.ctb_w];
-    const hm_slice& sl = v.slices[cb.slice_idx];
-    const bool sao_on = apply_sao && (dp.flags & HM_PIC_SAO_ENABLED) && (c == 0 ? sl.sao_luma : sl.sao_chroma);
-    const hm_sao s = cb.sao[c];
-    const int type = sao_on ? s.type : 0;
+    const uint32_t* cbq = reinterpret_cast<const uint32_t*>(v.ctbs + (cx + cy * dp.ctb_w)); // hm_ctb as dwords
+    const uint32_t cflags = cbq[2];                       // flags | sao_nb_mask << 8
+    const uint32_t s0 = cbq[3 + 2 * c], s1 = cbq[4 + 2 * c]; // hm_sao: type, eo_class, band_position, offset[0] | offset[1..3], reserved
+    const bool sao_on = apply_sao && (dp.flags & HM_PIC_SAO_ENABLED) && (cflags & (c == 0 ? HM_CTB_SAO_LUMA : HM_CTB_SAO_CHROMA));
+    const int type = sao_on ? (int)(s0 & 0xFF) : 0;
+    const uint32_t offs = (s0 >> 24) | (s1 << 8);         // the four int8 offsets in one register
+    const uint32_t nbm = (cflags >> 8) & 0xFF;
+    const Pix* rc = reinterpret_cast<const Pix*>(plane + (size_t)yy * pitch) + xs;
     Pix cur[G];
-    __builtin_memcpy(cur, reinterpret_cast<const Pix*>(plane + (size_t)yy * pitch) + xs, G * sizeof(Pix));
+    __builtin_memcpy(cur, rc, G * sizeof(Pix));
 #pragma unroll
     for (int k = 0; k < G; k++) out[k] = cur[k];
-    if (type == 1) {
+    if (type == 1) { // band offset (fallback-postfilter.h:218-241)
+      const int bp = (s0 >> 16) & 0xFF;
 #pragma unroll
       for (int k = 0; k < G; k++) {
-        const int bi = ((out[k] >> (bd - 5)) - s.band_position) & 31;
-        if (bi < 4) out[k] = clip3i(0, maxv, out[k] + s.offset[bi]);
+        const int bi = ((out[k] >> (bd - 5)) - bp) & 31;
+        const int o = (int)(int8_t)(offs >> (8 * (bi & 3)));
+        out[k] = bi < 4 ? clip3i(0, maxv, out[k] + o) : out[k];
       }
     }
-    else if (type == 2) {
-      const int cl = s.eo_class;
+    else if (type == 2) { // edge offset (sao.cc:336-424)
+      const int cl = (s0 >> 8) & 0xFF;
       const int hx0 = cl == 1 ? 0 : (cl == 3 ? 1 : -1);
       const int vy0 = cl == 0 ? 0 : -1;
-      // rows holding the two neighbours of every sample of the group: (yy+vy0, x+hx0) and (yy-vy0, x-hx0)
+      // neighbour a of sample x is (x + hx0, yy + vy0), neighbour b is (x - hx0, yy - vy0)
       const int ya = yy + vy0, yb = yy - vy0;
-      const bool rowa_ok = ya >= 0 && ya < Hh, rowb_ok = yb >= 0 && yb < Hh;
-      // neighbour-CTB permissions (only the CTB borders can fail): evaluate per sample, cheap integer tests
-      const Pix* ra = reinterpret_cast<const Pix*>(plane + (size_t)(rowa_ok ? ya : yy) * pitch);
-      const Pix* rb = reinterpret_cast<const Pix*>(plane + (size_t)(rowb_ok ? yb : yy) * pitch);
+      const bool rowa_ok = ya >= 0, rowb_ok = yb < Hh;
+      const int dya = (ya >> l2h) - cy, dyb = (yb >> l2h) - cy; // -1 / 0 and 0 / +1
+      auto perm = [&](int dy, int dx) -> bool { // may the neighbour CTB (dx, dy) be read?
+        const int k8 = (dy + 1) * 3 + (dx + 1);
+        const int bit = k8 < 4 ? k8 : k8 - 1;
+        return (dx | dy) == 0 || ((nbm >> bit) & 1);
+      };
+      const Pix* ra = reinterpret_cast<const Pix*>(plane + (size_t)(rowa_ok ? ya : yy) * pitch) + xs;
+      const Pix* rb = reinterpret_cast<const Pix*>(plane + (size_t)(rowb_ok ? yb : yy) * pitch) + xs;
+      Pix va[G], vb[G];
+      __builtin_memcpy(va, ra, G * sizeof(Pix));
+      __builtin_memcpy(vb, rb, G * sizeof(Pix));
+      // the sample left of / right of the group, on the side each row needs
+      const bool has_l = xs > 0, has_r = xs + G < W;
+      int ea = 0, eb = 0;
+      if (hx0 != 0) {
+        const bool a_left = hx0 < 0;
+        if (a_left ? has_l : has_r) ea = ra[a_left ? -1 : G];
+        if (a_left ? has_r : has_l) eb = rb[a_left ? G : -1];
+      }
+      const bool mid_ok = rowa_ok && rowb_ok && perm(dya, 0) && perm(dyb, 0);
+      // the first / last sample of the group may look into the CTB column to the left / right
+      const int dxl = ((xs - 1) >> l2w) - cx, dxr = ((xs + G) >> l2w) - cx;
+      const bool first_ok = rowa_ok && rowb_ok && (hx0 == 0 || has_l) && perm(hx0 < 0 ? dya : dyb, hx0 == 0 ? 0 : dxl) && perm(hx0 < 0 ? dyb : dya, 0);
+      const bool last_ok = rowa_ok && rowb_ok && (hx0 == 0 || has_r) && perm(hx0 > 0 ? dya : dyb, hx0 == 0 ? 0 : dxr) && perm(hx0 > 0 ? dyb : dya, 0);
 #pragma unroll
       for (int k = 0; k < G; k++) {
-        const int xx = xs + k;
-        const int xa = xx + hx0, xb = xx - hx0;
-        bool ok = rowa_ok && rowb_ok && xa >= 0 && xa < W && xb >= 0 && xb < W;
-        if (ok) {
-          const int dxa = (xa >> l2w) - cx, dya = (ya >> l2h) - cy;
-          const int dxb = (xb >> l2w) - cx, dyb = (yb >> l2h) - cy;
-          if (dxa | dya) { const int k8 = (dya + 1) * 3 + (dxa + 1); if (!(cb.sao_nb_mask & (1u << (k8 < 4 ? k8 : k8 - 1)))) ok = false; }
-          if (dxb | dyb) { const int k8 = (dyb + 1) * 3 + (dxb + 1); if (!(cb.sao_nb_mask & (1u << (k8 < 4 ? k8 : k8 - 1)))) ok = false; }
-        }
-        if (ok) {
-          const int a = ra[xa], b = rb[xb];
-          const int e = isign_(out[k] - a) + isign_(out[k] - b);
-          const int o = e == -2 ? s.offset[0] : (e == -1 ? s.offset[1] : (e == 1 ? s.offset[2] : (e == 2 ? s.offset[3] : 0)));
-          out[k] = clip3i(0, maxv, out[k] + o);
-        }
+        // a = row a shifted by hx0, b = row b shifted by -hx0
+        const int am = k > 0 ? (int)va[k > 0 ? k - 1 : 0] : ea, ap = k < G - 1 ? (int)va[k < G - 1 ? k + 1 : 0] : ea;
+        const int bm = k > 0 ? (int)vb[k > 0 ? k - 1 : 0] : eb, bp = k < G - 1 ? (int)vb[k < G - 1 ? k + 1 : 0] : eb;
+        const int a = hx0 < 0 ? am : (hx0 > 0 ? ap : (int)va[k]);
+        const int b = hx0 < 0 ? bp : (hx0 > 0 ? bm : (int)vb[k]);
+        const bool ok = k == 0 ? first_ok : (k == G - 1 ? last_ok : mid_ok);
+        const int e = isign_(out[k] - a) + isign_(out[k] - b);
+        const int idx = e < 0 ? e + 2 : e + 1; // -2,-1,1,2 -> 0,1,2,3
+        const int o = (int)(int8_t)(offs >> (8 * (idx & 3)));
+        out[k] = (ok && e != 0) ? clip3i(0, maxv, out[k] + o) : out[k];
       }
     }
   }

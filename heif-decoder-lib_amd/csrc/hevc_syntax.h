@@ -217,8 +217,10 @@ class SliceWalker {
     const int x0 = xCtb << sps_.log2_ctb, y0 = yCtb << sps_.log2_ctb;
     hm_ctb& c = pic_.ctbs[ctb_addr_rs_];
     // deblocking edge permissions of this CTB's left/top edge (deblock.cc:160-196 in the reference)
-    c.flags &= ~(HM_CTB_DEBLOCK_LEFT | HM_CTB_DEBLOCK_TOP | HM_CTB_DEBLOCK_OFF);
+    c.flags &= ~(HM_CTB_DEBLOCK_LEFT | HM_CTB_DEBLOCK_TOP | HM_CTB_DEBLOCK_OFF | HM_CTB_SAO_LUMA | HM_CTB_SAO_CHROMA);
     if (sh_.deblocking_disabled) c.flags |= HM_CTB_DEBLOCK_OFF;
+    if (sh_.sao_luma) c.flags |= HM_CTB_SAO_LUMA;
+    if (sh_.sao_chroma) c.flags |= HM_CTB_SAO_CHROMA;
     if (x0 > 0) {
       const int nb = ctb_addr_rs_ - 1;
       bool ok = true;

@@ -74,6 +74,8 @@ typedef struct hm_slice {
 #define HM_CTB_DEBLOCK_TOP   0x02u /* ... top edge                                                       */
 #define HM_CTB_CODED         0x04u /* CTB was present in the bitstream                                   */
 #define HM_CTB_DEBLOCK_OFF   0x08u /* slice_deblocking_filter_disabled_flag of the CTB's slice           */
+#define HM_CTB_SAO_LUMA      0x10u /* slice_sao_luma_flag of the CTB's slice                            */
+#define HM_CTB_SAO_CHROMA    0x20u /* slice_sao_chroma_flag of the CTB's slice                          */
 
 /* SAO parameters of one colour component of one CTB (slice.h:457-465, offsets pre-scaled
  * by log2_sao_offset_scale as slice.cc:2996-3007 does) */
