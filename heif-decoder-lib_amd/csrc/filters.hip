@@ -68,8 +68,8 @@ __device__ __forceinline__ const hm_slice& slice_at(const hm_dev_pic& dp, const 
 }
 
 // 8 samples along the edge (d), 8 across (i = 0..7 <-> p3 p2 p1 p0 | q0 q1 q2 q3)
-template <typename Pix>
-__device__ __forceinline__ void load_window(const uint8_t* plane, int pitch, int xD, int yD, int vertical, int px[8][8])
+template <typename Pix, bool vertical>
+__device__ __forceinline__ void load_window(const uint8_t* plane, int pitch, int xD, int yD, int px[8][8])
 {
   // row-major 8x8 tile whose top-left is (xD-4, yD) for vertical edges, (xD, yD-4) for horizontal
   const int tx = vertical ? xD - 4 : xD, ty = vertical ? yD : yD - 4;
@@ -85,8 +85,8 @@ __device__ __forceinline__ void load_window(const uint8_t* plane, int pitch, int
     }
   }
 }
-template <typename Pix>
-__device__ __forceinline__ void store_window(uint8_t* plane, int pitch, int xD, int yD, int vertical, const int px[8][8])
+template <typename Pix, bool vertical>
+__device__ __forceinline__ void store_window(uint8_t* plane, int pitch, int xD, int yD, const int px[8][8])
 {
   const int tx = vertical ? xD - 4 : xD, ty = vertical ? yD : yD - 4;
 #pragma unroll
@@ -147,8 +147,8 @@ __device__ __forceinline__ void filter_luma(int px[8][8], int beta, const int tc
 }
 
 // One launch = one direction for every picture of the batch.  blockIdx.y = picture.
-template <typename Pix>
-__global__ __launch_bounds__(256) void k_deblock(const hm_dev_pic* __restrict__ pics, int vertical)
+template <typename Pix, bool vertical>
+__global__ __launch_bounds__(256) void k_deblock(const hm_dev_pic* __restrict__ pics)
 {
   const hm_dev_pic& dp = pics[blockIdx.y];
   if (!(dp.flags & HM_PIC_DEBLOCK_ANY)) return;
@@ -173,9 +173,9 @@ __global__ __launch_bounds__(256) void k_deblock(const hm_dev_pic* __restrict__ 
     tc[0] = bs0 ? c_tc[clip3i(0, 53, qPL + 2 * (bs0 - 1) + sl.tc_offset_div2 * 2)] * (1 << (bd - 8)) : 0;
     tc[1] = bs1 ? c_tc[clip3i(0, 53, qPL + 2 * (bs1 - 1) + sl.tc_offset_div2 * 2)] * (1 << (bd - 8)) : 0;
     int px[8][8];
-    load_window<Pix>(dp.plane[0], dp.pitch[0], xD, yD, vertical, px);
+    load_window<Pix, vertical>(dp.plane[0], dp.pitch[0], xD, yD, px);
     filter_luma(px, beta, tc, maxv);
-    store_window<Pix>(dp.plane[0], dp.pitch[0], xD, yD, vertical, px);
+    store_window<Pix, vertical>(dp.plane[0], dp.pitch[0], xD, yD, px);
     return;
   }
   // ---- chroma segments (deblock.cc:1608-1772) ----
@@ -211,16 +211,35 @@ __global__ __launch_bounds__(256) void k_deblock(const hm_dev_pic* __restrict__ 
   tc[1] = bS1 == 2 ? c_tc[clip3i(0, 53, QP_C1 + 2 + tco)] * (1 << (bd - 8)) : 0;
   uint8_t* plane = dp.plane[cp + 1];
   const int pitch = dp.pitch[cp + 1];
+  // 8 samples along the edge, p1 p0 | q0 q1 across it: row-wise vector accesses
+  if (vertical) {
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
-    const int t = tc[k >> 2];
-    if (t == 0) continue;
-    Pix* b = reinterpret_cast<Pix*>(plane + (size_t)(vertical ? yDi + k : yDi) * pitch) + (vertical ? xDi : xDi + k);
-    const int xs = vertical ? 1 : pitch / (int)sizeof(Pix);
-    const int p1 = b[-2 * xs], p0 = b[-xs], q0 = b[0], q1 = b[xs];
-    const int delta = clip3i(-t, t, ((((q0 - p0) * 4) + p1 - q1 + 4) >> 3));
-    b[-xs] = (Pix)clip3i(0, maxv, p0 + delta);
-    b[0] = (Pix)clip3i(0, maxv, q0 - delta);
+    for (int k = 0; k < 8; k++) {
+      const int t = tc[k >> 2];
+      if (t == 0) continue;
+      Pix* row = reinterpret_cast<Pix*>(plane + (size_t)(yDi + k) * pitch) + xDi - 2;
+      Pix w[4];
+      __builtin_memcpy(w, row, 4 * sizeof(Pix));
+      const int p1 = w[0], p0 = w[1], q0 = w[2], q1 = w[3];
+      const int delta = clip3i(-t, t, ((((q0 - p0) * 4) + p1 - q1 + 4) >> 3));
+      Pix o[2] = {(Pix)clip3i(0, maxv, p0 + delta), (Pix)clip3i(0, maxv, q0 - delta)};
+      __builtin_memcpy(row + 1, o, 2 * sizeof(Pix));
+    }
+  }
+  else {
+    Pix r[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; j++) __builtin_memcpy(r[j], reinterpret_cast<const Pix*>(plane + (size_t)(yDi - 2 + j) * pitch) + xDi, 8 * sizeof(Pix));
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int t = tc[k >> 2];
+      const int p1 = r[0][k], p0 = r[1][k], q0 = r[2][k], q1 = r[3][k];
+      const int delta = clip3i(-t, t, ((((q0 - p0) * 4) + p1 - q1 + 4) >> 3)); // t == 0 leaves the samples unchanged
+      r[1][k] = (Pix)clip3i(0, maxv, p0 + delta);
+      r[2][k] = (Pix)clip3i(0, maxv, q0 - delta);
+    }
+    __builtin_memcpy(reinterpret_cast<Pix*>(plane + (size_t)(yDi - 1) * pitch) + xDi, r[1], 8 * sizeof(Pix));
+    __builtin_memcpy(reinterpret_cast<Pix*>(plane + (size_t)yDi * pitch) + xDi, r[2], 8 * sizeof(Pix));
   }
 }
 
@@ -415,9 +434,14 @@ extern "C" int hm_launch_deblock(const hm_dev_pic* d_pics, int n_pics, int max_w
   const int cwn = (max_w4 + 3) / 4, chn = (max_h4 + 2 * sh - 1) / (2 * sh);
   const long items = (long)lw * lh + 2L * cwn * chn;
   const int blocks = (int)((items + 255) / 256);
-  for (int vertical = 1; vertical >= 0; vertical--) {
-    if (bit_depth > 8) hipLaunchKernelGGL(k_deblock<uint16_t>, dim3(blocks, n_pics), dim3(256), 0, s, d_pics, vertical);
-    else hipLaunchKernelGGL(k_deblock<uint8_t>, dim3(blocks, n_pics), dim3(256), 0, s, d_pics, vertical);
+  // all vertical edges of every picture first, then the horizontal ones (deblock.cc:1775-1803)
+  if (bit_depth > 8) {
+    hipLaunchKernelGGL((k_deblock<uint16_t, true>), dim3(blocks, n_pics), dim3(256), 0, s, d_pics);
+    hipLaunchKernelGGL((k_deblock<uint16_t, false>), dim3(blocks, n_pics), dim3(256), 0, s, d_pics);
+  }
+  else {
+    hipLaunchKernelGGL((k_deblock<uint8_t, true>), dim3(blocks, n_pics), dim3(256), 0, s, d_pics);
+    hipLaunchKernelGGL((k_deblock<uint8_t, false>), dim3(blocks, n_pics), dim3(256), 0, s, d_pics);
   }
   return hm_check_hip(hipGetLastError(), "k_deblock launch");
 }
