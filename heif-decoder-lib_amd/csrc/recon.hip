@@ -159,6 +159,50 @@ __device__ __forceinline__ int border_value(const Blk<Pix>& b, const Avail& av, 
   return valid ? v : fill;
 }
 
+// Where the predictors take reference sample j (j = -2nT .. 2nT as above) from:
+//   RefArray   the gathered (and possibly smoothed) array bA
+//   RefDirect  straight from the CTU buffer / the line above, for interior blocks whose samples need no smoothing:
+//              substitution of a partly available run is a clamped coordinate, so no gather pass, no LDS write
+//              and one LDS round trip less on the block's dependency chain
+struct RefArray {
+  const int16_t* bc;
+  __device__ __forceinline__ int operator()(int j) const { return bc[j]; }
+};
+template <typename Pix>
+struct RefDirect {
+  const Pix* lp; // sample (x0-1, y0); lp[y * P] walks down the left column
+  const Pix* tp; // sample (x0, y0-1); tp[-1] is the corner
+  int P, nL1, nT1;
+  __device__ __forceinline__ int operator()(int j) const
+  {
+    const int ol = imin_(-j - 1, nL1) * P, ot = imin_(j - 1, nT1);
+    const Pix* const ql = lp + ol;
+    const Pix* const qt = tp + ot;
+    return *(j < 0 ? ql : qt);
+  }
+};
+template <typename Pix, int L2>
+__device__ __forceinline__ RefDirect<Pix> direct_refs(const Blk<Pix>& b)
+{
+  constexpr int nT = 1 << L2;
+  RefDirect<Pix> r;
+  r.lp = b.u + (b.y0 * b.P + UPAD + b.x0 - 1);
+  const Pix* const tpu = r.lp - b.P + 1;       // (x0, y0-1) inside the CTU
+  const Pix* const tpl = b.top + (1 + b.x0);   // ... in the line of the CTU row above
+  r.tp = b.y0 > 0 ? tpu : tpl;
+  r.P = b.P;
+  r.nL1 = nT + b.aBL - 1;
+  r.nT1 = nT + b.aTR - 1;
+  return r;
+}
+// interior <=> left and top runs complete (the counts are 0 or nT: bit L2) and the corner exists
+template <int L2>
+__device__ __forceinline__ bool is_interior(uint32_t avail, int info)
+{
+  constexpr uint32_t need = 0x00010001u << L2;
+  return (avail & need) == need && (info & HM_TU_AVAIL_TL);
+}
+
 // Per-lane loop over N items (N a compile-time constant, item = lane + 64 * trip): straight-line code for up to
 // two trips, otherwise a loop on a scalar counter; only the last, partial trip is predicated.
 template <int N, typename F>
@@ -205,23 +249,11 @@ __device__ __forceinline__ void make_border(const Blk<Pix>& b, int16_t* bA, int 
   constexpr int nT = 1 << L2, N = 4 * nT + 1;
   int16_t* const bc = bA + 64; // centre (corner sample)
 
-  // interior <=> left and top runs complete (the counts are 0 or nT: bit L2) and the corner exists
-  constexpr uint32_t need = 0x00010001u << L2;
-  if ((b.avail & need) == need && (b.info & HM_TU_AVAIL_TL)) {
+  if (is_interior<L2>(b.avail, b.info)) {
     // substitution only replicates the last available sample of a partly available below-left /
     // above-right run = a clamped coordinate.  One ds_read per lane.
-    const Pix* const lp = b.u + (b.y0 * b.P + UPAD + b.x0 - 1); // (x0-1, y0)
-    const Pix* const tpu = lp - b.P + 1;                        // (x0, y0-1) inside the CTU
-    const Pix* const tpl = b.top + (1 + b.x0);                  // ... in the line of the CTU row above
-    const Pix* const tp = b.y0 > 0 ? tpu : tpl;
-    const int nL1 = nT + b.aBL - 1, nT1 = nT + b.aTR - 1;
-    lanes_loop<N>(lane, [&](int e) {
-      const int i = e - 2 * nT;
-      const int ol = imin_(-i - 1, nL1) * b.P, ot = imin_(i - 1, nT1);
-      const Pix* const ql = lp + ol;
-      const Pix* const qt = tp + ot;
-      bc[i] = (int16_t)*(i < 0 ? ql : qt);
-    });
+    const RefDirect<Pix> R = direct_refs<Pix, L2>(b);
+    lanes_loop<N>(lane, [&](int e) { bc[e - 2 * nT] = (int16_t)R(e - 2 * nT); });
   }
   else { // picture / slice / tile border: full substitution process
     Avail av;
@@ -278,8 +310,8 @@ __device__ __forceinline__ void make_border(const Blk<Pix>& b, int16_t* bA, int 
 }
 
 // ---- predictors (intrapred.h:269-441) ------------------------------------------------------------------
-template <typename Pix, int L2>
-__device__ __forceinline__ void predict(const Blk<Pix>& B, const int16_t* b, const int16_t* tab, int lane)
+template <typename Pix, int L2, typename Ref>
+__device__ __forceinline__ void predict(const Blk<Pix>& B, const Ref& b, const int16_t* tab, int lane)
 {
   constexpr int nT = 1 << L2, log2 = L2;
   const int mode = B.mode, c = B.c;
@@ -291,18 +323,18 @@ __device__ __forceinline__ void predict(const Blk<Pix>& B, const int16_t* b, con
   if (mode == 0) {
     lanes_loop<npx>(lane, [&](int p) {
       const int x = p & (nT - 1), y = p >> log2;
-      dst[y * pitch + x] = (Pix)(((nT - 1 - x) * b[-1 - y] + (x + 1) * b[1 + nT] + (nT - 1 - y) * b[1 + x] + (y + 1) * b[-1 - nT] + nT) >> (log2 + 1));
+      dst[y * pitch + x] = (Pix)(((nT - 1 - x) * b(-1 - y) + (x + 1) * b(1 + nT) + (nT - 1 - y) * b(1 + x) + (y + 1) * b(-1 - nT) + nT) >> (log2 + 1));
     });
   }
   else if (mode == 1) {
     int s = 0;
-    if (lane < nT) s = b[lane + 1] + b[-lane - 1];
+    if (lane < nT) s = b(lane + 1) + b(-lane - 1);
     const int dc = (wave_sum(s) + nT) >> (log2 + 1);
     lanes_loop<npx>(lane, [&](int p) {
       const int x = p & (nT - 1), y = p >> log2;
       int v = dc;
       if (edge) {
-        const int t = b[x + 1], l = b[-y - 1];
+        const int t = b(x + 1), l = b(-y - 1);
         v = y == 0 ? (t + 3 * dc + 2) >> 2 : v;
         v = x == 0 ? (l + 3 * dc + 2) >> 2 : v;
         v = (x | y) == 0 ? (l + 2 * dc + t + 2) >> 2 : v;
@@ -312,14 +344,14 @@ __device__ __forceinline__ void predict(const Blk<Pix>& B, const int16_t* b, con
   }
   else if (mode == 26 || mode == 10) { // pure vertical / horizontal: copy, plus the gradient on the first column / row
     const bool vert = mode == 26;
-    const int corner = b[0];
+    const int corner = b(0);
     lanes_loop<npx>(lane, [&](int p) {
       const int x = p & (nT - 1), y = p >> log2;
-      const int t = b[1 + x], l = b[-1 - y];
+      const int t = b(1 + x), l = b(-1 - y);
       int v = vert ? t : l;
       if (edge) {
         const int along = vert ? x : y;                                  // distance from the smoothed border
-        const int g = vert ? b[1] + ((l - corner) >> 1) : b[-1] + ((t - corner) >> 1);
+        const int g = vert ? b(1) + ((l - corner) >> 1) : b(-1) + ((t - corner) >> 1);
         v = along == 0 ? clip3i(0, maxv, g) : v;
       }
       dst[y * pitch + x] = (Pix)v;
@@ -338,8 +370,8 @@ __device__ __forceinline__ void predict(const Blk<Pix>& B, const int16_t* b, con
       const int k0 = minor + iIdx + 1, k1 = k0 + 1;
       const int q0 = -((k0 * inv + 128) >> 8), q1 = -((k1 * inv + 128) >> 8);
       const int j0 = sgn * (k0 >= 0 ? k0 : q0), j1 = sgn * (k1 >= 0 ? k1 : q1);
-      // b[j1] is read even when iFact == 0 (then it has weight 0; the index stays inside bA: |j1| <= 2nT + 1)
-      const int r0 = b[j0], r1 = b[j1];
+      // b(j1) is read even when iFact == 0 (then it has weight 0; the index stays inside bA: |j1| <= 2nT + 1)
+      const int r0 = b(j0), r1 = b(j1);
       dst[y * pitch + x] = (Pix)(((32 - iFact) * r0 + iFact * r1 + 16) >> 5);
     });
   }
@@ -587,9 +619,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
           // variants is hoisted out of all loops and kept alive for the whole kernel (> 100 spilled SGPRs)
           int ln = lane;
           asm volatile("" : "+v"(ln));
-          make_border<Pix, L2>(B, l_bA, strong, ln);
-          WAVE_SYNC();
-          predict<Pix, L2>(B, l_bA + 64, tab, ln);
+          const bool smoothed = L2 != 2 && B.c == 0 && ((filter_mode_mask(L2) >> B.mode) & 1);
+          if (L2 <= 3 && !smoothed && is_interior<L2>(B.avail, B.info)) {
+            predict<Pix, L2>(B, direct_refs<Pix, L2>(B), tab, ln); // one lane pass: cheaper to address the samples in place
+          }
+          else {
+            make_border<Pix, L2>(B, l_bA, strong, ln);
+            WAVE_SYNC();
+            predict<Pix, L2>(B, RefArray{l_bA + 64}, tab, ln);
+          }
           WAVE_SYNC();
           if (cbf) {
             residual_add<Pix, L2>(B, l_coeff, l_tmp, dct, tab, coeffs + coeff_first, pre, ln);
