@@ -21,7 +21,7 @@ class HmError(RuntimeError):
 class ColourDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "width", "height", "bit_depth", "chroma", "has_nclx", "matrix", "primaries",
-        "full_range", "out_format", "y_stride", "cb_stride", "cr_stride", "out_stride")]
+        "full_range", "out_format", "y_stride", "cb_stride", "cr_stride", "out_stride", "chroma_upsampling")]
 
 
 _lib = None

@@ -226,9 +226,10 @@ struct heif_error heif_decode_image(const struct heif_image_handle* in, struct h
       return err(heif_error_Unsupported_feature, heif_suberror_Unsupported_color_conversion, "convert_hdr_to_8bit needs the reference's bit-depth ops (hdr_sdr.cc), not on the GPU path yet");
     if (opt->decoder_id && std::strcmp(opt->decoder_id, "mi355x") != 0)
       return err(heif_error_Unsupported_feature, heif_suberror_Unsupported_codec, "this build only carries the 'mi355x' HEVC decoder");
+    // bilinear only when the caller insists: otherwise the cheaper nearest-neighbour ops win the pipeline search
     if (opt->version >= 5 && opt->color_conversion_options.only_use_preferred_chroma_algorithm &&
         opt->color_conversion_options.preferred_chroma_upsampling_algorithm == heif_chroma_upsampling_bilinear)
-      return err(heif_error_Unsupported_feature, heif_suberror_Unsupported_color_conversion, "forced bilinear chroma upsampling is not on the GPU path yet");
+      prm.chroma_upsampling = HM_UPSAMPLE_BILINEAR;
   }
   // target state (context.cc:1516-1600): undefined = keep native
   int out_format = 0;

@@ -326,6 +326,70 @@ __global__ __launch_bounds__(256) void k_ycbcr_float(
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Bilinear chroma upsampling to 4:4:4 (only when the caller forces it: heif_color_conversion_options
+// .only_use_preferred_chroma_algorithm with heif_chroma_upsampling_bilinear).
+//   4:2:0  Op_YCbCr420_bilinear_to_YCbCr444, chroma_sampling.cc:489-710 (9-3-3-1 / 16 inside, 3-1 / 4 on the
+//          borders; the border loops read the source at cx/2, cy/2 - quirk Q8 - which is reproduced)
+//   4:2:2  Op_YCbCr422_bilinear_to_YCbCr444, chroma_sampling.cc:766-933
+// Each output sample is a pure function of its position: one lane per 4 consecutive samples of a row.
+// w, h = output (luma) size; strides in samples.
+// ---------------------------------------------------------------------------------------
+template <typename Pix>
+__device__ __forceinline__ int up420_sample(const Pix* __restrict__ in, int is, int w, int h, int x, int y)
+{
+  auto IN = [&](int yy, int xx) -> int { return (int)in[(size_t)yy * is + xx]; };
+  const bool top = y == 0, left = x == 0;
+  const bool bottom = (h & 1) == 0 && y == h - 1, right = (w & 1) == 0 && x == w - 1;
+  if (top || bottom) {
+    const int sy = top ? 0 : h / 2 - 1;
+    if (left) return IN(sy, 0);
+    if (right) return IN(sy, w / 2 - 1);
+    const int cx = (x - 1) >> 1, sx = cx >> 1; // Q8: source column cx/2
+    const int a = IN(sy, sx), b = IN(sy, sx + 1);
+    return (x & 1) ? (3 * a + b + 2) >> 2 : (a + 3 * b + 2) >> 2;
+  }
+  if (left || right) {
+    const int sx = left ? 0 : w / 2 - 1;
+    const int cy = (y - 1) >> 1, sy = cy >> 1; // Q8: source row cy/2
+    const int a = IN(sy, sx), b = IN(sy + 1, sx);
+    return (y & 1) ? (3 * a + b + 2) >> 2 : (a + 3 * b + 2) >> 2;
+  }
+  const int cx = (x - 1) >> 1, cy = (y - 1) >> 1; // 2x2 output quad at (2cx+1, 2cy+1)
+  const int a = IN(cy, cx), b = IN(cy, cx + 1), c = IN(cy + 1, cx), d = IN(cy + 1, cx + 1);
+  const int wx1 = (x & 1) ? 1 : 3, wx0 = 4 - wx1; // weight of the right / left source column
+  const int wy1 = (y & 1) ? 1 : 3, wy0 = 4 - wy1;
+  return (a * wx0 * wy0 + b * wx1 * wy0 + c * wx0 * wy1 + d * wx1 * wy1 + 8) >> 4;
+}
+template <typename Pix>
+__device__ __forceinline__ int up422_sample(const Pix* __restrict__ in, int is, int w, int x, int y)
+{
+  const Pix* r = in + (size_t)y * is;
+  if (x == 0) return r[0];
+  if ((w & 1) == 0 && x == w - 1) return r[w / 2 - 1];
+  const int cx = (x - 1) >> 1;
+  const int a = r[cx], b = r[cx + 1];
+  return (x & 1) ? (3 * a + b + 2) >> 2 : (a + 3 * b + 2) >> 2;
+}
+template <typename Pix, bool V420>
+__global__ __launch_bounds__(256) void k_upsample_bilinear(const Pix* __restrict__ in, int is, Pix* __restrict__ out, int os,
+                                                           int w, int h, int gpr, int total)
+{
+  const int item = blockIdx.x * 256 + threadIdx.x;
+  if (item >= total) return;
+  const int y = item / gpr, x0 = (item - y * gpr) * 4;
+  Pix v[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int x = x0 + k < w ? x0 + k : w - 1;
+    v[k] = (Pix)(V420 ? up420_sample<Pix>(in, is, w, h, x, y) : up422_sample<Pix>(in, is, w, x, y));
+  }
+  Pix* o = out + (size_t)y * os + x0;
+  if (x0 + 4 <= w) __builtin_memcpy(o, v, 4 * sizeof(Pix));
+  else
+    for (int k = 0; x0 + k < w; k++) o[k] = v[k];
+}
+
 } // namespace
 
 // ---------------------------------------------------------------------------------------
@@ -386,4 +450,23 @@ extern "C" int hm_launch_colour_float(const hm_colour_desc* d, const float coef[
   if (d->out_format == HM_OUT_RRGGBB_BE) return launch_float<uint16_t, OF_RRGGBB_BE>(d, p, y, cb, cr, out, s);
   if (d->out_format == HM_OUT_RRGGBB_LE) return launch_float<uint16_t, OF_RRGGBB_LE>(d, p, y, cb, cr, out, s);
   return HM_ERR_UNSUPPORTED;
+}
+
+// one chroma plane: 4:2:0 (v420 != 0) or 4:2:2 -> 4:4:4; strides in bytes
+extern "C" int hm_launch_upsample_bilinear(int bit_depth, int v420, const void* in, int in_stride, void* out, int out_stride,
+                                           int w, int h, hipStream_t s)
+{
+  const int gpr = (w + 3) / 4;
+  const long total = (long)gpr * h;
+  if (total <= 0) return HM_OK;
+  const int blocks = (int)((total + 255) / 256);
+  if (bit_depth == 8) {
+    if (v420) hipLaunchKernelGGL((k_upsample_bilinear<uint8_t, true>), dim3(blocks), dim3(256), 0, s, (const uint8_t*)in, in_stride, (uint8_t*)out, out_stride, w, h, gpr, (int)total);
+    else hipLaunchKernelGGL((k_upsample_bilinear<uint8_t, false>), dim3(blocks), dim3(256), 0, s, (const uint8_t*)in, in_stride, (uint8_t*)out, out_stride, w, h, gpr, (int)total);
+  }
+  else {
+    if (v420) hipLaunchKernelGGL((k_upsample_bilinear<uint16_t, true>), dim3(blocks), dim3(256), 0, s, (const uint16_t*)in, in_stride / 2, (uint16_t*)out, out_stride / 2, w, h, gpr, (int)total);
+    else hipLaunchKernelGGL((k_upsample_bilinear<uint16_t, false>), dim3(blocks), dim3(256), 0, s, (const uint16_t*)in, in_stride / 2, (uint16_t*)out, out_stride / 2, w, h, gpr, (int)total);
+  }
+  return hm_check_hip(hipGetLastError(), "k_upsample_bilinear launch");
 }

@@ -121,6 +121,13 @@ int hm_colour_pipeline(const hm_colour_desc* d)
   const bool rgb8 = d->out_format == HM_OUT_RGB || d->out_format == HM_OUT_RGBA;
   const bool rgb16 = d->out_format == HM_OUT_RRGGBB_BE || d->out_format == HM_OUT_RRGGBB_LE;
   if (!rgb8 && !rgb16) return hm_fail(HM_ERR_UNSUPPORTED, "output format %d", d->out_format);
+  if (d->chroma_upsampling == HM_UPSAMPLE_BILINEAR && d->chroma != HM_CHROMA_444) {
+    // every nearest-neighbour op refuses (yuv2rgb.cc:37-41, 268-272, 377-381, 506-510); the bilinear ops refuse
+    // matrix 0 (chroma_sampling.cc:466-468, 743-745) => convert_colorspace() finds no chain
+    if (matrix == 0) return hm_fail(HM_ERR_UNSUPPORTED, "no colour conversion: bilinear upsampling is not defined for matrix_coefficients 0");
+    if ((d->bit_depth == 8) != rgb8) return hm_fail(HM_ERR_UNSUPPORTED, "bit depth %d -> output format %d needs a depth-conversion op", d->bit_depth, d->out_format);
+    return HM_PIPE_BILINEAR_FLOAT; // Op_YCbCr42x_bilinear_to_YCbCr444 -> Op_YCbCr_to_RGB<Pixel> -> interleave
+  }
   if (d->bit_depth == 8 && rgb8) {
     // Op_YCbCr420_to_RGB24/32 accept: 4:2:0, 8 bit, matrix not in {0,8,11,14}, full range
     // (yuv2rgb.cc:274-287, 383-397); both cost 11 < 22 of the float chain
@@ -150,6 +157,27 @@ int hm_colour_convert(const hm_colour_desc* d, const void* d_y, const void* d_cb
   // ops read the image's own nclx (not the selection state): yuv2rgb.cc:190-198, 329-334
   hm_ycbcr_coefficients(d->has_nclx, d->matrix, d->primaries, cf);
   hipStream_t s = (hipStream_t)stream;
+  if (pipe == HM_PIPE_BILINEAR_FLOAT) {
+    const int cw = (d->width + 1) / 2;
+    if (d->cb_stride < cw * bps || d->cr_stride < cw * bps) return hm_fail(HM_ERR_INVALID_ARG, "stride smaller than row");
+    const int ts = hm_plane_stride(d->width, bps);
+    const size_t tbytes = (size_t)ts * d->height;
+    uint8_t* tmp = (uint8_t*)hm_pool_device_alloc(2 * tbytes);
+    if (!tmp) return hm_fail(HM_ERR_NOMEM, "bilinear upsampling: %zu bytes of device memory", 2 * tbytes);
+    const int v420 = d->chroma == HM_CHROMA_420;
+    int rc = hm_launch_upsample_bilinear(d->bit_depth, v420, d_cb, d->cb_stride, tmp, ts, d->width, d->height, s);
+    if (!rc) rc = hm_launch_upsample_bilinear(d->bit_depth, v420, d_cr, d->cr_stride, tmp + tbytes, ts, d->width, d->height, s);
+    if (!rc) {
+      hm_colour_desc d444 = *d;
+      d444.chroma = HM_CHROMA_444;
+      d444.cb_stride = d444.cr_stride = ts;
+      const int m = d->has_nclx ? d->matrix : 2;
+      rc = hm_launch_colour_float(&d444, cf, m == 8 ? 3 : 0, d_y, tmp, tmp + tbytes, d_out, s);
+    }
+    const hipError_t e = hipStreamSynchronize(s); // the temporaries go back to the pool
+    hm_pool_device_free(tmp);
+    return rc ? rc : hm_check_hip(e, "bilinear colour chain");
+  }
   if (pipe == HM_PIPE_INT420) {
     const int ci[4] = {(int)std::lround(256 * cf[0]), (int)std::lround(256 * cf[1]),
                        (int)std::lround(256 * cf[2]), (int)std::lround(256 * cf[3])}; // yuv2rgb.cc:336-339

@@ -274,6 +274,7 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
     cd.width = canvas_w; cd.height = canvas_h; cd.bit_depth = bd; cd.chroma = chroma;
     cd.has_nclx = out->has_nclx; cd.matrix = native.matrix; cd.primaries = native.primaries; cd.full_range = native.full_range;
     cd.out_format = params->out_format;
+    cd.chroma_upsampling = params->chroma_upsampling;
     const int obpp = hm_out_bytes_per_pixel(params->out_format);
     if (obpp < 0) return obpp;
     cd.y_stride = ys; cd.cb_stride = cs; cd.cr_stride = cs;

@@ -20,6 +20,8 @@ int hm_launch_colour_int420(const hm_colour_desc* d, const int coef[4], const vo
                             const void* cr, void* out, hipStream_t s);
 int hm_launch_colour_float(const hm_colour_desc* d, const float coef[4], int mode, const void* y,
                            const void* cb, const void* cr, void* out, hipStream_t s);
+int hm_launch_upsample_bilinear(int bit_depth, int v420, const void* in, int in_stride, void* out, int out_stride,
+                                int w, int h, hipStream_t s);
 
 // devpool.cpp: size-bucketed cache of device / pinned-host allocations (hipMalloc + hipFree cost more
 // than the kernels of a 12 MP image)

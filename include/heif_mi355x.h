@@ -74,10 +74,15 @@ typedef struct hm_colour_desc {
   int32_t matrix, primaries, full_range; /* the attached nclx (ignored when !has_nclx)          */
   int32_t out_format;           /* HM_OUT_*                                                     */
   int32_t y_stride, cb_stride, cr_stride, out_stride; /* bytes                                  */
+  int32_t chroma_upsampling;    /* 0 / HM_UPSAMPLE_NEAREST: whatever convert_colorspace() would pick (nearest
+                                   neighbour ops); HM_UPSAMPLE_BILINEAR: the caller set
+                                   only_use_preferred_chroma_algorithm with heif_chroma_upsampling_bilinear
+                                   (heif.h:1546-1562) => Op_YCbCr420/422_bilinear_to_YCbCr444 first           */
 } hm_colour_desc;
+enum { HM_UPSAMPLE_NEAREST = 1, HM_UPSAMPLE_BILINEAR = 2 }; /* == enum heif_chroma_upsampling_algorithm */
 
 /* which reference op chain convert_colorspace() would pick for this state (§3.4 of SURVEY) */
-enum { HM_PIPE_INT420 = 1, HM_PIPE_FLOAT = 2 };
+enum { HM_PIPE_INT420 = 1, HM_PIPE_FLOAT = 2, HM_PIPE_BILINEAR_FLOAT = 3 };
 HM_API int hm_colour_pipeline(const hm_colour_desc* d); /* HM_PIPE_* or negative status */
 
 /* Observable libheif plane stride for a plane `width` pixels wide (pixelimage.cc:139-218). */
@@ -88,7 +93,8 @@ HM_API int hm_out_bytes_per_pixel(int out_format);
 /* float32 coefficients exactly as nclx.cc:152-171 computes them: r_cr, g_cb, g_cr, b_cb */
 HM_API int hm_ycbcr_coefficients(int has_nclx, int matrix, int primaries, float out[4]);
 
-/* Convert device planes to the interleaved device buffer. Asynchronous on `stream`. */
+/* Convert device planes to the interleaved device buffer. Asynchronous on `stream` (the forced-bilinear chain
+ * works through two temporary 4:4:4 chroma planes and returns after the stream has drained). */
 HM_API int hm_colour_convert(const hm_colour_desc* d, const void* d_y, const void* d_cb,
                              const void* d_cr, void* d_out, void* stream);
 
@@ -164,7 +170,7 @@ typedef struct hm_decode_params {
   int32_t out_format;          /* 0 = native planar YCbCr, else HM_OUT_* (== enum heif_chroma)   */
   int32_t host_threads;        /* entropy-decode threads (heif_context_set_threads semantics)    */
   int32_t ignore_transformations;
-  int32_t reserved;
+  int32_t chroma_upsampling;   /* 0 = default op selection, HM_UPSAMPLE_BILINEAR = forced bilinear (see hm_colour_desc) */
   void*   stream;              /* hipStream_t or NULL                                            */
   void*   ext_dst;             /* optional caller buffer for interleaved output (fork API:       */
   uint32_t ext_dst_len;        /*   heif_decoding_options_add_external_dest, heif.h:1605-1615)   */

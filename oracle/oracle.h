@@ -72,6 +72,10 @@ int orc_paste_tile_plane(const uint8_t* tile, int tile_stride, int tile_w, int t
 
 /* chroma_sampling.cc:585-700: bilinear 4:2:0 chroma up-sampling to 4:4:4 (8 bit, one plane) */
 void orc_upsample_bilinear_420(const uint8_t* in, int is, int w, int h, uint8_t* out, int os);
+void orc_upsample_bilinear_420_u16(const uint16_t* in, int is, int w, int h, uint16_t* out, int os);
+/* chroma_sampling.cc:766-933 */
+void orc_upsample_bilinear_422(const uint8_t* in, int is, int w, int h, uint8_t* out, int os);
+void orc_upsample_bilinear_422_u16(const uint16_t* in, int is, int w, int h, uint16_t* out, int os);
 
 /* ---- HEVC intra reconstruction (oracle_recon.c) ------------------------------------------- */
 

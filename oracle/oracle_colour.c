@@ -327,3 +327,68 @@ void orc_upsample_bilinear_420(const uint8_t* in, int is, int w, int h, uint8_t*
 #undef IN
 #undef OUT
 }
+
+/* 16-bit storage variant (the reference instantiates the same template for uint16_t, chroma_sampling.cc:712-713) */
+void orc_upsample_bilinear_420_u16(const uint16_t* in, int is, int w, int h, uint16_t* out, int os)
+{
+#define IN(yy, xx)  ((int)in[(size_t)(yy) * is + (xx)])
+#define OUT(yy, xx) out[(size_t)(yy) * os + (xx)]
+  OUT(0, 0) = in[0];
+  /* top border: note the reference indexes the source with cx/2 (Q8) */
+  for (int cx = 0; cx < (w - 1) / 2; cx++) {
+    OUT(0, 2 * cx + 1) = (uint16_t)((3 * IN(0, cx / 2) + 1 * IN(0, cx / 2 + 1) + 2) / 4);
+    OUT(0, 2 * cx + 2) = (uint16_t)((1 * IN(0, cx / 2) + 3 * IN(0, cx / 2 + 1) + 2) / 4);
+  }
+  if (w % 2 == 0) OUT(0, w - 1) = (uint16_t)IN(0, w / 2 - 1);
+  /* left border (cy/2 source rows, Q8) */
+  for (int cy = 0; cy < (h - 1) / 2; cy++) {
+    OUT(2 * cy + 1, 0) = (uint16_t)((3 * IN(cy / 2, 0) + 1 * IN(cy / 2 + 1, 0) + 2) / 4);
+    OUT(2 * cy + 2, 0) = (uint16_t)((1 * IN(cy / 2, 0) + 3 * IN(cy / 2 + 1, 0) + 2) / 4);
+  }
+  if (h % 2 == 0) OUT(h - 1, 0) = (uint16_t)IN(h / 2 - 1, 0);
+  if (w % 2 == 0)
+    for (int cy = 0; cy < (h - 1) / 2; cy++) {
+      OUT(2 * cy + 1, w - 1) = (uint16_t)((3 * IN(cy / 2, w / 2 - 1) + 1 * IN(cy / 2 + 1, w / 2 - 1) + 2) / 4);
+      OUT(2 * cy + 2, w - 1) = (uint16_t)((1 * IN(cy / 2, w / 2 - 1) + 3 * IN(cy / 2 + 1, w / 2 - 1) + 2) / 4);
+    }
+  if (h % 2 == 0)
+    for (int cx = 0; cx < (w - 1) / 2; cx++) {
+      OUT(h - 1, 2 * cx + 1) = (uint16_t)((3 * IN(h / 2 - 1, cx / 2) + 1 * IN(h / 2 - 1, cx / 2 + 1) + 2) / 4);
+      OUT(h - 1, 2 * cx + 2) = (uint16_t)((1 * IN(h / 2 - 1, cx / 2) + 3 * IN(h / 2 - 1, cx / 2 + 1) + 2) / 4);
+    }
+  if (w % 2 == 0 && h % 2 == 0) OUT(h - 1, w - 1) = (uint16_t)IN(h / 2 - 1, w / 2 - 1);
+  /* interior: 9-3-3-1 / 16 */
+  for (int yy = 1; yy < h - 1; yy += 2)
+    for (int xx = 1; xx < w - 1; xx += 2) {
+      int cx = xx / 2, cy = yy / 2;
+      int a = IN(cy, cx), b = IN(cy, cx + 1), c = IN(cy + 1, cx), d = IN(cy + 1, cx + 1);
+      OUT(yy, xx)         = (uint16_t)((a * 9 + b * 3 + c * 3 + d * 1 + 8) / 16);
+      OUT(yy, xx + 1)     = (uint16_t)((a * 3 + b * 9 + c * 1 + d * 3 + 8) / 16);
+      OUT(yy + 1, xx)     = (uint16_t)((a * 3 + b * 1 + c * 9 + d * 3 + 8) / 16);
+      OUT(yy + 1, xx + 1) = (uint16_t)((a * 1 + b * 3 + c * 3 + d * 9 + 8) / 16);
+    }
+#undef IN
+#undef OUT
+}
+
+/* Op_YCbCr422_bilinear_to_YCbCr444 (chroma_sampling.cc:766-933): horizontal 3/4-1/4 filter, left / right border copied.
+ * w,h = output (luma) size; strides in samples. */
+#define ORC_BILINEAR_422(NAME, PIX)                                                                  \
+  void NAME(const PIX* in, int is, int w, int h, PIX* out, int os)                                    \
+  {                                                                                                   \
+    for (int y = 0; y < h; y++) {                                                                     \
+      const PIX* r = in + (size_t)y * is;                                                             \
+      PIX* o = out + (size_t)y * os;                                                                  \
+      o[0] = r[0];                                                                                    \
+      if (w % 2 == 0) o[w - 1] = r[w / 2 - 1];                                                        \
+      for (int x = 1; x < w - 1; x += 2) {                                                            \
+        const int cx = x / 2;                                                                         \
+        const int c0 = r[cx], c1 = r[cx + 1];                                                         \
+        o[x] = (PIX)((c0 * 3 + c1 * 1 + 2) / 4);                                                      \
+        o[x + 1] = (PIX)((c0 * 1 + c1 * 3 + 2) / 4);                                                  \
+      }                                                                                               \
+    }                                                                                                 \
+  }
+ORC_BILINEAR_422(orc_upsample_bilinear_422, uint8_t)
+ORC_BILINEAR_422(orc_upsample_bilinear_422_u16, uint16_t)
+

@@ -68,6 +68,17 @@ def colour_float(y, cb, cr, w, h, bpp, chroma, has_nclx, matrix, primaries, full
     return out, os_
 
 
+def upsample_bilinear(plane, w, h, bpp, chroma):
+    """Op_YCbCr420/422_bilinear_to_YCbCr444 on one chroma plane (buffer, stride) -> (buffer, stride) of size w x h."""
+    o = load()
+    bps = 2 if bpp > 8 else 1
+    out, os_ = alloc_plane(w, h, bps)
+    fn = {(1, 1): o.orc_upsample_bilinear_420, (1, 2): o.orc_upsample_bilinear_420_u16,
+          (2, 1): o.orc_upsample_bilinear_422, (2, 2): o.orc_upsample_bilinear_422_u16}[(chroma, bps)]
+    fn(ptr(plane[0]), plane[1] // bps, w, h, ptr(out), os_ // bps)
+    return out, os_
+
+
 def fnv_rows(buf, stride, row_bytes, rows):
     return load().orc_fnv1a64_rows(ptr(buf), stride, row_bytes, rows, 0)
 

@@ -18,7 +18,7 @@ class ImageInfo(C.Structure):
 
 class DecodeParams(C.Structure):
     _fields_ = [("out_format", C.c_int32), ("host_threads", C.c_int32), ("ignore_transformations", C.c_int32),
-                ("reserved", C.c_int32), ("stream", C.c_void_p), ("ext_dst", C.c_void_p),
+                ("chroma_upsampling", C.c_int32), ("stream", C.c_void_p), ("ext_dst", C.c_void_p),
                 ("ext_dst_len", C.c_uint32), ("ext_dst_stride", C.c_uint32)]
 
 
@@ -69,9 +69,9 @@ class HeifFile:
         self.hm.hm_free(p)
         return out
 
-    def decode(self, iid, out_format, threads=1):
+    def decode(self, iid, out_format, threads=1, upsampling=0):
         """GPU path through the C ABI; returns (array rows x stride, Decoded meta)."""
-        prm = DecodeParams(out_format, threads, 0, 0, None, None, 0, 0)
+        prm = DecodeParams(out_format, threads, 0, upsampling, None, None, 0, 0)
         d = Decoded()
         rc = self.hm.hm_decode_item(self.h, iid, C.byref(prm), C.byref(d))
         if rc:
@@ -93,7 +93,7 @@ class HeifFile:
             self.h = C.c_void_p()
 
 
-def cpu_decode(hm, tiles, tile_w, tile_h, canvas_w, canvas_h, cols, is_grid, out_fmt, tile_colr=None, decoder="oracle"):
+def cpu_decode(hm, tiles, tile_w, tile_h, canvas_w, canvas_h, cols, is_grid, out_fmt, tile_colr=None, decoder="oracle", bilinear=False):
     """tiles: list of [len][NAL] strings.  Returns (rgb array, stride) following the reference flow."""
     o = orc.load()
     first = None
@@ -132,7 +132,11 @@ def cpu_decode(hm, tiles, tile_w, tile_h, canvas_w, canvas_h, cols, is_grid, out
     sel_m = (mat if has_nclx else 2)
     sel_m = 6 if sel_m == 2 else sel_m
     sel_full = full if has_nclx else 1
-    if bd == 8 and cf == 1 and sel_full and sel_m not in (0, 8, 11, 14) and out_fmt in (10, 11):
+    if bilinear and cf != 3:  # forced bilinear: upsample to 4:4:4, then the float op (the NN ops are excluded)
+        up = [orc.upsample_bilinear(canv[c], canvas_w, canvas_h, bd, cf) for c in (1, 2)]
+        o.orc_ycbcr_to_rgb_float(orc.ptr(canv[0][0]), canv[0][1], orc.ptr(up[0][0]), up[0][1], orc.ptr(up[1][0]), up[1][1],
+                                 canvas_w, canvas_h, bd, 3, has_nclx, mat, prim, full, orc.ptr(out), os_, out_fmt)
+    elif bd == 8 and cf == 1 and sel_full and sel_m not in (0, 8, 11, 14) and out_fmt in (10, 11):
         o.orc_ycbcr420_to_rgb_int(orc.ptr(canv[0][0]), canv[0][1], orc.ptr(canv[1][0]), canv[1][1], orc.ptr(canv[2][0]), canv[2][1],
                                   canvas_w, canvas_h, has_nclx, mat, prim, orc.ptr(out), os_, out_fmt)
     else:

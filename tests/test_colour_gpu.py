@@ -18,7 +18,7 @@ def _chroma_dims(w, h, chroma):
     return w, h
 
 
-def _run_gpu(pkg, planes, w, h, bit_depth, chroma, nclx, out_fmt):
+def _run_gpu(pkg, planes, w, h, bit_depth, chroma, nclx, out_fmt, upsampling=0):
     import torch
     capi = pkg.capi
     L = pkg.lib()
@@ -30,7 +30,7 @@ def _run_gpu(pkg, planes, w, h, bit_depth, chroma, nclx, out_fmt):
     dy, dcb, dcr = (torch.from_numpy(a).to(dev) for a in (y, cb, cr))
     rows = max(64, (h + 1) & ~1)
     dout = torch.zeros((rows, ostride), dtype=torch.uint8, device=dev)
-    d = capi.ColourDesc(w, h, bit_depth, chroma, nclx[0], nclx[1], nclx[2], nclx[3], out_fmt, ys, cbs, crs, ostride)
+    d = capi.ColourDesc(w, h, bit_depth, chroma, nclx[0], nclx[1], nclx[2], nclx[3], out_fmt, ys, cbs, crs, ostride, upsampling)
     stream = torch.cuda.current_stream().cuda_stream
     capi.check(L.hm_colour_convert(C.byref(d), dy.data_ptr(), dcb.data_ptr(), dcr.data_ptr(), dout.data_ptr(), stream))
     torch.cuda.synchronize()
@@ -92,3 +92,37 @@ def test_no_silent_fallback(pkg):
     """unsupported states fail loudly instead of falling back"""
     d = pkg.capi.ColourDesc(64, 64, 8, 1, 0, 0, 0, 0, 14, 64, 64, 64, 384)
     assert pkg.lib().hm_colour_pipeline(C.byref(d)) == -2
+
+
+@pytest.mark.parametrize("w,h", [(64, 64), (1280, 854), (72, 72), (17, 9), (1, 1), (2, 2), (3, 2), (2, 3), (1023, 3), (4030, 31), (5, 1), (1, 6)])
+@pytest.mark.parametrize("chroma", [1, 2])
+@pytest.mark.parametrize("bit_depth,out_fmt", [(8, 10), (8, 11), (10, 12), (12, 14)])
+@pytest.mark.parametrize("nclx", [(0, 0, 0, 0), (1, 6, 1, 1), (1, 1, 1, 0), (1, 9, 9, 1), (1, 8, 1, 1)])
+def test_forced_bilinear_chain(pkg, w, h, chroma, bit_depth, out_fmt, nclx):
+    """Op_YCbCr420/422_bilinear_to_YCbCr444 (incl. the cx/2, cy/2 border quirk Q8) followed by
+    the float op on 4:4:4, as convert_colorspace() chains them when the caller forces bilinear upsampling."""
+    rng = np.random.default_rng(w * 131 + h * 7 + chroma + bit_depth)
+    cw, ch = _chroma_dims(w, h, chroma)
+    bps = 2 if bit_depth > 8 else 1
+    mv = (1 << bit_depth) - 1
+    planes = [orc.alloc_plane(w, h, bps, rng=rng, maxval=mv), orc.alloc_plane(cw, ch, bps, rng=rng, maxval=mv),
+              orc.alloc_plane(cw, ch, bps, rng=rng, maxval=mv)]
+    d = pkg.capi.ColourDesc(w, h, bit_depth, chroma, *nclx, out_fmt, 0, 0, 0, 0, 2)
+    assert pkg.lib().hm_colour_pipeline(C.byref(d)) == 3
+    got, ostride, obpp = _run_gpu(pkg, planes, w, h, bit_depth, chroma, nclx, out_fmt, upsampling=2)
+    up = [orc.upsample_bilinear(planes[c], w, h, bit_depth, chroma) for c in (1, 2)]
+    exp, es = orc.colour_float(planes[0], up[0], up[1], w, h, bit_depth, 3, *nclx, out_fmt)
+    np.testing.assert_array_equal(got[:h, :w * obpp], exp[:h, :w * obpp])
+
+
+def test_forced_bilinear_selection(pkg):
+    L = pkg.lib()
+    # 4:4:4 input needs no upsampling: the normal chain
+    d = pkg.capi.ColourDesc(64, 64, 8, 3, 1, 6, 1, 1, 10, 0, 0, 0, 0, 2)
+    assert L.hm_colour_pipeline(C.byref(d)) == pkg.capi.HM_PIPE_FLOAT
+    # matrix 0: neither the bilinear op nor (forced) the nearest-neighbour ops accept -> no chain, loud failure
+    d = pkg.capi.ColourDesc(64, 64, 8, 1, 1, 0, 1, 1, 10, 0, 0, 0, 0, 2)
+    assert L.hm_colour_pipeline(C.byref(d)) == -2
+    # not forced: the cheaper integer op
+    d = pkg.capi.ColourDesc(64, 64, 8, 1, 0, 0, 0, 0, 10, 0, 0, 0, 0, 1)
+    assert L.hm_colour_pipeline(C.byref(d)) == pkg.capi.HM_PIPE_INT420

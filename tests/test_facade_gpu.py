@@ -158,3 +158,40 @@ def test_decoder_plugin_call_sequence(api, hm):
             got = raw[:, :w * 2].copy().view(np.uint16).reshape(hgt, w) if wide else raw[:, :w].astype(np.uint16)
             np.testing.assert_array_equal(got, exp[c][:hgt, :w])
         api.heif_image_release(img)
+
+
+class _ColourConvOptions(C.Structure):  # heif.h:1546-1562
+    _fields_ = [("version", C.c_uint8), ("preferred_chroma_downsampling_algorithm", C.c_int),
+                ("preferred_chroma_upsampling_algorithm", C.c_int), ("only_use_preferred_chroma_algorithm", C.c_uint8)]
+
+
+class _DecodingOptions(C.Structure):  # heif.h:1565-1611 (fork layout with the trailing ext_dst fields)
+    _fields_ = [("version", C.c_uint8), ("ignore_transformations", C.c_uint8), ("start_progress", C.c_void_p),
+                ("on_progress", C.c_void_p), ("end_progress", C.c_void_p), ("progress_user_data", C.c_void_p),
+                ("convert_hdr_to_8bit", C.c_uint8), ("strict_decoding", C.c_uint8), ("decoder_id", C.c_char_p),
+                ("color_conversion_options", _ColourConvOptions), ("ext_dst_enable", C.c_bool), ("ext_dst", C.c_void_p),
+                ("ext_dst_len", C.c_uint32), ("ext_dst_stride", C.c_uint32)]
+
+
+def test_forced_bilinear_upsampling_option(api, hm):
+    """only_use_preferred_chroma_algorithm = 1 with the (default) bilinear preference switches the chain to
+    Op_YCbCr420_bilinear_to_YCbCr444 -> float op; without it the nearest-neighbour ops stay."""
+    case = GOLD["cases"][0]
+    data = open(os.path.join(HERE, "data", case["file"]), "rb").read()
+    opt = api.heif_decoding_options_alloc()
+    o = C.cast(opt, C.POINTER(_DecodingOptions)).contents
+    assert o.color_conversion_options.preferred_chroma_upsampling_algorithm == 2  # heif_chroma_upsampling_bilinear (heif.cc:1085)
+    assert o.color_conversion_options.only_use_preferred_chroma_algorithm == 0
+    o.color_conversion_options.only_use_preferred_chroma_algorithm = 1
+    ctx, h, img, e = _decode(api, data, case["item"], 1, 10, options=opt)
+    assert e.code == 0, e.message
+    stride = C.c_int()
+    p = api.heif_image_get_plane_readonly(img, 10, C.byref(stride))
+    got = np.ascontiguousarray(np.ctypeslib.as_array(p, shape=(case["h"], stride.value)))
+    f = pipeline.HeifFile(hm, data)
+    hevc = f.hevc_data(case["item"] or f.primary())
+    f.close()
+    exp, es, _ = pipeline.cpu_decode(hm, [hevc], case["w"], case["h"], case["w"], case["h"], 1, False, 10, bilinear=True)
+    assert es == stride.value
+    np.testing.assert_array_equal(got[:, :case["w"] * 3], exp[:case["h"], :case["w"] * 3])
+    api.heif_image_release(img); api.heif_image_handle_release(h); api.heif_context_free(ctx); api.heif_decoding_options_free(opt)

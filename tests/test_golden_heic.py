@@ -82,3 +82,36 @@ def test_gpu_grid_matches_reference_fingerprint(hm, threads):
     _, _, canv = pipeline.cpu_decode(hm, tiles, 1280, 854, g["w"], g["h"], 2, True, 10)
     np.testing.assert_array_equal(native[0][:g["h"], :g["w"]], canv[0][0][:g["h"], :g["w"]])
     np.testing.assert_array_equal(native[1][:g["h"] // 2, :g["w"] // 2], canv[1][0][:g["h"] // 2, :g["w"] // 2])
+
+
+@pytest.mark.gpu
+def test_gpu_decode_item_forced_bilinear(hm):
+    """heif_color_conversion_options.only_use_preferred_chroma_algorithm + bilinear through
+    hm_decode_item: example.heic (limited-range 4:2:0 with nclx) and a grid (canvas without nclx)."""
+    case = GOLD["cases"][0]
+    f = pipeline.HeifFile(hm, _load(case["file"]))
+    iid = case["item"] or f.primary()
+    planes, meta = f.decode(iid, 10, upsampling=2)
+    exp, stride, _ = pipeline.cpu_decode(hm, [f.hevc_data(iid)], case["w"], case["h"], case["w"], case["h"], 1, False, 10, bilinear=True)
+    f.close()
+    assert meta["stride"][0] == stride
+    np.testing.assert_array_equal(planes[0][:case["h"], :case["w"] * 3], exp[:case["h"], :case["w"] * 3])
+    # differs from the default (nearest-neighbour) result, i.e. the option is not ignored
+    ref, _, _ = pipeline.cpu_decode(hm, [_hevc_of(hm, case)], case["w"], case["h"], case["w"], case["h"], 1, False, 10)
+    assert not np.array_equal(ref[:case["h"], :case["w"] * 3], exp[:case["h"], :case["w"] * 3])
+
+    g = GOLD["grid_1x2"]
+    data, tiles = _grid_file(hm)
+    f = pipeline.HeifFile(hm, data)
+    planes, meta = f.decode(f.primary(), 11, upsampling=2)
+    f.close()
+    exp, stride, _ = pipeline.cpu_decode(hm, tiles, 1280, 854, g["w"], g["h"], 2, True, 11, bilinear=True)
+    np.testing.assert_array_equal(planes[0][:g["h"], :g["w"] * 4], exp[:g["h"], :g["w"] * 4])
+
+
+def _hevc_of(hm, case):
+    f = pipeline.HeifFile(hm, _load(case["file"]))
+    try:
+        return f.hevc_data(case["item"] or f.primary())
+    finally:
+        f.close()

@@ -48,3 +48,30 @@ def test_paste_rescale_quirk(oracle):
     assert cc[0, 0] == 128  # (128-16)*1.1429 = 128.0048 -> 128
     # origin outside canvas -> error
     assert oracle.orc_paste_tile_plane(orc.ptr(tile), 64, 64, 64, orc.ptr(canvas), 128, 64, 64, 64, 0, 0, 1, 8, 0, 1, 1) == -1
+
+
+def test_bilinear_variants(oracle):
+    """The 16-bit instantiation of the 4:2:0 op equals the 8-bit one on 8-bit data, and the 4:2:2 op
+    (chroma_sampling.cc:766-933) follows its 3/4-1/4 rule with copied borders.  (Only the 8-bit 4:2:0 op has a
+    reference KAT; these restatements are pinned by it through the shared template.)"""
+    rng = np.random.default_rng(5)
+    for w, h in ((4, 4), (7, 5), (16, 9), (33, 32), (2, 2), (1, 1), (3, 1), (1, 3)):
+        cw, ch = (w + 1) // 2, (h + 1) // 2
+        src = rng.integers(0, 256, (ch, cw), dtype=np.uint8)
+        o8 = np.zeros((h, w), np.uint8)
+        oracle.orc_upsample_bilinear_420(orc.ptr(src), cw, w, h, orc.ptr(o8), w)
+        src16 = src.astype(np.uint16)
+        o16 = np.zeros((h, w), np.uint16)
+        oracle.orc_upsample_bilinear_420_u16(orc.ptr(src16), cw, w, h, orc.ptr(o16), w)
+        np.testing.assert_array_equal(o8, o16)
+    row = np.array([[10, 20, 30]], np.uint8)
+    out = np.zeros((1, 6), np.uint8)
+    oracle.orc_upsample_bilinear_422(orc.ptr(row), 3, 6, 1, orc.ptr(out), 6)
+    assert out.tolist() == [[10, 13, 18, 23, 28, 30]]
+    out5 = np.zeros((1, 5), np.uint8)
+    oracle.orc_upsample_bilinear_422(orc.ptr(row), 3, 5, 1, orc.ptr(out5), 5)
+    assert out5.tolist() == [[10, 13, 18, 23, 28]]
+    row16 = (row.astype(np.uint16) * 4)
+    o16 = np.zeros((1, 6), np.uint16)
+    oracle.orc_upsample_bilinear_422_u16(orc.ptr(row16), 3, 6, 1, orc.ptr(o16), 6)
+    assert o16.tolist() == [[40, 50, 70, 90, 110, 120]]
