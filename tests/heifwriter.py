@@ -40,24 +40,30 @@ def _colr(nclx):
     return _box(b"colr", b"nclx" + struct.pack(">HHHB", prim, trc, mat, 0x80 if full else 0))
 
 
-def write_heic(pictures, size, grid=None, chroma_format=1, bit_depth=8, colr=None):
-    """pictures: list of [len][NAL] strings (each with VPS/SPS/PPS first); size: (w,h) of one picture.
+def write_heic(pictures, size, grid=None, chroma_format=1, bit_depth=8, colr=None, sizes=None):
+    """pictures: list of [len][NAL] strings (each with VPS/SPS/PPS first); size: (w,h) of one picture
+    (sizes: optional per-picture override of the declared ispe).
     grid: None for a single image, or (rows, cols, out_w, out_h).  colr: optional per-tile nclx tuple."""
     items = []
     props = []
     assoc = {}
+    index_of = {}
+
+    def prop(box):  # identical properties are stored once and shared (as real writers do)
+        if box not in index_of:
+            props.append(box)
+            index_of[box] = len(props)
+        return index_of[box]
+
     for k, lp in enumerate(pictures):
         nals = split_nals(lp)
         params = [n for n in nals if ((n[0] >> 1) & 0x3F) in (32, 33, 34)]
         vcl = [n for n in nals if ((n[0] >> 1) & 0x3F) not in (32, 33, 34)]
         payload = b"".join(struct.pack(">I", len(n)) + n for n in vcl)
-        props.append(_hvcc(params, chroma_format, bit_depth))
-        a = [0x80 | len(props)]
-        props.append(_full(b"ispe", 0, 0, struct.pack(">II", *size)))
-        a.append(len(props))
+        a = [0x8000 | prop(_hvcc(params, chroma_format, bit_depth))]  # essential
+        a.append(prop(_full(b"ispe", 0, 0, struct.pack(">II", *(sizes[k] if sizes else size)))))
         if colr is not None:
-            props.append(_colr(colr))
-            a.append(len(props))
+            a.append(prop(_colr(colr)))
         items.append((k + 1, b"hvc1", payload))
         assoc[k + 1] = a
     primary = 1
@@ -66,15 +72,17 @@ def write_heic(pictures, size, grid=None, chroma_format=1, bit_depth=8, colr=Non
         rows, cols, ow, oh = grid
         gid = len(pictures) + 1
         items.append((gid, b"grid", bytes([0, 0, rows - 1, cols - 1]) + struct.pack(">HH", ow, oh)))
-        props.append(_full(b"ispe", 0, 0, struct.pack(">II", ow, oh)))
-        assoc[gid] = [len(props)]
+        assoc[gid] = [prop(_full(b"ispe", 0, 0, struct.pack(">II", ow, oh)))]
         primary = gid
         iref = _full(b"iref", 0, 0, _box(b"dimg", struct.pack(">HH", gid, len(pictures)) +
                                          b"".join(struct.pack(">H", k + 1) for k in range(len(pictures)))))
+    wide = len(props) > 127  # ipma flags & 1: 15-bit property indices
     ipma = struct.pack(">I", len(assoc))
     for iid in sorted(assoc):
-        ipma += struct.pack(">HB", iid, len(assoc[iid])) + bytes(assoc[iid])
-    iprp = _box(b"iprp", _box(b"ipco", b"".join(props)) + _full(b"ipma", 0, 0, ipma))
+        ipma += struct.pack(">HB", iid, len(assoc[iid]))
+        for v in assoc[iid]:
+            ipma += struct.pack(">H", v) if wide else bytes([(0x80 if v & 0x8000 else 0) | (v & 0x7F)])
+    iprp = _box(b"iprp", _box(b"ipco", b"".join(props)) + _full(b"ipma", 0, 1 if wide else 0, ipma))
     hdlr = _full(b"hdlr", 0, 0, struct.pack(">I4s", 0, b"pict") + b"\0" * 13)
     pitm = _full(b"pitm", 0, 0, struct.pack(">H", primary))
     iinf = struct.pack(">H", len(items))

@@ -1,0 +1,70 @@
+"""BASELINE.json configurations 2, 4 and 5 at full size, end to end through the C ABI
+(hm_file_open -> hm_decode_item: box parse, host entropy decode, GPU reconstruction / filters / paste /
+colour, D2H), bit-exact against the CPU flow (oracle restatement).
+Config 3 (1024 images over 8 GPUs) is config 2 sharded by image: bench.py --gpus N + tests/test_shard_gloo.py."""
+import numpy as np
+import pytest
+
+import heifwriter
+import pipeline
+import synthutil
+from corpus import TILE
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("variant", [dict(vui=1, full_range=1, matrix=6), dict(vui=0)], ids=["vui_full_range", "no_vui_limited_paste"])
+@pytest.mark.parametrize("fmt", [10, 11])
+def test_config2_12mp_grid(hm, variant, fmt):
+    """4032x3024 output, 8x6 grid of 512x512 tiles (seeds 1200000 + i), right 64 / bottom 48 px cropped by the paste;
+    the no-VUI variant takes the limited->full range paste rescale (context.cc:2504-2528)."""
+    tiles = [synthutil.picture(1200000 + i, **TILE, **variant) for i in range(48)]
+    data = heifwriter.write_heic(tiles, (512, 512), grid=(6, 8, 4032, 3024))
+    f = pipeline.HeifFile(hm, data)
+    info = f.info(f.primary())
+    assert (info.is_grid, info.grid_rows, info.grid_cols, info.width, info.height) == (1, 6, 8, 4032, 3024)
+    planes, meta = f.decode(f.primary(), fmt, threads=8)
+    f.close()
+    exp, stride, _ = pipeline.cpu_decode(hm, tiles, 512, 512, 4032, 3024, 8, True, fmt)
+    bpp = 3 if fmt == 10 else 4
+    assert meta["stride"][0] == stride and (meta["width"], meta["height"]) == (4032, 3024)
+    np.testing.assert_array_equal(planes[0][:3024, :4032 * bpp], exp[:3024, :4032 * bpp])
+
+
+@pytest.mark.parametrize("nclx", [dict(full_range=0, matrix=9, primaries=9), dict(full_range=1, matrix=1, primaries=1)],
+                         ids=["bt2020_limited", "bt709_full"])
+@pytest.mark.parametrize("fmt", [14, 12], ids=["RRGGBB_LE", "RRGGBB_BE"])
+def test_config4_10bit_422_single_image(hm, nclx, fmt):
+    """2048x1536 single (non-grid) 10-bit 4:2:2 image -> interleaved 16-bit RGB (values stay 10-bit)."""
+    pic = synthutil.picture(4220010, width=2048, height=1536, chroma_format=2, bit_depth=10, log2_ctb=5, qp=30, vui=1, **nclx)
+    data = heifwriter.write_heic([pic], (2048, 1536), chroma_format=2, bit_depth=10)
+    f = pipeline.HeifFile(hm, data)
+    planes, meta = f.decode(f.primary(), fmt, threads=1)
+    native, nmeta = f.decode(f.primary(), 0)
+    f.close()
+    assert (meta["bit_depth"], meta["chroma"]) == (10, 2)
+    exp, stride, canv = pipeline.cpu_decode(hm, [pic], 2048, 1536, 2048, 1536, 1, False, fmt)
+    assert meta["stride"][0] == stride
+    np.testing.assert_array_equal(planes[0][:1536, :2048 * 6], exp[:1536, :2048 * 6])
+    # native planar output = the decoder plugin's planes (decoder_libde265.cc:88-157)
+    for c, (w, h) in enumerate(((2048, 1536), (1024, 1536), (1024, 1536))):
+        np.testing.assert_array_equal(native[c][:h, :w * 2], canv[c][0][:h, :w * 2])
+
+
+def test_config5_16384_grid(hm):
+    """16384x16384 output, 32x32 grid of 512x512 tiles.  The 1024 tiles are drawn from six distinct coded pictures
+    (seeds 5000000 + k), so every tile-sized region of the output must equal the single-tile result of its picture:
+    a size-independent check of grid geometry, batching (1024 pictures in one launch) and paste at full scale."""
+    pool = [synthutil.picture(5000000 + k, **TILE, vui=1, full_range=1, matrix=6) for k in range(6)]
+    pick = [(t * 7 + t // 32) % 6 for t in range(1024)]
+    data = heifwriter.write_heic([pool[k] for k in pick], (512, 512), grid=(32, 32, 16384, 16384))
+    f = pipeline.HeifFile(hm, data)
+    planes, meta = f.decode(f.primary(), 10, threads=16)
+    f.close()
+    assert (meta["width"], meta["height"]) == (16384, 16384)
+    rgb = planes[0]
+    expect = [pipeline.cpu_decode(hm, [p], 512, 512, 512, 512, 1, True, 10)[0][:512, :512 * 3] for p in pool]
+    for t in range(1024):
+        r, c = divmod(t, 32)
+        got = rgb[r * 512:(r + 1) * 512, c * 1536:(c + 1) * 1536]
+        assert np.array_equal(got, expect[pick[t]]), f"tile {t} (row {r}, col {c}) differs"

@@ -77,13 +77,11 @@ def test_invalid_grids_report_reference_errors(hm):
     # tiles do not cover the output (context.cc:2321-2326)
     rc, msg = _decode_status(hm, heifwriter.write_heic(t, (64, 64), grid=(2, 2, 200, 128)))
     assert rc == -3 and "cover" in msg
-    # tiles of different declared size (context.cc:2333-2337): patch the 2nd tile's ispe
+    # tiles of different declared size (context.cc:2333-2337)
     import synthutil
     mixed = t[:3] + [synthutil.picture(399, width=64, height=72)]
-    data = bytearray(heifwriter.write_heic(mixed, (64, 64), grid=(2, 2, 128, 128)))
-    ispe = [i for i in range(len(data) - 4) if data[i:i + 4] == b"ispe"]
-    data[ispe[3] + 8:ispe[3] + 16] = struct.pack(">II", 64, 72)
-    rc, msg = _decode_status(hm, bytes(data))
+    data = heifwriter.write_heic(mixed, (64, 64), grid=(2, 2, 128, 128), sizes=[(64, 64)] * 3 + [(64, 72)])
+    rc, msg = _decode_status(hm, data)
     assert rc == -3 and "different sizes" in msg
 
 
