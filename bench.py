@@ -199,6 +199,17 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # clock (D) of SURVEY 8d: H2D of the command streams + kernels, result on the device (not `value`)
+    d_ms = None
+    if rank == 0 and not args.no_e2e:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            batch.upload(st)
+            step()
+        torch.cuda.synchronize()
+        d_ms = (time.perf_counter() - t1) / 3 * 1e3
+
     if rank == 0:
         total_mp = world * B * MP_PER_IMAGE * args.steps
         value = total_mp / elapsed
@@ -228,6 +239,10 @@ def main():
             "host_entropy_decode": {"MP_per_s_per_core": round(B * 48 * 0.262144 / host_parse_s, 1) if host_parse_s else None,
                                     "note": "hm_hevc_parse (CABAC -> command stream), 1 thread, outside the timed region"},
         }
+        if d_ms is not None:
+            out["device_inclusive"] = {"ms_per_step": round(d_ms, 3), "MP_per_s": round(B * MP_PER_IMAGE / d_ms * 1e3, 1),
+                                       "command_stream_bytes": int(stream_b),
+                                       "note": "H2D of the command streams (pinned staging) + all kernels, RGB left on the device; 1 GPU"}
         if not args.no_e2e:
             out["end_to_end"] = end_to_end(pkg, images[0])
         if args.cpu_seconds > 0:

@@ -52,6 +52,9 @@ namespace {
 __device__ __forceinline__ int clip3i(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int iabs_(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int imin_(int a, int b) { return a < b ? a : b; }
+// 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): every product here is position x pitch, weight x
+// sample or basis x coefficient, far below 2^23 per operand
+__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 __device__ __forceinline__ int wave_max(int v)
@@ -97,6 +100,7 @@ __device__ __forceinline__ const GLOBAL_AS T* gptr(const void* p) { return (cons
 template <typename T>
 __device__ __forceinline__ GLOBAL_AS T* gptr_w(void* p) { return (GLOBAL_AS T*)(uintptr_t)p; }
 
+constexpr int BIG_BYTES = 2048 + 1024 + 16; // shared 32x32 coefficient block, its 16-row intermediate, lock
 constexpr int UPAD = 4; // unified CTU buffer: row = [3 unused | left neighbour | bw samples]; rows stay 4-byte aligned
 
 // One block to reconstruct.  Every member has the same value in all lanes, but only the fields that steer
@@ -123,7 +127,7 @@ struct Avail {
 template <typename Pix>
 __device__ __forceinline__ int nb(const Blk<Pix>& b, int x, int y)
 {
-  const Pix* p = (y < 0) ? (b.top + (x + 1)) : (b.u + (y * b.P + UPAD + x));
+  const Pix* p = (y < 0) ? (b.top + (x + 1)) : (b.u + (mul24(y, b.P) + UPAD + x));
   return *p;
 }
 
@@ -175,7 +179,7 @@ struct RefDirect {
   int P, nL1, nT1;
   __device__ __forceinline__ int operator()(int j) const
   {
-    const int ol = imin_(-j - 1, nL1) * P, ot = imin_(j - 1, nT1);
+    const int ol = mul24(imin_(-j - 1, nL1), P), ot = imin_(j - 1, nT1);
     const Pix* const ql = lp + ol;
     const Pix* const qt = tp + ot;
     return *(j < 0 ? ql : qt);
@@ -186,7 +190,7 @@ __device__ __forceinline__ RefDirect<Pix> direct_refs(const Blk<Pix>& b)
 {
   constexpr int nT = 1 << L2;
   RefDirect<Pix> r;
-  r.lp = b.u + (b.y0 * b.P + UPAD + b.x0 - 1);
+  r.lp = b.u + (mul24(b.y0, b.P) + UPAD + b.x0 - 1);
   const Pix* const tpu = r.lp - b.P + 1;       // (x0, y0-1) inside the CTU
   const Pix* const tpl = b.top + (1 + b.x0);   // ... in the line of the CTU row above
   r.tp = b.y0 > 0 ? tpu : tpl;
@@ -290,7 +294,7 @@ __device__ __forceinline__ void make_border(const Blk<Pix>& b, int16_t* bA, int 
       v[t] = 0;
       if (e < N) {
         if (bi) {
-          const int vl = p0 + (((-i) * (pL - p0) + 32) >> 6), vt = p0 + ((i * (pT - p0) + 32) >> 6);
+          const int vl = p0 + ((mul24(-i, pL - p0) + 32) >> 6), vt = p0 + ((mul24(i, pT - p0) + 32) >> 6);
           v[t] = i < 0 ? vl : vt;
         }
         else {
@@ -315,7 +319,7 @@ __device__ __forceinline__ void predict(const Blk<Pix>& B, const Ref& b, const i
 {
   constexpr int nT = 1 << L2, log2 = L2;
   const int mode = B.mode, c = B.c;
-  Pix* dst = B.u + B.y0 * B.P + UPAD + B.x0;
+  Pix* dst = B.u + mul24(B.y0, B.P) + UPAD + B.x0;
   const int pitch = B.P;
   const int maxv = (1 << B.bd) - 1;
   constexpr int npx = nT * nT;
@@ -323,7 +327,7 @@ __device__ __forceinline__ void predict(const Blk<Pix>& B, const Ref& b, const i
   if (mode == 0) {
     lanes_loop<npx>(lane, [&](int p) {
       const int x = p & (nT - 1), y = p >> log2;
-      dst[y * pitch + x] = (Pix)(((nT - 1 - x) * b(-1 - y) + (x + 1) * b(1 + nT) + (nT - 1 - y) * b(1 + x) + (y + 1) * b(-1 - nT) + nT) >> (log2 + 1));
+      dst[mul24(y, pitch) + x] = (Pix)((mul24(nT - 1 - x, b(-1 - y)) + mul24(x + 1, b(1 + nT)) + mul24(nT - 1 - y, b(1 + x)) + mul24(y + 1, b(-1 - nT)) + nT) >> (log2 + 1));
     });
   }
   else if (mode == 1) {
@@ -339,7 +343,7 @@ __device__ __forceinline__ void predict(const Blk<Pix>& B, const Ref& b, const i
         v = x == 0 ? (l + 3 * dc + 2) >> 2 : v;
         v = (x | y) == 0 ? (l + 2 * dc + t + 2) >> 2 : v;
       }
-      dst[y * pitch + x] = (Pix)v;
+      dst[mul24(y, pitch) + x] = (Pix)v;
     });
   }
   else if (mode == 26 || mode == 10) { // pure vertical / horizontal: copy, plus the gradient on the first column / row
@@ -354,7 +358,7 @@ __device__ __forceinline__ void predict(const Blk<Pix>& B, const Ref& b, const i
         const int g = vert ? b(1) + ((l - corner) >> 1) : b(-1) + ((t - corner) >> 1);
         v = along == 0 ? clip3i(0, maxv, g) : v;
       }
-      dst[y * pitch + x] = (Pix)v;
+      dst[mul24(y, pitch) + x] = (Pix)v;
     });
   }
   else {
@@ -365,14 +369,14 @@ __device__ __forceinline__ void predict(const Blk<Pix>& B, const Ref& b, const i
     lanes_loop<npx>(lane, [&](int p) {
       const int x = p & (nT - 1), y = p >> log2;
       const int major = vert ? y : x, minor = vert ? x : y;
-      const int t = (major + 1) * angle;
+      const int t = mul24(major + 1, angle);
       const int iIdx = t >> 5, iFact = t & 31;
       const int k0 = minor + iIdx + 1, k1 = k0 + 1;
-      const int q0 = -((k0 * inv + 128) >> 8), q1 = -((k1 * inv + 128) >> 8);
+      const int q0 = -((mul24(k0, inv) + 128) >> 8), q1 = -((mul24(k1, inv) + 128) >> 8);
       const int j0 = sgn * (k0 >= 0 ? k0 : q0), j1 = sgn * (k1 >= 0 ? k1 : q1);
       // b(j1) is read even when iFact == 0 (then it has weight 0; the index stays inside bA: |j1| <= 2nT + 1)
       const int r0 = b(j0), r1 = b(j1);
-      dst[y * pitch + x] = (Pix)(((32 - iFact) * r0 + iFact * r1 + 16) >> 5);
+      dst[mul24(y, pitch) + x] = (Pix)((mul24(32 - iFact, r0) + mul24(iFact, r1) + 16) >> 5);
     });
   }
 }
@@ -395,7 +399,8 @@ __device__ __forceinline__ void residual_add(const Blk<Pix>& B, int16_t* coeff, 
   for (int i = lane; i < B.n_coeff; i += 64) {
     const uint32_t raw = i < 64 ? pre_raw : cf[i]; // the first 64 pairs were fetched before the prediction started
     const int pos = raw & 0xFFFF, value = (int)(int16_t)(raw >> 16);
-    const int32_t prod = (int32_t)((uint32_t)value * (uint32_t)fact + (uint32_t)offset); // wraps like the reference (Q3)
+    // low 32 bits of value * fact (|value| < 2^15, fact < 2^23), i.e. the reference's wrapping int32 product (Q3)
+    const int32_t prod = (int32_t)((uint32_t)mul24(value, fact) + (uint32_t)offset);
     coeff[pos] = (int16_t)clip3i(-32768, 32767, prod >> bdShift);
     const int px = pos & (nT - 1), py = pos >> log2;
     mx = px > mx ? px : mx;
@@ -404,7 +409,7 @@ __device__ __forceinline__ void residual_add(const Blk<Pix>& B, int16_t* coeff, 
   if (L2 == 2) mx = my = 3; // a 4x4 block: four multiply-adds per sample are cheaper than the search
   else { mx = wave_max5(mx); my = wave_max5(my); }
   WAVE_SYNC();
-  Pix* dst = B.u + B.y0 * B.P + UPAD + B.x0;
+  Pix* dst = B.u + mul24(B.y0, B.P) + UPAD + B.x0;
   const int pitch = B.P;
   const int maxv = (1 << bit_depth) - 1;
   const int postShift = 20 - bit_depth, rnd2 = 1 << (postShift - 1);
@@ -416,7 +421,7 @@ __device__ __forceinline__ void residual_add(const Blk<Pix>& B, int16_t* coeff, 
       const int32_t cc = (int32_t)((uint32_t)(int32_t)coeff[p] << tsShift);
       int r = (cc + rnd2) >> postShift;
       if (bit_depth == 8 && nT == 4) r = (int16_t)r;
-      dst[y * pitch + x] = (Pix)clip3i(0, maxv, (int)dst[y * pitch + x] + r);
+      dst[mul24(y, pitch) + x] = (Pix)clip3i(0, maxv, (int)dst[mul24(y, pitch) + x] + r);
     });
   }
   else if (nT == 4 && c == 0) { // 4x4 DST-VII, fallback-dct.cc:311-449
@@ -424,7 +429,7 @@ __device__ __forceinline__ void residual_add(const Blk<Pix>& B, int16_t* coeff, 
       const int cc = lane & 3, i = lane >> 2;
       int sum = 0;
 #pragma unroll
-      for (int j = 0; j < 4; j++) sum += tab[76 + j * 4 + i] * coeff[cc + j * 4];
+      for (int j = 0; j < 4; j++) sum += mul24(tab[76 + j * 4 + i], coeff[cc + j * 4]);
       tmp[i * 4 + cc] = (int16_t)clip3i(-32768, 32767, (sum + 64) >> 7);
     }
     WAVE_SYNC();
@@ -432,9 +437,9 @@ __device__ __forceinline__ void residual_add(const Blk<Pix>& B, int16_t* coeff, 
       const int i = lane & 3, y = lane >> 2;
       int sum = 0;
 #pragma unroll
-      for (int j = 0; j < 4; j++) sum += tab[76 + j * 4 + i] * tmp[y * 4 + j];
+      for (int j = 0; j < 4; j++) sum += mul24(tab[76 + j * 4 + i], tmp[y * 4 + j]);
       const int out = clip3i(-32768, 32767, (sum + rnd2) >> postShift);
-      dst[y * pitch + i] = (Pix)clip3i(0, maxv, (int)dst[y * pitch + i] + out);
+      dst[mul24(y, pitch) + i] = (Pix)clip3i(0, maxv, (int)dst[mul24(y, pitch) + i] + out);
     }
   }
   else {
@@ -448,16 +453,16 @@ __device__ __forceinline__ void residual_add(const Blk<Pix>& B, int16_t* coeff, 
         const int cc = p & (nT - 1), ir = p >> log2, i = i0 + ir;
         int sum = 0;
         if (cc <= mx)
-          for (int j = 0; j <= my; j++) sum += (int)dct[(fct * j) * 32 + i] * (int)coeff[cc + j * nT];
+          for (int j = 0; j <= my; j++) sum += mul24((int)dct[(fct * j) * 32 + i], (int)coeff[cc + j * nT]);
         tmp[cc + ir * nT] = (int16_t)clip3i(-32768, 32767, (sum + 64) >> 7);
       });
       WAVE_SYNC();
       lanes_loop<n_part>(lane, [&](int p) {
         const int i = p & (nT - 1), yr = p >> log2, y = i0 + yr;
         int sum = 0;
-        for (int j = 0; j <= mx; j++) sum += (int)dct[(fct * j) * 32 + i] * (int)tmp[yr * nT + j];
+        for (int j = 0; j <= mx; j++) sum += mul24((int)dct[(fct * j) * 32 + i], (int)tmp[yr * nT + j]);
         const int out = (sum + rnd2) >> postShift; // stage 2 is not clipped to 16 bit (Q4)
-        dst[y * pitch + i] = (Pix)clip3i(0, maxv, (int)dst[y * pitch + i] + out);
+        dst[mul24(y, pitch) + i] = (Pix)clip3i(0, maxv, (int)dst[mul24(y, pitch) + i] + out);
       });
       WAVE_SYNC();
     }
@@ -498,13 +503,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
   constexpr int cw_c = ctb >> 1, P0 = ctb + UPAD, P1 = cw_c + UPAD;
   const int ch_c = ctb / sh; // chroma CTB height
 
-  // ---- LDS carve-up: [progress: ctb_h ints][dct 1024 B][tables 256 B][sample lines][per-wave regions]
+  // ---- LDS carve-up: [progress: ctb_h ints][dct 1024 B][tables 256 B][sample lines]
+  //                     [32x32 coefficient block + intermediate + lock, shared by the waves][per-wave regions]
+  // 32x32 transform blocks are rare; giving every wave its own 2 KiB + 1 KiB for them would cost one
+  // resident picture per CU, so the waves of a workgroup take turns on one shared set (LDS spin lock).
   int* progress = reinterpret_cast<int*>(lds);
   const int prog_bytes = ((ctb_h * 4) + 15) & ~15;
   int8_t* dct = reinterpret_cast<int8_t*>(lds + prog_bytes);
   int16_t* tab = reinterpret_cast<int16_t*>(lds + prog_bytes + 1024);
   uint8_t* const lines = lds + prog_bytes + 1024 + 256;
-  uint8_t* wbase = lines + (size_t)n_lines * line_bytes + (size_t)wave * per_wave_bytes;
+  uint8_t* const big = lines + (size_t)n_lines * line_bytes;
+  int16_t* const big_coeff = reinterpret_cast<int16_t*>(big);
+  int16_t* const big_tmp = reinterpret_cast<int16_t*>(big + 2048);
+  int* const big_lock = reinterpret_cast<int*>(big + 2048 + 1024);
+  uint8_t* wbase = big + BIG_BYTES + (size_t)wave * per_wave_bytes;
 
   for (int i = tid; i < ctb_h; i += blockDim.x) progress[i] = 0;
   for (int i = tid; i < 1024; i += blockDim.x) {
@@ -526,16 +538,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
     else v = c_dst[(i - 76) >> 2][(i - 76) & 3];
     tab[i] = (int16_t)v;
   }
-  // per-wave staging: coefficient block must start all-zero (residual_add keeps it so)
+  // coefficient blocks must start all-zero (residual_add keeps them so)
   {
     int16_t* cz = reinterpret_cast<int16_t*>(wbase);
-    for (int i = lane; i < 1024; i += 64) cz[i] = 0;
+    for (int i = lane; i < 256; i += 64) cz[i] = 0;
+    for (int i = tid; i < 1024; i += blockDim.x) big_coeff[i] = 0;
+    if (tid == 0) *big_lock = 0;
   }
   __syncthreads(); // the only workgroup barrier: all waves still converge here
 
   uint8_t* lp = wbase;
-  int16_t* const l_coeff = reinterpret_cast<int16_t*>(lp); lp += 2048;
-  int16_t* const l_tmp = reinterpret_cast<int16_t*>(lp); lp += 1024;
+  int16_t* const l_coeff = reinterpret_cast<int16_t*>(lp); lp += 512; // up to 16x16
+  int16_t* const l_tmp = reinterpret_cast<int16_t*>(lp); lp += 512;
   int16_t* const l_bA = reinterpret_cast<int16_t*>(lp); lp += 272;
   Pix* const u0 = reinterpret_cast<Pix*>(lp); lp += (size_t)P0 * ctb * sizeof(Pix);
   Pix* const u1 = reinterpret_cast<Pix*>(lp); lp += (size_t)P1 * ch_c * sizeof(Pix);
@@ -630,7 +644,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
           }
           WAVE_SYNC();
           if (cbf) {
-            residual_add<Pix, L2>(B, l_coeff, l_tmp, dct, tab, coeffs + coeff_first, pre, ln);
+            if (L2 == 5) { // take the workgroup's 32x32 staging
+              if (lane == 0)
+                while (__hip_atomic_exchange(big_lock, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) __builtin_amdgcn_s_sleep(2);
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+              __builtin_amdgcn_wave_barrier();
+              residual_add<Pix, L2>(B, big_coeff, big_tmp, dct, tab, coeffs + coeff_first, pre, ln);
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+              if (lane == 0) __hip_atomic_store(big_lock, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            else residual_add<Pix, L2>(B, l_coeff, l_tmp, dct, tab, coeffs + coeff_first, pre, ln);
             WAVE_SYNC();
           }
           if (B.c == 0) { // deblocking metadata (deblock.cc:31-62): transform edges + QpY
@@ -642,8 +665,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
                 const int left_ok = (B.x0 > 0) | ((cb_flags & HM_CTB_DEBLOCK_LEFT) != 0);
                 const int top_ok = (B.y0 > 0) | ((cb_flags & HM_CTB_DEBLOCK_TOP) != 0);
                 const int e = ((i == 0) & left_ok & deblock_en) | (((j == 0) & top_ok & deblock_en) << 1);
-                g_edge[bx + (size_t)by * dp.w4] = (uint8_t)e;
-                g_qpy[bx + (size_t)by * dp.w4] = (int8_t)qpy;
+                const uint32_t mo = (uint32_t)bx + __umul24((uint32_t)by, (uint32_t)dp.w4); // < 2^24 blocks per picture
+                g_edge[mo] = (uint8_t)e;
+                g_qpy[mo] = (int8_t)qpy;
               }
             }
           }
@@ -668,7 +692,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
         for (int rb = 0; rb < vh; rb += RPT) { // scalar trip counter; lanes only differ in (row, word)
           const int r = rb + r0;
           if (col_ok && r < vh)
-            *reinterpret_cast<GLOBAL_AS uint32_t*>(gp + (size_t)r * pitch) = *reinterpret_cast<const uint32_t*>(u + r * P + UPAD + q * PPW);
+            *reinterpret_cast<GLOBAL_AS uint32_t*>(gp + (uint32_t)mul24(r, pitch)) = *reinterpret_cast<const uint32_t*>(u + mul24(r, P) + UPAD + q * PPW);
         }
         if (lane < WPR)
           *reinterpret_cast<uint32_t*>(line + xo + lane * PPW) = *reinterpret_cast<const uint32_t*>(u + (bh - 1) * P + UPAD + lane * PPW);
@@ -691,7 +715,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
 static int per_wave_lds(int ctb, int chroma_format, int pix_bytes)
 {
   const int cw = ctb / 2, ch = chroma_format == 1 ? ctb / 2 : ctb;
-  int b = 2048 + 1024 + 272;
+  int b = 512 + 512 + 272;
   b += (ctb + UPAD) * ctb * pix_bytes + 2 * (cw + UPAD) * ch * pix_bytes;
   return (b + 15) & ~15;
 }
@@ -710,7 +734,7 @@ extern "C" int hm_launch_recon(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   const int pix_bytes = bit_depth > 8 ? 2 : 1;
   const int pw = per_wave_lds(ctb, chroma_format, pix_bytes);
   const int line = line_lds(ctb, max_ctb_w, pix_bytes);
-  const int fixed = (((max_ctb_h * 4) + 15) & ~15) + 1024 + 256;
+  const int fixed = (((max_ctb_h * 4) + 15) & ~15) + 1024 + 256 + BIG_BYTES;
   // useful waves: a CTU row can start once the row above is two CTUs ahead
   int nw = (max_ctb_w + 1) / 2;
   if (nw > max_ctb_h) nw = max_ctb_h;
