@@ -75,10 +75,11 @@ __device__ __forceinline__ int wave_max5(int v)
   }
   return m;
 }
+template <bool HALVES = false> // HALVES: independent sums over lanes 0-31 and 32-63
 __device__ __forceinline__ int wave_sum(int v)
 {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  for (int o = HALVES ? 16 : 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
 
@@ -114,6 +115,7 @@ struct Blk {
   const Pix* top;    // top[1 + x] = sample at (x,-1), x = -1 .. 2*bw-1 (inside the line of the CTU row above)
   int P;             // pitch of u in samples
   int x0, y0, log2, c, mode, qp, info;
+  int tskip;         // transform_skip_flag (a vector value when a Cb / Cr pair shares the wave)
   uint32_t avail;    // hm_tu.avail_* as one word: left | bottom_left << 8 | top << 16 | top_right << 24 (scalar)
   int aBL, aTR;      // vector copies of the two partial counts
   int n_coeff;
@@ -314,7 +316,7 @@ __device__ __forceinline__ void make_border(const Blk<Pix>& b, int16_t* bA, int 
 }
 
 // ---- predictors (intrapred.h:269-441) ------------------------------------------------------------------
-template <typename Pix, int L2, typename Ref>
+template <typename Pix, int L2, typename Ref, bool HALVES = false>
 __device__ __forceinline__ void predict(const Blk<Pix>& B, const Ref& b, const int16_t* tab, int lane)
 {
   constexpr int nT = 1 << L2, log2 = L2;
@@ -333,7 +335,7 @@ __device__ __forceinline__ void predict(const Blk<Pix>& B, const Ref& b, const i
   else if (mode == 1) {
     int s = 0;
     if (lane < nT) s = b(lane + 1) + b(-lane - 1);
-    const int dc = (wave_sum(s) + nT) >> (log2 + 1);
+    const int dc = (wave_sum<HALVES>(s) + nT) >> (log2 + 1);
     lanes_loop<npx>(lane, [&](int p) {
       const int x = p & (nT - 1), y = p >> log2;
       int v = dc;
@@ -414,7 +416,7 @@ __device__ __forceinline__ void residual_add(const Blk<Pix>& B, int16_t* coeff, 
   const int maxv = (1 << bit_depth) - 1;
   const int postShift = 20 - bit_depth, rnd2 = 1 << (postShift - 1);
 
-  if (B.info & HM_TU_TSKIP) { // transform.cc:566-643
+  if (B.tskip) { // transform.cc:566-643
     const int tsShift = 5 + log2;
     lanes_loop<npx>(lane, [&](int p) {
       const int x = p & (nT - 1), y = p >> log2;
@@ -569,13 +571,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
     // are contiguous (hm_stream.h: CTBs store their records in raster order), so the prefetch simply runs
     // on across CTU borders.
     uint32_t c0 = crow[0], c1 = crow[1], c2 = crow[2];
-    uint32_t n0, n1, n2, n3;
+    uint32_t n0, n1, n2, n3; // record of the current block
+    uint32_t m0, m1, m2, m3; // ... of the next one (a 4x4 Cb block is reconstructed together with its Cr twin)
+    uint32_t p0, p1, p2, p3; // ... and of the one after
     uint32_t gnext; // index of the next record to fetch (vector register: keeps the address arithmetic off the scalar unit)
+    auto fetch = [&](uint32_t idx, uint32_t& a0, uint32_t& a1, uint32_t& a2, uint32_t& a3) {
+      const uint32_t g = idx < n_tus - 1 ? idx : n_tus - 1; // past the last block of the picture: re-read it (never used)
+      const GLOBAL_AS uint32_t* q = tus + 4 * (size_t)g;
+      a0 = q[0]; a1 = q[1]; a2 = q[2]; a3 = q[3];
+    };
     {
       const uint32_t first = rfl((int)c0);
-      const GLOBAL_AS uint32_t* q = tus + 4 * (size_t)first;
-      n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3];
-      gnext = first + 1;
+      fetch(first, n0, n1, n2, n3);
+      fetch(first + 1, m0, m1, m2, m3);
+      fetch(first + 2, p0, p1, p2, p3);
+      gnext = first + 3;
       asm volatile("" : "+v"(gnext));
     }
     for (int cx = 0; cx < ctb_w; cx++) {
@@ -593,17 +603,74 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
       const Pix* const top2 = lr + lo2 + cx * cw_c - 1;
       const int deblock_en = !(cb_flags & HM_CTB_DEBLOCK_OFF);
 
-      for (int k = 0; k < tu_count; k++) {
+      for (int k = 0; k < tu_count;) {
         // control fields -> scalar registers; data fields stay in (opaque) vector registers
         const uint32_t r0 = rfl(n0), r3 = rfl(n3);
         uint32_t w0 = n0, w1 = n1, w2 = n2, w3 = n3;
         asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));
-        {
-          const uint32_t g = gnext < n_tus - 1 ? gnext : n_tus - 1; // the last block of the picture re-reads itself
-          const GLOBAL_AS uint32_t* q = tus + 4 * (size_t)g;
-          n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3];
+        // A 4x4 Cb block directly followed by its Cr twin (same place, mode and neighbourhood): both are
+        // reconstructed in one pass, Cb on lanes 0-31 and Cr on lanes 32-63 (a 4x4 block keeps 17 lanes busy).
+        bool pair = false;
+        uint32_t s0 = 0;
+        constexpr uint32_t kind_mask = (uint32_t)(HM_TU_LOG2_MASK | (3u << HM_TU_CIDX_SHIFT)) << 16;
+        if ((r0 & kind_mask) == ((2u | (1u << HM_TU_CIDX_SHIFT)) << 16) && k + 1 < tu_count) {
+          s0 = rfl(m0);
+          constexpr uint32_t differ = (uint32_t)(HM_TU_CBF | HM_TU_TSKIP | (3u << HM_TU_CIDX_SHIFT)) << 16;
+          pair = ((r0 ^ s0) & ~differ) == 0 && ((s0 >> (16 + HM_TU_CIDX_SHIFT)) & 3) == 2 && (uint32_t)rfl(m3) == r3;
+        }
+        if (pair) {
+          const int half = lane >> 5;
+          int ln = lane & 31;
+          asm volatile("" : "+v"(ln));
+          uint32_t v1 = m1, v2 = m2;
+          asm volatile("" : "+v"(v1), "+v"(v2));
+          { // both records are consumed: the one after becomes current, two new ones are requested
+            n0 = p0; n1 = p1; n2 = p2; n3 = p3;
+            fetch(gnext, m0, m1, m2, m3);
+            fetch(gnext + 1, p0, p1, p2, p3);
+            gnext += 2;
+          }
+          k += 2;
+          Blk<Pix> B;
+          const int info_l = (int)(((half ? s0 : r0) >> 16) & 0xFF);
+          B.info = (r0 >> 16) & 0xFF; // the shared bits (size, top-left availability)
+          B.mode = r0 >> 24;
+          B.log2 = 2;
+          B.c = 1;
+          B.avail = r3;
+          B.bd = bd;
+          B.x0 = w0 & 0xFF; B.y0 = (w0 >> 8) & 0xFF;
+          const uint32_t l1 = half ? v1 : w1, l2 = half ? v2 : w2;
+          B.qp = l1 & 0xFF;
+          B.n_coeff = l1 >> 16;
+          B.aBL = (w3 >> 8) & 0xFF; B.aTR = w3 >> 24;
+          B.u = half ? u2 : u1;
+          B.top = half ? top2 : top1;
+          B.P = P1;
+          B.tskip = info_l & HM_TU_TSKIP;
+          const bool cbf_l = (info_l & HM_TU_CBF) != 0;
+          const GLOBAL_AS uint32_t* const cf = coeffs + l2;
+          uint32_t pre = 0;
+          if (cbf_l && ln < B.n_coeff) pre = cf[ln];
+          if (is_interior<2>(B.avail, B.info)) predict<Pix, 2, RefDirect<Pix>, true>(B, direct_refs<Pix, 2>(B), tab, ln);
+          else {
+            int16_t* const bA = l_bA + half * 24; // 17 reference samples per half: centres 24 entries apart
+            make_border<Pix, 2>(B, bA, strong, ln);
+            WAVE_SYNC();
+            predict<Pix, 2, RefArray, true>(B, RefArray{bA + 64}, tab, ln);
+          }
+          WAVE_SYNC();
+          if (cbf_l) residual_add<Pix, 2>(B, l_coeff + half * 16, l_tmp + half * 16, dct, tab, cf, pre, ln);
+          WAVE_SYNC();
+          continue;
+        }
+        { // rotate the record pipeline by one
+          n0 = m0; n1 = m1; n2 = m2; n3 = m3;
+          m0 = p0; m1 = p1; m2 = p2; m3 = p3;
+          fetch(gnext, p0, p1, p2, p3);
           gnext += 1;
         }
+        k += 1;
         Blk<Pix> B;
         B.info = (r0 >> 16) & 0xFF;
         B.mode = r0 >> 24;
@@ -611,6 +678,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
         B.c = (B.info >> HM_TU_CIDX_SHIFT) & 3;
         B.avail = r3;
         B.bd = bd;
+        B.tskip = B.info & HM_TU_TSKIP;
         B.x0 = w0 & 0xFF; B.y0 = (w0 >> 8) & 0xFF;
         B.qp = w1 & 0xFF;
         const int qpy = (int)(int8_t)((w1 >> 8) & 0xFF);
