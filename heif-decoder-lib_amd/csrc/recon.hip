@@ -173,6 +173,8 @@ __device__ __forceinline__ int border_value(const Blk<Pix>& b, const Avail& av, 
 struct RefArray {
   const int16_t* bc;
   __device__ __forceinline__ int operator()(int j) const { return bc[j]; }
+  __device__ __forceinline__ int top(int k) const { return bc[k]; }   // k >= 0: corner, then the row above
+  __device__ __forceinline__ int left(int k) const { return bc[-k]; } // k >= 0: corner, then the left column
 };
 template <typename Pix>
 struct RefDirect {
@@ -186,6 +188,9 @@ struct RefDirect {
     const Pix* const qt = tp + ot;
     return *(j < 0 ? ql : qt);
   }
+  // one-sided accessors for the modes that only look up (or only left): no side select
+  __device__ __forceinline__ int top(int k) const { return tp[imin_(k - 1, nT1)]; }
+  __device__ __forceinline__ int left(int k) const { return lp[mul24(imin_(k - 1, nL1), P)]; }
 };
 template <typename Pix, int L2>
 __device__ __forceinline__ RefDirect<Pix> direct_refs(const Blk<Pix>& b)
@@ -365,8 +370,19 @@ __device__ __forceinline__ void predict(const Blk<Pix>& B, const Ref& b, const i
   }
   else {
     const int angle = tab[mode];
-    const int inv = tab[35 + mode]; // 0 outside modes 11..25
     const bool vert = mode >= 18;
+    if (angle > 0) { // modes 2-9 / 27-34: every reference index is positive, i.e. on one side only
+      lanes_loop<npx>(lane, [&](int p) {
+        const int x = p & (nT - 1), y = p >> log2;
+        const int major = vert ? y : x, minor = vert ? x : y;
+        const int t = mul24(major + 1, angle);
+        const int k0 = minor + (t >> 5) + 1, iFact = t & 31;
+        const int r0 = vert ? b.top(k0) : b.left(k0), r1 = vert ? b.top(k0 + 1) : b.left(k0 + 1); // weight 0 when iFact == 0
+        dst[mul24(y, pitch) + x] = (Pix)((mul24(32 - iFact, r0) + mul24(iFact, r1) + 16) >> 5);
+      });
+    }
+    else {
+    const int inv = tab[35 + mode]; // 0 outside modes 11..25
     const int sgn = vert ? 1 : -1; // ref[k] = border[sgn * k] for k >= 0, border[-sgn * proj(k)] for k < 0
     lanes_loop<npx>(lane, [&](int p) {
       const int x = p & (nT - 1), y = p >> log2;
@@ -380,6 +396,7 @@ __device__ __forceinline__ void predict(const Blk<Pix>& B, const Ref& b, const i
       const int r0 = b(j0), r1 = b(j1);
       dst[mul24(y, pitch) + x] = (Pix)((mul24(32 - iFact, r0) + mul24(iFact, r1) + 16) >> 5);
     });
+    }
   }
 }
 
