@@ -183,8 +183,7 @@ int hm_batch_upload(hm_batch* b, void* stream)
       d.plane[1] = wp; wp += align_up(pc * (h.height / sh), 256);
       d.plane[2] = wp; wp += align_up(pc * (h.height / sh), 256);
       d.pitch[0] = (int)py; d.pitch[1] = d.pitch[2] = (int)pc;
-      d.edge = wp; wp += align_up(w4 * h4, 256);
-      d.qpy = (int8_t*)wp;
+      d.meta = (uint16_t*)wp; // 2 bytes per 4x4 block (the size reserved above)
       d.w4 = (int)w4; d.h4 = (int)h4;
       d.width = h.width; d.height = h.height;
       d.chroma_format = h.chroma_format;

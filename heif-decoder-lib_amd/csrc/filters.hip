@@ -58,9 +58,9 @@ __device__ __forceinline__ PicView view(const hm_dev_pic& dp)
 __device__ __forceinline__ int edge_bs(const hm_dev_pic& dp, int x, int y, int vertical)
 {
   if ((x >> 2) >= dp.w4 || (y >> 2) >= dp.h4) return 0;
-  return (dp.edge[(x >> 2) + (size_t)(y >> 2) * dp.w4] & (vertical ? 1 : 2)) ? 2 : 0;
+  return (dp.meta[(x >> 2) + (size_t)(y >> 2) * dp.w4] & (vertical ? 1 : 2)) ? 2 : 0;
 }
-__device__ __forceinline__ int qpy_at(const hm_dev_pic& dp, int x, int y) { return dp.qpy[(x >> 2) + (size_t)(y >> 2) * dp.w4]; }
+__device__ __forceinline__ int qpy_at(const hm_dev_pic& dp, int x, int y) { return (int)(int8_t)(dp.meta[(x >> 2) + (size_t)(y >> 2) * dp.w4] >> 8); }
 __device__ __forceinline__ const hm_slice& slice_at(const hm_dev_pic& dp, const PicView& v, int x, int y)
 {
   const int ci = (x >> dp.log2_ctb) + (y >> dp.log2_ctb) * dp.ctb_w;

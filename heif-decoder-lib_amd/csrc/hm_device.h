@@ -12,8 +12,8 @@ struct hm_dev_pic {
   const uint8_t* blob;      // command stream (hm_pic at offset 0)
   uint8_t* plane[3];        // working planes: reconstruction, deblocked in place
   int32_t pitch[3];         // bytes
-  uint8_t* edge;            // per 4x4 luma block: bit0 vertical edge on its left, bit1 horizontal edge on top
-  int8_t* qpy;              // per 4x4 luma block: QpY
+  uint16_t* meta;           // per 4x4 luma block: bit0 vertical transform edge on its left, bit1 horizontal edge on
+                            // top (deblock.cc:31-62), bits 8-15 QpY (int8) - one store from k_recon, one load in k_deblock
   int32_t w4, h4;           // size of the 4x4-block maps
   // final output of the in-loop filters (SAO stage): written straight into the destination
   // image = fused tile paste (context.cc:2457-2535 of the reference)

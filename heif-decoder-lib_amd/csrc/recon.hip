@@ -510,8 +510,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
   const GLOBAL_AS uint32_t* tus = gptr<uint32_t>(blob + H->off_tus);     // 4 dwords per hm_tu
   const GLOBAL_AS uint32_t* coeffs = gptr<uint32_t>(blob + H->off_coeffs);
   const uint32_t n_tus = H->n_tus;
-  GLOBAL_AS uint8_t* g_edge = gptr_w<uint8_t>(dp.edge);
-  GLOBAL_AS int8_t* g_qpy = gptr_w<int8_t>(dp.qpy);
+  GLOBAL_AS uint16_t* g_meta = gptr_w<uint16_t>(dp.meta);
 
   const int tid = threadIdx.x, lane = tid & 63, NW = blockDim.x >> 6;
   const int wave = rfl(tid >> 6); // wave-uniform by construction: row state lives in SGPRs
@@ -619,6 +618,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
       const Pix* const top1 = lr + lo1 + cx * cw_c - 1;
       const Pix* const top2 = lr + lo2 + cx * cw_c - 1;
       const int deblock_en = !(cb_flags & HM_CTB_DEBLOCK_OFF);
+      GLOBAL_AS uint16_t* const ctb_meta = g_meta + (size_t)((row << log2_ctb) >> 2) * dp.w4 + ((cx << log2_ctb) >> 2); // this CTU's first 4x4 block
 
       for (int k = 0; k < tu_count;) {
         // control fields -> scalar registers; data fields stay in (opaque) vector registers
@@ -745,15 +745,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
             constexpr int n4 = 1 << (L2 - 2);
             if (ln < n4 * n4) {
               const int i = ln & (n4 - 1), j = ln >> (L2 - 2);
-              const int bx = (((cx << log2_ctb) + B.x0) >> 2) + i, by = (((row << log2_ctb) + B.y0) >> 2) + j;
-              if (bx < dp.w4 && by < dp.h4) {
-                const int left_ok = (B.x0 > 0) | ((cb_flags & HM_CTB_DEBLOCK_LEFT) != 0);
-                const int top_ok = (B.y0 > 0) | ((cb_flags & HM_CTB_DEBLOCK_TOP) != 0);
-                const int e = ((i == 0) & left_ok & deblock_en) | (((j == 0) & top_ok & deblock_en) << 1);
-                const uint32_t mo = (uint32_t)bx + __umul24((uint32_t)by, (uint32_t)dp.w4); // < 2^24 blocks per picture
-                g_edge[mo] = (uint8_t)e;
-                g_qpy[mo] = (int8_t)qpy;
-              }
+              // transform blocks lie inside the picture (its size is a multiple of the minimum coding block)
+              const int left_ok = (B.x0 > 0) | ((cb_flags & HM_CTB_DEBLOCK_LEFT) != 0);
+              const int top_ok = (B.y0 > 0) | ((cb_flags & HM_CTB_DEBLOCK_TOP) != 0);
+              const int e = ((i == 0) & left_ok & deblock_en) | (((j == 0) & top_ok & deblock_en) << 1);
+              const uint32_t mo = (uint32_t)((B.x0 >> 2) + i) + __umul24((uint32_t)((B.y0 >> 2) + j), (uint32_t)dp.w4);
+              ctb_meta[mo] = (uint16_t)(e | ((qpy & 0xFF) << 8));
             }
           }
         };
