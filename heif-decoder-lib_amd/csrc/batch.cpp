@@ -191,6 +191,9 @@ int hm_batch_upload(hm_batch* b, void* stream)
       d.log2_ctb = h.log2_ctb;
       d.ctb_w = h.ctb_w; d.ctb_h = h.ctb_h;
       d.flags = (int32_t)h.flags;
+      d.cb_qp_offset = h.pps_cb_qp_offset; d.cr_qp_offset = h.pps_cr_qp_offset;
+      d.slices = (const hm_slice*)(d.blob + h.off_slices);
+      d.ctbs = (const hm_ctb*)(d.blob + h.off_ctbs);
       // destination = tile paste geometry of context.cc:2457-2502
       const hm_tile_dest& t = it.dest;
       const int sw = 2;

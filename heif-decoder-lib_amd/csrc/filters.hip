@@ -43,16 +43,14 @@ __device__ __forceinline__ int chroma_qp_map(int qPi) // Table 8-10
 }
 
 struct PicView {
-  const hm_pic* H;
   const hm_slice* slices;
   const hm_ctb* ctbs;
 };
 __device__ __forceinline__ PicView view(const hm_dev_pic& dp)
 {
   PicView v;
-  v.H = reinterpret_cast<const hm_pic*>(dp.blob);
-  v.slices = reinterpret_cast<const hm_slice*>(dp.blob + v.H->off_slices);
-  v.ctbs = reinterpret_cast<const hm_ctb*>(dp.blob + v.H->off_ctbs);
+  v.slices = dp.slices;
+  v.ctbs = dp.ctbs;
   return v;
 }
 __device__ __forceinline__ int edge_bs(const hm_dev_pic& dp, int x, int y, int vertical)
@@ -192,7 +190,7 @@ __global__ __launch_bounds__(256) void k_deblock(const hm_dev_pic* __restrict__ 
   const int bS0 = edge_bs(dp, lx, ly, vertical);
   const int bS1 = vertical ? edge_bs(dp, lx, ly + 4 * sh, 1) : edge_bs(dp, lx + 4 * sw, ly, 0);
   if (bS0 != 2 && bS1 != 2) return;
-  const int off = cp == 0 ? v.H->pps_cb_qp_offset : v.H->pps_cr_qp_offset;
+  const int off = cp == 0 ? dp.cb_qp_offset : dp.cr_qp_offset;
   int QP_Q = qpy_at(dp, lx, ly);
   int QP_P = vertical ? qpy_at(dp, lx - 1, ly) : qpy_at(dp, lx, ly - 1);
   int qPi = ((QP_Q + QP_P + 1) >> 1) + off;
@@ -296,18 +294,79 @@ __device__ __forceinline__ int sao_sample(const hm_dev_pic& dp, const PicView& v
   return val;
 }
 
+// Edge offset of one group of G samples for one SaoEoClass (compile-time neighbour direction): neighbour a of
+// sample x is (x + HX, yy + VY), neighbour b is (x - HX, yy - VY) (sao.cc:336-424).
+template <typename Pix, int HX, int VY, int G>
+__device__ __forceinline__ void sao_edge_group(const uint8_t* plane, int pitch, int xs, int yy, int W, int Hh, int l2w, int l2h,
+                                               int cx, int cy, uint32_t nbm, uint32_t offs, int maxv, const Pix (&cur)[G], int (&out)[G])
+{
+  const int ya = yy + VY, yb = yy - VY;
+  const bool rows_ok = ya >= 0 && yb < Hh;
+  const int dya = (ya >> l2h) - cy, dyb = (yb >> l2h) - cy; // -1 / 0 and 0 / +1
+  auto perm = [&](int dy, int dx) -> bool { // may the neighbour CTB (dx, dy) be read?
+    const int k8 = (dy + 1) * 3 + (dx + 1);
+    const int bit = k8 < 4 ? k8 : k8 - 1;
+    return (dx | dy) == 0 || ((nbm >> bit) & 1);
+  };
+  Pix va[G], vb[G];
+  if (VY == 0) {
+#pragma unroll
+    for (int k = 0; k < G; k++) va[k] = vb[k] = cur[k];
+  }
+  else {
+    const Pix* ra = reinterpret_cast<const Pix*>(plane + (size_t)(ya >= 0 ? ya : yy) * pitch) + xs;
+    const Pix* rb = reinterpret_cast<const Pix*>(plane + (size_t)(yb < Hh ? yb : yy) * pitch) + xs;
+    __builtin_memcpy(va, ra, G * sizeof(Pix));
+    __builtin_memcpy(vb, rb, G * sizeof(Pix));
+  }
+  // the sample left of / right of the group, on the side each row needs
+  const bool has_l = xs > 0, has_r = xs + G < W;
+  int ea = 0, eb = 0;
+  if (HX != 0) {
+    const Pix* ra = reinterpret_cast<const Pix*>(plane + (size_t)(ya >= 0 ? ya : yy) * pitch) + xs;
+    const Pix* rb = reinterpret_cast<const Pix*>(plane + (size_t)(yb < Hh ? yb : yy) * pitch) + xs;
+    if (HX < 0 ? has_l : has_r) ea = ra[HX < 0 ? -1 : G];
+    if (HX < 0 ? has_r : has_l) eb = rb[HX < 0 ? G : -1];
+  }
+  const bool mid_ok = rows_ok && perm(dya, 0) && perm(dyb, 0);
+  // the first / last sample of the group may look into the CTB column to the left / right
+  const int dxl = ((xs - 1) >> l2w) - cx, dxr = ((xs + G) >> l2w) - cx;
+  const bool first_ok = HX == 0 ? mid_ok : rows_ok && has_l && perm(HX < 0 ? dya : dyb, dxl) && perm(HX < 0 ? dyb : dya, 0);
+  const bool last_ok = HX == 0 ? mid_ok : rows_ok && has_r && perm(HX > 0 ? dya : dyb, dxr) && perm(HX > 0 ? dyb : dya, 0);
+#pragma unroll
+  for (int k = 0; k < G; k++) {
+    const int a = HX < 0 ? (k > 0 ? (int)va[k > 0 ? k - 1 : 0] : ea) : (HX > 0 ? (k < G - 1 ? (int)va[k < G - 1 ? k + 1 : 0] : ea) : (int)va[k]);
+    const int b = HX < 0 ? (k < G - 1 ? (int)vb[k < G - 1 ? k + 1 : 0] : eb) : (HX > 0 ? (k > 0 ? (int)vb[k > 0 ? k - 1 : 0] : eb) : (int)vb[k]);
+    const bool ok = k == 0 ? first_ok : (k == G - 1 ? last_ok : mid_ok);
+    const int e = clip3i(-1, 1, out[k] - a) + clip3i(-1, 1, out[k] - b); // sign + sign
+    const int idx = e < 0 ? e + 2 : e + 1; // -2,-1,1,2 -> 0,1,2,3
+    const int o = (int)(int8_t)(offs >> (8 * (idx & 3)));
+    out[k] = (ok && e != 0) ? clip3i(0, maxv, out[k] + o) : out[k];
+  }
+}
+
+// SAO + paste.  blockIdx.y = picture; the planes' 64 x 8-sample tiles are numbered consecutively (luma, Cb, Cr),
+// one wave per tile: lane = (row lane >> 3, 8-sample group lane & 7).  A tile lies in one CTB row and in at most
+// two luma CTBs, so the lanes of a wave mostly agree on SAO type and class (the per-class code is branch-free).
+// (8 | every CTB width, so a group never straddles CTBs when the conformance-window offset is a multiple of 8 -
+// the common case; otherwise the generic per-sample path runs.)
 template <typename Pix>
 __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict__ pics, int apply_sao)
 {
   const hm_dev_pic& dp = pics[blockIdx.y];
-  const int c = blockIdx.z;
+  constexpr int G = 8, TW = 64, TH = 8;
+  const int wt = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int tx0 = (dp.copy_w[0] + TW - 1) / TW, n0 = dp.copy_w[0] > 0 && dp.copy_h[0] > 0 ? tx0 * ((dp.copy_h[0] + TH - 1) / TH) : 0;
+  const int tx1 = (dp.copy_w[1] + TW - 1) / TW, n1 = dp.copy_w[1] > 0 && dp.copy_h[1] > 0 ? tx1 * ((dp.copy_h[1] + TH - 1) / TH) : 0;
+  const int tx2 = (dp.copy_w[2] + TW - 1) / TW, n2 = dp.copy_w[2] > 0 && dp.copy_h[2] > 0 ? tx2 * ((dp.copy_h[2] + TH - 1) / TH) : 0;
+  if (wt >= n0 + n1 + n2) return;
+  const int c = wt < n0 ? 0 : (wt < n0 + n1 ? 1 : 2);
+  const int local = wt - (c == 0 ? 0 : (c == 1 ? n0 : n0 + n1));
+  const int txc = c == 0 ? tx0 : (c == 1 ? tx1 : tx2);
+  const int ty = local / txc, tx = local - ty * txc;
   const int cw = dp.copy_w[c], chh = dp.copy_h[c];
-  if (cw <= 0 || chh <= 0) return;
-  constexpr int G = 8;
-  const int groups = (cw + G - 1) / G;
-  const int item = blockIdx.x * 256 + threadIdx.x;
-  if (item >= groups * chh) return;
-  const int yd = item / groups, x8 = (item - yd * groups) * G; // destination coordinates
+  const int yd = ty * TH + (lane >> 3), x8 = tx * TW + (lane & 7) * G; // destination coordinates
+  if (yd >= chh || x8 >= cw) return;
   const PicView v = view(dp);
   const int sh = c ? (dp.chroma_format == 1 ? 2 : 1) : 1;
   const int W = dp.width >> (c ? 1 : 0), Hh = dp.height / sh;
@@ -343,50 +402,12 @@ __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict_
         out[k] = bi < 4 ? clip3i(0, maxv, out[k] + o) : out[k];
       }
     }
-    else if (type == 2) { // edge offset (sao.cc:336-424)
+    else if (type == 2) { // edge offset: SaoEoClass 0 horizontal, 1 vertical, 2 135 degrees, 3 45 degrees
       const int cl = (s0 >> 8) & 0xFF;
-      const int hx0 = cl == 1 ? 0 : (cl == 3 ? 1 : -1);
-      const int vy0 = cl == 0 ? 0 : -1;
-      // neighbour a of sample x is (x + hx0, yy + vy0), neighbour b is (x - hx0, yy - vy0)
-      const int ya = yy + vy0, yb = yy - vy0;
-      const bool rowa_ok = ya >= 0, rowb_ok = yb < Hh;
-      const int dya = (ya >> l2h) - cy, dyb = (yb >> l2h) - cy; // -1 / 0 and 0 / +1
-      auto perm = [&](int dy, int dx) -> bool { // may the neighbour CTB (dx, dy) be read?
-        const int k8 = (dy + 1) * 3 + (dx + 1);
-        const int bit = k8 < 4 ? k8 : k8 - 1;
-        return (dx | dy) == 0 || ((nbm >> bit) & 1);
-      };
-      const Pix* ra = reinterpret_cast<const Pix*>(plane + (size_t)(rowa_ok ? ya : yy) * pitch) + xs;
-      const Pix* rb = reinterpret_cast<const Pix*>(plane + (size_t)(rowb_ok ? yb : yy) * pitch) + xs;
-      Pix va[G], vb[G];
-      __builtin_memcpy(va, ra, G * sizeof(Pix));
-      __builtin_memcpy(vb, rb, G * sizeof(Pix));
-      // the sample left of / right of the group, on the side each row needs
-      const bool has_l = xs > 0, has_r = xs + G < W;
-      int ea = 0, eb = 0;
-      if (hx0 != 0) {
-        const bool a_left = hx0 < 0;
-        if (a_left ? has_l : has_r) ea = ra[a_left ? -1 : G];
-        if (a_left ? has_r : has_l) eb = rb[a_left ? G : -1];
-      }
-      const bool mid_ok = rowa_ok && rowb_ok && perm(dya, 0) && perm(dyb, 0);
-      // the first / last sample of the group may look into the CTB column to the left / right
-      const int dxl = ((xs - 1) >> l2w) - cx, dxr = ((xs + G) >> l2w) - cx;
-      const bool first_ok = rowa_ok && rowb_ok && (hx0 == 0 || has_l) && perm(hx0 < 0 ? dya : dyb, hx0 == 0 ? 0 : dxl) && perm(hx0 < 0 ? dyb : dya, 0);
-      const bool last_ok = rowa_ok && rowb_ok && (hx0 == 0 || has_r) && perm(hx0 > 0 ? dya : dyb, hx0 == 0 ? 0 : dxr) && perm(hx0 > 0 ? dyb : dya, 0);
-#pragma unroll
-      for (int k = 0; k < G; k++) {
-        // a = row a shifted by hx0, b = row b shifted by -hx0
-        const int am = k > 0 ? (int)va[k > 0 ? k - 1 : 0] : ea, ap = k < G - 1 ? (int)va[k < G - 1 ? k + 1 : 0] : ea;
-        const int bm = k > 0 ? (int)vb[k > 0 ? k - 1 : 0] : eb, bp = k < G - 1 ? (int)vb[k < G - 1 ? k + 1 : 0] : eb;
-        const int a = hx0 < 0 ? am : (hx0 > 0 ? ap : (int)va[k]);
-        const int b = hx0 < 0 ? bp : (hx0 > 0 ? bm : (int)vb[k]);
-        const bool ok = k == 0 ? first_ok : (k == G - 1 ? last_ok : mid_ok);
-        const int e = isign_(out[k] - a) + isign_(out[k] - b);
-        const int idx = e < 0 ? e + 2 : e + 1; // -2,-1,1,2 -> 0,1,2,3
-        const int o = (int)(int8_t)(offs >> (8 * (idx & 3)));
-        out[k] = (ok && e != 0) ? clip3i(0, maxv, out[k] + o) : out[k];
-      }
+      if (cl == 0) sao_edge_group<Pix, -1, 0, G>(plane, pitch, xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv, cur, out);
+      else if (cl == 1) sao_edge_group<Pix, 0, -1, G>(plane, pitch, xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv, cur, out);
+      else if (cl == 2) sao_edge_group<Pix, -1, -1, G>(plane, pitch, xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv, cur, out);
+      else sao_edge_group<Pix, 1, -1, G>(plane, pitch, xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv, cur, out);
     }
   }
   else {
@@ -450,9 +471,12 @@ extern "C" int hm_launch_sao_paste(const hm_dev_pic* d_pics, int n_pics, int max
                                    hipStream_t s)
 {
   if (n_pics <= 0) return HM_OK;
-  const long items = (long)((max_w + 7) / 8) * max_h;
-  const int blocks = (int)((items + 255) / 256);
-  if (bit_depth > 8) hipLaunchKernelGGL(k_sao_paste<uint16_t>, dim3(blocks, n_pics, 3), dim3(256), 0, s, d_pics, apply_sao);
-  else hipLaunchKernelGGL(k_sao_paste<uint8_t>, dim3(blocks, n_pics, 3), dim3(256), 0, s, d_pics, apply_sao);
+  // 64 x 8-sample tiles of the three planes (chroma at most as large as luma); one wave per tile, four per block
+  const long luma = (long)((max_w + 63) / 64) * ((max_h + 7) / 8);
+  const int cwm = (max_w + 1) / 2;
+  const long chroma = (long)((cwm + 63) / 64) * ((max_h + 7) / 8); // 4:2:2 height bound
+  const int blocks = (int)((luma + 2 * chroma + 3) / 4);
+  if (bit_depth > 8) hipLaunchKernelGGL(k_sao_paste<uint16_t>, dim3(blocks, n_pics), dim3(256), 0, s, d_pics, apply_sao);
+  else hipLaunchKernelGGL(k_sao_paste<uint8_t>, dim3(blocks, n_pics), dim3(256), 0, s, d_pics, apply_sao);
   return hm_check_hip(hipGetLastError(), "k_sao_paste launch");
 }

@@ -28,6 +28,10 @@ struct hm_dev_pic {
   int32_t log2_ctb;
   int32_t ctb_w, ctb_h;
   int32_t flags;            // hm_pic.flags
+  int32_t cb_qp_offset, cr_qp_offset; // pps offsets (chroma deblocking QpC)
+  // sections of the command stream, resolved on the host so that the filter kernels need no dependent load of the header
+  const hm_slice* slices;
+  const hm_ctb* ctbs;
 };
 
 #endif
