@@ -242,9 +242,26 @@ bool HeifFile::parse_iprp(const uint8_t* p, size_t n, HeifError& err)
             ip.colr.full_range = (int)(d.u(1) >> 7);
           }
         }
-        else if (pb.type == "irot") { ip.has_irot = true; ip.irot_angle = (int)(d.u(1) & 3); }
-        else if (pb.type == "imir") ip.has_imir = true;
-        else if (pb.type == "clap") ip.has_clap = true;
+        else if (pb.type == "irot") {
+          ip.has_irot = true;
+          ip.irot_angle = (int)(d.u(1) & 3);
+          Transform t; t.kind = Transform::Rotate; t.angle = ip.irot_angle * 90;
+          ip.transforms.push_back(t);
+        }
+        else if (pb.type == "imir") {
+          ip.has_imir = true;
+          Transform t; t.kind = Transform::Mirror; t.horizontal = (int)(d.u(1) & 1);
+          ip.transforms.push_back(t);
+        }
+        else if (pb.type == "clap") {
+          ip.has_clap = true;
+          Transform t; t.kind = Transform::CleanAperture;
+          t.width_n = (uint32_t)d.u(4); t.width_d = (uint32_t)d.u(4);
+          t.height_n = (uint32_t)d.u(4); t.height_d = (uint32_t)d.u(4);
+          t.hoff_n = (int32_t)(uint32_t)d.u(4); t.hoff_d = (uint32_t)d.u(4);
+          t.voff_n = (int32_t)(uint32_t)d.u(4); t.voff_d = (uint32_t)d.u(4);
+          ip.transforms.push_back(t);
+        }
         else if (pb.type == "auxC") { d.skip(4); ip.aux_type = d.cstr(); }
         else if (pb.type == "hvcC") {
           HvcC& h = ip.hvcc;

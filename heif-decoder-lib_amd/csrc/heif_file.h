@@ -28,12 +28,24 @@ struct HvcC {
   std::vector<std::vector<uint8_t>> nals; // parameter-set NAL units in order
 };
 
+// One transformative item property; a decoder applies them in the order of the item's ipma associations
+// (context.cc:1957-2020 of the reference).
+struct Transform {
+  enum Kind { Rotate = 1, Mirror = 2, CleanAperture = 3 } kind;
+  int angle = 0;            // irot: counter-clockwise, degrees (0, 90, 180, 270)  (box.cc:3590-3600)
+  int horizontal = 0;       // imir: axis & 1 -> heif_transform_mirror_direction_horizontal (box.cc:3626-3639)
+  uint32_t width_n = 0, width_d = 1, height_n = 0, height_d = 1; // clap (box.cc:3676-3716)
+  int32_t hoff_n = 0; uint32_t hoff_d = 1;
+  int32_t voff_n = 0; uint32_t voff_d = 1;
+};
+
 struct ItemProps {
   HvcC hvcc;
   int ispe_width = 0, ispe_height = 0;
   NclxProfile colr;
-  bool has_irot = false, has_imir = false, has_clap = false; // geometric transforms (not on the GPU path yet)
+  bool has_irot = false, has_imir = false, has_clap = false;
   int irot_angle = 0;
+  std::vector<Transform> transforms; // irot / imir / clap in association order
   std::string aux_type;
 };
 

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "heif_file.h"
+#include "clap.h"
 #include "hm_internal.h"
 #include "hm_stream.h"
 
@@ -26,13 +27,103 @@ namespace {
 
 struct DevMem {
   void* p = nullptr;
+  DevMem() = default;
+  DevMem(const DevMem&) = delete;
+  DevMem& operator=(const DevMem&) = delete;
   int alloc(size_t n)
   {
     p = hm_pool_device_alloc(n);
     return p ? HM_OK : HM_ERR_NO_DEVICE;
   }
+  void swap(DevMem& o) { void* t = p; p = o.p; o.p = t; }
   ~DevMem() { if (p) hm_pool_device_free(p); }
 };
+
+// one plane of the decoded image on the device, libheif plane layout (pixelimage.cc:139-218)
+struct DevPlane {
+  DevMem mem;
+  int w = 0, h = 0, stride = 0; // samples, samples, bytes
+};
+int mem_rows(int hgt) { const int r = (hgt + 1) & ~1; return r < 64 ? 64 : r; }
+size_t plane_bytes(const DevPlane& p) { return (size_t)p.stride * mem_rows(p.h); }
+int alloc_plane(DevPlane& p, int w, int h, int bps)
+{
+  p.w = w; p.h = h; p.stride = hm_plane_stride(w, bps);
+  return p.mem.alloc(plane_bytes(p));
+}
+
+// Transformative properties of the item, applied to the decoded YCbCr planes in association order
+// (context.cc:1957-2020): irot -> rotate_ccw, imir -> mirror_inplace, clap -> crop.
+// `retired` keeps the replaced buffers alive until the caller has synchronised the stream (the pool may hand a freed
+// buffer to another thread at once).
+int apply_transforms(const std::vector<hm::Transform>& list, DevPlane (&P)[3], int& img_w, int& img_h, int chroma, int bd, hipStream_t s,
+                     std::vector<std::unique_ptr<DevMem>>& retired)
+{
+  auto retire = [&](DevMem& m) { retired.emplace_back(new DevMem()); retired.back()->swap(m); };
+  const int bps = bd > 8 ? 2 : 1;
+  for (const hm::Transform& t : list) {
+    if (t.kind == hm::Transform::Rotate) {
+      if (t.angle == 0) continue;
+      // a 4:2:2 image rotated by 90 / 270 degrees keeps its chroma tag while its chroma planes swap their sizes
+      // (pixelimage.cc:552-586): the reference's later colour ops then read outside the planes - refuse loudly
+      if (chroma == 2 && t.angle != 180) return hm_fail(HM_ERR_UNSUPPORTED, "irot %d on a 4:2:2 image is undefined in the reference", t.angle);
+      for (int c = 0; c < 3; c++) {
+        DevPlane n;
+        const bool sw = t.angle != 180;
+        int rc = alloc_plane(n, sw ? P[c].h : P[c].w, sw ? P[c].w : P[c].h, bps);
+        if (rc) return rc;
+        if ((rc = hm_launch_rotate_ccw(bps, t.angle, P[c].mem.p, P[c].stride, P[c].w, P[c].h, n.mem.p, n.stride, s))) return rc;
+        P[c].mem.swap(n.mem); P[c].w = n.w; P[c].h = n.h; P[c].stride = n.stride;
+        retire(n.mem);
+      }
+      if (t.angle != 180) { const int tmp = img_w; img_w = img_h; img_h = tmp; }
+    }
+    else if (t.kind == hm::Transform::Mirror) {
+      if (bd != 8) return hm_fail(HM_ERR_UNSUPPORTED, "Can currently only mirror images with 8 bits per pixel"); // pixelimage.cc:748-752
+      for (int c = 0; c < 3; c++) {
+        DevPlane n;
+        int rc = alloc_plane(n, P[c].w, P[c].h, bps);
+        if (rc) return rc;
+        if ((rc = hm_launch_mirror(P[c].mem.p, P[c].stride, P[c].w, P[c].h, t.horizontal, n.mem.p, n.stride, s))) return rc;
+        P[c].mem.swap(n.mem);
+        retire(n.mem);
+      }
+    }
+    else {
+      if (t.width_n > 0x7FFFFFFFu || t.width_d > 0x7FFFFFFFu || t.height_n > 0x7FFFFFFFu || t.height_d > 0x7FFFFFFFu ||
+          t.hoff_d > 0x7FFFFFFFu || t.voff_d > 0x7FFFFFFFu)
+        return hm_fail(HM_ERR_BITSTREAM, "clap: Exceeded supported value range."); // box.cc:3692-3701
+      hm::Clap c;
+      c.width = hm::Fraction((int32_t)t.width_n, (int32_t)t.width_d);
+      c.height = hm::Fraction((int32_t)t.height_n, (int32_t)t.height_d);
+      c.hoff = hm::Fraction(t.hoff_n, (int32_t)t.hoff_d);
+      c.voff = hm::Fraction(t.voff_n, (int32_t)t.voff_d);
+      if (!c.width.valid() || !c.height.valid() || !c.hoff.valid() || !c.voff.valid())
+        return hm_fail(HM_ERR_BITSTREAM, "clap: invalid fractional number"); // box.cc:3709-3713
+      int left = c.left_rounded(img_w), right = c.right_rounded(img_w), top = c.top_rounded(img_h), bottom = c.bottom_rounded(img_h);
+      if (left < 0) left = 0;
+      if (top < 0) top = 0;
+      if (right >= img_w) right = img_w - 1;
+      if (bottom >= img_h) bottom = img_h - 1;
+      if (left > right || top > bottom) return hm_fail(HM_ERR_BITSTREAM, "Invalid clean aperture"); // context.cc:2004-2008
+      for (int k = 0; k < 3; k++) { // HeifPixelImage::crop, pixelimage.cc:797-888: plane rectangle by integer scaling
+        const int pl = (int)((int64_t)left * P[k].w / img_w), pr = (int)((int64_t)right * P[k].w / img_w);
+        const int pt = (int)((int64_t)top * P[k].h / img_h), pb = (int)((int64_t)bottom * P[k].h / img_h);
+        DevPlane n;
+        int rc = alloc_plane(n, pr - pl + 1, pb - pt + 1, bps);
+        if (rc) return rc;
+        const hipError_t e = hipMemcpy2DAsync(n.mem.p, n.stride, (const uint8_t*)P[k].mem.p + (size_t)pt * P[k].stride + (size_t)pl * bps,
+                                              P[k].stride, (size_t)n.w * bps, n.h, hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return hm_check_hip(e, "clap copy");
+        P[k].mem.swap(n.mem); P[k].w = n.w; P[k].h = n.h; P[k].stride = n.stride;
+        retire(n.mem);
+      }
+      img_w = right - left + 1;
+      img_h = bottom - top + 1;
+    }
+  }
+  return HM_OK;
+}
 
 struct Blob {
   uint8_t* p = nullptr;
@@ -100,6 +191,19 @@ int hm_file_image_info(const hm_file* f, uint32_t id, hm_image_info* info)
   info->bit_depth = first->props.hvcc.bit_depth_luma;
   info->chroma = first->props.hvcc.chroma_format;
   info->has_transforms = (it->props.has_irot || it->props.has_imir || it->props.has_clap) ? 1 : 0;
+  info->coded_width = info->width; info->coded_height = info->height;
+  // the size an image handle reports (context.cc:810-838): every clap sets it to the rounded aperture size,
+  // a 90 / 270 degree irot swaps it, in property order
+  for (const hm::Transform& t : it->props.transforms) {
+    if (t.kind == hm::Transform::CleanAperture && t.width_d && t.height_d && t.width_n <= 0x7FFFFFFFu && t.width_d <= 0x7FFFFFFFu &&
+        t.height_n <= 0x7FFFFFFFu && t.height_d <= 0x7FFFFFFFu) {
+      info->width = hm::Fraction((int32_t)t.width_n, (int32_t)t.width_d).round();
+      info->height = hm::Fraction((int32_t)t.height_n, (int32_t)t.height_d).round();
+    }
+    else if (t.kind == hm::Transform::Rotate && (t.angle == 90 || t.angle == 270)) {
+      const int32_t tmp = info->width; info->width = info->height; info->height = tmp;
+    }
+  }
   return HM_OK;
 }
 
@@ -131,9 +235,6 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
   std::memset(out, 0, sizeof(*out));
   const hm::Item* it = f->file.item(id);
   if (!it) return hm_fail(HM_ERR_INVALID_ARG, "no item %u", id);
-  if (it->props.has_irot || it->props.has_imir || it->props.has_clap)
-    if (!params->ignore_transformations)
-      return hm_fail(HM_ERR_UNSUPPORTED, "irot/imir/clap transformations are not on the GPU path yet (set ignore_transformations)");
   hm::HeifError err;
 
   // ---- which coded pictures, where ----
@@ -210,17 +311,16 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
   else { canvas_w = tile_w; canvas_h = tile_h; }
   const int bps = bd > 8 ? 2 : 1;
   const int cw = (canvas_w + 1) / 2, chh = chroma == 1 ? (canvas_h + 1) / 2 : canvas_h;
-  const int ys = hm_plane_stride(canvas_w, bps), cs = hm_plane_stride(cw, bps);
-  auto mem_rows = [](int hgt) { int r = (hgt + 1) & ~1; return r < 64 ? 64 : r; };
-  const size_t ybytes = (size_t)ys * mem_rows(canvas_h), cbytes = (size_t)cs * mem_rows(chh);
 
   hipStream_t s = (hipStream_t)params->stream;
-  DevMem dy, dcb, dcr, dout;
+  DevPlane P[3];
+  DevMem dout;
+  std::vector<std::unique_ptr<DevMem>> retired;
   int rc;
-  if ((rc = dy.alloc(ybytes)) || (rc = dcb.alloc(cbytes)) || (rc = dcr.alloc(cbytes))) return rc;
+  if ((rc = alloc_plane(P[0], canvas_w, canvas_h, bps)) || (rc = alloc_plane(P[1], cw, chh, bps)) || (rc = alloc_plane(P[2], cw, chh, bps))) return rc;
   // a grid canvas the tiles do not cover completely stays zero like a fresh HeifPixelImage? the
   // reference leaves it uninitialised; tiles must cover the output (context.cc:2321-2337)
-  hipMemsetAsync(dy.p, 0, ybytes, s); hipMemsetAsync(dcb.p, 0, cbytes, s); hipMemsetAsync(dcr.p, 0, cbytes, s);
+  for (int c = 0; c < 3; c++) hipMemsetAsync(P[c].mem.p, 0, plane_bytes(P[c]), s);
 
   hm_batch* batch = nullptr;
   if ((rc = hm_batch_create(&batch))) return rc;
@@ -237,8 +337,7 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
     if (i == 0) native = tp;
     hm_tile_dest d;
     std::memset(&d, 0, sizeof(d));
-    d.plane[0] = dy.p; d.plane[1] = dcb.p; d.plane[2] = dcr.p;
-    d.pitch[0] = ys; d.pitch[1] = cs; d.pitch[2] = cs;
+    for (int c = 0; c < 3; c++) { d.plane[c] = P[c].mem.p; d.pitch[c] = P[c].stride; }
     d.canvas_width = canvas_w; d.canvas_height = canvas_h;
     d.x0 = tiles[i].x0; d.y0 = tiles[i].y0;
     // the range rescale belongs to the grid paste only (context.cc:2504-2528)
@@ -249,46 +348,49 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
   if ((rc = hm_batch_upload(batch, s))) return rc;
   if ((rc = hm_batch_execute(batch, 3, s))) return rc;
 
-  out->width = canvas_w; out->height = canvas_h; out->bit_depth = bd; out->chroma = chroma;
+  // ---- transformative item properties on the decoded planes (context.cc:1957-2020) ----
+  int img_w = canvas_w, img_h = canvas_h;
+  if (!params->ignore_transformations && !it->props.transforms.empty())
+    if ((rc = apply_transforms(it->props.transforms, P, img_w, img_h, chroma, bd, s, retired))) return rc;
+
+  out->width = img_w; out->height = img_h; out->bit_depth = bd; out->chroma = chroma;
   // a grid canvas carries no nclx (context.cc:2250-2276); a single image keeps its own
   out->has_nclx = is_grid ? 0 : 1;
   out->primaries = native.primaries; out->transfer = native.transfer; out->matrix = native.matrix; out->full_range = native.full_range;
   hipError_t e;
   if (params->out_format == 0) { // native planar YCbCr
     out->out_format = 0;
-    const size_t sz[3] = {ybytes, cbytes, cbytes};
-    void* src[3] = {dy.p, dcb.p, dcr.p};
     for (int c = 0; c < 3; c++) {
-      out->plane[c] = (uint8_t*)hm_pool_pinned_alloc(sz[c]);
+      const size_t sz = plane_bytes(P[c]);
+      out->plane[c] = (uint8_t*)hm_pool_pinned_alloc(sz);
       if (!out->plane[c]) { hm_decoded_free(out); return hm_fail(HM_ERR_NOMEM, "out of memory"); }
-      out->stride[c] = c == 0 ? ys : cs;
-      e = hipMemcpyAsync(out->plane[c], src[c], sz[c], hipMemcpyDeviceToHost, s);
+      out->stride[c] = P[c].stride;
+      e = hipMemcpyAsync(out->plane[c], P[c].mem.p, sz, hipMemcpyDeviceToHost, s);
       if (e != hipSuccess) { hm_decoded_free(out); return hm_check_hip(e, "D2H"); }
+      out->plane_width[c] = P[c].w; out->plane_height[c] = P[c].h;
     }
-    out->plane_width[0] = canvas_w; out->plane_height[0] = canvas_h;
-    out->plane_width[1] = out->plane_width[2] = cw; out->plane_height[1] = out->plane_height[2] = chh;
   }
   else {
     hm_colour_desc cd;
     std::memset(&cd, 0, sizeof(cd));
-    cd.width = canvas_w; cd.height = canvas_h; cd.bit_depth = bd; cd.chroma = chroma;
+    cd.width = img_w; cd.height = img_h; cd.bit_depth = bd; cd.chroma = chroma;
     cd.has_nclx = out->has_nclx; cd.matrix = native.matrix; cd.primaries = native.primaries; cd.full_range = native.full_range;
     cd.out_format = params->out_format;
     cd.chroma_upsampling = params->chroma_upsampling;
     const int obpp = hm_out_bytes_per_pixel(params->out_format);
     if (obpp < 0) return obpp;
-    cd.y_stride = ys; cd.cb_stride = cs; cd.cr_stride = cs;
-    cd.out_stride = hm_plane_stride(canvas_w, obpp);
-    const size_t obytes = (size_t)cd.out_stride * mem_rows(canvas_h);
+    cd.y_stride = P[0].stride; cd.cb_stride = P[1].stride; cd.cr_stride = P[2].stride;
+    cd.out_stride = hm_plane_stride(img_w, obpp);
+    const size_t obytes = (size_t)cd.out_stride * mem_rows(img_h);
     if ((rc = dout.alloc(obytes))) return rc;
-    if ((rc = hm_colour_convert(&cd, dy.p, dcb.p, dcr.p, dout.p, s))) return rc;
+    if ((rc = hm_colour_convert(&cd, P[0].mem.p, P[1].mem.p, P[2].mem.p, dout.p, s))) return rc;
     out->out_format = params->out_format;
     out->stride[0] = cd.out_stride;
-    out->plane_width[0] = canvas_w; out->plane_height[0] = canvas_h;
-    if (params->ext_dst && params->ext_dst_stride >= (uint32_t)(canvas_w * obpp) &&
-        (size_t)params->ext_dst_len >= (size_t)params->ext_dst_stride * (size_t)canvas_h) {
+    out->plane_width[0] = img_w; out->plane_height[0] = img_h;
+    if (params->ext_dst && params->ext_dst_stride >= (uint32_t)(img_w * obpp) &&
+        (size_t)params->ext_dst_len >= (size_t)params->ext_dst_stride * (size_t)img_h) {
       // caller-provided destination (fork API heif_decoding_options_add_external_dest)
-      e = hipMemcpy2DAsync(params->ext_dst, params->ext_dst_stride, dout.p, cd.out_stride, (size_t)canvas_w * obpp, canvas_h,
+      e = hipMemcpy2DAsync(params->ext_dst, params->ext_dst_stride, dout.p, cd.out_stride, (size_t)img_w * obpp, img_h,
                            hipMemcpyDeviceToHost, s);
       if (e != hipSuccess) return hm_check_hip(e, "D2H ext_dst");
       out->used_ext_dst = 1;

@@ -22,6 +22,9 @@ int hm_launch_colour_float(const hm_colour_desc* d, const float coef[4], int mod
                            const void* cb, const void* cr, void* out, hipStream_t s);
 int hm_launch_upsample_bilinear(int bit_depth, int v420, const void* in, int in_stride, void* out, int out_stride,
                                 int w, int h, hipStream_t s);
+int hm_launch_rotate_ccw(int bytes_per_sample, int angle, const void* in, int in_stride, int w, int h, void* out,
+                         int out_stride, hipStream_t s);
+int hm_launch_mirror(const void* in, int in_stride, int w, int h, int horizontal, void* out, int out_stride, hipStream_t s);
 
 // devpool.cpp: size-bucketed cache of device / pinned-host allocations (hipMalloc + hipFree cost more
 // than the kernels of a 12 MP image)

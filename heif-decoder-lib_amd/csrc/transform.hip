@@ -1,0 +1,66 @@
+// transform.hip — geometric item transformations on the device planes (gfx950):
+//   irot  HeifPixelImage::rotate_ccw      (pixelimage.cc:539-740; every plane on its own, 8- and 16-bit samples)
+//   imir  HeifPixelImage::mirror_inplace  (pixelimage.cc:743-794; the reference only accepts 8-bit planes)
+// (clap is a 2-D device copy: pixelimage.cc:797-888.)  One lane per output sample group; HBM-bound byte moves.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hm_internal.h"
+
+namespace {
+
+// out(y, x) for an input plane of w x h samples (strides in samples):
+//   90 : out[y][x] = in[x][w - 1 - y]        out is h wide, w high
+//   180: out[y][x] = in[h - 1 - y][w - 1 - x]
+//   270: out[y][x] = in[h - 1 - x][y]        out is h wide, w high
+template <typename Pix, int ANGLE>
+__global__ __launch_bounds__(256) void k_rotate_ccw(const Pix* __restrict__ in, int is, int w, int h, Pix* __restrict__ out, int os)
+{
+  const int ow = ANGLE == 180 ? w : h, oh = ANGLE == 180 ? h : w;
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= ow || y >= oh) return;
+  Pix v;
+  if (ANGLE == 90) v = in[(size_t)x * is + (w - 1 - y)];
+  else if (ANGLE == 180) v = in[(size_t)(h - 1 - y) * is + (w - 1 - x)];
+  else v = in[(size_t)(h - 1 - x) * is + y];
+  out[(size_t)y * os + x] = v;
+}
+
+// horizontal: out[y][x] = in[y][w - 1 - x]; vertical: out[y][x] = in[h - 1 - y][x]
+__global__ __launch_bounds__(256) void k_mirror(const uint8_t* __restrict__ in, int is, int w, int h, int horizontal,
+                                                uint8_t* __restrict__ out, int os)
+{
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= w || y >= h) return;
+  out[(size_t)y * os + x] = horizontal ? in[(size_t)y * is + (w - 1 - x)] : in[(size_t)(h - 1 - y) * is + x];
+}
+
+} // namespace
+
+// one plane; strides in bytes; angle 90 / 180 / 270 (counter-clockwise)
+extern "C" int hm_launch_rotate_ccw(int bytes_per_sample, int angle, const void* in, int in_stride, int w, int h, void* out,
+                                    int out_stride, hipStream_t s)
+{
+  if (w <= 0 || h <= 0) return HM_OK;
+  const int ow = angle == 180 ? w : h, oh = angle == 180 ? h : w;
+  const dim3 grid((ow + 63) / 64, (oh + 3) / 4), block(256);
+#define HM_ROT(PIX, A) hipLaunchKernelGGL((k_rotate_ccw<PIX, A>), grid, block, 0, s, (const PIX*)in, in_stride / (int)sizeof(PIX), w, h, (PIX*)out, out_stride / (int)sizeof(PIX))
+  if (bytes_per_sample == 1) {
+    if (angle == 90) HM_ROT(uint8_t, 90); else if (angle == 180) HM_ROT(uint8_t, 180); else if (angle == 270) HM_ROT(uint8_t, 270);
+    else return hm_fail(HM_ERR_INVALID_ARG, "rotation %d", angle);
+  }
+  else {
+    if (angle == 90) HM_ROT(uint16_t, 90); else if (angle == 180) HM_ROT(uint16_t, 180); else if (angle == 270) HM_ROT(uint16_t, 270);
+    else return hm_fail(HM_ERR_INVALID_ARG, "rotation %d", angle);
+  }
+#undef HM_ROT
+  return hm_check_hip(hipGetLastError(), "k_rotate_ccw launch");
+}
+
+extern "C" int hm_launch_mirror(const void* in, int in_stride, int w, int h, int horizontal, void* out, int out_stride, hipStream_t s)
+{
+  if (w <= 0 || h <= 0) return HM_OK;
+  const dim3 grid((w + 63) / 64, (h + 3) / 4), block(256);
+  hipLaunchKernelGGL(k_mirror, grid, block, 0, s, (const uint8_t*)in, in_stride, w, h, horizontal, (uint8_t*)out, out_stride);
+  return hm_check_hip(hipGetLastError(), "k_mirror launch");
+}

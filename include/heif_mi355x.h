@@ -164,6 +164,9 @@ typedef struct hm_image_info {
   int32_t bit_depth, chroma;   /* from the (first tile's) hvcC                                   */
   int32_t is_grid, grid_rows, grid_cols, tile_width, tile_height;
   int32_t has_transforms;      /* irot / imir / clap present on the item                         */
+  int32_t coded_width, coded_height; /* size before the transformative properties (ispe / grid output size);
+                                        width / height above are what heif_image_handle_get_width/height report
+                                        (context.cc:810-838: clap size, swapped by a 90 / 270 degree irot)       */
 } hm_image_info;
 
 typedef struct hm_decode_params {

@@ -95,6 +95,15 @@ uint64_t orc_fnv1a64(const uint8_t* p, size_t n, uint64_t h);
 /* hash `rows` tight rows of `row_bytes` from a strided plane */
 uint64_t orc_fnv1a64_rows(const uint8_t* p, int stride, int row_bytes, int rows, uint64_t h);
 
+
+/* transformative item properties, one plane at a time (pixelimage.cc:539-888, box.cc:51-152, 3771-3814) */
+void orc_rotate_ccw_plane(const uint8_t* in, int is, int w, int h, int bps, int angle, uint8_t* out, int os);
+void orc_mirror_plane(uint8_t* data, int stride, int w, int h, int horizontal);
+int orc_clap_rect(const int64_t clap[8], int img_w, int img_h, int rect[4]);
+void orc_clap_size(const int64_t clap[8], int size[2]);
+void orc_crop_plane(const uint8_t* in, int is, int pw, int ph, int bps, int img_w, int img_h, const int rect[4], uint8_t* out, int os,
+                    int out_wh[2]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -392,3 +392,125 @@ void orc_upsample_bilinear_420_u16(const uint16_t* in, int is, int w, int h, uin
 ORC_BILINEAR_422(orc_upsample_bilinear_422, uint8_t)
 ORC_BILINEAR_422(orc_upsample_bilinear_422_u16, uint16_t)
 
+
+/* ------------------------------------------------------------------------------------------------
+ * Transformative item properties on one plane (test oracle for the device kernels of transform.hip).
+ * Restated from HeifPixelImage::rotate_ccw / mirror_inplace / crop (pixelimage.cc:539-888) and the
+ * Fraction / Box_clap arithmetic (box.cc:51-152, 3771-3814).  No reference vectors exist for these (libheif
+ * itself cannot be built here): parity of this part is "restatement only".
+ * ---------------------------------------------------------------------------------------------- */
+/* in: w x h samples of bps bytes; out: (angle 180: w x h, else h x w); strides in bytes */
+void orc_rotate_ccw_plane(const uint8_t* in, int is, int w, int h, int bps, int angle, uint8_t* out, int os)
+{
+  if (angle == 270) {
+    for (long long x = 0; x < h; x++)
+      for (long long y = 0; y < w; y++)
+        for (int b = 0; b < bps; b++) out[y * os + bps * x + b] = in[(h - 1 - x) * is + bps * y + b];
+  }
+  else if (angle == 180) {
+    for (long long y = 0; y < h; y++)
+      for (long long x = 0; x < w; x++)
+        for (int b = 0; b < bps; b++) out[y * os + bps * x + b] = in[(h - 1 - y) * is + bps * (w - 1 - x) + b];
+  }
+  else if (angle == 90) {
+    for (long long x = 0; x < h; x++)
+      for (long long y = 0; y < w; y++)
+        for (int b = 0; b < bps; b++) out[y * os + bps * x + b] = in[x * is + bps * (w - 1 - y) + b];
+  }
+}
+
+/* 8-bit planes only (pixelimage.cc:748-752), in place */
+void orc_mirror_plane(uint8_t* data, int stride, int w, int h, int horizontal)
+{
+  if (horizontal) {
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < w / 2; x++) {
+        uint8_t t = data[y * stride + x];
+        data[y * stride + x] = data[y * stride + w - 1 - x];
+        data[y * stride + w - 1 - x] = t;
+      }
+  }
+  else {
+    for (int y = 0; y < h / 2; y++)
+      for (int x = 0; x < w; x++) {
+        uint8_t t = data[y * stride + x];
+        data[y * stride + x] = data[(h - 1 - y) * stride + x];
+        data[(h - 1 - y) * stride + x] = t;
+      }
+  }
+}
+
+typedef struct { int32_t n, d; } orc_frac;
+static orc_frac frac32(int32_t n, int32_t d) /* box.cc:51-69 */
+{
+  orc_frac f = {n, d};
+  while (f.d > 0x10000 || f.d < -0x10000) { f.n /= 2; f.d /= 2; }
+  while (f.d > 1 && (f.n > 0x10000 || f.n < -0x10000)) { f.n /= 2; f.d /= 2; }
+  return f;
+}
+static orc_frac frac64(int64_t n, int64_t d) /* box.cc:79-89 */
+{
+  while (n < INT32_MIN || n > INT32_MAX || d < INT32_MIN || d > INT32_MAX) {
+    n = (n + (n >= 0 ? 1 : -1)) / 2;
+    d = (d + (d >= 0 ? 1 : -1)) / 2;
+  }
+  orc_frac f = {(int32_t)n, (int32_t)d};
+  return f;
+}
+static orc_frac frac_add(orc_frac a, orc_frac b)
+{
+  if (a.d == b.d) return frac64((int64_t)a.n + b.n, a.d);
+  return frac64((int64_t)a.n * b.d + (int64_t)b.n * a.d, (int64_t)a.d * b.d);
+}
+static orc_frac frac_sub(orc_frac a, orc_frac b)
+{
+  if (a.d == b.d) return frac64((int64_t)a.n - b.n, a.d);
+  return frac64((int64_t)a.n * b.d - (int64_t)b.n * a.d, (int64_t)a.d * b.d);
+}
+static orc_frac frac_addi(orc_frac a, int v) { return frac64(a.n + v * (int64_t)a.d, a.d); }
+static orc_frac frac_divi(orc_frac a, int v) { return frac64(a.n, (int64_t)a.d * v); }
+static int32_t frac_round(orc_frac a) { return (int32_t)((a.n + (int64_t)a.d / 2) / a.d); }
+
+/* clap = {width_n, width_d, height_n, height_d, hoff_n, hoff_d, voff_n, voff_d}; rect = left, right, top, bottom
+ * after the clamping of context.cc:1999-2003.  Returns 0, or -1 for an invalid aperture (context.cc:2004-2008),
+ * -2 for an invalid fraction. */
+int orc_clap_rect(const int64_t clap[8], int img_w, int img_h, int rect[4])
+{
+  for (int i = 0; i < 8; i++)
+    if (i != 4 && i != 6 && (clap[i] < 0 || clap[i] > INT32_MAX)) return -2;
+  const orc_frac cw = frac32((int32_t)clap[0], (int32_t)clap[1]), ch = frac32((int32_t)clap[2], (int32_t)clap[3]);
+  const orc_frac ho = frac32((int32_t)clap[4], (int32_t)clap[5]), vo = frac32((int32_t)clap[6], (int32_t)clap[7]);
+  if (!cw.d || !ch.d || !ho.d || !vo.d) return -2;
+  const orc_frac pcx = frac_add(ho, frac32(img_w - 1, 2));
+  const orc_frac fl = frac_sub(pcx, frac_divi(frac_addi(cw, -1), 2));
+  int left = fl.n / fl.d;                                            /* round_down */
+  int right = frac_round(frac_addi(frac_addi(cw, -1), left));
+  const orc_frac pcy = frac_add(vo, frac32(img_h - 1, 2));
+  int top = frac_round(frac_sub(pcy, frac_divi(frac_addi(ch, -1), 2)));
+  int bottom = frac_round(frac_addi(frac_addi(ch, -1), top));
+  if (left < 0) left = 0;
+  if (top < 0) top = 0;
+  if (right >= img_w) right = img_w - 1;
+  if (bottom >= img_h) bottom = img_h - 1;
+  if (left > right || top > bottom) return -1;
+  rect[0] = left; rect[1] = right; rect[2] = top; rect[3] = bottom;
+  return 0;
+}
+/* rounded aperture size (Box_clap::get_width_rounded / get_height_rounded) */
+void orc_clap_size(const int64_t clap[8], int size[2])
+{
+  size[0] = frac_round(frac32((int32_t)clap[0], (int32_t)clap[1]));
+  size[1] = frac_round(frac32((int32_t)clap[2], (int32_t)clap[3]));
+}
+
+/* HeifPixelImage::crop for one plane of pw x ph samples inside an img_w x img_h image; writes the plane rectangle
+ * size to out_wh and copies the rows */
+void orc_crop_plane(const uint8_t* in, int is, int pw, int ph, int bps, int img_w, int img_h, const int rect[4], uint8_t* out, int os,
+                    int out_wh[2])
+{
+  const int pl = rect[0] * pw / img_w, pr = rect[1] * pw / img_w, pt = rect[2] * ph / img_h, pb = rect[3] * ph / img_h;
+  out_wh[0] = pr - pl + 1;
+  out_wh[1] = pb - pt + 1;
+  if (!out) return;
+  for (int y = pt; y <= pb; y++) memcpy(out + (size_t)(y - pt) * os, in + (size_t)y * is + (size_t)pl * bps, (size_t)(pr - pl + 1) * bps);
+}

@@ -40,7 +40,20 @@ def _colr(nclx):
     return _box(b"colr", b"nclx" + struct.pack(">HHHB", prim, trc, mat, 0x80 if full else 0))
 
 
-def write_heic(pictures, size, grid=None, chroma_format=1, bit_depth=8, colr=None, sizes=None):
+def _transform_box(t):
+    """('irot', quarter_turns_ccw) | ('imir', axis) | ('clap', (wn, wd, hn, hd, hon, hod, von, vod))"""
+    kind, v = t
+    if kind == "irot":
+        return _box(b"irot", bytes([v & 3]))
+    if kind == "imir":
+        return _box(b"imir", bytes([v & 1]))
+    if kind == "clap":
+        wn, wd, hn, hd, hon, hod, von, vod = v
+        return _box(b"clap", struct.pack(">IIIIiIiI", wn, wd, hn, hd, hon, hod, von, vod))
+    raise ValueError(kind)
+
+
+def write_heic(pictures, size, grid=None, chroma_format=1, bit_depth=8, colr=None, sizes=None, transforms=None):
     """pictures: list of [len][NAL] strings (each with VPS/SPS/PPS first); size: (w,h) of one picture
     (sizes: optional per-picture override of the declared ispe).
     grid: None for a single image, or (rows, cols, out_w, out_h).  colr: optional per-tile nclx tuple."""
@@ -68,11 +81,14 @@ def write_heic(pictures, size, grid=None, chroma_format=1, bit_depth=8, colr=Non
         assoc[k + 1] = a
     primary = 1
     iref = b""
+    if grid is None and transforms:  # transformative properties of the single image, in order
+        assoc[1] += [0x8000 | prop(_transform_box(t)) for t in transforms]
     if grid is not None:
         rows, cols, ow, oh = grid
         gid = len(pictures) + 1
         items.append((gid, b"grid", bytes([0, 0, rows - 1, cols - 1]) + struct.pack(">HH", ow, oh)))
         assoc[gid] = [prop(_full(b"ispe", 0, 0, struct.pack(">II", ow, oh)))]
+        assoc[gid] += [0x8000 | prop(_transform_box(t)) for t in (transforms or [])]
         primary = gid
         iref = _full(b"iref", 0, 0, _box(b"dimg", struct.pack(">HH", gid, len(pictures)) +
                                          b"".join(struct.pack(">H", k + 1) for k in range(len(pictures)))))

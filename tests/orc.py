@@ -79,6 +79,47 @@ def upsample_bilinear(plane, w, h, bpp, chroma):
     return out, os_
 
 
+def transform_planes(planes, dims, img_w, img_h, bd, transforms):
+    """Apply ('irot', q) / ('imir', axis) / ('clap', 8-tuple) to [(buf, stride)] planes of sizes dims = [(w, h)] like
+    context.cc:1957-2020 does.  Returns (planes, dims, img_w, img_h)."""
+    o = load()
+    bps = 2 if bd > 8 else 1
+    planes, dims = list(planes), list(dims)
+    for kind, v in transforms:
+        if kind == "irot":
+            ang = (v & 3) * 90
+            if ang == 0:
+                continue
+            for c in range(3):
+                w, h = dims[c]
+                nw, nh = (w, h) if ang == 180 else (h, w)
+                out, os_ = alloc_plane(nw, nh, bps)
+                o.orc_rotate_ccw_plane(ptr(planes[c][0]), planes[c][1], w, h, bps, ang, ptr(out), os_)
+                planes[c], dims[c] = (out, os_), (nw, nh)
+            if ang != 180:
+                img_w, img_h = img_h, img_w
+        elif kind == "imir":
+            assert bd == 8
+            for c in range(3):
+                buf = planes[c][0].copy()
+                o.orc_mirror_plane(ptr(buf), planes[c][1], dims[c][0], dims[c][1], v & 1)
+                planes[c] = (buf, planes[c][1])
+        else:
+            clap = (C.c_int64 * 8)(*v)
+            rect = (C.c_int * 4)()
+            rc = o.orc_clap_rect(clap, img_w, img_h, rect)
+            if rc:
+                raise ValueError(f"clap invalid ({rc})")
+            for c in range(3):
+                wh = (C.c_int * 2)()
+                o.orc_crop_plane(ptr(planes[c][0]), planes[c][1], dims[c][0], dims[c][1], bps, img_w, img_h, rect, None, 0, wh)
+                out, os_ = alloc_plane(wh[0], wh[1], bps)
+                o.orc_crop_plane(ptr(planes[c][0]), planes[c][1], dims[c][0], dims[c][1], bps, img_w, img_h, rect, ptr(out), os_, wh)
+                planes[c], dims[c] = (out, os_), (wh[0], wh[1])
+            img_w, img_h = rect[1] - rect[0] + 1, rect[3] - rect[2] + 1
+    return planes, dims, img_w, img_h
+
+
 def fnv_rows(buf, stride, row_bytes, rows):
     return load().orc_fnv1a64_rows(ptr(buf), stride, row_bytes, rows, 0)
 

@@ -13,7 +13,7 @@ SURVEY_FNV_INIT = 1469598103934665603  # the survey's harness used this (truncat
 
 
 class ImageInfo(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in "width height bit_depth chroma is_grid grid_rows grid_cols tile_width tile_height has_transforms".split()]
+    _fields_ = [(n, C.c_int32) for n in "width height bit_depth chroma is_grid grid_rows grid_cols tile_width tile_height has_transforms coded_width coded_height".split()]
 
 
 class DecodeParams(C.Structure):
@@ -84,6 +84,7 @@ class HeifFile:
             planes.append(a)
         meta = {k: getattr(d, k) for k in "width height bit_depth chroma out_format has_nclx primaries transfer matrix full_range".split()}
         meta["stride"] = [d.stride[c] for c in range(3)]
+        meta["plane_size"] = [(d.plane_width[c], d.plane_height[c]) for c in range(3)]
         self.hm.hm_decoded_free(C.byref(d))
         return planes, meta
 
@@ -93,7 +94,7 @@ class HeifFile:
             self.h = C.c_void_p()
 
 
-def cpu_decode(hm, tiles, tile_w, tile_h, canvas_w, canvas_h, cols, is_grid, out_fmt, tile_colr=None, decoder="oracle", bilinear=False):
+def cpu_decode(hm, tiles, tile_w, tile_h, canvas_w, canvas_h, cols, is_grid, out_fmt, tile_colr=None, decoder="oracle", bilinear=False, transforms=None):
     """tiles: list of [len][NAL] strings.  Returns (rgb array, stride) following the reference flow."""
     o = orc.load()
     first = None
@@ -125,6 +126,10 @@ def cpu_decode(hm, tiles, tile_w, tile_h, canvas_w, canvas_h, cols, is_grid, out
                                         canvas_w, canvas_h, x0, y0, c, cf, bd, has, full, mat)
             assert rc == 0
     bd, cf = first["bd"], first["cf"]
+    if transforms:  # irot / imir / clap on the decoded planes, before the colour conversion (context.cc:1957-2020)
+        cw0 = (canvas_w + 1) // 2
+        ch0 = (canvas_h + 1) // 2 if cf == 1 else canvas_h
+        canv, _, canvas_w, canvas_h = orc.transform_planes(canv, [(canvas_w, canvas_h), (cw0, ch0), (cw0, ch0)], canvas_w, canvas_h, bd, transforms)
     has_nclx = 0 if is_grid else 1
     _, full, mat, prim = first["nclx"]
     obpp = {10: 3, 11: 4, 12: 6, 14: 6}[out_fmt]

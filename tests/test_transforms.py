@@ -1,0 +1,130 @@
+"""Transformative item properties irot / imir / clap on the device planes: hm_decode_item vs the
+CPU flow (oracle restatement of pixelimage.cc:539-888 and box.cc's clap arithmetic).  No reference vectors exist for
+these (libheif cannot be built here): the oracle side is a restatement only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import heifwriter
+import orc
+import pipeline
+import synthutil
+
+
+def _clap(w, h, cw, ch, dx2=0, dy2=0):
+    """aperture cw x ch, centre offset (dx2/2, dy2/2) from the image centre"""
+    return ("clap", (cw, 1, ch, 1, dx2, 2, dy2, 2))
+
+
+def test_clap_rectangle_arithmetic(oracle):
+    """Box_clap rounding (box.cc:3771-3804): left rounds down, top / right / bottom round to nearest."""
+    rect = (C.c_int * 4)()
+    def r(clap, w, h):
+        assert oracle.orc_clap_rect((C.c_int64 * 8)(*clap), w, h, rect) == 0
+        return list(rect)
+    assert r((100, 1, 50, 1, 0, 1, 0, 1), 200, 100) == [50, 149, 25, 74]      # centred, even sizes: exact
+    assert r((101, 1, 51, 1, 0, 1, 0, 1), 200, 100) == [49, 149, 25, 75]      # left 49.5 -> 49 (round down), top 24.5 -> 25 (round)
+    assert r((100, 1, 50, 1, -200, 2, 0, 1), 200, 100) == [0, 49, 25, 74]     # clamped at the left border (left -50.5 -> -50 -> 0)
+    assert r((64, 1, 64, 1, 0, 1, 0, 1), 64, 64) == [0, 63, 0, 63]
+    assert oracle.orc_clap_rect((C.c_int64 * 8)(10, 1, 10, 1, 4000, 1, 0, 1), 64, 64, rect) == -1  # outside the image
+    assert oracle.orc_clap_rect((C.c_int64 * 8)(10, 0, 10, 1, 0, 1, 0, 1), 64, 64, rect) == -2     # zero denominator
+
+
+def test_plane_transforms_oracle(oracle):
+    a = np.arange(12, dtype=np.uint8).reshape(3, 4)  # w = 4, h = 3
+    out = np.zeros((4, 3), np.uint8)
+    oracle.orc_rotate_ccw_plane(orc.ptr(a), 4, 4, 3, 1, 90, orc.ptr(out), 3)
+    assert out.tolist() == np.rot90(a, 1).tolist()
+    oracle.orc_rotate_ccw_plane(orc.ptr(a), 4, 4, 3, 1, 270, orc.ptr(out), 3)
+    assert out.tolist() == np.rot90(a, 3).tolist()
+    o2 = np.zeros((3, 4), np.uint8)
+    oracle.orc_rotate_ccw_plane(orc.ptr(a), 4, 4, 3, 1, 180, orc.ptr(o2), 4)
+    assert o2.tolist() == np.rot90(a, 2).tolist()
+    b = a.copy()
+    oracle.orc_mirror_plane(orc.ptr(b), 4, 4, 3, 1)
+    assert b.tolist() == a[:, ::-1].tolist()
+    b = a.copy()
+    oracle.orc_mirror_plane(orc.ptr(b), 4, 4, 3, 0)
+    assert b.tolist() == a[::-1].tolist()
+
+
+def test_handle_size_follows_transforms(hm):
+    pic = synthutil.picture(8101, width=96, height=64)
+    f = pipeline.HeifFile(hm, heifwriter.write_heic([pic], (96, 64), transforms=[_clap(96, 64, 80, 40), ("irot", 1)]))
+    info = f.info(f.primary())
+    f.close()
+    assert (info.coded_width, info.coded_height, info.has_transforms) == (96, 64, 1)
+    assert (info.width, info.height) == (40, 80)
+
+
+CASES = {
+    "rot90": [("irot", 1)], "rot180": [("irot", 2)], "rot270": [("irot", 3)], "rot0": [("irot", 0)],
+    "mirror_h": [("imir", 1)], "mirror_v": [("imir", 0)],
+    "clap_centre": [_clap(200, 136, 120, 80)], "clap_odd": [_clap(200, 136, 121, 77, 7, -5)], "clap_clamped": [_clap(200, 136, 180, 120, 60, 40)],
+    "iphone_like": [("irot", 3), _clap(136, 200, 130, 190)],
+    "clap_rot_mirror": [_clap(200, 136, 150, 100, -10, 6), ("irot", 1), ("imir", 1)],
+    "mirror_rot_clap": [("imir", 0), ("irot", 2), _clap(200, 136, 64, 64)],
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("fmt", [10, 0])
+def test_single_image_transforms(hm, name, fmt):
+    tr = CASES[name]
+    pic = synthutil.picture(8200, width=200, height=136, log2_ctb=5, qp=30, vui=1, full_range=1, matrix=6)
+    f = pipeline.HeifFile(hm, heifwriter.write_heic([pic], (200, 136), transforms=tr))
+    planes, meta = f.decode(f.primary(), fmt)
+    f.close()
+    exp, stride, canv = pipeline.cpu_decode(hm, [pic], 200, 136, 200, 136, 1, False, fmt or 10, transforms=tr)
+    if fmt:
+        w, h = meta["width"], meta["height"]
+        assert meta["stride"][0] == stride
+        np.testing.assert_array_equal(planes[0][:h, :w * 3], exp[:h, :w * 3])
+    else:  # native planar output: the transformed planes themselves
+        for c in range(3):
+            assert planes[c].shape[1] == canv[c][1]
+            pw, ph = meta["plane_size"][c]
+            np.testing.assert_array_equal(planes[c][:ph, :pw], canv[c][0][:ph, :pw])
+
+
+@pytest.mark.gpu
+def test_grid_with_rotation_and_clap(hm):
+    """the usual phone layout: a grid whose output is cropped and rotated by item properties of the grid item"""
+    from corpus import TILE
+    tiles = [synthutil.picture(8300 + i, **{**TILE, "width": 128, "height": 128}, vui=0) for i in range(6)]
+    tr = [_clap(360, 250, 350, 240), ("irot", 3)]
+    data = heifwriter.write_heic(tiles, (128, 128), grid=(2, 3, 360, 250), transforms=tr)
+    f = pipeline.HeifFile(hm, data)
+    info = f.info(f.primary())
+    assert (info.width, info.height, info.coded_width, info.coded_height) == (240, 350, 360, 250)
+    planes, meta = f.decode(f.primary(), 11, threads=2)
+    f.close()
+    assert (meta["width"], meta["height"]) == (240, 350)
+    exp, stride, _ = pipeline.cpu_decode(hm, tiles, 128, 128, 360, 250, 3, True, 11, transforms=tr)
+    np.testing.assert_array_equal(planes[0][:350, :240 * 4], exp[:350, :240 * 4])
+
+
+@pytest.mark.gpu
+def test_transform_limits_are_loud(hm):
+    hi = synthutil.picture(8400, width=64, height=64, bit_depth=10, chroma_format=2, log2_ctb=5)
+    # 10-bit planes cannot be mirrored (pixelimage.cc:748-752); 4:2:2 + quarter turn is undefined in the reference
+    for tr, text in (([("imir", 1)], "mirror"), ([("irot", 1)], "4:2:2")):
+        f = pipeline.HeifFile(hm, heifwriter.write_heic([hi], (64, 64), chroma_format=2, bit_depth=10, transforms=tr))
+        with pytest.raises(RuntimeError, match=text):
+            f.decode(f.primary(), 14)
+        f.close()
+    # 180 degrees on 10-bit 4:2:2 is fine
+    f = pipeline.HeifFile(hm, heifwriter.write_heic([hi], (64, 64), chroma_format=2, bit_depth=10, transforms=[("irot", 2)]))
+    planes, meta = f.decode(f.primary(), 14)
+    f.close()
+    exp, stride, _ = pipeline.cpu_decode(hm, [hi], 64, 64, 64, 64, 1, False, 14, transforms=[("irot", 2)])
+    np.testing.assert_array_equal(planes[0][:64, :64 * 6], exp[:64, :64 * 6])
+    # an aperture outside the image
+    pic = synthutil.picture(8401, width=64, height=64)
+    f = pipeline.HeifFile(hm, heifwriter.write_heic([pic], (64, 64), transforms=[("clap", (10, 1, 10, 1, 4000, 1, 0, 1))]))
+    with pytest.raises(RuntimeError, match="clean aperture"):
+        f.decode(f.primary(), 10)
+    # ... is skipped with ignore_transformations
+    f.close()
