@@ -53,7 +53,7 @@ template <int BPP>
 __global__ __launch_bounds__(INT_THREADS) void k_ycbcr420_int(
     const uint8_t* __restrict__ Y, const uint8_t* __restrict__ Cb, const uint8_t* __restrict__ Cr,
     uint8_t* __restrict__ out, int w, int h, int ys, int cbs, int crs, int os, IntCoef k,
-    int groups_per_row, int total_groups)
+    int groups_per_row, int row_pairs)
 {
   // LDS staging: per wave 64 lanes x (16*BPP) bytes per row, two rows.
   constexpr int LANE_BYTES = 16 * BPP;                // 48 or 64
@@ -64,22 +64,20 @@ __global__ __launch_bounds__(INT_THREADS) void k_ycbcr420_int(
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int gid = blockIdx.x * INT_THREADS + tid;
-  // wave-uniform geometry: all 64 lanes of a wave work on the same row pair when
-  // groups_per_row is a multiple of 64; otherwise fall back to the direct path.
-  const int wave_first = blockIdx.x * INT_THREADS + wave * 64;
-  const int rp_first = wave_first / groups_per_row;
-  const int g_first = wave_first - rp_first * groups_per_row;
-  const bool wave_in_one_row = (g_first + 63 < groups_per_row) && (wave_first + 63 < total_groups);
-
-  int rp = 0, g = 0;
-  bool active = gid < total_groups;
-  if (active) { rp = gid / groups_per_row; g = gid - rp * groups_per_row; }
+  // wave-uniform geometry: a wave never straddles row pairs (the last wave of a row pair is partly idle), so the
+  // transposed store path applies to every wave whose lanes are all complete 16 x 2 groups
+  const int waves_per_row = (groups_per_row + 63) >> 6;
+  const int wg = blockIdx.x * WAVES + wave;
+  const int rp = wg / waves_per_row;
+  const int g_first = (wg - rp * waves_per_row) * 64;
+  const int g = g_first + lane;
+  const bool active = rp < row_pairs && g < groups_per_row;
+  const int n_valid = (groups_per_row - g_first) < 64 ? (groups_per_row - g_first) : 64; // active lanes of this wave
   const int x0 = g * 16;
   const int y0 = rp * 2;
   const bool full = active && (x0 + 16 <= w) && (y0 + 1 < h);
 
-  uint32_t o0[LANE_WORDS], o1[LANE_WORDS];
+  uint32_t o0[LANE_WORDS] = {}, o1[LANE_WORDS] = {};
 
   if (full) {
     const uint4 ya = *reinterpret_cast<const uint4*>(Y + (size_t)y0 * ys + x0);
@@ -121,7 +119,7 @@ __global__ __launch_bounds__(INT_THREADS) void k_ycbcr420_int(
   }
 
   // wave-uniform: every lane full and all in one row pair -> LDS transpose, contiguous stores
-  const bool all_full = __all(full ? 1 : 0) && wave_in_one_row;
+  const bool all_full = __all((full || !active) ? 1 : 0) && rp < row_pairs;
   if (all_full) {
     uint32_t* s0 = stage[wave][0];
     uint32_t* s1 = stage[wave][1];
@@ -138,10 +136,12 @@ __global__ __launch_bounds__(INT_THREADS) void k_ycbcr420_int(
 #pragma unroll
     for (int j = 0; j < LANE_WORDS / 4; j++) {
       const int idx = (j * 64 + lane) * 4;
-      const uint4 a = *reinterpret_cast<const uint4*>(s0 + idx);
-      const uint4 b = *reinterpret_cast<const uint4*>(s1 + idx);
-      *reinterpret_cast<uint4*>(row0 + (size_t)idx * 4) = a;
-      *reinterpret_cast<uint4*>(row1 + (size_t)idx * 4) = b;
+      if (idx < n_valid * LANE_WORDS) { // LANE_WORDS is a multiple of 4: a 16-byte chunk is valid or not as a whole
+        const uint4 a = *reinterpret_cast<const uint4*>(s0 + idx);
+        const uint4 b = *reinterpret_cast<const uint4*>(s1 + idx);
+        *reinterpret_cast<uint4*>(row0 + (size_t)idx * 4) = a;
+        *reinterpret_cast<uint4*>(row1 + (size_t)idx * 4) = b;
+      }
     }
     return;
   }
@@ -401,18 +401,18 @@ extern "C" int hm_launch_colour_int420(const hm_colour_desc* d, const int coef[4
 {
   const int gpr = (d->width + 15) / 16;
   const int rps = (d->height + 1) / 2;
-  const long total = (long)gpr * rps;
+  const long total = (long)((gpr + 63) / 64) * rps; // waves
   if (total <= 0) return HM_OK;
-  const int blocks = (int)((total + INT_THREADS - 1) / INT_THREADS);
+  const int blocks = (int)((total + INT_THREADS / 64 - 1) / (INT_THREADS / 64));
   IntCoef k{coef[0], coef[1], coef[2], coef[3]};
   if (d->out_format == HM_OUT_RGB)
     hipLaunchKernelGGL(k_ycbcr420_int<3>, dim3(blocks), dim3(INT_THREADS), 0, s, (const uint8_t*)y, (const uint8_t*)cb,
                        (const uint8_t*)cr, (uint8_t*)out, d->width, d->height, d->y_stride, d->cb_stride, d->cr_stride,
-                       d->out_stride, k, gpr, (int)total);
+                       d->out_stride, k, gpr, rps);
   else
     hipLaunchKernelGGL(k_ycbcr420_int<4>, dim3(blocks), dim3(INT_THREADS), 0, s, (const uint8_t*)y, (const uint8_t*)cb,
                        (const uint8_t*)cr, (uint8_t*)out, d->width, d->height, d->y_stride, d->cb_stride, d->cr_stride,
-                       d->out_stride, k, gpr, (int)total);
+                       d->out_stride, k, gpr, rps);
   return hm_check_hip(hipGetLastError(), "k_ycbcr420_int launch");
 }
 
