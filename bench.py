@@ -263,11 +263,11 @@ def end_to_end(pkg, image0):
     f = pipeline.HeifFile(pkg.lib(), data)
     try:
         for threads in (1, 8, 48):
-            f.decode(f.primary(), 10, threads=threads)  # warm-up (allocations, code objects)
+            f.decode(f.primary(), 10, threads=threads, copy=False)  # warm-up (allocations, code objects, worker threads)
             t0 = time.perf_counter()
-            n = 3
+            n = 5
             for _ in range(n):
-                f.decode(f.primary(), 10, threads=threads)
+                f.decode(f.primary(), 10, threads=threads, copy=False)
             dt = (time.perf_counter() - t0) / n
             res[f"host_threads_{threads}"] = {"ms_per_image": round(dt * 1e3, 2), "MP_per_s": round(MP_PER_IMAGE / dt, 1)}
     finally:

@@ -7,6 +7,11 @@
 //   one GPU kernel : convert_colorspace() on the whole canvas (colorconversion.cc:487-596)
 //   one D2H copy   : into a host plane laid out like HeifPixelImage (pixelimage.cc:139-218)
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -131,6 +136,63 @@ struct Blob {
   ~Blob() { if (p) hm_free(p); }
 };
 
+// Host worker threads for the entropy decode, kept alive between calls (spawning 48 threads costs more than the
+// 1.6 ms one tile takes).  Mirrors the reference's std::async tile fan-out (context.cc:2361-2401) with a fixed crew.
+class Crew {
+ public:
+  static Crew& instance() { static Crew c; return c; }
+  // runs fn(0..n-1 claimed dynamically by the workers) on up to `threads` threads incl. the caller; returns when all are done
+  void run(int threads, const std::function<void()>& fn)
+  {
+    if (threads <= 1) { fn(); return; }
+    std::unique_lock<std::mutex> call(call_mutex_); // one fan-out at a time: concurrent callers queue up here
+    {
+      std::lock_guard<std::mutex> g(m_);
+      while ((int)workers_.size() < threads - 1 && workers_.size() < 255) workers_.emplace_back([this] { loop(); });
+      job_ = &fn;
+      wanted_ = threads - 1 < (int)workers_.size() ? threads - 1 : (int)workers_.size();
+      started_ = 0; running_ = 0; ++generation_;
+    }
+    cv_.notify_all();
+    fn(); // the caller works too
+    std::unique_lock<std::mutex> g(m_);
+    job_ = nullptr; // late workers must not start any more
+    done_.wait(g, [this] { return running_ == 0; });
+  }
+
+ private:
+  Crew() = default;
+  ~Crew()
+  {
+    { std::lock_guard<std::mutex> g(m_); quit_ = true; }
+    cv_.notify_all();
+    for (auto& t : workers_) t.join();
+  }
+  void loop()
+  {
+    uint64_t seen = 0;
+    std::unique_lock<std::mutex> g(m_);
+    for (;;) {
+      cv_.wait(g, [&] { return quit_ || (generation_ != seen && job_ && started_ < wanted_); });
+      if (quit_) return;
+      seen = generation_;
+      const std::function<void()>* job = job_;
+      ++started_; ++running_;
+      g.unlock();
+      (*job)();
+      g.lock();
+      if (--running_ == 0) done_.notify_all();
+    }
+  }
+  std::mutex call_mutex_, m_;
+  std::condition_variable cv_, done_;
+  std::vector<std::thread> workers_;
+  const std::function<void()>* job_ = nullptr;
+  int wanted_ = 0, started_ = 0, running_ = 0;
+  uint64_t generation_ = 0;
+  bool quit_ = false;
+};
+
 int fail_from(const hm::HeifError& e) { return hm_fail(e.status, "%s", e.message.c_str()); }
 
 } // namespace
@@ -236,6 +298,13 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
   const hm::Item* it = f->file.item(id);
   if (!it) return hm_fail(HM_ERR_INVALID_ARG, "no item %u", id);
   hm::HeifError err;
+  // HM_TRACE=1: wall-clock split of this call on stderr (diagnostics only)
+  static const bool trace = std::getenv("HM_TRACE") != nullptr;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (trace) std::fprintf(stderr, "[hm_decode_item] %-28s %8.3f ms\n", what,
+                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+  };
 
   // ---- which coded pictures, where ----
   struct Tile { uint32_t id; int x0, y0; };
@@ -274,14 +343,10 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
   };
   int nthreads = params->host_threads > 0 ? params->host_threads : 1;
   if (nthreads > nt) nthreads = nt;
-  if (nthreads <= 1) worker();
-  else {
-    std::vector<std::thread> th;
-    for (int i = 0; i < nthreads; i++) th.emplace_back(worker);
-    for (auto& t : th) t.join();
-  }
+  Crew::instance().run(nthreads, worker);
   for (int i = 0; i < nt; i++)
     if (status[i]) return hm_fail(status[i], "tile %d (item %u): %s", i, tiles[i].id, messages[i].c_str());
+  lap("host entropy decode done");
 
   // ---- geometry ----
   const hm_pic* h0 = reinterpret_cast<const hm_pic*>(blobs[0].p);
@@ -345,8 +410,11 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
     const int idx = hm_batch_add(batch, blobs[i].p, blobs[i].n, &d);
     if (idx < 0) return idx;
   }
+  lap("planes allocated, batch queued");
   if ((rc = hm_batch_upload(batch, s))) return rc;
+  lap("upload enqueued");
   if ((rc = hm_batch_execute(batch, 3, s))) return rc;
+  if (trace) { hipStreamSynchronize(s); lap("kernels finished (sync)"); }
 
   // ---- transformative item properties on the decoded planes (context.cc:1957-2020) ----
   int img_w = canvas_w, img_h = canvas_h;
@@ -403,7 +471,9 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
       if (e != hipSuccess) { hm_decoded_free(out); return hm_check_hip(e, "D2H"); }
     }
   }
+  lap("colour + D2H enqueued");
   e = hipStreamSynchronize(s);
+  lap("stream drained");
   if (e != hipSuccess) { hm_decoded_free(out); return hm_check_hip(e, "kernel execution"); }
   return HM_OK;
 }

@@ -69,15 +69,16 @@ class HeifFile:
         self.hm.hm_free(p)
         return out
 
-    def decode(self, iid, out_format, threads=1, upsampling=0):
-        """GPU path through the C ABI; returns (array rows x stride, Decoded meta)."""
+    def decode(self, iid, out_format, threads=1, upsampling=0, copy=True):
+        """GPU path through the C ABI; returns (array rows x stride, Decoded meta); copy=False only times the call
+        (the pinned result is released without being copied into numpy arrays)."""
         prm = DecodeParams(out_format, threads, 0, upsampling, None, None, 0, 0)
         d = Decoded()
         rc = self.hm.hm_decode_item(self.h, iid, C.byref(prm), C.byref(d))
         if rc:
             raise RuntimeError(f"hm_decode_item: {rc}: {self.hm.hm_last_error().decode()}")
         planes = []
-        n = 1 if out_format else 3
+        n = (1 if out_format else 3) if copy else 0
         for c in range(n):
             rows = d.plane_height[c]
             a = np.ctypeslib.as_array(d.plane[c], shape=(rows, d.stride[c])).copy()
