@@ -33,9 +33,29 @@ struct DeviceBuffer {
 };
 
 struct Item {
-  std::vector<uint8_t> blob;
+  size_t stage_off = 0;  // the command stream inside the pinned staging arena (256-B aligned = its device layout)
   hm_tile_dest dest;
   hm_pic hdr;
+};
+
+// Pinned host arena holding the command streams back to back exactly as they will lie in HBM: hm_batch_add copies
+// a stream once (into the arena), hm_batch_upload is a single asynchronous H2D of the used part.
+struct PinnedArena {
+  uint8_t* p = nullptr;
+  size_t cap = 0, used = 0;
+  bool reserve(size_t need)
+  {
+    if (need <= cap) return true;
+    size_t ncap = cap ? cap : (size_t)4 << 20;
+    while (ncap < need) ncap *= 2;
+    uint8_t* np = (uint8_t*)hm_pool_pinned_alloc(ncap);
+    if (!np) return false;
+    if (used) std::memcpy(np, p, used);
+    if (p) hm_pool_pinned_free(p);
+    p = np; cap = ncap;
+    return true;
+  }
+  ~PinnedArena() { if (p) hm_pool_pinned_free(p); }
 };
 
 struct Class {
@@ -54,13 +74,21 @@ struct hm_batch {
   std::vector<Class> classes;
   DeviceBuffer d_blobs, d_work, d_desc;
   std::vector<hm_dev_pic> h_desc;
+  PinnedArena stage;       // command streams
+  PinnedArena desc_stage;  // descriptor array (kept alive: the H2D copies are asynchronous)
   bool uploaded = false;
+  hipStream_t last_stream = nullptr; // stream of the last upload / execute: drained before the arenas are released
   size_t total_pixels = 0;
   // optional per-kernel timing with HIP events on the launch stream (bench / profiling)
   int profiling = 0;                // number of timing slots (0 = off)
   std::vector<hipEvent_t> events;   // per slot, 4 per class: before recon, after recon, after deblock, after sao
   long exec_count = 0;
-  ~hm_batch() { for (hipEvent_t e : events) hipEventDestroy(e); }
+  void drain() { if (uploaded) hipStreamSynchronize(last_stream); }
+  ~hm_batch()
+  {
+    drain();
+    for (hipEvent_t e : events) hipEventDestroy(e);
+  }
 };
 
 extern "C" {
@@ -79,9 +107,11 @@ void hm_batch_destroy(hm_batch* b) { delete b; }
 void hm_batch_clear(hm_batch* b)
 {
   if (!b) return;
+  b->drain();
   b->items.clear();
   b->classes.clear();
   b->h_desc.clear();
+  b->stage.used = 0;
   b->uploaded = false;
   b->total_pixels = 0;
 }
@@ -96,7 +126,11 @@ int hm_batch_add(hm_batch* b, const uint8_t* blob, size_t size, const hm_tile_de
   if (it.hdr.chroma_format != 1 && it.hdr.chroma_format != 2) return hm_fail(HM_ERR_UNSUPPORTED, "chroma format %d", it.hdr.chroma_format);
   for (int c = 0; c < 3; c++)
     if (!dest->plane[c]) return hm_fail(HM_ERR_INVALID_ARG, "null destination plane");
-  it.blob.assign(blob, blob + it.hdr.total_bytes);
+  // (a stream of a previous, still in-flight upload is never overwritten: the arena only grows until hm_batch_clear)
+  it.stage_off = (b->stage.used + 255) & ~(size_t)255;
+  if (!b->stage.reserve(it.stage_off + it.hdr.total_bytes)) return hm_fail(HM_ERR_NOMEM, "pinned staging: out of memory");
+  std::memcpy(b->stage.p + it.stage_off, blob, it.hdr.total_bytes);
+  b->stage.used = it.stage_off + it.hdr.total_bytes;
   it.dest = *dest;
   b->items.push_back(std::move(it));
   b->uploaded = false;
@@ -142,8 +176,8 @@ int hm_batch_upload(hm_batch* b, void* stream)
   b->total_pixels = 0;
   for (int i = 0; i < n; i++) {
     const hm_pic& h = b->items[i].hdr;
-    blob_off[i] = blob_bytes;
-    blob_bytes += align_up(h.total_bytes, 256);
+    blob_off[i] = b->items[i].stage_off;
+    blob_bytes = b->items[i].stage_off + h.total_bytes;
     work_off[i] = work_bytes;
     const int bps = h.bit_depth_y > 8 ? 2 : 1;
     const int sh = h.chroma_format == 1 ? 2 : 1;
@@ -157,12 +191,8 @@ int hm_batch_upload(hm_batch* b, void* stream)
   if ((rc = b->d_work.ensure(work_bytes))) return rc;
   if ((rc = b->d_desc.ensure(sizeof(hm_dev_pic) * (size_t)n))) return rc;
 
-  // stage all blobs in one pinned host buffer -> one H2D copy at PCIe rate
-  struct Pinned { void* p; ~Pinned() { hm_pool_pinned_free(p); } } staging{hm_pool_pinned_alloc(blob_bytes + sizeof(hm_dev_pic) * (size_t)n)};
-  if (!staging.p) return HM_ERR_NO_DEVICE;
-  uint8_t* stg = (uint8_t*)staging.p;
-  for (int i = 0; i < n; i++) std::memcpy(stg + blob_off[i], b->items[i].blob.data(), b->items[i].blob.size());
-  hipError_t e = hipMemcpyAsync(b->d_blobs.p, stg, blob_bytes, hipMemcpyHostToDevice, s);
+  // the streams already lie in the pinned arena in device layout -> one H2D copy at PCIe rate
+  hipError_t e = hipMemcpyAsync(b->d_blobs.p, b->stage.p, blob_bytes, hipMemcpyHostToDevice, s);
   if (e != hipSuccess) return hm_check_hip(e, "H2D command streams");
 
   size_t di = 0;
@@ -221,12 +251,13 @@ int hm_batch_upload(hm_batch* b, void* stream)
       b->h_desc[di++] = d;
     }
   }
-  std::memcpy(stg + blob_bytes, b->h_desc.data(), sizeof(hm_dev_pic) * (size_t)n);
-  e = hipMemcpyAsync(b->d_desc.p, stg + blob_bytes, sizeof(hm_dev_pic) * (size_t)n, hipMemcpyHostToDevice, s);
+  b->desc_stage.used = 0;
+  if (!b->desc_stage.reserve(sizeof(hm_dev_pic) * (size_t)n)) return hm_fail(HM_ERR_NOMEM, "pinned staging: out of memory");
+  std::memcpy(b->desc_stage.p, b->h_desc.data(), sizeof(hm_dev_pic) * (size_t)n);
+  e = hipMemcpyAsync(b->d_desc.p, b->desc_stage.p, sizeof(hm_dev_pic) * (size_t)n, hipMemcpyHostToDevice, s);
   if (e != hipSuccess) return hm_check_hip(e, "H2D descriptors");
-  e = hipStreamSynchronize(s); // the staging buffer goes back to the pool
-  if (e != hipSuccess) return hm_check_hip(e, "upload sync");
-  b->uploaded = true;
+  b->uploaded = true; // asynchronous: the arenas stay alive with the batch
+  b->last_stream = s;
   return HM_OK;
 }
 
@@ -237,6 +268,7 @@ int hm_batch_execute(hm_batch* b, int stages, void* stream)
   if (!b) return hm_fail(HM_ERR_INVALID_ARG, "null batch");
   if (!b->uploaded) return hm_fail(HM_ERR_INVALID_ARG, "hm_batch_upload() has not been called");
   hipStream_t s = (hipStream_t)stream;
+  b->last_stream = s;
   const hm_dev_pic* d = (const hm_dev_pic*)b->d_desc.p;
   const size_t per_slot = b->classes.size() * 4;
   size_t ev_next = 0;
