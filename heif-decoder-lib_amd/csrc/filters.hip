@@ -298,7 +298,8 @@ __device__ __forceinline__ int sao_sample(const hm_dev_pic& dp, const PicView& v
 // sample x is (x + HX, yy + VY), neighbour b is (x - HX, yy - VY) (sao.cc:336-424).
 template <typename Pix, int HX, int VY, int G>
 __device__ __forceinline__ void sao_edge_group(const uint8_t* plane, int pitch, int xs, int yy, int W, int Hh, int l2w, int l2h,
-                                               int cx, int cy, uint32_t nbm, uint32_t offs, int maxv, const Pix (&cur)[G], int (&out)[G])
+                                               int cx, int cy, uint32_t nbm, uint32_t offs, int maxv, const Pix (&cur)[G],
+                                               const Pix (&up)[G], const Pix (&dn)[G], int (&out)[G])
 {
   const int ya = yy + VY, yb = yy - VY;
   const bool rows_ok = ya >= 0 && yb < Hh;
@@ -308,17 +309,11 @@ __device__ __forceinline__ void sao_edge_group(const uint8_t* plane, int pitch, 
     const int bit = k8 < 4 ? k8 : k8 - 1;
     return (dx | dy) == 0 || ((nbm >> bit) & 1);
   };
+  // rows a / b: the centre row for the horizontal class, else the rows above / below (fetched by the caller together
+  // with the centre row, before the CTB's SAO parameters are known: one memory round trip less)
   Pix va[G], vb[G];
-  if (VY == 0) {
 #pragma unroll
-    for (int k = 0; k < G; k++) va[k] = vb[k] = cur[k];
-  }
-  else {
-    const Pix* ra = reinterpret_cast<const Pix*>(plane + (size_t)(ya >= 0 ? ya : yy) * pitch) + xs;
-    const Pix* rb = reinterpret_cast<const Pix*>(plane + (size_t)(yb < Hh ? yb : yy) * pitch) + xs;
-    __builtin_memcpy(va, ra, G * sizeof(Pix));
-    __builtin_memcpy(vb, rb, G * sizeof(Pix));
-  }
+  for (int k = 0; k < G; k++) { va[k] = VY == 0 ? cur[k] : up[k]; vb[k] = VY == 0 ? cur[k] : dn[k]; }
   // the sample left of / right of the group, on the side each row needs
   const bool has_l = xs > 0, has_r = xs + G < W;
   int ea = 0, eb = 0;
@@ -381,6 +376,11 @@ __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict_
   if (fast) {
     // ---- one aligned vector load per row, everything else in registers ----
     const int cx = xs >> l2w, cy = yy >> l2h;
+    const Pix* rc = reinterpret_cast<const Pix*>(plane + (size_t)yy * pitch) + xs;
+    Pix cur[G], up[G], dn[G];
+    __builtin_memcpy(cur, rc, G * sizeof(Pix));
+    __builtin_memcpy(up, reinterpret_cast<const Pix*>(plane + (size_t)(yy > 0 ? yy - 1 : yy) * pitch) + xs, G * sizeof(Pix));
+    __builtin_memcpy(dn, reinterpret_cast<const Pix*>(plane + (size_t)(yy + 1 < Hh ? yy + 1 : yy) * pitch) + xs, G * sizeof(Pix));
     const uint32_t* cbq = reinterpret_cast<const uint32_t*>(v.ctbs + (cx + cy * dp.ctb_w)); // hm_ctb as dwords
     const uint32_t cflags = cbq[2];                       // flags | sao_nb_mask << 8
     const uint32_t s0 = cbq[3 + 2 * c], s1 = cbq[4 + 2 * c]; // hm_sao: type, eo_class, band_position, offset[0] | offset[1..3], reserved
@@ -388,9 +388,6 @@ __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict_
     const int type = sao_on ? (int)(s0 & 0xFF) : 0;
     const uint32_t offs = (s0 >> 24) | (s1 << 8);         // the four int8 offsets in one register
     const uint32_t nbm = (cflags >> 8) & 0xFF;
-    const Pix* rc = reinterpret_cast<const Pix*>(plane + (size_t)yy * pitch) + xs;
-    Pix cur[G];
-    __builtin_memcpy(cur, rc, G * sizeof(Pix));
 #pragma unroll
     for (int k = 0; k < G; k++) out[k] = cur[k];
     if (type == 1) { // band offset (fallback-postfilter.h:218-241)
@@ -404,10 +401,10 @@ __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict_
     }
     else if (type == 2) { // edge offset: SaoEoClass 0 horizontal, 1 vertical, 2 135 degrees, 3 45 degrees
       const int cl = (s0 >> 8) & 0xFF;
-      if (cl == 0) sao_edge_group<Pix, -1, 0, G>(plane, pitch, xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv, cur, out);
-      else if (cl == 1) sao_edge_group<Pix, 0, -1, G>(plane, pitch, xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv, cur, out);
-      else if (cl == 2) sao_edge_group<Pix, -1, -1, G>(plane, pitch, xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv, cur, out);
-      else sao_edge_group<Pix, 1, -1, G>(plane, pitch, xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv, cur, out);
+      if (cl == 0) sao_edge_group<Pix, -1, 0, G>(plane, pitch, xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv, cur, up, dn, out);
+      else if (cl == 1) sao_edge_group<Pix, 0, -1, G>(plane, pitch, xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv, cur, up, dn, out);
+      else if (cl == 2) sao_edge_group<Pix, -1, -1, G>(plane, pitch, xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv, cur, up, dn, out);
+      else sao_edge_group<Pix, 1, -1, G>(plane, pitch, xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv, cur, up, dn, out);
     }
   }
   else {
