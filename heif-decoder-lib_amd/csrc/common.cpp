@@ -15,6 +15,9 @@ int hm_fail(int status, const char* fmt, ...)
   va_start(ap, fmt);
   vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
   va_end(ap);
+  // messages may quote bytes of a (malformed) file, e.g. an item type: keep them printable ASCII
+  for (char* c = g_last_error; *c; c++)
+    if ((unsigned char)*c < 0x20 || (unsigned char)*c > 0x7E) *c = '?';
   return status;
 }
 
