@@ -73,6 +73,29 @@ inline void build_subblock_scan(int scanIdx, int log2w, Scan* out)
     for (int x = 0; x < w; x++) for (int y = 0; y < w; y++) out[n++] = {(uint8_t)x, (uint8_t)y};
   }
 }
+// All scans of residual_coding, built once: sub-block scans for grids of 1..8 sub-blocks per side, the 4x4
+// position scan, and the inverse maps (position -> scan index) that locate the last significant coefficient.
+struct ScanTables {
+  Scan sub[3][4][64];        // [scanIdx][log2 of the grid width]
+  uint8_t sub_inv[3][4][8][8]; // [..][..][y][x] -> index in sub[]
+  uint8_t pos_inv[3][4][4];    // [scanIdx][y][x] -> index in scan4(scanIdx)
+  ScanTables()
+  {
+    for (int s = 0; s < 3; s++) {
+      for (int l = 0; l < 4; l++) {
+        build_subblock_scan(s, l, sub[s][l]);
+        for (int i = 0; i < (1 << (2 * l)); i++) sub_inv[s][l][sub[s][l][i].y][sub[s][l][i].x] = (uint8_t)i;
+      }
+      const Scan* p4 = scan4(s);
+      for (int i = 0; i < 16; i++) pos_inv[s][p4[i].y][p4[i].x] = (uint8_t)i;
+    }
+  }
+};
+inline const ScanTables& scan_tables()
+{
+  static const ScanTables t;
+  return t;
+}
 static const uint8_t kCtxIdxMap4x4[16] = {0, 1, 4, 5, 2, 3, 4, 5, 6, 6, 8, 8, 7, 7, 8, 8};
 // Table 8-10: QpC as a function of qPi (ChromaArrayType == 1)
 inline int chroma_qp_table(int qPi)
@@ -205,8 +228,11 @@ class SliceWalker {
     const int aN = pps_.MinTbAddrZS[(xN >> l2) + (yN >> l2) * sps_.min_tb_w];
     const int aC = pps_.MinTbAddrZS[(xCurr >> l2) + (yCurr >> l2) * sps_.min_tb_w];
     if (aN > aC) return false;
-    const int cc = (xCurr >> sps_.log2_ctb) + (yCurr >> sps_.log2_ctb) * sps_.ctb_w;
-    const int cn = (xN >> sps_.log2_ctb) + (yN >> sps_.log2_ctb) * sps_.ctb_w;
+    const int lc = sps_.log2_ctb;
+    // a neighbour inside the current CTB: same slice, same tile (neither can end inside a CTB)
+    if (((xCurr ^ xN) >> lc) == 0 && ((yCurr ^ yN) >> lc) == 0) return true;
+    const int cc = (xCurr >> lc) + (yCurr >> lc) * sps_.ctb_w;
+    const int cn = (xN >> lc) + (yN >> lc) * sps_.ctb_w;
     if (pic_.ctb_slice_addr[cn] < 0 || pic_.ctb_slice_addr[cn] != pic_.ctb_slice_addr[cc]) return false;
     return pps_.TileIdRS[cn] == pps_.TileIdRS[cc];
   }
@@ -609,13 +635,13 @@ class SliceWalker {
   // one (component) block: optional residual_coding(), then the hm_tu record
   void emit_block(int xc, int yc, int log2, int cIdx, int mode, int cbf)
   {
-    const int sw = cIdx ? sps_.SubWidthC : 1, shh = cIdx ? sps_.SubHeightC : 1;
+    // SubWidthC / SubHeightC are 1 or 2: shifts instead of divisions (this runs once per transform block)
+    const int lw = cIdx ? (sps_.SubWidthC >> 1) : 0, lh = cIdx ? (sps_.SubHeightC >> 1) : 0;
     const int nT = 1 << log2;
     hm_tu t;
     std::memset(&t, 0, sizeof(t));
-    const int ctb_c_w = (1 << sps_.log2_ctb) / sw, ctb_c_h = (1 << sps_.log2_ctb) / shh;
-    t.x = (uint8_t)(xc % ctb_c_w);
-    t.y = (uint8_t)(yc % ctb_c_h);
+    t.x = (uint8_t)(xc & ((1 << (sps_.log2_ctb - lw)) - 1));
+    t.y = (uint8_t)(yc & ((1 << (sps_.log2_ctb - lh)) - 1));
     t.info = (uint8_t)(log2 | (cIdx << HM_TU_CIDX_SHIFT));
     t.pred_mode = (uint8_t)mode;
     t.coeff_first = (uint32_t)pic_.coeffs.size();
@@ -630,13 +656,13 @@ class SliceWalker {
     t.qp = (uint8_t)qp_prime_[cIdx];
     t.qpy = (int8_t)cu_qpy_;
     // neighbour availability (intrapred.h:536-667 in the reference; equals §8.4.4.2.2)
-    const int xL = xc * sw, yL = yc * shh; // luma position of the block
-    const int cw = cIdx ? sps_.width / sw : sps_.width, chh = cIdx ? sps_.height / shh : sps_.height;
+    const int xL = xc << lw, yL = yc << lh; // luma position of the block
+    const int cw = sps_.width >> lw, chh = sps_.height >> lh;
     const bool aL = avail_z(xL, yL, xL - 1, yL);
     const bool aT = avail_z(xL, yL, xL, yL - 1);
     const bool aTL = avail_z(xL, yL, xL - 1, yL - 1);
-    const bool aBL = aL && (yc + nT < chh) && avail_z(xL, yL, xL - 1, (yc + nT) * shh);
-    const bool aTR = (xc + nT < cw) && avail_z(xL, yL, (xc + nT) * sw, yL - 1);
+    const bool aBL = aL && (yc + nT < chh) && avail_z(xL, yL, xL - 1, (yc + nT) << lh);
+    const bool aTR = (xc + nT < cw) && avail_z(xL, yL, (xc + nT) << lw, yL - 1);
     t.avail_left = aL ? (uint8_t)nT : 0;
     t.avail_top = aT ? (uint8_t)nT : 0;
     if (aTL) t.info |= HM_TU_AVAIL_TL;
@@ -669,18 +695,13 @@ class SliceWalker {
     if (lastX >= nT || lastY >= nT) throw ParseError(HM_ERR_BITSTREAM, "last significant coefficient outside block");
 
     const tables::Scan* pos4 = tables::scan4(scanIdx);
-    tables::Scan sbscan[64];
+    const tables::ScanTables& st = tables::scan_tables();
     const int log2sb = log2 - 2;
-    tables::build_subblock_scan(scanIdx, log2sb, sbscan);
+    const tables::Scan* sbscan = st.sub[scanIdx][log2sb];
     const int sbw = 1 << log2sb;
     // locate the last sub-block / position
-    int lastSub = 0, lastPos = 0;
-    {
-      const int sx = lastX >> 2, sy = lastY >> 2;
-      for (int i = 0; i < sbw * sbw; i++) if (sbscan[i].x == sx && sbscan[i].y == sy) { lastSub = i; break; }
-      const int px = lastX & 3, py = lastY & 3;
-      for (int i = 0; i < 16; i++) if (pos4[i].x == px && pos4[i].y == py) { lastPos = i; break; }
-    }
+    const int lastSub = st.sub_inv[scanIdx][log2sb][lastY >> 2][lastX >> 2];
+    const int lastPos = st.pos_inv[scanIdx][lastY & 3][lastX & 3];
     uint8_t csbf[8][8];
     std::memset(csbf, 0, sizeof(csbf));
     int c1 = 1; // greater1Ctx carried between sub-blocks
