@@ -88,7 +88,8 @@ typedef struct hm_sao {
 } hm_sao;
 
 typedef struct hm_ctb {
-  uint32_t tu_first;     /* index of the first hm_tu of this CTB                              */
+  uint32_t tu_first;     /* index of the first hm_tu of this CTB; CTBs store their records in raster
+                            order, so tu_first of CTB i+1 == tu_first + tu_count of CTB i            */
   uint16_t tu_count;
   uint16_t slice_idx;    /* index into hm_slice[]                                             */
   uint8_t  flags;        /* HM_CTB_*                                                          */
