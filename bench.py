@@ -140,11 +140,17 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     batch.upload(st)
 
+    # the canvases of the batch share one colour descriptor: one conversion call (hm_colour_convert_batch)
+    PtrArr = C.c_void_p * len(images)
+    p_y, p_cb, p_cr, p_rgb = (PtrArr(*[im[k].data_ptr() for im in images]) for k in ("y", "cb", "cr", "rgb"))
+    L.hm_colour_convert_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+
+    def colour():
+        capi.check(L.hm_colour_convert_batch(C.byref(images[0]["desc"]), len(images), p_y, p_cb, p_cr, p_rgb, st))
+
     def step():
         batch.execute(3, st)
-        for im in images:
-            capi.check(L.hm_colour_convert(C.byref(im["desc"]), im["y"].data_ptr(), im["cb"].data_ptr(), im["cr"].data_ptr(),
-                                           im["rgb"].data_ptr(), st))
+        colour()
 
     # ---- parity gate (rank 0, image 0) ----
     parity = "skipped"
@@ -180,9 +186,7 @@ def main():
     for i in range(args.steps):
         batch.execute(3, st)
         cev[i][0].record()
-        for im in images:
-            capi.check(L.hm_colour_convert(C.byref(im["desc"]), im["y"].data_ptr(), im["cb"].data_ptr(), im["cr"].data_ptr(),
-                                           im["rgb"].data_ptr(), st))
+        colour()
         cev[i][1].record()
     ev1.record()
     torch.cuda.synchronize()

@@ -47,14 +47,24 @@ __device__ __forceinline__ void px_int(int yv, int rt, int gt, int bt, int& r, i
 }
 
 constexpr int INT_THREADS = 256;
+constexpr int INT_BATCH = 32; // images of equal geometry per launch (blockIdx.y); pointers travel as kernel arguments
+struct IntPlanes {
+  const uint8_t* y[INT_BATCH];
+  const uint8_t* cb[INT_BATCH];
+  const uint8_t* cr[INT_BATCH];
+  uint8_t* out[INT_BATCH];
+};
 
 // One lane: 16 px x 2 rows.  BPP = 3 (RGB24) or 4 (RGBA32).
 template <int BPP>
 __global__ __launch_bounds__(INT_THREADS) void k_ycbcr420_int(
-    const uint8_t* __restrict__ Y, const uint8_t* __restrict__ Cb, const uint8_t* __restrict__ Cr,
-    uint8_t* __restrict__ out, int w, int h, int ys, int cbs, int crs, int os, IntCoef k,
+    const IntPlanes P, int w, int h, int ys, int cbs, int crs, int os, IntCoef k,
     int groups_per_row, int row_pairs)
 {
+  const uint8_t* __restrict__ Y = P.y[blockIdx.y];
+  const uint8_t* __restrict__ Cb = P.cb[blockIdx.y];
+  const uint8_t* __restrict__ Cr = P.cr[blockIdx.y];
+  uint8_t* __restrict__ out = P.out[blockIdx.y];
   // LDS staging: per wave 64 lanes x (16*BPP) bytes per row, two rows.
   constexpr int LANE_BYTES = 16 * BPP;                // 48 or 64
   constexpr int LANE_WORDS = LANE_BYTES / 4;          // 12 or 16
@@ -396,24 +406,37 @@ __global__ __launch_bounds__(256) void k_upsample_bilinear(const Pix* __restrict
 // host launchers (called from colour_host.cpp through hm_internal.h)
 // ---------------------------------------------------------------------------------------
 
-extern "C" int hm_launch_colour_int420(const hm_colour_desc* d, const int coef[4], const void* y, const void* cb,
-                                       const void* cr, void* out, hipStream_t s)
+// n images of identical geometry (d) in ceil(n / INT_BATCH) launches
+extern "C" int hm_launch_colour_int420_batch(const hm_colour_desc* d, const int coef[4], int n, const void* const* y,
+                                             const void* const* cb, const void* const* cr, void* const* out, hipStream_t s)
 {
   const int gpr = (d->width + 15) / 16;
   const int rps = (d->height + 1) / 2;
   const long total = (long)((gpr + 63) / 64) * rps; // waves
-  if (total <= 0) return HM_OK;
+  if (total <= 0 || n <= 0) return HM_OK;
   const int blocks = (int)((total + INT_THREADS / 64 - 1) / (INT_THREADS / 64));
   IntCoef k{coef[0], coef[1], coef[2], coef[3]};
-  if (d->out_format == HM_OUT_RGB)
-    hipLaunchKernelGGL(k_ycbcr420_int<3>, dim3(blocks), dim3(INT_THREADS), 0, s, (const uint8_t*)y, (const uint8_t*)cb,
-                       (const uint8_t*)cr, (uint8_t*)out, d->width, d->height, d->y_stride, d->cb_stride, d->cr_stride,
-                       d->out_stride, k, gpr, rps);
-  else
-    hipLaunchKernelGGL(k_ycbcr420_int<4>, dim3(blocks), dim3(INT_THREADS), 0, s, (const uint8_t*)y, (const uint8_t*)cb,
-                       (const uint8_t*)cr, (uint8_t*)out, d->width, d->height, d->y_stride, d->cb_stride, d->cr_stride,
-                       d->out_stride, k, gpr, rps);
+  for (int first = 0; first < n; first += INT_BATCH) {
+    const int m = n - first < INT_BATCH ? n - first : INT_BATCH;
+    IntPlanes P;
+    for (int i = 0; i < INT_BATCH; i++) {
+      const int j = first + (i < m ? i : 0);
+      P.y[i] = (const uint8_t*)y[j]; P.cb[i] = (const uint8_t*)cb[j]; P.cr[i] = (const uint8_t*)cr[j]; P.out[i] = (uint8_t*)out[j];
+    }
+    if (d->out_format == HM_OUT_RGB)
+      hipLaunchKernelGGL(k_ycbcr420_int<3>, dim3(blocks, m), dim3(INT_THREADS), 0, s, P, d->width, d->height, d->y_stride, d->cb_stride,
+                         d->cr_stride, d->out_stride, k, gpr, rps);
+    else
+      hipLaunchKernelGGL(k_ycbcr420_int<4>, dim3(blocks, m), dim3(INT_THREADS), 0, s, P, d->width, d->height, d->y_stride, d->cb_stride,
+                         d->cr_stride, d->out_stride, k, gpr, rps);
+  }
   return hm_check_hip(hipGetLastError(), "k_ycbcr420_int launch");
+}
+
+extern "C" int hm_launch_colour_int420(const hm_colour_desc* d, const int coef[4], const void* y, const void* cb,
+                                       const void* cr, void* out, hipStream_t s)
+{
+  return hm_launch_colour_int420_batch(d, coef, 1, &y, &cb, &cr, &out, s);
 }
 
 template <typename Pix, int OF>

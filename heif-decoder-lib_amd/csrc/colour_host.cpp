@@ -191,4 +191,34 @@ int hm_colour_convert(const hm_colour_desc* d, const void* d_y, const void* d_cb
   return hm_launch_colour_float(d, cf, mode, d_y, d_cb, d_cr, d_out, s);
 }
 
+// n images of identical state (one descriptor) in one go: the integer 4:2:0 chain runs as a single launch per 32
+// images; every other chain is converted image by image.  Same contract as hm_colour_convert.
+int hm_colour_convert_batch(const hm_colour_desc* d, int n, const void* const* d_y, const void* const* d_cb,
+                            const void* const* d_cr, void* const* d_out, void* stream)
+{
+  const int pipe = hm_colour_pipeline(d);
+  if (pipe < 0) return pipe;
+  if (n < 0 || (n > 0 && (!d_y || !d_cb || !d_cr || !d_out))) return hm_fail(HM_ERR_INVALID_ARG, "null pointer table");
+  if (pipe != HM_PIPE_INT420) {
+    for (int i = 0; i < n; i++) {
+      const int rc = hm_colour_convert(d, d_y[i], d_cb[i], d_cr[i], d_out[i], stream);
+      if (rc) return rc;
+    }
+    return HM_OK;
+  }
+  if ((d->y_stride % 16) || (d->cb_stride % 8) || (d->cr_stride % 8) || (d->out_stride % 16))
+    return hm_fail(HM_ERR_INVALID_ARG, "planes must be 16-byte aligned with 16-byte multiple strides");
+  if (d->y_stride < d->width || d->out_stride < d->width * hm_out_bytes_per_pixel(d->out_format))
+    return hm_fail(HM_ERR_INVALID_ARG, "stride smaller than row");
+  for (int i = 0; i < n; i++) {
+    if (!d_y[i] || !d_cb[i] || !d_cr[i] || !d_out[i]) return hm_fail(HM_ERR_INVALID_ARG, "null device pointer");
+    if (((uintptr_t)d_y[i] % 16) || ((uintptr_t)d_cb[i] % 16) || ((uintptr_t)d_cr[i] % 16) || ((uintptr_t)d_out[i] % 16))
+      return hm_fail(HM_ERR_INVALID_ARG, "planes must be 16-byte aligned with 16-byte multiple strides");
+  }
+  float cf[4];
+  hm_ycbcr_coefficients(d->has_nclx, d->matrix, d->primaries, cf);
+  const int ci[4] = {(int)std::lround(256 * cf[0]), (int)std::lround(256 * cf[1]), (int)std::lround(256 * cf[2]), (int)std::lround(256 * cf[3])};
+  return hm_launch_colour_int420_batch(d, ci, n, d_y, d_cb, d_cr, d_out, (hipStream_t)stream);
+}
+
 } // extern "C"

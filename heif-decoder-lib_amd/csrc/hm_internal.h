@@ -18,6 +18,8 @@ int hm_fail(int status, const char* fmt, ...) __attribute__((format(printf, 2, 3
 // colour.hip
 int hm_launch_colour_int420(const hm_colour_desc* d, const int coef[4], const void* y, const void* cb,
                             const void* cr, void* out, hipStream_t s);
+int hm_launch_colour_int420_batch(const hm_colour_desc* d, const int coef[4], int n, const void* const* y,
+                                  const void* const* cb, const void* const* cr, void* const* out, hipStream_t s);
 int hm_launch_colour_float(const hm_colour_desc* d, const float coef[4], int mode, const void* y,
                            const void* cb, const void* cr, void* out, hipStream_t s);
 int hm_launch_upsample_bilinear(int bit_depth, int v420, const void* in, int in_stride, void* out, int out_stride,

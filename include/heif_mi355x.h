@@ -97,6 +97,10 @@ HM_API int hm_ycbcr_coefficients(int has_nclx, int matrix, int primaries, float 
  * works through two temporary 4:4:4 chroma planes and returns after the stream has drained). */
 HM_API int hm_colour_convert(const hm_colour_desc* d, const void* d_y, const void* d_cb,
                              const void* d_cr, void* d_out, void* stream);
+/* The same for n images that share one descriptor (e.g. the 12 MP canvases of a batch of grids): arrays of n device
+ * pointers (host arrays).  The integer 4:2:0 chain covers up to 32 images per kernel launch. */
+HM_API int hm_colour_convert_batch(const hm_colour_desc* d, int n, const void* const* d_y, const void* const* d_cb,
+                                   const void* const* d_cr, void* const* d_out, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Host entropy decode: HEVC intra picture -> GPU command stream (hm_stream.h) */

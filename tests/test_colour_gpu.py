@@ -126,3 +126,30 @@ def test_forced_bilinear_selection(pkg):
     # not forced: the cheaper integer op
     d = pkg.capi.ColourDesc(64, 64, 8, 1, 0, 0, 0, 0, 10, 0, 0, 0, 0, 1)
     assert L.hm_colour_pipeline(C.byref(d)) == pkg.capi.HM_PIPE_INT420
+
+
+@pytest.mark.parametrize("n", [1, 3, 33, 70])
+@pytest.mark.parametrize("out_fmt", [10, 11])
+def test_batched_conversion_equals_single(pkg, n, out_fmt):
+    """hm_colour_convert_batch (one launch per 32 images of equal geometry) == n calls of hm_colour_convert"""
+    import torch
+    L = pkg.lib()
+    w, h = 200, 74
+    rng = np.random.default_rng(n * 5 + out_fmt)
+    dev = torch.device("cuda:0")
+    obpp = 3 if out_fmt == 10 else 4
+    ostride = L.hm_plane_stride(w, obpp)
+    imgs = []
+    for _ in range(n):
+        planes = [orc.alloc_plane(w, h, 1, rng=rng), orc.alloc_plane((w + 1) // 2, (h + 1) // 2, 1, rng=rng), orc.alloc_plane((w + 1) // 2, (h + 1) // 2, 1, rng=rng)]
+        t = [torch.from_numpy(p[0]).to(dev) for p in planes]
+        imgs.append((planes, t, torch.zeros((max(64, (h + 1) & ~1), ostride), dtype=torch.uint8, device=dev)))
+    d = pkg.capi.ColourDesc(w, h, 8, 1, 0, 0, 0, 0, out_fmt, imgs[0][0][0][1], imgs[0][0][1][1], imgs[0][0][2][1], ostride)
+    Arr = C.c_void_p * n
+    ptrs = [Arr(*[im[1][k].data_ptr() for im in imgs]) for k in range(3)] + [Arr(*[im[2].data_ptr() for im in imgs])]
+    L.hm_colour_convert_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    pkg.capi.check(L.hm_colour_convert_batch(C.byref(d), n, ptrs[0], ptrs[1], ptrs[2], ptrs[3], torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    for planes, _, out in imgs:
+        exp, _ = orc.colour_int(planes[0], planes[1], planes[2], w, h, 0, 0, 0, out_fmt)
+        np.testing.assert_array_equal(out.cpu().numpy()[:h, :w * obpp], exp[:h, :w * obpp])
