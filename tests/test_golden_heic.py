@@ -115,3 +115,42 @@ def _hevc_of(hm, case):
         return f.hevc_data(case["item"] or f.primary())
     finally:
         f.close()
+
+
+@pytest.mark.gpu
+def test_concurrent_decode_calls(hm):
+    """hm_decode_item from several application threads at once (libheif callers do that): shared worker crew, memory
+    pools and the default stream must give every caller its own correct picture."""
+    import threading
+    g = GOLD["grid_1x2"]
+    data, tiles = _grid_file(hm)
+    exp, stride, _ = pipeline.cpu_decode(hm, tiles, 1280, 854, g["w"], g["h"], 2, True, 10)
+    case = GOLD["cases"][0]
+    single = _load(case["file"])
+    results, errors = {}, []
+
+    def work(k):
+        try:
+            for it in range(3):
+                if k % 2 == 0:
+                    f = pipeline.HeifFile(hm, data)
+                    planes, meta = f.decode(f.primary(), 10, threads=1 + k)
+                    f.close()
+                    ok = np.array_equal(planes[0][:g["h"], :g["w"] * 3], exp[:g["h"], :g["w"] * 3])
+                else:
+                    f = pipeline.HeifFile(hm, single)
+                    planes, meta = f.decode(case["item"] or f.primary(), case["fmt"], threads=2)
+                    f.close()
+                    bpp = 3 if case["fmt"] == 10 else 4
+                    ok = pipeline.survey_fnv(planes[0], meta["stride"][0], case["w"] * bpp, case["h"]) == case["fnv"]
+                results[(k, it)] = ok
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(6)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    assert len(results) == 18 and all(results.values())
