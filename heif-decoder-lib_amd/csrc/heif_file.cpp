@@ -348,7 +348,8 @@ bool HeifFile::grid_info(uint32_t id, GridInfo& g, HeifError& err) const
   if (!it || it->type != "grid") { err = {HM_ERR_INVALID_ARG, "item is not a grid"}; return false; }
   std::vector<uint8_t> d;
   if (!item_data(id, d, err)) return false;
-  if (d.size() < 8) { err = {HM_ERR_BITSTREAM, "grid descriptor too small"}; return false; } // context.cc:180-184
+  if (d.size() < 8) { err = {HM_ERR_BITSTREAM, "grid descriptor too small"}; return false; } // context.cc:174-178
+  if (d[0] != 0) { err = {HM_ERR_UNSUPPORTED, "Grid image version " + std::to_string((int)d[0]) + " is not supported"}; return false; } // :180-187
   const int field = (d[1] & 1) ? 4 : 2;
   if (d.size() < (size_t)(4 + 2 * field)) { err = {HM_ERR_BITSTREAM, "grid descriptor too small"}; return false; }
   g.rows = d[2] + 1;

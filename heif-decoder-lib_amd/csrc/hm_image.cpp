@@ -363,6 +363,10 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
     for (int i = 0; i < nt; i++) {
       const hm_pic* h = reinterpret_cast<const hm_pic*>(blobs[i].p);
       const hm::Item* ti = f->file.item(tiles[i].id);
+      // the reference decodes every tile through decode_image_planar, which would also apply the tile item's own
+      // irot / imir / clap before the paste (context.cc:1957-2020): not on the GPU path - refuse rather than ignore
+      if (ti && !ti->props.transforms.empty() && !params->ignore_transformations)
+        return hm_fail(HM_ERR_UNSUPPORTED, "grid tile %d (item %u) carries its own irot/imir/clap", i, tiles[i].id);
       const int sw_ = ti ? ti->props.ispe_width : 0, sh_ = ti ? ti->props.ispe_height : 0;
       if (sw_ < canvas_w / g.cols || sh_ < canvas_h / g.rows) return hm_fail(HM_ERR_BITSTREAM, "Grid tiles do not cover whole image");
       if (sw_ != iw || sh_ != ih) return hm_fail(HM_ERR_BITSTREAM, "Grid tiles have different sizes");
