@@ -182,7 +182,7 @@ struct heif_error heif_context_set_threads(struct heif_context* ctx, struct heif
 void heif_image_handle_release(const struct heif_image_handle* h) { delete h; }
 int heif_image_handle_get_width(const struct heif_image_handle* h) { return h ? h->info.width : 0; }
 int heif_image_handle_get_height(const struct heif_image_handle* h) { return h ? h->info.height : 0; }
-int heif_image_handle_has_alpha_channel(const struct heif_image_handle*) { return 0; } // alpha aux images: outside the hot path
+int heif_image_handle_has_alpha_channel(const struct heif_image_handle* h) { return h ? h->info.has_alpha : 0; } // heif.cc: handle->image->get_alpha_channel() != nullptr
 int heif_image_handle_get_luma_bits_per_pixel(const struct heif_image_handle* h) { return h ? h->info.bit_depth : -1; }
 int heif_image_handle_get_chroma_bits_per_pixel(const struct heif_image_handle* h) { return h ? h->info.bit_depth : -1; }
 int heif_image_handle_is_primary_image(const struct heif_image_handle* h)
@@ -265,6 +265,12 @@ struct heif_error heif_decode_image(const struct heif_image_handle* in, struct h
     adopt(heif_channel_Y, 0, dec.plane_width[0], dec.plane_height[0]);
     adopt(heif_channel_Cb, 1, dec.plane_width[1], dec.plane_height[1]);
     adopt(heif_channel_Cr, 2, dec.plane_width[2], dec.plane_height[2]);
+    if (dec.alpha) { // the alpha auxiliary image's Y plane, transferred as heif_channel_Alpha (context.cc:2071)
+      std::unique_ptr<Plane> p(new Plane());
+      p->width = dec.width; p->height = dec.height; p->bit_depth = dec.bit_depth; p->stride = dec.alpha_stride;
+      p->allocated = dec.alpha; p->mem = dec.alpha; p->from_core = true; dec.alpha = nullptr;
+      img->planes[heif_channel_Alpha] = std::move(p);
+    }
   }
   else {
     img->colorspace = heif_colorspace_RGB;

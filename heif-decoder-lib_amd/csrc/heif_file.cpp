@@ -76,6 +76,21 @@ std::vector<uint32_t> HeifFile::references(uint32_t from, const char* type) cons
   return {};
 }
 
+uint32_t HeifFile::alpha_item_of(uint32_t id) const
+{
+  uint32_t alpha = 0;
+  for (const Ref& r : refs_) {
+    if (r.type != "auxl" || r.from == id) continue;
+    const Item* aux = item(r.from);
+    if (!aux) continue;
+    const std::string& t = aux->props.aux_type;
+    if (t != "urn:mpeg:avc:2015:auxid:1" && t != "urn:mpeg:hevc:2015:auxid:1" && t != "urn:mpeg:mpegB:cicp:systems:auxiliary:alpha") continue;
+    for (uint32_t to : r.to)
+      if (to == id) alpha = r.from; // a later reference replaces an earlier one (Image::set_alpha_channel)
+  }
+  return alpha;
+}
+
 std::vector<uint32_t> HeifFile::top_level_images() const
 {
   // images that are not tiles / thumbnails / auxiliary images of another item

@@ -83,6 +83,9 @@ class HeifFile {
   // 'grid' descriptor + 'dimg' references (context.cc:172-221, 2142-2153)
   bool grid_info(uint32_t id, GridInfo& g, HeifError& err) const;
   std::vector<uint32_t> references(uint32_t from, const char* type) const;
+  // the auxiliary image that is the alpha channel of image `id` (0 if none): an 'auxl' reference to `id` from an item
+  // whose auxC names an alpha type (context.cc:885-945)
+  uint32_t alpha_item_of(uint32_t id) const;
 
  private:
   struct Ref { std::string type; uint32_t from; std::vector<uint32_t> to; };

@@ -195,6 +195,18 @@ class Crew {
 
 int fail_from(const hm::HeifError& e) { return hm_fail(e.status, "%s", e.message.c_str()); }
 
+// A decoded image on the device: what HeifContext::decode_image_planar returns (YCbCr planes after the item's
+// transformative properties), plus everything that must outlive the asynchronous work that produced it.
+struct PlanarImage {
+  DevPlane P[3];
+  int w = 0, h = 0, chroma = 1, bd = 8;
+  hm::NclxProfile native; // profile of the decoded image (VUI, overridden by an item 'colr' nclx)
+  bool is_grid = false;
+  std::vector<std::unique_ptr<DevMem>> retired;
+  std::unique_ptr<hm_batch, void (*)(hm_batch*)> batch{nullptr, hm_batch_destroy};
+};
+int decode_planar(const hm_file* f, uint32_t id, const hm_decode_params* params, hipStream_t s, PlanarImage& I);
+
 } // namespace
 
 extern "C" {
@@ -253,6 +265,7 @@ int hm_file_image_info(const hm_file* f, uint32_t id, hm_image_info* info)
   info->bit_depth = first->props.hvcc.bit_depth_luma;
   info->chroma = first->props.hvcc.chroma_format;
   info->has_transforms = (it->props.has_irot || it->props.has_imir || it->props.has_clap) ? 1 : 0;
+  info->has_alpha = f->file.alpha_item_of(id) != 0;
   info->coded_width = info->width; info->coded_height = info->height;
   // the size an image handle reports (context.cc:810-838): every clap sets it to the rounded aperture size,
   // a 90 / 270 degree irot swaps it, in property order
@@ -268,6 +281,8 @@ int hm_file_image_info(const hm_file* f, uint32_t id, hm_image_info* info)
   }
   return HM_OK;
 }
+
+uint32_t hm_file_alpha_item(const hm_file* f, uint32_t id) { return f ? f->file.alpha_item_of(id) : 0; }
 
 int hm_file_item_hevc_data(const hm_file* f, uint32_t id, uint8_t** out, size_t* out_size)
 {
@@ -289,12 +304,18 @@ void hm_decoded_free(hm_decoded* d)
 {
   if (!d) return;
   for (int c = 0; c < 3; c++) { hm_pool_pinned_free(d->plane[c]); d->plane[c] = nullptr; }
+  hm_pool_pinned_free(d->alpha);
+  d->alpha = nullptr;
 }
 
-int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params, hm_decoded* out)
+} // extern "C"
+
+namespace {
+
+// decode_image_planar for an hvc1 item or a grid (context.cc:1729-2020): host entropy decode of every coded picture,
+// one GPU batch, then the item's irot / imir / clap.  Asynchronous on `s` (the caller synchronises).
+int decode_planar(const hm_file* f, uint32_t id, const hm_decode_params* params, hipStream_t s, PlanarImage& I)
 {
-  if (!f || !params || !out) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
-  std::memset(out, 0, sizeof(*out));
   const hm::Item* it = f->file.item(id);
   if (!it) return hm_fail(HM_ERR_INVALID_ARG, "no item %u", id);
   hm::HeifError err;
@@ -381,10 +402,8 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
   const int bps = bd > 8 ? 2 : 1;
   const int cw = (canvas_w + 1) / 2, chh = chroma == 1 ? (canvas_h + 1) / 2 : canvas_h;
 
-  hipStream_t s = (hipStream_t)params->stream;
-  DevPlane P[3];
-  DevMem dout;
-  std::vector<std::unique_ptr<DevMem>> retired;
+  DevPlane (&P)[3] = I.P;
+  std::vector<std::unique_ptr<DevMem>>& retired = I.retired;
   int rc;
   if ((rc = alloc_plane(P[0], canvas_w, canvas_h, bps)) || (rc = alloc_plane(P[1], cw, chh, bps)) || (rc = alloc_plane(P[2], cw, chh, bps))) return rc;
   // a grid canvas the tiles do not cover completely stays zero like a fresh HeifPixelImage? the
@@ -393,7 +412,7 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
 
   hm_batch* batch = nullptr;
   if ((rc = hm_batch_create(&batch))) return rc;
-  std::unique_ptr<hm_batch, void (*)(hm_batch*)> guard(batch, hm_batch_destroy);
+  I.batch.reset(batch);
   // colour profile of the decoded (native) image: 'colr' nclx of the item overrides the VUI one
   hm::NclxProfile native;
   for (int i = 0; i < nt; i++) {
@@ -424,6 +443,49 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
   int img_w = canvas_w, img_h = canvas_h;
   if (!params->ignore_transformations && !it->props.transforms.empty())
     if ((rc = apply_transforms(it->props.transforms, P, img_w, img_h, chroma, bd, s, retired))) return rc;
+  I.w = img_w; I.h = img_h; I.chroma = chroma; I.bd = bd; I.native = native; I.is_grid = is_grid;
+  return HM_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params, hm_decoded* out)
+{
+  if (!f || !params || !out) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
+  std::memset(out, 0, sizeof(*out));
+  hipStream_t s = (hipStream_t)params->stream;
+  PlanarImage I;
+  int rc = decode_planar(f, id, params, s, I);
+  if (rc) return rc;
+  // ---- alpha channel: the auxiliary image is decoded like any image (its own transformations included), its Y plane
+  //      becomes the alpha plane, scaled nearest-neighbour if its size differs (context.cc:2029-2078) ----
+  PlanarImage A;
+  DevPlane alpha_scaled;
+  const DevPlane* alpha = nullptr;
+  const uint32_t alpha_id = f->file.alpha_item_of(id);
+  if (alpha_id) {
+    if ((rc = decode_planar(f, alpha_id, params, s, A))) return rc;
+    alpha = &A.P[0];
+    if (A.w != I.w || A.h != I.h) {
+      if ((rc = alloc_plane(alpha_scaled, I.w, I.h, A.bd > 8 ? 2 : 1))) return rc;
+      if ((rc = hm_launch_scale_nn(A.bd > 8 ? 2 : 1, A.P[0].mem.p, A.P[0].stride, A.w, A.h, alpha_scaled.mem.p, alpha_scaled.stride, I.w, I.h, s))) return rc;
+      alpha = &alpha_scaled;
+    }
+    out->has_alpha = 1;
+  }
+  DevPlane (&P)[3] = I.P;
+  const int img_w = I.w, img_h = I.h, chroma = I.chroma, bd = I.bd;
+  const hm::NclxProfile& native = I.native;
+  const bool is_grid = I.is_grid;
+  DevMem dout;
+  static const bool trace = std::getenv("HM_TRACE") != nullptr;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (trace) std::fprintf(stderr, "[hm_decode_item] %-28s %8.3f ms (after the planar decode)\n", what,
+                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+  };
 
   out->width = img_w; out->height = img_h; out->bit_depth = bd; out->chroma = chroma;
   // a grid canvas carries no nclx (context.cc:2250-2276); a single image keeps its own
@@ -441,6 +503,14 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
       if (e != hipSuccess) { hm_decoded_free(out); return hm_check_hip(e, "D2H"); }
       out->plane_width[c] = P[c].w; out->plane_height[c] = P[c].h;
     }
+    if (alpha) {
+      const size_t sz = plane_bytes(*alpha);
+      out->alpha = (uint8_t*)hm_pool_pinned_alloc(sz);
+      if (!out->alpha) { hm_decoded_free(out); return hm_fail(HM_ERR_NOMEM, "out of memory"); }
+      out->alpha_stride = alpha->stride;
+      e = hipMemcpyAsync(out->alpha, alpha->mem.p, sz, hipMemcpyDeviceToHost, s);
+      if (e != hipSuccess) { hm_decoded_free(out); return hm_check_hip(e, "D2H"); }
+    }
   }
   else {
     hm_colour_desc cd;
@@ -456,6 +526,16 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
     const size_t obytes = (size_t)cd.out_stride * mem_rows(img_h);
     if ((rc = dout.alloc(obytes))) return rc;
     if ((rc = hm_colour_convert(&cd, P[0].mem.p, P[1].mem.p, P[2].mem.p, dout.p, s))) return rc;
+    if (alpha) {
+      // RGB24 / RRGGBB targets have no alpha: Op_drop_alpha_plane, the colour values do not depend on it.  RGBA: the 8-bit
+      // ops copy the plane (yuv2rgb.cc:483-488, rgb2rgb.cc:81-84 refuses any other alpha depth)
+      if (params->out_format == HM_OUT_RGBA) {
+        if (A.bd != 8) return hm_fail(HM_ERR_UNSUPPORTED, "alpha plane of %d bits with an 8-bit RGBA target", A.bd);
+        if ((rc = hm_launch_set_alpha(dout.p, cd.out_stride, img_w, img_h, alpha->mem.p, alpha->stride, s))) return rc;
+      }
+      else if (params->out_format != HM_OUT_RGB)
+        return hm_fail(HM_ERR_UNSUPPORTED, "16-bit interleaved output of an image with an alpha channel (RRGGBBAA) is not on the GPU path");
+    }
     out->out_format = params->out_format;
     out->stride[0] = cd.out_stride;
     out->plane_width[0] = img_w; out->plane_height[0] = img_h;

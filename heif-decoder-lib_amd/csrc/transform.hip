@@ -35,7 +35,46 @@ __global__ __launch_bounds__(256) void k_mirror(const uint8_t* __restrict__ in, 
   out[(size_t)y * os + x] = horizontal ? in[(size_t)y * is + (w - 1 - x)] : in[(size_t)(h - 1 - y) * is + x];
 }
 
+// HeifPixelImage::scale_nearest_neighbor (pixelimage.cc:1156-1254) for one plane: out[y][x] = in[y * ih / oh][x * iw / ow]
+template <typename Pix>
+__global__ __launch_bounds__(256) void k_scale_nn(const Pix* __restrict__ in, int is, int iw, int ih, Pix* __restrict__ out, int os, int ow, int oh)
+{
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= ow || y >= oh) return;
+  const int iy = (int)((long long)y * ih / oh), ix = (int)((long long)x * iw / ow);
+  out[(size_t)y * os + x] = in[(size_t)iy * is + ix];
+}
+
+// interleaved RGBA, 8 bit: byte 3 of every pixel = the alpha plane sample (Op_YCbCr420_to_RGB32, yuv2rgb.cc:483-488;
+// Op_RGB_to_RGB24_32 with an input alpha plane, rgb2rgb.cc:108-127)
+__global__ __launch_bounds__(256) void k_set_alpha(uint8_t* __restrict__ rgba, int os, int w, int h, const uint8_t* __restrict__ alpha, int as)
+{
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= w || y >= h) return;
+  rgba[(size_t)y * os + 4 * x + 3] = alpha[(size_t)y * as + x];
+}
+
 } // namespace
+
+extern "C" int hm_launch_set_alpha(void* rgba, int out_stride, int w, int h, const void* alpha, int alpha_stride, hipStream_t s)
+{
+  if (w <= 0 || h <= 0) return HM_OK;
+  const dim3 grid((w + 63) / 64, (h + 3) / 4), block(256);
+  hipLaunchKernelGGL(k_set_alpha, grid, block, 0, s, (uint8_t*)rgba, out_stride, w, h, (const uint8_t*)alpha, alpha_stride);
+  return hm_check_hip(hipGetLastError(), "k_set_alpha launch");
+}
+
+extern "C" int hm_launch_scale_nn(int bytes_per_sample, const void* in, int in_stride, int iw, int ih, void* out, int out_stride, int ow,
+                                  int oh, hipStream_t s)
+{
+  if (ow <= 0 || oh <= 0) return HM_OK;
+  const dim3 grid((ow + 63) / 64, (oh + 3) / 4), block(256);
+  if (bytes_per_sample == 1)
+    hipLaunchKernelGGL(k_scale_nn<uint8_t>, grid, block, 0, s, (const uint8_t*)in, in_stride, iw, ih, (uint8_t*)out, out_stride, ow, oh);
+  else
+    hipLaunchKernelGGL(k_scale_nn<uint16_t>, grid, block, 0, s, (const uint16_t*)in, in_stride / 2, iw, ih, (uint16_t*)out, out_stride / 2, ow, oh);
+  return hm_check_hip(hipGetLastError(), "k_scale_nn launch");
+}
 
 // one plane; strides in bytes; angle 90 / 180 / 270 (counter-clockwise)
 extern "C" int hm_launch_rotate_ccw(int bytes_per_sample, int angle, const void* in, int in_stride, int w, int h, void* out,

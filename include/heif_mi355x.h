@@ -168,6 +168,7 @@ typedef struct hm_image_info {
   int32_t bit_depth, chroma;   /* from the (first tile's) hvcC                                   */
   int32_t is_grid, grid_rows, grid_cols, tile_width, tile_height;
   int32_t has_transforms;      /* irot / imir / clap present on the item                         */
+  int32_t has_alpha;           /* an alpha auxiliary image is attached (heif_image_handle_has_alpha_channel) */
   int32_t coded_width, coded_height; /* size before the transformative properties (ispe / grid output size);
                                         width / height above are what heif_image_handle_get_width/height report
                                         (context.cc:810-838: clap size, swapped by a 90 / 270 degree irot)       */
@@ -193,6 +194,11 @@ typedef struct hm_decoded {
                                   hm_host_free), libheif plane layout (pixelimage.cc:139-218);      */
   int32_t stride[3];           /*   interleaved output uses plane[0] only                          */
   int32_t plane_width[3], plane_height[3];
+  /* alpha channel of the image (an auxiliary image item, context.cc:2029-2078): interleaved RGBA output carries it in
+   * byte 3; native planar output gets it as a fourth plane (same size as the image, same sample width) */
+  int32_t has_alpha;
+  uint8_t* alpha;              /* pinned host memory like plane[], NULL unless out_format == 0 && has_alpha */
+  int32_t alpha_stride;
 } hm_decoded;
 
 /* parse the box structure (the bytes are copied).  Replaces heif_context_read_from_memory. */
@@ -201,6 +207,8 @@ HM_API void     hm_file_close(hm_file* f);
 HM_API uint32_t hm_file_primary_item(const hm_file* f);
 HM_API int      hm_file_top_level_images(const hm_file* f, uint32_t* ids, int max_ids); /* returns the count */
 HM_API int      hm_file_image_info(const hm_file* f, uint32_t id, hm_image_info* info);
+/* the auxiliary image item that is the alpha channel of image `id` (context.cc:885-945), 0 if there is none */
+HM_API uint32_t hm_file_alpha_item(const hm_file* f, uint32_t id);
 /* the byte string a decoder plugin gets through push_data for an hvc1 item (free with hm_free) */
 HM_API int      hm_file_item_hevc_data(const hm_file* f, uint32_t id, uint8_t** out, size_t* out_size);
 /* decode an hvc1 image or a grid item.  Replaces heif_decode_image (heif.cc:1150-1186 ->

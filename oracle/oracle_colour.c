@@ -514,3 +514,21 @@ void orc_crop_plane(const uint8_t* in, int is, int pw, int ph, int bps, int img_
   if (!out) return;
   for (int y = pt; y <= pb; y++) memcpy(out + (size_t)(y - pt) * os, in + (size_t)y * is + (size_t)pl * bps, (size_t)(pr - pl + 1) * bps);
 }
+
+/* HeifPixelImage::scale_nearest_neighbor for one plane (pixelimage.cc:1230-1250): out[y][x] = in[y*ih/oh][x*iw/ow] */
+void orc_scale_nn_plane(const uint8_t* in, int is, int iw, int ih, int bps, uint8_t* out, int os, int ow, int oh)
+{
+  for (int y = 0; y < oh; y++) {
+    const int iy = y * ih / oh;
+    for (int x = 0; x < ow; x++) {
+      const int ix = x * iw / ow;
+      for (int b = 0; b < bps; b++) out[(size_t)y * os + (size_t)bps * x + b] = in[(size_t)iy * is + (size_t)bps * ix + b];
+    }
+  }
+}
+/* the alpha plane of an image goes to byte 3 of interleaved RGBA (yuv2rgb.cc:483-488, rgb2rgb.cc:108-127) */
+void orc_set_alpha_rgba(uint8_t* rgba, int os, int w, int h, const uint8_t* alpha, int as)
+{
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) rgba[(size_t)y * os + 4 * x + 3] = alpha[(size_t)y * as + x];
+}

@@ -53,7 +53,7 @@ def _transform_box(t):
     raise ValueError(kind)
 
 
-def write_heic(pictures, size, grid=None, chroma_format=1, bit_depth=8, colr=None, sizes=None, transforms=None):
+def write_heic(pictures, size, grid=None, chroma_format=1, bit_depth=8, colr=None, sizes=None, transforms=None, aux=None):
     """pictures: list of [len][NAL] strings (each with VPS/SPS/PPS first); size: (w,h) of one picture
     (sizes: optional per-picture override of the declared ispe).
     grid: None for a single image, or (rows, cols, out_w, out_h).  colr: optional per-tile nclx tuple."""
@@ -80,7 +80,7 @@ def write_heic(pictures, size, grid=None, chroma_format=1, bit_depth=8, colr=Non
         items.append((k + 1, b"hvc1", payload))
         assoc[k + 1] = a
     primary = 1
-    iref = b""
+    iref_boxes = []
     if grid is None and transforms:  # transformative properties of the single image, in order
         assoc[1] += [0x8000 | prop(_transform_box(t)) for t in transforms]
     if grid is not None:
@@ -90,9 +90,20 @@ def write_heic(pictures, size, grid=None, chroma_format=1, bit_depth=8, colr=Non
         assoc[gid] = [prop(_full(b"ispe", 0, 0, struct.pack(">II", ow, oh)))]
         assoc[gid] += [0x8000 | prop(_transform_box(t)) for t in (transforms or [])]
         primary = gid
-        iref = _full(b"iref", 0, 0, _box(b"dimg", struct.pack(">HH", gid, len(pictures)) +
-                                         b"".join(struct.pack(">H", k + 1) for k in range(len(pictures)))))
+        iref_boxes.append(_box(b"dimg", struct.pack(">HH", gid, len(pictures)) +
+                               b"".join(struct.pack(">H", k + 1) for k in range(len(pictures)))))
     wide = len(props) > 127  # ipma flags & 1: 15-bit property indices
+    # auxiliary images (e.g. alpha) of the primary item: (coded picture, (w, h), aux type URN)
+    for lp, asize, urn in (aux or []):
+        aid = len(items) + 1
+        nals = split_nals(lp)
+        params = [n for n in nals if ((n[0] >> 1) & 0x3F) in (32, 33, 34)]
+        vcl = [n for n in nals if ((n[0] >> 1) & 0x3F) not in (32, 33, 34)]
+        items.append((aid, b"hvc1", b"".join(struct.pack(">I", len(n)) + n for n in vcl)))
+        assoc[aid] = [0x8000 | prop(_hvcc(params, chroma_format, bit_depth)), prop(_full(b"ispe", 0, 0, struct.pack(">II", *asize))),
+                      0x8000 | prop(_full(b"auxC", 0, 0, urn.encode() + b"\0"))]
+        iref_boxes.append(_box(b"auxl", struct.pack(">HHH", aid, 1, primary)))
+    iref = _full(b"iref", 0, 0, b"".join(iref_boxes)) if iref_boxes else b""
     ipma = struct.pack(">I", len(assoc))
     for iid in sorted(assoc):
         ipma += struct.pack(">HB", iid, len(assoc[iid]))

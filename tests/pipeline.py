@@ -13,7 +13,7 @@ SURVEY_FNV_INIT = 1469598103934665603  # the survey's harness used this (truncat
 
 
 class ImageInfo(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in "width height bit_depth chroma is_grid grid_rows grid_cols tile_width tile_height has_transforms coded_width coded_height".split()]
+    _fields_ = [(n, C.c_int32) for n in "width height bit_depth chroma is_grid grid_rows grid_cols tile_width tile_height has_transforms has_alpha coded_width coded_height".split()]
 
 
 class DecodeParams(C.Structure):
@@ -24,7 +24,8 @@ class DecodeParams(C.Structure):
 
 class Decoded(C.Structure):
     _fields_ = [(n, C.c_int32) for n in "width height bit_depth chroma out_format has_nclx primaries transfer matrix full_range used_ext_dst".split()] + \
-               [("plane", C.POINTER(C.c_uint8) * 3), ("stride", C.c_int32 * 3), ("plane_width", C.c_int32 * 3), ("plane_height", C.c_int32 * 3)]
+               [("plane", C.POINTER(C.c_uint8) * 3), ("stride", C.c_int32 * 3), ("plane_width", C.c_int32 * 3), ("plane_height", C.c_int32 * 3),
+                ("has_alpha", C.c_int32), ("alpha", C.POINTER(C.c_uint8)), ("alpha_stride", C.c_int32)]
 
 
 def bind(hm):
@@ -48,6 +49,11 @@ class HeifFile:
         rc = hm.hm_file_open(data, len(data), C.byref(self.h))
         if rc:
             raise RuntimeError(f"hm_file_open: {rc}: {hm.hm_last_error().decode()}")
+
+    def alpha_item(self, iid):
+        self.hm.hm_file_alpha_item.restype = C.c_uint32
+        self.hm.hm_file_alpha_item.argtypes = [C.c_void_p, C.c_uint32]
+        return self.hm.hm_file_alpha_item(self.h, iid)
 
     def primary(self):
         return self.hm.hm_file_primary_item(self.h)
@@ -86,6 +92,10 @@ class HeifFile:
         meta = {k: getattr(d, k) for k in "width height bit_depth chroma out_format has_nclx primaries transfer matrix full_range".split()}
         meta["stride"] = [d.stride[c] for c in range(3)]
         meta["plane_size"] = [(d.plane_width[c], d.plane_height[c]) for c in range(3)]
+        meta["has_alpha"] = d.has_alpha
+        if copy and d.alpha:
+            rows = max(64, (d.height + 1) & ~1)
+            meta["alpha"] = np.ctypeslib.as_array(d.alpha, shape=(rows, d.alpha_stride)).copy()
         self.hm.hm_decoded_free(C.byref(d))
         return planes, meta
 
@@ -149,6 +159,20 @@ def cpu_decode(hm, tiles, tile_w, tile_h, canvas_w, canvas_h, cols, is_grid, out
         o.orc_ycbcr_to_rgb_float(orc.ptr(canv[0][0]), canv[0][1], orc.ptr(canv[1][0]), canv[1][1], orc.ptr(canv[2][0]), canv[2][1],
                                  canvas_w, canvas_h, bd, cf, has_nclx, mat, prim, full, orc.ptr(out), os_, out_fmt)
     return out, os_, canv
+
+
+def attach_alpha(hm, rgba, stride, w, h, alpha_hevc, aw, ah):
+    """CPU flow of context.cc:2029-2078 for an RGBA result: decode the alpha auxiliary image, take its Y plane, scale it
+    nearest-neighbour to the image size if needed, store it in byte 3 of every pixel."""
+    o = orc.load()
+    _, _, canv = cpu_decode(hm, [alpha_hevc], aw, ah, aw, ah, 1, False, 10)
+    a, a_stride = canv[0]
+    if (aw, ah) != (w, h):
+        scaled, s_stride = orc.alloc_plane(w, h, 1)
+        o.orc_scale_nn_plane(orc.ptr(a), a_stride, aw, ah, 1, orc.ptr(scaled), s_stride, w, h)
+        a, a_stride = scaled, s_stride
+    o.orc_set_alpha_rgba(orc.ptr(rgba), stride, w, h, orc.ptr(a), a_stride)
+    return a, a_stride
 
 
 def survey_fnv(buf, stride, row_bytes, rows):

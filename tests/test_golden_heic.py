@@ -32,6 +32,11 @@ def test_cpu_flow_matches_reference_fingerprint(hm, case):
     info = f.info(iid)
     assert (info.width, info.height) == (case["w"], case["h"])
     out, stride, _ = pipeline.cpu_decode(hm, [f.hevc_data(iid)], case["w"], case["h"], case["w"], case["h"], 1, False, case["fmt"])
+    assert bool(info.has_alpha) == (f.alpha_item(iid) != 0)
+    if case.get("alpha"):  # RGBA of an image with an alpha auxiliary image (fuzz-corpus colors-with-alpha*)
+        aid = f.alpha_item(iid)
+        ai = f.info(aid)
+        pipeline.attach_alpha(hm, out, stride, case["w"], case["h"], f.hevc_data(aid), ai.width, ai.height)
     f.close()
     bpp = 3 if case["fmt"] == 10 else 4
     if "stride" in case:

@@ -128,3 +128,32 @@ def test_transform_limits_are_loud(hm):
         f.decode(f.primary(), 10)
     # ... is skipped with ignore_transformations
     f.close()
+
+
+def _write_with_alpha(main, main_size, alpha, alpha_size, transforms=None):
+    """single image + an auxiliary alpha image (auxC urn:mpeg:mpegB:cicp:systems:auxiliary:alpha, 'auxl' reference)"""
+    return heifwriter.write_heic([main], main_size, transforms=transforms, aux=[(alpha, alpha_size, "urn:mpeg:mpegB:cicp:systems:auxiliary:alpha")])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("alpha_size", [(96, 64), (48, 32), (40, 56)], ids=["same_size", "half_size", "odd_ratio"])
+def test_alpha_auxiliary_image(hm, alpha_size):
+    """the alpha auxiliary image is decoded, scaled nearest-neighbour when its size differs
+    (context.cc:2029-2078) and lands in byte 3 of RGBA / as a fourth plane of the native output."""
+    main = synthutil.picture(8500, width=96, height=64, vui=1, full_range=1, matrix=6)
+    alpha = synthutil.picture(8501, width=alpha_size[0], height=alpha_size[1])
+    f = pipeline.HeifFile(hm, _write_with_alpha(main, (96, 64), alpha, alpha_size))
+    iid = f.primary()
+    assert f.info(iid).has_alpha == 1 and f.alpha_item(iid) != 0
+    rgba, meta = f.decode(iid, 11)
+    rgb, _ = f.decode(iid, 10)
+    native, nmeta = f.decode(iid, 0)
+    f.close()
+    exp, stride, _ = pipeline.cpu_decode(hm, [main], 96, 64, 96, 64, 1, False, 11)
+    a, a_stride = pipeline.attach_alpha(hm, exp, stride, 96, 64, alpha, *alpha_size)
+    assert meta["has_alpha"] == 1
+    np.testing.assert_array_equal(rgba[0][:64, :96 * 4], exp[:64, :96 * 4])
+    assert len(set(exp[:64, 3:96 * 4:4].ravel().tolist())) > 4  # a real alpha plane, not a constant
+    exp3, s3, _ = pipeline.cpu_decode(hm, [main], 96, 64, 96, 64, 1, False, 10)
+    np.testing.assert_array_equal(rgb[0][:64, :96 * 3], exp3[:64, :96 * 3])  # RGB24: the alpha plane is dropped
+    np.testing.assert_array_equal(nmeta["alpha"][:64, :96], a[:64, :96])
