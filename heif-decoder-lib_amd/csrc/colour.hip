@@ -475,6 +475,27 @@ extern "C" int hm_launch_colour_float(const hm_colour_desc* d, const float coef[
   return HM_ERR_UNSUPPORTED;
 }
 
+// Op_to_hdr_planes (hdr_sdr.cc:52-107) for one 8-bit plane: out = (in << (bits - 8)) | (in >> (16 - bits)), 16-bit storage
+namespace {
+__global__ __launch_bounds__(256) void k_to_hdr(const uint8_t* __restrict__ in, int is, uint16_t* __restrict__ out, int os, int w, int h,
+                                                int shift1, int shift2)
+{
+  const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= w || y >= h) return;
+  for (int k = 0; k < 4 && x + k < w; k++) {
+    const int v = in[(size_t)y * is + x + k];
+    out[(size_t)y * os + x + k] = (uint16_t)((v << shift1) | (v >> shift2));
+  }
+}
+} // namespace
+extern "C" int hm_launch_to_hdr(const void* in, int in_stride, void* out, int out_stride, int w, int h, int out_bits, hipStream_t s)
+{
+  if (w <= 0 || h <= 0) return HM_OK;
+  const dim3 grid((w + 255) / 256, (h + 3) / 4), block(256);
+  hipLaunchKernelGGL(k_to_hdr, grid, block, 0, s, (const uint8_t*)in, in_stride, (uint16_t*)out, out_stride / 2, w, h, out_bits - 8, 16 - out_bits);
+  return hm_check_hip(hipGetLastError(), "k_to_hdr launch");
+}
+
 // one chroma plane: 4:2:0 (v420 != 0) or 4:2:2 -> 4:4:4; strides in bytes
 extern "C" int hm_launch_upsample_bilinear(int bit_depth, int v420, const void* in, int in_stride, void* out, int out_stride,
                                            int w, int h, hipStream_t s)

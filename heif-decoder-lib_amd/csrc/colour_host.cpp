@@ -64,6 +64,24 @@ void selection_state(const hm_colour_desc* d, int& matrix, bool& full_range)
   if (matrix == 2) matrix = 6;
 }
 
+// What every op after the first one of a chain sees as the image's nclx: ColorConversionPipeline::convert_image
+// attaches the step's output state to each intermediate image (colorconversion.cc:452-455), and that state started
+// from the input profile (or the default-constructed one) with the undefined values replaced by the sRGB defaults
+// (colorconversion.cc:520-527, nclx.cc:346-359: matrix 2 -> 6, primaries 2 -> 1).  E.g. a matrix-2 image then gets
+// the BT.601 coefficients computed from Kr/Kb instead of the built-in defaults - the float values differ in the last
+// bits (pinned by BASELINE.md's RRGGBB_LE fingerprints of example.heic).
+hm_colour_desc second_step_desc(const hm_colour_desc* d)
+{
+  hm_colour_desc n = *d;
+  n.has_nclx = 1;
+  n.matrix = d->has_nclx ? d->matrix : 2;
+  n.primaries = d->has_nclx ? d->primaries : 2;
+  n.full_range = d->has_nclx ? (d->full_range != 0) : 1;
+  if (n.matrix == 2) n.matrix = 6;
+  if (n.primaries == 2) n.primaries = 1;
+  return n;
+}
+
 int validate(const hm_colour_desc* d)
 {
   if (!d) return hm_fail(HM_ERR_INVALID_ARG, "null colour descriptor");
@@ -136,6 +154,11 @@ int hm_colour_pipeline(const hm_colour_desc* d)
     return HM_PIPE_FLOAT; // Op_YCbCr_to_RGB<u8> -> Op_RGB_to_RGB24_32
   }
   if (d->bit_depth > 8 && rgb16) return HM_PIPE_FLOAT; // Op_YCbCr_to_RGB<u16> -> RRGGBB (or the 4:2:0 direct op: same arithmetic)
+  if (d->bit_depth == 8 && rgb16 && d->chroma == HM_CHROMA_420 && matrix != 0 && matrix != 8 && matrix != 11 && matrix != 14 &&
+      d->chroma_upsampling != HM_UPSAMPLE_BILINEAR)
+    // RRGGBB targets are "> 8 bit, 10 if unknown" (colorconversion.cc:575-585): Op_to_hdr_planes (8 -> 10 bit) followed by
+    // Op_YCbCr420_to_RRGGBBaa is the only cost-22 chain; other chroma formats tie between two 33-cost chains -> not offered
+    return HM_PIPE_TO_HDR_FLOAT;
   // 8 -> 16 or 16 -> 8 bit needs the reference's bit-depth ops (hdr_sdr.cc): outside the hot path (§8f rank 3)
   return hm_fail(HM_ERR_UNSUPPORTED, "bit depth %d -> output format %d needs a depth-conversion op", d->bit_depth, d->out_format);
 }
@@ -157,6 +180,28 @@ int hm_colour_convert(const hm_colour_desc* d, const void* d_y, const void* d_cb
   // ops read the image's own nclx (not the selection state): yuv2rgb.cc:190-198, 329-334
   hm_ycbcr_coefficients(d->has_nclx, d->matrix, d->primaries, cf);
   hipStream_t s = (hipStream_t)stream;
+  if (pipe == HM_PIPE_TO_HDR_FLOAT) {
+    const int cw = (d->width + 1) / 2, chh = (d->height + 1) / 2;
+    const int ys2 = hm_plane_stride(d->width, 2), cs2 = hm_plane_stride(cw, 2);
+    auto rows = [](int h) { const int r = (h + 1) & ~1; return r < 64 ? 64 : r; };
+    const size_t yb = (size_t)ys2 * rows(d->height), cb = (size_t)cs2 * rows(chh);
+    uint8_t* tmp = (uint8_t*)hm_pool_device_alloc(yb + 2 * cb);
+    if (!tmp) return hm_fail(HM_ERR_NOMEM, "8 -> 10 bit planes: %zu bytes of device memory", yb + 2 * cb);
+    int rc = hm_launch_to_hdr(d_y, d->y_stride, tmp, ys2, d->width, d->height, 10, s);
+    if (!rc) rc = hm_launch_to_hdr(d_cb, d->cb_stride, tmp + yb, cs2, cw, chh, 10, s);
+    if (!rc) rc = hm_launch_to_hdr(d_cr, d->cr_stride, tmp + yb + cb, cs2, cw, chh, 10, s);
+    if (!rc) {
+      hm_colour_desc d10 = second_step_desc(d);
+      d10.bit_depth = 10;
+      d10.y_stride = ys2; d10.cb_stride = d10.cr_stride = cs2;
+      float c2[4];
+      hm_ycbcr_coefficients(1, d10.matrix, d10.primaries, c2);
+      rc = hm_launch_colour_float(&d10, c2, 0, tmp, tmp + yb, tmp + yb + cb, d_out, s);
+    }
+    const hipError_t e = hipStreamSynchronize(s); // the temporaries go back to the pool
+    hm_pool_device_free(tmp);
+    return rc ? rc : hm_check_hip(e, "8 -> 10 bit colour chain");
+  }
   if (pipe == HM_PIPE_BILINEAR_FLOAT) {
     const int cw = (d->width + 1) / 2;
     if (d->cb_stride < cw * bps || d->cr_stride < cw * bps) return hm_fail(HM_ERR_INVALID_ARG, "stride smaller than row");
@@ -168,11 +213,12 @@ int hm_colour_convert(const hm_colour_desc* d, const void* d_y, const void* d_cb
     int rc = hm_launch_upsample_bilinear(d->bit_depth, v420, d_cb, d->cb_stride, tmp, ts, d->width, d->height, s);
     if (!rc) rc = hm_launch_upsample_bilinear(d->bit_depth, v420, d_cr, d->cr_stride, tmp + tbytes, ts, d->width, d->height, s);
     if (!rc) {
-      hm_colour_desc d444 = *d;
+      hm_colour_desc d444 = second_step_desc(d); // the float op is the chain's second step
       d444.chroma = HM_CHROMA_444;
       d444.cb_stride = d444.cr_stride = ts;
-      const int m = d->has_nclx ? d->matrix : 2;
-      rc = hm_launch_colour_float(&d444, cf, m == 8 ? 3 : 0, d_y, tmp, tmp + tbytes, d_out, s);
+      float c2[4];
+      hm_ycbcr_coefficients(1, d444.matrix, d444.primaries, c2);
+      rc = hm_launch_colour_float(&d444, c2, d444.matrix == 8 ? 3 : 0, d_y, tmp, tmp + tbytes, d_out, s);
     }
     const hipError_t e = hipStreamSynchronize(s); // the temporaries go back to the pool
     hm_pool_device_free(tmp);

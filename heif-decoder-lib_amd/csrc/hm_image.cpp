@@ -537,6 +537,15 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
         return hm_fail(HM_ERR_UNSUPPORTED, "16-bit interleaved output of an image with an alpha channel (RRGGBBAA) is not on the GPU path");
     }
     out->out_format = params->out_format;
+    // the converted image carries the output state's profile: the input one with undefined values replaced by the
+    // sRGB defaults (colorconversion.cc:452-455, 520-527); an 8-bit image becomes 10 bit in an RRGGBB target (:575-585)
+    out->has_nclx = 1;
+    if (!is_grid) { out->primaries = native.primaries; out->transfer = native.transfer; out->matrix = native.matrix; out->full_range = native.full_range; }
+    else { out->primaries = 2; out->transfer = 2; out->matrix = 2; out->full_range = 1; }
+    if (out->primaries == 2) out->primaries = 1;
+    if (out->transfer == 2) out->transfer = 13;
+    if (out->matrix == 2) out->matrix = 6;
+    if (bd == 8 && (params->out_format == HM_OUT_RRGGBB_BE || params->out_format == HM_OUT_RRGGBB_LE)) out->bit_depth = 10;
     out->stride[0] = cd.out_stride;
     out->plane_width[0] = img_w; out->plane_height[0] = img_h;
     if (params->ext_dst && params->ext_dst_stride >= (uint32_t)(img_w * obpp) &&

@@ -82,7 +82,7 @@ typedef struct hm_colour_desc {
 enum { HM_UPSAMPLE_NEAREST = 1, HM_UPSAMPLE_BILINEAR = 2 }; /* == enum heif_chroma_upsampling_algorithm */
 
 /* which reference op chain convert_colorspace() would pick for this state (§3.4 of SURVEY) */
-enum { HM_PIPE_INT420 = 1, HM_PIPE_FLOAT = 2, HM_PIPE_BILINEAR_FLOAT = 3 };
+enum { HM_PIPE_INT420 = 1, HM_PIPE_FLOAT = 2, HM_PIPE_BILINEAR_FLOAT = 3, HM_PIPE_TO_HDR_FLOAT = 4 };
 HM_API int hm_colour_pipeline(const hm_colour_desc* d); /* HM_PIPE_* or negative status */
 
 /* Observable libheif plane stride for a plane `width` pixels wide (pixelimage.cc:139-218). */

@@ -97,6 +97,7 @@ uint64_t orc_fnv1a64_rows(const uint8_t* p, int stride, int row_bytes, int rows,
 
 
 /* transformative item properties, one plane at a time (pixelimage.cc:539-888, box.cc:51-152, 3771-3814) */
+void orc_to_hdr_plane(const uint8_t* in, int is, int w, int h, int bits, uint8_t* out, int os);
 void orc_scale_nn_plane(const uint8_t* in, int is, int iw, int ih, int bps, uint8_t* out, int os, int ow, int oh);
 void orc_set_alpha_rgba(uint8_t* rgba, int os, int w, int h, const uint8_t* alpha, int as);
 void orc_rotate_ccw_plane(const uint8_t* in, int is, int w, int h, int bps, int angle, uint8_t* out, int os);

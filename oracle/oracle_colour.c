@@ -532,3 +532,16 @@ void orc_set_alpha_rgba(uint8_t* rgba, int os, int w, int h, const uint8_t* alph
   for (int y = 0; y < h; y++)
     for (int x = 0; x < w; x++) rgba[(size_t)y * os + 4 * x + 3] = alpha[(size_t)y * as + x];
 }
+
+/* Op_to_hdr_planes for one 8-bit plane (hdr_sdr.cc:84-103): out = (in << shift1) | (in >> shift2),
+ * shift1 = bits - 8, shift2 = 16 - bits; out in 16-bit storage, strides in bytes */
+void orc_to_hdr_plane(const uint8_t* in, int is, int w, int h, int bits, uint8_t* out, int os)
+{
+  const int shift1 = bits - 8, shift2 = 2 * 8 - bits;
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      const int v = in[(size_t)y * is + x];
+      const uint16_t o = (uint16_t)((v << shift1) | (v >> shift2));
+      memcpy(out + (size_t)y * os + 2 * (size_t)x, &o, 2);
+    }
+}

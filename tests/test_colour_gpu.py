@@ -90,7 +90,7 @@ def test_float_hdr(pkg, w, h, chroma, bit_depth, nclx, out_fmt):
 
 def test_no_silent_fallback(pkg):
     """unsupported states fail loudly instead of falling back"""
-    d = pkg.capi.ColourDesc(64, 64, 8, 1, 0, 0, 0, 0, 14, 64, 64, 64, 384)
+    d = pkg.capi.ColourDesc(64, 64, 8, 2, 0, 0, 0, 0, 14, 64, 64, 64, 384)  # 8-bit 4:2:2 -> RRGGBB: two equal-cost chains in the reference
     assert pkg.lib().hm_colour_pipeline(C.byref(d)) == -2
 
 
@@ -111,7 +111,10 @@ def test_forced_bilinear_chain(pkg, w, h, chroma, bit_depth, out_fmt, nclx):
     assert pkg.lib().hm_colour_pipeline(C.byref(d)) == 3
     got, ostride, obpp = _run_gpu(pkg, planes, w, h, bit_depth, chroma, nclx, out_fmt, upsampling=2)
     up = [orc.upsample_bilinear(planes[c], w, h, bit_depth, chroma) for c in (1, 2)]
-    exp, es = orc.colour_float(planes[0], up[0], up[1], w, h, bit_depth, 3, *nclx, out_fmt)
+    # the float op is the second step: it sees the intermediate state's profile (undefined -> sRGB defaults, cf. pipeline.cpu_decode)
+    m2, p2 = (nclx[1], nclx[2]) if nclx[0] else (2, 2)
+    step2 = (1, 6 if m2 == 2 else m2, 1 if p2 == 2 else p2, nclx[3] if nclx[0] else 1)
+    exp, es = orc.colour_float(planes[0], up[0], up[1], w, h, bit_depth, 3, *step2, out_fmt)
     np.testing.assert_array_equal(got[:h, :w * obpp], exp[:h, :w * obpp])
 
 
@@ -153,3 +156,28 @@ def test_batched_conversion_equals_single(pkg, n, out_fmt):
     for planes, _, out in imgs:
         exp, _ = orc.colour_int(planes[0], planes[1], planes[2], w, h, 0, 0, 0, out_fmt)
         np.testing.assert_array_equal(out.cpu().numpy()[:h, :w * obpp], exp[:h, :w * obpp])
+
+
+@pytest.mark.parametrize("w,h", [(64, 64), (1280, 854), (17, 9), (2, 2), (1023, 3)])
+@pytest.mark.parametrize("nclx", [(0, 0, 0, 0), (1, 2, 2, 0), (1, 6, 1, 1), (1, 1, 1, 0), (1, 9, 9, 1)])
+@pytest.mark.parametrize("out_fmt", [12, 14])
+def test_8bit_to_rrggbb_chain(pkg, w, h, nclx, out_fmt):
+    """8-bit 4:2:0 -> RRGGBB: the target becomes 10 bit (colorconversion.cc:575-585), reached by Op_to_hdr_planes +
+    Op_YCbCr420_to_RRGGBBaa; the second op reads the intermediate state's profile (matrix 2 -> 6).  Pinned end to end by
+    BASELINE.md's RRGGBB_LE fingerprints of example.heic (tests/test_golden_heic.py)."""
+    rng = np.random.default_rng(w * 3 + h + out_fmt)
+    cw, ch = _chroma_dims(w, h, 1)
+    planes = [orc.alloc_plane(w, h, 1, rng=rng), orc.alloc_plane(cw, ch, 1, rng=rng), orc.alloc_plane(cw, ch, 1, rng=rng)]
+    d = pkg.capi.ColourDesc(w, h, 8, 1, *nclx, out_fmt, 0, 0, 0, 0)
+    assert pkg.lib().hm_colour_pipeline(C.byref(d)) == 4
+    got, ostride, obpp = _run_gpu(pkg, planes, w, h, 8, 1, nclx, out_fmt)
+    o = orc.load()
+    hi = []
+    for (buf, st), (pw, ph) in zip(planes, ((w, h), (cw, ch), (cw, ch))):
+        b2, s2 = orc.alloc_plane(pw, ph, 2)
+        o.orc_to_hdr_plane(orc.ptr(buf), st, pw, ph, 10, orc.ptr(b2), s2)
+        hi.append((b2, s2))
+    m2, p2 = (nclx[1], nclx[2]) if nclx[0] else (2, 2)
+    step2 = (1, 6 if m2 == 2 else m2, 1 if p2 == 2 else p2, nclx[3] if nclx[0] else 1)
+    exp, es = orc.colour_float(hi[0], hi[1], hi[2], w, h, 10, 1, *step2, out_fmt)
+    np.testing.assert_array_equal(got[:h, :w * obpp], exp[:h, :w * obpp])

@@ -75,7 +75,7 @@ def test_heif_decode_image_like_reference_sample(api, case):
     p = api.heif_image_get_plane_readonly(img, 10, C.byref(stride))  # heif_channel_interleaved
     w, hh = api.heif_image_get_width(img, 10), api.heif_image_get_height(img, 10)
     assert (w, hh) == (case["w"], case["h"])
-    bpp = 3 if case["fmt"] == 10 else 4
+    bpp = {10: 3, 11: 4, 12: 6, 14: 6}[case["fmt"]]
     buf = np.ctypeslib.as_array(p, shape=(hh, stride.value))
     assert pipeline.survey_fnv(np.ascontiguousarray(buf), stride.value, w * bpp, hh) == case["fnv"]
     api.heif_image_release(img)
@@ -111,8 +111,14 @@ def test_grid_with_threads_and_ext_dst(api, hm):
 
 def test_unsupported_requests_fail_loudly(api):
     data = open(os.path.join(HERE, "data", "colors-no-alpha.heic"), "rb").read()
-    ctx, h, img, e = _decode(api, data, 0, 1, 14)  # 8-bit -> RRGGBB_LE needs a depth-conversion op
+    ctx, h, img, e = _decode(api, data, 0, 1, 3)  # planar RGB 4:4:4 target: only the interleaved targets are on the GPU path
     assert e.code == 4 and not img  # heif_error_Unsupported_feature
+    api.heif_image_handle_release(h); api.heif_context_free(ctx)
+    # 8-bit -> RRGGBB_LE is served (Op_to_hdr_planes + the 4:2:0 HDR op): 10-bit values in 16-bit words
+    ctx, h, img, e = _decode(api, data, 0, 1, 14)
+    assert e.code == 0 and img, e.message
+    assert api.heif_image_get_bits_per_pixel_range(img, 10) == 10
+    api.heif_image_release(img)
     api.heif_image_handle_release(h); api.heif_context_free(ctx)
 
 

@@ -38,7 +38,7 @@ def test_cpu_flow_matches_reference_fingerprint(hm, case):
         ai = f.info(aid)
         pipeline.attach_alpha(hm, out, stride, case["w"], case["h"], f.hevc_data(aid), ai.width, ai.height)
     f.close()
-    bpp = 3 if case["fmt"] == 10 else 4
+    bpp = {10: 3, 11: 4, 12: 6, 14: 6}[case["fmt"]]
     if "stride" in case:
         assert stride == case["stride"]
     if "first" in case:
@@ -65,7 +65,7 @@ def test_gpu_decode_item_matches_reference_fingerprint(hm, case):
     iid = case["item"] or f.primary()
     planes, meta = f.decode(iid, case["fmt"])
     f.close()
-    bpp = 3 if case["fmt"] == 10 else 4
+    bpp = {10: 3, 11: 4, 12: 6, 14: 6}[case["fmt"]]
     assert (meta["width"], meta["height"]) == (case["w"], case["h"])
     if "stride" in case:
         assert meta["stride"][0] == case["stride"]
@@ -81,7 +81,9 @@ def test_gpu_grid_matches_reference_fingerprint(hm, threads):
     planes, meta = f.decode(f.primary(), 10, threads=threads)
     native, nmeta = f.decode(f.primary(), 0)
     f.close()
-    assert meta["has_nclx"] == 0  # a grid canvas carries no nclx
+    assert nmeta["has_nclx"] == 0  # a grid canvas carries no nclx
+    # the converted image carries the conversion's output state: the default profile with the sRGB replacements
+    assert (meta["has_nclx"], meta["primaries"], meta["transfer"], meta["matrix"], meta["full_range"]) == (1, 1, 13, 6, 1)
     assert pipeline.survey_fnv(planes[0], meta["stride"][0], g["w"] * 3, g["h"]) == g["fnv"]
     # native canvas planes == CPU flow (limited->full rescale of the paste, context.cc:2504-2528)
     _, _, canv = pipeline.cpu_decode(hm, tiles, 1280, 854, g["w"], g["h"], 2, True, 10)
@@ -146,7 +148,7 @@ def test_concurrent_decode_calls(hm):
                     f = pipeline.HeifFile(hm, single)
                     planes, meta = f.decode(case["item"] or f.primary(), case["fmt"], threads=2)
                     f.close()
-                    bpp = 3 if case["fmt"] == 10 else 4
+                    bpp = {10: 3, 11: 4, 12: 6, 14: 6}[case["fmt"]]
                     ok = pipeline.survey_fnv(planes[0], meta["stride"][0], case["w"] * bpp, case["h"]) == case["fnv"]
                 results[(k, it)] = ok
         except Exception as e:  # noqa: BLE001
