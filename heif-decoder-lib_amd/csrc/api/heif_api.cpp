@@ -260,11 +260,14 @@ struct heif_error heif_decode_image(const struct heif_image_handle* in, struct h
     img->planes[ch] = std::move(p);
   };
   if (out_format == 0) {
-    img->colorspace = heif_colorspace_YCbCr;
+    // the plugin creates a monochrome image for 4:0:0 pictures (decoder_libde265.cc:97-110)
+    img->colorspace = dec.chroma == 0 ? heif_colorspace_monochrome : heif_colorspace_YCbCr;
     img->chroma = (heif_chroma)dec.chroma;
     adopt(heif_channel_Y, 0, dec.plane_width[0], dec.plane_height[0]);
-    adopt(heif_channel_Cb, 1, dec.plane_width[1], dec.plane_height[1]);
-    adopt(heif_channel_Cr, 2, dec.plane_width[2], dec.plane_height[2]);
+    if (dec.chroma != 0) {
+      adopt(heif_channel_Cb, 1, dec.plane_width[1], dec.plane_height[1]);
+      adopt(heif_channel_Cr, 2, dec.plane_width[2], dec.plane_height[2]);
+    }
     if (dec.alpha) { // the alpha auxiliary image's Y plane, transferred as heif_channel_Alpha (context.cc:2071)
       std::unique_ptr<Plane> p(new Plane());
       p->width = dec.width; p->height = dec.height; p->bit_depth = dec.bit_depth; p->stride = dec.alpha_stride;

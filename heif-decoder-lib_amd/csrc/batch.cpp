@@ -123,8 +123,8 @@ int hm_batch_add(hm_batch* b, const uint8_t* blob, size_t size, const hm_tile_de
   Item it;
   std::memcpy(&it.hdr, blob, sizeof(hm_pic));
   if (it.hdr.magic != HM_STREAM_MAGIC || it.hdr.total_bytes > size) return hm_fail(HM_ERR_INVALID_ARG, "not a command stream");
-  if (it.hdr.chroma_format != 1 && it.hdr.chroma_format != 2) return hm_fail(HM_ERR_UNSUPPORTED, "chroma format %d", it.hdr.chroma_format);
-  for (int c = 0; c < 3; c++)
+  if (it.hdr.chroma_format > 2) return hm_fail(HM_ERR_UNSUPPORTED, "chroma format %d", it.hdr.chroma_format);
+  for (int c = 0; c < (it.hdr.chroma_format == 0 ? 1 : 3); c++) // a monochrome picture only has a luma destination
     if (!dest->plane[c]) return hm_fail(HM_ERR_INVALID_ARG, "null destination plane");
   // (a stream of a previous, still in-flight upload is never overwritten: the arena only grows until hm_batch_clear)
   it.stage_off = (b->stage.used + 255) & ~(size_t)255;
@@ -227,7 +227,7 @@ int hm_batch_upload(hm_batch* b, void* stream)
       // destination = tile paste geometry of context.cc:2457-2502
       const hm_tile_dest& t = it.dest;
       const int sw = 2;
-      for (int p = 0; p < 3; p++) {
+      for (int p = 0; p < (h.chroma_format == 0 ? 1 : 3); p++) { // monochrome: copy_w/h of the chroma planes stay 0
         int chan_w = t.canvas_width, chan_h = t.canvas_height, cx0 = t.x0, cy0 = t.y0;
         // the decoder plugin hands libheif the conformance-window crop of the coded picture
         // (de265_get_image_width/height, decoder_libde265.cc:88-157)

@@ -87,7 +87,7 @@ int validate(const hm_colour_desc* d)
   if (!d) return hm_fail(HM_ERR_INVALID_ARG, "null colour descriptor");
   if (d->width <= 0 || d->height <= 0) return hm_fail(HM_ERR_INVALID_ARG, "bad image size %dx%d", d->width, d->height);
   if (d->bit_depth < 8 || d->bit_depth > 16) return hm_fail(HM_ERR_UNSUPPORTED, "bit depth %d", d->bit_depth);
-  if (d->chroma != HM_CHROMA_420 && d->chroma != HM_CHROMA_422 && d->chroma != HM_CHROMA_444)
+  if (d->chroma != HM_CHROMA_MONO && d->chroma != HM_CHROMA_420 && d->chroma != HM_CHROMA_422 && d->chroma != HM_CHROMA_444)
     return hm_fail(HM_ERR_UNSUPPORTED, "chroma format %d", d->chroma);
   return HM_OK;
 }
@@ -139,6 +139,10 @@ int hm_colour_pipeline(const hm_colour_desc* d)
   const bool rgb8 = d->out_format == HM_OUT_RGB || d->out_format == HM_OUT_RGBA;
   const bool rgb16 = d->out_format == HM_OUT_RRGGBB_BE || d->out_format == HM_OUT_RRGGBB_LE;
   if (!rgb8 && !rgb16) return hm_fail(HM_ERR_UNSUPPORTED, "output format %d", d->out_format);
+  if (d->chroma == HM_CHROMA_MONO) { // monochrome image: Op_mono_to_RGB24_32 (8 bit only, monochrome.cc:160-198)
+    if (d->bit_depth == 8 && rgb8) return HM_PIPE_MONO;
+    return hm_fail(HM_ERR_UNSUPPORTED, "monochrome %d-bit image -> output format %d", d->bit_depth, d->out_format);
+  }
   if (d->chroma_upsampling == HM_UPSAMPLE_BILINEAR && d->chroma != HM_CHROMA_444) {
     // every nearest-neighbour op refuses (yuv2rgb.cc:37-41, 268-272, 377-381, 506-510); the bilinear ops refuse
     // matrix 0 (chroma_sampling.cc:466-468, 743-745) => convert_colorspace() finds no chain
@@ -167,6 +171,11 @@ int hm_colour_convert(const hm_colour_desc* d, const void* d_y, const void* d_cb
 {
   const int pipe = hm_colour_pipeline(d);
   if (pipe < 0) return pipe;
+  if (pipe == HM_PIPE_MONO) {
+    if (!d_y || !d_out) return hm_fail(HM_ERR_INVALID_ARG, "null device pointer");
+    if (d->y_stride < d->width || d->out_stride < d->width * hm_out_bytes_per_pixel(d->out_format)) return hm_fail(HM_ERR_INVALID_ARG, "stride smaller than row");
+    return hm_launch_mono_to_rgb(d_y, d->y_stride, d_out, d->out_stride, d->width, d->height, hm_out_bytes_per_pixel(d->out_format), (hipStream_t)stream);
+  }
   if (!d_y || !d_cb || !d_cr || !d_out) return hm_fail(HM_ERR_INVALID_ARG, "null device pointer");
   const int bps = d->bit_depth > 8 ? 2 : 1;
   // the vector fast paths need 16 B aligned rows (true for every libheif-style plane)

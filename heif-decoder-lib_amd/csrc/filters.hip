@@ -177,6 +177,7 @@ __global__ __launch_bounds__(256) void k_deblock(const hm_dev_pic* __restrict__ 
     return;
   }
   // ---- chroma segments (deblock.cc:1608-1772) ----
+  if (dp.chroma_format == 0) return;
   const int sw = 2, sh = dp.chroma_format == 1 ? 2 : 1;
   const int xIncr = 2 * sw, yIncr = 2 * sh;
   const int cwn = (dp.w4 + xIncr - 1) / xIncr, chn = (dp.h4 + yIncr - 1) / yIncr;

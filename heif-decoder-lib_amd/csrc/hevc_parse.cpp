@@ -139,9 +139,9 @@ struct Decoder {
   {
     if (s.range_ext_any) throw ParseError(HM_ERR_UNSUPPORTED, "range-extension coding tools");
     if (s.scaling_list_enabled) throw ParseError(HM_ERR_UNSUPPORTED, "scaling lists");
-    if (s.ChromaArrayType == 0 || s.ChromaArrayType == 3 || s.separate_colour_plane)
-      throw ParseError(HM_ERR_UNSUPPORTED, "chroma format (only 4:2:0 and 4:2:2 are on the GPU path)");
-    if (s.bit_depth_y != s.bit_depth_c) throw ParseError(HM_ERR_UNSUPPORTED, "different luma / chroma bit depth");
+    if (s.chroma_format_idc == 3 || s.separate_colour_plane)
+      throw ParseError(HM_ERR_UNSUPPORTED, "chroma format (4:0:0, 4:2:0 and 4:2:2 are on the GPU path)");
+    if (s.chroma_format_idc != 0 && s.bit_depth_y != s.bit_depth_c) throw ParseError(HM_ERR_UNSUPPORTED, "different luma / chroma bit depth");
     if (s.bit_depth_y > 12) throw ParseError(HM_ERR_UNSUPPORTED, "bit depth above 12");
     if (p.cross_component_prediction || p.chroma_qp_offset_list_enabled)
       throw ParseError(HM_ERR_UNSUPPORTED, "range-extension PPS tools");

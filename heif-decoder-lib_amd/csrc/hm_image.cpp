@@ -73,6 +73,7 @@ int apply_transforms(const std::vector<hm::Transform>& list, DevPlane (&P)[3], i
       // (pixelimage.cc:552-586): the reference's later colour ops then read outside the planes - refuse loudly
       if (chroma == 2 && t.angle != 180) return hm_fail(HM_ERR_UNSUPPORTED, "irot %d on a 4:2:2 image is undefined in the reference", t.angle);
       for (int c = 0; c < 3; c++) {
+        if (!P[c].mem.p) continue; // monochrome
         DevPlane n;
         const bool sw = t.angle != 180;
         int rc = alloc_plane(n, sw ? P[c].h : P[c].w, sw ? P[c].w : P[c].h, bps);
@@ -86,6 +87,7 @@ int apply_transforms(const std::vector<hm::Transform>& list, DevPlane (&P)[3], i
     else if (t.kind == hm::Transform::Mirror) {
       if (bd != 8) return hm_fail(HM_ERR_UNSUPPORTED, "Can currently only mirror images with 8 bits per pixel"); // pixelimage.cc:748-752
       for (int c = 0; c < 3; c++) {
+        if (!P[c].mem.p) continue;
         DevPlane n;
         int rc = alloc_plane(n, P[c].w, P[c].h, bps);
         if (rc) return rc;
@@ -112,6 +114,7 @@ int apply_transforms(const std::vector<hm::Transform>& list, DevPlane (&P)[3], i
       if (bottom >= img_h) bottom = img_h - 1;
       if (left > right || top > bottom) return hm_fail(HM_ERR_BITSTREAM, "Invalid clean aperture"); // context.cc:2004-2008
       for (int k = 0; k < 3; k++) { // HeifPixelImage::crop, pixelimage.cc:797-888: plane rectangle by integer scaling
+        if (!P[k].mem.p) continue;
         const int pl = (int)((int64_t)left * P[k].w / img_w), pr = (int)((int64_t)right * P[k].w / img_w);
         const int pt = (int)((int64_t)top * P[k].h / img_h), pb = (int)((int64_t)bottom * P[k].h / img_h);
         DevPlane n;
@@ -405,10 +408,12 @@ int decode_planar(const hm_file* f, uint32_t id, const hm_decode_params* params,
   DevPlane (&P)[3] = I.P;
   std::vector<std::unique_ptr<DevMem>>& retired = I.retired;
   int rc;
-  if ((rc = alloc_plane(P[0], canvas_w, canvas_h, bps)) || (rc = alloc_plane(P[1], cw, chh, bps)) || (rc = alloc_plane(P[2], cw, chh, bps))) return rc;
+  if ((rc = alloc_plane(P[0], canvas_w, canvas_h, bps))) return rc;
+  if (chroma != 0 && ((rc = alloc_plane(P[1], cw, chh, bps)) || (rc = alloc_plane(P[2], cw, chh, bps)))) return rc; // 4:0:0: luma only
   // a grid canvas the tiles do not cover completely stays zero like a fresh HeifPixelImage? the
   // reference leaves it uninitialised; tiles must cover the output (context.cc:2321-2337)
-  for (int c = 0; c < 3; c++) hipMemsetAsync(P[c].mem.p, 0, plane_bytes(P[c]), s);
+  for (int c = 0; c < 3; c++)
+    if (P[c].mem.p) hipMemsetAsync(P[c].mem.p, 0, plane_bytes(P[c]), s);
 
   hm_batch* batch = nullptr;
   if ((rc = hm_batch_create(&batch))) return rc;
@@ -495,6 +500,7 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
   if (params->out_format == 0) { // native planar YCbCr
     out->out_format = 0;
     for (int c = 0; c < 3; c++) {
+      if (!P[c].mem.p) continue; // monochrome image: Y only
       const size_t sz = plane_bytes(P[c]);
       out->plane[c] = (uint8_t*)hm_pool_pinned_alloc(sz);
       if (!out->plane[c]) { hm_decoded_free(out); return hm_fail(HM_ERR_NOMEM, "out of memory"); }

@@ -30,6 +30,7 @@ int hm_launch_rotate_ccw(int bytes_per_sample, int angle, const void* in, int in
 int hm_launch_scale_nn(int bytes_per_sample, const void* in, int in_stride, int iw, int ih, void* out, int out_stride, int ow,
                        int oh, hipStream_t s);
 int hm_launch_set_alpha(void* rgba, int out_stride, int w, int h, const void* alpha, int alpha_stride, hipStream_t s);
+int hm_launch_mono_to_rgb(const void* y, int y_stride, void* out, int out_stride, int w, int h, int bpp, hipStream_t s);
 int hm_launch_mirror(const void* in, int in_stride, int w, int h, int horizontal, void* out, int out_stride, hipStream_t s);
 
 // devpool.cpp: size-bucketed cache of device / pinned-host allocations (hipMalloc + hipFree cost more

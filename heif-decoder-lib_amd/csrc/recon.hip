@@ -782,8 +782,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
         if (lane < bh) u[lane * P + UPAD - 1] = u[lane * P + UPAD + BW - 1]; // right column becomes the left neighbour
       };
       flush_plane(std::integral_constant<int, ctb>(), u0, P0, lw, dp.plane[0], dp.pitch[0], ctb, dp.width, dp.height);
-      flush_plane(std::integral_constant<int, cw_c>(), u1, P1, lw + lo1, dp.plane[1], dp.pitch[1], ch_c, planeWc, planeHc);
-      flush_plane(std::integral_constant<int, cw_c>(), u2, P1, lw + lo2, dp.plane[2], dp.pitch[2], ch_c, planeWc, planeHc);
+      if (dp.chroma_format != 0) { // 4:0:0 pictures carry luma blocks only
+        flush_plane(std::integral_constant<int, cw_c>(), u1, P1, lw + lo1, dp.plane[1], dp.pitch[1], ch_c, planeWc, planeHc);
+        flush_plane(std::integral_constant<int, cw_c>(), u2, P1, lw + lo2, dp.plane[2], dp.pitch[2], ch_c, planeWc, planeHc);
+      }
       // ---- publish progress: only LDS traffic has to be ordered (the picture stores stay in flight) ----
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
       if (lane == 0) __hip_atomic_store(&progress[row], cx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

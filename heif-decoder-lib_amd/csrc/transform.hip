@@ -54,7 +54,28 @@ __global__ __launch_bounds__(256) void k_set_alpha(uint8_t* __restrict__ rgba, i
   rgba[(size_t)y * os + 4 * x + 3] = alpha[(size_t)y * as + x];
 }
 
+// Op_mono_to_RGB24_32 (monochrome.cc:201-273): 8-bit luma -> (v, v, v[, 0xFF]); BPP 3 or 4
+template <int BPP>
+__global__ __launch_bounds__(256) void k_mono_to_rgb(const uint8_t* __restrict__ y, int ys, uint8_t* __restrict__ out, int os, int w, int h)
+{
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), r = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= w || r >= h) return;
+  const uint8_t v = y[(size_t)r * ys + x];
+  uint8_t* o = out + (size_t)r * os + BPP * x;
+  o[0] = v; o[1] = v; o[2] = v;
+  if (BPP == 4) o[3] = 0xFF;
+}
+
 } // namespace
+
+extern "C" int hm_launch_mono_to_rgb(const void* y, int y_stride, void* out, int out_stride, int w, int h, int bpp, hipStream_t s)
+{
+  if (w <= 0 || h <= 0) return HM_OK;
+  const dim3 grid((w + 63) / 64, (h + 3) / 4), block(256);
+  if (bpp == 3) hipLaunchKernelGGL(k_mono_to_rgb<3>, grid, block, 0, s, (const uint8_t*)y, y_stride, (uint8_t*)out, out_stride, w, h);
+  else hipLaunchKernelGGL(k_mono_to_rgb<4>, grid, block, 0, s, (const uint8_t*)y, y_stride, (uint8_t*)out, out_stride, w, h);
+  return hm_check_hip(hipGetLastError(), "k_mono_to_rgb launch");
+}
 
 extern "C" int hm_launch_set_alpha(void* rgba, int out_stride, int w, int h, const void* alpha, int alpha_stride, hipStream_t s)
 {

@@ -69,7 +69,7 @@ enum {
 typedef struct hm_colour_desc {
   int32_t width, height;        /* luma size in pixels                                         */
   int32_t bit_depth;            /* 8..16; planes are uint8 (8) or uint16 little-endian (>8)    */
-  int32_t chroma;               /* HM_CHROMA_420 / _422 / _444                                  */
+  int32_t chroma;               /* HM_CHROMA_MONO (d_cb / d_cr unused) / _420 / _422 / _444      */
   int32_t has_nclx;             /* 0: image carries no nclx (every grid canvas) => defaults     */
   int32_t matrix, primaries, full_range; /* the attached nclx (ignored when !has_nclx)          */
   int32_t out_format;           /* HM_OUT_*                                                     */
@@ -82,7 +82,7 @@ typedef struct hm_colour_desc {
 enum { HM_UPSAMPLE_NEAREST = 1, HM_UPSAMPLE_BILINEAR = 2 }; /* == enum heif_chroma_upsampling_algorithm */
 
 /* which reference op chain convert_colorspace() would pick for this state (§3.4 of SURVEY) */
-enum { HM_PIPE_INT420 = 1, HM_PIPE_FLOAT = 2, HM_PIPE_BILINEAR_FLOAT = 3, HM_PIPE_TO_HDR_FLOAT = 4 };
+enum { HM_PIPE_INT420 = 1, HM_PIPE_FLOAT = 2, HM_PIPE_BILINEAR_FLOAT = 3, HM_PIPE_TO_HDR_FLOAT = 4, HM_PIPE_MONO = 5 };
 HM_API int hm_colour_pipeline(const hm_colour_desc* d); /* HM_PIPE_* or negative status */
 
 /* Observable libheif plane stride for a plane `width` pixels wide (pixelimage.cc:139-218). */
@@ -113,7 +113,7 @@ HM_API int hm_colour_convert_batch(const hm_colour_desc* d, int n, const void* c
  * command stream (struct hm_pic at offset 0).  CABAC / parsing run on the calling CPU thread -
  * as in the reference (slice.cc) - and are thread-safe across different calls.
  * Returns HM_ERR_UNSUPPORTED for syntax outside the GPU hot path (inter slices, PCM,
- * transquant bypass, scaling lists, range-extension tools, 4:0:0 / 4:4:4). */
+ * transquant bypass, scaling lists, range-extension tools, 4:4:4). */
 HM_API int hm_hevc_parse(const uint8_t* data, size_t size, int annexb, uint8_t** out_blob, size_t* out_size);
 HM_API void hm_free(void* p);
 

@@ -454,7 +454,7 @@ static void apply_sao(pic_t* P, uint16_t* const src[3])
   const hm_pic* H = P->hdr;
   const int ctb = 1 << H->log2_ctb;
   static const int hPos[4][2] = {{-1, 1}, {0, 0}, {-1, 1}, {1, -1}}, vPos[4][2] = {{0, 0}, {-1, 1}, {-1, 1}, {-1, 1}};
-  for (int cIdx = 0; cIdx < 3; cIdx++) {
+  for (int cIdx = 0; cIdx < (H->chroma_format == 0 ? 1 : 3); cIdx++) {
     const int bd = cIdx ? H->bit_depth_c : H->bit_depth_y, maxv = (1 << bd) - 1;
     const int nSW = cIdx ? ctb / P->sw : ctb, nSH = cIdx ? ctb / P->sh : ctb;
     const int W = P->w[cIdx], Hh = P->h[cIdx];
@@ -531,37 +531,38 @@ int orc_decode_picture(const uint8_t* blob, size_t size, int stages, uint16_t* y
   P.hdr = (const hm_pic*)blob;
   const hm_pic* H = P.hdr;
   if (H->magic != HM_STREAM_MAGIC || H->total_bytes > size) return -1;
-  if (H->chroma_format != 1 && H->chroma_format != 2) return -2;
+  if (H->chroma_format > 2) return -2; /* 0 = monochrome: luma only (cb / cr may be NULL) */
   P.slices = (const hm_slice*)(blob + H->off_slices);
   P.ctbs = (const hm_ctb*)(blob + H->off_ctbs);
   P.tus = (const hm_tu*)(blob + H->off_tus);
   P.coeffs = (const hm_coeff*)(blob + H->off_coeffs);
+  const int ncomp = H->chroma_format == 0 ? 1 : 3;
   P.sw = 2; P.sh = H->chroma_format == 1 ? 2 : 1;
   P.w[0] = H->width; P.h[0] = H->height;
-  P.w[1] = P.w[2] = H->width / P.sw; P.h[1] = P.h[2] = H->height / P.sh;
+  if (ncomp == 3) { P.w[1] = P.w[2] = H->width / P.sw; P.h[1] = P.h[2] = H->height / P.sh; }
   P.pl[0] = y; P.pl[1] = cb; P.pl[2] = cr;
   P.w4 = (H->width + 3) >> 2; P.h4 = (H->height + 3) >> 2;
   P.edge = (uint8_t*)calloc((size_t)P.w4 * P.h4, 1);
   P.qpy = (int8_t*)calloc((size_t)P.w4 * P.h4, 1);
-  for (int c = 0; c < 3; c++) memset(P.pl[c], 0, sizeof(uint16_t) * (size_t)P.w[c] * P.h[c]);
+  for (int c = 0; c < ncomp; c++) memset(P.pl[c], 0, sizeof(uint16_t) * (size_t)P.w[c] * P.h[c]);
 
   reconstruct(&P);
 
   if ((stages & 1) && (H->flags & HM_PIC_DEBLOCK_ANY)) { /* deblock.cc:1921-1959: all vertical edges, then all horizontal */
     deblock_luma(&P, 1);
-    deblock_chroma(&P, 1);
+    if (ncomp == 3) deblock_chroma(&P, 1);
     deblock_luma(&P, 0);
-    deblock_chroma(&P, 0);
+    if (ncomp == 3) deblock_chroma(&P, 0);
   }
   if ((stages & 2) && (H->flags & HM_PIC_SAO_ENABLED)) { /* sao.cc:552-625: SAO reads a copy of the deblocked picture */
-    uint16_t* copy[3];
-    for (int c = 0; c < 3; c++) {
+    uint16_t* copy[3] = {NULL, NULL, NULL};
+    for (int c = 0; c < ncomp; c++) {
       const size_t n = (size_t)P.w[c] * P.h[c];
       copy[c] = (uint16_t*)malloc(n * sizeof(uint16_t));
       memcpy(copy[c], P.pl[c], n * sizeof(uint16_t));
     }
     apply_sao(&P, copy);
-    for (int c = 0; c < 3; c++) free(copy[c]);
+    for (int c = 0; c < ncomp; c++) free(copy[c]);
   }
   free(P.edge);
   free(P.qpy);

@@ -32,6 +32,10 @@ CASES = {
     "ragged": dict(seed=7007, width=72, height=40, log2_ctb=5),
     "min_cb16": dict(seed=7008, width=128, height=64, log2_ctb=5, log2_min_cb=4, log2_min_tb=3, max_th_depth_intra=1),
     "flat_qp": dict(seed=7009, width=128, height=128, cu_qp_delta=0, max_th_depth_intra=0),
+    # monochrome (4:0:0): alpha planes written by libheif-style encoders, depth / gain maps
+    "mono8": dict(seed=4000001, width=160, height=104, chroma_format=0, log2_ctb=5, qp=29),
+    "mono8_ctb64_wpp": dict(seed=4000002, width=192, height=136, chroma_format=0, log2_ctb=6, wpp=1, qp=24),
+    "mono10": dict(seed=4000010, width=128, height=96, chroma_format=0, bit_depth=10, log2_ctb=4, qp=33),
 }
 
 

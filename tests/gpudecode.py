@@ -19,11 +19,11 @@ def decode_pictures(pkg, blobs, stages=3, dests=None):
         bps = 2 if bd > 8 else 1
         cw, ch = w // 2, (hh // 2 if cf == 1 else hh)
         planes = []
-        for (pw, ph) in ((w, hh), (cw, ch), (cw, ch)):
+        for (pw, ph) in (((w, hh),) if cf == 0 else ((w, hh), (cw, ch), (cw, ch))):  # monochrome: luma only
             pitch = (pw * bps + 63) // 64 * 64
             planes.append((torch.zeros((ph, pitch), dtype=torch.uint8, device=dev), pitch, pw, ph))
         d = capi.TileDest()
-        for c in range(3):
+        for c in range(len(planes)):
             d.plane[c] = planes[c][0].data_ptr()
             d.pitch[c] = planes[c][1]
         d.canvas_width, d.canvas_height, d.x0, d.y0 = w, hh, 0, 0

@@ -94,13 +94,15 @@ def write_heic(pictures, size, grid=None, chroma_format=1, bit_depth=8, colr=Non
                                b"".join(struct.pack(">H", k + 1) for k in range(len(pictures)))))
     wide = len(props) > 127  # ipma flags & 1: 15-bit property indices
     # auxiliary images (e.g. alpha) of the primary item: (coded picture, (w, h), aux type URN)
-    for lp, asize, urn in (aux or []):
+    for entry in (aux or []):
+        lp, asize, urn = entry[:3]
+        aux_cf = entry[3] if len(entry) > 3 else chroma_format  # chroma_format_idc of the auxiliary picture (0 = monochrome)
         aid = len(items) + 1
         nals = split_nals(lp)
         params = [n for n in nals if ((n[0] >> 1) & 0x3F) in (32, 33, 34)]
         vcl = [n for n in nals if ((n[0] >> 1) & 0x3F) not in (32, 33, 34)]
         items.append((aid, b"hvc1", b"".join(struct.pack(">I", len(n)) + n for n in vcl)))
-        assoc[aid] = [0x8000 | prop(_hvcc(params, chroma_format, bit_depth)), prop(_full(b"ispe", 0, 0, struct.pack(">II", *asize))),
+        assoc[aid] = [0x8000 | prop(_hvcc(params, aux_cf, bit_depth)), prop(_full(b"ispe", 0, 0, struct.pack(">II", *asize))),
                       0x8000 | prop(_full(b"auxC", 0, 0, urn.encode() + b"\0"))]
         iref_boxes.append(_box(b"auxl", struct.pack(">HHH", aid, 1, primary)))
     iref = _full(b"iref", 0, 0, b"".join(iref_boxes)) if iref_boxes else b""

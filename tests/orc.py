@@ -157,7 +157,7 @@ def ref_decode(data, flags=0, threads=0):
     if rc != 0:
         raise RuntimeError(f"reference decoder failed: {rc}")
     planes = []
-    for c in range(3):
+    for c in range(1 if pic.chroma == 0 else 3):  # a monochrome picture has a luma plane only
         w, h, bd = pic.width[c], pic.height[c], pic.bit_depth[c]
         n = pic.plane_bytes[c]
         raw = np.frombuffer(C.string_at(pic.plane[c], n), dtype=np.uint8)
@@ -184,5 +184,5 @@ def oracle_decode(blob, stages=3):
     rc = o.orc_decode_picture(buf, len(blob), stages, ptr(y), ptr(cb), ptr(cr))
     if rc != 0:
         raise RuntimeError(f"oracle decode failed: {rc}")
-    return [y, cb, cr], dict(width=w, height=h, chroma=cf, bit_depth=info[3], full_range=info[4],
+    return ([y] if cf == 0 else [y, cb, cr]), dict(width=w, height=h, chroma=cf, bit_depth=info[3], full_range=info[4],
                              matrix=info[5], primaries=info[6], has_vui_colour=info[7])

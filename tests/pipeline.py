@@ -86,6 +86,8 @@ class HeifFile:
         planes = []
         n = (1 if out_format else 3) if copy else 0
         for c in range(n):
+            if not d.plane[c]:  # monochrome image: Y only
+                continue
             rows = d.plane_height[c]
             a = np.ctypeslib.as_array(d.plane[c], shape=(rows, d.stride[c])).copy()
             planes.append(a)

@@ -140,7 +140,7 @@ struct Rng {
 
 struct SynthParams {
   int32_t width, height;       // multiples of 8
-  int32_t chroma_format;       // 1 or 2
+  int32_t chroma_format;       // 0 (monochrome), 1 or 2
   int32_t bit_depth;           // 8..12
   int32_t log2_ctb;            // 4..6
   int32_t log2_min_cb;         // 3..log2_ctb
@@ -357,7 +357,7 @@ __attribute__((visibility("default"))) int hm_synth_picture(const SynthParams* p
   sh.first_slice_segment_in_pic = true;
   sh.slice_type = 2;
   sh.sao_luma = p.sao != 0;
-  sh.sao_chroma = p.sao != 0;
+  sh.sao_chroma = p.sao != 0 && p.chroma_format != 0;
   sh.slice_qp_delta = p.qp - 26;
   sh.SliceQPY = p.qp;
   sh.deblocking_disabled = p.deblock_disable != 0;
@@ -386,7 +386,7 @@ __attribute__((visibility("default"))) int hm_synth_picture(const SynthParams* p
     w.flag(0);                 // no_output_of_prior_pics_flag (IRAP)
     w.ue(0);                   // pps id
     w.ue(2);                   // slice_type I
-    if (p.sao) { w.flag(1); w.flag(1); }
+    if (p.sao) { w.flag(1); if (p.chroma_format != 0) w.flag(1); } // slice_sao_luma_flag [, slice_sao_chroma_flag if ChromaArrayType != 0]
     w.se(sh.slice_qp_delta);
     // pps_loop_filter_across_slices_enabled_flag = 1 and (sao || !deblocking_disabled)
     if (p.sao || !p.deblock_disable) w.flag(1);

@@ -63,7 +63,8 @@ def test_synth_corpus(pkg, name):
     for stage, bits in (("recon", 0), ("deblock", 1), ("full", 3)):
         got = gpudecode.decode_pictures(pkg, [blob], bits)[0]
         exp, _ = orc.oracle_decode(blob, bits)
-        for c in range(3):
+        assert len(got) == len(exp)  # one plane for monochrome pictures
+        for c in range(len(exp)):
             bad = np.argwhere(got[c] != exp[c])
             assert bad.size == 0, f"{name} {stage} plane {c}: {len(bad)} mismatches, first (y,x)={bad[0].tolist()}"
         assert _fp(got) == SYNTH[name][stage]

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import heifwriter
+import hevcutil
 import orc
 import pipeline
 import synthutil
@@ -157,3 +158,36 @@ def test_alpha_auxiliary_image(hm, alpha_size):
     exp3, s3, _ = pipeline.cpu_decode(hm, [main], 96, 64, 96, 64, 1, False, 10)
     np.testing.assert_array_equal(rgb[0][:64, :96 * 3], exp3[:64, :96 * 3])  # RGB24: the alpha plane is dropped
     np.testing.assert_array_equal(nmeta["alpha"][:64, :96], a[:64, :96])
+
+
+@pytest.mark.gpu
+def test_monochrome_alpha_and_monochrome_image(hm):
+    """4:0:0 pictures (the usual coding of alpha planes): as the alpha auxiliary image of a colour
+    image, and as a main image (Op_mono_to_RGB24_32, monochrome.cc:160-273: v, v, v[, 0xFF])."""
+    main = synthutil.picture(8600, width=96, height=64, vui=1, full_range=1, matrix=6)
+    alpha = synthutil.picture(8601, width=96, height=64, chroma_format=0)
+    data = heifwriter.write_heic([main], (96, 64), aux=[(alpha, (96, 64), "urn:mpeg:hevc:2015:auxid:1", 0)])
+    f = pipeline.HeifFile(hm, data)
+    rgba, meta = f.decode(f.primary(), 11)
+    f.close()
+    exp, stride, _ = pipeline.cpu_decode(hm, [main], 96, 64, 96, 64, 1, False, 11)
+    a_planes, _ = orc.oracle_decode(hevcutil.parse(hm, alpha), 3)
+    assert len(a_planes) == 1
+    exp[:64, 3:96 * 4:4] = a_planes[0][:64, :96].astype(np.uint8)
+    np.testing.assert_array_equal(rgba[0][:64, :96 * 4], exp[:64, :96 * 4])
+
+    mono = synthutil.picture(8602, width=200, height=136, chroma_format=0, log2_ctb=5)
+    y = orc.oracle_decode(hevcutil.parse(hm, mono), 3)[0][0].astype(np.uint8)
+    f = pipeline.HeifFile(hm, heifwriter.write_heic([mono], (200, 136), chroma_format=0, transforms=[("irot", 1)]))
+    info = f.info(f.primary())
+    assert (info.chroma, info.width, info.height) == (0, 136, 200)
+    rgb, m3 = f.decode(f.primary(), 10)
+    rgba, m4 = f.decode(f.primary(), 11)
+    native, nm = f.decode(f.primary(), 0)
+    f.close()
+    yr = np.rot90(y, 1)
+    np.testing.assert_array_equal(native[0][:200, :136], yr)
+    for k in range(3):
+        np.testing.assert_array_equal(rgb[0][:200, k:136 * 3:3], yr)
+        np.testing.assert_array_equal(rgba[0][:200, k:136 * 4:4], yr)
+    assert (rgba[0][:200, 3:136 * 4:4] == 255).all()
