@@ -65,63 +65,72 @@ __device__ __forceinline__ const hm_slice& slice_at(const hm_dev_pic& dp, const 
   return v.slices[v.ctbs[ci].slice_idx];
 }
 
-// 8 samples along the edge (d), 8 across (i = 0..7 <-> p3 p2 p1 p0 | q0 q1 q2 q3)
+// The 8x8 luma window of one edge segment, packed as loaded (row-major tile whose top-left is (xD-4, yD) for
+// vertical edges, (xD, yD-4) for horizontal): 16 (8-bit) / 32 (16-bit) registers instead of 64, which is what
+// decides the occupancy of this latency-bound kernel.  at(d, i): d = 0..7 along the edge, i = 0..7 across it
+// (p3 p2 p1 p0 | q0 q1 q2 q3).
 template <typename Pix, bool vertical>
-__device__ __forceinline__ void load_window(const uint8_t* plane, int pitch, int xD, int yD, int px[8][8])
-{
-  // row-major 8x8 tile whose top-left is (xD-4, yD) for vertical edges, (xD, yD-4) for horizontal
-  const int tx = vertical ? xD - 4 : xD, ty = vertical ? yD : yD - 4;
+struct Window {
+  static constexpr int PER = 4 / (int)sizeof(Pix), BITS = 8 * (int)sizeof(Pix);
+  static constexpr uint32_t MASK = (1u << BITS) - 1;
+  uint32_t w[8][8 / PER];
+  __device__ __forceinline__ int at(int d, int i) const
+  {
+    const int r = vertical ? d : i, q = vertical ? i : d;
+    return (int)((w[r][q / PER] >> ((q % PER) * BITS)) & MASK);
+  }
+  __device__ __forceinline__ void put(int d, int i, int v)
+  {
+    const int r = vertical ? d : i, q = vertical ? i : d, sh = (q % PER) * BITS;
+    w[r][q / PER] = (w[r][q / PER] & ~(MASK << sh)) | ((uint32_t)v << sh);
+  }
+  __device__ __forceinline__ void load(const uint8_t* plane, int pitch, int xD, int yD)
+  {
+    const int tx = vertical ? xD - 4 : xD, ty = vertical ? yD : yD - 4;
 #pragma unroll
-  for (int r = 0; r < 8; r++) {
-    const Pix* row = reinterpret_cast<const Pix*>(plane + (size_t)(ty + r) * pitch) + tx;
-    Pix v[8];
-    __builtin_memcpy(v, row, 8 * sizeof(Pix));
+    for (int r = 0; r < 8; r++) __builtin_memcpy(w[r], reinterpret_cast<const Pix*>(plane + (size_t)(ty + r) * pitch) + tx, 8 * sizeof(Pix));
+  }
+  __device__ __forceinline__ void store(uint8_t* plane, int pitch, int xD, int yD) const
+  {
+    const int tx = vertical ? xD - 4 : xD, ty = vertical ? yD : yD - 4;
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
-      if (vertical) px[r][q] = v[q]; // d = r, i = q
-      else px[q][r] = v[q];          // d = q, i = r
+    for (int r = 0; r < 8; r++) {
+      Pix* row = reinterpret_cast<Pix*>(plane + (size_t)(ty + r) * pitch) + tx;
+      if (vertical) { // only p2..q2 can change
+        Pix v[8];
+        __builtin_memcpy(v, w[r], 8 * sizeof(Pix));
+        __builtin_memcpy(row + 1, v + 1, 6 * sizeof(Pix));
+      }
+      else if (r >= 1 && r <= 6) __builtin_memcpy(row, w[r], 8 * sizeof(Pix));
     }
   }
-}
-template <typename Pix, bool vertical>
-__device__ __forceinline__ void store_window(uint8_t* plane, int pitch, int xD, int yD, const int px[8][8])
-{
-  const int tx = vertical ? xD - 4 : xD, ty = vertical ? yD : yD - 4;
-#pragma unroll
-  for (int r = 0; r < 8; r++) {
-    Pix v[8];
-#pragma unroll
-    for (int q = 0; q < 8; q++) v[q] = (Pix)(vertical ? px[r][q] : px[q][r]);
-    Pix* row = reinterpret_cast<Pix*>(plane + (size_t)(ty + r) * pitch) + tx;
-    if (vertical) __builtin_memcpy(row + 1, v + 1, 6 * sizeof(Pix)); // only p2..q2 can change
-    else if (r >= 1 && r <= 6) __builtin_memcpy(row, v, 8 * sizeof(Pix));
-  }
-}
+};
 
 // fallback-postfilter.h:32-138
-__device__ __forceinline__ void filter_luma(int px[8][8], int beta, const int tc2[2], int maxv)
+template <typename Win>
+__device__ __forceinline__ void filter_luma(Win& W, int beta, const int tc2[2], int maxv)
 {
 #pragma unroll
   for (int j = 0; j < 2; j++) {
-    int(*B)[8] = px + 4 * j;
-    const int dp0 = iabs_(B[0][1] - 2 * B[0][2] + B[0][3]), dq0 = iabs_(B[0][6] - 2 * B[0][5] + B[0][4]);
-    const int dp3 = iabs_(B[3][1] - 2 * B[3][2] + B[3][3]), dq3 = iabs_(B[3][6] - 2 * B[3][5] + B[3][4]);
+    const int o = 4 * j;
+    const int dp0 = iabs_(W.at(o, 1) - 2 * W.at(o, 2) + W.at(o, 3)), dq0 = iabs_(W.at(o, 6) - 2 * W.at(o, 5) + W.at(o, 4));
+    const int dp3 = iabs_(W.at(o + 3, 1) - 2 * W.at(o + 3, 2) + W.at(o + 3, 3)), dq3 = iabs_(W.at(o + 3, 6) - 2 * W.at(o + 3, 5) + W.at(o + 3, 4));
     const int d0 = dp0 + dq0, d3 = dp3 + dq3, tc = tc2[j];
     if (d0 + d3 >= beta) continue;
     const int beta_3 = beta >> 3, beta_2 = beta >> 2, tc25 = (tc * 5 + 1) >> 1;
-    if (iabs_(B[0][0] - B[0][3]) + iabs_(B[0][7] - B[0][4]) < beta_3 && iabs_(B[0][3] - B[0][4]) < tc25 &&
-        iabs_(B[3][0] - B[3][3]) + iabs_(B[3][7] - B[3][4]) < beta_3 && iabs_(B[3][3] - B[3][4]) < tc25 &&
-        (d0 << 1) < beta_2 && (d3 << 1) < beta_2) {
+    if (iabs_(W.at(o, 0) - W.at(o, 3)) + iabs_(W.at(o, 7) - W.at(o, 4)) < beta_3 && iabs_(W.at(o, 3) - W.at(o, 4)) < tc25 &&
+        iabs_(W.at(o + 3, 0) - W.at(o + 3, 3)) + iabs_(W.at(o + 3, 7) - W.at(o + 3, 4)) < beta_3 &&
+        iabs_(W.at(o + 3, 3) - W.at(o + 3, 4)) < tc25 && (d0 << 1) < beta_2 && (d3 << 1) < beta_2) {
       const int t2 = tc << 1;
 #pragma unroll
-      for (int d = 0; d < 4; d++) {
-        const int p3 = B[d][0], p2 = B[d][1], p1 = B[d][2], p0 = B[d][3], q0 = B[d][4], q1 = B[d][5], q2 = B[d][6], q3 = B[d][7];
-        B[d][3] = p0 + clip3i(-t2, t2, ((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3) - p0);
-        B[d][2] = p1 + clip3i(-t2, t2, ((p2 + p1 + p0 + q0 + 2) >> 2) - p1);
-        B[d][1] = p2 + clip3i(-t2, t2, ((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3) - p2);
-        B[d][4] = q0 + clip3i(-t2, t2, ((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3) - q0);
-        B[d][5] = q1 + clip3i(-t2, t2, ((p0 + q0 + q1 + q2 + 2) >> 2) - q1);
-        B[d][6] = q2 + clip3i(-t2, t2, ((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3) - q2);
+      for (int d = o; d < o + 4; d++) {
+        const int p3 = W.at(d, 0), p2 = W.at(d, 1), p1 = W.at(d, 2), p0 = W.at(d, 3), q0 = W.at(d, 4), q1 = W.at(d, 5), q2 = W.at(d, 6), q3 = W.at(d, 7);
+        W.put(d, 3, p0 + clip3i(-t2, t2, ((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3) - p0));
+        W.put(d, 2, p1 + clip3i(-t2, t2, ((p2 + p1 + p0 + q0 + 2) >> 2) - p1));
+        W.put(d, 1, p2 + clip3i(-t2, t2, ((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3) - p2));
+        W.put(d, 4, q0 + clip3i(-t2, t2, ((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3) - q0));
+        W.put(d, 5, q1 + clip3i(-t2, t2, ((p0 + q0 + q1 + q2 + 2) >> 2) - q1));
+        W.put(d, 6, q2 + clip3i(-t2, t2, ((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3) - q2));
       }
     }
     else {
@@ -129,15 +138,15 @@ __device__ __forceinline__ void filter_luma(int px[8][8], int beta, const int tc
       const int thr = (beta + (beta >> 1)) >> 3;
       const bool np2 = dp0 + dp3 < thr, nq2 = dq0 + dq3 < thr;
 #pragma unroll
-      for (int d = 0; d < 4; d++) {
-        const int p2 = B[d][1], p1 = B[d][2], p0 = B[d][3], q0 = B[d][4], q1 = B[d][5], q2 = B[d][6];
+      for (int d = o; d < o + 4; d++) {
+        const int p2 = W.at(d, 1), p1 = W.at(d, 2), p0 = W.at(d, 3), q0 = W.at(d, 4), q1 = W.at(d, 5), q2 = W.at(d, 6);
         int delta0 = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4;
         if (iabs_(delta0) < 10 * tc) {
           delta0 = clip3i(-tc, tc, delta0);
-          B[d][3] = clip3i(0, maxv, p0 + delta0);
-          B[d][4] = clip3i(0, maxv, q0 - delta0);
-          if (np2) B[d][2] = clip3i(0, maxv, p1 + clip3i(-tc_2, tc_2, (((p2 + p0 + 1) >> 1) - p1 + delta0) >> 1));
-          if (nq2) B[d][5] = clip3i(0, maxv, q1 + clip3i(-tc_2, tc_2, (((q2 + q0 + 1) >> 1) - q1 - delta0) >> 1));
+          W.put(d, 3, clip3i(0, maxv, p0 + delta0));
+          W.put(d, 4, clip3i(0, maxv, q0 - delta0));
+          if (np2) W.put(d, 2, clip3i(0, maxv, p1 + clip3i(-tc_2, tc_2, (((p2 + p0 + 1) >> 1) - p1 + delta0) >> 1)));
+          if (nq2) W.put(d, 5, clip3i(0, maxv, q1 + clip3i(-tc_2, tc_2, (((q2 + q0 + 1) >> 1) - q1 - delta0) >> 1)));
         }
       }
     }
@@ -146,7 +155,7 @@ __device__ __forceinline__ void filter_luma(int px[8][8], int beta, const int tc
 
 // One launch = one direction for every picture of the batch.  blockIdx.y = picture.
 template <typename Pix, bool vertical>
-__global__ __launch_bounds__(256) void k_deblock(const hm_dev_pic* __restrict__ pics)
+__global__ __launch_bounds__(256, sizeof(Pix) == 1 ? 8 : 6) void k_deblock(const hm_dev_pic* __restrict__ pics)
 {
   const hm_dev_pic& dp = pics[blockIdx.y];
   if (!(dp.flags & HM_PIC_DEBLOCK_ANY)) return;
@@ -170,10 +179,10 @@ __global__ __launch_bounds__(256) void k_deblock(const hm_dev_pic* __restrict__ 
     int tc[2];
     tc[0] = bs0 ? c_tc[clip3i(0, 53, qPL + 2 * (bs0 - 1) + sl.tc_offset_div2 * 2)] * (1 << (bd - 8)) : 0;
     tc[1] = bs1 ? c_tc[clip3i(0, 53, qPL + 2 * (bs1 - 1) + sl.tc_offset_div2 * 2)] * (1 << (bd - 8)) : 0;
-    int px[8][8];
-    load_window<Pix, vertical>(dp.plane[0], dp.pitch[0], xD, yD, px);
-    filter_luma(px, beta, tc, maxv);
-    store_window<Pix, vertical>(dp.plane[0], dp.pitch[0], xD, yD, px);
+    Window<Pix, vertical> win;
+    win.load(dp.plane[0], dp.pitch[0], xD, yD);
+    filter_luma(win, beta, tc, maxv);
+    win.store(dp.plane[0], dp.pitch[0], xD, yD);
     return;
   }
   // ---- chroma segments (deblock.cc:1608-1772) ----
@@ -297,11 +306,82 @@ __device__ __forceinline__ int sao_sample(const hm_dev_pic& dp, const PicView& v
 
 // Edge offset of one group of G samples for one SaoEoClass (compile-time neighbour direction): neighbour a of
 // sample x is (x + HX, yy + VY), neighbour b is (x - HX, yy - VY) (sao.cc:336-424).
-template <typename Pix, int HX, int VY, int G>
-__device__ __forceinline__ void sao_edge_group(const uint8_t* plane, int pitch, int xs, int yy, int W, int Hh, int l2w, int l2h,
-                                               int cx, int cy, uint32_t nbm, uint32_t offs, int maxv, const Pix (&cur)[G],
-                                               const Pix (&up)[G], const Pix (&dn)[G], int (&out)[G])
+// ---- SAO arithmetic on pairs of samples (two 16-bit halves per register, v_pk_* / v_perm_b32) ----
+// The per-sample version of this kernel was bound by VALU issue (~38 instructions per sample); here a group of 8
+// samples is 4 registers of sample pairs and the offset table is a byte lookup (v_perm_b32), ~8 per sample.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 as_s(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
+__device__ __forceinline__ u16x2 as_u(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ uint32_t as_w(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ uint32_t as_w(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+// per half: sign(c - a) as -1 / 0 / +1
+__device__ __forceinline__ uint32_t pk_sign_diff(uint32_t c, uint32_t a)
 {
+  // (inline asm: the compiler otherwise rewrites the vector clamp into per-half compares and selects)
+  uint32_t d = as_w(as_s(c) - as_s(a));
+  const uint32_t one = 0x00010001u, minus_one = 0xFFFFFFFFu;
+  asm("v_pk_min_i16 %0, %1, %2" : "=v"(d) : "v"(d), "v"(one));
+  asm("v_pk_max_i16 %0, %1, %2" : "=v"(d) : "v"(d), "v"(minus_one));
+  return d;
+}
+// per half: clip3(0, maxv, c + table[idx]) where sel holds idx (0..7) in the low byte and 0x0c in the high byte of each
+// half, and the table {t_hi, t_lo} holds offset + 128 per byte
+__device__ __forceinline__ uint32_t pk_apply(uint32_t c, uint32_t sel, uint32_t t_hi, uint32_t t_lo, uint32_t maxv2)
+{
+  const uint32_t o = __builtin_amdgcn_perm(t_hi, t_lo, sel);
+  u16x2 t = as_u(c) + as_u(o);
+  t = __builtin_elementwise_sub_sat(t, (u16x2)(128));
+  return as_w(__builtin_elementwise_min(t, as_u(maxv2)));
+}
+
+// One group of 8 samples of one row as 4 registers of pairs, plus the dwords holding its left / right neighbour.
+template <typename Pix>
+struct SaoRow {
+  uint32_t p[4];
+  uint32_t l, r;
+  __device__ __forceinline__ uint32_t left() const { return l >> (32 - 8 * (int)sizeof(Pix)); }
+  __device__ __forceinline__ uint32_t right() const { return r & ((1u << (8 * (int)sizeof(Pix))) - 1); }
+  // row y clamped into the picture; the side dwords fall back to the group itself at the picture's left / right end
+  // (their samples are not used there)
+  __device__ __forceinline__ void load(const uint8_t* plane, int pitch, int xs, int y, int W, int Hh)
+  {
+    constexpr int PER = 4 / (int)sizeof(Pix);
+    const Pix* row = reinterpret_cast<const Pix*>(plane + (size_t)(y < 0 ? 0 : (y < Hh ? y : Hh - 1)) * pitch);
+    if (sizeof(Pix) == 1) {
+      uint32_t d[2];
+      __builtin_memcpy(d, row + xs, 8);
+      p[0] = __builtin_amdgcn_perm(0, d[0], 0x0c010c00u); p[1] = __builtin_amdgcn_perm(0, d[0], 0x0c030c02u);
+      p[2] = __builtin_amdgcn_perm(0, d[1], 0x0c010c00u); p[3] = __builtin_amdgcn_perm(0, d[1], 0x0c030c02u);
+    }
+    else __builtin_memcpy(p, row + xs, 16);
+    __builtin_memcpy(&l, row + (xs > 0 ? xs - PER : xs), 4);
+    __builtin_memcpy(&r, row + (xs + 8 < W ? xs + 8 : xs), 4);
+  }
+  // the group shifted by one sample: q[k] = v[k - 1] with `in` entering on the left / q[k] = v[k + 1], `in` on the right
+  __device__ __forceinline__ void shifted(int dir, uint32_t in, uint32_t (&q)[4]) const
+  {
+    if (dir < 0) {
+      q[0] = (p[0] << 16) | in;
+#pragma unroll
+      for (int j = 1; j < 4; j++) q[j] = __builtin_amdgcn_alignbit(p[j], p[j - 1], 16);
+    }
+    else {
+#pragma unroll
+      for (int j = 0; j < 3; j++) q[j] = __builtin_amdgcn_alignbit(p[j + 1], p[j], 16);
+      q[3] = (p[3] >> 16) | (in << 16);
+    }
+  }
+};
+
+// Edge offset of one group of 8 samples for one SaoEoClass (compile-time neighbour direction): neighbour a of
+// sample x is (x + HX, yy + VY), neighbour b is (x - HX, yy - VY) (sao.cc:336-424).
+template <typename Pix, int HX, int VY>
+__device__ __forceinline__ void sao_edge_group(int xs, int yy, int W, int Hh, int l2w, int l2h, int cx, int cy, uint32_t nbm,
+                                               uint32_t offs, uint32_t maxv2, const SaoRow<Pix>& up, const SaoRow<Pix>& cur,
+                                               const SaoRow<Pix>& dn, uint32_t (&out)[4])
+{
+  constexpr int G = 8;
   const int ya = yy + VY, yb = yy - VY;
   const bool rows_ok = ya >= 0 && yb < Hh;
   const int dya = (ya >> l2h) - cy, dyb = (yb >> l2h) - cy; // -1 / 0 and 0 / +1
@@ -310,47 +390,49 @@ __device__ __forceinline__ void sao_edge_group(const uint8_t* plane, int pitch, 
     const int bit = k8 < 4 ? k8 : k8 - 1;
     return (dx | dy) == 0 || ((nbm >> bit) & 1);
   };
-  // rows a / b: the centre row for the horizontal class, else the rows above / below (fetched by the caller together
-  // with the centre row, before the CTB's SAO parameters are known: one memory round trip less)
-  Pix va[G], vb[G];
+  // rows a / b: the centre row for the horizontal class, else the rows above / below (all fetched by the caller with
+  // their left / right neighbour samples before the CTB's SAO parameters are known: no dependent memory round trip)
+  const SaoRow<Pix>& A = VY == 0 ? cur : up;
+  const SaoRow<Pix>& B = VY == 0 ? cur : dn;
+  uint32_t qa[4], qb[4];
+  if (HX == 0) {
 #pragma unroll
-  for (int k = 0; k < G; k++) { va[k] = VY == 0 ? cur[k] : up[k]; vb[k] = VY == 0 ? cur[k] : dn[k]; }
-  // the sample left of / right of the group, on the side each row needs
-  const bool has_l = xs > 0, has_r = xs + G < W;
-  int ea = 0, eb = 0;
-  if (HX != 0) {
-    const Pix* ra = reinterpret_cast<const Pix*>(plane + (size_t)(ya >= 0 ? ya : yy) * pitch) + xs;
-    const Pix* rb = reinterpret_cast<const Pix*>(plane + (size_t)(yb < Hh ? yb : yy) * pitch) + xs;
-    if (HX < 0 ? has_l : has_r) ea = ra[HX < 0 ? -1 : G];
-    if (HX < 0 ? has_r : has_l) eb = rb[HX < 0 ? G : -1];
+    for (int j = 0; j < 4; j++) { qa[j] = A.p[j]; qb[j] = B.p[j]; }
   }
+  else { // the entering samples are only used where has_l / has_r hold
+    A.shifted(HX, HX < 0 ? A.left() : A.right(), qa);
+    B.shifted(-HX, HX < 0 ? B.right() : B.left(), qb);
+  }
+  const bool has_l = xs > 0, has_r = xs + G < W;
   const bool mid_ok = rows_ok && perm(dya, 0) && perm(dyb, 0);
   // the first / last sample of the group may look into the CTB column to the left / right
   const int dxl = ((xs - 1) >> l2w) - cx, dxr = ((xs + G) >> l2w) - cx;
   const bool first_ok = HX == 0 ? mid_ok : rows_ok && has_l && perm(HX < 0 ? dya : dyb, dxl) && perm(HX < 0 ? dyb : dya, 0);
   const bool last_ok = HX == 0 ? mid_ok : rows_ok && has_r && perm(HX > 0 ? dya : dyb, dxr) && perm(HX > 0 ? dyb : dya, 0);
+  const uint32_t m_mid = mid_ok ? 0xFFFFFFFFu : 0u;
+  const uint32_t m_first = (first_ok ? 0x0000FFFFu : 0u) | (m_mid & 0xFFFF0000u);
+  const uint32_t m_last = (last_ok ? 0xFFFF0000u : 0u) | (m_mid & 0x0000FFFFu);
+  // table index = edgeIdx + 2: offsets 0, 1 for -2, -1; none for 0; offsets 2, 3 for +1, +2
+  const uint32_t biased = offs ^ 0x80808080u;
+  const uint32_t t_lo = (biased & 0x0000FFFFu) | 0x00800000u | ((biased & 0x00FF0000u) << 8), t_hi = biased >> 24;
 #pragma unroll
-  for (int k = 0; k < G; k++) {
-    const int a = HX < 0 ? (k > 0 ? (int)va[k > 0 ? k - 1 : 0] : ea) : (HX > 0 ? (k < G - 1 ? (int)va[k < G - 1 ? k + 1 : 0] : ea) : (int)va[k]);
-    const int b = HX < 0 ? (k < G - 1 ? (int)vb[k < G - 1 ? k + 1 : 0] : eb) : (HX > 0 ? (k > 0 ? (int)vb[k > 0 ? k - 1 : 0] : eb) : (int)vb[k]);
-    const bool ok = k == 0 ? first_ok : (k == G - 1 ? last_ok : mid_ok);
-    const int e = clip3i(-1, 1, out[k] - a) + clip3i(-1, 1, out[k] - b); // sign + sign
-    const int idx = e < 0 ? e + 2 : e + 1; // -2,-1,1,2 -> 0,1,2,3
-    const int o = (int)(int8_t)(offs >> (8 * (idx & 3)));
-    out[k] = (ok && e != 0) ? clip3i(0, maxv, out[k] + o) : out[k];
+  for (int j = 0; j < 4; j++) {
+    const s16x2 e = as_s(pk_sign_diff(cur.p[j], qa[j])) + as_s(pk_sign_diff(cur.p[j], qb[j]));
+    const uint32_t em = as_w(e) & (j == 0 ? m_first : (j == 3 ? m_last : m_mid));
+    const uint32_t sel = as_w(as_u(em) + (u16x2)(0x0c02));
+    out[j] = pk_apply(cur.p[j], sel, t_hi, t_lo, maxv2);
   }
 }
 
-// SAO + paste.  blockIdx.y = picture; the planes' 64 x 8-sample tiles are numbered consecutively (luma, Cb, Cr),
-// one wave per tile: lane = (row lane >> 3, 8-sample group lane & 7).  A tile lies in one CTB row and in at most
-// two luma CTBs, so the lanes of a wave mostly agree on SAO type and class (the per-class code is branch-free).
-// (8 | every CTB width, so a group never straddles CTBs when the conformance-window offset is a multiple of 8 -
-// the common case; otherwise the generic per-sample path runs.)
 template <typename Pix>
 __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict__ pics, int apply_sao)
 {
   const hm_dev_pic& dp = pics[blockIdx.y];
-  constexpr int G = 8, TW = 64, TH = 8;
+  // One wave = a 64 x 16 tile; one lane = 8 consecutive samples of two vertically adjacent rows.  Each lane has
+  // little arithmetic and a chain of dependent memory round trips (descriptor -> rows / CTB record -> store), so the
+  // kernel is paced by latency x waves in flight: two rows per lane, with all four source rows, their side samples
+  // and both CTB records fetched before anything is decided, halves the number of wave rounds.
+  constexpr int G = 8, TW = 64, TH = 16, R = 2;
   const int wt = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int tx0 = (dp.copy_w[0] + TW - 1) / TW, n0 = dp.copy_w[0] > 0 && dp.copy_h[0] > 0 ? tx0 * ((dp.copy_h[0] + TH - 1) / TH) : 0;
   const int tx1 = (dp.copy_w[1] + TW - 1) / TW, n1 = dp.copy_w[1] > 0 && dp.copy_h[1] > 0 ? tx1 * ((dp.copy_h[1] + TH - 1) / TH) : 0;
@@ -361,84 +443,113 @@ __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict_
   const int txc = c == 0 ? tx0 : (c == 1 ? tx1 : tx2);
   const int ty = local / txc, tx = local - ty * txc;
   const int cw = dp.copy_w[c], chh = dp.copy_h[c];
-  const int yd = ty * TH + (lane >> 3), x8 = tx * TW + (lane & 7) * G; // destination coordinates
-  if (yd >= chh || x8 >= cw) return;
+  const int yd0 = ty * TH + (lane >> 3) * R, x8 = tx * TW + (lane & 7) * G; // destination coordinates
+  if (yd0 >= chh || x8 >= cw) return;
   const PicView v = view(dp);
   const int sh = c ? (dp.chroma_format == 1 ? 2 : 1) : 1;
   const int W = dp.width >> (c ? 1 : 0), Hh = dp.height / sh;
   const int l2w = dp.log2_ctb - (c ? 1 : 0), l2h = dp.log2_ctb - (sh == 2 ? 1 : 0); // CTB size of this plane (log2)
-  const int bd = dp.bit_depth, maxv = (1 << bd) - 1;
+  const int bd = dp.bit_depth;
+  const uint32_t maxv2 = ((1u << bd) - 1) * 0x10001u;
   const uint8_t* plane = dp.plane[c];
   const int pitch = dp.pitch[c];
-  const int yy = yd + dp.src_y[c];            // source row inside the coded picture
+  const int yy0 = yd0 + dp.src_y[c];          // first source row inside the coded picture
   const int xs = x8 + dp.src_x[c];            // first source column of the group
-  int out[G];
   const bool fast = ((dp.src_x[c] & (G - 1)) == 0) && (x8 + G <= cw) && (xs + G <= W);
+  uint32_t res[R][4]; // results as sample pairs
   if (fast) {
-    // ---- one aligned vector load per row, everything else in registers ----
-    const int cx = xs >> l2w, cy = yy >> l2h;
-    const Pix* rc = reinterpret_cast<const Pix*>(plane + (size_t)yy * pitch) + xs;
-    Pix cur[G], up[G], dn[G];
-    __builtin_memcpy(cur, rc, G * sizeof(Pix));
-    __builtin_memcpy(up, reinterpret_cast<const Pix*>(plane + (size_t)(yy > 0 ? yy - 1 : yy) * pitch) + xs, G * sizeof(Pix));
-    __builtin_memcpy(dn, reinterpret_cast<const Pix*>(plane + (size_t)(yy + 1 < Hh ? yy + 1 : yy) * pitch) + xs, G * sizeof(Pix));
-    const uint32_t* cbq = reinterpret_cast<const uint32_t*>(v.ctbs + (cx + cy * dp.ctb_w)); // hm_ctb as dwords
-    const uint32_t cflags = cbq[2];                       // flags | sao_nb_mask << 8
-    const uint32_t s0 = cbq[3 + 2 * c], s1 = cbq[4 + 2 * c]; // hm_sao: type, eo_class, band_position, offset[0] | offset[1..3], reserved
-    const bool sao_on = apply_sao && (dp.flags & HM_PIC_SAO_ENABLED) && (cflags & (c == 0 ? HM_CTB_SAO_LUMA : HM_CTB_SAO_CHROMA));
-    const int type = sao_on ? (int)(s0 & 0xFF) : 0;
-    const uint32_t offs = (s0 >> 24) | (s1 << 8);         // the four int8 offsets in one register
-    const uint32_t nbm = (cflags >> 8) & 0xFF;
+    // ---- aligned vector loads, everything else in registers ----
+    SaoRow<Pix> rows[R + 2]; // source rows yy0 - 1 .. yy0 + R
 #pragma unroll
-    for (int k = 0; k < G; k++) out[k] = cur[k];
-    if (type == 1) { // band offset (fallback-postfilter.h:218-241)
-      const int bp = (s0 >> 16) & 0xFF;
+    for (int r = 0; r < R + 2; r++) rows[r].load(plane, pitch, xs, yy0 - 1 + r, W, Hh);
+    const int cx = xs >> l2w;
+    uint32_t cflags[R], s0[R], s1[R];
 #pragma unroll
-      for (int k = 0; k < G; k++) {
-        const int bi = ((out[k] >> (bd - 5)) - bp) & 31;
-        const int o = (int)(int8_t)(offs >> (8 * (bi & 3)));
-        out[k] = bi < 4 ? clip3i(0, maxv, out[k] + o) : out[k];
-      }
+    for (int r = 0; r < R; r++) {
+      const int yc = yy0 + r < Hh ? yy0 + r : Hh - 1;
+      const uint32_t* cbq = reinterpret_cast<const uint32_t*>(v.ctbs + (cx + (yc >> l2h) * dp.ctb_w)); // hm_ctb as dwords
+      cflags[r] = cbq[2];                            // flags | sao_nb_mask << 8
+      s0[r] = cbq[3 + 2 * c]; s1[r] = cbq[4 + 2 * c]; // hm_sao: type, eo_class, band_position, offset[0] | offset[1..3], reserved
     }
-    else if (type == 2) { // edge offset: SaoEoClass 0 horizontal, 1 vertical, 2 135 degrees, 3 45 degrees
-      const int cl = (s0 >> 8) & 0xFF;
-      if (cl == 0) sao_edge_group<Pix, -1, 0, G>(plane, pitch, xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv, cur, up, dn, out);
-      else if (cl == 1) sao_edge_group<Pix, 0, -1, G>(plane, pitch, xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv, cur, up, dn, out);
-      else if (cl == 2) sao_edge_group<Pix, -1, -1, G>(plane, pitch, xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv, cur, up, dn, out);
-      else sao_edge_group<Pix, 1, -1, G>(plane, pitch, xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv, cur, up, dn, out);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const int yy = yy0 + r, cy = yy >> l2h;
+      const SaoRow<Pix>&up = rows[r], &cur = rows[r + 1], &dn = rows[r + 2];
+      const bool sao_on = apply_sao && (dp.flags & HM_PIC_SAO_ENABLED) && (cflags[r] & (c == 0 ? HM_CTB_SAO_LUMA : HM_CTB_SAO_CHROMA));
+      const int type = sao_on ? (int)(s0[r] & 0xFF) : 0;
+      const uint32_t offs = (s0[r] >> 24) | (s1[r] << 8); // the four int8 offsets in one register
+      const uint32_t nbm = (cflags[r] >> 8) & 0xFF;
+#pragma unroll
+      for (int j = 0; j < 4; j++) res[r][j] = cur.p[j];
+      if (type == 1) { // band offset (fallback-postfilter.h:218-241): table index = band - band_position, 4 = none
+        const uint32_t bp = (s0[r] >> 16) & 0xFF;
+        const uint32_t biased = offs ^ 0x80808080u;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          u16x2 bi = (as_u(cur.p[j]) >> (u16x2)(bd - 5)) - (u16x2)(bp);
+          bi = __builtin_elementwise_min(bi & (u16x2)(31), (u16x2)(4));
+          res[r][j] = pk_apply(cur.p[j], as_w(bi) | 0x0c000c00u, 0x80u, biased, maxv2);
+        }
+      }
+      else if (type == 2) { // edge offset: SaoEoClass 0 horizontal, 1 vertical, 2 135 degrees, 3 45 degrees
+        const int cl = (s0[r] >> 8) & 0xFF;
+        if (cl == 0) sao_edge_group<Pix, -1, 0>(xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv2, up, cur, dn, res[r]);
+        else if (cl == 1) sao_edge_group<Pix, 0, -1>(xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv2, up, cur, dn, res[r]);
+        else if (cl == 2) sao_edge_group<Pix, -1, -1>(xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv2, up, cur, dn, res[r]);
+        else sao_edge_group<Pix, 1, -1>(xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv2, up, cur, dn, res[r]);
+      }
     }
   }
   else {
 #pragma unroll
-    for (int k = 0; k < G; k++) {
-      const int xx = xs + k;
-      out[k] = (xx < W && x8 + k < cw) ? sao_sample<Pix>(dp, v, plane, pitch, c, xx, yy, W, Hh, l2w, l2h, bd, apply_sao) : 0;
+    for (int r = 0; r < R; r++) {
+#pragma unroll
+      for (int k = 0; k < G; k++) {
+        const int xx = xs + k;
+        const int val = (xx < W && x8 + k < cw && yd0 + r < chh)
+                            ? sao_sample<Pix>(dp, v, plane, pitch, c, xx, yy0 + r, W, Hh, l2w, l2h, bd, apply_sao) : 0;
+        if (k & 1) res[r][k >> 1] |= (uint32_t)val << 16;
+        else res[r][k >> 1] = (uint32_t)val;
+      }
     }
   }
   // ---- paste (context.cc:2504-2535) ----
-  if (dp.rescale) {
-    const float off = (float)(16 << (bd - 8));
-    const float ratio = c ? 1.1429f : 1.1689f;
 #pragma unroll
-    for (int k = 0; k < G; k++) {
-      if (sizeof(Pix) == 1) out[k] = clip_f_u8(__fmul_rn(__fsub_rn((float)out[k], off), ratio));
-      else { // the reference rescales BYTES of the 16-bit storage (quirk Q1)
-        const int lo = clip_f_u8(__fmul_rn(__fsub_rn((float)(out[k] & 0xFF), off), ratio));
-        const int hi = clip_f_u8(__fmul_rn(__fsub_rn((float)(out[k] >> 8), off), ratio));
-        out[k] = lo | (hi << 8);
+  for (int r = 0; r < R; r++) {
+    if (yd0 + r >= chh) break;
+    if (dp.rescale) { // limited -> full range of a tile pasted into a canvas without nclx, per sample in float
+      const float off = (float)(16 << (bd - 8));
+      const float ratio = c ? 1.1429f : 1.1689f;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        uint32_t pair = 0;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int val = (int)((res[r][j] >> (16 * h)) & 0xFFFF);
+          int o;
+          if (sizeof(Pix) == 1) o = clip_f_u8(__fmul_rn(__fsub_rn((float)val, off), ratio));
+          else { // the reference rescales BYTES of the 16-bit storage (quirk Q1)
+            const int lo = clip_f_u8(__fmul_rn(__fsub_rn((float)(val & 0xFF), off), ratio));
+            const int hi = clip_f_u8(__fmul_rn(__fsub_rn((float)(val >> 8), off), ratio));
+            o = lo | (hi << 8);
+          }
+          pair |= (uint32_t)o << (16 * h);
+        }
+        res[r][j] = pair;
       }
     }
-  }
-  Pix* drow = reinterpret_cast<Pix*>(dp.dst[c] + (size_t)yd * dp.dst_pitch[c]) + x8;
-  if (x8 + G <= cw) {
-    Pix o[G];
-#pragma unroll
-    for (int k = 0; k < G; k++) o[k] = (Pix)out[k];
-    __builtin_memcpy(drow, o, G * sizeof(Pix));
-  }
-  else {
-    for (int k = 0; k < G; k++)
-      if (x8 + k < cw) drow[k] = (Pix)out[k];
+    Pix* drow = reinterpret_cast<Pix*>(dp.dst[c] + (size_t)(yd0 + r) * dp.dst_pitch[c]) + x8;
+    if (x8 + G <= cw) {
+      if (sizeof(Pix) == 1) {
+        const uint32_t o[2] = {__builtin_amdgcn_perm(res[r][1], res[r][0], 0x06040200u), __builtin_amdgcn_perm(res[r][3], res[r][2], 0x06040200u)};
+        __builtin_memcpy(drow, o, 8);
+      }
+      else __builtin_memcpy(drow, res[r], 16);
+    }
+    else {
+      for (int k = 0; k < G; k++)
+        if (x8 + k < cw) drow[k] = (Pix)(res[r][k >> 1] >> (16 * (k & 1)));
+    }
   }
 }
 
@@ -470,9 +581,9 @@ extern "C" int hm_launch_sao_paste(const hm_dev_pic* d_pics, int n_pics, int max
 {
   if (n_pics <= 0) return HM_OK;
   // 64 x 8-sample tiles of the three planes (chroma at most as large as luma); one wave per tile, four per block
-  const long luma = (long)((max_w + 63) / 64) * ((max_h + 7) / 8);
+  const long luma = (long)((max_w + 63) / 64) * ((max_h + 15) / 16);
   const int cwm = (max_w + 1) / 2;
-  const long chroma = (long)((cwm + 63) / 64) * ((max_h + 7) / 8); // 4:2:2 height bound
+  const long chroma = (long)((cwm + 63) / 64) * ((max_h + 15) / 16); // 4:2:2 height bound
   const int blocks = (int)((luma + 2 * chroma + 3) / 4);
   if (bit_depth > 8) hipLaunchKernelGGL(k_sao_paste<uint16_t>, dim3(blocks, n_pics), dim3(256), 0, s, d_pics, apply_sao);
   else hipLaunchKernelGGL(k_sao_paste<uint8_t>, dim3(blocks, n_pics), dim3(256), 0, s, d_pics, apply_sao);
