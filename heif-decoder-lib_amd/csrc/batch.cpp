@@ -60,6 +60,7 @@ struct PinnedArena {
 
 struct Class {
   int log2_ctb, chroma_format, bit_depth;
+  int rare = 0; // pictures with rarely used syntax (HM_PIC_RARE_SYNTAX) run the kernel variant that carries those paths
   std::vector<int> items;
   int max_ctb_w = 0, max_ctb_h = 0, max_w4 = 0, max_h4 = 0, max_w = 0, max_h = 0;
   size_t desc_offset = 0; // index of the first descriptor in the descriptor array
@@ -149,14 +150,15 @@ int hm_batch_upload(hm_batch* b, void* stream)
   if (n == 0) { b->uploaded = true; return HM_OK; }
 
   // classes: pictures of one launch share CTB size, chroma format and sample width
-  std::map<std::tuple<int, int, int>, int> cls_index;
+  std::map<std::tuple<int, int, int, int>, int> cls_index;
   for (int i = 0; i < n; i++) {
     const hm_pic& h = b->items[i].hdr;
-    auto key = std::make_tuple((int)h.log2_ctb, (int)h.chroma_format, (int)h.bit_depth_y);
+    const int rare = (h.flags & HM_PIC_RARE_SYNTAX) != 0;
+    auto key = std::make_tuple((int)h.log2_ctb, (int)h.chroma_format, (int)h.bit_depth_y, rare);
     auto f = cls_index.find(key);
     if (f == cls_index.end()) {
       Class c;
-      c.log2_ctb = h.log2_ctb; c.chroma_format = h.chroma_format; c.bit_depth = h.bit_depth_y;
+      c.log2_ctb = h.log2_ctb; c.chroma_format = h.chroma_format; c.bit_depth = h.bit_depth_y; c.rare = rare;
       f = cls_index.emplace(key, (int)b->classes.size()).first;
       b->classes.push_back(c);
     }
@@ -286,7 +288,7 @@ int hm_batch_execute(hm_batch* b, int stages, void* stream)
     const hm_dev_pic* dc = d + c.desc_offset;
     const int n = (int)c.items.size();
     mark();
-    int rc = hm_launch_recon(dc, n, c.log2_ctb, c.chroma_format, c.bit_depth, c.max_ctb_w, c.max_ctb_h, s);
+    int rc = hm_launch_recon(dc, n, c.log2_ctb, c.chroma_format, c.bit_depth, c.rare, c.max_ctb_w, c.max_ctb_h, s);
     if (rc) return rc;
     mark();
     if (stages & 1) {

@@ -46,21 +46,69 @@ void parse_profile_tier_level(BitReader& br, int max_sub_layers_minus1)
   }
 }
 
-// §7.3.4 scaling_list_data: parsed for bit alignment; the values are not used (streams with
-// scaling lists are reported HM_ERR_UNSUPPORTED by the caller).
-void skip_scaling_list_data(BitReader& br)
+// ---- scaling lists (§7.3.4 scaling_list_data, §7.4.5; sps.cc:805-1145 of the reference) ----
+// Table 7-5 / 7-6 default lists, in up-right diagonal scan order.  The 4x4 default is flat 16.
+static const uint8_t kDefaultList8x8Intra[64] = {
+    16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 17, 16, 17, 16, 17, 18, 17, 18, 18, 17, 18, 21, 19, 20, 21, 20, 19, 21, 24, 22, 22, 24,
+    24, 22, 22, 24, 25, 25, 27, 30, 27, 25, 25, 29, 31, 35, 35, 31, 29, 36, 41, 44, 41, 36, 47, 54, 54, 47, 65, 70, 65, 88, 88, 115};
+static const uint8_t kDefaultList8x8Inter[64] = {
+    16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 17, 17, 17, 17, 17, 18, 18, 18, 18, 18, 18, 20, 20, 20, 20, 20, 20, 20, 24, 24, 24, 24,
+    24, 24, 24, 24, 25, 25, 25, 25, 25, 25, 25, 28, 28, 28, 28, 28, 28, 33, 33, 33, 33, 33, 41, 41, 41, 41, 54, 54, 54, 71, 71, 91};
+
+// position i of the up-right diagonal scan of an n x n block (§6.5.3)
+static void diag_scan(int n, uint8_t* xs, uint8_t* ys)
 {
-  for (int sizeId = 0; sizeId < 4; sizeId++)
-    for (int matrixId = 0; matrixId < 6; matrixId += (sizeId == 3) ? 3 : 1) {
-      if (!br.flag()) { // scaling_list_pred_mode_flag
-        br.ue();        // scaling_list_pred_matrix_id_delta
+  int i = 0, x = 0, y = 0;
+  bool stop = false;
+  while (!stop) {
+    while (y >= 0) {
+      if (x < n && y < n) { xs[i] = (uint8_t)x; ys[i] = (uint8_t)y; i++; }
+      y--; x++;
+    }
+    y = x; x = 0;
+    if (i >= n * n) stop = true;
+  }
+}
+
+void parse_scaling_list_data(BitReader& br, ScalingFactors& out)
+{
+  for (int sizeId = 0; sizeId < 4; sizeId++) {
+    uint8_t lists[6][64];
+    int dcs[6] = {16, 16, 16, 16, 16, 16};
+    const int coefNum = sizeId == 0 ? 16 : 64;
+    const int step = sizeId == 3 ? 3 : 1;
+    for (int matrixId = 0; matrixId < 6; matrixId += step) {
+      uint8_t* cur = lists[matrixId];
+      if (!br.flag()) { // scaling_list_pred_mode_flag == 0: copy a reference list or the default
+        const uint32_t delta = br.ue() * (uint32_t)step; // scaling_list_pred_matrix_id_delta
+        if (delta > (uint32_t)matrixId) throw ParseError(HM_ERR_BITSTREAM, "scaling_list_pred_matrix_id_delta out of range");
+        if (delta == 0) {
+          if (sizeId == 0) std::memset(cur, 16, 16);
+          else std::memcpy(cur, matrixId < 3 ? kDefaultList8x8Intra : kDefaultList8x8Inter, 64);
+          dcs[matrixId] = 16;
+        }
+        else {
+          std::memcpy(cur, lists[matrixId - delta], coefNum);
+          dcs[matrixId] = dcs[matrixId - delta];
+        }
       }
       else {
-        int coefNum = std::min(64, 1 << (4 + (sizeId << 1)));
-        if (sizeId > 1) br.se(); // scaling_list_dc_coef_minus8
-        for (int i = 0; i < coefNum; i++) br.se();
+        int next = 8;
+        if (sizeId > 1) {
+          const int dc8 = br.se(); // scaling_list_dc_coef_minus8
+          if (dc8 < -7 || dc8 > 247) throw ParseError(HM_ERR_BITSTREAM, "scaling_list_dc_coef_minus8 out of range");
+          next = dcs[matrixId] = dc8 + 8;
+        }
+        for (int i = 0; i < coefNum; i++) {
+          const int d = br.se(); // scaling_list_delta_coef
+          if (d < -128 || d > 127) throw ParseError(HM_ERR_BITSTREAM, "scaling_list_delta_coef out of range");
+          next = (next + d + 256) % 256;
+          cur[i] = (uint8_t)next;
+        }
       }
+      out.set(sizeId, matrixId, cur, dcs[matrixId]);
     }
+  }
 }
 
 // §7.3.7 st_ref_pic_set: only NumDeltaPocs has to be tracked (needed to parse inter-RPS sets)
@@ -165,6 +213,40 @@ void parse_vui(BitReader& br, SPS& sps, int max_sub_layers_minus1)
 
 } // namespace
 
+// ScalingFactor (7-xx) of one matrix from its coded list: 4x4 and 8x8 directly, 16x16 / 32x32 by replicating the 8x8
+// list 2x2 / 4x4 and overriding the DC entry.
+void ScalingFactors::set(int sizeId, int matrixId, const uint8_t* list, int dc)
+{
+  if (matrixId > 2) return; // inter matrices: parsed, not used by intra pictures
+  if (sizeId == 3 && matrixId != 0) return;
+  static uint8_t x4[16], y4[16], x8[64], y8[64];
+  static const bool init = (diag_scan(4, x4, y4), diag_scan(8, x8, y8), true);
+  (void)init;
+  uint8_t* out = f + offset(sizeId, matrixId);
+  if (sizeId == 0) {
+    for (int i = 0; i < 16; i++) out[x4[i] + 4 * y4[i]] = list[i];
+    return;
+  }
+  const int rep = sizeId == 1 ? 1 : (sizeId == 2 ? 2 : 4), w = 8 * rep;
+  for (int i = 0; i < 64; i++)
+    for (int dy = 0; dy < rep; dy++)
+      for (int dx = 0; dx < rep; dx++) out[(rep * x8[i] + dx) + w * (rep * y8[i] + dy)] = list[i];
+  if (sizeId > 1) out[0] = (uint8_t)dc;
+}
+
+void ScalingFactors::set_defaults()
+{
+  uint8_t flat[16];
+  std::memset(flat, 16, sizeof(flat));
+  for (int m = 0; m < 3; m++) {
+    set(0, m, flat, 16);
+    set(1, m, kDefaultList8x8Intra, 16);
+    set(2, m, kDefaultList8x8Intra, 16);
+  }
+  set(3, 0, kDefaultList8x8Intra, 16);
+}
+
+
 void parse_sps(BitReader& br, SPS& sps)
 {
   sps = SPS();
@@ -213,7 +295,8 @@ void parse_sps(BitReader& br, SPS& sps)
   sps.scaling_list_enabled = br.flag();
   if (sps.scaling_list_enabled) {
     sps.sps_scaling_list_present = br.flag();
-    if (sps.sps_scaling_list_present) skip_scaling_list_data(br);
+    if (sps.sps_scaling_list_present) parse_scaling_list_data(br, sps.scaling);
+    else sps.scaling.set_defaults();
   }
   sps.amp_enabled = br.flag();
   sps.sao_enabled = br.flag();
@@ -322,7 +405,7 @@ void parse_pps(BitReader& br, PPS& pps, const SPS* sps_table)
     }
   }
   pps.scaling_list_present = br.flag();
-  if (pps.scaling_list_present) skip_scaling_list_data(br);
+  if (pps.scaling_list_present) parse_scaling_list_data(br, pps.scaling);
   pps.lists_modification_present = br.flag();
   pps.log2_parallel_merge_level = br.ue() + 2;
   pps.slice_header_extension_present = br.flag();

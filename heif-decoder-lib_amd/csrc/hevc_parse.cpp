@@ -138,7 +138,6 @@ struct Decoder {
   static void check_supported(const SPS& s, const PPS& p)
   {
     if (s.range_ext_any) throw ParseError(HM_ERR_UNSUPPORTED, "range-extension coding tools");
-    if (s.scaling_list_enabled) throw ParseError(HM_ERR_UNSUPPORTED, "scaling lists");
     if (s.chroma_format_idc == 3 || s.separate_colour_plane)
       throw ParseError(HM_ERR_UNSUPPORTED, "chroma format (4:0:0, 4:2:0 and 4:2:2 are on the GPU path)");
     if (s.chroma_format_idc != 0 && s.bit_depth_y != s.bit_depth_c) throw ParseError(HM_ERR_UNSUPPORTED, "different luma / chroma bit depth");
@@ -193,7 +192,8 @@ struct Decoder {
     const size_t off_ctbs = align16(off_slices + pic.slices.size() * sizeof(hm_slice));
     const size_t off_tus = align16(off_ctbs + (size_t)N * sizeof(hm_ctb));
     const size_t off_coeffs = align16(off_tus + n_tus * sizeof(hm_tu));
-    const size_t total = align16(off_coeffs + pic.coeffs.size() * sizeof(hm_coeff));
+    const size_t off_scaling = align16(off_coeffs + pic.coeffs.size() * sizeof(hm_coeff));
+    const size_t total = off_scaling + (s.scaling_list_enabled ? (size_t)HM_SCALING_BYTES : 0);
     if (total > 0xFFFFFFFFu) throw ParseError(HM_ERR_INTERNAL, "command stream too large");
     std::vector<uint8_t> blob(total, 0);
     hm_pic h;
@@ -228,6 +228,7 @@ struct Decoder {
     if (p.sign_data_hiding) flags |= HM_PIC_SIGN_HIDING;
     if (p.tiles_enabled) flags |= HM_PIC_TILES;
     if (p.lf_across_tiles) flags |= HM_PIC_LF_ACROSS_TILES;
+    if (s.scaling_list_enabled) flags |= HM_PIC_SCALING_LIST;
     h.flags = flags;
     h.colour_primaries = (uint8_t)s.colour_primaries;
     h.transfer_characteristics = (uint8_t)s.transfer_characteristics;
@@ -241,6 +242,11 @@ struct Decoder {
     h.off_ctbs = (uint32_t)off_ctbs;
     h.off_tus = (uint32_t)off_tus;
     h.off_coeffs = (uint32_t)off_coeffs;
+    if (s.scaling_list_enabled) { // the PPS lists when it carries its own, else the SPS lists / defaults (pps.cc:473-482)
+      static_assert(ScalingFactors::kBytes == HM_SCALING_BYTES, "scaling table layout");
+      h.off_scaling = (uint32_t)off_scaling;
+      std::memcpy(blob.data() + off_scaling, (p.scaling_list_present ? p.scaling : s.scaling).f, HM_SCALING_BYTES);
+    }
     std::memcpy(blob.data(), &h, sizeof(h));
     std::memcpy(blob.data() + off_slices, pic.slices.data(), pic.slices.size() * sizeof(hm_slice));
     std::memcpy(blob.data() + off_ctbs, pic.ctbs.data(), (size_t)N * sizeof(hm_ctb));

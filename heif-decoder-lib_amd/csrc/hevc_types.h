@@ -82,6 +82,20 @@ struct ScalingList {
   uint8_t factor32[6][1024];
 };
 
+// ScalingFactor arrays of the matrices an intra picture uses (matrixId = cIdx; 32x32: matrix 0), as the kernels index
+// them: raster order x + nT * y per matrix (transform.cc:509-533 of the reference).
+struct ScalingFactors {
+  static constexpr int kBytes = 2048; // 3 * 16 + 3 * 64 + 3 * 256 + 1024 = 2032, padded
+  uint8_t f[kBytes] = {};
+  static int offset(int sizeId, int matrixId)
+  {
+    static const int base[4] = {0, 48, 240, 1008};
+    return base[sizeId] + (matrixId << (4 + 2 * sizeId));
+  }
+  void set(int sizeId, int matrixId, const uint8_t* list_in_diagonal_order, int dc);
+  void set_defaults();
+};
+
 struct SPS {
   bool valid = false;
   int sps_id = 0;
@@ -96,6 +110,7 @@ struct SPS {
   int max_th_depth_inter = 0, max_th_depth_intra = 0;
   bool scaling_list_enabled = false;
   bool sps_scaling_list_present = false;
+  ScalingFactors scaling;               // SPS lists or the defaults (valid when scaling_list_enabled)
   bool amp_enabled = false, sao_enabled = false, pcm_enabled = false;
   int pcm_bit_depth_y = 8, pcm_bit_depth_c = 8, log2_min_pcm_cb = 3, log2_max_pcm_cb = 3;
   bool pcm_loop_filter_disabled = false;
@@ -138,6 +153,7 @@ struct PPS {
   bool deblocking_control_present = false, deblocking_override_enabled = false, deblocking_disabled = false;
   int beta_offset_div2 = 0, tc_offset_div2 = 0;
   bool scaling_list_present = false;
+  ScalingFactors scaling;               // valid when scaling_list_present
   bool lists_modification_present = false;
   int log2_parallel_merge_level = 2;
   bool slice_header_extension_present = false;

@@ -1,7 +1,7 @@
 // recon.hip — HEVC-intra reconstruction kernel for gfx950 (CDNA4, wave64).
 //
 // Replaces the reconstruction half of libde265's CTU loop:
-//   dequantisation            transform.cc:386-545          (flat scaling, wrapping int32: Q3)
+//   dequantisation            transform.cc:386-545          (flat scaling, wrapping int32: Q3; scaling lists: int64)
 //   inverse DST / DCT / skip  fallback-dct.cc:80-104, 311-449, 592-733
 //   reference-sample fetch    intrapred.h:620-836
 //   smoothing / planar / DC / angular   intrapred.h:192-441
@@ -287,7 +287,7 @@ __device__ __forceinline__ void make_border(const Blk<Pix>& b, int16_t* bA, int 
     // end samples stay as they are (the bilinear formula and the degenerate [c 2c c] both return them)
     bool bi = false;
     int p0 = 0, pL = 0, pT = 0;
-    if (L2 == 5 && strong) {
+    if (L2 == 5 && (strong & HM_PIC_STRONG_INTRA_SMOOTHING)) {
       p0 = bc[0]; pL = bc[-64]; pT = bc[64];
       const int mL = bc[-32], mT = bc[32];
       const int lim = 1 << (b.bd - 5);
@@ -402,9 +402,10 @@ __device__ __forceinline__ void predict(const Blk<Pix>& B, const Ref& b, const i
 
 // ---- dequantisation + inverse transform + add (transform.cc:386-689, fallback-dct.cc) --------------------
 // Invariant: the dense coefficient buffer is all zero on entry and on exit.
+constexpr int TAB_SCALING_PTR = 96; // int16 index into the table region (256 B; 92 entries used): 8-byte aligned slot
 template <typename Pix, int L2>
 __device__ __forceinline__ void residual_add(const Blk<Pix>& B, int16_t* coeff, int16_t* tmp, const int8_t* dct, const int16_t* tab,
-                                             const GLOBAL_AS uint32_t* __restrict__ cf, const uint32_t pre_raw, int lane)
+                                             const GLOBAL_AS uint32_t* __restrict__ cf, const uint32_t pre_raw, int lane, int picf, int matrix)
 {
   constexpr int nT = 1 << L2, log2 = L2;
   const int c = B.c, bit_depth = B.bd;
@@ -414,16 +415,39 @@ __device__ __forceinline__ void residual_add(const Blk<Pix>& B, int16_t* coeff, 
   const int32_t offset = 1 << (bdShift - 1);
   const int32_t fact = (int32_t)tab[70 + qP % 6] << (qP / 6);
   int mx = 0, my = 0;
+  if (picf & HM_PIC_SCALING_LIST) {
+    // scaling lists (transform.cc:507-545): m = ScalingFactor[pos] of matrix cIdx (32x32: matrix 0), 64-bit product.
+    // The rare path: the table address waits in LDS behind the tables instead of occupying registers.
+    const uint8_t* table = *reinterpret_cast<const uint8_t* const*>(tab + TAB_SCALING_PTR);
+    const GLOBAL_AS uint8_t* sclist = gptr<uint8_t>(table) + (L2 == 5 ? 1008 : HM_SCALING_OFFSET(L2, matrix));
+    const int sShift = bdShift + 4;
+    const int64_t sOffset = (int64_t)1 << (sShift - 1);
+    const int ls = tab[70 + qP % 6], lsh = qP / 6;
+#pragma unroll 1
+    for (int i = lane; i < B.n_coeff; i += 64) {
+      const uint32_t raw = i < 64 ? pre_raw : cf[i];
+      const int pos = raw & 0xFFFF, value = (int)(int16_t)(raw >> 16);
+      const int32_t f = (int32_t)((uint32_t)mul24((int)sclist[pos], ls) << lsh);
+      int64_t v = ((int64_t)value * f + sOffset) >> sShift;
+      v = v < -32768 ? -32768 : (v > 32767 ? 32767 : v);
+      coeff[pos] = (int16_t)v;
+      const int px = pos & (nT - 1), py = pos >> log2;
+      mx = px > mx ? px : mx;
+      my = py > my ? py : my;
+    }
+  }
+  else {
 #pragma unroll 1 // more than 64 levels in a block is rare: keep the register footprint of one iteration
-  for (int i = lane; i < B.n_coeff; i += 64) {
-    const uint32_t raw = i < 64 ? pre_raw : cf[i]; // the first 64 pairs were fetched before the prediction started
-    const int pos = raw & 0xFFFF, value = (int)(int16_t)(raw >> 16);
-    // low 32 bits of value * fact (|value| < 2^15, fact < 2^23), i.e. the reference's wrapping int32 product (Q3)
-    const int32_t prod = (int32_t)((uint32_t)mul24(value, fact) + (uint32_t)offset);
-    coeff[pos] = (int16_t)clip3i(-32768, 32767, prod >> bdShift);
-    const int px = pos & (nT - 1), py = pos >> log2;
-    mx = px > mx ? px : mx;
-    my = py > my ? py : my;
+    for (int i = lane; i < B.n_coeff; i += 64) {
+      const uint32_t raw = i < 64 ? pre_raw : cf[i]; // the first 64 pairs were fetched before the prediction started
+      const int pos = raw & 0xFFFF, value = (int)(int16_t)(raw >> 16);
+      // low 32 bits of value * fact (|value| < 2^15, fact < 2^23), i.e. the reference's wrapping int32 product (Q3)
+      const int32_t prod = (int32_t)((uint32_t)mul24(value, fact) + (uint32_t)offset);
+      coeff[pos] = (int16_t)clip3i(-32768, 32767, prod >> bdShift);
+      const int px = pos & (nT - 1), py = pos >> log2;
+      mx = px > mx ? px : mx;
+      my = py > my ? py : my;
+    }
   }
   if (L2 == 2) mx = my = 3; // a 4x4 block: four multiply-adds per sample are cheaper than the search
   else { mx = wave_max5(mx); my = wave_max5(my); }
@@ -498,7 +522,7 @@ __device__ __forceinline__ void residual_add(const Blk<Pix>& B, int16_t* coeff, 
 // =====================================================================================================
 // line_bytes: size of one sample line (all planes) as laid out by the launcher for the widest picture of the
 // batch class; n_lines = max(waves, 2) of them follow the tables in LDS.
-template <typename Pix, int LOG2_CTB>
+template <typename Pix, int LOG2_CTB, bool RARE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k_recon(const hm_dev_pic* __restrict__ pics, int per_wave_bytes, int line_bytes, int n_lines)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -556,6 +580,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
     else v = c_dst[(i - 76) >> 2][(i - 76) & 3];
     tab[i] = (int16_t)v;
   }
+  if (tid == 0) *reinterpret_cast<const uint8_t**>(tab + TAB_SCALING_PTR) = blob + H->off_scaling; // read when HM_PIC_SCALING_LIST
   // coefficient blocks must start all-zero (residual_add keeps them so)
   {
     int16_t* cz = reinterpret_cast<int16_t*>(wbase);
@@ -572,7 +597,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
   Pix* const u0 = reinterpret_cast<Pix*>(lp); lp += (size_t)P0 * ctb * sizeof(Pix);
   Pix* const u1 = reinterpret_cast<Pix*>(lp); lp += (size_t)P1 * ch_c * sizeof(Pix);
   Pix* const u2 = reinterpret_cast<Pix*>(lp); lp += (size_t)P1 * ch_c * sizeof(Pix);
-  const int strong = (dp.flags & HM_PIC_STRONG_INTRA_SMOOTHING) != 0;
+  // the picture flags the blocks look at; without RARE the rare-syntax bits are known to be clear and their paths fold away
+  const int strong = dp.flags & (HM_PIC_STRONG_INTRA_SMOOTHING | (RARE ? HM_PIC_RARE_SYNTAX : 0));
   const int planeWc = dp.width >> 1, planeHc = dp.height / sh;
   // one sample line: [4 pad | luma ctb_w*ctb][4 pad | cb ctb_w*cw_c][4 pad | cr ...]; sample x of a plane at base[x], x >= -1
   const int Wl = ctb_w << log2_ctb, Wc = ctb_w * cw_c;
@@ -677,7 +703,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
             predict<Pix, 2, RefArray, true>(B, RefArray{bA + 64}, tab, ln);
           }
           WAVE_SYNC();
-          if (cbf_l) residual_add<Pix, 2>(B, l_coeff + half * 16, l_tmp + half * 16, dct, tab, cf, pre, ln);
+          if (cbf_l) residual_add<Pix, 2>(B, l_coeff + half * 16, l_tmp + half * 16, dct, tab, cf, pre, ln, strong, 1 + half); // matrixId = cIdx
           WAVE_SYNC();
           continue;
         }
@@ -734,11 +760,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
                 while (__hip_atomic_exchange(big_lock, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) __builtin_amdgcn_s_sleep(2);
               __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
               __builtin_amdgcn_wave_barrier();
-              residual_add<Pix, L2>(B, big_coeff, big_tmp, dct, tab, coeffs + coeff_first, pre, ln);
+              residual_add<Pix, L2>(B, big_coeff, big_tmp, dct, tab, coeffs + coeff_first, pre, ln, strong, B.c);
               __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
               if (lane == 0) __hip_atomic_store(big_lock, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            else residual_add<Pix, L2>(B, l_coeff, l_tmp, dct, tab, coeffs + coeff_first, pre, ln);
+            else residual_add<Pix, L2>(B, l_coeff, l_tmp, dct, tab, coeffs + coeff_first, pre, ln, strong, B.c);
             WAVE_SYNC();
           }
           if (B.c == 0) { // deblocking metadata (deblock.cc:31-62): transform edges + QpY
@@ -810,7 +836,7 @@ static int line_lds(int ctb, int ctb_w, int pix_bytes)
 }
 
 // All pictures of one launch share (log2_ctb, chroma_format, bit depth class, ctb_h upper bound).
-extern "C" int hm_launch_recon(const hm_dev_pic* d_pics, int n_pics, int log2_ctb, int chroma_format, int bit_depth,
+extern "C" int hm_launch_recon(const hm_dev_pic* d_pics, int n_pics, int log2_ctb, int chroma_format, int bit_depth, int rare_syntax,
                                int max_ctb_w, int max_ctb_h, hipStream_t s)
 {
   if (n_pics <= 0) return HM_OK;
@@ -840,13 +866,21 @@ extern "C" int hm_launch_recon(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   const int n_lines = nw > 2 ? nw : 2;
   if (lds_bytes > 160 * 1024) return hm_fail(HM_ERR_UNSUPPORTED, "CTU staging does not fit LDS (%d bytes)", lds_bytes);
   const void* fn = nullptr;
-  switch (log2_ctb * 2 + (pix_bytes - 1)) {
-    case 8: fn = reinterpret_cast<const void*>(k_recon<uint8_t, 4>); break;
-    case 9: fn = reinterpret_cast<const void*>(k_recon<uint16_t, 4>); break;
-    case 10: fn = reinterpret_cast<const void*>(k_recon<uint8_t, 5>); break;
-    case 11: fn = reinterpret_cast<const void*>(k_recon<uint16_t, 5>); break;
-    case 12: fn = reinterpret_cast<const void*>(k_recon<uint8_t, 6>); break;
-    case 13: fn = reinterpret_cast<const void*>(k_recon<uint16_t, 6>); break;
+  // RARE = true: the variant that also carries the rarely used syntax (HM_PIC_RARE_SYNTAX: scaling lists); the
+  // common pictures run the variant without those branches and their register cost.
+  switch ((log2_ctb * 2 + (pix_bytes - 1)) * 2 + (rare_syntax ? 1 : 0)) {
+    case 16: fn = reinterpret_cast<const void*>(k_recon<uint8_t, 4, false>); break;
+    case 17: fn = reinterpret_cast<const void*>(k_recon<uint8_t, 4, true>); break;
+    case 18: fn = reinterpret_cast<const void*>(k_recon<uint16_t, 4, false>); break;
+    case 19: fn = reinterpret_cast<const void*>(k_recon<uint16_t, 4, true>); break;
+    case 20: fn = reinterpret_cast<const void*>(k_recon<uint8_t, 5, false>); break;
+    case 21: fn = reinterpret_cast<const void*>(k_recon<uint8_t, 5, true>); break;
+    case 22: fn = reinterpret_cast<const void*>(k_recon<uint16_t, 5, false>); break;
+    case 23: fn = reinterpret_cast<const void*>(k_recon<uint16_t, 5, true>); break;
+    case 24: fn = reinterpret_cast<const void*>(k_recon<uint8_t, 6, false>); break;
+    case 25: fn = reinterpret_cast<const void*>(k_recon<uint8_t, 6, true>); break;
+    case 26: fn = reinterpret_cast<const void*>(k_recon<uint16_t, 6, false>); break;
+    case 27: fn = reinterpret_cast<const void*>(k_recon<uint16_t, 6, true>); break;
     default: return hm_fail(HM_ERR_UNSUPPORTED, "CTB size 2^%d", log2_ctb);
   }
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);

@@ -34,6 +34,14 @@ extern "C" {
 #define HM_PIC_SIGN_HIDING            0x0020u /* informational                                 */
 #define HM_PIC_TILES                  0x0040u /* pps.tiles_enabled_flag                        */
 #define HM_PIC_LF_ACROSS_TILES        0x0080u /* pps.loop_filter_across_tiles_enabled_flag     */
+#define HM_PIC_SCALING_LIST           0x0100u /* sps.scaling_list_enable_flag: off_scaling valid */
+#define HM_PIC_RARE_SYNTAX            (HM_PIC_SCALING_LIST) /* pictures that need the kernel variant with the rare paths */
+
+/* ScalingFactor tables of a picture with scaling lists (transform.cc:509-533): one byte per coefficient position
+ * x + nT * y.  Matrices of intra blocks only: 4x4 cIdx 0..2 at 0, 8x8 at 48, 16x16 at 240, 32x32 (luma) at 1008. */
+#define HM_SCALING_BYTES 2048
+#define HM_SCALING_OFFSET(log2_size, cidx) \
+  ((log2_size) == 2 ? 16 * (cidx) : ((log2_size) == 3 ? 48 + 64 * (cidx) : ((log2_size) == 4 ? 240 + 256 * (cidx) : 1008)))
 
 typedef struct hm_pic {
   uint32_t magic;
@@ -55,7 +63,8 @@ typedef struct hm_pic {
   uint8_t  colour_primaries, transfer_characteristics, matrix_coeffs, full_range;
   uint32_t n_slices, n_ctbs, n_tus, n_coeffs;
   uint32_t off_slices, off_ctbs, off_tus, off_coeffs;
-  uint32_t reserved1[3];
+  uint32_t off_scaling;        /* HM_SCALING_BYTES of scaling factors when HM_PIC_SCALING_LIST  */
+  uint32_t reserved1[2];
 } hm_pic;
 
 /* one entry per slice (not slice segment) */

@@ -24,6 +24,7 @@ typedef struct {
   const hm_ctb* ctbs;
   const hm_tu* tus;
   const hm_coeff* coeffs;
+  const uint8_t* scaling; /* HM_SCALING_BYTES of scaling factors, or NULL (flat) */
   int w[3], h[3];      /* plane sizes */
   int sw, sh;          /* chroma subsampling factors */
   uint16_t* pl[3];
@@ -197,19 +198,35 @@ static void predict(uint16_t* dst, int stride, int nT, int log2, int cIdx, int m
 }
 
 /* ---- R1-R3: dequantisation + inverse transform + add (transform.cc:386-689, fallback-dct.cc) ---- */
-static void residual_add(uint16_t* dst, int stride, int nT, int log2, int cIdx, const hm_tu* t, const hm_coeff* cf, int bit_depth)
+static void residual_add(uint16_t* dst, int stride, int nT, int log2, int cIdx, const hm_tu* t, const hm_coeff* cf, int bit_depth,
+                         const uint8_t* scaling)
 {
   int16_t coeff[32 * 32];
   memset(coeff, 0, sizeof(int16_t) * nT * nT);
   const int qP = t->qp;
-  /* flat scaling (m = 16 folded into the shift), 32-bit wrapping arithmetic: transform.cc:486-506 (Q3) */
-  const int bdShift = bit_depth + log2 - 5 - 4;
-  const int32_t offset = 1 << (bdShift - 1);
-  const int32_t fact = kLevelScale[qP % 6] << (qP / 6);
-  for (int i = 0; i < t->n_coeff; i++) {
-    const int32_t c = cf[i].value;
-    const int32_t prod = (int32_t)((uint32_t)c * (uint32_t)fact + (uint32_t)offset); /* wraps like the reference's int */
-    coeff[cf[i].pos] = (int16_t)clip3(-32768, 32767, prod >> bdShift);
+  if (!scaling) {
+    /* flat scaling (m = 16 folded into the shift), 32-bit wrapping arithmetic: transform.cc:486-506 (Q3) */
+    const int bdShift = bit_depth + log2 - 5 - 4;
+    const int32_t offset = 1 << (bdShift - 1);
+    const int32_t fact = kLevelScale[qP % 6] << (qP / 6);
+    for (int i = 0; i < t->n_coeff; i++) {
+      const int32_t c = cf[i].value;
+      const int32_t prod = (int32_t)((uint32_t)c * (uint32_t)fact + (uint32_t)offset); /* wraps like the reference's int */
+      coeff[cf[i].pos] = (int16_t)clip3(-32768, 32767, prod >> bdShift);
+    }
+  }
+  else {
+    /* scaling lists: m = ScalingFactor[sizeId][matrixId = cIdx (0 for 32x32)][pos], 64-bit product: transform.cc:507-545 */
+    const int bdShift = bit_depth + log2 - 5;
+    const int64_t offset = 1 << (bdShift - 1);
+    const uint8_t* sclist = scaling + HM_SCALING_OFFSET(log2, cIdx);
+    for (int i = 0; i < t->n_coeff; i++) {
+      const int32_t fact = (int32_t)((uint32_t)(sclist[cf[i].pos] * kLevelScale[qP % 6]) << (qP / 6));
+      int64_t v = ((int64_t)cf[i].value * fact + offset) >> bdShift;
+      if (v < -32768) v = -32768;
+      if (v > 32767) v = 32767;
+      coeff[cf[i].pos] = (int16_t)v;
+    }
   }
   const int maxv = (1 << bit_depth) - 1;
   if (t->info & HM_TU_TSKIP) { /* transform.cc:566-643, fallback-dct.cc:80-104 */
@@ -283,7 +300,7 @@ static void reconstruct(pic_t* P)
       if (cIdx == 0) filter_border(border, nT, t->pred_mode, (H->flags & HM_PIC_STRONG_INTRA_SMOOTHING) != 0, H->bit_depth_y);
       uint16_t* dst = P->pl[cIdx] + x0 + (size_t)y0 * P->w[cIdx];
       predict(dst, P->w[cIdx], nT, log2, cIdx, t->pred_mode, border, bd);
-      if (t->info & HM_TU_CBF) residual_add(dst, P->w[cIdx], nT, log2, cIdx, t, P->coeffs + t->coeff_first, bd);
+      if (t->info & HM_TU_CBF) residual_add(dst, P->w[cIdx], nT, log2, cIdx, t, P->coeffs + t->coeff_first, bd, P->scaling);
       if (cIdx == 0) {
         /* deblocking metadata: transform-block edges (deblock.cc:31-62) and QpY map */
         const int left_ok = t->x > 0 ? 1 : (c->flags & HM_CTB_DEBLOCK_LEFT) != 0;
@@ -536,6 +553,7 @@ int orc_decode_picture(const uint8_t* blob, size_t size, int stages, uint16_t* y
   P.ctbs = (const hm_ctb*)(blob + H->off_ctbs);
   P.tus = (const hm_tu*)(blob + H->off_tus);
   P.coeffs = (const hm_coeff*)(blob + H->off_coeffs);
+  P.scaling = (H->flags & HM_PIC_SCALING_LIST) ? blob + H->off_scaling : NULL;
   const int ncomp = H->chroma_format == 0 ? 1 : 3;
   P.sw = 2; P.sh = H->chroma_format == 1 ? 2 : 1;
   P.w[0] = H->width; P.h[0] = H->height;

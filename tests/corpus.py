@@ -36,6 +36,12 @@ CASES = {
     "mono8": dict(seed=4000001, width=160, height=104, chroma_format=0, log2_ctb=5, qp=29),
     "mono8_ctb64_wpp": dict(seed=4000002, width=192, height=136, chroma_format=0, log2_ctb=6, wpp=1, qp=24),
     "mono10": dict(seed=4000010, width=128, height=96, chroma_format=0, bit_depth=10, log2_ctb=4, qp=33),
+    # scaling lists (transform.cc:507-545): default lists, random lists in the SPS, lists in the PPS overriding the SPS
+    "sl_default": dict(seed=5100001, width=128, height=96, log2_ctb=5, qp=30, scaling_list=1),
+    "sl_sps": dict(seed=5100002, width=192, height=128, log2_ctb=5, qp=26, scaling_list=2),
+    "sl_pps_422_10": dict(seed=5100003, width=128, height=128, log2_ctb=5, chroma_format=2, bit_depth=10, qp=34, scaling_list=3),
+    "sl_sps_ctb64_lowqp": dict(seed=5100004, width=192, height=136, log2_ctb=6, qp=8, density=90, scaling_list=2),
+    "sl_sps_12bit_highqp": dict(seed=5100005, width=64, height=64, log2_ctb=4, bit_depth=12, qp=50, scaling_list=2),
 }
 
 

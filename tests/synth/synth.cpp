@@ -157,6 +157,7 @@ struct SynthParams {
   int32_t full_range, matrix, primaries;
   int32_t density;             // residual density knob 0..100 (percent scale of cbf/sig probabilities)
   int32_t wpp;                 // entropy_coding_sync_enabled_flag
+  int32_t scaling_list;        // 0 off, 1 enabled with the default lists, 2 lists in the SPS, 3 lists in the PPS (SPS: default)
 };
 
 // entropy-coder adaptor for SliceWalker: chooses every bin, encodes it, returns it
@@ -228,6 +229,38 @@ class EncoderEC {
   ContextSet cs_;
 };
 
+// §7.3.4 scaling_list_data with seeded random content: every matrix is either predicted (default list or an
+// earlier matrix of the same size) or coded explicitly as a smooth random walk (values 1..255, wrapping deltas allowed).
+void write_scaling_list_data(BitWriter& w, Rng& rng)
+{
+  for (int sizeId = 0; sizeId < 4; sizeId++)
+    for (int matrixId = 0; matrixId < 6; matrixId += (sizeId == 3) ? 3 : 1) {
+      const int n_ref = sizeId == 3 ? matrixId / 3 : matrixId;
+      if (rng.chance(350)) {
+        w.flag(0);                                     // scaling_list_pred_mode_flag
+        w.ue((uint32_t)(rng.next() % (uint64_t)(n_ref + 1))); // scaling_list_pred_matrix_id_delta (0 = default list)
+        continue;
+      }
+      w.flag(1);
+      const int coefNum = sizeId == 0 ? 16 : 64;
+      int next = 8;
+      if (sizeId > 1) {
+        const int dc = 1 + (int)(rng.next() % 255);    // scaling_list_dc_coef_minus8 + 8 in 1..255
+        w.se(dc - 8);
+        next = dc;
+      }
+      for (int i = 0; i < coefNum; i++) {
+        int target = next + (int)(rng.next() % 25) - 10 + (rng.chance(30) ? (int)(rng.next() % 200) - 100 : 0);
+        target = target < 1 ? 1 : (target > 255 ? 255 : target);
+        int d = target - next;                          // -254..254
+        const int wrapped = d < 0 ? d + 256 : d - 256;  // the same value through the modulo-256 wrap
+        if (d < -128 || d > 127 || (rng.chance(20) && wrapped >= -128 && wrapped <= 127)) d = wrapped;
+        w.se(d);
+        next = target;
+      }
+    }
+}
+
 void write_ptl(BitWriter& w, const SynthParams& p)
 {
   const int profile = (p.chroma_format != 1 || p.bit_depth > 10) ? 4 : (p.bit_depth > 8 ? 2 : 1);
@@ -252,6 +285,7 @@ __attribute__((visibility("default"))) int hm_synth_picture(const SynthParams* p
   if ((p.width & 7) || (p.height & 7) || p.width <= 0 || p.height <= 0) return -1;
   if ((p.width & ((1 << p.log2_min_cb) - 1)) || (p.height & ((1 << p.log2_min_cb) - 1))) return -1;
   std::vector<uint8_t> stream;
+  Rng hdr_rng(seed ^ 0x5ca1ab1e5eedull); // parameter-set content (scaling lists); the slice data has its own stream
   // ---- VPS ----
   {
     BitWriter w;
@@ -279,7 +313,11 @@ __attribute__((visibility("default"))) int hm_synth_picture(const SynthParams* p
     w.ue(p.log2_min_cb - 3); w.ue(p.log2_ctb - p.log2_min_cb);
     w.ue(p.log2_min_tb - 2); w.ue(p.log2_max_tb - p.log2_min_tb);
     w.ue(0); w.ue(p.max_th_depth_intra);
-    w.flag(0);                 // scaling_list_enabled_flag
+    w.flag(p.scaling_list != 0); // scaling_list_enabled_flag
+    if (p.scaling_list) {
+      w.flag(p.scaling_list == 2); // sps_scaling_list_data_present_flag
+      if (p.scaling_list == 2) write_scaling_list_data(w, hdr_rng);
+    }
     w.flag(0);                 // amp
     w.flag(p.sao != 0);
     w.flag(0);                 // pcm
@@ -329,7 +367,8 @@ __attribute__((visibility("default"))) int hm_synth_picture(const SynthParams* p
     w.flag(0);                 //   override enabled
     w.flag(p.deblock_disable != 0);
     if (!p.deblock_disable) { w.se(p.beta_offset_div2); w.se(p.tc_offset_div2); }
-    w.flag(0);                 // pps_scaling_list_data_present
+    w.flag(p.scaling_list == 3); // pps_scaling_list_data_present
+    if (p.scaling_list == 3) write_scaling_list_data(w, hdr_rng);
     w.flag(0);                 // lists_modification_present
     w.ue(0);                   // log2_parallel_merge_level_minus2
     w.flag(0);                 // slice_segment_header_extension_present

@@ -12,13 +12,13 @@ class SynthParams(C.Structure):
         "width", "height", "chroma_format", "bit_depth", "log2_ctb", "log2_min_cb", "log2_min_tb", "log2_max_tb",
         "max_th_depth_intra", "qp", "cu_qp_delta", "diff_cu_qp_delta_depth", "sao", "deblock_disable",
         "sign_hiding", "transform_skip", "strong_intra", "cb_qp_offset", "cr_qp_offset",
-        "beta_offset_div2", "tc_offset_div2", "vui", "full_range", "matrix", "primaries", "density", "wpp")]
+        "beta_offset_div2", "tc_offset_div2", "vui", "full_range", "matrix", "primaries", "density", "wpp", "scaling_list")]
 
 
 DEFAULTS = dict(width=64, height=64, chroma_format=1, bit_depth=8, log2_ctb=5, log2_min_cb=3, log2_min_tb=2,
                 log2_max_tb=5, max_th_depth_intra=2, qp=27, cu_qp_delta=1, diff_cu_qp_delta_depth=1, sao=1,
                 deblock_disable=0, sign_hiding=1, transform_skip=1, strong_intra=1, cb_qp_offset=0, cr_qp_offset=0,
-                beta_offset_div2=0, tc_offset_div2=0, vui=1, full_range=1, matrix=6, primaries=1, density=60, wpp=0)
+                beta_offset_div2=0, tc_offset_div2=0, vui=1, full_range=1, matrix=6, primaries=1, density=60, wpp=0, scaling_list=0)
 
 _lib = None
 
