@@ -224,6 +224,7 @@ int hm_batch_upload(hm_batch* b, void* stream)
       d.ctb_w = h.ctb_w; d.ctb_h = h.ctb_h;
       d.flags = (int32_t)h.flags;
       d.cb_qp_offset = h.pps_cb_qp_offset; d.cr_qp_offset = h.pps_cr_qp_offset;
+      d.pcm_loop_filter_disabled = h.pcm_loop_filter_disabled;
       d.slices = (const hm_slice*)(d.blob + h.off_slices);
       d.ctbs = (const hm_ctb*)(d.blob + h.off_ctbs);
       // destination = tile paste geometry of context.cc:2457-2502
@@ -292,11 +293,11 @@ int hm_batch_execute(hm_batch* b, int stages, void* stream)
     if (rc) return rc;
     mark();
     if (stages & 1) {
-      rc = hm_launch_deblock(dc, n, c.max_w4, c.max_h4, c.chroma_format, c.bit_depth, s);
+      rc = hm_launch_deblock(dc, n, c.max_w4, c.max_h4, c.chroma_format, c.bit_depth, c.rare, s);
       if (rc) return rc;
     }
     mark();
-    rc = hm_launch_sao_paste(dc, n, c.max_w, c.max_h, c.bit_depth, (stages & 2) ? 1 : 0, s);
+    rc = hm_launch_sao_paste(dc, n, c.max_w, c.max_h, c.bit_depth, (stages & 2) ? 1 : 0, c.rare, s);
     if (rc) return rc;
     mark();
   }

@@ -107,8 +107,9 @@ struct Window {
 };
 
 // fallback-postfilter.h:32-138
+// mod_p / mod_q: may the P / Q side of each 4-line half be modified (all true outside the reference's "pcmf" branch)
 template <typename Win>
-__device__ __forceinline__ void filter_luma(Win& W, int beta, const int tc2[2], int maxv)
+__device__ __forceinline__ void filter_luma(Win& W, int beta, const int tc2[2], int maxv, const bool (&mod_p)[2], const bool (&mod_q)[2])
 {
 #pragma unroll
   for (int j = 0; j < 2; j++) {
@@ -125,12 +126,16 @@ __device__ __forceinline__ void filter_luma(Win& W, int beta, const int tc2[2], 
 #pragma unroll
       for (int d = o; d < o + 4; d++) {
         const int p3 = W.at(d, 0), p2 = W.at(d, 1), p1 = W.at(d, 2), p0 = W.at(d, 3), q0 = W.at(d, 4), q1 = W.at(d, 5), q2 = W.at(d, 6), q3 = W.at(d, 7);
-        W.put(d, 3, p0 + clip3i(-t2, t2, ((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3) - p0));
-        W.put(d, 2, p1 + clip3i(-t2, t2, ((p2 + p1 + p0 + q0 + 2) >> 2) - p1));
-        W.put(d, 1, p2 + clip3i(-t2, t2, ((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3) - p2));
-        W.put(d, 4, q0 + clip3i(-t2, t2, ((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3) - q0));
-        W.put(d, 5, q1 + clip3i(-t2, t2, ((p0 + q0 + q1 + q2 + 2) >> 2) - q1));
-        W.put(d, 6, q2 + clip3i(-t2, t2, ((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3) - q2));
+        if (mod_p[j]) {
+          W.put(d, 3, p0 + clip3i(-t2, t2, ((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3) - p0));
+          W.put(d, 2, p1 + clip3i(-t2, t2, ((p2 + p1 + p0 + q0 + 2) >> 2) - p1));
+          W.put(d, 1, p2 + clip3i(-t2, t2, ((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3) - p2));
+        }
+        if (mod_q[j]) {
+          W.put(d, 4, q0 + clip3i(-t2, t2, ((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3) - q0));
+          W.put(d, 5, q1 + clip3i(-t2, t2, ((p0 + q0 + q1 + q2 + 2) >> 2) - q1));
+          W.put(d, 6, q2 + clip3i(-t2, t2, ((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3) - q2));
+        }
       }
     }
     else {
@@ -143,10 +148,10 @@ __device__ __forceinline__ void filter_luma(Win& W, int beta, const int tc2[2], 
         int delta0 = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4;
         if (iabs_(delta0) < 10 * tc) {
           delta0 = clip3i(-tc, tc, delta0);
-          W.put(d, 3, clip3i(0, maxv, p0 + delta0));
-          W.put(d, 4, clip3i(0, maxv, q0 - delta0));
-          if (np2) W.put(d, 2, clip3i(0, maxv, p1 + clip3i(-tc_2, tc_2, (((p2 + p0 + 1) >> 1) - p1 + delta0) >> 1)));
-          if (nq2) W.put(d, 5, clip3i(0, maxv, q1 + clip3i(-tc_2, tc_2, (((q2 + q0 + 1) >> 1) - q1 - delta0) >> 1)));
+          if (mod_p[j]) W.put(d, 3, clip3i(0, maxv, p0 + delta0));
+          if (mod_q[j]) W.put(d, 4, clip3i(0, maxv, q0 - delta0));
+          if (np2 && mod_p[j]) W.put(d, 2, clip3i(0, maxv, p1 + clip3i(-tc_2, tc_2, (((p2 + p0 + 1) >> 1) - p1 + delta0) >> 1)));
+          if (nq2 && mod_q[j]) W.put(d, 5, clip3i(0, maxv, q1 + clip3i(-tc_2, tc_2, (((q2 + q0 + 1) >> 1) - q1 - delta0) >> 1)));
         }
       }
     }
@@ -154,7 +159,15 @@ __device__ __forceinline__ void filter_luma(Win& W, int beta, const int tc2[2], 
 }
 
 // One launch = one direction for every picture of the batch.  blockIdx.y = picture.
-template <typename Pix, bool vertical>
+// bits 2 / 3 of the block map: PCM / transquant-bypass coding unit at luma position (x, y); 0 outside the picture
+__device__ __forceinline__ int lossless_bits(const hm_dev_pic& dp, int x, int y)
+{
+  if (x < 0 || y < 0 || (x >> 2) >= dp.w4 || (y >> 2) >= dp.h4) return 0;
+  return dp.meta[(x >> 2) + (size_t)(y >> 2) * dp.w4] & 12;
+}
+
+// PCMF: the variant for pictures of the rare-syntax classes, which also follows the reference's "pcmf" branches.
+template <typename Pix, bool vertical, bool PCMF>
 __global__ __launch_bounds__(256, sizeof(Pix) == 1 ? 8 : 6) void k_deblock(const hm_dev_pic* __restrict__ pics)
 {
   const hm_dev_pic& dp = pics[blockIdx.y];
@@ -179,9 +192,29 @@ __global__ __launch_bounds__(256, sizeof(Pix) == 1 ? 8 : 6) void k_deblock(const
     int tc[2];
     tc[0] = bs0 ? c_tc[clip3i(0, 53, qPL + 2 * (bs0 - 1) + sl.tc_offset_div2 * 2)] * (1 << (bd - 8)) : 0;
     tc[1] = bs1 ? c_tc[clip3i(0, 53, qPL + 2 * (bs1 - 1) + sl.tc_offset_div2 * 2)] * (1 << (bd - 8)) : 0;
+    bool mod_p[2] = {true, true}, mod_q[2] = {true, true};
+    if (PCMF && (dp.flags & HM_PIC_PCMF)) {
+      // deblock.cc:755-786 + fallback-postfilter.h:60-125 as the reference's SIMD build behaves: per half a flag per
+      // side says "neither PCM nor transquant-bypass" (pcm_loop_filter_disable_flag is not consulted here).  All four
+      // set: 8-bit pictures take the SSE filter (normal filtering), 16-bit pictures the scalar filter, which reads
+      // the flags as "do not modify".  Otherwise the scalar filter runs and modifies exactly the PCM / bypass sides.
+      bool keep_p[2], keep_q[2];
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int xq = vertical ? xD : xD + 4 * j, yq = vertical ? yD + 4 * j : yD;
+        keep_q[j] = lossless_bits(dp, xq, yq) == 0;
+        keep_p[j] = lossless_bits(dp, vertical ? xq - 1 : xq, vertical ? yq : yq - 1) == 0;
+      }
+      const bool all = keep_p[0] && keep_p[1] && keep_q[0] && keep_q[1];
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        mod_p[j] = all ? sizeof(Pix) == 1 : !keep_p[j];
+        mod_q[j] = all ? sizeof(Pix) == 1 : !keep_q[j];
+      }
+    }
     Window<Pix, vertical> win;
     win.load(dp.plane[0], dp.pitch[0], xD, yD);
-    filter_luma(win, beta, tc, maxv);
+    filter_luma(win, beta, tc, maxv, mod_p, mod_q);
     win.store(dp.plane[0], dp.pitch[0], xD, yD);
     return;
   }
@@ -219,6 +252,20 @@ __global__ __launch_bounds__(256, sizeof(Pix) == 1 ? 8 : 6) void k_deblock(const
   tc[1] = bS1 == 2 ? c_tc[clip3i(0, 53, QP_C1 + 2 + tco)] * (1 << (bd - 8)) : 0;
   uint8_t* plane = dp.plane[cp + 1];
   const int pitch = dp.pitch[cp + 1];
+  bool cmod_p[2] = {true, true}, cmod_q[2] = {true, true};
+  if (PCMF && (dp.flags & HM_PIC_PCMF)) {
+    // deblock.cc:1724-1756 + fallback-postfilter.h:138-180: a side is filtered unless it is transquant-bypass or
+    // (pcm_loop_filter_disable_flag and PCM); for vertical edges the reference tests the P flag for both sides
+    const int mask = (dp.pcm_loop_filter_disabled ? 4 : 0) | 8;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int xq = vertical ? lx : lx + 4 * sw * j, yq = vertical ? ly + 4 * sh * j : ly;
+      const bool fq = !(lossless_bits(dp, xq, yq) & mask);
+      const bool fp = !(lossless_bits(dp, vertical ? xq - 1 : xq, vertical ? yq : yq - 1) & mask);
+      cmod_p[j] = fp;
+      cmod_q[j] = vertical ? fp : fq;
+    }
+  }
   // 8 samples along the edge, p1 p0 | q0 q1 across it: row-wise vector accesses
   if (vertical) {
 #pragma unroll
@@ -230,7 +277,7 @@ __global__ __launch_bounds__(256, sizeof(Pix) == 1 ? 8 : 6) void k_deblock(const
       __builtin_memcpy(w, row, 4 * sizeof(Pix));
       const int p1 = w[0], p0 = w[1], q0 = w[2], q1 = w[3];
       const int delta = clip3i(-t, t, ((((q0 - p0) * 4) + p1 - q1 + 4) >> 3));
-      Pix o[2] = {(Pix)clip3i(0, maxv, p0 + delta), (Pix)clip3i(0, maxv, q0 - delta)};
+      Pix o[2] = {cmod_p[k >> 2] ? (Pix)clip3i(0, maxv, p0 + delta) : (Pix)p0, cmod_q[k >> 2] ? (Pix)clip3i(0, maxv, q0 - delta) : (Pix)q0};
       __builtin_memcpy(row + 1, o, 2 * sizeof(Pix));
     }
   }
@@ -243,8 +290,8 @@ __global__ __launch_bounds__(256, sizeof(Pix) == 1 ? 8 : 6) void k_deblock(const
       const int t = tc[k >> 2];
       const int p1 = r[0][k], p0 = r[1][k], q0 = r[2][k], q1 = r[3][k];
       const int delta = clip3i(-t, t, ((((q0 - p0) * 4) + p1 - q1 + 4) >> 3)); // t == 0 leaves the samples unchanged
-      r[1][k] = (Pix)clip3i(0, maxv, p0 + delta);
-      r[2][k] = (Pix)clip3i(0, maxv, q0 - delta);
+      if (cmod_p[k >> 2]) r[1][k] = (Pix)clip3i(0, maxv, p0 + delta);
+      if (cmod_q[k >> 2]) r[2][k] = (Pix)clip3i(0, maxv, q0 - delta);
     }
     __builtin_memcpy(reinterpret_cast<Pix*>(plane + (size_t)(yDi - 1) * pitch) + xDi, r[1], 8 * sizeof(Pix));
     __builtin_memcpy(reinterpret_cast<Pix*>(plane + (size_t)yDi * pitch) + xDi, r[2], 8 * sizeof(Pix));
@@ -263,10 +310,14 @@ __device__ __forceinline__ int clip_f_u8(float fx)
 // multiple of 8 - the common case; otherwise the generic per-sample path runs).
 template <typename Pix>
 __device__ __forceinline__ int sao_sample(const hm_dev_pic& dp, const PicView& v, const uint8_t* plane, int pitch, int c,
-                                          int xx, int yy, int W, int Hh, int l2w, int l2h, int bd, int apply_sao)
+                                          int xx, int yy, int W, int Hh, int l2w, int l2h, int bd, int apply_sao, int keep_mask)
 {
   const int maxv = (1 << bd) - 1;
   int val = reinterpret_cast<const Pix*>(plane + (size_t)yy * pitch)[xx];
+  if (keep_mask) { // lossless coding units keep their samples (rare-syntax variant only)
+    const int lsx = c ? 1 : 0, lsy = c ? (dp.chroma_format == 1 ? 1 : 0) : 0;
+    if (lossless_bits(dp, xx << lsx, yy << lsy) & keep_mask) return val;
+  }
   const int cx = xx >> l2w, cy = yy >> l2h;
   const hm_ctb& cb = v.ctbs[cx + cy * dp.ctb_w];
   const hm_slice& sl = v.slices[cb.slice_idx];
@@ -424,7 +475,9 @@ __device__ __forceinline__ void sao_edge_group(int xs, int yy, int W, int Hh, in
   }
 }
 
-template <typename Pix>
+// RARE: the variant for the rare-syntax classes: samples of transquant-bypass units and, with
+// pcm_loop_filter_disable_flag, of PCM units keep their deblocked value (sao.cc:356-363, 452-456).
+template <typename Pix, bool RARE>
 __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict__ pics, int apply_sao)
 {
   const hm_dev_pic& dp = pics[blockIdx.y];
@@ -498,6 +551,14 @@ __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict_
         else if (cl == 2) sao_edge_group<Pix, -1, -1>(xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv2, up, cur, dn, res[r]);
         else sao_edge_group<Pix, 1, -1>(xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv2, up, cur, dn, res[r]);
       }
+      if (RARE && type != 0 && (dp.flags & HM_PIC_LOSSLESS_CUS)) {
+        // a pair of samples lies in one 4x4 luma block (chroma: 2 samples = 4 luma columns)
+        const int mask = (dp.pcm_loop_filter_disabled ? 4 : 0) | 8;
+        const int lsx = c ? 1 : 0, lsy = c ? sh - 1 : 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (lossless_bits(dp, (xs + 2 * j) << lsx, yy << lsy) & mask) res[r][j] = cur.p[j];
+      }
     }
   }
   else {
@@ -507,7 +568,8 @@ __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict_
       for (int k = 0; k < G; k++) {
         const int xx = xs + k;
         const int val = (xx < W && x8 + k < cw && yd0 + r < chh)
-                            ? sao_sample<Pix>(dp, v, plane, pitch, c, xx, yy0 + r, W, Hh, l2w, l2h, bd, apply_sao) : 0;
+                            ? sao_sample<Pix>(dp, v, plane, pitch, c, xx, yy0 + r, W, Hh, l2w, l2h, bd, apply_sao,
+                                              RARE && (dp.flags & HM_PIC_LOSSLESS_CUS) ? ((dp.pcm_loop_filter_disabled ? 4 : 0) | 8) : 0) : 0;
         if (k & 1) res[r][k >> 1] |= (uint32_t)val << 16;
         else res[r][k >> 1] = (uint32_t)val;
       }
@@ -555,8 +617,16 @@ __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict_
 
 } // namespace
 
+template <typename Pix, bool RARE>
+static void launch_deblock(const hm_dev_pic* d_pics, int n_pics, int blocks, hipStream_t s)
+{
+  // all vertical edges of every picture first, then the horizontal ones (deblock.cc:1775-1803)
+  hipLaunchKernelGGL((k_deblock<Pix, true, RARE>), dim3(blocks, n_pics), dim3(256), 0, s, d_pics);
+  hipLaunchKernelGGL((k_deblock<Pix, false, RARE>), dim3(blocks, n_pics), dim3(256), 0, s, d_pics);
+}
+
 extern "C" int hm_launch_deblock(const hm_dev_pic* d_pics, int n_pics, int max_w4, int max_h4, int chroma_format,
-                                 int bit_depth, hipStream_t s)
+                                 int bit_depth, int rare_syntax, hipStream_t s)
 {
   if (n_pics <= 0) return HM_OK;
   const int lw = (max_w4 + 1) >> 1, lh = (max_h4 + 1) >> 1;
@@ -564,28 +634,27 @@ extern "C" int hm_launch_deblock(const hm_dev_pic* d_pics, int n_pics, int max_w
   const int cwn = (max_w4 + 3) / 4, chn = (max_h4 + 2 * sh - 1) / (2 * sh);
   const long items = (long)lw * lh + 2L * cwn * chn;
   const int blocks = (int)((items + 255) / 256);
-  // all vertical edges of every picture first, then the horizontal ones (deblock.cc:1775-1803)
-  if (bit_depth > 8) {
-    hipLaunchKernelGGL((k_deblock<uint16_t, true>), dim3(blocks, n_pics), dim3(256), 0, s, d_pics);
-    hipLaunchKernelGGL((k_deblock<uint16_t, false>), dim3(blocks, n_pics), dim3(256), 0, s, d_pics);
-  }
-  else {
-    hipLaunchKernelGGL((k_deblock<uint8_t, true>), dim3(blocks, n_pics), dim3(256), 0, s, d_pics);
-    hipLaunchKernelGGL((k_deblock<uint8_t, false>), dim3(blocks, n_pics), dim3(256), 0, s, d_pics);
-  }
+  if (bit_depth > 8) rare_syntax ? launch_deblock<uint16_t, true>(d_pics, n_pics, blocks, s) : launch_deblock<uint16_t, false>(d_pics, n_pics, blocks, s);
+  else rare_syntax ? launch_deblock<uint8_t, true>(d_pics, n_pics, blocks, s) : launch_deblock<uint8_t, false>(d_pics, n_pics, blocks, s);
   return hm_check_hip(hipGetLastError(), "k_deblock launch");
 }
 
 extern "C" int hm_launch_sao_paste(const hm_dev_pic* d_pics, int n_pics, int max_w, int max_h, int bit_depth, int apply_sao,
-                                   hipStream_t s)
+                                   int rare_syntax, hipStream_t s)
 {
   if (n_pics <= 0) return HM_OK;
-  // 64 x 8-sample tiles of the three planes (chroma at most as large as luma); one wave per tile, four per block
+  // 64 x 16-sample tiles of the three planes (chroma at most as large as luma); one wave per tile, four per block
   const long luma = (long)((max_w + 63) / 64) * ((max_h + 15) / 16);
   const int cwm = (max_w + 1) / 2;
   const long chroma = (long)((cwm + 63) / 64) * ((max_h + 15) / 16); // 4:2:2 height bound
-  const int blocks = (int)((luma + 2 * chroma + 3) / 4);
-  if (bit_depth > 8) hipLaunchKernelGGL(k_sao_paste<uint16_t>, dim3(blocks, n_pics), dim3(256), 0, s, d_pics, apply_sao);
-  else hipLaunchKernelGGL(k_sao_paste<uint8_t>, dim3(blocks, n_pics), dim3(256), 0, s, d_pics, apply_sao);
+  const dim3 grid((int)((luma + 2 * chroma + 3) / 4), n_pics);
+  if (bit_depth > 8) {
+    if (rare_syntax) hipLaunchKernelGGL((k_sao_paste<uint16_t, true>), grid, dim3(256), 0, s, d_pics, apply_sao);
+    else hipLaunchKernelGGL((k_sao_paste<uint16_t, false>), grid, dim3(256), 0, s, d_pics, apply_sao);
+  }
+  else {
+    if (rare_syntax) hipLaunchKernelGGL((k_sao_paste<uint8_t, true>), grid, dim3(256), 0, s, d_pics, apply_sao);
+    else hipLaunchKernelGGL((k_sao_paste<uint8_t, false>), grid, dim3(256), 0, s, d_pics, apply_sao);
+  }
   return hm_check_hip(hipGetLastError(), "k_sao_paste launch");
 }

@@ -307,6 +307,11 @@ void parse_sps(BitReader& br, SPS& sps)
     sps.log2_min_pcm_cb = br.ue() + 3;
     sps.log2_max_pcm_cb = sps.log2_min_pcm_cb + br.ue();
     sps.pcm_loop_filter_disabled = br.flag();
+    // sps.cc:369-378 of the reference rejects PCM depths above the sample depth; §7.4.3.2.1 bounds the block sizes
+    if (sps.pcm_bit_depth_y > sps.bit_depth_y || sps.pcm_bit_depth_c > sps.bit_depth_c)
+      throw ParseError(HM_ERR_BITSTREAM, "PCM sample bit depth above the sample bit depth");
+    if (sps.log2_min_pcm_cb > 5 || sps.log2_max_pcm_cb > std::min(sps.log2_ctb, 5) || sps.log2_min_pcm_cb < sps.log2_min_cb)
+      throw ParseError(HM_ERR_BITSTREAM, "PCM coding block size out of range");
   }
   int num_st_rps = br.ue();
   if (num_st_rps > 64) throw ParseError(HM_ERR_BITSTREAM, "too many short-term RPS");

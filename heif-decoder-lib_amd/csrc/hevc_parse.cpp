@@ -22,6 +22,26 @@ class DecoderEC {
   inline int bypass(int, int) { return dec_.decode_bypass(); }
   inline int terminate(int) { int b = dec_.decode_terminate(); check(); return b; }
   ContextSet& contexts() { return cs_; }
+  inline int pcm_flag() { return terminate(0); }
+  // PCM samples start at the byte the arithmetic decoder's read pointer stands on after the terminating bin, and the
+  // decoder restarts on the next byte boundary behind them (slice.cc:4506-4536, cabac.cc:658-677 of the reference)
+  void pcm_begin() { raw_ = dec_.position(); raw_bit_ = 0; }
+  uint32_t pcm_bits(int n)
+  {
+    uint32_t v = 0;
+    for (int i = 0; i < n; i++) {
+      if (raw_ >= end_) throw ParseError(HM_ERR_BITSTREAM, "PCM samples run past the end of the slice data");
+      v = (v << 1) | ((*raw_ >> (7 - raw_bit_)) & 1u);
+      if (++raw_bit_ == 8) { raw_bit_ = 0; raw_++; }
+    }
+    return v;
+  }
+  void pcm_end()
+  {
+    if (raw_bit_) { raw_bit_ = 0; raw_++; }
+    if (end_ - raw_ < 2) throw ParseError(HM_ERR_BITSTREAM, "slice data ends inside a PCM coding unit");
+    dec_.init(raw_, end_);
+  }
   void start_substream()
   {
     if (started_) cur_ = dec_.position();
@@ -39,6 +59,8 @@ class DecoderEC {
   ContextSet cs_;
   const uint8_t* cur_;
   const uint8_t* end_;
+  const uint8_t* raw_ = nullptr; // PCM sample reader
+  int raw_bit_ = 0;
   bool started_ = false;
 };
 
@@ -229,6 +251,8 @@ struct Decoder {
     if (p.tiles_enabled) flags |= HM_PIC_TILES;
     if (p.lf_across_tiles) flags |= HM_PIC_LF_ACROSS_TILES;
     if (s.scaling_list_enabled) flags |= HM_PIC_SCALING_LIST;
+    if ((s.pcm_enabled && s.pcm_loop_filter_disabled) || p.transquant_bypass_enabled) flags |= HM_PIC_PCMF;
+    if (pic.uses_pcm || pic.uses_tq_bypass) flags |= HM_PIC_LOSSLESS_CUS;
     h.flags = flags;
     h.colour_primaries = (uint8_t)s.colour_primaries;
     h.transfer_characteristics = (uint8_t)s.transfer_characteristics;

@@ -16,6 +16,10 @@
 //                                               a conformant stream must carry here)
 //     ContextSet& contexts()
 //     void start_substream()                    (re)initialise the arithmetic engine at a byte boundary
+//     int  pcm_flag()                           the terminating bin that announces PCM samples
+//     void pcm_begin(); uint32_t pcm_bits(int n); void pcm_end()
+//                                               raw sample bits that follow pcm_flag = 1 at the coder's byte
+//                                               position, then byte alignment and a fresh arithmetic engine
 #ifndef HM_HEVC_SYNTAX_H
 #define HM_HEVC_SYNTAX_H
 
@@ -433,11 +437,10 @@ class SliceWalker {
     const int nCbS = 1 << log2CbSize;
     cu_first_tu_.clear();
     derive_qp(x0, y0, log2CbSize); // the reference derives QP at CU start (slice.cc:4593)
-    if (pps_.transquant_bypass_enabled) {
-      if (ec_.bin(CTX_TQ_BYPASS, K_TQ_BYPASS, 0)) {
-        pic_.uses_tq_bypass = true;
-        throw ParseError(HM_ERR_UNSUPPORTED, "cu_transquant_bypass_flag=1 is outside the GPU hot path");
-      }
+    cu_bypass_ = false;
+    if (pps_.transquant_bypass_enabled && ec_.bin(CTX_TQ_BYPASS, K_TQ_BYPASS, 0)) {
+      cu_bypass_ = true;
+      pic_.uses_tq_bypass = true;
     }
     // I slice: no cu_skip_flag / pred_mode_flag
     bool nxn = false;
@@ -448,9 +451,10 @@ class SliceWalker {
       if (nxn && log2CbSize <= sps_.log2_min_tb) throw ParseError(HM_ERR_BITSTREAM, "PART_NxN at minimum transform size");
     }
     if (sps_.pcm_enabled && !nxn && log2CbSize >= sps_.log2_min_pcm_cb && log2CbSize <= sps_.log2_max_pcm_cb) {
-      if (ec_.terminate(0)) {
+      if (ec_.pcm_flag()) {
         pic_.uses_pcm = true;
-        throw ParseError(HM_ERR_UNSUPPORTED, "pcm_flag=1 is outside the GPU hot path");
+        pcm_coding_unit(x0, y0, log2CbSize);
+        return;
       }
     }
     const int pbOffset = nxn ? (nCbS >> 1) : nCbS;
@@ -492,6 +496,52 @@ class SliceWalker {
     transform_tree(x0, y0, x0, y0, log2CbSize, 0, 0, max_depth, nxn, 1, 1);
     // all luma records of this CU must carry the CU's final QpY (deblocking uses the QpY map)
     for (auto& ref : cu_first_tu_) pic_.ctb_tus[ref.ctb][ref.idx].qpy = (int8_t)cu_qpy_;
+  }
+
+  // pcm_sample( ) (§7.3.8.7; slice.cc:4462-4536 of the reference): raw samples of all components at the entropy
+  // coder's byte position, then a fresh arithmetic engine.  One record per component block, whose "levels" are the
+  // samples shifted up to the bit depth.  Neighbours see a PCM unit as INTRA_DC (intrapred.cc:86-104).
+  void pcm_coding_unit(int x0, int y0, int log2CbSize)
+  {
+    const int n4 = 1 << (log2CbSize - 2);
+    for (int j = 0; j < n4; j++)
+      for (int k = 0; k < n4; k++) pic_.intra_mode[((x0 >> 2) + k) + (size_t)((y0 >> 2) + j) * w4_] = 1;
+    ec_.pcm_begin();
+    emit_pcm_block(x0, y0, log2CbSize, 0, 1 << log2CbSize, 1);
+    if (sps_.ChromaArrayType != 0) {
+      const int sw = sps_.SubWidthC, shh = sps_.SubHeightC; // 4:4:4 is refused before the slice data is read
+      const int log2C = log2CbSize - 1, parts = sw == 2 && shh == 1 ? 2 : 1; // 4:2:2: two square halves, top then bottom
+      for (int c = 1; c <= 2; c++) emit_pcm_block(x0 / sw, y0 / shh, log2C, c, 1 << log2C, parts);
+    }
+    ec_.pcm_end();
+  }
+  // rows of `w` samples; `parts` vertically stacked square blocks of that width
+  void emit_pcm_block(int xc, int yc, int log2, int cIdx, int w, int parts)
+  {
+    const int bits = cIdx ? sps_.pcm_bit_depth_c : sps_.pcm_bit_depth_y;
+    const int depth = cIdx ? sps_.bit_depth_c : sps_.bit_depth_y;
+    const int shift = depth > bits ? depth - bits : 0;
+    const int lw = cIdx ? (sps_.SubWidthC >> 1) : 0, lh = cIdx ? (sps_.SubHeightC >> 1) : 0;
+    for (int part = 0; part < parts; part++) {
+      hm_tu t;
+      std::memset(&t, 0, sizeof(t));
+      const int yb = yc + part * w;
+      t.x = (uint8_t)(xc & ((1 << (sps_.log2_ctb - lw)) - 1));
+      t.y = (uint8_t)(yb & ((1 << (sps_.log2_ctb - lh)) - 1));
+      t.info = (uint8_t)(log2 | (cIdx << HM_TU_CIDX_SHIFT) | HM_TU_CBF);
+      t.pred_mode = (uint8_t)(1 | HM_TU_MODE_PCM | (cu_bypass_ ? HM_TU_MODE_BYPASS : 0)); // a PCM unit may also be bypass: the filters test both
+      t.coeff_first = (uint32_t)pic_.coeffs.size();
+      t.n_coeff = (uint16_t)(w * w);
+      t.qp = (uint8_t)qp_prime_[cIdx];
+      t.qpy = (int8_t)cu_qpy_;
+      for (int i = 0; i < w * w; i++) {
+        hm_coeff c;
+        c.pos = (uint16_t)i;
+        c.value = (int16_t)(ec_.pcm_bits(bits) << shift);
+        pic_.coeffs.push_back(c);
+      }
+      pic_.ctb_tus[ctb_addr_rs_].push_back(t);
+    }
   }
 
   int read_chroma_pred_mode()
@@ -643,7 +693,7 @@ class SliceWalker {
     t.x = (uint8_t)(xc & ((1 << (sps_.log2_ctb - lw)) - 1));
     t.y = (uint8_t)(yc & ((1 << (sps_.log2_ctb - lh)) - 1));
     t.info = (uint8_t)(log2 | (cIdx << HM_TU_CIDX_SHIFT));
-    t.pred_mode = (uint8_t)mode;
+    t.pred_mode = (uint8_t)(mode | (cu_bypass_ ? HM_TU_MODE_BYPASS : 0));
     t.coeff_first = (uint32_t)pic_.coeffs.size();
     bool tskip = false;
     if (cbf) {
@@ -678,7 +728,7 @@ class SliceWalker {
   {
     const int nT = 1 << log2;
     tskip = false;
-    if (pps_.transform_skip_enabled && log2 <= pps_.log2_max_transform_skip_size)
+    if (pps_.transform_skip_enabled && !cu_bypass_ && log2 <= pps_.log2_max_transform_skip_size)
       tskip = ec_.bin(CTX_TSKIP + (cIdx ? 1 : 0), K_TSKIP, cIdx) != 0;
     // last significant coefficient position
     int lastX = last_prefix(log2, cIdx, CTX_LAST_X);
@@ -774,7 +824,7 @@ class SliceWalker {
       if (firstGt1 >= 0) gt2flag = ec_.bin(CTX_GT2 + ctxSet + (cIdx ? 4 : 0), K_GT2, 0);
 
       // signs
-      const bool signHidden = pps_.sign_data_hiding && (sigpos[0] - sigpos[nsig - 1] > 3);
+      const bool signHidden = pps_.sign_data_hiding && !cu_bypass_ && (sigpos[0] - sigpos[nsig - 1] > 3); // slice.cc:3565-3575
       const int nsign = signHidden ? nsig - 1 : nsig;
       uint32_t signbits = 0;
       for (int k = 0; k < nsign; k++) signbits = (signbits << 1) | (uint32_t)ec_.bypass(K_SIGN, k);
@@ -870,6 +920,7 @@ class SliceWalker {
   // current CU
   int cu_x_ = 0, cu_y_ = 0, cu_log2_ = 3;
   bool cu_nxn_ = false;
+  bool cu_bypass_ = false; // cu_transquant_bypass_flag of the current coding unit
   int luma_mode_[4] = {1, 1, 1, 1}, chroma_mode_[4] = {1, 1, 1, 1};
   std::vector<TuRef> cu_first_tu_;
 };

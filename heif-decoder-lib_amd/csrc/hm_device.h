@@ -13,7 +13,8 @@ struct hm_dev_pic {
   uint8_t* plane[3];        // working planes: reconstruction, deblocked in place
   int32_t pitch[3];         // bytes
   uint16_t* meta;           // per 4x4 luma block: bit0 vertical transform edge on its left, bit1 horizontal edge on
-                            // top (deblock.cc:31-62), bits 8-15 QpY (int8) - one store from k_recon, one load in k_deblock
+                            // top (deblock.cc:31-62), bit2 PCM / bit3 transquant-bypass coding unit, bits 8-15 QpY (int8)
+                            // - one store from k_recon, one load in k_deblock
   int32_t w4, h4;           // size of the 4x4-block maps
   // final output of the in-loop filters (SAO stage): written straight into the destination
   // image = fused tile paste (context.cc:2457-2535 of the reference)
@@ -29,6 +30,7 @@ struct hm_dev_pic {
   int32_t ctb_w, ctb_h;
   int32_t flags;            // hm_pic.flags
   int32_t cb_qp_offset, cr_qp_offset; // pps offsets (chroma deblocking QpC)
+  int32_t pcm_loop_filter_disabled;   // sps.pcm_loop_filter_disable_flag
   // sections of the command stream, resolved on the host so that the filter kernels need no dependent load of the header
   const hm_slice* slices;
   const hm_ctb* ctbs;

@@ -415,7 +415,14 @@ __device__ __forceinline__ void residual_add(const Blk<Pix>& B, int16_t* coeff, 
   const int32_t offset = 1 << (bdShift - 1);
   const int32_t fact = (int32_t)tab[70 + qP % 6] << (qP / 6);
   int mx = 0, my = 0;
-  if (picf & HM_PIC_SCALING_LIST) {
+  if (B.tskip & 0x100) { // transquant bypass (transform.cc:431-449): the levels are the residual
+#pragma unroll 1
+    for (int i = lane; i < B.n_coeff; i += 64) {
+      const uint32_t raw = i < 64 ? pre_raw : cf[i];
+      coeff[raw & 0xFFFF] = (int16_t)(raw >> 16);
+    }
+  }
+  else if (picf & HM_PIC_SCALING_LIST) {
     // scaling lists (transform.cc:507-545): m = ScalingFactor[pos] of matrix cIdx (32x32: matrix 0), 64-bit product.
     // The rare path: the table address waits in LDS behind the tables instead of occupying registers.
     const uint8_t* table = *reinterpret_cast<const uint8_t* const*>(tab + TAB_SCALING_PTR);
@@ -457,7 +464,13 @@ __device__ __forceinline__ void residual_add(const Blk<Pix>& B, int16_t* coeff, 
   const int maxv = (1 << bit_depth) - 1;
   const int postShift = 20 - bit_depth, rnd2 = 1 << (postShift - 1);
 
-  if (B.tskip) { // transform.cc:566-643
+  if (B.tskip & 0x100) {
+    lanes_loop<npx>(lane, [&](int p) {
+      const int x = p & (nT - 1), y = p >> log2;
+      dst[mul24(y, pitch) + x] = (Pix)clip3i(0, maxv, (int)dst[mul24(y, pitch) + x] + (int)coeff[p]);
+    });
+  }
+  else if (B.tskip) { // transform.cc:566-643
     const int tsShift = 5 + log2;
     lanes_loop<npx>(lane, [&](int p) {
       const int x = p & (nT - 1), y = p >> log2;
@@ -656,7 +669,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
         bool pair = false;
         uint32_t s0 = 0;
         constexpr uint32_t kind_mask = (uint32_t)(HM_TU_LOG2_MASK | (3u << HM_TU_CIDX_SHIFT)) << 16;
-        if ((r0 & kind_mask) == ((2u | (1u << HM_TU_CIDX_SHIFT)) << 16) && k + 1 < tu_count) {
+        // (PCM / transquant-bypass records, which only the RARE variant can meet, take the one-block path)
+        if ((r0 & kind_mask) == ((2u | (1u << HM_TU_CIDX_SHIFT)) << 16) && k + 1 < tu_count && (!RARE || (r0 >> 30) == 0)) {
           s0 = rfl(m0);
           constexpr uint32_t differ = (uint32_t)(HM_TU_CBF | HM_TU_TSKIP | (3u << HM_TU_CIDX_SHIFT)) << 16;
           pair = ((r0 ^ s0) & ~differ) == 0 && ((s0 >> (16 + HM_TU_CIDX_SHIFT)) & 3) == 2 && (uint32_t)rfl(m3) == r3;
@@ -716,12 +730,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
         k += 1;
         Blk<Pix> B;
         B.info = (r0 >> 16) & 0xFF;
-        B.mode = r0 >> 24;
+        B.mode = RARE ? (r0 >> 24) & HM_TU_MODE_MASK : r0 >> 24;
+        const int lossless = RARE ? (int)(r0 >> 30) : 0; // bit 0: transquant bypass, bit 1: PCM
         B.log2 = B.info & HM_TU_LOG2_MASK;
         B.c = (B.info >> HM_TU_CIDX_SHIFT) & 3;
         B.avail = r3;
         B.bd = bd;
-        B.tskip = B.info & HM_TU_TSKIP;
+        B.tskip = (B.info & HM_TU_TSKIP) | ((lossless & 1) << 8); // bit 8: the levels are the residual
         B.x0 = w0 & 0xFF; B.y0 = (w0 >> 8) & 0xFF;
         B.qp = w1 & 0xFF;
         const int qpy = (int)(int8_t)((w1 >> 8) & 0xFF);
@@ -745,7 +760,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
           int ln = lane;
           asm volatile("" : "+v"(ln));
           const bool smoothed = L2 != 2 && B.c == 0 && ((filter_mode_mask(L2) >> B.mode) & 1);
-          if (L2 <= 3 && !smoothed && is_interior<L2>(B.avail, B.info)) {
+          if (RARE && (lossless & 2)) { // PCM: the record's levels are the samples, in raster order (slice.cc:4462-4504)
+            Pix* dst = B.u + mul24(B.y0, B.P) + UPAD + B.x0;
+            const GLOBAL_AS uint32_t* cf = coeffs + coeff_first;
+            lanes_loop<(1 << (2 * L2))>(ln, [&](int p) { dst[mul24(p >> L2, B.P) + (p & ((1 << L2) - 1))] = (Pix)(cf[p] >> 16); });
+          }
+          else if (L2 <= 3 && !smoothed && is_interior<L2>(B.avail, B.info)) {
             predict<Pix, L2>(B, direct_refs<Pix, L2>(B), tab, ln); // one lane pass: cheaper to address the samples in place
           }
           else {
@@ -754,7 +774,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
             predict<Pix, L2>(B, RefArray{l_bA + 64}, tab, ln);
           }
           WAVE_SYNC();
-          if (cbf) {
+          if (cbf && !(RARE && (lossless & 2))) {
             if (L2 == 5) { // take the workgroup's 32x32 staging
               if (lane == 0)
                 while (__hip_atomic_exchange(big_lock, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) __builtin_amdgcn_s_sleep(2);
@@ -776,7 +796,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
               const int top_ok = (B.y0 > 0) | ((cb_flags & HM_CTB_DEBLOCK_TOP) != 0);
               const int e = ((i == 0) & left_ok & deblock_en) | (((j == 0) & top_ok & deblock_en) << 1);
               const uint32_t mo = (uint32_t)((B.x0 >> 2) + i) + __umul24((uint32_t)((B.y0 >> 2) + j), (uint32_t)dp.w4);
-              ctb_meta[mo] = (uint16_t)(e | ((qpy & 0xFF) << 8));
+              // bits 2 / 3: PCM / transquant-bypass coding unit (the loop filters leave such samples alone)
+              ctb_meta[mo] = (uint16_t)(e | ((lossless & 2) << 1) | ((lossless & 1) << 3) | ((qpy & 0xFF) << 8));
             }
           }
         };

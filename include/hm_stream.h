@@ -35,7 +35,11 @@ extern "C" {
 #define HM_PIC_TILES                  0x0040u /* pps.tiles_enabled_flag                        */
 #define HM_PIC_LF_ACROSS_TILES        0x0080u /* pps.loop_filter_across_tiles_enabled_flag     */
 #define HM_PIC_SCALING_LIST           0x0100u /* sps.scaling_list_enable_flag: off_scaling valid */
-#define HM_PIC_RARE_SYNTAX            (HM_PIC_SCALING_LIST) /* pictures that need the kernel variant with the rare paths */
+#define HM_PIC_PCMF                   0x0200u /* (pcm_enabled && pcm_loop_filter_disabled) || transquant_bypass_enabled:
+                                                 the reference's deblocking takes its "pcmf" branches (deblock.cc:723)  */
+#define HM_PIC_LOSSLESS_CUS           0x0400u /* at least one PCM or cu_transquant_bypass coding unit            */
+#define HM_PIC_RARE_SYNTAX            (HM_PIC_SCALING_LIST | HM_PIC_PCMF | HM_PIC_LOSSLESS_CUS) /* pictures that need the kernel
+                                                 variant of the reconstruction with the rare paths             */
 
 /* ScalingFactor tables of a picture with scaling lists (transform.cc:509-533): one byte per coefficient position
  * x + nT * y.  Matrices of intra blocks only: 4x4 cIdx 0..2 at 0, 8x8 at 48, 16x16 at 240, 32x32 (luma) at 1008. */
@@ -115,6 +119,12 @@ typedef struct hm_ctb {
 #define HM_TU_TSKIP   0x40u    /* transform_skip_flag                                         */
 #define HM_TU_AVAIL_TL 0x80u   /* top-left neighbour sample available                         */
 
+/* hm_tu.pred_mode: IntraPredMode in bits 0-5, and */
+#define HM_TU_MODE_MASK   0x3Fu
+#define HM_TU_MODE_BYPASS 0x40u /* cu_transquant_bypass_flag: the levels are the residual (transform.cc:431-449)     */
+#define HM_TU_MODE_PCM    0x80u /* pcm_flag: no prediction; the n_coeff = nT*nT "levels" are the samples, already
+                                   shifted to the bit depth, in raster order (slice.cc:4462-4504)                  */
+
 /* One reconstruction step: predict block, then add its residual.  x,y are relative to the CTB
  * origin in samples of the component (chroma: chroma samples).  avail_* count available
  * neighbour samples (intrapred.h:620-667: picture bounds, slice, tile and z-order already
@@ -122,7 +132,7 @@ typedef struct hm_ctb {
 typedef struct hm_tu {
   uint8_t  x, y;
   uint8_t  info;
-  uint8_t  pred_mode;    /* IntraPredMode 0..34 (chroma: final mode, 4:2:2 remap applied)     */
+  uint8_t  pred_mode;    /* IntraPredMode 0..34 (chroma: final mode, 4:2:2 remap applied) | HM_TU_MODE_* */
   uint8_t  qp;           /* qP of (8.6.1) incl. QpBdOffset: the dequantisation QP             */
   int8_t   qpy;          /* QpY of the coding unit (deblocking)                               */
   uint16_t n_coeff;      /* number of hm_coeff pairs                                          */

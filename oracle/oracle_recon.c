@@ -294,13 +294,28 @@ static void reconstruct(pic_t* P)
       const int bd = cIdx ? H->bit_depth_c : H->bit_depth_y;
       const int x0 = cx * (cIdx ? ctb / P->sw : ctb) + t->x;
       const int y0 = cy * (cIdx ? ctb / P->sh : ctb) + t->y;
-      int border_mem[4 * 32 + 1];
-      int* border = border_mem + 2 * 32;
-      build_border(P, t, cIdx, x0, y0, nT, bd, border);
-      if (cIdx == 0) filter_border(border, nT, t->pred_mode, (H->flags & HM_PIC_STRONG_INTRA_SMOOTHING) != 0, H->bit_depth_y);
       uint16_t* dst = P->pl[cIdx] + x0 + (size_t)y0 * P->w[cIdx];
-      predict(dst, P->w[cIdx], nT, log2, cIdx, t->pred_mode, border, bd);
-      if (t->info & HM_TU_CBF) residual_add(dst, P->w[cIdx], nT, log2, cIdx, t, P->coeffs + t->coeff_first, bd, P->scaling);
+      const int mode = t->pred_mode & HM_TU_MODE_MASK;
+      if (t->pred_mode & HM_TU_MODE_PCM) { /* pcm_sample: the samples themselves (slice.cc:4462-4504) */
+        const hm_coeff* cf = P->coeffs + t->coeff_first;
+        for (int i = 0; i < t->n_coeff; i++) dst[(cf[i].pos & (nT - 1)) + (size_t)(cf[i].pos >> log2) * P->w[cIdx]] = (uint16_t)cf[i].value;
+      }
+      else {
+        int border_mem[4 * 32 + 1];
+        int* border = border_mem + 2 * 32;
+        build_border(P, t, cIdx, x0, y0, nT, bd, border);
+        if (cIdx == 0) filter_border(border, nT, mode, (H->flags & HM_PIC_STRONG_INTRA_SMOOTHING) != 0, H->bit_depth_y);
+        predict(dst, P->w[cIdx], nT, log2, cIdx, mode, border, bd);
+        if ((t->info & HM_TU_CBF) && (t->pred_mode & HM_TU_MODE_BYPASS)) { /* transform.cc:431-449: residual = levels */
+          const hm_coeff* cf = P->coeffs + t->coeff_first;
+          const int maxv = (1 << bd) - 1;
+          for (int i = 0; i < t->n_coeff; i++) {
+            uint16_t* px = &dst[(cf[i].pos & (nT - 1)) + (size_t)(cf[i].pos >> log2) * P->w[cIdx]];
+            *px = (uint16_t)clip3(0, maxv, *px + cf[i].value);
+          }
+        }
+        else if (t->info & HM_TU_CBF) residual_add(dst, P->w[cIdx], nT, log2, cIdx, t, P->coeffs + t->coeff_first, bd, P->scaling);
+      }
       if (cIdx == 0) {
         /* deblocking metadata: transform-block edges (deblock.cc:31-62) and QpY map */
         const int left_ok = t->x > 0 ? 1 : (c->flags & HM_CTB_DEBLOCK_LEFT) != 0;
@@ -313,6 +328,8 @@ static void reconstruct(pic_t* P)
             uint8_t e = 0;
             if (i == 0 && left_ok && en) e |= 1;
             if (j == 0 && top_ok && en) e |= 2;
+            if (t->pred_mode & HM_TU_MODE_PCM) e |= 4;    /* pcm_flag of the coding unit */
+            if (t->pred_mode & HM_TU_MODE_BYPASS) e |= 8; /* cu_transquant_bypass_flag */
             P->edge[bx + (size_t)by * P->w4] = e;
             P->qpy[bx + (size_t)by * P->w4] = t->qpy;
           }
@@ -340,8 +357,15 @@ static const hm_slice* slice_at(const pic_t* P, int x, int y)
   return &P->slices[P->ctbs[ci].slice_idx];
 }
 
-static void filter_luma_segment(uint16_t* pix, int xs, int ys, int beta, const int tc2[2], int bit_depth)
-{ /* xs: step across the edge, ys: step along the edge */
+/* bit 2: PCM coding unit, bit 3: transquant-bypass coding unit at luma position (x, y); 0 outside the picture */
+static inline int blk_flags(const pic_t* P, int x, int y)
+{
+  if (x < 0 || y < 0 || (x >> 2) >= P->w4 || (y >> 2) >= P->h4) return 0;
+  return P->edge[(x >> 2) + (size_t)(y >> 2) * P->w4];
+}
+
+static void filter_luma_segment(uint16_t* pix, int xs, int ys, int beta, const int tc2[2], int bit_depth, const int mod_p[2], const int mod_q[2])
+{ /* xs: step across the edge, ys: step along the edge; mod_p / mod_q: which side of each half may be modified */
   const int maxv = (1 << bit_depth) - 1;
 #define PX(i, k) pix[(i) * xs + (k) * ys]
   for (int j = 0; j < 2; j++) {
@@ -358,12 +382,16 @@ static void filter_luma_segment(uint16_t* pix, int xs, int ys, int beta, const i
       const int t2 = tc << 1;
       for (int d = 0; d < 4; d++) {
         const int p3 = B(-4, d), p2 = B(-3, d), p1 = B(-2, d), p0 = B(-1, d), q0 = B(0, d), q1 = B(1, d), q2 = B(2, d), q3 = B(3, d);
-        B(-1, d) = (uint16_t)(p0 + clip3(-t2, t2, ((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3) - p0));
-        B(-2, d) = (uint16_t)(p1 + clip3(-t2, t2, ((p2 + p1 + p0 + q0 + 2) >> 2) - p1));
-        B(-3, d) = (uint16_t)(p2 + clip3(-t2, t2, ((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3) - p2));
-        B(0, d) = (uint16_t)(q0 + clip3(-t2, t2, ((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3) - q0));
-        B(1, d) = (uint16_t)(q1 + clip3(-t2, t2, ((p0 + q0 + q1 + q2 + 2) >> 2) - q1));
-        B(2, d) = (uint16_t)(q2 + clip3(-t2, t2, ((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3) - q2));
+        if (mod_p[j]) {
+          B(-1, d) = (uint16_t)(p0 + clip3(-t2, t2, ((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3) - p0));
+          B(-2, d) = (uint16_t)(p1 + clip3(-t2, t2, ((p2 + p1 + p0 + q0 + 2) >> 2) - p1));
+          B(-3, d) = (uint16_t)(p2 + clip3(-t2, t2, ((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3) - p2));
+        }
+        if (mod_q[j]) {
+          B(0, d) = (uint16_t)(q0 + clip3(-t2, t2, ((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3) - q0));
+          B(1, d) = (uint16_t)(q1 + clip3(-t2, t2, ((p0 + q0 + q1 + q2 + 2) >> 2) - q1));
+          B(2, d) = (uint16_t)(q2 + clip3(-t2, t2, ((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3) - q2));
+        }
       }
     }
     else {
@@ -376,10 +404,10 @@ static void filter_luma_segment(uint16_t* pix, int xs, int ys, int beta, const i
         int delta0 = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4;
         if (iabs(delta0) < 10 * tc) {
           delta0 = clip3(-tc, tc, delta0);
-          B(-1, d) = (uint16_t)clip3(0, maxv, p0 + delta0);
-          B(0, d) = (uint16_t)clip3(0, maxv, q0 - delta0);
-          if (nd_p > 1) B(-2, d) = (uint16_t)clip3(0, maxv, p1 + clip3(-tc_2, tc_2, (((p2 + p0 + 1) >> 1) - p1 + delta0) >> 1));
-          if (nd_q > 1) B(1, d) = (uint16_t)clip3(0, maxv, q1 + clip3(-tc_2, tc_2, (((q2 + q0 + 1) >> 1) - q1 - delta0) >> 1));
+          if (mod_p[j]) B(-1, d) = (uint16_t)clip3(0, maxv, p0 + delta0);
+          if (mod_q[j]) B(0, d) = (uint16_t)clip3(0, maxv, q0 - delta0);
+          if (mod_p[j] && nd_p > 1) B(-2, d) = (uint16_t)clip3(0, maxv, p1 + clip3(-tc_2, tc_2, (((p2 + p0 + 1) >> 1) - p1 + delta0) >> 1));
+          if (mod_q[j] && nd_q > 1) B(1, d) = (uint16_t)clip3(0, maxv, q1 + clip3(-tc_2, tc_2, (((q2 + q0 + 1) >> 1) - q1 - delta0) >> 1));
         }
       }
     }
@@ -407,7 +435,26 @@ static void deblock_luma(pic_t* P, int vertical)
       tc[0] = bs0 ? kTc[clip3(0, 53, qPL + 2 * (bs0 - 1) + sl->tc_offset_div2 * 2)] * (1 << (bd - 8)) : 0;
       tc[1] = bs1 ? kTc[clip3(0, 53, qPL + 2 * (bs1 - 1) + sl->tc_offset_div2 * 2)] * (1 << (bd - 8)) : 0;
       uint16_t* ptr = P->pl[0] + xD + (size_t)yD * stride;
-      filter_luma_segment(ptr, vertical ? 1 : stride, vertical ? stride : 1, beta, tc, bd);
+      int mod_p[2] = {1, 1}, mod_q[2] = {1, 1};
+      if (H->flags & HM_PIC_PCMF) {
+        /* The reference's "pcmf" branch (deblock.cc:755-786, fallback-postfilter.h:60-125) as its SIMD build behaves:
+           per 4-line half a flag per side says "neither PCM nor transquant-bypass" (the PCM test ignores
+           pcm_loop_filter_disable_flag here).  All four set: 8-bit pictures take the SSE filter (filters normally),
+           16-bit pictures the scalar filter, which reads the flags as "do not modify" -> nothing changes.  Otherwise the
+           scalar filter runs and, reading the flags with that polarity, modifies exactly the PCM / bypass sides. */
+        int keep_p[2], keep_q[2];
+        for (int j = 0; j < 2; j++) {
+          const int xq = vertical ? xD : xD + 4 * j, yq = vertical ? yD + 4 * j : yD;
+          keep_q[j] = !(blk_flags(P, xq, yq) & 12);
+          keep_p[j] = !(blk_flags(P, vertical ? xq - 1 : xq, vertical ? yq : yq - 1) & 12);
+        }
+        const int all = keep_p[0] && keep_p[1] && keep_q[0] && keep_q[1];
+        for (int j = 0; j < 2; j++) {
+          mod_p[j] = all ? bd <= 8 : !keep_p[j];
+          mod_q[j] = all ? bd <= 8 : !keep_q[j];
+        }
+      }
+      filter_luma_segment(ptr, vertical ? 1 : stride, vertical ? stride : 1, beta, tc, bd, mod_p, mod_q);
     }
 }
 
@@ -452,14 +499,27 @@ static void deblock_chroma(pic_t* P, int vertical)
         const int stride = P->w[cp + 1];
         uint16_t* ptr = P->pl[cp + 1] + xDi + (size_t)yDi * stride;
         const int xs = vertical ? 1 : stride, ys = vertical ? stride : 1;
+        int mod_p[2] = {1, 1}, mod_q[2] = {1, 1};
+        if (H->flags & HM_PIC_PCMF) {
+          /* deblock.cc:1724-1756 + fallback-postfilter.h:138-180: a side is filtered unless it is transquant-bypass or
+             (pcm_loop_filter_disable_flag and PCM); for vertical edges the reference tests the P flag for both sides */
+          const int pcm_mask = (H->pcm_loop_filter_disabled ? 4 : 0) | 8;
+          for (int j = 0; j < 2; j++) {
+            const int xq = vertical ? lx : lx + 4 * sw * j, yq = vertical ? ly + 4 * sh * j : ly;
+            const int fq = !(blk_flags(P, xq, yq) & pcm_mask);
+            const int fp = !(blk_flags(P, vertical ? xq - 1 : xq, vertical ? yq : yq - 1) & pcm_mask);
+            mod_p[j] = fp;
+            mod_q[j] = vertical ? fp : fq;
+          }
+        }
         for (int k = 0; k < 8; k++) {
           const int t = tc[k >> 2];
           if (t == 0) continue; /* delta clipped to [-0,0]: samples unchanged (and possibly outside the picture) */
           uint16_t* b = ptr + k * ys;
           const int p1 = b[-2 * xs], p0 = b[-xs], q0 = b[0], q1 = b[xs];
           const int delta = clip3(-t, t, ((((q0 - p0) * 4) + p1 - q1 + 4) >> 3));
-          b[-xs] = (uint16_t)clip3(0, maxv, p0 + delta);
-          b[0] = (uint16_t)clip3(0, maxv, q0 - delta);
+          if (mod_p[k >> 2]) b[-xs] = (uint16_t)clip3(0, maxv, p0 + delta);
+          if (mod_q[k >> 2]) b[0] = (uint16_t)clip3(0, maxv, q0 - delta);
         }
       }
     }
@@ -484,12 +544,17 @@ static void apply_sao(pic_t* P, uint16_t* const src[3])
         if (s->type == 0) continue;
         const int xC = cx * nSW, yC = cy * nSH;
         const int cw = imin(nSW, W - xC), ch = imin(nSH, Hh - yC);
+        /* samples of transquant-bypass units and, with pcm_loop_filter_disable_flag, of PCM units keep their value
+           (sao.cc:356-363, 452-456) */
+        const int keep_mask = (H->flags & HM_PIC_LOSSLESS_CUS) ? ((H->pcm_loop_filter_disabled ? 4 : 0) | 8) : 0;
+        const int lsx = cIdx ? P->sw >> 1 : 0, lsy = cIdx ? P->sh >> 1 : 0; /* sample -> luma position (shifts) */
         if (s->type == 2) {
           const int off[5] = {s->offset[0], s->offset[1], 0, s->offset[2], s->offset[3]};
           const int cl = s->eo_class;
           for (int j = 0; j < ch; j++)
             for (int i = 0; i < cw; i++) {
               const int xx = xC + i, yy = yC + j;
+              if (keep_mask && (blk_flags(P, xx << lsx, yy << lsy) & keep_mask)) continue;
               int ok = 1;
               for (int k = 0; k < 2 && ok; k++) {
                 const int xS = xx + hPos[cl][k], yS = yy + vPos[cl][k];
@@ -517,6 +582,7 @@ static void apply_sao(pic_t* P, uint16_t* const src[3])
           for (int k = 0; k < 4; k++) table[(k + s->band_position) & 31] = k + 1;
           for (int j = 0; j < ch; j++)
             for (int i = 0; i < cw; i++) {
+              if (keep_mask && (blk_flags(P, (xC + i) << lsx, (yC + j) << lsy) & keep_mask)) continue;
               const int v = src[cIdx][(xC + i) + (size_t)(yC + j) * W];
               const int bi = table[v >> shift];
               if (bi > 0) P->pl[cIdx][(xC + i) + (size_t)(yC + j) * W] = (uint16_t)clip3(0, maxv, v + s->offset[bi - 1]);

@@ -42,7 +42,25 @@ CASES = {
     "sl_pps_422_10": dict(seed=5100003, width=128, height=128, log2_ctb=5, chroma_format=2, bit_depth=10, qp=34, scaling_list=3),
     "sl_sps_ctb64_lowqp": dict(seed=5100004, width=192, height=136, log2_ctb=6, qp=8, density=90, scaling_list=2),
     "sl_sps_12bit_highqp": dict(seed=5100005, width=64, height=64, log2_ctb=4, bit_depth=12, qp=50, scaling_list=2),
+    # PCM and transquant-bypass coding units (slice.cc:4462-4536, transform.cc:431-449) and the reference's "pcmf"
+    # loop-filter branches (deblock.cc:723-786, 1635-1756; sao.cc:356-363)
+    "pcm_nofilter": dict(seed=5200001, width=128, height=96, log2_ctb=5, qp=30, pcm=300, pcm_bits_y=7, pcm_bits_c=5, pcm_loop_filter_disable=1),
+    "pcm_filtered": dict(seed=5200002, width=128, height=96, log2_ctb=5, qp=30, pcm=300, pcm_bits_y=8, pcm_bits_c=6, pcm_loop_filter_disable=0),
+    "pcm_422_10": dict(seed=5200003, width=128, height=64, log2_ctb=5, chroma_format=2, bit_depth=10, qp=32, pcm=250, pcm_bits_y=10, pcm_bits_c=8,
+                       pcm_loop_filter_disable=1, pcm_log2_max=4),
+    "tq_bypass": dict(seed=5200004, width=128, height=96, log2_ctb=5, qp=28, tq_bypass=400),
+    "lossless_all": dict(seed=5200005, width=96, height=64, log2_ctb=4, bit_depth=10, qp=22, tq_bypass=1000),
+    "pcm_bypass_mono12": dict(seed=5200006, width=96, height=72, log2_ctb=5, chroma_format=0, bit_depth=12, qp=36, pcm=200, pcm_bits_y=11,
+                              pcm_bits_c=12, pcm_loop_filter_disable=1, tq_bypass=250),
+    "pcm_bypass_sl_wpp": dict(seed=5200007, width=192, height=128, log2_ctb=6, bit_depth=10, qp=29, wpp=1, scaling_list=2, pcm=200,
+                              pcm_bits_y=9, pcm_bits_c=9, pcm_loop_filter_disable=0, tq_bypass=200),
 }
+
+# 8-bit pictures in which the reference takes its "pcmf" deblocking branch: its SIMD build (the configuration of
+# oracle/_ref, and what x86 / ARM users run) filters luma edges between ordinary units with the SSE / NEON kernel, its
+# scalar build leaves them unfiltered (fallback-postfilter.h:85-124 reads the flags with the opposite polarity).  The
+# fixtures and the product follow the SIMD build; tools/make_fixtures.py does not require the scalar build to agree.
+SIMD_BUILD_ONLY = {"pcm_nofilter", "tq_bypass"}
 
 
 def stream(name):
@@ -50,3 +68,20 @@ def stream(name):
     kw = dict(CASES[name])
     seed = kw.pop("seed")
     return synthutil.picture(seed, **kw)
+
+
+def rare_syntax_sweep(n, first_seed=2000):
+    """(seed, parameters) of a seeded sweep over the rarely used syntax: PCM and transquant-bypass units with every
+    loop-filter flag combination, scaling lists, WPP, 4:0:0 / 4:2:0 / 4:2:2, 8-12 bit, every CTB size."""
+    out = []
+    for seed in range(first_seed, first_seed + n):
+        kw = dict(width=[64, 96, 72, 128][seed % 4], height=[64, 40, 72][seed % 3], log2_ctb=[5, 4, 6, 5][seed % 4] if seed % 5 else 5,
+                  chroma_format=[1, 2, 1, 0][seed % 4], bit_depth=[8, 10, 8, 12, 9][seed % 5], pcm=[200, 0, 300][seed % 3],
+                  tq_bypass=[0, 300, 150, 1][seed % 4], pcm_loop_filter_disable=seed % 2, wpp=int(seed % 7 == 0), cu_qp_delta=1,
+                  scaling_list=[0, 0, 2][seed % 3])
+        if kw["log2_ctb"] == 4 and kw["bit_depth"] == 8 and kw["chroma_format"]:
+            kw["log2_ctb"] = 5  # 8-bit SAO on 8-sample-wide chroma CTBs: the reference's SIMD quirk Q9, not a corpus subject
+        kw["pcm_bits_y"] = max(1, kw["bit_depth"] - seed % 3)
+        kw["pcm_bits_c"] = max(1, kw["bit_depth"] - seed % 4)
+        out.append((seed, kw))
+    return out

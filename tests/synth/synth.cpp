@@ -158,6 +158,11 @@ struct SynthParams {
   int32_t density;             // residual density knob 0..100 (percent scale of cbf/sig probabilities)
   int32_t wpp;                 // entropy_coding_sync_enabled_flag
   int32_t scaling_list;        // 0 off, 1 enabled with the default lists, 2 lists in the SPS, 3 lists in the PPS (SPS: default)
+  int32_t pcm;                 // 0: pcm_enabled_flag = 0; else per-mille chance of pcm_flag = 1 where it may be coded
+  int32_t pcm_bits_y, pcm_bits_c; // PCM sample bit depths (<= bit_depth)
+  int32_t pcm_log2_min, pcm_log2_max; // PCM coding block sizes
+  int32_t pcm_loop_filter_disable;
+  int32_t tq_bypass;           // 0: transquant_bypass_enabled_flag = 0; else per-mille chance of cu_transquant_bypass_flag
 };
 
 // entropy-coder adaptor for SliceWalker: chooses every bin, encodes it, returns it
@@ -185,6 +190,26 @@ class EncoderEC {
   }
   ContextSet& contexts() { return cs_; }
   void start_substream() { enc.reset(); }
+  // pcm_flag = 1: the arithmetic coder is flushed (EncodeFlush ends with the bit 1) and zero bits pad to the byte
+  // boundary = pcm_alignment_zero_bits; the raw samples follow and the coder starts afresh behind them (9.3.2.5)
+  int pcm_flag()
+  {
+    const int b = rng_.chance(P.pcm);
+    enc.terminate(b);
+    return b;
+  }
+  void pcm_begin() {}
+  uint32_t pcm_bits(int n)
+  {
+    const uint32_t v = (uint32_t)(rng_.next() >> 11) & ((1u << n) - 1);
+    for (int i = n - 1; i >= 0; i--) enc.wbit((v >> i) & 1);
+    return v;
+  }
+  void pcm_end()
+  {
+    while (enc.nbits & 7) enc.wbit(0);
+    enc.reset();
+  }
 
   CabacEncoder enc;
   std::vector<size_t> substream_ends;
@@ -198,7 +223,7 @@ class EncoderEC {
       case K_SAO_TYPE: return idx == 0 ? rng_.chance(700) : rng_.chance(500);
       case K_SAO_OFFSET: return rng_.chance(450);
       case K_SPLIT_CU: return rng_.chance(idx >= 6 ? 900 : (idx == 5 ? 650 : 450));
-      case K_TQ_BYPASS: return 0;
+      case K_TQ_BYPASS: return rng_.chance(P.tq_bypass);
       case K_PART_MODE: return idx == 1 ? 1 : rng_.chance(600);
       case K_PREV_INTRA: return rng_.chance(550);
       case K_SPLIT_TF: return rng_.chance(idx >= 5 ? 550 : (idx == 4 ? 400 : 300));
@@ -320,7 +345,12 @@ __attribute__((visibility("default"))) int hm_synth_picture(const SynthParams* p
     }
     w.flag(0);                 // amp
     w.flag(p.sao != 0);
-    w.flag(0);                 // pcm
+    w.flag(p.pcm != 0);        // pcm_enabled_flag
+    if (p.pcm) {
+      w.put(p.pcm_bits_y - 1, 4); w.put(p.pcm_bits_c - 1, 4);
+      w.ue(p.pcm_log2_min - 3); w.ue(p.pcm_log2_max - p.pcm_log2_min);
+      w.flag(p.pcm_loop_filter_disable != 0);
+    }
     w.ue(0);                   // num_short_term_ref_pic_sets
     w.flag(0);                 // long_term_ref_pics_present
     w.flag(0);                 // temporal mvp
@@ -359,7 +389,7 @@ __attribute__((visibility("default"))) int hm_synth_picture(const SynthParams* p
     w.se(p.cb_qp_offset); w.se(p.cr_qp_offset);
     w.flag(0);                 // slice_chroma_qp_offsets_present
     w.flag(0); w.flag(0);      // weighted pred
-    w.flag(0);                 // transquant_bypass
+    w.flag(p.tq_bypass != 0);  // transquant_bypass_enabled_flag
     w.flag(0);                 // tiles
     w.flag(p.wpp != 0);        // entropy_coding_sync
     w.flag(1);                 // pps_loop_filter_across_slices_enabled

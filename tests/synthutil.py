@@ -12,13 +12,15 @@ class SynthParams(C.Structure):
         "width", "height", "chroma_format", "bit_depth", "log2_ctb", "log2_min_cb", "log2_min_tb", "log2_max_tb",
         "max_th_depth_intra", "qp", "cu_qp_delta", "diff_cu_qp_delta_depth", "sao", "deblock_disable",
         "sign_hiding", "transform_skip", "strong_intra", "cb_qp_offset", "cr_qp_offset",
-        "beta_offset_div2", "tc_offset_div2", "vui", "full_range", "matrix", "primaries", "density", "wpp", "scaling_list")]
+        "beta_offset_div2", "tc_offset_div2", "vui", "full_range", "matrix", "primaries", "density", "wpp", "scaling_list", "pcm", "pcm_bits_y", "pcm_bits_c",
+        "pcm_log2_min", "pcm_log2_max", "pcm_loop_filter_disable", "tq_bypass")]
 
 
 DEFAULTS = dict(width=64, height=64, chroma_format=1, bit_depth=8, log2_ctb=5, log2_min_cb=3, log2_min_tb=2,
                 log2_max_tb=5, max_th_depth_intra=2, qp=27, cu_qp_delta=1, diff_cu_qp_delta_depth=1, sao=1,
                 deblock_disable=0, sign_hiding=1, transform_skip=1, strong_intra=1, cb_qp_offset=0, cr_qp_offset=0,
-                beta_offset_div2=0, tc_offset_div2=0, vui=1, full_range=1, matrix=6, primaries=1, density=60, wpp=0, scaling_list=0)
+                beta_offset_div2=0, tc_offset_div2=0, vui=1, full_range=1, matrix=6, primaries=1, density=60, wpp=0, scaling_list=0,
+                pcm=0, pcm_bits_y=8, pcm_bits_c=8, pcm_log2_min=3, pcm_log2_max=5, pcm_loop_filter_disable=0, tq_bypass=0)
 
 _lib = None
 
@@ -39,6 +41,8 @@ def picture(seed, **kw):
     cfg = dict(DEFAULTS)
     cfg.update(kw)
     cfg["log2_max_tb"] = min(cfg["log2_max_tb"], cfg["log2_ctb"], 5)
+    cfg["pcm_log2_max"] = min(cfg["pcm_log2_max"], cfg["log2_ctb"], 5)
+    cfg["pcm_log2_min"] = min(max(cfg["pcm_log2_min"], cfg["log2_min_cb"]), cfg["pcm_log2_max"])
     p = SynthParams(**cfg)
     out = C.POINTER(C.c_uint8)()
     n = C.c_size_t()

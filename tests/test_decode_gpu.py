@@ -89,3 +89,19 @@ def test_batch_of_mixed_pictures(pkg):
         exp, _ = orc.oracle_decode(blob, 3)
         for c in range(3):
             np.testing.assert_array_equal(g[c], exp[c])
+
+
+def test_rare_syntax_sweep(pkg):
+    """PCM / transquant-bypass / scaling-list streams in one batch (rare-syntax kernel variants next to the common ones):
+    HIP == oracle at every stage"""
+    import synthutil
+    cases = corpus.rare_syntax_sweep(48) + [(9000 + i, dict(width=64, height=64)) for i in range(4)]  # + ordinary pictures
+    blobs = [pkg.capi.parse_hevc(synthutil.picture(seed, **kw)) for seed, kw in cases]
+    for bits in (0, 1, 3):
+        got = gpudecode.decode_pictures(pkg, blobs, bits)
+        for (seed, kw), blob, g in zip(cases, blobs, got):
+            exp, _ = orc.oracle_decode(blob, bits)
+            assert len(g) == len(exp)
+            for c in range(len(exp)):
+                bad = np.argwhere(g[c] != exp[c])
+                assert bad.size == 0, f"seed {seed} {kw} stages {bits} plane {c}: {len(bad)} mismatches, first (y,x)={bad[0].tolist()}"

@@ -71,3 +71,18 @@ def test_synth_corpus_matches_reference_fingerprints(hm, name):
     assert info["full_range"] == SYNTH[name]["info"]["full_range"]
     assert info["matrix"] == SYNTH[name]["info"]["matrix"]
     assert info["bit_depth"] == SYNTH[name]["info"]["bit_depth"]
+
+
+def test_rare_syntax_sweep_matches_reference_decoder_live(hm):
+    """PCM / transquant-bypass / scaling-list streams: host parser + oracle == libde265 at every stage (needs oracle/_ref)"""
+    if not orc.have_ref():
+        pytest.skip("oracle/_ref not built")
+    import synthutil
+    for seed, kw in corpus.rare_syntax_sweep(40):
+        data = synthutil.picture(seed, **kw)
+        blob = hevcutil.parse(hm, data)
+        for stage, rf, bits in (("recon", orc.REF_F_NO_DEBLOCK | orc.REF_F_NO_SAO, 0), ("deblock", orc.REF_F_NO_SAO, 1), ("full", 0, 3)):
+            ref, _ = orc.ref_decode(data, rf)
+            mine, _ = orc.oracle_decode(blob, bits)
+            for c in range(len(ref)):
+                assert np.array_equal(mine[c], ref[c]), f"seed {seed} {kw}: stage {stage} plane {c}"

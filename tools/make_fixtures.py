@@ -77,8 +77,9 @@ def main():
         entry = {"bytes": len(data), "stream_fnv": f"{orc.load().orc_fnv1a64(data, len(data), 0):016x}"}
         for stage, flags in (("recon", orc.REF_F_NO_DEBLOCK | orc.REF_F_NO_SAO), ("deblock", orc.REF_F_NO_SAO), ("full", 0)):
             planes, info = orc.ref_decode(data, flags)
-            scalar, _ = orc.ref_decode(data, flags | orc.REF_F_SCALAR)
-            assert all((a == b).all() for a, b in zip(planes, scalar)), f"{name}: reference SIMD != scalar"
+            if name not in corpus.SIMD_BUILD_ONLY:
+                scalar, _ = orc.ref_decode(data, flags | orc.REF_F_SCALAR)
+                assert all((a == b).all() for a, b in zip(planes, scalar)), f"{name}: reference SIMD != scalar"
             entry[stage] = fingerprint(planes)
         entry["width"], entry["height"] = int(planes[0].shape[1]), int(planes[0].shape[0])
         entry["info"] = info
