@@ -124,7 +124,7 @@ int hm_batch_add(hm_batch* b, const uint8_t* blob, size_t size, const hm_tile_de
   Item it;
   std::memcpy(&it.hdr, blob, sizeof(hm_pic));
   if (it.hdr.magic != HM_STREAM_MAGIC || it.hdr.total_bytes > size) return hm_fail(HM_ERR_INVALID_ARG, "not a command stream");
-  if (it.hdr.chroma_format > 2) return hm_fail(HM_ERR_UNSUPPORTED, "chroma format %d", it.hdr.chroma_format);
+  if (it.hdr.chroma_format > 3) return hm_fail(HM_ERR_UNSUPPORTED, "chroma format %d", it.hdr.chroma_format);
   for (int c = 0; c < (it.hdr.chroma_format == 0 ? 1 : 3); c++) // a monochrome picture only has a luma destination
     if (!dest->plane[c]) return hm_fail(HM_ERR_INVALID_ARG, "null destination plane");
   // (a stream of a previous, still in-flight upload is never overwritten: the arena only grows until hm_batch_clear)
@@ -183,7 +183,8 @@ int hm_batch_upload(hm_batch* b, void* stream)
     work_off[i] = work_bytes;
     const int bps = h.bit_depth_y > 8 ? 2 : 1;
     const int sh = h.chroma_format == 1 ? 2 : 1;
-    const size_t py = align_up((size_t)h.width * bps, 64), pc = align_up((size_t)(h.width / 2) * bps, 64);
+    const int swc = h.chroma_format == 3 ? 1 : 2;
+    const size_t py = align_up((size_t)h.width * bps, 64), pc = align_up((size_t)(h.width / swc) * bps, 64);
     const size_t w4 = (h.width + 3) >> 2, h4 = (h.height + 3) >> 2;
     work_bytes += align_up(py * h.height, 256) + 2 * align_up(pc * (h.height / sh), 256) + 2 * align_up(w4 * h4, 256);
     b->total_pixels += (size_t)h.width * h.height;
@@ -207,7 +208,8 @@ int hm_batch_upload(hm_batch* b, void* stream)
       std::memset(&d, 0, sizeof(d));
       const int bps = h.bit_depth_y > 8 ? 2 : 1;
       const int sh = h.chroma_format == 1 ? 2 : 1;
-      const size_t py = align_up((size_t)h.width * bps, 64), pc = align_up((size_t)(h.width / 2) * bps, 64);
+      const int sw = h.chroma_format == 3 ? 1 : 2;
+      const size_t py = align_up((size_t)h.width * bps, 64), pc = align_up((size_t)(h.width / sw) * bps, 64);
       const size_t w4 = (h.width + 3) >> 2, h4 = (h.height + 3) >> 2;
       uint8_t* wp = (uint8_t*)b->d_work.p + work_off[idx];
       d.blob = (const uint8_t*)b->d_blobs.p + blob_off[idx];
@@ -229,7 +231,6 @@ int hm_batch_upload(hm_batch* b, void* stream)
       d.ctbs = (const hm_ctb*)(d.blob + h.off_ctbs);
       // destination = tile paste geometry of context.cc:2457-2502
       const hm_tile_dest& t = it.dest;
-      const int sw = 2;
       for (int p = 0; p < (h.chroma_format == 0 ? 1 : 3); p++) { // monochrome: copy_w/h of the chroma planes stay 0
         int chan_w = t.canvas_width, chan_h = t.canvas_height, cx0 = t.x0, cy0 = t.y0;
         // the decoder plugin hands libheif the conformance-window crop of the coded picture
@@ -238,7 +239,7 @@ int hm_batch_upload(hm_batch* b, void* stream)
         d.src_x[p] = h.crop_left; d.src_y[p] = h.crop_top;
         if (pw <= 0 || ph <= 0) return hm_fail(HM_ERR_BITSTREAM, "empty conformance window");
         if (p > 0) {
-          chan_w = (t.canvas_width + 1) / 2; cx0 = (t.x0 + 1) / 2;
+          if (h.chroma_format != 3) { chan_w = (t.canvas_width + 1) / 2; cx0 = (t.x0 + 1) / 2; }
           if (h.chroma_format == 1) { chan_h = (t.canvas_height + 1) / 2; cy0 = (t.y0 + 1) / 2; }
           pw /= sw; ph /= sh;
           d.src_x[p] /= sw; d.src_y[p] /= sh;

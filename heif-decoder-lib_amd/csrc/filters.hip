@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256, sizeof(Pix) == 1 ? 8 : 6) void k_deblock(const
   }
   // ---- chroma segments (deblock.cc:1608-1772) ----
   if (dp.chroma_format == 0) return;
-  const int sw = 2, sh = dp.chroma_format == 1 ? 2 : 1;
+  const int sw = (PCMF && dp.chroma_format == 3) ? 1 : 2, sh = dp.chroma_format == 1 ? 2 : 1; // 4:4:4: rare-syntax classes only
   const int xIncr = 2 * sw, yIncr = 2 * sh;
   const int cwn = (dp.w4 + xIncr - 1) / xIncr, chn = (dp.h4 + yIncr - 1) / yIncr;
   int ci = item - nL;
@@ -315,7 +315,7 @@ __device__ __forceinline__ int sao_sample(const hm_dev_pic& dp, const PicView& v
   const int maxv = (1 << bd) - 1;
   int val = reinterpret_cast<const Pix*>(plane + (size_t)yy * pitch)[xx];
   if (keep_mask) { // lossless coding units keep their samples (rare-syntax variant only)
-    const int lsx = c ? 1 : 0, lsy = c ? (dp.chroma_format == 1 ? 1 : 0) : 0;
+    const int lsx = (c && dp.chroma_format != 3) ? 1 : 0, lsy = c ? (dp.chroma_format == 1 ? 1 : 0) : 0;
     if (lossless_bits(dp, xx << lsx, yy << lsy) & keep_mask) return val;
   }
   const int cx = xx >> l2w, cy = yy >> l2h;
@@ -500,8 +500,9 @@ __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict_
   if (yd0 >= chh || x8 >= cw) return;
   const PicView v = view(dp);
   const int sh = c ? (dp.chroma_format == 1 ? 2 : 1) : 1;
-  const int W = dp.width >> (c ? 1 : 0), Hh = dp.height / sh;
-  const int l2w = dp.log2_ctb - (c ? 1 : 0), l2h = dp.log2_ctb - (sh == 2 ? 1 : 0); // CTB size of this plane (log2)
+  const int sxs = (c && !(RARE && dp.chroma_format == 3)) ? 1 : 0; // horizontal chroma shift (4:4:4: rare-syntax classes only)
+  const int W = dp.width >> sxs, Hh = dp.height / sh;
+  const int l2w = dp.log2_ctb - sxs, l2h = dp.log2_ctb - (sh == 2 ? 1 : 0); // CTB size of this plane (log2)
   const int bd = dp.bit_depth;
   const uint32_t maxv2 = ((1u << bd) - 1) * 0x10001u;
   const uint8_t* plane = dp.plane[c];
@@ -554,10 +555,10 @@ __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict_
       if (RARE && type != 0 && (dp.flags & HM_PIC_LOSSLESS_CUS)) {
         // a pair of samples lies in one 4x4 luma block (chroma: 2 samples = 4 luma columns)
         const int mask = (dp.pcm_loop_filter_disabled ? 4 : 0) | 8;
-        const int lsx = c ? 1 : 0, lsy = c ? sh - 1 : 0;
+        const int lsy = c ? sh - 1 : 0;
 #pragma unroll
         for (int j = 0; j < 4; j++)
-          if (lossless_bits(dp, (xs + 2 * j) << lsx, yy << lsy) & mask) res[r][j] = cur.p[j];
+          if (lossless_bits(dp, (xs + 2 * j) << sxs, yy << lsy) & mask) res[r][j] = cur.p[j];
       }
     }
   }
@@ -630,8 +631,8 @@ extern "C" int hm_launch_deblock(const hm_dev_pic* d_pics, int n_pics, int max_w
 {
   if (n_pics <= 0) return HM_OK;
   const int lw = (max_w4 + 1) >> 1, lh = (max_h4 + 1) >> 1;
-  const int sh = chroma_format == 1 ? 2 : 1;
-  const int cwn = (max_w4 + 3) / 4, chn = (max_h4 + 2 * sh - 1) / (2 * sh);
+  const int sw = chroma_format == 3 ? 1 : 2, sh = chroma_format == 1 ? 2 : 1;
+  const int cwn = (max_w4 + 2 * sw - 1) / (2 * sw), chn = (max_h4 + 2 * sh - 1) / (2 * sh);
   const long items = (long)lw * lh + 2L * cwn * chn;
   const int blocks = (int)((items + 255) / 256);
   if (bit_depth > 8) rare_syntax ? launch_deblock<uint16_t, true>(d_pics, n_pics, blocks, s) : launch_deblock<uint16_t, false>(d_pics, n_pics, blocks, s);
@@ -645,7 +646,7 @@ extern "C" int hm_launch_sao_paste(const hm_dev_pic* d_pics, int n_pics, int max
   if (n_pics <= 0) return HM_OK;
   // 64 x 16-sample tiles of the three planes (chroma at most as large as luma); one wave per tile, four per block
   const long luma = (long)((max_w + 63) / 64) * ((max_h + 15) / 16);
-  const int cwm = (max_w + 1) / 2;
+  const int cwm = rare_syntax ? max_w : (max_w + 1) / 2; // rare-syntax classes may hold 4:4:4 pictures
   const long chroma = (long)((cwm + 63) / 64) * ((max_h + 15) / 16); // 4:2:2 height bound
   const dim3 grid((int)((luma + 2 * chroma + 3) / 4), n_pics);
   if (bit_depth > 8) {

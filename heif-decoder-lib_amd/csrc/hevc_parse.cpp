@@ -160,8 +160,7 @@ struct Decoder {
   static void check_supported(const SPS& s, const PPS& p)
   {
     if (s.range_ext_any) throw ParseError(HM_ERR_UNSUPPORTED, "range-extension coding tools");
-    if (s.chroma_format_idc == 3 || s.separate_colour_plane)
-      throw ParseError(HM_ERR_UNSUPPORTED, "chroma format (4:0:0, 4:2:0 and 4:2:2 are on the GPU path)");
+    if (s.separate_colour_plane) throw ParseError(HM_ERR_UNSUPPORTED, "separate colour planes");
     if (s.chroma_format_idc != 0 && s.bit_depth_y != s.bit_depth_c) throw ParseError(HM_ERR_UNSUPPORTED, "different luma / chroma bit depth");
     if (s.bit_depth_y > 12) throw ParseError(HM_ERR_UNSUPPORTED, "bit depth above 12");
     if (p.cross_component_prediction || p.chroma_qp_offset_list_enabled)
@@ -252,6 +251,7 @@ struct Decoder {
     if (p.lf_across_tiles) flags |= HM_PIC_LF_ACROSS_TILES;
     if (s.scaling_list_enabled) flags |= HM_PIC_SCALING_LIST;
     if ((s.pcm_enabled && s.pcm_loop_filter_disabled) || p.transquant_bypass_enabled) flags |= HM_PIC_PCMF;
+    if (s.chroma_format_idc == 3) flags |= HM_PIC_444;
     if (pic.uses_pcm || pic.uses_tq_bypass) flags |= HM_PIC_LOSSLESS_CUS;
     h.flags = flags;
     h.colour_primaries = (uint8_t)s.colour_primaries;

@@ -509,8 +509,8 @@ class SliceWalker {
     ec_.pcm_begin();
     emit_pcm_block(x0, y0, log2CbSize, 0, 1 << log2CbSize, 1);
     if (sps_.ChromaArrayType != 0) {
-      const int sw = sps_.SubWidthC, shh = sps_.SubHeightC; // 4:4:4 is refused before the slice data is read
-      const int log2C = log2CbSize - 1, parts = sw == 2 && shh == 1 ? 2 : 1; // 4:2:2: two square halves, top then bottom
+      const int sw = sps_.SubWidthC, shh = sps_.SubHeightC;
+      const int log2C = log2CbSize - (sw >> 1), parts = sw / shh; // 4:2:2: two square halves, top then bottom
       for (int c = 1; c <= 2; c++) emit_pcm_block(x0 / sw, y0 / shh, log2C, c, 1 << log2C, parts);
     }
     ec_.pcm_end();

@@ -403,7 +403,7 @@ int decode_planar(const hm_file* f, uint32_t id, const hm_decode_params* params,
   }
   else { canvas_w = tile_w; canvas_h = tile_h; }
   const int bps = bd > 8 ? 2 : 1;
-  const int cw = (canvas_w + 1) / 2, chh = chroma == 1 ? (canvas_h + 1) / 2 : canvas_h;
+  const int cw = chroma == 3 ? canvas_w : (canvas_w + 1) / 2, chh = chroma == 1 ? (canvas_h + 1) / 2 : canvas_h;
 
   DevPlane (&P)[3] = I.P;
   std::vector<std::unique_ptr<DevMem>>& retired = I.retired;

@@ -254,6 +254,7 @@ constexpr uint64_t filter_mode_mask(int log2)
 // them in place: all lanes read their three neighbours, then all lanes write.
 // Written select-style on purpose (both candidates computed, then chosen): a ternary with arithmetic in
 // its arms becomes an exec-mask branch, i.e. several scalar instructions per lane-level decision.
+constexpr int SMOOTH_CHROMA = 0x10000; // with the picture flags: chroma reference samples are smoothed like luma ones (4:4:4)
 template <typename Pix, int L2>
 __device__ __forceinline__ void make_border(const Blk<Pix>& b, int16_t* bA, int strong, int lane)
 {
@@ -281,13 +282,13 @@ __device__ __forceinline__ void make_border(const Blk<Pix>& b, int16_t* bA, int 
     lanes_loop<N>(lane, [&](int e) { bc[e - 2 * nT] = (int16_t)border_value<Pix, L2>(b, av, e - 2 * nT, noLeftFill, topFill); });
   }
 
-  if (L2 != 2 && b.c == 0 && ((filter_mode_mask(L2) >> b.mode) & 1)) {
+  if (L2 != 2 && (b.c == 0 || (strong & SMOOTH_CHROMA)) && ((filter_mode_mask(L2) >> b.mode) & 1)) { // intrapred.cc:307-311
     WAVE_SYNC();
     // strong (bilinear) smoothing of 32x32 blocks when both edges are nearly linear, else [1 2 1]; the two
     // end samples stay as they are (the bilinear formula and the degenerate [c 2c c] both return them)
     bool bi = false;
     int p0 = 0, pL = 0, pT = 0;
-    if (L2 == 5 && (strong & HM_PIC_STRONG_INTRA_SMOOTHING)) {
+    if (L2 == 5 && (strong & HM_PIC_STRONG_INTRA_SMOOTHING) && (b.c == 0 || !(strong & SMOOTH_CHROMA))) { // luma only (intrapred.h:224-229)
       p0 = bc[0]; pL = bc[-64]; pT = bc[64];
       const int mL = bc[-32], mT = bc[32];
       const int lim = 1 << (b.bd - 5);
@@ -555,7 +556,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
   const int ctb_w = dp.ctb_w, ctb_h = dp.ctb_h;
   const int sh = dp.chroma_format == 1 ? 2 : 1;
   const int bd = sizeof(Pix) == 1 ? 8 : dp.bit_depth; // 8-bit samples <=> bit depth 8 (compile-time constant)
-  constexpr int cw_c = ctb >> 1, P0 = ctb + UPAD, P1 = cw_c + UPAD;
+  // 4:4:4 pictures (always in a rare-syntax class): chroma CTBs as wide as luma ones; a constant in the common variant
+  const bool c444 = RARE && dp.chroma_format == 3;
+  constexpr int P0 = ctb + UPAD;
+  const int cw_c = c444 ? ctb : ctb >> 1, P1 = cw_c + UPAD;
   const int ch_c = ctb / sh; // chroma CTB height
 
   // ---- LDS carve-up: [progress: ctb_h ints][dct 1024 B][tables 256 B][sample lines]
@@ -611,8 +615,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
   Pix* const u1 = reinterpret_cast<Pix*>(lp); lp += (size_t)P1 * ch_c * sizeof(Pix);
   Pix* const u2 = reinterpret_cast<Pix*>(lp); lp += (size_t)P1 * ch_c * sizeof(Pix);
   // the picture flags the blocks look at; without RARE the rare-syntax bits are known to be clear and their paths fold away
-  const int strong = dp.flags & (HM_PIC_STRONG_INTRA_SMOOTHING | (RARE ? HM_PIC_RARE_SYNTAX : 0));
-  const int planeWc = dp.width >> 1, planeHc = dp.height / sh;
+  const int strong = (dp.flags & (HM_PIC_STRONG_INTRA_SMOOTHING | (RARE ? HM_PIC_RARE_SYNTAX : 0))) | (c444 ? SMOOTH_CHROMA : 0);
+  const int planeWc = c444 ? dp.width : dp.width >> 1, planeHc = dp.height / sh;
   // one sample line: [4 pad | luma ctb_w*ctb][4 pad | cb ctb_w*cw_c][4 pad | cr ...]; sample x of a plane at base[x], x >= -1
   const int Wl = ctb_w << log2_ctb, Wc = ctb_w * cw_c;
   const int lo1 = 4 + Wl + 4, lo2 = lo1 + Wc + 4; // offsets (in samples) of cb / cr sample 0
@@ -759,7 +763,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
           // variants is hoisted out of all loops and kept alive for the whole kernel (> 100 spilled SGPRs)
           int ln = lane;
           asm volatile("" : "+v"(ln));
-          const bool smoothed = L2 != 2 && B.c == 0 && ((filter_mode_mask(L2) >> B.mode) & 1);
+          const bool smoothed = L2 != 2 && (B.c == 0 || c444) && ((filter_mode_mask(L2) >> B.mode) & 1);
           if (RARE && (lossless & 2)) { // PCM: the record's levels are the samples, in raster order (slice.cc:4462-4504)
             Pix* dst = B.u + mul24(B.y0, B.P) + UPAD + B.x0;
             const GLOBAL_AS uint32_t* cf = coeffs + coeff_first;
@@ -830,8 +834,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
       };
       flush_plane(std::integral_constant<int, ctb>(), u0, P0, lw, dp.plane[0], dp.pitch[0], ctb, dp.width, dp.height);
       if (dp.chroma_format != 0) { // 4:0:0 pictures carry luma blocks only
-        flush_plane(std::integral_constant<int, cw_c>(), u1, P1, lw + lo1, dp.plane[1], dp.pitch[1], ch_c, planeWc, planeHc);
-        flush_plane(std::integral_constant<int, cw_c>(), u2, P1, lw + lo2, dp.plane[2], dp.pitch[2], ch_c, planeWc, planeHc);
+        if (c444) {
+          flush_plane(std::integral_constant<int, ctb>(), u1, P1, lw + lo1, dp.plane[1], dp.pitch[1], ch_c, planeWc, planeHc);
+          flush_plane(std::integral_constant<int, ctb>(), u2, P1, lw + lo2, dp.plane[2], dp.pitch[2], ch_c, planeWc, planeHc);
+        }
+        else {
+          flush_plane(std::integral_constant<int, (ctb >> 1)>(), u1, P1, lw + lo1, dp.plane[1], dp.pitch[1], ch_c, planeWc, planeHc);
+          flush_plane(std::integral_constant<int, (ctb >> 1)>(), u2, P1, lw + lo2, dp.plane[2], dp.pitch[2], ch_c, planeWc, planeHc);
+        }
       }
       // ---- publish progress: only LDS traffic has to be ordered (the picture stores stay in flight) ----
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -845,15 +855,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
 // LDS bytes one wave needs
 static int per_wave_lds(int ctb, int chroma_format, int pix_bytes)
 {
-  const int cw = ctb / 2, ch = chroma_format == 1 ? ctb / 2 : ctb;
+  const int cw = chroma_format == 3 ? ctb : ctb / 2, ch = chroma_format == 1 ? ctb / 2 : ctb;
   int b = 512 + 512 + 272;
   b += (ctb + UPAD) * ctb * pix_bytes + 2 * (cw + UPAD) * ch * pix_bytes;
   return (b + 15) & ~15;
 }
 // one line of samples (luma + cb + cr, 4 samples of padding in front of each) for a picture ctb_w CTBs wide
-static int line_lds(int ctb, int ctb_w, int pix_bytes)
+static int line_lds(int ctb, int ctb_w, int pix_bytes, int chroma_format)
 {
-  return ((3 * 4 + 2 * ctb_w * ctb) * pix_bytes + 15) & ~15;
+  return ((3 * 4 + (chroma_format == 3 ? 3 : 2) * ctb_w * ctb) * pix_bytes + 15) & ~15;
 }
 
 // All pictures of one launch share (log2_ctb, chroma_format, bit depth class, ctb_h upper bound).
@@ -864,7 +874,7 @@ extern "C" int hm_launch_recon(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   const int ctb = 1 << log2_ctb;
   const int pix_bytes = bit_depth > 8 ? 2 : 1;
   const int pw = per_wave_lds(ctb, chroma_format, pix_bytes);
-  const int line = line_lds(ctb, max_ctb_w, pix_bytes);
+  const int line = line_lds(ctb, max_ctb_w, pix_bytes, chroma_format);
   const int fixed = (((max_ctb_h * 4) + 15) & ~15) + 1024 + 256 + BIG_BYTES;
   // useful waves: a CTU row can start once the row above is two CTUs ahead
   int nw = (max_ctb_w + 1) / 2;

@@ -113,7 +113,7 @@ HM_API int hm_colour_convert_batch(const hm_colour_desc* d, int n, const void* c
  * command stream (struct hm_pic at offset 0).  CABAC / parsing run on the calling CPU thread -
  * as in the reference (slice.cc) - and are thread-safe across different calls.
  * Returns HM_ERR_UNSUPPORTED for syntax outside the GPU hot path (inter slices,
- * range-extension tools, 4:4:4). */
+ * range-extension tools, separate colour planes, more than 12 bits). */
 HM_API int hm_hevc_parse(const uint8_t* data, size_t size, int annexb, uint8_t** out_blob, size_t* out_size);
 HM_API void hm_free(void* p);
 

@@ -38,7 +38,9 @@ extern "C" {
 #define HM_PIC_PCMF                   0x0200u /* (pcm_enabled && pcm_loop_filter_disabled) || transquant_bypass_enabled:
                                                  the reference's deblocking takes its "pcmf" branches (deblock.cc:723)  */
 #define HM_PIC_LOSSLESS_CUS           0x0400u /* at least one PCM or cu_transquant_bypass coding unit            */
-#define HM_PIC_RARE_SYNTAX            (HM_PIC_SCALING_LIST | HM_PIC_PCMF | HM_PIC_LOSSLESS_CUS) /* pictures that need the kernel
+#define HM_PIC_444                    0x0800u /* chroma_format_idc 3 (chroma_format says the same; the flag puts such
+                                                 pictures into the rare-syntax classes)                        */
+#define HM_PIC_RARE_SYNTAX            (HM_PIC_SCALING_LIST | HM_PIC_PCMF | HM_PIC_LOSSLESS_CUS | HM_PIC_444) /* pictures that need the kernel
                                                  variant of the reconstruction with the rare paths             */
 
 /* ScalingFactor tables of a picture with scaling lists (transform.cc:509-533): one byte per coefficient position

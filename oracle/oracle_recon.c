@@ -304,7 +304,9 @@ static void reconstruct(pic_t* P)
         int border_mem[4 * 32 + 1];
         int* border = border_mem + 2 * 32;
         build_border(P, t, cIdx, x0, y0, nT, bd, border);
-        if (cIdx == 0) filter_border(border, nT, mode, (H->flags & HM_PIC_STRONG_INTRA_SMOOTHING) != 0, H->bit_depth_y);
+        /* luma, and chroma of 4:4:4 pictures (intrapred.cc:307-311); the strong filter is luma only (intrapred.h:224-229) */
+        if (cIdx == 0 || H->chroma_format == 3)
+          filter_border(border, nT, mode, cIdx == 0 && (H->flags & HM_PIC_STRONG_INTRA_SMOOTHING) != 0, H->bit_depth_y);
         predict(dst, P->w[cIdx], nT, log2, cIdx, mode, border, bd);
         if ((t->info & HM_TU_CBF) && (t->pred_mode & HM_TU_MODE_BYPASS)) { /* transform.cc:431-449: residual = levels */
           const hm_coeff* cf = P->coeffs + t->coeff_first;
@@ -614,14 +616,14 @@ int orc_decode_picture(const uint8_t* blob, size_t size, int stages, uint16_t* y
   P.hdr = (const hm_pic*)blob;
   const hm_pic* H = P.hdr;
   if (H->magic != HM_STREAM_MAGIC || H->total_bytes > size) return -1;
-  if (H->chroma_format > 2) return -2; /* 0 = monochrome: luma only (cb / cr may be NULL) */
+  if (H->chroma_format > 3) return -2; /* 0 = monochrome: luma only (cb / cr may be NULL) */
   P.slices = (const hm_slice*)(blob + H->off_slices);
   P.ctbs = (const hm_ctb*)(blob + H->off_ctbs);
   P.tus = (const hm_tu*)(blob + H->off_tus);
   P.coeffs = (const hm_coeff*)(blob + H->off_coeffs);
   P.scaling = (H->flags & HM_PIC_SCALING_LIST) ? blob + H->off_scaling : NULL;
   const int ncomp = H->chroma_format == 0 ? 1 : 3;
-  P.sw = 2; P.sh = H->chroma_format == 1 ? 2 : 1;
+  P.sw = H->chroma_format == 3 ? 1 : 2; P.sh = H->chroma_format == 1 ? 2 : 1;
   P.w[0] = H->width; P.h[0] = H->height;
   if (ncomp == 3) { P.w[1] = P.w[2] = H->width / P.sw; P.h[1] = P.h[2] = H->height / P.sh; }
   P.pl[0] = y; P.pl[1] = cb; P.pl[2] = cr;

@@ -54,13 +54,19 @@ CASES = {
                               pcm_bits_c=12, pcm_loop_filter_disable=1, tq_bypass=250),
     "pcm_bypass_sl_wpp": dict(seed=5200007, width=192, height=128, log2_ctb=6, bit_depth=10, qp=29, wpp=1, scaling_list=2, pcm=200,
                               pcm_bits_y=9, pcm_bits_c=9, pcm_loop_filter_disable=0, tq_bypass=200),
+    # 4:4:4 (chroma blocks as large as luma ones, chroma reference samples smoothed like luma: intrapred.cc:307-311)
+    "yuv444_8": dict(seed=5300001, width=160, height=96, chroma_format=3, log2_ctb=5, qp=28, matrix=0),
+    "yuv444_10_ctb64_wpp": dict(seed=5300002, width=192, height=136, chroma_format=3, bit_depth=10, log2_ctb=6, wpp=1, qp=31),
+    "yuv444_12_ctb16": dict(seed=5300003, width=96, height=64, chroma_format=3, bit_depth=12, log2_ctb=4, qp=36),
+    "yuv444_rare": dict(seed=5300004, width=128, height=96, chroma_format=3, log2_ctb=5, qp=30, scaling_list=2, pcm=200, pcm_bits_y=8,
+                        pcm_bits_c=7, pcm_loop_filter_disable=1, tq_bypass=200),
 }
 
 # 8-bit pictures in which the reference takes its "pcmf" deblocking branch: its SIMD build (the configuration of
 # oracle/_ref, and what x86 / ARM users run) filters luma edges between ordinary units with the SSE / NEON kernel, its
 # scalar build leaves them unfiltered (fallback-postfilter.h:85-124 reads the flags with the opposite polarity).  The
 # fixtures and the product follow the SIMD build; tools/make_fixtures.py does not require the scalar build to agree.
-SIMD_BUILD_ONLY = {"pcm_nofilter", "tq_bypass"}
+SIMD_BUILD_ONLY = {"pcm_nofilter", "tq_bypass", "yuv444_rare"}
 
 
 def stream(name):
@@ -72,14 +78,14 @@ def stream(name):
 
 def rare_syntax_sweep(n, first_seed=2000):
     """(seed, parameters) of a seeded sweep over the rarely used syntax: PCM and transquant-bypass units with every
-    loop-filter flag combination, scaling lists, WPP, 4:0:0 / 4:2:0 / 4:2:2, 8-12 bit, every CTB size."""
+    loop-filter flag combination, scaling lists, WPP, 4:0:0 / 4:2:0 / 4:2:2 / 4:4:4, 8-12 bit, every CTB size."""
     out = []
     for seed in range(first_seed, first_seed + n):
         kw = dict(width=[64, 96, 72, 128][seed % 4], height=[64, 40, 72][seed % 3], log2_ctb=[5, 4, 6, 5][seed % 4] if seed % 5 else 5,
-                  chroma_format=[1, 2, 1, 0][seed % 4], bit_depth=[8, 10, 8, 12, 9][seed % 5], pcm=[200, 0, 300][seed % 3],
+                  chroma_format=[1, 2, 3, 0][seed % 4], bit_depth=[8, 10, 8, 12, 9][seed % 5], pcm=[200, 0, 300][seed % 3],
                   tq_bypass=[0, 300, 150, 1][seed % 4], pcm_loop_filter_disable=seed % 2, wpp=int(seed % 7 == 0), cu_qp_delta=1,
                   scaling_list=[0, 0, 2][seed % 3])
-        if kw["log2_ctb"] == 4 and kw["bit_depth"] == 8 and kw["chroma_format"]:
+        if kw["log2_ctb"] == 4 and kw["bit_depth"] == 8 and kw["chroma_format"] in (1, 2):
             kw["log2_ctb"] = 5  # 8-bit SAO on 8-sample-wide chroma CTBs: the reference's SIMD quirk Q9, not a corpus subject
         kw["pcm_bits_y"] = max(1, kw["bit_depth"] - seed % 3)
         kw["pcm_bits_c"] = max(1, kw["bit_depth"] - seed % 4)

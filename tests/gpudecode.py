@@ -17,7 +17,7 @@ def decode_pictures(pkg, blobs, stages=3, dests=None):
         h = capi.stream_header(blob)
         w, hh, cf, bd = h["width"], h["height"], h["chroma_format"], h["bit_depth"]
         bps = 2 if bd > 8 else 1
-        cw, ch = w // 2, (hh // 2 if cf == 1 else hh)
+        cw, ch = (w if cf == 3 else w // 2), (hh // 2 if cf == 1 else hh)
         planes = []
         for (pw, ph) in (((w, hh),) if cf == 0 else ((w, hh), (cw, ch), (cw, ch))):  # monochrome: luma only
             pitch = (pw * bps + 63) // 64 * 64

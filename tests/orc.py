@@ -177,7 +177,7 @@ def oracle_decode(blob, stages=3):
     if o.orc_stream_info(buf, len(blob), info) != 0:
         raise RuntimeError("bad command stream")
     w, h, cf = info[0], info[1], info[2]
-    cw, ch = w // 2, (h // 2 if cf == 1 else h)
+    cw, ch = (w if cf == 3 else w // 2), (h // 2 if cf == 1 else h)
     y = np.zeros((h, w), np.uint16)
     cb = np.zeros((ch, cw), np.uint16)
     cr = np.zeros((ch, cw), np.uint16)

@@ -118,8 +118,8 @@ def cpu_decode(hm, tiles, tile_w, tile_h, canvas_w, canvas_h, cols, is_grid, out
         else:
             planes, info = orc.oracle_decode(hevcutil.parse(hm, data), 3)
             cf = info["chroma"]
-            planes = [planes[0][:tile_h, :tile_w], planes[1][:(tile_h + 1) // 2 if cf == 1 else tile_h, :(tile_w + 1) // 2],
-                      planes[2][:(tile_h + 1) // 2 if cf == 1 else tile_h, :(tile_w + 1) // 2]]
+            tcw, tch = (tile_w if cf == 3 else (tile_w + 1) // 2), ((tile_h + 1) // 2 if cf == 1 else tile_h)
+            planes = [planes[0][:tile_h, :tile_w], planes[1][:tch, :tcw], planes[2][:tch, :tcw]]
         bd, cf = info["bit_depth"], info["chroma"]
         bps = 2 if bd > 8 else 1
         nclx = (1, info["full_range"], info["matrix"], info["primaries"])
@@ -127,7 +127,7 @@ def cpu_decode(hm, tiles, tile_w, tile_h, canvas_w, canvas_h, cols, is_grid, out
             nclx = (1, tile_colr[3], tile_colr[2], tile_colr[0])
         if first is None:
             first = dict(bd=bd, cf=cf, nclx=nclx)
-            cw = (canvas_w + 1) // 2
+            cw = canvas_w if cf == 3 else (canvas_w + 1) // 2
             ch = (canvas_h + 1) // 2 if cf == 1 else canvas_h
             canv = [orc.alloc_plane(canvas_w, canvas_h, bps), orc.alloc_plane(cw, ch, bps), orc.alloc_plane(cw, ch, bps)]
         x0, y0 = (i % cols) * tile_w, (i // cols) * tile_h
@@ -140,7 +140,7 @@ def cpu_decode(hm, tiles, tile_w, tile_h, canvas_w, canvas_h, cols, is_grid, out
             assert rc == 0
     bd, cf = first["bd"], first["cf"]
     if transforms:  # irot / imir / clap on the decoded planes, before the colour conversion (context.cc:1957-2020)
-        cw0 = (canvas_w + 1) // 2
+        cw0 = canvas_w if cf == 3 else (canvas_w + 1) // 2
         ch0 = (canvas_h + 1) // 2 if cf == 1 else canvas_h
         canv, _, canvas_w, canvas_h = orc.transform_planes(canv, [(canvas_w, canvas_h), (cw0, ch0), (cw0, ch0)], canvas_w, canvas_h, bd, transforms)
     has_nclx = 0 if is_grid else 1

@@ -95,15 +95,11 @@ def test_no_gpu_means_loud_failure_not_cpu_fallback(hm):
 
 
 def test_unsupported_syntax_is_reported(hm):
-    """4:4:4 is outside the GPU path: HM_ERR_UNSUPPORTED with a reason, not garbage"""
+    """syntax outside the GPU path: HM_ERR_UNSUPPORTED with a reason, not garbage (here: 14-bit samples)"""
     import synthutil
-    for cf in (3,):
-        try:
-            data = synthutil.picture(5, width=64, height=64, chroma_format=cf)
-        except RuntimeError:
-            continue  # the synthesiser itself may refuse
-        with pytest.raises(RuntimeError, match="-2.*chroma format"):
-            hevcutil.parse(hm, data)
+    data = synthutil.picture(5, width=64, height=64, bit_depth=14)
+    with pytest.raises(RuntimeError, match="-2.*bit depth"):
+        hevcutil.parse(hm, data)
 
 
 def test_mutated_heif_boxes_never_crash(hm):

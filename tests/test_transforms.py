@@ -191,3 +191,40 @@ def test_monochrome_alpha_and_monochrome_image(hm):
         np.testing.assert_array_equal(rgb[0][:200, k:136 * 3:3], yr)
         np.testing.assert_array_equal(rgba[0][:200, k:136 * 4:4], yr)
     assert (rgba[0][:200, 3:136 * 4:4] == 255).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nclx", [dict(full_range=1, matrix=6), dict(full_range=0, matrix=1), dict(full_range=1, matrix=0)],
+                         ids=["bt601_full", "bt709_limited", "gbr"])
+def test_444_images(hm, nclx):
+    """4:4:4 pictures end to end: single image with a transformation -> RGB24 / RGBA / native planes
+    (Op_YCbCr_to_RGB incl. the GBR branch of matrix_coefficients 0), and a 2x2 grid with the paste geometry of
+    context.cc:2466-2480 (chroma origin = luma origin)."""
+    pic = synthutil.picture(8700, width=200, height=136, chroma_format=3, log2_ctb=5, qp=29, vui=1, **nclx)
+    tr = [("irot", 1), _clap(136, 200, 120, 180, 3, -4)]
+    f = pipeline.HeifFile(hm, heifwriter.write_heic([pic], (200, 136), chroma_format=3, transforms=tr))
+    info = f.info(f.primary())
+    assert info.chroma == 3
+    rgb, m3 = f.decode(f.primary(), 10)
+    rgba, m4 = f.decode(f.primary(), 11)
+    native, nm = f.decode(f.primary(), 0)
+    f.close()
+    exp, stride, canv = pipeline.cpu_decode(hm, [pic], 200, 136, 200, 136, 1, False, 10, transforms=tr)
+    exp4, stride4, _ = pipeline.cpu_decode(hm, [pic], 200, 136, 200, 136, 1, False, 11, transforms=tr)
+    w, h = m3["width"], m3["height"]
+    assert (w, h) == (120, 180) and m3["stride"][0] == stride
+    np.testing.assert_array_equal(rgb[0][:h, :w * 3], exp[:h, :w * 3])
+    np.testing.assert_array_equal(rgba[0][:h, :w * 4], exp4[:h, :w * 4])
+    for c in range(3):
+        pw, ph = nm["plane_size"][c]
+        assert (pw, ph) == (w, h)
+        np.testing.assert_array_equal(native[c][:ph, :pw], canv[c][0][:ph, :pw])
+
+    tiles = [synthutil.picture(8710 + i, width=128, height=64, chroma_format=3, bit_depth=10, log2_ctb=[4, 5, 6, 5][i], qp=30, vui=1, **nclx) for i in range(4)]
+    data = heifwriter.write_heic(tiles, (128, 64), grid=(2, 2, 250, 120), chroma_format=3, bit_depth=10)
+    f = pipeline.HeifFile(hm, data)
+    out, meta = f.decode(f.primary(), 14, threads=2)
+    f.close()
+    exp, stride, _ = pipeline.cpu_decode(hm, tiles, 128, 64, 250, 120, 2, True, 14)
+    assert (meta["width"], meta["height"], meta["bit_depth"]) == (250, 120, 10) and meta["stride"][0] == stride
+    np.testing.assert_array_equal(out[0][:120, :250 * 6], exp[:120, :250 * 6])
