@@ -232,11 +232,11 @@ def main():
         total_mp = world * B * MP_PER_IMAGE * args.steps
         value = total_mp / elapsed
         stream_b, sample_b = batch.algorithmic_bytes()
-        names = ["k_recon", "k_deblock(V+H)", "k_sao_paste", "k_ycbcr420_int(colour)"]
+        names = ["k_recon", "k_deblock", "k_sao_paste", "k_ycbcr420_int(colour)"]
         # algorithmic bytes per step of each kernel: recon = command stream + samples out;
-        # deblock = 2 passes x (read + write) of the samples it touches ~ 2 x sample bytes x 2;
+        # deblock = one pass: read + write of the samples = 2 x sample bytes;
         # sao+paste = read + write samples; colour = 4.5 B per output pixel
-        alg = [stream_b + sample_b, 4 * sample_b, 2 * sample_b, int(4.5 * OUT_W * OUT_H * B)]
+        alg = [stream_b + sample_b, 2 * sample_b, 2 * sample_b, int(4.5 * OUT_W * OUT_H * B)]
         avg_ms = [m / args.steps for m in k_ms]
         dom = max(range(4), key=lambda q: avg_ms[q])
         kernels = {names[q]: {"ms_per_step": round(avg_ms[q], 4), "algorithmic_bytes": int(alg[q]),

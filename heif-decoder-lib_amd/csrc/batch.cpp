@@ -227,6 +227,7 @@ int hm_batch_upload(hm_batch* b, void* stream)
       d.flags = (int32_t)h.flags;
       d.cb_qp_offset = h.pps_cb_qp_offset; d.cr_qp_offset = h.pps_cr_qp_offset;
       d.pcm_loop_filter_disabled = h.pcm_loop_filter_disabled;
+      d.n_slices = (int32_t)h.n_slices;
       d.slices = (const hm_slice*)(d.blob + h.off_slices);
       d.ctbs = (const hm_ctb*)(d.blob + h.off_ctbs);
       // destination = tile paste geometry of context.cc:2457-2502

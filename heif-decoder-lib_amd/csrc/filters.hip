@@ -53,11 +53,6 @@ __device__ __forceinline__ PicView view(const hm_dev_pic& dp)
   v.ctbs = dp.ctbs;
   return v;
 }
-__device__ __forceinline__ int edge_bs(const hm_dev_pic& dp, int x, int y, int vertical)
-{
-  if ((x >> 2) >= dp.w4 || (y >> 2) >= dp.h4) return 0;
-  return (dp.meta[(x >> 2) + (size_t)(y >> 2) * dp.w4] & (vertical ? 1 : 2)) ? 2 : 0;
-}
 __device__ __forceinline__ int qpy_at(const hm_dev_pic& dp, int x, int y) { return (int)(int8_t)(dp.meta[(x >> 2) + (size_t)(y >> 2) * dp.w4] >> 8); }
 __device__ __forceinline__ const hm_slice& slice_at(const hm_dev_pic& dp, const PicView& v, int x, int y)
 {
@@ -65,76 +60,72 @@ __device__ __forceinline__ const hm_slice& slice_at(const hm_dev_pic& dp, const 
   return v.slices[v.ctbs[ci].slice_idx];
 }
 
-// The 8x8 luma window of one edge segment, packed as loaded (row-major tile whose top-left is (xD-4, yD) for
-// vertical edges, (xD, yD-4) for horizontal): 16 (8-bit) / 32 (16-bit) registers instead of 64, which is what
-// decides the occupancy of this latency-bound kernel.  at(d, i): d = 0..7 along the edge, i = 0..7 across it
-// (p3 p2 p1 p0 | q0 q1 q2 q3).
-template <typename Pix, bool vertical>
+// ---- deblocking: both directions in one pass --------------------------------------------------------------
+// The reference filters all vertical edges of the picture, then all horizontal ones (deblock.cc:1775-1803).  Edges
+// lie on the 8-sample grid and a filter reads 4 / writes 3 samples on each side, so the 8x8 windows whose corners
+// are the grid crossings SHIFTED BY 4 are independent of each other: a window [8kx-4, 8kx+4) x [8ky-4, 8ky+4) holds
+// the vertical edge x = 8kx for its eight rows (the lower 4-line unit of the edge segment above the crossing and the
+// upper unit of the one below) and the horizontal edge y = 8ky for its eight columns, and every sample the
+// horizontal filter reads has been touched by no other vertical edge than this one.  One lane loads a window,
+// filters the vertical edge, then the horizontal edge on the result, and stores it: each sample is read once and
+// written once (the two-pass version moved twice the bytes), and no two lanes touch the same sample.
+//
+// The window stays packed as loaded (row-major; 16 registers for 8-bit samples, 32 for 16-bit, instead of 64),
+// which is what decides the occupancy of this latency-bound kernel.  at<V>(d, i): d = 0..7 along the edge, i = 0..7
+// across it (p3 p2 p1 p0 | q0 q1 q2 q3); V = vertical edge (d = row, i = column), else horizontal.
+template <typename Pix>
 struct Window {
-  static constexpr int PER = 4 / (int)sizeof(Pix), BITS = 8 * (int)sizeof(Pix);
+  static constexpr int PER = 4 / (int)sizeof(Pix), BITS = 8 * (int)sizeof(Pix), WORDS = 8 / PER;
   static constexpr uint32_t MASK = (1u << BITS) - 1;
-  uint32_t w[8][8 / PER];
+  uint32_t w[8][WORDS];
+  template <bool V>
   __device__ __forceinline__ int at(int d, int i) const
   {
-    const int r = vertical ? d : i, q = vertical ? i : d;
+    const int r = V ? d : i, q = V ? i : d;
     return (int)((w[r][q / PER] >> ((q % PER) * BITS)) & MASK);
   }
+  template <bool V>
   __device__ __forceinline__ void put(int d, int i, int v)
   {
-    const int r = vertical ? d : i, q = vertical ? i : d, sh = (q % PER) * BITS;
+    const int r = V ? d : i, q = V ? i : d, sh = (q % PER) * BITS;
     w[r][q / PER] = (w[r][q / PER] & ~(MASK << sh)) | ((uint32_t)v << sh);
-  }
-  __device__ __forceinline__ void load(const uint8_t* plane, int pitch, int xD, int yD)
-  {
-    const int tx = vertical ? xD - 4 : xD, ty = vertical ? yD : yD - 4;
-#pragma unroll
-    for (int r = 0; r < 8; r++) __builtin_memcpy(w[r], reinterpret_cast<const Pix*>(plane + (size_t)(ty + r) * pitch) + tx, 8 * sizeof(Pix));
-  }
-  __device__ __forceinline__ void store(uint8_t* plane, int pitch, int xD, int yD) const
-  {
-    const int tx = vertical ? xD - 4 : xD, ty = vertical ? yD : yD - 4;
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-      Pix* row = reinterpret_cast<Pix*>(plane + (size_t)(ty + r) * pitch) + tx;
-      if (vertical) { // only p2..q2 can change
-        Pix v[8];
-        __builtin_memcpy(v, w[r], 8 * sizeof(Pix));
-        __builtin_memcpy(row + 1, v + 1, 6 * sizeof(Pix));
-      }
-      else if (r >= 1 && r <= 6) __builtin_memcpy(row, w[r], 8 * sizeof(Pix));
-    }
   }
 };
 
-// fallback-postfilter.h:32-138
-// mod_p / mod_q: may the P / Q side of each 4-line half be modified (all true outside the reference's "pcmf" branch)
-template <typename Win>
-__device__ __forceinline__ void filter_luma(Win& W, int beta, const int tc2[2], int maxv, const bool (&mod_p)[2], const bool (&mod_q)[2])
+// fallback-postfilter.h:32-138 for one edge of the window: two 4-line units (j) with their own beta / tc.
+// mod_p / mod_q: may the P / Q side of a unit be modified (all true outside the reference's "pcmf" branch)
+template <bool V, typename Win>
+__device__ __forceinline__ void filter_luma(Win& W, const int beta2[2], const int tc2[2], int maxv, const bool (&mod_p)[2], const bool (&mod_q)[2])
 {
 #pragma unroll
   for (int j = 0; j < 2; j++) {
-    const int o = 4 * j;
-    const int dp0 = iabs_(W.at(o, 1) - 2 * W.at(o, 2) + W.at(o, 3)), dq0 = iabs_(W.at(o, 6) - 2 * W.at(o, 5) + W.at(o, 4));
-    const int dp3 = iabs_(W.at(o + 3, 1) - 2 * W.at(o + 3, 2) + W.at(o + 3, 3)), dq3 = iabs_(W.at(o + 3, 6) - 2 * W.at(o + 3, 5) + W.at(o + 3, 4));
-    const int d0 = dp0 + dq0, d3 = dp3 + dq3, tc = tc2[j];
+    const int o = 4 * j, tc = tc2[j], beta = beta2[j];
+    if (tc == 0) continue; // bS 0 (tc is 0 only then: the strong filter clips to +-2tc, the normal one needs |delta| < 10 tc)
+    const int dp0 = iabs_(W.template at<V>(o, 1) - 2 * W.template at<V>(o, 2) + W.template at<V>(o, 3));
+    const int dq0 = iabs_(W.template at<V>(o, 6) - 2 * W.template at<V>(o, 5) + W.template at<V>(o, 4));
+    const int dp3 = iabs_(W.template at<V>(o + 3, 1) - 2 * W.template at<V>(o + 3, 2) + W.template at<V>(o + 3, 3));
+    const int dq3 = iabs_(W.template at<V>(o + 3, 6) - 2 * W.template at<V>(o + 3, 5) + W.template at<V>(o + 3, 4));
+    const int d0 = dp0 + dq0, d3 = dp3 + dq3;
     if (d0 + d3 >= beta) continue;
     const int beta_3 = beta >> 3, beta_2 = beta >> 2, tc25 = (tc * 5 + 1) >> 1;
-    if (iabs_(W.at(o, 0) - W.at(o, 3)) + iabs_(W.at(o, 7) - W.at(o, 4)) < beta_3 && iabs_(W.at(o, 3) - W.at(o, 4)) < tc25 &&
-        iabs_(W.at(o + 3, 0) - W.at(o + 3, 3)) + iabs_(W.at(o + 3, 7) - W.at(o + 3, 4)) < beta_3 &&
-        iabs_(W.at(o + 3, 3) - W.at(o + 3, 4)) < tc25 && (d0 << 1) < beta_2 && (d3 << 1) < beta_2) {
+    if (iabs_(W.template at<V>(o, 0) - W.template at<V>(o, 3)) + iabs_(W.template at<V>(o, 7) - W.template at<V>(o, 4)) < beta_3 &&
+        iabs_(W.template at<V>(o, 3) - W.template at<V>(o, 4)) < tc25 &&
+        iabs_(W.template at<V>(o + 3, 0) - W.template at<V>(o + 3, 3)) + iabs_(W.template at<V>(o + 3, 7) - W.template at<V>(o + 3, 4)) < beta_3 &&
+        iabs_(W.template at<V>(o + 3, 3) - W.template at<V>(o + 3, 4)) < tc25 && (d0 << 1) < beta_2 && (d3 << 1) < beta_2) {
       const int t2 = tc << 1;
 #pragma unroll
       for (int d = o; d < o + 4; d++) {
-        const int p3 = W.at(d, 0), p2 = W.at(d, 1), p1 = W.at(d, 2), p0 = W.at(d, 3), q0 = W.at(d, 4), q1 = W.at(d, 5), q2 = W.at(d, 6), q3 = W.at(d, 7);
+        const int p3 = W.template at<V>(d, 0), p2 = W.template at<V>(d, 1), p1 = W.template at<V>(d, 2), p0 = W.template at<V>(d, 3);
+        const int q0 = W.template at<V>(d, 4), q1 = W.template at<V>(d, 5), q2 = W.template at<V>(d, 6), q3 = W.template at<V>(d, 7);
         if (mod_p[j]) {
-          W.put(d, 3, p0 + clip3i(-t2, t2, ((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3) - p0));
-          W.put(d, 2, p1 + clip3i(-t2, t2, ((p2 + p1 + p0 + q0 + 2) >> 2) - p1));
-          W.put(d, 1, p2 + clip3i(-t2, t2, ((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3) - p2));
+          W.template put<V>(d, 3, p0 + clip3i(-t2, t2, ((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3) - p0));
+          W.template put<V>(d, 2, p1 + clip3i(-t2, t2, ((p2 + p1 + p0 + q0 + 2) >> 2) - p1));
+          W.template put<V>(d, 1, p2 + clip3i(-t2, t2, ((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3) - p2));
         }
         if (mod_q[j]) {
-          W.put(d, 4, q0 + clip3i(-t2, t2, ((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3) - q0));
-          W.put(d, 5, q1 + clip3i(-t2, t2, ((p0 + q0 + q1 + q2 + 2) >> 2) - q1));
-          W.put(d, 6, q2 + clip3i(-t2, t2, ((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3) - q2));
+          W.template put<V>(d, 4, q0 + clip3i(-t2, t2, ((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3) - q0));
+          W.template put<V>(d, 5, q1 + clip3i(-t2, t2, ((p0 + q0 + q1 + q2 + 2) >> 2) - q1));
+          W.template put<V>(d, 6, q2 + clip3i(-t2, t2, ((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3) - q2));
         }
       }
     }
@@ -144,157 +135,183 @@ __device__ __forceinline__ void filter_luma(Win& W, int beta, const int tc2[2], 
       const bool np2 = dp0 + dp3 < thr, nq2 = dq0 + dq3 < thr;
 #pragma unroll
       for (int d = o; d < o + 4; d++) {
-        const int p2 = W.at(d, 1), p1 = W.at(d, 2), p0 = W.at(d, 3), q0 = W.at(d, 4), q1 = W.at(d, 5), q2 = W.at(d, 6);
+        const int p2 = W.template at<V>(d, 1), p1 = W.template at<V>(d, 2), p0 = W.template at<V>(d, 3);
+        const int q0 = W.template at<V>(d, 4), q1 = W.template at<V>(d, 5), q2 = W.template at<V>(d, 6);
         int delta0 = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4;
         if (iabs_(delta0) < 10 * tc) {
           delta0 = clip3i(-tc, tc, delta0);
-          if (mod_p[j]) W.put(d, 3, clip3i(0, maxv, p0 + delta0));
-          if (mod_q[j]) W.put(d, 4, clip3i(0, maxv, q0 - delta0));
-          if (np2 && mod_p[j]) W.put(d, 2, clip3i(0, maxv, p1 + clip3i(-tc_2, tc_2, (((p2 + p0 + 1) >> 1) - p1 + delta0) >> 1)));
-          if (nq2 && mod_q[j]) W.put(d, 5, clip3i(0, maxv, q1 + clip3i(-tc_2, tc_2, (((q2 + q0 + 1) >> 1) - q1 - delta0) >> 1)));
+          if (mod_p[j]) W.template put<V>(d, 3, clip3i(0, maxv, p0 + delta0));
+          if (mod_q[j]) W.template put<V>(d, 4, clip3i(0, maxv, q0 - delta0));
+          if (np2 && mod_p[j]) W.template put<V>(d, 2, clip3i(0, maxv, p1 + clip3i(-tc_2, tc_2, (((p2 + p0 + 1) >> 1) - p1 + delta0) >> 1)));
+          if (nq2 && mod_q[j]) W.template put<V>(d, 5, clip3i(0, maxv, q1 + clip3i(-tc_2, tc_2, (((q2 + q0 + 1) >> 1) - q1 - delta0) >> 1)));
         }
       }
     }
   }
 }
 
-// One launch = one direction for every picture of the batch.  blockIdx.y = picture.
+// chroma edge of the window (deblock.cc:1608-1772, fallback-postfilter.h:138-180): p1 p0 | q0 q1 = positions 2..5
+template <bool V, typename Win>
+__device__ __forceinline__ void filter_chroma(Win& W, const int tc2[2], int maxv, const bool (&mod_p)[2], const bool (&mod_q)[2])
+{
+#pragma unroll
+  for (int d = 0; d < 8; d++) {
+    const int t = tc2[d >> 2];
+    if (t == 0) continue; // delta clipped to [-0, 0]
+    const int p1 = W.template at<V>(d, 2), p0 = W.template at<V>(d, 3), q0 = W.template at<V>(d, 4), q1 = W.template at<V>(d, 5);
+    const int delta = clip3i(-t, t, ((((q0 - p0) * 4) + p1 - q1 + 4) >> 3));
+    if (mod_p[d >> 2]) W.template put<V>(d, 3, clip3i(0, maxv, p0 + delta));
+    if (mod_q[d >> 2]) W.template put<V>(d, 4, clip3i(0, maxv, q0 - delta));
+  }
+}
+
 // bits 2 / 3 of the block map: PCM / transquant-bypass coding unit at luma position (x, y); 0 outside the picture
 __device__ __forceinline__ int lossless_bits(const hm_dev_pic& dp, int x, int y)
 {
   if (x < 0 || y < 0 || (x >> 2) >= dp.w4 || (y >> 2) >= dp.h4) return 0;
   return dp.meta[(x >> 2) + (size_t)(y >> 2) * dp.w4] & 12;
 }
+// boundary strength of the edge unit at luma position (x, y): 2 on marked transform edges (all units are intra)
+__device__ __forceinline__ int unit_bs(const hm_dev_pic& dp, int x, int y, int vertical)
+{
+  if (x < 0 || y < 0 || (x >> 2) >= dp.w4 || (y >> 2) >= dp.h4) return 0;
+  return (dp.meta[(x >> 2) + (size_t)(y >> 2) * dp.w4] & (vertical ? 1 : 2)) ? 2 : 0;
+}
 
-// PCMF: the variant for pictures of the rare-syntax classes, which also follows the reference's "pcmf" branches.
-template <typename Pix, bool vertical, bool PCMF>
+// One launch = every picture of the batch class.  blockIdx.y = picture; an item is one window of one plane.
+// PCMF: the variant for pictures of the rare-syntax classes, which also follows the reference's "pcmf" branches
+// and knows 4:4:4.
+template <typename Pix, bool PCMF>
 __global__ __launch_bounds__(256, sizeof(Pix) == 1 ? 8 : 6) void k_deblock(const hm_dev_pic* __restrict__ pics)
 {
   const hm_dev_pic& dp = pics[blockIdx.y];
   if (!(dp.flags & HM_PIC_DEBLOCK_ANY)) return;
   const PicView v = view(dp);
-  const int bd = dp.bit_depth, maxv = (1 << bd) - 1;
-  const int item = blockIdx.x * 256 + threadIdx.x;
-  // ---- luma segments: 8x8 grid ----
-  const int lw = (dp.w4 + 1) >> 1, lh = (dp.h4 + 1) >> 1;
-  const int nL = lw * lh;
-  if (item < nL) {
-    const int sx = item % lw, sy = item / lw;
-    const int xD = sx << 3, yD = sy << 3;
-    const int bs0 = edge_bs(dp, xD, yD, vertical);
-    const int bs1 = vertical ? edge_bs(dp, xD, yD + 4, 1) : edge_bs(dp, xD + 4, yD, 0);
-    if (!bs0 && !bs1) return;
-    const int QP_Q = qpy_at(dp, xD, yD);
-    const int QP_P = vertical ? qpy_at(dp, xD - 1, yD) : qpy_at(dp, xD, yD - 1);
-    const int qPL = (QP_Q + QP_P + 1) >> 1;
-    const hm_slice& sl = slice_at(dp, v, xD, yD);
-    const int beta = c_beta[clip3i(0, 51, qPL + sl.beta_offset_div2 * 2)] * (1 << (bd - 8));
-    int tc[2];
-    tc[0] = bs0 ? c_tc[clip3i(0, 53, qPL + 2 * (bs0 - 1) + sl.tc_offset_div2 * 2)] * (1 << (bd - 8)) : 0;
-    tc[1] = bs1 ? c_tc[clip3i(0, 53, qPL + 2 * (bs1 - 1) + sl.tc_offset_div2 * 2)] * (1 << (bd - 8)) : 0;
-    bool mod_p[2] = {true, true}, mod_q[2] = {true, true};
+  const int bd = dp.bit_depth, maxv = (1 << bd) - 1, bdscale = 1 << (bd - 8);
+  int item = blockIdx.x * 256 + threadIdx.x;
+  const int nwx = (dp.width >> 3) + 1, nwy = (dp.height >> 3) + 1; // picture sizes are multiples of 8 (minimum coding block)
+  const int nL = nwx * nwy;
+  int c = 0, sw = 1, sh = 1, cwx = 0;
+  if (item >= nL) { // chroma windows: the same structure in chroma samples
+    if (dp.chroma_format == 0) return;
+    sw = (PCMF && dp.chroma_format == 3) ? 1 : 2; sh = dp.chroma_format == 1 ? 2 : 1;
+    const int Wc = dp.width / sw, Hc = dp.height / sh; // multiples of 4
+    cwx = ((Wc + 7) >> 3) + 1;
+    const int nC = cwx * (((Hc + 7) >> 3) + 1);
+    item -= nL;
+    if (item >= 2 * nC) return;
+    c = item >= nC ? 2 : 1;
+    item -= (c - 1) * nC;
+  }
+  const int wxn = c ? cwx : nwx;
+  const int ky = item / wxn, kx = item - ky * wxn;
+  const int PW = dp.width / sw, PH = dp.height / sh;                  // plane size
+  const int ex = kx << 3, ey = ky << 3, ox = ex - 4, oy = ey - 4;   // the crossing and the window origin (plane samples)
+  // the four edge units: vertical edge x = ex, rows oy.. (j = 0) and ey.. (j = 1); horizontal edge y = ey, columns ox.. / ex..
+  // (positions passed to the block map are luma positions)
+  const bool in_x = ex > 0 && ex < PW, in_y = ey > 0 && ey < PH;
+  int bsV[2] = {0, 0}, bsH[2] = {0, 0};
+  if (in_x) {
+    if (oy >= 0) bsV[0] = unit_bs(dp, ex * sw, oy * sh, 1);
+    if (ey < PH) bsV[1] = unit_bs(dp, ex * sw, ey * sh, 1);
+  }
+  if (in_y) {
+    if (ox >= 0) bsH[0] = unit_bs(dp, ox * sw, ey * sh, 0);
+    if (ex < PW) bsH[1] = unit_bs(dp, ex * sw, ey * sh, 0);
+  }
+  if (!(bsV[0] | bsV[1] | bsH[0] | bsH[1])) return;
+
+  // ---- parameters per unit ----
+  // Luma (deblock.cc:731-753): QP, beta and the slice offsets of an 8-sample edge SEGMENT come from its first unit; the
+  // upper / left unit of the window is the second unit of the segment before the crossing.
+  // Chroma (deblock.cc:1650-1716): the slice offsets come from the segment's first unit, QpC from the unit itself.
+  int betaV[2] = {0, 0}, tcV[2] = {0, 0}, betaH[2] = {0, 0}, tcH[2] = {0, 0};
+  bool mpV[2] = {true, true}, mqV[2] = {true, true}, mpH[2] = {true, true}, mqH[2] = {true, true};
+  const int qp_off = c == 0 ? 0 : (c == 1 ? dp.cb_qp_offset : dp.cr_qp_offset);
+  auto unit_params = [&](int vertical, int j, int bs, int& beta, int& tc, bool& mod_p, bool& mod_q) {
+    if (!bs) return;
+    // own position and segment start, in plane samples
+    const int ux = vertical ? ex : (j ? ex : ox), uy = vertical ? (j ? ey : oy) : ey;
+    const int sx = vertical ? ex : (j ? ex : ex - 8), sy = vertical ? (j ? ey : ey - 8) : ey;
+    const int lsx = sx * sw, lsy = sy * sh, lux = ux * sw, luy = uy * sh;
+    // one slice (the usual case): no CTB -> slice look-up, and the offsets come through the scalar cache
+    const hm_slice& sl = dp.n_slices == 1 ? v.slices[0] : slice_at(dp, v, lsx, lsy);
+    if (c == 0) {
+      const int QP_Q = qpy_at(dp, lsx, lsy);
+      const int QP_P = vertical ? qpy_at(dp, lsx - 1, lsy) : qpy_at(dp, lsx, lsy - 1);
+      const int qPL = (QP_Q + QP_P + 1) >> 1;
+      beta = c_beta[clip3i(0, 51, qPL + sl.beta_offset_div2 * 2)] * bdscale;
+      tc = c_tc[clip3i(0, 53, qPL + 2 * (bs - 1) + sl.tc_offset_div2 * 2)] * bdscale;
+    }
+    else {
+      const int QP_Q = qpy_at(dp, lux, luy);
+      const int QP_P = vertical ? qpy_at(dp, lux - 1, luy) : qpy_at(dp, lux, luy - 1);
+      const int qPi = ((QP_Q + QP_P + 1) >> 1) + qp_off;
+      const int QP_C = dp.chroma_format == 1 ? chroma_qp_map(qPi) : (qPi < 51 ? qPi : 51);
+      tc = c_tc[clip3i(0, 53, QP_C + 2 + sl.tc_offset_div2 * 2)] * bdscale;
+    }
     if (PCMF && (dp.flags & HM_PIC_PCMF)) {
-      // deblock.cc:755-786 + fallback-postfilter.h:60-125 as the reference's SIMD build behaves: per half a flag per
-      // side says "neither PCM nor transquant-bypass" (pcm_loop_filter_disable_flag is not consulted here).  All four
-      // set: 8-bit pictures take the SSE filter (normal filtering), 16-bit pictures the scalar filter, which reads
-      // the flags as "do not modify".  Otherwise the scalar filter runs and modifies exactly the PCM / bypass sides.
-      bool keep_p[2], keep_q[2];
+      if (c == 0) {
+        // deblock.cc:755-786 + fallback-postfilter.h:60-125 as the reference's SIMD build behaves: per unit a flag per side
+        // says "neither PCM nor transquant-bypass" (pcm_loop_filter_disable_flag is not consulted here).  All four flags
+        // of the SEGMENT set: 8-bit pictures take the SSE filter (normal filtering), 16-bit pictures the scalar filter,
+        // which reads the flags as "do not modify".  Otherwise the scalar filter modifies exactly the PCM / bypass sides.
+        bool all = true;
 #pragma unroll
-      for (int j = 0; j < 2; j++) {
-        const int xq = vertical ? xD : xD + 4 * j, yq = vertical ? yD + 4 * j : yD;
-        keep_q[j] = lossless_bits(dp, xq, yq) == 0;
-        keep_p[j] = lossless_bits(dp, vertical ? xq - 1 : xq, vertical ? yq : yq - 1) == 0;
+        for (int h = 0; h < 2; h++) { // both units of the segment
+          const int qx = vertical ? lsx : lsx + 4 * h, qy = vertical ? lsy + 4 * h : lsy;
+          all = all && lossless_bits(dp, qx, qy) == 0 && lossless_bits(dp, vertical ? qx - 1 : qx, vertical ? qy : qy - 1) == 0;
+        }
+        const bool keep_q = lossless_bits(dp, lux, luy) == 0, keep_p = lossless_bits(dp, vertical ? lux - 1 : lux, vertical ? luy : luy - 1) == 0;
+        mod_p = all ? sizeof(Pix) == 1 : !keep_p;
+        mod_q = all ? sizeof(Pix) == 1 : !keep_q;
       }
-      const bool all = keep_p[0] && keep_p[1] && keep_q[0] && keep_q[1];
-#pragma unroll
-      for (int j = 0; j < 2; j++) {
-        mod_p[j] = all ? sizeof(Pix) == 1 : !keep_p[j];
-        mod_q[j] = all ? sizeof(Pix) == 1 : !keep_q[j];
+      else {
+        // deblock.cc:1724-1756 + fallback-postfilter.h:138-180: a side is filtered unless it is transquant-bypass or
+        // (pcm_loop_filter_disable_flag and PCM); for vertical edges the reference tests the P flag for both sides
+        const int mask = (dp.pcm_loop_filter_disabled ? 4 : 0) | 8;
+        const bool fq = !(lossless_bits(dp, lux, luy) & mask);
+        const bool fp = !(lossless_bits(dp, vertical ? lux - 1 : lux, vertical ? luy : luy - 1) & mask);
+        mod_p = fp;
+        mod_q = vertical ? fp : fq;
       }
     }
-    Window<Pix, vertical> win;
-    win.load(dp.plane[0], dp.pitch[0], xD, yD);
-    filter_luma(win, beta, tc, maxv, mod_p, mod_q);
-    win.store(dp.plane[0], dp.pitch[0], xD, yD);
-    return;
-  }
-  // ---- chroma segments (deblock.cc:1608-1772) ----
-  if (dp.chroma_format == 0) return;
-  const int sw = (PCMF && dp.chroma_format == 3) ? 1 : 2, sh = dp.chroma_format == 1 ? 2 : 1; // 4:4:4: rare-syntax classes only
-  const int xIncr = 2 * sw, yIncr = 2 * sh;
-  const int cwn = (dp.w4 + xIncr - 1) / xIncr, chn = (dp.h4 + yIncr - 1) / yIncr;
-  int ci = item - nL;
-  if (ci >= 2 * cwn * chn) return;
-  const int cp = ci / (cwn * chn);
-  ci -= cp * cwn * chn;
-  const int x = (ci % cwn) * xIncr, y = (ci / cwn) * yIncr;
-  const int xDi = x << (3 - sw), yDi = y << (3 - sh);
-  const int lx = xDi * sw, ly = yDi * sh;
-  const int bS0 = edge_bs(dp, lx, ly, vertical);
-  const int bS1 = vertical ? edge_bs(dp, lx, ly + 4 * sh, 1) : edge_bs(dp, lx + 4 * sw, ly, 0);
-  if (bS0 != 2 && bS1 != 2) return;
-  const int off = cp == 0 ? dp.cb_qp_offset : dp.cr_qp_offset;
-  int QP_Q = qpy_at(dp, lx, ly);
-  int QP_P = vertical ? qpy_at(dp, lx - 1, ly) : qpy_at(dp, lx, ly - 1);
-  int qPi = ((QP_Q + QP_P + 1) >> 1) + off;
-  const int QP_C0 = dp.chroma_format == 1 ? chroma_qp_map(qPi) : (qPi < 51 ? qPi : 51);
-  int QP_C1 = QP_C0;
-  if (bS1 == 2) {
-    QP_Q = vertical ? qpy_at(dp, lx, ly + 4 * sh) : qpy_at(dp, lx + 4 * sw, ly);
-    QP_P = vertical ? qpy_at(dp, lx - 1, ly + 4 * sh) : qpy_at(dp, lx + 4 * sw, ly - 1);
-    qPi = ((QP_Q + QP_P + 1) >> 1) + off;
-    QP_C1 = dp.chroma_format == 1 ? chroma_qp_map(qPi) : (qPi < 51 ? qPi : 51);
-  }
-  const hm_slice& sl = slice_at(dp, v, lx, ly);
-  const int tco = sl.tc_offset_div2 * 2;
-  int tc[2];
-  tc[0] = bS0 == 2 ? c_tc[clip3i(0, 53, QP_C0 + 2 + tco)] * (1 << (bd - 8)) : 0;
-  tc[1] = bS1 == 2 ? c_tc[clip3i(0, 53, QP_C1 + 2 + tco)] * (1 << (bd - 8)) : 0;
-  uint8_t* plane = dp.plane[cp + 1];
-  const int pitch = dp.pitch[cp + 1];
-  bool cmod_p[2] = {true, true}, cmod_q[2] = {true, true};
-  if (PCMF && (dp.flags & HM_PIC_PCMF)) {
-    // deblock.cc:1724-1756 + fallback-postfilter.h:138-180: a side is filtered unless it is transquant-bypass or
-    // (pcm_loop_filter_disable_flag and PCM); for vertical edges the reference tests the P flag for both sides
-    const int mask = (dp.pcm_loop_filter_disabled ? 4 : 0) | 8;
+  };
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int xq = vertical ? lx : lx + 4 * sw * j, yq = vertical ? ly + 4 * sh * j : ly;
-      const bool fq = !(lossless_bits(dp, xq, yq) & mask);
-      const bool fp = !(lossless_bits(dp, vertical ? xq - 1 : xq, vertical ? yq : yq - 1) & mask);
-      cmod_p[j] = fp;
-      cmod_q[j] = vertical ? fp : fq;
-    }
+  for (int j = 0; j < 2; j++) {
+    unit_params(1, j, c == 0 ? bsV[j] : (bsV[j] == 2 ? 2 : 0), betaV[j], tcV[j], mpV[j], mqV[j]);
+    unit_params(0, j, c == 0 ? bsH[j] : (bsH[j] == 2 ? 2 : 0), betaH[j], tcH[j], mpH[j], mqH[j]);
   }
-  // 8 samples along the edge, p1 p0 | q0 q1 across it: row-wise vector accesses
-  if (vertical) {
+
+  // ---- the window ----
+  uint8_t* plane = dp.plane[c];
+  const int pitch = dp.pitch[c];
+  Window<Pix> win;
+  // rows outside the picture are clamped (their units have bS 0 and are not stored); columns left of / right of the
+  // picture are read as they lie in memory (inside the batch's allocation, never used) and not stored
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const int t = tc[k >> 2];
-      if (t == 0) continue;
-      Pix* row = reinterpret_cast<Pix*>(plane + (size_t)(yDi + k) * pitch) + xDi - 2;
-      Pix w[4];
-      __builtin_memcpy(w, row, 4 * sizeof(Pix));
-      const int p1 = w[0], p0 = w[1], q0 = w[2], q1 = w[3];
-      const int delta = clip3i(-t, t, ((((q0 - p0) * 4) + p1 - q1 + 4) >> 3));
-      Pix o[2] = {cmod_p[k >> 2] ? (Pix)clip3i(0, maxv, p0 + delta) : (Pix)p0, cmod_q[k >> 2] ? (Pix)clip3i(0, maxv, q0 - delta) : (Pix)q0};
-      __builtin_memcpy(row + 1, o, 2 * sizeof(Pix));
-    }
+  for (int r = 0; r < 8; r++) {
+    const int y = oy + r < 0 ? 0 : (oy + r < PH ? oy + r : PH - 1);
+    __builtin_memcpy(win.w[r], plane + (size_t)y * pitch + (ptrdiff_t)ox * (int)sizeof(Pix), 8 * sizeof(Pix));
+  }
+  if (c == 0) {
+    filter_luma<true>(win, betaV, tcV, maxv, mpV, mqV);
+    filter_luma<false>(win, betaH, tcH, maxv, mpH, mqH);
   }
   else {
-    Pix r[4][8];
+    filter_chroma<true>(win, tcV, maxv, mpV, mqV);
+    filter_chroma<false>(win, tcH, maxv, mpH, mqH);
+  }
+  const bool left_ok = ox >= 0, right_ok = ex < PW;
 #pragma unroll
-    for (int j = 0; j < 4; j++) __builtin_memcpy(r[j], reinterpret_cast<const Pix*>(plane + (size_t)(yDi - 2 + j) * pitch) + xDi, 8 * sizeof(Pix));
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const int t = tc[k >> 2];
-      const int p1 = r[0][k], p0 = r[1][k], q0 = r[2][k], q1 = r[3][k];
-      const int delta = clip3i(-t, t, ((((q0 - p0) * 4) + p1 - q1 + 4) >> 3)); // t == 0 leaves the samples unchanged
-      if (cmod_p[k >> 2]) r[1][k] = (Pix)clip3i(0, maxv, p0 + delta);
-      if (cmod_q[k >> 2]) r[2][k] = (Pix)clip3i(0, maxv, q0 - delta);
-    }
-    __builtin_memcpy(reinterpret_cast<Pix*>(plane + (size_t)(yDi - 1) * pitch) + xDi, r[1], 8 * sizeof(Pix));
-    __builtin_memcpy(reinterpret_cast<Pix*>(plane + (size_t)yDi * pitch) + xDi, r[2], 8 * sizeof(Pix));
+  for (int r = 0; r < 8; r++) {
+    const int y = oy + r;
+    if (y < 0 || y >= PH) continue;
+    uint8_t* row = plane + (size_t)y * pitch + (ptrdiff_t)ox * (int)sizeof(Pix);
+    constexpr int HALF = 4 * (int)sizeof(Pix), HW = Window<Pix>::WORDS / 2;
+    if (left_ok && right_ok) __builtin_memcpy(row, win.w[r], 2 * HALF);
+    else if (left_ok) __builtin_memcpy(row, win.w[r], HALF);
+    else if (right_ok) __builtin_memcpy(row + HALF, win.w[r] + HW, HALF);
   }
 }
 
@@ -618,25 +635,24 @@ __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict_
 
 } // namespace
 
-template <typename Pix, bool RARE>
-static void launch_deblock(const hm_dev_pic* d_pics, int n_pics, int blocks, hipStream_t s)
-{
-  // all vertical edges of every picture first, then the horizontal ones (deblock.cc:1775-1803)
-  hipLaunchKernelGGL((k_deblock<Pix, true, RARE>), dim3(blocks, n_pics), dim3(256), 0, s, d_pics);
-  hipLaunchKernelGGL((k_deblock<Pix, false, RARE>), dim3(blocks, n_pics), dim3(256), 0, s, d_pics);
-}
-
 extern "C" int hm_launch_deblock(const hm_dev_pic* d_pics, int n_pics, int max_w4, int max_h4, int chroma_format,
                                  int bit_depth, int rare_syntax, hipStream_t s)
 {
   if (n_pics <= 0) return HM_OK;
-  const int lw = (max_w4 + 1) >> 1, lh = (max_h4 + 1) >> 1;
+  // windows per picture: ((w/8) + 1) x ((h/8) + 1) for luma, the same count in chroma samples for Cb and Cr
+  const int w = max_w4 * 4, h = max_h4 * 4;
   const int sw = chroma_format == 3 ? 1 : 2, sh = chroma_format == 1 ? 2 : 1;
-  const int cwn = (max_w4 + 2 * sw - 1) / (2 * sw), chn = (max_h4 + 2 * sh - 1) / (2 * sh);
-  const long items = (long)lw * lh + 2L * cwn * chn;
-  const int blocks = (int)((items + 255) / 256);
-  if (bit_depth > 8) rare_syntax ? launch_deblock<uint16_t, true>(d_pics, n_pics, blocks, s) : launch_deblock<uint16_t, false>(d_pics, n_pics, blocks, s);
-  else rare_syntax ? launch_deblock<uint8_t, true>(d_pics, n_pics, blocks, s) : launch_deblock<uint8_t, false>(d_pics, n_pics, blocks, s);
+  const long luma = (long)((w >> 3) + 1) * ((h >> 3) + 1);
+  const long chroma = chroma_format == 0 ? 0 : (long)(((w / sw + 7) >> 3) + 1) * (((h / sh + 7) >> 3) + 1);
+  const dim3 grid((int)((luma + 2 * chroma + 255) / 256), n_pics);
+  if (bit_depth > 8) {
+    if (rare_syntax) hipLaunchKernelGGL((k_deblock<uint16_t, true>), grid, dim3(256), 0, s, d_pics);
+    else hipLaunchKernelGGL((k_deblock<uint16_t, false>), grid, dim3(256), 0, s, d_pics);
+  }
+  else {
+    if (rare_syntax) hipLaunchKernelGGL((k_deblock<uint8_t, true>), grid, dim3(256), 0, s, d_pics);
+    else hipLaunchKernelGGL((k_deblock<uint8_t, false>), grid, dim3(256), 0, s, d_pics);
+  }
   return hm_check_hip(hipGetLastError(), "k_deblock launch");
 }
 

@@ -31,6 +31,7 @@ struct hm_dev_pic {
   int32_t flags;            // hm_pic.flags
   int32_t cb_qp_offset, cr_qp_offset; // pps offsets (chroma deblocking QpC)
   int32_t pcm_loop_filter_disabled;   // sps.pcm_loop_filter_disable_flag
+  int32_t n_slices;                   // hm_pic.n_slices
   // sections of the command stream, resolved on the host so that the filter kernels need no dependent load of the header
   const hm_slice* slices;
   const hm_ctb* ctbs;
