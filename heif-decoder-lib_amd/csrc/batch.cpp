@@ -120,6 +120,15 @@ void hm_batch_clear(hm_batch* b)
 int hm_batch_add(hm_batch* b, const uint8_t* blob, size_t size, const hm_tile_dest* dest)
 {
   if (!b || !blob || !dest) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
+  const int rc = hm_stream_validate(blob, size);
+  if (rc) return rc;
+  return hm_batch_add_trusted(b, blob, size, dest);
+}
+
+// hm_decode_item's own streams (fresh out of hm_hevc_parse) skip the structural walk
+int hm_batch_add_trusted(hm_batch* b, const uint8_t* blob, size_t size, const hm_tile_dest* dest)
+{
+  if (!b || !blob || !dest) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
   if (size < sizeof(hm_pic)) return hm_fail(HM_ERR_INVALID_ARG, "command stream too small");
   Item it;
   std::memcpy(&it.hdr, blob, sizeof(hm_pic));

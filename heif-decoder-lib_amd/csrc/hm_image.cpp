@@ -435,7 +435,7 @@ int decode_planar(const hm_file* f, uint32_t id, const hm_decode_params* params,
     d.x0 = tiles[i].x0; d.y0 = tiles[i].y0;
     // the range rescale belongs to the grid paste only (context.cc:2504-2528)
     d.tile_has_nclx = is_grid ? 1 : 0; d.tile_full_range = tp.full_range; d.tile_matrix = tp.matrix;
-    const int idx = hm_batch_add(batch, blobs[i].p, blobs[i].n, &d);
+    const int idx = hm_batch_add_trusted(batch, blobs[i].p, blobs[i].n, &d);
     if (idx < 0) return idx;
   }
   lap("planes allocated, batch queued");

@@ -1,0 +1,71 @@
+// stream_check.cpp — structural validation of command streams handed to the C ABI from outside (pure host code).
+#include <cstdint>
+#include <cstring>
+
+#include "heif_mi355x.h"
+#include "hm_internal.h"
+#include "hm_stream.h"
+
+// A command stream that did not come straight out of hm_hevc_parse in this process (file, network, another
+// process) is input like any other: the kernels index LDS and HBM with its fields, so everything they use as an
+// index or a size is checked here, once, on the host.  O(records + levels).
+static const char* validate_stream(const uint8_t* blob, size_t size)
+{
+  hm_pic h;
+  std::memcpy(&h, blob, sizeof(h));
+  const uint64_t total = h.total_bytes;
+  if (total > size) return "total_bytes";
+  if (h.log2_ctb < 4 || h.log2_ctb > 6 || h.chroma_format > 3) return "CTB size / chroma format";
+  if (h.bit_depth_y < 8 || h.bit_depth_y > 12 || (h.chroma_format && h.bit_depth_c != h.bit_depth_y)) return "bit depth";
+  if (h.width == 0 || h.height == 0 || h.width > 16384 || h.height > 16384 || (h.width & 7) || (h.height & 7)) return "picture size";
+  const int ctb = 1 << h.log2_ctb;
+  if (h.ctb_w != (h.width + ctb - 1) / ctb || h.ctb_h != (h.height + ctb - 1) / ctb || h.n_ctbs != (uint32_t)h.ctb_w * h.ctb_h) return "CTB counts";
+  if (h.crop_left + h.crop_right >= h.width || h.crop_top + h.crop_bottom >= h.height) return "conformance window";
+  auto section = [&](uint64_t off, uint64_t count, uint64_t elem) { return (off & 3) == 0 && off >= sizeof(hm_pic) && off <= total && count * elem <= total - off; };
+  if (h.n_slices == 0 || !section(h.off_slices, h.n_slices, sizeof(hm_slice)) || !section(h.off_ctbs, h.n_ctbs, sizeof(hm_ctb)) ||
+      !section(h.off_tus, h.n_tus, sizeof(hm_tu)) || !section(h.off_coeffs, h.n_coeffs, sizeof(hm_coeff)))
+    return "section offsets";
+  if ((h.flags & HM_PIC_SCALING_LIST) && !section(h.off_scaling, HM_SCALING_BYTES, 1)) return "scaling tables";
+  if (h.n_tus == 0) return "no records";
+  const hm_ctb* ctbs = reinterpret_cast<const hm_ctb*>(blob + h.off_ctbs);
+  const hm_tu* tus = reinterpret_cast<const hm_tu*>(blob + h.off_tus);
+  const hm_coeff* cf = reinterpret_cast<const hm_coeff*>(blob + h.off_coeffs);
+  const int sw = h.chroma_format == 3 ? 1 : 2, sh = h.chroma_format == 1 ? 2 : 1;
+  uint64_t next = 0;
+  for (uint32_t i = 0; i < h.n_ctbs; i++) {
+    const hm_ctb& c = ctbs[i];
+    if (c.slice_idx >= h.n_slices) return "slice index";
+    if (c.tu_first != next) return "records of the CTBs are not contiguous in raster order";
+    next += c.tu_count;
+    if (next > h.n_tus) return "record range of a CTB";
+    for (int k = 0; k < 3; k++)
+      if (c.sao[k].type > 2 || c.sao[k].eo_class > 3 || c.sao[k].band_position > 31) return "SAO parameters";
+    for (uint32_t t = c.tu_first; t < next; t++) {
+      const hm_tu& u = tus[t];
+      const int log2 = u.info & HM_TU_LOG2_MASK, cidx = (u.info >> HM_TU_CIDX_SHIFT) & 3, nT = 1 << log2;
+      if (log2 < 2 || log2 > 5 || cidx > 2 || (cidx && h.chroma_format == 0)) return "block size / component";
+      const int bw = cidx ? ctb / sw : ctb, bh = cidx ? ctb / sh : ctb;
+      if (u.x + nT > bw || u.y + nT > bh || ((u.x | u.y) & 3)) return "block position";
+      if ((u.pred_mode & HM_TU_MODE_MASK) > 34) return "prediction mode";
+      if (u.avail_left > nT || u.avail_top > nT || u.avail_bottom_left > nT || u.avail_top_right > nT) return "neighbour availability";
+      if ((uint64_t)u.coeff_first + u.n_coeff > h.n_coeffs || u.n_coeff > nT * nT) return "level range of a record";
+      if ((u.pred_mode & HM_TU_MODE_PCM) && u.n_coeff != nT * nT) return "PCM sample count";
+      for (uint32_t q = 0; q < u.n_coeff; q++)
+        if (cf[u.coeff_first + q].pos >= nT * nT) return "level position";
+    }
+  }
+  if (next != h.n_tus) return "record count";
+  return nullptr;
+}
+
+int hm_stream_validate(const uint8_t* blob, size_t size)
+{
+  if (!blob) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
+  if (size < sizeof(hm_pic)) return hm_fail(HM_ERR_INVALID_ARG, "command stream too small");
+  uint32_t magic;
+  std::memcpy(&magic, blob, 4);
+  if (magic != HM_STREAM_MAGIC) return hm_fail(HM_ERR_INVALID_ARG, "not a command stream");
+  if (const char* what = validate_stream(blob, size)) return hm_fail(HM_ERR_INVALID_ARG, "malformed command stream: %s", what);
+  return HM_OK;
+}
+

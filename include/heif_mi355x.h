@@ -140,6 +140,9 @@ HM_API int  hm_batch_create(hm_batch** out);
 HM_API void hm_batch_destroy(hm_batch* b);
 HM_API void hm_batch_clear(hm_batch* b);
 /* queue one picture (command stream from hm_hevc_parse; copied); returns its index (>= 0) or a status */
+/* Structural check of a command stream that did not come straight out of hm_hevc_parse (everything the kernels use
+ * as an index or a size); hm_batch_add runs it on every stream it is given.  HM_OK or HM_ERR_INVALID_ARG. */
+HM_API int  hm_stream_validate(const uint8_t* blob, size_t size);
 HM_API int  hm_batch_add(hm_batch* b, const uint8_t* blob, size_t size, const hm_tile_dest* dest);
 HM_API int  hm_batch_size(const hm_batch* b);
 /* copy the queued command streams to the device and build the job descriptors (synchronous) */

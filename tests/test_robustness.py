@@ -134,3 +134,50 @@ def test_mutated_heif_boxes_never_crash(hm):
             except RuntimeError:
                 err += 1
     assert ok + err == 1200 and err > 50 and ok > 50
+
+
+def test_foreign_command_streams_are_validated(hm):
+    """hm_stream_validate (run by hm_batch_add on every stream it is given): streams of the parser pass; corrupting any
+    field the kernels use as an index or a size is caught on the host; the validator itself survives arbitrary bytes."""
+    import ctypes as C
+    import struct
+    hm.hm_stream_validate.argtypes = [C.c_char_p, C.c_size_t]
+    names = ("tiny", "ragged", "ctb64_wpp", "hi422_10", "pcm_bypass_sl_wpp", "yuv444_rare", "mono10")
+    blobs = [hevcutil.parse(hm, corpus.stream(n)) for n in names]
+    for b in blobs:
+        assert hm.hm_stream_validate(b, len(b)) == 0, hm.hm_last_error()
+    b = bytearray(blobs[2])
+    # hm_pic (include/hm_stream.h): n_slices, n_ctbs, n_tus, n_coeffs at 0x2C.., off_slices, off_ctbs, off_tus, off_coeffs at 0x3C..
+    off = {name: struct.unpack_from("<I", b, pos)[0] for name, pos in (("ctbs", 0x40), ("tus", 0x44), ("coeffs", 0x48))}
+
+    def bad(mut):
+        m = bytearray(b)
+        mut(m)
+        return hm.hm_stream_validate(bytes(m), len(m)) != 0
+
+    def put(fmt, pos, val):
+        return lambda m: struct.pack_into(fmt, m, pos, val)
+
+    tus, cfs, ctbs = off["tus"], off["coeffs"], off["ctbs"]
+    assert bad(put("<I", 4, len(b) + 1))                       # total_bytes beyond the buffer
+    assert bad(put("<I", 0x34, 0xFFFFFFF))                     # n_tus
+    assert bad(put("<I", 0x44, len(b) - 4))                    # off_tus
+    assert bad(put("<B", tus + 2, 7))                          # block size 2^7
+    assert bad(put("<B", tus + 0, 200))                        # block outside its CTB
+    assert bad(put("<B", tus + 3, 63))                         # prediction mode 63
+    assert bad(put("<H", tus + 6, 5000))                       # n_coeff > nT^2
+    assert bad(put("<I", tus + 8, 0x7FFFFFFF))                 # coeff_first
+    assert bad(put("<B", tus + 12, 250))                       # avail_left > nT
+    assert bad(put("<I", ctbs, 7))                             # tu_first of CTB 0 (records not contiguous)
+    assert bad(put("<H", ctbs + 6, 9))                         # slice index
+    assert bad(put("<B", ctbs + 12, 9))                        # SAO type
+    first_cf = next(struct.unpack_from("<I", b, tus + 16 * t + 8)[0] for t in range(64) if struct.unpack_from("<H", b, tus + 16 * t + 6)[0])
+    assert bad(put("<H", cfs + 4 * first_cf, 60000))           # level position outside the block
+    rng = random.Random(7)
+    for _ in range(3000):                                      # arbitrary corruption: any verdict, no crash
+        m = bytearray(blobs[rng.randrange(len(blobs))])
+        for _ in range(rng.randrange(1, 8)):
+            m[rng.randrange(len(m))] = rng.randrange(256)
+        hm.hm_stream_validate(bytes(m), len(m))
+        cut = rng.randrange(len(m))
+        hm.hm_stream_validate(bytes(m[:cut]), cut)

@@ -49,7 +49,7 @@ int main(int argc, char** argv)
 {
   int iterations = 2000;
   if (const char* e = std::getenv("HM_FUZZ_ITER")) iterations = std::atoi(e);
-  long heif_ok = 0, heif_err = 0, hevc_ok = 0, hevc_err = 0;
+  long heif_ok = 0, heif_err = 0, hevc_ok = 0, hevc_err = 0, stream_ok = 0, stream_err = 0;
   for (int a = 1; a < argc; a++) {
     const std::string path = argv[a];
     const std::vector<uint8_t> seed = slurp(argv[a]);
@@ -79,11 +79,25 @@ int main(int argc, char** argv)
       }
       else {
         uint8_t* blob = nullptr; size_t n = 0;
-        if (hm_hevc_parse(b.data(), b.size(), path.find(".hevc") != std::string::npos ? 1 : 0, &blob, &n) == 0) { hevc_ok++; hm_free(blob); }
+        if (hm_hevc_parse(b.data(), b.size(), path.find(".hevc") != std::string::npos ? 1 : 0, &blob, &n) == 0) {
+          hevc_ok++;
+          // the command stream as foreign input: the validator must accept the parser's output and survive anything
+          if (hm_stream_validate(blob, n) != 0) { std::fprintf(stderr, "validator rejects a parser stream: %s\n", hm_last_error()); return 3; }
+          std::vector<uint8_t> s(blob, blob + n);
+          for (int k = 0; k < 8; k++) {
+            std::vector<uint8_t> m = s;
+            mutate(m, m.size());
+            (hm_stream_validate(m.data(), m.size()) == 0 ? stream_ok : stream_err)++;
+            const size_t cut = rnd() % (m.size() + 1);
+            hm_stream_validate(m.data(), cut);
+          }
+          hm_free(blob);
+        }
         else hevc_err++;
       }
     }
   }
-  std::printf("heif ok %ld err %ld | hevc ok %ld err %ld\n", heif_ok, heif_err, hevc_ok, hevc_err);
+  std::printf("heif ok %ld err %ld | hevc ok %ld err %ld | mutated command streams accepted %ld rejected %ld\n", heif_ok, heif_err, hevc_ok, hevc_err,
+              stream_ok, stream_err);
   return 0;
 }
