@@ -254,6 +254,7 @@ constexpr uint64_t filter_mode_mask(int log2)
 // them in place: all lanes read their three neighbours, then all lanes write.
 // Written select-style on purpose (both candidates computed, then chosen): a ternary with arithmetic in
 // its arms becomes an exec-mask branch, i.e. several scalar instructions per lane-level decision.
+#define META_BYTES(ctb) (((ctb) >> 2) * ((ctb) >> 2) * 2) // 16-bit block map of one CTU
 constexpr int SMOOTH_CHROMA = 0x10000; // with the picture flags: chroma reference samples are smoothed like luma ones (4:4:4)
 template <typename Pix, int L2>
 __device__ __forceinline__ void make_border(const Blk<Pix>& b, int16_t* bA, int strong, int lane)
@@ -611,6 +612,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
   int16_t* const l_coeff = reinterpret_cast<int16_t*>(lp); lp += 512; // up to 16x16
   int16_t* const l_tmp = reinterpret_cast<int16_t*>(lp); lp += 512;
   int16_t* const l_bA = reinterpret_cast<int16_t*>(lp); lp += 272;
+  uint16_t* const l_meta = reinterpret_cast<uint16_t*>(lp); lp += META_BYTES(ctb); // block map of the current CTU
   Pix* const u0 = reinterpret_cast<Pix*>(lp); lp += (size_t)P0 * ctb * sizeof(Pix);
   Pix* const u1 = reinterpret_cast<Pix*>(lp); lp += (size_t)P1 * ch_c * sizeof(Pix);
   Pix* const u2 = reinterpret_cast<Pix*>(lp); lp += (size_t)P1 * ch_c * sizeof(Pix);
@@ -799,9 +801,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
               const int left_ok = (B.x0 > 0) | ((cb_flags & HM_CTB_DEBLOCK_LEFT) != 0);
               const int top_ok = (B.y0 > 0) | ((cb_flags & HM_CTB_DEBLOCK_TOP) != 0);
               const int e = ((i == 0) & left_ok & deblock_en) | (((j == 0) & top_ok & deblock_en) << 1);
-              const uint32_t mo = (uint32_t)((B.x0 >> 2) + i) + __umul24((uint32_t)((B.y0 >> 2) + j), (uint32_t)dp.w4);
-              // bits 2 / 3: PCM / transquant-bypass coding unit (the loop filters leave such samples alone)
-              ctb_meta[mo] = (uint16_t)(e | ((lossless & 2) << 1) | ((lossless & 1) << 3) | ((qpy & 0xFF) << 8));
+              // bits 2 / 3: PCM / transquant-bypass coding unit (the loop filters leave such samples alone).
+              // Collected in LDS and written to the picture's block map once per CTU (one coalesced store pass
+              // instead of a global store instruction per block).
+              l_meta[(((B.y0 >> 2) + j) << (log2_ctb - 2)) + (B.x0 >> 2) + i] =
+                  (uint16_t)(e | ((lossless & 2) << 1) | ((lossless & 1) << 3) | ((qpy & 0xFF) << 8));
             }
           }
         };
@@ -843,6 +847,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
           flush_plane(std::integral_constant<int, (ctb >> 1)>(), u2, P1, lw + lo2, dp.plane[2], dp.pitch[2], ch_c, planeWc, planeHc);
         }
       }
+      { // the CTU's block map; cells outside the picture were never written
+        constexpr int M4 = ctb >> 2;
+        const int gx0 = cx << (log2_ctb - 2), gy0 = row << (log2_ctb - 2);
+#pragma unroll
+        for (int idx0 = 0; idx0 < M4 * M4; idx0 += 64) {
+          const int idx = idx0 + lane, bi = idx & (M4 - 1), bj = idx >> (log2_ctb - 2);
+          if (idx < M4 * M4 && gx0 + bi < dp.w4 && gy0 + bj < dp.h4) ctb_meta[(uint32_t)bi + __umul24((uint32_t)bj, (uint32_t)dp.w4)] = l_meta[idx];
+        }
+      }
       // ---- publish progress: only LDS traffic has to be ordered (the picture stores stay in flight) ----
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
       if (lane == 0) __hip_atomic_store(&progress[row], cx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -856,7 +869,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
 static int per_wave_lds(int ctb, int chroma_format, int pix_bytes)
 {
   const int cw = chroma_format == 3 ? ctb : ctb / 2, ch = chroma_format == 1 ? ctb / 2 : ctb;
-  int b = 512 + 512 + 272;
+  int b = 512 + 512 + 272 + META_BYTES(ctb);
   b += (ctb + UPAD) * ctb * pix_bytes + 2 * (cw + UPAD) * ch * pix_bytes;
   return (b + 15) & ~15;
 }
