@@ -220,7 +220,7 @@ def main():
 
     # clock (D) of SURVEY 8d: H2D of the command streams + kernels, result on the device (not `value`)
     d_ms = None
-    if rank == 0 and not args.no_e2e:
+    if rank == 0 and world == 1 and not args.no_e2e:  # the side clocks belong to the single-GPU run
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(3):
@@ -262,9 +262,9 @@ def main():
             out["device_inclusive"] = {"ms_per_step": round(d_ms, 3), "MP_per_s": round(B * MP_PER_IMAGE / d_ms * 1e3, 1),
                                        "command_stream_bytes": int(stream_b),
                                        "note": "H2D of the command streams (pinned staging) + all kernels, RGB left on the device; 1 GPU"}
-        if not args.no_e2e:
+        if not args.no_e2e and world == 1:
             out["end_to_end"] = end_to_end(pkg, images[0])
-        if args.cpu_seconds > 0:
+        if args.cpu_seconds > 0 and world == 1:  # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(images[0], strides, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if dist:
