@@ -498,11 +498,11 @@ template <typename Pix, bool RARE>
 __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict__ pics, int apply_sao)
 {
   const hm_dev_pic& dp = pics[blockIdx.y];
-  // One wave = a 64 x 16 tile; one lane = 8 consecutive samples of two vertically adjacent rows.  Each lane has
+  // One wave = a 128 x 8 tile (full 128-byte rows; measured against 64 x 16, 32 x 32 and 256 x 4); one lane = 8 consecutive samples of two vertically adjacent rows.  Each lane has
   // little arithmetic and a chain of dependent memory round trips (descriptor -> rows / CTB record -> store), so the
   // kernel is paced by latency x waves in flight: two rows per lane, with all four source rows, their side samples
   // and both CTB records fetched before anything is decided, halves the number of wave rounds.
-  constexpr int G = 8, TW = 64, TH = 16, R = 2;
+  constexpr int G = 8, TW = 128, TH = 8, R = 2;
   const int wt = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int tx0 = (dp.copy_w[0] + TW - 1) / TW, n0 = dp.copy_w[0] > 0 && dp.copy_h[0] > 0 ? tx0 * ((dp.copy_h[0] + TH - 1) / TH) : 0;
   const int tx1 = (dp.copy_w[1] + TW - 1) / TW, n1 = dp.copy_w[1] > 0 && dp.copy_h[1] > 0 ? tx1 * ((dp.copy_h[1] + TH - 1) / TH) : 0;
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict_
   const int txc = c == 0 ? tx0 : (c == 1 ? tx1 : tx2);
   const int ty = local / txc, tx = local - ty * txc;
   const int cw = dp.copy_w[c], chh = dp.copy_h[c];
-  const int yd0 = ty * TH + (lane >> 3) * R, x8 = tx * TW + (lane & 7) * G; // destination coordinates
+  const int yd0 = ty * TH + (lane >> 4) * R, x8 = tx * TW + (lane & 15) * G; // destination coordinates
   if (yd0 >= chh || x8 >= cw) return;
   const PicView v = view(dp);
   const int sh = c ? (dp.chroma_format == 1 ? 2 : 1) : 1;
@@ -660,10 +660,10 @@ extern "C" int hm_launch_sao_paste(const hm_dev_pic* d_pics, int n_pics, int max
                                    int rare_syntax, hipStream_t s)
 {
   if (n_pics <= 0) return HM_OK;
-  // 64 x 16-sample tiles of the three planes (chroma at most as large as luma); one wave per tile, four per block
-  const long luma = (long)((max_w + 63) / 64) * ((max_h + 15) / 16);
+  // 128 x 8-sample tiles of the three planes (chroma at most as large as luma); one wave per tile, four per block
+  const long luma = (long)((max_w + 127) / 128) * ((max_h + 7) / 8);
   const int cwm = rare_syntax ? max_w : (max_w + 1) / 2; // rare-syntax classes may hold 4:4:4 pictures
-  const long chroma = (long)((cwm + 63) / 64) * ((max_h + 15) / 16); // 4:2:2 height bound
+  const long chroma = (long)((cwm + 127) / 128) * ((max_h + 7) / 8); // 4:2:2 height bound
   const dim3 grid((int)((luma + 2 * chroma + 3) / 4), n_pics);
   if (bit_depth > 8) {
     if (rare_syntax) hipLaunchKernelGGL((k_sao_paste<uint16_t, true>), grid, dim3(256), 0, s, d_pics, apply_sao);
