@@ -818,18 +818,31 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
       // ---- finished CTU: coalesced 4-byte stores to the picture, bottom row -> line, right column -> left column ----
       auto flush_plane = [&](auto bw_c, Pix* u, int P, Pix* line, uint8_t* plane, int pitch, int bh, int pw, int ph) {
         constexpr int BW = decltype(bw_c)::value;
-        constexpr int PPW = 4 / sizeof(Pix), WPR = BW / PPW, RPT = 64 / WPR; // samples per 32-bit word, words per row, rows per trip
+        constexpr int PPW = 4 / sizeof(Pix), WPR = BW / PPW; // samples per 32-bit word, words per row
         static_assert(WPR >= 1 && WPR <= 64 && (WPR & (WPR - 1)) == 0, "CTB row must be 1..64 words");
+        // picture stores in chunks of up to 16 bytes per lane (one store instruction moves 1 KiB).  A chunk that starts
+        // inside the picture may end in the row's padding (the pitch is a multiple of 64 bytes), never in another row.
+        constexpr int CW = WPR < 4 ? WPR : 4, LPR = WPR / CW, RPT = 64 / LPR; // words per chunk, lanes per row, rows per trip
         const int xo = cx * BW, yo = row * bh;
         const int vw = (pw - xo) < BW ? (pw - xo) : BW; // valid part inside the picture
         const int vh = (ph - yo) < bh ? (ph - yo) : bh;
-        const int q = lane & (WPR - 1), r0 = lane / WPR;
-        const bool col_ok = q * PPW < vw;
-        GLOBAL_AS uint8_t* const gp = gptr_w<uint8_t>(plane + (size_t)yo * pitch + (size_t)(xo + q * PPW) * sizeof(Pix));
-        for (int rb = 0; rb < vh; rb += RPT) { // scalar trip counter; lanes only differ in (row, word)
+        const int q = lane & (LPR - 1), r0 = lane / LPR;
+        const bool col_ok = q * CW * PPW < vw;
+        GLOBAL_AS uint8_t* const gp = gptr_w<uint8_t>(plane + (size_t)yo * pitch + (size_t)(xo + q * CW * PPW) * sizeof(Pix));
+        for (int rb = 0; rb < vh; rb += RPT) { // scalar trip counter; lanes only differ in (row, chunk)
           const int r = rb + r0;
-          if (col_ok && r < vh)
-            *reinterpret_cast<GLOBAL_AS uint32_t*>(gp + (uint32_t)mul24(r, pitch)) = *reinterpret_cast<const uint32_t*>(u + mul24(r, P) + UPAD + q * PPW);
+          if (col_ok && r < vh) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(u + mul24(r, P) + UPAD + q * CW * PPW); // rows are 4-byte aligned
+            uint32_t v[CW];
+#pragma unroll
+            for (int k = 0; k < CW; k++) v[k] = src[k];
+            GLOBAL_AS uint32_t* dst = reinterpret_cast<GLOBAL_AS uint32_t*>(gp + (uint32_t)mul24(r, pitch));
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            if (CW == 4) *reinterpret_cast<GLOBAL_AS u32x4*>(dst) = u32x4{v[0], v[1], v[2], v[3]};
+            else if (CW == 2) *reinterpret_cast<GLOBAL_AS u32x2*>(dst) = u32x2{v[0], v[1]};
+            else dst[0] = v[0];
+          }
         }
         if (lane < WPR)
           *reinterpret_cast<uint32_t*>(line + xo + lane * PPW) = *reinterpret_cast<const uint32_t*>(u + (bh - 1) * P + UPAD + lane * PPW);
