@@ -119,7 +119,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--images", type=int, default=384, help="12 MP images per GPU per step (384 x 48 = 18432 independent tiles, 25 GB of the 288 GB HBM; "
-                    "the reconstruction kernel's end-of-launch tail amortises with the batch: 48 images give 70, 192 give 82, 384 give 85, 768 give 86 GP/s)")
+                    "the reconstruction kernel's end-of-launch tail amortises with the batch: 48 images give 70, 192 give 83, 384 give 86, 768 give 87 GP/s)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N>1 code path on one GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-e2e", action="store_true", help="skip the hm_decode_item single-image clock (profiling runs)")
