@@ -671,6 +671,7 @@ class SliceWalker {
         emit_block(x0 / sw, y0 / shh, log2C, c, cmode, cbf & 1);
         if (cat == 2) emit_block(x0 / sw, y0 / shh + (1 << log2C), log2C, c, cmode, (cbf >> 1) & 1);
       }
+      if (cat == 2) interleave_422_records();
     }
     else if (blkIdx == 3) {
       const int cmode = chroma_mode_[0];
@@ -679,7 +680,16 @@ class SliceWalker {
         emit_block(xBase / sw, yBase / shh, 2, c, cmode, cbf & 1);
         if (cat == 2) emit_block(xBase / sw, yBase / shh + 4, 2, c, cmode, (cbf >> 1) & 1);
       }
+      if (cat == 2) interleave_422_records();
     }
+  }
+  // 4:2:2: the syntax carries Cb upper, Cb lower, Cr upper, Cr lower; the records are stored as Cb upper, Cr upper,
+  // Cb lower, Cr lower.  The planes are independent and each keeps its own order, so the result is the same - and a
+  // 4x4 Cb block is again directly followed by its Cr twin, which the kernel reconstructs in one pass.
+  void interleave_422_records()
+  {
+    auto& v = pic_.ctb_tus[ctb_addr_rs_];
+    std::swap(v[v.size() - 3], v[v.size() - 2]);
   }
 
   // one (component) block: optional residual_coding(), then the hm_tu record
