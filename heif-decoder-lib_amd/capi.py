@@ -94,10 +94,11 @@ def stream_header(blob):
     """(width, height, chroma_format, bit_depth, flags, full_range, matrix, primaries, has_vui_colour) of a command stream."""
     import struct
     magic, total, w, h = struct.unpack_from("<IIHH", blob, 0)
+    cl, cr, ct, cb = struct.unpack_from("<4H", blob, 12)
     cf, bdy, bdc, l2ctb = struct.unpack_from("<BBBB", blob, 20)
     flags, = struct.unpack_from("<I", blob, 36)
     prim, trc, mat, fr = struct.unpack_from("<BBBB", blob, 40)
-    return dict(width=w, height=h, chroma_format=cf, bit_depth=bdy, log2_ctb=l2ctb, flags=flags,
+    return dict(width=w, height=h, crop=(cl, cr, ct, cb), chroma_format=cf, bit_depth=bdy, log2_ctb=l2ctb, flags=flags,
                 primaries=prim, transfer=trc, matrix=mat, full_range=fr, has_vui_colour=bool(flags & 0x10))
 
 

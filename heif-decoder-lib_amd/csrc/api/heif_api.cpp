@@ -61,7 +61,8 @@ int interleaved_components(heif_chroma c)
 
 struct heif_context {
   hm_file* file = nullptr;
-  int max_threads = 0; // 0 = decode on the calling thread (context.h:558)
+  int max_decoding_threads = 0; // tile fan-out of a grid; 0 = decode on the calling thread (context.h:558)
+  int max_decoder_threads = 0;  // threads handed to the decoder of a single image (new_decoder(&dec, n))
   ~heif_context() { if (file) hm_file_close(file); }
 };
 struct heif_image_handle {
@@ -76,6 +77,7 @@ struct heif_image {
   std::map<int, std::unique_ptr<Plane>> planes;
   bool has_nclx = false;
   heif_color_profile_nclx nclx{};
+  std::vector<std::pair<heif_error_code, heif_suberror_code>> warnings; // pixelimage.h: m_warnings
 };
 
 namespace {
@@ -173,11 +175,12 @@ struct heif_error heif_context_get_primary_image_handle(struct heif_context* ctx
   if (e.code) return e;
   return heif_context_get_image_handle(ctx, id, out);
 }
-struct heif_error heif_context_set_threads(struct heif_context* ctx, struct heif_image_handle*, int nthreads)
-{
-  if (!ctx) return err(heif_error_Usage_error, heif_suberror_Null_pointer_argument, "NULL passed");
-  ctx->max_threads = nthreads < 0 ? 0 : nthreads;
-  return ok();
+void heif_context_set_threads(struct heif_context* ctx, const struct heif_image_handle* in_handle, int nthreads)
+{ // heif.cc:499-514: grid -> tile threads, single image -> decoder threads
+  if (!ctx || !in_handle) return;
+  if (nthreads < 0) nthreads = 0;
+  if (in_handle->info.is_grid) { ctx->max_decoding_threads = nthreads; ctx->max_decoder_threads = 0; }
+  else { ctx->max_decoding_threads = 0; ctx->max_decoder_threads = nthreads; }
 }
 void heif_image_handle_release(const struct heif_image_handle* h) { delete h; }
 int heif_image_handle_get_width(const struct heif_image_handle* h) { return h ? h->info.width : 0; }
@@ -219,9 +222,10 @@ struct heif_error heif_decode_image(const struct heif_image_handle* in, struct h
   *out_img = nullptr;
   hm_decode_params prm;
   std::memset(&prm, 0, sizeof(prm));
-  prm.host_threads = in->ctx->max_threads;
+  prm.host_threads = in->info.is_grid ? in->ctx->max_decoding_threads : in->ctx->max_decoder_threads;
   if (opt) {
     prm.ignore_transformations = opt->ignore_transformations;
+    if (opt->version >= 3) prm.strict_decoding = opt->strict_decoding; // heif.cc:1100-1103
     if (opt->version >= 2 && opt->convert_hdr_to_8bit && in->info.bit_depth > 8)
       return err(heif_error_Unsupported_feature, heif_suberror_Unsupported_color_conversion, "convert_hdr_to_8bit needs the reference's bit-depth ops (hdr_sdr.cc), not on the GPU path yet");
     if (opt->decoder_id && std::strcmp(opt->decoder_id, "mi355x") != 0)
@@ -286,6 +290,9 @@ struct heif_error heif_decode_image(const struct heif_image_handle* in, struct h
     img->nclx.color_primaries = dec.primaries; img->nclx.transfer_characteristics = dec.transfer;
     img->nclx.matrix_coefficients = dec.matrix; img->nclx.full_range_flag = (uint8_t)dec.full_range;
   }
+  if (dec.warnings & HM_WARN_UNKNOWN_PRIMARIES) img->warnings.emplace_back(heif_error_Invalid_input, heif_suberror_Unknown_NCLX_color_primaries);
+  if (dec.warnings & HM_WARN_UNKNOWN_TRANSFER) img->warnings.emplace_back(heif_error_Invalid_input, heif_suberror_Unknown_NCLX_transfer_characteristics);
+  if (dec.warnings & HM_WARN_UNKNOWN_MATRIX) img->warnings.emplace_back(heif_error_Invalid_input, heif_suberror_Unknown_NCLX_matrix_coefficients);
   hm_decoded_free(&dec);
   *out_img = img.release();
   return ok();
@@ -350,16 +357,19 @@ void heif_nclx_color_profile_free(struct heif_color_profile_nclx* n) { std::free
 struct heif_error heif_nclx_color_profile_set_color_primaries(struct heif_color_profile_nclx* n, uint16_t v)
 {
   if (!n) return err(heif_error_Usage_error, heif_suberror_Null_pointer_argument, "NULL passed");
+  if (!hm_nclx_code_known(0, v)) { n->color_primaries = 2; return {heif_error_Invalid_input, heif_suberror_Unknown_NCLX_color_primaries, "Unknown NCLX color primaries"}; } // heif.cc:1811-1828
   n->color_primaries = v; return ok();
 }
 struct heif_error heif_nclx_color_profile_set_transfer_characteristics(struct heif_color_profile_nclx* n, uint16_t v)
 {
   if (!n) return err(heif_error_Usage_error, heif_suberror_Null_pointer_argument, "NULL passed");
+  if (!hm_nclx_code_known(1, v)) { n->transfer_characteristics = 2; return {heif_error_Invalid_input, heif_suberror_Unknown_NCLX_transfer_characteristics, "Unknown NCLX transfer characteristics"}; } // heif.cc:1852-1869
   n->transfer_characteristics = v; return ok();
 }
 struct heif_error heif_nclx_color_profile_set_matrix_coefficients(struct heif_color_profile_nclx* n, uint16_t v)
 {
   if (!n) return err(heif_error_Usage_error, heif_suberror_Null_pointer_argument, "NULL passed");
+  if (!hm_nclx_code_known(2, v)) { n->matrix_coefficients = 2; return {heif_error_Invalid_input, heif_suberror_Unknown_NCLX_matrix_coefficients, "Unknown NCLX matrix coefficients"}; } // heif.cc:1888-1905
   n->matrix_coefficients = v; return ok();
 }
 struct heif_error heif_image_set_nclx_color_profile(struct heif_image* i, const struct heif_color_profile_nclx* n)
@@ -376,6 +386,24 @@ struct heif_error heif_image_get_nclx_color_profile(const struct heif_image* i, 
   if (!*out) return err(heif_error_Memory_allocation_error, heif_suberror_Unspecified, "out of memory");
   **out = i->nclx;
   return ok();
+}
+
+// ---- decoding warnings (heif.cc:1223-1245) ----------------------------------------------------------------------
+int heif_image_get_decoding_warnings(struct heif_image* image, int first, struct heif_error* out, int max_entries)
+{
+  if (!image) return 0;
+  if (max_entries == 0) return (int)image->warnings.size();
+  int n = 0;
+  for (; n + first < (int)image->warnings.size() && n < max_entries; n++) {
+    if (n + first < 0) continue;
+    const auto& w = image->warnings[n + first];
+    out[n] = {w.first, w.second, "decoding warning"};
+  }
+  return n;
+}
+void heif_image_add_decoding_warning(struct heif_image* image, struct heif_error e)
+{
+  if (image) image->warnings.emplace_back(e.code, e.subcode);
 }
 
 // ---- plugin registration (heif.cc:2138-2149, plugin_registry.cc:221-228) -------------------------------------

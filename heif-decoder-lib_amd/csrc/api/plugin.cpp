@@ -8,8 +8,6 @@
 // Built twice: into libheif_mi355x_api.so (static registration) and as libheif-mi355x-plugin.so
 // (exports `plugin_info` for LIBHEIF_PLUGIN_PATH loading, plugins_unix.cc:96-111); in the latter the
 // heif_image_* symbols resolve against the libheif that loads it.
-#include <hip/hip_runtime_api.h>
-
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -76,67 +74,54 @@ heif_error push_data(void* dec, const void* data, size_t size)
   return ok();
 }
 
-struct DevBuf {
-  void* p = nullptr;
-  ~DevBuf() { if (p) hipFree(p); }
-};
-
 heif_error decode_image(void* dec, struct heif_image** out_img)
 {
   Decoder* d = static_cast<Decoder*>(dec);
   *out_img = nullptr;
-  uint8_t* blob = nullptr;
-  size_t blob_size = 0;
-  int rc = hm_hevc_parse(d->data.data(), d->data.size(), 0, &blob, &blob_size);
+  hm_picture* pic = nullptr;
+  hm_picture_info I;
+  int rc = hm_picture_parse(d->data.data(), d->data.size(), &pic, &I);
   if (rc) return from_status(rc);
-  struct Free { uint8_t* p; ~Free() { hm_free(p); } } blob_guard{blob};
-  const hm_pic* h = reinterpret_cast<const hm_pic*>(blob);
-  const int w = h->width - h->crop_left - h->crop_right, hh = h->height - h->crop_top - h->crop_bottom;
-  const int bd = h->bit_depth_y, bps = bd > 8 ? 2 : 1;
-  const int cw = w / 2, ch = h->chroma_format == 1 ? hh / 2 : hh;
+  struct Free { hm_picture* p; ~Free() { hm_picture_free(p); } } guard{pic};
 
-  heif_error err = heif_image_create(w, hh, heif_colorspace_YCbCr, (heif_chroma)h->chroma_format, out_img);
+  // convert_libde265_image_to_heif_image (decoder_libde265.cc:88-157): monochrome colourspace + one plane for 4:0:0,
+  // else YCbCr with the chroma planes at the conformance-window size divided by SubWidthC / SubHeightC
+  heif_error err = heif_image_create(I.plane_width[0], I.plane_height[0], I.chroma == 0 ? heif_colorspace_monochrome : heif_colorspace_YCbCr,
+                                     (heif_chroma)I.chroma, out_img);
   if (err.code) return err;
   const heif_channel chan[3] = {heif_channel_Y, heif_channel_Cb, heif_channel_Cr};
-  const int pw[3] = {w, cw, cw}, ph[3] = {hh, ch, ch};
-  DevBuf dev[3];
-  hm_tile_dest dest;
-  std::memset(&dest, 0, sizeof(dest));
-  for (int c = 0; c < 3; c++) {
-    err = heif_image_add_plane(*out_img, chan[c], pw[c], ph[c], bd);
+  uint8_t* plane[3] = {nullptr, nullptr, nullptr};
+  int32_t stride[3] = {0, 0, 0};
+  for (int c = 0; c < I.n_planes; c++) {
+    err = heif_image_add_plane(*out_img, chan[c], I.plane_width[c], I.plane_height[c], I.bit_depth);
     if (err.code) { heif_image_release(*out_img); *out_img = nullptr; return err; }
-    const size_t pitch = ((size_t)pw[c] * bps + 63) / 64 * 64;
-    if (hipMalloc(&dev[c].p, pitch * ph[c]) != hipSuccess) {
-      heif_image_release(*out_img); *out_img = nullptr;
-      return {heif_error_Memory_allocation_error, heif_suberror_Unspecified, "hipMalloc failed"};
-    }
-    dest.plane[c] = dev[c].p;
-    dest.pitch[c] = (int32_t)pitch;
+    int st = 0;
+    plane[c] = heif_image_get_plane(*out_img, chan[c], &st);
+    stride[c] = st;
   }
-  dest.canvas_width = w; dest.canvas_height = hh; // the "canvas" is the picture itself: plain copy, no rescale
-  hm_batch* b = nullptr;
-  rc = hm_batch_create(&b);
-  if (!rc) {
-    rc = hm_batch_add(b, blob, blob_size, &dest);
-    if (rc >= 0) rc = hm_batch_upload(b, nullptr);
-    if (!rc) rc = hm_batch_execute(b, 3, nullptr);
-    for (int c = 0; c < 3 && !rc; c++) {
-      int stride = 0;
-      uint8_t* dst = heif_image_get_plane(*out_img, chan[c], &stride);
-      if (hipMemcpy2D(dst, stride, dev[c].p, dest.pitch[c], (size_t)pw[c] * bps, ph[c], hipMemcpyDeviceToHost) != hipSuccess)
-        rc = HM_ERR_NO_DEVICE;
-    }
-    hm_batch_destroy(b);
-  }
+  rc = hm_picture_decode_to_host(pic, plane, stride, nullptr);
   if (rc) { heif_image_release(*out_img); *out_img = nullptr; return from_status(rc); }
+  const int primaries = I.primaries, transfer = I.transfer, matrix = I.matrix, full_range = I.full_range;
 
   // VUI colour description -> nclx, always attached (defaults 2,2,2,limited when the VUI has none)
   struct heif_color_profile_nclx* nclx = heif_nclx_color_profile_alloc();
   if (nclx) {
-    heif_nclx_color_profile_set_color_primaries(nclx, h->colour_primaries);
-    heif_nclx_color_profile_set_transfer_characteristics(nclx, h->transfer_characteristics);
-    heif_nclx_color_profile_set_matrix_coefficients(nclx, h->matrix_coeffs);
-    nclx->full_range_flag = h->full_range;
+    // HEIF_WARN_OR_FAIL (heif_plugin.h:290-301, decoder_libde265.cc:339-357): an unknown code point is a decoding
+    // warning on the image - the setter has stored "unspecified" - or, with strict decoding, the error of the call
+    const heif_error set[3] = {heif_nclx_color_profile_set_color_primaries(nclx, (uint16_t)primaries),
+                               heif_nclx_color_profile_set_transfer_characteristics(nclx, (uint16_t)transfer),
+                               heif_nclx_color_profile_set_matrix_coefficients(nclx, (uint16_t)matrix)};
+    for (const heif_error& e : set) {
+      if (e.code == heif_error_Ok) continue;
+      if (d->strict) {
+        heif_nclx_color_profile_free(nclx);
+        heif_image_release(*out_img);
+        *out_img = nullptr;
+        return e;
+      }
+      heif_image_add_decoding_warning(*out_img, e);
+    }
+    nclx->full_range_flag = (uint8_t)full_range;
     heif_image_set_nclx_color_profile(*out_img, nclx);
     heif_nclx_color_profile_free(nclx);
   }

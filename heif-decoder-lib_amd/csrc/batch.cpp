@@ -78,13 +78,14 @@ struct hm_batch {
   PinnedArena stage;       // command streams
   PinnedArena desc_stage;  // descriptor array (kept alive: the H2D copies are asynchronous)
   bool uploaded = false;
+  bool inflight = false;             // something was enqueued on last_stream since the last drain
   hipStream_t last_stream = nullptr; // stream of the last upload / execute: drained before the arenas are released
   size_t total_pixels = 0;
   // optional per-kernel timing with HIP events on the launch stream (bench / profiling)
   int profiling = 0;                // number of timing slots (0 = off)
   std::vector<hipEvent_t> events;   // per slot, 4 per class: before recon, after recon, after deblock, after sao
   long exec_count = 0;
-  void drain() { if (uploaded) hipStreamSynchronize(last_stream); }
+  void drain() { if (inflight) { hipStreamSynchronize(last_stream); inflight = false; } }
   ~hm_batch()
   {
     drain();
@@ -154,6 +155,8 @@ int hm_batch_upload(hm_batch* b, void* stream)
   if (!b) return hm_fail(HM_ERR_INVALID_ARG, "null batch");
   hipStream_t s = (hipStream_t)stream;
   const int n = (int)b->items.size();
+  b->drain(); // descriptors and buffers of an earlier upload may still be in use
+  b->uploaded = false;
   b->classes.clear();
   b->h_desc.assign(n, hm_dev_pic());
   if (n == 0) { b->uploaded = true; return HM_OK; }
@@ -203,10 +206,8 @@ int hm_batch_upload(hm_batch* b, void* stream)
   if ((rc = b->d_work.ensure(work_bytes))) return rc;
   if ((rc = b->d_desc.ensure(sizeof(hm_dev_pic) * (size_t)n))) return rc;
 
-  // the streams already lie in the pinned arena in device layout -> one H2D copy at PCIe rate
-  hipError_t e = hipMemcpyAsync(b->d_blobs.p, b->stage.p, blob_bytes, hipMemcpyHostToDevice, s);
-  if (e != hipSuccess) return hm_check_hip(e, "H2D command streams");
-
+  // (every check that can fail on file data runs before anything is enqueued: an error return must not leave copies
+  //  in flight on buffers that go back to the pool)
   size_t di = 0;
   for (Class& c : b->classes) {
     c.desc_offset = di;
@@ -268,10 +269,14 @@ int hm_batch_upload(hm_batch* b, void* stream)
   b->desc_stage.used = 0;
   if (!b->desc_stage.reserve(sizeof(hm_dev_pic) * (size_t)n)) return hm_fail(HM_ERR_NOMEM, "pinned staging: out of memory");
   std::memcpy(b->desc_stage.p, b->h_desc.data(), sizeof(hm_dev_pic) * (size_t)n);
+  b->last_stream = s;
+  b->inflight = true;
+  // the streams already lie in the pinned arena in device layout -> one H2D copy at PCIe rate
+  hipError_t e = hipMemcpyAsync(b->d_blobs.p, b->stage.p, blob_bytes, hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) return hm_check_hip(e, "H2D command streams");
   e = hipMemcpyAsync(b->d_desc.p, b->desc_stage.p, sizeof(hm_dev_pic) * (size_t)n, hipMemcpyHostToDevice, s);
   if (e != hipSuccess) return hm_check_hip(e, "H2D descriptors");
   b->uploaded = true; // asynchronous: the arenas stay alive with the batch
-  b->last_stream = s;
   return HM_OK;
 }
 
@@ -282,7 +287,9 @@ int hm_batch_execute(hm_batch* b, int stages, void* stream)
   if (!b) return hm_fail(HM_ERR_INVALID_ARG, "null batch");
   if (!b->uploaded) return hm_fail(HM_ERR_INVALID_ARG, "hm_batch_upload() has not been called");
   hipStream_t s = (hipStream_t)stream;
+  if (b->inflight && s != b->last_stream) b->drain(); // a different stream than the upload's: order them
   b->last_stream = s;
+  b->inflight = true;
   const hm_dev_pic* d = (const hm_dev_pic*)b->d_desc.p;
   const size_t per_slot = b->classes.size() * 4;
   size_t ev_next = 0;
@@ -356,7 +363,8 @@ int hm_batch_algorithmic_bytes(const hm_batch* b, uint64_t* stream_bytes, uint64
     sb += it.hdr.total_bytes;
     const uint64_t bps = it.hdr.bit_depth_y > 8 ? 2 : 1;
     const uint64_t luma = (uint64_t)it.hdr.width * it.hdr.height;
-    pb += bps * (luma + 2 * (luma / (it.hdr.chroma_format == 1 ? 4 : 2)));
+    const uint64_t chroma = it.hdr.chroma_format == 0 ? 0 : (it.hdr.chroma_format == 1 ? luma / 4 : (it.hdr.chroma_format == 2 ? luma / 2 : luma));
+    pb += bps * (luma + 2 * chroma);
   }
   *stream_bytes = sb;
   *sample_bytes = pb;

@@ -43,6 +43,17 @@ const char* hm_status_string(int status)
   }
 }
 
+int hm_nclx_code_known(int kind, int v)
+{
+  // heif.cc:1795-1885 of the reference: known_color_primaries / known_transfer_characteristics / known_matrix_coefficients
+  switch (kind) {
+    case 0: return v == 1 || v == 2 || (v >= 4 && v <= 12) || v == 22;
+    case 1: return v == 1 || v == 2 || (v >= 4 && v <= 18);
+    case 2: return (v >= 0 && v <= 2) || (v >= 4 && v <= 14);
+    default: return 0;
+  }
+}
+
 const char* hm_version(void) { return "heif-mi355x 0.1.0 (gfx950)"; }
 
 int hm_device_count(void)

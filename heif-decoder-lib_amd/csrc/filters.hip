@@ -28,6 +28,7 @@ namespace {
 __device__ __forceinline__ int clip3i(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int iabs_(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int isign_(int v) { return (v > 0) - (v < 0); }
+__device__ __forceinline__ int imin_(int a, int b) { return a < b ? a : b; }
 
 __constant__ uint8_t c_beta[52] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15,
                                    16, 17, 18, 20, 22, 24, 26, 28, 30, 32, 34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64};
@@ -350,6 +351,12 @@ __device__ __forceinline__ int sao_sample(const hm_dev_pic& dp, const PicView& v
     const int hx0 = cl == 1 ? 0 : (cl == 3 ? 1 : -1), hx1 = -hx0;
     const int vy0 = cl == 0 ? 0 : -1, vy1 = -vy0;
     bool ok = true;
+    // the reference tests the samples of the CTB's outer ring only (sao.cc:366); a neighbour inside the own CTB is
+    // always usable for luma, for chroma per sao_ring_c (hm_stream.h: quirk Q13)
+    const uint32_t nbm = c == 0 ? cb.sao_nb_mask : cb.sao_nb_mask_c;
+    const int i = xx - (cx << l2w), j = yy - (cy << l2h);
+    const int cwc = imin_((1 << l2w), W - (cx << l2w)), chc = imin_((1 << l2h), Hh - (cy << l2h));
+    const bool ring_blocked = c != 0 && !cb.sao_ring_c && (i == 0 || j == 0 || i == cwc - 1 || j == chc - 1);
 #pragma unroll
     for (int n = 0; n < 2; n++) {
       const int xS = xx + (n ? hx1 : hx0), yS = yy + (n ? vy1 : vy0);
@@ -358,8 +365,9 @@ __device__ __forceinline__ int sao_sample(const hm_dev_pic& dp, const PicView& v
       if (dxc != 0 || dyc != 0) {
         const int k8 = (dyc + 1) * 3 + (dxc + 1); // 0..8 without the centre
         const int bit = k8 < 4 ? k8 : k8 - 1;
-        if (!(cb.sao_nb_mask & (1u << bit))) ok = false;
+        if (!(nbm & (1u << bit))) ok = false;
       }
+      else if (ring_blocked) ok = false;
     }
     if (ok) {
       const int a = reinterpret_cast<const Pix*>(plane + (size_t)(yy + vy0) * pitch)[xx + hx0];
@@ -549,9 +557,22 @@ __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict_
       const bool sao_on = apply_sao && (dp.flags & HM_PIC_SAO_ENABLED) && (cflags[r] & (c == 0 ? HM_CTB_SAO_LUMA : HM_CTB_SAO_CHROMA));
       const int type = sao_on ? (int)(s0[r] & 0xFF) : 0;
       const uint32_t offs = (s0[r] >> 24) | (s1[r] << 8); // the four int8 offsets in one register
-      const uint32_t nbm = (cflags[r] >> 8) & 0xFF;
+      // neighbour-CTB mask of this component; chroma CTBs whose ring flag is clear (quirk Q13: only with several slices
+      // whose filters stop at slice borders) take the per-sample path below
+      const uint32_t nbm = c == 0 ? (cflags[r] >> 8) & 0xFF : (cflags[r] >> 16) & 0xFF;
+      const bool ring_blocked = c != 0 && !((cflags[r] >> 24) & 0xFF);
 #pragma unroll
       for (int j = 0; j < 4; j++) res[r][j] = cur.p[j];
+      if (type == 2 && ring_blocked) {
+#pragma unroll 1
+        for (int k = 0; k < G; k++) {
+          const int val = sao_sample<Pix>(dp, v, plane, pitch, c, xs + k, yy, W, Hh, l2w, l2h, bd, apply_sao,
+                                          RARE && (dp.flags & HM_PIC_LOSSLESS_CUS) ? ((dp.pcm_loop_filter_disabled ? 4 : 0) | 8) : 0);
+          if (k & 1) res[r][k >> 1] = (res[r][k >> 1] & 0xFFFFu) | ((uint32_t)val << 16);
+          else res[r][k >> 1] = (res[r][k >> 1] & 0xFFFF0000u) | (uint32_t)val;
+        }
+        continue;
+      }
       if (type == 1) { // band offset (fallback-postfilter.h:218-241): table index = band - band_position, 4 = none
         const uint32_t bp = (s0[r] >> 16) & 0xFF;
         const uint32_t biased = offs ^ 0x80808080u;

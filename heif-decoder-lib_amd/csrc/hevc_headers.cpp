@@ -267,10 +267,15 @@ void parse_sps(BitReader& br, SPS& sps)
   if (sps.width <= 0 || sps.height <= 0 || sps.width > 65535 || sps.height > 65535)
     throw ParseError(HM_ERR_BITSTREAM, "bad picture size");
   if (br.flag()) { // conformance_window_flag
-    sps.conf_left = br.ue() * sps.SubWidthC;
-    sps.conf_right = br.ue() * sps.SubWidthC;
-    sps.conf_top = br.ue() * sps.SubHeightC;
-    sps.conf_bottom = br.ue() * sps.SubHeightC;
+    const uint32_t l = br.ue(), r = br.ue(), t = br.ue(), b = br.ue();
+    // 7.4.3.2.1: SubWidthC * (left + right) < pic_width, SubHeightC * (top + bottom) < pic_height
+    if (l > 65535 || r > 65535 || t > 65535 || b > 65535 || (l + r) * (uint32_t)sps.SubWidthC >= (uint32_t)sps.width ||
+        (t + b) * (uint32_t)sps.SubHeightC >= (uint32_t)sps.height)
+      throw ParseError(HM_ERR_BITSTREAM, "conformance window larger than the picture");
+    sps.conf_left = (int)l * sps.SubWidthC;
+    sps.conf_right = (int)r * sps.SubWidthC;
+    sps.conf_top = (int)t * sps.SubHeightC;
+    sps.conf_bottom = (int)b * sps.SubHeightC;
   }
   sps.bit_depth_y = br.ue() + 8;
   sps.bit_depth_c = br.ue() + 8;
@@ -376,12 +381,21 @@ void parse_pps(BitReader& br, PPS& pps, const SPS* sps_table)
   pps.cabac_init_present = br.flag();
   br.ue(); br.ue(); // num_ref_idx_l0/l1_default_active_minus1
   pps.init_qp = 26 + br.se();
+  // 7.4.3.3.1: init_qp_minus26 in [-(26 + QpBdOffsetY), 25]
+  if (pps.init_qp < -sps_table[pps.sps_id].qp_bd_offset_y || pps.init_qp > 51) throw ParseError(HM_ERR_BITSTREAM, "init_qp_minus26 out of range");
   pps.constrained_intra_pred = br.flag();
   pps.transform_skip_enabled = br.flag();
   pps.cu_qp_delta_enabled = br.flag();
-  if (pps.cu_qp_delta_enabled) pps.diff_cu_qp_delta_depth = br.ue();
+  if (pps.cu_qp_delta_enabled) {
+    pps.diff_cu_qp_delta_depth = br.ue();
+    const SPS& as = sps_table[pps.sps_id];
+    if (pps.diff_cu_qp_delta_depth < 0 || pps.diff_cu_qp_delta_depth > as.log2_ctb - as.log2_min_cb)
+      throw ParseError(HM_ERR_BITSTREAM, "diff_cu_qp_delta_depth out of range");
+  }
   pps.cb_qp_offset = br.se();
   pps.cr_qp_offset = br.se();
+  if (pps.cb_qp_offset < -12 || pps.cb_qp_offset > 12 || pps.cr_qp_offset < -12 || pps.cr_qp_offset > 12)
+    throw ParseError(HM_ERR_BITSTREAM, "pps_cb/cr_qp_offset out of range");
   pps.slice_chroma_qp_offsets_present = br.flag();
   pps.weighted_pred = br.flag();
   pps.weighted_bipred = br.flag();
@@ -407,6 +421,8 @@ void parse_pps(BitReader& br, PPS& pps, const SPS* sps_table)
     if (!pps.deblocking_disabled) {
       pps.beta_offset_div2 = br.se();
       pps.tc_offset_div2 = br.se();
+      if (pps.beta_offset_div2 < -6 || pps.beta_offset_div2 > 6 || pps.tc_offset_div2 < -6 || pps.tc_offset_div2 > 6)
+        throw ParseError(HM_ERR_BITSTREAM, "pps_beta/tc_offset_div2 out of range");
     }
   }
   pps.scaling_list_present = br.flag();
@@ -579,6 +595,8 @@ void parse_slice_header(BitReader& br, int nal_unit_type, const SPS* sps_table, 
     if (pps.slice_chroma_qp_offsets_present) {
       sh.cb_qp_offset = br.se();
       sh.cr_qp_offset = br.se();
+      if (sh.cb_qp_offset < -12 || sh.cb_qp_offset > 12 || sh.cr_qp_offset < -12 || sh.cr_qp_offset > 12)
+        throw ParseError(HM_ERR_BITSTREAM, "slice_cb/cr_qp_offset out of range");
     }
     if (pps.chroma_qp_offset_list_enabled) br.flag(); // cu_chroma_qp_offset_enabled_flag
     bool override_flag = false;
@@ -591,6 +609,8 @@ void parse_slice_header(BitReader& br, int nal_unit_type, const SPS* sps_table, 
       if (!sh.deblocking_disabled) {
         sh.beta_offset_div2 = br.se();
         sh.tc_offset_div2 = br.se();
+        if (sh.beta_offset_div2 < -6 || sh.beta_offset_div2 > 6 || sh.tc_offset_div2 < -6 || sh.tc_offset_div2 > 6)
+          throw ParseError(HM_ERR_BITSTREAM, "slice_beta/tc_offset_div2 out of range");
       }
     }
     sh.lf_across_slices = pps.lf_across_slices;
@@ -602,6 +622,12 @@ void parse_slice_header(BitReader& br, int nal_unit_type, const SPS* sps_table, 
   if (pps.tiles_enabled || pps.entropy_coding_sync) {
     sh.num_entry_points = br.ue();
     if (sh.num_entry_points > sps.ctb_w * sps.ctb_h) throw ParseError(HM_ERR_BITSTREAM, "too many entry points");
+    // the reference's own limits (slice.cc:813-829): with WPP the entry points are CTB rows of the picture, with tiles
+    // there are at most as many as tiles - a stream beyond them is refused there, so it is refused here
+    if (pps.entropy_coding_sync && sh.slice_segment_address / sps.ctb_w + sh.num_entry_points >= sps.ctb_h)
+      throw ParseError(HM_ERR_BITSTREAM, "num_entry_point_offsets beyond the last CTB row");
+    if (pps.tiles_enabled && sh.num_entry_points > pps.num_tile_cols * pps.num_tile_rows)
+      throw ParseError(HM_ERR_BITSTREAM, "more entry points than tiles");
     if (sh.num_entry_points > 0) {
       int len = br.ue() + 1;
       if (len > 32) throw ParseError(HM_ERR_BITSTREAM, "offset_len_minus1 out of range");

@@ -76,8 +76,6 @@ struct Decoder {
   SliceHeader prev_sh;
   bool have_prev_sh = false;
   int next_ts = 0;
-  ContextSet wpp_store, dep_store;
-  bool wpp_valid = false, dep_valid = false;
   bool picture_done = false;
 
   void handle_nal(const uint8_t* p, size_t n)
@@ -92,11 +90,17 @@ struct Decoder {
       if (nal_type == 33) {
         SPS s;
         parse_sps(br, s);
+        if (pic_started && cur_sps == &sps[s.sps_id]) throw ParseError(HM_ERR_BITSTREAM, "SPS replaced inside a picture");
+        // the scan tables of a PPS are derived from the SPS that was active when the PPS was parsed (pps.cc:585-800
+        // of the reference does the same and re-derives on activation): a new SPS with this id makes them stale
+        for (PPS& q : pps)
+          if (q.valid && q.sps_id == s.sps_id) q.valid = false;
         sps[s.sps_id] = s;
       }
       else if (nal_type == 34) {
         PPS q;
         parse_pps(br, q, sps);
+        if (pic_started && cur_pps == &pps[q.pps_id]) throw ParseError(HM_ERR_BITSTREAM, "PPS replaced inside a picture");
         pps[q.pps_id] = q;
       }
       else if (nal_type <= 9 || (nal_type >= 16 && nal_type <= 21)) {
@@ -113,6 +117,10 @@ struct Decoder {
     parse_slice_header(br, nal_type, sps, pps, have_prev_sh ? &prev_sh : nullptr, sh);
     const PPS& p = pps[sh.pps_id];
     const SPS& s = sps[p.sps_id];
+    // every table the slice walker indexes with CTB / minimum-TB addresses must have the active SPS's size
+    if (p.CtbAddrRStoTS.size() != (size_t)s.ctb_w * s.ctb_h || p.CtbAddrTStoRS.size() != p.CtbAddrRStoTS.size() ||
+        p.TileIdRS.size() != p.CtbAddrRStoTS.size() || p.MinTbAddrZS.size() != (size_t)s.min_tb_w * s.min_tb_h)
+      throw ParseError(HM_ERR_BITSTREAM, "PPS scan tables do not match the active SPS");
     if (sh.first_slice_segment_in_pic) {
       if (pic_started) throw ParseError(HM_ERR_UNSUPPORTED, "more than one coded picture in the item");
       check_supported(s, p);
@@ -121,7 +129,6 @@ struct Decoder {
       pic.reset(s, p);
       pic_started = true;
       next_ts = 0;
-      wpp_valid = dep_valid = false;
     }
     else if (!pic_started) throw ParseError(HM_ERR_BITSTREAM, "slice segment without a first_slice_segment_in_pic");
     if (&p != cur_pps) throw ParseError(HM_ERR_UNSUPPORTED, "PPS changes inside a picture");
@@ -151,7 +158,7 @@ struct Decoder {
     const uint8_t* end = rbsp.data() + rbsp.size();
     DecoderEC ec(begin, end);
     SliceWalker<DecoderEC> walker(ec, pic, sh, slice_idx);
-    next_ts = walker.decode_slice_segment(start_ts, &wpp_store, &wpp_valid, &dep_store, &dep_valid);
+    next_ts = walker.decode_slice_segment(start_ts);
     prev_sh = sh;
     have_prev_sh = true;
     if (next_ts == s.ctb_w * s.ctb_h) picture_done = true;
@@ -185,27 +192,41 @@ struct Decoder {
       pic.ctbs[i].tu_count = (uint16_t)pic.ctb_tus[i].size();
       n_tus += pic.ctb_tus[i].size();
     }
-    // SAO neighbour masks (sao.cc:323-424 of the reference)
-    const bool sao_fast = p.lf_across_slices && !p.tiles_enabled;
+    // SAO neighbour masks (sao.cc:323-424 of the reference).  The reference's fast path (all neighbours inside the
+    // picture usable, slice flags ignored) is taken per CTB: pps_loop_filter_across_slices && !tiles && the CTB holds no
+    // PCM / transquant-bypass unit (sao.cc:323).  Otherwise every sample of the CTB's outer ring is tested against the
+    // CTB that holds its neighbour sample - which may be the CTB itself - with "the slice of the current CTB" looked up
+    // at the CTB's position in samples of the *component* (sao.cc:291), i.e. at the wrong CTB for sub-sampled chroma
+    // (quirk Q13): chroma gets its own mask and a ring flag.
     static const int dx[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, dy[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+    const int csw = (s.chroma_format_idc == 1 || s.chroma_format_idc == 2) ? 1 : 0, csh = s.chroma_format_idc == 1 ? 1 : 0;
     for (int cy = 0; cy < s.ctb_h; cy++)
       for (int cx = 0; cx < s.ctb_w; cx++) {
         const int c = cx + cy * s.ctb_w;
-        uint8_t mask = 0;
+        const bool fast = p.lf_across_slices && !p.tiles_enabled && !(pic.ctbs[c].flags & HM_CTB_LOSSLESS);
+        const int so = pic.ctb_slice_addr[c];
+        const bool lf_own = pic.slices[pic.ctbs[c].slice_idx].lf_across_slices != 0;
+        // may a sample of CTB c use a neighbour sample lying in CTB nb, given the slice address the reference compares with
+        auto usable = [&](int nb, int sq) {
+          if (fast) return true;
+          const int sa = pic.ctb_slice_addr[nb];
+          if (sa < sq && !lf_own) return false;
+          if (sa > sq && !pic.slices[pic.ctbs[nb].slice_idx].lf_across_slices) return false;
+          if (!p.lf_across_tiles && p.TileIdRS[nb] != p.TileIdRS[c]) return false;
+          return true;
+        };
+        const int sq_c = pic.ctb_slice_addr[(cx >> csw) + (cy >> csh) * s.ctb_w]; // sao.cc:291 with chroma coordinates
+        uint8_t mask = 0, mask_c = 0;
         for (int k = 0; k < 8; k++) {
           const int nx = cx + dx[k], ny = cy + dy[k];
           if (nx < 0 || ny < 0 || nx >= s.ctb_w || ny >= s.ctb_h) continue;
           const int nb = nx + ny * s.ctb_w;
-          bool ok = true;
-          if (!sao_fast) {
-            const int sa = pic.ctb_slice_addr[nb], sc = pic.ctb_slice_addr[c];
-            if (sa < sc && !pic.slices[pic.ctbs[c].slice_idx].lf_across_slices) ok = false;
-            if (sa > sc && !pic.slices[pic.ctbs[nb].slice_idx].lf_across_slices) ok = false;
-            if (!p.lf_across_tiles && p.TileIdRS[nb] != p.TileIdRS[c]) ok = false;
-          }
-          if (ok) mask |= (uint8_t)(1u << k);
+          if (usable(nb, so)) mask |= (uint8_t)(1u << k);
+          if (usable(nb, sq_c)) mask_c |= (uint8_t)(1u << k);
         }
         pic.ctbs[c].sao_nb_mask = mask;
+        pic.ctbs[c].sao_nb_mask_c = mask_c;
+        pic.ctbs[c].sao_ring_c = usable(c, sq_c) ? 1 : 0;
       }
 
     auto align16 = [](size_t v) { return (v + 15) & ~(size_t)15; };

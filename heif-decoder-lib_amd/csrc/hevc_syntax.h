@@ -12,8 +12,9 @@
 // generated streams valid by construction.  EC provides:
 //     int  bin(int ctxIdx, int kind, int idx)   context coded bin
 //     int  bypass(int kind, int idx)            bypass bin
-//     int  terminate(int expect)                terminating bin (expect: -1 unknown, else the value
-//                                               a conformant stream must carry here)
+//     int  terminate(int expect)                terminating bin (expect: -1 = end_of_slice_segment_flag of any value,
+//                                               1 = ... that a conformant stream sets (last CTB of the picture),
+//                                               2 = end_of_subset_one_bit)
 //     ContextSet& contexts()
 //     void start_substream()                    (re)initialise the arithmetic engine at a byte boundary
 //     int  pcm_flag()                           the terminating bin that announces PCM samples
@@ -129,6 +130,12 @@ struct PictureState {
   bool uses_pcm = false, uses_tq_bypass = false;
   // QP predictor state, persists across dependent slice segments (decctx.h thread_context fields)
   struct { int last_qpy_prev_qg = 0, current_qpy = 0, cur_qg_x = -1, cur_qg_y = -1; } qs;
+  // context tables handed over between sub-streams / slice segments: per CTB row the tables after its 2nd CTB (WPP,
+  // image_unit::ctx_models of the reference), and the tables at the end of the last slice segment (dependent segments)
+  std::vector<ContextSet> wpp_ctx;
+  std::vector<uint8_t> wpp_ok;
+  ContextSet dep_ctx;
+  bool dep_ok = false;
 
   void reset(const SPS& s, const PPS& p)
   {
@@ -145,6 +152,9 @@ struct PictureState {
     ctb_tus.assign(n, {});
     coeffs.clear();
     uses_pcm = uses_tq_bypass = false;
+    wpp_ctx.assign(p.entropy_coding_sync ? (size_t)s.ctb_h : 0, ContextSet());
+    wpp_ok.assign(wpp_ctx.size(), 0);
+    dep_ok = false;
   }
 };
 
@@ -157,23 +167,33 @@ class SliceWalker {
     w4_ = (sps_.width + 3) >> 2;
   }
 
-  // §7.3.8.1 slice_segment_data(); `saved_wpp` / `saved_dep` carry context tables between calls
-  // Returns the CTB address (tile scan) following the last decoded CTB.
-  int decode_slice_segment(int start_ts, ContextSet* wpp_store, bool* wpp_valid,
-                           ContextSet* dep_store, bool* dep_valid)
+  // §7.3.8.1 slice_segment_data().  Returns the CTB address (tile scan) following the last decoded CTB.
+  //
+  // Context-table hand-over follows the REFERENCE (slice.cc:5350-5406 initialize_CABAC_at_slice_segment_start,
+  // :5004-5030 / :5134-5165 decode_substream_sequential, :5590-5594 read_slice_segment_data), which is the standard's
+  // process (9.3.1) for conformant streams of the shapes encoders produce and differs from it in corners (quirk Q14):
+  //   * a dependent slice segment restores the tables saved at the end of the previous segment (tile start: fresh
+  //     tables) and then, with WPP, if it starts at picture column 0 of a row >= 1, takes the tables stored after the
+  //     2nd CTB of the row above - without asking whether that CTB belongs to the same slice (the standard would);
+  //   * a sub-stream ends at a tile change, and with WPP wherever the CTB row changes provided the header carries
+  //     entry points; with tiles every new sub-stream starts from fresh tables; with WPP a sub-stream that starts at
+  //     picture column 0 (row >= 1) then takes the row-above tables - even at a tile start, and never in a tile that
+  //     does not begin at column 0.
+  int decode_slice_segment(int start_ts)
   {
     const int W = sps_.ctb_w, N = sps_.ctb_w * sps_.ctb_h;
     int ts = start_ts;
-    // context initialisation (§9.3.1 / §9.3.2; call pattern of the reference slice.cc:5004-5030,5521-5560)
     const int rs0 = pps_.CtbAddrTStoRS[ts];
-    const bool tile_start = pps_.tiles_enabled && (ts == 0 || pps_.TileId[ts] != pps_.TileId[ts - 1]);
-    if (tile_start) init_contexts(ec_.contexts(), sh_.SliceQPY);
-    else if (pps_.entropy_coding_sync && (rs0 % W) == 0 && rs0 >= W && wpp_sync_ok(rs0, wpp_valid)) ec_.contexts() = *wpp_store;
-    else if (sh_.dependent && *dep_valid) ec_.contexts() = *dep_store;
+    if (sh_.dependent) {
+      const bool tile_start = ts == 0 || (pps_.tiles_enabled && pps_.TileId[ts] != pps_.TileId[ts - 1]);
+      if (tile_start) init_contexts(ec_.contexts(), sh_.SliceQPY);
+      else if (pic_.dep_ok) ec_.contexts() = pic_.dep_ctx;
+      else throw ParseError(HM_ERR_BITSTREAM, "dependent slice segment without stored context tables");
+      if (pps_.entropy_coding_sync && (rs0 % W) == 0 && rs0 >= W) import_wpp_row(rs0 / W - 1);
+    }
     else init_contexts(ec_.contexts(), sh_.SliceQPY);
     ec_.start_substream();
     // QP predictor state
-    first_qg_in_slice_pending_ = !sh_.dependent;
     if (!sh_.dependent) { pic_.qs.last_qpy_prev_qg = sh_.SliceQPY; pic_.qs.current_qpy = sh_.SliceQPY; pic_.qs.cur_qg_x = pic_.qs.cur_qg_y = -1; }
 
     for (;;) {
@@ -185,29 +205,26 @@ class SliceWalker {
       pic_.ctbs[rs].slice_idx = (uint16_t)slice_idx_;
       pic_.ctbs[rs].flags |= HM_CTB_CODED;
       coding_tree_unit(rs % W, rs / W);
-      // WPP: store after the 2nd CTB of a row (libde265 slice.cc:5071-5083: ctbx == 1)
+      // WPP: store after the 2nd CTB of a row (libde265 slice.cc:5071-5083: ctbx == 1), except in the last row
       if (pps_.entropy_coding_sync && (rs % W) == 1 && (rs / W) < sps_.ctb_h - 1) {
-        *wpp_store = ec_.contexts();
-        *wpp_valid = true;
+        pic_.wpp_ctx[rs / W] = ec_.contexts();
+        pic_.wpp_ok[rs / W] = 1;
       }
       const bool last_in_pic = (ts + 1 == N);
       const int end_of_slice = ec_.terminate(last_in_pic ? 1 : -1);
       ts++;
       if (end_of_slice) {
-        if (pps_.dependent_slice_segments_enabled) { *dep_store = ec_.contexts(); *dep_valid = true; }
+        if (pps_.dependent_slice_segments_enabled) { pic_.dep_ctx = ec_.contexts(); pic_.dep_ok = true; }
         break;
       }
       if (ts >= N) throw ParseError(HM_ERR_BITSTREAM, "missing end_of_slice_segment_flag");
       const int nrs = pps_.CtbAddrTStoRS[ts];
       const bool new_tile = pps_.tiles_enabled && pps_.TileId[ts] != pps_.TileId[ts - 1];
-      const bool new_row = pps_.entropy_coding_sync && ((nrs % W) == 0 || new_tile);
+      const bool new_row = pps_.entropy_coding_sync && sh_.num_entry_points > 0 && (nrs / W) != (rs / W);
       if (new_tile || new_row) {
-        if (!ec_.terminate(1)) throw ParseError(HM_ERR_BITSTREAM, "end_of_subset_one_bit not set");
-        if (new_tile) init_contexts(ec_.contexts(), sh_.SliceQPY);
-        else { // WPP row start
-          if (wpp_sync_ok(nrs, wpp_valid)) ec_.contexts() = *wpp_store;
-          else init_contexts(ec_.contexts(), sh_.SliceQPY);
-        }
+        if (!ec_.terminate(2)) throw ParseError(HM_ERR_BITSTREAM, "end_of_subset_one_bit not set");
+        if (pps_.tiles_enabled) init_contexts(ec_.contexts(), sh_.SliceQPY);
+        if (pps_.entropy_coding_sync && (nrs % W) == 0 && nrs >= W) import_wpp_row(nrs / W - 1);
         ec_.start_substream();
       }
     }
@@ -216,13 +233,14 @@ class SliceWalker {
 
  private:
   // ---- availability ------------------------------------------------------------------------
-  // WPP: the CTB above-right of a row's first CTB (rs) belongs to this slice and tile, and its
-  // context table was stored
-  bool wpp_sync_ok(int rs, const bool* wpp_valid) const
+  // slice.cc:5010-5030: the tables stored after the 2nd CTB of `row` (a picture one CTB wide: fresh tables); a row
+  // whose tables were never stored, or were taken already, is a decoding error in the reference
+  void import_wpp_row(int row)
   {
-    if (sps_.ctb_w < 2 || !*wpp_valid) return false;
-    const int tr = rs - sps_.ctb_w + 1;
-    return pic_.ctb_slice_addr[tr] == sh_.SliceAddrRS && pps_.TileIdRS[tr] == pps_.TileIdRS[rs];
+    if (sps_.ctb_w < 2) { init_contexts(ec_.contexts(), sh_.SliceQPY); return; }
+    if (!pic_.wpp_ok[row]) throw ParseError(HM_ERR_BITSTREAM, "WPP context tables of the row above are missing");
+    ec_.contexts() = pic_.wpp_ctx[row];
+    pic_.wpp_ok[row] = 0;
   }
   // §6.4.1 z-scan order availability (luma sample positions)
   bool avail_z(int xCurr, int yCurr, int xN, int yN) const
@@ -247,7 +265,7 @@ class SliceWalker {
     const int x0 = xCtb << sps_.log2_ctb, y0 = yCtb << sps_.log2_ctb;
     hm_ctb& c = pic_.ctbs[ctb_addr_rs_];
     // deblocking edge permissions of this CTB's left/top edge (deblock.cc:160-196 in the reference)
-    c.flags &= ~(HM_CTB_DEBLOCK_LEFT | HM_CTB_DEBLOCK_TOP | HM_CTB_DEBLOCK_OFF | HM_CTB_SAO_LUMA | HM_CTB_SAO_CHROMA);
+    c.flags &= ~(HM_CTB_DEBLOCK_LEFT | HM_CTB_DEBLOCK_TOP | HM_CTB_DEBLOCK_OFF | HM_CTB_SAO_LUMA | HM_CTB_SAO_CHROMA | HM_CTB_LOSSLESS);
     if (sh_.deblocking_disabled) c.flags |= HM_CTB_DEBLOCK_OFF;
     if (sh_.sao_luma) c.flags |= HM_CTB_SAO_LUMA;
     if (sh_.sao_chroma) c.flags |= HM_CTB_SAO_CHROMA;
@@ -397,13 +415,19 @@ class SliceWalker {
     if (first_in_slice || first_in_tile || (first_in_ctb_row && pps_.entropy_coding_sync)) pred = sh_.SliceQPY;
     else pred = pic_.qs.last_qpy_prev_qg;
     int qa = pred, qb = pred;
+    // Quirk Q12 of the reference (fork): its table-driven MinTbAddrZS (pps.cc:700-790, the standard derivation is
+    // "#if 0") is built on the *raster* CTB address, and transform.cc:108-135 compares the CTB address taken out of
+    // it with CtbAddrInTS.  Without tiles the two agree ("the neighbour lies in the current CTB", 8.6.1); in a
+    // picture with several tile columns they do not: the left / upper quantisation group of the same CTB is then
+    // ignored (and a neighbouring CTB whose raster address happens to equal the current tile-scan address is used).
+    // Reproduced literally: bit-exactness to the reference, not to the standard, is the contract.
     if (avail_z(xQG, yQG, xQG - 1, yQG)) {
       const int cn = ((xQG - 1) >> sps_.log2_ctb) + (yQG >> sps_.log2_ctb) * sps_.ctb_w;
-      if (cn == ctb_addr_rs_) qa = qpy_at(xQG - 1, yQG);
+      if (cn == ctb_addr_ts_) qa = qpy_at(xQG - 1, yQG);
     }
     if (avail_z(xQG, yQG, xQG, yQG - 1)) {
       const int cn = (xQG >> sps_.log2_ctb) + ((yQG - 1) >> sps_.log2_ctb) * sps_.ctb_w;
-      if (cn == ctb_addr_rs_) qb = qpy_at(xQG, yQG - 1);
+      if (cn == ctb_addr_ts_) qb = qpy_at(xQG, yQG - 1);
     }
     pred = (qa + qb + 1) >> 1;
     const int bdY = sps_.qp_bd_offset_y, bdC = sps_.qp_bd_offset_c;
@@ -441,6 +465,7 @@ class SliceWalker {
     if (pps_.transquant_bypass_enabled && ec_.bin(CTX_TQ_BYPASS, K_TQ_BYPASS, 0)) {
       cu_bypass_ = true;
       pic_.uses_tq_bypass = true;
+      pic_.ctbs[ctb_addr_rs_].flags |= HM_CTB_LOSSLESS;
     }
     // I slice: no cu_skip_flag / pred_mode_flag
     bool nxn = false;
@@ -453,6 +478,7 @@ class SliceWalker {
     if (sps_.pcm_enabled && !nxn && log2CbSize >= sps_.log2_min_pcm_cb && log2CbSize <= sps_.log2_max_pcm_cb) {
       if (ec_.pcm_flag()) {
         pic_.uses_pcm = true;
+        pic_.ctbs[ctb_addr_rs_].flags |= HM_CTB_LOSSLESS;
         pcm_coding_unit(x0, y0, log2CbSize);
         return;
       }
@@ -924,7 +950,6 @@ class SliceWalker {
   // QP state (thread_context fields of the reference: decctx.h)
   bool is_cu_qp_delta_coded_ = false;
   int cu_qp_delta_val_ = 0;
-  bool first_qg_in_slice_pending_ = false;
   int qp_prime_[3] = {0, 0, 0};
   int cu_qpy_ = 0;
   // current CU

@@ -205,6 +205,7 @@ struct PlanarImage {
   int w = 0, h = 0, chroma = 1, bd = 8;
   hm::NclxProfile native; // profile of the decoded image (VUI, overridden by an item 'colr' nclx)
   bool is_grid = false;
+  int warnings = 0; // HM_WARN_* of the (single) coded picture
   std::vector<std::unique_ptr<DevMem>> retired;
   std::unique_ptr<hm_batch, void (*)(hm_batch*)> batch{nullptr, hm_batch_destroy};
 };
@@ -426,6 +427,16 @@ int decode_planar(const hm_file* f, uint32_t id, const hm_decode_params* params,
     hm::NclxProfile tp; // what the libde265 plugin attaches (decoder_libde265.cc:339-362) ...
     tp.present = true; tp.primaries = h->colour_primaries; tp.transfer = h->transfer_characteristics;
     tp.matrix = h->matrix_coeffs; tp.full_range = h->full_range;
+    // heif_nclx_color_profile_set_* (heif.cc:1811-1905) stores "unspecified" for a code point it does not know and
+    // returns an error, which the plugin turns into a decoding warning - or, with strict_decoding, into a failure
+    // (HEIF_WARN_OR_FAIL, decoder_libde265.cc:339-357).  The warnings of grid tiles die with the tile images.
+    int warn = 0;
+    if (!hm_nclx_code_known(0, tp.primaries)) { tp.primaries = 2; warn |= HM_WARN_UNKNOWN_PRIMARIES; }
+    if (!hm_nclx_code_known(1, tp.transfer)) { tp.transfer = 2; warn |= HM_WARN_UNKNOWN_TRANSFER; }
+    if (!hm_nclx_code_known(2, tp.matrix)) { tp.matrix = 2; warn |= HM_WARN_UNKNOWN_MATRIX; }
+    if (warn && params->strict_decoding)
+      return hm_fail(HM_ERR_BITSTREAM, "Unknown NCLX %s (strict decoding)", (warn & 1) ? "color primaries" : (warn & 2) ? "transfer characteristics" : "matrix coefficients");
+    if (!is_grid) I.warnings |= warn;
     if (ti && ti->props.colr.present) tp = ti->props.colr; // ... unless the item has a 'colr' nclx (context.cc:1844-1852)
     if (i == 0) native = tp;
     hm_tile_dest d;
@@ -461,17 +472,22 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
   if (!f || !params || !out) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
   std::memset(out, 0, sizeof(*out));
   hipStream_t s = (hipStream_t)params->stream;
-  PlanarImage I;
+  // Everything the asynchronous work touches is declared before the guard below, so on every return path - errors
+  // included - the stream is drained before a buffer goes back to the pool (which may hand it to another thread).
+  PlanarImage I, A;
+  DevPlane alpha_scaled;
+  DevMem dout;
+  struct DrainOnExit { hipStream_t s; ~DrainOnExit() { hipStreamSynchronize(s); } } drain_guard{s};
   int rc = decode_planar(f, id, params, s, I);
   if (rc) return rc;
   // ---- alpha channel: the auxiliary image is decoded like any image (its own transformations included), its Y plane
   //      becomes the alpha plane, scaled nearest-neighbour if its size differs (context.cc:2029-2078) ----
-  PlanarImage A;
-  DevPlane alpha_scaled;
   const DevPlane* alpha = nullptr;
   const uint32_t alpha_id = f->file.alpha_item_of(id);
   if (alpha_id) {
     if ((rc = decode_planar(f, alpha_id, params, s, A))) return rc;
+    // what the colour ops refuse is refused before more work is queued (rgb2rgb.cc:81-84: any alpha depth but 8)
+    if (params->out_format == HM_OUT_RGBA && A.bd != 8) return hm_fail(HM_ERR_UNSUPPORTED, "alpha plane of %d bits with an 8-bit RGBA target", A.bd);
     alpha = &A.P[0];
     if (A.w != I.w || A.h != I.h) {
       if ((rc = alloc_plane(alpha_scaled, I.w, I.h, A.bd > 8 ? 2 : 1))) return rc;
@@ -484,7 +500,6 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
   const int img_w = I.w, img_h = I.h, chroma = I.chroma, bd = I.bd;
   const hm::NclxProfile& native = I.native;
   const bool is_grid = I.is_grid;
-  DevMem dout;
   static const bool trace = std::getenv("HM_TRACE") != nullptr;
   const auto t_start = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {
@@ -493,6 +508,7 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
   };
 
   out->width = img_w; out->height = img_h; out->bit_depth = bd; out->chroma = chroma;
+  out->warnings = I.warnings;
   // a grid canvas carries no nclx (context.cc:2250-2276); a single image keeps its own
   out->has_nclx = is_grid ? 0 : 1;
   out->primaries = native.primaries; out->transfer = native.transfer; out->matrix = native.matrix; out->full_range = native.full_range;
@@ -503,19 +519,19 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
       if (!P[c].mem.p) continue; // monochrome image: Y only
       const size_t sz = plane_bytes(P[c]);
       out->plane[c] = (uint8_t*)hm_pool_pinned_alloc(sz);
-      if (!out->plane[c]) { hm_decoded_free(out); return hm_fail(HM_ERR_NOMEM, "out of memory"); }
+      if (!out->plane[c]) { hipStreamSynchronize(s); hm_decoded_free(out); return hm_fail(HM_ERR_NOMEM, "out of memory"); }
       out->stride[c] = P[c].stride;
       e = hipMemcpyAsync(out->plane[c], P[c].mem.p, sz, hipMemcpyDeviceToHost, s);
-      if (e != hipSuccess) { hm_decoded_free(out); return hm_check_hip(e, "D2H"); }
+      if (e != hipSuccess) { hipStreamSynchronize(s); hm_decoded_free(out); return hm_check_hip(e, "D2H"); }
       out->plane_width[c] = P[c].w; out->plane_height[c] = P[c].h;
     }
     if (alpha) {
       const size_t sz = plane_bytes(*alpha);
       out->alpha = (uint8_t*)hm_pool_pinned_alloc(sz);
-      if (!out->alpha) { hm_decoded_free(out); return hm_fail(HM_ERR_NOMEM, "out of memory"); }
+      if (!out->alpha) { hipStreamSynchronize(s); hm_decoded_free(out); return hm_fail(HM_ERR_NOMEM, "out of memory"); }
       out->alpha_stride = alpha->stride;
       e = hipMemcpyAsync(out->alpha, alpha->mem.p, sz, hipMemcpyDeviceToHost, s);
-      if (e != hipSuccess) { hm_decoded_free(out); return hm_check_hip(e, "D2H"); }
+      if (e != hipSuccess) { hipStreamSynchronize(s); hm_decoded_free(out); return hm_check_hip(e, "D2H"); }
     }
   }
   else {
@@ -536,7 +552,6 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
       // RGB24 / RRGGBB targets have no alpha: Op_drop_alpha_plane, the colour values do not depend on it.  RGBA: the 8-bit
       // ops copy the plane (yuv2rgb.cc:483-488, rgb2rgb.cc:81-84 refuses any other alpha depth)
       if (params->out_format == HM_OUT_RGBA) {
-        if (A.bd != 8) return hm_fail(HM_ERR_UNSUPPORTED, "alpha plane of %d bits with an 8-bit RGBA target", A.bd);
         if ((rc = hm_launch_set_alpha(dout.p, cd.out_stride, img_w, img_h, alpha->mem.p, alpha->stride, s))) return rc;
       }
       else if (params->out_format != HM_OUT_RGB)
@@ -567,13 +582,13 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
       out->plane[0] = (uint8_t*)hm_pool_pinned_alloc(obytes);
       if (!out->plane[0]) return hm_fail(HM_ERR_NOMEM, "out of memory");
       e = hipMemcpyAsync(out->plane[0], dout.p, obytes, hipMemcpyDeviceToHost, s);
-      if (e != hipSuccess) { hm_decoded_free(out); return hm_check_hip(e, "D2H"); }
+      if (e != hipSuccess) { hipStreamSynchronize(s); hm_decoded_free(out); return hm_check_hip(e, "D2H"); }
     }
   }
   lap("colour + D2H enqueued");
   e = hipStreamSynchronize(s);
   lap("stream drained");
-  if (e != hipSuccess) { hm_decoded_free(out); return hm_check_hip(e, "kernel execution"); }
+  if (e != hipSuccess) { hipStreamSynchronize(s); hm_decoded_free(out); return hm_check_hip(e, "kernel execution"); }
   return HM_OK;
 }
 

@@ -161,6 +161,27 @@ HM_API int  hm_batch_get_timings(hm_batch* b, int slot, float ms[3]);
 HM_API int  hm_batch_algorithmic_bytes(const hm_batch* b, uint64_t* stream_bytes, uint64_t* sample_bytes);
 
 /* ------------------------------------------------------------------------- */
+/* Plugin level: one coded picture -> host planes                              */
+/* ------------------------------------------------------------------------- */
+
+/* What heif_decoder_plugin::decode_image produces (libheif/plugins/decoder_libde265.cc:88-157, 311-369): the planes of
+ * the last pushed picture at the conformance-window size, chroma planes width / SubWidthC x height / SubHeightC
+ * (de265_get_image_width/height(img, c)), one plane for 4:0:0, all planes of one bit depth, plus the VUI colour
+ * description (defaults 2,2,2, limited).  `data` is the push_data() byte string ([u32 BE length][NAL]...). */
+typedef struct hm_picture hm_picture;
+typedef struct hm_picture_info {
+  int32_t chroma, bit_depth, n_planes;       /* enum heif_chroma value; 8..12; 1 (4:0:0) or 3             */
+  int32_t plane_width[3], plane_height[3];   /* samples                                                   */
+  int32_t primaries, transfer, matrix, full_range;
+} hm_picture_info;
+/* host entropy decode (CABAC on the calling thread); *out owns the command stream */
+HM_API int  hm_picture_parse(const uint8_t* data, size_t size, hm_picture** out, hm_picture_info* info);
+/* reconstruction + in-loop filters on the GPU, then rows of plane_width * bytes_per_sample bytes into plane[c]
+ * (host memory, e.g. heif_image_get_plane()); returns after the copy has completed */
+HM_API int  hm_picture_decode_to_host(hm_picture* p, uint8_t* const plane[3], const int32_t stride[3], void* stream);
+HM_API void hm_picture_free(hm_picture* p);
+
+/* ------------------------------------------------------------------------- */
 /* Image level: HEIF file -> pixels (host box parsing + CABAC, GPU everything else) */
 /* ------------------------------------------------------------------------- */
 
@@ -186,6 +207,9 @@ typedef struct hm_decode_params {
   void*   ext_dst;             /* optional caller buffer for interleaved output (fork API:       */
   uint32_t ext_dst_len;        /*   heif_decoding_options_add_external_dest, heif.h:1605-1615)   */
   uint32_t ext_dst_stride;
+  int32_t strict_decoding;     /* heif_decoding_options.strict_decoding (heif.h:1591): an unknown VUI colour code is an
+                                  error instead of a warning (HEIF_WARN_OR_FAIL, heif_plugin.h:290-301)              */
+  int32_t convert_hdr_to_8bit; /* heif_decoding_options.convert_hdr_to_8bit (heif.h:1577, context.cc:1550)          */
 } hm_decode_params;
 
 typedef struct hm_decoded {
@@ -202,7 +226,14 @@ typedef struct hm_decoded {
   int32_t has_alpha;
   uint8_t* alpha;              /* pinned host memory like plane[], NULL unless out_format == 0 && has_alpha */
   int32_t alpha_stride;
+  int32_t warnings;            /* HM_WARN_*: what heif_image_get_decoding_warnings reports (heif.cc:1223-1245)     */
 } hm_decoded;
+/* non-strict decoding replaces an unknown colour code of the VUI by "unspecified" and records a warning
+ * (decoder_libde265.cc:339-357 via heif_nclx_color_profile_set_*, heif.cc:1811-1905) */
+enum { HM_WARN_UNKNOWN_PRIMARIES = 1, HM_WARN_UNKNOWN_TRANSFER = 2, HM_WARN_UNKNOWN_MATRIX = 4 };
+/* 1 if `value` is a code point libheif knows for kind 0 = colour primaries, 1 = transfer characteristics,
+ * 2 = matrix coefficients (the known_* sets of heif.cc:1795-1885) */
+HM_API int hm_nclx_code_known(int kind, int value);
 
 /* parse the box structure (the bytes are copied).  Replaces heif_context_read_from_memory. */
 HM_API int      hm_file_open(const uint8_t* data, size_t size, hm_file** out);

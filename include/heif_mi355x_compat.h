@@ -39,7 +39,9 @@ enum heif_error_code {
 enum heif_suberror_code {
   heif_suberror_Unspecified = 0, heif_suberror_End_of_data = 100, heif_suberror_No_item_data = 117,
   heif_suberror_Invalid_grid_data = 118, heif_suberror_Wrong_tile_image_chroma_format = 127,
-  heif_suberror_Invalid_image_size = 129, heif_suberror_Nonexisting_item_referenced = 2000,
+  heif_suberror_Invalid_image_size = 129, heif_suberror_Unknown_NCLX_color_primaries = 133,
+  heif_suberror_Unknown_NCLX_transfer_characteristics = 134, heif_suberror_Unknown_NCLX_matrix_coefficients = 135,
+  heif_suberror_Nonexisting_item_referenced = 2000,
   heif_suberror_Null_pointer_argument = 2001, heif_suberror_Nonexisting_image_channel_referenced = 2002,
   heif_suberror_Unsupported_plugin_version = 2003, heif_suberror_Unsupported_codec = 3000,
   heif_suberror_Unsupported_image_type = 3001, heif_suberror_Unsupported_color_conversion = 3003,
@@ -122,8 +124,10 @@ HMC_API int heif_context_get_list_of_top_level_image_IDs(struct heif_context* ct
 HMC_API struct heif_error heif_context_get_primary_image_ID(struct heif_context* ctx, heif_item_id* id);
 HMC_API struct heif_error heif_context_get_primary_image_handle(struct heif_context* ctx, struct heif_image_handle**);
 HMC_API struct heif_error heif_context_get_image_handle(struct heif_context* ctx, heif_item_id id, struct heif_image_handle**);
-/* fork API, heif.cc:499-514: tile threads for a grid (here: host entropy-decode threads) */
-HMC_API struct heif_error heif_context_set_threads(struct heif_context* ctx, struct heif_image_handle* handle, int nthreads);
+/* fork API, heif.h:1015 / heif.cc:499-514: for a grid item the threads fan the tiles out (max_decoding_threads), for a
+ * single image they go to the decoder (max_decoder_threads -> new_decoder(&dec, nthreads)); here both feed the host
+ * entropy decode (tile-parallel for grids, sub-stream parallel inside one picture) */
+HMC_API void heif_context_set_threads(struct heif_context* ctx, const struct heif_image_handle* in_handle, int nthreads);
 HMC_API void heif_image_handle_release(const struct heif_image_handle*);
 HMC_API int heif_image_handle_get_width(const struct heif_image_handle* handle);
 HMC_API int heif_image_handle_get_height(const struct heif_image_handle* handle);
@@ -163,6 +167,9 @@ HMC_API struct heif_error heif_nclx_color_profile_set_transfer_characteristics(s
 HMC_API struct heif_error heif_nclx_color_profile_set_matrix_coefficients(struct heif_color_profile_nclx* nclx, uint16_t mc);
 HMC_API struct heif_error heif_image_set_nclx_color_profile(struct heif_image* image, const struct heif_color_profile_nclx* color_profile);
 HMC_API struct heif_error heif_image_get_nclx_color_profile(const struct heif_image* image, struct heif_color_profile_nclx** out_data);
+/* heif.h:1700-1712 / heif.cc:1223-1245: warnings of non-strict decoding (unknown VUI colour codes) */
+HMC_API int heif_image_get_decoding_warnings(struct heif_image* image, int first_warning_idx, struct heif_error* out_warnings, int max_output_buffer_entries);
+HMC_API void heif_image_add_decoding_warning(struct heif_image* image, struct heif_error err);
 
 /* ---- plugin ABI (heif_plugin.h:53-112, heif.h:584-596) ---- */
 struct heif_decoder_plugin {

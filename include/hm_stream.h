@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HM_STREAM_MAGIC 0x314d5348u /* "HSM1" */
+#define HM_STREAM_MAGIC 0x324d5348u /* "HSM2" */
 
 /* hm_pic.flags */
 #define HM_PIC_STRONG_INTRA_SMOOTHING 0x0001u /* sps.strong_intra_smoothing_enable_flag        */
@@ -91,6 +91,8 @@ typedef struct hm_slice {
 #define HM_CTB_DEBLOCK_OFF   0x08u /* slice_deblocking_filter_disabled_flag of the CTB's slice           */
 #define HM_CTB_SAO_LUMA      0x10u /* slice_sao_luma_flag of the CTB's slice                            */
 #define HM_CTB_SAO_CHROMA    0x20u /* slice_sao_chroma_flag of the CTB's slice                          */
+#define HM_CTB_LOSSLESS      0x40u /* the CTB holds a PCM or cu_transquant_bypass coding unit (image.h:190 of the reference:
+                                      has_pcm_or_cu_transquant_bypass, which sends SAO down its per-sample path)      */
 
 /* SAO parameters of one colour component of one CTB (slice.h:457-465, offsets pre-scaled
  * by log2_sao_offset_scale as slice.cc:2996-3007 does) */
@@ -108,9 +110,15 @@ typedef struct hm_ctb {
   uint16_t tu_count;
   uint16_t slice_idx;    /* index into hm_slice[]                                             */
   uint8_t  flags;        /* HM_CTB_*                                                          */
-  uint8_t  sao_nb_mask;  /* bit k set: neighbour CTB k usable by SAO edge offset; k = 0..7 =
+  uint8_t  sao_nb_mask;  /* luma: bit k set: neighbour CTB k usable by SAO edge offset; k = 0..7 =
                             NW,N,NE,W,E,SW,S,SE (sao.cc:336-424 slice/tile tests)             */
-  uint16_t reserved;
+  uint8_t  sao_nb_mask_c;/* the same for the chroma planes.  It differs from the luma mask because the reference
+                            looks up "the slice of this CTB" with the CTB's *chroma* sample position
+                            (sao.cc:291: get_SliceHeader(xC, yC), xC = xCtb * nSW), i.e. for 4:2:0 it takes
+                            the slice address of CTB (x/2, y/2) - quirk Q13, reproduced                   */
+  uint8_t  sao_ring_c;   /* chroma: 1 = the samples of the CTB's outer ring (first / last row / column: the
+                            only ones the reference tests, sao.cc:366) may use a neighbour sample inside
+                            their own CTB; 0 when the mis-addressed slice of Q13 forbids it (luma: always 1) */
   hm_sao   sao[3];
 } hm_ctb; /* 36 bytes */
 

@@ -558,16 +558,21 @@ static void apply_sao(pic_t* P, uint16_t* const src[3])
               const int xx = xC + i, yy = yC + j;
               if (keep_mask && (blk_flags(P, xx << lsx, yy << lsy) & keep_mask)) continue;
               int ok = 1;
+              /* sao.cc:366: only the samples of the CTB's outer ring are tested at all */
+              const int ring = (i == 0 || j == 0 || i == cw - 1 || j == ch - 1);
+              const unsigned nbm = cIdx == 0 ? c->sao_nb_mask : c->sao_nb_mask_c;
               for (int k = 0; k < 2 && ok; k++) {
                 const int xS = xx + hPos[cl][k], yS = yy + vPos[cl][k];
                 if (xS < 0 || yS < 0 || xS >= W || yS >= Hh) { ok = 0; break; }
-                /* neighbour in another CTB: usable only if the host marked that CTB (slice / tile rules) */
+                /* neighbour in another CTB: usable only if the host marked that CTB (slice / tile rules); in the own
+                   CTB: always for luma, per sao_ring_c for chroma (the reference's mis-addressed slice test, Q13) */
                 const int ncx = xS / nSW, ncy = yS / nSH;
                 if (ncx != cx || ncy != cy) {
                   static const int kidx[3][3] = {{0, 1, 2}, {3, -1, 4}, {5, 6, 7}};
                   const int k8 = kidx[ncy - cy + 1][ncx - cx + 1];
-                  if (!(c->sao_nb_mask & (1u << k8))) ok = 0;
+                  if (!(nbm & (1u << k8))) ok = 0;
                 }
+                else if (ring && cIdx != 0 && !c->sao_ring_c) ok = 0;
               }
               if (!ok) continue;
               const int v = src[cIdx][xx + (size_t)yy * W];

@@ -62,11 +62,35 @@ CASES = {
                         pcm_bits_c=7, pcm_loop_filter_disable=1, tq_bypass=200),
 }
 
+# slice / tile structure (slice.cc:5004-5083, 5350-5406; deblock.cc:160-196; sao.cc:336-424): several slices, dependent
+# slice segments, tiles (uniform / explicit), loop filters stopped at slice / tile borders, per-slice deblocking
+# override, SAO flags, QP and chroma QP offsets, WPP together with slices / tiles, conformance windows
+CASES.update({
+    "slices": dict(seed=6100001, width=256, height=192, slices=60),
+    "slices_dependent": dict(seed=6100002, width=256, height=192, slices=60, dependent=500),
+    "slices_nolf": dict(seed=6100003, width=256, height=192, slices=80, pps_lf_across_slices_off=1),
+    "slices_headers": dict(seed=6100004, width=256, height=192, slices=80, slice_lf_random=1, deblock_override=1, slice_sao_random=1,
+                           slice_qp_random=1, slice_chroma_qp=1, dependent=300),
+    "tiles_3x2": dict(seed=6100005, width=256, height=192, tile_cols=3, tile_rows=2),
+    "tiles_3x2_nolf": dict(seed=6100006, width=256, height=192, tile_cols=3, tile_rows=2, lf_across_tiles=0),
+    "tiles_explicit_slices": dict(seed=6100007, width=320, height=256, tile_cols=4, tile_rows=3, tiles_uniform=0, lf_across_tiles=0, slices=100,
+                                  dependent=400, slice_lf_random=1),
+    "wpp_slices_dependent": dict(seed=6100008, width=256, height=192, wpp=1, slices=100, dependent=600),
+    "wpp_tiles_slices": dict(seed=6100009, width=256, height=192, wpp=1, tile_cols=2, tile_rows=2, slices=50, dependent=300, lf_across_tiles=0),
+    "tiles_422_10_ctb64": dict(seed=6100010, width=256, height=192, log2_ctb=6, tile_cols=2, tile_rows=2, slices=300, chroma_format=2, bit_depth=10,
+                               lf_across_tiles=0, slice_lf_random=1),
+    "slices_444_pcm": dict(seed=6100011, width=192, height=128, chroma_format=3, slices=120, dependent=300, slice_lf_random=1, pcm=200,
+                           pcm_loop_filter_disable=1, tq_bypass=150, slice_sao_random=1),
+    "slices_mono_ctb16": dict(seed=6100012, width=160, height=96, chroma_format=0, log2_ctb=4, slices=60, dependent=400, pps_lf_across_slices_off=1),
+    "conf_window": dict(seed=6100013, width=200, height=136, conf_left=2, conf_right=6, conf_top=4, conf_bottom=2),
+    "conf_window_422_10": dict(seed=6100014, width=200, height=136, conf_right=8, conf_bottom=6, chroma_format=2, bit_depth=10),
+})
+
 # 8-bit pictures in which the reference takes its "pcmf" deblocking branch: its SIMD build (the configuration of
 # oracle/_ref, and what x86 / ARM users run) filters luma edges between ordinary units with the SSE / NEON kernel, its
 # scalar build leaves them unfiltered (fallback-postfilter.h:85-124 reads the flags with the opposite polarity).  The
 # fixtures and the product follow the SIMD build; tools/make_fixtures.py does not require the scalar build to agree.
-SIMD_BUILD_ONLY = {"pcm_nofilter", "tq_bypass", "yuv444_rare"}
+SIMD_BUILD_ONLY = {"pcm_nofilter", "tq_bypass", "yuv444_rare", "slices_444_pcm"}
 
 
 def stream(name):
@@ -89,5 +113,34 @@ def rare_syntax_sweep(n, first_seed=2000):
             kw["log2_ctb"] = 5  # 8-bit SAO on 8-sample-wide chroma CTBs: the reference's SIMD quirk Q9, not a corpus subject
         kw["pcm_bits_y"] = max(1, kw["bit_depth"] - seed % 3)
         kw["pcm_bits_c"] = max(1, kw["bit_depth"] - seed % 4)
+        out.append((seed, kw))
+    return out
+
+
+def structure_sweep(n, first_seed=7000):
+    """(seed, parameters) of a seeded sweep over slice / tile structures: slices, dependent segments, uniform / explicit
+    tiles, loop filters stopped at slice / tile borders, per-slice headers, WPP, all chroma formats, CTB sizes, depths."""
+    out = []
+    for seed in range(first_seed, first_seed + n):
+        r = seed * 2654435761 % (1 << 32)
+        pick = lambda k, opts: opts[(r >> k) % len(opts)]
+        kw = dict(width=pick(0, [128, 192, 256, 160]), height=pick(2, [128, 96, 192, 64]), log2_ctb=pick(4, [5, 5, 4, 6]),
+                  chroma_format=pick(6, [1, 1, 2, 3, 0]), bit_depth=pick(9, [8, 8, 10, 12]),
+                  slices=pick(11, [0, 40, 100, 300]), dependent=pick(13, [0, 300, 1000]),
+                  tile_cols=pick(15, [1, 1, 2, 3]), tile_rows=pick(17, [1, 2, 3]), tiles_uniform=pick(19, [1, 0]),
+                  lf_across_tiles=pick(20, [1, 0]), pps_lf_across_slices_off=pick(21, [0, 0, 1]), slice_lf_random=pick(23, [0, 1]),
+                  deblock_override=pick(24, [0, 1]), slice_sao_random=pick(25, [0, 1]), slice_qp_random=pick(26, [0, 1]),
+                  slice_chroma_qp=pick(27, [0, 1]), wpp=pick(28, [0, 0, 1]), cu_qp_delta=1, diff_cu_qp_delta_depth=pick(30, [1, 0, 2]))
+        if seed % 9 == 0:
+            kw.update(pcm=200, pcm_loop_filter_disable=seed % 2, tq_bypass=150)
+            kw["pcm_bits_y"] = kw["pcm_bits_c"] = kw["bit_depth"]
+        if kw["log2_ctb"] == 4 and kw["bit_depth"] == 8 and kw["chroma_format"] in (1, 2):
+            kw["log2_ctb"] = 5  # quirk Q9 (see rare_syntax_sweep)
+        if kw["wpp"] and (kw["tile_cols"] > 1 or kw["tile_rows"] > 1):
+            # WPP together with tiles: the reference accepts at most one entry point per tile and per remaining CTB row
+            # (slice.cc:813-829) and takes its row tables from picture column 1 - only short slices in full-width tiles
+            kw["tile_cols"] = 1
+            kw["slices"] = max(kw["slices"], 300)
+        kw["diff_cu_qp_delta_depth"] = min(kw["diff_cu_qp_delta_depth"], kw["log2_ctb"] - 3)
         out.append((seed, kw))
     return out

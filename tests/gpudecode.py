@@ -5,8 +5,8 @@ import numpy as np
 
 
 def decode_pictures(pkg, blobs, stages=3, dests=None):
-    """Decode a batch of command streams on cuda:0; every picture gets its own canvas unless
-    `dests` (list of (x0, y0, canvas_index)) says otherwise.  Returns list of [Y, Cb, Cr] uint16 arrays."""
+    """Decode a batch of command streams on cuda:0; every picture gets its own canvas of the size of its conformance
+    window (what a decoder plugin hands out).  Returns list of [Y, Cb, Cr] uint16 arrays."""
     import torch
     capi = pkg.capi
     dev = torch.device("cuda:0")
@@ -15,7 +15,8 @@ def decode_pictures(pkg, blobs, stages=3, dests=None):
     keep = []
     for blob in blobs:
         h = capi.stream_header(blob)
-        w, hh, cf, bd = h["width"], h["height"], h["chroma_format"], h["bit_depth"]
+        cl, cr, ct, cb = h["crop"]
+        w, hh, cf, bd = h["width"] - cl - cr, h["height"] - ct - cb, h["chroma_format"], h["bit_depth"]
         bps = 2 if bd > 8 else 1
         cw, ch = (w if cf == 3 else w // 2), (hh // 2 if cf == 1 else hh)
         planes = []

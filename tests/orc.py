@@ -169,8 +169,15 @@ def ref_decode(data, flags=0, threads=0):
     return planes, info
 
 
-def oracle_decode(blob, stages=3):
-    """Run the oracle's scalar executors on a command-stream blob (bytes)."""
+def conformance_window(blob):
+    """(left, right, top, bottom) of hm_pic in luma samples"""
+    import struct
+    return struct.unpack_from("<4H", blob, 12)
+
+
+def oracle_decode(blob, stages=3, crop=False):
+    """Run the oracle's scalar executors on a command-stream blob (bytes).  crop=True: the conformance window only,
+    i.e. the planes a decoder plugin hands out (de265_get_image_plane / width / height)."""
     o = load()
     info = (C.c_int * 8)()
     buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
@@ -184,5 +191,12 @@ def oracle_decode(blob, stages=3):
     rc = o.orc_decode_picture(buf, len(blob), stages, ptr(y), ptr(cb), ptr(cr))
     if rc != 0:
         raise RuntimeError(f"oracle decode failed: {rc}")
+    if crop:
+        cl, cr_, ct, cb_ = conformance_window(blob)
+        sw, sh = (1 if cf == 3 else 2), (2 if cf == 1 else 1)
+        y = np.ascontiguousarray(y[ct:h - cb_, cl:w - cr_])
+        cb = np.ascontiguousarray(cb[ct // sh:(h - cb_) // sh, cl // sw:(w - cr_) // sw])
+        cr = np.ascontiguousarray(cr[ct // sh:(h - cb_) // sh, cl // sw:(w - cr_) // sw])
+        w, h = w - cl - cr_, h - ct - cb_
     return ([y] if cf == 0 else [y, cb, cr]), dict(width=w, height=h, chroma=cf, bit_depth=info[3], full_range=info[4],
                              matrix=info[5], primaries=info[6], has_vui_colour=info[7])

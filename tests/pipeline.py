@@ -19,13 +19,14 @@ class ImageInfo(C.Structure):
 class DecodeParams(C.Structure):
     _fields_ = [("out_format", C.c_int32), ("host_threads", C.c_int32), ("ignore_transformations", C.c_int32),
                 ("chroma_upsampling", C.c_int32), ("stream", C.c_void_p), ("ext_dst", C.c_void_p),
-                ("ext_dst_len", C.c_uint32), ("ext_dst_stride", C.c_uint32)]
+                ("ext_dst_len", C.c_uint32), ("ext_dst_stride", C.c_uint32), ("strict_decoding", C.c_int32),
+                ("convert_hdr_to_8bit", C.c_int32)]
 
 
 class Decoded(C.Structure):
     _fields_ = [(n, C.c_int32) for n in "width height bit_depth chroma out_format has_nclx primaries transfer matrix full_range used_ext_dst".split()] + \
                [("plane", C.POINTER(C.c_uint8) * 3), ("stride", C.c_int32 * 3), ("plane_width", C.c_int32 * 3), ("plane_height", C.c_int32 * 3),
-                ("has_alpha", C.c_int32), ("alpha", C.POINTER(C.c_uint8)), ("alpha_stride", C.c_int32)]
+                ("has_alpha", C.c_int32), ("alpha", C.POINTER(C.c_uint8)), ("alpha_stride", C.c_int32), ("warnings", C.c_int32)]
 
 
 def bind(hm):

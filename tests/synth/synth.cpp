@@ -163,6 +163,19 @@ struct SynthParams {
   int32_t pcm_log2_min, pcm_log2_max; // PCM coding block sizes
   int32_t pcm_loop_filter_disable;
   int32_t tq_bypass;           // 0: transquant_bypass_enabled_flag = 0; else per-mille chance of cu_transquant_bypass_flag
+  // --- slice / tile structure (all 0 = one slice, no tiles: the streams of round 1, byte for byte) ---
+  int32_t slices;              // per-mille chance that a slice segment ends after a CTB
+  int32_t dependent;           // per-mille chance that a new slice segment is a dependent one
+  int32_t tile_cols, tile_rows;// > 1: tiles_enabled_flag
+  int32_t tiles_uniform;       // uniform_spacing_flag (else seeded column widths / row heights)
+  int32_t lf_across_tiles;     // loop_filter_across_tiles_enabled_flag
+  int32_t pps_lf_across_slices_off; // pps_loop_filter_across_slices_enabled_flag = 0
+  int32_t slice_lf_random;     // slice_loop_filter_across_slices_enabled_flag drawn per slice (else 1)
+  int32_t deblock_override;    // deblocking_filter_override_enabled_flag: per-slice disable flag / offsets
+  int32_t slice_sao_random;    // slice_sao_luma / chroma flags drawn per slice
+  int32_t slice_qp_random;     // slice_qp_delta drawn per slice (qp - 3 .. qp + 3)
+  int32_t slice_chroma_qp;     // pps_slice_chroma_qp_offsets_present_flag: per-slice cb / cr offsets
+  int32_t conf_left, conf_right, conf_top, conf_bottom; // conformance window, luma samples (multiples of 2)
 };
 
 // entropy-coder adaptor for SliceWalker: chooses every bin, encodes it, returns it
@@ -181,13 +194,23 @@ class EncoderEC {
     enc.bypass(b);
     return b;
   }
+  // expect: -1 = end_of_slice_segment_flag the stream is free to choose, 1 = ... that must be 1 (last CTB of the
+  // picture), 2 = end_of_subset_one_bit
   int terminate(int expect)
   {
-    const int b = expect < 0 ? 0 : expect;
+    int b;
+    if (expect == 2) b = 1;
+    else {
+      b = expect < 0 ? end_segment_after(ts_) : expect;
+      ts_++;
+    }
     enc.terminate(b);
     if (b) substream_ends.push_back(enc.out.size());
     return b;
   }
+  // position of the segment being written (tile-scan address of the next CTB) and what the walker must respect
+  void begin_segment(int ts, const SPS* sps, const PPS* pps) { ts_ = seg_start_ts_ = ts; sps_ = sps; pps_ = pps; }
+  int next_ts() const { return ts_; }
   ContextSet& contexts() { return cs_; }
   void start_substream() { enc.reset(); }
   // pcm_flag = 1: the arithmetic coder is flushed (EncodeFlush ends with the bit 1) and zero bits pad to the byte
@@ -215,6 +238,32 @@ class EncoderEC {
   std::vector<size_t> substream_ends;
 
  private:
+  // 1 if the slice segment ends after the CTB at tile-scan address ts (not the last of the picture)
+  int end_segment_after(int ts)
+  {
+    if (!P.slices || !pps_) return 0;
+    const int W = sps_->ctb_w;
+    const bool new_tile = pps_->tiles_enabled && pps_->TileId[ts + 1] != pps_->TileId[ts];
+    if (new_tile) return 1; // every slice (segment) lies inside one tile (6.3.1)
+    if (pps_->entropy_coding_sync) {
+      // a segment that does not start at the beginning of a CTB row (of its tile) ends in that row (7.4.7.1)
+      const int rs0 = pps_->CtbAddrTStoRS[seg_start_ts_], nrs = pps_->CtbAddrTStoRS[ts + 1];
+      const int tile_x0 = pps_->colBd[tile_col_of(rs0 % W)];
+      const bool started_mid_row = (rs0 % W) != tile_x0;
+      const bool next_is_row_start = (nrs % W) == pps_->colBd[tile_col_of(nrs % W)];
+      if (started_mid_row && next_is_row_start) return 1;
+    }
+    return rng_.chance(P.slices);
+  }
+  int tile_col_of(int x) const
+  {
+    int c = 0;
+    while (c + 1 < (int)pps_->colBd.size() - 1 && x >= pps_->colBd[c + 1]) c++;
+    return c;
+  }
+  int ts_ = 0, seg_start_ts_ = 0;
+  const SPS* sps_ = nullptr;
+  const PPS* pps_ = nullptr;
   int choose(int kind, int idx)
   {
     const int d = P.density; // percent
@@ -331,7 +380,12 @@ __attribute__((visibility("default"))) int hm_synth_picture(const SynthParams* p
     w.ue(p.chroma_format);
     if (p.chroma_format == 3) w.flag(0); // separate_colour_plane_flag
     w.ue(p.width); w.ue(p.height);
-    w.flag(0); // conformance window
+    const bool conf = p.conf_left || p.conf_right || p.conf_top || p.conf_bottom;
+    w.flag(conf); // conformance_window_flag: offsets in chroma units
+    if (conf) {
+      const int sw = (p.chroma_format == 1 || p.chroma_format == 2) ? 2 : 1, shh = p.chroma_format == 1 ? 2 : 1;
+      w.ue(p.conf_left / sw); w.ue(p.conf_right / sw); w.ue(p.conf_top / shh); w.ue(p.conf_bottom / shh);
+    }
     w.ue(p.bit_depth - 8); w.ue(p.bit_depth - 8);
     w.ue(4);   // log2_max_pic_order_cnt_lsb_minus4
     w.flag(1); w.ue(0); w.ue(0); w.ue(0);
@@ -377,7 +431,8 @@ __attribute__((visibility("default"))) int hm_synth_picture(const SynthParams* p
   {
     BitWriter w;
     w.ue(0); w.ue(0);
-    w.flag(0); w.flag(0); w.put(0, 3);
+    w.flag(p.dependent != 0);  // dependent_slice_segments_enabled_flag
+    w.flag(0); w.put(0, 3);
     w.flag(p.sign_hiding != 0);
     w.flag(0);                 // cabac_init_present
     w.ue(0); w.ue(0);
@@ -387,14 +442,28 @@ __attribute__((visibility("default"))) int hm_synth_picture(const SynthParams* p
     w.flag(p.cu_qp_delta != 0);
     if (p.cu_qp_delta) w.ue(p.diff_cu_qp_delta_depth);
     w.se(p.cb_qp_offset); w.se(p.cr_qp_offset);
-    w.flag(0);                 // slice_chroma_qp_offsets_present
+    w.flag(p.slice_chroma_qp != 0); // pps_slice_chroma_qp_offsets_present_flag
     w.flag(0); w.flag(0);      // weighted pred
     w.flag(p.tq_bypass != 0);  // transquant_bypass_enabled_flag
-    w.flag(0);                 // tiles
+    const bool tiles = p.tile_cols > 1 || p.tile_rows > 1;
+    w.flag(tiles);             // tiles_enabled_flag
     w.flag(p.wpp != 0);        // entropy_coding_sync
-    w.flag(1);                 // pps_loop_filter_across_slices_enabled
+    if (tiles) {
+      const int ctb = 1 << p.log2_ctb, cw = (p.width + ctb - 1) / ctb, chh = (p.height + ctb - 1) / ctb;
+      const int nc = p.tile_cols < 1 ? 1 : (p.tile_cols > cw ? cw : p.tile_cols), nr = p.tile_rows < 1 ? 1 : (p.tile_rows > chh ? chh : p.tile_rows);
+      w.ue(nc - 1); w.ue(nr - 1);
+      w.flag(p.tiles_uniform != 0);
+      if (!p.tiles_uniform) { // seeded explicit sizes: every tile at least one CTB
+        int left = cw;
+        for (int i = 0; i < nc - 1; i++) { const int mx = left - (nc - 1 - i); const int v = 1 + (int)(hdr_rng.next() % (uint64_t)mx); w.ue(v - 1); left -= v; }
+        left = chh;
+        for (int i = 0; i < nr - 1; i++) { const int mx = left - (nr - 1 - i); const int v = 1 + (int)(hdr_rng.next() % (uint64_t)mx); w.ue(v - 1); left -= v; }
+      }
+      w.flag(p.lf_across_tiles != 0);
+    }
+    w.flag(!p.pps_lf_across_slices_off); // pps_loop_filter_across_slices_enabled
     w.flag(1);                 // deblocking_filter_control_present
-    w.flag(0);                 //   override enabled
+    w.flag(p.deblock_override != 0); //   deblocking_filter_override_enabled_flag
     w.flag(p.deblock_disable != 0);
     if (!p.deblock_disable) { w.se(p.beta_offset_div2); w.se(p.tc_offset_div2); }
     w.flag(p.scaling_list == 3); // pps_scaling_list_data_present
@@ -420,46 +489,92 @@ __attribute__((visibility("default"))) int hm_synth_picture(const SynthParams* p
   const SPS& sps = sps_table[0];
   const PPS& pps = pps_table[0];
 
-  // ---- slice data ----
-  SliceHeader sh;
-  sh.nal_unit_type = 19;
-  sh.first_slice_segment_in_pic = true;
-  sh.slice_type = 2;
-  sh.sao_luma = p.sao != 0;
-  sh.sao_chroma = p.sao != 0 && p.chroma_format != 0;
-  sh.slice_qp_delta = p.qp - 26;
-  sh.SliceQPY = p.qp;
-  sh.deblocking_disabled = p.deblock_disable != 0;
-  sh.beta_offset_div2 = p.beta_offset_div2;
-  sh.tc_offset_div2 = p.tc_offset_div2;
-  sh.lf_across_slices = true;
-  sh.SliceAddrRS = 0;
+  // ---- slice segments: data first (the walker decides where a segment ends), then its header ----
   PictureState pic;
   pic.reset(sps, pps);
-  hm_slice hs; std::memset(&hs, 0, sizeof(hs));
-  pic.slices.push_back(hs);
   EncoderEC ec(seed, p);
-  ContextSet wpp_store, dep_store;
-  bool wpp_valid = false, dep_valid = false;
-  try {
-    SliceWalker<EncoderEC> walker(ec, pic, sh, 0);
-    walker.decode_slice_segment(0, &wpp_store, &wpp_valid, &dep_store, &dep_valid);
-  }
-  catch (const ParseError&) { return -3; }
-  const std::vector<uint8_t>& data = ec.enc.out;
+  Rng sl_rng(seed ^ 0x511ce5eedull); // per-slice header content
+  const int N = sps.ctb_w * sps.ctb_h;
+  SliceHeader sh;
+  int ts = 0;
+  while (ts < N) {
+    const bool first = ts == 0;
+    const bool tile_start = pps.tiles_enabled && (first || pps.TileId[ts] != pps.TileId[ts - 1]);
+    // a dependent segment continues the slice; a new tile always starts a new slice (every slice inside one tile)
+    const bool dependent = !first && p.dependent && !(tile_start && p.slices) && sl_rng.chance(p.dependent);
+    const int addr_rs = pps.CtbAddrTStoRS[ts];
+    if (!dependent) {
+      sh = SliceHeader();
+      sh.slice_type = 2;
+      sh.sao_luma = p.sao != 0;
+      sh.sao_chroma = p.sao != 0 && p.chroma_format != 0;
+      if (p.sao && p.slice_sao_random && !first) { sh.sao_luma = sl_rng.chance(600); sh.sao_chroma = p.chroma_format != 0 && sl_rng.chance(600); }
+      int qp = p.qp;
+      if (p.slice_qp_random && !first) qp += (int)(sl_rng.next() % 7) - 3;
+      qp = qp < 1 ? 1 : (qp > 51 ? 51 : qp);
+      sh.slice_qp_delta = qp - 26;
+      sh.SliceQPY = qp;
+      if (p.slice_chroma_qp) { sh.cb_qp_offset = (int)(sl_rng.next() % 7) - 3; sh.cr_qp_offset = (int)(sl_rng.next() % 7) - 3; }
+      sh.deblocking_disabled = p.deblock_disable != 0;
+      sh.beta_offset_div2 = p.beta_offset_div2;
+      sh.tc_offset_div2 = p.tc_offset_div2;
+      sh.lf_across_slices = !p.pps_lf_across_slices_off;
+      sh.SliceAddrRS = addr_rs;
+      hm_slice hs; std::memset(&hs, 0, sizeof(hs));
+      pic.slices.push_back(hs);
+    }
+    sh.nal_unit_type = 19;
+    sh.first_slice_segment_in_pic = first;
+    sh.dependent = dependent;
+    sh.slice_segment_address = addr_rs;
+    // header fields drawn before the data (the walker reads deblocking / SAO / filter flags from sh)
+    bool override_flag = false;
+    if (!dependent && p.deblock_override && !first) {
+      override_flag = sl_rng.chance(600);
+      if (override_flag) {
+        sh.deblocking_disabled = sl_rng.chance(400);
+        if (!sh.deblocking_disabled) { sh.beta_offset_div2 = (int)(sl_rng.next() % 13) - 6; sh.tc_offset_div2 = (int)(sl_rng.next() % 13) - 6; }
+      }
+    }
+    const bool lf_flag_coded = !p.pps_lf_across_slices_off && (sh.sao_luma || sh.sao_chroma || !sh.deblocking_disabled);
+    if (!dependent && lf_flag_coded && p.slice_lf_random && !first) sh.lf_across_slices = sl_rng.chance(500);
 
-  // ---- slice header ----
-  {
+    sh.num_entry_points = 1; // the walker ends a WPP sub-stream at a row change only if the header announces entry points
+    ec.enc = CabacEncoder();
+    ec.substream_ends.clear();
+    ec.begin_segment(ts, &sps, &pps);
+    int next_ts;
+    try {
+      SliceWalker<EncoderEC> walker(ec, pic, sh, (int)pic.slices.size() - 1);
+      next_ts = walker.decode_slice_segment(ts);
+    }
+    catch (const ParseError&) { return -3; }
+    const std::vector<uint8_t>& data = ec.enc.out;
+
     BitWriter w;
-    w.flag(1);                 // first_slice_segment_in_pic_flag
+    w.flag(first);             // first_slice_segment_in_pic_flag
     w.flag(0);                 // no_output_of_prior_pics_flag (IRAP)
     w.ue(0);                   // pps id
-    w.ue(2);                   // slice_type I
-    if (p.sao) { w.flag(1); if (p.chroma_format != 0) w.flag(1); } // slice_sao_luma_flag [, slice_sao_chroma_flag if ChromaArrayType != 0]
-    w.se(sh.slice_qp_delta);
-    // pps_loop_filter_across_slices_enabled_flag = 1 and (sao || !deblocking_disabled)
-    if (p.sao || !p.deblock_disable) w.flag(1);
-    if (p.wpp) {
+    if (!first) {
+      if (p.dependent) w.flag(dependent); // dependent_slice_segment_flag
+      w.put((uint32_t)addr_rs, ceil_log2((uint32_t)N)); // slice_segment_address
+    }
+    if (!dependent) {
+      w.ue(2);                 // slice_type I
+      if (p.sao) { w.flag(sh.sao_luma); if (p.chroma_format != 0) w.flag(sh.sao_chroma); } // slice_sao_luma_flag [, slice_sao_chroma_flag if ChromaArrayType != 0]
+      w.se(sh.slice_qp_delta);
+      if (p.slice_chroma_qp) { w.se(sh.cb_qp_offset); w.se(sh.cr_qp_offset); }
+      if (p.deblock_override) {
+        w.flag(override_flag);
+        if (override_flag) {
+          w.flag(sh.deblocking_disabled);
+          if (!sh.deblocking_disabled) { w.se(sh.beta_offset_div2); w.se(sh.tc_offset_div2); }
+        }
+      }
+      // pps_loop_filter_across_slices_enabled_flag = 1 and (sao || !deblocking_disabled)
+      if (lf_flag_coded) w.flag(sh.lf_across_slices);
+    }
+    if (p.wpp || pps.tiles_enabled) {
       // entry points: sizes of the sub-streams in the escaped domain.  A sub-stream never ends
       // in a zero byte (it ends with the terminating '1'), so escaping the slice data on its own
       // yields the same bytes as escaping the whole NAL.
@@ -491,7 +606,7 @@ __attribute__((visibility("default"))) int hm_synth_picture(const SynthParams* p
         while ((1u << len) < mx) len++;
         if (len > 32) return -4;
         w.ue(len - 1);
-        for (uint32_t s : sizes) w.put(s - 1, len);
+        for (uint32_t sz : sizes) w.put(sz - 1, len);
       }
     }
     w.put(1, 1);
@@ -499,6 +614,7 @@ __attribute__((visibility("default"))) int hm_synth_picture(const SynthParams* p
     std::vector<uint8_t> rbsp = w.buf;
     rbsp.insert(rbsp.end(), data.begin(), data.end());
     append_nal(stream, 19, rbsp);
+    ts = next_ts;
   }
   uint8_t* mem = (uint8_t*)std::malloc(stream.size());
   if (!mem) return -5;

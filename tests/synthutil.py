@@ -13,14 +13,19 @@ class SynthParams(C.Structure):
         "max_th_depth_intra", "qp", "cu_qp_delta", "diff_cu_qp_delta_depth", "sao", "deblock_disable",
         "sign_hiding", "transform_skip", "strong_intra", "cb_qp_offset", "cr_qp_offset",
         "beta_offset_div2", "tc_offset_div2", "vui", "full_range", "matrix", "primaries", "density", "wpp", "scaling_list", "pcm", "pcm_bits_y", "pcm_bits_c",
-        "pcm_log2_min", "pcm_log2_max", "pcm_loop_filter_disable", "tq_bypass")]
+        "pcm_log2_min", "pcm_log2_max", "pcm_loop_filter_disable", "tq_bypass",
+        "slices", "dependent", "tile_cols", "tile_rows", "tiles_uniform", "lf_across_tiles", "pps_lf_across_slices_off", "slice_lf_random",
+        "deblock_override", "slice_sao_random", "slice_qp_random", "slice_chroma_qp", "conf_left", "conf_right", "conf_top", "conf_bottom")]
 
 
 DEFAULTS = dict(width=64, height=64, chroma_format=1, bit_depth=8, log2_ctb=5, log2_min_cb=3, log2_min_tb=2,
                 log2_max_tb=5, max_th_depth_intra=2, qp=27, cu_qp_delta=1, diff_cu_qp_delta_depth=1, sao=1,
                 deblock_disable=0, sign_hiding=1, transform_skip=1, strong_intra=1, cb_qp_offset=0, cr_qp_offset=0,
                 beta_offset_div2=0, tc_offset_div2=0, vui=1, full_range=1, matrix=6, primaries=1, density=60, wpp=0, scaling_list=0,
-                pcm=0, pcm_bits_y=8, pcm_bits_c=8, pcm_log2_min=3, pcm_log2_max=5, pcm_loop_filter_disable=0, tq_bypass=0)
+                pcm=0, pcm_bits_y=8, pcm_bits_c=8, pcm_log2_min=3, pcm_log2_max=5, pcm_loop_filter_disable=0, tq_bypass=0,
+                slices=0, dependent=0, tile_cols=1, tile_rows=1, tiles_uniform=1, lf_across_tiles=1, pps_lf_across_slices_off=0,
+                slice_lf_random=0, deblock_override=0, slice_sao_random=0, slice_qp_random=0, slice_chroma_qp=0,
+                conf_left=0, conf_right=0, conf_top=0, conf_bottom=0)
 
 _lib = None
 

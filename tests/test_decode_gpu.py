@@ -23,7 +23,7 @@ def _streams():
 def test_stages_match_oracle(pkg, path, stages):
     data = open(path, "rb").read()
     blob = pkg.capi.parse_hevc(data, annexb=False)
-    exp, _ = orc.oracle_decode(blob, stages)
+    exp, _ = orc.oracle_decode(blob, stages, crop=True)
     got = gpudecode.decode_pictures(pkg, [blob], stages)[0]
     for c in range(3):
         bad = np.argwhere(got[c] != exp[c])
@@ -62,7 +62,7 @@ def test_synth_corpus(pkg, name):
     blob = pkg.capi.parse_hevc(corpus.stream(name))
     for stage, bits in (("recon", 0), ("deblock", 1), ("full", 3)):
         got = gpudecode.decode_pictures(pkg, [blob], bits)[0]
-        exp, _ = orc.oracle_decode(blob, bits)
+        exp, _ = orc.oracle_decode(blob, bits, crop=True)
         assert len(got) == len(exp)  # one plane for monochrome pictures
         for c in range(len(exp)):
             bad = np.argwhere(got[c] != exp[c])
@@ -86,7 +86,7 @@ def test_batch_of_mixed_pictures(pkg):
     blobs = [pkg.capi.parse_hevc(open(p, "rb").read()) for p in paths]
     got = gpudecode.decode_pictures(pkg, blobs, 3)
     for blob, g in zip(blobs, got):
-        exp, _ = orc.oracle_decode(blob, 3)
+        exp, _ = orc.oracle_decode(blob, 3, crop=True)
         for c in range(3):
             np.testing.assert_array_equal(g[c], exp[c])
 
@@ -100,7 +100,23 @@ def test_rare_syntax_sweep(pkg):
     for bits in (0, 1, 3):
         got = gpudecode.decode_pictures(pkg, blobs, bits)
         for (seed, kw), blob, g in zip(cases, blobs, got):
-            exp, _ = orc.oracle_decode(blob, bits)
+            exp, _ = orc.oracle_decode(blob, bits, crop=True)
+            assert len(g) == len(exp)
+            for c in range(len(exp)):
+                bad = np.argwhere(g[c] != exp[c])
+                assert bad.size == 0, f"seed {seed} {kw} stages {bits} plane {c}: {len(bad)} mismatches, first (y,x)={bad[0].tolist()}"
+
+
+def test_structure_sweep(pkg):
+    """several slices, dependent slice segments, tiles, WPP, loop filters stopped at slice / tile borders, conformance
+    windows - in one batch next to ordinary pictures: HIP == oracle at every stage"""
+    import synthutil
+    cases = corpus.structure_sweep(64)
+    blobs = [pkg.capi.parse_hevc(synthutil.picture(seed, **kw)) for seed, kw in cases]
+    for bits in (0, 1, 3):
+        got = gpudecode.decode_pictures(pkg, blobs, bits)
+        for (seed, kw), blob, g in zip(cases, blobs, got):
+            exp, _ = orc.oracle_decode(blob, bits, crop=True)
             assert len(g) == len(exp)
             for c in range(len(exp)):
                 bad = np.argwhere(g[c] != exp[c])

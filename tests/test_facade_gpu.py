@@ -34,8 +34,12 @@ def api(pkg):
     a.heif_context_get_primary_image_handle.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     a.heif_context_get_image_handle.restype = Err
     a.heif_context_get_image_handle.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
-    a.heif_context_set_threads.restype = Err
+    a.heif_context_set_threads.restype = None  # heif.h:1015: void f(ctx, const handle*, int)
     a.heif_context_set_threads.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    a.heif_image_get_decoding_warnings.argtypes = [C.c_void_p, C.c_int, C.POINTER(Err), C.c_int]
+    a.heif_image_get_colorspace.argtypes = [C.c_void_p]
+    a.heif_image_get_chroma_format.argtypes = [C.c_void_p]
+    a.heif_image_has_channel.argtypes = [C.c_void_p, C.c_int]
     a.heif_image_handle_release.argtypes = [C.c_void_p]
     a.heif_image_handle_get_width.argtypes = [C.c_void_p]
     a.heif_decode_image.restype = Err
@@ -141,7 +145,9 @@ def test_decoder_plugin_call_sequence(api, hm):
     assert api.heif_register_decoder_plugin(pl).code == 0
     p = pl.contents
     assert p.does_support_format(1) == 150
-    for name in ("tile512_novui", "hi422_10"):
+    # 4:2:0, 4:2:2, 4:0:0 (monochrome colourspace, one plane) and 4:4:4 (full-size chroma), 8 and 10 bit, a picture
+    # with a conformance window (ragged: 72x40 in 32-pixel CTBs): decoder_libde265.cc:88-157
+    for name in ("tile512_novui", "hi422_10", "mono8", "mono10", "yuv444_8", "yuv444_10_ctb64_wpp", "ragged", "hi420_10", "conf_window", "conf_window_422_10", "slices_mono_ctb16"):
         data = corpus.stream(name)
         dec = C.c_void_p()
         assert p.new_decoder(C.byref(dec), 0).code == 0
@@ -153,9 +159,17 @@ def test_decoder_plugin_call_sequence(api, hm):
         e = p.decode_image(dec, C.byref(img))
         assert e.code == 0, e.message
         p.free_decoder(dec)
-        exp, info = orc.oracle_decode(hevcutil.parse(hm, data), 3)
+        exp, info = orc.oracle_decode(hevcutil.parse(hm, data), 3, crop=True)
         wide = info["bit_depth"] > 8
-        for c in range(3):
+        cf = info["chroma"]
+        assert api.heif_image_get_colorspace(img) == (2 if cf == 0 else 0)  # heif_colorspace_monochrome / YCbCr
+        assert api.heif_image_get_chroma_format(img) == cf
+        assert api.heif_image_has_channel(img, 1) == (0 if cf == 0 else 1)
+        W, H = info["width"], info["height"]
+        for c in range(1 if cf == 0 else 3):
+            ew = W if (c == 0 or cf == 3) else W // 2
+            eh = H if (c == 0 or cf != 1) else H // 2
+            assert (api.heif_image_get_width(img, c), api.heif_image_get_height(img, c)) == (ew, eh)
             stride = C.c_int()
             ptr = api.heif_image_get_plane_readonly(img, c, C.byref(stride))
             w, hgt = api.heif_image_get_width(img, c), api.heif_image_get_height(img, c)
@@ -164,6 +178,30 @@ def test_decoder_plugin_call_sequence(api, hm):
             got = raw[:, :w * 2].copy().view(np.uint16).reshape(hgt, w) if wide else raw[:, :w].astype(np.uint16)
             np.testing.assert_array_equal(got, exp[c][:hgt, :w])
         api.heif_image_release(img)
+
+
+def test_strict_decoding_and_warnings(api, hm):
+    """unknown VUI colour codes: a decoding warning + 'unspecified' without strict decoding, an error with it
+    (HEIF_WARN_OR_FAIL, heif_plugin.h:290-301; decoder_libde265.cc:339-357; heif.cc:1223-1245, 1811-1905)"""
+    import synthutil
+    pic = synthutil.picture(77, width=64, height=64, vui=1, matrix=3, primaries=3, full_range=1)  # 3 = reserved code points
+    data = heifwriter.write_heic([pic], (64, 64))
+    ctx, h, img, e = _decode(api, data, 0, 0, 99)  # native planar
+    assert e.code == 0, e.message
+    assert api.heif_image_get_decoding_warnings(img, 0, None, 0) == 2
+    w = (Err * 4)()
+    assert api.heif_image_get_decoding_warnings(img, 0, w, 4) == 2
+    assert [(x.code, x.subcode) for x in w[:2]] == [(2, 133), (2, 135)]  # Invalid_input / Unknown_NCLX_color_primaries, _matrix_coefficients
+    api.heif_image_release(img); api.heif_image_handle_release(h); api.heif_context_free(ctx)
+    opt = api.heif_decoding_options_alloc()
+    C.cast(opt, C.POINTER(_DecodingOptions)).contents.strict_decoding = 1
+    ctx, h, img, e = _decode(api, data, 0, 0, 99, options=opt)
+    assert e.code == 2 and not img, (e.code, e.message)
+    api.heif_image_handle_release(h); api.heif_context_free(ctx); api.heif_decoding_options_free(opt)
+    # a well-formed file has no warnings
+    ctx, h, img, e = _decode(api, open(os.path.join(HERE, "data", "colors-no-alpha.heic"), "rb").read(), 0, 0, 99)
+    assert e.code == 0 and api.heif_image_get_decoding_warnings(img, 0, None, 0) == 0
+    api.heif_image_release(img); api.heif_image_handle_release(h); api.heif_context_free(ctx)
 
 
 class _ColourConvOptions(C.Structure):  # heif.h:1546-1562

@@ -66,7 +66,7 @@ def test_synth_corpus_matches_reference_fingerprints(hm, name):
     assert f"{orc.load().orc_fnv1a64(data, len(data), 0):016x}" == SYNTH[name]["stream_fnv"], "synthesiser is not deterministic"
     blob = hevcutil.parse(hm, data)
     for stage, bits in (("recon", 0), ("deblock", 1), ("full", 3)):
-        planes, info = orc.oracle_decode(blob, bits)
+        planes, info = orc.oracle_decode(blob, bits, crop=True)
         assert _fp(planes) == SYNTH[name][stage], f"{name}: stage {stage}"
     assert info["full_range"] == SYNTH[name]["info"]["full_range"]
     assert info["matrix"] == SYNTH[name]["info"]["matrix"]
@@ -86,3 +86,22 @@ def test_rare_syntax_sweep_matches_reference_decoder_live(hm):
             mine, _ = orc.oracle_decode(blob, bits)
             for c in range(len(ref)):
                 assert np.array_equal(mine[c], ref[c]), f"seed {seed} {kw}: stage {stage} plane {c}"
+
+
+def test_structure_sweep_matches_reference_decoder_live(hm):
+    """several slices, dependent slice segments, tiles, WPP, loop filters stopped at slice / tile borders, per-slice
+    headers, conformance windows: host parser + oracle == libde265 at every stage (needs oracle/_ref)"""
+    if not orc.have_ref():
+        pytest.skip("oracle/_ref not built")
+    import synthutil
+    multi = 0
+    for seed, kw in corpus.structure_sweep(100):
+        data = synthutil.picture(seed, **kw)
+        blob = hevcutil.parse(hm, data)
+        multi += int.from_bytes(blob[0x2C:0x30], "little") > 1
+        for stage, rf, bits in (("recon", orc.REF_F_NO_DEBLOCK | orc.REF_F_NO_SAO, 0), ("deblock", orc.REF_F_NO_SAO, 1), ("full", 0, 3)):
+            ref, _ = orc.ref_decode(data, rf)
+            mine, _ = orc.oracle_decode(blob, bits, crop=True)
+            for c in range(len(ref)):
+                assert np.array_equal(mine[c], ref[c]), f"seed {seed} {kw}: stage {stage} plane {c}"
+    assert multi > 40  # the sweep really holds multi-slice pictures

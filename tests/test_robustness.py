@@ -181,3 +181,44 @@ def test_foreign_command_streams_are_validated(hm):
         hm.hm_stream_validate(bytes(m), len(m))
         cut = rng.randrange(len(m))
         hm.hm_stream_validate(bytes(m[:cut]), cut)
+
+
+def _nals(data):
+    out, p = [], 0
+    while p < len(data):
+        n = struct.unpack_from(">I", data, p)[0]
+        out.append(data[p + 4:p + 4 + n])
+        p += 4 + n
+    return out
+
+
+def _frame(nals):
+    return b"".join(struct.pack(">I", len(n)) + n for n in nals)
+
+
+def test_sps_replaced_after_pps_invalidates_the_pps(hm):
+    """SPS(64x64), PPS, SPS(larger, same id), slice.  The PPS scan tables were derived from the first
+    SPS; a slice that walks the larger picture with them indexed past their end.  The PPS must be invalid now."""
+    import synthutil
+    small = _nals(synthutil.picture(11, width=64, height=64))
+    big = _nals(synthutil.picture(12, width=512, height=320))
+    kind = lambda n: (n[0] >> 1) & 0x3F
+    sps_big = [n for n in big if kind(n) == 33]
+    slices_big = [n for n in big if kind(n) <= 21]
+    assert sps_big and slices_big
+    evil = _frame([n for n in small if kind(n) in (32, 33, 34)] + sps_big + slices_big)
+    with pytest.raises(RuntimeError, match="missing PPS|scan tables"):
+        hevcutil.parse(hm, evil)
+    # re-sending the PPS after the new SPS is legal and decodes the large picture
+    good = _frame([n for n in small if kind(n) in (32, 33, 34)] + [n for n in big if kind(n) in (33, 34)] + slices_big)
+    blob = hevcutil.parse(hm, good)
+    assert struct.unpack_from("<HH", blob, 8) == (512, 320)
+
+
+def test_parameter_set_ranges_are_checked(hm):
+    """out-of-range PPS / SPS fields are refused at parse time (H.265 7.4.3.2.1, 7.4.3.3.1)."""
+    import synthutil
+    for kw in (dict(cb_qp_offset=13), dict(cr_qp_offset=-13), dict(beta_offset_div2=7), dict(tc_offset_div2=-7)):
+        # the synthesiser reads its own parameter sets back with the product's parser (parse_pps): -2 = it refused them
+        with pytest.raises(RuntimeError, match="out of range|synth failed: -2"):
+            hevcutil.parse(hm, synthutil.picture(3, width=64, height=64, **kw))

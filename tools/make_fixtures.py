@@ -53,6 +53,7 @@ def main():
     srcs = {
         "basketball_1080p_qp32": f"{REF}/third-party/libde265/testfile/BasketballDrive_1920x1080_32.265",
         "basketball_1080p_qp25": f"{REF}/third-party/libde265/testfile/BasketballDrive_1920x1080_25.265",
+        "basketball_1080p_qp1": f"{REF}/third-party/libde265/testfile/BasketballDrive_1920x1080_1.265",
     }
     for name, path in srcs.items():
         lp = annexb_to_lp(open(path, "rb").read())
