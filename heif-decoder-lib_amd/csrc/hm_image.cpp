@@ -18,37 +18,13 @@
 #include <thread>
 #include <vector>
 
-#include "heif_file.h"
 #include "clap.h"
-#include "hm_internal.h"
-#include "hm_stream.h"
+#include "hm_image_job.h"
 
-struct hm_file {
-  std::vector<uint8_t> bytes;
-  hm::HeifFile file;
-};
+using namespace hm_img;
 
 namespace {
 
-struct DevMem {
-  void* p = nullptr;
-  DevMem() = default;
-  DevMem(const DevMem&) = delete;
-  DevMem& operator=(const DevMem&) = delete;
-  int alloc(size_t n)
-  {
-    p = hm_pool_device_alloc(n);
-    return p ? HM_OK : HM_ERR_NO_DEVICE;
-  }
-  void swap(DevMem& o) { void* t = p; p = o.p; o.p = t; }
-  ~DevMem() { if (p) hm_pool_device_free(p); }
-};
-
-// one plane of the decoded image on the device, libheif plane layout (pixelimage.cc:139-218)
-struct DevPlane {
-  DevMem mem;
-  int w = 0, h = 0, stride = 0; // samples, samples, bytes
-};
 int mem_rows(int hgt) { const int r = (hgt + 1) & ~1; return r < 64 ? 64 : r; }
 size_t plane_bytes(const DevPlane& p) { return (size_t)p.stride * mem_rows(p.h); }
 int alloc_plane(DevPlane& p, int w, int h, int bps)
@@ -133,12 +109,6 @@ int apply_transforms(const std::vector<hm::Transform>& list, DevPlane (&P)[3], i
   return HM_OK;
 }
 
-struct Blob {
-  uint8_t* p = nullptr;
-  size_t n = 0;
-  ~Blob() { if (p) hm_free(p); }
-};
-
 // Host worker threads for the entropy decode, kept alive between calls (spawning 48 threads costs more than the
 // 1.6 ms one tile takes).  Mirrors the reference's std::async tile fan-out (context.cc:2361-2401) with a fixed crew.
 class Crew {
@@ -197,19 +167,6 @@ class Crew {
 };
 
 int fail_from(const hm::HeifError& e) { return hm_fail(e.status, "%s", e.message.c_str()); }
-
-// A decoded image on the device: what HeifContext::decode_image_planar returns (YCbCr planes after the item's
-// transformative properties), plus everything that must outlive the asynchronous work that produced it.
-struct PlanarImage {
-  DevPlane P[3];
-  int w = 0, h = 0, chroma = 1, bd = 8;
-  hm::NclxProfile native; // profile of the decoded image (VUI, overridden by an item 'colr' nclx)
-  bool is_grid = false;
-  int warnings = 0; // HM_WARN_* of the (single) coded picture
-  std::vector<std::unique_ptr<DevMem>> retired;
-  std::unique_ptr<hm_batch, void (*)(hm_batch*)> batch{nullptr, hm_batch_destroy};
-};
-int decode_planar(const hm_file* f, uint32_t id, const hm_decode_params* params, hipStream_t s, PlanarImage& I);
 
 } // namespace
 
@@ -316,114 +273,99 @@ void hm_decoded_free(hm_decoded* d)
 
 namespace {
 
-// decode_image_planar for an hvc1 item or a grid (context.cc:1729-2020): host entropy decode of every coded picture,
-// one GPU batch, then the item's irot / imir / clap.  Asynchronous on `s` (the caller synchronises).
-int decode_planar(const hm_file* f, uint32_t id, const hm_decode_params* params, hipStream_t s, PlanarImage& I)
+// HM_TRACE=1: wall-clock laps of the phases on stderr (diagnostics; the environment is read once)
+bool trace_enabled()
+{
+  static const bool on = std::getenv("HM_TRACE") != nullptr;
+  return on;
+}
+struct Lap {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  void operator()(const char* what) const
+  {
+    if (trace_enabled())
+      std::fprintf(stderr, "[hm_decode_item] %-32s %8.3f ms\n", what,
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  }
+};
+
+// which coded pictures an image item consists of (context.cc:2120-2160: grid descriptor + dimg references)
+int plan_item(const hm_file* f, uint32_t id, ItemPlan& P)
 {
   const hm::Item* it = f->file.item(id);
   if (!it) return hm_fail(HM_ERR_INVALID_ARG, "no item %u", id);
   hm::HeifError err;
-  // HM_TRACE=1: wall-clock split of this call on stderr (diagnostics only)
-  static const bool trace = std::getenv("HM_TRACE") != nullptr;
-  const auto t_start = std::chrono::steady_clock::now();
-  auto lap = [&](const char* what) {
-    if (trace) std::fprintf(stderr, "[hm_decode_item] %-28s %8.3f ms\n", what,
-                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
-  };
-
-  // ---- which coded pictures, where ----
-  struct Tile { uint32_t id; int x0, y0; };
-  std::vector<Tile> tiles;
-  int canvas_w = 0, canvas_h = 0;
-  const bool is_grid = it->type == "grid";
-  if (is_grid) {
+  P.id = id;
+  P.is_grid = it->type == "grid";
+  if (P.is_grid) {
     hm::GridInfo g;
     if (!f->file.grid_info(id, g, err)) return fail_from(err);
-    canvas_w = (int)g.width;
-    canvas_h = (int)g.height;
-    tiles.resize(g.tiles.size());
-    for (size_t i = 0; i < g.tiles.size(); i++) tiles[i].id = g.tiles[i];
+    P.canvas_w = (int)g.width;
+    P.canvas_h = (int)g.height;
+    P.cols = g.cols; P.rows = g.rows;
+    P.tiles.resize(g.tiles.size());
+    for (size_t i = 0; i < g.tiles.size(); i++) P.tiles[i].id = g.tiles[i];
   }
-  else if (it->type == "hvc1") tiles.push_back({id, 0, 0});
+  else if (it->type == "hvc1") { P.tiles.resize(1); P.tiles[0].id = id; P.cols = P.rows = 1; }
   else return hm_fail(HM_ERR_UNSUPPORTED, "item type '%s'", it->type.c_str());
-  if (canvas_w < 0 || canvas_h < 0 || (is_grid && (canvas_w == 0 || canvas_h == 0))) return hm_fail(HM_ERR_BITSTREAM, "bad grid size");
+  if (P.canvas_w < 0 || P.canvas_h < 0 || (P.is_grid && (P.canvas_w == 0 || P.canvas_h == 0))) return hm_fail(HM_ERR_BITSTREAM, "bad grid size");
+  if (P.tiles.empty()) return hm_fail(HM_ERR_BITSTREAM, "image without coded pictures");
+  const size_t nt = P.tiles.size();
+  P.blobs.clear(); P.blobs.resize(nt);
+  P.status.assign(nt, HM_OK);
+  P.messages.assign(nt, std::string());
+  return HM_OK;
+}
 
-  // ---- host: entropy-decode every tile (CABAC on the CPU, spread over threads like the
-  //      reference's heif_context_set_threads tile fan-out, context.cc:2361-2401) ----
-  const int nt = (int)tiles.size();
-  std::vector<Blob> blobs(nt);
-  std::vector<int> status(nt, HM_OK);
-  std::vector<std::string> messages(nt);
-  std::atomic<int> next{0};
-  auto worker = [&]() {
-    for (;;) {
-      const int i = next.fetch_add(1);
-      if (i >= nt) break;
-      std::vector<uint8_t> data;
-      hm::HeifError e;
-      if (!f->file.hevc_data(tiles[i].id, data, e)) { status[i] = e.status; messages[i] = e.message; continue; }
-      const int rc = hm_hevc_parse(data.data(), data.size(), 0, &blobs[i].p, &blobs[i].n);
-      if (rc) { status[i] = rc; messages[i] = hm_last_error(); }
-    }
-  };
-  int nthreads = params->host_threads > 0 ? params->host_threads : 1;
-  if (nthreads > nt) nthreads = nt;
-  Crew::instance().run(nthreads, worker);
+// decode_image_planar for an hvc1 item or a grid (context.cc:1729-2020) once the host entropy decode of its coded
+// pictures is done: one GPU batch, then the item's irot / imir / clap.  Asynchronous on `s`.
+int planar_from_blobs(const hm_file* f, ItemPlan& P, const hm_decode_params* params, hipStream_t s, PlanarImage& I)
+{
+  const hm::Item* it = f->file.item(P.id);
+  hm::HeifError err;
+  const int nt = (int)P.tiles.size();
   for (int i = 0; i < nt; i++)
-    if (status[i]) return hm_fail(status[i], "tile %d (item %u): %s", i, tiles[i].id, messages[i].c_str());
-  lap("host entropy decode done");
+    if (P.status[i]) return hm_fail(P.status[i], "tile %d (item %u): %s", i, P.tiles[i].id, P.messages[i].c_str());
+  const bool is_grid = P.is_grid;
+  int canvas_w = P.canvas_w, canvas_h = P.canvas_h;
 
   // ---- geometry ----
-  const hm_pic* h0 = reinterpret_cast<const hm_pic*>(blobs[0].p);
+  const hm_pic* h0 = reinterpret_cast<const hm_pic*>(P.blobs[0].p);
   const int chroma = h0->chroma_format, bd = h0->bit_depth_y;
   const int tile_w = h0->width - h0->crop_left - h0->crop_right, tile_h = h0->height - h0->crop_top - h0->crop_bottom;
   if (is_grid) {
-    hm::GridInfo g;
-    f->file.grid_info(id, g, err);
     // geometry checks and tile origins follow context.cc:2299-2359: positions advance by the tiles'
     // *declared* ('ispe') size; all tiles must be equally sized and cover the output
-    const hm::Item* t0 = f->file.item(tiles[0].id);
+    const hm::Item* t0 = f->file.item(P.tiles[0].id);
     const int iw = t0 ? t0->props.ispe_width : 0, ih = t0 ? t0->props.ispe_height : 0;
     if (canvas_w > 32768 || canvas_h > 32768) return hm_fail(HM_ERR_BITSTREAM, "Image size exceeds the maximum of 32768x32768 (security limit)");
     for (int i = 0; i < nt; i++) {
-      const hm_pic* h = reinterpret_cast<const hm_pic*>(blobs[i].p);
-      const hm::Item* ti = f->file.item(tiles[i].id);
+      const hm_pic* h = reinterpret_cast<const hm_pic*>(P.blobs[i].p);
+      const hm::Item* ti = f->file.item(P.tiles[i].id);
       // the reference decodes every tile through decode_image_planar, which would also apply the tile item's own
       // irot / imir / clap before the paste (context.cc:1957-2020): not on the GPU path - refuse rather than ignore
       if (ti && !ti->props.transforms.empty() && !params->ignore_transformations)
-        return hm_fail(HM_ERR_UNSUPPORTED, "grid tile %d (item %u) carries its own irot/imir/clap", i, tiles[i].id);
+        return hm_fail(HM_ERR_UNSUPPORTED, "grid tile %d (item %u) carries its own irot/imir/clap", i, P.tiles[i].id);
       const int sw_ = ti ? ti->props.ispe_width : 0, sh_ = ti ? ti->props.ispe_height : 0;
-      if (sw_ < canvas_w / g.cols || sh_ < canvas_h / g.rows) return hm_fail(HM_ERR_BITSTREAM, "Grid tiles do not cover whole image");
+      if (sw_ < canvas_w / P.cols || sh_ < canvas_h / P.rows) return hm_fail(HM_ERR_BITSTREAM, "Grid tiles do not cover whole image");
       if (sw_ != iw || sh_ != ih) return hm_fail(HM_ERR_BITSTREAM, "Grid tiles have different sizes");
       if (h->chroma_format != chroma) return hm_fail(HM_ERR_BITSTREAM, "Image tile has different chroma format than combined image");
       if (h->bit_depth_y != bd) return hm_fail(HM_ERR_BITSTREAM, "Image tile has different pixel depth than combined image");
-      tiles[i].x0 = (i % g.cols) * iw;
-      tiles[i].y0 = (i / g.cols) * ih;
+      P.tiles[i].x0 = (i % P.cols) * iw;
+      P.tiles[i].y0 = (i / P.cols) * ih;
     }
-    (void)tile_w; (void)tile_h;
   }
   else { canvas_w = tile_w; canvas_h = tile_h; }
   const int bps = bd > 8 ? 2 : 1;
   const int cw = chroma == 3 ? canvas_w : (canvas_w + 1) / 2, chh = chroma == 1 ? (canvas_h + 1) / 2 : canvas_h;
 
-  DevPlane (&P)[3] = I.P;
-  std::vector<std::unique_ptr<DevMem>>& retired = I.retired;
-  int rc;
-  if ((rc = alloc_plane(P[0], canvas_w, canvas_h, bps))) return rc;
-  if (chroma != 0 && ((rc = alloc_plane(P[1], cw, chh, bps)) || (rc = alloc_plane(P[2], cw, chh, bps)))) return rc; // 4:0:0: luma only
-  // a grid canvas the tiles do not cover completely stays zero like a fresh HeifPixelImage? the
-  // reference leaves it uninitialised; tiles must cover the output (context.cc:2321-2337)
-  for (int c = 0; c < 3; c++)
-    if (P[c].mem.p) hipMemsetAsync(P[c].mem.p, 0, plane_bytes(P[c]), s);
-
-  hm_batch* batch = nullptr;
-  if ((rc = hm_batch_create(&batch))) return rc;
-  I.batch.reset(batch);
-  // colour profile of the decoded (native) image: 'colr' nclx of the item overrides the VUI one
+  // colour profile of the decoded (native) image and the per-tile paste parameters; every check that can fail on file
+  // data comes before the first asynchronous call
   hm::NclxProfile native;
+  std::vector<hm::NclxProfile> tile_profile(nt);
   for (int i = 0; i < nt; i++) {
-    const hm_pic* h = reinterpret_cast<const hm_pic*>(blobs[i].p);
-    const hm::Item* ti = f->file.item(tiles[i].id);
+    const hm_pic* h = reinterpret_cast<const hm_pic*>(P.blobs[i].p);
+    const hm::Item* ti = f->file.item(P.tiles[i].id);
     hm::NclxProfile tp; // what the libde265 plugin attaches (decoder_libde265.cc:339-362) ...
     tp.present = true; tp.primaries = h->colour_primaries; tp.transfer = h->transfer_characteristics;
     tp.matrix = h->matrix_coeffs; tp.full_range = h->full_range;
@@ -439,73 +381,115 @@ int decode_planar(const hm_file* f, uint32_t id, const hm_decode_params* params,
     if (!is_grid) I.warnings |= warn;
     if (ti && ti->props.colr.present) tp = ti->props.colr; // ... unless the item has a 'colr' nclx (context.cc:1844-1852)
     if (i == 0) native = tp;
+    tile_profile[i] = tp;
+  }
+
+  DevPlane (&Pl)[3] = I.P;
+  int rc;
+  if ((rc = alloc_plane(Pl[0], canvas_w, canvas_h, bps))) return rc;
+  if (chroma != 0 && ((rc = alloc_plane(Pl[1], cw, chh, bps)) || (rc = alloc_plane(Pl[2], cw, chh, bps)))) return rc; // 4:0:0: luma only
+  hm_batch* batch = nullptr;
+  if ((rc = hm_batch_create(&batch))) return rc;
+  I.batch.reset(batch);
+  for (int i = 0; i < nt; i++) {
     hm_tile_dest d;
     std::memset(&d, 0, sizeof(d));
-    for (int c = 0; c < 3; c++) { d.plane[c] = P[c].mem.p; d.pitch[c] = P[c].stride; }
+    for (int c = 0; c < 3; c++) { d.plane[c] = Pl[c].mem.p; d.pitch[c] = Pl[c].stride; }
     d.canvas_width = canvas_w; d.canvas_height = canvas_h;
-    d.x0 = tiles[i].x0; d.y0 = tiles[i].y0;
+    d.x0 = P.tiles[i].x0; d.y0 = P.tiles[i].y0;
     // the range rescale belongs to the grid paste only (context.cc:2504-2528)
-    d.tile_has_nclx = is_grid ? 1 : 0; d.tile_full_range = tp.full_range; d.tile_matrix = tp.matrix;
-    const int idx = hm_batch_add_trusted(batch, blobs[i].p, blobs[i].n, &d);
+    d.tile_has_nclx = is_grid ? 1 : 0; d.tile_full_range = tile_profile[i].full_range; d.tile_matrix = tile_profile[i].matrix;
+    const int idx = hm_batch_add_trusted(batch, P.blobs[i].p, P.blobs[i].n, &d);
     if (idx < 0) return idx;
   }
-  lap("planes allocated, batch queued");
+  // a grid canvas the tiles do not cover completely: the reference leaves it uninitialised (tiles must cover the
+  // output, context.cc:2321-2337; its right / bottom padding is never read): zero it
+  for (int c = 0; c < 3; c++)
+    if (Pl[c].mem.p) hipMemsetAsync(Pl[c].mem.p, 0, plane_bytes(Pl[c]), s);
   if ((rc = hm_batch_upload(batch, s))) return rc;
-  lap("upload enqueued");
   if ((rc = hm_batch_execute(batch, 3, s))) return rc;
-  if (trace) { hipStreamSynchronize(s); lap("kernels finished (sync)"); }
 
   // ---- transformative item properties on the decoded planes (context.cc:1957-2020) ----
   int img_w = canvas_w, img_h = canvas_h;
   if (!params->ignore_transformations && !it->props.transforms.empty())
-    if ((rc = apply_transforms(it->props.transforms, P, img_w, img_h, chroma, bd, s, retired))) return rc;
+    if ((rc = apply_transforms(it->props.transforms, Pl, img_w, img_h, chroma, bd, s, I.retired))) return rc;
   I.w = img_w; I.h = img_h; I.chroma = chroma; I.bd = bd; I.native = native; I.is_grid = is_grid;
   return HM_OK;
 }
 
 } // namespace
 
-extern "C" {
+namespace hm_img {
 
-int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params, hm_decoded* out)
+int job_plan(DecodeJob& j)
 {
-  if (!f || !params || !out) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
-  std::memset(out, 0, sizeof(*out));
-  hipStream_t s = (hipStream_t)params->stream;
-  // Everything the asynchronous work touches is declared before the guard below, so on every return path - errors
-  // included - the stream is drained before a buffer goes back to the pool (which may hand it to another thread).
-  PlanarImage I, A;
-  DevPlane alpha_scaled;
-  DevMem dout;
-  struct DrainOnExit { hipStream_t s; ~DrainOnExit() { hipStreamSynchronize(s); } } drain_guard{s};
-  int rc = decode_planar(f, id, params, s, I);
+  int rc = plan_item(j.f, j.id, j.item[0]);
   if (rc) return rc;
-  // ---- alpha channel: the auxiliary image is decoded like any image (its own transformations included), its Y plane
-  //      becomes the alpha plane, scaled nearest-neighbour if its size differs (context.cc:2029-2078) ----
-  const DevPlane* alpha = nullptr;
-  const uint32_t alpha_id = f->file.alpha_item_of(id);
+  j.n_items = 1;
+  // the alpha channel: an auxiliary image decoded like any image (context.cc:2029-2078)
+  const uint32_t alpha_id = j.f->file.alpha_item_of(j.id);
   if (alpha_id) {
-    if ((rc = decode_planar(f, alpha_id, params, s, A))) return rc;
+    if ((rc = plan_item(j.f, alpha_id, j.item[1]))) return rc;
+    j.n_items = 2;
+  }
+  return HM_OK;
+}
+
+int job_tile_count(const DecodeJob& j)
+{
+  int n = 0;
+  for (int i = 0; i < j.n_items; i++) n += (int)j.item[i].tiles.size();
+  return n;
+}
+
+// host entropy decode of coded picture k (CABAC on the calling thread, like the reference's std::async tile tasks,
+// context.cc:2361-2401); distinct k may run concurrently
+void job_parse_tile(DecodeJob& j, int k)
+{
+  int which = 0;
+  if (k >= (int)j.item[0].tiles.size()) { which = 1; k -= (int)j.item[0].tiles.size(); }
+  ItemPlan& P = j.item[which];
+  std::vector<uint8_t> data;
+  hm::HeifError e;
+  if (!j.f->file.hevc_data(P.tiles[k].id, data, e)) { P.status[k] = e.status; P.messages[k] = e.message; return; }
+  const int rc = hm_hevc_parse(data.data(), data.size(), 0, &P.blobs[k].p, &P.blobs[k].n);
+  if (rc) { P.status[k] = rc; P.messages[k] = hm_last_error(); }
+}
+
+// Everything after the host entropy decode, queued on j.s without waiting: GPU batch(es), transforms, alpha, colour
+// conversion (HeifContext::decode_image_user, context.cc:1516-1600) and the copy to (pinned) host memory.
+int job_enqueue(DecodeJob& j, hm_decoded* out)
+{
+  const hm_file* f = j.f;
+  const hm_decode_params* params = &j.params;
+  hipStream_t s = j.s;
+  std::memset(out, 0, sizeof(*out));
+  j.enqueued = true; // from here on the destructor drains the stream before buffers are released
+  Lap lap;
+  PlanarImage &I = j.I, &A = j.A;
+  int rc = planar_from_blobs(f, j.item[0], params, s, I);
+  if (rc) return rc;
+  // ---- alpha channel: the auxiliary image's Y plane becomes the alpha plane, scaled nearest-neighbour if its size
+  //      differs (context.cc:2029-2078) ----
+  const DevPlane* alpha = nullptr;
+  if (j.n_items > 1) {
+    if ((rc = planar_from_blobs(f, j.item[1], params, s, A))) return rc;
     // what the colour ops refuse is refused before more work is queued (rgb2rgb.cc:81-84: any alpha depth but 8)
     if (params->out_format == HM_OUT_RGBA && A.bd != 8) return hm_fail(HM_ERR_UNSUPPORTED, "alpha plane of %d bits with an 8-bit RGBA target", A.bd);
     alpha = &A.P[0];
     if (A.w != I.w || A.h != I.h) {
-      if ((rc = alloc_plane(alpha_scaled, I.w, I.h, A.bd > 8 ? 2 : 1))) return rc;
-      if ((rc = hm_launch_scale_nn(A.bd > 8 ? 2 : 1, A.P[0].mem.p, A.P[0].stride, A.w, A.h, alpha_scaled.mem.p, alpha_scaled.stride, I.w, I.h, s))) return rc;
-      alpha = &alpha_scaled;
+      if ((rc = alloc_plane(j.alpha_scaled, I.w, I.h, A.bd > 8 ? 2 : 1))) return rc;
+      if ((rc = hm_launch_scale_nn(A.bd > 8 ? 2 : 1, A.P[0].mem.p, A.P[0].stride, A.w, A.h, j.alpha_scaled.mem.p, j.alpha_scaled.stride, I.w, I.h, s))) return rc;
+      alpha = &j.alpha_scaled;
     }
     out->has_alpha = 1;
   }
+  lap("planar decode queued");
   DevPlane (&P)[3] = I.P;
   const int img_w = I.w, img_h = I.h, chroma = I.chroma, bd = I.bd;
   const hm::NclxProfile& native = I.native;
   const bool is_grid = I.is_grid;
-  static const bool trace = std::getenv("HM_TRACE") != nullptr;
-  const auto t_start = std::chrono::steady_clock::now();
-  auto lap = [&](const char* what) {
-    if (trace) std::fprintf(stderr, "[hm_decode_item] %-28s %8.3f ms (after the planar decode)\n", what,
-                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
-  };
+  DevMem& dout = j.dout;
 
   out->width = img_w; out->height = img_h; out->bit_depth = bd; out->chroma = chroma;
   out->warnings = I.warnings;
@@ -519,19 +503,19 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
       if (!P[c].mem.p) continue; // monochrome image: Y only
       const size_t sz = plane_bytes(P[c]);
       out->plane[c] = (uint8_t*)hm_pool_pinned_alloc(sz);
-      if (!out->plane[c]) { hipStreamSynchronize(s); hm_decoded_free(out); return hm_fail(HM_ERR_NOMEM, "out of memory"); }
+      if (!out->plane[c]) return hm_fail(HM_ERR_NOMEM, "out of memory");
       out->stride[c] = P[c].stride;
       e = hipMemcpyAsync(out->plane[c], P[c].mem.p, sz, hipMemcpyDeviceToHost, s);
-      if (e != hipSuccess) { hipStreamSynchronize(s); hm_decoded_free(out); return hm_check_hip(e, "D2H"); }
+      if (e != hipSuccess) return hm_check_hip(e, "D2H");
       out->plane_width[c] = P[c].w; out->plane_height[c] = P[c].h;
     }
     if (alpha) {
       const size_t sz = plane_bytes(*alpha);
       out->alpha = (uint8_t*)hm_pool_pinned_alloc(sz);
-      if (!out->alpha) { hipStreamSynchronize(s); hm_decoded_free(out); return hm_fail(HM_ERR_NOMEM, "out of memory"); }
+      if (!out->alpha) return hm_fail(HM_ERR_NOMEM, "out of memory");
       out->alpha_stride = alpha->stride;
       e = hipMemcpyAsync(out->alpha, alpha->mem.p, sz, hipMemcpyDeviceToHost, s);
-      if (e != hipSuccess) { hipStreamSynchronize(s); hm_decoded_free(out); return hm_check_hip(e, "D2H"); }
+      if (e != hipSuccess) return hm_check_hip(e, "D2H");
     }
   }
   else {
@@ -543,20 +527,17 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
     cd.chroma_upsampling = params->chroma_upsampling;
     const int obpp = hm_out_bytes_per_pixel(params->out_format);
     if (obpp < 0) return obpp;
+    if (alpha && params->out_format != HM_OUT_RGBA && params->out_format != HM_OUT_RGB)
+      return hm_fail(HM_ERR_UNSUPPORTED, "16-bit interleaved output of an image with an alpha channel (RRGGBBAA) is not on the GPU path");
     cd.y_stride = P[0].stride; cd.cb_stride = P[1].stride; cd.cr_stride = P[2].stride;
     cd.out_stride = hm_plane_stride(img_w, obpp);
     const size_t obytes = (size_t)cd.out_stride * mem_rows(img_h);
     if ((rc = dout.alloc(obytes))) return rc;
     if ((rc = hm_colour_convert(&cd, P[0].mem.p, P[1].mem.p, P[2].mem.p, dout.p, s))) return rc;
-    if (alpha) {
-      // RGB24 / RRGGBB targets have no alpha: Op_drop_alpha_plane, the colour values do not depend on it.  RGBA: the 8-bit
-      // ops copy the plane (yuv2rgb.cc:483-488, rgb2rgb.cc:81-84 refuses any other alpha depth)
-      if (params->out_format == HM_OUT_RGBA) {
-        if ((rc = hm_launch_set_alpha(dout.p, cd.out_stride, img_w, img_h, alpha->mem.p, alpha->stride, s))) return rc;
-      }
-      else if (params->out_format != HM_OUT_RGB)
-        return hm_fail(HM_ERR_UNSUPPORTED, "16-bit interleaved output of an image with an alpha channel (RRGGBBAA) is not on the GPU path");
-    }
+    // RGB24 / RRGGBB targets have no alpha: Op_drop_alpha_plane, the colour values do not depend on it.  RGBA: the 8-bit
+    // ops copy the plane (yuv2rgb.cc:483-488)
+    if (alpha && params->out_format == HM_OUT_RGBA)
+      if ((rc = hm_launch_set_alpha(dout.p, cd.out_stride, img_w, img_h, alpha->mem.p, alpha->stride, s))) return rc;
     out->out_format = params->out_format;
     // the converted image carries the output state's profile: the input one with undefined values replaced by the
     // sRGB defaults (colorconversion.cc:452-455, 520-527); an 8-bit image becomes 10 bit in an RRGGBB target (:575-585)
@@ -582,14 +563,55 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
       out->plane[0] = (uint8_t*)hm_pool_pinned_alloc(obytes);
       if (!out->plane[0]) return hm_fail(HM_ERR_NOMEM, "out of memory");
       e = hipMemcpyAsync(out->plane[0], dout.p, obytes, hipMemcpyDeviceToHost, s);
-      if (e != hipSuccess) { hipStreamSynchronize(s); hm_decoded_free(out); return hm_check_hip(e, "D2H"); }
+      if (e != hipSuccess) return hm_check_hip(e, "D2H");
     }
   }
-  lap("colour + D2H enqueued");
-  e = hipStreamSynchronize(s);
-  lap("stream drained");
-  if (e != hipSuccess) { hipStreamSynchronize(s); hm_decoded_free(out); return hm_check_hip(e, "kernel execution"); }
+  lap("colour + D2H queued");
   return HM_OK;
+}
+
+int job_complete(DecodeJob& j, hm_decoded*)
+{
+  const hipError_t e = hipStreamSynchronize(j.s);
+  return e == hipSuccess ? HM_OK : hm_check_hip(e, "kernel execution");
+}
+
+} // namespace hm_img
+
+extern "C" {
+
+int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params, hm_decoded* out)
+{
+  if (!f || !params || !out) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
+  std::memset(out, 0, sizeof(*out));
+  Lap lap;
+  DecodeJob job;
+  job.f = f; job.id = id; job.params = *params; job.s = (hipStream_t)params->stream;
+  int rc = job_plan(job);
+  if (rc) return rc;
+  // ---- host: entropy-decode every coded picture (CABAC on the CPU, spread over threads like the reference's
+  //      heif_context_set_threads tile fan-out, context.cc:2361-2401) ----
+  const int nt = job_tile_count(job);
+  std::atomic<int> next{0};
+  auto worker = [&]() {
+    for (;;) {
+      const int i = next.fetch_add(1);
+      if (i >= nt) break;
+      job_parse_tile(job, i);
+    }
+  };
+  int nthreads = params->host_threads > 0 ? params->host_threads : 1;
+  if (nthreads > nt) nthreads = nt;
+  Crew::instance().run(nthreads, worker);
+  lap("host entropy decode done");
+  rc = job_enqueue(job, out);
+  if (!rc) rc = job_complete(job, out);
+  lap("stream drained");
+  if (rc) { // (the job's destructor drains the stream; the pinned outputs go back after that)
+    hipStreamSynchronize(job.s);
+    hm_decoded_free(out);
+  }
+  return rc;
 }
 
 } // extern "C"

@@ -1,0 +1,218 @@
+// pipeline.cpp — throughput-oriented end-to-end decode: many HEIF files in flight at once.
+//
+// The image-at-a-time entry (hm_decode_item) runs  parse tiles -> H2D -> kernels -> D2H  strictly in sequence, so the
+// GPU idles while the host entropy-decodes and the host idles while the GPU works.  Here the same phases
+// (hm_image_job.h) are overlapped across images:
+//   * submit: box parsing, tile list; the image's coded pictures become tasks in ONE queue shared by all images, so a
+//     crew of host threads is busy as long as any image has unparsed tiles (the reference fans out per image only:
+//     std::async per tile inside decode_full_grid_image, context.cc:2361-2401, with the images themselves serial);
+//   * the thread that parses the last coded picture of an image queues that image's GPU work (H2D of the command
+//     streams, reconstruction, filters, paste, colour conversion, D2H into pinned memory) on the image's own HIP
+//     stream and goes back to parsing: while image k is on the GPU, k+1.. are being parsed and the copy engines drain
+//     k-1 - the streams of different images overlap on the device;
+//   * results are handed out in submission order (hm_pipeline_next).
+// No collective, no CPU reconstruction fallback: CABAC stays on the host as in the reference, everything else is GPU.
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "hm_image_job.h"
+
+using namespace hm_img;
+
+namespace {
+
+struct Image {
+  hm_file* file = nullptr;          // owned copy of the HEIF bytes + box structure
+  DecodeJob job;
+  hm_decoded out{};
+  uint64_t tag = 0;
+  int status = HM_OK;
+  std::string message;
+  std::atomic<int> tiles_left{0};
+  bool queued = false;              // GPU work queued (or failed): the result can be waited for
+  hipStream_t stream = nullptr;
+  ~Image() {
+    if (job.enqueued) hipStreamSynchronize(job.s); // before `out` / the job's buffers go back to the pools
+    hm_decoded_free(&out);
+    if (file) hm_file_close(file);
+  }
+};
+
+struct Task { Image* img; int tile; };
+
+} // namespace
+
+struct hm_pipeline {
+  hm_pipeline_config cfg{};
+  std::mutex m;
+  std::condition_variable work_cv, result_cv;
+  std::deque<Task> tasks;
+  std::deque<Image*> order;         // submission order; front = next result
+  std::vector<std::thread> workers;
+  std::vector<hipStream_t> free_streams;
+  int in_flight = 0;
+  bool quit = false;
+
+  void worker_loop()
+  {
+    if (cfg.device >= 0) hipSetDevice(cfg.device);
+    std::unique_lock<std::mutex> g(m);
+    for (;;) {
+      work_cv.wait(g, [&] { return quit || !tasks.empty(); });
+      if (quit && tasks.empty()) return;
+      Task t = tasks.front();
+      tasks.pop_front();
+      g.unlock();
+      job_parse_tile(t.img->job, t.tile);
+      if (t.img->tiles_left.fetch_sub(1) == 1) finish(t.img); // last coded picture of the image: hand it to the GPU
+      g.lock();
+    }
+  }
+  // called by exactly one thread per image, after all its tiles are parsed
+  void finish(Image* im)
+  {
+    const int rc = job_enqueue(im->job, &im->out);
+    if (rc) { im->status = rc; im->message = hm_last_error(); }
+    {
+      std::lock_guard<std::mutex> g(m);
+      im->queued = true;
+    }
+    result_cv.notify_all();
+  }
+};
+
+extern "C" {
+
+int hm_pipeline_create(const hm_pipeline_config* cfg, hm_pipeline** out)
+{
+  if (!cfg || !out) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return hm_fail(HM_ERR_NO_DEVICE, "no HIP device available");
+  if (cfg->device >= ndev) return hm_fail(HM_ERR_INVALID_ARG, "device %d of %d", cfg->device, ndev);
+  hm_pipeline* p = new (std::nothrow) hm_pipeline();
+  if (!p) return hm_fail(HM_ERR_NOMEM, "out of memory");
+  p->cfg = *cfg;
+  if (p->cfg.host_threads < 1) p->cfg.host_threads = 1;
+  if (p->cfg.host_threads > 1024) p->cfg.host_threads = 1024;
+  if (p->cfg.max_in_flight < 1) p->cfg.max_in_flight = 16;
+  if (p->cfg.device >= 0) hipSetDevice(p->cfg.device);
+  else hipGetDevice(&p->cfg.device); // the crew works on the creator's device
+  for (int i = 0; i < p->cfg.max_in_flight; i++) {
+    hipStream_t s = nullptr;
+    const hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      for (hipStream_t t : p->free_streams) hipStreamDestroy(t);
+      delete p;
+      return hm_check_hip(e, "hipStreamCreate");
+    }
+    p->free_streams.push_back(s);
+  }
+  for (int i = 0; i < p->cfg.host_threads; i++) p->workers.emplace_back([p] { p->worker_loop(); });
+  *out = p;
+  return HM_OK;
+}
+
+void hm_pipeline_destroy(hm_pipeline* p)
+{
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> g(p->m);
+    p->quit = true;
+    // unparsed work of images nobody will collect: drop the tasks, the images are destroyed below
+    for (const Task& t : p->tasks) t.img->tiles_left.fetch_sub(1);
+    p->tasks.clear();
+  }
+  p->work_cv.notify_all();
+  for (std::thread& t : p->workers) t.join();
+  for (Image* im : p->order) delete im; // drains each image's stream first
+  for (hipStream_t s : p->free_streams) hipStreamDestroy(s);
+  delete p;
+}
+
+int hm_pipeline_submit(hm_pipeline* p, const uint8_t* heif, size_t size, uint32_t item_id, uint64_t tag)
+{
+  if (!p || !heif) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
+  Image* im = new (std::nothrow) Image();
+  if (!im) return hm_fail(HM_ERR_NOMEM, "out of memory");
+  im->tag = tag;
+  int rc = hm_file_open(heif, size, &im->file);
+  if (!rc) {
+    im->job.f = im->file;
+    im->job.id = item_id ? item_id : hm_file_primary_item(im->file);
+    std::memset(&im->job.params, 0, sizeof(im->job.params));
+    im->job.params.out_format = p->cfg.out_format;
+    im->job.params.chroma_upsampling = p->cfg.chroma_upsampling;
+    im->job.params.ignore_transformations = p->cfg.ignore_transformations;
+    im->job.params.strict_decoding = p->cfg.strict_decoding;
+    rc = job_plan(im->job);
+  }
+  if (rc) { delete im; return rc; }
+  const int nt = job_tile_count(im->job);
+  {
+    std::unique_lock<std::mutex> g(p->m);
+    // back-pressure: at most max_in_flight images hold device / pinned memory.  Not a wait: a single-threaded caller
+    // must be able to collect a result (hm_pipeline_next) to make room
+    if (p->free_streams.empty()) { g.unlock(); delete im; return HM_PIPELINE_FULL; }
+    im->stream = p->free_streams.back();
+    p->free_streams.pop_back();
+    im->job.s = im->stream;
+    im->job.params.stream = im->stream;
+    im->tiles_left.store(nt);
+    p->order.push_back(im);
+    for (int k = 0; k < nt; k++) p->tasks.push_back({im, k});
+  }
+  p->work_cv.notify_all();
+  return HM_OK;
+}
+
+int hm_pipeline_pending(hm_pipeline* p)
+{
+  if (!p) return 0;
+  std::lock_guard<std::mutex> g(p->m);
+  return (int)p->order.size();
+}
+
+int hm_pipeline_next(hm_pipeline* p, hm_pipeline_result* res)
+{
+  if (!p || !res) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
+  std::memset(res, 0, sizeof(*res));
+  Image* im;
+  {
+    std::unique_lock<std::mutex> g(p->m);
+    if (p->order.empty()) return hm_fail(HM_ERR_INVALID_ARG, "no image pending");
+    im = p->order.front();
+    p->result_cv.wait(g, [&] { return im->queued; });
+    p->order.pop_front();
+  }
+  if (im->status == HM_OK) {
+    im->status = job_complete(im->job, &im->out);
+    if (im->status) im->message = hm_last_error();
+  }
+  res->tag = im->tag;
+  res->status = im->status;
+  res->handle = im;
+  if (im->status == HM_OK) res->image = im->out;
+  else hm_fail(im->status, "%s", im->message.c_str());
+  return HM_OK;
+}
+
+void hm_pipeline_release(hm_pipeline* p, hm_pipeline_result* res)
+{
+  if (!p || !res || !res->handle) return;
+  Image* im = static_cast<Image*>(res->handle);
+  hipStream_t s = im->stream;
+  delete im; // pinned planes back to the pool
+  res->handle = nullptr;
+  std::memset(&res->image, 0, sizeof(res->image));
+  std::lock_guard<std::mutex> g(p->m);
+  p->free_streams.push_back(s);
+}
+
+} // extern "C"

@@ -252,6 +252,43 @@ HM_API void     hm_decoded_free(hm_decoded* d);
 /* release one plane taken out of an hm_decoded (ownership transfer, used by the libheif facade) */
 HM_API void     hm_host_free(void* plane);
 
+/* ------------------------------------------------------------------------- */
+/* Pipelined decode: many HEIF files in flight (host parse || H2D || kernels || D2H) */
+/* ------------------------------------------------------------------------- */
+
+/* The throughput form of heif_decode_image: what a server that decodes a stream of files does with the reference is a
+ * loop over heif_context_read_from_memory + heif_decode_image with heif_context_set_threads(n) (README.md:47-62 of the
+ * reference); there the tiles of ONE image fan out (context.cc:2361-2401) and images are serial.  Here the coded
+ * pictures of ALL submitted images share one crew of host entropy-decode threads, and each image's device work runs on
+ * its own HIP stream, so parsing image k+1, the kernels of image k and the D2H copy of image k-1 overlap. */
+typedef struct hm_pipeline hm_pipeline;
+typedef struct hm_pipeline_config {
+  int32_t host_threads;        /* entropy-decode crew (heif_context_set_threads semantics, shared by all images)  */
+  int32_t max_in_flight;       /* images that may hold device + pinned memory at once (back-pressure of submit)   */
+  int32_t out_format;          /* as hm_decode_params                                                              */
+  int32_t chroma_upsampling, ignore_transformations, strict_decoding;
+  int32_t device;              /* HIP device index, -1 = the calling thread's current device                       */
+} hm_pipeline_config;
+typedef struct hm_pipeline_result {
+  uint64_t   tag;              /* the caller's tag of hm_pipeline_submit                                            */
+  int32_t    status;           /* HM_OK or the hm_status of this image (detail: hm_last_error() of the calling thread) */
+  hm_decoded image;            /* valid when status == HM_OK, until hm_pipeline_release                            */
+  void*      handle;           /* internal                                                                         */
+} hm_pipeline_result;
+HM_API int  hm_pipeline_create(const hm_pipeline_config* cfg, hm_pipeline** out);
+HM_API void hm_pipeline_destroy(hm_pipeline* p);
+/* queue one HEIF file (the bytes are copied; item_id 0 = the primary item).  Returns HM_OK, a negative status (the file
+ * is malformed / unsupported: nothing was queued), or HM_PIPELINE_FULL when max_in_flight images are pending: take a
+ * result (hm_pipeline_next + hm_pipeline_release) and submit again */
+enum { HM_PIPELINE_FULL = 1 };
+HM_API int  hm_pipeline_submit(hm_pipeline* p, const uint8_t* heif, size_t size, uint32_t item_id, uint64_t tag);
+/* number of submitted images whose result has not been taken yet */
+HM_API int  hm_pipeline_pending(hm_pipeline* p);
+/* wait for the oldest pending image (results come in submission order); a failed image is reported in res->status */
+HM_API int  hm_pipeline_next(hm_pipeline* p, hm_pipeline_result* res);
+/* give the image's pinned planes and its slot back */
+HM_API void hm_pipeline_release(hm_pipeline* p, hm_pipeline_result* res);
+
 #ifdef __cplusplus
 }
 #endif

@@ -108,6 +108,65 @@ class HeifFile:
             self.h = C.c_void_p()
 
 
+class PipelineConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in "host_threads max_in_flight out_format chroma_upsampling ignore_transformations strict_decoding device".split()]
+
+
+class PipelineResult(C.Structure):
+    _fields_ = [("tag", C.c_uint64), ("status", C.c_int32), ("image", Decoded), ("handle", C.c_void_p)]
+
+
+class Pipeline:
+    """hm_pipeline_*: many HEIF files in flight (host entropy decode || H2D || kernels || D2H)."""
+
+    def __init__(self, hm, out_format, host_threads=4, max_in_flight=8, device=-1):
+        self.hm = bind(hm)
+        hm.hm_pipeline_create.argtypes = [C.POINTER(PipelineConfig), C.POINTER(C.c_void_p)]
+        hm.hm_pipeline_destroy.argtypes = [C.c_void_p]
+        hm.hm_pipeline_submit.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint64]
+        hm.hm_pipeline_pending.argtypes = [C.c_void_p]
+        hm.hm_pipeline_next.argtypes = [C.c_void_p, C.POINTER(PipelineResult)]
+        hm.hm_pipeline_release.argtypes = [C.c_void_p, C.POINTER(PipelineResult)]
+        cfg = PipelineConfig(host_threads, max_in_flight, out_format, 0, 0, 0, device)
+        self.h = C.c_void_p()
+        rc = hm.hm_pipeline_create(C.byref(cfg), C.byref(self.h))
+        if rc:
+            raise RuntimeError(f"hm_pipeline_create: {rc}: {hm.hm_last_error().decode()}")
+
+    def submit(self, data, tag, item=0):
+        """True if queued, False if the pipeline is full; raises on a malformed file"""
+        rc = self.hm.hm_pipeline_submit(self.h, data, len(data), item, tag)
+        if rc < 0:
+            raise RuntimeError(f"hm_pipeline_submit: {rc}: {self.hm.hm_last_error().decode()}")
+        return rc == 0
+
+    def pending(self):
+        return self.hm.hm_pipeline_pending(self.h)
+
+    def next(self, copy=True):
+        """(tag, status, array or None, meta) of the oldest pending image"""
+        r = PipelineResult()
+        rc = self.hm.hm_pipeline_next(self.h, C.byref(r))
+        if rc:
+            raise RuntimeError(f"hm_pipeline_next: {rc}: {self.hm.hm_last_error().decode()}")
+        arr, meta = None, None
+        if r.status == 0:
+            d = r.image
+            meta = dict(width=d.width, height=d.height, stride=d.stride[0], bit_depth=d.bit_depth)
+            if copy:
+                arr = np.ctypeslib.as_array(d.plane[0], shape=(d.plane_height[0], d.stride[0])).copy()
+        else:
+            meta = dict(error=self.hm.hm_last_error().decode())
+        tag, status = r.tag, r.status
+        self.hm.hm_pipeline_release(self.h, C.byref(r))
+        return tag, status, arr, meta
+
+    def close(self):
+        if self.h:
+            self.hm.hm_pipeline_destroy(self.h)
+            self.h = C.c_void_p()
+
+
 def cpu_decode(hm, tiles, tile_w, tile_h, canvas_w, canvas_h, cols, is_grid, out_fmt, tile_colr=None, decoder="oracle", bilinear=False, transforms=None):
     """tiles: list of [len][NAL] strings.  Returns (rgb array, stride) following the reference flow."""
     o = orc.load()

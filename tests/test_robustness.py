@@ -92,6 +92,8 @@ def test_no_gpu_means_loud_failure_not_cpu_fallback(hm):
     assert rc == -4, (rc, msg)  # HM_ERR_NO_DEVICE
     b = C.c_void_p()
     assert hm.hm_batch_create(C.byref(b)) == -4
+    with pytest.raises(RuntimeError, match="-4"):
+        pipeline.Pipeline(hm, 10)
 
 
 def test_unsupported_syntax_is_reported(hm):
