@@ -74,6 +74,7 @@ def bind_decode(L):
     L.hm_batch_size.argtypes = [C.c_void_p]
     L.hm_batch_upload.argtypes = [C.c_void_p, C.c_void_p]
     L.hm_batch_execute.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.hm_batch_upload_execute.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.hm_batch_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.hm_batch_get_timings.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     L.hm_batch_algorithmic_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -118,6 +119,9 @@ class Batch:
 
     def execute(self, stages=3, stream=None):
         check(self.L.hm_batch_execute(self.h, stages, stream))
+
+    def upload_execute(self, stages, chunks, copy_stream, stream):
+        check(self.L.hm_batch_upload_execute(self.h, stages, chunks, copy_stream, stream))
 
     def clear(self):
         self.L.hm_batch_clear(self.h)

@@ -79,17 +79,27 @@ struct hm_batch {
   PinnedArena desc_stage;  // descriptor array (kept alive: the H2D copies are asynchronous)
   bool uploaded = false;
   bool inflight = false;             // something was enqueued on last_stream since the last drain
+  hipEvent_t upload_done = nullptr;  // recorded behind the H2D copies: an execute on another stream waits for it on the device
+  std::vector<hipEvent_t> chunk_events; // hm_batch_upload_execute: one per chunk of command streams
+  hipStream_t copy_stream = nullptr;
+  bool copy_inflight = false;
   hipStream_t last_stream = nullptr; // stream of the last upload / execute: drained before the arenas are released
   size_t total_pixels = 0;
   // optional per-kernel timing with HIP events on the launch stream (bench / profiling)
   int profiling = 0;                // number of timing slots (0 = off)
   std::vector<hipEvent_t> events;   // per slot, 4 per class: before recon, after recon, after deblock, after sao
   long exec_count = 0;
-  void drain() { if (inflight) { hipStreamSynchronize(last_stream); inflight = false; } }
+  void drain()
+  {
+    if (copy_inflight) { hipStreamSynchronize(copy_stream); copy_inflight = false; }
+    if (inflight) { hipStreamSynchronize(last_stream); inflight = false; }
+  }
   ~hm_batch()
   {
     drain();
     for (hipEvent_t e : events) hipEventDestroy(e);
+    if (upload_done) hipEventDestroy(upload_done);
+    for (hipEvent_t e : chunk_events) hipEventDestroy(e);
   }
 };
 
@@ -148,18 +158,19 @@ int hm_batch_add_trusted(hm_batch* b, const uint8_t* blob, size_t size, const hm
   return (int)b->items.size() - 1;
 }
 
-// Upload command streams, build descriptors, size the working set.  After this the inputs are
-// resident in HBM; hm_batch_execute() only launches kernels.
-int hm_batch_upload(hm_batch* b, void* stream)
+} // extern "C"
+
+// Host half of an upload: picture classes, layout of the working set, device buffers, job descriptors (in the pinned
+// descriptor arena).  Every check that can fail on file data lives here, before anything is enqueued.
+static int batch_prepare(hm_batch* b, size_t* blob_bytes_out)
 {
-  if (!b) return hm_fail(HM_ERR_INVALID_ARG, "null batch");
-  hipStream_t s = (hipStream_t)stream;
   const int n = (int)b->items.size();
   b->drain(); // descriptors and buffers of an earlier upload may still be in use
   b->uploaded = false;
   b->classes.clear();
   b->h_desc.assign(n, hm_dev_pic());
-  if (n == 0) { b->uploaded = true; return HM_OK; }
+  *blob_bytes_out = 0;
+  if (n == 0) return HM_OK;
 
   // classes: pictures of one launch share CTB size, chroma format and sample width
   std::map<std::tuple<int, int, int, int>, int> cls_index;
@@ -269,6 +280,23 @@ int hm_batch_upload(hm_batch* b, void* stream)
   b->desc_stage.used = 0;
   if (!b->desc_stage.reserve(sizeof(hm_dev_pic) * (size_t)n)) return hm_fail(HM_ERR_NOMEM, "pinned staging: out of memory");
   std::memcpy(b->desc_stage.p, b->h_desc.data(), sizeof(hm_dev_pic) * (size_t)n);
+  *blob_bytes_out = blob_bytes;
+  return HM_OK;
+}
+
+extern "C" {
+
+// Upload command streams, build descriptors, size the working set.  After this the inputs are
+// resident in HBM; hm_batch_execute() only launches kernels.
+int hm_batch_upload(hm_batch* b, void* stream)
+{
+  if (!b) return hm_fail(HM_ERR_INVALID_ARG, "null batch");
+  hipStream_t s = (hipStream_t)stream;
+  const int n = (int)b->items.size();
+  size_t blob_bytes = 0;
+  const int rc = batch_prepare(b, &blob_bytes);
+  if (rc) return rc;
+  if (n == 0) { b->uploaded = true; return HM_OK; }
   b->last_stream = s;
   b->inflight = true;
   // the streams already lie in the pinned arena in device layout -> one H2D copy at PCIe rate
@@ -276,6 +304,12 @@ int hm_batch_upload(hm_batch* b, void* stream)
   if (e != hipSuccess) return hm_check_hip(e, "H2D command streams");
   e = hipMemcpyAsync(b->d_desc.p, b->desc_stage.p, sizeof(hm_dev_pic) * (size_t)n, hipMemcpyHostToDevice, s);
   if (e != hipSuccess) return hm_check_hip(e, "H2D descriptors");
+  if (!b->upload_done) {
+    e = hipEventCreateWithFlags(&b->upload_done, hipEventDisableTiming);
+    if (e != hipSuccess) return hm_check_hip(e, "hipEventCreate");
+  }
+  e = hipEventRecord(b->upload_done, s);
+  if (e != hipSuccess) return hm_check_hip(e, "hipEventRecord");
   b->uploaded = true; // asynchronous: the arenas stay alive with the batch
   return HM_OK;
 }
@@ -287,7 +321,11 @@ int hm_batch_execute(hm_batch* b, int stages, void* stream)
   if (!b) return hm_fail(HM_ERR_INVALID_ARG, "null batch");
   if (!b->uploaded) return hm_fail(HM_ERR_INVALID_ARG, "hm_batch_upload() has not been called");
   hipStream_t s = (hipStream_t)stream;
-  if (b->inflight && s != b->last_stream) b->drain(); // a different stream than the upload's: order them
+  // a different stream than the upload's (a copy stream feeding a compute stream): order them on the device
+  if (s != b->last_stream && b->upload_done) {
+    const hipError_t e = hipStreamWaitEvent(s, b->upload_done, 0);
+    if (e != hipSuccess) return hm_check_hip(e, "hipStreamWaitEvent");
+  }
   b->last_stream = s;
   b->inflight = true;
   const hm_dev_pic* d = (const hm_dev_pic*)b->d_desc.p;
@@ -319,6 +357,62 @@ int hm_batch_execute(hm_batch* b, int stages, void* stream)
     if (rc) return rc;
     mark();
   }
+  b->exec_count++;
+  return HM_OK;
+}
+
+// Upload and execute in one call, the H2D copy of chunk i+1 (copy stream) running under the kernels of chunk i (compute
+// stream): the device-inclusive clock becomes max(H2D, kernels) + one chunk instead of their sum.  Pictures are taken
+// in queue order; a batch that mixes picture classes (kernel variants) is handled serially.
+int hm_batch_upload_execute(hm_batch* b, int stages, int chunks, void* copy_stream, void* stream)
+{
+  if (!b) return hm_fail(HM_ERR_INVALID_ARG, "null batch");
+  hipStream_t cs = (hipStream_t)copy_stream, s = (hipStream_t)stream;
+  const int n = (int)b->items.size();
+  size_t blob_bytes = 0;
+  int rc = batch_prepare(b, &blob_bytes);
+  if (rc) return rc;
+  if (n == 0) { b->uploaded = true; return HM_OK; }
+  if (b->classes.size() != 1 || chunks < 2 || cs == s) {
+    if ((rc = hm_batch_upload(b, copy_stream))) return rc;
+    return hm_batch_execute(b, stages, stream);
+  }
+  if (chunks > n) chunks = n;
+  while ((int)b->chunk_events.size() < chunks) {
+    hipEvent_t ev;
+    const hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) return hm_check_hip(e, "hipEventCreate");
+    b->chunk_events.push_back(ev);
+  }
+  b->last_stream = s;
+  b->inflight = true;
+  b->copy_stream = cs;
+  b->copy_inflight = true;
+  hipError_t e = hipMemcpyAsync(b->d_desc.p, b->desc_stage.p, sizeof(hm_dev_pic) * (size_t)n, hipMemcpyHostToDevice, cs);
+  if (e != hipSuccess) return hm_check_hip(e, "H2D descriptors");
+  const Class& c = b->classes[0]; // its descriptors are in queue order = the order of the streams in the arena
+  const hm_dev_pic* d = (const hm_dev_pic*)b->d_desc.p;
+  size_t copied = 0;
+  for (int k = 0; k < chunks; k++) {
+    const int i0 = (int)((long)n * k / chunks), i1 = (int)((long)n * (k + 1) / chunks);
+    const size_t end = i1 == n ? blob_bytes : b->items[i1].stage_off;
+    e = hipMemcpyAsync((uint8_t*)b->d_blobs.p + copied, b->stage.p + copied, end - copied, hipMemcpyHostToDevice, cs);
+    if (e != hipSuccess) return hm_check_hip(e, "H2D command streams");
+    copied = end;
+    if ((e = hipEventRecord(b->chunk_events[k], cs)) != hipSuccess) return hm_check_hip(e, "hipEventRecord");
+    if ((e = hipStreamWaitEvent(s, b->chunk_events[k], 0)) != hipSuccess) return hm_check_hip(e, "hipStreamWaitEvent");
+    const hm_dev_pic* dc = d + i0;
+    const int m = i1 - i0;
+    if ((rc = hm_launch_recon(dc, m, c.log2_ctb, c.chroma_format, c.bit_depth, c.rare, c.max_ctb_w, c.max_ctb_h, s))) return rc;
+    if ((stages & 1) && (rc = hm_launch_deblock(dc, m, c.max_w4, c.max_h4, c.chroma_format, c.bit_depth, c.rare, s))) return rc;
+    if ((rc = hm_launch_sao_paste(dc, m, c.max_w, c.max_h, c.bit_depth, (stages & 2) ? 1 : 0, c.rare, s))) return rc;
+  }
+  if (!b->upload_done) {
+    e = hipEventCreateWithFlags(&b->upload_done, hipEventDisableTiming);
+    if (e != hipSuccess) return hm_check_hip(e, "hipEventCreate");
+  }
+  if ((e = hipEventRecord(b->upload_done, cs)) != hipSuccess) return hm_check_hip(e, "hipEventRecord");
+  b->uploaded = true;
   b->exec_count++;
   return HM_OK;
 }

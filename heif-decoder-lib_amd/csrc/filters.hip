@@ -536,6 +536,7 @@ __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict_
   const int xs = x8 + dp.src_x[c];            // first source column of the group
   const bool fast = ((dp.src_x[c] & (G - 1)) == 0) && (x8 + G <= cw) && (xs + G <= W);
   uint32_t res[R][4]; // results as sample pairs
+  bool generic = !fast;
   if (fast) {
     // ---- aligned vector loads, everything else in registers ----
     SaoRow<Pix> rows[R + 2]; // source rows yy0 - 1 .. yy0 + R
@@ -543,6 +544,7 @@ __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict_
     for (int r = 0; r < R + 2; r++) rows[r].load(plane, pitch, xs, yy0 - 1 + r, W, Hh);
     const int cx = xs >> l2w;
     uint32_t cflags[R], s0[R], s1[R];
+    uint32_t redo = 0; // rows whose CTB needs the per-sample ring test (rare)
 #pragma unroll
     for (int r = 0; r < R; r++) {
       const int yc = yy0 + r < Hh ? yy0 + r : Hh - 1;
@@ -558,21 +560,11 @@ __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict_
       const int type = sao_on ? (int)(s0[r] & 0xFF) : 0;
       const uint32_t offs = (s0[r] >> 24) | (s1[r] << 8); // the four int8 offsets in one register
       // neighbour-CTB mask of this component; chroma CTBs whose ring flag is clear (quirk Q13: only with several slices
-      // whose filters stop at slice borders) take the per-sample path below
+      // whose filters stop at slice borders) are redone sample by sample below
       const uint32_t nbm = c == 0 ? (cflags[r] >> 8) & 0xFF : (cflags[r] >> 16) & 0xFF;
-      const bool ring_blocked = c != 0 && !((cflags[r] >> 24) & 0xFF);
+      if (c != 0 && type == 2 && !(cflags[r] >> 24)) redo |= 1u << r;
 #pragma unroll
       for (int j = 0; j < 4; j++) res[r][j] = cur.p[j];
-      if (type == 2 && ring_blocked) {
-#pragma unroll 1
-        for (int k = 0; k < G; k++) {
-          const int val = sao_sample<Pix>(dp, v, plane, pitch, c, xs + k, yy, W, Hh, l2w, l2h, bd, apply_sao,
-                                          RARE && (dp.flags & HM_PIC_LOSSLESS_CUS) ? ((dp.pcm_loop_filter_disabled ? 4 : 0) | 8) : 0);
-          if (k & 1) res[r][k >> 1] = (res[r][k >> 1] & 0xFFFFu) | ((uint32_t)val << 16);
-          else res[r][k >> 1] = (res[r][k >> 1] & 0xFFFF0000u) | (uint32_t)val;
-        }
-        continue;
-      }
       if (type == 1) { // band offset (fallback-postfilter.h:218-241): table index = band - band_position, 4 = none
         const uint32_t bp = (s0[r] >> 16) & 0xFF;
         const uint32_t biased = offs ^ 0x80808080u;
@@ -599,8 +591,9 @@ __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict_
           if (lossless_bits(dp, (xs + 2 * j) << sxs, yy << lsy) & mask) res[r][j] = cur.p[j];
       }
     }
+    generic = redo != 0; // (rare: such a group is simply redone by the per-sample path below)
   }
-  else {
+  if (generic) {
 #pragma unroll
     for (int r = 0; r < R; r++) {
 #pragma unroll

@@ -151,6 +151,9 @@ HM_API int  hm_batch_upload(hm_batch* b, void* stream);
  * stages: bit0 = deblocking, bit1 = SAO; pass 3.  Pictures of a batch are independent: this is
  * the data-parallel replacement of the reference's std::async tile fan-out (context.cc:2361-2401). */
 HM_API int  hm_batch_execute(hm_batch* b, int stages, void* stream);
+/* hm_batch_upload + hm_batch_execute in one call, the command streams split into `chunks` parts: the H2D copy of part
+ * i+1 (on `copy_stream`) runs under the kernels of part i (on `stream`).  Asynchronous. */
+HM_API int  hm_batch_upload_execute(hm_batch* b, int stages, int chunks, void* copy_stream, void* stream);
 /* per-kernel timing with HIP events on the launch stream: `slots` execute calls are kept (ring),
  * 0 switches it off (default) */
 HM_API int  hm_batch_set_profiling(hm_batch* b, int slots);

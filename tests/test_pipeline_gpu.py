@@ -65,7 +65,9 @@ def test_pipeline_results_equal_image_at_a_time(hm, out_format, threads, depth):
     for t, (arr, meta) in got.items():
         exp, emeta = expected[t % 1000]
         assert (meta["width"], meta["height"], meta["stride"]) == (emeta["width"], emeta["height"], emeta["stride"][0])
-        np.testing.assert_array_equal(arr, exp)
+        bpp = 3 if out_format == 10 else 4
+        w, h = meta["width"], meta["height"]
+        np.testing.assert_array_equal(arr[:h, :w * bpp], exp[:h, :w * bpp])  # (row padding is not part of the image)
 
 
 def test_pipeline_order_and_reference_fingerprints(hm):
@@ -108,7 +110,7 @@ def test_pipeline_reports_bad_files_and_keeps_going(hm):
         res = [pl.next() for _ in range(3)]
         assert [r[0] for r in res] == [2, 3, 4]
         assert res[0][1] == 0 and res[2][1] == 0 and res[1][1] < 0 and "tile 1" in res[1][3]["error"]
-        np.testing.assert_array_equal(res[0][2], res[2][2])
+        np.testing.assert_array_equal(res[0][2][:128, :128 * 3], res[2][2][:128, :128 * 3])
         # closing with images still pending is fine
         assert pl.submit(good, 5) and pl.submit(good, 6)
     finally:
