@@ -8,9 +8,9 @@
 
 namespace hm {
 
-std::vector<uint8_t> unescape_nal(const uint8_t* p, size_t n)
+void unescape_nal(const uint8_t* p, size_t n, std::vector<uint8_t>& out)
 {
-  std::vector<uint8_t> out;
+  out.clear();
   out.reserve(n);
   int zeros = 0;
   for (size_t i = 0; i < n; i++) {
@@ -21,7 +21,6 @@ std::vector<uint8_t> unescape_nal(const uint8_t* p, size_t n)
     out.push_back(p[i]);
     zeros = (p[i] == 0) ? zeros + 1 : 0;
   }
-  return out;
 }
 
 namespace {

@@ -149,7 +149,9 @@ struct PictureState {
     hm_ctb z; std::memset(&z, 0, sizeof(z));
     ctbs.assign(n, z);
     slices.clear();
-    ctb_tus.assign(n, {});
+    // (inner vectors keep their capacity: a parser thread reuses its workspace for picture after picture)
+    if ((int)ctb_tus.size() != n) ctb_tus.resize(n);
+    for (auto& v : ctb_tus) v.clear();
     coeffs.clear();
     uses_pcm = uses_tq_bypass = false;
     wpp_ctx.assign(p.entropy_coding_sync ? (size_t)s.ctb_h : 0, ContextSet());

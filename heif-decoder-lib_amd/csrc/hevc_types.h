@@ -196,8 +196,8 @@ void derive_pps_tables(PPS& pps, const SPS& sps);
 void parse_slice_header(BitReader& br, int nal_unit_type, const SPS* sps_table, const PPS* pps_table,
                         const SliceHeader* prev, SliceHeader& sh);
 
-// remove emulation prevention bytes (00 00 03 -> 00 00); returns the RBSP incl. the 2-byte NAL header
-std::vector<uint8_t> unescape_nal(const uint8_t* p, size_t n);
+// remove emulation prevention bytes (00 00 03 -> 00 00): `out` receives the RBSP incl. the 2-byte NAL header
+void unescape_nal(const uint8_t* p, size_t n, std::vector<uint8_t>& out);
 
 inline int ceil_log2(uint32_t v)
 {

@@ -13,7 +13,10 @@
 //   * results are handed out in submission order (hm_pipeline_next).
 // No collective, no CPU reconstruction fallback: CABAC stays on the host as in the reference, everything else is GPU.
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -58,19 +61,30 @@ struct hm_pipeline {
   std::vector<hipStream_t> free_streams;
   int in_flight = 0;
   bool quit = false;
+  // HM_PIPELINE_STATS=1: where the crew's time went, printed by hm_pipeline_destroy (diagnostics)
+  std::atomic<uint64_t> ns_parse{0}, ns_enqueue{0}, ns_idle{0}, n_tiles{0}, n_images{0};
+  static uint64_t now_ns() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
   void worker_loop()
   {
     if (cfg.device >= 0) hipSetDevice(cfg.device);
     std::unique_lock<std::mutex> g(m);
     for (;;) {
+      const uint64_t t0 = now_ns();
       work_cv.wait(g, [&] { return quit || !tasks.empty(); });
       if (quit && tasks.empty()) return;
       Task t = tasks.front();
       tasks.pop_front();
       g.unlock();
+      const uint64_t t1 = now_ns();
       job_parse_tile(t.img->job, t.tile);
-      if (t.img->tiles_left.fetch_sub(1) == 1) finish(t.img); // last coded picture of the image: hand it to the GPU
+      const uint64_t t2 = now_ns();
+      if (t.img->tiles_left.fetch_sub(1) == 1) { // last coded picture of the image: hand it to the GPU
+        finish(t.img);
+        ns_enqueue += now_ns() - t2;
+        n_images++;
+      }
+      ns_idle += t1 - t0; ns_parse += t2 - t1; n_tiles++;
       g.lock();
     }
   }
@@ -125,12 +139,17 @@ void hm_pipeline_destroy(hm_pipeline* p)
   {
     std::lock_guard<std::mutex> g(p->m);
     p->quit = true;
-    // unparsed work of images nobody will collect: drop the tasks, the images are destroyed below
-    for (const Task& t : p->tasks) t.img->tiles_left.fetch_sub(1);
+    // unparsed work of images nobody will collect: drop the tasks (their images' tile counts then never reach zero, so no
+    // worker hands a half-parsed image to the GPU); the images are destroyed below
     p->tasks.clear();
   }
   p->work_cv.notify_all();
   for (std::thread& t : p->workers) t.join();
+  if (std::getenv("HM_PIPELINE_STATS"))
+    std::fprintf(stderr, "[hm_pipeline] %llu images, %llu coded pictures on %d threads: parse %.1f ms/picture, GPU hand-over %.2f ms/image, idle %.1f %% of the crew's time\n",
+                 (unsigned long long)p->n_images.load(), (unsigned long long)p->n_tiles.load(), p->cfg.host_threads,
+                 p->n_tiles ? p->ns_parse.load() / 1e6 / p->n_tiles.load() : 0.0, p->n_images ? p->ns_enqueue.load() / 1e6 / p->n_images.load() : 0.0,
+                 100.0 * p->ns_idle.load() / (double)(p->ns_idle.load() + p->ns_parse.load() + p->ns_enqueue.load() + 1));
   for (Image* im : p->order) delete im; // drains each image's stream first
   for (hipStream_t s : p->free_streams) hipStreamDestroy(s);
   delete p;

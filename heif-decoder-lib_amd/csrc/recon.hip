@@ -38,501 +38,9 @@
 #include "hm_device.h"
 #include "hm_internal.h"
 
+#include "recon_common.h"
+
 namespace {
-
-// LDS traffic inside a wave needs no barrier (DS ops of one wave execute in order); a
-// wavefront-scope fence is a pure compiler ordering point (no vmcnt drain: outstanding global
-// stores of the metadata maps / prefetches stay in flight).
-#define WAVE_SYNC()                                          \
-  do {                                                       \
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  \
-    __builtin_amdgcn_wave_barrier();                         \
-  } while (0)
-
-__device__ __forceinline__ int clip3i(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
-__device__ __forceinline__ int iabs_(int v) { return v < 0 ? -v : v; }
-__device__ __forceinline__ int imin_(int a, int b) { return a < b ? a : b; }
-// 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): every product here is position x pitch, weight x
-// sample or basis x coefficient, far below 2^23 per operand
-__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
-__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
-__device__ __forceinline__ int wave_max(int v)
-{
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o); v = t > v ? t : v; }
-  return v;
-}
-// maximum of a small non-negative value (< 32) over the active lanes: binary search with ballots
-// (VALU compare + SALU only; no cross-lane data movement)
-__device__ __forceinline__ int wave_max5(int v)
-{
-  int m = 0;
-#pragma unroll
-  for (int b = 4; b >= 0; b--) {
-    const int t = m | (1 << b);
-    if (__ballot(v >= t)) m = t;
-  }
-  return m;
-}
-template <bool HALVES = false> // HALVES: independent sums over lanes 0-31 and 32-63
-__device__ __forceinline__ int wave_sum(int v)
-{
-#pragma unroll
-  for (int o = HALVES ? 16 : 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-
-__constant__ int c_intra_angle[35] = {0, 0, 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26,
-                                      -32, -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32};
-__constant__ int c_inv_angle[15] = {-4096, -1638, -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096};
-__constant__ int c_level_scale[6] = {40, 45, 51, 57, 64, 72};
-__constant__ int8_t c_dst[4][4] = {{29, 55, 74, 84}, {74, 74, 0, -74}, {84, -29, -74, 55}, {55, -84, 74, -29}};
-// magnitudes of the inverse-DCT basis by angle index (cf. oracle_recon.c: init_dct)
-__constant__ int8_t c_dct_mag[33] = {64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
-                                     61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0};
-
-// Pointers into HBM are cast to the global address space so that the compiler emits global_load /
-// global_store (vmcnt only) instead of flat_* (which also count on lgkmcnt and would make every LDS wait
-// stall on the in-flight prefetches).
-#define GLOBAL_AS __attribute__((address_space(1)))
-template <typename T>
-__device__ __forceinline__ const GLOBAL_AS T* gptr(const void* p) { return (const GLOBAL_AS T*)(uintptr_t)p; }
-template <typename T>
-__device__ __forceinline__ GLOBAL_AS T* gptr_w(void* p) { return (GLOBAL_AS T*)(uintptr_t)p; }
-
-constexpr int BIG_BYTES = 2048 + 1024 + 16; // shared 32x32 coefficient block, its 16-row intermediate, lock
-constexpr int UPAD = 4; // unified CTU buffer: row = [3 unused | left neighbour | bw samples]; rows stay 4-byte aligned
-
-// One block to reconstruct.  Every member has the same value in all lanes, but only the fields that steer
-// control flow (c, mode, info, aL, aT, aTL) are held in SGPRs; the data fields (position, pointers, pitch,
-// QP, partial availabilities, coefficient count) are deliberately kept in VGPRs: the CU has ONE scalar ALU
-// (1 instruction / cycle for all its waves, measured: tools/ubench/salu_rate.hip) against four vector ALUs,
-// and the per-block address / index arithmetic would otherwise make the scalar unit the bottleneck.
-template <typename Pix>
-struct Blk {
-  Pix* u;            // unified CTU buffer of the plane: sample (x,y) at u[y*P + UPAD + x], x >= -1
-  const Pix* top;    // top[1 + x] = sample at (x,-1), x = -1 .. 2*bw-1 (inside the line of the CTU row above)
-  int P;             // pitch of u in samples
-  int x0, y0, log2, c, mode, qp, info;
-  int tskip;         // transform_skip_flag (a vector value when a Cb / Cr pair shares the wave)
-  uint32_t avail;    // hm_tu.avail_* as one word: left | bottom_left << 8 | top << 16 | top_right << 24 (scalar)
-  int aBL, aTR;      // vector copies of the two partial counts
-  int n_coeff;
-  int bd;
-};
-// neighbour availability of the slow (picture / slice / tile border) path, decoded from Blk::avail / Blk::info
-struct Avail {
-  int aL, aBL, aT, aTR, aTL;
-};
-
-template <typename Pix>
-__device__ __forceinline__ int nb(const Blk<Pix>& b, int x, int y)
-{
-  const Pix* p = (y < 0) ? (b.top + (x + 1)) : (b.u + (mul24(y, b.P) + UPAD + x));
-  return *p;
-}
-
-// Value of reference sample i (i = -2nT .. 2nT; negative = left column bottom-up, 0 = corner,
-// positive = top row) after the substitution process (intrapred.h:620-836 == H.265 8.4.4.2.2),
-// as a pure function of the staged neighbourhood: one ds_read per call.
-template <typename Pix, int L2>
-__device__ __forceinline__ int border_value(const Blk<Pix>& b, const Avail& av, int i, int noLeftFill, int topFill)
-{
-  constexpr int nT = 1 << L2;
-  int x, y, valid, fill;
-  if (i < 0) {
-    const int k = -i; // sample (x0-1, y0+k-1)
-    x = -1;
-    if (k <= nT) { y = k - 1; valid = av.aL; }
-    else if (av.aBL) { y = imin_(k - 1, nT + av.aBL - 1); valid = 1; }
-    else { y = nT - 1; valid = av.aL; }
-    fill = noLeftFill;
-  }
-  else if (i == 0) {
-    x = -1; y = av.aTL ? -1 : 0;
-    valid = av.aTL | av.aL;
-    fill = noLeftFill;
-  }
-  else {
-    y = -1;
-    if (i <= nT) { x = i - 1; valid = av.aT; }
-    else if (av.aTR) { x = imin_(i - 1, nT + av.aTR - 1); valid = 1; }
-    else { x = nT - 1; valid = av.aT; }
-    fill = topFill;
-  }
-  const int v = nb(b, b.x0 + x, b.y0 + y); // always a legal LDS address inside the staging area
-  return valid ? v : fill;
-}
-
-// Where the predictors take reference sample j (j = -2nT .. 2nT as above) from:
-//   RefArray   the gathered (and possibly smoothed) array bA
-//   RefDirect  straight from the CTU buffer / the line above, for interior blocks whose samples need no smoothing:
-//              substitution of a partly available run is a clamped coordinate, so no gather pass, no LDS write
-//              and one LDS round trip less on the block's dependency chain
-struct RefArray {
-  const int16_t* bc;
-  __device__ __forceinline__ int operator()(int j) const { return bc[j]; }
-  __device__ __forceinline__ int top(int k) const { return bc[k]; }   // k >= 0: corner, then the row above
-  __device__ __forceinline__ int left(int k) const { return bc[-k]; } // k >= 0: corner, then the left column
-};
-template <typename Pix>
-struct RefDirect {
-  const Pix* lp; // sample (x0-1, y0); lp[y * P] walks down the left column
-  const Pix* tp; // sample (x0, y0-1); tp[-1] is the corner
-  int P, nL1, nT1;
-  __device__ __forceinline__ int operator()(int j) const
-  {
-    const int ol = mul24(imin_(-j - 1, nL1), P), ot = imin_(j - 1, nT1);
-    const Pix* const ql = lp + ol;
-    const Pix* const qt = tp + ot;
-    return *(j < 0 ? ql : qt);
-  }
-  // one-sided accessors for the modes that only look up (or only left): no side select
-  __device__ __forceinline__ int top(int k) const { return tp[imin_(k - 1, nT1)]; }
-  __device__ __forceinline__ int left(int k) const { return lp[mul24(imin_(k - 1, nL1), P)]; }
-};
-template <typename Pix, int L2>
-__device__ __forceinline__ RefDirect<Pix> direct_refs(const Blk<Pix>& b)
-{
-  constexpr int nT = 1 << L2;
-  RefDirect<Pix> r;
-  r.lp = b.u + (mul24(b.y0, b.P) + UPAD + b.x0 - 1);
-  const Pix* const tpu = r.lp - b.P + 1;       // (x0, y0-1) inside the CTU
-  const Pix* const tpl = b.top + (1 + b.x0);   // ... in the line of the CTU row above
-  r.tp = b.y0 > 0 ? tpu : tpl;
-  r.P = b.P;
-  r.nL1 = nT + b.aBL - 1;
-  r.nT1 = nT + b.aTR - 1;
-  return r;
-}
-// interior <=> left and top runs complete (the counts are 0 or nT: bit L2) and the corner exists
-template <int L2>
-__device__ __forceinline__ bool is_interior(uint32_t avail, int info)
-{
-  constexpr uint32_t need = 0x00010001u << L2;
-  return (avail & need) == need && (info & HM_TU_AVAIL_TL);
-}
-
-// Per-lane loop over N items (N a compile-time constant, item = lane + 64 * trip): straight-line code for up to
-// two trips, otherwise a loop on a scalar counter; only the last, partial trip is predicated.
-template <int N, typename F>
-__device__ __forceinline__ void lanes_loop(int lane, F&& f)
-{
-  constexpr int FULL = N / 64, REST = N % 64;
-  if constexpr (FULL <= 2) {
-#pragma unroll
-    for (int t = 0; t < FULL; t++) f(lane + 64 * t);
-  }
-  else {
-#pragma unroll 1
-    for (int t = 0; t < FULL; t++) f(lane + 64 * t);
-  }
-  if constexpr (REST != 0) {
-    const int e = lane + 64 * FULL;
-    if (e < N) f(e);
-  }
-}
-
-// intra_smoothing decision of intrapred.h:192-214 as one bit per prediction mode: luma only, never for DC,
-// never for 4x4; min(|mode-26|, |mode-10|) > 7 (8x8), > 1 (16x16), > 0 (32x32); planar counts as "far".
-constexpr uint64_t filter_mode_mask(int log2)
-{
-  uint64_t m = 0;
-  for (int mode = 0; mode < 35; mode++) {
-    if (mode == 1 || log2 == 2) continue;
-    const int d1 = mode > 26 ? mode - 26 : 26 - mode, d2 = mode > 10 ? mode - 10 : 10 - mode;
-    const int d = d1 < d2 ? d1 : d2;
-    const bool f = log2 == 3 ? d > 7 : (log2 == 4 ? d > 1 : d > 0);
-    if (f) m |= 1ull << mode;
-  }
-  return m;
-}
-
-// ---- reference samples incl. smoothing (intrapred.h:192-266), written to bA ------------------------
-// Pass 1 gathers the 4nT+1 substituted samples, pass 2 (luma blocks >= 8x8, most angular modes) smooths
-// them in place: all lanes read their three neighbours, then all lanes write.
-// Written select-style on purpose (both candidates computed, then chosen): a ternary with arithmetic in
-// its arms becomes an exec-mask branch, i.e. several scalar instructions per lane-level decision.
-#define META_BYTES(ctb) (((ctb) >> 2) * ((ctb) >> 2) * 2) // 16-bit block map of one CTU
-constexpr int SMOOTH_CHROMA = 0x10000; // with the picture flags: chroma reference samples are smoothed like luma ones (4:4:4)
-template <typename Pix, int L2>
-__device__ __forceinline__ void make_border(const Blk<Pix>& b, int16_t* bA, int strong, int lane)
-{
-  constexpr int nT = 1 << L2, N = 4 * nT + 1;
-  int16_t* const bc = bA + 64; // centre (corner sample)
-
-  if (is_interior<L2>(b.avail, b.info)) {
-    // substitution only replicates the last available sample of a partly available below-left /
-    // above-right run = a clamped coordinate.  One ds_read per lane.
-    const RefDirect<Pix> R = direct_refs<Pix, L2>(b);
-    lanes_loop<N>(lane, [&](int e) { bc[e - 2 * nT] = (int16_t)R(e - 2 * nT); });
-  }
-  else { // picture / slice / tile border: full substitution process
-    Avail av;
-    av.aL = b.avail & 0xFF; av.aBL = (b.avail >> 8) & 0xFF; av.aT = (b.avail >> 16) & 0xFF; av.aTR = b.avail >> 24;
-    av.aTL = (b.info & HM_TU_AVAIL_TL) ? 1 : 0;
-    const int DEF = 1 << (b.bd - 1);
-    int noLeftFill = DEF, topFill = DEF;
-    if (av.aTL) noLeftFill = nb(b, b.x0 - 1, b.y0 - 1);
-    else if (av.aT) noLeftFill = nb(b, b.x0, b.y0 - 1);
-    else if (av.aTR) noLeftFill = nb(b, b.x0 + nT, b.y0 - 1);
-    if (av.aTL) topFill = noLeftFill;
-    else if (av.aL) topFill = nb(b, b.x0 - 1, b.y0);
-    else if (av.aTR) topFill = nb(b, b.x0 + nT, b.y0 - 1);
-    lanes_loop<N>(lane, [&](int e) { bc[e - 2 * nT] = (int16_t)border_value<Pix, L2>(b, av, e - 2 * nT, noLeftFill, topFill); });
-  }
-
-  if (L2 != 2 && (b.c == 0 || (strong & SMOOTH_CHROMA)) && ((filter_mode_mask(L2) >> b.mode) & 1)) { // intrapred.cc:307-311
-    WAVE_SYNC();
-    // strong (bilinear) smoothing of 32x32 blocks when both edges are nearly linear, else [1 2 1]; the two
-    // end samples stay as they are (the bilinear formula and the degenerate [c 2c c] both return them)
-    bool bi = false;
-    int p0 = 0, pL = 0, pT = 0;
-    if (L2 == 5 && (strong & HM_PIC_STRONG_INTRA_SMOOTHING) && (b.c == 0 || !(strong & SMOOTH_CHROMA))) { // luma only (intrapred.h:224-229)
-      p0 = bc[0]; pL = bc[-64]; pT = bc[64];
-      const int mL = bc[-32], mT = bc[32];
-      const int lim = 1 << (b.bd - 5);
-      bi = iabs_(p0 + pT - 2 * mT) < lim && iabs_(p0 + pL - 2 * mL) < lim;
-    }
-    constexpr int TRIPS = (N + 63) / 64;
-    int v[TRIPS];
-#pragma unroll
-    for (int t = 0; t < TRIPS; t++) {
-      const int e = lane + 64 * t, i = e - 2 * nT;
-      v[t] = 0;
-      if (e < N) {
-        if (bi) {
-          const int vl = p0 + ((mul24(-i, pL - p0) + 32) >> 6), vt = p0 + ((mul24(i, pT - p0) + 32) >> 6);
-          v[t] = i < 0 ? vl : vt;
-        }
-        else {
-          const bool end = (i == -2 * nT) | (i == 2 * nT);
-          const int im = end ? i : i - 1, ip = end ? i : i + 1;
-          v[t] = (bc[im] + 2 * bc[i] + bc[ip] + 2) >> 2;
-        }
-      }
-    }
-    WAVE_SYNC();
-#pragma unroll
-    for (int t = 0; t < TRIPS; t++) {
-      const int e = lane + 64 * t;
-      if (e < N) bc[e - 2 * nT] = (int16_t)v[t];
-    }
-  }
-}
-
-// ---- predictors (intrapred.h:269-441) ------------------------------------------------------------------
-template <typename Pix, int L2, typename Ref, bool HALVES = false>
-__device__ __forceinline__ void predict(const Blk<Pix>& B, const Ref& b, const int16_t* tab, int lane)
-{
-  constexpr int nT = 1 << L2, log2 = L2;
-  const int mode = B.mode, c = B.c;
-  Pix* dst = B.u + mul24(B.y0, B.P) + UPAD + B.x0;
-  const int pitch = B.P;
-  const int maxv = (1 << B.bd) - 1;
-  constexpr int npx = nT * nT;
-  const bool edge = (c == 0 && nT < 32); // boundary smoothing of DC / pure vertical / pure horizontal (luma, < 32x32)
-  if (mode == 0) {
-    lanes_loop<npx>(lane, [&](int p) {
-      const int x = p & (nT - 1), y = p >> log2;
-      dst[mul24(y, pitch) + x] = (Pix)((mul24(nT - 1 - x, b(-1 - y)) + mul24(x + 1, b(1 + nT)) + mul24(nT - 1 - y, b(1 + x)) + mul24(y + 1, b(-1 - nT)) + nT) >> (log2 + 1));
-    });
-  }
-  else if (mode == 1) {
-    int s = 0;
-    if (lane < nT) s = b(lane + 1) + b(-lane - 1);
-    const int dc = (wave_sum<HALVES>(s) + nT) >> (log2 + 1);
-    lanes_loop<npx>(lane, [&](int p) {
-      const int x = p & (nT - 1), y = p >> log2;
-      int v = dc;
-      if (edge) {
-        const int t = b(x + 1), l = b(-y - 1);
-        v = y == 0 ? (t + 3 * dc + 2) >> 2 : v;
-        v = x == 0 ? (l + 3 * dc + 2) >> 2 : v;
-        v = (x | y) == 0 ? (l + 2 * dc + t + 2) >> 2 : v;
-      }
-      dst[mul24(y, pitch) + x] = (Pix)v;
-    });
-  }
-  else if (mode == 26 || mode == 10) { // pure vertical / horizontal: copy, plus the gradient on the first column / row
-    const bool vert = mode == 26;
-    const int corner = b(0);
-    lanes_loop<npx>(lane, [&](int p) {
-      const int x = p & (nT - 1), y = p >> log2;
-      const int t = b(1 + x), l = b(-1 - y);
-      int v = vert ? t : l;
-      if (edge) {
-        const int along = vert ? x : y;                                  // distance from the smoothed border
-        const int g = vert ? b(1) + ((l - corner) >> 1) : b(-1) + ((t - corner) >> 1);
-        v = along == 0 ? clip3i(0, maxv, g) : v;
-      }
-      dst[mul24(y, pitch) + x] = (Pix)v;
-    });
-  }
-  else {
-    const int angle = tab[mode];
-    const bool vert = mode >= 18;
-    if (angle > 0) { // modes 2-9 / 27-34: every reference index is positive, i.e. on one side only
-      lanes_loop<npx>(lane, [&](int p) {
-        const int x = p & (nT - 1), y = p >> log2;
-        const int major = vert ? y : x, minor = vert ? x : y;
-        const int t = mul24(major + 1, angle);
-        const int k0 = minor + (t >> 5) + 1, iFact = t & 31;
-        const int r0 = vert ? b.top(k0) : b.left(k0), r1 = vert ? b.top(k0 + 1) : b.left(k0 + 1); // weight 0 when iFact == 0
-        dst[mul24(y, pitch) + x] = (Pix)((mul24(32 - iFact, r0) + mul24(iFact, r1) + 16) >> 5);
-      });
-    }
-    else {
-    const int inv = tab[35 + mode]; // 0 outside modes 11..25
-    const int sgn = vert ? 1 : -1; // ref[k] = border[sgn * k] for k >= 0, border[-sgn * proj(k)] for k < 0
-    lanes_loop<npx>(lane, [&](int p) {
-      const int x = p & (nT - 1), y = p >> log2;
-      const int major = vert ? y : x, minor = vert ? x : y;
-      const int t = mul24(major + 1, angle);
-      const int iIdx = t >> 5, iFact = t & 31;
-      const int k0 = minor + iIdx + 1, k1 = k0 + 1;
-      const int q0 = -((mul24(k0, inv) + 128) >> 8), q1 = -((mul24(k1, inv) + 128) >> 8);
-      const int j0 = sgn * (k0 >= 0 ? k0 : q0), j1 = sgn * (k1 >= 0 ? k1 : q1);
-      // b(j1) is read even when iFact == 0 (then it has weight 0; the index stays inside bA: |j1| <= 2nT + 1)
-      const int r0 = b(j0), r1 = b(j1);
-      dst[mul24(y, pitch) + x] = (Pix)((mul24(32 - iFact, r0) + mul24(iFact, r1) + 16) >> 5);
-    });
-    }
-  }
-}
-
-// ---- dequantisation + inverse transform + add (transform.cc:386-689, fallback-dct.cc) --------------------
-// Invariant: the dense coefficient buffer is all zero on entry and on exit.
-constexpr int TAB_SCALING_PTR = 96; // int16 index into the table region (256 B; 92 entries used): 8-byte aligned slot
-template <typename Pix, int L2>
-__device__ __forceinline__ void residual_add(const Blk<Pix>& B, int16_t* coeff, int16_t* tmp, const int8_t* dct, const int16_t* tab,
-                                             const GLOBAL_AS uint32_t* __restrict__ cf, const uint32_t pre_raw, int lane, int picf, int matrix)
-{
-  constexpr int nT = 1 << L2, log2 = L2;
-  const int c = B.c, bit_depth = B.bd;
-  constexpr int npx = nT * nT;
-  const int qP = B.qp;
-  const int bdShift = bit_depth + log2 - 9;
-  const int32_t offset = 1 << (bdShift - 1);
-  const int32_t fact = (int32_t)tab[70 + qP % 6] << (qP / 6);
-  int mx = 0, my = 0;
-  if (B.tskip & 0x100) { // transquant bypass (transform.cc:431-449): the levels are the residual
-#pragma unroll 1
-    for (int i = lane; i < B.n_coeff; i += 64) {
-      const uint32_t raw = i < 64 ? pre_raw : cf[i];
-      coeff[raw & 0xFFFF] = (int16_t)(raw >> 16);
-    }
-  }
-  else if (picf & HM_PIC_SCALING_LIST) {
-    // scaling lists (transform.cc:507-545): m = ScalingFactor[pos] of matrix cIdx (32x32: matrix 0), 64-bit product.
-    // The rare path: the table address waits in LDS behind the tables instead of occupying registers.
-    const uint8_t* table = *reinterpret_cast<const uint8_t* const*>(tab + TAB_SCALING_PTR);
-    const GLOBAL_AS uint8_t* sclist = gptr<uint8_t>(table) + (L2 == 5 ? 1008 : HM_SCALING_OFFSET(L2, matrix));
-    const int sShift = bdShift + 4;
-    const int64_t sOffset = (int64_t)1 << (sShift - 1);
-    const int ls = tab[70 + qP % 6], lsh = qP / 6;
-#pragma unroll 1
-    for (int i = lane; i < B.n_coeff; i += 64) {
-      const uint32_t raw = i < 64 ? pre_raw : cf[i];
-      const int pos = raw & 0xFFFF, value = (int)(int16_t)(raw >> 16);
-      const int32_t f = (int32_t)((uint32_t)mul24((int)sclist[pos], ls) << lsh);
-      int64_t v = ((int64_t)value * f + sOffset) >> sShift;
-      v = v < -32768 ? -32768 : (v > 32767 ? 32767 : v);
-      coeff[pos] = (int16_t)v;
-      const int px = pos & (nT - 1), py = pos >> log2;
-      mx = px > mx ? px : mx;
-      my = py > my ? py : my;
-    }
-  }
-  else {
-#pragma unroll 1 // more than 64 levels in a block is rare: keep the register footprint of one iteration
-    for (int i = lane; i < B.n_coeff; i += 64) {
-      const uint32_t raw = i < 64 ? pre_raw : cf[i]; // the first 64 pairs were fetched before the prediction started
-      const int pos = raw & 0xFFFF, value = (int)(int16_t)(raw >> 16);
-      // low 32 bits of value * fact (|value| < 2^15, fact < 2^23), i.e. the reference's wrapping int32 product (Q3)
-      const int32_t prod = (int32_t)((uint32_t)mul24(value, fact) + (uint32_t)offset);
-      coeff[pos] = (int16_t)clip3i(-32768, 32767, prod >> bdShift);
-      const int px = pos & (nT - 1), py = pos >> log2;
-      mx = px > mx ? px : mx;
-      my = py > my ? py : my;
-    }
-  }
-  if (L2 == 2) mx = my = 3; // a 4x4 block: four multiply-adds per sample are cheaper than the search
-  else { mx = wave_max5(mx); my = wave_max5(my); }
-  WAVE_SYNC();
-  Pix* dst = B.u + mul24(B.y0, B.P) + UPAD + B.x0;
-  const int pitch = B.P;
-  const int maxv = (1 << bit_depth) - 1;
-  const int postShift = 20 - bit_depth, rnd2 = 1 << (postShift - 1);
-
-  if (B.tskip & 0x100) {
-    lanes_loop<npx>(lane, [&](int p) {
-      const int x = p & (nT - 1), y = p >> log2;
-      dst[mul24(y, pitch) + x] = (Pix)clip3i(0, maxv, (int)dst[mul24(y, pitch) + x] + (int)coeff[p]);
-    });
-  }
-  else if (B.tskip) { // transform.cc:566-643
-    const int tsShift = 5 + log2;
-    lanes_loop<npx>(lane, [&](int p) {
-      const int x = p & (nT - 1), y = p >> log2;
-      const int32_t cc = (int32_t)((uint32_t)(int32_t)coeff[p] << tsShift);
-      int r = (cc + rnd2) >> postShift;
-      if (bit_depth == 8 && nT == 4) r = (int16_t)r;
-      dst[mul24(y, pitch) + x] = (Pix)clip3i(0, maxv, (int)dst[mul24(y, pitch) + x] + r);
-    });
-  }
-  else if (nT == 4 && c == 0) { // 4x4 DST-VII, fallback-dct.cc:311-449
-    if (lane < 16) {
-      const int cc = lane & 3, i = lane >> 2;
-      int sum = 0;
-#pragma unroll
-      for (int j = 0; j < 4; j++) sum += mul24(tab[76 + j * 4 + i], coeff[cc + j * 4]);
-      tmp[i * 4 + cc] = (int16_t)clip3i(-32768, 32767, (sum + 64) >> 7);
-    }
-    WAVE_SYNC();
-    if (lane < 16) {
-      const int i = lane & 3, y = lane >> 2;
-      int sum = 0;
-#pragma unroll
-      for (int j = 0; j < 4; j++) sum += mul24(tab[76 + j * 4 + i], tmp[y * 4 + j]);
-      const int out = clip3i(-32768, 32767, (sum + rnd2) >> postShift);
-      dst[mul24(y, pitch) + i] = (Pix)clip3i(0, maxv, (int)dst[mul24(y, pitch) + i] + out);
-    }
-  }
-  else {
-    // inverse DCT, fallback-dct.cc:592-733; rows/columns beyond the last non-zero coefficient are
-    // zero and contribute nothing, so the sums stop at (my, mx).  The intermediate holds 16 rows:
-    // a 32x32 block takes two column-transform / row-transform rounds.
-    const int fct = 32 >> log2;
-    constexpr int rpp = nT < 16 ? nT : 16, n_part = rpp << log2;
-    for (int i0 = 0; i0 < nT; i0 += rpp) {
-      lanes_loop<n_part>(lane, [&](int p) {
-        const int cc = p & (nT - 1), ir = p >> log2, i = i0 + ir;
-        int sum = 0;
-        if (cc <= mx)
-          for (int j = 0; j <= my; j++) sum += mul24((int)dct[(fct * j) * 32 + i], (int)coeff[cc + j * nT]);
-        tmp[cc + ir * nT] = (int16_t)clip3i(-32768, 32767, (sum + 64) >> 7);
-      });
-      WAVE_SYNC();
-      lanes_loop<n_part>(lane, [&](int p) {
-        const int i = p & (nT - 1), yr = p >> log2, y = i0 + yr;
-        int sum = 0;
-        for (int j = 0; j <= mx; j++) sum += mul24((int)dct[(fct * j) * 32 + i], (int)tmp[yr * nT + j]);
-        const int out = (sum + rnd2) >> postShift; // stage 2 is not clipped to 16 bit (Q4)
-        dst[mul24(y, pitch) + i] = (Pix)clip3i(0, maxv, (int)dst[mul24(y, pitch) + i] + out);
-      });
-      WAVE_SYNC();
-    }
-  }
-  // restore the all-zero invariant: every lane clears the entries it scattered (after the reads above)
-  WAVE_SYNC();
-#pragma unroll 1
-  for (int i = lane; i < B.n_coeff; i += 64) {
-    const uint32_t raw = i < 64 ? pre_raw : cf[i];
-    coeff[raw & 0xFFFF] = 0;
-  }
-}
 
 // =====================================================================================================
 // line_bytes: size of one sample line (all planes) as laid out by the launcher for the widest picture of the
