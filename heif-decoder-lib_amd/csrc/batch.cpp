@@ -7,6 +7,7 @@
 // by decode_and_paste_tile_image, context.cc:2407-2539).  Tiles are independent coded pictures,
 // so they become the workgroups of one launch.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -61,12 +62,26 @@ struct PinnedArena {
 struct Class {
   int log2_ctb, chroma_format, bit_depth;
   int rare = 0; // pictures with rarely used syntax (HM_PIC_RARE_SYNTAX) run the kernel variant that carries those paths
+  int split = 0; // record order of the pictures (HM_PIC_SPLIT_CHAINS)
   std::vector<int> items;
   int max_ctb_w = 0, max_ctb_h = 0, max_w4 = 0, max_h4 = 0, max_w = 0, max_h = 0;
   size_t desc_offset = 0; // index of the first descriptor in the descriptor array
 };
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// reconstruction of the pictures of one class: pictures whose records come as separate luma / chroma chains
+// (HM_PIC_SPLIT_CHAINS: everything without rare syntax) run the four-chains-per-wave kernel, the others (records in
+// decode order) the one-row-per-wave kernel
+int launch_recon(const hm_dev_pic* dc, int n, const Class& c, hipStream_t s)
+{
+  if (c.split) {
+    const int q = hm_launch_recon_quad(dc, n, c.log2_ctb, c.chroma_format, c.bit_depth, c.rare, c.max_ctb_w, c.max_ctb_h, s);
+    if (q == 0) return hm_fail(HM_ERR_UNSUPPORTED, "CTU staging does not fit LDS (CTB %d, %d bit, %d CTBs wide)", 1 << c.log2_ctb, c.bit_depth, c.max_ctb_w);
+    return q < 0 ? q : HM_OK;
+  }
+  return hm_launch_recon(dc, n, c.log2_ctb, c.chroma_format, c.bit_depth, c.rare, c.max_ctb_w, c.max_ctb_h, s);
+}
 
 } // namespace
 
@@ -173,15 +188,16 @@ static int batch_prepare(hm_batch* b, size_t* blob_bytes_out)
   if (n == 0) return HM_OK;
 
   // classes: pictures of one launch share CTB size, chroma format and sample width
-  std::map<std::tuple<int, int, int, int>, int> cls_index;
+  std::map<std::tuple<int, int, int, int, int>, int> cls_index;
   for (int i = 0; i < n; i++) {
     const hm_pic& h = b->items[i].hdr;
     const int rare = (h.flags & HM_PIC_RARE_SYNTAX) != 0;
-    auto key = std::make_tuple((int)h.log2_ctb, (int)h.chroma_format, (int)h.bit_depth_y, rare);
+    const int split = (h.flags & HM_PIC_SPLIT_CHAINS) != 0;
+    auto key = std::make_tuple((int)h.log2_ctb, (int)h.chroma_format, (int)h.bit_depth_y, rare, split);
     auto f = cls_index.find(key);
     if (f == cls_index.end()) {
       Class c;
-      c.log2_ctb = h.log2_ctb; c.chroma_format = h.chroma_format; c.bit_depth = h.bit_depth_y; c.rare = rare;
+      c.log2_ctb = h.log2_ctb; c.chroma_format = h.chroma_format; c.bit_depth = h.bit_depth_y; c.rare = rare; c.split = split;
       f = cls_index.emplace(key, (int)b->classes.size()).first;
       b->classes.push_back(c);
     }
@@ -345,7 +361,7 @@ int hm_batch_execute(hm_batch* b, int stages, void* stream)
     const hm_dev_pic* dc = d + c.desc_offset;
     const int n = (int)c.items.size();
     mark();
-    int rc = hm_launch_recon(dc, n, c.log2_ctb, c.chroma_format, c.bit_depth, c.rare, c.max_ctb_w, c.max_ctb_h, s);
+    int rc = launch_recon(dc, n, c, s);
     if (rc) return rc;
     mark();
     if (stages & 1) {
@@ -403,7 +419,7 @@ int hm_batch_upload_execute(hm_batch* b, int stages, int chunks, void* copy_stre
     if ((e = hipStreamWaitEvent(s, b->chunk_events[k], 0)) != hipSuccess) return hm_check_hip(e, "hipStreamWaitEvent");
     const hm_dev_pic* dc = d + i0;
     const int m = i1 - i0;
-    if ((rc = hm_launch_recon(dc, m, c.log2_ctb, c.chroma_format, c.bit_depth, c.rare, c.max_ctb_w, c.max_ctb_h, s))) return rc;
+    if ((rc = launch_recon(dc, m, c, s))) return rc;
     if ((stages & 1) && (rc = hm_launch_deblock(dc, m, c.max_w4, c.max_h4, c.chroma_format, c.bit_depth, c.rare, s))) return rc;
     if ((rc = hm_launch_sao_paste(dc, m, c.max_w, c.max_h, c.bit_depth, (stages & 2) ? 1 : 0, c.rare, s))) return rc;
   }

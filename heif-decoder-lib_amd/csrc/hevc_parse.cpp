@@ -197,13 +197,36 @@ struct Decoder {
     const int N = s.ctb_w * s.ctb_h;
     if (!picture_done) throw ParseError(HM_ERR_BITSTREAM, "picture incomplete: missing slice segments");
 
+    // Record order (hm_stream.h): pictures without rare syntax get their luma and chroma records in separate lists,
+    // row by row (the four-rows-per-wave kernel walks the two chains independently); HM_STREAM_INTERLEAVED=1 (read
+    // once; A/B measurements of the one-row-per-wave kernel) keeps the decode order for every picture.
+    static const bool force_interleaved = [] { const char* e = std::getenv("HM_STREAM_INTERLEAVED"); return e && e[0] == '1'; }();
+    const bool rare = s.scaling_list_enabled || (s.pcm_enabled && s.pcm_loop_filter_disabled) || p.transquant_bypass_enabled ||
+                      pic.uses_pcm || pic.uses_tq_bypass || s.chroma_format_idc == 3; // == HM_PIC_RARE_SYNTAX of the flags below
+    const bool split = !rare && !force_interleaved;
     size_t n_tus = 0;
     for (int i = 0; i < N; i++) {
       if (!(pic.ctbs[i].flags & HM_CTB_CODED)) throw ParseError(HM_ERR_BITSTREAM, "CTB not coded");
-      pic.ctbs[i].tu_first = (uint32_t)n_tus;
       if (pic.ctb_tus[i].size() > 65535) throw ParseError(HM_ERR_INTERNAL, "too many TUs in a CTB");
-      pic.ctbs[i].tu_count = (uint16_t)pic.ctb_tus[i].size();
       n_tus += pic.ctb_tus[i].size();
+    }
+    {
+      auto is_luma = [](const hm_tu& t) { return ((t.info >> HM_TU_CIDX_SHIFT) & 3) == 0; };
+      size_t at = 0;
+      for (int cy = 0; cy < s.ctb_h; cy++) {
+        for (int pass = 0; pass < (split ? 2 : 1); pass++)
+          for (int cx = 0; cx < s.ctb_w; cx++) {
+            const int i = cx + cy * s.ctb_w;
+            size_t cnt = pic.ctb_tus[i].size();
+            if (split) {
+              cnt = 0;
+              for (const hm_tu& t : pic.ctb_tus[i]) cnt += is_luma(t) == (pass == 0);
+            }
+            if (pass == 0) { pic.ctbs[i].tu_first = (uint32_t)at; pic.ctbs[i].tu_count = (uint16_t)cnt; pic.ctbs[i].tu_first_c = 0; pic.ctbs[i].tu_count_c = 0; }
+            else { pic.ctbs[i].tu_first_c = (uint32_t)at; pic.ctbs[i].tu_count_c = (uint16_t)cnt; }
+            at += cnt;
+          }
+      }
     }
     // SAO neighbour masks (sao.cc:323-424 of the reference).  The reference's fast path (all neighbours inside the
     // picture usable, slice flags ignored) is taken per CTB: pps_loop_filter_across_slices && !tiles && the CTB holds no
@@ -297,6 +320,8 @@ struct Decoder {
     if ((s.pcm_enabled && s.pcm_loop_filter_disabled) || p.transquant_bypass_enabled) flags |= HM_PIC_PCMF;
     if (s.chroma_format_idc == 3) flags |= HM_PIC_444;
     if (pic.uses_pcm || pic.uses_tq_bypass) flags |= HM_PIC_LOSSLESS_CUS;
+    if (split) flags |= HM_PIC_SPLIT_CHAINS;
+    if (rare != ((flags & HM_PIC_RARE_SYNTAX) != 0)) throw ParseError(HM_ERR_INTERNAL, "rare-syntax classification");
     h.flags = flags;
     h.colour_primaries = (uint8_t)s.colour_primaries;
     h.transfer_characteristics = (uint8_t)s.transfer_characteristics;
@@ -318,11 +343,18 @@ struct Decoder {
     std::memcpy(blob.data(), &h, sizeof(h));
     std::memcpy(blob.data() + off_slices, pic.slices.data(), pic.slices.size() * sizeof(hm_slice));
     std::memcpy(blob.data() + off_ctbs, pic.ctbs.data(), (size_t)N * sizeof(hm_ctb));
-    uint8_t* tp = blob.data() + off_tus;
+    hm_tu* const tp = reinterpret_cast<hm_tu*>(blob.data() + off_tus);
     for (int i = 0; i < N; i++) {
-      const size_t b = pic.ctb_tus[i].size() * sizeof(hm_tu);
-      if (b) std::memcpy(tp, pic.ctb_tus[i].data(), b);
-      tp += b;
+      if (!split) {
+        if (!pic.ctb_tus[i].empty()) std::memcpy(tp + pic.ctbs[i].tu_first, pic.ctb_tus[i].data(), pic.ctb_tus[i].size() * sizeof(hm_tu));
+        continue;
+      }
+      hm_tu* dl = tp + pic.ctbs[i].tu_first;
+      hm_tu* dc = tp + pic.ctbs[i].tu_first_c;
+      for (const hm_tu& t : pic.ctb_tus[i]) {
+        if (((t.info >> HM_TU_CIDX_SHIFT) & 3) == 0) *dl++ = t;
+        else *dc++ = t;
+      }
     }
     if (!pic.coeffs.empty()) std::memcpy(blob.data() + off_coeffs, pic.coeffs.data(), pic.coeffs.size() * sizeof(hm_coeff));
     *out_size = total;
@@ -334,7 +366,7 @@ struct Decoder {
 } // namespace hm
 
 static_assert(sizeof(hm_tu) == 16, "hm_tu layout");
-static_assert(sizeof(hm_ctb) == 36, "hm_ctb layout");
+static_assert(sizeof(hm_ctb) == 4 * HM_CTB_DWORDS, "hm_ctb layout");
 static_assert(sizeof(hm_coeff) == 4, "hm_coeff layout");
 static_assert(sizeof(hm_slice) == 12, "hm_slice layout");
 static_assert(sizeof(hm_sao) == 8, "hm_sao layout");

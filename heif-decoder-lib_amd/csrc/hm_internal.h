@@ -45,6 +45,9 @@ struct hm_dev_pic;
 int hm_batch_add_trusted(hm_batch* b, const uint8_t* blob, size_t size, const hm_tile_dest* dest); // no structural validation
 int hm_launch_recon(const struct hm_dev_pic* d_pics, int n_pics, int log2_ctb, int chroma_format, int bit_depth, int rare_syntax,
                     int max_ctb_w, int max_ctb_h, hipStream_t s);
+// recon_quad.hip: four CTU rows per wave; 1 = launched, 0 = not applicable (use hm_launch_recon), < 0 = error
+int hm_launch_recon_quad(const struct hm_dev_pic* d_pics, int n_pics, int log2_ctb, int chroma_format, int bit_depth, int rare_syntax,
+                         int max_ctb_w, int max_ctb_h, hipStream_t s);
 int hm_launch_deblock(const struct hm_dev_pic* d_pics, int n_pics, int max_w4, int max_h4, int chroma_format,
                       int bit_depth, int rare_syntax, hipStream_t s);
 int hm_launch_sao_paste(const struct hm_dev_pic* d_pics, int n_pics, int max_w, int max_h, int bit_depth, int apply_sao,

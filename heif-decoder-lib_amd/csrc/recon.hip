@@ -53,7 +53,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
   const hm_dev_pic dp = pics[blockIdx.x];
   const uint8_t* blob = dp.blob;
   const GLOBAL_AS hm_pic* H = gptr<hm_pic>(blob);
-  const GLOBAL_AS uint32_t* ctbq = gptr<uint32_t>(blob + H->off_ctbs);   // 9 dwords per hm_ctb
+  const GLOBAL_AS uint32_t* ctbq = gptr<uint32_t>(blob + H->off_ctbs);   // HM_CTB_DWORDS dwords per hm_ctb
   const GLOBAL_AS uint32_t* tus = gptr<uint32_t>(blob + H->off_tus);     // 4 dwords per hm_tu
   const GLOBAL_AS uint32_t* coeffs = gptr<uint32_t>(blob + H->off_coeffs);
   const uint32_t n_tus = H->n_tus;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
     // line written by this row / line of the row above (any legal line for row 0: nothing is read from it)
     Pix* const lw = reinterpret_cast<Pix*>(lines + (size_t)(row % n_lines) * line_bytes) + 4;
     const Pix* const lr = reinterpret_cast<const Pix*>(lines + (size_t)((row + n_lines - 1) % n_lines) * line_bytes) + 4;
-    const GLOBAL_AS uint32_t* const crow = ctbq + 9 * (size_t)row * ctb_w;
+    const GLOBAL_AS uint32_t* const crow = ctbq + HM_CTB_DWORDS * (size_t)row * ctb_w;
     // CTB descriptors are fetched one CTU ahead, block records one block ahead.  The records of a CTB row
     // are contiguous (hm_stream.h: CTBs store their records in raster order), so the prefetch simply runs
     // on across CTU borders.
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
     }
     for (int cx = 0; cx < ctb_w; cx++) {
       const int tu_count = rfl((int)(c1 & 0xFFFF)), cb_flags = rfl((int)(c2 & 0xFF));
-      if (cx + 1 < ctb_w) { const GLOBAL_AS uint32_t* q = crow + 9 * (size_t)(cx + 1); c0 = q[0]; c1 = q[1]; c2 = q[2]; }
+      if (cx + 1 < ctb_w) { const GLOBAL_AS uint32_t* q = crow + HM_CTB_DWORDS * (size_t)(cx + 1); c0 = q[0]; c1 = q[1]; c2 = q[2]; }
       // ---- wait for the above-right CTU (wavefront dependency) ----
       if (row > 0) {
         const int need = (cx + 2 < ctb_w) ? cx + 2 : ctb_w;
@@ -420,8 +420,8 @@ extern "C" int hm_launch_recon(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   // pictures queued, fewer waves per picture and more pictures per CU give more throughput.
   // Measured on MI355X (profiles/r01_recon_wave_sweep.txt): <= 768 tiles in flight -> 8 waves per
   // picture is fastest (latency), beyond that 4 waves per picture wins (+20 %).
-  const char* env_nw = getenv("HM_RECON_WAVES");
-  const int want = env_nw ? atoi(env_nw) : (n_pics > 1024 ? 4 : 8);
+  static const int env_nw = [] { const char* e = getenv("HM_RECON_WAVES"); return e ? atoi(e) : 0; }(); // (tuning aid, read once)
+  const int want = env_nw ? env_nw : (n_pics > 1024 ? 4 : 8);
   if (want >= 1 && want <= 8 && nw > want) nw = want;
   auto total = [&](int w) { return fixed + (w > 2 ? w : 2) * line + w * pw; };
   // prefer <= 64 KiB per workgroup (several pictures per CU); wide pictures may take the whole 160 KiB

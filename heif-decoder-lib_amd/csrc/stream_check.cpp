@@ -31,29 +31,41 @@ static const char* validate_stream(const uint8_t* blob, size_t size)
   const hm_tu* tus = reinterpret_cast<const hm_tu*>(blob + h.off_tus);
   const hm_coeff* cf = reinterpret_cast<const hm_coeff*>(blob + h.off_coeffs);
   const int sw = h.chroma_format == 3 ? 1 : 2, sh = h.chroma_format == 1 ? 2 : 1;
+  const bool split = (h.flags & HM_PIC_SPLIT_CHAINS) != 0;
+  if (split && (h.flags & HM_PIC_RARE_SYNTAX)) return "record order of a rare-syntax picture";
+  auto check_record = [&](const hm_tu& u, int want_luma) -> const char* { // want_luma: 1 luma list, 0 chroma list, -1 either
+    const int log2 = u.info & HM_TU_LOG2_MASK, cidx = (u.info >> HM_TU_CIDX_SHIFT) & 3, nT = 1 << log2;
+    if (log2 < 2 || log2 > 5 || cidx > 2 || (cidx && h.chroma_format == 0)) return "block size / component";
+    if (want_luma >= 0 && (cidx == 0) != (want_luma == 1)) return "component of a record in the luma / chroma list";
+    const int bw = cidx ? ctb / sw : ctb, bh = cidx ? ctb / sh : ctb;
+    if (u.x + nT > bw || u.y + nT > bh || ((u.x | u.y) & 3)) return "block position";
+    if ((u.pred_mode & HM_TU_MODE_MASK) > 34) return "prediction mode";
+    if (split && (u.pred_mode & ~HM_TU_MODE_MASK)) return "PCM / bypass record in a picture without rare syntax";
+    if (u.avail_left > nT || u.avail_top > nT || u.avail_bottom_left > nT || u.avail_top_right > nT) return "neighbour availability";
+    if ((uint64_t)u.coeff_first + u.n_coeff > h.n_coeffs || u.n_coeff > nT * nT) return "level range of a record";
+    if ((u.pred_mode & HM_TU_MODE_PCM) && u.n_coeff != nT * nT) return "PCM sample count";
+    for (uint32_t q = 0; q < u.n_coeff; q++)
+      if (cf[u.coeff_first + q].pos >= nT * nT) return "level position";
+    return nullptr;
+  };
   uint64_t next = 0;
-  for (uint32_t i = 0; i < h.n_ctbs; i++) {
-    const hm_ctb& c = ctbs[i];
-    if (c.slice_idx >= h.n_slices) return "slice index";
-    if (c.tu_first != next) return "records of the CTBs are not contiguous in raster order";
-    next += c.tu_count;
-    if (next > h.n_tus) return "record range of a CTB";
-    for (int k = 0; k < 3; k++)
-      if (c.sao[k].type > 2 || c.sao[k].eo_class > 3 || c.sao[k].band_position > 31) return "SAO parameters";
-    for (uint32_t t = c.tu_first; t < next; t++) {
-      const hm_tu& u = tus[t];
-      const int log2 = u.info & HM_TU_LOG2_MASK, cidx = (u.info >> HM_TU_CIDX_SHIFT) & 3, nT = 1 << log2;
-      if (log2 < 2 || log2 > 5 || cidx > 2 || (cidx && h.chroma_format == 0)) return "block size / component";
-      const int bw = cidx ? ctb / sw : ctb, bh = cidx ? ctb / sh : ctb;
-      if (u.x + nT > bw || u.y + nT > bh || ((u.x | u.y) & 3)) return "block position";
-      if ((u.pred_mode & HM_TU_MODE_MASK) > 34) return "prediction mode";
-      if (u.avail_left > nT || u.avail_top > nT || u.avail_bottom_left > nT || u.avail_top_right > nT) return "neighbour availability";
-      if ((uint64_t)u.coeff_first + u.n_coeff > h.n_coeffs || u.n_coeff > nT * nT) return "level range of a record";
-      if ((u.pred_mode & HM_TU_MODE_PCM) && u.n_coeff != nT * nT) return "PCM sample count";
-      for (uint32_t q = 0; q < u.n_coeff; q++)
-        if (cf[u.coeff_first + q].pos >= nT * nT) return "level position";
-    }
-  }
+  for (uint32_t cy = 0; cy < h.ctb_h; cy++)
+    for (int pass = 0; pass < (split ? 2 : 1); pass++)
+      for (uint32_t cx = 0; cx < h.ctb_w; cx++) {
+        const hm_ctb& c = ctbs[cx + cy * h.ctb_w];
+        if (pass == 0) {
+          if (c.slice_idx >= h.n_slices) return "slice index";
+          for (int k = 0; k < 3; k++)
+            if (c.sao[k].type > 2 || c.sao[k].eo_class > 3 || c.sao[k].band_position > 31) return "SAO parameters";
+          if (!split && c.tu_count_c) return "chroma list in a picture with interleaved records";
+        }
+        const uint64_t first = pass == 0 ? c.tu_first : c.tu_first_c, count = pass == 0 ? c.tu_count : c.tu_count_c;
+        if (first != next) return "records of the CTBs are not contiguous in (row, list, CTB) order";
+        next += count;
+        if (next > h.n_tus) return "record range of a CTB";
+        for (uint64_t t = first; t < next; t++)
+          if (const char* what = check_record(tus[t], split ? (pass == 0 ? 1 : 0) : -1)) return what;
+      }
   if (next != h.n_tus) return "record count";
   return nullptr;
 }

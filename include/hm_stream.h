@@ -11,8 +11,17 @@
  *     hm_pic            header
  *     hm_slice[n_slices]
  *     hm_ctb[n_ctbs]    raster order
- *     hm_tu[n_tus]      decode order; the records of one CTB are contiguous
+ *     hm_tu[n_tus]      see "record order" below
  *     hm_coeff[n_coeffs]
+ *
+ * Record order.  Intra prediction chains the blocks of one colour plane; luma and chroma never read each other (the
+ * supported profiles have no cross-component prediction), so a picture holds two independent block chains per CTB row.
+ *   HM_PIC_SPLIT_CHAINS set (every picture without rare syntax): for CTB row 0, 1, ...: the luma records of the row's
+ *     CTBs in raster order, each CTB's in decode order, then the chroma records (Cb and Cr, decode order) of the row's
+ *     CTBs likewise.  hm_ctb.tu_first / tu_count delimit the CTB's luma records, tu_first_c / tu_count_c its chroma
+ *     records; within a row both lists are contiguous from CTB to CTB, so a kernel walks each with a running index.
+ *   HM_PIC_SPLIT_CHAINS clear (pictures with HM_PIC_RARE_SYNTAX): all records of a CTB in decode order in
+ *     [tu_first, tu_first + tu_count), CTBs in raster order; tu_count_c = 0.
  */
 #ifndef HM_STREAM_H
 #define HM_STREAM_H
@@ -23,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HM_STREAM_MAGIC 0x324d5348u /* "HSM2" */
+#define HM_STREAM_MAGIC 0x334d5348u /* "HSM3" */
 
 /* hm_pic.flags */
 #define HM_PIC_STRONG_INTRA_SMOOTHING 0x0001u /* sps.strong_intra_smoothing_enable_flag        */
@@ -40,6 +49,7 @@ extern "C" {
 #define HM_PIC_LOSSLESS_CUS           0x0400u /* at least one PCM or cu_transquant_bypass coding unit            */
 #define HM_PIC_444                    0x0800u /* chroma_format_idc 3 (chroma_format says the same; the flag puts such
                                                  pictures into the rare-syntax classes)                        */
+#define HM_PIC_SPLIT_CHAINS           0x1000u /* luma and chroma records in separate lists (see "record order")   */
 #define HM_PIC_RARE_SYNTAX            (HM_PIC_SCALING_LIST | HM_PIC_PCMF | HM_PIC_LOSSLESS_CUS | HM_PIC_444) /* pictures that need the kernel
                                                  variant of the reconstruction with the rare paths             */
 
@@ -105,8 +115,8 @@ typedef struct hm_sao {
 } hm_sao;
 
 typedef struct hm_ctb {
-  uint32_t tu_first;     /* index of the first hm_tu of this CTB; CTBs store their records in raster
-                            order, so tu_first of CTB i+1 == tu_first + tu_count of CTB i            */
+  uint32_t tu_first;     /* index of the first (luma) hm_tu of this CTB; within a CTB row tu_first of CTB i+1
+                            == tu_first + tu_count of CTB i (see "record order")                      */
   uint16_t tu_count;
   uint16_t slice_idx;    /* index into hm_slice[]                                             */
   uint8_t  flags;        /* HM_CTB_*                                                          */
@@ -120,7 +130,11 @@ typedef struct hm_ctb {
                             only ones the reference tests, sao.cc:366) may use a neighbour sample inside
                             their own CTB; 0 when the mis-addressed slice of Q13 forbids it (luma: always 1) */
   hm_sao   sao[3];
-} hm_ctb; /* 36 bytes */
+  uint32_t tu_first_c;   /* HM_PIC_SPLIT_CHAINS: the CTB's chroma records (contiguous along the CTB row)  */
+  uint16_t tu_count_c;
+  uint16_t reserved;
+} hm_ctb; /* 44 bytes = HM_CTB_DWORDS dwords */
+#define HM_CTB_DWORDS 11
 
 /* hm_tu.info */
 #define HM_TU_LOG2_MASK 0x07u  /* log2 block size 2..5 (component samples)                    */

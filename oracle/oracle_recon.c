@@ -287,8 +287,9 @@ static void reconstruct(pic_t* P)
     const hm_ctb* c = &P->ctbs[ci];
     const int cx = (int)(ci % H->ctb_w), cy = (int)(ci / H->ctb_w);
     const hm_slice* sl = &P->slices[c->slice_idx];
-    for (unsigned k = 0; k < c->tu_count; k++) {
-      const hm_tu* t = &P->tus[c->tu_first + k];
+    /* hm_stream.h "record order": the CTB's luma list, then its chroma list (empty when the records are interleaved) */
+    for (unsigned k = 0; k < (unsigned)c->tu_count + c->tu_count_c; k++) {
+      const hm_tu* t = k < c->tu_count ? &P->tus[c->tu_first + k] : &P->tus[c->tu_first_c + (k - c->tu_count)];
       const int log2 = t->info & HM_TU_LOG2_MASK, nT = 1 << log2;
       const int cIdx = (t->info >> HM_TU_CIDX_SHIFT) & 3;
       const int bd = cIdx ? H->bit_depth_c : H->bit_depth_y;

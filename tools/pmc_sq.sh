@@ -11,7 +11,7 @@ g3="SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS
 i=0
 for g in "$g1" "$g2" "$g3"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $g -d $out/g$i --output-format csv -- python3 bench.py --no-parity --no-e2e --cpu-seconds 0 "$@" > $out/g$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $g -d $out/g$i --output-format csv -- python3 bench.py --no-parity --quick "$@" > $out/g$i.log 2>&1
   echo "group $i rc=$?"
 done
 python3 tools/pmc_summary.py $out

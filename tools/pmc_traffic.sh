@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 out=$PWD/gpurun_out/pmc_traffic_$tag
 mkdir -p $out
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c -d $out/$c --output-format csv -- python3 bench.py --no-parity --no-e2e --cpu-seconds 0 --steps 3 --warmup 1 --images $images > $out/$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c -d $out/$c --output-format csv -- python3 bench.py --no-parity --quick --steps 3 --warmup 1 --images $images > $out/$c.log 2>&1
   echo "$c rc=$?"
 done
 python3 - "$out" "$images" <<'PY'
