@@ -311,15 +311,22 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
   for (;;) {
     tag++;
     // ---- A: start the next CTU of every group whose dependency is met (the row above two CTUs ahead) ----
+    bool started = false;
     if (st == ST_START) {
       const int need = cx + 2 < ctb_w ? cx + 2 : ctb_w;
       const bool ok = row == 0 || my_progress[row > 0 ? row - 1 : 0] >= need;
       if (ok) {
         kleft = (int)(c1 & 0xFFFF);
         cb_flags = (int)(c2 & 0xFF);
-        if (cx + 1 < ctb_w) header(row, cx + 1);
         st = ST_RUN;
+        started = true;
       }
+    }
+    if (__ballot(started)) { // (wave-uniform: the loads below are not merged with anything, so nobody waits for them here)
+      // every lane asks for the header its chain needs next: a group inside CTU cx the one of cx + 1 (the last CTU of a
+      // row: its own again), a waiting group the one of the CTU it waits to start
+      const int hx = st == ST_RUN ? (cx + 1 < ctb_w ? cx + 1 : cx) : cx;
+      header(row < ctb_h ? row : ctb_h - 1, hx);
     }
     if (__ballot(st != ST_DONE) == 0) break;
     const bool running = st == ST_RUN && kleft > 0;
@@ -335,7 +342,11 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
     const Pix* const lr = line_of(kind, (row + NR - 1) & (NR - 1));
 
     // ---- C: interior 4x4 blocks of all groups side by side, one sample per lane ----
+#if defined(HM_Q_PROBE) && (HM_Q_PROBE & 1)
+    if (false) {
+#else
     if (quad) {
+#endif
       const int x0 = (int)(n0 & 0xFF), y0 = (int)((n0 >> 8) & 0xFF);
       const int mode = (int)(n0 >> 24);
       const int c = (info >> HM_TU_CIDX_SHIFT) & 3;
@@ -432,7 +443,11 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
     WAVE_SYNC();
 
     // ---- D: every other block, wave-wide, one group after the other ----
+#if defined(HM_Q_PROBE) && (HM_Q_PROBE & 2)
+    for (unsigned long long todo = 0; todo;) {
+#else
     for (unsigned long long todo = s_big; todo;) {
+#endif
       const int bg = rfl((int)(__builtin_ctzll(todo) >> 4));
       todo &= ~(0xFFFFull << (bg * 16));
       const int src = bg * 16;
