@@ -78,6 +78,8 @@ struct heif_image {
   bool has_nclx = false;
   heif_color_profile_nclx nclx{};
   std::vector<std::pair<heif_error_code, heif_suberror_code>> warnings; // pixelimage.h: m_warnings
+  uint32_t icc_type = 0;       // raw colour profile ('prof' / 'rICC'), copied from the file
+  std::vector<uint8_t> icc;
 };
 
 namespace {
@@ -290,6 +292,10 @@ struct heif_error heif_decode_image(const struct heif_image_handle* in, struct h
     img->nclx.color_primaries = dec.primaries; img->nclx.transfer_characteristics = dec.transfer;
     img->nclx.matrix_coefficients = dec.matrix; img->nclx.full_range_flag = (uint8_t)dec.full_range;
   }
+  { // the item's ICC profile travels with the decoded image, converted or not (context.cc:1849-1852, colorconversion.cc:456)
+    uint32_t t = 0; const uint8_t* p = nullptr; size_t n = 0;
+    if (hm_file_item_icc(in->ctx->file, in->id, 0, &t, &p, &n) == HM_OK && t) { img->icc_type = t; img->icc.assign(p, p + n); }
+  }
   if (dec.warnings & HM_WARN_UNKNOWN_PRIMARIES) img->warnings.emplace_back(heif_error_Invalid_input, heif_suberror_Unknown_NCLX_color_primaries);
   if (dec.warnings & HM_WARN_UNKNOWN_TRANSFER) img->warnings.emplace_back(heif_error_Invalid_input, heif_suberror_Unknown_NCLX_transfer_characteristics);
   if (dec.warnings & HM_WARN_UNKNOWN_MATRIX) img->warnings.emplace_back(heif_error_Invalid_input, heif_suberror_Unknown_NCLX_matrix_coefficients);
@@ -385,6 +391,41 @@ struct heif_error heif_image_get_nclx_color_profile(const struct heif_image* i, 
   *out = heif_nclx_color_profile_alloc();
   if (!*out) return err(heif_error_Memory_allocation_error, heif_suberror_Unspecified, "out of memory");
   **out = i->nclx;
+  return ok();
+}
+
+// ---- colour profile type / raw profile (heif.cc:1768-1793, 1931-2003): an ICC profile wins over an nclx one ----
+enum heif_color_profile_type heif_image_handle_get_color_profile_type(const struct heif_image_handle* h)
+{
+  if (!h) return heif_color_profile_type_not_present;
+  uint32_t t = 0; const uint8_t* p = nullptr; size_t n = 0;
+  if (hm_file_item_icc(h->ctx->file, h->id, 1, &t, &p, &n) == HM_OK && t) return (heif_color_profile_type)t;
+  return h->info.has_nclx ? heif_color_profile_type_nclx : heif_color_profile_type_not_present;
+}
+size_t heif_image_handle_get_raw_color_profile_size(const struct heif_image_handle* h)
+{
+  uint32_t t = 0; const uint8_t* p = nullptr; size_t n = 0;
+  return (h && hm_file_item_icc(h->ctx->file, h->id, 1, &t, &p, &n) == HM_OK && t) ? n : 0;
+}
+struct heif_error heif_image_handle_get_raw_color_profile(const struct heif_image_handle* h, void* out)
+{
+  if (!h || !out) return err(heif_error_Usage_error, heif_suberror_Null_pointer_argument, "NULL passed");
+  uint32_t t = 0; const uint8_t* p = nullptr; size_t n = 0;
+  if (hm_file_item_icc(h->ctx->file, h->id, 1, &t, &p, &n) != HM_OK || !t) return err(heif_error_Color_profile_does_not_exist, heif_suberror_Unspecified, "no raw colour profile");
+  std::memcpy(out, p, n);
+  return ok();
+}
+enum heif_color_profile_type heif_image_get_color_profile_type(const struct heif_image* i)
+{
+  if (!i) return heif_color_profile_type_not_present;
+  if (i->icc_type) return (heif_color_profile_type)i->icc_type;
+  return i->has_nclx ? heif_color_profile_type_nclx : heif_color_profile_type_not_present;
+}
+size_t heif_image_get_raw_color_profile_size(const struct heif_image* i) { return i && i->icc_type ? i->icc.size() : 0; }
+struct heif_error heif_image_get_raw_color_profile(const struct heif_image* i, void* out)
+{
+  if (!i || !out) return err(heif_error_Usage_error, heif_suberror_Null_pointer_argument, "NULL passed");
+  if (i->icc_type) std::memcpy(out, i->icc.data(), i->icc.size()); // (no profile: Ok and nothing written, heif.cc:1986-2003)
   return ok();
 }
 

@@ -1,21 +1,24 @@
-// filters.hip — in-loop filters for gfx950: deblocking (two passes) and SAO fused with the grid
-// tile paste.
+// filters.hip — in-loop filters for gfx950: deblocking (one pass) and SAO fused with the grid tile paste.
 //
 // Replaces:
 //   deblocking   deblock.cc:394-404,709-792,1608-1772 + fallback-postfilter.h:32-183
 //   SAO          sao.cc:261-488,552-625 + fallback-postfilter.h:218-315
 //   tile paste   libheif/context.cc:2457-2535 (incl. the limited->full range rescale quirk)
 //
-// Both are embarrassingly parallel byte work, HBM/L2 bound, no MFMA:
-//   * deblocking: one lane per 8-sample edge segment (the unit libde265 filters with one call);
-//     all vertical edges of all pictures in one launch, then all horizontal ones - segments of one
-//     pass touch disjoint samples, so the pass runs in place.  A lane loads its 8x8 window with
-//     eight 8-byte (16-byte for >8 bit) row loads - adjacent lanes cover adjacent windows, so a
-//     wave's row loads are contiguous - filters in registers and stores the window back.
-//   * SAO: one lane per 4 output samples; reads the deblocked plane (plus the one-sample halo
-//     the edge classes need) and writes the final samples straight into the destination image
-//     (the grid canvas at the tile's origin, cropped, optionally range-rescaled), so the decoded
-//     tile never makes a separate trip through HBM for the paste.
+// Both are byte work with O(1) operations per byte, HBM / L2 bound, no MFMA:
+//   * k_deblock: both edge directions in ONE pass.  A lane owns an 8x8 window whose corner is a grid crossing shifted
+//     by 4 samples: it holds the vertical edge for its 8 rows and the horizontal edge for its 8 columns, and no other
+//     edge touches what those two read, so windows are independent - each sample is read once and written once, and
+//     the reference's "all vertical edges, then all horizontal ones" order (deblock.cc:1921-1959) holds inside the
+//     window.  The window stays packed as loaded (16 registers for 8-bit samples); edge flags, PCM / bypass flags and
+//     QpY come from the 16-bit block map k_recon wrote; per-slice beta / tc offsets from the CTB's slice.
+//   * k_sao_paste: one wave per 128x8-sample tile, one lane per 8 samples of two rows; the four source rows, their side
+//     samples and both CTB records are fetched before anything is decided; edge / band offsets on sample pairs
+//     (v_pk_*), the offset table is one v_perm_b32 byte lookup.  The result goes straight into the destination image
+//     (the grid canvas at the tile's origin, cropped, optionally range-rescaled): the decoded tile never makes a
+//     separate trip through HBM for the paste.  Pictures with several slices / tiles whose filters stop at the
+//     borders use the per-CTB neighbour masks of the command stream (hm_ctb.sao_nb_mask*, incl. the reference's
+//     chroma quirk Q13); the rare groups that need a per-sample test are redone by the generic path.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>

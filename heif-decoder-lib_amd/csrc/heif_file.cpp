@@ -256,6 +256,10 @@ bool HeifFile::parse_iprp(const uint8_t* p, size_t n, HeifError& err)
             ip.colr.matrix = (int)d.u(2);
             ip.colr.full_range = (int)(d.u(1) >> 7);
           }
+          else if (ct == "prof" || ct == "rICC") { // the rest of the box is the profile
+            ip.icc_type = ((uint32_t)(uint8_t)ct[0] << 24) | ((uint32_t)(uint8_t)ct[1] << 16) | ((uint32_t)(uint8_t)ct[2] << 8) | (uint8_t)ct[3];
+            ip.icc.assign(pb.body + d.pos, pb.body + pb.size);
+          }
         }
         else if (pb.type == "irot") {
           ip.has_irot = true;

@@ -43,6 +43,10 @@ struct ItemProps {
   HvcC hvcc;
   int ispe_width = 0, ispe_height = 0;
   NclxProfile colr;
+  // raw colour profile of a 'colr' box of type 'prof' / 'rICC' (ICC data, passed through untouched: box.cc Box_colr,
+  // nclx.h color_profile_raw); an item may carry both an nclx and an ICC profile
+  uint32_t icc_type = 0;     // fourcc as a big-endian number, 0 = none
+  std::vector<uint8_t> icc;
   bool has_irot = false, has_imir = false, has_clap = false;
   int irot_angle = 0;
   std::vector<Transform> transforms; // irot / imir / clap in association order

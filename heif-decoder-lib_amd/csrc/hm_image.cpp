@@ -227,6 +227,7 @@ int hm_file_image_info(const hm_file* f, uint32_t id, hm_image_info* info)
   info->chroma = first->props.hvcc.chroma_format;
   info->has_transforms = (it->props.has_irot || it->props.has_imir || it->props.has_clap) ? 1 : 0;
   info->has_alpha = f->file.alpha_item_of(id) != 0;
+  info->has_nclx = (it->props.colr.present || (it != first && first->props.colr.present)) ? 1 : 0;
   info->coded_width = info->width; info->coded_height = info->height;
   // the size an image handle reports (context.cc:810-838): every clap sets it to the rounded aperture size,
   // a 90 / 270 degree irot swaps it, in property order
@@ -256,6 +257,26 @@ int hm_file_item_hevc_data(const hm_file* f, uint32_t id, uint8_t** out, size_t*
   std::memcpy(mem, v.data(), v.size());
   *out = mem;
   *out_size = v.size();
+  return HM_OK;
+}
+
+int hm_file_item_icc(const hm_file* f, uint32_t id, int for_handle, uint32_t* type, const uint8_t** data, size_t* size)
+{
+  if (!f || !type || !data || !size) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
+  *type = 0; *data = nullptr; *size = 0;
+  const hm::Item* it = f->file.item(id);
+  if (!it) return hm_fail(HM_ERR_INVALID_ARG, "no item %u", id);
+  const hm::Item* src = it;
+  if (it->type == "grid") {
+    if (!for_handle) return HM_OK; // the grid canvas carries no profile
+    if (!it->props.icc_type) { // inherited from the first tile
+      hm::GridInfo g;
+      hm::HeifError err;
+      if (f->file.grid_info(id, g, err) && !g.tiles.empty()) src = f->file.item(g.tiles[0]);
+      if (!src) return HM_OK;
+    }
+  }
+  if (src->props.icc_type) { *type = src->props.icc_type; *data = src->props.icc.data(); *size = src->props.icc.size(); }
   return HM_OK;
 }
 

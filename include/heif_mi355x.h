@@ -199,6 +199,7 @@ typedef struct hm_image_info {
   int32_t coded_width, coded_height; /* size before the transformative properties (ispe / grid output size);
                                         width / height above are what heif_image_handle_get_width/height report
                                         (context.cc:810-838: clap size, swapped by a 90 / 270 degree irot)       */
+  int32_t has_nclx;            /* the item carries a 'colr' nclx (a grid without one: its first tile's, context.cc:1087)    */
 } hm_image_info;
 
 typedef struct hm_decode_params {
@@ -246,6 +247,12 @@ HM_API int      hm_file_top_level_images(const hm_file* f, uint32_t* ids, int ma
 HM_API int      hm_file_image_info(const hm_file* f, uint32_t id, hm_image_info* info);
 /* the auxiliary image item that is the alpha channel of image `id` (context.cc:885-945), 0 if there is none */
 HM_API uint32_t hm_file_alpha_item(const hm_file* f, uint32_t id);
+/* The raw ('prof' / 'rICC') colour profile that goes with image `id` (passed through untouched; *data points into the
+ * file object and stays valid until hm_file_close).  for_handle != 0: what an image handle reports - the item's own
+ * 'colr', a grid without one inherits its first tile's (context.cc:780-800, 1075-1090); for_handle == 0: what the
+ * decoded image carries - the item's own 'colr' for a coded image, nothing for a grid (context.cc:1844-1852; the
+ * conversion keeps it, colorconversion.cc:456).  *type = the profile's fourcc as a big-endian number, 0 = none. */
+HM_API int      hm_file_item_icc(const hm_file* f, uint32_t id, int for_handle, uint32_t* type, const uint8_t** data, size_t* size);
 /* the byte string a decoder plugin gets through push_data for an hvc1 item (free with hm_free) */
 HM_API int      hm_file_item_hevc_data(const hm_file* f, uint32_t id, uint8_t** out, size_t* out_size);
 /* decode an hvc1 image or a grid item.  Replaces heif_decode_image (heif.cc:1150-1186 ->

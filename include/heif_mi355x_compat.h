@@ -167,6 +167,17 @@ HMC_API struct heif_error heif_nclx_color_profile_set_transfer_characteristics(s
 HMC_API struct heif_error heif_nclx_color_profile_set_matrix_coefficients(struct heif_color_profile_nclx* nclx, uint16_t mc);
 HMC_API struct heif_error heif_image_set_nclx_color_profile(struct heif_image* image, const struct heif_color_profile_nclx* color_profile);
 HMC_API struct heif_error heif_image_get_nclx_color_profile(const struct heif_image* image, struct heif_color_profile_nclx** out_data);
+/* heif.h:1333-1360, heif.cc:1768-1793, 1931-2003: colour profile type and raw (ICC) profile of handles and images */
+enum heif_color_profile_type {
+  heif_color_profile_type_not_present = 0, heif_color_profile_type_nclx = 0x6E636C78 /* 'nclx' */,
+  heif_color_profile_type_rICC = 0x72494343 /* 'rICC' */, heif_color_profile_type_prof = 0x70726F66 /* 'prof' */
+};
+HMC_API enum heif_color_profile_type heif_image_handle_get_color_profile_type(const struct heif_image_handle* handle);
+HMC_API size_t heif_image_handle_get_raw_color_profile_size(const struct heif_image_handle* handle);
+HMC_API struct heif_error heif_image_handle_get_raw_color_profile(const struct heif_image_handle* handle, void* out_data);
+HMC_API enum heif_color_profile_type heif_image_get_color_profile_type(const struct heif_image* image);
+HMC_API size_t heif_image_get_raw_color_profile_size(const struct heif_image* image);
+HMC_API struct heif_error heif_image_get_raw_color_profile(const struct heif_image* image, void* out_data);
 /* heif.h:1700-1712 / heif.cc:1223-1245: warnings of non-strict decoding (unknown VUI colour codes) */
 HMC_API int heif_image_get_decoding_warnings(struct heif_image* image, int first_warning_idx, struct heif_error* out_warnings, int max_output_buffer_entries);
 HMC_API void heif_image_add_decoding_warning(struct heif_image* image, struct heif_error err);

@@ -13,7 +13,7 @@ SURVEY_FNV_INIT = 1469598103934665603  # the survey's harness used this (truncat
 
 
 class ImageInfo(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in "width height bit_depth chroma is_grid grid_rows grid_cols tile_width tile_height has_transforms has_alpha coded_width coded_height".split()]
+    _fields_ = [(n, C.c_int32) for n in "width height bit_depth chroma is_grid grid_rows grid_cols tile_width tile_height has_transforms has_alpha coded_width coded_height has_nclx".split()]
 
 
 class DecodeParams(C.Structure):

@@ -104,3 +104,34 @@ def test_coefficients_match_oracle(hm, oracle):
                 assert hm.hm_ycbcr_coefficients(has, m, p, out) == 0
                 exp = oracle.orc_ycbcr_to_rgb_coeffs(has, m, p)
                 assert bytes(out) == bytes(exp.v), (has, m, p)
+
+
+def test_icc_profile_pass_through(hm):
+    """'colr' boxes of type prof / rICC travel untouched: a coded image reports and carries its own, a grid handle inherits
+    its first tile's, a decoded grid canvas carries none (context.cc:780-800, 1075-1090, 1844-1852)."""
+    import ctypes as C
+    import heifwriter
+    import pipeline
+    import synthutil
+    hm.hm_file_item_icc.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+    profile = bytes(range(1, 200)) * 3
+    tiles = [synthutil.picture(70 + i, width=64, height=64) for i in range(2)]
+
+    def icc(f, iid, for_handle):
+        t, p, n = C.c_uint32(), C.POINTER(C.c_uint8)(), C.c_size_t()
+        assert hm.hm_file_item_icc(f.h, iid, for_handle, C.byref(t), C.byref(p), C.byref(n)) == 0
+        return t.value, (C.string_at(p, n.value) if t.value else b"")
+
+    single = pipeline.HeifFile(hm, heifwriter.write_heic(tiles[:1], (64, 64), icc=(b"prof", profile), colr=(1, 13, 6, 1)))
+    assert icc(single, single.primary(), 1) == (0x70726F66, profile) and icc(single, single.primary(), 0) == (0x70726F66, profile)
+    assert single.info(single.primary()).has_nclx == 1
+    single.close()
+    grid = pipeline.HeifFile(hm, heifwriter.write_heic(tiles, (64, 64), grid=(1, 2, 128, 64), icc=(b"rICC", profile)))
+    gid = grid.primary()
+    assert icc(grid, gid, 1) == (0x72494343, profile)  # the handle: inherited from tile 1
+    assert icc(grid, gid, 0) == (0, b"")               # the decoded canvas: none
+    assert icc(grid, 1, 0) == (0x72494343, profile) and grid.info(gid).has_nclx == 0
+    grid.close()
+    plain = pipeline.HeifFile(hm, heifwriter.write_heic(tiles[:1], (64, 64)))
+    assert icc(plain, plain.primary(), 1) == (0, b"")
+    plain.close()

@@ -1,7 +1,7 @@
-"""BASELINE.json configurations 2, 4 and 5 at full size, end to end through the C ABI
-(hm_file_open -> hm_decode_item: box parse, host entropy decode, GPU reconstruction / filters / paste /
-colour, D2H), bit-exact against the CPU flow (oracle restatement).
-Config 3 (1024 images over 8 GPUs) is config 2 sharded by image: bench.py --gpus N + tests/test_shard_gloo.py."""
+"""BASELINE.json configurations 2, 3, 4 and 5 at full size through the C ABI (hm_file_open -> hm_decode_item: box parse,
+host entropy decode, GPU reconstruction / filters / paste / colour, D2H; config 3: hm_batch over many images),
+bit-exact against the CPU flow (oracle restatement / reference decoder).
+Config 3 over 8 GPUs is this batch sharded by image: bench.py --gpus N + tests/test_shard_gloo.py."""
 import numpy as np
 import pytest
 
@@ -68,3 +68,34 @@ def test_config5_16384_grid(hm):
         r, c = divmod(t, 32)
         got = rgb[r * 512:(r + 1) * 512, c * 1536:(c + 1) * 1536]
         assert np.array_equal(got, expect[pick[t]]), f"tile {t} (row {r}, col {c}) differs"
+
+
+def test_config3_batch_of_12mp_grids(pkg, hm):
+    """BASELINE config 3 on one rank: 32 DIFFERENT 12 MP grids (image j: tiles 1200000 + 48 j + i) in ONE hm_batch, one
+    batched colour conversion - EVERY image compared with the CPU flow (the real reference decoder oracle/_ref for the
+    tiles where it is present, else the oracle's executors; paste + colour by the oracle)."""
+    import ctypes as C
+    import bench
+    import orc
+    import torch
+    n_images = 32
+    dev = torch.device("cuda:0")
+    gb = bench.GridBatch(pkg, dev, 8, 6, 512, 4032, 3024)
+    kept = []
+    made = bench.make_streams(pkg.capi, (1200000 + k for k in range(n_images * 48)))
+    for j in range(n_images):
+        tiles = [next(made) for _ in range(48)]
+        gb.add_image([b for _, b in tiles])
+        kept.append(tiles)
+    st = torch.cuda.current_stream().cuda_stream
+    gb.finish(st)
+    gb.step(st)
+    torch.cuda.synchronize()
+    use_ref = orc.have_ref()
+    for j in range(n_images):
+        got = gb.images[j]["rgb"].cpu().numpy()
+        exp = bench.cpu_grid_image([d for d, _ in kept[j]], [b for _, b in kept[j]], 8, 6, 512, 4032, 3024, (gb.ys, gb.cs, gb.os), use_ref)
+        assert np.array_equal(got[:3024, :4032 * 3], exp[:3024, :4032 * 3]), f"image {j} of the batch differs"
+    # image sharding over ranks: the ranks' images are exactly these (bench.py --gpus N decodes images [rank B, rank B + B))
+    sh = pkg.shard
+    assert [list(sh.image_shard(1024, r, 8))[0] for r in range(8)] == [128 * r for r in range(8)]

@@ -40,6 +40,16 @@ def api(pkg):
     a.heif_image_get_colorspace.argtypes = [C.c_void_p]
     a.heif_image_get_chroma_format.argtypes = [C.c_void_p]
     a.heif_image_has_channel.argtypes = [C.c_void_p, C.c_int]
+    a.heif_image_handle_get_color_profile_type.argtypes = [C.c_void_p]
+    a.heif_image_handle_get_raw_color_profile_size.restype = C.c_size_t
+    a.heif_image_handle_get_raw_color_profile_size.argtypes = [C.c_void_p]
+    a.heif_image_handle_get_raw_color_profile.restype = Err
+    a.heif_image_handle_get_raw_color_profile.argtypes = [C.c_void_p, C.c_char_p]
+    a.heif_image_get_color_profile_type.argtypes = [C.c_void_p]
+    a.heif_image_get_raw_color_profile_size.restype = C.c_size_t
+    a.heif_image_get_raw_color_profile_size.argtypes = [C.c_void_p]
+    a.heif_image_get_raw_color_profile.restype = Err
+    a.heif_image_get_raw_color_profile.argtypes = [C.c_void_p, C.c_char_p]
     a.heif_image_handle_release.argtypes = [C.c_void_p]
     a.heif_image_handle_get_width.argtypes = [C.c_void_p]
     a.heif_decode_image.restype = Err
@@ -239,3 +249,29 @@ def test_forced_bilinear_upsampling_option(api, hm):
     assert es == stride.value
     np.testing.assert_array_equal(got[:, :case["w"] * 3], exp[:case["h"], :case["w"] * 3])
     api.heif_image_release(img); api.heif_image_handle_release(h); api.heif_context_free(ctx); api.heif_decoding_options_free(opt)
+
+
+def test_icc_profile_on_handles_and_images(api, hm):
+    """heif_image_handle_get_raw_color_profile / heif_image_get_raw_color_profile (heif.cc:1768-1793, 1931-2003): the
+    item's ICC profile on the handle and on the decoded image (converted or not); a grid handle inherits its tile's, the
+    decoded grid carries none"""
+    import synthutil
+    profile = bytes((7 * i) & 0xFF for i in range(1000))
+    tiles = [synthutil.picture(90 + i, width=64, height=64) for i in range(2)]
+    single = heifwriter.write_heic(tiles[:1], (64, 64), icc=(b"prof", profile))
+    for colorspace, chroma in ((0, 99), (1, 10)):  # native planar, RGB24
+        ctx, h, img, e = _decode(api, single, 0, colorspace, chroma)
+        assert e.code == 0, e.message
+        assert api.heif_image_handle_get_color_profile_type(h) == 0x70726F66 and api.heif_image_handle_get_raw_color_profile_size(h) == len(profile)
+        buf = C.create_string_buffer(len(profile))
+        assert api.heif_image_handle_get_raw_color_profile(h, buf).code == 0 and buf.raw == profile
+        assert api.heif_image_get_color_profile_type(img) == 0x70726F66 and api.heif_image_get_raw_color_profile_size(img) == len(profile)
+        buf2 = C.create_string_buffer(len(profile))
+        assert api.heif_image_get_raw_color_profile(img, buf2).code == 0 and buf2.raw == profile
+        api.heif_image_release(img); api.heif_image_handle_release(h); api.heif_context_free(ctx)
+    grid = heifwriter.write_heic(tiles, (64, 64), grid=(1, 2, 128, 64), icc=(b"rICC", profile))
+    ctx, h, img, e = _decode(api, grid, 0, 1, 10)
+    assert e.code == 0, e.message
+    assert api.heif_image_handle_get_color_profile_type(h) == 0x72494343
+    assert api.heif_image_get_raw_color_profile_size(img) == 0 and api.heif_image_get_color_profile_type(img) == 0x6E636C78  # the converted canvas: nclx only
+    api.heif_image_release(img); api.heif_image_handle_release(h); api.heif_context_free(ctx)
