@@ -93,21 +93,19 @@ class GridBatch:
             self.batch.add(blob, d)
         self.images.append(dict(y=y, cb=cb, cr=cr, rgb=rgb))
 
-    def finish(self, st):
-        capi, L = self.pkg.capi, self.pkg.lib()
+    def finish(self, st, images_per_group=0):
+        """upload, and attach the canvases' YCbCr -> RGB24 conversion to the batch (hm_batch_set_colour): one execute call
+        is then the whole hot path, the filters and the conversion running group of images by group of images"""
+        capi = self.pkg.capi
         self.batch.upload(st)
         n = len(self.images)
         PtrArr = C.c_void_p * n
         self.p = [PtrArr(*[im[k].data_ptr() for im in self.images]) for k in ("y", "cb", "cr", "rgb")]
         self.desc = capi.ColourDesc(self.out_w, self.out_h, 8, 1, 0, 0, 0, 0, capi.HM_OUT_RGB, self.ys, self.cs, self.cs, self.os)
-        L.hm_colour_convert_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-
-    def colour(self, st):
-        self.pkg.capi.check(self.pkg.lib().hm_colour_convert_batch(C.byref(self.desc), len(self.images), *self.p, st))
+        self.batch.set_colour(self.desc, n, *self.p, images_per_group)
 
     def step(self, st):
         self.batch.execute(3, st)
-        self.colour(st)
 
     def pixels(self):
         return len(self.images) * self.out_w * self.out_h
@@ -140,26 +138,21 @@ def cpu_grid_image(streams, blobs, cols, rows, tile, out_w, out_h, strides, use_
 
 def timed_steps(torch, gb, st, steps, dist=None):
     """K clock: `steps` passes bracketed by synchronize (+ barrier); per-kernel HIP-event times on the launch stream"""
-    gb.batch.set_profiling(steps)  # one HIP-event slot per timed step, read back after the timed region
-    cev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    gb.batch.set_profiling(steps)  # one HIP-event timeline per timed step, read back after the timed region
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     t0 = time.perf_counter()
     for i in range(steps):
-        gb.batch.execute(3, st)
-        cev[i][0].record()
-        gb.colour(st)
-        cev[i][1].record()
+        gb.step(st)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     k_ms = [0.0, 0.0, 0.0, 0.0]  # recon, deblock, sao+paste, colour
-    for i, (a, b) in enumerate(cev):
-        k_ms[3] += a.elapsed_time(b)
-        ms = gb.batch.timings_ms(i)
-        for q in range(3):
+    for i in range(steps):
+        ms = gb.batch.timings4_ms(i)
+        for q in range(4):
             k_ms[q] += ms[q]
     gb.batch.set_profiling(0)
     return elapsed, [m / steps for m in k_ms]
@@ -229,6 +222,7 @@ def main():
     ap.add_argument("--quick", action="store_true", help="headline only: skip the side clocks (D, E, pipelined E, CPU baseline, real content, configs 4 / 5)")
     ap.add_argument("--no-e2e", action="store_true", help="alias of --quick (profiling runs)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--group", type=int, default=0, help="images per filter + colour group (hm_batch_set_colour; 0 = the whole batch per kernel launch)")
     args = ap.parse_args()
     if args.no_e2e:
         args.quick = True
@@ -291,7 +285,7 @@ def run(args):
             kept.append([d for d, _ in tiles])
         if j == check_image:
             check = tiles
-    gb.finish(st)
+    gb.finish(st, args.group)
     strides = (gb.ys, gb.cs, gb.os)
 
     # ---- parity gate ----
@@ -417,6 +411,7 @@ def host_parse_rate(pkg, streams):
 
 
 def device_inclusive(torch, pkg, dev, gb, st, stream_b):
+    pkg.lib().hm_colour_convert_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     """clock (D) of SURVEY 8d: H2D of the command streams + kernels, result on the device.  Two figures: everything on
     one stream (the H2D in front of the kernels), and chunked with the H2D of chunk i+1 on a copy stream under the
     kernels of chunk i."""
@@ -436,7 +431,7 @@ def device_inclusive(torch, pkg, dev, gb, st, stream_b):
         t1 = time.perf_counter()
         for _ in range(3):
             gb.batch.upload_execute(3, chunks, copy.cuda_stream, st)
-            gb.colour(st)
+            pkg.capi.check(pkg.lib().hm_colour_convert_batch(C.byref(gb.desc), len(gb.images), *gb.p, st))
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t1) / 3 * 1e3
         res[f"overlapped_{chunks}_chunks"] = {"ms_per_step": round(ms, 3), "MP_per_s": round(B * MP_PER_IMAGE / ms * 1e3, 1)}

@@ -75,8 +75,10 @@ def bind_decode(L):
     L.hm_batch_upload.argtypes = [C.c_void_p, C.c_void_p]
     L.hm_batch_execute.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.hm_batch_upload_execute.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.hm_batch_set_colour.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.hm_batch_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.hm_batch_get_timings.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+    L.hm_batch_get_timings4.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     L.hm_batch_algorithmic_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
 
 
@@ -123,6 +125,9 @@ class Batch:
     def upload_execute(self, stages, chunks, copy_stream, stream):
         check(self.L.hm_batch_upload_execute(self.h, stages, chunks, copy_stream, stream))
 
+    def set_colour(self, desc, n_images, p_y, p_cb, p_cr, p_out, images_per_group=0):
+        check(self.L.hm_batch_set_colour(self.h, C.byref(desc) if desc is not None else None, n_images, p_y, p_cb, p_cr, p_out, images_per_group))
+
     def clear(self):
         self.L.hm_batch_clear(self.h)
 
@@ -133,6 +138,11 @@ class Batch:
         ms = (C.c_float * 3)()
         check(self.L.hm_batch_get_timings(self.h, slot, ms))
         return [ms[0], ms[1], ms[2]]
+
+    def timings4_ms(self, slot=0):
+        ms = (C.c_float * 4)()
+        check(self.L.hm_batch_get_timings4(self.h, slot, ms))
+        return [ms[0], ms[1], ms[2], ms[3]]
 
     def algorithmic_bytes(self):
         a, b = C.c_uint64(), C.c_uint64()

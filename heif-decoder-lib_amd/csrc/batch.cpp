@@ -96,14 +96,24 @@ struct hm_batch {
   bool inflight = false;             // something was enqueued on last_stream since the last drain
   hipEvent_t upload_done = nullptr;  // recorded behind the H2D copies: an execute on another stream waits for it on the device
   std::vector<hipEvent_t> chunk_events; // hm_batch_upload_execute: one per chunk of command streams
+  // optional colour conversion of the images' canvases inside hm_batch_execute (hm_batch_set_colour)
+  bool colour = false;
+  hm_colour_desc colour_desc{};
+  std::vector<const void*> col_y, col_cb, col_cr;
+  std::vector<void*> col_out;
+  int colour_chunk = 0;
   hipStream_t copy_stream = nullptr;
   bool copy_inflight = false;
   hipStream_t last_stream = nullptr; // stream of the last upload / execute: drained before the arenas are released
   size_t total_pixels = 0;
   // optional per-kernel timing with HIP events on the launch stream (bench / profiling)
   int profiling = 0;                // number of timing slots (0 = off)
-  std::vector<hipEvent_t> events;   // per slot, 4 per class: before recon, after recon, after deblock, after sao
+  // per slot: events on the launch stream; the interval that ends at event i belongs to kernel kind[i]
+  // (-1 start marker, 0 reconstruction, 1 deblocking, 2 SAO + paste, 3 colour conversion)
+  struct Timeline { std::vector<hipEvent_t> ev; std::vector<int8_t> kind; size_t used = 0; };
+  std::vector<Timeline> timelines;
   long exec_count = 0;
+  bool profiling_per_kernel_only() const { return false; }
   void drain()
   {
     if (copy_inflight) { hipStreamSynchronize(copy_stream); copy_inflight = false; }
@@ -112,7 +122,8 @@ struct hm_batch {
   ~hm_batch()
   {
     drain();
-    for (hipEvent_t e : events) hipEventDestroy(e);
+    for (Timeline& t : timelines)
+      for (hipEvent_t e : t.ev) hipEventDestroy(e);
     if (upload_done) hipEventDestroy(upload_done);
     for (hipEvent_t e : chunk_events) hipEventDestroy(e);
   }
@@ -136,6 +147,7 @@ void hm_batch_clear(hm_batch* b)
   if (!b) return;
   b->drain();
   b->items.clear();
+  b->colour = false;
   b->classes.clear();
   b->h_desc.clear();
   b->stage.used = 0;
@@ -345,33 +357,74 @@ int hm_batch_execute(hm_batch* b, int stages, void* stream)
   b->last_stream = s;
   b->inflight = true;
   const hm_dev_pic* d = (const hm_dev_pic*)b->d_desc.p;
-  const size_t per_slot = b->classes.size() * 4;
-  size_t ev_next = 0;
+  hm_batch::Timeline* tl = nullptr;
   if (b->profiling) {
-    ev_next = (size_t)(b->exec_count % b->profiling) * per_slot;
-    while (b->events.size() < per_slot * (size_t)b->profiling) {
-      hipEvent_t ev;
-      hipError_t e = hipEventCreate(&ev);
-      if (e != hipSuccess) return hm_check_hip(e, "hipEventCreate");
-      b->events.push_back(ev);
-    }
+    if ((int)b->timelines.size() < b->profiling) b->timelines.resize(b->profiling);
+    tl = &b->timelines[(size_t)(b->exec_count % b->profiling)];
+    tl->used = 0;
   }
-  auto mark = [&]() { if (b->profiling) hipEventRecord(b->events[ev_next++], s); };
+  auto mark = [&](int kind) {
+    if (!tl) return;
+    if (tl->used == tl->ev.size()) {
+      hipEvent_t ev;
+      if (hipEventCreate(&ev) != hipSuccess) return;
+      tl->ev.push_back(ev);
+      tl->kind.push_back(0);
+    }
+    tl->kind[tl->used] = (int8_t)kind;
+    hipEventRecord(tl->ev[tl->used++], s);
+  };
+  // With a colour conversion attached (hm_batch_set_colour: the pictures were queued image by image, one class) the
+  // filters and the conversion can run group of images by group of images, so that what k_deblock writes, k_sao_paste
+  // reads and writes and the colour kernel reads is still in the 256 MiB Infinity Cache.  Measured (r02, 384 x 12 MP,
+  // gpurun_out/r02_group.log -> DESIGN.md): groups of 1 / 2 / 4 / 8 images cost 28.4 / 23.4 / 19.9 / 17.9 ms for the three
+  // kernels against 17.3 ms for whole-batch launches - k_deblock and k_sao_paste are latency bound, not HBM bound, so
+  // the cache hits buy little (colour 3.65 -> 3.51 ms at 8) while launches of 48-384 pictures lose more to their tails.
+  // The default is therefore ONE group (= the plain kernel order); the knob stays for other shapes.
+  if (b->colour && b->classes.size() == 1) {
+    const Class& c = b->classes[0];
+    const int n = (int)c.items.size(), n_img = (int)b->col_y.size();
+    const int per_img = n / n_img;
+    const hm_dev_pic* dc = d + c.desc_offset;
+    mark(-1);
+    int rc = launch_recon(dc, n, c, s);
+    if (rc) return rc;
+    mark(0);
+    int chunk = b->colour_chunk;
+    if (chunk <= 0) chunk = n_img;
+    for (int i0 = 0; i0 < n_img; i0 += chunk) {
+      const int m_img = std::min(chunk, n_img - i0), m = m_img * per_img;
+      const hm_dev_pic* dk = dc + (size_t)i0 * per_img;
+      if ((stages & 1) && (rc = hm_launch_deblock(dk, m, c.max_w4, c.max_h4, c.chroma_format, c.bit_depth, c.rare, s))) return rc;
+      mark(1);
+      if ((rc = hm_launch_sao_paste(dk, m, c.max_w, c.max_h, c.bit_depth, (stages & 2) ? 1 : 0, c.rare, s))) return rc;
+      mark(2);
+      if ((rc = hm_colour_convert_batch(&b->colour_desc, m_img, b->col_y.data() + i0, b->col_cb.data() + i0, b->col_cr.data() + i0, b->col_out.data() + i0, s))) return rc;
+      mark(3);
+    }
+    b->exec_count++;
+    return HM_OK;
+  }
   for (const Class& c : b->classes) {
     const hm_dev_pic* dc = d + c.desc_offset;
     const int n = (int)c.items.size();
-    mark();
+    mark(-1);
     int rc = launch_recon(dc, n, c, s);
     if (rc) return rc;
-    mark();
+    mark(0);
     if (stages & 1) {
       rc = hm_launch_deblock(dc, n, c.max_w4, c.max_h4, c.chroma_format, c.bit_depth, c.rare, s);
       if (rc) return rc;
     }
-    mark();
+    mark(1);
     rc = hm_launch_sao_paste(dc, n, c.max_w, c.max_h, c.bit_depth, (stages & 2) ? 1 : 0, c.rare, s);
     if (rc) return rc;
-    mark();
+    mark(2);
+  }
+  if (b->colour) { // (several picture classes: plain order)
+    const int rc = hm_colour_convert_batch(&b->colour_desc, (int)b->col_y.size(), b->col_y.data(), b->col_cb.data(), b->col_cr.data(), b->col_out.data(), s);
+    if (rc) return rc;
+    mark(3);
   }
   b->exec_count++;
   return HM_OK;
@@ -433,6 +486,28 @@ int hm_batch_upload_execute(hm_batch* b, int stages, int chunks, void* copy_stre
   return HM_OK;
 }
 
+// Attach the colour conversion of the images' canvases to the batch: hm_batch_execute then also converts canvas i
+// (d_y[i], d_cb[i], d_cr[i]) to d_out[i].  The pictures must have been queued image by image, the same number for every
+// image.  images_per_group: 0 = as many as keep a group's traffic inside the Infinity Cache.  n_images = 0 detaches.
+int hm_batch_set_colour(hm_batch* b, const hm_colour_desc* d, int n_images, const void* const* d_y, const void* const* d_cb,
+                        const void* const* d_cr, void* const* d_out, int images_per_group)
+{
+  if (!b) return hm_fail(HM_ERR_INVALID_ARG, "null batch");
+  b->colour = false;
+  b->col_y.clear(); b->col_cb.clear(); b->col_cr.clear(); b->col_out.clear();
+  if (n_images == 0) return HM_OK;
+  if (!d || n_images < 0 || !d_y || !d_cb || !d_cr || !d_out) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
+  if (b->items.empty() || b->items.size() % (size_t)n_images) return hm_fail(HM_ERR_INVALID_ARG, "%zu pictures do not divide into %d images", b->items.size(), n_images);
+  const int pipe = hm_colour_pipeline(d);
+  if (pipe < 0) return pipe;
+  b->colour_desc = *d;
+  b->col_y.assign(d_y, d_y + n_images); b->col_cb.assign(d_cb, d_cb + n_images); b->col_cr.assign(d_cr, d_cr + n_images);
+  b->col_out.assign(d_out, d_out + n_images);
+  b->colour_chunk = images_per_group;
+  b->colour = true;
+  return HM_OK;
+}
+
 int hm_batch_set_profiling(hm_batch* b, int slots)
 {
   if (!b || slots < 0 || slots > 4096) return hm_fail(HM_ERR_INVALID_ARG, "bad argument");
@@ -442,25 +517,31 @@ int hm_batch_set_profiling(hm_batch* b, int slots)
 }
 
 // Kernel times (ms) of the execute call recorded in `slot` (= call index modulo the slot count):
-// recon, deblock (both passes), SAO+paste.  Synchronises on the recorded events.
-int hm_batch_get_timings(hm_batch* b, int slot, float ms[3])
+// recon, deblock, SAO+paste [, colour conversion when attached].  Synchronises on the recorded events.
+int hm_batch_get_timings4(hm_batch* b, int slot, float ms[4])
 {
   if (!b || !ms) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
-  ms[0] = ms[1] = ms[2] = 0.f;
-  const size_t per_slot = b->classes.size() * 4;
-  if (!b->profiling || slot < 0 || slot >= b->profiling || slot >= b->exec_count || b->events.size() < per_slot * (size_t)(slot + 1))
+  ms[0] = ms[1] = ms[2] = ms[3] = 0.f;
+  if (!b->profiling || slot < 0 || slot >= b->profiling || slot >= b->exec_count || slot >= (int)b->timelines.size() || b->timelines[slot].used == 0)
     return hm_fail(HM_ERR_INVALID_ARG, "profiling not enabled or slot not recorded");
-  const size_t base = (size_t)slot * per_slot;
-  hipError_t e = hipEventSynchronize(b->events[base + per_slot - 1]);
+  const hm_batch::Timeline& t = b->timelines[slot];
+  hipError_t e = hipEventSynchronize(t.ev[t.used - 1]);
   if (e != hipSuccess) return hm_check_hip(e, "hipEventSynchronize");
-  for (size_t i = base; i + 3 < base + per_slot; i += 4)
-    for (int k = 0; k < 3; k++) {
-      float t = 0.f;
-      e = hipEventElapsedTime(&t, b->events[i + k], b->events[i + k + 1]);
-      if (e != hipSuccess) return hm_check_hip(e, "hipEventElapsedTime");
-      ms[k] += t;
-    }
+  for (size_t i = 1; i < t.used; i++) {
+    if (t.kind[i] < 0) continue;
+    float v = 0.f;
+    e = hipEventElapsedTime(&v, t.ev[i - 1], t.ev[i]);
+    if (e != hipSuccess) return hm_check_hip(e, "hipEventElapsedTime");
+    ms[t.kind[i]] += v;
+  }
   return HM_OK;
+}
+int hm_batch_get_timings(hm_batch* b, int slot, float ms[3])
+{
+  float v[4];
+  const int rc = hm_batch_get_timings4(b, slot, v);
+  if (!rc) { ms[0] = v[0]; ms[1] = v[1]; ms[2] = v[2]; }
+  return rc;
 }
 
 // algorithmic bytes of the queued work: command-stream bytes read + sample bytes written by the

@@ -151,6 +151,13 @@ HM_API int  hm_batch_upload(hm_batch* b, void* stream);
  * stages: bit0 = deblocking, bit1 = SAO; pass 3.  Pictures of a batch are independent: this is
  * the data-parallel replacement of the reference's std::async tile fan-out (context.cc:2361-2401). */
 HM_API int  hm_batch_execute(hm_batch* b, int stages, void* stream);
+/* Attach the YCbCr -> RGB conversion of the images' canvases to the batch (convert_colorspace of the decoded grids,
+ * context.cc:1516-1600): one hm_batch_execute is then the whole hot path.  images_per_group > 0 runs the filters and the
+ * conversion group of images by group of images (Infinity-Cache blocking; measured not to pay for 12 MP grids, see
+ * batch.cpp), 0 = one group.  The pictures must have been queued image by image, equally many per image; arrays of
+ * n_images device pointers (copied).  n_images 0 detaches. */
+HM_API int  hm_batch_set_colour(hm_batch* b, const hm_colour_desc* d, int n_images, const void* const* d_y, const void* const* d_cb,
+                                const void* const* d_cr, void* const* d_out, int images_per_group);
 /* hm_batch_upload + hm_batch_execute in one call, the command streams split into `chunks` parts: the H2D copy of part
  * i+1 (on `copy_stream`) runs under the kernels of part i (on `stream`).  Asynchronous. */
 HM_API int  hm_batch_upload_execute(hm_batch* b, int stages, int chunks, void* copy_stream, void* stream);
@@ -160,6 +167,8 @@ HM_API int  hm_batch_set_profiling(hm_batch* b, int slots);
 /* kernel times in ms of the execute call in `slot` (call index mod slots):
  * [0] reconstruction, [1] deblocking (V+H), [2] SAO+paste.  Waits for that call to finish. */
 HM_API int  hm_batch_get_timings(hm_batch* b, int slot, float ms[3]);
+/* the same plus [3] the colour conversion attached with hm_batch_set_colour (summed over the groups of images) */
+HM_API int  hm_batch_get_timings4(hm_batch* b, int slot, float ms[4]);
 /* algorithmic bytes of the queued pictures: command streams read, reconstructed samples written */
 HM_API int  hm_batch_algorithmic_bytes(const hm_batch* b, uint64_t* stream_bytes, uint64_t* sample_bytes);
 
