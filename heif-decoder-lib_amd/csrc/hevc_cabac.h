@@ -77,10 +77,25 @@ static const uint8_t kRangeTabLps[64][4] = {
     {8, 10, 12, 14},      {8, 9, 11, 13},       {7, 9, 11, 12},       {7, 9, 10, 12},       {7, 8, 10, 11},
     {6, 8, 9, 11},        {6, 7, 9, 10},        {6, 7, 8, 9},         {2, 2, 2, 2}};
 
-static const uint8_t kTransIdxLps[64] = {0,  0,  1,  2,  2,  4,  4,  5,  6,  7,  8,  9,  9,  11, 11, 12,
+static constexpr uint8_t kTransIdxLps[64] = {0,  0,  1,  2,  2,  4,  4,  5,  6,  7,  8,  9,  9,  11, 11, 12,
                                          13, 13, 15, 15, 16, 16, 18, 18, 19, 19, 21, 21, 22, 22, 23, 24,
                                          24, 25, 26, 26, 27, 27, 28, 29, 29, 30, 30, 30, 31, 32, 32, 33,
                                          33, 33, 34, 34, 35, 35, 35, 36, 36, 36, 37, 37, 37, 38, 38, 63};
+
+// state after a bin: [0] most probable symbol decoded, [1] least probable (Table 9-47 transIdxMps / transIdxLps; valMps
+// flips when an LPS arrives in state 0), indexed by (pStateIdx << 1) | valMps
+struct NextState {
+  uint8_t v[2][128];
+  constexpr NextState() : v()
+  {
+    for (int c = 0; c < 128; c++) {
+      const int st = c >> 1, mps = c & 1;
+      v[0][c] = (uint8_t)(((st < 62 ? st + 1 : st) << 1) | mps);
+      v[1][c] = (uint8_t)((kTransIdxLps[st] << 1) | (st == 0 ? !mps : mps));
+    }
+  }
+};
+static constexpr NextState kNextState{};
 } // namespace cabac_tables
 
 // §9.3.2.2: initialisation of context variables
@@ -121,40 +136,29 @@ class CabacDecoder {
   const uint8_t* position() const { return cur_; }
   bool overrun() const { return overrun_ > 8; }
 
+  // One context-coded bin (9.3.4.3.2).  The MPS / LPS decision of a well-compressed stream is as good as random, so it
+  // is taken with masks instead of a branch (a mispredicted branch per bin costs more than the arithmetic of both
+  // paths); the state transition is one table look-up on (LPS?, state); renormalisation shifts by the leading zeros.
   inline int decode_bin(uint8_t& ctx)
   {
-    const int st = ctx >> 1;
-    int mps = ctx & 1;
-    const uint32_t lps = cabac_tables::kRangeTabLps[st][(range_ >> 6) & 3];
-    range_ -= lps;
-    const uint32_t scaled = range_ << 7;
-    int bin;
-    if (value_ < scaled) { // MPS path
-      bin = mps;
-      ctx = (uint8_t)(((st < 62 ? st + 1 : st) << 1) | mps);
-      if (scaled < (256u << 7)) {
-        range_ = scaled >> 6;
-        value_ <<= 1;
-        if (++bits_needed_ == 0) refill();
-      }
+    const uint32_t c = ctx;
+    const uint32_t lps_range = cabac_tables::kRangeTabLps[c >> 1][(range_ >> 6) & 3];
+    uint32_t r = range_ - lps_range;
+    const uint32_t scaled = r << 7;
+    const uint32_t lps = value_ >= scaled ? 1u : 0u;
+    const uint32_t mask = 0u - lps;
+    value_ -= scaled & mask;
+    r += (lps_range - r) & mask;
+    ctx = cabac_tables::kNextState.v[lps][c];
+    const int shift = __builtin_clz(r) - 23; // r in [6, 510]: 0 for r >= 256
+    range_ = r << shift;
+    value_ <<= shift;
+    bits_needed_ += shift;
+    if (bits_needed_ >= 0) {
+      value_ |= next_byte() << bits_needed_;
+      bits_needed_ -= 8;
     }
-    else { // LPS path
-      bin = !mps;
-      value_ -= scaled;
-      int shift = 0;
-      uint32_t r = lps;
-      while (r < 256) { r <<= 1; shift++; }
-      range_ = r;
-      value_ <<= shift;
-      if (st == 0) mps = !mps;
-      ctx = (uint8_t)((cabac_tables::kTransIdxLps[st] << 1) | mps);
-      bits_needed_ += shift;
-      if (bits_needed_ >= 0) {
-        value_ |= next_byte() << bits_needed_;
-        bits_needed_ -= 8;
-      }
-    }
-    return bin;
+    return (int)((c & 1u) ^ lps);
   }
 
   inline int decode_bypass()
@@ -165,11 +169,10 @@ class CabacDecoder {
       bits_needed_ = -8;
     }
     const uint32_t scaled = range_ << 7;
-    if (value_ >= scaled) {
-      value_ -= scaled;
-      return 1;
-    }
-    return 0;
+    const int32_t d = (int32_t)(value_ - scaled);
+    const uint32_t below = (uint32_t)(d >> 31); // all ones when value < scaled (bin 0)
+    value_ = (uint32_t)d + (scaled & below);
+    return (int)(below + 1u);
   }
 
   inline uint32_t decode_bypass_bits(int n)

@@ -504,19 +504,6 @@ void derive_pps_tables(PPS& pps, const SPS& sps)
           pps.TileIdRS[y * W + x] = tIdx;
         }
 
-  const int shift = sps.log2_ctb - sps.log2_min_tb;
-  pps.MinTbAddrZS.assign((size_t)sps.min_tb_w * sps.min_tb_h, 0);
-  for (int y = 0; y < sps.min_tb_h; y++)
-    for (int x = 0; x < sps.min_tb_w; x++) {
-      const int tbX = (x << sps.log2_min_tb) >> sps.log2_ctb;
-      const int tbY = (y << sps.log2_min_tb) >> sps.log2_ctb;
-      int v = pps.CtbAddrRStoTS[W * tbY + tbX] << (shift * 2);
-      for (int i = 0; i < shift; i++) {
-        const int m = 1 << i;
-        v += ((m & x) ? m * m : 0) + ((m & y) ? 2 * m * m : 0);
-      }
-      pps.MinTbAddrZS[x + y * sps.min_tb_w] = v;
-    }
   pps.Log2MinCuQpDeltaSize = sps.log2_ctb - pps.diff_cu_qp_delta_depth;
 }
 

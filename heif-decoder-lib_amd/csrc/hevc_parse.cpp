@@ -132,7 +132,7 @@ struct Decoder {
     const SPS& s = sps[p.sps_id];
     // every table the slice walker indexes with CTB / minimum-TB addresses must have the active SPS's size
     if (p.CtbAddrRStoTS.size() != (size_t)s.ctb_w * s.ctb_h || p.CtbAddrTStoRS.size() != p.CtbAddrRStoTS.size() ||
-        p.TileIdRS.size() != p.CtbAddrRStoTS.size() || p.MinTbAddrZS.size() != (size_t)s.min_tb_w * s.min_tb_h)
+        p.TileIdRS.size() != p.CtbAddrRStoTS.size())
       throw ParseError(HM_ERR_BITSTREAM, "PPS scan tables do not match the active SPS");
     if (sh.first_slice_segment_in_pic) {
       if (pic_started) throw ParseError(HM_ERR_UNSUPPORTED, "more than one coded picture in the item");

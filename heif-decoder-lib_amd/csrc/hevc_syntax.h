@@ -101,6 +101,59 @@ inline const ScanTables& scan_tables()
   static const ScanTables t;
   return t;
 }
+// ctxInc of sig_coeff_flag (9.3.4.2.5) for every scan position of a sub-block:
+// [chroma][size class: 4x4, 8x8, larger][scanIdx][sub-block is not the DC one][coded flags right | below << 1][n]
+struct SigCtxTable {
+  uint8_t v[2][3][3][2][4][16];
+  SigCtxTable()
+  {
+    for (int c = 0; c < 2; c++)
+      for (int cls = 0; cls < 3; cls++)
+        for (int scanIdx = 0; scanIdx < 3; scanIdx++)
+          for (int nondc = 0; nondc < 2; nondc++)
+            for (int prev = 0; prev < 4; prev++)
+              for (int n = 0; n < 16; n++) {
+                const Scan* pos4 = scan4(scanIdx);
+                const int xP = pos4[n].x, yP = pos4[n].y;
+                int sigCtx;
+                if (cls == 0) sigCtx = kCtxIdxMap4x4Values[(yP << 2) + xP];
+                else if (!nondc && n == 0) sigCtx = 0;
+                else {
+                  if (prev == 0) sigCtx = (xP + yP == 0) ? 2 : ((xP + yP < 3) ? 1 : 0);
+                  else if (prev == 1) sigCtx = (yP == 0) ? 2 : ((yP == 1) ? 1 : 0);
+                  else if (prev == 2) sigCtx = (xP == 0) ? 2 : ((xP == 1) ? 1 : 0);
+                  else sigCtx = 2;
+                  if (c == 0) {
+                    if (nondc) sigCtx += 3;
+                    sigCtx += (cls == 1) ? (scanIdx == 0 ? 9 : 15) : 21;
+                  }
+                  else sigCtx += (cls == 1) ? 9 : 12;
+                }
+                v[c][cls][scanIdx][nondc][prev][n] = (uint8_t)(c == 0 ? sigCtx : 27 + sigCtx);
+              }
+  }
+  static constexpr uint8_t kCtxIdxMap4x4Values[16] = {0, 1, 4, 5, 2, 3, 4, 5, 6, 6, 8, 8, 7, 7, 8, 8};
+};
+inline const SigCtxTable& sig_ctx_table()
+{
+  static const SigCtxTable t;
+  return t;
+}
+// z-order index of a 4x4 unit inside a 64x64 block: bits of x and y interleaved (6.5.2)
+struct ZOrder4 {
+  uint8_t v[16][16];
+  constexpr ZOrder4() : v()
+  {
+    for (int y = 0; y < 16; y++)
+      for (int x = 0; x < 16; x++) {
+        int z = 0;
+        for (int b = 0; b < 4; b++) z |= (((x >> b) & 1) << (2 * b)) | (((y >> b) & 1) << (2 * b + 1));
+        v[y][x] = (uint8_t)z;
+      }
+  }
+  constexpr const uint8_t* operator[](int y) const { return v[y]; }
+};
+static constexpr ZOrder4 kZOrder4{};
 static const uint8_t kCtxIdxMap4x4[16] = {0, 1, 4, 5, 2, 3, 4, 5, 6, 6, 8, 8, 7, 7, 8, 8};
 // Table 8-10: QpC as a function of qPi (ChromaArrayType == 1)
 inline int chroma_qp_table(int qPi)
@@ -244,27 +297,42 @@ class SliceWalker {
     ec_.contexts() = pic_.wpp_ctx[row];
     pic_.wpp_ok[row] = 0;
   }
-  // §6.4.1 z-scan order availability (luma sample positions)
+  // §6.4.1 z-scan order availability (luma sample positions).  (xCurr, yCurr) lies in the current CTB; the neighbour
+  // lies in it or in one of the eight CTBs around it.  Inside the CTB "decoded before" is a comparison of z-order
+  // indices of the two 4x4 units (finer than the minimum transform block, same order); for another CTB the answer -
+  // inside the picture, not later in tile scan, same slice, same tile - is fixed for the whole CTB and computed once
+  // per CTB (nb_ok_).
   bool avail_z(int xCurr, int yCurr, int xN, int yN) const
   {
     if (xN < 0 || yN < 0 || xN >= sps_.width || yN >= sps_.height) return false;
-    const int l2 = sps_.log2_min_tb;
-    const int aN = pps_.MinTbAddrZS[(xN >> l2) + (yN >> l2) * sps_.min_tb_w];
-    const int aC = pps_.MinTbAddrZS[(xCurr >> l2) + (yCurr >> l2) * sps_.min_tb_w];
-    if (aN > aC) return false;
     const int lc = sps_.log2_ctb;
-    // a neighbour inside the current CTB: same slice, same tile (neither can end inside a CTB)
-    if (((xCurr ^ xN) >> lc) == 0 && ((yCurr ^ yN) >> lc) == 0) return true;
-    const int cc = (xCurr >> lc) + (yCurr >> lc) * sps_.ctb_w;
-    const int cn = (xN >> lc) + (yN >> lc) * sps_.ctb_w;
-    if (pic_.ctb_slice_addr[cn] < 0 || pic_.ctb_slice_addr[cn] != pic_.ctb_slice_addr[cc]) return false;
-    return pps_.TileIdRS[cn] == pps_.TileIdRS[cc];
+    const int dx = (xN >> lc) - ctb_x_, dy = (yN >> lc) - ctb_y_;
+    if ((dx | dy) == 0) return tables::kZOrder4[(yN >> 2) & 15][(xN >> 2) & 15] <= tables::kZOrder4[(yCurr >> 2) & 15][(xCurr >> 2) & 15];
+    return nb_ok_[(dy + 1) * 3 + dx + 1] != 0;
+  }
+  void derive_ctb_neighbours()
+  {
+    const int cc = ctb_addr_rs_;
+    for (int dy = -1; dy <= 1; dy++)
+      for (int dx = -1; dx <= 1; dx++) {
+        uint8_t ok = 0;
+        const int nx = ctb_x_ + dx, ny = ctb_y_ + dy;
+        if (nx >= 0 && ny >= 0 && nx < sps_.ctb_w && ny < sps_.ctb_h) {
+          const int cn = nx + ny * sps_.ctb_w;
+          ok = pps_.CtbAddrRStoTS[cn] <= ctb_addr_ts_ && pic_.ctb_slice_addr[cn] >= 0 &&
+               pic_.ctb_slice_addr[cn] == pic_.ctb_slice_addr[cc] && pps_.TileIdRS[cn] == pps_.TileIdRS[cc];
+        }
+        nb_ok_[(dy + 1) * 3 + dx + 1] = ok;
+      }
   }
 
   // ---- CTU ---------------------------------------------------------------------------------
   void coding_tree_unit(int xCtb, int yCtb)
   {
     const int x0 = xCtb << sps_.log2_ctb, y0 = yCtb << sps_.log2_ctb;
+    ctb_x_ = xCtb; ctb_y_ = yCtb;
+    derive_ctb_neighbours();
+    avail_memo_[0].key = avail_memo_[1].key = 0xFFFFFFFFu;
     hm_ctb& c = pic_.ctbs[ctb_addr_rs_];
     // deblocking edge permissions of this CTB's left/top edge (deblock.cc:160-196 in the reference)
     c.flags &= ~(HM_CTB_DEBLOCK_LEFT | HM_CTB_DEBLOCK_TOP | HM_CTB_DEBLOCK_OFF | HM_CTB_SAO_LUMA | HM_CTB_SAO_CHROMA | HM_CTB_LOSSLESS);
@@ -381,8 +449,7 @@ class SliceWalker {
       // record depth for later split_cu_flag contexts
       const int n = size >> sps_.log2_min_cb;
       const int bx = x0 >> sps_.log2_min_cb, by = y0 >> sps_.log2_min_cb;
-      for (int j = 0; j < n; j++)
-        for (int i = 0; i < n; i++) pic_.ct_depth[(bx + i) + (size_t)(by + j) * sps_.min_cb_w] = (uint8_t)cqtDepth;
+      for (int j = 0; j < n; j++) std::memset(&pic_.ct_depth[bx + (size_t)(by + j) * sps_.min_cb_w], cqtDepth, (size_t)n);
       coding_unit(x0, y0, log2CbSize);
     }
   }
@@ -447,8 +514,7 @@ class SliceWalker {
     // store QpY for the whole CU
     const int n = (1 << log2CbSize) >> sps_.log2_min_cb;
     const int bx = xCU >> sps_.log2_min_cb, by = yCU >> sps_.log2_min_cb;
-    for (int j = 0; j < n; j++)
-      for (int i = 0; i < n; i++) pic_.qpy[(bx + i) + (size_t)(by + j) * sps_.min_cb_w] = (int8_t)qpy;
+    for (int j = 0; j < n; j++) std::memset(&pic_.qpy[bx + (size_t)(by + j) * sps_.min_cb_w], qpy, (size_t)n);
     pic_.qs.current_qpy = qpy;
     cu_qpy_ = qpy;
   }
@@ -503,8 +569,7 @@ class SliceWalker {
       const int xP = x0 + (i & 1) * pbOffset, yP = y0 + (i >> 1) * pbOffset;
       const int mode = derive_luma_mode(xP, yP, prev_flag[i], mpm_idx[i], rem[i]);
       const int n4 = pbOffset >> 2;
-      for (int j = 0; j < n4; j++)
-        for (int k = 0; k < n4; k++) pic_.intra_mode[((xP >> 2) + k) + (size_t)((yP >> 2) + j) * w4_] = (uint8_t)mode;
+      for (int j = 0; j < n4; j++) std::memset(&pic_.intra_mode[(xP >> 2) + (size_t)((yP >> 2) + j) * w4_], mode, (size_t)n4);
       luma_mode_[i] = mode;
     }
     if (!nxn) luma_mode_[1] = luma_mode_[2] = luma_mode_[3] = luma_mode_[0];
@@ -691,13 +756,13 @@ class SliceWalker {
     emit_block(x0, y0, log2TrafoSize, 0, luma_mode_[part], cbf_luma);
     if (cat == 0) return;
     // --- chroma ---
-    const int sw = sps_.SubWidthC, shh = sps_.SubHeightC;
+    const int lw = sps_.SubWidthC >> 1, lh = sps_.SubHeightC >> 1; // SubWidthC / SubHeightC are 1 or 2
     if (log2TrafoSize > 2 || cat == 3) {
       const int cmode = chroma_mode_[part];
       for (int c = 1; c <= 2; c++) {
         const int cbf = c == 1 ? cbf_cb : cbf_cr;
-        emit_block(x0 / sw, y0 / shh, log2C, c, cmode, cbf & 1);
-        if (cat == 2) emit_block(x0 / sw, y0 / shh + (1 << log2C), log2C, c, cmode, (cbf >> 1) & 1);
+        emit_block(x0 >> lw, y0 >> lh, log2C, c, cmode, cbf & 1);
+        if (cat == 2) emit_block(x0 >> lw, (y0 >> lh) + (1 << log2C), log2C, c, cmode, (cbf >> 1) & 1);
       }
       if (cat == 2) interleave_422_records();
     }
@@ -705,8 +770,8 @@ class SliceWalker {
       const int cmode = chroma_mode_[0];
       for (int c = 1; c <= 2; c++) {
         const int cbf = c == 1 ? cbf_cb : cbf_cr;
-        emit_block(xBase / sw, yBase / shh, 2, c, cmode, cbf & 1);
-        if (cat == 2) emit_block(xBase / sw, yBase / shh + 4, 2, c, cmode, (cbf >> 1) & 1);
+        emit_block(xBase >> lw, yBase >> lh, 2, c, cmode, cbf & 1);
+        if (cat == 2) emit_block(xBase >> lw, (yBase >> lh) + 4, 2, c, cmode, (cbf >> 1) & 1);
       }
       if (cat == 2) interleave_422_records();
     }
@@ -743,19 +808,37 @@ class SliceWalker {
     t.n_coeff = (uint16_t)ncoef;
     t.qp = (uint8_t)qp_prime_[cIdx];
     t.qpy = (int8_t)cu_qpy_;
-    // neighbour availability (intrapred.h:536-667 in the reference; equals §8.4.4.2.2)
+    // neighbour availability (intrapred.h:536-667 in the reference; equals §8.4.4.2.2).  It depends on the block's
+    // rectangle in luma samples only, which the Cb / Cr blocks of a transform unit share (and, for 4:2:0 / 4:4:4,
+    // share with the unit's luma block): the last two answers are kept.
     const int xL = xc << lw, yL = yc << lh; // luma position of the block
     const int cw = sps_.width >> lw, chh = sps_.height >> lh;
-    const bool aL = avail_z(xL, yL, xL - 1, yL);
-    const bool aT = avail_z(xL, yL, xL, yL - 1);
-    const bool aTL = avail_z(xL, yL, xL - 1, yL - 1);
-    const bool aBL = aL && (yc + nT < chh) && avail_z(xL, yL, xL - 1, (yc + nT) << lh);
-    const bool aTR = (xc + nT < cw) && avail_z(xL, yL, (xc + nT) << lw, yL - 1);
+    const uint32_t key = (uint32_t)(xL >> 2) | ((uint32_t)(yL >> 2) << 12) | ((uint32_t)(log2 + lw) << 24) | ((uint32_t)(log2 + lh) << 27);
+    AvailMemo& am = avail_memo_[avail_memo_[0].key == key ? 0 : 1];
+    if (am.key != key) {
+      // (replace the older entry: 4:2:2 alternates between the upper and the lower block of Cb and Cr)
+      AvailMemo& slot = avail_memo_[avail_memo_next_];
+      avail_memo_next_ ^= 1;
+      const bool l = avail_z(xL, yL, xL - 1, yL);
+      slot.key = key;
+      slot.left = l;
+      slot.top = avail_z(xL, yL, xL, yL - 1);
+      slot.top_left = avail_z(xL, yL, xL - 1, yL - 1);
+      slot.bottom_left = l && (yc + nT < chh) && avail_z(xL, yL, xL - 1, (yc + nT) << lh);
+      slot.top_right = (xc + nT < cw) && avail_z(xL, yL, (xc + nT) << lw, yL - 1);
+      return emit_record(t, nT, cIdx, slot, chh - (yc + nT), cw - (xc + nT));
+    }
+    return emit_record(t, nT, cIdx, am, chh - (yc + nT), cw - (xc + nT));
+  }
+  struct AvailMemo { uint32_t key = 0xFFFFFFFFu; bool left = false, top = false, top_left = false, bottom_left = false, top_right = false; };
+  void emit_record(hm_tu& t, int nT, int cIdx, const AvailMemo& a, int room_below, int room_right)
+  {
+    const bool aL = a.left, aT = a.top, aTL = a.top_left, aBL = a.bottom_left, aTR = a.top_right;
     t.avail_left = aL ? (uint8_t)nT : 0;
     t.avail_top = aT ? (uint8_t)nT : 0;
     if (aTL) t.info |= HM_TU_AVAIL_TL;
-    t.avail_bottom_left = aBL ? (uint8_t)std::min(nT, chh - (yc + nT)) : 0;
-    t.avail_top_right = aTR ? (uint8_t)std::min(nT, cw - (xc + nT)) : 0;
+    t.avail_bottom_left = aBL ? (uint8_t)std::min(nT, room_below) : 0;
+    t.avail_top_right = aTR ? (uint8_t)std::min(nT, room_right) : 0;
     auto& vec = pic_.ctb_tus[ctb_addr_rs_];
     if (cIdx == 0) cu_first_tu_.push_back({ctb_addr_rs_, (uint32_t)vec.size()});
     vec.push_back(t);
@@ -784,6 +867,7 @@ class SliceWalker {
 
     const tables::Scan* pos4 = tables::scan4(scanIdx);
     const tables::ScanTables& st = tables::scan_tables();
+    const tables::SigCtxTable& sig_tab = tables::sig_ctx_table();
     const int log2sb = log2 - 2;
     const tables::Scan* sbscan = st.sub[scanIdx][log2sb];
     const int sbw = 1 << log2sb;
@@ -818,27 +902,11 @@ class SliceWalker {
       int prevCsbf = 0;
       if (xS < sbw - 1) prevCsbf |= csbf[yS][xS + 1];
       if (yS < sbw - 1) prevCsbf |= csbf[yS + 1][xS] << 1;
+      const uint8_t* sig_inc = sig_tab.v[cIdx ? 1 : 0][log2 == 2 ? 0 : (log2 == 3 ? 1 : 2)][scanIdx][(xS | yS) ? 1 : 0][prevCsbf];
       for (int n = startPos; n >= 0; n--) {
-        const int xP = pos4[n].x, yP = pos4[n].y;
         int sig;
         if (n > 0 || !inferSbDcSig) {
-          // §9.3.4.2.5
-          int sigCtx;
-          if (log2 == 2) sigCtx = tables::kCtxIdxMap4x4[(yP << 2) + xP];
-          else if (xS == 0 && yS == 0 && n == 0) sigCtx = 0;
-          else {
-            if (prevCsbf == 0) sigCtx = (xP + yP == 0) ? 2 : ((xP + yP < 3) ? 1 : 0);
-            else if (prevCsbf == 1) sigCtx = (yP == 0) ? 2 : ((yP == 1) ? 1 : 0);
-            else if (prevCsbf == 2) sigCtx = (xP == 0) ? 2 : ((xP == 1) ? 1 : 0);
-            else sigCtx = 2;
-            if (cIdx == 0) {
-              if (xS + yS > 0) sigCtx += 3;
-              sigCtx += (log2 == 3) ? (scanIdx == 0 ? 9 : 15) : 21;
-            }
-            else sigCtx += (log2 == 3) ? 9 : 12;
-          }
-          const int inc = cIdx == 0 ? sigCtx : 27 + sigCtx;
-          sig = ec_.bin(CTX_SIG + inc, K_SIG, n);
+          sig = ec_.bin(CTX_SIG + sig_inc[n], K_SIG, n);
           if (sig) inferSbDcSig = 0;
         }
         else sig = 1; // inferred: the only coefficient of a coded sub-block
@@ -949,6 +1017,10 @@ class SliceWalker {
   int slice_idx_;
   int w4_ = 0;
   int ctb_addr_ts_ = 0, ctb_addr_rs_ = 0;
+  int ctb_x_ = 0, ctb_y_ = 0;      // current CTB in CTB units
+  AvailMemo avail_memo_[2];
+  int avail_memo_next_ = 0;
+  uint8_t nb_ok_[9] = {0};         // availability of the 3x3 CTBs around (and including) the current one, see avail_z
   // QP state (thread_context fields of the reference: decctx.h)
   bool is_cu_qp_delta_coded_ = false;
   int cu_qp_delta_val_ = 0;

@@ -165,7 +165,6 @@ struct PPS {
   int Log2MinCuQpDeltaSize = 0;
   std::vector<int> colBd, rowBd;            // tile boundaries in CTBs (size cols+1 / rows+1)
   std::vector<int> CtbAddrRStoTS, CtbAddrTStoRS, TileId /*by TS*/, TileIdRS;
-  std::vector<int> MinTbAddrZS;             // [x + y*min_tb_w]
 };
 
 struct SliceHeader {
