@@ -40,14 +40,16 @@ constexpr int Q_SHARED = ((Q_SHARED_TABLES + Q_TAB4_BYTES + 15) & ~15) + ((BIG_B
 constexpr int Q_SCRATCH = 512 + 512 + 272 + 8 + NG * 16 * 8; // wave-wide path: coefficients, intermediate, reference samples; 4x4 gather slots
 
 struct QLayout {
-  int wave_bytes;    // LDS per wave (picture)
+  int waves_per_pic; // W: waves working on one picture (1, 2, 4, 8), each on its own CTU rows
+  int pic_bytes;     // LDS per picture: the shared part (progress counters, sample lines) + W private parts
   int prog_ints;     // entries of one progress array (two arrays: luma chains, chroma chains)
-  int off_lines_l;   // from the wave's base: luma sample lines (one per row in flight) ...
+  int off_lines_l;   // from the picture's base: luma sample lines (one per row in flight) ...
   int line_l_bytes;
   int off_lines_c;   // ... and chroma sample lines (Cb then Cr)
   int line_c_bytes;
-  int off_scratch;
-  int off_groups;    // per row in flight: [luma chain: block map, CTU buffer][chroma chain: Cb, Cr CTU buffers]
+  int off_waves;     // from the picture's base: the waves' private parts
+  int wave_bytes;    // one private part: scratch, then the group buffers
+  int off_groups;    // from the private part's base, per row of the wave: [luma chain: block map, CTU buffer][chroma chain: Cb, Cr CTU buffers]
   int luma_bytes, chroma_bytes;
 };
 
@@ -105,7 +107,8 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = rfl(tid >> 6), NP = blockDim.x >> 6;
+  const int wave = rfl(tid >> 6), W = L.waves_per_pic, NP = (int)(blockDim.x >> 6) / W; // NP pictures x W waves
+  const int ps = wave / W, wi = wave - ps * W; // picture slot of the workgroup, wave of the picture
   constexpr int log2_ctb = LOG2_CTB, ctb = 1 << log2_ctb;
 
   // ---- workgroup-wide tables ----
@@ -169,6 +172,11 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
   }
   for (int i = tid; i < 1024; i += blockDim.x) big_coeff[i] = 0;
   if (tid == 0) *big_lock = 0;
+  // progress counters of the picture (shared by its waves: cleared before the barrier below)
+  if (wi == 0) {
+    int* const pr = reinterpret_cast<int*>(lds + Q_SHARED + (size_t)ps * L.pic_bytes);
+    for (int i = lane; i < 2 * L.prog_ints; i += 64) pr[i] = 0;
+  }
   __syncthreads();
   // 8-point inverse DCT basis (fallback-dct.cc:592-733: M[j][i] = dct[(32 / 8) j][i]) as pairs of consecutive inputs j
   for (int t = tid; t < 32; t += blockDim.x) {
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
     w8[t] = ((uint32_t)(uint16_t)(int16_t)dct[(4 * (2 * k)) * 32 + i]) | ((uint32_t)(uint16_t)(int16_t)dct[(4 * (2 * k + 1)) * 32 + i] << 16);
   }
   __syncthreads();
-  const int pic_index = blockIdx.x * NP + wave;
+  const int pic_index = blockIdx.x * NP + ps;
   if (pic_index >= n_pics) return;
 
   const hm_dev_pic dp = pics[pic_index];
@@ -196,17 +204,19 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
   const int planeWc = dp.width >> 1, planeHc = dp.height / sh;
   const int Wc = ctb_w * cw_c;
   const bool mono = dp.chroma_format == 0;
-  const int NR = mono ? 4 : 2; // CTU rows in flight
+  const int NR = mono ? 4 : 2; // CTU rows in flight per wave
+  const int NRT = NR * W;      // ... per picture (a power of two): row r is worked on by wave (r / NR) % W
 
-  // ---- this wave's LDS ----
-  uint8_t* const wbase = lds + Q_SHARED + (size_t)wave * L.wave_bytes;
-  int* const progress = reinterpret_cast<int*>(wbase); // [2][prog_ints]: finished CTUs of every row, per chain kind
-  uint8_t* const lines_l = wbase + L.off_lines_l;
-  uint8_t* const lines_c = wbase + L.off_lines_c;
-  int16_t* const l_coeff = reinterpret_cast<int16_t*>(wbase + L.off_scratch);
+  // ---- the picture's shared LDS and this wave's private part ----
+  uint8_t* const pbase = lds + Q_SHARED + (size_t)ps * L.pic_bytes;
+  uint8_t* const wbase = pbase + L.off_waves + (size_t)wi * L.wave_bytes;
+  int* const progress = reinterpret_cast<int*>(pbase); // [2][prog_ints]: finished CTUs of every row, per chain kind
+  uint8_t* const lines_l = pbase + L.off_lines_l;
+  uint8_t* const lines_c = pbase + L.off_lines_c;
+  int16_t* const l_coeff = reinterpret_cast<int16_t*>(wbase);
   int16_t* const l_tmp = l_coeff + 256;
   int16_t* const l_bA = l_tmp + 256;
-  uint64_t* const q_slots = reinterpret_cast<uint64_t*>(wbase + L.off_scratch + 512 + 512 + 272 + 8); // [NG][16] (tag << 32 | coefficient)
+  uint64_t* const q_slots = reinterpret_cast<uint64_t*>(wbase + 512 + 512 + 272 + 8); // [NG][16] (tag << 32 | coefficient)
   // group -> (chain kind, row slot): luma / chroma of two rows, or luma of four rows (monochrome)
   auto group_kind = [&](int gg) { return mono ? 0 : (gg & 1); };
   auto group_slot = [&](int gg) { return mono ? gg : (gg >> 1); };
@@ -225,7 +235,6 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
     uint8_t* p = kind ? lines_c + (size_t)slot * L.line_c_bytes : lines_l + (size_t)slot * L.line_l_bytes;
     return reinterpret_cast<Pix*>(p) + 4;
   };
-  for (int i = lane; i < 2 * L.prog_ints; i += 64) progress[i] = 0;
   for (int i = lane; i < 256; i += 64) l_coeff[i] = 0;
   for (int i = lane; i < NG * 16; i += 64) q_slots[i] = 0; // tag 0 is never used by a step
 
@@ -257,7 +266,7 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
   }
 
   // ---- group state (the same value in the 16 lanes of a group) ----
-  int row = group_slot(g), cx = 0, kleft = 0;
+  int row = wi * NR + group_slot(g), cx = 0, kleft = 0;
   int st = row < ctb_h ? ST_START : ST_DONE;
   int cb_flags = 0;
   uint32_t c0 = 0, c1 = 0, c2 = 0;         // header of the CTU to start next: first record of the chain, count, flags
@@ -314,7 +323,11 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
     bool started = false;
     if (st == ST_START) {
       const int need = cx + 2 < ctb_w ? cx + 2 : ctb_w;
-      const bool ok = row == 0 || my_progress[row > 0 ? row - 1 : 0] >= need;
+      // (the row above may belong to another wave of the workgroup: LDS serves the requests of a CU in order, so a
+      // counter value seen here means the line samples written before it are there; the atomic keeps the compiler
+      // from caching the counter, the fence from moving the sample reads above it)
+      const int done_above = __hip_atomic_load(my_progress + (row > 0 ? row - 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const bool ok = row == 0 || done_above >= need;
       if (ok) {
         kleft = (int)(c1 & 0xFFFF);
         cb_flags = (int)(c2 & 0xFF);
@@ -330,6 +343,10 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
     }
     if (__ballot(st != ST_DONE) == 0) break;
     const bool running = st == ST_RUN && kleft > 0;
+    if (W > 1) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+      if (__ballot(st == ST_RUN) == 0) __builtin_amdgcn_s_sleep(4); // every chain waits for another wave's row
+    }
 
     // fields of the current record, per group
     const int info = (int)((n0 >> 16) & 0xFF);
@@ -339,7 +356,7 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
     const unsigned long long s_big = __ballot(running && !quad);
 
     // the sample line of the row above (row 0 reads nothing from it)
-    const Pix* const lr = line_of(kind, (row + NR - 1) & (NR - 1));
+    const Pix* const lr = line_of(kind, (row + NRT - 1) & (NRT - 1));
 
     // ---- C: interior 4x4 blocks of all groups side by side, one sample per lane ----
 #if defined(HM_Q_PROBE) && (HM_Q_PROBE & 1)
@@ -460,7 +477,7 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
       Pix* const u1 = group_u(bg, 1);
       Pix* const u2 = group_u(bg, 2);
       uint16_t* const l_meta = group_meta(bg);
-      const Pix* const blr = line_of(group_kind(bg), (s_row + NR - 1) & (NR - 1));
+      const Pix* const blr = line_of(group_kind(bg), (s_row + NRT - 1) & (NRT - 1));
       const Pix* const top0 = blr + (s_cx << log2_ctb) - 1;
       const Pix* const top1 = blr + s_cx * cw_c - 1;
       const Pix* const top2 = blr + (Wc + 4) + s_cx * cw_c - 1;
@@ -558,7 +575,7 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
       const int src = fg * 16;
       const int s_row = __builtin_amdgcn_readlane(row, src), s_cx = __builtin_amdgcn_readlane(cx, src);
       const int fkind = group_kind(fg);
-      Pix* const lw = line_of(fkind, s_row & (NR - 1));
+      Pix* const lw = line_of(fkind, s_row & (NRT - 1));
       auto flush_plane = [&](auto bw_c, Pix* u, int P, Pix* line, uint8_t* plane, int pitch, int bh, int pw, int ph) {
         constexpr int BW = decltype(bw_c)::value;
         constexpr int PPW = 4 / sizeof(Pix), WPR = BW / PPW; // samples per 32-bit word, words per row
@@ -607,14 +624,16 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
         }
       }
       WAVE_SYNC();
-      if (lane == 0) progress[fkind * L.prog_ints + s_row] = s_cx + 1; // read by the chain of the row below (this wave: LDS traffic is in order)
+      // read by the chain of the row below - a group of this wave or of the next one (LDS traffic of a CU is in order)
+      if (W > 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+      if (lane == 0) __hip_atomic_store(progress + fkind * L.prog_ints + s_row, s_cx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       // the group's next CTU
       if (g == fg) {
         cx += 1;
         st = ST_START;
         if (cx == ctb_w) {
           cx = 0;
-          row += NR;
+          row += NRT;
           if (row < ctb_h) row_start();
           else st = ST_DONE;
         }
@@ -648,29 +667,53 @@ extern "C" int hm_launch_recon_quad(const hm_dev_pic* d_pics, int n_pics, int lo
   const int nr = mono ? 4 : 2;
   const int ch = chroma_format == 1 ? ctb / 2 : ctb;
   auto al = [](int v) { return (v + 15) & ~15; };
+  // Waves per picture.  A batch of many pictures (tile grids) keeps one wave per picture: every dependency stays inside
+  // a wave.  Few, large pictures (a single 1080p frame is 17 CTU rows of 64) would leave the machine empty - two rows
+  // in flight per picture - so W waves share a picture, wave w working on rows 2w, 2w+1, 2(w+W), ... and handing its
+  // bottom sample line to the next wave through LDS (the picture's waves sit in one workgroup).  W is limited by the
+  // wavefront itself (row r+1 stays two CTUs behind row r: at most ctb_w / 2 rows can be busy), by the rows there are,
+  // by 160 KiB of LDS for 2W full-width sample lines, and by the waves the other pictures of the batch already supply.
+  static const int force_w = [] { const char* e = getenv("HM_QUAD_WAVES"); return e ? atoi(e) : 0; }();
   QLayout L;
-  L.prog_ints = (max_ctb_h + 3) & ~3;
-  L.line_l_bytes = al((4 + max_ctb_w * ctb) * pb);
-  L.line_c_bytes = mono ? 0 : al((8 + 2 * max_ctb_w * (ctb / 2)) * pb);
-  L.off_lines_l = al(2 * L.prog_ints * 4);
-  L.off_lines_c = L.off_lines_l + nr * L.line_l_bytes;
-  L.off_scratch = L.off_lines_c + (mono ? 0 : nr * L.line_c_bytes);
-  L.off_groups = L.off_scratch + al(Q_SCRATCH);
-  L.luma_bytes = al(META_BYTES(ctb) + (ctb + UPAD) * ctb * pb);
-  L.chroma_bytes = mono ? 0 : al(2 * (ctb / 2 + UPAD) * ch * pb);
-  L.wave_bytes = al(L.off_groups + (mono ? 4 * L.luma_bytes : 2 * (L.luma_bytes + L.chroma_bytes)));
-  // pictures (waves) per workgroup: they only share the tables; the count that puts the most waves on a CU's 160 KiB
-  int np = 0, best = 0;
-  for (int k = 1; k <= 16; k++) {
-    const int bytes = Q_SHARED + k * L.wave_bytes;
-    if (bytes > 160 * 1024) break;
-    int per_cu = (160 * 1024 / bytes) * k;
-    if (per_cu > 16) per_cu = 16; // (the kernel needs up to 128 VGPRs: four waves per SIMD)
-    if (per_cu > best) { best = per_cu; np = k; }
+  int lds_bytes = 0, np = 0;
+  auto layout = [&](int W) {
+    const int nrt = nr * W;
+    L.waves_per_pic = W;
+    L.prog_ints = (max_ctb_h + 3) & ~3;
+    L.line_l_bytes = al((4 + max_ctb_w * ctb) * pb);
+    L.line_c_bytes = mono ? 0 : al((8 + 2 * max_ctb_w * (ctb / 2)) * pb);
+    L.off_lines_l = al(2 * L.prog_ints * 4);
+    L.off_lines_c = L.off_lines_l + nrt * L.line_l_bytes;
+    L.off_waves = L.off_lines_c + (mono ? 0 : nrt * L.line_c_bytes);
+    L.off_groups = al(Q_SCRATCH);
+    L.luma_bytes = al(META_BYTES(ctb) + (ctb + UPAD) * ctb * pb);
+    L.chroma_bytes = mono ? 0 : al(2 * (ctb / 2 + UPAD) * ch * pb);
+    L.wave_bytes = al(L.off_groups + (mono ? 4 * L.luma_bytes : 2 * (L.luma_bytes + L.chroma_bytes)));
+    L.pic_bytes = al(L.off_waves + W * L.wave_bytes);
+    // pictures per workgroup: they only share the tables; the count that puts the most waves on a CU's 160 KiB
+    np = 0;
+    int best = 0;
+    for (int k = 1; k * W <= 16; k++) {
+      const int bytes = Q_SHARED + k * L.pic_bytes;
+      if (bytes > 160 * 1024) break;
+      int per_cu = (160 * 1024 / bytes) * k * W;
+      if (per_cu > 16) per_cu = 16; // (the kernel needs up to 128 VGPRs: four waves per SIMD)
+      if (per_cu > best) { best = per_cu; np = k; }
+    }
+    if (np == 0) return false;
+    while (np > 1 && (long)np * 256 > n_pics) np--; // few pictures: spread them over the CUs first
+    lds_bytes = Q_SHARED + np * L.pic_bytes;
+    return true;
+  };
+  int W = 1;
+  if (force_w > 0) W = force_w;
+  else {
+    const int row_pairs = (max_ctb_h + nr - 1) / nr;             // W beyond this leaves waves without rows
+    const int front = max_ctb_w / (2 * nr) > 1 ? max_ctb_w / (2 * nr) : 1; // ... beyond this, rows that only wait
+    while (W < 8 && 2 * W <= row_pairs && 2 * W <= front && (long)n_pics * 2 * W <= 4096) W *= 2;
   }
-  if (np == 0) return 0;
-  while (np > 1 && (long)np * 256 > n_pics) np--; // few pictures: spread them over the CUs first
-  const int lds_bytes = Q_SHARED + np * L.wave_bytes;
+  while (W > 1 && !layout(W)) W /= 2;
+  if (!layout(W)) return 0;
   const void* fn = nullptr;
   switch (log2_ctb * 2 + (pb - 1)) {
     case 8: fn = reinterpret_cast<const void*>(k_recon_quad<uint8_t, 4>); break;
@@ -685,7 +728,7 @@ extern "C" int hm_launch_recon_quad(const hm_dev_pic* d_pics, int n_pics, int lo
   if (e != hipSuccess) return hm_check_hip(e, "hipFuncSetAttribute(k_recon_quad)");
   int a_n = n_pics;
   void* args[] = {(void*)&d_pics, &a_n, &L};
-  e = hipLaunchKernel(fn, dim3((n_pics + np - 1) / np), dim3(np * 64), args, lds_bytes, s);
+  e = hipLaunchKernel(fn, dim3((n_pics + np - 1) / np), dim3(np * W * 64), args, lds_bytes, s);
   if (e != hipSuccess) return hm_check_hip(e, "k_recon_quad launch");
   e = hipGetLastError();
   return e == hipSuccess ? 1 : hm_check_hip(e, "k_recon_quad launch");
