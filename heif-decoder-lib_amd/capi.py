@@ -75,6 +75,8 @@ def bind_decode(L):
     L.hm_batch_upload.argtypes = [C.c_void_p, C.c_void_p]
     L.hm_batch_execute.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.hm_batch_upload_execute.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.hm_batch_tail_fused.argtypes = [C.c_void_p]
+    L.hm_batch_tail_fused.restype = C.c_int
     L.hm_batch_set_colour.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.hm_batch_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.hm_batch_get_timings.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
@@ -143,6 +145,10 @@ class Batch:
         ms = (C.c_float * 4)()
         check(self.L.hm_batch_get_timings4(self.h, slot, ms))
         return [ms[0], ms[1], ms[2], ms[3]]
+
+    def tail_fused(self):
+        """True when the batch's executes run the fused tail kernel (timings4_ms: its time is in slot 2)"""
+        return bool(self.L.hm_batch_tail_fused(self.h))
 
     def algorithmic_bytes(self):
         a, b = C.c_uint64(), C.c_uint64()

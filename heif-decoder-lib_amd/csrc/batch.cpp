@@ -7,6 +7,7 @@
 // by decode_and_paste_tile_image, context.cc:2407-2539).  Tiles are independent coded pictures,
 // so they become the workgroups of one launch.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -102,6 +103,12 @@ struct hm_batch {
   std::vector<const void*> col_y, col_cb, col_cr;
   std::vector<void*> col_out;
   int colour_chunk = 0;
+  // fused tail (k_tail420: deblocking + SAO + paste + colour in one kernel) - decided at the first execute after
+  // hm_batch_set_colour / an upload: tail_state 0 = not decided, 1 = separate kernels, 2 = fused
+  int tail_state = 0;
+  int tail_bpp = 3;
+  int tail_coef[4] = {0, 0, 0, 0};
+  DeviceBuffer d_tail;
   hipStream_t copy_stream = nullptr;
   bool copy_inflight = false;
   hipStream_t last_stream = nullptr; // stream of the last upload / execute: drained before the arenas are released
@@ -128,6 +135,59 @@ struct hm_batch {
     for (hipEvent_t e : chunk_events) hipEventDestroy(e);
   }
 };
+
+
+// Can deblocking, SAO, paste and the attached colour conversion of this batch run as ONE kernel (filters.hip:
+// k_tail420)?  Yes for the mainstream shape: one class of 8-bit 4:2:0 pictures without rare syntax, each one slice
+// without HEVC tiles, 16-sample-aligned widths and paste positions, no conformance-window offset, no range rescale, the
+// images' canvases fully covered by their pictures, and the integer matrix chain to RGB24 / RGBA32.  The canvases are
+// then never written: the attached conversion's output is the batch's result.  HM_TAIL_FUSED=0 keeps the separate
+// kernels (A/B measurements).
+struct TailDstHost { uint8_t* rgb; int32_t pitch; int32_t pad; };
+static int decide_tail(hm_batch* b)
+{
+  b->tail_state = 1;
+  static const bool off = [] { const char* e = std::getenv("HM_TAIL_FUSED"); return e && e[0] == '0'; }();
+  if (off || !b->colour || b->colour_chunk < 0 || b->classes.size() != 1) return HM_OK;
+  const Class& c = b->classes[0];
+  const hm_colour_desc& d = b->colour_desc;
+  if (c.bit_depth != 8 || c.chroma_format != 1 || c.rare) return HM_OK;
+  if (hm_colour_pipeline(&d) != HM_PIPE_INT420 || (d.out_format != HM_OUT_RGB && d.out_format != HM_OUT_RGBA)) return HM_OK;
+  const int bpp = hm_out_bytes_per_pixel(d.out_format);
+  const int n = (int)c.items.size(), n_img = (int)b->col_y.size();
+  if (n_img <= 0 || n % n_img || (d.out_stride % 16)) return HM_OK;
+  const int per_img = n / n_img;
+  std::vector<TailDstHost> t((size_t)n);
+  for (int img = 0; img < n_img; img++) {
+    if ((uintptr_t)b->col_out[img] % 16) return HM_OK;
+    long covered = 0;
+    for (int k = img * per_img; k < (img + 1) * per_img; k++) {
+      if (c.items[k] != k) return HM_OK;
+      const Item& it = b->items[k];
+      const hm_pic& h = it.hdr;
+      const hm_dev_pic& dp = b->h_desc[c.desc_offset + k];
+      if (h.n_slices != 1 || (h.flags & HM_PIC_TILES) || (h.width % 16) || h.crop_left || h.crop_top || dp.rescale) return HM_OK;
+      if (it.dest.plane[0] != b->col_y[img] || it.dest.plane[1] != b->col_cb[img] || it.dest.plane[2] != b->col_cr[img]) return HM_OK;
+      if (it.dest.canvas_width != d.width || it.dest.canvas_height != d.height) return HM_OK;
+      if ((it.dest.x0 % 16) || (it.dest.y0 % 2)) return HM_OK;
+      covered += (long)dp.copy_w[0] * dp.copy_h[0];
+      t[k].rgb = (uint8_t*)b->col_out[img] + (size_t)it.dest.y0 * d.out_stride + (size_t)it.dest.x0 * bpp;
+      t[k].pitch = d.out_stride;
+      t[k].pad = 0;
+    }
+    if (covered != (long)d.width * d.height) return HM_OK; // (pictures of a grid do not overlap)
+  }
+  int rc = b->d_tail.ensure(sizeof(TailDstHost) * (size_t)n);
+  if (rc) return rc;
+  const hipError_t e = hipMemcpy(b->d_tail.p, t.data(), sizeof(TailDstHost) * (size_t)n, hipMemcpyHostToDevice);
+  if (e != hipSuccess) return hm_check_hip(e, "hipMemcpy(tail destinations)");
+  float cf[4];
+  hm_ycbcr_coefficients(d.has_nclx, d.matrix, d.primaries, cf);
+  for (int i = 0; i < 4; i++) b->tail_coef[i] = (int)std::lround(256 * cf[i]); // yuv2rgb.cc:336-339
+  b->tail_bpp = bpp;
+  b->tail_state = 2;
+  return HM_OK;
+}
 
 extern "C" {
 
@@ -194,6 +254,7 @@ static int batch_prepare(hm_batch* b, size_t* blob_bytes_out)
   const int n = (int)b->items.size();
   b->drain(); // descriptors and buffers of an earlier upload may still be in use
   b->uploaded = false;
+  b->tail_state = 0;
   b->classes.clear();
   b->h_desc.assign(n, hm_dev_pic());
   *blob_bytes_out = 0;
@@ -390,6 +451,13 @@ int hm_batch_execute(hm_batch* b, int stages, void* stream)
     int rc = launch_recon(dc, n, c, s);
     if (rc) return rc;
     mark(0);
+    if (b->tail_state == 0 && (rc = decide_tail(b))) return rc;
+    if (b->tail_state == 2) { // one kernel for everything behind the reconstruction (timeline: the SAO + paste slot)
+      if ((rc = hm_launch_tail420(dc, b->d_tail.p, n, c.max_w, c.max_h, b->tail_bpp, b->tail_coef, stages, s))) return rc;
+      mark(2);
+      b->exec_count++;
+      return HM_OK;
+    }
     int chunk = b->colour_chunk;
     if (chunk <= 0) chunk = n_img;
     for (int i0 = 0; i0 < n_img; i0 += chunk) {
@@ -494,6 +562,7 @@ int hm_batch_set_colour(hm_batch* b, const hm_colour_desc* d, int n_images, cons
 {
   if (!b) return hm_fail(HM_ERR_INVALID_ARG, "null batch");
   b->colour = false;
+  b->tail_state = 0;
   b->col_y.clear(); b->col_cb.clear(); b->col_cr.clear(); b->col_out.clear();
   if (n_images == 0) return HM_OK;
   if (!d || n_images < 0 || !d_y || !d_cb || !d_cr || !d_out) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
@@ -507,6 +576,10 @@ int hm_batch_set_colour(hm_batch* b, const hm_colour_desc* d, int n_images, cons
   b->colour = true;
   return HM_OK;
 }
+
+// 1 when the last execute ran the fused tail kernel (deblocking + SAO + paste + colour; its time is reported in the
+// SAO + paste slot of hm_batch_get_timings4, the deblocking and colour slots are 0)
+int hm_batch_tail_fused(const hm_batch* b) { return b && b->tail_state == 2 ? 1 : 0; }
 
 int hm_batch_set_profiling(hm_batch* b, int slots)
 {

@@ -22,6 +22,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "hm_device.h"
 #include "hm_internal.h"
@@ -185,30 +186,18 @@ __device__ __forceinline__ int unit_bs(const hm_dev_pic& dp, int x, int y, int v
 // One launch = every picture of the batch class.  blockIdx.y = picture; an item is one window of one plane.
 // PCMF: the variant for pictures of the rare-syntax classes, which also follows the reference's "pcmf" branches
 // and knows 4:4:4.
+// Edge parameters of one window (plane c, crossing kx, ky in units of 8 plane samples): beta / tc of the two units of
+// its vertical and of its horizontal edge, and which sides may be modified.  Returns false when the window holds no
+// edge to filter.
+template <bool PCMF>
+struct WindowEdges {
+  int betaV[2] = {0, 0}, tcV[2] = {0, 0}, betaH[2] = {0, 0}, tcH[2] = {0, 0};
+  bool mpV[2] = {true, true}, mqV[2] = {true, true}, mpH[2] = {true, true}, mqH[2] = {true, true};
+};
 template <typename Pix, bool PCMF>
-__global__ __launch_bounds__(256, sizeof(Pix) == 1 ? 8 : 6) void k_deblock(const hm_dev_pic* __restrict__ pics)
+__device__ __forceinline__ bool window_edges(const hm_dev_pic& dp, const PicView& v, int c, int kx, int ky, int sw, int sh, WindowEdges<PCMF>& E)
 {
-  const hm_dev_pic& dp = pics[blockIdx.y];
-  if (!(dp.flags & HM_PIC_DEBLOCK_ANY)) return;
-  const PicView v = view(dp);
-  const int bd = dp.bit_depth, maxv = (1 << bd) - 1, bdscale = 1 << (bd - 8);
-  int item = blockIdx.x * 256 + threadIdx.x;
-  const int nwx = (dp.width >> 3) + 1, nwy = (dp.height >> 3) + 1; // picture sizes are multiples of 8 (minimum coding block)
-  const int nL = nwx * nwy;
-  int c = 0, sw = 1, sh = 1, cwx = 0;
-  if (item >= nL) { // chroma windows: the same structure in chroma samples
-    if (dp.chroma_format == 0) return;
-    sw = (PCMF && dp.chroma_format == 3) ? 1 : 2; sh = dp.chroma_format == 1 ? 2 : 1;
-    const int Wc = dp.width / sw, Hc = dp.height / sh; // multiples of 4
-    cwx = ((Wc + 7) >> 3) + 1;
-    const int nC = cwx * (((Hc + 7) >> 3) + 1);
-    item -= nL;
-    if (item >= 2 * nC) return;
-    c = item >= nC ? 2 : 1;
-    item -= (c - 1) * nC;
-  }
-  const int wxn = c ? cwx : nwx;
-  const int ky = item / wxn, kx = item - ky * wxn;
+  const int bd = dp.bit_depth, bdscale = 1 << (bd - 8);
   const int PW = dp.width / sw, PH = dp.height / sh;                  // plane size
   const int ex = kx << 3, ey = ky << 3, ox = ex - 4, oy = ey - 4;   // the crossing and the window origin (plane samples)
   // the four edge units: vertical edge x = ex, rows oy.. (j = 0) and ey.. (j = 1); horizontal edge y = ey, columns ox.. / ex..
@@ -223,14 +212,12 @@ __global__ __launch_bounds__(256, sizeof(Pix) == 1 ? 8 : 6) void k_deblock(const
     if (ox >= 0) bsH[0] = unit_bs(dp, ox * sw, ey * sh, 0);
     if (ex < PW) bsH[1] = unit_bs(dp, ex * sw, ey * sh, 0);
   }
-  if (!(bsV[0] | bsV[1] | bsH[0] | bsH[1])) return;
+  if (!(bsV[0] | bsV[1] | bsH[0] | bsH[1])) return false;
 
   // ---- parameters per unit ----
   // Luma (deblock.cc:731-753): QP, beta and the slice offsets of an 8-sample edge SEGMENT come from its first unit; the
   // upper / left unit of the window is the second unit of the segment before the crossing.
   // Chroma (deblock.cc:1650-1716): the slice offsets come from the segment's first unit, QpC from the unit itself.
-  int betaV[2] = {0, 0}, tcV[2] = {0, 0}, betaH[2] = {0, 0}, tcH[2] = {0, 0};
-  bool mpV[2] = {true, true}, mqV[2] = {true, true}, mpH[2] = {true, true}, mqH[2] = {true, true};
   const int qp_off = c == 0 ? 0 : (c == 1 ? dp.cb_qp_offset : dp.cr_qp_offset);
   auto unit_params = [&](int vertical, int j, int bs, int& beta, int& tc, bool& mod_p, bool& mod_q) {
     if (!bs) return;
@@ -283,29 +270,74 @@ __global__ __launch_bounds__(256, sizeof(Pix) == 1 ? 8 : 6) void k_deblock(const
   };
 #pragma unroll
   for (int j = 0; j < 2; j++) {
-    unit_params(1, j, c == 0 ? bsV[j] : (bsV[j] == 2 ? 2 : 0), betaV[j], tcV[j], mpV[j], mqV[j]);
-    unit_params(0, j, c == 0 ? bsH[j] : (bsH[j] == 2 ? 2 : 0), betaH[j], tcH[j], mpH[j], mqH[j]);
+    unit_params(1, j, c == 0 ? bsV[j] : (bsV[j] == 2 ? 2 : 0), E.betaV[j], E.tcV[j], E.mpV[j], E.mqV[j]);
+    unit_params(0, j, c == 0 ? bsH[j] : (bsH[j] == 2 ? 2 : 0), E.betaH[j], E.tcH[j], E.mpH[j], E.mqH[j]);
   }
-
-  // ---- the window ----
-  uint8_t* plane = dp.plane[c];
-  const int pitch = dp.pitch[c];
-  Window<Pix> win;
-  // rows outside the picture are clamped (their units have bS 0 and are not stored); columns left of / right of the
-  // picture are read as they lie in memory (inside the batch's allocation, never used) and not stored
+  return true;
+}
+// the window's samples, as they lie in the plane: rows outside the picture are clamped (their units have bS 0 and are
+// not stored); columns left of / right of the picture are read as they lie in memory (inside the batch's allocation,
+// never used) and not stored
+template <typename Pix>
+__device__ __forceinline__ void window_load(Window<Pix>& win, const uint8_t* plane, int pitch, int ox, int oy, int PH)
+{
 #pragma unroll
   for (int r = 0; r < 8; r++) {
     const int y = oy + r < 0 ? 0 : (oy + r < PH ? oy + r : PH - 1);
     __builtin_memcpy(win.w[r], plane + (size_t)y * pitch + (ptrdiff_t)ox * (int)sizeof(Pix), 8 * sizeof(Pix));
   }
+}
+template <typename Pix, bool PCMF>
+__device__ __forceinline__ void window_filter(Window<Pix>& win, int c, const WindowEdges<PCMF>& E, int maxv)
+{
   if (c == 0) {
-    filter_luma<true>(win, betaV, tcV, maxv, mpV, mqV);
-    filter_luma<false>(win, betaH, tcH, maxv, mpH, mqH);
+    filter_luma<true>(win, E.betaV, E.tcV, maxv, E.mpV, E.mqV);
+    filter_luma<false>(win, E.betaH, E.tcH, maxv, E.mpH, E.mqH);
   }
   else {
-    filter_chroma<true>(win, tcV, maxv, mpV, mqV);
-    filter_chroma<false>(win, tcH, maxv, mpH, mqH);
+    filter_chroma<true>(win, E.tcV, maxv, E.mpV, E.mqV);
+    filter_chroma<false>(win, E.tcH, maxv, E.mpH, E.mqH);
   }
+}
+
+// One launch = every picture of the batch class.  blockIdx.y = picture; an item is one window of one plane.
+// PCMF: the variant for pictures of the rare-syntax classes, which also follows the reference's "pcmf" branches
+// and knows 4:4:4.
+template <typename Pix, bool PCMF>
+__global__ __launch_bounds__(256, sizeof(Pix) == 1 ? 8 : 6) void k_deblock(const hm_dev_pic* __restrict__ pics)
+{
+  const hm_dev_pic& dp = pics[blockIdx.y];
+  if (!(dp.flags & HM_PIC_DEBLOCK_ANY)) return;
+  const PicView v = view(dp);
+  const int bd = dp.bit_depth, maxv = (1 << bd) - 1;
+  int item = blockIdx.x * 256 + threadIdx.x;
+  const int nwx = (dp.width >> 3) + 1, nwy = (dp.height >> 3) + 1; // picture sizes are multiples of 8 (minimum coding block)
+  const int nL = nwx * nwy;
+  int c = 0, sw = 1, sh = 1, cwx = 0;
+  if (item >= nL) { // chroma windows: the same structure in chroma samples
+    if (dp.chroma_format == 0) return;
+    sw = (PCMF && dp.chroma_format == 3) ? 1 : 2; sh = dp.chroma_format == 1 ? 2 : 1;
+    const int Wc = dp.width / sw, Hc = dp.height / sh; // multiples of 4
+    cwx = ((Wc + 7) >> 3) + 1;
+    const int nC = cwx * (((Hc + 7) >> 3) + 1);
+    item -= nL;
+    if (item >= 2 * nC) return;
+    c = item >= nC ? 2 : 1;
+    item -= (c - 1) * nC;
+  }
+  const int wxn = c ? cwx : nwx;
+  const int ky = item / wxn, kx = item - ky * wxn;
+  WindowEdges<PCMF> E;
+  if (!window_edges<Pix, PCMF>(dp, v, c, kx, ky, sw, sh, E)) return;
+  const int PW = dp.width / sw, PH = dp.height / sh;
+  const int ex = kx << 3, ox = ex - 4, oy = (ky << 3) - 4;
+
+  // ---- the window ----
+  uint8_t* plane = dp.plane[c];
+  const int pitch = dp.pitch[c];
+  Window<Pix> win;
+  window_load(win, plane, pitch, ox, oy, PH);
+  window_filter<Pix, PCMF>(win, c, E, maxv);
   const bool left_ok = ox >= 0, right_ok = ex < PW;
 #pragma unroll
   for (int r = 0; r < 8; r++) {
@@ -650,6 +682,194 @@ __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict_
   }
 }
 
+
+// ---- fused tail: deblocking + SAO + paste + YCbCr 4:2:0 -> RGB in one pass ------------------------------------------
+// For the mainstream class (8-bit 4:2:0, one slice, no tiles, no rare syntax, integer colour chain of
+// Op_YCbCr420_to_RGB24 / _RGB32, yuv2rgb.cc:306-366, 416-495) the three kernels above and the colour kernel collapse
+// into one: the reconstruction is read once (1.5 B/px), the interleaved pixels are written once (3 B/px); the
+// deblocked planes, the YCbCr canvas and their re-reads (6 B/px of the 10.5 B/px the separate kernels move after
+// k_recon) never exist in HBM.  Same arithmetic: the device functions of k_deblock and k_sao_paste.
+//   * a workgroup owns a 128 x 64 luma tile of the picture's copy region.  Phase 1: one lane per shifted 8x8 deblocking
+//     window (17 x 9 luma + 2 x 9 x 5 chroma = 243 of 256 lanes) - the windows are independent of each other, so the
+//     tile's border windows are simply computed by both neighbours (20 % of the luma windows; their source samples come
+//     from L2) - filtered in registers and stored into the LDS tile (luma 72 x 144 B, chroma 2 x 40 x 80 B);
+//   * phase 2: one lane per 16 x 2 luma samples and their 8 Cb / 8 Cr samples: SAO on sample pairs with the rows read
+//     from LDS (no dependent trip to HBM), integer matrix, 48 / 64 B of pixels per row straight to the output image at
+//     the picture's paste position (cropped at the copy region).
+struct TailDst { uint8_t* rgb; int32_t pitch; int32_t pad; };
+struct TailCoef { int r_cr, g_cb, g_cr, b_cb; };
+constexpr int TAIL_TW = 128, TAIL_TH = 64;
+constexpr int TAIL_XO = 8;                   // the LDS tiles start 8 samples left of the tile, 4 rows above it
+constexpr int TAIL_LP = 144, TAIL_LR = 72;   // luma tile: pitch, rows
+constexpr int TAIL_CP = 80, TAIL_CR = 40;    // chroma tiles
+
+// a group of 8 samples of LDS tile row `row` (already clamped into the picture) at tile column xo, with its side dwords
+__device__ __forceinline__ void tail_row(SaoRow<uint8_t>& R, const uint8_t* tile, int pitch, int row, int xo)
+{
+  const uint8_t* q = tile + row * pitch + xo;
+  uint32_t d[2];
+  __builtin_memcpy(d, q, 8);
+  R.p[0] = __builtin_amdgcn_perm(0, d[0], 0x0c010c00u); R.p[1] = __builtin_amdgcn_perm(0, d[0], 0x0c030c02u);
+  R.p[2] = __builtin_amdgcn_perm(0, d[1], 0x0c010c00u); R.p[3] = __builtin_amdgcn_perm(0, d[1], 0x0c030c02u);
+  __builtin_memcpy(&R.l, q - 4, 4); // (the tile starts 8 columns left of x0: always inside it; used only where a left neighbour exists)
+  __builtin_memcpy(&R.r, q + 8, 4);
+}
+// SAO of NR rows of one 8-sample group of plane c (the fast path of k_sao_paste: one slice, no tiles, no lossless units)
+template <int NR>
+__device__ __forceinline__ void tail_sao(const hm_dev_pic& dp, const PicView& v, int c, const uint8_t* tile, int pitch, int tx0, int ty0,
+                                         int xs, int yy0, int W, int Hh, int l2w, int l2h, int apply_sao, uint32_t (&res)[NR][4])
+{
+  SaoRow<uint8_t> rows[NR + 2];
+#pragma unroll
+  for (int r = 0; r < NR + 2; r++) {
+    const int y = yy0 - 1 + r;
+    tail_row(rows[r], tile, pitch, (y < 0 ? 0 : (y < Hh ? y : Hh - 1)) - ty0, xs - tx0);
+  }
+  const int cx = xs >> l2w;
+#pragma unroll
+  for (int r = 0; r < NR; r++) {
+    const int yy = yy0 + r, yc = yy < Hh ? yy : Hh - 1, cy = yy >> l2h;
+    const uint32_t* cbq = reinterpret_cast<const uint32_t*>(v.ctbs + (cx + (yc >> l2h) * dp.ctb_w)); // hm_ctb as dwords
+    const uint32_t cflags = cbq[2], s0 = cbq[3 + 2 * c], s1 = cbq[4 + 2 * c];
+    const SaoRow<uint8_t>&up = rows[r], &cur = rows[r + 1], &dn = rows[r + 2];
+    const bool sao_on = apply_sao && (dp.flags & HM_PIC_SAO_ENABLED) && (cflags & (c == 0 ? HM_CTB_SAO_LUMA : HM_CTB_SAO_CHROMA));
+    const int type = sao_on ? (int)(s0 & 0xFF) : 0;
+    const uint32_t offs = (s0 >> 24) | (s1 << 8);
+    const uint32_t nbm = c == 0 ? (cflags >> 8) & 0xFF : (cflags >> 16) & 0xFF;
+    const uint32_t maxv2 = 0x00FF00FFu;
+#pragma unroll
+    for (int j = 0; j < 4; j++) res[r][j] = cur.p[j];
+    if (type == 1) { // band offset (fallback-postfilter.h:218-241)
+      const uint32_t bp = (s0 >> 16) & 0xFF;
+      const uint32_t biased = offs ^ 0x80808080u;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        u16x2 bi = (as_u(cur.p[j]) >> (u16x2)(3)) - (u16x2)(bp);
+        bi = __builtin_elementwise_min(bi & (u16x2)(31), (u16x2)(4));
+        res[r][j] = pk_apply(cur.p[j], as_w(bi) | 0x0c000c00u, 0x80u, biased, maxv2);
+      }
+    }
+    else if (type == 2) {
+      const int cl = (s0 >> 8) & 0xFF;
+      if (cl == 0) sao_edge_group<uint8_t, -1, 0>(xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv2, up, cur, dn, res[r]);
+      else if (cl == 1) sao_edge_group<uint8_t, 0, -1>(xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv2, up, cur, dn, res[r]);
+      else if (cl == 2) sao_edge_group<uint8_t, -1, -1>(xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv2, up, cur, dn, res[r]);
+      else sao_edge_group<uint8_t, 1, -1>(xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv2, up, cur, dn, res[r]);
+    }
+  }
+}
+
+template <int BPP, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_tail420(const hm_dev_pic* __restrict__ pics, const TailDst* __restrict__ dsts, int tiles_x, int stages, TailCoef k)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t s_all[TAIL_LR * TAIL_LP + 2 * TAIL_CR * TAIL_CP];
+  uint8_t* const s_l = s_all;
+  uint8_t* const s_c0 = s_all + TAIL_LR * TAIL_LP;
+  uint8_t* const s_c1 = s_c0 + TAIL_CR * TAIL_CP;
+  const hm_dev_pic& dp = pics[blockIdx.y];
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int x0 = tx * TAIL_TW, y0 = ty * TAIL_TH; // luma origin of the tile (source = destination coordinates: no crop offset)
+  const int cw = dp.copy_w[0], chh = dp.copy_h[0];
+  if (x0 >= cw || y0 >= chh) return; // (the whole workgroup)
+  const PicView v = view(dp);
+  const int tid = threadIdx.x;
+  const int W = dp.width, H = dp.height;
+
+  // ---- phase 1: deblocked samples of the tile (+ 4 around it) into LDS, one lane per window ----
+  // (measured against a coalesced 16-byte-per-lane copy of the tile into LDS followed by in-place window filtering
+  //  there: 10.2 / 19.3 ms without / with the filters instead of 7.6 / 15.8 ms - the eight independent row loads per lane
+  //  of this version keep more bytes in flight, and a second barrier costs more than the narrower loads)
+  {
+    int c = -1, kxl = 0, kyl = 0;
+    if (tid < 153) { c = 0; kyl = tid / 17; kxl = tid - kyl * 17; }
+    else if (tid < 243) {
+      int t = tid - 153;
+      c = t >= 45 ? 2 : 1;
+      t -= (c - 1) * 45;
+      kyl = t / 9; kxl = t - kyl * 9;
+    }
+    if (c >= 0) {
+      const int sw = c ? 2 : 1;
+      const int PW = W / sw, PH = H / sw;
+      const int kx = (c ? 8 * tx : 16 * tx) + kxl, ky = (c ? 4 * ty : 8 * ty) + kyl;
+      if (kx <= ((PW + 7) >> 3) && ky <= ((PH + 7) >> 3)) {
+        Window<uint8_t> win;
+        const int ox = (kx << 3) - 4, oy = (ky << 3) - 4;
+        if (ox >= 0) window_load(win, dp.plane[c], dp.pitch[c], ox, oy, PH);
+        else { // left picture border: the window's left half does not exist (k_deblock never loads the corner window)
+#pragma unroll
+          for (int r = 0; r < 8; r++) {
+            const int y = oy + r < 0 ? 0 : (oy + r < PH ? oy + r : PH - 1);
+            win.w[r][0] = 0;
+            __builtin_memcpy(&win.w[r][1], dp.plane[c] + (size_t)y * dp.pitch[c], 4);
+          }
+        }
+        if ((stages & 1) && (dp.flags & HM_PIC_DEBLOCK_ANY)) {
+          WindowEdges<false> E;
+          if (window_edges<uint8_t, false>(dp, v, c, kx, ky, sw, sw, E) && !(stages & 4)) window_filter<uint8_t, false>(win, c, E, 255);
+        }
+        uint8_t* const t0 = c == 0 ? s_l : (c == 1 ? s_c0 : s_c1);
+        const int tp = c == 0 ? TAIL_LP : TAIL_CP;
+        uint8_t* q = t0 + (8 * kyl) * tp + 8 * kxl + (TAIL_XO - 4);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          *reinterpret_cast<uint32_t*>(q + r * tp) = win.w[r][0];
+          *reinterpret_cast<uint32_t*>(q + r * tp + 4) = win.w[r][1];
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: SAO + matrix + store, one lane = 16 x 2 luma samples ----
+  const int gx = tid & 7, rp = tid >> 3;
+  const int lx = x0 + 16 * gx, ly = y0 + 2 * rp;
+  if (lx >= cw || ly >= chh) return;
+  const int l2 = dp.log2_ctb;
+  uint32_t ry[2][2][4], rcb[1][4], rcr[1][4];
+  tail_sao<2>(dp, v, 0, s_l, TAIL_LP, x0 - TAIL_XO, y0 - 4, lx, ly, W, H, l2, l2, stages & 2, ry[0]);
+  tail_sao<2>(dp, v, 0, s_l, TAIL_LP, x0 - TAIL_XO, y0 - 4, lx + 8, ly, W, H, l2, l2, stages & 2, ry[1]);
+  tail_sao<1>(dp, v, 1, s_c0, TAIL_CP, (x0 >> 1) - TAIL_XO, (y0 >> 1) - 4, lx >> 1, ly >> 1, W >> 1, H >> 1, l2 - 1, l2 - 1, stages & 2, rcb);
+  tail_sao<1>(dp, v, 2, s_c1, TAIL_CP, (x0 >> 1) - TAIL_XO, (y0 >> 1) - 4, lx >> 1, ly >> 1, W >> 1, H >> 1, l2 - 1, l2 - 1, stages & 2, rcr);
+
+  const TailDst D = dsts[blockIdx.y];
+  uint8_t b0[16 * BPP], b1[16 * BPP];
+#pragma unroll
+  for (int c = 0; c < 8; c++) {
+    const int u = (int)((rcb[0][c >> 1] >> (16 * (c & 1))) & 0xFF) - 128;
+    const int w = (int)((rcr[0][c >> 1] >> (16 * (c & 1))) & 0xFF) - 128;
+    const int rt = (k.r_cr * w + 128) >> 8;               // yuv2rgb.cc:359
+    const int gt = (k.g_cb * u + k.g_cr * w + 128) >> 8;  // :360
+    const int bt = (k.b_cb * u + 128) >> 8;               // :361
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++) {
+      const int p = 2 * c + s2, g2 = p >> 3, q = p & 7;
+      const int ya = (int)((ry[g2][0][q >> 1] >> (16 * (q & 1))) & 0xFF), yb = (int)((ry[g2][1][q >> 1] >> (16 * (q & 1))) & 0xFF);
+      b0[BPP * p + 0] = (uint8_t)clip3i(0, 255, ya + rt); b0[BPP * p + 1] = (uint8_t)clip3i(0, 255, ya + gt); b0[BPP * p + 2] = (uint8_t)clip3i(0, 255, ya + bt);
+      b1[BPP * p + 0] = (uint8_t)clip3i(0, 255, yb + rt); b1[BPP * p + 1] = (uint8_t)clip3i(0, 255, yb + gt); b1[BPP * p + 2] = (uint8_t)clip3i(0, 255, yb + bt);
+      if (BPP == 4) { b0[BPP * p + 3] = 0xFF; b1[BPP * p + 3] = 0xFF; }
+    }
+  }
+  uint8_t* o0 = D.rgb + (size_t)ly * D.pitch + (size_t)lx * BPP;
+  const int nvalid = cw - lx < 16 ? cw - lx : 16;
+  if (nvalid == 16) {
+    __builtin_memcpy(o0, b0, 16 * BPP);
+    if (ly + 1 < chh) __builtin_memcpy(o0 + D.pitch, b1, 16 * BPP);
+  }
+  else {
+#pragma unroll
+    for (int p = 0; p < 16; p++) {
+      if (p < nvalid) {
+#pragma unroll
+        for (int i = 0; i < BPP; i++) {
+          o0[BPP * p + i] = b0[BPP * p + i];
+          if (ly + 1 < chh) o0[D.pitch + BPP * p + i] = b1[BPP * p + i];
+        }
+      }
+    }
+  }
+}
+
 } // namespace
 
 extern "C" int hm_launch_deblock(const hm_dev_pic* d_pics, int n_pics, int max_w4, int max_h4, int chroma_format,
@@ -691,4 +911,21 @@ extern "C" int hm_launch_sao_paste(const hm_dev_pic* d_pics, int n_pics, int max
     else hipLaunchKernelGGL((k_sao_paste<uint8_t, false>), grid, dim3(256), 0, s, d_pics, apply_sao);
   }
   return hm_check_hip(hipGetLastError(), "k_sao_paste launch");
+}
+
+// Fused tail (k_tail420): n pictures of one class (8-bit 4:2:0, no rare syntax), output d_dsts[i] (device array of
+// {pointer, pitch} at the picture's paste position), bpp 3 / 4, integer matrix coefficients of yuv2rgb.cc:336-339.
+extern "C" int hm_launch_tail420(const hm_dev_pic* d_pics, const void* d_dsts, int n_pics, int max_w, int max_h, int bpp, const int coef[4],
+                                 int stages, hipStream_t s)
+{
+  if (n_pics <= 0) return HM_OK;
+  const int tiles_x = (max_w + TAIL_TW - 1) / TAIL_TW, tiles_y = (max_h + TAIL_TH - 1) / TAIL_TH;
+  const dim3 grid(tiles_x * tiles_y, n_pics);
+  const TailCoef k{coef[0], coef[1], coef[2], coef[3]};
+  const TailDst* dd = (const TailDst*)d_dsts;
+  // (105 VGPRs: four waves per SIMD; tighter register budgets spill and were measured slower: 15.5 / 17.3 / 21.7 ms
+  //  at 96 / 80 / 64 VGPRs against 15.7 ms)
+  if (bpp == 3) hipLaunchKernelGGL((k_tail420<3, 4>), grid, dim3(256), 0, s, d_pics, dd, tiles_x, stages, k);
+  else hipLaunchKernelGGL((k_tail420<4, 4>), grid, dim3(256), 0, s, d_pics, dd, tiles_x, stages, k);
+  return hm_check_hip(hipGetLastError(), "k_tail420 launch");
 }

@@ -52,6 +52,9 @@ int hm_launch_deblock(const struct hm_dev_pic* d_pics, int n_pics, int max_w4, i
                       int bit_depth, int rare_syntax, hipStream_t s);
 int hm_launch_sao_paste(const struct hm_dev_pic* d_pics, int n_pics, int max_w, int max_h, int bit_depth, int apply_sao,
                         int rare_syntax, hipStream_t s);
+// filters.hip: deblocking + SAO + paste + integer 4:2:0 colour chain in one kernel (8-bit 4:2:0, no rare syntax)
+int hm_launch_tail420(const struct hm_dev_pic* d_pics, const void* d_dsts, int n_pics, int max_w, int max_h, int bpp, const int coef[4],
+                      int stages, hipStream_t s);
 
 #ifdef __cplusplus
 }

@@ -32,6 +32,13 @@
 
 namespace {
 
+// -DHM_MARKS: named markers in the assembly (tools: static instruction counts per phase of the loop)
+#ifdef HM_MARKS
+#define HM_MARK(name) asm volatile("s_nop 0 ; HMMARK " name)
+#else
+#define HM_MARK(name)
+#endif
+
 constexpr int NG = 4;                       // groups per wave
 constexpr int Q_W8_BYTES = 8 * 4 * 4;       // 8-point basis as int16 pairs: [output index][pair of input indices]
 constexpr int Q_SHARED_TABLES = 1024 + 256 + Q_W8_BYTES; // dct basis, small tables (as recon.hip), 8-point pairs
@@ -318,6 +325,7 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
   restart = 0;
 
   for (;;) {
+    HM_MARK("A_begin");
     tag++;
     // ---- A: start the next CTU of every group whose dependency is met (the row above two CTUs ahead) ----
     bool started = false;
@@ -358,6 +366,7 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
     // the sample line of the row above (row 0 reads nothing from it)
     const Pix* const lr = line_of(kind, (row + NRT - 1) & (NRT - 1));
 
+    HM_MARK("C_begin");
     // ---- C: interior 4x4 blocks of all groups side by side, one sample per lane ----
 #if defined(HM_Q_PROBE) && (HM_Q_PROBE & 1)
     if (false) {
@@ -459,6 +468,7 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
     }
     WAVE_SYNC();
 
+    HM_MARK("D_begin");
     // ---- D: every other block, wave-wide, one group after the other ----
 #if defined(HM_Q_PROBE) && (HM_Q_PROBE & 2)
     for (unsigned long long todo = 0; todo;) {
@@ -510,11 +520,13 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
       if (lane >= 16) bpre = (cbf && lane < B.n_coeff) ? coeffs[coeff_first + lane] : 0u;
       else if (!(cbf && lane < B.n_coeff)) bpre = 0u;
 
+      HM_MARK("D_setup_end");
       auto block = [&](auto l2c) { // block size as a compile-time constant: fixed trip counts, shifts and masks
         constexpr int L2 = decltype(l2c)::value;
         int ln = lane;
         asm volatile("" : "+v"(ln));
         const bool smoothed = L2 != 2 && B.c == 0 && ((filter_mode_mask(L2) >> B.mode) & 1);
+#if !defined(HM_Q_PROBE) || !(HM_Q_PROBE & 4)
         if (L2 <= 3 && !smoothed && is_interior<L2>(B.avail, B.info)) {
           predict<Pix, L2>(B, direct_refs<Pix, L2>(B), tab, ln); // one lane pass: cheaper to address the samples in place
         }
@@ -523,8 +535,14 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
           WAVE_SYNC();
           predict<Pix, L2>(B, RefArray{l_bA + 64}, tab, ln);
         }
+#endif
         WAVE_SYNC();
+        HM_MARK("D_pred_end");
+#if defined(HM_Q_PROBE) && (HM_Q_PROBE & 8)
+        if (false) {
+#else
         if (cbf) {
+#endif
           if (L2 == 5) { // take the workgroup's 32x32 staging
             if (lane == 0)
               while (__hip_atomic_exchange(big_lock, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) __builtin_amdgcn_s_sleep(2);
@@ -538,6 +556,7 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
           else residual_add<Pix, L2>(B, l_coeff, l_tmp, dct, tab, coeffs + coeff_first, bpre, ln, strong, B.c);
           WAVE_SYNC();
         }
+        HM_MARK("D_resid_end");
         if (B.c == 0) { // deblocking metadata (deblock.cc:31-62): transform edges + QpY
           constexpr int n4 = 1 << (L2 - 2);
           if (ln < n4 * n4) {
@@ -549,6 +568,10 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
           }
         }
       };
+#if defined(HM_Q_PROBE) && (HM_Q_PROBE & 16)
+      if (true) { asm volatile("" :: "v"(bpre), "v"(B.u), "v"(B.top), "v"(B.P), "v"(B.x0), "v"(B.aBL), "s"(B.mode)); }
+      else
+#endif
       if (B.log2 == 2) block(std::integral_constant<int, 2>());
       else if (B.log2 == 3) block(std::integral_constant<int, 3>());
       else if (B.log2 == 4) block(std::integral_constant<int, 4>());
@@ -556,6 +579,7 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
       WAVE_SYNC();
     }
 
+    HM_MARK("E_begin");
     // ---- E: the groups that executed a block move to the next record ----
     if (running) {
       n0 = m0; n1 = m1; n2 = m2; n3 = m3;
@@ -568,6 +592,7 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
     }
     const bool advanced = running;
 
+    HM_MARK("F_begin");
     // ---- F: finished CTUs: coalesced stores to the picture, bottom row -> line, right column -> left column ----
     for (unsigned long long fin = __ballot(st == ST_RUN && kleft == 0); fin;) {
       const int fg = rfl((int)(__builtin_ctzll(fin) >> 4));
@@ -639,6 +664,7 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
         }
       }
     }
+    HM_MARK("G_begin");
     // ---- G: the in-flight stage, requested by every lane (no condition around the loads): groups that moved on ask for
     //      the next record and for the levels of the block three ahead; the others ask again for what they hold ----
     {

@@ -154,8 +154,12 @@ HM_API int  hm_batch_execute(hm_batch* b, int stages, void* stream);
 /* Attach the YCbCr -> RGB conversion of the images' canvases to the batch (convert_colorspace of the decoded grids,
  * context.cc:1516-1600): one hm_batch_execute is then the whole hot path.  images_per_group > 0 runs the filters and the
  * conversion group of images by group of images (Infinity-Cache blocking; measured not to pay for 12 MP grids, see
- * batch.cpp), 0 = one group.  The pictures must have been queued image by image, equally many per image; arrays of
- * n_images device pointers (copied).  n_images 0 detaches. */
+ * batch.cpp), 0 = one group, < 0 = one group and never the fused kernel described below.  The pictures must have been queued image by image, equally many per image; arrays of
+ * n_images device pointers (copied).  n_images 0 detaches.
+ * With a conversion attached the batch's result is the conversion's output; the canvases are an intermediate that the
+ * batch may skip: for the mainstream shape (8-bit 4:2:0 pictures of one slice, canvases fully covered, integer matrix
+ * chain to RGB24 / RGBA32) deblocking, SAO, paste and conversion run as ONE kernel that reads the reconstruction once
+ * and writes the pixels once (filters.hip: k_tail420) and the canvases are not written.  hm_batch_tail_fused tells. */
 HM_API int  hm_batch_set_colour(hm_batch* b, const hm_colour_desc* d, int n_images, const void* const* d_y, const void* const* d_cb,
                                 const void* const* d_cr, void* const* d_out, int images_per_group);
 /* hm_batch_upload + hm_batch_execute in one call, the command streams split into `chunks` parts: the H2D copy of part
@@ -169,6 +173,8 @@ HM_API int  hm_batch_set_profiling(hm_batch* b, int slots);
 HM_API int  hm_batch_get_timings(hm_batch* b, int slot, float ms[3]);
 /* the same plus [3] the colour conversion attached with hm_batch_set_colour (summed over the groups of images) */
 HM_API int  hm_batch_get_timings4(hm_batch* b, int slot, float ms[4]);
+/* 1 when the executes of this batch run the fused tail kernel: its time is reported in slot [2], [1] and [3] are 0 */
+HM_API int  hm_batch_tail_fused(const hm_batch* b);
 /* algorithmic bytes of the queued pictures: command streams read, reconstructed samples written */
 HM_API int  hm_batch_algorithmic_bytes(const hm_batch* b, uint64_t* stream_bytes, uint64_t* sample_bytes);
 

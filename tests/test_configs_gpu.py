@@ -99,3 +99,37 @@ def test_config3_batch_of_12mp_grids(pkg, hm):
     # image sharding over ranks: the ranks' images are exactly these (bench.py --gpus N decodes images [rank B, rank B + B))
     sh = pkg.shard
     assert [list(sh.image_shard(1024, r, 8))[0] for r in range(8)] == [128 * r for r in range(8)]
+
+
+@pytest.mark.parametrize("shape", [(8, 6, 4032, 3024), (3, 2, 1500, 1000), (2, 2, 1001, 999), (2, 2, 1024, 1024), (1, 1, 512, 512)],
+                         ids=["12mp_crop64x48", "crop_not_16_aligned", "odd_canvas", "no_crop", "single_tile"])
+@pytest.mark.parametrize("stages", [3, 1, 2, 0], ids=["deblock+sao", "deblock", "sao", "none"])
+def test_fused_tail_equals_separate_kernels(pkg, hm, shape, stages):
+    """hm_batch_set_colour: the fused kernel (deblocking + SAO + paste + colour, filters.hip k_tail420) against the four
+    separate kernels on the same batch - 3 images of different tiles, every filter-stage combination, canvases cropped
+    at 16-aligned and unaligned widths; the 12 MP shape is also checked against the CPU flow."""
+    import bench
+    import orc
+    import torch
+    cols, rows, w, h = shape
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    n_images = 3
+    made = list(bench.make_streams(pkg.capi, (7700000 + 31 * k for k in range(n_images * cols * rows))))
+    out = []
+    for group in (0, -1):  # 0: fused where possible, -1: never
+        gb = bench.GridBatch(pkg, dev, cols, rows, 512, w, h)
+        for j in range(n_images):
+            gb.add_image([b for _, b in made[j * cols * rows:(j + 1) * cols * rows]])
+        gb.finish(st, group)
+        gb.batch.execute(stages, st)
+        torch.cuda.synchronize()
+        assert gb.batch.tail_fused() == (group == 0)
+        out.append([im["rgb"].cpu().numpy()[:h, :w * 3].copy() for im in gb.images])
+        gb.batch.close()
+    for j in range(n_images):
+        assert np.array_equal(out[0][j], out[1][j]), f"image {j}: fused tail differs from the separate kernels"
+    if shape[2] == 4032 and stages == 3:
+        tiles = made[:cols * rows]
+        exp = bench.cpu_grid_image([d for d, _ in tiles], [b for _, b in tiles], cols, rows, 512, w, h, (gb.ys, gb.cs, gb.os), orc.have_ref())
+        assert np.array_equal(out[0][0], exp[:h, :w * 3])
