@@ -194,8 +194,26 @@ struct WindowEdges {
   int betaV[2] = {0, 0}, tcV[2] = {0, 0}, betaH[2] = {0, 0}, tcH[2] = {0, 0};
   bool mpV[2] = {true, true}, mqV[2] = {true, true}, mpH[2] = {true, true}, mqH[2] = {true, true};
 };
-template <typename Pix, bool PCMF>
-__device__ __forceinline__ bool window_edges(const hm_dev_pic& dp, const PicView& v, int c, int kx, int ky, int sw, int sh, WindowEdges<PCMF>& E)
+// beta / tc tables (Table 8-12): from constant memory (k_deblock) or from a copy in LDS (k_tail420: no trip to memory
+// on the window's dependency chain)
+struct TabConst {
+  __device__ __forceinline__ int beta(int i) const { return c_beta[i]; }
+  __device__ __forceinline__ int tc(int i) const { return c_tc[i]; }
+};
+struct TabLds {
+  const uint8_t* t; // [0, 52) beta, [52, 106) tc
+  __device__ __forceinline__ int beta(int i) const { return t[i]; }
+  __device__ __forceinline__ int tc(int i) const { return t[52 + i]; }
+};
+// block-map word of the 4x4 block at luma position (x, y), coordinates clamped into the map (callers ignore the value
+// where the position was outside)
+__device__ __forceinline__ uint32_t meta_at(const hm_dev_pic& dp, int x, int y)
+{
+  const int bx = x < 0 ? 0 : ((x >> 2) < dp.w4 ? (x >> 2) : dp.w4 - 1), by = y < 0 ? 0 : ((y >> 2) < dp.h4 ? (y >> 2) : dp.h4 - 1);
+  return dp.meta[bx + (size_t)by * dp.w4];
+}
+template <typename Pix, bool PCMF, typename Tab>
+__device__ __forceinline__ bool window_edges(const hm_dev_pic& dp, const PicView& v, int c, int kx, int ky, int sw, int sh, WindowEdges<PCMF>& E, const Tab& tab)
 {
   const int bd = dp.bit_depth, bdscale = 1 << (bd - 8);
   const int PW = dp.width / sw, PH = dp.height / sh;                  // plane size
@@ -203,14 +221,29 @@ __device__ __forceinline__ bool window_edges(const hm_dev_pic& dp, const PicView
   // the four edge units: vertical edge x = ex, rows oy.. (j = 0) and ey.. (j = 1); horizontal edge y = ey, columns ox.. / ex..
   // (positions passed to the block map are luma positions)
   const bool in_x = ex > 0 && ex < PW, in_y = ey > 0 && ey < PH;
+  // Every block-map word the window can need is requested before anything is decided (one round trip instead of a
+  // chain of three: edge flags -> QpY -> ...): the words of the four units, and the words holding QpY of the Q / P side
+  // of each unit's parameters (luma: at the start of the unit's 8-sample edge segment, chroma: at the unit itself).
+  const uint32_t mA = meta_at(dp, ex * sw, oy * sh), mB = meta_at(dp, ex * sw, ey * sh), mC = meta_at(dp, ox * sw, ey * sh);
+  int qq[2][2], qp[2][2]; // [vertical][j]: QpY on the Q side / on the P side
+#pragma unroll
+  for (int vertical = 0; vertical < 2; vertical++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int ux = vertical ? ex : (j ? ex : ox), uy = vertical ? (j ? ey : oy) : ey;               // the unit
+      const int sx = vertical ? ex : (j ? ex : ex - 8), sy = vertical ? (j ? ey : ey - 8) : ey;       // its segment's start
+      const int px = (c == 0 ? sx : ux) * sw, py = (c == 0 ? sy : uy) * sh;
+      qq[vertical][j] = (int)(int8_t)(meta_at(dp, px, py) >> 8);
+      qp[vertical][j] = (int)(int8_t)(meta_at(dp, vertical ? px - 1 : px, vertical ? py : py - 1) >> 8);
+    }
   int bsV[2] = {0, 0}, bsH[2] = {0, 0};
   if (in_x) {
-    if (oy >= 0) bsV[0] = unit_bs(dp, ex * sw, oy * sh, 1);
-    if (ey < PH) bsV[1] = unit_bs(dp, ex * sw, ey * sh, 1);
+    if (oy >= 0 && oy < PH) bsV[0] = (mA & 1) ? 2 : 0;
+    if (ey < PH) bsV[1] = (mB & 1) ? 2 : 0;
   }
   if (in_y) {
-    if (ox >= 0) bsH[0] = unit_bs(dp, ox * sw, ey * sh, 0);
-    if (ex < PW) bsH[1] = unit_bs(dp, ex * sw, ey * sh, 0);
+    if (ox >= 0 && ox < PW) bsH[0] = (mC & 2) ? 2 : 0;
+    if (ex < PW) bsH[1] = (mB & 2) ? 2 : 0;
   }
   if (!(bsV[0] | bsV[1] | bsH[0] | bsH[1])) return false;
 
@@ -227,19 +260,16 @@ __device__ __forceinline__ bool window_edges(const hm_dev_pic& dp, const PicView
     const int lsx = sx * sw, lsy = sy * sh, lux = ux * sw, luy = uy * sh;
     // one slice (the usual case): no CTB -> slice look-up, and the offsets come through the scalar cache
     const hm_slice& sl = dp.n_slices == 1 ? v.slices[0] : slice_at(dp, v, lsx, lsy);
+    const int QP_Q = qq[vertical][j], QP_P = qp[vertical][j];
     if (c == 0) {
-      const int QP_Q = qpy_at(dp, lsx, lsy);
-      const int QP_P = vertical ? qpy_at(dp, lsx - 1, lsy) : qpy_at(dp, lsx, lsy - 1);
       const int qPL = (QP_Q + QP_P + 1) >> 1;
-      beta = c_beta[clip3i(0, 51, qPL + sl.beta_offset_div2 * 2)] * bdscale;
-      tc = c_tc[clip3i(0, 53, qPL + 2 * (bs - 1) + sl.tc_offset_div2 * 2)] * bdscale;
+      beta = tab.beta(clip3i(0, 51, qPL + sl.beta_offset_div2 * 2)) * bdscale;
+      tc = tab.tc(clip3i(0, 53, qPL + 2 * (bs - 1) + sl.tc_offset_div2 * 2)) * bdscale;
     }
     else {
-      const int QP_Q = qpy_at(dp, lux, luy);
-      const int QP_P = vertical ? qpy_at(dp, lux - 1, luy) : qpy_at(dp, lux, luy - 1);
       const int qPi = ((QP_Q + QP_P + 1) >> 1) + qp_off;
       const int QP_C = dp.chroma_format == 1 ? chroma_qp_map(qPi) : (qPi < 51 ? qPi : 51);
-      tc = c_tc[clip3i(0, 53, QP_C + 2 + sl.tc_offset_div2 * 2)] * bdscale;
+      tc = tab.tc(clip3i(0, 53, QP_C + 2 + sl.tc_offset_div2 * 2)) * bdscale;
     }
     if (PCMF && (dp.flags & HM_PIC_PCMF)) {
       if (c == 0) {
@@ -270,8 +300,8 @@ __device__ __forceinline__ bool window_edges(const hm_dev_pic& dp, const PicView
   };
 #pragma unroll
   for (int j = 0; j < 2; j++) {
-    unit_params(1, j, c == 0 ? bsV[j] : (bsV[j] == 2 ? 2 : 0), E.betaV[j], E.tcV[j], E.mpV[j], E.mqV[j]);
-    unit_params(0, j, c == 0 ? bsH[j] : (bsH[j] == 2 ? 2 : 0), E.betaH[j], E.tcH[j], E.mpH[j], E.mqH[j]);
+    unit_params(1, j, bsV[j], E.betaV[j], E.tcV[j], E.mpV[j], E.mqV[j]);
+    unit_params(0, j, bsH[j], E.betaH[j], E.tcH[j], E.mpH[j], E.mqH[j]);
   }
   return true;
 }
@@ -328,7 +358,7 @@ __global__ __launch_bounds__(256, sizeof(Pix) == 1 ? 8 : 6) void k_deblock(const
   const int wxn = c ? cwx : nwx;
   const int ky = item / wxn, kx = item - ky * wxn;
   WindowEdges<PCMF> E;
-  if (!window_edges<Pix, PCMF>(dp, v, c, kx, ky, sw, sh, E)) return;
+  if (!window_edges<Pix, PCMF>(dp, v, c, kx, ky, sw, sh, E, TabConst())) return;
   const int PW = dp.width / sw, PH = dp.height / sh;
   const int ex = kx << 3, ox = ex - 4, oy = (ky << 3) - 4;
 
@@ -774,6 +804,9 @@ __global__ __launch_bounds__(256, MINW) void k_tail420(const hm_dev_pic* __restr
   const PicView v = view(dp);
   const int tid = threadIdx.x;
   const int W = dp.width, H = dp.height;
+  __shared__ uint8_t s_tab[112];
+  if (tid < 106) s_tab[tid] = tid < 52 ? c_beta[tid] : c_tc[tid - 52];
+  __syncthreads(); // (all waves have only just started: cheap)
 
   // ---- phase 1: deblocked samples of the tile (+ 4 around it) into LDS, one lane per window ----
   // (measured against a coalesced 16-byte-per-lane copy of the tile into LDS followed by in-place window filtering
@@ -806,7 +839,7 @@ __global__ __launch_bounds__(256, MINW) void k_tail420(const hm_dev_pic* __restr
         }
         if ((stages & 1) && (dp.flags & HM_PIC_DEBLOCK_ANY)) {
           WindowEdges<false> E;
-          if (window_edges<uint8_t, false>(dp, v, c, kx, ky, sw, sw, E) && !(stages & 4)) window_filter<uint8_t, false>(win, c, E, 255);
+          if (window_edges<uint8_t, false>(dp, v, c, kx, ky, sw, sw, E, TabLds{s_tab})) window_filter<uint8_t, false>(win, c, E, 255);
         }
         uint8_t* const t0 = c == 0 ? s_l : (c == 1 ? s_c0 : s_c1);
         const int tp = c == 0 ? TAIL_LP : TAIL_CP;
