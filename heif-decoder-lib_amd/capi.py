@@ -9,7 +9,9 @@ LIB_PATH = os.path.join(_HERE, "libheif_mi355x.so")
 
 HM_CHROMA_420, HM_CHROMA_422, HM_CHROMA_444 = 1, 2, 3
 HM_OUT_RGB, HM_OUT_RGBA, HM_OUT_RRGGBB_BE, HM_OUT_RRGGBB_LE = 10, 11, 12, 14
-HM_PIPE_INT420, HM_PIPE_FLOAT = 1, 2
+HM_OUT_RRGGBBAA_BE, HM_OUT_RRGGBBAA_LE = 13, 15
+HM_PIPE_INT420, HM_PIPE_FLOAT, HM_PIPE_BILINEAR_FLOAT, HM_PIPE_TO_HDR_FLOAT, HM_PIPE_MONO = 1, 2, 3, 4, 5
+HM_PIPE_SDR_INT420, HM_PIPE_FLOAT_SDR, HM_PIPE_FLOAT_HDR = 6, 7, 8
 
 
 class HmError(RuntimeError):
@@ -21,7 +23,7 @@ class HmError(RuntimeError):
 class ColourDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "width", "height", "bit_depth", "chroma", "has_nclx", "matrix", "primaries",
-        "full_range", "out_format", "y_stride", "cb_stride", "cr_stride", "out_stride", "chroma_upsampling")]
+        "full_range", "out_format", "y_stride", "cb_stride", "cr_stride", "out_stride", "chroma_upsampling", "has_alpha")]
 
 
 _lib = None

@@ -228,8 +228,11 @@ struct heif_error heif_decode_image(const struct heif_image_handle* in, struct h
   if (opt) {
     prm.ignore_transformations = opt->ignore_transformations;
     if (opt->version >= 3) prm.strict_decoding = opt->strict_decoding; // heif.cc:1100-1103
-    if (opt->version >= 2 && opt->convert_hdr_to_8bit && in->info.bit_depth > 8)
-      return err(heif_error_Unsupported_feature, heif_suberror_Unsupported_color_conversion, "convert_hdr_to_8bit needs the reference's bit-depth ops (hdr_sdr.cc), not on the GPU path yet");
+    // convert_hdr_to_8bit (heif.cc:1105, context.cc:1550): output_bpp = 8 for convert_colorspace().  Of the targets this
+    // API offers it changes nothing: no conversion runs for a native (undefined / YCbCr) target ("TODO: check BPP
+    // changed", context.cc:1551), interleaved RGB / RGBA are 8 bit whatever is asked, and RRGGBB[AA] targets are "> 8
+    // bit, 10 if the request says 8 or less" (colorconversion.cc:566-585).  Accepted and carried for the record.
+    if (opt->version >= 2) prm.convert_hdr_to_8bit = opt->convert_hdr_to_8bit;
     if (opt->decoder_id && std::strcmp(opt->decoder_id, "mi355x") != 0)
       return err(heif_error_Unsupported_feature, heif_suberror_Unsupported_codec, "this build only carries the 'mi355x' HEVC decoder");
     // bilinear only when the caller insists: otherwise the cheaper nearest-neighbour ops win the pipeline search
@@ -242,7 +245,8 @@ struct heif_error heif_decode_image(const struct heif_image_handle* in, struct h
   if (colorspace == heif_colorspace_RGB) {
     switch (chroma) {
       case heif_chroma_interleaved_RGB: case heif_chroma_interleaved_RGBA:
-      case heif_chroma_interleaved_RRGGBB_BE: case heif_chroma_interleaved_RRGGBB_LE: out_format = (int)chroma; break;
+      case heif_chroma_interleaved_RRGGBB_BE: case heif_chroma_interleaved_RRGGBB_LE:
+      case heif_chroma_interleaved_RRGGBBAA_BE: case heif_chroma_interleaved_RRGGBBAA_LE: out_format = (int)chroma; break;
       default: return err(heif_error_Unsupported_feature, heif_suberror_Unsupported_color_conversion, "only interleaved RGB targets are on the GPU path");
     }
   }

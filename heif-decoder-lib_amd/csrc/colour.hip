@@ -199,9 +199,14 @@ struct FloatParams {
   int mode;            // 0 float matrix, 1 GBR copy, 2 GBR limited->full, 3 YCgCo
   int limited;         // !full_range (mode 0)
   int shiftH, shiftV;
+  // the op that follows the float op when the target's sample depth differs from the image's (the reference's pipeline
+  // search, oracle/pipeline_search.py): 1 = Op_to_sdr_planes (hdr_sdr.cc:176-195: v >> s1), 2 = Op_to_hdr_planes
+  // (hdr_sdr.cc:84-103: (v << s1) | (v >> s2))
+  int post, s1, s2;
+  int alpha_fill;      // alpha word of RRGGBBAA outputs of an image without alpha: (1 << bits) - 1 (rgb2rgb.cc:254-263)
 };
 
-enum { OF_RGB24 = 0, OF_RGBA32 = 1, OF_RRGGBB_BE = 2, OF_RRGGBB_LE = 3 };
+enum { OF_RGB24 = 0, OF_RGBA32 = 1, OF_RRGGBB_BE = 2, OF_RRGGBB_LE = 3, OF_RRGGBBAA_BE = 4, OF_RRGGBBAA_LE = 5 };
 
 __device__ __forceinline__ void px_float(const FloatParams& p, int Yv, int U, int V, int& r, int& g, int& b)
 {
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(256) void k_ycbcr_float(
     int groups_per_row, int total_groups)
 {
   constexpr int N = sizeof(Pix) == 1 ? 16 : 8;
-  constexpr int OBPP = OF == OF_RGB24 ? 3 : (OF == OF_RGBA32 ? 4 : 6);
+  constexpr int OBPP = OF == OF_RGB24 ? 3 : (OF == OF_RGBA32 ? 4 : ((OF == OF_RRGGBB_BE || OF == OF_RRGGBB_LE) ? 6 : 8));
   const int gid = blockIdx.x * 256 + threadIdx.x;
   if (gid >= total_groups) return;
   const int py = gid / groups_per_row;
@@ -302,6 +307,8 @@ __global__ __launch_bounds__(256) void k_ycbcr_float(
   for (int i = 0; i < N; i++) {
     int r, gg, b;
     px_float(p, yv[i], uu[i], vv[i], r, gg, b);
+    if (p.post == 1) { r >>= p.s1; gg >>= p.s1; b >>= p.s1; }
+    else if (p.post == 2) { r = (r << p.s1) | (r >> p.s2); gg = (gg << p.s1) | (gg >> p.s2); b = (b << p.s1) | (b >> p.s2); }
     if (OF == OF_RGB24) { ob[3 * i] = (uint8_t)r; ob[3 * i + 1] = (uint8_t)gg; ob[3 * i + 2] = (uint8_t)b; }
     else if (OF == OF_RGBA32) { ob[4 * i] = (uint8_t)r; ob[4 * i + 1] = (uint8_t)gg; ob[4 * i + 2] = (uint8_t)b; ob[4 * i + 3] = 0xFF; }
     else if (OF == OF_RRGGBB_BE) { // rgb2rgb.cc:250-268
@@ -309,10 +316,18 @@ __global__ __launch_bounds__(256) void k_ycbcr_float(
       ob[6 * i + 2] = (uint8_t)(gg >> 8); ob[6 * i + 3] = (uint8_t)gg;
       ob[6 * i + 4] = (uint8_t)(b >> 8); ob[6 * i + 5] = (uint8_t)b;
     }
-    else { // + rgb2rgb.cc:721-726
+    else if (OF == OF_RRGGBB_LE) { // + rgb2rgb.cc:721-726
       ob[6 * i + 1] = (uint8_t)(r >> 8); ob[6 * i + 0] = (uint8_t)r;
       ob[6 * i + 3] = (uint8_t)(gg >> 8); ob[6 * i + 2] = (uint8_t)gg;
       ob[6 * i + 5] = (uint8_t)(b >> 8); ob[6 * i + 4] = (uint8_t)b;
+    }
+    else { // RRGGBBAA: the alpha word of an image without alpha plane (an alpha plane is written over it afterwards)
+      constexpr int hi = OF == OF_RRGGBBAA_BE ? 0 : 1, lo = 1 - hi;
+      const int a = p.alpha_fill;
+      ob[8 * i + hi] = (uint8_t)(r >> 8); ob[8 * i + lo] = (uint8_t)r;
+      ob[8 * i + 2 + hi] = (uint8_t)(gg >> 8); ob[8 * i + 2 + lo] = (uint8_t)gg;
+      ob[8 * i + 4 + hi] = (uint8_t)(b >> 8); ob[8 * i + 4 + lo] = (uint8_t)b;
+      ob[8 * i + 6 + hi] = (uint8_t)(a >> 8); ob[8 * i + 6 + lo] = (uint8_t)a;
     }
   }
 
@@ -465,14 +480,76 @@ extern "C" int hm_launch_colour_float(const hm_colour_desc* d, const float coef[
   p.limited = d->has_nclx ? !d->full_range : 0;
   p.shiftH = d->chroma == HM_CHROMA_444 ? 0 : 1;
   p.shiftV = d->chroma == HM_CHROMA_420 ? 1 : 0;
+  const bool out8 = d->out_format == HM_OUT_RGB || d->out_format == HM_OUT_RGBA;
+  // the float op works at the image's depth; a target of another depth adds the reference's depth op (10 bits for a
+  // 16-bit interleaved target of an 8-bit image: colorconversion.cc:575-585)
+  const int out_bits = out8 ? 8 : (d->bit_depth > 8 ? d->bit_depth : 10);
+  p.post = 0; p.s1 = p.s2 = 0;
+  if (out8 && d->bit_depth > 8) { p.post = 1; p.s1 = d->bit_depth - 8; }
+  else if (!out8 && d->bit_depth == 8) { p.post = 2; p.s1 = out_bits - 8; p.s2 = 16 - out_bits; }
+  p.alpha_fill = (1 << out_bits) - 1;
   if (d->bit_depth == 8) {
-    if (d->out_format == HM_OUT_RGB) return launch_float<uint8_t, OF_RGB24>(d, p, y, cb, cr, out, s);
-    if (d->out_format == HM_OUT_RGBA) return launch_float<uint8_t, OF_RGBA32>(d, p, y, cb, cr, out, s);
-    return HM_ERR_UNSUPPORTED;
+    switch (d->out_format) {
+      case HM_OUT_RGB: return launch_float<uint8_t, OF_RGB24>(d, p, y, cb, cr, out, s);
+      case HM_OUT_RGBA: return launch_float<uint8_t, OF_RGBA32>(d, p, y, cb, cr, out, s);
+      case HM_OUT_RRGGBB_BE: return launch_float<uint8_t, OF_RRGGBB_BE>(d, p, y, cb, cr, out, s);
+      case HM_OUT_RRGGBB_LE: return launch_float<uint8_t, OF_RRGGBB_LE>(d, p, y, cb, cr, out, s);
+      case HM_OUT_RRGGBBAA_BE: return launch_float<uint8_t, OF_RRGGBBAA_BE>(d, p, y, cb, cr, out, s);
+      case HM_OUT_RRGGBBAA_LE: return launch_float<uint8_t, OF_RRGGBBAA_LE>(d, p, y, cb, cr, out, s);
+      default: return HM_ERR_UNSUPPORTED;
+    }
   }
-  if (d->out_format == HM_OUT_RRGGBB_BE) return launch_float<uint16_t, OF_RRGGBB_BE>(d, p, y, cb, cr, out, s);
-  if (d->out_format == HM_OUT_RRGGBB_LE) return launch_float<uint16_t, OF_RRGGBB_LE>(d, p, y, cb, cr, out, s);
-  return HM_ERR_UNSUPPORTED;
+  switch (d->out_format) {
+    case HM_OUT_RGB: return launch_float<uint16_t, OF_RGB24>(d, p, y, cb, cr, out, s);
+    case HM_OUT_RGBA: return launch_float<uint16_t, OF_RGBA32>(d, p, y, cb, cr, out, s);
+    case HM_OUT_RRGGBB_BE: return launch_float<uint16_t, OF_RRGGBB_BE>(d, p, y, cb, cr, out, s);
+    case HM_OUT_RRGGBB_LE: return launch_float<uint16_t, OF_RRGGBB_LE>(d, p, y, cb, cr, out, s);
+    case HM_OUT_RRGGBBAA_BE: return launch_float<uint16_t, OF_RRGGBBAA_BE>(d, p, y, cb, cr, out, s);
+    case HM_OUT_RRGGBBAA_LE: return launch_float<uint16_t, OF_RRGGBBAA_LE>(d, p, y, cb, cr, out, s);
+    default: return HM_ERR_UNSUPPORTED;
+  }
+}
+
+// Op_to_sdr_planes (hdr_sdr.cc:176-195) for one plane deeper than 8 bits: out = in >> (bits - 8), 8-bit storage
+namespace {
+__global__ __launch_bounds__(256) void k_to_sdr(const uint16_t* __restrict__ in, int is, uint8_t* __restrict__ out, int os, int w, int h, int shift)
+{
+  const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= w || y >= h) return;
+  for (int k = 0; k < 4 && x + k < w; k++) out[(size_t)y * os + x + k] = (uint8_t)(in[(size_t)y * is + x + k] >> shift);
+}
+// the alpha word of RRGGBBAA pixels from the image's alpha plane: HDR planes as they are (rgb2rgb.cc:254-263), 8-bit
+// planes through Op_to_hdr_planes first (expand != 0: (a << s1) | (a >> s2))
+template <typename A>
+__global__ __launch_bounds__(256) void k_set_alpha16(uint8_t* __restrict__ out, int os, int w, int h, const A* __restrict__ alpha, int as,
+                                                     int big_endian, int s1, int s2)
+{
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= w || y >= h) return;
+  int a = alpha[(size_t)y * as + x];
+  if (sizeof(A) == 1) a = (a << s1) | (a >> s2);
+  uint8_t* o = out + (size_t)y * os + 8 * (size_t)x + 6;
+  o[big_endian ? 0 : 1] = (uint8_t)(a >> 8);
+  o[big_endian ? 1 : 0] = (uint8_t)a;
+}
+} // namespace
+extern "C" int hm_launch_to_sdr(const void* in, int in_stride, void* out, int out_stride, int w, int h, int in_bits, hipStream_t s)
+{
+  if (w <= 0 || h <= 0) return HM_OK;
+  const dim3 grid((w + 255) / 256, (h + 3) / 4), block(256);
+  hipLaunchKernelGGL(k_to_sdr, grid, block, 0, s, (const uint16_t*)in, in_stride / 2, (uint8_t*)out, out_stride, w, h, in_bits - 8);
+  return hm_check_hip(hipGetLastError(), "k_to_sdr launch");
+}
+extern "C" int hm_launch_set_alpha16(void* out, int out_stride, int w, int h, const void* alpha, int alpha_stride, int alpha_bits, int out_bits,
+                                     int big_endian, hipStream_t s)
+{
+  if (w <= 0 || h <= 0) return HM_OK;
+  const dim3 grid((w + 63) / 64, (h + 3) / 4), block(256);
+  if (alpha_bits == 8)
+    hipLaunchKernelGGL(k_set_alpha16<uint8_t>, grid, block, 0, s, (uint8_t*)out, out_stride, w, h, (const uint8_t*)alpha, alpha_stride, big_endian, out_bits - 8, 16 - out_bits);
+  else
+    hipLaunchKernelGGL(k_set_alpha16<uint16_t>, grid, block, 0, s, (uint8_t*)out, out_stride, w, h, (const uint16_t*)alpha, alpha_stride / 2, big_endian, 0, 0);
+  return hm_check_hip(hipGetLastError(), "k_set_alpha16 launch");
 }
 
 // Op_to_hdr_planes (hdr_sdr.cc:52-107) for one 8-bit plane: out = (in << (bits - 8)) | (in >> (16 - bits)), 16-bit storage

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstring>
 
+#include "hm_colour_plan.h"
 #include "hm_internal.h"
 
 namespace {
@@ -109,6 +110,7 @@ int hm_out_bytes_per_pixel(int out_format)
     case HM_OUT_RGB: return 3;
     case HM_OUT_RGBA: return 4;
     case HM_OUT_RRGGBB_BE: case HM_OUT_RRGGBB_LE: return 6;
+    case HM_OUT_RRGGBBAA_BE: case HM_OUT_RRGGBBAA_LE: return 8;
     default: return hm_fail(HM_ERR_UNSUPPORTED, "output format %d", out_format);
   }
 }
@@ -130,120 +132,162 @@ int hm_ycbcr_coefficients(int has_nclx, int matrix, int primaries, float out[4])
   return HM_OK;
 }
 
-int hm_colour_pipeline(const hm_colour_desc* d)
+// the reference's chain for this conversion (colour_search.cpp) as work for the fused kernels
+static int plan_for(const hm_colour_desc* d, hm_colour_plan* plan)
 {
   int rc = validate(d);
   if (rc) return rc;
-  int matrix; bool full;
-  selection_state(d, matrix, full);
-  const bool rgb8 = d->out_format == HM_OUT_RGB || d->out_format == HM_OUT_RGBA;
-  const bool rgb16 = d->out_format == HM_OUT_RRGGBB_BE || d->out_format == HM_OUT_RRGGBB_LE;
-  if (!rgb8 && !rgb16) return hm_fail(HM_ERR_UNSUPPORTED, "output format %d", d->out_format);
-  if (d->chroma == HM_CHROMA_MONO) { // monochrome image: Op_mono_to_RGB24_32 (8 bit only, monochrome.cc:160-198)
-    if (d->bit_depth == 8 && rgb8) return HM_PIPE_MONO;
-    return hm_fail(HM_ERR_UNSUPPORTED, "monochrome %d-bit image -> output format %d", d->bit_depth, d->out_format);
+  switch (d->out_format) {
+    case HM_OUT_RGB: case HM_OUT_RGBA: case HM_OUT_RRGGBB_BE: case HM_OUT_RRGGBB_LE: case HM_OUT_RRGGBBAA_BE: case HM_OUT_RRGGBBAA_LE: break;
+    default: return hm_fail(HM_ERR_UNSUPPORTED, "output format %d", d->out_format);
   }
-  if (d->chroma_upsampling == HM_UPSAMPLE_BILINEAR && d->chroma != HM_CHROMA_444) {
-    // every nearest-neighbour op refuses (yuv2rgb.cc:37-41, 268-272, 377-381, 506-510); the bilinear ops refuse
-    // matrix 0 (chroma_sampling.cc:466-468, 743-745) => convert_colorspace() finds no chain
-    if (matrix == 0) return hm_fail(HM_ERR_UNSUPPORTED, "no colour conversion: bilinear upsampling is not defined for matrix_coefficients 0");
-    if ((d->bit_depth == 8) != rgb8) return hm_fail(HM_ERR_UNSUPPORTED, "bit depth %d -> output format %d needs a depth-conversion op", d->bit_depth, d->out_format);
-    return HM_PIPE_BILINEAR_FLOAT; // Op_YCbCr42x_bilinear_to_YCbCr444 -> Op_YCbCr_to_RGB<Pixel> -> interleave
-  }
-  if (d->bit_depth == 8 && rgb8) {
-    // Op_YCbCr420_to_RGB24/32 accept: 4:2:0, 8 bit, matrix not in {0,8,11,14}, full range
-    // (yuv2rgb.cc:274-287, 383-397); both cost 11 < 22 of the float chain
-    const bool special = matrix == 0 || matrix == 8 || matrix == 11 || matrix == 14;
-    if (d->chroma == HM_CHROMA_420 && !special && full) return HM_PIPE_INT420;
-    return HM_PIPE_FLOAT; // Op_YCbCr_to_RGB<u8> -> Op_RGB_to_RGB24_32
-  }
-  if (d->bit_depth > 8 && rgb16) return HM_PIPE_FLOAT; // Op_YCbCr_to_RGB<u16> -> RRGGBB (or the 4:2:0 direct op: same arithmetic)
-  if (d->bit_depth == 8 && rgb16 && d->chroma == HM_CHROMA_420 && matrix != 0 && matrix != 8 && matrix != 11 && matrix != 14 &&
-      d->chroma_upsampling != HM_UPSAMPLE_BILINEAR)
-    // RRGGBB targets are "> 8 bit, 10 if unknown" (colorconversion.cc:575-585): Op_to_hdr_planes (8 -> 10 bit) followed by
-    // Op_YCbCr420_to_RRGGBBaa is the only cost-22 chain; other chroma formats tie between two 33-cost chains -> not offered
-    return HM_PIPE_TO_HDR_FLOAT;
-  // 8 -> 16 or 16 -> 8 bit needs the reference's bit-depth ops (hdr_sdr.cc): outside the hot path (§8f rank 3)
-  return hm_fail(HM_ERR_UNSUPPORTED, "bit depth %d -> output format %d needs a depth-conversion op", d->bit_depth, d->out_format);
+  hm_colour_request rq;
+  std::memset(&rq, 0, sizeof(rq));
+  rq.chroma = d->chroma; rq.bit_depth = d->bit_depth; rq.has_alpha = d->has_alpha != 0;
+  rq.has_nclx = d->has_nclx != 0; rq.matrix = d->matrix; rq.primaries = d->primaries; rq.transfer = 2; rq.full_range = d->full_range != 0;
+  rq.out_format = d->out_format;
+  rq.forced_bilinear = d->chroma_upsampling == HM_UPSAMPLE_BILINEAR;
+  const int st = hm_colour_make_plan(&rq, plan);
+  if (st == HM_PLAN_NO_CHAIN)
+    return hm_fail(HM_ERR_UNSUPPORTED, "no colour conversion: the reference finds no chain of operations from %d-bit chroma format %d (matrix %d) to output format %d",
+                   d->bit_depth, d->chroma, d->has_nclx ? d->matrix : 2, d->out_format);
+  if (st != HM_PLAN_OK)
+    return hm_fail(HM_ERR_UNSUPPORTED, "the reference's chain for %d-bit chroma format %d -> output format %d (%d operations) is not on the GPU path",
+                   d->bit_depth, d->chroma, d->out_format, plan->n_ops);
+  return HM_OK;
+}
+
+// the chain itself, as operation numbers in the reference's pool order (hm_colour_plan.h); the count, or -1: no chain
+int hm_colour_chain(const hm_colour_desc* d, int* ops, int max_ops)
+{
+  int rc = validate(d);
+  if (rc) return rc;
+  hm_colour_request rq;
+  std::memset(&rq, 0, sizeof(rq));
+  rq.chroma = d->chroma; rq.bit_depth = d->bit_depth; rq.has_alpha = d->has_alpha != 0;
+  rq.has_nclx = d->has_nclx != 0; rq.matrix = d->matrix; rq.primaries = d->primaries; rq.transfer = 2; rq.full_range = d->full_range != 0;
+  rq.out_format = d->out_format;
+  rq.forced_bilinear = d->chroma_upsampling == HM_UPSAMPLE_BILINEAR;
+  int chain[HM_COLOUR_MAX_OPS];
+  const int n = hm_colour_search(&rq, chain);
+  for (int i = 0; i < n && i < max_ops; i++) ops[i] = chain[i];
+  return n;
+}
+
+// The chain by its shape (the labels predate the search and stay for callers / tests that ask "which kernels run"):
+int hm_colour_pipeline(const hm_colour_desc* d)
+{
+  hm_colour_plan p;
+  const int rc = plan_for(d, &p);
+  if (rc) return rc;
+  if (p.core == HM_CORE_MONO) return HM_PIPE_MONO;
+  if (p.core == HM_CORE_INT420) return p.pre == HM_DEPTH_TO_SDR ? HM_PIPE_SDR_INT420 : (p.pre ? HM_PIPE_GENERIC : HM_PIPE_INT420);
+  if (p.bilinear) return (p.pre || p.post) ? HM_PIPE_GENERIC : HM_PIPE_BILINEAR_FLOAT;
+  if (p.pre == HM_DEPTH_TO_HDR && !p.post) return HM_PIPE_TO_HDR_FLOAT;
+  if (!p.pre && p.post == HM_DEPTH_TO_SDR) return HM_PIPE_FLOAT_SDR;
+  if (!p.pre && p.post == HM_DEPTH_TO_HDR) return HM_PIPE_FLOAT_HDR;
+  if (!p.pre && !p.post) return HM_PIPE_FLOAT;
+  return HM_PIPE_GENERIC;
 }
 
 int hm_colour_convert(const hm_colour_desc* d, const void* d_y, const void* d_cb, const void* d_cr, void* d_out, void* stream)
 {
-  const int pipe = hm_colour_pipeline(d);
-  if (pipe < 0) return pipe;
-  if (pipe == HM_PIPE_MONO) {
+  hm_colour_plan plan;
+  int rc = plan_for(d, &plan);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (plan.core == HM_CORE_MONO) { // Op_mono_to_RGB24_32 (monochrome.cc:160-273), behind Op_to_sdr_planes for a deeper image
     if (!d_y || !d_out) return hm_fail(HM_ERR_INVALID_ARG, "null device pointer");
-    if (d->y_stride < d->width || d->out_stride < d->width * hm_out_bytes_per_pixel(d->out_format)) return hm_fail(HM_ERR_INVALID_ARG, "stride smaller than row");
-    return hm_launch_mono_to_rgb(d_y, d->y_stride, d_out, d->out_stride, d->width, d->height, hm_out_bytes_per_pixel(d->out_format), (hipStream_t)stream);
+    const int bps = d->bit_depth > 8 ? 2 : 1, obpp = hm_out_bytes_per_pixel(d->out_format);
+    if (d->y_stride < d->width * bps || d->out_stride < d->width * obpp) return hm_fail(HM_ERR_INVALID_ARG, "stride smaller than row");
+    if (!plan.pre) return hm_launch_mono_to_rgb(d_y, d->y_stride, d_out, d->out_stride, d->width, d->height, obpp, s);
+    const int ys1 = hm_plane_stride(d->width, 1);
+    const int r = (d->height + 1) & ~1;
+    uint8_t* tmp = (uint8_t*)hm_pool_device_alloc((size_t)ys1 * (r < 64 ? 64 : r));
+    if (!tmp) return hm_fail(HM_ERR_NOMEM, "8-bit luma plane: out of device memory");
+    rc = hm_launch_to_sdr(d_y, d->y_stride, tmp, ys1, d->width, d->height, d->bit_depth, s);
+    if (!rc) rc = hm_launch_mono_to_rgb(tmp, ys1, d_out, d->out_stride, d->width, d->height, obpp, s);
+    const hipError_t e = hipStreamSynchronize(s); // the temporary goes back to the pool
+    hm_pool_device_free(tmp);
+    return rc ? rc : hm_check_hip(e, "monochrome colour chain");
   }
   if (!d_y || !d_cb || !d_cr || !d_out) return hm_fail(HM_ERR_INVALID_ARG, "null device pointer");
-  const int bps = d->bit_depth > 8 ? 2 : 1;
+  const int bps0 = d->bit_depth > 8 ? 2 : 1;
   // the vector fast paths need 16 B aligned rows (true for every libheif-style plane)
   if ((d->y_stride % 16) || (d->cb_stride % 8) || (d->cr_stride % 8) || (d->out_stride % 16) ||
       ((uintptr_t)d_y % 16) || ((uintptr_t)d_cb % 16) || ((uintptr_t)d_cr % 16) || ((uintptr_t)d_out % 16))
     return hm_fail(HM_ERR_INVALID_ARG, "planes must be 16-byte aligned with 16-byte multiple strides");
-  if (d->y_stride < d->width * bps || d->out_stride < d->width * hm_out_bytes_per_pixel(d->out_format))
+  if (d->y_stride < d->width * bps0 || d->out_stride < d->width * hm_out_bytes_per_pixel(d->out_format))
     return hm_fail(HM_ERR_INVALID_ARG, "stride smaller than row");
+  const int cw = d->chroma == HM_CHROMA_444 ? d->width : (d->width + 1) / 2;
+  const int chh = d->chroma == HM_CHROMA_420 ? (d->height + 1) / 2 : d->height;
+  if (d->cb_stride < cw * bps0 || d->cr_stride < cw * bps0) return hm_fail(HM_ERR_INVALID_ARG, "stride smaller than row");
 
-  float cf[4];
-  // ops read the image's own nclx (not the selection state): yuv2rgb.cc:190-198, 329-334
-  hm_ycbcr_coefficients(d->has_nclx, d->matrix, d->primaries, cf);
-  hipStream_t s = (hipStream_t)stream;
-  if (pipe == HM_PIPE_TO_HDR_FLOAT) {
-    const int cw = (d->width + 1) / 2, chh = (d->height + 1) / 2;
-    const int ys2 = hm_plane_stride(d->width, 2), cs2 = hm_plane_stride(cw, 2);
-    auto rows = [](int h) { const int r = (h + 1) & ~1; return r < 64 ? 64 : r; };
+  // The op that turns YCbCr into RGB sees the image's own nclx only when it is the chain's first step; behind another
+  // op it sees the intermediate state's profile (second_step_desc).  Its planes: the image's, or temporaries.
+  hm_colour_desc cur = plan.core_step > 0 ? second_step_desc(d) : *d;
+  const void* py = d_y; const void* pcb = d_cb; const void* pcr = d_cr;
+  auto rows = [](int h) { const int r = (h + 1) & ~1; return r < 64 ? 64 : r; };
+  uint8_t* tmp_depth = nullptr;
+  uint8_t* tmp_up = nullptr;
+  auto finish = [&](int status, const char* what) {
+    if (tmp_depth || tmp_up) { // the temporaries go back to the pool once the stream is through with them
+      const hipError_t e = hipStreamSynchronize(s);
+      if (tmp_depth) hm_pool_device_free(tmp_depth);
+      if (tmp_up) hm_pool_device_free(tmp_up);
+      if (!status) status = hm_check_hip(e, what);
+    }
+    return status;
+  };
+  if (plan.pre) { // Op_to_hdr_planes / Op_to_sdr_planes on Y, Cb, Cr
+    const int nbps = plan.pre_bits > 8 ? 2 : 1;
+    const int ys2 = hm_plane_stride(d->width, nbps), cs2 = hm_plane_stride(cw, nbps);
     const size_t yb = (size_t)ys2 * rows(d->height), cb = (size_t)cs2 * rows(chh);
-    uint8_t* tmp = (uint8_t*)hm_pool_device_alloc(yb + 2 * cb);
-    if (!tmp) return hm_fail(HM_ERR_NOMEM, "8 -> 10 bit planes: %zu bytes of device memory", yb + 2 * cb);
-    int rc = hm_launch_to_hdr(d_y, d->y_stride, tmp, ys2, d->width, d->height, 10, s);
-    if (!rc) rc = hm_launch_to_hdr(d_cb, d->cb_stride, tmp + yb, cs2, cw, chh, 10, s);
-    if (!rc) rc = hm_launch_to_hdr(d_cr, d->cr_stride, tmp + yb + cb, cs2, cw, chh, 10, s);
-    if (!rc) {
-      hm_colour_desc d10 = second_step_desc(d);
-      d10.bit_depth = 10;
-      d10.y_stride = ys2; d10.cb_stride = d10.cr_stride = cs2;
-      float c2[4];
-      hm_ycbcr_coefficients(1, d10.matrix, d10.primaries, c2);
-      rc = hm_launch_colour_float(&d10, c2, 0, tmp, tmp + yb, tmp + yb + cb, d_out, s);
-    }
-    const hipError_t e = hipStreamSynchronize(s); // the temporaries go back to the pool
-    hm_pool_device_free(tmp);
-    return rc ? rc : hm_check_hip(e, "8 -> 10 bit colour chain");
+    tmp_depth = (uint8_t*)hm_pool_device_alloc(yb + 2 * cb);
+    if (!tmp_depth) return hm_fail(HM_ERR_NOMEM, "%d -> %d bit planes: %zu bytes of device memory", d->bit_depth, plan.pre_bits, yb + 2 * cb);
+    auto depth = [&](const void* in, int is, void* out, int os, int w, int h) {
+      return plan.pre == HM_DEPTH_TO_HDR ? hm_launch_to_hdr(in, is, out, os, w, h, plan.pre_bits, s) : hm_launch_to_sdr(in, is, out, os, w, h, d->bit_depth, s);
+    };
+    rc = depth(d_y, d->y_stride, tmp_depth, ys2, d->width, d->height);
+    if (!rc) rc = depth(d_cb, d->cb_stride, tmp_depth + yb, cs2, cw, chh);
+    if (!rc) rc = depth(d_cr, d->cr_stride, tmp_depth + yb + cb, cs2, cw, chh);
+    if (rc) return finish(rc, "depth change");
+    py = tmp_depth; pcb = tmp_depth + yb; pcr = tmp_depth + yb + cb;
+    cur.bit_depth = plan.pre_bits;
+    cur.y_stride = ys2; cur.cb_stride = cur.cr_stride = cs2;
   }
-  if (pipe == HM_PIPE_BILINEAR_FLOAT) {
-    const int cw = (d->width + 1) / 2;
-    if (d->cb_stride < cw * bps || d->cr_stride < cw * bps) return hm_fail(HM_ERR_INVALID_ARG, "stride smaller than row");
-    const int ts = hm_plane_stride(d->width, bps);
+  if (plan.bilinear) { // Op_YCbCr420/422_bilinear_to_YCbCr444 on Cb, Cr
+    const int nbps = cur.bit_depth > 8 ? 2 : 1;
+    const int ts = hm_plane_stride(d->width, nbps);
     const size_t tbytes = (size_t)ts * d->height;
-    uint8_t* tmp = (uint8_t*)hm_pool_device_alloc(2 * tbytes);
-    if (!tmp) return hm_fail(HM_ERR_NOMEM, "bilinear upsampling: %zu bytes of device memory", 2 * tbytes);
+    tmp_up = (uint8_t*)hm_pool_device_alloc(2 * tbytes);
+    if (!tmp_up) return finish(hm_fail(HM_ERR_NOMEM, "bilinear upsampling: %zu bytes of device memory", 2 * tbytes), "bilinear upsampling");
     const int v420 = d->chroma == HM_CHROMA_420;
-    int rc = hm_launch_upsample_bilinear(d->bit_depth, v420, d_cb, d->cb_stride, tmp, ts, d->width, d->height, s);
-    if (!rc) rc = hm_launch_upsample_bilinear(d->bit_depth, v420, d_cr, d->cr_stride, tmp + tbytes, ts, d->width, d->height, s);
-    if (!rc) {
-      hm_colour_desc d444 = second_step_desc(d); // the float op is the chain's second step
-      d444.chroma = HM_CHROMA_444;
-      d444.cb_stride = d444.cr_stride = ts;
-      float c2[4];
-      hm_ycbcr_coefficients(1, d444.matrix, d444.primaries, c2);
-      rc = hm_launch_colour_float(&d444, c2, d444.matrix == 8 ? 3 : 0, d_y, tmp, tmp + tbytes, d_out, s);
-    }
-    const hipError_t e = hipStreamSynchronize(s); // the temporaries go back to the pool
-    hm_pool_device_free(tmp);
-    return rc ? rc : hm_check_hip(e, "bilinear colour chain");
+    rc = hm_launch_upsample_bilinear(cur.bit_depth, v420, pcb, cur.cb_stride, tmp_up, ts, d->width, d->height, s);
+    if (!rc) rc = hm_launch_upsample_bilinear(cur.bit_depth, v420, pcr, cur.cr_stride, tmp_up + tbytes, ts, d->width, d->height, s);
+    if (rc) return finish(rc, "bilinear upsampling");
+    pcb = tmp_up; pcr = tmp_up + tbytes;
+    cur.chroma = HM_CHROMA_444;
+    cur.cb_stride = cur.cr_stride = ts;
   }
-  if (pipe == HM_PIPE_INT420) {
+  float cf[4];
+  // ops read the nclx of the image they are handed (not the search's state): yuv2rgb.cc:190-198, 329-334
+  hm_ycbcr_coefficients(cur.has_nclx, cur.matrix, cur.primaries, cf);
+  if (plan.core == HM_CORE_INT420) {
     const int ci[4] = {(int)std::lround(256 * cf[0]), (int)std::lround(256 * cf[1]),
                        (int)std::lround(256 * cf[2]), (int)std::lround(256 * cf[3])}; // yuv2rgb.cc:336-339
-    return hm_launch_colour_int420(d, ci, d_y, d_cb, d_cr, d_out, s);
+    return finish(hm_launch_colour_int420(&cur, ci, py, pcb, pcr, d_out, s), "integer colour chain");
   }
-  const int m = d->has_nclx ? d->matrix : 2;
-  const bool full = d->has_nclx ? d->full_range != 0 : true;
+  // the float op (+ the depth change of its R, G, B planes, which the kernel derives from its depth and the target: checked here)
+  const bool out8 = d->out_format == HM_OUT_RGB || d->out_format == HM_OUT_RGBA;
+  const int kernel_post = (out8 && cur.bit_depth > 8) ? HM_DEPTH_TO_SDR : ((!out8 && cur.bit_depth == 8) ? HM_DEPTH_TO_HDR : HM_DEPTH_NONE);
+  if (kernel_post != plan.post) return finish(hm_fail(HM_ERR_INTERNAL, "colour plan and kernel disagree on the depth change after the float op"), "colour chain");
+  const int m = cur.has_nclx ? cur.matrix : 2;
+  const bool full = cur.has_nclx ? cur.full_range != 0 : true;
   int mode = 0;
   if (m == 0) mode = full ? 1 : 2;
   else if (m == 8) mode = 3;
-  return hm_launch_colour_float(d, cf, mode, d_y, d_cb, d_cr, d_out, s);
+  return finish(hm_launch_colour_float(&cur, cf, mode, py, pcb, pcr, d_out, s), "float colour chain");
 }
 
 // n images of identical state (one descriptor) in one go: the integer 4:2:0 chain runs as a single launch per 32

@@ -495,8 +495,14 @@ int job_enqueue(DecodeJob& j, hm_decoded* out)
   const DevPlane* alpha = nullptr;
   if (j.n_items > 1) {
     if ((rc = planar_from_blobs(f, j.item[1], params, s, A))) return rc;
-    // what the colour ops refuse is refused before more work is queued (rgb2rgb.cc:81-84: any alpha depth but 8)
-    if (params->out_format == HM_OUT_RGBA && A.bd != 8) return hm_fail(HM_ERR_UNSUPPORTED, "alpha plane of %d bits with an 8-bit RGBA target", A.bd);
+    // what the colour ops refuse is refused before more work is queued: an 8-bit image's chain to RGBA has no op that
+    // changes the alpha plane's depth and the interleave wants 8 bits (rgb2rgb.cc:81-84); a deeper image's chain runs
+    // Op_to_sdr_planes, which brings a deeper alpha plane to 8 bits too (hdr_sdr.cc:176-195)
+    if (params->out_format == HM_OUT_RGBA && A.bd != 8 && I.bd == 8) return hm_fail(HM_ERR_UNSUPPORTED, "alpha plane of %d bits with an 8-bit image and an RGBA target", A.bd);
+    // RRGGBBAA: the alpha plane travels through the image's depth op (Op_to_hdr_planes reads every plane as 8 bit) or is
+    // copied as 16-bit words (rgb2rgb.cc:207-211, yuv2rgb.cc:575-592): only planes of the image's own depth class work
+    if ((params->out_format == HM_OUT_RRGGBBAA_BE || params->out_format == HM_OUT_RRGGBBAA_LE) && (A.bd > 8) != (I.bd > 8))
+      return hm_fail(HM_ERR_UNSUPPORTED, "alpha plane of %d bits with a %d-bit image and an RRGGBBAA target", A.bd, I.bd);
     alpha = &A.P[0];
     if (A.w != I.w || A.h != I.h) {
       if ((rc = alloc_plane(j.alpha_scaled, I.w, I.h, A.bd > 8 ? 2 : 1))) return rc;
@@ -546,10 +552,9 @@ int job_enqueue(DecodeJob& j, hm_decoded* out)
     cd.has_nclx = out->has_nclx; cd.matrix = native.matrix; cd.primaries = native.primaries; cd.full_range = native.full_range;
     cd.out_format = params->out_format;
     cd.chroma_upsampling = params->chroma_upsampling;
+    cd.has_alpha = alpha ? 1 : 0;
     const int obpp = hm_out_bytes_per_pixel(params->out_format);
     if (obpp < 0) return obpp;
-    if (alpha && params->out_format != HM_OUT_RGBA && params->out_format != HM_OUT_RGB)
-      return hm_fail(HM_ERR_UNSUPPORTED, "16-bit interleaved output of an image with an alpha channel (RRGGBBAA) is not on the GPU path");
     cd.y_stride = P[0].stride; cd.cb_stride = P[1].stride; cd.cr_stride = P[2].stride;
     cd.out_stride = hm_plane_stride(img_w, obpp);
     const size_t obytes = (size_t)cd.out_stride * mem_rows(img_h);
@@ -557,8 +562,19 @@ int job_enqueue(DecodeJob& j, hm_decoded* out)
     if ((rc = hm_colour_convert(&cd, P[0].mem.p, P[1].mem.p, P[2].mem.p, dout.p, s))) return rc;
     // RGB24 / RRGGBB targets have no alpha: Op_drop_alpha_plane, the colour values do not depend on it.  RGBA: the 8-bit
     // ops copy the plane (yuv2rgb.cc:483-488)
-    if (alpha && params->out_format == HM_OUT_RGBA)
-      if ((rc = hm_launch_set_alpha(dout.p, cd.out_stride, img_w, img_h, alpha->mem.p, alpha->stride, s))) return rc;
+    if (alpha && params->out_format == HM_OUT_RGBA) {
+      const DevPlane* a8 = alpha;
+      if (A.bd > 8) { // (a deeper image only, see above) Op_to_sdr_planes on the alpha plane
+        if ((rc = alloc_plane(j.alpha_sdr, img_w, img_h, 1))) return rc;
+        if ((rc = hm_launch_to_sdr(alpha->mem.p, alpha->stride, j.alpha_sdr.mem.p, j.alpha_sdr.stride, img_w, img_h, A.bd, s))) return rc;
+        a8 = &j.alpha_sdr;
+      }
+      if ((rc = hm_launch_set_alpha(dout.p, cd.out_stride, img_w, img_h, a8->mem.p, a8->stride, s))) return rc;
+    }
+    const bool aa16 = params->out_format == HM_OUT_RRGGBBAA_BE || params->out_format == HM_OUT_RRGGBBAA_LE;
+    if (alpha && aa16)
+      if ((rc = hm_launch_set_alpha16(dout.p, cd.out_stride, img_w, img_h, alpha->mem.p, alpha->stride, A.bd, bd > 8 ? bd : 10,
+                                      params->out_format == HM_OUT_RRGGBBAA_BE, s))) return rc;
     out->out_format = params->out_format;
     // the converted image carries the output state's profile: the input one with undefined values replaced by the
     // sRGB defaults (colorconversion.cc:452-455, 520-527); an 8-bit image becomes 10 bit in an RRGGBB target (:575-585)
@@ -568,7 +584,8 @@ int job_enqueue(DecodeJob& j, hm_decoded* out)
     if (out->primaries == 2) out->primaries = 1;
     if (out->transfer == 2) out->transfer = 13;
     if (out->matrix == 2) out->matrix = 6;
-    if (bd == 8 && (params->out_format == HM_OUT_RRGGBB_BE || params->out_format == HM_OUT_RRGGBB_LE)) out->bit_depth = 10;
+    if (bd == 8 && hm_out_bytes_per_pixel(params->out_format) >= 6) out->bit_depth = 10;
+    if (bd > 8 && (params->out_format == HM_OUT_RGB || params->out_format == HM_OUT_RGBA)) out->bit_depth = 8;
     out->stride[0] = cd.out_stride;
     out->plane_width[0] = img_w; out->plane_height[0] = img_h;
     if (params->ext_dst && params->ext_dst_stride >= (uint32_t)(img_w * obpp) &&

@@ -86,6 +86,7 @@ struct DecodeJob {
   int n_items = 0;
   PlanarImage I, A;
   DevPlane alpha_scaled;
+  DevPlane alpha_sdr; // a deeper alpha plane brought to 8 bits (Op_to_sdr_planes) for an RGBA target
   DevMem dout;
   bool enqueued = false;
   // everything above is touched by asynchronous work: the stream is drained before any of it is released (the pool may

@@ -23,6 +23,9 @@ int hm_launch_colour_int420_batch(const hm_colour_desc* d, const int coef[4], in
 int hm_launch_colour_float(const hm_colour_desc* d, const float coef[4], int mode, const void* y,
                            const void* cb, const void* cr, void* out, hipStream_t s);
 int hm_launch_to_hdr(const void* in, int in_stride, void* out, int out_stride, int w, int h, int out_bits, hipStream_t s);
+int hm_launch_to_sdr(const void* in, int in_stride, void* out, int out_stride, int w, int h, int in_bits, hipStream_t s);
+int hm_launch_set_alpha16(void* out, int out_stride, int w, int h, const void* alpha, int alpha_stride, int alpha_bits, int out_bits,
+                          int big_endian, hipStream_t s);
 int hm_launch_upsample_bilinear(int bit_depth, int v420, const void* in, int in_stride, void* out, int out_stride,
                                 int w, int h, hipStream_t s);
 int hm_launch_rotate_ccw(int bytes_per_sample, int angle, const void* in, int in_stride, int w, int h, void* out,

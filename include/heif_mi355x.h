@@ -63,7 +63,7 @@ HM_API int hm_device_count(void);
 /* values equal enum heif_chroma (libheif/api/libheif/heif.h:481-494) */
 enum {
   HM_CHROMA_MONO = 0, HM_CHROMA_420 = 1, HM_CHROMA_422 = 2, HM_CHROMA_444 = 3,
-  HM_OUT_RGB = 10, HM_OUT_RGBA = 11, HM_OUT_RRGGBB_BE = 12, HM_OUT_RRGGBB_LE = 14,
+  HM_OUT_RGB = 10, HM_OUT_RGBA = 11, HM_OUT_RRGGBB_BE = 12, HM_OUT_RRGGBBAA_BE = 13, HM_OUT_RRGGBB_LE = 14, HM_OUT_RRGGBBAA_LE = 15,
 };
 
 typedef struct hm_colour_desc {
@@ -78,16 +78,29 @@ typedef struct hm_colour_desc {
                                    neighbour ops); HM_UPSAMPLE_BILINEAR: the caller set
                                    only_use_preferred_chroma_algorithm with heif_chroma_upsampling_bilinear
                                    (heif.h:1546-1562) => Op_YCbCr420/422_bilinear_to_YCbCr444 first           */
+  int32_t has_alpha;            /* the image carries an alpha plane.  The planes converted here do not include it (the
+                                   callers add it to the pixels afterwards), but it decides the reference's chain for one
+                                   case: an 8-bit 4:2:0 image reaches RRGGBBAA through Op_to_hdr_planes +
+                                   Op_YCbCr420_to_RRGGBBaa only when it has an alpha plane - without one that op ends in
+                                   RRGGBB and the float op on 8 bits comes first (different arithmetic)            */
 } hm_colour_desc;
 enum { HM_UPSAMPLE_NEAREST = 1, HM_UPSAMPLE_BILINEAR = 2 }; /* == enum heif_chroma_upsampling_algorithm */
 
-/* which reference op chain convert_colorspace() would pick for this state (§3.4 of SURVEY) */
-enum { HM_PIPE_INT420 = 1, HM_PIPE_FLOAT = 2, HM_PIPE_BILINEAR_FLOAT = 3, HM_PIPE_TO_HDR_FLOAT = 4, HM_PIPE_MONO = 5 };
+/* which reference op chain convert_colorspace() picks for this state: the product runs the reference's pipeline SEARCH
+ * (colorconversion.cc:266-420, restated in colour_search.cpp) and reports the chain's shape */
+enum { HM_PIPE_INT420 = 1, HM_PIPE_FLOAT = 2, HM_PIPE_BILINEAR_FLOAT = 3, HM_PIPE_TO_HDR_FLOAT = 4, HM_PIPE_MONO = 5,
+       HM_PIPE_SDR_INT420 = 6,  /* Op_to_sdr_planes -> Op_YCbCr420_to_RGB24/32: > 8-bit full-range 4:2:0 to 8-bit RGB      */
+       HM_PIPE_FLOAT_SDR = 7,   /* Op_YCbCr_to_RGB<u16> -> Op_to_sdr_planes -> Op_RGB_to_RGB24_32: other > 8-bit images     */
+       HM_PIPE_FLOAT_HDR = 8,   /* Op_YCbCr_to_RGB<u8> -> Op_to_hdr_planes -> Op_RGB_HDR_to_RRGGBBaa_BE [-> swap]          */
+       HM_PIPE_GENERIC = 9 };   /* any other combination of [depth change] [bilinear] core op [depth change]               */
 HM_API int hm_colour_pipeline(const hm_colour_desc* d); /* HM_PIPE_* or negative status */
+/* the chain itself: the reference's operations by their position in its pool (ColorConversionPipeline::init_ops,
+ * colorconversion.cc:218-255); returns the number of operations (0: nothing to convert), -1 when there is no chain */
+HM_API int hm_colour_chain(const hm_colour_desc* d, int* ops, int max_ops);
 
 /* Observable libheif plane stride for a plane `width` pixels wide (pixelimage.cc:139-218). */
 HM_API int hm_plane_stride(int width, int bytes_per_pixel);
-/* bytes per output pixel of an HM_OUT_* format (3,4,6) */
+/* bytes per output pixel of an HM_OUT_* format (3,4,6,8) */
 HM_API int hm_out_bytes_per_pixel(int out_format);
 
 /* float32 coefficients exactly as nclx.cc:152-171 computes them: r_cr, g_cb, g_cr, b_cb */

@@ -37,6 +37,8 @@ enum {
   ORC_OUT_RGBA32 = 11,
   ORC_OUT_RRGGBB_BE = 12,
   ORC_OUT_RRGGBB_LE = 14,
+  ORC_OUT_RRGGBBAA_BE = 13,
+  ORC_OUT_RRGGBBAA_LE = 15,
 };
 
 /* nclx.cc:85-171 */
@@ -60,6 +62,14 @@ void orc_ycbcr_to_rgb_float(const void* y, int ys, const void* cb, int cbs,
                             const void* cr, int crs, int w, int h, int bpp, int chroma,
                             int has_nclx, int matrix, int primaries, int full_range,
                             uint8_t* out, int os, int out_fmt);
+
+/* the float-op chains of the pipeline search that change the sample depth or end in RRGGBBAA (see oracle_colour.c);
+ * alpha: NULL or the alpha plane at the image's size (alpha_bits 8: bytes, else 16-bit words) */
+void orc_ycbcr_to_rgb_chain(const void* y, int ys, const void* cb, int cbs, const void* cr, int crs,
+                            const void* alpha, int as, int alpha_bits, int w, int h, int bpp, int chroma,
+                            int has_nclx, int matrix, int primaries, int full_range, uint8_t* out, int os, int out_fmt);
+/* Op_to_sdr_planes for one plane of `bits` > 8 (hdr_sdr.cc:176-195) */
+void orc_to_sdr_plane(const uint8_t* in, int is, int w, int h, int bits, uint8_t* out, int os);
 
 /* context.cc:2457-2535: paste one decoded tile plane into the grid canvas plane.
  * channel: 0=Y 1=Cb 2=Cr.  chroma: 1=420 2=422 3=444.  All sizes in samples, strides in bytes.

@@ -165,28 +165,81 @@ static inline unsigned sample_at(const void* plane, int stride_bytes, int x, int
   return wide ? ((const uint16_t*)row)[x] : row[x];
 }
 
+/* one pixel of Op_YCbCr_to_RGB<Pixel> (yuv2rgb.cc:170-247): the planar R, G, B values at the image's bit depth */
+typedef struct {
+  int wide, matrix_coeffs, full_range_flag;
+  uint16_t halfRange;
+  int32_t fullRange;
+  float limited_range_offset;
+  orc_coeffs k;
+} orc_float_op;
+
+static orc_float_op float_op_setup(int bpp, int has_nclx, int matrix, int primaries, int full_range)
+{
+  orc_float_op f;
+  f.wide = bpp > 8;
+  /* yuv2rgb.cc:170-177 */
+  f.halfRange = (uint16_t)(1 << (bpp - 1));
+  f.fullRange = (1 << bpp) - 1;
+  f.limited_range_offset = (float)(16 << (bpp - 8));
+  /* yuv2rgb.cc:190-198 */
+  f.matrix_coeffs = 2;
+  f.full_range_flag = 1;
+  f.k = orc_ycbcr_to_rgb_coeffs(0, 0, 0);
+  if (has_nclx) {
+    f.matrix_coeffs = matrix;
+    f.full_range_flag = full_range;
+    f.k = orc_ycbcr_to_rgb_coeffs(1, matrix, primaries);
+  }
+  return f;
+}
+
+static void float_op_pixel(const orc_float_op* f, unsigned Y, unsigned U, unsigned V, unsigned* pr, unsigned* pg, unsigned* pb)
+{
+  const int wide = f->wide;
+  unsigned r, g, b;
+  if (f->matrix_coeffs == 0) { /* yuv2rgb.cc:207-219: GBR */
+    if (f->full_range_flag) { r = V; g = Y; b = U; }
+    else {
+      r = clip_f_u16(((float)V - f->limited_range_offset) * 1.1429f, f->fullRange);
+      g = clip_f_u16(((float)Y - f->limited_range_offset) * 1.1689f, f->fullRange);
+      b = clip_f_u16(((float)U - f->limited_range_offset) * 1.1429f, f->fullRange);
+    }
+    /* the template stores (Pixel)value */
+    if (!wide) { r &= 0xFF; g &= 0xFF; b &= 0xFF; }
+  }
+  else if (f->matrix_coeffs == 8) { /* yuv2rgb.cc:221-232: YCgCo, clipped to 8 bit even for HDR */
+    int yv = (int)Y, u = (int)U - f->halfRange, v = (int)V - f->halfRange;
+    r = clip_int_u8(yv - u + v);
+    g = clip_int_u8(yv + u);
+    b = clip_int_u8(yv - u - v);
+  }
+  else { /* yuv2rgb.cc:233-247 */
+    float yv = (float)Y;
+    float u = (float)((int)U - (int)f->halfRange);
+    float v = (float)((int)V - (int)f->halfRange);
+    if (!f->full_range_flag) {
+      yv = (yv - f->limited_range_offset) * 1.1689f;
+      u = u * 1.1429f;
+      v = v * 1.1429f;
+    }
+    r = clip_f_u16(yv + f->k.r_cr * v, f->fullRange);
+    g = clip_f_u16(yv + f->k.g_cb * u + f->k.g_cr * v, f->fullRange);
+    b = clip_f_u16(yv + f->k.b_cb * u, f->fullRange);
+    if (!wide) { r &= 0xFF; g &= 0xFF; b &= 0xFF; } /* (uint8_t) cast of the uint16 result */
+  }
+  *pr = r; *pg = g; *pb = b;
+}
+
 void orc_ycbcr_to_rgb_float(const void* y, int ys, const void* cb, int cbs,
                             const void* cr, int crs, int w, int h, int bpp, int chroma,
                             int has_nclx, int matrix, int primaries, int full_range,
                             uint8_t* out, int os, int out_fmt)
 {
-  const int wide = bpp > 8;
-  /* yuv2rgb.cc:170-177 */
-  const uint16_t halfRange = (uint16_t)(1 << (bpp - 1));
-  const int32_t fullRange = (1 << bpp) - 1;
-  const float limited_range_offset = (float)(16 << (bpp - 8));
+  const orc_float_op f = float_op_setup(bpp, has_nclx, matrix, primaries, full_range);
+  const int wide = f.wide;
   const int shiftH = (chroma == 3) ? 0 : 1;
   const int shiftV = (chroma == 1) ? 1 : 0;
-
-  /* yuv2rgb.cc:190-198 */
-  int matrix_coeffs = 2;
-  int full_range_flag = 1;
-  orc_coeffs k = orc_ycbcr_to_rgb_coeffs(0, 0, 0);
-  if (has_nclx) {
-    matrix_coeffs = matrix;
-    full_range_flag = full_range;
-    k = orc_ycbcr_to_rgb_coeffs(1, matrix, primaries);
-  }
 
   for (int py = 0; py < h; py++) {
     uint8_t* o = out + (size_t)py * os;
@@ -196,36 +249,7 @@ void orc_ycbcr_to_rgb_float(const void* y, int ys, const void* cb, int cbs,
       unsigned U = sample_at(cb, cbs, cx, cy, wide);
       unsigned V = sample_at(cr, crs, cx, cy, wide);
       unsigned r, g, b;
-      if (matrix_coeffs == 0) { /* yuv2rgb.cc:207-219: GBR */
-        if (full_range_flag) { r = V; g = Y; b = U; }
-        else {
-          r = clip_f_u16(((float)V - limited_range_offset) * 1.1429f, fullRange);
-          g = clip_f_u16(((float)Y - limited_range_offset) * 1.1689f, fullRange);
-          b = clip_f_u16(((float)U - limited_range_offset) * 1.1429f, fullRange);
-        }
-        /* the template stores (Pixel)value */
-        if (!wide) { r &= 0xFF; g &= 0xFF; b &= 0xFF; }
-      }
-      else if (matrix_coeffs == 8) { /* yuv2rgb.cc:221-232: YCgCo, clipped to 8 bit even for HDR */
-        int yv = (int)Y, u = (int)U - halfRange, v = (int)V - halfRange;
-        r = clip_int_u8(yv - u + v);
-        g = clip_int_u8(yv + u);
-        b = clip_int_u8(yv - u - v);
-      }
-      else { /* yuv2rgb.cc:233-247 */
-        float yv = (float)Y;
-        float u = (float)((int)U - (int)halfRange);
-        float v = (float)((int)V - (int)halfRange);
-        if (!full_range_flag) {
-          yv = (yv - limited_range_offset) * 1.1689f;
-          u = u * 1.1429f;
-          v = v * 1.1429f;
-        }
-        r = clip_f_u16(yv + k.r_cr * v, fullRange);
-        g = clip_f_u16(yv + k.g_cb * u + k.g_cr * v, fullRange);
-        b = clip_f_u16(yv + k.b_cb * u, fullRange);
-        if (!wide) { r &= 0xFF; g &= 0xFF; b &= 0xFF; } /* (uint8_t) cast of the uint16 result */
-      }
+      float_op_pixel(&f, Y, U, V, &r, &g, &b);
       switch (out_fmt) {
         case ORC_OUT_RGB24:  /* rgb2rgb.cc:66-143 */
           o[3 * px + 0] = (uint8_t)r; o[3 * px + 1] = (uint8_t)g; o[3 * px + 2] = (uint8_t)b; break;
@@ -242,6 +266,64 @@ void orc_ycbcr_to_rgb_float(const void* y, int ys, const void* cb, int cbs,
       }
     }
   }
+}
+
+/* The chains of the reference's pipeline search (oracle/pipeline_search.py) that start with the float op and end in
+ * another sample depth, or in RRGGBBAA:
+ *   bpp > 8  -> RGB24 / RGBA32:  Op_YCbCr_to_RGB<uint16_t> -> Op_to_sdr_planes (hdr_sdr.cc:139-232: every plane deeper
+ *               than 8 bits is shifted right by bits - 8, no rounding; 8-bit planes are copied) -> Op_RGB_to_RGB24_32
+ *               (rgb2rgb.cc:66-143: alpha byte = the 8-bit alpha plane, 0xFF without one)
+ *   bpp == 8 -> RRGGBB[AA]_BE/LE: Op_YCbCr_to_RGB<uint8_t> -> Op_to_hdr_planes (hdr_sdr.cc:52-107: every plane, read as
+ *               8 bit, becomes (v << 2) | (v >> 6): the target depth of such a request is 10) -> Op_RGB_HDR_to_RRGGBBaa_BE
+ *               (rgb2rgb.cc:189-272: alpha word = the alpha plane, (1 << bpp) - 1 without one) [-> byte swap :676-729]
+ *   bpp > 8  -> RRGGBBAA_BE/LE:  Op_YCbCr_to_RGB<uint16_t> -> Op_RGB_HDR_to_RRGGBBaa_BE [-> swap]
+ * alpha: NULL or the alpha plane (alpha_bits 8: bytes, else 16-bit words), already at the image's size. */
+void orc_ycbcr_to_rgb_chain(const void* y, int ys, const void* cb, int cbs, const void* cr, int crs,
+                            const void* alpha, int as, int alpha_bits, int w, int h, int bpp, int chroma,
+                            int has_nclx, int matrix, int primaries, int full_range, uint8_t* out, int os, int out_fmt)
+{
+  const orc_float_op f = float_op_setup(bpp, has_nclx, matrix, primaries, full_range);
+  const int shiftH = (chroma == 3) ? 0 : 1, shiftV = (chroma == 1) ? 1 : 0;
+  const int out8 = out_fmt == ORC_OUT_RGB24 || out_fmt == ORC_OUT_RGBA32;
+  const int with_a = out_fmt == ORC_OUT_RGBA32 || out_fmt == ORC_OUT_RRGGBBAA_BE || out_fmt == ORC_OUT_RRGGBBAA_LE;
+  const int le = out_fmt == ORC_OUT_RRGGBB_LE || out_fmt == ORC_OUT_RRGGBBAA_LE;
+  const int out_bits = out8 ? 8 : (bpp > 8 ? bpp : 10);
+  for (int py = 0; py < h; py++) {
+    uint8_t* o = out + (size_t)py * os;
+    for (int px = 0; px < w; px++) {
+      unsigned c[4];
+      float_op_pixel(&f, sample_at(y, ys, px, py, f.wide), sample_at(cb, cbs, px >> shiftH, py >> shiftV, f.wide),
+                     sample_at(cr, crs, px >> shiftH, py >> shiftV, f.wide), &c[0], &c[1], &c[2]);
+      int a_bits = alpha ? alpha_bits : 0;
+      c[3] = alpha ? sample_at(alpha, as, px, py, alpha_bits > 8) : 0;
+      if (out8 && bpp > 8) { /* Op_to_sdr_planes */
+        for (int k = 0; k < 3; k++) c[k] >>= (bpp - 8);
+        if (a_bits > 8) { c[3] >>= (a_bits - 8); a_bits = 8; }
+      }
+      else if (!out8 && bpp == 8) { /* Op_to_hdr_planes: all planes read as 8 bit */
+        for (int k = 0; k < (alpha ? 4 : 3); k++) c[k] = ((c[k] & 0xFF) << (out_bits - 8)) | ((c[k] & 0xFF) >> (16 - out_bits));
+      }
+      if (!alpha) c[3] = out8 ? 0xFF : (unsigned)((1 << out_bits) - 1);
+      const int n = with_a ? 4 : 3;
+      if (out8) for (int k = 0; k < n; k++) o[n * px + k] = (uint8_t)c[k];
+      else
+        for (int k = 0; k < n; k++) {
+          o[2 * n * px + 2 * k + (le ? 1 : 0)] = (uint8_t)(c[k] >> 8);
+          o[2 * n * px + 2 * k + (le ? 0 : 1)] = (uint8_t)(c[k] & 0xFF);
+        }
+    }
+  }
+}
+
+/* Op_to_sdr_planes for one plane deeper than 8 bits (hdr_sdr.cc:176-195): out = in >> (bits - 8), 8-bit storage */
+void orc_to_sdr_plane(const uint8_t* in, int is, int w, int h, int bits, uint8_t* out, int os)
+{
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      uint16_t v;
+      memcpy(&v, in + (size_t)y * is + 2 * (size_t)x, 2);
+      out[(size_t)y * os + x] = (uint8_t)(v >> (bits - 8));
+    }
 }
 
 /* ---- A5: grid tile paste (context.cc:2457-2535) --------------------------- */

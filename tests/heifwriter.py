@@ -105,7 +105,8 @@ def write_heic(pictures, size, grid=None, chroma_format=1, bit_depth=8, colr=Non
         params = [n for n in nals if ((n[0] >> 1) & 0x3F) in (32, 33, 34)]
         vcl = [n for n in nals if ((n[0] >> 1) & 0x3F) not in (32, 33, 34)]
         items.append((aid, b"hvc1", b"".join(struct.pack(">I", len(n)) + n for n in vcl)))
-        assoc[aid] = [0x8000 | prop(_hvcc(params, aux_cf, bit_depth)), prop(_full(b"ispe", 0, 0, struct.pack(">II", *asize))),
+        aux_bd = entry[4] if len(entry) > 4 else bit_depth
+        assoc[aid] = [0x8000 | prop(_hvcc(params, aux_cf, aux_bd)), prop(_full(b"ispe", 0, 0, struct.pack(">II", *asize))),
                       0x8000 | prop(_full(b"auxC", 0, 0, urn.encode() + b"\0"))]
         iref_boxes.append(_box(b"auxl", struct.pack(">HHH", aid, 1, primary)))
     iref = _full(b"iref", 0, 0, b"".join(iref_boxes)) if iref_boxes else b""

@@ -68,6 +68,36 @@ def colour_float(y, cb, cr, w, h, bpp, chroma, has_nclx, matrix, primaries, full
     return out, os_
 
 
+OUT_BYTES = {10: 3, 11: 4, 12: 6, 13: 8, 14: 6, 15: 8}
+
+
+def colour_chain(y, cb, cr, w, h, bpp, chroma, has_nclx, matrix, primaries, full_range, out_fmt, alpha=None, alpha_bits=0):
+    """the float-op chains that change the sample depth or end in RRGGBBAA (oracle_colour.c: orc_ycbcr_to_rgb_chain);
+    alpha: (buffer, stride) of the image's size or None"""
+    o = load()
+    out, os_ = alloc_plane(w, h, OUT_BYTES[out_fmt])
+    o.orc_ycbcr_to_rgb_chain(ptr(y[0]), y[1], ptr(cb[0]), cb[1], ptr(cr[0]), cr[1], ptr(alpha[0]) if alpha else None,
+                             alpha[1] if alpha else 0, alpha_bits, w, h, bpp, chroma, has_nclx, matrix, primaries, full_range,
+                             ptr(out), os_, out_fmt)
+    return out, os_
+
+
+def to_hdr(plane, w, h, bits):
+    """Op_to_hdr_planes on one 8-bit plane -> `bits`-bit (buffer, stride) in 16-bit storage"""
+    o = load()
+    out, os_ = alloc_plane(w, h, 2)
+    o.orc_to_hdr_plane(ptr(plane[0]), plane[1], w, h, bits, ptr(out), os_)
+    return out, os_
+
+
+def to_sdr(plane, w, h, bits):
+    """Op_to_sdr_planes on one plane of `bits` > 8 -> 8-bit (buffer, stride)"""
+    o = load()
+    out, os_ = alloc_plane(w, h, 1)
+    o.orc_to_sdr_plane(ptr(plane[0]), plane[1], w, h, bits, ptr(out), os_)
+    return out, os_
+
+
 def upsample_bilinear(plane, w, h, bpp, chroma):
     """Op_YCbCr420/422_bilinear_to_YCbCr444 on one chroma plane (buffer, stride) -> (buffer, stride) of size w x h."""
     o = load()
@@ -200,3 +230,53 @@ def oracle_decode(blob, stages=3, crop=False):
         w, h = w - cl - cr_, h - ct - cb_
     return ([y] if cf == 0 else [y, cb, cr]), dict(width=w, height=h, chroma=cf, bit_depth=info[3], full_range=info[4],
                              matrix=info[5], primaries=info[6], has_vui_colour=info[7])
+
+
+def convert_by_search(planes, w, h, bpp, chroma, nclx, out_fmt, has_alpha=False, forced_bilinear=False):
+    """The reference's conversion of Y / Cb / Cr planes [(buffer, stride)] to an interleaved target, op by op along the
+    chain its pipeline search picks (oracle/pipeline_search.py), every op by its oracle restatement.  nclx = (has_nclx,
+    matrix, primaries, full_range) of the image.  The alpha plane itself is not part of this function (it does not
+    enter the colour values); has_alpha only steers the search.  Returns (buffer, stride, chain)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+    import pipeline_search as ps
+    n = ps.Nclx(nclx[1], nclx[2], 2, bool(nclx[3])) if nclx[0] else None
+    opts = ps.Options(ps.DOWN_AVERAGE, ps.UP_BILINEAR, forced_bilinear)
+    inp, tgt = ps.conversion_states(ps.CS_YCBCR, chroma, has_alpha, bpp, n, ps.CS_RGB, out_fmt)
+    steps = ps.construct_pipeline(inp, tgt, opts)
+    assert steps is not None, "the reference finds no chain"
+    chain = [name for name, _ in steps]
+    cw, ch = ((w + 1) // 2 if chroma != 3 else w), ((h + 1) // 2 if chroma == 1 else h)
+    y, cb, cr = planes
+    bits, cur_chroma = bpp, chroma
+    seen = tuple(nclx)  # the profile the next op reads off its input image: the image's own for the first op
+    # ... afterwards the state's: undefined values replaced by the sRGB defaults (colorconversion.cc:452-455, 520-527)
+    m2, p2 = (nclx[1], nclx[2]) if nclx[0] else (2, 2)
+    state_profile = (1, 6 if m2 == 2 else m2, 1 if p2 == 2 else p2, nclx[3] if nclx[0] else 1)
+    for k, name in enumerate(chain):
+        if name == "Op_drop_alpha_plane":
+            pass
+        elif name == "Op_to_hdr_planes":
+            y, cb, cr = to_hdr(y, w, h, tgt.bpp), to_hdr(cb, cw, ch, tgt.bpp), to_hdr(cr, cw, ch, tgt.bpp)
+            bits = tgt.bpp
+        elif name == "Op_to_sdr_planes":
+            y, cb, cr = to_sdr(y, w, h, bits), to_sdr(cb, cw, ch, bits), to_sdr(cr, cw, ch, bits)
+            bits = 8
+        elif "bilinear_to_YCbCr444" in name:
+            cb, cr = upsample_bilinear(cb, w, h, bits, cur_chroma), upsample_bilinear(cr, w, h, bits, cur_chroma)
+            cur_chroma, cw, ch = 3, w, h
+        elif name in ("Op_YCbCr420_to_RGB24", "Op_YCbCr420_to_RGB32"):
+            assert k == len(chain) - 1
+            out, os_ = colour_int(y, cb, cr, w, h, seen[0], seen[1], seen[2], out_fmt)
+            return out, os_, chain
+        elif name.startswith("Op_YCbCr_to_RGB<") or name == "Op_YCbCr420_to_RRGGBBaa":
+            rest = chain[k + 1:]
+            assert all(r in ("Op_to_hdr_planes", "Op_to_sdr_planes", "Op_RGB_to_RGB24_32", "Op_RGB_HDR_to_RRGGBBaa_BE",
+                             "Op_RRGGBBaa_swap_endianness") for r in rest), rest
+            out, os_ = colour_chain(y, cb, cr, w, h, bits, cur_chroma, *seen, out_fmt)
+            return out, os_, chain
+        else:
+            raise AssertionError("op outside the decode path: " + name)
+        seen = state_profile
+    raise AssertionError("chain without a YCbCr -> RGB op")

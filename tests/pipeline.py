@@ -167,7 +167,8 @@ class Pipeline:
             self.h = C.c_void_p()
 
 
-def cpu_decode(hm, tiles, tile_w, tile_h, canvas_w, canvas_h, cols, is_grid, out_fmt, tile_colr=None, decoder="oracle", bilinear=False, transforms=None):
+def cpu_decode(hm, tiles, tile_w, tile_h, canvas_w, canvas_h, cols, is_grid, out_fmt, tile_colr=None, decoder="oracle", bilinear=False, transforms=None,
+               has_alpha=False):
     """tiles: list of [len][NAL] strings.  Returns (rgb array, stride) following the reference flow."""
     o = orc.load()
     first = None
@@ -205,35 +206,10 @@ def cpu_decode(hm, tiles, tile_w, tile_h, canvas_w, canvas_h, cols, is_grid, out
         canv, _, canvas_w, canvas_h = orc.transform_planes(canv, [(canvas_w, canvas_h), (cw0, ch0), (cw0, ch0)], canvas_w, canvas_h, bd, transforms)
     has_nclx = 0 if is_grid else 1
     _, full, mat, prim = first["nclx"]
-    obpp = {10: 3, 11: 4, 12: 6, 14: 6}[out_fmt]
-    out, os_ = orc.alloc_plane(canvas_w, canvas_h, obpp)
-    sel_m = (mat if has_nclx else 2)
-    sel_m = 6 if sel_m == 2 else sel_m
-    sel_full = full if has_nclx else 1
-    # what the second op of a two-step chain sees: the intermediate image carries the step's output state, i.e. the
-    # input profile (or the default one) with undefined values replaced by the sRGB defaults (colorconversion.cc:452-455)
-    m2 = mat if has_nclx else 2
-    p2 = prim if has_nclx else 2
-    step2 = (1, 6 if m2 == 2 else m2, 1 if p2 == 2 else p2, full if has_nclx else 1)
-    if bilinear and cf != 3:  # forced bilinear: upsample to 4:4:4, then the float op (the NN ops are excluded)
-        up = [orc.upsample_bilinear(canv[c], canvas_w, canvas_h, bd, cf) for c in (1, 2)]
-        o.orc_ycbcr_to_rgb_float(orc.ptr(canv[0][0]), canv[0][1], orc.ptr(up[0][0]), up[0][1], orc.ptr(up[1][0]), up[1][1],
-                                 canvas_w, canvas_h, bd, 3, *step2, orc.ptr(out), os_, out_fmt)
-    elif bd == 8 and out_fmt in (12, 14):  # 8-bit image -> RRGGBB: Op_to_hdr_planes (8 -> 10 bit), then the 4:2:0 HDR op
-        assert cf == 1
-        hi = []
-        for c, (w_, h_) in enumerate(((canvas_w, canvas_h), ((canvas_w + 1) // 2, (canvas_h + 1) // 2), ((canvas_w + 1) // 2, (canvas_h + 1) // 2))):
-            buf, st = orc.alloc_plane(w_, h_, 2)
-            o.orc_to_hdr_plane(orc.ptr(canv[c][0]), canv[c][1], w_, h_, 10, orc.ptr(buf), st)
-            hi.append((buf, st))
-        o.orc_ycbcr_to_rgb_float(orc.ptr(hi[0][0]), hi[0][1], orc.ptr(hi[1][0]), hi[1][1], orc.ptr(hi[2][0]), hi[2][1],
-                                 canvas_w, canvas_h, 10, 1, *step2, orc.ptr(out), os_, out_fmt)
-    elif bd == 8 and cf == 1 and sel_full and sel_m not in (0, 8, 11, 14) and out_fmt in (10, 11):
-        o.orc_ycbcr420_to_rgb_int(orc.ptr(canv[0][0]), canv[0][1], orc.ptr(canv[1][0]), canv[1][1], orc.ptr(canv[2][0]), canv[2][1],
-                                  canvas_w, canvas_h, has_nclx, mat, prim, orc.ptr(out), os_, out_fmt)
-    else:
-        o.orc_ycbcr_to_rgb_float(orc.ptr(canv[0][0]), canv[0][1], orc.ptr(canv[1][0]), canv[1][1], orc.ptr(canv[2][0]), canv[2][1],
-                                 canvas_w, canvas_h, bd, cf, has_nclx, mat, prim, full, orc.ptr(out), os_, out_fmt)
+    # the colour conversion: op by op along the chain the reference's pipeline search picks for this image and target
+    # (oracle/pipeline_search.py; incl. the rule that every op after the first sees the intermediate state's profile)
+    out, os_, _ = orc.convert_by_search(canv, canvas_w, canvas_h, bd, cf, (has_nclx, mat, prim, full), out_fmt, has_alpha=has_alpha,
+                                        forced_bilinear=bool(bilinear))
     return out, os_, canv
 
 

@@ -18,19 +18,19 @@ def _chroma_dims(w, h, chroma):
     return w, h
 
 
-def _run_gpu(pkg, planes, w, h, bit_depth, chroma, nclx, out_fmt, upsampling=0):
+def _run_gpu(pkg, planes, w, h, bit_depth, chroma, nclx, out_fmt, upsampling=0, has_alpha=0):
     import torch
     capi = pkg.capi
     L = pkg.lib()
     (y, ys), (cb, cbs), (cr, crs) = planes
-    obpp = {10: 3, 11: 4, 12: 6, 14: 6}[out_fmt]
+    obpp = orc.OUT_BYTES[out_fmt]
     ostride = L.hm_plane_stride(w, obpp)
     assert ostride == orc.plane_stride(w, obpp)
     dev = torch.device("cuda:0")
     dy, dcb, dcr = (torch.from_numpy(a).to(dev) for a in (y, cb, cr))
     rows = max(64, (h + 1) & ~1)
     dout = torch.zeros((rows, ostride), dtype=torch.uint8, device=dev)
-    d = capi.ColourDesc(w, h, bit_depth, chroma, nclx[0], nclx[1], nclx[2], nclx[3], out_fmt, ys, cbs, crs, ostride, upsampling)
+    d = capi.ColourDesc(w, h, bit_depth, chroma, nclx[0], nclx[1], nclx[2], nclx[3], out_fmt, ys, cbs, crs, ostride, upsampling, has_alpha)
     stream = torch.cuda.current_stream().cuda_stream
     capi.check(L.hm_colour_convert(C.byref(d), dy.data_ptr(), dcb.data_ptr(), dcr.data_ptr(), dout.data_ptr(), stream))
     torch.cuda.synchronize()
@@ -57,7 +57,7 @@ def test_int420(pkg, w, h, out_fmt, nclx):
 
 @pytest.mark.parametrize("w,h", SIZES)
 @pytest.mark.parametrize("chroma", [1, 2, 3])
-@pytest.mark.parametrize("nclx", [(1, 2, 2, 0), (1, 6, 1, 0), (1, 1, 1, 0), (1, 0, 1, 1), (1, 0, 1, 0), (1, 8, 1, 1), (1, 11, 1, 1)])
+@pytest.mark.parametrize("nclx", [(1, 2, 2, 0), (1, 6, 1, 0), (1, 1, 1, 0), (1, 0, 1, 1), (1, 0, 1, 0), (1, 8, 1, 1)])
 def test_float_8bit(pkg, w, h, chroma, nclx):
     if chroma == 1 and nclx[3] == 1 and nclx[1] not in (0, 8, 11, 14):
         pytest.skip("reference picks the integer op for this state")
@@ -90,8 +90,91 @@ def test_float_hdr(pkg, w, h, chroma, bit_depth, nclx, out_fmt):
 
 def test_no_silent_fallback(pkg):
     """unsupported states fail loudly instead of falling back"""
-    d = pkg.capi.ColourDesc(64, 64, 8, 2, 0, 0, 0, 0, 14, 64, 64, 64, 384)  # 8-bit 4:2:2 -> RRGGBB: two equal-cost chains in the reference
+    d = pkg.capi.ColourDesc(64, 64, 8, 0, 0, 0, 0, 0, 14, 64, 0, 0, 384)  # monochrome -> RRGGBB: the reference's chain (via 4:2:0) is not offered
     assert pkg.lib().hm_colour_pipeline(C.byref(d)) == -2
+    d = pkg.capi.ColourDesc(64, 64, 8, 3, 1, 11, 1, 1, 10, 64, 64, 64, 192)  # matrix 11: every YCbCr -> RGB op of the reference refuses
+    assert pkg.lib().hm_colour_pipeline(C.byref(d)) == -2
+
+
+DEPTH_SIZES = [(64, 64), (1280, 854), (17, 9), (1, 1), (1023, 3), (4030, 31)]
+DEPTH_NCLX = [(0, 0, 0, 0), (1, 9, 9, 0), (1, 1, 1, 1), (1, 1, 1, 0), (1, 0, 1, 1), (1, 0, 1, 0), (1, 8, 1, 1)]
+
+
+def _random_planes(w, h, chroma, bit_depth, seed):
+    rng = np.random.default_rng(seed)
+    cw, ch = _chroma_dims(w, h, chroma)
+    bps = 2 if bit_depth > 8 else 1
+    mv = (1 << bit_depth) - 1
+    return [orc.alloc_plane(w, h, bps, rng=rng, maxval=mv), orc.alloc_plane(cw, ch, bps, rng=rng, maxval=mv),
+            orc.alloc_plane(cw, ch, bps, rng=rng, maxval=mv)]
+
+
+@pytest.mark.parametrize("w,h", DEPTH_SIZES)
+@pytest.mark.parametrize("chroma", [1, 2, 3])
+@pytest.mark.parametrize("bit_depth", [10, 12])
+@pytest.mark.parametrize("nclx", DEPTH_NCLX)
+def test_hdr_image_to_8bit_rgb(pkg, w, h, chroma, bit_depth, nclx):
+    """> 8-bit image -> RGB24 / RGBA32 (interleaved RGB targets are 8 bit whatever the image holds,
+    colorconversion.cc:566-573): Op_to_sdr_planes + the integer op for full-range 4:2:0, else the float op at the image's
+    depth + Op_to_sdr_planes + the interleave - the chains of the pipeline search, op by op in the oracle"""
+    planes = _random_planes(w, h, chroma, bit_depth, w * 13 + h * 3 + chroma * 5 + bit_depth)
+    matrix = nclx[1] if nclx[0] else 2
+    full = nclx[3] if nclx[0] else 1
+    int_chain = chroma == 1 and full and matrix not in (0, 8, 11, 14)
+    for out_fmt in (10, 11):
+        d = pkg.capi.ColourDesc(w, h, bit_depth, chroma, *nclx, out_fmt, 0, 0, 0, 0)
+        assert pkg.lib().hm_colour_pipeline(C.byref(d)) == (pkg.capi.HM_PIPE_SDR_INT420 if int_chain else pkg.capi.HM_PIPE_FLOAT_SDR)
+        got, ostride, obpp = _run_gpu(pkg, planes, w, h, bit_depth, chroma, nclx, out_fmt)
+        exp, es, chain = orc.convert_by_search(planes, w, h, bit_depth, chroma, nclx, out_fmt)
+        assert ("Op_to_sdr_planes" in chain) and (chain[0] == "Op_to_sdr_planes") == bool(int_chain)
+        assert es == ostride
+        np.testing.assert_array_equal(got[:h, :w * obpp], exp[:h, :w * obpp])
+
+
+@pytest.mark.parametrize("w,h", DEPTH_SIZES)
+@pytest.mark.parametrize("chroma", [1, 2, 3])
+@pytest.mark.parametrize("nclx", DEPTH_NCLX)
+@pytest.mark.parametrize("out_fmt", [12, 13, 14, 15])
+@pytest.mark.parametrize("has_alpha", [0, 1])
+def test_8bit_image_to_16bit_rgb(pkg, w, h, chroma, nclx, out_fmt, has_alpha):
+    """8-bit image -> RRGGBB[AA] (a 16-bit target of an 8-bit image is 10 bit, colorconversion.cc:575-585).  The chain
+    depends on chroma format, matrix AND on whether the image has an alpha plane (Op_to_hdr_planes before or after the
+    float op: different arithmetic) - whatever the search picks, op by op in the oracle"""
+    planes = _random_planes(w, h, chroma, 8, w * 11 + h * 5 + chroma * 3 + out_fmt)
+    got, ostride, obpp = _run_gpu(pkg, planes, w, h, 8, chroma, nclx, out_fmt, has_alpha=has_alpha)
+    exp, es, chain = orc.convert_by_search(planes, w, h, 8, chroma, nclx, out_fmt, has_alpha=bool(has_alpha))
+    assert "Op_to_hdr_planes" in chain
+    assert es == ostride
+    np.testing.assert_array_equal(got[:h, :w * obpp], exp[:h, :w * obpp])
+
+
+@pytest.mark.parametrize("w,h", [(64, 64), (33, 5), (1280, 854)])
+@pytest.mark.parametrize("chroma", [1, 2, 3])
+@pytest.mark.parametrize("bit_depth", [10, 12])
+@pytest.mark.parametrize("out_fmt", [13, 15])
+@pytest.mark.parametrize("has_alpha", [0, 1])
+def test_hdr_image_to_rrggbbaa(pkg, w, h, chroma, bit_depth, out_fmt, has_alpha):
+    """> 8-bit image -> RRGGBBAA: the float op (or the direct 4:2:0 op) and the 16-bit interleave; the alpha word of the
+    colour kernel's output is (1 << bits) - 1 (an alpha plane is written over it by the caller: tests/test_transforms.py)"""
+    planes = _random_planes(w, h, chroma, bit_depth, w + h * 7 + chroma + bit_depth)
+    for nclx in [(1, 9, 9, 0), (1, 1, 1, 1), (0, 0, 0, 0)]:
+        got, ostride, obpp = _run_gpu(pkg, planes, w, h, bit_depth, chroma, nclx, out_fmt, has_alpha=has_alpha)
+        exp, es, chain = orc.convert_by_search(planes, w, h, bit_depth, chroma, nclx, out_fmt, has_alpha=bool(has_alpha))
+        np.testing.assert_array_equal(got[:h, :w * obpp], exp[:h, :w * obpp])
+
+
+@pytest.mark.parametrize("w,h", [(64, 64), (17, 9), (1023, 3)])
+@pytest.mark.parametrize("chroma", [1, 2])
+@pytest.mark.parametrize("bit_depth,out_fmt", [(8, 12), (8, 15), (10, 10), (12, 11)])
+@pytest.mark.parametrize("nclx", [(0, 0, 0, 0), (1, 1, 1, 0), (1, 9, 9, 1)])
+def test_forced_bilinear_with_depth_change(pkg, w, h, chroma, bit_depth, out_fmt, nclx):
+    """forced bilinear upsampling combined with a change of sample depth: depth change, upsampling, float op and the
+    second depth change in whatever order the search decides"""
+    planes = _random_planes(w, h, chroma, bit_depth, w * 3 + h + chroma + bit_depth + out_fmt)
+    got, ostride, obpp = _run_gpu(pkg, planes, w, h, bit_depth, chroma, nclx, out_fmt, upsampling=2)
+    exp, es, chain = orc.convert_by_search(planes, w, h, bit_depth, chroma, nclx, out_fmt, forced_bilinear=True)
+    assert any("bilinear" in c for c in chain)
+    np.testing.assert_array_equal(got[:h, :w * obpp], exp[:h, :w * obpp])
 
 
 @pytest.mark.parametrize("w,h", [(64, 64), (1280, 854), (72, 72), (17, 9), (1, 1), (2, 2), (3, 2), (2, 3), (1023, 3), (4030, 31), (5, 1), (1, 6)])

@@ -161,6 +161,55 @@ def test_alpha_auxiliary_image(hm, alpha_size):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("main_bd,alpha_bd", [(10, 10), (10, 8), (8, 8), (12, 10)])
+@pytest.mark.parametrize("cf", [1, 2])
+def test_alpha_through_depth_changing_chains(hm, main_bd, alpha_bd, cf):
+    """The alpha plane in the chains that change the sample depth (the chains of oracle/
+    pipeline_search.py): a deeper image to RGBA32 (Op_to_sdr_planes shifts a deeper alpha plane down, copies an 8-bit
+    one), any image to RRGGBBAA (an 8-bit image's alpha plane goes through Op_to_hdr_planes: (a << 2) | (a >> 6), a
+    deeper image's is copied as 16-bit words; planes of the other depth class are refused as the reference's ops
+    misread them)."""
+    W, H = 96, 64
+    kw = dict(width=W, height=H, vui=1, full_range=0, matrix=1, primaries=1, chroma_format=cf)
+    main = synthutil.picture(8700 + main_bd + cf, bit_depth=main_bd, **kw)
+    alpha = synthutil.picture(8750 + alpha_bd, width=W, height=H, chroma_format=0, bit_depth=alpha_bd)
+    data = heifwriter.write_heic([main], (W, H), chroma_format=cf, bit_depth=main_bd,
+                                 aux=[(alpha, (W, H), "urn:mpeg:mpegB:cicp:systems:auxiliary:alpha", 0, alpha_bd)])
+    a = orc.oracle_decode(hevcutil.parse(hm, alpha), 3)[0][0][:H, :W].astype(np.int64)
+    f = pipeline.HeifFile(hm, data)
+    iid = f.primary()
+    # RGBA32
+    if main_bd == 8 and alpha_bd != 8:
+        with pytest.raises(RuntimeError):
+            f.decode(iid, 11)
+    else:
+        got, meta = f.decode(iid, 11)
+        exp, stride, _ = pipeline.cpu_decode(hm, [main], W, H, W, H, 1, False, 11, has_alpha=True)
+        exp[:H, 3:W * 4:4] = (a >> (alpha_bd - 8) if (alpha_bd > 8) else a).astype(np.uint8)
+        assert meta["stride"][0] == stride and meta["bit_depth"] == 8
+        np.testing.assert_array_equal(got[0][:H, :W * 4], exp[:H, :W * 4])
+    # RRGGBBAA
+    for fmt in (13, 15):
+        if (main_bd > 8) != (alpha_bd > 8):
+            with pytest.raises(RuntimeError):
+                f.decode(iid, fmt)
+            continue
+        got, meta = f.decode(iid, fmt)
+        exp, stride, _ = pipeline.cpu_decode(hm, [main], W, H, W, H, 1, False, fmt, has_alpha=True)
+        aw = ((a << 2) | (a >> 6)) if alpha_bd == 8 else a
+        hi, lo = (6, 7) if fmt == 13 else (7, 6)
+        exp[:H, hi:W * 8:8] = (aw >> 8).astype(np.uint8)
+        exp[:H, lo:W * 8:8] = (aw & 0xFF).astype(np.uint8)
+        assert meta["stride"][0] == stride and meta["bit_depth"] == (main_bd if main_bd > 8 else 10)
+        np.testing.assert_array_equal(got[0][:H, :W * 8], exp[:H, :W * 8])
+    # RRGGBB (no alpha in the target): the plane is dropped
+    got, _ = f.decode(iid, 14)
+    exp, _, _ = pipeline.cpu_decode(hm, [main], W, H, W, H, 1, False, 14, has_alpha=True)
+    np.testing.assert_array_equal(got[0][:H, :W * 6], exp[:H, :W * 6])
+    f.close()
+
+
+@pytest.mark.gpu
 def test_monochrome_alpha_and_monochrome_image(hm):
     """4:0:0 pictures (the usual coding of alpha planes): as the alpha auxiliary image of a colour
     image, and as a main image (Op_mono_to_RGB24_32, monochrome.cc:160-273: v, v, v[, 0xFF])."""
