@@ -384,6 +384,31 @@ def effective_cpus():
     return n
 
 
+def wpp_parse_rates(pkg):
+    """hm_hevc_parse_mt on the three real 1080p WPP pictures: ms per picture with 1 thread and with the usable CPUs
+    (rows of a picture entropy-decoded in parallel, two CTBs apart; single-image latency)"""
+    capi = pkg.capi
+    res = {}
+    n_cpu = effective_cpus()
+    for name in ("basketball_1080p_qp32", "basketball_1080p_qp25", "basketball_1080p_qp1"):
+        path = os.path.join(ROOT, "tests", "data", name + ".hevc")
+        if not os.path.exists(path):
+            continue
+        data = open(path, "rb").read()
+        row = {}
+        for threads in sorted({1, 4, min(8, n_cpu), n_cpu}):
+            capi.parse_hevc(data, threads=threads)
+            best = 1e9
+            for _ in range(5):
+                t0 = time.perf_counter()
+                capi.parse_hevc(data, threads=threads)
+                best = min(best, time.perf_counter() - t0)
+            row[f"threads_{threads}_ms"] = round(best * 1e3, 2)
+        res[name] = row
+    res["note"] = "1920x1080 intra pictures, CTB 64, 17 rows: best of 5; the command stream is identical to the serial parser's (tests/test_oracle_decode.py)"
+    return res
+
+
 def guarded(out, key, fn):
     try:
         out[key] = fn()
@@ -394,6 +419,7 @@ def guarded(out, key, fn):
 def side_legs(out, args, torch, pkg, dev, st, gb, kept, strides, stream_b):
     B = len(gb.images)
     guarded(out, "host_entropy_decode", lambda: host_parse_rate(pkg, kept[0]))
+    guarded(out, "wpp_row_parallel_parse", lambda: wpp_parse_rates(pkg))
     guarded(out, "device_inclusive", lambda: device_inclusive(torch, pkg, dev, gb, st, stream_b))
     guarded(out, "end_to_end", lambda: end_to_end_single(pkg, kept[0]))
     guarded(out, "end_to_end_pipelined", lambda: end_to_end_pipelined(pkg, kept))

@@ -86,12 +86,17 @@ def bind_decode(L):
     L.hm_batch_algorithmic_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
 
 
-def parse_hevc(data, annexb=False):
-    """hm_hevc_parse -> command-stream blob (bytes)."""
+def parse_hevc(data, annexb=False, threads=1):
+    """hm_hevc_parse[_mt] -> command-stream blob (bytes)."""
     L = lib()
     blob = C.POINTER(C.c_uint8)()
     size = C.c_size_t()
-    check(L.hm_hevc_parse(data, len(data), 1 if annexb else 0, C.byref(blob), C.byref(size)))
+    L.hm_hevc_parse_mt.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.hm_hevc_parse_mt.restype = C.c_int
+    if threads > 1:
+        check(L.hm_hevc_parse_mt(data, len(data), 1 if annexb else 0, threads, C.byref(blob), C.byref(size)))
+    else:
+        check(L.hm_hevc_parse(data, len(data), 1 if annexb else 0, C.byref(blob), C.byref(size)))
     out = C.string_at(blob, size.value)
     L.hm_free(blob)
     return out

@@ -8,14 +8,16 @@
 
 namespace hm {
 
-void unescape_nal(const uint8_t* p, size_t n, std::vector<uint8_t>& out)
+void unescape_nal(const uint8_t* p, size_t n, std::vector<uint8_t>& out, std::vector<uint32_t>* removed)
 {
   out.clear();
   out.reserve(n);
+  if (removed) removed->clear();
   int zeros = 0;
   for (size_t i = 0; i < n; i++) {
     if (zeros >= 2 && p[i] == 3) { // emulation_prevention_three_byte
       zeros = 0;
+      if (removed) removed->push_back((uint32_t)i);
       continue;
     }
     out.push_back(p[i]);

@@ -6,7 +6,13 @@
 // push_data) and in libde265's decctx.cc:1209-1290 / slice.cc (parameter sets, slice header,
 // slice data).  Reconstruction itself is NOT done here - that is the GPU's job.
 #include <cstdlib>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <mutex>
+#include <thread>
 #include <memory>
 
 #include "hevc_syntax.h"
@@ -22,6 +28,7 @@ class DecoderEC {
   inline int bypass(int, int) { return dec_.decode_bypass(); }
   inline int terminate(int) { int b = dec_.decode_terminate(); check(); return b; }
   ContextSet& contexts() { return cs_; }
+  const uint8_t* position() const { return dec_.position(); } // after a terminating bin: the next byte-aligned position
   inline int pcm_flag() { return terminate(0); }
   // PCM samples start at the byte the arithmetic decoder's read pointer stands on after the terminating bin, and the
   // decoder restarts on the next byte boundary behind them (slice.cc:4506-4536, cabac.cc:658-677 of the reference)
@@ -74,6 +81,8 @@ struct Decoder {
   PPS pps[64];
   PictureState pic;
   std::vector<uint8_t> rbsp; // unescaped NAL, reused
+  std::vector<uint32_t> removed; // positions of its emulation prevention bytes in the escaped NAL
+  int threads = 1;           // > 1: slice segments with WPP entry points are parsed row-parallel (parse_rows_parallel)
   void start_stream()
   {
     for (SPS& s : sps) s.valid = false;
@@ -97,7 +106,7 @@ struct Decoder {
     const int layer = ((p[0] & 1) << 5) | (p[1] >> 3);
     if (layer != 0) return; // only the base layer
     if (nal_type == 33 || nal_type == 34 || nal_type <= 21) {
-      unescape_nal(p, n, rbsp);
+      unescape_nal(p, n, rbsp, threads > 1 ? &removed : nullptr);
       if (rbsp.size() < 2) return;
       BitReader br(rbsp.data() + 2, rbsp.size() - 2);
       if (nal_type == 33) {
@@ -169,12 +178,144 @@ struct Decoder {
     // slice data starts right after the header in the unescaped payload (+2 for the NAL header)
     const uint8_t* begin = rbsp.data() + 2 + sh.data_byte_offset;
     const uint8_t* end = rbsp.data() + rbsp.size();
-    DecoderEC ec(begin, end);
-    SliceWalker<DecoderEC> walker(ec, pic, sh, slice_idx);
-    next_ts = walker.decode_slice_segment(start_ts);
+    if (threads > 1 && p.entropy_coding_sync && !p.tiles_enabled && !sh.dependent && sh.num_entry_points > 0 &&
+        (sh.slice_segment_address % s.ctb_w) == 0)
+      next_ts = parse_rows_parallel(sh, slice_idx, start_ts, begin, end);
+    else {
+      DecoderEC ec(begin, end);
+      SliceWalker<DecoderEC> walker(ec, pic, sh, slice_idx);
+      next_ts = walker.decode_slice_segment(start_ts);
+    }
     prev_sh = sh;
     have_prev_sh = true;
     if (next_ts == s.ctb_w * s.ctb_h) picture_done = true;
+  }
+
+  // Wavefront-parallel parse of one slice segment whose header carries an entry point per CTB row (WPP, no tiles): the
+  // rows are independent sub-streams except for the context tables handed down after the second CTB of a row
+  // (9.3.1 / slice.cc:5004-5083 of the reference) and the neighbour data of the row above, so row r may run two CTBs
+  // behind row r - 1 - the schedule of the reference's own WPP threads (decctx.cc:1004-1116).  Every row gets its own
+  // arithmetic decoder, walker, QP predictor state and level list; `threads` workers take the rows in order.
+  // The serial parser never looks at the entry point offsets (a sub-stream starts where the previous one's arithmetic
+  // decoder stopped); this path needs them and therefore checks them: a row that does not end exactly where the next
+  // one is said to begin makes the whole stream fall back to the serial parse (Inconsistent), as does any error - the
+  // serial parse then reports it in decoding order.
+  struct Inconsistent {};
+  int parse_rows_parallel(const SliceHeader& sh, int slice_idx, int start_ts, const uint8_t* begin, const uint8_t* end)
+  {
+    const SPS& s = *cur_sps;
+    const int W = s.ctb_w, row0 = sh.slice_segment_address / W, n_rows = sh.num_entry_points + 1;
+    // sub-stream starts in the unescaped payload: the offsets count the bytes of the escaped NAL (7.4.7.1)
+    const size_t data_unesc = (size_t)(begin - rbsp.data());
+    auto escaped_of = [&](size_t u) { size_t k = 0; while (k < removed.size() && removed[k] <= u + k) k++; return u + k; };
+    auto unescaped_of = [&](size_t e) { size_t k = 0; while (k < removed.size() && removed[k] < e) k++; return e - k; };
+    std::vector<const uint8_t*> start((size_t)n_rows + 1);
+    size_t e = escaped_of(data_unesc);
+    start[0] = begin;
+    for (int k = 1; k < n_rows; k++) {
+      e += sh.entry_point_offset[k - 1];
+      const size_t u = unescaped_of(e);
+      if (u > rbsp.size() || rbsp.data() + u < start[k - 1]) throw Inconsistent();
+      start[k] = rbsp.data() + u;
+    }
+    start[n_rows] = end;
+
+    struct alignas(128) Row { // (a row's private state and the counters its neighbour spins on: separate cache lines)
+      std::vector<hm_coeff> coeffs;
+      PictureState::QpState qs;
+      int ended_slice = 0;
+      bool uses_pcm = false, uses_tq = false;
+      alignas(128) std::atomic<int> done{0};      // CTBs finished
+      alignas(128) std::atomic<int> ctx_ready{0}; // wpp_ctx[row] stored
+    };
+    std::vector<Row> rows((size_t)n_rows);
+    std::atomic<int> next_row{0};
+    std::atomic<bool> failed{false};
+    std::exception_ptr first_error;
+    std::mutex error_lock;
+    const int N = W * s.ctb_h;
+
+    auto parse_row = [&](int k) {
+      const int row = row0 + k;
+      Row& R = rows[(size_t)k];
+      DecoderEC ec(start[k], start[k + 1]);
+      SliceWalker<DecoderEC> walker(ec, pic, sh, slice_idx);
+      R.qs.last_qpy_prev_qg = R.qs.current_qpy = sh.SliceQPY; // (the first quantisation group of a WPP row predicts from the slice QP)
+      walker.use_private_state(&R.qs, &R.coeffs);
+      auto wait_for = [&](std::atomic<int>& v, int need) {
+        for (int spins = 0; v.load(std::memory_order_acquire) < need; spins++) {
+          if (failed.load(std::memory_order_relaxed)) throw Inconsistent();
+          if (spins > 64) std::this_thread::yield();
+        }
+      };
+      if (k == 0) init_contexts(ec.contexts(), sh.SliceQPY);
+      else if (W < 2) init_contexts(ec.contexts(), sh.SliceQPY); // (import_wpp_row: a picture one CTB wide)
+      else {
+        wait_for(rows[(size_t)k - 1].ctx_ready, 1);
+        ec.contexts() = pic.wpp_ctx[(size_t)row - 1];
+        pic.wpp_ok[(size_t)row - 1] = 0; // taken (import_wpp_row)
+      }
+      ec.start_substream();
+      for (int x = 0; x < W; x++) {
+        if (k > 0) wait_for(rows[(size_t)k - 1].done, std::min(x + 2, W));
+        const int ts = row * W + x; // (no tiles: tile scan == raster scan)
+        walker.decode_ctu(ts);
+        if (x == 1 && row < s.ctb_h - 1) {
+          pic.wpp_ctx[(size_t)row] = ec.contexts();
+          pic.wpp_ok[(size_t)row] = 1; // (read by the row below behind ctx_ready, or by a later slice segment)
+          R.ctx_ready.store(1, std::memory_order_release);
+        }
+        const int end_of_slice = ec.terminate(ts + 1 == N ? 1 : -1);
+        R.done.store(x + 1, std::memory_order_release);
+        if (end_of_slice) {
+          if (k != n_rows - 1) throw Inconsistent(); // the slice ends before its last entry point
+          if (cur_pps->dependent_slice_segments_enabled) { pic.dep_ctx = ec.contexts(); pic.dep_ok = true; }
+          R.ended_slice = ts + 1;
+          break;
+        }
+        if (ts + 1 >= N) throw ParseError(HM_ERR_BITSTREAM, "missing end_of_slice_segment_flag");
+        if (x == W - 1) {
+          if (k == n_rows - 1) throw Inconsistent(); // the slice goes on behind its last entry point
+          if (!ec.terminate(2)) throw ParseError(HM_ERR_BITSTREAM, "end_of_subset_one_bit not set");
+          if (ec.position() != start[k + 1]) throw Inconsistent();
+        }
+      }
+      if (W == 1 && row < s.ctb_h - 1) R.ctx_ready.store(1, std::memory_order_release);
+      R.uses_pcm = walker.uses_pcm(); R.uses_tq = walker.uses_tq_bypass();
+    };
+    auto worker = [&]() {
+      for (;;) {
+        const int k = next_row.fetch_add(1);
+        if (k >= n_rows || failed.load()) return;
+        try { parse_row(k); }
+        catch (...) {
+          std::lock_guard<std::mutex> g(error_lock);
+          if (!first_error) first_error = std::current_exception();
+          failed.store(true);
+          return;
+        }
+      }
+    };
+    const int n_workers = std::min(threads, n_rows);
+    std::vector<std::thread> crew;
+    for (int i = 1; i < n_workers; i++) crew.emplace_back(worker);
+    worker();
+    for (std::thread& t : crew) t.join();
+    if (first_error) throw Inconsistent(); // (whatever it was: the serial parse finds it in decoding order)
+    if (!rows.back().ended_slice) throw Inconsistent();
+    // the rows' level lists behind the picture's, the records rebased
+    for (int k = 0; k < n_rows; k++) {
+      const uint32_t base = (uint32_t)pic.coeffs.size();
+      Row& R = rows[(size_t)k];
+      pic.coeffs.insert(pic.coeffs.end(), R.coeffs.begin(), R.coeffs.end());
+      if (base)
+        for (int x = 0; x < W; x++)
+          for (hm_tu& t : pic.ctb_tus[(size_t)(row0 + k) * W + x]) t.coeff_first += base;
+      pic.uses_pcm |= R.uses_pcm;
+      pic.uses_tq_bypass |= R.uses_tq;
+    }
+    pic.qs = rows.back().qs;
+    return rows.back().ended_slice;
   }
 
   static void check_supported(const SPS& s, const PPS& p)
@@ -372,17 +513,13 @@ static_assert(sizeof(hm_slice) == 12, "hm_slice layout");
 static_assert(sizeof(hm_sao) == 8, "hm_sao layout");
 static_assert(sizeof(hm_pic) % 4 == 0, "hm_pic layout");
 
-extern "C" {
-
-int hm_hevc_parse(const uint8_t* data, size_t size, int annexb, uint8_t** out_blob, size_t* out_size)
+static int hm_hevc_parse_run(const uint8_t* data, size_t size, int annexb, int threads, uint8_t** out_blob, size_t* out_size)
 {
-  if (!data || !out_blob || !out_size) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
-  *out_blob = nullptr;
-  *out_size = 0;
   try {
     static thread_local std::unique_ptr<hm::Decoder> workspace;
     if (!workspace) workspace = std::make_unique<hm::Decoder>();
     hm::Decoder* dec = workspace.get();
+    dec->threads = threads;
     dec->start_stream();
     if (annexb) {
       // split at 00 00 01 start codes
@@ -427,6 +564,39 @@ int hm_hevc_parse(const uint8_t* data, size_t size, int annexb, uint8_t** out_bl
     return hm_fail(HM_ERR_INTERNAL, "%s", e.what());
   }
 }
+
+extern "C" {
+
+int hm_hevc_parse(const uint8_t* data, size_t size, int annexb, uint8_t** out_blob, size_t* out_size)
+{
+  return hm_hevc_parse_mt(data, size, annexb, 1, out_blob, out_size);
+}
+
+// The same with up to `threads` host threads for one picture: slice segments coded with wavefront parallel processing
+// (an entry point per CTB row) are entropy-decoded row-parallel, two CTBs apart (the reference: decctx.cc:1004-1116).
+// Same command stream byte for byte; streams whose entry points do not match their sub-streams, and streams with
+// errors, are parsed again serially.
+int hm_hevc_parse_mt(const uint8_t* data, size_t size, int annexb, int threads, uint8_t** out_blob, size_t* out_size)
+{
+  if (!data || !out_blob || !out_size) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
+  *out_blob = nullptr;
+  *out_size = 0;
+  if (threads > 1) {
+    try {
+      if (hm_hevc_parse_run(data, size, annexb, threads, out_blob, out_size) == HM_OK) return HM_OK;
+    }
+    catch (const hm::Decoder::Inconsistent&) {
+    }
+    // entry points that do not match the sub-streams, or an error: the serial parse decides (and words the error)
+    if (*out_blob) { std::free(*out_blob); *out_blob = nullptr; }
+    *out_size = 0;
+  }
+  return hm_hevc_parse_run(data, size, annexb, 1, out_blob, out_size);
+}
+
+} // extern "C"
+
+extern "C" {
 
 void hm_free(void* p) { std::free(p); }
 

@@ -182,7 +182,8 @@ struct PictureState {
   std::vector<hm_coeff> coeffs;
   bool uses_pcm = false, uses_tq_bypass = false;
   // QP predictor state, persists across dependent slice segments (decctx.h thread_context fields)
-  struct { int last_qpy_prev_qg = 0, current_qpy = 0, cur_qg_x = -1, cur_qg_y = -1; } qs;
+  struct QpState { int last_qpy_prev_qg = 0, current_qpy = 0, cur_qg_x = -1, cur_qg_y = -1; };
+  QpState qs;
   // context tables handed over between sub-streams / slice segments: per CTB row the tables after its 2nd CTB (WPP,
   // image_unit::ctx_models of the reference), and the tables at the end of the last slice segment (dependent segments)
   std::vector<ContextSet> wpp_ctx;
@@ -217,9 +218,26 @@ template <class EC>
 class SliceWalker {
  public:
   SliceWalker(EC& ec, PictureState& pic, const SliceHeader& sh, int slice_idx)
-      : ec_(ec), pic_(pic), sps_(*pic.sps), pps_(*pic.pps), sh_(sh), slice_idx_(slice_idx)
+      : ec_(ec), pic_(pic), sps_(*pic.sps), pps_(*pic.pps), sh_(sh), slice_idx_(slice_idx), qs_(&pic.qs), coeffs_(&pic.coeffs)
   {
     w4_ = (sps_.width + 3) >> 2;
+  }
+  // A walker of one CTB row of a wavefront-parallel parse (hevc_parse.cpp) keeps the state a sub-stream carries in its
+  // own objects: the QP predictor state and the level list (rebased into the picture's list afterwards).
+  void use_private_state(PictureState::QpState* qs, std::vector<hm_coeff>* coeffs) { qs_ = qs; coeffs_ = coeffs; }
+  bool uses_pcm() const { return uses_pcm_; }
+  bool uses_tq_bypass() const { return uses_tq_bypass_; }
+  // one CTU at tile-scan address ts (the body of the slice_segment_data loop)
+  void decode_ctu(int ts)
+  {
+    const int W = sps_.ctb_w;
+    const int rs = pps_.CtbAddrTStoRS[ts];
+    ctb_addr_ts_ = ts;
+    ctb_addr_rs_ = rs;
+    pic_.ctb_slice_addr[rs] = sh_.SliceAddrRS;
+    pic_.ctbs[rs].slice_idx = (uint16_t)slice_idx_;
+    pic_.ctbs[rs].flags |= HM_CTB_CODED;
+    coding_tree_unit(rs % W, rs / W);
   }
 
   // §7.3.8.1 slice_segment_data().  Returns the CTB address (tile scan) following the last decoded CTB.
@@ -249,17 +267,12 @@ class SliceWalker {
     else init_contexts(ec_.contexts(), sh_.SliceQPY);
     ec_.start_substream();
     // QP predictor state
-    if (!sh_.dependent) { pic_.qs.last_qpy_prev_qg = sh_.SliceQPY; pic_.qs.current_qpy = sh_.SliceQPY; pic_.qs.cur_qg_x = pic_.qs.cur_qg_y = -1; }
+    if (!sh_.dependent) { qs_->last_qpy_prev_qg = sh_.SliceQPY; qs_->current_qpy = sh_.SliceQPY; qs_->cur_qg_x = qs_->cur_qg_y = -1; }
 
     for (;;) {
       if (ts >= N) throw ParseError(HM_ERR_BITSTREAM, "slice data runs past the picture");
       const int rs = pps_.CtbAddrTStoRS[ts];
-      ctb_addr_ts_ = ts;
-      ctb_addr_rs_ = rs;
-      pic_.ctb_slice_addr[rs] = sh_.SliceAddrRS;
-      pic_.ctbs[rs].slice_idx = (uint16_t)slice_idx_;
-      pic_.ctbs[rs].flags |= HM_CTB_CODED;
-      coding_tree_unit(rs % W, rs / W);
+      decode_ctu(ts);
       // WPP: store after the 2nd CTB of a row (libde265 slice.cc:5071-5083: ctbx == 1), except in the last row
       if (pps_.entropy_coding_sync && (rs % W) == 1 && (rs / W) < sps_.ctb_h - 1) {
         pic_.wpp_ctx[rs / W] = ec_.contexts();
@@ -270,6 +283,8 @@ class SliceWalker {
       ts++;
       if (end_of_slice) {
         if (pps_.dependent_slice_segments_enabled) { pic_.dep_ctx = ec_.contexts(); pic_.dep_ok = true; }
+        pic_.uses_pcm |= uses_pcm_;
+        pic_.uses_tq_bypass |= uses_tq_bypass_;
         break;
       }
       if (ts >= N) throw ParseError(HM_ERR_BITSTREAM, "missing end_of_slice_segment_flag");
@@ -463,10 +478,10 @@ class SliceWalker {
   {
     const int qgmask = (1 << pps_.Log2MinCuQpDeltaSize) - 1;
     const int xQG = xCU - (xCU & qgmask), yQG = yCU - (yCU & qgmask);
-    if (xQG != pic_.qs.cur_qg_x || yQG != pic_.qs.cur_qg_y) {
-      pic_.qs.last_qpy_prev_qg = pic_.qs.current_qpy;
-      pic_.qs.cur_qg_x = xQG;
-      pic_.qs.cur_qg_y = yQG;
+    if (xQG != qs_->cur_qg_x || yQG != qs_->cur_qg_y) {
+      qs_->last_qpy_prev_qg = qs_->current_qpy;
+      qs_->cur_qg_x = xQG;
+      qs_->cur_qg_y = yQG;
     }
     const int ctbmask = (1 << sps_.log2_ctb) - 1;
     const bool first_in_ctb_row = (xQG == 0 && (yQG & ctbmask) == 0);
@@ -482,7 +497,7 @@ class SliceWalker {
     }
     int pred;
     if (first_in_slice || first_in_tile || (first_in_ctb_row && pps_.entropy_coding_sync)) pred = sh_.SliceQPY;
-    else pred = pic_.qs.last_qpy_prev_qg;
+    else pred = qs_->last_qpy_prev_qg;
     int qa = pred, qb = pred;
     // Quirk Q12 of the reference (fork): its table-driven MinTbAddrZS (pps.cc:700-790, the standard derivation is
     // "#if 0") is built on the *raster* CTB address, and transform.cc:108-135 compares the CTB address taken out of
@@ -515,7 +530,7 @@ class SliceWalker {
     const int n = (1 << log2CbSize) >> sps_.log2_min_cb;
     const int bx = xCU >> sps_.log2_min_cb, by = yCU >> sps_.log2_min_cb;
     for (int j = 0; j < n; j++) std::memset(&pic_.qpy[bx + (size_t)(by + j) * sps_.min_cb_w], qpy, (size_t)n);
-    pic_.qs.current_qpy = qpy;
+    qs_->current_qpy = qpy;
     cu_qpy_ = qpy;
   }
   int qpy_at(int x, int y) const
@@ -532,7 +547,7 @@ class SliceWalker {
     cu_bypass_ = false;
     if (pps_.transquant_bypass_enabled && ec_.bin(CTX_TQ_BYPASS, K_TQ_BYPASS, 0)) {
       cu_bypass_ = true;
-      pic_.uses_tq_bypass = true;
+      uses_tq_bypass_ = true;
       pic_.ctbs[ctb_addr_rs_].flags |= HM_CTB_LOSSLESS;
     }
     // I slice: no cu_skip_flag / pred_mode_flag
@@ -545,7 +560,7 @@ class SliceWalker {
     }
     if (sps_.pcm_enabled && !nxn && log2CbSize >= sps_.log2_min_pcm_cb && log2CbSize <= sps_.log2_max_pcm_cb) {
       if (ec_.pcm_flag()) {
-        pic_.uses_pcm = true;
+        uses_pcm_ = true;
         pic_.ctbs[ctb_addr_rs_].flags |= HM_CTB_LOSSLESS;
         pcm_coding_unit(x0, y0, log2CbSize);
         return;
@@ -623,7 +638,7 @@ class SliceWalker {
       t.y = (uint8_t)(yb & ((1 << (sps_.log2_ctb - lh)) - 1));
       t.info = (uint8_t)(log2 | (cIdx << HM_TU_CIDX_SHIFT) | HM_TU_CBF);
       t.pred_mode = (uint8_t)(1 | HM_TU_MODE_PCM | (cu_bypass_ ? HM_TU_MODE_BYPASS : 0)); // a PCM unit may also be bypass: the filters test both
-      t.coeff_first = (uint32_t)pic_.coeffs.size();
+      t.coeff_first = (uint32_t)coeffs_->size();
       t.n_coeff = (uint16_t)(w * w);
       t.qp = (uint8_t)qp_prime_[cIdx];
       t.qpy = (int8_t)cu_qpy_;
@@ -631,7 +646,7 @@ class SliceWalker {
         hm_coeff c;
         c.pos = (uint16_t)i;
         c.value = (int16_t)(ec_.pcm_bits(bits) << shift);
-        pic_.coeffs.push_back(c);
+        coeffs_->push_back(c);
       }
       pic_.ctb_tus[ctb_addr_rs_].push_back(t);
     }
@@ -743,7 +758,7 @@ class SliceWalker {
           while (k--) v += ec_.bypass(K_QP_DELTA_SUFFIX, 32 + k) << k;
         }
         int sign = 0;
-        if (v) sign = ec_.bypass(K_QP_SIGN, pic_.qs.current_qpy - sh_.SliceQPY); // idx = QP drift (synthesiser hint)
+        if (v) sign = ec_.bypass(K_QP_SIGN, qs_->current_qpy - sh_.SliceQPY); // idx = QP drift (synthesiser hint)
         is_cu_qp_delta_coded_ = true;
         cu_qp_delta_val_ = sign ? -v : v;
         const int lim_lo = -(26 + sps_.qp_bd_offset_y / 2), lim_hi = 25 + sps_.qp_bd_offset_y / 2;
@@ -797,14 +812,14 @@ class SliceWalker {
     t.y = (uint8_t)(yc & ((1 << (sps_.log2_ctb - lh)) - 1));
     t.info = (uint8_t)(log2 | (cIdx << HM_TU_CIDX_SHIFT));
     t.pred_mode = (uint8_t)(mode | (cu_bypass_ ? HM_TU_MODE_BYPASS : 0));
-    t.coeff_first = (uint32_t)pic_.coeffs.size();
+    t.coeff_first = (uint32_t)coeffs_->size();
     bool tskip = false;
     if (cbf) {
       residual_coding(log2, cIdx, mode, tskip);
       t.info |= HM_TU_CBF;
       if (tskip) t.info |= HM_TU_TSKIP;
     }
-    const size_t ncoef = pic_.coeffs.size() - t.coeff_first;
+    const size_t ncoef = coeffs_->size() - t.coeff_first;
     t.n_coeff = (uint16_t)ncoef;
     t.qp = (uint8_t)qp_prime_[cIdx];
     t.qpy = (int8_t)cu_qpy_;
@@ -965,7 +980,7 @@ class SliceWalker {
         hm_coeff hc;
         hc.pos = (uint16_t)(xC + yC * nT);
         hc.value = (int16_t)val;
-        pic_.coeffs.push_back(hc);
+        coeffs_->push_back(hc);
       }
     }
   }
@@ -1015,6 +1030,9 @@ class SliceWalker {
   const PPS& pps_;
   const SliceHeader& sh_;
   int slice_idx_;
+  PictureState::QpState* qs_;
+  std::vector<hm_coeff>* coeffs_;
+  bool uses_pcm_ = false, uses_tq_bypass_ = false;
   int w4_ = 0;
   int ctb_addr_ts_ = 0, ctb_addr_rs_ = 0;
   int ctb_x_ = 0, ctb_y_ = 0;      // current CTB in CTB units

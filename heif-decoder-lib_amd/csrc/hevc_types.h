@@ -196,7 +196,9 @@ void parse_slice_header(BitReader& br, int nal_unit_type, const SPS* sps_table, 
                         const SliceHeader* prev, SliceHeader& sh);
 
 // remove emulation prevention bytes (00 00 03 -> 00 00): `out` receives the RBSP incl. the 2-byte NAL header
-void unescape_nal(const uint8_t* p, size_t n, std::vector<uint8_t>& out);
+// (removed: positions, in the escaped NAL, of the emulation prevention bytes that were dropped - entry point offsets
+//  count them, 7.4.7.1)
+void unescape_nal(const uint8_t* p, size_t n, std::vector<uint8_t>& out, std::vector<uint32_t>* removed = nullptr);
 
 inline int ceil_log2(uint32_t v)
 {

@@ -465,7 +465,7 @@ int job_tile_count(const DecodeJob& j)
 
 // host entropy decode of coded picture k (CABAC on the calling thread, like the reference's std::async tile tasks,
 // context.cc:2361-2401); distinct k may run concurrently
-void job_parse_tile(DecodeJob& j, int k)
+void job_parse_tile(DecodeJob& j, int k, int row_threads)
 {
   int which = 0;
   if (k >= (int)j.item[0].tiles.size()) { which = 1; k -= (int)j.item[0].tiles.size(); }
@@ -473,7 +473,7 @@ void job_parse_tile(DecodeJob& j, int k)
   std::vector<uint8_t> data;
   hm::HeifError e;
   if (!j.f->file.hevc_data(P.tiles[k].id, data, e)) { P.status[k] = e.status; P.messages[k] = e.message; return; }
-  const int rc = hm_hevc_parse(data.data(), data.size(), 0, &P.blobs[k].p, &P.blobs[k].n);
+  const int rc = hm_hevc_parse_mt(data.data(), data.size(), 0, row_threads, &P.blobs[k].p, &P.blobs[k].n);
   if (rc) { P.status[k] = rc; P.messages[k] = hm_last_error(); }
 }
 
@@ -631,14 +631,17 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
   //      heif_context_set_threads tile fan-out, context.cc:2361-2401) ----
   const int nt = job_tile_count(job);
   std::atomic<int> next{0};
+  int nthreads = params->host_threads > 0 ? params->host_threads : 1;
+  // fewer coded pictures than threads (a single image, or an image and its alpha plane): the threads left over parse
+  // the rows of a WPP-coded picture in parallel instead (the reference's decoder threads, decctx.cc:1004-1116)
+  const int row_threads = nt > 0 && nthreads > nt ? nthreads / nt : 1;
   auto worker = [&]() {
     for (;;) {
       const int i = next.fetch_add(1);
       if (i >= nt) break;
-      job_parse_tile(job, i);
+      job_parse_tile(job, i, row_threads);
     }
   };
-  int nthreads = params->host_threads > 0 ? params->host_threads : 1;
   if (nthreads > nt) nthreads = nt;
   Crew::instance().run(nthreads, worker);
   lap("host entropy decode done");

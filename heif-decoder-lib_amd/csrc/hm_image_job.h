@@ -96,7 +96,8 @@ struct DecodeJob {
 
 int job_plan(DecodeJob& j);
 int job_tile_count(const DecodeJob& j);
-void job_parse_tile(DecodeJob& j, int k); // k = 0 .. job_tile_count - 1 (main image tiles first, then alpha); thread-safe per tile
+void job_parse_tile(DecodeJob& j, int k, int row_threads = 1); // k = 0 .. job_tile_count - 1 (main image tiles first, then alpha); thread-safe per tile;
+                                                                // row_threads > 1: WPP rows of this picture in parallel (hm_hevc_parse_mt)
 int job_enqueue(DecodeJob& j, hm_decoded* out);
 int job_complete(DecodeJob& j, hm_decoded* out);
 

@@ -128,6 +128,10 @@ HM_API int hm_colour_convert_batch(const hm_colour_desc* d, int n, const void* c
  * Returns HM_ERR_UNSUPPORTED for syntax outside the GPU hot path (inter slices,
  * range-extension tools, separate colour planes, more than 12 bits). */
 HM_API int hm_hevc_parse(const uint8_t* data, size_t size, int annexb, uint8_t** out_blob, size_t* out_size);
+/* the same with up to `threads` host threads for ONE picture: slice segments coded with wavefront parallel processing
+ * (entry points per CTB row) are entropy-decoded row-parallel like the reference's WPP threads (decctx.cc:1004-1116);
+ * the command stream is the same byte for byte */
+HM_API int hm_hevc_parse_mt(const uint8_t* data, size_t size, int annexb, int threads, uint8_t** out_blob, size_t* out_size);
 HM_API void hm_free(void* p);
 
 /* ------------------------------------------------------------------------- */

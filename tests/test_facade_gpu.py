@@ -251,6 +251,34 @@ def test_forced_bilinear_upsampling_option(api, hm):
     api.heif_image_release(img); api.heif_image_handle_release(h); api.heif_context_free(ctx); api.heif_decoding_options_free(opt)
 
 
+def test_hdr_image_to_8bit_targets_and_convert_hdr_to_8bit(api, hm):
+    """heif_decode_image of a 10-bit image: RGB24 / RGBA32 targets are 8 bit whatever the image holds
+    (colorconversion.cc:566-573), RRGGBBAA carries (1 << 10) - 1 as alpha; convert_hdr_to_8bit (heif.h:1585, context.cc:1550)
+    changes none of these targets (RRGGBB stays "> 8 bit", a native target is not converted at all) and is accepted"""
+    import synthutil
+    W, H = 128, 72
+    pic = synthutil.picture(9100, width=W, height=H, bit_depth=10, chroma_format=2, vui=1, full_range=0, matrix=9, primaries=9)
+    data = heifwriter.write_heic([pic], (W, H), chroma_format=2, bit_depth=10)
+    for hdr_flag in (0, 1):
+        opt = api.heif_decoding_options_alloc()
+        C.cast(opt, C.POINTER(_DecodingOptions)).contents.convert_hdr_to_8bit = hdr_flag
+        for chroma, bpp, bits in ((10, 3, 8), (11, 4, 8), (14, 6, 10), (13, 8, 10), (15, 8, 10)):
+            ctx, h, img, e = _decode(api, data, 0, 1, chroma, options=opt)
+            assert e.code == 0, (chroma, e.message)
+            stride = C.c_int()
+            p = api.heif_image_get_plane_readonly(img, 10, C.byref(stride))
+            got = np.ascontiguousarray(np.ctypeslib.as_array(p, shape=(H, stride.value)))
+            exp, es, _ = pipeline.cpu_decode(hm, [pic], W, H, W, H, 1, False, chroma)
+            assert es == stride.value and api.heif_image_get_bits_per_pixel_range(img, 10) == bits
+            np.testing.assert_array_equal(got[:, :W * bpp], exp[:H, :W * bpp])
+            api.heif_image_release(img); api.heif_image_handle_release(h); api.heif_context_free(ctx)
+        # native target: no conversion runs, the planes stay 10 bit
+        ctx, h, img, e = _decode(api, data, 0, 0, 99, options=opt)
+        assert e.code == 0 and api.heif_image_get_bits_per_pixel_range(img, 0) == 10
+        api.heif_image_release(img); api.heif_image_handle_release(h); api.heif_context_free(ctx)
+        api.heif_decoding_options_free(opt)
+
+
 def test_icc_profile_on_handles_and_images(api, hm):
     """heif_image_handle_get_raw_color_profile / heif_image_get_raw_color_profile (heif.cc:1768-1793, 1931-2003): the
     item's ICC profile on the handle and on the decoded image (converted or not); a grid handle inherits its tile's, the

@@ -105,3 +105,43 @@ def test_structure_sweep_matches_reference_decoder_live(hm):
             for c in range(len(ref)):
                 assert np.array_equal(mine[c], ref[c]), f"seed {seed} {kw}: stage {stage} plane {c}"
     assert multi > 40  # the sweep really holds multi-slice pictures
+
+
+def test_row_parallel_parse_equals_serial(pkg, hm):
+    """hm_hevc_parse_mt (WPP rows entropy-decoded in parallel, decctx.cc:1004-1116 of the reference) must produce the
+    serial parser's command stream byte for byte: the three real 1080p WPP streams, the corpus, and a sweep of WPP
+    pictures with slices / dependent segments / PCM (segments that do not qualify run serially inside the same call)."""
+    import os
+    capi = pkg.capi
+    here = os.path.dirname(__file__)
+    n_parallel = 0
+    for name in ("basketball_1080p_qp32", "basketball_1080p_qp25", "basketball_1080p_qp1"):
+        data = open(os.path.join(here, "data", name + ".hevc"), "rb").read()
+        assert capi.parse_hevc(data, threads=6) == capi.parse_hevc(data), name
+        n_parallel += 1
+    import synthutil
+    for name in corpus.CASES:
+        data = corpus.stream(name)
+        assert capi.parse_hevc(data, threads=4) == capi.parse_hevc(data), name
+    for seed, kw in corpus.structure_sweep(60, first_seed=9000):
+        kw = dict(kw, wpp=1, tile_cols=1, tile_rows=1)
+        data = synthutil.picture(seed, **kw)
+
+        def outcome(threads):
+            try:
+                return capi.parse_hevc(data, threads=threads)
+            except capi.HmError as e:  # (a forced combination the parser refuses like the reference: the same refusal)
+                return str(e)
+        assert outcome(3 + seed % 4) == outcome(1), (seed, kw)
+    # errors come out of the serial pass: same status as the serial parser
+    data = bytearray(open(os.path.join(here, "data", "basketball_1080p_qp32.hevc"), "rb").read())
+    data[len(data) // 2] ^= 0x5A
+    for threads in (1, 4):
+        try:
+            a = capi.parse_hevc(bytes(data), threads=threads)
+        except capi.HmError as e:
+            a = str(e)
+        if threads == 1:
+            ref = a
+        else:
+            assert a == ref
