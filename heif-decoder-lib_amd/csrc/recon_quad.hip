@@ -736,7 +736,8 @@ extern "C" int hm_launch_recon_quad(const hm_dev_pic* d_pics, int n_pics, int lo
   else {
     const int row_pairs = (max_ctb_h + nr - 1) / nr;             // W beyond this leaves waves without rows
     const int front = max_ctb_w / (2 * nr) > 1 ? max_ctb_w / (2 * nr) : 1; // ... beyond this, rows that only wait
-    while (W < 8 && 2 * W <= row_pairs && 2 * W <= front && (long)n_pics * 2 * W <= 4096) W *= 2;
+    // (4096 = 256 CUs x 16 waves: more waves per picture only while the pictures alone do not fill the machine)
+    while (W < 8 && 2 * W <= row_pairs && 2 * W <= front && (long)n_pics * W < 4096) W *= 2;
   }
   while (W > 1 && !layout(W)) W /= 2;
   if (!layout(W)) return 0;
