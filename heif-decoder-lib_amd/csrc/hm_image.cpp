@@ -363,10 +363,8 @@ int planar_from_blobs(const hm_file* f, ItemPlan& P, const hm_decode_params* par
     for (int i = 0; i < nt; i++) {
       const hm_pic* h = reinterpret_cast<const hm_pic*>(P.blobs[i].p);
       const hm::Item* ti = f->file.item(P.tiles[i].id);
-      // the reference decodes every tile through decode_image_planar, which would also apply the tile item's own
-      // irot / imir / clap before the paste (context.cc:1957-2020): not on the GPU path - refuse rather than ignore
-      if (ti && !ti->props.transforms.empty() && !params->ignore_transformations)
-        return hm_fail(HM_ERR_UNSUPPORTED, "grid tile %d (item %u) carries its own irot/imir/clap", i, P.tiles[i].id);
+      // (a tile item with its own irot / imir / clap: decode_image_planar applies them to the tile image before the
+      //  paste, context.cc:1957-2020 - handled below by decoding such a tile to planes of its own)
       const int sw_ = ti ? ti->props.ispe_width : 0, sh_ = ti ? ti->props.ispe_height : 0;
       if (sw_ < canvas_w / P.cols || sh_ < canvas_h / P.rows) return hm_fail(HM_ERR_BITSTREAM, "Grid tiles do not cover whole image");
       if (sw_ != iw || sh_ != ih) return hm_fail(HM_ERR_BITSTREAM, "Grid tiles have different sizes");
@@ -412,9 +410,32 @@ int planar_from_blobs(const hm_file* f, ItemPlan& P, const hm_decode_params* par
   hm_batch* batch = nullptr;
   if ((rc = hm_batch_create(&batch))) return rc;
   I.batch.reset(batch);
+  // grid tiles whose item carries transformative properties: their picture goes to planes of its own (the size of its
+  // conformance window), is transformed there and pasted afterwards - what decode_and_paste_tile_image does with the
+  // image decode_image_planar returns (context.cc:2407-2539)
+  struct OwnTile { int index; DevPlane P[3]; int w, h; };
+  std::vector<std::unique_ptr<OwnTile>> own;
   for (int i = 0; i < nt; i++) {
     hm_tile_dest d;
     std::memset(&d, 0, sizeof(d));
+    const hm::Item* ti = is_grid ? f->file.item(P.tiles[i].id) : nullptr;
+    if (ti && !ti->props.transforms.empty() && !params->ignore_transformations) {
+      const hm_pic* h = reinterpret_cast<const hm_pic*>(P.blobs[i].p);
+      std::unique_ptr<OwnTile> o(new OwnTile());
+      o->index = i;
+      o->w = h->width - h->crop_left - h->crop_right; o->h = h->height - h->crop_top - h->crop_bottom;
+      const int tcw = chroma == 3 ? o->w : (o->w + 1) / 2, tch = chroma == 1 ? (o->h + 1) / 2 : o->h;
+      if ((rc = alloc_plane(o->P[0], o->w, o->h, bps))) return rc;
+      if (chroma != 0 && ((rc = alloc_plane(o->P[1], tcw, tch, bps)) || (rc = alloc_plane(o->P[2], tcw, tch, bps)))) return rc;
+      for (int c = 0; c < 3; c++) { d.plane[c] = o->P[c].mem.p; d.pitch[c] = o->P[c].stride; }
+      d.canvas_width = o->w; d.canvas_height = o->h;
+      d.x0 = d.y0 = 0;
+      d.tile_has_nclx = 0; // (the range rescale happens in the paste)
+      const int idx = hm_batch_add_trusted(batch, P.blobs[i].p, P.blobs[i].n, &d);
+      if (idx < 0) return idx;
+      own.push_back(std::move(o));
+      continue;
+    }
     for (int c = 0; c < 3; c++) { d.plane[c] = Pl[c].mem.p; d.pitch[c] = Pl[c].stride; }
     d.canvas_width = canvas_w; d.canvas_height = canvas_h;
     d.x0 = P.tiles[i].x0; d.y0 = P.tiles[i].y0;
@@ -429,6 +450,27 @@ int planar_from_blobs(const hm_file* f, ItemPlan& P, const hm_decode_params* par
     if (Pl[c].mem.p) hipMemsetAsync(Pl[c].mem.p, 0, plane_bytes(Pl[c]), s);
   if ((rc = hm_batch_upload(batch, s))) return rc;
   if ((rc = hm_batch_execute(batch, 3, s))) return rc;
+  for (std::unique_ptr<OwnTile>& o : own) {
+    const hm::Item* ti = f->file.item(P.tiles[o->index].id);
+    int tw = o->w, th = o->h;
+    if ((rc = apply_transforms(ti->props.transforms, o->P, tw, th, chroma, bd, s, I.retired))) return rc;
+    const hm::NclxProfile& tp = tile_profile[o->index];
+    const int rescale = (tp.present && !tp.full_range && tp.matrix != 0) ? 1 : 0; // context.cc:2504-2509
+    const int x0 = P.tiles[o->index].x0, y0 = P.tiles[o->index].y0;
+    for (int c = 0; c < 3; c++) {
+      if (!o->P[c].mem.p) continue;
+      int chan_w = canvas_w, chan_h = canvas_h, cx0 = x0, cy0 = y0; // context.cc:2466-2483
+      if (c > 0) {
+        if (chroma != 3) { chan_w = (canvas_w + 1) / 2; cx0 = (x0 + 1) / 2; }
+        if (chroma == 1) { chan_h = (canvas_h + 1) / 2; cy0 = (y0 + 1) / 2; }
+      }
+      if (chan_w <= cx0 || chan_h <= cy0) return hm_fail(HM_ERR_INVALID_ARG, "tile origin outside the canvas (invalid grid data)");
+      const int copy_w = std::min(o->P[c].w, chan_w - cx0), copy_h = std::min(o->P[c].h, chan_h - cy0);
+      if ((rc = hm_launch_paste_bytes(o->P[c].mem.p, o->P[c].stride, (uint8_t*)Pl[c].mem.p + (size_t)cy0 * Pl[c].stride + (size_t)cx0 * bps,
+                                      Pl[c].stride, copy_w * bps, copy_h, rescale, bd, c > 0, s))) return rc;
+    }
+    for (int c = 0; c < 3; c++) { I.retired.emplace_back(new DevMem()); I.retired.back()->swap(o->P[c].mem); }
+  }
 
   // ---- transformative item properties on the decoded planes (context.cc:1957-2020) ----
   int img_w = canvas_w, img_h = canvas_h;

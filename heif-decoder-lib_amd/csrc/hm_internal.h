@@ -34,6 +34,8 @@ int hm_launch_scale_nn(int bytes_per_sample, const void* in, int in_stride, int 
                        int oh, hipStream_t s);
 int hm_launch_set_alpha(void* rgba, int out_stride, int w, int h, const void* alpha, int alpha_stride, hipStream_t s);
 int hm_launch_mono_to_rgb(const void* y, int y_stride, void* out, int out_stride, int w, int h, int bpp, hipStream_t s);
+int hm_launch_paste_bytes(const void* in, int in_stride, void* out, int out_stride, int copy_bytes, int rows, int rescale, int bit_depth,
+                          int is_chroma, hipStream_t s);
 int hm_launch_mirror(const void* in, int in_stride, int w, int h, int horizontal, void* out, int out_stride, hipStream_t s);
 
 // devpool.cpp: size-bucketed cache of device / pinned-host allocations (hipMalloc + hipFree cost more

@@ -45,6 +45,24 @@ __global__ __launch_bounds__(256) void k_scale_nn(const Pix* __restrict__ in, in
   out[(size_t)y * os + x] = in[(size_t)iy * is + ix];
 }
 
+// Paste of one plane of a decoded tile image into the grid canvas plane (context.cc:2484-2535), for tiles that were not
+// pasted by k_sao_paste itself (tiles carrying their own irot / imir / clap are decoded to planes of their own,
+// transformed, then pasted).  Byte-wise, like the reference: copy_width is a byte count, and the limited -> full
+// range rescale of a tile with such an nclx works on BYTES of the storage (quirk Q1) with the luma offset for every
+// plane (Q2): clip_f_u8((v - (16 << (bpp - 8))) * ratio), ratio 1.1689f for Y, 1.1429f for Cb / Cr.
+__global__ __launch_bounds__(256) void k_paste_bytes(const uint8_t* __restrict__ in, int is, uint8_t* __restrict__ out, int os, int copy_bytes, int rows,
+                                                     int rescale, float offset, float ratio)
+{
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= copy_bytes || y >= rows) return;
+  int v = in[(size_t)y * is + x];
+  if (rescale) {
+    const int r = (int)__fadd_rn(__fmul_rn(__fsub_rn((float)v, offset), ratio), 0.5f); // common_utils.h:73-79
+    v = r < 0 ? 0 : (r > 255 ? 255 : r);
+  }
+  out[(size_t)y * os + x] = (uint8_t)v;
+}
+
 // interleaved RGBA, 8 bit: byte 3 of every pixel = the alpha plane sample (Op_YCbCr420_to_RGB32, yuv2rgb.cc:483-488;
 // Op_RGB_to_RGB24_32 with an input alpha plane, rgb2rgb.cc:108-127)
 __global__ __launch_bounds__(256) void k_set_alpha(uint8_t* __restrict__ rgba, int os, int w, int h, const uint8_t* __restrict__ alpha, int as)
@@ -75,6 +93,17 @@ extern "C" int hm_launch_mono_to_rgb(const void* y, int y_stride, void* out, int
   if (bpp == 3) hipLaunchKernelGGL(k_mono_to_rgb<3>, grid, block, 0, s, (const uint8_t*)y, y_stride, (uint8_t*)out, out_stride, w, h);
   else hipLaunchKernelGGL(k_mono_to_rgb<4>, grid, block, 0, s, (const uint8_t*)y, y_stride, (uint8_t*)out, out_stride, w, h);
   return hm_check_hip(hipGetLastError(), "k_mono_to_rgb launch");
+}
+
+// in / out: first byte to read / to write; copy_bytes x rows; is_chroma picks the ratio
+extern "C" int hm_launch_paste_bytes(const void* in, int in_stride, void* out, int out_stride, int copy_bytes, int rows, int rescale, int bit_depth,
+                                     int is_chroma, hipStream_t s)
+{
+  if (copy_bytes <= 0 || rows <= 0) return HM_OK;
+  const dim3 grid((copy_bytes + 63) / 64, (rows + 3) / 4), block(256);
+  hipLaunchKernelGGL(k_paste_bytes, grid, block, 0, s, (const uint8_t*)in, in_stride, (uint8_t*)out, out_stride, copy_bytes, rows, rescale,
+                     (float)(16 << (bit_depth - 8)), is_chroma ? 1.1429f : 1.1689f);
+  return hm_check_hip(hipGetLastError(), "k_paste_bytes launch");
 }
 
 extern "C" int hm_launch_set_alpha(void* rgba, int out_stride, int w, int h, const void* alpha, int alpha_stride, hipStream_t s)

@@ -53,11 +53,13 @@ def _transform_box(t):
     raise ValueError(kind)
 
 
-def write_heic(pictures, size, grid=None, chroma_format=1, bit_depth=8, colr=None, sizes=None, transforms=None, aux=None, icc=None):
+def write_heic(pictures, size, grid=None, chroma_format=1, bit_depth=8, colr=None, sizes=None, transforms=None, aux=None, icc=None,
+               tile_transforms=None):
     """pictures: list of [len][NAL] strings (each with VPS/SPS/PPS first); size: (w,h) of one picture
     (sizes: optional per-picture override of the declared ispe).
     grid: None for a single image, or (rows, cols, out_w, out_h).  colr: optional per-tile nclx tuple.
-    icc: optional (b"prof" | b"rICC", profile bytes) attached to every coded image item as a second 'colr' box."""
+    icc: optional (b"prof" | b"rICC", profile bytes) attached to every coded image item as a second 'colr' box.
+    tile_transforms: optional {picture index: [transforms]} - transformative properties of individual grid tile items."""
     items = []
     props = []
     assoc = {}
@@ -80,6 +82,8 @@ def write_heic(pictures, size, grid=None, chroma_format=1, bit_depth=8, colr=Non
             a.append(prop(_colr(colr)))
         if icc is not None:
             a.append(prop(_box(b"colr", icc[0] + icc[1])))
+        if tile_transforms and k in tile_transforms:
+            a += [0x8000 | prop(_transform_box(t)) for t in tile_transforms[k]]
         items.append((k + 1, b"hvc1", payload))
         assoc[k + 1] = a
     primary = 1

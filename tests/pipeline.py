@@ -76,10 +76,10 @@ class HeifFile:
         self.hm.hm_free(p)
         return out
 
-    def decode(self, iid, out_format, threads=1, upsampling=0, copy=True):
+    def decode(self, iid, out_format, threads=1, upsampling=0, copy=True, ignore_transformations=0):
         """GPU path through the C ABI; returns (array rows x stride, Decoded meta); copy=False only times the call
         (the pinned result is released without being copied into numpy arrays)."""
-        prm = DecodeParams(out_format, threads, 0, upsampling, None, None, 0, 0)
+        prm = DecodeParams(out_format, threads, ignore_transformations, upsampling, None, None, 0, 0)
         d = Decoded()
         rc = self.hm.hm_decode_item(self.h, iid, C.byref(prm), C.byref(d))
         if rc:
@@ -168,7 +168,7 @@ class Pipeline:
 
 
 def cpu_decode(hm, tiles, tile_w, tile_h, canvas_w, canvas_h, cols, is_grid, out_fmt, tile_colr=None, decoder="oracle", bilinear=False, transforms=None,
-               has_alpha=False):
+               has_alpha=False, tile_transforms=None):
     """tiles: list of [len][NAL] strings.  Returns (rgb array, stride) following the reference flow."""
     o = orc.load()
     first = None
@@ -192,6 +192,21 @@ def cpu_decode(hm, tiles, tile_w, tile_h, canvas_w, canvas_h, cols, is_grid, out
             ch = (canvas_h + 1) // 2 if cf == 1 else canvas_h
             canv = [orc.alloc_plane(canvas_w, canvas_h, bps), orc.alloc_plane(cw, ch, bps), orc.alloc_plane(cw, ch, bps)]
         x0, y0 = (i % cols) * tile_w, (i // cols) * tile_h
+        if tile_transforms and i in tile_transforms:
+            # the tile item's own irot / imir / clap: applied to the tile image before the paste (context.cc:1957-2020, 2407-2415)
+            tcw0 = tile_w if cf == 3 else (tile_w + 1) // 2
+            tch0 = (tile_h + 1) // 2 if cf == 1 else tile_h
+            bufs = []
+            for c, (w_, h_) in enumerate(((tile_w, tile_h), (tcw0, tch0), (tcw0, tch0))):
+                buf, st = orc.alloc_plane(w_, h_, bps)
+                src = np.ascontiguousarray(planes[c][:h_, :w_].astype(np.uint8 if bps == 1 else np.uint16))
+                buf[:h_, :w_ * bps] = src.view(np.uint8).reshape(h_, w_ * bps)
+                bufs.append((buf, st))
+            tp, tdims, _, _ = orc.transform_planes(bufs, [(tile_w, tile_h), (tcw0, tch0), (tcw0, tch0)], tile_w, tile_h, bd, tile_transforms[i])
+            planes = []
+            for (buf, st), (w_, h_) in zip(tp, tdims):
+                rows = np.ascontiguousarray(buf[:h_, :w_ * bps])
+                planes.append(rows.view(np.uint8 if bps == 1 else np.uint16).reshape(h_, w_))
         for c in range(3):
             p = planes[c]
             raw = np.ascontiguousarray(p.astype(np.uint8)) if bps == 1 else np.ascontiguousarray(p.astype(np.uint16))

@@ -277,3 +277,40 @@ def test_444_images(hm, nclx):
     exp, stride, _ = pipeline.cpu_decode(hm, tiles, 128, 64, 250, 120, 2, True, 14)
     assert (meta["width"], meta["height"], meta["bit_depth"]) == (250, 120, 10) and meta["stride"][0] == stride
     np.testing.assert_array_equal(out[0][:120, :250 * 6], exp[:120, :250 * 6])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["8bit_full", "8bit_limited_paste_rescale", "10bit"])
+def test_grid_tiles_with_their_own_transforms(hm, variant):
+    """VERDICT r01 item 9 / SURVEY 8a row A3: a grid whose TILE items carry irot / imir (decode_image_planar applies them to
+    the tile image before decode_and_paste_tile_image pastes it, context.cc:1957-2020, 2407-2539): such tiles are decoded
+    to planes of their own, transformed and pasted (k_paste_bytes, incl. the byte-wise range rescale), the others go
+    straight into the canvas.  2x2 grid of 64x64 tiles, canvas 120x100 (right / bottom tiles cropped)."""
+    kw = dict(width=64, height=64)
+    bd = 8
+    if variant == "8bit_full":
+        kw.update(vui=1, full_range=1, matrix=6)
+    elif variant == "8bit_limited_paste_rescale":
+        kw.update(vui=0)
+    else:
+        kw.update(vui=1, full_range=1, matrix=1, bit_depth=10)
+        bd = 10
+    tiles = [synthutil.picture(9300 + i, **kw) for i in range(4)]
+    tt = {0: [("irot", 1)], 1: [("irot", 2)], 3: [("irot", 3)]} if bd == 10 else {0: [("irot", 1)], 1: [("imir", 1)], 3: [("irot", 2), ("imir", 0)]}
+    data = heifwriter.write_heic(tiles, (64, 64), grid=(2, 2, 120, 100), bit_depth=bd, tile_transforms=tt)
+    f = pipeline.HeifFile(hm, data)
+    for fmt in ((10, 0) if bd == 8 else (14, 0)):
+        got, meta = f.decode(f.primary(), fmt)
+        exp, stride, canv = pipeline.cpu_decode(hm, tiles, 64, 64, 120, 100, 2, True, fmt if fmt else 10, tile_transforms=tt)
+        if fmt:
+            bpp = orc.OUT_BYTES[fmt]
+            np.testing.assert_array_equal(got[0][:100, :120 * bpp], exp[:100, :120 * bpp])
+        else:
+            bps = 2 if bd > 8 else 1
+            for c, (w, h) in enumerate(((120, 100), (60, 50), (60, 50))):
+                np.testing.assert_array_equal(got[c][:h, :w * bps], canv[c][0][:h, :w * bps])
+    # ignore_transformations: the tiles are pasted as coded
+    got, _ = f.decode(f.primary(), 0, ignore_transformations=1)
+    _, _, canv = pipeline.cpu_decode(hm, tiles, 64, 64, 120, 100, 2, True, 10 if bd == 8 else 14)
+    np.testing.assert_array_equal(got[0][:100, :120 * (2 if bd > 8 else 1)], canv[0][0][:100, :120 * (2 if bd > 8 else 1)])
+    f.close()
