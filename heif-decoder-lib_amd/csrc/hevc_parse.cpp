@@ -149,6 +149,10 @@ struct Decoder {
       cur_sps = &s;
       cur_pps = &p;
       pic.reset(s, p);
+      {
+        static const bool interleaved = [] { const char* e = std::getenv("HM_STREAM_INTERLEAVED"); return e && e[0] == '1'; }();
+        if (interleaved) pic.direct = false;
+      }
       pic_started = true;
       next_ts = 0;
     }
@@ -345,13 +349,30 @@ struct Decoder {
     const bool rare = s.scaling_list_enabled || (s.pcm_enabled && s.pcm_loop_filter_disabled) || p.transquant_bypass_enabled ||
                       pic.uses_pcm || pic.uses_tq_bypass || s.chroma_format_idc == 3; // == HM_PIC_RARE_SYNTAX of the flags below
     const bool split = !rare && !force_interleaved;
-    size_t n_tus = 0;
+    const bool direct = pic.direct; // the chains were written in their final form while parsing (hevc_syntax.h: PictureState::rows)
+    if (direct && !split) throw ParseError(HM_ERR_INTERNAL, "direct chains of a picture with rare syntax");
+    size_t n_tus = 0, n_levels = pic.coeffs.size();
     for (int i = 0; i < N; i++) {
       if (!(pic.ctbs[i].flags & HM_CTB_CODED)) throw ParseError(HM_ERR_BITSTREAM, "CTB not coded");
       if (pic.ctb_tus[i].size() > 65535) throw ParseError(HM_ERR_INTERNAL, "too many TUs in a CTB");
       n_tus += pic.ctb_tus[i].size();
     }
-    {
+    if (direct) { // row-relative indices -> picture-wide: row 0 luma, row 0 chroma, row 1 luma, ...
+      uint32_t tu_at = 0, lv_at = 0;
+      for (int cy = 0; cy < s.ctb_h; cy++) {
+        const PictureState::RowChains& R = pic.rows[(size_t)cy];
+        const uint32_t tl = tu_at, ll = lv_at;
+        tu_at += (uint32_t)R.tu[0].size(); lv_at += (uint32_t)R.lv[0].size();
+        const uint32_t tc = tu_at, lc = lv_at;
+        tu_at += (uint32_t)R.tu[1].size(); lv_at += (uint32_t)R.lv[1].size();
+        for (int cx = 0; cx < s.ctb_w; cx++) {
+          hm_ctb& c = pic.ctbs[(size_t)cx + (size_t)cy * s.ctb_w];
+          c.tu_first += tl; c.coeff_first += ll; c.tu_first_c += tc; c.coeff_first_c += lc;
+        }
+      }
+      n_tus = tu_at; n_levels = lv_at;
+    }
+    else {
       auto is_luma = [](const hm_tu& t) { return ((t.info >> HM_TU_CIDX_SHIFT) & 3) == 0; };
       size_t at = 0;
       for (int cy = 0; cy < s.ctb_h; cy++) {
@@ -410,21 +431,23 @@ struct Decoder {
     const size_t off_slices = align16(sizeof(hm_pic));
     const size_t off_ctbs = align16(off_slices + pic.slices.size() * sizeof(hm_slice));
     const size_t off_tus = align16(off_ctbs + (size_t)N * sizeof(hm_ctb));
-    const size_t off_coeffs = align16(off_tus + n_tus * sizeof(hm_tu));
-    const size_t off_scaling = align16(off_coeffs + pic.coeffs.size() * sizeof(hm_coeff));
+    const size_t tu_bytes = split ? sizeof(hm_tu8) : sizeof(hm_tu);
+    const size_t off_coeffs = align16(off_tus + n_tus * tu_bytes);
+    const size_t off_scaling = align16(off_coeffs + n_levels * sizeof(hm_coeff));
     const size_t total = off_scaling + (s.scaling_list_enabled ? (size_t)HM_SCALING_BYTES : 0);
     if (total > 0xFFFFFFFFu) throw ParseError(HM_ERR_INTERNAL, "command stream too large");
     struct Mem { // (the section gaps - at most 15 bytes each - are zeroed, the sections are copied straight in)
       uint8_t* p;
       uint8_t* data() const { return p; }
+      ~Mem() { std::free(p); } // (an exception on the way: the blob goes back)
     } blob{(uint8_t*)std::malloc(total)};
     if (!blob.p) throw std::bad_alloc();
     auto zero_gap = [&](size_t from, size_t to) { if (to > from) std::memset(blob.p + from, 0, to - from); };
     zero_gap(sizeof(hm_pic), off_slices);
     zero_gap(off_slices + pic.slices.size() * sizeof(hm_slice), off_ctbs);
     zero_gap(off_ctbs + (size_t)N * sizeof(hm_ctb), off_tus);
-    zero_gap(off_tus + n_tus * sizeof(hm_tu), off_coeffs);
-    zero_gap(off_coeffs + pic.coeffs.size() * sizeof(hm_coeff), total);
+    zero_gap(off_tus + n_tus * tu_bytes, off_coeffs);
+    zero_gap(off_coeffs + n_levels * sizeof(hm_coeff), total);
     hm_pic h;
     std::memset(&h, 0, sizeof(h));
     h.magic = HM_STREAM_MAGIC;
@@ -471,7 +494,7 @@ struct Decoder {
     h.n_slices = (uint32_t)pic.slices.size();
     h.n_ctbs = (uint32_t)N;
     h.n_tus = (uint32_t)n_tus;
-    h.n_coeffs = (uint32_t)pic.coeffs.size();
+    h.n_coeffs = (uint32_t)n_levels;
     h.off_slices = (uint32_t)off_slices;
     h.off_ctbs = (uint32_t)off_ctbs;
     h.off_tus = (uint32_t)off_tus;
@@ -483,23 +506,59 @@ struct Decoder {
     }
     std::memcpy(blob.data(), &h, sizeof(h));
     std::memcpy(blob.data() + off_slices, pic.slices.data(), pic.slices.size() * sizeof(hm_slice));
-    std::memcpy(blob.data() + off_ctbs, pic.ctbs.data(), (size_t)N * sizeof(hm_ctb));
-    hm_tu* const tp = reinterpret_cast<hm_tu*>(blob.data() + off_tus);
-    for (int i = 0; i < N; i++) {
-      if (!split) {
+    if (!split) {
+      hm_tu* const tp = reinterpret_cast<hm_tu*>(blob.data() + off_tus);
+      for (int i = 0; i < N; i++)
         if (!pic.ctb_tus[i].empty()) std::memcpy(tp + pic.ctbs[i].tu_first, pic.ctb_tus[i].data(), pic.ctb_tus[i].size() * sizeof(hm_tu));
-        continue;
-      }
-      hm_tu* dl = tp + pic.ctbs[i].tu_first;
-      hm_tu* dc = tp + pic.ctbs[i].tu_first_c;
-      for (const hm_tu& t : pic.ctb_tus[i]) {
-        if (((t.info >> HM_TU_CIDX_SHIFT) & 3) == 0) *dl++ = t;
-        else *dc++ = t;
-      }
+      std::memcpy(blob.data() + off_ctbs, pic.ctbs.data(), (size_t)N * sizeof(hm_ctb));
+      if (!pic.coeffs.empty()) std::memcpy(blob.data() + off_coeffs, pic.coeffs.data(), pic.coeffs.size() * sizeof(hm_coeff));
     }
-    if (!pic.coeffs.empty()) std::memcpy(blob.data() + off_coeffs, pic.coeffs.data(), pic.coeffs.size() * sizeof(hm_coeff));
+    else if (direct) {
+      uint8_t* tp = blob.data() + off_tus;
+      uint8_t* cp = blob.data() + off_coeffs;
+      for (int cy = 0; cy < s.ctb_h; cy++)
+        for (int k = 0; k < 2; k++) {
+          const PictureState::RowChains& R = pic.rows[(size_t)cy];
+          if (!R.tu[k].empty()) { std::memcpy(tp, R.tu[k].data(), R.tu[k].size() * sizeof(hm_tu8)); tp += R.tu[k].size() * sizeof(hm_tu8); }
+          if (!R.lv[k].empty()) { std::memcpy(cp, R.lv[k].data(), R.lv[k].size() * sizeof(hm_coeff)); cp += R.lv[k].size() * sizeof(hm_coeff); }
+        }
+      std::memcpy(blob.data() + off_ctbs, pic.ctbs.data(), (size_t)N * sizeof(hm_ctb));
+    }
+    else {
+      // compact records (hm_stream.h: hm_tu8) in chain order, the levels gathered into the order of the records
+      hm_tu8* const tp = reinterpret_cast<hm_tu8*>(blob.data() + off_tus);
+      hm_coeff* const cp = reinterpret_cast<hm_coeff*>(blob.data() + off_coeffs);
+      uint32_t level_at = 0;
+      auto put = [&](hm_tu8* d, const hm_tu& t) {
+        if ((t.x | t.y | t.avail_bottom_left | t.avail_top_right) & 3) throw ParseError(HM_ERR_INTERNAL, "block geometry not a multiple of 4");
+        const int nT = 1 << (t.info & HM_TU_LOG2_MASK);
+        if ((t.avail_left != 0 && t.avail_left != nT) || (t.avail_top != 0 && t.avail_top != nT) || t.n_coeff > HM_TU8_COUNT_MASK ||
+            (t.pred_mode & ~HM_TU_MODE_MASK))
+          throw ParseError(HM_ERR_INTERNAL, "record does not fit the compact form");
+        d->pos = (uint8_t)((t.x >> 2) | ((t.y >> 2) << 4));
+        d->info = t.info; d->pred_mode = t.pred_mode; d->qp = t.qp; d->qpy = t.qpy;
+        d->avail = (uint8_t)((t.avail_bottom_left >> 2) | ((t.avail_top_right >> 2) << 4));
+        d->count = (uint16_t)(t.n_coeff | (t.avail_left ? HM_TU8_LEFT : 0) | (t.avail_top ? HM_TU8_TOP : 0));
+        if (t.n_coeff) std::memcpy(cp + level_at, pic.coeffs.data() + t.coeff_first, t.n_coeff * sizeof(hm_coeff));
+        level_at += t.n_coeff;
+      };
+      // record order = CTB row by CTB row: the row's luma records, then its chroma records (the order of tu_first / tu_first_c)
+      for (int cy = 0; cy < s.ctb_h; cy++)
+        for (int pass = 0; pass < 2; pass++)
+          for (int cx = 0; cx < s.ctb_w; cx++) {
+            const int i = cx + cy * s.ctb_w;
+            hm_tu8* d = tp + (pass == 0 ? pic.ctbs[i].tu_first : pic.ctbs[i].tu_first_c);
+            (pass == 0 ? pic.ctbs[i].coeff_first : pic.ctbs[i].coeff_first_c) = level_at;
+            for (const hm_tu& t : pic.ctb_tus[i])
+              if ((((t.info >> HM_TU_CIDX_SHIFT) & 3) == 0) == (pass == 0)) put(d++, t);
+          }
+      if (level_at != pic.coeffs.size()) throw ParseError(HM_ERR_INTERNAL, "levels lost while reordering");
+      std::memcpy(blob.data() + off_ctbs, pic.ctbs.data(), (size_t)N * sizeof(hm_ctb));
+    }
     *out_size = total;
-    return blob.p;
+    uint8_t* const done = blob.p;
+    blob.p = nullptr;
+    return done;
   }
 };
 
@@ -507,6 +566,7 @@ struct Decoder {
 } // namespace hm
 
 static_assert(sizeof(hm_tu) == 16, "hm_tu layout");
+static_assert(sizeof(hm_tu8) == 8, "hm_tu8 layout");
 static_assert(sizeof(hm_ctb) == 4 * HM_CTB_DWORDS, "hm_ctb layout");
 static_assert(sizeof(hm_coeff) == 4, "hm_coeff layout");
 static_assert(sizeof(hm_slice) == 12, "hm_slice layout");

@@ -180,6 +180,13 @@ struct PictureState {
   std::vector<hm_slice> slices;
   std::vector<std::vector<hm_tu>> ctb_tus; // records per CTB (raster address)
   std::vector<hm_coeff> coeffs;
+  // Pictures that cannot turn out to carry rare syntax (no scaling lists, PCM, transquant bypass, 4:4:4 in their
+  // parameter sets) are written in their final form while they are parsed ("direct"): per CTB row the compact records
+  // (hm_stream.h: hm_tu8) of the luma chain and of the chroma chain with their levels in record order - what remains
+  // for the end is a concatenation.  hm_ctb.tu_first / coeff_first are row-relative until then.
+  struct RowChains { std::vector<hm_tu8> tu[2]; std::vector<hm_coeff> lv[2]; };
+  std::vector<RowChains> rows;
+  bool direct = false;
   bool uses_pcm = false, uses_tq_bypass = false;
   // QP predictor state, persists across dependent slice segments (decctx.h thread_context fields)
   struct QpState { int last_qpy_prev_qg = 0, current_qpy = 0, cur_qg_x = -1, cur_qg_y = -1; };
@@ -207,6 +214,10 @@ struct PictureState {
     if ((int)ctb_tus.size() != n) ctb_tus.resize(n);
     for (auto& v : ctb_tus) v.clear();
     coeffs.clear();
+    direct = !(s.scaling_list_enabled || s.pcm_enabled || p.transquant_bypass_enabled || s.chroma_format_idc == 3);
+    if ((int)rows.size() != s.ctb_h) rows.resize((size_t)s.ctb_h);
+    for (RowChains& r : rows)
+      for (int k = 0; k < 2; k++) { r.tu[k].clear(); r.lv[k].clear(); }
     uses_pcm = uses_tq_bypass = false;
     wpp_ctx.assign(p.entropy_coding_sync ? (size_t)s.ctb_h : 0, ContextSet());
     wpp_ok.assign(wpp_ctx.size(), 0);
@@ -346,6 +357,13 @@ class SliceWalker {
   {
     const int x0 = xCtb << sps_.log2_ctb, y0 = yCtb << sps_.log2_ctb;
     ctb_x_ = xCtb; ctb_y_ = yCtb;
+    if (pic_.direct) {
+      PictureState::RowChains& R = pic_.rows[(size_t)yCtb];
+      hm_ctb& cc = pic_.ctbs[ctb_addr_rs_];
+      cc.tu_first = (uint32_t)R.tu[0].size(); cc.tu_first_c = (uint32_t)R.tu[1].size();
+      cc.coeff_first = (uint32_t)R.lv[0].size(); cc.coeff_first_c = (uint32_t)R.lv[1].size();
+      cc.tu_count = cc.tu_count_c = 0;
+    }
     derive_ctb_neighbours();
     avail_memo_[0].key = avail_memo_[1].key = 0xFFFFFFFFu;
     hm_ctb& c = pic_.ctbs[ctb_addr_rs_];
@@ -603,7 +621,10 @@ class SliceWalker {
     const int max_depth = sps_.max_th_depth_intra + (nxn ? 1 : 0);
     transform_tree(x0, y0, x0, y0, log2CbSize, 0, 0, max_depth, nxn, 1, 1);
     // all luma records of this CU must carry the CU's final QpY (deblocking uses the QpY map)
-    for (auto& ref : cu_first_tu_) pic_.ctb_tus[ref.ctb][ref.idx].qpy = (int8_t)cu_qpy_;
+    if (pic_.direct)
+      for (auto& ref : cu_first_tu_) pic_.rows[(size_t)ctb_y_].tu[0][ref.idx].qpy = (int8_t)cu_qpy_;
+    else
+      for (auto& ref : cu_first_tu_) pic_.ctb_tus[ref.ctb][ref.idx].qpy = (int8_t)cu_qpy_;
   }
 
   // pcm_sample( ) (§7.3.8.7; slice.cc:4462-4536 of the reference): raw samples of all components at the entropy
@@ -796,6 +817,16 @@ class SliceWalker {
   // 4x4 Cb block is again directly followed by its Cr twin, which the kernel reconstructs in one pass.
   void interleave_422_records()
   {
+    if (pic_.direct) { // (the levels lie in record order: the two middle runs change places with their records)
+      PictureState::RowChains& R = pic_.rows[(size_t)ctb_y_];
+      std::vector<hm_tu8>& v = R.tu[1];
+      const size_t n = v.size();
+      const size_t c_cr_lo = v[n - 1].count & HM_TU8_COUNT_MASK, c_cr_up = v[n - 2].count & HM_TU8_COUNT_MASK, c_cb_lo = v[n - 3].count & HM_TU8_COUNT_MASK;
+      std::swap(v[n - 3], v[n - 2]);
+      hm_coeff* const end = R.lv[1].data() + R.lv[1].size() - c_cr_lo; // behind the run of Cr upper
+      std::rotate(end - c_cr_up - c_cb_lo, end - c_cr_up, end);
+      return;
+    }
     auto& v = pic_.ctb_tus[ctb_addr_rs_];
     std::swap(v[v.size() - 3], v[v.size() - 2]);
   }
@@ -812,6 +843,7 @@ class SliceWalker {
     t.y = (uint8_t)(yc & ((1 << (sps_.log2_ctb - lh)) - 1));
     t.info = (uint8_t)(log2 | (cIdx << HM_TU_CIDX_SHIFT));
     t.pred_mode = (uint8_t)(mode | (cu_bypass_ ? HM_TU_MODE_BYPASS : 0));
+    if (pic_.direct) coeffs_ = &pic_.rows[(size_t)ctb_y_].lv[cIdx ? 1 : 0];
     t.coeff_first = (uint32_t)coeffs_->size();
     bool tskip = false;
     if (cbf) {
@@ -854,6 +886,19 @@ class SliceWalker {
     if (aTL) t.info |= HM_TU_AVAIL_TL;
     t.avail_bottom_left = aBL ? (uint8_t)std::min(nT, room_below) : 0;
     t.avail_top_right = aTR ? (uint8_t)std::min(nT, room_right) : 0;
+    if (pic_.direct) {
+      std::vector<hm_tu8>& vec = pic_.rows[(size_t)ctb_y_].tu[cIdx ? 1 : 0];
+      hm_ctb& cc = pic_.ctbs[ctb_addr_rs_];
+      if (cIdx == 0) { cu_first_tu_.push_back({ctb_addr_rs_, (uint32_t)vec.size()}); cc.tu_count++; }
+      else cc.tu_count_c++;
+      hm_tu8 c;
+      c.pos = (uint8_t)((t.x >> 2) | ((t.y >> 2) << 4));
+      c.info = t.info; c.pred_mode = t.pred_mode; c.qp = t.qp; c.qpy = t.qpy;
+      c.avail = (uint8_t)((t.avail_bottom_left >> 2) | ((t.avail_top_right >> 2) << 4));
+      c.count = (uint16_t)(t.n_coeff | (aL ? HM_TU8_LEFT : 0) | (aT ? HM_TU8_TOP : 0));
+      vec.push_back(c);
+      return;
+    }
     auto& vec = pic_.ctb_tus[ctb_addr_rs_];
     if (cIdx == 0) cu_first_tu_.push_back({ctb_addr_rs_, (uint32_t)vec.size()});
     vec.push_back(t);

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
   const uint8_t* blob = dp.blob;
   const GLOBAL_AS hm_pic* H = gptr<hm_pic>(blob);
   const GLOBAL_AS uint32_t* ctbq = gptr<uint32_t>(blob + H->off_ctbs);   // 9 dwords per hm_ctb
-  const GLOBAL_AS uint32_t* tus = gptr<uint32_t>(blob + H->off_tus);     // 4 dwords per hm_tu
+  const GLOBAL_AS uint32_t* tus = gptr<uint32_t>(blob + H->off_tus);     // 2 dwords per hm_tu8 (hm_stream.h)
   const GLOBAL_AS uint32_t* coeffs = gptr<uint32_t>(blob + H->off_coeffs);
   const uint32_t n_tus = H->n_tus;
   GLOBAL_AS uint16_t* g_meta = gptr_w<uint16_t>(dp.meta);
@@ -276,51 +276,56 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
   int row = wi * NR + group_slot(g), cx = 0, kleft = 0;
   int st = row < ctb_h ? ST_START : ST_DONE;
   int cb_flags = 0;
-  uint32_t c0 = 0, c1 = 0, c2 = 0;         // header of the CTU to start next: first record of the chain, count, flags
-  uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0; // record of the current block
-  uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0; // ... of the next one
-  uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0; // ... and of the two after
-  uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-  uint32_t f0 = 0, f1 = 0, f2 = 0, f3 = 0; // the record in flight (index gnext - 1): requested at the end of a step by
+  uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0; // header of the CTU to start next: first record of the chain, count, flags, first level
+  // records (hm_tu8 as two dwords: pos | info << 8 | mode << 16 | qp << 24, qpy | avail << 8 | count << 16)
+  uint32_t n0 = 0, n1 = 0;                 // record of the current block
+  uint32_t m0 = 0, m1 = 0;                 // ... of the next one
+  uint32_t p0 = 0, p1 = 0;                 // ... and of the two after
+  uint32_t q0 = 0, q1 = 0;
+  uint32_t f0 = 0, f1 = 0;                 // the record in flight (index gnext - 1): requested at the end of a step by
                                            // every lane, looked at one step later - a load whose result is merged with
                                            // anything (a conditional assignment, a copy) is waited for on the spot
   uint32_t gnext = 0;                      // index of the next record to fetch
+  uint32_t loff = 0;                       // index of the current block's first level: the levels lie in record order
   uint32_t pre = 0, pre_m = 0, lv = 0;     // level number gl (pos | value << 16) of the current / the next block; in flight: of the one after
   uint32_t tag = 0;                        // step number: marks the gather slots written in this step
   int restart = 0;                         // the group has just (re)filled its record registers: the in-flight stage is stale
-  auto fetch = [&](uint32_t idx, uint32_t& a0, uint32_t& a1, uint32_t& a2, uint32_t& a3) {
+  auto fetch = [&](uint32_t idx, uint32_t& a0, uint32_t& a1) {
     const uint32_t gi = idx < n_tus - 1 ? idx : n_tus - 1; // past the last block of the picture: re-read it (never used)
-    const GLOBAL_AS uint32_t* q = tus + 4 * (size_t)gi;
-    a0 = q[0]; a1 = q[1]; a2 = q[2]; a3 = q[3];
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 v = *reinterpret_cast<const GLOBAL_AS u32x2*>(tus + 2 * (size_t)gi);
+    a0 = v.x; a1 = v.y;
   };
+  auto count_of = [](uint32_t r1) -> uint32_t { return (r1 >> 16) & HM_TU8_COUNT_MASK; };
   // The first 16 levels of a block, one per lane of the group.  The load is unconditional (a block without levels reads
   // some valid word that nobody looks at: validity = cbf && lane < n_coeff is judged where the word is used): a
   // conditional load would make the compiler merge the loaded value with a zero right away, i.e. wait for it here.
   const uint32_t n_lv1 = H->n_coeffs ? H->n_coeffs - 1 : 0;
-  auto levels_of = [&](uint32_t r1, uint32_t r2) -> uint32_t {
-    uint32_t idx = r2 + (uint32_t)gl;
+  auto levels_of = [&](uint32_t first) -> uint32_t {
+    uint32_t idx = first + (uint32_t)gl;
     idx = idx < n_lv1 ? idx : n_lv1;
     return coeffs[idx];
   };
   auto header = [&](int r, int x) { // chain header of CTU (r, x): first record, count, flags
     const GLOBAL_AS uint32_t* q = ctbq + HM_CTB_DWORDS * ((size_t)r * ctb_w + x);
-    c0 = q[kind ? 9 : 0]; c1 = q[kind ? 10 : 1]; c2 = q[2]; // (masked where they are used: no wait for the loads here)
+    c0 = q[kind ? 9 : 0]; c1 = q[kind ? 10 : 1]; c2 = q[2]; c3 = q[kind ? 12 : 11]; // (masked where they are used: no wait for the loads here)
   };
   auto row_start = [&]() { // header of CTU (row, 0) and the first four records of the row's chain
     header(row, 0);
-    fetch(c0, n0, n1, n2, n3);
-    fetch(c0 + 1, m0, m1, m2, m3);
-    fetch(c0 + 2, p0, p1, p2, p3);
-    fetch(c0 + 3, q0, q1, q2, q3);
+    fetch(c0, n0, n1);
+    fetch(c0 + 1, m0, m1);
+    fetch(c0 + 2, p0, p1);
+    fetch(c0 + 3, q0, q1);
     gnext = c0 + 4;
-    pre = levels_of(n1, n2);
-    pre_m = levels_of(m1, m2);
+    loff = c3;
+    pre = levels_of(loff);
+    pre_m = levels_of(loff + count_of(n1));
     restart = 1; // the in-flight stage is refilled at the end of this step
   };
   if (st == ST_START) row_start();
   // (first requests of the in-flight stage: record gnext, levels of p)
-  fetch(gnext, f0, f1, f2, f3);
-  lv = levels_of(p1, p2);
+  fetch(gnext, f0, f1);
+  lv = levels_of(loff + count_of(n1) + count_of(m1));
   gnext += 1;
   restart = 0;
 
@@ -357,9 +362,10 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
     }
 
     // fields of the current record, per group
-    const int info = (int)((n0 >> 16) & 0xFF);
+    const int info = (int)((n0 >> 8) & 0xFF);
     const int l2 = info & HM_TU_LOG2_MASK;
-    const bool interior4 = (n3 & 0x00040004u) == 0x00040004u && (info & HM_TU_AVAIL_TL);
+    constexpr uint32_t LT = (uint32_t)(HM_TU8_LEFT | HM_TU8_TOP) << 16;
+    const bool interior4 = (n1 & LT) == LT && (info & HM_TU_AVAIL_TL);
     const bool quad = running && l2 == 2 && interior4;
     const unsigned long long s_big = __ballot(running && !quad);
 
@@ -373,15 +379,16 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
 #else
     if (quad) {
 #endif
-      const int x0 = (int)(n0 & 0xFF), y0 = (int)((n0 >> 8) & 0xFF);
-      const int mode = (int)(n0 >> 24);
+      const int x4 = (int)(n0 & 15), y4 = (int)((n0 >> 4) & 15); // pos: x >> 2 | (y >> 2) << 4
+      const int x0 = x4 << 2; // (shift folded into the address adds)
+      const int mode = (int)((n0 >> 16) & 0xFF);
       const int c = (info >> HM_TU_CIDX_SHIFT) & 3;
       Pix* const u = c == 2 ? gu2 : gu01;
       const int P = Pk;
       const Pix* const top = lr + (cx << l2w) - 1 + (c == 2 ? Wc + 4 : 0);
-      Pix* const lp = u + (mul24(y0, P) + UPAD + x0 - 1);             // sample (x0-1, y0): walks down the left column
-      const Pix* const tp = y0 > 0 ? lp - P + 1 : top + 1 + x0;       // sample (x0, y0-1): walks along the row above; tp[-1] = corner
-      const int nL1 = 3 + (int)((n3 >> 8) & 0xFF), nT1 = 3 + (int)(n3 >> 24); // last usable position of the left / top run
+      Pix* const lp = u + (mul24(y4, 4 * P) + UPAD + x0 - 1);         // sample (x0-1, y0): walks down the left column
+      const Pix* const tp = y4 > 0 ? lp - P + 1 : top + 1 + x0;       // sample (x0, y0-1): walks along the row above; tp[-1] = corner
+      const int nL1 = 3 + (int)((n1 >> 6) & 0x3C), nT1 = 3 + (int)((n1 >> 10) & 0x3C); // last usable position of the left / top run
       const uint32_t e = tab4[mode * 16 + gl];
       const int j0 = (int)(e & 31) - 8, j1 = (int)((e >> 5) & 31) - 8, f = (int)(e >> 10);
       auto ref = [&](int j) -> int {
@@ -417,11 +424,11 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
       }
       if (info & HM_TU_CBF) {
         // dequantisation (transform.cc:496-502, wrapping int32) of level number gl, scattered to the lane of its position
-        const int qP = (int)(n1 & 0xFF);
+        const int qP = (int)(n0 >> 24);
         const int q6 = (qP * 43) >> 8, rem = qP - 6 * q6; // qP / 6, qP % 6 for qP < 128
         const int bdShift = bd - 7;
         const int32_t fact = (int32_t)tab[70 + rem] << q6;
-        const uint32_t nc = n1 >> 16;
+        const uint32_t nc = count_of(n1);
         uint64_t* const slots = q_slots + g * 16;
         if ((uint32_t)gl < nc) {
           const int pos = (int)(pre & 0xFFFF), value = (int)(int16_t)(pre >> 16);
@@ -460,10 +467,10 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
       lp[mul24(by, P) + 1 + bx] = (Pix)v;
       if (c == 0 && gl == 0) { // deblocking metadata (deblock.cc:31-62): transform edges + QpY of the 4x4 block
         const int deblock_en = !(cb_flags & HM_CTB_DEBLOCK_OFF);
-        const int left_ok = (x0 > 0) | ((cb_flags & HM_CTB_DEBLOCK_LEFT) != 0);
-        const int top_ok = (y0 > 0) | ((cb_flags & HM_CTB_DEBLOCK_TOP) != 0);
-        const int qpy = (int)((n1 >> 8) & 0xFF);
-        gmeta[((y0 >> 2) << (log2_ctb - 2)) + (x0 >> 2)] = (uint16_t)((left_ok & deblock_en) | ((top_ok & deblock_en) << 1) | (qpy << 8));
+        const int left_ok = (x4 > 0) | ((cb_flags & HM_CTB_DEBLOCK_LEFT) != 0);
+        const int top_ok = (y4 > 0) | ((cb_flags & HM_CTB_DEBLOCK_TOP) != 0);
+        const int qpy = (int)(n1 & 0xFF);
+        gmeta[(y4 << (log2_ctb - 2)) + x4] = (uint16_t)((left_ok & deblock_en) | ((top_ok & deblock_en) << 1) | (qpy << 8));
       }
     }
     WAVE_SYNC();
@@ -478,9 +485,9 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
       const int bg = rfl((int)(__builtin_ctzll(todo) >> 4));
       todo &= ~(0xFFFFull << (bg * 16));
       const int src = bg * 16;
-      const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)n0, src), r3 = (uint32_t)__builtin_amdgcn_readlane((int)n3, src);
-      uint32_t w0 = r0, w1 = (uint32_t)__builtin_amdgcn_readlane((int)n1, src), w2 = (uint32_t)__builtin_amdgcn_readlane((int)n2, src), w3 = r3;
-      asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3)); // data fields: vector registers (see Blk)
+      const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)n0, src), r1 = (uint32_t)__builtin_amdgcn_readlane((int)n1, src);
+      uint32_t w0 = r0, w1 = r1, w2 = (uint32_t)__builtin_amdgcn_readlane((int)loff, src);
+      asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2)); // data fields: vector registers (see Blk)
       const int s_row = __builtin_amdgcn_readlane(row, src), s_cx = __builtin_amdgcn_readlane(cx, src);
       const int s_flags = __builtin_amdgcn_readlane(cb_flags, src);
       Pix* const u0 = group_u(bg, 0);
@@ -494,21 +501,26 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
       const int deblock_en = !(s_flags & HM_CTB_DEBLOCK_OFF);
 
       Blk<Pix> B;
-      B.info = (r0 >> 16) & 0xFF;
-      B.mode = r0 >> 24;
+      B.info = (r0 >> 8) & 0xFF;
+      B.mode = (r0 >> 16) & 0xFF;
       B.log2 = B.info & HM_TU_LOG2_MASK;
       B.c = (B.info >> HM_TU_CIDX_SHIFT) & 3;
-      B.avail = r3;
+      {
+        // the availability word of the full record (left | below-left << 8 | top << 16 | top-right << 24): complete runs = nT
+        const uint32_t nT = 1u << B.log2;
+        B.avail = ((r1 & ((uint32_t)HM_TU8_LEFT << 16)) ? nT : 0u) | ((((r1 >> 8) & 15) << 2) << 8) |
+                  ((r1 & ((uint32_t)HM_TU8_TOP << 16)) ? nT << 16 : 0u) | ((((r1 >> 12) & 15) << 2) << 24);
+      }
       B.bd = bd;
       B.tskip = B.info & HM_TU_TSKIP;
-      B.x0 = w0 & 0xFF; B.y0 = (w0 >> 8) & 0xFF;
-      B.qp = w1 & 0xFF;
-      const int qpy = (int)(int8_t)((w1 >> 8) & 0xFF);
-      B.n_coeff = w1 >> 16;
+      B.x0 = (w0 << 2) & 0x3C; B.y0 = (w0 >> 2) & 0x3C;
+      B.qp = w0 >> 24;
+      const int qpy = (int)(int8_t)(w1 & 0xFF);
+      B.n_coeff = (w1 >> 16) & HM_TU8_COUNT_MASK;
       const uint32_t coeff_first = w2;
-      B.aBL = (w3 >> 8) & 0xFF; B.aTR = w3 >> 24;
+      B.aBL = (w1 >> 6) & 0x3C; B.aTR = (w1 >> 10) & 0x3C;
       {
-        const int vc = (w0 >> (16 + HM_TU_CIDX_SHIFT)) & 3; // colour component, vector copy for the selects
+        const int vc = (w0 >> (8 + HM_TU_CIDX_SHIFT)) & 3; // colour component, vector copy for the selects
         B.u = vc == 0 ? u0 : (vc == 1 ? u1 : u2);
         B.top = vc == 0 ? top0 : (vc == 1 ? top1 : top2);
         B.P = vc == 0 ? P0 : P1;
@@ -582,10 +594,11 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
     HM_MARK("E_begin");
     // ---- E: the groups that executed a block move to the next record ----
     if (running) {
-      n0 = m0; n1 = m1; n2 = m2; n3 = m3;
-      m0 = p0; m1 = p1; m2 = p2; m3 = p3;
-      p0 = q0; p1 = q1; p2 = q2; p3 = q3;
-      q0 = f0; q1 = f1; q2 = f2; q3 = f3; // requested one step ago
+      loff += count_of(n1);
+      n0 = m0; n1 = m1;
+      m0 = p0; m1 = p1;
+      p0 = q0; p1 = q1;
+      q0 = f0; q1 = f1; // requested one step ago
       pre = pre_m;
       pre_m = lv;
       kleft -= 1;
@@ -669,8 +682,8 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
     //      the next record and for the levels of the block three ahead; the others ask again for what they hold ----
     {
       const uint32_t want = (advanced || restart) ? gnext : gnext - 1;
-      fetch(want, f0, f1, f2, f3);
-      lv = levels_of(p1, p2);
+      fetch(want, f0, f1);
+      lv = levels_of(loff + count_of(n1) + count_of(m1));
       gnext = want + 1;
       restart = 0;
     }

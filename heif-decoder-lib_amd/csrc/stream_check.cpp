@@ -23,7 +23,7 @@ static const char* validate_stream(const uint8_t* blob, size_t size)
   if (h.crop_left + h.crop_right >= h.width || h.crop_top + h.crop_bottom >= h.height) return "conformance window";
   auto section = [&](uint64_t off, uint64_t count, uint64_t elem) { return (off & 3) == 0 && off >= sizeof(hm_pic) && off <= total && count * elem <= total - off; };
   if (h.n_slices == 0 || !section(h.off_slices, h.n_slices, sizeof(hm_slice)) || !section(h.off_ctbs, h.n_ctbs, sizeof(hm_ctb)) ||
-      !section(h.off_tus, h.n_tus, sizeof(hm_tu)) || !section(h.off_coeffs, h.n_coeffs, sizeof(hm_coeff)))
+      !section(h.off_tus, h.n_tus, (h.flags & HM_PIC_SPLIT_CHAINS) ? sizeof(hm_tu8) : sizeof(hm_tu)) || !section(h.off_coeffs, h.n_coeffs, sizeof(hm_coeff)))
     return "section offsets";
   if ((h.flags & HM_PIC_SCALING_LIST) && !section(h.off_scaling, HM_SCALING_BYTES, 1)) return "scaling tables";
   if (h.n_tus == 0) return "no records";
@@ -48,6 +48,25 @@ static const char* validate_stream(const uint8_t* blob, size_t size)
       if (cf[u.coeff_first + q].pos >= nT * nT) return "level position";
     return nullptr;
   };
+  // compact records (split chains): the full form of record t; its levels start at the running sum of the counts before
+  // it, which must agree with the sums the CTB headers carry (the kernels start from those)
+  const hm_tu8* tus8 = reinterpret_cast<const hm_tu8*>(blob + h.off_tus);
+  uint64_t level_at = 0;
+  auto expand = [&](uint64_t t) {
+    hm_tu u;
+    std::memset(&u, 0, sizeof(u));
+    const hm_tu8& c = tus8[t];
+    const int nT = 1 << (c.info & HM_TU_LOG2_MASK);
+    u.x = (uint8_t)((c.pos & 15) << 2); u.y = (uint8_t)((c.pos >> 4) << 2);
+    u.info = c.info; u.pred_mode = c.pred_mode; u.qp = c.qp; u.qpy = c.qpy;
+    u.n_coeff = (uint16_t)(c.count & HM_TU8_COUNT_MASK);
+    u.coeff_first = (uint32_t)(level_at < 0xFFFFFFFFu ? level_at : 0xFFFFFFFFu);
+    u.avail_left = (c.count & HM_TU8_LEFT) ? (uint8_t)nT : 0;
+    u.avail_top = (c.count & HM_TU8_TOP) ? (uint8_t)nT : 0;
+    u.avail_bottom_left = (uint8_t)((c.avail & 15) << 2);
+    u.avail_top_right = (uint8_t)((c.avail >> 4) << 2);
+    return u;
+  };
   uint64_t next = 0;
   for (uint32_t cy = 0; cy < h.ctb_h; cy++)
     for (int pass = 0; pass < (split ? 2 : 1); pass++)
@@ -63,10 +82,20 @@ static const char* validate_stream(const uint8_t* blob, size_t size)
         if (first != next) return "records of the CTBs are not contiguous in (row, list, CTB) order";
         next += count;
         if (next > h.n_tus) return "record range of a CTB";
-        for (uint64_t t = first; t < next; t++)
-          if (const char* what = check_record(tus[t], split ? (pass == 0 ? 1 : 0) : -1)) return what;
+        if (split && (pass == 0 ? c.coeff_first : c.coeff_first_c) != level_at) return "level index of a CTB's first record";
+        for (uint64_t t = first; t < next; t++) {
+          if (!split) {
+            if (const char* what = check_record(tus[t], -1)) return what;
+            continue;
+          }
+          if (tus8[t].count & ~(HM_TU8_COUNT_MASK | HM_TU8_LEFT | HM_TU8_TOP)) return "reserved bits of a record";
+          const hm_tu u = expand(t);
+          if (const char* what = check_record(u, pass == 0 ? 1 : 0)) return what;
+          level_at += u.n_coeff;
+        }
       }
   if (next != h.n_tus) return "record count";
+  if (split && level_at != h.n_coeffs) return "level count";
   return nullptr;
 }
 

@@ -11,7 +11,7 @@
  *     hm_pic            header
  *     hm_slice[n_slices]
  *     hm_ctb[n_ctbs]    raster order
- *     hm_tu[n_tus]      see "record order" below
+ *     hm_tu[n_tus]      see "record order" below (hm_tu8[n_tus] in pictures with HM_PIC_SPLIT_CHAINS)
  *     hm_coeff[n_coeffs]
  *
  * Record order.  Intra prediction chains the blocks of one colour plane; luma and chroma never read each other (the
@@ -20,6 +20,10 @@
  *     CTBs in raster order, each CTB's in decode order, then the chroma records (Cb and Cr, decode order) of the row's
  *     CTBs likewise.  hm_ctb.tu_first / tu_count delimit the CTB's luma records, tu_first_c / tu_count_c its chroma
  *     records; within a row both lists are contiguous from CTB to CTB, so a kernel walks each with a running index.
+ *     The records are the compact 8-byte hm_tu8, and the levels (hm_coeff) lie in the order of the records, so a
+ *     record's first level is the running sum of the counts before it: hm_ctb.coeff_first / coeff_first_c give that
+ *     sum at the CTB's first luma / chroma record (format HSM4: 0.47 instead of 0.78 bytes of command stream per
+ *     luma sample on the benchmark tiles - the stream crosses PCIe, and it is what bounds the device-inclusive clock).
  *   HM_PIC_SPLIT_CHAINS clear (pictures with HM_PIC_RARE_SYNTAX): all records of a CTB in decode order in
  *     [tu_first, tu_first + tu_count), CTBs in raster order; tu_count_c = 0.
  */
@@ -32,7 +36,7 @@
 extern "C" {
 #endif
 
-#define HM_STREAM_MAGIC 0x334d5348u /* "HSM3" */
+#define HM_STREAM_MAGIC 0x344d5348u /* "HSM4" */
 
 /* hm_pic.flags */
 #define HM_PIC_STRONG_INTRA_SMOOTHING 0x0001u /* sps.strong_intra_smoothing_enable_flag        */
@@ -133,8 +137,10 @@ typedef struct hm_ctb {
   uint32_t tu_first_c;   /* HM_PIC_SPLIT_CHAINS: the CTB's chroma records (contiguous along the CTB row)  */
   uint16_t tu_count_c;
   uint16_t reserved;
-} hm_ctb; /* 44 bytes = HM_CTB_DWORDS dwords */
-#define HM_CTB_DWORDS 11
+  uint32_t coeff_first;  /* HM_PIC_SPLIT_CHAINS: index of the first level of the CTB's first luma record ...     */
+  uint32_t coeff_first_c;/* ... and of its first chroma record (levels lie in record order)                       */
+} hm_ctb; /* 52 bytes = HM_CTB_DWORDS dwords */
+#define HM_CTB_DWORDS 13
 
 /* hm_tu.info */
 #define HM_TU_LOG2_MASK 0x07u  /* log2 block size 2..5 (component samples)                    */
@@ -163,6 +169,24 @@ typedef struct hm_tu {
   uint32_t coeff_first;  /* index into hm_coeff[]                                             */
   uint8_t  avail_left, avail_bottom_left, avail_top, avail_top_right;
 } hm_tu; /* 16 bytes */
+
+/* The same step in pictures with HM_PIC_SPLIT_CHAINS (no rare syntax: no PCM / bypass flags, levels in record order):
+ *   pos        x >> 2 | (y >> 2) << 4           (block positions are multiples of 4 samples of their plane)
+ *   info, pred_mode, qp, qpy                     as in hm_tu (pred_mode without flags)
+ *   avail      below-left count >> 2 | (top-right count >> 2) << 4   (counts are multiples of 4: 0 .. nT)
+ *   count      n_coeff (bits 0-10) | HM_TU8_LEFT | HM_TU8_TOP: left / top run complete (the counts are 0 or nT) */
+#define HM_TU8_COUNT_MASK 0x07FFu
+#define HM_TU8_LEFT       0x0800u
+#define HM_TU8_TOP        0x1000u
+typedef struct hm_tu8 {
+  uint8_t  pos;
+  uint8_t  info;
+  uint8_t  pred_mode;
+  uint8_t  qp;
+  int8_t   qpy;
+  uint8_t  avail;
+  uint16_t count;
+} hm_tu8; /* 8 bytes */
 
 typedef struct hm_coeff {
   uint16_t pos;          /* x + y * nT (coeffPos, slice.cc:3694-3696)                         */

@@ -627,6 +627,34 @@ int orc_decode_picture(const uint8_t* blob, size_t size, int stages, uint16_t* y
   P.ctbs = (const hm_ctb*)(blob + H->off_ctbs);
   P.tus = (const hm_tu*)(blob + H->off_tus);
   P.coeffs = (const hm_coeff*)(blob + H->off_coeffs);
+  hm_tu* expanded = NULL;
+  if (H->flags & HM_PIC_SPLIT_CHAINS) {
+    /* compact records (hm_stream.h: hm_tu8): back to the full form; the levels lie in record order, so a record's first
+     * level is the running sum of the counts before it (checked against the per-CTB sums of the stream below) */
+    const hm_tu8* c8 = (const hm_tu8*)(blob + H->off_tus);
+    expanded = (hm_tu*)calloc(H->n_tus ? H->n_tus : 1, sizeof(hm_tu));
+    uint32_t at = 0;
+    for (uint32_t i = 0; i < H->n_tus; i++) {
+      hm_tu* t = &expanded[i];
+      const int nT = 1 << (c8[i].info & HM_TU_LOG2_MASK);
+      t->x = (uint8_t)((c8[i].pos & 15) << 2); t->y = (uint8_t)((c8[i].pos >> 4) << 2);
+      t->info = c8[i].info; t->pred_mode = c8[i].pred_mode; t->qp = c8[i].qp; t->qpy = c8[i].qpy;
+      t->n_coeff = (uint16_t)(c8[i].count & HM_TU8_COUNT_MASK);
+      t->coeff_first = at;
+      at += t->n_coeff;
+      t->avail_left = (c8[i].count & HM_TU8_LEFT) ? (uint8_t)nT : 0;
+      t->avail_top = (c8[i].count & HM_TU8_TOP) ? (uint8_t)nT : 0;
+      t->avail_bottom_left = (uint8_t)((c8[i].avail & 15) << 2);
+      t->avail_top_right = (uint8_t)((c8[i].avail >> 4) << 2);
+    }
+    if (at != H->n_coeffs) { free(expanded); return -3; }
+    for (uint32_t i = 0; i < H->n_ctbs; i++) { /* the per-CTB level sums the kernels start from */
+      const hm_ctb* c = &P.ctbs[i];
+      if ((c->tu_count && expanded[c->tu_first].coeff_first != c->coeff_first) ||
+          (c->tu_count_c && expanded[c->tu_first_c].coeff_first != c->coeff_first_c)) { free(expanded); return -3; }
+    }
+    P.tus = expanded;
+  }
   P.scaling = (H->flags & HM_PIC_SCALING_LIST) ? blob + H->off_scaling : NULL;
   const int ncomp = H->chroma_format == 0 ? 1 : 3;
   P.sw = H->chroma_format == 3 ? 1 : 2; P.sh = H->chroma_format == 1 ? 2 : 1;
@@ -658,5 +686,6 @@ int orc_decode_picture(const uint8_t* blob, size_t size, int stages, uint16_t* y
   }
   free(P.edge);
   free(P.qpy);
+  free(expanded);
   return 0;
 }

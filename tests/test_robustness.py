@@ -148,33 +148,49 @@ def test_foreign_command_streams_are_validated(hm):
     blobs = [hevcutil.parse(hm, corpus.stream(n)) for n in names]
     for b in blobs:
         assert hm.hm_stream_validate(b, len(b)) == 0, hm.hm_last_error()
-    b = bytearray(blobs[2])
     # hm_pic (include/hm_stream.h): n_slices, n_ctbs, n_tus, n_coeffs at 0x2C.., off_slices, off_ctbs, off_tus, off_coeffs at 0x3C..
-    off = {name: struct.unpack_from("<I", b, pos)[0] for name, pos in (("ctbs", 0x40), ("tus", 0x44), ("coeffs", 0x48))}
+    def mutations(b, compact):
+        off = {name: struct.unpack_from("<I", b, pos)[0] for name, pos in (("ctbs", 0x40), ("tus", 0x44), ("coeffs", 0x48))}
 
-    def bad(mut):
-        m = bytearray(b)
-        mut(m)
-        return hm.hm_stream_validate(bytes(m), len(m)) != 0
+        def bad(mut):
+            m = bytearray(b)
+            mut(m)
+            return hm.hm_stream_validate(bytes(m), len(m)) != 0
 
-    def put(fmt, pos, val):
-        return lambda m: struct.pack_into(fmt, m, pos, val)
+        def put(fmt, pos, val):
+            return lambda m: struct.pack_into(fmt, m, pos, val)
 
-    tus, cfs, ctbs = off["tus"], off["coeffs"], off["ctbs"]
-    assert bad(put("<I", 4, len(b) + 1))                       # total_bytes beyond the buffer
-    assert bad(put("<I", 0x34, 0xFFFFFFF))                     # n_tus
-    assert bad(put("<I", 0x44, len(b) - 4))                    # off_tus
-    assert bad(put("<B", tus + 2, 7))                          # block size 2^7
-    assert bad(put("<B", tus + 0, 200))                        # block outside its CTB
-    assert bad(put("<B", tus + 3, 63))                         # prediction mode 63
-    assert bad(put("<H", tus + 6, 5000))                       # n_coeff > nT^2
-    assert bad(put("<I", tus + 8, 0x7FFFFFFF))                 # coeff_first
-    assert bad(put("<B", tus + 12, 250))                       # avail_left > nT
-    assert bad(put("<I", ctbs, 7))                             # tu_first of CTB 0 (records not contiguous)
-    assert bad(put("<H", ctbs + 6, 9))                         # slice index
-    assert bad(put("<B", ctbs + 12, 9))                        # SAO type
-    first_cf = next(struct.unpack_from("<I", b, tus + 16 * t + 8)[0] for t in range(64) if struct.unpack_from("<H", b, tus + 16 * t + 6)[0])
-    assert bad(put("<H", cfs + 4 * first_cf, 60000))           # level position outside the block
+        tus, cfs, ctbs = off["tus"], off["coeffs"], off["ctbs"]
+        assert bad(put("<I", 4, len(b) + 1))                       # total_bytes beyond the buffer
+        assert bad(put("<I", 0x34, 0xFFFFFFF))                     # n_tus
+        assert bad(put("<I", 0x44, len(b) - 4))                    # off_tus
+        assert bad(put("<I", ctbs, 7))                             # tu_first of CTB 0 (records not contiguous)
+        assert bad(put("<H", ctbs + 6, 9))                         # slice index
+        assert bad(put("<B", ctbs + 12, 9))                        # SAO type
+        if compact:  # hm_tu8: pos, info, pred_mode, qp, qpy, avail, count
+            assert bad(put("<B", tus + 1, 7))                      # block size 2^7
+            assert bad(put("<B", tus + 2, 63))                     # prediction mode 63
+            assert bad(put("<B", tus + 2, 0x80 | 1))               # PCM flag in a picture without rare syntax
+            assert bad(put("<H", tus + 6, 0x07FF))                 # more levels than the block has positions
+            assert bad(put("<H", tus + 6, 0xE000))                 # reserved bits
+            assert bad(put("<B", tus + 5, 0xFF))                   # below-left / top-right counts beyond the block size
+            assert bad(put("<I", ctbs + 44, 7))                    # level index of the CTB's first record
+            size0 = struct.unpack_from("<B", b, tus + 1)[0] & 7
+            assert bad(put("<B", tus + 0, 0xFF)) or size0 == 2    # block outside its CTB (a 4x4 block at 60,60 of a 64 CTB is inside)
+            counts = [struct.unpack_from("<H", b, tus + 8 * t + 6)[0] & 0x7FF for t in range(64)]
+            first_cf = sum(counts[:next(t for t in range(64) if counts[t])])
+        else:        # hm_tu
+            assert bad(put("<B", tus + 2, 7))                      # block size 2^7
+            assert bad(put("<B", tus + 0, 200))                    # block outside its CTB
+            assert bad(put("<B", tus + 3, 63))                     # prediction mode 63
+            assert bad(put("<H", tus + 6, 5000))                   # n_coeff > nT^2
+            assert bad(put("<I", tus + 8, 0x7FFFFFFF))             # coeff_first
+            assert bad(put("<B", tus + 12, 250))                   # avail_left > nT
+            first_cf = next(struct.unpack_from("<I", b, tus + 16 * t + 8)[0] for t in range(64) if struct.unpack_from("<H", b, tus + 16 * t + 6)[0])
+        assert bad(put("<H", cfs + 4 * first_cf, 60000))           # level position outside the block
+
+    mutations(bytearray(blobs[2]), True)    # compact records (split chains)
+    mutations(bytearray(blobs[4]), False)   # rare syntax: full records in decode order
     rng = random.Random(7)
     for _ in range(3000):                                      # arbitrary corruption: any verdict, no crash
         m = bytearray(blobs[rng.randrange(len(blobs))])
