@@ -736,7 +736,7 @@ extern "C" int hm_launch_recon_quad(const hm_dev_pic* d_pics, int n_pics, int lo
       const int bytes = Q_SHARED + k * L.pic_bytes;
       if (bytes > 160 * 1024) break;
       int per_cu = (160 * 1024 / bytes) * k * W;
-      if (per_cu > 16) per_cu = 16; // (the kernel needs up to 128 VGPRs: four waves per SIMD)
+      if (per_cu > 16) per_cu = 16; // (the kernel needs up to 128 VGPRs: four waves per SIMD; capped at 96 it spills 27-43 of them: 60 ms instead of 37.6)
       if (per_cu > best) { best = per_cu; np = k; }
     }
     if (np == 0) return false;
