@@ -22,6 +22,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include <stdlib.h>
 
 #include "hm_device.h"
@@ -317,9 +318,157 @@ __device__ __forceinline__ void window_load(Window<Pix>& win, const uint8_t* pla
     __builtin_memcpy(win.w[r], plane + (size_t)y * pitch + (ptrdiff_t)ox * (int)sizeof(Pix), 8 * sizeof(Pix));
   }
 }
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 as_s(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
+__device__ __forceinline__ u16x2 as_u(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ uint32_t as_w(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ uint32_t as_w(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+
+// ---- the window filters on TWO lines at once (8-bit samples, no "pcmf" branches) ---------------------------------------
+// filter_luma / filter_chroma above spend most of their instructions on one line of an edge at a time; every value of
+// the filters fits 16 bits (sums of at most eight 8-bit samples, 9 * 255), so two lines travel through the arithmetic as
+// the halves of one register (v_pk_*), gathered from / scattered to the packed window with v_perm_b32.  Same results.
+__device__ __forceinline__ s16x2 pk_clamp(s16x2 x, s16x2 lo, s16x2 hi) { return __builtin_elementwise_min(__builtin_elementwise_max(x, lo), hi); }
+__device__ __forceinline__ s16x2 pk_abs(s16x2 x) { return __builtin_elementwise_max(x, (s16x2)(0) - x); }
+__device__ __forceinline__ uint32_t pk_select(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); } // m ? a : b, per bit
+
+// P[i] = sample i (0..7 across the edge: p3 p2 p1 p0 | q0 q1 q2 q3) of line a (low half) and of line a + 1 (high half)
+template <bool V, int A, int I0 = 0, int I1 = 8>
+__device__ __forceinline__ void pk_gather(const Window<uint8_t>& W, uint32_t (&P)[8])
+{
+#pragma unroll
+  for (int i = I0; i < I1; i++) {
+    if (V) P[i] = __builtin_amdgcn_perm(W.w[A + 1][i >> 2], W.w[A][i >> 2], 0x0c000c00u | (uint32_t)(i & 3) | ((uint32_t)(4 + (i & 3)) << 16));
+    else P[i] = __builtin_amdgcn_perm(0u, W.w[i][A >> 2], 0x0c000c00u | (uint32_t)(A & 3) | ((uint32_t)((A & 3) + 1) << 16));
+  }
+}
+// samples I0 .. I1-1 of lines a, a + 1 back into the window
+template <bool V, int A, int I0, int I1>
+__device__ __forceinline__ void pk_scatter(Window<uint8_t>& W, const uint32_t (&P)[8])
+{
+#pragma unroll
+  for (int i = I0; i < I1; i++) {
+    if (V) { // byte i & 3 of word i >> 2 of rows a (from the low half) and a + 1 (from the high half)
+      constexpr uint32_t keep = 0x03020100u;
+      const int b = i & 3;
+      const uint32_t sel_lo = (keep & ~(0xFFu << (8 * b))) | (4u << (8 * b)), sel_hi = (keep & ~(0xFFu << (8 * b))) | (6u << (8 * b));
+      W.w[A][i >> 2] = __builtin_amdgcn_perm(P[i], W.w[A][i >> 2], sel_lo);
+      W.w[A + 1][i >> 2] = __builtin_amdgcn_perm(P[i], W.w[A + 1][i >> 2], sel_hi);
+    }
+    else { // bytes a & 3 and (a & 3) + 1 of word a >> 2 of row i
+      constexpr uint32_t keep = 0x03020100u;
+      constexpr int b = A & 3;
+      constexpr uint32_t sel = (keep & ~(0xFFFFu << (8 * b))) | (0x0604u << (8 * b));
+      W.w[i][A >> 2] = __builtin_amdgcn_perm(P[i], W.w[i][A >> 2], sel);
+    }
+  }
+}
+
+// fallback-postfilter.h:32-138 for the two 4-line units of one edge of the window, two lines per pass
+template <bool V>
+__device__ __forceinline__ void filter_luma_pk(Window<uint8_t>& W, const int beta2[2], const int tc2[2])
+{
+  auto unit = [&](auto jc) {
+    constexpr int J = decltype(jc)::value, O = 4 * J;
+    const int tc = tc2[J], beta = beta2[J];
+    if (tc == 0) return; // bS 0
+    uint32_t A[8], B[8];
+    pk_gather<V, O>(W, A);
+    pk_gather<V, O + 2>(W, B);
+    // the decisions look at lines 0 and 3 of the unit: low half of A, high half of B
+    s16x2 C[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) C[i] = as_s(pk_select(0x0000FFFFu, A[i], B[i]));
+    const uint32_t dp = as_w(pk_abs(C[1] - C[2] - C[2] + C[3])), dq = as_w(pk_abs(C[6] - C[5] - C[5] + C[4]));
+    const int dp0 = (int)(dp & 0xFFFF), dp3 = (int)(dp >> 16), dq0 = (int)(dq & 0xFFFF), dq3 = (int)(dq >> 16);
+    const int d0 = dp0 + dq0, d3 = dp3 + dq3;
+    if (d0 + d3 >= beta) return;
+    const int beta_3 = beta >> 3, beta_2 = beta >> 2, tc25 = (tc * 5 + 1) >> 1;
+    const uint32_t flat = as_w(pk_abs(C[0] - C[3]) + pk_abs(C[7] - C[4])), step = as_w(pk_abs(C[3] - C[4]));
+    const bool strong = (int)(flat & 0xFFFF) < beta_3 && (int)(flat >> 16) < beta_3 && (int)(step & 0xFFFF) < tc25 && (int)(step >> 16) < tc25 &&
+                        (d0 << 1) < beta_2 && (d3 << 1) < beta_2;
+    if (strong) {
+      const s16x2 t2 = (s16x2)((short)(tc << 1)), nt2 = (s16x2)(0) - t2;
+      auto pass = [&](uint32_t (&X)[8]) {
+        const s16x2 p3 = as_s(X[0]), p2 = as_s(X[1]), p1 = as_s(X[2]), p0 = as_s(X[3]), q0 = as_s(X[4]), q1 = as_s(X[5]), q2 = as_s(X[6]), q3 = as_s(X[7]);
+        const s16x2 s = p0 + q0;
+        X[3] = as_w(p0 + pk_clamp(((p2 + p1 + p1 + s + s + q1 + (s16x2)(4)) >> (s16x2)(3)) - p0, nt2, t2));
+        X[2] = as_w(p1 + pk_clamp(((p2 + p1 + s + (s16x2)(2)) >> (s16x2)(2)) - p1, nt2, t2));
+        X[1] = as_w(p2 + pk_clamp(((p3 + p3 + p2 + p2 + p2 + p1 + s + (s16x2)(4)) >> (s16x2)(3)) - p2, nt2, t2));
+        X[4] = as_w(q0 + pk_clamp(((p1 + s + s + q1 + q1 + q2 + (s16x2)(4)) >> (s16x2)(3)) - q0, nt2, t2));
+        X[5] = as_w(q1 + pk_clamp(((s + q1 + q2 + (s16x2)(2)) >> (s16x2)(2)) - q1, nt2, t2));
+        X[6] = as_w(q2 + pk_clamp(((q3 + q3 + q2 + q2 + q2 + q1 + s + (s16x2)(4)) >> (s16x2)(3)) - q2, nt2, t2));
+      };
+      pass(A);
+      pass(B);
+      pk_scatter<V, O, 1, 7>(W, A);
+      pk_scatter<V, O + 2, 1, 7>(W, B);
+    }
+    else {
+      const int tc_2 = tc >> 1;
+      const int thr = (beta + (beta >> 1)) >> 3;
+      const bool np2 = dp0 + dp3 < thr, nq2 = dq0 + dq3 < thr;
+      const s16x2 tcv = (s16x2)((short)tc), ntcv = (s16x2)(0) - tcv, tc2v = (s16x2)((short)tc_2), ntc2v = (s16x2)(0) - tc2v;
+      const s16x2 zero = (s16x2)(0), maxv = (s16x2)(255), lim = (s16x2)((short)(10 * tc));
+      auto pass = [&](uint32_t (&X)[8]) {
+        const s16x2 p2 = as_s(X[1]), p1 = as_s(X[2]), p0 = as_s(X[3]), q0 = as_s(X[4]), q1 = as_s(X[5]), q2 = as_s(X[6]);
+        const s16x2 dqp = q0 - p0, dqp1 = q1 - p1;
+        const s16x2 delta0 = ((dqp << (s16x2)(3)) + dqp - dqp1 - dqp1 - dqp1 + (s16x2)(8)) >> (s16x2)(4);
+        const uint32_t m = as_w((pk_abs(delta0) - lim) >> (s16x2)(15)); // all ones in the halves whose |delta0| < 10 tc
+        const s16x2 delta = pk_clamp(delta0, ntcv, tcv);
+        X[3] = pk_select(m, as_w(pk_clamp(p0 + delta, zero, maxv)), X[3]);
+        X[4] = pk_select(m, as_w(pk_clamp(q0 - delta, zero, maxv)), X[4]);
+        if (np2) X[2] = pk_select(m, as_w(pk_clamp(p1 + pk_clamp(((((p2 + p0 + (s16x2)(1)) >> (s16x2)(1)) - p1 + delta) >> (s16x2)(1)), ntc2v, tc2v), zero, maxv)), X[2]);
+        if (nq2) X[5] = pk_select(m, as_w(pk_clamp(q1 + pk_clamp(((((q2 + q0 + (s16x2)(1)) >> (s16x2)(1)) - q1 - delta) >> (s16x2)(1)), ntc2v, tc2v), zero, maxv)), X[5]);
+      };
+      pass(A);
+      pass(B);
+      pk_scatter<V, O, 2, 6>(W, A);
+      pk_scatter<V, O + 2, 2, 6>(W, B);
+    }
+  };
+  unit(std::integral_constant<int, 0>());
+  unit(std::integral_constant<int, 1>());
+}
+
+// chroma edge (fallback-postfilter.h:138-180), two lines per pass: p1 p0 | q0 q1 = samples 2..5
+template <bool V>
+__device__ __forceinline__ void filter_chroma_pk(Window<uint8_t>& W, const int tc2[2])
+{
+  auto pair = [&](auto ac) {
+    constexpr int A = decltype(ac)::value;
+    const int t = tc2[A >> 2];
+    if (t == 0) return;
+    uint32_t X[8];
+    pk_gather<V, A, 2, 6>(W, X);
+    const s16x2 p1 = as_s(X[2]), p0 = as_s(X[3]), q0 = as_s(X[4]), q1 = as_s(X[5]);
+    const s16x2 tv = (s16x2)((short)t);
+    const s16x2 delta = pk_clamp((((q0 - p0) << (s16x2)(2)) + p1 - q1 + (s16x2)(4)) >> (s16x2)(3), (s16x2)(0) - tv, tv);
+    X[3] = as_w(pk_clamp(p0 + delta, (s16x2)(0), (s16x2)(255)));
+    X[4] = as_w(pk_clamp(q0 - delta, (s16x2)(0), (s16x2)(255)));
+    pk_scatter<V, A, 3, 5>(W, X);
+  };
+  pair(std::integral_constant<int, 0>());
+  pair(std::integral_constant<int, 2>());
+  pair(std::integral_constant<int, 4>());
+  pair(std::integral_constant<int, 6>());
+}
+
 template <typename Pix, bool PCMF>
 __device__ __forceinline__ void window_filter(Window<Pix>& win, int c, const WindowEdges<PCMF>& E, int maxv)
 {
+  if constexpr (sizeof(Pix) == 1 && !PCMF) { // 8-bit pictures without the "pcmf" branches: two lines per instruction
+    if (c == 0) {
+      filter_luma_pk<true>(win, E.betaV, E.tcV);
+      filter_luma_pk<false>(win, E.betaH, E.tcH);
+    }
+    else {
+      filter_chroma_pk<true>(win, E.tcV);
+      filter_chroma_pk<false>(win, E.tcH);
+    }
+    return;
+  }
   if (c == 0) {
     filter_luma<true>(win, E.betaV, E.tcV, maxv, E.mpV, E.mqV);
     filter_luma<false>(win, E.betaH, E.tcH, maxv, E.mpH, E.mqH);
@@ -450,12 +599,6 @@ __device__ __forceinline__ int sao_sample(const hm_dev_pic& dp, const PicView& v
 // ---- SAO arithmetic on pairs of samples (two 16-bit halves per register, v_pk_* / v_perm_b32) ----
 // The per-sample version of this kernel was bound by VALU issue (~38 instructions per sample); here a group of 8
 // samples is 4 registers of sample pairs and the offset table is a byte lookup (v_perm_b32), ~8 per sample.
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ s16x2 as_s(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
-__device__ __forceinline__ u16x2 as_u(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
-__device__ __forceinline__ uint32_t as_w(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
-__device__ __forceinline__ uint32_t as_w(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
 // per half: sign(c - a) as -1 / 0 / +1
 __device__ __forceinline__ uint32_t pk_sign_diff(uint32_t c, uint32_t a)
 {

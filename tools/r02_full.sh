@@ -7,5 +7,5 @@ rocprofv3 --kernel-trace --stats -d gpurun_out/r02_prof_stats --output-format cs
 HM_TAIL_FUSED=0 rocprofv3 --kernel-trace --stats -d gpurun_out/r02_prof_stats_unfused --output-format csv -- python3 bench.py --no-parity --quick > gpurun_out/r02_bench_under_rocprof_unfused.json 2> gpurun_out/r02_bench_under_rocprof_unfused.err
 find gpurun_out/r02_prof_stats gpurun_out/r02_prof_stats_unfused -name "*kernel_stats.csv" | head -4
 bash tools/pmc_traffic.sh r02 384 2>&1 | tail -40
-bash tools/pmc_sq.sh r02 --steps 3 --warmup 1 --images 48 2>&1 | tail -60
+bash tools/pmc_sq.sh r02 --steps 2 --warmup 1 --images 384 2>&1 | tail -60
 cat gpurun_out/r02_gputest_full.log
