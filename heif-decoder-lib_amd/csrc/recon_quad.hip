@@ -201,14 +201,12 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
   const GLOBAL_AS uint32_t* tus = gptr<uint32_t>(blob + H->off_tus);     // 2 dwords per hm_tu8 (hm_stream.h)
   const GLOBAL_AS uint32_t* coeffs = gptr<uint32_t>(blob + H->off_coeffs);
   const uint32_t n_tus = H->n_tus;
-  GLOBAL_AS uint16_t* g_meta = gptr_w<uint16_t>(dp.meta);
   const int ctb_w = dp.ctb_w, ctb_h = dp.ctb_h;
   const int sh = dp.chroma_format == 1 ? 2 : 1;
   const int bd = sizeof(Pix) == 1 ? 8 : dp.bit_depth;
   constexpr int P0 = ctb + UPAD, cw_c = ctb >> 1, P1 = cw_c + UPAD;
   const int ch_c = ctb / sh;
   const int strong = dp.flags & HM_PIC_STRONG_INTRA_SMOOTHING;
-  const int planeWc = dp.width >> 1, planeHc = dp.height / sh;
   const int Wc = ctb_w * cw_c;
   const bool mono = dp.chroma_format == 0;
   const int NR = mono ? 4 : 2; // CTU rows in flight per wave
@@ -246,7 +244,7 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
   for (int i = lane; i < NG * 16; i += 64) q_slots[i] = 0; // tag 0 is never used by a step
 
   // ---- per-lane constants of the 4x4 path ----
-  const int g = lane >> 4, gl = lane & 15, bx = gl & 3, by = gl >> 2;
+  const int g = lane >> 4, gl = lane & 15, bx_ = gl & 3, by_ = gl >> 2;
   const int kind = group_kind(g); // 0: luma chain, 1: chroma chain
   Pix* const gu01 = group_u(g, kind ? 1 : 0); // CTU buffer of the luma plane / of Cb
   Pix* const gu2 = group_u(g, 2);             // ... of Cr (chroma chains)
@@ -267,8 +265,8 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int j = (src[k] >> 2) & 3;
-      w1[k] = kind ? (int)dct[(8 * j) * 32 + by] : (int)tab[76 + j * 4 + by];
-      w2[k] = kind ? (int)dct[(8 * k) * 32 + bx] : (int)tab[76 + k * 4 + bx];
+      w1[k] = kind ? (int)dct[(8 * j) * 32 + by_] : (int)tab[76 + j * 4 + by_];
+      w2[k] = kind ? (int)dct[(8 * k) * 32 + bx_] : (int)tab[76 + k * 4 + bx_];
     }
   }
 
@@ -379,6 +377,11 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
 #else
     if (quad) {
 #endif
+      // (the comparisons of the lane's position inside its block are loop invariants the compiler would keep as 64-bit
+      //  lane masks - in scalar registers it does not have: they came back from spill lanes with two v_readlane each;
+      //  an opaque copy makes them one v_cmp where they are used)
+      int bx = bx_, by = by_;
+      asm volatile("" : "+v"(bx), "+v"(by));
       const int x4 = (int)(n0 & 15), y4 = (int)((n0 >> 4) & 15); // pos: x >> 2 | (y >> 2) << 4
       const int x0 = x4 << 2; // (shift folded into the address adds)
       const int mode = (int)((n0 >> 16) & 0xFF);
@@ -645,20 +648,32 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
         WAVE_SYNC();
         if (lane < bh) u[lane * P + UPAD - 1] = u[lane * P + UPAD + BW - 1]; // right column becomes the left neighbour
       };
-      if (fkind == 0) flush_plane(std::integral_constant<int, ctb>(), group_u(fg, 0), P0, lw, dp.plane[0], dp.pitch[0], ctb, dp.width, dp.height);
+      // The picture's planes, pitches and sizes are only needed here, once per CTU: they are read again from the
+      // descriptor through a pointer the compiler cannot see through, instead of occupying ~16 scalar registers for the
+      // whole loop (the kernel is short of them: scalar registers spilled to vector lanes cost VALU instructions).
+      const hm_dev_pic* fp;
+      {
+        const uint64_t a = (uint64_t)(uintptr_t)(pics + pic_index);
+        uint64_t u = ((uint64_t)(uint32_t)rfl((int)(a >> 32)) << 32) | (uint32_t)rfl((int)a);
+        asm volatile("" : "+s"(u));
+        fp = reinterpret_cast<const hm_dev_pic*>((uintptr_t)u);
+      }
+      const int planeWc = fp->width >> 1, planeHc = fp->height / sh;
+      if (fkind == 0) flush_plane(std::integral_constant<int, ctb>(), group_u(fg, 0), P0, lw, fp->plane[0], fp->pitch[0], ctb, fp->width, fp->height);
       else {
-        flush_plane(std::integral_constant<int, (ctb >> 1)>(), group_u(fg, 1), P1, lw, dp.plane[1], dp.pitch[1], ch_c, planeWc, planeHc);
-        flush_plane(std::integral_constant<int, (ctb >> 1)>(), group_u(fg, 2), P1, lw + (Wc + 4), dp.plane[2], dp.pitch[2], ch_c, planeWc, planeHc);
+        flush_plane(std::integral_constant<int, (ctb >> 1)>(), group_u(fg, 1), P1, lw, fp->plane[1], fp->pitch[1], ch_c, planeWc, planeHc);
+        flush_plane(std::integral_constant<int, (ctb >> 1)>(), group_u(fg, 2), P1, lw + (Wc + 4), fp->plane[2], fp->pitch[2], ch_c, planeWc, planeHc);
       }
       if (fkind == 0) { // the CTU's block map; cells outside the picture were never written
         constexpr int M4 = ctb >> 2;
         const uint16_t* const l_meta = group_meta(fg);
-        GLOBAL_AS uint16_t* const ctb_meta = g_meta + (size_t)((s_row << log2_ctb) >> 2) * dp.w4 + ((s_cx << log2_ctb) >> 2);
+        const int w4 = fp->w4, h4 = fp->h4;
+        GLOBAL_AS uint16_t* const ctb_meta = gptr_w<uint16_t>(fp->meta) + (size_t)((s_row << log2_ctb) >> 2) * w4 + ((s_cx << log2_ctb) >> 2);
         const int gx0 = s_cx << (log2_ctb - 2), gy0 = s_row << (log2_ctb - 2);
 #pragma unroll
         for (int idx0 = 0; idx0 < M4 * M4; idx0 += 64) {
           const int idx = idx0 + lane, bi = idx & (M4 - 1), bj = idx >> (log2_ctb - 2);
-          if (idx < M4 * M4 && gx0 + bi < dp.w4 && gy0 + bj < dp.h4) ctb_meta[(uint32_t)bi + __umul24((uint32_t)bj, (uint32_t)dp.w4)] = l_meta[idx];
+          if (idx < M4 * M4 && gx0 + bi < w4 && gy0 + bj < h4) ctb_meta[(uint32_t)bi + __umul24((uint32_t)bj, (uint32_t)w4)] = l_meta[idx];
         }
       }
       WAVE_SYNC();
