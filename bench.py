@@ -420,6 +420,7 @@ def side_legs(out, args, torch, pkg, dev, st, gb, kept, strides, stream_b):
     B = len(gb.images)
     guarded(out, "host_entropy_decode", lambda: host_parse_rate(pkg, kept[0]))
     guarded(out, "wpp_row_parallel_parse", lambda: wpp_parse_rates(pkg))
+    guarded(out, "colour_kernel_standalone", lambda: colour_standalone(torch, pkg, gb, st))
     guarded(out, "device_inclusive", lambda: device_inclusive(torch, pkg, dev, gb, st, stream_b))
     guarded(out, "end_to_end", lambda: end_to_end_single(pkg, kept[0]))
     guarded(out, "end_to_end_pipelined", lambda: end_to_end_pipelined(pkg, kept))
@@ -442,6 +443,34 @@ def host_parse_rate(pkg, streams):
     dt = time.perf_counter() - t0
     return {"MP_per_s_per_core": round(len(streams) * TILE * TILE / 1e6 / dt, 1),
             "note": "hm_hevc_parse (CABAC -> command stream), 1 thread, outside the timed region"}
+
+
+def colour_standalone(torch, pkg, gb, st):
+    """the YCbCr 4:2:0 -> RGB24 kernel alone (k_ycbcr420_int over the batch's canvases, hm_colour_convert_batch): the
+    north star's colour-kernel roofline figure.  The default hot path no longer launches it (k_tail420 converts while it
+    filters), so it is timed here beside the headline, with events on the launch stream (torch's current stream)."""
+    L = pkg.lib()
+    L.hm_colour_convert_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    n = len(gb.images)
+
+    def run():
+        pkg.capi.check(L.hm_colour_convert_batch(C.byref(gb.desc), n, *gb.p, st))
+    for _ in range(2):
+        run()
+    evs = []
+    for _ in range(5):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        run()
+        b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+    px = gb.pixels()
+    return {"kernel": KERNEL_NAMES[3], "ms_per_step": round(ms, 4), "images": n,
+            "GBps": round(4.5 * px / ms / 1e6, 1), "frac_of_hbm_peak": round(4.5 * px / ms / 1e6 / HBM_PEAK_GBPS, 4),
+            "read_only_GBps": round(1.5 * px / ms / 1e6, 1), "read_only_frac_of_hbm_peak": round(1.5 * px / ms / 1e6 / HBM_PEAK_GBPS, 4),
+            "note": "1.5 B/px read + 3 B/px written (SURVEY 8d: both conventions); part of the hot path only when the tail is not fused"}
 
 
 def device_inclusive(torch, pkg, dev, gb, st, stream_b):

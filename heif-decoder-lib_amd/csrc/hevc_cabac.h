@@ -32,7 +32,12 @@ enum Ctx : int {
   CTX_SIG = 63,            // 44
   CTX_GT1 = 107,           // 24
   CTX_GT2 = 131,           // 6
-  CTX_COUNT = 137
+  // range extensions (contextmodel.cc:350-353 of the reference: all initialised from the value 154)
+  CTX_CHROMA_QP_OFFSET_FLAG = 137,
+  CTX_CHROMA_QP_OFFSET_IDX = 138,
+  CTX_RES_SCALE_ABS = 139, // 8: 4 * (cIdx - 1) + binIdx
+  CTX_RES_SCALE_SIGN = 147, // 2
+  CTX_COUNT = 149
 };
 
 struct ContextSet {
@@ -60,6 +65,9 @@ static const uint8_t kInit[CTX_COUNT] = {
     125, 141, 179, 153, 125, 140, 139, 182, 182, 152, 136, 152, 136, 153, 136, 139, 111, 136, 139, 111, 141, 111, // sig
     140, 92, 137, 138, 140, 152, 138, 139, 153, 74, 149, 92, 139, 107, 122, 152, 140, 179, 166, 182, 140, 227, 122, 197, // gt1
     138, 153, 136, 167, 152, 152,          // gt2
+    154, 154,                              // cu_chroma_qp_offset_flag / idx
+    154, 154, 154, 154, 154, 154, 154, 154, // log2_res_scale_abs_plus1
+    154, 154,                              // res_scale_sign_flag
 };
 
 static const uint8_t kRangeTabLps[64][4] = {

@@ -350,11 +350,8 @@ void parse_sps(BitReader& br, SPS& sps)
       sps.high_precision_offsets = br.flag();
       sps.persistent_rice = br.flag();
       sps.cabac_bypass_alignment = br.flag();
-      sps.range_ext_any = sps.transform_skip_rotation || sps.transform_skip_context || sps.implicit_rdpcm ||
-                          sps.explicit_rdpcm || sps.extended_precision || sps.intra_smoothing_disabled ||
-                          sps.persistent_rice || sps.cabac_bypass_alignment;
     }
-    if (multilayer || ext3d || scc) sps.range_ext_any = true; // not on the still-image path
+    if (multilayer || ext3d || scc) sps.unsupported_extension = true; // not on the still-image path
   }
   const int ctb = 1 << sps.log2_ctb;
   sps.ctb_w = (sps.width + ctb - 1) >> sps.log2_ctb;
@@ -439,14 +436,27 @@ void parse_pps(BitReader& br, PPS& pps, const SPS* sps_table)
       if (pps.transform_skip_enabled) pps.log2_max_transform_skip_size = br.ue() + 2;
       pps.cross_component_prediction = br.flag();
       pps.chroma_qp_offset_list_enabled = br.flag();
-      if (pps.chroma_qp_offset_list_enabled) {
-        br.ue();
-        int n = br.ue() + 1;
+      if (pps.chroma_qp_offset_list_enabled) { // pps.cc:80-117 of the reference
+        const SPS& s = sps_table[pps.sps_id];
+        pps.diff_cu_chroma_qp_offset_depth = (int)br.ue();
+        if (pps.diff_cu_chroma_qp_offset_depth > s.log2_ctb - s.log2_min_cb) throw ParseError(HM_ERR_BITSTREAM, "diff_cu_chroma_qp_offset_depth out of range");
+        const int n = (int)br.ue() + 1;
         if (n > 6) throw ParseError(HM_ERR_BITSTREAM, "chroma_qp_offset_list too long");
-        for (int i = 0; i < n; i++) { br.se(); br.se(); }
+        pps.chroma_qp_offset_list_len = n;
+        for (int i = 0; i < n; i++) {
+          pps.cb_qp_offset_list[i] = br.se();
+          pps.cr_qp_offset_list[i] = br.se();
+          if (pps.cb_qp_offset_list[i] < -12 || pps.cb_qp_offset_list[i] > 12 || pps.cr_qp_offset_list[i] < -12 || pps.cr_qp_offset_list[i] > 12)
+            throw ParseError(HM_ERR_BITSTREAM, "cb/cr_qp_offset_list entry out of range");
+        }
       }
       pps.log2_sao_offset_scale_luma = br.ue();
       pps.log2_sao_offset_scale_chroma = br.ue();
+      { // pps.cc:120-137 of the reference
+        const SPS& s = sps_table[pps.sps_id];
+        if (pps.log2_sao_offset_scale_luma > std::max(0, s.bit_depth_y - 10) || pps.log2_sao_offset_scale_chroma > std::max(0, s.bit_depth_c - 10))
+          throw ParseError(HM_ERR_BITSTREAM, "log2_sao_offset_scale out of range");
+      }
     }
   }
   derive_pps_tables(pps, sps_table[pps.sps_id]);
@@ -507,6 +517,7 @@ void derive_pps_tables(PPS& pps, const SPS& sps)
         }
 
   pps.Log2MinCuQpDeltaSize = sps.log2_ctb - pps.diff_cu_qp_delta_depth;
+  pps.Log2MinCuChromaQpOffsetSize = sps.log2_ctb - pps.diff_cu_chroma_qp_offset_depth;
 }
 
 void parse_slice_header(BitReader& br, int nal_unit_type, const SPS* sps_table, const PPS* pps_table,
@@ -586,7 +597,7 @@ void parse_slice_header(BitReader& br, int nal_unit_type, const SPS* sps_table, 
       if (sh.cb_qp_offset < -12 || sh.cb_qp_offset > 12 || sh.cr_qp_offset < -12 || sh.cr_qp_offset > 12)
         throw ParseError(HM_ERR_BITSTREAM, "slice_cb/cr_qp_offset out of range");
     }
-    if (pps.chroma_qp_offset_list_enabled) br.flag(); // cu_chroma_qp_offset_enabled_flag
+    if (pps.chroma_qp_offset_list_enabled) sh.cu_chroma_qp_offset_enabled = br.flag();
     bool override_flag = false;
     if (pps.deblocking_override_enabled) override_flag = br.flag();
     sh.deblocking_disabled = pps.deblocking_disabled;

@@ -182,8 +182,9 @@ struct Decoder {
     // slice data starts right after the header in the unescaped payload (+2 for the NAL header)
     const uint8_t* begin = rbsp.data() + 2 + sh.data_byte_offset;
     const uint8_t* end = rbsp.data() + rbsp.size();
+    // (StatCoeff and CuQpOffsetCb / Cr run on from one CTB row into the next in the reference: such segments stay serial)
     if (threads > 1 && p.entropy_coding_sync && !p.tiles_enabled && !sh.dependent && sh.num_entry_points > 0 &&
-        (sh.slice_segment_address % s.ctb_w) == 0)
+        (sh.slice_segment_address % s.ctb_w) == 0 && !s.persistent_rice && !sh.cu_chroma_qp_offset_enabled)
       next_ts = parse_rows_parallel(sh, slice_idx, start_ts, begin, end);
     else {
       DecoderEC ec(begin, end);
@@ -324,12 +325,12 @@ struct Decoder {
 
   static void check_supported(const SPS& s, const PPS& p)
   {
-    if (s.range_ext_any) throw ParseError(HM_ERR_UNSUPPORTED, "range-extension coding tools");
+    if (s.unsupported_extension) throw ParseError(HM_ERR_UNSUPPORTED, "multilayer / 3D / screen-content extension");
     if (s.separate_colour_plane) throw ParseError(HM_ERR_UNSUPPORTED, "separate colour planes");
     if (s.chroma_format_idc != 0 && s.bit_depth_y != s.bit_depth_c) throw ParseError(HM_ERR_UNSUPPORTED, "different luma / chroma bit depth");
     if (s.bit_depth_y > 12) throw ParseError(HM_ERR_UNSUPPORTED, "bit depth above 12");
-    if (p.cross_component_prediction || p.chroma_qp_offset_list_enabled)
-      throw ParseError(HM_ERR_UNSUPPORTED, "range-extension PPS tools");
+    // (the reference only warns about this combination and then predicts from mis-sized blocks, pps.cc:68-72)
+    if (p.cross_component_prediction && s.chroma_format_idc != 3) throw ParseError(HM_ERR_UNSUPPORTED, "cross-component prediction outside 4:4:4");
     if (s.width > 16384 || s.height > 16384) throw ParseError(HM_ERR_UNSUPPORTED, "picture larger than 16384x16384");
   }
 
@@ -347,7 +348,8 @@ struct Decoder {
     // once; A/B measurements of the one-row-per-wave kernel) keeps the decode order for every picture.
     static const bool force_interleaved = [] { const char* e = std::getenv("HM_STREAM_INTERLEAVED"); return e && e[0] == '1'; }();
     const bool rare = s.scaling_list_enabled || (s.pcm_enabled && s.pcm_loop_filter_disabled) || p.transquant_bypass_enabled ||
-                      pic.uses_pcm || pic.uses_tq_bypass || s.chroma_format_idc == 3; // == HM_PIC_RARE_SYNTAX of the flags below
+                      pic.uses_pcm || pic.uses_tq_bypass || s.chroma_format_idc == 3 || s.transform_skip_rotation || s.implicit_rdpcm ||
+                      s.intra_smoothing_disabled || p.cross_component_prediction; // == HM_PIC_RARE_SYNTAX of the flags below
     const bool split = !rare && !force_interleaved;
     const bool direct = pic.direct; // the chains were written in their final form while parsing (hevc_syntax.h: PictureState::rows)
     if (direct && !split) throw ParseError(HM_ERR_INTERNAL, "direct chains of a picture with rare syntax");
@@ -484,6 +486,10 @@ struct Decoder {
     if ((s.pcm_enabled && s.pcm_loop_filter_disabled) || p.transquant_bypass_enabled) flags |= HM_PIC_PCMF;
     if (s.chroma_format_idc == 3) flags |= HM_PIC_444;
     if (pic.uses_pcm || pic.uses_tq_bypass) flags |= HM_PIC_LOSSLESS_CUS;
+    if (s.transform_skip_rotation) flags |= HM_PIC_TS_ROTATION;
+    if (s.implicit_rdpcm) flags |= HM_PIC_IMPLICIT_RDPCM;
+    if (s.intra_smoothing_disabled) flags |= HM_PIC_NO_INTRA_SMOOTHING;
+    if (p.cross_component_prediction) flags |= HM_PIC_CROSS_COMPONENT;
     if (split) flags |= HM_PIC_SPLIT_CHAINS;
     if (rare != ((flags & HM_PIC_RARE_SYNTAX) != 0)) throw ParseError(HM_ERR_INTERNAL, "rare-syntax classification");
     h.flags = flags;

@@ -41,6 +41,7 @@ enum BinKind : int {
   K_SPLIT_CU, K_TQ_BYPASS, K_PART_MODE, K_PCM, K_PREV_INTRA, K_MPM_IDX, K_REM_MODE, K_CHROMA_MODE,
   K_SPLIT_TF, K_CBF_LUMA, K_CBF_CHROMA, K_QP_DELTA, K_QP_DELTA_SUFFIX, K_QP_SIGN, K_TSKIP,
   K_LAST_PREFIX, K_LAST_SUFFIX, K_CSBF, K_SIG, K_GT1, K_GT2, K_SIGN, K_CALR_PREFIX, K_CALR_SUFFIX,
+  K_CHROMA_QP_OFFSET_FLAG, K_CHROMA_QP_OFFSET_IDX, K_RES_SCALE_ABS, K_RES_SCALE_SIGN,
   K_COUNT
 };
 
@@ -214,7 +215,8 @@ struct PictureState {
     if ((int)ctb_tus.size() != n) ctb_tus.resize(n);
     for (auto& v : ctb_tus) v.clear();
     coeffs.clear();
-    direct = !(s.scaling_list_enabled || s.pcm_enabled || p.transquant_bypass_enabled || s.chroma_format_idc == 3);
+    direct = !(s.scaling_list_enabled || s.pcm_enabled || p.transquant_bypass_enabled || s.chroma_format_idc == 3 ||
+               s.transform_skip_rotation || s.implicit_rdpcm || s.intra_smoothing_disabled || p.cross_component_prediction);
     if ((int)rows.size() != s.ctb_h) rows.resize((size_t)s.ctb_h);
     for (RowChains& r : rows)
       for (int k = 0; k < 2; k++) { r.tu[k].clear(); r.lv[k].clear(); }
@@ -270,12 +272,17 @@ class SliceWalker {
     const int rs0 = pps_.CtbAddrTStoRS[ts];
     if (sh_.dependent) {
       const bool tile_start = ts == 0 || (pps_.tiles_enabled && pps_.TileId[ts] != pps_.TileId[ts - 1]);
-      if (tile_start) init_contexts(ec_.contexts(), sh_.SliceQPY);
-      else if (pic_.dep_ok) ec_.contexts() = pic_.dep_ctx;
+      if (tile_start) fresh_contexts();
+      else if (pic_.dep_ok) {
+        // the reference starts every slice segment with a new thread context and restores the context tables only:
+        // StatCoeff of a dependent segment is uninitialised memory there (decctx.cc:835, slice.cc:5357-5395)
+        if (sps_.persistent_rice) throw ParseError(HM_ERR_UNSUPPORTED, "persistent_rice_adaptation across dependent slice segments (undefined in the reference)");
+        ec_.contexts() = pic_.dep_ctx;
+      }
       else throw ParseError(HM_ERR_BITSTREAM, "dependent slice segment without stored context tables");
       if (pps_.entropy_coding_sync && (rs0 % W) == 0 && rs0 >= W) import_wpp_row(rs0 / W - 1);
     }
-    else init_contexts(ec_.contexts(), sh_.SliceQPY);
+    else fresh_contexts();
     ec_.start_substream();
     // QP predictor state
     if (!sh_.dependent) { qs_->last_qpy_prev_qg = sh_.SliceQPY; qs_->current_qpy = sh_.SliceQPY; qs_->cur_qg_x = qs_->cur_qg_y = -1; }
@@ -304,7 +311,7 @@ class SliceWalker {
       const bool new_row = pps_.entropy_coding_sync && sh_.num_entry_points > 0 && (nrs / W) != (rs / W);
       if (new_tile || new_row) {
         if (!ec_.terminate(2)) throw ParseError(HM_ERR_BITSTREAM, "end_of_subset_one_bit not set");
-        if (pps_.tiles_enabled) init_contexts(ec_.contexts(), sh_.SliceQPY);
+        if (pps_.tiles_enabled) fresh_contexts();
         if (pps_.entropy_coding_sync && (nrs % W) == 0 && nrs >= W) import_wpp_row(nrs / W - 1);
         ec_.start_substream();
       }
@@ -316,9 +323,17 @@ class SliceWalker {
   // ---- availability ------------------------------------------------------------------------
   // slice.cc:5010-5030: the tables stored after the 2nd CTB of `row` (a picture one CTB wide: fresh tables); a row
   // whose tables were never stored, or were taken already, is a decoding error in the reference
+  // initialize_CABAC_models of the reference (slice.cc:1507-1518): fresh tables and StatCoeff = 0.  Tables taken over
+  // from the row above (WPP) leave StatCoeff as the previous row left it - the standard would synchronise it with the
+  // tables (9.3.2.4); the reference's sequential decoder does not (slice.cc:5017-5022): quirk Q18, reproduced.
+  void fresh_contexts()
+  {
+    init_contexts(ec_.contexts(), sh_.SliceQPY);
+    stat_coeff_[0] = stat_coeff_[1] = stat_coeff_[2] = stat_coeff_[3] = 0;
+  }
   void import_wpp_row(int row)
   {
-    if (sps_.ctb_w < 2) { init_contexts(ec_.contexts(), sh_.SliceQPY); return; }
+    if (sps_.ctb_w < 2) { fresh_contexts(); return; }
     if (!pic_.wpp_ok[row]) throw ParseError(HM_ERR_BITSTREAM, "WPP context tables of the row above are missing");
     ec_.contexts() = pic_.wpp_ctx[row];
     pic_.wpp_ok[row] = 0;
@@ -471,6 +486,7 @@ class SliceWalker {
       is_cu_qp_delta_coded_ = false;
       cu_qp_delta_val_ = 0;
     }
+    if (sh_.cu_chroma_qp_offset_enabled && log2CbSize >= pps_.Log2MinCuChromaQpOffsetSize) is_cu_chroma_qp_offset_coded_ = false; // slice.cc:4944-4947
     if (split) {
       const int x1 = x0 + (size >> 1), y1 = y0 + (size >> 1);
       coding_quadtree(x0, y0, log2CbSize - 1, cqtDepth + 1);
@@ -536,7 +552,8 @@ class SliceWalker {
     const int qpy = ((pred + cu_qp_delta_val_ + 52 + 2 * bdY) % (52 + bdY)) - bdY;
     qp_prime_[0] = std::max(0, qpy + bdY);
     for (int c = 1; c <= 2; c++) {
-      const int off = c == 1 ? pps_.cb_qp_offset + sh_.cb_qp_offset : pps_.cr_qp_offset + sh_.cr_qp_offset;
+      // CuQpOffsetCb / Cr (transform.cc:154-155): the value of the last cu_chroma_qp_offset_flag of this slice segment
+      const int off = c == 1 ? pps_.cb_qp_offset + sh_.cb_qp_offset + cu_qp_offset_[0] : pps_.cr_qp_offset + sh_.cr_qp_offset + cu_qp_offset_[1];
       int qpi = qpy + off;
       qpi = qpi < -bdC ? -bdC : (qpi > 57 ? 57 : qpi);
       // the reference applies Table 8-10 for 4:2:0 and uses qPi unchanged otherwise
@@ -608,8 +625,15 @@ class SliceWalker {
     if (!nxn) luma_mode_[1] = luma_mode_[2] = luma_mode_[3] = luma_mode_[0];
     // chroma prediction mode(s)
     if (sps_.ChromaArrayType == 3) {
-      for (int i = 0; i < nParts; i++) chroma_mode_[i] = map_chroma(read_chroma_pred_mode(), luma_mode_[i]);
-      if (!nxn) chroma_mode_[1] = chroma_mode_[2] = chroma_mode_[3] = chroma_mode_[0];
+      for (int i = 0; i < nParts; i++) {
+        const int m = read_chroma_pred_mode();
+        chroma_mode_[i] = map_chroma(m, luma_mode_[i]);
+        chroma_dm_[i] = m == 4; // intra_chroma_pred_mode 4: the block may use cross-component prediction (image.h:672)
+      }
+      if (!nxn) {
+        chroma_mode_[1] = chroma_mode_[2] = chroma_mode_[3] = chroma_mode_[0];
+        chroma_dm_[1] = chroma_dm_[2] = chroma_dm_[3] = chroma_dm_[0];
+      }
     }
     else if (sps_.ChromaArrayType != 0) {
       int m = map_chroma(read_chroma_pred_mode(), luma_mode_[0]);
@@ -767,6 +791,7 @@ class SliceWalker {
     const int log2C = std::max(2, cat == 3 ? log2TrafoSize : log2TrafoSize - 1);
     const int cbfChroma = cbf_cb | cbf_cr;
     if (cbf_luma || cbfChroma) {
+      bool need_qp = false;
       if (pps_.cu_qp_delta_enabled && !is_cu_qp_delta_coded_) {
         int v = 0;
         while (v < 5 && ec_.bin(CTX_CU_QP_DELTA + (v > 0 ? 1 : 0), K_QP_DELTA, v)) v++;
@@ -784,20 +809,37 @@ class SliceWalker {
         cu_qp_delta_val_ = sign ? -v : v;
         const int lim_lo = -(26 + sps_.qp_bd_offset_y / 2), lim_hi = 25 + sps_.qp_bd_offset_y / 2;
         if (cu_qp_delta_val_ < lim_lo || cu_qp_delta_val_ > lim_hi) throw ParseError(HM_ERR_BITSTREAM, "CuQpDeltaVal out of range");
-        derive_qp(cu_x_, cu_y_, cu_log2_);
+        need_qp = true;
       }
+      // cu_chroma_qp_offset_flag / idx (slice.cc:3928-3957 of the reference).  The reference reads ONE bin for the index
+      // whatever chroma_qp_offset_list_len is (the standard: truncated Rice up to the list length): quirk Q16, reproduced.
+      if (sh_.cu_chroma_qp_offset_enabled && cbfChroma && !cu_bypass_ && !is_cu_chroma_qp_offset_coded_) {
+        const int flag = ec_.bin(CTX_CHROMA_QP_OFFSET_FLAG, K_CHROMA_QP_OFFSET_FLAG, 0);
+        int idx = 0;
+        if (flag && pps_.chroma_qp_offset_list_len > 1) idx = ec_.bin(CTX_CHROMA_QP_OFFSET_IDX, K_CHROMA_QP_OFFSET_IDX, 0);
+        is_cu_chroma_qp_offset_coded_ = true;
+        cu_qp_offset_[0] = flag ? pps_.cb_qp_offset_list[idx] : 0;
+        cu_qp_offset_[1] = flag ? pps_.cr_qp_offset_list[idx] : 0;
+        need_qp = true;
+      }
+      if (need_qp) derive_qp(cu_x_, cu_y_, cu_log2_);
     }
     // --- luma ---
     const int part = cu_nxn_ ? (((y0 - cu_y_) >= (1 << (cu_log2_ - 1)) ? 2 : 0) + ((x0 - cu_x_) >= (1 << (cu_log2_ - 1)) ? 1 : 0)) : 0;
     emit_block(x0, y0, log2TrafoSize, 0, luma_mode_[part], cbf_luma);
     if (cat == 0) return;
+    // cross-component prediction (slice.cc:3993-4040 of the reference): ResScaleVal of Cb, then of Cr, each in front
+    // of the component's residual; only where luma has a residual and the chroma mode is the derived one
+    const bool ccp = pps_.cross_component_prediction && cbf_luma && chroma_dm_[part];
+    const bool luma_res16 = luma_tskip_ && !cu_bypass_ && sps_.bit_depth_y == 8 && log2TrafoSize == 2;
     // --- chroma ---
     const int lw = sps_.SubWidthC >> 1, lh = sps_.SubHeightC >> 1; // SubWidthC / SubHeightC are 1 or 2
     if (log2TrafoSize > 2 || cat == 3) {
       const int cmode = chroma_mode_[part];
       for (int c = 1; c <= 2; c++) {
         const int cbf = c == 1 ? cbf_cb : cbf_cr;
-        emit_block(x0 >> lw, y0 >> lh, log2C, c, cmode, cbf & 1);
+        const int res_scale = ccp ? cross_comp_pred(c - 1, luma_res16) : 0;
+        emit_block(x0 >> lw, y0 >> lh, log2C, c, cmode, cbf & 1, res_scale);
         if (cat == 2) emit_block(x0 >> lw, (y0 >> lh) + (1 << log2C), log2C, c, cmode, (cbf >> 1) & 1);
       }
       if (cat == 2) interleave_422_records();
@@ -811,6 +853,19 @@ class SliceWalker {
       }
       if (cat == 2) interleave_422_records();
     }
+  }
+  // cross_comp_pred( ) (§7.3.8.12; slice.cc:3809-3864 of the reference): returns ResScaleVal in {0, +-1, +-2, +-4, +-8}.
+  // luma_res16: the luma block of this unit is an 8-bit 4x4 transform-skip block, whose residual the reference keeps in
+  // a second (16-bit) buffer while its cross-component step reads the 32-bit one (transform.cc:578-606, 264): it would
+  // predict from the residual of an EARLIER luma block.  Such a unit with a non-zero ResScaleVal is refused (Q17).
+  int cross_comp_pred(int c, bool luma_res16)
+  {
+    int v = 0;
+    while (v < 4 && ec_.bin(CTX_RES_SCALE_ABS + 4 * c + v, K_RES_SCALE_ABS, v | (luma_res16 ? 256 : 0))) v++;
+    if (v == 0) return 0;
+    if (luma_res16) throw ParseError(HM_ERR_UNSUPPORTED, "cross-component prediction from an 8-bit 4x4 transform-skip luma block (the reference reads a stale buffer)");
+    const int sign = ec_.bin(CTX_RES_SCALE_SIGN + c, K_RES_SCALE_SIGN, c);
+    return sign ? -(1 << (v - 1)) : (1 << (v - 1));
   }
   // 4:2:2: the syntax carries Cb upper, Cb lower, Cr upper, Cr lower; the records are stored as Cb upper, Cr upper,
   // Cb lower, Cr lower.  The planes are independent and each keeps its own order, so the result is the same - and a
@@ -832,7 +887,7 @@ class SliceWalker {
   }
 
   // one (component) block: optional residual_coding(), then the hm_tu record
-  void emit_block(int xc, int yc, int log2, int cIdx, int mode, int cbf)
+  void emit_block(int xc, int yc, int log2, int cIdx, int mode, int cbf, int res_scale = 0)
   {
     // SubWidthC / SubHeightC are 1 or 2: shifts instead of divisions (this runs once per transform block)
     const int lw = cIdx ? (sps_.SubWidthC >> 1) : 0, lh = cIdx ? (sps_.SubHeightC >> 1) : 0;
@@ -851,10 +906,12 @@ class SliceWalker {
       t.info |= HM_TU_CBF;
       if (tskip) t.info |= HM_TU_TSKIP;
     }
+    if (cIdx == 0) luma_tskip_ = tskip;
     const size_t ncoef = coeffs_->size() - t.coeff_first;
     t.n_coeff = (uint16_t)ncoef;
     t.qp = (uint8_t)qp_prime_[cIdx];
     t.qpy = (int8_t)cu_qpy_;
+    if (cIdx && pps_.cross_component_prediction) t.qpy = (int8_t)res_scale; // hm_stream.h: chroma records of such pictures carry ResScaleVal
     // neighbour availability (intrapred.h:536-667 in the reference; equals §8.4.4.2.2).  It depends on the block's
     // rectangle in luma samples only, which the Cb / Cr blocks of a transform unit share (and, for 4:2:0 / 4:4:4,
     // share with the unit's luma block): the last two answers are kept.
@@ -936,6 +993,10 @@ class SliceWalker {
     const int lastPos = st.pos_inv[scanIdx][lastY & 3][lastX & 3];
     uint8_t csbf[8][8];
     std::memset(csbf, 0, sizeof(csbf));
+    // range extensions (slice.cc:3172-3177, 3425-3432, 3565-3575, 3611-3655 of the reference)
+    const bool flat_sig_ctx = sps_.transform_skip_context && (cu_bypass_ || tskip); // one sig_coeff_flag context per component
+    const bool rdpcm = sps_.implicit_rdpcm && tskip && (predMode == 10 || predMode == 26); // (a bypass unit never hides signs)
+    uint8_t& stat = stat_coeff_[(cIdx == 0 ? 2 : 0) + ((tskip || cu_bypass_) ? 1 : 0)];
     int c1 = 1; // greater1Ctx carried between sub-blocks
     bool first_subblock = true;
 
@@ -966,7 +1027,7 @@ class SliceWalker {
       for (int n = startPos; n >= 0; n--) {
         int sig;
         if (n > 0 || !inferSbDcSig) {
-          sig = ec_.bin(CTX_SIG + sig_inc[n], K_SIG, n);
+          sig = ec_.bin(CTX_SIG + (flat_sig_ctx ? (cIdx == 0 ? 42 : 43) : sig_inc[n]), K_SIG, n);
           if (sig) inferSbDcSig = 0;
         }
         else sig = 1; // inferred: the only coefficient of a coded sub-block
@@ -990,14 +1051,15 @@ class SliceWalker {
       if (firstGt1 >= 0) gt2flag = ec_.bin(CTX_GT2 + ctxSet + (cIdx ? 4 : 0), K_GT2, 0);
 
       // signs
-      const bool signHidden = pps_.sign_data_hiding && !cu_bypass_ && (sigpos[0] - sigpos[nsig - 1] > 3); // slice.cc:3565-3575
+      const bool signHidden = pps_.sign_data_hiding && !cu_bypass_ && !rdpcm && (sigpos[0] - sigpos[nsig - 1] > 3); // slice.cc:3565-3575
       const int nsign = signHidden ? nsig - 1 : nsig;
       uint32_t signbits = 0;
       for (int k = 0; k < nsign; k++) signbits = (signbits << 1) | (uint32_t)ec_.bypass(K_SIGN, k);
       signbits <<= (16 - nsign);
 
       // remaining levels
-      int rice = 0, sumAbs = 0;
+      int rice = sps_.persistent_rice ? stat / 4 : 0, sumAbs = 0;
+      bool first_remaining = true;
       for (int k = 0; k < nsig; k++) {
         int base;
         if (k < 8) base = 1 + gt1[k] + ((k == firstGt1) ? gt2flag : 0);
@@ -1008,8 +1070,15 @@ class SliceWalker {
         (void)thresh;
         int absv = base;
         if (base == need) {
-          absv += coeff_abs_level_remaining(rice);
-          if (absv > 3 * (1 << rice)) rice = std::min(rice + 1, 4);
+          if (rice > 16) throw ParseError(HM_ERR_BITSTREAM, "Rice parameter out of range");
+          const int rem = coeff_abs_level_remaining(rice);
+          absv += rem;
+          if (absv > 3 * (1 << rice)) rice = sps_.persistent_rice ? rice + 1 : std::min(rice + 1, 4);
+          if (sps_.persistent_rice && first_remaining) { // StatCoeff update by the first remaining level of the sub-block
+            if (rem >= (3 << (stat / 4))) stat++;
+            else if (2 * rem < (1 << (stat / 4)) && stat > 0) stat--;
+          }
+          first_remaining = false;
         }
         if (absv > 32768) throw ParseError(HM_ERR_BITSTREAM, "transform coefficient out of range");
         int val = absv;
@@ -1087,6 +1156,10 @@ class SliceWalker {
   // QP state (thread_context fields of the reference: decctx.h)
   bool is_cu_qp_delta_coded_ = false;
   int cu_qp_delta_val_ = 0;
+  bool is_cu_chroma_qp_offset_coded_ = false;
+  int cu_qp_offset_[2] = {0, 0};   // CuQpOffsetCb / Cr
+  uint8_t stat_coeff_[4] = {0, 0, 0, 0}; // StatCoeff (persistent_rice_adaptation): see reset_stat_coeff()
+  bool luma_tskip_ = false;        // transform_skip_flag of the unit's luma block
   int qp_prime_[3] = {0, 0, 0};
   int cu_qpy_ = 0;
   // current CU
@@ -1094,6 +1167,7 @@ class SliceWalker {
   bool cu_nxn_ = false;
   bool cu_bypass_ = false; // cu_transquant_bypass_flag of the current coding unit
   int luma_mode_[4] = {1, 1, 1, 1}, chroma_mode_[4] = {1, 1, 1, 1};
+  bool chroma_dm_[4] = {false, false, false, false};
   std::vector<TuRef> cu_first_tu_;
 };
 

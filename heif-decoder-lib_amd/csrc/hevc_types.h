@@ -121,8 +121,11 @@ struct SPS {
   // VUI colour description (defaults as libde265 vui.cc:93-97)
   bool vui_colour_present = false;
   int video_full_range = 0, colour_primaries = 2, transfer_characteristics = 2, matrix_coeffs = 2;
-  // range extension flags (§7.3.2.2.2); any set flag puts the stream outside the hot path
-  bool range_ext_any = false;
+  // range extension flags (§7.3.2.2.2; sps.cc:1375-1390 of the reference).  The reference reads
+  // extended_precision_processing_flag and cabac_bypass_alignment_enabled_flag and then ignores them (transform.cc:568
+  // hard-codes 0, the CABAC engine never aligns): so does this parser (quirk Q15).  high_precision_offsets and
+  // explicit_rdpcm only act on inter pictures.
+  bool unsupported_extension = false; // multilayer / 3D / SCC extension data present
   bool transform_skip_rotation = false, transform_skip_context = false, implicit_rdpcm = false,
        explicit_rdpcm = false, extended_precision = false, intra_smoothing_disabled = false,
        high_precision_offsets = false, persistent_rice = false, cabac_bypass_alignment = false;
@@ -160,6 +163,9 @@ struct PPS {
   // range extension (§7.3.2.3.2)
   int log2_max_transform_skip_size = 2;
   bool cross_component_prediction = false, chroma_qp_offset_list_enabled = false;
+  int diff_cu_chroma_qp_offset_depth = 0, chroma_qp_offset_list_len = 0;
+  int cb_qp_offset_list[6] = {0, 0, 0, 0, 0, 0}, cr_qp_offset_list[6] = {0, 0, 0, 0, 0, 0};
+  int Log2MinCuChromaQpOffsetSize = 0; // derived (pps.cc:540)
   int log2_sao_offset_scale_luma = 0, log2_sao_offset_scale_chroma = 0;
   // derived (pps.cc:536-800 in the reference): scan conversion tables
   int Log2MinCuQpDeltaSize = 0;
@@ -176,6 +182,7 @@ struct SliceHeader {
   int slice_type = 2; // 0 B, 1 P, 2 I
   bool sao_luma = false, sao_chroma = false;
   int slice_qp_delta = 0, cb_qp_offset = 0, cr_qp_offset = 0;
+  bool cu_chroma_qp_offset_enabled = false;
   bool deblocking_disabled = false;
   int beta_offset_div2 = 0, tc_offset_div2 = 0;
   bool lf_across_slices = false;

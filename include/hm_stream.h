@@ -14,8 +14,9 @@
  *     hm_tu[n_tus]      see "record order" below (hm_tu8[n_tus] in pictures with HM_PIC_SPLIT_CHAINS)
  *     hm_coeff[n_coeffs]
  *
- * Record order.  Intra prediction chains the blocks of one colour plane; luma and chroma never read each other (the
- * supported profiles have no cross-component prediction), so a picture holds two independent block chains per CTB row.
+ * Record order.  Intra prediction chains the blocks of one colour plane; luma and chroma never read each other (pictures
+ * with cross-component prediction are rare-syntax pictures in decode order), so a picture holds two independent block
+ * chains per CTB row.
  *   HM_PIC_SPLIT_CHAINS set (every picture without rare syntax): for CTB row 0, 1, ...: the luma records of the row's
  *     CTBs in raster order, each CTB's in decode order, then the chroma records (Cb and Cr, decode order) of the row's
  *     CTBs likewise.  hm_ctb.tu_first / tu_count delimit the CTB's luma records, tu_first_c / tu_count_c its chroma
@@ -54,8 +55,21 @@ extern "C" {
 #define HM_PIC_444                    0x0800u /* chroma_format_idc 3 (chroma_format says the same; the flag puts such
                                                  pictures into the rare-syntax classes)                        */
 #define HM_PIC_SPLIT_CHAINS           0x1000u /* luma and chroma records in separate lists (see "record order")   */
-#define HM_PIC_RARE_SYNTAX            (HM_PIC_SCALING_LIST | HM_PIC_PCMF | HM_PIC_LOSSLESS_CUS | HM_PIC_444) /* pictures that need the kernel
-                                                 variant of the reconstruction with the rare paths             */
+/* range-extension tools that change the reconstruction (sps.cc:1375-1390, pps.cc:68 of the reference) */
+#define HM_PIC_TS_ROTATION            0x2000u /* transform_skip_rotation_enabled_flag: the levels of a 4x4 transform-skip /
+                                                 bypass block are rotated by 180 degrees (transform.cc:427-447, 575)   */
+#define HM_PIC_IMPLICIT_RDPCM         0x4000u /* implicit_rdpcm_enabled_flag: a transform-skip / bypass block predicted
+                                                 with mode 10 (26) accumulates its residual along rows (columns)
+                                                 (slice.cc:3774-3779); bypass blocks: no boundary filter of modes 10 / 26
+                                                 (intrapred.cc:323-326)                                             */
+#define HM_PIC_NO_INTRA_SMOOTHING     0x8000u /* intra_smoothing_disabled_flag (intrapred.cc:307)                       */
+#define HM_PIC_CROSS_COMPONENT        0x10000u /* cross_component_prediction_enabled_flag (4:4:4): hm_tu.qpy of a chroma
+                                                 record holds ResScaleVal (0, +-1, +-2, +-4, +-8); its residual gets
+                                                 (ResScaleVal * luma residual) >> 3 added (transform.cc:251-267), also
+                                                 when the record has no levels of its own (slice.cc:3797-3805)        */
+#define HM_PIC_RARE_SYNTAX            (HM_PIC_SCALING_LIST | HM_PIC_PCMF | HM_PIC_LOSSLESS_CUS | HM_PIC_444 | HM_PIC_TS_ROTATION | \
+                                       HM_PIC_IMPLICIT_RDPCM | HM_PIC_NO_INTRA_SMOOTHING | HM_PIC_CROSS_COMPONENT) /* pictures that
+                                                 need the kernel variant of the reconstruction with the rare paths   */
 
 /* ScalingFactor tables of a picture with scaling lists (transform.cc:509-533): one byte per coefficient position
  * x + nT * y.  Matrices of intra blocks only: 4x4 cIdx 0..2 at 0, 8x8 at 48, 16x16 at 240, 32x32 (luma) at 1008. */
@@ -164,7 +178,7 @@ typedef struct hm_tu {
   uint8_t  info;
   uint8_t  pred_mode;    /* IntraPredMode 0..34 (chroma: final mode, 4:2:2 remap applied) | HM_TU_MODE_* */
   uint8_t  qp;           /* qP of (8.6.1) incl. QpBdOffset: the dequantisation QP             */
-  int8_t   qpy;          /* QpY of the coding unit (deblocking)                               */
+  int8_t   qpy;          /* luma: QpY of the coding unit (deblocking); chroma in HM_PIC_CROSS_COMPONENT pictures: ResScaleVal */
   uint16_t n_coeff;      /* number of hm_coeff pairs                                          */
   uint32_t coeff_first;  /* index into hm_coeff[]                                             */
   uint8_t  avail_left, avail_bottom_left, avail_top, avail_top_right;

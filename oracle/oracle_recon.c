@@ -138,7 +138,8 @@ static void filter_border(int* p, int nT, int mode, int strong_enabled, int bit_
 }
 
 /* ---- R5: predictors (intrapred.h:269-441) --------------------------------------------------- */
-static void predict(uint16_t* dst, int stride, int nT, int log2, int cIdx, int mode, const int* border, int bit_depth)
+/* no_edge: disableIntraBoundaryFilter of the pure vertical / horizontal modes (intrapred.cc:323-326, intrapred.h:386,424) */
+static void predict(uint16_t* dst, int stride, int nT, int log2, int cIdx, int mode, const int* border, int bit_depth, int no_edge)
 {
   const int maxv = (1 << bit_depth) - 1;
   if (mode == 0) {
@@ -175,7 +176,7 @@ static void predict(uint16_t* dst, int stride, int nT, int log2, int cIdx, int m
           const int iIdx = ((y + 1) * angle) >> 5, iFact = ((y + 1) * angle) & 31;
           dst[x + y * stride] = (uint16_t)(iFact ? ((32 - iFact) * ref[x + iIdx + 1] + iFact * ref[x + iIdx + 2] + 16) >> 5 : ref[x + iIdx + 1]);
         }
-      if (mode == 26 && cIdx == 0 && nT < 32)
+      if (mode == 26 && cIdx == 0 && nT < 32 && !no_edge)
         for (int y = 0; y < nT; y++) dst[y * stride] = (uint16_t)clip3(0, maxv, border[1] + ((border[-1 - y] - border[0]) >> 1));
     }
     else {
@@ -191,89 +192,138 @@ static void predict(uint16_t* dst, int stride, int nT, int log2, int cIdx, int m
           const int iIdx = ((x + 1) * angle) >> 5, iFact = ((x + 1) * angle) & 31;
           dst[x + y * stride] = (uint16_t)(iFact ? ((32 - iFact) * ref[y + iIdx + 1] + iFact * ref[y + iIdx + 2] + 16) >> 5 : ref[y + iIdx + 1]);
         }
-      if (mode == 10 && cIdx == 0 && nT < 32)
+      if (mode == 10 && cIdx == 0 && nT < 32 && !no_edge)
         for (int x = 0; x < nT; x++) dst[x] = (uint16_t)clip3(0, maxv, border[-1] + ((border[1 + x] - border[0]) >> 1));
     }
   }
 }
 
-/* ---- R1-R3: dequantisation + inverse transform + add (transform.cc:386-689, fallback-dct.cc) ---- */
+/* ---- R1-R3: dequantisation + inverse transform + add (transform.cc:251-689, fallback-dct.cc) ----
+ * The residual of the block is formed first (r), as the reference's "explicit" path does (transform.cc:288-336), then the
+ * cross-component term is added and the sum goes onto the prediction.  Without cross-component prediction this equals
+ * the fused add-and-clip kernels the reference runs otherwise (Q4: whether stage 2 saturates to 16 bit never shows in
+ * the clipped sample).
+ *   res_luma  residual of the unit's luma block (tctx->residual_luma), written by luma blocks of HM_PIC_CROSS_COMPONENT
+ *             pictures, read by chroma blocks with ResScaleVal != 0
+ *   rdpcm     0 off, 1 along rows (mode 10), 2 along columns (mode 26): slice.cc:3774-3779 */
+static void rotate4(int16_t* c) /* fallback-dct.cc:292-299 for nT = 4 */
+{
+  for (int i = 0; i < 8; i++) { const int16_t a = c[i]; c[i] = c[15 - i]; c[15 - i] = a; }
+}
 static void residual_add(uint16_t* dst, int stride, int nT, int log2, int cIdx, const hm_tu* t, const hm_coeff* cf, int bit_depth,
-                         const uint8_t* scaling)
+                         const uint8_t* scaling, uint32_t pic_flags, int32_t* res_luma, int res_scale)
 {
   int16_t coeff[32 * 32];
-  memset(coeff, 0, sizeof(int16_t) * nT * nT);
+  int32_t r[32 * 32];
+  const int n = nT * nT;
+  memset(coeff, 0, sizeof(int16_t) * n);
+  memset(r, 0, sizeof(int32_t) * n);
   const int qP = t->qp;
-  if (!scaling) {
-    /* flat scaling (m = 16 folded into the shift), 32-bit wrapping arithmetic: transform.cc:486-506 (Q3) */
-    const int bdShift = bit_depth + log2 - 5 - 4;
-    const int32_t offset = 1 << (bdShift - 1);
-    const int32_t fact = kLevelScale[qP % 6] << (qP / 6);
-    for (int i = 0; i < t->n_coeff; i++) {
-      const int32_t c = cf[i].value;
-      const int32_t prod = (int32_t)((uint32_t)c * (uint32_t)fact + (uint32_t)offset); /* wraps like the reference's int */
-      coeff[cf[i].pos] = (int16_t)clip3(-32768, 32767, prod >> bdShift);
-    }
+  const int cbf = (t->info & HM_TU_CBF) != 0, bypass = (t->pred_mode & HM_TU_MODE_BYPASS) != 0, tskip = (t->info & HM_TU_TSKIP) != 0;
+  const int mode = t->pred_mode & HM_TU_MODE_MASK;
+  const int cross = (pic_flags & HM_PIC_CROSS_COMPONENT) != 0;
+  const int rotate = (pic_flags & HM_PIC_TS_ROTATION) && nT == 4;
+  int rdpcm = 0;
+  if ((pic_flags & HM_PIC_IMPLICIT_RDPCM) && (bypass || tskip) && (mode == 10 || mode == 26)) rdpcm = mode == 26 ? 2 : 1;
+  int res16 = 0; /* the reference's 16-bit residual variant (8-bit 4x4 transform skip, transform.cc:578-607) */
+  const int postShift = 20 - bit_depth, rnd2 = 1 << (postShift - 1);
+  if (!cbf) { /* a chroma block without levels whose residual is the cross-component term alone (slice.cc:3797-3805) */ }
+  else if (bypass) { /* transform.cc:431-466: the levels are the residual */
+    for (int i = 0; i < t->n_coeff; i++) coeff[cf[i].pos] = cf[i].value;
+    if (rotate) rotate4(coeff);
+    for (int y = 0; y < nT; y++)
+      for (int x = 0; x < nT; x++) {
+        int v = coeff[x + y * nT];
+        if (rdpcm == 1 && x > 0) v += r[x - 1 + y * nT];
+        if (rdpcm == 2 && y > 0) v += r[x + (y - 1) * nT];
+        r[x + y * nT] = v;
+      }
   }
   else {
-    /* scaling lists: m = ScalingFactor[sizeId][matrixId = cIdx (0 for 32x32)][pos], 64-bit product: transform.cc:507-545 */
-    const int bdShift = bit_depth + log2 - 5;
-    const int64_t offset = 1 << (bdShift - 1);
-    const uint8_t* sclist = scaling + HM_SCALING_OFFSET(log2, cIdx);
-    for (int i = 0; i < t->n_coeff; i++) {
-      const int32_t fact = (int32_t)((uint32_t)(sclist[cf[i].pos] * kLevelScale[qP % 6]) << (qP / 6));
-      int64_t v = ((int64_t)cf[i].value * fact + offset) >> bdShift;
-      if (v < -32768) v = -32768;
-      if (v > 32767) v = 32767;
-      coeff[cf[i].pos] = (int16_t)v;
+    if (!scaling) {
+      /* flat scaling (m = 16 folded into the shift), 32-bit wrapping arithmetic: transform.cc:486-506 (Q3) */
+      const int bdShift = bit_depth + log2 - 5 - 4;
+      const int32_t offset = 1 << (bdShift - 1);
+      const int32_t fact = kLevelScale[qP % 6] << (qP / 6);
+      for (int i = 0; i < t->n_coeff; i++) {
+        const int32_t c = cf[i].value;
+        const int32_t prod = (int32_t)((uint32_t)c * (uint32_t)fact + (uint32_t)offset); /* wraps like the reference's int */
+        coeff[cf[i].pos] = (int16_t)clip3(-32768, 32767, prod >> bdShift);
+      }
+    }
+    else {
+      /* scaling lists: m = ScalingFactor[sizeId][matrixId = cIdx (0 for 32x32)][pos], 64-bit product: transform.cc:507-545 */
+      const int bdShift = bit_depth + log2 - 5;
+      const int64_t offset = 1 << (bdShift - 1);
+      const uint8_t* sclist = scaling + HM_SCALING_OFFSET(log2, cIdx);
+      for (int i = 0; i < t->n_coeff; i++) {
+        const int32_t fact = (int32_t)((uint32_t)(sclist[cf[i].pos] * kLevelScale[qP % 6]) << (qP / 6));
+        int64_t v = ((int64_t)cf[i].value * fact + offset) >> bdShift;
+        if (v < -32768) v = -32768;
+        if (v > 32767) v = 32767;
+        coeff[cf[i].pos] = (int16_t)v;
+      }
+    }
+    if (tskip) { /* transform.cc:566-643, fallback-dct.cc:80-104, 199-255 */
+      const int tsShift = 5 + log2; /* (extended_precision_processing_flag is hard-wired to 0 in the reference) */
+      if (rotate) rotate4(coeff);
+      res16 = bit_depth == 8 && nT == 4;
+      for (int y = 0; y < nT; y++)
+        for (int x = 0; x < nT; x++) {
+          const int32_t c = (int32_t)((uint32_t)(int32_t)coeff[x + y * nT] << tsShift);
+          r[x + y * nT] = (c + rnd2) >> postShift;
+        }
+      /* accumulate in int, store through the buffer's type (rdpcm_h16 / rdpcm_v16: int16 stores of an int sum) */
+      if (rdpcm == 1)
+        for (int y = 0; y < nT; y++) { int sum = 0; for (int x = 0; x < nT; x++) { sum += r[x + y * nT]; r[x + y * nT] = sum; } }
+      if (rdpcm == 2)
+        for (int x = 0; x < nT; x++) { int sum = 0; for (int y = 0; y < nT; y++) { sum += r[x + y * nT]; r[x + y * nT] = sum; } }
+      if (res16) for (int i = 0; i < n; i++) r[i] = (int16_t)r[i];
+    }
+    else if (nT == 4 && cIdx == 0) { /* DST-VII, fallback-dct.cc:311-449 (fused add) / :511-551 (explicit) */
+      int16_t g[4][4];
+      for (int c = 0; c < 4; c++)
+        for (int i = 0; i < 4; i++) {
+          int sum = 0;
+          for (int j = 0; j < 4; j++) sum += kDst[j][i] * coeff[c + j * 4];
+          g[i][c] = (int16_t)clip3(-32768, 32767, (sum + 64) >> 7);
+        }
+      for (int y = 0; y < 4; y++)
+        for (int i = 0; i < 4; i++) {
+          int sum = 0;
+          for (int j = 0; j < 4; j++) sum += kDst[j][i] * g[y][j];
+          const int out = (sum + rnd2) >> postShift;
+          r[i + y * 4] = cross ? out : clip3(-32768, 32767, out); /* the explicit variant does not clip stage 2 */
+        }
+    }
+    else {
+      init_dct();
+      const int fct = 32 >> log2;
+      int16_t g[32 * 32];
+      for (int c = 0; c < nT; c++)
+        for (int i = 0; i < nT; i++) {
+          int sum = 0;
+          for (int j = 0; j < nT; j++) sum += g_dct[fct * j][i] * coeff[c + j * nT];
+          g[c + i * nT] = (int16_t)clip3(-32768, 32767, (sum + 64) >> 7);
+        }
+      for (int y = 0; y < nT; y++)
+        for (int i = 0; i < nT; i++) {
+          int sum = 0;
+          for (int j = 0; j < nT; j++) sum += g_dct[fct * j][i] * g[y * nT + j];
+          r[i + y * nT] = (sum + rnd2) >> postShift; /* not clipped to 16 bit (fallback-dct.cc:722-723, Q4) */
+        }
+    }
+  }
+  if (cross && cIdx == 0 && cbf && !res16) memcpy(res_luma, r, sizeof(int32_t) * n); /* (the 16-bit variant fills another buffer: Q17) */
+  if (cIdx != 0 && res_scale != 0) { /* cross_comp_pred / cross_comp_pred16, transform.cc:251-285; equal bit depths */
+    for (int i = 0; i < n; i++) {
+      const int32_t v = r[i] + ((res_scale * res_luma[i]) >> 3);
+      r[i] = res16 ? (int16_t)v : v;
     }
   }
   const int maxv = (1 << bit_depth) - 1;
-  if (t->info & HM_TU_TSKIP) { /* transform.cc:566-643, fallback-dct.cc:80-104 */
-    const int tsShift = 5 + log2, bd2 = 20 - bit_depth, rnd = 1 << (bd2 - 1);
-    for (int y = 0; y < nT; y++)
-      for (int x = 0; x < nT; x++) {
-        const int32_t c = (int32_t)((uint32_t)(int32_t)coeff[x + y * nT] << tsShift);
-        int r = (c + rnd) >> bd2;
-        if (bit_depth == 8 && nT == 4) r = (int16_t)r; /* int16 residual buffer variant (transform.cc:581-607) */
-        dst[x + y * stride] = (uint16_t)clip3(0, maxv, dst[x + y * stride] + r);
-      }
-    return;
-  }
-  const int postShift = 20 - bit_depth, rnd2 = 1 << (postShift - 1);
-  if (nT == 4 && cIdx == 0) { /* DST-VII, fallback-dct.cc:311-449 */
-    int16_t g[4][4];
-    for (int c = 0; c < 4; c++)
-      for (int i = 0; i < 4; i++) {
-        int sum = 0;
-        for (int j = 0; j < 4; j++) sum += kDst[j][i] * coeff[c + j * 4];
-        g[i][c] = (int16_t)clip3(-32768, 32767, (sum + 64) >> 7);
-      }
-    for (int y = 0; y < 4; y++)
-      for (int i = 0; i < 4; i++) {
-        int sum = 0;
-        for (int j = 0; j < 4; j++) sum += kDst[j][i] * g[y][j];
-        const int out = clip3(-32768, 32767, (sum + rnd2) >> postShift);
-        dst[i + y * stride] = (uint16_t)clip3(0, maxv, dst[i + y * stride] + out);
-      }
-    return;
-  }
-  init_dct();
-  const int fct = 32 >> log2;
-  int16_t g[32 * 32];
-  for (int c = 0; c < nT; c++)
-    for (int i = 0; i < nT; i++) {
-      int sum = 0;
-      for (int j = 0; j < nT; j++) sum += g_dct[fct * j][i] * coeff[c + j * nT];
-      g[c + i * nT] = (int16_t)clip3(-32768, 32767, (sum + 64) >> 7);
-    }
   for (int y = 0; y < nT; y++)
-    for (int i = 0; i < nT; i++) {
-      int sum = 0;
-      for (int j = 0; j < nT; j++) sum += g_dct[fct * j][i] * g[y * nT + j];
-      const int out = (sum + rnd2) >> postShift; /* not clipped to 16 bit (fallback-dct.cc:722-723, Q4) */
-      dst[i + y * stride] = (uint16_t)clip3(0, maxv, dst[i + y * stride] + out);
-    }
+    for (int x = 0; x < nT; x++) dst[x + y * stride] = (uint16_t)clip3(0, maxv, dst[x + y * stride] + r[x + y * nT]);
 }
 
 /* ---- reconstruction of the whole picture in decoding order --------------------------------- */
@@ -281,6 +331,7 @@ static void reconstruct(pic_t* P)
 {
   const hm_pic* H = P->hdr;
   const int ctb = 1 << H->log2_ctb;
+  static __thread int32_t res_luma[32 * 32];
   for (unsigned ci = 0; ci < H->n_ctbs; ci++) {
     /* decoding order differs from raster order only with tiles; intra dependencies are satisfied
        in raster order as well (left / above / above-right CTBs precede in both). */
@@ -306,18 +357,13 @@ static void reconstruct(pic_t* P)
         int* border = border_mem + 2 * 32;
         build_border(P, t, cIdx, x0, y0, nT, bd, border);
         /* luma, and chroma of 4:4:4 pictures (intrapred.cc:307-311); the strong filter is luma only (intrapred.h:224-229) */
-        if (cIdx == 0 || H->chroma_format == 3)
+        if ((cIdx == 0 || H->chroma_format == 3) && !(H->flags & HM_PIC_NO_INTRA_SMOOTHING))
           filter_border(border, nT, mode, cIdx == 0 && (H->flags & HM_PIC_STRONG_INTRA_SMOOTHING) != 0, H->bit_depth_y);
-        predict(dst, P->w[cIdx], nT, log2, cIdx, mode, border, bd);
-        if ((t->info & HM_TU_CBF) && (t->pred_mode & HM_TU_MODE_BYPASS)) { /* transform.cc:431-449: residual = levels */
-          const hm_coeff* cf = P->coeffs + t->coeff_first;
-          const int maxv = (1 << bd) - 1;
-          for (int i = 0; i < t->n_coeff; i++) {
-            uint16_t* px = &dst[(cf[i].pos & (nT - 1)) + (size_t)(cf[i].pos >> log2) * P->w[cIdx]];
-            *px = (uint16_t)clip3(0, maxv, *px + cf[i].value);
-          }
-        }
-        else if (t->info & HM_TU_CBF) residual_add(dst, P->w[cIdx], nT, log2, cIdx, t, P->coeffs + t->coeff_first, bd, P->scaling);
+        predict(dst, P->w[cIdx], nT, log2, cIdx, mode, border, bd, (H->flags & HM_PIC_IMPLICIT_RDPCM) && (t->pred_mode & HM_TU_MODE_BYPASS));
+        const int res_scale = (cIdx && (H->flags & HM_PIC_CROSS_COMPONENT)) ? t->qpy : 0;
+        if ((t->info & HM_TU_CBF) || res_scale)
+          residual_add(dst, P->w[cIdx], nT, log2, cIdx, t, P->coeffs + t->coeff_first, bd, (t->pred_mode & HM_TU_MODE_BYPASS) ? NULL : P->scaling,
+                       H->flags, res_luma, res_scale);
       }
       if (cIdx == 0) {
         /* deblocking metadata: transform-block edges (deblock.cc:31-62) and QpY map */

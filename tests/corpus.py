@@ -86,6 +86,24 @@ CASES.update({
     "conf_window_422_10": dict(seed=6100014, width=200, height=136, conf_right=8, conf_bottom=6, chroma_format=2, bit_depth=10),
 })
 
+# range-extension coding tools (sps.cc:1375-1390, pps.cc:47-142; slice.cc:3143-3177, 3425-3432, 3565-3655, 3774-3805,
+# 3809-3864, 3928-3957; transform.cc:251-285, 427-466, 566-643; intrapred.cc:307-326 of the reference).  rext_sps bits:
+# 1 transform_skip_rotation, 2 transform_skip_context, 4 implicit_rdpcm, 8 explicit_rdpcm, 16 extended_precision,
+# 32 intra_smoothing_disabled, 64 high_precision_offsets, 128 persistent_rice, 256 cabac_bypass_alignment
+CASES.update({
+    "rext_ts_tools": dict(seed=6200001, width=128, height=96, rext_sps=1 | 2 | 4, log2_max_ts=4, qp=26),
+    "rext_ts_bypass_422_10": dict(seed=6200002, width=128, height=96, chroma_format=2, bit_depth=10, rext_sps=1 | 2 | 4, log2_max_ts=5, tq_bypass=250, qp=30),
+    "rext_nosmooth_rice": dict(seed=6200003, width=160, height=96, log2_ctb=6, rext_sps=32 | 128, big_levels=300, qp=22),
+    "rext_chroma_qp_list": dict(seed=6200004, width=128, height=128, chroma_qp_list=2, chroma_qp_depth=1, cb_qp_offset=2, slices=80),
+    "rext_chroma_qp_list6_422": dict(seed=6200005, width=128, height=64, chroma_format=2, bit_depth=10, chroma_qp_list=6, chroma_qp_depth=0, wpp=1),
+    "rext_cross_444": dict(seed=6200006, width=128, height=96, chroma_format=3, cross_component=1, qp=27),
+    "rext_cross_444_all": dict(seed=6200007, width=128, height=96, chroma_format=3, bit_depth=10, cross_component=1, rext_sps=1 | 2 | 4 | 32 | 128,
+                               log2_max_ts=5, tq_bypass=150, chroma_qp_list=3, big_levels=200, qp=24, wpp=1),
+    "rext_ignored_flags": dict(seed=6200008, width=96, height=64, rext_sps=8 | 16 | 64 | 256, qp=30),
+    "rext_sao_scale_12": dict(seed=6200009, width=96, height=64, bit_depth=12, sao_scale_y=2, sao_scale_c=1, qp=34),
+    "rext_mono_rice_rdpcm": dict(seed=6200010, width=96, height=72, chroma_format=0, bit_depth=12, rext_sps=4 | 128 | 1, big_levels=250, tq_bypass=200, qp=33),
+})
+
 # 8-bit pictures in which the reference takes its "pcmf" deblocking branch: its SIMD build (the configuration of
 # oracle/_ref, and what x86 / ARM users run) filters luma edges between ordinary units with the SSE / NEON kernel, its
 # scalar build leaves them unfiltered (fallback-postfilter.h:85-124 reads the flags with the opposite polarity).  The
@@ -142,5 +160,36 @@ def structure_sweep(n, first_seed=7000):
             kw["tile_cols"] = 1
             kw["slices"] = max(kw["slices"], 300)
         kw["diff_cu_qp_delta_depth"] = min(kw["diff_cu_qp_delta_depth"], kw["log2_ctb"] - 3)
+        out.append((seed, kw))
+    return out
+
+
+def rext_sweep(n, first_seed=11000):
+    """(seed, parameters) of a seeded sweep over the range-extension tools, alone and combined with each other and with
+    transquant bypass, scaling lists, WPP, slices, tiles, every chroma format / bit depth / CTB size."""
+    out = []
+    for seed in range(first_seed, first_seed + n):
+        r = seed * 2654435761 % (1 << 32)
+        pick = lambda k, opts: opts[(r >> k) % len(opts)]
+        kw = dict(width=pick(0, [64, 96, 128, 72]), height=pick(2, [64, 40, 96, 72]), log2_ctb=pick(4, [5, 5, 4, 6]),
+                  chroma_format=pick(6, [1, 3, 2, 3, 0]), bit_depth=pick(9, [8, 8, 10, 12]), cu_qp_delta=1,
+                  rext_sps=pick(11, [0, 1, 2, 4, 32, 128, 7, 135, 167, 511, 39, 5]), log2_max_ts=pick(15, [0, 0, 3, 4, 5]),
+                  tq_bypass=pick(18, [0, 0, 200, 500]), chroma_qp_list=pick(20, [0, 0, 1, 2, 6]), chroma_qp_depth=pick(23, [0, 1, 2]),
+                  big_levels=pick(25, [0, 200, 400]), wpp=pick(27, [0, 0, 1]), slices=pick(29, [0, 0, 100]),
+                  scaling_list=pick(30, [0, 0, 0, 2]), qp=pick(12, [27, 22, 33, 38]))
+        kw["cross_component"] = int(kw["chroma_format"] == 3 and seed % 3 != 0)
+        kw["chroma_qp_depth"] = min(kw["chroma_qp_depth"], kw["log2_ctb"] - 3)
+        if kw["chroma_format"] == 0:
+            kw["chroma_qp_list"] = 0
+        if seed % 11 == 0:
+            kw.update(tile_cols=2, tile_rows=2, wpp=0)
+        if seed % 13 == 0 and not (kw["rext_sps"] & 128):
+            kw.update(dependent=500, slices=max(kw["slices"], 100))  # (persistent_rice + dependent segments: refused, see below)
+        if kw["bit_depth"] == 12 and seed % 2:
+            kw.update(sao_scale_y=seed % 3, sao_scale_c=(seed // 3) % 3)
+        if kw["log2_ctb"] == 4 and kw["bit_depth"] == 8 and kw["chroma_format"] in (1, 2):
+            kw["log2_ctb"] = 5  # quirk Q9 (see rare_syntax_sweep)
+        if kw["tq_bypass"] and kw["bit_depth"] == 8:
+            pass  # (the "pcmf" deblocking branch: the SIMD build of the reference is the oracle, as for SIMD_BUILD_ONLY)
         out.append((seed, kw))
     return out

@@ -176,6 +176,16 @@ struct SynthParams {
   int32_t slice_qp_random;     // slice_qp_delta drawn per slice (qp - 3 .. qp + 3)
   int32_t slice_chroma_qp;     // pps_slice_chroma_qp_offsets_present_flag: per-slice cb / cr offsets
   int32_t conf_left, conf_right, conf_top, conf_bottom; // conformance window, luma samples (multiples of 2)
+  // --- range extensions (all 0 = no sps / pps range extension: the streams of rounds 1-2, byte for byte) ---
+  int32_t rext_sps;            // bit mask of the nine sps_range_extension flags in syntax order: bit 0 transform_skip_rotation,
+                               // 1 transform_skip_context, 2 implicit_rdpcm, 3 explicit_rdpcm, 4 extended_precision,
+                               // 5 intra_smoothing_disabled, 6 high_precision_offsets, 7 persistent_rice, 8 cabac_bypass_alignment
+  int32_t log2_max_ts;         // 0: not written; 2..5: log2_max_transform_skip_block_size
+  int32_t cross_component;     // cross_component_prediction_enabled_flag (4:4:4); per-mille chance of a non-zero scale = 600
+  int32_t chroma_qp_list;      // 0: off; 1..6: chroma_qp_offset_list_len (entries seeded in -6..6)
+  int32_t chroma_qp_depth;     // diff_cu_chroma_qp_offset_depth
+  int32_t sao_scale_y, sao_scale_c; // log2_sao_offset_scale_luma / chroma (<= bit_depth - 10)
+  int32_t big_levels;          // per-mille chance of a long coeff_abs_level_remaining prefix (exercises the Rice adaptation)
 };
 
 // entropy-coder adaptor for SliceWalker: chooses every bin, encodes it, returns it
@@ -281,7 +291,9 @@ class EncoderEC {
       case K_QP_DELTA: return idx >= 3 ? 0 : rng_.chance(idx == 0 ? 350 : 400);
       case K_QP_DELTA_SUFFIX: return 0;
       case K_QP_SIGN: return idx > 2 ? 1 : (idx < -2 ? 0 : (int)(rng_.next() & 1)); // keep QpY near the slice QP
-      case K_TSKIP: return rng_.chance(150);
+      case K_TSKIP: return rng_.chance(P.rext_sps ? 400 : 150);
+      case K_CHROMA_QP_OFFSET_FLAG: return rng_.chance(600);
+      case K_RES_SCALE_ABS: return (idx & 256) ? 0 : rng_.chance(idx == 0 ? 600 : 500); // (bit 8: a unit the product refuses with a scale, Q17)
       case K_LAST_PREFIX: return rng_.chance(520);
       case K_CSBF: return rng_.chance(5 * d);
       case K_SIG: return rng_.chance(4 * d + 50);
@@ -293,6 +305,7 @@ class EncoderEC {
         // scalar builds disagree
         const int prefix = idx & 15, rice = idx >> 4;
         const int maxprefix = P.qp >= 40 ? 0 : (rice >= 2 ? 0 : 2);
+        if (P.big_levels && P.qp < 40 && rice < 6 && prefix < 5 + (rice < 2 ? 2 : 0)) return prefix < 3 ? rng_.chance(P.big_levels) : rng_.chance(500);
         return prefix >= maxprefix ? 0 : rng_.chance(350);
       }
       default: return (int)(rng_.next() & 1); // uniform: signs, suffixes, modes, band position, classes
@@ -421,7 +434,11 @@ __attribute__((visibility("default"))) int hm_synth_picture(const SynthParams* p
       w.flag(0);               // timing info
       w.flag(0);               // bitstream restriction
     }
-    w.flag(0);                 // sps_extension
+    w.flag(p.rext_sps != 0);   // sps_extension_present_flag
+    if (p.rext_sps) {
+      w.flag(1); w.flag(0); w.flag(0); w.flag(0); w.put(0, 4); // range extension only
+      for (int i = 0; i < 9; i++) w.flag((p.rext_sps >> i) & 1);
+    }
     w.trailing();
     sps_rbsp = w.buf;
     append_nal(stream, 33, w.buf);
@@ -471,7 +488,20 @@ __attribute__((visibility("default"))) int hm_synth_picture(const SynthParams* p
     w.flag(0);                 // lists_modification_present
     w.ue(0);                   // log2_parallel_merge_level_minus2
     w.flag(0);                 // slice_segment_header_extension_present
-    w.flag(0);                 // pps_extension
+    const bool pps_rext = p.log2_max_ts || p.cross_component || p.chroma_qp_list || p.sao_scale_y || p.sao_scale_c;
+    w.flag(pps_rext);          // pps_extension_present_flag
+    if (pps_rext) {
+      w.flag(1); w.flag(0); w.flag(0); w.flag(0); w.put(0, 4); // range extension only
+      if (p.transform_skip) w.ue((p.log2_max_ts ? p.log2_max_ts : 2) - 2);
+      w.flag(p.cross_component != 0);
+      w.flag(p.chroma_qp_list != 0);
+      if (p.chroma_qp_list) {
+        w.ue(p.chroma_qp_depth);
+        w.ue(p.chroma_qp_list - 1);
+        for (int i = 0; i < p.chroma_qp_list; i++) { w.se((int)(hdr_rng.next() % 13) - 6); w.se((int)(hdr_rng.next() % 13) - 6); }
+      }
+      w.ue(p.sao_scale_y); w.ue(p.sao_scale_c);
+    }
     w.trailing();
     pps_rbsp = w.buf;
     append_nal(stream, 34, w.buf);
@@ -515,6 +545,7 @@ __attribute__((visibility("default"))) int hm_synth_picture(const SynthParams* p
       sh.slice_qp_delta = qp - 26;
       sh.SliceQPY = qp;
       if (p.slice_chroma_qp) { sh.cb_qp_offset = (int)(sl_rng.next() % 7) - 3; sh.cr_qp_offset = (int)(sl_rng.next() % 7) - 3; }
+      sh.cu_chroma_qp_offset_enabled = p.chroma_qp_list != 0 && (first || sl_rng.chance(800));
       sh.deblocking_disabled = p.deblock_disable != 0;
       sh.beta_offset_div2 = p.beta_offset_div2;
       sh.tc_offset_div2 = p.tc_offset_div2;
@@ -564,6 +595,7 @@ __attribute__((visibility("default"))) int hm_synth_picture(const SynthParams* p
       if (p.sao) { w.flag(sh.sao_luma); if (p.chroma_format != 0) w.flag(sh.sao_chroma); } // slice_sao_luma_flag [, slice_sao_chroma_flag if ChromaArrayType != 0]
       w.se(sh.slice_qp_delta);
       if (p.slice_chroma_qp) { w.se(sh.cb_qp_offset); w.se(sh.cr_qp_offset); }
+      if (p.chroma_qp_list) w.flag(sh.cu_chroma_qp_offset_enabled);
       if (p.deblock_override) {
         w.flag(override_flag);
         if (override_flag) {

@@ -107,6 +107,38 @@ def test_structure_sweep_matches_reference_decoder_live(hm):
     assert multi > 40  # the sweep really holds multi-slice pictures
 
 
+def test_range_extension_sweep_matches_reference_decoder_live(hm):
+    """range-extension tools (transform-skip rotation / context / block sizes, implicit RDPCM, intra smoothing off,
+    persistent Rice adaptation, CU chroma QP offsets, cross-component prediction, SAO offset scaling, and the flags the
+    reference reads and ignores): host parser + oracle == libde265 at every stage (needs oracle/_ref)"""
+    if not orc.have_ref():
+        pytest.skip("oracle/_ref not built")
+    import synthutil
+    used = {"ccp": 0, "rot": 0, "rdpcm": 0}
+    for seed, kw in corpus.rext_sweep(160):
+        data = synthutil.picture(seed, **kw)
+        blob = hevcutil.parse(hm, data)
+        flags = int.from_bytes(blob[36:40], "little")
+        used["ccp"] += bool(flags & 0x10000); used["rot"] += bool(flags & 0x2000); used["rdpcm"] += bool(flags & 0x4000)
+        for stage, rf, bits in (("recon", orc.REF_F_NO_DEBLOCK | orc.REF_F_NO_SAO, 0), ("deblock", orc.REF_F_NO_SAO, 1), ("full", 0, 3)):
+            ref, _ = orc.ref_decode(data, rf)
+            mine, _ = orc.oracle_decode(blob, bits, crop=True)
+            for c in range(len(ref)):
+                assert np.array_equal(mine[c], ref[c]), f"seed {seed} {kw}: stage {stage} plane {c}"
+    assert min(used.values()) > 20, used
+
+
+def test_range_extension_refusals(hm):
+    """combinations whose result in the reference is undefined or mis-sized are refused, not guessed"""
+    import synthutil
+    with pytest.raises(RuntimeError, match="outside 4:4:4"):
+        hevcutil.parse(hm, synthutil.picture(1, cross_component=1, chroma_format=1))
+    # (the synthesiser drives the product's own syntax walker, hevc_syntax.h, which raises the refusal while encoding)
+    with pytest.raises(RuntimeError, match="synth failed: -3"):
+        synthutil.picture(2, width=128, height=128, rext_sps=128, slices=200, dependent=1000)
+    assert len(synthutil.picture(2, width=128, height=128, rext_sps=128, slices=200, dependent=0)) > 100
+
+
 def test_row_parallel_parse_equals_serial(pkg, hm):
     """hm_hevc_parse_mt (WPP rows entropy-decoded in parallel, decctx.cc:1004-1116 of the reference) must produce the
     serial parser's command stream byte for byte: the three real 1080p WPP streams, the corpus, and a sweep of WPP
