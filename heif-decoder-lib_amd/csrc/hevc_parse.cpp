@@ -349,7 +349,8 @@ struct Decoder {
     static const bool force_interleaved = [] { const char* e = std::getenv("HM_STREAM_INTERLEAVED"); return e && e[0] == '1'; }();
     const bool rare = s.scaling_list_enabled || (s.pcm_enabled && s.pcm_loop_filter_disabled) || p.transquant_bypass_enabled ||
                       pic.uses_pcm || pic.uses_tq_bypass || s.chroma_format_idc == 3 || s.transform_skip_rotation || s.implicit_rdpcm ||
-                      s.intra_smoothing_disabled || p.cross_component_prediction; // == HM_PIC_RARE_SYNTAX of the flags below
+                      s.intra_smoothing_disabled || p.cross_component_prediction ||
+                      (p.transform_skip_enabled && p.log2_max_transform_skip_size > 2); // == HM_PIC_RARE_SYNTAX of the flags below
     const bool split = !rare && !force_interleaved;
     const bool direct = pic.direct; // the chains were written in their final form while parsing (hevc_syntax.h: PictureState::rows)
     if (direct && !split) throw ParseError(HM_ERR_INTERNAL, "direct chains of a picture with rare syntax");
@@ -490,6 +491,7 @@ struct Decoder {
     if (s.implicit_rdpcm) flags |= HM_PIC_IMPLICIT_RDPCM;
     if (s.intra_smoothing_disabled) flags |= HM_PIC_NO_INTRA_SMOOTHING;
     if (p.cross_component_prediction) flags |= HM_PIC_CROSS_COMPONENT;
+    if (p.transform_skip_enabled && p.log2_max_transform_skip_size > 2) flags |= HM_PIC_LARGE_TSKIP;
     if (split) flags |= HM_PIC_SPLIT_CHAINS;
     if (rare != ((flags & HM_PIC_RARE_SYNTAX) != 0)) throw ParseError(HM_ERR_INTERNAL, "rare-syntax classification");
     h.flags = flags;

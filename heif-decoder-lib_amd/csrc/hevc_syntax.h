@@ -216,7 +216,8 @@ struct PictureState {
     for (auto& v : ctb_tus) v.clear();
     coeffs.clear();
     direct = !(s.scaling_list_enabled || s.pcm_enabled || p.transquant_bypass_enabled || s.chroma_format_idc == 3 ||
-               s.transform_skip_rotation || s.implicit_rdpcm || s.intra_smoothing_disabled || p.cross_component_prediction);
+               s.transform_skip_rotation || s.implicit_rdpcm || s.intra_smoothing_disabled || p.cross_component_prediction ||
+               (p.transform_skip_enabled && p.log2_max_transform_skip_size > 2));
     if ((int)rows.size() != s.ctb_h) rows.resize((size_t)s.ctb_h);
     for (RowChains& r : rows)
       for (int k = 0; k < 2; k++) { r.tu[k].clear(); r.lv[k].clear(); }
@@ -686,7 +687,7 @@ class SliceWalker {
       t.coeff_first = (uint32_t)coeffs_->size();
       t.n_coeff = (uint16_t)(w * w);
       t.qp = (uint8_t)qp_prime_[cIdx];
-      t.qpy = (int8_t)cu_qpy_;
+      t.qpy = (int8_t)((cIdx && pps_.cross_component_prediction) ? 0 : cu_qpy_); // (chroma records of such pictures: ResScaleVal)
       for (int i = 0; i < w * w; i++) {
         hm_coeff c;
         c.pos = (uint16_t)i;

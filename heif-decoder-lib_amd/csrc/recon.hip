@@ -124,8 +124,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
   Pix* const u0 = reinterpret_cast<Pix*>(lp); lp += (size_t)P0 * ctb * sizeof(Pix);
   Pix* const u1 = reinterpret_cast<Pix*>(lp); lp += (size_t)P1 * ch_c * sizeof(Pix);
   Pix* const u2 = reinterpret_cast<Pix*>(lp); lp += (size_t)P1 * ch_c * sizeof(Pix);
+  // 4:4:4 rare-syntax classes: residual of the current unit's luma block for cross-component prediction (4 KiB per wave)
+  int32_t* const l_res = c444 ? reinterpret_cast<int32_t*>(wbase + ((lp - wbase + 15) & ~(size_t)15)) : nullptr;
   // the picture flags the blocks look at; without RARE the rare-syntax bits are known to be clear and their paths fold away
   const int strong = (dp.flags & (HM_PIC_STRONG_INTRA_SMOOTHING | (RARE ? HM_PIC_RARE_SYNTAX : 0))) | (c444 ? SMOOTH_CHROMA : 0);
+  const int ext = RARE ? strong & (HM_PIC_TS_ROTATION | HM_PIC_IMPLICIT_RDPCM | HM_PIC_CROSS_COMPONENT) : 0;
   const int planeWc = c444 ? dp.width : dp.width >> 1, planeHc = dp.height / sh;
   // one sample line: [4 pad | luma ctb_w*ctb][4 pad | cb ctb_w*cw_c][4 pad | cr ...]; sample x of a plane at base[x], x >= -1
   const int Wl = ctb_w << log2_ctb, Wc = ctb_w * cw_c;
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
         uint32_t s0 = 0;
         constexpr uint32_t kind_mask = (uint32_t)(HM_TU_LOG2_MASK | (3u << HM_TU_CIDX_SHIFT)) << 16;
         // (PCM / transquant-bypass records, which only the RARE variant can meet, take the one-block path)
-        if ((r0 & kind_mask) == ((2u | (1u << HM_TU_CIDX_SHIFT)) << 16) && k + 1 < tu_count && (!RARE || (r0 >> 30) == 0)) {
+        if ((r0 & kind_mask) == ((2u | (1u << HM_TU_CIDX_SHIFT)) << 16) && k + 1 < tu_count && (!RARE || ((r0 >> 30) == 0 && !(ext & HM_PIC_CROSS_COMPONENT)))) {
           s0 = rfl(m0);
           constexpr uint32_t differ = (uint32_t)(HM_TU_CBF | HM_TU_TSKIP | (3u << HM_TU_CIDX_SHIFT)) << 16;
           pair = ((r0 ^ s0) & ~differ) == 0 && ((s0 >> (16 + HM_TU_CIDX_SHIFT)) & 3) == 2 && (uint32_t)rfl(m3) == r3;
@@ -219,6 +222,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
           B.top = half ? top2 : top1;
           B.P = P1;
           B.tskip = info_l & HM_TU_TSKIP;
+          B.ext = ext;
           const bool cbf_l = (info_l & HM_TU_CBF) != 0;
           const GLOBAL_AS uint32_t* const cf = coeffs + l2;
           uint32_t pre = 0;
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
             predict<Pix, 2, RefArray, true>(B, RefArray{bA + 64}, tab, ln);
           }
           WAVE_SYNC();
-          if (cbf_l) residual_add<Pix, 2>(B, l_coeff + half * 16, l_tmp + half * 16, dct, tab, cf, pre, ln, strong, 1 + half); // matrixId = cIdx
+          if (cbf_l) residual_add<Pix, 2, RARE>(B, l_coeff + half * 16, l_tmp + half * 16, dct, tab, cf, pre, ln, strong, 1 + half); // matrixId = cIdx
           WAVE_SYNC();
           continue;
         }
@@ -254,6 +258,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
         B.x0 = w0 & 0xFF; B.y0 = (w0 >> 8) & 0xFF;
         B.qp = w1 & 0xFF;
         const int qpy = (int)(int8_t)((w1 >> 8) & 0xFF);
+        B.ext = ext;
+        B.res_scale = (RARE && (ext & HM_PIC_CROSS_COMPONENT) && B.c != 0) ? qpy : 0; // hm_stream.h: chroma records carry ResScaleVal there
         B.n_coeff = w1 >> 16;
         const uint32_t coeff_first = w2;
         B.aBL = (w3 >> 8) & 0xFF; B.aTR = w3 >> 24;
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
           // variants is hoisted out of all loops and kept alive for the whole kernel (> 100 spilled SGPRs)
           int ln = lane;
           asm volatile("" : "+v"(ln));
-          const bool smoothed = L2 != 2 && (B.c == 0 || c444) && ((filter_mode_mask(L2) >> B.mode) & 1);
+          const bool smoothed = L2 != 2 && (B.c == 0 || c444) && !(RARE && (strong & HM_PIC_NO_INTRA_SMOOTHING)) && ((filter_mode_mask(L2) >> B.mode) & 1);
           if (RARE && (lossless & 2)) { // PCM: the record's levels are the samples, in raster order (slice.cc:4462-4504)
             Pix* dst = B.u + mul24(B.y0, B.P) + UPAD + B.x0;
             const GLOBAL_AS uint32_t* cf = coeffs + coeff_first;
@@ -294,11 +300,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
                 while (__hip_atomic_exchange(big_lock, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) __builtin_amdgcn_s_sleep(2);
               __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
               __builtin_amdgcn_wave_barrier();
-              residual_add<Pix, L2>(B, big_coeff, big_tmp, dct, tab, coeffs + coeff_first, pre, ln, strong, B.c);
+              residual_add<Pix, L2, RARE>(B, big_coeff, big_tmp, dct, tab, coeffs + coeff_first, pre, ln, strong, B.c, l_res);
               __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
               if (lane == 0) __hip_atomic_store(big_lock, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            else residual_add<Pix, L2>(B, l_coeff, l_tmp, dct, tab, coeffs + coeff_first, pre, ln, strong, B.c);
+            else residual_add<Pix, L2, RARE>(B, l_coeff, l_tmp, dct, tab, coeffs + coeff_first, pre, ln, strong, B.c, l_res);
+            WAVE_SYNC();
+          }
+          else if (RARE && B.res_scale != 0 && !(lossless & 2)) { // no levels of its own: the cross-component term alone
+            cross_component_only<Pix, L2>(B, l_res, ln);
             WAVE_SYNC();
           }
           if (B.c == 0) { // deblocking metadata (deblock.cc:31-62): transform edges + QpY
@@ -392,7 +402,9 @@ static int per_wave_lds(int ctb, int chroma_format, int pix_bytes)
   const int cw = chroma_format == 3 ? ctb : ctb / 2, ch = chroma_format == 1 ? ctb / 2 : ctb;
   int b = 512 + 512 + 272 + META_BYTES(ctb);
   b += (ctb + UPAD) * ctb * pix_bytes + 2 * (cw + UPAD) * ch * pix_bytes;
-  return (b + 15) & ~15;
+  b = (b + 15) & ~15;
+  if (chroma_format == 3) b += 32 * 32 * 4; // luma residual of the current unit (cross-component prediction)
+  return b;
 }
 // one line of samples (luma + cb + cr, 4 samples of padding in front of each) for a picture ctb_w CTBs wide
 static int line_lds(int ctb, int ctb_w, int pix_bytes, int chroma_format)

@@ -93,6 +93,8 @@ struct Blk {
   int aBL, aTR;      // vector copies of the two partial counts
   int n_coeff;
   int bd;
+  int ext = 0;       // range-extension picture flags (HM_PIC_TS_ROTATION | _IMPLICIT_RDPCM | _CROSS_COMPONENT), rare-syntax kernel only
+  int res_scale = 0; // ResScaleVal of a chroma block of a HM_PIC_CROSS_COMPONENT picture
 };
 // neighbour availability of the slow (picture / slice / tile border) path, decoded from Blk::avail / Blk::info
 struct Avail {
@@ -228,7 +230,7 @@ constexpr uint64_t filter_mode_mask(int log2)
 // Written select-style on purpose (both candidates computed, then chosen): a ternary with arithmetic in
 // its arms becomes an exec-mask branch, i.e. several scalar instructions per lane-level decision.
 #define META_BYTES(ctb) (((ctb) >> 2) * ((ctb) >> 2) * 2) // 16-bit block map of one CTU
-constexpr int SMOOTH_CHROMA = 0x10000; // with the picture flags: chroma reference samples are smoothed like luma ones (4:4:4)
+constexpr int SMOOTH_CHROMA = 0x40000000; // with the picture flags: chroma reference samples are smoothed like luma ones (4:4:4)
 template <typename Pix, int L2>
 __device__ __forceinline__ void make_border(const Blk<Pix>& b, int16_t* bA, int strong, int lane)
 {
@@ -256,7 +258,7 @@ __device__ __forceinline__ void make_border(const Blk<Pix>& b, int16_t* bA, int 
     lanes_loop<N>(lane, [&](int e) { bc[e - 2 * nT] = (int16_t)border_value<Pix, L2>(b, av, e - 2 * nT, noLeftFill, topFill); });
   }
 
-  if (L2 != 2 && (b.c == 0 || (strong & SMOOTH_CHROMA)) && ((filter_mode_mask(L2) >> b.mode) & 1)) { // intrapred.cc:307-311
+  if (L2 != 2 && (b.c == 0 || (strong & SMOOTH_CHROMA)) && !(strong & HM_PIC_NO_INTRA_SMOOTHING) && ((filter_mode_mask(L2) >> b.mode) & 1)) { // intrapred.cc:307-311
     WAVE_SYNC();
     // strong (bilinear) smoothing of 32x32 blocks when both edges are nearly linear, else [1 2 1]; the two
     // end samples stay as they are (the bilinear formula and the degenerate [c 2c c] both return them)
@@ -331,11 +333,13 @@ __device__ __forceinline__ void predict(const Blk<Pix>& B, const Ref& b, const i
   else if (mode == 26 || mode == 10) { // pure vertical / horizontal: copy, plus the gradient on the first column / row
     const bool vert = mode == 26;
     const int corner = b(0);
+    // disableIntraBoundaryFilter (intrapred.cc:323-326): transquant-bypass units of implicit-RDPCM pictures
+    const bool edge_hv = edge && !((B.ext & HM_PIC_IMPLICIT_RDPCM) && (B.tskip & 0x100));
     lanes_loop<npx>(lane, [&](int p) {
       const int x = p & (nT - 1), y = p >> log2;
       const int t = b(1 + x), l = b(-1 - y);
       int v = vert ? t : l;
-      if (edge) {
+      if (edge_hv) {
         const int along = vert ? x : y;                                  // distance from the smoothed border
         const int g = vert ? b(1) + ((l - corner) >> 1) : b(-1) + ((t - corner) >> 1);
         v = along == 0 ? clip3i(0, maxv, g) : v;
@@ -378,11 +382,34 @@ __device__ __forceinline__ void predict(const Blk<Pix>& B, const Ref& b, const i
 // ---- dequantisation + inverse transform + add (transform.cc:386-689, fallback-dct.cc) --------------------
 // Invariant: the dense coefficient buffer is all zero on entry and on exit.
 constexpr int TAB_SCALING_PTR = 96; // int16 index into the table region (256 B; 92 entries used): 8-byte aligned slot
-template <typename Pix, int L2>
+// (residual_luma << BitDepthC) >> BitDepthY of transform.cc:264 with equal depths: the identity unless the 32-bit shift
+// wraps (|residual| >= 2^(31 - depth): only a stream built for it gets there), reproduced as the reference computes it
+__device__ __forceinline__ int ccp_term(int rl, int bd) { return (int)((uint32_t)rl << bd) >> bd; }
+
+// REXT (rare-syntax kernel): transform-skip rotation, implicit RDPCM, cross-component prediction (res_luma: the wave's
+// copy of tctx->residual_luma; transform.cc:251-285, 427-466, 566-643, fallback-dct.cc:173-299 of the reference).
+template <typename Pix, int L2, bool REXT = false>
 __device__ __forceinline__ void residual_add(const Blk<Pix>& B, int16_t* coeff, int16_t* tmp, const int8_t* dct, const int16_t* tab,
-                                             const GLOBAL_AS uint32_t* __restrict__ cf, const uint32_t pre_raw, int lane, int picf, int matrix)
+                                             const GLOBAL_AS uint32_t* __restrict__ cf, const uint32_t pre_raw, int lane, int picf, int matrix,
+                                             int32_t* res_luma = nullptr)
 {
   constexpr int nT = 1 << L2, log2 = L2;
+  // levels of a 4x4 transform-skip / bypass block change places (x, y) <-> (3 - x, 3 - y): position 15 - pos
+  const int rot = (REXT && L2 == 2 && (B.ext & HM_PIC_TS_ROTATION) && B.tskip) ? 15 : 0;
+  int rdpcm = 0; // 1: accumulate along rows (mode 10), 2: along columns (mode 26)
+  if (REXT && (B.ext & HM_PIC_IMPLICIT_RDPCM) && B.tskip && (B.mode == 10 || B.mode == 26)) rdpcm = B.mode == 26 ? 2 : 1;
+  const bool cross = REXT && (B.ext & HM_PIC_CROSS_COMPONENT);
+  // residual -> sample: the cross-component term of a chroma block, the luma block's residual kept for it
+  auto finish = [&](int p, int r, bool res16) {
+    if (cross) {
+      if (B.c == 0) { if (!res16) res_luma[p] = r; } // (the reference's 16-bit variant fills another buffer: Q17)
+      else if (B.res_scale != 0) {
+        r += (B.res_scale * ccp_term(res_luma[p], B.bd)) >> 3;
+        if (res16) r = (int16_t)r;
+      }
+    }
+    return r;
+  };
   const int c = B.c, bit_depth = B.bd;
   constexpr int npx = nT * nT;
   const int qP = B.qp;
@@ -394,7 +421,7 @@ __device__ __forceinline__ void residual_add(const Blk<Pix>& B, int16_t* coeff, 
 #pragma unroll 1
     for (int i = lane; i < B.n_coeff; i += 64) {
       const uint32_t raw = i < 64 ? pre_raw : cf[i];
-      coeff[raw & 0xFFFF] = (int16_t)(raw >> 16);
+      coeff[rot ? rot - (raw & 0xFFFF) : (raw & 0xFFFF)] = (int16_t)(raw >> 16);
     }
   }
   else if (picf & HM_PIC_SCALING_LIST) {
@@ -412,7 +439,7 @@ __device__ __forceinline__ void residual_add(const Blk<Pix>& B, int16_t* coeff, 
       const int32_t f = (int32_t)((uint32_t)mul24((int)sclist[pos], ls) << lsh);
       int64_t v = ((int64_t)value * f + sOffset) >> sShift;
       v = v < -32768 ? -32768 : (v > 32767 ? 32767 : v);
-      coeff[pos] = (int16_t)v;
+      coeff[rot ? rot - pos : pos] = (int16_t)v;
       const int px = pos & (nT - 1), py = pos >> log2;
       mx = px > mx ? px : mx;
       my = py > my ? py : my;
@@ -425,7 +452,7 @@ __device__ __forceinline__ void residual_add(const Blk<Pix>& B, int16_t* coeff, 
       const int pos = raw & 0xFFFF, value = (int)(int16_t)(raw >> 16);
       // low 32 bits of value * fact (|value| < 2^15, fact < 2^23), i.e. the reference's wrapping int32 product (Q3)
       const int32_t prod = (int32_t)((uint32_t)mul24(value, fact) + (uint32_t)offset);
-      coeff[pos] = (int16_t)clip3i(-32768, 32767, prod >> bdShift);
+      coeff[rot ? rot - pos : pos] = (int16_t)clip3i(-32768, 32767, prod >> bdShift);
       const int px = pos & (nT - 1), py = pos >> log2;
       mx = px > mx ? px : mx;
       my = py > my ? py : my;
@@ -439,19 +466,41 @@ __device__ __forceinline__ void residual_add(const Blk<Pix>& B, int16_t* coeff, 
   const int maxv = (1 << bit_depth) - 1;
   const int postShift = 20 - bit_depth, rnd2 = 1 << (postShift - 1);
 
+  // RDPCM: sample (x, y) sums the residuals of its row up to x (column up to y): first element, stride, count
+  auto run_of = [&](int p, int& first, int& step, int& n) {
+    const int x = p & (nT - 1), y = p >> log2;
+    first = p; step = 0; n = 1;
+    if (REXT && rdpcm == 1) { first = p - x; step = 1; n = x + 1; }
+    if (REXT && rdpcm == 2) { first = x; step = nT; n = y + 1; }
+  };
   if (B.tskip & 0x100) {
     lanes_loop<npx>(lane, [&](int p) {
       const int x = p & (nT - 1), y = p >> log2;
-      dst[mul24(y, pitch) + x] = (Pix)clip3i(0, maxv, (int)dst[mul24(y, pitch) + x] + (int)coeff[p]);
+      int r = (int)coeff[p];
+      if (REXT && rdpcm) {
+        int first, step, n;
+        run_of(p, first, step, n);
+        r = 0;
+        for (int k = 0; k < n; k++) r += (int)coeff[first + mul24(k, step)];
+      }
+      if (REXT) r = finish(p, r, false);
+      dst[mul24(y, pitch) + x] = (Pix)clip3i(0, maxv, (int)dst[mul24(y, pitch) + x] + r);
     });
   }
   else if (B.tskip) { // transform.cc:566-643
     const int tsShift = 5 + log2;
+    const bool res16 = bit_depth == 8 && nT == 4;
     lanes_loop<npx>(lane, [&](int p) {
       const int x = p & (nT - 1), y = p >> log2;
-      const int32_t cc = (int32_t)((uint32_t)(int32_t)coeff[p] << tsShift);
-      int r = (cc + rnd2) >> postShift;
-      if (bit_depth == 8 && nT == 4) r = (int16_t)r;
+      int first = p, step = 0, n = 1;
+      if (REXT && rdpcm) run_of(p, first, step, n);
+      int r = 0;
+      for (int k = 0; k < n; k++) { // (n = 1 without RDPCM)
+        const int32_t cc = (int32_t)((uint32_t)(int32_t)coeff[first + mul24(k, step)] << tsShift);
+        r += (cc + rnd2) >> postShift;
+      }
+      if (res16) r = (int16_t)r;
+      if (REXT) r = finish(p, r, res16);
       dst[mul24(y, pitch) + x] = (Pix)clip3i(0, maxv, (int)dst[mul24(y, pitch) + x] + r);
     });
   }
@@ -469,7 +518,9 @@ __device__ __forceinline__ void residual_add(const Blk<Pix>& B, int16_t* coeff, 
       int sum = 0;
 #pragma unroll
       for (int j = 0; j < 4; j++) sum += mul24(tab[76 + j * 4 + i], tmp[y * 4 + j]);
-      const int out = clip3i(-32768, 32767, (sum + rnd2) >> postShift);
+      int out = (sum + rnd2) >> postShift;
+      if (!cross) out = clip3i(-32768, 32767, out); // (the explicit variant of cross-component pictures does not clip: fallback-dct.cc:511-551)
+      else out = finish(y * 4 + i, out, false);
       dst[mul24(y, pitch) + i] = (Pix)clip3i(0, maxv, (int)dst[mul24(y, pitch) + i] + out);
     }
   }
@@ -492,7 +543,8 @@ __device__ __forceinline__ void residual_add(const Blk<Pix>& B, int16_t* coeff, 
         const int i = p & (nT - 1), yr = p >> log2, y = i0 + yr;
         int sum = 0;
         for (int j = 0; j <= mx; j++) sum += mul24((int)dct[(fct * j) * 32 + i], (int)tmp[yr * nT + j]);
-        const int out = (sum + rnd2) >> postShift; // stage 2 is not clipped to 16 bit (Q4)
+        int out = (sum + rnd2) >> postShift; // stage 2 is not clipped to 16 bit (Q4)
+        if (REXT) out = finish(mul24(y, nT) + i, out, false);
         dst[mul24(y, pitch) + i] = (Pix)clip3i(0, maxv, (int)dst[mul24(y, pitch) + i] + out);
       });
       WAVE_SYNC();
@@ -503,8 +555,21 @@ __device__ __forceinline__ void residual_add(const Blk<Pix>& B, int16_t* coeff, 
 #pragma unroll 1
   for (int i = lane; i < B.n_coeff; i += 64) {
     const uint32_t raw = i < 64 ? pre_raw : cf[i];
-    coeff[raw & 0xFFFF] = 0;
+    coeff[rot ? rot - (raw & 0xFFFF) : (raw & 0xFFFF)] = 0;
   }
+}
+
+// a chroma block without levels in a cross-component picture: its residual is the cross-component term (slice.cc:3797-3805)
+template <typename Pix, int L2>
+__device__ __forceinline__ void cross_component_only(const Blk<Pix>& B, const int32_t* res_luma, int lane)
+{
+  constexpr int nT = 1 << L2;
+  Pix* dst = B.u + mul24(B.y0, B.P) + UPAD + B.x0;
+  const int maxv = (1 << B.bd) - 1;
+  lanes_loop<nT * nT>(lane, [&](int p) {
+    const int x = p & (nT - 1), y = p >> L2;
+    dst[mul24(y, B.P) + x] = (Pix)clip3i(0, maxv, (int)dst[mul24(y, B.P) + x] + ((B.res_scale * ccp_term(res_luma[p], B.bd)) >> 3));
+  });
 }
 
 } // namespace

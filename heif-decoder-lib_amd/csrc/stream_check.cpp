@@ -33,6 +33,9 @@ static const char* validate_stream(const uint8_t* blob, size_t size)
   const int sw = h.chroma_format == 3 ? 1 : 2, sh = h.chroma_format == 1 ? 2 : 1;
   const bool split = (h.flags & HM_PIC_SPLIT_CHAINS) != 0;
   if (split && (h.flags & HM_PIC_RARE_SYNTAX)) return "record order of a rare-syntax picture";
+  // (the kernel keeps the luma residual of cross-component pictures in a buffer only 4:4:4 launches allocate)
+  const bool cross = (h.flags & HM_PIC_CROSS_COMPONENT) != 0;
+  if (cross && h.chroma_format != 3) return "cross-component prediction outside 4:4:4";
   auto check_record = [&](const hm_tu& u, int want_luma) -> const char* { // want_luma: 1 luma list, 0 chroma list, -1 either
     const int log2 = u.info & HM_TU_LOG2_MASK, cidx = (u.info >> HM_TU_CIDX_SHIFT) & 3, nT = 1 << log2;
     if (log2 < 2 || log2 > 5 || cidx > 2 || (cidx && h.chroma_format == 0)) return "block size / component";
@@ -41,9 +44,14 @@ static const char* validate_stream(const uint8_t* blob, size_t size)
     if (u.x + nT > bw || u.y + nT > bh || ((u.x | u.y) & 3)) return "block position";
     if ((u.pred_mode & HM_TU_MODE_MASK) > 34) return "prediction mode";
     if (split && (u.pred_mode & ~HM_TU_MODE_MASK)) return "PCM / bypass record in a picture without rare syntax";
+    if (split && (u.info & HM_TU_TSKIP) && log2 > 2) return "large transform-skip block in a picture without rare syntax";
     if (u.avail_left > nT || u.avail_top > nT || u.avail_bottom_left > nT || u.avail_top_right > nT) return "neighbour availability";
     if ((uint64_t)u.coeff_first + u.n_coeff > h.n_coeffs || u.n_coeff > nT * nT) return "level range of a record";
     if ((u.pred_mode & HM_TU_MODE_PCM) && u.n_coeff != nT * nT) return "PCM sample count";
+    if (cross && cidx) { // ResScaleVal
+      const int v = u.qpy < 0 ? -u.qpy : u.qpy;
+      if (v != 0 && v != 1 && v != 2 && v != 4 && v != 8) return "cross-component scale";
+    }
     for (uint32_t q = 0; q < u.n_coeff; q++)
       if (cf[u.coeff_first + q].pos >= nT * nT) return "level position";
     return nullptr;

@@ -67,8 +67,10 @@ extern "C" {
                                                  record holds ResScaleVal (0, +-1, +-2, +-4, +-8); its residual gets
                                                  (ResScaleVal * luma residual) >> 3 added (transform.cc:251-267), also
                                                  when the record has no levels of its own (slice.cc:3797-3805)        */
+#define HM_PIC_LARGE_TSKIP            0x20000u /* log2_max_transform_skip_block_size > 2: transform-skip blocks of 8x8 and
+                                                 larger may occur (the common kernel's 8x8 path has no skip branch)  */
 #define HM_PIC_RARE_SYNTAX            (HM_PIC_SCALING_LIST | HM_PIC_PCMF | HM_PIC_LOSSLESS_CUS | HM_PIC_444 | HM_PIC_TS_ROTATION | \
-                                       HM_PIC_IMPLICIT_RDPCM | HM_PIC_NO_INTRA_SMOOTHING | HM_PIC_CROSS_COMPONENT) /* pictures that
+                                       HM_PIC_IMPLICIT_RDPCM | HM_PIC_NO_INTRA_SMOOTHING | HM_PIC_CROSS_COMPONENT | HM_PIC_LARGE_TSKIP) /* pictures that
                                                  need the kernel variant of the reconstruction with the rare paths   */
 
 /* ScalingFactor tables of a picture with scaling lists (transform.cc:509-533): one byte per coefficient position

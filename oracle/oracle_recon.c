@@ -317,7 +317,9 @@ static void residual_add(uint16_t* dst, int stride, int nT, int log2, int cIdx, 
   if (cross && cIdx == 0 && cbf && !res16) memcpy(res_luma, r, sizeof(int32_t) * n); /* (the 16-bit variant fills another buffer: Q17) */
   if (cIdx != 0 && res_scale != 0) { /* cross_comp_pred / cross_comp_pred16, transform.cc:251-285; equal bit depths */
     for (int i = 0; i < n; i++) {
-      const int32_t v = r[i] + ((res_scale * res_luma[i]) >> 3);
+      /* (residual_luma << BitDepthC) >> BitDepthY in 32 bits, as compiled: wraps for |residual| >= 2^(31 - depth) */
+      const int32_t rl = (int32_t)((uint32_t)res_luma[i] << bit_depth) >> bit_depth;
+      const int32_t v = r[i] + ((res_scale * rl) >> 3);
       r[i] = res16 ? (int16_t)v : v;
     }
   }

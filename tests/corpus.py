@@ -193,3 +193,12 @@ def rext_sweep(n, first_seed=11000):
             pass  # (the "pcmf" deblocking branch: the SIMD build of the reference is the oracle, as for SIMD_BUILD_ONLY)
         out.append((seed, kw))
     return out
+
+
+def rext_large():
+    """larger pictures with 32x32 transform-skip / bypass blocks and CTB 64: RDPCM runs of 32 samples, cross-component
+    prediction of 32x32 blocks"""
+    return [(12000 + i, dict(width=192, height=128, log2_ctb=[6, 5][i % 2], chroma_format=[3, 1, 3, 2][i % 4], bit_depth=[8, 10, 12][i % 3],
+                             rext_sps=[7, 135, 167, 39][i % 4], log2_max_ts=5, tq_bypass=[0, 300][i % 2], cross_component=int(i % 4 in (0, 2)),
+                             chroma_qp_list=[0, 3][i % 2], big_levels=200, wpp=i % 2, qp=[24, 30, 36][i % 3], max_th_depth_intra=[0, 1, 2][i % 3]))
+            for i in range(12)]

@@ -121,3 +121,35 @@ def test_structure_sweep(pkg):
             for c in range(len(exp)):
                 bad = np.argwhere(g[c] != exp[c])
                 assert bad.size == 0, f"seed {seed} {kw} stages {bits} plane {c}: {len(bad)} mismatches, first (y,x)={bad[0].tolist()}"
+
+
+def test_range_extension_sweep(pkg):
+    """range-extension tools (transform-skip rotation / context / block sizes up to 32x32, implicit RDPCM, intra smoothing
+    off, persistent Rice adaptation, CU chroma QP offsets, cross-component prediction, SAO offset scaling) in one batch:
+    HIP == oracle at every stage.  The oracle equals the reference decoder on the same sweep (test_oracle_decode.py)."""
+    import synthutil
+    cases = corpus.rext_sweep(120)
+    blobs = [pkg.capi.parse_hevc(synthutil.picture(seed, **kw)) for seed, kw in cases]
+    for bits in (0, 1, 3):
+        got = gpudecode.decode_pictures(pkg, blobs, bits)
+        for (seed, kw), blob, g in zip(cases, blobs, got):
+            exp, _ = orc.oracle_decode(blob, bits, crop=True)
+            assert len(g) == len(exp)
+            for c in range(len(exp)):
+                bad = np.argwhere(g[c] != exp[c])
+                assert bad.size == 0, f"seed {seed} {kw} stages {bits} plane {c}: {len(bad)} mismatches, first (y,x)={bad[0].tolist()}"
+
+
+def test_range_extension_large_blocks(pkg):
+    """the same tools on larger pictures with 32x32 transform-skip / bypass blocks and CTB 64 (RDPCM runs of 32 samples,
+    cross-component prediction of 32x32 blocks through the workgroup's shared staging)"""
+    import synthutil
+    cases = corpus.rext_large()
+    blobs = [pkg.capi.parse_hevc(synthutil.picture(seed, **kw)) for seed, kw in cases]
+    for bits in (0, 3):
+        got = gpudecode.decode_pictures(pkg, blobs, bits)
+        for (seed, kw), blob, g in zip(cases, blobs, got):
+            exp, _ = orc.oracle_decode(blob, bits, crop=True)
+            for c in range(len(exp)):
+                bad = np.argwhere(g[c] != exp[c])
+                assert bad.size == 0, f"seed {seed} {kw} stages {bits} plane {c}: {len(bad)} mismatches, first (y,x)={bad[0].tolist()}"

@@ -115,7 +115,7 @@ def test_range_extension_sweep_matches_reference_decoder_live(hm):
         pytest.skip("oracle/_ref not built")
     import synthutil
     used = {"ccp": 0, "rot": 0, "rdpcm": 0}
-    for seed, kw in corpus.rext_sweep(160):
+    for seed, kw in corpus.rext_sweep(160) + corpus.rext_large():
         data = synthutil.picture(seed, **kw)
         blob = hevcutil.parse(hm, data)
         flags = int.from_bytes(blob[36:40], "little")
