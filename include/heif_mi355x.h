@@ -125,8 +125,8 @@ HM_API int hm_colour_convert_batch(const hm_colour_desc* d, int n, const void* c
  * (00 00 01 start codes) instead.  On success *out_blob (free with hm_free) holds the picture's
  * command stream (struct hm_pic at offset 0).  CABAC / parsing run on the calling CPU thread -
  * as in the reference (slice.cc) - and are thread-safe across different calls.
- * Returns HM_ERR_UNSUPPORTED for syntax outside the GPU hot path (inter slices,
- * range-extension tools, separate colour planes, more than 12 bits). */
+ * Returns HM_ERR_UNSUPPORTED for syntax outside the GPU hot path (inter slices, multilayer / 3D / screen-content
+ * extensions, separate colour planes, more than 12 bits, range-extension corners undefined in the reference). */
 HM_API int hm_hevc_parse(const uint8_t* data, size_t size, int annexb, uint8_t** out_blob, size_t* out_size);
 /* the same with up to `threads` host threads for ONE picture: slice segments coded with wavefront parallel processing
  * (entry points per CTB row) are entropy-decoded row-parallel like the reference's WPP threads (decctx.cc:1004-1116);

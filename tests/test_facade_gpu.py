@@ -303,3 +303,33 @@ def test_icc_profile_on_handles_and_images(api, hm):
     assert api.heif_image_handle_get_color_profile_type(h) == 0x72494343
     assert api.heif_image_get_raw_color_profile_size(img) == 0 and api.heif_image_get_color_profile_type(img) == 0x6E636C78  # the converted canvas: nclx only
     api.heif_image_release(img); api.heif_image_handle_release(h); api.heif_context_free(ctx)
+
+
+def test_range_extension_images_through_heif_decode_image(api, hm):
+    """HEIC files whose coded pictures use the range-extension tools (4:4:4 with cross-component prediction, implicit
+    RDPCM + rotation + large transform-skip blocks in a 10-bit 4:2:2 grid, persistent Rice adaptation + CU chroma QP
+    offsets in an 8-bit 4:2:0 grid): heif_decode_image == the CPU restatement of the whole path (entropy decode by the
+    product's parser, reconstruction / filters / paste / colour by the oracle - equal to libde265 on these tools:
+    test_oracle_decode.py::test_range_extension_sweep_matches_reference_decoder_live)"""
+    import synthutil
+    cases = [
+        (dict(chroma_format=3, cross_component=1, rext_sps=1 | 2 | 4 | 32, log2_max_ts=4, tq_bypass=150, matrix=0), 3, 8, (1, 1, 128, 72), 10),
+        (dict(chroma_format=3, bit_depth=10, cross_component=1, rext_sps=128, big_levels=200, matrix=1, full_range=0), 3, 10, (1, 1, 128, 72), 14),
+        (dict(chroma_format=2, bit_depth=10, rext_sps=1 | 4, log2_max_ts=5, matrix=9, full_range=0, primaries=9), 2, 10, (2, 2, 250, 140), 14),
+        (dict(chroma_format=1, rext_sps=128 | 2, chroma_qp_list=3, chroma_qp_depth=1, big_levels=300, matrix=6, full_range=1), 1, 8, (2, 3, 380, 140), 10),
+    ]
+    for k, (kw, cf, bd, (rows, cols, ow, oh), chroma) in enumerate(cases):
+        W, H = 128, 72
+        pics = [synthutil.picture(9300 + 10 * k + t, width=W, height=H, vui=1, **kw) for t in range(rows * cols)]
+        grid = None if rows * cols == 1 else (rows, cols, ow, oh)
+        data = heifwriter.write_heic(pics, (W, H), grid=grid, chroma_format=cf, bit_depth=bd)
+        ctx, h, img, e = _decode(api, data, 0, 1, chroma, threads=3)
+        assert e.code == 0, (k, e.message)
+        stride = C.c_int()
+        p = api.heif_image_get_plane_readonly(img, 10, C.byref(stride))
+        got = np.ascontiguousarray(np.ctypeslib.as_array(p, shape=(oh, stride.value)))
+        exp, es, _ = pipeline.cpu_decode(hm, pics, W, H, ow, oh, cols, grid is not None, chroma)
+        bpp = {10: 3, 14: 6}[chroma]
+        assert es == stride.value
+        np.testing.assert_array_equal(got[:, :ow * bpp], exp[:oh, :ow * bpp], err_msg=f"case {k}")
+        api.heif_image_release(img); api.heif_image_handle_release(h); api.heif_context_free(ctx)
