@@ -111,6 +111,9 @@ struct hm_batch {
   DeviceBuffer d_tail;
   hipStream_t copy_stream = nullptr;
   bool copy_inflight = false;
+  std::vector<hipStream_t> aux_streams; // further launch streams of the grouped execute
+  std::vector<hipEvent_t> join_evs;
+  hipEvent_t fork_ev = nullptr;
   hipStream_t last_stream = nullptr; // stream of the last upload / execute: drained before the arenas are released
   size_t total_pixels = 0;
   // optional per-kernel timing with HIP events on the launch stream (bench / profiling)
@@ -447,11 +450,57 @@ int hm_batch_execute(hm_batch* b, int stages, void* stream)
     const int n = (int)c.items.size(), n_img = (int)b->col_y.size();
     const int per_img = n / n_img;
     const hm_dev_pic* dc = d + c.desc_offset;
+    if (b->tail_state == 0) { const int rc0 = decide_tail(b); if (rc0) return rc0; }
+    static const int k_groups = [] { const char* e = std::getenv("HM_K_GROUPS"); return e ? atoi(e) : 0; }();
+    static const int k_streams = [] { const char* e = std::getenv("HM_K_STREAMS"); return e ? atoi(e) : 2; }();
+    static const int k_prio = [] { const char* e = std::getenv("HM_K_PRIO"); return e ? atoi(e) : 0; }();
+    static const int k_split = [] { const char* e = std::getenv("HM_K_SPLIT"); return e ? atoi(e) : 0; }(); // percent of the images in group 0 (2 groups)
+    if (b->tail_state == 2 && k_groups > 1 && n_img >= k_groups) {
+      mark(-1);
+      // EXPERIMENT: groups of images go round-robin over the caller's stream and k_streams - 1 others, so that the fused
+      // tail of one group runs while the reconstruction of another one does
+      const int ns = k_streams < 2 ? 2 : (k_streams > 8 ? 8 : k_streams);
+      if (b->aux_streams.empty()) {
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi); // lo = least priority (largest number)
+        for (int k = 1; k < ns; k++) {
+          hipStream_t t;
+          const int pr = k_prio ? (hi + k > lo ? lo : hi + k) : 0;
+          if (hipStreamCreateWithPriority(&t, hipStreamNonBlocking, pr) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipStreamCreate failed");
+          b->aux_streams.push_back(t);
+          hipEvent_t ev;
+          hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+          b->join_evs.push_back(ev);
+        }
+        hipEventCreateWithFlags(&b->fork_ev, hipEventDisableTiming);
+      }
+      hipEventRecord(b->fork_ev, s);
+      for (hipStream_t t : b->aux_streams) hipStreamWaitEvent(t, b->fork_ev, 0);
+      const TailDstHost* td = (const TailDstHost*)b->d_tail.p;
+      for (int g = 0; g < k_groups; g++) {
+        int i0 = (int)((long)n_img * g / k_groups), i1 = (int)((long)n_img * (g + 1) / k_groups);
+        if (k_groups == 2 && k_split > 0) { const int cut = (int)((long)n_img * k_split / 100); i0 = g ? cut : 0; i1 = g ? n_img : cut; }
+        const int m = (i1 - i0) * per_img;
+        if (m <= 0) continue;
+        const hm_dev_pic* dk = dc + (size_t)i0 * per_img;
+        const int si = g % ns;
+        hipStream_t sg = si ? b->aux_streams[(size_t)si - 1] : s;
+        int rc = launch_recon(dk, m, c, sg);
+        if (!rc) rc = hm_launch_tail420(dk, td + (size_t)i0 * per_img, m, c.max_w, c.max_h, b->tail_bpp, b->tail_coef, stages, sg);
+        if (rc) return rc;
+      }
+      for (size_t k = 0; k < b->aux_streams.size(); k++) {
+        hipEventRecord(b->join_evs[k], b->aux_streams[k]);
+        hipStreamWaitEvent(s, b->join_evs[k], 0);
+      }
+      mark(2); // (the whole step in the tail's slot: per-kernel intervals overlap)
+      b->exec_count++;
+      return HM_OK;
+    }
     mark(-1);
     int rc = launch_recon(dc, n, c, s);
     if (rc) return rc;
     mark(0);
-    if (b->tail_state == 0 && (rc = decide_tail(b))) return rc;
     if (b->tail_state == 2) { // one kernel for everything behind the reconstruction (timeline: the SAO + paste slot)
       if ((rc = hm_launch_tail420(dc, b->d_tail.p, n, c.max_w, c.max_h, b->tail_bpp, b->tail_coef, stages, s))) return rc;
       mark(2);
