@@ -95,6 +95,9 @@ int validate(const hm_colour_desc* d)
 
 } // namespace
 
+static int convert_planes(const hm_colour_desc* d, const hm_colour_plan& plan, bool own_profile_gone, const void* d_y, const void* d_cb, const void* d_cr,
+                          void* d_out, hipStream_t s);
+
 extern "C" {
 
 int hm_plane_stride(int width, int bytes_per_pixel) // pixelimage.cc:139-148,198-199
@@ -211,7 +214,38 @@ int hm_colour_convert(const hm_colour_desc* d, const void* d_y, const void* d_cb
     hm_pool_device_free(tmp);
     return rc ? rc : hm_check_hip(e, "monochrome colour chain");
   }
-  if (!d_y || !d_cb || !d_cr || !d_out) return hm_fail(HM_ERR_INVALID_ARG, "null device pointer");
+  if (!d_y || !d_out || (!plan.mono_expand && (!d_cb || !d_cr))) return hm_fail(HM_ERR_INVALID_ARG, "null device pointer");
+  const int bps0 = d->bit_depth > 8 ? 2 : 1;
+  if (plan.mono_expand) { // Op_mono_to_YCbCr420 (monochrome.cc:26-155): Cb = Cr = 128 << (depth - 8) at 4:2:0 size, then a plain 4:2:0 chain
+    hm_colour_desc e = *d;
+    e.chroma = HM_CHROMA_420;
+    const int ecw = (d->width + 1) / 2, ech = (d->height + 1) / 2;
+    e.cb_stride = e.cr_stride = hm_plane_stride(ecw, bps0);
+    // the op's output image carries the profile of a fresh ColorState: the sRGB defaults (colorconversion.cc:452-455,
+    // nclx.h:124), whatever the monochrome image declared
+    e.has_nclx = 1; e.matrix = 6; e.primaries = 1; e.full_range = 1;
+    const int erows = ((ech + 1) & ~1) < 64 ? 64 : ((ech + 1) & ~1);
+    const size_t cbytes = (size_t)e.cb_stride * erows;
+    uint8_t* neutral = (uint8_t*)hm_pool_device_alloc(cbytes); // one plane serves as Cb and as Cr
+    if (!neutral) return hm_fail(HM_ERR_NOMEM, "neutral chroma plane: %zu bytes of device memory", cbytes);
+    hipError_t he = bps0 == 1 ? hipMemsetAsync(neutral, 128, cbytes, s) : hipMemsetD16Async((hipDeviceptr_t)neutral, (unsigned short)(128 << (d->bit_depth - 8)), cbytes / 2, s);
+    rc = hm_check_hip(he, "neutral chroma plane");
+    if (!rc) rc = convert_planes(&e, plan, /*after_first_op=*/true, d_y, neutral, neutral, d_out, s);
+    he = hipStreamSynchronize(s); // the temporary goes back to the pool
+    hm_pool_device_free(neutral);
+    return rc ? rc : hm_check_hip(he, "monochrome colour chain");
+  }
+  return convert_planes(d, plan, plan.core_step > 0, d_y, d_cb, d_cr, d_out, s);
+}
+
+} // extern "C"
+
+// the chain of a Y / Cb / Cr image: [depth change] [bilinear] core op [depth change].  own_profile_gone: the op that turns
+// YCbCr into RGB is not the chain's first step
+static int convert_planes(const hm_colour_desc* d, const hm_colour_plan& plan, bool own_profile_gone, const void* d_y, const void* d_cb, const void* d_cr,
+                          void* d_out, hipStream_t s)
+{
+  int rc;
   const int bps0 = d->bit_depth > 8 ? 2 : 1;
   // the vector fast paths need 16 B aligned rows (true for every libheif-style plane)
   if ((d->y_stride % 16) || (d->cb_stride % 8) || (d->cr_stride % 8) || (d->out_stride % 16) ||
@@ -225,7 +259,7 @@ int hm_colour_convert(const hm_colour_desc* d, const void* d_y, const void* d_cb
 
   // The op that turns YCbCr into RGB sees the image's own nclx only when it is the chain's first step; behind another
   // op it sees the intermediate state's profile (second_step_desc).  Its planes: the image's, or temporaries.
-  hm_colour_desc cur = plan.core_step > 0 ? second_step_desc(d) : *d;
+  hm_colour_desc cur = own_profile_gone ? second_step_desc(d) : *d;
   const void* py = d_y; const void* pcb = d_cb; const void* pcr = d_cr;
   auto rows = [](int h) { const int r = (h + 1) & ~1; return r < 64 ? 64 : r; };
   uint8_t* tmp_depth = nullptr;
@@ -289,6 +323,8 @@ int hm_colour_convert(const hm_colour_desc* d, const void* d_y, const void* d_cb
   else if (m == 8) mode = 3;
   return finish(hm_launch_colour_float(&cur, cf, mode, py, pcb, pcr, d_out, s), "float colour chain");
 }
+
+extern "C" {
 
 // n images of identical state (one descriptor) in one go: the integer 4:2:0 chain runs as a single launch per 32
 // images; every other chain is converted image by image.  Same contract as hm_colour_convert.

@@ -301,6 +301,10 @@ int hm_colour_make_plan(const hm_colour_request* rq, hm_colour_plan* plan)
     plan->ops[i] = ops[i];
     switch (ops[i]) {
       case HM_OP_DROP_ALPHA_PLANE: break; // (the planes converted here never include it)
+      case HM_OP_MONO_TO_YCBCR420: // monochrome.cc:26-155: the chain continues as for a 4:2:0 image with neutral chroma
+        if (plan->core || plan->pre || plan->bilinear || plan->mono_expand) return HM_PLAN_UNSUPPORTED;
+        plan->mono_expand = 1;
+        break;
       case HM_OP_TO_HDR_PLANES:
       case HM_OP_TO_SDR_PLANES: {
         const int kind = ops[i] == HM_OP_TO_HDR_PLANES ? HM_DEPTH_TO_HDR : HM_DEPTH_TO_SDR;

@@ -58,6 +58,7 @@ enum { HM_PLAN_OK = 0, HM_PLAN_NO_CHAIN = 1, HM_PLAN_UNSUPPORTED = 2 };
 
 typedef struct hm_colour_plan {
   int n_ops, ops[HM_COLOUR_MAX_OPS]; // the chain (hm_colour_op)
+  int mono_expand;                   // Op_mono_to_YCbCr420 first: neutral chroma planes are added, the rest sees a 4:2:0 image with sRGB-default profile
   int pre, pre_bits;                 // depth change of the Y / Cb / Cr planes before the core op
   int bilinear;                      // chroma planes upsampled to 4:4:4 before the core op
   int core, core_bits, core_step;    // the YCbCr -> RGB op, the depth it works at, its position in the chain (0: it sees the image's own profile)

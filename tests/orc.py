@@ -243,7 +243,7 @@ def convert_by_search(planes, w, h, bpp, chroma, nclx, out_fmt, has_alpha=False,
     import pipeline_search as ps
     n = ps.Nclx(nclx[1], nclx[2], 2, bool(nclx[3])) if nclx[0] else None
     opts = ps.Options(ps.DOWN_AVERAGE, ps.UP_BILINEAR, forced_bilinear)
-    inp, tgt = ps.conversion_states(ps.CS_YCBCR, chroma, has_alpha, bpp, n, ps.CS_RGB, out_fmt)
+    inp, tgt = ps.conversion_states(ps.CS_MONO if chroma == 0 else ps.CS_YCBCR, chroma, has_alpha, bpp, n, ps.CS_RGB, out_fmt)
     steps = ps.construct_pipeline(inp, tgt, opts)
     assert steps is not None, "the reference finds no chain"
     chain = [name for name, _ in steps]
@@ -257,6 +257,18 @@ def convert_by_search(planes, w, h, bpp, chroma, nclx, out_fmt, has_alpha=False,
     for k, name in enumerate(chain):
         if name == "Op_drop_alpha_plane":
             pass
+        elif name == "Op_mono_to_YCbCr420":  # monochrome.cc:26-155: neutral chroma planes at 4:2:0 size
+            cur_chroma, cw, ch = 1, (w + 1) // 2, (h + 1) // 2
+            bps = 2 if bits > 8 else 1
+            cb = alloc_plane(cw, ch, bps)
+            if bps == 1:
+                cb[0][:] = 128
+            else:
+                cb[0].view(np.uint16)[:] = 128 << (bits - 8)
+            cr = cb
+            # the op's output state is a fresh ColorState: its profile is the sRGB default set (nclx.h:124), and that is
+            # what every later op reads off its input image (colorconversion.cc:452-455)
+            state_profile = (1, 6, 1, 1)
         elif name == "Op_to_hdr_planes":
             y, cb, cr = to_hdr(y, w, h, tgt.bpp), to_hdr(cb, cw, ch, tgt.bpp), to_hdr(cr, cw, ch, tgt.bpp)
             bits = tgt.bpp

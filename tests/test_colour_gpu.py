@@ -90,8 +90,8 @@ def test_float_hdr(pkg, w, h, chroma, bit_depth, nclx, out_fmt):
 
 def test_no_silent_fallback(pkg):
     """unsupported states fail loudly instead of falling back"""
-    d = pkg.capi.ColourDesc(64, 64, 8, 0, 0, 0, 0, 0, 14, 64, 0, 0, 384)  # monochrome -> RRGGBB: the reference's chain (via 4:2:0) is not offered
-    assert pkg.lib().hm_colour_pipeline(C.byref(d)) == -2
+    d = pkg.capi.ColourDesc(64, 64, 8, 0, 0, 0, 0, 0, 14, 64, 0, 0, 384)  # monochrome -> RRGGBB: offered (test_monochrome_to_16bit_targets)
+    assert pkg.lib().hm_colour_pipeline(C.byref(d)) >= 0
     d = pkg.capi.ColourDesc(64, 64, 8, 3, 1, 11, 1, 1, 10, 64, 64, 64, 192)  # matrix 11: every YCbCr -> RGB op of the reference refuses
     assert pkg.lib().hm_colour_pipeline(C.byref(d)) == -2
 
@@ -264,3 +264,31 @@ def test_8bit_to_rrggbb_chain(pkg, w, h, nclx, out_fmt):
     step2 = (1, 6 if m2 == 2 else m2, 1 if p2 == 2 else p2, nclx[3] if nclx[0] else 1)
     exp, es = orc.colour_float(hi[0], hi[1], hi[2], w, h, 10, 1, *step2, out_fmt)
     np.testing.assert_array_equal(got[:h, :w * obpp], exp[:h, :w * obpp])
+
+
+@pytest.mark.parametrize("w,h", [(64, 64), (33, 5), (1, 1), (1280, 854), (1023, 3)])
+@pytest.mark.parametrize("bit_depth", [8, 10, 12])
+@pytest.mark.parametrize("out_fmt", [12, 13, 14, 15])
+@pytest.mark.parametrize("has_alpha", [0, 1])
+def test_monochrome_to_16bit_targets(pkg, w, h, bit_depth, out_fmt, has_alpha):
+    """monochrome image -> RRGGBB[AA]: the reference's chain starts with Op_mono_to_YCbCr420 (neutral chroma planes,
+    monochrome.cc:26-155) and continues as for a 4:2:0 image whose profile is the sRGB default set - whatever the
+    monochrome image itself declared (limited range, BT.709 ...)"""
+    import torch
+    rng = np.random.default_rng(w * 7 + h + bit_depth + out_fmt)
+    bps = 2 if bit_depth > 8 else 1
+    y = orc.alloc_plane(w, h, bps, rng=rng, maxval=(1 << bit_depth) - 1)
+    capi, L = pkg.capi, pkg.lib()
+    obpp = orc.OUT_BYTES[out_fmt]
+    ostride = L.hm_plane_stride(w, obpp)
+    dev = torch.device("cuda:0")
+    for nclx in [(0, 0, 0, 0), (1, 1, 1, 0), (1, 9, 9, 1)]:
+        dy = torch.from_numpy(y[0]).to(dev)
+        dout = torch.zeros((max(64, (h + 1) & ~1), ostride), dtype=torch.uint8, device=dev)
+        d = capi.ColourDesc(w, h, bit_depth, 0, nclx[0], nclx[1], nclx[2], nclx[3], out_fmt, y[1], 0, 0, ostride, 0, has_alpha)
+        capi.check(L.hm_colour_convert(C.byref(d), dy.data_ptr(), None, None, dout.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        got = dout.cpu().numpy()
+        exp, es, chain = orc.convert_by_search([y, None, None], w, h, bit_depth, 0, nclx, out_fmt, has_alpha=bool(has_alpha))
+        assert "Op_mono_to_YCbCr420" in chain and es == ostride
+        np.testing.assert_array_equal(got[:h, :w * obpp], exp[:h, :w * obpp])

@@ -333,3 +333,28 @@ def test_range_extension_images_through_heif_decode_image(api, hm):
         assert es == stride.value
         np.testing.assert_array_equal(got[:, :ow * bpp], exp[:oh, :ow * bpp], err_msg=f"case {k}")
         api.heif_image_release(img); api.heif_image_handle_release(h); api.heif_context_free(ctx)
+
+
+def test_monochrome_image_to_16bit_targets(api, hm):
+    """heif_decode_image of a 4:0:0 item to RRGGBB_LE / RRGGBBAA_BE: the chain through Op_mono_to_YCbCr420 (rank 3 of SURVEY 8f)"""
+    import hevcutil
+    import orc
+    import synthutil
+    W, H = 96, 72
+    for bd in (8, 10):
+        pic = synthutil.picture(9400 + bd, width=W, height=H, chroma_format=0, bit_depth=bd, log2_ctb=4, vui=1, full_range=0, matrix=1)
+        data = heifwriter.write_heic([pic], (W, H), chroma_format=0, bit_depth=bd)
+        planes, info = orc.oracle_decode(hevcutil.parse(hm, pic), 3)
+        bps = 2 if bd > 8 else 1
+        y = orc.alloc_plane(W, H, bps)
+        y[0][:H, :W * bps] = np.ascontiguousarray(planes[0][:H, :W].astype(np.uint8 if bps == 1 else np.uint16)).view(np.uint8).reshape(H, W * bps)
+        for chroma, bpp in ((14, 6), (13, 8)):
+            ctx, h, img, e = _decode(api, data, 0, 1, chroma)
+            assert e.code == 0, (bd, chroma, e.message)
+            stride = C.c_int()
+            p = api.heif_image_get_plane_readonly(img, 10, C.byref(stride))
+            got = np.ascontiguousarray(np.ctypeslib.as_array(p, shape=(H, stride.value)))
+            exp, es, chain = orc.convert_by_search([y, None, None], W, H, bd, 0, (1, info["matrix"], info["primaries"], info["full_range"]), chroma)
+            assert chain[0] == "Op_mono_to_YCbCr420" and es == stride.value
+            np.testing.assert_array_equal(got[:, :W * bpp], exp[:H, :W * bpp])
+            api.heif_image_release(img); api.heif_image_handle_release(h); api.heif_context_free(ctx)
