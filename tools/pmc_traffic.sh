@@ -15,7 +15,7 @@ python3 - "$out" "$images" <<'PY'
 import csv, glob, json, os, sys
 from collections import defaultdict
 root, images = sys.argv[1], int(sys.argv[2])
-names = {"k_recon": "k_recon", "k_deblock": "k_deblock", "k_sao_paste": "k_sao_paste", "k_ycbcr420_int": "k_ycbcr420_int(colour)", "k_tail420": "k_tail420(deblock+sao+paste+colour)"}
+names = {"k_recon": "k_recon_quad", "k_deblock": "k_deblock", "k_sao_paste": "k_sao_paste", "k_ycbcr420_int": "k_ycbcr420_int(colour)", "k_tail420": "k_tail420(deblock+sao+paste+colour)"}
 acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob(os.path.join(root, c, "**", "*counter_collection.csv"), recursive=True):
