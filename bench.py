@@ -422,6 +422,7 @@ def side_legs(out, args, torch, pkg, dev, st, gb, kept, strides, stream_b):
     guarded(out, "host_entropy_decode", lambda: host_parse_rate(pkg, kept[0]))
     guarded(out, "wpp_row_parallel_parse", lambda: wpp_parse_rates(pkg))
     guarded(out, "colour_kernel_standalone", lambda: colour_standalone(torch, pkg, gb, st))
+    guarded(out, "kernels_grouped_streams", lambda: grouped_streams(torch, gb, st))
     guarded(out, "device_inclusive", lambda: device_inclusive(torch, pkg, dev, gb, st, stream_b))
     guarded(out, "end_to_end", lambda: end_to_end_single(pkg, kept[0]))
     guarded(out, "end_to_end_pipelined", lambda: end_to_end_pipelined(pkg, kept))
@@ -472,6 +473,38 @@ def colour_standalone(torch, pkg, gb, st):
             "GBps": round(4.5 * px / ms / 1e6, 1), "frac_of_hbm_peak": round(4.5 * px / ms / 1e6 / HBM_PEAK_GBPS, 4),
             "read_only_GBps": round(1.5 * px / ms / 1e6, 1), "read_only_frac_of_hbm_peak": round(1.5 * px / ms / 1e6 / HBM_PEAK_GBPS, 4),
             "note": "1.5 B/px read + 3 B/px written (SURVEY 8d: both conventions); part of the hot path only when the tail is not fused"}
+
+
+def grouped_streams(torch, gb, st):
+    """K clock with hm_batch_set_concurrency: the images of the step in 2 / 3 / 4 groups, each group's reconstruction and
+    fused tail on a stream of its own.  A side clock: kernels that run side by side have no separable launch times, so
+    `value` and `roofline` stay on the single-stream launches."""
+    B = len(gb.images)
+    res = {}
+    sample = list(range(0, B, max(1, B // 16)))
+    gb.batch.set_concurrency(0)
+    gb.step(st)  # (the legs before this one may have written other things into the output buffers)
+    torch.cuda.synchronize()
+    want = {i: gb.images[i]["rgb"].clone() for i in sample}  # what the (parity-gated) single-stream step produces
+    same = True
+    for groups in (2, 3, 4):
+        gb.batch.set_concurrency(groups)
+        for i in sample:
+            gb.images[i]["rgb"].zero_()
+        for _ in range(2):
+            gb.step(st)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            gb.step(st)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 5 * 1e3
+        res[f"{groups}_groups"] = {"ms_per_step": round(ms, 3), "MP_per_s": round(B * MP_PER_IMAGE / ms * 1e3, 1)}
+        same = same and all(torch.equal(gb.images[i]["rgb"], want[i]) for i in sample)
+    gb.batch.set_concurrency(0)
+    res["outputs_equal_single_stream"] = f"{'yes' if same else 'NO'} ({len(sample)} images compared in every mode)"
+    res["note"] = "same step as the headline, images split over streams inside hm_batch_execute (opt-in API); never `value`"
+    return res
 
 
 def device_inclusive(torch, pkg, dev, gb, st, stream_b):

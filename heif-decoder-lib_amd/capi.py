@@ -81,6 +81,7 @@ def bind_decode(L):
     L.hm_batch_tail_fused.restype = C.c_int
     L.hm_batch_set_colour.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.hm_batch_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.hm_batch_set_concurrency.argtypes = [C.c_void_p, C.c_int]
     L.hm_batch_get_timings.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     L.hm_batch_get_timings4.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     L.hm_batch_algorithmic_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -142,6 +143,9 @@ class Batch:
 
     def set_profiling(self, slots=1):
         check(self.L.hm_batch_set_profiling(self.h, int(slots)))
+
+    def set_concurrency(self, groups):
+        check(self.L.hm_batch_set_concurrency(self.h, int(groups)))
 
     def timings_ms(self, slot=0):
         ms = (C.c_float * 3)()

@@ -133,3 +133,36 @@ def test_fused_tail_equals_separate_kernels(pkg, hm, shape, stages):
         tiles = made[:cols * rows]
         exp = bench.cpu_grid_image([d for d, _ in tiles], [b for _, b in tiles], cols, rows, 512, w, h, (gb.ys, gb.cs, gb.os), orc.have_ref())
         assert np.array_equal(out[0][0], exp[:h, :w * 3])
+
+
+@pytest.mark.parametrize("groups", [2, 3, 8])
+def test_grouped_streams_equal_single_stream(pkg, hm, groups):
+    """hm_batch_set_concurrency: the images of a step as `groups` groups on streams of their own - the same pixels as the
+    single-stream step, execute after execute (the streams are joined on the caller's), also with fewer images than groups"""
+    import bench
+    import torch
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    n_images = 5
+    made = list(bench.make_streams(pkg.capi, (7800000 + 17 * k for k in range(n_images * 4))))
+    gb = bench.GridBatch(pkg, dev, 2, 2, 512, 1000, 900)
+    for j in range(n_images):
+        gb.add_image([b for _, b in made[j * 4:(j + 1) * 4]])
+    gb.finish(st, 0)
+    gb.batch.execute(3, st)
+    torch.cuda.synchronize()
+    assert gb.batch.tail_fused()
+    want = [im["rgb"].clone() for im in gb.images]
+    gb.batch.set_concurrency(groups)
+    for _ in range(3):
+        for im in gb.images:
+            im["rgb"].zero_()
+        gb.batch.execute(3, st)
+        torch.cuda.synchronize()
+        for j in range(n_images):
+            assert torch.equal(gb.images[j]["rgb"], want[j]), f"image {j}"
+    gb.batch.set_concurrency(0)
+    gb.batch.execute(3, st)
+    torch.cuda.synchronize()
+    assert all(torch.equal(gb.images[j]["rgb"], want[j]) for j in range(n_images))
+    gb.batch.close()
