@@ -129,6 +129,7 @@ struct hm_batch {
   {
     if (copy_inflight) { hipStreamSynchronize(copy_stream); copy_inflight = false; }
     if (inflight) { hipStreamSynchronize(last_stream); inflight = false; }
+    for (hipStream_t t : aux_streams) hipStreamSynchronize(t); // (joined on last_stream by every execute: idle here)
   }
   ~hm_batch()
   {
@@ -468,13 +469,25 @@ int hm_batch_execute(hm_batch* b, int stages, void* stream)
           if (hipStreamCreateWithFlags(&t, hipStreamNonBlocking) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipStreamCreate failed");
           b->aux_streams.push_back(t);
           hipEvent_t ev;
-          hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+          if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { hipStreamDestroy(b->aux_streams.back()); b->aux_streams.pop_back(); return hm_fail(HM_ERR_NO_DEVICE, "hipEventCreate failed"); }
           b->join_evs.push_back(ev);
         }
-        if (!b->fork_ev) hipEventCreateWithFlags(&b->fork_ev, hipEventDisableTiming);
       }
-      hipEventRecord(b->fork_ev, s);
-      for (hipStream_t t : b->aux_streams) hipStreamWaitEvent(t, b->fork_ev, 0);
+      if (!b->fork_ev && hipEventCreateWithFlags(&b->fork_ev, hipEventDisableTiming) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipEventCreate failed");
+      hipError_t he = hipEventRecord(b->fork_ev, s);
+      for (hipStream_t t : b->aux_streams)
+        if (he == hipSuccess) he = hipStreamWaitEvent(t, b->fork_ev, 0);
+      if (he != hipSuccess) return hm_check_hip(he, "fork of the launch streams");
+      // whatever happens below, the caller's stream waits for everything the other streams were given
+      auto join = [&]() {
+        hipError_t je = hipSuccess;
+        for (size_t k = 0; k < b->aux_streams.size(); k++) {
+          hipError_t e1 = hipEventRecord(b->join_evs[k], b->aux_streams[k]);
+          if (e1 == hipSuccess) e1 = hipStreamWaitEvent(s, b->join_evs[k], 0);
+          if (e1 != hipSuccess) { hipStreamSynchronize(b->aux_streams[k]); je = e1; }
+        }
+        return je;
+      };
       const TailDstHost* td = (const TailDstHost*)b->d_tail.p;
       for (int g = 0; g < k_groups; g++) {
         const int i0 = (int)((long)n_img * g / k_groups), i1 = (int)((long)n_img * (g + 1) / k_groups);
@@ -485,12 +498,9 @@ int hm_batch_execute(hm_batch* b, int stages, void* stream)
         hipStream_t sg = si ? b->aux_streams[(size_t)si - 1] : s;
         int rc = launch_recon(dk, m, c, sg);
         if (!rc) rc = hm_launch_tail420(dk, td + (size_t)i0 * per_img, m, c.max_w, c.max_h, b->tail_bpp, b->tail_coef, stages, sg);
-        if (rc) return rc;
+        if (rc) { join(); return rc; }
       }
-      for (size_t k = 0; k < b->aux_streams.size(); k++) {
-        hipEventRecord(b->join_evs[k], b->aux_streams[k]);
-        hipStreamWaitEvent(s, b->join_evs[k], 0);
-      }
+      if ((he = join()) != hipSuccess) return hm_check_hip(he, "join of the launch streams");
       mark(2); // (the whole step in the tail's slot: per-kernel intervals overlap)
       b->exec_count++;
       return HM_OK;
