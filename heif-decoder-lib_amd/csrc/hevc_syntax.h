@@ -228,6 +228,20 @@ struct PictureState {
   }
 };
 
+// n x n bytes of value v in a map `stride` bytes wide: the squares are 1 to 16 bytes wide, where a call to memset costs
+// more than the stores
+inline void fill_square(uint8_t* p, size_t stride, int n, uint8_t v)
+{
+  if (n == 1) { p[0] = v; return; }
+  if (n == 2) { p[0] = p[1] = v; p[stride] = p[stride + 1] = v; return; }
+  if (n == 4) {
+    const uint32_t w = 0x01010101u * v;
+    for (int j = 0; j < 4; j++) std::memcpy(p + j * stride, &w, 4);
+    return;
+  }
+  for (int j = 0; j < n; j++) std::memset(p + j * stride, v, (size_t)n);
+}
+
 template <class EC>
 class SliceWalker {
  public:
@@ -499,7 +513,7 @@ class SliceWalker {
       // record depth for later split_cu_flag contexts
       const int n = size >> sps_.log2_min_cb;
       const int bx = x0 >> sps_.log2_min_cb, by = y0 >> sps_.log2_min_cb;
-      for (int j = 0; j < n; j++) std::memset(&pic_.ct_depth[bx + (size_t)(by + j) * sps_.min_cb_w], cqtDepth, (size_t)n);
+      fill_square(&pic_.ct_depth[bx + (size_t)by * sps_.min_cb_w], (size_t)sps_.min_cb_w, n, (uint8_t)cqtDepth);
       coding_unit(x0, y0, log2CbSize);
     }
   }
@@ -565,7 +579,7 @@ class SliceWalker {
     // store QpY for the whole CU
     const int n = (1 << log2CbSize) >> sps_.log2_min_cb;
     const int bx = xCU >> sps_.log2_min_cb, by = yCU >> sps_.log2_min_cb;
-    for (int j = 0; j < n; j++) std::memset(&pic_.qpy[bx + (size_t)(by + j) * sps_.min_cb_w], qpy, (size_t)n);
+    fill_square(reinterpret_cast<uint8_t*>(&pic_.qpy[bx + (size_t)by * sps_.min_cb_w]), (size_t)sps_.min_cb_w, n, (uint8_t)(int8_t)qpy);
     qs_->current_qpy = qpy;
     cu_qpy_ = qpy;
   }
@@ -620,7 +634,7 @@ class SliceWalker {
       const int xP = x0 + (i & 1) * pbOffset, yP = y0 + (i >> 1) * pbOffset;
       const int mode = derive_luma_mode(xP, yP, prev_flag[i], mpm_idx[i], rem[i]);
       const int n4 = pbOffset >> 2;
-      for (int j = 0; j < n4; j++) std::memset(&pic_.intra_mode[(xP >> 2) + (size_t)((yP >> 2) + j) * w4_], mode, (size_t)n4);
+      fill_square(&pic_.intra_mode[(xP >> 2) + (size_t)(yP >> 2) * w4_], (size_t)w4_, n4, (uint8_t)mode);
       luma_mode_[i] = mode;
     }
     if (!nxn) luma_mode_[1] = luma_mode_[2] = luma_mode_[3] = luma_mode_[0];
@@ -993,7 +1007,7 @@ class SliceWalker {
     const int lastSub = st.sub_inv[scanIdx][log2sb][lastY >> 2][lastX >> 2];
     const int lastPos = st.pos_inv[scanIdx][lastY & 3][lastX & 3];
     uint8_t csbf[8][8];
-    std::memset(csbf, 0, sizeof(csbf));
+    if (log2 > 2) std::memset(csbf, 0, sizeof(csbf)); // (a 4x4 block: csbf[0][0] only, written before it is read)
     // range extensions (slice.cc:3172-3177, 3425-3432, 3565-3575, 3611-3655 of the reference)
     const bool flat_sig_ctx = sps_.transform_skip_context && (cu_bypass_ || tskip); // one sig_coeff_flag context per component
     const bool rdpcm = sps_.implicit_rdpcm && tskip && (predMode == 10 || predMode == 26); // (a bypass unit never hides signs)
