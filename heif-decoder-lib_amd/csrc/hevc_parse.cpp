@@ -351,7 +351,7 @@ struct Decoder {
                       pic.uses_pcm || pic.uses_tq_bypass || s.chroma_format_idc == 3 || s.transform_skip_rotation || s.implicit_rdpcm ||
                       s.intra_smoothing_disabled || p.cross_component_prediction ||
                       (p.transform_skip_enabled && p.log2_max_transform_skip_size > 2); // == HM_PIC_RARE_SYNTAX of the flags below
-    const bool split = !rare && !force_interleaved;
+    const bool split = !rare && !force_interleaved && quad_class(s);
     const bool direct = pic.direct; // the chains were written in their final form while parsing (hevc_syntax.h: PictureState::rows)
     if (direct && !split) throw ParseError(HM_ERR_INTERNAL, "direct chains of a picture with rare syntax");
     size_t n_tus = 0, n_levels = pic.coeffs.size();

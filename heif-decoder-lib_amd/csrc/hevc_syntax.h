@@ -169,6 +169,12 @@ static const uint8_t kMode422[35] = {0, 1, 2, 2, 2, 2, 3, 5, 7, 8, 10, 12, 13, 1
                                      21, 22, 23, 23, 24, 24, 25, 25, 26, 27, 27, 28, 28, 29, 29, 30, 31};
 } // namespace tables
 
+// Picture classes whose records go out as split chains for k_recon_quad: 8-bit samples, CTBs of 32 or 64.  Measured on
+// MI355X (profiles/r02_class_sweep.json, 1536 to 18432 tiles of 512x512): with 16-bit samples the one-row-per-wave
+// kernel k_recon is 1.1-1.8 times faster at every batch size (the quad kernel's four CTU buffers per wave take the LDS
+// that k_recon spends on more rows in flight: 3-11 waves per CU against 16), with 16x16 CTBs 1.1-1.3 times.
+inline bool quad_class(const SPS& s) { return s.bit_depth_y == 8 && s.log2_ctb >= 5; }
+
 // Per-picture state shared by all slice segments of the picture
 struct PictureState {
   const SPS* sps = nullptr;
@@ -215,7 +221,9 @@ struct PictureState {
     if ((int)ctb_tus.size() != n) ctb_tus.resize(n);
     for (auto& v : ctb_tus) v.clear();
     coeffs.clear();
-    direct = !(s.scaling_list_enabled || s.pcm_enabled || p.transquant_bypass_enabled || s.chroma_format_idc == 3 ||
+    // ... and only the classes the four-chains-per-wave kernel is the faster one for (quad_class)
+    direct = quad_class(s) &&
+             !(s.scaling_list_enabled || s.pcm_enabled || p.transquant_bypass_enabled || s.chroma_format_idc == 3 ||
                s.transform_skip_rotation || s.implicit_rdpcm || s.intra_smoothing_disabled || p.cross_component_prediction ||
                (p.transform_skip_enabled && p.log2_max_transform_skip_size > 2));
     if ((int)rows.size() != s.ctb_h) rows.resize((size_t)s.ctb_h);

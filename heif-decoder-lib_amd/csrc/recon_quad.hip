@@ -729,7 +729,7 @@ extern "C" int hm_launch_recon_quad(const hm_dev_pic* d_pics, int n_pics, int lo
   // by 160 KiB of LDS for 2W full-width sample lines, and by the waves the other pictures of the batch already supply.
   static const int force_w = [] { const char* e = getenv("HM_QUAD_WAVES"); return e ? atoi(e) : 0; }();
   QLayout L;
-  int lds_bytes = 0, np = 0;
+  int lds_bytes = 0, np = 0, cu_waves = 0; // cu_waves: waves one CU holds with this layout
   auto layout = [&](int W) {
     const int nrt = nr * W;
     L.waves_per_pic = W;
@@ -755,6 +755,7 @@ extern "C" int hm_launch_recon_quad(const hm_dev_pic* d_pics, int n_pics, int lo
       if (per_cu > best) { best = per_cu; np = k; }
     }
     if (np == 0) return false;
+    cu_waves = best;
     while (np > 1 && (long)np * 256 > n_pics) np--; // few pictures: spread them over the CUs first
     lds_bytes = Q_SHARED + np * L.pic_bytes;
     return true;
@@ -764,8 +765,13 @@ extern "C" int hm_launch_recon_quad(const hm_dev_pic* d_pics, int n_pics, int lo
   else {
     const int row_pairs = (max_ctb_h + nr - 1) / nr;             // W beyond this leaves waves without rows
     const int front = max_ctb_w / (2 * nr) > 1 ? max_ctb_w / (2 * nr) : 1; // ... beyond this, rows that only wait
-    // (4096 = 256 CUs x 16 waves: more waves per picture only while the pictures alone do not fill the machine)
-    while (W < 8 && 2 * W <= row_pairs && 2 * W <= front && (long)n_pics * W < 4096) W *= 2;
+    // More waves per picture only while all of them are resident at once (256 CUs x the waves a CU holds with the
+    // wider layout): beyond that the extra waves of a picture only queue behind other pictures while its rows wait
+    // for each other.  Measured on 1536 tiles (profiles/r02_class_sweep.json): 8-bit CTB 32: W = 2 4.3 ms, W = 4 5.4;
+    // 8-bit CTB 64: W = 1 6.5, W = 2 8.1; 12-bit 4:2:2 CTB 64: W = 1 19.7, W = 2 35.1.
+    static const int debug = [] { const char* e = getenv("HM_QUAD_DEBUG"); return e ? atoi(e) : 0; }();
+    while (W < 8 && 2 * W <= row_pairs && 2 * W <= front && layout(2 * W) && (long)n_pics * 2 * W <= 256L * cu_waves) W *= 2;
+    if (debug) { layout(W); fprintf(stderr, "[k_recon_quad] %d pictures, CTB %d, %d bytes/sample: W = %d, %d waves per CU\n", n_pics, ctb, pb, W, cu_waves); }
   }
   while (W > 1 && !layout(W)) W /= 2;
   if (!layout(W)) return 0;

@@ -26,7 +26,7 @@ def main():
     pkg = g.load_package()
     capi, L = pkg.capi, pkg.lib()
     dev = torch.device("cuda:0")
-    n = 1536
+    n = int(os.environ.get("HM_CLASS_TILES", "1536"))
     out = {}
     for name, kw in CLASSES.items():
         cfg = dict(width=512, height=512, qp=27, cu_qp_delta=1, sao=1, sign_hiding=1, density=60)
