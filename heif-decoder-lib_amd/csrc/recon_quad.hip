@@ -770,7 +770,10 @@ extern "C" int hm_launch_recon_quad(const hm_dev_pic* d_pics, int n_pics, int lo
     // for each other.  Measured on 1536 tiles (profiles/r02_class_sweep.json): 8-bit CTB 32: W = 2 4.3 ms, W = 4 5.4;
     // 8-bit CTB 64: W = 1 6.5, W = 2 8.1; 12-bit 4:2:2 CTB 64: W = 1 19.7, W = 2 35.1.
     static const int debug = [] { const char* e = getenv("HM_QUAD_DEBUG"); return e ? atoi(e) : 0; }();
-    while (W < 8 && 2 * W <= row_pairs && 2 * W <= front && layout(2 * W) && (long)n_pics * 2 * W <= 256L * cu_waves) W *= 2;
+    // The first doubling of 32x32-CTB pictures pays for up to 2.25 rounds (bench.py --images 48 / 96: 7.6 / 11.6 ms with
+    // W = 2 against 7.9 / 13.2 with W = 1; 192 images: 20.8 against 20.3).
+    while (W < 8 && 2 * W <= row_pairs && 2 * W <= front && layout(2 * W) &&
+           (long)n_pics * 2 * W <= (W == 1 && log2_ctb == 5 ? 576L : 256L) * cu_waves) W *= 2;
     if (debug) { layout(W); fprintf(stderr, "[k_recon_quad] %d pictures, CTB %d, %d bytes/sample: W = %d, %d waves per CU\n", n_pics, ctb, pb, W, cu_waves); }
   }
   while (W > 1 && !layout(W)) W /= 2;
