@@ -23,7 +23,7 @@ for j in range(n):
     tiles = [next(made)[0] for _ in range(NT)]
     files.append(heifwriter.write_heic(tiles, (512, 512), grid=(6, 8, 4032, 3024)))
 print("files ready", len(files), sum(map(len, files)) / 1e6, "MB", flush=True)
-for threads, depth in ((16, 8), (64, 16), (128, 32), (192, 32), (192, 64), (240, 96)):
+for threads, depth in ((14, 16), (15, 16), (16, 16), (17, 16), (18, 16), (20, 24), (24, 32), (32, 32)):
     pl = pipeline.Pipeline(hm, 10, host_threads=threads, max_in_flight=depth)
     for rnd in range(2):
         pend = 0
