@@ -47,7 +47,7 @@ constexpr int Q_SHARED = ((Q_SHARED_TABLES + Q_TAB4_BYTES + 15) & ~15) + ((BIG_B
 constexpr int Q_SCRATCH = 512 + 512 + 272 + 8 + NG * 16 * 8; // wave-wide path: coefficients, intermediate, reference samples; 4x4 gather slots
 
 struct QLayout {
-  int waves_per_pic; // W: waves working on one picture (1, 2, 4, 8), each on its own CTU rows
+  int waves_per_pic; // W: waves working on one picture (1 .. 8), each on its own CTU rows
   int pic_bytes;     // LDS per picture: the shared part (progress counters, sample lines) + W private parts
   int prog_ints;     // entries of one progress array (two arrays: luma chains, chroma chains)
   int off_lines_l;   // from the picture's base: luma sample lines (one per row in flight) ...
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
   const int Wc = ctb_w * cw_c;
   const bool mono = dp.chroma_format == 0;
   const int NR = mono ? 4 : 2; // CTU rows in flight per wave
-  const int NRT = NR * W;      // ... per picture (a power of two): row r is worked on by wave (r / NR) % W
+  const int NRT = NR * W;      // ... per picture: row r is worked on by wave (r / NR) % W
 
   // ---- the picture's shared LDS and this wave's private part ----
   uint8_t* const pbase = lds + Q_SHARED + (size_t)ps * L.pic_bytes;
@@ -272,6 +272,8 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
 
   // ---- group state (the same value in the 16 lanes of a group) ----
   int row = wi * NR + group_slot(g), cx = 0, kleft = 0;
+  // the sample lines are slots row % NRT; a group's rows are NRT apart, so its slot - and the slot of the row above - never change
+  const int line_above = row ? row - 1 : NRT - 1;
   int st = row < ctb_h ? ST_START : ST_DONE;
   int cb_flags = 0;
   uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0; // header of the CTU to start next: first record of the chain, count, flags, first level
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
     const unsigned long long s_big = __ballot(running && !quad);
 
     // the sample line of the row above (row 0 reads nothing from it)
-    const Pix* const lr = line_of(kind, (row + NRT - 1) & (NRT - 1));
+    const Pix* const lr = line_of(kind, line_above); // (row + NRT - 1) % NRT
 
     HM_MARK("C_begin");
     // ---- C: interior 4x4 blocks of all groups side by side, one sample per lane ----
@@ -491,13 +493,14 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
       const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)n0, src), r1 = (uint32_t)__builtin_amdgcn_readlane((int)n1, src);
       uint32_t w0 = r0, w1 = r1, w2 = (uint32_t)__builtin_amdgcn_readlane((int)loff, src);
       asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2)); // data fields: vector registers (see Blk)
-      const int s_row = __builtin_amdgcn_readlane(row, src), s_cx = __builtin_amdgcn_readlane(cx, src);
+      const int s_cx = __builtin_amdgcn_readlane(cx, src);
       const int s_flags = __builtin_amdgcn_readlane(cb_flags, src);
       Pix* const u0 = group_u(bg, 0);
       Pix* const u1 = group_u(bg, 1);
       Pix* const u2 = group_u(bg, 2);
       uint16_t* const l_meta = group_meta(bg);
-      const Pix* const blr = line_of(group_kind(bg), (s_row + NRT - 1) & (NRT - 1));
+      const int b_slot = wi * NR + group_slot(bg); // s_row % NRT: a group's rows are NRT apart
+      const Pix* const blr = line_of(group_kind(bg), b_slot ? b_slot - 1 : NRT - 1);
       const Pix* const top0 = blr + (s_cx << log2_ctb) - 1;
       const Pix* const top1 = blr + s_cx * cw_c - 1;
       const Pix* const top2 = blr + (Wc + 4) + s_cx * cw_c - 1;
@@ -616,7 +619,7 @@ __global__ __launch_bounds__(1024) void k_recon_quad(const hm_dev_pic* __restric
       const int src = fg * 16;
       const int s_row = __builtin_amdgcn_readlane(row, src), s_cx = __builtin_amdgcn_readlane(cx, src);
       const int fkind = group_kind(fg);
-      Pix* const lw = line_of(fkind, s_row & (NRT - 1));
+      Pix* const lw = line_of(fkind, wi * NR + group_slot(fg)); // s_row % NRT
       auto flush_plane = [&](auto bw_c, Pix* u, int P, Pix* line, uint8_t* plane, int pitch, int bh, int pw, int ph) {
         constexpr int BW = decltype(bw_c)::value;
         constexpr int PPW = 4 / sizeof(Pix), WPR = BW / PPW; // samples per 32-bit word, words per row
@@ -761,22 +764,25 @@ extern "C" int hm_launch_recon_quad(const hm_dev_pic* d_pics, int n_pics, int lo
     return true;
   };
   int W = 1;
-  if (force_w > 0) W = force_w;
+  if (force_w > 0) { W = force_w; while (W > 1 && !layout(W)) W--; }
   else {
     const int row_pairs = (max_ctb_h + nr - 1) / nr;             // W beyond this leaves waves without rows
     const int front = max_ctb_w / (2 * nr) > 1 ? max_ctb_w / (2 * nr) : 1; // ... beyond this, rows that only wait
-    // More waves per picture only while all of them are resident at once (256 CUs x the waves a CU holds with the
-    // wider layout): beyond that the extra waves of a picture only queue behind other pictures while its rows wait
-    // for each other.  Measured on 1536 tiles (profiles/r02_class_sweep.json): 8-bit CTB 32: W = 2 4.3 ms, W = 4 5.4;
-    // 8-bit CTB 64: W = 1 6.5, W = 2 8.1; 12-bit 4:2:2 CTB 64: W = 1 19.7, W = 2 35.1.
-    static const int debug = [] { const char* e = getenv("HM_QUAD_DEBUG"); return e ? atoi(e) : 0; }();
-    // The first doubling of 32x32-CTB pictures pays for up to 2.25 rounds (bench.py --images 48 / 96: 7.6 / 11.6 ms with
+    // The most waves per picture (up to 8) that the wavefront can keep busy, that fit the LDS, and that are all resident
+    // at once (256 CUs x the waves a CU holds with that layout): beyond that the extra waves of a picture only queue
+    // behind other pictures while its rows wait for each other.  Any count, not only powers of two (tools/shape_probe.py:
+    // one 4032x3024 picture 71 ms with W = 4, 44 ms with W = 7 - 8 do not fit the LDS; 1080p CTB 64: 13.6 ms with W = 4,
+    // 11.6 with W = 6; 2048x1536 10-bit 4:2:2: 29.1 ms with W = 4, 24.3 with W = 5).  Tiles (profiles/r02_class_sweep.json,
+    // 1536 of them): 8-bit CTB 32: W = 2 4.3 ms, W = 4 5.4; 8-bit CTB 64: W = 1 6.5, W = 2 8.1.
+    // The second wave of 32x32-CTB pictures pays for up to 2.25 rounds (bench.py --images 48 / 96: 7.6 / 11.6 ms with
     // W = 2 against 7.9 / 13.2 with W = 1; 192 images: 20.8 against 20.3).
-    while (W < 8 && 2 * W <= row_pairs && 2 * W <= front && layout(2 * W) &&
-           (long)n_pics * 2 * W <= (W == 1 && log2_ctb == 5 ? 576L : 256L) * cu_waves) W *= 2;
-    if (debug) { layout(W); fprintf(stderr, "[k_recon_quad] %d pictures, CTB %d, %d bytes/sample: W = %d, %d waves per CU\n", n_pics, ctb, pb, W, cu_waves); }
+    static const int debug = [] { const char* e = getenv("HM_QUAD_DEBUG"); return e ? atoi(e) : 0; }();
+    int limit = row_pairs < front ? row_pairs : front;
+    if (limit > 8) limit = 8;
+    for (W = limit; W > 1; W--)
+      if (layout(W) && (long)n_pics * W <= (W == 2 && log2_ctb == 5 ? 576L : 256L) * cu_waves) break;
+    if (debug) { layout(W); fprintf(stderr, "[k_recon_quad] %d pictures %dx%d CTBs of %d, %d bytes/sample: W = %d, %d waves per CU\n", n_pics, max_ctb_w, max_ctb_h, ctb, pb, W, cu_waves); }
   }
-  while (W > 1 && !layout(W)) W /= 2;
   if (!layout(W)) return 0;
   const void* fn = nullptr;
   switch (log2_ctb * 2 + (pb - 1)) {

@@ -153,3 +153,22 @@ def test_range_extension_large_blocks(pkg):
             for c in range(len(exp)):
                 bad = np.argwhere(g[c] != exp[c])
                 assert bad.size == 0, f"seed {seed} {kw} stages {bits} plane {c}: {len(bad)} mismatches, first (y,x)={bad[0].tolist()}"
+
+
+@pytest.mark.parametrize("shape", [dict(width=2304, height=1296, log2_ctb=5), dict(width=1920, height=1080, log2_ctb=4),
+                                   dict(width=1600, height=1200, log2_ctb=6, bit_depth=10), dict(width=2048, height=1152, log2_ctb=5, chroma_format=2, bit_depth=10),
+                                   dict(width=1536, height=1024, log2_ctb=6, chroma_format=0)],
+                         ids=["8bit_ctb32", "8bit_ctb16", "10bit_ctb64", "10bit_422_ctb32", "mono_ctb64"])
+def test_large_single_pictures(pkg, shape):
+    """pictures of a megapixel or more go to k_recon_quad in every class, with as many waves per picture as the wavefront,
+    the LDS and the machine allow - 3, 5, 6, 7 as well as powers of two (sample lines are handed from wave to wave through
+    LDS slots row % (rows in flight)): HIP == oracle"""
+    import synthutil
+    blob = pkg.capi.parse_hevc(synthutil.picture(424242, qp=30, density=40, **shape))
+    assert int.from_bytes(blob[36:40], "little") & 0x1000  # split chains: the quad kernel
+    got = gpudecode.decode_pictures(pkg, [blob, blob], 3)
+    exp, _ = orc.oracle_decode(blob, 3, crop=True)
+    for g in got:
+        for c in range(len(exp)):
+            bad = np.argwhere(g[c] != exp[c])
+            assert bad.size == 0, f"{shape} plane {c}: {len(bad)} mismatches, first (y,x)={bad[0].tolist()}"

@@ -13,6 +13,9 @@ for name, (w, h, n, kw) in {
     "10b420_1920x1080_ctb64_x8": (1920, 1080, 8, dict(bit_depth=10, log2_ctb=6)),
     "10b420_1024x1024_ctb32_x64": (1024, 1024, 64, dict(bit_depth=10, log2_ctb=5)),
     "8b420_1920x1080_ctb16_x8": (1920, 1080, 8, dict(log2_ctb=4)),
+    "8b420_1920x1080_ctb64_x8": (1920, 1080, 8, dict(log2_ctb=6)),
+    "8b420_1920x1080_ctb64_x1": (1920, 1080, 1, dict(log2_ctb=6)),
+    "8b420_4032x3024_ctb32_x1": (4032, 3024, 1, dict(log2_ctb=5)),
     "8b420_4096x2304_ctb32_x4": (4096, 2304, 4, dict(log2_ctb=5)),
 }.items():
     blob = capi.parse_hevc(synthutil.picture(4220010, width=w, height=h, qp=30, **kw))
@@ -35,4 +38,4 @@ for name, (w, h, n, kw) in {
     torch.cuda.synchronize()
     out[name] = round(sum(batch.timings_ms(s)[0] for s in range(3)) / 3, 3)
     batch.close()
-print(os.environ.get("HM_QUAD_CLASS"), json.dumps(out))
+print(os.environ.get("HM_QUAD_CLASS"), os.environ.get("HM_QUAD_WAVES"), json.dumps(out))
