@@ -172,3 +172,36 @@ def test_large_single_pictures(pkg, shape):
         for c in range(len(exp)):
             bad = np.argwhere(g[c] != exp[c])
             assert bad.size == 0, f"{shape} plane {c}: {len(bad)} mismatches, first (y,x)={bad[0].tolist()}"
+
+
+def test_corrupted_but_parsable_streams(pkg, hm):
+    """differential check on wild syntax: bit flips in the slice data of streams of every kernel class; whatever the
+    parser still accepts (the entropy decoder re-synchronises on other - extreme - modes, levels and QPs) must come out of
+    the HIP kernels exactly as out of the oracle, at the reconstruction stage and after the filters.  (tools/fuzz_gpu.py
+    runs the same with thousands of streams; tools/fuzz_ref.py compares parser + oracle with the reference decoder.)"""
+    import random
+    import hevcutil
+    rng = random.Random(20260)
+    blobs, tags = [], []
+    for name in ("ragged", "ctb64_wpp", "hi422_10", "ctb16_nosao", "pcm_bypass_sl_wpp", "yuv444_rare", "rext_cross_444_all", "rext_ts_bypass_422_10",
+                 "slices_headers", "tiles_3x2_nolf", "dense_lowqp", "sl_sps_12bit_highqp"):
+        data = corpus.stream(name)
+        got = tries = 0
+        while got < 8 and tries < 600:
+            tries += 1
+            b = bytearray(data)
+            for _ in range(rng.randrange(1, 4)):
+                b[rng.randrange(len(b) // 3, len(b))] ^= 1 << rng.randrange(8)
+            try:
+                blobs.append(hevcutil.parse(hm, bytes(b)))
+            except RuntimeError:
+                continue
+            tags.append((name, tries))
+            got += 1
+    assert len(blobs) > 60
+    for bits in (0, 3):
+        out = gpudecode.decode_pictures(pkg, blobs, bits)
+        for tag, blob, g in zip(tags, blobs, out):
+            exp, _ = orc.oracle_decode(blob, bits, crop=True)
+            for c in range(len(exp)):
+                assert np.array_equal(g[c], exp[c]), f"{tag} stages {bits} plane {c}"
