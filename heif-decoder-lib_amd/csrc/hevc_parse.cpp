@@ -82,6 +82,7 @@ struct Decoder {
   PictureState pic;
   std::vector<uint8_t> rbsp; // unescaped NAL, reused
   std::vector<uint32_t> removed; // positions of its emulation prevention bytes in the escaped NAL
+  bool decode_order = false; // records of the current picture in decode order although it has no rare syntax
   int threads = 1;           // > 1: slice segments with WPP entry points are parsed row-parallel (parse_rows_parallel)
   void start_stream()
   {
@@ -151,7 +152,10 @@ struct Decoder {
       pic.reset(s, p);
       {
         static const bool interleaved = [] { const char* e = std::getenv("HM_STREAM_INTERLEAVED"); return e && e[0] == '1'; }();
-        if (interleaved) pic.direct = false;
+        // (hm_tls_few_pictures: the caller decodes one image of a few small pictures - the one-row-per-wave kernel, which
+        //  reads records in decode order, has the shorter critical path there; large pictures keep the quad kernel)
+        decode_order = interleaved || (hm_tls_few_pictures && (long)s.width * s.height < (1L << 20));
+        if (decode_order) pic.direct = false;
       }
       pic_started = true;
       next_ts = 0;
@@ -351,7 +355,7 @@ struct Decoder {
                       pic.uses_pcm || pic.uses_tq_bypass || s.chroma_format_idc == 3 || s.transform_skip_rotation || s.implicit_rdpcm ||
                       s.intra_smoothing_disabled || p.cross_component_prediction ||
                       (p.transform_skip_enabled && p.log2_max_transform_skip_size > 2); // == HM_PIC_RARE_SYNTAX of the flags below
-    const bool split = !rare && !force_interleaved && quad_class(s);
+    const bool split = !rare && !force_interleaved && !decode_order && quad_class(s);
     const bool direct = pic.direct; // the chains were written in their final form while parsing (hevc_syntax.h: PictureState::rows)
     if (direct && !split) throw ParseError(HM_ERR_INTERNAL, "direct chains of a picture with rare syntax");
     size_t n_tus = 0, n_levels = pic.coeffs.size();

@@ -515,7 +515,9 @@ void job_parse_tile(DecodeJob& j, int k, int row_threads)
   std::vector<uint8_t> data;
   hm::HeifError e;
   if (!j.f->file.hevc_data(P.tiles[k].id, data, e)) { P.status[k] = e.status; P.messages[k] = e.message; return; }
+  hm_tls_few_pictures = j.few_pictures;
   const int rc = hm_hevc_parse_mt(data.data(), data.size(), 0, row_threads, &P.blobs[k].p, &P.blobs[k].n);
+  hm_tls_few_pictures = 0;
   if (rc) { P.status[k] = rc; P.messages[k] = hm_last_error(); }
 }
 
@@ -672,6 +674,7 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
   // ---- host: entropy-decode every coded picture (CABAC on the CPU, spread over threads like the reference's
   //      heif_context_set_threads tile fan-out, context.cc:2361-2401) ----
   const int nt = job_tile_count(job);
+  job.few_pictures = nt <= 64; // one image at a time: its tiles are the whole batch (single 12 MP grid: 6.95 -> 6.65 ms)
   std::atomic<int> next{0};
   int nthreads = params->host_threads > 0 ? params->host_threads : 1;
   // fewer coded pictures than threads (a single image, or an image and its alpha plane): the threads left over parse

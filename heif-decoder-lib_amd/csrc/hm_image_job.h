@@ -88,6 +88,7 @@ struct DecodeJob {
   DevPlane alpha_scaled;
   DevPlane alpha_sdr; // a deeper alpha plane brought to 8 bits (Op_to_sdr_planes) for an RGBA target
   DevMem dout;
+  int few_pictures = 0; // the parser may write decode-order records for small pictures (hm_internal.h: hm_tls_few_pictures)
   bool enqueued = false;
   // everything above is touched by asynchronous work: the stream is drained before any of it is released (the pool may
   // hand a freed block to another thread at once)

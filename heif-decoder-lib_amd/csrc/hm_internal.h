@@ -47,6 +47,8 @@ void hm_pool_pinned_free(void* p);
 
 // recon.hip / filters.hip
 struct hm_dev_pic;
+// set (per thread) around hm_hevc_parse* by callers whose batch is one image of a few small pictures (hm_decode_item)
+extern thread_local int hm_tls_few_pictures;
 int hm_batch_add_trusted(hm_batch* b, const uint8_t* blob, size_t size, const hm_tile_dest* dest); // no structural validation
 int hm_launch_recon(const struct hm_dev_pic* d_pics, int n_pics, int log2_ctb, int chroma_format, int bit_depth, int rare_syntax,
                     int max_ctb_w, int max_ctb_h, hipStream_t s);
