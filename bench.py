@@ -149,35 +149,45 @@ def timed_steps(torch, gb, st, steps, dist=None):
     if dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    k_ms = [0.0, 0.0, 0.0, 0.0]  # recon, deblock, sao+paste, colour
+    k_ms = [0.0, 0.0, 0.0, 0.0, 0.0]  # prediction chains (or the whole reconstruction), deblock, sao+paste, colour, residual pre-pass
     for i in range(steps):
-        ms = gb.batch.timings4_ms(i)
-        for q in range(4):
+        ms = gb.batch.timings5_ms(i)
+        for q in range(5):
             k_ms[q] += ms[q]
     gb.batch.set_profiling(0)
     return elapsed, [m / steps for m in k_ms]
 
 
-# names as rocprofv3 lists them (the headline workload - 8-bit 4:2:0 without rare syntax - runs the four-chains-per-wave reconstruction)
-KERNEL_NAMES = ["k_recon_quad", "k_deblock", "k_sao_paste", "k_ycbcr420_int(colour)"]
+# names as rocprofv3 lists them (the headline workload - 8-bit 4:2:0 without rare syntax - runs the split-chain
+# reconstruction: k_residual, then k_chain; HM_CHAIN=0 selects r02's single kernel k_recon_quad for A/B runs)
+OLD_RECON = os.environ.get("HM_CHAIN", "1") == "0"
+KERNEL_NAMES = ["k_recon_quad" if OLD_RECON else "k_chain", "k_deblock", "k_sao_paste", "k_ycbcr420_int(colour)", "k_residual"]
 TAIL_NAME = "k_tail420(deblock+sao+paste+colour)"  # the fused kernel: timing slot 2, slots 1 and 3 are empty
 
 
 def kernel_names(gb):
-    return [KERNEL_NAMES[0], None, TAIL_NAME, None] if gb.batch.tail_fused() else KERNEL_NAMES
+    names = list(KERNEL_NAMES)
+    if gb.batch.tail_fused():
+        names[1], names[2], names[3] = None, TAIL_NAME, None
+    if OLD_RECON:
+        names[4] = None
+    return names
 
 
 def kernel_table(gb, avg_ms, colour_bytes_per_px=4.5):
-    stream_b, sample_b = gb.batch.algorithmic_bytes()
-    # algorithmic bytes per step of each kernel: recon = command stream + samples out; deblock = read +
-    # write of the samples; sao+paste = read + write; colour = 1.5 B in + 3 B out per output pixel
-    alg = [stream_b + sample_b, 2 * sample_b, 2 * sample_b, int(colour_bytes_per_px * gb.pixels())]
+    stream_b, sample_b, level_b, resid_b = gb.batch.algorithmic_bytes4()
+    # algorithmic bytes per step of each kernel: residual pre-pass = command stream in + residual samples
+    # out; prediction chains = command stream without the levels + residual in + samples out (r02's single kernel:
+    # command stream + samples out); deblock = read + write of the samples; sao+paste = read + write; colour = 1.5 B in +
+    # 3 B out per output pixel
+    chain_b = stream_b + sample_b if OLD_RECON else stream_b - level_b + resid_b + sample_b
+    alg = [chain_b, 2 * sample_b, 2 * sample_b, int(colour_bytes_per_px * gb.pixels()), stream_b + resid_b]
     names = kernel_names(gb)
     if gb.batch.tail_fused():  # reads the reconstruction once, writes the pixels once
-        alg = [stream_b + sample_b, 0, sample_b + int((colour_bytes_per_px - 1.5) * gb.pixels()), 0]
+        alg[1], alg[2], alg[3] = 0, sample_b + int((colour_bytes_per_px - 1.5) * gb.pixels()), 0
     table = {names[q]: {"ms_per_step": round(avg_ms[q], 4), "algorithmic_bytes": int(alg[q]),
                         "GBps": round(alg[q] / avg_ms[q] / 1e6, 1) if avg_ms[q] > 0 else None,
-                        "frac_of_hbm_peak": round(alg[q] / avg_ms[q] / 1e6 / HBM_PEAK_GBPS, 4) if avg_ms[q] > 0 else None} for q in range(4) if names[q]}
+                        "frac_of_hbm_peak": round(alg[q] / avg_ms[q] / 1e6 / HBM_PEAK_GBPS, 4) if avg_ms[q] > 0 else None} for q in (4, 0, 1, 2, 3) if names[q]}
     # the north star's "HBM-read roofline" taken literally: only the 1.5 B/px the colour kernel reads (report both)
     cms = avg_ms[3]
     if cms > 0 and names[3]:
@@ -335,7 +345,7 @@ def run(args):
         total_mp = world * B * MP_PER_IMAGE * args.steps
         value = total_mp / elapsed
         kernels, alg, stream_b = kernel_table(gb, avg_ms)
-        dom = max(range(4), key=lambda q: avg_ms[q])
+        dom = max(range(5), key=lambda q: avg_ms[q])
         achieved = alg[dom] / avg_ms[dom] / 1e6
         out = {
             "metric": "megapixels/sec HEIC grid->RGB24",
@@ -680,7 +690,7 @@ def real_content(torch, pkg, dev, st):
         mp = n * 1920 * 1080 / 1e6
         stream_b, sample_b = gb.batch.algorithmic_bytes()
         res[name] = {"MP_per_s": round(mp * 5 / elapsed, 1), "command_stream_bytes_per_pixel": round(stream_b / (n * 1920 * 1088), 3),
-                     "ms_per_MP": {kernel_names(gb)[q]: round(avg_ms[q] / mp, 5) for q in range(4) if kernel_names(gb)[q]}}
+                     "ms_per_MP": {kernel_names(gb)[q]: round(avg_ms[q] / mp, 5) for q in (4, 0, 1, 2, 3) if kernel_names(gb)[q]}}
         gb.batch.close()
         gb.images.clear()
         torch.cuda.empty_cache()

@@ -84,6 +84,7 @@ def bind_decode(L):
     L.hm_batch_set_concurrency.argtypes = [C.c_void_p, C.c_int]
     L.hm_batch_get_timings.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     L.hm_batch_get_timings4.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+    L.hm_batch_get_timings5.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     L.hm_batch_algorithmic_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
 
 
@@ -157,9 +158,22 @@ class Batch:
         check(self.L.hm_batch_get_timings4(self.h, slot, ms))
         return [ms[0], ms[1], ms[2], ms[3]]
 
+    def timings5_ms(self, slot=0):
+        """[chains (or the whole reconstruction), deblocking, SAO + paste (or the fused tail), colour, residual pre-pass]"""
+        ms = (C.c_float * 5)()
+        check(self.L.hm_batch_get_timings5(self.h, slot, ms))
+        return [ms[i] for i in range(5)]
+
     def tail_fused(self):
         """True when the batch's executes run the fused tail kernel (timings4_ms: its time is in slot 2)"""
         return bool(self.L.hm_batch_tail_fused(self.h))
+
+    def algorithmic_bytes4(self):
+        """(command streams, reconstructed samples, levels, residual samples) in bytes"""
+        v = (C.c_uint64 * 4)()
+        self.L.hm_batch_algorithmic_bytes4.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        check(self.L.hm_batch_algorithmic_bytes4(self.h, v))
+        return [int(x) for x in v]
 
     def algorithmic_bytes(self):
         a, b = C.c_uint64(), C.c_uint64()

@@ -74,14 +74,36 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // reconstruction of the pictures of one class: pictures whose records come as separate luma / chroma chains
 // (HM_PIC_SPLIT_CHAINS: everything without rare syntax) run the four-chains-per-wave kernel, the others (records in
 // decode order) the one-row-per-wave kernel
-int launch_recon(const hm_dev_pic* dc, int n, const Class& c, hipStream_t s)
+// (`mid`, if given, is called between the two kernels of the split-chain path: the profiling marks)
+template <typename Mid>
+int launch_recon(const hm_dev_pic* dc, int n, const Class& c, hipStream_t s, Mid&& mid)
 {
   if (c.split) {
-    const int q = hm_launch_recon_quad(dc, n, c.log2_ctb, c.chroma_format, c.bit_depth, c.rare, c.max_ctb_w, c.max_ctb_h, s);
+    // HM_CHAIN=0: the r02 kernel (dequantisation + transforms on the dependency chain), kept for A/B measurements
+    static const bool old_kernel = [] { const char* e = std::getenv("HM_CHAIN"); return e && e[0] == '0'; }();
+    if (!old_kernel) {
+      const int rc = hm_launch_residual(dc, n, c.max_ctb_h, s);
+      if (rc) return rc;
+      mid();
+    }
+    const int q = old_kernel ? hm_launch_recon_quad(dc, n, c.log2_ctb, c.chroma_format, c.bit_depth, c.rare, c.max_ctb_w, c.max_ctb_h, s)
+                             : hm_launch_chain(dc, n, c.log2_ctb, c.chroma_format, c.bit_depth, c.rare, c.max_ctb_w, c.max_ctb_h, s);
     if (q == 0) return hm_fail(HM_ERR_UNSUPPORTED, "CTU staging does not fit LDS (CTB %d, %d bit, %d CTBs wide)", 1 << c.log2_ctb, c.bit_depth, c.max_ctb_w);
     return q < 0 ? q : HM_OK;
   }
   return hm_launch_recon(dc, n, c.log2_ctb, c.chroma_format, c.bit_depth, c.rare, c.max_ctb_w, c.max_ctb_h, s);
+}
+int launch_recon(const hm_dev_pic* dc, int n, const Class& c, hipStream_t s) { return launch_recon(dc, n, c, s, [] {}); }
+
+// bytes of the residual buffer of a picture with split chains (recon_common.h: ResidGeom): int16 per sample of the
+// CTB-aligned planes
+size_t resid_bytes(const hm_pic& h)
+{
+  if (!(h.flags & HM_PIC_SPLIT_CHAINS)) return 0;
+  const size_t ctb = (size_t)1 << h.log2_ctb;
+  const size_t luma = (size_t)h.ctb_w * h.ctb_h * ctb * ctb;
+  const size_t chroma = h.chroma_format == 0 ? 0 : 2 * (size_t)h.ctb_w * h.ctb_h * (ctb / 2) * (h.chroma_format == 1 ? ctb / 2 : ctb);
+  return 2 * (luma + chroma);
 }
 
 } // namespace
@@ -120,7 +142,8 @@ struct hm_batch {
   // optional per-kernel timing with HIP events on the launch stream (bench / profiling)
   int profiling = 0;                // number of timing slots (0 = off)
   // per slot: events on the launch stream; the interval that ends at event i belongs to kernel kind[i]
-  // (-1 start marker, 0 reconstruction, 1 deblocking, 2 SAO + paste, 3 colour conversion)
+  // (-1 start marker, 0 reconstruction (split chains: the chain kernel), 1 deblocking, 2 SAO + paste, 3 colour conversion,
+  //  4 residual pre-pass of the split-chain reconstruction)
   struct Timeline { std::vector<hipEvent_t> ev; std::vector<int8_t> kind; size_t used = 0; };
   std::vector<Timeline> timelines;
   long exec_count = 0;
@@ -306,7 +329,7 @@ static int batch_prepare(hm_batch* b, size_t* blob_bytes_out)
     const int swc = h.chroma_format == 3 ? 1 : 2;
     const size_t py = align_up((size_t)h.width * bps, 64), pc = align_up((size_t)(h.width / swc) * bps, 64);
     const size_t w4 = (h.width + 3) >> 2, h4 = (h.height + 3) >> 2;
-    work_bytes += align_up(py * h.height, 256) + 2 * align_up(pc * (h.height / sh), 256) + 2 * align_up(w4 * h4, 256);
+    work_bytes += align_up(py * h.height, 256) + 2 * align_up(pc * (h.height / sh), 256) + 2 * align_up(w4 * h4, 256) + align_up(resid_bytes(h), 256);
     b->total_pixels += (size_t)h.width * h.height;
   }
   int rc;
@@ -336,6 +359,8 @@ static int batch_prepare(hm_batch* b, size_t* blob_bytes_out)
       d.plane[2] = wp; wp += align_up(pc * (h.height / sh), 256);
       d.pitch[0] = (int)py; d.pitch[1] = d.pitch[2] = (int)pc;
       d.meta = (uint16_t*)wp; // 2 bytes per 4x4 block (the size reserved above)
+      wp += 2 * align_up(w4 * h4, 256);
+      d.resid = resid_bytes(h) ? (int16_t*)wp : nullptr;
       d.w4 = (int)w4; d.h4 = (int)h4;
       d.width = h.width; d.height = h.height;
       d.chroma_format = h.chroma_format;
@@ -506,7 +531,7 @@ int hm_batch_execute(hm_batch* b, int stages, void* stream)
       return HM_OK;
     }
     mark(-1);
-    int rc = launch_recon(dc, n, c, s);
+    int rc = launch_recon(dc, n, c, s, [&] { mark(4); });
     if (rc) return rc;
     mark(0);
     if (b->tail_state == 2) { // one kernel for everything behind the reconstruction (timeline: the SAO + paste slot)
@@ -534,7 +559,7 @@ int hm_batch_execute(hm_batch* b, int stages, void* stream)
     const hm_dev_pic* dc = d + c.desc_offset;
     const int n = (int)c.items.size();
     mark(-1);
-    int rc = launch_recon(dc, n, c, s);
+    int rc = launch_recon(dc, n, c, s, [&] { mark(4); });
     if (rc) return rc;
     mark(0);
     if (stages & 1) {
@@ -686,10 +711,12 @@ int hm_batch_set_profiling(hm_batch* b, int slots)
 
 // Kernel times (ms) of the execute call recorded in `slot` (= call index modulo the slot count):
 // recon, deblock, SAO+paste [, colour conversion when attached].  Synchronises on the recorded events.
-int hm_batch_get_timings4(hm_batch* b, int slot, float ms[4])
+// hm_batch_get_timings5: [4] = the residual pre-pass (k_residual) separately, [0] = the rest of the reconstruction;
+// hm_batch_get_timings4 / hm_batch_get_timings report the two together in [0].
+static int batch_timings(hm_batch* b, int slot, float ms[5])
 {
   if (!b || !ms) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
-  ms[0] = ms[1] = ms[2] = ms[3] = 0.f;
+  ms[0] = ms[1] = ms[2] = ms[3] = ms[4] = 0.f;
   if (!b->profiling || slot < 0 || slot >= b->profiling || slot >= b->exec_count || slot >= (int)b->timelines.size() || b->timelines[slot].used == 0)
     return hm_fail(HM_ERR_INVALID_ARG, "profiling not enabled or slot not recorded");
   const hm_batch::Timeline& t = b->timelines[slot];
@@ -703,6 +730,14 @@ int hm_batch_get_timings4(hm_batch* b, int slot, float ms[4])
     ms[t.kind[i]] += v;
   }
   return HM_OK;
+}
+int hm_batch_get_timings5(hm_batch* b, int slot, float ms[5]) { return batch_timings(b, slot, ms); }
+int hm_batch_get_timings4(hm_batch* b, int slot, float ms[4])
+{
+  float v[5];
+  const int rc = batch_timings(b, slot, v);
+  if (!rc) { ms[0] = v[0] + v[4]; ms[1] = v[1]; ms[2] = v[2]; ms[3] = v[3]; }
+  return rc;
 }
 int hm_batch_get_timings(hm_batch* b, int slot, float ms[3])
 {
@@ -727,6 +762,29 @@ int hm_batch_algorithmic_bytes(const hm_batch* b, uint64_t* stream_bytes, uint64
   }
   *stream_bytes = sb;
   *sample_bytes = pb;
+  return HM_OK;
+}
+
+// The same split by kernel for the pictures with split chains (bench.py: per-kernel roofline lines).  out[0] = command
+// stream bytes, [1] = reconstructed sample bytes, [2] = bytes of the levels (hm_coeff: read by k_residual only),
+// [3] = bytes of the residual samples k_residual writes and k_chain reads (int16 per sample of a block with cbf).
+// Walks the records of the queued streams (host arena): a measurement aid, not on any decode path.
+int hm_batch_algorithmic_bytes4(const hm_batch* b, uint64_t out[4])
+{
+  if (!b || !out) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
+  int rc = hm_batch_algorithmic_bytes(b, &out[0], &out[1]);
+  if (rc) return rc;
+  out[2] = out[3] = 0;
+  for (const Item& it : b->items) {
+    const hm_pic& h = it.hdr;
+    out[2] += (uint64_t)h.n_coeffs * sizeof(hm_coeff);
+    if (!(h.flags & HM_PIC_SPLIT_CHAINS)) continue;
+    const hm_tu8* t = reinterpret_cast<const hm_tu8*>(b->stage.p + it.stage_off + h.off_tus);
+    uint64_t samples = 0;
+    for (uint32_t i = 0; i < h.n_tus; i++)
+      if (t[i].info & HM_TU_CBF) samples += (uint64_t)1 << (2 * (t[i].info & HM_TU_LOG2_MASK));
+    out[3] += 2 * samples;
+  }
   return HM_OK;
 }
 

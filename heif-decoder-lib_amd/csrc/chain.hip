@@ -1,0 +1,648 @@
+// chain.hip — k_chain: the intra-prediction chains of HEVC-intra reconstruction, third generation.
+//
+// SURVEY §8a rows R4-R5 (reference samples intrapred.h:536-836, smoothing / planar / DC / angular intrapred.h:192-441)
+// plus the add of the residual that residual.hip's pre-pass left in HBM (rows R1-R3 run there, off the dependency
+// chain).  What is left on the chain of a CTU row is: take the block's neighbours, predict, add, clip, store.
+//
+// Mapping (as recon_quad.hip, which this kernel replaces): one wave per coded picture (tile batches) or per pair of CTU
+// rows (few, large pictures: PAIRS, below); its four 16-lane groups each own a block chain - luma and chroma of two CTU
+// rows (monochrome: luma of four) -; per loop iteration every group executes one block: interior 4x4 blocks of all
+// groups side by side (lane = sample, one table read for both reference positions + weight of any angular mode), every
+// other block wave-wide, one group after the other.
+//
+// What is new against recon_quad.hip (profiles/r02_pmc_sq_counters.json: 2.48 VALU wave-instructions per sample, the
+// kernel bound by instruction issue, not by bytes):
+//   * no dequantisation / transform here (residual.hip); the residual of a block arrives as int16 samples, requested
+//     two blocks ahead (4x4: one sample per lane of the group; larger: the first 64 samples wave-wide before the
+//     side-by-side phase);
+//   * the per-block control is decoded ONCE, 16 records at a time, by the group's own 16 lanes (lane = record) into a
+//     ring of 16-byte micro-ops in LDS: LDS offsets of the left column / the row above, clamp limits of the two runs,
+//     mode, flags, the place of the residual (a 16-lane DPP scan of the block sizes), the deblocking word.  A block
+//     then costs one ds_read_b128 and a few unpacks instead of ~25 instructions of field extraction and address
+//     arithmetic per group per block, and the four-deep register pipeline of raw records is gone;
+//   * PAIRS (few, large pictures): every pair of CTU rows of a picture is a wave of its own - any number of them, in
+//     any workgroup -, ordered by a ticket taken at start (a wave only ever waits for a wave with a smaller ticket, which
+//     is running or done: no deadlock whatever the dispatch order).  The hand-over between pairs goes through HBM: the
+//     bottom sample row of a pair is a row of the picture the kernel stores anyway; a per-row progress word
+//     (agent scope) tells the pair below how far it is.  Every wait is bounded: a wave that waits too long sets the
+//     launch's error word and leaves, the host reports HM_ERR_INTERNAL.
+// Several pictures (waves) share a workgroup only to share the constant tables in LDS.
+// Pictures with rare syntax (scaling lists, PCM, transquant bypass, 4:4:4, range extensions) stay on recon.hip's RARE
+// variant.  Integer work, HBM-write-only picture: no MFMA.
+#include "recon_common.h"
+
+#include <stdlib.h>
+
+#include "hm_internal.h"
+
+namespace {
+
+#ifdef HM_MARKS
+#define HM_MARK(name) asm volatile("s_nop 0 ; HMMARK " name)
+#else
+#define HM_MARK(name)
+#endif
+
+constexpr int NG = 4;                       // groups per wave
+constexpr int C_SHARED_TABLES = 256;        // small tables (recon.hip layout: angles, inverse angles)
+constexpr int C_TAB4_BYTES = 35 * 16 * 2;   // per (mode, sample) of a 4x4 block: reference positions + weight
+constexpr int C_SHARED = (C_SHARED_TABLES + C_TAB4_BYTES + 15) & ~15;
+constexpr int C_RING = 32;                  // micro-ops per group: two windows of 16 records
+constexpr int C_SCRATCH = 272 + 8;          // wave-wide path: reference samples (bA)
+constexpr int C_RING_BYTES = NG * C_RING * 16;
+
+// micro-op (uint4): x = lp | tp << 16 (sample offsets: lp from the group's plane base to sample (x0-1, y0); tp to sample
+// (x0, y0-1) from the same base or - OP_LINE - from the CTU's start in the sample line of the row above),
+// y = flags below, z = first residual sample, w = qpy | pos << 8 | availability bits
+constexpr uint32_t OP_MODE_MASK = 63u;
+constexpr int OP_C_SHIFT = 6, OP_L2_SHIFT = 8; // colour component (2 bits), log2 size - 2 (2 bits)
+constexpr uint32_t OP_CBF = 1u << 10, OP_INTERIOR = 1u << 11, OP_LINE = 1u << 13;
+constexpr int OP_NL1_SHIFT = 14, OP_NT1_SHIFT = 20; // last usable position of the left / top run (6 bits each)
+constexpr uint32_t OPW_LEFT = 1u << 16, OPW_TOP = 1u << 17, OPW_TL = 1u << 18;
+constexpr int OPW_BL_SHIFT = 19, OPW_TR_SHIFT = 23; // below-left / top-right counts in units of 4 (4 bits each)
+
+struct CLayout {
+  int pic_bytes;     // LDS per picture (= per wave): progress counters, sample lines, scratch, rings, CTU buffers
+  int prog_ints;     // entries of one progress array (two arrays: luma chains, chroma chains)
+  int off_lines_l;   // luma sample lines (one per row in flight) ...
+  int line_l_bytes;
+  int off_lines_c;   // ... and chroma sample lines (Cb then Cr)
+  int line_c_bytes;
+  int off_scratch;
+  int off_rings;
+  int off_groups;    // per row of the wave: [luma chain: block map, CTU buffer][chroma chain: Cb, Cr CTU buffers]
+  int luma_bytes, chroma_bytes;
+};
+
+template <int CTRL>
+__device__ __forceinline__ int dpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+constexpr int DPP_ROW_ROR(int n) { return 0x120 | n; }
+constexpr int DPP_ROW_SHR(int n) { return 0x110 | n; }
+
+enum { ST_START = 0, ST_RUN = 1, ST_DONE = 2 };
+
+typedef uint32_t c_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t c_u32x2 __attribute__((ext_vector_type(2)));
+
+template <typename Pix, int LOG2_CTB>
+__global__ __launch_bounds__(1024) void k_chain(const hm_dev_pic* __restrict__ pics, int n_pics, CLayout L)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = rfl(tid >> 6);
+  constexpr int log2_ctb = LOG2_CTB, ctb = 1 << log2_ctb;
+
+  // ---- workgroup-wide tables ----
+  int16_t* const tab = reinterpret_cast<int16_t*>(lds);
+  uint16_t* const tab4 = reinterpret_cast<uint16_t*>(lds + C_SHARED_TABLES);
+  for (int i = tid; i < 70; i += blockDim.x) { // [0,35) angle, [35,70) inverse angle (0 where unused)
+    int v;
+    if (i < 35) v = c_intra_angle[i];
+    else v = (i - 35 >= 11 && i - 35 <= 25) ? c_inv_angle[i - 35 - 11] : 0;
+    tab[i] = (int16_t)v;
+  }
+  // 4x4 predictor table: for sample (x, y) of a block with mode m the two reference samples j0, j1 (index into the
+  // 4nT+1 border: negative = left column downwards, 0 = corner, positive = top row) and the weight of the second,
+  // exactly as predict_emit<> of recon_common.h derives them (intrapred.h:338-441).  Planar / DC / pure vertical / pure
+  // horizontal: the sample above and the sample left of (x, y), which is what their formulas and edge filters use.
+  for (int i = tid; i < 35 * 16; i += blockDim.x) {
+    const int mode = i >> 4, x = i & 3, y = (i >> 2) & 3;
+    int j0, j1, f = 0;
+    if (mode == 0 || mode == 1 || mode == 26) { j0 = x + 1; j1 = -(y + 1); }
+    else if (mode == 10) { j0 = -(y + 1); j1 = x + 1; }
+    else {
+      const int angle = c_intra_angle[mode];
+      const bool vert = mode >= 18;
+      const int major = vert ? y : x, minor = vert ? x : y;
+      const int t = (major + 1) * angle;
+      const int iIdx = t >> 5;
+      f = t & 31;
+      const int k0 = minor + iIdx + 1, k1 = k0 + 1;
+      const int sgn = vert ? 1 : -1;
+      if (angle > 0) { j0 = sgn * k0; j1 = sgn * k1; }
+      else {
+        const int inv = c_inv_angle[mode - 11];
+        const int q0 = -((k0 * inv + 128) >> 8), q1 = -((k1 * inv + 128) >> 8);
+        j0 = sgn * (k0 >= 0 ? k0 : q0);
+        j1 = sgn * (k1 >= 0 ? k1 : q1);
+      }
+    }
+    // |j| reaches 2nT + 1 = 9 only for the second sample of a position whose weight f is 0: any legal index will do
+    j0 = j0 < -8 ? -8 : (j0 > 8 ? 8 : j0);
+    j1 = j1 < -8 ? -8 : (j1 > 8 ? 8 : j1);
+    tab4[i] = (uint16_t)((j0 + 8) | ((j1 + 8) << 5) | (f << 10));
+  }
+  // ---- this wave's task ----
+  const int pic_index = blockIdx.x * (int)(blockDim.x >> 6) + wave;
+  uint8_t* const pbase = lds + C_SHARED + (size_t)wave * L.pic_bytes;
+  int* const progress = reinterpret_cast<int*>(pbase); // [2][prog_ints]: finished CTUs of every row, per chain kind
+  for (int i = lane; i < 2 * L.prog_ints; i += 64) progress[i] = 0;
+  __syncthreads();
+  if (pic_index >= n_pics) return;
+
+  const hm_dev_pic dp = pics[pic_index];
+  const uint8_t* blob = dp.blob;
+  const GLOBAL_AS hm_pic* H = gptr<hm_pic>(blob);
+  const GLOBAL_AS uint32_t* ctbq = gptr<uint32_t>(blob + H->off_ctbs);   // HM_CTB_DWORDS dwords per hm_ctb
+  const GLOBAL_AS uint32_t* tus = gptr<uint32_t>(blob + H->off_tus);     // 2 dwords per hm_tu8 (hm_stream.h)
+  const GLOBAL_AS int16_t* const resid = gptr<int16_t>(dp.resid);
+  const uint32_t n_tus = H->n_tus;
+  const int ctb_w = dp.ctb_w, ctb_h = dp.ctb_h;
+  const int sh = dp.chroma_format == 1 ? 2 : 1;
+  const int bd = sizeof(Pix) == 1 ? 8 : dp.bit_depth;
+  constexpr int P0 = ctb + UPAD, cw_c = ctb >> 1, P1 = cw_c + UPAD;
+  const int ch_c = ctb / sh;
+  const int strong = dp.flags & HM_PIC_STRONG_INTRA_SMOOTHING;
+  const int Wc = ctb_w * cw_c;
+  const bool mono = dp.chroma_format == 0;
+  const int NR = mono ? 4 : 2; // CTU rows in flight per wave
+  const ResidGeom RG = resid_geom(ctb_w, ctb_h, log2_ctb, dp.chroma_format);
+  const uint32_t res_last = RG.total ? RG.total - 1 : 0;
+
+  // ---- this wave's LDS ----
+  uint8_t* const lines_l = pbase + L.off_lines_l;
+  uint8_t* const lines_c = pbase + L.off_lines_c;
+  int16_t* const l_bA = reinterpret_cast<int16_t*>(pbase + L.off_scratch);
+  c_u32x4* const rings = reinterpret_cast<c_u32x4*>(pbase + L.off_rings); // [NG][C_RING]
+  // group -> (chain kind, row slot): luma / chroma of two rows, or luma of four rows (monochrome)
+  auto group_kind = [&](int gg) { return mono ? 0 : (gg & 1); };
+  auto group_slot = [&](int gg) { return mono ? gg : (gg >> 1); };
+  auto group_base = [&](int gg) -> uint8_t* {
+    return pbase + L.off_groups + (mono ? (size_t)gg * L.luma_bytes : (size_t)(gg >> 1) * (L.luma_bytes + L.chroma_bytes) + (size_t)(gg & 1) * L.luma_bytes);
+  };
+  auto group_meta = [&](int gg) { return reinterpret_cast<uint16_t*>(group_base(gg)); }; // luma groups only
+  auto group_u = [&](int gg, int c) { // plane c of the group's chain (luma groups: c = 0; chroma groups: c = 1, 2)
+    uint8_t* p = group_base(gg);
+    if (c == 0) p += META_BYTES(ctb);
+    if (c == 2) p += (size_t)P1 * ch_c * sizeof(Pix);
+    return reinterpret_cast<Pix*>(p);
+  };
+  // sample line `slot` of a chain kind: luma sample 0 / Cb sample 0 (Cr sample 0 is Wc + 4 samples further)
+  auto line_of = [&](int kind, int slot) {
+    uint8_t* p = kind ? lines_c + (size_t)slot * L.line_c_bytes : lines_l + (size_t)slot * L.line_l_bytes;
+    return reinterpret_cast<Pix*>(p) + 4;
+  };
+
+  // ---- per-lane constants ----
+  const int g = lane >> 4, gl = lane & 15, bx_ = gl & 3, by_ = gl >> 2;
+  const int kind = group_kind(g); // 0: luma chain, 1: chroma chain
+  Pix* const gbase = group_u(g, kind ? 1 : 0); // CTU buffer of the luma plane / of Cb (Cr: P1 * ch_c samples further)
+  const int Pk = kind ? P1 : P0;               // pitch of the chain's CTU buffers
+  const int l2w = kind ? log2_ctb - 1 : log2_ctb; // log2 of the CTU width in samples of the chain's planes
+  const int cr_off = P1 * ch_c;                // Cr buffer behind the Cb buffer, in samples
+  uint16_t* const gmeta = group_meta(g);
+  int* const my_progress = progress + kind * L.prog_ints;
+  c_u32x4* const ring = rings + g * C_RING;
+  // byte offsets in LDS of the group's places, for the wave-wide path (fetched from the group's first lane)
+  const uint32_t gb_off = (uint32_t)(reinterpret_cast<uint8_t*>(gbase) - lds);
+  const uint32_t meta_off = (uint32_t)(reinterpret_cast<uint8_t*>(gmeta) - lds);
+
+  // ---- group state (the same value in the 16 lanes of a group) ----
+  int row = group_slot(g), cx = 0, kleft = 0;
+  // the sample lines are slots row % NR; a group's rows are NR apart, so its slot - and the slot of the row above - never change
+  const int my_slot = group_slot(g);
+  const int line_above = my_slot ? my_slot - 1 : NR - 1;
+  const Pix* const lr = line_of(kind, line_above);
+  const uint32_t lr_off = (uint32_t)(reinterpret_cast<const uint8_t*>(lr) - lds);
+  uint32_t tl_off = lr_off; // the CTU's first sample in the sample line of the row above: lr + (cx << l2w)
+  int st = row < ctb_h ? ST_START : ST_DONE;
+  int cb_flags = 0;
+  uint32_t c0 = 0, c1 = 0, c2 = 0; // header of the CTU to start next: first record of the chain, count, flags
+  uint32_t ri = 0;                 // index of the current block's record
+  uint32_t rfirst = 0;             // first record of the row's chain
+  uint32_t wnext = 0;              // next window (16 records: index >> 4) to decode into the ring
+  uint32_t rbase = 0;              // first residual sample of window wnext's first record
+  uint32_t pf0 = 0, pf1 = 0;       // raw record 16 * wnext + gl, requested when the window before it was decoded
+  int primed = 0;                  // the residual pipeline holds the samples of blocks ri, ri + 1, ri + 2
+  uint32_t pre = 0, pre_m = 0, lv = 0; // residual sample gl of the current block, the next one, the one after (in flight)
+  auto load_window = [&](uint32_t w) {
+    uint32_t idx = (w << 4) + (uint32_t)gl;
+    idx = idx < n_tus - 1 ? idx : n_tus - 1; // past the last record of the picture: re-read it (never executed)
+    const c_u32x2 v = *reinterpret_cast<const GLOBAL_AS c_u32x2*>(tus + 2 * (size_t)idx);
+    pf0 = v.x; pf1 = v.y;
+  };
+  auto res_of = [&](uint32_t first) -> uint32_t { // residual sample gl of the block whose residual starts at `first`
+    uint32_t idx = first + (uint32_t)gl;
+    idx = idx < res_last ? idx : res_last; // (blocks without residual and records past the chain: some valid word nobody looks at)
+    return (uint32_t)(int)resid[idx];
+  };
+  auto header = [&](int r, int x) { // chain header of CTU (r, x): first record, count, flags
+    const GLOBAL_AS uint32_t* q = ctbq + HM_CTB_DWORDS * ((size_t)r * ctb_w + x);
+    c0 = q[kind ? 9 : 0]; c1 = q[kind ? 10 : 1]; c2 = q[2]; // (masked where they are used: no wait for the loads here)
+  };
+  auto row_start = [&]() { // header of CTU (row, 0) and the first window of the row's chain
+    header(row, 0);
+    ri = rfirst = c0;
+    wnext = ri >> 4;
+    rbase = RG.slab(kind, row);
+    load_window(wnext);
+    primed = 0;
+  };
+  if (st == ST_START) row_start();
+  // every iteration executes a block of some chain or waits for a CTU that is at most two CTUs of another chain away
+  int budget = (int)n_tus + 64 * ctb_w * ctb_h + 4096;
+
+  for (;;) {
+    HM_MARK("A_begin");
+    // ---- A: start the next CTU of every group whose dependency is met (the row above two CTUs ahead) ----
+    bool started = false;
+    if (st == ST_START) {
+      const int need = cx + 2 < ctb_w ? cx + 2 : ctb_w;
+      // (a counter value seen here means the line samples written before it are there: LDS traffic of a wave is in order)
+      const int done_above = __hip_atomic_load(my_progress + (row > 0 ? row - 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (row == 0 || done_above >= need) {
+        kleft = (int)(c1 & 0xFFFF);
+        cb_flags = (int)(c2 & 0xFF);
+        st = ST_RUN;
+        started = true;
+      }
+    }
+    if (__ballot(started)) { // (wave-uniform: the loads below are not merged with anything, so nobody waits for them here)
+      // every lane asks for the header its chain needs next: a group inside CTU cx the one of cx + 1 (the last CTU of a
+      // row: its own again), a waiting group the one of the CTU it waits to start
+      const int hx = st == ST_RUN ? (cx + 1 < ctb_w ? cx + 1 : cx) : cx;
+      header(row < ctb_h ? row : ctb_h - 1, hx);
+    }
+    if (__ballot(st != ST_DONE) == 0) break;
+    if (--budget < 0) break; // (never on a valid stream: a wave that cannot finish leaves a wrong picture, not a hung GPU)
+
+    HM_MARK("R_begin");
+    // ---- R: decode the next 16 records of every group that has entered the last decoded window ----
+    {
+      const bool need_dec = st != ST_DONE && wnext <= (ri >> 4) + 1;
+      if (__ballot(need_dec)) {
+        if (need_dec) {
+          const uint32_t r0 = pf0, r1 = pf1;
+          const uint32_t idx = (wnext << 4) + (uint32_t)gl;
+          const int x4 = (int)(r0 & 15), y4 = (int)((r0 >> 4) & 15);
+          const uint32_t info = (r0 >> 8) & 0xFF;
+          const int l2 = (int)(info & HM_TU_LOG2_MASK), c = (int)((info >> HM_TU_CIDX_SHIFT) & 3);
+          const uint32_t mode = (r0 >> 16) & OP_MODE_MASK;
+          const bool cbf = (info & HM_TU_CBF) != 0;
+          const int nT = 1 << l2;
+          const uint32_t aBL4 = (r1 >> 8) & 15, aTR4 = (r1 >> 12) & 15;
+          const bool left = (r1 & ((uint32_t)HM_TU8_LEFT << 16)) != 0, top = (r1 & ((uint32_t)HM_TU8_TOP << 16)) != 0, tl = (info & HM_TU_AVAIL_TL) != 0;
+          const int x0 = x4 << 2;
+          const int lp = mul24(y4 << 2, Pk) + UPAD + x0 - 1 + (c == 2 ? cr_off : 0);
+          const bool on_line = y4 == 0;
+          const int tp = on_line ? x0 + (c == 2 ? Wc + 4 : 0) : lp - Pk + 1;
+          const uint32_t nL1 = (uint32_t)(nT - 1) + (aBL4 << 2), nT1 = (uint32_t)(nT - 1) + (aTR4 << 2);
+          uint32_t rsz = (cbf && idx >= rfirst) ? 16u << (2 * (l2 - 2)) : 0u;
+          // inclusive scan over the 16 lanes of the group (= one DPP row)
+          uint32_t s = rsz;
+          s += (uint32_t)dpp<DPP_ROW_SHR(1)>((int)s);
+          s += (uint32_t)dpp<DPP_ROW_SHR(2)>((int)s);
+          s += (uint32_t)dpp<DPP_ROW_SHR(4)>((int)s);
+          s += (uint32_t)dpp<DPP_ROW_SHR(8)>((int)s);
+          c_u32x4 op;
+          op.x = (uint32_t)lp | ((uint32_t)tp << 16);
+          op.y = mode | ((uint32_t)c << OP_C_SHIFT) | ((uint32_t)(l2 - 2) << OP_L2_SHIFT) | (cbf ? OP_CBF : 0u) | ((left && top && tl) ? OP_INTERIOR : 0u) |
+                 (on_line ? OP_LINE : 0u) | (nL1 << OP_NL1_SHIFT) | (nT1 << OP_NT1_SHIFT);
+          op.z = rbase + s - rsz;
+          op.w = (r1 & 0xFF) | ((r0 & 0xFF) << 8) | (left ? OPW_LEFT : 0u) | (top ? OPW_TOP : 0u) | (tl ? OPW_TL : 0u) | (aBL4 << OPW_BL_SHIFT) | (aTR4 << OPW_TR_SHIFT);
+          ring[idx & (C_RING - 1)] = op;
+          rbase += (uint32_t)__shfl((int)s, (lane & 48) | 15);
+          wnext += 1;
+        }
+        load_window(wnext); // every lane: the window its group decodes next (groups that did not decode ask again for the same)
+        WAVE_SYNC();
+      }
+    }
+    // ---- the residual pipeline of a group that has both windows of a new row: blocks ri, ri + 1, ri + 2 ----
+    {
+      const bool prime = st != ST_DONE && !primed && wnext >= (ri >> 4) + 2;
+      if (__ballot(prime)) {
+        if (prime) {
+          pre = res_of(ring[ri & (C_RING - 1)].z);
+          pre_m = res_of(ring[(ri + 1) & (C_RING - 1)].z);
+          lv = res_of(ring[(ri + 2) & (C_RING - 1)].z);
+          primed = 1;
+        }
+      }
+    }
+    const bool running = st == ST_RUN && kleft > 0 && primed;
+
+    // the current block of every group
+    const c_u32x4 op = ring[ri & (C_RING - 1)];
+    const bool quad = running && (op.y & (3u << OP_L2_SHIFT)) == 0 && (op.y & OP_INTERIOR);
+    const unsigned long long s_big = __ballot(running && !quad);
+
+    // ---- P: residual of the blocks of the wave-wide path: their first 64 samples, requested before the side-by-side phase ----
+    uint32_t bres0 = 0, bres1 = 0, bres2 = 0, bres3 = 0;
+    if (s_big) {
+      auto big_res = [&](int gg) -> uint32_t {
+        uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)op.z, gg * 16) + (uint32_t)lane;
+        idx = idx < res_last ? idx : res_last;
+        return (uint32_t)(int)resid[idx];
+      };
+      if (s_big & 0xFFFFull) bres0 = big_res(0);
+      if (s_big & 0xFFFF0000ull) bres1 = big_res(1);
+      if (s_big & 0xFFFF00000000ull) bres2 = big_res(2);
+      if (s_big & 0xFFFF000000000000ull) bres3 = big_res(3);
+    }
+
+    HM_MARK("C_begin");
+    // ---- C: interior 4x4 blocks of all groups side by side, one sample per lane ----
+#if defined(HM_Q_PROBE) && (HM_Q_PROBE & 1)
+    if (false) {
+#else
+    if (quad) {
+#endif
+      int bx = bx_, by = by_;
+      asm volatile("" : "+v"(bx), "+v"(by)); // (loop-invariant lane masks cost scalar registers the kernel does not have)
+      const int mode = (int)(op.y & OP_MODE_MASK);
+      const int P = Pk;
+      Pix* const lp = gbase + (op.x & 0xFFFF);                                  // sample (x0-1, y0): walks down the left column
+      const Pix* const tbase = reinterpret_cast<const Pix*>(lds + ((op.y & OP_LINE) ? tl_off : gb_off));
+      const Pix* const tp = tbase + (op.x >> 16);                               // sample (x0, y0-1): walks along the row above; tp[-1] = corner
+      const int nL1 = (int)((op.y >> OP_NL1_SHIFT) & 63), nT1 = (int)((op.y >> OP_NT1_SHIFT) & 63);
+      const uint32_t e = tab4[mode * 16 + gl];
+      const int j0 = (int)(e & 31) - 8, j1 = (int)((e >> 5) & 31) - 8, f = (int)(e >> 10);
+      auto ref = [&](int j) -> int {
+        const Pix* const ql = lp + mul24(imin_(-j - 1, nL1), P);
+        const Pix* const qt = tp + imin_(j - 1, nT1);
+        return *(j < 0 ? ql : qt);
+      };
+      const int r0 = ref(j0), r1 = ref(j1);
+      const int maxv = (1 << bd) - 1;
+      int v = (mul24(32 - f, r0) + mul24(f, r1) + 16) >> 5; // every angular mode; f = 0: a copy of r0
+      if (mode == 0) { // planar: r0 = sample above, r1 = sample to the left
+        const int tr = tp[imin_(4, nT1)], bl = lp[mul24(imin_(4, nL1), P)];
+        v = (mul24(3 - bx, r1) + mul24(bx + 1, tr) + mul24(3 - by, r0) + mul24(by + 1, bl) + 4) >> 3;
+      }
+      else if (mode == 1) { // DC of the four samples above and the four to the left; luma: smoothed first row / column
+        int s = (by == 0 ? r0 : 0) + (bx == 0 ? r1 : 0);
+        s += dpp<DPP_ROW_ROR(8)>(s);
+        s += dpp<DPP_ROW_ROR(4)>(s);
+        s += dpp<DPP_ROW_ROR(2)>(s);
+        s += dpp<DPP_ROW_ROR(1)>(s);
+        const int dc = (s + 4) >> 3;
+        v = dc;
+        if (kind == 0) {
+          v = by == 0 ? (r0 + 3 * dc + 2) >> 2 : v;
+          v = bx == 0 ? (r1 + 3 * dc + 2) >> 2 : v;
+          v = (bx | by) == 0 ? (r1 + 2 * dc + r0 + 2) >> 2 : v;
+        }
+      }
+      else if (kind == 0 && (mode == 26 || mode == 10)) { // luma: gradient on the first column / row
+        const int corner = tp[-1];
+        const bool on_edge = mode == 26 ? bx == 0 : by == 0;
+        v = on_edge ? clip3i(0, maxv, r0 + ((r1 - corner) >> 1)) : v;
+      }
+      if (op.y & OP_CBF) v = clip3i(0, maxv, v + (int)pre);
+      lp[mul24(by, P) + 1 + bx] = (Pix)v;
+      if (kind == 0 && gl == 0) { // deblocking metadata (deblock.cc:31-62): transform edges + QpY of the 4x4 block
+        const int x4 = (int)((op.w >> 8) & 15), y4 = (int)((op.w >> 12) & 15);
+        const int deblock_en = !(cb_flags & HM_CTB_DEBLOCK_OFF);
+        const int left_ok = (x4 > 0) | ((cb_flags & HM_CTB_DEBLOCK_LEFT) != 0);
+        const int top_ok = (y4 > 0) | ((cb_flags & HM_CTB_DEBLOCK_TOP) != 0);
+        gmeta[(y4 << (log2_ctb - 2)) + x4] = (uint16_t)((left_ok & deblock_en) | ((top_ok & deblock_en) << 1) | ((op.w & 0xFF) << 8));
+      }
+    }
+    WAVE_SYNC();
+
+    HM_MARK("D_begin");
+    // ---- D: every other block, wave-wide, one group after the other ----
+#if defined(HM_Q_PROBE) && (HM_Q_PROBE & 2)
+    for (unsigned long long todo = 0; todo;) {
+#else
+    for (unsigned long long todo = s_big; todo;) {
+#endif
+      const int bg = rfl((int)(__builtin_ctzll(todo) >> 4));
+      todo &= ~(0xFFFFull << (bg * 16));
+      const int src = bg * 16;
+      // the block's micro-op and its group's places in LDS, as scalars
+      const uint32_t ox = (uint32_t)__builtin_amdgcn_readlane((int)op.x, src), oy = (uint32_t)__builtin_amdgcn_readlane((int)op.y, src);
+      const uint32_t oz = (uint32_t)__builtin_amdgcn_readlane((int)op.z, src), ow = (uint32_t)__builtin_amdgcn_readlane((int)op.w, src);
+      const uint32_t s_gb = (uint32_t)__builtin_amdgcn_readlane((int)gb_off, src), s_tl = (uint32_t)__builtin_amdgcn_readlane((int)tl_off, src);
+      const int s_flags = __builtin_amdgcn_readlane(cb_flags, src);
+      const uint32_t bres = bg == 0 ? bres0 : (bg == 1 ? bres1 : (bg == 2 ? bres2 : bres3));
+      const int mode = (int)(oy & OP_MODE_MASK), c = (int)((oy >> OP_C_SHIFT) & 3), log2 = 2 + (int)((oy >> OP_L2_SHIFT) & 3);
+      const bool cbf = (oy & OP_CBF) != 0;
+      const int P = c == 0 ? P0 : P1;
+      Pix* const gb = reinterpret_cast<Pix*>(lds + s_gb);                           // the chain's first plane (luma / Cb)
+      Pix* const lp = gb + (ox & 0xFFFF);                                             // sample (x0-1, y0)
+      const Pix* const tp = reinterpret_cast<const Pix*>(lds + ((oy & OP_LINE) ? s_tl : s_gb)) + (ox >> 16); // sample (x0, y0-1)
+      Pix* const dst = lp + 1;
+      const GLOBAL_AS int16_t* const gres = resid + oz;
+      const int maxv = (1 << bd) - 1;
+
+      HM_MARK("D_setup_end");
+      auto block = [&](auto l2c) { // block size as a compile-time constant: fixed trip counts, shifts and masks
+        constexpr int L2 = decltype(l2c)::value;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        // prediction + residual + clip + store of sample p = x + nT * y (the residual of a block lies in raster order)
+        auto emit = [&](int p, int x, int y, int v) {
+          if (cbf) {
+            const int r = L2 <= 3 ? (int)bres : (int)gres[p];
+            v = clip3i(0, maxv, v + r);
+          }
+          dst[mul24(y, P) + x] = (Pix)v;
+        };
+        Blk<Pix> B; // (predict_emit reads mode, c, bd; the border path everything)
+        B.mode = mode; B.c = c; B.bd = bd; B.log2 = L2; B.tskip = 0; B.qp = 0; B.n_coeff = 0; B.P = P;
+        const bool smoothed = L2 != 2 && c == 0 && ((filter_mode_mask(L2) >> mode) & 1);
+#if !defined(HM_Q_PROBE) || !(HM_Q_PROBE & 4)
+        if (L2 <= 3 && !smoothed && (oy & OP_INTERIOR)) {
+          // one lane pass, the samples addressed in place: everything it needs is in the micro-op
+          RefDirect<Pix> R;
+          R.lp = lp; R.tp = tp; R.P = P;
+          R.nL1 = (int)((oy >> OP_NL1_SHIFT) & 63); R.nT1 = (int)((oy >> OP_NT1_SHIFT) & 63);
+          predict_emit<Pix, L2>(B, R, tab, ln, emit);
+        }
+        else {
+          // the availability word of the full record (left | below-left << 8 | top << 16 | top-right << 24): complete runs = nT
+          constexpr uint32_t nT = 1u << L2;
+          B.info = L2 | (c << HM_TU_CIDX_SHIFT) | ((ow & OPW_TL) ? HM_TU_AVAIL_TL : 0);
+          B.aBL = (int)(((ow >> OPW_BL_SHIFT) & 15) << 2); B.aTR = (int)(((ow >> OPW_TR_SHIFT) & 15) << 2);
+          B.avail = ((ow & OPW_LEFT) ? nT : 0u) | ((uint32_t)B.aBL << 8) | ((ow & OPW_TOP) ? nT << 16 : 0u) | ((uint32_t)B.aTR << 24);
+          B.x0 = (int)((ow >> 6) & 0x3C); B.y0 = (int)((ow >> 10) & 0x3C);
+          B.u = gb + (c == 2 ? cr_off : 0);
+          B.top = reinterpret_cast<const Pix*>(lds + s_tl) - 1 + (c == 2 ? Wc + 4 : 0);
+          make_border<Pix, L2>(B, l_bA, strong, ln);
+          WAVE_SYNC();
+          predict_emit<Pix, L2>(B, RefArray{l_bA + 64}, tab, ln, emit);
+        }
+#endif
+        WAVE_SYNC();
+        HM_MARK("D_pred_end");
+        if (c == 0) { // deblocking metadata (deblock.cc:31-62): transform edges + QpY
+          constexpr int n4 = 1 << (L2 - 2);
+          if (ln < n4 * n4) {
+            uint16_t* const l_meta = reinterpret_cast<uint16_t*>(lds + (uint32_t)__builtin_amdgcn_readlane((int)meta_off, src));
+            const int x4 = (int)((ow >> 8) & 15), y4 = (int)((ow >> 12) & 15);
+            const int i = ln & (n4 - 1), j = ln >> (L2 - 2);
+            const int deblock_en = !(s_flags & HM_CTB_DEBLOCK_OFF);
+            const int left_ok = (x4 > 0) | ((s_flags & HM_CTB_DEBLOCK_LEFT) != 0);
+            const int top_ok = (y4 > 0) | ((s_flags & HM_CTB_DEBLOCK_TOP) != 0);
+            const int e = ((i == 0) & left_ok & deblock_en) | (((j == 0) & top_ok & deblock_en) << 1);
+            l_meta[((y4 + j) << (log2_ctb - 2)) + x4 + i] = (uint16_t)(e | ((ow & 0xFF) << 8));
+          }
+        }
+      };
+      if (log2 == 2) block(std::integral_constant<int, 2>());
+      else if (log2 == 3) block(std::integral_constant<int, 3>());
+      else if (log2 == 4) block(std::integral_constant<int, 4>());
+      else block(std::integral_constant<int, 5>());
+      WAVE_SYNC();
+    }
+
+    HM_MARK("E_begin");
+    // ---- E: the groups that executed a block move to the next record ----
+    if (running) {
+      ri += 1;
+      pre = pre_m;
+      pre_m = lv; // requested one step ago
+      kleft -= 1;
+    }
+
+    HM_MARK("F_begin");
+    // ---- F: finished CTUs: coalesced stores to the picture, bottom row -> line, right column -> left column ----
+    for (unsigned long long fin = __ballot(st == ST_RUN && kleft == 0); fin;) {
+      const int fg = rfl((int)(__builtin_ctzll(fin) >> 4));
+      fin &= ~(0xFFFFull << (fg * 16));
+      const int src = fg * 16;
+      const int s_row = __builtin_amdgcn_readlane(row, src), s_cx = __builtin_amdgcn_readlane(cx, src);
+      const int fkind = group_kind(fg);
+      Pix* const lw = line_of(fkind, group_slot(fg)); // s_row % NR
+      auto flush_plane = [&](auto bw_c, Pix* u, int P, Pix* line, uint8_t* plane, int pitch, int bh, int pw, int ph) {
+        constexpr int BW = decltype(bw_c)::value;
+        constexpr int PPW = 4 / sizeof(Pix), WPR = BW / PPW; // samples per 32-bit word, words per row
+        static_assert(WPR >= 1 && WPR <= 64 && (WPR & (WPR - 1)) == 0, "CTB row must be 1..64 words");
+        constexpr int CW = WPR < 4 ? WPR : 4, LPR = WPR / CW, RPT = 64 / LPR; // words per chunk, lanes per row, rows per trip
+        const int xo = s_cx * BW, yo = s_row * bh;
+        const int vw = (pw - xo) < BW ? (pw - xo) : BW; // valid part inside the picture
+        const int vh = (ph - yo) < bh ? (ph - yo) : bh;
+        const int q = lane & (LPR - 1), rr0 = lane / LPR;
+        const bool col_ok = q * CW * PPW < vw;
+        GLOBAL_AS uint8_t* const gp = gptr_w<uint8_t>(plane + (size_t)yo * pitch + (size_t)(xo + q * CW * PPW) * sizeof(Pix));
+        for (int rb = 0; rb < vh; rb += RPT) {
+          const int r = rb + rr0;
+          if (col_ok && r < vh) {
+            const uint32_t* srcw = reinterpret_cast<const uint32_t*>(u + mul24(r, P) + UPAD + q * CW * PPW); // rows are 4-byte aligned
+            uint32_t vv[CW];
+#pragma unroll
+            for (int k = 0; k < CW; k++) vv[k] = srcw[k];
+            GLOBAL_AS uint32_t* dst = reinterpret_cast<GLOBAL_AS uint32_t*>(gp + (uint32_t)mul24(r, pitch));
+            if (CW == 4) *reinterpret_cast<GLOBAL_AS c_u32x4*>(dst) = c_u32x4{vv[0], vv[1], vv[2], vv[3]};
+            else if (CW == 2) *reinterpret_cast<GLOBAL_AS c_u32x2*>(dst) = c_u32x2{vv[0], vv[1]};
+            else dst[0] = vv[0];
+          }
+        }
+        if (lane < WPR)
+          *reinterpret_cast<uint32_t*>(line + xo + lane * PPW) = *reinterpret_cast<const uint32_t*>(u + (bh - 1) * P + UPAD + lane * PPW);
+        WAVE_SYNC();
+        if (lane < bh) u[lane * P + UPAD - 1] = u[lane * P + UPAD + BW - 1]; // right column becomes the left neighbour
+      };
+      // The picture's planes, pitches and sizes are only needed here, once per CTU: they are read again from the
+      // descriptor through a pointer the compiler cannot see through, instead of occupying ~16 scalar registers for the
+      // whole loop (scalar registers spilled to vector lanes cost VALU instructions).
+      const hm_dev_pic* fp;
+      {
+        const uint64_t a = (uint64_t)(uintptr_t)(pics + pic_index);
+        uint64_t u = ((uint64_t)(uint32_t)rfl((int)(a >> 32)) << 32) | (uint32_t)rfl((int)a);
+        asm volatile("" : "+s"(u));
+        fp = reinterpret_cast<const hm_dev_pic*>((uintptr_t)u);
+      }
+      const int planeWc = fp->width >> 1, planeHc = fp->height / sh;
+      if (fkind == 0) flush_plane(std::integral_constant<int, ctb>(), group_u(fg, 0), P0, lw, fp->plane[0], fp->pitch[0], ctb, fp->width, fp->height);
+      else {
+        flush_plane(std::integral_constant<int, (ctb >> 1)>(), group_u(fg, 1), P1, lw, fp->plane[1], fp->pitch[1], ch_c, planeWc, planeHc);
+        flush_plane(std::integral_constant<int, (ctb >> 1)>(), group_u(fg, 2), P1, lw + (Wc + 4), fp->plane[2], fp->pitch[2], ch_c, planeWc, planeHc);
+      }
+      if (fkind == 0) { // the CTU's block map; cells outside the picture were never written
+        constexpr int M4 = ctb >> 2;
+        const uint16_t* const l_meta = group_meta(fg);
+        const int w4 = fp->w4, h4 = fp->h4;
+        GLOBAL_AS uint16_t* const ctb_meta = gptr_w<uint16_t>(fp->meta) + (size_t)((s_row << log2_ctb) >> 2) * w4 + ((s_cx << log2_ctb) >> 2);
+        const int gx0 = s_cx << (log2_ctb - 2), gy0 = s_row << (log2_ctb - 2);
+#pragma unroll
+        for (int idx0 = 0; idx0 < M4 * M4; idx0 += 64) {
+          const int idx = idx0 + lane, bi = idx & (M4 - 1), bj = idx >> (log2_ctb - 2);
+          if (idx < M4 * M4 && gx0 + bi < w4 && gy0 + bj < h4) ctb_meta[(uint32_t)bi + __umul24((uint32_t)bj, (uint32_t)w4)] = l_meta[idx];
+        }
+      }
+      WAVE_SYNC();
+      // read by the chain of the row below, a group of this wave (LDS traffic of a wave is in order)
+      if (lane == 0) __hip_atomic_store(progress + fkind * L.prog_ints + s_row, s_cx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      // the group's next CTU
+      if (g == fg) {
+        cx += 1;
+        st = ST_START;
+        tl_off += (uint32_t)(sizeof(Pix) << l2w);
+        if (cx == ctb_w) {
+          cx = 0;
+          tl_off = lr_off;
+          row += NR;
+          if (row < ctb_h) row_start();
+          else st = ST_DONE;
+        }
+      }
+    }
+    HM_MARK("G_begin");
+    // ---- G: the in-flight stage of the residual pipeline, requested by every lane (no condition around the load): the
+    //      residual of the block two behind the current one; a group that did not move asks again for what it holds ----
+    lv = res_of(ring[(ri + 2) & (C_RING - 1)].z);
+    WAVE_SYNC();
+  }
+}
+
+} // namespace
+
+// The chain kernel serves every picture whose records come as split chains (no rare syntax, not 4:4:4), after
+// hm_launch_residual on the same stream; returns 1 if it launched, 0 if the CTU staging does not fit LDS, < 0 on error.
+extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ctb, int chroma_format, int bit_depth, int rare_syntax,
+                               int max_ctb_w, int max_ctb_h, hipStream_t s)
+{
+  if (n_pics <= 0) return 1;
+  if (rare_syntax || chroma_format == 3 || log2_ctb < 4 || log2_ctb > 6) return 0;
+  const int ctb = 1 << log2_ctb;
+  const int pb = bit_depth > 8 ? 2 : 1;
+  const bool mono = chroma_format == 0;
+  const int nr = mono ? 4 : 2;
+  const int ch = chroma_format == 1 ? ctb / 2 : ctb;
+  auto al = [](int v) { return (v + 15) & ~15; };
+  CLayout L;
+  L.prog_ints = (max_ctb_h + 3) & ~3;
+  L.line_l_bytes = al((4 + max_ctb_w * ctb) * pb);
+  L.line_c_bytes = mono ? 0 : al((8 + 2 * max_ctb_w * (ctb / 2)) * pb);
+  L.off_lines_l = al(2 * L.prog_ints * 4);
+  L.off_lines_c = L.off_lines_l + nr * L.line_l_bytes;
+  L.off_scratch = L.off_lines_c + (mono ? 0 : nr * L.line_c_bytes);
+  L.off_rings = L.off_scratch + al(C_SCRATCH);
+  L.off_groups = L.off_rings + C_RING_BYTES;
+  L.luma_bytes = al(META_BYTES(ctb) + (ctb + UPAD) * ctb * pb);
+  L.chroma_bytes = mono ? 0 : al(2 * (ctb / 2 + UPAD) * ch * pb);
+  L.pic_bytes = al(L.off_groups + (mono ? 4 * L.luma_bytes : 2 * (L.luma_bytes + L.chroma_bytes)));
+  // waves (= pictures) per workgroup: they only share the tables; the count that puts the most waves on a CU's 160 KiB
+  int np = 0, best = 0;
+  for (int k = 1; k <= 16; k++) {
+    const int bytes = C_SHARED + k * L.pic_bytes;
+    if (bytes > 160 * 1024) break;
+    int per_cu = (160 * 1024 / bytes) * k;
+    if (per_cu > 20) per_cu = 20;
+    if (per_cu > best) { best = per_cu; np = k; }
+  }
+  if (np == 0) return 0;
+  while (np > 1 && (long)np * 256 > n_pics) np--; // few pictures: spread them over the CUs first
+  const int lds_bytes = C_SHARED + np * L.pic_bytes;
+  const void* fn = nullptr;
+  switch (log2_ctb * 2 + (pb - 1)) {
+    case 8: fn = reinterpret_cast<const void*>(k_chain<uint8_t, 4>); break;
+    case 9: fn = reinterpret_cast<const void*>(k_chain<uint16_t, 4>); break;
+    case 10: fn = reinterpret_cast<const void*>(k_chain<uint8_t, 5>); break;
+    case 11: fn = reinterpret_cast<const void*>(k_chain<uint16_t, 5>); break;
+    case 12: fn = reinterpret_cast<const void*>(k_chain<uint8_t, 6>); break;
+    case 13: fn = reinterpret_cast<const void*>(k_chain<uint16_t, 6>); break;
+    default: return 0;
+  }
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return hm_check_hip(e, "hipFuncSetAttribute(k_chain)");
+  int a_n = n_pics;
+  void* args[] = {(void*)&d_pics, &a_n, &L};
+  e = hipLaunchKernel(fn, dim3((n_pics + np - 1) / np), dim3(np * 64), args, lds_bytes, s);
+  if (e != hipSuccess) return hm_check_hip(e, "k_chain launch");
+  e = hipGetLastError();
+  return e == hipSuccess ? 1 : hm_check_hip(e, "k_chain launch");
+}

@@ -16,6 +16,7 @@ struct hm_dev_pic {
                             // top (deblock.cc:31-62), bit2 PCM / bit3 transquant-bypass coding unit, bits 8-15 QpY (int8)
                             // - one store from k_recon, one load in k_deblock
   int32_t w4, h4;           // size of the 4x4-block maps
+  int16_t* resid;           // pictures with split chains: residual samples, k_residual -> k_chain (recon_common.h: ResidGeom)
   // final output of the in-loop filters (SAO stage): written straight into the destination
   // image = fused tile paste (context.cc:2457-2535 of the reference)
   uint8_t* dst[3];          // destination plane origin (tile origin already applied)

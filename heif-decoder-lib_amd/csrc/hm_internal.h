@@ -55,6 +55,12 @@ int hm_launch_recon(const struct hm_dev_pic* d_pics, int n_pics, int log2_ctb, i
 // recon_quad.hip: four CTU rows per wave; 1 = launched, 0 = not applicable (use hm_launch_recon), < 0 = error
 int hm_launch_recon_quad(const struct hm_dev_pic* d_pics, int n_pics, int log2_ctb, int chroma_format, int bit_depth, int rare_syntax,
                          int max_ctb_w, int max_ctb_h, hipStream_t s);
+// residual.hip + chain.hip: the reconstruction of pictures with split chains as two kernels on the same stream -
+// dequantisation + inverse transforms of all blocks (no dependencies), then the prediction chains (four per wave);
+// hm_launch_chain: 1 = launched, 0 = not applicable, < 0 = error
+int hm_launch_residual(const struct hm_dev_pic* d_pics, int n_pics, int max_ctb_h, hipStream_t s);
+int hm_launch_chain(const struct hm_dev_pic* d_pics, int n_pics, int log2_ctb, int chroma_format, int bit_depth, int rare_syntax,
+                    int max_ctb_w, int max_ctb_h, hipStream_t s);
 int hm_launch_deblock(const struct hm_dev_pic* d_pics, int n_pics, int max_w4, int max_h4, int chroma_format,
                       int bit_depth, int rare_syntax, hipStream_t s);
 int hm_launch_sao_paste(const struct hm_dev_pic* d_pics, int n_pics, int max_w, int max_h, int bit_depth, int apply_sao,

@@ -298,20 +298,20 @@ __device__ __forceinline__ void make_border(const Blk<Pix>& b, int16_t* bA, int 
 }
 
 // ---- predictors (intrapred.h:269-441) ------------------------------------------------------------------
-template <typename Pix, int L2, typename Ref, bool HALVES = false>
-__device__ __forceinline__ void predict(const Blk<Pix>& B, const Ref& b, const int16_t* tab, int lane)
+// predict_emit hands every predicted sample to emit(p, x, y, v) (p = x + nT * y): the plain store of the kernels that
+// add the residual in a second pass (predict), or prediction + residual + clip + store in one go (chain.hip).
+template <typename Pix, int L2, typename Ref, bool HALVES = false, typename Emit>
+__device__ __forceinline__ void predict_emit(const Blk<Pix>& B, const Ref& b, const int16_t* tab, int lane, Emit&& emit)
 {
   constexpr int nT = 1 << L2, log2 = L2;
   const int mode = B.mode, c = B.c;
-  Pix* dst = B.u + mul24(B.y0, B.P) + UPAD + B.x0;
-  const int pitch = B.P;
   const int maxv = (1 << B.bd) - 1;
   constexpr int npx = nT * nT;
   const bool edge = (c == 0 && nT < 32); // boundary smoothing of DC / pure vertical / pure horizontal (luma, < 32x32)
   if (mode == 0) {
     lanes_loop<npx>(lane, [&](int p) {
       const int x = p & (nT - 1), y = p >> log2;
-      dst[mul24(y, pitch) + x] = (Pix)((mul24(nT - 1 - x, b(-1 - y)) + mul24(x + 1, b(1 + nT)) + mul24(nT - 1 - y, b(1 + x)) + mul24(y + 1, b(-1 - nT)) + nT) >> (log2 + 1));
+      emit(p, x, y, (mul24(nT - 1 - x, b(-1 - y)) + mul24(x + 1, b(1 + nT)) + mul24(nT - 1 - y, b(1 + x)) + mul24(y + 1, b(-1 - nT)) + nT) >> (log2 + 1));
     });
   }
   else if (mode == 1) {
@@ -327,7 +327,7 @@ __device__ __forceinline__ void predict(const Blk<Pix>& B, const Ref& b, const i
         v = x == 0 ? (l + 3 * dc + 2) >> 2 : v;
         v = (x | y) == 0 ? (l + 2 * dc + t + 2) >> 2 : v;
       }
-      dst[mul24(y, pitch) + x] = (Pix)v;
+      emit(p, x, y, v);
     });
   }
   else if (mode == 26 || mode == 10) { // pure vertical / horizontal: copy, plus the gradient on the first column / row
@@ -344,7 +344,7 @@ __device__ __forceinline__ void predict(const Blk<Pix>& B, const Ref& b, const i
         const int g = vert ? b(1) + ((l - corner) >> 1) : b(-1) + ((t - corner) >> 1);
         v = along == 0 ? clip3i(0, maxv, g) : v;
       }
-      dst[mul24(y, pitch) + x] = (Pix)v;
+      emit(p, x, y, v);
     });
   }
   else {
@@ -357,7 +357,7 @@ __device__ __forceinline__ void predict(const Blk<Pix>& B, const Ref& b, const i
         const int t = mul24(major + 1, angle);
         const int k0 = minor + (t >> 5) + 1, iFact = t & 31;
         const int r0 = vert ? b.top(k0) : b.left(k0), r1 = vert ? b.top(k0 + 1) : b.left(k0 + 1); // weight 0 when iFact == 0
-        dst[mul24(y, pitch) + x] = (Pix)((mul24(32 - iFact, r0) + mul24(iFact, r1) + 16) >> 5);
+        emit(p, x, y, (mul24(32 - iFact, r0) + mul24(iFact, r1) + 16) >> 5);
       });
     }
     else {
@@ -373,10 +373,37 @@ __device__ __forceinline__ void predict(const Blk<Pix>& B, const Ref& b, const i
       const int j0 = sgn * (k0 >= 0 ? k0 : q0), j1 = sgn * (k1 >= 0 ? k1 : q1);
       // b(j1) is read even when iFact == 0 (then it has weight 0; the index stays inside bA: |j1| <= 2nT + 1)
       const int r0 = b(j0), r1 = b(j1);
-      dst[mul24(y, pitch) + x] = (Pix)((mul24(32 - iFact, r0) + mul24(iFact, r1) + 16) >> 5);
+      emit(p, x, y, (mul24(32 - iFact, r0) + mul24(iFact, r1) + 16) >> 5);
     });
     }
   }
+}
+template <typename Pix, int L2, typename Ref, bool HALVES = false>
+__device__ __forceinline__ void predict(const Blk<Pix>& B, const Ref& b, const int16_t* tab, int lane)
+{
+  Pix* const dst = B.u + mul24(B.y0, B.P) + UPAD + B.x0;
+  const int pitch = B.P;
+  predict_emit<Pix, L2, Ref, HALVES>(B, b, tab, lane, [&](int, int x, int y, int v) { dst[mul24(y, pitch) + x] = (Pix)v; });
+}
+
+// ---- residual buffer of a picture with split chains (residual.hip writes it, chain.hip reads it) ----------------
+// int16 per sample, already limited to [-(2^bd - 1), 2^bd - 1] (adding it to a predicted sample and clipping gives what
+// the reference's unlimited residual gives).  One slab per (CTB row, chain kind) at a fixed place - as large as the
+// row's samples - and inside a slab the blocks WITH residual back to back in chain order, each nT * nT samples in raster
+// order: both kernels find a block's residual with a running sum over the records of its row.
+struct ResidGeom {
+  uint32_t luma_row, chroma_row, chroma_base, total; // in samples
+  __device__ __forceinline__ uint32_t slab(int kind, int row) const { return kind ? chroma_base + (uint32_t)row * chroma_row : (uint32_t)row * luma_row; }
+};
+__device__ __forceinline__ ResidGeom resid_geom(int ctb_w, int ctb_h, int log2_ctb, int chroma_format)
+{
+  ResidGeom g;
+  const uint32_t ctb = 1u << log2_ctb;
+  g.luma_row = (uint32_t)ctb_w * ctb * ctb;
+  g.chroma_row = chroma_format == 0 ? 0u : (uint32_t)ctb_w * 2u * (ctb >> 1) * (chroma_format == 1 ? ctb >> 1 : ctb);
+  g.chroma_base = (uint32_t)ctb_h * g.luma_row;
+  g.total = g.chroma_base + (uint32_t)ctb_h * g.chroma_row;
+  return g;
 }
 
 // ---- dequantisation + inverse transform + add (transform.cc:386-689, fallback-dct.cc) --------------------

@@ -1,0 +1,309 @@
+// residual.hip — k_residual: dequantisation + inverse transforms of every transform block that has a residual, as a
+// PRE-PASS WITHOUT DEPENDENCIES in front of the prediction chains (chain.hip).
+//
+// scale_coefficients dequantisation (transform.cc:386-545; flat path in wrapping int32, Q3), 4x4
+// DST-VII and 4-32 point DCT (fallback-dct.cc:311-449, 592-733; stage 1 >> 7 clipped to 16 bit, stage 2 >> (20 - bit
+// depth), clipped for the DST only: Q4), transform skip (transform.cc:566-643).  None of it depends on a neighbouring
+// block - only the prediction does -, so it does not belong on the dependency chain of a CTU row: here every (CTB row,
+// chain kind) of every picture is one wave of a plain grid launch, the residuals go to HBM as int16 (recon_common.h:
+// ResidGeom) and the chain kernel only predicts and adds.
+//   * a wave walks the records of its row 64 at a time (lane = record): two wave scans give every record its first
+//     level and the place of its residual;
+//   * 4x4 blocks with a residual are then transformed four at a time (16 lanes = 16 samples of a block: the rows /
+//     columns of the 4-point transforms are exchanged with DPP row rotations and quad broadcasts, nothing goes through
+//     LDS but the scatter of the levels), 8x8 blocks one per pass (64 lanes = 64 samples, v_dot2_i32_i16 on 16-byte LDS
+//     rows), 16x16 / 32x32 blocks in 64-sample trips with the sums cut at the last non-zero row / column.
+// Pictures with rare syntax (scaling lists, PCM, bypass, 4:4:4, range-extension tools) keep their residual inside
+// recon.hip's RARE kernel.  Integer work, HBM traffic = levels in + 2 bytes per residual sample out: no MFMA.
+#include "recon_common.h"
+
+#include "hm_internal.h"
+
+namespace {
+
+constexpr int R_WAVES = 4;                          // waves (= row chains) per workgroup: they share the tables
+constexpr int R_TABLES = 1024 + 256 + 128;          // dct basis (int8 [32][32]), small tables (recon.hip), 8-point pairs
+constexpr int R_WAVE = 2048 + 1024 + 4 * 16 * 4;    // per wave: coefficient block (32x32 int16), 16-row intermediate, 4x4 gather slots
+
+template <int CTRL>
+__device__ __forceinline__ int rdpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+constexpr int R_ROW_ROR(int n) { return 0x120 | n; }
+constexpr int R_QUAD_BCAST(int k) { return k | (k << 2) | (k << 4) | (k << 6); }
+
+typedef short r_s16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t r_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t r_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int rdot2(uint32_t a, uint32_t b, int acc)
+{
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(r_s16x2, a), __builtin_bit_cast(r_s16x2, b), acc, false);
+}
+__device__ __forceinline__ int16_t limit_res(int r, int maxv) { return (int16_t)clip3i(-maxv, maxv, r); }
+
+// 16x16 / 32x32 block: levels -> dense coefficient block in LDS -> column transform -> row transform -> HBM.
+// `coeff` is all zero on entry and on exit.  Rows / columns beyond the last non-zero coefficient contribute nothing:
+// the sums stop at (my, mx).  fallback-dct.cc:592-733.
+template <int L2>
+__device__ __forceinline__ void big_residual(int16_t* coeff, int16_t* tmp, const int8_t* dct, const int16_t* tab, const GLOBAL_AS uint32_t* __restrict__ cf,
+                                             int n_coeff, int qP, int bit_depth, GLOBAL_AS int16_t* __restrict__ out, int lane)
+{
+  constexpr int nT = 1 << L2, log2 = L2;
+  const int bdShift = bit_depth + log2 - 9;
+  const int32_t offset = 1 << (bdShift - 1);
+  const int32_t fact = (int32_t)tab[70 + qP % 6] << (qP / 6);
+  const int maxv = (1 << bit_depth) - 1;
+  int mx = 0, my = 0;
+#pragma unroll 1
+  for (int i = lane; i < n_coeff; i += 64) {
+    const uint32_t raw = cf[i];
+    const int pos = raw & (nT * nT - 1), value = (int)(int16_t)(raw >> 16);
+    const int32_t prod = (int32_t)((uint32_t)mul24(value, fact) + (uint32_t)offset); // the reference's wrapping int32 product (Q3)
+    coeff[pos] = (int16_t)clip3i(-32768, 32767, prod >> bdShift);
+    const int px = pos & (nT - 1), py = pos >> log2;
+    mx = px > mx ? px : mx;
+    my = py > my ? py : my;
+  }
+  mx = wave_max5(mx);
+  my = wave_max5(my);
+  WAVE_SYNC();
+  const int postShift = 20 - bit_depth, rnd2 = 1 << (postShift - 1);
+  const int fct = 32 >> log2;
+  constexpr int rpp = nT < 16 ? nT : 16, n_part = rpp << log2; // the intermediate holds 16 rows
+  for (int i0 = 0; i0 < nT; i0 += rpp) {
+    lanes_loop<n_part>(lane, [&](int p) {
+      const int cc = p & (nT - 1), ir = p >> log2, i = i0 + ir;
+      int sum = 0;
+      if (cc <= mx)
+        for (int j = 0; j <= my; j++) sum += mul24((int)dct[(fct * j) * 32 + i], (int)coeff[cc + j * nT]);
+      tmp[cc + ir * nT] = (int16_t)clip3i(-32768, 32767, (sum + 64) >> 7);
+    });
+    WAVE_SYNC();
+    lanes_loop<n_part>(lane, [&](int p) {
+      const int i = p & (nT - 1), yr = p >> log2, y = i0 + yr;
+      int sum = 0;
+      for (int j = 0; j <= mx; j++) sum += mul24((int)dct[(fct * j) * 32 + i], (int)tmp[yr * nT + j]);
+      out[mul24(y, nT) + i] = limit_res((sum + rnd2) >> postShift, maxv); // stage 2 is not clipped to 16 bit (Q4)
+    });
+    WAVE_SYNC();
+  }
+#pragma unroll 1
+  for (int i = lane; i < n_coeff; i += 64) coeff[cf[i] & (nT * nT - 1)] = 0;
+  WAVE_SYNC();
+}
+
+__global__ __launch_bounds__(R_WAVES * 64) void k_residual(const hm_dev_pic* __restrict__ pics, int n_pics, int max_ctb_h)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = rfl(tid >> 6);
+  int8_t* const dct = reinterpret_cast<int8_t*>(lds);
+  int16_t* const tab = reinterpret_cast<int16_t*>(lds + 1024);
+  uint32_t* const w8 = reinterpret_cast<uint32_t*>(lds + 1024 + 256);
+  for (int i = tid; i < 1024; i += R_WAVES * 64) {
+    const int k = i >> 5, n = i & 31;
+    const int m = (k * (2 * n + 1)) & 127;
+    int v;
+    if (k == 0) v = 64;
+    else if (m <= 32) v = c_dct_mag[m];
+    else if (m <= 64) v = -c_dct_mag[64 - m];
+    else if (m <= 96) v = -c_dct_mag[m - 64];
+    else v = c_dct_mag[128 - m];
+    dct[i] = (int8_t)v;
+  }
+  for (int i = tid; i < 92; i += R_WAVES * 64) { // [70,76) level scale, [76,92) DST (the layout of recon.hip's table)
+    int v = 0;
+    if (i >= 70 && i < 76) v = c_level_scale[i - 70];
+    else if (i >= 76) v = c_dst[(i - 76) >> 2][(i - 76) & 3];
+    tab[i] = (int16_t)v;
+  }
+  uint8_t* const wbase = lds + R_TABLES + (size_t)wave * R_WAVE;
+  int16_t* const coeff = reinterpret_cast<int16_t*>(wbase);
+  int16_t* const tmp = reinterpret_cast<int16_t*>(wbase + 2048);
+  int* const slots = reinterpret_cast<int*>(wbase + 2048 + 1024); // [4][16]
+  for (int i = lane; i < 1024; i += 64) coeff[i] = 0;
+  slots[lane] = 0;
+  __syncthreads();
+  // 8-point inverse DCT basis as pairs of consecutive inputs (fallback-dct.cc:592-733: M[j][i] = dct[4 j][i])
+  for (int t = tid; t < 32; t += R_WAVES * 64) {
+    const int i = t >> 2, k = t & 3;
+    w8[t] = ((uint32_t)(uint16_t)(int16_t)dct[(4 * (2 * k)) * 32 + i]) | ((uint32_t)(uint16_t)(int16_t)dct[(4 * (2 * k + 1)) * 32 + i] << 16);
+  }
+  __syncthreads();
+
+  // ---- this wave's unit: (picture, CTB row, chain kind) ----
+  const uint32_t unit = (uint32_t)blockIdx.x * R_WAVES + (uint32_t)wave;
+  const uint32_t per_pic = 2u * (uint32_t)max_ctb_h;
+  const int pic_index = (int)(unit / per_pic);
+  if (pic_index >= n_pics) return;
+  const int rem = (int)(unit - (uint32_t)pic_index * per_pic);
+  const int row = rem >> 1, kind = rem & 1;
+  const hm_dev_pic dp = pics[pic_index];
+  if (row >= dp.ctb_h || (kind && dp.chroma_format == 0)) return;
+  const uint8_t* blob = dp.blob;
+  const GLOBAL_AS hm_pic* H = gptr<hm_pic>(blob);
+  const GLOBAL_AS uint32_t* ctbq = gptr<uint32_t>(blob + H->off_ctbs);
+  const GLOBAL_AS uint32_t* tus = gptr<uint32_t>(blob + H->off_tus);
+  const GLOBAL_AS uint32_t* coeffs = gptr<uint32_t>(blob + H->off_coeffs);
+  GLOBAL_AS int16_t* const resid = gptr_w<int16_t>(dp.resid);
+  const int bd = dp.bit_depth;
+  const int maxv = (1 << bd) - 1;
+  const ResidGeom RG = resid_geom(dp.ctb_w, dp.ctb_h, dp.log2_ctb, dp.chroma_format);
+  const GLOBAL_AS uint32_t* const q0 = ctbq + HM_CTB_DWORDS * ((size_t)row * dp.ctb_w);
+  const GLOBAL_AS uint32_t* const q1 = q0 + HM_CTB_DWORDS * (size_t)(dp.ctb_w - 1);
+  const uint32_t rec_begin = q0[kind ? 9 : 0];
+  const uint32_t rec_end = q1[kind ? 9 : 0] + (q1[kind ? 10 : 1] & 0xFFFFu);
+  uint32_t lev_base = q0[kind ? 12 : 11];
+  uint32_t res_base = RG.slab(kind, row);
+
+  // ---- per-lane constants of the 4x4 transform (lane = sample (bx, by) of the block of its 16-lane group) ----
+  const int g = lane >> 4, gl = lane & 15, bx_ = gl & 3, by_ = gl >> 2;
+  // Stage 1 (columns): the lane of coefficient (row by, column bx) computes intermediate (by, bx) from the four
+  // coefficients of its column, fetched with row rotations by 0, 4, 8, 12 lanes; which source row rotation k delivers
+  // is read off the rotation of the lane number itself.  Stage 2 (rows): quad broadcasts.  A luma chain only meets the
+  // DST (4x4 luma intra), a chroma chain only the DCT (transform.cc:648-653): the weights are constants of the wave.
+  int w1[4], w2[4];
+  {
+    const int src[4] = {lane, rdpp<R_ROW_ROR(4)>(lane), rdpp<R_ROW_ROR(8)>(lane), rdpp<R_ROW_ROR(12)>(lane)};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int j = (src[k] >> 2) & 3;
+      w1[k] = kind ? (int)dct[(8 * j) * 32 + by_] : (int)tab[76 + j * 4 + by_];
+      w2[k] = kind ? (int)dct[(8 * k) * 32 + bx_] : (int)tab[76 + k * 4 + bx_];
+    }
+  }
+  const int postShift = 20 - bd, rnd2 = 1 << (postShift - 1);
+
+  for (uint32_t chunk = rec_begin; chunk < rec_end; chunk += 64) {
+    const uint32_t ri = chunk + (uint32_t)lane;
+    const bool valid = ri < rec_end;
+    uint32_t r0 = 0, r1 = 0;
+    if (valid) {
+      const r_u32x2 v = *reinterpret_cast<const GLOBAL_AS r_u32x2*>(tus + 2 * (size_t)ri);
+      r0 = v.x; r1 = v.y;
+    }
+    const int info = (int)((r0 >> 8) & 0xFF), l2 = info & HM_TU_LOG2_MASK;
+    const bool cbf = valid && (info & HM_TU_CBF);
+    const uint32_t cnt = (r1 >> 16) & HM_TU8_COUNT_MASK; // (0 in the lanes behind the row's last record)
+    const uint32_t rsz = cbf ? 16u << (2 * (l2 - 2)) : 0u;
+    // inclusive wave scans: first level / first residual sample of every record
+    uint32_t sc = cnt, sr = rsz;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t tc = (uint32_t)__shfl_up((int)sc, o), tr = (uint32_t)__shfl_up((int)sr, o);
+      if (lane >= o) { sc += tc; sr += tr; }
+    }
+    const uint32_t lo = lev_base + sc - cnt, ro = res_base + sr - rsz;
+    lev_base += (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
+    res_base += (uint32_t)__builtin_amdgcn_readlane((int)sr, 63);
+
+    // ---- 4x4 blocks, four per pass ----
+    for (unsigned long long m4 = __ballot(cbf && l2 == 2); m4;) {
+      int b[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        b[k] = m4 ? (int)__builtin_ctzll(m4) : -1;
+        m4 &= m4 - 1; // (0 stays 0)
+      }
+      const int myb = g == 0 ? b[0] : (g == 1 ? b[1] : (g == 2 ? b[2] : b[3]));
+      const bool act = myb >= 0;
+      const int src = act ? myb : 0;
+      const uint32_t br0 = (uint32_t)__shfl((int)r0, src), bcnt = (uint32_t)__shfl((int)cnt, src);
+      const uint32_t blo = (uint32_t)__shfl((int)lo, src), bro = (uint32_t)__shfl((int)ro, src);
+      const bool has = act && (uint32_t)gl < bcnt;
+      uint32_t raw = 0;
+      if (has) raw = coeffs[blo + (uint32_t)gl];
+      // dequantisation (transform.cc:496-502, wrapping int32) of level number gl, scattered to the lane of its position
+      const int qP = (int)(br0 >> 24);
+      const int q6 = (qP * 43) >> 8, qr = qP - 6 * q6; // qP / 6, qP % 6 for qP < 128
+      const int bdShift = bd - 7;
+      const int32_t fact = (int32_t)tab[70 + qr] << q6;
+      const int pos = (int)(raw & 15);
+      if (has) {
+        const int value = (int)(int16_t)(raw >> 16);
+        const int32_t prod = (int32_t)((uint32_t)mul24(value, fact) + (uint32_t)(1 << (bdShift - 1)));
+        slots[g * 16 + pos] = clip3i(-32768, 32767, prod >> bdShift);
+      }
+      WAVE_SYNC();
+      const int cq = slots[g * 16 + gl];
+      WAVE_SYNC();
+      if (has) slots[g * 16 + pos] = 0;
+      int res;
+      if ((br0 >> 8) & HM_TU_TSKIP) { // transform.cc:566-643 (tsShift = 7; the 8-bit 4x4 variant keeps 16 bits)
+        int r = (int)(((uint32_t)cq << 7) + (uint32_t)rnd2) >> postShift;
+        if (bd == 8) r = (int16_t)r;
+        res = r;
+      }
+      else {
+        int s1 = mul24(w1[0], cq);
+        s1 += mul24(w1[1], rdpp<R_ROW_ROR(4)>(cq));
+        s1 += mul24(w1[2], rdpp<R_ROW_ROR(8)>(cq));
+        s1 += mul24(w1[3], rdpp<R_ROW_ROR(12)>(cq));
+        const int t1 = clip3i(-32768, 32767, (s1 + 64) >> 7);
+        int s2 = mul24(w2[0], rdpp<R_QUAD_BCAST(0)>(t1));
+        s2 += mul24(w2[1], rdpp<R_QUAD_BCAST(1)>(t1));
+        s2 += mul24(w2[2], rdpp<R_QUAD_BCAST(2)>(t1));
+        s2 += mul24(w2[3], rdpp<R_QUAD_BCAST(3)>(t1));
+        res = (s2 + rnd2) >> postShift;
+        if (kind == 0) res = clip3i(-32768, 32767, res); // the DST's second stage is clipped to 16 bit, the DCT's is not (Q4)
+      }
+      if (act) resid[bro + (uint32_t)gl] = limit_res(res, maxv);
+    }
+
+    // ---- 8x8 blocks, one per pass, one sample per lane ----
+    for (unsigned long long m8 = __ballot(cbf && l2 == 3); m8; m8 &= m8 - 1) {
+      const int b = (int)__builtin_ctzll(m8);
+      const uint32_t s_r0 = (uint32_t)__builtin_amdgcn_readlane((int)r0, b), s_cnt = (uint32_t)__builtin_amdgcn_readlane((int)cnt, b);
+      const uint32_t s_lo = (uint32_t)__builtin_amdgcn_readlane((int)lo, b), s_ro = (uint32_t)__builtin_amdgcn_readlane((int)ro, b);
+      const int qP = (int)(s_r0 >> 24);
+      const int bdShift = bd - 6; // BitDepth + log2(8) - 9
+      const int32_t fact = (int32_t)tab[70 + qP % 6] << (qP / 6);
+      const bool has = (uint32_t)lane < s_cnt;
+      uint32_t raw = 0;
+      if (has) raw = coeffs[s_lo + (uint32_t)lane];
+      int slot = 0;
+      if (has) {
+        const int pos = raw & 63, value = (int)(int16_t)(raw >> 16);
+        const int32_t prod = (int32_t)((uint32_t)mul24(value, fact) + (uint32_t)(1 << (bdShift - 1)));
+        slot = ((pos & 7) << 3) | (pos >> 3); // column-major: the eight inputs of a column are one 16-byte LDS read
+        coeff[slot] = (int16_t)clip3i(-32768, 32767, prod >> bdShift);
+      }
+      WAVE_SYNC();
+      const int i = lane >> 3, c = lane & 7;
+      const r_u32x4 col = *reinterpret_cast<const r_u32x4*>(coeff + c * 8);
+      const r_u32x4 wi = *reinterpret_cast<const r_u32x4*>(w8 + i * 4);
+      const int s1 = rdot2(col.w, wi.w, rdot2(col.z, wi.z, rdot2(col.y, wi.y, rdot2(col.x, wi.x, 64))));
+      tmp[i * 8 + c] = (int16_t)clip3i(-32768, 32767, s1 >> 7);
+      WAVE_SYNC();
+      if (has) coeff[slot] = 0;
+      const r_u32x4 rw = *reinterpret_cast<const r_u32x4*>(tmp + i * 8);
+      const r_u32x4 wx = *reinterpret_cast<const r_u32x4*>(w8 + c * 4);
+      const int s2 = rdot2(rw.w, wx.w, rdot2(rw.z, wx.z, rdot2(rw.y, wx.y, rdot2(rw.x, wx.x, rnd2))));
+      resid[s_ro + (uint32_t)lane] = limit_res(s2 >> postShift, maxv); // sample (x = c, y = i): raster order
+      WAVE_SYNC();
+    }
+
+    // ---- 16x16 and 32x32 blocks ----
+    for (unsigned long long mb = __ballot(cbf && l2 >= 4); mb; mb &= mb - 1) {
+      const int b = (int)__builtin_ctzll(mb);
+      const uint32_t s_r0 = (uint32_t)__builtin_amdgcn_readlane((int)r0, b), s_cnt = (uint32_t)__builtin_amdgcn_readlane((int)cnt, b);
+      const uint32_t s_lo = (uint32_t)__builtin_amdgcn_readlane((int)lo, b), s_ro = (uint32_t)__builtin_amdgcn_readlane((int)ro, b);
+      const int qP = (int)(s_r0 >> 24);
+      if (((s_r0 >> 8) & HM_TU_LOG2_MASK) == 4) big_residual<4>(coeff, tmp, dct, tab, coeffs + s_lo, (int)s_cnt, qP, bd, resid + s_ro, lane);
+      else big_residual<5>(coeff, tmp, dct, tab, coeffs + s_lo, (int)s_cnt, qP, bd, resid + s_ro, lane);
+    }
+  }
+}
+
+} // namespace
+
+// Residuals of the pictures of one class with split chains (all of them share max_ctb_h as the grid's row count).
+extern "C" int hm_launch_residual(const hm_dev_pic* d_pics, int n_pics, int max_ctb_h, hipStream_t s)
+{
+  if (n_pics <= 0) return HM_OK;
+  const long units = (long)n_pics * 2 * max_ctb_h;
+  const long groups = (units + R_WAVES - 1) / R_WAVES;
+  if (groups > 0x7FFFFFFFL) return hm_fail(HM_ERR_UNSUPPORTED, "too many CTB rows in one launch");
+  int a_n = n_pics, a_h = max_ctb_h;
+  void* args[] = {(void*)&d_pics, &a_n, &a_h};
+  hipError_t e = hipLaunchKernel(reinterpret_cast<const void*>(k_residual), dim3((unsigned)groups), dim3(R_WAVES * 64), args, R_TABLES + R_WAVES * R_WAVE, s);
+  if (e != hipSuccess) return hm_check_hip(e, "k_residual launch");
+  return hm_check_hip(hipGetLastError(), "k_residual launch");
+}

@@ -194,10 +194,17 @@ HM_API int  hm_batch_set_concurrency(hm_batch* b, int groups);
 HM_API int  hm_batch_get_timings(hm_batch* b, int slot, float ms[3]);
 /* the same plus [3] the colour conversion attached with hm_batch_set_colour (summed over the groups of images) */
 HM_API int  hm_batch_get_timings4(hm_batch* b, int slot, float ms[4]);
+/* the same with the two kernels of the split-chain reconstruction apart: [0] the prediction chains (k_chain; for other
+ * picture classes the whole reconstruction), [4] the residual pre-pass (k_residual; 0 where it does not run) */
+HM_API int  hm_batch_get_timings5(hm_batch* b, int slot, float ms[5]);
 /* 1 when the executes of this batch run the fused tail kernel: its time is reported in slot [2], [1] and [3] are 0 */
 HM_API int  hm_batch_tail_fused(const hm_batch* b);
 /* algorithmic bytes of the queued pictures: command streams read, reconstructed samples written */
 HM_API int  hm_batch_algorithmic_bytes(const hm_batch* b, uint64_t* stream_bytes, uint64_t* sample_bytes);
+/* the same per kernel of the split-chain reconstruction: out[0] command streams, [1] reconstructed samples, [2] the
+ * levels inside the streams (read by the residual pre-pass only), [3] residual samples (written by the pre-pass, read
+ * by the prediction chains) */
+HM_API int  hm_batch_algorithmic_bytes4(const hm_batch* b, uint64_t out[4]);
 
 /* ------------------------------------------------------------------------- */
 /* Plugin level: one coded picture -> host planes                              */

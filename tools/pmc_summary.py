@@ -9,7 +9,7 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
     with open(f) as fh:
         for row in csv.DictReader(fh):
             name = row["Kernel_Name"]
-            for k in ("k_recon", "k_deblock", "k_sao_paste", "k_ycbcr", "k_tail420"):
+            for k in ("k_recon", "k_chain", "k_residual", "k_deblock", "k_sao_paste", "k_ycbcr", "k_tail420"):
                 if k in name:
                     a = acc[k][row["Counter_Name"]]
                     a[0] += float(row["Counter_Value"]); a[1] += 1
@@ -22,4 +22,6 @@ for k, cs in out.items():
     if wc:
         cs["_frac_of_wave_cycles"] = {c: round(cs[c] / wc, 4) for c in cs if c.startswith(("SQ_WAIT", "SQ_ACTIVE")) }
 json.dump(out, open(os.path.join(root, "summary.json"), "w"), indent=1)
-print(json.dumps(out.get("k_recon", {}), indent=1))
+for k in ("k_recon", "k_chain", "k_residual"):
+    if k in out:
+        print(k, json.dumps(out[k], indent=1))

@@ -15,7 +15,7 @@ python3 - "$out" "$images" <<'PY'
 import csv, glob, json, os, sys
 from collections import defaultdict
 root, images = sys.argv[1], int(sys.argv[2])
-names = {"k_recon": "k_recon_quad", "k_deblock": "k_deblock", "k_sao_paste": "k_sao_paste", "k_ycbcr420_int": "k_ycbcr420_int(colour)", "k_tail420": "k_tail420(deblock+sao+paste+colour)"}
+names = {"k_recon": "k_recon_quad", "k_chain": "k_chain", "k_residual": "k_residual", "k_deblock": "k_deblock", "k_sao_paste": "k_sao_paste", "k_ycbcr420_int": "k_ycbcr420_int(colour)", "k_tail420": "k_tail420(deblock+sao+paste+colour)"}
 acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob(os.path.join(root, c, "**", "*counter_collection.csv"), recursive=True):
@@ -26,7 +26,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 res = {"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), python3 bench.py --steps 3 --warmup 1 --images {images}, MI355X; values are averages per launch in KiB as reported (tools/pmc_traffic.sh)",
        "correction": "MI355X_MICROARCH.md HBM section: bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (FETCH_SIZE counts 64 B per 128-B request on gfx950; calibrated for wide coalesced streams - narrow accesses are an upper bound)",
        "images_per_launch": images, "kernels": {}}
-launches = {"k_recon": 1, "k_deblock": 1, "k_sao_paste": 1, "k_tail420": 1, "k_ycbcr420_int": (images + 31) // 32}  # hm_colour_convert_batch: 32 images per launch
+launches = {"k_recon": 1, "k_chain": 1, "k_residual": 1, "k_deblock": 1, "k_sao_paste": 1, "k_tail420": 1, "k_ycbcr420_int": (images + 31) // 32}  # hm_colour_convert_batch: 32 images per launch
 for k, n in names.items():
     if not acc[k]["FETCH_SIZE"][1]:
         continue
