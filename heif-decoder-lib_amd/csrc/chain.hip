@@ -20,6 +20,8 @@
 //     mode, flags, the place of the residual (a 16-lane DPP scan of the block sizes), the deblocking word.  A block
 //     then costs one ds_read_b128 and a few unpacks instead of ~25 instructions of field extraction and address
 //     arithmetic per group per block, and the four-deep register pipeline of raw records is gone;
+//   * the block map of the deblocking filter (transform edges + QpY per 4x4 block) is no business of the chains either:
+//     residual.hip writes it;
 //   * PAIRS (few, large pictures): every pair of CTU rows of a picture is a wave of its own - any number of them, in
 //     any workgroup -, ordered by a ticket taken at start (a wave only ever waits for a wave with a smaller ticket, which
 //     is running or done: no deadlock whatever the dispatch order).  The hand-over between pairs goes through HBM: the
@@ -48,7 +50,8 @@ constexpr int C_SHARED_TABLES = 256;        // small tables (recon.hip layout: a
 constexpr int C_TAB4_BYTES = 35 * 16 * 2;   // per (mode, sample) of a 4x4 block: reference positions + weight
 constexpr int C_SHARED = (C_SHARED_TABLES + C_TAB4_BYTES + 15) & ~15;
 constexpr int C_RING = 32;                  // micro-ops per group: two windows of 16 records
-constexpr int C_SCRATCH = 272 + 8;          // wave-wide path: reference samples (bA)
+constexpr int C_SCRATCH = 272;              // wave-wide path: reference samples (bA)
+constexpr int C_PROG = 8;                   // progress counters per chain kind: rows r and r + 8 share one (at most 4 rows of a wave are in flight)
 constexpr int C_RING_BYTES = NG * C_RING * 16;
 
 // micro-op (uint4): x = lp | tp << 16 (sample offsets: lp from the group's plane base to sample (x0-1, y0); tp to sample
@@ -63,14 +66,13 @@ constexpr int OPW_BL_SHIFT = 19, OPW_TR_SHIFT = 23; // below-left / top-right co
 
 struct CLayout {
   int pic_bytes;     // LDS per picture (= per wave): progress counters, sample lines, scratch, rings, CTU buffers
-  int prog_ints;     // entries of one progress array (two arrays: luma chains, chroma chains)
   int off_lines_l;   // luma sample lines (one per row in flight) ...
   int line_l_bytes;
   int off_lines_c;   // ... and chroma sample lines (Cb then Cr)
   int line_c_bytes;
   int off_scratch;
   int off_rings;
-  int off_groups;    // per row of the wave: [luma chain: block map, CTU buffer][chroma chain: Cb, Cr CTU buffers]
+  int off_groups;    // per row of the wave: [luma chain: CTU buffer][chroma chain: Cb, Cr CTU buffers]
   int luma_bytes, chroma_bytes;
 };
 
@@ -84,8 +86,13 @@ enum { ST_START = 0, ST_RUN = 1, ST_DONE = 2 };
 typedef uint32_t c_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t c_u32x2 __attribute__((ext_vector_type(2)));
 
+#ifdef HM_WPE
+#define HM_CHAIN_ATTR __attribute__((amdgpu_waves_per_eu(HM_WPE, HM_WPE)))
+#else
+#define HM_CHAIN_ATTR
+#endif
 template <typename Pix, int LOG2_CTB>
-__global__ __launch_bounds__(1024) void k_chain(const hm_dev_pic* __restrict__ pics, int n_pics, CLayout L)
+__global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* __restrict__ pics, int n_pics, CLayout L)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -135,8 +142,8 @@ __global__ __launch_bounds__(1024) void k_chain(const hm_dev_pic* __restrict__ p
   // ---- this wave's task ----
   const int pic_index = blockIdx.x * (int)(blockDim.x >> 6) + wave;
   uint8_t* const pbase = lds + C_SHARED + (size_t)wave * L.pic_bytes;
-  int* const progress = reinterpret_cast<int*>(pbase); // [2][prog_ints]: finished CTUs of every row, per chain kind
-  for (int i = lane; i < 2 * L.prog_ints; i += 64) progress[i] = 0;
+  int* const progress = reinterpret_cast<int*>(pbase); // [2][C_PROG]: finished CTUs of the rows in flight, per chain kind
+  if (lane < 2 * C_PROG) progress[lane] = 0;
   __syncthreads();
   if (pic_index >= n_pics) return;
 
@@ -170,10 +177,8 @@ __global__ __launch_bounds__(1024) void k_chain(const hm_dev_pic* __restrict__ p
   auto group_base = [&](int gg) -> uint8_t* {
     return pbase + L.off_groups + (mono ? (size_t)gg * L.luma_bytes : (size_t)(gg >> 1) * (L.luma_bytes + L.chroma_bytes) + (size_t)(gg & 1) * L.luma_bytes);
   };
-  auto group_meta = [&](int gg) { return reinterpret_cast<uint16_t*>(group_base(gg)); }; // luma groups only
   auto group_u = [&](int gg, int c) { // plane c of the group's chain (luma groups: c = 0; chroma groups: c = 1, 2)
     uint8_t* p = group_base(gg);
-    if (c == 0) p += META_BYTES(ctb);
     if (c == 2) p += (size_t)P1 * ch_c * sizeof(Pix);
     return reinterpret_cast<Pix*>(p);
   };
@@ -190,12 +195,10 @@ __global__ __launch_bounds__(1024) void k_chain(const hm_dev_pic* __restrict__ p
   const int Pk = kind ? P1 : P0;               // pitch of the chain's CTU buffers
   const int l2w = kind ? log2_ctb - 1 : log2_ctb; // log2 of the CTU width in samples of the chain's planes
   const int cr_off = P1 * ch_c;                // Cr buffer behind the Cb buffer, in samples
-  uint16_t* const gmeta = group_meta(g);
-  int* const my_progress = progress + kind * L.prog_ints;
+  int* const my_progress = progress + kind * C_PROG;
   c_u32x4* const ring = rings + g * C_RING;
   // byte offsets in LDS of the group's places, for the wave-wide path (fetched from the group's first lane)
   const uint32_t gb_off = (uint32_t)(reinterpret_cast<uint8_t*>(gbase) - lds);
-  const uint32_t meta_off = (uint32_t)(reinterpret_cast<uint8_t*>(gmeta) - lds);
 
   // ---- group state (the same value in the 16 lanes of a group) ----
   int row = group_slot(g), cx = 0, kleft = 0;
@@ -206,8 +209,7 @@ __global__ __launch_bounds__(1024) void k_chain(const hm_dev_pic* __restrict__ p
   const uint32_t lr_off = (uint32_t)(reinterpret_cast<const uint8_t*>(lr) - lds);
   uint32_t tl_off = lr_off; // the CTU's first sample in the sample line of the row above: lr + (cx << l2w)
   int st = row < ctb_h ? ST_START : ST_DONE;
-  int cb_flags = 0;
-  uint32_t c0 = 0, c1 = 0, c2 = 0; // header of the CTU to start next: first record of the chain, count, flags
+  uint32_t c0 = 0, c1 = 0; // header of the CTU to start next: first record of the chain, count
   uint32_t ri = 0;                 // index of the current block's record
   uint32_t rfirst = 0;             // first record of the row's chain
   uint32_t wnext = 0;              // next window (16 records: index >> 4) to decode into the ring
@@ -228,9 +230,12 @@ __global__ __launch_bounds__(1024) void k_chain(const hm_dev_pic* __restrict__ p
   };
   auto header = [&](int r, int x) { // chain header of CTU (r, x): first record, count, flags
     const GLOBAL_AS uint32_t* q = ctbq + HM_CTB_DWORDS * ((size_t)r * ctb_w + x);
-    c0 = q[kind ? 9 : 0]; c1 = q[kind ? 10 : 1]; c2 = q[2]; // (masked where they are used: no wait for the loads here)
+    c0 = q[kind ? 9 : 0]; c1 = q[kind ? 10 : 1]; // (masked where they are used: no wait for the loads here)
   };
   auto row_start = [&]() { // header of CTU (row, 0) and the first window of the row's chain
+    // the row's progress counter: last used by row - 8.  The chain of row + 1 - a group of this wave that starts its row
+    // after this one: it finished row - 1 behind this group's row - 2 - reads it from now on.
+    if (gl == 0) __hip_atomic_store(my_progress + (row & (C_PROG - 1)), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     header(row, 0);
     ri = rfirst = c0;
     wnext = ri >> 4;
@@ -249,28 +254,27 @@ __global__ __launch_bounds__(1024) void k_chain(const hm_dev_pic* __restrict__ p
     if (st == ST_START) {
       const int need = cx + 2 < ctb_w ? cx + 2 : ctb_w;
       // (a counter value seen here means the line samples written before it are there: LDS traffic of a wave is in order)
-      const int done_above = __hip_atomic_load(my_progress + (row > 0 ? row - 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const int done_above = __hip_atomic_load(my_progress + ((row - 1) & (C_PROG - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (row == 0 || done_above >= need) {
         kleft = (int)(c1 & 0xFFFF);
-        cb_flags = (int)(c2 & 0xFF);
         st = ST_RUN;
         started = true;
       }
     }
-    if (__ballot(started)) { // (wave-uniform: the loads below are not merged with anything, so nobody waits for them here)
+    if (ballot(started)) { // (wave-uniform: the loads below are not merged with anything, so nobody waits for them here)
       // every lane asks for the header its chain needs next: a group inside CTU cx the one of cx + 1 (the last CTU of a
       // row: its own again), a waiting group the one of the CTU it waits to start
       const int hx = st == ST_RUN ? (cx + 1 < ctb_w ? cx + 1 : cx) : cx;
       header(row < ctb_h ? row : ctb_h - 1, hx);
     }
-    if (__ballot(st != ST_DONE) == 0) break;
+    if (ballot(st != ST_DONE) == 0) break;
     if (--budget < 0) break; // (never on a valid stream: a wave that cannot finish leaves a wrong picture, not a hung GPU)
 
     HM_MARK("R_begin");
     // ---- R: decode the next 16 records of every group that has entered the last decoded window ----
     {
       const bool need_dec = st != ST_DONE && wnext <= (ri >> 4) + 1;
-      if (__ballot(need_dec)) {
+      if (ballot(need_dec)) {
         if (need_dec) {
           const uint32_t r0 = pf0, r1 = pf1;
           const uint32_t idx = (wnext << 4) + (uint32_t)gl;
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(1024) void k_chain(const hm_dev_pic* __restrict__ p
     // ---- the residual pipeline of a group that has both windows of a new row: blocks ri, ri + 1, ri + 2 ----
     {
       const bool prime = st != ST_DONE && !primed && wnext >= (ri >> 4) + 2;
-      if (__ballot(prime)) {
+      if (ballot(prime)) {
         if (prime) {
           pre = res_of(ring[ri & (C_RING - 1)].z);
           pre_m = res_of(ring[(ri + 1) & (C_RING - 1)].z);
@@ -325,20 +329,21 @@ __global__ __launch_bounds__(1024) void k_chain(const hm_dev_pic* __restrict__ p
     // the current block of every group
     const c_u32x4 op = ring[ri & (C_RING - 1)];
     const bool quad = running && (op.y & (3u << OP_L2_SHIFT)) == 0 && (op.y & OP_INTERIOR);
-    const unsigned long long s_big = __ballot(running && !quad);
+    const unsigned long long s_big = ballot(running && !quad);
+    const unsigned long long s_bres = ballot(running && !quad && (op.y & OP_CBF) && (op.y & (2u << OP_L2_SHIFT)) == 0);
 
-    // ---- P: residual of the blocks of the wave-wide path: their first 64 samples, requested before the side-by-side phase ----
+    // ---- P: residual of the 4x4 / 8x8 blocks of the wave-wide path (lane = sample), requested before the side-by-side phase ----
     uint32_t bres0 = 0, bres1 = 0, bres2 = 0, bres3 = 0;
-    if (s_big) {
+    if (s_bres) {
       auto big_res = [&](int gg) -> uint32_t {
         uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)op.z, gg * 16) + (uint32_t)lane;
         idx = idx < res_last ? idx : res_last;
         return (uint32_t)(int)resid[idx];
       };
-      if (s_big & 0xFFFFull) bres0 = big_res(0);
-      if (s_big & 0xFFFF0000ull) bres1 = big_res(1);
-      if (s_big & 0xFFFF00000000ull) bres2 = big_res(2);
-      if (s_big & 0xFFFF000000000000ull) bres3 = big_res(3);
+      if (s_bres & 0xFFFFull) bres0 = big_res(0);
+      if (s_bres & 0xFFFF0000ull) bres1 = big_res(1);
+      if (s_bres & 0xFFFF00000000ull) bres2 = big_res(2);
+      if (s_bres & 0xFFFF000000000000ull) bres3 = big_res(3);
     }
 
     HM_MARK("C_begin");
@@ -391,13 +396,6 @@ __global__ __launch_bounds__(1024) void k_chain(const hm_dev_pic* __restrict__ p
       }
       if (op.y & OP_CBF) v = clip3i(0, maxv, v + (int)pre);
       lp[mul24(by, P) + 1 + bx] = (Pix)v;
-      if (kind == 0 && gl == 0) { // deblocking metadata (deblock.cc:31-62): transform edges + QpY of the 4x4 block
-        const int x4 = (int)((op.w >> 8) & 15), y4 = (int)((op.w >> 12) & 15);
-        const int deblock_en = !(cb_flags & HM_CTB_DEBLOCK_OFF);
-        const int left_ok = (x4 > 0) | ((cb_flags & HM_CTB_DEBLOCK_LEFT) != 0);
-        const int top_ok = (y4 > 0) | ((cb_flags & HM_CTB_DEBLOCK_TOP) != 0);
-        gmeta[(y4 << (log2_ctb - 2)) + x4] = (uint16_t)((left_ok & deblock_en) | ((top_ok & deblock_en) << 1) | ((op.w & 0xFF) << 8));
-      }
     }
     WAVE_SYNC();
 
@@ -415,8 +413,6 @@ __global__ __launch_bounds__(1024) void k_chain(const hm_dev_pic* __restrict__ p
       const uint32_t ox = (uint32_t)__builtin_amdgcn_readlane((int)op.x, src), oy = (uint32_t)__builtin_amdgcn_readlane((int)op.y, src);
       const uint32_t oz = (uint32_t)__builtin_amdgcn_readlane((int)op.z, src), ow = (uint32_t)__builtin_amdgcn_readlane((int)op.w, src);
       const uint32_t s_gb = (uint32_t)__builtin_amdgcn_readlane((int)gb_off, src), s_tl = (uint32_t)__builtin_amdgcn_readlane((int)tl_off, src);
-      const int s_flags = __builtin_amdgcn_readlane(cb_flags, src);
-      const uint32_t bres = bg == 0 ? bres0 : (bg == 1 ? bres1 : (bg == 2 ? bres2 : bres3));
       const int mode = (int)(oy & OP_MODE_MASK), c = (int)((oy >> OP_C_SHIFT) & 3), log2 = 2 + (int)((oy >> OP_L2_SHIFT) & 3);
       const bool cbf = (oy & OP_CBF) != 0;
       const int P = c == 0 ? P0 : P1;
@@ -433,9 +429,28 @@ __global__ __launch_bounds__(1024) void k_chain(const hm_dev_pic* __restrict__ p
         int ln = lane;
         asm volatile("" : "+v"(ln));
         // prediction + residual + clip + store of sample p = x + nT * y (the residual of a block lies in raster order)
+        // (the residual is only looked at - waited for - by blocks that have one)
+        int res_s = 0, res_t[4] = {0, 0, 0, 0};
+        if (cbf) {
+          if (L2 <= 3) {
+            uint32_t b = bg == 0 ? bres0 : (bg == 1 ? bres1 : (bg == 2 ? bres2 : bres3));
+            asm volatile("" : "+v"(b)); // keeps the select - and the wait for the load - inside this branch
+            res_s = (int)b;
+          }
+          else if (L2 == 4) { // 256 samples = four trips of the prediction: requested here, in flight while the border is made
+#pragma unroll
+            for (int t = 0; t < 4; t++) res_t[t] = (int)gres[ln + 64 * t];
+          }
+        }
         auto emit = [&](int p, int x, int y, int v) {
           if (cbf) {
-            const int r = L2 <= 3 ? (int)bres : (int)gres[p];
+            int r;
+            if (L2 <= 3) r = res_s;
+            else if (L2 == 4) {
+              const int t = rfl(p >> 6); // the trip: the same in every lane
+              r = t == 0 ? res_t[0] : (t == 1 ? res_t[1] : (t == 2 ? res_t[2] : res_t[3]));
+            }
+            else r = (int)gres[p];
             v = clip3i(0, maxv, v + r);
           }
           dst[mul24(y, P) + x] = (Pix)v;
@@ -460,31 +475,29 @@ __global__ __launch_bounds__(1024) void k_chain(const hm_dev_pic* __restrict__ p
           B.x0 = (int)((ow >> 6) & 0x3C); B.y0 = (int)((ow >> 10) & 0x3C);
           B.u = gb + (c == 2 ? cr_off : 0);
           B.top = reinterpret_cast<const Pix*>(lds + s_tl) - 1 + (c == 2 ? Wc + 4 : 0);
+#if !defined(HM_Q_PROBE) || !(HM_Q_PROBE & 16)
           make_border<Pix, L2>(B, l_bA, strong, ln);
           WAVE_SYNC();
           predict_emit<Pix, L2>(B, RefArray{l_bA + 64}, tab, ln, emit);
+#endif
         }
 #endif
         WAVE_SYNC();
         HM_MARK("D_pred_end");
-        if (c == 0) { // deblocking metadata (deblock.cc:31-62): transform edges + QpY
-          constexpr int n4 = 1 << (L2 - 2);
-          if (ln < n4 * n4) {
-            uint16_t* const l_meta = reinterpret_cast<uint16_t*>(lds + (uint32_t)__builtin_amdgcn_readlane((int)meta_off, src));
-            const int x4 = (int)((ow >> 8) & 15), y4 = (int)((ow >> 12) & 15);
-            const int i = ln & (n4 - 1), j = ln >> (L2 - 2);
-            const int deblock_en = !(s_flags & HM_CTB_DEBLOCK_OFF);
-            const int left_ok = (x4 > 0) | ((s_flags & HM_CTB_DEBLOCK_LEFT) != 0);
-            const int top_ok = (y4 > 0) | ((s_flags & HM_CTB_DEBLOCK_TOP) != 0);
-            const int e = ((i == 0) & left_ok & deblock_en) | (((j == 0) & top_ok & deblock_en) << 1);
-            l_meta[((y4 + j) << (log2_ctb - 2)) + x4 + i] = (uint16_t)(e | ((ow & 0xFF) << 8));
-          }
-        }
       };
+#if defined(HM_Q_PROBE) && (HM_Q_PROBE & 96)
+      { // class probes: 32 = only the blocks of the one-pass path (4x4 / 8x8, interior, not smoothed), 64 = only the others
+        const bool sm = log2 == 3 && c == 0 && ((filter_mode_mask(3) >> mode) & 1);
+        const bool fast = log2 <= 3 && !sm && (oy & OP_INTERIOR);
+        if (((HM_Q_PROBE & 32) && !fast) || ((HM_Q_PROBE & 64) && fast)) continue;
+      }
+#endif
       if (log2 == 2) block(std::integral_constant<int, 2>());
       else if (log2 == 3) block(std::integral_constant<int, 3>());
+#if !defined(HM_Q_PROBE) || !(HM_Q_PROBE & 8)
       else if (log2 == 4) block(std::integral_constant<int, 4>());
       else block(std::integral_constant<int, 5>());
+#endif
       WAVE_SYNC();
     }
 
@@ -499,7 +512,7 @@ __global__ __launch_bounds__(1024) void k_chain(const hm_dev_pic* __restrict__ p
 
     HM_MARK("F_begin");
     // ---- F: finished CTUs: coalesced stores to the picture, bottom row -> line, right column -> left column ----
-    for (unsigned long long fin = __ballot(st == ST_RUN && kleft == 0); fin;) {
+    for (unsigned long long fin = ballot(st == ST_RUN && kleft == 0); fin;) {
       const int fg = rfl((int)(__builtin_ctzll(fin) >> 4));
       fin &= ~(0xFFFFull << (fg * 16));
       const int src = fg * 16;
@@ -551,21 +564,9 @@ __global__ __launch_bounds__(1024) void k_chain(const hm_dev_pic* __restrict__ p
         flush_plane(std::integral_constant<int, (ctb >> 1)>(), group_u(fg, 1), P1, lw, fp->plane[1], fp->pitch[1], ch_c, planeWc, planeHc);
         flush_plane(std::integral_constant<int, (ctb >> 1)>(), group_u(fg, 2), P1, lw + (Wc + 4), fp->plane[2], fp->pitch[2], ch_c, planeWc, planeHc);
       }
-      if (fkind == 0) { // the CTU's block map; cells outside the picture were never written
-        constexpr int M4 = ctb >> 2;
-        const uint16_t* const l_meta = group_meta(fg);
-        const int w4 = fp->w4, h4 = fp->h4;
-        GLOBAL_AS uint16_t* const ctb_meta = gptr_w<uint16_t>(fp->meta) + (size_t)((s_row << log2_ctb) >> 2) * w4 + ((s_cx << log2_ctb) >> 2);
-        const int gx0 = s_cx << (log2_ctb - 2), gy0 = s_row << (log2_ctb - 2);
-#pragma unroll
-        for (int idx0 = 0; idx0 < M4 * M4; idx0 += 64) {
-          const int idx = idx0 + lane, bi = idx & (M4 - 1), bj = idx >> (log2_ctb - 2);
-          if (idx < M4 * M4 && gx0 + bi < w4 && gy0 + bj < h4) ctb_meta[(uint32_t)bi + __umul24((uint32_t)bj, (uint32_t)w4)] = l_meta[idx];
-        }
-      }
       WAVE_SYNC();
       // read by the chain of the row below, a group of this wave (LDS traffic of a wave is in order)
-      if (lane == 0) __hip_atomic_store(progress + fkind * L.prog_ints + s_row, s_cx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (lane == 0) __hip_atomic_store(progress + fkind * C_PROG + (s_row & (C_PROG - 1)), s_cx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       // the group's next CTU
       if (g == fg) {
         cx += 1;
@@ -604,29 +605,17 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   const int ch = chroma_format == 1 ? ctb / 2 : ctb;
   auto al = [](int v) { return (v + 15) & ~15; };
   CLayout L;
-  L.prog_ints = (max_ctb_h + 3) & ~3;
-  L.line_l_bytes = al((4 + max_ctb_w * ctb) * pb);
-  L.line_c_bytes = mono ? 0 : al((8 + 2 * max_ctb_w * (ctb / 2)) * pb);
-  L.off_lines_l = al(2 * L.prog_ints * 4);
+  auto al4 = [](int v) { return (v + 3) & ~3; };
+  L.line_l_bytes = al4((4 + max_ctb_w * ctb) * pb); // (every byte counts: 8048 per wave put 20 waves on a CU, 8064 only 18)
+  L.line_c_bytes = mono ? 0 : al4((8 + 2 * max_ctb_w * (ctb / 2)) * pb);
+  L.off_lines_l = 2 * C_PROG * 4;
   L.off_lines_c = L.off_lines_l + nr * L.line_l_bytes;
   L.off_scratch = L.off_lines_c + (mono ? 0 : nr * L.line_c_bytes);
-  L.off_rings = L.off_scratch + al(C_SCRATCH);
+  L.off_rings = al(L.off_scratch + C_SCRATCH);
   L.off_groups = L.off_rings + C_RING_BYTES;
-  L.luma_bytes = al(META_BYTES(ctb) + (ctb + UPAD) * ctb * pb);
+  L.luma_bytes = al((ctb + UPAD) * ctb * pb);
   L.chroma_bytes = mono ? 0 : al(2 * (ctb / 2 + UPAD) * ch * pb);
   L.pic_bytes = al(L.off_groups + (mono ? 4 * L.luma_bytes : 2 * (L.luma_bytes + L.chroma_bytes)));
-  // waves (= pictures) per workgroup: they only share the tables; the count that puts the most waves on a CU's 160 KiB
-  int np = 0, best = 0;
-  for (int k = 1; k <= 16; k++) {
-    const int bytes = C_SHARED + k * L.pic_bytes;
-    if (bytes > 160 * 1024) break;
-    int per_cu = (160 * 1024 / bytes) * k;
-    if (per_cu > 20) per_cu = 20;
-    if (per_cu > best) { best = per_cu; np = k; }
-  }
-  if (np == 0) return 0;
-  while (np > 1 && (long)np * 256 > n_pics) np--; // few pictures: spread them over the CUs first
-  const int lds_bytes = C_SHARED + np * L.pic_bytes;
   const void* fn = nullptr;
   switch (log2_ctb * 2 + (pb - 1)) {
     case 8: fn = reinterpret_cast<const void*>(k_chain<uint8_t, 4>); break;
@@ -637,6 +626,33 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
     case 13: fn = reinterpret_cast<const void*>(k_chain<uint16_t, 6>); break;
     default: return 0;
   }
+  // waves (= pictures) per workgroup: they only share the tables.  The count that puts the most waves on a CU: its
+  // 160 KiB of LDS and the waves its four SIMDs hold with the kernel's register count (512 VGPRs per lane and SIMD, in
+  // steps of 8) both limit whole workgroups
+  static int cu_waves_of[6] = {0, 0, 0, 0, 0, 0}; // (per instantiation; a benign race: every thread computes the same value)
+  int& cu_waves = cu_waves_of[log2_ctb * 2 + (pb - 1) - 8];
+  if (cu_waves == 0) {
+    hipFuncAttributes fa;
+    int w = 16;
+    if (hipFuncGetAttributes(&fa, fn) == hipSuccess && fa.numRegs > 0) {
+      const int per_simd = 512 / ((fa.numRegs + 7) & ~7);
+      w = 4 * (per_simd < 1 ? 1 : (per_simd > 8 ? 8 : per_simd));
+    }
+    cu_waves = w;
+  }
+  int np = 0, best = 0;
+  for (int k = 1; k <= 16; k++) {
+    const int bytes = C_SHARED + k * L.pic_bytes;
+    if (bytes > 160 * 1024) break;
+    const int by_lds = 160 * 1024 / bytes, by_regs = cu_waves / k;
+    const int per_cu = (by_lds < by_regs ? by_lds : by_regs) * k;
+    if (per_cu > best) { best = per_cu; np = k; }
+  }
+  if (np == 0) return 0;
+  while (np > 1 && (long)np * 256 > n_pics) np--; // few pictures: spread them over the CUs first
+  const int lds_bytes = C_SHARED + np * L.pic_bytes;
+  static const int debug = [] { const char* e = getenv("HM_CHAIN_DEBUG"); return e ? atoi(e) : 0; }();
+  if (debug) fprintf(stderr, "[k_chain] %d pictures, %d bytes of LDS per wave, %d waves per workgroup, %d waves per CU (registers allow %d)\n", n_pics, L.pic_bytes, np, best, cu_waves);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return hm_check_hip(e, "hipFuncSetAttribute(k_chain)");
   int a_n = n_pics;

@@ -29,6 +29,9 @@ __device__ __forceinline__ int imin_(int a, int b) { return a < b ? a : b; }
 // sample or basis x coefficient, far below 2^23 per operand
 __device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// lane mask of a condition, straight from the compare (HIP's __ballot(int) converts the condition to an integer and
+// compares it again: two vector instructions per use)
+__device__ __forceinline__ unsigned long long ballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 
 __device__ __forceinline__ int wave_max(int v)
 {

@@ -8,7 +8,8 @@
 // chain kind) of every picture is one wave of a plain grid launch, the residuals go to HBM as int16 (recon_common.h:
 // ResidGeom) and the chain kernel only predicts and adds.
 //   * a wave walks the records of its row 64 at a time (lane = record): two wave scans give every record its first
-//     level and the place of its residual;
+//     level and the place of its residual; the luma chains also write the deblocking filter's block map (transform
+//     edges + QpY per 4x4 block, deblock.cc:31-62) - another thing that needs no neighbour;
 //   * 4x4 blocks with a residual are then transformed four at a time (16 lanes = 16 samples of a block: the rows /
 //     columns of the 4-point transforms are exchanged with DPP row rotations and quad broadcasts, nothing goes through
 //     LDS but the scatter of the levels), 8x8 blocks one per pass (64 lanes = 64 samples, v_dot2_i32_i16 on 16-byte LDS
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(R_WAVES * 64) void k_residual(const hm_dev_pic* __r
   const uint32_t rec_end = q1[kind ? 9 : 0] + (q1[kind ? 10 : 1] & 0xFFFFu);
   uint32_t lev_base = q0[kind ? 12 : 11];
   uint32_t res_base = RG.slab(kind, row);
+  int cur_ctb = 0; // CTB (column) of the chunk's first record
 
   // ---- per-lane constants of the 4x4 transform (lane = sample (bx, by) of the block of its 16-lane group) ----
   const int g = lane >> 4, gl = lane & 15, bx_ = gl & 3, by_ = gl >> 2;
@@ -194,8 +196,61 @@ __global__ __launch_bounds__(R_WAVES * 64) void k_residual(const hm_dev_pic* __r
     lev_base += (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
     res_base += (uint32_t)__builtin_amdgcn_readlane((int)sr, 63);
 
+    // ---- the block map of the deblocking filter (luma chains): per 4x4 block the transform edges on its left / on top
+    //      (bit 0 / bit 1) and QpY (bits 8-15), deblock.cc:31-62 of the reference ----
+    if (kind == 0) {
+      // the CTB of every record of the chunk: the CTBs that start inside it are marked at their first record, a scan
+      // counts them (every CTB has records, so at most 63 start behind the chunk's first record)
+      {
+        const int cand = cur_ctb + 1 + lane;
+        if (cand < dp.ctb_w) {
+          const uint32_t tf = q0[HM_CTB_DWORDS * (size_t)cand] - chunk;
+          if (tf < 64u) __hip_atomic_fetch_add(slots + tf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+      }
+      WAVE_SYNC();
+      int sm = slots[lane];
+      WAVE_SYNC();
+      slots[lane] = 0;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(sm, o);
+        if (lane >= o) sm += t;
+      }
+      const int my_ctb = cur_ctb + sm;
+      cur_ctb += __builtin_amdgcn_readlane(sm, 63);
+      const int flags = valid ? (int)(q0[HM_CTB_DWORDS * (size_t)my_ctb + 2] & 0xFF) : 0;
+      const int en = !(flags & HM_CTB_DEBLOCK_OFF);
+      const int x4 = (int)(r0 & 15), y4 = (int)((r0 >> 4) & 15);
+      const int left_ok = ((x4 > 0) | ((flags & HM_CTB_DEBLOCK_LEFT) != 0)) & en;
+      const int top_ok = ((y4 > 0) | ((flags & HM_CTB_DEBLOCK_TOP) != 0)) & en;
+      const uint32_t qword = (r1 & 0xFF) << 8;
+      const int l4 = dp.log2_ctb - 2;
+      const int gx = (my_ctb << l4) + x4, gy = (row << l4) + y4; // the block's first cell in the picture's map
+      GLOBAL_AS uint16_t* const meta = gptr_w<uint16_t>(dp.meta);
+      const int w4 = dp.w4, h4 = dp.h4;
+      // 4x4 and 8x8 blocks: the lane of the record writes its 1 / 4 cells
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int i = k & 1, j = k >> 1;
+        if (valid && l2 <= 3 && (k == 0 || l2 == 3) && gx + i < w4 && gy + j < h4)
+          meta[(uint32_t)(gx + i) + __umul24((uint32_t)(gy + j), (uint32_t)w4)] = (uint16_t)((i == 0 ? left_ok : 0) | ((j == 0 ? top_ok : 0) << 1) | qword);
+      }
+      // 16x16 and 32x32 blocks: one cell per lane
+      for (unsigned long long mb = ballot(valid && l2 >= 4); mb; mb &= mb - 1) {
+        const int b = (int)__builtin_ctzll(mb);
+        const int s_l2 = __builtin_amdgcn_readlane(l2, b), s_gx = __builtin_amdgcn_readlane(gx, b), s_gy = __builtin_amdgcn_readlane(gy, b);
+        const int s_left = __builtin_amdgcn_readlane(left_ok, b), s_top = __builtin_amdgcn_readlane(top_ok, b);
+        const uint32_t s_q = (uint32_t)__builtin_amdgcn_readlane((int)qword, b);
+        const int n4 = 1 << (s_l2 - 2);
+        const int i = lane & (n4 - 1), j = lane >> (s_l2 - 2);
+        if (lane < n4 * n4 && s_gx + i < w4 && s_gy + j < h4)
+          meta[(uint32_t)(s_gx + i) + __umul24((uint32_t)(s_gy + j), (uint32_t)w4)] = (uint16_t)((i == 0 ? s_left : 0) | ((j == 0 ? s_top : 0) << 1) | s_q);
+      }
+    }
+
     // ---- 4x4 blocks, four per pass ----
-    for (unsigned long long m4 = __ballot(cbf && l2 == 2); m4;) {
+    for (unsigned long long m4 = ballot(cbf && l2 == 2); m4;) {
       int b[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) {
@@ -248,7 +303,7 @@ __global__ __launch_bounds__(R_WAVES * 64) void k_residual(const hm_dev_pic* __r
     }
 
     // ---- 8x8 blocks, one per pass, one sample per lane ----
-    for (unsigned long long m8 = __ballot(cbf && l2 == 3); m8; m8 &= m8 - 1) {
+    for (unsigned long long m8 = ballot(cbf && l2 == 3); m8; m8 &= m8 - 1) {
       const int b = (int)__builtin_ctzll(m8);
       const uint32_t s_r0 = (uint32_t)__builtin_amdgcn_readlane((int)r0, b), s_cnt = (uint32_t)__builtin_amdgcn_readlane((int)cnt, b);
       const uint32_t s_lo = (uint32_t)__builtin_amdgcn_readlane((int)lo, b), s_ro = (uint32_t)__builtin_amdgcn_readlane((int)ro, b);
@@ -281,7 +336,7 @@ __global__ __launch_bounds__(R_WAVES * 64) void k_residual(const hm_dev_pic* __r
     }
 
     // ---- 16x16 and 32x32 blocks ----
-    for (unsigned long long mb = __ballot(cbf && l2 >= 4); mb; mb &= mb - 1) {
+    for (unsigned long long mb = ballot(cbf && l2 >= 4); mb; mb &= mb - 1) {
       const int b = (int)__builtin_ctzll(mb);
       const uint32_t s_r0 = (uint32_t)__builtin_amdgcn_readlane((int)r0, b), s_cnt = (uint32_t)__builtin_amdgcn_readlane((int)cnt, b);
       const uint32_t s_lo = (uint32_t)__builtin_amdgcn_readlane((int)lo, b), s_ro = (uint32_t)__builtin_amdgcn_readlane((int)ro, b);
