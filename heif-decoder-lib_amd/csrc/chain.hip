@@ -60,6 +60,7 @@ constexpr int C_RING_BYTES = NG * C_RING * 16;
 constexpr uint32_t OP_MODE_MASK = 63u;
 constexpr int OP_C_SHIFT = 6, OP_L2_SHIFT = 8; // colour component (2 bits), log2 size - 2 (2 bits)
 constexpr uint32_t OP_CBF = 1u << 10, OP_INTERIOR = 1u << 11, OP_LINE = 1u << 13;
+constexpr uint32_t OP_FAST8 = 1u << 12; // 8x8 block, neighbours complete, reference samples not smoothed: the one-pass path of phase D
 constexpr int OP_NL1_SHIFT = 14, OP_NT1_SHIFT = 20; // last usable position of the left / top run (6 bits each)
 constexpr uint32_t OPW_LEFT = 1u << 16, OPW_TOP = 1u << 17, OPW_TL = 1u << 18;
 constexpr int OPW_BL_SHIFT = 19, OPW_TR_SHIFT = 23; // below-left / top-right counts in units of 4 (4 bits each)
@@ -247,6 +248,9 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   // every iteration executes a block of some chain or waits for a CTU that is at most two CTUs of another chain away
   int budget = (int)n_tus + 64 * ctb_w * ctb_h + 4096;
 
+#if defined(HM_PAD_S) || defined(HM_PAD_V)
+  int lane0_dummy = 0, pad_v = lane;
+#endif
   for (;;) {
     HM_MARK("A_begin");
     // ---- A: start the next CTU of every group whose dependency is met (the row above two CTUs ahead) ----
@@ -268,6 +272,9 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       header(row < ctb_h ? row : ctb_h - 1, hx);
     }
     if (ballot(st != ST_DONE) == 0) break;
+#if defined(HM_PAD_S) || defined(HM_PAD_V)
+    if (lane0_dummy + pad_v == -12345) break; // (keeps the padding alive)
+#endif
     if (--budget < 0) break; // (never on a valid stream: a wave that cannot finish leaves a wrong picture, not a hung GPU)
 
     HM_MARK("R_begin");
@@ -300,8 +307,11 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
           s += (uint32_t)dpp<DPP_ROW_SHR(8)>((int)s);
           c_u32x4 op;
           op.x = (uint32_t)lp | ((uint32_t)tp << 16);
-          op.y = mode | ((uint32_t)c << OP_C_SHIFT) | ((uint32_t)(l2 - 2) << OP_L2_SHIFT) | (cbf ? OP_CBF : 0u) | ((left && top && tl) ? OP_INTERIOR : 0u) |
-                 (on_line ? OP_LINE : 0u) | (nL1 << OP_NL1_SHIFT) | (nT1 << OP_NT1_SHIFT);
+          const bool interior = left && top && tl;
+          // (8x8 luma reference samples are smoothed for planar and the three diagonals only: intrapred.h:192-214)
+          const bool fast8 = l2 == 3 && interior && !(c == 0 && (mode == 0 || mode == 2 || mode == 18 || mode == 34));
+          op.y = mode | ((uint32_t)c << OP_C_SHIFT) | ((uint32_t)(l2 - 2) << OP_L2_SHIFT) | (cbf ? OP_CBF : 0u) | (interior ? OP_INTERIOR : 0u) |
+                 (fast8 ? OP_FAST8 : 0u) | (on_line ? OP_LINE : 0u) | (nL1 << OP_NL1_SHIFT) | (nT1 << OP_NT1_SHIFT);
           op.z = rbase + s - rsz;
           op.w = (r1 & 0xFF) | ((r0 & 0xFF) << 8) | (left ? OPW_LEFT : 0u) | (top ? OPW_TOP : 0u) | (tl ? OPW_TL : 0u) | (aBL4 << OPW_BL_SHIFT) | (aTR4 << OPW_TR_SHIFT);
           ring[idx & (C_RING - 1)] = op;
@@ -414,7 +424,11 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       const uint32_t oz = (uint32_t)__builtin_amdgcn_readlane((int)op.z, src), ow = (uint32_t)__builtin_amdgcn_readlane((int)op.w, src);
       const uint32_t s_gb = (uint32_t)__builtin_amdgcn_readlane((int)gb_off, src), s_tl = (uint32_t)__builtin_amdgcn_readlane((int)tl_off, src);
       const int mode = (int)(oy & OP_MODE_MASK), c = (int)((oy >> OP_C_SHIFT) & 3), log2 = 2 + (int)((oy >> OP_L2_SHIFT) & 3);
+#if defined(HM_Q_PROBE) && (HM_Q_PROBE & 512)
+      const bool cbf = false;
+#else
       const bool cbf = (oy & OP_CBF) != 0;
+#endif
       const int P = c == 0 ? P0 : P1;
       Pix* const gb = reinterpret_cast<Pix*>(lds + s_gb);                           // the chain's first plane (luma / Cb)
       Pix* const lp = gb + (ox & 0xFFFF);                                             // sample (x0-1, y0)
@@ -485,6 +499,53 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         WAVE_SYNC();
         HM_MARK("D_pred_end");
       };
+#if defined(HM_Q_PROBE) && (HM_Q_PROBE & 256)
+      if ((oy & OP_FAST8) && mode >= 2 && mode != 10 && mode != 26) continue; // probe: what the written-out path costs
+#endif
+#if !defined(HM_Q_PROBE) || !(HM_Q_PROBE & 128)
+      if ((oy & OP_FAST8) && mode >= 2 && mode != 10 && mode != 26) {
+        // ---- the commonest block of this phase, written out: 8x8, neighbours complete, an angular mode, reference samples
+        //      read in place (intrapred.h:338-441).  One sample per lane. ----
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int x = ln & 7, y = ln >> 3;
+        const int nL1 = (int)((oy >> OP_NL1_SHIFT) & 63), nT1 = (int)((oy >> OP_NT1_SHIFT) & 63);
+        const int angle = c_intra_angle[mode];
+        const bool vert = mode >= 18;
+        const int major = vert ? y : x, minor = vert ? x : y;
+        const int t = mul24(major + 1, angle);
+        const int f = t & 31, k = minor + (t >> 5); // k + 1, k + 2: the two reference positions of the main run
+        int r0, r1;
+        if (angle > 0) { // every position lies on one side (top row for the vertical modes)
+          if (vert) { r0 = tp[imin_(k, nT1)]; r1 = tp[imin_(k + 1, nT1)]; }
+          else { r0 = lp[mul24(imin_(k, nL1), P)]; r1 = lp[mul24(imin_(k + 1, nL1), P)]; }
+        }
+        else { // positions <= 0 are projected onto the other side with the inverse angle
+          const int inv = c_inv_angle[mode - 11];
+          const int k0 = k + 1, k1 = k + 2;
+          const int q0 = -((mul24(k0, inv) + 128) >> 8), q1 = -((mul24(k1, inv) + 128) >> 8); // (<= 0: positions along the side run)
+          // border index j: > 0 main run position j, 0 corner, < 0 side run position -j; tp[-1] is the corner
+          const int j0 = k0 >= 0 ? k0 : q0, j1 = k1 >= 0 ? k1 : q1;
+          auto at = [&](int j, bool main_side) -> int {
+            const Pix* const qm = vert ? tp + imin_(j - 1, nT1) : lp + mul24(imin_(j - 1, nL1), P);
+            const Pix* const qs = vert ? lp + mul24(imin_(-j - 1, nL1), P) : tp + imin_(-j - 1, nT1);
+            return *(main_side ? qm : qs);
+          };
+          // (horizontal modes: the corner is reached as position -1 of the top row, i.e. as side position 0)
+          r0 = vert ? at(j0, j0 >= 0) : at(j0, j0 > 0);
+          r1 = vert ? at(j1, j1 >= 0) : at(j1, j1 > 0);
+        }
+        int v = (mul24(32 - f, r0) + mul24(f, r1) + 16) >> 5;
+        if (cbf) {
+          uint32_t b = bg == 0 ? bres0 : (bg == 1 ? bres1 : (bg == 2 ? bres2 : bres3));
+          asm volatile("" : "+v"(b)); // keeps the select - and the wait for the load - inside this branch
+          v = clip3i(0, maxv, v + (int)b);
+        }
+        dst[mul24(y, P) + x] = (Pix)v;
+        WAVE_SYNC();
+        continue;
+      }
+#endif
 #if defined(HM_Q_PROBE) && (HM_Q_PROBE & 96)
       { // class probes: 32 = only the blocks of the one-pass path (4x4 / 8x8, interior, not smoothed), 64 = only the others
         const bool sm = log2 == 3 && c == 0 && ((filter_mode_mask(3) >> mode) & 1);
@@ -501,12 +562,32 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       WAVE_SYNC();
     }
 
+#if defined(HM_PAD_S) || defined(HM_PAD_V)
+    { // sensitivity probes: HM_PAD_S / HM_PAD_V extra scalar / vector instructions per iteration (tools/probe_chain.sh)
+#ifdef HM_PAD_S
+      int ps = lane0_dummy;
+#pragma unroll
+      for (int k = 0; k < HM_PAD_S; k++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(ps));
+      lane0_dummy = ps;
+#endif
+#ifdef HM_PAD_V
+      int pv = pad_v;
+#pragma unroll
+      for (int k = 0; k < HM_PAD_V; k++) asm volatile("v_add_u32 %0, %0, 1" : "+v"(pv));
+      pad_v = pv;
+#endif
+    }
+#endif
     HM_MARK("E_begin");
     // ---- E: the groups that executed a block move to the next record ----
     if (running) {
       ri += 1;
       pre = pre_m;
+#if defined(HM_Q_PROBE) && (HM_Q_PROBE & 512)
+      pre_m = 0; // probe: nobody waits for a residual (pictures wrong)
+#else
       pre_m = lv; // requested one step ago
+#endif
       kleft -= 1;
     }
 
@@ -641,7 +722,8 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
     cu_waves = w;
   }
   int np = 0, best = 0;
-  for (int k = 1; k <= 16; k++) {
+  // (workgroups of more than 8 waves: measured 40 ms instead of 27 - two of 80 KiB each do not share a CU)
+  for (int k = 1; k <= 8; k++) {
     const int bytes = C_SHARED + k * L.pic_bytes;
     if (bytes > 160 * 1024) break;
     const int by_lds = 160 * 1024 / bytes, by_regs = cu_waves / k;
@@ -649,6 +731,8 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
     if (per_cu > best) { best = per_cu; np = k; }
   }
   if (np == 0) return 0;
+  static const int force_np = [] { const char* e = getenv("HM_CHAIN_NP"); return e ? atoi(e) : 0; }(); // (tuning aid, read once)
+  if (force_np > 0 && force_np <= 16 && C_SHARED + force_np * L.pic_bytes <= 160 * 1024) np = force_np;
   while (np > 1 && (long)np * 256 > n_pics) np--; // few pictures: spread them over the CUs first
   const int lds_bytes = C_SHARED + np * L.pic_bytes;
   static const int debug = [] { const char* e = getenv("HM_CHAIN_DEBUG"); return e ? atoi(e) : 0; }();

@@ -9,6 +9,6 @@ for v in "${VS[@]}"; do
   rm -f build/hip_chain.o
   make HIPFLAGS="--offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fvisibility=hidden -Wall -Wno-unused-function -I../../include -I. -I/opt/rocm/include $v" >/dev/null 2>&1
   echo -n "variant [$v]: "
-  (cd ../.. && python3 bench.py --quick --no-parity --steps 5 "$@" 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print({k: v['ms_per_step'] for k, v in d['kernels'].items()})")
+  (cd ../.. && HM_CHAIN_DEBUG=1 python3 bench.py --quick --no-parity --steps 5 "$@" 2>/tmp/probe_err.log | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print({k: v['ms_per_step'] for k, v in d['kernels'].items()})"; grep -m1 "k_chain" /tmp/probe_err.log)
 done
 rm -f build/hip_chain.o; make >/dev/null 2>&1
