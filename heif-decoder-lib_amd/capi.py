@@ -164,6 +164,11 @@ class Batch:
         check(self.L.hm_batch_get_timings5(self.h, slot, ms))
         return [ms[i] for i in range(5)]
 
+    def check(self):
+        """waits for the batch; raises when a reconstruction wave gave up a bounded wait (hm_batch_check)"""
+        self.L.hm_batch_check.argtypes = [C.c_void_p]
+        check(self.L.hm_batch_check(self.h))
+
     def tail_fused(self):
         """True when the batch's executes run the fused tail kernel (timings4_ms: its time is in slot 2)"""
         return bool(self.L.hm_batch_tail_fused(self.h))

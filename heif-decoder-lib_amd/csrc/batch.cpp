@@ -75,8 +75,10 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // (HM_PIC_SPLIT_CHAINS: everything without rare syntax) run the four-chains-per-wave kernel, the others (records in
 // decode order) the one-row-per-wave kernel
 // (`mid`, if given, is called between the two kernels of the split-chain path: the profiling marks)
+// (`sync`: the launch's own region of the batch's synchronisation words, hm_internal.h: hm_launch_chain)
+struct SyncRegion { uint32_t* p = nullptr; size_t bytes = 0; std::vector<uint32_t*>* used = nullptr; };
 template <typename Mid>
-int launch_recon(const hm_dev_pic* dc, int n, const Class& c, hipStream_t s, Mid&& mid)
+int launch_recon(const hm_dev_pic* dc, int n, const Class& c, hipStream_t s, SyncRegion sync, Mid&& mid)
 {
   if (c.split) {
     // HM_CHAIN=0: the r02 kernel (dequantisation + transforms on the dependency chain), kept for A/B measurements
@@ -87,13 +89,14 @@ int launch_recon(const hm_dev_pic* dc, int n, const Class& c, hipStream_t s, Mid
       mid();
     }
     const int q = old_kernel ? hm_launch_recon_quad(dc, n, c.log2_ctb, c.chroma_format, c.bit_depth, c.rare, c.max_ctb_w, c.max_ctb_h, s)
-                             : hm_launch_chain(dc, n, c.log2_ctb, c.chroma_format, c.bit_depth, c.rare, c.max_ctb_w, c.max_ctb_h, s);
+                             : hm_launch_chain(dc, n, c.log2_ctb, c.chroma_format, c.bit_depth, c.rare, c.max_ctb_w, c.max_ctb_h, sync.p, sync.bytes, s);
+    if (q == 2 && sync.used && sync.used->size() < 4096) sync.used->push_back(sync.p); // the launch's error flag is word 1
     if (q == 0) return hm_fail(HM_ERR_UNSUPPORTED, "CTU staging does not fit LDS (CTB %d, %d bit, %d CTBs wide)", 1 << c.log2_ctb, c.bit_depth, c.max_ctb_w);
     return q < 0 ? q : HM_OK;
   }
   return hm_launch_recon(dc, n, c.log2_ctb, c.chroma_format, c.bit_depth, c.rare, c.max_ctb_w, c.max_ctb_h, s);
 }
-int launch_recon(const hm_dev_pic* dc, int n, const Class& c, hipStream_t s) { return launch_recon(dc, n, c, s, [] {}); }
+int launch_recon(const hm_dev_pic* dc, int n, const Class& c, hipStream_t s, SyncRegion sync) { return launch_recon(dc, n, c, s, sync, [] {}); }
 
 // bytes of the residual buffer of a picture with split chains (recon_common.h: ResidGeom): int16 per sample of the
 // CTB-aligned planes
@@ -104,6 +107,14 @@ size_t resid_bytes(const hm_pic& h)
   const size_t luma = (size_t)h.ctb_w * h.ctb_h * ctb * ctb;
   const size_t chroma = h.chroma_format == 0 ? 0 : 2 * (size_t)h.ctb_w * h.ctb_h * (ctb / 2) * (h.chroma_format == 1 ? ctb / 2 : ctb);
   return 2 * (luma + chroma);
+}
+// bytes of its hand-over lines (hm_device.h: hm_dev_pic.hand)
+size_t hand_bytes(const hm_pic& h)
+{
+  if (!(h.flags & HM_PIC_SPLIT_CHAINS)) return 0;
+  const size_t ctb = (size_t)1 << h.log2_ctb, bps = h.bit_depth_y > 8 ? 2 : 1;
+  const size_t pairs = h.chroma_format == 0 ? (h.ctb_h + 3) / 4 : (h.ctb_h + 1) / 2;
+  return pairs * (h.chroma_format == 0 ? 1 : 2) * (size_t)h.ctb_w * ctb * bps;
 }
 
 } // namespace
@@ -131,6 +142,22 @@ struct hm_batch {
   int tail_bpp = 3;
   int tail_coef[4] = {0, 0, 0, 0};
   DeviceBuffer d_tail;
+  // synchronisation words of the reconstruction's wave-per-row-pair mode: sync_stride words per picture, so that the
+  // launch over pictures [i0, i0 + n) owns the words from i0 * sync_stride on (launches of disjoint picture ranges - chunks,
+  // groups on several streams - never share any); sync_used: the regions handed out since the last hm_batch_check
+  DeviceBuffer d_sync;
+  size_t sync_stride = 0;
+  std::vector<uint32_t*> sync_used;
+  SyncRegion sync_region(const hm_dev_pic* dc, int n)
+  {
+    SyncRegion r;
+    if (!d_sync.p || !sync_stride) return r;
+    const size_t i0 = (size_t)(dc - (const hm_dev_pic*)d_desc.p);
+    r.p = (uint32_t*)d_sync.p + i0 * sync_stride;
+    r.bytes = (size_t)n * sync_stride * sizeof(uint32_t);
+    r.used = &sync_used;
+    return r;
+  }
   hipStream_t copy_stream = nullptr;
   bool copy_inflight = false;
   int groups = 0;                       // hm_batch_set_concurrency
@@ -329,13 +356,22 @@ static int batch_prepare(hm_batch* b, size_t* blob_bytes_out)
     const int swc = h.chroma_format == 3 ? 1 : 2;
     const size_t py = align_up((size_t)h.width * bps, 64), pc = align_up((size_t)(h.width / swc) * bps, 64);
     const size_t w4 = (h.width + 3) >> 2, h4 = (h.height + 3) >> 2;
-    work_bytes += align_up(py * h.height, 256) + 2 * align_up(pc * (h.height / sh), 256) + 2 * align_up(w4 * h4, 256) + align_up(resid_bytes(h), 256);
+    work_bytes += align_up(py * h.height, 256) + 2 * align_up(pc * (h.height / sh), 256) + 2 * align_up(w4 * h4, 256) + align_up(resid_bytes(h), 256) + align_up(hand_bytes(h), 256);
     b->total_pixels += (size_t)h.width * h.height;
   }
   int rc;
   if ((rc = b->d_blobs.ensure(blob_bytes))) return rc;
   if ((rc = b->d_work.ensure(work_bytes))) return rc;
   if ((rc = b->d_desc.ensure(sizeof(hm_dev_pic) * (size_t)n))) return rc;
+  {
+    // (8 words of launch header + 2 per pair of CTB rows: a launch over n pictures needs 8 + 2 * n * pairs <= n * stride)
+    size_t pairs = 0;
+    for (const Class& c : b->classes)
+      if (c.split) pairs = std::max(pairs, (size_t)(c.max_ctb_h + 1) / 2);
+    b->sync_stride = pairs ? 8 + 2 * pairs : 0;
+    b->sync_used.clear();
+    if (b->sync_stride && (rc = b->d_sync.ensure((size_t)n * b->sync_stride * sizeof(uint32_t)))) return rc;
+  }
 
   // (every check that can fail on file data runs before anything is enqueued: an error return must not leave copies
   //  in flight on buffers that go back to the pool)
@@ -361,6 +397,8 @@ static int batch_prepare(hm_batch* b, size_t* blob_bytes_out)
       d.meta = (uint16_t*)wp; // 2 bytes per 4x4 block (the size reserved above)
       wp += 2 * align_up(w4 * h4, 256);
       d.resid = resid_bytes(h) ? (int16_t*)wp : nullptr;
+      wp += align_up(resid_bytes(h), 256);
+      d.hand = hand_bytes(h) ? wp : nullptr;
       d.w4 = (int)w4; d.h4 = (int)h4;
       d.width = h.width; d.height = h.height;
       d.chroma_format = h.chroma_format;
@@ -521,7 +559,7 @@ int hm_batch_execute(hm_batch* b, int stages, void* stream)
         const hm_dev_pic* dk = dc + (size_t)i0 * per_img;
         const int si = g % ns;
         hipStream_t sg = si ? b->aux_streams[(size_t)si - 1] : s;
-        int rc = launch_recon(dk, m, c, sg);
+        int rc = launch_recon(dk, m, c, sg, b->sync_region(dk, m));
         if (!rc) rc = hm_launch_tail420(dk, td + (size_t)i0 * per_img, m, c.max_w, c.max_h, b->tail_bpp, b->tail_coef, stages, sg);
         if (rc) { join(); return rc; }
       }
@@ -531,7 +569,7 @@ int hm_batch_execute(hm_batch* b, int stages, void* stream)
       return HM_OK;
     }
     mark(-1);
-    int rc = launch_recon(dc, n, c, s, [&] { mark(4); });
+    int rc = launch_recon(dc, n, c, s, b->sync_region(dc, n), [&] { mark(4); });
     if (rc) return rc;
     mark(0);
     if (b->tail_state == 2) { // one kernel for everything behind the reconstruction (timeline: the SAO + paste slot)
@@ -559,7 +597,7 @@ int hm_batch_execute(hm_batch* b, int stages, void* stream)
     const hm_dev_pic* dc = d + c.desc_offset;
     const int n = (int)c.items.size();
     mark(-1);
-    int rc = launch_recon(dc, n, c, s, [&] { mark(4); });
+    int rc = launch_recon(dc, n, c, s, b->sync_region(dc, n), [&] { mark(4); });
     if (rc) return rc;
     mark(0);
     if (stages & 1) {
@@ -636,7 +674,7 @@ int hm_batch_upload_execute(hm_batch* b, int stages, int chunks, void* copy_stre
     if ((e = hipStreamWaitEvent(s, b->chunk_events[k], 0)) != hipSuccess) return hm_check_hip(e, "hipStreamWaitEvent");
     const hm_dev_pic* dc = d + i0;
     const int m = i1 - i0;
-    if ((rc = launch_recon(dc, m, c, s))) return rc;
+    if ((rc = launch_recon(dc, m, c, s, b->sync_region(dc, m)))) return rc;
     if (b->colour && b->tail_state == 2) {
       if ((rc = hm_launch_tail420(dc, (const uint8_t*)b->d_tail.p + sizeof(TailDstHost) * (size_t)i0, m, c.max_w, c.max_h, b->tail_bpp, b->tail_coef, stages, s))) return rc;
     }
@@ -786,6 +824,24 @@ int hm_batch_algorithmic_bytes4(const hm_batch* b, uint64_t out[4])
     out[3] += 2 * samples;
   }
   return HM_OK;
+}
+
+// Waits for the batch's work and reports whether a reconstruction wave gave up waiting for another one (the
+// wave-per-row-pair mode bounds every wait): HM_ERR_INTERNAL, the pictures of that execute are not valid.  Never on a
+// healthy device; the image-level entry points call it before they hand pixels out.
+int hm_batch_check(hm_batch* b)
+{
+  if (!b) return hm_fail(HM_ERR_INVALID_ARG, "null batch");
+  b->drain();
+  int bad = 0;
+  for (const uint32_t* region : b->sync_used) {
+    uint32_t flag = 0;
+    const hipError_t e = hipMemcpy(&flag, region + 1, sizeof(flag), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hm_check_hip(e, "hipMemcpy(reconstruction error flag)");
+    bad |= flag != 0;
+  }
+  b->sync_used.clear();
+  return bad ? hm_fail(HM_ERR_INTERNAL, "a reconstruction wave gave up waiting for the rows above it") : HM_OK;
 }
 
 int hm_batch_size(const hm_batch* b) { return b ? (int)b->items.size() : 0; }

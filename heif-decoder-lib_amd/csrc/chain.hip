@@ -75,7 +75,12 @@ struct CLayout {
   int off_rings;
   int off_groups;    // per row of the wave: [luma chain: CTU buffer][chroma chain: Cb, Cr CTU buffers]
   int luma_bytes, chroma_bytes;
+  int max_pairs;     // PAIRS: row pairs (monochrome: quads) per picture the launch is laid out for
 };
+// PAIRS: words of the launch's synchronisation buffer (zeroed before the launch): a ticket counter, an error flag, then
+// per (picture, pair, chain kind) the finished CTUs of the pair's last row
+constexpr int SYNC_TICKET = 0, SYNC_ERROR = 1, SYNC_PROGRESS = 8;
+constexpr int SPIN_LIMIT = 1 << 20; // PAIRS: polls of the pair above without news before a wave gives up (error flag, wrong picture, no hang)
 
 template <int CTRL>
 __device__ __forceinline__ int dpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
@@ -92,8 +97,8 @@ typedef uint32_t c_u32x2 __attribute__((ext_vector_type(2)));
 #else
 #define HM_CHAIN_ATTR
 #endif
-template <typename Pix, int LOG2_CTB>
-__global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* __restrict__ pics, int n_pics, CLayout L)
+template <typename Pix, int LOG2_CTB, bool PAIRS>
+__global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* __restrict__ pics, int n_pics, CLayout L, uint32_t* __restrict__ sync)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -141,7 +146,17 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     tab4[i] = (uint16_t)((j0 + 8) | ((j1 + 8) << 5) | (f << 10));
   }
   // ---- this wave's task ----
-  const int pic_index = blockIdx.x * (int)(blockDim.x >> 6) + wave;
+  int pic_index, pair_index = 0;
+  if (PAIRS) {
+    // a ticket: the order in which the waves of the launch START decides who works on what, so a wave only ever waits
+    // for rows that an earlier - running or finished - wave holds, whatever the order of dispatch
+    uint32_t t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(sync + SYNC_TICKET, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = (uint32_t)rfl((int)t);
+    pic_index = (int)(t / (uint32_t)L.max_pairs);
+    pair_index = (int)(t - (uint32_t)pic_index * (uint32_t)L.max_pairs);
+  }
+  else pic_index = blockIdx.x * (int)(blockDim.x >> 6) + wave;
   uint8_t* const pbase = lds + C_SHARED + (size_t)wave * L.pic_bytes;
   int* const progress = reinterpret_cast<int*>(pbase); // [2][C_PROG]: finished CTUs of the rows in flight, per chain kind
   if (lane < 2 * C_PROG) progress[lane] = 0;
@@ -166,6 +181,13 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   const int NR = mono ? 4 : 2; // CTU rows in flight per wave
   const ResidGeom RG = resid_geom(ctb_w, ctb_h, log2_ctb, dp.chroma_format);
   const uint32_t res_last = RG.total ? RG.total - 1 : 0;
+  if (PAIRS && pair_index * NR >= ctb_h) return;
+  // PAIRS: progress words of this picture's pairs ([pair][chain kind]); this pair reads those of the pair above
+  uint32_t* const pair_progress = PAIRS ? sync + SYNC_PROGRESS + 2 * ((size_t)pic_index * L.max_pairs) : nullptr;
+  // ... and the hand-over lines (hm_device.h: hm_dev_pic.hand): per pair the bottom sample line of its last row, luma, Cb, Cr
+  uint32_t* const hand_words = reinterpret_cast<uint32_t*>(dp.hand);
+  const uint32_t hand_luma_words = (uint32_t)(ctb_w * ctb) * sizeof(Pix) / 4, hand_chroma_words = mono ? 0u : (uint32_t)Wc * sizeof(Pix) / 4;
+  const uint32_t hand_pair_words = hand_luma_words + 2 * hand_chroma_words;
 
   // ---- this wave's LDS ----
   uint8_t* const lines_l = pbase + L.off_lines_l;
@@ -202,7 +224,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   const uint32_t gb_off = (uint32_t)(reinterpret_cast<uint8_t*>(gbase) - lds);
 
   // ---- group state (the same value in the 16 lanes of a group) ----
-  int row = group_slot(g), cx = 0, kleft = 0;
+  int row = (PAIRS ? pair_index * NR : 0) + group_slot(g), cx = 0, kleft = 0;
   // the sample lines are slots row % NR; a group's rows are NR apart, so its slot - and the slot of the row above - never change
   const int my_slot = group_slot(g);
   const int line_above = my_slot ? my_slot - 1 : NR - 1;
@@ -217,6 +239,10 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   uint32_t rbase = 0;              // first residual sample of window wnext's first record
   uint32_t pf0 = 0, pf1 = 0;       // raw record 16 * wnext + gl, requested when the window before it was decoded
   int primed = 0;                  // the residual pipeline holds the samples of blocks ri, ri + 1, ri + 2
+  // PAIRS, first row of a pair: CTUs of the row above (the last row of the pair above, another wave's) whose bottom
+  // sample line has been copied from the picture into this wave's line
+  int hbm_have = 0, hbm_polls = 0;
+  const bool from_hbm = PAIRS && my_slot == 0 && pair_index > 0;
   uint32_t pre = 0, pre_m = 0, lv = 0; // residual sample gl of the current block, the next one, the one after (in flight)
   auto load_window = [&](uint32_t w) {
     uint32_t idx = (w << 4) + (uint32_t)gl;
@@ -246,7 +272,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   };
   if (st == ST_START) row_start();
   // every iteration executes a block of some chain or waits for a CTU that is at most two CTUs of another chain away
-  int budget = (int)n_tus + 64 * ctb_w * ctb_h + 4096;
+  int budget = PAIRS ? 0x7FFFFFF0 : (int)n_tus + 64 * ctb_w * ctb_h + 4096; // (PAIRS: the waits have their own limit)
 
 #if defined(HM_PAD_S) || defined(HM_PAD_V)
   int lane0_dummy = 0, pad_v = lane;
@@ -258,7 +284,8 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     if (st == ST_START) {
       const int need = cx + 2 < ctb_w ? cx + 2 : ctb_w;
       // (a counter value seen here means the line samples written before it are there: LDS traffic of a wave is in order)
-      const int done_above = __hip_atomic_load(my_progress + ((row - 1) & (C_PROG - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      int done_above = __hip_atomic_load(my_progress + ((row - 1) & (C_PROG - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (from_hbm) done_above = hbm_have;
       if (row == 0 || done_above >= need) {
         kleft = (int)(c1 & 0xFFFF);
         st = ST_RUN;
@@ -271,11 +298,57 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       const int hx = st == ST_RUN ? (cx + 1 < ctb_w ? cx + 1 : cx) : cx;
       header(row < ctb_h ? row : ctb_h - 1, hx);
     }
+    if (PAIRS) {
+      // ---- the sample line of the pair above, through HBM: the chains of a pair's first row poll the progress word of
+      //      the pair above (while they wait, and every eighth iteration while they run, so that the line is usually
+      //      there before it is needed) and copy what has become available from the picture into the line ----
+      const bool poll = from_hbm && st != ST_DONE && hbm_have < ctb_w && (st == ST_START || (budget & 15) == 0);
+      if (ballot(poll)) {
+        // (the word and the line are written and read with agent-scope accesses that pass the caches which are not
+        //  coherent across the chip: no cache write-back / invalidation - those cost more than the hand-over itself
+        //  when thousands of waves do them per CTU; the reader's loads are issued behind the word's value)
+        int avail = 0;
+        if (poll) avail = (int)__hip_atomic_load(pair_progress + 2 * (size_t)(pair_index - 1) + kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (unsigned long long todo = ballot(poll && avail > hbm_have); todo;) {
+          const int cg = rfl((int)(__builtin_ctzll(todo) >> 4));
+          todo &= ~(0xFFFFull << (cg * 16));
+          const int src = cg * 16;
+          const int s_have = __builtin_amdgcn_readlane(hbm_have, src);
+          int s_avail = __builtin_amdgcn_readlane(avail, src);
+          if (s_avail > s_have + 8) s_avail = s_have + 8; // (bounded work per iteration)
+          const int ckind = group_kind(cg);
+          Pix* const lw = line_of(ckind, NR - 1); // the line the pair's first row reads: that of the row above
+          // CTUs [s_have, s_avail) of the hand-over line of the pair above: whole 32-bit words
+          constexpr int PPW = 4 / sizeof(Pix);
+          auto copy_line = [&](const uint32_t* words, int ctu_w, Pix* line) {
+            const int w0 = s_have * ctu_w / PPW, w1 = s_avail * ctu_w / PPW;
+            for (int w = w0 + lane; w < w1; w += 64)
+              *reinterpret_cast<uint32_t*>(line + w * PPW) = __hip_atomic_load(words + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          };
+          const uint32_t* const hand = hand_words + (size_t)(pair_index - 1) * hand_pair_words;
+          if (ckind == 0) copy_line(hand, ctb, lw);
+          else {
+            copy_line(hand + hand_luma_words, cw_c, lw);
+            copy_line(hand + hand_luma_words + hand_chroma_words, cw_c, lw + (Wc + 4));
+          }
+          WAVE_SYNC();
+          if (g == cg) { hbm_have = s_avail; hbm_polls = 0; }
+        }
+        if (poll && st == ST_START && ++hbm_polls > SPIN_LIMIT) { // the pair above is not coming: give up (never on a healthy launch)
+          if (gl == 0) __hip_atomic_store(sync + SYNC_ERROR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          st = ST_DONE;
+        }
+        if (ballot(st == ST_RUN) == 0) __builtin_amdgcn_s_sleep(8); // every chain of the wave waits
+      }
+    }
     if (ballot(st != ST_DONE) == 0) break;
 #if defined(HM_PAD_S) || defined(HM_PAD_V)
     if (lane0_dummy + pad_v == -12345) break; // (keeps the padding alive)
 #endif
-    if (--budget < 0) break; // (never on a valid stream: a wave that cannot finish leaves a wrong picture, not a hung GPU)
+    if (--budget < 0) { // (never on a valid stream: a wave that cannot finish leaves a wrong picture, not a hung GPU)
+      if (PAIRS && lane == 0) __hip_atomic_store(sync + SYNC_ERROR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
 
     HM_MARK("R_begin");
     // ---- R: decode the next 16 records of every group that has entered the last decoded window ----
@@ -648,6 +721,24 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       WAVE_SYNC();
       // read by the chain of the row below, a group of this wave (LDS traffic of a wave is in order)
       if (lane == 0) __hip_atomic_store(progress + fkind * C_PROG + (s_row & (C_PROG - 1)), s_cx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (PAIRS && group_slot(fg) == NR - 1 && s_row + 1 < ctb_h) {
+        // ... or, for the pair's last row, the first row of the pair below: another wave, anywhere on the chip.  The
+        // CTU's bottom sample line goes to the pair's hand-over line with agent-scope stores; once they have left this
+        // wave (vmcnt 0) the word that announces them follows
+        constexpr int PPW = 4 / sizeof(Pix);
+        uint32_t* const hand = hand_words + (size_t)pair_index * hand_pair_words;
+        auto put_line = [&](uint32_t* words, int ctu_w, const Pix* line) {
+          const int w0 = s_cx * ctu_w / PPW, nw = ctu_w / PPW; // (at most 64 words: a CTU row of 64 16-bit samples is 32)
+          if (lane < nw) __hip_atomic_store(words + w0 + lane, *reinterpret_cast<const uint32_t*>(line + (w0 + lane) * PPW), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        if (fkind == 0) put_line(hand, ctb, lw);
+        else {
+          put_line(hand + hand_luma_words, cw_c, lw);
+          put_line(hand + hand_luma_words + hand_chroma_words, cw_c, lw + (Wc + 4));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(pair_progress + 2 * (size_t)pair_index + fkind, (uint32_t)(s_cx + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       // the group's next CTU
       if (g == fg) {
         cx += 1;
@@ -656,7 +747,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         if (cx == ctb_w) {
           cx = 0;
           tl_off = lr_off;
-          row += NR;
+          row += PAIRS ? ctb_h : NR; // (PAIRS: one pass per wave)
           if (row < ctb_h) row_start();
           else st = ST_DONE;
         }
@@ -673,9 +764,10 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
 } // namespace
 
 // The chain kernel serves every picture whose records come as split chains (no rare syntax, not 4:4:4), after
-// hm_launch_residual on the same stream; returns 1 if it launched, 0 if the CTU staging does not fit LDS, < 0 on error.
+// hm_launch_residual on the same stream; returns 1 if it launched (2: in the wave-per-row-pair mode, i.e. using d_sync),
+// 0 if the CTU staging does not fit LDS, < 0 on error.
 extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ctb, int chroma_format, int bit_depth, int rare_syntax,
-                               int max_ctb_w, int max_ctb_h, hipStream_t s)
+                               int max_ctb_w, int max_ctb_h, uint32_t* d_sync, size_t sync_bytes, hipStream_t s)
 {
   if (n_pics <= 0) return 1;
   if (rare_syntax || chroma_format == 3 || log2_ctb < 4 || log2_ctb > 6) return 0;
@@ -685,9 +777,10 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   const int nr = mono ? 4 : 2;
   const int ch = chroma_format == 1 ? ctb / 2 : ctb;
   auto al = [](int v) { return (v + 15) & ~15; };
-  CLayout L;
   auto al4 = [](int v) { return (v + 3) & ~3; };
-  L.line_l_bytes = al4((4 + max_ctb_w * ctb) * pb); // (every byte counts: 8048 per wave put 20 waves on a CU, 8064 only 18)
+  CLayout L;
+  L.max_pairs = (max_ctb_h + nr - 1) / nr;
+  L.line_l_bytes = al4((4 + max_ctb_w * ctb) * pb); // (every byte counts for the waves a CU holds)
   L.line_c_bytes = mono ? 0 : al4((8 + 2 * max_ctb_w * (ctb / 2)) * pb);
   L.off_lines_l = 2 * C_PROG * 4;
   L.off_lines_c = L.off_lines_l + nr * L.line_l_bytes;
@@ -697,21 +790,36 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   L.luma_bytes = al((ctb + UPAD) * ctb * pb);
   L.chroma_bytes = mono ? 0 : al(2 * (ctb / 2 + UPAD) * ch * pb);
   L.pic_bytes = al(L.off_groups + (mono ? 4 * L.luma_bytes : 2 * (L.luma_bytes + L.chroma_bytes)));
+  // One wave per picture, or - few pictures - one wave per pair of CTU rows (PAIRS): a batch that cannot fill the
+  // machine with a wave per picture (256 CUs x 16 waves) gets its parallelism from the rows instead.  HM_CHAIN_PAIRS=0 / 1
+  // forces the choice (A/B measurements).
+  static const int force_pairs = [] { const char* e = getenv("HM_CHAIN_PAIRS"); return e ? atoi(e) : -1; }();
+  const size_t sync_need = ((size_t)SYNC_PROGRESS + 2 * (size_t)n_pics * L.max_pairs) * sizeof(uint32_t);
+  bool pairs = L.max_pairs > 1 && n_pics < 3072;
+  if (force_pairs >= 0) pairs = force_pairs != 0 && L.max_pairs > 1;
+  if (!d_sync || sync_bytes < sync_need) pairs = false;
   const void* fn = nullptr;
-  switch (log2_ctb * 2 + (pb - 1)) {
-    case 8: fn = reinterpret_cast<const void*>(k_chain<uint8_t, 4>); break;
-    case 9: fn = reinterpret_cast<const void*>(k_chain<uint16_t, 4>); break;
-    case 10: fn = reinterpret_cast<const void*>(k_chain<uint8_t, 5>); break;
-    case 11: fn = reinterpret_cast<const void*>(k_chain<uint16_t, 5>); break;
-    case 12: fn = reinterpret_cast<const void*>(k_chain<uint8_t, 6>); break;
-    case 13: fn = reinterpret_cast<const void*>(k_chain<uint16_t, 6>); break;
+  const int inst = log2_ctb * 2 + (pb - 1) - 8;
+  switch (inst * 2 + (pairs ? 1 : 0)) {
+    case 0: fn = reinterpret_cast<const void*>(k_chain<uint8_t, 4, false>); break;
+    case 1: fn = reinterpret_cast<const void*>(k_chain<uint8_t, 4, true>); break;
+    case 2: fn = reinterpret_cast<const void*>(k_chain<uint16_t, 4, false>); break;
+    case 3: fn = reinterpret_cast<const void*>(k_chain<uint16_t, 4, true>); break;
+    case 4: fn = reinterpret_cast<const void*>(k_chain<uint8_t, 5, false>); break;
+    case 5: fn = reinterpret_cast<const void*>(k_chain<uint8_t, 5, true>); break;
+    case 6: fn = reinterpret_cast<const void*>(k_chain<uint16_t, 5, false>); break;
+    case 7: fn = reinterpret_cast<const void*>(k_chain<uint16_t, 5, true>); break;
+    case 8: fn = reinterpret_cast<const void*>(k_chain<uint8_t, 6, false>); break;
+    case 9: fn = reinterpret_cast<const void*>(k_chain<uint8_t, 6, true>); break;
+    case 10: fn = reinterpret_cast<const void*>(k_chain<uint16_t, 6, false>); break;
+    case 11: fn = reinterpret_cast<const void*>(k_chain<uint16_t, 6, true>); break;
     default: return 0;
   }
-  // waves (= pictures) per workgroup: they only share the tables.  The count that puts the most waves on a CU: its
-  // 160 KiB of LDS and the waves its four SIMDs hold with the kernel's register count (512 VGPRs per lane and SIMD, in
-  // steps of 8) both limit whole workgroups
-  static int cu_waves_of[6] = {0, 0, 0, 0, 0, 0}; // (per instantiation; a benign race: every thread computes the same value)
-  int& cu_waves = cu_waves_of[log2_ctb * 2 + (pb - 1) - 8];
+  // waves per workgroup: they only share the tables.  The count that puts the most waves on a CU: its 160 KiB of LDS
+  // and the waves its four SIMDs hold with the kernel's register count (512 VGPRs per lane and SIMD, in steps of 8)
+  // both limit whole workgroups
+  static int cu_waves_of[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // (per instantiation; a benign race: every thread computes the same value)
+  int& cu_waves = cu_waves_of[inst * 2 + (pairs ? 1 : 0)];
   if (cu_waves == 0) {
     hipFuncAttributes fa;
     int w = 16;
@@ -733,16 +841,32 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   if (np == 0) return 0;
   static const int force_np = [] { const char* e = getenv("HM_CHAIN_NP"); return e ? atoi(e) : 0; }(); // (tuning aid, read once)
   if (force_np > 0 && force_np <= 16 && C_SHARED + force_np * L.pic_bytes <= 160 * 1024) np = force_np;
-  while (np > 1 && (long)np * 256 > n_pics) np--; // few pictures: spread them over the CUs first
+  const long n_waves = pairs ? (long)n_pics * L.max_pairs : (long)n_pics;
+  while (np > 1 && (long)np * 256 > n_waves) np--; // few waves: spread them over the CUs first
   const int lds_bytes = C_SHARED + np * L.pic_bytes;
   static const int debug = [] { const char* e = getenv("HM_CHAIN_DEBUG"); return e ? atoi(e) : 0; }();
-  if (debug) fprintf(stderr, "[k_chain] %d pictures, %d bytes of LDS per wave, %d waves per workgroup, %d waves per CU (registers allow %d)\n", n_pics, L.pic_bytes, np, best, cu_waves);
+  if (debug) fprintf(stderr, "[k_chain] %d pictures%s, %d bytes of LDS per wave, %d waves per workgroup, registers allow %d waves per CU\n", n_pics,
+                     pairs ? " (a wave per pair of CTU rows)" : "", L.pic_bytes, np, cu_waves);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return hm_check_hip(e, "hipFuncSetAttribute(k_chain)");
+  if (pairs) {
+    e = hipMemsetAsync(d_sync, 0, sync_need, s);
+    if (e != hipSuccess) return hm_check_hip(e, "hipMemsetAsync(k_chain sync words)");
+  }
   int a_n = n_pics;
-  void* args[] = {(void*)&d_pics, &a_n, &L};
-  e = hipLaunchKernel(fn, dim3((n_pics + np - 1) / np), dim3(np * 64), args, lds_bytes, s);
+  uint32_t* a_sync = pairs ? d_sync : nullptr;
+  void* args[] = {(void*)&d_pics, &a_n, &L, &a_sync};
+  e = hipLaunchKernel(fn, dim3((unsigned)((n_waves + np - 1) / np)), dim3(np * 64), args, lds_bytes, s);
   if (e != hipSuccess) return hm_check_hip(e, "k_chain launch");
   e = hipGetLastError();
-  return e == hipSuccess ? 1 : hm_check_hip(e, "k_chain launch");
+  if (e != hipSuccess) return hm_check_hip(e, "k_chain launch");
+  return pairs ? 2 : 1; // (2: the synchronisation words were used - word 1 is the launch's error flag)
+}
+
+// bytes of the synchronisation buffer hm_launch_chain wants for its wave-per-row-pair mode (0: never uses it)
+extern "C" size_t hm_chain_sync_bytes(int n_pics, int chroma_format, int max_ctb_h)
+{
+  const int nr = chroma_format == 0 ? 4 : 2;
+  const int max_pairs = (max_ctb_h + nr - 1) / nr;
+  return ((size_t)SYNC_PROGRESS + 2 * (size_t)n_pics * max_pairs) * sizeof(uint32_t);
 }

@@ -17,6 +17,9 @@ struct hm_dev_pic {
                             // - one store from k_recon, one load in k_deblock
   int32_t w4, h4;           // size of the 4x4-block maps
   int16_t* resid;           // pictures with split chains: residual samples, k_residual -> k_chain (recon_common.h: ResidGeom)
+  uint8_t* hand;            // pictures with split chains: hand-over lines of k_chain's wave-per-row-pair mode - per pair of CTB
+                            // rows (monochrome: four rows) the bottom sample line of its last row: ctb_w * ctb luma samples, then
+                            // Cb, then Cr (ctb_w * ctb / 2 each)
   // final output of the in-loop filters (SAO stage): written straight into the destination
   // image = fused tile paste (context.cc:2457-2535 of the reference)
   uint8_t* dst[3];          // destination plane origin (tile origin already applied)

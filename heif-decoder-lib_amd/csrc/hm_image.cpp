@@ -655,7 +655,14 @@ int job_enqueue(DecodeJob& j, hm_decoded* out)
 int job_complete(DecodeJob& j, hm_decoded*)
 {
   const hipError_t e = hipStreamSynchronize(j.s);
-  return e == hipSuccess ? HM_OK : hm_check_hip(e, "kernel execution");
+  if (e != hipSuccess) return hm_check_hip(e, "kernel execution");
+  // (the reconstruction bounds its cross-wave waits: a wave that gave up has flagged its launch)
+  for (PlanarImage* im : {&j.I, &j.A})
+    if (im->batch) {
+      const int rc = hm_batch_check(im->batch.get());
+      if (rc) return rc;
+    }
+  return HM_OK;
 }
 
 } // namespace hm_img

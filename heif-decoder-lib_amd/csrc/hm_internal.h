@@ -59,8 +59,11 @@ int hm_launch_recon_quad(const struct hm_dev_pic* d_pics, int n_pics, int log2_c
 // dequantisation + inverse transforms of all blocks (no dependencies), then the prediction chains (four per wave);
 // hm_launch_chain: 1 = launched, 0 = not applicable, < 0 = error
 int hm_launch_residual(const struct hm_dev_pic* d_pics, int n_pics, int max_ctb_h, hipStream_t s);
+// d_sync / sync_bytes: zero-initialised-by-the-launch words for the wave-per-row-pair mode (few, large pictures);
+// word 1 is set when a wave had to give up waiting (hm_batch_check).  hm_chain_sync_bytes: the size that mode needs.
 int hm_launch_chain(const struct hm_dev_pic* d_pics, int n_pics, int log2_ctb, int chroma_format, int bit_depth, int rare_syntax,
-                    int max_ctb_w, int max_ctb_h, hipStream_t s);
+                    int max_ctb_w, int max_ctb_h, uint32_t* d_sync, size_t sync_bytes, hipStream_t s);
+size_t hm_chain_sync_bytes(int n_pics, int chroma_format, int max_ctb_h);
 int hm_launch_deblock(const struct hm_dev_pic* d_pics, int n_pics, int max_w4, int max_h4, int chroma_format,
                       int bit_depth, int rare_syntax, hipStream_t s);
 int hm_launch_sao_paste(const struct hm_dev_pic* d_pics, int n_pics, int max_w, int max_h, int bit_depth, int apply_sao,

@@ -88,6 +88,7 @@ int hm_picture_decode_to_host(hm_picture* p, uint8_t* const plane[3], const int3
     hipError_t e = hipMemcpyAsync(pin.p, dev.p, total, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     rc = hm_check_hip(e, "D2H of the decoded planes");
+    if (!rc) rc = hm_batch_check(b);
   }
   hm_batch_destroy(b); // drains the stream before the pool blocks above are released
   if (rc) return rc;

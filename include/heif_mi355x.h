@@ -199,6 +199,9 @@ HM_API int  hm_batch_get_timings4(hm_batch* b, int slot, float ms[4]);
 HM_API int  hm_batch_get_timings5(hm_batch* b, int slot, float ms[5]);
 /* 1 when the executes of this batch run the fused tail kernel: its time is reported in slot [2], [1] and [3] are 0 */
 HM_API int  hm_batch_tail_fused(const hm_batch* b);
+/* waits for the batch's work; HM_ERR_INTERNAL when a reconstruction wave had to give up a (bounded) wait for the rows
+ * above it - the pictures of that execute are then not valid.  Never on a healthy device. */
+HM_API int  hm_batch_check(hm_batch* b);
 /* algorithmic bytes of the queued pictures: command streams read, reconstructed samples written */
 HM_API int  hm_batch_algorithmic_bytes(const hm_batch* b, uint64_t* stream_bytes, uint64_t* sample_bytes);
 /* the same per kernel of the split-chain reconstruction: out[0] command streams, [1] reconstructed samples, [2] the

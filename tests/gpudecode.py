@@ -36,6 +36,7 @@ def decode_pictures(pkg, blobs, stages=3, dests=None):
     batch.upload(st)
     batch.execute(stages, st)
     torch.cuda.synchronize()
+    batch.check()
     res = []
     for planes, bps in outs:
         pic = []
