@@ -108,13 +108,14 @@ size_t resid_bytes(const hm_pic& h)
   const size_t chroma = h.chroma_format == 0 ? 0 : 2 * (size_t)h.ctb_w * h.ctb_h * (ctb / 2) * (h.chroma_format == 1 ? ctb / 2 : ctb);
   return 2 * (luma + chroma);
 }
+// bytes of the residuals of its 4x4 blocks (hm_device.h: hm_dev_pic.res4)
+size_t res4_bytes(const hm_pic& h) { return (h.flags & HM_PIC_SPLIT_CHAINS) ? (size_t)h.n_tus * 32 : 0; }
 // bytes of its hand-over lines (hm_device.h: hm_dev_pic.hand)
 size_t hand_bytes(const hm_pic& h)
 {
   if (!(h.flags & HM_PIC_SPLIT_CHAINS)) return 0;
   const size_t ctb = (size_t)1 << h.log2_ctb, bps = h.bit_depth_y > 8 ? 2 : 1;
-  const size_t pairs = h.chroma_format == 0 ? (h.ctb_h + 3) / 4 : (h.ctb_h + 1) / 2;
-  return pairs * (h.chroma_format == 0 ? 1 : 2) * (size_t)h.ctb_w * ctb * bps;
+  return (size_t)h.ctb_h * (h.chroma_format == 0 ? 1 : 2) * (size_t)h.ctb_w * ctb * bps; // (one line per CTB row: the finest cut)
 }
 
 } // namespace
@@ -356,7 +357,7 @@ static int batch_prepare(hm_batch* b, size_t* blob_bytes_out)
     const int swc = h.chroma_format == 3 ? 1 : 2;
     const size_t py = align_up((size_t)h.width * bps, 64), pc = align_up((size_t)(h.width / swc) * bps, 64);
     const size_t w4 = (h.width + 3) >> 2, h4 = (h.height + 3) >> 2;
-    work_bytes += align_up(py * h.height, 256) + 2 * align_up(pc * (h.height / sh), 256) + 2 * align_up(w4 * h4, 256) + align_up(resid_bytes(h), 256) + align_up(hand_bytes(h), 256);
+    work_bytes += align_up(py * h.height, 256) + 2 * align_up(pc * (h.height / sh), 256) + 2 * align_up(w4 * h4, 256) + align_up(resid_bytes(h), 256) + align_up(hand_bytes(h), 256) + align_up(res4_bytes(h), 256);
     b->total_pixels += (size_t)h.width * h.height;
   }
   int rc;
@@ -364,11 +365,11 @@ static int batch_prepare(hm_batch* b, size_t* blob_bytes_out)
   if ((rc = b->d_work.ensure(work_bytes))) return rc;
   if ((rc = b->d_desc.ensure(sizeof(hm_dev_pic) * (size_t)n))) return rc;
   {
-    // (8 words of launch header + 2 per pair of CTB rows: a launch over n pictures needs 8 + 2 * n * pairs <= n * stride)
-    size_t pairs = 0;
+    // (8 words of launch header + 2 per CTB row: a launch over n pictures needs 8 + 2 * n * rows <= n * stride)
+    size_t rows = 0;
     for (const Class& c : b->classes)
-      if (c.split) pairs = std::max(pairs, (size_t)(c.max_ctb_h + 1) / 2);
-    b->sync_stride = pairs ? 8 + 2 * pairs : 0;
+      if (c.split) rows = std::max(rows, (size_t)c.max_ctb_h);
+    b->sync_stride = rows ? 8 + 2 * rows : 0;
     b->sync_used.clear();
     if (b->sync_stride && (rc = b->d_sync.ensure((size_t)n * b->sync_stride * sizeof(uint32_t)))) return rc;
   }
@@ -399,6 +400,8 @@ static int batch_prepare(hm_batch* b, size_t* blob_bytes_out)
       d.resid = resid_bytes(h) ? (int16_t*)wp : nullptr;
       wp += align_up(resid_bytes(h), 256);
       d.hand = hand_bytes(h) ? wp : nullptr;
+      wp += align_up(hand_bytes(h), 256);
+      d.res4 = res4_bytes(h) ? (int16_t*)wp : nullptr;
       d.w4 = (int)w4; d.h4 = (int)h4;
       d.width = h.width; d.height = h.height;
       d.chroma_format = h.chroma_format;

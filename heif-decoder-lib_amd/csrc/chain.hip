@@ -12,11 +12,12 @@
 //
 // What is new against recon_quad.hip (profiles/r02_pmc_sq_counters.json: 2.48 VALU wave-instructions per sample, the
 // kernel bound by instruction issue, not by bytes):
-//   * no dequantisation / transform here (residual.hip); the residual of a block arrives as int16 samples, requested
-//     two blocks ahead (4x4: one sample per lane of the group; larger: the first 64 samples wave-wide before the
-//     side-by-side phase);
-//   * the per-block control is decoded ONCE, 16 records at a time, by the group's own 16 lanes (lane = record) into a
-//     ring of 16-byte micro-ops in LDS: LDS offsets of the left column / the row above, clamp limits of the two runs,
+//   * no dequantisation / transform here (residual.hip); the residual of a block arrives as int16 samples.  Those of a
+//     4x4 block lie in an array indexed like the records: a group fetches the 16 records it needs next and their
+//     residuals while it works on the 16 before them, so nothing on the chain of the 4x4 blocks ever waits for HBM; the residual
+//     of a larger block is requested from the row's slab when the block comes up (8x8: before the side-by-side phase);
+//   * the per-block control is decoded ONCE, 16 records at a time, by the group's own 16 lanes (lane = record) into
+//     16-byte micro-ops in LDS: LDS offsets of the left column / the row above, clamp limits of the two runs,
 //     mode, flags, the place of the residual (a 16-lane DPP scan of the block sizes), the deblocking word.  A block
 //     then costs one ds_read_b128 and a few unpacks instead of ~25 instructions of field extraction and address
 //     arithmetic per group per block, and the four-deep register pipeline of raw records is gone;
@@ -49,7 +50,9 @@ constexpr int NG = 4;                       // groups per wave
 constexpr int C_SHARED_TABLES = 256;        // small tables (recon.hip layout: angles, inverse angles)
 constexpr int C_TAB4_BYTES = 35 * 16 * 2;   // per (mode, sample) of a 4x4 block: reference positions + weight
 constexpr int C_SHARED = (C_SHARED_TABLES + C_TAB4_BYTES + 15) & ~15;
-constexpr int C_RING = 32;                  // micro-ops per group: two windows of 16 records
+constexpr int C_RING = 16;                  // micro-ops per group: one window of 16 records
+constexpr int C_ITEM_DWORDS = 10;           // what a lane fetches per record: the 8-byte record + the 16 residual samples of a 4x4 block (hm_dev_pic.res4)
+constexpr int C_RRES_BYTES = NG * 16 * 32;  // per group: the 4x4 residuals of the window
 constexpr int C_SCRATCH = 272;              // wave-wide path: reference samples (bA)
 constexpr int C_PROG = 8;                   // progress counters per chain kind: rows r and r + 8 share one (at most 4 rows of a wave are in flight)
 constexpr int C_RING_BYTES = NG * C_RING * 16;
@@ -73,15 +76,24 @@ struct CLayout {
   int line_c_bytes;
   int off_scratch;
   int off_rings;
+  int off_rres;      // the window's 4x4 residuals: [group][record][16] int16
   int off_groups;    // per row of the wave: [luma chain: CTU buffer][chroma chain: Cb, Cr CTU buffers]
   int luma_bytes, chroma_bytes;
-  int max_pairs;     // PAIRS: row pairs (monochrome: quads) per picture the launch is laid out for
+  int line_slots;    // sample lines per chain kind: one per row in flight, or - a wave per row / per chain - only the one
+                     // that receives the row above from the hand-over lines
+  int row_bytes;     // CTU buffers of one row of the wave; the chroma chain's lie chroma_off behind the luma chain's
+  int chroma_off;    // (0 when a wave only ever works on one kind of chain)
+  // PAIRS: a wave works on rows_per_wave consecutive CTU rows of a picture (2 - monochrome 4 -, or 1 when there are
+  // few waves: fewer chains per wave = shorter iterations) and, with split_kinds, on their luma or their chroma chains
+  // only (the two never read each other); the picture's rows are bands_per_pic such bands
+  int rows_per_wave, split_kinds, bands_per_pic;
 };
 // PAIRS: words of the launch's synchronisation buffer (zeroed before the launch): a ticket counter, an error flag, then
 // per (picture, pair, chain kind) the finished CTUs of the pair's last row
 constexpr int SYNC_TICKET = 0, SYNC_ERROR = 1, SYNC_PROGRESS = 8;
 constexpr int SPIN_LIMIT = 1 << 20; // PAIRS: polls of the pair above without news before a wave gives up (error flag, wrong picture, no hang)
 
+__device__ __forceinline__ int g_of(int lane) { return lane >> 4; }
 template <int CTRL>
 __device__ __forceinline__ int dpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
 constexpr int DPP_ROW_ROR(int n) { return 0x120 | n; }
@@ -146,15 +158,18 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     tab4[i] = (uint16_t)((j0 + 8) | ((j1 + 8) << 5) | (f << 10));
   }
   // ---- this wave's task ----
-  int pic_index, pair_index = 0;
+  int pic_index, pair_index = 0, kind_sel = -1; // (kind_sel: the only chain kind this wave works on, -1: both)
   if (PAIRS) {
     // a ticket: the order in which the waves of the launch START decides who works on what, so a wave only ever waits
     // for rows that an earlier - running or finished - wave holds, whatever the order of dispatch
     uint32_t t = 0;
     if (lane == 0) t = __hip_atomic_fetch_add(sync + SYNC_TICKET, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     t = (uint32_t)rfl((int)t);
-    pic_index = (int)(t / (uint32_t)L.max_pairs);
-    pair_index = (int)(t - (uint32_t)pic_index * (uint32_t)L.max_pairs);
+    const uint32_t per_pic = (uint32_t)L.bands_per_pic << L.split_kinds;
+    pic_index = (int)(t / per_pic);
+    const uint32_t task = t - (uint32_t)pic_index * per_pic;
+    pair_index = (int)(task >> L.split_kinds); // the band of rows
+    kind_sel = L.split_kinds ? (int)(task & 1) : -1;
   }
   else pic_index = blockIdx.x * (int)(blockDim.x >> 6) + wave;
   uint8_t* const pbase = lds + C_SHARED + (size_t)wave * L.pic_bytes;
@@ -168,6 +183,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   const GLOBAL_AS hm_pic* H = gptr<hm_pic>(blob);
   const GLOBAL_AS uint32_t* ctbq = gptr<uint32_t>(blob + H->off_ctbs);   // HM_CTB_DWORDS dwords per hm_ctb
   const GLOBAL_AS uint32_t* tus = gptr<uint32_t>(blob + H->off_tus);     // 2 dwords per hm_tu8 (hm_stream.h)
+  const GLOBAL_AS uint32_t* const res4 = gptr<uint32_t>(dp.res4);        // 8 dwords per record: residual of a 4x4 block (residual.hip)
   const GLOBAL_AS int16_t* const resid = gptr<int16_t>(dp.resid);
   const uint32_t n_tus = H->n_tus;
   const int ctb_w = dp.ctb_w, ctb_h = dp.ctb_h;
@@ -181,9 +197,10 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   const int NR = mono ? 4 : 2; // CTU rows in flight per wave
   const ResidGeom RG = resid_geom(ctb_w, ctb_h, log2_ctb, dp.chroma_format);
   const uint32_t res_last = RG.total ? RG.total - 1 : 0;
-  if (PAIRS && pair_index * NR >= ctb_h) return;
+  const int RPW = PAIRS ? L.rows_per_wave : NR; // rows this wave works on at a time
+  if (PAIRS && (pair_index * RPW >= ctb_h || (mono && kind_sel == 1))) return;
   // PAIRS: progress words of this picture's pairs ([pair][chain kind]); this pair reads those of the pair above
-  uint32_t* const pair_progress = PAIRS ? sync + SYNC_PROGRESS + 2 * ((size_t)pic_index * L.max_pairs) : nullptr;
+  uint32_t* const pair_progress = PAIRS ? sync + SYNC_PROGRESS + 2 * ((size_t)pic_index * L.bands_per_pic) : nullptr;
   // ... and the hand-over lines (hm_device.h: hm_dev_pic.hand): per pair the bottom sample line of its last row, luma, Cb, Cr
   uint32_t* const hand_words = reinterpret_cast<uint32_t*>(dp.hand);
   const uint32_t hand_luma_words = (uint32_t)(ctb_w * ctb) * sizeof(Pix) / 4, hand_chroma_words = mono ? 0u : (uint32_t)Wc * sizeof(Pix) / 4;
@@ -194,11 +211,12 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   uint8_t* const lines_c = pbase + L.off_lines_c;
   int16_t* const l_bA = reinterpret_cast<int16_t*>(pbase + L.off_scratch);
   c_u32x4* const rings = reinterpret_cast<c_u32x4*>(pbase + L.off_rings); // [NG][C_RING]
+  int16_t* const rres = reinterpret_cast<int16_t*>(pbase + L.off_rres) + g_of(lane) * 256; // [16 records][16 samples] of the lane's group
   // group -> (chain kind, row slot): luma / chroma of two rows, or luma of four rows (monochrome)
   auto group_kind = [&](int gg) { return mono ? 0 : (gg & 1); };
   auto group_slot = [&](int gg) { return mono ? gg : (gg >> 1); };
   auto group_base = [&](int gg) -> uint8_t* {
-    return pbase + L.off_groups + (mono ? (size_t)gg * L.luma_bytes : (size_t)(gg >> 1) * (L.luma_bytes + L.chroma_bytes) + (size_t)(gg & 1) * L.luma_bytes);
+    return pbase + L.off_groups + (mono ? (size_t)gg * L.row_bytes : (size_t)(gg >> 1) * L.row_bytes + (size_t)(gg & 1) * L.chroma_off);
   };
   auto group_u = [&](int gg, int c) { // plane c of the group's chain (luma groups: c = 0; chroma groups: c = 1, 2)
     uint8_t* p = group_base(gg);
@@ -207,6 +225,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   };
   // sample line `slot` of a chain kind: luma sample 0 / Cb sample 0 (Cr sample 0 is Wc + 4 samples further)
   auto line_of = [&](int kind, int slot) {
+    if (L.line_slots == 1) slot = 0;
     uint8_t* p = kind ? lines_c + (size_t)slot * L.line_c_bytes : lines_l + (size_t)slot * L.line_l_bytes;
     return reinterpret_cast<Pix*>(p) + 4;
   };
@@ -224,36 +243,31 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   const uint32_t gb_off = (uint32_t)(reinterpret_cast<uint8_t*>(gbase) - lds);
 
   // ---- group state (the same value in the 16 lanes of a group) ----
-  int row = (PAIRS ? pair_index * NR : 0) + group_slot(g), cx = 0, kleft = 0;
+  int row = (PAIRS ? pair_index * RPW : 0) + group_slot(g), cx = 0, kleft = 0;
   // the sample lines are slots row % NR; a group's rows are NR apart, so its slot - and the slot of the row above - never change
   const int my_slot = group_slot(g);
   const int line_above = my_slot ? my_slot - 1 : NR - 1;
   const Pix* const lr = line_of(kind, line_above);
   const uint32_t lr_off = (uint32_t)(reinterpret_cast<const uint8_t*>(lr) - lds);
   uint32_t tl_off = lr_off; // the CTU's first sample in the sample line of the row above: lr + (cx << l2w)
-  int st = row < ctb_h ? ST_START : ST_DONE;
+  int st = (row < ctb_h && my_slot < RPW && (kind_sel < 0 || kind == kind_sel)) ? ST_START : ST_DONE;
   uint32_t c0 = 0, c1 = 0; // header of the CTU to start next: first record of the chain, count
   uint32_t ri = 0;                 // index of the current block's record
   uint32_t rfirst = 0;             // first record of the row's chain
-  uint32_t wnext = 0;              // next window (16 records: index >> 4) to decode into the ring
-  uint32_t rbase = 0;              // first residual sample of window wnext's first record
-  uint32_t pf0 = 0, pf1 = 0;       // raw record 16 * wnext + gl, requested when the window before it was decoded
-  int primed = 0;                  // the residual pipeline holds the samples of blocks ri, ri + 1, ri + 2
+  uint32_t wdec = 0;               // the window (16 records: index >> 4) whose micro-ops and 4x4 residuals are in LDS
+  uint32_t rbase = 0;              // first residual sample (blocks of 8x8 and more) of window wdec + 1's first record
+  uint32_t pf[C_ITEM_DWORDS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // expanded record 16 * (wdec + 1) + gl, requested when window wdec was decoded
   // PAIRS, first row of a pair: CTUs of the row above (the last row of the pair above, another wave's) whose bottom
   // sample line has been copied from the picture into this wave's line
   int hbm_have = 0, hbm_polls = 0;
   const bool from_hbm = PAIRS && my_slot == 0 && pair_index > 0;
-  uint32_t pre = 0, pre_m = 0, lv = 0; // residual sample gl of the current block, the next one, the one after (in flight)
   auto load_window = [&](uint32_t w) {
     uint32_t idx = (w << 4) + (uint32_t)gl;
     idx = idx < n_tus - 1 ? idx : n_tus - 1; // past the last record of the picture: re-read it (never executed)
-    const c_u32x2 v = *reinterpret_cast<const GLOBAL_AS c_u32x2*>(tus + 2 * (size_t)idx);
-    pf0 = v.x; pf1 = v.y;
-  };
-  auto res_of = [&](uint32_t first) -> uint32_t { // residual sample gl of the block whose residual starts at `first`
-    uint32_t idx = first + (uint32_t)gl;
-    idx = idx < res_last ? idx : res_last; // (blocks without residual and records past the chain: some valid word nobody looks at)
-    return (uint32_t)(int)resid[idx];
+    const c_u32x2 c = *reinterpret_cast<const GLOBAL_AS c_u32x2*>(tus + 2 * (size_t)idx);
+    const GLOBAL_AS uint32_t* const it = res4 + (size_t)idx * 8;
+    const c_u32x4 a = *reinterpret_cast<const GLOBAL_AS c_u32x4*>(it), b = *reinterpret_cast<const GLOBAL_AS c_u32x4*>(it + 4);
+    pf[0] = c.x; pf[1] = c.y; pf[2] = a.x; pf[3] = a.y; pf[4] = a.z; pf[5] = a.w; pf[6] = b.x; pf[7] = b.y; pf[8] = b.z; pf[9] = b.w;
   };
   auto header = [&](int r, int x) { // chain header of CTU (r, x): first record, count, flags
     const GLOBAL_AS uint32_t* q = ctbq + HM_CTB_DWORDS * ((size_t)r * ctb_w + x);
@@ -265,10 +279,9 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     if (gl == 0) __hip_atomic_store(my_progress + (row & (C_PROG - 1)), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     header(row, 0);
     ri = rfirst = c0;
-    wnext = ri >> 4;
+    wdec = (ri >> 4) - 1; // (nothing of this row is decoded yet)
     rbase = RG.slab(kind, row);
-    load_window(wnext);
-    primed = 0;
+    load_window(ri >> 4);
   };
   if (st == ST_START) row_start();
   // every iteration executes a block of some chain or waits for a CTU that is at most two CTUs of another chain away
@@ -353,11 +366,11 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     HM_MARK("R_begin");
     // ---- R: decode the next 16 records of every group that has entered the last decoded window ----
     {
-      const bool need_dec = st != ST_DONE && wnext <= (ri >> 4) + 1;
+      const bool need_dec = st != ST_DONE && (ri >> 4) != wdec; // the chain has entered window wdec + 1: its records are in pf
       if (ballot(need_dec)) {
         if (need_dec) {
-          const uint32_t r0 = pf0, r1 = pf1;
-          const uint32_t idx = (wnext << 4) + (uint32_t)gl;
+          const uint32_t r0 = pf[0], r1 = pf[1];
+          const uint32_t idx = ((wdec + 1) << 4) + (uint32_t)gl;
           const int x4 = (int)(r0 & 15), y4 = (int)((r0 >> 4) & 15);
           const uint32_t info = (r0 >> 8) & 0xFF;
           const int l2 = (int)(info & HM_TU_LOG2_MASK), c = (int)((info >> HM_TU_CIDX_SHIFT) & 3);
@@ -371,7 +384,8 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
           const bool on_line = y4 == 0;
           const int tp = on_line ? x0 + (c == 2 ? Wc + 4 : 0) : lp - Pk + 1;
           const uint32_t nL1 = (uint32_t)(nT - 1) + (aBL4 << 2), nT1 = (uint32_t)(nT - 1) + (aTR4 << 2);
-          uint32_t rsz = (cbf && idx >= rfirst) ? 16u << (2 * (l2 - 2)) : 0u;
+          // the residual of blocks of 8x8 and more lies in the row's slab, back to back (4x4: in the expanded record)
+          uint32_t rsz = (cbf && l2 >= 3 && idx >= rfirst) ? 16u << (2 * (l2 - 2)) : 0u;
           // inclusive scan over the 16 lanes of the group (= one DPP row)
           uint32_t s = rsz;
           s += (uint32_t)dpp<DPP_ROW_SHR(1)>((int)s);
@@ -387,35 +401,28 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
                  (fast8 ? OP_FAST8 : 0u) | (on_line ? OP_LINE : 0u) | (nL1 << OP_NL1_SHIFT) | (nT1 << OP_NT1_SHIFT);
           op.z = rbase + s - rsz;
           op.w = (r1 & 0xFF) | ((r0 & 0xFF) << 8) | (left ? OPW_LEFT : 0u) | (top ? OPW_TOP : 0u) | (tl ? OPW_TL : 0u) | (aBL4 << OPW_BL_SHIFT) | (aTR4 << OPW_TR_SHIFT);
-          ring[idx & (C_RING - 1)] = op;
+          ring[gl] = op;
+          // the record's 16 residual samples (meaningful for 4x4 blocks with a residual)
+          c_u32x4* const rr = reinterpret_cast<c_u32x4*>(rres + gl * 16);
+          rr[0] = c_u32x4{pf[2], pf[3], pf[4], pf[5]};
+          rr[1] = c_u32x4{pf[6], pf[7], pf[8], pf[9]};
           rbase += (uint32_t)__shfl((int)s, (lane & 48) | 15);
-          wnext += 1;
+          wdec += 1;
         }
-        load_window(wnext); // every lane: the window its group decodes next (groups that did not decode ask again for the same)
+        load_window(wdec + 1); // every lane: the window its group decodes next (groups that did not decode ask again for the same)
         WAVE_SYNC();
       }
     }
-    // ---- the residual pipeline of a group that has both windows of a new row: blocks ri, ri + 1, ri + 2 ----
-    {
-      const bool prime = st != ST_DONE && !primed && wnext >= (ri >> 4) + 2;
-      if (ballot(prime)) {
-        if (prime) {
-          pre = res_of(ring[ri & (C_RING - 1)].z);
-          pre_m = res_of(ring[(ri + 1) & (C_RING - 1)].z);
-          lv = res_of(ring[(ri + 2) & (C_RING - 1)].z);
-          primed = 1;
-        }
-      }
-    }
-    const bool running = st == ST_RUN && kleft > 0 && primed;
+    const bool running = st == ST_RUN && kleft > 0 && (ri >> 4) == wdec;
 
     // the current block of every group
     const c_u32x4 op = ring[ri & (C_RING - 1)];
+    const int16_t* const my_res = rres + (ri & 15) * 16; // the 16 residual samples of the group's block if it is a 4x4 block
     const bool quad = running && (op.y & (3u << OP_L2_SHIFT)) == 0 && (op.y & OP_INTERIOR);
     const unsigned long long s_big = ballot(running && !quad);
-    const unsigned long long s_bres = ballot(running && !quad && (op.y & OP_CBF) && (op.y & (2u << OP_L2_SHIFT)) == 0);
+    const unsigned long long s_bres = ballot(running && (op.y & OP_CBF) && (op.y & (3u << OP_L2_SHIFT)) == (1u << OP_L2_SHIFT));
 
-    // ---- P: residual of the 4x4 / 8x8 blocks of the wave-wide path (lane = sample), requested before the side-by-side phase ----
+    // ---- P: residual of the 8x8 blocks (lane = sample), requested before the side-by-side phase ----
     uint32_t bres0 = 0, bres1 = 0, bres2 = 0, bres3 = 0;
     if (s_bres) {
       auto big_res = [&](int gg) -> uint32_t {
@@ -477,7 +484,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         const bool on_edge = mode == 26 ? bx == 0 : by == 0;
         v = on_edge ? clip3i(0, maxv, r0 + ((r1 - corner) >> 1)) : v;
       }
-      if (op.y & OP_CBF) v = clip3i(0, maxv, v + (int)pre);
+      if (op.y & OP_CBF) v = clip3i(0, maxv, v + (int)my_res[gl]);
       lp[mul24(by, P) + 1 + bx] = (Pix)v;
     }
     WAVE_SYNC();
@@ -519,7 +526,11 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         // (the residual is only looked at - waited for - by blocks that have one)
         int res_s = 0, res_t[4] = {0, 0, 0, 0};
         if (cbf) {
-          if (L2 <= 3) {
+          if (L2 == 2) { // lanes 0-15: the block's 16 samples in the window's residuals of its group
+            const int s_ri = __builtin_amdgcn_readlane((int)ri, src);
+            res_s = (int)(reinterpret_cast<const int16_t*>(pbase + L.off_rres) + bg * 256 + (s_ri & 15) * 16)[ln & 15];
+          }
+          else if (L2 == 3) {
             uint32_t b = bg == 0 ? bres0 : (bg == 1 ? bres1 : (bg == 2 ? bres2 : bres3));
             asm volatile("" : "+v"(b)); // keeps the select - and the wait for the load - inside this branch
             res_s = (int)b;
@@ -655,12 +666,6 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     // ---- E: the groups that executed a block move to the next record ----
     if (running) {
       ri += 1;
-      pre = pre_m;
-#if defined(HM_Q_PROBE) && (HM_Q_PROBE & 512)
-      pre_m = 0; // probe: nobody waits for a residual (pictures wrong)
-#else
-      pre_m = lv; // requested one step ago
-#endif
       kleft -= 1;
     }
 
@@ -673,6 +678,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       const int s_row = __builtin_amdgcn_readlane(row, src), s_cx = __builtin_amdgcn_readlane(cx, src);
       const int fkind = group_kind(fg);
       Pix* const lw = line_of(fkind, group_slot(fg)); // s_row % NR
+      const bool keep_line = !PAIRS || RPW > 1;
       auto flush_plane = [&](auto bw_c, Pix* u, int P, Pix* line, uint8_t* plane, int pitch, int bh, int pw, int ph) {
         constexpr int BW = decltype(bw_c)::value;
         constexpr int PPW = 4 / sizeof(Pix), WPR = BW / PPW; // samples per 32-bit word, words per row
@@ -697,7 +703,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
             else dst[0] = vv[0];
           }
         }
-        if (lane < WPR)
+        if (keep_line && lane < WPR) // (a wave per row / per chain: nobody in this wave reads the row's bottom line)
           *reinterpret_cast<uint32_t*>(line + xo + lane * PPW) = *reinterpret_cast<const uint32_t*>(u + (bh - 1) * P + UPAD + lane * PPW);
         WAVE_SYNC();
         if (lane < bh) u[lane * P + UPAD - 1] = u[lane * P + UPAD + BW - 1]; // right column becomes the left neighbour
@@ -721,20 +727,20 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       WAVE_SYNC();
       // read by the chain of the row below, a group of this wave (LDS traffic of a wave is in order)
       if (lane == 0) __hip_atomic_store(progress + fkind * C_PROG + (s_row & (C_PROG - 1)), s_cx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (PAIRS && group_slot(fg) == NR - 1 && s_row + 1 < ctb_h) {
+      if (PAIRS && group_slot(fg) == RPW - 1 && s_row + 1 < ctb_h) {
         // ... or, for the pair's last row, the first row of the pair below: another wave, anywhere on the chip.  The
         // CTU's bottom sample line goes to the pair's hand-over line with agent-scope stores; once they have left this
         // wave (vmcnt 0) the word that announces them follows
         constexpr int PPW = 4 / sizeof(Pix);
         uint32_t* const hand = hand_words + (size_t)pair_index * hand_pair_words;
-        auto put_line = [&](uint32_t* words, int ctu_w, const Pix* line) {
-          const int w0 = s_cx * ctu_w / PPW, nw = ctu_w / PPW; // (at most 64 words: a CTU row of 64 16-bit samples is 32)
-          if (lane < nw) __hip_atomic_store(words + w0 + lane, *reinterpret_cast<const uint32_t*>(line + (w0 + lane) * PPW), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        auto put_line = [&](uint32_t* words, int ctu_w, const Pix* u, int P, int bh) { // the bottom row of the CTU buffer
+          const int w0 = s_cx * ctu_w / PPW, nw = ctu_w / PPW; // (at most 32 words: a CTU row of 64 16-bit samples)
+          if (lane < nw) __hip_atomic_store(words + w0 + lane, *reinterpret_cast<const uint32_t*>(u + (bh - 1) * P + UPAD + lane * PPW), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
-        if (fkind == 0) put_line(hand, ctb, lw);
+        if (fkind == 0) put_line(hand, ctb, group_u(fg, 0), P0, ctb);
         else {
-          put_line(hand + hand_luma_words, cw_c, lw);
-          put_line(hand + hand_luma_words + hand_chroma_words, cw_c, lw + (Wc + 4));
+          put_line(hand + hand_luma_words, cw_c, group_u(fg, 1), P1, ch_c);
+          put_line(hand + hand_luma_words + hand_chroma_words, cw_c, group_u(fg, 2), P1, ch_c);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_store(pair_progress + 2 * (size_t)pair_index + fkind, (uint32_t)(s_cx + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -753,10 +759,6 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         }
       }
     }
-    HM_MARK("G_begin");
-    // ---- G: the in-flight stage of the residual pipeline, requested by every lane (no condition around the load): the
-    //      residual of the block two behind the current one; a group that did not move asks again for what it holds ----
-    lv = res_of(ring[(ri + 2) & (C_RING - 1)].z);
     WAVE_SYNC();
   }
 }
@@ -779,25 +781,52 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   auto al = [](int v) { return (v + 15) & ~15; };
   auto al4 = [](int v) { return (v + 3) & ~3; };
   CLayout L;
-  L.max_pairs = (max_ctb_h + nr - 1) / nr;
-  L.line_l_bytes = al4((4 + max_ctb_w * ctb) * pb); // (every byte counts for the waves a CU holds)
-  L.line_c_bytes = mono ? 0 : al4((8 + 2 * max_ctb_w * (ctb / 2)) * pb);
-  L.off_lines_l = 2 * C_PROG * 4;
-  L.off_lines_c = L.off_lines_l + nr * L.line_l_bytes;
-  L.off_scratch = L.off_lines_c + (mono ? 0 : nr * L.line_c_bytes);
-  L.off_rings = al(L.off_scratch + C_SCRATCH);
-  L.off_groups = L.off_rings + C_RING_BYTES;
-  L.luma_bytes = al((ctb + UPAD) * ctb * pb);
-  L.chroma_bytes = mono ? 0 : al(2 * (ctb / 2 + UPAD) * ch * pb);
-  L.pic_bytes = al(L.off_groups + (mono ? 4 * L.luma_bytes : 2 * (L.luma_bytes + L.chroma_bytes)));
   // One wave per picture, or - few pictures - one wave per pair of CTU rows (PAIRS): a batch that cannot fill the
   // machine with a wave per picture (256 CUs x 16 waves) gets its parallelism from the rows instead.  HM_CHAIN_PAIRS=0 / 1
   // forces the choice (A/B measurements).
   static const int force_pairs = [] { const char* e = getenv("HM_CHAIN_PAIRS"); return e ? atoi(e) : -1; }();
-  const size_t sync_need = ((size_t)SYNC_PROGRESS + 2 * (size_t)n_pics * L.max_pairs) * sizeof(uint32_t);
-  bool pairs = L.max_pairs > 1 && n_pics < 3072;
-  if (force_pairs >= 0) pairs = force_pairs != 0 && L.max_pairs > 1;
+  // The fewer waves there are, the finer the work is cut: a wave per pair of rows (4 chains per wave), per row (2), per
+  // chain (1) - every chain a wave drops makes its iterations shorter, and a picture is a wavefront of CTUs whose length
+  // in iterations does not change.  HM_CHAIN_PAIRS = 1 / 2 / 3 forces pair / row / chain waves.
+  L.rows_per_wave = nr; L.split_kinds = 0;
+  bool pairs = max_ctb_h > nr && n_pics < 3072;
+  if (pairs) {
+    const long pair_waves = (long)n_pics * ((max_ctb_h + nr - 1) / nr);
+    if (pair_waves <= 2048) L.rows_per_wave = 1;
+    if (pair_waves <= 1024 && !mono) L.split_kinds = 1;
+  }
+  if (force_pairs >= 0) {
+    pairs = force_pairs != 0 && max_ctb_h > 1;
+    L.rows_per_wave = force_pairs >= 2 ? 1 : nr;
+    L.split_kinds = force_pairs >= 3 && !mono ? 1 : 0;
+  }
+  L.bands_per_pic = (max_ctb_h + L.rows_per_wave - 1) / L.rows_per_wave;
+  const size_t sync_need = ((size_t)SYNC_PROGRESS + 2 * (size_t)n_pics * L.bands_per_pic) * sizeof(uint32_t);
   if (!d_sync || sync_bytes < sync_need) pairs = false;
+  if (!pairs) { L.rows_per_wave = nr; L.split_kinds = 0; }
+  // ---- LDS of a wave ----
+  L.line_l_bytes = al4((4 + max_ctb_w * ctb) * pb); // (every byte counts for the waves a CU holds)
+  L.line_c_bytes = mono ? 0 : al4((8 + 2 * max_ctb_w * (ctb / 2)) * pb);
+  L.luma_bytes = al((ctb + UPAD) * ctb * pb);
+  L.chroma_bytes = mono ? 0 : al(2 * (ctb / 2 + UPAD) * ch * pb);
+  L.line_slots = L.rows_per_wave == 1 ? 1 : nr;
+  L.off_lines_l = 2 * C_PROG * 4;
+  if (L.split_kinds) { // one kind of chain per wave: one place for its line, one for its CTU buffers
+    L.off_lines_c = L.off_lines_l;
+    L.off_scratch = L.off_lines_l + (L.line_l_bytes > L.line_c_bytes ? L.line_l_bytes : L.line_c_bytes);
+    L.row_bytes = L.luma_bytes > L.chroma_bytes ? L.luma_bytes : L.chroma_bytes;
+    L.chroma_off = 0;
+  }
+  else {
+    L.off_lines_c = L.off_lines_l + L.line_slots * L.line_l_bytes;
+    L.off_scratch = L.off_lines_c + L.line_slots * L.line_c_bytes;
+    L.row_bytes = L.luma_bytes + L.chroma_bytes;
+    L.chroma_off = L.luma_bytes;
+  }
+  L.off_rings = al(L.off_scratch + C_SCRATCH);
+  L.off_rres = L.off_rings + C_RING_BYTES;
+  L.off_groups = L.off_rres + C_RRES_BYTES;
+  L.pic_bytes = al(L.off_groups + (mono && L.rows_per_wave > 1 ? 4 : L.rows_per_wave) * L.row_bytes);
   const void* fn = nullptr;
   const int inst = log2_ctb * 2 + (pb - 1) - 8;
   switch (inst * 2 + (pairs ? 1 : 0)) {
@@ -841,12 +870,13 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   if (np == 0) return 0;
   static const int force_np = [] { const char* e = getenv("HM_CHAIN_NP"); return e ? atoi(e) : 0; }(); // (tuning aid, read once)
   if (force_np > 0 && force_np <= 16 && C_SHARED + force_np * L.pic_bytes <= 160 * 1024) np = force_np;
-  const long n_waves = pairs ? (long)n_pics * L.max_pairs : (long)n_pics;
+  const long n_waves = pairs ? ((long)n_pics * L.bands_per_pic) << L.split_kinds : (long)n_pics;
   while (np > 1 && (long)np * 256 > n_waves) np--; // few waves: spread them over the CUs first
   const int lds_bytes = C_SHARED + np * L.pic_bytes;
   static const int debug = [] { const char* e = getenv("HM_CHAIN_DEBUG"); return e ? atoi(e) : 0; }();
-  if (debug) fprintf(stderr, "[k_chain] %d pictures%s, %d bytes of LDS per wave, %d waves per workgroup, registers allow %d waves per CU\n", n_pics,
-                     pairs ? " (a wave per pair of CTU rows)" : "", L.pic_bytes, np, cu_waves);
+  if (debug) fprintf(stderr, "[k_chain] %d pictures, %ld waves (%s), %d bytes of LDS per wave, %d waves per workgroup, registers allow %d waves per CU\n", n_pics, n_waves,
+                     !pairs ? "one per picture" : (L.split_kinds ? "one per chain of a CTU row" : (L.rows_per_wave == 1 ? "one per CTU row" : "one per pair of CTU rows")),
+                     L.pic_bytes, np, cu_waves);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return hm_check_hip(e, "hipFuncSetAttribute(k_chain)");
   if (pairs) {
@@ -866,7 +896,6 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
 // bytes of the synchronisation buffer hm_launch_chain wants for its wave-per-row-pair mode (0: never uses it)
 extern "C" size_t hm_chain_sync_bytes(int n_pics, int chroma_format, int max_ctb_h)
 {
-  const int nr = chroma_format == 0 ? 4 : 2;
-  const int max_pairs = (max_ctb_h + nr - 1) / nr;
-  return ((size_t)SYNC_PROGRESS + 2 * (size_t)n_pics * max_pairs) * sizeof(uint32_t);
+  (void)chroma_format; // (the finest cut: a band per CTU row)
+  return ((size_t)SYNC_PROGRESS + 2 * (size_t)n_pics * max_ctb_h) * sizeof(uint32_t);
 }

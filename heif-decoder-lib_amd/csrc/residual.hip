@@ -5,8 +5,10 @@
 // DST-VII and 4-32 point DCT (fallback-dct.cc:311-449, 592-733; stage 1 >> 7 clipped to 16 bit, stage 2 >> (20 - bit
 // depth), clipped for the DST only: Q4), transform skip (transform.cc:566-643).  None of it depends on a neighbouring
 // block - only the prediction does -, so it does not belong on the dependency chain of a CTU row: here every (CTB row,
-// chain kind) of every picture is one wave of a plain grid launch, the residuals go to HBM as int16 (recon_common.h:
-// ResidGeom) and the chain kernel only predicts and adds.
+// chain kind) of every picture is one wave of a plain grid launch, the residuals go to HBM as int16 and the chain
+// kernel only predicts and adds.  Output: for blocks of 8x8 and more the row's slab (recon_common.h: ResidGeom); for
+// 4x4 blocks - three quarters of all blocks - an array indexed like the records (hm_dev_pic.res4: 16 samples = 32 bytes
+// per record), which the chain kernel fetches together with the records, a whole window of 16 blocks before it needs them.
 //   * a wave walks the records of its row 64 at a time (lane = record): two wave scans give every record its first
 //     level and the place of its residual; the luma chains also write the deblocking filter's block map (transform
 //     edges + QpY per 4x4 block, deblock.cc:31-62) - another thing that needs no neighbour;
@@ -24,7 +26,8 @@ namespace {
 
 constexpr int R_WAVES = 4;                          // waves (= row chains) per workgroup: they share the tables
 constexpr int R_TABLES = 1024 + 256 + 128;          // dct basis (int8 [32][32]), small tables (recon.hip), 8-point pairs
-constexpr int R_WAVE = 2048 + 1024 + 4 * 16 * 4;    // per wave: coefficient block (32x32 int16), 16-row intermediate, 4x4 gather slots
+constexpr int R_STAGE = 256;                        // levels of a chunk of 64 records staged in LDS (the rest - dense chunks - is read in place)
+constexpr int R_WAVE = 2048 + 1024 + 4 * 16 * 4 + R_STAGE * 4; // per wave: coefficient block (32x32 int16), 16-row intermediate, 4x4 gather slots, levels
 
 template <int CTRL>
 __device__ __forceinline__ int rdpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
@@ -39,12 +42,25 @@ __device__ __forceinline__ int rdot2(uint32_t a, uint32_t b, int acc)
   return __builtin_amdgcn_sdot2(__builtin_bit_cast(r_s16x2, a), __builtin_bit_cast(r_s16x2, b), acc, false);
 }
 __device__ __forceinline__ int16_t limit_res(int r, int maxv) { return (int16_t)clip3i(-maxv, maxv, r); }
+// inclusive prefix sum over the 64 lanes: within the rows of 16 with row shifts, across them with the row broadcasts
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t rdpp_m(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false); }
+__device__ __forceinline__ uint32_t wave_scan(uint32_t v)
+{
+  v += rdpp_m<0x111, 0xF>(v); // row_shr:1
+  v += rdpp_m<0x112, 0xF>(v); // row_shr:2
+  v += rdpp_m<0x114, 0xF>(v); // row_shr:4
+  v += rdpp_m<0x118, 0xF>(v); // row_shr:8
+  v += rdpp_m<0x142, 0xA>(v); // row_bcast:15 into rows 1 and 3
+  v += rdpp_m<0x143, 0xC>(v); // row_bcast:31 into rows 2 and 3
+  return v;
+}
 
 // 16x16 / 32x32 block: levels -> dense coefficient block in LDS -> column transform -> row transform -> HBM.
 // `coeff` is all zero on entry and on exit.  Rows / columns beyond the last non-zero coefficient contribute nothing:
 // the sums stop at (my, mx).  fallback-dct.cc:592-733.
-template <int L2>
-__device__ __forceinline__ void big_residual(int16_t* coeff, int16_t* tmp, const int8_t* dct, const int16_t* tab, const GLOBAL_AS uint32_t* __restrict__ cf,
+template <int L2, typename Levels>
+__device__ __forceinline__ void big_residual(int16_t* coeff, int16_t* tmp, const int8_t* dct, const int16_t* tab, Levels cf,
                                              int n_coeff, int qP, int bit_depth, GLOBAL_AS int16_t* __restrict__ out, int lane)
 {
   constexpr int nT = 1 << L2, log2 = L2;
@@ -55,7 +71,7 @@ __device__ __forceinline__ void big_residual(int16_t* coeff, int16_t* tmp, const
   int mx = 0, my = 0;
 #pragma unroll 1
   for (int i = lane; i < n_coeff; i += 64) {
-    const uint32_t raw = cf[i];
+    const uint32_t raw = cf(i);
     const int pos = raw & (nT * nT - 1), value = (int)(int16_t)(raw >> 16);
     const int32_t prod = (int32_t)((uint32_t)mul24(value, fact) + (uint32_t)offset); // the reference's wrapping int32 product (Q3)
     coeff[pos] = (int16_t)clip3i(-32768, 32767, prod >> bdShift);
@@ -87,7 +103,7 @@ __device__ __forceinline__ void big_residual(int16_t* coeff, int16_t* tmp, const
     WAVE_SYNC();
   }
 #pragma unroll 1
-  for (int i = lane; i < n_coeff; i += 64) coeff[cf[i] & (nT * nT - 1)] = 0;
+  for (int i = lane; i < n_coeff; i += 64) coeff[cf(i) & (nT * nT - 1)] = 0;
   WAVE_SYNC();
 }
 
@@ -119,6 +135,7 @@ __global__ __launch_bounds__(R_WAVES * 64) void k_residual(const hm_dev_pic* __r
   int16_t* const coeff = reinterpret_cast<int16_t*>(wbase);
   int16_t* const tmp = reinterpret_cast<int16_t*>(wbase + 2048);
   int* const slots = reinterpret_cast<int*>(wbase + 2048 + 1024); // [4][16]
+  uint32_t* const lvl = reinterpret_cast<uint32_t*>(wbase + 2048 + 1024 + 4 * 16 * 4); // [R_STAGE]: the chunk's first levels
   for (int i = lane; i < 1024; i += 64) coeff[i] = 0;
   slots[lane] = 0;
   __syncthreads();
@@ -144,6 +161,7 @@ __global__ __launch_bounds__(R_WAVES * 64) void k_residual(const hm_dev_pic* __r
   const GLOBAL_AS uint32_t* tus = gptr<uint32_t>(blob + H->off_tus);
   const GLOBAL_AS uint32_t* coeffs = gptr<uint32_t>(blob + H->off_coeffs);
   GLOBAL_AS int16_t* const resid = gptr_w<int16_t>(dp.resid);
+  GLOBAL_AS int16_t* const res4 = gptr_w<int16_t>(dp.res4);
   const int bd = dp.bit_depth;
   const int maxv = (1 << bd) - 1;
   const ResidGeom RG = resid_geom(dp.ctb_w, dp.ctb_h, dp.log2_ctb, dp.chroma_format);
@@ -184,17 +202,29 @@ __global__ __launch_bounds__(R_WAVES * 64) void k_residual(const hm_dev_pic* __r
     const int info = (int)((r0 >> 8) & 0xFF), l2 = info & HM_TU_LOG2_MASK;
     const bool cbf = valid && (info & HM_TU_CBF);
     const uint32_t cnt = (r1 >> 16) & HM_TU8_COUNT_MASK; // (0 in the lanes behind the row's last record)
-    const uint32_t rsz = cbf ? 16u << (2 * (l2 - 2)) : 0u;
+    const uint32_t rsz = (cbf && l2 >= 3) ? 16u << (2 * (l2 - 2)) : 0u; // (the residual of a 4x4 block has a place of its own: res4)
     // inclusive wave scans: first level / first residual sample of every record
-    uint32_t sc = cnt, sr = rsz;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t tc = (uint32_t)__shfl_up((int)sc, o), tr = (uint32_t)__shfl_up((int)sr, o);
-      if (lane >= o) { sc += tc; sr += tr; }
-    }
+    const uint32_t sc = wave_scan(cnt), sr = wave_scan(rsz);
     const uint32_t lo = lev_base + sc - cnt, ro = res_base + sr - rsz;
-    lev_base += (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
+    // the chunk's levels lie back to back: one coalesced read puts the first R_STAGE of them into LDS, so that the
+    // passes below wait for LDS, not for HBM
+    const uint32_t chunk_lev = lev_base, n_lev = (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
+    {
+      const uint32_t n_stage = n_lev < (uint32_t)R_STAGE ? n_lev : (uint32_t)R_STAGE;
+#pragma unroll
+      for (int k = 0; k < R_STAGE / 64; k++) {
+        const uint32_t i = (uint32_t)(lane + 64 * k);
+        if (i < n_stage) lvl[i] = coeffs[chunk_lev + i];
+      }
+    }
+    lev_base += n_lev;
     res_base += (uint32_t)__builtin_amdgcn_readlane((int)sr, 63);
+    WAVE_SYNC();
+    // level number i of a block whose levels start at index `first`
+    auto level = [&](uint32_t first, uint32_t i) -> uint32_t {
+      const uint32_t rel = first - chunk_lev + i;
+      return rel < (uint32_t)R_STAGE ? lvl[rel] : coeffs[first + i];
+    };
 
     // ---- the block map of the deblocking filter (luma chains): per 4x4 block the transform edges on its left / on top
     //      (bit 0 / bit 1) and QpY (bits 8-15), deblock.cc:31-62 of the reference ----
@@ -212,11 +242,7 @@ __global__ __launch_bounds__(R_WAVES * 64) void k_residual(const hm_dev_pic* __r
       int sm = slots[lane];
       WAVE_SYNC();
       slots[lane] = 0;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(sm, o);
-        if (lane >= o) sm += t;
-      }
+      sm = (int)wave_scan((uint32_t)sm);
       const int my_ctb = cur_ctb + sm;
       cur_ctb += __builtin_amdgcn_readlane(sm, 63);
       const int flags = valid ? (int)(q0[HM_CTB_DWORDS * (size_t)my_ctb + 2] & 0xFF) : 0;
@@ -261,10 +287,10 @@ __global__ __launch_bounds__(R_WAVES * 64) void k_residual(const hm_dev_pic* __r
       const bool act = myb >= 0;
       const int src = act ? myb : 0;
       const uint32_t br0 = (uint32_t)__shfl((int)r0, src), bcnt = (uint32_t)__shfl((int)cnt, src);
-      const uint32_t blo = (uint32_t)__shfl((int)lo, src), bro = (uint32_t)__shfl((int)ro, src);
+      const uint32_t blo = (uint32_t)__shfl((int)lo, src);
       const bool has = act && (uint32_t)gl < bcnt;
       uint32_t raw = 0;
-      if (has) raw = coeffs[blo + (uint32_t)gl];
+      if (has) raw = level(blo, (uint32_t)gl);
       // dequantisation (transform.cc:496-502, wrapping int32) of level number gl, scattered to the lane of its position
       const int qP = (int)(br0 >> 24);
       const int q6 = (qP * 43) >> 8, qr = qP - 6 * q6; // qP / 6, qP % 6 for qP < 128
@@ -299,7 +325,7 @@ __global__ __launch_bounds__(R_WAVES * 64) void k_residual(const hm_dev_pic* __r
         res = (s2 + rnd2) >> postShift;
         if (kind == 0) res = clip3i(-32768, 32767, res); // the DST's second stage is clipped to 16 bit, the DCT's is not (Q4)
       }
-      if (act) resid[bro + (uint32_t)gl] = limit_res(res, maxv);
+      if (act) res4[(size_t)(chunk + (uint32_t)myb) * 16 + (uint32_t)gl] = limit_res(res, maxv); // 32 bytes per record, indexed like the records
     }
 
     // ---- 8x8 blocks, one per pass, one sample per lane ----
@@ -312,7 +338,7 @@ __global__ __launch_bounds__(R_WAVES * 64) void k_residual(const hm_dev_pic* __r
       const int32_t fact = (int32_t)tab[70 + qP % 6] << (qP / 6);
       const bool has = (uint32_t)lane < s_cnt;
       uint32_t raw = 0;
-      if (has) raw = coeffs[s_lo + (uint32_t)lane];
+      if (has) raw = level(s_lo, (uint32_t)lane);
       int slot = 0;
       if (has) {
         const int pos = raw & 63, value = (int)(int16_t)(raw >> 16);
@@ -341,8 +367,9 @@ __global__ __launch_bounds__(R_WAVES * 64) void k_residual(const hm_dev_pic* __r
       const uint32_t s_r0 = (uint32_t)__builtin_amdgcn_readlane((int)r0, b), s_cnt = (uint32_t)__builtin_amdgcn_readlane((int)cnt, b);
       const uint32_t s_lo = (uint32_t)__builtin_amdgcn_readlane((int)lo, b), s_ro = (uint32_t)__builtin_amdgcn_readlane((int)ro, b);
       const int qP = (int)(s_r0 >> 24);
-      if (((s_r0 >> 8) & HM_TU_LOG2_MASK) == 4) big_residual<4>(coeff, tmp, dct, tab, coeffs + s_lo, (int)s_cnt, qP, bd, resid + s_ro, lane);
-      else big_residual<5>(coeff, tmp, dct, tab, coeffs + s_lo, (int)s_cnt, qP, bd, resid + s_ro, lane);
+      auto cf = [&](int i) -> uint32_t { return level(s_lo, (uint32_t)i); };
+      if (((s_r0 >> 8) & HM_TU_LOG2_MASK) == 4) big_residual<4>(coeff, tmp, dct, tab, cf, (int)s_cnt, qP, bd, resid + s_ro, lane);
+      else big_residual<5>(coeff, tmp, dct, tab, cf, (int)s_cnt, qP, bd, resid + s_ro, lane);
     }
   }
 }
