@@ -189,6 +189,9 @@ def kernel_table(gb, avg_ms, colour_bytes_per_px=4.5):
                         "GBps": round(alg[q] / avg_ms[q] / 1e6, 1) if avg_ms[q] > 0 else None,
                         "frac_of_hbm_peak": round(alg[q] / avg_ms[q] / 1e6 / HBM_PEAK_GBPS, 4) if avg_ms[q] > 0 else None} for q in (4, 0, 1, 2, 3) if names[q]}
     # the north star's "HBM-read roofline" taken literally: only the 1.5 B/px the colour kernel reads (report both)
+    if names[2] == TAIL_NAME and avg_ms[2] > 0:  # the fused tail on the literal "HBM-read" convention: the 1.5 B/px of samples it reads
+        table[TAIL_NAME]["read_only_GBps"] = round(sample_b / avg_ms[2] / 1e6, 1)
+        table[TAIL_NAME]["read_only_frac_of_hbm_peak"] = round(sample_b / avg_ms[2] / 1e6 / HBM_PEAK_GBPS, 4)
     cms = avg_ms[3]
     if cms > 0 and names[3]:
         table[KERNEL_NAMES[3]]["read_only_GBps"] = round(1.5 * gb.pixels() / cms / 1e6, 1)
@@ -197,16 +200,17 @@ def kernel_table(gb, avg_ms, colour_bytes_per_px=4.5):
 
 
 def pmc_traffic(kernel, images):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r0N_pmc_traffic.json:
-    FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, separate passes, scaled per image); None when no
-    measurement for this kernel is on file."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC passes (profiles/r0N_pmc_traffic.json:
+    FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, separate passes, scaled per image) - a table look-up, not
+    counters of this run (counters need their own rocprofv3 passes: tools/pmc_traffic.sh).  Returns (bytes, source);
+    (None, None) when no measurement for this kernel is on file."""
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))
-            return int(t["kernels"][kernel]["hbm_bytes_per_image"] * images)
+            return int(t["kernels"][kernel]["hbm_bytes_per_image"] * images), f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh, scaled per image; not live counters of this run)"
         except Exception:
             continue
-    return None
+    return None, None
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -347,9 +351,13 @@ def run(args):
         kernels, alg, stream_b = kernel_table(gb, avg_ms)
         dom = max(range(5), key=lambda q: avg_ms[q])
         achieved = alg[dom] / avg_ms[dom] / 1e6
+        traffic, traffic_source = pmc_traffic(kernel_names(gb)[dom], B)
         out = {
             "metric": "megapixels/sec HEIC grid->RGB24",
-            "value": round(value, 1), "unit": "MP/s", "n_gpus": world, "world_size": dist.get_world_size() if dist else 1,
+            "value": round(value, 1), "unit": "MP/s",
+            "value_clock": "K: GPU kernels only (reconstruction -> deblocking -> SAO/paste -> colour) on command streams already in HBM - no CABAC, no H2D, no D2H; "
+                           ".heic bytes in -> RGB in host memory is end_to_end_MP_per_s below (host entropy decode bound)",
+            "end_to_end_MP_per_s": None, "device_inclusive_MP_per_s": None, "n_gpus": world, "world_size": dist.get_world_size() if dist else 1,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
@@ -359,13 +367,19 @@ def run(args):
                                        "the transfer- and host-inclusive clocks are device_inclusive / end_to_end_pipelined below",
                        "parity": parity},
             "roofline": {"bound": "hbm", "kernel": kernel_names(gb)[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": pmc_traffic(kernel_names(gb)[dom], B)},
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_source},
             "kernels": kernels,
         }
         if world > ndev:
             out["config"]["shared_gpu"] = f"{world} ranks on {ndev} GPU(s): functional run of the N>1 path, not a scaling number"
+        gb.batch.check()  # (a reconstruction wave that gave up a bounded wait would have flagged its launch)
         if not args.quick and world == 1:  # the side clocks belong to the single-GPU run
             side_legs(out, args, torch, pkg, dev, st, gb, kept, strides, stream_b)
+            try:
+                out["end_to_end_MP_per_s"] = out["end_to_end_pipelined"]["MP_per_s"]
+                out["device_inclusive_MP_per_s"] = max(v["MP_per_s"] for k, v in out["device_inclusive"].items() if isinstance(v, dict) and "MP_per_s" in v)
+            except Exception:
+                pass
         print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()
@@ -746,16 +760,17 @@ def config4(torch, pkg, dev, st):
         evs.append((a, b))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    k = [0.0, 0.0, 0.0]
+    k = [0.0, 0.0, 0.0, 0.0, 0.0]
     for i in range(5):
-        ms = batch.timings_ms(i)
-        k = [k[q] + ms[q] / 5 for q in range(3)]
+        ms = batch.timings5_ms(i)
+        k = [k[q] + ms[q] / 5 for q in range(5)]
     col_ms = sum(a.elapsed_time(b) for a, b in evs) / 5
+    batch.check()
     mp = n * W * H / 1e6
     stream_b, sample_b = batch.algorithmic_bytes()
     batch.close()
     return {"MP_per_s": round(mp * 5 / dt, 1), "images_per_step": n,
-            "kernels_ms_per_step": {"k_recon": round(k[0], 3), "k_deblock": round(k[1], 3), "k_sao_paste": round(k[2], 3), "k_ycbcr_float(colour)": round(col_ms, 3)},
+            "kernels_ms_per_step": {"k_residual": round(k[4], 3), KERNEL_NAMES[0]: round(k[0], 3), "k_deblock": round(k[1], 3), "k_sao_paste": round(k[2], 3), "k_ycbcr_float(colour)": round(col_ms, 3)},
             "colour_GBps": round(10.0 * n * W * H / col_ms / 1e6, 1), "colour_frac_of_hbm_peak": round(10.0 * n * W * H / col_ms / 1e6 / HBM_PEAK_GBPS, 4),
             "command_stream_bytes_per_pixel": round(stream_b / (n * W * H), 3),
             "note": "10-bit 4:2:2 2048x1536 (seed 4220010) -> RRGGBB_LE, 4 B/px in + 6 B/px out for the colour kernel; K clock"}

@@ -788,15 +788,20 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   // The fewer waves there are, the finer the work is cut: a wave per pair of rows (4 chains per wave), per row (2), per
   // chain (1) - every chain a wave drops makes its iterations shorter, and a picture is a wavefront of CTUs whose length
   // in iterations does not change.  HM_CHAIN_PAIRS = 1 / 2 / 3 forces pair / row / chain waves.
+  // Measured on MI355X with 512x512 tiles (tools/r03_thresh.sh, ms of both reconstruction kernels; per picture / pair /
+  // row / chain): 48 tiles 4.20 / 2.11 / 1.69 / 1.46, 192: 4.21 / 2.31 / 1.96 / 2.33, 768: 5.23 / 4.69 / 5.06 / 6.40,
+  // 1536: 6.00 / 7.67 / 9.04 / 11.9, 3072: 7.25 / 14.3 / 16.9 / 22.8 - a wave that waits for the rows above it holds its
+  // place on the machine, so the finer cuts only pay while all their waves fit it (4096) with room to spare.
   L.rows_per_wave = nr; L.split_kinds = 0;
-  bool pairs = max_ctb_h > nr && n_pics < 3072;
-  if (pairs) {
-    const long pair_waves = (long)n_pics * ((max_ctb_h + nr - 1) / nr);
-    if (pair_waves <= 2048) L.rows_per_wave = 1;
-    if (pair_waves <= 1024 && !mono) L.split_kinds = 1;
+  const long pair_waves = (long)n_pics * ((max_ctb_h + nr - 1) / nr), row_waves = (long)n_pics * max_ctb_h;
+  bool pairs = max_ctb_h > 1 && pair_waves <= 7000;
+  if (pairs && row_waves <= 3500) {
+    L.rows_per_wave = 1;
+    if (2 * row_waves <= 3500 && !mono) L.split_kinds = 1;
   }
+  if (pairs && L.rows_per_wave == nr && max_ctb_h <= nr) pairs = false; // (a single band: nothing to hand over)
   if (force_pairs >= 0) {
-    pairs = force_pairs != 0 && max_ctb_h > 1;
+    pairs = force_pairs != 0 && max_ctb_h > (force_pairs >= 2 ? 1 : nr);
     L.rows_per_wave = force_pairs >= 2 ? 1 : nr;
     L.split_kinds = force_pairs >= 3 && !mono ? 1 : 0;
   }
