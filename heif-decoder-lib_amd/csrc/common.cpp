@@ -6,7 +6,6 @@
 #include "hm_internal.h"
 
 static thread_local char g_last_error[512] = "";
-thread_local int hm_tls_few_pictures = 0; // hm_internal.h
 
 extern "C" {
 

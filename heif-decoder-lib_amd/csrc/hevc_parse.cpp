@@ -82,7 +82,8 @@ struct Decoder {
   PictureState pic;
   std::vector<uint8_t> rbsp; // unescaped NAL, reused
   std::vector<uint32_t> removed; // positions of its emulation prevention bytes in the escaped NAL
-  bool decode_order = false; // records of the current picture in decode order although it has no rare syntax
+  int record_order = 0;      // hm_parse_options.record_order
+  bool want_split = false;   // the current picture's records go out as split chains (unless it turns out to use rare syntax)
   int threads = 1;           // > 1: slice segments with WPP entry points are parsed row-parallel (parse_rows_parallel)
   void start_stream()
   {
@@ -149,14 +150,11 @@ struct Decoder {
       check_supported(s, p);
       cur_sps = &s;
       cur_pps = &p;
-      pic.reset(s, p);
       {
         static const bool interleaved = [] { const char* e = std::getenv("HM_STREAM_INTERLEAVED"); return e && e[0] == '1'; }();
-        // (hm_tls_few_pictures: the caller decodes one image of a few small pictures - the one-row-per-wave kernel, which
-        //  reads records in decode order, has the shorter critical path there; large pictures keep the quad kernel)
-        decode_order = interleaved || (hm_tls_few_pictures && (long)s.width * s.height < (1L << 20));
-        if (decode_order) pic.direct = false;
+        want_split = !interleaved && (record_order == HM_RECORDS_SPLIT || (record_order == HM_RECORDS_AUTO && quad_class(s)));
       }
+      pic.reset(s, p, want_split);
       pic_started = true;
       next_ts = 0;
     }
@@ -307,7 +305,14 @@ struct Decoder {
     };
     const int n_workers = std::min(threads, n_rows);
     std::vector<std::thread> crew;
-    for (int i = 1; i < n_workers; i++) crew.emplace_back(worker);
+    try {
+      for (int i = 1; i < n_workers; i++) crew.emplace_back(worker);
+    }
+    catch (...) { // no more threads to be had: the rows that were started finish, the serial parse takes over
+      failed.store(true);
+      for (std::thread& t : crew) t.join();
+      throw Inconsistent();
+    }
     worker();
     for (std::thread& t : crew) t.join();
     if (first_error) throw Inconsistent(); // (whatever it was: the serial parse finds it in decoding order)
@@ -355,7 +360,7 @@ struct Decoder {
                       pic.uses_pcm || pic.uses_tq_bypass || s.chroma_format_idc == 3 || s.transform_skip_rotation || s.implicit_rdpcm ||
                       s.intra_smoothing_disabled || p.cross_component_prediction ||
                       (p.transform_skip_enabled && p.log2_max_transform_skip_size > 2); // == HM_PIC_RARE_SYNTAX of the flags below
-    const bool split = !rare && !force_interleaved && !decode_order && quad_class(s);
+    const bool split = !rare && !force_interleaved && want_split;
     const bool direct = pic.direct; // the chains were written in their final form while parsing (hevc_syntax.h: PictureState::rows)
     if (direct && !split) throw ParseError(HM_ERR_INTERNAL, "direct chains of a picture with rare syntax");
     size_t n_tus = 0, n_levels = pic.coeffs.size();
@@ -585,13 +590,14 @@ static_assert(sizeof(hm_slice) == 12, "hm_slice layout");
 static_assert(sizeof(hm_sao) == 8, "hm_sao layout");
 static_assert(sizeof(hm_pic) % 4 == 0, "hm_pic layout");
 
-static int hm_hevc_parse_run(const uint8_t* data, size_t size, int annexb, int threads, uint8_t** out_blob, size_t* out_size)
+static int hm_hevc_parse_run(const uint8_t* data, size_t size, int annexb, int threads, int record_order, uint8_t** out_blob, size_t* out_size)
 {
   try {
     static thread_local std::unique_ptr<hm::Decoder> workspace;
     if (!workspace) workspace = std::make_unique<hm::Decoder>();
     hm::Decoder* dec = workspace.get();
     dec->threads = threads;
+    dec->record_order = record_order;
     dec->start_stream();
     if (annexb) {
       // split at 00 00 01 start codes
@@ -644,18 +650,27 @@ int hm_hevc_parse(const uint8_t* data, size_t size, int annexb, uint8_t** out_bl
   return hm_hevc_parse_mt(data, size, annexb, 1, out_blob, out_size);
 }
 
+int hm_hevc_parse_mt(const uint8_t* data, size_t size, int annexb, int threads, uint8_t** out_blob, size_t* out_size)
+{
+  hm_parse_options o;
+  o.annexb = annexb; o.threads = threads; o.record_order = HM_RECORDS_AUTO;
+  return hm_hevc_parse_opts(data, size, &o, out_blob, out_size);
+}
+
 // The same with up to `threads` host threads for one picture: slice segments coded with wavefront parallel processing
 // (an entry point per CTB row) are entropy-decoded row-parallel, two CTBs apart (the reference: decctx.cc:1004-1116).
 // Same command stream byte for byte; streams whose entry points do not match their sub-streams, and streams with
 // errors, are parsed again serially.
-int hm_hevc_parse_mt(const uint8_t* data, size_t size, int annexb, int threads, uint8_t** out_blob, size_t* out_size)
+int hm_hevc_parse_opts(const uint8_t* data, size_t size, const hm_parse_options* opts, uint8_t** out_blob, size_t* out_size)
 {
-  if (!data || !out_blob || !out_size) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
+  if (!data || !opts || !out_blob || !out_size) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
+  if (opts->record_order < HM_RECORDS_AUTO || opts->record_order > HM_RECORDS_DECODE_ORDER) return hm_fail(HM_ERR_INVALID_ARG, "record_order %d", opts->record_order);
+  const int annexb = opts->annexb, threads = opts->threads, order = opts->record_order;
   *out_blob = nullptr;
   *out_size = 0;
   if (threads > 1) {
     try {
-      if (hm_hevc_parse_run(data, size, annexb, threads, out_blob, out_size) == HM_OK) return HM_OK;
+      if (hm_hevc_parse_run(data, size, annexb, threads, order, out_blob, out_size) == HM_OK) return HM_OK;
     }
     catch (const hm::Decoder::Inconsistent&) {
     }
@@ -663,7 +678,7 @@ int hm_hevc_parse_mt(const uint8_t* data, size_t size, int annexb, int threads, 
     if (*out_blob) { std::free(*out_blob); *out_blob = nullptr; }
     *out_size = 0;
   }
-  return hm_hevc_parse_run(data, size, annexb, 1, out_blob, out_size);
+  return hm_hevc_parse_run(data, size, annexb, 1, order, out_blob, out_size);
 }
 
 } // extern "C"

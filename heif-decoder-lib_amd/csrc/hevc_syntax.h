@@ -216,7 +216,8 @@ struct PictureState {
   ContextSet dep_ctx;
   bool dep_ok = false;
 
-  void reset(const SPS& s, const PPS& p)
+  // want_split: the caller's choice of record order (hm_parse_options.record_order), quad_class(s) by default
+  void reset(const SPS& s, const PPS& p, bool want_split)
   {
     sps = &s; pps = &p;
     ct_depth.assign((size_t)s.min_cb_w * s.min_cb_h, 0);
@@ -233,7 +234,7 @@ struct PictureState {
     for (auto& v : ctb_tus) v.clear();
     coeffs.clear();
     // ... and only the classes the four-chains-per-wave kernel is the faster one for (quad_class)
-    direct = quad_class(s) &&
+    direct = want_split &&
              !(s.scaling_list_enabled || s.pcm_enabled || p.transquant_bypass_enabled || s.chroma_format_idc == 3 ||
                s.transform_skip_rotation || s.implicit_rdpcm || s.intra_smoothing_disabled || p.cross_component_prediction ||
                (p.transform_skip_enabled && p.log2_max_transform_skip_size > 2));

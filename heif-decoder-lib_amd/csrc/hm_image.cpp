@@ -413,8 +413,8 @@ int planar_from_blobs(const hm_file* f, ItemPlan& P, const hm_decode_params* par
   // grid tiles whose item carries transformative properties: their picture goes to planes of its own (the size of its
   // conformance window), is transformed there and pasted afterwards - what decode_and_paste_tile_image does with the
   // image decode_image_planar returns (context.cc:2407-2539)
-  struct OwnTile { int index; DevPlane P[3]; int w, h; };
-  std::vector<std::unique_ptr<OwnTile>> own;
+  std::vector<std::unique_ptr<OwnTile>>& own = I.own;
+  own.clear();
   for (int i = 0; i < nt; i++) {
     hm_tile_dest d;
     std::memset(&d, 0, sizeof(d));
@@ -424,6 +424,15 @@ int planar_from_blobs(const hm_file* f, ItemPlan& P, const hm_decode_params* par
       std::unique_ptr<OwnTile> o(new OwnTile());
       o->index = i;
       o->w = h->width - h->crop_left - h->crop_right; o->h = h->height - h->crop_top - h->crop_bottom;
+      // (file data is checked before anything is queued: the tile's origin inside the canvas, per channel, context.cc:2466-2483)
+      for (int c = 0; c < (chroma == 0 ? 1 : 3); c++) {
+        int chan_w = canvas_w, chan_h = canvas_h, cx0 = P.tiles[i].x0, cy0 = P.tiles[i].y0;
+        if (c > 0) {
+          if (chroma != 3) { chan_w = (canvas_w + 1) / 2; cx0 = (cx0 + 1) / 2; }
+          if (chroma == 1) { chan_h = (canvas_h + 1) / 2; cy0 = (cy0 + 1) / 2; }
+        }
+        if (chan_w <= cx0 || chan_h <= cy0) return hm_fail(HM_ERR_INVALID_ARG, "tile origin outside the canvas (invalid grid data)");
+      }
       const int tcw = chroma == 3 ? o->w : (o->w + 1) / 2, tch = chroma == 1 ? (o->h + 1) / 2 : o->h;
       if ((rc = alloc_plane(o->P[0], o->w, o->h, bps))) return rc;
       if (chroma != 0 && ((rc = alloc_plane(o->P[1], tcw, tch, bps)) || (rc = alloc_plane(o->P[2], tcw, tch, bps)))) return rc;
@@ -515,9 +524,10 @@ void job_parse_tile(DecodeJob& j, int k, int row_threads)
   std::vector<uint8_t> data;
   hm::HeifError e;
   if (!j.f->file.hevc_data(P.tiles[k].id, data, e)) { P.status[k] = e.status; P.messages[k] = e.message; return; }
-  hm_tls_few_pictures = j.few_pictures;
-  const int rc = hm_hevc_parse_mt(data.data(), data.size(), 0, row_threads, &P.blobs[k].p, &P.blobs[k].n);
-  hm_tls_few_pictures = 0;
+  hm_parse_options po;
+  po.annexb = 0; po.threads = row_threads;
+  po.record_order = j.few_pictures ? HM_RECORDS_SPLIT : HM_RECORDS_AUTO;
+  const int rc = hm_hevc_parse_opts(data.data(), data.size(), &po, &P.blobs[k].p, &P.blobs[k].n);
   if (rc) { P.status[k] = rc; P.messages[k] = hm_last_error(); }
 }
 
@@ -681,7 +691,7 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
   // ---- host: entropy-decode every coded picture (CABAC on the CPU, spread over threads like the reference's
   //      heif_context_set_threads tile fan-out, context.cc:2361-2401) ----
   const int nt = job_tile_count(job);
-  job.few_pictures = nt <= 64; // one image at a time: its tiles are the whole batch (single 12 MP grid: 6.95 -> 6.65 ms)
+  job.few_pictures = nt <= 64; // one image at a time: its tiles are the whole batch - split chains for every class (hm_image_job.h)
   std::atomic<int> next{0};
   int nthreads = params->host_threads > 0 ? params->host_threads : 1;
   // fewer coded pictures than threads (a single image, or an image and its alpha plane): the threads left over parse

@@ -55,6 +55,8 @@ struct Blob {
 
 // A decoded image on the device: what HeifContext::decode_image_planar returns (YCbCr planes after the item's
 // transformative properties), plus everything that must outlive the asynchronous work that produced it.
+// planes of a grid tile whose item carries its own irot / imir / clap: decoded there, transformed, then pasted
+struct OwnTile { int index = 0; DevPlane P[3]; int w = 0, h = 0; };
 struct PlanarImage {
   DevPlane P[3];
   int w = 0, h = 0, chroma = 1, bd = 8;
@@ -62,6 +64,9 @@ struct PlanarImage {
   bool is_grid = false;
   int warnings = 0; // HM_WARN_* of the (single) coded picture
   std::vector<std::unique_ptr<DevMem>> retired;
+  // (a member, not a local of the function that queues work on them: every early return of that function leaves them
+  //  alive until the job's destructor has drained the stream)
+  std::vector<std::unique_ptr<OwnTile>> own;
   std::unique_ptr<hm_batch, void (*)(hm_batch*)> batch{nullptr, hm_batch_destroy};
 };
 
@@ -88,7 +93,8 @@ struct DecodeJob {
   DevPlane alpha_scaled;
   DevPlane alpha_sdr; // a deeper alpha plane brought to 8 bits (Op_to_sdr_planes) for an RGBA target
   DevMem dout;
-  int few_pictures = 0; // the parser may write decode-order records for small pictures (hm_internal.h: hm_tls_few_pictures)
+  int few_pictures = 0; // the job's pictures are a whole (small) batch: HM_RECORDS_SPLIT - with few pictures the rows of a picture are
+                        // the parallel work, which only the split-chain kernels offer (profiles/r03_class_shape_sweeps.txt)
   bool enqueued = false;
   // everything above is touched by asynchronous work: the stream is drained before any of it is released (the pool may
   // hand a freed block to another thread at once)

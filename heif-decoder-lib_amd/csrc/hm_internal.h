@@ -39,16 +39,16 @@ int hm_launch_paste_bytes(const void* in, int in_stride, void* out, int out_stri
 int hm_launch_mirror(const void* in, int in_stride, int w, int h, int horizontal, void* out, int out_stride, hipStream_t s);
 
 // devpool.cpp: size-bucketed cache of device / pinned-host allocations (hipMalloc + hipFree cost more
-// than the kernels of a 12 MP image)
+// than the kernels of a 12 MP image).  Device blocks: one pool per GPU, served from / returned to the pool of the
+// device that was current at allocation; pinned blocks: portable, one pool
 void* hm_pool_device_alloc(size_t bytes);
 void hm_pool_device_free(void* p);
 void* hm_pool_pinned_alloc(size_t bytes);
 void hm_pool_pinned_free(void* p);
+size_t hm_pool_device_cached(int device); // bytes the pool of `device` holds for reuse
 
 // recon.hip / filters.hip
 struct hm_dev_pic;
-// set (per thread) around hm_hevc_parse* by callers whose batch is one image of a few small pictures (hm_decode_item)
-extern thread_local int hm_tls_few_pictures;
 int hm_batch_add_trusted(hm_batch* b, const uint8_t* blob, size_t size, const hm_tile_dest* dest); // no structural validation
 int hm_launch_recon(const struct hm_dev_pic* d_pics, int n_pics, int log2_ctb, int chroma_format, int bit_depth, int rare_syntax,
                     int max_ctb_w, int max_ctb_h, hipStream_t s);

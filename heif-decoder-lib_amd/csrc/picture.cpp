@@ -26,9 +26,9 @@ int hm_picture_parse(const uint8_t* data, size_t size, hm_picture** out, hm_pict
   *out = nullptr;
   hm_picture* p = new (std::nothrow) hm_picture();
   if (!p) return hm_fail(HM_ERR_NOMEM, "out of memory");
-  hm_tls_few_pictures = 1; // one picture per decoder instance (plugin ABI): a small one takes the one-row-per-wave kernel
-  const int rc = hm_hevc_parse(data, size, 0, &p->blob, &p->blob_size);
-  hm_tls_few_pictures = 0;
+  hm_parse_options po; // one picture per decoder instance (plugin ABI): its rows are the parallel work
+  po.annexb = 0; po.threads = 1; po.record_order = HM_RECORDS_SPLIT;
+  const int rc = hm_hevc_parse_opts(data, size, &po, &p->blob, &p->blob_size);
   if (rc) { delete p; return rc; }
   const hm_pic* h = reinterpret_cast<const hm_pic*>(p->blob);
   hm_picture_info& I = p->info;

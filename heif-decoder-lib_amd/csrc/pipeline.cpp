@@ -24,6 +24,8 @@
 #include <thread>
 #include <vector>
 
+#include <sched.h>
+
 #include "hm_image_job.h"
 
 using namespace hm_img;
@@ -38,6 +40,7 @@ struct Image {
   int status = HM_OK;
   std::string message;
   std::atomic<int> tiles_left{0};
+  std::atomic<bool> failed{false};  // an exception escaped the parse of one of its pictures
   bool queued = false;              // GPU work queued (or failed): the result can be waited for
   hipStream_t stream = nullptr;
   ~Image() {
@@ -68,6 +71,12 @@ struct hm_pipeline {
   void worker_loop()
   {
     if (cfg.device >= 0) hipSetDevice(cfg.device);
+    if (cfg.cpu_count > 0) { // the crew stays on the CPUs next to its GPU (a failure only loses the placement)
+      cpu_set_t set;
+      CPU_ZERO(&set);
+      for (int c = cfg.cpu_first; c < cfg.cpu_first + cfg.cpu_count && c < CPU_SETSIZE; c++) CPU_SET(c, &set);
+      sched_setaffinity(0, sizeof(set), &set);
+    }
     std::unique_lock<std::mutex> g(m);
     for (;;) {
       const uint64_t t0 = now_ns();
@@ -77,7 +86,12 @@ struct hm_pipeline {
       tasks.pop_front();
       g.unlock();
       const uint64_t t1 = now_ns();
-      job_parse_tile(t.img->job, t.tile);
+      try {
+        job_parse_tile(t.img->job, t.tile);
+      }
+      catch (...) { // (out of memory while copying item data: this image fails, the crew goes on)
+        t.img->failed.store(true);
+      }
       const uint64_t t2 = now_ns();
       if (t.img->tiles_left.fetch_sub(1) == 1) { // last coded picture of the image: hand it to the GPU
         finish(t.img);
@@ -91,8 +105,14 @@ struct hm_pipeline {
   // called by exactly one thread per image, after all its tiles are parsed
   void finish(Image* im)
   {
-    const int rc = job_enqueue(im->job, &im->out);
-    if (rc) { im->status = rc; im->message = hm_last_error(); }
+    int rc;
+    try {
+      rc = im->failed.load() ? hm_fail(HM_ERR_NOMEM, "out of memory in the entropy decode") : job_enqueue(im->job, &im->out);
+      if (rc) { im->status = rc; im->message = hm_last_error(); }
+    }
+    catch (...) {
+      im->status = HM_ERR_NOMEM;
+    }
     {
       std::lock_guard<std::mutex> g(m);
       im->queued = true;
@@ -110,6 +130,8 @@ int hm_pipeline_create(const hm_pipeline_config* cfg, hm_pipeline** out)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return hm_fail(HM_ERR_NO_DEVICE, "no HIP device available");
   if (cfg->device >= ndev) return hm_fail(HM_ERR_INVALID_ARG, "device %d of %d", cfg->device, ndev);
+  if (cfg->cpu_count < 0 || cfg->cpu_first < 0 || (cfg->cpu_count > 0 && cfg->cpu_first + cfg->cpu_count > CPU_SETSIZE))
+    return hm_fail(HM_ERR_INVALID_ARG, "CPU set [%d, %d)", cfg->cpu_first, cfg->cpu_first + cfg->cpu_count);
   hm_pipeline* p = new (std::nothrow) hm_pipeline();
   if (!p) return hm_fail(HM_ERR_NOMEM, "out of memory");
   p->cfg = *cfg;
@@ -150,7 +172,11 @@ void hm_pipeline_destroy(hm_pipeline* p)
                  (unsigned long long)p->n_images.load(), (unsigned long long)p->n_tiles.load(), p->cfg.host_threads,
                  p->n_tiles ? p->ns_parse.load() / 1e6 / p->n_tiles.load() : 0.0, p->n_images ? p->ns_enqueue.load() / 1e6 / p->n_images.load() : 0.0,
                  100.0 * p->ns_idle.load() / (double)(p->ns_idle.load() + p->ns_parse.load() + p->ns_enqueue.load() + 1));
-  for (Image* im : p->order) delete im; // drains each image's stream first
+  for (Image* im : p->order) { // images nobody collected: drain, release, and their streams go too
+    hipStream_t s = im->stream;
+    delete im; // drains the image's stream first
+    if (s) hipStreamDestroy(s);
+  }
   for (hipStream_t s : p->free_streams) hipStreamDestroy(s);
   delete p;
 }
@@ -158,8 +184,19 @@ void hm_pipeline_destroy(hm_pipeline* p)
 int hm_pipeline_submit(hm_pipeline* p, const uint8_t* heif, size_t size, uint32_t item_id, uint64_t tag)
 {
   if (!p || !heif) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
+  hipStream_t stream = nullptr;
+  {
+    // back-pressure first (before the file is copied and its boxes parsed: a caller that retries HM_PIPELINE_FULL would
+    // repeat that work every time): at most max_in_flight images hold device / pinned memory.  Not a wait: a
+    // single-threaded caller must be able to collect a result (hm_pipeline_next) to make room
+    std::lock_guard<std::mutex> g(p->m);
+    if (p->free_streams.empty()) return HM_PIPELINE_FULL;
+    stream = p->free_streams.back();
+    p->free_streams.pop_back();
+  }
+  auto give_back = [&]() { std::lock_guard<std::mutex> g(p->m); p->free_streams.push_back(stream); };
   Image* im = new (std::nothrow) Image();
-  if (!im) return hm_fail(HM_ERR_NOMEM, "out of memory");
+  if (!im) { give_back(); return hm_fail(HM_ERR_NOMEM, "out of memory"); }
   im->tag = tag;
   int rc = hm_file_open(heif, size, &im->file);
   if (!rc) {
@@ -172,15 +209,11 @@ int hm_pipeline_submit(hm_pipeline* p, const uint8_t* heif, size_t size, uint32_
     im->job.params.strict_decoding = p->cfg.strict_decoding;
     rc = job_plan(im->job);
   }
-  if (rc) { delete im; return rc; }
+  if (rc) { delete im; give_back(); return rc; }
   const int nt = job_tile_count(im->job);
   {
     std::unique_lock<std::mutex> g(p->m);
-    // back-pressure: at most max_in_flight images hold device / pinned memory.  Not a wait: a single-threaded caller
-    // must be able to collect a result (hm_pipeline_next) to make room
-    if (p->free_streams.empty()) { g.unlock(); delete im; return HM_PIPELINE_FULL; }
-    im->stream = p->free_streams.back();
-    p->free_streams.pop_back();
+    im->stream = stream;
     im->job.s = im->stream;
     im->job.params.stream = im->stream;
     im->tiles_left.store(nt);
@@ -207,8 +240,8 @@ int hm_pipeline_next(hm_pipeline* p, hm_pipeline_result* res)
     std::unique_lock<std::mutex> g(p->m);
     if (p->order.empty()) return hm_fail(HM_ERR_INVALID_ARG, "no image pending");
     im = p->order.front();
+    p->order.pop_front(); // claimed before the wait: a second consumer takes the next image, never this one
     p->result_cv.wait(g, [&] { return im->queued; });
-    p->order.pop_front();
   }
   if (im->status == HM_OK) {
     im->status = job_complete(im->job, &im->out);

@@ -132,6 +132,18 @@ HM_API int hm_hevc_parse(const uint8_t* data, size_t size, int annexb, uint8_t**
  * (entry points per CTB row) are entropy-decoded row-parallel like the reference's WPP threads (decctx.cc:1004-1116);
  * the command stream is the same byte for byte */
 HM_API int hm_hevc_parse_mt(const uint8_t* data, size_t size, int annexb, int threads, uint8_t** out_blob, size_t* out_size);
+/* the same with every choice spelled out.  record_order decides the order of the block records in the command stream
+ * (hm_stream.h), i.e. which reconstruction kernels the picture runs: HM_RECORDS_AUTO - by picture class, tuned for
+ * batches of thousands of tiles -, HM_RECORDS_SPLIT - separate luma / chroma chains whenever the picture's syntax allows
+ * (the faster choice when a batch holds few pictures: their rows then become the parallel work) -, HM_RECORDS_DECODE_ORDER.
+ * The same bytes always parse to the same stream for the same options: nothing depends on who calls. */
+enum { HM_RECORDS_AUTO = 0, HM_RECORDS_SPLIT = 1, HM_RECORDS_DECODE_ORDER = 2 };
+typedef struct hm_parse_options {
+  int32_t annexb;        /* 0: [u32 length][NAL] records, 1: Annex-B start codes */
+  int32_t threads;       /* host threads for the rows of a WPP-coded picture     */
+  int32_t record_order;  /* HM_RECORDS_*                                          */
+} hm_parse_options;
+HM_API int hm_hevc_parse_opts(const uint8_t* data, size_t size, const hm_parse_options* opts, uint8_t** out_blob, size_t* out_size);
 HM_API void hm_free(void* p);
 
 /* ------------------------------------------------------------------------- */
@@ -324,6 +336,9 @@ typedef struct hm_pipeline_config {
   int32_t out_format;          /* as hm_decode_params                                                              */
   int32_t chroma_upsampling, ignore_transformations, strict_decoding;
   int32_t device;              /* HIP device index, -1 = the calling thread's current device                       */
+  int32_t cpu_first, cpu_count; /* the crew's CPUs: [cpu_first, cpu_first + cpu_count), 0 count = wherever the caller may
+                                  run.  One pipeline per GPU, each with the CPUs (NUMA node) next to its GPU, is how a
+                                  node of 8 GPUs is fed: the entropy decode of one GPU's images never migrates away     */
 } hm_pipeline_config;
 typedef struct hm_pipeline_result {
   uint64_t   tag;              /* the caller's tag of hm_pipeline_submit                                            */
@@ -340,7 +355,8 @@ enum { HM_PIPELINE_FULL = 1 };
 HM_API int  hm_pipeline_submit(hm_pipeline* p, const uint8_t* heif, size_t size, uint32_t item_id, uint64_t tag);
 /* number of submitted images whose result has not been taken yet */
 HM_API int  hm_pipeline_pending(hm_pipeline* p);
-/* wait for the oldest pending image (results come in submission order); a failed image is reported in res->status */
+/* wait for the oldest pending image (results come in submission order; several consumers each get a different image);
+ * a failed image is reported in res->status */
 HM_API int  hm_pipeline_next(hm_pipeline* p, hm_pipeline_result* res);
 /* give the image's pinned planes and its slot back */
 HM_API void hm_pipeline_release(hm_pipeline* p, hm_pipeline_result* res);

@@ -109,7 +109,7 @@ class HeifFile:
 
 
 class PipelineConfig(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in "host_threads max_in_flight out_format chroma_upsampling ignore_transformations strict_decoding device".split()]
+    _fields_ = [(n, C.c_int32) for n in "host_threads max_in_flight out_format chroma_upsampling ignore_transformations strict_decoding device cpu_first cpu_count".split()]
 
 
 class PipelineResult(C.Structure):
@@ -119,7 +119,7 @@ class PipelineResult(C.Structure):
 class Pipeline:
     """hm_pipeline_*: many HEIF files in flight (host entropy decode || H2D || kernels || D2H)."""
 
-    def __init__(self, hm, out_format, host_threads=4, max_in_flight=8, device=-1):
+    def __init__(self, hm, out_format, host_threads=4, max_in_flight=8, device=-1, cpus=None):
         self.hm = bind(hm)
         hm.hm_pipeline_create.argtypes = [C.POINTER(PipelineConfig), C.POINTER(C.c_void_p)]
         hm.hm_pipeline_destroy.argtypes = [C.c_void_p]
@@ -127,7 +127,8 @@ class Pipeline:
         hm.hm_pipeline_pending.argtypes = [C.c_void_p]
         hm.hm_pipeline_next.argtypes = [C.c_void_p, C.POINTER(PipelineResult)]
         hm.hm_pipeline_release.argtypes = [C.c_void_p, C.POINTER(PipelineResult)]
-        cfg = PipelineConfig(host_threads, max_in_flight, out_format, 0, 0, 0, device)
+        cpu_first, cpu_count = cpus if cpus else (0, 0)  # the crew's CPUs [first, first + count)
+        cfg = PipelineConfig(host_threads, max_in_flight, out_format, 0, 0, 0, device, cpu_first, cpu_count)
         self.h = C.c_void_p()
         rc = hm.hm_pipeline_create(C.byref(cfg), C.byref(self.h))
         if rc:

@@ -521,7 +521,7 @@ __attribute__((visibility("default"))) int hm_synth_picture(const SynthParams* p
 
   // ---- slice segments: data first (the walker decides where a segment ends), then its header ----
   PictureState pic;
-  pic.reset(sps, pps);
+  pic.reset(sps, pps, quad_class(sps));
   EncoderEC ec(seed, p);
   Rng sl_rng(seed ^ 0x511ce5eedull); // per-slice header content
   const int N = sps.ctb_w * sps.ctb_h;

@@ -115,3 +115,32 @@ def test_pipeline_reports_bad_files_and_keeps_going(hm):
         assert pl.submit(good, 5) and pl.submit(good, 6)
     finally:
         pl.close()
+
+
+def test_two_pipelines_with_their_own_cpu_sets(hm):
+    """one pipeline per GPU, each with a CPU set of its own for its entropy-decode crew (here both on
+    device 0 - the box has one GPU -, CPUs split in halves).  Results equal the image-at-a-time path; a device index
+    beyond the visible devices and a CPU set outside the machine are refused."""
+    import os
+    data = open(os.path.join(HERE, "data", "example.heic"), "rb").read()
+    f = pipeline.HeifFile(hm, data)
+    exp, _ = f.decode(f.primary(), 10)
+    f.close()
+    cpus = sorted(os.sched_getaffinity(0))
+    half = max(1, len(cpus) // 2)
+    a = pipeline.Pipeline(hm, 10, host_threads=2, max_in_flight=4, device=0, cpus=(cpus[0], half))
+    b = pipeline.Pipeline(hm, 10, host_threads=2, max_in_flight=4, device=0, cpus=(cpus[0] + half, max(1, len(cpus) - half)))
+    for p in (a, b):
+        for k in range(4):
+            assert p.submit(data, k)
+    for p in (a, b):
+        for k in range(4):
+            tag, status, arr, meta = p.next()
+            assert (tag, status) == (k, 0)
+            np.testing.assert_array_equal(arr, exp[0])
+    a.close()
+    b.close()
+    with pytest.raises(RuntimeError):
+        pipeline.Pipeline(hm, 10, device=64)
+    with pytest.raises(RuntimeError):
+        pipeline.Pipeline(hm, 10, cpus=(0, 100000))

@@ -314,3 +314,25 @@ def test_grid_tiles_with_their_own_transforms(hm, variant):
     _, _, canv = pipeline.cpu_decode(hm, tiles, 64, 64, 120, 100, 2, True, 10 if bd == 8 else 14)
     np.testing.assert_array_equal(got[0][:100, :120 * (2 if bd > 8 else 1)], canv[0][0][:100, :120 * (2 if bd > 8 else 1)])
     f.close()
+
+
+@pytest.mark.gpu
+def test_own_transform_tile_outside_the_canvas_is_refused_before_anything_runs(hm):
+    """A crafted grid: tiles with their own irot, a canvas narrower than one tile column, so that the second column's origin
+    lies at / beyond the canvas edge (the reference: context.cc:2466-2483 returns an error for it).  The image must be
+    refused - by the per-tile check that runs before any device work is queued - and the next decode of a good file on
+    the same thread must be unaffected (the own-tile planes of the refused job are released behind its stream)."""
+    tiles = [synthutil.picture(9400 + i, width=64, height=64) for i in range(4)]
+    tt = {0: [("irot", 1)], 1: [("irot", 1)], 2: [("irot", 2)], 3: [("irot", 3)]}
+    bad = heifwriter.write_heic(tiles, (64, 64), grid=(2, 2, 64, 100), tile_transforms=tt)  # canvas 64 wide: column 1 starts at x = 64
+    f = pipeline.HeifFile(hm, bad)
+    for _ in range(3):
+        with pytest.raises(RuntimeError):
+            f.decode(f.primary(), 10)
+    f.close()
+    good = heifwriter.write_heic(tiles, (64, 64), grid=(2, 2, 120, 100), tile_transforms=tt)
+    g = pipeline.HeifFile(hm, good)
+    got, _ = g.decode(g.primary(), 10)
+    exp, _, _ = pipeline.cpu_decode(hm, tiles, 64, 64, 120, 100, 2, True, 10, tile_transforms=tt)
+    np.testing.assert_array_equal(got[0][:100, :120 * 3], exp[:100, :120 * 3])
+    g.close()
