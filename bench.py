@@ -345,7 +345,11 @@ def run(args):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    out = {}
+    if world > 1 and not args.quick:
+        multi_rank_legs(out, args, torch, pkg, dev, dev_index, st, gb, kept, dist, rank, world)
     if rank == 0:
+        extra = out
         total_mp = world * B * MP_PER_IMAGE * args.steps
         value = total_mp / elapsed
         kernels, alg, stream_b = kernel_table(gb, avg_ms)
@@ -370,6 +374,7 @@ def run(args):
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_source},
             "kernels": kernels,
         }
+        out.update(extra)
         if world > ndev:
             out["config"]["shared_gpu"] = f"{world} ranks on {ndev} GPU(s): functional run of the N>1 path, not a scaling number"
         gb.batch.check()  # (a reconstruction wave that gave up a bounded wait would have flagged its launch)
@@ -384,6 +389,68 @@ def run(args):
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# --------------------------------------------------------------------------------------------------------------
+# N > 1: the transfer- and host-inclusive clocks on EVERY rank (one pipeline / one host crew per GPU)
+# --------------------------------------------------------------------------------------------------------------
+
+def rank_cpu_share(rank, world):
+    """this rank's share of the CPUs the job may use: (threads, (first cpu, count)) - contiguous slices of the affinity
+    mask (the CPUs next to a GPU are contiguous on the usual two-socket hosts), threads = usable CPUs (cgroup quota) / world"""
+    cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    per = max(1, len(cpus) // world)
+    mine = cpus[(rank * per) % len(cpus):][:per]
+    contiguous = bool(mine) and mine == list(range(mine[0], mine[0] + len(mine)))
+    threads = max(1, effective_cpus() // world)
+    return threads, ((mine[0], len(mine)) if contiguous else None)
+
+
+def multi_rank_legs(out, args, torch, pkg, dev, dev_index, st, gb, kept, dist, rank, world):
+    """D (H2D of the command streams under the kernels) and E (.heic bytes in, RGB in host memory out, one pipeline per
+    rank) measured on all ranks at the same time; rank 0 reports the aggregate over the slowest rank and every rank's own
+    numbers.  Called by every rank."""
+    B = len(gb.images)
+    cpu = "cpu" if args.dist_backend != "nccl" else dev
+
+    def gather(vals):
+        t = torch.tensor(vals, dtype=torch.float64, device=cpu)
+        parts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        return [[float(x) for x in p.tolist()] for p in parts]
+
+    # ---- D ----
+    copy = torch.cuda.Stream(device=dev)
+    gb.batch.upload_execute(3, 3, copy.cuda_stream, st)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        gb.batch.upload_execute(3, 3, copy.cuda_stream, st)
+    torch.cuda.synchronize()
+    d_ms = (time.perf_counter() - t0) / 3 * 1e3
+    gb.batch.check()
+    # ---- E ----
+    threads, cpus = rank_cpu_share(rank, world)
+    n_files = max(16, min(len(kept), 256 // world))
+    dist.barrier()
+    e = end_to_end_pipelined(pkg, kept[:n_files], threads=threads, cpus=cpus, device=dev_index)
+    rows = gather([d_ms, e["seconds"], e["images"], threads, cpus[0] if cpus else -1, cpus[1] if cpus else 0, e["outputs_hash_checked"]])
+    if rank == 0:
+        d_max = max(r[0] for r in rows)
+        e_max = max(r[1] for r in rows)
+        out["dist"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
+        out["device_inclusive_all_ranks"] = {
+            "MP_per_s": round(world * B * MP_PER_IMAGE / d_max * 1e3, 1), "ms_per_step_slowest_rank": round(d_max, 3),
+            "per_rank_ms": [round(r[0], 3) for r in rows],
+            "note": "hm_batch_upload_execute, 3 chunks, every rank its own GPU and copy stream, all ranks at once"}
+        out["end_to_end_pipelined_all_ranks"] = {
+            "MP_per_s": round(sum(r[2] for r in rows) * MP_PER_IMAGE / e_max, 1),
+            "per_rank": [{"images": int(r[2]), "seconds": round(r[1], 3), "host_threads": int(r[3]), "cpu_set": [int(r[4]), int(r[5])] if r[5] else None,
+                          "MP_per_s": round(r[2] * MP_PER_IMAGE / r[1], 1), "outputs_hash_checked": int(r[6])} for r in rows],
+            "note": "one hm_pipeline per rank (its GPU, its share of the usable CPUs, pinned to its slice of the affinity mask); aggregate = all images / slowest rank"}
+        out["end_to_end_MP_per_s"] = out["end_to_end_pipelined_all_ranks"]["MP_per_s"]
+        out["device_inclusive_MP_per_s"] = out["device_inclusive_all_ranks"]["MP_per_s"]
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -450,6 +517,7 @@ def side_legs(out, args, torch, pkg, dev, st, gb, kept, strides, stream_b):
     guarded(out, "device_inclusive", lambda: device_inclusive(torch, pkg, dev, gb, st, stream_b))
     guarded(out, "end_to_end", lambda: end_to_end_single(pkg, kept[0]))
     guarded(out, "end_to_end_pipelined", lambda: end_to_end_pipelined(pkg, kept))
+    guarded(out, "plugin_path", lambda: plugin_path(pkg, kept[0]))
     if args.cpu_seconds > 0:
         guarded(out, "cpu_baseline", lambda: cpu_baseline(kept, args.cpu_seconds, 1))
         guarded(out, "cpu_baseline_all_cores", lambda: cpu_baseline(kept, args.cpu_seconds, effective_cpus()))
@@ -585,17 +653,72 @@ def end_to_end_single(pkg, tiles):
     return res
 
 
-def end_to_end_pipelined(pkg, kept):
+def plugin_path(pkg, tiles):
+    """The decoder-plugin boundary driven the way the reference drives it for a grid (context.cc:2361-2401, 1787-1835;
+    decoder_libde265.cc:306-369): one decoder instance per tile - new_decoder, push_data, decode_image, free_decoder - from
+    8 concurrent threads, one 12 MP grid = 48 tiles.  Behind decode_image the calls meet in the device's shared worker
+    (csrc/picture.cpp) and run as one GPU batch.  Beside it: hm_decode_item on the same tiles as a .heic (planar output,
+    8 host threads), which also pastes."""
+    import heifwriter
+    import numpy as np
+    import orc
+    import pipeline
+    import pluginapi
+    from concurrent.futures import ThreadPoolExecutor
+    api = pluginapi.load_api(pkg)
+    plugin = api.hm_get_decoder_plugin().contents
+    hm = pkg.lib()
+
+    def run(pool):
+        imgs = list(pool.map(lambda d: pluginapi.decode_tile(plugin, d, 8), tiles))
+        return imgs
+
+    with ThreadPoolExecutor(max_workers=8) as pool:
+        imgs = run(pool)  # warm-up, and a check of tile 0 against the oracle
+        stride = C.c_int()
+        ptr = api.heif_image_get_plane_readonly(imgs[0], 0, C.byref(stride))
+        got = np.ctypeslib.as_array(ptr, shape=(TILE, stride.value))[:, :TILE].copy()
+        exp, _ = orc.oracle_decode(pkg.capi.parse_hevc(tiles[0]), 3, crop=True)
+        if not np.array_equal(got.astype(np.uint16), exp[0]):
+            raise RuntimeError("plugin path: tile 0 differs from the oracle")
+        for im in imgs:
+            api.heif_image_release(im)
+        best = 1e9
+        for _ in range(5):
+            t0 = time.perf_counter()
+            imgs = run(pool)
+            best = min(best, time.perf_counter() - t0)
+            for im in imgs:
+                api.heif_image_release(im)
+    data = heifwriter.write_heic(tiles, (TILE, TILE), grid=(GRID_ROWS, GRID_COLS, OUT_W, OUT_H))
+    f = pipeline.HeifFile(hm, data)
+    try:
+        f.decode(f.primary(), 0, threads=8, copy=False)
+        item = 1e9
+        for _ in range(5):
+            t0 = time.perf_counter()
+            f.decode(f.primary(), 0, threads=8, copy=False)
+            item = min(item, time.perf_counter() - t0)
+    finally:
+        f.close()
+    return {"ms_per_12MP_grid": round(best * 1e3, 2), "MP_per_s": round(MP_PER_IMAGE / best, 1), "tiles": len(tiles), "threads": 8,
+            "hm_decode_item_ms": round(item * 1e3, 2), "ratio_to_hm_decode_item": round(best / item, 2),
+            "note": "48 decoder instances (new_decoder / push_data / decode_image / free_decoder) from 8 threads, best of 5; host entropy decode on the "
+                    "calling threads, the GPU work of concurrent calls coalesced by the shared device worker; tile 0 checked against the oracle"}
+
+
+def end_to_end_pipelined(pkg, kept, threads=None, cpus=None, device=-1):
     """Clock (E) at throughput: hm_pipeline_* over >= 256 different 12 MP .heic files, all host cores parsing, the images'
     device work on their own streams (parse of k+1 || kernels of k || D2H of k-1); every output is hash-checked against
-    the image-at-a-time path."""
+    the image-at-a-time path.  threads / cpus / device: the crew of ONE rank of a multi-GPU run (its share of the usable
+    CPUs, pinned to its slice of the affinity mask, feeding its own GPU)."""
     import heifwriter
     import numpy as np
     import pipeline
     hm = pkg.lib()
     files = [heifwriter.write_heic(t, (TILE, TILE), grid=(GRID_ROWS, GRID_COLS, OUT_W, OUT_H)) for t in kept]
     ncpu = effective_cpus()
-    threads = max(1, min(ncpu, 192))
+    threads = threads or max(1, min(ncpu, 192))
     depth = 16
 
     def fnv(arr, stride):
@@ -609,7 +732,7 @@ def end_to_end_pipelined(pkg, kept):
         planes, meta = f.decode(f.primary(), 10, threads=min(48, threads))
         expected[i] = fnv(planes[0], meta["stride"][0])
         f.close()
-    pl = pipeline.Pipeline(hm, 10, host_threads=threads, max_in_flight=depth)
+    pl = pipeline.Pipeline(hm, 10, host_threads=threads, max_in_flight=depth, device=device, cpus=cpus)
     checked = 0
     import collections
     order = collections.deque()  # results come back in submission order
@@ -641,7 +764,7 @@ def end_to_end_pipelined(pkg, kept):
     finally:
         pl.close()
     n = len(files)
-    return {"images": n, "host_threads": threads, "host_cpus_usable": ncpu, "host_cpus_visible": os.cpu_count(), "max_in_flight": depth,
+    return {"images": n, "seconds": dt, "host_threads": threads, "cpu_set": list(cpus) if cpus else None, "host_cpus_usable": ncpu, "host_cpus_visible": os.cpu_count(), "max_in_flight": depth,
             "ms_per_image": round(dt / n * 1e3, 3), "MP_per_s": round(n * MP_PER_IMAGE / dt, 1),
             "outputs_hash_checked": checked,
             "note": "hm_pipeline_*: .heic bytes in, RGB24 in pinned host memory out; box parsing + CABAC on the host crew, H2D, kernels, "

@@ -40,8 +40,12 @@ enum Ctx : int {
   CTX_COUNT = 149
 };
 
+// (16-bit states on purpose: a store through a character type may alias anything, the arithmetic decoder's range / value /
+//  bit count included - the compiler then writes them to memory and reads them back around every bin; a 16-bit store
+//  cannot alias their 32-bit type, so they stay in registers across the bins of an inlined loop)
+typedef uint16_t ctx_state;
 struct ContextSet {
-  uint8_t state[CTX_COUNT]; // (pStateIdx << 1) | valMps
+  ctx_state state[CTX_COUNT]; // (pStateIdx << 1) | valMps
 };
 
 namespace cabac_tables {
@@ -118,7 +122,7 @@ inline void init_contexts(ContextSet& cs, int slice_qp_y)
     pre = pre < 1 ? 1 : (pre > 126 ? 126 : pre);
     int mps = pre <= 63 ? 0 : 1;
     int st = mps ? pre - 64 : 63 - pre;
-    cs.state[i] = (uint8_t)((st << 1) | mps);
+    cs.state[i] = (ctx_state)((st << 1) | mps);
   }
 }
 
@@ -147,7 +151,7 @@ class CabacDecoder {
   // One context-coded bin (9.3.4.3.2).  The MPS / LPS decision of a well-compressed stream is as good as random, so it
   // is taken with masks instead of a branch (a mispredicted branch per bin costs more than the arithmetic of both
   // paths); the state transition is one table look-up on (LPS?, state); renormalisation shifts by the leading zeros.
-  inline int decode_bin(uint8_t& ctx)
+  inline int decode_bin(ctx_state& ctx)
   {
     const uint32_t c = ctx;
     const uint32_t lps_range = cabac_tables::kRangeTabLps[c >> 1][(range_ >> 6) & 3];

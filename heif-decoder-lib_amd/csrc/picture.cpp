@@ -1,12 +1,20 @@
 // picture.cpp — one coded picture (what a heif_decoder_plugin gets through push_data) -> host planes.
 //
 // The C-ABI behind the decoder plugin's decode_image (libheif/plugins/decoder_libde265.cc:88-157, 311-369): host entropy
-// decode, one GPU batch of one picture, planes of the conformance-window size copied into caller memory.  Device and
+// decode on the calling thread, the GPU work through the device's shared worker (below: concurrent callers share one
+// batch), planes of the conformance-window size copied into caller memory.  Device and
 // pinned staging memory come from the caching pool (devpool.cpp): a 48-tile grid decoded through the reference's
 // registry makes 48 of these calls from concurrent threads, and a hipMalloc per plane would serialise them.
+#include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <new>
+#include <string>
+#include <thread>
+#include <vector>
 
 #include "hm_internal.h"
 #include "hm_stream.h"
@@ -52,6 +60,125 @@ int hm_picture_parse(const uint8_t* data, size_t size, hm_picture** out, hm_pict
 
 void hm_picture_free(hm_picture* p) { delete p; }
 
+} // extern "C"
+
+// ---- the shared device worker -------------------------------------------------------------------------------------
+// The reference decodes the tiles of a grid with one decoder instance per tile from up to m_max_decoding_threads threads
+// at once (context.cc:2385-2387); each thread ends in this file's hm_picture_decode_to_host.  One GPU batch per call
+// would be 48 uploads, 48 launch sequences, 48 critical paths; instead the calls hand their picture to ONE worker per
+// device ("treat decode_image as enqueue to a shared device worker and wait"), which puts everything that is
+// waiting into one hm_batch on a stream of its own - the pictures that arrive together run together - and wakes the
+// callers, each of which then copies its own planes out of its pinned block.
+namespace {
+
+struct Request {
+  hm_picture* pic = nullptr;
+  void* dev = nullptr;  // the picture's planes on the device / in pinned host memory (one block each, pool)
+  void* pin = nullptr;
+  size_t off[3] = {0, 0, 0}, pitch[3] = {0, 0, 0}, total = 0;
+  int status = 1;       // > 0: pending
+  std::string message;
+};
+
+class DeviceWorker {
+ public:
+  static DeviceWorker& of_current_device()
+  {
+    static std::mutex m;
+    static DeviceWorker* workers[64] = {};
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = 0;
+    std::lock_guard<std::mutex> l(m);
+    if (!workers[d]) workers[d] = new DeviceWorker(d); // leaked on purpose: no HIP calls at exit
+    return *workers[d];
+  }
+  int run(Request& r)
+  {
+    std::unique_lock<std::mutex> l(m_);
+    queue_.push_back(&r);
+    work_.notify_one();
+    done_.wait(l, [&] { return r.status <= 0; });
+    if (r.status) hm_fail(r.status, "%s", r.message.c_str());
+    return r.status;
+  }
+
+ private:
+  explicit DeviceWorker(int device) : device_(device)
+  {
+    const char* e = std::getenv("HM_PLUGIN_LINGER_US");
+    linger_us_ = e ? std::atoi(e) : 150;
+    std::thread([this] { loop(); }).detach();
+  }
+  void loop()
+  {
+    hipSetDevice(device_);
+    hipStream_t s = nullptr;
+    const hipError_t se = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    for (;;) {
+      std::vector<Request*> reqs;
+      {
+        std::unique_lock<std::mutex> l(m_);
+        work_.wait(l, [&] { return !queue_.empty(); });
+        // the callers of one grid arrive within microseconds of each other: keep collecting while they keep coming
+        // (at most 64 pictures, at most ~1 ms)
+        for (int rounds = 0; rounds < 8; rounds++) {
+          while (!queue_.empty() && reqs.size() < 64) { reqs.push_back(queue_.front()); queue_.pop_front(); }
+          if (reqs.size() >= 64 || linger_us_ <= 0) break;
+          if (!work_.wait_for(l, std::chrono::microseconds(linger_us_), [&] { return !queue_.empty(); })) break;
+        }
+      }
+      int rc = se == hipSuccess ? HM_OK : hm_check_hip(se, "hipStreamCreate");
+      std::string msg = rc ? hm_last_error() : "";
+      if (!rc) rc = run_batch(reqs, s, msg);
+      {
+        std::lock_guard<std::mutex> l(m_);
+        for (Request* r : reqs) { r->status = rc; r->message = msg; }
+      }
+      done_.notify_all();
+    }
+  }
+  // one batch for all pictures: upload, kernels, D2H of every picture into its pinned block; returns when it is all there
+  int run_batch(const std::vector<Request*>& reqs, hipStream_t s, std::string& msg)
+  {
+    hm_batch* b = nullptr;
+    int rc = hm_batch_create(&b);
+    for (Request* r : reqs) {
+      if (rc) break;
+      const hm_picture_info& I = r->pic->info;
+      hm_tile_dest dest;
+      std::memset(&dest, 0, sizeof(dest));
+      for (int c = 0; c < I.n_planes; c++) { dest.plane[c] = (uint8_t*)r->dev + r->off[c]; dest.pitch[c] = (int32_t)r->pitch[c]; }
+      dest.canvas_width = I.plane_width[0]; dest.canvas_height = I.plane_height[0]; // the "canvas" is the picture itself: plain copy, no rescale
+      const int idx = hm_batch_add_trusted(b, r->pic->blob, r->pic->blob_size, &dest);
+      if (idx < 0) rc = idx;
+    }
+    if (!rc) rc = hm_batch_upload(b, s);
+    if (!rc) rc = hm_batch_execute(b, 3, s);
+    if (!rc) {
+      hipError_t e = hipSuccess;
+      for (Request* r : reqs)
+        if (e == hipSuccess) e = hipMemcpyAsync(r->pin, r->dev, r->total, hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess) e = hipStreamSynchronize(s);
+      rc = hm_check_hip(e, "D2H of the decoded planes");
+      if (!rc) rc = hm_batch_check(b);
+    }
+    if (rc) msg = hm_last_error();
+    if (b) hm_batch_destroy(b); // drains the stream before the callers release their blocks
+    return rc;
+  }
+  int device_;
+  int linger_us_ = 150;
+  std::mutex m_;
+  std::condition_variable work_, done_;
+  std::deque<Request*> queue_;
+};
+
+} // namespace
+
+extern "C" {
+
+// stream == nullptr: through the device's shared worker (concurrent callers end up in one batch); a stream of the
+// caller's: a batch of its own on that stream, as before
 int hm_picture_decode_to_host(hm_picture* p, uint8_t* const plane[3], const int32_t stride[3], void* stream)
 {
   if (!p || !plane || !stride) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
@@ -59,43 +186,49 @@ int hm_picture_decode_to_host(hm_picture* p, uint8_t* const plane[3], const int3
   const int bps = I.bit_depth > 8 ? 2 : 1;
   for (int c = 0; c < I.n_planes; c++)
     if (!plane[c] || stride[c] < I.plane_width[c] * bps) return hm_fail(HM_ERR_INVALID_ARG, "plane %d: null or stride too small", c);
-  hipStream_t s = (hipStream_t)stream;
 
   // one device block and one pinned block for all planes (pitch 64-byte aligned)
-  size_t off[3] = {0, 0, 0}, pitch[3] = {0, 0, 0}, total = 0;
+  Request r;
+  r.pic = p;
   for (int c = 0; c < I.n_planes; c++) {
-    pitch[c] = ((size_t)I.plane_width[c] * bps + 63) / 64 * 64;
-    off[c] = total;
-    total += (pitch[c] * I.plane_height[c] + 255) & ~(size_t)255;
+    r.pitch[c] = ((size_t)I.plane_width[c] * bps + 63) / 64 * 64;
+    r.off[c] = r.total;
+    r.total += (r.pitch[c] * I.plane_height[c] + 255) & ~(size_t)255;
   }
   struct Dev { void* p = nullptr; ~Dev() { hm_pool_device_free(p); } } dev;
   struct Pin { void* p = nullptr; ~Pin() { hm_pool_pinned_free(p); } } pin;
-  dev.p = hm_pool_device_alloc(total);
-  pin.p = hm_pool_pinned_alloc(total);
-  if (!dev.p || !pin.p) return hm_fail(HM_ERR_NOMEM, "device / pinned staging for %zu bytes", total);
+  dev.p = hm_pool_device_alloc(r.total);
+  pin.p = hm_pool_pinned_alloc(r.total);
+  if (!dev.p || !pin.p) return hm_fail(HM_ERR_NOMEM, "device / pinned staging for %zu bytes", r.total);
+  r.dev = dev.p; r.pin = pin.p;
 
-  hm_tile_dest dest;
-  std::memset(&dest, 0, sizeof(dest));
-  for (int c = 0; c < I.n_planes; c++) { dest.plane[c] = (uint8_t*)dev.p + off[c]; dest.pitch[c] = (int32_t)pitch[c]; }
-  dest.canvas_width = I.plane_width[0]; dest.canvas_height = I.plane_height[0]; // the "canvas" is the picture itself: plain copy, no rescale
-  hm_batch* b = nullptr;
-  int rc = hm_batch_create(&b);
-  if (rc) return rc;
-  rc = hm_batch_add_trusted(b, p->blob, p->blob_size, &dest);
-  if (rc >= 0) rc = hm_batch_upload(b, s);
-  if (!rc) rc = hm_batch_execute(b, 3, s);
-  if (!rc) {
-    hipError_t e = hipMemcpyAsync(pin.p, dev.p, total, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    rc = hm_check_hip(e, "D2H of the decoded planes");
-    if (!rc) rc = hm_batch_check(b);
+  int rc;
+  if (!stream) rc = DeviceWorker::of_current_device().run(r);
+  else {
+    hipStream_t s = (hipStream_t)stream;
+    hm_tile_dest dest;
+    std::memset(&dest, 0, sizeof(dest));
+    for (int c = 0; c < I.n_planes; c++) { dest.plane[c] = (uint8_t*)dev.p + r.off[c]; dest.pitch[c] = (int32_t)r.pitch[c]; }
+    dest.canvas_width = I.plane_width[0]; dest.canvas_height = I.plane_height[0];
+    hm_batch* b = nullptr;
+    rc = hm_batch_create(&b);
+    if (rc) return rc;
+    rc = hm_batch_add_trusted(b, p->blob, p->blob_size, &dest);
+    if (rc >= 0) rc = hm_batch_upload(b, s);
+    if (!rc) rc = hm_batch_execute(b, 3, s);
+    if (!rc) {
+      hipError_t e = hipMemcpyAsync(pin.p, dev.p, r.total, hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess) e = hipStreamSynchronize(s);
+      rc = hm_check_hip(e, "D2H of the decoded planes");
+      if (!rc) rc = hm_batch_check(b);
+    }
+    hm_batch_destroy(b); // drains the stream before the pool blocks above are released
   }
-  hm_batch_destroy(b); // drains the stream before the pool blocks above are released
   if (rc) return rc;
-  for (int c = 0; c < I.n_planes; c++) {
-    const uint8_t* src = (const uint8_t*)pin.p + off[c];
+  for (int c = 0; c < I.n_planes; c++) { // (on the caller's thread: the copies of concurrent callers run side by side)
+    const uint8_t* src = (const uint8_t*)pin.p + r.off[c];
     const size_t row = (size_t)I.plane_width[c] * bps; // decoder_libde265.cc:150-152: w * bytes_per_pixel per row
-    for (int y = 0; y < I.plane_height[c]; y++) std::memcpy(plane[c] + (size_t)y * stride[c], src + (size_t)y * pitch[c], row);
+    for (int y = 0; y < I.plane_height[c]; y++) std::memcpy(plane[c] + (size_t)y * stride[c], src + (size_t)y * r.pitch[c], row);
   }
   return HM_OK;
 }

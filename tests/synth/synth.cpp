@@ -91,7 +91,7 @@ struct CabacEncoder {
       low <<= 1;
     }
   }
-  void encode(uint8_t& ctx, int bin)
+  void encode(hm::ctx_state& ctx, int bin)
   {
     int st = ctx >> 1, mps = ctx & 1;
     const uint32_t lps = cabac_tables::kRangeTabLps[st][(range >> 6) & 3];
