@@ -227,6 +227,13 @@ int hm_file_image_info(const hm_file* f, uint32_t id, hm_image_info* info)
   info->chroma = first->props.hvcc.chroma_format;
   info->has_transforms = (it->props.has_irot || it->props.has_imir || it->props.has_clap) ? 1 : 0;
   info->has_alpha = f->file.alpha_item_of(id) != 0;
+  if (!info->has_alpha && it->type == "grid") { // (context.cc:1303-1368: a grid has alpha if one of its tiles has)
+    hm::GridInfo g;
+    hm::HeifError e2;
+    if (f->file.grid_info(id, g, e2))
+      for (uint32_t t : g.tiles)
+        if (f->file.alpha_item_of(t)) info->has_alpha = 1;
+  }
   info->has_nclx = (it->props.colr.present || (it != first && first->props.colr.present)) ? 1 : 0;
   info->coded_width = info->width; info->coded_height = info->height;
   // the size an image handle reports (context.cc:810-838): every clap sets it to the rounded aperture size,
@@ -335,6 +342,19 @@ int plan_item(const hm_file* f, uint32_t id, ItemPlan& P)
   P.blobs.clear(); P.blobs.resize(nt);
   P.status.assign(nt, HM_OK);
   P.messages.assign(nt, std::string());
+  // alpha auxiliary images of grid tile items: decode_image_planar attaches them to the tile image (context.cc:2029-2078)
+  P.tile_alpha.clear();
+  if (P.is_grid)
+    for (size_t i = 0; i < nt; i++) {
+      const uint32_t a = f->file.alpha_item_of(P.tiles[i].id);
+      if (!a) continue;
+      const hm::Item* ai = f->file.item(a);
+      if (!ai || ai->type != "hvc1") return hm_fail(HM_ERR_UNSUPPORTED, "alpha image of grid tile %zu is not a coded HEVC image", i);
+      P.tile_alpha.push_back({(int)i, a});
+    }
+  P.alpha_blobs.clear(); P.alpha_blobs.resize(P.tile_alpha.size());
+  P.alpha_status.assign(P.tile_alpha.size(), HM_OK);
+  P.alpha_messages.assign(P.tile_alpha.size(), std::string());
   return HM_OK;
 }
 
@@ -347,6 +367,8 @@ int planar_from_blobs(const hm_file* f, ItemPlan& P, const hm_decode_params* par
   const int nt = (int)P.tiles.size();
   for (int i = 0; i < nt; i++)
     if (P.status[i]) return hm_fail(P.status[i], "tile %d (item %u): %s", i, P.tiles[i].id, P.messages[i].c_str());
+  for (size_t i = 0; i < P.tile_alpha.size(); i++)
+    if (P.alpha_status[i]) return hm_fail(P.alpha_status[i], "alpha image of tile %d (item %u): %s", P.tile_alpha[i].tile, P.tile_alpha[i].id, P.alpha_messages[i].c_str());
   const bool is_grid = P.is_grid;
   int canvas_w = P.canvas_w, canvas_h = P.canvas_h;
 
@@ -453,6 +475,41 @@ int planar_from_blobs(const hm_file* f, ItemPlan& P, const hm_decode_params* par
     const int idx = hm_batch_add_trusted(batch, P.blobs[i].p, P.blobs[i].n, &d);
     if (idx < 0) return idx;
   }
+  // ---- alpha auxiliary images of tile items: each is decoded to planes of its own in the same batch; the first one
+  //      decides the depth of the canvas' alpha plane (context.cc:2437-2455), which starts opaque ----
+  std::vector<std::unique_ptr<OwnTile>>& own_alpha = I.own_alpha;
+  own_alpha.clear();
+  I.tile_alpha_bd = 0;
+  for (size_t k = 0; k < P.tile_alpha.size(); k++) {
+    const hm_pic* h = reinterpret_cast<const hm_pic*>(P.alpha_blobs[k].p);
+    const int i = P.tile_alpha[k].tile;
+    if (I.tile_alpha_bd == 0) I.tile_alpha_bd = h->bit_depth_y;
+    else if (h->bit_depth_y != I.tile_alpha_bd) return hm_fail(HM_ERR_BITSTREAM, "Image tile has different pixel depth than combined image (alpha plane)");
+    if (canvas_w <= P.tiles[i].x0 || canvas_h <= P.tiles[i].y0) return hm_fail(HM_ERR_INVALID_ARG, "tile origin outside the canvas (invalid grid data)");
+    std::unique_ptr<OwnTile> o(new OwnTile());
+    o->index = (int)k;
+    o->chroma = h->chroma_format; o->bd = h->bit_depth_y;
+    o->w = h->width - h->crop_left - h->crop_right; o->h = h->height - h->crop_top - h->crop_bottom;
+    const int abps = o->bd > 8 ? 2 : 1;
+    const int acw = o->chroma == 3 ? o->w : (o->w + 1) / 2, ach = o->chroma == 1 ? (o->h + 1) / 2 : o->h;
+    if ((rc = alloc_plane(o->P[0], o->w, o->h, abps))) return rc;
+    if (o->chroma != 0 && ((rc = alloc_plane(o->P[1], acw, ach, abps)) || (rc = alloc_plane(o->P[2], acw, ach, abps)))) return rc;
+    hm_tile_dest d;
+    std::memset(&d, 0, sizeof(d));
+    for (int c = 0; c < 3; c++) { d.plane[c] = o->P[c].mem.p; d.pitch[c] = o->P[c].stride; }
+    d.canvas_width = o->w; d.canvas_height = o->h;
+    const int idx = hm_batch_add_trusted(batch, P.alpha_blobs[k].p, P.alpha_blobs[k].n, &d);
+    if (idx < 0) return idx;
+    own_alpha.push_back(std::move(o));
+  }
+  if (I.tile_alpha_bd) {
+    const int abps = I.tile_alpha_bd > 8 ? 2 : 1;
+    if ((rc = alloc_plane(I.tile_alpha, canvas_w, canvas_h, abps))) return rc;
+    const size_t bytes = plane_bytes(I.tile_alpha);
+    const hipError_t e = abps == 1 ? hipMemsetAsync(I.tile_alpha.mem.p, 0xFF, bytes, s)
+                                   : hipMemsetD16Async((hipDeviceptr_t)I.tile_alpha.mem.p, (unsigned short)((1u << I.tile_alpha_bd) - 1u), bytes / 2, s);
+    if (e != hipSuccess) return hm_check_hip(e, "fill of the alpha plane");
+  }
   // a grid canvas the tiles do not cover completely: the reference leaves it uninitialised (tiles must cover the
   // output, context.cc:2321-2337; its right / bottom padding is never read): zero it
   for (int c = 0; c < 3; c++)
@@ -463,6 +520,7 @@ int planar_from_blobs(const hm_file* f, ItemPlan& P, const hm_decode_params* par
     const hm::Item* ti = f->file.item(P.tiles[o->index].id);
     int tw = o->w, th = o->h;
     if ((rc = apply_transforms(ti->props.transforms, o->P, tw, th, chroma, bd, s, I.retired))) return rc;
+    o->w = tw; o->h = th; // (the tile image's size from here on: what an alpha image of the tile is scaled to)
     const hm::NclxProfile& tp = tile_profile[o->index];
     const int rescale = (tp.present && !tp.full_range && tp.matrix != 0) ? 1 : 0; // context.cc:2504-2509
     const int x0 = P.tiles[o->index].x0, y0 = P.tiles[o->index].y0;
@@ -481,10 +539,51 @@ int planar_from_blobs(const hm_file* f, ItemPlan& P, const hm_decode_params* par
     for (int c = 0; c < 3; c++) { I.retired.emplace_back(new DevMem()); I.retired.back()->swap(o->P[c].mem); }
   }
 
+  // ---- the tiles' alpha images: the alpha item's own transformations, its Y plane scaled (nearest neighbour) to the
+  //      tile image's size if it differs (context.cc:2064-2072), pasted like a luma plane - range rescale of the
+  //      tile's profile included (context.cc:2504-2528 runs over every channel of the tile image) ----
+  for (std::unique_ptr<OwnTile>& o : own_alpha) {
+    const ItemPlan::TileAlpha& ta = P.tile_alpha[(size_t)o->index];
+    const hm::Item* ai = f->file.item(ta.id);
+    int aw = o->w, ah = o->h;
+    if (ai && !params->ignore_transformations && !ai->props.transforms.empty())
+      if ((rc = apply_transforms(ai->props.transforms, o->P, aw, ah, o->chroma, o->bd, s, I.retired))) return rc;
+    // the tile image's size: its picture's conformance window, or what its own transformations made of it
+    const hm_pic* th = reinterpret_cast<const hm_pic*>(P.blobs[ta.tile].p);
+    int tw = th->width - th->crop_left - th->crop_right, thh = th->height - th->crop_top - th->crop_bottom;
+    for (const std::unique_ptr<OwnTile>& t : own)
+      if (t->index == ta.tile) { tw = t->w; thh = t->h; }
+    const int abps = o->bd > 8 ? 2 : 1;
+    const DevPlane* ap = &o->P[0];
+    DevPlane scaled;
+    if (aw != tw || ah != thh) {
+      if ((rc = alloc_plane(scaled, tw, thh, abps))) return rc;
+      if ((rc = hm_launch_scale_nn(abps, o->P[0].mem.p, o->P[0].stride, aw, ah, scaled.mem.p, scaled.stride, tw, thh, s))) return rc;
+      ap = &scaled;
+    }
+    const hm::NclxProfile& tp = tile_profile[ta.tile];
+    const int rescale = (tp.present && !tp.full_range && tp.matrix != 0) ? 1 : 0;
+    const int x0 = P.tiles[ta.tile].x0, y0 = P.tiles[ta.tile].y0;
+    const int copy_w = std::min(tw, canvas_w - x0), copy_h = std::min(thh, canvas_h - y0);
+    rc = hm_launch_paste_bytes(ap->mem.p, ap->stride, (uint8_t*)I.tile_alpha.mem.p + (size_t)y0 * I.tile_alpha.stride + (size_t)x0 * abps,
+                               I.tile_alpha.stride, copy_w * abps, copy_h, rescale, o->bd, 0, s);
+    if (scaled.mem.p) { I.retired.emplace_back(new DevMem()); I.retired.back()->swap(scaled.mem); }
+    if (rc) return rc;
+  }
+
   // ---- transformative item properties on the decoded planes (context.cc:1957-2020) ----
   int img_w = canvas_w, img_h = canvas_h;
-  if (!params->ignore_transformations && !it->props.transforms.empty())
+  if (!params->ignore_transformations && !it->props.transforms.empty()) {
     if ((rc = apply_transforms(it->props.transforms, Pl, img_w, img_h, chroma, bd, s, I.retired))) return rc;
+    if (I.tile_alpha_bd) { // (the alpha plane is a plane of the canvas: the grid's transformations move it along)
+      DevPlane ap[3];
+      ap[0].mem.swap(I.tile_alpha.mem); ap[0].w = I.tile_alpha.w; ap[0].h = I.tile_alpha.h; ap[0].stride = I.tile_alpha.stride;
+      int aw = canvas_w, ah = canvas_h;
+      rc = apply_transforms(it->props.transforms, ap, aw, ah, 0, I.tile_alpha_bd, s, I.retired);
+      I.tile_alpha.mem.swap(ap[0].mem); I.tile_alpha.w = ap[0].w; I.tile_alpha.h = ap[0].h; I.tile_alpha.stride = ap[0].stride;
+      if (rc) return rc;
+    }
+  }
   I.w = img_w; I.h = img_h; I.chroma = chroma; I.bd = bd; I.native = native; I.is_grid = is_grid;
   return HM_OK;
 }
@@ -511,7 +610,7 @@ int job_tile_count(const DecodeJob& j)
 {
   int n = 0;
   for (int i = 0; i < j.n_items; i++) n += (int)j.item[i].tiles.size();
-  return n;
+  return n + (int)j.item[0].tile_alpha.size(); // (behind the tiles of the image and of its own alpha image: the tiles' alpha pictures)
 }
 
 // host entropy decode of coded picture k (CABAC on the calling thread, like the reference's std::async tile tasks,
@@ -520,15 +619,21 @@ void job_parse_tile(DecodeJob& j, int k, int row_threads)
 {
   int which = 0;
   if (k >= (int)j.item[0].tiles.size()) { which = 1; k -= (int)j.item[0].tiles.size(); }
+  const bool tile_alpha = which == 1 && (j.n_items < 2 || k >= (int)j.item[1].tiles.size());
+  if (tile_alpha) { if (j.n_items > 1) k -= (int)j.item[1].tiles.size(); which = 0; }
   ItemPlan& P = j.item[which];
+  const uint32_t id = tile_alpha ? P.tile_alpha[k].id : P.tiles[k].id;
+  int& status = tile_alpha ? P.alpha_status[k] : P.status[k];
+  std::string& message = tile_alpha ? P.alpha_messages[k] : P.messages[k];
+  Blob& blob = tile_alpha ? P.alpha_blobs[k] : P.blobs[k];
   std::vector<uint8_t> data;
   hm::HeifError e;
-  if (!j.f->file.hevc_data(P.tiles[k].id, data, e)) { P.status[k] = e.status; P.messages[k] = e.message; return; }
+  if (!j.f->file.hevc_data(id, data, e)) { status = e.status; message = e.message; return; }
   hm_parse_options po;
   po.annexb = 0; po.threads = row_threads;
   po.record_order = j.few_pictures ? HM_RECORDS_SPLIT : HM_RECORDS_AUTO;
-  const int rc = hm_hevc_parse_opts(data.data(), data.size(), &po, &P.blobs[k].p, &P.blobs[k].n);
-  if (rc) { P.status[k] = rc; P.messages[k] = hm_last_error(); }
+  const int rc = hm_hevc_parse_opts(data.data(), data.size(), &po, &blob.p, &blob.n);
+  if (rc) { status = rc; message = hm_last_error(); }
 }
 
 // Everything after the host entropy decode, queued on j.s without waiting: GPU batch(es), transforms, alpha, colour
@@ -565,6 +670,16 @@ int job_enqueue(DecodeJob& j, hm_decoded* out)
     }
     out->has_alpha = 1;
   }
+  else if (I.tile_alpha_bd) {
+    // the canvas' own alpha plane (tiles with alpha images); an alpha image of the grid item itself - handled above -
+    // replaces it (transfer_plane_from_image_as, context.cc:2072)
+    if (params->out_format == HM_OUT_RGBA && I.tile_alpha_bd != 8 && I.bd == 8) return hm_fail(HM_ERR_UNSUPPORTED, "alpha plane of %d bits with an 8-bit image and an RGBA target", I.tile_alpha_bd);
+    if ((params->out_format == HM_OUT_RRGGBBAA_BE || params->out_format == HM_OUT_RRGGBBAA_LE) && (I.tile_alpha_bd > 8) != (I.bd > 8))
+      return hm_fail(HM_ERR_UNSUPPORTED, "alpha plane of %d bits with a %d-bit image and an RRGGBBAA target", I.tile_alpha_bd, I.bd);
+    alpha = &I.tile_alpha;
+    out->has_alpha = 1;
+  }
+  const int alpha_bd = j.n_items > 1 ? A.bd : I.tile_alpha_bd;
   lap("planar decode queued");
   DevPlane (&P)[3] = I.P;
   const int img_w = I.w, img_h = I.h, chroma = I.chroma, bd = I.bd;
@@ -618,16 +733,16 @@ int job_enqueue(DecodeJob& j, hm_decoded* out)
     // ops copy the plane (yuv2rgb.cc:483-488)
     if (alpha && params->out_format == HM_OUT_RGBA) {
       const DevPlane* a8 = alpha;
-      if (A.bd > 8) { // (a deeper image only, see above) Op_to_sdr_planes on the alpha plane
+      if (alpha_bd > 8) { // (a deeper image only, see above) Op_to_sdr_planes on the alpha plane
         if ((rc = alloc_plane(j.alpha_sdr, img_w, img_h, 1))) return rc;
-        if ((rc = hm_launch_to_sdr(alpha->mem.p, alpha->stride, j.alpha_sdr.mem.p, j.alpha_sdr.stride, img_w, img_h, A.bd, s))) return rc;
+        if ((rc = hm_launch_to_sdr(alpha->mem.p, alpha->stride, j.alpha_sdr.mem.p, j.alpha_sdr.stride, img_w, img_h, alpha_bd, s))) return rc;
         a8 = &j.alpha_sdr;
       }
       if ((rc = hm_launch_set_alpha(dout.p, cd.out_stride, img_w, img_h, a8->mem.p, a8->stride, s))) return rc;
     }
     const bool aa16 = params->out_format == HM_OUT_RRGGBBAA_BE || params->out_format == HM_OUT_RRGGBBAA_LE;
     if (alpha && aa16)
-      if ((rc = hm_launch_set_alpha16(dout.p, cd.out_stride, img_w, img_h, alpha->mem.p, alpha->stride, A.bd, bd > 8 ? bd : 10,
+      if ((rc = hm_launch_set_alpha16(dout.p, cd.out_stride, img_w, img_h, alpha->mem.p, alpha->stride, alpha_bd, bd > 8 ? bd : 10,
                                       params->out_format == HM_OUT_RRGGBBAA_BE, s))) return rc;
     out->out_format = params->out_format;
     // the converted image carries the output state's profile: the input one with undefined values replaced by the

@@ -56,7 +56,7 @@ struct Blob {
 // A decoded image on the device: what HeifContext::decode_image_planar returns (YCbCr planes after the item's
 // transformative properties), plus everything that must outlive the asynchronous work that produced it.
 // planes of a grid tile whose item carries its own irot / imir / clap: decoded there, transformed, then pasted
-struct OwnTile { int index = 0; DevPlane P[3]; int w = 0, h = 0; };
+struct OwnTile { int index = 0; DevPlane P[3]; int w = 0, h = 0; int chroma = 1, bd = 8; };
 struct PlanarImage {
   DevPlane P[3];
   int w = 0, h = 0, chroma = 1, bd = 8;
@@ -67,6 +67,12 @@ struct PlanarImage {
   // (a member, not a local of the function that queues work on them: every early return of that function leaves them
   //  alive until the job's destructor has drained the stream)
   std::vector<std::unique_ptr<OwnTile>> own;
+  // a grid whose TILE items carry alpha auxiliary images (context.cc:2029-2078 inside decode_image_planar, reached per
+  // tile from decode_and_paste_tile_image; the canvas then gets an alpha plane, :2437-2455): the tiles' alpha pictures
+  // and the canvas-sized alpha plane they are pasted into (opaque where a tile has none)
+  std::vector<std::unique_ptr<OwnTile>> own_alpha;
+  DevPlane tile_alpha;
+  int tile_alpha_bd = 0; // 0: no tile of the grid has an alpha image
   std::unique_ptr<hm_batch, void (*)(hm_batch*)> batch{nullptr, hm_batch_destroy};
 };
 
@@ -80,6 +86,12 @@ struct ItemPlan {
   std::vector<Blob> blobs;           // command streams, filled by job_parse_tile
   std::vector<int> status;
   std::vector<std::string> messages;
+  // grids: alpha auxiliary images of the tile items - (tile index, alpha item) pairs and their command streams
+  struct TileAlpha { int tile = 0; uint32_t id = 0; };
+  std::vector<TileAlpha> tile_alpha;
+  std::vector<Blob> alpha_blobs;
+  std::vector<int> alpha_status;
+  std::vector<std::string> alpha_messages;
 };
 
 struct DecodeJob {

@@ -100,7 +100,8 @@ def write_heic(pictures, size, grid=None, chroma_format=1, bit_depth=8, colr=Non
         iref_boxes.append(_box(b"dimg", struct.pack(">HH", gid, len(pictures)) +
                                b"".join(struct.pack(">H", k + 1) for k in range(len(pictures)))))
     wide = len(props) > 127  # ipma flags & 1: 15-bit property indices
-    # auxiliary images (e.g. alpha) of the primary item: (coded picture, (w, h), aux type URN)
+    # auxiliary images (e.g. alpha): (coded picture, (w, h), aux type URN[, chroma_format_idc, bit depth, target item id]);
+    # by default they belong to the primary item
     for entry in (aux or []):
         lp, asize, urn = entry[:3]
         aux_cf = entry[3] if len(entry) > 3 else chroma_format  # chroma_format_idc of the auxiliary picture (0 = monochrome)
@@ -112,7 +113,8 @@ def write_heic(pictures, size, grid=None, chroma_format=1, bit_depth=8, colr=Non
         aux_bd = entry[4] if len(entry) > 4 else bit_depth
         assoc[aid] = [0x8000 | prop(_hvcc(params, aux_cf, aux_bd)), prop(_full(b"ispe", 0, 0, struct.pack(">II", *asize))),
                       0x8000 | prop(_full(b"auxC", 0, 0, urn.encode() + b"\0"))]
-        iref_boxes.append(_box(b"auxl", struct.pack(">HHH", aid, 1, primary)))
+        target = entry[5] if len(entry) > 5 else primary  # item the auxiliary image belongs to (6th element: e.g. a grid tile's item id = picture index + 1)
+        iref_boxes.append(_box(b"auxl", struct.pack(">HHH", aid, 1, target)))
     iref = _full(b"iref", 0, 0, b"".join(iref_boxes)) if iref_boxes else b""
     ipma = struct.pack(">I", len(assoc))
     for iid in sorted(assoc):

@@ -336,3 +336,52 @@ def test_own_transform_tile_outside_the_canvas_is_refused_before_anything_runs(h
     exp, _, _ = pipeline.cpu_decode(hm, tiles, 64, 64, 120, 100, 2, True, 10, tile_transforms=tt)
     np.testing.assert_array_equal(got[0][:100, :120 * 3], exp[:100, :120 * 3])
     g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("vui", [1, 0])
+def test_alpha_images_of_grid_tiles(hm, vui):
+    """VERDICT r02 missing 5: alpha auxiliary images that belong to TILE items of a grid.  decode_image_planar attaches a
+    tile's alpha image to the tile image (context.cc:2029-2078: Y plane, scaled nearest-neighbour to the tile's size);
+    decode_and_paste_tile_image gives the canvas an alpha plane filled with the maximum value as soon as a tile has one
+    (:2437-2455) and pastes the tile's alpha like its luma plane - with the byte-wise range rescale when the tile's VUI
+    says limited range (:2504-2528: the loop runs over every channel of the tile image).  2x2 grid of 64x64 tiles on a
+    120x100 canvas; tile 0 has a same-size alpha image, tile 3 a half-size one (scaled), tiles 1 and 2 none (opaque)."""
+    kw = dict(width=64, height=64)
+    kw.update(dict(vui=1, full_range=1, matrix=6) if vui else dict(vui=0))
+    tiles = [synthutil.picture(9500 + i, **kw) for i in range(4)]
+    a0 = synthutil.picture(9510, width=64, height=64, chroma_format=0)
+    a3 = synthutil.picture(9511, width=32, height=32)
+    urn = "urn:mpeg:mpegB:cicp:systems:auxiliary:alpha"
+    data = heifwriter.write_heic(tiles, (64, 64), grid=(2, 2, 120, 100),
+                                 aux=[(a0, (64, 64), urn, 0, 8, 1), (a3, (32, 32), urn, 1, 8, 4)])
+    f = pipeline.HeifFile(hm, data)
+    iid = f.primary()
+    assert f.info(iid).has_alpha == 1
+    rgba, meta = f.decode(iid, 11)
+    native, nmeta = f.decode(iid, 0)
+    rgb, _ = f.decode(iid, 10)
+    f.close()
+    assert meta["has_alpha"] == 1
+    # expected alpha plane: opaque canvas, the tiles' alpha Y planes pasted at the tile origins (cropped at the canvas edge)
+    o = orc.load()
+    exp_a = np.full((100, 120), 255, np.uint8)
+    ya0 = orc.oracle_decode(hevcutil.parse(hm, a0), 3)[0][0][:64, :64].astype(np.uint8)
+    ya3 = orc.oracle_decode(hevcutil.parse(hm, a3), 3)[0][0][:32, :32].astype(np.uint8)
+    src, s_stride = orc.alloc_plane(32, 32, 1)
+    src[:32, :32] = ya3
+    scaled, sc_stride = orc.alloc_plane(64, 64, 1)
+    o.orc_scale_nn_plane(orc.ptr(src), s_stride, 32, 32, 1, orc.ptr(scaled), sc_stride, 64, 64)
+    for (x0, y0, plane) in ((0, 0, ya0), (64, 64, scaled[:64, :64])):
+        p = plane.astype(np.float32)
+        if not vui:  # tile nclx (from the VUI defaults) says limited range: the paste rescales, luma constants
+            p = np.clip(np.trunc((p - np.float32(16)) * np.float32(1.1689) + np.float32(0.5)), 0, 255)
+        h, w = min(64, 100 - y0), min(64, 120 - x0)
+        exp_a[y0:y0 + h, x0:x0 + w] = p[:h, :w].astype(np.uint8)
+    np.testing.assert_array_equal(nmeta["alpha"][:100, :120], exp_a)
+    np.testing.assert_array_equal(rgba[0][:100, 3:120 * 4:4], exp_a)
+    # the colour channels are those of the same grid without alpha images
+    exp, _, _ = pipeline.cpu_decode(hm, tiles, 64, 64, 120, 100, 2, True, 10)
+    np.testing.assert_array_equal(rgb[0][:100, :120 * 3], exp[:100, :120 * 3])
+    for c in range(3):
+        np.testing.assert_array_equal(rgba[0][:100, c:120 * 4:4], exp[:100, c:120 * 3:3])
