@@ -87,11 +87,13 @@ struct CLayout {
   // few waves: fewer chains per wave = shorter iterations) and, with split_kinds, on their luma or their chroma chains
   // only (the two never read each other); the picture's rows are bands_per_pic such bands
   int rows_per_wave, split_kinds, bands_per_pic;
+  int spin_limit;    // PAIRS: polls of the band above without news before a wave gives up (error flag, wrong picture, no hang)
+  int test_stall;    // fault injection (tests): the first band of every picture never announces its progress
 };
 // PAIRS: words of the launch's synchronisation buffer (zeroed before the launch): a ticket counter, an error flag, then
 // per (picture, pair, chain kind) the finished CTUs of the pair's last row
 constexpr int SYNC_TICKET = 0, SYNC_ERROR = 1, SYNC_PROGRESS = 8;
-constexpr int SPIN_LIMIT = 1 << 20; // PAIRS: polls of the pair above without news before a wave gives up (error flag, wrong picture, no hang)
+constexpr int SPIN_LIMIT = 1 << 20; // default of CLayout.spin_limit
 
 __device__ __forceinline__ int g_of(int lane) { return lane >> 4; }
 template <int CTRL>
@@ -285,7 +287,9 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   };
   if (st == ST_START) row_start();
   // every iteration executes a block of some chain or waits for a CTU that is at most two CTUs of another chain away
-  int budget = PAIRS ? 0x7FFFFFF0 : (int)n_tus + 64 * ctb_w * ctb_h + 4096; // (PAIRS: the waits have their own limit)
+  // (PAIRS: plus the bounded waits for the band above, one per CTU at most)
+  const long long budget_ll = (long long)n_tus + 64ll * ctb_w * ctb_h + 4096 + (PAIRS ? (long long)ctb_w * L.spin_limit : 0);
+  int budget = budget_ll < 0x7FFFFFF0ll ? (int)budget_ll : 0x7FFFFFF0;
 
 #if defined(HM_PAD_S) || defined(HM_PAD_V)
   int lane0_dummy = 0, pad_v = lane;
@@ -347,8 +351,11 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
           WAVE_SYNC();
           if (g == cg) { hbm_have = s_avail; hbm_polls = 0; }
         }
-        if (poll && st == ST_START && ++hbm_polls > SPIN_LIMIT) { // the pair above is not coming: give up (never on a healthy launch)
-          if (gl == 0) __hip_atomic_store(sync + SYNC_ERROR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the band above is not coming: give up (never on a healthy launch) - the whole wave, since its other chains
+        // wait for this one - with the launch flagged: the bands below give up in turn, nothing hangs
+        const bool gave_up = poll && st == ST_START && ++hbm_polls > L.spin_limit;
+        if (ballot(gave_up)) {
+          if (lane == 0) __hip_atomic_store(sync + SYNC_ERROR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           st = ST_DONE;
         }
         if (ballot(st == ST_RUN) == 0) __builtin_amdgcn_s_sleep(8); // every chain of the wave waits
@@ -743,7 +750,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
           put_line(hand + hand_luma_words + hand_chroma_words, cw_c, group_u(fg, 2), P1, ch_c);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(pair_progress + 2 * (size_t)pair_index + fkind, (uint32_t)(s_cx + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0 && !(L.test_stall && pair_index == 0)) __hip_atomic_store(pair_progress + 2 * (size_t)pair_index + fkind, (uint32_t)(s_cx + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       // the group's next CTU
       if (g == fg) {
@@ -806,6 +813,12 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
     L.split_kinds = force_pairs >= 3 && !mono ? 1 : 0;
   }
   L.bands_per_pic = (max_ctb_h + L.rows_per_wave - 1) / L.rows_per_wave;
+  // (tests: HM_CHAIN_SPIN_LIMIT shortens the bounded waits, HM_CHAIN_TEST_STALL=1 makes the first band of every picture
+  //  keep its progress to itself - the bands below must then give up, flag the launch and leave)
+  static const int env_spin = [] { const char* e = getenv("HM_CHAIN_SPIN_LIMIT"); return e ? atoi(e) : 0; }();
+  static const int env_stall = [] { const char* e = getenv("HM_CHAIN_TEST_STALL"); return e ? atoi(e) : 0; }();
+  L.spin_limit = env_spin > 0 ? env_spin : SPIN_LIMIT;
+  L.test_stall = env_stall;
   const size_t sync_need = ((size_t)SYNC_PROGRESS + 2 * (size_t)n_pics * L.bands_per_pic) * sizeof(uint32_t);
   if (!d_sync || sync_bytes < sync_need) pairs = false;
   if (!pairs) { L.rows_per_wave = nr; L.split_kinds = 0; }

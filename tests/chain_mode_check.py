@@ -1,0 +1,35 @@
+"""Helper of test_chain_modes_gpu.py (run as a script: the reconstruction's tuning / fault-injection knobs are read from
+the environment once per process): reconstruct a few corpus pictures on the GPU and compare with the oracle.
+Prints OK, or the first difference; exit status 0 / 1; 3 = hm_batch_check reported a wave that gave up."""
+import sys
+
+import numpy as np
+
+import __graft_entry__ as g
+import corpus
+import gpudecode
+import orc
+
+
+def main():
+    pkg = g.load_package()
+    names = sys.argv[1:] or ["tile512_a", "ctb64_wpp", "hi422_10", "mono8", "ragged"]
+    for name in names:
+        blob = pkg.capi.parse_hevc(corpus.stream(name))
+        try:
+            got = gpudecode.decode_pictures(pkg, [blob] * 3, 3)
+        except RuntimeError as e:
+            print("CHECK FAILED:", e)
+            return 3
+        exp, _ = orc.oracle_decode(blob, 3, crop=True)
+        for pic in got:
+            for c in range(len(exp)):
+                if not np.array_equal(pic[c], exp[c]):
+                    print(f"{name}: plane {c} differs")
+                    return 1
+    print("OK")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

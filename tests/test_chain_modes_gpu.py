@@ -1,0 +1,37 @@
+"""GPU: the cuts of the prediction-chain kernel (chain.hip) - a wave per picture, per pair of CTU rows, per row, per
+chain - must all give the oracle's pictures, for every picture class that can take the split-chain path
+(HM_QUAD_CLASS=1 sends all of them there); and the waits between waves are bounded: with the first band's progress
+withheld (fault injection) the launch is flagged, hm_batch_check reports HM_ERR_INTERNAL, nothing hangs."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _run(env_extra, *names, timeout=300):
+    env = dict(os.environ)
+    env.update(env_extra)
+    env["PYTHONPATH"] = os.pathsep.join([ROOT, HERE, env.get("PYTHONPATH", "")])
+    return subprocess.run([sys.executable, os.path.join(HERE, "chain_mode_check.py"), *names], env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("cut", [0, 1, 2, 3])
+def test_every_cut_gives_the_same_pictures(cut):
+    r = _run({"HM_CHAIN_PAIRS": str(cut), "HM_QUAD_CLASS": "1"})
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_r02_kernel_still_selectable():
+    r = _run({"HM_CHAIN": "0"}, "tile512_a", "ctb64")
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("cut", [1, 2, 3])
+def test_bounded_waits_flag_the_launch(cut):
+    r = _run({"HM_CHAIN_PAIRS": str(cut), "HM_CHAIN_TEST_STALL": "1", "HM_CHAIN_SPIN_LIMIT": "2000"}, "tile512_a", timeout=120)
+    assert r.returncode == 3 and "gave up waiting" in r.stdout, r.stdout + r.stderr

@@ -1,5 +1,5 @@
 #!/bin/bash
 mkdir -p gpurun_out
 {
-timeout 900 python3 -m pytest tests/test_pipeline_gpu.py tests/test_transforms.py tests/test_facade_gpu.py tests/test_golden_heic.py -x -q -m gpu 2>&1 | tail -15
+timeout 900 python3 -m pytest tests/test_chain_modes_gpu.py -x -q -m gpu 2>&1 | tail -15
 } > gpurun_out/r03_host.log 2>&1
