@@ -191,14 +191,21 @@ __global__ __launch_bounds__(R_WAVES * 64) void k_residual(const hm_dev_pic* __r
   }
   const int postShift = 20 - bd, rnd2 = 1 << (postShift - 1);
 
+  // records are requested a chunk ahead (unconditionally, the index clamped: a load whose result is merged with
+  // anything is waited for on the spot), the chunk's levels as soon as their place is known and looked at only after
+  // the block map has been written: a wave's time is mostly the latency of these two reads
+  const uint32_t n_tus1 = H->n_tus ? H->n_tus - 1 : 0, n_lev1 = H->n_coeffs ? H->n_coeffs - 1 : 0;
+  auto fetch_records = [&](uint32_t first) -> r_u32x2 {
+    uint32_t i = first + (uint32_t)lane;
+    i = i < n_tus1 ? i : n_tus1;
+    return *reinterpret_cast<const GLOBAL_AS r_u32x2*>(tus + 2 * (size_t)i);
+  };
+  r_u32x2 ahead = fetch_records(rec_begin);
   for (uint32_t chunk = rec_begin; chunk < rec_end; chunk += 64) {
     const uint32_t ri = chunk + (uint32_t)lane;
     const bool valid = ri < rec_end;
-    uint32_t r0 = 0, r1 = 0;
-    if (valid) {
-      const r_u32x2 v = *reinterpret_cast<const GLOBAL_AS r_u32x2*>(tus + 2 * (size_t)ri);
-      r0 = v.x; r1 = v.y;
-    }
+    const uint32_t r0 = valid ? ahead.x : 0u, r1 = valid ? ahead.y : 0u;
+    ahead = fetch_records(chunk + 64);
     const int info = (int)((r0 >> 8) & 0xFF), l2 = info & HM_TU_LOG2_MASK;
     const bool cbf = valid && (info & HM_TU_CBF);
     const uint32_t cnt = (r1 >> 16) & HM_TU8_COUNT_MASK; // (0 in the lanes behind the row's last record)
@@ -209,17 +216,15 @@ __global__ __launch_bounds__(R_WAVES * 64) void k_residual(const hm_dev_pic* __r
     // the chunk's levels lie back to back: one coalesced read puts the first R_STAGE of them into LDS, so that the
     // passes below wait for LDS, not for HBM
     const uint32_t chunk_lev = lev_base, n_lev = (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
-    {
-      const uint32_t n_stage = n_lev < (uint32_t)R_STAGE ? n_lev : (uint32_t)R_STAGE;
+    uint32_t staged[R_STAGE / 64];
 #pragma unroll
-      for (int k = 0; k < R_STAGE / 64; k++) {
-        const uint32_t i = (uint32_t)(lane + 64 * k);
-        if (i < n_stage) lvl[i] = coeffs[chunk_lev + i];
-      }
+    for (int k = 0; k < R_STAGE / 64; k++) {
+      uint32_t i = chunk_lev + (uint32_t)(lane + 64 * k);
+      i = i < n_lev1 ? i : n_lev1;
+      staged[k] = coeffs[i]; // (requested here, written to LDS behind the block map)
     }
     lev_base += n_lev;
     res_base += (uint32_t)__builtin_amdgcn_readlane((int)sr, 63);
-    WAVE_SYNC();
     // level number i of a block whose levels start at index `first`
     auto level = [&](uint32_t first, uint32_t i) -> uint32_t {
       const uint32_t rel = first - chunk_lev + i;
@@ -275,8 +280,60 @@ __global__ __launch_bounds__(R_WAVES * 64) void k_residual(const hm_dev_pic* __r
       }
     }
 
+    // the chunk's first R_STAGE levels into LDS: the passes below wait for LDS, not for HBM
+#pragma unroll
+    for (int k = 0; k < R_STAGE / 64; k++) lvl[lane + 64 * k] = staged[k];
+    WAVE_SYNC();
+
+    // ---- blocks whose only level is the DC coefficient (a third of the blocks with a residual): both transform stages
+    //      collapse - the column stage leaves t(i) = clip16((M[0][i] * c + 64) >> 7) in column 0 and zeros elsewhere, the
+    //      row stage (M[0][x] * t(y) + round) >> shift - which needs neither the coefficient block in LDS nor any exchange
+    //      between lanes.  DCT: M[0][.] = 64, the residual is one constant; 4x4 luma DST: M[0][.] = 29 55 74 84. ----
+    const uint32_t first_level = cbf ? level(lo, 0) : 0xFFFFu; // (position in the low half: 0 = DC)
+    const bool dc_only = cbf && cnt == 1 && (first_level & 0xFFFF) == 0 && !(info & HM_TU_TSKIP);
+    auto dequant = [&](uint32_t raw, int qP, int l2b) -> int { // transform.cc:496-502, wrapping int32
+      const int q6 = (qP * 43) >> 8, qr = qP - 6 * q6; // qP / 6, qP % 6 for qP < 128
+      const int bdShift = bd + l2b - 9;
+      const int32_t fact = (int32_t)tab[70 + qr] << q6;
+      const int32_t prod = (int32_t)((uint32_t)mul24((int)(int16_t)(raw >> 16), fact) + (uint32_t)(1 << (bdShift - 1)));
+      return clip3i(-32768, 32767, prod >> bdShift);
+    };
+    // 4x4, four per pass
+    for (unsigned long long m4 = ballot(dc_only && l2 == 2); m4;) {
+      int b[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        b[k] = m4 ? (int)__builtin_ctzll(m4) : -1;
+        m4 &= m4 - 1; // (0 stays 0)
+      }
+      const int myb = g == 0 ? b[0] : (g == 1 ? b[1] : (g == 2 ? b[2] : b[3]));
+      const bool act = myb >= 0;
+      const int src = act ? myb : 0;
+      const uint32_t br0 = (uint32_t)__shfl((int)r0, src), braw = (uint32_t)__shfl((int)first_level, src);
+      const int c = dequant(braw, (int)(br0 >> 24), 2);
+      const int m0y = kind ? 64 : (int)tab[76 + by_], m0x = kind ? 64 : (int)tab[76 + bx_];
+      const int t1 = clip3i(-32768, 32767, (mul24(m0y, c) + 64) >> 7);
+      int res = (mul24(m0x, t1) + rnd2) >> postShift;
+      if (kind == 0) res = clip3i(-32768, 32767, res); // (the DST's second stage is clipped to 16 bit: Q4)
+      if (act) res4[(size_t)(chunk + (uint32_t)myb) * 16 + (uint32_t)gl] = limit_res(res, maxv);
+    }
+    // 8x8 and larger: one constant per block, written by all lanes
+    for (unsigned long long mdc = ballot(dc_only && l2 >= 3); mdc; mdc &= mdc - 1) {
+      const int b = (int)__builtin_ctzll(mdc);
+      const uint32_t s_r0 = (uint32_t)__builtin_amdgcn_readlane((int)r0, b), s_raw = (uint32_t)__builtin_amdgcn_readlane((int)first_level, b);
+      const uint32_t s_ro = (uint32_t)__builtin_amdgcn_readlane((int)ro, b);
+      const int s_l2 = (int)((s_r0 >> 8) & HM_TU_LOG2_MASK);
+      const int c = dequant(s_raw, (int)(s_r0 >> 24), s_l2);
+      const int t1 = clip3i(-32768, 32767, (64 * c + 64) >> 7);
+      const int16_t k16 = limit_res((64 * t1 + rnd2) >> postShift, maxv);
+      const uint32_t pair = (uint32_t)(uint16_t)k16 * 0x10001u;
+      const int n_words = 1 << (2 * s_l2 - 1); // nT * nT samples, two per 32-bit word (the slab is 32-byte aligned at every block)
+      GLOBAL_AS uint32_t* const out = reinterpret_cast<GLOBAL_AS uint32_t*>(resid + s_ro);
+      for (int w = lane; w < n_words; w += 64) out[w] = pair;
+    }
+
     // ---- 4x4 blocks, four per pass ----
-    for (unsigned long long m4 = ballot(cbf && l2 == 2); m4;) {
+    for (unsigned long long m4 = ballot(cbf && l2 == 2 && !dc_only); m4;) {
       int b[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) {
@@ -329,7 +386,7 @@ __global__ __launch_bounds__(R_WAVES * 64) void k_residual(const hm_dev_pic* __r
     }
 
     // ---- 8x8 blocks, one per pass, one sample per lane ----
-    for (unsigned long long m8 = ballot(cbf && l2 == 3); m8; m8 &= m8 - 1) {
+    for (unsigned long long m8 = ballot(cbf && l2 == 3 && !dc_only); m8; m8 &= m8 - 1) {
       const int b = (int)__builtin_ctzll(m8);
       const uint32_t s_r0 = (uint32_t)__builtin_amdgcn_readlane((int)r0, b), s_cnt = (uint32_t)__builtin_amdgcn_readlane((int)cnt, b);
       const uint32_t s_lo = (uint32_t)__builtin_amdgcn_readlane((int)lo, b), s_ro = (uint32_t)__builtin_amdgcn_readlane((int)ro, b);
@@ -362,7 +419,7 @@ __global__ __launch_bounds__(R_WAVES * 64) void k_residual(const hm_dev_pic* __r
     }
 
     // ---- 16x16 and 32x32 blocks ----
-    for (unsigned long long mb = ballot(cbf && l2 >= 4); mb; mb &= mb - 1) {
+    for (unsigned long long mb = ballot(cbf && l2 >= 4 && !dc_only); mb; mb &= mb - 1) {
       const int b = (int)__builtin_ctzll(mb);
       const uint32_t s_r0 = (uint32_t)__builtin_amdgcn_readlane((int)r0, b), s_cnt = (uint32_t)__builtin_amdgcn_readlane((int)cnt, b);
       const uint32_t s_lo = (uint32_t)__builtin_amdgcn_readlane((int)lo, b), s_ro = (uint32_t)__builtin_amdgcn_readlane((int)ro, b);

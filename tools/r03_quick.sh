@@ -1,0 +1,7 @@
+#!/bin/bash
+mkdir -p gpurun_out
+{
+echo "== pytest decode (all split)"; HM_QUAD_CLASS=1 timeout 900 python3 -m pytest tests/test_decode_gpu.py -x -q -m gpu 2>&1 | tail -3
+echo "== pytest decode (default)"; timeout 900 python3 -m pytest tests/test_decode_gpu.py tests/test_configs_gpu.py -x -q -m gpu 2>&1 | tail -3
+echo "== bench quick"; timeout 600 python3 bench.py --quick --steps 5 2>&1 | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], {k: v['ms_per_step'] for k, v in d['kernels'].items()})"
+} > gpurun_out/r03_quick.log 2>&1
