@@ -110,6 +110,8 @@ size_t resid_bytes(const hm_pic& h)
 }
 // bytes of the residuals of its 4x4 blocks (hm_device.h: hm_dev_pic.res4)
 size_t res4_bytes(const hm_pic& h) { return (h.flags & HM_PIC_SPLIT_CHAINS) ? (size_t)h.n_tus * 32 : 0; }
+// ... and of its micro-ops (hm_dev_pic.mops)
+size_t mops_bytes(const hm_pic& h) { return (h.flags & HM_PIC_SPLIT_CHAINS) ? (size_t)h.n_tus * 16 : 0; }
 // bytes of its hand-over lines (hm_device.h: hm_dev_pic.hand)
 size_t hand_bytes(const hm_pic& h)
 {
@@ -357,7 +359,7 @@ static int batch_prepare(hm_batch* b, size_t* blob_bytes_out)
     const int swc = h.chroma_format == 3 ? 1 : 2;
     const size_t py = align_up((size_t)h.width * bps, 64), pc = align_up((size_t)(h.width / swc) * bps, 64);
     const size_t w4 = (h.width + 3) >> 2, h4 = (h.height + 3) >> 2;
-    work_bytes += align_up(py * h.height, 256) + 2 * align_up(pc * (h.height / sh), 256) + 2 * align_up(w4 * h4, 256) + align_up(resid_bytes(h), 256) + align_up(hand_bytes(h), 256) + align_up(res4_bytes(h), 256);
+    work_bytes += align_up(py * h.height, 256) + 2 * align_up(pc * (h.height / sh), 256) + 2 * align_up(w4 * h4, 256) + align_up(resid_bytes(h), 256) + align_up(hand_bytes(h), 256) + align_up(res4_bytes(h), 256) + align_up(mops_bytes(h), 256);
     b->total_pixels += (size_t)h.width * h.height;
   }
   int rc;
@@ -402,6 +404,8 @@ static int batch_prepare(hm_batch* b, size_t* blob_bytes_out)
       d.hand = hand_bytes(h) ? wp : nullptr;
       wp += align_up(hand_bytes(h), 256);
       d.res4 = res4_bytes(h) ? (int16_t*)wp : nullptr;
+      wp += align_up(res4_bytes(h), 256);
+      d.mops = mops_bytes(h) ? (uint32_t*)wp : nullptr;
       d.w4 = (int)w4; d.h4 = (int)h4;
       d.width = h.width; d.height = h.height;
       d.chroma_format = h.chroma_format;

@@ -16,8 +16,8 @@
 //     4x4 block lie in an array indexed like the records: a group fetches the 16 records it needs next and their
 //     residuals while it works on the 16 before them, so nothing on the chain of the 4x4 blocks ever waits for HBM; the residual
 //     of a larger block is requested from the row's slab when the block comes up (8x8: before the side-by-side phase);
-//   * the per-block control is decoded ONCE, 16 records at a time, by the group's own 16 lanes (lane = record) into
-//     16-byte micro-ops in LDS: LDS offsets of the left column / the row above, clamp limits of the two runs,
+//   * the per-block control is decoded ONCE - by residual.hip, where every lane has a record of its own - into 16-byte
+//     micro-ops, which a group fetches 16 at a time into LDS: LDS offsets of the left column / the row above, clamp limits of the two runs,
 //     mode, flags, the place of the residual (a 16-lane DPP scan of the block sizes), the deblocking word.  A block
 //     then costs one ds_read_b128 and a few unpacks instead of ~25 instructions of field extraction and address
 //     arithmetic per group per block, and the four-deep register pipeline of raw records is gone;
@@ -51,22 +51,11 @@ constexpr int C_SHARED_TABLES = 256;        // small tables (recon.hip layout: a
 constexpr int C_TAB4_BYTES = 35 * 16 * 2;   // per (mode, sample) of a 4x4 block: reference positions + weight
 constexpr int C_SHARED = (C_SHARED_TABLES + C_TAB4_BYTES + 15) & ~15;
 constexpr int C_RING = 16;                  // micro-ops per group: one window of 16 records
-constexpr int C_ITEM_DWORDS = 10;           // what a lane fetches per record: the 8-byte record + the 16 residual samples of a 4x4 block (hm_dev_pic.res4)
+constexpr int C_ITEM_DWORDS = 12;           // what a lane fetches per record: its micro-op (hm_dev_pic.mops) + the 16 residual samples of a 4x4 block (hm_dev_pic.res4)
 constexpr int C_RRES_BYTES = NG * 16 * 32;  // per group: the 4x4 residuals of the window
 constexpr int C_SCRATCH = 272;              // wave-wide path: reference samples (bA)
 constexpr int C_PROG = 8;                   // progress counters per chain kind: rows r and r + 8 share one (at most 4 rows of a wave are in flight)
 constexpr int C_RING_BYTES = NG * C_RING * 16;
-
-// micro-op (uint4): x = lp | tp << 16 (sample offsets: lp from the group's plane base to sample (x0-1, y0); tp to sample
-// (x0, y0-1) from the same base or - OP_LINE - from the CTU's start in the sample line of the row above),
-// y = flags below, z = first residual sample, w = qpy | pos << 8 | availability bits
-constexpr uint32_t OP_MODE_MASK = 63u;
-constexpr int OP_C_SHIFT = 6, OP_L2_SHIFT = 8; // colour component (2 bits), log2 size - 2 (2 bits)
-constexpr uint32_t OP_CBF = 1u << 10, OP_INTERIOR = 1u << 11, OP_LINE = 1u << 13;
-constexpr uint32_t OP_FAST8 = 1u << 12; // 8x8 block, neighbours complete, reference samples not smoothed: the one-pass path of phase D
-constexpr int OP_NL1_SHIFT = 14, OP_NT1_SHIFT = 20; // last usable position of the left / top run (6 bits each)
-constexpr uint32_t OPW_LEFT = 1u << 16, OPW_TOP = 1u << 17, OPW_TL = 1u << 18;
-constexpr int OPW_BL_SHIFT = 19, OPW_TR_SHIFT = 23; // below-left / top-right counts in units of 4 (4 bits each)
 
 struct CLayout {
   int pic_bytes;     // LDS per picture (= per wave): progress counters, sample lines, scratch, rings, CTU buffers
@@ -184,7 +173,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   const uint8_t* blob = dp.blob;
   const GLOBAL_AS hm_pic* H = gptr<hm_pic>(blob);
   const GLOBAL_AS uint32_t* ctbq = gptr<uint32_t>(blob + H->off_ctbs);   // HM_CTB_DWORDS dwords per hm_ctb
-  const GLOBAL_AS uint32_t* tus = gptr<uint32_t>(blob + H->off_tus);     // 2 dwords per hm_tu8 (hm_stream.h)
+  const GLOBAL_AS uint32_t* const mops = gptr<uint32_t>(dp.mops);        // 4 dwords per record: its micro-op (residual.hip)
   const GLOBAL_AS uint32_t* const res4 = gptr<uint32_t>(dp.res4);        // 8 dwords per record: residual of a 4x4 block (residual.hip)
   const GLOBAL_AS int16_t* const resid = gptr<int16_t>(dp.resid);
   const uint32_t n_tus = H->n_tus;
@@ -255,10 +244,8 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   int st = (row < ctb_h && my_slot < RPW && (kind_sel < 0 || kind == kind_sel)) ? ST_START : ST_DONE;
   uint32_t c0 = 0, c1 = 0; // header of the CTU to start next: first record of the chain, count
   uint32_t ri = 0;                 // index of the current block's record
-  uint32_t rfirst = 0;             // first record of the row's chain
   uint32_t wdec = 0;               // the window (16 records: index >> 4) whose micro-ops and 4x4 residuals are in LDS
-  uint32_t rbase = 0;              // first residual sample (blocks of 8x8 and more) of window wdec + 1's first record
-  uint32_t pf[C_ITEM_DWORDS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // expanded record 16 * (wdec + 1) + gl, requested when window wdec was decoded
+  uint32_t pf[C_ITEM_DWORDS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // micro-op + 4x4 residual of record 16 * (wdec + 1) + gl, requested when window wdec was taken
   // PAIRS, first row of a pair: CTUs of the row above (the last row of the pair above, another wave's) whose bottom
   // sample line has been copied from the picture into this wave's line
   int hbm_have = 0, hbm_polls = 0;
@@ -266,10 +253,10 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   auto load_window = [&](uint32_t w) {
     uint32_t idx = (w << 4) + (uint32_t)gl;
     idx = idx < n_tus - 1 ? idx : n_tus - 1; // past the last record of the picture: re-read it (never executed)
-    const c_u32x2 c = *reinterpret_cast<const GLOBAL_AS c_u32x2*>(tus + 2 * (size_t)idx);
+    const c_u32x4 m = *reinterpret_cast<const GLOBAL_AS c_u32x4*>(mops + (size_t)idx * 4);
     const GLOBAL_AS uint32_t* const it = res4 + (size_t)idx * 8;
     const c_u32x4 a = *reinterpret_cast<const GLOBAL_AS c_u32x4*>(it), b = *reinterpret_cast<const GLOBAL_AS c_u32x4*>(it + 4);
-    pf[0] = c.x; pf[1] = c.y; pf[2] = a.x; pf[3] = a.y; pf[4] = a.z; pf[5] = a.w; pf[6] = b.x; pf[7] = b.y; pf[8] = b.z; pf[9] = b.w;
+    pf[0] = m.x; pf[1] = m.y; pf[2] = m.z; pf[3] = m.w; pf[4] = a.x; pf[5] = a.y; pf[6] = a.z; pf[7] = a.w; pf[8] = b.x; pf[9] = b.y; pf[10] = b.z; pf[11] = b.w;
   };
   auto header = [&](int r, int x) { // chain header of CTU (r, x): first record, count, flags
     const GLOBAL_AS uint32_t* q = ctbq + HM_CTB_DWORDS * ((size_t)r * ctb_w + x);
@@ -280,9 +267,8 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     // after this one: it finished row - 1 behind this group's row - 2 - reads it from now on.
     if (gl == 0) __hip_atomic_store(my_progress + (row & (C_PROG - 1)), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     header(row, 0);
-    ri = rfirst = c0;
-    wdec = (ri >> 4) - 1; // (nothing of this row is decoded yet)
-    rbase = RG.slab(kind, row);
+    ri = c0;
+    wdec = (ri >> 4) - 1; // (nothing of this row is in LDS yet)
     load_window(ri >> 4);
   };
   if (st == ST_START) row_start();
@@ -371,49 +357,16 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     }
 
     HM_MARK("R_begin");
-    // ---- R: decode the next 16 records of every group that has entered the last decoded window ----
+    // ---- R: the micro-ops and 4x4 residuals of the next 16 records, for every group that has entered that window ----
     {
       const bool need_dec = st != ST_DONE && (ri >> 4) != wdec; // the chain has entered window wdec + 1: its records are in pf
       if (ballot(need_dec)) {
         if (need_dec) {
-          const uint32_t r0 = pf[0], r1 = pf[1];
-          const uint32_t idx = ((wdec + 1) << 4) + (uint32_t)gl;
-          const int x4 = (int)(r0 & 15), y4 = (int)((r0 >> 4) & 15);
-          const uint32_t info = (r0 >> 8) & 0xFF;
-          const int l2 = (int)(info & HM_TU_LOG2_MASK), c = (int)((info >> HM_TU_CIDX_SHIFT) & 3);
-          const uint32_t mode = (r0 >> 16) & OP_MODE_MASK;
-          const bool cbf = (info & HM_TU_CBF) != 0;
-          const int nT = 1 << l2;
-          const uint32_t aBL4 = (r1 >> 8) & 15, aTR4 = (r1 >> 12) & 15;
-          const bool left = (r1 & ((uint32_t)HM_TU8_LEFT << 16)) != 0, top = (r1 & ((uint32_t)HM_TU8_TOP << 16)) != 0, tl = (info & HM_TU_AVAIL_TL) != 0;
-          const int x0 = x4 << 2;
-          const int lp = mul24(y4 << 2, Pk) + UPAD + x0 - 1 + (c == 2 ? cr_off : 0);
-          const bool on_line = y4 == 0;
-          const int tp = on_line ? x0 + (c == 2 ? Wc + 4 : 0) : lp - Pk + 1;
-          const uint32_t nL1 = (uint32_t)(nT - 1) + (aBL4 << 2), nT1 = (uint32_t)(nT - 1) + (aTR4 << 2);
-          // the residual of blocks of 8x8 and more lies in the row's slab, back to back (4x4: in the expanded record)
-          uint32_t rsz = (cbf && l2 >= 3 && idx >= rfirst) ? 16u << (2 * (l2 - 2)) : 0u;
-          // inclusive scan over the 16 lanes of the group (= one DPP row)
-          uint32_t s = rsz;
-          s += (uint32_t)dpp<DPP_ROW_SHR(1)>((int)s);
-          s += (uint32_t)dpp<DPP_ROW_SHR(2)>((int)s);
-          s += (uint32_t)dpp<DPP_ROW_SHR(4)>((int)s);
-          s += (uint32_t)dpp<DPP_ROW_SHR(8)>((int)s);
-          c_u32x4 op;
-          op.x = (uint32_t)lp | ((uint32_t)tp << 16);
-          const bool interior = left && top && tl;
-          // (8x8 luma reference samples are smoothed for planar and the three diagonals only: intrapred.h:192-214)
-          const bool fast8 = l2 == 3 && interior && !(c == 0 && (mode == 0 || mode == 2 || mode == 18 || mode == 34));
-          op.y = mode | ((uint32_t)c << OP_C_SHIFT) | ((uint32_t)(l2 - 2) << OP_L2_SHIFT) | (cbf ? OP_CBF : 0u) | (interior ? OP_INTERIOR : 0u) |
-                 (fast8 ? OP_FAST8 : 0u) | (on_line ? OP_LINE : 0u) | (nL1 << OP_NL1_SHIFT) | (nT1 << OP_NT1_SHIFT);
-          op.z = rbase + s - rsz;
-          op.w = (r1 & 0xFF) | ((r0 & 0xFF) << 8) | (left ? OPW_LEFT : 0u) | (top ? OPW_TOP : 0u) | (tl ? OPW_TL : 0u) | (aBL4 << OPW_BL_SHIFT) | (aTR4 << OPW_TR_SHIFT);
-          ring[gl] = op;
+          ring[gl] = c_u32x4{pf[0], pf[1], pf[2], pf[3]};
           // the record's 16 residual samples (meaningful for 4x4 blocks with a residual)
           c_u32x4* const rr = reinterpret_cast<c_u32x4*>(rres + gl * 16);
-          rr[0] = c_u32x4{pf[2], pf[3], pf[4], pf[5]};
-          rr[1] = c_u32x4{pf[6], pf[7], pf[8], pf[9]};
-          rbase += (uint32_t)__shfl((int)s, (lane & 48) | 15);
+          rr[0] = c_u32x4{pf[4], pf[5], pf[6], pf[7]};
+          rr[1] = c_u32x4{pf[8], pf[9], pf[10], pf[11]};
           wdec += 1;
         }
         load_window(wdec + 1); // every lane: the window its group decodes next (groups that did not decode ask again for the same)

@@ -17,6 +17,8 @@ struct hm_dev_pic {
                             // - one store from k_recon, one load in k_deblock
   int32_t w4, h4;           // size of the 4x4-block maps
   int16_t* resid;           // pictures with split chains: residual samples, k_residual -> k_chain (recon_common.h: ResidGeom)
+  uint32_t* mops;           // pictures with split chains: micro-ops, k_residual -> k_chain: 4 dwords per record (recon_common.h:
+                            // make_micro_op)
   int16_t* res4;            // pictures with split chains: residual of the 4x4 blocks, k_residual -> k_chain: 16 samples per
                             // record, indexed like the records (entries of other records are never written / looked at)
   uint8_t* hand;            // pictures with split chains: hand-over lines of k_chain's wave-per-row-pair mode - per pair of CTB

@@ -409,6 +409,49 @@ __device__ __forceinline__ ResidGeom resid_geom(int ctb_w, int ctb_h, int log2_c
   return g;
 }
 
+// ---- micro-ops: the per-block control of the prediction chains (chain.hip), decoded from the 8-byte records by the
+//      dependency-free pre-pass (residual.hip: lane = record, all 64 lanes busy) so that the chains only fetch and use them.
+//      uint4: x = lp | tp << 16 (sample offsets: lp from the chain's first CTU buffer to sample (x0-1, y0); tp to sample
+//      (x0, y0-1) from the same base or - OP_LINE - from the CTU's start in the sample line of the row above),
+//      y = the flags below, z = first residual sample of a block of 8x8 and more in the row's slab,
+//      w = qpy | pos << 8 | availability bits ----
+constexpr uint32_t OP_MODE_MASK = 63u;
+constexpr int OP_C_SHIFT = 6, OP_L2_SHIFT = 8; // colour component (2 bits), log2 size - 2 (2 bits)
+constexpr uint32_t OP_CBF = 1u << 10, OP_INTERIOR = 1u << 11, OP_LINE = 1u << 13;
+constexpr uint32_t OP_FAST8 = 1u << 12; // 8x8 block, neighbours complete, reference samples not smoothed: the one-pass path of phase D
+constexpr int OP_NL1_SHIFT = 14, OP_NT1_SHIFT = 20; // last usable position of the left / top run (6 bits each)
+constexpr uint32_t OPW_LEFT = 1u << 16, OPW_TOP = 1u << 17, OPW_TL = 1u << 18;
+constexpr int OPW_BL_SHIFT = 19, OPW_TR_SHIFT = 23; // below-left / top-right counts in units of 4 (4 bits each)
+typedef uint32_t mop_u32x4 __attribute__((ext_vector_type(4)));
+// r0, r1: the hm_tu8 as two dwords; Pk: pitch of the chain's CTU buffers in samples; cr_off: the Cr buffer behind the
+// Cb buffer, Wc: the Cr line behind the Cb line (+ 4), both in samples; roff: see z
+__device__ __forceinline__ mop_u32x4 make_micro_op(uint32_t r0, uint32_t r1, int Pk, int cr_off, int Wc, uint32_t roff)
+{
+  const int x4 = (int)(r0 & 15), y4 = (int)((r0 >> 4) & 15);
+  const uint32_t info = (r0 >> 8) & 0xFF;
+  const int l2 = (int)(info & HM_TU_LOG2_MASK), c = (int)((info >> HM_TU_CIDX_SHIFT) & 3);
+  const uint32_t mode = (r0 >> 16) & OP_MODE_MASK;
+  const bool cbf = (info & HM_TU_CBF) != 0;
+  const int nT = 1 << l2;
+  const uint32_t aBL4 = (r1 >> 8) & 15, aTR4 = (r1 >> 12) & 15;
+  const bool left = (r1 & ((uint32_t)HM_TU8_LEFT << 16)) != 0, top = (r1 & ((uint32_t)HM_TU8_TOP << 16)) != 0, tl = (info & HM_TU_AVAIL_TL) != 0;
+  const int x0 = x4 << 2;
+  const int lp = mul24(y4 << 2, Pk) + UPAD + x0 - 1 + (c == 2 ? cr_off : 0);
+  const bool on_line = y4 == 0;
+  const int tp = on_line ? x0 + (c == 2 ? Wc + 4 : 0) : lp - Pk + 1;
+  const uint32_t nL1 = (uint32_t)(nT - 1) + (aBL4 << 2), nT1 = (uint32_t)(nT - 1) + (aTR4 << 2);
+  const bool interior = left && top && tl;
+  // (8x8 luma reference samples are smoothed for planar and the three diagonals only: intrapred.h:192-214)
+  const bool fast8 = l2 == 3 && interior && !(c == 0 && (mode == 0 || mode == 2 || mode == 18 || mode == 34));
+  mop_u32x4 op;
+  op.x = (uint32_t)lp | ((uint32_t)tp << 16);
+  op.y = mode | ((uint32_t)c << OP_C_SHIFT) | ((uint32_t)(l2 - 2) << OP_L2_SHIFT) | (cbf ? OP_CBF : 0u) | (interior ? OP_INTERIOR : 0u) |
+         (fast8 ? OP_FAST8 : 0u) | (on_line ? OP_LINE : 0u) | (nL1 << OP_NL1_SHIFT) | (nT1 << OP_NT1_SHIFT);
+  op.z = roff;
+  op.w = (r1 & 0xFF) | ((r0 & 0xFF) << 8) | (left ? OPW_LEFT : 0u) | (top ? OPW_TOP : 0u) | (tl ? OPW_TL : 0u) | (aBL4 << OPW_BL_SHIFT) | (aTR4 << OPW_TR_SHIFT);
+  return op;
+}
+
 // ---- dequantisation + inverse transform + add (transform.cc:386-689, fallback-dct.cc) --------------------
 // Invariant: the dense coefficient buffer is all zero on entry and on exit.
 constexpr int TAB_SCALING_PTR = 96; // int16 index into the table region (256 B; 92 entries used): 8-byte aligned slot

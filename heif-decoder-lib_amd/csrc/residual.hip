@@ -8,7 +8,10 @@
 // chain kind) of every picture is one wave of a plain grid launch, the residuals go to HBM as int16 and the chain
 // kernel only predicts and adds.  Output: for blocks of 8x8 and more the row's slab (recon_common.h: ResidGeom); for
 // 4x4 blocks - three quarters of all blocks - an array indexed like the records (hm_dev_pic.res4: 16 samples = 32 bytes
-// per record), which the chain kernel fetches together with the records, a whole window of 16 blocks before it needs them.
+// per record), which the chain kernel fetches a whole window of 16 blocks before it needs them - together with the
+// records' MICRO-OPS (hm_dev_pic.mops, recon_common.h: make_micro_op): the per-block control of the chains (LDS
+// offsets of the neighbours, clamp limits, mode, flags, place of the residual), decoded here where every lane has a
+// record of its own instead of by 16 lanes of a chain wave.
 //   * a wave walks the records of its row 64 at a time (lane = record): two wave scans give every record its first
 //     level and the place of its residual; the luma chains also write the deblocking filter's block map (transform
 //     edges + QpY per 4x4 block, deblock.cc:31-62) - another thing that needs no neighbour;
@@ -162,6 +165,10 @@ __global__ __launch_bounds__(R_WAVES * 64) void k_residual(const hm_dev_pic* __r
   const GLOBAL_AS uint32_t* coeffs = gptr<uint32_t>(blob + H->off_coeffs);
   GLOBAL_AS int16_t* const resid = gptr_w<int16_t>(dp.resid);
   GLOBAL_AS int16_t* const res4 = gptr_w<int16_t>(dp.res4);
+  GLOBAL_AS mop_u32x4* const mops = gptr_w<mop_u32x4>(dp.mops);
+  // geometry of the chain kernel's CTU buffers and sample lines (chain.hip), which the micro-ops address
+  const int m_ctb = 1 << dp.log2_ctb, m_cw = m_ctb >> 1, m_P1 = m_cw + UPAD;
+  const int m_Pk = kind ? m_P1 : m_ctb + UPAD, m_cr_off = m_P1 * (dp.chroma_format == 1 ? m_ctb >> 1 : m_ctb), m_Wc = dp.ctb_w * m_cw;
   const int bd = dp.bit_depth;
   const int maxv = (1 << bd) - 1;
   const ResidGeom RG = resid_geom(dp.ctb_w, dp.ctb_h, dp.log2_ctb, dp.chroma_format);
@@ -225,6 +232,8 @@ __global__ __launch_bounds__(R_WAVES * 64) void k_residual(const hm_dev_pic* __r
     }
     lev_base += n_lev;
     res_base += (uint32_t)__builtin_amdgcn_readlane((int)sr, 63);
+    // the record's micro-op for the chain kernel
+    if (valid) mops[ri] = make_micro_op(r0, r1, m_Pk, m_cr_off, m_Wc, ro);
     // level number i of a block whose levels start at index `first`
     auto level = [&](uint32_t first, uint32_t i) -> uint32_t {
       const uint32_t rel = first - chunk_lev + i;
