@@ -906,7 +906,11 @@ __device__ __forceinline__ void tail_sao(const hm_dev_pic& dp, const PicView& v,
     const uint32_t cflags = cbq[2], s0 = cbq[3 + 2 * c], s1 = cbq[4 + 2 * c];
     const SaoRow<uint8_t>&up = rows[r], &cur = rows[r + 1], &dn = rows[r + 2];
     const bool sao_on = apply_sao && (dp.flags & HM_PIC_SAO_ENABLED) && (cflags & (c == 0 ? HM_CTB_SAO_LUMA : HM_CTB_SAO_CHROMA));
+#if defined(HM_T_PROBE) && (HM_T_PROBE & 2)
+    const int type = 0; (void)sao_on; // probe: no SAO arithmetic
+#else
     const int type = sao_on ? (int)(s0 & 0xFF) : 0;
+#endif
     const uint32_t offs = (s0 >> 24) | (s1 << 8);
     const uint32_t nbm = c == 0 ? (cflags >> 8) & 0xFF : (cflags >> 16) & 0xFF;
     const uint32_t maxv2 = 0x00FF00FFu;
@@ -980,10 +984,12 @@ __global__ __launch_bounds__(256, MINW) void k_tail420(const hm_dev_pic* __restr
             __builtin_memcpy(&win.w[r][1], dp.plane[c] + (size_t)y * dp.pitch[c], 4);
           }
         }
+#if !defined(HM_T_PROBE) || !(HM_T_PROBE & 1)
         if ((stages & 1) && (dp.flags & HM_PIC_DEBLOCK_ANY)) {
           WindowEdges<false> E;
           if (window_edges<uint8_t, false>(dp, v, c, kx, ky, sw, sw, E, TabLds{s_tab})) window_filter<uint8_t, false>(win, c, E, 255);
         }
+#endif
         uint8_t* const t0 = c == 0 ? s_l : (c == 1 ? s_c0 : s_c1);
         const int tp = c == 0 ? TAIL_LP : TAIL_CP;
         uint8_t* q = t0 + (8 * kyl) * tp + 8 * kxl + (TAIL_XO - 4);
@@ -997,52 +1003,106 @@ __global__ __launch_bounds__(256, MINW) void k_tail420(const hm_dev_pic* __restr
   }
   __syncthreads();
 
-  // ---- phase 2: SAO + matrix + store, one lane = 16 x 2 luma samples ----
-  const int gx = tid & 7, rp = tid >> 3;
-  const int lx = x0 + 16 * gx, ly = y0 + 2 * rp;
-  if (lx >= cw || ly >= chh) return;
+  // ---- phase 2: SAO + matrix + store, one wave = one 32 x 32 cell at a time ----
+  // The SAO parameters change per CTB and the arithmetic per (type, class): a wave whose lanes lie in several CTBs runs
+  // every path one of them needs (measured: 128 x 16 samples per wave = four 32 x 32 CTBs, ~2 of the 5 paths per group
+  // on average).  Here the wave's lanes share a 32 x 32 cell - one CTB unless the CTBs are 16 x 16 -: 64 lanes = 4 x 16
+  // groups of 8 x 2 luma samples, and before that 2 x 32 lanes = the cell's 16 x 16 Cb / Cr samples as 2 x 16 groups of
+  // 8 x 1, whose results reach the luma lanes through 512 bytes of LDS.  The matrix runs on sample pairs.
+  __shared__ __attribute__((aligned(16))) uint8_t s_x[4][2][16][16];
+  const int wave = tid >> 6, lane = tid & 63;
   const int l2 = dp.log2_ctb;
-  uint32_t ry[2][2][4], rcb[1][4], rcr[1][4];
-  tail_sao<2>(dp, v, 0, s_l, TAIL_LP, x0 - TAIL_XO, y0 - 4, lx, ly, W, H, l2, l2, stages & 2, ry[0]);
-  tail_sao<2>(dp, v, 0, s_l, TAIL_LP, x0 - TAIL_XO, y0 - 4, lx + 8, ly, W, H, l2, l2, stages & 2, ry[1]);
-  tail_sao<1>(dp, v, 1, s_c0, TAIL_CP, (x0 >> 1) - TAIL_XO, (y0 >> 1) - 4, lx >> 1, ly >> 1, W >> 1, H >> 1, l2 - 1, l2 - 1, stages & 2, rcb);
-  tail_sao<1>(dp, v, 2, s_c1, TAIL_CP, (x0 >> 1) - TAIL_XO, (y0 >> 1) - 4, lx >> 1, ly >> 1, W >> 1, H >> 1, l2 - 1, l2 - 1, stages & 2, rcr);
-
   const TailDst D = dsts[blockIdx.y];
-  uint8_t b0[16 * BPP], b1[16 * BPP];
-#pragma unroll
-  for (int c = 0; c < 8; c++) {
-    const int u = (int)((rcb[0][c >> 1] >> (16 * (c & 1))) & 0xFF) - 128;
-    const int w = (int)((rcr[0][c >> 1] >> (16 * (c & 1))) & 0xFF) - 128;
-    const int rt = (k.r_cr * w + 128) >> 8;               // yuv2rgb.cc:359
-    const int gt = (k.g_cb * u + k.g_cr * w + 128) >> 8;  // :360
-    const int bt = (k.b_cb * u + 128) >> 8;               // :361
-#pragma unroll
-    for (int s2 = 0; s2 < 2; s2++) {
-      const int p = 2 * c + s2, g2 = p >> 3, q = p & 7;
-      const int ya = (int)((ry[g2][0][q >> 1] >> (16 * (q & 1))) & 0xFF), yb = (int)((ry[g2][1][q >> 1] >> (16 * (q & 1))) & 0xFF);
-      b0[BPP * p + 0] = (uint8_t)clip3i(0, 255, ya + rt); b0[BPP * p + 1] = (uint8_t)clip3i(0, 255, ya + gt); b0[BPP * p + 2] = (uint8_t)clip3i(0, 255, ya + bt);
-      b1[BPP * p + 0] = (uint8_t)clip3i(0, 255, yb + rt); b1[BPP * p + 1] = (uint8_t)clip3i(0, 255, yb + gt); b1[BPP * p + 2] = (uint8_t)clip3i(0, 255, yb + bt);
-      if (BPP == 4) { b0[BPP * p + 3] = 0xFF; b1[BPP * p + 3] = 0xFF; }
+  const int Kr = 128 - 128 * k.r_cr, Kg = 128 - 128 * (k.g_cb + k.g_cr), Kb = 128 - 128 * k.b_cb; // (x - 128) * k + 128 = x * k + K
+  for (int it = 0; it < 2; it++) {
+    const int cellx = x0 + 32 * wave, celly = y0 + 32 * it;
+    if (cellx >= cw || celly >= chh) continue; // (the whole wave)
+    {
+      const int pl = lane >> 5, gxc = lane & 1, row = (lane >> 1) & 15;
+      const int xc = (cellx >> 1) + 8 * gxc, yc = (celly >> 1) + row;
+      if (xc < (W >> 1) && yc < (H >> 1)) {
+        uint32_t rc[1][4];
+        tail_sao<1>(dp, v, 1 + pl, s_c0 + pl * (TAIL_CR * TAIL_CP), TAIL_CP, (x0 >> 1) - TAIL_XO, (y0 >> 1) - 4, xc, yc, W >> 1, H >> 1, l2 - 1, l2 - 1, stages & 2, rc);
+        const uint32_t o[2] = {__builtin_amdgcn_perm(rc[0][1], rc[0][0], 0x06040200u), __builtin_amdgcn_perm(rc[0][3], rc[0][2], 0x06040200u)};
+        __builtin_memcpy(&s_x[wave][pl][row][8 * gxc], o, 8);
+      }
     }
-  }
-  uint8_t* o0 = D.rgb + (size_t)ly * D.pitch + (size_t)lx * BPP;
-  const int nvalid = cw - lx < 16 ? cw - lx : 16;
-  if (nvalid == 16) {
-    __builtin_memcpy(o0, b0, 16 * BPP);
-    if (ly + 1 < chh) __builtin_memcpy(o0 + D.pitch, b1, 16 * BPP);
-  }
-  else {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int gx = lane & 3, rp = lane >> 2;
+    const int lx = cellx + 8 * gx, ly = celly + 2 * rp;
+    if (lx < cw && ly < chh) {
+      uint32_t ry[2][4];
+      tail_sao<2>(dp, v, 0, s_l, TAIL_LP, x0 - TAIL_XO, y0 - 4, lx, ly, W, H, l2, l2, stages & 2, ry);
+      uint32_t cb4, cr4;
+      __builtin_memcpy(&cb4, &s_x[wave][0][rp][4 * gx], 4);
+      __builtin_memcpy(&cr4, &s_x[wave][1][rp][4 * gx], 4);
+      constexpr int OW = 2 * BPP; // dwords of 8 pixels
+      uint32_t o[2][OW];
+      auto sat_pk = [](uint32_t x) -> uint32_t { // two signed 16-bit halves -> two bytes clipped to 0..255, upper half 0
+        uint32_t d;
+        asm("v_sat_pk_u8_i16 %0, %1" : "=v"(d) : "v"(x));
+        return d;
+      };
 #pragma unroll
-    for (int p = 0; p < 16; p++) {
-      if (p < nvalid) {
+      for (int h = 0; h < 2; h++) { // two chroma samples = 4 pixels of both rows
+        uint32_t rg[2][2], bb[2][2]; // [row][pair]: R0 R1 G0 G1 / B0 B1 0 0
 #pragma unroll
-        for (int i = 0; i < BPP; i++) {
-          o0[BPP * p + i] = b0[BPP * p + i];
-          if (ly + 1 < chh) o0[D.pitch + BPP * p + i] = b1[BPP * p + i];
+        for (int q = 0; q < 2; q++) {
+          const int c = 2 * h + q;
+          const int u = (int)((cb4 >> (8 * c)) & 0xFF), w = (int)((cr4 >> (8 * c)) & 0xFF);
+#if defined(HM_T_PROBE) && (HM_T_PROBE & 4)
+          const int rt = u, gt = w, bt = u; // probe: no matrix
+#else
+          const int rt = (k.r_cr * w + Kr) >> 8;               // yuv2rgb.cc:359
+          const int gt = (k.g_cb * u + k.g_cr * w + Kg) >> 8;  // :360
+          const int bt = (k.b_cb * u + Kb) >> 8;               // :361
+#endif
+          const uint32_t rt2 = __builtin_amdgcn_perm((uint32_t)rt, (uint32_t)rt, 0x01000100u), gt2 = __builtin_amdgcn_perm((uint32_t)gt, (uint32_t)gt, 0x01000100u),
+                         bt2 = __builtin_amdgcn_perm((uint32_t)bt, (uint32_t)bt, 0x01000100u);
+#pragma unroll
+          for (int r = 0; r < 2; r++) {
+            const s16x2 y2 = as_s(ry[r][c]); // the pixels 2c, 2c + 1 of the row
+            const uint32_t R = sat_pk(as_w(y2 + as_s(rt2))), G = sat_pk(as_w(y2 + as_s(gt2))), B = sat_pk(as_w(y2 + as_s(bt2)));
+            rg[r][q] = R | (G << 16);
+            bb[r][q] = B;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+          if (BPP == 3) {
+            const uint32_t x01 = rg[r][0], x23 = rg[r][1], b4 = bb[r][0] | (bb[r][1] << 16);
+            o[r][3 * h + 0] = __builtin_amdgcn_perm(b4, x01, 0x01040200u);                                          // R0 G0 B0 R1
+            o[r][3 * h + 1] = __builtin_amdgcn_perm(b4, __builtin_amdgcn_perm(x23, x01, 0x06040003u), 0x03020500u); // G1 B1 R2 G2
+            o[r][3 * h + 2] = __builtin_amdgcn_perm(b4, x23, 0x07030106u);                                          // B2 R3 G3 B3
+          }
+          else {
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+              o[r][4 * h + 2 * q + 0] = __builtin_amdgcn_perm(bb[r][q], rg[r][q], 0x0d040200u); // R0 G0 B0 255
+              o[r][4 * h + 2 * q + 1] = __builtin_amdgcn_perm(bb[r][q], rg[r][q], 0x0d050301u); // R1 G1 B1 255
+            }
+          }
+        }
+      }
+      uint8_t* o0 = D.rgb + (size_t)ly * D.pitch + (size_t)lx * BPP;
+      const int nvalid = cw - lx < 8 ? cw - lx : 8;
+      if (nvalid == 8) {
+        __builtin_memcpy(o0, o[0], 8 * BPP);
+        if (ly + 1 < chh) __builtin_memcpy(o0 + D.pitch, o[1], 8 * BPP);
+      }
+      else {
+#pragma unroll
+        for (int i = 0; i < 8 * BPP; i++) {
+          if (i < nvalid * BPP) {
+            o0[i] = (uint8_t)(o[0][i >> 2] >> (8 * (i & 3)));
+            if (ly + 1 < chh) o0[D.pitch + i] = (uint8_t)(o[1][i >> 2] >> (8 * (i & 3)));
+          }
         }
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
