@@ -30,6 +30,12 @@
 
 namespace {
 
+#ifdef HM_MARKS
+#define HM_MARK(name) asm volatile("s_nop 0 ; HMMARK " name)
+#else
+#define HM_MARK(name)
+#endif
+
 __device__ __forceinline__ int clip3i(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int iabs_(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int isign_(int v) { return (v > 0) - (v < 0); }
@@ -388,6 +394,9 @@ __device__ __forceinline__ void filter_luma_pk(Window<uint8_t>& W, const int bet
     const uint32_t flat = as_w(pk_abs(C[0] - C[3]) + pk_abs(C[7] - C[4])), step = as_w(pk_abs(C[3] - C[4]));
     const bool strong = (int)(flat & 0xFFFF) < beta_3 && (int)(flat >> 16) < beta_3 && (int)(step & 0xFFFF) < tc25 && (int)(step >> 16) < tc25 &&
                         (d0 << 1) < beta_2 && (d3 << 1) < beta_2;
+#if defined(HM_T_PROBE) && (HM_T_PROBE & 24)
+    if (((HM_T_PROBE & 8) && strong) || ((HM_T_PROBE & 16) && !strong)) return; // probes: without the strong / the normal filter
+#endif
     if (strong) {
       const s16x2 t2 = (s16x2)((short)(tc << 1)), nt2 = (s16x2)(0) - t2;
       auto pass = [&](uint32_t (&X)[8]) {
@@ -871,10 +880,15 @@ __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict_
 //     the picture's paste position (cropped at the copy region).
 struct TailDst { uint8_t* rgb; int32_t pitch; int32_t pad; };
 struct TailCoef { int r_cr, g_cb, g_cr, b_cb; };
-constexpr int TAIL_TW = 128, TAIL_TH = 64;
+#ifndef HM_TAIL_TH
+#define HM_TAIL_TH 128
+#endif
+constexpr int TAIL_TW = 128, TAIL_TH = HM_TAIL_TH;
+constexpr int TAIL_THREADS = TAIL_TW * TAIL_TH / 32; // one lane per 8 x 2 luma samples of two cells; 4 or 8 waves
+constexpr int TAIL_MINW = TAIL_THREADS == 256 ? 4 : 2;
 constexpr int TAIL_XO = 8;                   // the LDS tiles start 8 samples left of the tile, 4 rows above it
-constexpr int TAIL_LP = 144, TAIL_LR = 72;   // luma tile: pitch, rows
-constexpr int TAIL_CP = 80, TAIL_CR = 40;    // chroma tiles
+constexpr int TAIL_LP = 144, TAIL_LR = TAIL_TH + 8;   // luma tile: pitch, rows
+constexpr int TAIL_CP = 80, TAIL_CR = TAIL_TH / 2 + 8;    // chroma tiles
 
 // a group of 8 samples of LDS tile row `row` (already clamped into the picture) at tile column xo, with its side dwords
 __device__ __forceinline__ void tail_row(SaoRow<uint8_t>& R, const uint8_t* tile, int pitch, int row, int xo)
@@ -937,14 +951,20 @@ __device__ __forceinline__ void tail_sao(const hm_dev_pic& dp, const PicView& v,
 }
 
 template <int BPP, int MINW>
-__global__ __launch_bounds__(256, MINW) void k_tail420(const hm_dev_pic* __restrict__ pics, const TailDst* __restrict__ dsts, int tiles_x, int stages, TailCoef k)
+__global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic* __restrict__ pics, const TailDst* __restrict__ dsts, int tiles_x, int n_tiles, int stages, TailCoef k)
 {
   __shared__ __attribute__((aligned(16))) uint8_t s_all[TAIL_LR * TAIL_LP + 2 * TAIL_CR * TAIL_CP];
   uint8_t* const s_l = s_all;
   uint8_t* const s_c0 = s_all + TAIL_LR * TAIL_LP;
   uint8_t* const s_c1 = s_c0 + TAIL_CR * TAIL_CP;
   const hm_dev_pic& dp = pics[blockIdx.y];
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  // Workgroups go to the 8 XCDs in turn (linear id % 8) and every XCD has an L2 of its own: neighbouring tiles share the
+  // cache lines at their common border (the windows overlap by 4 samples, rows are read in 128-byte lines), so each XCD
+  // gets a contiguous run of the picture's tiles - gridDim.x = 8 * chunk - instead of every eighth tile.
+  const int chunk = gridDim.x >> 3;
+  const int tile = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+  if (tile >= n_tiles) return;
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int x0 = tx * TAIL_TW, y0 = ty * TAIL_TH; // luma origin of the tile (source = destination coordinates: no crop offset)
   const int cw = dp.copy_w[0], chh = dp.copy_h[0];
   if (x0 >= cw || y0 >= chh) return; // (the whole workgroup)
@@ -960,18 +980,23 @@ __global__ __launch_bounds__(256, MINW) void k_tail420(const hm_dev_pic* __restr
   //  there: 10.2 / 19.3 ms without / with the filters instead of 7.6 / 15.8 ms - the eight independent row loads per lane
   //  of this version keep more bytes in flight, and a second barrier costs more than the narrower loads)
   {
+    // windows per tile: (TW / 8 + 1) x (TH / 8 + 1) luma from lane 0 up, 2 x (TW / 16 + 1) x (TH / 16 + 1) chroma at the end
+    // of the workgroup (so that at most one wave runs both the luma and the chroma filters)
+    constexpr int NLX = TAIL_TW / 8 + 1, NLY = TAIL_TH / 8 + 1, NCX = TAIL_TW / 16 + 1, NCY = TAIL_TH / 16 + 1;
+    constexpr int NL = NLX * NLY, NC = NCX * NCY, C0 = TAIL_THREADS - 2 * NC;
+    static_assert(NL <= C0, "one lane per window");
     int c = -1, kxl = 0, kyl = 0;
-    if (tid < 153) { c = 0; kyl = tid / 17; kxl = tid - kyl * 17; }
-    else if (tid < 243) {
-      int t = tid - 153;
-      c = t >= 45 ? 2 : 1;
-      t -= (c - 1) * 45;
-      kyl = t / 9; kxl = t - kyl * 9;
+    if (tid < NL) { c = 0; kyl = tid / NLX; kxl = tid - kyl * NLX; }
+    else if (tid >= C0) {
+      int t = tid - C0;
+      c = t >= NC ? 2 : 1;
+      t -= (c - 1) * NC;
+      kyl = t / NCX; kxl = t - kyl * NCX;
     }
     if (c >= 0) {
       const int sw = c ? 2 : 1;
       const int PW = W / sw, PH = H / sw;
-      const int kx = (c ? 8 * tx : 16 * tx) + kxl, ky = (c ? 4 * ty : 8 * ty) + kyl;
+      const int kx = (c ? TAIL_TW / 16 * tx : TAIL_TW / 8 * tx) + kxl, ky = (c ? TAIL_TH / 16 * ty : TAIL_TH / 8 * ty) + kyl;
       if (kx <= ((PW + 7) >> 3) && ky <= ((PH + 7) >> 3)) {
         Window<uint8_t> win;
         const int ox = (kx << 3) - 4, oy = (ky << 3) - 4;
@@ -987,7 +1012,11 @@ __global__ __launch_bounds__(256, MINW) void k_tail420(const hm_dev_pic* __restr
 #if !defined(HM_T_PROBE) || !(HM_T_PROBE & 1)
         if ((stages & 1) && (dp.flags & HM_PIC_DEBLOCK_ANY)) {
           WindowEdges<false> E;
-          if (window_edges<uint8_t, false>(dp, v, c, kx, ky, sw, sw, E, TabLds{s_tab})) window_filter<uint8_t, false>(win, c, E, 255);
+          HM_MARK("edges_begin");
+          const bool any_edge = window_edges<uint8_t, false>(dp, v, c, kx, ky, sw, sw, E, TabLds{s_tab});
+          HM_MARK("edges_end");
+          if (any_edge) window_filter<uint8_t, false>(win, c, E, 255);
+          HM_MARK("filter_end");
         }
 #endif
         uint8_t* const t0 = c == 0 ? s_l : (c == 1 ? s_c0 : s_c1);
@@ -1009,13 +1038,15 @@ __global__ __launch_bounds__(256, MINW) void k_tail420(const hm_dev_pic* __restr
   // on average).  Here the wave's lanes share a 32 x 32 cell - one CTB unless the CTBs are 16 x 16 -: 64 lanes = 4 x 16
   // groups of 8 x 2 luma samples, and before that 2 x 32 lanes = the cell's 16 x 16 Cb / Cr samples as 2 x 16 groups of
   // 8 x 1, whose results reach the luma lanes through 512 bytes of LDS.  The matrix runs on sample pairs.
-  __shared__ __attribute__((aligned(16))) uint8_t s_x[4][2][16][16];
+  constexpr int NWAVES = TAIL_THREADS / 64;
+  __shared__ __attribute__((aligned(16))) uint8_t s_x[NWAVES][2][16][16];
   const int wave = tid >> 6, lane = tid & 63;
   const int l2 = dp.log2_ctb;
   const TailDst D = dsts[blockIdx.y];
   const int Kr = 128 - 128 * k.r_cr, Kg = 128 - 128 * (k.g_cb + k.g_cr), Kb = 128 - 128 * k.b_cb; // (x - 128) * k + 128 = x * k + K
   for (int it = 0; it < 2; it++) {
-    const int cellx = x0 + 32 * wave, celly = y0 + 32 * it;
+    const int cell = wave + it * NWAVES; // 4 cells per row of the tile
+    const int cellx = x0 + 32 * (cell & 3), celly = y0 + 32 * (cell >> 2);
     if (cellx >= cw || celly >= chh) continue; // (the whole wave)
     {
       const int pl = lane >> 5, gxc = lane & 1, row = (lane >> 1) & 15;
@@ -1156,12 +1187,12 @@ extern "C" int hm_launch_tail420(const hm_dev_pic* d_pics, const void* d_dsts, i
 {
   if (n_pics <= 0) return HM_OK;
   const int tiles_x = (max_w + TAIL_TW - 1) / TAIL_TW, tiles_y = (max_h + TAIL_TH - 1) / TAIL_TH;
-  const dim3 grid(tiles_x * tiles_y, n_pics);
+  const dim3 grid((tiles_x * tiles_y + 7) / 8 * 8, n_pics); // (a multiple of 8: see the tile mapping in the kernel)
   const TailCoef k{coef[0], coef[1], coef[2], coef[3]};
   const TailDst* dd = (const TailDst*)d_dsts;
   // (105 VGPRs: four waves per SIMD; tighter register budgets spill and were measured slower: 15.5 / 17.3 / 21.7 ms
   //  at 96 / 80 / 64 VGPRs against 15.7 ms)
-  if (bpp == 3) hipLaunchKernelGGL((k_tail420<3, 4>), grid, dim3(256), 0, s, d_pics, dd, tiles_x, stages, k);
-  else hipLaunchKernelGGL((k_tail420<4, 4>), grid, dim3(256), 0, s, d_pics, dd, tiles_x, stages, k);
+  if (bpp == 3) hipLaunchKernelGGL((k_tail420<3, TAIL_MINW>), grid, dim3(TAIL_THREADS), 0, s, d_pics, dd, tiles_x, tiles_x * tiles_y, stages, k);
+  else hipLaunchKernelGGL((k_tail420<4, TAIL_MINW>), grid, dim3(TAIL_THREADS), 0, s, d_pics, dd, tiles_x, tiles_x * tiles_y, stages, k);
   return hm_check_hip(hipGetLastError(), "k_tail420 launch");
 }
