@@ -772,32 +772,46 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   static const int env_stall = [] { const char* e = getenv("HM_CHAIN_TEST_STALL"); return e ? atoi(e) : 0; }();
   L.spin_limit = env_spin > 0 ? env_spin : SPIN_LIMIT;
   L.test_stall = env_stall;
-  const size_t sync_need = ((size_t)SYNC_PROGRESS + 2 * (size_t)n_pics * L.bands_per_pic) * sizeof(uint32_t);
-  if (!d_sync || sync_bytes < sync_need) pairs = false;
+  auto sync_words = [&](int bands) { return ((size_t)SYNC_PROGRESS + 2 * (size_t)n_pics * bands) * sizeof(uint32_t); };
+  if (!d_sync || sync_bytes < sync_words(L.bands_per_pic)) pairs = false;
   if (!pairs) { L.rows_per_wave = nr; L.split_kinds = 0; }
   // ---- LDS of a wave ----
-  L.line_l_bytes = al4((4 + max_ctb_w * ctb) * pb); // (every byte counts for the waves a CU holds)
-  L.line_c_bytes = mono ? 0 : al4((8 + 2 * max_ctb_w * (ctb / 2)) * pb);
-  L.luma_bytes = al((ctb + UPAD) * ctb * pb);
-  L.chroma_bytes = mono ? 0 : al(2 * (ctb / 2 + UPAD) * ch * pb);
-  L.line_slots = L.rows_per_wave == 1 ? 1 : nr;
-  L.off_lines_l = 2 * C_PROG * 4;
-  if (L.split_kinds) { // one kind of chain per wave: one place for its line, one for its CTU buffers
-    L.off_lines_c = L.off_lines_l;
-    L.off_scratch = L.off_lines_l + (L.line_l_bytes > L.line_c_bytes ? L.line_l_bytes : L.line_c_bytes);
-    L.row_bytes = L.luma_bytes > L.chroma_bytes ? L.luma_bytes : L.chroma_bytes;
-    L.chroma_off = 0;
+  auto set_layout = [&]() -> bool { // for the cut in L; false if a wave does not fit the CU's LDS
+    L.line_l_bytes = al4((4 + max_ctb_w * ctb) * pb); // (every byte counts for the waves a CU holds)
+    L.line_c_bytes = mono ? 0 : al4((8 + 2 * max_ctb_w * (ctb / 2)) * pb);
+    L.luma_bytes = al((ctb + UPAD) * ctb * pb);
+    L.chroma_bytes = mono ? 0 : al(2 * (ctb / 2 + UPAD) * ch * pb);
+    L.line_slots = L.rows_per_wave == 1 ? 1 : nr;
+    L.off_lines_l = 2 * C_PROG * 4;
+    if (L.split_kinds) { // one kind of chain per wave: one place for its line, one for its CTU buffers
+      L.off_lines_c = L.off_lines_l;
+      L.off_scratch = L.off_lines_l + (L.line_l_bytes > L.line_c_bytes ? L.line_l_bytes : L.line_c_bytes);
+      L.row_bytes = L.luma_bytes > L.chroma_bytes ? L.luma_bytes : L.chroma_bytes;
+      L.chroma_off = 0;
+    }
+    else {
+      L.off_lines_c = L.off_lines_l + L.line_slots * L.line_l_bytes;
+      L.off_scratch = L.off_lines_c + L.line_slots * L.line_c_bytes;
+      L.row_bytes = L.luma_bytes + L.chroma_bytes;
+      L.chroma_off = L.luma_bytes;
+    }
+    L.off_rings = al(L.off_scratch + C_SCRATCH);
+    L.off_rres = L.off_rings + C_RING_BYTES;
+    L.off_groups = L.off_rres + C_RRES_BYTES;
+    L.pic_bytes = al(L.off_groups + (mono && L.rows_per_wave > 1 ? 4 : L.rows_per_wave) * L.row_bytes);
+    return C_SHARED + L.pic_bytes <= 160 * 1024;
+  };
+  bool fits = set_layout();
+  if (!fits && max_ctb_h > 1 && d_sync && sync_bytes >= sync_words(max_ctb_h)) {
+    // a very wide picture (16-bit samples, > ~9000 columns): its sample lines of two rows and both kinds do not fit one
+    // wave's share of LDS - the finer cuts keep one line per wave (a wave per CTU row), or one line of one kind
+    pairs = true;
+    L.rows_per_wave = 1; L.split_kinds = 0; L.bands_per_pic = max_ctb_h;
+    fits = set_layout();
+    if (!fits && !mono) { L.split_kinds = 1; fits = set_layout(); }
   }
-  else {
-    L.off_lines_c = L.off_lines_l + L.line_slots * L.line_l_bytes;
-    L.off_scratch = L.off_lines_c + L.line_slots * L.line_c_bytes;
-    L.row_bytes = L.luma_bytes + L.chroma_bytes;
-    L.chroma_off = L.luma_bytes;
-  }
-  L.off_rings = al(L.off_scratch + C_SCRATCH);
-  L.off_rres = L.off_rings + C_RING_BYTES;
-  L.off_groups = L.off_rres + C_RRES_BYTES;
-  L.pic_bytes = al(L.off_groups + (mono && L.rows_per_wave > 1 ? 4 : L.rows_per_wave) * L.row_bytes);
+  if (!fits) return 0;
+  const size_t sync_need = sync_words(L.bands_per_pic);
   const void* fn = nullptr;
   const int inst = log2_ctb * 2 + (pb - 1) - 8;
   switch (inst * 2 + (pairs ? 1 : 0)) {

@@ -15,7 +15,11 @@ def main():
     pkg = g.load_package()
     names = sys.argv[1:] or ["tile512_a", "ctb64_wpp", "hi422_10", "mono8", "ragged"]
     for name in names:
-        blob = pkg.capi.parse_hevc(corpus.stream(name))
+        if name == "wide16k":  # the widest picture class: CTB 64, 16-bit storage, 4:2:2, 16384 columns, two CTU rows
+            import synthutil
+            blob = pkg.capi.parse_hevc(synthutil.picture(515151, width=16384, height=128, log2_ctb=6, bit_depth=10, chroma_format=2, qp=32, density=30))
+        else:
+            blob = pkg.capi.parse_hevc(corpus.stream(name))
         try:
             got = gpudecode.decode_pictures(pkg, [blob] * 3, 3)
         except RuntimeError as e:

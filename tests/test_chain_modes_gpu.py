@@ -26,6 +26,14 @@ def test_every_cut_gives_the_same_pictures(cut):
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
 
 
+def test_widest_pictures_fall_back_to_a_finer_cut():
+    """16384 columns of 16-bit 4:2:2 samples with 64x64 CTBs: the sample lines of a wave per picture (forced here) do not
+    fit a wave's share of LDS; the launcher then cuts the pictures into a wave per CTU row (or chain) instead of refusing"""
+    r = _run({"HM_CHAIN_PAIRS": "0", "HM_CHAIN_DEBUG": "1"}, "wide16k")
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+    assert "one per CTU row" in r.stderr or "one per chain" in r.stderr, r.stderr
+
+
 def test_r02_kernel_still_selectable():
     r = _run({"HM_CHAIN": "0"}, "tile512_a", "ctb64")
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
