@@ -8,6 +8,9 @@
 // Built twice: into libheif_mi355x_api.so (static registration) and as libheif-mi355x-plugin.so
 // (exports `plugin_info` for LIBHEIF_PLUGIN_PATH loading, plugins_unix.cc:96-111); in the latter the
 // heif_image_* symbols resolve against the libheif that loads it.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -80,27 +83,42 @@ heif_error decode_image(void* dec, struct heif_image** out_img)
   *out_img = nullptr;
   hm_picture* pic = nullptr;
   hm_picture_info I;
+  // HM_PLUGIN_DEBUG=1: the phases of every call on stderr
+  static const bool debug = [] { const char* e = std::getenv("HM_PLUGIN_DEBUG"); return e && e[0] == '1'; }();
+  using clock = std::chrono::steady_clock;
+  const clock::time_point t0 = clock::now();
   int rc = hm_picture_parse(d->data.data(), d->data.size(), &pic, &I);
   if (rc) return from_status(rc);
+  const clock::time_point t1 = clock::now();
   struct Free { hm_picture* p; ~Free() { hm_picture_free(p); } } guard{pic};
+
+  // the picture goes to the device first; the image it ends up in is allocated while the device works
+  hm_picture_job* job = nullptr;
+  rc = hm_picture_decode_begin(pic, nullptr, &job);
+  if (rc) return from_status(rc);
 
   // convert_libde265_image_to_heif_image (decoder_libde265.cc:88-157): monochrome colourspace + one plane for 4:0:0,
   // else YCbCr with the chroma planes at the conformance-window size divided by SubWidthC / SubHeightC
   heif_error err = heif_image_create(I.plane_width[0], I.plane_height[0], I.chroma == 0 ? heif_colorspace_monochrome : heif_colorspace_YCbCr,
                                      (heif_chroma)I.chroma, out_img);
-  if (err.code) return err;
+  if (err.code) { hm_picture_decode_finish(job, nullptr, nullptr); return err; }
   const heif_channel chan[3] = {heif_channel_Y, heif_channel_Cb, heif_channel_Cr};
   uint8_t* plane[3] = {nullptr, nullptr, nullptr};
   int32_t stride[3] = {0, 0, 0};
   for (int c = 0; c < I.n_planes; c++) {
     err = heif_image_add_plane(*out_img, chan[c], I.plane_width[c], I.plane_height[c], I.bit_depth);
-    if (err.code) { heif_image_release(*out_img); *out_img = nullptr; return err; }
+    if (err.code) { hm_picture_decode_finish(job, nullptr, nullptr); heif_image_release(*out_img); *out_img = nullptr; return err; }
     int st = 0;
     plane[c] = heif_image_get_plane(*out_img, chan[c], &st);
     stride[c] = st;
   }
-  rc = hm_picture_decode_to_host(pic, plane, stride, nullptr);
+  const clock::time_point t2 = clock::now();
+  rc = hm_picture_decode_finish(job, plane, stride);
   if (rc) { heif_image_release(*out_img); *out_img = nullptr; return from_status(rc); }
+  if (debug) {
+    const auto ms = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    std::fprintf(stderr, "[plugin decode_image] entropy decode %.3f ms, image %.3f ms, rest of the device work + copies %.3f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, clock::now()));
+  }
   const int primaries = I.primaries, transfer = I.transfer, matrix = I.matrix, full_range = I.full_range;
 
   // VUI colour description -> nclx, always attached (defaults 2,2,2,limited when the VUI has none)

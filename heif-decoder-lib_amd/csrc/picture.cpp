@@ -7,6 +7,7 @@
 // registry makes 48 of these calls from concurrent threads, and a hipMalloc per plane would serialise them.
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -92,11 +93,17 @@ class DeviceWorker {
     if (!workers[d]) workers[d] = new DeviceWorker(d); // leaked on purpose: no HIP calls at exit
     return *workers[d];
   }
-  int run(Request& r)
+  int submit(Request& r) // queues the picture; wait() returns when its planes are in its pinned block
+  {
+    if (executors_ == 0) return hm_fail(HM_ERR_NOMEM, "the device worker could not start a thread");
+    std::lock_guard<std::mutex> l(m_);
+    queue_.push_back(&r);
+    work_.notify_all(); // (the executor that is collecting, or an idle one)
+    return HM_OK;
+  }
+  int wait(Request& r)
   {
     std::unique_lock<std::mutex> l(m_);
-    queue_.push_back(&r);
-    work_.notify_one();
     done_.wait(l, [&] { return r.status <= 0; });
     if (r.status) hm_fail(r.status, "%s", r.message.c_str());
     return r.status;
@@ -106,8 +113,18 @@ class DeviceWorker {
   explicit DeviceWorker(int device) : device_(device)
   {
     const char* e = std::getenv("HM_PLUGIN_LINGER_US");
-    linger_us_ = e ? std::atoi(e) : 150;
-    std::thread([this] { loop(); }).detach();
+    linger_us_ = e ? std::atoi(e) : 30; // (measured: 30 us beats 150 and 0 - the callers are staggered by their entropy decode)
+    // A small batch is as long as its longest dependency chain (~1.4 ms for 512 x 512 tiles) whatever its size, and the
+    // callers of a grid arrive staggered (each decodes its tile's entropy layer first): with ONE executor a call that
+    // arrives just behind a batch waits for that batch and then for its own.  Several executors, each with a stream of
+    // its own, take what has arrived while the others' batches are on the device; one of them collects at a time.
+    const char* w = std::getenv("HM_PLUGIN_WORKERS");
+    int n = w ? std::atoi(w) : 3;
+    n = n < 1 ? 1 : (n > 8 ? 8 : n);
+    for (int i = 0; i < n; i++) {
+      try { std::thread([this] { loop(); }).detach(); executors_++; }
+      catch (...) { break; } // (no more threads to be had: the ones that started serve; none: run() reports it)
+    }
   }
   void loop()
   {
@@ -118,7 +135,8 @@ class DeviceWorker {
       std::vector<Request*> reqs;
       {
         std::unique_lock<std::mutex> l(m_);
-        work_.wait(l, [&] { return !queue_.empty(); });
+        work_.wait(l, [&] { return !queue_.empty() && !collecting_; });
+        collecting_ = true;
         // the callers of one grid arrive within microseconds of each other: keep collecting while they keep coming
         // (at most 64 pictures, at most ~1 ms)
         for (int rounds = 0; rounds < 8; rounds++) {
@@ -126,6 +144,8 @@ class DeviceWorker {
           if (reqs.size() >= 64 || linger_us_ <= 0) break;
           if (!work_.wait_for(l, std::chrono::microseconds(linger_us_), [&] { return !queue_.empty(); })) break;
         }
+        collecting_ = false;
+        if (!queue_.empty()) work_.notify_all(); // (more than one batch's worth: the next executor takes over)
       }
       int rc = se == hipSuccess ? HM_OK : hm_check_hip(se, "hipStreamCreate");
       std::string msg = rc ? hm_last_error() : "";
@@ -140,6 +160,12 @@ class DeviceWorker {
   // one batch for all pictures: upload, kernels, D2H of every picture into its pinned block; returns when it is all there
   int run_batch(const std::vector<Request*>& reqs, hipStream_t s, std::string& msg)
   {
+    // HM_PLUGIN_DEBUG=1: the phases of every batch on stderr (pictures; ms for queueing the pictures, the upload, the
+    // kernels + copies back)
+    static const bool debug = [] { const char* e = std::getenv("HM_PLUGIN_DEBUG"); return e && e[0] == '1'; }();
+    using clock = std::chrono::steady_clock;
+    const clock::time_point t0 = clock::now();
+    clock::time_point t1 = t0, t2 = t0;
     hm_batch* b = nullptr;
     int rc = hm_batch_create(&b);
     for (Request* r : reqs) {
@@ -152,7 +178,9 @@ class DeviceWorker {
       const int idx = hm_batch_add_trusted(b, r->pic->blob, r->pic->blob_size, &dest);
       if (idx < 0) rc = idx;
     }
+    if (debug) t1 = clock::now();
     if (!rc) rc = hm_batch_upload(b, s);
+    if (debug) { hipStreamSynchronize(s); t2 = clock::now(); }
     if (!rc) rc = hm_batch_execute(b, 3, s);
     if (!rc) {
       hipError_t e = hipSuccess;
@@ -162,53 +190,98 @@ class DeviceWorker {
       rc = hm_check_hip(e, "D2H of the decoded planes");
       if (!rc) rc = hm_batch_check(b);
     }
+    if (debug) {
+      const auto ms = [](clock::time_point a, clock::time_point b2) { return std::chrono::duration<double, std::milli>(b2 - a).count(); };
+      std::fprintf(stderr, "[plugin worker] %zu pictures: add %.3f ms, upload %.3f ms, kernels + D2H %.3f ms\n", reqs.size(), ms(t0, t1), ms(t1, t2), ms(t2, clock::now()));
+    }
     if (rc) msg = hm_last_error();
     if (b) hm_batch_destroy(b); // drains the stream before the callers release their blocks
     return rc;
   }
   int device_;
-  int linger_us_ = 150;
+  int linger_us_ = 30;
   std::mutex m_;
   std::condition_variable work_, done_;
   std::deque<Request*> queue_;
+  bool collecting_ = false; // an executor is gathering the next batch
+  int executors_ = 0;
 };
 
 } // namespace
 
+// a picture on its way through the device: the request, its device and pinned blocks
+struct hm_picture_job {
+  hm_picture* pic = nullptr;
+  Request r;
+  void* stream = nullptr;
+  void* worker = nullptr; // the DeviceWorker the request is queued with
+  bool queued = false;
+  ~hm_picture_job()
+  {
+    hm_pool_device_free(r.dev);
+    hm_pool_pinned_free(r.pin);
+  }
+};
+
 extern "C" {
 
-// stream == nullptr: through the device's shared worker (concurrent callers end up in one batch); a stream of the
-// caller's: a batch of its own on that stream, as before
-int hm_picture_decode_to_host(hm_picture* p, uint8_t* const plane[3], const int32_t stride[3], void* stream)
+// hm_picture_decode_to_host in two halves, so that the caller can do something else - allocate the image the planes go
+// into, as the plugin's decode_image does - while the device works.  begin: queues the picture with the device's shared
+// worker (stream == nullptr: concurrent callers end up in one batch) or only notes the caller's stream (the work is then
+// done inside finish, on a batch of its own, as before).  finish: waits, copies the planes out, frees the job - also
+// when it fails.  A job that was begun must be finished.
+int hm_picture_decode_begin(hm_picture* p, void* stream, hm_picture_job** out)
 {
-  if (!p || !plane || !stride) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
+  if (!p || !out) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
+  *out = nullptr;
   const hm_picture_info& I = p->info;
   const int bps = I.bit_depth > 8 ? 2 : 1;
-  for (int c = 0; c < I.n_planes; c++)
-    if (!plane[c] || stride[c] < I.plane_width[c] * bps) return hm_fail(HM_ERR_INVALID_ARG, "plane %d: null or stride too small", c);
-
-  // one device block and one pinned block for all planes (pitch 64-byte aligned)
-  Request r;
+  hm_picture_job* j = new (std::nothrow) hm_picture_job();
+  if (!j) return hm_fail(HM_ERR_NOMEM, "out of memory");
+  Request& r = j->r;
+  j->pic = p; j->stream = stream;
   r.pic = p;
+  // one device block and one pinned block for all planes (pitch 64-byte aligned)
   for (int c = 0; c < I.n_planes; c++) {
     r.pitch[c] = ((size_t)I.plane_width[c] * bps + 63) / 64 * 64;
     r.off[c] = r.total;
     r.total += (r.pitch[c] * I.plane_height[c] + 255) & ~(size_t)255;
   }
-  struct Dev { void* p = nullptr; ~Dev() { hm_pool_device_free(p); } } dev;
-  struct Pin { void* p = nullptr; ~Pin() { hm_pool_pinned_free(p); } } pin;
-  dev.p = hm_pool_device_alloc(r.total);
-  pin.p = hm_pool_pinned_alloc(r.total);
-  if (!dev.p || !pin.p) return hm_fail(HM_ERR_NOMEM, "device / pinned staging for %zu bytes", r.total);
-  r.dev = dev.p; r.pin = pin.p;
+  r.dev = hm_pool_device_alloc(r.total);
+  r.pin = hm_pool_pinned_alloc(r.total);
+  if (!r.dev || !r.pin) { const size_t total = r.total; delete j; return hm_fail(HM_ERR_NOMEM, "device / pinned staging for %zu bytes", total); }
+  if (!stream) {
+    DeviceWorker& w = DeviceWorker::of_current_device();
+    const int rc = w.submit(r);
+    if (rc) { delete j; return rc; }
+    j->worker = &w;
+    j->queued = true;
+  }
+  *out = j;
+  return HM_OK;
+}
 
-  int rc;
-  if (!stream) rc = DeviceWorker::of_current_device().run(r);
-  else {
-    hipStream_t s = (hipStream_t)stream;
+int hm_picture_decode_finish(hm_picture_job* j, uint8_t* const plane[3], const int32_t stride[3])
+{
+  if (!j) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
+  struct Free { hm_picture_job* j; ~Free() { delete j; } } guard{j}; // (after the worker is done with the request: wait() below)
+  Request& r = j->r;
+  hm_picture* p = j->pic;
+  const hm_picture_info& I = p->info;
+  const int bps = I.bit_depth > 8 ? 2 : 1;
+  int rc = HM_OK;
+  if (j->queued) rc = static_cast<DeviceWorker*>(j->worker)->wait(r);
+  if (!rc && plane && stride) {
+    for (int c = 0; c < I.n_planes; c++)
+      if (!plane[c] || stride[c] < I.plane_width[c] * bps) rc = hm_fail(HM_ERR_INVALID_ARG, "plane %d: null or stride too small", c);
+  }
+  else if (!rc) rc = hm_fail(HM_ERR_INVALID_ARG, "null argument");
+  if (rc) return rc;
+  if (!j->queued) {
+    hipStream_t s = (hipStream_t)j->stream;
     hm_tile_dest dest;
     std::memset(&dest, 0, sizeof(dest));
-    for (int c = 0; c < I.n_planes; c++) { dest.plane[c] = (uint8_t*)dev.p + r.off[c]; dest.pitch[c] = (int32_t)r.pitch[c]; }
+    for (int c = 0; c < I.n_planes; c++) { dest.plane[c] = (uint8_t*)r.dev + r.off[c]; dest.pitch[c] = (int32_t)r.pitch[c]; }
     dest.canvas_width = I.plane_width[0]; dest.canvas_height = I.plane_height[0];
     hm_batch* b = nullptr;
     rc = hm_batch_create(&b);
@@ -217,20 +290,35 @@ int hm_picture_decode_to_host(hm_picture* p, uint8_t* const plane[3], const int3
     if (rc >= 0) rc = hm_batch_upload(b, s);
     if (!rc) rc = hm_batch_execute(b, 3, s);
     if (!rc) {
-      hipError_t e = hipMemcpyAsync(pin.p, dev.p, r.total, hipMemcpyDeviceToHost, s);
+      hipError_t e = hipMemcpyAsync(r.pin, r.dev, r.total, hipMemcpyDeviceToHost, s);
       if (e == hipSuccess) e = hipStreamSynchronize(s);
       rc = hm_check_hip(e, "D2H of the decoded planes");
       if (!rc) rc = hm_batch_check(b);
     }
-    hm_batch_destroy(b); // drains the stream before the pool blocks above are released
+    hm_batch_destroy(b); // drains the stream before the pool blocks are released
+    if (rc) return rc;
   }
-  if (rc) return rc;
   for (int c = 0; c < I.n_planes; c++) { // (on the caller's thread: the copies of concurrent callers run side by side)
-    const uint8_t* src = (const uint8_t*)pin.p + r.off[c];
+    const uint8_t* src = (const uint8_t*)r.pin + r.off[c];
     const size_t row = (size_t)I.plane_width[c] * bps; // decoder_libde265.cc:150-152: w * bytes_per_pixel per row
     for (int y = 0; y < I.plane_height[c]; y++) std::memcpy(plane[c] + (size_t)y * stride[c], src + (size_t)y * r.pitch[c], row);
   }
   return HM_OK;
+}
+
+// stream == nullptr: through the device's shared worker (concurrent callers end up in one batch); a stream of the
+// caller's: a batch of its own on that stream
+int hm_picture_decode_to_host(hm_picture* p, uint8_t* const plane[3], const int32_t stride[3], void* stream)
+{
+  if (!p || !plane || !stride) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
+  const hm_picture_info& I = p->info;
+  const int bps = I.bit_depth > 8 ? 2 : 1;
+  for (int c = 0; c < I.n_planes; c++)
+    if (!plane[c] || stride[c] < I.plane_width[c] * bps) return hm_fail(HM_ERR_INVALID_ARG, "plane %d: null or stride too small", c);
+  hm_picture_job* j = nullptr;
+  const int rc = hm_picture_decode_begin(p, stream, &j);
+  if (rc) return rc;
+  return hm_picture_decode_finish(j, plane, stride);
 }
 
 } // extern "C"

@@ -240,6 +240,13 @@ HM_API int  hm_picture_parse(const uint8_t* data, size_t size, hm_picture** out,
 /* reconstruction + in-loop filters on the GPU, then rows of plane_width * bytes_per_sample bytes into plane[c]
  * (host memory, e.g. heif_image_get_plane()); returns after the copy has completed */
 HM_API int  hm_picture_decode_to_host(hm_picture* p, uint8_t* const plane[3], const int32_t stride[3], void* stream);
+/* the same in two halves: begin hands the picture to the device (stream == NULL: to the device's shared worker, where
+ * concurrent callers - the tile threads of context.cc:2361-2401 - meet in one batch) and returns; finish waits, copies
+ * the planes out and frees the job, also when it fails.  The plugin's decode_image allocates its heif_image in between.
+ * A job that was begun must be finished (plane == NULL: abandon it), before hm_picture_free. */
+typedef struct hm_picture_job hm_picture_job;
+HM_API int  hm_picture_decode_begin(hm_picture* p, void* stream, hm_picture_job** out);
+HM_API int  hm_picture_decode_finish(hm_picture_job* job, uint8_t* const plane[3], const int32_t stride[3]);
 HM_API void hm_picture_free(hm_picture* p);
 
 /* ------------------------------------------------------------------------- */

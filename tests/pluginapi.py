@@ -51,3 +51,24 @@ def decode_tile(plugin, data, nthreads=0):
         return img
     finally:
         plugin.free_decoder(dec)
+
+
+_driver = None
+
+
+def drive_grid(plugin_ptr, tiles, max_threads):
+    """the tiles of one grid through the plugin from C++ threads, the reference's way (tests/synth/plugin_driver.cpp:
+    context.cc:2361-2401's window of max_threads async tasks); returns the heif_image* of every tile (caller releases)"""
+    global _driver
+    if _driver is None:
+        _driver = C.CDLL(os.path.join(ROOT, "tests", "synth", "libhm_plugin_driver.so"))
+        _driver.hm_test_drive_grid.restype = C.c_int
+        _driver.hm_test_drive_grid.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    n = len(tiles)
+    data = (C.c_char_p * n)(*tiles)
+    size = (C.c_size_t * n)(*[len(t) for t in tiles])
+    out = (C.c_void_p * n)()
+    rc = _driver.hm_test_drive_grid(C.cast(plugin_ptr, C.c_void_p), data, size, n, max_threads, out)
+    if rc:
+        raise RuntimeError(f"plugin driver: heif_error code {rc}")
+    return [C.c_void_p(v) for v in out]
