@@ -259,7 +259,8 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     pf[0] = m.x; pf[1] = m.y; pf[2] = m.z; pf[3] = m.w; pf[4] = a.x; pf[5] = a.y; pf[6] = a.z; pf[7] = a.w; pf[8] = b.x; pf[9] = b.y; pf[10] = b.z; pf[11] = b.w;
   };
   auto header = [&](int r, int x) { // chain header of CTU (r, x): first record, count, flags
-    const GLOBAL_AS uint32_t* q = ctbq + HM_CTB_DWORDS * ((size_t)r * ctb_w + x);
+    // (32-bit index arithmetic: at most 2^20 CTBs of 13 dwords; 64-bit multiplies run at a quarter of the rate)
+    const GLOBAL_AS uint32_t* q = ctbq + (uint32_t)mul24(mul24(r, ctb_w) + x, HM_CTB_DWORDS);
     c0 = q[kind ? 9 : 0]; c1 = q[kind ? 10 : 1]; // (masked where they are used: no wait for the loads here)
   };
   auto row_start = [&]() { // header of CTU (row, 0) and the first window of the row's chain
@@ -420,10 +421,10 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       };
       const int r0 = ref(j0), r1 = ref(j1);
       const int maxv = (1 << bd) - 1;
-      int v = (mul24(32 - f, r0) + mul24(f, r1) + 16) >> 5; // every angular mode; f = 0: a copy of r0
+      int v = blend32(f, r0, r1); // every angular mode; f = 0: a copy of r0
       if (mode == 0) { // planar: r0 = sample above, r1 = sample to the left
         const int tr = tp[imin_(4, nT1)], bl = lp[mul24(imin_(4, nL1), P)];
-        v = (mul24(3 - bx, r1) + mul24(bx + 1, tr) + mul24(3 - by, r0) + mul24(by + 1, bl) + 4) >> 3;
+        v = planar_sample<2>(bx, by, r1, r0, tr, bl);
       }
       else if (mode == 1) { // DC of the four samples above and the four to the left; luma: smoothed first row / column
         int s = (by == 0 ? r0 : 0) + (bx == 0 ? r1 : 0);
@@ -579,7 +580,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
           r0 = vert ? at(j0, j0 >= 0) : at(j0, j0 > 0);
           r1 = vert ? at(j1, j1 >= 0) : at(j1, j1 > 0);
         }
-        int v = (mul24(32 - f, r0) + mul24(f, r1) + 16) >> 5;
+        int v = blend32(f, r0, r1);
         if (cbf) {
           uint32_t b = bg == 0 ? bres0 : (bg == 1 ? bres1 : (bg == 2 ? bres2 : bres3));
           asm volatile("" : "+v"(b)); // keeps the select - and the wait for the load - inside this branch

@@ -28,6 +28,25 @@ __device__ __forceinline__ int imin_(int a, int b) { return a < b ? a : b; }
 // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): every product here is position x pitch, weight x
 // sample or basis x coefficient, far below 2^23 per operand
 __device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
+// the instruction itself, for operands the compiler cannot bound (it then picks the full 32-bit multiply, a quarter of the rate)
+__device__ __forceinline__ int mul24_raw(int a, int b)
+{
+  int d;
+  asm("v_mul_i32_i24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+// ((32 - f) * r0 + f * r1 + 16) >> 5 of the angular modes (intrapred.h:429) as r0 * 32 + f * (r1 - r0): the same integer,
+// four instructions instead of eight (the compiler expands a 24-bit product of 32 - f into shifts)
+__device__ __forceinline__ int blend32(int f, int r0, int r1) { return (mul24(f, r1 - r0) + (r0 << 5) + 16) >> 5; }
+// planar sample (intrapred.h:262-281): ((nT-1-x) * l + (x+1) * tr + (nT-1-y) * t + (y+1) * bl + nT) >> (log2+1), regrouped
+// around x and y (the same integer): l, t = the left / top neighbour of the sample's row / column, tr / bl = the block's
+// top-right / bottom-left neighbours
+template <int L2>
+__device__ __forceinline__ int planar_sample(int x, int y, int l, int t, int tr, int bl)
+{
+  constexpr int nT = 1 << L2;
+  return (mul24(nT - 1, l + t) + tr + bl + nT + mul24(x, tr - l) + mul24(y, bl - t)) >> (L2 + 1);
+}
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // lane mask of a condition, straight from the compare (HIP's __ballot(int) converts the condition to an integer and
 // compares it again: two vector instructions per use)
@@ -161,14 +180,14 @@ struct RefDirect {
   int P, nL1, nT1;
   __device__ __forceinline__ int operator()(int j) const
   {
-    const int ol = mul24(imin_(-j - 1, nL1), P), ot = imin_(j - 1, nT1);
+    const int ol = mul24_raw(imin_(-j - 1, nL1), P), ot = imin_(j - 1, nT1);
     const Pix* const ql = lp + ol;
     const Pix* const qt = tp + ot;
     return *(j < 0 ? ql : qt);
   }
   // one-sided accessors for the modes that only look up (or only left): no side select
   __device__ __forceinline__ int top(int k) const { return tp[imin_(k - 1, nT1)]; }
-  __device__ __forceinline__ int left(int k) const { return lp[mul24(imin_(k - 1, nL1), P)]; }
+  __device__ __forceinline__ int left(int k) const { return lp[mul24_raw(imin_(k - 1, nL1), P)]; }
 };
 template <typename Pix, int L2>
 __device__ __forceinline__ RefDirect<Pix> direct_refs(const Blk<Pix>& b)
@@ -314,7 +333,7 @@ __device__ __forceinline__ void predict_emit(const Blk<Pix>& B, const Ref& b, co
   if (mode == 0) {
     lanes_loop<npx>(lane, [&](int p) {
       const int x = p & (nT - 1), y = p >> log2;
-      emit(p, x, y, (mul24(nT - 1 - x, b(-1 - y)) + mul24(x + 1, b(1 + nT)) + mul24(nT - 1 - y, b(1 + x)) + mul24(y + 1, b(-1 - nT)) + nT) >> (log2 + 1));
+      emit(p, x, y, planar_sample<L2>(x, y, b(-1 - y), b(1 + x), b(1 + nT), b(-1 - nT)));
     });
   }
   else if (mode == 1) {
@@ -360,12 +379,12 @@ __device__ __forceinline__ void predict_emit(const Blk<Pix>& B, const Ref& b, co
         const int t = mul24(major + 1, angle);
         const int k0 = minor + (t >> 5) + 1, iFact = t & 31;
         const int r0 = vert ? b.top(k0) : b.left(k0), r1 = vert ? b.top(k0 + 1) : b.left(k0 + 1); // weight 0 when iFact == 0
-        emit(p, x, y, (mul24(32 - iFact, r0) + mul24(iFact, r1) + 16) >> 5);
+        emit(p, x, y, blend32(iFact, r0, r1));
       });
     }
     else {
     const int inv = tab[35 + mode]; // 0 outside modes 11..25
-    const int sgn = vert ? 1 : -1; // ref[k] = border[sgn * k] for k >= 0, border[-sgn * proj(k)] for k < 0
+    // ref[k] = border[sgn * k] for k >= 0, border[-sgn * proj(k)] for k < 0, sgn = vert ? 1 : -1
     lanes_loop<npx>(lane, [&](int p) {
       const int x = p & (nT - 1), y = p >> log2;
       const int major = vert ? y : x, minor = vert ? x : y;
@@ -373,10 +392,11 @@ __device__ __forceinline__ void predict_emit(const Blk<Pix>& B, const Ref& b, co
       const int iIdx = t >> 5, iFact = t & 31;
       const int k0 = minor + iIdx + 1, k1 = k0 + 1;
       const int q0 = -((mul24(k0, inv) + 128) >> 8), q1 = -((mul24(k1, inv) + 128) >> 8);
-      const int j0 = sgn * (k0 >= 0 ? k0 : q0), j1 = sgn * (k1 >= 0 ? k1 : q1);
+      const int a0 = k0 >= 0 ? k0 : q0, a1 = k1 >= 0 ? k1 : q1;
+      const int j0 = vert ? a0 : -a0, j1 = vert ? a1 : -a1;
       // b(j1) is read even when iFact == 0 (then it has weight 0; the index stays inside bA: |j1| <= 2nT + 1)
       const int r0 = b(j0), r1 = b(j1);
-      emit(p, x, y, (mul24(32 - iFact, r0) + mul24(iFact, r1) + 16) >> 5);
+      emit(p, x, y, blend32(iFact, r0, r1));
     });
     }
   }
