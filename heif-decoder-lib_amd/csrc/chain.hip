@@ -55,6 +55,7 @@ constexpr int C_ITEM_DWORDS = 12;           // what a lane fetches per record: i
 constexpr int C_RRES_BYTES = NG * 16 * 32;  // per group: the 4x4 residuals of the window
 constexpr int C_SCRATCH = 272;              // wave-wide path: reference samples (bA)
 constexpr int C_PROG = 8;                   // progress counters per chain kind: rows r and r + 8 share one (at most 4 rows of a wave are in flight)
+constexpr int C_FDESC_BYTES = 48; // behind a wave's progress counters: what the CTU flush needs of the picture's descriptor (planes, pitches, size)
 constexpr int C_RING_BYTES = NG * C_RING * 16;
 
 struct CLayout {
@@ -170,6 +171,18 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   if (pic_index >= n_pics) return;
 
   const hm_dev_pic dp = pics[pic_index];
+  // what the CTU flush needs of the descriptor, once per CTU: in LDS (a broadcast read) rather than in ~16 scalar registers
+  // for the whole loop (scalar registers spilled to vector lanes cost VALU instructions) or re-read from memory per CTU
+  uint32_t* const fdesc = reinterpret_cast<uint32_t*>(pbase + 2 * C_PROG * 4);
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const uint64_t a = (uint64_t)(uintptr_t)dp.plane[c];
+      fdesc[2 * c] = (uint32_t)a; fdesc[2 * c + 1] = (uint32_t)(a >> 32);
+      fdesc[6 + c] = (uint32_t)dp.pitch[c];
+    }
+    fdesc[9] = (uint32_t)dp.width; fdesc[10] = (uint32_t)dp.height;
+  }
   const uint8_t* blob = dp.blob;
   const GLOBAL_AS hm_pic* H = gptr<hm_pic>(blob);
   const GLOBAL_AS uint32_t* ctbq = gptr<uint32_t>(blob + H->off_ctbs);   // HM_CTB_DWORDS dwords per hm_ctb
@@ -555,7 +568,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         asm volatile("" : "+v"(ln));
         const int x = ln & 7, y = ln >> 3;
         const int nL1 = (int)((oy >> OP_NL1_SHIFT) & 63), nT1 = (int)((oy >> OP_NT1_SHIFT) & 63);
-        const int angle = c_intra_angle[mode];
+        const int angle = intra_angle_of(mode); // (scalar arithmetic: no table in memory on this path)
         const bool vert = mode >= 18;
         const int major = vert ? y : x, minor = vert ? x : y;
         const int t = mul24(major + 1, angle);
@@ -566,7 +579,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
           else { r0 = lp[mul24(imin_(k, nL1), P)]; r1 = lp[mul24(imin_(k + 1, nL1), P)]; }
         }
         else { // positions <= 0 are projected onto the other side with the inverse angle
-          const int inv = c_inv_angle[mode - 11];
+          const int inv = inv_angle_of(mode);
           const int k0 = k + 1, k1 = k + 2;
           const int q0 = -((mul24(k0, inv) + 128) >> 8), q1 = -((mul24(k1, inv) + 128) >> 8); // (<= 0: positions along the side run)
           // border index j: > 0 main run position j, 0 corner, < 0 side run position -j; tp[-1] is the corner
@@ -669,21 +682,14 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         WAVE_SYNC();
         if (lane < bh) u[lane * P + UPAD - 1] = u[lane * P + UPAD + BW - 1]; // right column becomes the left neighbour
       };
-      // The picture's planes, pitches and sizes are only needed here, once per CTU: they are read again from the
-      // descriptor through a pointer the compiler cannot see through, instead of occupying ~16 scalar registers for the
-      // whole loop (scalar registers spilled to vector lanes cost VALU instructions).
-      const hm_dev_pic* fp;
-      {
-        const uint64_t a = (uint64_t)(uintptr_t)(pics + pic_index);
-        uint64_t u = ((uint64_t)(uint32_t)rfl((int)(a >> 32)) << 32) | (uint32_t)rfl((int)a);
-        asm volatile("" : "+s"(u));
-        fp = reinterpret_cast<const hm_dev_pic*>((uintptr_t)u);
-      }
-      const int planeWc = fp->width >> 1, planeHc = fp->height / sh;
-      if (fkind == 0) flush_plane(std::integral_constant<int, ctb>(), group_u(fg, 0), P0, lw, fp->plane[0], fp->pitch[0], ctb, fp->width, fp->height);
+      // (the picture's planes, pitches and size: from the wave's copy in LDS, see fdesc)
+      auto f_plane = [&](int c) { return reinterpret_cast<uint8_t*>((uintptr_t)(((uint64_t)fdesc[2 * c + 1] << 32) | fdesc[2 * c])); };
+      const int f_width = (int)fdesc[9], f_height = (int)fdesc[10];
+      const int planeWc = f_width >> 1, planeHc = f_height / sh;
+      if (fkind == 0) flush_plane(std::integral_constant<int, ctb>(), group_u(fg, 0), P0, lw, f_plane(0), (int)fdesc[6], ctb, f_width, f_height);
       else {
-        flush_plane(std::integral_constant<int, (ctb >> 1)>(), group_u(fg, 1), P1, lw, fp->plane[1], fp->pitch[1], ch_c, planeWc, planeHc);
-        flush_plane(std::integral_constant<int, (ctb >> 1)>(), group_u(fg, 2), P1, lw + (Wc + 4), fp->plane[2], fp->pitch[2], ch_c, planeWc, planeHc);
+        flush_plane(std::integral_constant<int, (ctb >> 1)>(), group_u(fg, 1), P1, lw, f_plane(1), (int)fdesc[7], ch_c, planeWc, planeHc);
+        flush_plane(std::integral_constant<int, (ctb >> 1)>(), group_u(fg, 2), P1, lw + (Wc + 4), f_plane(2), (int)fdesc[8], ch_c, planeWc, planeHc);
       }
       WAVE_SYNC();
       // read by the chain of the row below, a group of this wave (LDS traffic of a wave is in order)
@@ -783,7 +789,7 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
     L.luma_bytes = al((ctb + UPAD) * ctb * pb);
     L.chroma_bytes = mono ? 0 : al(2 * (ctb / 2 + UPAD) * ch * pb);
     L.line_slots = L.rows_per_wave == 1 ? 1 : nr;
-    L.off_lines_l = 2 * C_PROG * 4;
+    L.off_lines_l = 2 * C_PROG * 4 + C_FDESC_BYTES;
     if (L.split_kinds) { // one kind of chain per wave: one place for its line, one for its CTU buffers
       L.off_lines_c = L.off_lines_l;
       L.off_scratch = L.off_lines_l + (L.line_l_bytes > L.line_c_bytes ? L.line_l_bytes : L.line_c_bytes);

@@ -81,6 +81,37 @@ __device__ __forceinline__ int wave_sum(int v)
 __constant__ int c_intra_angle[35] = {0, 0, 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26,
                                       -32, -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32};
 __constant__ int c_inv_angle[15] = {-4096, -1638, -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096};
+// The same two tables as arithmetic on the mode (for a mode that lives in a scalar register: a handful of scalar
+// instructions instead of a trip to constant memory on the block's critical path): intraPredAngle depends on the distance
+// to the pure horizontal (10) / vertical (26) mode only - magnitudes 0 2 5 9 13 17 21 26 32, six bits each -, invAngle on
+// the same distance (modes 11..25).
+__host__ __device__ constexpr int intra_angle_of(int mode)
+{
+  const bool vert = mode >= 18;
+  const int d = mode - (vert ? 26 : 10), ad = d < 0 ? -d : d;
+  constexpr unsigned long long K = (2ull << 6) | (5ull << 12) | (9ull << 18) | (13ull << 24) | (17ull << 30) | (21ull << 36) | (26ull << 42) | (32ull << 48);
+  const int mag = (int)((K >> (6 * ad)) & 63);
+  return (vert ? d > 0 : d < 0) ? mag : -mag;
+}
+__host__ __device__ constexpr int inv_angle_of(int mode) // modes 11..25 except 18's neighbours' centre: 256 * 32 / angle
+{
+  const int d = mode - (mode >= 18 ? 26 : 10), ad = d < 0 ? -d : d; // 1..8
+  constexpr unsigned long long K1 = 4096ull | (1638ull << 16) | (910ull << 32) | (630ull << 48), K2 = 482ull | (390ull << 16) | (315ull << 32) | (256ull << 48);
+  return -(int)(((ad <= 4 ? K1 : K2) >> (16 * ((ad - 1) & 3))) & 0xFFFF);
+}
+namespace angle_check {
+constexpr int kAngle[35] = {0, 0, 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26, -32, -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32};
+constexpr int kInv[15] = {-4096, -1638, -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096};
+constexpr bool same()
+{
+  for (int m = 2; m < 35; m++)
+    if (intra_angle_of(m) != kAngle[m]) return false;
+  for (int m = 11; m <= 25; m++)
+    if (inv_angle_of(m) != kInv[m - 11]) return false;
+  return true;
+}
+static_assert(same(), "intra_angle_of / inv_angle_of must reproduce Tables 8-4 / 8-5");
+} // namespace angle_check
 __constant__ int c_level_scale[6] = {40, 45, 51, 57, 64, 72};
 __constant__ int8_t c_dst[4][4] = {{29, 55, 74, 84}, {74, 74, 0, -74}, {84, -29, -74, 55}, {55, -84, 74, -29}};
 // magnitudes of the inverse-DCT basis by angle index (cf. oracle_recon.c: init_dct)
