@@ -294,6 +294,10 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
 #if defined(HM_PAD_S) || defined(HM_PAD_V)
   int lane0_dummy = 0, pad_v = lane;
 #endif
+  // residual of the groups' current 8x8 blocks (lane = sample); not re-initialised per iteration: overwriting a register
+  // means waiting for every load in flight
+  uint32_t bres0 = 0, bres1 = 0, bres2 = 0, bres3 = 0;
+  bool fetch_next = false;
   for (;;) {
     HM_MARK("A_begin");
     // ---- A: start the next CTU of every group whose dependency is met (the row above two CTUs ahead) ----
@@ -304,7 +308,9 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       int done_above = __hip_atomic_load(my_progress + ((row - 1) & (C_PROG - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (from_hbm) done_above = hbm_have;
       if (row == 0 || done_above >= need) {
-        kleft = (int)(c1 & 0xFFFF);
+        uint32_t count = c1;
+        asm volatile("" : "+v"(count)); // (keeps the mask - and with it the wait for the header load - here, a CTU later than the load)
+        kleft = (int)(count & 0xFFFF);
         st = ST_RUN;
         started = true;
       }
@@ -373,6 +379,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     HM_MARK("R_begin");
     // ---- R: the micro-ops and 4x4 residuals of the next 16 records, for every group that has entered that window ----
     {
+      fetch_next = false;
       const bool need_dec = st != ST_DONE && (ri >> 4) != wdec; // the chain has entered window wdec + 1: its records are in pf
       if (ballot(need_dec)) {
         if (need_dec) {
@@ -383,7 +390,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
           rr[1] = c_u32x4{pf[8], pf[9], pf[10], pf[11]};
           wdec += 1;
         }
-        load_window(wdec + 1); // every lane: the window its group decodes next (groups that did not decode ask again for the same)
+        fetch_next = true; // (requested at the end of the iteration, behind this iteration's residual loads: see there)
         WAVE_SYNC();
       }
     }
@@ -397,7 +404,6 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     const unsigned long long s_bres = ballot(running && (op.y & OP_CBF) && (op.y & (3u << OP_L2_SHIFT)) == (1u << OP_L2_SHIFT));
 
     // ---- P: residual of the 8x8 blocks (lane = sample), requested before the side-by-side phase ----
-    uint32_t bres0 = 0, bres1 = 0, bres2 = 0, bres3 = 0;
     if (s_bres) {
       auto big_res = [&](int gg) -> uint32_t {
         uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)op.z, gg * 16) + (uint32_t)lane;
@@ -554,6 +560,11 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
 #endif
         }
 #endif
+        // (every residual load of the block has been used by now: saying so keeps the compiler from guarding later,
+        //  unrelated register writes with a wait for ALL loads in flight - the next window's among them)
+        //  The compiler's wait insertion does not know that "residual requested" and "residual used" are the same condition,
+        //  hence unconditionally, for the block sizes whose residual is loaded here.)
+        if (L2 >= 4) __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
         WAVE_SYNC();
         HM_MARK("D_pred_end");
       };
@@ -726,6 +737,10 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         }
       }
     }
+    // the window behind the one taken in phase R, for every lane (groups that did not take one ask again for the same).
+    // Loads return in order: issued here, behind the iteration's residual loads, they delay nobody who waits for those,
+    // and a whole window of iterations passes before phase R wants them.
+    if (ballot(fetch_next)) load_window(wdec + 1);
     WAVE_SYNC();
   }
 }
