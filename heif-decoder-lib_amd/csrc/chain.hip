@@ -423,6 +423,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
 #else
     if (quad) {
 #endif
+      const int res_q = (int)my_res[gl]; // (requested first and unconditionally: not a fourth LDS round trip behind the reference samples)
       int bx = bx_, by = by_;
       asm volatile("" : "+v"(bx), "+v"(by)); // (loop-invariant lane masks cost scalar registers the kernel does not have)
       const int mode = (int)(op.y & OP_MODE_MASK);
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         const bool on_edge = mode == 26 ? bx == 0 : by == 0;
         v = on_edge ? clip3i(0, maxv, r0 + ((r1 - corner) >> 1)) : v;
       }
-      if (op.y & OP_CBF) v = clip3i(0, maxv, v + (int)my_res[gl]);
+      v = (op.y & OP_CBF) ? clip3i(0, maxv, v + res_q) : v;
       lp[mul24(by, P) + 1 + bx] = (Pix)v;
     }
     WAVE_SYNC();
