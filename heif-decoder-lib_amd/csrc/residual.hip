@@ -207,12 +207,23 @@ __global__ __launch_bounds__(R_WAVES * 64) void k_residual(const hm_dev_pic* __r
     i = i < n_tus1 ? i : n_tus1;
     return *reinterpret_cast<const GLOBAL_AS r_u32x2*>(tus + 2 * (size_t)i);
   };
-  r_u32x2 ahead = fetch_records(rec_begin);
+  uint32_t cur_x, cur_y; // the chunk's records (lane = record)
+  {
+    const r_u32x2 first = fetch_records(rec_begin);
+    cur_x = first.x; cur_y = first.y;
+  }
   for (uint32_t chunk = rec_begin; chunk < rec_end; chunk += 64) {
     const uint32_t ri = chunk + (uint32_t)lane;
     const bool valid = ri < rec_end;
-    const uint32_t r0 = valid ? ahead.x : 0u, r1 = valid ? ahead.y : 0u;
-    ahead = fetch_records(chunk + 64);
+    const uint32_t r0 = valid ? cur_x : 0u, r1 = valid ? cur_y : 0u;
+    const r_u32x2 ahead = fetch_records(chunk + 64);
+    // (luma chains, block map: the first records and the flags of the CTBs that may start inside this chunk - requested
+    //  here with everything else, used below)
+    const int cand = cur_ctb + 1 + lane;
+    const bool cand_ok = kind == 0 && cand < dp.ctb_w;
+    const int last_ctb = dp.ctb_w - 1;
+    const uint32_t cand_first = q0[HM_CTB_DWORDS * (size_t)(cand < last_ctb ? cand : last_ctb)];
+    const uint32_t ctb_flags = q0[HM_CTB_DWORDS * (size_t)(cand - 1 < last_ctb ? cand - 1 : last_ctb) + 2]; // flags of CTB cur_ctb + lane
     const int info = (int)((r0 >> 8) & 0xFF), l2 = info & HM_TU_LOG2_MASK;
     const bool cbf = valid && (info & HM_TU_CBF);
     const uint32_t cnt = (r1 >> 16) & HM_TU8_COUNT_MASK; // (0 in the lanes behind the row's last record)
@@ -245,12 +256,9 @@ __global__ __launch_bounds__(R_WAVES * 64) void k_residual(const hm_dev_pic* __r
     if (kind == 0) {
       // the CTB of every record of the chunk: the CTBs that start inside it are marked at their first record, a scan
       // counts them (every CTB has records, so at most 63 start behind the chunk's first record)
-      {
-        const int cand = cur_ctb + 1 + lane;
-        if (cand < dp.ctb_w) {
-          const uint32_t tf = q0[HM_CTB_DWORDS * (size_t)cand] - chunk;
-          if (tf < 64u) __hip_atomic_fetch_add(slots + tf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        }
+      if (cand_ok) {
+        const uint32_t tf = cand_first - chunk;
+        if (tf < 64u) __hip_atomic_fetch_add(slots + tf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       }
       WAVE_SYNC();
       int sm = slots[lane];
@@ -259,7 +267,13 @@ __global__ __launch_bounds__(R_WAVES * 64) void k_residual(const hm_dev_pic* __r
       sm = (int)wave_scan((uint32_t)sm);
       const int my_ctb = cur_ctb + sm;
       cur_ctb += __builtin_amdgcn_readlane(sm, 63);
-      const int flags = valid ? (int)(q0[HM_CTB_DWORDS * (size_t)my_ctb + 2] & 0xFF) : 0;
+      // (the flags of CTB cur_ctb + k were requested by lane k: at most 63 CTBs start behind the chunk's first record)
+      // (by ALL lanes: a lane that holds no record may hold the flags a record needs - the row's last record alone in its chunk and
+      //  first of its CTB reads lane 1 -, and lanes switched off deliver nothing)
+      int lane_flags = __builtin_amdgcn_ds_bpermute((sm & 63) << 2, (int)ctb_flags);
+      asm volatile("" : "+v"(lane_flags));
+      if (sm >= 64) lane_flags = (int)q0[HM_CTB_DWORDS * (size_t)my_ctb + 2]; // (64 CTBs start in the chunk: each is one record)
+      const int flags = valid ? (lane_flags & 0xFF) : 0;
       const int en = !(flags & HM_CTB_DEBLOCK_OFF);
       const int x4 = (int)(r0 & 15), y4 = (int)((r0 >> 4) & 15);
       const int left_ok = ((x4 > 0) | ((flags & HM_CTB_DEBLOCK_LEFT) != 0)) & en;
@@ -292,6 +306,10 @@ __global__ __launch_bounds__(R_WAVES * 64) void k_residual(const hm_dev_pic* __r
     // the chunk's first R_STAGE levels into LDS: the passes below wait for LDS, not for HBM
 #pragma unroll
     for (int k = 0; k < R_STAGE / 64; k++) lvl[lane + 64 * k] = staged[k];
+    // the next chunk's records have arrived with the levels (they were requested first): taken over here, in front of
+    // this chunk's stores - taken over at the top of the next trip they would be waited for behind all those stores
+    cur_x = ahead.x; cur_y = ahead.y;
+    asm volatile("" : "+v"(cur_x), "+v"(cur_y));
     WAVE_SYNC();
 
     // ---- blocks whose only level is the DC coefficient (a third of the blocks with a residual): both transform stages

@@ -186,6 +186,7 @@ struct SynthParams {
   int32_t chroma_qp_depth;     // diff_cu_chroma_qp_offset_depth
   int32_t sao_scale_y, sao_scale_c; // log2_sao_offset_scale_luma / chroma (<= bit_depth - 10)
   int32_t big_levels;          // per-mille chance of a long coeff_abs_level_remaining prefix (exercises the Rice adaptation)
+  int32_t no_split;            // 1: no coding-quadtree / NxN / transform-tree split is ever chosen (one transform unit per CTB where the syntax allows)
 };
 
 // entropy-coder adaptor for SliceWalker: chooses every bin, encodes it, returns it
@@ -281,11 +282,11 @@ class EncoderEC {
       case K_SAO_MERGE: return rng_.chance(300);
       case K_SAO_TYPE: return idx == 0 ? rng_.chance(700) : rng_.chance(500);
       case K_SAO_OFFSET: return rng_.chance(450);
-      case K_SPLIT_CU: return rng_.chance(idx >= 6 ? 900 : (idx == 5 ? 650 : 450));
+      case K_SPLIT_CU: return P.no_split ? 0 : rng_.chance(idx >= 6 ? 900 : (idx == 5 ? 650 : 450));
       case K_TQ_BYPASS: return rng_.chance(P.tq_bypass);
-      case K_PART_MODE: return idx == 1 ? 1 : rng_.chance(600);
+      case K_PART_MODE: return (idx == 1 || P.no_split) ? 1 : rng_.chance(600);
       case K_PREV_INTRA: return rng_.chance(550);
-      case K_SPLIT_TF: return rng_.chance(idx >= 5 ? 550 : (idx == 4 ? 400 : 300));
+      case K_SPLIT_TF: return P.no_split ? 0 : rng_.chance(idx >= 5 ? 550 : (idx == 4 ? 400 : 300));
       case K_CBF_LUMA: return rng_.chance(7 * d);
       case K_CBF_CHROMA: return rng_.chance(5 * d);
       case K_QP_DELTA: return idx >= 3 ? 0 : rng_.chance(idx == 0 ? 350 : 400);

@@ -16,7 +16,7 @@ class SynthParams(C.Structure):
         "pcm_log2_min", "pcm_log2_max", "pcm_loop_filter_disable", "tq_bypass",
         "slices", "dependent", "tile_cols", "tile_rows", "tiles_uniform", "lf_across_tiles", "pps_lf_across_slices_off", "slice_lf_random",
         "deblock_override", "slice_sao_random", "slice_qp_random", "slice_chroma_qp", "conf_left", "conf_right", "conf_top", "conf_bottom",
-        "rext_sps", "log2_max_ts", "cross_component", "chroma_qp_list", "chroma_qp_depth", "sao_scale_y", "sao_scale_c", "big_levels")]
+        "rext_sps", "log2_max_ts", "cross_component", "chroma_qp_list", "chroma_qp_depth", "sao_scale_y", "sao_scale_c", "big_levels", "no_split")]
 
 # bits of rext_sps (sps_range_extension flags in syntax order)
 REXT_TS_ROTATION, REXT_TS_CONTEXT, REXT_IMPLICIT_RDPCM, REXT_EXPLICIT_RDPCM, REXT_EXTENDED_PRECISION = 1, 2, 4, 8, 16
@@ -31,7 +31,7 @@ DEFAULTS = dict(width=64, height=64, chroma_format=1, bit_depth=8, log2_ctb=5, l
                 slices=0, dependent=0, tile_cols=1, tile_rows=1, tiles_uniform=1, lf_across_tiles=1, pps_lf_across_slices_off=0,
                 slice_lf_random=0, deblock_override=0, slice_sao_random=0, slice_qp_random=0, slice_chroma_qp=0,
                 conf_left=0, conf_right=0, conf_top=0, conf_bottom=0,
-                rext_sps=0, log2_max_ts=0, cross_component=0, chroma_qp_list=0, chroma_qp_depth=0, sao_scale_y=0, sao_scale_c=0, big_levels=0)
+                rext_sps=0, log2_max_ts=0, cross_component=0, chroma_qp_list=0, chroma_qp_depth=0, sao_scale_y=0, sao_scale_c=0, big_levels=0, no_split=0)
 
 _lib = None
 

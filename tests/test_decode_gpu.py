@@ -157,8 +157,10 @@ def test_range_extension_large_blocks(pkg):
 
 @pytest.mark.parametrize("shape", [dict(width=2304, height=1296, log2_ctb=5), dict(width=1920, height=1080, log2_ctb=4),
                                    dict(width=1600, height=1200, log2_ctb=6, bit_depth=10), dict(width=2048, height=1152, log2_ctb=5, chroma_format=2, bit_depth=10),
-                                   dict(width=1536, height=1024, log2_ctb=6, chroma_format=0)],
-                         ids=["8bit_ctb32", "8bit_ctb16", "10bit_ctb64", "10bit_422_ctb32", "mono_ctb64"])
+                                   dict(width=1536, height=1024, log2_ctb=6, chroma_format=0),
+                                   # one 16x16 transform block per CTB: 64 CTBs start inside one 64-record chunk of the residual pre-pass
+                                   dict(width=2048, height=512, log2_ctb=4, no_split=1)],
+                         ids=["8bit_ctb32", "8bit_ctb16", "10bit_ctb64", "10bit_422_ctb32", "mono_ctb64", "8bit_ctb16_one_block_per_ctb"])
 def test_large_single_pictures(pkg, shape):
     """pictures of a megapixel or more go to k_recon_quad in every class, with as many waves per picture as the wavefront,
     the LDS and the machine allow - 3, 5, 6, 7 as well as powers of two (sample lines are handed from wave to wave through
