@@ -297,7 +297,6 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   // residual of the groups' current 8x8 blocks (lane = sample); not re-initialised per iteration: overwriting a register
   // means waiting for every load in flight
   uint32_t bres0 = 0, bres1 = 0, bres2 = 0, bres3 = 0;
-  bool fetch_next = false;
   for (;;) {
     HM_MARK("A_begin");
     // ---- A: start the next CTU of every group whose dependency is met (the row above two CTUs ahead) ----
@@ -379,7 +378,6 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     HM_MARK("R_begin");
     // ---- R: the micro-ops and 4x4 residuals of the next 16 records, for every group that has entered that window ----
     {
-      fetch_next = false;
       const bool need_dec = st != ST_DONE && (ri >> 4) != wdec; // the chain has entered window wdec + 1: its records are in pf
       if (ballot(need_dec)) {
         if (need_dec) {
@@ -390,7 +388,10 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
           rr[1] = c_u32x4{pf[8], pf[9], pf[10], pf[11]};
           wdec += 1;
         }
-        fetch_next = true; // (requested at the end of the iteration, behind this iteration's residual loads: see there)
+        // every lane: the window its group decodes next (groups that did not decode ask again for the same).  (Measured against
+        // requesting it at the end of the iteration, behind the iteration's residual loads: 23.7 against 24.1 ms at full load,
+        // 7.5 against 8.1 ms for config 4.)
+        load_window(wdec + 1);
         WAVE_SYNC();
       }
     }
@@ -738,10 +739,6 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         }
       }
     }
-    // the window behind the one taken in phase R, for every lane (groups that did not take one ask again for the same).
-    // Loads return in order: issued here, behind the iteration's residual loads, they delay nobody who waits for those,
-    // and a whole window of iterations passes before phase R wants them.
-    if (ballot(fetch_next)) load_window(wdec + 1);
     WAVE_SYNC();
   }
 }
