@@ -77,6 +77,10 @@ struct CLayout {
   // few waves: fewer chains per wave = shorter iterations) and, with split_kinds, on their luma or their chroma chains
   // only (the two never read each other); the picture's rows are bands_per_pic such bands
   int rows_per_wave, split_kinds, bands_per_pic;
+  // ... and the picture has `passes` such bands.  bands_per_pic == passes: a wave per band.  Fewer: the waves of a picture take
+  // the bands in turn - wave b the bands b, b + bands_per_pic, ... - so that they work side by side like the rows of a
+  // wavefront (a wave per run of CONSECUTIVE bands would wait for the last row of the run above: no overlap at all)
+  int passes;
   int spin_limit;    // PAIRS: polls of the band above without news before a wave gives up (error flag, wrong picture, no hang)
   int test_stall;    // fault injection (tests): the first band of every picture never announces its progress
 };
@@ -203,8 +207,9 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   const uint32_t res_last = RG.total ? RG.total - 1 : 0;
   const int RPW = PAIRS ? L.rows_per_wave : NR; // rows this wave works on at a time
   if (PAIRS && (pair_index * RPW >= ctb_h || (mono && kind_sel == 1))) return;
+  const int W = PAIRS ? L.bands_per_pic : 1; // waves that share this picture's bands (per chain kind)
   // PAIRS: progress words of this picture's pairs ([pair][chain kind]); this pair reads those of the pair above
-  uint32_t* const pair_progress = PAIRS ? sync + SYNC_PROGRESS + 2 * ((size_t)pic_index * L.bands_per_pic) : nullptr;
+  uint32_t* const pair_progress = PAIRS ? sync + SYNC_PROGRESS + 2 * ((size_t)pic_index * L.passes) : nullptr;
   // ... and the hand-over lines (hm_device.h: hm_dev_pic.hand): per pair the bottom sample line of its last row, luma, Cb, Cr
   uint32_t* const hand_words = reinterpret_cast<uint32_t*>(dp.hand);
   const uint32_t hand_luma_words = (uint32_t)(ctb_w * ctb) * sizeof(Pix) / 4, hand_chroma_words = mono ? 0u : (uint32_t)Wc * sizeof(Pix) / 4;
@@ -262,7 +267,12 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   // PAIRS, first row of a pair: CTUs of the row above (the last row of the pair above, another wave's) whose bottom
   // sample line has been copied from the picture into this wave's line
   int hbm_have = 0, hbm_polls = 0;
-  const bool from_hbm = PAIRS && my_slot == 0 && pair_index > 0;
+  int pidx = pair_index; // the band the group works on now (the wave's next one: pidx + W)
+  // progress counter of a row in flight: row % 8 (rows of a wave per picture are NR apart), PAIRS: alternating halves per
+  // band the group has worked on (the rows of a wave's consecutive bands may be a multiple of 8 apart)
+  int pbank = 0;
+  auto prog_index = [&](int r, int slot) { return PAIRS ? pbank * 4 + (slot & 3) : (r & (C_PROG - 1)); };
+  bool from_hbm = PAIRS && my_slot == 0 && pidx > 0; // the row above belongs to another wave
   auto load_window = [&](uint32_t w) {
     uint32_t idx = (w << 4) + (uint32_t)gl;
     idx = idx < n_tus - 1 ? idx : n_tus - 1; // past the last record of the picture: re-read it (never executed)
@@ -279,7 +289,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   auto row_start = [&]() { // header of CTU (row, 0) and the first window of the row's chain
     // the row's progress counter: last used by row - 8.  The chain of row + 1 - a group of this wave that starts its row
     // after this one: it finished row - 1 behind this group's row - 2 - reads it from now on.
-    if (gl == 0) __hip_atomic_store(my_progress + (row & (C_PROG - 1)), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (gl == 0) __hip_atomic_store(my_progress + prog_index(row, my_slot), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     header(row, 0);
     ri = c0;
     wdec = (ri >> 4) - 1; // (nothing of this row is in LDS yet)
@@ -304,7 +314,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     if (st == ST_START) {
       const int need = cx + 2 < ctb_w ? cx + 2 : ctb_w;
       // (a counter value seen here means the line samples written before it are there: LDS traffic of a wave is in order)
-      int done_above = __hip_atomic_load(my_progress + ((row - 1) & (C_PROG - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      int done_above = __hip_atomic_load(my_progress + prog_index(row - 1, my_slot - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (from_hbm) done_above = hbm_have;
       if (row == 0 || done_above >= need) {
         uint32_t count = c1;
@@ -330,7 +340,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         //  coherent across the chip: no cache write-back / invalidation - those cost more than the hand-over itself
         //  when thousands of waves do them per CTU; the reader's loads are issued behind the word's value)
         int avail = 0;
-        if (poll) avail = (int)__hip_atomic_load(pair_progress + 2 * (size_t)(pair_index - 1) + kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (poll) avail = (int)__hip_atomic_load(pair_progress + 2 * (size_t)(pidx - 1) + kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (unsigned long long todo = ballot(poll && avail > hbm_have); todo;) {
           const int cg = rfl((int)(__builtin_ctzll(todo) >> 4));
           todo &= ~(0xFFFFull << (cg * 16));
@@ -339,6 +349,14 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
           int s_avail = __builtin_amdgcn_readlane(avail, src);
           if (s_avail > s_have + 8) s_avail = s_have + 8; // (bounded work per iteration)
           const int ckind = group_kind(cg);
+          const int s_pidx = __builtin_amdgcn_readlane(pidx, src);
+          if (RPW > 1) {
+            // the line this copy fills is also where the wave's last row of the PREVIOUS band puts its bottom samples: while
+            // that row is still on its way, only the CTUs it has finished may be overwritten (it runs 2 CTUs per row behind)
+            const int wsrc = (mono ? RPW - 1 : (((RPW - 1) << 1) | ckind)) * 16;
+            const int w_pidx = __builtin_amdgcn_readlane(pidx, wsrc), w_cx = __builtin_amdgcn_readlane(cx, wsrc);
+            if (w_pidx < s_pidx && s_avail > w_cx) s_avail = w_cx;
+          }
           Pix* const lw = line_of(ckind, NR - 1); // the line the pair's first row reads: that of the row above
           // CTUs [s_have, s_avail) of the hand-over line of the pair above: whole 32-bit words
           constexpr int PPW = 4 / sizeof(Pix);
@@ -347,14 +365,14 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
             for (int w = w0 + lane; w < w1; w += 64)
               *reinterpret_cast<uint32_t*>(line + w * PPW) = __hip_atomic_load(words + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           };
-          const uint32_t* const hand = hand_words + (size_t)(pair_index - 1) * hand_pair_words;
+          const uint32_t* const hand = hand_words + (size_t)(s_pidx - 1) * hand_pair_words;
           if (ckind == 0) copy_line(hand, ctb, lw);
           else {
             copy_line(hand + hand_luma_words, cw_c, lw);
             copy_line(hand + hand_luma_words + hand_chroma_words, cw_c, lw + (Wc + 4));
           }
           WAVE_SYNC();
-          if (g == cg) { hbm_have = s_avail; hbm_polls = 0; }
+          if (g == cg && s_avail > s_have) { hbm_have = s_avail; hbm_polls = 0; }
         }
         // the band above is not coming: give up (never on a healthy launch) - the whole wave, since its other chains
         // wait for this one - with the launch flagged: the bands below give up in turn, nothing hangs
@@ -706,13 +724,15 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       }
       WAVE_SYNC();
       // read by the chain of the row below, a group of this wave (LDS traffic of a wave is in order)
-      if (lane == 0) __hip_atomic_store(progress + fkind * C_PROG + (s_row & (C_PROG - 1)), s_cx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const int s_prog = PAIRS ? __builtin_amdgcn_readlane(pbank, src) * 4 + group_slot(fg) : (s_row & (C_PROG - 1));
+      if (lane == 0) __hip_atomic_store(progress + fkind * C_PROG + s_prog, s_cx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (PAIRS && group_slot(fg) == RPW - 1 && s_row + 1 < ctb_h) {
         // ... or, for the pair's last row, the first row of the pair below: another wave, anywhere on the chip.  The
         // CTU's bottom sample line goes to the pair's hand-over line with agent-scope stores; once they have left this
         // wave (vmcnt 0) the word that announces them follows
         constexpr int PPW = 4 / sizeof(Pix);
-        uint32_t* const hand = hand_words + (size_t)pair_index * hand_pair_words;
+        const int s_pidx = __builtin_amdgcn_readlane(pidx, src);
+        uint32_t* const hand = hand_words + (size_t)s_pidx * hand_pair_words;
         auto put_line = [&](uint32_t* words, int ctu_w, const Pix* u, int P, int bh) { // the bottom row of the CTU buffer
           const int w0 = s_cx * ctu_w / PPW, nw = ctu_w / PPW; // (at most 32 words: a CTU row of 64 16-bit samples)
           if (lane < nw) __hip_atomic_store(words + w0 + lane, *reinterpret_cast<const uint32_t*>(u + (bh - 1) * P + UPAD + lane * PPW), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -723,7 +743,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
           put_line(hand + hand_luma_words + hand_chroma_words, cw_c, group_u(fg, 2), P1, ch_c);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0 && !(L.test_stall && pair_index == 0)) __hip_atomic_store(pair_progress + 2 * (size_t)pair_index + fkind, (uint32_t)(s_cx + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0 && !(L.test_stall && s_pidx == 0)) __hip_atomic_store(pair_progress + 2 * (size_t)s_pidx + fkind, (uint32_t)(s_cx + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       // the group's next CTU
       if (g == fg) {
@@ -733,7 +753,9 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         if (cx == ctb_w) {
           cx = 0;
           tl_off = lr_off;
-          row += PAIRS ? ctb_h : NR; // (PAIRS: one pass per wave)
+          // the group's next row: NR further (a wave per picture), or in the wave's next band (PAIRS)
+          row += PAIRS ? RPW * W : NR;
+          if (PAIRS) { pidx += W; pbank ^= 1; from_hbm = my_slot == 0; hbm_have = 0; hbm_polls = 0; }
           if (row < ctb_h) row_start();
           else st = ST_DONE;
         }
@@ -779,13 +801,31 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
     L.rows_per_wave = 1;
     if (2 * row_waves <= 3500 && !mono) L.split_kinds = 1;
   }
-  if (pairs && L.rows_per_wave == nr && max_ctb_h <= nr) pairs = false; // (a single band: nothing to hand over)
+  // Too many pictures for a wave per pair of rows, too few to fill the machine with a wave per picture (about 400 ... 2000
+  // tiles of 512x512): W waves per picture that take its pairs of rows in turn - at most 4 (more hand-overs than that cost
+  // more than the extra parallelism gives) and only as many as are resident together (4096 waves at 16 per CU: one more
+  // and a resident wave waits for one that is not).  Measured (tools/r03_share.sh, k_chain ms; a wave per picture / per
+  // pair of rows / W in turn): 384 tiles 4.03 / 2.55 / 2.42 (W = 4), 576: 4.44 / 3.70 / 2.52 (4), 1056: 4.78 / 5.32 / 3.18 (3),
+  // 1536: 4.92 / 7.03 / 4.02 (2), 2064: 4.92 / 9.18 / 5.94 (2, 4128 waves: too many).
+  int share = 0; // waves per picture in that mode
+  if (pair_waves > 3000 && max_ctb_h > nr) {
+    int w = (int)(4096 / (long)n_pics);
+    if (w > 4) w = 4;
+    pairs = w >= 2;
+    share = pairs ? w : 0;
+    L.rows_per_wave = nr; L.split_kinds = 0;
+  }
+  if (pairs && !share && L.rows_per_wave == nr && max_ctb_h <= nr) pairs = false; // (a single band: nothing to hand over)
   if (force_pairs >= 0) {
     pairs = force_pairs != 0 && max_ctb_h > (force_pairs >= 2 ? 1 : nr);
     L.rows_per_wave = force_pairs >= 2 ? 1 : nr;
     L.split_kinds = force_pairs >= 3 && !mono ? 1 : 0;
+    share = 0;
   }
-  L.bands_per_pic = (max_ctb_h + L.rows_per_wave - 1) / L.rows_per_wave;
+  static const int force_share = [] { const char* e = getenv("HM_CHAIN_SHARE"); return e ? atoi(e) : 0; }(); // (tuning aid: waves per picture that take its pairs of rows in turn)
+  if (force_share >= 2 && max_ctb_h > nr) { pairs = true; L.rows_per_wave = nr; L.split_kinds = 0; share = force_share; }
+  L.passes = (max_ctb_h + L.rows_per_wave - 1) / L.rows_per_wave;
+  L.bands_per_pic = share && share < L.passes ? share : L.passes;
   // (tests: HM_CHAIN_SPIN_LIMIT shortens the bounded waits, HM_CHAIN_TEST_STALL=1 makes the first band of every picture
   //  keep its progress to itself - the bands below must then give up, flag the launch and leave)
   static const int env_spin = [] { const char* e = getenv("HM_CHAIN_SPIN_LIMIT"); return e ? atoi(e) : 0; }();
@@ -793,7 +833,7 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   L.spin_limit = env_spin > 0 ? env_spin : SPIN_LIMIT;
   L.test_stall = env_stall;
   auto sync_words = [&](int bands) { return ((size_t)SYNC_PROGRESS + 2 * (size_t)n_pics * bands) * sizeof(uint32_t); };
-  if (!d_sync || sync_bytes < sync_words(L.bands_per_pic)) pairs = false;
+  if (!d_sync || sync_bytes < sync_words(L.passes)) pairs = false;
   if (!pairs) { L.rows_per_wave = nr; L.split_kinds = 0; }
   // ---- LDS of a wave ----
   auto set_layout = [&]() -> bool { // for the cut in L; false if a wave does not fit the CU's LDS
@@ -826,12 +866,12 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
     // a very wide picture (16-bit samples, > ~9000 columns): its sample lines of two rows and both kinds do not fit one
     // wave's share of LDS - the finer cuts keep one line per wave (a wave per CTU row), or one line of one kind
     pairs = true;
-    L.rows_per_wave = 1; L.split_kinds = 0; L.bands_per_pic = max_ctb_h;
+    L.rows_per_wave = 1; L.split_kinds = 0; L.bands_per_pic = L.passes = max_ctb_h;
     fits = set_layout();
     if (!fits && !mono) { L.split_kinds = 1; fits = set_layout(); }
   }
   if (!fits) return 0;
-  const size_t sync_need = sync_words(L.bands_per_pic);
+  const size_t sync_need = sync_words(L.passes);
   const void* fn = nullptr;
   const int inst = log2_ctb * 2 + (pb - 1) - 8;
   switch (inst * 2 + (pairs ? 1 : 0)) {
@@ -880,7 +920,7 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   const int lds_bytes = C_SHARED + np * L.pic_bytes;
   static const int debug = [] { const char* e = getenv("HM_CHAIN_DEBUG"); return e ? atoi(e) : 0; }();
   if (debug) fprintf(stderr, "[k_chain] %d pictures, %ld waves (%s), %d bytes of LDS per wave, %d waves per workgroup, registers allow %d waves per CU\n", n_pics, n_waves,
-                     !pairs ? "one per picture" : (L.split_kinds ? "one per chain of a CTU row" : (L.rows_per_wave == 1 ? "one per CTU row" : "one per pair of CTU rows")),
+                     !pairs ? "one per picture" : (L.split_kinds ? "one per chain of a CTU row" : (L.rows_per_wave == 1 ? "one per CTU row" : (L.bands_per_pic < L.passes ? "several per picture, taking its pairs of CTU rows in turn" : "one per pair of CTU rows"))),
                      L.pic_bytes, np, cu_waves);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return hm_check_hip(e, "hipFuncSetAttribute(k_chain)");

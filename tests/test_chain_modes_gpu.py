@@ -26,6 +26,15 @@ def test_every_cut_gives_the_same_pictures(cut):
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("share", [2, 3, 4])
+def test_waves_that_take_the_row_pairs_of_a_picture_in_turn(share):
+    """mid-size batches: W waves per picture, wave b works on the pairs of CTU rows b, b + W, ... (hand-over in both
+    directions, the wave's line of the row above refilled from the hand-over lines for every pair)"""
+    r = _run({"HM_CHAIN_SHARE": str(share), "HM_QUAD_CLASS": "1", "HM_CHAIN_DEBUG": "1"})
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+    assert "in turn" in r.stderr, r.stderr
+
+
 def test_widest_pictures_fall_back_to_a_finer_cut():
     """16384 columns of 16-bit 4:2:2 samples with 64x64 CTBs: the sample lines of a wave per picture (forced here) do not
     fit a wave's share of LDS; the launcher then cuts the pictures into a wave per CTU row (or chain) instead of refusing"""
