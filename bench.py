@@ -501,6 +501,25 @@ def wpp_parse_rates(pkg):
     return res
 
 
+def tile_parse_rates(pkg):
+    """hm_hevc_parse_mt on one synthetic 12 MP picture coded with 2 x 6 HEVC tiles (an entry point per tile, no WPP): ms
+    with 1 thread and with the rows of tiles entropy-decoded side by side"""
+    import synthutil
+    capi = pkg.capi
+    data = synthutil.picture(7300001, width=4032, height=3024, log2_ctb=5, tile_cols=2, tile_rows=6, qp=30, density=40)
+    row = {"stream_bytes": len(data)}
+    for threads in (1, 2, 3, 6):
+        capi.parse_hevc(data, threads=threads)
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            capi.parse_hevc(data, threads=threads)
+            best = min(best, time.perf_counter() - t0)
+        row[f"threads_{threads}_ms"] = round(best * 1e3, 2)
+    row["note"] = "4032x3024 8-bit 4:2:0, CTB 32, 2 x 6 tiles: the six rows of tiles are the units of work; same command stream as the serial parser (tests/test_oracle_decode.py)"
+    return row
+
+
 def guarded(out, key, fn):
     try:
         out[key] = fn()
@@ -512,6 +531,7 @@ def side_legs(out, args, torch, pkg, dev, st, gb, kept, strides, stream_b):
     B = len(gb.images)
     guarded(out, "host_entropy_decode", lambda: host_parse_rate(pkg, kept[0]))
     guarded(out, "wpp_row_parallel_parse", lambda: wpp_parse_rates(pkg))
+    guarded(out, "tile_parallel_parse", lambda: tile_parse_rates(pkg))
     guarded(out, "colour_kernel_standalone", lambda: colour_standalone(torch, pkg, gb, st))
     guarded(out, "kernels_grouped_streams", lambda: grouped_streams(torch, gb, st))
     guarded(out, "device_inclusive", lambda: device_inclusive(torch, pkg, dev, gb, st, stream_b))

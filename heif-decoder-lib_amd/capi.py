@@ -88,14 +88,24 @@ def bind_decode(L):
     L.hm_batch_algorithmic_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
 
 
-def parse_hevc(data, annexb=False, threads=1):
-    """hm_hevc_parse[_mt] -> command-stream blob (bytes)."""
+class ParseOptions(C.Structure):
+    """hm_parse_options (include/heif_mi355x.h)"""
+    _fields_ = [("annexb", C.c_int32), ("threads", C.c_int32), ("record_order", C.c_int32)]
+
+
+def parse_hevc(data, annexb=False, threads=1, record_order=None):
+    """hm_hevc_parse[_mt] - or, with a record order (HM_RECORDS_*), hm_hevc_parse_opts - -> command-stream blob (bytes)."""
     L = lib()
     blob = C.POINTER(C.c_uint8)()
     size = C.c_size_t()
     L.hm_hevc_parse_mt.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.hm_hevc_parse_mt.restype = C.c_int
-    if threads > 1:
+    if record_order is not None:
+        L.hm_hevc_parse_opts.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(ParseOptions), C.c_void_p, C.c_void_p]
+        L.hm_hevc_parse_opts.restype = C.c_int
+        o = ParseOptions(1 if annexb else 0, threads, record_order)
+        check(L.hm_hevc_parse_opts(data, len(data), C.byref(o), C.byref(blob), C.byref(size)))
+    elif threads > 1:
         check(L.hm_hevc_parse_mt(data, len(data), 1 if annexb else 0, threads, C.byref(blob), C.byref(size)))
     else:
         check(L.hm_hevc_parse(data, len(data), 1 if annexb else 0, C.byref(blob), C.byref(size)))

@@ -19,6 +19,8 @@
 #include "hm_internal.h"
 
 namespace hm {
+// slice segments whose sub-streams were entropy-decoded side by side since the library was loaded (tests): [0] WPP rows, [1] tiles
+static std::atomic<long> g_parallel_segments[2];
 
 // entropy-coder adaptor handed to SliceWalker: plain CABAC decoding, kinds ignored
 class DecoderEC {
@@ -188,6 +190,9 @@ struct Decoder {
     if (threads > 1 && p.entropy_coding_sync && !p.tiles_enabled && !sh.dependent && sh.num_entry_points > 0 &&
         (sh.slice_segment_address % s.ctb_w) == 0 && !s.persistent_rice && !sh.cu_chroma_qp_offset_enabled)
       next_ts = parse_rows_parallel(sh, slice_idx, start_ts, begin, end);
+    else if (threads > 1 && p.tiles_enabled && !p.entropy_coding_sync && !sh.dependent && sh.num_entry_points > 0 && p.num_tile_rows > 1 &&
+             !s.persistent_rice && !sh.cu_chroma_qp_offset_enabled)
+      next_ts = parse_tiles_parallel(sh, slice_idx, start_ts, begin, end);
     else {
       DecoderEC ec(begin, end);
       SliceWalker<DecoderEC> walker(ec, pic, sh, slice_idx);
@@ -329,7 +334,134 @@ struct Decoder {
       pic.uses_tq_bypass |= R.uses_tq;
     }
     pic.qs = rows.back().qs;
+    g_parallel_segments[0]++;
     return rows.back().ended_slice;
+  }
+
+  // HEVC tiles in parallel: a slice segment whose header carries an entry point per tile (no WPP).  Tiles are
+  // independent sub-streams - fresh context tables, no prediction and no QP history across their borders (the first
+  // quantisation group of a tile predicts from the slice QP) -; what they share is where their records go: the chains of
+  // a CTB row (hevc_syntax.h: PictureState::rows) take the records of every tile the row crosses, from left to right.
+  // So the unit of work is a ROW of tiles: its tiles one after the other on one thread - exactly the serial order inside
+  // the CTB rows it covers -, the rows of tiles side by side on up to `threads` threads.  Same command stream byte for
+  // byte; anything that does not fit (entry points that do not match the sub-streams, a slice that ends early or goes
+  // on behind its last entry point, any error) falls back to the serial parse, which reports errors in decoding order.
+  int parse_tiles_parallel(const SliceHeader& sh, int slice_idx, int start_ts, const uint8_t* begin, const uint8_t* end)
+  {
+    const SPS& s = *cur_sps;
+    const PPS& p = *cur_pps;
+    const int W = s.ctb_w, N = W * s.ctb_h, n_sub = sh.num_entry_points + 1;
+    if (start_ts > 0 && p.TileId[start_ts] == p.TileId[start_ts - 1]) throw Inconsistent(); // (the segment starts inside a tile)
+    // tile-scan ranges of the sub-streams = tiles
+    std::vector<int> ts0((size_t)n_sub + 1);
+    {
+      int ts = start_ts;
+      for (int k = 0; k < n_sub; k++) {
+        if (ts >= N) throw Inconsistent(); // more entry points than tiles left
+        ts0[(size_t)k] = ts;
+        const int tid = p.TileId[ts];
+        while (ts < N && p.TileId[ts] == tid) ts++;
+      }
+      ts0[(size_t)n_sub] = ts;
+    }
+    // sub-stream starts in the unescaped payload (the offsets count bytes of the escaped NAL, 7.4.7.1)
+    const size_t data_unesc = (size_t)(begin - rbsp.data());
+    auto escaped_of = [&](size_t u) { size_t k = 0; while (k < removed.size() && removed[k] <= u + k) k++; return u + k; };
+    auto unescaped_of = [&](size_t e) { size_t k = 0; while (k < removed.size() && removed[k] < e) k++; return e - k; };
+    std::vector<const uint8_t*> start((size_t)n_sub + 1);
+    size_t e = escaped_of(data_unesc);
+    start[0] = begin;
+    for (int k = 1; k < n_sub; k++) {
+      e += sh.entry_point_offset[k - 1];
+      const size_t u = unescaped_of(e);
+      if (u > rbsp.size() || rbsp.data() + u < start[(size_t)k - 1]) throw Inconsistent();
+      start[(size_t)k] = rbsp.data() + u;
+    }
+    start[(size_t)n_sub] = end;
+    // the rows of tiles: consecutive sub-streams whose tiles have the same tile row
+    struct alignas(128) Group {
+      int first = 0, count = 0; // sub-streams
+      std::vector<hm_coeff> coeffs;
+      PictureState::QpState qs;
+      int ended_slice = 0;
+      bool uses_pcm = false, uses_tq = false;
+    };
+    std::vector<Group> groups;
+    for (int k = 0; k < n_sub; k++) {
+      const int trow = p.TileId[ts0[(size_t)k]] / p.num_tile_cols;
+      if (groups.empty() || p.TileId[ts0[(size_t)groups.back().first]] / p.num_tile_cols != trow) { groups.emplace_back(); groups.back().first = k; }
+      groups.back().count++;
+    }
+    const int n_groups = (int)groups.size();
+    if (n_groups < 2) throw Inconsistent(); // (nothing to run side by side: the serial parse is the cheaper one)
+    std::atomic<int> next_group{0};
+    std::atomic<bool> failed{false};
+
+    auto parse_group = [&](int gi) {
+      Group& G = groups[(size_t)gi];
+      for (int k = G.first; k < G.first + G.count; k++) {
+        DecoderEC ec(start[(size_t)k], start[(size_t)k + 1]);
+        SliceWalker<DecoderEC> walker(ec, pic, sh, slice_idx);
+        G.qs.last_qpy_prev_qg = G.qs.current_qpy = sh.SliceQPY; // (the first quantisation group of a tile predicts from the slice QP)
+        G.qs.cur_qg_x = G.qs.cur_qg_y = -1;
+        walker.use_private_state(&G.qs, &G.coeffs);
+        init_contexts(ec.contexts(), sh.SliceQPY); // every tile starts with fresh tables
+        ec.start_substream();
+        for (int ts = ts0[(size_t)k]; ts < ts0[(size_t)k + 1]; ts++) {
+          if (failed.load(std::memory_order_relaxed)) throw Inconsistent();
+          walker.decode_ctu(ts);
+          const int end_of_slice = ec.terminate(ts + 1 == N ? 1 : -1);
+          if (end_of_slice) {
+            if (k != n_sub - 1 || ts + 1 != ts0[(size_t)k + 1]) throw Inconsistent(); // the slice ends before its last entry point / inside a tile
+            if (cur_pps->dependent_slice_segments_enabled) { pic.dep_ctx = ec.contexts(); pic.dep_ok = true; }
+            G.ended_slice = ts + 1;
+            break;
+          }
+          if (ts + 1 >= N) throw ParseError(HM_ERR_BITSTREAM, "missing end_of_slice_segment_flag");
+          if (ts + 1 == ts0[(size_t)k + 1]) { // the tile is done, the slice is not
+            if (k == n_sub - 1) throw Inconsistent(); // the slice goes on behind its last entry point
+            if (!ec.terminate(2)) throw ParseError(HM_ERR_BITSTREAM, "end_of_subset_one_bit not set");
+            if (ec.position() != start[(size_t)k + 1]) throw Inconsistent();
+          }
+        }
+        G.uses_pcm |= walker.uses_pcm(); G.uses_tq |= walker.uses_tq_bypass();
+      }
+    };
+    auto worker = [&]() {
+      for (;;) {
+        const int gi = next_group.fetch_add(1);
+        if (gi >= n_groups || failed.load()) return;
+        try { parse_group(gi); }
+        catch (...) { failed.store(true); return; } // (whatever it was: the serial parse finds it in decoding order)
+      }
+    };
+    const int n_workers = std::min(threads, n_groups);
+    std::vector<std::thread> crew;
+    try {
+      for (int i = 1; i < n_workers; i++) crew.emplace_back(worker);
+    }
+    catch (...) { // no more threads to be had: what was started finishes, the serial parse takes over
+      failed.store(true);
+      for (std::thread& t : crew) t.join();
+      throw Inconsistent();
+    }
+    worker();
+    for (std::thread& t : crew) t.join();
+    if (failed.load() || !groups.back().ended_slice) throw Inconsistent();
+    // the groups' level lists behind the picture's, the records rebased (split chains keep their levels per CTB row: nothing to do)
+    for (int gi = 0; gi < n_groups; gi++) {
+      Group& G = groups[(size_t)gi];
+      const uint32_t base = (uint32_t)pic.coeffs.size();
+      pic.coeffs.insert(pic.coeffs.end(), G.coeffs.begin(), G.coeffs.end());
+      if (base)
+        for (int ts = ts0[(size_t)G.first]; ts < ts0[(size_t)(G.first + G.count)]; ts++)
+          for (hm_tu& t : pic.ctb_tus[(size_t)p.CtbAddrTStoRS[ts]]) t.coeff_first += base;
+      pic.uses_pcm |= G.uses_pcm;
+      pic.uses_tq_bypass |= G.uses_tq;
+    }
+    pic.qs = groups.back().qs;
+    g_parallel_segments[1]++;
+    return groups.back().ended_slice;
   }
 
   static void check_supported(const SPS& s, const PPS& p)
@@ -684,6 +816,9 @@ int hm_hevc_parse_opts(const uint8_t* data, size_t size, const hm_parse_options*
 } // extern "C"
 
 extern "C" {
+
+// (test hook, hm_internal.h) slice segments parsed with their WPP rows (which = 0) / their rows of tiles (1) side by side
+long hm_parse_parallel_segments(int which) { return which == 0 || which == 1 ? hm::g_parallel_segments[which].load() : -1; }
 
 void hm_free(void* p) { std::free(p); }
 

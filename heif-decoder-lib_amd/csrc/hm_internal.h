@@ -72,6 +72,9 @@ int hm_launch_sao_paste(const struct hm_dev_pic* d_pics, int n_pics, int max_w, 
 int hm_launch_tail420(const struct hm_dev_pic* d_pics, const void* d_dsts, int n_pics, int max_w, int max_h, int bpp, const int coef[4],
                       int stages, hipStream_t s);
 
+// (test hook) slice segments whose sub-streams were entropy-decoded side by side since the library was loaded: which = 0 WPP rows, 1 rows of tiles
+HM_API long hm_parse_parallel_segments(int which);
+
 #ifdef __cplusplus
 }
 #endif

@@ -179,6 +179,40 @@ def test_row_parallel_parse_equals_serial(pkg, hm):
             assert a == ref
 
 
+def test_tile_parallel_parse_equals_serial(pkg, hm):
+    """slice segments with an entry point per HEVC tile (no WPP): the rows of tiles are entropy-decoded side by side
+    (hevc_parse.cpp: parse_tiles_parallel) and must give the serial parser's command stream byte for byte - in both record
+    orders (split chains share a CTB row's record lists between the tiles of a row of tiles; decode order rebases the level
+    indices) -, and the parallel path must actually have been taken"""
+    import ctypes as C
+    import synthutil
+    capi = pkg.capi
+    hm.hm_parse_parallel_segments.restype = C.c_long
+    hm.hm_parse_parallel_segments.argtypes = [C.c_int]
+    before = hm.hm_parse_parallel_segments(1)
+    shapes = [dict(width=256, height=192, tile_cols=3, tile_rows=2), dict(width=320, height=256, tile_cols=4, tile_rows=3, tiles_uniform=0),
+              dict(width=256, height=256, log2_ctb=4, tile_cols=2, tile_rows=4, bit_depth=10), dict(width=384, height=256, log2_ctb=6, tile_cols=2, tile_rows=2, chroma_format=2, bit_depth=10),
+              dict(width=1024, height=1024, tile_cols=2, tile_rows=3, density=20), dict(width=256, height=192, tile_cols=1, tile_rows=3, chroma_format=0),
+              dict(width=256, height=192, tile_cols=3, tile_rows=2, pcm=200, tq_bypass=100), dict(width=256, height=192, tile_cols=2, tile_rows=2, lf_across_tiles=0, slices=0)]
+    for i, kw in enumerate(shapes):
+        for seed in (8100 + i, 8200 + i):
+            data = synthutil.picture(seed, **kw)
+            for order in (0, 1, 2):  # HM_RECORDS_AUTO / SPLIT / DECODE_ORDER
+                assert capi.parse_hevc(data, threads=3, record_order=order) == capi.parse_hevc(data, record_order=order), (seed, kw, order)
+    assert hm.hm_parse_parallel_segments(1) >= before + len(shapes) * 2 * 3
+    # several slices, each a whole number of tiles or not: whatever does not qualify runs serially inside the same call
+    for seed, kw in corpus.structure_sweep(40, first_seed=9500):
+        kw = dict(kw, wpp=0, tile_cols=2, tile_rows=3)
+        data = synthutil.picture(seed, **kw)
+
+        def outcome(threads):
+            try:
+                return capi.parse_hevc(data, threads=threads)
+            except capi.HmError as e:
+                return str(e)
+        assert outcome(4) == outcome(1), (seed, kw)
+
+
 def test_record_order_follows_the_picture_class(hm):
     """which reconstruction kernel a picture is written for (hevc_syntax.h: quad_class): split chains (HM_PIC_SPLIT_CHAINS,
     k_recon_quad) for 8-bit pictures with CTBs of 32 / 64 and for every picture of a megapixel or more; decode order
