@@ -694,7 +694,8 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         const int vh = (ph - yo) < bh ? (ph - yo) : bh;
         const int q = lane & (LPR - 1), rr0 = lane / LPR;
         const bool col_ok = q * CW * PPW < vw;
-        GLOBAL_AS uint8_t* const gp = gptr_w<uint8_t>(plane + (size_t)yo * pitch + (size_t)(xo + q * CW * PPW) * sizeof(Pix));
+        // (a plane is smaller than 4 GiB: 32-bit offset arithmetic - 64-bit multiplies run at a quarter of the rate)
+        GLOBAL_AS uint8_t* const gp = gptr_w<uint8_t>(plane + (uint32_t)((uint32_t)yo * (uint32_t)pitch + (uint32_t)(xo + q * CW * PPW) * (uint32_t)sizeof(Pix)));
         for (int rb = 0; rb < vh; rb += RPT) {
           const int r = rb + rr0;
           if (col_ok && r < vh) {
@@ -716,7 +717,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       // (the picture's planes, pitches and size: from the wave's copy in LDS, see fdesc)
       auto f_plane = [&](int c) { return reinterpret_cast<uint8_t*>((uintptr_t)(((uint64_t)fdesc[2 * c + 1] << 32) | fdesc[2 * c])); };
       const int f_width = (int)fdesc[9], f_height = (int)fdesc[10];
-      const int planeWc = f_width >> 1, planeHc = f_height / sh;
+      const int planeWc = f_width >> 1, planeHc = sh == 2 ? f_height >> 1 : f_height; // (sh is 1 or 2: no division)
       if (fkind == 0) flush_plane(std::integral_constant<int, ctb>(), group_u(fg, 0), P0, lw, f_plane(0), (int)fdesc[6], ctb, f_width, f_height);
       else {
         flush_plane(std::integral_constant<int, (ctb >> 1)>(), group_u(fg, 1), P1, lw, f_plane(1), (int)fdesc[7], ch_c, planeWc, planeHc);

@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 CLASSES = {
     "8bit_420_ctb32": dict(log2_ctb=5),
+    "8bit_mono_ctb32": dict(log2_ctb=5, chroma_format=0),
     "8bit_420_ctb16": dict(log2_ctb=4),
     "8bit_420_ctb64": dict(log2_ctb=6),
     "10bit_420_ctb32": dict(log2_ctb=5, bit_depth=10),
@@ -34,6 +35,8 @@ def main():
         blobs = [capi.parse_hevc(synthutil.picture(7700000 + i, **cfg)) for i in range(8)]
         bps = 2 if cfg.get("bit_depth", 8) > 8 else 1
         cf = cfg.get("chroma_format", 1)
+        if os.environ.get("HM_CLASS_ONLY") and name not in os.environ["HM_CLASS_ONLY"].split(","):
+            continue
         ys, cs = L.hm_plane_stride(512, bps), L.hm_plane_stride(256, bps)
         ch = 256 if cf == 1 else 512
         y = torch.zeros((512, ys), dtype=torch.uint8, device=dev)
