@@ -1059,14 +1059,19 @@ class SliceWalker {
       if (xS < sbw - 1) prevCsbf |= csbf[yS][xS + 1];
       if (yS < sbw - 1) prevCsbf |= csbf[yS + 1][xS] << 1;
       const uint8_t* sig_inc = sig_tab.v[cIdx ? 1 : 0][log2 == 2 ? 0 : (log2 == 3 ? 1 : 2)][scanIdx][(xS | yS) ? 1 : 0][prevCsbf];
-      for (int n = startPos; n >= 0; n--) {
-        int sig;
-        if (n > 0 || !inferSbDcSig) {
-          sig = ec_.bin(CTX_SIG + (flat_sig_ctx ? (cIdx == 0 ? 42 : 43) : sig_inc[n]), K_SIG, n);
-          if (sig) inferSbDcSig = 0;
-        }
-        else sig = 1; // inferred: the only coefficient of a coded sub-block
-        if (sig) sigpos[nsig++] = n;
+      // (the flag's value is as good as random: its position is stored unconditionally and kept by advancing the count -
+      //  no branch on the bin)
+      const int flat_ctx = CTX_SIG + (cIdx == 0 ? 42 : 43);
+      for (int n = startPos; n > 0; n--) {
+        const int sig = ec_.bin(flat_sig_ctx ? flat_ctx : CTX_SIG + sig_inc[n], K_SIG, n);
+        sigpos[nsig] = n;
+        nsig += sig;
+      }
+      if (startPos >= 0) { // position 0: inferred when it is the only coefficient of a sub-block that was signalled as coded
+        int sig = 1;
+        if (!(inferSbDcSig && nsig == (i == lastSub ? 1 : 0))) sig = ec_.bin(flat_sig_ctx ? flat_ctx : CTX_SIG + sig_inc[0], K_SIG, 0);
+        sigpos[nsig] = 0;
+        nsig += sig;
       }
       if (nsig == 0) continue;
 
@@ -1078,10 +1083,13 @@ class SliceWalker {
       int gt1[16], gt2flag = 0;
       int firstGt1 = -1;
       const int ngt1 = std::min(nsig, 8);
+      const int gt1_ctx = CTX_GT1 + ctxSet * 4 + (cIdx ? 16 : 0);
       for (int k = 0; k < ngt1; k++) {
-        gt1[k] = ec_.bin(CTX_GT1 + ctxSet * 4 + c1 + (cIdx ? 16 : 0), K_GT1, k);
-        if (gt1[k]) { c1 = 0; if (firstGt1 < 0) firstGt1 = k; }
-        else if (c1 > 0 && c1 < 3) c1++;
+        const int b = ec_.bin(gt1_ctx + c1, K_GT1, k);
+        gt1[k] = b;
+        // (selects, not branches: c1 = 0 after a greater1 flag, else it counts up to 3 while it is 1 or 2)
+        firstGt1 = (b && firstGt1 < 0) ? k : firstGt1;
+        c1 = b ? 0 : c1 + ((c1 > 0) & (c1 < 3));
       }
       if (firstGt1 >= 0) gt2flag = ec_.bin(CTX_GT2 + ctxSet + (cIdx ? 4 : 0), K_GT2, 0);
 
@@ -1093,6 +1101,7 @@ class SliceWalker {
       signbits <<= (16 - nsign);
 
       // remaining levels
+      hm_coeff sub[16]; // the sub-block's levels, appended at once
       int rice = sps_.persistent_rice ? stat / 4 : 0, sumAbs = 0;
       bool first_remaining = true;
       for (int k = 0; k < nsig; k++) {
@@ -1126,11 +1135,10 @@ class SliceWalker {
         if (val > 32767) val = 32767; // |coeff| == 32768 only valid negative
         const int n = sigpos[k];
         const int xC = (xS << 2) + pos4[n].x, yC = (yS << 2) + pos4[n].y;
-        hm_coeff hc;
-        hc.pos = (uint16_t)(xC + yC * nT);
-        hc.value = (int16_t)val;
-        coeffs_->push_back(hc);
+        sub[k].pos = (uint16_t)(xC + yC * nT);
+        sub[k].value = (int16_t)val;
       }
+      coeffs_->insert(coeffs_->end(), sub, sub + nsig); // (one capacity check per sub-block)
     }
   }
 
