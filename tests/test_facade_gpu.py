@@ -190,6 +190,44 @@ def test_decoder_plugin_call_sequence(api, hm):
         api.heif_image_release(img)
 
 
+def test_plugin_driven_like_the_reference_drives_a_grid(api, hm):
+    """context.cc:2361-2401: the tiles of a grid, one decoder instance each, from a window of concurrent C++ tasks
+    (tests/synth/plugin_driver.cpp).  Behind decode_image the concurrent calls meet in the device's shared worker and
+    run as shared batches on several executor streams (picture.cpp): every tile of every round must still be the
+    oracle's, whatever was batched with what - pictures of different classes (8 / 10 bit, 4:2:0 / 4:2:2 / 4:0:0, ragged
+    sizes) mixed on purpose."""
+    import corpus
+    import hevcutil
+    import pluginapi
+    names = ["tile512_a", "hi422_10", "mono8", "ragged", "tile512_novui", "hi420_10", "conf_window", "ctb64_wpp"]
+    datas = [bytes(corpus.stream(n)) for n in names]
+    expected = []
+    for d in datas:
+        exp, info = orc.oracle_decode(hevcutil.parse(hm, d), 3, crop=True)
+        expected.append((exp, info))
+    saved = api.hm_get_decoder_plugin.restype
+    api.hm_get_decoder_plugin.restype = C.c_void_p
+    plugin_ptr = api.hm_get_decoder_plugin()
+    api.hm_get_decoder_plugin.restype = saved
+    tiles = [datas[i % len(datas)] for i in range(40)]
+    for threads in (8, 3, 1):
+        imgs = pluginapi.drive_grid(plugin_ptr, tiles, threads)
+        try:
+            for i, img in enumerate(imgs):
+                exp, info = expected[i % len(datas)]
+                wide = info["bit_depth"] > 8
+                for c in range(1 if info["chroma"] == 0 else 3):
+                    stride = C.c_int()
+                    ptr = api.heif_image_get_plane_readonly(img, c, C.byref(stride))
+                    w, hgt = api.heif_image_get_width(img, c), api.heif_image_get_height(img, c)
+                    raw = np.ctypeslib.as_array(ptr, shape=(hgt, stride.value))
+                    got = raw[:, :w * 2].copy().view(np.uint16).reshape(hgt, w) if wide else raw[:, :w].astype(np.uint16)
+                    np.testing.assert_array_equal(got, exp[c][:hgt, :w], err_msg=f"tile {i} ({names[i % len(datas)]}) plane {c}, {threads} threads")
+        finally:
+            for img in imgs:
+                api.heif_image_release(img)
+
+
 def test_strict_decoding_and_warnings(api, hm):
     """unknown VUI colour codes: a decoding warning + 'unspecified' without strict decoding, an error with it
     (HEIF_WARN_OR_FAIL, heif_plugin.h:290-301; decoder_libde265.cc:339-357; heif.cc:1223-1245, 1811-1905)"""
