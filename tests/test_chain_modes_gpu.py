@@ -52,3 +52,10 @@ def test_r02_kernel_still_selectable():
 def test_bounded_waits_flag_the_launch(cut):
     r = _run({"HM_CHAIN_PAIRS": str(cut), "HM_CHAIN_TEST_STALL": "1", "HM_CHAIN_SPIN_LIMIT": "2000"}, "tile512_a", timeout=120)
     assert r.returncode == 3 and "gave up waiting" in r.stdout, r.stdout + r.stderr
+
+
+def test_bounded_waits_with_several_waves_per_picture():
+    """the same fault injection when three waves take a picture's pairs of rows in turn: the wave that owns pair 0 keeps
+    its progress to itself, the others give up, the launch is flagged, nothing hangs"""
+    r = _run({"HM_CHAIN_SHARE": "3", "HM_CHAIN_TEST_STALL": "1", "HM_CHAIN_SPIN_LIMIT": "2000"}, "tile512_a", timeout=120)
+    assert r.returncode == 3 and "gave up waiting" in r.stdout, r.stdout + r.stderr
