@@ -6,6 +6,7 @@
 // (libheif/context.cc:2361-2401: one libde265 instance per tile, pasted into the shared canvas
 // by decode_and_paste_tile_image, context.cc:2407-2539).  Tiles are independent coded pictures,
 // so they become the workgroups of one launch.
+#include <cstdio>
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -846,6 +847,13 @@ int hm_batch_check(hm_batch* b)
     const hipError_t e = hipMemcpy(&flag, region + 1, sizeof(flag), hipMemcpyDeviceToHost);
     if (e != hipSuccess) return hm_check_hip(e, "hipMemcpy(reconstruction error flag)");
     bad |= flag != 0;
+    // HM_CHAIN_TIMING builds of chain.hip (tools/chain_timing.sh) leave per-phase cycle sums in words 2..7
+    static const bool timing = [] { const char* t = std::getenv("HM_CHAIN_TIMING_PRINT"); return t && t[0] == '1'; }();
+    if (timing) {
+      uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (hipMemcpy(w, region, sizeof(w), hipMemcpyDeviceToHost) == hipSuccess)
+        std::fprintf(stderr, "[k_chain phases, 64-cycle units summed over waves] A+poll %u, R+fetch %u, P+C %u, D %u, E+F %u, iterations %u\n", w[2], w[3], w[4], w[5], w[6], w[7]);
+    }
   }
   b->sync_used.clear();
   return bad ? hm_fail(HM_ERR_INTERNAL, "a reconstruction wave gave up waiting for the rows above it") : HM_OK;

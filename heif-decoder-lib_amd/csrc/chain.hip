@@ -40,6 +40,16 @@
 
 namespace {
 
+// HM_CHAIN_TIMING (tools/chain_timing.sh): per-phase cycle sums of the PAIRS kernel in words 2..7 of the launch's sync region
+#ifdef HM_CHAIN_TIMING
+#define HM_T_DECL unsigned long long t_prev = __builtin_amdgcn_s_memtime(); unsigned int t_acc[6] = {0, 0, 0, 0, 0, 0}
+#define HM_T_LAP(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_acc[i] += (unsigned int)(t_now - t_prev); t_prev = t_now; } while (0)
+#define HM_T_FLUSH() do { if (PAIRS && lane == 0) { for (int q = 0; q < 5; q++) atomicAdd(sync + 2 + q, t_acc[q] >> 6); atomicAdd(sync + 7, t_acc[5]); } } while (0)
+#else
+#define HM_T_DECL
+#define HM_T_LAP(i)
+#define HM_T_FLUSH()
+#endif
 #ifdef HM_MARKS
 #define HM_MARK(name) asm volatile("s_nop 0 ; HMMARK " name)
 #else
@@ -307,6 +317,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   // residual of the groups' current 8x8 blocks (lane = sample); not re-initialised per iteration: overwriting a register
   // means waiting for every load in flight
   uint32_t bres0 = 0, bres1 = 0, bres2 = 0, bres3 = 0;
+  HM_T_DECL;
   for (;;) {
     HM_MARK("A_begin");
     // ---- A: start the next CTU of every group whose dependency is met (the row above two CTUs ahead) ----
@@ -384,6 +395,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         if (ballot(st == ST_RUN) == 0) __builtin_amdgcn_s_sleep(8); // every chain of the wave waits
       }
     }
+    HM_T_LAP(0);
     if (ballot(st != ST_DONE) == 0) break;
 #if defined(HM_PAD_S) || defined(HM_PAD_V)
     if (lane0_dummy + pad_v == -12345) break; // (keeps the padding alive)
@@ -422,6 +434,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     const unsigned long long s_big = ballot(running && !quad);
     const unsigned long long s_bres = ballot(running && (op.y & OP_CBF) && (op.y & (3u << OP_L2_SHIFT)) == (1u << OP_L2_SHIFT));
 
+    HM_T_LAP(1);
     // ---- P: residual of the 8x8 blocks (lane = sample), requested before the side-by-side phase ----
     if (s_bres) {
       auto big_res = [&](int gg) -> uint32_t {
@@ -489,6 +502,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     }
     WAVE_SYNC();
 
+    HM_T_LAP(2);
     HM_MARK("D_begin");
     // ---- D: every other block, wave-wide, one group after the other ----
 #if defined(HM_Q_PROBE) && (HM_Q_PROBE & 2)
@@ -667,6 +681,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
 #endif
     }
 #endif
+    HM_T_LAP(3);
     HM_MARK("E_begin");
     // ---- E: the groups that executed a block move to the next record ----
     if (running) {
@@ -763,7 +778,12 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       }
     }
     WAVE_SYNC();
+    HM_T_LAP(4);
+#ifdef HM_CHAIN_TIMING
+    t_acc[5] += 1;
+#endif
   }
+  HM_T_FLUSH();
 }
 
 } // namespace
