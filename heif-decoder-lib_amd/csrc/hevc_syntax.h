@@ -282,7 +282,9 @@ class SliceWalker {
     const int rs = pps_.CtbAddrTStoRS[ts];
     ctb_addr_ts_ = ts;
     ctb_addr_rs_ = rs;
-    pic_.ctb_slice_addr[rs] = sh_.SliceAddrRS;
+    // (relaxed atomics: rows of tiles parsed side by side read the entries of their neighbours across the tile border -
+    //  with the same outcome whether the neighbour has been parsed yet or not, see slice_addr_of)
+    __atomic_store_n(&pic_.ctb_slice_addr[rs], sh_.SliceAddrRS, __ATOMIC_RELAXED);
     pic_.ctbs[rs].slice_idx = (uint16_t)slice_idx_;
     pic_.ctbs[rs].flags |= HM_CTB_CODED;
     coding_tree_unit(rs % W, rs / W);
@@ -386,6 +388,10 @@ class SliceWalker {
     if ((dx | dy) == 0) return tables::kZOrder4[(yN >> 2) & 15][(xN >> 2) & 15] <= tables::kZOrder4[(yCurr >> 2) & 15][(xCurr >> 2) & 15];
     return nb_ok_[(dy + 1) * 3 + dx + 1] != 0;
   }
+  // slice address of a CTB (-1: not parsed yet).  A neighbour across a tile border may be parsed by another thread at this
+  // moment (hevc_parse.cpp: parse_tiles_parallel): it belongs to the same slice segment, so "not yet" and its final value
+  // lead to the same decisions below.
+  int slice_addr_of(int rs) const { return __atomic_load_n(&pic_.ctb_slice_addr[rs], __ATOMIC_RELAXED); }
   void derive_ctb_neighbours()
   {
     const int cc = ctb_addr_rs_;
@@ -395,8 +401,8 @@ class SliceWalker {
         const int nx = ctb_x_ + dx, ny = ctb_y_ + dy;
         if (nx >= 0 && ny >= 0 && nx < sps_.ctb_w && ny < sps_.ctb_h) {
           const int cn = nx + ny * sps_.ctb_w;
-          ok = pps_.CtbAddrRStoTS[cn] <= ctb_addr_ts_ && pic_.ctb_slice_addr[cn] >= 0 &&
-               pic_.ctb_slice_addr[cn] == pic_.ctb_slice_addr[cc] && pps_.TileIdRS[cn] == pps_.TileIdRS[cc];
+          const int sn = slice_addr_of(cn);
+          ok = pps_.CtbAddrRStoTS[cn] <= ctb_addr_ts_ && sn >= 0 && sn == slice_addr_of(cc) && pps_.TileIdRS[cn] == pps_.TileIdRS[cc];
         }
         nb_ok_[(dy + 1) * 3 + dx + 1] = ok;
       }
@@ -425,14 +431,16 @@ class SliceWalker {
     if (x0 > 0) {
       const int nb = ctb_addr_rs_ - 1;
       bool ok = true;
-      if (!sh_.lf_across_slices && pic_.ctb_slice_addr[nb] >= 0 && pic_.ctb_slice_addr[nb] != sh_.SliceAddrRS) ok = false;
+      const int sn = slice_addr_of(nb);
+      if (!sh_.lf_across_slices && sn >= 0 && sn != sh_.SliceAddrRS) ok = false;
       else if (!pps_.lf_across_tiles && pps_.TileIdRS[nb] != pps_.TileIdRS[ctb_addr_rs_]) ok = false;
       if (ok) c.flags |= HM_CTB_DEBLOCK_LEFT;
     }
     if (y0 > 0) {
       const int nb = ctb_addr_rs_ - sps_.ctb_w;
       bool ok = true;
-      if (!sh_.lf_across_slices && pic_.ctb_slice_addr[nb] >= 0 && pic_.ctb_slice_addr[nb] != sh_.SliceAddrRS) ok = false;
+      const int sn = slice_addr_of(nb);
+      if (!sh_.lf_across_slices && sn >= 0 && sn != sh_.SliceAddrRS) ok = false;
       else if (!pps_.lf_across_tiles && pps_.TileIdRS[nb] != pps_.TileIdRS[ctb_addr_rs_]) ok = false;
       if (ok) c.flags |= HM_CTB_DEBLOCK_TOP;
     }
