@@ -60,9 +60,13 @@ constexpr int NG = 4;                       // groups per wave
 constexpr int C_SHARED_TABLES = 256;        // small tables (recon.hip layout: angles, inverse angles)
 constexpr int C_TAB4_BYTES = 35 * 16 * 2;   // per (mode, sample) of a 4x4 block: reference positions + weight
 constexpr int C_SHARED = (C_SHARED_TABLES + C_TAB4_BYTES + 15) & ~15;
-constexpr int C_RING = 16;                  // micro-ops per group: one window of 16 records
-constexpr int C_ITEM_DWORDS = 12;           // what a lane fetches per record: its micro-op (hm_dev_pic.mops) + the 16 residual samples of a 4x4 block (hm_dev_pic.res4)
-constexpr int C_RRES_BYTES = NG * 16 * 32;  // per group: the 4x4 residuals of the window
+#ifndef HM_CHAIN_WLOG
+#define HM_CHAIN_WLOG 3
+#endif
+constexpr int C_WLOG = HM_CHAIN_WLOG;        // log2 of the records per window: 4 (a record per lane) or 3 (half a record per lane: fewer registers, 1.5 KB less LDS per wave)
+constexpr int C_RING = 1 << C_WLOG;         // micro-ops per group: one window of records
+constexpr int C_ITEM_DWORDS = C_WLOG == 4 ? 12 : 6; // what a lane fetches: a record's micro-op (hm_dev_pic.mops) + the 16 residual samples of a 4x4 block (hm_dev_pic.res4), or half of that
+constexpr int C_RRES_BYTES = NG * C_RING * 32; // per group: the 4x4 residuals of the window
 constexpr int C_SCRATCH = 272;              // wave-wide path: reference samples (bA)
 constexpr int C_PROG = 8;                   // progress counters per chain kind: rows r and r + 8 share one (at most 4 rows of a wave are in flight)
 constexpr int C_FDESC_BYTES = 48; // behind a wave's progress counters: what the CTU flush needs of the picture's descriptor (planes, pitches, size)
@@ -110,10 +114,15 @@ enum { ST_START = 0, ST_RUN = 1, ST_DONE = 2 };
 typedef uint32_t c_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t c_u32x2 __attribute__((ext_vector_type(2)));
 
+// Waves per SIMD the register allocation aims for: five (<= 96 VGPRs) where that needs no spilling - 8-bit samples, a wave per
+// picture: the headline kernel, whose 7.6 KB of LDS per wave then allow 20 waves per CU instead of 16 -, four elsewhere
+// (16-bit samples and the few-pictures variants would spill a few registers).  HM_WPE overrides (A/B builds).
+template <typename Pix, bool PAIRS>
+constexpr int chain_waves_per_simd = (sizeof(Pix) == 1 && !PAIRS) ? 5 : 4;
 #ifdef HM_WPE
 #define HM_CHAIN_ATTR __attribute__((amdgpu_waves_per_eu(HM_WPE, HM_WPE)))
 #else
-#define HM_CHAIN_ATTR
+#define HM_CHAIN_ATTR __attribute__((amdgpu_waves_per_eu(chain_waves_per_simd<Pix, PAIRS>, chain_waves_per_simd<Pix, PAIRS>)))
 #endif
 template <typename Pix, int LOG2_CTB, bool PAIRS>
 __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* __restrict__ pics, int n_pics, CLayout L, uint32_t* __restrict__ sync)
@@ -230,7 +239,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   uint8_t* const lines_c = pbase + L.off_lines_c;
   int16_t* const l_bA = reinterpret_cast<int16_t*>(pbase + L.off_scratch);
   c_u32x4* const rings = reinterpret_cast<c_u32x4*>(pbase + L.off_rings); // [NG][C_RING]
-  int16_t* const rres = reinterpret_cast<int16_t*>(pbase + L.off_rres) + g_of(lane) * 256; // [16 records][16 samples] of the lane's group
+  int16_t* const rres = reinterpret_cast<int16_t*>(pbase + L.off_rres) + g_of(lane) * (C_RING * 16); // [records of the window][16 samples] of the lane's group
   // group -> (chain kind, row slot): luma / chroma of two rows, or luma of four rows (monochrome)
   auto group_kind = [&](int gg) { return mono ? 0 : (gg & 1); };
   auto group_slot = [&](int gg) { return mono ? gg : (gg >> 1); };
@@ -272,8 +281,8 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   int st = (row < ctb_h && my_slot < RPW && (kind_sel < 0 || kind == kind_sel)) ? ST_START : ST_DONE;
   uint32_t c0 = 0, c1 = 0; // header of the CTU to start next: first record of the chain, count
   uint32_t ri = 0;                 // index of the current block's record
-  uint32_t wdec = 0;               // the window (16 records: index >> 4) whose micro-ops and 4x4 residuals are in LDS
-  uint32_t pf[C_ITEM_DWORDS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // micro-op + 4x4 residual of record 16 * (wdec + 1) + gl, requested when window wdec was taken
+  uint32_t wdec = 0;               // the window (C_RING records: index >> C_WLOG) whose micro-ops and 4x4 residuals are in LDS
+  uint32_t pf[C_ITEM_DWORDS] = {}; // the lane's share of window wdec + 1 (micro-ops + 4x4 residuals), requested when window wdec was taken
   // PAIRS, first row of a pair: CTUs of the row above (the last row of the pair above, another wave's) whose bottom
   // sample line has been copied from the picture into this wave's line
   int hbm_have = 0, hbm_polls = 0;
@@ -284,12 +293,26 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   auto prog_index = [&](int r, int slot) { return PAIRS ? pbank * 4 + (slot & 3) : (r & (C_PROG - 1)); };
   bool from_hbm = PAIRS && my_slot == 0 && pidx > 0; // the row above belongs to another wave
   auto load_window = [&](uint32_t w) {
-    uint32_t idx = (w << 4) + (uint32_t)gl;
-    idx = idx < n_tus - 1 ? idx : n_tus - 1; // past the last record of the picture: re-read it (never executed)
-    const c_u32x4 m = *reinterpret_cast<const GLOBAL_AS c_u32x4*>(mops + (size_t)idx * 4);
-    const GLOBAL_AS uint32_t* const it = res4 + (size_t)idx * 8;
-    const c_u32x4 a = *reinterpret_cast<const GLOBAL_AS c_u32x4*>(it), b = *reinterpret_cast<const GLOBAL_AS c_u32x4*>(it + 4);
-    pf[0] = m.x; pf[1] = m.y; pf[2] = m.z; pf[3] = m.w; pf[4] = a.x; pf[5] = a.y; pf[6] = a.z; pf[7] = a.w; pf[8] = b.x; pf[9] = b.y; pf[10] = b.z; pf[11] = b.w;
+    if constexpr (C_WLOG == 4) { // a record per lane
+      uint32_t idx = (w << 4) + (uint32_t)gl;
+      idx = idx < n_tus - 1 ? idx : n_tus - 1; // past the last record of the picture: re-read it (never executed)
+      const c_u32x4 m = *reinterpret_cast<const GLOBAL_AS c_u32x4*>(mops + (size_t)idx * 4);
+      const GLOBAL_AS uint32_t* const it = res4 + (size_t)idx * 8;
+      const c_u32x4 a = *reinterpret_cast<const GLOBAL_AS c_u32x4*>(it), b = *reinterpret_cast<const GLOBAL_AS c_u32x4*>(it + 4);
+      pf[0] = m.x; pf[1] = m.y; pf[2] = m.z; pf[3] = m.w; pf[4] = a.x; pf[5] = a.y; pf[6] = a.z; pf[7] = a.w;
+      pf[C_ITEM_DWORDS - 4] = b.x; pf[C_ITEM_DWORDS - 3] = b.y; pf[C_ITEM_DWORDS - 2] = b.z; pf[C_ITEM_DWORDS - 1] = b.w;
+    }
+    else { // half a record per lane: even lanes the micro-op + residual samples 0-3, odd lanes samples 8-15 + 4-7
+      uint32_t idx = (w << 3) + (uint32_t)(gl >> 1);
+      idx = idx < n_tus - 1 ? idx : n_tus - 1;
+      const bool odd = (gl & 1) != 0;
+      const GLOBAL_AS uint32_t* const it = res4 + (size_t)idx * 8;
+      const GLOBAL_AS uint32_t* const pa = odd ? it + 4 : mops + (size_t)idx * 4; // 16 bytes
+      const GLOBAL_AS uint32_t* const pb = odd ? it + 2 : it;                      // 8 bytes
+      const c_u32x4 a = *reinterpret_cast<const GLOBAL_AS c_u32x4*>(pa);
+      const c_u32x2 b = *reinterpret_cast<const GLOBAL_AS c_u32x2*>(pb);
+      pf[0] = a.x; pf[1] = a.y; pf[2] = a.z; pf[3] = a.w; pf[4] = b.x; pf[5] = b.y;
+    }
   };
   auto header = [&](int r, int x) { // chain header of CTU (r, x): first record, count, flags
     // (32-bit index arithmetic: at most 2^20 CTBs of 13 dwords; 64-bit multiplies run at a quarter of the rate)
@@ -302,8 +325,8 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     if (gl == 0) __hip_atomic_store(my_progress + prog_index(row, my_slot), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     header(row, 0);
     ri = c0;
-    wdec = (ri >> 4) - 1; // (nothing of this row is in LDS yet)
-    load_window(ri >> 4);
+    wdec = (ri >> C_WLOG) - 1; // (nothing of this row is in LDS yet)
+    load_window(ri >> C_WLOG);
   };
   if (st == ST_START) row_start();
   // every iteration executes a block of some chain or waits for a CTU that is at most two CTUs of another chain away
@@ -406,16 +429,29 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     }
 
     HM_MARK("R_begin");
-    // ---- R: the micro-ops and 4x4 residuals of the next 16 records, for every group that has entered that window ----
+    // ---- R: the micro-ops and 4x4 residuals of the next window of records, for every group that has entered it ----
     {
-      const bool need_dec = st != ST_DONE && (ri >> 4) != wdec; // the chain has entered window wdec + 1: its records are in pf
+      const bool need_dec = st != ST_DONE && (ri >> C_WLOG) != wdec; // the chain has entered window wdec + 1: its records are in pf
       if (ballot(need_dec)) {
         if (need_dec) {
-          ring[gl] = c_u32x4{pf[0], pf[1], pf[2], pf[3]};
-          // the record's 16 residual samples (meaningful for 4x4 blocks with a residual)
-          c_u32x4* const rr = reinterpret_cast<c_u32x4*>(rres + gl * 16);
-          rr[0] = c_u32x4{pf[4], pf[5], pf[6], pf[7]};
-          rr[1] = c_u32x4{pf[8], pf[9], pf[10], pf[11]};
+          if constexpr (C_WLOG == 4) {
+            ring[gl] = c_u32x4{pf[0], pf[1], pf[2], pf[3]};
+            // the record's 16 residual samples (meaningful for 4x4 blocks with a residual)
+            c_u32x4* const rr = reinterpret_cast<c_u32x4*>(rres + gl * 16);
+            rr[0] = c_u32x4{pf[4], pf[5], pf[6], pf[7]};
+            rr[1] = c_u32x4{pf[C_ITEM_DWORDS - 4], pf[C_ITEM_DWORDS - 3], pf[C_ITEM_DWORDS - 2], pf[C_ITEM_DWORDS - 1]};
+          }
+          else {
+            uint32_t* const rr = reinterpret_cast<uint32_t*>(rres + (gl >> 1) * 16); // the record's 8 dwords of residual
+            if (gl & 1) {
+              *reinterpret_cast<c_u32x4*>(rr + 4) = c_u32x4{pf[0], pf[1], pf[2], pf[3]};
+              *reinterpret_cast<c_u32x2*>(rr + 2) = c_u32x2{pf[4], pf[5]};
+            }
+            else {
+              ring[gl >> 1] = c_u32x4{pf[0], pf[1], pf[2], pf[3]};
+              *reinterpret_cast<c_u32x2*>(rr) = c_u32x2{pf[4], pf[5]};
+            }
+          }
           wdec += 1;
         }
         // every lane: the window its group decodes next (groups that did not decode ask again for the same).  (Measured against
@@ -425,11 +461,11 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         WAVE_SYNC();
       }
     }
-    const bool running = st == ST_RUN && kleft > 0 && (ri >> 4) == wdec;
+    const bool running = st == ST_RUN && kleft > 0 && (ri >> C_WLOG) == wdec;
 
     // the current block of every group
     const c_u32x4 op = ring[ri & (C_RING - 1)];
-    const int16_t* const my_res = rres + (ri & 15) * 16; // the 16 residual samples of the group's block if it is a 4x4 block
+    const int16_t* const my_res = rres + (ri & (C_RING - 1)) * 16; // the 16 residual samples of the group's block if it is a 4x4 block
     const bool quad = running && (op.y & (3u << OP_L2_SHIFT)) == 0 && (op.y & OP_INTERIOR);
     const unsigned long long s_big = ballot(running && !quad);
     const unsigned long long s_bres = ballot(running && (op.y & OP_CBF) && (op.y & (3u << OP_L2_SHIFT)) == (1u << OP_L2_SHIFT));
@@ -542,7 +578,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         if (cbf) {
           if (L2 == 2) { // lanes 0-15: the block's 16 samples in the window's residuals of its group
             const int s_ri = __builtin_amdgcn_readlane((int)ri, src);
-            res_s = (int)(reinterpret_cast<const int16_t*>(pbase + L.off_rres) + bg * 256 + (s_ri & 15) * 16)[ln & 15];
+            res_s = (int)(reinterpret_cast<const int16_t*>(pbase + L.off_rres) + bg * (C_RING * 16) + (s_ri & (C_RING - 1)) * 16)[ln & 15];
           }
           else if (L2 == 3) {
             uint32_t b = bg == 0 ? bres0 : (bg == 1 ? bres1 : (bg == 2 ? bres2 : bres3));
