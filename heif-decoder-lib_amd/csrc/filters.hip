@@ -885,7 +885,11 @@ struct TailCoef { int r_cr, g_cb, g_cr, b_cb; };
 #endif
 constexpr int TAIL_TW = 128, TAIL_TH = HM_TAIL_TH;
 constexpr int TAIL_THREADS = TAIL_TW * TAIL_TH / 32; // one lane per 8 x 2 luma samples of two cells; 4 or 8 waves
+#ifdef HM_TAIL_MINW
+constexpr int TAIL_MINW = HM_TAIL_MINW; // (A/B builds)
+#else
 constexpr int TAIL_MINW = TAIL_THREADS == 256 ? 4 : 2;
+#endif
 constexpr int TAIL_XO = 8;                   // the LDS tiles start 8 samples left of the tile, 4 rows above it
 constexpr int TAIL_LP = 144, TAIL_LR = TAIL_TH + 8;   // luma tile: pitch, rows
 constexpr int TAIL_CP = 80, TAIL_CR = TAIL_TH / 2 + 8;    // chroma tiles

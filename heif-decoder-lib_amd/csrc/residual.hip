@@ -110,7 +110,12 @@ __device__ __forceinline__ void big_residual(int16_t* coeff, int16_t* tmp, const
   WAVE_SYNC();
 }
 
-__global__ __launch_bounds__(R_WAVES * 64) void k_residual(const hm_dev_pic* __restrict__ pics, int n_pics, int max_ctb_h)
+#ifdef HM_R_WPE
+#define HM_R_ATTR __attribute__((amdgpu_waves_per_eu(HM_R_WPE, HM_R_WPE)))
+#else
+#define HM_R_ATTR
+#endif
+__global__ __launch_bounds__(R_WAVES * 64) HM_R_ATTR void k_residual(const hm_dev_pic* __restrict__ pics, int n_pics, int max_ctb_h)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = rfl(tid >> 6);
