@@ -684,6 +684,48 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         WAVE_SYNC();
         continue;
       }
+      else if (oy & OP_FAST8) {
+        // ---- ... and the same block with planar (chroma: luma planar blocks are smoothed), DC, pure horizontal or pure
+        //      vertical prediction (intrapred.h:262-336): the formulas of predict_emit<> on samples read in place ----
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int x = ln & 7, y = ln >> 3;
+        const int nL1 = (int)((oy >> OP_NL1_SHIFT) & 63), nT1 = (int)((oy >> OP_NT1_SHIFT) & 63);
+        const int t = tp[x], l = lp[mul24(y, P)]; // the sample above the lane's column / left of its row
+        int v;
+        if (mode == 0) v = planar_sample<3>(x, y, l, t, tp[imin_(8, nT1)], lp[mul24(imin_(8, nL1), P)]);
+        else if (mode == 1) {
+          int s2 = ln < 8 ? t : (ln < 16 ? (int)lp[mul24(ln - 8, P)] : 0); // lanes 0-7: the top row, 8-15: the left column
+          s2 += dpp<DPP_ROW_ROR(8)>(s2);
+          s2 += dpp<DPP_ROW_ROR(4)>(s2);
+          s2 += dpp<DPP_ROW_ROR(2)>(s2);
+          s2 += dpp<DPP_ROW_ROR(1)>(s2);
+          const int dc = (__builtin_amdgcn_readlane(s2, 0) + 8) >> 4;
+          v = dc;
+          if (c == 0) { // luma: smoothed first row / column
+            v = y == 0 ? (t + 3 * dc + 2) >> 2 : v;
+            v = x == 0 ? (l + 3 * dc + 2) >> 2 : v;
+            v = (x | y) == 0 ? (l + 2 * dc + t + 2) >> 2 : v;
+          }
+        }
+        else { // 10 / 26: a copy of the left column / the top row; luma: the gradient on the first row / column
+          const bool vert = mode == 26;
+          v = vert ? t : l;
+          if (c == 0) {
+            const int corner = tp[-1];
+            const int gq = vert ? (int)tp[0] + ((l - corner) >> 1) : (int)lp[0] + ((t - corner) >> 1);
+            v = (vert ? x == 0 : y == 0) ? clip3i(0, maxv, gq) : v;
+          }
+        }
+        if (cbf) {
+          uint32_t b = bg == 0 ? bres0 : (bg == 1 ? bres1 : (bg == 2 ? bres2 : bres3));
+          asm volatile("" : "+v"(b)); // keeps the select - and the wait for the load - inside this branch
+          v = clip3i(0, maxv, v + (int)b);
+        }
+        dst[mul24(y, P) + x] = (Pix)v;
+        WAVE_SYNC();
+        continue;
+      }
 #endif
 #if defined(HM_Q_PROBE) && (HM_Q_PROBE & 96)
       { // class probes: 32 = only the blocks of the one-pass path (4x4 / 8x8, interior, not smoothed), 64 = only the others
