@@ -726,6 +726,35 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         WAVE_SYNC();
         continue;
       }
+      else if ((oy & OP_INTERIOR) && log2 == 3 && c == 0) {
+        // ---- luma 8x8, neighbours complete, reference samples SMOOTHED (intrapred.h:192-260): planar and the three
+        //      diagonals 2 / 18 / 34 (the other modes of such a block took the paths above).  The 33 reference samples, one per
+        //      lane, with their neighbours from the lanes next door; the diagonals copy one smoothed sample per position. ----
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int nL1 = (int)((oy >> OP_NL1_SHIFT) & 63), nT1 = (int)((oy >> OP_NT1_SHIFT) & 63);
+        const int j = ln < 32 ? ln - 16 : 16; // -16 .. 16: left column upwards from the bottom, corner, top row (lanes 33-63: idle copies of the end)
+        const Pix* const ql = lp + mul24_raw(imin_(-j - 1, nL1), P);
+        const Pix* const qt = tp + imin_(j - 1, nT1);
+        const int p = *(j < 0 ? ql : qt);
+        const int pm = dpp<0x138>(p), pp = dpp<0x130>(p); // wave_shr:1 / wave_shl:1: the samples at j - 1 / j + 1
+        const int pf = (j == -16 || j == 16) ? p : (pm + 2 * p + pp + 2) >> 2; // (the two ends stay as they are)
+        int16_t* const bc = l_bA + 64;
+        if (ln <= 32) bc[j] = (int16_t)pf;
+        WAVE_SYNC();
+        const int x = ln & 7, y = ln >> 3;
+        int v;
+        if (mode == 0) v = planar_sample<3>(x, y, bc[-1 - y], bc[1 + x], bc[9], bc[-9]);
+        else v = bc[mode == 34 ? x + y + 2 : (mode == 2 ? -(x + y + 2) : x - y)]; // angle +-32: weight 0, one sample
+        if (cbf) {
+          uint32_t b = bg == 0 ? bres0 : (bg == 1 ? bres1 : (bg == 2 ? bres2 : bres3));
+          asm volatile("" : "+v"(b)); // keeps the select - and the wait for the load - inside this branch
+          v = clip3i(0, maxv, v + (int)b);
+        }
+        dst[mul24(y, P) + x] = (Pix)v;
+        WAVE_SYNC();
+        continue;
+      }
 #endif
 #if defined(HM_Q_PROBE) && (HM_Q_PROBE & 96)
       { // class probes: 32 = only the blocks of the one-pass path (4x4 / 8x8, interior, not smoothed), 64 = only the others
