@@ -614,6 +614,27 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
           R.nL1 = (int)((oy >> OP_NL1_SHIFT) & 63); R.nT1 = (int)((oy >> OP_NT1_SHIFT) & 63);
           predict_emit<Pix, L2>(B, R, tab, ln, emit);
         }
+        else if (L2 == 4 && (oy & OP_INTERIOR)) {
+          // 16x16, neighbours complete: the 65 reference samples one per lane (and the last one by all), smoothed - where the
+          // mode asks for it - with the neighbours from the lanes next door; the prediction reads them from the array
+          RefDirect<Pix> R;
+          R.lp = lp; R.tp = tp; R.P = P;
+          R.nL1 = (int)((oy >> OP_NL1_SHIFT) & 63); R.nT1 = (int)((oy >> OP_NT1_SHIFT) & 63);
+          const int j = ln - 32;
+          const int p = R(j), p_end = R(32);
+          int pf = p;
+          if (smoothed) { // [1 2 1], the two ends stay as they are (intrapred.h:231-260)
+            const int pm = dpp<0x138>(p); // wave_shr:1: the sample at j - 1
+            int pp = dpp<0x130>(p);       // wave_shl:1: the sample at j + 1
+            pp = ln == 63 ? p_end : pp;
+            pf = j == -32 ? p : (pm + 2 * p + pp + 2) >> 2;
+          }
+          int16_t* const bc = l_bA + 64;
+          bc[j] = (int16_t)pf;
+          if (ln == 0) bc[32] = (int16_t)p_end;
+          WAVE_SYNC();
+          predict_emit<Pix, L2>(B, RefArray{bc}, tab, ln, emit);
+        }
         else {
           // the availability word of the full record (left | below-left << 8 | top << 16 | top-right << 24): complete runs = nT
           constexpr uint32_t nT = 1u << L2;
