@@ -635,6 +635,26 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
           WAVE_SYNC();
           predict_emit<Pix, L2>(B, RefArray{bc}, tab, ln, emit);
         }
+        else if (L2 == 2) {
+          // 4x4 at a picture / slice / tile border (the interior ones took the side-by-side path): the substitution process of
+          // 8.4.4.2.2 on a 17-bit availability mask (scalar) - an unavailable sample takes the nearest available one before
+          // it in the order bottom-left ... corner ... top-right, the leading ones the first available one - one sample per lane
+          const uint32_t avail = ((ow & OPW_LEFT) ? 0xF0u : 0u) | (((ow >> OPW_BL_SHIFT) & 15) ? 0x0Fu : 0u) | ((ow & OPW_TL) ? 0x100u : 0u) |
+                                 ((ow & OPW_TOP) ? 0x1E00u : 0u) | (((ow >> OPW_TR_SHIFT) & 15) ? 0x1E000u : 0u);
+          const int b = ln < 16 ? ln : 16; // bit of the lane's sample: j = b - 8
+          const uint32_t lower = avail & ((1u << b) - 1u);
+          const int first = avail ? (int)__builtin_ctz(avail) : 0;
+          const int from = ((avail >> b) & 1u) ? b : (lower ? 31 - (int)__builtin_clz(lower) : first);
+          const int j = from - 8;
+          const Pix* const ql = lp + mul24_raw(-j - 1, P);
+          const Pix* const qt = tp + (j - 1);
+          int pv = *(j < 0 ? ql : qt);
+          pv = avail ? pv : 1 << (bd - 1); // nothing around: the mid value
+          int16_t* const bc = l_bA + 64;
+          if (ln <= 16) bc[ln - 8] = (int16_t)pv;
+          WAVE_SYNC();
+          predict_emit<Pix, L2>(B, RefArray{bc}, tab, ln, emit);
+        }
         else {
           // the availability word of the full record (left | below-left << 8 | top << 16 | top-right << 24): complete runs = nT
           constexpr uint32_t nT = 1u << L2;
