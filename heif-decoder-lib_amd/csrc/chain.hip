@@ -432,7 +432,9 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     // ---- R: the micro-ops and 4x4 residuals of the next window of records, for every group that has entered it ----
     {
       const bool need_dec = st != ST_DONE && (ri >> C_WLOG) != wdec; // the chain has entered window wdec + 1: its records are in pf
-      if (ballot(need_dec)) {
+      // (lane masks of conjunctions: the masks of the single compares, combined by the scalar unit - the mask of a boolean
+      //  expression costs two more vector instructions, a select and a compare)
+      if (ballot(st != ST_DONE) & ballot((ri >> C_WLOG) != wdec)) {
         if (need_dec) {
           if constexpr (C_WLOG == 4) {
             ring[gl] = c_u32x4{pf[0], pf[1], pf[2], pf[3]};
@@ -467,8 +469,9 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     const c_u32x4 op = ring[ri & (C_RING - 1)];
     const int16_t* const my_res = rres + (ri & (C_RING - 1)) * 16; // the 16 residual samples of the group's block if it is a 4x4 block
     const bool quad = running && (op.y & (3u << OP_L2_SHIFT)) == 0 && (op.y & OP_INTERIOR);
-    const unsigned long long s_big = ballot(running && !quad);
-    const unsigned long long s_bres = ballot(running && (op.y & OP_CBF) && (op.y & (3u << OP_L2_SHIFT)) == (1u << OP_L2_SHIFT));
+    const unsigned long long m_running = ballot(st == ST_RUN) & ballot(kleft > 0) & ballot((ri >> C_WLOG) == wdec);
+    const unsigned long long s_big = m_running & ~ballot((op.y & ((3u << OP_L2_SHIFT) | OP_INTERIOR)) == OP_INTERIOR);
+    const unsigned long long s_bres = m_running & ballot((op.y & (OP_CBF | (3u << OP_L2_SHIFT))) == (OP_CBF | (1u << OP_L2_SHIFT)));
 
     HM_T_LAP(1);
     // ---- P: residual of the 8x8 blocks (lane = sample), requested before the side-by-side phase ----
@@ -839,7 +842,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
 
     HM_MARK("F_begin");
     // ---- F: finished CTUs: coalesced stores to the picture, bottom row -> line, right column -> left column ----
-    for (unsigned long long fin = ballot(st == ST_RUN && kleft == 0); fin;) {
+    for (unsigned long long fin = ballot(st == ST_RUN) & ballot(kleft == 0); fin;) {
       const int fg = rfl((int)(__builtin_ctzll(fin) >> 4));
       fin &= ~(0xFFFFull << (fg * 16));
       const int src = fg * 16;
