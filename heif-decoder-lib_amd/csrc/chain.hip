@@ -316,7 +316,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   };
   auto header = [&](int r, int x) { // chain header of CTU (r, x): first record, count, flags
     // (32-bit index arithmetic: at most 2^20 CTBs of 13 dwords; 64-bit multiplies run at a quarter of the rate)
-    const GLOBAL_AS uint32_t* q = ctbq + (uint32_t)mul24(mul24(r, ctb_w) + x, HM_CTB_DWORDS);
+    const GLOBAL_AS uint32_t* q = ctbq + (uint32_t)mul24_raw(mul24_raw(r, ctb_w) + x, HM_CTB_DWORDS);
     c0 = q[kind ? 9 : 0]; c1 = q[kind ? 10 : 1]; // (masked where they are used: no wait for the loads here)
   };
   auto row_start = [&]() { // header of CTU (row, 0) and the first window of the row's chain

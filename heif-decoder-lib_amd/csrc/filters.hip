@@ -37,6 +37,20 @@ namespace {
 #endif
 
 __device__ __forceinline__ int clip3i(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+// Loads and stores through pointers of the global address space: a generic (flat) access also counts as an LDS access for
+// s_waitcnt - a wait for the LDS then waits for the trip to memory as well.
+#define GLOBAL_AS __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ const GLOBAL_AS T* gptr(const void* p) { return (const GLOBAL_AS T*)(uintptr_t)p; }
+template <typename T>
+__device__ __forceinline__ GLOBAL_AS T* gptr_w(void* p) { return (GLOBAL_AS T*)(uintptr_t)p; }
+// the 24-bit multiply itself, for operands the compiler cannot bound (it then picks a 64-bit multiply-add: a quarter of the rate)
+__device__ __forceinline__ int mul24_raw(int a, int b)
+{
+  int d;
+  asm("v_mul_i32_i24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
 __device__ __forceinline__ int iabs_(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int isign_(int v) { return (v > 0) - (v < 0); }
 __device__ __forceinline__ int imin_(int a, int b) { return a < b ? a : b; }
@@ -119,7 +133,7 @@ __device__ __forceinline__ void filter_luma(Win& W, const int beta2[2], const in
     const int dq3 = iabs_(W.template at<V>(o + 3, 6) - 2 * W.template at<V>(o + 3, 5) + W.template at<V>(o + 3, 4));
     const int d0 = dp0 + dq0, d3 = dp3 + dq3;
     if (d0 + d3 >= beta) continue;
-    const int beta_3 = beta >> 3, beta_2 = beta >> 2, tc25 = (tc * 5 + 1) >> 1;
+    const int beta_3 = beta >> 3, beta_2 = beta >> 2, tc25 = ((tc << 2) + tc + 1) >> 1;
     if (iabs_(W.template at<V>(o, 0) - W.template at<V>(o, 3)) + iabs_(W.template at<V>(o, 7) - W.template at<V>(o, 4)) < beta_3 &&
         iabs_(W.template at<V>(o, 3) - W.template at<V>(o, 4)) < tc25 &&
         iabs_(W.template at<V>(o + 3, 0) - W.template at<V>(o + 3, 3)) + iabs_(W.template at<V>(o + 3, 7) - W.template at<V>(o + 3, 4)) < beta_3 &&
@@ -217,7 +231,7 @@ struct TabLds {
 __device__ __forceinline__ uint32_t meta_at(const hm_dev_pic& dp, int x, int y)
 {
   const int bx = x < 0 ? 0 : ((x >> 2) < dp.w4 ? (x >> 2) : dp.w4 - 1), by = y < 0 ? 0 : ((y >> 2) < dp.h4 ? (y >> 2) : dp.h4 - 1);
-  return dp.meta[bx + (size_t)by * dp.w4];
+  return gptr<uint16_t>(dp.meta)[(uint32_t)(bx + mul24_raw(by, dp.w4))]; // (32-bit index: at most 4096 x 4096 blocks; 64-bit multiplies run at a quarter of the rate)
 }
 template <typename Pix, bool PCMF, typename Tab>
 __device__ __forceinline__ bool window_edges(const hm_dev_pic& dp, const PicView& v, int c, int kx, int ky, int sw, int sh, WindowEdges<PCMF>& E, const Tab& tab)
@@ -266,7 +280,13 @@ __device__ __forceinline__ bool window_edges(const hm_dev_pic& dp, const PicView
     const int sx = vertical ? ex : (j ? ex : ex - 8), sy = vertical ? (j ? ey : ey - 8) : ey;
     const int lsx = sx * sw, lsy = sy * sh, lux = ux * sw, luy = uy * sh;
     // one slice (the usual case): no CTB -> slice look-up, and the offsets come through the scalar cache
-    const hm_slice& sl = dp.n_slices == 1 ? v.slices[0] : slice_at(dp, v, lsx, lsy);
+    hm_slice sl; // (a copy through a global-address-space pointer: no flat loads)
+    if (dp.n_slices == 1) {
+      const GLOBAL_AS uint32_t* const sw = gptr<uint32_t>(v.slices);
+      uint32_t w3[3] = {sw[0], sw[1], sw[2]};
+      __builtin_memcpy(&sl, w3, sizeof(sl));
+    }
+    else sl = slice_at(dp, v, lsx, lsy);
     const int QP_Q = qq[vertical][j], QP_P = qp[vertical][j];
     if (c == 0) {
       const int qPL = (QP_Q + QP_P + 1) >> 1;
@@ -321,7 +341,8 @@ __device__ __forceinline__ void window_load(Window<Pix>& win, const uint8_t* pla
 #pragma unroll
   for (int r = 0; r < 8; r++) {
     const int y = oy + r < 0 ? 0 : (oy + r < PH ? oy + r : PH - 1);
-    __builtin_memcpy(win.w[r], plane + (size_t)y * pitch + (ptrdiff_t)ox * (int)sizeof(Pix), 8 * sizeof(Pix));
+    // (a plane is smaller than 2 GiB: 32-bit offsets)
+    __builtin_memcpy(win.w[r], gptr<uint8_t>(plane + (ptrdiff_t)(int32_t)(mul24_raw(y, pitch) + ox * (int)sizeof(Pix))), 8 * sizeof(Pix));
   }
 }
 typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -390,7 +411,7 @@ __device__ __forceinline__ void filter_luma_pk(Window<uint8_t>& W, const int bet
     const int dp0 = (int)(dp & 0xFFFF), dp3 = (int)(dp >> 16), dq0 = (int)(dq & 0xFFFF), dq3 = (int)(dq >> 16);
     const int d0 = dp0 + dq0, d3 = dp3 + dq3;
     if (d0 + d3 >= beta) return;
-    const int beta_3 = beta >> 3, beta_2 = beta >> 2, tc25 = (tc * 5 + 1) >> 1;
+    const int beta_3 = beta >> 3, beta_2 = beta >> 2, tc25 = ((tc << 2) + tc + 1) >> 1;
     const uint32_t flat = as_w(pk_abs(C[0] - C[3]) + pk_abs(C[7] - C[4])), step = as_w(pk_abs(C[3] - C[4]));
     const bool strong = (int)(flat & 0xFFFF) < beta_3 && (int)(flat >> 16) < beta_3 && (int)(step & 0xFFFF) < tc25 && (int)(step >> 16) < tc25 &&
                         (d0 << 1) < beta_2 && (d3 << 1) < beta_2;
@@ -897,7 +918,7 @@ constexpr int TAIL_CP = 80, TAIL_CR = TAIL_TH / 2 + 8;    // chroma tiles
 // a group of 8 samples of LDS tile row `row` (already clamped into the picture) at tile column xo, with its side dwords
 __device__ __forceinline__ void tail_row(SaoRow<uint8_t>& R, const uint8_t* tile, int pitch, int row, int xo)
 {
-  const uint8_t* q = tile + row * pitch + xo;
+  const uint8_t* q = tile + (mul24_raw(row, pitch) + xo);
   uint32_t d[2];
   __builtin_memcpy(d, q, 8);
   R.p[0] = __builtin_amdgcn_perm(0, d[0], 0x0c010c00u); R.p[1] = __builtin_amdgcn_perm(0, d[0], 0x0c030c02u);
@@ -920,7 +941,7 @@ __device__ __forceinline__ void tail_sao(const hm_dev_pic& dp, const PicView& v,
 #pragma unroll
   for (int r = 0; r < NR; r++) {
     const int yy = yy0 + r, yc = yy < Hh ? yy : Hh - 1, cy = yy >> l2h;
-    const uint32_t* cbq = reinterpret_cast<const uint32_t*>(v.ctbs + (cx + (yc >> l2h) * dp.ctb_w)); // hm_ctb as dwords
+    const GLOBAL_AS uint32_t* cbq = gptr<uint32_t>(reinterpret_cast<const uint8_t*>(v.ctbs) + (uint32_t)mul24_raw(cx + mul24_raw(yc >> l2h, dp.ctb_w), (int)sizeof(hm_ctb))); // hm_ctb as dwords (32-bit offset)
     const uint32_t cflags = cbq[2], s0 = cbq[3 + 2 * c], s1 = cbq[4 + 2 * c];
     const SaoRow<uint8_t>&up = rows[r], &cur = rows[r + 1], &dn = rows[r + 2];
     const bool sao_on = apply_sao && (dp.flags & HM_PIC_SAO_ENABLED) && (cflags & (c == 0 ? HM_CTB_SAO_LUMA : HM_CTB_SAO_CHROMA));
@@ -1010,7 +1031,7 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
           for (int r = 0; r < 8; r++) {
             const int y = oy + r < 0 ? 0 : (oy + r < PH ? oy + r : PH - 1);
             win.w[r][0] = 0;
-            __builtin_memcpy(&win.w[r][1], dp.plane[c] + (size_t)y * dp.pitch[c], 4);
+            win.w[r][1] = *gptr<uint32_t>(dp.plane[c] + (uint32_t)mul24_raw(y, dp.pitch[c]));
           }
         }
 #if !defined(HM_T_PROBE) || !(HM_T_PROBE & 1)
@@ -1120,11 +1141,11 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
           }
         }
       }
-      uint8_t* o0 = D.rgb + (size_t)ly * D.pitch + (size_t)lx * BPP;
+      uint8_t* o0 = D.rgb + (uint32_t)(mul24_raw(ly, D.pitch) + lx * BPP); // (an image is smaller than 4 GiB)
       const int nvalid = cw - lx < 8 ? cw - lx : 8;
       if (nvalid == 8) {
-        __builtin_memcpy(o0, o[0], 8 * BPP);
-        if (ly + 1 < chh) __builtin_memcpy(o0 + D.pitch, o[1], 8 * BPP);
+        __builtin_memcpy(gptr_w<uint8_t>(o0), o[0], 8 * BPP);
+        if (ly + 1 < chh) __builtin_memcpy(gptr_w<uint8_t>(o0 + D.pitch), o[1], 8 * BPP);
       }
       else {
 #pragma unroll
