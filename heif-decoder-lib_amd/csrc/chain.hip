@@ -228,9 +228,11 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   if (PAIRS && (pair_index * RPW >= ctb_h || (mono && kind_sel == 1))) return;
   const int W = PAIRS ? L.bands_per_pic : 1; // waves that share this picture's bands (per chain kind)
   // PAIRS: progress words of this picture's pairs ([pair][chain kind]); this pair reads those of the pair above
-  uint32_t* const pair_progress = PAIRS ? sync + SYNC_PROGRESS + 2 * ((size_t)pic_index * L.passes) : nullptr;
+  // (global-address-space pointers: a generic access would also count as an LDS access, and the waits for the LDS then
+  //  wait for these trips to memory)
+  GLOBAL_AS uint32_t* const pair_progress = PAIRS ? gptr_w<uint32_t>(sync + SYNC_PROGRESS + 2 * ((size_t)pic_index * L.passes)) : nullptr;
   // ... and the hand-over lines (hm_device.h: hm_dev_pic.hand): per pair the bottom sample line of its last row, luma, Cb, Cr
-  uint32_t* const hand_words = reinterpret_cast<uint32_t*>(dp.hand);
+  GLOBAL_AS uint32_t* const hand_words = gptr_w<uint32_t>(dp.hand);
   const uint32_t hand_luma_words = (uint32_t)(ctb_w * ctb) * sizeof(Pix) / 4, hand_chroma_words = mono ? 0u : (uint32_t)Wc * sizeof(Pix) / 4;
   const uint32_t hand_pair_words = hand_luma_words + 2 * hand_chroma_words;
 
@@ -394,12 +396,12 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
           Pix* const lw = line_of(ckind, NR - 1); // the line the pair's first row reads: that of the row above
           // CTUs [s_have, s_avail) of the hand-over line of the pair above: whole 32-bit words
           constexpr int PPW = 4 / sizeof(Pix);
-          auto copy_line = [&](const uint32_t* words, int ctu_w, Pix* line) {
+          auto copy_line = [&](const GLOBAL_AS uint32_t* words, int ctu_w, Pix* line) {
             const int w0 = s_have * ctu_w / PPW, w1 = s_avail * ctu_w / PPW;
             for (int w = w0 + lane; w < w1; w += 64)
               *reinterpret_cast<uint32_t*>(line + w * PPW) = __hip_atomic_load(words + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           };
-          const uint32_t* const hand = hand_words + (size_t)(s_pidx - 1) * hand_pair_words;
+          const GLOBAL_AS uint32_t* const hand = hand_words + (size_t)(s_pidx - 1) * hand_pair_words;
           if (ckind == 0) copy_line(hand, ctb, lw);
           else {
             copy_line(hand + hand_luma_words, cw_c, lw);
@@ -899,8 +901,8 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         // wave (vmcnt 0) the word that announces them follows
         constexpr int PPW = 4 / sizeof(Pix);
         const int s_pidx = __builtin_amdgcn_readlane(pidx, src);
-        uint32_t* const hand = hand_words + (size_t)s_pidx * hand_pair_words;
-        auto put_line = [&](uint32_t* words, int ctu_w, const Pix* u, int P, int bh) { // the bottom row of the CTU buffer
+        GLOBAL_AS uint32_t* const hand = hand_words + (size_t)s_pidx * hand_pair_words;
+        auto put_line = [&](GLOBAL_AS uint32_t* words, int ctu_w, const Pix* u, int P, int bh) { // the bottom row of the CTU buffer
           const int w0 = s_cx * ctu_w / PPW, nw = ctu_w / PPW; // (at most 32 words: a CTU row of 64 16-bit samples)
           if (lane < nw) __hip_atomic_store(words + w0 + lane, *reinterpret_cast<const uint32_t*>(u + (bh - 1) * P + UPAD + lane * PPW), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
