@@ -51,6 +51,14 @@ __device__ __forceinline__ int mul24_raw(int a, int b)
   asm("v_mul_i32_i24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
   return d;
 }
+// a * K + c with a small constant K as ONE full-rate instruction (written as C the compiler forms v_mad_u64_u32: a quarter of the rate)
+template <int K>
+__device__ __forceinline__ int mad24_k(int a, int c)
+{
+  int d;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "n"(K), "v"(c));
+  return d;
+}
 __device__ __forceinline__ int iabs_(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int isign_(int v) { return (v > 0) - (v < 0); }
 __device__ __forceinline__ int imin_(int a, int b) { return a < b ? a : b; }
@@ -133,7 +141,7 @@ __device__ __forceinline__ void filter_luma(Win& W, const int beta2[2], const in
     const int dq3 = iabs_(W.template at<V>(o + 3, 6) - 2 * W.template at<V>(o + 3, 5) + W.template at<V>(o + 3, 4));
     const int d0 = dp0 + dq0, d3 = dp3 + dq3;
     if (d0 + d3 >= beta) continue;
-    const int beta_3 = beta >> 3, beta_2 = beta >> 2, tc25 = ((tc << 2) + tc + 1) >> 1;
+    const int beta_3 = beta >> 3, beta_2 = beta >> 2, tc25 = mad24_k<5>(tc, 1) >> 1;
     if (iabs_(W.template at<V>(o, 0) - W.template at<V>(o, 3)) + iabs_(W.template at<V>(o, 7) - W.template at<V>(o, 4)) < beta_3 &&
         iabs_(W.template at<V>(o, 3) - W.template at<V>(o, 4)) < tc25 &&
         iabs_(W.template at<V>(o + 3, 0) - W.template at<V>(o + 3, 3)) + iabs_(W.template at<V>(o + 3, 7) - W.template at<V>(o + 3, 4)) < beta_3 &&
@@ -237,7 +245,7 @@ template <typename Pix, bool PCMF, typename Tab>
 __device__ __forceinline__ bool window_edges(const hm_dev_pic& dp, const PicView& v, int c, int kx, int ky, int sw, int sh, WindowEdges<PCMF>& E, const Tab& tab)
 {
   const int bd = dp.bit_depth, bdscale = 1 << (bd - 8);
-  const int PW = dp.width / sw, PH = dp.height / sh;                  // plane size
+  const int PW = dp.width >> (sw >> 1), PH = dp.height >> (sh >> 1);  // plane size (sw, sh are 1 or 2: a shift, not a division)
   const int ex = kx << 3, ey = ky << 3, ox = ex - 4, oy = ey - 4;   // the crossing and the window origin (plane samples)
   // the four edge units: vertical edge x = ex, rows oy.. (j = 0) and ey.. (j = 1); horizontal edge y = ey, columns ox.. / ex..
   // (positions passed to the block map are luma positions)
@@ -411,7 +419,7 @@ __device__ __forceinline__ void filter_luma_pk(Window<uint8_t>& W, const int bet
     const int dp0 = (int)(dp & 0xFFFF), dp3 = (int)(dp >> 16), dq0 = (int)(dq & 0xFFFF), dq3 = (int)(dq >> 16);
     const int d0 = dp0 + dq0, d3 = dp3 + dq3;
     if (d0 + d3 >= beta) return;
-    const int beta_3 = beta >> 3, beta_2 = beta >> 2, tc25 = ((tc << 2) + tc + 1) >> 1;
+    const int beta_3 = beta >> 3, beta_2 = beta >> 2, tc25 = mad24_k<5>(tc, 1) >> 1;
     const uint32_t flat = as_w(pk_abs(C[0] - C[3]) + pk_abs(C[7] - C[4])), step = as_w(pk_abs(C[3] - C[4]));
     const bool strong = (int)(flat & 0xFFFF) < beta_3 && (int)(flat >> 16) < beta_3 && (int)(step & 0xFFFF) < tc25 && (int)(step >> 16) < tc25 &&
                         (d0 << 1) < beta_2 && (d3 << 1) < beta_2;
@@ -526,7 +534,7 @@ __global__ __launch_bounds__(256, sizeof(Pix) == 1 ? 8 : 6) void k_deblock(const
   if (item >= nL) { // chroma windows: the same structure in chroma samples
     if (dp.chroma_format == 0) return;
     sw = (PCMF && dp.chroma_format == 3) ? 1 : 2; sh = dp.chroma_format == 1 ? 2 : 1;
-    const int Wc = dp.width / sw, Hc = dp.height / sh; // multiples of 4
+    const int Wc = dp.width >> (sw >> 1), Hc = dp.height >> (sh >> 1); // multiples of 4
     cwx = ((Wc + 7) >> 3) + 1;
     const int nC = cwx * (((Hc + 7) >> 3) + 1);
     item -= nL;
@@ -538,7 +546,7 @@ __global__ __launch_bounds__(256, sizeof(Pix) == 1 ? 8 : 6) void k_deblock(const
   const int ky = item / wxn, kx = item - ky * wxn;
   WindowEdges<PCMF> E;
   if (!window_edges<Pix, PCMF>(dp, v, c, kx, ky, sw, sh, E, TabConst())) return;
-  const int PW = dp.width / sw, PH = dp.height / sh;
+  const int PW = dp.width >> (sw >> 1), PH = dp.height >> (sh >> 1);
   const int ex = kx << 3, ox = ex - 4, oy = (ky << 3) - 4;
 
   // ---- the window ----
@@ -699,11 +707,10 @@ __device__ __forceinline__ void sao_edge_group(int xs, int yy, int W, int Hh, in
   const int ya = yy + VY, yb = yy - VY;
   const bool rows_ok = ya >= 0 && yb < Hh;
   const int dya = (ya >> l2h) - cy, dyb = (yb >> l2h) - cy; // -1 / 0 and 0 / +1
-  auto perm = [&](int dy, int dx) -> bool { // may the neighbour CTB (dx, dy) be read?
-    const int k8 = (dy + 1) * 3 + (dx + 1);
-    const int bit = k8 < 4 ? k8 : k8 - 1;
-    return (dx | dy) == 0 || ((nbm >> bit) & 1);
-  };
+  // may the neighbour CTB (dx, dy) be read?  nbm holds the eight neighbours in raster order; with a set bit for the CTB
+  // itself in the middle the answer is bit 3 * dy + dx + 4, without a case distinction
+  const uint32_t nbm9 = (nbm & 15u) | 16u | ((nbm & 0xF0u) << 1);
+  auto perm = [&](int dy, int dx) -> bool { return (nbm9 >> mad24_k<3>(dy, dx + 4)) & 1u; };
   // rows a / b: the centre row for the horizontal class, else the rows above / below (all fetched by the caller with
   // their left / right neighbour samples before the CTB's SAO parameters are known: no dependent memory round trip)
   const SaoRow<Pix>& A = VY == 0 ? cur : up;
@@ -764,7 +771,7 @@ __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict_
   const PicView v = view(dp);
   const int sh = c ? (dp.chroma_format == 1 ? 2 : 1) : 1;
   const int sxs = (c && !(RARE && dp.chroma_format == 3)) ? 1 : 0; // horizontal chroma shift (4:4:4: rare-syntax classes only)
-  const int W = dp.width >> sxs, Hh = dp.height / sh;
+  const int W = dp.width >> sxs, Hh = dp.height >> (sh >> 1);
   const int l2w = dp.log2_ctb - sxs, l2h = dp.log2_ctb - (sh == 2 ? 1 : 0); // CTB size of this plane (log2)
   const int bd = dp.bit_depth;
   const uint32_t maxv2 = ((1u << bd) - 1) * 0x10001u;
@@ -1020,7 +1027,7 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
     }
     if (c >= 0) {
       const int sw = c ? 2 : 1;
-      const int PW = W / sw, PH = H / sw;
+      const int PW = W >> (sw >> 1), PH = H >> (sw >> 1);
       const int kx = (c ? TAIL_TW / 16 * tx : TAIL_TW / 8 * tx) + kxl, ky = (c ? TAIL_TH / 16 * ty : TAIL_TH / 8 * ty) + kyl;
       if (kx <= ((PW + 7) >> 3) && ky <= ((PH + 7) >> 3)) {
         Window<uint8_t> win;
