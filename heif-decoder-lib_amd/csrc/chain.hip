@@ -528,8 +528,9 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         const int dc = (s + 4) >> 3;
         v = dc;
         if (kind == 0) {
-          v = by == 0 ? (r0 + 3 * dc + 2) >> 2 : v;
-          v = bx == 0 ? (r1 + 3 * dc + 2) >> 2 : v;
+          const int dc3 = mad24_k<3>(dc, 2);
+          v = by == 0 ? (r0 + dc3) >> 2 : v;
+          v = bx == 0 ? (r1 + dc3) >> 2 : v;
           v = (bx | by) == 0 ? (r1 + 2 * dc + r0 + 2) >> 2 : v;
         }
       }
@@ -749,8 +750,9 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
           const int dc = (__builtin_amdgcn_readlane(s2, 0) + 8) >> 4;
           v = dc;
           if (c == 0) { // luma: smoothed first row / column
-            v = y == 0 ? (t + 3 * dc + 2) >> 2 : v;
-            v = x == 0 ? (l + 3 * dc + 2) >> 2 : v;
+            const int dc3 = mad24_k<3>(dc, 2);
+            v = y == 0 ? (t + dc3) >> 2 : v;
+            v = x == 0 ? (l + dc3) >> 2 : v;
             v = (x | y) == 0 ? (l + 2 * dc + t + 2) >> 2 : v;
           }
         }

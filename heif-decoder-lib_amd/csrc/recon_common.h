@@ -35,6 +35,14 @@ __device__ __forceinline__ int mul24_raw(int a, int b)
   asm("v_mul_i32_i24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
   return d;
 }
+// a * K + c with a small constant K as one full-rate instruction (written in C the compiler forms v_mad_u64_u32)
+template <int K>
+__device__ __forceinline__ int mad24_k(int a, int c)
+{
+  int d;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "n"(K), "v"(c));
+  return d;
+}
 // ((32 - f) * r0 + f * r1 + 16) >> 5 of the angular modes (intrapred.h:429) as r0 * 32 + f * (r1 - r0): the same integer,
 // four instructions instead of eight (the compiler expands a 24-bit product of 32 - f into shifts)
 __device__ __forceinline__ int blend32(int f, int r0, int r1) { return (mul24(f, r1 - r0) + (r0 << 5) + 16) >> 5; }
@@ -376,8 +384,9 @@ __device__ __forceinline__ void predict_emit(const Blk<Pix>& B, const Ref& b, co
       int v = dc;
       if (edge) {
         const int t = b(x + 1), l = b(-y - 1);
-        v = y == 0 ? (t + 3 * dc + 2) >> 2 : v;
-        v = x == 0 ? (l + 3 * dc + 2) >> 2 : v;
+        const int dc3 = mad24_k<3>(dc, 2);
+        v = y == 0 ? (t + dc3) >> 2 : v;
+        v = x == 0 ? (l + dc3) >> 2 : v;
         v = (x | y) == 0 ? (l + 2 * dc + t + 2) >> 2 : v;
       }
       emit(p, x, y, v);
