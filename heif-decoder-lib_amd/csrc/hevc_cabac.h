@@ -127,104 +127,114 @@ inline void init_contexts(ContextSet& cs, int slice_qp_y)
 }
 
 // ---- arithmetic decoder (§9.3.4.3) -----------------------------------------------------------
-// 9-bit range; `value` carries 7 look-ahead bits (compared against range << 7) and is refilled a
-// byte at a time, so that after a terminating bin the read pointer sits on the next byte-aligned
-// position (start of the next sub-stream / PCM samples).
+// The 9-bit offset (ivlOffset) sits in bits 62..54 of a 64-bit window (bit 63 is room for the doubling of a bypass
+// bin), `bits_` look-ahead bits follow it; the window
+// is refilled 32 bits at a time when the look-ahead runs out (about once per 32 stream bits: a well-predicted branch -
+// a byte-at-a-time refill is taken on every fourth bin or so and mispredicts).  The read position the standard defines
+// (9 bits at start-up, one more per renormalisation shift) is P = 8 * pos_ - bits_; the last bit read before a
+// terminating bin of value 1 is the stop bit, so the next syntax (the next sub-stream, PCM samples) starts at byte
+// ceil(P / 8).
 class CabacDecoder {
  public:
   void init(const uint8_t* p, const uint8_t* end)
   {
-    cur_ = p;
-    end_ = end;
+    base_ = p;
+    len_ = (size_t)(end - p);
+    pos_ = 0;
     range_ = 510;
-    bits_needed_ = 8;
     value_ = 0;
-    value_ = next_byte() << 8;
-    bits_needed_ -= 8;
-    value_ |= next_byte();
-    bits_needed_ -= 8;
-    // value_ now holds 16 bits: 9 + 7 look-ahead; bits_needed_ == -8
+    bits_ = -9;
+    refill();
   }
-  const uint8_t* position() const { return cur_; }
-  bool overrun() const { return overrun_ > 8; }
+  const uint8_t* position() const { return base_ + ((ptrdiff_t)pos_ - (bits_ >> 3)); }
+  // more than 8 bytes past the end of the data would have been read byte by byte (position P, rounded up to bytes)
+  bool overrun() const { return (ptrdiff_t)pos_ - (bits_ >> 3) > (ptrdiff_t)len_ + 8; }
 
   // One context-coded bin (9.3.4.3.2).  The MPS / LPS decision of a well-compressed stream is as good as random, so it
   // is taken with masks instead of a branch (a mispredicted branch per bin costs more than the arithmetic of both
   // paths); the state transition is one table look-up on (LPS?, state); renormalisation shifts by the leading zeros.
-  inline int decode_bin(ctx_state& ctx)
+  __attribute__((always_inline)) inline int decode_bin(ctx_state& ctx)
   {
     const uint32_t c = ctx;
     const uint32_t lps_range = cabac_tables::kRangeTabLps[c >> 1][(range_ >> 6) & 3];
     uint32_t r = range_ - lps_range;
-    const uint32_t scaled = r << 7;
+    const uint64_t scaled = (uint64_t)r << kOffsetShift;
     const uint32_t lps = value_ >= scaled ? 1u : 0u;
     const uint32_t mask = 0u - lps;
-    value_ -= scaled & mask;
+    value_ -= scaled & (uint64_t)(int64_t)(int32_t)mask;
     r += (lps_range - r) & mask;
     ctx = cabac_tables::kNextState.v[lps][c];
     const int shift = __builtin_clz(r) - 23; // r in [6, 510]: 0 for r >= 256
     range_ = r << shift;
     value_ <<= shift;
-    bits_needed_ += shift;
-    if (bits_needed_ >= 0) {
-      value_ |= next_byte() << bits_needed_;
-      bits_needed_ -= 8;
-    }
+    bits_ -= shift;
+    if (__builtin_expect(bits_ < 0, 0)) refill();
     return (int)((c & 1u) ^ lps);
   }
 
-  inline int decode_bypass()
+  __attribute__((always_inline)) inline int decode_bypass()
   {
     value_ <<= 1;
-    if (++bits_needed_ >= 0) {
-      value_ |= next_byte();
-      bits_needed_ = -8;
-    }
-    const uint32_t scaled = range_ << 7;
-    const int32_t d = (int32_t)(value_ - scaled);
-    const uint32_t below = (uint32_t)(d >> 31); // all ones when value < scaled (bin 0)
-    value_ = (uint32_t)d + (scaled & below);
-    return (int)(below + 1u);
+    if (__builtin_expect(--bits_ < 0, 0)) refill();
+    const uint64_t scaled = (uint64_t)range_ << kOffsetShift;
+    const uint64_t keep = value_ < scaled ? 0 : ~(uint64_t)0; // all ones when value >= scaled (bin 1)
+    value_ -= scaled & keep;
+    return (int)((uint32_t)keep & 1u);
   }
 
-  inline uint32_t decode_bypass_bits(int n)
+  // n bypass bins at once, first bin in the most significant bit (n <= 16).  Bypass bins leave the range alone: bin after
+  // bin is the long division of the offset, extended by the next n stream bits, by the range - done here as one 32-bit
+  // division (25-bit dividend, 9-bit divisor) instead of n dependent compare-subtract steps.
+  __attribute__((always_inline)) inline uint32_t decode_bypass_bits(int n)
   {
-    uint32_t v = 0;
-    for (int i = 0; i < n; i++) v = (v << 1) | (uint32_t)decode_bypass();
-    return v;
+    if (n <= 0) return 0;
+    if (bits_ < n) refill();
+    const int s = kOffsetShift - n;
+    const uint32_t q = (uint32_t)(value_ >> s) / range_;
+    value_ = (value_ - ((uint64_t)(q * range_) << s)) << n;
+    bits_ -= n;
+    return q;
   }
 
   inline int decode_terminate()
   {
     range_ -= 2;
-    const uint32_t scaled = range_ << 7;
+    const uint64_t scaled = (uint64_t)range_ << kOffsetShift;
     if (value_ >= scaled) return 1;
-    if (scaled < (256u << 7)) {
-      range_ = scaled >> 6;
+    if (range_ < 256u) {
+      range_ <<= 1;
       value_ <<= 1;
-      if (++bits_needed_ == 0) refill();
+      if (--bits_ < 0) refill();
     }
     return 0;
   }
 
  private:
-  inline uint32_t next_byte()
+  static constexpr int kOffsetShift = 54;
+  // 32 more bits below the valid ones (bits_ <= 22 here); bytes behind the end of the data read as zero
+  __attribute__((always_inline)) inline void refill()
   {
-    if (cur_ < end_) return *cur_++;
-    overrun_++;
-    return 0;
+    uint32_t w;
+    if (__builtin_expect(pos_ + 4 <= len_, 1)) {
+      std::memcpy(&w, base_ + pos_, 4);
+      w = __builtin_bswap32(w);
+    }
+    else w = tail_word(base_, pos_, len_);
+    pos_ += 4;
+    value_ |= (uint64_t)w << (kOffsetShift - 32 - bits_);
+    bits_ += 32;
   }
-  inline void refill()
+  __attribute__((noinline)) static uint32_t tail_word(const uint8_t* base, size_t pos, size_t len)
   {
-    bits_needed_ = -8;
-    value_ |= next_byte();
+    uint32_t w = 0;
+    for (size_t k = 0; k < 4; k++) w = (w << 8) | (pos + k < len ? base[pos + k] : 0u);
+    return w;
   }
-  const uint8_t* cur_ = nullptr;
-  const uint8_t* end_ = nullptr;
+  const uint8_t* base_ = nullptr;
+  size_t len_ = 0, pos_ = 0;
+  uint64_t value_ = 0;
   uint32_t range_ = 510;
-  uint32_t value_ = 0;
-  int bits_needed_ = 0;
-  int overrun_ = 0;
+  int bits_ = 0;
 };
 
 } // namespace hm

@@ -28,6 +28,13 @@ class DecoderEC {
   DecoderEC(const uint8_t* begin, const uint8_t* end) : cur_(begin), end_(end) {}
   inline int bin(int ctx, int, int) { return dec_.decode_bin(cs_.state[ctx]); }
   inline int bypass(int, int) { return dec_.decode_bypass(); }
+  // n bypass bins (index idx0, idx0 + step, ...; the first one most significant), n <= 16 per division
+  inline uint32_t bypass_bits(int, int, int, int n)
+  {
+    uint32_t v = 0;
+    for (; n > 16; n -= 16) v = (v << 16) | dec_.decode_bypass_bits(16);
+    return (v << n) | dec_.decode_bypass_bits(n);
+  }
   inline int terminate(int) { int b = dec_.decode_terminate(); check(); return b; }
   ContextSet& contexts() { return cs_; }
   const uint8_t* position() const { return dec_.position(); } // after a terminating bin: the next byte-aligned position

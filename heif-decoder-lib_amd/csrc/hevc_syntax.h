@@ -388,6 +388,9 @@ class SliceWalker {
     if ((dx | dy) == 0) return tables::kZOrder4[(yN >> 2) & 15][(xN >> 2) & 15] <= tables::kZOrder4[(yCurr >> 2) & 15][(xCurr >> 2) & 15];
     return nb_ok_[(dy + 1) * 3 + dx + 1] != 0;
   }
+  // the unit to the left of / above a position of the current CTB: inside the CTB it always comes earlier in z-order
+  bool avail_left(int x) const { return (x & ((1 << sps_.log2_ctb) - 1)) ? true : nb_ok_[3] != 0; }
+  bool avail_top(int y) const { return (y & ((1 << sps_.log2_ctb) - 1)) ? true : nb_ok_[1] != 0; }
   // slice address of a CTB (-1: not parsed yet).  A neighbour across a tile border may be parsed by another thread at this
   // moment (hevc_parse.cpp: parse_tiles_parallel): it belongs to the same slice segment, so "not yet" and its final value
   // lead to the same decisions below.
@@ -494,7 +497,7 @@ class SliceWalker {
           if (absv[i] != 0) sign[i] = ec_.bypass(K_SAO_SIGN, i) ? -1 : 1;
         }
         int bp = 0;
-        for (int i = 0; i < 5; i++) bp = (bp << 1) | ec_.bypass(K_SAO_BAND, i);
+        bp = (int)ec_.bypass_bits(K_SAO_BAND, 0, 1, 5);
         s.band_position = (uint8_t)bp;
       }
       else {
@@ -518,8 +521,8 @@ class SliceWalker {
     if (x0 + size <= sps_.width && y0 + size <= sps_.height && log2CbSize > sps_.log2_min_cb) {
       // §9.3.4.2.2: ctxInc from the coding quadtree depth of the left / above neighbours
       int inc = 0;
-      if (avail_z(x0, y0, x0 - 1, y0) && ct_depth_at(x0 - 1, y0) > cqtDepth) inc++;
-      if (avail_z(x0, y0, x0, y0 - 1) && ct_depth_at(x0, y0 - 1) > cqtDepth) inc++;
+      if (avail_left(x0) && ct_depth_at(x0 - 1, y0) > cqtDepth) inc++;
+      if (avail_top(y0) && ct_depth_at(x0, y0 - 1) > cqtDepth) inc++;
       split = ec_.bin(CTX_SPLIT_CU + inc, K_SPLIT_CU, log2CbSize);
     }
     else {
@@ -582,11 +585,11 @@ class SliceWalker {
     // picture with several tile columns they do not: the left / upper quantisation group of the same CTB is then
     // ignored (and a neighbouring CTB whose raster address happens to equal the current tile-scan address is used).
     // Reproduced literally: bit-exactness to the reference, not to the standard, is the contract.
-    if (avail_z(xQG, yQG, xQG - 1, yQG)) {
+    if (avail_left(xQG)) {
       const int cn = ((xQG - 1) >> sps_.log2_ctb) + (yQG >> sps_.log2_ctb) * sps_.ctb_w;
       if (cn == ctb_addr_ts_) qa = qpy_at(xQG - 1, yQG);
     }
-    if (avail_z(xQG, yQG, xQG, yQG - 1)) {
+    if (avail_top(yQG)) {
       const int cn = (xQG >> sps_.log2_ctb) + ((yQG - 1) >> sps_.log2_ctb) * sps_.ctb_w;
       if (cn == ctb_addr_ts_) qb = qpy_at(xQG, yQG - 1);
     }
@@ -656,7 +659,7 @@ class SliceWalker {
       }
       else {
         int v = 0;
-        for (int k = 0; k < 5; k++) v = (v << 1) | ec_.bypass(K_REM_MODE, k);
+        v = (int)ec_.bypass_bits(K_REM_MODE, 0, 1, 5);
         rem[i] = v;
       }
       const int xP = x0 + (i & 1) * pbOffset, yP = y0 + (i >> 1) * pbOffset;
@@ -758,8 +761,8 @@ class SliceWalker {
   int derive_luma_mode(int x, int y, int prev_flag, int mpm_idx, int rem)
   {
     int candA = 1, candB = 1; // INTRA_DC
-    if (avail_z(x, y, x - 1, y)) candA = pic_.intra_mode[((x - 1) >> 2) + (size_t)(y >> 2) * w4_];
-    if (avail_z(x, y, x, y - 1) && (y - 1) >= ((y >> sps_.log2_ctb) << sps_.log2_ctb))
+    if (avail_left(x)) candA = pic_.intra_mode[((x - 1) >> 2) + (size_t)(y >> 2) * w4_];
+    if (y & ((1 << sps_.log2_ctb) - 1)) // (the unit above counts only inside the CTB, where it always comes earlier)
       candB = pic_.intra_mode[(x >> 2) + (size_t)((y - 1) >> 2) * w4_];
     int c[3];
     if (candA == candB) {
@@ -966,13 +969,29 @@ class SliceWalker {
       // (replace the older entry: 4:2:2 alternates between the upper and the lower block of Cb and Cr)
       AvailMemo& slot = avail_memo_[avail_memo_next_];
       avail_memo_next_ ^= 1;
-      const bool l = avail_z(xL, yL, xL - 1, yL);
+      // (left, above and above-left of a block always come before it in z-order when they lie in its CTB; else the answer
+      //  is the neighbouring CTB's, see avail_z; only below-left and above-right inside the CTB compare z-order indices)
+      const int cs = 1 << sps_.log2_ctb, xi = xL & (cs - 1), yi = yL & (cs - 1);
+      const bool l = xi ? true : nb_ok_[3] != 0, tp = yi ? true : nb_ok_[1] != 0;
+      const int z_cur = tables::kZOrder4[(yL >> 2) & 15][(xL >> 2) & 15];
       slot.key = key;
       slot.left = l;
-      slot.top = avail_z(xL, yL, xL, yL - 1);
-      slot.top_left = avail_z(xL, yL, xL - 1, yL - 1);
-      slot.bottom_left = l && (yc + nT < chh) && avail_z(xL, yL, xL - 1, (yc + nT) << lh);
-      slot.top_right = (xc + nT < cw) && avail_z(xL, yL, (xc + nT) << lw, yL - 1);
+      slot.top = tp;
+      slot.top_left = xi ? tp : (yi ? l : nb_ok_[0] != 0);
+      bool bl = false, tr = false;
+      if (l && yc + nT < chh) {
+        const int yB = yL + (nT << lh);
+        if (yi + (nT << lh) >= cs) bl = nb_ok_[xi ? 7 : 6] != 0;
+        else bl = xi == 0 || tables::kZOrder4[(yB >> 2) & 15][((xL - 1) >> 2) & 15] <= z_cur;
+      }
+      if (xc + nT < cw) {
+        const int xR = xL + (nT << lw);
+        const bool beyond = xi + (nT << lw) >= cs;
+        if (yi == 0) tr = nb_ok_[beyond ? 2 : 1] != 0;
+        else tr = beyond ? nb_ok_[5] != 0 : tables::kZOrder4[((yL - 1) >> 2) & 15][(xR >> 2) & 15] <= z_cur;
+      }
+      slot.bottom_left = bl;
+      slot.top_right = tr;
       return emit_record(t, nT, cIdx, slot, chh - (yc + nT), cw - (xc + nT));
     }
     return emit_record(t, nT, cIdx, am, chh - (yc + nT), cw - (xc + nT));
@@ -1105,7 +1124,7 @@ class SliceWalker {
       const bool signHidden = pps_.sign_data_hiding && !cu_bypass_ && !rdpcm && (sigpos[0] - sigpos[nsig - 1] > 3); // slice.cc:3565-3575
       const int nsign = signHidden ? nsig - 1 : nsig;
       uint32_t signbits = 0;
-      for (int k = 0; k < nsign; k++) signbits = (signbits << 1) | (uint32_t)ec_.bypass(K_SIGN, k);
+      signbits = ec_.bypass_bits(K_SIGN, 0, 1, nsign); // (all signs of the sub-block in one read)
       signbits <<= (16 - nsign);
 
       // remaining levels
@@ -1163,8 +1182,7 @@ class SliceWalker {
   int last_suffix(int prefix)
   {
     const int nbits = (prefix >> 1) - 1;
-    int s = 0;
-    for (int i = 0; i < nbits; i++) s = (s << 1) | ec_.bypass(K_LAST_SUFFIX, i);
+    const int s = (int)ec_.bypass_bits(K_LAST_SUFFIX, 0, 1, nbits);
     return (1 << nbits) * (2 + (prefix & 1)) + s;
   }
   // §9.3.3.11 binarisation of coeff_abs_level_remaining
@@ -1175,16 +1193,12 @@ class SliceWalker {
       if (++prefix > 32) throw ParseError(HM_ERR_BITSTREAM, "coeff_abs_level_remaining prefix too long");
     }
     if (prefix <= 3) {
-      int v = prefix << rice;
-      for (int i = rice - 1; i >= 0; i--) v += ec_.bypass(K_CALR_SUFFIX, i) << i;
-      return v;
+      return (prefix << rice) + (int)ec_.bypass_bits(K_CALR_SUFFIX, rice - 1, -1, rice);
     }
     const int nb = prefix - 3 + rice;
     if (nb > 30) throw ParseError(HM_ERR_BITSTREAM, "coeff_abs_level_remaining too large");
     int v = (((1 << (prefix - 3)) + 3 - 1) << rice);
-    int s = 0;
-    for (int i = nb - 1; i >= 0; i--) s += ec_.bypass(K_CALR_SUFFIX, i) << i;
-    return v + s;
+    return v + (int)ec_.bypass_bits(K_CALR_SUFFIX, nb - 1, -1, nb);
   }
 
   struct TuRef { int ctb; uint32_t idx; };

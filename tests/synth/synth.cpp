@@ -205,6 +205,13 @@ class EncoderEC {
     enc.bypass(b);
     return b;
   }
+  // the bins idx0, idx0 + step, ... of a fixed-length bypass code, the first one most significant
+  uint32_t bypass_bits(int kind, int idx0, int step, int n)
+  {
+    uint32_t v = 0;
+    for (int k = 0; k < n; k++) v = (v << 1) | (uint32_t)bypass(kind, idx0 + k * step);
+    return v;
+  }
   // expect: -1 = end_of_slice_segment_flag the stream is free to choose, 1 = ... that must be 1 (last CTB of the
   // picture), 2 = end_of_subset_one_bit
   int terminate(int expect)
