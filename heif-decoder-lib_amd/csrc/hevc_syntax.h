@@ -623,7 +623,8 @@ class SliceWalker {
   void coding_unit(int x0, int y0, int log2CbSize)
   {
     const int nCbS = 1 << log2CbSize;
-    cu_first_tu_.clear();
+    // the unit's luma records (patched with its final QpY at the end): everything behind this index, one CTB only
+    cu_tu_start_ = pic_.direct ? pic_.rows[(size_t)ctb_y_].tu[0].size() : pic_.ctb_tus[ctb_addr_rs_].size();
     derive_qp(x0, y0, log2CbSize); // the reference derives QP at CU start (slice.cc:4593)
     cu_bypass_ = false;
     if (pps_.transquant_bypass_enabled && ec_.bin(CTX_TQ_BYPASS, K_TQ_BYPASS, 0)) {
@@ -692,9 +693,10 @@ class SliceWalker {
     transform_tree(x0, y0, x0, y0, log2CbSize, 0, 0, max_depth, nxn, 1, 1);
     // all luma records of this CU must carry the CU's final QpY (deblocking uses the QpY map)
     if (pic_.direct)
-      for (auto& ref : cu_first_tu_) pic_.rows[(size_t)ctb_y_].tu[0][ref.idx].qpy = (int8_t)cu_qpy_;
+      for (std::vector<hm_tu8>& v = pic_.rows[(size_t)ctb_y_].tu[0]; cu_tu_start_ < v.size(); cu_tu_start_++) v[cu_tu_start_].qpy = (int8_t)cu_qpy_;
     else
-      for (auto& ref : cu_first_tu_) pic_.ctb_tus[ref.ctb][ref.idx].qpy = (int8_t)cu_qpy_;
+      for (std::vector<hm_tu>& v = pic_.ctb_tus[ctb_addr_rs_]; cu_tu_start_ < v.size(); cu_tu_start_++)
+        if (((v[cu_tu_start_].info >> HM_TU_CIDX_SHIFT) & 3) == 0) v[cu_tu_start_].qpy = (int8_t)cu_qpy_;
   }
 
   // pcm_sample( ) (§7.3.8.7; slice.cc:4462-4536 of the reference): raw samples of all components at the entropy
@@ -1008,7 +1010,7 @@ class SliceWalker {
     if (pic_.direct) {
       std::vector<hm_tu8>& vec = pic_.rows[(size_t)ctb_y_].tu[cIdx ? 1 : 0];
       hm_ctb& cc = pic_.ctbs[ctb_addr_rs_];
-      if (cIdx == 0) { cu_first_tu_.push_back({ctb_addr_rs_, (uint32_t)vec.size()}); cc.tu_count++; }
+      if (cIdx == 0) cc.tu_count++;
       else cc.tu_count_c++;
       hm_tu8 c;
       c.pos = (uint8_t)((t.x >> 2) | ((t.y >> 2) << 4));
@@ -1019,7 +1021,6 @@ class SliceWalker {
       return;
     }
     auto& vec = pic_.ctb_tus[ctb_addr_rs_];
-    if (cIdx == 0) cu_first_tu_.push_back({ctb_addr_rs_, (uint32_t)vec.size()});
     vec.push_back(t);
   }
 
@@ -1201,8 +1202,6 @@ class SliceWalker {
     return v + (int)ec_.bypass_bits(K_CALR_SUFFIX, nb - 1, -1, nb);
   }
 
-  struct TuRef { int ctb; uint32_t idx; };
-
   EC& ec_;
   PictureState& pic_;
   const SPS& sps_;
@@ -1233,7 +1232,7 @@ class SliceWalker {
   bool cu_bypass_ = false; // cu_transquant_bypass_flag of the current coding unit
   int luma_mode_[4] = {1, 1, 1, 1}, chroma_mode_[4] = {1, 1, 1, 1};
   bool chroma_dm_[4] = {false, false, false, false};
-  std::vector<TuRef> cu_first_tu_;
+  size_t cu_tu_start_ = 0;
 };
 
 } // namespace hm
