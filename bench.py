@@ -689,8 +689,8 @@ def plugin_path(pkg, tiles):
     hm = pkg.lib()
     tiles = [bytes(t) for t in tiles]
 
-    def run():
-        return pluginapi.drive_grid(plugin_ptr, tiles, 8)
+    def run(window=8):
+        return pluginapi.drive_grid(plugin_ptr, tiles, window)
 
     imgs = run()  # warm-up, and a check of tile 0 against the oracle
     stride = C.c_int()
@@ -701,29 +701,45 @@ def plugin_path(pkg, tiles):
         raise RuntimeError("plugin path: tile 0 differs from the oracle")
     for im in imgs:
         api.heif_image_release(im)
-    best = 1e9
-    for _ in range(5):
-        t0 = time.perf_counter()
-        imgs = run()
-        best = min(best, time.perf_counter() - t0)
-        for im in imgs:
-            api.heif_image_release(im)
+
+    def best_plugin(window):
+        best = 1e9
+        for _ in range(5):
+            t0 = time.perf_counter()
+            imgs = run(window)
+            best = min(best, time.perf_counter() - t0)
+            for im in imgs:
+                api.heif_image_release(im)
+        return best
+
     data = heifwriter.write_heic(tiles, (TILE, TILE), grid=(GRID_ROWS, GRID_COLS, OUT_W, OUT_H))
     f = pipeline.HeifFile(hm, data)
-    try:
-        f.decode(f.primary(), 0, threads=8, copy=False)
+
+    def best_item(threads):
+        f.decode(f.primary(), 0, threads=threads, copy=False)
         item = 1e9
         for _ in range(5):
             t0 = time.perf_counter()
-            f.decode(f.primary(), 0, threads=8, copy=False)
+            f.decode(f.primary(), 0, threads=threads, copy=False)
             item = min(item, time.perf_counter() - t0)
+        return item
+
+    try:
+        best, item = best_plugin(8), best_item(8)
+        # the window is the caller's choice (heif_context_set_threads -> m_max_decoding_threads, heif.cc:499-513): wider
+        # windows next to hm_decode_item with as many host threads
+        wider = {}
+        for w in (16, 48):
+            b, i = best_plugin(w), best_item(w)
+            wider[str(w)] = {"ms_per_12MP_grid": round(b * 1e3, 2), "hm_decode_item_ms": round(i * 1e3, 2), "ratio_to_hm_decode_item": round(b / i, 2)}
     finally:
         f.close()
     return {"ms_per_12MP_grid": round(best * 1e3, 2), "MP_per_s": round(MP_PER_IMAGE / best, 1), "tiles": len(tiles), "threads": 8,
-            "hm_decode_item_ms": round(item * 1e3, 2), "ratio_to_hm_decode_item": round(best / item, 2),
+            "hm_decode_item_ms": round(item * 1e3, 2), "ratio_to_hm_decode_item": round(best / item, 2), "wider_windows": wider,
             "note": "48 decoder instances (new_decoder / push_data / decode_image / free_decoder) from a window of 8 async C++ tasks - the reference's caller, "
                     "context.cc:2361-2401 (tests/synth/plugin_driver.cpp) -, best of 5; host entropy decode on the calling threads, the GPU work of "
-                    "concurrent calls coalesced by the shared device worker; tile 0 checked against the oracle"}
+                    "concurrent calls coalesced by the shared device worker; tile 0 checked against the oracle; wider_windows: the same with 16 / 48 "
+                    "tasks (and hm_decode_item with 16 / 48 host threads)"}
 
 
 def end_to_end_pipelined(pkg, kept, threads=None, cpus=None, device=-1):
