@@ -827,6 +827,33 @@ extern "C" {
 // (test hook, hm_internal.h) slice segments parsed with their WPP rows (which = 0) / their rows of tiles (1) side by side
 long hm_parse_parallel_segments(int which) { return which == 0 || which == 1 ? hm::g_parallel_segments[which].load() : -1; }
 
+// (test hook, hm_internal.h) the arithmetic decoder alone: runs a script of bins over `data` with all contexts
+// initialised for slice QP `qp` - op >= 0: a context-coded bin with that context index, -1: a bypass bin, -2: a
+// terminating bin, -(n + 2), n = 1..32: n bypass bins in one read - and writes the value of every op to out[]; returns the
+// byte position the standard's read pointer corresponds to after the last op (see CabacDecoder), -1 for a bad script
+long hm_test_cabac_script(const uint8_t* data, size_t size, int qp, const int32_t* ops, int n_ops, uint32_t* out)
+{
+  if (!data || !ops || !out || size < 2) return -1;
+  hm::ContextSet cs;
+  hm::init_contexts(cs, qp);
+  hm::CabacDecoder d;
+  d.init(data, data + size);
+  for (int i = 0; i < n_ops; i++) {
+    const int op = ops[i];
+    if (op >= hm::CTX_COUNT || op < -34) return -1;
+    if (op >= 0) out[i] = (uint32_t)d.decode_bin(cs.state[op]);
+    else if (op == -1) out[i] = (uint32_t)d.decode_bypass();
+    else if (op == -2) out[i] = (uint32_t)d.decode_terminate();
+    else {
+      int n = -op - 2;
+      uint32_t v = 0;
+      for (; n > 16; n -= 16) v = (v << 16) | d.decode_bypass_bits(16);
+      out[i] = (v << n) | d.decode_bypass_bits(n);
+    }
+  }
+  return (long)(d.position() - data);
+}
+
 void hm_free(void* p) { std::free(p); }
 
 } // extern "C"

@@ -74,6 +74,7 @@ int hm_launch_tail420(const struct hm_dev_pic* d_pics, const void* d_dsts, int n
 
 // (test hook) slice segments whose sub-streams were entropy-decoded side by side since the library was loaded: which = 0 WPP rows, 1 rows of tiles
 HM_API long hm_parse_parallel_segments(int which);
+HM_API long hm_test_cabac_script(const uint8_t* data, size_t size, int qp, const int32_t* ops, int n_ops, uint32_t* out);
 
 #ifdef __cplusplus
 }
