@@ -21,6 +21,8 @@
 //     rows), 16x16 / 32x32 blocks in 64-sample trips with the sums cut at the last non-zero row / column.
 // Pictures with rare syntax (scaling lists, PCM, bypass, 4:4:4, range-extension tools) keep their residual inside
 // recon.hip's RARE kernel.  Integer work, HBM traffic = levels in + 2 bytes per residual sample out: no MFMA.
+#include <cstdlib>
+
 #include "recon_common.h"
 
 #include "hm_internal.h"
@@ -115,7 +117,7 @@ __device__ __forceinline__ void big_residual(int16_t* coeff, int16_t* tmp, const
 #else
 #define HM_R_ATTR
 #endif
-__global__ __launch_bounds__(R_WAVES * 64) HM_R_ATTR void k_residual(const hm_dev_pic* __restrict__ pics, int n_pics, int max_ctb_h)
+__global__ __launch_bounds__(R_WAVES * 64) HM_R_ATTR void k_residual(const hm_dev_pic* __restrict__ pics, int n_pics, int max_ctb_h, int segs)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = rfl(tid >> 6);
@@ -154,15 +156,23 @@ __global__ __launch_bounds__(R_WAVES * 64) HM_R_ATTR void k_residual(const hm_de
   }
   __syncthreads();
 
-  // ---- this wave's unit: (picture, CTB row, chain kind) ----
+  // ---- this wave's unit: (picture, CTB row, chain kind, segment of the row) ----
+  // A batch of few pictures has too few rows to fill the chip with a wave per row and chain (32 pictures of 1080p: 1088
+  // waves, each with a whole row of 30 CTUs in front of it): the launcher then cuts every row into `segs` runs of CTUs.
+  // Nothing here depends on the records in front of a CTU except two running sums, and both have a known value at a CTU
+  // boundary: the first level of the CTU's first record stands in its header, and the residual slab of a row has room for
+  // ctb x ctb samples per CTU, so a segment that starts at CTU x0 packs its residuals from x0 x (CTU size) on.
   const uint32_t unit = (uint32_t)blockIdx.x * R_WAVES + (uint32_t)wave;
-  const uint32_t per_pic = 2u * (uint32_t)max_ctb_h;
+  const uint32_t per_pic = 2u * (uint32_t)max_ctb_h * (uint32_t)segs;
   const int pic_index = (int)(unit / per_pic);
   if (pic_index >= n_pics) return;
   const int rem = (int)(unit - (uint32_t)pic_index * per_pic);
-  const int row = rem >> 1, kind = rem & 1;
+  const int seg = rem % segs, rk = rem / segs; // (once per wave)
+  const int row = rk >> 1, kind = rk & 1;
   const hm_dev_pic dp = pics[pic_index];
   if (row >= dp.ctb_h || (kind && dp.chroma_format == 0)) return;
+  const int x0 = (int)((long)seg * dp.ctb_w / segs), x1 = (int)((long)(seg + 1) * dp.ctb_w / segs); // the segment's CTUs [x0, x1)
+  if (x0 >= x1) return; // (more segments than CTUs)
   const uint8_t* blob = dp.blob;
   const GLOBAL_AS hm_pic* H = gptr<hm_pic>(blob);
   const GLOBAL_AS uint32_t* ctbq = gptr<uint32_t>(blob + H->off_ctbs);
@@ -178,12 +188,13 @@ __global__ __launch_bounds__(R_WAVES * 64) HM_R_ATTR void k_residual(const hm_de
   const int maxv = (1 << bd) - 1;
   const ResidGeom RG = resid_geom(dp.ctb_w, dp.ctb_h, dp.log2_ctb, dp.chroma_format);
   const GLOBAL_AS uint32_t* const q0 = ctbq + HM_CTB_DWORDS * ((size_t)row * dp.ctb_w);
-  const GLOBAL_AS uint32_t* const q1 = q0 + HM_CTB_DWORDS * (size_t)(dp.ctb_w - 1);
-  const uint32_t rec_begin = q0[kind ? 9 : 0];
+  const GLOBAL_AS uint32_t* const qs = q0 + HM_CTB_DWORDS * (size_t)x0;       // the segment's first CTU
+  const GLOBAL_AS uint32_t* const q1 = q0 + HM_CTB_DWORDS * (size_t)(x1 - 1); // ... and its last
+  const uint32_t rec_begin = qs[kind ? 9 : 0];
   const uint32_t rec_end = q1[kind ? 9 : 0] + (q1[kind ? 10 : 1] & 0xFFFFu);
-  uint32_t lev_base = q0[kind ? 12 : 11];
-  uint32_t res_base = RG.slab(kind, row);
-  int cur_ctb = 0; // CTB (column) of the chunk's first record
+  uint32_t lev_base = qs[kind ? 12 : 11];
+  uint32_t res_base = RG.slab(kind, row) + (uint32_t)x0 * ((kind ? RG.chroma_row : RG.luma_row) / (uint32_t)dp.ctb_w);
+  int cur_ctb = x0; // CTB (column) of the chunk's first record
 
   // ---- per-lane constants of the 4x4 transform (lane = sample (bx, by) of the block of its 16-lane group) ----
   const int g = lane >> 4, gl = lane & 15, bx_ = gl & 3, by_ = gl >> 2;
@@ -225,7 +236,7 @@ __global__ __launch_bounds__(R_WAVES * 64) HM_R_ATTR void k_residual(const hm_de
     // (luma chains, block map: the first records and the flags of the CTBs that may start inside this chunk - requested
     //  here with everything else, used below)
     const int cand = cur_ctb + 1 + lane;
-    const bool cand_ok = kind == 0 && cand < dp.ctb_w;
+    const bool cand_ok = kind == 0 && cand < x1;
     const int last_ctb = dp.ctb_w - 1;
     const uint32_t cand_first = q0[HM_CTB_DWORDS * (size_t)(cand < last_ctb ? cand : last_ctb)];
     const uint32_t ctb_flags = q0[HM_CTB_DWORDS * (size_t)(cand - 1 < last_ctb ? cand - 1 : last_ctb) + 2]; // flags of CTB cur_ctb + lane
@@ -469,11 +480,16 @@ __global__ __launch_bounds__(R_WAVES * 64) HM_R_ATTR void k_residual(const hm_de
 extern "C" int hm_launch_residual(const hm_dev_pic* d_pics, int n_pics, int max_ctb_h, hipStream_t s)
 {
   if (n_pics <= 0) return HM_OK;
-  const long units = (long)n_pics * 2 * max_ctb_h;
+  long units = (long)n_pics * 2 * max_ctb_h;
+  // few pictures: the rows in segments, towards ~8192 waves (HM_RESID_SEGS forces a count: tests)
+  static const int forced = [] { const char* e = std::getenv("HM_RESID_SEGS"); return e ? std::atoi(e) : 0; }();
+  int segs = forced > 0 ? forced : (int)(8192 / units);
+  segs = segs < 1 ? 1 : (segs > 16 ? 16 : segs);
+  units *= segs;
   const long groups = (units + R_WAVES - 1) / R_WAVES;
   if (groups > 0x7FFFFFFFL) return hm_fail(HM_ERR_UNSUPPORTED, "too many CTB rows in one launch");
   int a_n = n_pics, a_h = max_ctb_h;
-  void* args[] = {(void*)&d_pics, &a_n, &a_h};
+  void* args[] = {(void*)&d_pics, &a_n, &a_h, &segs};
   hipError_t e = hipLaunchKernel(reinterpret_cast<const void*>(k_residual), dim3((unsigned)groups), dim3(R_WAVES * 64), args, R_TABLES + R_WAVES * R_WAVE, s);
   if (e != hipSuccess) return hm_check_hip(e, "k_residual launch");
   return hm_check_hip(hipGetLastError(), "k_residual launch");

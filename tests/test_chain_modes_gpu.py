@@ -35,6 +35,14 @@ def test_waves_that_take_the_row_pairs_of_a_picture_in_turn(share):
     assert "in turn" in r.stderr, r.stderr
 
 
+@pytest.mark.parametrize("segs", [2, 5, 16])
+def test_residual_prepass_in_segments_of_a_row(segs):
+    """few pictures: k_residual cuts every CTU row into runs of CTUs (the levels of a run start where the CTU header says,
+    its residuals at the CTU's own place in the row's slab); forced here for every class, also more segments than CTUs"""
+    r = _run({"HM_RESID_SEGS": str(segs), "HM_QUAD_CLASS": "1"})
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
 def test_widest_pictures_fall_back_to_a_finer_cut():
     """16384 columns of 16-bit 4:2:2 samples with 64x64 CTBs: the sample lines of a wave per picture (forced here) do not
     fit a wave's share of LDS; the launcher then cuts the pictures into a wave per CTU row (or chain) instead of refusing"""
