@@ -117,12 +117,15 @@ typedef uint32_t c_u32x2 __attribute__((ext_vector_type(2)));
 // Waves per SIMD the register allocation aims for: five (<= 96 VGPRs) where that needs no spilling - 8-bit samples, a wave per
 // picture: the headline kernel, whose 7.6 KB of LDS per wave then allow 20 waves per CU instead of 16 -, four elsewhere
 // (16-bit samples and the few-pictures variants would spill a few registers).  HM_WPE overrides (A/B builds).
-template <typename Pix, bool PAIRS>
-constexpr int chain_waves_per_simd = (sizeof(Pix) == 1 && !PAIRS) ? 5 : 4;
+#ifndef HM_WPE_CTB64
+#define HM_WPE_CTB64 4 // (CTUs of 64x64: the wave's LDS - two rows of CTU buffers - allows ten waves per CU at most; five per SIMD only costs spills)
+#endif
+template <typename Pix, int LOG2_CTB, bool PAIRS>
+constexpr int chain_waves_per_simd = (sizeof(Pix) == 1 && !PAIRS) ? (LOG2_CTB <= 5 ? 5 : HM_WPE_CTB64) : 4;
 #ifdef HM_WPE
 #define HM_CHAIN_ATTR __attribute__((amdgpu_waves_per_eu(HM_WPE, HM_WPE)))
 #else
-#define HM_CHAIN_ATTR __attribute__((amdgpu_waves_per_eu(chain_waves_per_simd<Pix, PAIRS>, chain_waves_per_simd<Pix, PAIRS>)))
+#define HM_CHAIN_ATTR __attribute__((amdgpu_waves_per_eu(chain_waves_per_simd<Pix, LOG2_CTB, PAIRS>, chain_waves_per_simd<Pix, LOG2_CTB, PAIRS>)))
 #endif
 template <typename Pix, int LOG2_CTB, bool PAIRS>
 __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* __restrict__ pics, int n_pics, CLayout L, uint32_t* __restrict__ sync)
