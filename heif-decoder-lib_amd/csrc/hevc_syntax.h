@@ -409,6 +409,8 @@ class SliceWalker {
         }
         nb_ok_[(dy + 1) * 3 + dx + 1] = ok;
       }
+    nb9_ = 0;
+    for (int k = 0; k < 9; k++) nb9_ |= (unsigned)(nb_ok_[k] != 0) << k;
   }
 
   // ---- CTU ---------------------------------------------------------------------------------
@@ -416,15 +418,16 @@ class SliceWalker {
   {
     const int x0 = xCtb << sps_.log2_ctb, y0 = yCtb << sps_.log2_ctb;
     ctb_x_ = xCtb; ctb_y_ = yCtb;
+    ctb_cur_ = &pic_.ctbs[ctb_addr_rs_];
     if (pic_.direct) {
       PictureState::RowChains& R = pic_.rows[(size_t)yCtb];
+      row_ = &R;
       hm_ctb& cc = pic_.ctbs[ctb_addr_rs_];
       cc.tu_first = (uint32_t)R.tu[0].size(); cc.tu_first_c = (uint32_t)R.tu[1].size();
       cc.coeff_first = (uint32_t)R.lv[0].size(); cc.coeff_first_c = (uint32_t)R.lv[1].size();
       cc.tu_count = cc.tu_count_c = 0;
     }
     derive_ctb_neighbours();
-    avail_memo_[0].key = avail_memo_[1].key = 0xFFFFFFFFu;
     hm_ctb& c = pic_.ctbs[ctb_addr_rs_];
     // deblocking edge permissions of this CTB's left/top edge (deblock.cc:160-196 in the reference)
     c.flags &= ~(HM_CTB_DEBLOCK_LEFT | HM_CTB_DEBLOCK_TOP | HM_CTB_DEBLOCK_OFF | HM_CTB_SAO_LUMA | HM_CTB_SAO_CHROMA | HM_CTB_LOSSLESS);
@@ -934,94 +937,71 @@ class SliceWalker {
     std::swap(v[v.size() - 3], v[v.size() - 2]);
   }
 
-  // one (component) block: optional residual_coding(), then the hm_tu record
+  // one (component) block: optional residual_coding(), then the block's record (hm_tu8 in pictures whose records go out as
+  // split chains, hm_tu else).  Runs ten thousand times per 512x512 tile: the record is built straight from locals, the
+  // row's vectors and the CTB header come from pointers set once per CTU (row_, ctb_cur_).
   void emit_block(int xc, int yc, int log2, int cIdx, int mode, int cbf, int res_scale = 0)
   {
-    // SubWidthC / SubHeightC are 1 or 2: shifts instead of divisions (this runs once per transform block)
+    // SubWidthC / SubHeightC are 1 or 2: shifts instead of divisions
     const int lw = cIdx ? (sps_.SubWidthC >> 1) : 0, lh = cIdx ? (sps_.SubHeightC >> 1) : 0;
-    const int nT = 1 << log2;
-    hm_tu t;
-    std::memset(&t, 0, sizeof(t));
-    t.x = (uint8_t)(xc & ((1 << (sps_.log2_ctb - lw)) - 1));
-    t.y = (uint8_t)(yc & ((1 << (sps_.log2_ctb - lh)) - 1));
-    t.info = (uint8_t)(log2 | (cIdx << HM_TU_CIDX_SHIFT));
-    t.pred_mode = (uint8_t)(mode | (cu_bypass_ ? HM_TU_MODE_BYPASS : 0));
-    if (pic_.direct) coeffs_ = &pic_.rows[(size_t)ctb_y_].lv[cIdx ? 1 : 0];
-    t.coeff_first = (uint32_t)coeffs_->size();
+    const int nT = 1 << log2, k = cIdx ? 1 : 0;
+    const bool direct = pic_.direct;
+    if (direct) coeffs_ = &row_->lv[k];
+    const uint32_t coeff_first = (uint32_t)coeffs_->size();
+    uint32_t info = (uint32_t)(log2 | (cIdx << HM_TU_CIDX_SHIFT));
     bool tskip = false;
     if (cbf) {
       residual_coding(log2, cIdx, mode, tskip);
-      t.info |= HM_TU_CBF;
-      if (tskip) t.info |= HM_TU_TSKIP;
+      info |= HM_TU_CBF | (tskip ? HM_TU_TSKIP : 0);
     }
     if (cIdx == 0) luma_tskip_ = tskip;
-    const size_t ncoef = coeffs_->size() - t.coeff_first;
-    t.n_coeff = (uint16_t)ncoef;
-    t.qp = (uint8_t)qp_prime_[cIdx];
-    t.qpy = (int8_t)cu_qpy_;
-    if (cIdx && pps_.cross_component_prediction) t.qpy = (int8_t)res_scale; // hm_stream.h: chroma records of such pictures carry ResScaleVal
-    // neighbour availability (intrapred.h:536-667 in the reference; equals §8.4.4.2.2).  It depends on the block's
-    // rectangle in luma samples only, which the Cb / Cr blocks of a transform unit share (and, for 4:2:0 / 4:4:4,
-    // share with the unit's luma block): the last two answers are kept.
+    const uint32_t ncoef = (uint32_t)coeffs_->size() - coeff_first;
+    // neighbour availability (intrapred.h:536-667 in the reference; equals §8.4.4.2.2), from the block's rectangle in
+    // luma samples.  Left, above and above-left of a block always come before it in z-order when they lie in its CTB;
+    // else the answer is the neighbouring CTB's (nb9_, see avail_z); only below-left and above-right inside the CTB
+    // compare z-order indices.  Written without branches on purpose (selects over always-valid table reads): the outcomes
+    // follow the block structure of the picture, which no predictor learns - and a memo of the last two rectangles (the
+    // Cb / Cr blocks of a unit share theirs) cost as much as it saved.
     const int xL = xc << lw, yL = yc << lh; // luma position of the block
     const int cw = sps_.width >> lw, chh = sps_.height >> lh;
-    const uint32_t key = (uint32_t)(xL >> 2) | ((uint32_t)(yL >> 2) << 12) | ((uint32_t)(log2 + lw) << 24) | ((uint32_t)(log2 + lh) << 27);
-    AvailMemo& am = avail_memo_[avail_memo_[0].key == key ? 0 : 1];
-    if (am.key != key) {
-      // (replace the older entry: 4:2:2 alternates between the upper and the lower block of Cb and Cr)
-      AvailMemo& slot = avail_memo_[avail_memo_next_];
-      avail_memo_next_ ^= 1;
-      // (left, above and above-left of a block always come before it in z-order when they lie in its CTB; else the answer
-      //  is the neighbouring CTB's, see avail_z; only below-left and above-right inside the CTB compare z-order indices)
-      const int cs = 1 << sps_.log2_ctb, xi = xL & (cs - 1), yi = yL & (cs - 1);
-      const bool l = xi ? true : nb_ok_[3] != 0, tp = yi ? true : nb_ok_[1] != 0;
-      const int z_cur = tables::kZOrder4[(yL >> 2) & 15][(xL >> 2) & 15];
-      slot.key = key;
-      slot.left = l;
-      slot.top = tp;
-      slot.top_left = xi ? tp : (yi ? l : nb_ok_[0] != 0);
-      bool bl = false, tr = false;
-      if (l && yc + nT < chh) {
-        const int yB = yL + (nT << lh);
-        if (yi + (nT << lh) >= cs) bl = nb_ok_[xi ? 7 : 6] != 0;
-        else bl = xi == 0 || tables::kZOrder4[(yB >> 2) & 15][((xL - 1) >> 2) & 15] <= z_cur;
-      }
-      if (xc + nT < cw) {
-        const int xR = xL + (nT << lw);
-        const bool beyond = xi + (nT << lw) >= cs;
-        if (yi == 0) tr = nb_ok_[beyond ? 2 : 1] != 0;
-        else tr = beyond ? nb_ok_[5] != 0 : tables::kZOrder4[((yL - 1) >> 2) & 15][(xR >> 2) & 15] <= z_cur;
-      }
-      slot.bottom_left = bl;
-      slot.top_right = tr;
-      return emit_record(t, nT, cIdx, slot, chh - (yc + nT), cw - (xc + nT));
-    }
-    return emit_record(t, nT, cIdx, am, chh - (yc + nT), cw - (xc + nT));
-  }
-  struct AvailMemo { uint32_t key = 0xFFFFFFFFu; bool left = false, top = false, top_left = false, bottom_left = false, top_right = false; };
-  void emit_record(hm_tu& t, int nT, int cIdx, const AvailMemo& a, int room_below, int room_right)
-  {
-    const bool aL = a.left, aT = a.top, aTL = a.top_left, aBL = a.bottom_left, aTR = a.top_right;
-    t.avail_left = aL ? (uint8_t)nT : 0;
-    t.avail_top = aT ? (uint8_t)nT : 0;
-    if (aTL) t.info |= HM_TU_AVAIL_TL;
-    t.avail_bottom_left = aBL ? (uint8_t)std::min(nT, room_below) : 0;
-    t.avail_top_right = aTR ? (uint8_t)std::min(nT, room_right) : 0;
-    if (pic_.direct) {
-      std::vector<hm_tu8>& vec = pic_.rows[(size_t)ctb_y_].tu[cIdx ? 1 : 0];
-      hm_ctb& cc = pic_.ctbs[ctb_addr_rs_];
-      if (cIdx == 0) cc.tu_count++;
-      else cc.tu_count_c++;
+    const int cs = 1 << sps_.log2_ctb, xi = xL & (cs - 1), yi = yL & (cs - 1);
+    const int wL = nT << lw, hL = nT << lh;
+    const unsigned nb = nb9_;
+    const unsigned a_left = xi ? 1u : (nb >> 3) & 1u;
+    const unsigned a_top = yi ? 1u : (nb >> 1) & 1u;
+    const unsigned a_tl = xi ? a_top : (yi ? a_left : (nb & 1u));
+    const int z_cur = tables::kZOrder4[(yL >> 2) & 15][(xL >> 2) & 15];
+    const unsigned z_bl = tables::kZOrder4[((yL + hL) >> 2) & 15][((xL - 1) >> 2) & 15] <= z_cur; // (meaningful inside the CTB)
+    const unsigned z_tr = tables::kZOrder4[((yL - 1) >> 2) & 15][((xL + wL) >> 2) & 15] <= z_cur;
+    const bool below = yi + hL >= cs, beyond = xi + wL >= cs;
+    const unsigned bl = below ? (nb >> (xi ? 7 : 6)) & 1u : (xi ? z_bl : a_left);
+    const unsigned tr = yi == 0 ? (nb >> (beyond ? 2 : 1)) & 1u : (beyond ? (nb >> 5) & 1u : z_tr);
+    const unsigned a_bl = bl & a_left & (unsigned)(yc + nT < chh);
+    const unsigned a_tr = tr & (unsigned)(xc + nT < cw);
+    if (a_tl) info |= HM_TU_AVAIL_TL;
+    const int n_bl = a_bl ? std::min(nT, chh - (yc + nT)) : 0, n_tr = a_tr ? std::min(nT, cw - (xc + nT)) : 0;
+    const int x = xc & ((1 << (sps_.log2_ctb - lw)) - 1), y = yc & ((1 << (sps_.log2_ctb - lh)) - 1);
+    const int pm = mode | (cu_bypass_ ? HM_TU_MODE_BYPASS : 0);
+    const int qpy = (cIdx && pps_.cross_component_prediction) ? res_scale : cu_qpy_; // hm_stream.h: chroma records of such pictures carry ResScaleVal
+    if (direct) {
       hm_tu8 c;
-      c.pos = (uint8_t)((t.x >> 2) | ((t.y >> 2) << 4));
-      c.info = t.info; c.pred_mode = t.pred_mode; c.qp = t.qp; c.qpy = t.qpy;
-      c.avail = (uint8_t)((t.avail_bottom_left >> 2) | ((t.avail_top_right >> 2) << 4));
-      c.count = (uint16_t)(t.n_coeff | (aL ? HM_TU8_LEFT : 0) | (aT ? HM_TU8_TOP : 0));
-      vec.push_back(c);
+      c.pos = (uint8_t)((x >> 2) | ((y >> 2) << 4));
+      c.info = (uint8_t)info; c.pred_mode = (uint8_t)pm; c.qp = (uint8_t)qp_prime_[cIdx]; c.qpy = (int8_t)qpy;
+      c.avail = (uint8_t)((n_bl >> 2) | ((n_tr >> 2) << 4));
+      c.count = (uint16_t)(ncoef | (a_left ? HM_TU8_LEFT : 0) | (a_top ? HM_TU8_TOP : 0));
+      row_->tu[k].push_back(c);
+      if (cIdx == 0) ctb_cur_->tu_count++;
+      else ctb_cur_->tu_count_c++;
       return;
     }
-    auto& vec = pic_.ctb_tus[ctb_addr_rs_];
-    vec.push_back(t);
+    hm_tu t;
+    t.x = (uint8_t)x; t.y = (uint8_t)y;
+    t.info = (uint8_t)info; t.pred_mode = (uint8_t)pm;
+    t.qp = (uint8_t)qp_prime_[cIdx]; t.qpy = (int8_t)qpy;
+    t.n_coeff = (uint16_t)ncoef; t.coeff_first = coeff_first;
+    t.avail_left = a_left ? (uint8_t)nT : 0; t.avail_top = a_top ? (uint8_t)nT : 0;
+    t.avail_bottom_left = (uint8_t)n_bl; t.avail_top_right = (uint8_t)n_tr;
+    pic_.ctb_tus[ctb_addr_rs_].push_back(t);
   }
 
   // ---- residual_coding (§7.3.8.11) --------------------------------------------------------------
@@ -1214,8 +1194,9 @@ class SliceWalker {
   int w4_ = 0;
   int ctb_addr_ts_ = 0, ctb_addr_rs_ = 0;
   int ctb_x_ = 0, ctb_y_ = 0;      // current CTB in CTB units
-  AvailMemo avail_memo_[2];
-  int avail_memo_next_ = 0;
+  unsigned nb9_ = 0;               // nb_ok_ as bits (bit k = nb_ok_[k])
+  PictureState::RowChains* row_ = nullptr; // the current CTU's row (split chains)
+  hm_ctb* ctb_cur_ = nullptr;      // ... and its header
   uint8_t nb_ok_[9] = {0};         // availability of the 3x3 CTBs around (and including) the current one, see avail_z
   // QP state (thread_context fields of the reference: decctx.h)
   bool is_cu_qp_delta_coded_ = false;
