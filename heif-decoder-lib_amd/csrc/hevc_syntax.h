@@ -269,6 +269,9 @@ class SliceWalker {
       : ec_(ec), pic_(pic), sps_(*pic.sps), pps_(*pic.pps), sh_(sh), slice_idx_(slice_idx), qs_(&pic.qs), coeffs_(&pic.coeffs)
   {
     w4_ = (sps_.width + 3) >> 2;
+    // position of the slice's first CTB (derive_qp asks for it once per coding unit: no division there)
+    slice_x0_ = (sh_.SliceAddrRS % sps_.ctb_w) << sps_.log2_ctb;
+    slice_y0_ = (sh_.SliceAddrRS / sps_.ctb_w) << sps_.log2_ctb;
   }
   // A walker of one CTB row of a wavefront-parallel parse (hevc_parse.cpp) keeps the state a sub-stream carries in its
   // own objects: the QP predictor state and the level list (rebased into the picture's list afterwards).
@@ -568,8 +571,7 @@ class SliceWalker {
     }
     const int ctbmask = (1 << sps_.log2_ctb) - 1;
     const bool first_in_ctb_row = (xQG == 0 && (yQG & ctbmask) == 0);
-    const int sx = (sh_.SliceAddrRS % sps_.ctb_w) << sps_.log2_ctb, sy = (sh_.SliceAddrRS / sps_.ctb_w) << sps_.log2_ctb;
-    const bool first_in_slice = (sx == xQG && sy == yQG);
+    const bool first_in_slice = (slice_x0_ == xQG && slice_y0_ == yQG);
     bool first_in_tile = false;
     if (pps_.tiles_enabled && (xQG & ctbmask) == 0 && (yQG & ctbmask) == 0) {
       const int cx = xQG >> sps_.log2_ctb, cy = yQG >> sps_.log2_ctb;
@@ -598,7 +600,16 @@ class SliceWalker {
     }
     pred = (qa + qb + 1) >> 1;
     const int bdY = sps_.qp_bd_offset_y, bdC = sps_.qp_bd_offset_c;
-    const int qpy = ((pred + cu_qp_delta_val_ + 52 + 2 * bdY) % (52 + bdY)) - bdY;
+    // ((pred + CuQpDeltaVal + 52 + 2 * QpBdOffset) % (52 + QpBdOffset)) - QpBdOffset; a valid stream keeps the sum inside
+    // [0, 3 * (52 + QpBdOffset)): two conditional subtractions instead of a division per coding unit
+    int qsum = pred + cu_qp_delta_val_ + 52 + 2 * bdY;
+    const int qmod = 52 + bdY;
+    if ((unsigned)qsum < (unsigned)(3 * qmod)) {
+      qsum -= qsum >= qmod ? qmod : 0;
+      qsum -= qsum >= qmod ? qmod : 0;
+    }
+    else qsum %= qmod; // (a damaged stream: the plain expression)
+    const int qpy = qsum - bdY;
     qp_prime_[0] = std::max(0, qpy + bdY);
     for (int c = 1; c <= 2; c++) {
       // CuQpOffsetCb / Cr (transform.cc:154-155): the value of the last cu_chroma_qp_offset_flag of this slice segment
@@ -1195,6 +1206,7 @@ class SliceWalker {
   int ctb_addr_ts_ = 0, ctb_addr_rs_ = 0;
   int ctb_x_ = 0, ctb_y_ = 0;      // current CTB in CTB units
   unsigned nb9_ = 0;               // nb_ok_ as bits (bit k = nb_ok_[k])
+  int slice_x0_ = 0, slice_y0_ = 0; // luma position of the slice's first CTB
   PictureState::RowChains* row_ = nullptr; // the current CTU's row (split chains)
   hm_ctb* ctb_cur_ = nullptr;      // ... and its header
   uint8_t nb_ok_[9] = {0};         // availability of the 3x3 CTBs around (and including) the current one, see avail_z
