@@ -141,3 +141,13 @@ def test_engine_equals_the_standard_bit_by_bit(tables, seed):
     pos = hm.hm_test_cabac_script(data, len(data), qp, arr, used, out)
     assert list(out) == want
     assert pos == (spec.bitpos + 7) // 8
+
+
+def test_script_hook_refuses_bad_scripts():
+    hm = C.CDLL(os.path.join(ROOT, "heif-decoder-lib_amd", "libheif_mi355x.so"))
+    hm.hm_test_cabac_script.restype = C.c_long
+    hm.hm_test_cabac_script.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_uint32)]
+    out = (C.c_uint32 * 1)()
+    for bad in (100000, -35):
+        assert hm.hm_test_cabac_script(b"\x12\x34\x56", 3, 30, (C.c_int32 * 1)(bad), 1, out) == -1
+    assert hm.hm_test_cabac_script(b"\x12", 1, 30, (C.c_int32 * 1)(0), 1, out) == -1  # (an arithmetic code has two bytes at least)
