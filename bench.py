@@ -551,12 +551,14 @@ def side_legs(out, args, torch, pkg, dev, st, gb, kept, strides, stream_b):
 
 
 def host_parse_rate(pkg, streams):
-    t0 = time.perf_counter()
-    for data in streams:
-        pkg.capi.parse_hevc(data)
-    dt = time.perf_counter() - t0
+    dt = 1e9
+    for _ in range(5):
+        t0 = time.perf_counter()
+        for data in streams:
+            pkg.capi.parse_hevc(data)
+        dt = min(dt, time.perf_counter() - t0)
     return {"MP_per_s_per_core": round(len(streams) * TILE * TILE / 1e6 / dt, 1),
-            "note": "hm_hevc_parse (CABAC -> command stream), 1 thread, outside the timed region"}
+            "note": "hm_hevc_parse (CABAC -> command stream), 1 thread, best of 5 passes over the tiles of one image, outside the timed region"}
 
 
 def colour_standalone(torch, pkg, gb, st):
