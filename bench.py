@@ -159,9 +159,8 @@ def timed_steps(torch, gb, st, steps, dist=None):
 
 
 # names as rocprofv3 lists them (the headline workload - 8-bit 4:2:0 without rare syntax - runs the split-chain
-# reconstruction: k_residual, then k_chain; HM_CHAIN=0 selects r02's single kernel k_recon_quad for A/B runs)
-OLD_RECON = os.environ.get("HM_CHAIN", "1") == "0"
-KERNEL_NAMES = ["k_recon_quad" if OLD_RECON else "k_chain", "k_deblock", "k_sao_paste", "k_ycbcr420_int(colour)", "k_residual"]
+# reconstruction: k_residual, then k_chain)
+KERNEL_NAMES = ["k_chain", "k_deblock", "k_sao_paste", "k_ycbcr420_int(colour)", "k_residual"]
 TAIL_NAME = "k_tail420(deblock+sao+paste+colour)"  # the fused kernel: timing slot 2, slots 1 and 3 are empty
 
 
@@ -169,8 +168,6 @@ def kernel_names(gb):
     names = list(KERNEL_NAMES)
     if gb.batch.tail_fused():
         names[1], names[2], names[3] = None, TAIL_NAME, None
-    if OLD_RECON:
-        names[4] = None
     return names
 
 
@@ -180,7 +177,7 @@ def kernel_table(gb, avg_ms, colour_bytes_per_px=4.5):
     # out; prediction chains = command stream without the levels + residual in + samples out (r02's single kernel:
     # command stream + samples out); deblock = read + write of the samples; sao+paste = read + write; colour = 1.5 B in +
     # 3 B out per output pixel
-    chain_b = stream_b + sample_b if OLD_RECON else stream_b - level_b + resid_b + sample_b
+    chain_b = stream_b - level_b + resid_b + sample_b
     alg = [chain_b, 2 * sample_b, 2 * sample_b, int(colour_bytes_per_px * gb.pixels()), stream_b + resid_b]
     names = kernel_names(gb)
     if gb.batch.tail_fused():  # reads the reconstruction once, writes the pixels once
@@ -196,21 +193,58 @@ def kernel_table(gb, avg_ms, colour_bytes_per_px=4.5):
     if cms > 0 and names[3]:
         table[KERNEL_NAMES[3]]["read_only_GBps"] = round(1.5 * gb.pixels() / cms / 1e6, 1)
         table[KERNEL_NAMES[3]]["read_only_frac_of_hbm_peak"] = round(1.5 * gb.pixels() / cms / 1e6 / HBM_PEAK_GBPS, 4)
-    return table, alg, stream_b
+    return table, alg, stream_b, sample_b
 
 
-def pmc_traffic(kernel, images):
-    """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC passes (profiles/r0N_pmc_traffic.json:
+PMC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+
+
+def pmc_traffic(kernels, images):
+    """HBM bytes per launch of the named kernels (summed) from the COMMITTED rocprofv3 PMC passes (profiles/r0N_pmc_traffic.json:
     FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, separate passes, scaled per image) - a table look-up, not
     counters of this run (counters need their own rocprofv3 passes: tools/pmc_traffic.sh).  Returns (bytes, source);
-    (None, None) when no measurement for this kernel is on file."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    (None, None) when no measurement for one of the kernels is on file."""
+    for name in PMC_FILES:
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))
-            return int(t["kernels"][kernel]["hbm_bytes_per_image"] * images), f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh, scaled per image; not live counters of this run)"
+            total = sum(t["kernels"][k]["hbm_bytes_per_image"] for k in kernels)
+            return int(total * images), f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh, scaled per image; not live counters of this run)"
         except Exception:
             continue
     return None, None
+
+
+def roofline_lines(gb, avg_ms, alg, stream_b, sample_b, step_ms, images):
+    """The roofline object of the JSON line, on the byte model of SURVEY 8(d) - which cannot rise by adding a pass:
+      stage  reconstruction (k_residual + k_chain): command stream in + reconstructed samples out (1.5 B/px of 8-bit 4:2:0);
+             the residuals / micro-ops the two kernels hand each other are intermediates, not algorithmic bytes
+      step   the whole hot path: the stage + the tail (samples in, RGB out)
+    `achieved` / `frac` at the top level are the stage's (the kernels that take the largest share of the step); the
+    per-kernel figures on each kernel's own input + output stay in `kernels` and, for the dominant one, in `own_io`."""
+    names = kernel_names(gb)
+    recon = [names[q] for q in (4, 0) if names[q]]
+    recon_ms = avg_ms[4] + avg_ms[0]
+    stage_b = stream_b + sample_b
+    tail_b = sum(alg[q] for q in (1, 2, 3))
+    step_b = stage_b + tail_b
+    stage_gbps = stage_b / recon_ms / 1e6
+    tr_stage, src = pmc_traffic(recon, images)
+    tr_step, _ = pmc_traffic([n for n in names if n], images)
+    dom = max(range(5), key=lambda q: avg_ms[q])
+    own = alg[dom] / avg_ms[dom] / 1e6
+    tr_dom, _ = pmc_traffic([names[dom]], images)
+    r = {"bound": "hbm", "kernel": " + ".join(recon) + " (the reconstruction stage of SURVEY 8d)",
+         "bytes_model": "SURVEY 8(d): command stream in + 1.5 B/px of reconstructed samples out; intermediates between the two kernels not counted",
+         "achieved": round(stage_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(stage_gbps / HBM_PEAK_GBPS, 5),
+         "traffic": tr_stage, "traffic_ratio": round(tr_stage / stage_b, 2) if tr_stage else None, "traffic_source": src,
+         "stage": {"algorithmic_bytes": int(stage_b), "ms": round(recon_ms, 4), "GBps": round(stage_gbps, 1), "frac": round(stage_gbps / HBM_PEAK_GBPS, 5)},
+         "step": {"algorithmic_bytes": int(step_b), "ms": round(step_ms, 4), "GBps": round(step_b / step_ms / 1e6, 1),
+                  "frac": round(step_b / step_ms / 1e6 / HBM_PEAK_GBPS, 5), "traffic": tr_step,
+                  "traffic_ratio": round(tr_step / step_b, 2) if tr_step else None},
+         "own_io": {"kernel": names[dom], "note": "the dominant kernel on its OWN input + output bytes (includes the intermediates of the split: secondary figure)",
+                    "algorithmic_bytes": int(alg[dom]), "ms": round(avg_ms[dom], 4), "GBps": round(own, 1), "frac": round(own / HBM_PEAK_GBPS, 5),
+                    "traffic": tr_dom, "traffic_ratio": round(tr_dom / alg[dom], 2) if tr_dom else None}}
+    return r
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -228,6 +262,36 @@ def launch_ranks(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
+
+
+def rccl_selftest(torch, pkg, dev):
+    """N = 1: a one-rank process group on the requested backend ("nccl" IS RCCL on ROCm), so that the line shows librccl
+    loads on this image and a collective on a device tensor runs - an all_reduce and the design's only data-path
+    collective, shard.gather_slabs (a padded dist.gather), checked against its input.  Never fatal: an error is reported
+    as text (the decode path needs no collective)."""
+    import torch.distributed as dist
+    info = {}
+    try:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+        try:
+            t = torch.arange(1024, dtype=torch.float32, device=dev)
+            dist.all_reduce(t)
+            slab = torch.randint(0, 256, (37, 12096), dtype=torch.uint8, device=dev)
+            full = pkg.shard.gather_slabs(slab, [37], dst=0)
+            torch.cuda.synchronize()
+            info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                    "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()),
+                    "all_reduce_ok": bool(torch.equal(t.cpu(), torch.arange(1024, dtype=torch.float32))),
+                    "gather_slabs_ok": bool(full is not None and torch.equal(full, slab)),
+                    "note": "one-rank RCCL group at N = 1 (a load + execute check of the backend); the N > 1 legs use the same calls"}
+        finally:
+            dist.destroy_process_group()
+    except Exception as e:  # noqa: BLE001 - reported, not raised
+        info = {"backend": "nccl", "error": f"{type(e).__name__}: {e}"[:300]}
+    return info
 
 
 def main():
@@ -286,6 +350,9 @@ def run(args):
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"only {dist.get_world_size()} of {args.gpus} ranks joined")
+    dist_info = None
+    if world == 1 and args.dist_backend == "nccl":
+        dist_info = rccl_selftest(torch, pkg, dev)
     st = torch.cuda.current_stream().cuda_stream
     if args.mode == "grid":
         return run_grid(args, torch, pkg, dev, dist, rank, world, st, shared=world > ndev)
@@ -352,16 +419,14 @@ def run(args):
         extra = out
         total_mp = world * B * MP_PER_IMAGE * args.steps
         value = total_mp / elapsed
-        kernels, alg, stream_b = kernel_table(gb, avg_ms)
-        dom = max(range(5), key=lambda q: avg_ms[q])
-        achieved = alg[dom] / avg_ms[dom] / 1e6
-        traffic, traffic_source = pmc_traffic(kernel_names(gb)[dom], B)
+        kernels, alg, stream_b, sample_b = kernel_table(gb, avg_ms)
         out = {
             "metric": "megapixels/sec HEIC grid->RGB24",
             "value": round(value, 1), "unit": "MP/s",
             "value_clock": "K: GPU kernels only (reconstruction -> deblocking -> SAO/paste -> colour) on command streams already in HBM - no CABAC, no H2D, no D2H; "
                            ".heic bytes in -> RGB in host memory is end_to_end_MP_per_s below (host entropy decode bound)",
             "end_to_end_MP_per_s": None, "device_inclusive_MP_per_s": None, "n_gpus": world, "world_size": dist.get_world_size() if dist else 1,
+            "dist": {"backend": dist.get_backend(), "world_size": dist.get_world_size()} if dist else dist_info,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
@@ -370,8 +435,7 @@ def run(args):
                        "timed_region": "K clock of SURVEY 8d: recon+deblock+SAO/paste+colour kernels, command streams (host CABAC output) resident in HBM; "
                                        "the transfer- and host-inclusive clocks are device_inclusive / end_to_end_pipelined below",
                        "parity": parity},
-            "roofline": {"bound": "hbm", "kernel": kernel_names(gb)[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_source},
+            "roofline": roofline_lines(gb, avg_ms, alg, stream_b, sample_b, elapsed / args.steps * 1e3, B),
             "kernels": kernels,
         }
         out.update(extra)
@@ -419,23 +483,45 @@ def multi_rank_legs(out, args, torch, pkg, dev, dev_index, st, gb, kept, dist, r
         dist.all_gather(parts, t)
         return [[float(x) for x in p.tolist()] for p in parts]
 
+    # Every rank always reaches every collective below: a rank whose leg fails (output hash mismatch, pipeline error, fewer
+    # files) reports status 0 and zeros instead of leaving the others blocked in all_gather until the backend's timeout.
     # ---- D ----
-    copy = torch.cuda.Stream(device=dev)
-    gb.batch.upload_execute(3, 3, copy.cuda_stream, st)
-    torch.cuda.synchronize()
-    dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(3):
+    d_ms, d_ok, err = 0.0, 1, ""
+    try:
+        copy = torch.cuda.Stream(device=dev)
         gb.batch.upload_execute(3, 3, copy.cuda_stream, st)
-    torch.cuda.synchronize()
-    d_ms = (time.perf_counter() - t0) / 3 * 1e3
-    gb.batch.check()
+        torch.cuda.synchronize()
+    except Exception as ex:  # noqa: BLE001
+        d_ok, err = 0, f"D warm-up: {ex}"
+    dist.barrier()
+    if d_ok:
+        try:
+            t0 = time.perf_counter()
+            for _ in range(3):
+                gb.batch.upload_execute(3, 3, copy.cuda_stream, st)
+            torch.cuda.synchronize()
+            d_ms = (time.perf_counter() - t0) / 3 * 1e3
+            gb.batch.check()
+        except Exception as ex:  # noqa: BLE001
+            d_ok, err = 0, f"D: {ex}"
     # ---- E ----
     threads, cpus = rank_cpu_share(rank, world)
     n_files = max(16, min(len(kept), 256 // world))
     dist.barrier()
-    e = end_to_end_pipelined(pkg, kept[:n_files], threads=threads, cpus=cpus, device=dev_index)
-    rows = gather([d_ms, e["seconds"], e["images"], threads, cpus[0] if cpus else -1, cpus[1] if cpus else 0, e["outputs_hash_checked"]])
+    e_ok = 1
+    e = {"seconds": 0.0, "images": 0, "outputs_hash_checked": 0}
+    try:
+        e = end_to_end_pipelined(pkg, kept[:n_files], threads=threads, cpus=cpus, device=dev_index)
+    except Exception as ex:  # noqa: BLE001
+        e_ok, err = 0, (err + "; " if err else "") + f"E: {ex}"
+    if err:
+        print(f"[bench rank {rank}] multi_rank_legs: {err}", file=sys.stderr, flush=True)
+    rows = gather([d_ms, e["seconds"], e["images"], threads, cpus[0] if cpus else -1, cpus[1] if cpus else 0, e["outputs_hash_checked"], d_ok, e_ok])
+    if rank == 0 and not all(r[7] and r[8] for r in rows):
+        out["multi_rank_legs_failed"] = {"ranks_D": [i for i, r in enumerate(rows) if not r[7]], "ranks_E": [i for i, r in enumerate(rows) if not r[8]],
+                                         "note": "see the failing rank's stderr; D / E aggregates omitted"}
+        out["dist"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
+        return
     if rank == 0:
         d_max = max(r[0] for r in rows)
         e_max = max(r[1] for r in rows)
@@ -950,7 +1036,7 @@ def config5_single(torch, pkg, dev, st):
     for _ in range(2):
         gb.step(st)
     elapsed, avg_ms = timed_steps(torch, gb, st, 10)
-    kernels, alg, _ = kernel_table(gb, avg_ms)
+    kernels, alg, _, _ = kernel_table(gb, avg_ms)
     mp = 16384 * 16384 / 1e6
     res = {"MP_per_s": round(mp * 10 / elapsed, 1), "ms_per_grid": round(elapsed / 10 * 1e3, 3), "kernels": kernels,
            "note": "one 268 MP grid = 1024 tiles per launch (a third of the headline's tiles in flight: the reconstruction kernel's wavefront tail weighs more)"}

@@ -73,25 +73,21 @@ struct Class {
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // reconstruction of the pictures of one class: pictures whose records come as separate luma / chroma chains
-// (HM_PIC_SPLIT_CHAINS: everything without rare syntax) run the four-chains-per-wave kernel, the others (records in
-// decode order) the one-row-per-wave kernel
+// (HM_PIC_SPLIT_CHAINS: everything without rare syntax) run the residual pre-pass and the prediction-chain kernel, the
+// others (records in decode order) the one-row-per-wave kernel
 // (`mid`, if given, is called between the two kernels of the split-chain path: the profiling marks)
 // (`sync`: the launch's own region of the batch's synchronisation words, hm_internal.h: hm_launch_chain)
-struct SyncRegion { uint32_t* p = nullptr; size_t bytes = 0; std::vector<uint32_t*>* used = nullptr; };
+struct SyncRegion { uint32_t* p = nullptr; size_t bytes = 0; std::vector<uint32_t*>* used = nullptr; uint32_t* err = nullptr; };
 template <typename Mid>
 int launch_recon(const hm_dev_pic* dc, int n, const Class& c, hipStream_t s, SyncRegion sync, Mid&& mid)
 {
   if (c.split) {
-    // HM_CHAIN=0: the r02 kernel (dequantisation + transforms on the dependency chain), kept for A/B measurements
-    static const bool old_kernel = [] { const char* e = std::getenv("HM_CHAIN"); return e && e[0] == '0'; }();
-    if (!old_kernel) {
-      const int rc = hm_launch_residual(dc, n, c.max_ctb_h, s);
-      if (rc) return rc;
-      mid();
-    }
-    const int q = old_kernel ? hm_launch_recon_quad(dc, n, c.log2_ctb, c.chroma_format, c.bit_depth, c.rare, c.max_ctb_w, c.max_ctb_h, s)
-                             : hm_launch_chain(dc, n, c.log2_ctb, c.chroma_format, c.bit_depth, c.rare, c.max_ctb_w, c.max_ctb_h, sync.p, sync.bytes, s);
-    if (q == 2 && sync.used && sync.used->size() < 4096) sync.used->push_back(sync.p); // the launch's error flag is word 1
+    const int rc = hm_launch_residual(dc, n, c.max_ctb_h, s);
+    if (rc) return rc;
+    mid();
+    const int q = hm_launch_chain(dc, n, c.log2_ctb, c.chroma_format, c.bit_depth, c.rare, c.max_ctb_w, c.max_ctb_h, sync.p, sync.bytes, sync.err, s);
+    // (HM_CHAIN_TIMING builds leave their phase sums in the launch's region: remembered once per region for hm_batch_check's print)
+    if (q == 2 && sync.used && sync.used->size() < 64 && std::find(sync.used->begin(), sync.used->end(), sync.p) == sync.used->end()) sync.used->push_back(sync.p);
     if (q == 0) return hm_fail(HM_ERR_UNSUPPORTED, "CTU staging does not fit LDS (CTB %d, %d bit, %d CTBs wide)", 1 << c.log2_ctb, c.bit_depth, c.max_ctb_w);
     return q < 0 ? q : HM_OK;
   }
@@ -152,6 +148,10 @@ struct hm_batch {
   DeviceBuffer d_sync;
   size_t sync_stride = 0;
   std::vector<uint32_t*> sync_used;
+  // ... and the batch's sticky error word: the LAST word of d_sync, zeroed when the buffer is laid out and when
+  // hm_batch_check has read it - never by a launch, so that a check after many executes sees a give-up of any of them
+  uint32_t* err_word() { return d_sync.p && sync_stride ? (uint32_t*)d_sync.p + sync_words_total : nullptr; }
+  size_t sync_words_total = 0;
   SyncRegion sync_region(const hm_dev_pic* dc, int n)
   {
     SyncRegion r;
@@ -160,6 +160,7 @@ struct hm_batch {
     r.p = (uint32_t*)d_sync.p + i0 * sync_stride;
     r.bytes = (size_t)n * sync_stride * sizeof(uint32_t);
     r.used = &sync_used;
+    r.err = err_word();
     return r;
   }
   hipStream_t copy_stream = nullptr;
@@ -374,7 +375,12 @@ static int batch_prepare(hm_batch* b, size_t* blob_bytes_out)
       if (c.split) rows = std::max(rows, (size_t)c.max_ctb_h);
     b->sync_stride = rows ? 8 + 2 * rows : 0;
     b->sync_used.clear();
-    if (b->sync_stride && (rc = b->d_sync.ensure((size_t)n * b->sync_stride * sizeof(uint32_t)))) return rc;
+    b->sync_words_total = (size_t)n * b->sync_stride;
+    if (b->sync_stride) {
+      if ((rc = b->d_sync.ensure((b->sync_words_total + 1) * sizeof(uint32_t)))) return rc;
+      const hipError_t ez = hipMemset(b->err_word(), 0, sizeof(uint32_t)); // (the batch was drained above: nothing in flight)
+      if (ez != hipSuccess) return hm_check_hip(ez, "hipMemset(reconstruction error word)");
+    }
   }
 
   // (every check that can fail on file data runs before anything is enqueued: an error return must not leave copies
@@ -488,6 +494,9 @@ int hm_batch_execute(hm_batch* b, int stages, void* stream)
 {
   if (!b) return hm_fail(HM_ERR_INVALID_ARG, "null batch");
   if (!b->uploaded) return hm_fail(HM_ERR_INVALID_ARG, "hm_batch_upload() has not been called");
+  if (const int fw = hm_debug_batch_fail_width()) // (test hook, hm_internal.h: never set in production)
+    for (const Item& it : b->items)
+      if ((int)it.hdr.width == fw) return hm_fail(HM_ERR_UNSUPPORTED, "test hook: pictures %d samples wide are refused", fw);
   hipStream_t s = (hipStream_t)stream;
   // a different stream than the upload's (a copy stream feeding a compute stream): order them on the device
   if (s != b->last_stream && b->upload_done) {
@@ -842,19 +851,21 @@ int hm_batch_check(hm_batch* b)
   if (!b) return hm_fail(HM_ERR_INVALID_ARG, "null batch");
   b->drain();
   int bad = 0;
-  for (const uint32_t* region : b->sync_used) {
+  if (uint32_t* ew = b->err_word()) { // one word for the whole batch, whatever ran since the last check
     uint32_t flag = 0;
-    const hipError_t e = hipMemcpy(&flag, region + 1, sizeof(flag), hipMemcpyDeviceToHost);
-    if (e != hipSuccess) return hm_check_hip(e, "hipMemcpy(reconstruction error flag)");
-    bad |= flag != 0;
-    // HM_CHAIN_TIMING builds of chain.hip (tools/chain_timing.sh) leave per-phase cycle sums in words 2..7
-    static const bool timing = [] { const char* t = std::getenv("HM_CHAIN_TIMING_PRINT"); return t && t[0] == '1'; }();
-    if (timing) {
+    hipError_t e = hipMemcpy(&flag, ew, sizeof(flag), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && flag) e = hipMemset(ew, 0, sizeof(flag));
+    if (e != hipSuccess) return hm_check_hip(e, "hipMemcpy(reconstruction error word)");
+    bad = flag != 0;
+  }
+  // HM_CHAIN_TIMING builds of chain.hip (tools/chain_timing.sh) leave per-phase cycle sums in words 2..7 of a launch's region
+  static const bool timing = [] { const char* t = std::getenv("HM_CHAIN_TIMING_PRINT"); return t && t[0] == '1'; }();
+  if (timing)
+    for (const uint32_t* region : b->sync_used) {
       uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       if (hipMemcpy(w, region, sizeof(w), hipMemcpyDeviceToHost) == hipSuccess)
         std::fprintf(stderr, "[k_chain phases, 64-cycle units summed over waves] A+poll %u, R+fetch %u, P+C %u, D %u, E+F %u, iterations %u\n", w[2], w[3], w[4], w[5], w[6], w[7]);
     }
-  }
   b->sync_used.clear();
   return bad ? hm_fail(HM_ERR_INTERNAL, "a reconstruction wave gave up waiting for the rows above it") : HM_OK;
 }

@@ -24,8 +24,11 @@
 //   * the block map of the deblocking filter (transform edges + QpY per 4x4 block) is no business of the chains either:
 //     residual.hip writes it;
 //   * PAIRS (few, large pictures): every pair of CTU rows of a picture is a wave of its own - any number of them, in
-//     any workgroup -, ordered by a ticket taken at start (a wave only ever waits for a wave with a smaller ticket, which
-//     is running or done: no deadlock whatever the dispatch order).  The hand-over between pairs goes through HBM: the
+//     any workgroup -, ordered by a ticket taken at start.  With a wave per band a wave only ever waits for a wave with a
+//     smaller ticket, which is running or done: no deadlock whatever the dispatch order.  When W waves take a picture's
+//     bands in turn (the "share" cut) that does not hold - wave 0's second band waits for band W - 1, which the wave
+//     with ticket W - 1 holds -: forward progress then needs all W waves of a picture resident together, which the
+//     launcher guarantees by capping W x pictures at the waves the device holds at once (resident_waves below).  The hand-over between pairs goes through HBM: the
 //     bottom sample row of a pair is a row of the picture the kernel stores anyway; a per-row progress word
 //     (agent scope) tells the pair below how far it is.  Every wait is bounded: a wave that waits too long sets the
 //     launch's error word and leaves, the host reports HM_ERR_INTERNAL.
@@ -40,11 +43,11 @@
 
 namespace {
 
-// HM_CHAIN_TIMING (tools/chain_timing.sh): per-phase cycle sums of the PAIRS kernel in words 2..7 of the launch's sync region
+// HM_CHAIN_TIMING (tools/chain_timing.sh): per-phase cycle sums of the kernel (every cut) in words 2..7 of the launch's sync region
 #ifdef HM_CHAIN_TIMING
 #define HM_T_DECL unsigned long long t_prev = __builtin_amdgcn_s_memtime(); unsigned int t_acc[6] = {0, 0, 0, 0, 0, 0}
 #define HM_T_LAP(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_acc[i] += (unsigned int)(t_now - t_prev); t_prev = t_now; } while (0)
-#define HM_T_FLUSH() do { if (PAIRS && lane == 0) { for (int q = 0; q < 5; q++) atomicAdd(sync + 2 + q, t_acc[q] >> 6); atomicAdd(sync + 7, t_acc[5]); } } while (0)
+#define HM_T_FLUSH() do { if (sync && lane == 0) { for (int q = 0; q < 5; q++) atomicAdd(sync + 2 + q, t_acc[q] >> 6); atomicAdd(sync + 7, t_acc[5]); } } while (0)
 #else
 #define HM_T_DECL
 #define HM_T_LAP(i)
@@ -98,9 +101,10 @@ struct CLayout {
   int spin_limit;    // PAIRS: polls of the band above without news before a wave gives up (error flag, wrong picture, no hang)
   int test_stall;    // fault injection (tests): the first band of every picture never announces its progress
 };
-// PAIRS: words of the launch's synchronisation buffer (zeroed before the launch): a ticket counter, an error flag, then
-// per (picture, pair, chain kind) the finished CTUs of the pair's last row
-constexpr int SYNC_TICKET = 0, SYNC_ERROR = 1, SYNC_PROGRESS = 8;
+// PAIRS: words of the launch's synchronisation buffer (zeroed before the launch): a ticket counter, then per (picture,
+// pair, chain kind) the finished CTUs of the pair's last row.  A wave that gives up a bounded wait sets the BATCH's error
+// word (err_word: a word of its own that no launch clears - hm_batch_check reads and resets it)
+constexpr int SYNC_TICKET = 0, SYNC_PROGRESS = 8;
 constexpr int SPIN_LIMIT = 1 << 20; // default of CLayout.spin_limit
 
 __device__ __forceinline__ int g_of(int lane) { return lane >> 4; }
@@ -128,7 +132,7 @@ constexpr int chain_waves_per_simd = (sizeof(Pix) == 1 && !PAIRS) ? (LOG2_CTB <=
 #define HM_CHAIN_ATTR __attribute__((amdgpu_waves_per_eu(chain_waves_per_simd<Pix, LOG2_CTB, PAIRS>, chain_waves_per_simd<Pix, LOG2_CTB, PAIRS>)))
 #endif
 template <typename Pix, int LOG2_CTB, bool PAIRS>
-__global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* __restrict__ pics, int n_pics, CLayout L, uint32_t* __restrict__ sync)
+__global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* __restrict__ pics, int n_pics, CLayout L, uint32_t* __restrict__ sync, uint32_t* __restrict__ err_word)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         // wait for this one - with the launch flagged: the bands below give up in turn, nothing hangs
         const bool gave_up = poll && st == ST_START && ++hbm_polls > L.spin_limit;
         if (ballot(gave_up)) {
-          if (lane == 0) __hip_atomic_store(sync + SYNC_ERROR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lane == 0) __hip_atomic_store(err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           st = ST_DONE;
         }
         if (ballot(st == ST_RUN) == 0) __builtin_amdgcn_s_sleep(8); // every chain of the wave waits
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     if (lane0_dummy + pad_v == -12345) break; // (keeps the padding alive)
 #endif
     if (--budget < 0) { // (never on a valid stream: a wave that cannot finish leaves a wrong picture, not a hung GPU)
-      if (PAIRS && lane == 0) __hip_atomic_store(sync + SYNC_ERROR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (PAIRS && lane == 0) __hip_atomic_store(err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       break;
     }
 
@@ -946,11 +950,21 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
 
 } // namespace
 
+// Test hooks (tests/chain_mode_check.py through hm_debug_set, common.cpp): a shorter bound for the waits and the fault
+// injection "the first band of every picture never announces its progress".  Not read from the environment: a stray
+// variable must not be able to fail decodes in production.
+static int g_chain_spin_limit = 0, g_chain_test_stall = 0;
+extern "C" void hm_chain_test_knobs(int spin_limit, int test_stall)
+{
+  if (spin_limit >= 0) g_chain_spin_limit = spin_limit;
+  if (test_stall >= 0) g_chain_test_stall = test_stall;
+}
+
 // The chain kernel serves every picture whose records come as split chains (no rare syntax, not 4:4:4), after
 // hm_launch_residual on the same stream; returns 1 if it launched (2: in the wave-per-row-pair mode, i.e. using d_sync),
-// 0 if the CTU staging does not fit LDS, < 0 on error.
+// 0 if the CTU staging does not fit LDS, < 0 on error.  d_err: the batch's sticky error word (never cleared here).
 extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ctb, int chroma_format, int bit_depth, int rare_syntax,
-                               int max_ctb_w, int max_ctb_h, uint32_t* d_sync, size_t sync_bytes, hipStream_t s)
+                               int max_ctb_w, int max_ctb_h, uint32_t* d_sync, size_t sync_bytes, uint32_t* d_err, hipStream_t s)
 {
   if (n_pics <= 0) return 1;
   if (rare_syntax || chroma_format == 3 || log2_ctb < 4 || log2_ctb > 6) return 0;
@@ -982,16 +996,14 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   }
   // Too many pictures for a wave per pair of rows, too few to fill the machine with a wave per picture (about 400 ... 2000
   // tiles of 512x512): W waves per picture that take its pairs of rows in turn - at most 4 (more hand-overs than that cost
-  // more than the extra parallelism gives) and only as many as are resident together (4096 waves at 16 per CU: one more
-  // and a resident wave waits for one that is not).  Measured (tools/r03_share.sh, k_chain ms; a wave per picture / per
+  // more than the extra parallelism gives) and only as many as are resident together (below: one more and a resident wave
+  // waits for one that is not).  Measured (tools/r03_share.sh, k_chain ms; a wave per picture / per
   // pair of rows / W in turn): 384 tiles 4.03 / 2.55 / 2.42 (W = 4), 576: 4.44 / 3.70 / 2.52 (4), 1056: 4.78 / 5.32 / 3.18 (3),
   // 1536: 4.92 / 7.03 / 4.02 (2), 2064: 4.92 / 9.18 / 5.94 (2, 4128 waves: too many).
   int share = 0; // waves per picture in that mode
   if (pair_waves > 3000 && max_ctb_h > nr) {
-    int w = (int)(4096 / (long)n_pics);
-    if (w > 4) w = 4;
-    pairs = w >= 2;
-    share = pairs ? w : 0;
+    share = 4; // (clamped to what the device holds at once below)
+    pairs = true;
     L.rows_per_wave = nr; L.split_kinds = 0;
   }
   if (pairs && !share && L.rows_per_wave == nr && max_ctb_h <= nr) pairs = false; // (a single band: nothing to hand over)
@@ -1003,16 +1015,11 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   }
   static const int force_share = [] { const char* e = getenv("HM_CHAIN_SHARE"); return e ? atoi(e) : 0; }(); // (tuning aid: waves per picture that take its pairs of rows in turn)
   if (force_share >= 2 && max_ctb_h > nr) { pairs = true; L.rows_per_wave = nr; L.split_kinds = 0; share = force_share; }
-  L.passes = (max_ctb_h + L.rows_per_wave - 1) / L.rows_per_wave;
-  L.bands_per_pic = share && share < L.passes ? share : L.passes;
-  // (tests: HM_CHAIN_SPIN_LIMIT shortens the bounded waits, HM_CHAIN_TEST_STALL=1 makes the first band of every picture
-  //  keep its progress to itself - the bands below must then give up, flag the launch and leave)
-  static const int env_spin = [] { const char* e = getenv("HM_CHAIN_SPIN_LIMIT"); return e ? atoi(e) : 0; }();
-  static const int env_stall = [] { const char* e = getenv("HM_CHAIN_TEST_STALL"); return e ? atoi(e) : 0; }();
-  L.spin_limit = env_spin > 0 ? env_spin : SPIN_LIMIT;
-  L.test_stall = env_stall;
+  L.spin_limit = g_chain_spin_limit > 0 ? g_chain_spin_limit : SPIN_LIMIT;
+  L.test_stall = g_chain_test_stall;
   auto sync_words = [&](int bands) { return ((size_t)SYNC_PROGRESS + 2 * (size_t)n_pics * bands) * sizeof(uint32_t); };
-  if (!d_sync || sync_bytes < sync_words(L.passes)) pairs = false;
+  auto passes_of = [&]() { return (max_ctb_h + L.rows_per_wave - 1) / L.rows_per_wave; };
+  if (!d_sync || !d_err || sync_bytes < sync_words(passes_of())) { pairs = false; share = 0; }
   if (!pairs) { L.rows_per_wave = nr; L.split_kinds = 0; }
   // ---- LDS of a wave ----
   auto set_layout = [&]() -> bool { // for the cut in L; false if a wave does not fit the CU's LDS
@@ -1041,66 +1048,95 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
     return C_SHARED + L.pic_bytes <= 160 * 1024;
   };
   bool fits = set_layout();
-  if (!fits && max_ctb_h > 1 && d_sync && sync_bytes >= sync_words(max_ctb_h)) {
+  if (!fits && d_sync && d_err && sync_bytes >= sync_words(max_ctb_h)) {
     // a very wide picture (16-bit samples, > ~9000 columns): its sample lines of two rows and both kinds do not fit one
-    // wave's share of LDS - the finer cuts keep one line per wave (a wave per CTU row), or one line of one kind
-    pairs = true;
-    L.rows_per_wave = 1; L.split_kinds = 0; L.bands_per_pic = L.passes = max_ctb_h;
+    // wave's share of LDS - the finer cuts keep one line per wave (a wave per CTU row), or one line of one kind (also for
+    // a picture of ONE CTU row: its two kinds of chains are two waves)
+    pairs = true; share = 0;
+    L.rows_per_wave = 1; L.split_kinds = 0;
     fits = set_layout();
     if (!fits && !mono) { L.split_kinds = 1; fits = set_layout(); }
   }
   if (!fits) return 0;
-  const size_t sync_need = sync_words(L.passes);
-  const void* fn = nullptr;
-  const int inst = log2_ctb * 2 + (pb - 1) - 8;
-  switch (inst * 2 + (pairs ? 1 : 0)) {
-    case 0: fn = reinterpret_cast<const void*>(k_chain<uint8_t, 4, false>); break;
-    case 1: fn = reinterpret_cast<const void*>(k_chain<uint8_t, 4, true>); break;
-    case 2: fn = reinterpret_cast<const void*>(k_chain<uint16_t, 4, false>); break;
-    case 3: fn = reinterpret_cast<const void*>(k_chain<uint16_t, 4, true>); break;
-    case 4: fn = reinterpret_cast<const void*>(k_chain<uint8_t, 5, false>); break;
-    case 5: fn = reinterpret_cast<const void*>(k_chain<uint8_t, 5, true>); break;
-    case 6: fn = reinterpret_cast<const void*>(k_chain<uint16_t, 5, false>); break;
-    case 7: fn = reinterpret_cast<const void*>(k_chain<uint16_t, 5, true>); break;
-    case 8: fn = reinterpret_cast<const void*>(k_chain<uint8_t, 6, false>); break;
-    case 9: fn = reinterpret_cast<const void*>(k_chain<uint8_t, 6, true>); break;
-    case 10: fn = reinterpret_cast<const void*>(k_chain<uint16_t, 6, false>); break;
-    case 11: fn = reinterpret_cast<const void*>(k_chain<uint16_t, 6, true>); break;
-    default: return 0;
-  }
+  // ---- the kernel and the waves of it a CU holds ----
   // waves per workgroup: they only share the tables.  The count that puts the most waves on a CU: its 160 KiB of LDS
   // and the waves its four SIMDs hold with the kernel's register count (512 VGPRs per lane and SIMD, in steps of 8)
   // both limit whole workgroups
-  static int cu_waves_of[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // (per instantiation; a benign race: every thread computes the same value)
-  int& cu_waves = cu_waves_of[inst * 2 + (pairs ? 1 : 0)];
-  if (cu_waves == 0) {
-    hipFuncAttributes fa;
-    int w = 16;
-    if (hipFuncGetAttributes(&fa, fn) == hipSuccess && fa.numRegs > 0) {
-      const int per_simd = 512 / ((fa.numRegs + 7) & ~7);
-      w = 4 * (per_simd < 1 ? 1 : (per_simd > 8 ? 8 : per_simd));
-    }
-    cu_waves = w;
-  }
+  const int inst = log2_ctb * 2 + (pb - 1) - 8;
+  const void* fn = nullptr;
   int np = 0, best = 0;
-  // (workgroups of more than 8 waves: measured 40 ms instead of 27 - two of 80 KiB each do not share a CU)
-  for (int k = 1; k <= 8; k++) {
-    const int bytes = C_SHARED + k * L.pic_bytes;
-    if (bytes > 160 * 1024) break;
-    const int by_lds = 160 * 1024 / bytes, by_regs = cu_waves / k;
-    const int per_cu = (by_lds < by_regs ? by_lds : by_regs) * k;
-    if (per_cu > best) { best = per_cu; np = k; }
+  auto pick = [&](bool prs) -> bool {
+    switch (inst * 2 + (prs ? 1 : 0)) {
+      case 0: fn = reinterpret_cast<const void*>(k_chain<uint8_t, 4, false>); break;
+      case 1: fn = reinterpret_cast<const void*>(k_chain<uint8_t, 4, true>); break;
+      case 2: fn = reinterpret_cast<const void*>(k_chain<uint16_t, 4, false>); break;
+      case 3: fn = reinterpret_cast<const void*>(k_chain<uint16_t, 4, true>); break;
+      case 4: fn = reinterpret_cast<const void*>(k_chain<uint8_t, 5, false>); break;
+      case 5: fn = reinterpret_cast<const void*>(k_chain<uint8_t, 5, true>); break;
+      case 6: fn = reinterpret_cast<const void*>(k_chain<uint16_t, 5, false>); break;
+      case 7: fn = reinterpret_cast<const void*>(k_chain<uint16_t, 5, true>); break;
+      case 8: fn = reinterpret_cast<const void*>(k_chain<uint8_t, 6, false>); break;
+      case 9: fn = reinterpret_cast<const void*>(k_chain<uint8_t, 6, true>); break;
+      case 10: fn = reinterpret_cast<const void*>(k_chain<uint16_t, 6, false>); break;
+      case 11: fn = reinterpret_cast<const void*>(k_chain<uint16_t, 6, true>); break;
+      default: return false;
+    }
+    static int cu_waves_of[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // (per instantiation; a benign race: every thread computes the same value)
+    int& cu_waves = cu_waves_of[inst * 2 + (prs ? 1 : 0)];
+    if (cu_waves == 0) {
+      hipFuncAttributes fa;
+      int w = 16;
+      if (hipFuncGetAttributes(&fa, fn) == hipSuccess && fa.numRegs > 0) {
+        const int per_simd = 512 / ((fa.numRegs + 7) & ~7);
+        w = 4 * (per_simd < 1 ? 1 : (per_simd > 8 ? 8 : per_simd));
+      }
+      cu_waves = w;
+    }
+    np = 0; best = 0;
+    // (workgroups of more than 8 waves: measured 40 ms instead of 27 - two of 80 KiB each do not share a CU)
+    for (int k = 1; k <= 8; k++) {
+      const int bytes = C_SHARED + k * L.pic_bytes;
+      if (bytes > 160 * 1024) break;
+      const int by_lds = 160 * 1024 / bytes, by_regs = cu_waves / k;
+      const int per_cu = (by_lds < by_regs ? by_lds : by_regs) * k;
+      if (per_cu > best) { best = per_cu; np = k; }
+    }
+    return np > 0;
+  };
+  if (!pick(pairs)) return 0;
+  if (share) {
+    // The waves of a picture that take its bands in turn wait for each other in both directions: all of them must be on
+    // the device together.  Its capacity for this kernel: compute units x the waves a CU holds of it (`best`: registers
+    // and this cut's LDS); the forced value (HM_CHAIN_SHARE) is clamped like the chosen one.
+    static int cus_of[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (cus_of[dev] == 0) {
+      int v = 0;
+      cus_of[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    const long resident_waves = (long)cus_of[dev] * best;
+    long w = resident_waves / n_pics;
+    if (!force_share || force_share < 2) w = w > 4 ? 4 : w;
+    if (w < share) share = (int)w;
+    if (share < 2) { // not even two waves per picture fit: a wave per picture
+      share = 0; pairs = false;
+      L.rows_per_wave = nr; L.split_kinds = 0;
+      if (!set_layout() || !pick(false)) return 0;
+    }
   }
-  if (np == 0) return 0;
+  L.passes = passes_of();
+  L.bands_per_pic = share && share < L.passes ? share : L.passes;
+  const size_t sync_need = sync_words(L.passes);
   static const int force_np = [] { const char* e = getenv("HM_CHAIN_NP"); return e ? atoi(e) : 0; }(); // (tuning aid, read once)
   if (force_np > 0 && force_np <= 16 && C_SHARED + force_np * L.pic_bytes <= 160 * 1024) np = force_np;
   const long n_waves = pairs ? ((long)n_pics * L.bands_per_pic) << L.split_kinds : (long)n_pics;
   while (np > 1 && (long)np * 256 > n_waves) np--; // few waves: spread them over the CUs first
   const int lds_bytes = C_SHARED + np * L.pic_bytes;
   static const int debug = [] { const char* e = getenv("HM_CHAIN_DEBUG"); return e ? atoi(e) : 0; }();
-  if (debug) fprintf(stderr, "[k_chain] %d pictures, %ld waves (%s), %d bytes of LDS per wave, %d waves per workgroup, registers allow %d waves per CU\n", n_pics, n_waves,
+  if (debug) fprintf(stderr, "[k_chain] %d pictures, %ld waves (%s), %d bytes of LDS per wave, %d waves per workgroup, %d waves per CU\n", n_pics, n_waves,
                      !pairs ? "one per picture" : (L.split_kinds ? "one per chain of a CTU row" : (L.rows_per_wave == 1 ? "one per CTU row" : (L.bands_per_pic < L.passes ? "several per picture, taking its pairs of CTU rows in turn" : "one per pair of CTU rows"))),
-                     L.pic_bytes, np, cu_waves);
+                     L.pic_bytes, np, best);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return hm_check_hip(e, "hipFuncSetAttribute(k_chain)");
   if (pairs) {
@@ -1108,13 +1144,21 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
     if (e != hipSuccess) return hm_check_hip(e, "hipMemsetAsync(k_chain sync words)");
   }
   int a_n = n_pics;
+#ifdef HM_CHAIN_TIMING
+  const bool timing_words = !pairs && d_sync && sync_bytes >= 32; // (a wave per picture: the sync words only hold the phase sums)
+  if (timing_words && hipMemsetAsync(d_sync, 0, 32, s) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipMemsetAsync");
+  uint32_t* a_sync = pairs || timing_words ? d_sync : nullptr;
+#else
+  const bool timing_words = false;
   uint32_t* a_sync = pairs ? d_sync : nullptr;
-  void* args[] = {(void*)&d_pics, &a_n, &L, &a_sync};
+#endif
+  uint32_t* a_err = d_err;
+  void* args[] = {(void*)&d_pics, &a_n, &L, &a_sync, &a_err};
   e = hipLaunchKernel(fn, dim3((unsigned)((n_waves + np - 1) / np)), dim3(np * 64), args, lds_bytes, s);
   if (e != hipSuccess) return hm_check_hip(e, "k_chain launch");
   e = hipGetLastError();
   if (e != hipSuccess) return hm_check_hip(e, "k_chain launch");
-  return pairs ? 2 : 1; // (2: the synchronisation words were used - word 1 is the launch's error flag)
+  return pairs || timing_words ? 2 : 1; // (2: the synchronisation words were used)
 }
 
 // bytes of the synchronisation buffer hm_launch_chain wants for its wave-per-row-pair mode (0: never uses it)

@@ -54,6 +54,17 @@ int hm_nclx_code_known(int kind, int v)
   }
 }
 
+static int g_batch_fail_width = 0;
+int hm_debug_batch_fail_width(void) { return g_batch_fail_width; }
+int hm_debug_set(const char* name, int value)
+{
+  if (!name) return -1;
+  if (!std::strcmp(name, "chain_spin_limit")) { hm_chain_test_knobs(value, -1); return 0; }
+  if (!std::strcmp(name, "chain_test_stall")) { hm_chain_test_knobs(-1, value); return 0; }
+  if (!std::strcmp(name, "batch_fail_width")) { g_batch_fail_width = value; return 0; }
+  return -1;
+}
+
 const char* hm_version(void) { return "heif-mi355x 0.1.0 (gfx950)"; }
 
 int hm_device_count(void)

@@ -52,17 +52,21 @@ struct hm_dev_pic;
 int hm_batch_add_trusted(hm_batch* b, const uint8_t* blob, size_t size, const hm_tile_dest* dest); // no structural validation
 int hm_launch_recon(const struct hm_dev_pic* d_pics, int n_pics, int log2_ctb, int chroma_format, int bit_depth, int rare_syntax,
                     int max_ctb_w, int max_ctb_h, hipStream_t s);
-// recon_quad.hip: four CTU rows per wave; 1 = launched, 0 = not applicable (use hm_launch_recon), < 0 = error
-int hm_launch_recon_quad(const struct hm_dev_pic* d_pics, int n_pics, int log2_ctb, int chroma_format, int bit_depth, int rare_syntax,
-                         int max_ctb_w, int max_ctb_h, hipStream_t s);
 // residual.hip + chain.hip: the reconstruction of pictures with split chains as two kernels on the same stream -
 // dequantisation + inverse transforms of all blocks (no dependencies), then the prediction chains (four per wave);
 // hm_launch_chain: 1 = launched, 0 = not applicable, < 0 = error
 int hm_launch_residual(const struct hm_dev_pic* d_pics, int n_pics, int max_ctb_h, hipStream_t s);
 // d_sync / sync_bytes: zero-initialised-by-the-launch words for the wave-per-row-pair mode (few, large pictures);
-// word 1 is set when a wave had to give up waiting (hm_batch_check).  hm_chain_sync_bytes: the size that mode needs.
+// d_err: the batch's sticky error word - set (never cleared) when a wave had to give up waiting, read and reset by
+// hm_batch_check.  hm_chain_sync_bytes: the size that mode needs.
 int hm_launch_chain(const struct hm_dev_pic* d_pics, int n_pics, int log2_ctb, int chroma_format, int bit_depth, int rare_syntax,
-                    int max_ctb_w, int max_ctb_h, uint32_t* d_sync, size_t sync_bytes, hipStream_t s);
+                    int max_ctb_w, int max_ctb_h, uint32_t* d_sync, size_t sync_bytes, uint32_t* d_err, hipStream_t s);
+void hm_chain_test_knobs(int spin_limit, int test_stall); // (< 0: leave as it is)
+// Test hook, exported but in no public header: sets an internal knob by name ("chain_spin_limit", "chain_test_stall",
+// "batch_fail_width": hm_batch_execute refuses batches holding a picture of that width - for the failure-isolation
+// tests).  Returns 0, or -1 for an unknown name.  Nothing in the library reads these from the environment.
+__attribute__((visibility("default"))) int hm_debug_set(const char* name, int value);
+int hm_debug_batch_fail_width(void);
 size_t hm_chain_sync_bytes(int n_pics, int chroma_format, int max_ctb_h);
 int hm_launch_deblock(const struct hm_dev_pic* d_pics, int n_pics, int max_w4, int max_h4, int chroma_format,
                       int bit_depth, int rare_syntax, hipStream_t s);

@@ -149,10 +149,26 @@ class DeviceWorker {
       }
       int rc = se == hipSuccess ? HM_OK : hm_check_hip(se, "hipStreamCreate");
       std::string msg = rc ? hm_last_error() : "";
-      if (!rc) rc = run_batch(reqs, s, msg);
+      std::vector<int> rcs;
+      std::vector<std::string> msgs;
+      if (!rc) {
+        rc = run_batch(reqs, s, msg);
+        if (rc && reqs.size() > 1) {
+          // The merged batch is the fast path only: its pictures come from unrelated decoder instances (other files, other
+          // contexts), and a batch fails as a whole - one picture the kernels cannot take (a class whose CTU staging does
+          // not fit LDS, a pool that is out of memory for it) must not fail its neighbours' valid pictures.  Every
+          // request again, in a batch of its own: each caller gets its own picture's verdict.
+          rcs.resize(reqs.size());
+          msgs.resize(reqs.size());
+          for (size_t i = 0; i < reqs.size(); i++) rcs[i] = run_batch(std::vector<Request*>(1, reqs[i]), s, msgs[i]);
+        }
+      }
       {
         std::lock_guard<std::mutex> l(m_);
-        for (Request* r : reqs) { r->status = rc; r->message = msg; }
+        for (size_t i = 0; i < reqs.size(); i++) {
+          reqs[i]->status = rcs.empty() ? rc : rcs[i];
+          reqs[i]->message = rcs.empty() ? msg : msgs[i];
+        }
       }
       done_.notify_all();
     }

@@ -12,7 +12,16 @@ import orc
 
 
 def main():
+    import ctypes
+    import os
     pkg = g.load_package()
+    # the fault-injection knobs are library test hooks (hm_debug_set), not environment variables of the product: the test
+    # hands them to this script through the environment and the script sets them
+    hm = pkg.lib()
+    hm.hm_debug_set.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    for env, knob in (("HM_CHAIN_SPIN_LIMIT", b"chain_spin_limit"), ("HM_CHAIN_TEST_STALL", b"chain_test_stall")):
+        if os.environ.get(env):
+            assert hm.hm_debug_set(knob, int(os.environ[env])) == 0
     names = sys.argv[1:] or ["tile512_a", "ctb64_wpp", "hi422_10", "mono8", "ragged"]
     for name in names:
         if name == "wide16k":  # the widest picture class: CTB 64, 16-bit storage, 4:2:2, 16384 columns, two CTU rows

@@ -51,11 +51,6 @@ def test_widest_pictures_fall_back_to_a_finer_cut():
     assert "one per CTU row" in r.stderr or "one per chain" in r.stderr, r.stderr
 
 
-def test_r02_kernel_still_selectable():
-    r = _run({"HM_CHAIN": "0"}, "tile512_a", "ctb64")
-    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
-
-
 @pytest.mark.parametrize("cut", [1, 2, 3])
 def test_bounded_waits_flag_the_launch(cut):
     r = _run({"HM_CHAIN_PAIRS": str(cut), "HM_CHAIN_TEST_STALL": "1", "HM_CHAIN_SPIN_LIMIT": "2000"}, "tile512_a", timeout=120)

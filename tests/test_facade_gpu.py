@@ -228,6 +228,57 @@ def test_plugin_driven_like_the_reference_drives_a_grid(api, hm):
                 api.heif_image_release(img)
 
 
+def test_a_failing_picture_does_not_fail_its_batch_neighbours(api, hm):
+    """Concurrent decode_image calls share batches behind the device worker (picture.cpp).  A picture whose batch fails
+    at execute (stood in for by the library's test hook: batches holding a picture 192 samples wide are refused) must
+    fail alone: the valid tiles queued with it - from unrelated decoder instances - come back decoded."""
+    import ctypes
+    import corpus
+    import hevcutil
+    import pluginapi
+    import synthutil
+    saved = api.hm_get_decoder_plugin.restype
+    api.hm_get_decoder_plugin.restype = C.c_void_p
+    pl = api.hm_get_decoder_plugin()
+    api.hm_get_decoder_plugin.restype = saved
+    good = bytes(corpus.stream("tile512_a"))
+    bad = synthutil.picture(616161, width=192, height=64)
+    hm.hm_debug_set.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    assert hm.hm_debug_set(b"batch_fail_width", 192) == 0
+    exp, info = orc.oracle_decode(hevcutil.parse(hm, good), 3, crop=True)
+    for img in pluginapi.drive_grid(pl, [good], 1):  # (loads the driver)
+        api.heif_image_release(img)
+    drv = pluginapi._driver
+    tiles = [good] * 5 + [bad] + [good] * 6
+    n = len(tiles)
+    try:
+        _check_isolation(api, drv, pl, tiles, n, exp)
+    finally:
+        hm.hm_debug_set(b"batch_fail_width", 0)
+
+
+def _check_isolation(api, drv, pl, tiles, n, exp):
+    import ctypes
+    for _ in range(3):
+        data = (ctypes.c_char_p * n)(*tiles)
+        size = (ctypes.c_size_t * n)(*[len(t) for t in tiles])
+        out = (ctypes.c_void_p * n)()
+        rc = drv.hm_test_drive_grid(ctypes.cast(pl, ctypes.c_void_p), data, size, n, n, out)
+        assert rc != 0  # the marked picture is refused (heif_error code of the failed tile) ...
+        for i in range(n):
+            if i == 5:
+                assert not out[i]
+                continue
+            assert out[i], f"tile {i} failed with its neighbour"  # ... and only it
+            img = ctypes.c_void_p(out[i])
+            stride = ctypes.c_int()
+            ptr = api.heif_image_get_plane_readonly(img, 0, ctypes.byref(stride))
+            w, h = api.heif_image_get_width(img, 0), api.heif_image_get_height(img, 0)
+            got = np.ctypeslib.as_array(ptr, shape=(h, stride.value))[:, :w]
+            np.testing.assert_array_equal(got, exp[0][:h, :w])
+            api.heif_image_release(img)
+
+
 def test_strict_decoding_and_warnings(api, hm):
     """unknown VUI colour codes: a decoding warning + 'unspecified' without strict decoding, an error with it
     (HEIF_WARN_OR_FAIL, heif_plugin.h:290-301; decoder_libde265.cc:339-357; heif.cc:1223-1245, 1811-1905)"""
