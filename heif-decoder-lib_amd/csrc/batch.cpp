@@ -834,10 +834,12 @@ int hm_batch_algorithmic_bytes4(const hm_batch* b, uint64_t out[4])
     const hm_pic& h = it.hdr;
     out[2] += (uint64_t)h.n_coeffs * sizeof(hm_coeff);
     if (!(h.flags & HM_PIC_SPLIT_CHAINS)) continue;
-    const hm_tu8* t = reinterpret_cast<const hm_tu8*>(b->stage.p + it.stage_off + h.off_tus);
+    const uint8_t* t = b->stage.p + it.stage_off + h.off_tus; // hm_tu6 records: info is byte 1 of 6
     uint64_t samples = 0;
-    for (uint32_t i = 0; i < h.n_tus; i++)
-      if (t[i].info & HM_TU_CBF) samples += (uint64_t)1 << (2 * (t[i].info & HM_TU_LOG2_MASK));
+    for (uint32_t i = 0; i < h.n_tus; i++) {
+      const uint8_t info = t[(size_t)i * sizeof(hm_tu6) + 1];
+      if (info & HM_TU_CBF) samples += (uint64_t)1 << (2 * (info & HM_TU_LOG2_MASK));
+    }
     out[3] += 2 * samples;
   }
   return HM_OK;

@@ -582,7 +582,7 @@ struct Decoder {
     const size_t off_slices = align16(sizeof(hm_pic));
     const size_t off_ctbs = align16(off_slices + pic.slices.size() * sizeof(hm_slice));
     const size_t off_tus = align16(off_ctbs + (size_t)N * sizeof(hm_ctb));
-    const size_t tu_bytes = split ? sizeof(hm_tu8) : sizeof(hm_tu);
+    const size_t tu_bytes = split ? sizeof(hm_tu6) : sizeof(hm_tu);
     const size_t off_coeffs = align16(off_tus + n_tus * tu_bytes);
     const size_t off_scaling = align16(off_coeffs + n_levels * sizeof(hm_coeff));
     const size_t total = off_scaling + (s.scaling_list_enabled ? (size_t)HM_SCALING_BYTES : 0);
@@ -675,26 +675,25 @@ struct Decoder {
       for (int cy = 0; cy < s.ctb_h; cy++)
         for (int k = 0; k < 2; k++) {
           const PictureState::RowChains& R = pic.rows[(size_t)cy];
-          if (!R.tu[k].empty()) { std::memcpy(tp, R.tu[k].data(), R.tu[k].size() * sizeof(hm_tu8)); tp += R.tu[k].size() * sizeof(hm_tu8); }
+          if (!R.tu[k].empty()) { std::memcpy(tp, R.tu[k].data(), R.tu[k].size() * sizeof(hm_tu6)); tp += R.tu[k].size() * sizeof(hm_tu6); }
           if (!R.lv[k].empty()) { std::memcpy(cp, R.lv[k].data(), R.lv[k].size() * sizeof(hm_coeff)); cp += R.lv[k].size() * sizeof(hm_coeff); }
         }
       std::memcpy(blob.data() + off_ctbs, pic.ctbs.data(), (size_t)N * sizeof(hm_ctb));
     }
     else {
-      // compact records (hm_stream.h: hm_tu8) in chain order, the levels gathered into the order of the records
-      hm_tu8* const tp = reinterpret_cast<hm_tu8*>(blob.data() + off_tus);
+      // compact records (hm_stream.h: hm_tu6) in chain order, the levels gathered into the order of the records
+      hm_tu6* const tp = reinterpret_cast<hm_tu6*>(blob.data() + off_tus);
       hm_coeff* const cp = reinterpret_cast<hm_coeff*>(blob.data() + off_coeffs);
       uint32_t level_at = 0;
-      auto put = [&](hm_tu8* d, const hm_tu& t) {
-        if ((t.x | t.y | t.avail_bottom_left | t.avail_top_right) & 3) throw ParseError(HM_ERR_INTERNAL, "block geometry not a multiple of 4");
-        const int nT = 1 << (t.info & HM_TU_LOG2_MASK);
-        if ((t.avail_left != 0 && t.avail_left != nT) || (t.avail_top != 0 && t.avail_top != nT) || t.n_coeff > HM_TU8_COUNT_MASK ||
-            (t.pred_mode & ~HM_TU_MODE_MASK))
-          throw ParseError(HM_ERR_INTERNAL, "record does not fit the compact form");
+      const int qp_bd_offset_y = 6 * (s.bit_depth_y - 8);
+      auto put = [&](hm_tu6* d, const hm_tu& t) {
+        if ((t.x | t.y) & 3) throw ParseError(HM_ERR_INTERNAL, "block geometry not a multiple of 4");
+        if (t.n_coeff > HM_TU6_COUNT_MASK || (t.pred_mode & ~HM_TU_MODE_MASK)) throw ParseError(HM_ERR_INTERNAL, "record does not fit the compact form");
         d->pos = (uint8_t)((t.x >> 2) | ((t.y >> 2) << 4));
-        d->info = t.info; d->pred_mode = t.pred_mode; d->qp = t.qp; d->qpy = t.qpy;
-        d->avail = (uint8_t)((t.avail_bottom_left >> 2) | ((t.avail_top_right >> 2) << 4));
-        d->count = (uint16_t)(t.n_coeff | (t.avail_left ? HM_TU8_LEFT : 0) | (t.avail_top ? HM_TU8_TOP : 0));
+        d->info = (uint8_t)(t.info & ~HM_TU_AVAIL_TL); d->pred_mode = t.pred_mode;
+        // (a luma record's QP is QpY + QpBdOffsetY of its coding unit - what it was dequantised with if it has a residual)
+        d->qp = ((t.info >> HM_TU_CIDX_SHIFT) & 3) == 0 ? (uint8_t)(t.qpy + qp_bd_offset_y) : t.qp;
+        d->count = (uint16_t)t.n_coeff;
         if (t.n_coeff) std::memcpy(cp + level_at, pic.coeffs.data() + t.coeff_first, t.n_coeff * sizeof(hm_coeff));
         level_at += t.n_coeff;
       };
@@ -703,7 +702,7 @@ struct Decoder {
         for (int pass = 0; pass < 2; pass++)
           for (int cx = 0; cx < s.ctb_w; cx++) {
             const int i = cx + cy * s.ctb_w;
-            hm_tu8* d = tp + (pass == 0 ? pic.ctbs[i].tu_first : pic.ctbs[i].tu_first_c);
+            hm_tu6* d = tp + (pass == 0 ? pic.ctbs[i].tu_first : pic.ctbs[i].tu_first_c);
             (pass == 0 ? pic.ctbs[i].coeff_first : pic.ctbs[i].coeff_first_c) = level_at;
             for (const hm_tu& t : pic.ctb_tus[i])
               if ((((t.info >> HM_TU_CIDX_SHIFT) & 3) == 0) == (pass == 0)) put(d++, t);
@@ -722,7 +721,7 @@ struct Decoder {
 } // namespace hm
 
 static_assert(sizeof(hm_tu) == 16, "hm_tu layout");
-static_assert(sizeof(hm_tu8) == 8, "hm_tu8 layout");
+static_assert(sizeof(hm_tu6) == 6, "hm_tu6 layout");
 static_assert(sizeof(hm_ctb) == 4 * HM_CTB_DWORDS, "hm_ctb layout");
 static_assert(sizeof(hm_coeff) == 4, "hm_coeff layout");
 static_assert(sizeof(hm_slice) == 12, "hm_slice layout");

@@ -33,6 +33,7 @@
 #include "hevc_cabac.h"
 #include "hevc_types.h"
 #include "hm_stream.h"
+#include "hm_avail.h"
 
 namespace hm {
 
@@ -200,9 +201,9 @@ struct PictureState {
   std::vector<hm_coeff> coeffs;
   // Pictures that cannot turn out to carry rare syntax (no scaling lists, PCM, transquant bypass, 4:4:4 in their
   // parameter sets) are written in their final form while they are parsed ("direct"): per CTB row the compact records
-  // (hm_stream.h: hm_tu8) of the luma chain and of the chroma chain with their levels in record order - what remains
+  // (hm_stream.h: hm_tu6) of the luma chain and of the chroma chain with their levels in record order - what remains
   // for the end is a concatenation.  hm_ctb.tu_first / coeff_first are row-relative until then.
-  struct RowChains { std::vector<hm_tu8> tu[2]; std::vector<hm_coeff> lv[2]; };
+  struct RowChains { std::vector<hm_tu6> tu[2]; std::vector<hm_coeff> lv[2]; };
   std::vector<RowChains> rows;
   bool direct = false;
   bool uses_pcm = false, uses_tq_bypass = false;
@@ -432,6 +433,7 @@ class SliceWalker {
     }
     derive_ctb_neighbours();
     hm_ctb& c = pic_.ctbs[ctb_addr_rs_];
+    c.nb_avail = (uint8_t)(nb9_ & 15u); // HM_CTB_NB_*: NW, N, NE, W (the CTBs to the right and below are never available)
     // deblocking edge permissions of this CTB's left/top edge (deblock.cc:160-196 in the reference)
     c.flags &= ~(HM_CTB_DEBLOCK_LEFT | HM_CTB_DEBLOCK_TOP | HM_CTB_DEBLOCK_OFF | HM_CTB_SAO_LUMA | HM_CTB_SAO_CHROMA | HM_CTB_LOSSLESS);
     if (sh_.deblocking_disabled) c.flags |= HM_CTB_DEBLOCK_OFF;
@@ -706,8 +708,10 @@ class SliceWalker {
     const int max_depth = sps_.max_th_depth_intra + (nxn ? 1 : 0);
     transform_tree(x0, y0, x0, y0, log2CbSize, 0, 0, max_depth, nxn, 1, 1);
     // all luma records of this CU must carry the CU's final QpY (deblocking uses the QpY map)
+    // (compact records carry it as the luma record's QP: QpY + QpBdOffsetY - the value a block with a residual was
+    //  dequantised with anyway, since cu_qp_delta precedes the first residual of its quantisation group)
     if (pic_.direct)
-      for (std::vector<hm_tu8>& v = pic_.rows[(size_t)ctb_y_].tu[0]; cu_tu_start_ < v.size(); cu_tu_start_++) v[cu_tu_start_].qpy = (int8_t)cu_qpy_;
+      for (std::vector<hm_tu6>& v = pic_.rows[(size_t)ctb_y_].tu[0]; cu_tu_start_ < v.size(); cu_tu_start_++) v[cu_tu_start_].qp = (uint8_t)(cu_qpy_ + sps_.qp_bd_offset_y);
     else
       for (std::vector<hm_tu>& v = pic_.ctb_tus[ctb_addr_rs_]; cu_tu_start_ < v.size(); cu_tu_start_++)
         if (((v[cu_tu_start_].info >> HM_TU_CIDX_SHIFT) & 3) == 0) v[cu_tu_start_].qpy = (int8_t)cu_qpy_;
@@ -936,9 +940,9 @@ class SliceWalker {
   {
     if (pic_.direct) { // (the levels lie in record order: the two middle runs change places with their records)
       PictureState::RowChains& R = pic_.rows[(size_t)ctb_y_];
-      std::vector<hm_tu8>& v = R.tu[1];
+      std::vector<hm_tu6>& v = R.tu[1];
       const size_t n = v.size();
-      const size_t c_cr_lo = v[n - 1].count & HM_TU8_COUNT_MASK, c_cr_up = v[n - 2].count & HM_TU8_COUNT_MASK, c_cb_lo = v[n - 3].count & HM_TU8_COUNT_MASK;
+      const size_t c_cr_lo = v[n - 1].count & HM_TU6_COUNT_MASK, c_cr_up = v[n - 2].count & HM_TU6_COUNT_MASK, c_cb_lo = v[n - 3].count & HM_TU6_COUNT_MASK;
       std::swap(v[n - 3], v[n - 2]);
       hm_coeff* const end = R.lv[1].data() + R.lv[1].size() - c_cr_lo; // behind the run of Cr upper
       std::rotate(end - c_cr_up - c_cb_lo, end - c_cr_up, end);
@@ -948,7 +952,7 @@ class SliceWalker {
     std::swap(v[v.size() - 3], v[v.size() - 2]);
   }
 
-  // one (component) block: optional residual_coding(), then the block's record (hm_tu8 in pictures whose records go out as
+  // one (component) block: optional residual_coding(), then the block's record (hm_tu6 in pictures whose records go out as
   // split chains, hm_tu else).  Runs ten thousand times per 512x512 tile: the record is built straight from locals, the
   // row's vectors and the CTB header come from pointers set once per CTU (row_, ctb_cur_).
   void emit_block(int xc, int yc, int log2, int cIdx, int mode, int cbf, int res_scale = 0)
@@ -967,44 +971,28 @@ class SliceWalker {
     }
     if (cIdx == 0) luma_tskip_ = tskip;
     const uint32_t ncoef = (uint32_t)coeffs_->size() - coeff_first;
-    // neighbour availability (intrapred.h:536-667 in the reference; equals §8.4.4.2.2), from the block's rectangle in
-    // luma samples.  Left, above and above-left of a block always come before it in z-order when they lie in its CTB;
-    // else the answer is the neighbouring CTB's (nb9_, see avail_z); only below-left and above-right inside the CTB
-    // compare z-order indices.  Written without branches on purpose (selects over always-valid table reads): the outcomes
-    // follow the block structure of the picture, which no predictor learns - and a memo of the last two rectangles (the
-    // Cb / Cr blocks of a unit share theirs) cost as much as it saved.
-    const int xL = xc << lw, yL = yc << lh; // luma position of the block
-    const int cw = sps_.width >> lw, chh = sps_.height >> lh;
-    const int cs = 1 << sps_.log2_ctb, xi = xL & (cs - 1), yi = yL & (cs - 1);
-    const int wL = nT << lw, hL = nT << lh;
-    const unsigned nb = nb9_;
-    const unsigned a_left = xi ? 1u : (nb >> 3) & 1u;
-    const unsigned a_top = yi ? 1u : (nb >> 1) & 1u;
-    const unsigned a_tl = xi ? a_top : (yi ? a_left : (nb & 1u));
-    const int z_cur = tables::kZOrder4[(yL >> 2) & 15][(xL >> 2) & 15];
-    const unsigned z_bl = tables::kZOrder4[((yL + hL) >> 2) & 15][((xL - 1) >> 2) & 15] <= z_cur; // (meaningful inside the CTB)
-    const unsigned z_tr = tables::kZOrder4[((yL - 1) >> 2) & 15][((xL + wL) >> 2) & 15] <= z_cur;
-    const bool below = yi + hL >= cs, beyond = xi + wL >= cs;
-    const unsigned bl = below ? (nb >> (xi ? 7 : 6)) & 1u : (xi ? z_bl : a_left);
-    const unsigned tr = yi == 0 ? (nb >> (beyond ? 2 : 1)) & 1u : (beyond ? (nb >> 5) & 1u : z_tr);
-    const unsigned a_bl = bl & a_left & (unsigned)(yc + nT < chh);
-    const unsigned a_tr = tr & (unsigned)(xc + nT < cw);
-    if (a_tl) info |= HM_TU_AVAIL_TL;
-    const int n_bl = a_bl ? std::min(nT, chh - (yc + nT)) : 0, n_tr = a_tr ? std::min(nT, cw - (xc + nT)) : 0;
     const int x = xc & ((1 << (sps_.log2_ctb - lw)) - 1), y = yc & ((1 << (sps_.log2_ctb - lh)) - 1);
     const int pm = mode | (cu_bypass_ ? HM_TU_MODE_BYPASS : 0);
-    const int qpy = (cIdx && pps_.cross_component_prediction) ? res_scale : cu_qpy_; // hm_stream.h: chroma records of such pictures carry ResScaleVal
     if (direct) {
-      hm_tu8 c;
+      // compact record: position, size, mode, QP, level count.  The neighbour availability of the block is NOT worked out
+      // here (format HSM5): it is a function of this rectangle and the CTB's four neighbour bits (hm_avail.h), which the
+      // residual pre-pass evaluates with a lane per record.
+      hm_tu6 c;
       c.pos = (uint8_t)((x >> 2) | ((y >> 2) << 4));
-      c.info = (uint8_t)info; c.pred_mode = (uint8_t)pm; c.qp = (uint8_t)qp_prime_[cIdx]; c.qpy = (int8_t)qpy;
-      c.avail = (uint8_t)((n_bl >> 2) | ((n_tr >> 2) << 4));
-      c.count = (uint16_t)(ncoef | (a_left ? HM_TU8_LEFT : 0) | (a_top ? HM_TU8_TOP : 0));
+      c.info = (uint8_t)info; c.pred_mode = (uint8_t)pm; c.qp = (uint8_t)qp_prime_[cIdx];
+      c.count = (uint16_t)ncoef;
       row_->tu[k].push_back(c);
       if (cIdx == 0) ctb_cur_->tu_count++;
       else ctb_cur_->tu_count_c++;
       return;
     }
+    // neighbour availability (intrapred.h:536-667 in the reference; equals §8.4.4.2.2), from the block's rectangle and the
+    // neighbour bits of the CTB (hm_avail.h - the same function the device runs for the compact records)
+    const hm_avail av = hm_derive_avail(xc, yc, nT, lw, lh, sps_.log2_ctb, sps_.width, sps_.height, nb9_ & 15u);
+    if (av.tl) info |= HM_TU_AVAIL_TL;
+    const unsigned a_left = av.left, a_top = av.top;
+    const int n_bl = av.n_bl, n_tr = av.n_tr;
+    const int qpy = (cIdx && pps_.cross_component_prediction) ? res_scale : cu_qpy_; // hm_stream.h: chroma records of such pictures carry ResScaleVal
     hm_tu t;
     t.x = (uint8_t)x; t.y = (uint8_t)y;
     t.info = (uint8_t)info; t.pred_mode = (uint8_t)pm;

@@ -483,9 +483,12 @@ constexpr int OP_NL1_SHIFT = 14, OP_NT1_SHIFT = 20; // last usable position of t
 constexpr uint32_t OPW_LEFT = 1u << 16, OPW_TOP = 1u << 17, OPW_TL = 1u << 18;
 constexpr int OPW_BL_SHIFT = 19, OPW_TR_SHIFT = 23; // below-left / top-right counts in units of 4 (4 bits each)
 typedef uint32_t mop_u32x4 __attribute__((ext_vector_type(4)));
-// r0, r1: the hm_tu8 as two dwords; Pk: pitch of the chain's CTU buffers in samples; cr_off: the Cr buffer behind the
-// Cb buffer, Wc: the Cr line behind the Cb line (+ 4), both in samples; roff: see z
-__device__ __forceinline__ mop_u32x4 make_micro_op(uint32_t r0, uint32_t r1, int Pk, int cr_off, int Wc, uint32_t roff)
+// r0: the first four bytes of the hm_tu6 (pos | info << 8 | pred_mode << 16 | qp << 24); left / top / tl, aBL4 / aTR4: the
+// block's neighbour availability (hm_avail.h; counts in units of 4 samples); qpy: QpY of a luma block; Pk: pitch of the
+// chain's CTU buffers in samples; cr_off: the Cr buffer behind the Cb buffer, Wc: the Cr line behind the Cb line (+ 4),
+// both in samples; roff: see z
+__device__ __forceinline__ mop_u32x4 make_micro_op(uint32_t r0, unsigned a_left, unsigned a_top, unsigned a_tl, uint32_t aBL4, uint32_t aTR4, uint32_t qpy,
+                                                   int Pk, int cr_off, int Wc, uint32_t roff)
 {
   const int x4 = (int)(r0 & 15), y4 = (int)((r0 >> 4) & 15);
   const uint32_t info = (r0 >> 8) & 0xFF;
@@ -493,8 +496,7 @@ __device__ __forceinline__ mop_u32x4 make_micro_op(uint32_t r0, uint32_t r1, int
   const uint32_t mode = (r0 >> 16) & OP_MODE_MASK;
   const bool cbf = (info & HM_TU_CBF) != 0;
   const int nT = 1 << l2;
-  const uint32_t aBL4 = (r1 >> 8) & 15, aTR4 = (r1 >> 12) & 15;
-  const bool left = (r1 & ((uint32_t)HM_TU8_LEFT << 16)) != 0, top = (r1 & ((uint32_t)HM_TU8_TOP << 16)) != 0, tl = (info & HM_TU_AVAIL_TL) != 0;
+  const bool left = a_left != 0, top = a_top != 0, tl = a_tl != 0;
   const int x0 = x4 << 2;
   const int lp = mul24(y4 << 2, Pk) + UPAD + x0 - 1 + (c == 2 ? cr_off : 0);
   const bool on_line = y4 == 0;
@@ -508,7 +510,7 @@ __device__ __forceinline__ mop_u32x4 make_micro_op(uint32_t r0, uint32_t r1, int
   op.y = mode | ((uint32_t)c << OP_C_SHIFT) | ((uint32_t)(l2 - 2) << OP_L2_SHIFT) | (cbf ? OP_CBF : 0u) | (interior ? OP_INTERIOR : 0u) |
          (fast8 ? OP_FAST8 : 0u) | (on_line ? OP_LINE : 0u) | (nL1 << OP_NL1_SHIFT) | (nT1 << OP_NT1_SHIFT);
   op.z = roff;
-  op.w = (r1 & 0xFF) | ((r0 & 0xFF) << 8) | (left ? OPW_LEFT : 0u) | (top ? OPW_TOP : 0u) | (tl ? OPW_TL : 0u) | (aBL4 << OPW_BL_SHIFT) | (aTR4 << OPW_TR_SHIFT);
+  op.w = (qpy & 0xFF) | ((r0 & 0xFF) << 8) | (left ? OPW_LEFT : 0u) | (top ? OPW_TOP : 0u) | (tl ? OPW_TL : 0u) | (aBL4 << OPW_BL_SHIFT) | (aTR4 << OPW_TR_SHIFT);
   return op;
 }
 

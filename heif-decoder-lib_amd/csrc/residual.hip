@@ -24,6 +24,7 @@
 #include <cstdlib>
 
 #include "recon_common.h"
+#include "hm_avail.h"
 
 #include "hm_internal.h"
 
@@ -218,31 +219,43 @@ __global__ __launch_bounds__(R_WAVES * 64) HM_R_ATTR void k_residual(const hm_de
   // anything is waited for on the spot), the chunk's levels as soon as their place is known and looked at only after
   // the block map has been written: a wave's time is mostly the latency of these two reads
   const uint32_t n_tus1 = H->n_tus ? H->n_tus - 1 : 0, n_lev1 = H->n_coeffs ? H->n_coeffs - 1 : 0;
-  auto fetch_records = [&](uint32_t first) -> r_u32x2 {
-    uint32_t i = first + (uint32_t)lane;
-    i = i < n_tus1 ? i : n_tus1;
-    return *reinterpret_cast<const GLOBAL_AS r_u32x2*>(tus + 2 * (size_t)i);
+  // (6-byte records, hm_stream.h: hm_tu6: record i lies in the two dwords from byte 6 i & ~3 on - fetched raw here, taken
+  //  apart where they are used, so that nothing waits for the load at the request)
+  auto record_index = [&](uint32_t first) -> uint32_t {
+    const uint32_t i = first + (uint32_t)lane;
+    return i < n_tus1 ? i : n_tus1;
   };
-  uint32_t cur_x, cur_y; // the chunk's records (lane = record)
+  auto fetch_records = [&](uint32_t first) -> r_u32x2 {
+    const GLOBAL_AS uint32_t* const p = tus + ((3u * record_index(first)) >> 1);
+    return r_u32x2{p[0], p[1]};
+  };
+  uint32_t cur_x, cur_y; // the chunk's records (lane = record), raw
   {
     const r_u32x2 first = fetch_records(rec_begin);
     cur_x = first.x; cur_y = first.y;
   }
+  const int sub_w = 1, sub_h = dp.chroma_format == 1 ? 1 : 0; // log2 of the chroma planes' sub-sampling (4:2:0 / 4:2:2)
+  const int qp_bd_offset = 6 * (bd - 8);
   for (uint32_t chunk = rec_begin; chunk < rec_end; chunk += 64) {
     const uint32_t ri = chunk + (uint32_t)lane;
     const bool valid = ri < rec_end;
-    const uint32_t r0 = valid ? cur_x : 0u, r1 = valid ? cur_y : 0u;
+    // pos | info << 8 | pred_mode << 16 | qp << 24, and the level count
+    const uint32_t rsh = (record_index(chunk) & 1u) << 4;
+    const uint32_t r0 = valid ? __builtin_amdgcn_alignbit(cur_y, cur_x, rsh) : 0u;
+    const uint32_t cnt = valid ? (cur_y >> rsh) & HM_TU6_COUNT_MASK : 0u; // (0 in the lanes behind the row's last record)
     const r_u32x2 ahead = fetch_records(chunk + 64);
-    // (luma chains, block map: the first records and the flags of the CTBs that may start inside this chunk - requested
-    //  here with everything else, used below)
+    // (the first records, the neighbour bits and - luma chains: block map - the flags of the CTBs that may start inside
+    //  this chunk: requested here with everything else, used below)
     const int cand = cur_ctb + 1 + lane;
-    const bool cand_ok = kind == 0 && cand < x1;
+    const bool cand_ok = cand < x1;
     const int last_ctb = dp.ctb_w - 1;
-    const uint32_t cand_first = q0[HM_CTB_DWORDS * (size_t)(cand < last_ctb ? cand : last_ctb)];
-    const uint32_t ctb_flags = q0[HM_CTB_DWORDS * (size_t)(cand - 1 < last_ctb ? cand - 1 : last_ctb) + 2]; // flags of CTB cur_ctb + lane
+    const GLOBAL_AS uint32_t* const q_cand = q0 + HM_CTB_DWORDS * (size_t)(cand < last_ctb ? cand : last_ctb);
+    const GLOBAL_AS uint32_t* const q_lane = q0 + HM_CTB_DWORDS * (size_t)(cand - 1 < last_ctb ? cand - 1 : last_ctb); // CTB cur_ctb + lane
+    const uint32_t cand_first = q_cand[kind ? 9 : 0];
+    const uint32_t ctb_flags = q_lane[kind ? 10 : 2]; // luma: flags | SAO masks; chroma: only dword 10 is of interest
+    const uint32_t ctb_nb = q_lane[10] >> 16;         // hm_ctb.nb_avail (| reserved << 8)
     const int info = (int)((r0 >> 8) & 0xFF), l2 = info & HM_TU_LOG2_MASK;
     const bool cbf = valid && (info & HM_TU_CBF);
-    const uint32_t cnt = (r1 >> 16) & HM_TU8_COUNT_MASK; // (0 in the lanes behind the row's last record)
     const uint32_t rsz = (cbf && l2 >= 3) ? 16u << (2 * (l2 - 2)) : 0u; // (the residual of a 4x4 block has a place of its own: res4)
     // inclusive wave scans: first level / first residual sample of every record
     const uint32_t sc = wave_scan(cnt), sr = wave_scan(rsz);
@@ -259,42 +272,56 @@ __global__ __launch_bounds__(R_WAVES * 64) HM_R_ATTR void k_residual(const hm_de
     }
     lev_base += n_lev;
     res_base += (uint32_t)__builtin_amdgcn_readlane((int)sr, 63);
-    // the record's micro-op for the chain kernel
-    if (valid) mops[ri] = make_micro_op(r0, r1, m_Pk, m_cr_off, m_Wc, ro);
     // level number i of a block whose levels start at index `first`
     auto level = [&](uint32_t first, uint32_t i) -> uint32_t {
       const uint32_t rel = first - chunk_lev + i;
       return rel < (uint32_t)R_STAGE ? lvl[rel] : coeffs[first + i];
     };
 
+    // ---- the CTB of every record of the chunk: the CTBs that start inside it are marked at their first record, a scan
+    //      counts them (every CTB has records of both kinds, so at most 63 start behind the chunk's first record) ----
+    if (cand_ok) {
+      const uint32_t tf = cand_first - chunk;
+      if (tf < 64u) __hip_atomic_fetch_add(slots + tf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+    WAVE_SYNC();
+    int sm = slots[lane];
+    WAVE_SYNC();
+    slots[lane] = 0;
+    sm = (int)wave_scan((uint32_t)sm);
+    const int my_ctb = cur_ctb + sm;
+    cur_ctb += __builtin_amdgcn_readlane(sm, 63);
+    // (the header words of CTB cur_ctb + k were requested by lane k: at most 63 CTBs start behind the chunk's first record)
+    // (by ALL lanes: a lane that holds no record may hold the words a record needs - the row's last record alone in its chunk and
+    //  first of its CTB reads lane 1 -, and lanes switched off deliver nothing)
+    int lane_flags = __builtin_amdgcn_ds_bpermute((sm & 63) << 2, (int)ctb_flags);
+    int lane_nb = __builtin_amdgcn_ds_bpermute((sm & 63) << 2, (int)ctb_nb);
+    asm volatile("" : "+v"(lane_flags), "+v"(lane_nb));
+    if (sm >= 64) { // (64 CTBs start in the chunk: each is one record)
+      const GLOBAL_AS uint32_t* const q_mine = q0 + HM_CTB_DWORDS * (size_t)my_ctb;
+      lane_flags = (int)q_mine[kind ? 10 : 2];
+      lane_nb = (int)(q_mine[10] >> 16);
+    }
+    const int x4 = (int)(r0 & 15), y4 = (int)((r0 >> 4) & 15);
+
+    // ---- neighbour availability of the record's block (hm_avail.h: intrapred.h:536-667 of the reference) and its micro-op
+    //      for the chain kernel ----
+    {
+      const int lw = kind ? sub_w : 0, lh = kind ? sub_h : 0;
+      const int xc = (my_ctb << (dp.log2_ctb - lw)) + (x4 << 2), yc = (row << (dp.log2_ctb - lh)) + (y4 << 2);
+      const hm_avail av = hm_derive_avail(xc, yc, 1 << l2, lw, lh, dp.log2_ctb, dp.width, dp.height, (unsigned)lane_nb & 15u);
+      const uint32_t qpy = kind ? 0u : ((r0 >> 24) - (uint32_t)qp_bd_offset) & 0xFFu;
+      if (valid) mops[ri] = make_micro_op(r0, av.left, av.top, av.tl, (uint32_t)av.n_bl >> 2, (uint32_t)av.n_tr >> 2, qpy, m_Pk, m_cr_off, m_Wc, ro);
+    }
+
     // ---- the block map of the deblocking filter (luma chains): per 4x4 block the transform edges on its left / on top
     //      (bit 0 / bit 1) and QpY (bits 8-15), deblock.cc:31-62 of the reference ----
     if (kind == 0) {
-      // the CTB of every record of the chunk: the CTBs that start inside it are marked at their first record, a scan
-      // counts them (every CTB has records, so at most 63 start behind the chunk's first record)
-      if (cand_ok) {
-        const uint32_t tf = cand_first - chunk;
-        if (tf < 64u) __hip_atomic_fetch_add(slots + tf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      }
-      WAVE_SYNC();
-      int sm = slots[lane];
-      WAVE_SYNC();
-      slots[lane] = 0;
-      sm = (int)wave_scan((uint32_t)sm);
-      const int my_ctb = cur_ctb + sm;
-      cur_ctb += __builtin_amdgcn_readlane(sm, 63);
-      // (the flags of CTB cur_ctb + k were requested by lane k: at most 63 CTBs start behind the chunk's first record)
-      // (by ALL lanes: a lane that holds no record may hold the flags a record needs - the row's last record alone in its chunk and
-      //  first of its CTB reads lane 1 -, and lanes switched off deliver nothing)
-      int lane_flags = __builtin_amdgcn_ds_bpermute((sm & 63) << 2, (int)ctb_flags);
-      asm volatile("" : "+v"(lane_flags));
-      if (sm >= 64) lane_flags = (int)q0[HM_CTB_DWORDS * (size_t)my_ctb + 2]; // (64 CTBs start in the chunk: each is one record)
       const int flags = valid ? (lane_flags & 0xFF) : 0;
       const int en = !(flags & HM_CTB_DEBLOCK_OFF);
-      const int x4 = (int)(r0 & 15), y4 = (int)((r0 >> 4) & 15);
       const int left_ok = ((x4 > 0) | ((flags & HM_CTB_DEBLOCK_LEFT) != 0)) & en;
       const int top_ok = ((y4 > 0) | ((flags & HM_CTB_DEBLOCK_TOP) != 0)) & en;
-      const uint32_t qword = (r1 & 0xFF) << 8;
+      const uint32_t qword = (((r0 >> 24) - (uint32_t)qp_bd_offset) & 0xFFu) << 8; // QpY of the coding unit (hm_tu6.qp of a luma record)
       const int l4 = dp.log2_ctb - 2;
       const int gx = (my_ctb << l4) + x4, gy = (row << l4) + y4; // the block's first cell in the picture's map
       GLOBAL_AS uint16_t* const meta = gptr_w<uint16_t>(dp.meta);

@@ -23,7 +23,7 @@ static const char* validate_stream(const uint8_t* blob, size_t size)
   if (h.crop_left + h.crop_right >= h.width || h.crop_top + h.crop_bottom >= h.height) return "conformance window";
   auto section = [&](uint64_t off, uint64_t count, uint64_t elem) { return (off & 3) == 0 && off >= sizeof(hm_pic) && off <= total && count * elem <= total - off; };
   if (h.n_slices == 0 || !section(h.off_slices, h.n_slices, sizeof(hm_slice)) || !section(h.off_ctbs, h.n_ctbs, sizeof(hm_ctb)) ||
-      !section(h.off_tus, h.n_tus, (h.flags & HM_PIC_SPLIT_CHAINS) ? sizeof(hm_tu8) : sizeof(hm_tu)) || !section(h.off_coeffs, h.n_coeffs, sizeof(hm_coeff)))
+      !section(h.off_tus, h.n_tus, (h.flags & HM_PIC_SPLIT_CHAINS) ? sizeof(hm_tu6) : sizeof(hm_tu)) || !section(h.off_coeffs, h.n_coeffs, sizeof(hm_coeff)))
     return "section offsets";
   if ((h.flags & HM_PIC_SCALING_LIST) && !section(h.off_scaling, HM_SCALING_BYTES, 1)) return "scaling tables";
   if (h.n_tus == 0) return "no records";
@@ -58,21 +58,21 @@ static const char* validate_stream(const uint8_t* blob, size_t size)
   };
   // compact records (split chains): the full form of record t; its levels start at the running sum of the counts before
   // it, which must agree with the sums the CTB headers carry (the kernels start from those)
-  const hm_tu8* tus8 = reinterpret_cast<const hm_tu8*>(blob + h.off_tus);
+  // (6-byte records: read field by field, no alignment assumed; their neighbour availability is derived by the kernels
+  //  from position + hm_ctb.nb_avail, so there is nothing of it to check here)
+  const uint8_t* tus6 = blob + h.off_tus;
   uint64_t level_at = 0;
+  struct Expanded : hm_tu { uint16_t reserved_bits; };
   auto expand = [&](uint64_t t) {
-    hm_tu u;
+    Expanded u;
     std::memset(&u, 0, sizeof(u));
-    const hm_tu8& c = tus8[t];
-    const int nT = 1 << (c.info & HM_TU_LOG2_MASK);
+    hm_tu6 c;
+    std::memcpy(&c, tus6 + t * sizeof(hm_tu6), sizeof(c));
     u.x = (uint8_t)((c.pos & 15) << 2); u.y = (uint8_t)((c.pos >> 4) << 2);
-    u.info = c.info; u.pred_mode = c.pred_mode; u.qp = c.qp; u.qpy = c.qpy;
-    u.n_coeff = (uint16_t)(c.count & HM_TU8_COUNT_MASK);
+    u.info = c.info; u.pred_mode = c.pred_mode; u.qp = c.qp;
+    u.n_coeff = (uint16_t)(c.count & HM_TU6_COUNT_MASK);
     u.coeff_first = (uint32_t)(level_at < 0xFFFFFFFFu ? level_at : 0xFFFFFFFFu);
-    u.avail_left = (c.count & HM_TU8_LEFT) ? (uint8_t)nT : 0;
-    u.avail_top = (c.count & HM_TU8_TOP) ? (uint8_t)nT : 0;
-    u.avail_bottom_left = (uint8_t)((c.avail & 15) << 2);
-    u.avail_top_right = (uint8_t)((c.avail >> 4) << 2);
+    u.reserved_bits = (uint16_t)((c.count & ~HM_TU6_COUNT_MASK) | (c.info & HM_TU_AVAIL_TL));
     return u;
   };
   uint64_t next = 0;
@@ -85,6 +85,11 @@ static const char* validate_stream(const uint8_t* blob, size_t size)
           for (int k = 0; k < 3; k++)
             if (c.sao[k].type > 2 || c.sao[k].eo_class > 3 || c.sao[k].band_position > 31) return "SAO parameters";
           if (!split && c.tu_count_c) return "chroma list in a picture with interleaved records";
+          if ((c.nb_avail & ~0x0Fu) || c.reserved) return "reserved bits of a CTB";
+          // a neighbour outside the picture cannot be available (the kernels index sample lines with these answers)
+          if ((cx == 0 && (c.nb_avail & (HM_CTB_NB_W | HM_CTB_NB_NW))) || (cy == 0 && (c.nb_avail & (HM_CTB_NB_N | HM_CTB_NB_NW | HM_CTB_NB_NE))) ||
+              (cx + 1 == h.ctb_w && (c.nb_avail & HM_CTB_NB_NE)))
+            return "CTB neighbour outside the picture";
         }
         const uint64_t first = pass == 0 ? c.tu_first : c.tu_first_c, count = pass == 0 ? c.tu_count : c.tu_count_c;
         if (first != next) return "records of the CTBs are not contiguous in (row, list, CTB) order";
@@ -96,8 +101,8 @@ static const char* validate_stream(const uint8_t* blob, size_t size)
             if (const char* what = check_record(tus[t], -1)) return what;
             continue;
           }
-          if (tus8[t].count & ~(HM_TU8_COUNT_MASK | HM_TU8_LEFT | HM_TU8_TOP)) return "reserved bits of a record";
-          const hm_tu u = expand(t);
+          const auto u = expand(t);
+          if (u.reserved_bits) return "reserved bits of a record";
           if (const char* what = check_record(u, pass == 0 ? 1 : 0)) return what;
           level_at += u.n_coeff;
         }

@@ -11,7 +11,7 @@
  *     hm_pic            header
  *     hm_slice[n_slices]
  *     hm_ctb[n_ctbs]    raster order
- *     hm_tu[n_tus]      see "record order" below (hm_tu8[n_tus] in pictures with HM_PIC_SPLIT_CHAINS)
+ *     hm_tu[n_tus]      see "record order" below (hm_tu6[n_tus] in pictures with HM_PIC_SPLIT_CHAINS)
  *     hm_coeff[n_coeffs]
  *
  * Record order.  Intra prediction chains the blocks of one colour plane; luma and chroma never read each other (pictures
@@ -21,10 +21,14 @@
  *     CTBs in raster order, each CTB's in decode order, then the chroma records (Cb and Cr, decode order) of the row's
  *     CTBs likewise.  hm_ctb.tu_first / tu_count delimit the CTB's luma records, tu_first_c / tu_count_c its chroma
  *     records; within a row both lists are contiguous from CTB to CTB, so a kernel walks each with a running index.
- *     The records are the compact 8-byte hm_tu8, and the levels (hm_coeff) lie in the order of the records, so a
+ *     The records are the compact 6-byte hm_tu6, and the levels (hm_coeff) lie in the order of the records, so a
  *     record's first level is the running sum of the counts before it: hm_ctb.coeff_first / coeff_first_c give that
- *     sum at the CTB's first luma / chroma record (format HSM4: 0.47 instead of 0.78 bytes of command stream per
- *     luma sample on the benchmark tiles - the stream crosses PCIe, and it is what bounds the device-inclusive clock).
+ *     sum at the CTB's first luma / chroma record.  Format HSM5 (r04): the records no longer carry the five neighbour-
+ *     availability answers of a block - they are a pure function of the block's rectangle, the picture size and four
+ *     bits per CTB (hm_ctb.nb_avail), which the residual pre-pass evaluates with a lane per record (hm_avail.h) - nor a
+ *     second QP (the deblocking QpY of a luma block is its dequantisation QP minus QpBdOffset; chroma records need
+ *     none): 0.40 bytes of command stream per luma sample on the benchmark tiles (HSM4: 0.48, HSM3: 0.78) - the
+ *     stream crosses PCIe, and it is what bounds the device-inclusive clock.
  *   HM_PIC_SPLIT_CHAINS clear (pictures with HM_PIC_RARE_SYNTAX): all records of a CTB in decode order in
  *     [tu_first, tu_first + tu_count), CTBs in raster order; tu_count_c = 0.
  */
@@ -37,7 +41,7 @@
 extern "C" {
 #endif
 
-#define HM_STREAM_MAGIC 0x344d5348u /* "HSM4" */
+#define HM_STREAM_MAGIC 0x354d5348u /* "HSM5" */
 
 /* hm_pic.flags */
 #define HM_PIC_STRONG_INTRA_SMOOTHING 0x0001u /* sps.strong_intra_smoothing_enable_flag        */
@@ -124,6 +128,12 @@ typedef struct hm_slice {
 #define HM_CTB_LOSSLESS      0x40u /* the CTB holds a PCM or cu_transquant_bypass coding unit (image.h:190 of the reference:
                                       has_pcm_or_cu_transquant_bypass, which sends SAO down its per-sample path)      */
 
+/* hm_ctb.nb_avail */
+#define HM_CTB_NB_NW 0x01u
+#define HM_CTB_NB_N  0x02u
+#define HM_CTB_NB_NE 0x04u
+#define HM_CTB_NB_W  0x08u
+
 /* SAO parameters of one colour component of one CTB (slice.h:457-465, offsets pre-scaled
  * by log2_sao_offset_scale as slice.cc:2996-3007 does) */
 typedef struct hm_sao {
@@ -152,7 +162,10 @@ typedef struct hm_ctb {
   hm_sao   sao[3];
   uint32_t tu_first_c;   /* HM_PIC_SPLIT_CHAINS: the CTB's chroma records (contiguous along the CTB row)  */
   uint16_t tu_count_c;
-  uint16_t reserved;
+  uint8_t  nb_avail;     /* HM_CTB_NB_*: which neighbouring CTBs intra prediction may read (inside the picture, earlier in
+                            tile scan, same slice, same tile: intrapred.h:536-618 of the reference); the CTBs to the right
+                            and below are always later                                                             */
+  uint8_t  reserved;
   uint32_t coeff_first;  /* HM_PIC_SPLIT_CHAINS: index of the first level of the CTB's first luma record ...     */
   uint32_t coeff_first_c;/* ... and of its first chroma record (levels lie in record order)                       */
 } hm_ctb; /* 52 bytes = HM_CTB_DWORDS dwords */
@@ -188,21 +201,21 @@ typedef struct hm_tu {
 
 /* The same step in pictures with HM_PIC_SPLIT_CHAINS (no rare syntax: no PCM / bypass flags, levels in record order):
  *   pos        x >> 2 | (y >> 2) << 4           (block positions are multiples of 4 samples of their plane)
- *   info, pred_mode, qp, qpy                     as in hm_tu (pred_mode without flags)
- *   avail      below-left count >> 2 | (top-right count >> 2) << 4   (counts are multiples of 4: 0 .. nT)
- *   count      n_coeff (bits 0-10) | HM_TU8_LEFT | HM_TU8_TOP: left / top run complete (the counts are 0 or nT) */
-#define HM_TU8_COUNT_MASK 0x07FFu
-#define HM_TU8_LEFT       0x0800u
-#define HM_TU8_TOP        0x1000u
-typedef struct hm_tu8 {
+ *   info       as in hm_tu, without HM_TU_AVAIL_TL (bit 7 is 0)
+ *   pred_mode  as in hm_tu, without flags
+ *   qp         the dequantisation qP as in hm_tu; for a luma record also QpY + QpBdOffsetY of its coding unit (the
+ *              deblocking filter's QpY = qp - 6 * (bit_depth_y - 8)), also when the record has no residual
+ *   count      n_coeff (bits 0-10); bits 11-15 are 0
+ * Neighbour availability is not stored: hm_avail.h derives it from the record's position, hm_ctb.nb_avail of its CTB
+ * and the picture size, exactly as the parser derives the hm_tu fields. */
+#define HM_TU6_COUNT_MASK 0x07FFu
+typedef struct hm_tu6 {
   uint8_t  pos;
   uint8_t  info;
   uint8_t  pred_mode;
   uint8_t  qp;
-  int8_t   qpy;
-  uint8_t  avail;
   uint16_t count;
-} hm_tu8; /* 8 bytes */
+} hm_tu6; /* 6 bytes */
 
 typedef struct hm_coeff {
   uint16_t pos;          /* x + y * nT (coeffPos, slice.cc:3694-3696)                         */

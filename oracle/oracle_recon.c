@@ -660,6 +660,71 @@ int orc_stream_info(const uint8_t* blob, size_t size, int out[8])
   return 0;
 }
 
+static unsigned z_code(int x4, int y4) /* Morton code of a 4x4 unit inside its CTB (pps.cc:585-700: MinTbAddrZS) */
+{
+  unsigned z = 0;
+  for (int b = 0; b < 4; b++) z |= (unsigned)((x4 >> b) & 1) << (2 * b) | (unsigned)((y4 >> b) & 1) << (2 * b + 1);
+  return z;
+}
+/* one neighbouring luma sample as seen from a block of CTB (ctb_x, ctb_y) whose first 4x4 unit has the z-scan code zc:
+ * inside the picture, in a usable CTB, and - inside the block's own CTB - earlier in z-scan order */
+static int sample_ok(const hm_pic* H, int usable[2][3], int ctb_x, int ctb_y, unsigned zc, int x, int y)
+{
+  if (x < 0 || y < 0 || x >= H->width || y >= H->height) return 0;
+  const int dx = (x >> H->log2_ctb) - ctb_x, dy = (y >> H->log2_ctb) - ctb_y;
+  if (dx < -1 || dx > 1 || dy < -1 || dy > 0) return 0; /* the CTB row below comes later in every scan */
+  if (dx == 0 && dy == 0) {
+    const int cs = 1 << H->log2_ctb;
+    return z_code((x & (cs - 1)) >> 2, (y & (cs - 1)) >> 2) < zc;
+  }
+  return usable[dy + 1][dx + 1];
+}
+/* Neighbour availability of an intra block, restated from the reference (intrapred.h:536-667: preproc_non_constraned_intra
+ * and the head of fill_from_image_non_constraned_intra; = 8.4.4.2.2 / 6.4.1 of the standard): a neighbouring sample is
+ * available iff it lies inside the picture, in a CTB of the same slice and tile (the CTB-level answer: hm_ctb.nb_avail,
+ * intrapred.h:576-613) and in a block that precedes the current one in z-scan order (intrapred.h:632-642: comparison of
+ * MinTbAddrZS; inside one CTB that is the order of the Morton codes of the 4x4 units, a neighbouring CTB that is usable
+ * at all was decoded completely before).  Below-left / above-right counts are clamped to the picture (intrapred.h:645-646).
+ * Fills avail_left / avail_top (0 or nT), avail_bottom_left / avail_top_right (samples) and HM_TU_AVAIL_TL of *t. */
+static void derive_avail(const hm_pic* H, const hm_ctb* ctb, int ctb_x, int ctb_y, hm_tu* t)
+{
+  const int cidx = (t->info >> HM_TU_CIDX_SHIFT) & 3, nT = 1 << (t->info & HM_TU_LOG2_MASK);
+  const int sw = (cidx && H->chroma_format != 3) ? 2 : 1, sh = (cidx && H->chroma_format == 1) ? 2 : 1; /* SubWidthC / SubHeightC */
+  const int cs = 1 << H->log2_ctb;
+  /* the block in luma samples of the picture (intrapred.h:546-547) */
+  const int xB = ctb_x * (cs / sw) + t->x, yB = ctb_y * (cs / sh) + t->y; /* plane samples */
+  const int xL = xB * sw, yL = yB * sh, wL = nT * sw, hL = nT * sh;
+  const unsigned zc = z_code((xL & (cs - 1)) >> 2, (yL & (cs - 1)) >> 2);
+  /* is the luma sample (x, y) available to this block? */
+  int usable[2][3]; /* [dy + 1][dx + 1] of the CTBs NW N NE / W self - */
+  usable[0][0] = (ctb->nb_avail & HM_CTB_NB_NW) != 0; usable[0][1] = (ctb->nb_avail & HM_CTB_NB_N) != 0; usable[0][2] = (ctb->nb_avail & HM_CTB_NB_NE) != 0;
+  usable[1][0] = (ctb->nb_avail & HM_CTB_NB_W) != 0; usable[1][1] = 1; usable[1][2] = 0;
+#define SAMPLE_OK(x, y) sample_ok(H, usable, ctb_x, ctb_y, zc, (x), (y))
+  const int left = xL > 0 && SAMPLE_OK(xL - 1, yL);
+  const int top = yL > 0 && SAMPLE_OK(xL, yL - 1);
+  const int tl = xL > 0 && yL > 0 && SAMPLE_OK(xL - 1, yL - 1);
+  const int bl = left && yL + hL < H->height && SAMPLE_OK(xL - 1, yL + hL);
+  /* (above-right does not ask for `top`: intrapred.h:642 - a slice may start between the CTB above and the one above-right) */
+  const int tr = yL > 0 && xL + wL < H->width && SAMPLE_OK(xL + wL, yL - 1);
+#undef SAMPLE_OK
+  int n_bl = 0, n_tr = 0;
+  if (bl) { /* bottom_left_size: (min((yB + 2 nT) SubHeight, height) - (yB + nT) SubHeight) >> (SubHeight - 1) */
+    int lim = (yB + 2 * nT) * sh;
+    if (lim > H->height) lim = H->height;
+    n_bl = (lim - (yB + nT) * sh) >> (sh - 1);
+  }
+  if (tr) {
+    int lim = (xB + 2 * nT) * sw;
+    if (lim > H->width) lim = H->width;
+    n_tr = (lim - (xB + nT) * sw) >> (sw - 1);
+  }
+  t->avail_left = left ? (uint8_t)nT : 0;
+  t->avail_top = top ? (uint8_t)nT : 0;
+  t->avail_bottom_left = (uint8_t)n_bl;
+  t->avail_top_right = (uint8_t)n_tr;
+  if (tl) t->info |= HM_TU_AVAIL_TL;
+}
+
 /* stages: bit0 deblocking, bit1 SAO (reconstruction always runs).  Output planes are tight
  * (stride = plane width in samples), uint16 for every bit depth. */
 int orc_decode_picture(const uint8_t* blob, size_t size, int stages, uint16_t* y, uint16_t* cb, uint16_t* cr)
@@ -677,29 +742,35 @@ int orc_decode_picture(const uint8_t* blob, size_t size, int stages, uint16_t* y
   P.coeffs = (const hm_coeff*)(blob + H->off_coeffs);
   hm_tu* expanded = NULL;
   if (H->flags & HM_PIC_SPLIT_CHAINS) {
-    /* compact records (hm_stream.h: hm_tu8): back to the full form; the levels lie in record order, so a record's first
-     * level is the running sum of the counts before it (checked against the per-CTB sums of the stream below) */
-    const hm_tu8* c8 = (const hm_tu8*)(blob + H->off_tus);
+    /* compact records (hm_stream.h: hm_tu6): back to the full form; the levels lie in record order, so a record's first
+     * level is the running sum of the counts before it (checked against the per-CTB sums of the stream below); the
+     * neighbour availability is not stored - derive_avail() restates the reference's rules from the block's position */
+    const uint8_t* c6 = blob + H->off_tus;
     expanded = (hm_tu*)calloc(H->n_tus ? H->n_tus : 1, sizeof(hm_tu));
     uint32_t at = 0;
     for (uint32_t i = 0; i < H->n_tus; i++) {
       hm_tu* t = &expanded[i];
-      const int nT = 1 << (c8[i].info & HM_TU_LOG2_MASK);
-      t->x = (uint8_t)((c8[i].pos & 15) << 2); t->y = (uint8_t)((c8[i].pos >> 4) << 2);
-      t->info = c8[i].info; t->pred_mode = c8[i].pred_mode; t->qp = c8[i].qp; t->qpy = c8[i].qpy;
-      t->n_coeff = (uint16_t)(c8[i].count & HM_TU8_COUNT_MASK);
+      hm_tu6 c;
+      memcpy(&c, c6 + (size_t)i * sizeof(hm_tu6), sizeof(c));
+      t->x = (uint8_t)((c.pos & 15) << 2); t->y = (uint8_t)((c.pos >> 4) << 2);
+      t->info = c.info; t->pred_mode = c.pred_mode; t->qp = c.qp;
+      /* a luma record's QP is QpY + QpBdOffsetY of its coding unit: the deblocking filter's QpY */
+      t->qpy = ((c.info >> HM_TU_CIDX_SHIFT) & 3) == 0 ? (int8_t)((int)c.qp - 6 * ((int)H->bit_depth_y - 8)) : 0;
+      t->n_coeff = (uint16_t)(c.count & HM_TU6_COUNT_MASK);
       t->coeff_first = at;
       at += t->n_coeff;
-      t->avail_left = (c8[i].count & HM_TU8_LEFT) ? (uint8_t)nT : 0;
-      t->avail_top = (c8[i].count & HM_TU8_TOP) ? (uint8_t)nT : 0;
-      t->avail_bottom_left = (uint8_t)((c8[i].avail & 15) << 2);
-      t->avail_top_right = (uint8_t)((c8[i].avail >> 4) << 2);
     }
     if (at != H->n_coeffs) { free(expanded); return -3; }
     for (uint32_t i = 0; i < H->n_ctbs; i++) { /* the per-CTB level sums the kernels start from */
       const hm_ctb* c = &P.ctbs[i];
       if ((c->tu_count && expanded[c->tu_first].coeff_first != c->coeff_first) ||
           (c->tu_count_c && expanded[c->tu_first_c].coeff_first != c->coeff_first_c)) { free(expanded); return -3; }
+      const int cx = (int)(i % H->ctb_w), cy = (int)(i / H->ctb_w);
+      for (uint32_t k = 0; k < (uint32_t)c->tu_count + c->tu_count_c; k++) {
+        const uint32_t r = k < c->tu_count ? c->tu_first + k : c->tu_first_c + (k - c->tu_count);
+        if (r >= H->n_tus) { free(expanded); return -3; }
+        derive_avail(H, c, cx, cy, &expanded[r]);
+      }
     }
     P.tus = expanded;
   }

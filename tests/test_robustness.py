@@ -167,17 +167,20 @@ def test_foreign_command_streams_are_validated(hm):
         assert bad(put("<I", ctbs, 7))                             # tu_first of CTB 0 (records not contiguous)
         assert bad(put("<H", ctbs + 6, 9))                         # slice index
         assert bad(put("<B", ctbs + 12, 9))                        # SAO type
-        if compact:  # hm_tu8: pos, info, pred_mode, qp, qpy, avail, count
+        if compact:  # hm_tu6: pos, info, pred_mode, qp, count
             assert bad(put("<B", tus + 1, 7))                      # block size 2^7
             assert bad(put("<B", tus + 2, 63))                     # prediction mode 63
             assert bad(put("<B", tus + 2, 0x80 | 1))               # PCM flag in a picture without rare syntax
-            assert bad(put("<H", tus + 6, 0x07FF))                 # more levels than the block has positions
-            assert bad(put("<H", tus + 6, 0xE000))                 # reserved bits
-            assert bad(put("<B", tus + 5, 0xFF))                   # below-left / top-right counts beyond the block size
+            assert bad(put("<H", tus + 4, 0x07FF))                 # more levels than the block has positions
+            assert bad(put("<H", tus + 4, 0xE000))                 # reserved bits
+            info0 = struct.unpack_from("<B", b, tus + 1)[0]
+            assert bad(put("<B", tus + 1, info0 | 0x80))           # reserved bit of info (hm_tu's top-left flag: derived, not stored)
+            assert bad(put("<B", ctbs + 42, 0x08))                 # CTB 0 claims a usable CTB to its left (outside the picture)
+            assert bad(put("<B", ctbs + 42, 0x10))                 # reserved bits of hm_ctb.nb_avail
             assert bad(put("<I", ctbs + 44, 7))                    # level index of the CTB's first record
-            size0 = struct.unpack_from("<B", b, tus + 1)[0] & 7
+            size0 = info0 & 7
             assert bad(put("<B", tus + 0, 0xFF)) or size0 == 2    # block outside its CTB (a 4x4 block at 60,60 of a 64 CTB is inside)
-            counts = [struct.unpack_from("<H", b, tus + 8 * t + 6)[0] & 0x7FF for t in range(64)]
+            counts = [struct.unpack_from("<H", b, tus + 6 * t + 4)[0] & 0x7FF for t in range(64)]
             first_cf = sum(counts[:next(t for t in range(64) if counts[t])])
         else:        # hm_tu
             assert bad(put("<B", tus + 2, 7))                      # block size 2^7
