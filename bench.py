@@ -264,6 +264,18 @@ def launch_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def emit(obj):
+    """the run's JSON line.  RCCL prints a version banner through C stdio when its first communicator comes up; that text
+    sits in libc's buffer until the process exits - flushed here first, so that the JSON is the LAST line of stdout."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+    sys.stdout.flush()
+    print(json.dumps(obj), flush=True)
+
+
 def rccl_selftest(torch, pkg, dev):
     """N = 1: a one-rank process group on the requested backend ("nccl" IS RCCL on ROCm), so that the line shows librccl
     loads on this image and a collective on a device tensor runs - an all_reduce and the design's only data-path
@@ -401,7 +413,7 @@ def run(args):
         ok = int(t.item())
     if not ok:
         if rank == 0:
-            print(json.dumps({"error": "parity gate failed: GPU RGB != CPU oracle / reference on at least one rank"}))
+            emit({"error": "parity gate failed: GPU RGB != CPU oracle / reference on at least one rank"})
         raise SystemExit(3)
 
     for _ in range(args.warmup):
@@ -449,7 +461,7 @@ def run(args):
                 out["device_inclusive_MP_per_s"] = max(v["MP_per_s"] for k, v in out["device_inclusive"].items() if isinstance(v, dict) and "MP_per_s" in v)
             except Exception:
                 pass
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -1103,7 +1115,7 @@ def run_grid(args, torch, pkg, dev, dist, rank, world, st, shared):
         ok = int(t.item())
     if not ok:
         if rank == 0:
-            print(json.dumps({"error": "grid mode self-check failed: gathered RGB != one-rank decode"}))
+            emit({"error": "grid mode self-check failed: gathered RGB != one-rank decode"})
         raise SystemExit(3)
 
     for _ in range(args.warmup):
@@ -1145,7 +1157,7 @@ def run_grid(args, torch, pkg, dev, dist, rank, world, st, shared):
                "with_gather_MP_per_s": round(mp / (per_step + gather_s), 1)}
         if shared:
             out["config"]["shared_gpu"] = "ranks share one GPU: functional run of the N>1 path, not a scaling number"
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -63,6 +63,7 @@ struct heif_context {
   hm_file* file = nullptr;
   int max_decoding_threads = 0; // tile fan-out of a grid; 0 = decode on the calling thread (context.h:558)
   int max_decoder_threads = 0;  // threads handed to the decoder of a single image (new_decoder(&dec, n))
+  std::vector<int32_t> devices; // heif_mi355x_context_set_devices: the GPUs a grid's tile rows are spread over (empty: the current one)
   ~heif_context() { if (file) hm_file_close(file); }
 };
 struct heif_image_handle {
@@ -184,6 +185,15 @@ void heif_context_set_threads(struct heif_context* ctx, const struct heif_image_
   if (in_handle->info.is_grid) { ctx->max_decoding_threads = nthreads; ctx->max_decoder_threads = 0; }
   else { ctx->max_decoding_threads = 0; ctx->max_decoder_threads = nthreads; }
 }
+// Extension (not in libheif): the HIP devices heif_decode_image may use for ONE grid of this context - its tile rows are cut
+// into a slab per listed device (hm_decode_item_devices; context.cc:2361-2401's tile fan-out across GPUs instead of threads).
+// n = 0 restores the default (the calling thread's current device).
+void heif_mi355x_context_set_devices(struct heif_context* ctx, const int* devices, int n)
+{
+  if (!ctx) return;
+  ctx->devices.clear();
+  for (int i = 0; devices && i < n && i < 64; i++) ctx->devices.push_back(devices[i]);
+}
 void heif_image_handle_release(const struct heif_image_handle* h) { delete h; }
 int heif_image_handle_get_width(const struct heif_image_handle* h) { return h ? h->info.width : 0; }
 int heif_image_handle_get_height(const struct heif_image_handle* h) { return h ? h->info.height : 0; }
@@ -257,7 +267,9 @@ struct heif_error heif_decode_image(const struct heif_image_handle* in, struct h
   if (want_ext) { prm.ext_dst = opt->ext_dst; prm.ext_dst_len = opt->ext_dst_len; prm.ext_dst_stride = opt->ext_dst_stride; }
 
   hm_decoded dec;
-  const int rc = hm_decode_item(in->ctx->file, in->id, &prm, &dec);
+  const std::vector<int32_t>& devs = in->ctx->devices;
+  const int rc = devs.empty() ? hm_decode_item(in->ctx->file, in->id, &prm, &dec)
+                              : hm_decode_item_devices(in->ctx->file, in->id, &prm, devs.data(), (int)devs.size(), &dec);
   if (rc) return from_status(rc);
   std::unique_ptr<heif_image> img(new (std::nothrow) heif_image());
   if (!img) { hm_decoded_free(&dec); return err(heif_error_Memory_allocation_error, heif_suberror_Unspecified, "out of memory"); }

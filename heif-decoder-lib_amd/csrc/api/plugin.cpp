@@ -34,12 +34,23 @@ struct Decoder {
 
 heif_error ok() { return {heif_error_Ok, heif_suberror_Unspecified, kSuccess}; }
 
+// What the caller of a decoder plugin sees when a coded picture cannot be decoded.  The reference's libde265 plugin
+// reports a failed decode as "Ok, but no image" (decoder_libde265.cc:311-336: de265_decode's error only ends the loop),
+// which HeifContext::decode_image_planar turns into Error(heif_error_Decoder_plugin_error, heif_suberror_Unspecified)
+// (context.cc:1826-1830); a [length][NAL] record that runs past the pushed bytes is {Decoder_plugin_error, End_of_data}
+// (decoder_libde265.cc:276-292).  This plugin returns exactly those codes - with a message that says what was wrong - so a
+// caller that branches on them behaves the same.  NOTE the behavioural difference that remains ("Damaged
+// streams"): libde265 conceals most damage INSIDE slice data and hands out a picture; this decoder refuses such a picture
+// (HM_ERR_BITSTREAM).  The recovery path is the caller's: heif_decoding_options.decoder_id = "libde265".
 heif_error from_status(int rc)
 {
   std::snprintf(g_msg, sizeof(g_msg), "%s", hm_last_error());
   switch (rc) {
     case HM_ERR_UNSUPPORTED: return {heif_error_Unsupported_feature, heif_suberror_Unsupported_codec, g_msg};
-    case HM_ERR_BITSTREAM: return {heif_error_Invalid_input, heif_suberror_Unspecified, g_msg};
+    case HM_ERR_BITSTREAM: {
+      const bool framing = std::strstr(g_msg, "NAL length") != nullptr; // (hevc_parse.cpp: "truncated NAL length field" / "NAL length exceeds the data")
+      return {heif_error_Decoder_plugin_error, framing ? heif_suberror_End_of_data : heif_suberror_Unspecified, g_msg};
+    }
     case HM_ERR_NOMEM: return {heif_error_Memory_allocation_error, heif_suberror_Unspecified, g_msg};
     default: return {heif_error_Decoder_plugin_error, heif_suberror_Unspecified, g_msg};
   }

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
 
   // ---- workgroup-wide tables ----
   int16_t* const tab = reinterpret_cast<int16_t*>(lds);
-  uint16_t* const tab4 = reinterpret_cast<uint16_t*>(lds + C_SHARED_TABLES);
+  int16_t* const tab4 = reinterpret_cast<int16_t*>(lds + C_SHARED_TABLES);
   for (int i = tid; i < 70; i += blockDim.x) { // [0,35) angle, [35,70) inverse angle (0 where unused)
     int v;
     if (i < 35) v = c_intra_angle[i];
@@ -177,7 +177,10 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     // |j| reaches 2nT + 1 = 9 only for the second sample of a position whose weight f is 0: any legal index will do
     j0 = j0 < -8 ? -8 : (j0 > 8 ? 8 : j0);
     j1 = j1 < -8 ? -8 : (j1 > 8 ? 8 : j1);
-    tab4[i] = (uint16_t)((j0 + 8) | ((j1 + 8) << 5) | (f << 10));
+    // as (side, position): left column -> side 1, position -j - 1 (0 .. 7); corner and row above -> side 0, position j (0 .. 8).
+    // The side of the first sample sits in bit 15: the entry is read sign-extended and tested with one compare.
+    const int s0 = j0 < 0, k0 = j0 < 0 ? -j0 - 1 : j0, s1 = j1 < 0, k1 = j1 < 0 ? -j1 - 1 : j1;
+    tab4[i] = (int16_t)(uint16_t)(k0 | (s1 << 4) | (k1 << 5) | (f << 9) | (s0 << 15));
   }
   // ---- this wave's task ----
   int pic_index, pair_index = 0, kind_sel = -1; // (kind_sel: the only chain kind this wave works on, -1: both)
@@ -252,18 +255,19 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   // group -> (chain kind, row slot): luma / chroma of two rows, or luma of four rows (monochrome)
   auto group_kind = [&](int gg) { return mono ? 0 : (gg & 1); };
   auto group_slot = [&](int gg) { return mono ? gg : (gg >> 1); };
+  // (offsets inside the wave's LDS in 32-bit arithmetic: with size_t factors every use costs a 64-bit scalar multiply)
   auto group_base = [&](int gg) -> uint8_t* {
-    return pbase + L.off_groups + (mono ? (size_t)gg * L.row_bytes : (size_t)(gg >> 1) * L.row_bytes + (size_t)(gg & 1) * L.chroma_off);
+    return pbase + (L.off_groups + (mono ? gg * L.row_bytes : (gg >> 1) * L.row_bytes + (gg & 1) * L.chroma_off));
   };
   auto group_u = [&](int gg, int c) { // plane c of the group's chain (luma groups: c = 0; chroma groups: c = 1, 2)
     uint8_t* p = group_base(gg);
-    if (c == 2) p += (size_t)P1 * ch_c * sizeof(Pix);
+    if (c == 2) p += P1 * ch_c * (int)sizeof(Pix);
     return reinterpret_cast<Pix*>(p);
   };
   // sample line `slot` of a chain kind: luma sample 0 / Cb sample 0 (Cr sample 0 is Wc + 4 samples further)
   auto line_of = [&](int kind, int slot) {
     if (L.line_slots == 1) slot = 0;
-    uint8_t* p = kind ? lines_c + (size_t)slot * L.line_c_bytes : lines_l + (size_t)slot * L.line_l_bytes;
+    uint8_t* p = kind ? lines_c + slot * L.line_c_bytes : lines_l + slot * L.line_l_bytes;
     return reinterpret_cast<Pix*>(p) + 4;
   };
 
@@ -274,13 +278,16 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   const int Pk = kind ? P1 : P0;               // pitch of the chain's CTU buffers
   const int l2w = kind ? log2_ctb - 1 : log2_ctb; // log2 of the CTU width in samples of the chain's planes
   const int cr_off = P1 * ch_c;                // Cr buffer behind the Cb buffer, in samples
+  const int st_off = by_ * Pk + 1 + bx_;       // a 4x4 block's sample of this lane, from the block's (x0 - 1, y0)
   int* const my_progress = progress + kind * C_PROG;
   c_u32x4* const ring = rings + g * C_RING;
   // byte offsets in LDS of the group's places, for the wave-wide path (fetched from the group's first lane)
   const uint32_t gb_off = (uint32_t)(reinterpret_cast<uint8_t*>(gbase) - lds);
 
   // ---- group state (the same value in the 16 lanes of a group) ----
-  int row = (PAIRS ? pair_index * RPW : 0) + group_slot(g), cx = 0, kleft = 0;
+  int row = (PAIRS ? pair_index * RPW : 0) + group_slot(g), cx = 0;
+  uint32_t ctu_end = 0; // one behind the last record of the group's current CTU
+  int left = 0;         // records the group may execute before its next event (see the service phase of the loop)
   // the sample lines are slots row % NR; a group's rows are NR apart, so its slot - and the slot of the row above - never change
   const int my_slot = group_slot(g);
   const int line_above = my_slot ? my_slot - 1 : NR - 1;
@@ -341,7 +348,8 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   // every iteration executes a block of some chain or waits for a CTU that is at most two CTUs of another chain away
   // (PAIRS: plus the bounded waits for the band above, one per CTU at most)
   const long long budget_ll = (long long)n_tus + 64ll * ctb_w * ctb_h + 4096 + (PAIRS ? (long long)ctb_w * L.spin_limit : 0);
-  int budget = budget_ll < 0x7FFFFFF0ll ? (int)budget_ll : 0x7FFFFFF0;
+  int budget = rfl(budget_ll < 0x7FFFFFF0ll ? (int)budget_ll : 0x7FFFFFF0); // (a scalar: the loop's exit test costs no vector instruction)
+  unsigned long long m_done = ballot(st == ST_DONE);
 
 #if defined(HM_PAD_S) || defined(HM_PAD_V)
   int lane0_dummy = 0, pad_v = lane;
@@ -350,85 +358,223 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   // means waiting for every load in flight
   uint32_t bres0 = 0, bres1 = 0, bres2 = 0, bres3 = 0;
   HM_T_DECL;
+  if (~m_done == 0) return; // (nothing to do for this wave)
   for (;;) {
     HM_MARK("A_begin");
-    // ---- A: start the next CTU of every group whose dependency is met (the row above two CTUs ahead) ----
-    bool started = false;
-    if (st == ST_START) {
-      const int need = cx + 2 < ctb_w ? cx + 2 : ctb_w;
-      // (a counter value seen here means the line samples written before it are there: LDS traffic of a wave is in order)
-      int done_above = __hip_atomic_load(my_progress + prog_index(row - 1, my_slot - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (from_hbm) done_above = hbm_have;
-      if (row == 0 || done_above >= need) {
-        uint32_t count = c1;
-        asm volatile("" : "+v"(count)); // (keeps the mask - and with it the wait for the header load - here, a CTU later than the load)
-        kleft = (int)(count & 0xFFFF);
-        st = ST_RUN;
-        started = true;
-      }
-    }
-    if (ballot(started)) { // (wave-uniform: the loads below are not merged with anything, so nobody waits for them here)
-      // every lane asks for the header its chain needs next: a group inside CTU cx the one of cx + 1 (the last CTU of a
-      // row: its own again), a waiting group the one of the CTU it waits to start
-      const int hx = st == ST_RUN ? (cx + 1 < ctb_w ? cx + 1 : cx) : cx;
-      header(row < ctb_h ? row : ctb_h - 1, hx);
-    }
-    if (PAIRS) {
-      // ---- the sample line of the pair above, through HBM: the chains of a pair's first row poll the progress word of
-      //      the pair above (while they wait, and every eighth iteration while they run, so that the line is usually
-      //      there before it is needed) and copy what has become available from the picture into the line ----
-      const bool poll = from_hbm && st != ST_DONE && hbm_have < ctb_w && (st == ST_START || (budget & 15) == 0);
-      if (ballot(poll)) {
-        // (the word and the line are written and read with agent-scope accesses that pass the caches which are not
-        //  coherent across the chip: no cache write-back / invalidation - those cost more than the hand-over itself
-        //  when thousands of waves do them per CTU; the reader's loads are issued behind the word's value)
-        int avail = 0;
-        if (poll) avail = (int)__hip_atomic_load(pair_progress + 2 * (size_t)(pidx - 1) + kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (unsigned long long todo = ballot(poll && avail > hbm_have); todo;) {
-          const int cg = rfl((int)(__builtin_ctzll(todo) >> 4));
-          todo &= ~(0xFFFFull << (cg * 16));
-          const int src = cg * 16;
-          const int s_have = __builtin_amdgcn_readlane(hbm_have, src);
-          int s_avail = __builtin_amdgcn_readlane(avail, src);
-          if (s_avail > s_have + 8) s_avail = s_have + 8; // (bounded work per iteration)
-          const int ckind = group_kind(cg);
-          const int s_pidx = __builtin_amdgcn_readlane(pidx, src);
-          if (RPW > 1) {
-            // the line this copy fills is also where the wave's last row of the PREVIOUS band puts its bottom samples: while
-            // that row is still on its way, only the CTUs it has finished may be overwritten (it runs 2 CTUs per row behind)
-            const int wsrc = (mono ? RPW - 1 : (((RPW - 1) << 1) | ckind)) * 16;
-            const int w_pidx = __builtin_amdgcn_readlane(pidx, wsrc), w_cx = __builtin_amdgcn_readlane(cx, wsrc);
-            if (w_pidx < s_pidx && s_avail > w_cx) s_avail = w_cx;
+    // ---- S: service.  `left` counts the records a group may execute before its next EVENT - the end of its CTU's records,
+    //      the end of the window of micro-ops in LDS - and is 0 in a group that waits to start a CTU; a group that is done
+    //      holds 0 too and is masked out.  An iteration without events (nearly half of them) costs one compare here: the
+    //      state checks of all three phases below (r03: ~20 vector instructions per iteration) run only when something is due.
+    const unsigned long long m_left0 = ballot(left == 0);
+    if ((m_left0 & ~m_done) || (PAIRS && (budget & 15) == 0)) {
+      // ---- F: finished CTUs: coalesced stores to the picture, bottom row -> line, right column -> left column ----
+      for (unsigned long long fin = ballot(st == ST_RUN) & ballot(ri == ctu_end); fin;) {
+        const int fg = rfl((int)(__builtin_ctzll(fin) >> 4));
+        fin &= ~(0xFFFFull << (fg * 16));
+        const int src = fg * 16;
+        const int s_row = __builtin_amdgcn_readlane(row, src), s_cx = __builtin_amdgcn_readlane(cx, src);
+        const int fkind = group_kind(fg);
+        Pix* const lw = line_of(fkind, group_slot(fg)); // s_row % NR
+        const bool keep_line = !PAIRS || RPW > 1;
+        auto flush_plane = [&](auto bw_c, Pix* u, int P, Pix* line, uint8_t* plane, int pitch, int bh, int pw, int ph) {
+          constexpr int BW = decltype(bw_c)::value;
+          constexpr int PPW = 4 / sizeof(Pix), WPR = BW / PPW; // samples per 32-bit word, words per row
+          static_assert(WPR >= 1 && WPR <= 64 && (WPR & (WPR - 1)) == 0, "CTB row must be 1..64 words");
+          constexpr int CW = WPR < 4 ? WPR : 4, LPR = WPR / CW, RPT = 64 / LPR; // words per chunk, lanes per row, rows per trip
+          const int xo = s_cx * BW, yo = s_row * bh;
+          const int vw = (pw - xo) < BW ? (pw - xo) : BW; // valid part inside the picture
+          const int vh = (ph - yo) < bh ? (ph - yo) : bh;
+          const int q = lane & (LPR - 1), rr0 = lane / LPR;
+          const bool col_ok = q * CW * PPW < vw;
+          // (a plane is smaller than 4 GiB: 32-bit offset arithmetic - 64-bit multiplies run at a quarter of the rate)
+          GLOBAL_AS uint8_t* const gp = gptr_w<uint8_t>(plane + (uint32_t)((uint32_t)yo * (uint32_t)pitch + (uint32_t)(xo + q * CW * PPW) * (uint32_t)sizeof(Pix)));
+          for (int rb = 0; rb < vh; rb += RPT) {
+            const int r = rb + rr0;
+            if (col_ok && r < vh) {
+              const uint32_t* srcw = reinterpret_cast<const uint32_t*>(u + mul24(r, P) + UPAD + q * CW * PPW); // rows are 4-byte aligned
+              uint32_t vv[CW];
+#pragma unroll
+              for (int k = 0; k < CW; k++) vv[k] = srcw[k];
+              GLOBAL_AS uint32_t* dst = reinterpret_cast<GLOBAL_AS uint32_t*>(gp + (uint32_t)mul24(r, pitch));
+              if (CW == 4) *reinterpret_cast<GLOBAL_AS c_u32x4*>(dst) = c_u32x4{vv[0], vv[1], vv[2], vv[3]};
+              else if (CW == 2) *reinterpret_cast<GLOBAL_AS c_u32x2*>(dst) = c_u32x2{vv[0], vv[1]};
+              else dst[0] = vv[0];
+            }
           }
-          Pix* const lw = line_of(ckind, NR - 1); // the line the pair's first row reads: that of the row above
-          // CTUs [s_have, s_avail) of the hand-over line of the pair above: whole 32-bit words
-          constexpr int PPW = 4 / sizeof(Pix);
-          auto copy_line = [&](const GLOBAL_AS uint32_t* words, int ctu_w, Pix* line) {
-            const int w0 = s_have * ctu_w / PPW, w1 = s_avail * ctu_w / PPW;
-            for (int w = w0 + lane; w < w1; w += 64)
-              *reinterpret_cast<uint32_t*>(line + w * PPW) = __hip_atomic_load(words + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          };
-          const GLOBAL_AS uint32_t* const hand = hand_words + (size_t)(s_pidx - 1) * hand_pair_words;
-          if (ckind == 0) copy_line(hand, ctb, lw);
-          else {
-            copy_line(hand + hand_luma_words, cw_c, lw);
-            copy_line(hand + hand_luma_words + hand_chroma_words, cw_c, lw + (Wc + 4));
-          }
+          if (keep_line && lane < WPR) // (a wave per row / per chain: nobody in this wave reads the row's bottom line)
+            *reinterpret_cast<uint32_t*>(line + xo + lane * PPW) = *reinterpret_cast<const uint32_t*>(u + (bh - 1) * P + UPAD + lane * PPW);
           WAVE_SYNC();
-          if (g == cg && s_avail > s_have) { hbm_have = s_avail; hbm_polls = 0; }
+          if (lane < bh) u[lane * P + UPAD - 1] = u[lane * P + UPAD + BW - 1]; // right column becomes the left neighbour
+        };
+        // (the picture's planes, pitches and size: from the wave's copy in LDS, see fdesc)
+        auto f_plane = [&](int c) { return reinterpret_cast<uint8_t*>((uintptr_t)(((uint64_t)fdesc[2 * c + 1] << 32) | fdesc[2 * c])); };
+        const int f_width = (int)fdesc[9], f_height = (int)fdesc[10];
+        const int planeWc = f_width >> 1, planeHc = sh == 2 ? f_height >> 1 : f_height; // (sh is 1 or 2: no division)
+        if (fkind == 0) flush_plane(std::integral_constant<int, ctb>(), group_u(fg, 0), P0, lw, f_plane(0), (int)fdesc[6], ctb, f_width, f_height);
+        else {
+          flush_plane(std::integral_constant<int, (ctb >> 1)>(), group_u(fg, 1), P1, lw, f_plane(1), (int)fdesc[7], ch_c, planeWc, planeHc);
+          flush_plane(std::integral_constant<int, (ctb >> 1)>(), group_u(fg, 2), P1, lw + (Wc + 4), f_plane(2), (int)fdesc[8], ch_c, planeWc, planeHc);
         }
-        // the band above is not coming: give up (never on a healthy launch) - the whole wave, since its other chains
-        // wait for this one - with the launch flagged: the bands below give up in turn, nothing hangs
-        const bool gave_up = poll && st == ST_START && ++hbm_polls > L.spin_limit;
-        if (ballot(gave_up)) {
-          if (lane == 0) __hip_atomic_store(err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          st = ST_DONE;
+        WAVE_SYNC();
+        // read by the chain of the row below, a group of this wave (LDS traffic of a wave is in order)
+        const int s_prog = PAIRS ? __builtin_amdgcn_readlane(pbank, src) * 4 + group_slot(fg) : (s_row & (C_PROG - 1));
+        if (lane == 0) __hip_atomic_store(progress + fkind * C_PROG + s_prog, s_cx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (PAIRS && group_slot(fg) == RPW - 1 && s_row + 1 < ctb_h) {
+          // ... or, for the pair's last row, the first row of the pair below: another wave, anywhere on the chip.  The
+          // CTU's bottom sample line goes to the pair's hand-over line with agent-scope stores; once they have left this
+          // wave (vmcnt 0) the word that announces them follows
+          constexpr int PPW = 4 / sizeof(Pix);
+          const int s_pidx = __builtin_amdgcn_readlane(pidx, src);
+          GLOBAL_AS uint32_t* const hand = hand_words + (size_t)s_pidx * hand_pair_words;
+          auto put_line = [&](GLOBAL_AS uint32_t* words, int ctu_w, const Pix* u, int P, int bh) { // the bottom row of the CTU buffer
+            const int w0 = s_cx * ctu_w / PPW, nw = ctu_w / PPW; // (at most 32 words: a CTU row of 64 16-bit samples)
+            if (lane < nw) __hip_atomic_store(words + w0 + lane, *reinterpret_cast<const uint32_t*>(u + (bh - 1) * P + UPAD + lane * PPW), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          };
+          if (fkind == 0) put_line(hand, ctb, group_u(fg, 0), P0, ctb);
+          else {
+            put_line(hand + hand_luma_words, cw_c, group_u(fg, 1), P1, ch_c);
+            put_line(hand + hand_luma_words + hand_chroma_words, cw_c, group_u(fg, 2), P1, ch_c);
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0 && !(L.test_stall && s_pidx == 0)) __hip_atomic_store(pair_progress + 2 * (size_t)s_pidx + fkind, (uint32_t)(s_cx + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (ballot(st == ST_RUN) == 0) __builtin_amdgcn_s_sleep(8); // every chain of the wave waits
+        // the group's next CTU
+        if (g == fg) {
+          cx += 1;
+          st = ST_START;
+          tl_off += (uint32_t)(sizeof(Pix) << l2w);
+          if (cx == ctb_w) {
+            cx = 0;
+            tl_off = lr_off;
+            // the group's next row: NR further (a wave per picture), or in the wave's next band (PAIRS)
+            row += PAIRS ? RPW * W : NR;
+            if (PAIRS) { pidx += W; pbank ^= 1; from_hbm = my_slot == 0; hbm_have = 0; hbm_polls = 0; }
+            if (row < ctb_h) row_start();
+            else st = ST_DONE;
+          }
+        }
       }
+      WAVE_SYNC();
+      // ---- A: start the next CTU of every group whose dependency is met (the row above two CTUs ahead) ----
+      bool started = false;
+      if (st == ST_START) {
+        const int need = cx + 2 < ctb_w ? cx + 2 : ctb_w;
+        // (a counter value seen here means the line samples written before it are there: LDS traffic of a wave is in order)
+        int done_above = __hip_atomic_load(my_progress + prog_index(row - 1, my_slot - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (from_hbm) done_above = hbm_have;
+        if (row == 0 || done_above >= need) {
+          uint32_t count = c1;
+          asm volatile("" : "+v"(count)); // (keeps the mask - and with it the wait for the header load - here, a CTU later than the load)
+          ctu_end = ri + (count & 0xFFFF);
+          st = ST_RUN;
+          started = true;
+        }
+      }
+      if (ballot(started)) { // (wave-uniform: the loads below are not merged with anything, so nobody waits for them here)
+        // every lane asks for the header its chain needs next: a group inside CTU cx the one of cx + 1 (the last CTU of a
+        // row: its own again), a waiting group the one of the CTU it waits to start
+        const int hx = st == ST_RUN ? (cx + 1 < ctb_w ? cx + 1 : cx) : cx;
+        header(row < ctb_h ? row : ctb_h - 1, hx);
+      }
+      if (PAIRS) {
+        // ---- the sample line of the pair above, through HBM: the chains of a pair's first row poll the progress word of
+        //      the pair above (while they wait, and every eighth iteration while they run, so that the line is usually
+        //      there before it is needed) and copy what has become available from the picture into the line ----
+        const bool poll = from_hbm && st != ST_DONE && hbm_have < ctb_w && (st == ST_START || (budget & 15) == 0);
+        if (ballot(poll)) {
+          // (the word and the line are written and read with agent-scope accesses that pass the caches which are not
+          //  coherent across the chip: no cache write-back / invalidation - those cost more than the hand-over itself
+          //  when thousands of waves do them per CTU; the reader's loads are issued behind the word's value)
+          int avail = 0;
+          if (poll) avail = (int)__hip_atomic_load(pair_progress + 2 * (size_t)(pidx - 1) + kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (unsigned long long todo = ballot(poll && avail > hbm_have); todo;) {
+            const int cg = rfl((int)(__builtin_ctzll(todo) >> 4));
+            todo &= ~(0xFFFFull << (cg * 16));
+            const int src = cg * 16;
+            const int s_have = __builtin_amdgcn_readlane(hbm_have, src);
+            int s_avail = __builtin_amdgcn_readlane(avail, src);
+            if (s_avail > s_have + 8) s_avail = s_have + 8; // (bounded work per iteration)
+            const int ckind = group_kind(cg);
+            const int s_pidx = __builtin_amdgcn_readlane(pidx, src);
+            if (RPW > 1) {
+              // the line this copy fills is also where the wave's last row of the PREVIOUS band puts its bottom samples: while
+              // that row is still on its way, only the CTUs it has finished may be overwritten (it runs 2 CTUs per row behind)
+              const int wsrc = (mono ? RPW - 1 : (((RPW - 1) << 1) | ckind)) * 16;
+              const int w_pidx = __builtin_amdgcn_readlane(pidx, wsrc), w_cx = __builtin_amdgcn_readlane(cx, wsrc);
+              if (w_pidx < s_pidx && s_avail > w_cx) s_avail = w_cx;
+            }
+            Pix* const lw = line_of(ckind, NR - 1); // the line the pair's first row reads: that of the row above
+            // CTUs [s_have, s_avail) of the hand-over line of the pair above: whole 32-bit words
+            constexpr int PPW = 4 / sizeof(Pix);
+            auto copy_line = [&](const GLOBAL_AS uint32_t* words, int ctu_w, Pix* line) {
+              const int w0 = s_have * ctu_w / PPW, w1 = s_avail * ctu_w / PPW;
+              for (int w = w0 + lane; w < w1; w += 64)
+                *reinterpret_cast<uint32_t*>(line + w * PPW) = __hip_atomic_load(words + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            };
+            const GLOBAL_AS uint32_t* const hand = hand_words + (size_t)(s_pidx - 1) * hand_pair_words;
+            if (ckind == 0) copy_line(hand, ctb, lw);
+            else {
+              copy_line(hand + hand_luma_words, cw_c, lw);
+              copy_line(hand + hand_luma_words + hand_chroma_words, cw_c, lw + (Wc + 4));
+            }
+            WAVE_SYNC();
+            if (g == cg && s_avail > s_have) { hbm_have = s_avail; hbm_polls = 0; }
+          }
+          // the band above is not coming: give up (never on a healthy launch) - the whole wave, since its other chains
+          // wait for this one - with the launch flagged: the bands below give up in turn, nothing hangs
+          const bool gave_up = poll && st == ST_START && ++hbm_polls > L.spin_limit;
+          if (ballot(gave_up)) {
+            if (lane == 0) __hip_atomic_store(err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            st = ST_DONE;
+          }
+          if (ballot(st == ST_RUN) == 0) __builtin_amdgcn_s_sleep(8); // every chain of the wave waits
+        }
+      }
+      if (ballot(st != ST_DONE) == 0) break;
+      HM_MARK("R_begin");
+      // ---- R: the micro-ops and 4x4 residuals of the next window of records, for every group that has entered it ----
+      {
+        const bool need_dec = st != ST_DONE && (ri >> C_WLOG) != wdec; // the chain has entered window wdec + 1: its records are in pf
+        // (lane masks of conjunctions: the masks of the single compares, combined by the scalar unit - the mask of a boolean
+        //  expression costs two more vector instructions, a select and a compare)
+        if (ballot(st != ST_DONE) & ballot((ri >> C_WLOG) != wdec)) {
+          if (need_dec) {
+            if constexpr (C_WLOG == 4) {
+              ring[gl] = c_u32x4{pf[0], pf[1], pf[2], pf[3]};
+              // the record's 16 residual samples (meaningful for 4x4 blocks with a residual)
+              c_u32x4* const rr = reinterpret_cast<c_u32x4*>(rres + gl * 16);
+              rr[0] = c_u32x4{pf[4], pf[5], pf[6], pf[7]};
+              rr[1] = c_u32x4{pf[C_ITEM_DWORDS - 4], pf[C_ITEM_DWORDS - 3], pf[C_ITEM_DWORDS - 2], pf[C_ITEM_DWORDS - 1]};
+            }
+            else {
+              uint32_t* const rr = reinterpret_cast<uint32_t*>(rres + (gl >> 1) * 16); // the record's 8 dwords of residual
+              if (gl & 1) {
+                *reinterpret_cast<c_u32x4*>(rr + 4) = c_u32x4{pf[0], pf[1], pf[2], pf[3]};
+                *reinterpret_cast<c_u32x2*>(rr + 2) = c_u32x2{pf[4], pf[5]};
+              }
+              else {
+                ring[gl >> 1] = c_u32x4{pf[0], pf[1], pf[2], pf[3]};
+                *reinterpret_cast<c_u32x2*>(rr) = c_u32x2{pf[4], pf[5]};
+              }
+            }
+            wdec += 1;
+          }
+          // every lane: the window its group decodes next (groups that did not decode ask again for the same).  (Measured against
+          // requesting it at the end of the iteration, behind the iteration's residual loads: 23.7 against 24.1 ms at full load,
+          // 7.5 against 8.1 ms for config 4.)
+          load_window(wdec + 1);
+          WAVE_SYNC();
+        }
+      }
+      // the records each group may execute from here on without another look at its state
+      {
+        const int to_ctu = (int)(ctu_end - ri), to_win = C_RING - (int)(ri & (C_RING - 1));
+        const int n = to_ctu < to_win ? to_ctu : to_win;
+        left = (st == ST_RUN && (ri >> C_WLOG) == wdec) ? n : 0;
+      }
+      m_done = ballot(st == ST_DONE);
     }
     HM_T_LAP(0);
-    if (ballot(st != ST_DONE) == 0) break;
 #if defined(HM_PAD_S) || defined(HM_PAD_V)
     if (lane0_dummy + pad_v == -12345) break; // (keeps the padding alive)
 #endif
@@ -436,49 +582,15 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       if (PAIRS && lane == 0) __hip_atomic_store(err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       break;
     }
-
-    HM_MARK("R_begin");
-    // ---- R: the micro-ops and 4x4 residuals of the next window of records, for every group that has entered it ----
-    {
-      const bool need_dec = st != ST_DONE && (ri >> C_WLOG) != wdec; // the chain has entered window wdec + 1: its records are in pf
-      // (lane masks of conjunctions: the masks of the single compares, combined by the scalar unit - the mask of a boolean
-      //  expression costs two more vector instructions, a select and a compare)
-      if (ballot(st != ST_DONE) & ballot((ri >> C_WLOG) != wdec)) {
-        if (need_dec) {
-          if constexpr (C_WLOG == 4) {
-            ring[gl] = c_u32x4{pf[0], pf[1], pf[2], pf[3]};
-            // the record's 16 residual samples (meaningful for 4x4 blocks with a residual)
-            c_u32x4* const rr = reinterpret_cast<c_u32x4*>(rres + gl * 16);
-            rr[0] = c_u32x4{pf[4], pf[5], pf[6], pf[7]};
-            rr[1] = c_u32x4{pf[C_ITEM_DWORDS - 4], pf[C_ITEM_DWORDS - 3], pf[C_ITEM_DWORDS - 2], pf[C_ITEM_DWORDS - 1]};
-          }
-          else {
-            uint32_t* const rr = reinterpret_cast<uint32_t*>(rres + (gl >> 1) * 16); // the record's 8 dwords of residual
-            if (gl & 1) {
-              *reinterpret_cast<c_u32x4*>(rr + 4) = c_u32x4{pf[0], pf[1], pf[2], pf[3]};
-              *reinterpret_cast<c_u32x2*>(rr + 2) = c_u32x2{pf[4], pf[5]};
-            }
-            else {
-              ring[gl >> 1] = c_u32x4{pf[0], pf[1], pf[2], pf[3]};
-              *reinterpret_cast<c_u32x2*>(rr) = c_u32x2{pf[4], pf[5]};
-            }
-          }
-          wdec += 1;
-        }
-        // every lane: the window its group decodes next (groups that did not decode ask again for the same).  (Measured against
-        // requesting it at the end of the iteration, behind the iteration's residual loads: 23.7 against 24.1 ms at full load,
-        // 7.5 against 8.1 ms for config 4.)
-        load_window(wdec + 1);
-        WAVE_SYNC();
-      }
-    }
-    const bool running = st == ST_RUN && kleft > 0 && (ri >> C_WLOG) == wdec;
+    const bool running = left != 0;
+    const unsigned long long m_running = ballot(left != 0);
+    if (m_running == 0) continue; // (every chain of the wave waits: PAIRS, for the band above)
 
     // the current block of every group
-    const c_u32x4 op = ring[ri & (C_RING - 1)];
-    const int16_t* const my_res = rres + (ri & (C_RING - 1)) * 16; // the 16 residual samples of the group's block if it is a 4x4 block
-    const bool quad = running && (op.y & (3u << OP_L2_SHIFT)) == 0 && (op.y & OP_INTERIOR);
-    const unsigned long long m_running = ballot(st == ST_RUN) & ballot(kleft > 0) & ballot((ri >> C_WLOG) == wdec);
+    const uint32_t rslot = ri & (C_RING - 1);
+    const c_u32x4 op = ring[rslot];
+    const int16_t* const my_res = rres + rslot * 16; // the 16 residual samples of the group's block if it is a 4x4 block
+    const bool quad = running && (op.y & ((3u << OP_L2_SHIFT) | OP_INTERIOR)) == OP_INTERIOR;
     const unsigned long long s_big = m_running & ~ballot((op.y & ((3u << OP_L2_SHIFT) | OP_INTERIOR)) == OP_INTERIOR);
     const unsigned long long s_bres = m_running & ballot((op.y & (OP_CBF | (3u << OP_L2_SHIFT))) == (OP_CBF | (1u << OP_L2_SHIFT)));
 
@@ -504,50 +616,53 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     if (quad) {
 #endif
       const int res_q = (int)my_res[gl]; // (requested first and unconditionally: not a fourth LDS round trip behind the reference samples)
-      int bx = bx_, by = by_;
-      asm volatile("" : "+v"(bx), "+v"(by)); // (loop-invariant lane masks cost scalar registers the kernel does not have)
       const int mode = (int)(op.y & OP_MODE_MASK);
       const int P = Pk;
       Pix* const lp = gbase + (op.x & 0xFFFF);                                  // sample (x0-1, y0): walks down the left column
       const Pix* const tbase = reinterpret_cast<const Pix*>(lds + ((op.y & OP_LINE) ? tl_off : gb_off));
-      const Pix* const tp = tbase + (op.x >> 16);                               // sample (x0, y0-1): walks along the row above; tp[-1] = corner
-      const int nL1 = (int)((op.y >> OP_NL1_SHIFT) & 63), nT1 = (int)((op.y >> OP_NT1_SHIFT) & 63);
-      const uint32_t e = tab4[mode * 16 + gl];
-      const int j0 = (int)(e & 31) - 8, j1 = (int)((e >> 5) & 31) - 8, f = (int)(e >> 10);
-      auto ref = [&](int j) -> int {
-        const Pix* const ql = lp + mul24(imin_(-j - 1, nL1), P);
-        const Pix* const qt = tp + imin_(j - 1, nT1);
-        return *(j < 0 ? ql : qt);
+      const Pix* const tc = tbase + (op.x >> 16) - 1;                           // the corner sample (x0-1, y0-1): tc[k] walks along the row above
+      const int nL1 = (int)((op.y >> OP_NL1_SHIFT) & 63), nT1c = (int)((op.y >> OP_NT1_SHIFT) & 63) + 1;
+      // (side, position) of the lane's two reference samples and the weight of the second (tab4, sign-extended: bit 15 = side of the first)
+      const int e = (int)tab4[mode * 16 + gl];
+      auto ref = [&](bool left, int k) -> int { // left: sample k of the left column (0 = beside the block's first row); else sample k of the row above (0 = corner)
+        const int kk = imin_(k, left ? nL1 : nT1c);
+        const Pix* const base = left ? lp : tc;
+        return base[mul24(kk, left ? P : 1)];
       };
-      const int r0 = ref(j0), r1 = ref(j1);
+      const int r0 = ref(e < 0, e & 15), r1 = ref((e & 16) != 0, (e >> 5) & 15);
       const int maxv = (1 << bd) - 1;
-      int v = blend32(f, r0, r1); // every angular mode; f = 0: a copy of r0
-      if (mode == 0) { // planar: r0 = sample above, r1 = sample to the left
-        const int tr = tp[imin_(4, nT1)], bl = lp[mul24(imin_(4, nL1), P)];
-        v = planar_sample<2>(bx, by, r1, r0, tr, bl);
-      }
-      else if (mode == 1) { // DC of the four samples above and the four to the left; luma: smoothed first row / column
-        int s = (by == 0 ? r0 : 0) + (bx == 0 ? r1 : 0);
-        s += dpp<DPP_ROW_ROR(8)>(s);
-        s += dpp<DPP_ROW_ROR(4)>(s);
-        s += dpp<DPP_ROW_ROR(2)>(s);
-        s += dpp<DPP_ROW_ROR(1)>(s);
-        const int dc = (s + 4) >> 3;
-        v = dc;
-        if (kind == 0) {
-          const int dc3 = mad24_k<3>(dc, 2);
-          v = by == 0 ? (r0 + dc3) >> 2 : v;
-          v = bx == 0 ? (r1 + dc3) >> 2 : v;
-          v = (bx | by) == 0 ? (r1 + 2 * dc + r0 + 2) >> 2 : v;
+      int v = blend32((e >> 9) & 31, r0, r1); // every angular mode; weight 0: a copy of r0
+      // planar, DC and - luma - the pure horizontal / vertical modes with their edge filters: one wave-uniform test keeps the
+      // mode dispatch (five lane-mask regions) off the path of the three passes in four that hold none of them
+      if (ballot((op.y & OP_SPECIAL) != 0)) {
+        const int bx = gl & 3, by = gl >> 2;
+        if (mode == 0) { // planar: r0 = sample above, r1 = sample to the left
+          const int tr = tc[imin_(5, nT1c)], bl = lp[mul24(imin_(4, nL1), P)];
+          v = planar_sample<2>(bx, by, r1, r0, tr, bl);
+        }
+        else if (mode == 1) { // DC of the four samples above and the four to the left; luma: smoothed first row / column
+          int s = (by == 0 ? r0 : 0) + (bx == 0 ? r1 : 0);
+          s += dpp<DPP_ROW_ROR(8)>(s);
+          s += dpp<DPP_ROW_ROR(4)>(s);
+          s += dpp<DPP_ROW_ROR(2)>(s);
+          s += dpp<DPP_ROW_ROR(1)>(s);
+          const int dc = (s + 4) >> 3;
+          v = dc;
+          if (kind == 0) {
+            const int dc3 = mad24_k<3>(dc, 2);
+            v = by == 0 ? (r0 + dc3) >> 2 : v;
+            v = bx == 0 ? (r1 + dc3) >> 2 : v;
+            v = (bx | by) == 0 ? (r1 + 2 * dc + r0 + 2) >> 2 : v;
+          }
+        }
+        else if (kind == 0 && (mode == 26 || mode == 10)) { // luma: gradient on the first column / row
+          const int corner = tc[0];
+          const bool on_edge = mode == 26 ? bx == 0 : by == 0;
+          v = on_edge ? clip3i(0, maxv, r0 + ((r1 - corner) >> 1)) : v;
         }
       }
-      else if (kind == 0 && (mode == 26 || mode == 10)) { // luma: gradient on the first column / row
-        const int corner = tp[-1];
-        const bool on_edge = mode == 26 ? bx == 0 : by == 0;
-        v = on_edge ? clip3i(0, maxv, r0 + ((r1 - corner) >> 1)) : v;
-      }
       v = (op.y & OP_CBF) ? clip3i(0, maxv, v + res_q) : v;
-      lp[mul24(by, P) + 1 + bx] = (Pix)v;
+      lp[st_off] = (Pix)v; // (st_off: the lane's sample inside its block, by * pitch + 1 + bx)
     }
     WAVE_SYNC();
 
@@ -567,6 +682,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       const uint32_t oz = (uint32_t)__builtin_amdgcn_readlane((int)op.z, src), ow = (uint32_t)__builtin_amdgcn_readlane((int)op.w, src);
       const uint32_t s_gb = (uint32_t)__builtin_amdgcn_readlane((int)gb_off, src), s_tl = (uint32_t)__builtin_amdgcn_readlane((int)tl_off, src);
       const int mode = (int)(oy & OP_MODE_MASK), c = (int)((oy >> OP_C_SHIFT) & 3), log2 = 2 + (int)((oy >> OP_L2_SHIFT) & 3);
+      const int path = (int)((oy >> OP_PATH_SHIFT) & 7);
 #if defined(HM_Q_PROBE) && (HM_Q_PROBE & 512)
       const bool cbf = false;
 #else
@@ -581,8 +697,8 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       const int maxv = (1 << bd) - 1;
 
       HM_MARK("D_setup_end");
-      auto block = [&](auto l2c) { // block size as a compile-time constant: fixed trip counts, shifts and masks
-        constexpr int L2 = decltype(l2c)::value;
+      auto block = [&](auto l2c, auto which) { // block size and path as compile-time constants: fixed trip counts, shifts and masks
+        constexpr int L2 = decltype(l2c)::value, WHICH = decltype(which)::value; // WHICH: PATH_GEN, PATH_I16 or PATH_B4
         int ln = lane;
         asm volatile("" : "+v"(ln));
         // prediction + residual + clip + store of sample p = x + nT * y (the residual of a block lies in raster order)
@@ -620,14 +736,9 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         B.mode = mode; B.c = c; B.bd = bd; B.log2 = L2; B.tskip = 0; B.qp = 0; B.n_coeff = 0; B.P = P;
         const bool smoothed = L2 != 2 && c == 0 && ((filter_mode_mask(L2) >> mode) & 1);
 #if !defined(HM_Q_PROBE) || !(HM_Q_PROBE & 4)
-        if (L2 <= 3 && !smoothed && (oy & OP_INTERIOR)) {
-          // one lane pass, the samples addressed in place: everything it needs is in the micro-op
-          RefDirect<Pix> R;
-          R.lp = lp; R.tp = tp; R.P = P;
-          R.nL1 = (int)((oy >> OP_NL1_SHIFT) & 63); R.nT1 = (int)((oy >> OP_NT1_SHIFT) & 63);
-          predict_emit<Pix, L2>(B, R, tab, ln, emit);
-        }
-        else if (L2 == 4 && (oy & OP_INTERIOR)) {
+        // (8x8 blocks with complete neighbours took the written-out paths above; what is left is sorted by the micro-op's path)
+        if (false) {}
+        else if (WHICH == PATH_I16) {
           // 16x16, neighbours complete: the 65 reference samples one per lane (and the last one by all), smoothed - where the
           // mode asks for it - with the neighbours from the lanes next door; the prediction reads them from the array
           RefDirect<Pix> R;
@@ -648,7 +759,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
           WAVE_SYNC();
           predict_emit<Pix, L2>(B, RefArray{bc}, tab, ln, emit);
         }
-        else if (L2 == 2) {
+        else if (WHICH == PATH_B4) {
           // 4x4 at a picture / slice / tile border (the interior ones took the side-by-side path): the substitution process of
           // 8.4.4.2.2 on a 17-bit availability mask (scalar) - an unavailable sample takes the nearest available one before
           // it in the order bottom-left ... corner ... top-right, the leading ones the first available one - one sample per lane
@@ -693,17 +804,17 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         HM_MARK("D_pred_end");
       };
 #if defined(HM_Q_PROBE) && (HM_Q_PROBE & 256)
-      if ((oy & OP_FAST8) && mode >= 2 && mode != 10 && mode != 26) continue; // probe: what the written-out path costs
+      if (path == PATH_F8A) continue; // probe: what the written-out path costs
 #endif
 #if !defined(HM_Q_PROBE) || !(HM_Q_PROBE & 128)
-      if ((oy & OP_FAST8) && mode >= 2 && mode != 10 && mode != 26) {
+      if (path == PATH_F8A) {
         // ---- the commonest block of this phase, written out: 8x8, neighbours complete, an angular mode, reference samples
         //      read in place (intrapred.h:338-441).  One sample per lane. ----
         int ln = lane;
         asm volatile("" : "+v"(ln));
         const int x = ln & 7, y = ln >> 3;
         const int nL1 = (int)((oy >> OP_NL1_SHIFT) & 63), nT1 = (int)((oy >> OP_NT1_SHIFT) & 63);
-        const int angle = intra_angle_of(mode); // (scalar arithmetic: no table in memory on this path)
+        const int angle = (int)(int8_t)(ow & 0xFF); // (intraPredAngle of the mode: worked out with the micro-op, residual.hip)
         const bool vert = mode >= 18;
         const int major = vert ? y : x, minor = vert ? x : y;
         const int t = mul24(major + 1, angle);
@@ -738,7 +849,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         WAVE_SYNC();
         continue;
       }
-      else if (oy & OP_FAST8) {
+      else if (path == PATH_F8O) {
         // ---- ... and the same block with planar (chroma: luma planar blocks are smoothed), DC, pure horizontal or pure
         //      vertical prediction (intrapred.h:262-336): the formulas of predict_emit<> on samples read in place ----
         int ln = lane;
@@ -781,7 +892,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         WAVE_SYNC();
         continue;
       }
-      else if ((oy & OP_INTERIOR) && log2 == 3 && c == 0) {
+      else if (path == PATH_S8) {
         // ---- luma 8x8, neighbours complete, reference samples SMOOTHED (intrapred.h:192-260): planar and the three
         //      diagonals 2 / 18 / 34 (the other modes of such a block took the paths above).  The 33 reference samples, one per
         //      lane, with their neighbours from the lanes next door; the diagonals copy one smoothed sample per position. ----
@@ -818,11 +929,13 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         if (((HM_Q_PROBE & 32) && !fast) || ((HM_Q_PROBE & 64) && fast)) continue;
       }
 #endif
-      if (log2 == 2) block(std::integral_constant<int, 2>());
-      else if (log2 == 3) block(std::integral_constant<int, 3>());
+      typedef std::integral_constant<int, PATH_GEN> gen_t;
+      if (path == PATH_I16) block(std::integral_constant<int, 4>(), std::integral_constant<int, PATH_I16>());
+      else if (path == PATH_B4) block(std::integral_constant<int, 2>(), std::integral_constant<int, PATH_B4>());
+      else if (log2 == 3) block(std::integral_constant<int, 3>(), gen_t());
 #if !defined(HM_Q_PROBE) || !(HM_Q_PROBE & 8)
-      else if (log2 == 4) block(std::integral_constant<int, 4>());
-      else block(std::integral_constant<int, 5>());
+      else if (log2 == 4) block(std::integral_constant<int, 4>(), gen_t());
+      else block(std::integral_constant<int, 5>(), gen_t());
 #endif
       WAVE_SYNC();
     }
@@ -848,98 +961,8 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     // ---- E: the groups that executed a block move to the next record ----
     if (running) {
       ri += 1;
-      kleft -= 1;
+      left -= 1;
     }
-
-    HM_MARK("F_begin");
-    // ---- F: finished CTUs: coalesced stores to the picture, bottom row -> line, right column -> left column ----
-    for (unsigned long long fin = ballot(st == ST_RUN) & ballot(kleft == 0); fin;) {
-      const int fg = rfl((int)(__builtin_ctzll(fin) >> 4));
-      fin &= ~(0xFFFFull << (fg * 16));
-      const int src = fg * 16;
-      const int s_row = __builtin_amdgcn_readlane(row, src), s_cx = __builtin_amdgcn_readlane(cx, src);
-      const int fkind = group_kind(fg);
-      Pix* const lw = line_of(fkind, group_slot(fg)); // s_row % NR
-      const bool keep_line = !PAIRS || RPW > 1;
-      auto flush_plane = [&](auto bw_c, Pix* u, int P, Pix* line, uint8_t* plane, int pitch, int bh, int pw, int ph) {
-        constexpr int BW = decltype(bw_c)::value;
-        constexpr int PPW = 4 / sizeof(Pix), WPR = BW / PPW; // samples per 32-bit word, words per row
-        static_assert(WPR >= 1 && WPR <= 64 && (WPR & (WPR - 1)) == 0, "CTB row must be 1..64 words");
-        constexpr int CW = WPR < 4 ? WPR : 4, LPR = WPR / CW, RPT = 64 / LPR; // words per chunk, lanes per row, rows per trip
-        const int xo = s_cx * BW, yo = s_row * bh;
-        const int vw = (pw - xo) < BW ? (pw - xo) : BW; // valid part inside the picture
-        const int vh = (ph - yo) < bh ? (ph - yo) : bh;
-        const int q = lane & (LPR - 1), rr0 = lane / LPR;
-        const bool col_ok = q * CW * PPW < vw;
-        // (a plane is smaller than 4 GiB: 32-bit offset arithmetic - 64-bit multiplies run at a quarter of the rate)
-        GLOBAL_AS uint8_t* const gp = gptr_w<uint8_t>(plane + (uint32_t)((uint32_t)yo * (uint32_t)pitch + (uint32_t)(xo + q * CW * PPW) * (uint32_t)sizeof(Pix)));
-        for (int rb = 0; rb < vh; rb += RPT) {
-          const int r = rb + rr0;
-          if (col_ok && r < vh) {
-            const uint32_t* srcw = reinterpret_cast<const uint32_t*>(u + mul24(r, P) + UPAD + q * CW * PPW); // rows are 4-byte aligned
-            uint32_t vv[CW];
-#pragma unroll
-            for (int k = 0; k < CW; k++) vv[k] = srcw[k];
-            GLOBAL_AS uint32_t* dst = reinterpret_cast<GLOBAL_AS uint32_t*>(gp + (uint32_t)mul24(r, pitch));
-            if (CW == 4) *reinterpret_cast<GLOBAL_AS c_u32x4*>(dst) = c_u32x4{vv[0], vv[1], vv[2], vv[3]};
-            else if (CW == 2) *reinterpret_cast<GLOBAL_AS c_u32x2*>(dst) = c_u32x2{vv[0], vv[1]};
-            else dst[0] = vv[0];
-          }
-        }
-        if (keep_line && lane < WPR) // (a wave per row / per chain: nobody in this wave reads the row's bottom line)
-          *reinterpret_cast<uint32_t*>(line + xo + lane * PPW) = *reinterpret_cast<const uint32_t*>(u + (bh - 1) * P + UPAD + lane * PPW);
-        WAVE_SYNC();
-        if (lane < bh) u[lane * P + UPAD - 1] = u[lane * P + UPAD + BW - 1]; // right column becomes the left neighbour
-      };
-      // (the picture's planes, pitches and size: from the wave's copy in LDS, see fdesc)
-      auto f_plane = [&](int c) { return reinterpret_cast<uint8_t*>((uintptr_t)(((uint64_t)fdesc[2 * c + 1] << 32) | fdesc[2 * c])); };
-      const int f_width = (int)fdesc[9], f_height = (int)fdesc[10];
-      const int planeWc = f_width >> 1, planeHc = sh == 2 ? f_height >> 1 : f_height; // (sh is 1 or 2: no division)
-      if (fkind == 0) flush_plane(std::integral_constant<int, ctb>(), group_u(fg, 0), P0, lw, f_plane(0), (int)fdesc[6], ctb, f_width, f_height);
-      else {
-        flush_plane(std::integral_constant<int, (ctb >> 1)>(), group_u(fg, 1), P1, lw, f_plane(1), (int)fdesc[7], ch_c, planeWc, planeHc);
-        flush_plane(std::integral_constant<int, (ctb >> 1)>(), group_u(fg, 2), P1, lw + (Wc + 4), f_plane(2), (int)fdesc[8], ch_c, planeWc, planeHc);
-      }
-      WAVE_SYNC();
-      // read by the chain of the row below, a group of this wave (LDS traffic of a wave is in order)
-      const int s_prog = PAIRS ? __builtin_amdgcn_readlane(pbank, src) * 4 + group_slot(fg) : (s_row & (C_PROG - 1));
-      if (lane == 0) __hip_atomic_store(progress + fkind * C_PROG + s_prog, s_cx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (PAIRS && group_slot(fg) == RPW - 1 && s_row + 1 < ctb_h) {
-        // ... or, for the pair's last row, the first row of the pair below: another wave, anywhere on the chip.  The
-        // CTU's bottom sample line goes to the pair's hand-over line with agent-scope stores; once they have left this
-        // wave (vmcnt 0) the word that announces them follows
-        constexpr int PPW = 4 / sizeof(Pix);
-        const int s_pidx = __builtin_amdgcn_readlane(pidx, src);
-        GLOBAL_AS uint32_t* const hand = hand_words + (size_t)s_pidx * hand_pair_words;
-        auto put_line = [&](GLOBAL_AS uint32_t* words, int ctu_w, const Pix* u, int P, int bh) { // the bottom row of the CTU buffer
-          const int w0 = s_cx * ctu_w / PPW, nw = ctu_w / PPW; // (at most 32 words: a CTU row of 64 16-bit samples)
-          if (lane < nw) __hip_atomic_store(words + w0 + lane, *reinterpret_cast<const uint32_t*>(u + (bh - 1) * P + UPAD + lane * PPW), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        };
-        if (fkind == 0) put_line(hand, ctb, group_u(fg, 0), P0, ctb);
-        else {
-          put_line(hand + hand_luma_words, cw_c, group_u(fg, 1), P1, ch_c);
-          put_line(hand + hand_luma_words + hand_chroma_words, cw_c, group_u(fg, 2), P1, ch_c);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0 && !(L.test_stall && s_pidx == 0)) __hip_atomic_store(pair_progress + 2 * (size_t)s_pidx + fkind, (uint32_t)(s_cx + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      // the group's next CTU
-      if (g == fg) {
-        cx += 1;
-        st = ST_START;
-        tl_off += (uint32_t)(sizeof(Pix) << l2w);
-        if (cx == ctb_w) {
-          cx = 0;
-          tl_off = lr_off;
-          // the group's next row: NR further (a wave per picture), or in the wave's next band (PAIRS)
-          row += PAIRS ? RPW * W : NR;
-          if (PAIRS) { pidx += W; pbank ^= 1; from_hbm = my_slot == 0; hbm_have = 0; hbm_polls = 0; }
-          if (row < ctb_h) row_start();
-          else st = ST_DONE;
-        }
-      }
-    }
-    WAVE_SYNC();
     HM_T_LAP(4);
 #ifdef HM_CHAIN_TIMING
     t_acc[5] += 1;

@@ -686,14 +686,14 @@ struct Decoder {
       hm_coeff* const cp = reinterpret_cast<hm_coeff*>(blob.data() + off_coeffs);
       uint32_t level_at = 0;
       const int qp_bd_offset_y = 6 * (s.bit_depth_y - 8);
-      auto put = [&](hm_tu6* d, const hm_tu& t) {
+      auto put = [&](hm_tu6* d, const hm_tu& t, uint32_t ctb_bits, uint32_t info_bits) {
         if ((t.x | t.y) & 3) throw ParseError(HM_ERR_INTERNAL, "block geometry not a multiple of 4");
         if (t.n_coeff > HM_TU6_COUNT_MASK || (t.pred_mode & ~HM_TU_MODE_MASK)) throw ParseError(HM_ERR_INTERNAL, "record does not fit the compact form");
         d->pos = (uint8_t)((t.x >> 2) | ((t.y >> 2) << 4));
-        d->info = (uint8_t)(t.info & ~HM_TU_AVAIL_TL); d->pred_mode = t.pred_mode;
+        d->info = (uint8_t)((t.info & ~HM_TU_AVAIL_TL) | info_bits); d->pred_mode = t.pred_mode;
         // (a luma record's QP is QpY + QpBdOffsetY of its coding unit - what it was dequantised with if it has a residual)
         d->qp = ((t.info >> HM_TU_CIDX_SHIFT) & 3) == 0 ? (uint8_t)(t.qpy + qp_bd_offset_y) : t.qp;
-        d->count = (uint16_t)t.n_coeff;
+        d->count = (uint16_t)(t.n_coeff | ctb_bits);
         if (t.n_coeff) std::memcpy(cp + level_at, pic.coeffs.data() + t.coeff_first, t.n_coeff * sizeof(hm_coeff));
         level_at += t.n_coeff;
       };
@@ -704,8 +704,9 @@ struct Decoder {
             const int i = cx + cy * s.ctb_w;
             hm_tu6* d = tp + (pass == 0 ? pic.ctbs[i].tu_first : pic.ctbs[i].tu_first_c);
             (pass == 0 ? pic.ctbs[i].coeff_first : pic.ctbs[i].coeff_first_c) = level_at;
+            const uint32_t ctb_bits = ((uint32_t)pic.ctbs[i].nb_avail << HM_TU6_NB_SHIFT) | (cx + 1 == s.ctb_w ? HM_TU6_LAST_COLUMN : 0u);
             for (const hm_tu& t : pic.ctb_tus[i])
-              if ((((t.info >> HM_TU_CIDX_SHIFT) & 3) == 0) == (pass == 0)) put(d++, t);
+              if ((((t.info >> HM_TU_CIDX_SHIFT) & 3) == 0) == (pass == 0)) put(d++, t, ctb_bits, cx + 2 == s.ctb_w ? HM_TU6_NEXT_TO_LAST : 0u);
           }
       if (level_at != pic.coeffs.size()) throw ParseError(HM_ERR_INTERNAL, "levels lost while reordering");
       std::memcpy(blob.data() + off_ctbs, pic.ctbs.data(), (size_t)N * sizeof(hm_ctb));

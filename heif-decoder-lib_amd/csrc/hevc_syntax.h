@@ -434,6 +434,8 @@ class SliceWalker {
     derive_ctb_neighbours();
     hm_ctb& c = pic_.ctbs[ctb_addr_rs_];
     c.nb_avail = (uint8_t)(nb9_ & 15u); // HM_CTB_NB_*: NW, N, NE, W (the CTBs to the right and below are never available)
+    tu6_ctb_bits_ = ((nb9_ & 15u) << HM_TU6_NB_SHIFT) | (xCtb + 1 == sps_.ctb_w ? HM_TU6_LAST_COLUMN : 0u); // (hm_tu6.count of this CTB's records)
+    tu6_info_bits_ = xCtb + 2 == sps_.ctb_w ? HM_TU6_NEXT_TO_LAST : 0u;                                        // (... and hm_tu6.info)
     // deblocking edge permissions of this CTB's left/top edge (deblock.cc:160-196 in the reference)
     c.flags &= ~(HM_CTB_DEBLOCK_LEFT | HM_CTB_DEBLOCK_TOP | HM_CTB_DEBLOCK_OFF | HM_CTB_SAO_LUMA | HM_CTB_SAO_CHROMA | HM_CTB_LOSSLESS);
     if (sh_.deblocking_disabled) c.flags |= HM_CTB_DEBLOCK_OFF;
@@ -979,8 +981,8 @@ class SliceWalker {
       // residual pre-pass evaluates with a lane per record.
       hm_tu6 c;
       c.pos = (uint8_t)((x >> 2) | ((y >> 2) << 4));
-      c.info = (uint8_t)info; c.pred_mode = (uint8_t)pm; c.qp = (uint8_t)qp_prime_[cIdx];
-      c.count = (uint16_t)ncoef;
+      c.info = (uint8_t)(info | tu6_info_bits_); c.pred_mode = (uint8_t)pm; c.qp = (uint8_t)qp_prime_[cIdx];
+      c.count = (uint16_t)(ncoef | tu6_ctb_bits_);
       row_->tu[k].push_back(c);
       if (cIdx == 0) ctb_cur_->tu_count++;
       else ctb_cur_->tu_count_c++;
@@ -988,7 +990,9 @@ class SliceWalker {
     }
     // neighbour availability (intrapred.h:536-667 in the reference; equals §8.4.4.2.2), from the block's rectangle and the
     // neighbour bits of the CTB (hm_avail.h - the same function the device runs for the compact records)
-    const hm_avail av = hm_derive_avail(xc, yc, nT, lw, lh, sps_.log2_ctb, sps_.width, sps_.height, nb9_ & 15u);
+    const int ctb_mask = (1 << sps_.log2_ctb) - 1;
+    const hm_avail av = hm_derive_avail((xc << lw) & ctb_mask, (yc << lh) & ctb_mask, nT << lw, nT << lh, nT, (sps_.width >> lw) - (xc + nT),
+                                        (sps_.height >> lh) - (yc + nT), sps_.log2_ctb, nb9_ & 15u);
     if (av.tl) info |= HM_TU_AVAIL_TL;
     const unsigned a_left = av.left, a_top = av.top;
     const int n_bl = av.n_bl, n_tr = av.n_tr;
@@ -1197,6 +1201,8 @@ class SliceWalker {
   int slice_x0_ = 0, slice_y0_ = 0; // luma position of the slice's first CTB
   PictureState::RowChains* row_ = nullptr; // the current CTU's row (split chains)
   hm_ctb* ctb_cur_ = nullptr;      // ... and its header
+  uint32_t tu6_info_bits_ = 0;
+  uint32_t tu6_ctb_bits_ = 0;     // what every compact record of the current CTB carries of it (hm_stream.h: hm_tu6.count)
   uint8_t nb_ok_[9] = {0};         // availability of the 3x3 CTBs around (and including) the current one, see avail_z
   // QP state (thread_context fields of the reference: decctx.h)
   bool is_cu_qp_delta_coded_ = false;

@@ -25,19 +25,19 @@ HM_HD unsigned hm_zorder4(unsigned x4, unsigned y4)
   return (x4 & 1u) | ((y4 & 1u) << 1) | ((x4 & 2u) << 1) | ((y4 & 2u) << 2) | ((x4 & 4u) << 2) | ((y4 & 4u) << 3) | ((x4 & 8u) << 3) | ((y4 & 8u) << 4);
 }
 
+HM_HD unsigned hm_ctz32(unsigned v) { return (unsigned)__builtin_ctz(v); } // v != 0
+
 struct hm_avail {
   unsigned left, top, tl; // 0 / 1: the left run / the top run (nT samples each) / the corner sample
   int n_bl, n_tr;         // available samples below-left / above-right: 0 .. nT, multiples of 4, clamped to the picture
 };
 
-// xc, yc: the block's position in its PLANE (samples of the component, picture coordinates), nT its size, lw / lh: log2 of
-// the plane's horizontal / vertical sub-sampling (0 for luma), width / height: the picture in luma samples, nb: HM_CTB_NB_*
-HM_HD hm_avail hm_derive_avail(int xc, int yc, int nT, int lw, int lh, int log2_ctb, int width, int height, unsigned nb)
+// xi, yi: the block's position inside its CTB in LUMA samples, wL / hL its size in luma samples, nT its size in samples
+// of its plane, room_x / room_y: samples of its plane between the block's right / lower edge and the picture's (any value
+// >= nT when there are at least nT), nb: HM_CTB_NB_*
+HM_HD hm_avail hm_derive_avail(int xi, int yi, int wL, int hL, int nT, int room_x, int room_y, int log2_ctb, unsigned nb)
 {
-  const int xL = xc << lw, yL = yc << lh; // luma position of the block
-  const int cw = width >> lw, chh = height >> lh;
-  const int cs = 1 << log2_ctb, xi = xL & (cs - 1), yi = yL & (cs - 1);
-  const int wL = nT << lw, hL = nT << lh;
+  const int cs = 1 << log2_ctb;
   const unsigned n_nw = nb & 1u, n_n = (nb >> 1) & 1u, n_ne = (nb >> 2) & 1u, n_w = (nb >> 3) & 1u;
   hm_avail a;
   // left, above and above-left of a block always come before it in z-order when they lie in its CTB; else the answer is
@@ -45,19 +45,25 @@ HM_HD hm_avail hm_derive_avail(int xc, int yc, int nT, int lw, int lh, int log2_
   a.left = xi ? 1u : n_w;
   a.top = yi ? 1u : n_n;
   a.tl = xi ? a.top : (yi ? a.left : n_nw);
-  // below-left and above-right inside the CTB: decoded before the block iff earlier in z-order
-  const unsigned z_cur = hm_zorder4((unsigned)(xL >> 2) & 15u, (unsigned)(yL >> 2) & 15u);
-  const unsigned z_bl = hm_zorder4((unsigned)((xL - 1) >> 2) & 15u, (unsigned)((yL + hL) >> 2) & 15u) <= z_cur;
-  const unsigned z_tr = hm_zorder4((unsigned)((xL + wL) >> 2) & 15u, (unsigned)((yL - 1) >> 2) & 15u) <= z_cur;
+  // below-left and above-right inside the CTB: decoded before the block iff earlier in z-order.  For a block aligned to its
+  // size this has a closed form in the 4-sample unit coordinates (X, Y) and sizes (W, H = powers of two) of its luma
+  // footprint: the unit above-right, (X + W, Y - 1), differs from (X, Y) up to bit ctz(Y) of y (the borrow) and up to
+  // the lowest zero bit of X at or above log2 W of x (the carry); y bits outrank x bits of the same weight in the
+  // interleaved order, so the neighbour comes EARLIER iff ctz(Y) >= that x bit.  Below-left likewise with the roles
+  // exchanged (strictly: a tie goes to y).  (hm_zorder4 above is the definition; tests/test_avail.py compares the two
+  // exhaustively.)
+  const unsigned X = (unsigned)xi >> 2, Y = (unsigned)yi >> 2;
+  const unsigned lW = hm_ctz32((unsigned)wL >> 2), lH = hm_ctz32((unsigned)hL >> 2);
+  const unsigned z_tr = hm_ctz32(Y | 0x100u) >= hm_ctz32(~(X >> lW)) + lW;
+  const unsigned z_bl = hm_ctz32(X | 0x100u) > hm_ctz32(~(Y >> lH)) + lH;
   const bool below = yi + hL >= cs, beyond = xi + wL >= cs;
   // (the CTBs below and to the right come later in every scan: never available)
   const unsigned bl = below ? 0u : (xi ? z_bl : a.left);
   const unsigned tr = yi == 0 ? (beyond ? n_ne : n_n) : (beyond ? 0u : z_tr);
-  const unsigned a_bl = bl & a.left & (unsigned)(yc + nT < chh);
-  const unsigned a_tr = tr & (unsigned)(xc + nT < cw);
-  const int rb = chh - (yc + nT), rr = cw - (xc + nT);
-  a.n_bl = a_bl ? (nT < rb ? nT : rb) : 0;
-  a.n_tr = a_tr ? (nT < rr ? nT : rr) : 0;
+  const unsigned a_bl = bl & a.left & (unsigned)(room_y > 0);
+  const unsigned a_tr = tr & (unsigned)(room_x > 0);
+  a.n_bl = a_bl ? (nT < room_y ? nT : room_y) : 0;
+  a.n_tr = a_tr ? (nT < room_x ? nT : room_x) : 0;
   return a;
 }
 

@@ -833,3 +833,203 @@ int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params
 }
 
 } // extern "C"
+
+// ---- one grid over several devices -----------------------------------------------------------------------------------
+// The reference fans the tiles of a grid out inside one process (context.cc:2281-2294, 2361-2401); the tiles are independent
+// coded pictures, so the device-side form of that fan-out needs no exchange between devices: the grid's tile
+// rows are cut into contiguous slabs, one per entry of `devices`; every slab is decoded, filtered, pasted and converted on
+// its device (its own batch, its own stream, a host thread that makes the device current) and copied from there straight
+// into its rows of the caller's destination (`ext_dst`) or of the one pinned output plane - no collective, no second copy.
+// Colour conversion is per pixel with nearest-neighbour chroma, so slabs that start on even rows need no halo.
+// What does not cut this way runs on devices[0] alone: single images, planar output, alpha planes, transformative
+// properties of the grid item, forced bilinear up-sampling (a one-row chroma halo), tile heights that are odd.
+namespace {
+
+struct Slab {
+  int device = 0;
+  int row0 = 0, rows = 0; // tile rows
+  int y0 = 0, h = 0;      // canvas rows
+  ItemPlan P;
+  int rc = HM_OK;
+  std::string message;
+};
+
+// decode + convert one slab on its device and copy it to dst (row 0 of the slab), all on a stream of its own; returns when
+// the pixels are in host memory.  Runs on any thread.
+void run_slab(const hm_file* f, const hm_decode_params* params, Slab& S, uint8_t* dst, size_t dst_stride, int canvas_w)
+{
+  auto fail = [&](int rc) { S.rc = rc; S.message = hm_last_error(); };
+  hipError_t e = hipSetDevice(S.device);
+  if (e != hipSuccess) return fail(hm_check_hip(e, "hipSetDevice"));
+  hipStream_t s = nullptr;
+  if ((e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess) return fail(hm_check_hip(e, "hipStreamCreate"));
+  int rc;
+  { // (the slab's image, batch and output buffer live inside this scope: gone before the stream they worked on)
+    PlanarImage I;
+    DevMem dout;
+    rc = planar_from_blobs(f, S.P, params, s, I);
+    if (!rc) {
+      hm_colour_desc cd;
+      std::memset(&cd, 0, sizeof(cd));
+      cd.width = canvas_w; cd.height = S.h; cd.bit_depth = I.bd; cd.chroma = I.chroma;
+      cd.has_nclx = 0; // (a grid canvas carries no nclx: context.cc:2250-2276)
+      cd.matrix = I.native.matrix; cd.primaries = I.native.primaries; cd.full_range = I.native.full_range;
+      cd.out_format = params->out_format;
+      cd.chroma_upsampling = params->chroma_upsampling;
+      const int obpp = hm_out_bytes_per_pixel(params->out_format);
+      cd.y_stride = I.P[0].stride; cd.cb_stride = I.P[1].stride; cd.cr_stride = I.P[2].stride;
+      cd.out_stride = hm_plane_stride(canvas_w, obpp);
+      rc = dout.alloc((size_t)cd.out_stride * mem_rows(S.h));
+      if (!rc) rc = hm_colour_convert(&cd, I.P[0].mem.p, I.P[1].mem.p, I.P[2].mem.p, dout.p, s);
+      if (!rc) {
+        e = hipMemcpy2DAsync(dst, dst_stride, dout.p, cd.out_stride, (size_t)canvas_w * obpp, (size_t)S.h, hipMemcpyDeviceToHost, s);
+        rc = hm_check_hip(e, "D2H of a slab");
+      }
+    }
+    e = hipStreamSynchronize(s); // (also on failure: nothing of the slab may be in flight when its buffers go back)
+    if (!rc) rc = hm_check_hip(e, "kernel execution");
+    if (!rc && I.batch) rc = hm_batch_check(I.batch.get());
+    if (rc) fail(rc);
+  }
+  hipStreamDestroy(s);
+}
+
+} // namespace
+
+extern "C" {
+
+// Contiguous slabs of tile rows for n devices (sizes differ by at most one row, devices beyond the row count get none):
+// first[d] / count[d] = tile rows of device d.  Pure host arithmetic (the same cut as shard.row_slabs of the harness).
+int hm_plan_device_slabs(int grid_rows, int n_devices, int32_t* first, int32_t* count)
+{
+  if (grid_rows < 0 || n_devices <= 0 || !first || !count) return hm_fail(HM_ERR_INVALID_ARG, "bad argument");
+  const int base = grid_rows / n_devices, extra = grid_rows % n_devices;
+  for (int d = 0; d < n_devices; d++) {
+    first[d] = d * base + (d < extra ? d : extra);
+    count[d] = base + (d < extra ? 1 : 0);
+  }
+  return HM_OK;
+}
+
+int hm_decode_item_devices(const hm_file* f, uint32_t id, const hm_decode_params* params, const int32_t* devices, int n_devices, hm_decoded* out)
+{
+  if (!f || !params || !out || !devices || n_devices <= 0 || n_devices > 64) return hm_fail(HM_ERR_INVALID_ARG, "bad argument");
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) return hm_fail(HM_ERR_NO_DEVICE, "no HIP device available");
+  for (int d = 0; d < n_devices; d++)
+    if (devices[d] < 0 || devices[d] >= n_dev) return hm_fail(HM_ERR_INVALID_ARG, "device %d of the list does not exist (%d devices)", devices[d], n_dev);
+  int prev_dev = 0;
+  hipGetDevice(&prev_dev);
+  struct Restore { int d; ~Restore() { hipSetDevice(d); } } restore{prev_dev};
+
+  // ---- can the item be cut? ----
+  ItemPlan plan;
+  int rc = plan_item(f, id, plan);
+  if (rc) return rc;
+  const hm::Item* it = f->file.item(id);
+  const hm::Item* t0 = plan.is_grid ? f->file.item(plan.tiles[0].id) : nullptr;
+  const int ih = t0 ? t0->props.ispe_height : 0;
+  const bool cut = n_devices > 1 && plan.is_grid && plan.rows >= 2 && params->out_format != 0 && hm_out_bytes_per_pixel(params->out_format) > 0 &&
+                   params->chroma_upsampling == 0 && !f->file.alpha_item_of(id) && plan.tile_alpha.empty() &&
+                   (params->ignore_transformations || !it || it->props.transforms.empty()) && ih > 0 && (ih % 2) == 0 && params->stream == nullptr;
+  if (!cut) {
+    if (hipSetDevice(devices[0]) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipSetDevice(%d) failed", devices[0]);
+    return hm_decode_item(f, id, params, out);
+  }
+  std::memset(out, 0, sizeof(*out));
+
+  // ---- host: entropy-decode every tile (as hm_decode_item) ----
+  const int nt = (int)plan.tiles.size();
+  {
+    std::atomic<int> next{0};
+    int nthreads = params->host_threads > 0 ? params->host_threads : 1;
+    if (nthreads > nt) nthreads = nt;
+    const int few = nt <= 64;
+    auto worker = [&]() {
+      for (;;) {
+        const int i = next.fetch_add(1);
+        if (i >= nt) break;
+        std::vector<uint8_t> data;
+        hm::HeifError e;
+        if (!f->file.hevc_data(plan.tiles[i].id, data, e)) { plan.status[i] = e.status; plan.messages[i] = e.message; continue; }
+        hm_parse_options po;
+        po.annexb = 0; po.threads = 1;
+        po.record_order = few ? HM_RECORDS_SPLIT : HM_RECORDS_AUTO;
+        const int prc = hm_hevc_parse_opts(data.data(), data.size(), &po, &plan.blobs[i].p, &plan.blobs[i].n);
+        if (prc) { plan.status[i] = prc; plan.messages[i] = hm_last_error(); }
+      }
+    };
+    Crew::instance().run(nthreads, worker);
+  }
+  for (int i = 0; i < nt; i++)
+    if (plan.status[i]) return hm_fail(plan.status[i], "tile %d (item %u): %s", i, plan.tiles[i].id, plan.messages[i].c_str());
+
+  // ---- the slabs ----
+  std::vector<int32_t> first(n_devices), count(n_devices);
+  hm_plan_device_slabs(plan.rows, n_devices, first.data(), count.data());
+  std::vector<std::unique_ptr<Slab>> slabs;
+  for (int d = 0; d < n_devices; d++) {
+    if (count[d] == 0) continue;
+    const int y0 = std::min(first[d] * ih, plan.canvas_h), y1 = std::min((first[d] + count[d]) * ih, plan.canvas_h);
+    if (y1 <= y0) continue; // (tile rows below the canvas: nothing of them is visible)
+    std::unique_ptr<Slab> S(new Slab());
+    S->device = devices[d]; S->row0 = first[d]; S->rows = count[d]; S->y0 = y0; S->h = y1 - y0;
+    ItemPlan& P = S->P;
+    P.id = plan.id; P.is_grid = true; P.canvas_w = plan.canvas_w; P.canvas_h = S->h; P.cols = plan.cols; P.rows = count[d];
+    const int t_first = first[d] * plan.cols, t_n = count[d] * plan.cols;
+    P.tiles.assign(plan.tiles.begin() + t_first, plan.tiles.begin() + t_first + t_n);
+    P.blobs.resize(t_n);
+    for (int k = 0; k < t_n; k++) { P.blobs[k].p = plan.blobs[t_first + k].p; P.blobs[k].n = plan.blobs[t_first + k].n; plan.blobs[t_first + k].p = nullptr; plan.blobs[t_first + k].n = 0; }
+    P.status.assign(t_n, HM_OK);
+    P.messages.assign(t_n, std::string());
+    slabs.push_back(std::move(S));
+  }
+  if (slabs.empty()) return hm_fail(HM_ERR_BITSTREAM, "grid without visible tile rows");
+
+  // ---- the destination: the caller's buffer or one pinned plane ----
+  const hm_pic* h0 = reinterpret_cast<const hm_pic*>(slabs[0]->P.blobs[0].p);
+  const int bd = h0->bit_depth_y, chroma = h0->chroma_format;
+  const int obpp = hm_out_bytes_per_pixel(params->out_format);
+  const int img_w = plan.canvas_w, img_h = plan.canvas_h;
+  uint8_t* dst = nullptr;
+  size_t dst_stride = 0;
+  if (params->ext_dst && params->ext_dst_stride >= (uint32_t)(img_w * obpp) && (size_t)params->ext_dst_len >= (size_t)params->ext_dst_stride * (size_t)img_h) {
+    dst = (uint8_t*)params->ext_dst; dst_stride = params->ext_dst_stride;
+    out->used_ext_dst = 1;
+  }
+  else {
+    dst_stride = (size_t)hm_plane_stride(img_w, obpp);
+    out->plane[0] = (uint8_t*)hm_pool_pinned_alloc(dst_stride * mem_rows(img_h)); // (portable pinned memory: every device copies into it)
+    if (!out->plane[0]) return hm_fail(HM_ERR_NOMEM, "out of memory");
+    dst = out->plane[0];
+  }
+
+  // ---- every slab on its device: the first on this thread, the others on threads of their own ----
+  std::vector<std::thread> threads;
+  for (size_t k = 1; k < slabs.size(); k++) {
+    Slab* S = slabs[k].get();
+    try { threads.emplace_back([=]() { run_slab(f, params, *S, dst + (size_t)S->y0 * dst_stride, dst_stride, img_w); }); }
+    catch (...) { S->rc = HM_ERR_NOMEM; S->message = "could not start a thread for a device slab"; }
+  }
+  run_slab(f, params, *slabs[0], dst + (size_t)slabs[0]->y0 * dst_stride, dst_stride, img_w);
+  for (std::thread& t : threads) t.join();
+  for (const std::unique_ptr<Slab>& S : slabs)
+    if (S->rc) {
+      const int src = S->rc;
+      hm_fail(src, "tile rows %d-%d on device %d: %s", S->row0, S->row0 + S->rows - 1, S->device, S->message.c_str());
+      hm_decoded_free(out);
+      return src;
+    }
+
+  // ---- what the decoded image says about itself (as job_enqueue for a converted grid canvas) ----
+  out->width = img_w; out->height = img_h; out->bit_depth = bd; out->chroma = chroma;
+  out->out_format = params->out_format;
+  out->has_nclx = 1; out->primaries = 1; out->transfer = 13; out->matrix = 6; out->full_range = 1;
+  if (bd == 8 && obpp >= 6) out->bit_depth = 10;
+  if (bd > 8 && (params->out_format == HM_OUT_RGB || params->out_format == HM_OUT_RGBA)) out->bit_depth = 8;
+  out->stride[0] = (int32_t)dst_stride;
+  out->plane_width[0] = img_w; out->plane_height[0] = img_h;
+  return HM_OK;
+}
+
+} // extern "C"

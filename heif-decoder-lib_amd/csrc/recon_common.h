@@ -474,11 +474,22 @@ __device__ __forceinline__ ResidGeom resid_geom(int ctb_w, int ctb_h, int log2_c
 //      uint4: x = lp | tp << 16 (sample offsets: lp from the chain's first CTU buffer to sample (x0-1, y0); tp to sample
 //      (x0, y0-1) from the same base or - OP_LINE - from the CTU's start in the sample line of the row above),
 //      y = the flags below, z = first residual sample of a block of 8x8 and more in the row's slab,
-//      w = qpy | pos << 8 | availability bits ----
+//      w = prediction angle | pos << 8 | availability bits ----
 constexpr uint32_t OP_MODE_MASK = 63u;
 constexpr int OP_C_SHIFT = 6, OP_L2_SHIFT = 8; // colour component (2 bits), log2 size - 2 (2 bits)
 constexpr uint32_t OP_CBF = 1u << 10, OP_INTERIOR = 1u << 11, OP_LINE = 1u << 13;
 constexpr uint32_t OP_FAST8 = 1u << 12; // 8x8 block, neighbours complete, reference samples not smoothed: the one-pass path of phase D
+// which of the wave-wide paths of phase D executes the block (blocks that are not interior 4x4 blocks): decided here, once, by the
+// lane that holds the record - the chain kernel switches on three bits instead of re-deriving the class with a dozen scalar
+// compares per block
+constexpr int OP_PATH_SHIFT = 27;
+enum { PATH_GEN = 0,  // the general path: reference samples gathered with substitution (blocks on a picture / slice / tile border, 32x32)
+       PATH_F8A = 1,  // 8x8, neighbours complete, angular mode, reference samples not smoothed
+       PATH_F8O = 2,  // 8x8, neighbours complete, planar (chroma) / DC / pure horizontal / vertical
+       PATH_S8 = 3,   // 8x8 luma, neighbours complete, smoothed reference samples (planar, modes 2 / 18 / 34)
+       PATH_I16 = 4,  // 16x16, neighbours complete
+       PATH_B4 = 5 }; // 4x4 on a border
+constexpr uint32_t OP_SPECIAL = 1u << 26; // planar, DC or - luma - pure horizontal / vertical prediction (the side-by-side 4x4 pass: modes with more than the two-sample blend)
 constexpr int OP_NL1_SHIFT = 14, OP_NT1_SHIFT = 20; // last usable position of the left / top run (6 bits each)
 constexpr uint32_t OPW_LEFT = 1u << 16, OPW_TOP = 1u << 17, OPW_TL = 1u << 18;
 constexpr int OPW_BL_SHIFT = 19, OPW_TR_SHIFT = 23; // below-left / top-right counts in units of 4 (4 bits each)
@@ -507,10 +518,16 @@ __device__ __forceinline__ mop_u32x4 make_micro_op(uint32_t r0, unsigned a_left,
   const bool fast8 = l2 == 3 && interior && !(c == 0 && (mode == 0 || mode == 2 || mode == 18 || mode == 34));
   mop_u32x4 op;
   op.x = (uint32_t)lp | ((uint32_t)tp << 16);
+  const bool special = mode <= 1 || (c == 0 && (mode == 10 || mode == 26));
+  const bool angular = mode >= 2 && mode != 10 && mode != 26;
+  const uint32_t path = l2 == 3 ? (fast8 ? (angular ? PATH_F8A : PATH_F8O) : (interior ? PATH_S8 : PATH_GEN))
+                                : (l2 == 4 ? (interior ? PATH_I16 : PATH_GEN) : (l2 == 2 && !interior ? PATH_B4 : PATH_GEN));
   op.y = mode | ((uint32_t)c << OP_C_SHIFT) | ((uint32_t)(l2 - 2) << OP_L2_SHIFT) | (cbf ? OP_CBF : 0u) | (interior ? OP_INTERIOR : 0u) |
-         (fast8 ? OP_FAST8 : 0u) | (on_line ? OP_LINE : 0u) | (nL1 << OP_NL1_SHIFT) | (nT1 << OP_NT1_SHIFT);
+         (fast8 ? OP_FAST8 : 0u) | (on_line ? OP_LINE : 0u) | (nL1 << OP_NL1_SHIFT) | (nT1 << OP_NT1_SHIFT) | (special ? OP_SPECIAL : 0u) | (path << OP_PATH_SHIFT);
   op.z = roff;
-  op.w = (qpy & 0xFF) | ((r0 & 0xFF) << 8) | (left ? OPW_LEFT : 0u) | (top ? OPW_TOP : 0u) | (tl ? OPW_TL : 0u) | (aBL4 << OPW_BL_SHIFT) | (aTR4 << OPW_TR_SHIFT);
+  (void)qpy;
+  // (bits 0-7: intraPredAngle of the mode, signed - a scalar sign extension in the chain kernel instead of the arithmetic on the mode)
+  op.w = ((uint32_t)intra_angle_of((int)mode) & 0xFF) | ((r0 & 0xFF) << 8) | (left ? OPW_LEFT : 0u) | (top ? OPW_TOP : 0u) | (tl ? OPW_TL : 0u) | (aBL4 << OPW_BL_SHIFT) | (aTR4 << OPW_TR_SHIFT);
   return op;
 }
 

@@ -113,11 +113,13 @@ __device__ __forceinline__ void big_residual(int16_t* coeff, int16_t* tmp, const
   WAVE_SYNC();
 }
 
-#ifdef HM_R_WPE
-#define HM_R_ATTR __attribute__((amdgpu_waves_per_eu(HM_R_WPE, HM_R_WPE)))
-#else
-#define HM_R_ATTR
+// Six waves per SIMD (<= 80 VGPRs): the kernel lives on the latency of its two memory round trips per chunk, which only more
+// waves hide.  Without the hint the allocator settles at 85 registers = five waves (r04: 7.0-8.2 ms instead of 6.3 for the
+// headline); with it everything fits without spilling.  HM_R_WPE overrides (A/B builds).
+#ifndef HM_R_WPE
+#define HM_R_WPE 6
 #endif
+#define HM_R_ATTR __attribute__((amdgpu_waves_per_eu(HM_R_WPE, HM_R_WPE)))
 __global__ __launch_bounds__(R_WAVES * 64) HM_R_ATTR void k_residual(const hm_dev_pic* __restrict__ pics, int n_pics, int max_ctb_h, int segs)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -242,24 +244,44 @@ __global__ __launch_bounds__(R_WAVES * 64) HM_R_ATTR void k_residual(const hm_de
     // pos | info << 8 | pred_mode << 16 | qp << 24, and the level count
     const uint32_t rsh = (record_index(chunk) & 1u) << 4;
     const uint32_t r0 = valid ? __builtin_amdgcn_alignbit(cur_y, cur_x, rsh) : 0u;
-    const uint32_t cnt = valid ? (cur_y >> rsh) & HM_TU6_COUNT_MASK : 0u; // (0 in the lanes behind the row's last record)
-    const r_u32x2 ahead = fetch_records(chunk + 64);
-    // (the first records, the neighbour bits and - luma chains: block map - the flags of the CTBs that may start inside
-    //  this chunk: requested here with everything else, used below)
-    const int cand = cur_ctb + 1 + lane;
-    const bool cand_ok = cand < x1;
-    const int last_ctb = dp.ctb_w - 1;
-    const GLOBAL_AS uint32_t* const q_cand = q0 + HM_CTB_DWORDS * (size_t)(cand < last_ctb ? cand : last_ctb);
-    const GLOBAL_AS uint32_t* const q_lane = q0 + HM_CTB_DWORDS * (size_t)(cand - 1 < last_ctb ? cand - 1 : last_ctb); // CTB cur_ctb + lane
-    const uint32_t cand_first = q_cand[kind ? 9 : 0];
-    const uint32_t ctb_flags = q_lane[kind ? 10 : 2]; // luma: flags | SAO masks; chroma: only dword 10 is of interest
-    const uint32_t ctb_nb = q_lane[10] >> 16;         // hm_ctb.nb_avail (| reserved << 8)
+    const uint32_t cnt_raw = valid ? (cur_y >> rsh) & 0xFFFFu : 0u; // level count | the CTB's neighbour bits | "last column"
+    const uint32_t cnt = cnt_raw & HM_TU6_COUNT_MASK; // (0 in the lanes behind the row's last record)
+    // ---- neighbour availability of the record's block (hm_avail.h: intrapred.h:536-667 of the reference) and its micro-op
+    //      for the chain kernel - first thing in the chunk, while little else is alive (the kernel's register count decides
+    //      how many waves hide its two memory round trips per chunk).  What the lane needs to know of the record's CTB
+    //      travels in the record's spare bits: the four neighbour bits and whether the CTB is the last / the last but one of
+    //      its row - the only columns in which the picture's right edge can cut an above-right run (a run is at most as long
+    //      as a CTB is wide).  The place of the block's residual (op.z) follows from the scan below. ----
+    const int x4 = (int)(r0 & 15), y4 = (int)((r0 >> 4) & 15);
     const int info = (int)((r0 >> 8) & 0xFF), l2 = info & HM_TU_LOG2_MASK;
+    mop_u32x4 mop;
+    {
+      const int lw = kind ? sub_w : 0, lh = kind ? sub_h : 0;
+      const int nT = 1 << l2;
+      const int xin = x4 << 2, yc = (row << (dp.log2_ctb - lh)) + (y4 << 2); // x inside the CTB / y in the picture, samples of the plane
+      const int ctb_pw = m_ctb >> lw;
+      const int rem_last = (dp.width >> lw) - (dp.ctb_w - 1) * ctb_pw; // samples of the plane in the last CTB column
+      const int room_x = (cnt_raw & HM_TU6_LAST_COLUMN) ? rem_last - (xin + nT) : ((info & HM_TU6_NEXT_TO_LAST) ? ctb_pw + rem_last - (xin + nT) : nT);
+      const int room_y = (dp.height >> lh) - (yc + nT);
+      const hm_avail av = hm_derive_avail(xin << lw, (y4 << 2) << lh, nT << lw, nT << lh, nT, room_x, room_y, dp.log2_ctb, (cnt_raw >> HM_TU6_NB_SHIFT) & 15u);
+      mop = make_micro_op(r0, av.left, av.top, av.tl, (uint32_t)av.n_bl >> 2, (uint32_t)av.n_tr >> 2, 0u, m_Pk, m_cr_off, m_Wc, 0u);
+      asm volatile("" : "+v"(mop.x), "+v"(mop.y), "+v"(mop.w)); // (worked out here, not where the scheduler would like it)
+    }
+    const r_u32x2 ahead = fetch_records(chunk + 64);
+    // (luma chains, block map: the first records and the flags of the CTBs that may start inside this chunk - requested
+    //  here with everything else, used below)
+    const int cand = cur_ctb + 1 + lane;
+    const bool cand_ok = kind == 0 && cand < x1;
+    const int last_ctb = dp.ctb_w - 1;
+    const uint32_t cand_first = q0[HM_CTB_DWORDS * (size_t)(cand < last_ctb ? cand : last_ctb)];
+    const uint32_t ctb_flags = q0[HM_CTB_DWORDS * (size_t)(cand - 1 < last_ctb ? cand - 1 : last_ctb) + 2]; // flags of CTB cur_ctb + lane
     const bool cbf = valid && (info & HM_TU_CBF);
     const uint32_t rsz = (cbf && l2 >= 3) ? 16u << (2 * (l2 - 2)) : 0u; // (the residual of a 4x4 block has a place of its own: res4)
     // inclusive wave scans: first level / first residual sample of every record
     const uint32_t sc = wave_scan(cnt), sr = wave_scan(rsz);
     const uint32_t lo = lev_base + sc - cnt, ro = res_base + sr - rsz;
+    mop.z = ro;
+    if (valid) mops[ri] = mop;
     // the chunk's levels lie back to back: one coalesced read puts the first R_STAGE of them into LDS, so that the
     // passes below wait for LDS, not for HBM
     const uint32_t chunk_lev = lev_base, n_lev = (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
@@ -277,46 +299,28 @@ __global__ __launch_bounds__(R_WAVES * 64) HM_R_ATTR void k_residual(const hm_de
       const uint32_t rel = first - chunk_lev + i;
       return rel < (uint32_t)R_STAGE ? lvl[rel] : coeffs[first + i];
     };
-
-    // ---- the CTB of every record of the chunk: the CTBs that start inside it are marked at their first record, a scan
-    //      counts them (every CTB has records of both kinds, so at most 63 start behind the chunk's first record) ----
-    if (cand_ok) {
-      const uint32_t tf = cand_first - chunk;
-      if (tf < 64u) __hip_atomic_fetch_add(slots + tf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    }
-    WAVE_SYNC();
-    int sm = slots[lane];
-    WAVE_SYNC();
-    slots[lane] = 0;
-    sm = (int)wave_scan((uint32_t)sm);
-    const int my_ctb = cur_ctb + sm;
-    cur_ctb += __builtin_amdgcn_readlane(sm, 63);
-    // (the header words of CTB cur_ctb + k were requested by lane k: at most 63 CTBs start behind the chunk's first record)
-    // (by ALL lanes: a lane that holds no record may hold the words a record needs - the row's last record alone in its chunk and
-    //  first of its CTB reads lane 1 -, and lanes switched off deliver nothing)
-    int lane_flags = __builtin_amdgcn_ds_bpermute((sm & 63) << 2, (int)ctb_flags);
-    int lane_nb = __builtin_amdgcn_ds_bpermute((sm & 63) << 2, (int)ctb_nb);
-    asm volatile("" : "+v"(lane_flags), "+v"(lane_nb));
-    if (sm >= 64) { // (64 CTBs start in the chunk: each is one record)
-      const GLOBAL_AS uint32_t* const q_mine = q0 + HM_CTB_DWORDS * (size_t)my_ctb;
-      lane_flags = (int)q_mine[kind ? 10 : 2];
-      lane_nb = (int)(q_mine[10] >> 16);
-    }
-    const int x4 = (int)(r0 & 15), y4 = (int)((r0 >> 4) & 15);
-
-    // ---- neighbour availability of the record's block (hm_avail.h: intrapred.h:536-667 of the reference) and its micro-op
-    //      for the chain kernel ----
-    {
-      const int lw = kind ? sub_w : 0, lh = kind ? sub_h : 0;
-      const int xc = (my_ctb << (dp.log2_ctb - lw)) + (x4 << 2), yc = (row << (dp.log2_ctb - lh)) + (y4 << 2);
-      const hm_avail av = hm_derive_avail(xc, yc, 1 << l2, lw, lh, dp.log2_ctb, dp.width, dp.height, (unsigned)lane_nb & 15u);
-      const uint32_t qpy = kind ? 0u : ((r0 >> 24) - (uint32_t)qp_bd_offset) & 0xFFu;
-      if (valid) mops[ri] = make_micro_op(r0, av.left, av.top, av.tl, (uint32_t)av.n_bl >> 2, (uint32_t)av.n_tr >> 2, qpy, m_Pk, m_cr_off, m_Wc, ro);
-    }
-
     // ---- the block map of the deblocking filter (luma chains): per 4x4 block the transform edges on its left / on top
     //      (bit 0 / bit 1) and QpY (bits 8-15), deblock.cc:31-62 of the reference ----
     if (kind == 0) {
+      // the CTB of every record of the chunk: the CTBs that start inside it are marked at their first record, a scan
+      // counts them (every CTB has records, so at most 63 start behind the chunk's first record)
+      if (cand_ok) {
+        const uint32_t tf = cand_first - chunk;
+        if (tf < 64u) __hip_atomic_fetch_add(slots + tf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+      WAVE_SYNC();
+      int sm = slots[lane];
+      WAVE_SYNC();
+      slots[lane] = 0;
+      sm = (int)wave_scan((uint32_t)sm);
+      const int my_ctb = cur_ctb + sm;
+      cur_ctb += __builtin_amdgcn_readlane(sm, 63);
+      // (the flags of CTB cur_ctb + k were requested by lane k: at most 63 CTBs start behind the chunk's first record)
+      // (by ALL lanes: a lane that holds no record may hold the flags a record needs - the row's last record alone in its chunk and
+      //  first of its CTB reads lane 1 -, and lanes switched off deliver nothing)
+      int lane_flags = __builtin_amdgcn_ds_bpermute((sm & 63) << 2, (int)ctb_flags);
+      asm volatile("" : "+v"(lane_flags));
+      if (sm >= 64) lane_flags = (int)q0[HM_CTB_DWORDS * (size_t)my_ctb + 2]; // (64 CTBs start in the chunk: each is one record)
       const int flags = valid ? (lane_flags & 0xFF) : 0;
       const int en = !(flags & HM_CTB_DEBLOCK_OFF);
       const int left_ok = ((x4 > 0) | ((flags & HM_CTB_DEBLOCK_LEFT) != 0)) & en;

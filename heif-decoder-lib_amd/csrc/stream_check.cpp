@@ -62,17 +62,18 @@ static const char* validate_stream(const uint8_t* blob, size_t size)
   //  from position + hm_ctb.nb_avail, so there is nothing of it to check here)
   const uint8_t* tus6 = blob + h.off_tus;
   uint64_t level_at = 0;
-  struct Expanded : hm_tu { uint16_t reserved_bits; };
+  struct Expanded : hm_tu { uint16_t ctb_bits; };
   auto expand = [&](uint64_t t) {
     Expanded u;
     std::memset(&u, 0, sizeof(u));
     hm_tu6 c;
     std::memcpy(&c, tus6 + t * sizeof(hm_tu6), sizeof(c));
     u.x = (uint8_t)((c.pos & 15) << 2); u.y = (uint8_t)((c.pos >> 4) << 2);
-    u.info = c.info; u.pred_mode = c.pred_mode; u.qp = c.qp;
+    u.info = (uint8_t)(c.info & ~HM_TU6_NEXT_TO_LAST); u.pred_mode = c.pred_mode; u.qp = c.qp;
     u.n_coeff = (uint16_t)(c.count & HM_TU6_COUNT_MASK);
     u.coeff_first = (uint32_t)(level_at < 0xFFFFFFFFu ? level_at : 0xFFFFFFFFu);
-    u.reserved_bits = (uint16_t)((c.count & ~HM_TU6_COUNT_MASK) | (c.info & HM_TU_AVAIL_TL));
+    u.ctb_bits = (uint16_t)(c.count & ~HM_TU6_COUNT_MASK);
+    u.ctb_bits |= (c.info & HM_TU6_NEXT_TO_LAST) ? 1u : 0u; // (bit 0: the info flag)
     return u;
   };
   uint64_t next = 0;
@@ -102,7 +103,7 @@ static const char* validate_stream(const uint8_t* blob, size_t size)
             continue;
           }
           const auto u = expand(t);
-          if (u.reserved_bits) return "reserved bits of a record";
+          if (u.ctb_bits != (((uint32_t)c.nb_avail << HM_TU6_NB_SHIFT) | (cx + 1 == h.ctb_w ? HM_TU6_LAST_COLUMN : 0u) | (cx + 2 == h.ctb_w ? 1u : 0u))) return "CTB bits of a record";
           if (const char* what = check_record(u, pass == 0 ? 1 : 0)) return what;
           level_at += u.n_coeff;
         }

@@ -323,6 +323,14 @@ HM_API int      hm_file_item_hevc_data(const hm_file* f, uint32_t id, uint8_t** 
 /* decode an hvc1 image or a grid item.  Replaces heif_decode_image (heif.cc:1150-1186 ->
  * context.cc:1516-1600, 2120-2404).  Free the result with hm_decoded_free. */
 HM_API int      hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params, hm_decoded* out);
+/* The same with ONE GRID OVER SEVERAL DEVICES of this process: the grid's tile rows are cut into contiguous slabs, one per
+ * entry of `devices` (HIP device indices; an index may repeat), each slab is decoded and converted on its device and copied
+ * from there straight into its rows of params->ext_dst / of the pinned output plane - the in-process tile fan-out of the
+ * reference (context.cc:2281-2294, 2361-2401) across GPUs, without any exchange between them.  Items that do not cut this
+ * way (single images, planar output, alpha, transformed grids, forced bilinear up-sampling) are decoded on devices[0].
+ * params->stream must be NULL (every slab runs on a stream of its own).  hm_plan_device_slabs: the cut it uses. */
+HM_API int      hm_decode_item_devices(const hm_file* f, uint32_t id, const hm_decode_params* params, const int32_t* devices, int n_devices, hm_decoded* out);
+HM_API int      hm_plan_device_slabs(int grid_rows, int n_devices, int32_t* first_row, int32_t* row_count);
 HM_API void     hm_decoded_free(hm_decoded* d);
 /* release one plane taken out of an hm_decoded (ownership transfer, used by the libheif facade) */
 HM_API void     hm_host_free(void* plane);

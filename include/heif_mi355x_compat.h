@@ -128,6 +128,9 @@ HMC_API struct heif_error heif_context_get_image_handle(struct heif_context* ctx
  * single image they go to the decoder (max_decoder_threads -> new_decoder(&dec, nthreads)); here both feed the host
  * entropy decode (tile-parallel for grids, sub-stream parallel inside one picture) */
 HMC_API void heif_context_set_threads(struct heif_context* ctx, const struct heif_image_handle* in_handle, int nthreads);
+/* extension of this library (no libheif counterpart): the HIP devices one grid of this context is spread over, a slab of
+ * tile rows per listed device (context.cc:2361-2401's fan-out of the tiles, across GPUs); n = 0: the current device */
+HMC_API void heif_mi355x_context_set_devices(struct heif_context* ctx, const int* devices, int n);
 HMC_API void heif_image_handle_release(const struct heif_image_handle*);
 HMC_API int heif_image_handle_get_width(const struct heif_image_handle* handle);
 HMC_API int heif_image_handle_get_height(const struct heif_image_handle* handle);

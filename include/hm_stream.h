@@ -201,14 +201,19 @@ typedef struct hm_tu {
 
 /* The same step in pictures with HM_PIC_SPLIT_CHAINS (no rare syntax: no PCM / bypass flags, levels in record order):
  *   pos        x >> 2 | (y >> 2) << 4           (block positions are multiples of 4 samples of their plane)
- *   info       as in hm_tu, without HM_TU_AVAIL_TL (bit 7 is 0)
+ *   info       as in hm_tu, without HM_TU_AVAIL_TL; bit 7 instead: HM_TU6_NEXT_TO_LAST, the record's CTB is the last but
+ *              one of its row
  *   pred_mode  as in hm_tu, without flags
  *   qp         the dequantisation qP as in hm_tu; for a luma record also QpY + QpBdOffsetY of its coding unit (the
  *              deblocking filter's QpY = qp - 6 * (bit_depth_y - 8)), also when the record has no residual
- *   count      n_coeff (bits 0-10); bits 11-15 are 0
- * Neighbour availability is not stored: hm_avail.h derives it from the record's position, hm_ctb.nb_avail of its CTB
- * and the picture size, exactly as the parser derives the hm_tu fields. */
-#define HM_TU6_COUNT_MASK 0x07FFu
+ *   count      n_coeff (bits 0-10) | hm_ctb.nb_avail of the record's CTB << 11 | HM_TU6_LAST_COLUMN if that CTB is the
+ *              last of its row (what a lane that holds a record needs to know of its CTB, so that it need not find it)
+ * Neighbour availability is not stored: hm_avail.h derives it from the record's position, the four neighbour bits of
+ * its CTB and the picture size, exactly as the parser derives the hm_tu fields. */
+#define HM_TU6_COUNT_MASK  0x07FFu
+#define HM_TU6_NB_SHIFT    11
+#define HM_TU6_LAST_COLUMN 0x8000u
+#define HM_TU6_NEXT_TO_LAST 0x80u /* in info (the only columns in which the picture's right edge can cut an above-right run) */
 typedef struct hm_tu6 {
   uint8_t  pos;
   uint8_t  info;

@@ -753,7 +753,7 @@ int orc_decode_picture(const uint8_t* blob, size_t size, int stages, uint16_t* y
       hm_tu6 c;
       memcpy(&c, c6 + (size_t)i * sizeof(hm_tu6), sizeof(c));
       t->x = (uint8_t)((c.pos & 15) << 2); t->y = (uint8_t)((c.pos >> 4) << 2);
-      t->info = c.info; t->pred_mode = c.pred_mode; t->qp = c.qp;
+      t->info = (uint8_t)(c.info & ~HM_TU6_NEXT_TO_LAST); t->pred_mode = c.pred_mode; t->qp = c.qp;
       /* a luma record's QP is QpY + QpBdOffsetY of its coding unit: the deblocking filter's QpY */
       t->qpy = ((c.info >> HM_TU_CIDX_SHIFT) & 3) == 0 ? (int8_t)((int)c.qp - 6 * ((int)H->bit_depth_y - 8)) : 0;
       t->n_coeff = (uint16_t)(c.count & HM_TU6_COUNT_MASK);
@@ -769,6 +769,13 @@ int orc_decode_picture(const uint8_t* blob, size_t size, int stages, uint16_t* y
       for (uint32_t k = 0; k < (uint32_t)c->tu_count + c->tu_count_c; k++) {
         const uint32_t r = k < c->tu_count ? c->tu_first + k : c->tu_first_c + (k - c->tu_count);
         if (r >= H->n_tus) { free(expanded); return -3; }
+        /* (the records repeat their CTB's neighbour bits and "last column" for the kernels: they must agree with the header) */
+        {
+          uint16_t cnt;
+          memcpy(&cnt, c6 + (size_t)r * sizeof(hm_tu6) + 4, 2);
+          if ((cnt & ~HM_TU6_COUNT_MASK) != (((unsigned)c->nb_avail << HM_TU6_NB_SHIFT) | (cx + 1 == H->ctb_w ? HM_TU6_LAST_COLUMN : 0u)) ||
+              ((c6[(size_t)r * sizeof(hm_tu6) + 1] & HM_TU6_NEXT_TO_LAST) != 0) != (cx + 2 == H->ctb_w)) { free(expanded); return -3; }
+        }
         derive_avail(H, c, cx, cy, &expanded[r]);
       }
     }

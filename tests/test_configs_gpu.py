@@ -70,6 +70,68 @@ def test_config5_16384_grid(hm):
         assert np.array_equal(got, expect[pick[t]]), f"tile {t} (row {r}, col {c}) differs"
 
 
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]], ids=["two_slabs", "three_slabs"])
+@pytest.mark.parametrize("ext", [False, True], ids=["pinned_plane", "ext_dst"])
+def test_one_grid_over_several_devices(hm, devices, ext):
+    """hm_decode_item_devices: ONE grid cut into slabs of tile rows, one per listed device, each decoded and converted on
+    its device (own batch, own stream, own host thread) and copied straight into its rows of the destination - here the
+    one GPU of the box listed several times: the slabs run side by side on it.  BASELINE config 5's shape (16384 x 16384,
+    32 x 32 tiles; 24 distinct tiles as in the config-5 test) must come out bit for bit as the one-device decode; a second,
+    cropped grid (5 tile rows for 2 / 3 devices: uneven slabs, a last slab cut by the canvas) likewise, also into ext_dst."""
+    import ctypes as C
+    pool = [synthutil.picture(5000000 + i, **TILE, vui=1, full_range=1, matrix=6) for i in range(24)]
+    for (rows, cols, w, h) in ((32, 32, 16384, 16384), (5, 3, 1500, 2300)):
+        if ext and rows == 32:
+            continue  # (the large grid once is enough)
+        pick = [(7 * t + 3 * (t // cols)) % 24 for t in range(rows * cols)]
+        data = heifwriter.write_heic([pool[k] for k in pick], (512, 512), grid=(rows, cols, w, h))
+        f = pipeline.HeifFile(hm, data)
+        fmt = 11 if ext else 10
+        one, meta1 = f.decode(f.primary(), fmt, threads=16)
+        bpp = 4 if ext else 3
+        dev = (C.c_int32 * len(devices))(*devices)
+        d = pipeline.Decoded()
+        buf = None
+        if ext:
+            stride = w * 4 + 64
+            buf = np.zeros((h, stride), dtype=np.uint8)
+            prm = pipeline.DecodeParams(fmt, 16, 0, 0, None, buf.ctypes.data_as(C.c_void_p), buf.size, stride, 0, 0)
+        else:
+            prm = pipeline.DecodeParams(fmt, 16, 0, 0, None, None, 0, 0, 0, 0)
+        hm.hm_decode_item_devices.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.c_void_p]
+        rc = hm.hm_decode_item_devices(f.h, f.primary(), C.byref(prm), dev, len(devices), C.byref(d))
+        assert rc == 0, hm.hm_last_error()
+        assert (d.width, d.height, d.out_format, d.has_nclx, d.primaries, d.transfer, d.matrix, d.full_range) == (w, h, fmt, 1, 1, 13, 6, 1)
+        if ext:
+            assert d.used_ext_dst == 1 and not d.plane[0]
+            got = buf
+        else:
+            assert d.stride[0] == meta1["stride"][0]
+            got = np.ctypeslib.as_array(d.plane[0], shape=(h, d.stride[0]))
+        assert np.array_equal(got[:h, :w * bpp], one[0][:h, :w * bpp]), f"{rows}x{cols} grid over {len(devices)} slabs differs from the one-device decode"
+        hm.hm_decoded_free(C.byref(d))
+        f.close()
+
+
+def test_items_that_do_not_cut_fall_back_to_the_first_device(hm):
+    """a single image, and a grid asked for planar output: hm_decode_item_devices decodes them on devices[0] like hm_decode_item"""
+    import ctypes as C
+    pic = synthutil.picture(4242, **TILE, vui=1, full_range=1, matrix=6)
+    f = pipeline.HeifFile(hm, heifwriter.write_heic([pic], (512, 512)))
+    one, _ = f.decode(f.primary(), 10, threads=2)
+    dev = (C.c_int32 * 2)(0, 0)
+    d = pipeline.Decoded()
+    prm = pipeline.DecodeParams(10, 2, 0, 0, None, None, 0, 0, 0, 0)
+    hm.hm_decode_item_devices.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.c_void_p]
+    assert hm.hm_decode_item_devices(f.h, f.primary(), C.byref(prm), dev, 2, C.byref(d)) == 0
+    got = np.ctypeslib.as_array(d.plane[0], shape=(512, d.stride[0]))
+    assert np.array_equal(got[:, :1536], one[0][:512, :1536])
+    hm.hm_decoded_free(C.byref(d))
+    bad = (C.c_int32 * 2)(0, 99)
+    assert hm.hm_decode_item_devices(f.h, f.primary(), C.byref(prm), bad, 2, C.byref(d)) != 0  # a device that does not exist
+    f.close()
+
+
 def test_config3_batch_of_12mp_grids(pkg, hm):
     """BASELINE config 3 on one rank: 32 DIFFERENT 12 MP grids (image j: tiles 1200000 + 48 j + i) in ONE hm_batch, one
     batched colour conversion - EVERY image compared with the CPU flow (the real reference decoder oracle/_ref for the

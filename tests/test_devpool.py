@@ -54,3 +54,22 @@ def test_buckets_recycle(pool):
     b = pool.hm_pool_device_alloc(105_000)  # same bucket: recycled
     assert b == a
     pool.hm_pool_device_free(b)
+
+
+def test_device_slab_plan_of_a_grid(hm):
+    """hm_plan_device_slabs: the cut hm_decode_item_devices makes - contiguous slabs of tile rows, one per listed device,
+    sizes at most one row apart, devices beyond the row count get nothing; the same cut as shard.row_slabs (N > 1 harness)."""
+    import __graft_entry__ as g
+    sh = g.load_package().shard
+    hm.hm_plan_device_slabs.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    for rows in (0, 1, 2, 5, 6, 32, 33):
+        for n in (1, 2, 3, 8):
+            first = (C.c_int32 * n)()
+            count = (C.c_int32 * n)()
+            assert hm.hm_plan_device_slabs(rows, n, first, count) == 0
+            got = [(first[d], count[d]) for d in range(n)]
+            assert got == sh.row_slabs(rows, n)
+            assert sum(c for _, c in got) == rows and max(c for _, c in got) - min(c for _, c in got) <= 1
+            covered = [r for f, c in got for r in range(f, f + c)]
+            assert covered == list(range(rows))
+    assert hm.hm_plan_device_slabs(4, 0, None, None) != 0

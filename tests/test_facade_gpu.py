@@ -279,6 +279,75 @@ def _check_isolation(api, drv, pl, tiles, n, exp):
             api.heif_image_release(img)
 
 
+@pytest.mark.parametrize("strict", [0, 1])
+def test_damaged_streams_through_the_plugin(api, hm, strict):
+    """The contract at the plugin boundary for damaged slice data ("Damaged streams"), over the stream
+    classes of tools/fuzz_ref.py with 1-2 flipped bits: decode_image either hands out a picture - then it is the oracle's
+    picture of the same bytes - or fails the way the reference's caller sees a failed libde265 decode: heif_error_
+    Decoder_plugin_error / heif_suberror_Unspecified (context.cc:1826-1830), End_of_data for broken [length][NAL] framing
+    (decoder_libde265.cc:276-292), Unsupported_feature for syntax outside the decoder; never a crash, never another code.
+    Strict decoding only changes the handling of unknown colour code points, not this."""
+    import random
+    import corpus
+    import hevcutil
+    import pluginapi
+    saved = api.hm_get_decoder_plugin.restype
+    api.hm_get_decoder_plugin.restype = C.POINTER(pluginapi.Plugin)
+    p = api.hm_get_decoder_plugin().contents
+    api.hm_get_decoder_plugin.restype = saved
+    rng = random.Random(4242 + strict)
+    seen = {"ok": 0, "failed": 0}
+
+    def mutate(data):
+        b = bytearray(data)
+        for _ in range(rng.randrange(1, 3)):
+            b[rng.randrange(len(b) // 3, len(b))] ^= 1 << rng.randrange(8)
+        return bytes(b)
+
+    for name in ("ragged", "ctb64_wpp", "hi422_10", "ctb16_nosao", "mono10", "slices_headers", "tiles_3x2_nolf", "dense_lowqp"):
+        data = bytes(corpus.stream(name))
+        # ten mutations as they come (nearly all of them are refused), one that the parser still accepts (searched on the
+        # host: a few in a hundred are), one with a truncated last NAL record
+        cases = [mutate(data) for _ in range(10)]
+        for _ in range(400):
+            b = mutate(data)
+            try:
+                hevcutil.parse(hm, b)
+            except RuntimeError:
+                continue
+            cases.append(b)
+            break
+        cases.append(data[:len(data) - 7])
+        for t, b in enumerate(cases):
+            truncated = t == len(cases) - 1
+            b = bytes(b)
+            dec = C.c_void_p()
+            assert p.new_decoder(C.byref(dec), 0).code == 0
+            p.set_strict_decoding(dec, strict)
+            assert p.push_data(dec, b, len(b)).code == 0
+            img = C.c_void_p()
+            e = p.decode_image(dec, C.byref(img))
+            p.free_decoder(dec)
+            if e.code == 0:
+                assert img
+                exp, info = orc.oracle_decode(hevcutil.parse(hm, b), 3, crop=True)
+                stride = C.c_int()
+                ptr = api.heif_image_get_plane_readonly(img, 0, C.byref(stride))
+                w, h = api.heif_image_get_width(img, 0), api.heif_image_get_height(img, 0)
+                raw = np.ctypeslib.as_array(ptr, shape=(h, stride.value))
+                got = raw[:, :w * 2].copy().view(np.uint16).reshape(h, w) if info["bit_depth"] > 8 else raw[:, :w].astype(np.uint16)
+                np.testing.assert_array_equal(got, exp[0][:h, :w], err_msg=f"{name} mutation {t}")
+                api.heif_image_release(img)
+                seen["ok"] += 1
+            else:
+                assert not img
+                assert (e.code, e.subcode) in ((7, 0), (7, 100), (4, 3000)) or e.code == 4, (name, t, e.code, e.subcode, e.message)
+                if truncated:
+                    assert (e.code, e.subcode) == (7, 100), (name, e.code, e.subcode, e.message)  # Decoder_plugin_error / End_of_data
+                seen["failed"] += 1
+    assert seen["ok"] > 0 and seen["failed"] > 0, seen
+
+
 def test_strict_decoding_and_warnings(api, hm):
     """unknown VUI colour codes: a decoding warning + 'unspecified' without strict decoding, an error with it
     (HEIF_WARN_OR_FAIL, heif_plugin.h:290-301; decoder_libde265.cc:339-357; heif.cc:1223-1245, 1811-1905)"""
