@@ -251,9 +251,19 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   uint8_t* const lines_c = pbase + L.off_lines_c;
   int16_t* const l_bA = reinterpret_cast<int16_t*>(pbase + L.off_scratch);
   c_u32x4* const rings = reinterpret_cast<c_u32x4*>(pbase + L.off_rings); // [NG][C_RING]
-  int16_t* const rres = reinterpret_cast<int16_t*>(pbase + L.off_rres) + g_of(lane) * (C_RING * 16); // [records of the window][16 samples] of the lane's group
+  int16_t* const rres_all = reinterpret_cast<int16_t*>(pbase + L.off_rres); // [chain][records of the window][16 samples]
+  // PAIRS, cuts with fewer than four chains per wave (a wave per CTU row: two, a wave per chain: one): the wave's spare groups do
+  // not idle - group g works on chain g & (chains - 1), `my_off` = g / chains records AHEAD of that chain's current record.
+  // Everything of a block that does not depend on the block before it (micro-op, predictor table entry, residual, addresses)
+  // is then worked out for up to four consecutive records side by side, as the four groups do for four chains in the other
+  // cuts; only reading the reference samples, the blend and the store run one record after the other (phase C below).  In
+  // these cuts a wave is alone on its SIMD and an iteration is a chain of latencies, not of instructions: what counts is the
+  // number of iterations per record.  All groups of a chain hold identical chain state (the same loads, the same updates).
+  const int NCL = !PAIRS ? 2 : (L.split_kinds ? 0 : (RPW == 1 ? (mono ? 0 : 1) : 2)); // log2 of the chains per wave
+  const int SUB = 4 >> NCL;                                                              // records of a chain per iteration
+  const unsigned long long main_mask = NCL == 2 ? ~0ull : (NCL == 1 ? 0xFFFFFFFFull : 0xFFFFull); // the groups with offset 0
   // group -> (chain kind, row slot): luma / chroma of two rows, or luma of four rows (monochrome)
-  auto group_kind = [&](int gg) { return mono ? 0 : (gg & 1); };
+  auto group_kind = [&](int gg) { return mono ? 0 : (PAIRS && L.split_kinds ? kind_sel : (gg & 1)); };
   auto group_slot = [&](int gg) { return mono ? gg : (gg >> 1); };
   // (offsets inside the wave's LDS in 32-bit arithmetic: with size_t factors every use costs a 64-bit scalar multiply)
   auto group_base = [&](int gg) -> uint8_t* {
@@ -272,7 +282,10 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   };
 
   // ---- per-lane constants ----
-  const int g = lane >> 4, gl = lane & 15, bx_ = gl & 3, by_ = gl >> 2;
+  const int g_phys = lane >> 4, gl = lane & 15, bx_ = gl & 3, by_ = gl >> 2;
+  const int g = PAIRS ? g_phys & ((1 << NCL) - 1) : g_phys; // the chain (= its first group) this lane works on
+  const int my_off = PAIRS ? g_phys >> NCL : 0;             // ... and how many records ahead of the chain's current one
+  int16_t* const rres = rres_all + g * (C_RING * 16);
   const int kind = group_kind(g); // 0: luma chain, 1: chroma chain
   Pix* const gbase = group_u(g, kind ? 1 : 0); // CTU buffer of the luma plane / of Cb (Cr: P1 * ch_c samples further)
   const int Pk = kind ? P1 : P0;               // pitch of the chain's CTU buffers
@@ -368,7 +381,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     const unsigned long long m_left0 = ballot(left == 0);
     if ((m_left0 & ~m_done) || (PAIRS && (budget & 15) == 0)) {
       // ---- F: finished CTUs: coalesced stores to the picture, bottom row -> line, right column -> left column ----
-      for (unsigned long long fin = ballot(st == ST_RUN) & ballot(ri == ctu_end); fin;) {
+      for (unsigned long long fin = ballot(st == ST_RUN) & ballot(ri == ctu_end) & main_mask; fin;) {
         const int fg = rfl((int)(__builtin_ctzll(fin) >> 4));
         fin &= ~(0xFFFFull << (fg * 16));
         const int src = fg * 16;
@@ -487,7 +500,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
           //  when thousands of waves do them per CTU; the reader's loads are issued behind the word's value)
           int avail = 0;
           if (poll) avail = (int)__hip_atomic_load(pair_progress + 2 * (size_t)(pidx - 1) + kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          for (unsigned long long todo = ballot(poll && avail > hbm_have); todo;) {
+          for (unsigned long long todo = ballot(poll && avail > hbm_have) & main_mask; todo;) {
             const int cg = rfl((int)(__builtin_ctzll(todo) >> 4));
             todo &= ~(0xFFFFull << (cg * 16));
             const int src = cg * 16;
@@ -582,17 +595,41 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       if (PAIRS && lane == 0) __hip_atomic_store(err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       break;
     }
-    const bool running = left != 0;
-    const unsigned long long m_running = ballot(left != 0);
-    if (m_running == 0) continue; // (every chain of the wave waits: PAIRS, for the band above)
-
-    // the current block of every group
-    const uint32_t rslot = ri & (C_RING - 1);
+    if (ballot(left != 0) == 0) continue; // (every chain of the wave waits: PAIRS, for the band above)
+    // the group's record: the chain's current one, or - PAIRS - my_off records further if the chain may go that far before
+    // its next event (the same CTU, the same window of micro-ops)
+    const bool running = PAIRS ? my_off < left : left != 0;
+    const unsigned long long m_running = PAIRS ? ballot(my_off < left) : ballot(left != 0);
+    const uint32_t ri_me = PAIRS ? ri + (uint32_t)my_off : ri;
+    const uint32_t rslot = ri_me & (C_RING - 1);
     const c_u32x4 op = ring[rslot];
     const int16_t* const my_res = rres + rslot * 16; // the 16 residual samples of the group's block if it is a 4x4 block
-    const bool quad = running && (op.y & ((3u << OP_L2_SHIFT) | OP_INTERIOR)) == OP_INTERIOR;
-    const unsigned long long s_big = m_running & ~ballot((op.y & ((3u << OP_L2_SHIFT) | OP_INTERIOR)) == OP_INTERIOR);
-    const unsigned long long s_bres = m_running & ballot((op.y & (OP_CBF | (3u << OP_L2_SHIFT))) == (OP_CBF | (1u << OP_L2_SHIFT)));
+    const unsigned long long m_q4 = m_running & ballot((op.y & ((3u << OP_L2_SHIFT) | OP_INTERIOR)) == OP_INTERIOR); // interior 4x4 blocks
+    // which records execute in this iteration: per chain the run of interior 4x4 blocks from its current record on (phase C,
+    // one after the other), then - if the record behind that run is of another kind - that block (phase D)
+    unsigned long long m_quad = m_q4, s_big = m_running & ~m_q4;
+    int n_exec = 1, n_sub = 1; // records the lane's chain advances by (not PAIRS: one, for the groups that are running); turns of phase C
+    bool quad = running && (op.y & ((3u << OP_L2_SHIFT) | OP_INTERIOR)) == OP_INTERIOR;
+    if (PAIRS && NCL != 2) {
+      // bit k of `gq` / `gr`: group k holds an interior 4x4 block / a record of its chain's current CTU and window
+      const uint32_t gq = (uint32_t)((m_q4 & 1) | ((m_q4 >> 15) & 2) | ((m_q4 >> 30) & 4) | ((m_q4 >> 45) & 8));
+      const uint32_t gr = (uint32_t)((m_running & 1) | ((m_running >> 15) & 2) | ((m_running >> 30) & 4) | ((m_running >> 45) & 8));
+      uint32_t run[2] = {0, 0}, big[2] = {0, 0}; // per chain: length of the run, 1 if a phase-D block follows it
+      for (int c = 0; c < (1 << NCL); c++) {
+        uint32_t n = 0;
+        while ((int)n < SUB && ((gq >> (c + (n << NCL))) & 1u)) n++;
+        run[c] = n;
+        big[c] = ((int)n < SUB && ((gr >> (c + (n << NCL))) & 1u)) ? 1u : 0u; // (running and not part of the run: not an interior 4x4 block)
+      }
+      const uint32_t my_run = g == 0 ? run[0] : run[1], my_big = g == 0 ? big[0] : big[1];
+      quad = (uint32_t)my_off < my_run;
+      m_quad = ballot(quad);
+      s_big = ballot((uint32_t)my_off == my_run && my_big != 0);
+      n_exec = (int)(my_run + my_big);
+      n_sub = (int)(run[0] > run[1] ? run[0] : run[1]);
+    }
+    (void)m_quad;
+    const unsigned long long s_bres = s_big & ballot((op.y & (OP_CBF | (3u << OP_L2_SHIFT))) == (OP_CBF | (1u << OP_L2_SHIFT)));
 
     HM_T_LAP(1);
     // ---- P: residual of the 8x8 blocks (lane = sample), requested before the side-by-side phase ----
@@ -624,13 +661,17 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       const int nL1 = (int)((op.y >> OP_NL1_SHIFT) & 63), nT1c = (int)((op.y >> OP_NT1_SHIFT) & 63) + 1;
       // (side, position) of the lane's two reference samples and the weight of the second (tab4, sign-extended: bit 15 = side of the first)
       const int e = (int)tab4[mode * 16 + gl];
-      auto ref = [&](bool left, int k) -> int { // left: sample k of the left column (0 = beside the block's first row); else sample k of the row above (0 = corner)
+      auto ref_at = [&](bool left, int k) -> const Pix* { // left: sample k of the left column (0 = beside the block's first row); else sample k of the row above (0 = corner)
         const int kk = imin_(k, left ? nL1 : nT1c);
         const Pix* const base = left ? lp : tc;
-        return base[mul24(kk, left ? P : 1)];
+        return base + mul24(kk, left ? P : 1);
       };
-      const int r0 = ref(e < 0, e & 15), r1 = ref((e & 16) != 0, (e >> 5) & 15);
+      const Pix* const q0 = ref_at(e < 0, e & 15);
+      const Pix* const q1 = ref_at((e & 16) != 0, (e >> 5) & 15);
       const int maxv = (1 << bd) - 1;
+      // what depends on the block before: the reference samples, the blend, the store
+      auto execute = [&]() {
+      const int r0 = *q0, r1 = *q1;
       int v = blend32((e >> 9) & 31, r0, r1); // every angular mode; weight 0: a copy of r0
       // planar, DC and - luma - the pure horizontal / vertical modes with their edge filters: one wave-uniform test keeps the
       // mode dispatch (five lane-mask regions) off the path of the three passes in four that hold none of them
@@ -663,6 +704,15 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       }
       v = (op.y & OP_CBF) ? clip3i(0, maxv, v + res_q) : v;
       lp[st_off] = (Pix)v; // (st_off: the lane's sample inside its block, by * pitch + 1 + bx)
+      };
+      if (PAIRS && NCL != 2) {
+        // the records of a chain one after the other (LDS traffic of a wave is in order: what a turn stores the next one reads)
+        for (int t = 0; t < n_sub; t++) {
+          if (my_off == t) execute();
+          WAVE_SYNC();
+        }
+      }
+      else execute();
     }
     WAVE_SYNC();
 
@@ -706,8 +756,9 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         int res_s = 0, res_t[4] = {0, 0, 0, 0};
         if (cbf) {
           if (L2 == 2) { // lanes 0-15: the block's 16 samples in the window's residuals of its group
-            const int s_ri = __builtin_amdgcn_readlane((int)ri, src);
-            res_s = (int)(reinterpret_cast<const int16_t*>(pbase + L.off_rres) + bg * (C_RING * 16) + (s_ri & (C_RING - 1)) * 16)[ln & 15];
+            const int s_ri = __builtin_amdgcn_readlane((int)ri_me, src);
+            const int s_chain = PAIRS ? bg & ((1 << NCL) - 1) : bg; // (the window's residuals lie per chain)
+            res_s = (int)(rres_all + s_chain * (C_RING * 16) + (s_ri & (C_RING - 1)) * 16)[ln & 15];
           }
           else if (L2 == 3) {
             uint32_t b = bg == 0 ? bres0 : (bg == 1 ? bres1 : (bg == 2 ? bres2 : bres3));
@@ -959,7 +1010,11 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     HM_T_LAP(3);
     HM_MARK("E_begin");
     // ---- E: the groups that executed a block move to the next record ----
-    if (running) {
+    if (PAIRS && NCL != 2) { // (every group of a chain: by the records the chain executed)
+      ri += (uint32_t)n_exec;
+      left -= n_exec;
+    }
+    else if (running) {
       ri += 1;
       left -= 1;
     }
