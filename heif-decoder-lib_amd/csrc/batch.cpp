@@ -577,7 +577,7 @@ int hm_batch_execute(hm_batch* b, int stages, void* stream)
         const int si = g % ns;
         hipStream_t sg = si ? b->aux_streams[(size_t)si - 1] : s;
         int rc = launch_recon(dk, m, c, sg, b->sync_region(dk, m));
-        if (!rc) rc = hm_launch_tail420(dk, td + (size_t)i0 * per_img, m, c.max_w, c.max_h, b->tail_bpp, b->tail_coef, stages, sg);
+        if (!rc) rc = hm_launch_tail420(dk, td + (size_t)i0 * per_img, m, c.max_w, c.max_h, c.log2_ctb, b->tail_bpp, b->tail_coef, stages, sg);
         if (rc) { join(); return rc; }
       }
       if ((he = join()) != hipSuccess) return hm_check_hip(he, "join of the launch streams");
@@ -590,7 +590,7 @@ int hm_batch_execute(hm_batch* b, int stages, void* stream)
     if (rc) return rc;
     mark(0);
     if (b->tail_state == 2) { // one kernel for everything behind the reconstruction (timeline: the SAO + paste slot)
-      if ((rc = hm_launch_tail420(dc, b->d_tail.p, n, c.max_w, c.max_h, b->tail_bpp, b->tail_coef, stages, s))) return rc;
+      if ((rc = hm_launch_tail420(dc, b->d_tail.p, n, c.max_w, c.max_h, c.log2_ctb, b->tail_bpp, b->tail_coef, stages, s))) return rc;
       mark(2);
       b->exec_count++;
       return HM_OK;
@@ -693,7 +693,7 @@ int hm_batch_upload_execute(hm_batch* b, int stages, int chunks, void* copy_stre
     const int m = i1 - i0;
     if ((rc = launch_recon(dc, m, c, s, b->sync_region(dc, m)))) return rc;
     if (b->colour && b->tail_state == 2) {
-      if ((rc = hm_launch_tail420(dc, (const uint8_t*)b->d_tail.p + sizeof(TailDstHost) * (size_t)i0, m, c.max_w, c.max_h, b->tail_bpp, b->tail_coef, stages, s))) return rc;
+      if ((rc = hm_launch_tail420(dc, (const uint8_t*)b->d_tail.p + sizeof(TailDstHost) * (size_t)i0, m, c.max_w, c.max_h, c.log2_ctb, b->tail_bpp, b->tail_coef, stages, s))) return rc;
     }
     else {
       if ((stages & 1) && (rc = hm_launch_deblock(dc, m, c.max_w4, c.max_h4, c.chroma_format, c.bit_depth, c.rare, s))) return rc;

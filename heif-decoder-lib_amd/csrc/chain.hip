@@ -67,13 +67,14 @@ constexpr int C_SHARED = (C_SHARED_TABLES + C_TAB4_BYTES + 15) & ~15;
 #define HM_CHAIN_WLOG 3
 #endif
 constexpr int C_WLOG = HM_CHAIN_WLOG;        // log2 of the records per window: 4 (a record per lane) or 3 (half a record per lane: fewer registers, 1.5 KB less LDS per wave)
-constexpr int C_RING = 1 << C_WLOG;         // micro-ops per group: one window of records
-constexpr int C_ITEM_DWORDS = C_WLOG == 4 ? 12 : 6; // what a lane fetches: a record's micro-op (hm_dev_pic.mops) + the 16 residual samples of a 4x4 block (hm_dev_pic.res4), or half of that
-constexpr int C_RRES_BYTES = NG * C_RING * 32; // per group: the 4x4 residuals of the window
+
+template <bool PAIRS>
+constexpr int chain_wlog = PAIRS ? 4 : C_WLOG; // (the kernel's comment at WLOG)
+// (what a lane fetches per window: a record's micro-op (hm_dev_pic.mops) + the 16 residual samples of a 4x4 block (hm_dev_pic.res4) -
+//  12 dwords -, or half of that with windows of 8 records; in LDS per group: 16 bytes of micro-op + 32 bytes of residual per record)
 constexpr int C_SCRATCH = 272;              // wave-wide path: reference samples (bA)
 constexpr int C_PROG = 8;                   // progress counters per chain kind: rows r and r + 8 share one (at most 4 rows of a wave are in flight)
 constexpr int C_FDESC_BYTES = 48; // behind a wave's progress counters: what the CTU flush needs of the picture's descriptor (planes, pitches, size)
-constexpr int C_RING_BYTES = NG * C_RING * 16;
 
 struct CLayout {
   int pic_bytes;     // LDS per picture (= per wave): progress counters, sample lines, scratch, rings, CTU buffers
@@ -135,6 +136,9 @@ template <typename Pix, int LOG2_CTB, bool PAIRS>
 __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* __restrict__ pics, int n_pics, CLayout L, uint32_t* __restrict__ sync, uint32_t* __restrict__ err_word)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  // records per window of micro-ops: the few-pictures cuts (PAIRS) take windows of 16 - their waves have LDS and registers to
+  // spare, a chain executes up to five records per iteration there and a window's end cuts such a run short
+  constexpr int WLOG = chain_wlog<PAIRS>, RING = 1 << WLOG, ITEM_DWORDS = WLOG == 4 ? 12 : 6;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = rfl(tid >> 6);
   constexpr int log2_ctb = LOG2_CTB, ctb = 1 << log2_ctb;
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   uint8_t* const lines_l = pbase + L.off_lines_l;
   uint8_t* const lines_c = pbase + L.off_lines_c;
   int16_t* const l_bA = reinterpret_cast<int16_t*>(pbase + L.off_scratch);
-  c_u32x4* const rings = reinterpret_cast<c_u32x4*>(pbase + L.off_rings); // [NG][C_RING]
+  c_u32x4* const rings = reinterpret_cast<c_u32x4*>(pbase + L.off_rings); // [NG][RING]
   int16_t* const rres_all = reinterpret_cast<int16_t*>(pbase + L.off_rres); // [chain][records of the window][16 samples]
   // PAIRS, cuts with fewer than four chains per wave (a wave per CTU row: two, a wave per chain: one): the wave's spare groups do
   // not idle - group g works on chain g & (chains - 1), `my_off` = g / chains records AHEAD of that chain's current record.
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   const int g_phys = lane >> 4, gl = lane & 15, bx_ = gl & 3, by_ = gl >> 2;
   const int g = PAIRS ? g_phys & ((1 << NCL) - 1) : g_phys; // the chain (= its first group) this lane works on
   const int my_off = PAIRS ? g_phys >> NCL : 0;             // ... and how many records ahead of the chain's current one
-  int16_t* const rres = rres_all + g * (C_RING * 16);
+  int16_t* const rres = rres_all + g * (RING * 16);
   const int kind = group_kind(g); // 0: luma chain, 1: chroma chain
   Pix* const gbase = group_u(g, kind ? 1 : 0); // CTU buffer of the luma plane / of Cb (Cr: P1 * ch_c samples further)
   const int Pk = kind ? P1 : P0;               // pitch of the chain's CTU buffers
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   const int cr_off = P1 * ch_c;                // Cr buffer behind the Cb buffer, in samples
   const int st_off = by_ * Pk + 1 + bx_;       // a 4x4 block's sample of this lane, from the block's (x0 - 1, y0)
   int* const my_progress = progress + kind * C_PROG;
-  c_u32x4* const ring = rings + g * C_RING;
+  c_u32x4* const ring = rings + g * RING;
   // byte offsets in LDS of the group's places, for the wave-wide path (fetched from the group's first lane)
   const uint32_t gb_off = (uint32_t)(reinterpret_cast<uint8_t*>(gbase) - lds);
 
@@ -310,8 +314,8 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   int st = (row < ctb_h && my_slot < RPW && (kind_sel < 0 || kind == kind_sel)) ? ST_START : ST_DONE;
   uint32_t c0 = 0, c1 = 0; // header of the CTU to start next: first record of the chain, count
   uint32_t ri = 0;                 // index of the current block's record
-  uint32_t wdec = 0;               // the window (C_RING records: index >> C_WLOG) whose micro-ops and 4x4 residuals are in LDS
-  uint32_t pf[C_ITEM_DWORDS] = {}; // the lane's share of window wdec + 1 (micro-ops + 4x4 residuals), requested when window wdec was taken
+  uint32_t wdec = 0;               // the window (RING records: index >> WLOG) whose micro-ops and 4x4 residuals are in LDS
+  uint32_t pf[ITEM_DWORDS] = {}; // the lane's share of window wdec + 1 (micro-ops + 4x4 residuals), requested when window wdec was taken
   // PAIRS, first row of a pair: CTUs of the row above (the last row of the pair above, another wave's) whose bottom
   // sample line has been copied from the picture into this wave's line
   int hbm_have = 0, hbm_polls = 0;
@@ -322,14 +326,14 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   auto prog_index = [&](int r, int slot) { return PAIRS ? pbank * 4 + (slot & 3) : (r & (C_PROG - 1)); };
   bool from_hbm = PAIRS && my_slot == 0 && pidx > 0; // the row above belongs to another wave
   auto load_window = [&](uint32_t w) {
-    if constexpr (C_WLOG == 4) { // a record per lane
+    if constexpr (WLOG == 4) { // a record per lane
       uint32_t idx = (w << 4) + (uint32_t)gl;
       idx = idx < n_tus - 1 ? idx : n_tus - 1; // past the last record of the picture: re-read it (never executed)
       const c_u32x4 m = *reinterpret_cast<const GLOBAL_AS c_u32x4*>(mops + (size_t)idx * 4);
       const GLOBAL_AS uint32_t* const it = res4 + (size_t)idx * 8;
       const c_u32x4 a = *reinterpret_cast<const GLOBAL_AS c_u32x4*>(it), b = *reinterpret_cast<const GLOBAL_AS c_u32x4*>(it + 4);
       pf[0] = m.x; pf[1] = m.y; pf[2] = m.z; pf[3] = m.w; pf[4] = a.x; pf[5] = a.y; pf[6] = a.z; pf[7] = a.w;
-      pf[C_ITEM_DWORDS - 4] = b.x; pf[C_ITEM_DWORDS - 3] = b.y; pf[C_ITEM_DWORDS - 2] = b.z; pf[C_ITEM_DWORDS - 1] = b.w;
+      pf[ITEM_DWORDS - 4] = b.x; pf[ITEM_DWORDS - 3] = b.y; pf[ITEM_DWORDS - 2] = b.z; pf[ITEM_DWORDS - 1] = b.w;
     }
     else { // half a record per lane: even lanes the micro-op + residual samples 0-3, odd lanes samples 8-15 + 4-7
       uint32_t idx = (w << 3) + (uint32_t)(gl >> 1);
@@ -354,8 +358,8 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     if (gl == 0) __hip_atomic_store(my_progress + prog_index(row, my_slot), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     header(row, 0);
     ri = c0;
-    wdec = (ri >> C_WLOG) - 1; // (nothing of this row is in LDS yet)
-    load_window(ri >> C_WLOG);
+    wdec = (ri >> WLOG) - 1; // (nothing of this row is in LDS yet)
+    load_window(ri >> WLOG);
   };
   if (st == ST_START) row_start();
   // every iteration executes a block of some chain or waits for a CTU that is at most two CTUs of another chain away
@@ -547,17 +551,17 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       HM_MARK("R_begin");
       // ---- R: the micro-ops and 4x4 residuals of the next window of records, for every group that has entered it ----
       {
-        const bool need_dec = st != ST_DONE && (ri >> C_WLOG) != wdec; // the chain has entered window wdec + 1: its records are in pf
+        const bool need_dec = st != ST_DONE && (ri >> WLOG) != wdec; // the chain has entered window wdec + 1: its records are in pf
         // (lane masks of conjunctions: the masks of the single compares, combined by the scalar unit - the mask of a boolean
         //  expression costs two more vector instructions, a select and a compare)
-        if (ballot(st != ST_DONE) & ballot((ri >> C_WLOG) != wdec)) {
+        if (ballot(st != ST_DONE) & ballot((ri >> WLOG) != wdec)) {
           if (need_dec) {
-            if constexpr (C_WLOG == 4) {
+            if constexpr (WLOG == 4) {
               ring[gl] = c_u32x4{pf[0], pf[1], pf[2], pf[3]};
               // the record's 16 residual samples (meaningful for 4x4 blocks with a residual)
               c_u32x4* const rr = reinterpret_cast<c_u32x4*>(rres + gl * 16);
               rr[0] = c_u32x4{pf[4], pf[5], pf[6], pf[7]};
-              rr[1] = c_u32x4{pf[C_ITEM_DWORDS - 4], pf[C_ITEM_DWORDS - 3], pf[C_ITEM_DWORDS - 2], pf[C_ITEM_DWORDS - 1]};
+              rr[1] = c_u32x4{pf[ITEM_DWORDS - 4], pf[ITEM_DWORDS - 3], pf[ITEM_DWORDS - 2], pf[ITEM_DWORDS - 1]};
             }
             else {
               uint32_t* const rr = reinterpret_cast<uint32_t*>(rres + (gl >> 1) * 16); // the record's 8 dwords of residual
@@ -581,9 +585,9 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       }
       // the records each group may execute from here on without another look at its state
       {
-        const int to_ctu = (int)(ctu_end - ri), to_win = C_RING - (int)(ri & (C_RING - 1));
+        const int to_ctu = (int)(ctu_end - ri), to_win = RING - (int)(ri & (RING - 1));
         const int n = to_ctu < to_win ? to_ctu : to_win;
-        left = (st == ST_RUN && (ri >> C_WLOG) == wdec) ? n : 0;
+        left = (st == ST_RUN && (ri >> WLOG) == wdec) ? n : 0;
       }
       m_done = ballot(st == ST_DONE);
     }
@@ -601,7 +605,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     const bool running = PAIRS ? my_off < left : left != 0;
     const unsigned long long m_running = PAIRS ? ballot(my_off < left) : ballot(left != 0);
     const uint32_t ri_me = PAIRS ? ri + (uint32_t)my_off : ri;
-    const uint32_t rslot = ri_me & (C_RING - 1);
+    const uint32_t rslot = ri_me & (RING - 1);
     const c_u32x4 op = ring[rslot];
     const int16_t* const my_res = rres + rslot * 16; // the 16 residual samples of the group's block if it is a 4x4 block
     const unsigned long long m_q4 = m_running & ballot((op.y & ((3u << OP_L2_SHIFT) | OP_INTERIOR)) == OP_INTERIOR); // interior 4x4 blocks
@@ -758,7 +762,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
           if (L2 == 2) { // lanes 0-15: the block's 16 samples in the window's residuals of its group
             const int s_ri = __builtin_amdgcn_readlane((int)ri_me, src);
             const int s_chain = PAIRS ? bg & ((1 << NCL) - 1) : bg; // (the window's residuals lie per chain)
-            res_s = (int)(rres_all + s_chain * (C_RING * 16) + (s_ri & (C_RING - 1)) * 16)[ln & 15];
+            res_s = (int)(rres_all + s_chain * (RING * 16) + (s_ri & (RING - 1)) * 16)[ln & 15];
           }
           else if (L2 == 3) {
             uint32_t b = bg == 0 ? bres0 : (bg == 1 ? bres1 : (bg == 2 ? bres2 : bres3));
@@ -1120,8 +1124,9 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
       L.chroma_off = L.luma_bytes;
     }
     L.off_rings = al(L.off_scratch + C_SCRATCH);
-    L.off_rres = L.off_rings + C_RING_BYTES;
-    L.off_groups = L.off_rres + C_RRES_BYTES;
+    const int ring_records = 1 << (pairs ? chain_wlog<true> : chain_wlog<false>);
+    L.off_rres = L.off_rings + NG * ring_records * 16;
+    L.off_groups = L.off_rres + NG * ring_records * 32;
     L.pic_bytes = al(L.off_groups + (mono && L.rows_per_wave > 1 ? 4 : L.rows_per_wave) * L.row_bytes);
     return C_SHARED + L.pic_bytes <= 160 * 1024;
   };

@@ -934,7 +934,9 @@ __device__ __forceinline__ void tail_row(SaoRow<uint8_t>& R, const uint8_t* tile
   __builtin_memcpy(&R.r, q + 8, 4);
 }
 // SAO of NR rows of one 8-sample group of plane c (the fast path of k_sao_paste: one slice, no tiles, no lossless units)
-template <int NR>
+// UNI: the wave's lanes lie in ONE CTB (cells of 32 x 32 luma samples, CTBs of 32 or 64): the CTB's record is read through
+// the scalar unit once per wave instead of by every lane, and SAO type / class become wave-uniform branches
+template <int NR, bool UNI>
 __device__ __forceinline__ void tail_sao(const hm_dev_pic& dp, const PicView& v, int c, const uint8_t* tile, int pitch, int tx0, int ty0,
                                          int xs, int yy0, int W, int Hh, int l2w, int l2h, int apply_sao, uint32_t (&res)[NR][4])
 {
@@ -948,7 +950,9 @@ __device__ __forceinline__ void tail_sao(const hm_dev_pic& dp, const PicView& v,
 #pragma unroll
   for (int r = 0; r < NR; r++) {
     const int yy = yy0 + r, yc = yy < Hh ? yy : Hh - 1, cy = yy >> l2h;
-    const GLOBAL_AS uint32_t* cbq = gptr<uint32_t>(reinterpret_cast<const uint8_t*>(v.ctbs) + (uint32_t)mul24_raw(cx + mul24_raw(yc >> l2h, dp.ctb_w), (int)sizeof(hm_ctb))); // hm_ctb as dwords (32-bit offset)
+    int ctb_index = cx + mul24_raw(yc >> l2h, dp.ctb_w);
+    if (UNI) ctb_index = __builtin_amdgcn_readfirstlane(ctb_index);
+    const GLOBAL_AS uint32_t* cbq = gptr<uint32_t>(reinterpret_cast<const uint8_t*>(v.ctbs) + (uint32_t)mul24_raw(ctb_index, (int)sizeof(hm_ctb))); // hm_ctb as dwords (32-bit offset)
     const uint32_t cflags = cbq[2], s0 = cbq[3 + 2 * c], s1 = cbq[4 + 2 * c];
     const SaoRow<uint8_t>&up = rows[r], &cur = rows[r + 1], &dn = rows[r + 2];
     const bool sao_on = apply_sao && (dp.flags & HM_PIC_SAO_ENABLED) && (cflags & (c == 0 ? HM_CTB_SAO_LUMA : HM_CTB_SAO_CHROMA));
@@ -982,7 +986,7 @@ __device__ __forceinline__ void tail_sao(const hm_dev_pic& dp, const PicView& v,
   }
 }
 
-template <int BPP, int MINW>
+template <int BPP, int MINW, bool UNI>
 __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic* __restrict__ pics, const TailDst* __restrict__ dsts, int tiles_x, int n_tiles, int stages, TailCoef k)
 {
   __shared__ __attribute__((aligned(16))) uint8_t s_all[TAIL_LR * TAIL_LP + 2 * TAIL_CR * TAIL_CP];
@@ -1085,7 +1089,7 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
       const int xc = (cellx >> 1) + 8 * gxc, yc = (celly >> 1) + row;
       if (xc < (W >> 1) && yc < (H >> 1)) {
         uint32_t rc[1][4];
-        tail_sao<1>(dp, v, 1 + pl, s_c0 + pl * (TAIL_CR * TAIL_CP), TAIL_CP, (x0 >> 1) - TAIL_XO, (y0 >> 1) - 4, xc, yc, W >> 1, H >> 1, l2 - 1, l2 - 1, stages & 2, rc);
+        tail_sao<1, UNI>(dp, v, 1 + pl, s_c0 + pl * (TAIL_CR * TAIL_CP), TAIL_CP, (x0 >> 1) - TAIL_XO, (y0 >> 1) - 4, xc, yc, W >> 1, H >> 1, l2 - 1, l2 - 1, stages & 2, rc);
         const uint32_t o[2] = {__builtin_amdgcn_perm(rc[0][1], rc[0][0], 0x06040200u), __builtin_amdgcn_perm(rc[0][3], rc[0][2], 0x06040200u)};
         __builtin_memcpy(&s_x[wave][pl][row][8 * gxc], o, 8);
       }
@@ -1096,7 +1100,7 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
     const int lx = cellx + 8 * gx, ly = celly + 2 * rp;
     if (lx < cw && ly < chh) {
       uint32_t ry[2][4];
-      tail_sao<2>(dp, v, 0, s_l, TAIL_LP, x0 - TAIL_XO, y0 - 4, lx, ly, W, H, l2, l2, stages & 2, ry);
+      tail_sao<2, UNI>(dp, v, 0, s_l, TAIL_LP, x0 - TAIL_XO, y0 - 4, lx, ly, W, H, l2, l2, stages & 2, ry);
       uint32_t cb4, cr4;
       __builtin_memcpy(&cb4, &s_x[wave][0][rp][4 * gx], 4);
       __builtin_memcpy(&cr4, &s_x[wave][1][rp][4 * gx], 4);
@@ -1214,7 +1218,7 @@ extern "C" int hm_launch_sao_paste(const hm_dev_pic* d_pics, int n_pics, int max
 
 // Fused tail (k_tail420): n pictures of one class (8-bit 4:2:0, no rare syntax), output d_dsts[i] (device array of
 // {pointer, pitch} at the picture's paste position), bpp 3 / 4, integer matrix coefficients of yuv2rgb.cc:336-339.
-extern "C" int hm_launch_tail420(const hm_dev_pic* d_pics, const void* d_dsts, int n_pics, int max_w, int max_h, int bpp, const int coef[4],
+extern "C" int hm_launch_tail420(const hm_dev_pic* d_pics, const void* d_dsts, int n_pics, int max_w, int max_h, int log2_ctb, int bpp, const int coef[4],
                                  int stages, hipStream_t s)
 {
   if (n_pics <= 0) return HM_OK;
@@ -1224,7 +1228,14 @@ extern "C" int hm_launch_tail420(const hm_dev_pic* d_pics, const void* d_dsts, i
   const TailDst* dd = (const TailDst*)d_dsts;
   // (105 VGPRs: four waves per SIMD; tighter register budgets spill and were measured slower: 15.5 / 17.3 / 21.7 ms
   //  at 96 / 80 / 64 VGPRs against 15.7 ms)
-  if (bpp == 3) hipLaunchKernelGGL((k_tail420<3, TAIL_MINW>), grid, dim3(TAIL_THREADS), 0, s, d_pics, dd, tiles_x, tiles_x * tiles_y, stages, k);
-  else hipLaunchKernelGGL((k_tail420<4, TAIL_MINW>), grid, dim3(TAIL_THREADS), 0, s, d_pics, dd, tiles_x, tiles_x * tiles_y, stages, k);
+  // (pictures with CTBs of 32 / 64: a wave's 32 x 32 cell lies in one CTB - its SAO record through the scalar unit)
+  if (log2_ctb >= 5) {
+    if (bpp == 3) hipLaunchKernelGGL((k_tail420<3, TAIL_MINW, true>), grid, dim3(TAIL_THREADS), 0, s, d_pics, dd, tiles_x, tiles_x * tiles_y, stages, k);
+    else hipLaunchKernelGGL((k_tail420<4, TAIL_MINW, true>), grid, dim3(TAIL_THREADS), 0, s, d_pics, dd, tiles_x, tiles_x * tiles_y, stages, k);
+  }
+  else {
+    if (bpp == 3) hipLaunchKernelGGL((k_tail420<3, TAIL_MINW, false>), grid, dim3(TAIL_THREADS), 0, s, d_pics, dd, tiles_x, tiles_x * tiles_y, stages, k);
+    else hipLaunchKernelGGL((k_tail420<4, TAIL_MINW, false>), grid, dim3(TAIL_THREADS), 0, s, d_pics, dd, tiles_x, tiles_x * tiles_y, stages, k);
+  }
   return hm_check_hip(hipGetLastError(), "k_tail420 launch");
 }
