@@ -77,7 +77,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // others (records in decode order) the one-row-per-wave kernel
 // (`mid`, if given, is called between the two kernels of the split-chain path: the profiling marks)
 // (`sync`: the launch's own region of the batch's synchronisation words, hm_internal.h: hm_launch_chain)
-struct SyncRegion { uint32_t* p = nullptr; size_t bytes = 0; std::vector<uint32_t*>* used = nullptr; uint32_t* err = nullptr; };
+struct SyncRegion { uint32_t* p = nullptr; size_t bytes = 0; std::vector<uint32_t*>* used = nullptr; uint32_t* err = nullptr; bool* err_possible = nullptr; };
 template <typename Mid>
 int launch_recon(const hm_dev_pic* dc, int n, const Class& c, hipStream_t s, SyncRegion sync, Mid&& mid)
 {
@@ -88,6 +88,7 @@ int launch_recon(const hm_dev_pic* dc, int n, const Class& c, hipStream_t s, Syn
     const int q = hm_launch_chain(dc, n, c.log2_ctb, c.chroma_format, c.bit_depth, c.rare, c.max_ctb_w, c.max_ctb_h, sync.p, sync.bytes, sync.err, s);
     // (HM_CHAIN_TIMING builds leave their phase sums in the launch's region: remembered once per region for hm_batch_check's print)
     if (q == 2 && sync.used && sync.used->size() < 64 && std::find(sync.used->begin(), sync.used->end(), sync.p) == sync.used->end()) sync.used->push_back(sync.p);
+    if (q == 2 && sync.err_possible) *sync.err_possible = true;
     if (q == 0) return hm_fail(HM_ERR_UNSUPPORTED, "CTU staging does not fit LDS (CTB %d, %d bit, %d CTBs wide)", 1 << c.log2_ctb, c.bit_depth, c.max_ctb_w);
     return q < 0 ? q : HM_OK;
   }
@@ -152,6 +153,8 @@ struct hm_batch {
   // hm_batch_check has read it - never by a launch, so that a check after many executes sees a give-up of any of them
   uint32_t* err_word() { return d_sync.p && sync_stride ? (uint32_t*)d_sync.p + sync_words_total : nullptr; }
   size_t sync_words_total = 0;
+  bool err_fresh = false;  // the error word has been zeroed since the buffers were laid out
+  bool err_possible = false; // a launch since the last check may have written it (a cut with waits between waves ran)
   SyncRegion sync_region(const hm_dev_pic* dc, int n)
   {
     SyncRegion r;
@@ -160,7 +163,8 @@ struct hm_batch {
     r.p = (uint32_t*)d_sync.p + i0 * sync_stride;
     r.bytes = (size_t)n * sync_stride * sizeof(uint32_t);
     r.used = &sync_used;
-    r.err = err_word();
+    r.err = err_fresh ? err_word() : nullptr; // (no zeroed word: the cuts with waits between waves stay off)
+    r.err_possible = &err_possible;
     return r;
   }
   hipStream_t copy_stream = nullptr;
@@ -376,11 +380,8 @@ static int batch_prepare(hm_batch* b, size_t* blob_bytes_out)
     b->sync_stride = rows ? 8 + 2 * rows : 0;
     b->sync_used.clear();
     b->sync_words_total = (size_t)n * b->sync_stride;
-    if (b->sync_stride) {
-      if ((rc = b->d_sync.ensure((b->sync_words_total + 1) * sizeof(uint32_t)))) return rc;
-      const hipError_t ez = hipMemset(b->err_word(), 0, sizeof(uint32_t)); // (the batch was drained above: nothing in flight)
-      if (ez != hipSuccess) return hm_check_hip(ez, "hipMemset(reconstruction error word)");
-    }
+    if (b->sync_stride && (rc = b->d_sync.ensure((b->sync_words_total + 1) * sizeof(uint32_t)))) return rc;
+    b->err_fresh = false; // (zeroed on the upload's stream, behind the copies: no synchronous call on the way of small batches)
   }
 
   // (every check that can fail on file data runs before anything is enqueued: an error return must not leave copies
@@ -473,6 +474,11 @@ int hm_batch_upload(hm_batch* b, void* stream)
   if (n == 0) { b->uploaded = true; return HM_OK; }
   b->last_stream = s;
   b->inflight = true;
+  if (uint32_t* ew = b->err_word()) {
+    const hipError_t ez = hipMemsetAsync(ew, 0, sizeof(uint32_t), s);
+    if (ez != hipSuccess) return hm_check_hip(ez, "hipMemsetAsync(reconstruction error word)");
+    b->err_fresh = true;
+  }
   // the streams already lie in the pinned arena in device layout -> one H2D copy at PCIe rate
   hipError_t e = hipMemcpyAsync(b->d_blobs.p, b->stage.p, blob_bytes, hipMemcpyHostToDevice, s);
   if (e != hipSuccess) return hm_check_hip(e, "H2D command streams");
@@ -662,6 +668,11 @@ int hm_batch_upload_execute(hm_batch* b, int stages, int chunks, void* copy_stre
   b->inflight = true;
   b->copy_stream = cs;
   b->copy_inflight = true;
+  if (uint32_t* ew = b->err_word()) { // (on the copy stream: every chunk's kernels wait for an event behind it)
+    const hipError_t ez = hipMemsetAsync(ew, 0, sizeof(uint32_t), cs);
+    if (ez != hipSuccess) return hm_check_hip(ez, "hipMemsetAsync(reconstruction error word)");
+    b->err_fresh = true;
+  }
   hipError_t e = hipMemcpyAsync(b->d_desc.p, b->desc_stage.p, sizeof(hm_dev_pic) * (size_t)n, hipMemcpyHostToDevice, cs);
   if (e != hipSuccess) return hm_check_hip(e, "H2D descriptors");
   const Class& c = b->classes[0]; // its descriptors are in queue order = the order of the streams in the arena
@@ -853,7 +864,8 @@ int hm_batch_check(hm_batch* b)
   if (!b) return hm_fail(HM_ERR_INVALID_ARG, "null batch");
   b->drain();
   int bad = 0;
-  if (uint32_t* ew = b->err_word()) { // one word for the whole batch, whatever ran since the last check
+  if (uint32_t* ew = b->err_possible ? b->err_word() : nullptr) { // one word for the whole batch, whatever ran since the last check
+    b->err_possible = false;
     uint32_t flag = 0;
     hipError_t e = hipMemcpy(&flag, ew, sizeof(flag), hipMemcpyDeviceToHost);
     if (e == hipSuccess && flag) e = hipMemset(ew, 0, sizeof(flag));

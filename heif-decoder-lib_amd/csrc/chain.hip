@@ -1061,7 +1061,7 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   // One wave per picture, or - few pictures - one wave per pair of CTU rows (PAIRS): a batch that cannot fill the
   // machine with a wave per picture (256 CUs x 16 waves) gets its parallelism from the rows instead.  HM_CHAIN_PAIRS=0 / 1
   // forces the choice (A/B measurements).
-  static const int force_pairs = [] { const char* e = getenv("HM_CHAIN_PAIRS"); return e ? atoi(e) : -1; }();
+  static const int force_pairs = [] { const char* e = getenv("HM_CHAIN_PAIRS"); return e && e[0] ? atoi(e) : -1; }();
   // The fewer waves there are, the finer the work is cut: a wave per pair of rows (4 chains per wave), per row (2), per
   // chain (1) - every chain a wave drops makes its iterations shorter, and a picture is a wavefront of CTUs whose length
   // in iterations does not change.  HM_CHAIN_PAIRS = 1 / 2 / 3 forces pair / row / chain waves.

@@ -79,6 +79,11 @@ struct Request {
   size_t off[3] = {0, 0, 0}, pitch[3] = {0, 0, 0}, total = 0;
   int status = 1;       // > 0: pending
   std::string message;
+  std::chrono::steady_clock::time_point t_submit, t_taken, t_done; // (HM_PLUGIN_DEBUG: where a call's time on the device goes)
+  // every caller sleeps on a condition of its own: a batch of 20 that ends wakes 20 threads, and with one shared condition
+  // + mutex the last of them got going 0.3 ms after the first (profiles/r04_plugin_trace.txt)
+  std::mutex m;
+  std::condition_variable cv;
 };
 
 class DeviceWorker {
@@ -97,14 +102,21 @@ class DeviceWorker {
   {
     if (executors_ == 0) return hm_fail(HM_ERR_NOMEM, "the device worker could not start a thread");
     std::lock_guard<std::mutex> l(m_);
+    r.t_submit = std::chrono::steady_clock::now();
     queue_.push_back(&r);
     work_.notify_all(); // (the executor that is collecting, or an idle one)
     return HM_OK;
   }
   int wait(Request& r)
   {
-    std::unique_lock<std::mutex> l(m_);
-    done_.wait(l, [&] { return r.status <= 0; });
+    std::unique_lock<std::mutex> l(r.m);
+    r.cv.wait(l, [&] { return r.status <= 0; });
+    static const bool debug = [] { const char* e = std::getenv("HM_PLUGIN_DEBUG"); return e && e[0] == '1'; }();
+    if (debug) {
+      const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+      std::fprintf(stderr, "[plugin request] queued %.3f ms, in its batch %.3f ms, woken after %.3f ms\n", ms(r.t_submit, r.t_taken), ms(r.t_taken, r.t_done),
+                   ms(r.t_done, std::chrono::steady_clock::now()));
+    }
     if (r.status) hm_fail(r.status, "%s", r.message.c_str());
     return r.status;
   }
@@ -146,6 +158,8 @@ class DeviceWorker {
         }
         collecting_ = false;
         if (!queue_.empty()) work_.notify_all(); // (more than one batch's worth: the next executor takes over)
+        const std::chrono::steady_clock::time_point now = std::chrono::steady_clock::now();
+        for (Request* r : reqs) r->t_taken = now;
       }
       int rc = se == hipSuccess ? HM_OK : hm_check_hip(se, "hipStreamCreate");
       std::string msg = rc ? hm_last_error() : "";
@@ -163,14 +177,17 @@ class DeviceWorker {
           for (size_t i = 0; i < reqs.size(); i++) rcs[i] = run_batch(std::vector<Request*>(1, reqs[i]), s, msgs[i]);
         }
       }
-      {
-        std::lock_guard<std::mutex> l(m_);
-        for (size_t i = 0; i < reqs.size(); i++) {
-          reqs[i]->status = rcs.empty() ? rc : rcs[i];
-          reqs[i]->message = rcs.empty() ? msg : msgs[i];
-        }
+      const std::chrono::steady_clock::time_point now = std::chrono::steady_clock::now();
+      for (size_t i = 0; i < reqs.size(); i++) {
+        Request* r = reqs[i];
+        // (notified with the lock held: the caller cannot leave its wait - and free the request - before the lock is
+        //  released, and nothing of the request is touched after that)
+        std::lock_guard<std::mutex> l(r->m);
+        r->t_done = now;
+        r->message = rcs.empty() ? msg : msgs[i];
+        r->status = rcs.empty() ? rc : rcs[i];
+        r->cv.notify_one();
       }
-      done_.notify_all();
     }
   }
   // one batch for all pictures: upload, kernels, D2H of every picture into its pinned block; returns when it is all there
@@ -217,7 +234,7 @@ class DeviceWorker {
   int device_;
   int linger_us_ = 30;
   std::mutex m_;
-  std::condition_variable work_, done_;
+  std::condition_variable work_;
   std::deque<Request*> queue_;
   bool collecting_ = false; // an executor is gathering the next batch
   int executors_ = 0;
