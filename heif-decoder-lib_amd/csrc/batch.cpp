@@ -39,6 +39,7 @@ struct Item {
   size_t stage_off = 0;  // the command stream inside the pinned staging arena (256-B aligned = its device layout)
   hm_tile_dest dest;
   hm_pic hdr;
+  bool sao_ring_uniform = true; // no CTB whose chroma SAO needs the per-sample ring test (hm_ctb.sao_ring_c = 0: several slices whose filters stop at slice borders)
 };
 
 // Pinned host arena holding the command streams back to back exactly as they will lie in HBM: hm_batch_add copies
@@ -233,7 +234,9 @@ static int decide_tail(hm_batch* b)
       const Item& it = b->items[k];
       const hm_pic& h = it.hdr;
       const hm_dev_pic& dp = b->h_desc[c.desc_offset + k];
-      if (h.n_slices != 1 || (h.flags & HM_PIC_TILES) || (h.width % 16) || h.crop_left || h.crop_top || dp.rescale) return HM_OK;
+      // (several slices: the fused kernel's SAO takes the per-CTB neighbour masks like k_sao_paste's fast path, but has no per-sample
+      //  redo for the chroma CTBs of quirk Q13 - pictures that hold one keep the separate kernels)
+      if (!it.sao_ring_uniform || (h.flags & HM_PIC_TILES) || (h.width % 16) || h.crop_left || h.crop_top || dp.rescale) return HM_OK;
       if (it.dest.plane[0] != b->col_y[img] || it.dest.plane[1] != b->col_cb[img] || it.dest.plane[2] != b->col_cr[img]) return HM_OK;
       if (it.dest.canvas_width != d.width || it.dest.canvas_height != d.height) return HM_OK;
       if ((it.dest.x0 % 16) || (it.dest.y0 % 2)) return HM_OK;
@@ -306,6 +309,11 @@ int hm_batch_add_trusted(hm_batch* b, const uint8_t* blob, size_t size, const hm
   if (!b->stage.reserve(it.stage_off + it.hdr.total_bytes)) return hm_fail(HM_ERR_NOMEM, "pinned staging: out of memory");
   std::memcpy(b->stage.p + it.stage_off, blob, it.hdr.total_bytes);
   b->stage.used = it.stage_off + it.hdr.total_bytes;
+  if (it.hdr.n_slices > 1 && (size_t)it.hdr.off_ctbs + (size_t)it.hdr.n_ctbs * sizeof(hm_ctb) <= it.hdr.total_bytes) {
+    // (what the fused tail asks of a picture with several slices - decide_tail; one slice: the flag is 1 in every CTB)
+    const hm_ctb* cb = reinterpret_cast<const hm_ctb*>(static_cast<const uint8_t*>(blob) + it.hdr.off_ctbs);
+    for (uint32_t k = 0; k < it.hdr.n_ctbs && it.sao_ring_uniform; k++) it.sao_ring_uniform = cb[k].sao_ring_c != 0;
+  }
   it.dest = *dest;
   b->items.push_back(std::move(it));
   b->uploaded = false;

@@ -44,13 +44,22 @@
 namespace {
 
 // HM_CHAIN_TIMING (tools/chain_timing.sh): per-phase cycle sums of the kernel (every cut) in words 2..7 of the launch's sync region
+// (HM_CHAIN_TIMING=2: the same five words count events instead - service phases, CTU flushes, window take-overs, 4x4 passes,
+//  wave-wide blocks - per wave, in units of 1/64 so that the print's ">> 6" gives the counts)
 #ifdef HM_CHAIN_TIMING
 #define HM_T_DECL unsigned long long t_prev = __builtin_amdgcn_s_memtime(); unsigned int t_acc[6] = {0, 0, 0, 0, 0, 0}
+#if HM_CHAIN_TIMING == 2
+#define HM_T_LAP(i) (void)t_prev
+#define HM_T_COUNT(i) t_acc[i] += 64
+#else
 #define HM_T_LAP(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_acc[i] += (unsigned int)(t_now - t_prev); t_prev = t_now; } while (0)
+#define HM_T_COUNT(i)
+#endif
 #define HM_T_FLUSH() do { if (sync && lane == 0) { for (int q = 0; q < 5; q++) atomicAdd(sync + 2 + q, t_acc[q] >> 6); atomicAdd(sync + 7, t_acc[5]); } } while (0)
 #else
 #define HM_T_DECL
 #define HM_T_LAP(i)
+#define HM_T_COUNT(i)
 #define HM_T_FLUSH()
 #endif
 #ifdef HM_MARKS
@@ -62,6 +71,8 @@ namespace {
 constexpr int NG = 4;                       // groups per wave
 constexpr int C_SHARED_TABLES = 256;        // small tables (recon.hip layout: angles, inverse angles)
 constexpr int C_TAB4_BYTES = 35 * 16 * 2;   // per (mode, sample) of a 4x4 block: reference positions + weight
+// (a field per byte - 32-bit entries, which the instructions that use them would select themselves (SDWA): three extractions
+//  less per 4x4 pass - does not fit: a workgroup of four waves has 288 bytes to spare before a CU holds four instead of five)
 constexpr int C_SHARED = (C_SHARED_TABLES + C_TAB4_BYTES + 15) & ~15;
 #ifndef HM_CHAIN_WLOG
 #define HM_CHAIN_WLOG 3
@@ -145,7 +156,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
 
   // ---- workgroup-wide tables ----
   int16_t* const tab = reinterpret_cast<int16_t*>(lds);
-  int16_t* const tab4 = reinterpret_cast<int16_t*>(lds + C_SHARED_TABLES);
+  uint16_t* const tab4 = reinterpret_cast<uint16_t*>(lds + C_SHARED_TABLES);
   for (int i = tid; i < 70; i += blockDim.x) { // [0,35) angle, [35,70) inverse angle (0 where unused)
     int v;
     if (i < 35) v = c_intra_angle[i];
@@ -182,9 +193,10 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     j0 = j0 < -8 ? -8 : (j0 > 8 ? 8 : j0);
     j1 = j1 < -8 ? -8 : (j1 > 8 ? 8 : j1);
     // as (side, position): left column -> side 1, position -j - 1 (0 .. 7); corner and row above -> side 0, position j (0 .. 8).
-    // The side of the first sample sits in bit 15: the entry is read sign-extended and tested with one compare.
+    // Position of the first sample in bits 0-3, of the second in bits 4-7, the weight in bits 8-12, the side of the second sample in
+    // bit 14, of the first in bit 15 (one compare of the entry, read zero-extended).
     const int s0 = j0 < 0, k0 = j0 < 0 ? -j0 - 1 : j0, s1 = j1 < 0, k1 = j1 < 0 ? -j1 - 1 : j1;
-    tab4[i] = (int16_t)(uint16_t)(k0 | (s1 << 4) | (k1 << 5) | (f << 9) | (s0 << 15));
+    tab4[i] = (uint16_t)(k0 | (k1 << 4) | (f << 8) | (s1 << 14) | (s0 << 15));
   }
   // ---- this wave's task ----
   int pic_index, pair_index = 0, kind_sel = -1; // (kind_sel: the only chain kind this wave works on, -1: both)
@@ -309,8 +321,9 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   const int my_slot = group_slot(g);
   const int line_above = my_slot ? my_slot - 1 : NR - 1;
   const Pix* const lr = line_of(kind, line_above);
-  const uint32_t lr_off = (uint32_t)(reinterpret_cast<const uint8_t*>(lr) - lds);
-  uint32_t tl_off = lr_off; // the CTU's first sample in the sample line of the row above: lr + (cx << l2w)
+  // (one sample before the line's first: the micro-ops count the positions of the row above from the CTU's CORNER sample)
+  const uint32_t lr_off = (uint32_t)(reinterpret_cast<const uint8_t*>(lr) - lds) - (uint32_t)sizeof(Pix);
+  uint32_t tl_off = lr_off; // the sample before the CTU's first in the sample line of the row above: lr + (cx << l2w) - 1
   int st = (row < ctb_h && my_slot < RPW && (kind_sel < 0 || kind == kind_sel)) ? ST_START : ST_DONE;
   uint32_t c0 = 0, c1 = 0; // header of the CTU to start next: first record of the chain, count
   uint32_t ri = 0;                 // index of the current block's record
@@ -384,10 +397,12 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     //      state checks of all three phases below (r03: ~20 vector instructions per iteration) run only when something is due.
     const unsigned long long m_left0 = ballot(left == 0);
     if ((m_left0 & ~m_done) || (PAIRS && (budget & 15) == 0)) {
+      HM_T_COUNT(0);
       // ---- F: finished CTUs: coalesced stores to the picture, bottom row -> line, right column -> left column ----
       for (unsigned long long fin = ballot(st == ST_RUN) & ballot(ri == ctu_end) & main_mask; fin;) {
         const int fg = rfl((int)(__builtin_ctzll(fin) >> 4));
         fin &= ~(0xFFFFull << (fg * 16));
+        HM_T_COUNT(1);
         const int src = fg * 16;
         const int s_row = __builtin_amdgcn_readlane(row, src), s_cx = __builtin_amdgcn_readlane(cx, src);
         const int fkind = group_kind(fg);
@@ -407,7 +422,11 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
           GLOBAL_AS uint8_t* const gp = gptr_w<uint8_t>(plane + (uint32_t)((uint32_t)yo * (uint32_t)pitch + (uint32_t)(xo + q * CW * PPW) * (uint32_t)sizeof(Pix)));
           for (int rb = 0; rb < vh; rb += RPT) {
             const int r = rb + rr0;
+#if defined(HM_Q_PROBE) && (HM_Q_PROBE & 1024)
+            if (col_ok && r < vh && n_pics < 0) {
+#else
             if (col_ok && r < vh) {
+#endif
               const uint32_t* srcw = reinterpret_cast<const uint32_t*>(u + mul24(r, P) + UPAD + q * CW * PPW); // rows are 4-byte aligned
               uint32_t vv[CW];
 #pragma unroll
@@ -555,6 +574,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         // (lane masks of conjunctions: the masks of the single compares, combined by the scalar unit - the mask of a boolean
         //  expression costs two more vector instructions, a select and a compare)
         if (ballot(st != ST_DONE) & ballot((ri >> WLOG) != wdec)) {
+          HM_T_COUNT(2);
           if (need_dec) {
             if constexpr (WLOG == 4) {
               ring[gl] = c_u32x4{pf[0], pf[1], pf[2], pf[3]};
@@ -579,6 +599,9 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
           // every lane: the window its group decodes next (groups that did not decode ask again for the same).  (Measured against
           // requesting it at the end of the iteration, behind the iteration's residual loads: 23.7 against 24.1 ms at full load,
           // 7.5 against 8.1 ms for config 4.)
+#if defined(HM_Q_PROBE) && (HM_Q_PROBE & 4096)
+          if (n_pics < 0)
+#endif
           load_window(wdec + 1);
           WAVE_SYNC();
         }
@@ -637,7 +660,11 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
 
     HM_T_LAP(1);
     // ---- P: residual of the 8x8 blocks (lane = sample), requested before the side-by-side phase ----
+#if defined(HM_Q_PROBE) && (HM_Q_PROBE & 2048)
+    if (s_bres && n_pics < 0) {
+#else
     if (s_bres) {
+#endif
       auto big_res = [&](int gg) -> uint32_t {
         uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)op.z, gg * 16) + (uint32_t)lane;
         idx = idx < res_last ? idx : res_last;
@@ -656,30 +683,31 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
 #else
     if (quad) {
 #endif
+      if (lane == (int)__builtin_ctzll(ballot(true))) HM_T_COUNT(3);
       const int res_q = (int)my_res[gl]; // (requested first and unconditionally: not a fourth LDS round trip behind the reference samples)
       const int mode = (int)(op.y & OP_MODE_MASK);
       const int P = Pk;
       Pix* const lp = gbase + (op.x & 0xFFFF);                                  // sample (x0-1, y0): walks down the left column
       const Pix* const tbase = reinterpret_cast<const Pix*>(lds + ((op.y & OP_LINE) ? tl_off : gb_off));
-      const Pix* const tc = tbase + (op.x >> 16) - 1;                           // the corner sample (x0-1, y0-1): tc[k] walks along the row above
+      const Pix* const tc = tbase + (op.x >> 16);                               // the corner sample (x0-1, y0-1): tc[k] walks along the row above
       const int nL1 = (int)((op.y >> OP_NL1_SHIFT) & 63), nT1c = (int)((op.y >> OP_NT1_SHIFT) & 63) + 1;
-      // (side, position) of the lane's two reference samples and the weight of the second (tab4, sign-extended: bit 15 = side of the first)
-      const int e = (int)tab4[mode * 16 + gl];
+      // (side, position) of the lane's two reference samples and the weight of the second (tab4)
+      const uint32_t e = tab4[mode * 16 + gl];
       auto ref_at = [&](bool left, int k) -> const Pix* { // left: sample k of the left column (0 = beside the block's first row); else sample k of the row above (0 = corner)
         const int kk = imin_(k, left ? nL1 : nT1c);
         const Pix* const base = left ? lp : tc;
         return base + mul24(kk, left ? P : 1);
       };
-      const Pix* const q0 = ref_at(e < 0, e & 15);
-      const Pix* const q1 = ref_at((e & 16) != 0, (e >> 5) & 15);
+      const Pix* const q0 = ref_at(e > 0x7FFFu, (int)(e & 15));
+      const Pix* const q1 = ref_at((e & 0x4000u) != 0, (int)((e >> 4) & 15));
       const int maxv = (1 << bd) - 1;
       // what depends on the block before: the reference samples, the blend, the store
       auto execute = [&]() {
       const int r0 = *q0, r1 = *q1;
-      int v = blend32((e >> 9) & 31, r0, r1); // every angular mode; weight 0: a copy of r0
+      int v = blend32((int)((e >> 8) & 31), r0, r1); // every angular mode; weight 0: a copy of r0
       // planar, DC and - luma - the pure horizontal / vertical modes with their edge filters: one wave-uniform test keeps the
       // mode dispatch (five lane-mask regions) off the path of the three passes in four that hold none of them
-      if (ballot((op.y & OP_SPECIAL) != 0)) {
+      if (ballot((int)op.y < 0)) { // OP_SPECIAL
         const int bx = gl & 3, by = gl >> 2;
         if (mode == 0) { // planar: r0 = sample above, r1 = sample to the left
           const int tr = tc[imin_(5, nT1c)], bl = lp[mul24(imin_(4, nL1), P)];
@@ -706,7 +734,10 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
           v = on_edge ? clip3i(0, maxv, r0 + ((r1 - corner) >> 1)) : v;
         }
       }
-      v = (op.y & OP_CBF) ? clip3i(0, maxv, v + res_q) : v;
+      // (a prediction is inside the sample range: clipping it again changes nothing, so blocks without a residual add 0 -
+      //  the bit as a mask - instead of choosing between two values)
+      v = clip3i(0, maxv, v + (res_q & __builtin_amdgcn_sbfe((int)op.y, 10, 1)));
+      static_assert(OP_CBF == 1u << 10, "the mask above");
       lp[st_off] = (Pix)v; // (st_off: the lane's sample inside its block, by * pitch + 1 + bx)
       };
       if (PAIRS && NCL != 2) {
@@ -730,6 +761,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
 #endif
       const int bg = rfl((int)(__builtin_ctzll(todo) >> 4));
       todo &= ~(0xFFFFull << (bg * 16));
+      HM_T_COUNT(4);
       const int src = bg * 16;
       // the block's micro-op and its group's places in LDS, as scalars
       const uint32_t ox = (uint32_t)__builtin_amdgcn_readlane((int)op.x, src), oy = (uint32_t)__builtin_amdgcn_readlane((int)op.y, src);
@@ -745,7 +777,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       const int P = c == 0 ? P0 : P1;
       Pix* const gb = reinterpret_cast<Pix*>(lds + s_gb);                           // the chain's first plane (luma / Cb)
       Pix* const lp = gb + (ox & 0xFFFF);                                             // sample (x0-1, y0)
-      const Pix* const tp = reinterpret_cast<const Pix*>(lds + ((oy & OP_LINE) ? s_tl : s_gb)) + (ox >> 16); // sample (x0, y0-1)
+      const Pix* const tp = reinterpret_cast<const Pix*>(lds + ((oy & OP_LINE) ? s_tl : s_gb)) + (ox >> 16) + 1; // sample (x0, y0-1)
       Pix* const dst = lp + 1;
       const GLOBAL_AS int16_t* const gres = resid + oz;
       const int maxv = (1 << bd) - 1;
@@ -842,7 +874,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
           B.avail = ((ow & OPW_LEFT) ? nT : 0u) | ((uint32_t)B.aBL << 8) | ((ow & OPW_TOP) ? nT << 16 : 0u) | ((uint32_t)B.aTR << 24);
           B.x0 = (int)((ow >> 6) & 0x3C); B.y0 = (int)((ow >> 10) & 0x3C);
           B.u = gb + (c == 2 ? cr_off : 0);
-          B.top = reinterpret_cast<const Pix*>(lds + s_tl) - 1 + (c == 2 ? Wc + 4 : 0);
+          B.top = reinterpret_cast<const Pix*>(lds + s_tl) + (c == 2 ? Wc + 4 : 0);
 #if !defined(HM_Q_PROBE) || !(HM_Q_PROBE & 16)
           make_border<Pix, L2>(B, l_bA, strong, ln);
           WAVE_SYNC();
@@ -1177,10 +1209,14 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
     }
     np = 0; best = 0;
     // (workgroups of more than 8 waves: measured 40 ms instead of 27 - two of 80 KiB each do not share a CU)
+    // (gfx950 hands out its 160 KiB of LDS in granules of 320 dwords: a workgroup's bytes round up to a multiple of 1280 - measured
+    //  r04: 32720 bytes per workgroup put four workgroups on a CU, 31712 five; and four workgroups of 40960 - all 160 KiB - did
+    //  not share a CU either, so one granule is kept out of the sum)
+    constexpr int LDS_GRANULE = 1280, LDS_USABLE = 160 * 1024 - LDS_GRANULE;
     for (int k = 1; k <= 8; k++) {
-      const int bytes = C_SHARED + k * L.pic_bytes;
+      const int bytes = (C_SHARED + k * L.pic_bytes + LDS_GRANULE - 1) / LDS_GRANULE * LDS_GRANULE;
       if (bytes > 160 * 1024) break;
-      const int by_lds = 160 * 1024 / bytes, by_regs = cu_waves / k;
+      const int by_lds = LDS_USABLE / bytes, by_regs = cu_waves / k;
       const int per_cu = (by_lds < by_regs ? by_lds : by_regs) * k;
       if (per_cu > best) { best = per_cu; np = k; }
     }

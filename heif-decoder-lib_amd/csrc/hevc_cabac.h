@@ -147,8 +147,11 @@ class CabacDecoder {
     refill();
   }
   const uint8_t* position() const { return base_ + ((ptrdiff_t)pos_ - (bits_ >> 3)); }
-  // more than 8 bytes past the end of the data would have been read byte by byte (position P, rounded up to bytes)
-  bool overrun() const { return (ptrdiff_t)pos_ - (bits_ >> 3) > (ptrdiff_t)len_ + 8; }
+  // a decision has depended on bits behind the end of the data: the read position P (see above; it only grows) lies past
+  // the last bit.  No valid slice gets there - the last bit a terminating bin of value 1 reads is the stop bit -, and what a
+  // damaged one decodes to from there on is not defined by the data: this decoder reads zeros, the reference (its 16-bit
+  // refill, cabac.cc:276-296) whatever follows the NAL in its buffer.
+  bool overrun() const { return (ptrdiff_t)(8 * pos_) - bits_ > (ptrdiff_t)(8 * len_); }
 
   // One context-coded bin (9.3.4.3.2).  The MPS / LPS decision of a well-compressed stream is as good as random, so it
   // is taken with masks instead of a branch (a mispredicted branch per bin costs more than the arithmetic of both

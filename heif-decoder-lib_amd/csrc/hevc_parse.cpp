@@ -65,6 +65,7 @@ class DecoderEC {
     dec_.init(cur_, end_);
     started_ = true;
   }
+  // (checked once per CTB, behind its terminating bin: the read position only grows)
   void check() const
   {
     if (dec_.overrun()) throw ParseError(HM_ERR_BITSTREAM, "CABAC read past the end of the slice data");

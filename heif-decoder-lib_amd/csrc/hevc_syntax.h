@@ -346,7 +346,13 @@ class SliceWalker {
         pic_.uses_tq_bypass |= uses_tq_bypass_;
         break;
       }
-      if (ts >= N) throw ParseError(HM_ERR_BITSTREAM, "missing end_of_slice_segment_flag");
+      if (ts >= N) {
+        // the picture's last CTB without end_of_slice_segment_flag (damaged slice data): the reference notes "CTB outside
+        // image area" and keeps the picture, every CTB of which it has decoded (slice.cc:5107-5115) - so does this parser
+        pic_.uses_pcm |= uses_pcm_;
+        pic_.uses_tq_bypass |= uses_tq_bypass_;
+        break;
+      }
       const int nrs = pps_.CtbAddrTStoRS[ts];
       const bool new_tile = pps_.tiles_enabled && pps_.TileId[ts] != pps_.TileId[ts - 1];
       const bool new_row = pps_.entropy_coding_sync && sh_.num_entry_points > 0 && (nrs / W) != (rs / W);

@@ -489,7 +489,7 @@ enum { PATH_GEN = 0,  // the general path: reference samples gathered with subst
        PATH_S8 = 3,   // 8x8 luma, neighbours complete, smoothed reference samples (planar, modes 2 / 18 / 34)
        PATH_I16 = 4,  // 16x16, neighbours complete
        PATH_B4 = 5 }; // 4x4 on a border
-constexpr uint32_t OP_SPECIAL = 1u << 26; // planar, DC or - luma - pure horizontal / vertical prediction (the side-by-side 4x4 pass: modes with more than the two-sample blend)
+constexpr uint32_t OP_SPECIAL = 1u << 31; // (the sign bit: one compare) planar, DC or - luma - pure horizontal / vertical prediction (the side-by-side 4x4 pass: modes with more than the two-sample blend)
 constexpr int OP_NL1_SHIFT = 14, OP_NT1_SHIFT = 20; // last usable position of the left / top run (6 bits each)
 constexpr uint32_t OPW_LEFT = 1u << 16, OPW_TOP = 1u << 17, OPW_TL = 1u << 18;
 constexpr int OPW_BL_SHIFT = 19, OPW_TR_SHIFT = 23; // below-left / top-right counts in units of 4 (4 bits each)
@@ -511,7 +511,9 @@ __device__ __forceinline__ mop_u32x4 make_micro_op(uint32_t r0, unsigned a_left,
   const int x0 = x4 << 2;
   const int lp = mul24(y4 << 2, Pk) + UPAD + x0 - 1 + (c == 2 ? cr_off : 0);
   const bool on_line = y4 == 0;
-  const int tp = on_line ? x0 + (c == 2 ? Wc + 4 : 0) : lp - Pk + 1;
+  // the corner sample (x0 - 1, y0 - 1): in the CTU buffer, or - first block row of the CTU - in the sample line of the row
+  // above, counted from one sample BEFORE the CTU's first (the chain kernel keeps its line offset that way: no negative field)
+  const int tp = on_line ? x0 + (c == 2 ? Wc + 4 : 0) : lp - Pk;
   const uint32_t nL1 = (uint32_t)(nT - 1) + (aBL4 << 2), nT1 = (uint32_t)(nT - 1) + (aTR4 << 2);
   const bool interior = left && top && tl;
   // (8x8 luma reference samples are smoothed for planar and the three diagonals only: intrapred.h:192-214)

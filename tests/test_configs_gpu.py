@@ -197,6 +197,36 @@ def test_fused_tail_equals_separate_kernels(pkg, hm, shape, stages):
         assert np.array_equal(out[0][0], exp[:h, :w * 3])
 
 
+@pytest.mark.parametrize("slicing", [dict(slices=40), dict(slices=60, dependent=400, slice_lf_random=1, deblock_override=1, slice_sao_random=1, slice_qp_random=1),
+                                     dict(slices=60, pps_lf_across_slices_off=1, slice_lf_random=1)],
+                         ids=["slices", "slice_headers", "filters_stop_at_slices"])
+def test_fused_tail_with_several_slices(pkg, hm, slicing):
+    """pictures of several slices (own deblocking / SAO switches and offsets per slice) through the fused kernel: equal to the
+    separate kernels; fused whenever no CTB needs the per-sample SAO ring test (always when the filters cross slice borders)"""
+    import bench
+    import torch
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    cols, rows, w, h = 3, 2, 1500, 1000
+    made = list(bench.make_streams(pkg.capi, (7900000 + 13 * k for k in range(2 * cols * rows)), **slicing))
+    out, fused = [], []
+    for group in (0, -1):
+        gb = bench.GridBatch(pkg, dev, cols, rows, 512, w, h)
+        for j in range(2):
+            gb.add_image([b for _, b in made[j * cols * rows:(j + 1) * cols * rows]])
+        gb.finish(st, group)
+        gb.batch.execute(3, st)
+        torch.cuda.synchronize()
+        fused.append(gb.batch.tail_fused())
+        out.append([im["rgb"].cpu().numpy()[:h, :w * 3].copy() for im in gb.images])
+        gb.batch.close()
+    assert not fused[1]
+    if not slicing.get("pps_lf_across_slices_off"):
+        assert fused[0], "pictures whose filters cross slice borders take the fused tail"
+    for j in range(2):
+        assert np.array_equal(out[0][j], out[1][j]), f"image {j}: fused tail differs from the separate kernels"
+
+
 @pytest.mark.parametrize("groups", [2, 3, 8])
 def test_grouped_streams_equal_single_stream(pkg, hm, groups):
     """hm_batch_set_concurrency: the images of a step as `groups` groups on streams of their own - the same pixels as the

@@ -48,6 +48,39 @@ def test_truncated_and_corrupted_hevc_never_crashes(hm):
     assert ok + err == 150 * len(base) and err > 100
 
 
+def test_damaged_slice_data_is_accepted_only_where_the_reference_is_defined(hm):
+    """1-2 bit flips in the slice data (the classes of tools/fuzz_ref.py).  The parser takes a damaged slice exactly when what
+    the reference decodes from it is defined by the data: every CTB parsed from bits inside the slice data, a missing
+    end_of_slice_segment_flag at the picture's last CTB included (slice.cc:5107-5115: a warning, the picture kept).  Every
+    accepted stream must give the reference's picture (oracle/_ref where it is built); the others fail with HM_ERR_BITSTREAM."""
+    import numpy as np
+    import orc
+    rng = random.Random(5)
+    accepted = refused = 0
+    for name in ("ragged", "ctb64_wpp", "hi420_10", "slices_headers", "dense_lowqp"):
+        data = corpus.stream(name)
+        for _ in range(40):
+            b = bytearray(data)
+            for _ in range(rng.randrange(1, 3)):
+                b[rng.randrange(len(data) // 3, len(b))] ^= 1 << rng.randrange(8)
+            b = bytes(b)
+            try:
+                blob = hevcutil.parse(hm, b)
+            except RuntimeError as e:
+                refused += 1
+                assert "failed: -3:" in str(e) or "failed: -2:" in str(e), e  # HM_ERR_BITSTREAM (a flipped header bit may also name unsupported syntax)
+                continue
+            accepted += 1
+            if orc.have_ref():
+                mine, _ = orc.oracle_decode(blob, 3, crop=True)
+                try:
+                    ref, _ = orc.ref_decode(b, 0)
+                except RuntimeError:
+                    continue  # (the reference refuses what this parser takes: a damaged header field it checks and the product does not need)
+                assert len(mine) == len(ref) and all(np.array_equal(m, r) for m, r in zip(mine, ref)), f"{name}: accepted damaged stream decodes differently"
+    assert accepted >= 15 and refused >= 40, (accepted, refused)
+
+
 def test_truncated_heif_is_an_error(hm):
     data = heifwriter.write_heic(_tiles(1), (64, 64))
     for cut in (0, 4, 11, 40, len(data) // 2):

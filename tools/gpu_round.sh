@@ -9,6 +9,8 @@
 #   traffic      tools/pmc_traffic.sh (TCC FETCH_SIZE / WRITE_SIZE passes, 48 images) -> <tag>_pmc_traffic.json
 #   sq           tools/pmc_sq.sh (SQ issue / stall counters, 48 images) -> <tag>_pmc_sq.json
 #   timing       chain.hip built with -DHM_CHAIN_TIMING: where a wave's cycles go, at full load and for few pictures
+#   counts       the same build with -DHM_CHAIN_TIMING=2: events per wave instead of cycles (service phases, CTU flushes, window
+#                take-overs, 4x4 passes, wave-wide blocks, iterations)
 #   probes       VARIANTS / OBJ / MODE of tools/probe_chain.sh from the environment
 #   classes      tools/bench_classes.py (picture classes x batch sizes)
 #   sh:<file>    any other script, run with bash
@@ -31,8 +33,12 @@ for a in "$@"; do
            { echo "== full load (384 images)"; HM_CHAIN_TIMING_PRINT=1 timeout 600 python3 bench.py --quick --no-parity --steps 3 2>&1 | grep "k_chain phases" | tail -2
              echo "== few pictures"; HM_CHAIN_TIMING_PRINT=1 timeout 600 python3 tools/few_pictures_probe.py 2>&1 | grep "k_chain phases" | sort | uniq -c | sort -rn | head -6; } > $log 2>&1
            (cd heif-decoder-lib_amd/csrc && rm -f build/hip_chain.o && make >/dev/null 2>&1); cat $log ;;
+  counts)  (cd heif-decoder-lib_amd/csrc && rm -f build/hip_chain.o && make HIPFLAGS="--offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fvisibility=hidden -Wall -Wno-unused-function -I../../include -I. -I/opt/rocm/include -DHM_CHAIN_TIMING=2" >/dev/null 2>&1)
+           { echo "== full load (384 images): service phases, CTU flushes, window take-overs, 4x4 passes, wave-wide blocks, iterations"; HM_CHAIN_TIMING_PRINT=1 timeout 600 python3 bench.py --quick --no-parity --steps 3 2>&1 | grep "k_chain phases" | tail -1; } > $log 2>&1
+           (cd heif-decoder-lib_amd/csrc && rm -f build/hip_chain.o && make >/dev/null 2>&1); cat $log ;;
   probes)  tools/probe_chain.sh > $log 2>&1; cat $log ;;
-  classes) timeout 1200 python3 tools/bench_classes.py > $log 2>&1; tail -30 $log ;;
+  classes) { echo "== 1536 tiles per class"; timeout 1200 python3 tools/bench_classes.py 2>/dev/null | tr -d '\n' | sed 's/},/},\n/g'; echo
+             echo "== 18432 tiles per class"; HM_CLASS_TILES=18432 timeout 1200 python3 tools/bench_classes.py 2>/dev/null | tr -d '\n' | sed 's/},/},\n/g'; echo; } > $log 2>&1; cat $log ;;
   sh:*)    bash ${a#sh:} > $log 2>&1; tail -30 $log ;;
   *)       echo "unknown action $a" ;;
   esac

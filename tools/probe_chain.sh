@@ -1,12 +1,13 @@
 #!/bin/bash
 # A/B builds of one kernel source on the GPU box.  Every entry of VARIANTS ('|'-separated) is a set of extra compiler flags
 # ("-DHM_Q_PROBE=n" compiles parts of k_chain's loop out - pictures wrong, parity gate off -: 1 no 4x4 path, 2 no wave-wide
-# path, 4 wave-wide path without prediction, 512 no residual of the large blocks; "-DHM_WPE=n" sets the waves per SIMD the
+# path, 4 wave-wide path without prediction, 512 no residual of the large blocks, 1024 the CTU flush without its stores to the picture, 2048 no residual loads of the
+# 8x8 blocks, 4096 windows of micro-ops never reloaded; "-DHM_WPE=n" sets the waves per SIMD the
 # register allocation aims for; "-DHM_T_PROBE=n" the same idea in filters.hip).
 #   OBJ=chain|filters|residual   the object rebuilt per variant (default chain)
 #   MODE=bench|few|counters      bench: kernel times of `bench.py --quick` (default); few: tools/few_pictures_probe.py
 #                                (32 large pictures per class); counters: SQ instruction counts of KERNEL per tile
-#                                (rocprofv3 --pmc, 48 images)
+#                                (rocprofv3 --pmc, 48 images; PMC="..." replaces the counter list)
 # usage (repo root): VARIANTS="-DHM_Q_PROBE=1|-DHM_Q_PROBE=2" [OBJ=..] [MODE=..] tools/probe_chain.sh [bench args]
 OBJ=${OBJ:-chain}; MODE=${MODE:-bench}; export KERNEL=${KERNEL:-k_chain}
 export TMPDIR=/tmp
@@ -23,7 +24,7 @@ for v in "${VS[@]}"; do
     (cd ../.. && python3 tools/few_pictures_probe.py 2>/dev/null | tail -1) ;;
   counters)
     out=/tmp/pmcv; rm -rf $out; mkdir -p $out
-    (cd ../.. && rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $out --output-format csv -- python3 bench.py --no-parity --quick --steps 2 --warmup 1 --images 48 > $out/log 2>&1)
+    (cd ../.. && rocprofv3 --kernel-trace --pmc ${PMC:-SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE} -d $out --output-format csv -- python3 bench.py --no-parity --quick --steps 2 --warmup 1 --images 48 > $out/log 2>&1)
     python3 - $out <<'PY'
 import csv, glob, os, sys
 from collections import defaultdict
