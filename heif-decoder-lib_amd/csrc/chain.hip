@@ -138,14 +138,20 @@ typedef uint32_t c_u32x2 __attribute__((ext_vector_type(2)));
 #endif
 template <typename Pix, int LOG2_CTB, bool PAIRS>
 constexpr int chain_waves_per_simd = (sizeof(Pix) == 1 && !PAIRS) ? (LOG2_CTB <= 5 ? 5 : HM_WPE_CTB64) : 4;
+// MODE of the kernel: 0 a wave per picture; else PAIRS (waves that hand rows over to each other through HBM) with 4 chains per
+// wave (1: a pair of CTU rows), 2 chains (2: one CTU row) or 1 chain (3: one chain of a row) - the chains per wave as a compile-time
+// constant: the multi-record bookkeeping of the cuts with fewer than four chains sits on the critical path of a wave that is
+// alone on its SIMD, and with a run-time count it was loops, selects and a dozen spilled scalar registers (r04)
+constexpr int chain_mode_ncl(int mode) { return mode <= 1 ? 2 : (mode == 2 ? 1 : 0); }
 #ifdef HM_WPE
 #define HM_CHAIN_ATTR __attribute__((amdgpu_waves_per_eu(HM_WPE, HM_WPE)))
 #else
-#define HM_CHAIN_ATTR __attribute__((amdgpu_waves_per_eu(chain_waves_per_simd<Pix, LOG2_CTB, PAIRS>, chain_waves_per_simd<Pix, LOG2_CTB, PAIRS>)))
+#define HM_CHAIN_ATTR __attribute__((amdgpu_waves_per_eu(chain_waves_per_simd<Pix, LOG2_CTB, (MODE != 0)>, chain_waves_per_simd<Pix, LOG2_CTB, (MODE != 0)>)))
 #endif
-template <typename Pix, int LOG2_CTB, bool PAIRS>
+template <typename Pix, int LOG2_CTB, int MODE>
 __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* __restrict__ pics, int n_pics, CLayout L, uint32_t* __restrict__ sync, uint32_t* __restrict__ err_word)
 {
+  constexpr bool PAIRS = MODE != 0;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   // records per window of micro-ops: the few-pictures cuts (PAIRS) take windows of 16 - their waves have LDS and registers to
   // spare, a chain executes up to five records per iteration there and a window's end cuts such a run short
@@ -275,9 +281,9 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   // cuts; only reading the reference samples, the blend and the store run one record after the other (phase C below).  In
   // these cuts a wave is alone on its SIMD and an iteration is a chain of latencies, not of instructions: what counts is the
   // number of iterations per record.  All groups of a chain hold identical chain state (the same loads, the same updates).
-  const int NCL = !PAIRS ? 2 : (L.split_kinds ? 0 : (RPW == 1 ? (mono ? 0 : 1) : 2)); // log2 of the chains per wave
-  const int SUB = 4 >> NCL;                                                              // records of a chain per iteration
-  const unsigned long long main_mask = NCL == 2 ? ~0ull : (NCL == 1 ? 0xFFFFFFFFull : 0xFFFFull); // the groups with offset 0
+  constexpr int NCL = chain_mode_ncl(MODE); // log2 of the chains per wave (the launcher: split kinds or one row of a monochrome picture 0, one row 1, else 2)
+  constexpr int SUB = 4 >> NCL;             // records of a chain per iteration
+  constexpr unsigned long long main_mask = NCL == 2 ? ~0ull : (NCL == 1 ? 0xFFFFFFFFull : 0xFFFFull); // the groups with offset 0
   // group -> (chain kind, row slot): luma / chroma of two rows, or luma of four rows (monochrome)
   auto group_kind = [&](int gg) { return mono ? 0 : (PAIRS && L.split_kinds ? kind_sel : (gg & 1)); };
   auto group_slot = [&](int gg) { return mono ? gg : (gg >> 1); };
@@ -645,7 +651,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       // interior 4x4 block).  Without loops or branches: on the scalar unit a taken branch costs more than the arithmetic of both
       // chains, and this sits on the critical path of every iteration of a wave that is alone on its SIMD.
       // (one chain: its records are the groups 0 1 2 3; two chains: chain c's are the groups c and c + 2)
-      const bool two = NCL == 1;
+      constexpr bool two = NCL == 1;
       auto of_chain = [&](uint32_t m, int c) { return two ? (((m >> c) & 1u) | (((m >> (c + 2)) & 1u) << 1)) : (c ? 0u : m); };
       uint32_t run[2], big[2];
 #pragma unroll
@@ -1185,25 +1191,31 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   // both limit whole workgroups
   const int inst = log2_ctb * 2 + (pb - 1) - 8;
   const void* fn = nullptr;
-  int np = 0, best = 0;
+  int np = 0, best = 0, mode = 0;
+  auto fn_of = [](auto pix, auto l2c, int m) -> const void* {
+    typedef decltype(pix) P;
+    constexpr int L2 = decltype(l2c)::value;
+    switch (m) {
+      case 0: return reinterpret_cast<const void*>(k_chain<P, L2, 0>);
+      case 1: return reinterpret_cast<const void*>(k_chain<P, L2, 1>);
+      case 2: return reinterpret_cast<const void*>(k_chain<P, L2, 2>);
+      default: return reinterpret_cast<const void*>(k_chain<P, L2, 3>);
+    }
+  };
   auto pick = [&](bool prs) -> bool {
-    switch (inst * 2 + (prs ? 1 : 0)) {
-      case 0: fn = reinterpret_cast<const void*>(k_chain<uint8_t, 4, false>); break;
-      case 1: fn = reinterpret_cast<const void*>(k_chain<uint8_t, 4, true>); break;
-      case 2: fn = reinterpret_cast<const void*>(k_chain<uint16_t, 4, false>); break;
-      case 3: fn = reinterpret_cast<const void*>(k_chain<uint16_t, 4, true>); break;
-      case 4: fn = reinterpret_cast<const void*>(k_chain<uint8_t, 5, false>); break;
-      case 5: fn = reinterpret_cast<const void*>(k_chain<uint8_t, 5, true>); break;
-      case 6: fn = reinterpret_cast<const void*>(k_chain<uint16_t, 5, false>); break;
-      case 7: fn = reinterpret_cast<const void*>(k_chain<uint16_t, 5, true>); break;
-      case 8: fn = reinterpret_cast<const void*>(k_chain<uint8_t, 6, false>); break;
-      case 9: fn = reinterpret_cast<const void*>(k_chain<uint8_t, 6, true>); break;
-      case 10: fn = reinterpret_cast<const void*>(k_chain<uint16_t, 6, false>); break;
-      case 11: fn = reinterpret_cast<const void*>(k_chain<uint16_t, 6, true>); break;
+    // the kernel's MODE: the chains a wave works on (k_chain: NCL) follow from the cut in L
+    mode = !prs ? 0 : (L.split_kinds ? 3 : (L.rows_per_wave == 1 ? (mono ? 3 : 2) : 1));
+    switch (inst) {
+      case 0: fn = fn_of(uint8_t(), std::integral_constant<int, 4>(), mode); break;
+      case 1: fn = fn_of(uint16_t(), std::integral_constant<int, 4>(), mode); break;
+      case 2: fn = fn_of(uint8_t(), std::integral_constant<int, 5>(), mode); break;
+      case 3: fn = fn_of(uint16_t(), std::integral_constant<int, 5>(), mode); break;
+      case 4: fn = fn_of(uint8_t(), std::integral_constant<int, 6>(), mode); break;
+      case 5: fn = fn_of(uint16_t(), std::integral_constant<int, 6>(), mode); break;
       default: return false;
     }
-    static int cu_waves_of[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // (per instantiation; a benign race: every thread computes the same value)
-    int& cu_waves = cu_waves_of[inst * 2 + (prs ? 1 : 0)];
+    static int cu_waves_of[24] = {}; // (per instantiation; a benign race: every thread computes the same value)
+    int& cu_waves = cu_waves_of[inst * 4 + mode];
     if (cu_waves == 0) {
       hipFuncAttributes fa;
       int w = 16;
