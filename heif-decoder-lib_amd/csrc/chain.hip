@@ -205,24 +205,29 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     tab4[i] = (uint16_t)(k0 | (k1 << 4) | (f << 8) | (s1 << 14) | (s0 << 15));
   }
   // ---- this wave's task ----
-  int pic_index, pair_index = 0, kind_sel = -1; // (kind_sel: the only chain kind this wave works on, -1: both)
+  // PAIRS: a ticket per WORKGROUP - the order in which the workgroups of the launch START decides who works on what, so a wave
+  // only ever waits for rows that a wave of its own workgroup (resident with it) or of an earlier - running or finished -
+  // workgroup holds, whatever the order of dispatch.  The waves of a workgroup take consecutive tasks: consecutive bands of a
+  // picture, which hand their rows over through the workgroup's LDS instead of HBM (below: lds_above / lds_below).
+  uint32_t* const wg_ticket = reinterpret_cast<uint32_t*>(lds + 192); // (spare bytes of the small tables)
+  int pic_index = 0, pair_index = 0, kind_sel = -1; // (kind_sel: the only chain kind this wave works on, -1: both)
   if (PAIRS) {
-    // a ticket: the order in which the waves of the launch START decides who works on what, so a wave only ever waits
-    // for rows that an earlier - running or finished - wave holds, whatever the order of dispatch
-    uint32_t t = 0;
-    if (lane == 0) t = __hip_atomic_fetch_add(sync + SYNC_TICKET, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    t = (uint32_t)rfl((int)t);
-    const uint32_t per_pic = (uint32_t)L.bands_per_pic << L.split_kinds;
-    pic_index = (int)(t / per_pic);
-    const uint32_t task = t - (uint32_t)pic_index * per_pic;
-    pair_index = (int)(task >> L.split_kinds); // the band of rows
-    kind_sel = L.split_kinds ? (int)(task & 1) : -1;
+    if (tid == 0) *wg_ticket = __hip_atomic_fetch_add(sync + SYNC_TICKET, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   else pic_index = blockIdx.x * (int)(blockDim.x >> 6) + wave;
   uint8_t* const pbase = lds + C_SHARED + (size_t)wave * L.pic_bytes;
   int* const progress = reinterpret_cast<int*>(pbase); // [2][C_PROG]: finished CTUs of the rows in flight, per chain kind
   if (lane < 2 * C_PROG) progress[lane] = 0;
   __syncthreads();
+  const int wg_waves = PAIRS ? (int)(blockDim.x >> 6) : 0;
+  if (PAIRS) {
+    const uint32_t t = (uint32_t)rfl((int)*wg_ticket) * (uint32_t)wg_waves + (uint32_t)wave;
+    const uint32_t per_pic = (uint32_t)L.bands_per_pic << L.split_kinds;
+    pic_index = (int)(t / per_pic);
+    const uint32_t task = t - (uint32_t)pic_index * per_pic;
+    pair_index = (int)(task >> L.split_kinds); // the band of rows
+    kind_sel = L.split_kinds ? (int)(task & 1) : -1;
+  }
   if (pic_index >= n_pics) return;
 
   const hm_dev_pic dp = pics[pic_index];
@@ -343,7 +348,18 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   // band the group has worked on (the rows of a wave's consecutive bands may be a multiple of 8 apart)
   int pbank = 0;
   auto prog_index = [&](int r, int slot) { return PAIRS ? pbank * 4 + (slot & 3) : (r & (C_PROG - 1)); };
-  bool from_hbm = PAIRS && my_slot == 0 && pidx > 0; // the row above belongs to another wave
+  // One CTU row per wave, a wave per band: the band above is the task S before this one, the band below the task S behind it -
+  // waves of this workgroup unless the workgroup ends in between.  Such neighbours skip HBM: the wave above writes the bottom
+  // sample line of every CTU it finishes straight into this wave's sample line (the place the copy from the hand-over line
+  // would fill) and its progress into this wave's counter for "the row above" - exactly what a group of a wave that works
+  // on two rows does for the group below it, one pic_bytes further.  (r04: the trip through HBM - drain the stores, flag,
+  // poll, copy the line - was ~40 % of a CTU step on the critical path of the few-pictures cuts.)
+  const int S = PAIRS ? 1 << L.split_kinds : 0;
+  const bool lds_rows = PAIRS && MODE >= 2 && L.bands_per_pic == L.passes; // (MODE >= 2: RPW == 1)
+  const bool lds_above = lds_rows && pair_index > 0 && wave >= S;
+  const bool lds_below = lds_rows && wave + S < wg_waves; // (if there is a band below at all)
+  uint8_t* const pbase_below = PAIRS ? pbase + S * L.pic_bytes : pbase;
+  bool from_hbm = PAIRS && my_slot == 0 && pidx > 0 && !lds_above; // the row above belongs to a wave of another workgroup
   auto load_window = [&](uint32_t w) {
     if constexpr (WLOG == 4) { // a record per lane
       uint32_t idx = (w << 4) + (uint32_t)gl;
@@ -412,8 +428,10 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         const int src = fg * 16;
         const int s_row = __builtin_amdgcn_readlane(row, src), s_cx = __builtin_amdgcn_readlane(cx, src);
         const int fkind = group_kind(fg);
-        Pix* const lw = line_of(fkind, group_slot(fg)); // s_row % NR
-        const bool keep_line = !PAIRS || RPW > 1;
+        const bool to_lds_below = lds_below && s_row + 1 < ctb_h; // (RPW == 1: the band below is a wave of this workgroup)
+        Pix* lw = line_of(fkind, group_slot(fg)); // s_row % NR
+        if (to_lds_below) lw = reinterpret_cast<Pix*>(pbase_below + (fkind ? L.off_lines_c : L.off_lines_l)) + 4; // (its only line: line_of(kind, 0))
+        const bool keep_line = !PAIRS || RPW > 1 || to_lds_below;
         auto flush_plane = [&](auto bw_c, Pix* u, int P, Pix* line, uint8_t* plane, int pitch, int bh, int pw, int ph) {
           constexpr int BW = decltype(bw_c)::value;
           constexpr int PPW = 4 / sizeof(Pix), WPR = BW / PPW; // samples per 32-bit word, words per row
@@ -461,7 +479,12 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         // read by the chain of the row below, a group of this wave (LDS traffic of a wave is in order)
         const int s_prog = PAIRS ? __builtin_amdgcn_readlane(pbank, src) * 4 + group_slot(fg) : (s_row & (C_PROG - 1));
         if (lane == 0) __hip_atomic_store(progress + fkind * C_PROG + s_prog, s_cx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (PAIRS && group_slot(fg) == RPW - 1 && s_row + 1 < ctb_h) {
+        // ... or a wave of this workgroup: its counter of the row above (prog_index(row - 1, -1) of a wave's first band)
+        // (the fault injection of the tests - a first band that never announces its progress - applies to either way: the wave below
+        //  then runs out of its iteration budget, flags the launch and leaves)
+        if (to_lds_below && lane == 0 && !(L.test_stall && __builtin_amdgcn_readlane(pidx, src) == 0))
+          __hip_atomic_store(reinterpret_cast<int*>(pbase_below) + fkind * C_PROG + 3, s_cx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (PAIRS && !to_lds_below && group_slot(fg) == RPW - 1 && s_row + 1 < ctb_h) {
           // ... or, for the pair's last row, the first row of the pair below: another wave, anywhere on the chip.  The
           // CTU's bottom sample line goes to the pair's hand-over line with agent-scope stores; once they have left this
           // wave (vmcnt 0) the word that announces them follows
@@ -490,7 +513,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
             tl_off = lr_off;
             // the group's next row: NR further (a wave per picture), or in the wave's next band (PAIRS)
             row += PAIRS ? RPW * W : NR;
-            if (PAIRS) { pidx += W; pbank ^= 1; from_hbm = my_slot == 0; hbm_have = 0; hbm_polls = 0; }
+            if (PAIRS) { pidx += W; pbank ^= 1; from_hbm = my_slot == 0 && !lds_above; hbm_have = 0; hbm_polls = 0; }
             if (row < ctb_h) row_start();
             else st = ST_DONE;
           }
@@ -572,6 +595,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
           if (ballot(st == ST_RUN) == 0) __builtin_amdgcn_s_sleep(8); // every chain of the wave waits
         }
       }
+      if (PAIRS && lds_above && ballot(st == ST_RUN) == 0) __builtin_amdgcn_s_sleep(2); // (every chain waits for the wave above: leave the SIMD to it)
       if (ballot(st != ST_DONE) == 0) break;
       HM_MARK("R_begin");
       // ---- R: the micro-ops and 4x4 residuals of the next window of records, for every group that has entered it ----
@@ -1266,9 +1290,16 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   L.bands_per_pic = share && share < L.passes ? share : L.passes;
   const size_t sync_need = sync_words(L.passes);
   static const int force_np = [] { const char* e = getenv("HM_CHAIN_NP"); return e ? atoi(e) : 0; }(); // (tuning aid, read once)
-  if (force_np > 0 && force_np <= 16 && C_SHARED + force_np * L.pic_bytes <= 160 * 1024) np = force_np;
   const long n_waves = pairs ? ((long)n_pics * L.bands_per_pic) << L.split_kinds : (long)n_pics;
-  while (np > 1 && (long)np * 256 > n_waves) np--; // few waves: spread them over the CUs first
+  // A wave per CTU row (or per chain of one): neighbouring rows in one workgroup hand over through LDS (k_chain: lds_above) -
+  // the more waves a workgroup holds, the fewer hand-overs go through HBM.  Eight: one in eight (sixteen measured no better).
+  const bool lds_rows = pairs && L.rows_per_wave == 1 && L.bands_per_pic == L.passes;
+  if (lds_rows) {
+    np = 8;
+    while (np > 1 && C_SHARED + np * L.pic_bytes > 64 * 1024) np--;
+  }
+  else while (np > 1 && (long)np * 256 > n_waves) np--; // few waves: spread them over the CUs first
+  if (force_np > 0 && force_np <= 16 && C_SHARED + force_np * L.pic_bytes <= 160 * 1024) np = force_np;
   const int lds_bytes = C_SHARED + np * L.pic_bytes;
   static const int debug = [] { const char* e = getenv("HM_CHAIN_DEBUG"); return e ? atoi(e) : 0; }();
   if (debug) fprintf(stderr, "[k_chain] %d pictures, %ld waves (%s), %d bytes of LDS per wave, %d waves per workgroup, %d waves per CU\n", n_pics, n_waves,
