@@ -994,44 +994,40 @@ def config4(torch, pkg, dev, st):
         ims.append((y, cb, cr, rgb))
     batch.upload(st)
     desc = capi.ColourDesc(W, H, 10, 2, 1, 9, 9, 0, capi.HM_OUT_RRGGBB_LE, ys, cs, cs, os_)
-
-    def step():
-        batch.execute(3, st)
-        for (y, cb, cr, rgb) in ims:
-            capi.check(L.hm_colour_convert(C.byref(desc), y.data_ptr(), cb.data_ptr(), cr.data_ptr(), rgb.data_ptr(), st))
-
+    # the conversion attached to the batch (hm_batch_set_colour): one execute is the whole hot path, and - r04 - this class
+    # takes the fused float tail (filters.hip k_tailf: deblocking + SAO + paste + float matrix + repack in one kernel)
+    PtrArr = C.c_void_p * n
+    ptrs = [PtrArr(*[im[k].data_ptr() for im in ims]) for k in range(4)]
+    batch.set_colour(desc, n, *ptrs, 0)
     for _ in range(2):
-        step()
+        batch.execute(3, st)
     batch.set_profiling(5)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    col_ms = 0.0
-    evs = []
     for i in range(5):
         batch.execute(3, st)
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for (y, cb, cr, rgb) in ims:
-            capi.check(L.hm_colour_convert(C.byref(desc), y.data_ptr(), cb.data_ptr(), cr.data_ptr(), rgb.data_ptr(), st))
-        b.record()
-        evs.append((a, b))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     k = [0.0, 0.0, 0.0, 0.0, 0.0]
     for i in range(5):
         ms = batch.timings5_ms(i)
         k = [k[q] + ms[q] / 5 for q in range(5)]
-    col_ms = sum(a.elapsed_time(b) for a, b in evs) / 5
     batch.check()
+    fused = bool(batch.tail_fused())
     mp = n * W * H / 1e6
     stream_b, sample_b = batch.algorithmic_bytes()
     batch.close()
-    return {"MP_per_s": round(mp * 5 / dt, 1), "images_per_step": n,
-            "kernels_ms_per_step": {"k_residual": round(k[4], 3), KERNEL_NAMES[0]: round(k[0], 3), "k_deblock": round(k[1], 3), "k_sao_paste": round(k[2], 3), "k_ycbcr_float(colour)": round(col_ms, 3)},
-            "colour_GBps": round(10.0 * n * W * H / col_ms / 1e6, 1), "colour_frac_of_hbm_peak": round(10.0 * n * W * H / col_ms / 1e6 / HBM_PEAK_GBPS, 4),
+    if fused:
+        kernels = {"k_residual": round(k[4], 3), KERNEL_NAMES[0]: round(k[0], 3), "k_tailf(deblock+sao+paste+float colour)": round(k[2], 3)}
+        tail_ms, tail_bytes = k[2], 10.0 * n * W * H  # 4 B/px of samples in + 6 B/px of pixels out
+    else:
+        kernels = {"k_residual": round(k[4], 3), KERNEL_NAMES[0]: round(k[0], 3), "k_deblock": round(k[1], 3), "k_sao_paste": round(k[2], 3), "k_ycbcr_float(colour)": round(k[3], 3)}
+        tail_ms, tail_bytes = k[3], 10.0 * n * W * H
+    return {"MP_per_s": round(mp * 5 / dt, 1), "images_per_step": n, "tail_fused": fused,
+            "kernels_ms_per_step": kernels,
+            "tail_GBps": round(tail_bytes / tail_ms / 1e6, 1) if tail_ms > 0 else None, "tail_frac_of_hbm_peak": round(tail_bytes / tail_ms / 1e6 / HBM_PEAK_GBPS, 4) if tail_ms > 0 else None,
             "command_stream_bytes_per_pixel": round(stream_b / (n * W * H), 3),
-            "note": "10-bit 4:2:2 2048x1536 (seed 4220010) -> RRGGBB_LE, 4 B/px in + 6 B/px out for the colour kernel; K clock"}
+            "note": "10-bit 4:2:2 2048x1536 (seed 4220010) -> RRGGBB_LE, K clock; the tail reads 4 B/px of samples and writes 6 B/px of pixels (fused: once each)"}
 
 
 def grid_tile_seeds(tile_rows, cols):

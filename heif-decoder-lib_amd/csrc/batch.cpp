@@ -143,6 +143,9 @@ struct hm_batch {
   int tail_state = 0;
   int tail_bpp = 3;
   int tail_coef[4] = {0, 0, 0, 0};
+  int tail_kind = 0;              // fused tail: 0 = k_tail420 (integer 4:2:0 chain), 1 = k_tailf (float chain)
+  float tail_cf[4] = {0, 0, 0, 0}; // ... its matrix coefficients and mode
+  int tail_mode = 0;
   DeviceBuffer d_tail;
   // synchronisation words of the reconstruction's wave-per-row-pair mode: sync_stride words per picture, so that the
   // launch over pictures [i0, i0 + n) owns the words from i0 * sync_stride on (launches of disjoint picture ranges - chunks,
@@ -219,8 +222,16 @@ static int decide_tail(hm_batch* b)
   if (off || !b->colour || b->colour_chunk < 0 || b->classes.size() != 1) return HM_OK;
   const Class& c = b->classes[0];
   const hm_colour_desc& d = b->colour_desc;
-  if (c.bit_depth != 8 || c.chroma_format != 1 || c.rare) return HM_OK;
-  if (hm_colour_pipeline(&d) != HM_PIPE_INT420 || (d.out_format != HM_OUT_RGB && d.out_format != HM_OUT_RGBA)) return HM_OK;
+  if (c.rare || (c.chroma_format != 1 && c.chroma_format != 2)) return HM_OK;
+  // which fused kernel: the integer chain of 8-bit 4:2:0 (k_tail420), or - r04 - the float operation on the image's own planes
+  // (k_tailf: 10 / 12 bit, 4:2:2, limited range; RGB24 / RGBA32 / RRGGBB)
+  int kind = -1, fmode = 0;
+  float fcf[4] = {0, 0, 0, 0};
+  if (c.bit_depth == 8 && c.chroma_format == 1 && hm_colour_pipeline(&d) == HM_PIPE_INT420 && (d.out_format == HM_OUT_RGB || d.out_format == HM_OUT_RGBA)) kind = 0;
+  else if (d.bit_depth == c.bit_depth && d.chroma == (c.chroma_format == 1 ? HM_CHROMA_420 : HM_CHROMA_422) &&
+           (d.out_format == HM_OUT_RGB || d.out_format == HM_OUT_RGBA || d.out_format == HM_OUT_RRGGBB_BE || d.out_format == HM_OUT_RRGGBB_LE) &&
+           hm_colour_float_chain(&d, fcf, &fmode) == 1) kind = 1;
+  if (kind < 0) return HM_OK;
   const int bpp = hm_out_bytes_per_pixel(d.out_format);
   const int n = (int)c.items.size(), n_img = (int)b->col_y.size();
   if (n_img <= 0 || n % n_img || (d.out_stride % 16)) return HM_OK;
@@ -255,8 +266,18 @@ static int decide_tail(hm_batch* b)
   hm_ycbcr_coefficients(d.has_nclx, d.matrix, d.primaries, cf);
   for (int i = 0; i < 4; i++) b->tail_coef[i] = (int)std::lround(256 * cf[i]); // yuv2rgb.cc:336-339
   b->tail_bpp = bpp;
+  b->tail_kind = kind;
+  for (int i = 0; i < 4; i++) b->tail_cf[i] = fcf[i];
+  b->tail_mode = fmode;
   b->tail_state = 2;
   return HM_OK;
+}
+
+// the fused tail of m pictures (descriptors dk, destinations td) of the batch's only class
+static int launch_tail(const hm_batch* b, const Class& c, const hm_dev_pic* dk, const void* td, int m, int stages, hipStream_t s)
+{
+  if (b->tail_kind == 1) return hm_launch_tailf(dk, td, m, c.max_w, c.max_h, &b->colour_desc, b->tail_cf, b->tail_mode, stages, s);
+  return hm_launch_tail420(dk, td, m, c.max_w, c.max_h, c.log2_ctb, b->tail_bpp, b->tail_coef, stages, s);
 }
 
 extern "C" {
@@ -591,7 +612,7 @@ int hm_batch_execute(hm_batch* b, int stages, void* stream)
         const int si = g % ns;
         hipStream_t sg = si ? b->aux_streams[(size_t)si - 1] : s;
         int rc = launch_recon(dk, m, c, sg, b->sync_region(dk, m));
-        if (!rc) rc = hm_launch_tail420(dk, td + (size_t)i0 * per_img, m, c.max_w, c.max_h, c.log2_ctb, b->tail_bpp, b->tail_coef, stages, sg);
+        if (!rc) rc = launch_tail(b, c, dk, td + (size_t)i0 * per_img, m, stages, sg);
         if (rc) { join(); return rc; }
       }
       if ((he = join()) != hipSuccess) return hm_check_hip(he, "join of the launch streams");
@@ -604,7 +625,7 @@ int hm_batch_execute(hm_batch* b, int stages, void* stream)
     if (rc) return rc;
     mark(0);
     if (b->tail_state == 2) { // one kernel for everything behind the reconstruction (timeline: the SAO + paste slot)
-      if ((rc = hm_launch_tail420(dc, b->d_tail.p, n, c.max_w, c.max_h, c.log2_ctb, b->tail_bpp, b->tail_coef, stages, s))) return rc;
+      if ((rc = launch_tail(b, c, dc, b->d_tail.p, n, stages, s))) return rc;
       mark(2);
       b->exec_count++;
       return HM_OK;
@@ -712,7 +733,7 @@ int hm_batch_upload_execute(hm_batch* b, int stages, int chunks, void* copy_stre
     const int m = i1 - i0;
     if ((rc = launch_recon(dc, m, c, s, b->sync_region(dc, m)))) return rc;
     if (b->colour && b->tail_state == 2) {
-      if ((rc = hm_launch_tail420(dc, (const uint8_t*)b->d_tail.p + sizeof(TailDstHost) * (size_t)i0, m, c.max_w, c.max_h, c.log2_ctb, b->tail_bpp, b->tail_coef, stages, s))) return rc;
+      if ((rc = launch_tail(b, c, dc, (const uint8_t*)b->d_tail.p + sizeof(TailDstHost) * (size_t)i0, m, stages, s))) return rc;
     }
     else {
       if ((stages & 1) && (rc = hm_launch_deblock(dc, m, c.max_w4, c.max_h4, c.chroma_format, c.bit_depth, c.rare, s))) return rc;

@@ -193,6 +193,25 @@ int hm_colour_pipeline(const hm_colour_desc* d)
   return HM_PIPE_GENERIC;
 }
 
+// Is the chain of this request ONE launch of the float operation on the image's own planes (no depth change or up-sampling
+// in front of it, the image's own nclx - what convert_planes() ends in for such a request)?  Then: its matrix coefficients
+// and mode, for a kernel that runs the operation itself (filters.hip: k_tailf).  1 / 0, negative status on error.
+int hm_colour_float_chain(const hm_colour_desc* d, float cf[4], int* mode)
+{
+  hm_colour_plan plan;
+  const int rc = plan_for(d, &plan);
+  if (rc) return rc;
+  if (plan.core == HM_CORE_MONO || plan.core == HM_CORE_INT420 || plan.mono_expand || plan.pre || plan.bilinear || plan.core_step > 0) return 0;
+  const bool out8 = d->out_format == HM_OUT_RGB || d->out_format == HM_OUT_RGBA;
+  const int kernel_post = (out8 && d->bit_depth > 8) ? HM_DEPTH_TO_SDR : ((!out8 && d->bit_depth == 8) ? HM_DEPTH_TO_HDR : HM_DEPTH_NONE);
+  if (kernel_post != plan.post) return 0;
+  hm_ycbcr_coefficients(d->has_nclx, d->matrix, d->primaries, cf);
+  const int m = d->has_nclx ? d->matrix : 2;
+  const bool full = d->has_nclx ? d->full_range != 0 : true;
+  *mode = m == 0 ? (full ? 1 : 2) : (m == 8 ? 3 : 0);
+  return 1;
+}
+
 int hm_colour_convert(const hm_colour_desc* d, const void* d_y, const void* d_cb, const void* d_cr, void* d_out, void* stream)
 {
   hm_colour_plan plan;

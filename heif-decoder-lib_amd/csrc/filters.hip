@@ -27,6 +27,7 @@
 
 #include "hm_device.h"
 #include "hm_internal.h"
+#include "colour_float.h"
 
 namespace {
 
@@ -1173,6 +1174,205 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_tailf: the fused tail of the classes whose colour chain is the reference's FLOAT operation (yuv2rgb.cc:79-254 + the
+// repack that follows it) - 10 / 12-bit 4:2:0 and 4:2:2 (BASELINE config 4: 10-bit 4:2:2 -> RRGGBB) and the 8-bit pictures
+// the integer 4:2:0 chain does not take (4:2:2, limited range).  Same structure as k_tail420 - deblocking windows into an
+// LDS tile, SAO from there, colour, interleaved pixels straight to the image at the picture's paste position: the
+// deblocked planes and the YCbCr canvas never exist in HBM - with the general device functions of k_deblock /
+// k_sao_paste / k_ycbcr_float instead of the packed 8-bit ones, in two phases: (1) one lane per deblocking window, (2) one
+// lane per 16 luma samples of a row (two rows for 4:2:0) and the 8 Cb / 8 Cr samples under them: SAO, float matrix, pixels out.
+// A workgroup owns 128 x 64 luma samples; Pix = uint8_t / uint16_t, CF = 1 (4:2:0) / 2 (4:2:2), OF = output format.
+template <typename Pix>
+__device__ __forceinline__ void tile_row(SaoRow<Pix>& R, const Pix* tile, int pitch, int row, int xo)
+{
+  const Pix* q = tile + (mul24_raw(row, pitch) + xo);
+  if (sizeof(Pix) == 1) {
+    uint32_t d[2];
+    __builtin_memcpy(d, q, 8);
+    R.p[0] = __builtin_amdgcn_perm(0, d[0], 0x0c010c00u); R.p[1] = __builtin_amdgcn_perm(0, d[0], 0x0c030c02u);
+    R.p[2] = __builtin_amdgcn_perm(0, d[1], 0x0c010c00u); R.p[3] = __builtin_amdgcn_perm(0, d[1], 0x0c030c02u);
+  }
+  else __builtin_memcpy(R.p, q, 16);
+  // (the tile starts 8 columns left of the workgroup's samples and ends 8 behind them: both side dwords lie inside it)
+  __builtin_memcpy(&R.l, reinterpret_cast<const uint8_t*>(q) - 4, 4);
+  __builtin_memcpy(&R.r, q + 8, 4);
+}
+// SAO of one group of 8 samples of row yy of plane c, rows read from an LDS tile whose sample (tx0, ty0) is its first (the
+// fast path of k_sao_paste: the per-CTB neighbour masks, no lossless units, no per-sample ring test)
+template <typename Pix>
+__device__ __forceinline__ void tile_sao(const hm_dev_pic& dp, const PicView& v, int c, const Pix* tile, int pitch, int tx0, int ty0,
+                                         int xs, int yy, int W, int Hh, int l2w, int l2h, int apply_sao, int bd, uint32_t (&res)[4])
+{
+  SaoRow<Pix> rows[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    const int y = yy - 1 + r;
+    tile_row(rows[r], tile, pitch, (y < 0 ? 0 : (y < Hh ? y : Hh - 1)) - ty0, xs - tx0);
+  }
+  const int cx = xs >> l2w, cy = yy >> l2h;
+  const GLOBAL_AS uint32_t* cbq = gptr<uint32_t>(reinterpret_cast<const uint8_t*>(v.ctbs) + (uint32_t)mul24_raw(cx + mul24_raw(cy, dp.ctb_w), (int)sizeof(hm_ctb)));
+  const uint32_t cflags = cbq[2], s0 = cbq[3 + 2 * c], s1 = cbq[4 + 2 * c];
+  const SaoRow<Pix>&up = rows[0], &cur = rows[1], &dn = rows[2];
+  const bool sao_on = apply_sao && (dp.flags & HM_PIC_SAO_ENABLED) && (cflags & (c == 0 ? HM_CTB_SAO_LUMA : HM_CTB_SAO_CHROMA));
+  const int type = sao_on ? (int)(s0 & 0xFF) : 0;
+  const uint32_t offs = (s0 >> 24) | (s1 << 8);
+  const uint32_t nbm = c == 0 ? (cflags >> 8) & 0xFF : (cflags >> 16) & 0xFF;
+  const uint32_t maxv2 = ((1u << bd) - 1) * 0x10001u;
+#pragma unroll
+  for (int j = 0; j < 4; j++) res[j] = cur.p[j];
+  if (type == 1) { // band offset (fallback-postfilter.h:218-241)
+    const uint32_t bp = (s0 >> 16) & 0xFF;
+    const uint32_t biased = offs ^ 0x80808080u;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      u16x2 bi = (as_u(cur.p[j]) >> (u16x2)((unsigned short)(bd - 5))) - (u16x2)((unsigned short)bp);
+      bi = __builtin_elementwise_min(bi & (u16x2)(31), (u16x2)(4));
+      res[j] = pk_apply(cur.p[j], as_w(bi) | 0x0c000c00u, 0x80u, biased, maxv2);
+    }
+  }
+  else if (type == 2) {
+    const int cl = (s0 >> 8) & 0xFF;
+    if (cl == 0) sao_edge_group<Pix, -1, 0>(xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv2, up, cur, dn, res);
+    else if (cl == 1) sao_edge_group<Pix, 0, -1>(xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv2, up, cur, dn, res);
+    else if (cl == 2) sao_edge_group<Pix, -1, -1>(xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv2, up, cur, dn, res);
+    else sao_edge_group<Pix, 1, -1>(xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv2, up, cur, dn, res);
+  }
+}
+
+constexpr int TF_TW = 128, TF_TH = 32, TF_XO = 8, TF_THREADS = 256;
+template <typename Pix, int CF, int OF>
+__global__ __launch_bounds__(TF_THREADS) void k_tailf(const hm_dev_pic* __restrict__ pics, const TailDst* __restrict__ dsts, int tiles_x, int n_tiles, int stages, FloatParams fp)
+{
+  constexpr int SV = CF == 1 ? 1 : 0;                                 // log2 of the vertical chroma sub-sampling
+  constexpr int LP = TF_TW + 16, LR = TF_TH + 8;                      // luma tile: pitch in samples, rows
+  constexpr int CW = TF_TW / 2, CH = TF_TH >> SV;                     // chroma samples of the workgroup's tile
+  constexpr int CP = CW + 16, CR = CH + 8;                            // chroma tiles
+  constexpr int OBPP = OF == OF_RGB24 ? 3 : (OF == OF_RGBA32 ? 4 : 6);
+  __shared__ __attribute__((aligned(16))) Pix s_l[LR * LP];
+  __shared__ __attribute__((aligned(16))) Pix s_c[2][CR * CP];
+  __shared__ uint8_t s_tab[112];
+  const hm_dev_pic& dp = pics[blockIdx.y];
+  const int chunk = gridDim.x >> 3; // (workgroups go to the XCDs in turn: a contiguous run of tiles per XCD, as in k_tail420)
+  const int tile = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+  if (tile >= n_tiles) return;
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int x0 = tx * TF_TW, y0 = ty * TF_TH;
+  const int cw = dp.copy_w[0], chh = dp.copy_h[0];
+  if (x0 >= cw || y0 >= chh) return; // (the whole workgroup)
+  const PicView v = view(dp);
+  const int tid = threadIdx.x;
+  const int W = dp.width, H = dp.height;
+  const int bd = dp.bit_depth, maxv = (1 << bd) - 1;
+  if (tid < 106) s_tab[tid] = tid < 52 ? c_beta[tid] : c_tc[tid - 52];
+  __syncthreads();
+
+  // ---- phase 1: deblocked samples of the tile (+ 4 around it) into LDS, one lane per window ----
+  {
+    constexpr int NLX = TF_TW / 8 + 1, NLY = TF_TH / 8 + 1, NCX = CW / 8 + 1, NCY = CH / 8 + 1;
+    constexpr int NL = NLX * NLY, NC = NCX * NCY;
+    for (int item = tid; item < NL + 2 * NC; item += TF_THREADS) {
+      int c = 0, kxl, kyl;
+      if (item < NL) { kyl = item / NLX; kxl = item - kyl * NLX; }
+      else {
+        int t = item - NL;
+        c = t >= NC ? 2 : 1;
+        t -= (c - 1) * NC;
+        kyl = t / NCX; kxl = t - kyl * NCX;
+      }
+      const int sw = c ? 2 : 1, sh = c ? (CF == 1 ? 2 : 1) : 1;
+      const int PW = W >> (sw >> 1), PH = H >> (sh >> 1);
+      const int kx = (c ? CW / 8 * tx : TF_TW / 8 * tx) + kxl, ky = (c ? CH / 8 * ty : TF_TH / 8 * ty) + kyl;
+      if (kx > ((PW + 7) >> 3) || ky > ((PH + 7) >> 3)) continue;
+      Window<Pix> win;
+      const int ox = (kx << 3) - 4, oy = (ky << 3) - 4;
+      if (ox >= 0) window_load(win, dp.plane[c], dp.pitch[c], ox, oy, PH);
+      else { // left picture border: the window's left half does not exist
+        constexpr int HW = Window<Pix>::WORDS / 2;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          const int y = oy + r < 0 ? 0 : (oy + r < PH ? oy + r : PH - 1);
+#pragma unroll
+          for (int k = 0; k < HW; k++) win.w[r][k] = 0;
+          __builtin_memcpy(win.w[r] + HW, gptr<uint8_t>(dp.plane[c] + (uint32_t)mul24_raw(y, dp.pitch[c])), 4 * sizeof(Pix));
+        }
+      }
+      if ((stages & 1) && (dp.flags & HM_PIC_DEBLOCK_ANY)) {
+        WindowEdges<false> E;
+        if (window_edges<Pix, false>(dp, v, c, kx, ky, sw, sh, E, TabLds{s_tab})) window_filter<Pix, false>(win, c, E, maxv);
+      }
+      Pix* const t0 = c == 0 ? s_l : s_c[c - 1];
+      const int tp = c == 0 ? LP : CP;
+      Pix* const q = t0 + (8 * kyl) * tp + 8 * kxl + (TF_XO - 4);
+#pragma unroll
+      for (int r = 0; r < 8; r++) __builtin_memcpy(q + r * tp, win.w[r], 8 * sizeof(Pix));
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: one lane = 16 luma samples of a row (of two rows: 4:2:0) and the 8 Cb / 8 Cr samples under them: SAO of all
+  //      of them from the LDS tiles, the float operation, 16 pixels per row to the image ----
+  const int l2 = dp.log2_ctb;
+  const TailDst D = dsts[blockIdx.y];
+  constexpr int RL = 1 << SV;              // luma rows per lane
+  constexpr int LG = TF_TW / 16, NROWS = TF_TH / RL;
+  for (int item = tid; item < NROWS * LG; item += TF_THREADS) {
+    const int rp = item / LG, g = item - rp * LG;
+    const int lx = x0 + 16 * g, ly = y0 + RL * rp;
+    if (lx >= cw || ly >= chh) continue;
+    uint32_t cbs[4], crs[4]; // the chroma samples after SAO, as pairs
+    {
+      const int xc = lx >> 1, yc = ly >> SV;
+      tile_sao<Pix>(dp, v, 1, s_c[0], CP, (x0 >> 1) - TF_XO, (y0 >> SV) - 4, xc, yc, W >> 1, H >> SV, l2 - 1, l2 - SV, stages & 2, bd, cbs);
+      tile_sao<Pix>(dp, v, 2, s_c[1], CP, (x0 >> 1) - TF_XO, (y0 >> SV) - 4, xc, yc, W >> 1, H >> SV, l2 - 1, l2 - SV, stages & 2, bd, crs);
+    }
+#pragma unroll
+    for (int r = 0; r < RL; r++) {
+      if (ly + r >= chh) break;
+#pragma unroll
+      for (int half = 0; half < 2; half++) { // 8 luma samples each
+        const int hx = lx + 8 * half;
+        if (hx >= cw) break;
+        uint32_t ry[4];
+        tile_sao<Pix>(dp, v, 0, s_l, LP, x0 - TF_XO, y0 - 4, hx, ly + r, W, H, l2, l2, stages & 2, bd, ry);
+        uint8_t ob[8 * OBPP];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const int yv = (int)((ry[i >> 1] >> (16 * (i & 1))) & 0xFFFF);
+          const int ci = 4 * half + (i >> 1); // the chroma sample of the pixel (nearest: yuv2rgb.cc:201-205)
+          const int u = (int)((cbs[ci >> 1] >> (16 * (ci & 1))) & 0xFFFF), w = (int)((crs[ci >> 1] >> (16 * (ci & 1))) & 0xFFFF);
+          int rr, gg, b;
+          px_float(fp, yv, u, w, rr, gg, b);
+          if (fp.post == 1) { rr >>= fp.s1; gg >>= fp.s1; b >>= fp.s1; }
+          else if (fp.post == 2) { rr = (rr << fp.s1) | (rr >> fp.s2); gg = (gg << fp.s1) | (gg >> fp.s2); b = (b << fp.s1) | (b >> fp.s2); }
+          if (OF == OF_RGB24) { ob[3 * i] = (uint8_t)rr; ob[3 * i + 1] = (uint8_t)gg; ob[3 * i + 2] = (uint8_t)b; }
+          else if (OF == OF_RGBA32) { ob[4 * i] = (uint8_t)rr; ob[4 * i + 1] = (uint8_t)gg; ob[4 * i + 2] = (uint8_t)b; ob[4 * i + 3] = 0xFF; }
+          else { // RRGGBB big / little endian (rgb2rgb.cc:250-268, 721-726)
+            constexpr int hi = OF == OF_RRGGBB_BE ? 0 : 1, lo = 1 - hi;
+            ob[6 * i + hi] = (uint8_t)(rr >> 8); ob[6 * i + lo] = (uint8_t)rr;
+            ob[6 * i + 2 + hi] = (uint8_t)(gg >> 8); ob[6 * i + 2 + lo] = (uint8_t)gg;
+            ob[6 * i + 4 + hi] = (uint8_t)(b >> 8); ob[6 * i + 4 + lo] = (uint8_t)b;
+          }
+        }
+        uint8_t* const o0 = D.rgb + (uint32_t)(mul24_raw(ly + r, D.pitch) + hx * OBPP); // (an image is smaller than 4 GiB)
+        const int nvalid = cw - hx < 8 ? cw - hx : 8;
+        if (nvalid == 8) {
+          uint32_t wd[2 * OBPP];
+#pragma unroll
+          for (int k = 0; k < 2 * OBPP; k++) wd[k] = (uint32_t)ob[4 * k] | ((uint32_t)ob[4 * k + 1] << 8) | ((uint32_t)ob[4 * k + 2] << 16) | ((uint32_t)ob[4 * k + 3] << 24);
+          __builtin_memcpy(gptr_w<uint8_t>(o0), wd, 8 * OBPP);
+        }
+        else {
+#pragma unroll
+          for (int i = 0; i < 8 * OBPP; i++)
+            if (i < nvalid * OBPP) o0[i] = ob[i];
+        }
+      }
+    }
+  }
+}
+
 } // namespace
 
 extern "C" int hm_launch_deblock(const hm_dev_pic* d_pics, int n_pics, int max_w4, int max_h4, int chroma_format,
@@ -1238,4 +1438,35 @@ extern "C" int hm_launch_tail420(const hm_dev_pic* d_pics, const void* d_dsts, i
     else hipLaunchKernelGGL((k_tail420<4, TAIL_MINW, false>), grid, dim3(TAIL_THREADS), 0, s, d_pics, dd, tiles_x, tiles_x * tiles_y, stages, k);
   }
   return hm_check_hip(hipGetLastError(), "k_tail420 launch");
+}
+
+// Fused tail of the float-chain classes (k_tailf): n pictures of one class, the colour request d (a chain that is the float
+// operation on the image's own planes: colour_host.cpp hm_colour_float_chain), its matrix coefficients and mode.  Returns
+// HM_ERR_UNSUPPORTED for a combination that has no instantiation (the caller keeps the separate kernels).
+template <typename Pix, int CF>
+static int launch_tailf(const hm_dev_pic* d_pics, const TailDst* dd, int n_pics, int tiles_x, int tiles_y, int out_format, int stages, const FloatParams& fp, hipStream_t s)
+{
+  const dim3 grid((tiles_x * tiles_y + 7) / 8 * 8, n_pics);
+  const int nt = tiles_x * tiles_y;
+  switch (out_format) {
+    case HM_OUT_RGB: hipLaunchKernelGGL((k_tailf<Pix, CF, OF_RGB24>), grid, dim3(TF_THREADS), 0, s, d_pics, dd, tiles_x, nt, stages, fp); break;
+    case HM_OUT_RGBA: hipLaunchKernelGGL((k_tailf<Pix, CF, OF_RGBA32>), grid, dim3(TF_THREADS), 0, s, d_pics, dd, tiles_x, nt, stages, fp); break;
+    case HM_OUT_RRGGBB_BE: hipLaunchKernelGGL((k_tailf<Pix, CF, OF_RRGGBB_BE>), grid, dim3(TF_THREADS), 0, s, d_pics, dd, tiles_x, nt, stages, fp); break;
+    case HM_OUT_RRGGBB_LE: hipLaunchKernelGGL((k_tailf<Pix, CF, OF_RRGGBB_LE>), grid, dim3(TF_THREADS), 0, s, d_pics, dd, tiles_x, nt, stages, fp); break;
+    default: return HM_ERR_UNSUPPORTED;
+  }
+  return hm_check_hip(hipGetLastError(), "k_tailf launch");
+}
+extern "C" int hm_launch_tailf(const hm_dev_pic* d_pics, const void* d_dsts, int n_pics, int max_w, int max_h, const hm_colour_desc* d, const float coef[4], int mode,
+                               int stages, hipStream_t s)
+{
+  if (n_pics <= 0) return HM_OK;
+  FloatParams fp;
+  hm_float_params(d, coef, mode, &fp);
+  const int tiles_x = (max_w + TF_TW - 1) / TF_TW, tiles_y = (max_h + TF_TH - 1) / TF_TH;
+  const TailDst* dd = (const TailDst*)d_dsts;
+  const bool v420 = d->chroma == HM_CHROMA_420;
+  if (d->chroma != HM_CHROMA_420 && d->chroma != HM_CHROMA_422) return HM_ERR_UNSUPPORTED;
+  if (d->bit_depth > 8) return v420 ? launch_tailf<uint16_t, 1>(d_pics, dd, n_pics, tiles_x, tiles_y, d->out_format, stages, fp, s) : launch_tailf<uint16_t, 2>(d_pics, dd, n_pics, tiles_x, tiles_y, d->out_format, stages, fp, s);
+  return v420 ? launch_tailf<uint8_t, 1>(d_pics, dd, n_pics, tiles_x, tiles_y, d->out_format, stages, fp, s) : launch_tailf<uint8_t, 2>(d_pics, dd, n_pics, tiles_x, tiles_y, d->out_format, stages, fp, s);
 }

@@ -227,6 +227,68 @@ def test_fused_tail_with_several_slices(pkg, hm, slicing):
         assert np.array_equal(out[0][j], out[1][j]), f"image {j}: fused tail differs from the separate kernels"
 
 
+FLOAT_TAIL_CLASSES = {
+    # name: (bit depth, chroma format, full range, matrix, output format, bytes per pixel)
+    "config4_422_10_rrggbb_le": (10, 2, 0, 9, "HM_OUT_RRGGBB_LE", 6),
+    "420_10_rrggbb_be": (10, 1, 1, 1, "HM_OUT_RRGGBB_BE", 6),
+    "420_10_rgb24": (10, 1, 0, 6, "HM_OUT_RGB", 3),
+    "422_12_rrggbb_le": (12, 2, 1, 6, "HM_OUT_RRGGBB_LE", 6),
+    "422_8_rgb24": (8, 2, 1, 6, "HM_OUT_RGB", 3),
+    "420_8_limited_rgba": (8, 1, 0, 1, "HM_OUT_RGBA", 4),
+}
+
+
+@pytest.mark.parametrize("name", list(FLOAT_TAIL_CLASSES))
+@pytest.mark.parametrize("stages", [3, 0], ids=["deblock+sao", "none"])
+def test_fused_float_tail_equals_separate_kernels(pkg, hm, name, stages):
+    """hm_batch_set_colour on the classes whose colour chain is the reference's float operation (10 / 12 bit, 4:2:2, limited
+    range; BASELINE config 4 is the first): the fused kernel k_tailf (deblocking + SAO + paste + float matrix + repack) against
+    k_deblock + k_sao_paste + k_ycbcr_float on the same batch - two images of 3 x 2 tiles of 256 x 192, the canvas cropped."""
+    import ctypes as C
+    import torch
+    capi, L = pkg.capi, pkg.lib()
+    bd, cf, full, matrix, fmt, obpp = FLOAT_TAIL_CLASSES[name]
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    cols, rows, tw, th, w, h = 3, 2, 256, 192, 700, 330
+    bps = 2 if bd > 8 else 1
+    blobs = [capi.parse_hevc(synthutil.picture(8100000 + 7 * k, width=tw, height=th, chroma_format=cf, bit_depth=bd, log2_ctb=5, qp=28, vui=1,
+                                               full_range=full, matrix=matrix, primaries=1, slices=(30 if k % 3 == 0 else 0))) for k in range(2 * cols * rows)]
+    ys, cs, os_ = L.hm_plane_stride(w, bps), L.hm_plane_stride((w + 1) // 2, bps), L.hm_plane_stride(w, obpp)
+    ch = (h + 1) // 2 if cf == 1 else h
+    out = []
+    for group in (0, -1):  # 0: fused where possible, -1: never
+        batch = capi.Batch()
+        ims = []
+        for j in range(2):
+            im = dict(y=torch.zeros((max(64, h), ys), dtype=torch.uint8, device=dev), cb=torch.zeros((max(64, ch), cs), dtype=torch.uint8, device=dev),
+                      cr=torch.zeros((max(64, ch), cs), dtype=torch.uint8, device=dev), rgb=torch.zeros((max(64, h), os_), dtype=torch.uint8, device=dev))
+            for t in range(cols * rows):
+                d = capi.TileDest()
+                d.plane[0], d.plane[1], d.plane[2] = im["y"].data_ptr(), im["cb"].data_ptr(), im["cr"].data_ptr()
+                d.pitch[0], d.pitch[1], d.pitch[2] = ys, cs, cs
+                d.canvas_width, d.canvas_height = w, h
+                d.x0, d.y0 = (t % cols) * tw, (t // cols) * th
+                # (tile_has_nclx stays 0: a limited-range tile WITH an nclx is rescaled while it is pasted - context.cc:2504-2509 - and
+                #  such grids keep the separate kernels)
+                batch.add(blobs[j * cols * rows + t], d)
+            ims.append(im)
+        batch.upload(st)
+        PtrArr = C.c_void_p * 2
+        ptrs = [PtrArr(*[im[k].data_ptr() for im in ims]) for k in ("y", "cb", "cr", "rgb")]
+        desc = capi.ColourDesc(w, h, bd, cf, 1, matrix, 1, full, getattr(capi, fmt), ys, cs, cs, os_)
+        batch.set_colour(desc, 2, *ptrs, group)
+        batch.execute(stages, st)
+        torch.cuda.synchronize()
+        batch.check()
+        assert batch.tail_fused() == (group == 0), name
+        out.append([im["rgb"].cpu().numpy()[:h, :w * obpp].copy() for im in ims])
+        batch.close()
+    for j in range(2):
+        assert np.array_equal(out[0][j], out[1][j]), f"{name}, image {j}: fused float tail differs from the separate kernels"
+    assert out[0][0].any()
+
+
 @pytest.mark.parametrize("groups", [2, 3, 8])
 def test_grouped_streams_equal_single_stream(pkg, hm, groups):
     """hm_batch_set_concurrency: the images of a step as `groups` groups on streams of their own - the same pixels as the
