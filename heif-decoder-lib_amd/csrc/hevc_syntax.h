@@ -171,20 +171,18 @@ static const uint8_t kMode422[35] = {0, 1, 2, 2, 2, 2, 3, 5, 7, 8, 10, 12, 13, 1
                                      21, 22, 23, 23, 24, 24, 25, 25, 26, 27, 27, 28, 28, 29, 29, 30, 31};
 } // namespace tables
 
-// Picture classes whose records go out as split chains for k_recon_quad: 8-bit samples with CTBs of 32 or 64, and every
-// picture of a megapixel or more.  Tiles (many small pictures) measured on
-// MI355X (profiles/r02_class_sweep.json, 1536 to 18432 tiles of 512x512): with 16-bit samples the one-row-per-wave
-// kernel k_recon is 1.1-1.8 times faster at every batch size (the quad kernel's four CTU buffers per wave take the LDS
-// that k_recon spends on more rows in flight: 3-11 waves per CU against 16), with 16x16 CTBs 1.1-1.3 times.
+// Picture classes whose records go out as split chains (k_residual + k_chain): every class (r04).  Until r03 pictures of less
+// than a megapixel with 16-bit samples or CTBs of 16 kept decode-order records for the one-row-per-wave kernel k_recon, which
+// was 1.1-1.8 times faster for them (r02_class_sweep.json).  With r04's chain kernel the split chains win at full load in
+// every class (18432 tiles of 512x512, reconstruction ms: 8-bit CTB 16 47.0 -> 34.3, 10-bit 4:2:0 48.4 -> 38.4, 10-bit 4:2:2
+// 66.2 -> 59.5, 12-bit 4:2:2 CTB 64 145 -> 130) and are level at 1536 tiles except for CTB 16 (4.7 -> 5.3 ms)
+// (profiles/r04_class_sweep.txt).  Pictures with rare syntax keep decode-order records whatever this says (PictureState::reset).
 inline bool quad_class(const SPS& s)
 {
   static const int force = [] { const char* e = std::getenv("HM_QUAD_CLASS"); return e ? std::atoi(e) : -1; }(); // (A/B measurements: 1 all, 0 none)
   if (force >= 0) return force != 0;
-  // Large pictures come in small batches, where what counts is the rows a picture keeps in flight: the quad kernel
-  // runs 16 of them (8 waves x 2), k_recon 8 - it wins there for every class (tools/shape_probe.py: 32 x 2048x1536 10-bit
-  // 4:2:2 29.2 against 31.6 ms, 8 x 1080p 10-bit CTB 64 24.5 / 31.1, 64 x 1024x1024 10-bit 5.4 / 6.3, 8 x 1080p CTB 16 9.7 / 10.7)
-  if ((long)s.width * s.height >= (1L << 20)) return true;
-  return s.bit_depth_y == 8 && s.log2_ctb >= 5;
+  (void)s;
+  return true;
 }
 
 // Per-picture state shared by all slice segments of the picture

@@ -214,9 +214,9 @@ def test_tile_parallel_parse_equals_serial(pkg, hm):
 
 
 def test_record_order_follows_the_picture_class(hm):
-    """which reconstruction kernel a picture is written for (hevc_syntax.h: quad_class): split chains (HM_PIC_SPLIT_CHAINS,
-    k_recon_quad) for 8-bit pictures with CTBs of 32 / 64 and for every picture of a megapixel or more; decode order
-    (k_recon) for small 16-bit or 16x16-CTB pictures; never split for rare syntax"""
+    """which reconstruction kernels a picture is written for (hevc_syntax.h: quad_class): split chains (HM_PIC_SPLIT_CHAINS:
+    k_residual + k_chain) for every class since r04 - 8 to 12 bit, CTBs of 16 / 32 / 64, small and large pictures -; records in
+    decode order (k_recon) only for rare syntax and 4:4:4"""
     import synthutil
     SPLIT = 0x1000
 
@@ -224,7 +224,7 @@ def test_record_order_follows_the_picture_class(hm):
         blob = hevcutil.parse(hm, synthutil.picture(77, **kw))
         return bool(int.from_bytes(blob[36:40], "little") & SPLIT)
     assert split(width=128, height=128, log2_ctb=5) and split(width=128, height=128, log2_ctb=6)
-    assert not split(width=128, height=128, log2_ctb=4)
-    assert not split(width=128, height=128, log2_ctb=5, bit_depth=10) and not split(width=128, height=128, log2_ctb=6, bit_depth=12, chroma_format=2)
+    assert split(width=128, height=128, log2_ctb=4)
+    assert split(width=128, height=128, log2_ctb=5, bit_depth=10) and split(width=128, height=128, log2_ctb=6, bit_depth=12, chroma_format=2)
     assert split(width=1024, height=1024, log2_ctb=5, bit_depth=10, density=5) and split(width=1024, height=1024, log2_ctb=4, density=5)
     assert not split(width=1024, height=1024, log2_ctb=5, density=5, scaling_list=1) and not split(width=128, height=128, chroma_format=3)
