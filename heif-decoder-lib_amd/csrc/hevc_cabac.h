@@ -146,6 +146,10 @@ class CabacDecoder {
     bits_ = -9;
     refill();
   }
+  // 9.3.2.5: the first nine bits are the offset, and 510 / 511 are not allowed - with an offset >= range every bin would
+  // decode from a state the arithmetic never reaches (multi-bin bypass reads leave their value range, the excess doubles with
+  // every renormalisation and wraps at the register width: nothing a second implementation reproduces).  Callers refuse.
+  bool bad_start() const { return (value_ >> kOffsetShift) >= 510u; }
   const uint8_t* position() const { return base_ + ((ptrdiff_t)pos_ - (bits_ >> 3)); }
   // a decision has depended on bits behind the end of the data: the read position P (see above; it only grows) lies past
   // the last bit.  No valid slice gets there - the last bit a terminating bin of value 1 reads is the stop bit -, and what a

@@ -57,12 +57,14 @@ class DecoderEC {
     if (raw_bit_) { raw_bit_ = 0; raw_++; }
     if (end_ - raw_ < 2) throw ParseError(HM_ERR_BITSTREAM, "slice data ends inside a PCM coding unit");
     dec_.init(raw_, end_);
+    if (dec_.bad_start()) throw ParseError(HM_ERR_BITSTREAM, "arithmetic decoder restarts with an offset of 510 or 511 (9.3.2.5)");
   }
   void start_substream()
   {
     if (started_) cur_ = dec_.position();
     if (end_ - cur_ < 2) throw ParseError(HM_ERR_BITSTREAM, "slice data truncated");
     dec_.init(cur_, end_);
+    if (dec_.bad_start()) throw ParseError(HM_ERR_BITSTREAM, "arithmetic decoder starts with an offset of 510 or 511 (9.3.2.5)");
     started_ = true;
   }
   // (checked once per CTB, behind its terminating bin: the read position only grows)

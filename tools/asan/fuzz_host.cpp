@@ -45,6 +45,9 @@ static void mutate(std::vector<uint8_t>& b, size_t span)
   }
 }
 
+// (common.cpp's test hooks reach into the device side of the library, which this host-only build leaves out)
+extern "C" void hm_chain_test_knobs(int, int) {}
+
 int main(int argc, char** argv)
 {
   int iterations = 2000;
@@ -82,7 +85,11 @@ int main(int argc, char** argv)
         if (hm_hevc_parse(b.data(), b.size(), path.find(".hevc") != std::string::npos ? 1 : 0, &blob, &n) == 0) {
           hevc_ok++;
           // the command stream as foreign input: the validator must accept the parser's output and survive anything
-          if (hm_stream_validate(blob, n) != 0) { std::fprintf(stderr, "validator rejects a parser stream: %s\n", hm_last_error()); return 3; }
+          if (hm_stream_validate(blob, n) != 0) {
+            std::fprintf(stderr, "validator rejects a parser stream (%s, mutation %d): %s\n", argv[a], it, hm_last_error());
+            if (const char* dump = std::getenv("HM_FUZZ_DUMP")) { if (FILE* f = std::fopen(dump, "wb")) { std::fwrite(b.data(), 1, b.size(), f); std::fclose(f); } }
+            return 3;
+          }
           std::vector<uint8_t> s(blob, blob + n);
           for (int k = 0; k < 8; k++) {
             std::vector<uint8_t> m = s;

@@ -3,6 +3,9 @@
 #include <cstdlib>
 #include <vector>
 #include "heif_mi355x.h"
+// (common.cpp's test hooks reach into the device side of the library, which this host-only build leaves out)
+extern "C" void hm_chain_test_knobs(int, int) {}
+
 int main(int argc, char** argv)
 {
   const int threads = argc > 1 ? atoi(argv[1]) : 4;
