@@ -5,6 +5,7 @@
 // batch), planes of the conformance-window size copied into caller memory.  Device and
 // pinned staging memory come from the caching pool (devpool.cpp): a 48-tile grid decoded through the reference's
 // registry makes 48 of these calls from concurrent threads, and a hipMalloc per plane would serialise them.
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -24,8 +25,14 @@ struct hm_picture {
   uint8_t* blob = nullptr;
   size_t blob_size = 0;
   hm_picture_info info;
-  ~hm_picture() { hm_free(blob); }
+  // Pictures alive = callers inside decode_image right now, entropy-decoding or waiting for the device: the width of the
+  // caller's window (the reference: m_max_decoding_threads tasks, one decoder instance each), which the device worker's
+  // collecting policy goes by.
+  static std::atomic<int> alive;
+  hm_picture() { alive++; }
+  ~hm_picture() { alive--; hm_free(blob); }
 };
+std::atomic<int> hm_picture::alive{0};
 
 extern "C" {
 
@@ -124,14 +131,19 @@ class DeviceWorker {
  private:
   explicit DeviceWorker(int device) : device_(device)
   {
+    // How long an executor keeps collecting after the last arrival.  The callers are staggered by their entropy decode; whether
+    // waiting for the next one pays depends on how many there are (r04 sweep, ms per 12 MP grid from a window of 8 / 16 / 48
+    // callers: no lingering 11.5 / 8.7 / 4.3, 30 us 12.6 / 6.7 / 3.7, 100 us 13.2 / 7.1 / 4.2) - so: none while at most eight
+    // pictures are alive (callers inside decode_image: the window), 30 us beyond.  HM_PLUGIN_LINGER_US fixes the value.
     const char* e = std::getenv("HM_PLUGIN_LINGER_US");
-    linger_us_ = e ? std::atoi(e) : 30; // (measured: 30 us beats 150 and 0 - the callers are staggered by their entropy decode)
+    linger_us_ = e ? std::atoi(e) : 30;
+    linger_adaptive_ = e == nullptr;
     // A small batch is as long as its longest dependency chain (~1.4 ms for 512 x 512 tiles) whatever its size, and the
     // callers of a grid arrive staggered (each decodes its tile's entropy layer first): with ONE executor a call that
     // arrives just behind a batch waits for that batch and then for its own.  Several executors, each with a stream of
     // its own, take what has arrived while the others' batches are on the device; one of them collects at a time.
     const char* w = std::getenv("HM_PLUGIN_WORKERS");
-    int n = w ? std::atoi(w) : 3;
+    int n = w ? std::atoi(w) : 4;
     n = n < 1 ? 1 : (n > 8 ? 8 : n);
     for (int i = 0; i < n; i++) {
       try { std::thread([this] { loop(); }).detach(); executors_++; }
@@ -151,10 +163,11 @@ class DeviceWorker {
         collecting_ = true;
         // the callers of one grid arrive within microseconds of each other: keep collecting while they keep coming
         // (at most 64 pictures, at most ~1 ms)
+        const int linger = (linger_adaptive_ && hm_picture::alive.load(std::memory_order_relaxed) <= 8) ? 0 : linger_us_;
         for (int rounds = 0; rounds < 8; rounds++) {
           while (!queue_.empty() && reqs.size() < 64) { reqs.push_back(queue_.front()); queue_.pop_front(); }
-          if (reqs.size() >= 64 || linger_us_ <= 0) break;
-          if (!work_.wait_for(l, std::chrono::microseconds(linger_us_), [&] { return !queue_.empty(); })) break;
+          if (reqs.size() >= 64 || linger <= 0) break;
+          if (!work_.wait_for(l, std::chrono::microseconds(linger), [&] { return !queue_.empty(); })) break;
         }
         collecting_ = false;
         if (!queue_.empty()) work_.notify_all(); // (more than one batch's worth: the next executor takes over)
@@ -233,6 +246,7 @@ class DeviceWorker {
   }
   int device_;
   int linger_us_ = 30;
+  bool linger_adaptive_ = true;
   std::mutex m_;
   std::condition_variable work_;
   std::deque<Request*> queue_;
