@@ -360,7 +360,11 @@ int plan_item(const hm_file* f, uint32_t id, ItemPlan& P)
 
 // decode_image_planar for an hvc1 item or a grid (context.cc:1729-2020) once the host entropy decode of its coded
 // pictures is done: one GPU batch, then the item's irot / imir / clap.  Asynchronous on `s`.
-int planar_from_blobs(const hm_file* f, ItemPlan& P, const hm_decode_params* params, hipStream_t s, PlanarImage& I)
+// attach: the caller will convert the planes to params->out_format as they come out of this function (no alpha plane, nothing
+// else in between) - then the conversion is attached to the batch, which runs deblocking, SAO, paste and colour as ONE kernel
+// for the picture classes that allow it, and I.rgb holds the pixels (I.rgb_attached); it stays off whenever something works on
+// the planes after the batch (tiles with transformations or alpha images, transformations of the item).
+int planar_from_blobs(const hm_file* f, ItemPlan& P, const hm_decode_params* params, hipStream_t s, PlanarImage& I, bool attach = false)
 {
   const hm::Item* it = f->file.item(P.id);
   hm::HeifError err;
@@ -515,6 +519,27 @@ int planar_from_blobs(const hm_file* f, ItemPlan& P, const hm_decode_params* par
   for (int c = 0; c < 3; c++)
     if (Pl[c].mem.p) hipMemsetAsync(Pl[c].mem.p, 0, plane_bytes(Pl[c]), s);
   if ((rc = hm_batch_upload(batch, s))) return rc;
+  I.rgb_attached = false;
+  if (attach && params->out_format != 0 && chroma != 0 && own.empty() && own_alpha.empty() && I.tile_alpha_bd == 0 &&
+      (params->ignore_transformations || it->props.transforms.empty())) {
+    hm_colour_desc cd; // (exactly the request job_enqueue / run_slab would hand to hm_colour_convert)
+    std::memset(&cd, 0, sizeof(cd));
+    cd.width = canvas_w; cd.height = canvas_h; cd.bit_depth = bd; cd.chroma = chroma;
+    cd.has_nclx = is_grid ? 0 : 1; cd.matrix = native.matrix; cd.primaries = native.primaries; cd.full_range = native.full_range;
+    cd.out_format = params->out_format;
+    cd.chroma_upsampling = params->chroma_upsampling;
+    const int obpp = hm_out_bytes_per_pixel(params->out_format);
+    if (obpp > 0) {
+      cd.y_stride = Pl[0].stride; cd.cb_stride = Pl[1].stride; cd.cr_stride = Pl[2].stride;
+      cd.out_stride = hm_plane_stride(canvas_w, obpp);
+      if (!I.rgb.alloc((size_t)cd.out_stride * mem_rows(canvas_h))) {
+        const void* py = Pl[0].mem.p; const void* pcb = Pl[1].mem.p; const void* pcr = Pl[2].mem.p;
+        void* po = I.rgb.p;
+        // (a request the colour chain refuses is refused by the caller's own conversion in a moment: not an error here)
+        I.rgb_attached = hm_batch_set_colour(batch, &cd, 1, &py, &pcb, &pcr, &po, 0) == HM_OK;
+      }
+    }
+  }
   if ((rc = hm_batch_execute(batch, 3, s))) return rc;
   for (std::unique_ptr<OwnTile>& o : own) {
     const hm::Item* ti = f->file.item(P.tiles[o->index].id);
@@ -647,7 +672,7 @@ int job_enqueue(DecodeJob& j, hm_decoded* out)
   j.enqueued = true; // from here on the destructor drains the stream before buffers are released
   Lap lap;
   PlanarImage &I = j.I, &A = j.A;
-  int rc = planar_from_blobs(f, j.item[0], params, s, I);
+  int rc = planar_from_blobs(f, j.item[0], params, s, I, /*attach=*/j.n_items == 1);
   if (rc) return rc;
   // ---- alpha channel: the auxiliary image's Y plane becomes the alpha plane, scaled nearest-neighbour if its size
   //      differs (context.cc:2029-2078) ----
@@ -727,8 +752,11 @@ int job_enqueue(DecodeJob& j, hm_decoded* out)
     cd.y_stride = P[0].stride; cd.cb_stride = P[1].stride; cd.cr_stride = P[2].stride;
     cd.out_stride = hm_plane_stride(img_w, obpp);
     const size_t obytes = (size_t)cd.out_stride * mem_rows(img_h);
-    if ((rc = dout.alloc(obytes))) return rc;
-    if ((rc = hm_colour_convert(&cd, P[0].mem.p, P[1].mem.p, P[2].mem.p, dout.p, s))) return rc;
+    if (I.rgb_attached && !alpha) dout.swap(I.rgb); // (converted with the batch: planar_from_blobs)
+    else {
+      if ((rc = dout.alloc(obytes))) return rc;
+      if ((rc = hm_colour_convert(&cd, P[0].mem.p, P[1].mem.p, P[2].mem.p, dout.p, s))) return rc;
+    }
     // RGB24 / RRGGBB targets have no alpha: Op_drop_alpha_plane, the colour values do not depend on it.  RGBA: the 8-bit
     // ops copy the plane (yuv2rgb.cc:483-488)
     if (alpha && params->out_format == HM_OUT_RGBA) {
@@ -867,7 +895,7 @@ void run_slab(const hm_file* f, const hm_decode_params* params, Slab& S, uint8_t
   { // (the slab's image, batch and output buffer live inside this scope: gone before the stream they worked on)
     PlanarImage I;
     DevMem dout;
-    rc = planar_from_blobs(f, S.P, params, s, I);
+    rc = planar_from_blobs(f, S.P, params, s, I, /*attach=*/true);
     if (!rc) {
       hm_colour_desc cd;
       std::memset(&cd, 0, sizeof(cd));
@@ -879,8 +907,11 @@ void run_slab(const hm_file* f, const hm_decode_params* params, Slab& S, uint8_t
       const int obpp = hm_out_bytes_per_pixel(params->out_format);
       cd.y_stride = I.P[0].stride; cd.cb_stride = I.P[1].stride; cd.cr_stride = I.P[2].stride;
       cd.out_stride = hm_plane_stride(canvas_w, obpp);
-      rc = dout.alloc((size_t)cd.out_stride * mem_rows(S.h));
-      if (!rc) rc = hm_colour_convert(&cd, I.P[0].mem.p, I.P[1].mem.p, I.P[2].mem.p, dout.p, s);
+      if (I.rgb_attached) dout.swap(I.rgb); // (converted with the batch)
+      else {
+        rc = dout.alloc((size_t)cd.out_stride * mem_rows(S.h));
+        if (!rc) rc = hm_colour_convert(&cd, I.P[0].mem.p, I.P[1].mem.p, I.P[2].mem.p, dout.p, s);
+      }
       if (!rc) {
         e = hipMemcpy2DAsync(dst, dst_stride, dout.p, cd.out_stride, (size_t)canvas_w * obpp, (size_t)S.h, hipMemcpyDeviceToHost, s);
         rc = hm_check_hip(e, "D2H of a slab");

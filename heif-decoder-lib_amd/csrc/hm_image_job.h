@@ -74,6 +74,10 @@ struct PlanarImage {
   DevPlane tile_alpha;
   int tile_alpha_bd = 0; // 0: no tile of the grid has an alpha image
   std::unique_ptr<hm_batch, void (*)(hm_batch*)> batch{nullptr, hm_batch_destroy};
+  // the interleaved pixels, when the colour conversion was attached to the batch (hm_batch_set_colour: the fused tail kernels
+  // where the pictures allow them, else the same kernels as hm_colour_convert) - planar_from_blobs, `attach`
+  DevMem rgb;
+  bool rgb_attached = false;
 };
 
 struct TilePlan { uint32_t id = 0; int x0 = 0, y0 = 0; };
