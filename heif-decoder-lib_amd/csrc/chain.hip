@@ -4,14 +4,15 @@
 // plus the add of the residual that residual.hip's pre-pass left in HBM (rows R1-R3 run there, off the dependency
 // chain).  What is left on the chain of a CTU row is: take the block's neighbours, predict, add, clip, store.
 //
-// Mapping (as recon_quad.hip, which this kernel replaces): one wave per coded picture (tile batches) or per pair of CTU
-// rows (few, large pictures: PAIRS, below); its four 16-lane groups each own a block chain - luma and chroma of two CTU
-// rows (monochrome: luma of four) -; per loop iteration every group executes one block: interior 4x4 blocks of all
-// groups side by side (lane = sample, one table read for both reference positions + weight of any angular mode), every
-// other block wave-wide, one group after the other.
+// Mapping: one wave per coded picture (tile batches: MODE 0) or per pair of CTU rows / CTU row / chain of a row (few, large
+// pictures: PAIRS, MODE 1-3, below); its four 16-lane groups each own a block chain - luma and chroma of two CTU rows
+// (monochrome: luma of four) -; per loop iteration every group executes one block: interior 4x4 blocks of all groups side by
+// side (lane = sample, one table read for both reference positions + weight of any angular mode), every other block
+// wave-wide, one group after the other.  With fewer than four chains per wave the spare groups work consecutive records of
+// a chain side by side (see NCL below).
 //
-// What is new against recon_quad.hip (profiles/r02_pmc_sq_counters.json: 2.48 VALU wave-instructions per sample, the
-// kernel bound by instruction issue, not by bytes):
+// Against r02's single reconstruction kernel (profiles/r02_pmc_sq_counters.json: 2.48 VALU wave-instructions per sample, bound
+// by instruction issue, not by bytes):
 //   * no dequantisation / transform here (residual.hip); the residual of a block arrives as int16 samples.  Those of a
 //     4x4 block lie in an array indexed like the records: a group fetches the 16 records it needs next and their
 //     residuals while it works on the 16 before them, so nothing on the chain of the 4x4 blocks ever waits for HBM; the residual

@@ -1,5 +1,5 @@
 // recon_common.h - device code shared by the reconstruction kernels (recon.hip: one transform block per wave step;
-// recon_quad.hip: four CTU rows per wave, 4x4 blocks of all four side by side): reference-sample fetch and
+// residual.hip + chain.hip: the residual pre-pass and the prediction chains, four block chains per wave): reference-sample fetch and
 // substitution, smoothing, the predictors, dequantisation + inverse transforms + add (intrapred.h:192-441,
 // transform.cc:386-689, fallback-dct.cc of the reference).  Included inside each translation unit's anonymous namespace.
 #ifndef HM_RECON_COMMON_H

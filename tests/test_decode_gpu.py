@@ -162,12 +162,12 @@ def test_range_extension_large_blocks(pkg):
                                    dict(width=2048, height=512, log2_ctb=4, no_split=1)],
                          ids=["8bit_ctb32", "8bit_ctb16", "10bit_ctb64", "10bit_422_ctb32", "mono_ctb64", "8bit_ctb16_one_block_per_ctb"])
 def test_large_single_pictures(pkg, shape):
-    """pictures of a megapixel or more go to k_recon_quad in every class, with as many waves per picture as the wavefront,
+    """large single pictures of every class through the split chains (k_residual + k_chain), with as many waves per picture as the wavefront,
     the LDS and the machine allow - 3, 5, 6, 7 as well as powers of two (sample lines are handed from wave to wave through
     LDS slots row % (rows in flight)): HIP == oracle"""
     import synthutil
     blob = pkg.capi.parse_hevc(synthutil.picture(424242, qp=30, density=40, **shape))
-    assert int.from_bytes(blob[36:40], "little") & 0x1000  # split chains: the quad kernel
+    assert int.from_bytes(blob[36:40], "little") & 0x1000  # split chains
     got = gpudecode.decode_pictures(pkg, [blob, blob], 3)
     exp, _ = orc.oracle_decode(blob, 3, crop=True)
     for g in got:
