@@ -672,8 +672,8 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       // bit k of `gq` / `gr`: group k holds an interior 4x4 block / a record of its chain's current CTU and window
       const uint32_t gq = (uint32_t)((m_q4 & 1) | ((m_q4 >> 15) & 2) | ((m_q4 >> 30) & 4) | ((m_q4 >> 45) & 8));
       const uint32_t gr = (uint32_t)((m_running & 1) | ((m_running >> 15) & 2) | ((m_running >> 30) & 4) | ((m_running >> 45) & 8));
-      // per chain: length of the run, 1 if a phase-D block follows it (a record that is running and not part of the run: not an
-      // interior 4x4 block).  Without loops or branches: on the scalar unit a taken branch costs more than the arithmetic of both
+      // per chain: length of the run, and how many phase-D blocks follow it (records that are running and not interior 4x4
+      // blocks).  Without loops or branches: on the scalar unit a taken branch costs more than the arithmetic of both
       // chains, and this sits on the critical path of every iteration of a wave that is alone on its SIMD.
       // (one chain: its records are the groups 0 1 2 3; two chains: chain c's are the groups c and c + 2)
       constexpr bool two = NCL == 1;
@@ -683,12 +683,14 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       for (int c = 0; c < 2; c++) {
         const uint32_t q = of_chain(gq, c), r = of_chain(gr, c);
         run[c] = (uint32_t)__builtin_ctz(~q | (1u << SUB)); // leading interior 4x4 blocks, at most SUB
-        big[c] = (r >> run[c]) & 1u;                         // (r has no bit SUB)
+        // ... and the records of any other kind that follow the run directly: phase D takes them one after the other, in this
+        // iteration (a 4x4 block behind them would have to run before them - phase C comes first: it waits for the next one)
+        big[c] = (uint32_t)__builtin_ctz(~((r & ~q) >> run[c])); // (r has no bit SUB: at most SUB - run)
       }
       const uint32_t my_run = g == 0 ? run[0] : run[1], my_big = g == 0 ? big[0] : big[1];
       quad = (uint32_t)my_off < my_run;
       m_quad = ballot(quad);
-      s_big = ballot((uint32_t)my_off == my_run && my_big != 0);
+      s_big = ballot((uint32_t)my_off >= my_run && (uint32_t)my_off < my_run + my_big);
       n_exec = (int)(my_run + my_big);
       n_sub = (int)(run[0] > run[1] ? run[0] : run[1]);
     }
