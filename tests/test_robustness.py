@@ -81,6 +81,30 @@ def test_damaged_slice_data_is_accepted_only_where_the_reference_is_defined(hm):
     assert accepted >= 15 and refused >= 40, (accepted, refused)
 
 
+def test_the_validator_accepts_whatever_the_parser_emits(hm):
+    """mutated slice data that the parser takes must come out as a command stream every field of which is in range
+    (hm_stream_validate is what hm_batch_add runs on foreign streams) - the invariant of tools/asan/fuzz_host.cpp, which found a
+    5-bit field read as 45 from an arithmetic decoder that started with an offset of 510 (refused since: 9.3.2.5)"""
+    import ctypes as C
+    hm.hm_stream_validate.argtypes = [C.c_char_p, C.c_size_t]
+    rng = random.Random(670)
+    taken = 0
+    for name in ("rext_cross_444_all", "pcm_bypass_sl_wpp", "slices_headers", "wpp_tiles_slices", "rext_ts_bypass_422_10"):
+        data = corpus.stream(name)
+        for _ in range(250):
+            b = bytearray(data)
+            for _ in range(rng.randrange(1, 4)):
+                i = rng.randrange(len(b) // 4, len(b))
+                b[i] = rng.randrange(256) if rng.random() < 0.3 else b[i] ^ (1 << rng.randrange(8))
+            try:
+                blob = hevcutil.parse(hm, bytes(b))
+            except RuntimeError:
+                continue
+            taken += 1
+            assert hm.hm_stream_validate(blob, len(blob)) == 0, f"{name}: {hm.hm_last_error().decode()}"
+    assert taken > 50
+
+
 def test_truncated_heif_is_an_error(hm):
     data = heifwriter.write_heic(_tiles(1), (64, 64))
     for cut in (0, 4, 11, 40, len(data) // 2):
