@@ -111,6 +111,8 @@ struct CLayout {
   // the bands in turn - wave b the bands b, b + bands_per_pic, ... - so that they work side by side like the rows of a
   // wavefront (a wave per run of CONSECUTIVE bands would wait for the last row of the run above: no overlap at all)
   int passes;
+  int ring;          // PAIRS: the bands_per_pic waves of a picture lie in ONE workgroup and hand every row over through its LDS,
+                     // the last of them to the first (k_chain: wg_ring) - no wave of the launch waits for another workgroup
   int spin_limit;    // PAIRS: polls of the band above without news before a wave gives up (error flag, wrong picture, no hang)
   int test_stall;    // fault injection (tests): the first band of every picture never announces its progress
 };
@@ -347,19 +349,30 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   int pidx = pair_index; // the band the group works on now (the wave's next one: pidx + W)
   // progress counter of a row in flight: row % 8 (rows of a wave per picture are NR apart), PAIRS: alternating halves per
   // band the group has worked on (the rows of a wave's consecutive bands may be a multiple of 8 apart)
-  int pbank = 0;
-  auto prog_index = [&](int r, int slot) { return PAIRS ? pbank * 4 + (slot & 3) : (r & (C_PROG - 1)); };
+  int npass = 0; // bands the group has finished
+  auto prog_index = [&](int r, int slot) { return PAIRS ? (npass & 1) * 4 + (slot & 3) : (r & (C_PROG - 1)); };
   // One CTU row per wave, a wave per band: the band above is the task S before this one, the band below the task S behind it -
   // waves of this workgroup unless the workgroup ends in between.  Such neighbours skip HBM: the wave above writes the bottom
   // sample line of every CTU it finishes straight into this wave's sample line (the place the copy from the hand-over line
   // would fill) and its progress into this wave's counter for "the row above" - exactly what a group of a wave that works
   // on two rows does for the group below it, one pic_bytes further.  (r04: the trip through HBM - drain the stores, flag,
   // poll, copy the line - was ~40 % of a CTU step on the critical path of the few-pictures cuts.)
+  // Mid-size batches (`wg_ring`): the W waves that take a picture's bands in turn all lie in one workgroup and wave W - 1 hands over
+  // to wave 0 - every hand-over of the launch stays in LDS, whatever the rows per wave.  The line a wave receives for band
+  // p + W is written while it may still work on band p, but only where band p has read it for the last time (the writer depends on
+  // band p through the W - 1 bands in between, each two CTUs behind the one above); the counter carries the receiving band's
+  // pass in its upper half, so a value of the band before compares as "nothing yet" and none of the band after can come too early.
   const int S = PAIRS ? 1 << L.split_kinds : 0;
-  const bool lds_rows = PAIRS && MODE >= 2 && L.bands_per_pic == L.passes; // (MODE >= 2: RPW == 1)
-  const bool lds_above = lds_rows && pair_index > 0 && wave >= S;
-  const bool lds_below = lds_rows && wave + S < wg_waves; // (if there is a band below at all)
-  uint8_t* const pbase_below = PAIRS ? pbase + S * L.pic_bytes : pbase;
+  const bool wg_ring = PAIRS && L.ring != 0;
+  const bool lds_rows = PAIRS && !wg_ring && MODE >= 2 && L.bands_per_pic == L.passes; // (MODE >= 2: RPW == 1)
+  const bool lds_above = wg_ring || (lds_rows && pair_index > 0 && wave >= S);
+  const bool lds_below = wg_ring || (lds_rows && wave + S < wg_waves); // (if there is a band below at all)
+  const int below_waves = wg_ring && pair_index == W - 1 ? -(W - 1) * S : S;
+  uint8_t* const pbase_below = PAIRS ? pbase + below_waves * L.pic_bytes : pbase;
+  const int below_pass = wg_ring && pair_index == W - 1 ? 1 : 0; // (the band below a ring's last wave belongs to the next pass)
+  // the counter of "the row above a wave's first row" when that row is another wave's (monochrome: every counter of the luma
+  // chains may be in use - four rows, two banks -, the chroma chains' are not)
+  const int above_ctr_index = (mono ? 1 : 0) * C_PROG + 3;
   bool from_hbm = PAIRS && my_slot == 0 && pidx > 0 && !lds_above; // the row above belongs to a wave of another workgroup
   auto load_window = [&](uint32_t w) {
     if constexpr (WLOG == 4) { // a record per lane
@@ -429,9 +442,12 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         const int src = fg * 16;
         const int s_row = __builtin_amdgcn_readlane(row, src), s_cx = __builtin_amdgcn_readlane(cx, src);
         const int fkind = group_kind(fg);
-        const bool to_lds_below = lds_below && s_row + 1 < ctb_h; // (RPW == 1: the band below is a wave of this workgroup)
+        const bool to_lds_below = lds_below && group_slot(fg) == RPW - 1 && s_row + 1 < ctb_h; // (the band below is a wave of this workgroup)
         Pix* lw = line_of(fkind, group_slot(fg)); // s_row % NR
-        if (to_lds_below) lw = reinterpret_cast<Pix*>(pbase_below + (fkind ? L.off_lines_c : L.off_lines_l)) + 4; // (its only line: line_of(kind, 0))
+        if (to_lds_below) { // the line its first row reads: line_of(kind, NR - 1) of that wave (its only line if it works on one row)
+          const int slot_b = L.line_slots == 1 ? 0 : NR - 1;
+          lw = reinterpret_cast<Pix*>(pbase_below + (fkind ? L.off_lines_c + slot_b * L.line_c_bytes : L.off_lines_l + slot_b * L.line_l_bytes)) + 4;
+        }
         const bool keep_line = !PAIRS || RPW > 1 || to_lds_below;
         auto flush_plane = [&](auto bw_c, Pix* u, int P, Pix* line, uint8_t* plane, int pitch, int bh, int pw, int ph) {
           constexpr int BW = decltype(bw_c)::value;
@@ -478,13 +494,15 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         }
         WAVE_SYNC();
         // read by the chain of the row below, a group of this wave (LDS traffic of a wave is in order)
-        const int s_prog = PAIRS ? __builtin_amdgcn_readlane(pbank, src) * 4 + group_slot(fg) : (s_row & (C_PROG - 1));
+        const int s_pass = PAIRS ? __builtin_amdgcn_readlane(npass, src) : 0;
+        const int s_prog = PAIRS ? (s_pass & 1) * 4 + group_slot(fg) : (s_row & (C_PROG - 1));
         if (lane == 0) __hip_atomic_store(progress + fkind * C_PROG + s_prog, s_cx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        // ... or a wave of this workgroup: its counter of the row above (prog_index(row - 1, -1) of a wave's first band)
+        // ... or a wave of this workgroup: its counter of the row above
         // (the fault injection of the tests - a first band that never announces its progress - applies to either way: the wave below
         //  then runs out of its iteration budget, flags the launch and leaves)
         if (to_lds_below && lane == 0 && !(L.test_stall && __builtin_amdgcn_readlane(pidx, src) == 0))
-          __hip_atomic_store(reinterpret_cast<int*>(pbase_below) + fkind * C_PROG + 3, s_cx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_store(reinterpret_cast<int*>(pbase_below) + fkind * C_PROG + above_ctr_index, ((s_pass + below_pass) << 16) + s_cx + 1, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_WORKGROUP);
         if (PAIRS && !to_lds_below && group_slot(fg) == RPW - 1 && s_row + 1 < ctb_h) {
           // ... or, for the pair's last row, the first row of the pair below: another wave, anywhere on the chip.  The
           // CTU's bottom sample line goes to the pair's hand-over line with agent-scope stores; once they have left this
@@ -514,7 +532,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
             tl_off = lr_off;
             // the group's next row: NR further (a wave per picture), or in the wave's next band (PAIRS)
             row += PAIRS ? RPW * W : NR;
-            if (PAIRS) { pidx += W; pbank ^= 1; from_hbm = my_slot == 0 && !lds_above; hbm_have = 0; hbm_polls = 0; }
+            if (PAIRS) { pidx += W; npass += 1; from_hbm = my_slot == 0 && !lds_above; hbm_have = 0; hbm_polls = 0; }
             if (row < ctb_h) row_start();
             else st = ST_DONE;
           }
@@ -526,7 +544,10 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       if (st == ST_START) {
         const int need = cx + 2 < ctb_w ? cx + 2 : ctb_w;
         // (a counter value seen here means the line samples written before it are there: LDS traffic of a wave is in order)
-        int done_above = __hip_atomic_load(my_progress + prog_index(row - 1, my_slot - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const bool wave_above = lds_above && my_slot == 0; // (the counter a wave of this workgroup writes, with the pass in its upper half)
+        int done_above = __hip_atomic_load(wave_above ? my_progress + above_ctr_index : my_progress + prog_index(row - 1, my_slot - 1), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (wave_above) done_above -= npass << 16;
         if (from_hbm) done_above = hbm_have;
         if (row == 0 || done_above >= need) {
           uint32_t count = c1;
@@ -1168,11 +1189,27 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   }
   static const int force_share = [] { const char* e = getenv("HM_CHAIN_SHARE"); return e ? atoi(e) : 0; }(); // (tuning aid: waves per picture that take its pairs of rows in turn)
   if (force_share >= 2 && max_ctb_h > nr) { pairs = true; L.rows_per_wave = nr; L.split_kinds = 0; share = force_share; }
+  // ... with all of them in one workgroup, handing over through LDS in a ring (k_chain: wg_ring): no wave waits for another
+  // workgroup, so any number of them may be in flight.  HM_CHAIN_RING = W forces it (0: never), with HM_CHAIN_PAIRS = 1 / 2 / 3
+  // for the rows and chains per wave.
+  static const int force_ring = [] { const char* e = getenv("HM_CHAIN_RING"); return e && e[0] ? atoi(e) : -1; }();
+  int ring_w = 0; // (chosen below, once the layout and the kernel of a cut can be worked out)
+  if (force_ring >= 0) {
+    ring_w = force_ring >= 2 && max_ctb_h > 1 ? (force_ring > 16 ? 16 : force_ring) : 0;
+    if (ring_w) {
+      L.rows_per_wave = force_pairs >= 2 ? 1 : nr;
+      L.split_kinds = force_pairs >= 3 && !mono ? 1 : 0;
+      if (max_ctb_h <= L.rows_per_wave) ring_w = 0;
+    }
+  }
+  if (ring_w) { pairs = true; share = 0; }
   L.spin_limit = g_chain_spin_limit > 0 ? g_chain_spin_limit : SPIN_LIMIT;
   L.test_stall = g_chain_test_stall;
   auto sync_words = [&](int bands) { return ((size_t)SYNC_PROGRESS + 2 * (size_t)n_pics * bands) * sizeof(uint32_t); };
   auto passes_of = [&]() { return (max_ctb_h + L.rows_per_wave - 1) / L.rows_per_wave; };
-  if (!d_sync || !d_err || sync_bytes < sync_words(passes_of())) { pairs = false; share = 0; }
+  if (!d_sync || !d_err || sync_bytes < sync_words(passes_of())) { pairs = false; share = 0; ring_w = 0; }
+  if (ring_w > passes_of()) ring_w = passes_of(); // (a wave per band)
+  while (ring_w && (ring_w << L.split_kinds) > 16) ring_w--; // (a workgroup holds 16 waves)
   if (!pairs) { L.rows_per_wave = nr; L.split_kinds = 0; }
   // ---- LDS of a wave ----
   auto set_layout = [&]() -> bool { // for the cut in L; false if a wave does not fit the CU's LDS
@@ -1206,7 +1243,7 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
     // a very wide picture (16-bit samples, > ~9000 columns): its sample lines of two rows and both kinds do not fit one
     // wave's share of LDS - the finer cuts keep one line per wave (a wave per CTU row), or one line of one kind (also for
     // a picture of ONE CTU row: its two kinds of chains are two waves)
-    pairs = true; share = 0;
+    pairs = true; share = 0; ring_w = 0;
     L.rows_per_wave = 1; L.split_kinds = 0;
     fits = set_layout();
     if (!fits && !mono) { L.split_kinds = 1; fits = set_layout(); }
@@ -1258,7 +1295,8 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
     //  r04: 32720 bytes per workgroup put four workgroups on a CU, 31712 five; and four workgroups of 40960 - all 160 KiB - did
     //  not share a CU either, so one granule is kept out of the sum)
     constexpr int LDS_GRANULE = 1280, LDS_USABLE = 160 * 1024 - LDS_GRANULE;
-    for (int k = 1; k <= 8; k++) {
+    const int unit = prs && ring_w ? ring_w << L.split_kinds : 1; // (a ring: whole pictures per workgroup)
+    for (int k = unit; k <= (unit > 8 ? unit : 8); k += unit) {
       const int bytes = (C_SHARED + k * L.pic_bytes + LDS_GRANULE - 1) / LDS_GRANULE * LDS_GRANULE;
       if (bytes > 160 * 1024) break;
       const int by_lds = LDS_USABLE / bytes, by_regs = cu_waves / k;
@@ -1267,11 +1305,7 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
     }
     return np > 0;
   };
-  if (!pick(pairs)) return 0;
-  if (share) {
-    // The waves of a picture that take its bands in turn wait for each other in both directions: all of them must be on
-    // the device together.  Its capacity for this kernel: compute units x the waves a CU holds of it (`best`: registers
-    // and this cut's LDS); the forced value (HM_CHAIN_SHARE) is clamped like the chosen one.
+  auto cus = [] { // compute units of the current device
     static int cus_of[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -1279,7 +1313,43 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
       int v = 0;
       cus_of[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
     }
-    const long resident_waves = (long)cus_of[dev] * best;
+    return cus_of[dev];
+  };
+  if (force_ring < 0 && force_pairs < 0 && force_share < 2 && fits && 2 * row_waves > 3500 && d_sync && d_err) {
+    // Too many pictures for a wave per chain of every CTU row: the finest cut whose waves are all resident at once, with a
+    // picture's waves in one workgroup (the ring).  Measured on MI355X with 512x512 tiles (r04, ms of both reconstruction
+    // kernels; without the ring / with): 128 tiles 1.09 / 0.76, 256: 1.99 / 0.82 (8 bands x 2 kinds of chains), 384: 2.11 / 1.21,
+    // 512: 2.15 / 1.28 (4 x 2), 768: 2.43 / 2.01, 1024: 2.70 / 2.34 (2 x 2), 1536: 3.51 / 3.32, 2048: 4.04 / 3.87 (2 waves, a pair
+    // of rows each).  More waves than the device holds cost more than they give (320 tiles: 16 waves per picture 1.49, 8: 1.20),
+    // and between 1024 and 1365 tiles three waves per picture handing over through HBM beat two in a ring (1280: 3.12 / 3.21).
+    const CLayout keep = L;
+    const bool keep_pairs = pairs;
+    static const struct { int one_row, split, w; } cand[4] = {{1, 1, 8}, {1, 1, 4}, {1, 1, 2}, {0, 0, 2}};
+    for (const auto& c : cand) {
+      const int rpw = c.one_row ? 1 : nr, split = mono ? 0 : c.split;
+      if (max_ctb_h <= rpw) continue;
+      const int bands = (max_ctb_h + rpw - 1) / rpw, w = c.w < bands ? c.w : bands, per_pic = w << split;
+      if (per_pic <= 2 && share >= 3 && 3l * n_pics <= (long)cus() * 16) break; // (three per picture through HBM, all resident)
+      if ((long)n_pics * per_pic > (long)cus() * 16 || sync_bytes < sync_words(bands)) continue;
+      L.rows_per_wave = rpw; L.split_kinds = split; pairs = true; ring_w = w;
+      // (four waves per SIMD: a fifth - the one-chain kernel's registers would allow it - measured no gain, 1100 tiles 3.07 ms against 3.00)
+      if (set_layout() && pick(true) && (long)n_pics * per_pic <= (long)cus() * (best < 16 ? best : 16)) { share = 0; break; }
+      ring_w = 0;
+    }
+    if (!ring_w) { L = keep; pairs = keep_pairs; set_layout(); }
+  }
+  if (!pick(pairs)) {
+    if (!ring_w) return 0;
+    // (the waves of a picture do not fit one workgroup's LDS: the cut for many pictures, a wave each)
+    ring_w = 0; pairs = false;
+    L.rows_per_wave = nr; L.split_kinds = 0;
+    if (!set_layout() || !pick(false)) return 0;
+  }
+  if (share) {
+    // The waves of a picture that take its bands in turn wait for each other in both directions: all of them must be on
+    // the device together.  Its capacity for this kernel: compute units x the waves a CU holds of it (`best`: registers
+    // and this cut's LDS); the forced value (HM_CHAIN_SHARE) is clamped like the chosen one.
+    const long resident_waves = (long)cus() * best;
     long w = resident_waves / n_pics;
     if (!force_share || force_share < 2) w = w > 4 ? 4 : w;
     if (w < share) share = (int)w;
@@ -1290,24 +1360,27 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
     }
   }
   L.passes = passes_of();
-  L.bands_per_pic = share && share < L.passes ? share : L.passes;
+  L.bands_per_pic = share && share < L.passes ? share : (ring_w ? ring_w : L.passes);
+  L.ring = ring_w ? 1 : 0;
   const size_t sync_need = sync_words(L.passes);
   static const int force_np = [] { const char* e = getenv("HM_CHAIN_NP"); return e ? atoi(e) : 0; }(); // (tuning aid, read once)
   const long n_waves = pairs ? ((long)n_pics * L.bands_per_pic) << L.split_kinds : (long)n_pics;
   // A wave per CTU row (or per chain of one): neighbouring rows in one workgroup hand over through LDS (k_chain: lds_above) -
   // the more waves a workgroup holds, the fewer hand-overs go through HBM.  Eight: one in eight (sixteen measured no better).
-  const bool lds_rows = pairs && L.rows_per_wave == 1 && L.bands_per_pic == L.passes;
-  if (lds_rows) {
+  const bool lds_rows = pairs && !ring_w && L.rows_per_wave == 1 && L.bands_per_pic == L.passes;
+  if (ring_w) {} // (whole pictures per workgroup: pick())
+  else if (lds_rows) {
     np = 8;
     while (np > 1 && C_SHARED + np * L.pic_bytes > 64 * 1024) np--;
   }
   else while (np > 1 && (long)np * 256 > n_waves) np--; // few waves: spread them over the CUs first
-  if (force_np > 0 && force_np <= 16 && C_SHARED + force_np * L.pic_bytes <= 160 * 1024) np = force_np;
+  if (force_np > 0 && force_np <= 16 && C_SHARED + force_np * L.pic_bytes <= 160 * 1024 && (!ring_w || force_np % (ring_w << L.split_kinds) == 0)) np = force_np;
   const int lds_bytes = C_SHARED + np * L.pic_bytes;
   static const int debug = [] { const char* e = getenv("HM_CHAIN_DEBUG"); return e ? atoi(e) : 0; }();
   if (debug) fprintf(stderr, "[k_chain] %d pictures, %ld waves (%s), %d bytes of LDS per wave, %d waves per workgroup, %d waves per CU\n", n_pics, n_waves,
                      !pairs ? "one per picture" : (L.split_kinds ? "one per chain of a CTU row" : (L.rows_per_wave == 1 ? "one per CTU row" : (L.bands_per_pic < L.passes ? "several per picture, taking its pairs of CTU rows in turn" : "one per pair of CTU rows"))),
                      L.pic_bytes, np, best);
+  if (debug && ring_w) fprintf(stderr, "[k_chain] a picture's %d waves in one workgroup, rows handed over through LDS in a ring\n", ring_w << L.split_kinds);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return hm_check_hip(e, "hipFuncSetAttribute(k_chain)");
   if (pairs) {

@@ -23,22 +23,28 @@ def main():
         if os.environ.get(env):
             assert hm.hm_debug_set(knob, int(os.environ[env])) == 0
     names = sys.argv[1:] or ["tile512_a", "ctb64_wpp", "hi422_10", "mono8", "ragged"]
+    copies = int(os.environ.get("HM_CHECK_COPIES", "3"))  # (hundreds: the cuts the launcher chooses for mid-size batches)
     for name in names:
         if name == "wide16k":  # the widest picture class: CTB 64, 16-bit storage, 4:2:2, 16384 columns, two CTU rows
             import synthutil
-            blob = pkg.capi.parse_hevc(synthutil.picture(515151, width=16384, height=128, log2_ctb=6, bit_depth=10, chroma_format=2, qp=32, density=30))
+            blobs = [pkg.capi.parse_hevc(synthutil.picture(515151, width=16384, height=128, log2_ctb=6, bit_depth=10, chroma_format=2, qp=32, density=30))] * copies
+        elif name == "mixed":  # pictures of one class and different sizes in one launch (the cut follows the tallest; short ones leave waves idle)
+            blobs = [pkg.capi.parse_hevc(corpus.stream(n)) for n in ("tile512_a", "ragged", "dense_lowqp", "no_deblock", "tile512_b", "ragged")] * 2
         else:
-            blob = pkg.capi.parse_hevc(corpus.stream(name))
+            blobs = [pkg.capi.parse_hevc(corpus.stream(name))] * copies
         try:
-            got = gpudecode.decode_pictures(pkg, [blob] * 3, 3)
+            got = gpudecode.decode_pictures(pkg, blobs, 3)
         except RuntimeError as e:
             print("CHECK FAILED:", e)
             return 3
-        exp, _ = orc.oracle_decode(blob, 3, crop=True)
-        for pic in got:
+        expected = {}
+        for i, pic in enumerate(got):
+            if id(blobs[i]) not in expected:
+                expected[id(blobs[i])] = orc.oracle_decode(blobs[i], 3, crop=True)[0]
+            exp = expected[id(blobs[i])]
             for c in range(len(exp)):
                 if not np.array_equal(pic[c], exp[c]):
-                    print(f"{name}: plane {c} differs")
+                    print(f"{name}: picture {i} plane {c} differs")
                     return 1
     print("OK")
     return 0

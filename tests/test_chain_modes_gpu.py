@@ -35,6 +35,26 @@ def test_waves_that_take_the_row_pairs_of_a_picture_in_turn(share):
     assert "in turn" in r.stderr, r.stderr
 
 
+@pytest.mark.parametrize("cut", [1, 2, 3])
+@pytest.mark.parametrize("waves", [2, 3, 8])
+def test_waves_of_a_picture_in_one_workgroup_hand_over_in_a_ring(waves, cut):
+    """mid-size batches: the W waves that take a picture's bands (pairs of rows, rows, chains of a row) in turn lie in one workgroup,
+    every hand-over - also from the last wave back to the first - goes through its LDS (chain.hip: wg_ring)"""
+    r = _run({"HM_CHAIN_RING": str(waves), "HM_CHAIN_PAIRS": str(cut), "HM_QUAD_CLASS": "1", "HM_CHAIN_DEBUG": "1"})
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+    assert "in a ring" in r.stderr, r.stderr
+    r = _run({"HM_CHAIN_RING": str(waves), "HM_CHAIN_PAIRS": str(cut)}, "mixed")
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_mid_size_batches_choose_the_ring():
+    """300 tiles of 512x512: too many for a wave per chain of every CTU row, too few for a wave per picture - the launcher's own
+    choice must be the ring, and the pictures the oracle's"""
+    r = _run({"HM_CHECK_COPIES": "300", "HM_CHAIN_DEBUG": "1"}, "tile512_a")
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+    assert "in a ring" in r.stderr, r.stderr
+
+
 @pytest.mark.parametrize("segs", [2, 5, 16])
 def test_residual_prepass_in_segments_of_a_row(segs):
     """few pictures: k_residual cuts every CTU row into runs of CTUs (the levels of a run start where the CTU header says,
@@ -54,6 +74,11 @@ def test_widest_pictures_fall_back_to_a_finer_cut():
 @pytest.mark.parametrize("cut", [1, 2, 3])
 def test_bounded_waits_flag_the_launch(cut):
     r = _run({"HM_CHAIN_PAIRS": str(cut), "HM_CHAIN_TEST_STALL": "1", "HM_CHAIN_SPIN_LIMIT": "2000"}, "tile512_a", timeout=120)
+    assert r.returncode == 3 and "gave up waiting" in r.stdout, r.stdout + r.stderr
+
+
+def test_bounded_waits_in_the_ring():
+    r = _run({"HM_CHAIN_RING": "4", "HM_CHAIN_PAIRS": "2", "HM_CHAIN_TEST_STALL": "1", "HM_CHAIN_SPIN_LIMIT": "2000"}, "tile512_a", timeout=120)
     assert r.returncode == 3 and "gave up waiting" in r.stdout, r.stdout + r.stderr
 
 
