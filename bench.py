@@ -644,6 +644,7 @@ def side_legs(out, args, torch, pkg, dev, st, gb, kept, strides, stream_b):
     gb.images.clear()
     torch.cuda.empty_cache()
     guarded(out, "real_content", lambda: real_content(torch, pkg, dev, st))
+    guarded(out, "real_content_256_pictures", lambda: real_content(torch, pkg, dev, st, n=256))  # (a mid-size batch: k_chain's ring cut)
     guarded(out, "config4_422_10bit_rgb48", lambda: config4(torch, pkg, dev, st))
     guarded(out, "config5_16384_grid", lambda: config5_single(torch, pkg, dev, st))
 
@@ -940,7 +941,7 @@ def cpu_baseline(kept, budget_s, threads):
                       f"cmake); one tile per task on {threads} thread(s); {os.cpu_count()} host cpus visible"}
 
 
-def real_content(torch, pkg, dev, st):
+def real_content(torch, pkg, dev, st, n=32):
     """The three real 1080p intra frames of the reference's test material (third-party/libde265/testfile, committed
     as tests/data/*.hevc; CTB 64, WPP, SAO, SDH, transform skip), 32 copies of each in one batch: per-kernel ms / MP on
     real-encoder block statistics next to the random-syntax headline."""
@@ -951,7 +952,6 @@ def real_content(torch, pkg, dev, st):
         if not os.path.exists(path):
             continue
         blob = capi.parse_hevc(open(path, "rb").read())
-        n = 32
         gb = GridBatch(pkg, dev, 1, 1, 0, 1920, 1080)
         for _ in range(n):
             gb.add_image([blob])
@@ -966,16 +966,16 @@ def real_content(torch, pkg, dev, st):
         gb.batch.close()
         gb.images.clear()
         torch.cuda.empty_cache()
-    res["note"] = "32 copies of one 1080p intra picture per batch (2073600 px each), K clock; the headline's synthetic tiles cost the ms/MP of 'kernels' / 4644.9 MP"
+    res["note"] = f"{n} copies of one 1080p intra picture per batch (2073600 px each), K clock; the headline's synthetic tiles cost the ms/MP of 'kernels' / 4644.9 MP"
     return res
 
 
-def config4(torch, pkg, dev, st):
+def config4(torch, pkg, dev, st, n=32):
     """a single 2048x1536 10-bit 4:2:2 image (seed 4220010, CTB 32, VUI matrix 9 limited range)
     -> interleaved RRGGBB_LE (6 B/px, float chain); 32 copies per batch, K clock incl. the colour kernel."""
     import synthutil
     capi, L = pkg.capi, pkg.lib()
-    W, H, n = 2048, 1536, 32
+    W, H = 2048, 1536
     data = synthutil.picture(4220010, width=W, height=H, chroma_format=2, bit_depth=10, log2_ctb=5, qp=30, vui=1, full_range=0, matrix=9, primaries=9)
     blob = capi.parse_hevc(data)
     ys, cs, os_ = L.hm_plane_stride(W, 2), L.hm_plane_stride(W // 2, 2), L.hm_plane_stride(W, 6)

@@ -1315,13 +1315,30 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
     }
     return cus_of[dev];
   };
-  if (force_ring < 0 && force_pairs < 0 && force_share < 2 && fits && 2 * row_waves > 3500 && d_sync && d_err) {
+  if (force_ring < 0 && force_pairs < 0 && force_share < 2 && fits && 2 * row_waves > 2800 && d_sync && d_err) {
     // Too many pictures for a wave per chain of every CTU row: the finest cut whose waves are all resident at once, with a
-    // picture's waves in one workgroup (the ring).  Measured on MI355X with 512x512 tiles (r04, ms of both reconstruction
-    // kernels; without the ring / with): 128 tiles 1.09 / 0.76, 256: 1.99 / 0.82 (8 bands x 2 kinds of chains), 384: 2.11 / 1.21,
-    // 512: 2.15 / 1.28 (4 x 2), 768: 2.43 / 2.01, 1024: 2.70 / 2.34 (2 x 2), 1536: 3.51 / 3.32, 2048: 4.04 / 3.87 (2 waves, a pair
-    // of rows each).  More waves than the device holds cost more than they give (320 tiles: 16 waves per picture 1.49, 8: 1.20),
-    // and between 1024 and 1365 tiles three waves per picture handing over through HBM beat two in a ring (1280: 3.12 / 3.21).
+    // picture's waves in one workgroup (the ring) - if it beats the cut chosen above by this estimate: a picture takes
+    // `steps` CTU steps (R rows in flight: rows x columns / R + 2 R; the whole wavefront: columns + 2 rows), and a step costs by the
+    // chains a wave works on - 1 : 2.5 : 3.3 for one, two (a row), four (a pair of rows); a wave per chain of every row: 1.4 once
+    // its waves crowd the SIMDs.  Calibrated on MI355X (r04, profiles/r04_ring_sweep.txt), ms of both reconstruction kernels
+    // without / with the ring: 512x512 tiles 128: 1.09 / 0.76, 256: 1.99 / 0.82, 512: 2.15 / 1.28, 1024: 2.70 / 2.34, 2048: 4.04 / 3.87,
+    // but 1280: 3.12 / 3.21 (three waves per picture through HBM: kept); 1080p CTB 64, GP/s: 64 pictures 39 / 35 (kept), 96: 40 / 47,
+    // 256: 28 / 82; 2048x1536 10-bit 4:2:2 (48 rows of 64 CTUs), k_chain ms: 32 pictures 2.9 / 55 and 64: 9.2 / 11.4 (kept), 128: 18.6 / 11.4.
+    // More waves than the device holds at four per SIMD cost more than they give (320 tiles: 16 per picture 1.49 ms, 8: 1.20).
+    const long capacity = (long)cus() * 16;
+    auto steps_of = [&](long in_flight) -> long {
+      return in_flight >= max_ctb_h ? (long)max_ctb_w + 2l * max_ctb_h : ((long)max_ctb_h * max_ctb_w + in_flight - 1) / in_flight + 2 * in_flight;
+    };
+    auto step_cost = [&](int rpw, int split) -> long { return rpw > 1 ? 330 : (split || mono ? 105 : 250); };
+    long cost_now;
+    if (!pairs) cost_now = steps_of(nr) * 330;
+    else if (share) {
+      const long fit = capacity / n_pics;
+      cost_now = steps_of((fit < share ? (fit < 1 ? 1 : fit) : share) * nr) * 330;
+    }
+    else if (L.rows_per_wave > 1) cost_now = steps_of(max_ctb_h) * 330;
+    else if (L.split_kinds || mono) cost_now = steps_of(max_ctb_h) * 140;
+    else cost_now = steps_of(max_ctb_h) * 250;
     const CLayout keep = L;
     const bool keep_pairs = pairs;
     static const struct { int one_row, split, w; } cand[4] = {{1, 1, 8}, {1, 1, 4}, {1, 1, 2}, {0, 0, 2}};
@@ -1329,10 +1346,9 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
       const int rpw = c.one_row ? 1 : nr, split = mono ? 0 : c.split;
       if (max_ctb_h <= rpw) continue;
       const int bands = (max_ctb_h + rpw - 1) / rpw, w = c.w < bands ? c.w : bands, per_pic = w << split;
-      if (per_pic <= 2 && share >= 3 && 3l * n_pics <= (long)cus() * 16) break; // (three per picture through HBM, all resident)
-      if ((long)n_pics * per_pic > (long)cus() * 16 || sync_bytes < sync_words(bands)) continue;
+      if ((long)n_pics * per_pic > capacity || sync_bytes < sync_words(bands)) continue;
+      if (steps_of((long)w * rpw) * step_cost(rpw, split) > cost_now) continue;
       L.rows_per_wave = rpw; L.split_kinds = split; pairs = true; ring_w = w;
-      // (four waves per SIMD: a fifth - the one-chain kernel's registers would allow it - measured no gain, 1100 tiles 3.07 ms against 3.00)
       if (set_layout() && pick(true) && (long)n_pics * per_pic <= (long)cus() * (best < 16 ? best : 16)) { share = 0; break; }
       ring_w = 0;
     }
