@@ -61,6 +61,7 @@ def main():
         mp = n * 0.262144
         out[name] = {"tiles": n, "k_recon_ms": round(ms[0], 3), "k_deblock_ms": round(ms[1], 3), "k_sao_paste_ms": round(ms[2], 3),
                      "GP_per_s_kernels": round(mp / sum(ms), 1)}
+        batch.check()  # (also prints the phase sums of an instrumented k_chain: HM_CHAIN_TIMING_PRINT=1)
         batch.close()
     print(json.dumps(out, indent=1))
 
