@@ -29,10 +29,12 @@
 //     smaller ticket, which is running or done: no deadlock whatever the dispatch order.  When W waves take a picture's
 //     bands in turn (the "share" cut) that does not hold - wave 0's second band waits for band W - 1, which the wave
 //     with ticket W - 1 holds -: forward progress then needs all W waves of a picture resident together, which the
-//     launcher guarantees by capping W x pictures at the waves the device holds at once (resident_waves below).  The hand-over between pairs goes through HBM: the
-//     bottom sample row of a pair is a row of the picture the kernel stores anyway; a per-row progress word
-//     (agent scope) tells the pair below how far it is.  Every wait is bounded: a wave that waits too long sets the
-//     launch's error word and leaves, the host reports HM_ERR_INTERNAL.
+//     launcher guarantees by capping W x pictures at the waves the device holds at once (resident_waves below).  The hand-over
+//     between workgroups goes through HBM: the bottom sample row of a band goes to a hand-over line with agent-scope stores, a
+//     per-band progress word tells the band below how far it is; between waves of ONE workgroup it goes through LDS (lds_above /
+//     lds_below).  Mid-size batches put all W waves of a picture into one workgroup (the ring, wg_ring): nothing through HBM,
+//     no residency condition.  Every wait is bounded: a wave that waits too long sets the launch's error word and leaves,
+//     the host reports HM_ERR_INTERNAL.
 // Several pictures (waves) share a workgroup only to share the constant tables in LDS.
 // Pictures with rare syntax (scaling lists, PCM, transquant bypass, 4:4:4, range extensions) stay on recon.hip's RARE
 // variant.  Integer work, HBM-write-only picture: no MFMA.
