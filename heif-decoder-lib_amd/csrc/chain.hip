@@ -1324,7 +1324,7 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
     // chains a wave works on - 1 : 2.5 : 3.3 for one, two (a row), four (a pair of rows); a wave per chain of every row: 1.4 once
     // its waves crowd the SIMDs.  Calibrated on MI355X (r04, profiles/r04_ring_sweep.txt), ms of both reconstruction kernels
     // without / with the ring: 512x512 tiles 128: 1.09 / 0.76, 256: 1.99 / 0.82, 512: 2.15 / 1.28, 1024: 2.70 / 2.34, 2048: 4.04 / 3.87,
-    // but 1280: 3.12 / 3.21 (three waves per picture through HBM: kept); 1080p CTB 64, GP/s: 64 pictures 39 / 35 (kept), 96: 40 / 47,
+    // 1280: 3.12 / 2.92 (three waves of a row pair each; two: 3.21); 1080p CTB 64, GP/s: 64 pictures 39 / 35 (kept), 96: 40 / 47,
     // 256: 28 / 82; 2048x1536 10-bit 4:2:2 (48 rows of 64 CTUs), k_chain ms: 32 pictures 2.9 / 55 and 64: 9.2 / 11.4 (kept), 128: 18.6 / 11.4.
     // More waves than the device holds at four per SIMD cost more than they give (320 tiles: 16 per picture 1.49 ms, 8: 1.20).
     const long capacity = (long)cus() * 16;
@@ -1343,7 +1343,7 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
     else cost_now = steps_of(max_ctb_h) * 250;
     const CLayout keep = L;
     const bool keep_pairs = pairs;
-    static const struct { int one_row, split, w; } cand[4] = {{1, 1, 8}, {1, 1, 4}, {1, 1, 2}, {0, 0, 2}};
+    static const struct { int one_row, split, w; } cand[5] = {{1, 1, 8}, {1, 1, 4}, {1, 1, 2}, {0, 0, 3}, {0, 0, 2}};
     for (const auto& c : cand) {
       const int rpw = c.one_row ? 1 : nr, split = mono ? 0 : c.split;
       if (max_ctb_h <= rpw) continue;
