@@ -147,6 +147,7 @@ constexpr int chain_waves_per_simd = (sizeof(Pix) == 1 && !PAIRS) ? (LOG2_CTB <=
 // wave (1: a pair of CTU rows), 2 chains (2: one CTU row) or 1 chain (3: one chain of a row) - the chains per wave as a compile-time
 // constant: the multi-record bookkeeping of the cuts with fewer than four chains sits on the critical path of a wave that is
 // alone on its SIMD, and with a run-time count it was loops, selects and a dozen spilled scalar registers (r04)
+// MODE 4 = MODE 3 in a ring whose waves ALTERNATE between the luma and the chroma chains from band to band (ALT in the kernel)
 constexpr int chain_mode_ncl(int mode) { return mode <= 1 ? 2 : (mode == 2 ? 1 : 0); }
 #ifdef HM_WPE
 #define HM_CHAIN_ATTR __attribute__((amdgpu_waves_per_eu(HM_WPE, HM_WPE)))
@@ -291,6 +292,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   // cuts; only reading the reference samples, the blend and the store run one record after the other (phase C below).  In
   // these cuts a wave is alone on its SIMD and an iteration is a chain of latencies, not of instructions: what counts is the
   // number of iterations per record.  All groups of a chain hold identical chain state (the same loads, the same updates).
+  constexpr bool ALT = MODE == 4;
   constexpr int NCL = chain_mode_ncl(MODE); // log2 of the chains per wave (the launcher: split kinds or one row of a monochrome picture 0, one row 1, else 2)
   constexpr int SUB = 4 >> NCL;             // records of a chain per iteration
   constexpr unsigned long long main_mask = NCL == 2 ? ~0ull : (NCL == 1 ? 0xFFFFFFFFull : 0xFFFFull); // the groups with offset 0
@@ -318,13 +320,14 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   const int g = PAIRS ? g_phys & ((1 << NCL) - 1) : g_phys; // the chain (= its first group) this lane works on
   const int my_off = PAIRS ? g_phys >> NCL : 0;             // ... and how many records ahead of the chain's current one
   int16_t* const rres = rres_all + g * (RING * 16);
-  const int kind = group_kind(g); // 0: luma chain, 1: chroma chain
+  // (constants of the lane, except in the cut whose waves change the kind of chain from band to band: ALT, set_kind below)
+  int kind = group_kind(g); // 0: luma chain, 1: chroma chain
   Pix* const gbase = group_u(g, kind ? 1 : 0); // CTU buffer of the luma plane / of Cb (Cr: P1 * ch_c samples further)
-  const int Pk = kind ? P1 : P0;               // pitch of the chain's CTU buffers
-  const int l2w = kind ? log2_ctb - 1 : log2_ctb; // log2 of the CTU width in samples of the chain's planes
+  int Pk = kind ? P1 : P0;               // pitch of the chain's CTU buffers
+  int l2w = kind ? log2_ctb - 1 : log2_ctb; // log2 of the CTU width in samples of the chain's planes
   const int cr_off = P1 * ch_c;                // Cr buffer behind the Cb buffer, in samples
-  const int st_off = by_ * Pk + 1 + bx_;       // a 4x4 block's sample of this lane, from the block's (x0 - 1, y0)
-  int* const my_progress = progress + kind * C_PROG;
+  int st_off = by_ * Pk + 1 + bx_;       // a 4x4 block's sample of this lane, from the block's (x0 - 1, y0)
+  int* my_progress = progress + kind * C_PROG;
   c_u32x4* const ring = rings + g * RING;
   // byte offsets in LDS of the group's places, for the wave-wide path (fetched from the group's first lane)
   const uint32_t gb_off = (uint32_t)(reinterpret_cast<uint8_t*>(gbase) - lds);
@@ -336,9 +339,8 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   // the sample lines are slots row % NR; a group's rows are NR apart, so its slot - and the slot of the row above - never change
   const int my_slot = group_slot(g);
   const int line_above = my_slot ? my_slot - 1 : NR - 1;
-  const Pix* const lr = line_of(kind, line_above);
   // (one sample before the line's first: the micro-ops count the positions of the row above from the CTU's CORNER sample)
-  const uint32_t lr_off = (uint32_t)(reinterpret_cast<const uint8_t*>(lr) - lds) - (uint32_t)sizeof(Pix);
+  uint32_t lr_off = (uint32_t)(reinterpret_cast<const uint8_t*>(line_of(kind, line_above)) - lds) - (uint32_t)sizeof(Pix);
   uint32_t tl_off = lr_off; // the sample before the CTU's first in the sample line of the row above: lr + (cx << l2w) - 1
   int st = (row < ctb_h && my_slot < RPW && (kind_sel < 0 || kind == kind_sel)) ? ST_START : ST_DONE;
   uint32_t c0 = 0, c1 = 0; // header of the CTU to start next: first record of the chain, count
@@ -369,7 +371,12 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   const bool lds_rows = PAIRS && !wg_ring && MODE >= 2 && L.bands_per_pic == L.passes; // (MODE >= 2: RPW == 1)
   const bool lds_above = wg_ring || (lds_rows && pair_index > 0 && wave >= S);
   const bool lds_below = wg_ring || (lds_rows && wave + S < wg_waves); // (if there is a band below at all)
-  const int below_waves = wg_ring && pair_index == W - 1 ? -(W - 1) * S : S;
+  // ALT (a ring of waves with one chain each): a band's two waves - tasks 2 b and 2 b + 1 - start with the luma and the chroma
+  // chain of band b and SWAP kinds with every band they move on to: a chroma chain is half the work of its luma twin, and a wave
+  // that only ever worked on chroma chains would idle half of the time in a slot that holds no other wave (r04: 29 % of the
+  // wave cycles of 1024 tiles in the service phase).  The band below the ring's last wave belongs to the next pass, where
+  // the chain of this wave's kind is the OTHER wave's of band 0.
+  const int below_waves = wg_ring && pair_index == W - 1 ? -(W - 1) * S + (ALT ? 1 - 2 * (int)(kind_sel & 1) : 0) : S;
   uint8_t* const pbase_below = PAIRS ? pbase + below_waves * L.pic_bytes : pbase;
   const int below_pass = wg_ring && pair_index == W - 1 ? 1 : 0; // (the band below a ring's last wave belongs to the next pass)
   // the counter of "the row above a wave's first row" when that row is another wave's (monochrome: every counter of the luma
@@ -523,6 +530,15 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
           }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if (lane == 0 && !(L.test_stall && s_pidx == 0)) __hip_atomic_store(pair_progress + 2 * (size_t)s_pidx + fkind, (uint32_t)(s_cx + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (ALT && s_cx + 1 == ctb_w) { // the row is done: the wave's next band is of the other kind (every lane: one chain per wave)
+          kind_sel ^= 1;
+          kind = kind_sel;
+          Pk = kind ? P1 : P0;
+          l2w = kind ? log2_ctb - 1 : log2_ctb;
+          st_off = by_ * Pk + 1 + bx_;
+          my_progress = progress + kind * C_PROG;
+          lr_off = (uint32_t)(reinterpret_cast<const uint8_t*>(line_of(kind, line_above)) - lds) - (uint32_t)sizeof(Pix);
         }
         // the group's next CTU
         if (g == fg) {
@@ -1214,6 +1230,10 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   while (ring_w && (ring_w << L.split_kinds) > 16) ring_w--; // (a workgroup holds 16 waves)
   if (!pairs) { L.rows_per_wave = nr; L.split_kinds = 0; }
   // ---- LDS of a wave ----
+  // (a ring of waves with one chain each: the waves alternate between the kinds, k_chain: ALT; HM_CHAIN_ALT=0: they keep theirs - A/B)
+  static const bool alt_allowed = [] { const char* e = getenv("HM_CHAIN_ALT"); return !(e && e[0] == '0'); }();
+  bool alt_wanted = alt_allowed; // (cleared where the second line does not fit a workgroup's LDS)
+  auto alt_kinds = [&]() { return ring_w != 0 && L.split_kinds != 0 && !mono && alt_wanted; };
   auto set_layout = [&]() -> bool { // for the cut in L; false if a wave does not fit the CU's LDS
     L.line_l_bytes = al4((4 + max_ctb_w * ctb) * pb); // (every byte counts for the waves a CU holds)
     L.line_c_bytes = mono ? 0 : al4((8 + 2 * max_ctb_w * (ctb / 2)) * pb);
@@ -1221,7 +1241,14 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
     L.chroma_bytes = mono ? 0 : al(2 * (ctb / 2 + UPAD) * ch * pb);
     L.line_slots = L.rows_per_wave == 1 ? 1 : nr;
     L.off_lines_l = 2 * C_PROG * 4 + C_FDESC_BYTES;
-    if (L.split_kinds) { // one kind of chain per wave: one place for its line, one for its CTU buffers
+    if (L.split_kinds && alt_kinds()) { // one chain per wave, of either kind in turn (k_chain: ALT): a line per kind - the one of the
+      // wave's next band is filled while the wave still reads the other -, one place for the CTU buffers
+      L.off_lines_c = L.off_lines_l + L.line_l_bytes;
+      L.off_scratch = L.off_lines_c + L.line_c_bytes;
+      L.row_bytes = L.luma_bytes > L.chroma_bytes ? L.luma_bytes : L.chroma_bytes;
+      L.chroma_off = 0;
+    }
+    else if (L.split_kinds) { // one kind of chain per wave: one place for its line, one for its CTU buffers
       L.off_lines_c = L.off_lines_l;
       L.off_scratch = L.off_lines_l + (L.line_l_bytes > L.line_c_bytes ? L.line_l_bytes : L.line_c_bytes);
       L.row_bytes = L.luma_bytes > L.chroma_bytes ? L.luma_bytes : L.chroma_bytes;
@@ -1265,12 +1292,13 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
       case 0: return reinterpret_cast<const void*>(k_chain<P, L2, 0>);
       case 1: return reinterpret_cast<const void*>(k_chain<P, L2, 1>);
       case 2: return reinterpret_cast<const void*>(k_chain<P, L2, 2>);
-      default: return reinterpret_cast<const void*>(k_chain<P, L2, 3>);
+      case 3: return reinterpret_cast<const void*>(k_chain<P, L2, 3>);
+      default: return reinterpret_cast<const void*>(k_chain<P, L2, 4>);
     }
   };
   auto pick = [&](bool prs) -> bool {
     // the kernel's MODE: the chains a wave works on (k_chain: NCL) follow from the cut in L
-    mode = !prs ? 0 : (L.split_kinds ? 3 : (L.rows_per_wave == 1 ? (mono ? 3 : 2) : 1));
+    mode = !prs ? 0 : (L.split_kinds ? (alt_kinds() ? 4 : 3) : (L.rows_per_wave == 1 ? (mono ? 3 : 2) : 1));
     switch (inst) {
       case 0: fn = fn_of(uint8_t(), std::integral_constant<int, 4>(), mode); break;
       case 1: fn = fn_of(uint16_t(), std::integral_constant<int, 4>(), mode); break;
@@ -1280,8 +1308,8 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
       case 5: fn = fn_of(uint16_t(), std::integral_constant<int, 6>(), mode); break;
       default: return false;
     }
-    static int cu_waves_of[24] = {}; // (per instantiation; a benign race: every thread computes the same value)
-    int& cu_waves = cu_waves_of[inst * 4 + mode];
+    static int cu_waves_of[30] = {}; // (per instantiation; a benign race: every thread computes the same value)
+    int& cu_waves = cu_waves_of[inst * 5 + mode];
     if (cu_waves == 0) {
       hipFuncAttributes fa;
       int w = 16;
@@ -1351,7 +1379,13 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
       if ((long)n_pics * per_pic > capacity || sync_bytes < sync_words(bands)) continue;
       if (steps_of((long)w * rpw) * step_cost(rpw, split) > cost_now) continue;
       L.rows_per_wave = rpw; L.split_kinds = split; pairs = true; ring_w = w;
-      if (set_layout() && pick(true) && (long)n_pics * per_pic <= (long)cus() * (best < 16 ? best : 16)) { share = 0; break; }
+      auto fits_device = [&]() { return set_layout() && pick(true) && (long)n_pics * per_pic <= (long)cus() * (best < 16 ? best : 16); };
+      if (fits_device()) { share = 0; break; }
+      if (alt_kinds()) { // (1080p with CTBs of 64: sixteen waves with a line per kind are 187 KB)
+        alt_wanted = false;
+        if (fits_device()) { share = 0; break; }
+        alt_wanted = alt_allowed;
+      }
       ring_w = 0;
     }
     if (!ring_w) { L = keep; pairs = keep_pairs; set_layout(); }

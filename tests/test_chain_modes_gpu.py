@@ -45,6 +45,9 @@ def test_waves_of_a_picture_in_one_workgroup_hand_over_in_a_ring(waves, cut):
     assert "in a ring" in r.stderr, r.stderr
     r = _run({"HM_CHAIN_RING": str(waves), "HM_CHAIN_PAIRS": str(cut)}, "mixed")
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+    if cut == 3:  # a wave per chain: by default the waves swap the luma and the chroma chain from band to band; also with fixed kinds
+        r = _run({"HM_CHAIN_RING": str(waves), "HM_CHAIN_PAIRS": "3", "HM_CHAIN_ALT": "0", "HM_QUAD_CLASS": "1"})
+        assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
 
 
 def test_mid_size_batches_choose_the_ring():
