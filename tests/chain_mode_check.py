@@ -28,6 +28,10 @@ def main():
         if name == "wide16k":  # the widest picture class: CTB 64, 16-bit storage, 4:2:2, 16384 columns, two CTU rows
             import synthutil
             blobs = [pkg.capi.parse_hevc(synthutil.picture(515151, width=16384, height=128, log2_ctb=6, bit_depth=10, chroma_format=2, qp=32, density=30))] * copies
+        elif name == "big422":  # BASELINE config 4's picture: 2048x1536 10-bit 4:2:2, 48 rows of 64 CTUs - a long wavefront
+            import synthutil
+            blobs = [pkg.capi.parse_hevc(synthutil.picture(4220010, width=2048, height=1536, chroma_format=2, bit_depth=10, log2_ctb=5, qp=30, vui=1,
+                                                           full_range=0, matrix=9, primaries=9))] * copies
         elif name == "mixed":  # pictures of one class and different sizes in one launch (the cut follows the tallest; short ones leave waves idle)
             blobs = [pkg.capi.parse_hevc(corpus.stream(n)) for n in ("tile512_a", "ragged", "dense_lowqp", "no_deblock", "tile512_b", "ragged")] * 2
         else:

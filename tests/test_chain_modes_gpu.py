@@ -50,12 +50,24 @@ def test_waves_of_a_picture_in_one_workgroup_hand_over_in_a_ring(waves, cut):
         assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
 
 
-def test_mid_size_batches_choose_the_ring():
-    """300 tiles of 512x512: too many for a wave per chain of every CTU row, too few for a wave per picture - the launcher's own
-    choice must be the ring, and the pictures the oracle's"""
-    r = _run({"HM_CHECK_COPIES": "300", "HM_CHAIN_DEBUG": "1"}, "tile512_a")
+def test_large_pictures_keep_their_wavefront():
+    """32 pictures of 48 x 64 CTUs (BASELINE config 4): a wave per chain of every row still fits the device, and a ring of 8 rows in
+    flight would cost the picture its wavefront (measured 8.3 instead of 27.7 GP/s) - the launcher's estimate must say no; with 128 of
+    them the cuts without the ring are the slower ones (18.6 against 11.4 ms)"""
+    r = _run({"HM_CHECK_COPIES": "32", "HM_CHAIN_DEBUG": "1"}, "big422", timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+    assert "in a ring" not in r.stderr and "one per chain of a CTU row" in r.stderr, r.stderr
+    r = _run({"HM_CHECK_COPIES": "128", "HM_CHAIN_DEBUG": "1"}, "big422", timeout=900)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
     assert "in a ring" in r.stderr, r.stderr
+
+
+@pytest.mark.parametrize("tiles, waves", [(300, 8), (1000, 4), (1100, 3), (1500, 2)])
+def test_the_ring_the_launcher_chooses(tiles, waves):
+    """512x512 tiles: the finest cut whose waves are all resident (profiles/r04_ring_sweep.txt) - and the oracle's pictures"""
+    r = _run({"HM_CHECK_COPIES": str(tiles), "HM_CHAIN_DEBUG": "1"}, "tile512_a", timeout=900)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+    assert f"a picture's {waves} waves in one workgroup" in r.stderr, r.stderr
 
 
 @pytest.mark.parametrize("segs", [2, 5, 16])
