@@ -1371,10 +1371,24 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
     else cost_now = steps_of(max_ctb_h) * 250;
     const CLayout keep = L;
     const bool keep_pairs = pairs;
+    // Classes whose wave per picture needs so much LDS - two rows of CTU buffers and lines of both kinds: CTBs of 64, 16-bit
+    // samples, 4:2:2 - that a CU holds ten of them or fewer are bound by the latency of a lone wave (12-bit 4:2:2 with CTBs of 64:
+    // 10 ms per 512x512 tile).  For them a ring of 2 bands x 2 kinds beats every cut with four chains per wave even when its
+    // waves do not all fit the device - the workgroups are self-contained, the rest start as the first finish.  Measured r04
+    // (profiles/r04_ring_sweep.txt), 18432 tiles, ms of both reconstruction kernels: 12-bit 4:2:2 CTB 64 129 -> 68, 10-bit 4:2:2
+    // 59 -> 46, 8-bit CTB 64 37.2 -> 31.8, 10-bit 4:2:0 38.2 -> 35.0; the classes that hold 20 waves per CU lose (8-bit CTB 32:
+    // 24.7 -> 33.6, CTB 16: 34.3 -> 47.8).
+    bool heavy = false;
+    if (!mono) {
+      const bool sv_pairs = pairs;
+      pairs = false; L.rows_per_wave = nr; L.split_kinds = 0;
+      heavy = set_layout() && pick(false) && best <= 10;
+      L = keep; pairs = sv_pairs;
+    }
     static const struct { int one_row, split, w; } cand[5] = {{1, 1, 8}, {1, 1, 4}, {1, 1, 2}, {0, 0, 3}, {0, 0, 2}};
     for (const auto& c : cand) {
       const int rpw = c.one_row ? 1 : nr, split = mono ? 0 : c.split;
-      if (max_ctb_h <= rpw) continue;
+      if (max_ctb_h <= rpw || (heavy && !c.one_row)) continue; // (rings of row pairs: as short of LDS as a wave per picture)
       const int bands = (max_ctb_h + rpw - 1) / rpw, w = c.w < bands ? c.w : bands, per_pic = w << split;
       if ((long)n_pics * per_pic > capacity || sync_bytes < sync_words(bands)) continue;
       if (steps_of((long)w * rpw) * step_cost(rpw, split) > cost_now) continue;
@@ -1387,6 +1401,18 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
         alt_wanted = alt_allowed;
       }
       ring_w = 0;
+    }
+    // (more waves than the device holds, see `heavy` - against the cuts with four chains per wave only: a wave per chain or per row
+    //  of every row keeps the picture's whole wavefront)
+    if (!ring_w && heavy && (!keep_pairs || keep.rows_per_wave > 1) && sync_bytes >= sync_words(max_ctb_h)) {
+      L.rows_per_wave = 1; L.split_kinds = 1; pairs = true; ring_w = 2; // (max_ctb_h >= 2: the single-row pictures took no split)
+      if (max_ctb_h < 2) ring_w = 0;
+      else if (set_layout() && pick(true)) share = 0;
+      else {
+        alt_wanted = false;
+        if (set_layout() && pick(true)) share = 0;
+        else { alt_wanted = alt_allowed; ring_w = 0; }
+      }
     }
     if (!ring_w) { L = keep; pairs = keep_pairs; set_layout(); }
   }
