@@ -62,10 +62,13 @@ def test_large_pictures_keep_their_wavefront():
     assert "in a ring" in r.stderr, r.stderr
 
 
-@pytest.mark.parametrize("tiles, waves", [(300, 8), (1000, 4), (1100, 3), (1500, 2)])
-def test_the_ring_the_launcher_chooses(tiles, waves):
-    """512x512 tiles: the finest cut whose waves are all resident (profiles/r04_ring_sweep.txt) - and the oracle's pictures"""
-    r = _run({"HM_CHECK_COPIES": str(tiles), "HM_CHAIN_DEBUG": "1"}, "tile512_a", timeout=900)
+@pytest.mark.parametrize("name, copies, waves", [("tile512_a", 300, 8), ("tile512_a", 1000, 4), ("tile512_a", 1100, 3), ("tile512_a", 1500, 2),
+                                                 ("hi422_10", 3000, 4)])
+def test_the_ring_the_launcher_chooses(name, copies, waves):
+    """512x512 tiles: the finest cut whose waves are all resident; 10-bit 4:2:2 pictures, whose wave per picture is so short of LDS that
+    a CU holds ten: rings of 2 bands x 2 kinds even when they do not all fit the device (profiles/r04_ring_sweep.txt) - and the
+    oracle's pictures"""
+    r = _run({"HM_CHECK_COPIES": str(copies), "HM_CHAIN_DEBUG": "1"}, name, timeout=900)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
     assert f"a picture's {waves} waves in one workgroup" in r.stderr, r.stderr
 
