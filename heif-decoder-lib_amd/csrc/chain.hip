@@ -1262,8 +1262,11 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
     }
     L.off_rings = al(L.off_scratch + C_SCRATCH);
     const int ring_records = 1 << (pairs ? chain_wlog<true> : chain_wlog<false>);
-    L.off_rres = L.off_rings + NG * ring_records * 16;
-    L.off_groups = L.off_rres + NG * ring_records * 32;
+    // (a window of micro-ops and 4x4 residuals per CHAIN of the wave - k_chain: NCL -, not per group: the cuts with one chain per
+    //  wave carried 2304 unused bytes, a third of a CU's waves in the classes that are short of LDS)
+    const int chains = !pairs ? NG : (L.split_kinds || (mono && L.rows_per_wave == 1) ? 1 : (L.rows_per_wave == 1 ? 2 : NG));
+    L.off_rres = L.off_rings + chains * ring_records * 16;
+    L.off_groups = L.off_rres + chains * ring_records * 32;
     L.pic_bytes = al(L.off_groups + (mono && L.rows_per_wave > 1 ? 4 : L.rows_per_wave) * L.row_bytes);
     return C_SHARED + L.pic_bytes <= 160 * 1024;
   };
@@ -1448,8 +1451,17 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   const bool lds_rows = pairs && !ring_w && L.rows_per_wave == 1 && L.bands_per_pic == L.passes;
   if (ring_w) {} // (whole pictures per workgroup: pick())
   else if (lds_rows) {
-    np = 8;
-    while (np > 1 && C_SHARED + np * L.pic_bytes > 64 * 1024) np--;
+    // ... of the counts from four to eight that fit, the one that loads the CUs most evenly: whole workgroups go to a CU, and the
+    // waves of the fullest CU set the pace (config 4, 3072 waves: 384 workgroups of 8 put 16 waves on half of the CUs and 8 on the
+    // others - 3.21 ms -, 512 of 6 put 12 on every one - 2.91 ms)
+    int np_max = 8;
+    while (np_max > 1 && C_SHARED + np_max * L.pic_bytes > 64 * 1024) np_max--;
+    np = np_max;
+    long fullest = -1;
+    for (int k = np_max; k >= (np_max < 4 ? 1 : 4); k--) {
+      const long groups = (n_waves + k - 1) / k, per_cu = (groups + cus() - 1) / cus() * k;
+      if (fullest < 0 || per_cu < fullest) { fullest = per_cu; np = k; }
+    }
   }
   else while (np > 1 && (long)np * 256 > n_waves) np--; // few waves: spread them over the CUs first
   if (force_np > 0 && force_np <= 16 && C_SHARED + force_np * L.pic_bytes <= 160 * 1024 && (!ring_w || force_np % (ring_w << L.split_kinds) == 0)) np = force_np;
