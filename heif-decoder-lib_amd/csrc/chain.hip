@@ -1381,8 +1381,9 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
     // (profiles/r04_ring_sweep.txt), 18432 tiles, ms of both reconstruction kernels: 12-bit 4:2:2 CTB 64 129 -> 68, 10-bit 4:2:2
     // 59 -> 46, 8-bit CTB 64 37.2 -> 31.8, 10-bit 4:2:0 38.2 -> 35.0; the classes that hold 20 waves per CU lose (8-bit CTB 32:
     // 24.7 -> 33.6, CTB 16: 34.3 -> 47.8).
+    // (monochrome, 16-bit samples - luma of four rows per wave -: two waves of a row each, 18432 tiles 27.1 -> 23.1 ms)
     bool heavy = false;
-    if (!mono) {
+    {
       const bool sv_pairs = pairs;
       pairs = false; L.rows_per_wave = nr; L.split_kinds = 0;
       heavy = set_layout() && pick(false) && best <= 10;
@@ -1408,7 +1409,7 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
     // (more waves than the device holds, see `heavy` - against the cuts with four chains per wave only: a wave per chain or per row
     //  of every row keeps the picture's whole wavefront)
     if (!ring_w && heavy && (!keep_pairs || keep.rows_per_wave > 1) && sync_bytes >= sync_words(max_ctb_h)) {
-      L.rows_per_wave = 1; L.split_kinds = 1; pairs = true; ring_w = 2; // (max_ctb_h >= 2: the single-row pictures took no split)
+      L.rows_per_wave = 1; L.split_kinds = mono ? 0 : 1; pairs = true; ring_w = 2;
       if (max_ctb_h < 2) ring_w = 0;
       else if (set_layout() && pick(true)) share = 0;
       else {

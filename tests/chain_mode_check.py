@@ -32,6 +32,9 @@ def main():
             import synthutil
             blobs = [pkg.capi.parse_hevc(synthutil.picture(4220010, width=2048, height=1536, chroma_format=2, bit_depth=10, log2_ctb=5, qp=30, vui=1,
                                                            full_range=0, matrix=9, primaries=9))] * copies
+        elif name == "mono10_wide":  # 16-bit monochrome, CTBs of 32, 512 columns: luma of four rows per wave = 15 KB of LDS
+            import synthutil
+            blobs = [pkg.capi.parse_hevc(synthutil.picture(4001032, width=512, height=192, chroma_format=0, bit_depth=10, log2_ctb=5, qp=30))] * copies
         elif name == "mixed":  # pictures of one class and different sizes in one launch (the cut follows the tallest; short ones leave waves idle)
             blobs = [pkg.capi.parse_hevc(corpus.stream(n)) for n in ("tile512_a", "ragged", "dense_lowqp", "no_deblock", "tile512_b", "ragged")] * 2
         else:

@@ -63,7 +63,7 @@ def test_large_pictures_keep_their_wavefront():
 
 
 @pytest.mark.parametrize("name, copies, waves", [("tile512_a", 300, 8), ("tile512_a", 1000, 4), ("tile512_a", 1100, 3), ("tile512_a", 1500, 2),
-                                                 ("hi422_10", 3000, 4)])
+                                                 ("hi422_10", 3000, 4), ("mono10_wide", 2500, 2)])
 def test_the_ring_the_launcher_chooses(name, copies, waves):
     """512x512 tiles: the finest cut whose waves are all resident; 10-bit 4:2:2 pictures, whose wave per picture is so short of LDS that
     a CU holds ten: rings of 2 bands x 2 kinds even when they do not all fit the device (profiles/r04_ring_sweep.txt) - and the

@@ -18,6 +18,13 @@ CLASSES = {
     "10bit_422_ctb32": dict(log2_ctb=5, bit_depth=10, chroma_format=2),
     "12bit_422_ctb64": dict(log2_ctb=6, bit_depth=12, chroma_format=2),
 }
+# (only on request, HM_CLASS_ONLY=...: what lies between the classes above)
+MORE = {
+    "8bit_422_ctb32": dict(log2_ctb=5, chroma_format=2),
+    "10bit_420_ctb16": dict(log2_ctb=4, bit_depth=10),
+    "10bit_420_ctb64": dict(log2_ctb=6, bit_depth=10),
+    "10bit_mono_ctb32": dict(log2_ctb=5, bit_depth=10, chroma_format=0),
+}
 
 
 def main():
@@ -29,7 +36,8 @@ def main():
     dev = torch.device("cuda:0")
     n = int(os.environ.get("HM_CLASS_TILES", "1536"))
     out = {}
-    for name, kw in CLASSES.items():
+    only = os.environ.get("HM_CLASS_ONLY", "").split(",")
+    for name, kw in list(CLASSES.items()) + [(k, v) for k, v in MORE.items() if k in only]:
         cfg = dict(width=512, height=512, qp=27, cu_qp_delta=1, sao=1, sign_hiding=1, density=60)
         cfg.update(kw)
         blobs = [capi.parse_hevc(synthutil.picture(7700000 + i, **cfg)) for i in range(8)]
