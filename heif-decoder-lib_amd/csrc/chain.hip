@@ -1378,7 +1378,7 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
     // samples, 4:2:2 - that a CU holds ten of them or fewer are bound by the latency of a lone wave (12-bit 4:2:2 with CTBs of 64:
     // 10 ms per 512x512 tile).  For them a ring of 2 bands x 2 kinds beats every cut with four chains per wave even when its
     // waves do not all fit the device - the workgroups are self-contained, the rest start as the first finish.  Measured r04
-    // (profiles/r04_ring_sweep.txt), 18432 tiles, ms of both reconstruction kernels: 12-bit 4:2:2 CTB 64 129 -> 68, 10-bit 4:2:2
+    // (profiles/r04_ring_sweep.txt), 18432 tiles, ms of both reconstruction kernels: 12-bit 4:2:2 CTB 64 129 -> 51, 10-bit 4:2:2
     // 59 -> 46, 8-bit CTB 64 37.2 -> 31.8, 10-bit 4:2:0 38.2 -> 35.0; the classes that hold 20 waves per CU lose (8-bit CTB 32:
     // 24.7 -> 33.6, CTB 16: 34.3 -> 47.8).
     // (monochrome, 16-bit samples - luma of four rows per wave -: two waves of a row each, 18432 tiles 27.1 -> 23.1 ms)
@@ -1399,7 +1399,7 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
       L.rows_per_wave = rpw; L.split_kinds = split; pairs = true; ring_w = w;
       auto fits_device = [&]() { return set_layout() && pick(true) && (long)n_pics * per_pic <= (long)cus() * (best < 16 ? best : 16); };
       if (fits_device()) { share = 0; break; }
-      if (alt_kinds()) { // (1080p with CTBs of 64: sixteen waves with a line per kind are 187 KB)
+      if (alt_kinds()) { // (the workgroup's waves with a line per kind each may not fit its LDS: then with fixed kinds)
         alt_wanted = false;
         if (fits_device()) { share = 0; break; }
         alt_wanted = alt_allowed;
