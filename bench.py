@@ -67,8 +67,12 @@ class GridBatch:
     """n images, each a cols x rows grid of tile x tile coded pictures pasted into an out_w x out_h canvas (8-bit 4:2:0),
     converted to RGB24: device canvases + one hm_batch."""
 
-    def __init__(self, pkg, dev, cols, rows, tile, out_w, out_h):
+    def __init__(self, pkg, dev, cols, rows, tile, out_w, out_h, nclx=(1, 1, 6)):
+        # nclx: (present, full_range, matrix) of the tile items' colour profile as the decoder plugin / the colr box reports it
+        # (decoder_libde265.cc:339-362, context.cc:1840-1850); present && !full_range && matrix != 0 = the paste rescales
+        # (context.cc:2504-2528).  A stream without a VUI reports (1, 0, 2).
         self.pkg, self.dev = pkg, dev
+        self.nclx = nclx
         self.cols, self.rows, self.tile, self.out_w, self.out_h = cols, rows, tile, out_w, out_h
         L = pkg.lib()
         self.ys, self.cs, self.os = L.hm_plane_stride(out_w, 1), L.hm_plane_stride((out_w + 1) // 2, 1), L.hm_plane_stride(out_w, 3)
@@ -89,7 +93,7 @@ class GridBatch:
             d.pitch[0], d.pitch[1], d.pitch[2] = self.ys, self.cs, self.cs
             d.canvas_width, d.canvas_height = self.out_w, self.out_h
             d.x0, d.y0 = (t % self.cols) * self.tile, (t // self.cols) * self.tile
-            d.tile_has_nclx, d.tile_full_range, d.tile_matrix = 1, 1, 6
+            d.tile_has_nclx, d.tile_full_range, d.tile_matrix = self.nclx
             self.batch.add(blob, d)
         self.images.append(dict(y=y, cb=cb, cr=cr, rgb=rgb))
 
@@ -111,8 +115,9 @@ class GridBatch:
         return len(self.images) * self.out_w * self.out_h
 
 
-def cpu_grid_image(streams, blobs, cols, rows, tile, out_w, out_h, strides, use_ref):
-    """CPU restatement of the same path for one image: decode the tiles, paste, convert.  Returns the RGB array."""
+def cpu_grid_image(streams, blobs, cols, rows, tile, out_w, out_h, strides, use_ref, nclx=None):
+    """CPU restatement of the same path for one image: decode the tiles, paste, convert.  Returns the RGB array.
+    nclx: (present, full_range, matrix) of the tile items when a colr box overrides the streams' VUI."""
     import numpy as np
     import orc
     ys, cs, os_ = strides
@@ -129,7 +134,7 @@ def cpu_grid_image(streams, blobs, cols, rows, tile, out_w, out_h, strides, use_
         for c, (canvas, stride) in enumerate(((y, ys), (cb, cs), (cr, cs))):
             p8 = np.ascontiguousarray(planes[c].astype(np.uint8))
             rc = o.orc_paste_tile_plane(orc.ptr(p8), p8.shape[1], p8.shape[1], p8.shape[0], orc.ptr(canvas), stride,
-                                        out_w, out_h, x0, y0, c, 1, 8, 1, info["full_range"], info["matrix"])
+                                        out_w, out_h, x0, y0, c, 1, 8, *(nclx if nclx else (1, info["full_range"], info["matrix"])))
             assert rc == 0
     out = np.zeros((max(64, out_h), os_), np.uint8)
     o.orc_ycbcr420_to_rgb_int(orc.ptr(y), ys, orc.ptr(cb), cs, orc.ptr(cr), cs, out_w, out_h, 0, 0, 0, orc.ptr(out), os_, 10)

@@ -210,9 +210,10 @@ struct hm_batch {
 
 // Can deblocking, SAO, paste and the attached colour conversion of this batch run as ONE kernel (filters.hip:
 // k_tail420)?  Yes for the mainstream shape: one class of 8-bit 4:2:0 pictures without rare syntax, each one slice
-// without HEVC tiles, 16-sample-aligned widths and paste positions, no conformance-window offset, no range rescale, the
+// without HEVC tiles, 16-sample-aligned widths and paste positions, no conformance-window offset, the
 // images' canvases fully covered by their pictures, and the integer matrix chain to RGB24 / RGBA32.  The canvases are
-// then never written: the attached conversion's output is the batch's result.  HM_TAIL_FUSED=0 keeps the separate
+// then never written: the attached conversion's output is the batch's result.  The limited -> full range rescale of a grid's
+// paste (context.cc:2504-2528) is part of the fused kernels (r05).  HM_TAIL_FUSED=0 keeps the separate
 // kernels (A/B measurements).
 struct TailDstHost { uint8_t* rgb; int32_t pitch; int32_t pad; };
 static int decide_tail(hm_batch* b)
@@ -247,7 +248,7 @@ static int decide_tail(hm_batch* b)
       const hm_dev_pic& dp = b->h_desc[c.desc_offset + k];
       // (several slices: the fused kernel's SAO takes the per-CTB neighbour masks like k_sao_paste's fast path, but has no per-sample
       //  redo for the chroma CTBs of quirk Q13 - pictures that hold one keep the separate kernels)
-      if (!it.sao_ring_uniform || (h.flags & HM_PIC_TILES) || (h.width % 16) || h.crop_left || h.crop_top || dp.rescale) return HM_OK;
+      if (!it.sao_ring_uniform || (h.flags & HM_PIC_TILES) || (h.width % 16) || h.crop_left || h.crop_top) return HM_OK;
       if (it.dest.plane[0] != b->col_y[img] || it.dest.plane[1] != b->col_cb[img] || it.dest.plane[2] != b->col_cr[img]) return HM_OK;
       if (it.dest.canvas_width != d.width || it.dest.canvas_height != d.height) return HM_OK;
       if ((it.dest.x0 % 16) || (it.dest.y0 % 2)) return HM_OK;

@@ -847,6 +847,9 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       const uint32_t s_gb = (uint32_t)__builtin_amdgcn_readlane((int)gb_off, src), s_tl = (uint32_t)__builtin_amdgcn_readlane((int)tl_off, src);
       const int mode = (int)(oy & OP_MODE_MASK), c = (int)((oy >> OP_C_SHIFT) & 3), log2 = 2 + (int)((oy >> OP_L2_SHIFT) & 3);
       const int path = (int)((oy >> OP_PATH_SHIFT) & 7);
+#ifdef HM_D_SKIP // probe: the blocks of the classes in the mask are not executed (bit = PATH_*, general path: 6 + log2 size - 2)
+      if ((HM_D_SKIP >> (path != PATH_GEN ? path : 4 + log2)) & 1) continue;
+#endif
 #if defined(HM_Q_PROBE) && (HM_Q_PROBE & 512)
       const bool cbf = false;
 #else

@@ -987,6 +987,49 @@ __device__ __forceinline__ void tail_sao(const hm_dev_pic& dp, const PicView& v,
   }
 }
 
+// The limited -> full range rescale of the grid paste (context.cc:2504-2528: clip_f_u8((v - 16) * k), k = 1.1689f for luma,
+// 1.1429f for chroma - with luma's offset, quirk Q2 - in float, trunc(x + 0.5f)) on 8-bit samples, in integers: with
+// t = max(v, 16) - 16 the result is min(255, t + ((t * A + B) >> S)) for (A, B, S) = (173, 507, 10) / (73, 256, 9) - every
+// intermediate fits 16 bits, so sample pairs travel as the halves of one register.  Exact for all 256 values: checked here at
+// compile time against the float expression (constant evaluation is IEEE round-to-nearest, no contraction), and by
+// tests/test_oracle_colour.py against the oracle's float code.
+constexpr int rescale_float_u8(int v, float k)
+{
+  const float fx = ((float)v - 16.0f) * k;
+  const int x = (int)(fx + 0.5f);
+  return x < 0 ? 0 : (x > 255 ? 255 : x);
+}
+constexpr int rescale_int_u8(int v, int A, int B, int S)
+{
+  const int t = (v > 16 ? v : 16) - 16, o = t + ((t * A + B) >> S);
+  return o > 255 ? 255 : o;
+}
+constexpr bool rescale_forms_agree()
+{
+  for (int v = 0; v < 256; v++)
+    if (rescale_int_u8(v, 173, 507, 10) != rescale_float_u8(v, 1.1689f) || rescale_int_u8(v, 73, 256, 9) != rescale_float_u8(v, 1.1429f) ||
+        (v - 16) * 173 + 507 >= 65536)
+      return false;
+  return true;
+}
+static_assert(rescale_forms_agree(), "integer form of the paste rescale");
+template <bool CHROMA>
+__device__ __forceinline__ uint32_t pk_rescale(uint32_t pair)
+{
+  const u16x2 t = __builtin_elementwise_sub_sat(as_u(pair), (u16x2)(16));
+  const u16x2 o = t + ((t * (u16x2)(CHROMA ? 73 : 173) + (u16x2)(CHROMA ? 256 : 507)) >> (u16x2)(CHROMA ? 9 : 10));
+  return as_w(__builtin_elementwise_min(o, (u16x2)(255)));
+}
+
+// ... of a pair of samples as they lie in memory: 8-bit samples as above; 16-bit storage byte by byte (quirk Q1: the reference's
+// loop runs over the BYTES of the plane, context.cc:2499-2525)
+template <typename Pix, bool CHROMA>
+__device__ __forceinline__ uint32_t pk_rescale_stored(uint32_t pair)
+{
+  if (sizeof(Pix) == 1) return pk_rescale<CHROMA>(pair);
+  return pk_rescale<CHROMA>(pair & 0x00FF00FFu) | (pk_rescale<CHROMA>((pair >> 8) & 0x00FF00FFu) << 8);
+}
+
 template <int BPP, int MINW, bool UNI>
 __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic* __restrict__ pics, const TailDst* __restrict__ dsts, int tiles_x, int n_tiles, int stages, TailCoef k)
 {
@@ -1079,6 +1122,7 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
   __shared__ __attribute__((aligned(16))) uint8_t s_x[NWAVES][2][16][16];
   const int wave = tid >> 6, lane = tid & 63;
   const int l2 = dp.log2_ctb;
+  const bool rescale = dp.rescale != 0; // (the same for every lane of the workgroup)
   const TailDst D = dsts[blockIdx.y];
   const int Kr = 128 - 128 * k.r_cr, Kg = 128 - 128 * (k.g_cb + k.g_cr), Kb = 128 - 128 * k.b_cb; // (x - 128) * k + 128 = x * k + K
   for (int it = 0; it < 2; it++) {
@@ -1091,6 +1135,10 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
       if (xc < (W >> 1) && yc < (H >> 1)) {
         uint32_t rc[1][4];
         tail_sao<1, UNI>(dp, v, 1 + pl, s_c0 + pl * (TAIL_CR * TAIL_CP), TAIL_CP, (x0 >> 1) - TAIL_XO, (y0 >> 1) - 4, xc, yc, W >> 1, H >> 1, l2 - 1, l2 - 1, stages & 2, rc);
+        if (rescale) { // (the paste of a limited-range tile: context.cc:2504-2528)
+#pragma unroll
+          for (int j = 0; j < 4; j++) rc[0][j] = pk_rescale<true>(rc[0][j]);
+        }
         const uint32_t o[2] = {__builtin_amdgcn_perm(rc[0][1], rc[0][0], 0x06040200u), __builtin_amdgcn_perm(rc[0][3], rc[0][2], 0x06040200u)};
         __builtin_memcpy(&s_x[wave][pl][row][8 * gxc], o, 8);
       }
@@ -1102,6 +1150,12 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
     if (lx < cw && ly < chh) {
       uint32_t ry[2][4];
       tail_sao<2, UNI>(dp, v, 0, s_l, TAIL_LP, x0 - TAIL_XO, y0 - 4, lx, ly, W, H, l2, l2, stages & 2, ry);
+      if (rescale) {
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) ry[r][j] = pk_rescale<false>(ry[r][j]);
+      }
       uint32_t cb4, cr4;
       __builtin_memcpy(&cb4, &s_x[wave][0][rp][4 * gx], 4);
       __builtin_memcpy(&cr4, &s_x[wave][1][rp][4 * gx], 4);
@@ -1314,6 +1368,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_tailf(const hm_dev_pic* __restri
   // ---- phase 2: one lane = 16 luma samples of a row (of two rows: 4:2:0) and the 8 Cb / 8 Cr samples under them: SAO of all
   //      of them from the LDS tiles, the float operation, 16 pixels per row to the image ----
   const int l2 = dp.log2_ctb;
+  const bool rescale = dp.rescale != 0; // (the same for every lane of the workgroup)
   const TailDst D = dsts[blockIdx.y];
   constexpr int RL = 1 << SV;              // luma rows per lane
   constexpr int LG = TF_TW / 16, NROWS = TF_TH / RL;
@@ -1326,6 +1381,10 @@ __global__ __launch_bounds__(TF_THREADS) void k_tailf(const hm_dev_pic* __restri
       const int xc = lx >> 1, yc = ly >> SV;
       tile_sao<Pix>(dp, v, 1, s_c[0], CP, (x0 >> 1) - TF_XO, (y0 >> SV) - 4, xc, yc, W >> 1, H >> SV, l2 - 1, l2 - SV, stages & 2, bd, cbs);
       tile_sao<Pix>(dp, v, 2, s_c[1], CP, (x0 >> 1) - TF_XO, (y0 >> SV) - 4, xc, yc, W >> 1, H >> SV, l2 - 1, l2 - SV, stages & 2, bd, crs);
+      if (rescale) { // (the paste of a limited-range tile: context.cc:2504-2528)
+#pragma unroll
+        for (int j = 0; j < 4; j++) { cbs[j] = pk_rescale_stored<Pix, true>(cbs[j]); crs[j] = pk_rescale_stored<Pix, true>(crs[j]); }
+      }
     }
 #pragma unroll
     for (int r = 0; r < RL; r++) {
@@ -1336,6 +1395,10 @@ __global__ __launch_bounds__(TF_THREADS) void k_tailf(const hm_dev_pic* __restri
         if (hx >= cw) break;
         uint32_t ry[4];
         tile_sao<Pix>(dp, v, 0, s_l, LP, x0 - TF_XO, y0 - 4, hx, ly + r, W, H, l2, l2, stages & 2, bd, ry);
+        if (rescale) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) ry[j] = pk_rescale_stored<Pix, false>(ry[j]);
+        }
         uint8_t ob[8 * OBPP];
 #pragma unroll
         for (int i = 0; i < 8; i++) {

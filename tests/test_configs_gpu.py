@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import heifwriter
+import orc
 import pipeline
 import synthutil
 from corpus import TILE
@@ -29,6 +30,9 @@ def test_config2_12mp_grid(hm, variant, fmt):
     bpp = 3 if fmt == 10 else 4
     assert meta["stride"][0] == stride and (meta["width"], meta["height"]) == (4032, 3024)
     np.testing.assert_array_equal(planes[0][:3024, :4032 * bpp], exp[:3024, :4032 * bpp])
+    if orc.have_ref():  # ... and against the real libde265's tiles (the product's parser is not in this leg)
+        exp2, _, _ = pipeline.cpu_decode(hm, tiles, 512, 512, 4032, 3024, 8, True, fmt, decoder="ref")
+        np.testing.assert_array_equal(planes[0][:3024, :4032 * bpp], exp2[:3024, :4032 * bpp])
 
 
 @pytest.mark.parametrize("nclx", [dict(full_range=0, matrix=9, primaries=9), dict(full_range=1, matrix=1, primaries=1)],
@@ -46,6 +50,9 @@ def test_config4_10bit_422_single_image(hm, nclx, fmt):
     exp, stride, canv = pipeline.cpu_decode(hm, [pic], 2048, 1536, 2048, 1536, 1, False, fmt)
     assert meta["stride"][0] == stride
     np.testing.assert_array_equal(planes[0][:1536, :2048 * 6], exp[:1536, :2048 * 6])
+    if orc.have_ref():  # the same image with the real libde265 as the decoder
+        exp2, _, _ = pipeline.cpu_decode(hm, [pic], 2048, 1536, 2048, 1536, 1, False, fmt, decoder="ref")
+        np.testing.assert_array_equal(planes[0][:1536, :2048 * 6], exp2[:1536, :2048 * 6])
     # native planar output = the decoder plugin's planes (decoder_libde265.cc:88-157)
     for c, (w, h) in enumerate(((2048, 1536), (1024, 1536), (1024, 1536))):
         np.testing.assert_array_equal(native[c][:h, :w * 2], canv[c][0][:h, :w * 2])
@@ -64,6 +71,9 @@ def test_config5_16384_grid(hm):
     assert (meta["width"], meta["height"]) == (16384, 16384)
     rgb = planes[0]
     expect = [pipeline.cpu_decode(hm, [p], 512, 512, 512, 512, 1, True, 10)[0][:512, :512 * 3] for p in pool]
+    if orc.have_ref():  # the six pictures by the real libde265: the same tiles
+        for k, p in enumerate(pool):
+            assert np.array_equal(pipeline.cpu_decode(hm, [p], 512, 512, 512, 512, 1, True, 10, decoder="ref")[0][:512, :512 * 3], expect[k]), f"picture {k}: oracle != libde265"
     for t in range(1024):
         r, c = divmod(t, 32)
         got = rgb[r * 512:(r + 1) * 512, c * 1536:(c + 1) * 1536]
@@ -197,6 +207,48 @@ def test_fused_tail_equals_separate_kernels(pkg, hm, shape, stages):
         assert np.array_equal(out[0][0], exp[:h, :w * 3])
 
 
+@pytest.mark.parametrize("shape", [(8, 6, 4032, 3024), (3, 2, 1500, 1000)], ids=["12mp_crop64x48", "crop_not_16_aligned"])
+def test_fused_tail_with_limited_range_paste(pkg, hm, shape):
+    """tiles without a VUI (the decoder plugin then reports limited range, matrix 2: decoder_libde265.cc:339-362) are rescaled
+    to full range while they are pasted (context.cc:2504-2528) - the class of the reference's own examples/example.heic.  r05: part
+    of the fused kernel (integer form of the float expression, filters.hip pk_rescale): fused, equal to the separate kernels,
+    and equal to the CPU flow (oracle / real libde265 tiles, the oracle's float paste, integer matrix)."""
+    import bench
+    import torch
+    cols, rows, w, h = shape
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    n_images = 2
+    made = list(bench.make_streams(pkg.capi, (7600000 + 29 * k for k in range(n_images * cols * rows)), vui=0))
+    out = []
+    for group in (0, -1):  # 0: fused where possible, -1: never
+        gb = bench.GridBatch(pkg, dev, cols, rows, 512, w, h, nclx=(1, 0, 2))
+        for j in range(n_images):
+            gb.add_image([b for _, b in made[j * cols * rows:(j + 1) * cols * rows]])
+        gb.finish(st, group)
+        gb.batch.execute(3, st)
+        torch.cuda.synchronize()
+        gb.batch.check()
+        assert gb.batch.tail_fused() == (group == 0)
+        out.append([im["rgb"].cpu().numpy()[:h, :w * 3].copy() for im in gb.images])
+        strides = (gb.ys, gb.cs, gb.os)
+        gb.batch.close()
+    for j in range(n_images):
+        assert np.array_equal(out[0][j], out[1][j]), f"image {j}: fused tail differs from the separate kernels"
+        tiles = made[j * cols * rows:(j + 1) * cols * rows]
+        for use_ref in [False] + ([True] if orc.have_ref() else []):
+            exp = bench.cpu_grid_image([d for d, _ in tiles], [b for _, b in tiles], cols, rows, 512, w, h, strides, use_ref)
+            assert np.array_equal(out[0][j], exp[:h, :w * 3]), f"image {j}: differs from the CPU flow (libde265: {use_ref})"
+    # the rescale really happened: a full-range paste of the same tiles gives other pixels
+    gb = bench.GridBatch(pkg, dev, cols, rows, 512, w, h, nclx=(1, 1, 2))
+    gb.add_image([b for _, b in made[:cols * rows]])
+    gb.finish(st, 0)
+    gb.batch.execute(3, st)
+    torch.cuda.synchronize()
+    assert not np.array_equal(gb.images[0]["rgb"].cpu().numpy()[:h, :w * 3], out[0][0])
+    gb.batch.close()
+
+
 @pytest.mark.parametrize("slicing", [dict(slices=40), dict(slices=60, dependent=400, slice_lf_random=1, deblock_override=1, slice_sao_random=1, slice_qp_random=1),
                                      dict(slices=60, pps_lf_across_slices_off=1, slice_lf_random=1)],
                          ids=["slices", "slice_headers", "filters_stop_at_slices"])
@@ -235,6 +287,11 @@ FLOAT_TAIL_CLASSES = {
     "422_12_rrggbb_le": (12, 2, 1, 6, "HM_OUT_RRGGBB_LE", 6),
     "422_8_rgb24": (8, 2, 1, 6, "HM_OUT_RGB", 3),
     "420_8_limited_rgba": (8, 1, 0, 1, "HM_OUT_RGBA", 4),
+    # grids as decode_full_grid_image builds them: the tiles carry their nclx, the canvas none - limited-range tiles are rescaled
+    # while they are pasted (context.cc:2504-2528; 16-bit storage byte by byte: quirk Q1), part of the fused kernel since r05
+    "grid_422_8_limited_rgb24": (8, 2, 0, 1, "HM_OUT_RGB", 3, True),
+    "grid_420_10_limited_rrggbb_le": (10, 1, 0, 9, "HM_OUT_RRGGBB_LE", 6, True),
+    "grid_422_10_full_rrggbb_be": (10, 2, 1, 9, "HM_OUT_RRGGBB_BE", 6, True),
 }
 
 
@@ -247,13 +304,15 @@ def test_fused_float_tail_equals_separate_kernels(pkg, hm, name, stages):
     import ctypes as C
     import torch
     capi, L = pkg.capi, pkg.lib()
-    bd, cf, full, matrix, fmt, obpp = FLOAT_TAIL_CLASSES[name]
+    bd, cf, full, matrix, fmt, obpp = FLOAT_TAIL_CLASSES[name][:6]
+    grid = len(FLOAT_TAIL_CLASSES[name]) > 6
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream().cuda_stream
     cols, rows, tw, th, w, h = 3, 2, 256, 192, 700, 330
     bps = 2 if bd > 8 else 1
-    blobs = [capi.parse_hevc(synthutil.picture(8100000 + 7 * k, width=tw, height=th, chroma_format=cf, bit_depth=bd, log2_ctb=5, qp=28, vui=1,
-                                               full_range=full, matrix=matrix, primaries=1, slices=(30 if k % 3 == 0 else 0))) for k in range(2 * cols * rows)]
+    datas = [synthutil.picture(8100000 + 7 * k, width=tw, height=th, chroma_format=cf, bit_depth=bd, log2_ctb=5, qp=28, vui=1,
+                               full_range=full, matrix=matrix, primaries=1, slices=(30 if k % 3 == 0 else 0)) for k in range(2 * cols * rows)]
+    blobs = [capi.parse_hevc(d) for d in datas]
     ys, cs, os_ = L.hm_plane_stride(w, bps), L.hm_plane_stride((w + 1) // 2, bps), L.hm_plane_stride(w, obpp)
     ch = (h + 1) // 2 if cf == 1 else h
     out = []
@@ -269,14 +328,16 @@ def test_fused_float_tail_equals_separate_kernels(pkg, hm, name, stages):
                 d.pitch[0], d.pitch[1], d.pitch[2] = ys, cs, cs
                 d.canvas_width, d.canvas_height = w, h
                 d.x0, d.y0 = (t % cols) * tw, (t // cols) * th
-                # (tile_has_nclx stays 0: a limited-range tile WITH an nclx is rescaled while it is pasted - context.cc:2504-2509 - and
-                #  such grids keep the separate kernels)
+                # (tile_has_nclx: 0 = the canvas carries the tiles' profile, nothing is rescaled; the grid classes: the tiles' own
+                #  profile - a limited-range tile is rescaled while it is pasted, context.cc:2504-2509)
+                if grid:
+                    d.tile_has_nclx, d.tile_full_range, d.tile_matrix = 1, full, matrix
                 batch.add(blobs[j * cols * rows + t], d)
             ims.append(im)
         batch.upload(st)
         PtrArr = C.c_void_p * 2
         ptrs = [PtrArr(*[im[k].data_ptr() for im in ims]) for k in ("y", "cb", "cr", "rgb")]
-        desc = capi.ColourDesc(w, h, bd, cf, 1, matrix, 1, full, getattr(capi, fmt), ys, cs, cs, os_)
+        desc = capi.ColourDesc(w, h, bd, cf, 0 if grid else 1, matrix, 1, full, getattr(capi, fmt), ys, cs, cs, os_)
         batch.set_colour(desc, 2, *ptrs, group)
         batch.execute(stages, st)
         torch.cuda.synchronize()
@@ -287,6 +348,14 @@ def test_fused_float_tail_equals_separate_kernels(pkg, hm, name, stages):
     for j in range(2):
         assert np.array_equal(out[0][j], out[1][j]), f"{name}, image {j}: fused float tail differs from the separate kernels"
     assert out[0][0].any()
+    if stages == 3:
+        # ... and against the CPU flow: the tiles decoded by the oracle's executors and by the real libde265, pasted by the oracle
+        # (no rescale: the canvas carries the tiles' own profile), converted along the chain the reference's search picks
+        for j in range(2):
+            tiles = datas[j * cols * rows:(j + 1) * cols * rows]
+            for decoder in ["oracle"] + (["ref"] if orc.have_ref() else []):
+                exp, _, _ = pipeline.cpu_decode(hm, tiles, tw, th, w, h, cols, grid, getattr(capi, fmt), decoder=decoder)
+                assert np.array_equal(out[0][j], exp[:h, :w * obpp]), f"{name}, image {j}: fused float tail differs from the CPU flow ({decoder})"
 
 
 @pytest.mark.parametrize("groups", [2, 3, 8])

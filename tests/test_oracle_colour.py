@@ -75,3 +75,18 @@ def test_bilinear_variants(oracle):
     o16 = np.zeros((1, 6), np.uint16)
     oracle.orc_upsample_bilinear_422_u16(orc.ptr(row16), 3, 6, 1, orc.ptr(o16), 6)
     assert o16.tolist() == [[40, 50, 70, 90, 110, 120]]
+
+
+def test_paste_rescale_integer_form(oracle):
+    """The fused tail kernels (filters.hip: pk_rescale) rescale 8-bit samples with
+    t = max(v, 16) - 16; out = min(255, t + ((t * A + B) >> S)), (A, B, S) = (173, 507, 10) luma / (73, 256, 9) chroma,
+    every intermediate below 2^16: equal to the oracle's float paste (context.cc:2504-2528) for all 256 values of both
+    kinds of plane (the kernel source checks the same identity at compile time)."""
+    ramp = np.tile(np.arange(256, dtype=np.uint8), (64, 1))
+    for c, (A, B, S) in ((0, (173, 507, 10)), (1, (73, 256, 9))):
+        canvas = np.zeros((64, 256), np.uint8)
+        assert oracle.orc_paste_tile_plane(orc.ptr(ramp), 256, 256, 64, orc.ptr(canvas), 256, 256, 64, 0, 0, c, 3, 8, 1, 0, 2) == 0
+        t = np.maximum(np.arange(256), 16) - 16
+        assert (t * A + B).max() < 65536
+        form = np.minimum(255, t + ((t * A + B) >> S))
+        np.testing.assert_array_equal(canvas[0], form)
