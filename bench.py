@@ -340,7 +340,7 @@ def main():
 def run(args):
     import torch
     import __graft_entry__ as g
-    pkg = g.load_package()
+    pkg = g.load_package(test_knobs=True)
     L = pkg.lib()
     capi = pkg.capi
 

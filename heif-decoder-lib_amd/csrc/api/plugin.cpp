@@ -48,7 +48,7 @@ heif_error from_status(int rc)
   switch (rc) {
     case HM_ERR_UNSUPPORTED: return {heif_error_Unsupported_feature, heif_suberror_Unsupported_codec, g_msg};
     case HM_ERR_BITSTREAM: {
-      const bool framing = std::strstr(g_msg, "NAL length") != nullptr; // (hevc_parse.cpp: "truncated NAL length field" / "NAL length exceeds the data")
+      const bool framing = hm_last_error_detail() == HM_DETAIL_END_OF_DATA; // (hevc_parse.cpp: a [length][NAL] record past the pushed bytes)
       return {heif_error_Decoder_plugin_error, framing ? heif_suberror_End_of_data : heif_suberror_Unspecified, g_msg};
     }
     case HM_ERR_NOMEM: return {heif_error_Memory_allocation_error, heif_suberror_Unspecified, g_msg};

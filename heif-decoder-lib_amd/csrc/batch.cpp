@@ -213,13 +213,13 @@ struct hm_batch {
 // without HEVC tiles, 16-sample-aligned widths and paste positions, no conformance-window offset, the
 // images' canvases fully covered by their pictures, and the integer matrix chain to RGB24 / RGBA32.  The canvases are
 // then never written: the attached conversion's output is the batch's result.  The limited -> full range rescale of a grid's
-// paste (context.cc:2504-2528) is part of the fused kernels (r05).  HM_TAIL_FUSED=0 keeps the separate
+// paste (context.cc:2504-2528) is part of the fused kernels (r05).  The knob tail_fused = 0 keeps the separate
 // kernels (A/B measurements).
 struct TailDstHost { uint8_t* rgb; int32_t pitch; int32_t pad; };
 static int decide_tail(hm_batch* b)
 {
   b->tail_state = 1;
-  static const bool off = [] { const char* e = std::getenv("HM_TAIL_FUSED"); return e && e[0] == '0'; }();
+  const bool off = hm_knob(HM_KNOB_TAIL_FUSED) == 0; // (A/B measurements and tests: hm_debug_set)
   if (off || !b->colour || b->colour_chunk < 0 || b->classes.size() != 1) return HM_OK;
   const Class& c = b->classes[0];
   const hm_colour_desc& d = b->colour_desc;
@@ -530,7 +530,7 @@ int hm_batch_execute(hm_batch* b, int stages, void* stream)
 {
   if (!b) return hm_fail(HM_ERR_INVALID_ARG, "null batch");
   if (!b->uploaded) return hm_fail(HM_ERR_INVALID_ARG, "hm_batch_upload() has not been called");
-  if (const int fw = hm_debug_batch_fail_width()) // (test hook, hm_internal.h: never set in production)
+  if (const int fw = hm_knob(HM_KNOB_BATCH_FAIL_WIDTH)) // (test hook, hm_internal.h: never set in production)
     for (const Item& it : b->items)
       if ((int)it.hdr.width == fw) return hm_fail(HM_ERR_UNSUPPORTED, "test hook: pictures %d samples wide are refused", fw);
   hipStream_t s = (hipStream_t)stream;

@@ -1145,15 +1145,9 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
 
 } // namespace
 
-// Test hooks (tests/chain_mode_check.py through hm_debug_set, common.cpp): a shorter bound for the waits and the fault
-// injection "the first band of every picture never announces its progress".  Not read from the environment: a stray
-// variable must not be able to fail decodes in production.
-static int g_chain_spin_limit = 0, g_chain_test_stall = 0;
-extern "C" void hm_chain_test_knobs(int spin_limit, int test_stall)
-{
-  if (spin_limit >= 0) g_chain_spin_limit = spin_limit;
-  if (test_stall >= 0) g_chain_test_stall = test_stall;
-}
+// Test hooks (hm_internal.h: hm_knob / hm_debug_set): a shorter bound for the waits, the fault injection "the first band of
+// every picture never announces its progress", and the forced cuts of the measurement scripts.  Nothing is read from the
+// environment: a stray variable must not be able to change or fail decodes in production.
 
 // The chain kernel serves every picture whose records come as split chains (no rare syntax, not 4:4:4), after
 // hm_launch_residual on the same stream; returns 1 if it launched (2: in the wave-per-row-pair mode, i.e. using d_sync),
@@ -1172,12 +1166,12 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   auto al4 = [](int v) { return (v + 3) & ~3; };
   CLayout L;
   // One wave per picture, or - few pictures - one wave per pair of CTU rows (PAIRS): a batch that cannot fill the
-  // machine with a wave per picture (256 CUs x 16 waves) gets its parallelism from the rows instead.  HM_CHAIN_PAIRS=0 / 1
+  // machine with a wave per picture (256 CUs x 16 waves) gets its parallelism from the rows instead.  The knob chain_pairs = 0 / 1
   // forces the choice (A/B measurements).
-  static const int force_pairs = [] { const char* e = getenv("HM_CHAIN_PAIRS"); return e && e[0] ? atoi(e) : -1; }();
+  const int force_pairs = hm_knob(HM_KNOB_CHAIN_PAIRS);
   // The fewer waves there are, the finer the work is cut: a wave per pair of rows (4 chains per wave), per row (2), per
   // chain (1) - every chain a wave drops makes its iterations shorter, and a picture is a wavefront of CTUs whose length
-  // in iterations does not change.  HM_CHAIN_PAIRS = 1 / 2 / 3 forces pair / row / chain waves.
+  // in iterations does not change.  chain_pairs = 1 / 2 / 3 forces pair / row / chain waves.
   // Measured on MI355X with 512x512 tiles (tools/r03_thresh.sh, ms of both reconstruction kernels; per picture / pair /
   // row / chain): 48 tiles 4.20 / 2.11 / 1.69 / 1.46, 192: 4.21 / 2.31 / 1.96 / 2.33, 768: 5.23 / 4.69 / 5.06 / 6.40,
   // 1536: 6.00 / 7.67 / 9.04 / 11.9, 3072: 7.25 / 14.3 / 16.9 / 22.8 - a wave that waits for the rows above it holds its
@@ -1208,12 +1202,12 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
     L.split_kinds = force_pairs >= 3 && !mono ? 1 : 0;
     share = 0;
   }
-  static const int force_share = [] { const char* e = getenv("HM_CHAIN_SHARE"); return e ? atoi(e) : 0; }(); // (tuning aid: waves per picture that take its pairs of rows in turn)
+  const int force_share = hm_knob(HM_KNOB_CHAIN_SHARE); // (tuning aid: waves per picture that take its pairs of rows in turn)
   if (force_share >= 2 && max_ctb_h > nr) { pairs = true; L.rows_per_wave = nr; L.split_kinds = 0; share = force_share; }
   // ... with all of them in one workgroup, handing over through LDS in a ring (k_chain: wg_ring): no wave waits for another
-  // workgroup, so any number of them may be in flight.  HM_CHAIN_RING = W forces it (0: never), with HM_CHAIN_PAIRS = 1 / 2 / 3
+  // workgroup, so any number of them may be in flight.  The knob chain_ring = W forces it (0: never), with chain_pairs = 1 / 2 / 3
   // for the rows and chains per wave.
-  static const int force_ring = [] { const char* e = getenv("HM_CHAIN_RING"); return e && e[0] ? atoi(e) : -1; }();
+  const int force_ring = hm_knob(HM_KNOB_CHAIN_RING);
   int ring_w = 0; // (chosen below, once the layout and the kernel of a cut can be worked out)
   if (force_ring >= 0) {
     ring_w = force_ring >= 2 && max_ctb_h > 1 ? (force_ring > 16 ? 16 : force_ring) : 0;
@@ -1224,8 +1218,8 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
     }
   }
   if (ring_w) { pairs = true; share = 0; }
-  L.spin_limit = g_chain_spin_limit > 0 ? g_chain_spin_limit : SPIN_LIMIT;
-  L.test_stall = g_chain_test_stall;
+  L.spin_limit = hm_knob(HM_KNOB_CHAIN_SPIN_LIMIT) > 0 ? hm_knob(HM_KNOB_CHAIN_SPIN_LIMIT) : SPIN_LIMIT;
+  L.test_stall = hm_knob(HM_KNOB_CHAIN_TEST_STALL);
   auto sync_words = [&](int bands) { return ((size_t)SYNC_PROGRESS + 2 * (size_t)n_pics * bands) * sizeof(uint32_t); };
   auto passes_of = [&]() { return (max_ctb_h + L.rows_per_wave - 1) / L.rows_per_wave; };
   if (!d_sync || !d_err || sync_bytes < sync_words(passes_of())) { pairs = false; share = 0; ring_w = 0; }
@@ -1233,8 +1227,8 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   while (ring_w && (ring_w << L.split_kinds) > 16) ring_w--; // (a workgroup holds 16 waves)
   if (!pairs) { L.rows_per_wave = nr; L.split_kinds = 0; }
   // ---- LDS of a wave ----
-  // (a ring of waves with one chain each: the waves alternate between the kinds, k_chain: ALT; HM_CHAIN_ALT=0: they keep theirs - A/B)
-  static const bool alt_allowed = [] { const char* e = getenv("HM_CHAIN_ALT"); return !(e && e[0] == '0'); }();
+  // (a ring of waves with one chain each: the waves alternate between the kinds, k_chain: ALT; knob chain_alt = 0: they keep theirs - A/B)
+  const bool alt_allowed = hm_knob(HM_KNOB_CHAIN_ALT) != 0;
   bool alt_wanted = alt_allowed; // (cleared where the second line does not fit a workgroup's LDS)
   auto alt_kinds = [&]() { return ring_w != 0 && L.split_kinds != 0 && !mono && alt_wanted; };
   auto set_layout = [&]() -> bool { // for the cut in L; false if a wave does not fit the CU's LDS
@@ -1433,7 +1427,7 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   if (share) {
     // The waves of a picture that take its bands in turn wait for each other in both directions: all of them must be on
     // the device together.  Its capacity for this kernel: compute units x the waves a CU holds of it (`best`: registers
-    // and this cut's LDS); the forced value (HM_CHAIN_SHARE) is clamped like the chosen one.
+    // and this cut's LDS); the forced value (knob chain_share) is clamped like the chosen one.
     const long resident_waves = (long)cus() * best;
     long w = resident_waves / n_pics;
     if (!force_share || force_share < 2) w = w > 4 ? 4 : w;
@@ -1448,7 +1442,7 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   L.bands_per_pic = share && share < L.passes ? share : (ring_w ? ring_w : L.passes);
   L.ring = ring_w ? 1 : 0;
   const size_t sync_need = sync_words(L.passes);
-  static const int force_np = [] { const char* e = getenv("HM_CHAIN_NP"); return e ? atoi(e) : 0; }(); // (tuning aid, read once)
+  const int force_np = hm_knob(HM_KNOB_CHAIN_NP); // (tuning aid)
   const long n_waves = pairs ? ((long)n_pics * L.bands_per_pic) << L.split_kinds : (long)n_pics;
   // A wave per CTU row (or per chain of one): neighbouring rows in one workgroup hand over through LDS (k_chain: lds_above) -
   // the more waves a workgroup holds, the fewer hand-overs go through HBM.  Eight: one in eight (sixteen measured no better).
@@ -1470,7 +1464,7 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   else while (np > 1 && (long)np * 256 > n_waves) np--; // few waves: spread them over the CUs first
   if (force_np > 0 && force_np <= 16 && C_SHARED + force_np * L.pic_bytes <= 160 * 1024 && (!ring_w || force_np % (ring_w << L.split_kinds) == 0)) np = force_np;
   const int lds_bytes = C_SHARED + np * L.pic_bytes;
-  static const int debug = [] { const char* e = getenv("HM_CHAIN_DEBUG"); return e ? atoi(e) : 0; }();
+  const int debug = hm_knob(HM_KNOB_CHAIN_DEBUG);
   if (debug) fprintf(stderr, "[k_chain] %d pictures, %ld waves (%s), %d bytes of LDS per wave, %d waves per workgroup, %d waves per CU\n", n_pics, n_waves,
                      !pairs ? "one per picture" : (L.split_kinds ? "one per chain of a CTU row" : (L.rows_per_wave == 1 ? "one per CTU row" : (L.bands_per_pic < L.passes ? "several per picture, taking its pairs of CTU rows in turn" : "one per pair of CTU rows"))),
                      L.pic_bytes, np, best);

@@ -1022,12 +1022,17 @@ __device__ __forceinline__ uint32_t pk_rescale(uint32_t pair)
 }
 
 // ... of a pair of samples as they lie in memory: 8-bit samples as above; 16-bit storage byte by byte (quirk Q1: the reference's
-// loop runs over the BYTES of the plane, context.cc:2499-2525)
+// loop runs over the BYTES of the plane, context.cc:2499-2525) with the offset of the picture's depth, 16 << (depth - 8) - the
+// float expression itself, as k_sao_paste evaluates it (rare: a grid of deeper limited-range tiles)
 template <typename Pix, bool CHROMA>
-__device__ __forceinline__ uint32_t pk_rescale_stored(uint32_t pair)
+__device__ __forceinline__ uint32_t pk_rescale_stored(uint32_t pair, int bd)
 {
   if (sizeof(Pix) == 1) return pk_rescale<CHROMA>(pair);
-  return pk_rescale<CHROMA>(pair & 0x00FF00FFu) | (pk_rescale<CHROMA>((pair >> 8) & 0x00FF00FFu) << 8);
+  const float off = (float)(16 << (bd - 8)), ratio = CHROMA ? 1.1429f : 1.1689f;
+  uint32_t o = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) o |= (uint32_t)clip_f_u8(__fmul_rn(__fsub_rn((float)((pair >> (8 * k)) & 0xFF), off), ratio)) << (8 * k);
+  return o;
 }
 
 template <int BPP, int MINW, bool UNI>
@@ -1383,7 +1388,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_tailf(const hm_dev_pic* __restri
       tile_sao<Pix>(dp, v, 2, s_c[1], CP, (x0 >> 1) - TF_XO, (y0 >> SV) - 4, xc, yc, W >> 1, H >> SV, l2 - 1, l2 - SV, stages & 2, bd, crs);
       if (rescale) { // (the paste of a limited-range tile: context.cc:2504-2528)
 #pragma unroll
-        for (int j = 0; j < 4; j++) { cbs[j] = pk_rescale_stored<Pix, true>(cbs[j]); crs[j] = pk_rescale_stored<Pix, true>(crs[j]); }
+        for (int j = 0; j < 4; j++) { cbs[j] = pk_rescale_stored<Pix, true>(cbs[j], bd); crs[j] = pk_rescale_stored<Pix, true>(crs[j], bd); }
       }
     }
 #pragma unroll
@@ -1397,7 +1402,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_tailf(const hm_dev_pic* __restri
         tile_sao<Pix>(dp, v, 0, s_l, LP, x0 - TF_XO, y0 - 4, hx, ly + r, W, H, l2, l2, stages & 2, bd, ry);
         if (rescale) {
 #pragma unroll
-          for (int j = 0; j < 4; j++) ry[j] = pk_rescale_stored<Pix, false>(ry[j]);
+          for (int j = 0; j < 4; j++) ry[j] = pk_rescale_stored<Pix, false>(ry[j], bd);
         }
         uint8_t ob[8 * OBPP];
 #pragma unroll

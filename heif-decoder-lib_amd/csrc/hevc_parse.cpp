@@ -16,6 +16,7 @@
 #include <memory>
 
 #include "hevc_syntax.h"
+#include "hm_knobs.h"
 #include "hm_internal.h"
 
 namespace hm {
@@ -163,8 +164,9 @@ struct Decoder {
       cur_sps = &s;
       cur_pps = &p;
       {
-        static const bool interleaved = [] { const char* e = std::getenv("HM_STREAM_INTERLEAVED"); return e && e[0] == '1'; }();
-        want_split = !interleaved && (record_order == HM_RECORDS_SPLIT || (record_order == HM_RECORDS_AUTO && quad_class(s)));
+        const bool interleaved = hm_knob(HM_KNOB_STREAM_INTERLEAVED) == 1;
+        const int force_class = hm_knob(HM_KNOB_QUAD_CLASS); // (A/B measurements: 1 split chains for all classes, 0 for none)
+        want_split = !interleaved && (record_order == HM_RECORDS_SPLIT || (record_order == HM_RECORDS_AUTO && (force_class >= 0 ? force_class != 0 : quad_class(s))));
       }
       pic.reset(s, p, want_split);
       pic_started = true;
@@ -495,9 +497,9 @@ struct Decoder {
     if (!picture_done) throw ParseError(HM_ERR_BITSTREAM, "picture incomplete: missing slice segments");
 
     // Record order (hm_stream.h): pictures without rare syntax get their luma and chroma records in separate lists,
-    // row by row (the four-rows-per-wave kernel walks the two chains independently); HM_STREAM_INTERLEAVED=1 (read
-    // once; A/B measurements of the one-row-per-wave kernel) keeps the decode order for every picture.
-    static const bool force_interleaved = [] { const char* e = std::getenv("HM_STREAM_INTERLEAVED"); return e && e[0] == '1'; }();
+    // row by row (the four-rows-per-wave kernel walks the two chains independently); the knob stream_interleaved = 1 (hm_debug_set;
+    // A/B measurements of the one-row-per-wave kernel) keeps the decode order for every picture.
+    const bool force_interleaved = hm_knob(HM_KNOB_STREAM_INTERLEAVED) == 1;
     const bool rare = s.scaling_list_enabled || (s.pcm_enabled && s.pcm_loop_filter_disabled) || p.transquant_bypass_enabled ||
                       pic.uses_pcm || pic.uses_tq_bypass || s.chroma_format_idc == 3 || s.transform_skip_rotation || s.implicit_rdpcm ||
                       s.intra_smoothing_disabled || p.cross_component_prediction ||
@@ -734,6 +736,10 @@ static_assert(sizeof(hm_pic) % 4 == 0, "hm_pic layout");
 
 static int hm_hevc_parse_run(const uint8_t* data, size_t size, int annexb, int threads, int record_order, uint8_t** out_blob, size_t* out_size)
 {
+#if defined(__BMI2__) || defined(__LZCNT__)
+  // this translation unit is built with BMI / BMI2 / LZCNT (Makefile: HOST_ISA): a host without them gets an error, not SIGILL
+  if (!hm_host_has_bmi2_lzcnt()) return hm_fail(HM_ERR_UNSUPPORTED, "this build of the entropy decoder needs BMI2 and LZCNT (rebuild with HOST_ISA=)");
+#endif
   try {
     static thread_local std::unique_ptr<hm::Decoder> workspace;
     if (!workspace) workspace = std::make_unique<hm::Decoder>();
@@ -763,10 +769,10 @@ static int hm_hevc_parse_run(const uint8_t* data, size_t size, int annexb, int t
       // [u32 big-endian length][NAL] records (decoder_libde265.cc:269-303)
       size_t p = 0;
       while (p < size) {
-        if (p + 4 > size) return hm_fail(HM_ERR_BITSTREAM, "truncated NAL length field");
+        if (p + 4 > size) return hm_fail_detail(HM_ERR_BITSTREAM, HM_DETAIL_END_OF_DATA, "truncated NAL length field");
         const uint32_t n = ((uint32_t)data[p] << 24) | ((uint32_t)data[p + 1] << 16) | ((uint32_t)data[p + 2] << 8) | data[p + 3];
         p += 4;
-        if (n > size - p) return hm_fail(HM_ERR_BITSTREAM, "NAL length exceeds the data");
+        if (n > size - p) return hm_fail_detail(HM_ERR_BITSTREAM, HM_DETAIL_END_OF_DATA, "NAL length exceeds the data");
         dec->handle_nal(data + p, n);
         p += n;
       }

@@ -179,9 +179,7 @@ static const uint8_t kMode422[35] = {0, 1, 2, 2, 2, 2, 3, 5, 7, 8, 10, 12, 13, 1
 // (profiles/r04_class_sweep.txt).  Pictures with rare syntax keep decode-order records whatever this says (PictureState::reset).
 inline bool quad_class(const SPS& s)
 {
-  static const int force = [] { const char* e = std::getenv("HM_QUAD_CLASS"); return e ? std::atoi(e) : -1; }(); // (A/B measurements: 1 all, 0 none)
-  if (force >= 0) return force != 0;
-  (void)s;
+  (void)s; // (the parser's knob quad_class overrides this for A/B measurements: hevc_parse.cpp)
   return true;
 }
 

@@ -963,7 +963,22 @@ int hm_decode_item_devices(const hm_file* f, uint32_t id, const hm_decode_params
   const bool cut = n_devices > 1 && plan.is_grid && plan.rows >= 2 && params->out_format != 0 && hm_out_bytes_per_pixel(params->out_format) > 0 &&
                    params->chroma_upsampling == 0 && !f->file.alpha_item_of(id) && plan.tile_alpha.empty() &&
                    (params->ignore_transformations || !it || it->props.transforms.empty()) && ih > 0 && (ih % 2) == 0 && params->stream == nullptr;
-  if (!cut) {
+  // The whole-grid geometry checks of the one-device path (planar_from_blobs: context.cc:2299-2359) look at the grid BEFORE it is
+  // cut - a slab only ever sees its own reduced canvas: tiles of one declared size that cover the canvas, and every tile's origin
+  // inside it.  A grid that fails one is not cut: hm_decode_item on the first device reports it exactly as it always does
+  // (r04 advice: such a grid came back HM_OK with rows of the destination never written).
+  bool geometry_ok = cut;
+  if (cut) {
+    const int iw = t0->props.ispe_width;
+    if (plan.canvas_w > 32768 || plan.canvas_h > 32768 || iw <= 0) geometry_ok = false;
+    for (size_t i = 0; geometry_ok && i < plan.tiles.size(); i++) {
+      const hm::Item* ti = f->file.item(plan.tiles[i].id);
+      const int sw_ = ti ? ti->props.ispe_width : 0, sh_ = ti ? ti->props.ispe_height : 0;
+      const long x0 = (long)((int)i % plan.cols) * iw, y0 = (long)((int)i / plan.cols) * ih;
+      if (sw_ != iw || sh_ != ih || sw_ < plan.canvas_w / plan.cols || sh_ < plan.canvas_h / plan.rows || x0 >= plan.canvas_w || y0 >= plan.canvas_h) geometry_ok = false;
+    }
+  }
+  if (!cut || !geometry_ok) {
     if (hipSetDevice(devices[0]) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipSetDevice(%d) failed", devices[0]);
     return hm_decode_item(f, id, params, out);
   }

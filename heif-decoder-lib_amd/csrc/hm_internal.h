@@ -14,6 +14,8 @@ extern "C" {
 // records `what` + the HIP error string in the thread-local last-error slot
 int hm_check_hip(hipError_t e, const char* what);
 int hm_fail(int status, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+int hm_host_has_bmi2_lzcnt(void); // (common.cpp, built for the x86-64 baseline: the check must not need what it checks for)
+int hm_fail_detail(int status, int detail, const char* message); // ... with an hm_error_detail callers may branch on (hm_last_error_detail)
 
 // colour.hip
 int hm_launch_colour_int420(const hm_colour_desc* d, const int coef[4], const void* y, const void* cb,
@@ -61,12 +63,7 @@ int hm_launch_residual(const struct hm_dev_pic* d_pics, int n_pics, int max_ctb_
 // hm_batch_check.  hm_chain_sync_bytes: the size that mode needs.
 int hm_launch_chain(const struct hm_dev_pic* d_pics, int n_pics, int log2_ctb, int chroma_format, int bit_depth, int rare_syntax,
                     int max_ctb_w, int max_ctb_h, uint32_t* d_sync, size_t sync_bytes, uint32_t* d_err, hipStream_t s);
-void hm_chain_test_knobs(int spin_limit, int test_stall); // (< 0: leave as it is)
-// Test hook, exported but in no public header: sets an internal knob by name ("chain_spin_limit", "chain_test_stall",
-// "batch_fail_width": hm_batch_execute refuses batches holding a picture of that width - for the failure-isolation
-// tests).  Returns 0, or -1 for an unknown name.  Nothing in the library reads these from the environment.
-__attribute__((visibility("default"))) int hm_debug_set(const char* name, int value);
-int hm_debug_batch_fail_width(void);
+#include "hm_knobs.h" // hm_knob / hm_debug_set
 size_t hm_chain_sync_bytes(int n_pics, int chroma_format, int max_ctb_h);
 int hm_launch_deblock(const struct hm_dev_pic* d_pics, int n_pics, int max_w4, int max_h4, int chroma_format,
                       int bit_depth, int rare_syntax, hipStream_t s);

@@ -1,0 +1,33 @@
+// hm_knobs.h - the library's tuning and test knobs (common.cpp); no HIP types: the host parser includes it too.
+#ifndef HM_KNOBS_H
+#define HM_KNOBS_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+// Tuning and test knobs.  NOTHING in the library reads them from the environment (r05: a stray HM_CHAIN_RING in a service's
+// environment must not change every decode's kernel): they are set by name through hm_debug_set - exported, in no public
+// header, used by tests/, tools/ and bench.py (tests/knobs.py maps the HM_* variables of the measurement scripts onto it) -
+// and read through hm_knob().  Atomic words: worker threads read them while a test sets them.
+//   chain_spin_limit (0)   polls without news before a chain wave gives up a wait (0: the default bound)
+//   chain_test_stall (0)   fault injection: the first band of every picture never announces its progress
+//   batch_fail_width (0)   hm_batch_execute refuses batches holding a picture of that width (failure-isolation tests)
+//   chain_pairs (-1)       cut of a picture in k_chain: 0 a wave per picture, 1 / 2 / 3 a wave per pair of rows / row / chain
+//   chain_share (0)        >= 2: waves per picture that take its pairs of rows in turn through HBM
+//   chain_ring (-1)        W >= 2: the ring of W waves per picture in one workgroup; 0: never
+//   chain_alt (1)          0: the one-chain waves of a ring keep their kind of chain
+//   chain_np (0)           pictures per workgroup of the wave-per-picture cut
+//   chain_debug (0)        print the launcher's choice to stderr
+//   resid_segs (0)         runs of CTUs a row of k_residual is cut into
+//   recon_waves (0)        waves per workgroup of k_recon
+//   quad_class (-1)        record order of the parser: 1 split chains for every class that has them, 0 for none
+//   tail_fused (1)         0: the separate filter / colour kernels also where the fused ones apply
+//   stream_interleaved (0) 1: records in decode order (format of the rare-syntax classes) for every picture
+enum hm_knob_id { HM_KNOB_CHAIN_SPIN_LIMIT, HM_KNOB_CHAIN_TEST_STALL, HM_KNOB_BATCH_FAIL_WIDTH, HM_KNOB_CHAIN_PAIRS, HM_KNOB_CHAIN_SHARE, HM_KNOB_CHAIN_RING,
+                  HM_KNOB_CHAIN_ALT, HM_KNOB_CHAIN_NP, HM_KNOB_CHAIN_DEBUG, HM_KNOB_RESID_SEGS, HM_KNOB_RECON_WAVES, HM_KNOB_QUAD_CLASS, HM_KNOB_TAIL_FUSED,
+                  HM_KNOB_STREAM_INTERLEAVED, HM_KNOB_COUNT };
+int hm_knob(int id);
+__attribute__((visibility("default"))) int hm_debug_set(const char* name, int value); // 0, or -1 for an unknown name
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -185,9 +185,20 @@ class DeviceWorker {
           // contexts), and a batch fails as a whole - one picture the kernels cannot take (a class whose CTU staging does
           // not fit LDS, a pool that is out of memory for it) must not fail its neighbours' valid pictures.  Every
           // request again, in a batch of its own: each caller gets its own picture's verdict.
-          rcs.resize(reqs.size());
-          msgs.resize(reqs.size());
-          for (size_t i = 0; i < reqs.size(); i++) rcs[i] = run_batch(std::vector<Request*>(1, reqs[i]), s, msgs[i]);
+          // Only where the verdict can be a picture's own: a device-level failure (a HIP error - sticky -, no device) goes to every
+          // request as it is - re-running 64 batches into the same dead stream helps nobody -, and when the single batches run
+          // out of memory or lose the device too, the rest take that verdict without being tried.
+          if (rc != HM_ERR_NO_DEVICE) {
+            rcs.assign(reqs.size(), rc);
+            msgs.assign(reqs.size(), msg);
+            for (size_t i = 0; i < reqs.size(); i++) {
+              rcs[i] = run_batch(std::vector<Request*>(1, reqs[i]), s, msgs[i]);
+              if (rcs[i] == HM_ERR_NO_DEVICE || rcs[i] == HM_ERR_NOMEM) {
+                for (size_t k = i + 1; k < reqs.size(); k++) { rcs[k] = rcs[i]; msgs[k] = msgs[i]; }
+                break;
+              }
+            }
+          }
         }
       }
       const std::chrono::steady_clock::time_point now = std::chrono::steady_clock::now();

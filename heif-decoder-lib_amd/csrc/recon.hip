@@ -432,7 +432,7 @@ extern "C" int hm_launch_recon(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   // pictures queued, fewer waves per picture and more pictures per CU give more throughput.
   // Measured on MI355X (profiles/r01_recon_wave_sweep.txt): <= 768 tiles in flight -> 8 waves per
   // picture is fastest (latency), beyond that 4 waves per picture wins (+20 %).
-  static const int env_nw = [] { const char* e = getenv("HM_RECON_WAVES"); return e ? atoi(e) : 0; }(); // (tuning aid, read once)
+  const int env_nw = hm_knob(HM_KNOB_RECON_WAVES); // (tuning aid)
   const int want = env_nw ? env_nw : (n_pics > 1024 ? 4 : 8);
   if (want >= 1 && want <= 8 && nw > want) nw = want;
   auto total = [&](int w) { return fixed + (w > 2 ? w : 2) * line + w * pw; };

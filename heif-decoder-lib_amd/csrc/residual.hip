@@ -512,8 +512,8 @@ extern "C" int hm_launch_residual(const hm_dev_pic* d_pics, int n_pics, int max_
 {
   if (n_pics <= 0) return HM_OK;
   long units = (long)n_pics * 2 * max_ctb_h;
-  // few pictures: the rows in segments, towards ~8192 waves (HM_RESID_SEGS forces a count: tests)
-  static const int forced = [] { const char* e = std::getenv("HM_RESID_SEGS"); return e ? std::atoi(e) : 0; }();
+  // few pictures: the rows in segments, towards ~8192 waves (the knob resid_segs forces a count: tests)
+  const int forced = hm_knob(HM_KNOB_RESID_SEGS);
   int segs = forced > 0 ? forced : (int)(8192 / units);
   segs = segs < 1 ? 1 : (segs > 16 ? 16 : segs);
   units *= segs;

@@ -52,6 +52,11 @@ typedef enum hm_status {
 HM_API const char* hm_status_string(int status);
 /* last error detail for the calling thread (static storage, never NULL) */
 HM_API const char* hm_last_error(void);
+/* What kind of failure the calling thread's last error was, where callers branch on more than the status: the decoder plugin
+ * maps HM_DETAIL_END_OF_DATA - a [length][NAL] record that runs past the pushed bytes - to heif_suberror_End_of_data as the
+ * reference's plugin does (libheif/plugins/decoder_libde265.cc:276-292).  Set by the call that failed, HM_DETAIL_NONE otherwise. */
+typedef enum hm_error_detail { HM_DETAIL_NONE = 0, HM_DETAIL_END_OF_DATA = 1 } hm_error_detail;
+HM_API int hm_last_error_detail(void);
 HM_API const char* hm_version(void);
 /* number of visible HIP devices (0 if none); does not initialise a context */
 HM_API int hm_device_count(void);

@@ -1,5 +1,5 @@
-"""Helper of test_chain_modes_gpu.py (run as a script: the reconstruction's tuning / fault-injection knobs are read from
-the environment once per process): reconstruct a few corpus pictures on the GPU and compare with the oracle.
+"""Helper of test_chain_modes_gpu.py (run as a script, a process per set of tuning / fault-injection knobs, which the
+script takes from its environment and sets through the library's test hook): reconstruct a few corpus pictures on the GPU and compare with the oracle.
 Prints OK, or the first difference; exit status 0 / 1; 3 = hm_batch_check reported a wave that gave up."""
 import sys
 
@@ -14,14 +14,10 @@ import orc
 def main():
     import ctypes
     import os
-    pkg = g.load_package()
-    # the fault-injection knobs are library test hooks (hm_debug_set), not environment variables of the product: the test
-    # hands them to this script through the environment and the script sets them
+    pkg = g.load_package(test_knobs=True)
+    # the cuts and the fault-injection knobs are library test hooks (hm_debug_set), not environment variables of the product: the
+    # test hands them to this script through the environment and load_package(test_knobs=True) sets them (tests/knobs.py)
     hm = pkg.lib()
-    hm.hm_debug_set.argtypes = [ctypes.c_char_p, ctypes.c_int]
-    for env, knob in (("HM_CHAIN_SPIN_LIMIT", b"chain_spin_limit"), ("HM_CHAIN_TEST_STALL", b"chain_test_stall")):
-        if os.environ.get(env):
-            assert hm.hm_debug_set(knob, int(os.environ[env])) == 0
     names = sys.argv[1:] or ["tile512_a", "ctb64_wpp", "hi422_10", "mono8", "ragged"]
     copies = int(os.environ.get("HM_CHECK_COPIES", "3"))  # (hundreds: the cuts the launcher chooses for mid-size batches)
     for name in names:

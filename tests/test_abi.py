@@ -135,3 +135,19 @@ def test_icc_profile_pass_through(hm):
     plain = pipeline.HeifFile(hm, heifwriter.write_heic(tiles[:1], (64, 64)))
     assert icc(plain, plain.primary(), 1) == (0, b"")
     plain.close()
+
+
+def test_tuning_knobs_are_not_read_from_the_environment(pkg, hm):
+    """r05: the kernels' tuning / fault-injection knobs are set through the test hook hm_debug_set only - no binary of the
+    product holds the name of one of the measurement scripts' variables (tests/knobs.py maps those onto the hook), so a
+    stray HM_CHAIN_RING in a service's environment cannot change a decode."""
+    import knobs
+    hm.hm_debug_set.argtypes = [C.c_char_p, C.c_int]
+    assert hm.hm_debug_set(b"no_such_knob", 1) == -1
+    for name in knobs.ENV_TO_KNOB.values():
+        assert name in ("chain_spin_limit", "chain_test_stall") or hm.hm_debug_set(name.encode(), {"chain_alt": 1, "tail_fused": 1}.get(name, -1 if name in ("chain_pairs", "chain_ring", "quad_class") else 0)) == 0, name
+    here = os.path.dirname(pkg.capi.LIB_PATH)
+    for so in glob.glob(os.path.join(here, "*.so")):
+        blob = open(so, "rb").read()
+        for env in knobs.ENV_TO_KNOB:
+            assert env.encode() not in blob, f"{os.path.basename(so)} mentions {env}"

@@ -142,6 +142,34 @@ def test_items_that_do_not_cut_fall_back_to_the_first_device(hm):
     f.close()
 
 
+@pytest.mark.parametrize("case", ["tiles_do_not_cover", "tile_row_below_canvas", "tiles_of_different_sizes"])
+def test_grids_with_bad_geometry_are_not_cut(hm, case):
+    """the whole-grid checks of the one-device path (context.cc:2299-2359: equal tile sizes, the canvas covered, every tile's
+    origin inside it) happen before hm_decode_item_devices cuts a grid into slabs - a slab only sees its own reduced canvas
+    (r04 advice: such a grid returned HM_OK with rows of the destination never written).  The call reports what
+    hm_decode_item reports."""
+    import ctypes as C
+    small = dict(TILE, width=128, height=128)
+    pics = [synthutil.picture(6600000 + i, **small, vui=1, full_range=1, matrix=6) for i in range(6)]
+    if case == "tiles_do_not_cover":      # 3 rows of 128 declared for a canvas of 600 rows: 128 < 600 / 3
+        data = heifwriter.write_heic(pics, (128, 128), grid=(3, 2, 256, 600))
+    elif case == "tile_row_below_canvas":  # the third tile row starts at y = 256 = the canvas height
+        data = heifwriter.write_heic(pics, (128, 128), grid=(3, 2, 256, 256))
+    else:
+        data = heifwriter.write_heic(pics, (128, 128), grid=(3, 2, 256, 384), sizes=[(128, 128)] * 5 + [(128, 120)])
+    f = pipeline.HeifFile(hm, data)
+    prm = pipeline.DecodeParams(10, 2, 0, 0, None, None, 0, 0, 0, 0)
+    d1, d2 = pipeline.Decoded(), pipeline.Decoded()
+    rc1 = hm.hm_decode_item(f.h, f.primary(), C.byref(prm), C.byref(d1))
+    msg1 = hm.hm_last_error()
+    dev = (C.c_int32 * 2)(0, 0)
+    hm.hm_decode_item_devices.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.c_void_p]
+    rc2 = hm.hm_decode_item_devices(f.h, f.primary(), C.byref(prm), dev, 2, C.byref(d2))
+    msg2 = hm.hm_last_error()
+    assert rc1 != 0 and rc2 == rc1 and msg2 == msg1, (case, rc1, msg1, rc2, msg2)
+    f.close()
+
+
 def test_config3_batch_of_12mp_grids(pkg, hm):
     """BASELINE config 3 on one rank: 32 DIFFERENT 12 MP grids (image j: tiles 1200000 + 48 j + i) in ONE hm_batch, one
     batched colour conversion - EVERY image compared with the CPU flow (the real reference decoder oracle/_ref for the

@@ -31,7 +31,7 @@ def main():
     import torch
     import __graft_entry__ as g
     import synthutil
-    pkg = g.load_package()
+    pkg = g.load_package(test_knobs=True)
     capi, L = pkg.capi, pkg.lib()
     dev = torch.device("cuda:0")
     n = int(os.environ.get("HM_CLASS_TILES", "1536"))

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, random
 import corpus, synthutil, orc, gpudecode
 import __graft_entry__ as g
-pkg = g.load_package()
+pkg = g.load_package(test_knobs=True)
 rng = random.Random(20261002)
 cases = corpus.rare_syntax_sweep(240, first_seed=4000)
 for i in range(260):   # ordinary syntax, wide parameter ranges

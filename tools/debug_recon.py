@@ -48,7 +48,7 @@ def records(blob):
 
 
 def main():
-    pkg = g.load_package()
+    pkg = g.load_package(test_knobs=True)
     name = sys.argv[1]
     if os.path.exists(name):
         data = open(name, "rb").read()

@@ -12,7 +12,7 @@ import torch  # noqa: E402
 import __graft_entry__ as g  # noqa: E402
 import bench  # noqa: E402
 
-pkg = g.load_package()
+pkg = g.load_package(test_knobs=True)
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
 st = torch.cuda.current_stream().cuda_stream

@@ -12,6 +12,6 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as g  # noqa: E402
 import bench  # noqa: E402
 
-pkg = g.load_package()
+pkg = g.load_package(test_knobs=True)
 tiles = [d for d, _ in bench.make_streams(pkg.capi, range(1200000, 1200048))]
 print(json.dumps(bench.plugin_path(pkg, tiles)))
