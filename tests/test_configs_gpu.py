@@ -80,7 +80,7 @@ def test_config5_16384_grid(hm):
         assert np.array_equal(got, expect[pick[t]]), f"tile {t} (row {r}, col {c}) differs"
 
 
-@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]], ids=["two_slabs", "three_slabs"])
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0], "all"], ids=["two_slabs", "three_slabs", "every_gpu_of_the_box"])
 @pytest.mark.parametrize("ext", [False, True], ids=["pinned_plane", "ext_dst"])
 def test_one_grid_over_several_devices(hm, devices, ext):
     """hm_decode_item_devices: ONE grid cut into slabs of tile rows, one per listed device, each decoded and converted on
@@ -89,6 +89,12 @@ def test_one_grid_over_several_devices(hm, devices, ext):
     32 x 32 tiles; 24 distinct tiles as in the config-5 test) must come out bit for bit as the one-device decode; a second,
     cropped grid (5 tile rows for 2 / 3 devices: uneven slabs, a last slab cut by the canvas) likewise, also into ext_dst."""
     import ctypes as C
+    if devices == "all":  # (r05) the case that scales itself to the box: a slab per GPU that is there
+        import torch
+        n = min(torch.cuda.device_count(), 8)
+        if n < 2:
+            pytest.skip("one GPU visible: the slabs of the other cases share it")
+        devices = list(range(n))
     pool = [synthutil.picture(5000000 + i, **TILE, vui=1, full_range=1, matrix=6) for i in range(24)]
     for (rows, cols, w, h) in ((32, 32, 16384, 16384), (5, 3, 1500, 2300)):
         if ext and rows == 32:

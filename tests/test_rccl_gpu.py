@@ -54,3 +54,59 @@ def test_rccl_one_rank_gather_of_device_slabs():
     res = json.loads(line[-1][7:])
     assert res["backend"] == "nccl" and res["world"] == 1
     assert res["all_reduce"] and res["gather"], res
+
+
+def _gpus_here():
+    import torch
+    return min(torch.cuda.device_count(), 8)  # (counting devices does not initialise the GPU in this process)
+
+
+def _bench_ranks(world, extra, timeout):
+    """bench.py as the driver launches it for N > 1: one process per GPU, torch.distributed.run, RCCL; -> its JSON line"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert lines, r.stdout[-2000:] + r.stderr[-2000:]
+    return json.loads(lines[-1])
+
+
+@pytest.mark.parametrize("world", ["two_gpus", "all_gpus"])
+def test_one_grid_over_the_gpus_that_are_there(world):
+    """SURVEY 8e on real devices: ONE 16384 x 16384 grid (BASELINE config 5), its 32 tile rows cut into a slab per rank, every rank
+    decoding its slab on its own GPU, the RGB row slabs gathered with ONE RCCL collective (shard.gather_slabs) - and rank 0
+    comparing the gathered image bit for bit with its own one-rank decode of the whole grid (bench.py --mode grid's self-check;
+    the reference's in-process tile fan-out context.cc:2361-2401 across processes).  Scales itself to the box: 2 ranks and
+    min(device_count, 8) ranks; skipped on a one-GPU box, where tests/test_shard_gloo.py (2 gloo ranks) and the one-rank test
+    above stand in."""
+    n = _gpus_here()
+    w = 2 if world == "two_gpus" else n
+    if n < 2 or (world == "all_gpus" and n == 2):
+        pytest.skip(f"{n} GPU(s) visible: nothing beyond the other cases to run")
+    res = _bench_ranks(w, ["--mode", "grid", "--steps", "2", "--warmup", "1"], timeout=1800)
+    assert "error" not in res, res
+    assert res["n_gpus"] == w and res["world_size"] == w and res["gather"]["backend"] == "nccl"
+    assert "bit-exact" in res["config"]["self_check"], res["config"]
+    assert sum(res["config"]["tile_rows_per_rank"]) == 32
+
+
+@pytest.mark.parametrize("world", ["two_gpus", "all_gpus"])
+def test_image_batch_sharded_over_the_gpus_that_are_there(world):
+    """BASELINE config 3's partitioning on real devices: the image batch block-sharded over the ranks (no collective on the
+    data path), every rank's parity gate (a random image of ITS shard against the oracle and the real libde265) reduced over
+    the ranks with RCCL - bench.py --gpus N exactly as the driver's scaling run starts it, with a small batch."""
+    n = _gpus_here()
+    w = 2 if world == "two_gpus" else n
+    if n < 2 or (world == "all_gpus" and n == 2):
+        pytest.skip(f"{n} GPU(s) visible: nothing beyond the other cases to run")
+    res = _bench_ranks(w, ["--quick", "--images", "8", "--steps", "2", "--warmup", "1"], timeout=1800)
+    assert "error" not in res, res
+    assert res["n_gpus"] == w and res["dist"]["backend"] == "nccl" and res["dist"]["world_size"] == w
+    assert "bit-exact" in res["config"]["parity"], res["config"]
+    assert res["config"]["tiles_per_step_per_gpu"] == 8 * 48
