@@ -401,74 +401,92 @@ __device__ __forceinline__ void pk_scatter(Window<uint8_t>& W, const uint32_t (&
   }
 }
 
-// fallback-postfilter.h:32-138 for the two 4-line units of one edge of the window, two lines per pass
+// fallback-postfilter.h:32-138 for one 4-line unit (lines O .. O + 3) of one edge of the window, in two steps, so that a kernel
+// may decide for every unit first and then run each filter on the units that need it (k_tail420: the windows' units sorted by
+// kind in LDS - a wave that holds both kinds executes both filters for all its lanes):
+//   luma_unit_decide   deblock.cc:731-792 - the decisions look at lines 0 and 3 of the unit.  0 = leave the unit as it is (bS 0,
+//                      or dE = 0), else tc | dEp << 8 | dEq << 9 | strong << 10 | 1 << 11
+//   luma_unit_apply    the strong or the normal filter on the unit's four lines, two lines per pass
+constexpr uint32_t DEC_NP2 = 1u << 8, DEC_NQ2 = 1u << 9, DEC_STRONG = 1u << 10, DEC_FILTER = 1u << 11;
+template <bool V, int O>
+__device__ __forceinline__ uint32_t luma_unit_decide(const Window<uint8_t>& W, int beta, int tc)
+{
+  if (tc == 0) return 0; // bS 0 (tc is 0 only then: the strong filter clips to +-2tc, the normal one needs |delta| < 10 tc)
+  // C[i] = sample i (p3 p2 p1 p0 | q0 q1 q2 q3) of line O (low half) and of line O + 3 (high half)
+  s16x2 C[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    if (V) C[i] = as_s(__builtin_amdgcn_perm(W.w[O + 3][i >> 2], W.w[O][i >> 2], 0x0c000c00u | (uint32_t)(i & 3) | ((uint32_t)(4 + (i & 3)) << 16)));
+    else C[i] = as_s(__builtin_amdgcn_perm(0u, W.w[i][O >> 2], 0x0c000c00u | (uint32_t)(O & 3) | ((uint32_t)((O & 3) + 3) << 16)));
+  }
+  const uint32_t dp = as_w(pk_abs(C[1] - C[2] - C[2] + C[3])), dq = as_w(pk_abs(C[6] - C[5] - C[5] + C[4]));
+  const int dp0 = (int)(dp & 0xFFFF), dp3 = (int)(dp >> 16), dq0 = (int)(dq & 0xFFFF), dq3 = (int)(dq >> 16);
+  const int d0 = dp0 + dq0, d3 = dp3 + dq3;
+  if (d0 + d3 >= beta) return 0;
+  const int beta_3 = beta >> 3, beta_2 = beta >> 2, tc25 = mad24_k<5>(tc, 1) >> 1;
+  const uint32_t flat = as_w(pk_abs(C[0] - C[3]) + pk_abs(C[7] - C[4])), step = as_w(pk_abs(C[3] - C[4]));
+  const bool strong = (int)(flat & 0xFFFF) < beta_3 && (int)(flat >> 16) < beta_3 && (int)(step & 0xFFFF) < tc25 && (int)(step >> 16) < tc25 &&
+                      (d0 << 1) < beta_2 && (d3 << 1) < beta_2;
+  const int thr = (beta + (beta >> 1)) >> 3;
+  return (uint32_t)tc | (dp0 + dp3 < thr ? DEC_NP2 : 0u) | (dq0 + dq3 < thr ? DEC_NQ2 : 0u) | (strong ? DEC_STRONG : 0u) | DEC_FILTER;
+}
+template <bool V, int O>
+__device__ __forceinline__ void luma_unit_apply(Window<uint8_t>& W, uint32_t dec)
+{
+  const int tc = (int)(dec & 0xFF);
+  uint32_t A[8], B[8];
+  pk_gather<V, O>(W, A);
+  pk_gather<V, O + 2>(W, B);
+#if defined(HM_T_PROBE) && (HM_T_PROBE & 24)
+  if (((HM_T_PROBE & 8) && (dec & DEC_STRONG)) || ((HM_T_PROBE & 16) && !(dec & DEC_STRONG))) return; // probes: without the strong / the normal filter
+#endif
+  if (dec & DEC_STRONG) {
+    const s16x2 t2 = (s16x2)((short)(tc << 1)), nt2 = (s16x2)(0) - t2;
+    auto pass = [&](uint32_t (&X)[8]) {
+      const s16x2 p3 = as_s(X[0]), p2 = as_s(X[1]), p1 = as_s(X[2]), p0 = as_s(X[3]), q0 = as_s(X[4]), q1 = as_s(X[5]), q2 = as_s(X[6]), q3 = as_s(X[7]);
+      const s16x2 s = p0 + q0;
+      X[3] = as_w(p0 + pk_clamp(((p2 + p1 + p1 + s + s + q1 + (s16x2)(4)) >> (s16x2)(3)) - p0, nt2, t2));
+      X[2] = as_w(p1 + pk_clamp(((p2 + p1 + s + (s16x2)(2)) >> (s16x2)(2)) - p1, nt2, t2));
+      X[1] = as_w(p2 + pk_clamp(((p3 + p3 + p2 + p2 + p2 + p1 + s + (s16x2)(4)) >> (s16x2)(3)) - p2, nt2, t2));
+      X[4] = as_w(q0 + pk_clamp(((p1 + s + s + q1 + q1 + q2 + (s16x2)(4)) >> (s16x2)(3)) - q0, nt2, t2));
+      X[5] = as_w(q1 + pk_clamp(((s + q1 + q2 + (s16x2)(2)) >> (s16x2)(2)) - q1, nt2, t2));
+      X[6] = as_w(q2 + pk_clamp(((q3 + q3 + q2 + q2 + q2 + q1 + s + (s16x2)(4)) >> (s16x2)(3)) - q2, nt2, t2));
+    };
+    pass(A);
+    pass(B);
+    pk_scatter<V, O, 1, 7>(W, A);
+    pk_scatter<V, O + 2, 1, 7>(W, B);
+  }
+  else {
+    const int tc_2 = tc >> 1;
+    const bool np2 = (dec & DEC_NP2) != 0, nq2 = (dec & DEC_NQ2) != 0;
+    const s16x2 tcv = (s16x2)((short)tc), ntcv = (s16x2)(0) - tcv, tc2v = (s16x2)((short)tc_2), ntc2v = (s16x2)(0) - tc2v;
+    const s16x2 zero = (s16x2)(0), maxv = (s16x2)(255), lim = (s16x2)((short)(10 * tc));
+    auto pass = [&](uint32_t (&X)[8]) {
+      const s16x2 p2 = as_s(X[1]), p1 = as_s(X[2]), p0 = as_s(X[3]), q0 = as_s(X[4]), q1 = as_s(X[5]), q2 = as_s(X[6]);
+      const s16x2 dqp = q0 - p0, dqp1 = q1 - p1;
+      const s16x2 delta0 = ((dqp << (s16x2)(3)) + dqp - dqp1 - dqp1 - dqp1 + (s16x2)(8)) >> (s16x2)(4);
+      const uint32_t m = as_w((pk_abs(delta0) - lim) >> (s16x2)(15)); // all ones in the halves whose |delta0| < 10 tc
+      const s16x2 delta = pk_clamp(delta0, ntcv, tcv);
+      X[3] = pk_select(m, as_w(pk_clamp(p0 + delta, zero, maxv)), X[3]);
+      X[4] = pk_select(m, as_w(pk_clamp(q0 - delta, zero, maxv)), X[4]);
+      if (np2) X[2] = pk_select(m, as_w(pk_clamp(p1 + pk_clamp(((((p2 + p0 + (s16x2)(1)) >> (s16x2)(1)) - p1 + delta) >> (s16x2)(1)), ntc2v, tc2v), zero, maxv)), X[2]);
+      if (nq2) X[5] = pk_select(m, as_w(pk_clamp(q1 + pk_clamp(((((q2 + q0 + (s16x2)(1)) >> (s16x2)(1)) - q1 - delta) >> (s16x2)(1)), ntc2v, tc2v), zero, maxv)), X[5]);
+    };
+    pass(A);
+    pass(B);
+    pk_scatter<V, O, 2, 6>(W, A);
+    pk_scatter<V, O + 2, 2, 6>(W, B);
+  }
+}
+// ... for the two units of one edge of the window, one after the other (k_deblock, k_tailf)
 template <bool V>
 __device__ __forceinline__ void filter_luma_pk(Window<uint8_t>& W, const int beta2[2], const int tc2[2])
 {
-  auto unit = [&](auto jc) {
-    constexpr int J = decltype(jc)::value, O = 4 * J;
-    const int tc = tc2[J], beta = beta2[J];
-    if (tc == 0) return; // bS 0
-    uint32_t A[8], B[8];
-    pk_gather<V, O>(W, A);
-    pk_gather<V, O + 2>(W, B);
-    // the decisions look at lines 0 and 3 of the unit: low half of A, high half of B
-    s16x2 C[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) C[i] = as_s(pk_select(0x0000FFFFu, A[i], B[i]));
-    const uint32_t dp = as_w(pk_abs(C[1] - C[2] - C[2] + C[3])), dq = as_w(pk_abs(C[6] - C[5] - C[5] + C[4]));
-    const int dp0 = (int)(dp & 0xFFFF), dp3 = (int)(dp >> 16), dq0 = (int)(dq & 0xFFFF), dq3 = (int)(dq >> 16);
-    const int d0 = dp0 + dq0, d3 = dp3 + dq3;
-    if (d0 + d3 >= beta) return;
-    const int beta_3 = beta >> 3, beta_2 = beta >> 2, tc25 = mad24_k<5>(tc, 1) >> 1;
-    const uint32_t flat = as_w(pk_abs(C[0] - C[3]) + pk_abs(C[7] - C[4])), step = as_w(pk_abs(C[3] - C[4]));
-    const bool strong = (int)(flat & 0xFFFF) < beta_3 && (int)(flat >> 16) < beta_3 && (int)(step & 0xFFFF) < tc25 && (int)(step >> 16) < tc25 &&
-                        (d0 << 1) < beta_2 && (d3 << 1) < beta_2;
-#if defined(HM_T_PROBE) && (HM_T_PROBE & 24)
-    if (((HM_T_PROBE & 8) && strong) || ((HM_T_PROBE & 16) && !strong)) return; // probes: without the strong / the normal filter
-#endif
-    if (strong) {
-      const s16x2 t2 = (s16x2)((short)(tc << 1)), nt2 = (s16x2)(0) - t2;
-      auto pass = [&](uint32_t (&X)[8]) {
-        const s16x2 p3 = as_s(X[0]), p2 = as_s(X[1]), p1 = as_s(X[2]), p0 = as_s(X[3]), q0 = as_s(X[4]), q1 = as_s(X[5]), q2 = as_s(X[6]), q3 = as_s(X[7]);
-        const s16x2 s = p0 + q0;
-        X[3] = as_w(p0 + pk_clamp(((p2 + p1 + p1 + s + s + q1 + (s16x2)(4)) >> (s16x2)(3)) - p0, nt2, t2));
-        X[2] = as_w(p1 + pk_clamp(((p2 + p1 + s + (s16x2)(2)) >> (s16x2)(2)) - p1, nt2, t2));
-        X[1] = as_w(p2 + pk_clamp(((p3 + p3 + p2 + p2 + p2 + p1 + s + (s16x2)(4)) >> (s16x2)(3)) - p2, nt2, t2));
-        X[4] = as_w(q0 + pk_clamp(((p1 + s + s + q1 + q1 + q2 + (s16x2)(4)) >> (s16x2)(3)) - q0, nt2, t2));
-        X[5] = as_w(q1 + pk_clamp(((s + q1 + q2 + (s16x2)(2)) >> (s16x2)(2)) - q1, nt2, t2));
-        X[6] = as_w(q2 + pk_clamp(((q3 + q3 + q2 + q2 + q2 + q1 + s + (s16x2)(4)) >> (s16x2)(3)) - q2, nt2, t2));
-      };
-      pass(A);
-      pass(B);
-      pk_scatter<V, O, 1, 7>(W, A);
-      pk_scatter<V, O + 2, 1, 7>(W, B);
-    }
-    else {
-      const int tc_2 = tc >> 1;
-      const int thr = (beta + (beta >> 1)) >> 3;
-      const bool np2 = dp0 + dp3 < thr, nq2 = dq0 + dq3 < thr;
-      const s16x2 tcv = (s16x2)((short)tc), ntcv = (s16x2)(0) - tcv, tc2v = (s16x2)((short)tc_2), ntc2v = (s16x2)(0) - tc2v;
-      const s16x2 zero = (s16x2)(0), maxv = (s16x2)(255), lim = (s16x2)((short)(10 * tc));
-      auto pass = [&](uint32_t (&X)[8]) {
-        const s16x2 p2 = as_s(X[1]), p1 = as_s(X[2]), p0 = as_s(X[3]), q0 = as_s(X[4]), q1 = as_s(X[5]), q2 = as_s(X[6]);
-        const s16x2 dqp = q0 - p0, dqp1 = q1 - p1;
-        const s16x2 delta0 = ((dqp << (s16x2)(3)) + dqp - dqp1 - dqp1 - dqp1 + (s16x2)(8)) >> (s16x2)(4);
-        const uint32_t m = as_w((pk_abs(delta0) - lim) >> (s16x2)(15)); // all ones in the halves whose |delta0| < 10 tc
-        const s16x2 delta = pk_clamp(delta0, ntcv, tcv);
-        X[3] = pk_select(m, as_w(pk_clamp(p0 + delta, zero, maxv)), X[3]);
-        X[4] = pk_select(m, as_w(pk_clamp(q0 - delta, zero, maxv)), X[4]);
-        if (np2) X[2] = pk_select(m, as_w(pk_clamp(p1 + pk_clamp(((((p2 + p0 + (s16x2)(1)) >> (s16x2)(1)) - p1 + delta) >> (s16x2)(1)), ntc2v, tc2v), zero, maxv)), X[2]);
-        if (nq2) X[5] = pk_select(m, as_w(pk_clamp(q1 + pk_clamp(((((q2 + q0 + (s16x2)(1)) >> (s16x2)(1)) - q1 - delta) >> (s16x2)(1)), ntc2v, tc2v), zero, maxv)), X[5]);
-      };
-      pass(A);
-      pass(B);
-      pk_scatter<V, O, 2, 6>(W, A);
-      pk_scatter<V, O + 2, 2, 6>(W, B);
-    }
-  };
-  unit(std::integral_constant<int, 0>());
-  unit(std::integral_constant<int, 1>());
+  const uint32_t d0 = luma_unit_decide<V, 0>(W, beta2[0], tc2[0]);
+  if (d0) luma_unit_apply<V, 0>(W, d0);
+  const uint32_t d1 = luma_unit_decide<V, 4>(W, beta2[1], tc2[1]);
+  if (d1) luma_unit_apply<V, 4>(W, d1);
 }
 
 // chroma edge (fallback-postfilter.h:138-180), two lines per pass: p1 p0 | q0 q1 = samples 2..5
@@ -910,7 +928,7 @@ __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict_
 struct TailDst { uint8_t* rgb; int32_t pitch; int32_t pad; };
 struct TailCoef { int r_cr, g_cb, g_cr, b_cb; };
 #ifndef HM_TAIL_TH
-#define HM_TAIL_TH 128
+#define HM_TAIL_TH 64
 #endif
 constexpr int TAIL_TW = 128, TAIL_TH = HM_TAIL_TH;
 constexpr int TAIL_THREADS = TAIL_TW * TAIL_TH / 32; // one lane per 8 x 2 luma samples of two cells; 4 or 8 waves
@@ -937,9 +955,12 @@ __device__ __forceinline__ void tail_row(SaoRow<uint8_t>& R, const uint8_t* tile
 // SAO of NR rows of one 8-sample group of plane c (the fast path of k_sao_paste: one slice, no tiles, no lossless units)
 // UNI: the wave's lanes lie in ONE CTB (cells of 32 x 32 luma samples, CTBs of 32 or 64): the CTB's record is read through
 // the scalar unit once per wave instead of by every lane, and SAO type / class become wave-uniform branches
+// rec_*: UNI only - dword 2 of the cell's hm_ctb (flags and masks) and the plane's hm_sao, loaded by the caller long before (r05: a
+// load here, behind the previous cell's pixel stores, waits for those stores too - loads and stores share one counter)
 template <int NR, bool UNI>
 __device__ __forceinline__ void tail_sao(const hm_dev_pic& dp, const PicView& v, int c, const uint8_t* tile, int pitch, int tx0, int ty0,
-                                         int xs, int yy0, int W, int Hh, int l2w, int l2h, int apply_sao, uint32_t (&res)[NR][4])
+                                         int xs, int yy0, int W, int Hh, int l2w, int l2h, int apply_sao, uint32_t (&res)[NR][4], uint32_t rec_flags = 0, uint32_t rec_s0 = 0,
+                                         uint32_t rec_s1 = 0)
 {
   SaoRow<uint8_t> rows[NR + 2];
 #pragma unroll
@@ -951,10 +972,14 @@ __device__ __forceinline__ void tail_sao(const hm_dev_pic& dp, const PicView& v,
 #pragma unroll
   for (int r = 0; r < NR; r++) {
     const int yy = yy0 + r, yc = yy < Hh ? yy : Hh - 1, cy = yy >> l2h;
-    int ctb_index = cx + mul24_raw(yc >> l2h, dp.ctb_w);
-    if (UNI) ctb_index = __builtin_amdgcn_readfirstlane(ctb_index);
-    const GLOBAL_AS uint32_t* cbq = gptr<uint32_t>(reinterpret_cast<const uint8_t*>(v.ctbs) + (uint32_t)mul24_raw(ctb_index, (int)sizeof(hm_ctb))); // hm_ctb as dwords (32-bit offset)
-    const uint32_t cflags = cbq[2], s0 = cbq[3 + 2 * c], s1 = cbq[4 + 2 * c];
+    uint32_t cflags, s0, s1;
+    if (UNI) { cflags = rec_flags; s0 = rec_s0; s1 = rec_s1; (void)yc; }
+    else {
+      int ctb_index = cx + mul24_raw(yc >> l2h, dp.ctb_w);
+      if (UNI) ctb_index = __builtin_amdgcn_readfirstlane(ctb_index);
+      const GLOBAL_AS uint32_t* cbq = gptr<uint32_t>(reinterpret_cast<const uint8_t*>(v.ctbs) + (uint32_t)mul24_raw(ctb_index, (int)sizeof(hm_ctb))); // hm_ctb as dwords (32-bit offset)
+      cflags = cbq[2]; s0 = cbq[3 + 2 * c]; s1 = cbq[4 + 2 * c];
+    }
     const SaoRow<uint8_t>&up = rows[r], &cur = rows[r + 1], &dn = rows[r + 2];
     const bool sao_on = apply_sao && (dp.flags & HM_PIC_SAO_ENABLED) && (cflags & (c == 0 ? HM_CTB_SAO_LUMA : HM_CTB_SAO_CHROMA));
 #if defined(HM_T_PROBE) && (HM_T_PROBE & 2)
@@ -1057,19 +1082,100 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
   const int tid = threadIdx.x;
   const int W = dp.width, H = dp.height;
   __shared__ uint8_t s_tab[112];
+  __shared__ uint32_t s_cnt[4]; // luma edge units waiting for a filter: vertical strong / normal, horizontal strong / normal
+  constexpr int NWAVES = TAIL_THREADS / 64;
+  __shared__ __attribute__((aligned(16))) uint8_t s_x[NWAVES][2][16][16]; // phase 2: a cell's chroma on its way to the luma lanes; phase 1: the unit lists
   if (tid < 106) s_tab[tid] = tid < 52 ? c_beta[tid] : c_tc[tid - 52];
+  if (tid < 4) s_cnt[tid] = 0;
+  // The SAO parameters of the two cells this wave converts in phase 2 (cells of 32 x 32 inside ONE CTB: UNI), requested now:
+  // they arrive under phase 1, and phase 2 has no load left between its pixel stores - a wait for a load is a wait for every
+  // store before it (one counter), which put the whole write latency of a cell's pixels in front of the next cell (r05: 9.2 ms
+  // with, 6.5 without the stores; the stores alone are 1.9 ms of HBM time).
+  const int l2 = dp.log2_ctb;
+  uint32_t ctb_rec[2][7] = {};
+  if (UNI) {
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+      const int cell = (tid >> 6) + it * NWAVES;
+      const int cellx = x0 + 32 * (cell & 3), celly = y0 + 32 * (cell >> 2);
+      const int qx = cellx < W ? cellx : W - 1, qy = celly < H ? celly : H - 1; // (cells outside the picture are skipped below)
+      const int ctb_index = __builtin_amdgcn_readfirstlane((qx >> l2) + (qy >> l2) * dp.ctb_w);
+      const GLOBAL_AS uint32_t* const cbq = gptr<uint32_t>(reinterpret_cast<const uint8_t*>(v.ctbs) + (uint32_t)ctb_index * (uint32_t)sizeof(hm_ctb));
+#pragma unroll
+      for (int k = 0; k < 7; k++) ctb_rec[it][k] = cbq[2 + k];
+    }
+  }
   __syncthreads(); // (all waves have only just started: cheap)
 
-  // ---- phase 1: deblocked samples of the tile (+ 4 around it) into LDS, one lane per window ----
-  // (measured against a coalesced 16-byte-per-lane copy of the tile into LDS followed by in-place window filtering
-  //  there: 10.2 / 19.3 ms without / with the filters instead of 7.6 / 15.8 ms - the eight independent row loads per lane
-  //  of this version keep more bytes in flight, and a second barrier costs more than the narrower loads)
+  // ---- phase 1: deblocked samples of the tile (+ 4 around it) into LDS ----
+  // One lane per shifted 8x8 window loads it (eight independent row loads per lane keep more bytes in flight than a coalesced copy
+  // of the tile: measured r03) and works out the parameters of its four edge units.  Chroma windows are filtered in registers
+  // on the spot (one cheap filter, no decisions).  Luma (r05): a wave holds units that need the strong filter, the normal
+  // filter or none side by side - as code of the window's lane that was both filters executed for all 64 lanes at 27 lanes
+  // active on average, half of the kernel's vector instructions (profiles/r04_tail_counters.txt: 8.7 % of the units are
+  // strong, 49 % normal, the rest unfiltered).  Now a lane only DECIDES for its units (deblock.cc:731-792), stores the window
+  // unfiltered and enters the units that need a filter into a list in LDS - strong ones from its start, normal ones from its
+  // end -; then all lanes of the workgroup (the chroma waves too) take units off the list, a wave holding one kind: first the
+  // vertical edges, then - decided on the result, as the reference's order demands (deblock.cc:1921-1959) - the horizontal
+  // ones.  A unit is four lines of eight samples inside its own window; windows never share a sample, so nothing but the
+  // redistribution needs the barriers.
+  constexpr int NLX = TAIL_TW / 8 + 1, NLY = TAIL_TH / 8 + 1, NCX = TAIL_TW / 16 + 1, NCY = TAIL_TH / 16 + 1;
+  constexpr int NL = NLX * NLY, NC = NCX * NCY, C0 = TAIL_THREADS - 2 * NC;
+  static_assert(NL <= C0, "one lane per window");
+  constexpr uint32_t LIST_N = sizeof(s_x) / 4;
+  static_assert(2 * NL <= (int)LIST_N, "the unit list holds every unit of one direction");
+  uint32_t* const ulist = reinterpret_cast<uint32_t*>(&s_x[0][0][0][0]);
+  const int lane_id = tid & 63;
+  // entry: the unit's place in the luma tile (bytes) | decision << 16 (luma_unit_decide)
+  auto push_units = [&](uint32_t d0, uint32_t d1, uint32_t off0, uint32_t off1, uint32_t* cnt) { // (every lane of the wave takes part)
+#pragma unroll
+    for (int k = 0; k < 2; k++) { // 0: strong units, 1: normal ones
+      const bool w0 = d0 != 0 && ((d0 & DEC_STRONG) != 0) == (k == 0), w1 = d1 != 0 && ((d1 & DEC_STRONG) != 0) == (k == 0);
+      const unsigned long long m0 = __ballot(w0), m1 = __ballot(w1);
+      const int n0 = __popcll(m0), n = n0 + __popcll(m1);
+      if (n == 0) continue; // (the same for the whole wave)
+      uint32_t base = 0;
+      if (lane_id == 0) base = atomicAdd(cnt + k, (uint32_t)n);
+      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+      const uint32_t p0 = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
+      const uint32_t p1 = base + (uint32_t)n0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+      if (w0) ulist[k ? LIST_N - 1 - p0 : p0] = off0 | (d0 << 16);
+      if (w1) ulist[k ? LIST_N - 1 - p1 : p1] = off1 | (d1 << 16);
+    }
+  };
+  // the filters on the listed units: strong ones (padded to whole waves), then normal ones
+  auto apply_units = [&](auto vertical, const uint32_t* cnt) {
+    constexpr bool VV = decltype(vertical)::value;
+    const uint32_t ns = cnt[0], nn = cnt[1], ns_pad = (ns + 63u) & ~63u;
+    for (uint32_t item = (uint32_t)tid; item < ns_pad + nn; item += TAIL_THREADS) {
+      const bool strong = item < ns_pad;
+      if (strong && item >= ns) continue;
+      const uint32_t e = ulist[strong ? item : LIST_N - 1 - (item - ns_pad)];
+      uint8_t* const q = s_l + (e & 0xFFFFu);
+      Window<uint8_t> W;
+      if (VV) { // four rows of eight samples across the vertical edge
+#pragma unroll
+        for (int r = 0; r < 4; r++) { W.w[r][0] = *reinterpret_cast<const uint32_t*>(q + r * TAIL_LP); W.w[r][1] = *reinterpret_cast<const uint32_t*>(q + r * TAIL_LP + 4); }
+        luma_unit_apply<true, 0>(W, e >> 16);
+#pragma unroll
+        for (int r = 0; r < 4; r++) { *reinterpret_cast<uint32_t*>(q + r * TAIL_LP) = W.w[r][0]; *reinterpret_cast<uint32_t*>(q + r * TAIL_LP + 4) = W.w[r][1]; }
+      }
+      else { // eight rows of four samples: four columns across the horizontal edge
+#pragma unroll
+        for (int r = 0; r < 8; r++) W.w[r][0] = *reinterpret_cast<const uint32_t*>(q + r * TAIL_LP);
+        luma_unit_apply<false, 0>(W, e >> 16);
+#pragma unroll
+        for (int r = 1; r < 7; r++) *reinterpret_cast<uint32_t*>(q + r * TAIL_LP) = W.w[r][0]; // (p3 and q3 stay as they are)
+      }
+    }
+  };
+  bool luma_window = false;  // this lane holds a luma window with an edge to filter
+  uint32_t woff = 0;         // ... at this place of the luma tile
+  uint32_t decV0 = 0, decV1 = 0;
+  int betaH0 = 0, betaH1 = 0, tcH0 = 0, tcH1 = 0;
   {
     // windows per tile: (TW / 8 + 1) x (TH / 8 + 1) luma from lane 0 up, 2 x (TW / 16 + 1) x (TH / 16 + 1) chroma at the end
-    // of the workgroup (so that at most one wave runs both the luma and the chroma filters)
-    constexpr int NLX = TAIL_TW / 8 + 1, NLY = TAIL_TH / 8 + 1, NCX = TAIL_TW / 16 + 1, NCY = TAIL_TH / 16 + 1;
-    constexpr int NL = NLX * NLY, NC = NCX * NCY, C0 = TAIL_THREADS - 2 * NC;
-    static_assert(NL <= C0, "one lane per window");
+    // of the workgroup
     int c = -1, kxl = 0, kyl = 0;
     if (tid < NL) { c = 0; kyl = tid / NLX; kxl = tid - kyl * NLX; }
     else if (tid >= C0) {
@@ -1085,6 +1191,13 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
       if (kx <= ((PW + 7) >> 3) && ky <= ((PH + 7) >> 3)) {
         Window<uint8_t> win;
         const int ox = (kx << 3) - 4, oy = (ky << 3) - 4;
+#if defined(HM_T_PROBE) && (HM_T_PROBE & 64)
+        if (n_tiles < 0) window_load(win, dp.plane[c], dp.pitch[c], ox, oy, PH); // probe: no loads of samples
+        else {
+#pragma unroll
+          for (int r = 0; r < 8; r++) { win.w[r][0] = (uint32_t)(ox + r) * 0x01010101u; win.w[r][1] = (uint32_t)(oy + r) * 0x01010101u; }
+        }
+#else
         if (ox >= 0) window_load(win, dp.plane[c], dp.pitch[c], ox, oy, PH);
         else { // left picture border: the window's left half does not exist (k_deblock never loads the corner window)
 #pragma unroll
@@ -1094,19 +1207,30 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
             win.w[r][1] = *gptr<uint32_t>(dp.plane[c] + (uint32_t)mul24_raw(y, dp.pitch[c]));
           }
         }
+#endif
 #if !defined(HM_T_PROBE) || !(HM_T_PROBE & 1)
         if ((stages & 1) && (dp.flags & HM_PIC_DEBLOCK_ANY)) {
           WindowEdges<false> E;
           HM_MARK("edges_begin");
           const bool any_edge = window_edges<uint8_t, false>(dp, v, c, kx, ky, sw, sw, E, TabLds{s_tab});
           HM_MARK("edges_end");
-          if (any_edge) window_filter<uint8_t, false>(win, c, E, 255);
+          if (any_edge && c == 0) {
+            luma_window = true;
+            decV0 = luma_unit_decide<true, 0>(win, E.betaV[0], E.tcV[0]);
+            decV1 = luma_unit_decide<true, 4>(win, E.betaV[1], E.tcV[1]);
+            betaH0 = E.betaH[0]; betaH1 = E.betaH[1]; tcH0 = E.tcH[0]; tcH1 = E.tcH[1];
+          }
+          else if (any_edge) {
+            filter_chroma_pk<true>(win, E.tcV);
+            filter_chroma_pk<false>(win, E.tcH);
+          }
           HM_MARK("filter_end");
         }
 #endif
         uint8_t* const t0 = c == 0 ? s_l : (c == 1 ? s_c0 : s_c1);
         const int tp = c == 0 ? TAIL_LP : TAIL_CP;
         uint8_t* q = t0 + (8 * kyl) * tp + 8 * kxl + (TAIL_XO - 4);
+        woff = (uint32_t)((8 * kyl) * TAIL_LP + 8 * kxl + (TAIL_XO - 4));
 #pragma unroll
         for (int r = 0; r < 8; r++) {
           *reinterpret_cast<uint32_t*>(q + r * tp) = win.w[r][0];
@@ -1115,6 +1239,31 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
       }
     }
   }
+  push_units(decV0, decV1, woff, woff + 4 * TAIL_LP, s_cnt);
+  __syncthreads();
+  apply_units(std::true_type(), s_cnt);
+  __syncthreads();
+  uint32_t decH0 = 0, decH1 = 0;
+  if (luma_window && (tcH0 | tcH1)) { // the horizontal edge of the window, on the samples its vertical edge left
+    Window<uint8_t> win;
+    const uint8_t* const q = s_l + woff;
+#pragma unroll
+    for (int r = 0; r < 8; r++) { win.w[r][0] = *reinterpret_cast<const uint32_t*>(q + r * TAIL_LP); win.w[r][1] = *reinterpret_cast<const uint32_t*>(q + r * TAIL_LP + 4); }
+    decH0 = luma_unit_decide<false, 0>(win, betaH0, tcH0);
+    decH1 = luma_unit_decide<false, 4>(win, betaH1, tcH1);
+  }
+  push_units(decH0, decH1, woff, woff + 4, s_cnt + 2);
+  __syncthreads();
+  apply_units(std::false_type(), s_cnt + 2);
+  if (UNI) { // the cells' SAO parameters have long arrived: from here on scalars - nothing in phase 2 refers to a load any more
+#pragma unroll
+    for (int it = 0; it < 2; it++)
+#pragma unroll
+      for (int k = 0; k < 7; k++) ctb_rec[it][k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctb_rec[it][k]);
+  }
+  // (said explicitly, on every path: no load of phase 1 is outstanding - the compiler's wait insertion otherwise guards register
+  //  reuse in phase 2 with waits for "everything", i.e. for the first cell's pixel stores)
+  __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
   __syncthreads();
 
   // ---- phase 2: SAO + matrix + store, one wave = one 32 x 32 cell at a time ----
@@ -1123,13 +1272,11 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
   // on average).  Here the wave's lanes share a 32 x 32 cell - one CTB unless the CTBs are 16 x 16 -: 64 lanes = 4 x 16
   // groups of 8 x 2 luma samples, and before that 2 x 32 lanes = the cell's 16 x 16 Cb / Cr samples as 2 x 16 groups of
   // 8 x 1, whose results reach the luma lanes through 512 bytes of LDS.  The matrix runs on sample pairs.
-  constexpr int NWAVES = TAIL_THREADS / 64;
-  __shared__ __attribute__((aligned(16))) uint8_t s_x[NWAVES][2][16][16];
   const int wave = tid >> 6, lane = tid & 63;
-  const int l2 = dp.log2_ctb;
   const bool rescale = dp.rescale != 0; // (the same for every lane of the workgroup)
   const TailDst D = dsts[blockIdx.y];
   const int Kr = 128 - 128 * k.r_cr, Kg = 128 - 128 * (k.g_cb + k.g_cr), Kb = 128 - 128 * k.b_cb; // (x - 128) * k + 128 = x * k + K
+#pragma unroll
   for (int it = 0; it < 2; it++) {
     const int cell = wave + it * NWAVES; // 4 cells per row of the tile
     const int cellx = x0 + 32 * (cell & 3), celly = y0 + 32 * (cell >> 2);
@@ -1139,7 +1286,8 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
       const int xc = (cellx >> 1) + 8 * gxc, yc = (celly >> 1) + row;
       if (xc < (W >> 1) && yc < (H >> 1)) {
         uint32_t rc[1][4];
-        tail_sao<1, UNI>(dp, v, 1 + pl, s_c0 + pl * (TAIL_CR * TAIL_CP), TAIL_CP, (x0 >> 1) - TAIL_XO, (y0 >> 1) - 4, xc, yc, W >> 1, H >> 1, l2 - 1, l2 - 1, stages & 2, rc);
+        tail_sao<1, UNI>(dp, v, 1 + pl, s_c0 + pl * (TAIL_CR * TAIL_CP), TAIL_CP, (x0 >> 1) - TAIL_XO, (y0 >> 1) - 4, xc, yc, W >> 1, H >> 1, l2 - 1, l2 - 1, stages & 2, rc,
+                         ctb_rec[it][0], pl ? ctb_rec[it][5] : ctb_rec[it][3], pl ? ctb_rec[it][6] : ctb_rec[it][4]);
         if (rescale) { // (the paste of a limited-range tile: context.cc:2504-2528)
 #pragma unroll
           for (int j = 0; j < 4; j++) rc[0][j] = pk_rescale<true>(rc[0][j]);
@@ -1154,7 +1302,7 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
     const int lx = cellx + 8 * gx, ly = celly + 2 * rp;
     if (lx < cw && ly < chh) {
       uint32_t ry[2][4];
-      tail_sao<2, UNI>(dp, v, 0, s_l, TAIL_LP, x0 - TAIL_XO, y0 - 4, lx, ly, W, H, l2, l2, stages & 2, ry);
+      tail_sao<2, UNI>(dp, v, 0, s_l, TAIL_LP, x0 - TAIL_XO, y0 - 4, lx, ly, W, H, l2, l2, stages & 2, ry, ctb_rec[it][0], ctb_rec[it][1], ctb_rec[it][2]);
       if (rescale) {
 #pragma unroll
         for (int r = 0; r < 2; r++)
@@ -1213,12 +1361,16 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
         }
       }
       uint8_t* o0 = D.rgb + (uint32_t)(mul24_raw(ly, D.pitch) + lx * BPP); // (an image is smaller than 4 GiB)
+#if defined(HM_T_PROBE) && (HM_T_PROBE & 32)
+      const int nvalid = n_tiles < 0 ? 8 : 9; // probe: no stores of pixels
+#else
       const int nvalid = cw - lx < 8 ? cw - lx : 8;
+#endif
       if (nvalid == 8) {
         __builtin_memcpy(gptr_w<uint8_t>(o0), o[0], 8 * BPP);
         if (ly + 1 < chh) __builtin_memcpy(gptr_w<uint8_t>(o0 + D.pitch), o[1], 8 * BPP);
       }
-      else {
+      else if (nvalid < 8) {
 #pragma unroll
         for (int i = 0; i < 8 * BPP; i++) {
           if (i < nvalid * BPP) {
