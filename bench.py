@@ -201,19 +201,22 @@ def kernel_table(gb, avg_ms, colour_bytes_per_px=4.5):
     return table, alg, stream_b, sample_b
 
 
-PMC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+PMC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
 
 
 def pmc_traffic(kernels, images):
     """HBM bytes per launch of the named kernels (summed) from the COMMITTED rocprofv3 PMC passes (profiles/r0N_pmc_traffic.json:
-    FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, separate passes, scaled per image) - a table look-up, not
-    counters of this run (counters need their own rocprofv3 passes: tools/pmc_traffic.sh).  Returns (bytes, source);
-    (None, None) when no measurement for one of the kernels is on file."""
+    FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, separate passes of tools/pmc_traffic.sh).  Only a file taken at
+    THIS run's load counts (r05: its images_per_launch equals --images - L2 behaviour and the traffic per image change with the
+    rounds of waves in flight); otherwise (None, None): the line then says null, not a number scaled from another load.
+    A table look-up of a committed measurement of the same command, not live counters of this run."""
     for name in PMC_FILES:
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))
-            total = sum(t["kernels"][k]["hbm_bytes_per_image"] for k in kernels)
-            return int(total * images), f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh, scaled per image; not live counters of this run)"
+            if int(t.get("images_per_launch", -1)) != int(images):
+                continue
+            total = sum(t["kernels"][k]["hbm_bytes_per_step"] for k in kernels)
+            return int(total), f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh at {images} images per launch = this run's load; not live counters of this run)"
         except Exception:
             continue
     return None, None
@@ -383,11 +386,15 @@ def run(args):
     rng = random.Random(1234 + rank)
     check_image = rng.randrange(B)  # parity gate: a random image of every rank
     kept, check = [], None
+    keep_blobs = world == 1 and not args.quick  # (the variant legs of the single-GPU run build batches of their own from them)
+    all_blobs = []
     seeds = (1200000 + 48 * (first_image + k // NT) + k % NT for k in range(B * NT))
     made = make_streams(capi, seeds)
     for j in range(B):
         tiles = [next(made) for _ in range(NT)]
         gb.add_image([b for _, b in tiles])
+        if keep_blobs or (world > 1 and j < SHARE_IMAGES):
+            all_blobs.append([b for _, b in tiles])
         if j < keep:
             kept.append([d for d, _ in tiles])
         if j == check_image:
@@ -432,6 +439,7 @@ def run(args):
     out = {}
     if world > 1 and not args.quick:
         multi_rank_legs(out, args, torch, pkg, dev, dev_index, st, gb, kept, dist, rank, world)
+        share_leg_all_ranks(out, args, torch, pkg, dev, st, all_blobs, dist, rank, world)
     if rank == 0:
         extra = out
         total_mp = world * B * MP_PER_IMAGE * args.steps
@@ -460,7 +468,7 @@ def run(args):
             out["config"]["shared_gpu"] = f"{world} ranks on {ndev} GPU(s): functional run of the N>1 path, not a scaling number"
         gb.batch.check()  # (a reconstruction wave that gave up a bounded wait would have flagged its launch)
         if not args.quick and world == 1:  # the side clocks belong to the single-GPU run
-            side_legs(out, args, torch, pkg, dev, st, gb, kept, strides, stream_b)
+            side_legs(out, args, torch, pkg, dev, st, gb, kept, strides, stream_b, all_blobs)
             try:
                 out["end_to_end_MP_per_s"] = out["end_to_end_pipelined"]["MP_per_s"]
                 out["device_inclusive_MP_per_s"] = max(v["MP_per_s"] for k, v in out["device_inclusive"].items() if isinstance(v, dict) and "MP_per_s" in v)
@@ -630,7 +638,7 @@ def guarded(out, key, fn):
         out[key] = {"error": f"{type(e).__name__}: {e}"}
 
 
-def side_legs(out, args, torch, pkg, dev, st, gb, kept, strides, stream_b):
+def side_legs(out, args, torch, pkg, dev, st, gb, kept, strides, stream_b, all_blobs=()):
     B = len(gb.images)
     guarded(out, "host_entropy_decode", lambda: host_parse_rate(pkg, kept[0]))
     guarded(out, "wpp_row_parallel_parse", lambda: wpp_parse_rates(pkg))
@@ -648,10 +656,102 @@ def side_legs(out, args, torch, pkg, dev, st, gb, kept, strides, stream_b):
     gb.batch.close()
     gb.images.clear()
     torch.cuda.empty_cache()
+    if all_blobs:
+        guarded(out, "config2_no_vui", lambda: no_vui_leg(torch, pkg, dev, st, all_blobs, out.get("ms_per_step")))
+        guarded(out, "config3_per_gpu_share", lambda: share_leg(torch, pkg, dev, st, all_blobs[:SHARE_IMAGES]))
     guarded(out, "real_content", lambda: real_content(torch, pkg, dev, st))
     guarded(out, "real_content_256_pictures", lambda: real_content(torch, pkg, dev, st, n=256))  # (a mid-size batch: k_chain's ring cut)
     guarded(out, "config4_422_10bit_rgb48", lambda: config4(torch, pkg, dev, st))
     guarded(out, "config5_16384_grid", lambda: config5_single(torch, pkg, dev, st))
+
+
+SHARE_IMAGES = 128  # BASELINE config 3: 1024 images over 8 GPUs
+
+
+def variant_batch(torch, pkg, dev, st, blobs_by_image, nclx, steps=10, warmup=2):
+    """K clock of a batch of 12 MP grids built from parsed tiles (the headline's workload with another tile profile / count)"""
+    gb = GridBatch(pkg, dev, GRID_COLS, GRID_ROWS, TILE, OUT_W, OUT_H, nclx=nclx)
+    for blobs in blobs_by_image:
+        gb.add_image(blobs)
+    gb.finish(st)
+    for _ in range(warmup):
+        gb.step(st)
+    elapsed, avg_ms = timed_steps(torch, gb, st, steps)
+    gb.batch.check()
+    kernels, _, _, _ = kernel_table(gb, avg_ms)
+    n = len(blobs_by_image)
+    res = {"MP_per_s": round(n * MP_PER_IMAGE * steps / elapsed, 1), "ms_per_step": round(elapsed / steps * 1e3, 4), "images_per_step": n,
+           "tiles_per_step": n * GRID_COLS * GRID_ROWS, "tail_fused": bool(gb.batch.tail_fused()),
+           "kernels_ms": {k: v["ms_per_step"] for k, v in kernels.items()}}
+    return gb, res
+
+
+def no_vui_leg(torch, pkg, dev, st, all_blobs, headline_ms):
+    """SURVEY 8(d) config 2, second variant: tiles WITHOUT a full-range colour description - the class of the reference's own
+    examples/example.heic.  The decoder plugin reports such a tile as limited range (decoder_libde265.cc:339-362: VUI defaults,
+    matrix 2), and decode_and_paste_tile_image rescales every sample to full range while it pastes (context.cc:2504-2528).
+    Image 0 of the leg is 48 freshly synthesised tiles without a VUI, checked bit for bit against the CPU flow (oracle and real
+    libde265 tiles, the oracle's float paste); the other images are the headline's tiles pasted under the same limited-range
+    profile (a tile item's colr box overrides the VUI: context.cc:1840-1850) - the kernels' work does not depend on which."""
+    import numpy as np
+    import orc
+    NT = GRID_COLS * GRID_ROWS
+    fresh = list(make_streams(pkg.capi, (1300000 + i for i in range(NT)), vui=0))
+    images = [[b for _, b in fresh]] + list(all_blobs[1:])
+    gb, res = variant_batch(torch, pkg, dev, st, images, nclx=(1, 0, 2))
+    got = gb.images[0]["rgb"].cpu().numpy()
+    strides = (gb.ys, gb.cs, gb.os)
+    ok = True
+    for use_ref in [False] + ([True] if orc.have_ref() else []):
+        exp = cpu_grid_image([d for d, _ in fresh], [b for _, b in fresh], GRID_COLS, GRID_ROWS, TILE, OUT_W, OUT_H, strides, use_ref)
+        ok = ok and bool(np.array_equal(got[:OUT_H, :OUT_W * 3], exp[:OUT_H, :OUT_W * 3]))
+    res["parity"] = ("bit-exact vs oracle" + (" and reference libde265" if orc.have_ref() else "") + " (image 0: 48 tiles without a VUI)") if ok else "MISMATCH"
+    if headline_ms:
+        res["ratio_to_headline"] = round(res["ms_per_step"] / headline_ms, 4)
+    res["note"] = "the headline's step with every tile rescaled limited -> full range in the paste (part of the fused tail kernel since r05)"
+    gb.batch.close()
+    gb.images.clear()
+    torch.cuda.empty_cache()
+    if not ok:
+        raise RuntimeError("config2_no_vui: GPU RGB != CPU flow")
+    return res
+
+
+def share_leg(torch, pkg, dev, st, blobs):
+    """BASELINE config 3 as it lands on ONE of 8 GPUs: 128 of the 1024 images = 6144 tiles per step (the default step keeps 384
+    images per GPU).  6144 pictures are 1.2 rounds of the 5120 wave-per-picture chains the device holds at once."""
+    gb, res = variant_batch(torch, pkg, dev, st, blobs, nclx=(1, 1, 6))
+    recon = sum(v for k, v in res["kernels_ms"].items() if k in ("k_residual", "k_chain"))
+    res["recon_us_per_tile"] = round(recon * 1e3 / res["tiles_per_step"], 4)
+    gb.batch.close()
+    gb.images.clear()
+    torch.cuda.empty_cache()
+    return res
+
+
+def share_leg_all_ranks(out, args, torch, pkg, dev, st, blobs, dist, rank, world):
+    """N > 1: the config-3 share (128 images per GPU) on every rank at once; rank 0 reports the aggregate over the slowest rank"""
+    cpu = "cpu" if args.dist_backend != "nccl" else dev
+    ms, ok = 0.0, 1
+    try:
+        dist.barrier()
+        r = share_leg(torch, pkg, dev, st, blobs)
+        ms = r["ms_per_step"]
+    except Exception as ex:  # noqa: BLE001
+        ok = 0
+        print(f"[bench rank {rank}] config3_per_gpu_share: {ex}", file=sys.stderr, flush=True)
+    t = torch.tensor([ms, ok], dtype=torch.float64, device=cpu)
+    parts = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    if rank == 0:
+        rows = [[float(x) for x in p.tolist()] for p in parts]
+        if all(r[1] for r in rows):
+            slow = max(r[0] for r in rows)
+            out["config3_per_gpu_share_all_ranks"] = {"MP_per_s": round(world * len(blobs) * MP_PER_IMAGE / slow * 1e3, 1), "images_per_gpu": len(blobs),
+                                                      "ms_per_step_slowest_rank": round(slow, 4), "per_rank_ms": [round(r[0], 4) for r in rows],
+                                                      "note": "BASELINE config 3's own load per GPU (1024 images / 8); K clock, all ranks at once"}
+        else:
+            out["config3_per_gpu_share_all_ranks"] = {"failed_ranks": [i for i, r in enumerate(rows) if not r[1]]}
 
 
 def host_parse_rate(pkg, streams):

@@ -41,6 +41,9 @@
 #include "recon_common.h"
 
 #include <stdlib.h>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "hm_internal.h"
 
@@ -1152,8 +1155,10 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
 // The chain kernel serves every picture whose records come as split chains (no rare syntax, not 4:4:4), after
 // hm_launch_residual on the same stream; returns 1 if it launched (2: in the wave-per-row-pair mode, i.e. using d_sync),
 // 0 if the CTU staging does not fit LDS, < 0 on error.  d_err: the batch's sticky error word (never cleared here).
-extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ctb, int chroma_format, int bit_depth, int rare_syntax,
-                               int max_ctb_w, int max_ctb_h, uint32_t* d_sync, size_t sync_bytes, uint32_t* d_err, hipStream_t s)
+// (plan: if given, nothing is launched - the cut the launcher would take is reported instead)
+struct ChainPlan { bool per_picture = false; long resident = 0; };
+static int launch_chain_impl(const hm_dev_pic* d_pics, int n_pics, int log2_ctb, int chroma_format, int bit_depth, int rare_syntax,
+                             int max_ctb_w, int max_ctb_h, uint32_t* d_sync, size_t sync_bytes, uint32_t* d_err, hipStream_t s, ChainPlan* plan)
 {
   if (n_pics <= 0) return 1;
   if (rare_syntax || chroma_format == 3 || log2_ctb < 4 || log2_ctb > 6) return 0;
@@ -1464,6 +1469,11 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   else while (np > 1 && (long)np * 256 > n_waves) np--; // few waves: spread them over the CUs first
   if (force_np > 0 && force_np <= 16 && C_SHARED + force_np * L.pic_bytes <= 160 * 1024 && (!ring_w || force_np % (ring_w << L.split_kinds) == 0)) np = force_np;
   const int lds_bytes = C_SHARED + np * L.pic_bytes;
+  if (plan) { // (hm_launch_chain: is this a wave per picture, and how many of them does the device hold at once?)
+    plan->per_picture = !pairs;
+    plan->resident = (long)cus() * best;
+    return 1;
+  }
   const int debug = hm_knob(HM_KNOB_CHAIN_DEBUG);
   if (debug) fprintf(stderr, "[k_chain] %d pictures, %ld waves (%s), %d bytes of LDS per wave, %d waves per workgroup, %d waves per CU\n", n_pics, n_waves,
                      !pairs ? "one per picture" : (L.split_kinds ? "one per chain of a CTU row" : (L.rows_per_wave == 1 ? "one per CTU row" : (L.bands_per_pic < L.passes ? "several per picture, taking its pairs of CTU rows in turn" : "one per pair of CTU rows"))),
@@ -1491,6 +1501,76 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
   e = hipGetLastError();
   if (e != hipSuccess) return hm_check_hip(e, "k_chain launch");
   return pairs || timing_words ? 2 : 1; // (2: the synchronisation words were used)
+}
+
+// The partial last round of a wave per picture (r05).  The device holds `resident` such waves (5120 for 8-bit CTB 32); a launch of
+// k x resident + r pictures runs its last r pictures when the first finish - r waves spread over 1024 SIMDs, each at the 4.2 ms of
+// a lone wave instead of the 1.4 ms per wave of a full device (profiles/r04_notes.txt: 5120 tiles 7.28 ms, 5632: 9.78, 6144: 9.95 -
+// BASELINE config 3 on 8 GPUs is 6144 tiles per GPU).  The reference keeps every worker busy until the tiles run out
+// (context.cc:2366-2387).  Here: a remainder of at most a quarter of a round goes to a launch of its own, in the cut the launcher
+// takes for so few pictures - rings of waves that finish a picture in a third of the time -, on a second stream beside the full
+// rounds: its workgroups are self-contained, they start as the first workgroups of the full rounds finish.  5632 tiles: 9.90 ->
+// 7.87 ms (1.40 us per tile, the full device's rate), 6144: 10.11 -> 8.80.
+namespace {
+struct AuxStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+AuxStream* aux_stream_of(hipStream_t s)
+{
+  static std::mutex m;
+  static std::map<std::pair<int, hipStream_t>, AuxStream> streams; // (per caller stream: calls on one stream come one after the other)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> l(m);
+  AuxStream& a = streams[std::make_pair(dev, s)];
+  if (!a.stream) {
+    hipStream_t t = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipStreamCreateWithFlags(&t, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&e0, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) {
+      if (e0) hipEventDestroy(e0);
+      hipStreamDestroy(t);
+      return nullptr;
+    }
+    a.stream = t; a.fork = e0; a.join = e1;
+  }
+  return &a;
+}
+} // namespace
+
+extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ctb, int chroma_format, int bit_depth, int rare_syntax,
+                               int max_ctb_w, int max_ctb_h, uint32_t* d_sync, size_t sync_bytes, uint32_t* d_err, hipStream_t s)
+{
+  const int split = hm_knob(HM_KNOB_CHAIN_SPLIT); // 0: never; 1: the remainder's launch first; 2: the full rounds' first
+  const bool forced = hm_knob(HM_KNOB_CHAIN_PAIRS) >= 0 || hm_knob(HM_KNOB_CHAIN_RING) >= 0 || hm_knob(HM_KNOB_CHAIN_SHARE) >= 2;
+  if (split && !forced && d_sync && d_err && n_pics > 1024) {
+    ChainPlan plan;
+    const int q = launch_chain_impl(d_pics, n_pics, log2_ctb, chroma_format, bit_depth, rare_syntax, max_ctb_w, max_ctb_h, d_sync, sync_bytes, d_err, s, &plan);
+    if (q <= 0) return q;
+    const long r = plan.resident > 0 ? n_pics % plan.resident : 0;
+    // (measured r05, profiles/r05_staircase.txt, ms of both reconstruction kernels without / with: one full round + 256: 9.80 / 7.68,
+    //  + 512: 9.90 / 7.87, + 1024: 10.11 / 8.80, + 1280: 10.61 / 9.92; two full rounds + 512: 16.10 / 14.44, + 1024: 16.30 / 17.5 - the
+    //  later rounds start staggered, a remainder hurts them less: the more full rounds, the smaller the remainder worth a launch)
+    const long rounds = n_pics / (plan.resident > 0 ? plan.resident : 1);
+    if (plan.per_picture && n_pics > plan.resident && r > 0 && 4 * rounds * r <= plan.resident) {
+      ChainPlan rest; // (only if the remainder alone would not be a wave per picture again)
+      const hm_dev_pic* const d_rest = d_pics + (n_pics - r);
+      AuxStream* const ax = aux_stream_of(s);
+      if (ax && launch_chain_impl(d_rest, (int)r, log2_ctb, chroma_format, bit_depth, rare_syntax, max_ctb_w, max_ctb_h, d_sync, sync_bytes, d_err, ax->stream, &rest) > 0 &&
+          !rest.per_picture && hipEventRecord(ax->fork, s) == hipSuccess && hipStreamWaitEvent(ax->stream, ax->fork, 0) == hipSuccess) {
+        int q1 = 1, q2 = 1;
+        if (split == 2) q1 = launch_chain_impl(d_pics, n_pics - (int)r, log2_ctb, chroma_format, bit_depth, rare_syntax, max_ctb_w, max_ctb_h, nullptr, 0, d_err, s, nullptr);
+        q2 = launch_chain_impl(d_rest, (int)r, log2_ctb, chroma_format, bit_depth, rare_syntax, max_ctb_w, max_ctb_h, d_sync, sync_bytes, d_err, ax->stream, nullptr);
+        if (split != 2) q1 = launch_chain_impl(d_pics, n_pics - (int)r, log2_ctb, chroma_format, bit_depth, rare_syntax, max_ctb_w, max_ctb_h, nullptr, 0, d_err, s, nullptr);
+        // whatever happened, the caller's stream waits for what the second stream was given
+        hipError_t e = hipEventRecord(ax->join, ax->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s, ax->join, 0);
+        if (e != hipSuccess) { hipStreamSynchronize(ax->stream); return hm_check_hip(e, "join of the remainder's stream"); }
+        if (q1 <= 0) return q1 < 0 ? q1 : hm_fail(HM_ERR_INTERNAL, "k_chain: the full rounds did not launch");
+        if (q2 <= 0) return q2 < 0 ? q2 : hm_fail(HM_ERR_INTERNAL, "k_chain: the remainder did not launch");
+        return q1 > q2 ? q1 : q2;
+      }
+    }
+  }
+  return launch_chain_impl(d_pics, n_pics, log2_ctb, chroma_format, bit_depth, rare_syntax, max_ctb_w, max_ctb_h, d_sync, sync_bytes, d_err, s, nullptr);
 }
 
 // bytes of the synchronisation buffer hm_launch_chain wants for its wave-per-row-pair mode (0: never uses it)

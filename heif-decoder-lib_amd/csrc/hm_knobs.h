@@ -17,6 +17,8 @@ extern "C" {
 //   chain_alt (1)          0: the one-chain waves of a ring keep their kind of chain
 //   chain_np (0)           pictures per workgroup of the wave-per-picture cut
 //   chain_debug (0)        print the launcher's choice to stderr
+//   chain_split (1)        0: the partial last round of a wave per picture stays in the one launch; 1 / 2: a launch of its own beside
+//                          the full rounds (queued first / second)
 //   resid_segs (0)         runs of CTUs a row of k_residual is cut into
 //   recon_waves (0)        waves per workgroup of k_recon
 //   quad_class (-1)        record order of the parser: 1 split chains for every class that has them, 0 for none
@@ -24,7 +26,7 @@ extern "C" {
 //   stream_interleaved (0) 1: records in decode order (format of the rare-syntax classes) for every picture
 enum hm_knob_id { HM_KNOB_CHAIN_SPIN_LIMIT, HM_KNOB_CHAIN_TEST_STALL, HM_KNOB_BATCH_FAIL_WIDTH, HM_KNOB_CHAIN_PAIRS, HM_KNOB_CHAIN_SHARE, HM_KNOB_CHAIN_RING,
                   HM_KNOB_CHAIN_ALT, HM_KNOB_CHAIN_NP, HM_KNOB_CHAIN_DEBUG, HM_KNOB_RESID_SEGS, HM_KNOB_RECON_WAVES, HM_KNOB_QUAD_CLASS, HM_KNOB_TAIL_FUSED,
-                  HM_KNOB_STREAM_INTERLEAVED, HM_KNOB_COUNT };
+                  HM_KNOB_STREAM_INTERLEAVED, HM_KNOB_CHAIN_SPLIT, HM_KNOB_COUNT };
 int hm_knob(int id);
 __attribute__((visibility("default"))) int hm_debug_set(const char* name, int value); // 0, or -1 for an unknown name
 #ifdef __cplusplus
