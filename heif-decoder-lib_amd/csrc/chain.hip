@@ -1526,8 +1526,8 @@ AuxStream* aux_stream_of(hipStream_t s)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipStreamCreateWithFlags(&t, hipStreamNonBlocking) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&e0, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) {
-      if (e0) hipEventDestroy(e0);
-      hipStreamDestroy(t);
+      if (e0) (void)hipEventDestroy(e0);
+      (void)hipStreamDestroy(t);
       return nullptr;
     }
     a.stream = t; a.fork = e0; a.join = e1;
@@ -1563,7 +1563,7 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
         // whatever happened, the caller's stream waits for what the second stream was given
         hipError_t e = hipEventRecord(ax->join, ax->stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(s, ax->join, 0);
-        if (e != hipSuccess) { hipStreamSynchronize(ax->stream); return hm_check_hip(e, "join of the remainder's stream"); }
+        if (e != hipSuccess) { (void)hipStreamSynchronize(ax->stream); return hm_check_hip(e, "join of the remainder's stream"); }
         if (q1 <= 0) return q1 < 0 ? q1 : hm_fail(HM_ERR_INTERNAL, "k_chain: the full rounds did not launch");
         if (q2 <= 0) return q2 < 0 ? q2 : hm_fail(HM_ERR_INTERNAL, "k_chain: the remainder did not launch");
         return q1 > q2 ? q1 : q2;
