@@ -1127,6 +1127,10 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
 #endif
     }
 #endif
+#ifdef HM_PAD_VNOP // sensitivity probe without a register of its own: N vector no-ops per iteration (tools/probe_chain.sh)
+#pragma unroll
+    for (int k = 0; k < HM_PAD_VNOP; k++) asm volatile("v_nop");
+#endif
     HM_T_LAP(3);
     HM_MARK("E_begin");
     // ---- E: the groups that executed a block move to the next record ----

@@ -912,6 +912,47 @@ __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict_
 }
 
 
+// window_edges() for the fused tail's mainstream case - 8-bit 4:2:0 pictures of ONE slice - from a copy of the tile's part of the
+// block map in LDS (r05: the general function fetches eleven 16-bit words per window from memory, each with its own clamped
+// address, and was the largest single item of the kernel's phase 1: ~300 of ~630 vector instructions per wave of windows).
+// `m` points at the word of the block that holds the window's crossing - luma block (2 kx, 2 ky), chroma (4 kx, 4 ky) - in a
+// map of pitch MP whose border cells hold the clamped neighbours (meta_at's clamping, done once per cell).  The seven words a
+// window can need lie at fixed offsets from it: the edge flags of its four units, and QpY on the Q / P side of each unit
+// (luma: at the start of the unit's 8-sample segment, chroma: at the unit) - deblock.cc:731-753, 1650-1716.
+__device__ __forceinline__ bool tail_window_edges(const uint16_t* m, int MP, int c, int kx, int ky, int PW, int PH, int beta_off, int tc_off, int qp_off,
+                                                  const uint8_t* tab, WindowEdges<false>& E)
+{
+  const int ex = kx << 3, ey = ky << 3, ox = ex - 4, oy = ey - 4;
+  const uint32_t m00 = m[0], m10 = m[-1], m20 = m[-2], m01 = m[-MP], m21 = m[-MP - 2], m02 = m[-2 * MP], m12 = m[-2 * MP - 1];
+  const uint32_t mA = c ? m02 : m01, mC = c ? m20 : m10; // the words of the upper / left unit (chroma units are two blocks away)
+  const bool in_x = ex > 0 && ex < PW, in_y = ey > 0 && ey < PH;
+  const bool bV0 = in_x && oy >= 0 && oy < PH && (mA & 1), bV1 = in_x && ey < PH && (m00 & 1);
+  const bool bH0 = in_y && ox >= 0 && ox < PW && (mC & 2), bH1 = in_y && ex < PW && (m00 & 2);
+  if (!(bV0 | bV1 | bH0 | bH1)) return false;
+  auto qpy = [](uint32_t w) { return (int)(int8_t)(w >> 8); };
+  // Q / P side of: vertical edge upper, lower unit; horizontal edge left, right unit
+  const int q[4] = {qpy(m02), qpy(m00), qpy(m20), qpy(m00)}, p[4] = {qpy(m12), qpy(m10), qpy(m21), qpy(m01)};
+  const bool bs[4] = {bV0, bV1, bH0, bH1};
+  int beta[4], tc[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int avg = (q[u] + p[u] + 1) >> 1;
+    int qt;
+    if (c == 0) {
+      beta[u] = bs[u] ? (int)tab[clip3i(0, 51, avg + beta_off)] : 0;
+      qt = avg;
+    }
+    else {
+      beta[u] = 0;
+      qt = chroma_qp_map(avg + qp_off); // (4:2:0: Table 8-10)
+    }
+    tc[u] = bs[u] ? (int)tab[52 + clip3i(0, 53, qt + 2 + tc_off)] : 0; // (bS 2: + 2 (bS - 1))
+  }
+  E.betaV[0] = beta[0]; E.betaV[1] = beta[1]; E.betaH[0] = beta[2]; E.betaH[1] = beta[3];
+  E.tcV[0] = tc[0]; E.tcV[1] = tc[1]; E.tcH[0] = tc[2]; E.tcH[1] = tc[3];
+  return true;
+}
+
 // ---- fused tail: deblocking + SAO + paste + YCbCr 4:2:0 -> RGB in one pass ------------------------------------------
 // For the mainstream class (8-bit 4:2:0, one slice, no tiles, no rare syntax, integer colour chain of
 // Op_YCbCr420_to_RGB24 / _RGB32, yuv2rgb.cc:306-366, 416-495) the three kernels above and the colour kernel collapse
@@ -1085,8 +1126,63 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
   __shared__ uint32_t s_cnt[4]; // luma edge units waiting for a filter: vertical strong / normal, horizontal strong / normal
   constexpr int NWAVES = TAIL_THREADS / 64;
   __shared__ __attribute__((aligned(16))) uint8_t s_x[NWAVES][2][16][16]; // phase 2: a cell's chroma on its way to the luma lanes; phase 1: the unit lists
+  // ---- the lane's window: its loads go out first - the block map and the first barrier wait behind them, not in front ----
+  // windows per tile: (TW / 8 + 1) x (TH / 8 + 1) luma from lane 0 up, 2 x (TW / 16 + 1) x (TH / 16 + 1) chroma at the end of the workgroup
+  constexpr int NLX = TAIL_TW / 8 + 1, NLY = TAIL_TH / 8 + 1, NCX = TAIL_TW / 16 + 1, NCY = TAIL_TH / 16 + 1;
+  constexpr int NL = NLX * NLY, NC = NCX * NCY, C0 = TAIL_THREADS - 2 * NC;
+  static_assert(NL <= C0, "one lane per window");
+  int c = -1, kxl = 0, kyl = 0, kx = 0, ky = 0, PW = 0, PH = 0;
+  bool have_window = false;
+  Window<uint8_t> win;
+  if (tid < NL) { c = 0; kyl = tid / NLX; kxl = tid - kyl * NLX; }
+  else if (tid >= C0) {
+    int t = tid - C0;
+    c = t >= NC ? 2 : 1;
+    t -= (c - 1) * NC;
+    kyl = t / NCX; kxl = t - kyl * NCX;
+  }
+  if (c >= 0) {
+    const int sw = c ? 2 : 1;
+    PW = W >> (sw >> 1); PH = H >> (sw >> 1);
+    kx = (c ? TAIL_TW / 16 * tx : TAIL_TW / 8 * tx) + kxl; ky = (c ? TAIL_TH / 16 * ty : TAIL_TH / 8 * ty) + kyl;
+    if (kx <= ((PW + 7) >> 3) && ky <= ((PH + 7) >> 3)) {
+      have_window = true;
+      const int ox = (kx << 3) - 4, oy = (ky << 3) - 4;
+#if defined(HM_T_PROBE) && (HM_T_PROBE & 64)
+      if (n_tiles < 0) window_load(win, dp.plane[c], dp.pitch[c], ox, oy, PH); // probe: no loads of samples
+      else {
+#pragma unroll
+        for (int r = 0; r < 8; r++) { win.w[r][0] = (uint32_t)(ox + r) * 0x01010101u; win.w[r][1] = (uint32_t)(oy + r) * 0x01010101u; }
+      }
+#else
+      if (ox >= 0) window_load(win, dp.plane[c], dp.pitch[c], ox, oy, PH);
+      else { // left picture border: the window's left half does not exist (k_deblock never loads the corner window)
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          const int y = oy + r < 0 ? 0 : (oy + r < PH ? oy + r : PH - 1);
+          win.w[r][0] = 0;
+          win.w[r][1] = *gptr<uint32_t>(dp.plane[c] + (uint32_t)mul24_raw(y, dp.pitch[c]));
+        }
+      }
+#endif
+    }
+  }
   if (tid < 106) s_tab[tid] = tid < 52 ? c_beta[tid] : c_tc[tid - 52];
   if (tid < 4) s_cnt[tid] = 0;
+  // the tile's part of the block map (4x4 luma blocks x0 / 4 - 2 .. x0 / 4 + TW / 4, y0 / 4 - 2 .. y0 / 4 + TH / 4: what the windows of
+  // the tile can ask for), cells outside the picture clamped into it (tail_window_edges)
+  constexpr int MP = TAIL_TW / 4 + 4, MR = TAIL_TH / 4 + 3;
+  __shared__ uint16_t s_meta[MR * MP];
+  const bool one_slice = dp.n_slices == 1; // (pictures of several slices: the general window_edges)
+  if (one_slice && (stages & 1) && (dp.flags & HM_PIC_DEBLOCK_ANY)) {
+    const GLOBAL_AS uint16_t* const meta = gptr<uint16_t>(dp.meta);
+    const int bx0 = (x0 >> 2) - 2, by0 = (y0 >> 2) - 2, w4 = dp.w4, h4 = dp.h4;
+    for (int i = tid; i < MR * MP; i += TAIL_THREADS) {
+      const int my = i / MP, mx = i - my * MP;
+      const int bx = bx0 + mx < 0 ? 0 : (bx0 + mx < w4 ? bx0 + mx : w4 - 1), by = by0 + my < 0 ? 0 : (by0 + my < h4 ? by0 + my : h4 - 1);
+      s_meta[i] = meta[(uint32_t)(bx + mul24_raw(by, w4))];
+    }
+  }
   // The SAO parameters of the two cells this wave converts in phase 2 (cells of 32 x 32 inside ONE CTB: UNI), requested now:
   // they arrive under phase 1, and phase 2 has no load left between its pixel stores - a wait for a load is a wait for every
   // store before it (one counter), which put the whole write latency of a cell's pixels in front of the next cell (r05: 9.2 ms
@@ -1119,9 +1215,6 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
   // vertical edges, then - decided on the result, as the reference's order demands (deblock.cc:1921-1959) - the horizontal
   // ones.  A unit is four lines of eight samples inside its own window; windows never share a sample, so nothing but the
   // redistribution needs the barriers.
-  constexpr int NLX = TAIL_TW / 8 + 1, NLY = TAIL_TH / 8 + 1, NCX = TAIL_TW / 16 + 1, NCY = TAIL_TH / 16 + 1;
-  constexpr int NL = NLX * NLY, NC = NCX * NCY, C0 = TAIL_THREADS - 2 * NC;
-  static_assert(NL <= C0, "one lane per window");
   constexpr uint32_t LIST_N = sizeof(s_x) / 4;
   static_assert(2 * NL <= (int)LIST_N, "the unit list holds every unit of one direction");
   uint32_t* const ulist = reinterpret_cast<uint32_t*>(&s_x[0][0][0][0]);
@@ -1169,50 +1262,30 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
       }
     }
   };
+  int slice_beta_off = 0, slice_tc_off = 0; // one slice: its deblocking offsets (x 2: slice_beta_offset_div2 / slice_tc_offset_div2)
+  if (one_slice) {
+    const uint32_t w1 = gptr<uint32_t>(v.slices)[1]; // hm_slice: slice_addr | beta_offset_div2, tc_offset_div2, deblocking_disabled, sao_luma | ...
+    slice_beta_off = 2 * (int)(int8_t)(w1 & 0xFF);
+    slice_tc_off = 2 * (int)(int8_t)((w1 >> 8) & 0xFF);
+  }
   bool luma_window = false;  // this lane holds a luma window with an edge to filter
   uint32_t woff = 0;         // ... at this place of the luma tile
   uint32_t decV0 = 0, decV1 = 0;
   int betaH0 = 0, betaH1 = 0, tcH0 = 0, tcH1 = 0;
   {
-    // windows per tile: (TW / 8 + 1) x (TH / 8 + 1) luma from lane 0 up, 2 x (TW / 16 + 1) x (TH / 16 + 1) chroma at the end
-    // of the workgroup
-    int c = -1, kxl = 0, kyl = 0;
-    if (tid < NL) { c = 0; kyl = tid / NLX; kxl = tid - kyl * NLX; }
-    else if (tid >= C0) {
-      int t = tid - C0;
-      c = t >= NC ? 2 : 1;
-      t -= (c - 1) * NC;
-      kyl = t / NCX; kxl = t - kyl * NCX;
-    }
-    if (c >= 0) {
-      const int sw = c ? 2 : 1;
-      const int PW = W >> (sw >> 1), PH = H >> (sw >> 1);
-      const int kx = (c ? TAIL_TW / 16 * tx : TAIL_TW / 8 * tx) + kxl, ky = (c ? TAIL_TH / 16 * ty : TAIL_TH / 8 * ty) + kyl;
-      if (kx <= ((PW + 7) >> 3) && ky <= ((PH + 7) >> 3)) {
-        Window<uint8_t> win;
-        const int ox = (kx << 3) - 4, oy = (ky << 3) - 4;
-#if defined(HM_T_PROBE) && (HM_T_PROBE & 64)
-        if (n_tiles < 0) window_load(win, dp.plane[c], dp.pitch[c], ox, oy, PH); // probe: no loads of samples
-        else {
-#pragma unroll
-          for (int r = 0; r < 8; r++) { win.w[r][0] = (uint32_t)(ox + r) * 0x01010101u; win.w[r][1] = (uint32_t)(oy + r) * 0x01010101u; }
-        }
-#else
-        if (ox >= 0) window_load(win, dp.plane[c], dp.pitch[c], ox, oy, PH);
-        else { // left picture border: the window's left half does not exist (k_deblock never loads the corner window)
-#pragma unroll
-          for (int r = 0; r < 8; r++) {
-            const int y = oy + r < 0 ? 0 : (oy + r < PH ? oy + r : PH - 1);
-            win.w[r][0] = 0;
-            win.w[r][1] = *gptr<uint32_t>(dp.plane[c] + (uint32_t)mul24_raw(y, dp.pitch[c]));
-          }
-        }
-#endif
+    if (have_window) {
+      {
 #if !defined(HM_T_PROBE) || !(HM_T_PROBE & 1)
         if ((stages & 1) && (dp.flags & HM_PIC_DEBLOCK_ANY)) {
           WindowEdges<false> E;
           HM_MARK("edges_begin");
-          const bool any_edge = window_edges<uint8_t, false>(dp, v, c, kx, ky, sw, sw, E, TabLds{s_tab});
+          bool any_edge;
+          if (one_slice) {
+            // (the crossing's block: luma (2 kx, 2 ky), chroma (4 kx, 4 ky) = 2 kxl / 4 kxl columns right of the tile's first block)
+            const uint16_t* const mw = s_meta + ((c ? 4 * kyl : 2 * kyl) + 2) * MP + (c ? 4 * kxl : 2 * kxl) + 2;
+            any_edge = tail_window_edges(mw, MP, c, kx, ky, PW, PH, slice_beta_off, slice_tc_off, c == 0 ? 0 : (c == 1 ? dp.cb_qp_offset : dp.cr_qp_offset), s_tab, E);
+          }
+          else any_edge = window_edges<uint8_t, false>(dp, v, c, kx, ky, c ? 2 : 1, c ? 2 : 1, E, TabLds{s_tab});
           HM_MARK("edges_end");
           if (any_edge && c == 0) {
             luma_window = true;
