@@ -41,8 +41,10 @@
 #include "recon_common.h"
 
 #include <stdlib.h>
+#include <atomic>
 #include <map>
 #include <mutex>
+#include <new>
 #include <utility>
 
 #include "hm_internal.h"
@@ -1159,6 +1161,29 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
 // The chain kernel serves every picture whose records come as split chains (no rare syntax, not 4:4:4), after
 // hm_launch_residual on the same stream; returns 1 if it launched (2: in the wave-per-row-pair mode, i.e. using d_sync),
 // 0 if the CTU staging does not fit LDS, < 0 on error.  d_err: the batch's sticky error word (never cleared here).
+// The "share" cut needs all W waves of every picture resident together (k_chain's comment): the launcher clamps W x pictures to
+// the waves the device holds - of ONE launch.  Two such launches side by side (the plugin worker's executor streams,
+// hm_batch_set_concurrency, several batches of one process) could each hold half of the device and wait for the other half for
+// ever - until the bounded spins give up and the batches report HM_ERR_INTERNAL.  So the waves a share
+// launch needs are RESERVED per device for as long as the launch is in flight (given back by a host function queued behind the
+// kernel); a launch that does not get them takes a cut without the residency condition (a wave per picture).
+namespace {
+std::atomic<long> g_share_in_use[64];
+struct ShareRelease { int dev; long waves; };
+void share_release_cb(void* p)
+{
+  ShareRelease* const r = static_cast<ShareRelease*>(p);
+  g_share_in_use[r->dev].fetch_sub(r->waves, std::memory_order_acq_rel);
+  delete r;
+}
+bool share_reserve(int dev, long waves, long capacity)
+{
+  long cur = g_share_in_use[dev].load(std::memory_order_acquire);
+  while (cur + waves <= capacity)
+    if (g_share_in_use[dev].compare_exchange_weak(cur, cur + waves, std::memory_order_acq_rel)) return true;
+  return false;
+}
+} // namespace
 // (plan: if given, nothing is launched - the cut the launcher would take is reported instead)
 struct ChainPlan { bool per_picture = false; long resident = 0; };
 static int launch_chain_impl(const hm_dev_pic* d_pics, int n_pics, int log2_ctb, int chroma_format, int bit_depth, int rare_syntax,
@@ -1218,6 +1243,9 @@ static int launch_chain_impl(const hm_dev_pic* d_pics, int n_pics, int log2_ctb,
   // for the rows and chains per wave.
   const int force_ring = hm_knob(HM_KNOB_CHAIN_RING);
   int ring_w = 0; // (chosen below, once the layout and the kernel of a cut can be worked out)
+  int share_dev = -1;
+  long share_reserved = 0; // waves reserved for a share launch (share_reserve), given back when the kernel has run
+  auto give_back = [&]() { if (share_reserved) { g_share_in_use[share_dev].fetch_sub(share_reserved, std::memory_order_acq_rel); share_reserved = 0; } };
   if (force_ring >= 0) {
     ring_w = force_ring >= 2 && max_ctb_h > 1 ? (force_ring > 16 ? 16 : force_ring) : 0;
     if (ring_w) {
@@ -1441,7 +1469,12 @@ static int launch_chain_impl(const hm_dev_pic* d_pics, int n_pics, int log2_ctb,
     long w = resident_waves / n_pics;
     if (!force_share || force_share < 2) w = w > 4 ? 4 : w;
     if (w < share) share = (int)w;
-    if (share < 2) { // not even two waves per picture fit: a wave per picture
+    if (share >= 2 && !plan) { // (see share_reserve)
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || !share_reserve(dev, (long)n_pics * share, resident_waves)) share = 0;
+      else { share_dev = dev; share_reserved = (long)n_pics * share; }
+    }
+    if (share < 2) { // not even two waves per picture fit (or another launch holds them): a wave per picture
       share = 0; pairs = false;
       L.rows_per_wave = nr; L.split_kinds = 0;
       if (!set_layout() || !pick(false)) return 0;
@@ -1484,15 +1517,15 @@ static int launch_chain_impl(const hm_dev_pic* d_pics, int n_pics, int log2_ctb,
                      L.pic_bytes, np, best);
   if (debug && ring_w) fprintf(stderr, "[k_chain] a picture's %d waves in one workgroup, rows handed over through LDS in a ring\n", ring_w << L.split_kinds);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) return hm_check_hip(e, "hipFuncSetAttribute(k_chain)");
+  if (e != hipSuccess) { give_back(); return hm_check_hip(e, "hipFuncSetAttribute(k_chain)"); }
   if (pairs) {
     e = hipMemsetAsync(d_sync, 0, sync_need, s);
-    if (e != hipSuccess) return hm_check_hip(e, "hipMemsetAsync(k_chain sync words)");
+    if (e != hipSuccess) { give_back(); return hm_check_hip(e, "hipMemsetAsync(k_chain sync words)"); }
   }
   int a_n = n_pics;
 #ifdef HM_CHAIN_TIMING
   const bool timing_words = !pairs && d_sync && sync_bytes >= 32; // (a wave per picture: the sync words only hold the phase sums)
-  if (timing_words && hipMemsetAsync(d_sync, 0, 32, s) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipMemsetAsync");
+  if (timing_words && hipMemsetAsync(d_sync, 0, 32, s) != hipSuccess) { give_back(); return hm_fail(HM_ERR_NO_DEVICE, "hipMemsetAsync"); }
   uint32_t* a_sync = pairs || timing_words ? d_sync : nullptr;
 #else
   const bool timing_words = false;
@@ -1501,9 +1534,17 @@ static int launch_chain_impl(const hm_dev_pic* d_pics, int n_pics, int log2_ctb,
   uint32_t* a_err = d_err;
   void* args[] = {(void*)&d_pics, &a_n, &L, &a_sync, &a_err};
   e = hipLaunchKernel(fn, dim3((unsigned)((n_waves + np - 1) / np)), dim3(np * 64), args, lds_bytes, s);
-  if (e != hipSuccess) return hm_check_hip(e, "k_chain launch");
-  e = hipGetLastError();
-  if (e != hipSuccess) return hm_check_hip(e, "k_chain launch");
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e != hipSuccess) { give_back(); return hm_check_hip(e, "k_chain launch"); }
+  if (share_reserved) { // the reservation ends when the kernel has run
+    ShareRelease* const r = new (std::nothrow) ShareRelease{share_dev, share_reserved};
+    if (!r || hipLaunchHostFunc(s, share_release_cb, r) != hipSuccess) {
+      delete r;
+      (void)hipStreamSynchronize(s); // (never on a healthy runtime: wait for the kernel, then give the waves back here)
+      give_back();
+    }
+    share_reserved = 0;
+  }
   return pairs || timing_words ? 2 : 1; // (2: the synchronisation words were used)
 }
 

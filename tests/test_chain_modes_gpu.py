@@ -117,3 +117,57 @@ def test_partial_last_round_goes_to_a_launch_of_its_own():
     r = _run({"HM_CHECK_COPIES": "5632", "HM_CHAIN_DEBUG": "1", "HM_CHAIN_SPLIT": "0"}, "tile512_a", timeout=1200)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
     assert "[k_chain] 5632 pictures, 5632 waves (one per picture)" in r.stderr, r.stderr
+
+
+def test_two_mid_size_batches_side_by_side_never_starve_each_other():
+    """1300 tiles is where the launcher lets several waves per picture take its row pairs in turn through HBM -
+    a cut whose waves must all be resident together.  Two such launches side by side (two batches on two streams of one process, as
+    the plugin worker's executors and hm_batch_set_concurrency produce them) must not hold half of the device each and wait for the
+    other half: the waves are reserved per device for the launch's lifetime, the launch that does not get them takes a wave per
+    picture (chain.hip: share_reserve).  50 rounds: no HM_ERR_INTERNAL, every picture the oracle's."""
+    code = r'''
+import sys, numpy as np, torch
+import __graft_entry__ as g, corpus, orc
+pkg = g.load_package(test_knobs=True)
+capi, L = pkg.capi, pkg.lib()
+dev = torch.device("cuda:0")
+blob = capi.parse_hevc(corpus.stream("tile512_a"))
+exp = orc.oracle_decode(blob, 3, crop=True)[0]
+ys, cs = L.hm_plane_stride(512, 1), L.hm_plane_stride(256, 1)
+streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+batches, planes = [], []
+for k in range(2):
+    p = [torch.zeros((512, ys), dtype=torch.uint8, device=dev), torch.zeros((256, cs), dtype=torch.uint8, device=dev), torch.zeros((256, cs), dtype=torch.uint8, device=dev)]
+    b = capi.Batch()
+    for i in range(1300):
+        d = capi.TileDest()
+        d.plane[0], d.plane[1], d.plane[2] = p[0].data_ptr(), p[1].data_ptr(), p[2].data_ptr()
+        d.pitch[0], d.pitch[1], d.pitch[2] = ys, cs, cs
+        d.canvas_width, d.canvas_height, d.x0, d.y0 = 512, 512, 0, 0
+        b.add(blob, d)
+    b.upload(streams[k].cuda_stream)
+    batches.append(b); planes.append(p)
+torch.cuda.synchronize()
+for rnd in range(50):
+    for k in range(2):
+        for t in planes[k]:
+            t.zero_()
+    torch.cuda.synchronize()
+    for k in range(2):
+        batches[k].execute(3, streams[k].cuda_stream)
+    torch.cuda.synchronize()
+    for k in range(2):
+        batches[k].check()  # raises on HM_ERR_INTERNAL
+        for c, (w, h) in enumerate(((512, 512), (256, 256), (256, 256))):
+            if not np.array_equal(planes[k][c].cpu().numpy()[:h, :w], exp[c].astype(np.uint8)):
+                print(f"round {rnd}, batch {k}, plane {c} differs"); sys.exit(1)
+print("OK")
+'''
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([ROOT, HERE, env.get("PYTHONPATH", "")])
+    env["HM_CHAIN_DEBUG"] = "1"
+    env["HM_CHAIN_SHARE"] = "3"  # (the cut under test, whatever the launcher's own choice for 1300 tiles is on this device)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "taking its pairs of CTU rows in turn" in r.stderr, r.stderr[-2000:]  # (the cut under test ran ...)
+    assert "1300 waves (one per picture)" in r.stderr, r.stderr[-2000:]          # (... and a launch beside it stepped aside)
