@@ -1161,6 +1161,40 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
 // The chain kernel serves every picture whose records come as split chains (no rare syntax, not 4:4:4), after
 // hm_launch_residual on the same stream; returns 1 if it launched (2: in the wave-per-row-pair mode, i.e. using d_sync),
 // 0 if the CTU staging does not fit LDS, < 0 on error.  d_err: the batch's sticky error word (never cleared here).
+// ---- the launcher's calibration, in one place (r05) -------------------------------------------------------
+// Everything the choice of a cut depends on besides the batch itself: wave counts up to which a finer cut pays, and the relative
+// cost of a CTU step by the chains a wave works on.  Calibrated on MI355X (256 CUs) with the sweeps named at each value; the wave
+// counts are stated for that device and scale with its compute units (scaled()).  Regenerate: tools/bench_classes.py with
+// HM_CLASS_TILES = 24 ... 3072 and the knobs chain_pairs / chain_ring / chain_share (profiles/r03_chain_cut_sweep.txt,
+// r03_share_sweep.txt, r04_ring_sweep.txt, r05_staircase.txt hold the runs the values were read from).
+namespace {
+struct ChainTuning {
+  int calibrated_cus = 256;
+  long pair_waves_max = 7000;  // a wave per pair of CTU rows while the launch has at most this many of them (r03_chain_cut_sweep: 768 tiles 4.69 vs 5.23 ms per picture)
+  long row_waves_max = 3500;   // a wave per CTU row / per chain of a row while their waves stay below this (192 tiles: 1.96 / 2.33 vs 2.31)
+  long share_waves_min = 3000; // above this many row-pair waves: several waves per picture in turn (r03_share_sweep: 576 tiles 2.52 vs 3.70)
+  long ring_waves_min = 2800;  // the ring is considered once a wave per chain of every row would be more than this (r04_ring_sweep)
+  int ring_waves_per_cu = 16;  // the ring's waves must all be resident: at most this many per CU (320 tiles: 16 per picture 1.49 ms, 8: 1.20)
+  // cost of a CTU step of the wavefront by what a wave works on (r04_ring_sweep: 1 : 2.5 : 3.3 for one chain, a row, a pair of rows;
+  // a wave per chain of EVERY row crowds the SIMDs: 1.4)
+  long step_pair = 330, step_row = 250, step_chain = 105, step_chain_crowded = 140;
+  int heavy_waves_per_cu = 10; // classes whose wave per picture fits at most this often on a CU take the ring of 2 x 2 at any count (r04_ring_sweep: 12-bit 4:2:2 CTB 64 129 -> 51 ms)
+  int split_round_fraction = 4; // a partial last round of at most 1 / (this x full rounds) of a round gets a launch of its own (r05_staircase)
+};
+constexpr ChainTuning k_tune{};
+int device_cus() // compute units of the current device
+{
+  static int cus_of[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (cus_of[dev] == 0) {
+    int v = 0;
+    cus_of[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  }
+  return cus_of[dev];
+}
+} // namespace
+
 // The "share" cut needs all W waves of every picture resident together (k_chain's comment): the launcher clamps W x pictures to
 // the waves the device holds - of ONE launch.  Two such launches side by side (the plugin worker's executor streams,
 // hm_batch_set_concurrency, several batches of one process) could each hold half of the device and wait for the other half for
@@ -1211,11 +1245,12 @@ static int launch_chain_impl(const hm_dev_pic* d_pics, int n_pics, int log2_ctb,
   // 1536: 6.00 / 7.67 / 9.04 / 11.9, 3072: 7.25 / 14.3 / 16.9 / 22.8 - a wave that waits for the rows above it holds its
   // place on the machine, so the finer cuts only pay while all their waves fit it (4096) with room to spare.
   L.rows_per_wave = nr; L.split_kinds = 0;
+  auto scaled = [](long waves) { return waves * device_cus() / k_tune.calibrated_cus; }; // (a wave count of the calibration device on this one)
   const long pair_waves = (long)n_pics * ((max_ctb_h + nr - 1) / nr), row_waves = (long)n_pics * max_ctb_h;
-  bool pairs = max_ctb_h > 1 && pair_waves <= 7000;
-  if (pairs && row_waves <= 3500) {
+  bool pairs = max_ctb_h > 1 && pair_waves <= scaled(k_tune.pair_waves_max);
+  if (pairs && row_waves <= scaled(k_tune.row_waves_max)) {
     L.rows_per_wave = 1;
-    if (2 * row_waves <= 3500 && !mono) L.split_kinds = 1;
+    if (2 * row_waves <= scaled(k_tune.row_waves_max) && !mono) L.split_kinds = 1;
   }
   // Too many pictures for a wave per pair of rows, too few to fill the machine with a wave per picture (about 400 ... 2000
   // tiles of 512x512): W waves per picture that take its pairs of rows in turn - at most 4 (more hand-overs than that cost
@@ -1224,7 +1259,7 @@ static int launch_chain_impl(const hm_dev_pic* d_pics, int n_pics, int log2_ctb,
   // pair of rows / W in turn): 384 tiles 4.03 / 2.55 / 2.42 (W = 4), 576: 4.44 / 3.70 / 2.52 (4), 1056: 4.78 / 5.32 / 3.18 (3),
   // 1536: 4.92 / 7.03 / 4.02 (2), 2064: 4.92 / 9.18 / 5.94 (2, 4128 waves: too many).
   int share = 0; // waves per picture in that mode
-  if (pair_waves > 3000 && max_ctb_h > nr) {
+  if (pair_waves > scaled(k_tune.share_waves_min) && max_ctb_h > nr) {
     share = 4; // (clamped to what the device holds at once below)
     pairs = true;
     L.rows_per_wave = nr; L.split_kinds = 0;
@@ -1372,17 +1407,7 @@ static int launch_chain_impl(const hm_dev_pic* d_pics, int n_pics, int log2_ctb,
     }
     return np > 0;
   };
-  auto cus = [] { // compute units of the current device
-    static int cus_of[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (cus_of[dev] == 0) {
-      int v = 0;
-      cus_of[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-    }
-    return cus_of[dev];
-  };
-  if (force_ring < 0 && force_pairs < 0 && force_share < 2 && fits && 2 * row_waves > 2800 && d_sync && d_err) {
+  if (force_ring < 0 && force_pairs < 0 && force_share < 2 && fits && 2 * row_waves > scaled(k_tune.ring_waves_min) && d_sync && d_err) {
     // Too many pictures for a wave per chain of every CTU row: the finest cut whose waves are all resident at once, with a
     // picture's waves in one workgroup (the ring) - if it beats the cut chosen above by this estimate: a picture takes
     // `steps` CTU steps (R rows in flight: rows x columns / R + 2 R; the whole wavefront: columns + 2 rows), and a step costs by the
@@ -1392,20 +1417,20 @@ static int launch_chain_impl(const hm_dev_pic* d_pics, int n_pics, int log2_ctb,
     // 1280: 3.12 / 2.92 (three waves of a row pair each; two: 3.21); 1080p CTB 64, GP/s: 64 pictures 39 / 35 (kept), 96: 40 / 47,
     // 256: 28 / 82; 2048x1536 10-bit 4:2:2 (48 rows of 64 CTUs), k_chain ms: 32 pictures 2.9 / 55 and 64: 9.2 / 11.4 (kept), 128: 18.6 / 11.4.
     // More waves than the device holds at four per SIMD cost more than they give (320 tiles: 16 per picture 1.49 ms, 8: 1.20).
-    const long capacity = (long)cus() * 16;
+    const long capacity = (long)device_cus() * k_tune.ring_waves_per_cu;
     auto steps_of = [&](long in_flight) -> long {
       return in_flight >= max_ctb_h ? (long)max_ctb_w + 2l * max_ctb_h : ((long)max_ctb_h * max_ctb_w + in_flight - 1) / in_flight + 2 * in_flight;
     };
-    auto step_cost = [&](int rpw, int split) -> long { return rpw > 1 ? 330 : (split || mono ? 105 : 250); };
+    auto step_cost = [&](int rpw, int split) -> long { return rpw > 1 ? k_tune.step_pair : (split || mono ? k_tune.step_chain : k_tune.step_row); };
     long cost_now;
-    if (!pairs) cost_now = steps_of(nr) * 330;
+    if (!pairs) cost_now = steps_of(nr) * k_tune.step_pair;
     else if (share) {
       const long fit = capacity / n_pics;
-      cost_now = steps_of((fit < share ? (fit < 1 ? 1 : fit) : share) * nr) * 330;
+      cost_now = steps_of((fit < share ? (fit < 1 ? 1 : fit) : share) * nr) * k_tune.step_pair;
     }
-    else if (L.rows_per_wave > 1) cost_now = steps_of(max_ctb_h) * 330;
-    else if (L.split_kinds || mono) cost_now = steps_of(max_ctb_h) * 140;
-    else cost_now = steps_of(max_ctb_h) * 250;
+    else if (L.rows_per_wave > 1) cost_now = steps_of(max_ctb_h) * k_tune.step_pair;
+    else if (L.split_kinds || mono) cost_now = steps_of(max_ctb_h) * k_tune.step_chain_crowded;
+    else cost_now = steps_of(max_ctb_h) * k_tune.step_row;
     const CLayout keep = L;
     const bool keep_pairs = pairs;
     // Classes whose wave per picture needs so much LDS - two rows of CTU buffers and lines of both kinds: CTBs of 64, 16-bit
@@ -1420,7 +1445,7 @@ static int launch_chain_impl(const hm_dev_pic* d_pics, int n_pics, int log2_ctb,
     {
       const bool sv_pairs = pairs;
       pairs = false; L.rows_per_wave = nr; L.split_kinds = 0;
-      heavy = set_layout() && pick(false) && best <= 10;
+      heavy = set_layout() && pick(false) && best <= k_tune.heavy_waves_per_cu;
       L = keep; pairs = sv_pairs;
     }
     static const struct { int one_row, split, w; } cand[5] = {{1, 1, 8}, {1, 1, 4}, {1, 1, 2}, {0, 0, 3}, {0, 0, 2}};
@@ -1431,7 +1456,7 @@ static int launch_chain_impl(const hm_dev_pic* d_pics, int n_pics, int log2_ctb,
       if ((long)n_pics * per_pic > capacity || sync_bytes < sync_words(bands)) continue;
       if (steps_of((long)w * rpw) * step_cost(rpw, split) > cost_now) continue;
       L.rows_per_wave = rpw; L.split_kinds = split; pairs = true; ring_w = w;
-      auto fits_device = [&]() { return set_layout() && pick(true) && (long)n_pics * per_pic <= (long)cus() * (best < 16 ? best : 16); };
+      auto fits_device = [&]() { return set_layout() && pick(true) && (long)n_pics * per_pic <= (long)device_cus() * (best < k_tune.ring_waves_per_cu ? best : k_tune.ring_waves_per_cu); };
       if (fits_device()) { share = 0; break; }
       if (alt_kinds()) { // (the workgroup's waves with a line per kind each may not fit its LDS: then with fixed kinds)
         alt_wanted = false;
@@ -1465,7 +1490,7 @@ static int launch_chain_impl(const hm_dev_pic* d_pics, int n_pics, int log2_ctb,
     // The waves of a picture that take its bands in turn wait for each other in both directions: all of them must be on
     // the device together.  Its capacity for this kernel: compute units x the waves a CU holds of it (`best`: registers
     // and this cut's LDS); the forced value (knob chain_share) is clamped like the chosen one.
-    const long resident_waves = (long)cus() * best;
+    const long resident_waves = (long)device_cus() * best;
     long w = resident_waves / n_pics;
     if (!force_share || force_share < 2) w = w > 4 ? 4 : w;
     if (w < share) share = (int)w;
@@ -1499,7 +1524,7 @@ static int launch_chain_impl(const hm_dev_pic* d_pics, int n_pics, int log2_ctb,
     np = np_max;
     long fullest = -1;
     for (int k = np_max; k >= (np_max < 4 ? 1 : 4); k--) {
-      const long groups = (n_waves + k - 1) / k, per_cu = (groups + cus() - 1) / cus() * k;
+      const long groups = (n_waves + k - 1) / k, per_cu = (groups + device_cus() - 1) / device_cus() * k;
       if (fullest < 0 || per_cu < fullest) { fullest = per_cu; np = k; }
     }
   }
@@ -1508,7 +1533,7 @@ static int launch_chain_impl(const hm_dev_pic* d_pics, int n_pics, int log2_ctb,
   const int lds_bytes = C_SHARED + np * L.pic_bytes;
   if (plan) { // (hm_launch_chain: is this a wave per picture, and how many of them does the device hold at once?)
     plan->per_picture = !pairs;
-    plan->resident = (long)cus() * best;
+    plan->resident = (long)device_cus() * best;
     return 1;
   }
   const int debug = hm_knob(HM_KNOB_CHAIN_DEBUG);
@@ -1595,7 +1620,7 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
     //  + 512: 9.90 / 7.87, + 1024: 10.11 / 8.80, + 1280: 10.61 / 9.92; two full rounds + 512: 16.10 / 14.44, + 1024: 16.30 / 17.5 - the
     //  later rounds start staggered, a remainder hurts them less: the more full rounds, the smaller the remainder worth a launch)
     const long rounds = n_pics / (plan.resident > 0 ? plan.resident : 1);
-    if (plan.per_picture && n_pics > plan.resident && r > 0 && 4 * rounds * r <= plan.resident) {
+    if (plan.per_picture && n_pics > plan.resident && r > 0 && k_tune.split_round_fraction * rounds * r <= plan.resident) {
       ChainPlan rest; // (only if the remainder alone would not be a wave per picture again)
       const hm_dev_pic* const d_rest = d_pics + (n_pics - r);
       AuxStream* const ax = aux_stream_of(s);

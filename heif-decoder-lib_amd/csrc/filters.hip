@@ -1371,6 +1371,10 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+#ifdef HM_PAD_VNOP // sensitivity probe: N vector no-ops per cell (tools/probe_chain.sh, OBJ=filters)
+#pragma unroll
+    for (int k = 0; k < HM_PAD_VNOP; k++) asm volatile("v_nop");
+#endif
     const int gx = lane & 3, rp = lane >> 2;
     const int lx = cellx + 8 * gx, ly = celly + 2 * rp;
     if (lx < cw && ly < chh) {
