@@ -315,6 +315,8 @@ struct heif_error heif_decode_image(const struct heif_image_handle* in, struct h
   if (dec.warnings & HM_WARN_UNKNOWN_PRIMARIES) img->warnings.emplace_back(heif_error_Invalid_input, heif_suberror_Unknown_NCLX_color_primaries);
   if (dec.warnings & HM_WARN_UNKNOWN_TRANSFER) img->warnings.emplace_back(heif_error_Invalid_input, heif_suberror_Unknown_NCLX_transfer_characteristics);
   if (dec.warnings & HM_WARN_UNKNOWN_MATRIX) img->warnings.emplace_back(heif_error_Invalid_input, heif_suberror_Unknown_NCLX_matrix_coefficients);
+  // (not a warning the reference raises - libde265 keeps its decoding warnings to itself -: part of the picture is concealment)
+  if (dec.warnings & HM_WARN_CONCEALED) img->warnings.emplace_back(heif_error_Decoder_plugin_error, heif_suberror_Unspecified);
   hm_decoded_free(&dec);
   *out_img = img.release();
   return ok();

@@ -98,7 +98,8 @@ heif_error decode_image(void* dec, struct heif_image** out_img)
   static const bool debug = [] { const char* e = std::getenv("HM_PLUGIN_DEBUG"); return e && e[0] == '1'; }();
   using clock = std::chrono::steady_clock;
   const clock::time_point t0 = clock::now();
-  int rc = hm_picture_parse(d->data.data(), d->data.size(), &pic, &I);
+  // (damaged slice data: concealed like the reference's plugin hands such pictures out - unless the caller asked for strict decoding)
+  int rc = hm_picture_parse_opts(d->data.data(), d->data.size(), d->strict ? 1 : 0, &pic, &I, nullptr);
   if (rc) return from_status(rc);
   const clock::time_point t1 = clock::now();
   struct Free { hm_picture* p; ~Free() { hm_picture_free(p); } } guard{pic};

@@ -96,6 +96,15 @@ struct Decoder {
   std::vector<uint8_t> rbsp; // unescaped NAL, reused
   std::vector<uint32_t> removed; // positions of its emulation prevention bytes in the escaped NAL
   int record_order = 0;      // hm_parse_options.record_order
+  // Concealment (HM_PARSE_CONCEAL; r05).  The reference keeps a picture whose slice data is damaged: libde265 notes the error, marks
+  // the slice as processed (decctx.cc:876-995) and hands the picture out (decoder_libde265.cc:311-336) - with the CTBs it did not
+  // decode holding whatever its image memory held.  What the data DEFINES is the CTBs in front of the error; this parser decodes
+  // exactly those and writes every other CTB - the rest of the damaged slice segment, the segments that depended on it, CTBs no
+  // segment covers - as plain intra CTUs without a residual (hevc_syntax.h: ConcealEC): a valid command stream, a picture, and
+  // hm_pic.concealed_ctbs says how much of it is made up.  Without the option such streams are refused (HM_ERR_BITSTREAM) as before.
+  bool conceal = false;
+  int concealed = 0, first_concealed = -1; // CTBs written by conceal_range; the first one's raster address
+  int last_slice_idx = -1;                 // of the last slice segment that was parsed (concealed CTBs join its slice)
   bool want_split = false;   // the current picture's records go out as split chains (unless it turns out to use rare syntax)
   int threads = 1;           // > 1: slice segments with WPP entry points are parsed row-parallel (parse_rows_parallel)
   void start_stream()
@@ -105,6 +114,7 @@ struct Decoder {
     pic_started = have_prev_sh = picture_done = false;
     cur_sps = nullptr; cur_pps = nullptr;
     next_ts = 0;
+    concealed = 0; first_concealed = -1; last_slice_idx = -1;
   }
   bool pic_started = false;
   const SPS* cur_sps = nullptr;
@@ -141,8 +151,18 @@ struct Decoder {
         pps[q.pps_id] = q;
       }
       else if (nal_type <= 9 || (nal_type >= 16 && nal_type <= 21)) {
-        if (picture_done) return; // a still-image item holds one picture; ignore anything after it
-        slice_nal(br, nal_type, rbsp);
+        if (picture_done && !conceal) return; // a still-image item holds one picture; ignore anything after it
+        // (concealing: a damaged segment may have run on to the picture's last CTB - the segments behind it still take their CTBs over)
+        if (!conceal) slice_nal(br, nal_type, rbsp);
+        else {
+          // a slice segment whose HEADER is damaged is dropped like the reference drops it (decctx.cc:639-712: the NAL's decoding
+          // error ends that NAL only); its CTBs are concealed when the next segment - or the picture's end - shows the gap
+          try { slice_nal(br, nal_type, rbsp); }
+          catch (const ParseError& e) {
+            if (e.status != HM_ERR_BITSTREAM || !pic_started) throw;
+            pic.dep_ok = false;
+          }
+        }
       }
     }
     // VPS (32), AUD, SEI, EOS ...: nothing the reconstruction needs
@@ -152,6 +172,7 @@ struct Decoder {
   {
     SliceHeader sh;
     parse_slice_header(br, nal_type, sps, pps, have_prev_sh ? &prev_sh : nullptr, sh);
+    if (picture_done && sh.first_slice_segment_in_pic) return; // (another picture behind the item's one: ignored)
     const PPS& p = pps[sh.pps_id];
     const SPS& s = sps[p.sps_id];
     // every table the slice walker indexes with CTB / minimum-TB addresses must have the active SPS's size
@@ -194,7 +215,13 @@ struct Decoder {
     slice_idx = (int)pic.slices.size() - 1;
 
     const int start_ts = p.CtbAddrRStoTS[sh.slice_segment_address];
-    if (start_ts != next_ts) throw ParseError(HM_ERR_BITSTREAM, "slice segments out of order or CTBs missing");
+    if (start_ts != next_ts) {
+      // (concealing: the CTBs between the last decoded one and this segment's first - the rest of a damaged segment, a lost one -
+      //  join the slice in front of them)
+      if (conceal && start_ts > next_ts && have_prev_sh && last_slice_idx >= 0) conceal_range(next_ts, start_ts, prev_sh, last_slice_idx);
+      else if (conceal && start_ts < next_ts && !sh.dependent) take_back(start_ts);
+      else throw ParseError(HM_ERR_BITSTREAM, "slice segments out of order or CTBs missing");
+    }
     // slice data starts right after the header in the unescaped payload (+2 for the NAL header)
     const uint8_t* begin = rbsp.data() + 2 + sh.data_byte_offset;
     const uint8_t* end = rbsp.data() + rbsp.size();
@@ -208,11 +235,69 @@ struct Decoder {
     else {
       DecoderEC ec(begin, end);
       SliceWalker<DecoderEC> walker(ec, pic, sh, slice_idx);
-      next_ts = walker.decode_slice_segment(start_ts);
+      if (!conceal) next_ts = walker.decode_slice_segment(start_ts);
+      else {
+        try { next_ts = walker.decode_slice_segment(start_ts); }
+        catch (const ParseError& e) {
+          if (e.status != HM_ERR_BITSTREAM) throw;
+          // the segment ends in front of the CTU it failed in; that CTU is taken back, the tables a dependent segment would inherit
+          // are gone.  How far the segment would have reached shows with the next one (the gap above) or at the picture's end.
+          next_ts = walker.current_ts();
+          walker.discard_current_ctu();
+          pic.dep_ok = false;
+          pic.uses_pcm |= walker.uses_pcm();
+          pic.uses_tq_bypass |= walker.uses_tq_bypass();
+        }
+      }
     }
     prev_sh = sh;
     have_prev_sh = true;
+    last_slice_idx = slice_idx;
     if (next_ts == s.ctb_w * s.ctb_h) picture_done = true;
+  }
+
+  // Concealing: a slice segment that starts INSIDE what the segment in front of it has written - a damaged segment runs on behind
+  // its real end until the arithmetic decoder notices - takes those CTBs over, as in the reference, where every segment decodes into
+  // its own CTBs whatever stood there (decctx.cc: decode_slice_unit_sequential).  The CTBs [ts0, next_ts), the last ones written, are
+  // taken back in reverse order: their records and levels are the tails of their lists.
+  void take_back(int ts0)
+  {
+    const PPS& p = *cur_pps;
+    const SPS& s = *cur_sps;
+    for (int ts = next_ts - 1; ts >= ts0; ts--) {
+      const int rs = p.CtbAddrTStoRS[ts];
+      hm_ctb& c = pic.ctbs[rs];
+      if (!(c.flags & HM_CTB_CODED)) continue;
+      if (pic.direct) {
+        PictureState::RowChains& R = pic.rows[(size_t)(rs / s.ctb_w)];
+        R.tu[0].resize(c.tu_first); R.tu[1].resize(c.tu_first_c);
+        R.lv[0].resize(c.coeff_first); R.lv[1].resize(c.coeff_first_c);
+        c.tu_count = c.tu_count_c = 0;
+      }
+      else {
+        pic.ctb_tus[rs].clear();
+        pic.coeffs.resize(pic.ctb_coeff_mark[rs]);
+      }
+      c.flags &= (uint8_t)~HM_CTB_CODED;
+      __atomic_store_n(&pic.ctb_slice_addr[rs], -1, __ATOMIC_RELAXED);
+    }
+    next_ts = ts0;
+    picture_done = false;
+    pic.dep_ok = false;
+  }
+
+  // CTBs [from_ts, to_ts) in tile scan as concealed CTUs of slice `slice_idx` (header sh)
+  void conceal_range(int from_ts, int to_ts, const SliceHeader& sh, int slice_idx)
+  {
+    const PPS& p = *cur_pps;
+    ConcealEC cec;
+    SliceWalker<ConcealEC> w(cec, pic, sh, slice_idx);
+    for (int ts = from_ts; ts < to_ts; ts++) {
+      if (first_concealed < 0) first_concealed = p.CtbAddrTStoRS[ts];
+      w.decode_ctu(ts);
+      concealed++;
+    }
+    next_ts = to_ts;
   }
 
   // Wavefront-parallel parse of one slice segment whose header carries an entry point per CTB row (WPP, no tiles): the
@@ -494,6 +579,10 @@ struct Decoder {
     const SPS& s = *cur_sps;
     const PPS& p = *cur_pps;
     const int N = s.ctb_w * s.ctb_h;
+    if (!picture_done && conceal && have_prev_sh && last_slice_idx >= 0 && next_ts < N) { // (the picture's last CTBs: lost with a damaged segment)
+      conceal_range(next_ts, N, prev_sh, last_slice_idx);
+      picture_done = true;
+    }
     if (!picture_done) throw ParseError(HM_ERR_BITSTREAM, "picture incomplete: missing slice segments");
 
     // Record order (hm_stream.h): pictures without rare syntax get their luma and chroma records in separate lists,
@@ -625,6 +714,8 @@ struct Decoder {
     h.pps_cb_qp_offset = (int8_t)p.cb_qp_offset;
     h.pps_cr_qp_offset = (int8_t)p.cr_qp_offset;
     h.pcm_loop_filter_disabled = s.pcm_loop_filter_disabled;
+    h.concealed_ctbs = (uint32_t)concealed;
+    h.first_concealed_ctb = first_concealed < 0 ? 0u : (uint32_t)first_concealed + 1u;
     uint32_t flags = 0;
     if (s.strong_intra_smoothing) flags |= HM_PIC_STRONG_INTRA_SMOOTHING;
     if (s.sao_enabled) flags |= HM_PIC_SAO_ENABLED;
@@ -734,8 +825,10 @@ static_assert(sizeof(hm_slice) == 12, "hm_slice layout");
 static_assert(sizeof(hm_sao) == 8, "hm_sao layout");
 static_assert(sizeof(hm_pic) % 4 == 0, "hm_pic layout");
 
-static int hm_hevc_parse_run(const uint8_t* data, size_t size, int annexb, int threads, int record_order, uint8_t** out_blob, size_t* out_size)
+static int hm_hevc_parse_run(const uint8_t* data, size_t size, int annexb, int threads, int record_order_and_flags, uint8_t** out_blob, size_t* out_size)
 {
+  const int record_order = record_order_and_flags & 0xFF;
+  const bool conceal = (record_order_and_flags & HM_PARSE_CONCEAL) != 0;
 #if defined(__BMI2__) || defined(__LZCNT__)
   // this translation unit is built with BMI / BMI2 / LZCNT (Makefile: HOST_ISA): a host without them gets an error, not SIGILL
   if (!hm_host_has_bmi2_lzcnt()) return hm_fail(HM_ERR_UNSUPPORTED, "this build of the entropy decoder needs BMI2 and LZCNT (rebuild with HOST_ISA=)");
@@ -746,6 +839,7 @@ static int hm_hevc_parse_run(const uint8_t* data, size_t size, int annexb, int t
     hm::Decoder* dec = workspace.get();
     dec->threads = threads;
     dec->record_order = record_order;
+    dec->conceal = conceal;
     dec->start_stream();
     if (annexb) {
       // split at 00 00 01 start codes
@@ -812,7 +906,8 @@ int hm_hevc_parse_mt(const uint8_t* data, size_t size, int annexb, int threads, 
 int hm_hevc_parse_opts(const uint8_t* data, size_t size, const hm_parse_options* opts, uint8_t** out_blob, size_t* out_size)
 {
   if (!data || !opts || !out_blob || !out_size) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
-  if (opts->record_order < HM_RECORDS_AUTO || opts->record_order > HM_RECORDS_DECODE_ORDER) return hm_fail(HM_ERR_INVALID_ARG, "record_order %d", opts->record_order);
+  if ((opts->record_order & ~HM_PARSE_CONCEAL) < HM_RECORDS_AUTO || (opts->record_order & ~HM_PARSE_CONCEAL) > HM_RECORDS_DECODE_ORDER)
+    return hm_fail(HM_ERR_INVALID_ARG, "record_order %d", opts->record_order);
   const int annexb = opts->annexb, threads = opts->threads, order = opts->record_order;
   *out_blob = nullptr;
   *out_size = 0;

@@ -195,6 +195,7 @@ struct PictureState {
   std::vector<hm_slice> slices;
   std::vector<std::vector<hm_tu>> ctb_tus; // records per CTB (raster address)
   std::vector<hm_coeff> coeffs;
+  std::vector<uint32_t> ctb_coeff_mark;    // length of `coeffs` when the CTB was started (records in decode order; concealment: take_back)
   // Pictures that cannot turn out to carry rare syntax (no scaling lists, PCM, transquant bypass, 4:4:4 in their
   // parameter sets) are written in their final form while they are parsed ("direct"): per CTB row the compact records
   // (hm_stream.h: hm_tu6) of the luma chain and of the chroma chain with their levels in record order - what remains
@@ -230,6 +231,7 @@ struct PictureState {
     if ((int)ctb_tus.size() != n) ctb_tus.resize(n);
     for (auto& v : ctb_tus) v.clear();
     coeffs.clear();
+    ctb_coeff_mark.assign(n, 0);
     // ... and only the classes the four-chains-per-wave kernel is the faster one for (quad_class)
     direct = want_split &&
              !(s.scaling_list_enabled || s.pcm_enabled || p.transquant_bypass_enabled || s.chroma_format_idc == 3 ||
@@ -259,6 +261,32 @@ inline void fill_square(uint8_t* p, size_t stride, int n, uint8_t v)
   for (int j = 0; j < n; j++) std::memset(p + j * stride, v, (size_t)n);
 }
 
+// The "entropy coder" of a CONCEALED CTU (hevc_parse.cpp: Decoder::conceal_range): a CTU the data does not define - the rest of a
+// slice segment behind an error, CTBs no slice segment covers - is written as the walker itself would parse the plainest CTU
+// there is: no SAO, no split beyond what the picture border and the largest transform force, 2N x 2N intra units whose luma mode is
+// the first most probable one and whose chroma mode is derived from it, no residual.  Every bin the walker can ask for under
+// those answers has a fixed value; a valid command stream comes out, and the kernels need no notion of a missing CTB.
+struct ConcealEC {
+  ContextSet cs;
+  int bin(int, int kind, int)
+  {
+    switch (kind) {
+      case K_PART_MODE: return 1;  // PART_2Nx2N
+      case K_PREV_INTRA: return 1; // prev_intra_luma_pred_flag: the mode is mpm_idx 0
+      default: return 0;           // SAO merge / type, split_cu_flag, cu_transquant_bypass, chroma mode 4, split_transform, cbf, ...
+    }
+  }
+  int bypass(int, int) { return 0; }
+  uint32_t bypass_bits(int, int, int, int) { return 0; }
+  int terminate(int) { return 0; }
+  ContextSet& contexts() { return cs; }
+  void start_substream() {}
+  int pcm_flag() { return 0; }
+  void pcm_begin() {}
+  uint32_t pcm_bits(int) { return 0; }
+  void pcm_end() {}
+};
+
 template <class EC>
 class SliceWalker {
  public:
@@ -282,12 +310,45 @@ class SliceWalker {
     const int rs = pps_.CtbAddrTStoRS[ts];
     ctb_addr_ts_ = ts;
     ctb_addr_rs_ = rs;
+    // (what discard_current_ctu needs to take this CTU back)
+    ctu_started_ = true;
+    ctu_coeff_mark_ = coeffs_->size();
+    if (coeffs_ == &pic_.coeffs) pic_.ctb_coeff_mark[rs] = (uint32_t)ctu_coeff_mark_;
+    ctu_qs_mark_ = *qs_;
+    ctu_pcm_mark_ = uses_pcm_; ctu_bypass_mark_ = uses_tq_bypass_;
     // (relaxed atomics: rows of tiles parsed side by side read the entries of their neighbours across the tile border -
     //  with the same outcome whether the neighbour has been parsed yet or not, see slice_addr_of)
     __atomic_store_n(&pic_.ctb_slice_addr[rs], sh_.SliceAddrRS, __ATOMIC_RELAXED);
     pic_.ctbs[rs].slice_idx = (uint16_t)slice_idx_;
     pic_.ctbs[rs].flags |= HM_CTB_CODED;
     coding_tree_unit(rs % W, rs / W);
+  }
+
+  // Concealment (hevc_parse.cpp: Decoder::conceal): the CTU a damaged slice segment failed in is taken back - its records and
+  // levels, the QP predictor state, the "uses PCM / bypass" marks - so that the picture holds whole CTUs only; the maps it wrote
+  // (coding depth, QpY, intra modes) are overwritten by the CTU that takes its place.
+  int current_ts() const { return ctb_addr_ts_; }
+  bool ctu_started() const { return ctu_started_; }
+  void discard_current_ctu()
+  {
+    if (!ctu_started_) return;
+    const int rs = ctb_addr_rs_;
+    hm_ctb& c = pic_.ctbs[rs];
+    if (pic_.direct) {
+      PictureState::RowChains& R = pic_.rows[(size_t)(rs / sps_.ctb_w)];
+      R.tu[0].resize(c.tu_first); R.tu[1].resize(c.tu_first_c);
+      R.lv[0].resize(c.coeff_first); R.lv[1].resize(c.coeff_first_c);
+      c.tu_count = c.tu_count_c = 0;
+    }
+    else {
+      pic_.ctb_tus[rs].clear();
+      coeffs_->resize(ctu_coeff_mark_);
+    }
+    *qs_ = ctu_qs_mark_;
+    uses_pcm_ = ctu_pcm_mark_; uses_tq_bypass_ = ctu_bypass_mark_;
+    c.flags &= (uint8_t)~HM_CTB_CODED;
+    __atomic_store_n(&pic_.ctb_slice_addr[rs], -1, __ATOMIC_RELAXED);
+    ctu_started_ = false;
   }
 
   // §7.3.8.1 slice_segment_data().  Returns the CTB address (tile scan) following the last decoded CTB.
@@ -306,6 +367,7 @@ class SliceWalker {
   {
     const int W = sps_.ctb_w, N = sps_.ctb_w * sps_.ctb_h;
     int ts = start_ts;
+    ctb_addr_ts_ = start_ts; // (an error before the first CTU is an error at the segment's first CTB)
     const int rs0 = pps_.CtbAddrTStoRS[ts];
     if (sh_.dependent) {
       const bool tile_start = ts == 0 || (pps_.tiles_enabled && pps_.TileId[ts] != pps_.TileId[ts - 1]);
@@ -1196,6 +1258,10 @@ class SliceWalker {
   PictureState::QpState* qs_;
   std::vector<hm_coeff>* coeffs_;
   bool uses_pcm_ = false, uses_tq_bypass_ = false;
+  bool ctu_started_ = false;        // a CTU has been started by this walker (decode_ctu) ...
+  size_t ctu_coeff_mark_ = 0;       // ... with the level list at this length, this QP predictor state and these marks
+  PictureState::QpState ctu_qs_mark_;
+  bool ctu_pcm_mark_ = false, ctu_bypass_mark_ = false;
   int w4_ = 0;
   int ctb_addr_ts_ = 0, ctb_addr_rs_ = 0;
   int ctb_x_ = 0, ctb_y_ = 0;      // current CTB in CTB units

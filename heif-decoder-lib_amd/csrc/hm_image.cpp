@@ -424,6 +424,7 @@ int planar_from_blobs(const hm_file* f, ItemPlan& P, const hm_decode_params* par
     if (warn && params->strict_decoding)
       return hm_fail(HM_ERR_BITSTREAM, "Unknown NCLX %s (strict decoding)", (warn & 1) ? "color primaries" : (warn & 2) ? "transfer characteristics" : "matrix coefficients");
     if (!is_grid) I.warnings |= warn;
+    if (h->concealed_ctbs) I.warnings |= HM_WARN_CONCEALED; // (damaged slice data, HM_PARSE_CONCEAL: of a grid's tiles too - the image is the caller's)
     if (ti && ti->props.colr.present) tp = ti->props.colr; // ... unless the item has a 'colr' nclx (context.cc:1844-1852)
     if (i == 0) native = tp;
     tile_profile[i] = tp;
@@ -656,7 +657,7 @@ void job_parse_tile(DecodeJob& j, int k, int row_threads)
   if (!j.f->file.hevc_data(id, data, e)) { status = e.status; message = e.message; return; }
   hm_parse_options po;
   po.annexb = 0; po.threads = row_threads;
-  po.record_order = j.few_pictures ? HM_RECORDS_SPLIT : HM_RECORDS_AUTO;
+  po.record_order = (j.few_pictures ? HM_RECORDS_SPLIT : HM_RECORDS_AUTO) | (j.params.strict_decoding ? 0 : HM_PARSE_CONCEAL);
   const int rc = hm_hevc_parse_opts(data.data(), data.size(), &po, &blob.p, &blob.n);
   if (rc) { status = rc; message = hm_last_error(); }
 }
@@ -1000,7 +1001,7 @@ int hm_decode_item_devices(const hm_file* f, uint32_t id, const hm_decode_params
         if (!f->file.hevc_data(plan.tiles[i].id, data, e)) { plan.status[i] = e.status; plan.messages[i] = e.message; continue; }
         hm_parse_options po;
         po.annexb = 0; po.threads = 1;
-        po.record_order = few ? HM_RECORDS_SPLIT : HM_RECORDS_AUTO;
+        po.record_order = (few ? HM_RECORDS_SPLIT : HM_RECORDS_AUTO) | (params->strict_decoding ? 0 : HM_PARSE_CONCEAL);
         const int prc = hm_hevc_parse_opts(data.data(), data.size(), &po, &plan.blobs[i].p, &plan.blobs[i].n);
         if (prc) { plan.status[i] = prc; plan.messages[i] = hm_last_error(); }
       }
@@ -1009,6 +1010,9 @@ int hm_decode_item_devices(const hm_file* f, uint32_t id, const hm_decode_params
   }
   for (int i = 0; i < nt; i++)
     if (plan.status[i]) return hm_fail(plan.status[i], "tile %d (item %u): %s", i, plan.tiles[i].id, plan.messages[i].c_str());
+  int tile_warnings = 0;
+  for (int i = 0; i < nt; i++)
+    if (plan.blobs[i].p && reinterpret_cast<const hm_pic*>(plan.blobs[i].p)->concealed_ctbs) tile_warnings |= HM_WARN_CONCEALED;
 
   // ---- the slabs ----
   std::vector<int32_t> first(n_devices), count(n_devices);
@@ -1075,6 +1079,7 @@ int hm_decode_item_devices(const hm_file* f, uint32_t id, const hm_decode_params
   if (bd > 8 && (params->out_format == HM_OUT_RGB || params->out_format == HM_OUT_RGBA)) out->bit_depth = 8;
   out->stride[0] = (int32_t)dst_stride;
   out->plane_width[0] = img_w; out->plane_height[0] = img_h;
+  out->warnings = tile_warnings;
   return HM_OK;
 }
 

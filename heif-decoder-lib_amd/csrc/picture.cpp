@@ -38,15 +38,22 @@ extern "C" {
 
 int hm_picture_parse(const uint8_t* data, size_t size, hm_picture** out, hm_picture_info* info)
 {
+  return hm_picture_parse_opts(data, size, 0, out, info, nullptr);
+}
+
+int hm_picture_parse_opts(const uint8_t* data, size_t size, int strict, hm_picture** out, hm_picture_info* info, int32_t* concealed_ctbs)
+{
   if (!data || !out) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
+  if (concealed_ctbs) *concealed_ctbs = 0;
   *out = nullptr;
   hm_picture* p = new (std::nothrow) hm_picture();
   if (!p) return hm_fail(HM_ERR_NOMEM, "out of memory");
   hm_parse_options po; // one picture per decoder instance (plugin ABI): its rows are the parallel work
-  po.annexb = 0; po.threads = 1; po.record_order = HM_RECORDS_SPLIT;
+  po.annexb = 0; po.threads = 1; po.record_order = HM_RECORDS_SPLIT | (strict ? 0 : HM_PARSE_CONCEAL);
   const int rc = hm_hevc_parse_opts(data, size, &po, &p->blob, &p->blob_size);
   if (rc) { delete p; return rc; }
   const hm_pic* h = reinterpret_cast<const hm_pic*>(p->blob);
+  if (concealed_ctbs) *concealed_ctbs = (int32_t)h->concealed_ctbs;
   hm_picture_info& I = p->info;
   std::memset(&I, 0, sizeof(I));
   // de265_get_image_width/height(img, c): the conformance window, chroma planes divided by SubWidthC / SubHeightC

@@ -143,6 +143,14 @@ HM_API int hm_hevc_parse_mt(const uint8_t* data, size_t size, int annexb, int th
  * (the faster choice when a batch holds few pictures: their rows then become the parallel work) -, HM_RECORDS_DECODE_ORDER.
  * The same bytes always parse to the same stream for the same options: nothing depends on who calls. */
 enum { HM_RECORDS_AUTO = 0, HM_RECORDS_SPLIT = 1, HM_RECORDS_DECODE_ORDER = 2 };
+/* ... | HM_PARSE_CONCEAL (r05): a picture whose SLICE DATA is damaged is not refused - the reference keeps such pictures
+ * (libde265 notes the error and hands the picture out, third-party/libde265/libde265/decctx.cc:876-995,
+ * libheif/plugins/decoder_libde265.cc:311-336).  Every CTB in front of the error is decoded from the data, exactly; every
+ * other CTB - the rest of the damaged slice segment, segments that depended on it, CTBs no segment covers - is written as a
+ * plain intra CTU without a residual (the reference's samples there are whatever its image memory held: nothing to match).
+ * hm_pic.concealed_ctbs / first_concealed_ctb of the command stream say how much was made up.  Damaged parameter sets and a
+ * damaged first slice header remain errors.  hm_decode_item / the facade / the plugin set it unless strict decoding is asked. */
+#define HM_PARSE_CONCEAL 0x100
 typedef struct hm_parse_options {
   int32_t annexb;        /* 0: [u32 length][NAL] records, 1: Annex-B start codes */
   int32_t threads;       /* host threads for the rows of a WPP-coded picture     */
@@ -242,6 +250,10 @@ typedef struct hm_picture_info {
 } hm_picture_info;
 /* host entropy decode (CABAC on the calling thread); *out owns the command stream */
 HM_API int  hm_picture_parse(const uint8_t* data, size_t size, hm_picture** out, hm_picture_info* info);
+/* ... with strict != 0: a picture with damaged slice data is refused (HM_ERR_BITSTREAM) instead of concealed (HM_PARSE_CONCEAL:
+ * what hm_picture_parse does, as the reference's plugin hands such pictures out); *concealed_ctbs (may be NULL): how many CTBs of
+ * the picture are concealment */
+HM_API int  hm_picture_parse_opts(const uint8_t* data, size_t size, int strict, hm_picture** out, hm_picture_info* info, int32_t* concealed_ctbs);
 /* reconstruction + in-loop filters on the GPU, then rows of plane_width * bytes_per_sample bytes into plane[c]
  * (host memory, e.g. heif_image_get_plane()); returns after the copy has completed */
 HM_API int  hm_picture_decode_to_host(hm_picture* p, uint8_t* const plane[3], const int32_t stride[3], void* stream);
@@ -304,7 +316,8 @@ typedef struct hm_decoded {
 } hm_decoded;
 /* non-strict decoding replaces an unknown colour code of the VUI by "unspecified" and records a warning
  * (decoder_libde265.cc:339-357 via heif_nclx_color_profile_set_*, heif.cc:1811-1905) */
-enum { HM_WARN_UNKNOWN_PRIMARIES = 1, HM_WARN_UNKNOWN_TRANSFER = 2, HM_WARN_UNKNOWN_MATRIX = 4 };
+enum { HM_WARN_UNKNOWN_PRIMARIES = 1, HM_WARN_UNKNOWN_TRANSFER = 2, HM_WARN_UNKNOWN_MATRIX = 4,
+       HM_WARN_CONCEALED = 8 /* damaged slice data: part of the picture (of one of a grid's tiles) is concealment, HM_PARSE_CONCEAL */ };
 /* 1 if `value` is a code point libheif knows for kind 0 = colour primaries, 1 = transfer characteristics,
  * 2 = matrix coefficients (the known_* sets of heif.cc:1795-1885) */
 HM_API int hm_nclx_code_known(int kind, int value);

@@ -104,7 +104,9 @@ typedef struct hm_pic {
   uint32_t n_slices, n_ctbs, n_tus, n_coeffs;
   uint32_t off_slices, off_ctbs, off_tus, off_coeffs;
   uint32_t off_scaling;        /* HM_SCALING_BYTES of scaling factors when HM_PIC_SCALING_LIST  */
-  uint32_t reserved1[2];
+  uint32_t concealed_ctbs;     /* CTBs the data did not define (damaged slice data parsed with HM_PARSE_CONCEAL): written as
+                                  plain intra CTUs without a residual; 0 for every intact picture                           */
+  uint32_t first_concealed_ctb;/* raster address + 1 of the first of them (0: none)                                         */
 } hm_pic;
 
 /* one entry per slice (not slice segment) */

@@ -286,7 +286,9 @@ def test_damaged_streams_through_the_plugin(api, hm, strict):
     picture of the same bytes - or fails the way the reference's caller sees a failed libde265 decode: heif_error_
     Decoder_plugin_error / heif_suberror_Unspecified (context.cc:1826-1830), End_of_data for broken [length][NAL] framing
     (decoder_libde265.cc:276-292), Unsupported_feature for syntax outside the decoder; never a crash, never another code.
-    Strict decoding only changes the handling of unknown colour code points, not this."""
+    r05: without strict decoding a picture with damaged SLICE DATA is handed out like the reference's plugin hands it out
+    (decoder_libde265.cc:311-336) - decoded up to the damage, concealed behind it (HM_PARSE_CONCEAL) - and equals the oracle's
+    picture of the same concealing parse; with strict decoding (an extension of what the reference's flag covers) it is refused."""
     import random
     import corpus
     import hevcutil
@@ -296,7 +298,7 @@ def test_damaged_streams_through_the_plugin(api, hm, strict):
     p = api.hm_get_decoder_plugin().contents
     api.hm_get_decoder_plugin.restype = saved
     rng = random.Random(4242 + strict)
-    seen = {"ok": 0, "failed": 0}
+    seen = {"ok": 0, "failed": 0, "concealed": 0}
 
     def mutate(data):
         b = bytearray(data)
@@ -330,7 +332,10 @@ def test_damaged_streams_through_the_plugin(api, hm, strict):
             p.free_decoder(dec)
             if e.code == 0:
                 assert img
-                exp, info = orc.oracle_decode(hevcutil.parse(hm, b), 3, crop=True)
+                # (strict: the parser takes the stream as it is or not at all; otherwise damaged slice data is concealed, HM_PARSE_CONCEAL)
+                blob = hevcutil.parse(hm, b) if strict else hevcutil.parse_concealing(hm, b)[0]
+                seen["concealed"] += 0 if strict else hevcutil.parse_concealing(hm, b)[1] > 0
+                exp, info = orc.oracle_decode(blob, 3, crop=True)
                 stride = C.c_int()
                 ptr = api.heif_image_get_plane_readonly(img, 0, C.byref(stride))
                 w, h = api.heif_image_get_width(img, 0), api.heif_image_get_height(img, 0)
@@ -346,6 +351,7 @@ def test_damaged_streams_through_the_plugin(api, hm, strict):
                     assert (e.code, e.subcode) == (7, 100), (name, e.code, e.subcode, e.message)  # Decoder_plugin_error / End_of_data
                 seen["failed"] += 1
     assert seen["ok"] > 0 and seen["failed"] > 0, seen
+    assert (seen["concealed"] > 20) == (strict == 0), seen  # (without strict decoding most damaged pictures come back, concealed)
 
 
 def test_strict_decoding_and_warnings(api, hm):

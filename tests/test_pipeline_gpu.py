@@ -98,9 +98,13 @@ def test_pipeline_order_and_reference_fingerprints(hm):
 
 def test_pipeline_reports_bad_files_and_keeps_going(hm):
     good = heifwriter.write_heic([synthutil.picture(8800 + t, width=64, height=64) for t in range(4)], (64, 64), grid=(2, 2, 128, 128))
-    # a tile whose slice data is cut: the container parses, the entropy decode of that tile fails
-    broken_tile = synthutil.picture(8811, width=64, height=64)
-    bad = heifwriter.write_heic([synthutil.picture(8810, width=64, height=64), broken_tile[:len(broken_tile) - 40]], (64, 64), grid=(1, 2, 128, 64))
+    # a tile without a coded picture (its slice NALs are gone): the container parses, the entropy decode of that tile fails
+    # (a tile whose slice data is merely cut short is concealed since r05 - HM_PARSE_CONCEAL - and comes back as a picture: below)
+    import hevcutil
+    whole = synthutil.picture(8811, width=64, height=64)
+    broken_tile = hevcutil.join_nals([n for n in hevcutil.split_nals(whole) if ((n[0] >> 1) & 0x3F) > 21])
+    bad = heifwriter.write_heic([synthutil.picture(8810, width=64, height=64), broken_tile], (64, 64), grid=(1, 2, 128, 64))
+    cut = heifwriter.write_heic([synthutil.picture(8810, width=64, height=64), whole[:len(whole) - 40]], (64, 64), grid=(1, 2, 128, 64))
     pl = pipeline.Pipeline(hm, 10, host_threads=2, max_in_flight=4)
     try:
         with pytest.raises(RuntimeError):
@@ -111,6 +115,9 @@ def test_pipeline_reports_bad_files_and_keeps_going(hm):
         assert [r[0] for r in res] == [2, 3, 4]
         assert res[0][1] == 0 and res[2][1] == 0 and res[1][1] < 0 and "tile 1" in res[1][3]["error"]
         np.testing.assert_array_equal(res[0][2][:128, :128 * 3], res[2][2][:128, :128 * 3])
+        assert pl.submit(cut, 7)
+        t7 = pl.next()
+        assert t7[0] == 7 and t7[1] == 0, t7[3]  # damaged slice data: a picture (its damaged part concealed)
         # closing with images still pending is fine
         assert pl.submit(good, 5) and pl.submit(good, 6)
     finally:

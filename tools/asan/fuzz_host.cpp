@@ -82,7 +82,12 @@ int main(int argc, char** argv)
       }
       else {
         uint8_t* blob = nullptr; size_t n = 0;
-        if (hm_hevc_parse(b.data(), b.size(), path.find(".hevc") != std::string::npos ? 1 : 0, &blob, &n) == 0) {
+        // every second mutation through the concealing parse (HM_PARSE_CONCEAL: damaged slice data is taken back to whole CTUs and
+        // filled in - the paths that truncate record lists)
+        hm_parse_options po;
+        po.annexb = path.find(".hevc") != std::string::npos ? 1 : 0; po.threads = 1;
+        po.record_order = (it & 2 ? HM_RECORDS_SPLIT : HM_RECORDS_AUTO) | (it & 1 ? HM_PARSE_CONCEAL : 0);
+        if (hm_hevc_parse_opts(b.data(), b.size(), &po, &blob, &n) == 0) {
           hevc_ok++;
           // the command stream as foreign input: the validator must accept the parser's output and survive anything
           if (hm_stream_validate(blob, n) != 0) {

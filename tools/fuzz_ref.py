@@ -8,6 +8,13 @@ ROOT = "/root/repo"
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import corpus, hevcutil, orc
+if len(sys.argv) > 3 and sys.argv[1] == "--child-planes":  # the reference's luma plane of one stream -> .npy (or nothing)
+    try:
+        planes, _ = orc.ref_decode(open(sys.argv[2], "rb").read(), 0)
+        np.save(sys.argv[3], planes[0])
+    except Exception:
+        pass
+    sys.exit(0)
 if len(sys.argv) > 2 and sys.argv[1] == "--child":  # md5 of the reference's planes of one stream (or "fail")
     try:
         planes, _ = orc.ref_decode(open(sys.argv[2], "rb").read(), 0)
@@ -78,3 +85,94 @@ if "--determinism" in sys.argv:
     print("both accept, pictures differ:", dd, real[:30])
     import collections
     print("the product's reasons for the deterministic ones:", collections.Counter(w[:60] for _, _, w in same_cases).most_common(20))
+
+if "--conceal" in sys.argv:
+    # r05: the same 900 streams with HM_PARSE_CONCEAL.  A stream the strict parser refuses comes back as a picture: every CTB in front of
+    # the damage decoded from the data, the rest concealed.  Against the reference: the CTBs up to one CTB row + 2 in front of the first
+    # concealed one must be the reference's - unless the reference itself gave up earlier (its picture is then memory it never wrote
+    # from there on: two runs under different MALLOC_PERTURB_ differ) - that is checked for every stream that does not match.
+    import struct
+    rng = random.Random(5)
+    st = dict(intact=0, concealed=0, refused=0, reference_fails=0, front_equal=0, front_differs_reference_undefined=0, front_differs_REAL=0, tiles_not_compared=0)
+    real = []
+    with tempfile.TemporaryDirectory() as d:
+        for name in names:
+            data = corpus.stream(name)
+            lo = len(data) // 3
+            for t in range(60):
+                b = bytearray(data)
+                for _ in range(rng.randrange(1, 3)):
+                    b[rng.randrange(lo, len(b))] ^= 1 << rng.randrange(8)
+                b = bytes(b)
+                try:
+                    blob, n_conc, first = hevcutil.parse_concealing(hm, b)
+                except RuntimeError:
+                    st["refused"] += 1
+                    continue
+                if n_conc == 0:
+                    st["intact"] += 1
+                    # a stream the strict parser refuses that needs no concealed CTB: a damaged segment ran on into CTBs the segments
+                    # behind it then took over - the whole picture must be the reference's
+                    try:
+                        hevcutil.parse(hm, b)
+                    except RuntimeError:
+                        mine, _ = orc.oracle_decode(blob, 3, crop=True)
+                        try:
+                            ref, _ = orc.ref_decode(b, 0)
+                            same = len(mine) == len(ref) and all(m.shape == r.shape and np.array_equal(m, r) for m, r in zip(mine, ref))
+                        except Exception:
+                            same = None
+                        key = "taken_over_equal" if same else ("taken_over_reference_fails" if same is None else "taken_over_DIFFERS")
+                        st[key] = st.get(key, 0) + 1
+                    continue
+                st["concealed"] += 1
+                mine, _ = orc.oracle_decode(blob, 3)
+                try:
+                    ref, _ = orc.ref_decode(b, 0)
+                except Exception:
+                    st["reference_fails"] += 1
+                    continue
+                w, h = struct.unpack_from("<HH", blob, 8)
+                cl, cr, ct, cb = struct.unpack_from("<4H", blob, 12)
+                ctb = 1 << blob[23]
+                ctb_w = (w + ctb - 1) // ctb
+                flags = struct.unpack_from("<I", blob, 36)[0]
+                if flags & 0x40:  # HEVC tiles: "in front of" is not raster order
+                    st["tiles_not_compared"] += 1
+                    continue
+
+                def ctb_equal(a, r, c):
+                    x0, y0 = max((c % ctb_w) * ctb, cl), max((c // ctb_w) * ctb, ct)
+                    x1, y1 = min((c % ctb_w) * ctb + ctb, w - cr), min((c // ctb_w) * ctb + ctb, h - cb)
+                    return x1 <= x0 or y1 <= y0 or np.array_equal(a[y0:y1, x0:x1], r[y0 - ct:y1 - ct, x0 - cl:x1 - cl])
+
+                front = range(max(0, first - ctb_w - 2))
+                bad = [c for c in front if not ctb_equal(mine[0], ref[0], c)]
+                if not bad:
+                    st["front_equal"] += 1
+                    continue
+                f = os.path.join(d, "s.bin")
+                open(f, "wb").write(b)
+                runs = []
+                for v in (85, 170):
+                    o = os.path.join(d, f"p{v}.npy")
+                    if os.path.exists(o):
+                        os.remove(o)
+                    subprocess.run([sys.executable, __file__, "--child-planes", f, o], env=dict(os.environ, MALLOC_PERTURB_=str(v)), capture_output=True)
+                    runs.append(np.load(o) if os.path.exists(o) else None)
+                undefined_from = None
+                if runs[0] is not None and runs[1] is not None:
+                    n_ctbs = ctb_w * ((h + ctb - 1) // ctb)
+                    full = lambda p: np.pad(p, ((ct, cb), (cl, cr)))
+                    for c in range(n_ctbs):
+                        x0, y0 = (c % ctb_w) * ctb, (c // ctb_w) * ctb
+                        if not np.array_equal(full(runs[0])[y0:y0 + ctb, x0:x0 + ctb], full(runs[1])[y0:y0 + ctb, x0:x0 + ctb]):
+                            undefined_from = c
+                            break
+                if undefined_from is not None and bad[0] >= undefined_from - ctb_w - 2:
+                    st["front_differs_reference_undefined"] += 1
+                else:
+                    st["front_differs_REAL"] += 1
+                    real.append((name, t, first, bad[0], undefined_from))
+    print("with HM_PARSE_CONCEAL:", st)
+    print("front differs although the reference is defined there:", real[:20])
