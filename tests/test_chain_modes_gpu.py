@@ -110,13 +110,10 @@ def test_bounded_waits_with_several_waves_per_picture():
 def test_partial_last_round_goes_to_a_launch_of_its_own():
     """r05: 5632 pictures = one full round of the 5120 wave-per-picture chains the device holds + 512.  The 512 go to a launch of
     their own on a second stream, in the cut the launcher takes for 512 pictures (rings), beside the full round (9.9 -> 7.9 ms);
-    every picture equals the oracle's; with the knob chain_split = 0 the one launch of r04 takes them all."""
+    every picture equals the oracle's (the knob chain_split = 0 keeps r04's one launch: tools/r05_staircase.sh)."""
     r = _run({"HM_CHECK_COPIES": "5632", "HM_CHAIN_DEBUG": "1"}, "tile512_a", timeout=1200)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
     assert "[k_chain] 512 pictures" in r.stderr and "in a ring" in r.stderr and "[k_chain] 5120 pictures, 5120 waves (one per picture)" in r.stderr, r.stderr
-    r = _run({"HM_CHECK_COPIES": "5632", "HM_CHAIN_DEBUG": "1", "HM_CHAIN_SPLIT": "0"}, "tile512_a", timeout=1200)
-    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
-    assert "[k_chain] 5632 pictures, 5632 waves (one per picture)" in r.stderr, r.stderr
 
 
 def test_two_mid_size_batches_side_by_side_never_starve_each_other():
