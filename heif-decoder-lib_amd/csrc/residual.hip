@@ -113,11 +113,12 @@ __device__ __forceinline__ void big_residual(int16_t* coeff, int16_t* tmp, const
   WAVE_SYNC();
 }
 
-// Six waves per SIMD (<= 80 VGPRs): the kernel lives on the latency of its two memory round trips per chunk, which only more
+// Seven waves per SIMD (<= 72 VGPRs): the kernel lives on the latency of its two memory round trips per chunk, which only more
 // waves hide.  Without the hint the allocator settles at 85 registers = five waves (r04: 7.0-8.2 ms instead of 6.3 for the
-// headline); with it everything fits without spilling.  HM_R_WPE overrides (A/B builds).
+// headline); six waves (80 registers): 6.6-6.8 ms; seven (72, no vector spill, 17 scalars parked in vector lanes): 6.5 (r05); eight: 7.0.
+// HM_R_WPE overrides (A/B builds).
 #ifndef HM_R_WPE
-#define HM_R_WPE 6
+#define HM_R_WPE 7
 #endif
 #define HM_R_ATTR __attribute__((amdgpu_waves_per_eu(HM_R_WPE, HM_R_WPE)))
 __global__ __launch_bounds__(R_WAVES * 64) HM_R_ATTR void k_residual(const hm_dev_pic* __restrict__ pics, int n_pics, int max_ctb_h, int segs)
