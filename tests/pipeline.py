@@ -76,10 +76,10 @@ class HeifFile:
         self.hm.hm_free(p)
         return out
 
-    def decode(self, iid, out_format, threads=1, upsampling=0, copy=True, ignore_transformations=0):
+    def decode(self, iid, out_format, threads=1, upsampling=0, copy=True, ignore_transformations=0, strict=0):
         """GPU path through the C ABI; returns (array rows x stride, Decoded meta); copy=False only times the call
         (the pinned result is released without being copied into numpy arrays)."""
-        prm = DecodeParams(out_format, threads, ignore_transformations, upsampling, None, None, 0, 0)
+        prm = DecodeParams(out_format, threads, ignore_transformations, upsampling, None, None, 0, 0, strict, 0)
         d = Decoded()
         rc = self.hm.hm_decode_item(self.h, iid, C.byref(prm), C.byref(d))
         if rc:
@@ -96,6 +96,7 @@ class HeifFile:
         meta["stride"] = [d.stride[c] for c in range(3)]
         meta["plane_size"] = [(d.plane_width[c], d.plane_height[c]) for c in range(3)]
         meta["has_alpha"] = d.has_alpha
+        meta["warnings"] = d.warnings
         if copy and d.alpha:
             rows = max(64, (d.height + 1) & ~1)
             meta["alpha"] = np.ctypeslib.as_array(d.alpha, shape=(rows, d.alpha_stride)).copy()
@@ -178,7 +179,8 @@ def cpu_decode(hm, tiles, tile_w, tile_h, canvas_w, canvas_h, cols, is_grid, out
         if decoder == "ref":
             planes, info = orc.ref_decode(data, 0)
         else:
-            planes, info = orc.oracle_decode(hevcutil.parse(hm, data), 3)
+            blob = hevcutil.parse_concealing(hm, data)[0] if decoder == "oracle_concealing" else hevcutil.parse(hm, data)
+            planes, info = orc.oracle_decode(blob, 3)
             cf = info["chroma"]
             tcw, tch = (tile_w if cf == 3 else (tile_w + 1) // 2), ((tile_h + 1) // 2 if cf == 1 else tile_h)
             planes = [planes[0][:tile_h, :tile_w], planes[1][:tch, :tcw], planes[2][:tch, :tcw]]
