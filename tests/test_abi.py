@@ -145,7 +145,7 @@ def test_tuning_knobs_are_not_read_from_the_environment(pkg, hm):
     hm.hm_debug_set.argtypes = [C.c_char_p, C.c_int]
     assert hm.hm_debug_set(b"no_such_knob", 1) == -1
     for name in knobs.ENV_TO_KNOB.values():
-        assert name in ("chain_spin_limit", "chain_test_stall") or hm.hm_debug_set(name.encode(), {"chain_alt": 1, "tail_fused": 1}.get(name, -1 if name in ("chain_pairs", "chain_ring", "quad_class") else 0)) == 0, name
+        assert name in ("chain_spin_limit", "chain_test_stall") or hm.hm_debug_set(name.encode(), {"chain_alt": 1, "tail_fused": 1, "chain_split": 1}.get(name, -1 if name in ("chain_pairs", "chain_ring", "quad_class") else 0)) == 0, name
     here = os.path.dirname(pkg.capi.LIB_PATH)
     for so in glob.glob(os.path.join(here, "*.so")):
         blob = open(so, "rb").read()
