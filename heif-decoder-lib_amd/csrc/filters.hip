@@ -720,7 +720,7 @@ struct SaoRow {
 template <typename Pix, int HX, int VY>
 __device__ __forceinline__ void sao_edge_group(int xs, int yy, int W, int Hh, int l2w, int l2h, int cx, int cy, uint32_t nbm,
                                                uint32_t offs, uint32_t maxv2, const SaoRow<Pix>& up, const SaoRow<Pix>& cur,
-                                               const SaoRow<Pix>& dn, uint32_t (&out)[4])
+                                               const SaoRow<Pix>& dn, uint32_t (&out)[4], bool all_ok = false)
 {
   constexpr int G = 8;
   const int ya = yy + VY, yb = yy - VY;
@@ -743,15 +743,20 @@ __device__ __forceinline__ void sao_edge_group(int xs, int yy, int W, int Hh, in
     A.shifted(HX, HX < 0 ? A.left() : A.right(), qa);
     B.shifted(-HX, HX < 0 ? B.right() : B.left(), qb);
   }
-  const bool has_l = xs > 0, has_r = xs + G < W;
-  const bool mid_ok = rows_ok && perm(dya, 0) && perm(dyb, 0);
-  // the first / last sample of the group may look into the CTB column to the left / right
-  const int dxl = ((xs - 1) >> l2w) - cx, dxr = ((xs + G) >> l2w) - cx;
-  const bool first_ok = HX == 0 ? mid_ok : rows_ok && has_l && perm(HX < 0 ? dya : dyb, dxl) && perm(HX < 0 ? dyb : dya, 0);
-  const bool last_ok = HX == 0 ? mid_ok : rows_ok && has_r && perm(HX > 0 ? dya : dyb, dxr) && perm(HX > 0 ? dyb : dya, 0);
-  const uint32_t m_mid = mid_ok ? 0xFFFFFFFFu : 0u;
-  const uint32_t m_first = (first_ok ? 0x0000FFFFu : 0u) | (m_mid & 0xFFFF0000u);
-  const uint32_t m_last = (last_ok ? 0xFFFF0000u : 0u) | (m_mid & 0x0000FFFFu);
+  // all_ok (k_tail420, a wave inside ONE CTB all of whose eight neighbours may be read - the CTB lies inside the picture, slice
+  // and tile -: the same for every lane): every neighbour sample exists and may be used, no mask to work out
+  uint32_t m_mid = 0xFFFFFFFFu, m_first = 0xFFFFFFFFu, m_last = 0xFFFFFFFFu;
+  if (!all_ok) {
+    const bool has_l = xs > 0, has_r = xs + G < W;
+    const bool mid_ok = rows_ok && perm(dya, 0) && perm(dyb, 0);
+    // the first / last sample of the group may look into the CTB column to the left / right
+    const int dxl = ((xs - 1) >> l2w) - cx, dxr = ((xs + G) >> l2w) - cx;
+    const bool first_ok = HX == 0 ? mid_ok : rows_ok && has_l && perm(HX < 0 ? dya : dyb, dxl) && perm(HX < 0 ? dyb : dya, 0);
+    const bool last_ok = HX == 0 ? mid_ok : rows_ok && has_r && perm(HX > 0 ? dya : dyb, dxr) && perm(HX > 0 ? dyb : dya, 0);
+    m_mid = mid_ok ? 0xFFFFFFFFu : 0u;
+    m_first = (first_ok ? 0x0000FFFFu : 0u) | (m_mid & 0xFFFF0000u);
+    m_last = (last_ok ? 0xFFFF0000u : 0u) | (m_mid & 0x0000FFFFu);
+  }
   // table index = edgeIdx + 2: offsets 0, 1 for -2, -1; none for 0; offsets 2, 3 for +1, +2
   const uint32_t biased = offs ^ 0x80808080u;
   const uint32_t t_lo = (biased & 0x0000FFFFu) | 0x00800000u | ((biased & 0x00FF0000u) << 8), t_hi = biased >> 24;
@@ -1004,9 +1009,18 @@ __device__ __forceinline__ void tail_sao(const hm_dev_pic& dp, const PicView& v,
                                          uint32_t rec_s1 = 0)
 {
   SaoRow<uint8_t> rows[NR + 2];
+  // UNI: the CTB's parameters are known (scalars) before anything is read - the row above the group's first and the row below
+  // its last are only looked at by the edge classes with a vertical component (r05: they were fetched unconditionally, as in
+  // k_sao_paste, where the trip to memory had to start before the parameters were known; here the rows come from LDS)
+  bool need_vertical = true;
+  if (UNI) {
+    const bool on = apply_sao && (dp.flags & HM_PIC_SAO_ENABLED) && (rec_flags & (c == 0 ? HM_CTB_SAO_LUMA : HM_CTB_SAO_CHROMA));
+    need_vertical = on && (rec_s0 & 0xFF) == 2 && ((rec_s0 >> 8) & 0xFF) != 0;
+  }
 #pragma unroll
   for (int r = 0; r < NR + 2; r++) {
     const int y = yy0 - 1 + r;
+    if ((r == 0 || r == NR + 1) && !need_vertical) { rows[r] = SaoRow<uint8_t>(); continue; }
     tail_row(rows[r], tile, pitch, (y < 0 ? 0 : (y < Hh ? y : Hh - 1)) - ty0, xs - tx0);
   }
   const int cx = xs >> l2w;
@@ -1045,10 +1059,11 @@ __device__ __forceinline__ void tail_sao(const hm_dev_pic& dp, const PicView& v,
     }
     else if (type == 2) {
       const int cl = (s0 >> 8) & 0xFF;
-      if (cl == 0) sao_edge_group<uint8_t, -1, 0>(xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv2, up, cur, dn, res[r]);
-      else if (cl == 1) sao_edge_group<uint8_t, 0, -1>(xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv2, up, cur, dn, res[r]);
-      else if (cl == 2) sao_edge_group<uint8_t, -1, -1>(xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv2, up, cur, dn, res[r]);
-      else sao_edge_group<uint8_t, 1, -1>(xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv2, up, cur, dn, res[r]);
+      const bool all_ok = UNI && nbm == 0xFFu; // (the CTB's eight neighbours exist and may be read: nothing to mask)
+      if (cl == 0) sao_edge_group<uint8_t, -1, 0>(xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv2, up, cur, dn, res[r], all_ok);
+      else if (cl == 1) sao_edge_group<uint8_t, 0, -1>(xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv2, up, cur, dn, res[r], all_ok);
+      else if (cl == 2) sao_edge_group<uint8_t, -1, -1>(xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv2, up, cur, dn, res[r], all_ok);
+      else sao_edge_group<uint8_t, 1, -1>(xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv2, up, cur, dn, res[r], all_ok);
     }
   }
 }
