@@ -1421,9 +1421,11 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
 #if defined(HM_T_PROBE) && (HM_T_PROBE & 4)
           const int rt = u, gt = w, bt = u; // probe: no matrix
 #else
-          const int rt = (k.r_cr * w + Kr) >> 8;               // yuv2rgb.cc:359
-          const int gt = (k.g_cb * u + k.g_cr * w + Kg) >> 8;  // :360
-          const int bt = (k.b_cb * u + Kb) >> 8;               // :361
+          // (24-bit multiplies: 8-bit samples x coefficients below 2^11 - as plain C the compiler picks v_mul_lo_u32, a quarter-rate
+          //  instruction: the sixteen of them per lane were a tenth of the kernel's vector issue time, r05)
+          const int rt = (__mul24(k.r_cr, w) + Kr) >> 8;                        // yuv2rgb.cc:359
+          const int gt = (__mul24(k.g_cb, u) + __mul24(k.g_cr, w) + Kg) >> 8;   // :360
+          const int bt = (__mul24(k.b_cb, u) + Kb) >> 8;                        // :361
 #endif
           const uint32_t rt2 = __builtin_amdgcn_perm((uint32_t)rt, (uint32_t)rt, 0x01000100u), gt2 = __builtin_amdgcn_perm((uint32_t)gt, (uint32_t)gt, 0x01000100u),
                          bt2 = __builtin_amdgcn_perm((uint32_t)bt, (uint32_t)bt, 0x01000100u);
