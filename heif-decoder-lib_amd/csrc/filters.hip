@@ -1427,12 +1427,17 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
           const int gt = (__mul24(k.g_cb, u) + __mul24(k.g_cr, w) + Kg) >> 8;   // :360
           const int bt = (__mul24(k.b_cb, u) + Kb) >> 8;                        // :361
 #endif
-          const uint32_t rt2 = __builtin_amdgcn_perm((uint32_t)rt, (uint32_t)rt, 0x01000100u), gt2 = __builtin_amdgcn_perm((uint32_t)gt, (uint32_t)gt, 0x01000100u),
-                         bt2 = __builtin_amdgcn_perm((uint32_t)bt, (uint32_t)bt, 0x01000100u);
+          // (the term of both pixels of a pair: its low half on both halves of the packed add - v_pk_add_u16 with op_sel_hi:[1,0]
+          //  takes it from there, no splat instruction)
+          auto add_lo = [](uint32_t y2, int t) -> uint32_t {
+            uint32_t d;
+            asm("v_pk_add_u16 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(y2), "v"(t));
+            return d;
+          };
 #pragma unroll
           for (int r = 0; r < 2; r++) {
-            const s16x2 y2 = as_s(ry[r][c]); // the pixels 2c, 2c + 1 of the row
-            const uint32_t R = sat_pk(as_w(y2 + as_s(rt2))), G = sat_pk(as_w(y2 + as_s(gt2))), B = sat_pk(as_w(y2 + as_s(bt2)));
+            const uint32_t y2 = ry[r][c]; // the pixels 2c, 2c + 1 of the row
+            const uint32_t R = sat_pk(add_lo(y2, rt)), G = sat_pk(add_lo(y2, gt)), B = sat_pk(add_lo(y2, bt));
             rg[r][q] = R | (G << 16);
             bb[r][q] = B;
           }
