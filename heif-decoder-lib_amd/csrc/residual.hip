@@ -31,7 +31,7 @@
 namespace {
 
 constexpr int R_WAVES = 4;                          // waves (= row chains) per workgroup: they share the tables
-constexpr int R_TABLES = 1024 + 256 + 128;          // dct basis (int8 [32][32]), small tables (recon.hip), 8-point pairs
+constexpr int R_TABLES_SMALL = 1024 + 256 + 128;    // dct basis (int8 [32][32]), small tables (recon.hip), 8-point pairs
 constexpr int R_STAGE = 256;                        // levels of a chunk of 64 records staged in LDS (the rest - dense chunks - is read in place)
 constexpr int R_WAVE = 2048 + 1024 + 4 * 16 * 4 + R_STAGE * 4; // per wave: coefficient block (32x32 int16), 16-row intermediate, 4x4 gather slots, levels
 
@@ -63,53 +63,95 @@ __device__ __forceinline__ uint32_t wave_scan(uint32_t v)
 }
 
 // 16x16 / 32x32 block: levels -> dense coefficient block in LDS -> column transform -> row transform -> HBM.
-// `coeff` is all zero on entry and on exit.  Rows / columns beyond the last non-zero coefficient contribute nothing:
-// the sums stop at (my, mx).  fallback-dct.cc:592-733.
+// `coeff` is all zero on entry and on exit.  fallback-dct.cc:592-733.
+// r05: four out of five of these blocks hold all their levels in the top-left 4x4 corner (bench tiles: 81 %; nine out of ten blocks
+// fewer than eight levels), and rows / columns beyond the last non-zero coefficient contribute nothing: both stages run over
+// GROUPS OF FOUR inputs - kx / ky = groups that hold a level - with v_dot2_i32_i16 on 8-byte LDS reads (the coefficient block lies
+// column-major, the basis `mt` as 16-bit rows M[.][i]: the four inputs of a group and their weights are one read each); stage 1
+// only works out the 4 kx columns stage 2 reads.  A block with one group each way: 1 + nT / 4 trips of two dot products instead of
+// nT / 2 trips of loops over single products (330 -> ~90 vector instructions per block).
+template <int L2>
+struct BigGeom {
+  static constexpr int nT = 1 << L2;
+  static constexpr int MT_STRIDE = nT + 4; // int16 per basis row: 8-byte reads of 16 / 32 consecutive rows fall into distinct LDS banks
+};
+constexpr int R_MT16 = 16 * BigGeom<4>::MT_STRIDE * 2, R_MT32 = 32 * BigGeom<5>::MT_STRIDE * 2; // bytes
+constexpr int R_TABLES = R_TABLES_SMALL + R_MT16 + R_MT32; // ... + the 16- and 32-point bases as 16-bit rows
+static_assert(R_TABLES % 16 == 0, "the waves' blocks are read 16 bytes at a time");
+// maximum of a value < 8 over the active lanes (ballots: one vector compare per bit)
+__device__ __forceinline__ int wave_max3(int v)
+{
+  int m = 0;
+#pragma unroll
+  for (int b = 2; b >= 0; b--) {
+    const int t = m | (1 << b);
+    if (ballot(v >= t)) m = t;
+  }
+  return m;
+}
 template <int L2, typename Levels>
-__device__ __forceinline__ void big_residual(int16_t* coeff, int16_t* tmp, const int8_t* dct, const int16_t* tab, Levels cf,
+__device__ __forceinline__ void big_residual(int16_t* coeff, int16_t* tmp, const int16_t* mt, const int16_t* tab, Levels cf,
                                              int n_coeff, int qP, int bit_depth, GLOBAL_AS int16_t* __restrict__ out, int lane)
 {
-  constexpr int nT = 1 << L2, log2 = L2;
+  constexpr int nT = 1 << L2, log2 = L2, MS = BigGeom<L2>::MT_STRIDE;
   const int bdShift = bit_depth + log2 - 9;
   const int32_t offset = 1 << (bdShift - 1);
   const int32_t fact = (int32_t)tab[70 + qP % 6] << (qP / 6);
   const int maxv = (1 << bit_depth) - 1;
-  int mx = 0, my = 0;
+  int gx = 0, gy = 0; // the lane's last group of four columns / rows with a level
 #pragma unroll 1
   for (int i = lane; i < n_coeff; i += 64) {
     const uint32_t raw = cf(i);
     const int pos = raw & (nT * nT - 1), value = (int)(int16_t)(raw >> 16);
     const int32_t prod = (int32_t)((uint32_t)mul24(value, fact) + (uint32_t)offset); // the reference's wrapping int32 product (Q3)
-    coeff[pos] = (int16_t)clip3i(-32768, 32767, prod >> bdShift);
     const int px = pos & (nT - 1), py = pos >> log2;
-    mx = px > mx ? px : mx;
-    my = py > my ? py : my;
+    coeff[px * nT + py] = (int16_t)clip3i(-32768, 32767, prod >> bdShift); // column-major
+    gx = (px >> 2) > gx ? (px >> 2) : gx;
+    gy = (py >> 2) > gy ? (py >> 2) : gy;
   }
-  mx = wave_max5(mx);
-  my = wave_max5(my);
+  const int kx = wave_max3(gx) + 1, ky = wave_max3(gy) + 1;
   WAVE_SYNC();
   const int postShift = 20 - bit_depth, rnd2 = 1 << (postShift - 1);
-  const int fct = 32 >> log2;
-  constexpr int rpp = nT < 16 ? nT : 16, n_part = rpp << log2; // the intermediate holds 16 rows
-  for (int i0 = 0; i0 < nT; i0 += rpp) {
-    lanes_loop<n_part>(lane, [&](int p) {
-      const int cc = p & (nT - 1), ir = p >> log2, i = i0 + ir;
-      int sum = 0;
-      if (cc <= mx)
-        for (int j = 0; j <= my; j++) sum += mul24((int)dct[(fct * j) * 32 + i], (int)coeff[cc + j * nT]);
-      tmp[cc + ir * nT] = (int16_t)clip3i(-32768, 32767, (sum + 64) >> 7);
-    });
+  constexpr int TR = nT / 4, YS = 64 >> log2; // stage 2: trips per 16 rows, rows per trip
+  const int i2 = lane & (nT - 1), y2 = lane >> log2;
+  for (int i0 = 0; i0 < nT; i0 += 16) {
+    // stage 1 (columns), rows i0 .. i0 + 15 of the intermediate, columns < 4 kx: lane = (row ir, column cc)
+#pragma unroll 1
+    for (int t = 0; t < kx; t++) {
+      const int ir = lane & 15, cc = (lane >> 4) + 4 * t;
+      const int16_t* const mrow = mt + (i0 + ir) * MS;
+      const int16_t* const ccol = coeff + cc * nT;
+      int sum = 64;
+#pragma unroll 1
+      for (int q = 0; q < ky; q++) {
+        const r_u32x2 m = *reinterpret_cast<const r_u32x2*>(mrow + 4 * q), c = *reinterpret_cast<const r_u32x2*>(ccol + 4 * q);
+        sum = rdot2(c.y, m.y, rdot2(c.x, m.x, sum));
+      }
+      tmp[ir * nT + cc] = (int16_t)clip3i(-32768, 32767, sum >> 7);
+    }
     WAVE_SYNC();
-    lanes_loop<n_part>(lane, [&](int p) {
-      const int i = p & (nT - 1), yr = p >> log2, y = i0 + yr;
-      int sum = 0;
-      for (int j = 0; j <= mx; j++) sum += mul24((int)dct[(fct * j) * 32 + i], (int)tmp[yr * nT + j]);
-      out[mul24(y, nT) + i] = limit_res((sum + rnd2) >> postShift, maxv); // stage 2 is not clipped to 16 bit (Q4)
-    });
+    // stage 2 (rows): lane = column i2 of the rows y2, y2 + YS, ... of the sixteen
+    int acc[TR];
+#pragma unroll
+    for (int t = 0; t < TR; t++) acc[t] = rnd2;
+#pragma unroll 1
+    for (int q = 0; q < kx; q++) {
+      const r_u32x2 m = *reinterpret_cast<const r_u32x2*>(mt + i2 * MS + 4 * q);
+#pragma unroll
+      for (int t = 0; t < TR; t++) {
+        const r_u32x2 v = *reinterpret_cast<const r_u32x2*>(tmp + (y2 + YS * t) * nT + 4 * q);
+        acc[t] = rdot2(v.y, m.y, rdot2(v.x, m.x, acc[t]));
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TR; t++) out[mul24(i0 + y2 + YS * t, nT) + i2] = limit_res(acc[t] >> postShift, maxv); // stage 2 is not clipped to 16 bit (Q4)
     WAVE_SYNC();
   }
 #pragma unroll 1
-  for (int i = lane; i < n_coeff; i += 64) coeff[cf(i) & (nT * nT - 1)] = 0;
+  for (int i = lane; i < n_coeff; i += 64) {
+    const int pos = cf(i) & (nT * nT - 1);
+    coeff[(pos & (nT - 1)) * nT + (pos >> log2)] = 0;
+  }
   WAVE_SYNC();
 }
 
@@ -120,6 +162,11 @@ __device__ __forceinline__ void big_residual(int16_t* coeff, int16_t* tmp, const
 #ifndef HM_R_WPE
 #define HM_R_WPE 7
 #endif
+// HM_R_SKIP (tools/probe_chain.sh, OBJ=residual): parts compiled out to count their instructions - 1 / 2 the DC-only 4x4 / larger
+// blocks, 4 / 8 / 16 the 4x4 / 8x8 / 16x16 + 32x32 transforms, 32 the block map, 64 availability + micro-op (residuals and pictures wrong)
+#ifndef HM_R_SKIP
+#define HM_R_SKIP 0
+#endif
 #define HM_R_ATTR __attribute__((amdgpu_waves_per_eu(HM_R_WPE, HM_R_WPE)))
 __global__ __launch_bounds__(R_WAVES * 64) HM_R_ATTR void k_residual(const hm_dev_pic* __restrict__ pics, int n_pics, int max_ctb_h, int segs)
 {
@@ -128,6 +175,8 @@ __global__ __launch_bounds__(R_WAVES * 64) HM_R_ATTR void k_residual(const hm_de
   int8_t* const dct = reinterpret_cast<int8_t*>(lds);
   int16_t* const tab = reinterpret_cast<int16_t*>(lds + 1024);
   uint32_t* const w8 = reinterpret_cast<uint32_t*>(lds + 1024 + 256);
+  int16_t* const mt16 = reinterpret_cast<int16_t*>(lds + R_TABLES_SMALL);
+  int16_t* const mt32 = reinterpret_cast<int16_t*>(lds + R_TABLES_SMALL + R_MT16);
   for (int i = tid; i < 1024; i += R_WAVES * 64) {
     const int k = i >> 5, n = i & 31;
     const int m = (k * (2 * n + 1)) & 127;
@@ -157,6 +206,12 @@ __global__ __launch_bounds__(R_WAVES * 64) HM_R_ATTR void k_residual(const hm_de
   for (int t = tid; t < 32; t += R_WAVES * 64) {
     const int i = t >> 2, k = t & 3;
     w8[t] = ((uint32_t)(uint16_t)(int16_t)dct[(4 * (2 * k)) * 32 + i]) | ((uint32_t)(uint16_t)(int16_t)dct[(4 * (2 * k + 1)) * 32 + i] << 16);
+  }
+  // ... and the 16- / 32-point bases as rows of 16-bit weights: mt[i][j] = M[j][i] = dct[(32 / nT) j][i] (big_residual)
+  for (int t = tid; t < 256 + 1024; t += R_WAVES * 64) {
+    const bool big = t >= 256;
+    const int u = big ? t - 256 : t, i = big ? u >> 5 : u >> 4, j = big ? u & 31 : u & 15;
+    (big ? mt32 + i * BigGeom<5>::MT_STRIDE : mt16 + i * BigGeom<4>::MT_STRIDE)[j] = (int16_t)dct[((big ? 1 : 2) * j) * 32 + i];
   }
   __syncthreads();
 
@@ -255,8 +310,8 @@ __global__ __launch_bounds__(R_WAVES * 64) HM_R_ATTR void k_residual(const hm_de
     //      as a CTB is wide).  The place of the block's residual (op.z) follows from the scan below. ----
     const int x4 = (int)(r0 & 15), y4 = (int)((r0 >> 4) & 15);
     const int info = (int)((r0 >> 8) & 0xFF), l2 = info & HM_TU_LOG2_MASK;
-    mop_u32x4 mop;
-    {
+    mop_u32x4 mop = {r0, 0u, 0u, 0u};
+    if (!(HM_R_SKIP & 64)) {
       const int lw = kind ? sub_w : 0, lh = kind ? sub_h : 0;
       const int nT = 1 << l2;
       const int xin = x4 << 2, yc = (row << (dp.log2_ctb - lh)) + (y4 << 2); // x inside the CTB / y in the picture, samples of the plane
@@ -298,11 +353,20 @@ __global__ __launch_bounds__(R_WAVES * 64) HM_R_ATTR void k_residual(const hm_de
     // level number i of a block whose levels start at index `first`
     auto level = [&](uint32_t first, uint32_t i) -> uint32_t {
       const uint32_t rel = first - chunk_lev + i;
-      return rel < (uint32_t)R_STAGE ? lvl[rel] : coeffs[first + i];
+      uint32_t v;
+      if (rel < (uint32_t)R_STAGE) v = lvl[rel];
+      else {
+        // (a level beyond the staged ones - dense chunks only - comes from memory and is WAITED FOR HERE, inside the branch: loads
+        //  and stores share one in-order counter, and a wait at the use - behind the merge, where the compiler puts it - is
+        //  executed by every pass and waits for the previous pass's residual STORES: a trip to HBM per block, r05)
+        v = coeffs[first + i];
+        asm volatile("" : "+v"(v));
+      }
+      return v;
     };
     // ---- the block map of the deblocking filter (luma chains): per 4x4 block the transform edges on its left / on top
     //      (bit 0 / bit 1) and QpY (bits 8-15), deblock.cc:31-62 of the reference ----
-    if (kind == 0) {
+    if (kind == 0 && !(HM_R_SKIP & 32)) {
       // the CTB of every record of the chunk: the CTBs that start inside it are marked at their first record, a scan
       // counts them (every CTB has records, so at most 63 start behind the chunk's first record)
       if (cand_ok) {
@@ -374,7 +438,7 @@ __global__ __launch_bounds__(R_WAVES * 64) HM_R_ATTR void k_residual(const hm_de
       return clip3i(-32768, 32767, prod >> bdShift);
     };
     // 4x4, four per pass
-    for (unsigned long long m4 = ballot(dc_only && l2 == 2); m4;) {
+    for (unsigned long long m4 = (HM_R_SKIP & 1) ? 0 : ballot(dc_only && l2 == 2); m4;) {
       int b[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) {
@@ -393,7 +457,7 @@ __global__ __launch_bounds__(R_WAVES * 64) HM_R_ATTR void k_residual(const hm_de
       if (act) res4[(size_t)(chunk + (uint32_t)myb) * 16 + (uint32_t)gl] = limit_res(res, maxv);
     }
     // 8x8 and larger: one constant per block, written by all lanes
-    for (unsigned long long mdc = ballot(dc_only && l2 >= 3); mdc; mdc &= mdc - 1) {
+    for (unsigned long long mdc = (HM_R_SKIP & 2) ? 0 : ballot(dc_only && l2 >= 3); mdc; mdc &= mdc - 1) {
       const int b = (int)__builtin_ctzll(mdc);
       const uint32_t s_r0 = (uint32_t)__builtin_amdgcn_readlane((int)r0, b), s_raw = (uint32_t)__builtin_amdgcn_readlane((int)first_level, b);
       const uint32_t s_ro = (uint32_t)__builtin_amdgcn_readlane((int)ro, b);
@@ -408,7 +472,7 @@ __global__ __launch_bounds__(R_WAVES * 64) HM_R_ATTR void k_residual(const hm_de
     }
 
     // ---- 4x4 blocks, four per pass ----
-    for (unsigned long long m4 = ballot(cbf && l2 == 2 && !dc_only); m4;) {
+    for (unsigned long long m4 = (HM_R_SKIP & 4) ? 0 : ballot(cbf && l2 == 2 && !dc_only); m4;) {
       int b[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) {
@@ -461,7 +525,7 @@ __global__ __launch_bounds__(R_WAVES * 64) HM_R_ATTR void k_residual(const hm_de
     }
 
     // ---- 8x8 blocks, one per pass, one sample per lane ----
-    for (unsigned long long m8 = ballot(cbf && l2 == 3 && !dc_only); m8; m8 &= m8 - 1) {
+    for (unsigned long long m8 = (HM_R_SKIP & 8) ? 0 : ballot(cbf && l2 == 3 && !dc_only); m8; m8 &= m8 - 1) {
       const int b = (int)__builtin_ctzll(m8);
       const uint32_t s_r0 = (uint32_t)__builtin_amdgcn_readlane((int)r0, b), s_cnt = (uint32_t)__builtin_amdgcn_readlane((int)cnt, b);
       const uint32_t s_lo = (uint32_t)__builtin_amdgcn_readlane((int)lo, b), s_ro = (uint32_t)__builtin_amdgcn_readlane((int)ro, b);
@@ -494,14 +558,14 @@ __global__ __launch_bounds__(R_WAVES * 64) HM_R_ATTR void k_residual(const hm_de
     }
 
     // ---- 16x16 and 32x32 blocks ----
-    for (unsigned long long mb = ballot(cbf && l2 >= 4 && !dc_only); mb; mb &= mb - 1) {
+    for (unsigned long long mb = (HM_R_SKIP & 16) ? 0 : ballot(cbf && l2 >= 4 && !dc_only); mb; mb &= mb - 1) {
       const int b = (int)__builtin_ctzll(mb);
       const uint32_t s_r0 = (uint32_t)__builtin_amdgcn_readlane((int)r0, b), s_cnt = (uint32_t)__builtin_amdgcn_readlane((int)cnt, b);
       const uint32_t s_lo = (uint32_t)__builtin_amdgcn_readlane((int)lo, b), s_ro = (uint32_t)__builtin_amdgcn_readlane((int)ro, b);
       const int qP = (int)(s_r0 >> 24);
       auto cf = [&](int i) -> uint32_t { return level(s_lo, (uint32_t)i); };
-      if (((s_r0 >> 8) & HM_TU_LOG2_MASK) == 4) big_residual<4>(coeff, tmp, dct, tab, cf, (int)s_cnt, qP, bd, resid + s_ro, lane);
-      else big_residual<5>(coeff, tmp, dct, tab, cf, (int)s_cnt, qP, bd, resid + s_ro, lane);
+      if (((s_r0 >> 8) & HM_TU_LOG2_MASK) == 4) big_residual<4>(coeff, tmp, mt16, tab, cf, (int)s_cnt, qP, bd, resid + s_ro, lane);
+      else big_residual<5>(coeff, tmp, mt32, tab, cf, (int)s_cnt, qP, bd, resid + s_ro, lane);
     }
   }
 }
