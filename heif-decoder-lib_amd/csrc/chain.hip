@@ -423,6 +423,9 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     ri = c0;
     wdec = (ri >> WLOG) - 1; // (nothing of this row is in LDS yet)
     load_window(ri >> WLOG);
+#ifndef HM_NO_SERVICE_WAIT
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): waited for here, once per row - see the top of the service phase
+#endif
   };
   if (st == ST_START) row_start();
   // every iteration executes a block of some chain or waits for a CTU that is at most two CTUs of another chain away
@@ -448,6 +451,13 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     const unsigned long long m_left0 = ballot(left == 0);
     if ((m_left0 & ~m_done) || (PAIRS && (budget & 15) == 0)) {
       HM_T_COUNT(0);
+#ifndef HM_NO_SERVICE_WAIT
+      // (r05) Loads and stores share one in-order counter: the header of the CTU to start (requested a CTU ago) and the next window
+      // (requested a window ago) are looked at below, BEHIND the stores of the CTUs this phase flushes - a wait for them there is a
+      // wait for those stores: a trip to HBM on the critical path of every CTU.  Waited for here instead, in front of the stores,
+      // where everything in flight is at least an iteration old.
+      __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+#endif
       // ---- F: finished CTUs: coalesced stores to the picture, bottom row -> line, right column -> left column ----
       for (unsigned long long fin = ballot(st == ST_RUN) & ballot(ri == ctu_end) & main_mask; fin;) {
         const int fg = rfl((int)(__builtin_ctzll(fin) >> 4));
