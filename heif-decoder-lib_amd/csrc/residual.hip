@@ -276,7 +276,10 @@ __global__ __launch_bounds__(R_WAVES * 64) HM_R_ATTR void k_residual(const hm_de
   // records are requested a chunk ahead (unconditionally, the index clamped: a load whose result is merged with
   // anything is waited for on the spot), the chunk's levels as soon as their place is known and looked at only after
   // the block map has been written: a wave's time is mostly the latency of these two reads
-  const uint32_t n_tus1 = H->n_tus ? H->n_tus - 1 : 0, n_lev1 = H->n_coeffs ? H->n_coeffs - 1 : 0;
+  // (the same in every lane, but read through the vector memory path: made scalars, or they take two of the kernel's 72 vector
+  //  registers - and a spilled register comes back with a load, which waits for every load in flight, r05)
+  const uint32_t n_tus_s = (uint32_t)rfl((int)H->n_tus), n_coeffs_s = (uint32_t)rfl((int)H->n_coeffs);
+  const uint32_t n_tus1 = (uint32_t)rfl((int)(n_tus_s ? n_tus_s - 1 : 0)), n_lev1 = (uint32_t)rfl((int)(n_coeffs_s ? n_coeffs_s - 1 : 0));
   // (6-byte records, hm_stream.h: hm_tu6: record i lies in the two dwords from byte 6 i & ~3 on - fetched raw here, taken
   //  apart where they are used, so that nothing waits for the load at the request)
   auto record_index = [&](uint32_t first) -> uint32_t {
@@ -291,9 +294,15 @@ __global__ __launch_bounds__(R_WAVES * 64) HM_R_ATTR void k_residual(const hm_de
   {
     const r_u32x2 first = fetch_records(rec_begin);
     cur_x = first.x; cur_y = first.y;
+    // (waited for here, once: a wait at the top of the loop would also be executed on the way back from a chunk - behind its stores)
+    asm volatile("" : "+v"(cur_x), "+v"(cur_y));
   }
   const int sub_w = 1, sub_h = dp.chroma_format == 1 ? 1 : 0; // log2 of the chroma planes' sub-sampling (4:2:0 / 4:2:2)
   const int qp_bd_offset = 6 * (bd - 8);
+  // the plane geometry of the wave's chain kind, as scalars (selects on the kind otherwise end up in vector registers)
+  const int k_lw = rfl(kind ? sub_w : 0), k_lh = rfl(kind ? sub_h : 0);
+  const int k_ctb_pw = rfl(m_ctb >> k_lw), k_rem_last = rfl((dp.width >> k_lw) - (dp.ctb_w - 1) * (m_ctb >> k_lw)); // samples of the plane in a CTB column / in the last one
+  const int k_plane_h = rfl(dp.height >> k_lh), k_row_y0 = rfl(row << (dp.log2_ctb - k_lh));
   for (uint32_t chunk = rec_begin; chunk < rec_end; chunk += 64) {
     const uint32_t ri = chunk + (uint32_t)lane;
     const bool valid = ri < rec_end;
@@ -308,46 +317,49 @@ __global__ __launch_bounds__(R_WAVES * 64) HM_R_ATTR void k_residual(const hm_de
     //      travels in the record's spare bits: the four neighbour bits and whether the CTB is the last / the last but one of
     //      its row - the only columns in which the picture's right edge can cut an above-right run (a run is at most as long
     //      as a CTB is wide).  The place of the block's residual (op.z) follows from the scan below. ----
-    const int x4 = (int)(r0 & 15), y4 = (int)((r0 >> 4) & 15);
-    const int info = (int)((r0 >> 8) & 0xFF), l2 = info & HM_TU_LOG2_MASK;
-    mop_u32x4 mop = {r0, 0u, 0u, 0u};
-    if (!(HM_R_SKIP & 64)) {
-      const int lw = kind ? sub_w : 0, lh = kind ? sub_h : 0;
-      const int nT = 1 << l2;
-      const int xin = x4 << 2, yc = (row << (dp.log2_ctb - lh)) + (y4 << 2); // x inside the CTB / y in the picture, samples of the plane
-      const int ctb_pw = m_ctb >> lw;
-      const int rem_last = (dp.width >> lw) - (dp.ctb_w - 1) * ctb_pw; // samples of the plane in the last CTB column
-      const int room_x = (cnt_raw & HM_TU6_LAST_COLUMN) ? rem_last - (xin + nT) : ((info & HM_TU6_NEXT_TO_LAST) ? ctb_pw + rem_last - (xin + nT) : nT);
-      const int room_y = (dp.height >> lh) - (yc + nT);
-      const hm_avail av = hm_derive_avail(xin << lw, (y4 << 2) << lh, nT << lw, nT << lh, nT, room_x, room_y, dp.log2_ctb, (cnt_raw >> HM_TU6_NB_SHIFT) & 15u);
-      mop = make_micro_op(r0, av.left, av.top, av.tl, (uint32_t)av.n_bl >> 2, (uint32_t)av.n_tr >> 2, 0u, m_Pk, m_cr_off, m_Wc, 0u);
-      asm volatile("" : "+v"(mop.x), "+v"(mop.y), "+v"(mop.w)); // (worked out here, not where the scheduler would like it)
-    }
-    const r_u32x2 ahead = fetch_records(chunk + 64);
-    // (luma chains, block map: the first records and the flags of the CTBs that may start inside this chunk - requested
-    //  here with everything else, used below)
+    // ---- everything the chunk reads from memory is requested HERE, in one go, and waited for ONCE, behind the availability /
+    //      micro-op arithmetic and the scans, in front of the chunk's first store (r05).  Loads and stores share one in-order
+    //      counter: a load requested behind a store is only there when the store has been acknowledged, so every wait that follows
+    //      a store costs a trip to memory - the chunk used to have two of them (the block map's inputs behind the previous chunk's
+    //      residuals, the levels behind the micro-ops and the block map) plus one per pass (see level() below). ----
+    const r_u32x2 ahead = fetch_records(chunk + 64); // the next chunk's records
+    // (luma chains, block map: the first records and the flags of the CTBs that may start inside this chunk)
     const int cand = cur_ctb + 1 + lane;
     const bool cand_ok = kind == 0 && cand < x1;
     const int last_ctb = dp.ctb_w - 1;
     const uint32_t cand_first = q0[HM_CTB_DWORDS * (size_t)(cand < last_ctb ? cand : last_ctb)];
     const uint32_t ctb_flags = q0[HM_CTB_DWORDS * (size_t)(cand - 1 < last_ctb ? cand - 1 : last_ctb) + 2]; // flags of CTB cur_ctb + lane
+    // the chunk's levels lie back to back from the running sum on: one coalesced read puts the first R_STAGE of them into LDS,
+    // so that the passes below wait for LDS, not for HBM
+    const uint32_t chunk_lev = lev_base;
+    uint32_t staged[R_STAGE / 64];
+#pragma unroll
+    for (int k = 0; k < R_STAGE / 64; k++) {
+      uint32_t i = chunk_lev + (uint32_t)(lane + 64 * k);
+      i = i < n_lev1 ? i : n_lev1;
+      staged[k] = coeffs[i];
+    }
+    const int x4 = (int)(r0 & 15), y4 = (int)((r0 >> 4) & 15);
+    const int info = (int)((r0 >> 8) & 0xFF), l2 = info & HM_TU_LOG2_MASK;
+    mop_u32x4 mop = {r0, 0u, 0u, 0u};
+    if (!(HM_R_SKIP & 64)) {
+      const int lw = k_lw, lh = k_lh;
+      const int nT = 1 << l2;
+      const int xin = x4 << 2, yc = k_row_y0 + (y4 << 2); // x inside the CTB / y in the picture, samples of the plane
+      const int ctb_pw = k_ctb_pw, rem_last = k_rem_last;
+      const int room_x = (cnt_raw & HM_TU6_LAST_COLUMN) ? rem_last - (xin + nT) : ((info & HM_TU6_NEXT_TO_LAST) ? ctb_pw + rem_last - (xin + nT) : nT);
+      const int room_y = k_plane_h - (yc + nT);
+      const hm_avail av = hm_derive_avail(xin << lw, (y4 << 2) << lh, nT << lw, nT << lh, nT, room_x, room_y, dp.log2_ctb, (cnt_raw >> HM_TU6_NB_SHIFT) & 15u);
+      mop = make_micro_op(r0, av.left, av.top, av.tl, (uint32_t)av.n_bl >> 2, (uint32_t)av.n_tr >> 2, 0u, m_Pk, m_cr_off, m_Wc, 0u);
+      asm volatile("" : "+v"(mop.x), "+v"(mop.y), "+v"(mop.w)); // (worked out here, not where the scheduler would like it)
+    }
     const bool cbf = valid && (info & HM_TU_CBF);
     const uint32_t rsz = (cbf && l2 >= 3) ? 16u << (2 * (l2 - 2)) : 0u; // (the residual of a 4x4 block has a place of its own: res4)
     // inclusive wave scans: first level / first residual sample of every record
     const uint32_t sc = wave_scan(cnt), sr = wave_scan(rsz);
     const uint32_t lo = lev_base + sc - cnt, ro = res_base + sr - rsz;
     mop.z = ro;
-    if (valid) mops[ri] = mop;
-    // the chunk's levels lie back to back: one coalesced read puts the first R_STAGE of them into LDS, so that the
-    // passes below wait for LDS, not for HBM
-    const uint32_t chunk_lev = lev_base, n_lev = (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
-    uint32_t staged[R_STAGE / 64];
-#pragma unroll
-    for (int k = 0; k < R_STAGE / 64; k++) {
-      uint32_t i = chunk_lev + (uint32_t)(lane + 64 * k);
-      i = i < n_lev1 ? i : n_lev1;
-      staged[k] = coeffs[i]; // (requested here, written to LDS behind the block map)
-    }
+    const uint32_t n_lev = (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
     lev_base += n_lev;
     res_base += (uint32_t)__builtin_amdgcn_readlane((int)sr, 63);
     // level number i of a block whose levels start at index `first`
@@ -364,6 +376,13 @@ __global__ __launch_bounds__(R_WAVES * 64) HM_R_ATTR void k_residual(const hm_de
       }
       return v;
     };
+    // the loads have had the arithmetic above to arrive: the levels into LDS, the next chunk's records taken over - then the stores
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+#pragma unroll
+    for (int k = 0; k < R_STAGE / 64; k++) lvl[lane + 64 * k] = staged[k];
+    cur_x = ahead.x; cur_y = ahead.y;
+    asm volatile("" : "+v"(cur_x), "+v"(cur_y));
+    if (valid) mops[ri] = mop;
     // ---- the block map of the deblocking filter (luma chains): per 4x4 block the transform edges on its left / on top
     //      (bit 0 / bit 1) and QpY (bits 8-15), deblock.cc:31-62 of the reference ----
     if (kind == 0 && !(HM_R_SKIP & 32)) {
@@ -385,7 +404,10 @@ __global__ __launch_bounds__(R_WAVES * 64) HM_R_ATTR void k_residual(const hm_de
       //  first of its CTB reads lane 1 -, and lanes switched off deliver nothing)
       int lane_flags = __builtin_amdgcn_ds_bpermute((sm & 63) << 2, (int)ctb_flags);
       asm volatile("" : "+v"(lane_flags));
-      if (sm >= 64) lane_flags = (int)q0[HM_CTB_DWORDS * (size_t)my_ctb + 2]; // (64 CTBs start in the chunk: each is one record)
+      if (sm >= 64) { // (64 CTBs start in the chunk: each is one record)
+        lane_flags = (int)q0[HM_CTB_DWORDS * (size_t)my_ctb + 2];
+        asm volatile("" : "+v"(lane_flags)); // (waited for inside the branch)
+      }
       const int flags = valid ? (lane_flags & 0xFF) : 0;
       const int en = !(flags & HM_CTB_DEBLOCK_OFF);
       const int left_ok = ((x4 > 0) | ((flags & HM_CTB_DEBLOCK_LEFT) != 0)) & en;
@@ -415,13 +437,6 @@ __global__ __launch_bounds__(R_WAVES * 64) HM_R_ATTR void k_residual(const hm_de
       }
     }
 
-    // the chunk's first R_STAGE levels into LDS: the passes below wait for LDS, not for HBM
-#pragma unroll
-    for (int k = 0; k < R_STAGE / 64; k++) lvl[lane + 64 * k] = staged[k];
-    // the next chunk's records have arrived with the levels (they were requested first): taken over here, in front of
-    // this chunk's stores - taken over at the top of the next trip they would be waited for behind all those stores
-    cur_x = ahead.x; cur_y = ahead.y;
-    asm volatile("" : "+v"(cur_x), "+v"(cur_y));
     WAVE_SYNC();
 
     // ---- blocks whose only level is the DC coefficient (a third of the blocks with a residual): both transform stages
