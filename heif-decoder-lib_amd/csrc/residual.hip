@@ -47,7 +47,13 @@ __device__ __forceinline__ int rdot2(uint32_t a, uint32_t b, int acc)
 {
   return __builtin_amdgcn_sdot2(__builtin_bit_cast(r_s16x2, a), __builtin_bit_cast(r_s16x2, b), acc, false);
 }
-__device__ __forceinline__ int16_t limit_res(int r, int maxv) { return (int16_t)clip3i(-maxv, maxv, r); }
+// (as a minimum and a maximum: the bounds are not constants, so the compiler may not assume lo <= hi and turns clip3i into a compare,
+//  a minimum and two moves)
+__device__ __forceinline__ int16_t limit_res(int r, int maxv)
+{
+  const int t = r < maxv ? r : maxv;
+  return (int16_t)(t > -maxv ? t : -maxv);
+}
 // inclusive prefix sum over the 64 lanes: within the rows of 16 with row shifts, across them with the row broadcasts
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ uint32_t rdpp_m(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false); }
