@@ -155,6 +155,32 @@ def test_range_extension_large_blocks(pkg):
                 assert bad.size == 0, f"seed {seed} {kw} stages {bits} plane {c}: {len(bad)} mismatches, first (y,x)={bad[0].tolist()}"
 
 
+@pytest.mark.parametrize("shape", [dict(log2_ctb=5), dict(log2_ctb=6), dict(log2_ctb=5, bit_depth=10), dict(log2_ctb=6, bit_depth=12, chroma_format=2),
+                                   dict(log2_ctb=4), dict(log2_ctb=5, chroma_format=0)],
+                         ids=["8bit_ctb32", "8bit_ctb64", "10bit_ctb32", "12bit_422_ctb64", "8bit_ctb16", "mono_ctb32"])
+@pytest.mark.parametrize("density, qp", [(97, 4), (80, 22), (30, 40)], ids=["dense_qp4", "qp22", "sparse_qp40"])
+def test_large_transform_blocks(pkg, shape, density, qp):
+    """16x16 / 32x32 transform blocks wherever the quadtree allows them (no_split), from a few levels in the top-left corner to levels
+    in every group of four rows and columns: the residual pre-pass's large-block path (k_residual: big_residual - both stages over
+    the groups of four inputs that hold a level, fallback-dct.cc:592-733; DC-only blocks; levels beyond the staged ones, read from
+    memory inside a pass) at every bit depth's shifts, against the oracle and - where it is there - the real libde265"""
+    import synthutil
+    data = synthutil.picture(515151 + density, width=320, height=192, qp=qp, density=density, no_split=1, cu_qp_delta=1, transform_skip=0, **shape)
+    blob = pkg.capi.parse_hevc(data)
+    assert int.from_bytes(blob[36:40], "little") & 0x1000  # split chains: k_residual + k_chain
+    got = gpudecode.decode_pictures(pkg, [blob], 3)[0]
+    exp, _ = orc.oracle_decode(blob, 3, crop=True)
+    for c in range(len(exp)):
+        bad = np.argwhere(got[c] != exp[c])
+        assert bad.size == 0, f"{shape} density {density} qp {qp} plane {c}: {len(bad)} mismatches, first (y,x)={bad[0].tolist()}"
+    if orc.have_ref():
+        # (8-bit CTB 16: the reference's AVX2 SAO filters 8 columns too many of 8-sample-wide chroma CTBs, its SSE4 and scalar code do
+        #  not - quirk Q9, DESIGN.md 3: the scalar build is the one to meet there)
+        ref, _ = orc.ref_decode(data, orc.REF_F_SCALAR if shape.get("log2_ctb") == 4 and shape.get("bit_depth", 8) == 8 else 0)
+        for c in range(len(ref)):
+            assert np.array_equal(got[c], ref[c]), f"{shape} density {density} qp {qp} plane {c} differs from the reference decoder"
+
+
 @pytest.mark.parametrize("shape", [dict(width=2304, height=1296, log2_ctb=5), dict(width=1920, height=1080, log2_ctb=4),
                                    dict(width=1600, height=1200, log2_ctb=6, bit_depth=10), dict(width=2048, height=1152, log2_ctb=5, chroma_format=2, bit_depth=10),
                                    dict(width=1536, height=1024, log2_ctb=6, chroma_format=0),
