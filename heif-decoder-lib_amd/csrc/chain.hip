@@ -1458,7 +1458,10 @@ static int launch_chain_impl(const hm_dev_pic* d_pics, int n_pics, int log2_ctb,
       heavy = set_layout() && pick(false) && best <= k_tune.heavy_waves_per_cu;
       L = keep; pairs = sv_pairs;
     }
-    static const struct { int one_row, split, w; } cand[5] = {{1, 1, 8}, {1, 1, 4}, {1, 1, 2}, {0, 0, 3}, {0, 0, 2}};
+    // (r05: four waves of a row pair each as well - wherever the four waves per picture that take its row pairs in turn through HBM
+    //  were chosen, the same four in a ring hand over through LDS: 8-bit CTB 16, 768 / 1024 tiles 3.05 / 3.28 -> 2.45 / 2.81 ms,
+    //  profiles/r05_launcher_check.txt)
+    static const struct { int one_row, split, w; } cand[6] = {{1, 1, 8}, {1, 1, 4}, {1, 1, 2}, {0, 0, 4}, {0, 0, 3}, {0, 0, 2}};
     for (const auto& c : cand) {
       const int rpw = c.one_row ? 1 : nr, split = mono ? 0 : c.split;
       if (max_ctb_h <= rpw || (heavy && !c.one_row)) continue; // (rings of row pairs: as short of LDS as a wave per picture)
