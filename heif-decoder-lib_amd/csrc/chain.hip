@@ -143,11 +143,18 @@ typedef uint32_t c_u32x2 __attribute__((ext_vector_type(2)));
 // Waves per SIMD the register allocation aims for: five (<= 96 VGPRs) where that needs no spilling - 8-bit samples, a wave per
 // picture: the headline kernel, whose 7.6 KB of LDS per wave then allow 20 waves per CU instead of 16 -, four elsewhere
 // (16-bit samples and the few-pictures variants would spill a few registers).  HM_WPE overrides (A/B builds).
+// (r05) the cuts with ONE chain per wave (MODE 3 / 4: the rings of the classes short of LDS at any picture count, the few-pictures cuts)
+// fit 96 registers without a spill in every class: five waves per SIMD where their LDS allows it - 18432 tiles, reconstruction ms:
+// 8-bit CTB 64 29.8 -> 26.5, 10-bit 4:2:0 32.9 -> 29.5, 10-bit 4:2:2 43.2 -> 38.9 (16-bit CTB 64: LDS allows no more waves, stays at four)
+#ifndef HM_WPE_ONE_CHAIN
+#define HM_WPE_ONE_CHAIN 5
+#endif
 #ifndef HM_WPE_CTB64
 #define HM_WPE_CTB64 4 // (CTUs of 64x64: the wave's LDS - two rows of CTU buffers - allows ten waves per CU at most; five per SIMD only costs spills)
 #endif
-template <typename Pix, int LOG2_CTB, bool PAIRS>
-constexpr int chain_waves_per_simd = (sizeof(Pix) == 1 && !PAIRS) ? (LOG2_CTB <= 5 ? 5 : HM_WPE_CTB64) : 4;
+template <typename Pix, int LOG2_CTB, int MODE>
+constexpr int chain_waves_per_simd = (sizeof(Pix) == 1 && MODE == 0) ? (LOG2_CTB <= 5 ? 5 : HM_WPE_CTB64) :
+                                     ((MODE >= 3 && !(sizeof(Pix) == 2 && LOG2_CTB == 6)) ? HM_WPE_ONE_CHAIN : 4);
 // MODE of the kernel: 0 a wave per picture; else PAIRS (waves that hand rows over to each other through HBM) with 4 chains per
 // wave (1: a pair of CTU rows), 2 chains (2: one CTU row) or 1 chain (3: one chain of a row) - the chains per wave as a compile-time
 // constant: the multi-record bookkeeping of the cuts with fewer than four chains sits on the critical path of a wave that is
@@ -157,7 +164,7 @@ constexpr int chain_mode_ncl(int mode) { return mode <= 1 ? 2 : (mode == 2 ? 1 :
 #ifdef HM_WPE
 #define HM_CHAIN_ATTR __attribute__((amdgpu_waves_per_eu(HM_WPE, HM_WPE)))
 #else
-#define HM_CHAIN_ATTR __attribute__((amdgpu_waves_per_eu(chain_waves_per_simd<Pix, LOG2_CTB, (MODE != 0)>, chain_waves_per_simd<Pix, LOG2_CTB, (MODE != 0)>)))
+#define HM_CHAIN_ATTR __attribute__((amdgpu_waves_per_eu(chain_waves_per_simd<Pix, LOG2_CTB, MODE>, chain_waves_per_simd<Pix, LOG2_CTB, MODE>)))
 #endif
 template <typename Pix, int LOG2_CTB, int MODE>
 __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* __restrict__ pics, int n_pics, CLayout L, uint32_t* __restrict__ sync, uint32_t* __restrict__ err_word)
@@ -1184,10 +1191,11 @@ struct ChainTuning {
   long row_waves_max = 3500;   // a wave per CTU row / per chain of a row while their waves stay below this (192 tiles: 1.96 / 2.33 vs 2.31)
   long share_waves_min = 3000; // above this many row-pair waves: several waves per picture in turn (r03_share_sweep: 576 tiles 2.52 vs 3.70)
   long ring_waves_min = 2800;  // the ring is considered once a wave per chain of every row would be more than this (r04_ring_sweep)
-  int ring_waves_per_cu = 16;  // the ring's waves must all be resident: at most this many per CU (320 tiles: 16 per picture 1.49 ms, 8: 1.20)
+  int ring_waves_per_cu = 20;  // the ring's waves should all be resident: at most this many per CU (r05: the cuts with one chain per wave hold five waves per SIMD; rings of row pairs are limited to 16 by their registers - pick())
   // cost of a CTU step of the wavefront by what a wave works on (r04_ring_sweep: 1 : 2.5 : 3.3 for one chain, a row, a pair of rows;
   // a wave per chain of EVERY row crowds the SIMDs: 1.4)
   long step_pair = 330, step_row = 250, step_chain = 105, step_chain_crowded = 140;
+  long step_picture_mono = 500; // a wave per monochrome picture works on FOUR luma chains (r05_launcher_check: 4096 tiles 5.85 ms, rings of four one-row waves in four rounds 4.68)
   int heavy_waves_per_cu = 10; // classes whose wave per picture fits at most this often on a CU take the ring of 2 x 2 at any count (r04_ring_sweep: 12-bit 4:2:2 CTB 64 129 -> 51 ms)
   int split_round_fraction = 4; // a partial last round of at most 1 / (this x full rounds) of a round gets a launch of its own (r05_staircase)
 };
@@ -1433,10 +1441,11 @@ static int launch_chain_impl(const hm_dev_pic* d_pics, int n_pics, int log2_ctb,
     };
     auto step_cost = [&](int rpw, int split) -> long { return rpw > 1 ? k_tune.step_pair : (split || mono ? k_tune.step_chain : k_tune.step_row); };
     long cost_now;
-    if (!pairs) cost_now = steps_of(nr) * k_tune.step_pair;
+    if (!pairs) cost_now = steps_of(nr) * (mono ? k_tune.step_picture_mono : k_tune.step_pair);
     else if (share) {
-      const long fit = capacity / n_pics;
-      cost_now = steps_of((fit < share ? (fit < 1 ? 1 : fit) : share) * nr) * k_tune.step_pair;
+      const long fit = (long)device_cus() * 16 / n_pics; // (waves of row pairs: four per SIMD)
+      const long per_pic_now = fit < share ? (fit < 1 ? 1 : fit) : share; // (1: what is left of it is a wave per picture)
+      cost_now = steps_of(per_pic_now * nr) * (per_pic_now == 1 && mono ? k_tune.step_picture_mono : k_tune.step_pair);
     }
     else if (L.rows_per_wave > 1) cost_now = steps_of(max_ctb_h) * k_tune.step_pair;
     else if (L.split_kinds || mono) cost_now = steps_of(max_ctb_h) * k_tune.step_chain_crowded;
@@ -1477,6 +1486,35 @@ static int launch_chain_impl(const hm_dev_pic* d_pics, int n_pics, int log2_ctb,
         alt_wanted = alt_allowed;
       }
       ring_w = 0;
+    }
+    // (r05) No resident ring beats the cut chosen above: rings of one-chain waves are self-contained workgroups, so more of them than
+    // the device holds run in turn - in whole ROUNDS of what is resident.  Taken if rounds x steps still beat the chosen cut with a
+    // margin (profiles/r05_launcher_check.txt: 8-bit CTB 32, 2560 tiles: a wave per picture 4.86 ms, two rounds of rings of two 4.40;
+    // monochrome 4096 tiles: 5.85 against 4.68).
+    if (!ring_w && !heavy && max_ctb_h > 1) {
+      const CLayout keep2 = L;
+      const bool keep2_pairs = pairs, keep2_alt = alt_wanted;
+      int best_w = 0;
+      long best_cost = cost_now - cost_now / 20; // (5 % margin: the estimate is coarse)
+      for (int w : {4, 2}) {
+        const int split = mono ? 0 : 1, bands = max_ctb_h, ww = w < bands ? w : bands, per_pic = ww << split;
+        if (sync_bytes < sync_words(bands)) continue;
+        L.rows_per_wave = 1; L.split_kinds = split; pairs = true; ring_w = ww; alt_wanted = alt_allowed;
+        bool ok = set_layout() && pick(true);
+        if (!ok && alt_kinds()) { alt_wanted = false; ok = set_layout() && pick(true); }
+        if (ok) {
+          const long resident = (long)device_cus() * (best < k_tune.ring_waves_per_cu ? best : k_tune.ring_waves_per_cu);
+          const long rounds = ((long)n_pics * per_pic + resident - 1) / resident;
+          const long cost = rounds * steps_of((long)ww) * step_cost(1, split);
+          if (cost < best_cost) { best_cost = cost; best_w = ww | (alt_wanted ? 0x100 : 0); }
+        }
+        L = keep2; pairs = keep2_pairs; alt_wanted = keep2_alt; ring_w = 0;
+      }
+      if (best_w) {
+        L.rows_per_wave = 1; L.split_kinds = mono ? 0 : 1; pairs = true; ring_w = best_w & 0xFF; alt_wanted = (best_w & 0x100) != 0;
+        if (set_layout() && pick(true)) share = 0;
+        else { L = keep2; pairs = keep2_pairs; alt_wanted = keep2_alt; ring_w = 0; }
+      }
     }
     // (more waves than the device holds, see `heavy` - against the cuts with four chains per wave only: a wave per chain or per row
     //  of every row keeps the picture's whole wavefront)
