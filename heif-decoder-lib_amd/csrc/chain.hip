@@ -1695,6 +1695,27 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
 }
 
 // bytes of the synchronisation buffer hm_launch_chain wants for its wave-per-row-pair mode (0: never uses it)
+// (hm_debug_kernel_regs) the kernel of a (CTB size, sample size, mode), or null
+extern "C" const void* hm_chain_kernel_of(int log2_ctb, int bytes_per_sample, int mode)
+{
+  if (log2_ctb < 4 || log2_ctb > 6 || bytes_per_sample < 1 || bytes_per_sample > 2 || mode < 0 || mode > 4) return nullptr;
+  auto of = [&](auto pix) -> const void* {
+    typedef decltype(pix) P;
+    auto by_mode = [&](auto l2c) -> const void* {
+      constexpr int L2 = decltype(l2c)::value;
+      switch (mode) {
+        case 0: return reinterpret_cast<const void*>(k_chain<P, L2, 0>);
+        case 1: return reinterpret_cast<const void*>(k_chain<P, L2, 1>);
+        case 2: return reinterpret_cast<const void*>(k_chain<P, L2, 2>);
+        case 3: return reinterpret_cast<const void*>(k_chain<P, L2, 3>);
+        default: return reinterpret_cast<const void*>(k_chain<P, L2, 4>);
+      }
+    };
+    return log2_ctb == 4 ? by_mode(std::integral_constant<int, 4>()) : (log2_ctb == 5 ? by_mode(std::integral_constant<int, 5>()) : by_mode(std::integral_constant<int, 6>()));
+  };
+  return bytes_per_sample == 1 ? of(uint8_t()) : of(uint16_t());
+}
+
 extern "C" size_t hm_chain_sync_bytes(int n_pics, int chroma_format, int max_ctb_h)
 {
   (void)chroma_format; // (the finest cut: a band per CTU row)

@@ -593,6 +593,8 @@ __global__ __launch_bounds__(R_WAVES * 64) HM_R_ATTR void k_residual(const hm_de
 
 } // namespace
 
+extern "C" const void* hm_residual_kernel() { return reinterpret_cast<const void*>(k_residual); } // (hm_debug_kernel_regs)
+
 // Residuals of the pictures of one class with split chains (all of them share max_ctb_h as the grid's row count).
 extern "C" int hm_launch_residual(const hm_dev_pic* d_pics, int n_pics, int max_ctb_h, hipStream_t s)
 {

@@ -169,3 +169,33 @@ print("OK")
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
     assert "taking its pairs of CTU rows in turn" in r.stderr, r.stderr[-2000:]  # (the cut under test ran ...)
     assert "1300 waves (one per picture)" in r.stderr, r.stderr[-2000:]          # (... and a launch beside it stepped aside)
+
+
+def test_hot_path_kernels_hold_their_registers_without_a_spill():
+    """A spilled register comes back with a LOAD, and loads and stores share one in-order counter: a reload inside a loop waits for every
+    store in flight ("One counter" - k_residual lost 10 % to three spilled values).  The kernels of the hot path as the
+    loaded code object has them (test hook hm_debug_kernel_regs): no scratch, and the register counts their waves per SIMD need -
+    k_residual seven (72), the wave per picture of the 8-bit classes and every cut with one chain per wave five (96), k_tail420 eight (64)."""
+    import ctypes as C
+    import __graft_entry__ as g
+    L = g.load_package().lib()
+    L.hm_debug_kernel_regs.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int * 2)]
+    out = (C.c_int * 2)()
+
+    def regs(which, a=0, b=0, c=0):
+        assert L.hm_debug_kernel_regs(which, a, b, c, C.byref(out)) == 0
+        return out[0], out[1]
+    r, scratch = regs(0)
+    assert scratch == 0 and r <= 72, ("k_residual", r, scratch)
+    r, scratch = regs(1)
+    assert scratch == 0 and r <= 64, ("k_tail420", r, scratch)
+    for l2 in (4, 5):  # (CTBs of 64: the wave per picture stays at four waves per SIMD - its LDS allows ten waves per CU)
+        r, scratch = regs(2, l2, 1, 0)
+        assert scratch == 0 and r <= 96, ("k_chain, a wave per picture", l2, r, scratch)
+    for l2 in (4, 5, 6):
+        for bps in (1, 2):
+            for mode in (0, 1, 2, 3, 4):
+                r, scratch = regs(2, l2, bps, mode)
+                assert scratch == 0, ("k_chain", l2, bps, mode, r, scratch)
+                if mode >= 3 and not (bps == 2 and l2 == 6):
+                    assert r <= 96, ("k_chain, one chain per wave", l2, bps, mode, r)
