@@ -24,6 +24,8 @@ MORE = {
     "10bit_420_ctb16": dict(log2_ctb=4, bit_depth=10),
     "10bit_420_ctb64": dict(log2_ctb=6, bit_depth=10),
     "10bit_mono_ctb32": dict(log2_ctb=5, bit_depth=10, chroma_format=0),
+    "8bit_444_ctb32": dict(log2_ctb=5, chroma_format=3),  # (the rare-syntax kernel k_recon: records in decode order)
+    "10bit_444_ctb32": dict(log2_ctb=5, chroma_format=3, bit_depth=10),
 }
 
 
@@ -45,7 +47,7 @@ def main():
         cf = cfg.get("chroma_format", 1)
         if os.environ.get("HM_CLASS_ONLY") and name not in os.environ["HM_CLASS_ONLY"].split(","):
             continue
-        ys, cs = L.hm_plane_stride(512, bps), L.hm_plane_stride(256, bps)
+        ys, cs = L.hm_plane_stride(512, bps), L.hm_plane_stride(512 if cf == 3 else 256, bps)
         ch = 256 if cf == 1 else 512
         y = torch.zeros((512, ys), dtype=torch.uint8, device=dev)
         cb = torch.zeros((ch, cs), dtype=torch.uint8, device=dev)
