@@ -199,3 +199,17 @@ def test_hot_path_kernels_hold_their_registers_without_a_spill():
                 assert scratch == 0, ("k_chain", l2, bps, mode, r, scratch)
                 if mode >= 3 and not (bps == 2 and l2 == 6):
                     assert r <= 96, ("k_chain, one chain per wave", l2, bps, mode, r)
+
+
+@pytest.mark.parametrize("cls", ["8bit_420_ctb32", "8bit_420_ctb16", "10bit_420_ctb32"])
+def test_the_launcher_stays_near_the_best_cut(cls):
+    """tools/check_launcher.py on three tile counts between the regimes: the launcher's own cut within 15 % of the best of the 27 cuts
+    it can be forced into (profiles/r05_launcher_check.txt: within 4 % at 118 of 126 points).  A kernel change that makes some cut
+    faster than the launcher's calibration knows - r05: five waves per SIMD for the one-chain cuts - shows up here."""
+    import json
+    env = dict(os.environ, HM_CLASS_ONLY=cls)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_launcher.py"), "768", "1280", "2560"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rows = json.loads(r.stdout.strip().splitlines()[-1])["rows"]
+    for row in rows:
+        assert row["ratio"] < 1.15, (cls, row["tiles"], row["ratio"], row["best_forced"], row["auto_ms"], row["best_ms"])
