@@ -663,6 +663,7 @@ def side_legs(out, args, torch, pkg, dev, st, gb, kept, strides, stream_b, all_b
     guarded(out, "real_content_256_pictures", lambda: real_content(torch, pkg, dev, st, n=256))  # (a mid-size batch: k_chain's ring cut)
     guarded(out, "config4_422_10bit_rgb48", lambda: config4(torch, pkg, dev, st))
     guarded(out, "config5_16384_grid", lambda: config5_single(torch, pkg, dev, st))
+    guarded(out, "hdr10_420_grid_rgb24", lambda: hdr10_leg(torch, pkg, dev, st))
 
 
 SHARE_IMAGES = 128  # BASELINE config 3: 1024 images over 8 GPUs
@@ -1133,6 +1134,70 @@ def config4(torch, pkg, dev, st, n=32):
             "tail_GBps": round(tail_bytes / tail_ms / 1e6, 1) if tail_ms > 0 else None, "tail_frac_of_hbm_peak": round(tail_bytes / tail_ms / 1e6 / HBM_PEAK_GBPS, 4) if tail_ms > 0 else None,
             "command_stream_bytes_per_pixel": round(stream_b / (n * W * H), 3),
             "note": "10-bit 4:2:2 2048x1536 (seed 4220010) -> RRGGBB_LE, K clock; the tail reads 4 B/px of samples and writes 6 B/px of pixels (fused: once each)"}
+
+
+def hdr10_leg(torch, pkg, dev, st, n=96):
+    """The headline's 12 MP grid with 10-bit 4:2:0 tiles (the class of HDR photographs) -> RGB24 along the chain the reference's search
+    picks for it (float operation, fused: k_tailf): n copies of one image of 48 tiles per batch, K clock; the first image against
+    the CPU flow (oracle executors, oracle paste, the searched chain - tests/pipeline.py: the flow of tests/test_configs_gpu.py)."""
+    import numpy as np
+    import pipeline
+    capi, L = pkg.capi, pkg.lib()
+    W, H, cols, rows, tile = OUT_W, OUT_H, GRID_COLS, GRID_ROWS, TILE
+    datas = [tile_stream(9100000 + k, bit_depth=10) for k in range(cols * rows)]
+    blobs = [capi.parse_hevc(d) for d in datas]
+    ys, cs, os_ = L.hm_plane_stride(W, 2), L.hm_plane_stride((W + 1) // 2, 2), L.hm_plane_stride(W, 3)
+    ch = (H + 1) // 2
+    batch = capi.Batch()
+    ims = []
+    for _ in range(n):
+        im = (torch.zeros((H, ys), dtype=torch.uint8, device=dev), torch.zeros((max(64, ch), cs), dtype=torch.uint8, device=dev),
+              torch.zeros((max(64, ch), cs), dtype=torch.uint8, device=dev), torch.zeros((H, os_), dtype=torch.uint8, device=dev))
+        for t in range(cols * rows):
+            d = capi.TileDest()
+            d.plane[0], d.plane[1], d.plane[2] = im[0].data_ptr(), im[1].data_ptr(), im[2].data_ptr()
+            d.pitch[0], d.pitch[1], d.pitch[2] = ys, cs, cs
+            d.canvas_width, d.canvas_height = W, H
+            d.x0, d.y0 = (t % cols) * tile, (t // cols) * tile
+            d.tile_has_nclx, d.tile_full_range, d.tile_matrix = 1, 1, 6  # (full range: nothing is rescaled in the paste)
+            batch.add(blobs[t], d)
+        ims.append(im)
+    batch.upload(st)
+    desc = capi.ColourDesc(W, H, 10, 1, 0, 6, 1, 1, capi.HM_OUT_RGB, ys, cs, cs, os_)
+    PtrArr = C.c_void_p * n
+    ptrs = [PtrArr(*[im[k].data_ptr() for im in ims]) for k in range(4)]
+    batch.set_colour(desc, n, *ptrs, 0)
+    for _ in range(2):
+        batch.execute(3, st)
+    batch.set_profiling(5)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(5):
+        batch.execute(3, st)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    k = [0.0, 0.0, 0.0, 0.0, 0.0]
+    for i in range(5):
+        ms = batch.timings5_ms(i)
+        k = [k[q] + ms[q] / 5 for q in range(5)]
+    batch.check()
+    fused = bool(batch.tail_fused())
+    got = ims[n // 2][3].cpu().numpy()[:H, :W * 3]
+    batch.close()
+    exp, _, _ = pipeline.cpu_decode(L, datas, tile, tile, W, H, cols, True, capi.HM_OUT_RGB, decoder="oracle")
+    parity = "bit-exact vs the oracle flow" if np.array_equal(got, exp[:H, :W * 3]) else "MISMATCH vs the oracle flow"
+    mp = n * W * H / 1e6
+    if fused:
+        kernels = {"k_residual": round(k[4], 3), KERNEL_NAMES[0]: round(k[0], 3), "k_tailf(deblock+sao+paste+float colour)": round(k[2], 3)}
+        tail_ms = k[2]
+    else:
+        kernels = {"k_residual": round(k[4], 3), KERNEL_NAMES[0]: round(k[0], 3), "k_deblock": round(k[1], 3), "k_sao_paste": round(k[2], 3), "k_ycbcr_float(colour)": round(k[3], 3)}
+        tail_ms = k[1] + k[2] + k[3]
+    tail_bytes = 6.0 * n * W * H  # 3 B/px of samples in (1.5 samples of 2 bytes) + 3 B/px of pixels out
+    return {"MP_per_s": round(mp * 5 / dt, 1), "images_per_step": n, "tiles_per_step": n * cols * rows, "tail_fused": fused, "kernels_ms_per_step": kernels,
+            "tail_GBps": round(tail_bytes / tail_ms / 1e6, 1) if tail_ms > 0 else None, "tail_frac_of_hbm_peak": round(tail_bytes / tail_ms / 1e6 / HBM_PEAK_GBPS, 4) if tail_ms > 0 else None,
+            "parity": parity,
+            "note": "12 MP grids of 10-bit 4:2:0 tiles (CTB 32, full range, matrix 6) -> RGB24, K clock; the tail reads 3 B/px of samples and writes 3 B/px of pixels"}
 
 
 def grid_tile_seeds(tile_rows, cols):

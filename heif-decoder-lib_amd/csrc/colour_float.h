@@ -32,6 +32,10 @@ struct FloatParams {
   // (hdr_sdr.cc:84-103: (v << s1) | (v >> s2))
   int post, s1, s2;
   int alpha_fill;      // alpha word of RRGGBBAA outputs of an image without alpha: (1 << bits) - 1 (rgb2rgb.cc:254-263)
+  // mode 4 (r05; the fused tail k_tailf only): Op_to_sdr_planes on Y / Cb / Cr (hdr_sdr.cc:176-195: v >> pre_shift), then the INTEGER
+  // 4:2:0 operation (yuv2rgb.cc:306-366) with the coefficients x 256 rounded (:336-339) - the chain of a deep full-range 4:2:0
+  // image to RGB24 / RGBA32
+  int pre_shift, i_r_cr, i_g_cb, i_g_cr, i_b_cb;
 };
 
 enum { OF_RGB24 = 0, OF_RGBA32 = 1, OF_RRGGBB_BE = 2, OF_RRGGBB_LE = 3, OF_RRGGBBAA_BE = 4, OF_RRGGBBAA_LE = 5 };
@@ -86,6 +90,14 @@ static inline void hm_float_params(const hm_colour_desc* d, const float coef[4],
   if (out8 && d->bit_depth > 8) { p.post = 1; p.s1 = d->bit_depth - 8; }
   else if (!out8 && d->bit_depth == 8) { p.post = 2; p.s1 = out_bits - 8; p.s2 = 16 - out_bits; }
   p.alpha_fill = (1 << out_bits) - 1;
+  p.pre_shift = 0; p.i_r_cr = p.i_g_cb = p.i_g_cr = p.i_b_cb = 0;
+  if (mode == 4) {
+    p.pre_shift = d->bit_depth - 8;
+    p.post = 0; p.s1 = p.s2 = 0; // (the depth change comes in FRONT of the operation here)
+    const float* c = coef;
+    auto r256 = [](float v) { const float x = 256.0f * v; return (int)(x < 0 ? x - 0.5f : x + 0.5f); }; // lround
+    p.i_r_cr = r256(c[0]); p.i_g_cb = r256(c[1]); p.i_g_cr = r256(c[2]); p.i_b_cb = r256(c[3]);
+  }
 }
 
 #endif

@@ -201,6 +201,16 @@ int hm_colour_float_chain(const hm_colour_desc* d, float cf[4], int* mode)
   hm_colour_plan plan;
   const int rc = plan_for(d, &plan);
   if (rc) return rc;
+  // (r05) ... or Op_to_sdr_planes on the three planes and then the INTEGER 4:2:0 operation - the chain of a deep full-range 4:2:0
+  // image to RGB24 / RGBA32, e.g. 10-bit HDR photographs: mode 4 of the same kernel.  The integer operation is the chain's second
+  // step there: it reads the profile of the intermediate image (second_step_desc), not the image's own.
+  if (plan.core == HM_CORE_INT420 && plan.pre == HM_DEPTH_TO_SDR && !plan.mono_expand && !plan.bilinear && !plan.post && d->bit_depth > 8 &&
+      d->chroma == HM_CHROMA_420 && (d->out_format == HM_OUT_RGB || d->out_format == HM_OUT_RGBA)) {
+    const hm_colour_desc cur = plan.core_step > 0 ? second_step_desc(d) : *d;
+    hm_ycbcr_coefficients(cur.has_nclx, cur.matrix, cur.primaries, cf);
+    *mode = 4;
+    return 1;
+  }
   if (plan.core == HM_CORE_MONO || plan.core == HM_CORE_INT420 || plan.mono_expand || plan.pre || plan.bilinear || plan.core_step > 0) return 0;
   const bool out8 = d->out_format == HM_OUT_RGB || d->out_format == HM_OUT_RGBA;
   const int kernel_post = (out8 && d->bit_depth > 8) ? HM_DEPTH_TO_SDR : ((!out8 && d->bit_depth == 8) ? HM_DEPTH_TO_HDR : HM_DEPTH_NONE);

@@ -1667,7 +1667,14 @@ __global__ __launch_bounds__(TF_THREADS) void k_tailf(const hm_dev_pic* __restri
           const int ci = 4 * half + (i >> 1); // the chroma sample of the pixel (nearest: yuv2rgb.cc:201-205)
           const int u = (int)((cbs[ci >> 1] >> (16 * (ci & 1))) & 0xFFFF), w = (int)((crs[ci >> 1] >> (16 * (ci & 1))) & 0xFFFF);
           int rr, gg, b;
-          px_float(fp, yv, u, w, rr, gg, b);
+          // (mode 4 exists for deep 4:2:0 images and 8-bit targets only: the other instantiations do not carry the branch)
+          if (sizeof(Pix) == 2 && CF == 1 && (OF == OF_RGB24 || OF == OF_RGBA32) && fp.mode == 4) { // Op_to_sdr_planes, then the integer 4:2:0 operation (yuv2rgb.cc:359-364)
+            const int y8 = yv >> fp.pre_shift, u8 = (u >> fp.pre_shift) - 128, w8 = (w >> fp.pre_shift) - 128;
+            rr = clip3i(0, 255, y8 + ((__mul24(fp.i_r_cr, w8) + 128) >> 8));
+            gg = clip3i(0, 255, y8 + ((__mul24(fp.i_g_cb, u8) + __mul24(fp.i_g_cr, w8) + 128) >> 8));
+            b = clip3i(0, 255, y8 + ((__mul24(fp.i_b_cb, u8) + 128) >> 8));
+          }
+          else px_float(fp, yv, u, w, rr, gg, b);
           if (fp.post == 1) { rr >>= fp.s1; gg >>= fp.s1; b >>= fp.s1; }
           else if (fp.post == 2) { rr = (rr << fp.s1) | (rr >> fp.s2); gg = (gg << fp.s1) | (gg >> fp.s2); b = (b << fp.s1) | (b >> fp.s2); }
           if (OF == OF_RGB24) { ob[3 * i] = (uint8_t)rr; ob[3 * i + 1] = (uint8_t)gg; ob[3 * i + 2] = (uint8_t)b; }

@@ -350,11 +350,18 @@ FLOAT_TAIL_CLASSES = {
     "422_12_rrggbb_le": (12, 2, 1, 6, "HM_OUT_RRGGBB_LE", 6),
     "422_8_rgb24": (8, 2, 1, 6, "HM_OUT_RGB", 3),
     "420_8_limited_rgba": (8, 1, 0, 1, "HM_OUT_RGBA", 4),
+    # r05: deep full-range 4:2:0 -> RGB24 / RGBA32 is Op_to_sdr_planes + the INTEGER 4:2:0 operation (the class of 10-bit HDR
+    # photographs): mode 4 of the same fused kernel
+    "420_10_full_rgb24": (10, 1, 1, 6, "HM_OUT_RGB", 3),
+    "420_12_full_rgba": (12, 1, 1, 1, "HM_OUT_RGBA", 4),
+    "420_10_full_bt2020_rgb24": (10, 1, 1, 9, "HM_OUT_RGB", 3),
     # grids as decode_full_grid_image builds them: the tiles carry their nclx, the canvas none - limited-range tiles are rescaled
     # while they are pasted (context.cc:2504-2528; 16-bit storage byte by byte: quirk Q1), part of the fused kernel since r05
     "grid_422_8_limited_rgb24": (8, 2, 0, 1, "HM_OUT_RGB", 3, True),
     "grid_420_10_limited_rrggbb_le": (10, 1, 0, 9, "HM_OUT_RRGGBB_LE", 6, True),
     "grid_422_10_full_rrggbb_be": (10, 2, 1, 9, "HM_OUT_RRGGBB_BE", 6, True),
+    "grid_420_10_full_rgb24": (10, 1, 1, 9, "HM_OUT_RGB", 3, True),
+    "grid_420_10_limited_rgb24": (10, 1, 0, 9, "HM_OUT_RGB", 3, True),
 }
 
 
