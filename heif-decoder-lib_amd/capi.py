@@ -6,6 +6,10 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libheif_mi355x.so")
+# the same objects + csrc/test_hooks.cpp (hm_debug_set, hm_debug_kernel_regs): tests and measurement scripts that force a cut of the
+# chain kernel, inject a fault or read a kernel's registers load THIS one (use_test_hooks() before the first lib()); the shipping
+# library exports no such entry point
+TEST_LIB_PATH = os.path.join(_HERE, "libheif_mi355x_test.so")
 
 HM_CHROMA_420, HM_CHROMA_422, HM_CHROMA_444 = 1, 2, 3
 HM_OUT_RGB, HM_OUT_RGBA, HM_OUT_RRGGBB_BE, HM_OUT_RRGGBB_LE = 10, 11, 12, 14
@@ -27,6 +31,14 @@ class ColourDesc(C.Structure):
 
 
 _lib = None
+
+
+def use_test_hooks():
+    """Make lib() load libheif_mi355x_test.so (test infrastructure: tests/knobs.py, tools/).  Must come before the first lib()."""
+    global LIB_PATH
+    if _lib is not None and LIB_PATH != TEST_LIB_PATH:
+        raise RuntimeError("the shipping library is already loaded in this process: call use_test_hooks() first")
+    LIB_PATH = TEST_LIB_PATH
 
 
 def lib():

@@ -90,7 +90,7 @@ int hm_knob(int id)
   if (id < 0 || id >= HM_KNOB_COUNT) return 0;
   return (g_knob_set.load(std::memory_order_acquire) >> id) & 1u ? g_knob[id].load(std::memory_order_relaxed) : k_knobs[id].def;
 }
-int hm_debug_set(const char* name, int value)
+int hm_knob_set(const char* name, int value)
 {
   if (!name) return -1;
   for (int i = 0; i < HM_KNOB_COUNT; i++)

@@ -1749,21 +1749,7 @@ extern "C" int hm_launch_sao_paste(const hm_dev_pic* d_pics, int n_pics, int max
 
 // Fused tail (k_tail420): n pictures of one class (8-bit 4:2:0, no rare syntax), output d_dsts[i] (device array of
 // {pointer, pitch} at the picture's paste position), bpp 3 / 4, integer matrix coefficients of yuv2rgb.cc:336-339.
-// (test hook, hm_internal.h) registers and scratch of the hot path's kernels
-extern "C" const void* hm_chain_kernel_of(int log2_ctb, int bytes_per_sample, int mode);
-extern "C" const void* hm_residual_kernel();
-extern "C" __attribute__((visibility("default"))) int hm_debug_kernel_regs(int which, int a, int b, int c, int out[2])
-{
-  const void* fn = nullptr;
-  if (which == 0) fn = hm_residual_kernel();
-  else if (which == 1) fn = reinterpret_cast<const void*>(k_tail420<3, TAIL_MINW, true>);
-  else if (which == 2) fn = hm_chain_kernel_of(a, b, c);
-  hipFuncAttributes fa;
-  if (!fn || !out || hipFuncGetAttributes(&fa, fn) != hipSuccess) return -1;
-  out[0] = fa.numRegs;
-  out[1] = (int)fa.localSizeBytes;
-  return 0;
-}
+extern "C" const void* hm_tail420_kernel() { return reinterpret_cast<const void*>(k_tail420<3, TAIL_MINW, true>); } // (test_hooks.cpp: hm_debug_kernel_regs)
 
 extern "C" int hm_launch_tail420(const hm_dev_pic* d_pics, const void* d_dsts, int n_pics, int max_w, int max_h, int log2_ctb, int bpp, const int coef[4],
                                  int stages, hipStream_t s)

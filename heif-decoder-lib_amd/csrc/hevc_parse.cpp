@@ -103,7 +103,13 @@ struct Decoder {
   // segment covers - as plain intra CTUs without a residual (hevc_syntax.h: ConcealEC): a valid command stream, a picture, and
   // hm_pic.concealed_ctbs says how much of it is made up.  Without the option such streams are refused (HM_ERR_BITSTREAM) as before.
   bool conceal = false;
-  int concealed = 0, first_concealed = -1; // CTBs written by conceal_range; the first one's raster address
+  int concealed = 0;                       // CTBs written by conceal_range and still standing (ctb_concealed)
+  std::vector<uint8_t> ctb_concealed;      // per CTB (raster address): written by conceal_range, not taken over by a later segment
+  // Something in the picture's slice data has been seen to be wrong (a caught error, a gap, segments that overlap).  Only then may
+  // slice NALs behind the picture's last CTB still belong to it (a damaged segment ran on to the end; the segments behind it take
+  // their CTBs over): behind an INTACT picture they are another picture's and are ignored, as without concealment.
+  bool damage_seen = false;
+  bool later_picture = false;              // a first_slice_segment_in_pic behind the finished picture: nothing after it is ours
   int last_slice_idx = -1;                 // of the last slice segment that was parsed (concealed CTBs join its slice)
   bool want_split = false;   // the current picture's records go out as split chains (unless it turns out to use rare syntax)
   int threads = 1;           // > 1: slice segments with WPP entry points are parsed row-parallel (parse_rows_parallel)
@@ -114,7 +120,9 @@ struct Decoder {
     pic_started = have_prev_sh = picture_done = false;
     cur_sps = nullptr; cur_pps = nullptr;
     next_ts = 0;
-    concealed = 0; first_concealed = -1; last_slice_idx = -1;
+    concealed = 0; last_slice_idx = -1;
+    ctb_concealed.clear();
+    damage_seen = later_picture = false;
   }
   bool pic_started = false;
   const SPS* cur_sps = nullptr;
@@ -151,8 +159,9 @@ struct Decoder {
         pps[q.pps_id] = q;
       }
       else if (nal_type <= 9 || (nal_type >= 16 && nal_type <= 21)) {
-        if (picture_done && !conceal) return; // a still-image item holds one picture; ignore anything after it
-        // (concealing: a damaged segment may have run on to the picture's last CTB - the segments behind it still take their CTBs over)
+        // a still-image item holds one picture; ignore anything after it (concealing, and damage was seen: a damaged segment may have
+        // run on to the picture's last CTB - the segments behind it still take their CTBs over, up to the next picture's first one)
+        if (picture_done && !(conceal && damage_seen && !later_picture)) return;
         if (!conceal) slice_nal(br, nal_type, rbsp);
         else {
           // a slice segment whose HEADER is damaged is dropped like the reference drops it (decctx.cc:639-712: the NAL's decoding
@@ -161,6 +170,7 @@ struct Decoder {
           catch (const ParseError& e) {
             if (e.status != HM_ERR_BITSTREAM || !pic_started) throw;
             pic.dep_ok = false;
+            damage_seen = true;
           }
         }
       }
@@ -172,7 +182,7 @@ struct Decoder {
   {
     SliceHeader sh;
     parse_slice_header(br, nal_type, sps, pps, have_prev_sh ? &prev_sh : nullptr, sh);
-    if (picture_done && sh.first_slice_segment_in_pic) return; // (another picture behind the item's one: ignored)
+    if (picture_done && sh.first_slice_segment_in_pic) { later_picture = true; return; } // (another picture behind the item's one: ignored, with all its segments)
     const PPS& p = pps[sh.pps_id];
     const SPS& s = sps[p.sps_id];
     // every table the slice walker indexes with CTB / minimum-TB addresses must have the active SPS's size
@@ -219,7 +229,7 @@ struct Decoder {
       // (concealing: the CTBs between the last decoded one and this segment's first - the rest of a damaged segment, a lost one -
       //  join the slice in front of them)
       if (conceal && start_ts > next_ts && have_prev_sh && last_slice_idx >= 0) conceal_range(next_ts, start_ts, prev_sh, last_slice_idx);
-      else if (conceal && start_ts < next_ts && !sh.dependent) take_back(start_ts);
+      else if (conceal && start_ts < next_ts && !sh.dependent) take_back(start_ts); // (overlapping segments: no conforming stream has them)
       else throw ParseError(HM_ERR_BITSTREAM, "slice segments out of order or CTBs missing");
     }
     // slice data starts right after the header in the unescaped payload (+2 for the NAL header)
@@ -245,6 +255,7 @@ struct Decoder {
           next_ts = walker.current_ts();
           walker.discard_current_ctu();
           pic.dep_ok = false;
+          damage_seen = true;
           pic.uses_pcm |= walker.uses_pcm();
           pic.uses_tq_bypass |= walker.uses_tq_bypass();
         }
@@ -280,10 +291,12 @@ struct Decoder {
       }
       c.flags &= (uint8_t)~HM_CTB_CODED;
       __atomic_store_n(&pic.ctb_slice_addr[rs], -1, __ATOMIC_RELAXED);
+      if (!ctb_concealed.empty() && ctb_concealed[(size_t)rs]) { ctb_concealed[(size_t)rs] = 0; concealed--; } // (no longer made up: the segment that takes it over defines it)
     }
     next_ts = ts0;
     picture_done = false;
     pic.dep_ok = false;
+    damage_seen = true;
   }
 
   // CTBs [from_ts, to_ts) in tile scan as concealed CTUs of slice `slice_idx` (header sh)
@@ -292,12 +305,14 @@ struct Decoder {
     const PPS& p = *cur_pps;
     ConcealEC cec;
     SliceWalker<ConcealEC> w(cec, pic, sh, slice_idx);
+    if (ctb_concealed.size() != pic.ctbs.size()) ctb_concealed.assign(pic.ctbs.size(), 0);
     for (int ts = from_ts; ts < to_ts; ts++) {
-      if (first_concealed < 0) first_concealed = p.CtbAddrTStoRS[ts];
       w.decode_ctu(ts);
+      ctb_concealed[(size_t)p.CtbAddrTStoRS[ts]] = 1;
       concealed++;
     }
     next_ts = to_ts;
+    damage_seen = true;
   }
 
   // Wavefront-parallel parse of one slice segment whose header carries an entry point per CTB row (WPP, no tiles): the
@@ -425,8 +440,11 @@ struct Decoder {
       Row& R = rows[(size_t)k];
       pic.coeffs.insert(pic.coeffs.end(), R.coeffs.begin(), R.coeffs.end());
       if (base)
-        for (int x = 0; x < W; x++)
-          for (hm_tu& t : pic.ctb_tus[(size_t)(row0 + k) * W + x]) t.coeff_first += base;
+        for (int x = 0; x < W; x++) {
+          const size_t rs = (size_t)(row0 + k) * W + x;
+          for (hm_tu& t : pic.ctb_tus[rs]) t.coeff_first += base;
+          pic.ctb_coeff_mark[rs] += base; // (take_back cuts the picture's list there)
+        }
       pic.uses_pcm |= R.uses_pcm;
       pic.uses_tq_bypass |= R.uses_tq;
     }
@@ -551,8 +569,11 @@ struct Decoder {
       const uint32_t base = (uint32_t)pic.coeffs.size();
       pic.coeffs.insert(pic.coeffs.end(), G.coeffs.begin(), G.coeffs.end());
       if (base)
-        for (int ts = ts0[(size_t)G.first]; ts < ts0[(size_t)(G.first + G.count)]; ts++)
-          for (hm_tu& t : pic.ctb_tus[(size_t)p.CtbAddrTStoRS[ts]]) t.coeff_first += base;
+        for (int ts = ts0[(size_t)G.first]; ts < ts0[(size_t)(G.first + G.count)]; ts++) {
+          const size_t rs = (size_t)p.CtbAddrTStoRS[ts];
+          for (hm_tu& t : pic.ctb_tus[rs]) t.coeff_first += base;
+          pic.ctb_coeff_mark[rs] += base;
+        }
       pic.uses_pcm |= G.uses_pcm;
       pic.uses_tq_bypass |= G.uses_tq;
     }
@@ -584,6 +605,10 @@ struct Decoder {
       picture_done = true;
     }
     if (!picture_done) throw ParseError(HM_ERR_BITSTREAM, "picture incomplete: missing slice segments");
+    int first_concealed = -1; // the first CTB in decoding order that is still a concealed one: its raster address
+    if (concealed > 0)
+      for (int ts = 0; ts < N && first_concealed < 0; ts++)
+        if (ctb_concealed[(size_t)p.CtbAddrTStoRS[ts]]) first_concealed = p.CtbAddrTStoRS[ts];
 
     // Record order (hm_stream.h): pictures without rare syntax get their luma and chroma records in separate lists,
     // row by row (the four-rows-per-wave kernel walks the two chains independently); the knob stream_interleaved = 1 (hm_debug_set;
@@ -618,6 +643,10 @@ struct Decoder {
       n_tus = tu_at; n_levels = lv_at;
     }
     else {
+      if (damage_seen) // (CTBs were taken back and written again: every record's levels must lie inside the list that goes out)
+        for (int i = 0; i < N; i++)
+          for (const hm_tu& t : pic.ctb_tus[i])
+            if ((size_t)t.coeff_first + t.n_coeff > n_levels) throw ParseError(HM_ERR_INTERNAL, "levels of a record outside the picture's list");
       auto is_luma = [](const hm_tu& t) { return ((t.info >> HM_TU_CIDX_SHIFT) & 3) == 0; };
       size_t at = 0;
       for (int cy = 0; cy < s.ctb_h; cy++) {
@@ -716,6 +745,7 @@ struct Decoder {
     h.pcm_loop_filter_disabled = s.pcm_loop_filter_disabled;
     h.concealed_ctbs = (uint32_t)concealed;
     h.first_concealed_ctb = first_concealed < 0 ? 0u : (uint32_t)first_concealed + 1u;
+    if (concealed < 0 || (concealed > 0) != (first_concealed >= 0)) throw ParseError(HM_ERR_INTERNAL, "concealment bookkeeping");
     uint32_t flags = 0;
     if (s.strong_intra_smoothing) flags |= HM_PIC_STRONG_INTRA_SMOOTHING;
     if (s.sao_enabled) flags |= HM_PIC_SAO_ENABLED;

@@ -313,7 +313,8 @@ class SliceWalker {
     // (what discard_current_ctu needs to take this CTU back)
     ctu_started_ = true;
     ctu_coeff_mark_ = coeffs_->size();
-    if (coeffs_ == &pic_.coeffs) pic_.ctb_coeff_mark[rs] = (uint32_t)ctu_coeff_mark_;
+    // (relative to the list the walker writes: a row / a row of tiles parsed in parallel rebases its CTBs' marks together with its records)
+    pic_.ctb_coeff_mark[rs] = (uint32_t)ctu_coeff_mark_;
     ctu_qs_mark_ = *qs_;
     ctu_pcm_mark_ = uses_pcm_; ctu_bypass_mark_ = uses_tq_bypass_;
     // (relaxed atomics: rows of tiles parsed side by side read the entries of their neighbours across the tile border -

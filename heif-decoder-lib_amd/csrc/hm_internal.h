@@ -63,7 +63,7 @@ int hm_launch_residual(const struct hm_dev_pic* d_pics, int n_pics, int max_ctb_
 // hm_batch_check.  hm_chain_sync_bytes: the size that mode needs.
 int hm_launch_chain(const struct hm_dev_pic* d_pics, int n_pics, int log2_ctb, int chroma_format, int bit_depth, int rare_syntax,
                     int max_ctb_w, int max_ctb_h, uint32_t* d_sync, size_t sync_bytes, uint32_t* d_err, hipStream_t s);
-#include "hm_knobs.h" // hm_knob / hm_debug_set
+#include "hm_knobs.h" // hm_knob / hm_knob_set
 size_t hm_chain_sync_bytes(int n_pics, int chroma_format, int max_ctb_h);
 int hm_launch_deblock(const struct hm_dev_pic* d_pics, int n_pics, int max_w4, int max_h4, int chroma_format,
                       int bit_depth, int rare_syntax, hipStream_t s);
@@ -78,7 +78,7 @@ int hm_launch_tailf(const struct hm_dev_pic* d_pics, const void* d_dsts, int n_p
 
 // (test hook) slice segments whose sub-streams were entropy-decoded side by side since the library was loaded: which = 0 WPP rows, 1 rows of tiles
 HM_API long hm_parse_parallel_segments(int which);
-// (test hook, r05) registers and scratch of a hot-path kernel as the loaded code object has them: which = 0 k_residual, 1 k_tail420 (RGB24),
+// (test hook, r05; r06: test_hooks.cpp - in libheif_mi355x_test.so only) registers and scratch of a hot-path kernel as the loaded code object has them: which = 0 k_residual, 1 k_tail420 (RGB24),
 // 2 k_chain with (log2_ctb 4..6, bytes per sample 1 / 2, mode 0..4) in a, b, c.  out[0] = vector registers, out[1] = scratch bytes per
 // lane - a spilled register comes back with a LOAD, and a wait for it waits for every store in flight ("One counter"):
 // tests/test_chain_modes_gpu.py holds the kernels of the hot path to zero.  -> 0, or -1

@@ -5,9 +5,11 @@
 extern "C" {
 #endif
 // Tuning and test knobs.  NOTHING in the library reads them from the environment (r05: a stray HM_CHAIN_RING in a service's
-// environment must not change every decode's kernel): they are set by name through hm_debug_set - exported, in no public
-// header, used by tests/, tools/ and bench.py (tests/knobs.py maps the HM_* variables of the measurement scripts onto it) -
-// and read through hm_knob().  Atomic words: worker threads read them while a test sets them.
+// environment must not change every decode's kernel), and (r06) the library that ships has no exported way to set them:
+// hm_knob_set is hidden.  The setter the tests and measurement scripts use, hm_debug_set, lives in test_hooks.cpp, which is
+// linked only into libheif_mi355x_test.so - the same objects as libheif_mi355x.so plus that one file (csrc/Makefile);
+// tests/knobs.py maps the HM_* variables of the measurement scripts onto it.  Read through hm_knob().  Atomic words: worker
+// threads read them while a test sets them.
 //   chain_spin_limit (0)   polls without news before a chain wave gives up a wait (0: the default bound)
 //   chain_test_stall (0)   fault injection: the first band of every picture never announces its progress
 //   batch_fail_width (0)   hm_batch_execute refuses batches holding a picture of that width (failure-isolation tests)
@@ -28,7 +30,7 @@ enum hm_knob_id { HM_KNOB_CHAIN_SPIN_LIMIT, HM_KNOB_CHAIN_TEST_STALL, HM_KNOB_BA
                   HM_KNOB_CHAIN_ALT, HM_KNOB_CHAIN_NP, HM_KNOB_CHAIN_DEBUG, HM_KNOB_RESID_SEGS, HM_KNOB_RECON_WAVES, HM_KNOB_QUAD_CLASS, HM_KNOB_TAIL_FUSED,
                   HM_KNOB_STREAM_INTERLEAVED, HM_KNOB_CHAIN_SPLIT, HM_KNOB_COUNT };
 int hm_knob(int id);
-__attribute__((visibility("default"))) int hm_debug_set(const char* name, int value); // 0, or -1 for an unknown name
+int hm_knob_set(const char* name, int value); // 0, or -1 for an unknown name (hidden: reached through test_hooks.cpp's hm_debug_set only)
 #ifdef __cplusplus
 }
 #endif

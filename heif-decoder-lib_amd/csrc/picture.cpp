@@ -193,14 +193,15 @@ class DeviceWorker {
           // not fit LDS, a pool that is out of memory for it) must not fail its neighbours' valid pictures.  Every
           // request again, in a batch of its own: each caller gets its own picture's verdict.
           // Only where the verdict can be a picture's own: a device-level failure (a HIP error - sticky -, no device) goes to every
-          // request as it is - re-running 64 batches into the same dead stream helps nobody -, and when the single batches run
-          // out of memory or lose the device too, the rest take that verdict without being tried.
+          // request as it is - re-running 64 batches into the same dead stream helps nobody -, and when a single batch loses the
+          // device too, the rest take that verdict without being tried.  Out of memory is a picture's own verdict (one oversized
+          // picture must not fail the up to 63 valid ones queued behind it, r06): the others are still tried.
           if (rc != HM_ERR_NO_DEVICE) {
             rcs.assign(reqs.size(), rc);
             msgs.assign(reqs.size(), msg);
             for (size_t i = 0; i < reqs.size(); i++) {
               rcs[i] = run_batch(std::vector<Request*>(1, reqs[i]), s, msgs[i]);
-              if (rcs[i] == HM_ERR_NO_DEVICE || rcs[i] == HM_ERR_NOMEM) {
+              if (rcs[i] == HM_ERR_NO_DEVICE) {
                 for (size_t k = i + 1; k < reqs.size(); k++) { rcs[k] = rcs[i]; msgs[k] = msgs[i]; }
                 break;
               }

@@ -25,6 +25,21 @@ def hm(pkg):
 
 
 @pytest.fixture(scope="session")
+def hm_hooks(pkg):
+    """libheif_mi355x_test.so: the shipping library's objects + csrc/test_hooks.cpp (hm_debug_set, hm_debug_kernel_regs).  A library
+    of its own beside `hm` in this process (own knobs, own device pool): what is set here does not reach `hm`."""
+    import ctypes
+    pkg.lib()  # (torch's HIP runtime first)
+    L = ctypes.CDLL(pkg.capi.TEST_LIB_PATH)
+    L.hm_status_string.restype = ctypes.c_char_p
+    L.hm_last_error.restype = ctypes.c_char_p
+    L.hm_debug_set.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    L.hm_debug_set.restype = ctypes.c_int
+    pkg.capi.bind_decode(L)
+    return L
+
+
+@pytest.fixture(scope="session")
 def oracle():
     import orc
     return orc.load()

@@ -137,15 +137,20 @@ def test_icc_profile_pass_through(hm):
     plain.close()
 
 
-def test_tuning_knobs_are_not_read_from_the_environment(pkg, hm):
+def test_tuning_knobs_are_not_read_from_the_environment(pkg, hm, hm_hooks):
     """r05: the kernels' tuning / fault-injection knobs are set through the test hook hm_debug_set only - no binary of the
     product holds the name of one of the measurement scripts' variables (tests/knobs.py maps those onto the hook), so a
-    stray HM_CHAIN_RING in a service's environment cannot change a decode."""
+    stray HM_CHAIN_RING in a service's environment cannot change a decode.  r06: the hook itself is not in the libraries that
+    ship - only libheif_mi355x_test.so (the same objects + csrc/test_hooks.cpp) exports it."""
+    import subprocess
     import knobs
-    hm.hm_debug_set.argtypes = [C.c_char_p, C.c_int]
-    assert hm.hm_debug_set(b"no_such_knob", 1) == -1
+    assert not hasattr(hm, "hm_debug_set") and not hasattr(hm, "hm_debug_kernel_regs")
+    assert hm_hooks.hm_debug_set(b"no_such_knob", 1) == -1
     for name in knobs.ENV_TO_KNOB.values():
-        assert name in ("chain_spin_limit", "chain_test_stall") or hm.hm_debug_set(name.encode(), {"chain_alt": 1, "tail_fused": 1, "chain_split": 1}.get(name, -1 if name in ("chain_pairs", "chain_ring", "quad_class") else 0)) == 0, name
+        assert name in ("chain_spin_limit", "chain_test_stall") or hm_hooks.hm_debug_set(name.encode(), {"chain_alt": 1, "tail_fused": 1, "chain_split": 1}.get(name, -1 if name in ("chain_pairs", "chain_ring", "quad_class") else 0)) == 0, name
+    for so in ("libheif_mi355x.so", "libheif_mi355x_api.so", "libheif-mi355x-plugin.so"):
+        syms = subprocess.run(["nm", "-D", "--defined-only", os.path.join(os.path.dirname(pkg.capi.LIB_PATH), so)], capture_output=True, text=True, check=True).stdout
+        assert "hm_debug" not in syms and "hm_knob" not in syms, so
     here = os.path.dirname(pkg.capi.LIB_PATH)
     for so in glob.glob(os.path.join(here, "*.so")):
         blob = open(so, "rb").read()

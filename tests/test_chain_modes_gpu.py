@@ -178,7 +178,9 @@ def test_hot_path_kernels_hold_their_registers_without_a_spill():
     k_residual seven (72), the wave per picture of the 8-bit classes and every cut with one chain per wave five (96), k_tail420 eight (64)."""
     import ctypes as C
     import __graft_entry__ as g
-    L = g.load_package().lib()
+    pkg = g.load_package()
+    pkg.lib()  # (torch's HIP runtime first)
+    L = C.CDLL(pkg.capi.TEST_LIB_PATH)  # (the shipping library's objects + the probe: csrc/test_hooks.cpp)
     L.hm_debug_kernel_regs.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int * 2)]
     out = (C.c_int * 2)()
 

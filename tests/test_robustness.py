@@ -398,3 +398,65 @@ def test_parameter_set_ranges_are_checked(hm):
         # the synthesiser reads its own parameter sets back with the product's parser (parse_pps): -2 = it refused them
         with pytest.raises(RuntimeError, match="out of range|synth failed: -2"):
             hevcutil.parse(hm, synthutil.picture(3, width=64, height=64, **kw))
+
+
+def _parse_opts(hm, data, threads, conceal):
+    o = hevcutil._ParseOptions(0, threads, hevcutil.HM_PARSE_CONCEAL if conceal else 0)
+    hm.hm_hevc_parse_opts.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(hevcutil._ParseOptions), C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+    hm.hm_last_error.restype = C.c_char_p
+    blob, size = C.POINTER(C.c_uint8)(), C.c_size_t()
+    rc = hm.hm_hevc_parse_opts(data, len(data), C.byref(o), C.byref(blob), C.byref(size))
+    if rc:
+        raise RuntimeError(f"hm_hevc_parse_opts failed: {rc}: {hm.hm_last_error().decode()}")
+    out = C.string_at(blob, size.value)
+    hm.hm_free(blob)
+    return out
+
+
+def test_a_second_coded_picture_behind_an_intact_one_is_ignored_when_concealing(hm):
+    """with concealment on (the default of the plugin / facade / hm_decode_item) the slice segments of a SECOND coded picture
+    behind an intact one must not take CTBs of the finished picture back (they did: every segment but the first one of that picture,
+    with no warning).  The item's picture is the first one, byte for byte the strict parse's, and nothing counts as concealed."""
+    a = hevcutil.split_nals(corpus.stream("slices"))
+    b = hevcutil.split_nals(corpus.stream("slices_headers"))
+    ref = hevcutil.parse(hm, corpus.stream("slices"))
+    two = hevcutil.join_nals(a + [n for n in b if ((n[0] >> 1) & 63) <= 21])  # + the slice segments of another picture (first, then five more)
+    blob, n_conc, first = hevcutil.parse_concealing(hm, two)
+    assert blob == ref and n_conc == 0 and first == -1
+    # ... also when the first picture WAS damaged (its last segment lost): the other picture's segments do not fill the gap
+    cut = hevcutil.join_nals(a[:-1] + [n for n in b if ((n[0] >> 1) & 63) <= 21])
+    blob_cut, n_cut, first_cut = hevcutil.parse_concealing(hm, hevcutil.join_nals(a[:-1]))
+    assert n_cut > 0
+    try:
+        got = hevcutil.parse_concealing(hm, cut)
+    except RuntimeError:  # (a first_slice_segment_in_pic inside an unfinished picture, or its header read with the wrong PPS: refused, as before)
+        pass
+    else:
+        assert got == (blob_cut, n_cut, first_cut)
+
+
+def test_overlapping_segments_of_a_picture_parsed_in_parallel_keep_their_levels(hm, oracle):
+    """a rare-syntax (records in decode order) WPP picture parsed with several threads keeps its levels in per-row lists that
+    are merged afterwards; a later independent segment that starts inside what has been parsed takes those CTBs back - the picture's
+    level list was cut at a mark the parallel rows never set (0: every earlier CTB lost its levels while its records still pointed at
+    them).  A duplicated middle segment must give the picture of the stream without the duplicate, with 1 and with 4 threads."""
+    import numpy as np
+    import orc
+    import synthutil
+    d = synthutil.picture(9102, width=256, height=256, log2_ctb=5, wpp=1, slices=20, pcm=200, pcm_bits_y=8, pcm_bits_c=8)
+    nals = hevcutil.split_nals(d)
+    segs = [n for n in nals if ((n[0] >> 1) & 63) <= 21]
+    assert len(segs) >= 4
+    ref, _ = orc.oracle_decode(_parse_opts(hm, d, 1, False), 3)
+    hm.hm_parse_parallel_segments.restype = C.c_long
+    for k in range(1, len(segs) - 1):
+        i = nals.index(segs[k])
+        dup = hevcutil.join_nals(nals[:i + 1] + [segs[k]] + nals[i + 1:])
+        for threads in (1, 4):
+            before = hm.hm_parse_parallel_segments(0)
+            blob = _parse_opts(hm, dup, threads, True)
+            assert threads == 1 or hm.hm_parse_parallel_segments(0) > before  # (the rows of these segments did run side by side)
+            n_tus, n_coeffs = struct.unpack_from("<II", blob, 56)
+            assert struct.unpack_from("<II", blob, 80) == (0, 0)  # nothing made up
+            got, _ = orc.oracle_decode(blob, 3)
+            assert all(np.array_equal(x, y) for x, y in zip(ref, got)), (k, threads)

@@ -30,7 +30,7 @@ def main():
     import __graft_entry__ as g
     import knobs
     import synthutil
-    pkg = g.load_package(test_knobs=True)
+    pkg = g.load_package(test_knobs="always")
     capi, L = pkg.capi, pkg.lib()
     dev = torch.device("cuda:0")
     counts = [int(a) for a in sys.argv[1:]] or [24, 48, 96, 192, 384, 768, 1280, 1536, 2048, 3072, 5120, 6144]
