@@ -1185,7 +1185,9 @@ def hdr10_leg(torch, pkg, dev, st, n=96):
     got = ims[n // 2][3].cpu().numpy()[:H, :W * 3]
     batch.close()
     exp, _, _ = pipeline.cpu_decode(L, datas, tile, tile, W, H, cols, True, capi.HM_OUT_RGB, decoder="oracle")
-    parity = "bit-exact vs the oracle flow" if np.array_equal(got, exp[:H, :W * 3]) else "MISMATCH vs the oracle flow"
+    if not np.array_equal(got, exp[:H, :W * 3]):  # (a rate for a wrong picture is no rate: guarded() reports the error instead)
+        raise RuntimeError("hdr10_420_grid_rgb24: the fused tail's image differs from the oracle flow")
+    parity = "bit-exact vs the oracle flow"
     mp = n * W * H / 1e6
     if fused:
         kernels = {"k_residual": round(k[4], 3), KERNEL_NAMES[0]: round(k[0], 3), "k_tailf(deblock+sao+paste+float colour)": round(k[2], 3)}

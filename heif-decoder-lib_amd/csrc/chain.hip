@@ -43,6 +43,7 @@
 #include <stdlib.h>
 #include <atomic>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <utility>
@@ -1633,27 +1634,60 @@ static int launch_chain_impl(const hm_dev_pic* d_pics, int n_pics, int log2_ctb,
 // rounds: its workgroups are self-contained, they start as the first workgroups of the full rounds finish.  5632 tiles: 9.90 ->
 // 7.87 ms (1.40 us per tile, the full device's rate), 6144: 10.11 -> 8.80.
 namespace {
-struct AuxStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
-AuxStream* aux_stream_of(hipStream_t s)
+struct AuxStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  unsigned long long last_use = 0;
+  AuxStream() = default;
+  AuxStream(const AuxStream&) = delete;
+  ~AuxStream() // (the caller's stream waits for `join`: what was queued here is part of that stream's work; the destroy waits for it)
+  {
+    if (fork) (void)hipEventDestroy(fork);
+    if (join) (void)hipEventDestroy(join);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+// One second stream (+ two events) per (device, caller stream).  Callers that create a stream per batch (the plugin worker's executors
+// keep theirs, but nothing says every caller does) must not leave a stream behind for each one for ever, and a recycled stream handle must
+// not matter: the map is bounded - beyond AUX_MAX entries the least recently used ones go (r06); a launch that is still
+// using an evicted entry holds it through its shared_ptr.
+constexpr size_t AUX_MAX = 16;
+std::shared_ptr<AuxStream> aux_stream_of(hipStream_t s)
 {
   static std::mutex m;
-  static std::map<std::pair<int, hipStream_t>, AuxStream> streams; // (per caller stream: calls on one stream come one after the other)
+  static std::map<std::pair<int, hipStream_t>, std::shared_ptr<AuxStream>> streams; // (per caller stream: calls on one stream come one after the other)
+  static unsigned long long tick = 0;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  std::lock_guard<std::mutex> l(m);
-  AuxStream& a = streams[std::make_pair(dev, s)];
-  if (!a.stream) {
-    hipStream_t t = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (hipStreamCreateWithFlags(&t, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&e0, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) {
-      if (e0) (void)hipEventDestroy(e0);
-      (void)hipStreamDestroy(t);
-      return nullptr;
+  std::vector<std::shared_ptr<AuxStream>> evicted; // (destroyed outside the lock)
+  std::shared_ptr<AuxStream> a;
+  {
+    std::lock_guard<std::mutex> l(m);
+    std::shared_ptr<AuxStream>& slot = streams[std::make_pair(dev, s)];
+    if (!slot) {
+      hipStream_t t = nullptr;
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (hipStreamCreateWithFlags(&t, hipStreamNonBlocking) != hipSuccess) { streams.erase(std::make_pair(dev, s)); return nullptr; }
+      if (hipEventCreateWithFlags(&e0, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) {
+        if (e0) (void)hipEventDestroy(e0);
+        (void)hipStreamDestroy(t);
+        streams.erase(std::make_pair(dev, s));
+        return nullptr;
+      }
+      slot = std::make_shared<AuxStream>();
+      slot->stream = t; slot->fork = e0; slot->join = e1;
     }
-    a.stream = t; a.fork = e0; a.join = e1;
+    slot->last_use = ++tick;
+    a = slot;
+    while (streams.size() > AUX_MAX) {
+      auto oldest = streams.begin();
+      for (auto it = streams.begin(); it != streams.end(); ++it)
+        if (it->second->last_use < oldest->second->last_use) oldest = it;
+      evicted.push_back(std::move(oldest->second));
+      streams.erase(oldest);
+    }
   }
-  return &a;
+  return a;
 }
 } // namespace
 
@@ -1674,7 +1708,7 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
     if (plan.per_picture && n_pics > plan.resident && r > 0 && k_tune.split_round_fraction * rounds * r <= plan.resident) {
       ChainPlan rest; // (only if the remainder alone would not be a wave per picture again)
       const hm_dev_pic* const d_rest = d_pics + (n_pics - r);
-      AuxStream* const ax = aux_stream_of(s);
+      const std::shared_ptr<AuxStream> ax = aux_stream_of(s);
       if (ax && launch_chain_impl(d_rest, (int)r, log2_ctb, chroma_format, bit_depth, rare_syntax, max_ctb_w, max_ctb_h, d_sync, sync_bytes, d_err, ax->stream, &rest) > 0 &&
           !rest.per_picture && hipEventRecord(ax->fork, s) == hipSuccess && hipStreamWaitEvent(ax->stream, ax->fork, 0) == hipSuccess) {
         int q1 = 1, q2 = 1;
