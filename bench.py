@@ -79,14 +79,18 @@ class GridBatch:
         self.batch = pkg.capi.Batch()
         self.images = []
 
-    def add_image(self, blobs, y0_tiles=0):
-        """blobs: cols * rows command streams, row-major"""
+    def add_image(self, blobs, y0_tiles=0, rgb=None):
+        """blobs: cols * rows command streams, row-major; rgb: the image's RGB rows somewhere else ([out_h, self.os] view, e.g. rows of a
+        larger image: grid mode decodes a slab straight into its rows of the gathered image)"""
         import torch
         capi = self.pkg.capi
         y = torch.zeros((max(64, self.out_h), self.ys), dtype=torch.uint8, device=self.dev)
         cb = torch.zeros((max(64, (self.out_h + 1) // 2), self.cs), dtype=torch.uint8, device=self.dev)
         cr = torch.zeros((max(64, (self.out_h + 1) // 2), self.cs), dtype=torch.uint8, device=self.dev)
-        rgb = torch.zeros((max(64, self.out_h), self.os), dtype=torch.uint8, device=self.dev)
+        if rgb is None:
+            rgb = torch.zeros((max(64, self.out_h), self.os), dtype=torch.uint8, device=self.dev)
+        else:
+            assert rgb.shape[0] >= self.out_h and rgb.stride(0) == self.os and rgb.stride(1) == 1
         for t, blob in enumerate(blobs):
             d = capi.TileDest()
             d.plane[0], d.plane[1], d.plane[2] = y.data_ptr(), cb.data_ptr(), cr.data_ptr()
@@ -329,6 +333,8 @@ def main():
     ap.add_argument("--quick", action="store_true", help="headline only: skip the side clocks (D, E, pipelined E, CPU baseline, real content, configs 4 / 5)")
     ap.add_argument("--no-e2e", action="store_true", help="alias of --quick (profiling runs)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--grid-chunk-rows", type=int, default=0, help="--mode grid: tile rows per chunk a rank decodes and hands to the gather (0 = its whole slab: "
+                    "32 tiles per launch sit deep in the few-pictures regime of the chain kernel, profiles/r05_launcher_check.txt)")
     ap.add_argument("--group", type=int, default=0, help="images per filter + colour group (hm_batch_set_colour; 0 = the whole batch per kernel launch)")
     args = ap.parse_args()
     if args.no_e2e:
@@ -659,6 +665,7 @@ def side_legs(out, args, torch, pkg, dev, st, gb, kept, strides, stream_b, all_b
     if all_blobs:
         guarded(out, "config2_no_vui", lambda: no_vui_leg(torch, pkg, dev, st, all_blobs, out.get("ms_per_step")))
         guarded(out, "config3_per_gpu_share", lambda: share_leg(torch, pkg, dev, st, all_blobs[:SHARE_IMAGES]))
+        guarded(out, "config2_single_image", lambda: single_image_leg(out, torch, pkg, dev, st, all_blobs[0]))
     guarded(out, "real_content", lambda: real_content(torch, pkg, dev, st))
     guarded(out, "real_content_256_pictures", lambda: real_content(torch, pkg, dev, st, n=256))  # (a mid-size batch: k_chain's ring cut)
     guarded(out, "config4_422_10bit_rgb48", lambda: config4(torch, pkg, dev, st))
@@ -667,6 +674,40 @@ def side_legs(out, args, torch, pkg, dev, st, gb, kept, strides, stream_b, all_b
 
 
 SHARE_IMAGES = 128  # BASELINE config 3: 1024 images over 8 GPUs
+
+
+def single_image_leg(out, torch, pkg, dev, st, blobs):
+    """BASELINE config 2 as it is written: ONE 12 MP grid (48 tiles) on one MI355X.  K = the kernels of that one image (command streams
+    resident), D = + the H2D of its command streams, E = the caller's clock (hm_decode_item: box parsing + entropy decode on the host
+    threads + H2D + kernels + D2H, from the end_to_end leg); the stage roofline on SURVEY 8(d)'s bytes.  48 tiles are the few-pictures
+    regime of the chain kernel: the time is the wavefront of ONE tile (16 x 16 CTUs), not the device's throughput."""
+    gb, res = variant_batch(torch, pkg, dev, st, [blobs], nclx=(1, 1, 6), steps=20, warmup=3)
+    stream_b, sample_b, level_b, resid_b = gb.batch.algorithmic_bytes4()
+    recon_ms = sum(v for k, v in res["kernels_ms"].items() if k in ("k_residual", "k_chain"))
+    tail_ms = sum(v for k, v in res["kernels_ms"].items() if k not in ("k_residual", "k_chain"))
+    stage_b = stream_b + sample_b
+    res["roofline_stage"] = {"bound": "hbm", "achieved": round(stage_b / recon_ms / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                             "frac": round(stage_b / recon_ms / 1e6 / HBM_PEAK_GBPS, 5), "bytes": int(stage_b),
+                             "note": "command stream + 1.5 B/px over k_residual + k_chain; latency-bound at 48 tiles (one tile's wavefront of 46 CTU steps)"}
+    res["recon_ms"] = round(recon_ms, 4)
+    res["tail_ms"] = round(tail_ms, 4)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        gb.batch.upload(st)
+        gb.step(st)
+    torch.cuda.synchronize()
+    d_ms = (time.perf_counter() - t0) / 10 * 1e3
+    res["K"] = {"ms": res["ms_per_step"], "MP_per_s": res["MP_per_s"]}
+    res["D"] = {"ms": round(d_ms, 4), "MP_per_s": round(MP_PER_IMAGE / d_ms * 1e3, 1), "command_stream_bytes": int(stream_b)}
+    e = out.get("end_to_end", {})
+    best = min((v for k, v in e.items() if k.startswith("host_threads_")), key=lambda v: v["ms_per_image"], default=None) if isinstance(e, dict) else None
+    if best:
+        res["E"] = {"ms": best["ms_per_image"], "MP_per_s": best["MP_per_s"], "what": "hm_decode_item, the best of the end_to_end leg's thread counts"}
+    gb.batch.close()
+    gb.images.clear()
+    torch.cuda.empty_cache()
+    return res
 
 
 def variant_batch(torch, pkg, dev, st, blobs_by_image, nclx, steps=10, warmup=2):
@@ -1231,37 +1272,83 @@ def config5_single(torch, pkg, dev, st):
 # --------------------------------------------------------------------------------------------------------------
 
 def run_grid(args, torch, pkg, dev, dist, rank, world, st, shared):
+    """ONE 16384^2 grid, tile rows sharded over the ranks (shard.row_slabs).  r06: the gather is part of the timed loop and runs
+    UNDER the decode - two image buffers per rank: while grid i + 1 is decoded into one, the slabs of grid i travel from the other
+    (a second stream behind an event per chunk of tile rows; point-to-point, no padding, the root receiving straight into the
+    rows of its final image and decoding its own slab in place: shard.SlabGather).  `value` at N > 1 is that pipelined rate;
+    beside it the K-only rate (no gather), the latency of one grid (decode, then gather) and - the alternative SURVEY 8(e) prefers
+    for a caller whose planes live in host memory (heif_image_get_plane*) - every rank copying its rows into ONE pinned host image
+    (what hm_decode_item_devices does in-process), so that the first run on an 8-GPU box decides between the two."""
     capi = pkg.capi
     sh = pkg.shard
     COLS = ROWS = 32
     W = H = 16384
+    nccl = dist is not None and args.dist_backend == "nccl"
     slabs = sh.row_slabs(ROWS, world)
     r0, nr = slabs[rank]
-    heights = [sh.slab_pixel_rows(a, b, TILE, H)[1] - sh.slab_pixel_rows(a, b, TILE, H)[0] for a, b in slabs]
-    # this rank's slab: its tile rows pasted into a canvas of the slab's height
-    gb = GridBatch(pkg, dev, COLS, max(nr, 1), TILE, W, max(heights[rank], 2))
-    if nr:
-        blobs = [b for _, b in make_streams(capi, grid_tile_seeds(range(r0, r0 + nr), COLS), keep_data=False)]
-        gb.add_image(blobs)
+    y0, y1 = sh.slab_pixel_rows(r0, nr, TILE, H)
+    chunk_rows = args.grid_chunk_rows
+    gat = sh.SlabGather(slabs, TILE, H, chunk_tile_rows=chunk_rows, dst=0, stage_through_host=not nccl) if dist else None
+    chunks = sh.slab_chunks(r0, nr, chunk_rows)  # the decode is cut like the transfer: a launch + an event per chunk
+    out_stride = pkg.lib().hm_plane_stride(W, 3)
+    NB = 2 if dist else 1
+    # the image buffers: the root's are whole images (its own rows decoded in place, the others' received into theirs), the other
+    # ranks' hold their slab
+    if rank == 0:
+        images = [torch.zeros((H, out_stride), dtype=torch.uint8, device=dev) for _ in range(NB)]
+        local = [im[y0:y1] for im in images]
     else:
-        gb.images.append(dict(rgb=torch.zeros((0, gb.os), dtype=torch.uint8, device=dev)))
-    if nr:
-        gb.finish(st)
-    step = (lambda: gb.step(st)) if nr else (lambda: None)
-    step()
-    torch.cuda.synchronize()
+        images = None
+        local = [torch.zeros((max(y1 - y0, 64), out_stride), dtype=torch.uint8, device=dev) for _ in range(NB)]
+    # one batch per (buffer, chunk): the destination pointers of a batch's tiles are fixed when they are added
+    batches = []
+    for b in range(NB):
+        per_chunk = []
+        for c0, cn in chunks:
+            cy0, cy1 = sh.slab_pixel_rows(c0, cn, TILE, H)
+            if cy1 <= cy0:
+                continue
+            gbc = GridBatch(pkg, dev, COLS, cn, TILE, W, cy1 - cy0)
+            gbc.add_image([bl for _, bl in make_streams(capi, grid_tile_seeds(range(c0, c0 + cn), COLS), keep_data=False)], rgb=local[b][cy0 - y0:cy1 - y0])
+            gbc.finish(st)
+            per_chunk.append(gbc)
+        batches.append(per_chunk)
+    comm = torch.cuda.Stream(device=dev) if dist else None
+    events = [[torch.cuda.Event() for _ in per_chunk] for per_chunk in batches]
 
-    def gather():
-        local = gb.images[0]["rgb"][:heights[rank]]
+    def decode(b):
+        for gbc, ev in zip(batches[b], events[b]):
+            gbc.step(st)
+            ev.record(torch.cuda.current_stream())
+
+    def start_gather(b):
+        """hand buffer b's rows to the gather (asynchronous); returns what finish_gather waits for"""
         if dist is None:
-            return local
-        if args.dist_backend != "nccl":
-            full = sh.gather_slabs(local.cpu(), heights, dst=0)
-            return None if full is None else full.to(dev)
-        return sh.gather_slabs(local, heights, dst=0)
+            return None
+        with torch.cuda.stream(comm):
+            if rank == 0:
+                return gat.post_recvs(images[b])
+            evs = events[b]
+            return gat.send(local[b], chunk_ready=(lambda i: comm.wait_event(evs[min(i, len(evs) - 1)])) if evs else None)
 
+    def finish_gather(works):
+        if works is None:
+            return
+        if rank == 0:
+            with torch.cuda.stream(comm):
+                gat.wait(works)
+        else:
+            for w in works:
+                w.wait()
+
+    decode(0)
+    torch.cuda.synchronize()
     # ---- self-check: the gathered image equals the one-rank decode, bit for bit ----
-    full = gather()
+    works = start_gather(0)
+    finish_gather(works)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
     ok = 1
     check = "skipped"
     if rank == 0 and not args.no_parity:
@@ -1271,14 +1358,13 @@ def run_grid(args, torch, pkg, dev, dist, rank, world, st, shared):
         one.step(st)
         torch.cuda.synchronize()
         ref = one.images[0]["rgb"][:H]
-        ok = int(torch.equal(full[:, :W * 3], ref[:, :W * 3]))
+        ok = int(torch.equal(images[0][:, :W * 3], ref[:, :W * 3]))
         check = "gathered slabs == one-rank decode (bit-exact)" if ok else "MISMATCH"
-        # and the one-rank decode against the oracle on one random tile row (the whole grid is 1024 tile decodes on the CPU)
         one.batch.close()
-        del one
+        del one, ref
         torch.cuda.empty_cache()
     if dist:
-        t = torch.tensor([ok], dtype=torch.int32, device=dev if args.dist_backend == "nccl" else "cpu")
+        t = torch.tensor([ok], dtype=torch.int32, device=dev if nccl else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         ok = int(t.item())
     if not ok:
@@ -1286,49 +1372,156 @@ def run_grid(args, torch, pkg, dev, dist, rank, world, st, shared):
             emit({"error": "grid mode self-check failed: gathered RGB != one-rank decode"})
         raise SystemExit(3)
 
+    def barrier_sync():
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+
+    # ---- K only: the decode loop without any gather ----
     for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
+        decode(0)
+    barrier_sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
+    for i in range(args.steps):
+        decode(i % NB)
+    barrier_sync()
     decode_s = time.perf_counter() - t0
+    # ---- the pipelined loop: grid i's slabs travel while grid i + 1 is decoded into the other buffer ----
+    pending = [None] * NB
+    barrier_sync()
     t0 = time.perf_counter()
+    for i in range(args.steps):
+        b = i % NB
+        finish_gather(pending[b])  # (the buffer's previous grid has left it)
+        decode(b)
+        pending[b] = start_gather(b)
+    for b in range(NB):
+        finish_gather(pending[b])
+    barrier_sync()
+    piped_s = time.perf_counter() - t0
+    # ---- one grid at a time: decode, then gather (the latency a single caller sees) ----
     n_g = max(1, min(args.steps, 5))
+    barrier_sync()
+    t0 = time.perf_counter()
     for _ in range(n_g):
-        full = gather()
-    torch.cuda.synchronize()
+        decode(0)
+        finish_gather(start_gather(0))
+        barrier_sync()
+    serial_s = (time.perf_counter() - t0) / n_g
+    # ---- the alternative: every rank copies its rows into ONE pinned host image (shared memory between the ranks' processes) ----
+    host = host_gather_leg(args, torch, dist, rank, world, dev, st, H, out_stride, y0, y1, local, decode, barrier_sync, images)
     if dist:
-        dist.barrier()
-    gather_s = (time.perf_counter() - t0) / n_g
-    if dist:
-        tt = torch.tensor([decode_s, gather_s], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        tt = torch.tensor([decode_s, piped_s, serial_s], dtype=torch.float64, device=dev if nccl else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        decode_s, gather_s = float(tt[0].item()), float(tt[1].item())
+        decode_s, piped_s, serial_s = (float(x) for x in tt.tolist())
     if rank == 0:
         mp = W * H / 1e6
-        per_step = decode_s / args.steps
+        k_step = decode_s / args.steps
+        per_step = (piped_s if dist else decode_s) / args.steps
+        gather_bytes = int(sum(y1_ - y0_ for r in range(1, world) for (y0_, y1_) in (gat.rows[r] if gat else [])) * out_stride)
         out = {"metric": "megapixels/sec HEIC grid->RGB24", "value": round(mp / per_step, 1), "unit": "MP/s", "n_gpus": world,
                "world_size": dist.get_world_size() if dist else 1, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(per_step * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
                "data": "synthetic",
                "config": {"workload": "ONE 16384x16384 HEIC grid (32x32 tiles of 512x512, 8-bit 4:2:0, CTB32) -> RGB24, tile rows sharded over the ranks",
-                          "tile_rows_per_rank": [b for _, b in slabs], "self_check": check,
-                          "timed_region": "K clock per rank (kernels, command streams resident); the gather is timed separately"},
-               "gather": {"ms": round(gather_s * 1e3, 3), "bytes": int(sum(heights[1:]) * gb.os), "backend": args.dist_backend if dist else "none",
-                          "note": "one padded gather collective of the RGB row slabs to rank 0 (RCCL over xGMI with nccl)"},
-               "with_gather_MP_per_s": round(mp / (per_step + gather_s), 1)}
+                          "tile_rows_per_rank": [b for _, b in slabs], "chunk_tile_rows": chunk_rows, "chunks_per_rank": [len(sh.slab_chunks(a, b, chunk_rows)) for a, b in slabs],
+                          "self_check": check,
+                          "timed_region": ("K clock + the gather of the RGB row slabs to rank 0, pipelined: grid i's slabs travel under the decode of grid i + 1 (two buffers per rank); "
+                                           "point-to-point, no padding, received straight into the rows of the root's image") if dist else "K clock (one rank: nothing to gather)"},
+               "k_only": {"MP_per_s": round(mp / k_step, 1), "ms_per_step": round(k_step * 1e3, 4)},
+               "single_grid_latency": {"ms": round(serial_s * 1e3, 3), "MP_per_s": round(mp / serial_s, 1), "what": "decode, then gather, one grid at a time"},
+               "gather": {"bytes": gather_bytes, "backend": args.dist_backend if dist else "none",
+                          "ms_not_hidden_per_step": round((per_step - k_step) * 1e3, 3)},
+               "with_gather_MP_per_s": round(mp / per_step, 1),
+               "host_gather": host}
         if shared:
             out["config"]["shared_gpu"] = "ranks share one GPU: functional run of the N>1 path, not a scaling number"
         emit(out)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def host_gather_leg(args, torch, dist, rank, world, dev, st, H, out_stride, y0, y1, local, decode, barrier_sync, images):
+    """Every rank copies its slab device -> host into ITS ROWS of one image in host memory that all ranks' processes map (a file in
+    /dev/shm, registered with the HIP runtime so that the copy is a DMA into it) - the collective-free form of the gather for a caller
+    that wants the planes in host memory anyway (in-process: hm_decode_item_devices).  -> dict (rank 0), timings max over ranks"""
+    import mmap
+    import numpy as np
+    path = f"/dev/shm/hm_grid_{os.environ.get('MASTER_PORT', '0')}_{os.getppid() if dist else os.getpid()}.bin"
+    nbytes = H * out_stride
+    try:
+        if rank == 0:
+            with open(path, "wb") as f:
+                f.truncate(nbytes)
+        if dist:
+            dist.barrier()
+        f = open(path, "r+b")
+        mm = mmap.mmap(f.fileno(), nbytes)
+        host = torch.frombuffer(mm, dtype=torch.uint8).view(H, out_stride)
+        rt = torch.cuda.cudart()
+        registered = int(rt.cudaHostRegister(host.data_ptr(), nbytes, 0)) == 0
+        copy_stream = torch.cuda.Stream(device=dev)
+        copied = [torch.cuda.Event() for _ in local]  # buffer b's rows have left it
+        rows = host[y0:y1]
+
+        def d2h(b):
+            copy_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(copy_stream):
+                rows.copy_(local[b][:y1 - y0], non_blocking=True)
+                copied[b].record(copy_stream)
+
+        n = max(1, min(args.steps, 5))
+        decode(0)
+        d2h(0)
+        barrier_sync()
+        ok = True
+        if rank == 0 and images is not None and not args.no_parity and world > 1:
+            ok = bool(torch.equal(host, images[0].cpu()))  # (images[0] holds the RCCL / gloo gather of the same grid)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            decode(0)
+            d2h(0)
+            barrier_sync()
+        serial = (time.perf_counter() - t0) / n
+        barrier_sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            b = i % len(local)
+            torch.cuda.current_stream().wait_event(copied[b])  # (the buffer's previous grid has been copied out)
+            decode(b)
+            d2h(b)
+        barrier_sync()
+        piped = (time.perf_counter() - t0) / args.steps
+        if registered:
+            rt.cudaHostUnregister(host.data_ptr())
+        res = [serial, piped]
+        if dist:
+            tt = torch.tensor(res, dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            res = [float(x) for x in tt.tolist()]
+        del host
+        mm.close()
+        f.close()
+        if dist:
+            dist.barrier()
+        if rank == 0:
+            os.unlink(path)
+            mp = H * H / 1e6
+            return {"what": "every rank D2H into its rows of ONE host image shared by the ranks (file in /dev/shm, hipHostRegister'ed): no collective; the image ends in HOST memory, "
+                            "where heif_image_get_plane* hands it out (the gather above ends on rank 0's GPU)",
+                    "registered": registered, "equals_the_gathered_image": ok,
+                    "single_grid_latency_ms": round(res[0] * 1e3, 3), "pipelined_ms_per_grid": round(res[1] * 1e3, 3), "pipelined_MP_per_s": round(mp / res[1], 1)}
+        return None
+    except Exception as e:  # (a leg of its own: its failure must not take the grid line with it)
+        try:
+            if rank == 0 and os.path.exists(path):
+                os.unlink(path)
+        except OSError:
+            pass
+        if dist:
+            raise
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 if __name__ == "__main__":

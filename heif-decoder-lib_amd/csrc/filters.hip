@@ -401,6 +401,34 @@ __device__ __forceinline__ void pk_scatter(Window<uint8_t>& W, const uint32_t (&
   }
 }
 
+// ... and of a window of 16-bit samples (r06: 10-bit pictures - the class of HDR photographs - ran the one-line-at-a-time filters, 42 % of
+// k_tailf's time on that class).  Every value of the filters still fits a signed 16-bit half while the samples have at most 11 bits
+// (normal filter: 9 |q0 - p0| + 3 |q1 - p1| + 8 <= 12 * 2047 + 8; strong filter: sums of eight samples + 4); 12-bit pictures keep the
+// general functions.  A row of the window is four dwords of sample pairs: for a HORIZONTAL edge (lines = columns) two neighbouring
+// lines already lie in one register - no gather at all -, for a vertical edge the halves of two rows are merged.
+template <bool V, int A, int I0 = 0, int I1 = 8>
+__device__ __forceinline__ void pk_gather(const Window<uint16_t>& W, uint32_t (&P)[8])
+{
+  static_assert((A & 1) == 0, "pairs of lines start at an even line");
+#pragma unroll
+  for (int i = I0; i < I1; i++) {
+    if (V) P[i] = __builtin_amdgcn_perm(W.w[A + 1][i >> 1], W.w[A][i >> 1], (i & 1) ? 0x07060302u : 0x05040100u);
+    else P[i] = W.w[i][A >> 1];
+  }
+}
+template <bool V, int A, int I0, int I1>
+__device__ __forceinline__ void pk_scatter(Window<uint16_t>& W, const uint32_t (&P)[8])
+{
+#pragma unroll
+  for (int i = I0; i < I1; i++) {
+    if (V) {
+      W.w[A][i >> 1] = __builtin_amdgcn_perm(P[i], W.w[A][i >> 1], (i & 1) ? 0x05040100u : 0x03020504u);
+      W.w[A + 1][i >> 1] = __builtin_amdgcn_perm(P[i], W.w[A + 1][i >> 1], (i & 1) ? 0x07060100u : 0x03020706u);
+    }
+    else W.w[i][A >> 1] = P[i];
+  }
+}
+
 // fallback-postfilter.h:32-138 for one 4-line unit (lines O .. O + 3) of one edge of the window, in two steps, so that a kernel
 // may decide for every unit first and then run each filter on the units that need it (k_tail420: the windows' units sorted by
 // kind in LDS - a wave that holds both kinds executes both filters for all its lanes):
@@ -408,16 +436,22 @@ __device__ __forceinline__ void pk_scatter(Window<uint8_t>& W, const uint32_t (&
 //                      or dE = 0), else tc | dEp << 8 | dEq << 9 | strong << 10 | 1 << 11
 //   luma_unit_apply    the strong or the normal filter on the unit's four lines, two lines per pass
 constexpr uint32_t DEC_NP2 = 1u << 8, DEC_NQ2 = 1u << 9, DEC_STRONG = 1u << 10, DEC_FILTER = 1u << 11;
-template <bool V, int O>
-__device__ __forceinline__ uint32_t luma_unit_decide(const Window<uint8_t>& W, int beta, int tc)
+template <bool V, int O, typename Pix = uint8_t>
+__device__ __forceinline__ uint32_t luma_unit_decide(const Window<Pix>& W, int beta, int tc)
 {
   if (tc == 0) return 0; // bS 0 (tc is 0 only then: the strong filter clips to +-2tc, the normal one needs |delta| < 10 tc)
   // C[i] = sample i (p3 p2 p1 p0 | q0 q1 q2 q3) of line O (low half) and of line O + 3 (high half)
   s16x2 C[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) {
-    if (V) C[i] = as_s(__builtin_amdgcn_perm(W.w[O + 3][i >> 2], W.w[O][i >> 2], 0x0c000c00u | (uint32_t)(i & 3) | ((uint32_t)(4 + (i & 3)) << 16)));
-    else C[i] = as_s(__builtin_amdgcn_perm(0u, W.w[i][O >> 2], 0x0c000c00u | (uint32_t)(O & 3) | ((uint32_t)((O & 3) + 3) << 16)));
+    if constexpr (sizeof(Pix) == 1) {
+      if (V) C[i] = as_s(__builtin_amdgcn_perm(W.w[O + 3][i >> 2], W.w[O][i >> 2], 0x0c000c00u | (uint32_t)(i & 3) | ((uint32_t)(4 + (i & 3)) << 16)));
+      else C[i] = as_s(__builtin_amdgcn_perm(0u, W.w[i][O >> 2], 0x0c000c00u | (uint32_t)(O & 3) | ((uint32_t)((O & 3) + 3) << 16)));
+    }
+    else { // 16-bit samples: halves of two rows (vertical edge) / columns O and O + 3 of row i (horizontal edge)
+      if (V) C[i] = as_s(__builtin_amdgcn_perm(W.w[O + 3][i >> 1], W.w[O][i >> 1], (i & 1) ? 0x07060302u : 0x05040100u));
+      else C[i] = as_s(__builtin_amdgcn_perm(W.w[i][(O + 3) >> 1], W.w[i][O >> 1], 0x07060100u));
+    }
   }
   const uint32_t dp = as_w(pk_abs(C[1] - C[2] - C[2] + C[3])), dq = as_w(pk_abs(C[6] - C[5] - C[5] + C[4]));
   const int dp0 = (int)(dp & 0xFFFF), dp3 = (int)(dp >> 16), dq0 = (int)(dq & 0xFFFF), dq3 = (int)(dq >> 16);
@@ -430,8 +464,9 @@ __device__ __forceinline__ uint32_t luma_unit_decide(const Window<uint8_t>& W, i
   const int thr = (beta + (beta >> 1)) >> 3;
   return (uint32_t)tc | (dp0 + dp3 < thr ? DEC_NP2 : 0u) | (dq0 + dq3 < thr ? DEC_NQ2 : 0u) | (strong ? DEC_STRONG : 0u) | DEC_FILTER;
 }
-template <bool V, int O>
-__device__ __forceinline__ void luma_unit_apply(Window<uint8_t>& W, uint32_t dec)
+// maxv: the largest sample value (255; a window of 16-bit samples: (1 << bit depth) - 1, bit depth <= 11)
+template <bool V, int O, typename Pix = uint8_t>
+__device__ __forceinline__ void luma_unit_apply(Window<Pix>& W, uint32_t dec, int maxv_s = 255)
 {
   const int tc = (int)(dec & 0xFF);
   uint32_t A[8], B[8];
@@ -461,7 +496,7 @@ __device__ __forceinline__ void luma_unit_apply(Window<uint8_t>& W, uint32_t dec
     const int tc_2 = tc >> 1;
     const bool np2 = (dec & DEC_NP2) != 0, nq2 = (dec & DEC_NQ2) != 0;
     const s16x2 tcv = (s16x2)((short)tc), ntcv = (s16x2)(0) - tcv, tc2v = (s16x2)((short)tc_2), ntc2v = (s16x2)(0) - tc2v;
-    const s16x2 zero = (s16x2)(0), maxv = (s16x2)(255), lim = (s16x2)((short)(10 * tc));
+    const s16x2 zero = (s16x2)(0), maxv = (s16x2)((short)maxv_s), lim = (s16x2)((short)(10 * tc));
     auto pass = [&](uint32_t (&X)[8]) {
       const s16x2 p2 = as_s(X[1]), p1 = as_s(X[2]), p0 = as_s(X[3]), q0 = as_s(X[4]), q1 = as_s(X[5]), q2 = as_s(X[6]);
       const s16x2 dqp = q0 - p0, dqp1 = q1 - p1;
@@ -480,18 +515,18 @@ __device__ __forceinline__ void luma_unit_apply(Window<uint8_t>& W, uint32_t dec
   }
 }
 // ... for the two units of one edge of the window, one after the other (k_deblock, k_tailf)
-template <bool V>
-__device__ __forceinline__ void filter_luma_pk(Window<uint8_t>& W, const int beta2[2], const int tc2[2])
+template <bool V, typename Pix = uint8_t>
+__device__ __forceinline__ void filter_luma_pk(Window<Pix>& W, const int beta2[2], const int tc2[2], int maxv = 255)
 {
-  const uint32_t d0 = luma_unit_decide<V, 0>(W, beta2[0], tc2[0]);
-  if (d0) luma_unit_apply<V, 0>(W, d0);
-  const uint32_t d1 = luma_unit_decide<V, 4>(W, beta2[1], tc2[1]);
-  if (d1) luma_unit_apply<V, 4>(W, d1);
+  const uint32_t d0 = luma_unit_decide<V, 0, Pix>(W, beta2[0], tc2[0]);
+  if (d0) luma_unit_apply<V, 0, Pix>(W, d0, maxv);
+  const uint32_t d1 = luma_unit_decide<V, 4, Pix>(W, beta2[1], tc2[1]);
+  if (d1) luma_unit_apply<V, 4, Pix>(W, d1, maxv);
 }
 
 // chroma edge (fallback-postfilter.h:138-180), two lines per pass: p1 p0 | q0 q1 = samples 2..5
-template <bool V>
-__device__ __forceinline__ void filter_chroma_pk(Window<uint8_t>& W, const int tc2[2])
+template <bool V, typename Pix = uint8_t>
+__device__ __forceinline__ void filter_chroma_pk(Window<Pix>& W, const int tc2[2], int maxv = 255)
 {
   auto pair = [&](auto ac) {
     constexpr int A = decltype(ac)::value;
@@ -502,8 +537,8 @@ __device__ __forceinline__ void filter_chroma_pk(Window<uint8_t>& W, const int t
     const s16x2 p1 = as_s(X[2]), p0 = as_s(X[3]), q0 = as_s(X[4]), q1 = as_s(X[5]);
     const s16x2 tv = (s16x2)((short)t);
     const s16x2 delta = pk_clamp((((q0 - p0) << (s16x2)(2)) + p1 - q1 + (s16x2)(4)) >> (s16x2)(3), (s16x2)(0) - tv, tv);
-    X[3] = as_w(pk_clamp(p0 + delta, (s16x2)(0), (s16x2)(255)));
-    X[4] = as_w(pk_clamp(q0 - delta, (s16x2)(0), (s16x2)(255)));
+    X[3] = as_w(pk_clamp(p0 + delta, (s16x2)(0), (s16x2)((short)maxv)));
+    X[4] = as_w(pk_clamp(q0 - delta, (s16x2)(0), (s16x2)((short)maxv)));
     pk_scatter<V, A, 3, 5>(W, X);
   };
   pair(std::integral_constant<int, 0>());
@@ -525,6 +560,19 @@ __device__ __forceinline__ void window_filter(Window<Pix>& win, int c, const Win
       filter_chroma_pk<false>(win, E.tcH);
     }
     return;
+  }
+  if constexpr (sizeof(Pix) == 2 && !PCMF) { // (r06) ... and deep pictures of at most 11 bits: every value of the filters fits a 16-bit half
+    if (maxv < 2048) { // (the same for every lane: the picture's bit depth)
+      if (c == 0) {
+        filter_luma_pk<true, Pix>(win, E.betaV, E.tcV, maxv);
+        filter_luma_pk<false, Pix>(win, E.betaH, E.tcH, maxv);
+      }
+      else {
+        filter_chroma_pk<true, Pix>(win, E.tcV, maxv);
+        filter_chroma_pk<false, Pix>(win, E.tcH, maxv);
+      }
+      return;
+    }
   }
   if (c == 0) {
     filter_luma<true>(win, E.betaV, E.tcV, maxv, E.mpV, E.mqV);
@@ -929,19 +977,25 @@ __global__ __launch_bounds__(256) void k_sao_paste(const hm_dev_pic* __restrict_
 // map of pitch MP whose border cells hold the clamped neighbours (meta_at's clamping, done once per cell).  The seven words a
 // window can need lie at fixed offsets from it: the edge flags of its four units, and QpY on the Q / P side of each unit
 // (luma: at the start of the unit's 8-sample segment, chroma: at the unit) - deblock.cc:731-753, 1650-1716.
+// CF (r06: k_tailf's classes): 1 = 4:2:0 (a chroma unit of a vertical edge is two block rows high: its upper one lies two blocks above
+// the crossing, like the start of a luma segment), 2 = 4:2:2 (chroma rows are luma rows: one block above; QpC without Table 8-10);
+// bd_shift = bit depth - 8 (beta and tc scale with the depth, 8.7.2.5.3).
+template <int CF = 1>
 __device__ __forceinline__ bool tail_window_edges(const uint16_t* m, int MP, int c, int kx, int ky, int PW, int PH, int beta_off, int tc_off, int qp_off,
-                                                  const uint8_t* tab, WindowEdges<false>& E)
+                                                  const uint8_t* tab, WindowEdges<false>& E, int bd_shift = 0)
 {
   const int ex = kx << 3, ey = ky << 3, ox = ex - 4, oy = ey - 4;
   const uint32_t m00 = m[0], m10 = m[-1], m20 = m[-2], m01 = m[-MP], m21 = m[-MP - 2], m02 = m[-2 * MP], m12 = m[-2 * MP - 1];
-  const uint32_t mA = c ? m02 : m01, mC = c ? m20 : m10; // the words of the upper / left unit (chroma units are two blocks away)
+  const uint32_t m11 = CF == 2 ? m[-MP - 1] : 0u;
+  const bool c422 = CF == 2 && c != 0; // (a chroma plane whose rows are luma rows)
+  const uint32_t mA = (c && !c422) ? m02 : m01, mC = c ? m20 : m10; // the words of the upper / left unit (chroma units are two blocks away where the plane is sub-sampled)
   const bool in_x = ex > 0 && ex < PW, in_y = ey > 0 && ey < PH;
   const bool bV0 = in_x && oy >= 0 && oy < PH && (mA & 1), bV1 = in_x && ey < PH && (m00 & 1);
   const bool bH0 = in_y && ox >= 0 && ox < PW && (mC & 2), bH1 = in_y && ex < PW && (m00 & 2);
   if (!(bV0 | bV1 | bH0 | bH1)) return false;
   auto qpy = [](uint32_t w) { return (int)(int8_t)(w >> 8); };
   // Q / P side of: vertical edge upper, lower unit; horizontal edge left, right unit
-  const int q[4] = {qpy(m02), qpy(m00), qpy(m20), qpy(m00)}, p[4] = {qpy(m12), qpy(m10), qpy(m21), qpy(m01)};
+  const int q[4] = {qpy(c422 ? m01 : m02), qpy(m00), qpy(m20), qpy(m00)}, p[4] = {qpy(c422 ? m11 : m12), qpy(m10), qpy(m21), qpy(m01)};
   const bool bs[4] = {bV0, bV1, bH0, bH1};
   int beta[4], tc[4];
 #pragma unroll
@@ -949,14 +1003,15 @@ __device__ __forceinline__ bool tail_window_edges(const uint16_t* m, int MP, int
     const int avg = (q[u] + p[u] + 1) >> 1;
     int qt;
     if (c == 0) {
-      beta[u] = bs[u] ? (int)tab[clip3i(0, 51, avg + beta_off)] : 0;
+      beta[u] = bs[u] ? (int)tab[clip3i(0, 51, avg + beta_off)] << bd_shift : 0;
       qt = avg;
     }
     else {
       beta[u] = 0;
-      qt = chroma_qp_map(avg + qp_off); // (4:2:0: Table 8-10)
+      const int qPi = avg + qp_off;
+      qt = CF == 1 ? chroma_qp_map(qPi) : (qPi < 51 ? qPi : 51); // (4:2:0: Table 8-10; deblock.cc:1690-1696)
     }
-    tc[u] = bs[u] ? (int)tab[52 + clip3i(0, 53, qt + 2 + tc_off)] : 0; // (bS 2: + 2 (bS - 1))
+    tc[u] = bs[u] ? (int)tab[52 + clip3i(0, 53, qt + 2 + tc_off)] << bd_shift : 0; // (bS 2: + 2 (bS - 1))
   }
   E.betaV[0] = beta[0]; E.betaV[1] = beta[1]; E.betaH[0] = beta[2]; E.betaH[1] = beta[3];
   E.tcV[0] = tc[0]; E.tcV[1] = tc[1]; E.tcH[0] = tc[2]; E.tcH[1] = tc[3];
@@ -1135,6 +1190,9 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
   const int chunk = gridDim.x >> 3;
   const int tile = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
   if (tile >= n_tiles) return;
+  // (r06, tried and dropped: several consecutive tiles per workgroup in a loop, so that the next tile's window loads are in flight with
+  //  this tile's pixel stores - 2 / 4 / 8 tiles: 8.09 -> 12.0 / 12.1 / 19.2 ms.  A wave that ENDS does not wait for its stores, a wave that
+  //  goes on does at its next wait for a load: one counter, in order.  profiles/r06_tail_probes.txt)
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int x0 = tx * TAIL_TW, y0 = ty * TAIL_TH; // luma origin of the tile (source = destination coordinates: no crop offset)
   const int cw = dp.copy_w[0], chh = dp.copy_h[0];
@@ -1516,8 +1574,12 @@ __device__ __forceinline__ void tile_row(SaoRow<Pix>& R, const Pix* tile, int pi
 }
 // SAO of one group of 8 samples of row yy of plane c, rows read from an LDS tile whose sample (tx0, ty0) is its first (the
 // fast path of k_sao_paste: the per-CTB neighbour masks, no lossless units, no per-sample ring test)
+// rec: dwords 2..8 of the group's hm_ctb (flags and masks, then hm_sao of the three planes) in LDS - r06: read from memory here, the
+// words of a lane's second, third ... group were requested behind the pixel stores of the group before, and a wait for a load is
+// a wait for every store in front of it ("One counter"); the workgroup now copies the records of its tile's CTBs to
+// LDS before phase 1
 template <typename Pix>
-__device__ __forceinline__ void tile_sao(const hm_dev_pic& dp, const PicView& v, int c, const Pix* tile, int pitch, int tx0, int ty0,
+__device__ __forceinline__ void tile_sao(const hm_dev_pic& dp, const uint32_t* rec, int c, const Pix* tile, int pitch, int tx0, int ty0,
                                          int xs, int yy, int W, int Hh, int l2w, int l2h, int apply_sao, int bd, uint32_t (&res)[4])
 {
   SaoRow<Pix> rows[3];
@@ -1527,8 +1589,7 @@ __device__ __forceinline__ void tile_sao(const hm_dev_pic& dp, const PicView& v,
     tile_row(rows[r], tile, pitch, (y < 0 ? 0 : (y < Hh ? y : Hh - 1)) - ty0, xs - tx0);
   }
   const int cx = xs >> l2w, cy = yy >> l2h;
-  const GLOBAL_AS uint32_t* cbq = gptr<uint32_t>(reinterpret_cast<const uint8_t*>(v.ctbs) + (uint32_t)mul24_raw(cx + mul24_raw(cy, dp.ctb_w), (int)sizeof(hm_ctb)));
-  const uint32_t cflags = cbq[2], s0 = cbq[3 + 2 * c], s1 = cbq[4 + 2 * c];
+  const uint32_t cflags = rec[0], s0 = rec[1 + 2 * c], s1 = rec[2 + 2 * c];
   const SaoRow<Pix>&up = rows[0], &cur = rows[1], &dn = rows[2];
   const bool sao_on = apply_sao && (dp.flags & HM_PIC_SAO_ENABLED) && (cflags & (c == 0 ? HM_CTB_SAO_LUMA : HM_CTB_SAO_CHROMA));
   const int type = sao_on ? (int)(s0 & 0xFF) : 0;
@@ -1568,6 +1629,12 @@ __global__ __launch_bounds__(TF_THREADS) void k_tailf(const hm_dev_pic* __restri
   __shared__ __attribute__((aligned(16))) Pix s_l[LR * LP];
   __shared__ __attribute__((aligned(16))) Pix s_c[2][CR * CP];
   __shared__ uint8_t s_tab[112];
+  // r06: the tile's part of the block map (as in k_tail420: the windows' edge parameters from fixed offsets in it instead of eleven
+  // clamped loads per window) and the hm_ctb words 2..8 of the CTBs the tile touches (at most 8 x 2: CTBs of 16, tiles of 128 x 32)
+  constexpr int MP = TF_TW / 4 + 4, MR = TF_TH / 4 + 3;
+  constexpr int NREC = (TF_TW / 16) * (TF_TH / 16 > 0 ? TF_TH / 16 : 1);
+  __shared__ uint16_t s_meta[MR * MP];
+  __shared__ uint32_t s_rec[NREC][8];
   const hm_dev_pic& dp = pics[blockIdx.y];
   const int chunk = gridDim.x >> 3; // (workgroups go to the XCDs in turn: a contiguous run of tiles per XCD, as in k_tail420)
   const int tile = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
@@ -1580,27 +1647,38 @@ __global__ __launch_bounds__(TF_THREADS) void k_tailf(const hm_dev_pic* __restri
   const int tid = threadIdx.x;
   const int W = dp.width, H = dp.height;
   const int bd = dp.bit_depth, maxv = (1 << bd) - 1;
+  const int l2 = dp.log2_ctb;
   if (tid < 106) s_tab[tid] = tid < 52 ? c_beta[tid] : c_tc[tid - 52];
-  __syncthreads();
-
+  const bool one_slice = dp.n_slices == 1; // (pictures of several slices: the general window_edges)
+  const bool deblock = (stages & 1) && (dp.flags & HM_PIC_DEBLOCK_ANY);
+  int slice_beta_off = 0, slice_tc_off = 0;
+  if (one_slice) {
+    const uint32_t w1 = gptr<uint32_t>(v.slices)[1]; // hm_slice: slice_addr | beta_offset_div2, tc_offset_div2, ...
+    slice_beta_off = 2 * (int)(int8_t)(w1 & 0xFF);
+    slice_tc_off = 2 * (int)(int8_t)((w1 >> 8) & 0xFF);
+  }
   // ---- phase 1: deblocked samples of the tile (+ 4 around it) into LDS, one lane per window ----
-  {
-    constexpr int NLX = TF_TW / 8 + 1, NLY = TF_TH / 8 + 1, NCX = CW / 8 + 1, NCY = CH / 8 + 1;
-    constexpr int NL = NLX * NLY, NC = NCX * NCY;
-    for (int item = tid; item < NL + 2 * NC; item += TF_THREADS) {
-      int c = 0, kxl, kyl;
-      if (item < NL) { kyl = item / NLX; kxl = item - kyl * NLX; }
-      else {
-        int t = item - NL;
-        c = t >= NC ? 2 : 1;
-        t -= (c - 1) * NC;
-        kyl = t / NCX; kxl = t - kyl * NCX;
-      }
-      const int sw = c ? 2 : 1, sh = c ? (CF == 1 ? 2 : 1) : 1;
-      const int PW = W >> (sw >> 1), PH = H >> (sh >> 1);
-      const int kx = (c ? CW / 8 * tx : TF_TW / 8 * tx) + kxl, ky = (c ? CH / 8 * ty : TF_TH / 8 * ty) + kyl;
-      if (kx > ((PW + 7) >> 3) || ky > ((PH + 7) >> 3)) continue;
-      Window<Pix> win;
+  // The lane's window loads go out first; the records of the tile's CTBs and the block map are requested behind them: one trip to
+  // memory for all of it.
+  constexpr int NLX = TF_TW / 8 + 1, NLY = TF_TH / 8 + 1, NCX = CW / 8 + 1, NCY = CH / 8 + 1;
+  constexpr int NL = NLX * NLY, NC = NCX * NCY;
+  static_assert(NL + 2 * NC <= TF_THREADS, "one lane per window");
+  int c = 0, kxl = 0, kyl = 0, kx = 0, ky = 0, PW = 0, PH = 0;
+  bool have_window = false;
+  Window<Pix> win;
+  if (tid < NL + 2 * NC) {
+    if (tid < NL) { kyl = tid / NLX; kxl = tid - kyl * NLX; }
+    else {
+      int t = tid - NL;
+      c = t >= NC ? 2 : 1;
+      t -= (c - 1) * NC;
+      kyl = t / NCX; kxl = t - kyl * NCX;
+    }
+    const int sw = c ? 2 : 1, sh = c ? (CF == 1 ? 2 : 1) : 1;
+    PW = W >> (sw >> 1); PH = H >> (sh >> 1);
+    kx = (c ? CW / 8 * tx : TF_TW / 8 * tx) + kxl; ky = (c ? CH / 8 * ty : TF_TH / 8 * ty) + kyl;
+    if (kx <= ((PW + 7) >> 3) && ky <= ((PH + 7) >> 3)) {
+      have_window = true;
       const int ox = (kx << 3) - 4, oy = (ky << 3) - 4;
       if (ox >= 0) window_load(win, dp.plane[c], dp.pitch[c], ox, oy, PH);
       else { // left picture border: the window's left half does not exist
@@ -1613,22 +1691,57 @@ __global__ __launch_bounds__(TF_THREADS) void k_tailf(const hm_dev_pic* __restri
           __builtin_memcpy(win.w[r] + HW, gptr<uint8_t>(dp.plane[c] + (uint32_t)mul24_raw(y, dp.pitch[c])), 4 * sizeof(Pix));
         }
       }
-      if ((stages & 1) && (dp.flags & HM_PIC_DEBLOCK_ANY)) {
-        WindowEdges<false> E;
-        if (window_edges<Pix, false>(dp, v, c, kx, ky, sw, sh, E, TabLds{s_tab})) window_filter<Pix, false>(win, c, E, maxv);
-      }
-      Pix* const t0 = c == 0 ? s_l : s_c[c - 1];
-      const int tp = c == 0 ? LP : CP;
-      Pix* const q = t0 + (8 * kyl) * tp + 8 * kxl + (TF_XO - 4);
-#pragma unroll
-      for (int r = 0; r < 8; r++) __builtin_memcpy(q + r * tp, win.w[r], 8 * sizeof(Pix));
     }
   }
+  // the records of the tile's CTBs: columns x0 >> l2 .., rows y0 >> l2 ..
+  const int ncx = (TF_TW >> l2) > 0 ? (TF_TW >> l2) : 1, ncy = (TF_TH >> l2) > 0 ? (TF_TH >> l2) : 1;
+  const int cx0 = x0 >> l2, cy0 = y0 >> l2;
+  uint32_t rec_word = 0;
+  if (tid < NREC * 8) {
+    const int r = tid >> 3, k = tid & 7;
+    const int rx = r % ncx, ry = r / ncx;
+    if (k < 7 && ry < ncy) {
+      const int qx = cx0 + rx < dp.ctb_w ? cx0 + rx : dp.ctb_w - 1, qy = cy0 + ry < dp.ctb_h ? cy0 + ry : dp.ctb_h - 1;
+      rec_word = gptr<uint32_t>(reinterpret_cast<const uint8_t*>(v.ctbs) + (uint32_t)(qx + qy * dp.ctb_w) * (uint32_t)sizeof(hm_ctb))[2 + k];
+    }
+  }
+  if (one_slice && deblock) {
+    const GLOBAL_AS uint16_t* const meta = gptr<uint16_t>(dp.meta);
+    const int bx0 = (x0 >> 2) - 2, by0 = (y0 >> 2) - 2, w4 = dp.w4, h4 = dp.h4;
+    for (int i = tid; i < MR * MP; i += TF_THREADS) {
+      const int my = i / MP, mx = i - my * MP;
+      const int bx = bx0 + mx < 0 ? 0 : (bx0 + mx < w4 ? bx0 + mx : w4 - 1), by = by0 + my < 0 ? 0 : (by0 + my < h4 ? by0 + my : h4 - 1);
+      s_meta[i] = meta[(uint32_t)(bx + mul24_raw(by, w4))];
+    }
+  }
+  __syncthreads(); // (the block map and the tables are there)
+  if (tid < NREC * 8) s_rec[tid >> 3][tid & 7] = rec_word;
+  if (have_window) {
+    if (deblock) {
+      WindowEdges<false> E;
+      bool any_edge;
+      if (one_slice) {
+        // (the crossing's block: luma (2 kx, 2 ky); chroma (4 kx, 4 ky) for 4:2:0, (4 kx, 2 ky) for 4:2:2)
+        const int mby = c ? (CF == 1 ? 4 : 2) * kyl : 2 * kyl, mbx = c ? 4 * kxl : 2 * kxl;
+        any_edge = tail_window_edges<CF>(s_meta + (mby + 2) * MP + mbx + 2, MP, c, kx, ky, PW, PH, slice_beta_off, slice_tc_off,
+                                         c == 0 ? 0 : (c == 1 ? dp.cb_qp_offset : dp.cr_qp_offset), s_tab, E, bd - 8);
+      }
+      else any_edge = window_edges<Pix, false>(dp, v, c, kx, ky, c ? 2 : 1, c ? (CF == 1 ? 2 : 1) : 1, E, TabLds{s_tab});
+      if (any_edge) window_filter<Pix, false>(win, c, E, maxv);
+    }
+    Pix* const t0 = c == 0 ? s_l : s_c[c - 1];
+    const int tp = c == 0 ? LP : CP;
+    Pix* const q = t0 + (8 * kyl) * tp + 8 * kxl + (TF_XO - 4);
+#pragma unroll
+    for (int r = 0; r < 8; r++) __builtin_memcpy(q + r * tp, win.w[r], 8 * sizeof(Pix));
+  }
+  // (said explicitly: no load is outstanding when phase 2 begins - nothing in it refers to one any more, and the compiler's wait
+  //  insertion must not guard register reuse there with waits for "everything", i.e. for the pixel stores of the lane's previous group)
+  __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
   __syncthreads();
 
   // ---- phase 2: one lane = 16 luma samples of a row (of two rows: 4:2:0) and the 8 Cb / 8 Cr samples under them: SAO of all
   //      of them from the LDS tiles, the float operation, 16 pixels per row to the image ----
-  const int l2 = dp.log2_ctb;
   const bool rescale = dp.rescale != 0; // (the same for every lane of the workgroup)
   const TailDst D = dsts[blockIdx.y];
   constexpr int RL = 1 << SV;              // luma rows per lane
@@ -1637,11 +1750,14 @@ __global__ __launch_bounds__(TF_THREADS) void k_tailf(const hm_dev_pic* __restri
     const int rp = item / LG, g = item - rp * LG;
     const int lx = x0 + 16 * g, ly = y0 + RL * rp;
     if (lx >= cw || ly >= chh) continue;
+    // (the lane's 16 x RL luma samples and the chroma under them lie in ONE CTB - CTBs are at least 16 x 16, lx and ly are multiples
+    //  of 16 and RL: one record for all of its groups)
+    const uint32_t* const rec = s_rec[((lx >> l2) - cx0) + ((ly >> l2) - cy0) * ncx];
     uint32_t cbs[4], crs[4]; // the chroma samples after SAO, as pairs
     {
       const int xc = lx >> 1, yc = ly >> SV;
-      tile_sao<Pix>(dp, v, 1, s_c[0], CP, (x0 >> 1) - TF_XO, (y0 >> SV) - 4, xc, yc, W >> 1, H >> SV, l2 - 1, l2 - SV, stages & 2, bd, cbs);
-      tile_sao<Pix>(dp, v, 2, s_c[1], CP, (x0 >> 1) - TF_XO, (y0 >> SV) - 4, xc, yc, W >> 1, H >> SV, l2 - 1, l2 - SV, stages & 2, bd, crs);
+      tile_sao<Pix>(dp, rec, 1, s_c[0], CP, (x0 >> 1) - TF_XO, (y0 >> SV) - 4, xc, yc, W >> 1, H >> SV, l2 - 1, l2 - SV, stages & 2, bd, cbs);
+      tile_sao<Pix>(dp, rec, 2, s_c[1], CP, (x0 >> 1) - TF_XO, (y0 >> SV) - 4, xc, yc, W >> 1, H >> SV, l2 - 1, l2 - SV, stages & 2, bd, crs);
       if (rescale) { // (the paste of a limited-range tile: context.cc:2504-2528)
 #pragma unroll
         for (int j = 0; j < 4; j++) { cbs[j] = pk_rescale_stored<Pix, true>(cbs[j], bd); crs[j] = pk_rescale_stored<Pix, true>(crs[j], bd); }
@@ -1655,7 +1771,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_tailf(const hm_dev_pic* __restri
         const int hx = lx + 8 * half;
         if (hx >= cw) break;
         uint32_t ry[4];
-        tile_sao<Pix>(dp, v, 0, s_l, LP, x0 - TF_XO, y0 - 4, hx, ly + r, W, H, l2, l2, stages & 2, bd, ry);
+        tile_sao<Pix>(dp, rec, 0, s_l, LP, x0 - TF_XO, y0 - 4, hx, ly + r, W, H, l2, l2, stages & 2, bd, ry);
         if (rescale) {
 #pragma unroll
           for (int j = 0; j < 4; j++) ry[j] = pk_rescale_stored<Pix, false>(ry[j], bd);

@@ -56,3 +56,81 @@ def gather_slabs(local, heights: List[int], dst: int = 0, group=None):
         return torch.cat([b[:h] for b, h in zip(bufs, heights)], 0)
     dist.gather(local, None, dst=dst, group=group)
     return None
+
+
+def slab_chunks(first_tile_row: int, n_tile_rows: int, chunk_tile_rows: int) -> List[Tuple[int, int]]:
+    """a slab of tile rows cut into chunks of at most `chunk_tile_rows` (the last one may be shorter; 0 or less: one chunk):
+    [(first_tile_row, n_tile_rows), ...] - the unit a rank hands to the gather as soon as its rows are decoded"""
+    if n_tile_rows <= 0:
+        return []
+    if chunk_tile_rows <= 0 or chunk_tile_rows >= n_tile_rows:
+        return [(first_tile_row, n_tile_rows)]
+    return [(r, min(chunk_tile_rows, first_tile_row + n_tile_rows - r)) for r in range(first_tile_row, first_tile_row + n_tile_rows, chunk_tile_rows)]
+
+
+class SlabGather:
+    """The grid gather without padding and without a copy on the root (r06): every rank sends the rows of its slab in chunks of tile
+    rows (point-to-point, in order per peer), the root receives every chunk STRAIGHT INTO ITS ROWS of the final image and decodes its
+    own slab in place (`root_rows`).  `gather_slabs` above pads every slab to the tallest one and concatenates on the root - one more
+    pass over the whole image on the root GPU, and 1/world of the bytes moved for nothing when the rows do not divide.
+
+    stage_through_host: the transport cannot take device tensors (gloo): the chunks travel as CPU tensors (tests, `--dist-backend gloo`).
+    Usage per image:  root: recvs = g.post_recvs(full) ... g.wait(recvs);   every other rank: g.send(local, stream_event=None)"""
+
+    def __init__(self, slabs: List[Tuple[int, int]], tile_h: int, out_h: int, chunk_tile_rows: int = 0, dst: int = 0, group=None,
+                 stage_through_host: bool = False):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group, self.dst = group, dst
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        assert len(slabs) == self.world
+        self.stage = stage_through_host
+        # per rank: the pixel rows [y0, y1) of each of its chunks, in sending order; empty chunks (cropped away) are skipped on both sides
+        self.rows = []
+        for first, n in slabs:
+            ch = [slab_pixel_rows(a, b, tile_h, out_h) for a, b in slab_chunks(first, n, chunk_tile_rows)]
+            self.rows.append([(y0, y1) for y0, y1 in ch if y1 > y0])
+        self.slab_y0 = [slab_pixel_rows(a, b, tile_h, out_h)[0] for a, b in slabs]
+
+    def root_rows(self, full):
+        """root only: the rows of `full` that hold the root's own slab (decode into them: no copy)"""
+        r = self.rows[self.dst]
+        return full[r[0][0]:r[-1][1]] if r else full[0:0]
+
+    def post_recvs(self, full):
+        """root only: one receive per (rank, chunk) into the chunk's rows of `full` ([out_h, stride], contiguous rows)"""
+        import torch
+        assert self.rank == self.dst
+        works = []
+        for r in range(self.world):
+            if r == self.dst:
+                continue
+            for y0, y1 in self.rows[r]:
+                view = full[y0:y1]
+                if self.stage:
+                    buf = torch.empty(view.shape, dtype=view.dtype, device="cpu")
+                    works.append((self.dist.irecv(buf, src=r, group=self.group), buf, view))
+                else:
+                    works.append((self.dist.irecv(view, src=r, group=self.group), None, view))
+        return works
+
+    def wait(self, works):
+        for w, buf, view in works:
+            w.wait()
+            if buf is not None:
+                view.copy_(buf)
+
+    def send(self, local, chunk_ready=None):
+        """every other rank: `local` = its slab ([rows of the slab, stride], row 0 = the slab's first pixel row).  chunk_ready(i): called
+        before chunk i is handed over (e.g. waits for the event behind that chunk's decode on the sending stream); returns the works"""
+        assert self.rank != self.dst
+        works = []
+        base = self.slab_y0[self.rank]
+        for i, (y0, y1) in enumerate(self.rows[self.rank]):
+            if chunk_ready is not None:
+                chunk_ready(i)
+            chunk = local[y0 - base:y1 - base]
+            if self.stage:
+                chunk = chunk.cpu()
+            works.append(self.dist.isend(chunk.contiguous(), dst=self.dst, group=self.group))
+        return works

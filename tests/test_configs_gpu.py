@@ -317,7 +317,9 @@ def test_fused_tail_with_limited_range_paste(pkg, hm, shape):
                          ids=["slices", "slice_headers", "filters_stop_at_slices"])
 def test_fused_tail_with_several_slices(pkg, hm, slicing):
     """pictures of several slices (own deblocking / SAO switches and offsets per slice) through the fused kernel: equal to the
-    separate kernels; fused whenever no CTB needs the per-sample SAO ring test (always when the filters cross slice borders)"""
+    separate kernels; fused whenever no CTB needs the per-sample SAO ring test (always when the filters cross slice borders).
+    r06: ... and both equal to the CPU flow - the oracle's filters and, where it is built, the real libde265's tiles, then the oracle's paste
+    and integer matrix -, so that the fused tail and the separate kernels cannot drift TOGETHER."""
     import bench
     import torch
     dev = torch.device("cuda:0")
@@ -334,12 +336,17 @@ def test_fused_tail_with_several_slices(pkg, hm, slicing):
         torch.cuda.synchronize()
         fused.append(gb.batch.tail_fused())
         out.append([im["rgb"].cpu().numpy()[:h, :w * 3].copy() for im in gb.images])
+        strides = (gb.ys, gb.cs, gb.os)
         gb.batch.close()
     assert not fused[1]
     if not slicing.get("pps_lf_across_slices_off"):
         assert fused[0], "pictures whose filters cross slice borders take the fused tail"
     for j in range(2):
         assert np.array_equal(out[0][j], out[1][j]), f"image {j}: fused tail differs from the separate kernels"
+        tiles = made[j * cols * rows:(j + 1) * cols * rows]
+        for use_ref in [False] + ([True] if orc.have_ref() else []):
+            exp = bench.cpu_grid_image([d for d, _ in tiles], [b for _, b in tiles], cols, rows, 512, w, h, strides, use_ref)
+            assert np.array_equal(out[0][j], exp[:h, :w * 3]), f"image {j}: differs from the CPU flow (libde265: {use_ref})"
 
 
 FLOAT_TAIL_CLASSES = {

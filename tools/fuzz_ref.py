@@ -86,6 +86,68 @@ if "--determinism" in sys.argv:
     import collections
     print("the product's reasons for the deterministic ones:", collections.Counter(w[:60] for _, _, w in same_cases).most_common(20))
 
+def tile_scan(stream, ctb_w, ctb_h):
+    """raster address -> tile-scan address (CtbAddrRsToTs, 6.5.1) from the stream's PPS (7.3.2.3.1): [u32 length][NAL] records"""
+    import hevcutil
+    pps = next(n for n in hevcutil.split_nals(stream) if ((n[0] >> 1) & 63) == 34)
+    rbsp = bytearray()
+    z = 0
+    for x in pps[2:]:  # without the emulation prevention bytes
+        if z >= 2 and x == 3:
+            z = 0
+            continue
+        rbsp.append(x)
+        z = z + 1 if x == 0 else 0
+    pos = [0]
+
+    def u(n):
+        v = 0
+        for _ in range(n):
+            v = (v << 1) | ((rbsp[pos[0] >> 3] >> (7 - (pos[0] & 7))) & 1)
+            pos[0] += 1
+        return v
+
+    def ue():
+        k = 0
+        while u(1) == 0:
+            k += 1
+        return (1 << k) - 1 + u(k)
+
+    def se():
+        v = ue()
+        return (v + 1) // 2 if v & 1 else -(v // 2)
+    ue(); ue(); u(1); u(1); u(3); u(1); u(1); ue(); ue(); se(); u(1); u(1)
+    if u(1):
+        ue()  # diff_cu_qp_delta_depth
+    se(); se(); u(1); u(1); u(1); u(1)
+    tiles = u(1)
+    u(1)  # entropy_coding_sync_enabled_flag
+    cols, rows = [ctb_w], [ctb_h]
+    if tiles:
+        nc, nr = ue() + 1, ue() + 1
+        if u(1):  # uniform_spacing_flag (6-3, 6-4)
+            cols = [(i + 1) * ctb_w // nc - i * ctb_w // nc for i in range(nc)]
+            rows = [(i + 1) * ctb_h // nr - i * ctb_h // nr for i in range(nr)]
+        else:
+            cols = [ue() + 1 for _ in range(nc - 1)]
+            cols.append(ctb_w - sum(cols))
+            rows = [ue() + 1 for _ in range(nr - 1)]
+            rows.append(ctb_h - sum(rows))
+    ts_of = [0] * (ctb_w * ctb_h)
+    ts = 0
+    y0 = 0
+    for rh in rows:
+        x0 = 0
+        for cw_ in cols:
+            for y in range(y0, y0 + rh):
+                for x in range(x0, x0 + cw_):
+                    ts_of[y * ctb_w + x] = ts
+                    ts += 1
+            x0 += cw_
+        y0 += rh
+    return ts_of
+
+
 if "--conceal" in sys.argv:
     # r05: the same 900 streams with HM_PARSE_CONCEAL.  A stream the strict parser refuses comes back as a picture: every CTB in front of
     # the damage decoded from the data, the rest concealed.  Against the reference: the CTBs up to one CTB row + 2 in front of the first
@@ -137,16 +199,25 @@ if "--conceal" in sys.argv:
                 ctb = 1 << blob[23]
                 ctb_w = (w + ctb - 1) // ctb
                 flags = struct.unpack_from("<I", blob, 36)[0]
-                if flags & 0x40:  # HEVC tiles: "in front of" is not raster order
-                    st["tiles_not_compared"] += 1
-                    continue
-
                 def ctb_equal(a, r, c):
                     x0, y0 = max((c % ctb_w) * ctb, cl), max((c // ctb_w) * ctb, ct)
                     x1, y1 = min((c % ctb_w) * ctb + ctb, w - cr), min((c // ctb_w) * ctb + ctb, h - cb)
                     return x1 <= x0 or y1 <= y0 or np.array_equal(a[y0:y1, x0:x1], r[y0 - ct:y1 - ct, x0 - cl:x1 - cl])
 
-                front = range(max(0, first - ctb_w - 2))
+                if flags & 0x40:
+                    # HEVC tiles (r06): "in front of" is the DECODING order - tile by tile, raster inside a tile (6.5.1).  A CTB can be
+                    # compared when it and its eight neighbours (whose samples the in-loop filters of the CTB read) all come before the
+                    # first concealed CTB in that order - for a picture without tiles that is the "one CTB row + 2" rule below.
+                    ctb_h = (h + ctb - 1) // ctb
+                    ts_of = tile_scan(b, ctb_w, ctb_h)
+                    ts_first = ts_of[first]
+                    front = [c for c in range(ctb_w * ctb_h)
+                             if all(ts_of[(c // ctb_w + dy) * ctb_w + c % ctb_w + dx] < ts_first
+                                    for dy in (-1, 0, 1) for dx in (-1, 0, 1) if 0 <= c // ctb_w + dy < ctb_h and 0 <= c % ctb_w + dx < ctb_w)]
+                    st["tiles_compared_in_decoding_order"] = st.get("tiles_compared_in_decoding_order", 0) + 1
+                    st["tile_ctbs_compared"] = st.get("tile_ctbs_compared", 0) + len(front)
+                else:
+                    front = range(max(0, first - ctb_w - 2))
                 bad = [c for c in front if not ctb_equal(mine[0], ref[0], c)]
                 if not bad:
                     st["front_equal"] += 1
