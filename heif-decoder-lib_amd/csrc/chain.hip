@@ -894,7 +894,17 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         // prediction + residual + clip + store of sample p = x + nT * y (the residual of a block lies in raster order)
         // (the residual is only looked at - waited for - by blocks that have one)
         int res_s = 0, res_t[4] = {0, 0, 0, 0};
-        if (cbf) {
+        // (r06) 8-bit blocks of 16x16 / 32x32 with an angular mode: two samples per lane on packed 16-bit halves (predict_pairs8)
+        const bool pairs = sizeof(Pix) == 1 && L2 >= 4 && WHICH != PATH_B4 && mode >= 2 && mode != 10 && mode != 26;
+#ifdef HM_PAIRS_PRE // (A/B: the pair residuals of a 16x16 block requested before its border is made - two more live registers: spills at 96)
+        uint32_t res_p[2] = {0, 0};
+        if (cbf && pairs && L2 == 4) {
+#pragma unroll
+          for (int t = 0; t < 2; t++) res_p[t] = pairs8_residual<4>(mode >= 18, ln, t, gres);
+        }
+        else
+#endif
+        if (cbf && !pairs) {
           if (L2 == 2) { // lanes 0-15: the block's 16 samples in the window's residuals of its group
             const int s_ri = __builtin_amdgcn_readlane((int)ri_me, src);
             const int s_chain = PAIRS ? bg & ((1 << NCL) - 1) : bg; // (the window's residuals lie per chain)
@@ -948,7 +958,15 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
           bc[j] = (int16_t)pf;
           if (ln == 0) bc[32] = (int16_t)p_end;
           WAVE_SYNC();
-          predict_emit<Pix, L2>(B, RefArray{bc}, tab, ln, emit);
+          if constexpr (sizeof(Pix) == 1 && L2 == 4) {
+#ifdef HM_PAIRS_PRE
+            if (pairs) predict_pairs8<4, true>(mode, bc, tab, ln, cbf, gres, reinterpret_cast<uint8_t*>(dst), P, res_p);
+#else
+            if (pairs) predict_pairs8<4, false>(mode, bc, tab, ln, cbf, gres, reinterpret_cast<uint8_t*>(dst), P);
+#endif
+            else predict_emit<Pix, L2>(B, RefArray{bc}, tab, ln, emit);
+          }
+          else predict_emit<Pix, L2>(B, RefArray{bc}, tab, ln, emit);
         }
         else if (WHICH == PATH_B4) {
           // 4x4 at a picture / slice / tile border (the interior ones took the side-by-side path): the substitution process of
@@ -982,7 +1000,17 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
 #if !defined(HM_Q_PROBE) || !(HM_Q_PROBE & 16)
           make_border<Pix, L2>(B, l_bA, strong, ln);
           WAVE_SYNC();
-          predict_emit<Pix, L2>(B, RefArray{l_bA + 64}, tab, ln, emit);
+          if constexpr (sizeof(Pix) == 1 && L2 >= 4) {
+            if (pairs) {
+#ifdef HM_PAIRS_PRE
+              if constexpr (L2 == 4) predict_pairs8<4, true>(mode, l_bA + 64, tab, ln, cbf, gres, reinterpret_cast<uint8_t*>(dst), P, res_p);
+              else
+#endif
+              predict_pairs8<L2, false>(mode, l_bA + 64, tab, ln, cbf, gres, reinterpret_cast<uint8_t*>(dst), P);
+            }
+            else predict_emit<Pix, L2>(B, RefArray{l_bA + 64}, tab, ln, emit);
+          }
+          else predict_emit<Pix, L2>(B, RefArray{l_bA + 64}, tab, ln, emit);
 #endif
         }
 #endif

@@ -1617,10 +1617,19 @@ __device__ __forceinline__ void tile_sao(const hm_dev_pic& dp, const uint32_t* r
   }
 }
 
-constexpr int TF_TW = 128, TF_TH = 32, TF_XO = 8, TF_THREADS = 256;
+// Tile height by chroma format (r06): a lane of phase 2 takes 16 luma samples of TWO rows of a 4:2:0 picture - tiles of 32 rows gave it 128
+// items for 256 lanes: two of the workgroup's four waves idle, i.e. two of the CU's four SIMDs idle, during the larger half of the kernel.
+// 64 rows: every lane an item (and 13 % fewer windows computed twice); 4:2:2 (one row per lane) keeps 32: 256 items, and 64 rows would
+// be 315 windows for the 256 lanes of phase 1.
+#ifndef HM_TF_TH420
+#define HM_TF_TH420 64
+#endif
+constexpr int TF_TW = 128, TF_XO = 8, TF_THREADS = 256;
+constexpr int tf_th(int cf) { return cf == 1 ? HM_TF_TH420 : 32; }
 template <typename Pix, int CF, int OF>
 __global__ __launch_bounds__(TF_THREADS) void k_tailf(const hm_dev_pic* __restrict__ pics, const TailDst* __restrict__ dsts, int tiles_x, int n_tiles, int stages, FloatParams fp)
 {
+  constexpr int TF_TH = tf_th(CF);
   constexpr int SV = CF == 1 ? 1 : 0;                                 // log2 of the vertical chroma sub-sampling
   constexpr int LP = TF_TW + 16, LR = TF_TH + 8;                      // luma tile: pitch in samples, rows
   constexpr int CW = TF_TW / 2, CH = TF_TH >> SV;                     // chroma samples of the workgroup's tile
@@ -1776,6 +1785,51 @@ __global__ __launch_bounds__(TF_THREADS) void k_tailf(const hm_dev_pic* __restri
 #pragma unroll
           for (int j = 0; j < 4; j++) ry[j] = pk_rescale_stored<Pix, false>(ry[j], bd);
         }
+        uint8_t* const o0 = D.rgb + (uint32_t)(mul24_raw(ly + r, D.pitch) + hx * OBPP); // (an image is smaller than 4 GiB)
+        const int nvalid = cw - hx < 8 ? cw - hx : 8;
+        // (r06) mode 4 - a deep full-range 4:2:0 image to RGB24 / RGBA32: the class of HDR photographs - on sample PAIRS, with k_tail420's
+        // packed integer matrix (the same arithmetic: yuv2rgb.cc:359-364 after hdr_sdr.cc:176-195's shift) instead of ~30 scalar
+        // instructions per pixel
+        if constexpr (sizeof(Pix) == 2 && CF == 1 && (OF == OF_RGB24 || OF == OF_RGBA32)) {
+          if (fp.mode == 4 && fp.post == 0 && nvalid == 8) { // (the same for every lane but the last group of a cropped row)
+            constexpr int OW = 2 * OBPP;
+            uint32_t wd[OW];
+            auto sat_pk = [](uint32_t x) -> uint32_t { uint32_t d; asm("v_sat_pk_u8_i16 %0, %1" : "=v"(d) : "v"(x)); return d; };
+            auto add_lo = [](uint32_t y2, int t) -> uint32_t { uint32_t d; asm("v_pk_add_u16 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(y2), "v"(t)); return d; };
+            const int Kr = 128 - 128 * fp.i_r_cr, Kg = 128 - 128 * (fp.i_g_cb + fp.i_g_cr), Kb = 128 - 128 * fp.i_b_cb; // (x - 128) * k + 128 = x * k + K
+#pragma unroll
+            for (int h = 0; h < 2; h++) { // two chroma samples = 4 pixels
+              uint32_t rg[2], bb[2];
+#pragma unroll
+              for (int q = 0; q < 2; q++) {
+                const int j = 2 * h + q, ci = 4 * half + j; // the pair of pixels 2 j, 2 j + 1 and its chroma sample
+                const int u = (int)(((cbs[ci >> 1] >> (16 * (ci & 1))) & 0xFFFF) >> fp.pre_shift), w = (int)(((crs[ci >> 1] >> (16 * (ci & 1))) & 0xFFFF) >> fp.pre_shift);
+                const int rt = (__mul24(fp.i_r_cr, w) + Kr) >> 8;
+                const int gt = (__mul24(fp.i_g_cb, u) + __mul24(fp.i_g_cr, w) + Kg) >> 8;
+                const int bt = (__mul24(fp.i_b_cb, u) + Kb) >> 8;
+                const uint32_t y2 = as_w(as_u(ry[j]) >> (u16x2)((unsigned short)fp.pre_shift));
+                const uint32_t R = sat_pk(add_lo(y2, rt)), G = sat_pk(add_lo(y2, gt)), B = sat_pk(add_lo(y2, bt));
+                rg[q] = R | (G << 16);
+                bb[q] = B;
+              }
+              if (OBPP == 3) {
+                const uint32_t x01 = rg[0], x23 = rg[1], b4 = bb[0] | (bb[1] << 16);
+                wd[3 * h + 0] = __builtin_amdgcn_perm(b4, x01, 0x01040200u);                                          // R0 G0 B0 R1
+                wd[3 * h + 1] = __builtin_amdgcn_perm(b4, __builtin_amdgcn_perm(x23, x01, 0x06040003u), 0x03020500u); // G1 B1 R2 G2
+                wd[3 * h + 2] = __builtin_amdgcn_perm(b4, x23, 0x07030106u);                                          // B2 R3 G3 B3
+              }
+              else {
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                  wd[4 * h + 2 * q + 0] = __builtin_amdgcn_perm(bb[q], rg[q], 0x0d040200u); // R0 G0 B0 255
+                  wd[4 * h + 2 * q + 1] = __builtin_amdgcn_perm(bb[q], rg[q], 0x0d050301u); // R1 G1 B1 255
+                }
+              }
+            }
+            __builtin_memcpy(gptr_w<uint8_t>(o0), wd, 8 * OBPP);
+            continue;
+          }
+        }
         uint8_t ob[8 * OBPP];
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -1802,8 +1856,6 @@ __global__ __launch_bounds__(TF_THREADS) void k_tailf(const hm_dev_pic* __restri
             ob[6 * i + 4 + hi] = (uint8_t)(b >> 8); ob[6 * i + 4 + lo] = (uint8_t)b;
           }
         }
-        uint8_t* const o0 = D.rgb + (uint32_t)(mul24_raw(ly + r, D.pitch) + hx * OBPP); // (an image is smaller than 4 GiB)
-        const int nvalid = cw - hx < 8 ? cw - hx : 8;
         if (nvalid == 8) {
           uint32_t wd[2 * OBPP];
 #pragma unroll
@@ -1912,6 +1964,7 @@ extern "C" int hm_launch_tailf(const hm_dev_pic* d_pics, const void* d_dsts, int
   if (n_pics <= 0) return HM_OK;
   FloatParams fp;
   hm_float_params(d, coef, mode, &fp);
+  const int TF_TH = tf_th(d->chroma == HM_CHROMA_420 ? 1 : 2);
   const int tiles_x = (max_w + TF_TW - 1) / TF_TW, tiles_y = (max_h + TF_TH - 1) / TF_TH;
   const TailDst* dd = (const TailDst*)d_dsts;
   const bool v420 = d->chroma == HM_CHROMA_420;

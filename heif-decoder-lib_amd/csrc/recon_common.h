@@ -441,6 +441,81 @@ __device__ __forceinline__ void predict_emit(const Blk<Pix>& B, const Ref& b, co
     }
   }
 }
+// The angular modes (2-9, 11-25, 27-34: intrapred.h:338-441) of a 16x16 / 32x32 block of 8-bit samples, TWO samples per lane (r06;
+// chain.hip, where these trips of 64 samples at ~39 vector instructions were a tenth of the kernel's instructions): a lane takes two
+// neighbouring samples ALONG THE MINOR AXIS - (x, x + 1) of a row for the vertical modes, (y, y + 1) of a column for the horizontal ones -,
+// which share the row's / column's displacement iIdx and weight iFact and read the consecutive reference samples k0, k0 + 1, k0 + 2.
+// Blend, residual and clip then run on the pair as the 16-bit halves of one register: every value fits - (32 - f) a + f b + 16 <= 8176,
+// a residual is limited to +-255 (residual.hip).  bc: the block's border array (bc[0] the corner, bc[k] the row above, bc[-k] the left
+// column); gres: the block's residual in raster order (looked at only with cbf); dst: the block's first sample, pitch P.
+// Same results as predict_emit<uint8_t, L2> + chain.hip's emit, sample by sample.
+// pairs8_residual: the residual of the lane's pair in trip t, as the block's prediction will add it (requested by the caller of a 16x16
+// block before the border is made: in flight meanwhile)
+template <int L2>
+__device__ __forceinline__ uint32_t pairs8_residual(bool vert, int lane, int t, const GLOBAL_AS int16_t* gres)
+{
+  constexpr int nT = 1 << L2;
+  const int q = lane + 64 * t;
+  const int x = vert ? (q & (nT / 2 - 1)) << 1 : q & (nT - 1), y = vert ? q >> (L2 - 1) : (q >> L2) << 1;
+  if (vert) return *reinterpret_cast<const GLOBAL_AS uint32_t*>(gres + (x + (y << L2)));
+  return (uint32_t)(uint16_t)gres[x + (y << L2)] | ((uint32_t)(uint16_t)gres[x + ((y + 1) << L2)] << 16);
+}
+template <int L2, bool PRE = false>
+__device__ __forceinline__ void predict_pairs8(int mode, const int16_t* bc, const int16_t* tab, int lane, bool cbf, const GLOBAL_AS int16_t* gres, uint8_t* dst, int P,
+                                               const uint32_t* pre = nullptr)
+{
+  constexpr int nT = 1 << L2, TRIPS = nT * nT / 128;
+  typedef short s16x2_t __attribute__((ext_vector_type(2)));
+  typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+  // (the same in every lane - the mode is the block's -: scalars, not two vector registers for the whole loop)
+  const int angle = __builtin_amdgcn_readfirstlane((int)tab[mode]);
+  const int inv = __builtin_amdgcn_readfirstlane((int)tab[35 + mode]); // 0 outside modes 11..25
+  const bool vert = mode >= 18;
+  auto ref = [&](int k) -> uint32_t { // reference sample k of the main run; k < 0: projected from the side run with the inverse angle
+    const int a = k >= 0 ? k : -((mul24(k, inv) + 128) >> 8);
+    return (uint32_t)(uint16_t)bc[vert ? a : -a];
+  };
+  auto ref_pos = [&](int k) -> uint32_t { return (uint32_t)(uint16_t)bc[vert ? k : -k]; }; // (angle > 0: every index is positive)
+  auto trip = [&](int t) {
+    const int q = lane + 64 * t;
+    // vertical modes: the pair (x, x + 1) of row y; horizontal modes: the pair (y, y + 1) of column x.  major: the coordinate the
+    // displacement depends on, m0: the first sample's coordinate along the reference run
+    const int major = vert ? q >> (L2 - 1) : q & (nT - 1);
+    const int m0 = vert ? (q & (nT / 2 - 1)) << 1 : (q >> L2) << 1;
+    const int tt = mul24(major + 1, angle);
+    const int k0 = m0 + (tt >> 5) + 1;
+    const uint32_t f = (uint32_t)(tt & 31);
+    uint32_t r0, r1, r2;
+    if (angle > 0) { r0 = ref_pos(k0); r1 = ref_pos(k0 + 1); r2 = ref_pos(k0 + 2); }
+    else { r0 = ref(k0); r1 = ref(k0 + 1); r2 = ref(k0 + 2); }
+    const uint32_t A = r0 | (r1 << 16), B = r1 | (r2 << 16);
+    const uint32_t w1 = f | (f << 16), w0 = 0x00200020u - w1;
+    u16x2_t v = __builtin_bit_cast(u16x2_t, A) * __builtin_bit_cast(u16x2_t, w0) + __builtin_bit_cast(u16x2_t, B) * __builtin_bit_cast(u16x2_t, w1) + (u16x2_t)(16);
+    v = v >> (u16x2_t)(5);
+    const int x = vert ? m0 : major, y = vert ? major : m0; // the pair's first sample
+    if (cbf) {
+      uint32_t rr;
+      if constexpr (PRE) rr = pre[t];
+      else rr = pairs8_residual<L2>(vert, lane, t, gres);
+      s16x2_t s = __builtin_bit_cast(s16x2_t, v) + __builtin_bit_cast(s16x2_t, rr);
+      s = __builtin_elementwise_min(__builtin_elementwise_max(s, (s16x2_t)(0)), (s16x2_t)(255));
+      v = __builtin_bit_cast(u16x2_t, s);
+    }
+    const uint32_t vw = __builtin_bit_cast(uint32_t, v);
+    uint8_t* const o = dst + mul24(y, P) + x;
+    if (vert) *reinterpret_cast<uint16_t*>(o) = (uint16_t)((vw & 0xFFu) | ((vw >> 8) & 0xFF00u)); // (x even, rows 4-byte aligned: a 16-bit store)
+    else { o[0] = (uint8_t)vw; o[P] = (uint8_t)(vw >> 16); }
+  };
+  if constexpr (TRIPS <= 2) { // (16x16: straight-line code, the preloaded residuals stay in registers)
+#pragma unroll
+    for (int t = 0; t < TRIPS; t++) trip(t);
+  }
+  else {
+#pragma unroll 2
+    for (int t = 0; t < TRIPS; t++) trip(t);
+  }
+}
+
 template <typename Pix, int L2, typename Ref, bool HALVES = false>
 __device__ __forceinline__ void predict(const Blk<Pix>& B, const Ref& b, const int16_t* tab, int lane)
 {

@@ -102,16 +102,25 @@ class SlabGather:
         import torch
         assert self.rank == self.dst
         works = []
-        for r in range(self.world):
-            if r == self.dst:
-                continue
-            for y0, y1 in self.rows[r]:
-                view = full[y0:y1]
-                if self.stage:
+        peers = [r for r in range(self.world) if r != self.dst]
+        if self.stage:
+            for r in peers:
+                for y0, y1 in self.rows[r]:
+                    view = full[y0:y1]
                     buf = torch.empty(view.shape, dtype=view.dtype, device="cpu")
                     works.append((self.dist.irecv(buf, src=r, group=self.group), buf, view))
-                else:
-                    works.append((self.dist.irecv(view, src=r, group=self.group), None, view))
+            return works
+        # device tensors (RCCL): receives posted one by one run one after the other on the root - one xGMI link busy at a time.  Chunk k
+        # of EVERY peer goes into one group (ncclGroupStart / End behind batch_isend_irecv): the root's seven links fill side by side;
+        # per peer the groups come in the order of its sends.
+        k = 0
+        while True:
+            ops = [self.dist.P2POp(self.dist.irecv, full[self.rows[r][k][0]:self.rows[r][k][1]], r, self.group) for r in peers if k < len(self.rows[r])]
+            if not ops:
+                break
+            for w in self.dist.batch_isend_irecv(ops):
+                works.append((w, None, None))
+            k += 1
         return works
 
     def wait(self, works):

@@ -80,7 +80,8 @@ def _bench_ranks(world, extra, timeout):
 @pytest.mark.parametrize("world", ["two_gpus", "all_gpus"])
 def test_one_grid_over_the_gpus_that_are_there(world):
     """SURVEY 8e on real devices: ONE 16384 x 16384 grid (BASELINE config 5), its 32 tile rows cut into a slab per rank, every rank
-    decoding its slab on its own GPU, the RGB row slabs gathered with ONE RCCL collective (shard.gather_slabs) - and rank 0
+    decoding its slab on its own GPU, the RGB row slabs sent point-to-point over RCCL straight into their rows of rank 0's image
+    (shard.SlabGather, r06: no padding, no concatenation; pipelined under the next grid's decode) - and rank 0
     comparing the gathered image bit for bit with its own one-rank decode of the whole grid (bench.py --mode grid's self-check;
     the reference's in-process tile fan-out context.cc:2361-2401 across processes).  Scales itself to the box: 2 ranks and
     min(device_count, 8) ranks; skipped on a one-GPU box, where tests/test_shard_gloo.py (2 gloo ranks) and the one-rank test
@@ -94,6 +95,7 @@ def test_one_grid_over_the_gpus_that_are_there(world):
     assert res["n_gpus"] == w and res["world_size"] == w and res["gather"]["backend"] == "nccl"
     assert "bit-exact" in res["config"]["self_check"], res["config"]
     assert sum(res["config"]["tile_rows_per_rank"]) == 32
+    assert res["host_gather"].get("equals_the_gathered_image") is True, res["host_gather"]  # (the collective-free alternative: one host image)
 
 
 @pytest.mark.parametrize("world", ["two_gpus", "all_gpus"])
