@@ -167,6 +167,13 @@ constexpr int chain_mode_ncl(int mode) { return mode <= 1 ? 2 : (mode == 2 ? 1 :
 #else
 #define HM_CHAIN_ATTR __attribute__((amdgpu_waves_per_eu(chain_waves_per_simd<Pix, LOG2_CTB, MODE>, chain_waves_per_simd<Pix, LOG2_CTB, MODE>)))
 #endif
+// HM_CHAIN_LATE (r06; A/B builds): a wave per picture whose two chroma chains have finished - they hold half the
+// records of their luma twins, so that is at half time - hands their two groups to the luma chains: group 1 joins chain 0, group 3
+// chain 2, each one record AHEAD of its chain's current one, with the multi-record machinery of the few-pictures cuts (a run of
+// interior 4x4 blocks side by side up to the reference reads, other blocks one after the other).  See profiles/r06_notes.txt.
+#ifndef HM_CHAIN_LATE
+#define HM_CHAIN_LATE 0
+#endif
 template <typename Pix, int LOG2_CTB, int MODE>
 __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* __restrict__ pics, int n_pics, CLayout L, uint32_t* __restrict__ sync, uint32_t* __restrict__ err_word)
 {
@@ -330,20 +337,22 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
 
   // ---- per-lane constants ----
   const int g_phys = lane >> 4, gl = lane & 15, bx_ = gl & 3, by_ = gl >> 2;
-  const int g = PAIRS ? g_phys & ((1 << NCL) - 1) : g_phys; // the chain (= its first group) this lane works on
-  const int my_off = PAIRS ? g_phys >> NCL : 0;             // ... and how many records ahead of the chain's current one
-  int16_t* const rres = rres_all + g * (RING * 16);
+  constexpr bool CAN_LATE = MODE == 0 && HM_CHAIN_LATE != 0;
+  int late = 0; // (wave-uniform) CAN_LATE: the chroma chains are done, their groups work for the luma chains
+  int g = PAIRS ? g_phys & ((1 << NCL) - 1) : g_phys; // the chain (= its first group) this lane works on
+  int my_off = PAIRS ? g_phys >> NCL : 0;             // ... and how many records ahead of the chain's current one
+  int16_t* rres = rres_all + g * (RING * 16);
   // (constants of the lane, except in the cut whose waves change the kind of chain from band to band: ALT, set_kind below)
   int kind = group_kind(g); // 0: luma chain, 1: chroma chain
-  Pix* const gbase = group_u(g, kind ? 1 : 0); // CTU buffer of the luma plane / of Cb (Cr: P1 * ch_c samples further)
+  Pix* gbase = group_u(g, kind ? 1 : 0); // CTU buffer of the luma plane / of Cb (Cr: P1 * ch_c samples further)
   int Pk = kind ? P1 : P0;               // pitch of the chain's CTU buffers
   int l2w = kind ? log2_ctb - 1 : log2_ctb; // log2 of the CTU width in samples of the chain's planes
   const int cr_off = P1 * ch_c;                // Cr buffer behind the Cb buffer, in samples
   int st_off = by_ * Pk + 1 + bx_;       // a 4x4 block's sample of this lane, from the block's (x0 - 1, y0)
   int* my_progress = progress + kind * C_PROG;
-  c_u32x4* const ring = rings + g * RING;
+  c_u32x4* ring = rings + g * RING;
   // byte offsets in LDS of the group's places, for the wave-wide path (fetched from the group's first lane)
-  const uint32_t gb_off = (uint32_t)(reinterpret_cast<uint8_t*>(gbase) - lds);
+  uint32_t gb_off = (uint32_t)(reinterpret_cast<uint8_t*>(gbase) - lds);
 
   // ---- group state (the same value in the 16 lanes of a group) ----
   int row = (PAIRS ? pair_index * RPW : 0) + group_slot(g), cx = 0;
@@ -467,7 +476,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
 #endif
       // ---- F: finished CTUs: coalesced stores to the picture, bottom row -> line, right column -> left column ----
-      for (unsigned long long fin = ballot(st == ST_RUN) & ballot(ri == ctu_end) & main_mask; fin;) {
+      for (unsigned long long fin = ballot(st == ST_RUN) & ballot(ri == ctu_end) & ((CAN_LATE && late) ? 0x0000FFFF0000FFFFull : main_mask); fin;) {
         const int fg = rfl((int)(__builtin_ctzll(fin) >> 4));
         fin &= ~(0xFFFFull << (fg * 16));
         HM_T_COUNT(1);
@@ -706,6 +715,32 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         left = (st == ST_RUN && (ri >> WLOG) == wdec) ? n : 0;
       }
       m_done = ballot(st == ST_DONE);
+      if (CAN_LATE && !late && !mono) {
+        constexpr unsigned long long CHROMA = 0xFFFF0000FFFF0000ull; // the groups 1 and 3
+        if ((m_done & CHROMA) == CHROMA && (~m_done & ~CHROMA)) { // both chroma chains are done, a luma chain is not
+          late = 1;
+          // groups 1 / 3 take over the state of the chain of group 0 / 2 (every group of a chain holds the same state: the same
+          // loads, the same updates) and work one record ahead of it
+          const int from = ((lane & 16) ? lane - 16 : lane) << 2;
+          auto take = [&](auto& v) { v = (std::remove_reference_t<decltype(v)>)__builtin_amdgcn_ds_bpermute(from, (int)v); };
+          take(row); take(cx); take(ctu_end); take(left); take(st); take(c0); take(c1); take(ri); take(wdec); take(tl_off);
+#pragma unroll
+          for (int k = 0; k < ITEM_DWORDS; k++) take(pf[k]);
+          if (lane & 16) {
+            g = g_phys - 1;
+            my_off = 1;
+            kind = 0; Pk = P0; l2w = log2_ctb;
+            st_off = by_ * Pk + 1 + bx_;
+            my_progress = progress;
+            lr_off = (uint32_t)(reinterpret_cast<const uint8_t*>(line_of(0, line_above)) - lds) - (uint32_t)sizeof(Pix);
+            rres = rres_all + g * (RING * 16);
+            gbase = group_u(g, 0);
+            ring = rings + g * RING;
+            gb_off = (uint32_t)(reinterpret_cast<uint8_t*>(gbase) - lds);
+          }
+          m_done = ballot(st == ST_DONE);
+        }
+      }
     }
     HM_T_LAP(0);
 #if defined(HM_PAD_S) || defined(HM_PAD_V)
@@ -718,9 +753,10 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     if (ballot(left != 0) == 0) continue; // (every chain of the wave waits: PAIRS, for the band above)
     // the group's record: the chain's current one, or - PAIRS - my_off records further if the chain may go that far before
     // its next event (the same CTU, the same window of micro-ops)
-    const bool running = PAIRS ? my_off < left : left != 0;
-    const unsigned long long m_running = PAIRS ? ballot(my_off < left) : ballot(left != 0);
-    const uint32_t ri_me = PAIRS ? ri + (uint32_t)my_off : ri;
+    const bool multi = (PAIRS && NCL != 2) || (CAN_LATE && late); // several records of a chain per iteration
+    const bool running = (PAIRS || CAN_LATE) ? my_off < left : left != 0;
+    const unsigned long long m_running = (PAIRS || CAN_LATE) ? ballot(my_off < left) : ballot(left != 0);
+    const uint32_t ri_me = (PAIRS || CAN_LATE) ? ri + (uint32_t)my_off : ri;
     const uint32_t rslot = ri_me & (RING - 1);
     const c_u32x4 op = ring[rslot];
     const int16_t* const my_res = rres + rslot * 16; // the 16 residual samples of the group's block if it is a 4x4 block
@@ -730,7 +766,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     unsigned long long m_quad = m_q4, s_big = m_running & ~m_q4;
     int n_exec = 1, n_sub = 1; // records the lane's chain advances by (not PAIRS: one, for the groups that are running); turns of phase C
     bool quad = running && (op.y & ((3u << OP_L2_SHIFT) | OP_INTERIOR)) == OP_INTERIOR;
-    if (PAIRS && NCL != 2) {
+    if (multi) {
       // bit k of `gq` / `gr`: group k holds an interior 4x4 block / a record of its chain's current CTU and window
       const uint32_t gq = (uint32_t)((m_q4 & 1) | ((m_q4 >> 15) & 2) | ((m_q4 >> 30) & 4) | ((m_q4 >> 45) & 8));
       const uint32_t gr = (uint32_t)((m_running & 1) | ((m_running >> 15) & 2) | ((m_running >> 30) & 4) | ((m_running >> 45) & 8));
@@ -738,13 +774,15 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       // blocks).  Without loops or branches: on the scalar unit a taken branch costs more than the arithmetic of both
       // chains, and this sits on the critical path of every iteration of a wave that is alone on its SIMD.
       // (one chain: its records are the groups 0 1 2 3; two chains: chain c's are the groups c and c + 2)
+      // (CAN_LATE: chain 0's records are the groups 0 1, chain 1's - the lanes with g = 2 - the groups 2 3)
       constexpr bool two = NCL == 1;
-      auto of_chain = [&](uint32_t m, int c) { return two ? (((m >> c) & 1u) | (((m >> (c + 2)) & 1u) << 1)) : (c ? 0u : m); };
+      constexpr int SUBX = CAN_LATE ? 2 : SUB;
+      auto of_chain = [&](uint32_t m, int c) { return CAN_LATE ? ((m >> (2 * c)) & 3u) : (two ? (((m >> c) & 1u) | (((m >> (c + 2)) & 1u) << 1)) : (c ? 0u : m)); };
       uint32_t run[2], big[2];
 #pragma unroll
       for (int c = 0; c < 2; c++) {
         const uint32_t q = of_chain(gq, c), r = of_chain(gr, c);
-        run[c] = (uint32_t)__builtin_ctz(~q | (1u << SUB)); // leading interior 4x4 blocks, at most SUB
+        run[c] = (uint32_t)__builtin_ctz(~q | (1u << SUBX)); // leading interior 4x4 blocks, at most SUB
         // ... and the records of any other kind that follow the run directly: phase D takes them one after the other, in this
         // iteration (a 4x4 block behind them would have to run before them - phase C comes first: it waits for the next one)
         big[c] = (uint32_t)__builtin_ctz(~((r & ~q) >> run[c])); // (r has no bit SUB: at most SUB - run)
@@ -841,7 +879,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       static_assert(OP_CBF == 1u << 10, "the mask above");
       lp[st_off] = (Pix)v; // (st_off: the lane's sample inside its block, by * pitch + 1 + bx)
       };
-      if (PAIRS && NCL != 2) {
+      if (multi) {
         // the records of a chain one after the other (LDS traffic of a wave is in order: what a turn stores the next one reads)
         for (int t = 0; t < n_sub; t++) {
           if (my_off == t) execute();
@@ -907,7 +945,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         if (cbf && !pairs) {
           if (L2 == 2) { // lanes 0-15: the block's 16 samples in the window's residuals of its group
             const int s_ri = __builtin_amdgcn_readlane((int)ri_me, src);
-            const int s_chain = PAIRS ? bg & ((1 << NCL) - 1) : bg; // (the window's residuals lie per chain)
+            const int s_chain = PAIRS ? bg & ((1 << NCL) - 1) : ((CAN_LATE && late) ? bg & 2 : bg); // (the window's residuals lie per chain)
             res_s = (int)(rres_all + s_chain * (RING * 16) + (s_ri & (RING - 1)) * 16)[ln & 15];
           }
           else if (L2 == 3) {
@@ -1182,7 +1220,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     HM_T_LAP(3);
     HM_MARK("E_begin");
     // ---- E: the groups that executed a block move to the next record ----
-    if (PAIRS && NCL != 2) { // (every group of a chain: by the records the chain executed)
+    if (multi) { // (every group of a chain: by the records the chain executed)
       ri += (uint32_t)n_exec;
       left -= n_exec;
     }
