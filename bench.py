@@ -205,7 +205,7 @@ def kernel_table(gb, avg_ms, colour_bytes_per_px=4.5):
     return table, alg, stream_b, sample_b
 
 
-PMC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+PMC_FILES = ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
 
 
 def pmc_traffic(kernels, images):

@@ -464,6 +464,36 @@ __device__ __forceinline__ uint32_t luma_unit_decide(const Window<Pix>& W, int b
   const int thr = (beta + (beta >> 1)) >> 3;
   return (uint32_t)tc | (dp0 + dp3 < thr ? DEC_NP2 : 0u) | (dq0 + dq3 < thr ? DEC_NQ2 : 0u) | (strong ? DEC_STRONG : 0u) | DEC_FILTER;
 }
+// the strong (fallback-postfilter.h:60-97) / the normal (:98-135) filter on ONE pair of lines: X[i] = sample i (p3 p2 p1 p0 | q0 q1 q2 q3) of
+// both lines as 16-bit halves; strong: X[1..6] change, normal: X[2..5].  maxv: the largest sample value.
+__device__ __forceinline__ void luma_pair_strong(uint32_t (&X)[8], int tc)
+{
+  const s16x2 t2 = (s16x2)((short)(tc << 1)), nt2 = (s16x2)(0) - t2;
+  const s16x2 p3 = as_s(X[0]), p2 = as_s(X[1]), p1 = as_s(X[2]), p0 = as_s(X[3]), q0 = as_s(X[4]), q1 = as_s(X[5]), q2 = as_s(X[6]), q3 = as_s(X[7]);
+  const s16x2 s = p0 + q0;
+  X[3] = as_w(p0 + pk_clamp(((p2 + p1 + p1 + s + s + q1 + (s16x2)(4)) >> (s16x2)(3)) - p0, nt2, t2));
+  X[2] = as_w(p1 + pk_clamp(((p2 + p1 + s + (s16x2)(2)) >> (s16x2)(2)) - p1, nt2, t2));
+  X[1] = as_w(p2 + pk_clamp(((p3 + p3 + p2 + p2 + p2 + p1 + s + (s16x2)(4)) >> (s16x2)(3)) - p2, nt2, t2));
+  X[4] = as_w(q0 + pk_clamp(((p1 + s + s + q1 + q1 + q2 + (s16x2)(4)) >> (s16x2)(3)) - q0, nt2, t2));
+  X[5] = as_w(q1 + pk_clamp(((s + q1 + q2 + (s16x2)(2)) >> (s16x2)(2)) - q1, nt2, t2));
+  X[6] = as_w(q2 + pk_clamp(((q3 + q3 + q2 + q2 + q2 + q1 + s + (s16x2)(4)) >> (s16x2)(3)) - q2, nt2, t2));
+}
+__device__ __forceinline__ void luma_pair_normal(uint32_t (&X)[8], uint32_t dec, int maxv_s)
+{
+  const int tc = (int)(dec & 0xFF), tc_2 = tc >> 1;
+  const bool np2 = (dec & DEC_NP2) != 0, nq2 = (dec & DEC_NQ2) != 0;
+  const s16x2 tcv = (s16x2)((short)tc), ntcv = (s16x2)(0) - tcv, tc2v = (s16x2)((short)tc_2), ntc2v = (s16x2)(0) - tc2v;
+  const s16x2 zero = (s16x2)(0), maxv = (s16x2)((short)maxv_s), lim = (s16x2)((short)(10 * tc));
+  const s16x2 p2 = as_s(X[1]), p1 = as_s(X[2]), p0 = as_s(X[3]), q0 = as_s(X[4]), q1 = as_s(X[5]), q2 = as_s(X[6]);
+  const s16x2 dqp = q0 - p0, dqp1 = q1 - p1;
+  const s16x2 delta0 = ((dqp << (s16x2)(3)) + dqp - dqp1 - dqp1 - dqp1 + (s16x2)(8)) >> (s16x2)(4);
+  const uint32_t m = as_w((pk_abs(delta0) - lim) >> (s16x2)(15)); // all ones in the halves whose |delta0| < 10 tc
+  const s16x2 delta = pk_clamp(delta0, ntcv, tcv);
+  X[3] = pk_select(m, as_w(pk_clamp(p0 + delta, zero, maxv)), X[3]);
+  X[4] = pk_select(m, as_w(pk_clamp(q0 - delta, zero, maxv)), X[4]);
+  if (np2) X[2] = pk_select(m, as_w(pk_clamp(p1 + pk_clamp(((((p2 + p0 + (s16x2)(1)) >> (s16x2)(1)) - p1 + delta) >> (s16x2)(1)), ntc2v, tc2v), zero, maxv)), X[2]);
+  if (nq2) X[5] = pk_select(m, as_w(pk_clamp(q1 + pk_clamp(((((q2 + q0 + (s16x2)(1)) >> (s16x2)(1)) - q1 - delta) >> (s16x2)(1)), ntc2v, tc2v), zero, maxv)), X[5]);
+}
 // maxv: the largest sample value (255; a window of 16-bit samples: (1 << bit depth) - 1, bit depth <= 11)
 template <bool V, int O, typename Pix = uint8_t>
 __device__ __forceinline__ void luma_unit_apply(Window<Pix>& W, uint32_t dec, int maxv_s = 255)
@@ -476,40 +506,14 @@ __device__ __forceinline__ void luma_unit_apply(Window<Pix>& W, uint32_t dec, in
   if (((HM_T_PROBE & 8) && (dec & DEC_STRONG)) || ((HM_T_PROBE & 16) && !(dec & DEC_STRONG))) return; // probes: without the strong / the normal filter
 #endif
   if (dec & DEC_STRONG) {
-    const s16x2 t2 = (s16x2)((short)(tc << 1)), nt2 = (s16x2)(0) - t2;
-    auto pass = [&](uint32_t (&X)[8]) {
-      const s16x2 p3 = as_s(X[0]), p2 = as_s(X[1]), p1 = as_s(X[2]), p0 = as_s(X[3]), q0 = as_s(X[4]), q1 = as_s(X[5]), q2 = as_s(X[6]), q3 = as_s(X[7]);
-      const s16x2 s = p0 + q0;
-      X[3] = as_w(p0 + pk_clamp(((p2 + p1 + p1 + s + s + q1 + (s16x2)(4)) >> (s16x2)(3)) - p0, nt2, t2));
-      X[2] = as_w(p1 + pk_clamp(((p2 + p1 + s + (s16x2)(2)) >> (s16x2)(2)) - p1, nt2, t2));
-      X[1] = as_w(p2 + pk_clamp(((p3 + p3 + p2 + p2 + p2 + p1 + s + (s16x2)(4)) >> (s16x2)(3)) - p2, nt2, t2));
-      X[4] = as_w(q0 + pk_clamp(((p1 + s + s + q1 + q1 + q2 + (s16x2)(4)) >> (s16x2)(3)) - q0, nt2, t2));
-      X[5] = as_w(q1 + pk_clamp(((s + q1 + q2 + (s16x2)(2)) >> (s16x2)(2)) - q1, nt2, t2));
-      X[6] = as_w(q2 + pk_clamp(((q3 + q3 + q2 + q2 + q2 + q1 + s + (s16x2)(4)) >> (s16x2)(3)) - q2, nt2, t2));
-    };
-    pass(A);
-    pass(B);
+    luma_pair_strong(A, tc);
+    luma_pair_strong(B, tc);
     pk_scatter<V, O, 1, 7>(W, A);
     pk_scatter<V, O + 2, 1, 7>(W, B);
   }
   else {
-    const int tc_2 = tc >> 1;
-    const bool np2 = (dec & DEC_NP2) != 0, nq2 = (dec & DEC_NQ2) != 0;
-    const s16x2 tcv = (s16x2)((short)tc), ntcv = (s16x2)(0) - tcv, tc2v = (s16x2)((short)tc_2), ntc2v = (s16x2)(0) - tc2v;
-    const s16x2 zero = (s16x2)(0), maxv = (s16x2)((short)maxv_s), lim = (s16x2)((short)(10 * tc));
-    auto pass = [&](uint32_t (&X)[8]) {
-      const s16x2 p2 = as_s(X[1]), p1 = as_s(X[2]), p0 = as_s(X[3]), q0 = as_s(X[4]), q1 = as_s(X[5]), q2 = as_s(X[6]);
-      const s16x2 dqp = q0 - p0, dqp1 = q1 - p1;
-      const s16x2 delta0 = ((dqp << (s16x2)(3)) + dqp - dqp1 - dqp1 - dqp1 + (s16x2)(8)) >> (s16x2)(4);
-      const uint32_t m = as_w((pk_abs(delta0) - lim) >> (s16x2)(15)); // all ones in the halves whose |delta0| < 10 tc
-      const s16x2 delta = pk_clamp(delta0, ntcv, tcv);
-      X[3] = pk_select(m, as_w(pk_clamp(p0 + delta, zero, maxv)), X[3]);
-      X[4] = pk_select(m, as_w(pk_clamp(q0 - delta, zero, maxv)), X[4]);
-      if (np2) X[2] = pk_select(m, as_w(pk_clamp(p1 + pk_clamp(((((p2 + p0 + (s16x2)(1)) >> (s16x2)(1)) - p1 + delta) >> (s16x2)(1)), ntc2v, tc2v), zero, maxv)), X[2]);
-      if (nq2) X[5] = pk_select(m, as_w(pk_clamp(q1 + pk_clamp(((((q2 + q0 + (s16x2)(1)) >> (s16x2)(1)) - q1 - delta) >> (s16x2)(1)), ntc2v, tc2v), zero, maxv)), X[5]);
-    };
-    pass(A);
-    pass(B);
+    luma_pair_normal(A, dec, maxv_s);
+    luma_pair_normal(B, dec, maxv_s);
     pk_scatter<V, O, 2, 6>(W, A);
     pk_scatter<V, O + 2, 2, 6>(W, B);
   }
@@ -1315,8 +1319,44 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
     }
   };
   // the filters on the listed units: strong ones (padded to whole waves), then normal ones
+#ifndef HM_TAIL_HALF_UNITS
+#define HM_TAIL_HALF_UNITS 0 // (r06 A/B: bit-exact, 53.7 instead of 52.3 lanes per vector instruction, but 231.5 k instead of 230.7 k instructions per tile
+#endif                       //  and 8.04 instead of 7.95 ms - a half unit's own set-up costs what the fuller waves save; profiles/r06_tail_probes.txt)
   auto apply_units = [&](auto vertical, const uint32_t* cnt) {
     constexpr bool VV = decltype(vertical)::value;
+#if HM_TAIL_HALF_UNITS
+    // (r06, measured and left off) a lane per HALF unit - one pair of lines, what the filters work on anyway: the ~27 strong units of a
+    // tile's direction fill one wave pass at half its cost instead of 27 of 64 lanes at the full one, the normal ones waste half a pass less
+    const uint32_t ns2 = 2u * cnt[0], nn2 = 2u * cnt[1], ns_pad = (ns2 + 63u) & ~63u;
+    for (uint32_t item = (uint32_t)tid; item < ns_pad + nn2; item += TAIL_THREADS) {
+      const bool strong = item < ns_pad;
+      if (strong && item >= ns2) continue;
+      const uint32_t idx = strong ? item : item - ns_pad, half = idx & 1u;
+      const uint32_t e = ulist[strong ? (idx >> 1) : LIST_N - 1 - (idx >> 1)];
+      const uint32_t dec = e >> 16;
+      uint32_t X[8];
+      if (VV) { // lines = rows 2 half, 2 half + 1 of the unit: eight samples across the vertical edge each
+        uint8_t* const q = s_l + (e & 0xFFFFu) + half * (2 * TAIL_LP);
+        Window<uint8_t> W; // (rows 0 and 1 only)
+        W.w[0][0] = *reinterpret_cast<const uint32_t*>(q); W.w[0][1] = *reinterpret_cast<const uint32_t*>(q + 4);
+        W.w[1][0] = *reinterpret_cast<const uint32_t*>(q + TAIL_LP); W.w[1][1] = *reinterpret_cast<const uint32_t*>(q + TAIL_LP + 4);
+        pk_gather<true, 0>(W, X);
+        if (strong) { luma_pair_strong(X, (int)(dec & 0xFF)); pk_scatter<true, 0, 1, 7>(W, X); }
+        else { luma_pair_normal(X, dec, 255); pk_scatter<true, 0, 2, 6>(W, X); }
+        *reinterpret_cast<uint32_t*>(q) = W.w[0][0]; *reinterpret_cast<uint32_t*>(q + 4) = W.w[0][1];
+        *reinterpret_cast<uint32_t*>(q + TAIL_LP) = W.w[1][0]; *reinterpret_cast<uint32_t*>(q + TAIL_LP + 4) = W.w[1][1];
+      }
+      else { // lines = columns 2 half, 2 half + 1 of the unit: eight rows across the horizontal edge, two bytes each
+        uint8_t* const q = s_l + (e & 0xFFFFu) + 2u * half;
+#pragma unroll
+        for (int r = 0; r < 8; r++) X[r] = __builtin_amdgcn_perm(0u, (uint32_t)*reinterpret_cast<const uint16_t*>(q + r * TAIL_LP), 0x0c010c00u);
+        if (strong) luma_pair_strong(X, (int)(dec & 0xFF));
+        else luma_pair_normal(X, dec, 255);
+#pragma unroll
+        for (int r = 1; r < 7; r++) *reinterpret_cast<uint16_t*>(q + r * TAIL_LP) = (uint16_t)__builtin_amdgcn_perm(0u, X[r], 0x0c0c0200u); // (p3 and q3 stay as they are)
+      }
+    }
+#else
     const uint32_t ns = cnt[0], nn = cnt[1], ns_pad = (ns + 63u) & ~63u;
     for (uint32_t item = (uint32_t)tid; item < ns_pad + nn; item += TAIL_THREADS) {
       const bool strong = item < ns_pad;
@@ -1339,6 +1379,7 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
         for (int r = 1; r < 7; r++) *reinterpret_cast<uint32_t*>(q + r * TAIL_LP) = W.w[r][0]; // (p3 and q3 stay as they are)
       }
     }
+#endif
   };
   int slice_beta_off = 0, slice_tc_off = 0; // one slice: its deblocking offsets (x 2: slice_beta_offset_div2 / slice_tc_offset_div2)
   if (one_slice) {

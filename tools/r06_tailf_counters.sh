@@ -6,7 +6,7 @@ out=/tmp/pmc_tailf; rm -rf $out; mkdir -p $out
 i=0
 for g in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  (cd /tmp && rocprofv3 --kernel-trace --pmc $g -d $out/g$i --output-format csv -- python3 $OLDPWD/tools/tailf_probe.py > $out/g$i.log 2>&1)
+  (cd /tmp && rocprofv3 --kernel-trace --pmc $g -d $out/g$i --output-format csv -- python3 $OLDPWD/tools/tailf_probe.py 3 > $out/g$i.log 2>&1)
 done
 python3 - $out <<'PY'
 import csv, glob, os, sys
@@ -16,11 +16,9 @@ for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), r
     for row in csv.DictReader(open(f)):
         if "k_tailf" in row["Kernel_Name"]:
             a = acc[row["Counter_Name"]]; a[0] += float(row["Counter_Value"]); a[1] += 1
-# (the probe launches the kernel with stages 3, 2, 1, 0 - four launches each plus a warm-up: the averages are over all of them; the stage-3 figure is
-#  the first group below, taken from the launches in file order)
 per = {k: v[0] / v[1] for k, v in acc.items()}
 tiles = 4608
-print("k_tailf<uint16_t, 4:2:0, RGB24>, 4608 tiles of 512 x 512 per launch, averages over the probe's launches (stages 3 / 2 / 1 / 0 mixed: deblocking and SAO on in half of them)")
+print("k_tailf<uint16_t, 4:2:0, RGB24>, 4608 tiles of 512 x 512 per launch (deblocking + SAO + paste + depth change + integer matrix), averages over the probe's four launches")
 for k in sorted(per):
     print(f"  {k:24s} {per[k]:16.0f} per launch   {per[k] / tiles / 1000:10.2f} k per tile")
 if per.get("SQ_THREAD_CYCLES_VALU") and per.get("SQ_ACTIVE_INST_VALU"):

@@ -4,7 +4,9 @@ stages switched off in turn: 3 = deblocking + SAO, 2 = SAO only, 1 = deblocking 
 r05: 5.26 / 3.07 / 4.56 / 2.63 ms - deblocking (the general one-line-at-a-time filters on 16-bit samples, edge parameters from memory) is
 42 % of the kernel.  usage (repo root, GPU box): python3 tools/tailf_probe.py"""
 import sys, json, ctypes as C
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch, bench
 import __graft_entry__ as g
 pkg = g.load_package()
@@ -29,7 +31,7 @@ desc=capi.ColourDesc(W,H,10,1,0,6,1,1,capi.HM_OUT_RGB,ys,cs,cs,os_)
 PtrArr=C.c_void_p*n
 ptrs=[PtrArr(*[im[k].data_ptr() for im in ims]) for k in range(4)]
 batch.set_colour(desc,n,*ptrs,0)
-for stages in (3,2,1,0):
+for stages in ([int(a) for a in sys.argv[1:]] or [3,2,1,0]):  # (tools/r06_tailf_counters.sh: "3" only)
     batch.execute(stages,st); torch.cuda.synchronize()
     batch.set_profiling(3)
     for _ in range(3): batch.execute(stages,st)
