@@ -74,27 +74,6 @@ class DecoderEC {
     if (dec_.overrun()) throw ParseError(HM_ERR_BITSTREAM, "CABAC read past the end of the slice data");
   }
 
-  // (r06) the decoder's registers in a local object for the length of residual_coding's loops (hevc_syntax.h: ec_scope): the compiler keeps a
-  // non-escaping local's fields in registers, the member's it stores after every bin
-  class Scope {
-   public:
-    explicit Scope(DecoderEC& ec) : d_(ec.dec_), ec_(ec) {}
-    Scope(const Scope&) = delete;
-    ~Scope() { ec_.dec_ = d_; }
-    __attribute__((always_inline)) inline int bin(int ctx, int, int) { return d_.decode_bin(ec_.cs_.state[ctx]); }
-    __attribute__((always_inline)) inline int bypass(int, int) { return d_.decode_bypass(); }
-    __attribute__((always_inline)) inline uint32_t bypass_bits(int, int, int, int n)
-    {
-      uint32_t v = 0;
-      for (; n > 16; n -= 16) v = (v << 16) | d_.decode_bypass_bits(16);
-      return (v << n) | d_.decode_bypass_bits(n);
-    }
-
-   private:
-    CabacDecoder d_;
-    DecoderEC& ec_;
-  };
-
  private:
   CabacDecoder dec_;
   ContextSet cs_;
@@ -104,8 +83,6 @@ class DecoderEC {
   int raw_bit_ = 0;
   bool started_ = false;
 };
-
-inline DecoderEC::Scope ec_scope(DecoderEC& ec) { return DecoderEC::Scope(ec); }
 
 namespace {
 

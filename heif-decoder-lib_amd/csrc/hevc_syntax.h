@@ -287,12 +287,6 @@ struct ConcealEC {
   void pcm_end() {}
 };
 
-// What residual_coding's sub-block loops talk to: by default the entropy coder itself; an adaptor may overload ec_scope for its type
-// (found by argument-dependent lookup) and return an object with the same bin / bypass / bypass_bits members that works on a local copy
-// of the coder's hot state and writes it back in its destructor (hevc_parse.cpp: DecoderEC).
-template <class EC>
-inline EC& ec_scope(EC& ec) { return ec; }
-
 template <class EC>
 class SliceWalker {
  public:
@@ -740,18 +734,16 @@ class SliceWalker {
     const int pbOffset = nxn ? (nCbS >> 1) : nCbS;
     const int nParts = nxn ? 4 : 1;
     int prev_flag[4], mpm_idx[4] = {0, 0, 0, 0}, rem[4] = {0, 0, 0, 0};
-    { // (the prediction modes of the unit - 5 to 20 bins - on a local copy of the decoder's registers: see residual_coding)
-    auto&& ec = ec_scope(ec_);
-    for (int i = 0; i < nParts; i++) prev_flag[i] = ec.bin(CTX_PREV_INTRA, K_PREV_INTRA, i);
+    for (int i = 0; i < nParts; i++) prev_flag[i] = ec_.bin(CTX_PREV_INTRA, K_PREV_INTRA, i);
     for (int i = 0; i < nParts; i++) {
       if (prev_flag[i]) {
         int v = 0;
-        if (ec.bypass(K_MPM_IDX, 0)) v = ec.bypass(K_MPM_IDX, 1) ? 2 : 1;
+        if (ec_.bypass(K_MPM_IDX, 0)) v = ec_.bypass(K_MPM_IDX, 1) ? 2 : 1;
         mpm_idx[i] = v;
       }
       else {
         int v = 0;
-        v = (int)ec.bypass_bits(K_REM_MODE, 0, 1, 5);
+        v = (int)ec_.bypass_bits(K_REM_MODE, 0, 1, 5);
         rem[i] = v;
       }
       const int xP = x0 + (i & 1) * pbOffset, yP = y0 + (i >> 1) * pbOffset;
@@ -764,7 +756,7 @@ class SliceWalker {
     // chroma prediction mode(s)
     if (sps_.ChromaArrayType == 3) {
       for (int i = 0; i < nParts; i++) {
-        const int m = read_chroma_pred_mode(ec);
+        const int m = read_chroma_pred_mode();
         chroma_mode_[i] = map_chroma(m, luma_mode_[i]);
         chroma_dm_[i] = m == 4; // intra_chroma_pred_mode 4: the block may use cross-component prediction (image.h:672)
       }
@@ -774,11 +766,10 @@ class SliceWalker {
       }
     }
     else if (sps_.ChromaArrayType != 0) {
-      int m = map_chroma(read_chroma_pred_mode(ec), luma_mode_[0]);
+      int m = map_chroma(read_chroma_pred_mode(), luma_mode_[0]);
       if (sps_.ChromaArrayType == 2) m = tables::kMode422[m];
       chroma_mode_[0] = chroma_mode_[1] = chroma_mode_[2] = chroma_mode_[3] = m;
     }
-    } // (the decoder's registers are back in the coder)
     cu_x_ = x0; cu_y_ = y0; cu_log2_ = log2CbSize; cu_nxn_ = nxn;
     // intra CU: rqt_root_cbf is not coded; transform_tree always follows
     const int max_depth = sps_.max_th_depth_intra + (nxn ? 1 : 0);
@@ -839,12 +830,11 @@ class SliceWalker {
     }
   }
 
-  template <typename ECX>
-  int read_chroma_pred_mode(ECX& ec)
+  int read_chroma_pred_mode()
   {
-    if (!ec.bin(CTX_CHROMA_PRED, K_CHROMA_MODE, 0)) return 4;
-    int v = ec.bypass(K_CHROMA_MODE, 1);
-    return (v << 1) | ec.bypass(K_CHROMA_MODE, 2);
+    if (!ec_.bin(CTX_CHROMA_PRED, K_CHROMA_MODE, 0)) return 4;
+    int v = ec_.bypass(K_CHROMA_MODE, 1);
+    return (v << 1) | ec_.bypass(K_CHROMA_MODE, 2);
   }
   static int map_chroma(int intra_chroma_pred_mode, int luma_mode) // §8.4.3, Table 8-2
   {
@@ -1087,17 +1077,13 @@ class SliceWalker {
   {
     const int nT = 1 << log2;
     tskip = false;
-    // (r06) the arithmetic decoder's registers - range, offset window, look-ahead count - in a LOCAL copy for this function: as members
-    // behind the walker's reference they were written back to memory after every bin (the context store may alias them as far as the
-    // compiler knows); the copy goes back when the scope ends, also when a ParseError leaves the function
-    auto&& ec = ec_scope(ec_);
     if (pps_.transform_skip_enabled && !cu_bypass_ && log2 <= pps_.log2_max_transform_skip_size)
-      tskip = ec.bin(CTX_TSKIP + (cIdx ? 1 : 0), K_TSKIP, cIdx) != 0;
+      tskip = ec_.bin(CTX_TSKIP + (cIdx ? 1 : 0), K_TSKIP, cIdx) != 0;
     // last significant coefficient position
-    int lastX = last_prefix(ec, log2, cIdx, CTX_LAST_X);
-    int lastY = last_prefix(ec, log2, cIdx, CTX_LAST_Y);
-    if (lastX > 3) lastX = last_suffix(ec, lastX);
-    if (lastY > 3) lastY = last_suffix(ec, lastY);
+    int lastX = last_prefix(log2, cIdx, CTX_LAST_X);
+    int lastY = last_prefix(log2, cIdx, CTX_LAST_Y);
+    if (lastX > 3) lastX = last_suffix(lastX);
+    if (lastY > 3) lastY = last_suffix(lastY);
     // scanIdx (§7.4.9.11)
     int scanIdx = 0;
     if (log2 == 2 || (log2 == 3 && cIdx == 0) || (log2 == 3 && sps_.ChromaArrayType == 3)) {
@@ -1133,7 +1119,7 @@ class SliceWalker {
         int ctx = 0;
         if (xS < sbw - 1) ctx |= csbf[yS][xS + 1];
         if (yS < sbw - 1) ctx |= csbf[yS + 1][xS];
-        coded = ec.bin(CTX_CSBF + (ctx ? 1 : 0) + (cIdx ? 2 : 0), K_CSBF, 0);
+        coded = ec_.bin(CTX_CSBF + (ctx ? 1 : 0) + (cIdx ? 2 : 0), K_CSBF, 0);
         inferSbDcSig = 1;
       }
       else coded = 1; // first (DC) and last sub-block are inferred coded
@@ -1153,13 +1139,13 @@ class SliceWalker {
       //  no branch on the bin)
       const int flat_ctx = CTX_SIG + (cIdx == 0 ? 42 : 43);
       for (int n = startPos; n > 0; n--) {
-        const int sig = ec.bin(flat_sig_ctx ? flat_ctx : CTX_SIG + sig_inc[n], K_SIG, n);
+        const int sig = ec_.bin(flat_sig_ctx ? flat_ctx : CTX_SIG + sig_inc[n], K_SIG, n);
         sigpos[nsig] = n;
         nsig += sig;
       }
       if (startPos >= 0) { // position 0: inferred when it is the only coefficient of a sub-block that was signalled as coded
         int sig = 1;
-        if (!(inferSbDcSig && nsig == (i == lastSub ? 1 : 0))) sig = ec.bin(flat_sig_ctx ? flat_ctx : CTX_SIG + sig_inc[0], K_SIG, 0);
+        if (!(inferSbDcSig && nsig == (i == lastSub ? 1 : 0))) sig = ec_.bin(flat_sig_ctx ? flat_ctx : CTX_SIG + sig_inc[0], K_SIG, 0);
         sigpos[nsig] = 0;
         nsig += sig;
       }
@@ -1175,19 +1161,19 @@ class SliceWalker {
       const int ngt1 = std::min(nsig, 8);
       const int gt1_ctx = CTX_GT1 + ctxSet * 4 + (cIdx ? 16 : 0);
       for (int k = 0; k < ngt1; k++) {
-        const int b = ec.bin(gt1_ctx + c1, K_GT1, k);
+        const int b = ec_.bin(gt1_ctx + c1, K_GT1, k);
         gt1[k] = b;
         // (selects, not branches: c1 = 0 after a greater1 flag, else it counts up to 3 while it is 1 or 2)
         firstGt1 = (b && firstGt1 < 0) ? k : firstGt1;
         c1 = b ? 0 : c1 + ((c1 > 0) & (c1 < 3));
       }
-      if (firstGt1 >= 0) gt2flag = ec.bin(CTX_GT2 + ctxSet + (cIdx ? 4 : 0), K_GT2, 0);
+      if (firstGt1 >= 0) gt2flag = ec_.bin(CTX_GT2 + ctxSet + (cIdx ? 4 : 0), K_GT2, 0);
 
       // signs
       const bool signHidden = pps_.sign_data_hiding && !cu_bypass_ && !rdpcm && (sigpos[0] - sigpos[nsig - 1] > 3); // slice.cc:3565-3575
       const int nsign = signHidden ? nsig - 1 : nsig;
       uint32_t signbits = 0;
-      signbits = ec.bypass_bits(K_SIGN, 0, 1, nsign); // (all signs of the sub-block in one read)
+      signbits = ec_.bypass_bits(K_SIGN, 0, 1, nsign); // (all signs of the sub-block in one read)
       signbits <<= (16 - nsign);
 
       // remaining levels
@@ -1205,7 +1191,7 @@ class SliceWalker {
         int absv = base;
         if (base == need) {
           if (rice > 16) throw ParseError(HM_ERR_BITSTREAM, "Rice parameter out of range");
-          const int rem = coeff_abs_level_remaining(ec, rice);
+          const int rem = coeff_abs_level_remaining(rice);
           absv += rem;
           if (absv > 3 * (1 << rice)) rice = sps_.persistent_rice ? rice + 1 : std::min(rice + 1, 4);
           if (sps_.persistent_rice && first_remaining) { // StatCoeff update by the first remaining level of the sub-block
@@ -1232,39 +1218,36 @@ class SliceWalker {
     }
   }
 
-  template <typename ECX>
-  int last_prefix(ECX& ec, int log2, int cIdx, int base)
+  int last_prefix(int log2, int cIdx, int base)
   {
     int off, shift;
     if (cIdx == 0) { off = 3 * (log2 - 2) + ((log2 - 1) >> 2); shift = (log2 + 1) >> 2; }
     else { off = 15; shift = log2 - 2; }
     const int cmax = (log2 << 1) - 1;
     int v = 0;
-    while (v < cmax && ec.bin(base + off + (v >> shift), K_LAST_PREFIX, v | (log2 << 8))) v++;
+    while (v < cmax && ec_.bin(base + off + (v >> shift), K_LAST_PREFIX, v | (log2 << 8))) v++;
     return v;
   }
-  template <typename ECX>
-  int last_suffix(ECX& ec, int prefix)
+  int last_suffix(int prefix)
   {
     const int nbits = (prefix >> 1) - 1;
-    const int s = (int)ec.bypass_bits(K_LAST_SUFFIX, 0, 1, nbits);
+    const int s = (int)ec_.bypass_bits(K_LAST_SUFFIX, 0, 1, nbits);
     return (1 << nbits) * (2 + (prefix & 1)) + s;
   }
   // §9.3.3.11 binarisation of coeff_abs_level_remaining
-  template <typename ECX>
-  int coeff_abs_level_remaining(ECX& ec, int rice)
+  int coeff_abs_level_remaining(int rice)
   {
     int prefix = 0;
-    while (ec.bypass(K_CALR_PREFIX, prefix | (rice << 4))) {
+    while (ec_.bypass(K_CALR_PREFIX, prefix | (rice << 4))) {
       if (++prefix > 32) throw ParseError(HM_ERR_BITSTREAM, "coeff_abs_level_remaining prefix too long");
     }
     if (prefix <= 3) {
-      return (prefix << rice) + (int)ec.bypass_bits(K_CALR_SUFFIX, rice - 1, -1, rice);
+      return (prefix << rice) + (int)ec_.bypass_bits(K_CALR_SUFFIX, rice - 1, -1, rice);
     }
     const int nb = prefix - 3 + rice;
     if (nb > 30) throw ParseError(HM_ERR_BITSTREAM, "coeff_abs_level_remaining too large");
     int v = (((1 << (prefix - 3)) + 3 - 1) << rice);
-    return v + (int)ec.bypass_bits(K_CALR_SUFFIX, nb - 1, -1, nb);
+    return v + (int)ec_.bypass_bits(K_CALR_SUFFIX, nb - 1, -1, nb);
   }
 
   EC& ec_;
