@@ -34,6 +34,14 @@ slab = torch.randint(0, 256, (512, 12096), dtype=torch.uint8, device=dev)
 full = pkg.shard.gather_slabs(slab, [512], dst=0)
 torch.cuda.synchronize()
 out["gather"] = bool(full is not None and full.is_cuda and torch.equal(full, slab))
+# (r06) the same through SlabGather: the root's slab is a view of the final image's rows (decoded in place), nothing to receive at one rank
+gat = pkg.shard.SlabGather([(0, 2)], 256, 500, chunk_tile_rows=1, dst=0)
+image = torch.zeros((500, 12096), dtype=torch.uint8, device=dev)
+mine = gat.root_rows(image)
+mine.copy_(slab[:500])
+gat.wait(gat.post_recvs(image))
+torch.cuda.synchronize()
+out["slab_gather"] = bool(mine.shape[0] == 500 and mine.data_ptr() == image.data_ptr() and torch.equal(image, slab[:500]) and gat.rows == [[(0, 256), (256, 500)]])
 # an empty slab (a rank beyond the grid's tile rows) next to nothing else: the padded gather still returns the rows
 out["version"] = list(torch.cuda.nccl.version())
 dist.destroy_process_group()
@@ -53,7 +61,21 @@ def test_rccl_one_rank_gather_of_device_slabs():
     assert line, r.stdout + r.stderr
     res = json.loads(line[-1][7:])
     assert res["backend"] == "nccl" and res["world"] == 1
-    assert res["all_reduce"] and res["gather"], res
+    assert res["all_reduce"] and res["gather"] and res["slab_gather"], res
+
+
+def test_grid_mode_on_one_rank_decodes_in_place_and_fills_the_shared_host_image():
+    """bench.py --mode grid at N = 1 (r06): the 16384 x 16384 grid decoded straight into the rows of the final image (the root's path of
+    shard.SlabGather), checked bit for bit against a separate one-rank decode, and the collective-free alternative - the rank's rows copied
+    device -> host into ONE image in shared memory that is registered with the HIP runtime - filled and timed."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "grid", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "error" not in res, res
+    assert res["n_gpus"] == 1 and "bit-exact" in res["config"]["self_check"], res["config"]
+    assert res["config"]["tile_rows_per_rank"] == [32] and res["k_only"]["MP_per_s"] > 0
+    h = res["host_gather"]
+    assert "error" not in h and h["registered"] is True and h["equals_the_gathered_image"] is True and h["pipelined_ms_per_grid"] > 0, h
 
 
 def _gpus_here():
