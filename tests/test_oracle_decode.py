@@ -228,3 +228,26 @@ def test_record_order_follows_the_picture_class(hm):
     assert split(width=128, height=128, log2_ctb=5, bit_depth=10) and split(width=128, height=128, log2_ctb=6, bit_depth=12, chroma_format=2)
     assert split(width=1024, height=1024, log2_ctb=5, bit_depth=10, density=5) and split(width=1024, height=1024, log2_ctb=4, density=5)
     assert not split(width=1024, height=1024, log2_ctb=5, density=5, scaling_list=1) and not split(width=128, height=128, chroma_format=3)
+
+
+def test_q9_class_equals_the_reference_scalar_build(hm):
+    """Quirk Q9: 8-bit pictures with CTBs of 16 and sub-sampled chroma, SAO on.  The fork's AVX2 SAO kernels write
+    8 columns past a chroma CTB (x86_new/x86_sao.cc:271,320-369); its scalar / SSE4 code does not.  Parser + oracle must equal the reference's
+    SCALAR build on this class, sample for sample (tools/q9_count.py counts how often the default build differs: profiles/r06_q9_count.txt)."""
+    import random
+    import synthutil
+    if not orc.have_ref():
+        pytest.skip("reference decoder not built")
+    rng = random.Random(99)
+    differ_from_default = 0
+    for i in range(12):
+        cf = 1 + (i & 1)
+        data = synthutil.picture(881000 + i, width=8 * rng.randrange(4, 30), height=8 * rng.randrange(4, 24), chroma_format=cf, bit_depth=8, log2_ctb=4,
+                                 qp=rng.randrange(18, 42), sao=1, density=rng.randrange(30, 90), cu_qp_delta=rng.randrange(2))
+        mine, _ = orc.oracle_decode(hevcutil.parse(hm, data), 3, crop=True)
+        scalar, _ = orc.ref_decode(data, orc.REF_F_SCALAR)
+        assert len(mine) == len(scalar) and all(np.array_equal(m, r) for m, r in zip(mine, scalar)), f"picture {i}: differs from the reference's scalar build"
+        default, _ = orc.ref_decode(data, 0)
+        assert np.array_equal(default[0], scalar[0])  # (the quirk only ever touches chroma)
+        differ_from_default += any(not np.array_equal(a, b) for a, b in zip(default[1:], scalar[1:]))
+    print(f"Q9: the default build differs from the scalar build in {differ_from_default} of 12 pictures on this host")
