@@ -1447,81 +1447,109 @@ def host_gather_leg(args, torch, dist, rank, world, dev, st, H, out_stride, y0, 
     /dev/shm, registered with the HIP runtime so that the copy is a DMA into it) - the collective-free form of the gather for a caller
     that wants the planes in host memory anyway (in-process: hm_decode_item_devices).  -> dict (rank 0), timings max over ranks"""
     import mmap
-    import numpy as np
     path = f"/dev/shm/hm_grid_{os.environ.get('MASTER_PORT', '0')}_{os.getppid() if dist else os.getpid()}.bin"
     nbytes = H * out_stride
-    try:
-        if rank == 0:
-            with open(path, "wb") as f:
-                f.truncate(nbytes)
-        if dist:
-            dist.barrier()
-        f = open(path, "r+b")
-        mm = mmap.mmap(f.fileno(), nbytes)
-        host = torch.frombuffer(mm, dtype=torch.uint8).view(H, out_stride)
-        rt = torch.cuda.cudart()
-        registered = int(rt.cudaHostRegister(host.data_ptr(), nbytes, 0)) == 0
-        copy_stream = torch.cuda.Stream(device=dev)
-        copied = [torch.cuda.Event() for _ in local]  # buffer b's rows have left it
-        rows = host[y0:y1]
+    cpu = "cpu" if (dist is None or args.dist_backend != "nccl") else dev
 
-        def d2h(b):
-            copy_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(copy_stream):
-                rows.copy_(local[b][:y1 - y0], non_blocking=True)
-                copied[b].record(copy_stream)
+    def all_ok(flag):  # the ranks agree before anything that waits for the others: a rank that failed must not leave them at a barrier
+        if dist is None:
+            return bool(flag)
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=cpu)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
 
-        n = max(1, min(args.steps, 5))
-        decode(0)
-        d2h(0)
-        barrier_sync()
-        ok = True
-        if rank == 0 and images is not None and not args.no_parity and world > 1:
-            ok = bool(torch.equal(host, images[0].cpu()))  # (images[0] holds the RCCL / gloo gather of the same grid)
-        t0 = time.perf_counter()
-        for _ in range(n):
-            decode(0)
-            d2h(0)
-            barrier_sync()
-        serial = (time.perf_counter() - t0) / n
-        barrier_sync()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            b = i % len(local)
-            torch.cuda.current_stream().wait_event(copied[b])  # (the buffer's previous grid has been copied out)
-            decode(b)
-            d2h(b)
-        barrier_sync()
-        piped = (time.perf_counter() - t0) / args.steps
-        if registered:
-            rt.cudaHostUnregister(host.data_ptr())
-        res = [serial, piped]
-        if dist:
-            tt = torch.tensor(res, dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            res = [float(x) for x in tt.tolist()]
-        del host
-        mm.close()
-        f.close()
-        if dist:
-            dist.barrier()
-        if rank == 0:
-            os.unlink(path)
-            mp = H * H / 1e6
-            return {"what": "every rank D2H into its rows of ONE host image shared by the ranks (file in /dev/shm, hipHostRegister'ed): no collective; the image ends in HOST memory, "
-                            "where heif_image_get_plane* hands it out (the gather above ends on rank 0's GPU)",
-                    "registered": registered, "equals_the_gathered_image": ok,
-                    "single_grid_latency_ms": round(res[0] * 1e3, 3), "pipelined_ms_per_grid": round(res[1] * 1e3, 3), "pipelined_MP_per_s": round(mp / res[1], 1)}
-        return None
-    except Exception as e:  # (a leg of its own: its failure must not take the grid line with it)
+    def cleanup():
         try:
             if rank == 0 and os.path.exists(path):
                 os.unlink(path)
         except OSError:
             pass
+
+    # ---- set-up: the file, the mapping, the registration (everything that can fail on a box's limits) ----
+    err, f, mm, host, registered = None, None, None, None, False
+    try:
+        if rank == 0:
+            with open(path, "wb") as f0:
+                f0.truncate(nbytes)
+    except Exception as e:  # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"
+    if not all_ok(err is None):
+        cleanup()
+        return {"error": err or "another rank could not create the shared image"} if rank == 0 else None
+    try:
+        f = open(path, "r+b")
+        mm = mmap.mmap(f.fileno(), nbytes)
+        host = torch.frombuffer(mm, dtype=torch.uint8).view(H, out_stride)
+        rt = torch.cuda.cudart()
+        registered = int(rt.cudaHostRegister(host.data_ptr(), nbytes, 0)) == 0  # (not registered: the copies still work, through the runtime's staging)
+    except Exception as e:  # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"
+    if not all_ok(err is None):
+        host = None
+        if mm is not None:
+            mm.close()
+        if f is not None:
+            f.close()
         if dist:
-            raise
-        return {"error": f"{type(e).__name__}: {e}"}
+            dist.barrier()
+        cleanup()
+        return {"error": err or "another rank could not map the shared image"} if rank == 0 else None
+
+    copy_stream = torch.cuda.Stream(device=dev)
+    copied = [torch.cuda.Event() for _ in local]  # buffer b's rows have left it
+    rows = host[y0:y1]
+
+    def d2h(b):
+        copy_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(copy_stream):
+            rows.copy_(local[b][:y1 - y0], non_blocking=True)
+            copied[b].record(copy_stream)
+
+    n = max(1, min(args.steps, 5))
+    decode(0)
+    d2h(0)
+    barrier_sync()
+    ok = True
+    if rank == 0 and images is not None and not args.no_parity and world > 1:
+        ok = bool(torch.equal(host, images[0].cpu()))  # (images[0] holds the RCCL / gloo gather of the same grid)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        decode(0)
+        d2h(0)
+        barrier_sync()
+    serial = (time.perf_counter() - t0) / n
+    barrier_sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        b = i % len(local)
+        torch.cuda.current_stream().wait_event(copied[b])  # (the buffer's previous grid has been copied out)
+        decode(b)
+        d2h(b)
+    barrier_sync()
+    piped = (time.perf_counter() - t0) / args.steps
+    if registered:
+        rt.cudaHostUnregister(host.data_ptr())
+    res = [serial, piped]
+    if dist:
+        tt = torch.tensor(res, dtype=torch.float64, device=cpu)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        res = [float(x) for x in tt.tolist()]
+    del rows, host
+    try:
+        mm.close()
+    except BufferError:  # (a view of the mapping is still alive somewhere: the mapping goes with the process)
+        pass
+    f.close()
+    if dist:
+        dist.barrier()
+    cleanup()
+    if rank == 0:
+        mp = H * H / 1e6
+        return {"what": "every rank D2H into its rows of ONE host image shared by the ranks (file in /dev/shm, hipHostRegister'ed): no collective; the image ends in HOST memory, "
+                        "where heif_image_get_plane* hands it out (the gather above ends on rank 0's GPU)",
+                "registered": registered, "equals_the_gathered_image": ok,
+                "single_grid_latency_ms": round(res[0] * 1e3, 3), "pipelined_ms_per_grid": round(res[1] * 1e3, 3), "pipelined_MP_per_s": round(mp / res[1], 1)}
+    return None
 
 
 if __name__ == "__main__":
