@@ -1179,8 +1179,8 @@ def config4(torch, pkg, dev, st, n=32):
 
 def hdr10_leg(torch, pkg, dev, st, n=96):
     """The headline's 12 MP grid with 10-bit 4:2:0 tiles (the class of HDR photographs) -> RGB24 along the chain the reference's search
-    picks for it (float operation, fused: k_tailf): n copies of one image of 48 tiles per batch, K clock; the first image against
-    the CPU flow (oracle executors, oracle paste, the searched chain - tests/pipeline.py: the flow of tests/test_configs_gpu.py)."""
+    picks for it (the shift to 8 bits and the integer 4:2:0 operation, fused: k_tail420's 16-bit instantiation since r06, k_tailf before):
+    n copies of one image of 48 tiles per batch, K clock; the first image against the CPU flow (oracle executors, oracle paste, the searched chain - tests/pipeline.py: the flow of tests/test_configs_gpu.py)."""
     import numpy as np
     import pipeline
     capi, L = pkg.capi, pkg.lib()
@@ -1231,7 +1231,7 @@ def hdr10_leg(torch, pkg, dev, st, n=96):
     parity = "bit-exact vs the oracle flow"
     mp = n * W * H / 1e6
     if fused:
-        kernels = {"k_residual": round(k[4], 3), KERNEL_NAMES[0]: round(k[0], 3), "k_tailf(deblock+sao+paste+float colour)": round(k[2], 3)}
+        kernels = {"k_residual": round(k[4], 3), KERNEL_NAMES[0]: round(k[0], 3), "k_tail420<16-bit>(deblock+sao+paste+shift+integer colour)": round(k[2], 3)}
         tail_ms = k[2]
     else:
         kernels = {"k_residual": round(k[4], 3), KERNEL_NAMES[0]: round(k[0], 3), "k_deblock": round(k[1], 3), "k_sao_paste": round(k[2], 3), "k_ycbcr_float(colour)": round(k[3], 3)}

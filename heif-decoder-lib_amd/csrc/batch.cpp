@@ -277,7 +277,7 @@ static int decide_tail(hm_batch* b)
 // the fused tail of m pictures (descriptors dk, destinations td) of the batch's only class
 static int launch_tail(const hm_batch* b, const Class& c, const hm_dev_pic* dk, const void* td, int m, int stages, hipStream_t s)
 {
-  if (b->tail_kind == 1) return hm_launch_tailf(dk, td, m, c.max_w, c.max_h, &b->colour_desc, b->tail_cf, b->tail_mode, stages, s);
+  if (b->tail_kind == 1) return hm_launch_tailf(dk, td, m, c.max_w, c.max_h, c.log2_ctb, &b->colour_desc, b->tail_cf, b->tail_mode, stages, s);
   return hm_launch_tail420(dk, td, m, c.max_w, c.max_h, c.log2_ctb, b->tail_bpp, b->tail_coef, stages, s);
 }
 

@@ -1052,14 +1052,19 @@ constexpr int TAIL_LP = 144, TAIL_LR = TAIL_TH + 8;   // luma tile: pitch, rows
 constexpr int TAIL_CP = 80, TAIL_CR = TAIL_TH / 2 + 8;    // chroma tiles
 
 // a group of 8 samples of LDS tile row `row` (already clamped into the picture) at tile column xo, with its side dwords
-__device__ __forceinline__ void tail_row(SaoRow<uint8_t>& R, const uint8_t* tile, int pitch, int row, int xo)
+template <typename Pix>
+__device__ __forceinline__ void tile_row(SaoRow<Pix>& R, const Pix* tile, int pitch, int row, int xo)
 {
-  const uint8_t* q = tile + (mul24_raw(row, pitch) + xo);
-  uint32_t d[2];
-  __builtin_memcpy(d, q, 8);
-  R.p[0] = __builtin_amdgcn_perm(0, d[0], 0x0c010c00u); R.p[1] = __builtin_amdgcn_perm(0, d[0], 0x0c030c02u);
-  R.p[2] = __builtin_amdgcn_perm(0, d[1], 0x0c010c00u); R.p[3] = __builtin_amdgcn_perm(0, d[1], 0x0c030c02u);
-  __builtin_memcpy(&R.l, q - 4, 4); // (the tile starts 8 columns left of x0: always inside it; used only where a left neighbour exists)
+  const Pix* q = tile + (mul24_raw(row, pitch) + xo);
+  if (sizeof(Pix) == 1) {
+    uint32_t d[2];
+    __builtin_memcpy(d, q, 8);
+    R.p[0] = __builtin_amdgcn_perm(0, d[0], 0x0c010c00u); R.p[1] = __builtin_amdgcn_perm(0, d[0], 0x0c030c02u);
+    R.p[2] = __builtin_amdgcn_perm(0, d[1], 0x0c010c00u); R.p[3] = __builtin_amdgcn_perm(0, d[1], 0x0c030c02u);
+  }
+  else __builtin_memcpy(R.p, q, 16);
+  // (the tile starts 8 columns left of the workgroup's samples and ends 8 behind them: both side dwords lie inside it)
+  __builtin_memcpy(&R.l, reinterpret_cast<const uint8_t*>(q) - 4, 4);
   __builtin_memcpy(&R.r, q + 8, 4);
 }
 // SAO of NR rows of one 8-sample group of plane c (the fast path of k_sao_paste: one slice, no tiles, no lossless units)
@@ -1067,12 +1072,12 @@ __device__ __forceinline__ void tail_row(SaoRow<uint8_t>& R, const uint8_t* tile
 // the scalar unit once per wave instead of by every lane, and SAO type / class become wave-uniform branches
 // rec_*: UNI only - dword 2 of the cell's hm_ctb (flags and masks) and the plane's hm_sao, loaded by the caller long before (r05: a
 // load here, behind the previous cell's pixel stores, waits for those stores too - loads and stores share one counter)
-template <int NR, bool UNI>
-__device__ __forceinline__ void tail_sao(const hm_dev_pic& dp, const PicView& v, int c, const uint8_t* tile, int pitch, int tx0, int ty0,
+template <int NR, bool UNI, typename Pix = uint8_t>
+__device__ __forceinline__ void tail_sao(const hm_dev_pic& dp, const PicView& v, int c, const Pix* tile, int pitch, int tx0, int ty0,
                                          int xs, int yy0, int W, int Hh, int l2w, int l2h, int apply_sao, uint32_t (&res)[NR][4], uint32_t rec_flags = 0, uint32_t rec_s0 = 0,
-                                         uint32_t rec_s1 = 0)
+                                         uint32_t rec_s1 = 0, int bd = 8)
 {
-  SaoRow<uint8_t> rows[NR + 2];
+  SaoRow<Pix> rows[NR + 2];
   // UNI: the CTB's parameters are known (scalars) before anything is read - the row above the group's first and the row below
   // its last are only looked at by the edge classes with a vertical component (r05: they were fetched unconditionally, as in
   // k_sao_paste, where the trip to memory had to start before the parameters were known; here the rows come from LDS)
@@ -1084,8 +1089,8 @@ __device__ __forceinline__ void tail_sao(const hm_dev_pic& dp, const PicView& v,
 #pragma unroll
   for (int r = 0; r < NR + 2; r++) {
     const int y = yy0 - 1 + r;
-    if ((r == 0 || r == NR + 1) && !need_vertical) { rows[r] = SaoRow<uint8_t>(); continue; }
-    tail_row(rows[r], tile, pitch, (y < 0 ? 0 : (y < Hh ? y : Hh - 1)) - ty0, xs - tx0);
+    if ((r == 0 || r == NR + 1) && !need_vertical) { rows[r] = SaoRow<Pix>(); continue; }
+    tile_row(rows[r], tile, pitch, (y < 0 ? 0 : (y < Hh ? y : Hh - 1)) - ty0, xs - tx0);
   }
   const int cx = xs >> l2w;
 #pragma unroll
@@ -1099,7 +1104,7 @@ __device__ __forceinline__ void tail_sao(const hm_dev_pic& dp, const PicView& v,
       const GLOBAL_AS uint32_t* cbq = gptr<uint32_t>(reinterpret_cast<const uint8_t*>(v.ctbs) + (uint32_t)mul24_raw(ctb_index, (int)sizeof(hm_ctb))); // hm_ctb as dwords (32-bit offset)
       cflags = cbq[2]; s0 = cbq[3 + 2 * c]; s1 = cbq[4 + 2 * c];
     }
-    const SaoRow<uint8_t>&up = rows[r], &cur = rows[r + 1], &dn = rows[r + 2];
+    const SaoRow<Pix>&up = rows[r], &cur = rows[r + 1], &dn = rows[r + 2];
     const bool sao_on = apply_sao && (dp.flags & HM_PIC_SAO_ENABLED) && (cflags & (c == 0 ? HM_CTB_SAO_LUMA : HM_CTB_SAO_CHROMA));
 #if defined(HM_T_PROBE) && (HM_T_PROBE & 2)
     const int type = 0; (void)sao_on; // probe: no SAO arithmetic
@@ -1108,7 +1113,7 @@ __device__ __forceinline__ void tail_sao(const hm_dev_pic& dp, const PicView& v,
 #endif
     const uint32_t offs = (s0 >> 24) | (s1 << 8);
     const uint32_t nbm = c == 0 ? (cflags >> 8) & 0xFF : (cflags >> 16) & 0xFF;
-    const uint32_t maxv2 = 0x00FF00FFu;
+    const uint32_t maxv2 = sizeof(Pix) == 1 ? 0x00FF00FFu : ((1u << bd) - 1) * 0x10001u; // (bd: the picture's bit depth; 8-bit samples: a constant)
 #pragma unroll
     for (int j = 0; j < 4; j++) res[r][j] = cur.p[j];
     if (type == 1) { // band offset (fallback-postfilter.h:218-241)
@@ -1116,7 +1121,7 @@ __device__ __forceinline__ void tail_sao(const hm_dev_pic& dp, const PicView& v,
       const uint32_t biased = offs ^ 0x80808080u;
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        u16x2 bi = (as_u(cur.p[j]) >> (u16x2)(3)) - (u16x2)(bp);
+        u16x2 bi = (as_u(cur.p[j]) >> (u16x2)((unsigned short)(sizeof(Pix) == 1 ? 3 : bd - 5))) - (u16x2)((unsigned short)bp);
         bi = __builtin_elementwise_min(bi & (u16x2)(31), (u16x2)(4));
         res[r][j] = pk_apply(cur.p[j], as_w(bi) | 0x0c000c00u, 0x80u, biased, maxv2);
       }
@@ -1124,10 +1129,10 @@ __device__ __forceinline__ void tail_sao(const hm_dev_pic& dp, const PicView& v,
     else if (type == 2) {
       const int cl = (s0 >> 8) & 0xFF;
       const bool all_ok = UNI && nbm == 0xFFu; // (the CTB's eight neighbours exist and may be read: nothing to mask)
-      if (cl == 0) sao_edge_group<uint8_t, -1, 0>(xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv2, up, cur, dn, res[r], all_ok);
-      else if (cl == 1) sao_edge_group<uint8_t, 0, -1>(xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv2, up, cur, dn, res[r], all_ok);
-      else if (cl == 2) sao_edge_group<uint8_t, -1, -1>(xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv2, up, cur, dn, res[r], all_ok);
-      else sao_edge_group<uint8_t, 1, -1>(xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv2, up, cur, dn, res[r], all_ok);
+      if (cl == 0) sao_edge_group<Pix, -1, 0>(xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv2, up, cur, dn, res[r], all_ok);
+      else if (cl == 1) sao_edge_group<Pix, 0, -1>(xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv2, up, cur, dn, res[r], all_ok);
+      else if (cl == 2) sao_edge_group<Pix, -1, -1>(xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv2, up, cur, dn, res[r], all_ok);
+      else sao_edge_group<Pix, 1, -1>(xs, yy, W, Hh, l2w, l2h, cx, cy, nbm, offs, maxv2, up, cur, dn, res[r], all_ok);
     }
   }
 }
@@ -1180,13 +1185,25 @@ __device__ __forceinline__ uint32_t pk_rescale_stored(uint32_t pair, int bd)
   return o;
 }
 
-template <int BPP, int MINW, bool UNI>
+// N bytes of LDS at an address known to be a multiple of ALIGN (a byte pointer alone would make the compiler split the access)
+template <int ALIGN, int N>
+__device__ __forceinline__ void lds_get(uint32_t* d, const uint8_t* p) { __builtin_memcpy(d, __builtin_assume_aligned(p, ALIGN), N); }
+template <int ALIGN, int N>
+__device__ __forceinline__ void lds_put(uint8_t* p, const uint32_t* d) { __builtin_memcpy(__builtin_assume_aligned(p, ALIGN), d, N); }
+
+// Pix = uint16_t (r06): the class of HDR photographs - 4:2:0 pictures of 9..11 bits to RGB24 / RGBA32 through the reference's shift to 8 bits and
+// the same integer matrix (hdr_sdr.cc:176-195, then yuv2rgb.cc:359-364; colour_float.h "mode 4") - on this kernel's cells, unit lists and scalar
+// SAO parameters instead of k_tailf's: the LDS tiles hold 16-bit samples, everything else is the same code
+template <int BPP, int MINW, bool UNI, typename Pix = uint8_t>
 __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic* __restrict__ pics, const TailDst* __restrict__ dsts, int tiles_x, int n_tiles, int stages, TailCoef k)
 {
-  __shared__ __attribute__((aligned(16))) uint8_t s_all[TAIL_LR * TAIL_LP + 2 * TAIL_CR * TAIL_CP];
+  constexpr int BPS = (int)sizeof(Pix);                    // bytes per sample
+  constexpr int LPB = TAIL_LP * BPS, CPB = TAIL_CP * BPS;  // the tiles' pitches in bytes
+  __shared__ __attribute__((aligned(16))) uint8_t s_all[(TAIL_LR * TAIL_LP + 2 * TAIL_CR * TAIL_CP) * BPS];
   uint8_t* const s_l = s_all;
-  uint8_t* const s_c0 = s_all + TAIL_LR * TAIL_LP;
-  uint8_t* const s_c1 = s_c0 + TAIL_CR * TAIL_CP;
+  uint8_t* const s_c0 = s_all + TAIL_LR * LPB;
+  uint8_t* const s_c1 = s_c0 + TAIL_CR * CPB;
+  const int bd = BPS == 1 ? 8 : (int)pics[blockIdx.y].bit_depth, maxv = (1 << bd) - 1, pre_shift = bd - 8;
   const hm_dev_pic& dp = pics[blockIdx.y];
   // Workgroups go to the 8 XCDs in turn (linear id % 8) and every XCD has an L2 of its own: neighbouring tiles share the
   // cache lines at their common border (the windows overlap by 4 samples, rows are read in 128-byte lines), so each XCD
@@ -1207,7 +1224,7 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
   __shared__ uint8_t s_tab[112];
   __shared__ uint32_t s_cnt[4]; // luma edge units waiting for a filter: vertical strong / normal, horizontal strong / normal
   constexpr int NWAVES = TAIL_THREADS / 64;
-  __shared__ __attribute__((aligned(16))) uint8_t s_x[NWAVES][2][16][16]; // phase 2: a cell's chroma on its way to the luma lanes; phase 1: the unit lists
+  __shared__ __attribute__((aligned(16))) uint8_t s_x[NWAVES][2][16][16 * BPS]; // phase 2: a cell's chroma on its way to the luma lanes; phase 1: the unit lists
   // ---- the lane's window: its loads go out first - the block map and the first barrier wait behind them, not in front ----
   // windows per tile: (TW / 8 + 1) x (TH / 8 + 1) luma from lane 0 up, 2 x (TW / 16 + 1) x (TH / 16 + 1) chroma at the end of the workgroup
   constexpr int NLX = TAIL_TW / 8 + 1, NLY = TAIL_TH / 8 + 1, NCX = TAIL_TW / 16 + 1, NCY = TAIL_TH / 16 + 1;
@@ -1215,7 +1232,7 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
   static_assert(NL <= C0, "one lane per window");
   int c = -1, kxl = 0, kyl = 0, kx = 0, ky = 0, PW = 0, PH = 0;
   bool have_window = false;
-  Window<uint8_t> win;
+  Window<Pix> win;
   if (tid < NL) { c = 0; kyl = tid / NLX; kxl = tid - kyl * NLX; }
   else if (tid >= C0) {
     int t = tid - C0;
@@ -1234,16 +1251,20 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
       if (n_tiles < 0) window_load(win, dp.plane[c], dp.pitch[c], ox, oy, PH); // probe: no loads of samples
       else {
 #pragma unroll
-        for (int r = 0; r < 8; r++) { win.w[r][0] = (uint32_t)(ox + r) * 0x01010101u; win.w[r][1] = (uint32_t)(oy + r) * 0x01010101u; }
+        for (int r = 0; r < 8; r++)
+#pragma unroll
+          for (int k = 0; k < Window<Pix>::WORDS; k++) win.w[r][k] = (uint32_t)((k & 1 ? oy : ox) + r) * 0x01010101u;
       }
 #else
       if (ox >= 0) window_load(win, dp.plane[c], dp.pitch[c], ox, oy, PH);
       else { // left picture border: the window's left half does not exist (k_deblock never loads the corner window)
+        constexpr int HW = Window<Pix>::WORDS / 2;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
           const int y = oy + r < 0 ? 0 : (oy + r < PH ? oy + r : PH - 1);
-          win.w[r][0] = 0;
-          win.w[r][1] = *gptr<uint32_t>(dp.plane[c] + (uint32_t)mul24_raw(y, dp.pitch[c]));
+#pragma unroll
+          for (int k = 0; k < HW; k++) win.w[r][k] = 0;
+          __builtin_memcpy(win.w[r] + HW, gptr<uint8_t>(dp.plane[c] + (uint32_t)mul24_raw(y, dp.pitch[c])), 4 * BPS);
         }
       }
 #endif
@@ -1325,6 +1346,7 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
   auto apply_units = [&](auto vertical, const uint32_t* cnt) {
     constexpr bool VV = decltype(vertical)::value;
 #if HM_TAIL_HALF_UNITS
+    static_assert(BPS == 1, "the half-unit A/B path is 8-bit only");
     // (r06, measured and left off) a lane per HALF unit - one pair of lines, what the filters work on anyway: the ~27 strong units of a
     // tile's direction fill one wave pass at half its cost instead of 27 of 64 lanes at the full one, the normal ones waste half a pass less
     const uint32_t ns2 = 2u * cnt[0], nn2 = 2u * cnt[1], ns_pad = (ns2 + 63u) & ~63u;
@@ -1363,20 +1385,20 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
       if (strong && item >= ns) continue;
       const uint32_t e = ulist[strong ? item : LIST_N - 1 - (item - ns_pad)];
       uint8_t* const q = s_l + (e & 0xFFFFu);
-      Window<uint8_t> W;
+      Window<Pix> W;
       if (VV) { // four rows of eight samples across the vertical edge
 #pragma unroll
-        for (int r = 0; r < 4; r++) { W.w[r][0] = *reinterpret_cast<const uint32_t*>(q + r * TAIL_LP); W.w[r][1] = *reinterpret_cast<const uint32_t*>(q + r * TAIL_LP + 4); }
-        luma_unit_apply<true, 0>(W, e >> 16);
+        for (int r = 0; r < 4; r++) lds_get<4 * BPS, 8 * BPS>(W.w[r], q + r * LPB);
+        luma_unit_apply<true, 0, Pix>(W, e >> 16, maxv);
 #pragma unroll
-        for (int r = 0; r < 4; r++) { *reinterpret_cast<uint32_t*>(q + r * TAIL_LP) = W.w[r][0]; *reinterpret_cast<uint32_t*>(q + r * TAIL_LP + 4) = W.w[r][1]; }
+        for (int r = 0; r < 4; r++) lds_put<4 * BPS, 8 * BPS>(q + r * LPB, W.w[r]);
       }
       else { // eight rows of four samples: four columns across the horizontal edge
 #pragma unroll
-        for (int r = 0; r < 8; r++) W.w[r][0] = *reinterpret_cast<const uint32_t*>(q + r * TAIL_LP);
-        luma_unit_apply<false, 0>(W, e >> 16);
+        for (int r = 0; r < 8; r++) lds_get<4 * BPS, 4 * BPS>(W.w[r], q + r * LPB);
+        luma_unit_apply<false, 0, Pix>(W, e >> 16, maxv);
 #pragma unroll
-        for (int r = 1; r < 7; r++) *reinterpret_cast<uint32_t*>(q + r * TAIL_LP) = W.w[r][0]; // (p3 and q3 stay as they are)
+        for (int r = 1; r < 7; r++) lds_put<4 * BPS, 4 * BPS>(q + r * LPB, W.w[r]); // (p3 and q3 stay as they are)
       }
     }
 #endif
@@ -1402,49 +1424,46 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
           if (one_slice) {
             // (the crossing's block: luma (2 kx, 2 ky), chroma (4 kx, 4 ky) = 2 kxl / 4 kxl columns right of the tile's first block)
             const uint16_t* const mw = s_meta + ((c ? 4 * kyl : 2 * kyl) + 2) * MP + (c ? 4 * kxl : 2 * kxl) + 2;
-            any_edge = tail_window_edges(mw, MP, c, kx, ky, PW, PH, slice_beta_off, slice_tc_off, c == 0 ? 0 : (c == 1 ? dp.cb_qp_offset : dp.cr_qp_offset), s_tab, E);
+            any_edge = tail_window_edges(mw, MP, c, kx, ky, PW, PH, slice_beta_off, slice_tc_off, c == 0 ? 0 : (c == 1 ? dp.cb_qp_offset : dp.cr_qp_offset), s_tab, E, bd - 8);
           }
-          else any_edge = window_edges<uint8_t, false>(dp, v, c, kx, ky, c ? 2 : 1, c ? 2 : 1, E, TabLds{s_tab});
+          else any_edge = window_edges<Pix, false>(dp, v, c, kx, ky, c ? 2 : 1, c ? 2 : 1, E, TabLds{s_tab});
           HM_MARK("edges_end");
           if (any_edge && c == 0) {
             luma_window = true;
-            decV0 = luma_unit_decide<true, 0>(win, E.betaV[0], E.tcV[0]);
-            decV1 = luma_unit_decide<true, 4>(win, E.betaV[1], E.tcV[1]);
+            decV0 = luma_unit_decide<true, 0, Pix>(win, E.betaV[0], E.tcV[0]);
+            decV1 = luma_unit_decide<true, 4, Pix>(win, E.betaV[1], E.tcV[1]);
             betaH0 = E.betaH[0]; betaH1 = E.betaH[1]; tcH0 = E.tcH[0]; tcH1 = E.tcH[1];
           }
           else if (any_edge) {
-            filter_chroma_pk<true>(win, E.tcV);
-            filter_chroma_pk<false>(win, E.tcH);
+            filter_chroma_pk<true, Pix>(win, E.tcV, maxv);
+            filter_chroma_pk<false, Pix>(win, E.tcH, maxv);
           }
           HM_MARK("filter_end");
         }
 #endif
         uint8_t* const t0 = c == 0 ? s_l : (c == 1 ? s_c0 : s_c1);
-        const int tp = c == 0 ? TAIL_LP : TAIL_CP;
-        uint8_t* q = t0 + (8 * kyl) * tp + 8 * kxl + (TAIL_XO - 4);
-        woff = (uint32_t)((8 * kyl) * TAIL_LP + 8 * kxl + (TAIL_XO - 4));
+        const int tp = c == 0 ? LPB : CPB;
+        uint8_t* q = t0 + (8 * kyl) * tp + (8 * kxl + (TAIL_XO - 4)) * BPS;
+        woff = (uint32_t)((8 * kyl) * LPB + (8 * kxl + (TAIL_XO - 4)) * BPS);
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-          *reinterpret_cast<uint32_t*>(q + r * tp) = win.w[r][0];
-          *reinterpret_cast<uint32_t*>(q + r * tp + 4) = win.w[r][1];
-        }
+        for (int r = 0; r < 8; r++) lds_put<4 * BPS, 8 * BPS>(q + r * tp, win.w[r]);
       }
     }
   }
-  push_units(decV0, decV1, woff, woff + 4 * TAIL_LP, s_cnt);
+  push_units(decV0, decV1, woff, woff + 4 * LPB, s_cnt);
   __syncthreads();
   apply_units(std::true_type(), s_cnt);
   __syncthreads();
   uint32_t decH0 = 0, decH1 = 0;
   if (luma_window && (tcH0 | tcH1)) { // the horizontal edge of the window, on the samples its vertical edge left
-    Window<uint8_t> win;
+    Window<Pix> win;
     const uint8_t* const q = s_l + woff;
 #pragma unroll
-    for (int r = 0; r < 8; r++) { win.w[r][0] = *reinterpret_cast<const uint32_t*>(q + r * TAIL_LP); win.w[r][1] = *reinterpret_cast<const uint32_t*>(q + r * TAIL_LP + 4); }
-    decH0 = luma_unit_decide<false, 0>(win, betaH0, tcH0);
-    decH1 = luma_unit_decide<false, 4>(win, betaH1, tcH1);
+    for (int r = 0; r < 8; r++) lds_get<4 * BPS, 8 * BPS>(win.w[r], q + r * LPB);
+    decH0 = luma_unit_decide<false, 0, Pix>(win, betaH0, tcH0);
+    decH1 = luma_unit_decide<false, 4, Pix>(win, betaH1, tcH1);
   }
-  push_units(decH0, decH1, woff, woff + 4, s_cnt + 2);
+  push_units(decH0, decH1, woff, woff + 4 * BPS, s_cnt + 2);
   __syncthreads();
   apply_units(std::false_type(), s_cnt + 2);
   if (UNI) { // the cells' SAO parameters have long arrived: from here on scalars - nothing in phase 2 refers to a load any more
@@ -1478,14 +1497,22 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
       const int xc = (cellx >> 1) + 8 * gxc, yc = (celly >> 1) + row;
       if (xc < (W >> 1) && yc < (H >> 1)) {
         uint32_t rc[1][4];
-        tail_sao<1, UNI>(dp, v, 1 + pl, s_c0 + pl * (TAIL_CR * TAIL_CP), TAIL_CP, (x0 >> 1) - TAIL_XO, (y0 >> 1) - 4, xc, yc, W >> 1, H >> 1, l2 - 1, l2 - 1, stages & 2, rc,
-                         ctb_rec[it][0], pl ? ctb_rec[it][5] : ctb_rec[it][3], pl ? ctb_rec[it][6] : ctb_rec[it][4]);
+        tail_sao<1, UNI, Pix>(dp, v, 1 + pl, reinterpret_cast<const Pix*>(s_c0 + pl * (TAIL_CR * CPB)), TAIL_CP, (x0 >> 1) - TAIL_XO, (y0 >> 1) - 4, xc, yc, W >> 1, H >> 1, l2 - 1, l2 - 1,
+                              stages & 2, rc, ctb_rec[it][0], pl ? ctb_rec[it][5] : ctb_rec[it][3], pl ? ctb_rec[it][6] : ctb_rec[it][4], bd);
         if (rescale) { // (the paste of a limited-range tile: context.cc:2504-2528)
 #pragma unroll
-          for (int j = 0; j < 4; j++) rc[0][j] = pk_rescale<true>(rc[0][j]);
+          for (int j = 0; j < 4; j++) rc[0][j] = pk_rescale_stored<Pix, true>(rc[0][j], bd);
         }
-        const uint32_t o[2] = {__builtin_amdgcn_perm(rc[0][1], rc[0][0], 0x06040200u), __builtin_amdgcn_perm(rc[0][3], rc[0][2], 0x06040200u)};
-        __builtin_memcpy(&s_x[wave][pl][row][8 * gxc], o, 8);
+        if constexpr (BPS == 1) {
+          const uint32_t o[2] = {__builtin_amdgcn_perm(rc[0][1], rc[0][0], 0x06040200u), __builtin_amdgcn_perm(rc[0][3], rc[0][2], 0x06040200u)};
+          __builtin_memcpy(&s_x[wave][pl][row][8 * gxc], o, 8);
+        }
+        else { // (the shift to 8 bits, hdr_sdr.cc:176-195, here: once per chroma sample)
+          uint32_t o[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) o[j] = as_w(as_u(rc[0][j]) >> (u16x2)((unsigned short)pre_shift));
+          __builtin_memcpy(&s_x[wave][pl][row][16 * gxc], o, 16);
+        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1498,16 +1525,22 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
     const int lx = cellx + 8 * gx, ly = celly + 2 * rp;
     if (lx < cw && ly < chh) {
       uint32_t ry[2][4];
-      tail_sao<2, UNI>(dp, v, 0, s_l, TAIL_LP, x0 - TAIL_XO, y0 - 4, lx, ly, W, H, l2, l2, stages & 2, ry, ctb_rec[it][0], ctb_rec[it][1], ctb_rec[it][2]);
+      tail_sao<2, UNI, Pix>(dp, v, 0, reinterpret_cast<const Pix*>(s_l), TAIL_LP, x0 - TAIL_XO, y0 - 4, lx, ly, W, H, l2, l2, stages & 2, ry, ctb_rec[it][0], ctb_rec[it][1], ctb_rec[it][2], bd);
       if (rescale) {
 #pragma unroll
         for (int r = 0; r < 2; r++)
 #pragma unroll
-          for (int j = 0; j < 4; j++) ry[r][j] = pk_rescale<false>(ry[r][j]);
+          for (int j = 0; j < 4; j++) ry[r][j] = pk_rescale_stored<Pix, false>(ry[r][j], bd);
       }
-      uint32_t cb4, cr4;
-      __builtin_memcpy(&cb4, &s_x[wave][0][rp][4 * gx], 4);
-      __builtin_memcpy(&cr4, &s_x[wave][1][rp][4 * gx], 4);
+      if constexpr (BPS == 2) {
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) ry[r][j] = as_w(as_u(ry[r][j]) >> (u16x2)((unsigned short)pre_shift));
+      }
+      uint32_t cbw[BPS], crw[BPS]; // the four Cb / Cr samples under the lane's eight columns (8 bits each by now)
+      __builtin_memcpy(cbw, &s_x[wave][0][rp][4 * BPS * gx], 4 * BPS);
+      __builtin_memcpy(crw, &s_x[wave][1][rp][4 * BPS * gx], 4 * BPS);
       constexpr int OW = 2 * BPP; // dwords of 8 pixels
       uint32_t o[2][OW];
       auto sat_pk = [](uint32_t x) -> uint32_t { // two signed 16-bit halves -> two bytes clipped to 0..255, upper half 0
@@ -1521,7 +1554,8 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
 #pragma unroll
         for (int q = 0; q < 2; q++) {
           const int c = 2 * h + q;
-          const int u = (int)((cb4 >> (8 * c)) & 0xFF), w = (int)((cr4 >> (8 * c)) & 0xFF);
+          const int u = BPS == 1 ? (int)((cbw[0] >> (8 * c)) & 0xFF) : (int)((cbw[c >> 1] >> (16 * (c & 1))) & 0xFFFF);
+          const int w = BPS == 1 ? (int)((crw[0] >> (8 * c)) & 0xFF) : (int)((crw[c >> 1] >> (16 * (c & 1))) & 0xFFFF);
 #if defined(HM_T_PROBE) && (HM_T_PROBE & 4)
           const int rt = u, gt = w, bt = u; // probe: no matrix
 #else
@@ -1598,21 +1632,6 @@ __global__ __launch_bounds__(TAIL_THREADS, MINW) void k_tail420(const hm_dev_pic
 // k_sao_paste / k_ycbcr_float instead of the packed 8-bit ones, in two phases: (1) one lane per deblocking window, (2) one
 // lane per 16 luma samples of a row (two rows for 4:2:0) and the 8 Cb / 8 Cr samples under them: SAO, float matrix, pixels out.
 // A workgroup owns 128 x 64 luma samples; Pix = uint8_t / uint16_t, CF = 1 (4:2:0) / 2 (4:2:2), OF = output format.
-template <typename Pix>
-__device__ __forceinline__ void tile_row(SaoRow<Pix>& R, const Pix* tile, int pitch, int row, int xo)
-{
-  const Pix* q = tile + (mul24_raw(row, pitch) + xo);
-  if (sizeof(Pix) == 1) {
-    uint32_t d[2];
-    __builtin_memcpy(d, q, 8);
-    R.p[0] = __builtin_amdgcn_perm(0, d[0], 0x0c010c00u); R.p[1] = __builtin_amdgcn_perm(0, d[0], 0x0c030c02u);
-    R.p[2] = __builtin_amdgcn_perm(0, d[1], 0x0c010c00u); R.p[3] = __builtin_amdgcn_perm(0, d[1], 0x0c030c02u);
-  }
-  else __builtin_memcpy(R.p, q, 16);
-  // (the tile starts 8 columns left of the workgroup's samples and ends 8 behind them: both side dwords lie inside it)
-  __builtin_memcpy(&R.l, reinterpret_cast<const uint8_t*>(q) - 4, 4);
-  __builtin_memcpy(&R.r, q + 8, 4);
-}
 // SAO of one group of 8 samples of row yy of plane c, rows read from an LDS tile whose sample (tx0, ty0) is its first (the
 // fast path of k_sao_paste: the per-CTB neighbour masks, no lossless units, no per-sample ring test)
 // rec: dwords 2..8 of the group's hm_ctb (flags and masks, then hm_sao of the three planes) in LDS - r06: read from memory here, the
@@ -1960,8 +1979,8 @@ extern "C" int hm_launch_sao_paste(const hm_dev_pic* d_pics, int n_pics, int max
 // {pointer, pitch} at the picture's paste position), bpp 3 / 4, integer matrix coefficients of yuv2rgb.cc:336-339.
 extern "C" const void* hm_tail420_kernel() { return reinterpret_cast<const void*>(k_tail420<3, TAIL_MINW, true>); } // (test_hooks.cpp: hm_debug_kernel_regs)
 
-extern "C" int hm_launch_tail420(const hm_dev_pic* d_pics, const void* d_dsts, int n_pics, int max_w, int max_h, int log2_ctb, int bpp, const int coef[4],
-                                 int stages, hipStream_t s)
+template <typename Pix>
+static int launch_tail420(const hm_dev_pic* d_pics, const void* d_dsts, int n_pics, int max_w, int max_h, int log2_ctb, int bpp, const int coef[4], int stages, hipStream_t s)
 {
   if (n_pics <= 0) return HM_OK;
   const int tiles_x = (max_w + TAIL_TW - 1) / TAIL_TW, tiles_y = (max_h + TAIL_TH - 1) / TAIL_TH;
@@ -1972,14 +1991,20 @@ extern "C" int hm_launch_tail420(const hm_dev_pic* d_pics, const void* d_dsts, i
   //  at 96 / 80 / 64 VGPRs against 15.7 ms)
   // (pictures with CTBs of 32 / 64: a wave's 32 x 32 cell lies in one CTB - its SAO record through the scalar unit)
   if (log2_ctb >= 5) {
-    if (bpp == 3) hipLaunchKernelGGL((k_tail420<3, TAIL_MINW, true>), grid, dim3(TAIL_THREADS), 0, s, d_pics, dd, tiles_x, tiles_x * tiles_y, stages, k);
-    else hipLaunchKernelGGL((k_tail420<4, TAIL_MINW, true>), grid, dim3(TAIL_THREADS), 0, s, d_pics, dd, tiles_x, tiles_x * tiles_y, stages, k);
+    if (bpp == 3) hipLaunchKernelGGL((k_tail420<3, TAIL_MINW, true, Pix>), grid, dim3(TAIL_THREADS), 0, s, d_pics, dd, tiles_x, tiles_x * tiles_y, stages, k);
+    else hipLaunchKernelGGL((k_tail420<4, TAIL_MINW, true, Pix>), grid, dim3(TAIL_THREADS), 0, s, d_pics, dd, tiles_x, tiles_x * tiles_y, stages, k);
   }
   else {
-    if (bpp == 3) hipLaunchKernelGGL((k_tail420<3, TAIL_MINW, false>), grid, dim3(TAIL_THREADS), 0, s, d_pics, dd, tiles_x, tiles_x * tiles_y, stages, k);
-    else hipLaunchKernelGGL((k_tail420<4, TAIL_MINW, false>), grid, dim3(TAIL_THREADS), 0, s, d_pics, dd, tiles_x, tiles_x * tiles_y, stages, k);
+    if (bpp == 3) hipLaunchKernelGGL((k_tail420<3, TAIL_MINW, false, Pix>), grid, dim3(TAIL_THREADS), 0, s, d_pics, dd, tiles_x, tiles_x * tiles_y, stages, k);
+    else hipLaunchKernelGGL((k_tail420<4, TAIL_MINW, false, Pix>), grid, dim3(TAIL_THREADS), 0, s, d_pics, dd, tiles_x, tiles_x * tiles_y, stages, k);
   }
   return hm_check_hip(hipGetLastError(), "k_tail420 launch");
+}
+
+extern "C" int hm_launch_tail420(const hm_dev_pic* d_pics, const void* d_dsts, int n_pics, int max_w, int max_h, int log2_ctb, int bpp, const int coef[4],
+                                 int stages, hipStream_t s)
+{
+  return launch_tail420<uint8_t>(d_pics, d_dsts, n_pics, max_w, max_h, log2_ctb, bpp, coef, stages, s);
 }
 
 // Fused tail of the float-chain classes (k_tailf): n pictures of one class, the colour request d (a chain that is the float
@@ -1999,12 +2024,20 @@ static int launch_tailf(const hm_dev_pic* d_pics, const TailDst* dd, int n_pics,
   }
   return hm_check_hip(hipGetLastError(), "k_tailf launch");
 }
-extern "C" int hm_launch_tailf(const hm_dev_pic* d_pics, const void* d_dsts, int n_pics, int max_w, int max_h, const hm_colour_desc* d, const float coef[4], int mode,
+extern "C" int hm_launch_tailf(const hm_dev_pic* d_pics, const void* d_dsts, int n_pics, int max_w, int max_h, int log2_ctb, const hm_colour_desc* d, const float coef[4], int mode,
                                int stages, hipStream_t s)
 {
   if (n_pics <= 0) return HM_OK;
   FloatParams fp;
   hm_float_params(d, coef, mode, &fp);
+  // (r06) the class of HDR photographs - 9..11-bit 4:2:0, shifted to 8 bits and through the integer matrix to RGB24 / RGBA32 (mode 4) - on
+  // k_tail420's 16-bit instantiation: same arithmetic, that kernel's cells / unit lists / scalar SAO parameters (12-bit pictures stay here:
+  // the packed deblocking filters need samples of at most 11 bits)
+  if (mode == 4 && fp.post == 0 && d->chroma == HM_CHROMA_420 && d->bit_depth > 8 && d->bit_depth <= 11 && (d->out_format == HM_OUT_RGB || d->out_format == HM_OUT_RGBA) &&
+      hm_knob(HM_KNOB_TAIL_HDR16) != 0) {
+    const int coef_i[4] = {fp.i_r_cr, fp.i_g_cb, fp.i_g_cr, fp.i_b_cb};
+    return launch_tail420<uint16_t>(d_pics, d_dsts, n_pics, max_w, max_h, log2_ctb, d->out_format == HM_OUT_RGB ? 3 : 4, coef_i, stages, s);
+  }
   const int TF_TH = tf_th(d->chroma == HM_CHROMA_420 ? 1 : 2);
   const int tiles_x = (max_w + TF_TW - 1) / TF_TW, tiles_y = (max_h + TF_TH - 1) / TF_TH;
   const TailDst* dd = (const TailDst*)d_dsts;

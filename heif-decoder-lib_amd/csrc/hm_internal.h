@@ -73,7 +73,7 @@ int hm_launch_sao_paste(const struct hm_dev_pic* d_pics, int n_pics, int max_w, 
 int hm_launch_tail420(const struct hm_dev_pic* d_pics, const void* d_dsts, int n_pics, int max_w, int max_h, int log2_ctb, int bpp, const int coef[4],
                       int stages, hipStream_t s);
 int hm_colour_float_chain(const hm_colour_desc* d, float cf[4], int* mode); /* colour_host.cpp */
-int hm_launch_tailf(const struct hm_dev_pic* d_pics, const void* d_dsts, int n_pics, int max_w, int max_h, const hm_colour_desc* d, const float coef[4], int mode,
+int hm_launch_tailf(const struct hm_dev_pic* d_pics, const void* d_dsts, int n_pics, int max_w, int max_h, int log2_ctb, const hm_colour_desc* d, const float coef[4], int mode,
                     int stages, hipStream_t s);
 
 // (test hook) slice segments whose sub-streams were entropy-decoded side by side since the library was loaded: which = 0 WPP rows, 1 rows of tiles

@@ -369,6 +369,15 @@ FLOAT_TAIL_CLASSES = {
     "grid_422_10_full_rrggbb_be": (10, 2, 1, 9, "HM_OUT_RRGGBB_BE", 6, True),
     "grid_420_10_full_rgb24": (10, 1, 1, 9, "HM_OUT_RGB", 3, True),
     "grid_420_10_limited_rgb24": (10, 1, 0, 9, "HM_OUT_RGB", 3, True),
+    # r06: the HDR class runs on k_tail420's 16-bit instantiation (9..11 bits; 12-bit pictures keep k_tailf) - its CTB-16 variant (SAO
+    # parameters per lane), CTBs of 64, RGBA32, the other depths (8th element: log2 of the CTB size)
+    "hdr_420_10_full_rgba": (10, 1, 1, 9, "HM_OUT_RGBA", 4, False, 5),
+    "hdr_420_10_ctb16_rgb24": (10, 1, 1, 9, "HM_OUT_RGB", 3, False, 4),
+    "hdr_420_10_ctb16_grid_rgba": (10, 1, 1, 1, "HM_OUT_RGBA", 4, True, 4),
+    "hdr_420_10_ctb64_rgb24": (10, 1, 1, 6, "HM_OUT_RGB", 3, False, 6),
+    "hdr_420_9_full_rgb24": (9, 1, 1, 9, "HM_OUT_RGB", 3, False, 5),
+    "hdr_420_11_ctb16_rgba": (11, 1, 1, 9, "HM_OUT_RGBA", 4, False, 4),
+    "hdr_420_11_ctb64_grid_rgb24": (11, 1, 1, 1, "HM_OUT_RGB", 3, True, 6),
 }
 
 
@@ -382,12 +391,13 @@ def test_fused_float_tail_equals_separate_kernels(pkg, hm, name, stages):
     import torch
     capi, L = pkg.capi, pkg.lib()
     bd, cf, full, matrix, fmt, obpp = FLOAT_TAIL_CLASSES[name][:6]
-    grid = len(FLOAT_TAIL_CLASSES[name]) > 6
+    grid = len(FLOAT_TAIL_CLASSES[name]) > 6 and FLOAT_TAIL_CLASSES[name][6]
+    log2_ctb = FLOAT_TAIL_CLASSES[name][7] if len(FLOAT_TAIL_CLASSES[name]) > 7 else 5
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream().cuda_stream
     cols, rows, tw, th, w, h = 3, 2, 256, 192, 700, 330
     bps = 2 if bd > 8 else 1
-    datas = [synthutil.picture(8100000 + 7 * k, width=tw, height=th, chroma_format=cf, bit_depth=bd, log2_ctb=5, qp=28, vui=1,
+    datas = [synthutil.picture(8100000 + 7 * k, width=tw, height=th, chroma_format=cf, bit_depth=bd, log2_ctb=log2_ctb, qp=28, vui=1,
                                full_range=full, matrix=matrix, primaries=1, slices=(30 if k % 3 == 0 else 0)) for k in range(2 * cols * rows)]
     blobs = [capi.parse_hevc(d) for d in datas]
     ys, cs, os_ = L.hm_plane_stride(w, bps), L.hm_plane_stride((w + 1) // 2, bps), L.hm_plane_stride(w, obpp)

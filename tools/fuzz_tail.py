@@ -40,12 +40,14 @@ print("images that differ between the fused tail and the separate kernels:", bad
 # ---- the same for the float-chain classes (k_tailf): corrupted 256x256 tiles as 2x2 grids -------------------------------------
 import ctypes as C
 capi, L = pkg.capi, pkg.lib()
-for name, (bd, cf, full, matrix, fmt, obpp) in {"422_10_rrggbb_le": (10, 2, 0, 9, "HM_OUT_RRGGBB_LE", 6), "420_10_rgb24": (10, 1, 0, 6, "HM_OUT_RGB", 3),
-                                                  "422_8_rgba": (8, 2, 1, 6, "HM_OUT_RGBA", 4)}.items():
+# (r06: the hdr_* classes - deep full-range 4:2:0 to RGB24 / RGBA32 - run on k_tail420's 16-bit instantiation; 7th element: log2 of the CTB size)
+for name, (bd, cf, full, matrix, fmt, obpp, l2) in {"422_10_rrggbb_le": (10, 2, 0, 9, "HM_OUT_RRGGBB_LE", 6, 5), "420_10_rgb24": (10, 1, 0, 6, "HM_OUT_RGB", 3, 5),
+                                                      "422_8_rgba": (8, 2, 1, 6, "HM_OUT_RGBA", 4, 5), "hdr_420_10_full_rgb24": (10, 1, 1, 9, "HM_OUT_RGB", 3, 5),
+                                                      "hdr_420_10_ctb16_rgba": (10, 1, 1, 6, "HM_OUT_RGBA", 4, 4), "hdr_420_11_ctb64_rgb24": (11, 1, 1, 1, "HM_OUT_RGB", 3, 6)}.items():
     fb, tries = [], 0
     while len(fb) < 32 and tries < 20000:
         tries += 1
-        data = synthutil.picture(8300000 + tries % 8, width=256, height=256, chroma_format=cf, bit_depth=bd, log2_ctb=5, qp=27, vui=1, full_range=full, matrix=matrix)
+        data = synthutil.picture(8300000 + tries % 8, width=256, height=256, chroma_format=cf, bit_depth=bd, log2_ctb=l2, qp=27, vui=1, full_range=full, matrix=matrix)
         b = bytearray(data)
         for _ in range(rng.randrange(1, 5)):
             b[rng.randrange(len(b) // 4, len(b))] ^= 1 << rng.randrange(8)

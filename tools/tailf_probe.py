@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch, bench
 import __graft_entry__ as g
-pkg = g.load_package()
+pkg = g.load_package(test_knobs=True)  # (HM_TAIL_HDR16=0: k_tailf instead of k_tail420's 16-bit instantiation)
 capi, L = pkg.capi, pkg.lib()
 dev = torch.device("cuda:0"); st = torch.cuda.current_stream().cuda_stream
 W,H,cols,rows,tile = bench.OUT_W, bench.OUT_H, bench.GRID_COLS, bench.GRID_ROWS, bench.TILE
