@@ -123,6 +123,8 @@ struct CLayout {
                      // the last of them to the first (k_chain: wg_ring) - no wave of the launch waits for another workgroup
   int spin_limit;    // PAIRS: polls of the band above without news before a wave gives up (error flag, wrong picture, no hang)
   int test_stall;    // fault injection (tests): the first band of every picture never announces its progress
+  int early;         // PAIRS, a CTU row (or one chain of it) per wave: a CTU starts when the CTU ABOVE it is done and waits for the one above-right
+                     // only in front of the first block that reads it (k_chain: EARLY)
 };
 // PAIRS: words of the launch's synchronisation buffer (zeroed before the launch): a ticket counter, then per (picture,
 // pair, chain kind) the finished CTUs of the pair's last row.  A wave that gives up a bounded wait sets the BATCH's error
@@ -173,6 +175,9 @@ constexpr int chain_mode_ncl(int mode) { return mode <= 1 ? 2 : (mode == 2 ? 1 :
 // interior 4x4 blocks side by side up to the reference reads, other blocks one after the other).  See profiles/r06_notes.txt.
 #ifndef HM_CHAIN_LATE
 #define HM_CHAIN_LATE 0
+#endif
+#ifndef HM_CHAIN_EARLY_ALT
+#define HM_CHAIN_EARLY_ALT 1 // (A/B builds: 0 = the alternating ring starts a CTU when the CTU above-right is done; the other cuts: knob chain_early)
 #endif
 template <typename Pix, int LOG2_CTB, int MODE>
 __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* __restrict__ pics, int n_pics, CLayout L, uint32_t* __restrict__ sync, uint32_t* __restrict__ err_word)
@@ -372,6 +377,18 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   // PAIRS, first row of a pair: CTUs of the row above (the last row of the pair above, another wave's) whose bottom
   // sample line has been copied from the picture into this wave's line
   int hbm_have = 0, hbm_polls = 0;
+  // EARLY (r06; the cuts with one CTU row - or one chain of it - per wave, where a picture's time is its wavefront: rows + 2 (rows - 1) CTU
+  // steps with the rule "CTU (r, c) starts when (r - 1, c + 1) is done").  Only blocks of a CTU's first block row whose top-right run
+  // crosses the CTU's right edge read a sample of CTU (r - 1, c + 1) - in decoding order the first of them comes a quarter to a third
+  // into the CTU (residual.hip marks them: OP_FAR).  So a CTU starts when (r - 1, c) is done, and the chain stops in front of an
+  // OP_FAR block until (r - 1, c + 1) is: a row lags ~1.3 CTUs behind the one above instead of 2 - 16 x 16 CTUs: ~36 steps instead of 46.
+  // No state for it, neither per chain nor per wave (a register more is a spilled one in the 16-bit kernels): the counter of the row above is
+  // read again in front of every OP_FAR block - one or two per CTU -, and a chain that has to stop there sets its `left` to 0: the next
+  // iteration passes through the service phase (which polls the band above where that goes through HBM, and works `left` out again)
+  constexpr bool EARLY_CT = PAIRS && MODE >= 2;
+  // (the launcher's say - CLayout.early - for the cuts that may run as a ring of two bands; the alternating ring (MODE 4) never needs the
+  //  old rule: a wave's line of a kind is written for every SECOND band it takes)
+  const bool early = MODE == 4 ? HM_CHAIN_EARLY_ALT != 0 : (EARLY_CT && L.early != 0);
   int pidx = pair_index; // the band the group works on now (the wave's next one: pidx + W)
   // progress counter of a row in flight: row % 8 (rows of a wave per picture are NR apart), PAIRS: alternating halves per
   // band the group has worked on (the rows of a wave's consecutive bands may be a multiple of 8 apart)
@@ -447,7 +464,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   if (st == ST_START) row_start();
   // every iteration executes a block of some chain or waits for a CTU that is at most two CTUs of another chain away
   // (PAIRS: plus the bounded waits for the band above, one per CTU at most)
-  const long long budget_ll = (long long)n_tus + 64ll * ctb_w * ctb_h + 4096 + (PAIRS ? (long long)ctb_w * L.spin_limit : 0);
+  const long long budget_ll = (long long)n_tus + 64ll * ctb_w * ctb_h + 4096 + (PAIRS ? (long long)(EARLY_CT ? 2 : 1) * ctb_w * L.spin_limit : 0); // (EARLY: two waits per CTU)
   int budget = rfl(budget_ll < 0x7FFFFFF0ll ? (int)budget_ll : 0x7FFFFFF0); // (a scalar: the loop's exit test costs no vector instruction)
   unsigned long long m_done = ballot(st == ST_DONE);
 
@@ -466,7 +483,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     //      holds 0 too and is masked out.  An iteration without events (nearly half of them) costs one compare here: the
     //      state checks of all three phases below (r03: ~20 vector instructions per iteration) run only when something is due.
     const unsigned long long m_left0 = ballot(left == 0);
-    if ((m_left0 & ~m_done) || (PAIRS && (budget & 15) == 0)) {
+    if ((m_left0 & ~m_done) || (PAIRS && (budget & 15) == 0) ) {
       HM_T_COUNT(0);
 #ifndef HM_NO_SERVICE_WAIT
       // (r05) Loads and stores share one in-order counter: the header of the CTU to start (requested a CTU ago) and the next window
@@ -592,7 +609,8 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       // ---- A: start the next CTU of every group whose dependency is met (the row above two CTUs ahead) ----
       bool started = false;
       if (st == ST_START) {
-        const int need = cx + 2 < ctb_w ? cx + 2 : ctb_w;
+        const int need2 = cx + 2 < ctb_w ? cx + 2 : ctb_w;
+        const int need = early ? cx + 1 : need2; // (EARLY: the CTU above; the one above-right in front of the first block that reads it)
         // (a counter value seen here means the line samples written before it are there: LDS traffic of a wave is in order)
         const bool wave_above = lds_above && my_slot == 0; // (the counter a wave of this workgroup writes, with the pass in its upper half)
         int done_above = __hip_atomic_load(wave_above ? my_progress + above_ctr_index : my_progress + prog_index(row - 1, my_slot - 1), __ATOMIC_RELAXED,
@@ -617,7 +635,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         // ---- the sample line of the pair above, through HBM: the chains of a pair's first row poll the progress word of
         //      the pair above (while they wait, and every eighth iteration while they run, so that the line is usually
         //      there before it is needed) and copy what has become available from the picture into the line ----
-        const bool poll = from_hbm && st != ST_DONE && hbm_have < ctb_w && (st == ST_START || (budget & 15) == 0);
+        const bool poll = from_hbm && st != ST_DONE && hbm_have < ctb_w && (st == ST_START || (budget & 15) == 0 || (EARLY_CT && st == ST_RUN && left == 0 && ri != ctu_end && (ri >> WLOG) == wdec)); // (EARLY: or stopped in front of an OP_FAR block)
         if (ballot(poll)) {
           // (the word and the line are written and read with agent-scope accesses that pass the caches which are not
           //  coherent across the chip: no cache write-back / invalidation - those cost more than the hand-over itself
@@ -754,11 +772,30 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     // the group's record: the chain's current one, or - PAIRS - my_off records further if the chain may go that far before
     // its next event (the same CTU, the same window of micro-ops)
     const bool multi = (PAIRS && NCL != 2) || (CAN_LATE && late); // several records of a chain per iteration
-    const bool running = (PAIRS || CAN_LATE) ? my_off < left : left != 0;
-    const unsigned long long m_running = (PAIRS || CAN_LATE) ? ballot(my_off < left) : ballot(left != 0);
+    bool running = (PAIRS || CAN_LATE) ? my_off < left : left != 0;
     const uint32_t ri_me = (PAIRS || CAN_LATE) ? ri + (uint32_t)my_off : ri;
     const uint32_t rslot = ri_me & (RING - 1);
     const c_u32x4 op = ring[rslot];
+    if constexpr (EARLY_CT) {
+      // a record that reads the CTU above-right while that CTU is not known to be done: look again; if it still is not, the chain stops in
+      // front of the record (the records before it - groups of the chain with a smaller offset - go on)
+      const bool far_wait = running && (op.y & OP_FAR) != 0;
+      if (ballot(far_wait)) {
+        const int done_above = lds_above ? __hip_atomic_load(my_progress + above_ctr_index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - (npass << 16) : hbm_have;
+        const unsigned long long mb = ballot(far_wait && row != 0 && done_above < (cx + 2 < ctb_w ? cx + 2 : ctb_w));
+        if (mb) {
+          const uint32_t gbm = (uint32_t)((mb & 1) | ((mb >> 15) & 2) | ((mb >> 30) & 4) | ((mb >> 45) & 8)); // bit k: group k is stopped
+          // per chain the offset of its first stopped record (one chain: its records are the groups 0 1 2 3; two: chain c's the groups c, c + 2)
+          const uint32_t kb0 = (uint32_t)__builtin_ctz((NCL == 0 ? gbm : ((gbm & 1u) | ((gbm >> 1) & 2u))) | (1u << SUB));
+          const uint32_t kb1 = NCL == 0 ? kb0 : (uint32_t)__builtin_ctz(((gbm >> 1) & 1u) | ((gbm >> 2) & 2u) | (1u << SUB));
+          const uint32_t my_kb = g == 0 ? kb0 : kb1;
+          running = running && (uint32_t)my_off < my_kb;
+          left = my_kb == 0 ? 0 : left; // (stopped at its current record: an event - see EARLY above)
+          if (ballot(running) == 0) { __builtin_amdgcn_s_sleep(1); continue; } // (every chain of the wave waits)
+        }
+      }
+    }
+    const unsigned long long m_running = ballot(running);
     const int16_t* const my_res = rres + rslot * 16; // the 16 residual samples of the group's block if it is a 4x4 block
     const unsigned long long m_q4 = m_running & ballot((op.y & ((3u << OP_L2_SHIFT) | OP_INTERIOR)) == OP_INTERIOR); // interior 4x4 blocks
     // which records execute in this iteration: per chain the run of interior 4x4 blocks from its current record on (phase C,
@@ -809,10 +846,14 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         idx = idx < res_last ? idx : res_last;
         return (uint32_t)(int)resid[idx];
       };
-      if (s_bres & 0xFFFFull) bres0 = big_res(0);
-      if (s_bres & 0xFFFF0000ull) bres1 = big_res(1);
-      if (s_bres & 0xFFFF00000000ull) bres2 = big_res(2);
-      if (s_bres & 0xFFFF000000000000ull) bres3 = big_res(3);
+      // (tests on the halves of the mask: as 64-bit tests the compiler turned the last one into an unsigned compare with a constant it kept
+      //  in a pair of VECTOR registers for the whole loop - and spilled, in the kernels at the register limit)
+      uint32_t sb_lo = (uint32_t)s_bres, sb_hi = (uint32_t)(s_bres >> 32);
+      asm volatile("" : "+s"(sb_lo), "+s"(sb_hi)); // (... and puts the halves together again if it can see where they come from)
+      if (sb_lo & 0xFFFFu) bres0 = big_res(0);
+      if (sb_lo >> 16) bres1 = big_res(1);
+      if (sb_hi & 0xFFFFu) bres2 = big_res(2);
+      if (sb_hi >> 16) bres3 = big_res(3);
     }
 
     HM_MARK("C_begin");
@@ -1626,6 +1667,10 @@ static int launch_chain_impl(const hm_dev_pic* d_pics, int n_pics, int log2_ctb,
   L.passes = passes_of();
   L.bands_per_pic = share && share < L.passes ? share : (ring_w ? ring_w : L.passes);
   L.ring = ring_w ? 1 : 0;
+  // EARLY (k_chain): not in a short ring - the line a wave receives for band p + W is written by the wave of band p + W - 1, which depends on
+  // band p through W - 1 hand-overs: "two CTUs behind" per hand-over keeps it off the samples band p still reads from W = 2 on, "one CTU
+  // behind" needs three hand-overs for the same distance, W >= 4 (the alternating ring, MODE 4, has 2 W - 1 in between: always)
+  L.early = hm_knob(HM_KNOB_CHAIN_EARLY) != 0 && !(ring_w && ring_w < 4) ? 1 : 0;
   const size_t sync_need = sync_words(L.passes);
   const int force_np = hm_knob(HM_KNOB_CHAIN_NP); // (tuning aid)
   const long n_waves = pairs ? ((long)n_pics * L.bands_per_pic) << L.split_kinds : (long)n_pics;

@@ -553,6 +553,10 @@ __device__ __forceinline__ ResidGeom resid_geom(int ctb_w, int ctb_h, int log2_c
 constexpr uint32_t OP_MODE_MASK = 63u;
 constexpr int OP_C_SHIFT = 6, OP_L2_SHIFT = 8; // colour component (2 bits), log2 size - 2 (2 bits)
 constexpr uint32_t OP_CBF = 1u << 10, OP_INTERIOR = 1u << 11, OP_LINE = 1u << 13;
+// (r06) OP_FAR: the block reads samples of the row above that lie in the NEXT CTU's columns (a block of the CTU's first block row whose
+// top-right run crosses the CTU's right edge): the few-pictures cuts of the chain kernel start a CTU when the CTU above it is done and wait
+// for the one above-right only in front of such a block - about a third into the CTU (chain.hip: EARLY)
+constexpr uint32_t OP_FAR = 1u << 26;
 constexpr uint32_t OP_FAST8 = 1u << 12; // 8x8 block, neighbours complete, reference samples not smoothed: the one-pass path of phase D
 // which of the wave-wide paths of phase D executes the block (blocks that are not interior 4x4 blocks): decided here, once, by the
 // lane that holds the record - the chain kernel switches on three bits instead of re-deriving the class with a dozen scalar

@@ -357,6 +357,7 @@ __global__ __launch_bounds__(R_WAVES * 64) HM_R_ATTR void k_residual(const hm_de
       const int room_y = k_plane_h - (yc + nT);
       const hm_avail av = hm_derive_avail(xin << lw, (y4 << 2) << lh, nT << lw, nT << lh, nT, room_x, room_y, dp.log2_ctb, (cnt_raw >> HM_TU6_NB_SHIFT) & 15u);
       mop = make_micro_op(r0, av.left, av.top, av.tl, (uint32_t)av.n_bl >> 2, (uint32_t)av.n_tr >> 2, 0u, m_Pk, m_cr_off, m_Wc, 0u);
+      if (y4 == 0 && xin + nT + (int)(((uint32_t)av.n_tr >> 2) << 2) > ctb_pw) mop.y |= OP_FAR; // (the last sample of the top run lies behind the CTU's right edge)
       asm volatile("" : "+v"(mop.x), "+v"(mop.y), "+v"(mop.w)); // (worked out here, not where the scheduler would like it)
     }
     const bool cbf = valid && (info & HM_TU_CBF);
