@@ -56,20 +56,37 @@ namespace {
 // (HM_CHAIN_TIMING=2: the same five words count events instead - service phases, CTU flushes, window take-overs, 4x4 passes,
 //  wave-wide blocks - per wave, in units of 1/64 so that the print's ">> 6" gives the counts)
 #ifdef HM_CHAIN_TIMING
-#define HM_T_DECL unsigned long long t_prev = __builtin_amdgcn_s_memtime(); unsigned int t_acc[6] = {0, 0, 0, 0, 0, 0}
+#define HM_T_DECL unsigned long long t_prev = __builtin_amdgcn_s_memtime(); unsigned int t_acc[6] = {0, 0, 0, 0, 0, 0}, t_part[4] = {0, 0, 0, 0}; int t_in_svc = 0; (void)t_part; (void)t_in_svc
 #if HM_CHAIN_TIMING == 2
 #define HM_T_LAP(i) (void)t_prev
 #define HM_T_COUNT(i) t_acc[i] += 64
 #else
-#define HM_T_LAP(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_acc[i] += (unsigned int)(t_now - t_prev); t_prev = t_now; } while (0)
+#define HM_T_LAP(i) do { if (HM_CHAIN_TIMING != 4) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_acc[i] += (unsigned int)(t_now - t_prev); t_prev = t_now; } } while (0)
 #define HM_T_COUNT(i)
 #endif
-#define HM_T_FLUSH() do { if (sync && lane == 0) { for (int q = 0; q < 5; q++) atomicAdd(sync + 2 + q, t_acc[q] >> 6); atomicAdd(sync + 7, t_acc[5]); } } while (0)
+// (HM_CHAIN_TIMING=3: cycles as in mode 1, of the waves that work on LUMA chains only, with the service phase split - word 0: service phases
+//  after which a chain of the wave can go on (flush, start, window), word 4: those after which every chain still waits; E counts as D)
+// (HM_CHAIN_TIMING=4: the service phases of the luma waves by part - word 0: the wait for the loads and stores in flight at its top, 1: CTU flushes,
+//  2: CTU starts + polls of the band above, 3: window take-over + bookkeeping, 4: phases after which every chain still waits; the rest of the loop is not counted)
+#if HM_CHAIN_TIMING == 4
+#define HM_T_SVC_BEGIN() do { t_prev = __builtin_amdgcn_s_memtime(); t_in_svc = 1; } while (0)
+#define HM_T_SVC(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_part[i] = (unsigned int)(t_now - t_prev); t_prev = t_now; } while (0)
+#define HM_T_SVC_END(work) do { if (t_in_svc) { HM_T_SVC(3); if (work) { t_acc[0] += t_part[0]; t_acc[1] += t_part[1]; t_acc[2] += t_part[2]; t_acc[3] += t_part[3]; } \
+                                else t_acc[4] += t_part[0] + t_part[1] + t_part[2] + t_part[3]; t_part[0] = t_part[1] = t_part[2] = 0; t_in_svc = 0; } } while (0)
+#else
+#define HM_T_SVC_BEGIN()
+#define HM_T_SVC(i)
+#define HM_T_SVC_END(work)
+#endif
+#define HM_T_FLUSH() do { if (sync && lane == 0 && !(HM_CHAIN_TIMING >= 3 && kind_sel != 0)) { for (int q = 0; q < 5; q++) atomicAdd(sync + 2 + q, t_acc[q] >> 6); atomicAdd(sync + 7, t_acc[5]); } } while (0)
 #else
 #define HM_T_DECL
 #define HM_T_LAP(i)
 #define HM_T_COUNT(i)
 #define HM_T_FLUSH()
+#define HM_T_SVC_BEGIN()
+#define HM_T_SVC(i)
+#define HM_T_SVC_END(work)
 #endif
 #ifdef HM_MARKS
 #define HM_MARK(name) asm volatile("s_nop 0 ; HMMARK " name)
@@ -485,6 +502,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     const unsigned long long m_left0 = ballot(left == 0);
     if ((m_left0 & ~m_done) || (PAIRS && (budget & 15) == 0) ) {
       HM_T_COUNT(0);
+      HM_T_SVC_BEGIN();
 #ifndef HM_NO_SERVICE_WAIT
       // (r05) Loads and stores share one in-order counter: the header of the CTU to start (requested a CTU ago) and the next window
       // (requested a window ago) are looked at below, BEHIND the stores of the CTUs this phase flushes - a wait for them there is a
@@ -492,6 +510,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       // where everything in flight is at least an iteration old.
       __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
 #endif
+      HM_T_SVC(0);
       // ---- F: finished CTUs: coalesced stores to the picture, bottom row -> line, right column -> left column ----
       for (unsigned long long fin = ballot(st == ST_RUN) & ballot(ri == ctu_end) & ((CAN_LATE && late) ? 0x0000FFFF0000FFFFull : main_mask); fin;) {
         const int fg = rfl((int)(__builtin_ctzll(fin) >> 4));
@@ -606,6 +625,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         }
       }
       WAVE_SYNC();
+      HM_T_SVC(1);
       // ---- A: start the next CTU of every group whose dependency is met (the row above two CTUs ahead) ----
       bool started = false;
       if (st == ST_START) {
@@ -687,6 +707,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       }
       if (PAIRS && lds_above && ballot(st == ST_RUN) == 0) __builtin_amdgcn_s_sleep(2); // (every chain waits for the wave above: leave the SIMD to it)
       if (ballot(st != ST_DONE) == 0) break;
+      HM_T_SVC(2);
       HM_MARK("R_begin");
       // ---- R: the micro-ops and 4x4 residuals of the next window of records, for every group that has entered it ----
       {
@@ -760,7 +781,13 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         }
       }
     }
+#if defined(HM_CHAIN_TIMING) && HM_CHAIN_TIMING == 4
+    HM_T_SVC_END(ballot(left != 0) != 0);
+#elif defined(HM_CHAIN_TIMING) && HM_CHAIN_TIMING == 3
+    if (ballot(left != 0)) HM_T_LAP(0); else HM_T_LAP(4);
+#else
     HM_T_LAP(0);
+#endif
 #if defined(HM_PAD_S) || defined(HM_PAD_V)
     if (lane0_dummy + pad_v == -12345) break; // (keeps the padding alive)
 #endif
@@ -1269,7 +1296,11 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       ri += 1;
       left -= 1;
     }
+#if defined(HM_CHAIN_TIMING) && HM_CHAIN_TIMING == 3
+    HM_T_LAP(3);
+#else
     HM_T_LAP(4);
+#endif
 #ifdef HM_CHAIN_TIMING
     t_acc[5] += 1;
 #endif

@@ -82,7 +82,7 @@ int hm_nclx_code_known(int kind, int v)
 static const struct { const char* name; int def; } k_knobs[HM_KNOB_COUNT] = {
     {"chain_spin_limit", 0}, {"chain_test_stall", 0}, {"batch_fail_width", 0}, {"chain_pairs", -1}, {"chain_share", 0}, {"chain_ring", -1},
     {"chain_alt", 1}, {"chain_np", 0}, {"chain_debug", 0}, {"resid_segs", 0}, {"recon_waves", 0}, {"quad_class", -1}, {"tail_fused", 1},
-    {"stream_interleaved", 0}, {"chain_split", 1}, {"tail_hdr16", 1}, {"chain_early", 1}};
+    {"stream_interleaved", 0}, {"chain_split", 1}, {"tail_hdr16", 1}, {"chain_early", 1}, {"grid_slab_rows", -1}};
 static std::atomic<int> g_knob[HM_KNOB_COUNT];
 static std::atomic<unsigned> g_knob_set{0}; // bit i: knob i has been set (otherwise its default)
 int hm_knob(int id)

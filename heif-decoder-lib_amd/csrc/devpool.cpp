@@ -138,6 +138,35 @@ void hm_pool_device_free(void* p)
 }
 void* hm_pool_pinned_alloc(size_t bytes) { return pin_pool().alloc(bytes); }
 void hm_pool_pinned_free(void* p) { pin_pool().release(p); }
+// Streams for work that wants one of its own for the length of a call (the slabs of a grid: hm_image.cpp).  hipStreamCreate is ~0.2 ms and
+// hipStreamDestroy ~0.5 ms on this runtime - more than queueing a slab's whole batch -, so idle streams are kept per device (at most 16,
+// leaked at exit like the pools: no HIP calls in static destructors).  A stream handed back must be drained.
+#ifndef HM_POOL_HOST_STUB // (the host build of tests/test_devpool.py links no HIP runtime)
+static std::mutex g_stream_mu;
+static std::vector<hipStream_t> g_streams[MAX_DEVICES];
+hipStream_t hm_pool_stream_get()
+{
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAX_DEVICES) { hm_fail(HM_ERR_NO_DEVICE, "no current HIP device"); return nullptr; }
+  {
+    std::lock_guard<std::mutex> l(g_stream_mu);
+    if (!g_streams[d].empty()) { hipStream_t s = g_streams[d].back(); g_streams[d].pop_back(); return s; }
+  }
+  hipStream_t s = nullptr;
+  const hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  if (e != hipSuccess) { hm_check_hip(e, "hipStreamCreate"); return nullptr; }
+  return s;
+}
+void hm_pool_stream_put(hipStream_t s, int device)
+{
+  if (!s) return;
+  if (device >= 0 && device < MAX_DEVICES) {
+    std::lock_guard<std::mutex> l(g_stream_mu);
+    if (g_streams[device].size() < 16) { g_streams[device].push_back(s); return; }
+  }
+  (void)hipStreamDestroy(s);
+}
+#endif
 // bytes the device pool of `device` holds for reuse (tests)
 size_t hm_pool_device_cached(int device) { Pool* p = dev_pool(device, false); return p ? p->cached() : 0; }
 }

@@ -48,6 +48,9 @@ void hm_pool_device_free(void* p);
 void* hm_pool_pinned_alloc(size_t bytes);
 void hm_pool_pinned_free(void* p);
 size_t hm_pool_device_cached(int device); // bytes the pool of `device` holds for reuse
+// an idle non-blocking stream of the current device (kept for reuse: creating and destroying one costs more than queueing a batch); put: drained
+hipStream_t hm_pool_stream_get(void);
+void hm_pool_stream_put(hipStream_t s, int device);
 
 // recon.hip / filters.hip
 struct hm_dev_pic;

@@ -25,12 +25,13 @@ extern "C" {
 //   recon_waves (0)        waves per workgroup of k_recon
 //   quad_class (-1)        record order of the parser: 1 split chains for every class that has them, 0 for none
 //   tail_fused (1)         0: the separate filter / colour kernels also where the fused ones apply
+//   grid_slab_rows (-1)    hm_decode_item on a grid: tile rows per slab of the decode that runs under the host's entropy decode (0: one batch behind it, as before r06; -1: about a round of the parsing threads)
 //   chain_early (1)        0: the few-pictures cuts of k_chain start a CTU when the CTU above-RIGHT is done (the rule before r06) instead of the CTU above
 //   tail_hdr16 (1)         0: 9..11-bit 4:2:0 pictures -> RGB24 / RGBA32 (the HDR class) through k_tailf instead of k_tail420's 16-bit instantiation
 //   stream_interleaved (0) 1: records in decode order (format of the rare-syntax classes) for every picture
 enum hm_knob_id { HM_KNOB_CHAIN_SPIN_LIMIT, HM_KNOB_CHAIN_TEST_STALL, HM_KNOB_BATCH_FAIL_WIDTH, HM_KNOB_CHAIN_PAIRS, HM_KNOB_CHAIN_SHARE, HM_KNOB_CHAIN_RING,
                   HM_KNOB_CHAIN_ALT, HM_KNOB_CHAIN_NP, HM_KNOB_CHAIN_DEBUG, HM_KNOB_RESID_SEGS, HM_KNOB_RECON_WAVES, HM_KNOB_QUAD_CLASS, HM_KNOB_TAIL_FUSED,
-                  HM_KNOB_STREAM_INTERLEAVED, HM_KNOB_CHAIN_SPLIT, HM_KNOB_TAIL_HDR16, HM_KNOB_CHAIN_EARLY, HM_KNOB_COUNT };
+                  HM_KNOB_STREAM_INTERLEAVED, HM_KNOB_CHAIN_SPLIT, HM_KNOB_TAIL_HDR16, HM_KNOB_CHAIN_EARLY, HM_KNOB_GRID_SLAB_ROWS, HM_KNOB_COUNT };
 int hm_knob(int id);
 int hm_knob_set(const char* name, int value); // 0, or -1 for an unknown name (hidden: reached through test_hooks.cpp's hm_debug_set only)
 #ifdef __cplusplus

@@ -9,7 +9,7 @@ ENV_TO_KNOB = {
     "HM_CHAIN_SPIN_LIMIT": "chain_spin_limit", "HM_CHAIN_TEST_STALL": "chain_test_stall",
     "HM_CHAIN_PAIRS": "chain_pairs", "HM_CHAIN_SHARE": "chain_share", "HM_CHAIN_RING": "chain_ring", "HM_CHAIN_ALT": "chain_alt",
     "HM_CHAIN_NP": "chain_np", "HM_CHAIN_DEBUG": "chain_debug", "HM_RESID_SEGS": "resid_segs", "HM_RECON_WAVES": "recon_waves",
-    "HM_QUAD_CLASS": "quad_class", "HM_TAIL_FUSED": "tail_fused", "HM_STREAM_INTERLEAVED": "stream_interleaved", "HM_CHAIN_SPLIT": "chain_split", "HM_TAIL_HDR16": "tail_hdr16", "HM_CHAIN_EARLY": "chain_early",
+    "HM_QUAD_CLASS": "quad_class", "HM_TAIL_FUSED": "tail_fused", "HM_STREAM_INTERLEAVED": "stream_interleaved", "HM_CHAIN_SPLIT": "chain_split", "HM_TAIL_HDR16": "tail_hdr16", "HM_CHAIN_EARLY": "chain_early", "HM_GRID_SLAB_ROWS": "grid_slab_rows",
 }
 
 

@@ -147,7 +147,7 @@ def test_tuning_knobs_are_not_read_from_the_environment(pkg, hm, hm_hooks):
     assert not hasattr(hm, "hm_debug_set") and not hasattr(hm, "hm_debug_kernel_regs")
     assert hm_hooks.hm_debug_set(b"no_such_knob", 1) == -1
     for name in knobs.ENV_TO_KNOB.values():
-        assert name in ("chain_spin_limit", "chain_test_stall") or hm_hooks.hm_debug_set(name.encode(), {"chain_alt": 1, "tail_fused": 1, "chain_split": 1, "tail_hdr16": 1, "chain_early": 1}.get(name, -1 if name in ("chain_pairs", "chain_ring", "quad_class") else 0)) == 0, name
+        assert name in ("chain_spin_limit", "chain_test_stall") or hm_hooks.hm_debug_set(name.encode(), {"chain_alt": 1, "tail_fused": 1, "chain_split": 1, "tail_hdr16": 1, "chain_early": 1}.get(name, -1 if name in ("chain_pairs", "chain_ring", "quad_class", "grid_slab_rows") else 0)) == 0, name
     for so in ("libheif_mi355x.so", "libheif_mi355x_api.so", "libheif-mi355x-plugin.so"):
         syms = subprocess.run(["nm", "-D", "--defined-only", os.path.join(os.path.dirname(pkg.capi.LIB_PATH), so)], capture_output=True, text=True, check=True).stdout
         assert "hm_debug" not in syms and "hm_knob" not in syms, so

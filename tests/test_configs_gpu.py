@@ -129,6 +129,49 @@ def test_one_grid_over_several_devices(hm, devices, ext):
         f.close()
 
 
+@pytest.mark.parametrize("case", ["8bit_rgb24", "8bit_rgba_ext_dst", "10bit_rrggbb"])
+def test_a_grid_decoded_slab_by_slab_equals_the_one_batch_decode(hm_hooks, case):
+    """r06: hm_decode_item takes a grid of more tiles than parsing threads in slabs of tile rows, each queued on a stream of its own as
+    soon as its tiles are through the entropy decode (hm_image.cpp: decode_grid_cut, pipelined) - the pixels must be those of the one
+    batch behind the whole entropy decode (knob grid_slab_rows = 0, the path before r06), whatever the slab height: the default (up to
+    eight slabs), two rows, a height that does not divide the grid's rows.  5 x 3 tiles of 512 x 512, the canvas cropped inside the last
+    tile row and column; the same metadata."""
+    import ctypes as C
+    L = hm_hooks
+    bd = 10 if case.startswith("10bit") else 8
+    fmt = {"8bit_rgb24": 10, "8bit_rgba_ext_dst": 11, "10bit_rrggbb": 14}[case]  # HM_OUT_RGB / RGBA / RRGGBB_LE
+    bpp = {10: 3, 11: 4, 14: 6}[fmt]
+    rows, cols, w, h = 5, 3, 1500, 2300
+    pool = [synthutil.picture(5100000 + i, **dict(TILE, bit_depth=bd), vui=1, full_range=1, matrix=6) for i in range(8)]
+    data = heifwriter.write_heic([pool[(5 * t + 3 * (t // cols)) % 8] for t in range(rows * cols)], (512, 512), grid=(rows, cols, w, h), bit_depth=bd)
+    f = pipeline.HeifFile(L, data)
+    ext = case.endswith("ext_dst")
+
+    def decode(slab_rows):
+        assert L.hm_debug_set(b"grid_slab_rows", slab_rows) == 0
+        if not ext:
+            img, meta = f.decode(f.primary(), fmt, threads=4)
+            return img[0][:h, :w * bpp].copy(), {k: v for k, v in meta.items() if k != "stride"}
+        stride = w * bpp + 64
+        buf = np.zeros((h, stride), dtype=np.uint8)
+        prm = pipeline.DecodeParams(fmt, 4, 0, 0, None, buf.ctypes.data_as(C.c_void_p), buf.size, stride, 0, 0)
+        d = pipeline.Decoded()
+        assert L.hm_decode_item(f.h, f.primary(), C.byref(prm), C.byref(d)) == 0, L.hm_last_error()
+        meta = (d.width, d.height, d.out_format, d.used_ext_dst, d.bit_depth, d.has_nclx, d.primaries, d.transfer, d.matrix, d.full_range, d.warnings)
+        L.hm_decoded_free(C.byref(d))
+        return buf[:, :w * bpp].copy(), meta
+    try:
+        one, meta1 = decode(0)
+        assert one.any()
+        for slab_rows in (-1, 2, 3, 4):
+            got, meta = decode(slab_rows)
+            assert meta == meta1, (slab_rows, meta, meta1)
+            assert np.array_equal(got, one), f"{case}: slabs of {slab_rows} tile rows differ from the one-batch decode"
+    finally:
+        L.hm_debug_set(b"grid_slab_rows", -1)
+        f.close()
+
+
 def test_items_that_do_not_cut_fall_back_to_the_first_device(hm):
     """a single image, and a grid asked for planar output: hm_decode_item_devices decodes them on devices[0] like hm_decode_item"""
     import ctypes as C
