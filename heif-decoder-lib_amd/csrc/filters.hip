@@ -1048,8 +1048,14 @@ constexpr int TAIL_MINW = HM_TAIL_MINW; // (A/B builds)
 constexpr int TAIL_MINW = TAIL_THREADS == 256 ? 4 : 2;
 #endif
 constexpr int TAIL_XO = 8;                   // the LDS tiles start 8 samples left of the tile, 4 rows above it
-constexpr int TAIL_LP = 144, TAIL_LR = TAIL_TH + 8;   // luma tile: pitch, rows
-constexpr int TAIL_CP = 80, TAIL_CR = TAIL_TH / 2 + 8;    // chroma tiles
+#ifndef HM_TAIL_LP
+#define HM_TAIL_LP 144 // (A/B builds: the pitches of the LDS tiles, in samples)
+#endif
+#ifndef HM_TAIL_CP
+#define HM_TAIL_CP 80
+#endif
+constexpr int TAIL_LP = HM_TAIL_LP, TAIL_LR = TAIL_TH + 8;   // luma tile: pitch, rows
+constexpr int TAIL_CP = HM_TAIL_CP, TAIL_CR = TAIL_TH / 2 + 8;    // chroma tiles
 
 // a group of 8 samples of LDS tile row `row` (already clamped into the picture) at tile column xo, with its side dwords
 template <typename Pix>

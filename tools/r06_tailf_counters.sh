@@ -12,13 +12,15 @@ python3 - $out <<'PY'
 import csv, glob, os, sys
 from collections import defaultdict
 acc = defaultdict(lambda: [0.0, 0])
+names = set()
 for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
-        if "k_tailf" in row["Kernel_Name"]:
+        if "k_tailf" in row["Kernel_Name"] or "k_tail420" in row["Kernel_Name"]:  # (the HDR class: k_tail420<16-bit> since r06; HM_TAIL_HDR16=0: k_tailf)
+            names.add(row["Kernel_Name"].split("(")[0][:80])
             a = acc[row["Counter_Name"]]; a[0] += float(row["Counter_Value"]); a[1] += 1
 per = {k: v[0] / v[1] for k, v in acc.items()}
 tiles = 4608
-print("k_tailf<uint16_t, 4:2:0, RGB24>, 4608 tiles of 512 x 512 per launch (deblocking + SAO + paste + depth change + integer matrix), averages over the probe's four launches")
+print("the fused tail of the HDR class (10-bit 4:2:0 -> RGB24), 4608 tiles of 512 x 512 per launch (deblocking + SAO + paste + depth change + integer matrix), averages over the probe's four launches; kernel:", sorted(names))
 for k in sorted(per):
     print(f"  {k:24s} {per[k]:16.0f} per launch   {per[k] / tiles / 1000:10.2f} k per tile")
 if per.get("SQ_THREAD_CYCLES_VALU") and per.get("SQ_ACTIVE_INST_VALU"):
