@@ -1698,10 +1698,16 @@ static int launch_chain_impl(const hm_dev_pic* d_pics, int n_pics, int log2_ctb,
   L.passes = passes_of();
   L.bands_per_pic = share && share < L.passes ? share : (ring_w ? ring_w : L.passes);
   L.ring = ring_w ? 1 : 0;
-  // EARLY (k_chain): not in a short ring - the line a wave receives for band p + W is written by the wave of band p + W - 1, which depends on
-  // band p through W - 1 hand-overs: "two CTUs behind" per hand-over keeps it off the samples band p still reads from W = 2 on, "one CTU
-  // behind" needs three hand-overs for the same distance, W >= 4 (the alternating ring, MODE 4, has 2 W - 1 in between: always)
+  // EARLY (k_chain): not in a short ring.  The line a wave receives for band p + W is written by the wave of band p + W - 1 while the wave may still read it
+  // for band p.  A band FINISHES CTU j - and flushes its bottom line - only behind the OP_FAR block of j, i.e. when the band above has finished j + 1: the
+  // distance of the old rule, wherever the CTU above-right is available.  Where it is not (a slice that ends in the middle of the row above) a CTU has no
+  // such block and a band may finish CTU j while the band above still works on j + 1, whose corner sample lies in j's columns of the line: per hand-over one
+  // CTU of distance instead of two.  Two hand-overs (W = 3) are enough; W >= 4 is what runs (the alternating ring, MODE 4, has 2 W - 1 in between: always).
+  // tools/stress_cuts.py hunts for such races (3 600 executes per run in 15 cuts: none, also with the rule forced in the short rings - its tiles are one slice each).
   L.early = hm_knob(HM_KNOB_CHAIN_EARLY) != 0 && !(ring_w && ring_w < 4) ? 1 : 0;
+#ifdef HM_CHAIN_EARLY_FORCE // (negative control of tools/stress_cuts.py: the early start also where a ring's line reuse forbids it)
+  L.early = 1;
+#endif
   const size_t sync_need = sync_words(L.passes);
   const int force_np = hm_knob(HM_KNOB_CHAIN_NP); // (tuning aid)
   const long n_waves = pairs ? ((long)n_pics * L.bands_per_pic) << L.split_kinds : (long)n_pics;
