@@ -1984,6 +1984,7 @@ extern "C" int hm_launch_sao_paste(const hm_dev_pic* d_pics, int n_pics, int max
 // Fused tail (k_tail420): n pictures of one class (8-bit 4:2:0, no rare syntax), output d_dsts[i] (device array of
 // {pointer, pitch} at the picture's paste position), bpp 3 / 4, integer matrix coefficients of yuv2rgb.cc:336-339.
 extern "C" const void* hm_tail420_kernel() { return reinterpret_cast<const void*>(k_tail420<3, TAIL_MINW, true>); } // (test_hooks.cpp: hm_debug_kernel_regs)
+extern "C" const void* hm_tail420_kernel16() { return reinterpret_cast<const void*>(k_tail420<3, TAIL_MINW, true, uint16_t>); } // (the HDR class)
 
 template <typename Pix>
 static int launch_tail420(const hm_dev_pic* d_pics, const void* d_dsts, int n_pics, int max_w, int max_h, int log2_ctb, int bpp, const int coef[4], int stages, hipStream_t s)

@@ -1037,7 +1037,6 @@ static int decode_grid_cut(const hm_file* f, uint32_t id, const hm_decode_params
   if (!cut || !geometry_ok) return HM_OK;
   *applicable = true;
   std::memset(out, 0, sizeof(*out));
-  Lap lap;
   trace_mark("grid cut begins, slabs of rows", slab_rows);
 
   // ---- the slabs ----
@@ -1135,7 +1134,7 @@ static int decode_grid_cut(const hm_file* f, uint32_t id, const hm_decode_params
     int parse_rc = HM_OK;
     std::string parse_msg;
     auto slab_of_tile = [&](int i) { return (size_t)((i / plan.cols) / slab_rows); }; // (slabs below the canvas do not exist: clamped)
-    std::thread queuer([&]() {
+    auto queue_slabs = [&]() {
       for (size_t k = 0; k < slabs.size(); k++) {
         Slab& S = *slabs[k];
         const int t_first = S.row0 * plan.cols, t_n = S.rows * plan.cols;
@@ -1153,7 +1152,10 @@ static int decode_grid_cut(const hm_file* f, uint32_t id, const hm_decode_params
         slab_enqueue(f, params, S, dst + (size_t)S.y0 * dst_stride, dst_stride, img_w);
         if (S.rc) return; // (reported below)
       }
-    });
+    };
+    std::thread queuer;
+    try { queuer = std::thread(queue_slabs); }
+    catch (...) {} // (no thread to be had: the slabs are queued behind the entropy decode, on this thread)
     {
       std::atomic<int> next{0};
       auto worker = [&]() {
@@ -1180,7 +1182,8 @@ static int decode_grid_cut(const hm_file* f, uint32_t id, const hm_decode_params
       };
       Crew::instance().run(nthreads, worker);
     }
-    queuer.join();
+    if (queuer.joinable()) queuer.join();
+    else queue_slabs(); // (every slab is complete by now: no wait)
     trace_mark("slabs queued");
     for (const std::unique_ptr<Slab>& S : slabs) slab_finish(*S);
     trace_mark("slabs drained");

@@ -12,6 +12,7 @@
 extern "C" const void* hm_chain_kernel_of(int log2_ctb, int bytes_per_sample, int mode); // chain.hip
 extern "C" const void* hm_residual_kernel();                                             // residual.hip
 extern "C" const void* hm_tail420_kernel();                                              // filters.hip
+extern "C" const void* hm_tail420_kernel16();
 
 extern "C" {
 
@@ -24,6 +25,7 @@ __attribute__((visibility("default"))) int hm_debug_kernel_regs(int which, int a
   if (which == 0) fn = hm_residual_kernel();
   else if (which == 1) fn = hm_tail420_kernel();
   else if (which == 2) fn = hm_chain_kernel_of(a, b, c);
+  else if (which == 3) fn = hm_tail420_kernel16();
   hipFuncAttributes fa;
   if (!fn || !out || hipFuncGetAttributes(&fa, fn) != hipSuccess) return -1;
   out[0] = fa.numRegs;

@@ -191,6 +191,8 @@ def test_hot_path_kernels_hold_their_registers_without_a_spill():
     assert scratch == 0 and r <= 72, ("k_residual", r, scratch)
     r, scratch = regs(1)
     assert scratch == 0 and r <= 64, ("k_tail420", r, scratch)
+    r, scratch = regs(3)  # (r06: its 16-bit instantiation, the class of HDR photographs - four workgroups per CU by LDS, 128 registers would do)
+    assert scratch == 0 and r <= 96, ("k_tail420<16-bit>", r, scratch)
     for l2 in (4, 5):  # (CTBs of 64: the wave per picture stays at four waves per SIMD - its LDS allows ten waves per CU)
         r, scratch = regs(2, l2, 1, 0)
         assert scratch == 0 and r <= 96, ("k_chain, a wave per picture", l2, r, scratch)
