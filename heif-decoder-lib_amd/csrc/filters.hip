@@ -1994,8 +1994,8 @@ static int launch_tail420(const hm_dev_pic* d_pics, const void* d_dsts, int n_pi
   const dim3 grid((tiles_x * tiles_y + 7) / 8 * 8, n_pics); // (a multiple of 8: see the tile mapping in the kernel)
   const TailCoef k{coef[0], coef[1], coef[2], coef[3]};
   const TailDst* dd = (const TailDst*)d_dsts;
-  // (105 VGPRs: four waves per SIMD; tighter register budgets spill and were measured slower: 15.5 / 17.3 / 21.7 ms
-  //  at 96 / 80 / 64 VGPRs against 15.7 ms)
+  // (8-bit samples: 59 VGPRs and 20 KB of LDS - eight workgroups per CU; 16-bit samples: 70 VGPRs, 39 KB - four.  tests/test_chain_modes_gpu.py holds the
+  //  register counts and zero scratch)
   // (pictures with CTBs of 32 / 64: a wave's 32 x 32 cell lies in one CTB - its SAO record through the scalar unit)
   if (log2_ctb >= 5) {
     if (bpp == 3) hipLaunchKernelGGL((k_tail420<3, TAIL_MINW, true, Pix>), grid, dim3(TAIL_THREADS), 0, s, d_pics, dd, tiles_x, tiles_x * tiles_y, stages, k);
