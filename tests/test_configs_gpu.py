@@ -172,6 +172,39 @@ def test_a_grid_decoded_slab_by_slab_equals_the_one_batch_decode(hm_hooks, case)
         f.close()
 
 
+def test_grids_decoded_by_several_threads_at_once(hm):
+    """r06: hm_decode_item on a grid runs a queueing thread of its own beside the parsing crew (slabs under the entropy decode) - three caller
+    threads decode three different grids at the same time, four times each: every image equals the one decoded alone (the crew takes one
+    fan-out at a time, the slabs' streams come from the shared per-device cache)."""
+    import threading
+    small = dict(TILE, width=256, height=256)
+    files, want = [], []
+    for k in range(3):
+        tiles = [synthutil.picture(6800000 + 10 * k + i, **small, vui=1, full_range=1, matrix=6) for i in range(12)]
+        f = pipeline.HeifFile(hm, heifwriter.write_heic(tiles, (256, 256), grid=(4, 3, 760, 1000)))
+        files.append(f)
+        want.append(f.decode(f.primary(), 10, threads=4)[0][0][:1000, :760 * 3].copy())
+    errors = []
+
+    def work(k):
+        try:
+            for _ in range(4):
+                got = files[k].decode(files[k].primary(), 10, threads=4)[0][0][:1000, :760 * 3]
+                if not np.array_equal(got, want[k]):
+                    errors.append(f"grid {k} differs")
+        except Exception as e:  # noqa: BLE001
+            errors.append(f"grid {k}: {e}")
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), "a decode hangs"
+    assert not errors, errors
+    for f in files:
+        f.close()
+
+
 def test_items_that_do_not_cut_fall_back_to_the_first_device(hm):
     """a single image, and a grid asked for planar output: hm_decode_item_devices decodes them on devices[0] like hm_decode_item"""
     import ctypes as C
