@@ -82,7 +82,7 @@ int hm_launch_tailf(const struct hm_dev_pic* d_pics, const void* d_dsts, int n_p
 // (test hook) slice segments whose sub-streams were entropy-decoded side by side since the library was loaded: which = 0 WPP rows, 1 rows of tiles
 HM_API long hm_parse_parallel_segments(int which);
 // (test hook, r05; r06: test_hooks.cpp - in libheif_mi355x_test.so only) registers and scratch of a hot-path kernel as the loaded code object has them: which = 0 k_residual, 1 k_tail420 (RGB24),
-// 2 k_chain with (log2_ctb 4..6, bytes per sample 1 / 2, mode 0..4) in a, b, c, 3 k_tail420 on 16-bit samples (RGB24).  out[0] = vector registers, out[1] = scratch bytes per
+// 2 k_chain with (log2_ctb 4..6, bytes per sample 1 / 2, mode 0..6) in a, b, c, 3 k_tail420 on 16-bit samples (RGB24).  out[0] = vector registers, out[1] = scratch bytes per
 // lane - a spilled register comes back with a LOAD, and a wait for it waits for every store in flight ("One counter"):
 // tests/test_chain_modes_gpu.py holds the kernels of the hot path to zero.  -> 0, or -1
 HM_API int hm_debug_kernel_regs(int which, int a, int b, int c, int out[2]);

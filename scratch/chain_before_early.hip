@@ -56,37 +56,20 @@ namespace {
 // (HM_CHAIN_TIMING=2: the same five words count events instead - service phases, CTU flushes, window take-overs, 4x4 passes,
 //  wave-wide blocks - per wave, in units of 1/64 so that the print's ">> 6" gives the counts)
 #ifdef HM_CHAIN_TIMING
-#define HM_T_DECL unsigned long long t_prev = __builtin_amdgcn_s_memtime(); unsigned int t_acc[6] = {0, 0, 0, 0, 0, 0}, t_part[4] = {0, 0, 0, 0}; int t_in_svc = 0; (void)t_part; (void)t_in_svc
+#define HM_T_DECL unsigned long long t_prev = __builtin_amdgcn_s_memtime(); unsigned int t_acc[6] = {0, 0, 0, 0, 0, 0}
 #if HM_CHAIN_TIMING == 2
 #define HM_T_LAP(i) (void)t_prev
 #define HM_T_COUNT(i) t_acc[i] += 64
 #else
-#define HM_T_LAP(i) do { if (HM_CHAIN_TIMING != 4) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_acc[i] += (unsigned int)(t_now - t_prev); t_prev = t_now; } } while (0)
+#define HM_T_LAP(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_acc[i] += (unsigned int)(t_now - t_prev); t_prev = t_now; } while (0)
 #define HM_T_COUNT(i)
 #endif
-// (HM_CHAIN_TIMING=3: cycles as in mode 1, of the waves that work on LUMA chains only, with the service phase split - word 0: service phases
-//  after which a chain of the wave can go on (flush, start, window), word 4: those after which every chain still waits; E counts as D)
-// (HM_CHAIN_TIMING=4: the service phases of the luma waves by part - word 0: the wait for the loads and stores in flight at its top, 1: CTU flushes,
-//  2: CTU starts + polls of the band above, 3: window take-over + bookkeeping, 4: phases after which every chain still waits; the rest of the loop is not counted)
-#if HM_CHAIN_TIMING == 4
-#define HM_T_SVC_BEGIN() do { t_prev = __builtin_amdgcn_s_memtime(); t_in_svc = 1; } while (0)
-#define HM_T_SVC(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_part[i] = (unsigned int)(t_now - t_prev); t_prev = t_now; } while (0)
-#define HM_T_SVC_END(work) do { if (t_in_svc) { HM_T_SVC(3); if (work) { t_acc[0] += t_part[0]; t_acc[1] += t_part[1]; t_acc[2] += t_part[2]; t_acc[3] += t_part[3]; } \
-                                else t_acc[4] += t_part[0] + t_part[1] + t_part[2] + t_part[3]; t_part[0] = t_part[1] = t_part[2] = 0; t_in_svc = 0; } } while (0)
-#else
-#define HM_T_SVC_BEGIN()
-#define HM_T_SVC(i)
-#define HM_T_SVC_END(work)
-#endif
-#define HM_T_FLUSH() do { if (sync && lane == 0 && !(HM_CHAIN_TIMING >= 3 && kind_sel != 0)) { for (int q = 0; q < 5; q++) atomicAdd(sync + 2 + q, t_acc[q] >> 6); atomicAdd(sync + 7, t_acc[5]); } } while (0)
+#define HM_T_FLUSH() do { if (sync && lane == 0) { for (int q = 0; q < 5; q++) atomicAdd(sync + 2 + q, t_acc[q] >> 6); atomicAdd(sync + 7, t_acc[5]); } } while (0)
 #else
 #define HM_T_DECL
 #define HM_T_LAP(i)
 #define HM_T_COUNT(i)
 #define HM_T_FLUSH()
-#define HM_T_SVC_BEGIN()
-#define HM_T_SVC(i)
-#define HM_T_SVC_END(work)
 #endif
 #ifdef HM_MARKS
 #define HM_MARK(name) asm volatile("s_nop 0 ; HMMARK " name)
@@ -140,8 +123,6 @@ struct CLayout {
                      // the last of them to the first (k_chain: wg_ring) - no wave of the launch waits for another workgroup
   int spin_limit;    // PAIRS: polls of the band above without news before a wave gives up (error flag, wrong picture, no hang)
   int test_stall;    // fault injection (tests): the first band of every picture never announces its progress
-  int early;         // (informational; the launcher's choice of the MODE 5 / 6 kernels) PAIRS, one chain per wave: a CTU starts when the CTU ABOVE it is done
-                     // and waits for the one above-right only in front of the first block that reads it (k_chain: EARLY)
 };
 // PAIRS: words of the launch's synchronisation buffer (zeroed before the launch): a ticket counter, then per (picture,
 // pair, chain kind) the finished CTUs of the pair's last row.  A wave that gives up a bounded wait sets the BATCH's error
@@ -180,7 +161,6 @@ constexpr int chain_waves_per_simd = (sizeof(Pix) == 1 && MODE == 0) ? (LOG2_CTB
 // constant: the multi-record bookkeeping of the cuts with fewer than four chains sits on the critical path of a wave that is
 // alone on its SIMD, and with a run-time count it was loops, selects and a dozen spilled scalar registers (r04)
 // MODE 4 = MODE 3 in a ring whose waves ALTERNATE between the luma and the chroma chains from band to band (ALT in the kernel)
-// MODE 5 / 6 (r06) = MODE 3 / 4 with the early CTU start (EARLY in the kernel): launches of few pictures
 constexpr int chain_mode_ncl(int mode) { return mode <= 1 ? 2 : (mode == 2 ? 1 : 0); }
 #ifdef HM_WPE
 #define HM_CHAIN_ATTR __attribute__((amdgpu_waves_per_eu(HM_WPE, HM_WPE)))
@@ -332,7 +312,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   // cuts; only reading the reference samples, the blend and the store run one record after the other (phase C below).  In
   // these cuts a wave is alone on its SIMD and an iteration is a chain of latencies, not of instructions: what counts is the
   // number of iterations per record.  All groups of a chain hold identical chain state (the same loads, the same updates).
-  constexpr bool ALT = MODE == 4 || MODE == 6;
+  constexpr bool ALT = MODE == 4;
   constexpr int NCL = chain_mode_ncl(MODE); // log2 of the chains per wave (the launcher: split kinds or one row of a monochrome picture 0, one row 1, else 2)
   constexpr int SUB = 4 >> NCL;             // records of a chain per iteration
   constexpr unsigned long long main_mask = NCL == 2 ? ~0ull : (NCL == 1 ? 0xFFFFFFFFull : 0xFFFFull); // the groups with offset 0
@@ -392,17 +372,6 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   // PAIRS, first row of a pair: CTUs of the row above (the last row of the pair above, another wave's) whose bottom
   // sample line has been copied from the picture into this wave's line
   int hbm_have = 0, hbm_polls = 0;
-  // EARLY (r06; the cuts with one CTU row - or one chain of it - per wave, where a picture's time is its wavefront: rows + 2 (rows - 1) CTU
-  // steps with the rule "CTU (r, c) starts when (r - 1, c + 1) is done").  Only blocks of a CTU's first block row whose top-right run
-  // crosses the CTU's right edge read a sample of CTU (r - 1, c + 1) - in decoding order the first of them comes a quarter to a third
-  // into the CTU (residual.hip marks them: OP_FAR).  So a CTU starts when (r - 1, c) is done, and the chain stops in front of an
-  // OP_FAR block until (r - 1, c + 1) is: a row lags ~1.3 CTUs behind the one above instead of 2 - 16 x 16 CTUs: ~36 steps instead of 46.
-  // No state for it, neither per chain nor per wave (a register more is a spilled one in the 16-bit kernels): the counter of the row above is
-  // read again in front of every OP_FAR block - one or two per CTU -, and a chain that has to stop there sets its `left` to 0: the next
-  // iteration passes through the service phase (which polls the band above where that goes through HBM, and works `left` out again)
-  constexpr bool EARLY_CT = MODE >= 5; // (kernels of their own, MODE 5 = 3 + EARLY, 6 = 4 + EARLY: the launcher takes them for launches the device holds at once - in the
-                                       //  loop of the kernels that run saturated the same code cost 3-4 % (its scalars spill to vector lanes at the register limit) and bought nothing)
-  constexpr bool early = EARLY_CT;
   int pidx = pair_index; // the band the group works on now (the wave's next one: pidx + W)
   // progress counter of a row in flight: row % 8 (rows of a wave per picture are NR apart), PAIRS: alternating halves per
   // band the group has worked on (the rows of a wave's consecutive bands may be a multiple of 8 apart)
@@ -478,7 +447,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
   if (st == ST_START) row_start();
   // every iteration executes a block of some chain or waits for a CTU that is at most two CTUs of another chain away
   // (PAIRS: plus the bounded waits for the band above, one per CTU at most)
-  const long long budget_ll = (long long)n_tus + 64ll * ctb_w * ctb_h + 4096 + (PAIRS ? (long long)(EARLY_CT ? 2 : 1) * ctb_w * L.spin_limit : 0); // (EARLY: two waits per CTU)
+  const long long budget_ll = (long long)n_tus + 64ll * ctb_w * ctb_h + 4096 + (PAIRS ? (long long)ctb_w * L.spin_limit : 0);
   int budget = rfl(budget_ll < 0x7FFFFFF0ll ? (int)budget_ll : 0x7FFFFFF0); // (a scalar: the loop's exit test costs no vector instruction)
   unsigned long long m_done = ballot(st == ST_DONE);
 
@@ -497,9 +466,8 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     //      holds 0 too and is masked out.  An iteration without events (nearly half of them) costs one compare here: the
     //      state checks of all three phases below (r03: ~20 vector instructions per iteration) run only when something is due.
     const unsigned long long m_left0 = ballot(left == 0);
-    if ((m_left0 & ~m_done) || (PAIRS && (budget & 15) == 0) ) {
+    if ((m_left0 & ~m_done) || (PAIRS && (budget & 15) == 0)) {
       HM_T_COUNT(0);
-      HM_T_SVC_BEGIN();
 #ifndef HM_NO_SERVICE_WAIT
       // (r05) Loads and stores share one in-order counter: the header of the CTU to start (requested a CTU ago) and the next window
       // (requested a window ago) are looked at below, BEHIND the stores of the CTUs this phase flushes - a wait for them there is a
@@ -507,7 +475,6 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       // where everything in flight is at least an iteration old.
       __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
 #endif
-      HM_T_SVC(0);
       // ---- F: finished CTUs: coalesced stores to the picture, bottom row -> line, right column -> left column ----
       for (unsigned long long fin = ballot(st == ST_RUN) & ballot(ri == ctu_end) & ((CAN_LATE && late) ? 0x0000FFFF0000FFFFull : main_mask); fin;) {
         const int fg = rfl((int)(__builtin_ctzll(fin) >> 4));
@@ -622,12 +589,10 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         }
       }
       WAVE_SYNC();
-      HM_T_SVC(1);
       // ---- A: start the next CTU of every group whose dependency is met (the row above two CTUs ahead) ----
       bool started = false;
       if (st == ST_START) {
-        const int need2 = cx + 2 < ctb_w ? cx + 2 : ctb_w;
-        const int need = early ? cx + 1 : need2; // (EARLY: the CTU above; the one above-right in front of the first block that reads it)
+        const int need = cx + 2 < ctb_w ? cx + 2 : ctb_w;
         // (a counter value seen here means the line samples written before it are there: LDS traffic of a wave is in order)
         const bool wave_above = lds_above && my_slot == 0; // (the counter a wave of this workgroup writes, with the pass in its upper half)
         int done_above = __hip_atomic_load(wave_above ? my_progress + above_ctr_index : my_progress + prog_index(row - 1, my_slot - 1), __ATOMIC_RELAXED,
@@ -652,7 +617,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         // ---- the sample line of the pair above, through HBM: the chains of a pair's first row poll the progress word of
         //      the pair above (while they wait, and every eighth iteration while they run, so that the line is usually
         //      there before it is needed) and copy what has become available from the picture into the line ----
-        const bool poll = from_hbm && st != ST_DONE && hbm_have < ctb_w && (st == ST_START || (budget & 15) == 0 || (EARLY_CT && st == ST_RUN && left == 0 && ri != ctu_end && (ri >> WLOG) == wdec)); // (EARLY: or stopped in front of an OP_FAR block)
+        const bool poll = from_hbm && st != ST_DONE && hbm_have < ctb_w && (st == ST_START || (budget & 15) == 0);
         if (ballot(poll)) {
           // (the word and the line are written and read with agent-scope accesses that pass the caches which are not
           //  coherent across the chip: no cache write-back / invalidation - those cost more than the hand-over itself
@@ -704,7 +669,6 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       }
       if (PAIRS && lds_above && ballot(st == ST_RUN) == 0) __builtin_amdgcn_s_sleep(2); // (every chain waits for the wave above: leave the SIMD to it)
       if (ballot(st != ST_DONE) == 0) break;
-      HM_T_SVC(2);
       HM_MARK("R_begin");
       // ---- R: the micro-ops and 4x4 residuals of the next window of records, for every group that has entered it ----
       {
@@ -778,13 +742,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         }
       }
     }
-#if defined(HM_CHAIN_TIMING) && HM_CHAIN_TIMING == 4
-    HM_T_SVC_END(ballot(left != 0) != 0);
-#elif defined(HM_CHAIN_TIMING) && HM_CHAIN_TIMING == 3
-    if (ballot(left != 0)) HM_T_LAP(0); else HM_T_LAP(4);
-#else
     HM_T_LAP(0);
-#endif
 #if defined(HM_PAD_S) || defined(HM_PAD_V)
     if (lane0_dummy + pad_v == -12345) break; // (keeps the padding alive)
 #endif
@@ -796,30 +754,11 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
     // the group's record: the chain's current one, or - PAIRS - my_off records further if the chain may go that far before
     // its next event (the same CTU, the same window of micro-ops)
     const bool multi = (PAIRS && NCL != 2) || (CAN_LATE && late); // several records of a chain per iteration
-    bool running = (PAIRS || CAN_LATE) ? my_off < left : left != 0;
+    const bool running = (PAIRS || CAN_LATE) ? my_off < left : left != 0;
+    const unsigned long long m_running = (PAIRS || CAN_LATE) ? ballot(my_off < left) : ballot(left != 0);
     const uint32_t ri_me = (PAIRS || CAN_LATE) ? ri + (uint32_t)my_off : ri;
     const uint32_t rslot = ri_me & (RING - 1);
     const c_u32x4 op = ring[rslot];
-    if constexpr (EARLY_CT) {
-      // a record that reads the CTU above-right while that CTU is not known to be done: look again; if it still is not, the chain stops in
-      // front of the record (the records before it - groups of the chain with a smaller offset - go on)
-      const bool far_wait = running && (op.y & OP_FAR) != 0;
-      if (ballot(far_wait)) {
-        const int done_above = lds_above ? __hip_atomic_load(my_progress + above_ctr_index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - (npass << 16) : hbm_have;
-        const unsigned long long mb = ballot(far_wait && row != 0 && done_above < (cx + 2 < ctb_w ? cx + 2 : ctb_w));
-        if (mb) {
-          const uint32_t gbm = (uint32_t)((mb & 1) | ((mb >> 15) & 2) | ((mb >> 30) & 4) | ((mb >> 45) & 8)); // bit k: group k is stopped
-          // per chain the offset of its first stopped record (one chain: its records are the groups 0 1 2 3; two: chain c's the groups c, c + 2)
-          const uint32_t kb0 = (uint32_t)__builtin_ctz((NCL == 0 ? gbm : ((gbm & 1u) | ((gbm >> 1) & 2u))) | (1u << SUB));
-          const uint32_t kb1 = NCL == 0 ? kb0 : (uint32_t)__builtin_ctz(((gbm >> 1) & 1u) | ((gbm >> 2) & 2u) | (1u << SUB));
-          const uint32_t my_kb = g == 0 ? kb0 : kb1;
-          running = running && (uint32_t)my_off < my_kb;
-          left = my_kb == 0 ? 0 : left; // (stopped at its current record: an event - see EARLY above)
-          if (ballot(running) == 0) { __builtin_amdgcn_s_sleep(1); continue; } // (every chain of the wave waits)
-        }
-      }
-    }
-    const unsigned long long m_running = ballot(running);
     const int16_t* const my_res = rres + rslot * 16; // the 16 residual samples of the group's block if it is a 4x4 block
     const unsigned long long m_q4 = m_running & ballot((op.y & ((3u << OP_L2_SHIFT) | OP_INTERIOR)) == OP_INTERIOR); // interior 4x4 blocks
     // which records execute in this iteration: per chain the run of interior 4x4 blocks from its current record on (phase C,
@@ -870,14 +809,10 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
         idx = idx < res_last ? idx : res_last;
         return (uint32_t)(int)resid[idx];
       };
-      // (tests on the halves of the mask: as 64-bit tests the compiler turned the last one into an unsigned compare with a constant it kept
-      //  in a pair of VECTOR registers for the whole loop - and spilled, in the kernels at the register limit)
-      uint32_t sb_lo = (uint32_t)s_bres, sb_hi = (uint32_t)(s_bres >> 32);
-      asm volatile("" : "+s"(sb_lo), "+s"(sb_hi)); // (... and puts the halves together again if it can see where they come from)
-      if (sb_lo & 0xFFFFu) bres0 = big_res(0);
-      if (sb_lo >> 16) bres1 = big_res(1);
-      if (sb_hi & 0xFFFFu) bres2 = big_res(2);
-      if (sb_hi >> 16) bres3 = big_res(3);
+      if (s_bres & 0xFFFFull) bres0 = big_res(0);
+      if (s_bres & 0xFFFF0000ull) bres1 = big_res(1);
+      if (s_bres & 0xFFFF00000000ull) bres2 = big_res(2);
+      if (s_bres & 0xFFFF000000000000ull) bres3 = big_res(3);
     }
 
     HM_MARK("C_begin");
@@ -1293,11 +1228,7 @@ __global__ __launch_bounds__(1024) HM_CHAIN_ATTR void k_chain(const hm_dev_pic* 
       ri += 1;
       left -= 1;
     }
-#if defined(HM_CHAIN_TIMING) && HM_CHAIN_TIMING == 3
-    HM_T_LAP(3);
-#else
     HM_T_LAP(4);
-#endif
 #ifdef HM_CHAIN_TIMING
     t_acc[5] += 1;
 #endif
@@ -1519,29 +1450,23 @@ static int launch_chain_impl(const hm_dev_pic* d_pics, int n_pics, int log2_ctb,
       case 1: return reinterpret_cast<const void*>(k_chain<P, L2, 1>);
       case 2: return reinterpret_cast<const void*>(k_chain<P, L2, 2>);
       case 3: return reinterpret_cast<const void*>(k_chain<P, L2, 3>);
-      case 4: return reinterpret_cast<const void*>(k_chain<P, L2, 4>);
-      case 5: return reinterpret_cast<const void*>(k_chain<P, L2, 5>);
-      default: return reinterpret_cast<const void*>(k_chain<P, L2, 6>);
-    }
-  };
-  auto fn_for = [&](int m) -> const void* {
-    switch (inst) {
-      case 0: return fn_of(uint8_t(), std::integral_constant<int, 4>(), m);
-      case 1: return fn_of(uint16_t(), std::integral_constant<int, 4>(), m);
-      case 2: return fn_of(uint8_t(), std::integral_constant<int, 5>(), m);
-      case 3: return fn_of(uint16_t(), std::integral_constant<int, 5>(), m);
-      case 4: return fn_of(uint8_t(), std::integral_constant<int, 6>(), m);
-      case 5: return fn_of(uint16_t(), std::integral_constant<int, 6>(), m);
-      default: return nullptr;
+      default: return reinterpret_cast<const void*>(k_chain<P, L2, 4>);
     }
   };
   auto pick = [&](bool prs) -> bool {
     // the kernel's MODE: the chains a wave works on (k_chain: NCL) follow from the cut in L
     mode = !prs ? 0 : (L.split_kinds ? (alt_kinds() ? 4 : 3) : (L.rows_per_wave == 1 ? (mono ? 3 : 2) : 1));
-    fn = fn_for(mode);
-    if (!fn) return false;
-    static int cu_waves_of[42] = {}; // (per instantiation; a benign race: every thread computes the same value)
-    int& cu_waves = cu_waves_of[inst * 7 + mode];
+    switch (inst) {
+      case 0: fn = fn_of(uint8_t(), std::integral_constant<int, 4>(), mode); break;
+      case 1: fn = fn_of(uint16_t(), std::integral_constant<int, 4>(), mode); break;
+      case 2: fn = fn_of(uint8_t(), std::integral_constant<int, 5>(), mode); break;
+      case 3: fn = fn_of(uint16_t(), std::integral_constant<int, 5>(), mode); break;
+      case 4: fn = fn_of(uint8_t(), std::integral_constant<int, 6>(), mode); break;
+      case 5: fn = fn_of(uint16_t(), std::integral_constant<int, 6>(), mode); break;
+      default: return false;
+    }
+    static int cu_waves_of[30] = {}; // (per instantiation; a benign race: every thread computes the same value)
+    int& cu_waves = cu_waves_of[inst * 5 + mode];
     if (cu_waves == 0) {
       hipFuncAttributes fa;
       int w = 16;
@@ -1701,24 +1626,9 @@ static int launch_chain_impl(const hm_dev_pic* d_pics, int n_pics, int log2_ctb,
   L.passes = passes_of();
   L.bands_per_pic = share && share < L.passes ? share : (ring_w ? ring_w : L.passes);
   L.ring = ring_w ? 1 : 0;
-  // EARLY (k_chain): not in a short ring.  The line a wave receives for band p + W is written by the wave of band p + W - 1 while the wave may still read it
-  // for band p.  A band FINISHES CTU j - and flushes its bottom line - only behind the OP_FAR block of j, i.e. when the band above has finished j + 1: the
-  // distance of the old rule, wherever the CTU above-right is available.  Where it is not (a slice that ends in the middle of the row above) a CTU has no
-  // such block and a band may finish CTU j while the band above still works on j + 1, whose corner sample lies in j's columns of the line: per hand-over one
-  // CTU of distance instead of two.  Two hand-overs (W = 3) are enough; W >= 4 is what runs (the alternating ring, MODE 4, has 2 W - 1 in between: always).
-  // tools/stress_cuts.py hunts for such races (3 600 executes per run in 15 cuts: none, also with the rule forced in the short rings - its tiles are one slice each).
-  L.early = hm_knob(HM_KNOB_CHAIN_EARLY) != 0 && !(ring_w && ring_w < 4 && !alt_kinds()) ? 1 : 0;
-#ifdef HM_CHAIN_EARLY_FORCE // (negative control of tools/stress_cuts.py: the early start also where a ring's line reuse forbids it)
-  L.early = 1;
-#endif
   const size_t sync_need = sync_words(L.passes);
   const int force_np = hm_knob(HM_KNOB_CHAIN_NP); // (tuning aid)
   const long n_waves = pairs ? ((long)n_pics * L.bands_per_pic) << L.split_kinds : (long)n_pics;
-  // ... and only for launches of at most a picture per CU that the device holds at once (kernels of their own, MODE 5 / 6: k_chain EARLY_CT): 48 / 96 / 192 tiles
-  // of 512 x 512 are 5-7 % faster with it (10 % against round 5's code), 384 tiles 1 % slower, 1536 and more - several rounds of waves, bound by issue - the same
-  // (profiles/r06_few_pictures.txt)
-  if (pairs && L.early && (mode == 3 || mode == 4) && n_pics <= device_cus() && n_waves <= (long)device_cus() * 20 && fn_for(mode + 2)) { mode += 2; fn = fn_for(mode); }
-  else L.early = 0;
   // A wave per CTU row (or per chain of one): neighbouring rows in one workgroup hand over through LDS (k_chain: lds_above) -
   // the more waves a workgroup holds, the fewer hand-overs go through HBM.  Eight: one in eight (sixteen measured no better).
   const bool lds_rows = pairs && !ring_w && L.rows_per_wave == 1 && L.bands_per_pic == L.passes;
@@ -1749,7 +1659,6 @@ static int launch_chain_impl(const hm_dev_pic* d_pics, int n_pics, int log2_ctb,
                      !pairs ? "one per picture" : (L.split_kinds ? "one per chain of a CTU row" : (L.rows_per_wave == 1 ? "one per CTU row" : (L.bands_per_pic < L.passes ? "several per picture, taking its pairs of CTU rows in turn" : "one per pair of CTU rows"))),
                      L.pic_bytes, np, best);
   if (debug && ring_w) fprintf(stderr, "[k_chain] a picture's %d waves in one workgroup, rows handed over through LDS in a ring\n", ring_w << L.split_kinds);
-  if (debug && L.early) fprintf(stderr, "[k_chain] a CTU starts when the CTU above it is done (the kernels with the early start)\n");
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) { give_back(); return hm_check_hip(e, "hipFuncSetAttribute(k_chain)"); }
   if (pairs) {
@@ -1889,7 +1798,7 @@ extern "C" int hm_launch_chain(const hm_dev_pic* d_pics, int n_pics, int log2_ct
 // (hm_debug_kernel_regs) the kernel of a (CTB size, sample size, mode), or null
 extern "C" const void* hm_chain_kernel_of(int log2_ctb, int bytes_per_sample, int mode)
 {
-  if (log2_ctb < 4 || log2_ctb > 6 || bytes_per_sample < 1 || bytes_per_sample > 2 || mode < 0 || mode > 6) return nullptr;
+  if (log2_ctb < 4 || log2_ctb > 6 || bytes_per_sample < 1 || bytes_per_sample > 2 || mode < 0 || mode > 4) return nullptr;
   auto of = [&](auto pix) -> const void* {
     typedef decltype(pix) P;
     auto by_mode = [&](auto l2c) -> const void* {
@@ -1899,9 +1808,7 @@ extern "C" const void* hm_chain_kernel_of(int log2_ctb, int bytes_per_sample, in
         case 1: return reinterpret_cast<const void*>(k_chain<P, L2, 1>);
         case 2: return reinterpret_cast<const void*>(k_chain<P, L2, 2>);
         case 3: return reinterpret_cast<const void*>(k_chain<P, L2, 3>);
-        case 4: return reinterpret_cast<const void*>(k_chain<P, L2, 4>);
-        case 5: return reinterpret_cast<const void*>(k_chain<P, L2, 5>);
-        default: return reinterpret_cast<const void*>(k_chain<P, L2, 6>);
+        default: return reinterpret_cast<const void*>(k_chain<P, L2, 4>);
       }
     };
     return log2_ctb == 4 ? by_mode(std::integral_constant<int, 4>()) : (log2_ctb == 5 ? by_mode(std::integral_constant<int, 5>()) : by_mode(std::integral_constant<int, 6>()));

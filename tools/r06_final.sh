@@ -11,6 +11,5 @@ python3 tools/check_launcher.py > gpurun_out/r06f_launcher_check.txt 2>&1
 tail -5 gpurun_out/r06f_launcher_check.txt
 # the few-pictures regime: the early CTU start A/B (knob for the cuts with a wave per chain / row, compile flag for the alternating ring), slabs of hm_decode_item
 { echo "== k_chain, early CTU start (tools/r06_early.sh)"; bash tools/r06_early.sh 2>&1 | grep -v "^== tests" | head -16
-  echo "== the alternating ring built with -DHM_CHAIN_EARLY_ALT=0 (4 images = 192 tiles)"; VARIANTS="-DHM_NONE=1|-DHM_CHAIN_EARLY_ALT=0" tools/probe_chain.sh --images 4 2>&1 | grep variant
   echo "== hm_decode_item, one 12 MP grid, by tile rows per slab (0 = one batch behind the entropy decode)"; bash tools/r06_slabs.sh 2>&1; } > gpurun_out/r06f_few_pictures.txt 2>&1
 TIMINGS="1 2 4" IMAGES=1 bash tools/r06_lat.sh > gpurun_out/r06f_chain_latency.txt 2>&1
