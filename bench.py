@@ -688,7 +688,7 @@ def single_image_leg(out, torch, pkg, dev, st, blobs):
     stage_b = stream_b + sample_b
     res["roofline_stage"] = {"bound": "hbm", "achieved": round(stage_b / recon_ms / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                              "frac": round(stage_b / recon_ms / 1e6 / HBM_PEAK_GBPS, 5), "bytes": int(stage_b),
-                             "note": "command stream + 1.5 B/px over k_residual + k_chain; latency-bound at 48 tiles (one tile's wavefront of 46 CTU steps)"}
+                             "note": "command stream + 1.5 B/px over k_residual + k_chain; latency-bound at 48 tiles (one tile's wavefront: ~36 CTU steps since r06's early CTU start, 46 before)"}
     res["recon_ms"] = round(recon_ms, 4)
     res["tail_ms"] = round(tail_ms, 4)
     torch.cuda.synchronize()
