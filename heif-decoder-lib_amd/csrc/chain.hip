@@ -1613,6 +1613,7 @@ static int launch_chain_impl(const hm_dev_pic* d_pics, int n_pics, int log2_ctb,
     //  were chosen, the same four in a ring hand over through LDS: 8-bit CTB 16, 768 / 1024 tiles 3.05 / 3.28 -> 2.45 / 2.81 ms,
     //  profiles/r05_launcher_check.txt)
     static const struct { int one_row, split, w; } cand[6] = {{1, 1, 8}, {1, 1, 4}, {1, 1, 2}, {0, 0, 4}, {0, 0, 3}, {0, 0, 2}};
+    long ring_cost = 0; // the estimate of the resident ring taken below
     for (const auto& c : cand) {
       const int rpw = c.one_row ? 1 : nr, split = mono ? 0 : c.split;
       if (max_ctb_h <= rpw || (heavy && !c.one_row)) continue; // (rings of row pairs: as short of LDS as a wave per picture)
@@ -1620,6 +1621,7 @@ static int launch_chain_impl(const hm_dev_pic* d_pics, int n_pics, int log2_ctb,
       if ((long)n_pics * per_pic > capacity || sync_bytes < sync_words(bands)) continue;
       if (steps_of((long)w * rpw) * step_cost(rpw, split) > cost_now) continue;
       L.rows_per_wave = rpw; L.split_kinds = split; pairs = true; ring_w = w;
+      ring_cost = steps_of((long)w * rpw) * step_cost(rpw, split);
       auto fits_device = [&]() { return set_layout() && pick(true) && (long)n_pics * per_pic <= (long)device_cus() * (best < k_tune.ring_waves_per_cu ? best : k_tune.ring_waves_per_cu); };
       if (fits_device()) { share = 0; break; }
       if (alt_kinds()) { // (the workgroup's waves with a line per kind each may not fit its LDS: then with fixed kinds)
@@ -1633,30 +1635,42 @@ static int launch_chain_impl(const hm_dev_pic* d_pics, int n_pics, int log2_ctb,
     // the device holds run in turn - in whole ROUNDS of what is resident.  Taken if rounds x steps still beat the chosen cut with a
     // margin (profiles/r05_launcher_check.txt: 8-bit CTB 32, 2560 tiles: a wave per picture 4.86 ms, two rounds of rings of two 4.40;
     // monochrome 4096 tiles: 5.85 against 4.68).
-    if (!ring_w && !heavy && max_ctb_h > 1) {
+    // (r06) ... and a resident ring is measured against them too: the thresholds were read from 512 x 512 tiles, where the two meet
+    // around 1536 pictures; with other picture sizes the one-chain rings in rounds win earlier or later (tools/check_launcher.py with HM_CHECK_TILE,
+    // 1536 tiles: 256 x 256 1.16 ms against 0.94 for rings of two, 1024 x 1024 12.5 against 11.0 for rings of four).  Rounds count between their whole
+    // number and the fraction the last one is filled to - the fit of those points and of 512 x 512 at 1280 ... 2048.
+    const bool ring_of_pairs = ring_w != 0; // (any resident ring - the name is the first case it was built for: rings of row pairs)
+    const int resident_chain_w = ring_w != 0 && L.rows_per_wave == 1 ? ring_w : 0;
+    if ((!ring_w || ring_of_pairs) && !heavy && max_ctb_h > 1) {
       const CLayout keep2 = L;
       const bool keep2_pairs = pairs, keep2_alt = alt_wanted;
+      const int keep2_ring = ring_w;
       int best_w = 0;
-      long best_cost = cost_now - cost_now / 20; // (5 % margin: the estimate is coarse)
+      const long base_cost = ring_of_pairs ? ring_cost : cost_now;
+      long best_cost = ring_of_pairs ? base_cost : base_cost - base_cost / 20; // (5 % margin against a cut without rings: the estimate is coarse; ring against ring: none)
       for (int w : {4, 2}) {
         const int split = mono ? 0 : 1, bands = max_ctb_h, ww = w < bands ? w : bands, per_pic = ww << split;
-        if (sync_bytes < sync_words(bands)) continue;
+        if (sync_bytes < sync_words(bands) || ww == resident_chain_w) continue;
         L.rows_per_wave = 1; L.split_kinds = split; pairs = true; ring_w = ww; alt_wanted = alt_allowed;
         bool ok = set_layout() && pick(true);
         if (!ok && alt_kinds()) { alt_wanted = false; ok = set_layout() && pick(true); }
         if (ok) {
           const long resident = (long)device_cus() * (best < k_tune.ring_waves_per_cu ? best : k_tune.ring_waves_per_cu);
-          const long rounds = ((long)n_pics * per_pic + resident - 1) / resident;
-          const long cost = rounds * steps_of((long)ww) * step_cost(1, split);
+          const long waves = (long)n_pics * per_pic, rounds = (waves + resident - 1) / resident;
+          // (tenths of a round against a ring that is resident as a whole; whole rounds where the alternative is a cut without rings - r05's calibration)
+          const long rounds10 = ring_of_pairs && rounds > 1 ? (10 * rounds + (10 * waves + resident - 1) / resident) / 2 : 10 * rounds; // (one round is one round)
+          const long cost = rounds10 * steps_of((long)ww) * step_cost(1, split) / 10;
+          if (hm_knob(HM_KNOB_CHAIN_DEBUG)) fprintf(stderr, "[k_chain] rings of %d one-chain bands in rounds: %ld waves, %ld resident, cost %ld against %ld\n", ww, waves, resident, cost, best_cost);
           if (cost < best_cost) { best_cost = cost; best_w = ww | (alt_wanted ? 0x100 : 0); }
         }
-        L = keep2; pairs = keep2_pairs; alt_wanted = keep2_alt; ring_w = 0;
+        L = keep2; pairs = keep2_pairs; alt_wanted = keep2_alt; ring_w = keep2_ring;
       }
       if (best_w) {
         L.rows_per_wave = 1; L.split_kinds = mono ? 0 : 1; pairs = true; ring_w = best_w & 0xFF; alt_wanted = (best_w & 0x100) != 0;
         if (set_layout() && pick(true)) share = 0;
-        else { L = keep2; pairs = keep2_pairs; alt_wanted = keep2_alt; ring_w = 0; }
+        else { L = keep2; pairs = keep2_pairs; alt_wanted = keep2_alt; ring_w = keep2_ring; if (ring_of_pairs) { set_layout(); pick(true); } }
       }
+      else if (ring_of_pairs) { set_layout(); pick(true); } // (the probes above moved the layout and the kernel: back to the ring taken)
     }
     // (more waves than the device holds, see `heavy` - against the cuts with four chains per wave only: a wave per chain or per row
     //  of every row keeps the picture's whole wavefront)

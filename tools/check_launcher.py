@@ -4,7 +4,8 @@ been forced into?  For N = 24 ... 6144 copies of one 512x512 tile (class HM_CLAS
 ms (k_residual + k_chain, HIP events, best of 3) with the launcher left alone and with every cut forced through the test hook
 (hm_debug_set: chain_pairs / chain_ring / chain_share) - one process, one batch per N.  The table is the regression check of the
 launcher's calibration: a threshold that has drifted shows up as a row whose ratio is well above 1.
-usage (repo root, GPU box): python3 tools/check_launcher.py [N ...]"""
+usage (repo root, GPU box): [HM_CHECK_TILE=256|1024] python3 tools/check_launcher.py [N ...]   (HM_CHECK_TILE: another tile size than 512 - the calibration
+was read from 512 x 512 tiles)"""
 import json
 import os
 import sys
@@ -35,15 +36,16 @@ def main():
     dev = torch.device("cuda:0")
     counts = [int(a) for a in sys.argv[1:]] or [24, 48, 96, 192, 384, 768, 1280, 1536, 2048, 3072, 5120, 6144]
     name = os.environ.get("HM_CLASS_ONLY", "8bit_420_ctb32")
-    cfg = dict(width=512, height=512, qp=27, cu_qp_delta=1, sao=1, sign_hiding=1, density=60)
+    T = int(os.environ.get("HM_CHECK_TILE", "512"))
+    cfg = dict(width=T, height=T, qp=27, cu_qp_delta=1, sao=1, sign_hiding=1, density=60)
     cfg.update({**CLASSES, **MORE}[name])
     blobs = [capi.parse_hevc(synthutil.picture(7700000 + i, **cfg)) for i in range(8)]
     bps = 2 if cfg.get("bit_depth", 8) > 8 else 1
-    ys, cs = L.hm_plane_stride(512, bps), L.hm_plane_stride(256, bps)
-    ch = 256 if cfg.get("chroma_format", 1) == 1 else 512
-    y = torch.zeros((512, ys), dtype=torch.uint8, device=dev)
-    cb = torch.zeros((ch, cs), dtype=torch.uint8, device=dev)
-    cr = torch.zeros((ch, cs), dtype=torch.uint8, device=dev)
+    ys, cs = L.hm_plane_stride(T, bps), L.hm_plane_stride(T // 2, bps)
+    ch = T // 2 if cfg.get("chroma_format", 1) == 1 else T
+    y = torch.zeros((max(64, T), ys), dtype=torch.uint8, device=dev)
+    cb = torch.zeros((max(64, ch), cs), dtype=torch.uint8, device=dev)
+    cr = torch.zeros((max(64, ch), cs), dtype=torch.uint8, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     rows = []
     for n in counts:
@@ -52,7 +54,7 @@ def main():
             d = capi.TileDest()
             d.plane[0], d.plane[1], d.plane[2] = y.data_ptr(), cb.data_ptr(), cr.data_ptr()
             d.pitch[0], d.pitch[1], d.pitch[2] = ys, cs, cs
-            d.canvas_width, d.canvas_height, d.x0, d.y0 = 512, 512, 0, 0
+            d.canvas_width, d.canvas_height, d.x0, d.y0 = T, T, 0, 0
             batch.add(blobs[i % 8], d)
         batch.upload(st)
         ms = {}
@@ -75,7 +77,7 @@ def main():
         best = min(forced, key=forced.get)
         rows.append(dict(tiles=n, auto_ms=ms["auto"], best_forced=best, best_ms=forced[best], ratio=round(ms["auto"] / forced[best], 3), all=ms))
         print(f"{n:5d} tiles: launcher {ms['auto']:7.3f} ms, best forced cut {best:13s} {forced[best]:7.3f} ms, ratio {ms['auto'] / forced[best]:.3f}", flush=True)
-    print(json.dumps({"class": name, "rows": rows}))
+    print(json.dumps({"class": name, "tile": T, "rows": rows}))
 
 
 if __name__ == "__main__":
