@@ -62,11 +62,12 @@ def test_large_pictures_keep_their_wavefront():
     assert "in a ring" in r.stderr, r.stderr
 
 
-@pytest.mark.parametrize("name, copies, waves", [("tile512_a", 300, 8), ("tile512_a", 1000, 4), ("tile512_a", 1100, 4), ("tile512_a", 1500, 2),
+@pytest.mark.parametrize("name, copies, waves", [("tile512_a", 300, 8), ("tile512_a", 1000, 4), ("tile512_a", 1100, 4), ("tile512_a", 1500, 4), ("tile512_a", 2048, 2),
                                                  ("hi422_10", 3000, 4), ("mono10_wide", 2500, 2)])
 def test_the_ring_the_launcher_chooses(name, copies, waves):
     """512x512 tiles: the finest cut whose waves are all resident (r05: twenty one-chain waves per CU, sixteen of row pairs - 1100 tiles
-    take rings of two one-chain waves per kind, where three row-pair waves fitted before); 10-bit 4:2:2 pictures, whose wave per picture is so short of LDS that
+    take rings of two one-chain waves per kind, where three row-pair waves fitted before; r06: 1500 tiles take rings of two one-chain bands per kind in two rounds - measured
+    against the resident ring of two row-pair waves, which 2048 tiles keep); 10-bit 4:2:2 pictures, whose wave per picture is so short of LDS that
     a CU holds ten: rings of 2 bands x 2 kinds even when they do not all fit the device (profiles/r04_ring_sweep.txt) - and the
     oracle's pictures"""
     r = _run({"HM_CHECK_COPIES": str(copies), "HM_CHAIN_DEBUG": "1"}, name, timeout=900)
