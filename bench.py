@@ -1248,10 +1248,15 @@ def grid_tile_seeds(tile_rows, cols):
 
 
 def config5_single(torch, pkg, dev, st):
-    """SURVEY 8d config 5 on one GPU: ONE 16384x16384 grid (32x32 tiles of 512x512, seeds 5000000+i) -> RGB24, K clock."""
+    """SURVEY 8d config 5 on one GPU: ONE 16384x16384 grid (32x32 tiles of 512x512, seeds 5000000+i) -> RGB24, K clock; beside it (r06) the
+    caller's clock E for the same grid as a .heic through hm_decode_item (box parsing + entropy decode on the host threads + the grid's slabs of tile
+    rows under it + D2H into the 805 MB host plane)."""
     capi = pkg.capi
     gb = GridBatch(pkg, dev, 32, 32, TILE, 16384, 16384)
-    blobs = [b for _, b in make_streams(capi, grid_tile_seeds(range(32), 32), keep_data=False)]
+    made = list(make_streams(capi, grid_tile_seeds(range(32), 32), keep_data=True))
+    datas = [d for d, _ in made]
+    blobs = [b for _, b in made]
+    del made
     gb.add_image(blobs)
     gb.finish(st)
     for _ in range(2):
@@ -1263,7 +1268,26 @@ def config5_single(torch, pkg, dev, st):
            "note": "one 268 MP grid = 1024 tiles per launch (a third of the headline's tiles in flight: the reconstruction kernel's wavefront tail weighs more)"}
     gb.batch.close()
     gb.images.clear()
+    del blobs
     torch.cuda.empty_cache()
+    try:  # (the E clock is a side figure: its failure must not take the K figure with it)
+        import heifwriter
+        import pipeline
+        f = pipeline.HeifFile(pkg.lib(), heifwriter.write_heic(datas, (TILE, TILE), grid=(32, 32, 16384, 16384)))
+        threads = min(48, effective_cpus())
+        try:
+            f.decode(f.primary(), 10, threads=threads, copy=False)
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                f.decode(f.primary(), 10, threads=threads, copy=False)
+                ts.append(time.perf_counter() - t0)
+        finally:
+            f.close()
+        res["E"] = {"ms": round(min(ts) * 1e3, 1), "MP_per_s": round(mp / min(ts), 1), "host_threads": threads,
+                    "what": "hm_decode_item on the grid as a .heic, best of 3: host entropy decode of 1024 tiles with the grid's slabs of tile rows (kernels + D2H) under it"}
+    except Exception as e:  # noqa: BLE001
+        res["E"] = {"error": str(e)[:200]}
     return res
 
 
