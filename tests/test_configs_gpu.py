@@ -172,6 +172,39 @@ def test_a_grid_decoded_slab_by_slab_equals_the_one_batch_decode(hm_hooks, case)
         f.close()
 
 
+def test_a_broken_tile_fails_the_slabbed_decode_like_the_one_batch_decode(hm_hooks):
+    """strict decoding, a grid of 4 x 3 tiles whose tile 7 (third tile row) has its slice data cut short: hm_decode_item must fail with the SAME status and
+    message whether the grid goes to the device in slabs under the entropy decode (the slabs in front of the broken one are already queued then: they are
+    drained before the call returns) or as one batch behind it; without strict decoding both give the same concealed image."""
+    import ctypes as C
+    import hevcutil
+    L = hm_hooks
+    small = dict(TILE, width=256, height=256)
+    tiles = [synthutil.picture(6900000 + i, **small, vui=1, full_range=1, matrix=6) for i in range(12)]
+    nals = hevcutil.split_nals(tiles[7])
+    tiles[7] = hevcutil.join_nals(nals[:-1] + [nals[-1][:len(nals[-1]) // 2]])
+    f = pipeline.HeifFile(L, heifwriter.write_heic(tiles, (256, 256), grid=(4, 3, 768, 1024)))
+    got = {}
+    try:
+        for slab_rows in (0, -1, 2):
+            assert L.hm_debug_set(b"grid_slab_rows", slab_rows) == 0
+            prm = pipeline.DecodeParams(10, 4, 0, 0, None, None, 0, 0, 1, 0)  # strict
+            d = pipeline.Decoded()
+            rc = L.hm_decode_item(f.h, f.primary(), C.byref(prm), C.byref(d))
+            got[slab_rows] = (rc, L.hm_last_error().decode())
+            assert rc != 0
+            img, meta = f.decode(f.primary(), 10, threads=4)  # concealing
+            got[("img", slab_rows)] = (img[0][:1024, :768 * 3].copy(), meta["warnings"])
+    finally:
+        L.hm_debug_set(b"grid_slab_rows", -1)
+        f.close()
+    assert got[0] == got[-1] == got[2], got
+    assert "tile 7" in got[0][1]
+    for slab_rows in (-1, 2):
+        assert got[("img", slab_rows)][1] == got[("img", 0)][1] and (got[("img", 0)][1] & 8)
+        assert np.array_equal(got[("img", slab_rows)][0], got[("img", 0)][0])
+
+
 def test_grids_decoded_by_several_threads_at_once(hm):
     """r06: hm_decode_item on a grid runs a queueing thread of its own beside the parsing crew (slabs under the entropy decode) - three caller
     threads decode three different grids at the same time, four times each: every image equals the one decoded alone (the crew takes one
