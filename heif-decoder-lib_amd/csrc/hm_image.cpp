@@ -835,6 +835,7 @@ static int decode_grid_cut(const hm_file* f, uint32_t id, const hm_decode_params
 int hm_decode_item(const hm_file* f, uint32_t id, const hm_decode_params* params, hm_decoded* out)
 {
   if (!f || !params || !out) return hm_fail(HM_ERR_INVALID_ARG, "null argument");
+  std::memset(out, 0, sizeof(*out)); // (whatever fails below: nothing of an earlier call is left in it)
   { // (r06) a grid of more tiles than parsing threads, to interleaved pixels: slab by slab under the entropy decode (decode_grid_cut)
     bool applicable = false;
     const int prc = decode_grid_cut(f, id, params, nullptr, 1, /*pipelined=*/true, out, &applicable);
